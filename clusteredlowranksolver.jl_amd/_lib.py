@@ -1,0 +1,123 @@
+"""ctypes binding of the C ABI (include/clrs_hip.h) -> libclrs_hip.so built in csrc/.
+
+The library is the product: there is NO CPU fallback.  Importing this module never touches the GPU;
+`load()` raises if the shared library is missing, and every call raises `ClrsError` on a negative
+return code.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libclrs_hip.so")
+
+p_d = C.POINTER(C.c_double)
+p_i32 = C.POINTER(C.c_int32)
+p_i64 = C.POINTER(C.c_int64)
+
+
+class SdpDesc(C.Structure):
+    """struct clrs_sdp_desc"""
+    _fields_ = [
+        ("n_clusters", C.c_int32), ("n_free", C.c_int32), ("cluster_P", p_i32), ("B", p_d),
+        ("n_blocks", C.c_int32), ("block_cluster", p_i32), ("block_m", p_i32), ("block_delta", p_i32),
+        ("block_kind", p_i32), ("term_ptr", p_i64), ("term_p", p_i32), ("term_r", p_i32), ("term_s", p_i32),
+        ("term_rank", p_i32), ("term_lambda", p_d), ("term_vec_ptr", p_i64), ("term_vs", p_d), ("term_ws", p_d),
+        ("dense_ptr", p_i64), ("dense_p", p_i32), ("dense_A_ptr", p_i64), ("dense_A", p_d),
+    ]
+
+
+class Dims(C.Structure):
+    """struct clrs_dims"""
+    _fields_ = [("xy_len", C.c_int64), ("x_len", C.c_int64), ("S_len", C.c_int64), ("n_terms", C.c_int64),
+                ("n_free", C.c_int32), ("n_clusters", C.c_int32), ("n_blocks", C.c_int32), ("reserved", C.c_int32)]
+
+
+class ClrsError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"clrs error {code}: {msg}")
+        self.code = code
+
+
+# every symbol include/clrs_hip.h declares: (restype, argtypes)
+SYMBOLS = {
+    "clrs_ctx_create": (C.c_int, [C.POINTER(SdpDesc), C.c_int, C.POINTER(C.c_void_p)]),
+    "clrs_ctx_destroy": (None, [C.c_void_p]),
+    "clrs_get_dims": (C.c_int, [C.c_void_p, C.POINTER(Dims)]),
+    "clrs_get_unique_counts": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, p_i32, p_i32]),
+    "clrs_cholesky_blocks": (C.c_int, [C.c_void_p, p_d, p_d]),
+    "clrs_schur_assemble": (C.c_int, [C.c_void_p, p_d, p_d, p_d, p_d]),
+    "clrs_schur_factor": (C.c_int, [C.c_void_p]),
+    "clrs_get_factor": (C.c_int, [C.c_void_p, p_d, p_d, p_d]),
+    "clrs_schur_solve": (C.c_int, [C.c_void_p, p_d, p_d, p_d, p_d]),
+    "clrs_schur_assemble_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "clrs_schur_factor_local_dev": (C.c_int, [C.c_void_p]),
+    "clrs_q_buffer_dev": (C.c_void_p, [C.c_void_p]),
+    "clrs_schur_factor_finish_dev": (C.c_int, [C.c_void_p]),
+    "clrs_schur_solve_fwd_dev": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "clrs_u_buffer_dev": (C.c_void_p, [C.c_void_p]),
+    "clrs_schur_solve_bwd_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "clrs_S_buffer_dev": (C.c_void_p, [C.c_void_p]),
+    "clrs_AY_buffer_dev": (C.c_void_p, [C.c_void_p]),
+    "clrs_sync_status": (C.c_int, [C.c_void_p]),
+    "clrs_stream": (C.c_void_p, [C.c_void_p]),
+    "clrs_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "clrs_get_timings": (C.c_int, [C.c_void_p, p_d]),
+    "clrs_get_counters": (C.c_int, [C.c_void_p, p_d, p_d, p_d, p_d]),
+    "clrs_set_graph_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "clrs_plan_info": (C.c_int, [C.c_void_p, p_i32, p_i32, p_i32]),
+    "clrs_strerror": (C.c_char_p, [C.c_int]),
+    "clrs_last_error": (C.c_char_p, []),
+    "clrs_version": (C.c_char_p, []),
+    "clrs_test_gemm": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, p_d, C.c_int, p_d, C.c_int,
+                                 C.c_double, p_d, C.c_int]),
+    "clrs_test_potrf": (C.c_int, [C.c_int, C.c_int, p_d, C.c_int]),
+    "clrs_test_trsm": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, p_d, C.c_int, p_d, C.c_int]),
+}
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile csrc/clrs_hip.hip for gfx950 into csrc/libclrs_hip.so (in-tree, travels with gpurun)."""
+    src = [os.path.join(CSRC, f) for f in ("clrs_hip.hip", "clrs_kernels.hip.h")] + \
+          [os.path.join(_HERE, "..", "include", "clrs_hip.h")]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in src):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+           "-o", LIB_PATH, os.path.join(CSRC, "clrs_hip.hip")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + r.stderr[-4000:])
+    if verbose:
+        print(" ".join(cmd))
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load():
+    """Load libclrs_hip.so; fails loudly when it has not been built (no fallback path exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ClrsError(-100, f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                  f"(the HIP extension is the only compute path)")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)   # AttributeError here = header and library out of sync
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(code: int) -> int:
+    """Raise on negative codes; positive codes (factorisation failures) are returned to the caller."""
+    if code < 0:
+        L = load()
+        raise ClrsError(code, f"{L.clrs_strerror(code).decode()}: {L.clrs_last_error().decode()}")
+    return code

@@ -1,0 +1,1076 @@
+// clrs_hip.hip -- host side of the C ABI (include/clrs_hip.h): context creation (vector
+// de-duplication, gather tables, launch plan), and the per-iteration drivers that replay the plan.
+//
+// Design (MI355X-first, not a translation of the reference's j -> l -> r -> s serial walk):
+//   * every step of the path is ONE grouped launch over all PSD blocks / clusters, driven by
+//     device-resident descriptor tables that are built once at context creation;
+//   * blocked Cholesky / triangular solves are level-synchronous across matrices: panel k of every
+//     matrix is processed by the same launch;
+//   * the explicit inverse of X (reference "method 3", src/solver.jl:1107-1119) is avoided:
+//     V^T X^-1 V = (L^-1 V)^T (L^-1 V), one triangular solve + one MFMA contraction;
+//   * each S entry is produced by exactly one thread (deterministic, no atomics);
+//   * the launch sequences are static, so they can be captured into hipGraphs.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <array>
+#include <climits>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/clrs_hip.h"
+#include "clrs_kernels.hip.h"
+
+using namespace clrs;
+typedef long long i64;
+
+static thread_local std::string g_last_error;
+static int fail(int code, const std::string &msg) {
+    g_last_error = msg;
+    return code;
+}
+#define HIPCHECK(expr)                                                                                   \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess)                                                                            \
+            return fail(CLRS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                \
+    } while (0)
+
+static const int INFO_NONE = 0x7f7f7f7f;
+
+// ------------------------------------------------------------------------------------------------
+// launch plan
+// ------------------------------------------------------------------------------------------------
+enum StepKind { STEP_MEMCPY, STEP_GEMM, STEP_TRSM, STEP_POTRF, STEP_GATHER_S, STEP_GATHER_SCALAR, STEP_SUB, STEP_MEMSET_INFO };
+
+struct Step {
+    StepKind kind;
+    int grid = 0;
+    void *d0 = nullptr, *d1 = nullptr, *d2 = nullptr;  // device descriptor tables
+    void *dst = nullptr;
+    const void *src = nullptr;
+    size_t bytes = 0;
+    i64 n = 0;
+};
+
+struct Plan {
+    std::vector<Step> steps;
+    hipGraphExec_t graph = nullptr;
+    int launches() const { return (int)steps.size(); }
+};
+
+struct DeviceArena {  // bump allocator over one hipMalloc (static tables + work buffers)
+    char *base = nullptr;
+    size_t size = 0, used = 0;
+};
+
+struct TrsmJob {
+    const double *L;
+    int ldl, n;
+    double *B;
+    int ldb, nrhs;
+};
+struct PotrfJob {
+    double *A;
+    int lda, n, code;
+};
+
+struct BlockInfo {
+    int j = 0, m = 1, delta = 1, n = 1, kind = 0;
+    i64 xyoff = 0, t0 = 0, t1 = 0, d0 = 0, d1 = 0;
+    std::vector<int> UR, UL, offR, offL;
+    int URt = 0, ULt = 0;
+    bool sym = false;
+    // offsets (in doubles) inside the work / static arenas
+    i64 zr_off = -1, zl_off = -1, ty_off = -1, g_off = -1;  // ZR/ZL in the "solve" arena; TY; GX,GY
+    int cnt = 0;
+    i64 w_off = -1, tt_off = -1, sd_off = -1;
+};
+
+struct clrs_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int J = 0, N = 0, NB = 0;
+    i64 T = 0, D = 0;
+    std::vector<int> P;
+    std::vector<i64> coff, Soff;
+    i64 xylen = 0, xlen = 0, Slen = 0;
+    std::vector<BlockInfo> blk;
+    std::vector<void *> allocs;  // every hipMalloc, for destroy
+    // device buffers
+    double *d_Xc = nullptr, *d_Y = nullptr;        // inputs (xy layout)
+    double *d_static = nullptr, *d_work = nullptr; // [Vexp | Astack] and [Z | W] (identical layouts: one memcpy)
+    i64 solve_arena_len = 0;
+    double *d_TY = nullptr, *d_G = nullptr, *d_TT = nullptr, *d_Sd = nullptr;
+    double *d_S = nullptr, *d_B = nullptr, *d_LB = nullptr, *d_Q = nullptr;
+    double *d_t = nullptr, *d_u = nullptr, *d_dy = nullptr, *d_rhsy = nullptr, *d_dx = nullptr, *d_rhsx = nullptr;
+    double *d_AY = nullptr;
+    i64 *d_ayidx = nullptr;
+    int *d_info = nullptr;
+    double *d_X = nullptr;  // scratch for clrs_cholesky_blocks
+    Plan p_assemble, p_cholS, p_linvB, p_Q, p_cholQ, p_fwd, p_bwd, p_cholX, p_zeroL;
+    bool factored = false, assembled = false;
+    bool timing = false, graph_mode = false;
+    hipEvent_t ev[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    double times[6] = {0, 0, 0, 0, 0, 0};
+    bool times_pending = false, solve_time_pending = false;
+    double cnt_bytes = 0, cnt_flops = 0, cnt_factor_flops = 0, cnt_solve_flops = 0;
+    std::vector<int> host_UR, host_UL;       // flattened per (block, r) for clrs_get_unique_counts
+    std::vector<i64> host_U_off;
+};
+
+template <class T>
+static int upload(clrs_ctx *c, const std::vector<T> &h, T **d) {
+    *d = nullptr;
+    size_t bytes = std::max<size_t>(h.size(), 1) * sizeof(T);
+    HIPCHECK(hipMalloc((void **)d, bytes));
+    c->allocs.push_back(*d);
+    if (!h.empty()) HIPCHECK(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+static int dmalloc(clrs_ctx *c, double **d, i64 n) {
+    size_t bytes = (size_t)std::max<i64>(n, 1) * sizeof(double);
+    HIPCHECK(hipMalloc((void **)d, bytes));
+    c->allocs.push_back(*d);
+    HIPCHECK(hipMemset(*d, 0, bytes));
+    return 0;
+}
+
+// ---- stage builders -----------------------------------------------------------------------------
+static int add_gemm_stage(clrs_ctx *c, Plan &pl, const std::vector<GemmDesc> &descs) {
+    std::vector<GemmDesc> ds;
+    std::vector<GemmTile> tiles;
+    for (const GemmDesc &d : descs) {
+        if (d.M <= 0 || d.N <= 0) continue;
+        int id = (int)ds.size();
+        ds.push_back(d);
+        int tm = (d.M + GEMM_BM - 1) / GEMM_BM, tn = (d.N + GEMM_BN - 1) / GEMM_BN;
+        int batch = 1;
+        // batch count is encoded by the caller through pad0 (>=1)
+        batch = std::max(1, d.pad0);
+        for (int b = 0; b < batch; b++)
+            for (int j = 0; j < tn; j++)
+                for (int i = 0; i < tm; i++) {
+                    if (d.lower_only && (i + 1) * GEMM_BM <= j * GEMM_BN) continue;
+                    tiles.push_back(GemmTile{id, b, i, j});
+                }
+    }
+    if (tiles.empty()) return 0;
+    Step s;
+    s.kind = STEP_GEMM;
+    s.grid = (int)tiles.size();
+    GemmDesc *dd; GemmTile *dt;
+    int rc;
+    if ((rc = upload(c, ds, &dd))) return rc;
+    if ((rc = upload(c, tiles, &dt))) return rc;
+    s.d0 = dd; s.d1 = dt;
+    pl.steps.push_back(s);
+    return 0;
+}
+
+static GemmDesc mk_gemm(int ta, int tb, int M, int N, int K, double alpha, const double *A, int lda, const double *B, int ldb,
+                        double beta, double *C, int ldc, int batch = 1, i64 sA = 0, i64 sB = 0, i64 sC = 0, int lower_only = 0) {
+    GemmDesc d;
+    d.A = A; d.B = B; d.C = C; d.M = M; d.N = N; d.K = K; d.lda = lda; d.ldb = ldb; d.ldc = ldc;
+    d.ta = ta; d.tb = tb; d.lower_only = lower_only; d.pad0 = batch; d.alpha = alpha; d.beta = beta;
+    d.sA = sA; d.sB = sB; d.sC = sC;
+    return d;
+}
+
+static int add_trsm_stage(clrs_ctx *c, Plan &pl, const std::vector<TrsmDesc> &descs) {
+    std::vector<TrsmDesc> ds;
+    std::vector<TrsmWork> work;
+    for (const TrsmDesc &d : descs) {
+        if (d.n <= 0 || d.nvec <= 0) continue;
+        int id = (int)ds.size();
+        ds.push_back(d);
+        for (int ch = 0; ch * 64 < d.nvec; ch++) work.push_back(TrsmWork{id, ch});
+    }
+    if (work.empty()) return 0;
+    Step s;
+    s.kind = STEP_TRSM;
+    s.grid = (int)work.size();
+    TrsmDesc *dd; TrsmWork *dw;
+    int rc;
+    if ((rc = upload(c, ds, &dd))) return rc;
+    if ((rc = upload(c, work, &dw))) return rc;
+    s.d0 = dd; s.d1 = dw;
+    pl.steps.push_back(s);
+    return 0;
+}
+
+// B <- L^-1 B (trans = 0) or L^-T B (trans = 1) for a list of independent problems, blocked by
+// TRSM_NB, level-synchronous over the problems.
+static int plan_trsm(clrs_ctx *c, Plan &pl, const std::vector<TrsmJob> &jobs, int trans) {
+    int maxp = 0;
+    for (const TrsmJob &j : jobs) maxp = std::max(maxp, (j.n + TRSM_NB - 1) / TRSM_NB);
+    int rc;
+    for (int step = 0; step < maxp; step++) {
+        std::vector<TrsmDesc> td;
+        std::vector<GemmDesc> gd;
+        for (const TrsmJob &j : jobs) {
+            if (j.n <= 0 || j.nrhs <= 0) continue;
+            int np = (j.n + TRSM_NB - 1) / TRSM_NB;
+            if (step >= np) continue;
+            int k = trans ? np - 1 - step : step;
+            int r0 = k * TRSM_NB, nk = std::min(TRSM_NB, j.n - r0);
+            TrsmDesc d;
+            d.L = j.L + r0 + (i64)r0 * j.ldl; d.ldl = j.ldl; d.n = nk; d.B = j.B + r0; d.nvec = j.nrhs; d.trans = trans;
+            d.es = 1; d.vs = j.ldb;
+            td.push_back(d);
+            if (!trans) {
+                int rem = j.n - (r0 + nk);
+                if (rem > 0)  // B[r0+nk:, :] -= L[r0+nk:, r0:r0+nk] B[r0:r0+nk, :]
+                    gd.push_back(mk_gemm(0, 0, rem, j.nrhs, nk, -1.0, j.L + (r0 + nk) + (i64)r0 * j.ldl, j.ldl, j.B + r0, j.ldb, 1.0,
+                                         j.B + r0 + nk, j.ldb));
+            } else {
+                if (r0 > 0)  // B[0:r0, :] -= L[r0:r0+nk, 0:r0]^T B[r0:r0+nk, :]
+                    gd.push_back(mk_gemm(1, 0, r0, j.nrhs, nk, -1.0, j.L + r0, j.ldl, j.B + r0, j.ldb, 1.0, j.B, j.ldb));
+            }
+        }
+        if ((rc = add_trsm_stage(c, pl, td))) return rc;
+        if ((rc = add_gemm_stage(c, pl, gd))) return rc;
+    }
+    return 0;
+}
+
+// in-place lower Cholesky of a list of independent matrices, blocked by POTRF_NB, level-synchronous.
+static int plan_potrf(clrs_ctx *c, Plan &pl, const std::vector<PotrfJob> &jobs) {
+    int maxp = 0;
+    for (const PotrfJob &j : jobs) maxp = std::max(maxp, (j.n + POTRF_NB - 1) / POTRF_NB);
+    int rc;
+    for (int k = 0; k < maxp; k++) {
+        std::vector<PotrfDesc> pd;
+        std::vector<TrsmDesc> td;
+        std::vector<GemmDesc> gd;
+        for (const PotrfJob &j : jobs) {
+            int r0 = k * POTRF_NB;
+            if (r0 >= j.n) continue;
+            int nk = std::min(POTRF_NB, j.n - r0), rem = j.n - r0 - nk;
+            double *Akk = j.A + r0 + (i64)r0 * j.lda;
+            pd.push_back(PotrfDesc{Akk, j.lda, nk, j.code, 0});
+            if (rem > 0) {
+                double *Pn = j.A + (r0 + nk) + (i64)r0 * j.lda;  // panel below the diagonal block
+                TrsmDesc d;                                       // rows of the panel: x L_kk^T = b
+                d.L = Akk; d.ldl = j.lda; d.n = nk; d.B = Pn; d.nvec = rem; d.trans = 0; d.es = j.lda; d.vs = 1;
+                td.push_back(d);
+                double *A22 = j.A + (r0 + nk) + (i64)(r0 + nk) * j.lda;
+                gd.push_back(mk_gemm(0, 1, rem, rem, nk, -1.0, Pn, j.lda, Pn, j.lda, 1.0, A22, j.lda, 1, 0, 0, 0, 1));
+            }
+        }
+        if (pd.empty()) continue;
+        Step s;
+        s.kind = STEP_POTRF;
+        s.grid = (int)pd.size();
+        PotrfDesc *dd;
+        if ((rc = upload(c, pd, &dd))) return rc;
+        s.d0 = dd;
+        pl.steps.push_back(s);
+        if ((rc = add_trsm_stage(c, pl, td))) return rc;
+        if ((rc = add_gemm_stage(c, pl, gd))) return rc;
+    }
+    return 0;
+}
+
+static void add_memcpy(Plan &pl, void *dst, const void *src, size_t bytes) {
+    if (bytes == 0) return;
+    Step s;
+    s.kind = STEP_MEMCPY;
+    s.dst = dst; s.src = src; s.bytes = bytes;
+    pl.steps.push_back(s);
+}
+
+// ---- plan execution -----------------------------------------------------------------------------
+static int run_steps(clrs_ctx *c, const Plan &pl) {
+    hipStream_t st = c->stream;
+    for (const Step &s : pl.steps) {
+        switch (s.kind) {
+            case STEP_MEMCPY:
+                HIPCHECK(hipMemcpyAsync(s.dst, s.src, s.bytes, hipMemcpyDeviceToDevice, st));
+                break;
+            case STEP_GEMM:
+                hipLaunchKernelGGL(k_gemm_f64, dim3(s.grid), dim3(256), 0, st, (const GemmDesc *)s.d0, (const GemmTile *)s.d1);
+                break;
+            case STEP_TRSM:
+                hipLaunchKernelGGL(k_trsm_diag, dim3(s.grid), dim3(64), 0, st, (const TrsmDesc *)s.d0, (const TrsmWork *)s.d1);
+                break;
+            case STEP_POTRF:
+                hipLaunchKernelGGL(k_potrf_diag, dim3(s.grid), dim3(256), 0, st, (const PotrfDesc *)s.d0, c->d_info);
+                break;
+            case STEP_GATHER_S:
+                hipLaunchKernelGGL(k_schur_gather, dim3(s.grid), dim3(256), 0, st, (const SClusterDesc *)s.d0, (const SBlockDesc *)s.d1,
+                                   (const STile *)s.d2);
+                break;
+            case STEP_GATHER_SCALAR:
+                hipLaunchKernelGGL(k_gather_scalar, dim3((unsigned)((s.n + 255) / 256)), dim3(256), 0, st, (double *)s.dst, (const double *)s.src,
+                                   (const i64 *)s.d0, s.n);
+                break;
+            case STEP_SUB:
+                hipLaunchKernelGGL(k_sub, dim3((unsigned)((s.n + 255) / 256)), dim3(256), 0, st, (double *)s.dst, (const double *)s.src,
+                                   (const double *)s.d0, (int)s.n);
+                break;
+            case STEP_MEMSET_INFO:
+                HIPCHECK(hipMemsetAsync(c->d_info, 0x7f, sizeof(int), st));
+                break;
+        }
+    }
+    HIPCHECK(hipGetLastError());
+    return 0;
+}
+
+static int run_plan(clrs_ctx *c, Plan &pl) {
+    if (pl.steps.empty()) return 0;
+    if (!c->graph_mode) return run_steps(c, pl);
+    if (!pl.graph) {
+        hipGraph_t g;
+        HIPCHECK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        int rc = run_steps(c, pl);
+        hipError_t e = hipStreamEndCapture(c->stream, &g);
+        if (rc) return rc;
+        if (e != hipSuccess) return fail(CLRS_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+        HIPCHECK(hipGraphInstantiate(&pl.graph, g, nullptr, nullptr, 0));
+        HIPCHECK(hipGraphDestroy(g));
+    }
+    HIPCHECK(hipGraphLaunch(pl.graph, c->stream));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// context creation
+// ------------------------------------------------------------------------------------------------
+static bool vec_eq(const double *a, const double *b, int n) {   // exact equality, like the reference's == (src/tools.jl:134)
+    for (int i = 0; i < n; i++)
+        if (a[i] != b[i]) return false;
+    return true;
+}
+
+extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **out) {
+    if (!d || !out) return fail(CLRS_ERR_INVALID, "null argument");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(CLRS_ERR_NO_DEVICE, "no HIP device");
+    if (device < 0 || device >= ndev) return fail(CLRS_ERR_NO_DEVICE, "device index out of range");
+    HIPCHECK(hipSetDevice(device));
+    clrs_ctx *c = new clrs_ctx();
+    c->device = device;
+    int rc = 0;
+#define CK(x) do { rc = (x); if (rc) { clrs_ctx_destroy(c); return rc; } } while (0)
+#define HIPCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { clrs_ctx_destroy(c); return fail(CLRS_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } } while (0)
+    HIPCK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (int i = 0; i < 10; i++) HIPCK(hipEventCreate(&c->ev[i]));
+    c->J = d->n_clusters; c->N = d->n_free; c->NB = d->n_blocks;
+    if (c->J < 0 || c->N < 0 || c->NB < 0) { clrs_ctx_destroy(c); return fail(CLRS_ERR_INVALID, "negative sizes"); }
+    const int J = c->J, N = c->N, NB = c->NB;
+    c->P.assign(d->cluster_P, d->cluster_P + J);
+    c->coff.assign(J + 1, 0); c->Soff.assign(J + 1, 0);
+    for (int j = 0; j < J; j++) {
+        if (c->P[j] <= 0) { clrs_ctx_destroy(c); return fail(CLRS_ERR_INVALID, "cluster with no constraints"); }
+        c->coff[j + 1] = c->coff[j] + c->P[j];
+        c->Soff[j + 1] = c->Soff[j] + (i64)c->P[j] * c->P[j];
+    }
+    c->xlen = c->coff[J]; c->Slen = c->Soff[J];
+    c->T = d->term_ptr[NB]; c->D = d->dense_ptr[NB];
+    const i64 T = c->T;
+
+    // ---- blocks, de-duplication of the sampled vectors (src/solver.jl:985-1059) ----
+    c->blk.resize(NB);
+    std::vector<int> ridx(T), lidx(T);
+    std::vector<i64> partner(T, -1);
+    std::vector<std::vector<std::vector<i64>>> uniqR(NB), uniqL(NB);
+    i64 xyoff = 0;
+    int prevj = 0;
+    for (int b = 0; b < NB; b++) {
+        BlockInfo &k = c->blk[b];
+        k.j = d->block_cluster[b]; k.m = d->block_m[b]; k.delta = d->block_delta[b]; k.kind = d->block_kind[b];
+        k.n = k.m * k.delta;
+        if (k.j < prevj || k.j >= J || k.m <= 0 || k.delta <= 0) { clrs_ctx_destroy(c); return fail(CLRS_ERR_INVALID, "bad block description (clusters must be listed in order)"); }
+        prevj = k.j;
+        k.xyoff = xyoff; xyoff += (i64)k.n * k.n;
+        k.t0 = d->term_ptr[b]; k.t1 = d->term_ptr[b + 1]; k.d0 = d->dense_ptr[b]; k.d1 = d->dense_ptr[b + 1];
+        c->host_U_off.push_back((i64)c->host_UR.size());
+        if (k.kind != 0) {
+            if (k.m != 1) { clrs_ctx_destroy(c); return fail(CLRS_ERR_INVALID, "dense blocks need m == 1"); }
+            k.cnt = (int)(k.d1 - k.d0);
+            for (i64 e = k.d0; e < k.d1; e++)
+                if (d->dense_p[e] < 0 || d->dense_p[e] >= c->P[k.j]) { clrs_ctx_destroy(c); return fail(CLRS_ERR_INVALID, "dense constraint index out of range"); }
+            continue;
+        }
+        const int m = k.m, dl = k.delta;
+        k.UR.assign(m, 0); k.UL.assign(m, 0); k.offR.assign(m + 1, 0); k.offL.assign(m + 1, 0);
+        uniqR[b].resize(m); uniqL[b].resize(m);
+        for (i64 t = k.t0; t < k.t1; t++) {
+            int r = d->term_r[t], s = d->term_s[t], p = d->term_p[t];
+            if (r < 0 || r >= m || s < 0 || s >= m || p < 0 || p >= c->P[k.j] || d->term_vec_ptr[t + 1] - d->term_vec_ptr[t] != dl) {
+                clrs_ctx_destroy(c);
+                return fail(CLRS_ERR_INVALID, "bad term description");
+            }
+            const double *v = d->term_vs + d->term_vec_ptr[t], *w = d->term_ws + d->term_vec_ptr[t];
+            std::vector<i64> &uR = uniqR[b][r], &uL = uniqL[b][r];
+            int f = -1;
+            for (size_t u = 0; u < uR.size(); u++) if (vec_eq(d->term_vs + d->term_vec_ptr[uR[u]], v, dl)) { f = (int)u; break; }
+            if (f < 0) { f = (int)uR.size(); uR.push_back(t); }
+            ridx[t] = f;
+            f = -1;
+            for (size_t u = 0; u < uL.size(); u++) if (vec_eq(d->term_ws + d->term_vec_ptr[uL[u]], w, dl)) { f = (int)u; break; }
+            if (f < 0) { f = (int)uL.size(); uL.push_back(t); }
+            lidx[t] = f;
+        }
+        {   // transposed partner (p, s, r, rank) of every term; required by the convention src/solver.jl:1009
+            std::map<std::array<int, 4>, i64> index;
+            for (i64 t = k.t0; t < k.t1; t++) index[{d->term_p[t], d->term_r[t], d->term_s[t], d->term_rank[t]}] = t;
+            for (i64 t = k.t0; t < k.t1; t++) {
+                auto it = index.find({d->term_p[t], d->term_s[t], d->term_r[t], d->term_rank[t]});
+                if (it == index.end()) { clrs_ctx_destroy(c); return fail(CLRS_ERR_INVALID, "term without transposed partner: A[r,s][p] must equal A[s,r][p]^T"); }
+                partner[t] = it->second;
+            }
+        }
+        k.sym = true;
+        for (int r = 0; r < m; r++) {
+            k.UR[r] = (int)uniqR[b][r].size(); k.UL[r] = (int)uniqL[b][r].size();
+            k.offR[r + 1] = k.offR[r] + k.UR[r]; k.offL[r + 1] = k.offL[r] + k.UL[r];
+            c->host_UR.push_back(k.UR[r]); c->host_UL.push_back(k.UL[r]);
+            if (k.UR[r] != k.UL[r]) k.sym = false;
+            else
+                for (int u = 0; u < k.UR[r] && k.sym; u++)
+                    if (!vec_eq(d->term_vs + d->term_vec_ptr[uniqR[b][r][u]], d->term_ws + d->term_vec_ptr[uniqL[b][r][u]], dl)) k.sym = false;
+        }
+        k.URt = k.offR[m]; k.ULt = k.offL[m];
+    }
+    c->xylen = xyoff;
+
+    // ---- arena layout ----
+    // "solve" arena: per low-rank block ZR (n x URt) [+ ZL (n x ULt) if not symmetric]; per dense block W (n x n*cnt).
+    // the static arena has the identical layout and holds the expanded vectors / the dense A stacks.
+    i64 so = 0, tyo = 0, go = 0, tto = 0, sdo = 0;
+    for (int b = 0; b < NB; b++) {
+        BlockInfo &k = c->blk[b];
+        if (k.kind == 0) {
+            k.zr_off = so; so += (i64)k.n * k.URt;
+            if (k.sym) k.zl_off = k.zr_off; else { k.zl_off = so; so += (i64)k.n * k.ULt; }
+            k.ty_off = tyo; tyo += (i64)k.n * k.URt;
+            k.g_off = go; go += 2 * (i64)k.ULt * k.URt;
+        } else {
+            k.w_off = so; so += (i64)k.n * k.n * k.cnt;
+            k.tt_off = tto; tto += (i64)k.n * k.n * k.cnt;
+            k.sd_off = sdo; sdo += (i64)k.cnt * k.cnt;
+        }
+    }
+    c->solve_arena_len = so;
+    std::vector<double> h_static((size_t)std::max<i64>(so, 1), 0.0);
+    for (int b = 0; b < NB; b++) {
+        BlockInfo &k = c->blk[b];
+        if (k.kind == 0) {
+            const int dl = k.delta, n = k.n;
+            for (int r = 0; r < k.m; r++) {
+                for (int u = 0; u < k.UR[r]; u++) {
+                    const double *v = d->term_vs + d->term_vec_ptr[uniqR[b][r][u]];
+                    double *dst = h_static.data() + k.zr_off + (i64)(k.offR[r] + u) * n + (i64)r * dl;
+                    std::memcpy(dst, v, sizeof(double) * dl);
+                }
+                if (!k.sym)
+                    for (int u = 0; u < k.UL[r]; u++) {
+                        const double *w = d->term_ws + d->term_vec_ptr[uniqL[b][r][u]];
+                        double *dst = h_static.data() + k.zl_off + (i64)(k.offL[r] + u) * n + (i64)r * dl;
+                        std::memcpy(dst, w, sizeof(double) * dl);
+                    }
+            }
+        } else {
+            for (i64 e = k.d0; e < k.d1; e++) {
+                if (d->dense_A_ptr[e + 1] - d->dense_A_ptr[e] != (i64)k.n * k.n) { clrs_ctx_destroy(c); return fail(CLRS_ERR_INVALID, "dense matrix has the wrong size"); }
+                std::memcpy(h_static.data() + k.w_off + (e - k.d0) * (i64)k.n * k.n, d->dense_A + d->dense_A_ptr[e], sizeof(double) * k.n * k.n);
+            }
+        }
+    }
+    CK(upload(c, h_static, &c->d_static));
+    CK(dmalloc(c, &c->d_work, so));
+    CK(dmalloc(c, &c->d_Xc, c->xylen)); CK(dmalloc(c, &c->d_Y, c->xylen)); CK(dmalloc(c, &c->d_X, c->xylen));
+    CK(dmalloc(c, &c->d_TY, tyo)); CK(dmalloc(c, &c->d_G, go)); CK(dmalloc(c, &c->d_TT, tto)); CK(dmalloc(c, &c->d_Sd, sdo));
+    CK(dmalloc(c, &c->d_S, c->Slen));
+    CK(dmalloc(c, &c->d_LB, c->xlen * (i64)N)); CK(dmalloc(c, &c->d_Q, (i64)N * N));
+    CK(dmalloc(c, &c->d_t, c->xlen)); CK(dmalloc(c, &c->d_u, N)); CK(dmalloc(c, &c->d_dy, N)); CK(dmalloc(c, &c->d_rhsy, N));
+    CK(dmalloc(c, &c->d_dx, c->xlen)); CK(dmalloc(c, &c->d_rhsx, c->xlen));
+    CK(dmalloc(c, &c->d_AY, T));
+    {   // B stacked: rows = all constraints (cluster after cluster), columns = free variables; ld = xlen
+        std::vector<double> hB((size_t)std::max<i64>(c->xlen * (i64)N, 1), 0.0);
+        i64 boff = 0;
+        for (int j = 0; j < J; j++) {
+            for (int col = 0; col < N; col++)
+                for (int r = 0; r < c->P[j]; r++) hB[(size_t)(c->coff[j] + r + (i64)col * c->xlen)] = d->B[boff + r + (i64)col * c->P[j]];
+            boff += (i64)c->P[j] * N;
+        }
+        CK(upload(c, hB, &c->d_B));
+    }
+    {
+        int *di;
+        std::vector<int> hi(1, INFO_NONE);
+        CK(upload(c, hi, &di));
+        c->d_info = di;
+    }
+
+    // ---- per-term gather tables ----
+    std::vector<int> h_tL(T), h_tR(T);
+    std::vector<double> h_tlam(d->term_lambda, d->term_lambda + T);
+    std::vector<i64> h_ayidx(T);
+    // the kernel wants the terms of a block sorted by p (CSR over p); build a permutation per block
+    std::vector<i64> perm(T);
+    std::vector<std::vector<int>> h_tptr(NB);
+    for (int b = 0; b < NB; b++) {
+        BlockInfo &k = c->blk[b];
+        if (k.kind != 0) continue;
+        std::vector<i64> idx;
+        for (i64 t = k.t0; t < k.t1; t++) idx.push_back(t);
+        std::stable_sort(idx.begin(), idx.end(), [&](i64 a, i64 bb) { return d->term_p[a] < d->term_p[bb]; });
+        const int Pj = c->P[k.j];
+        h_tptr[b].assign(Pj + 1, 0);
+        for (size_t q = 0; q < idx.size(); q++) {
+            i64 t = idx[q];
+            perm[k.t0 + q] = t;
+            h_tptr[b][d->term_p[t] + 1]++;
+        }
+        for (int p = 0; p < Pj; p++) h_tptr[b][p + 1] += h_tptr[b][p];
+        for (i64 t = k.t0; t < k.t1; t++) {
+            int r = d->term_r[t], s = d->term_s[t];
+            // A_Y[t] = bpY[r,s][pointers_left[r][(s,p,k)], pointers_right[s][(r,p,k)]]  (src/solver.jl:1163)
+            h_ayidx[t] = k.g_off + (i64)k.ULt * k.URt + (k.offL[r] + lidx[t]) + (i64)(k.offR[s] + ridx[partner[t]]) * k.ULt;
+        }
+    }
+    std::vector<int> s_tL(T), s_tR(T);
+    std::vector<double> s_tlam(T);
+    for (int b = 0; b < NB; b++) {
+        BlockInfo &k = c->blk[b];
+        if (k.kind != 0) continue;
+        for (i64 q = k.t0; q < k.t1; q++) {
+            i64 t = perm[q];
+            s_tL[q] = k.offL[d->term_s[t]] + lidx[partner[t]];   // pointers_left[s][(r,p,k)]
+            s_tR[q] = k.offR[d->term_r[t]] + ridx[t];            // pointers_right[r][(s,p,k)]
+            s_tlam[q] = d->term_lambda[t];
+        }
+    }
+    int *d_tL, *d_tR; double *d_tlam;
+    CK(upload(c, s_tL, &d_tL)); CK(upload(c, s_tR, &d_tR)); CK(upload(c, s_tlam, &d_tlam));
+    CK(upload(c, h_ayidx, &c->d_ayidx));
+
+    // =============================================================================================
+    // plan: assemble
+    // =============================================================================================
+    {
+        Plan &pl = c->p_assemble;
+        add_memcpy(pl, c->d_work, c->d_static, sizeof(double) * (size_t)so);
+        std::vector<TrsmJob> fwd, bwd;
+        std::vector<GemmDesc> g1, g2;
+        for (int b = 0; b < NB; b++) {
+            BlockInfo &k = c->blk[b];
+            const double *Lx = c->d_Xc + k.xyoff, *Yb = c->d_Y + k.xyoff;
+            const int n = k.n, dl = k.delta;
+            if (k.kind == 0) {
+                double *ZR = c->d_work + k.zr_off, *ZL = c->d_work + k.zl_off, *TY = c->d_TY + k.ty_off;
+                double *GX = c->d_G + k.g_off, *GY = GX + (i64)k.ULt * k.URt;
+                const double *VR = c->d_static + k.zr_off, *WL = c->d_static + k.zl_off;
+                for (int r = 0; r < k.m; r++) {
+                    const int r0 = r * dl;
+                    // columns of sub-block row r are zero above row r0: solve with the trailing triangle only
+                    if (k.UR[r] > 0) fwd.push_back(TrsmJob{Lx + r0 + (i64)r0 * n, n, n - r0, ZR + r0 + (i64)k.offR[r] * n, n, k.UR[r]});
+                    if (!k.sym && k.UL[r] > 0) fwd.push_back(TrsmJob{Lx + r0 + (i64)r0 * n, n, n - r0, ZL + r0 + (i64)k.offL[r] * n, n, k.UL[r]});
+                    // T_Y[:, cols r] = Y[:, r-block] V_r            (src/solver.jl:1125)
+                    if (k.UR[r] > 0)
+                        g1.push_back(mk_gemm(0, 0, n, k.UR[r], dl, 1.0, Yb + (i64)r0 * n, n, VR + r0 + (i64)k.offR[r] * n, n, 0.0, TY + (i64)k.offR[r] * n, n));
+                }
+                for (int s = 0; s < k.m; s++)  // GY[rows s, :] = W_s^T T_Y[s-block, :]   (src/solver.jl:1131)
+                    if (k.UL[s] > 0 && k.URt > 0)
+                        g2.push_back(mk_gemm(1, 0, k.UL[s], k.URt, dl, 1.0, WL + s * dl + (i64)k.offL[s] * n, n, TY + s * dl, n, 0.0, GY + k.offL[s], k.ULt));
+                // GX = ZL^T ZR = W^T X^-1 V       (replaces src/solver.jl:1117,1137-1143)
+                if (k.ULt > 0 && k.URt > 0) g2.push_back(mk_gemm(1, 0, k.ULt, k.URt, n, 1.0, ZL, n, ZR, n, 0.0, GX, k.ULt));
+            } else if (k.cnt > 0) {
+                double *W = c->d_work + k.w_off, *TT = c->d_TT + k.tt_off, *Sd = c->d_Sd + k.sd_off;
+                const double *Ast = c->d_static + k.w_off;
+                fwd.push_back(TrsmJob{Lx, n, n, W, n, n * k.cnt});      // X^-1 A_p for all p  (src/solver.jl:1095)
+                bwd.push_back(TrsmJob{Lx, n, n, W, n, n * k.cnt});
+                g1.push_back(mk_gemm(0, 0, n, n, n, 1.0, W, n, Yb, n, 0.0, TT, n, k.cnt, (i64)n * n, 0, (i64)n * n));  // (X^-1 A_p) Y  (:1097)
+                g2.push_back(mk_gemm(1, 0, k.cnt, k.cnt, n * n, 1.0, Ast, n * n, TT, n * n, 0.0, Sd, k.cnt));           // <A_i, T_k>   (:1102)
+            }
+        }
+        CK(plan_trsm(c, pl, fwd, 0));
+        CK(plan_trsm(c, pl, bwd, 1));
+        CK(add_gemm_stage(c, pl, g1));
+        CK(add_gemm_stage(c, pl, g2));
+        // gather
+        std::vector<SClusterDesc> cl(J);
+        std::vector<SBlockDesc> bl;
+        std::vector<STile> tiles;
+        int b = 0;
+        for (int j = 0; j < J; j++) {
+            cl[j].S = c->d_S + c->Soff[j]; cl[j].P = c->P[j]; cl[j].b0 = (int)bl.size(); cl[j].pad = 0;
+            for (; b < NB && c->blk[b].j == j; b++) {
+                BlockInfo &k = c->blk[b];
+                SBlockDesc sd;
+                std::memset(&sd, 0, sizeof(sd));
+                sd.kind = k.kind;
+                if (k.kind == 0) {
+                    if (k.t1 == k.t0) continue;
+                    sd.ldg = k.ULt;
+                    sd.GX = c->d_G + k.g_off; sd.GY = sd.GX + (i64)k.ULt * k.URt;
+                    int *dp;
+                    for (int &v : h_tptr[b]) v += (int)k.t0;   // absolute positions in the sorted term arrays
+                    CK(upload(c, h_tptr[b], &dp));
+                    sd.tptr = dp; sd.tL = d_tL; sd.tR = d_tR; sd.tlam = d_tlam;
+                } else {
+                    if (k.cnt == 0) continue;
+                    sd.cnt = k.cnt; sd.Sd = c->d_Sd + k.sd_off;
+                    std::vector<int> inv(c->P[j], -1);
+                    for (i64 e = k.d0; e < k.d1; e++) inv[d->dense_p[e]] = (int)(e - k.d0);
+                    int *dinv;
+                    CK(upload(c, inv, &dinv));
+                    sd.inv = dinv;
+                }
+                bl.push_back(sd);
+            }
+            cl[j].b1 = (int)bl.size();
+            int nt = (c->P[j] + 15) / 16;
+            for (int tj = 0; tj < nt; tj++)
+                for (int ti = 0; ti <= tj; ti++) tiles.push_back(STile{j, ti, tj, 0});
+        }
+        if (!tiles.empty()) {
+            Step s;
+            s.kind = STEP_GATHER_S;
+            s.grid = (int)tiles.size();
+            SClusterDesc *dcl; SBlockDesc *dbl; STile *dt;
+            CK(upload(c, cl, &dcl)); CK(upload(c, bl, &dbl)); CK(upload(c, tiles, &dt));
+            s.d0 = dcl; s.d1 = dbl; s.d2 = dt;
+            pl.steps.push_back(s);
+        }
+        if (T > 0) {
+            Step s;
+            s.kind = STEP_GATHER_SCALAR;
+            s.dst = c->d_AY; s.src = c->d_G; s.d0 = c->d_ayidx; s.n = T;
+            pl.steps.push_back(s);
+        }
+    }
+    // =============================================================================================
+    // plan: factor (src/solver.jl:1244-1279), split like the reference's timings
+    // =============================================================================================
+    {
+        std::vector<PotrfJob> pj;
+        std::vector<TrsmJob> tj;
+        for (int j = 0; j < J; j++) {
+            pj.push_back(PotrfJob{c->d_S + c->Soff[j], c->P[j], c->P[j], j + 1});
+            if (N > 0) tj.push_back(TrsmJob{c->d_S + c->Soff[j], c->P[j], c->P[j], c->d_LB + c->coff[j], (int)c->xlen, N});
+        }
+        Step ms; ms.kind = STEP_MEMSET_INFO;
+        c->p_cholS.steps.push_back(ms);
+        CK(plan_potrf(c, c->p_cholS, pj));
+        if (N > 0) {
+            add_memcpy(c->p_linvB, c->d_LB, c->d_B, sizeof(double) * (size_t)(c->xlen * N));
+            CK(plan_trsm(c, c->p_linvB, tj, 0));
+            std::vector<GemmDesc> gq;   // Q = LB^T LB  (vcat + matmul, src/solver.jl:1268-1269)
+            gq.push_back(mk_gemm(1, 0, N, N, (int)c->xlen, 1.0, c->d_LB, (int)c->xlen, c->d_LB, (int)c->xlen, 0.0, c->d_Q, N));
+            CK(add_gemm_stage(c, c->p_Q, gq));
+            std::vector<PotrfJob> qj;
+            qj.push_back(PotrfJob{c->d_Q, N, N, J + 1});
+            CK(plan_potrf(c, c->p_cholQ, qj));
+        }
+    }
+    // =============================================================================================
+    // plan: solve (src/solver.jl:1527-1582)
+    // =============================================================================================
+    {
+        std::vector<TrsmJob> tj;
+        for (int j = 0; j < J; j++) tj.push_back(TrsmJob{c->d_S + c->Soff[j], c->P[j], c->P[j], c->d_t + c->coff[j], (int)c->xlen, 1});
+        add_memcpy(c->p_fwd, c->d_t, c->d_rhsx, sizeof(double) * (size_t)c->xlen);
+        CK(plan_trsm(c, c->p_fwd, tj, 0));                                                  // t_j = L_j^-1 rhs_x[j]   (:1538)
+        if (N > 0) {
+            std::vector<GemmDesc> g;                                                        // u = LB^T t             (:1546)
+            g.push_back(mk_gemm(1, 0, N, 1, (int)c->xlen, 1.0, c->d_LB, (int)c->xlen, c->d_t, (int)c->xlen, 0.0, c->d_u, N));
+            CK(add_gemm_stage(c, c->p_fwd, g));
+            Step s;                                                                         // dy = rhs_y - u         (:1550-1553)
+            s.kind = STEP_SUB; s.dst = c->d_dy; s.src = c->d_rhsy; s.d0 = c->d_u; s.n = N;
+            c->p_bwd.steps.push_back(s);
+            std::vector<TrsmJob> qj;
+            qj.push_back(TrsmJob{c->d_Q, N, N, c->d_dy, N, 1});
+            CK(plan_trsm(c, c->p_bwd, qj, 0));                                              // dy = Q^-1 dy           (:1557)
+            CK(plan_trsm(c, c->p_bwd, qj, 1));
+            std::vector<GemmDesc> g2;                                                       // t += LB dy             (:1568-1569)
+            g2.push_back(mk_gemm(0, 0, (int)c->xlen, 1, N, 1.0, c->d_LB, (int)c->xlen, c->d_dy, N, 1.0, c->d_t, (int)c->xlen));
+            CK(add_gemm_stage(c, c->p_bwd, g2));
+        }
+        CK(plan_trsm(c, c->p_bwd, tj, 1));                                                  // dx_j = L_j^-T t_j      (:1571)
+    }
+    // plan: Cholesky of X blocks (src/solver.jl:388-399)
+    {
+        std::vector<PotrfJob> pj;
+        for (int b = 0; b < NB; b++) pj.push_back(PotrfJob{c->d_X + c->blk[b].xyoff, c->blk[b].n, c->blk[b].n, b + 1});
+        Step ms; ms.kind = STEP_MEMSET_INFO;
+        c->p_cholX.steps.push_back(ms);
+        CK(plan_potrf(c, c->p_cholX, pj));
+    }
+
+    // ---- algorithmic work counters ----
+    for (int b = 0; b < NB; b++) {
+        BlockInfo &k = c->blk[b];
+        double n = k.n;
+        if (k.kind == 0) {
+            double U = 0.5 * (k.URt + k.ULt), m = k.m, dl = k.delta, nt = (double)(k.t1 - k.t0);
+            c->cnt_bytes += 8.0 * (2 * n * n + dl * U);
+            c->cnt_flops += (m == 1) ? 2.0 * (2 * n * n * U + 2 * n * U * U) + U * U : 2.0 * m * (2 * n * dl * U / m + 2 * U * dl * U / m) + nt * nt;
+        } else {
+            double Pc = k.cnt;
+            c->cnt_bytes += 8.0 * (Pc * n * n + 2 * n * n);
+            c->cnt_flops += Pc * 6 * n * n * n + Pc * Pc * n * n;
+        }
+    }
+    for (int j = 0; j < J; j++) {
+        double Pj = c->P[j];
+        c->cnt_bytes += 8.0 * Pj * Pj;
+        c->cnt_factor_flops += Pj * Pj * Pj / 3 + Pj * Pj * N + 2.0 * N * N * Pj;
+        c->cnt_solve_flops += 2 * Pj * Pj + 4 * Pj * N;
+    }
+    c->cnt_factor_flops += (double)N * N * N / 3;
+    c->cnt_solve_flops += 2.0 * N * N;
+    HIPCK(hipStreamSynchronize(c->stream));
+    *out = c;
+    return 0;
+#undef CK
+#undef HIPCK
+}
+
+extern "C" void clrs_ctx_destroy(clrs_ctx *c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    Plan *plans[] = {&c->p_assemble, &c->p_cholS, &c->p_linvB, &c->p_Q, &c->p_cholQ, &c->p_fwd, &c->p_bwd, &c->p_cholX, &c->p_zeroL};
+    for (Plan *p : plans)
+        if (p->graph) hipGraphExecDestroy(p->graph);
+    for (void *p : c->allocs) hipFree(p);
+    for (int i = 0; i < 10; i++)
+        if (c->ev[i]) hipEventDestroy(c->ev[i]);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int clrs_get_dims(const clrs_ctx *c, clrs_dims *o) {
+    if (!c || !o) return fail(CLRS_ERR_INVALID, "null argument");
+    o->xy_len = c->xylen; o->x_len = c->xlen; o->S_len = c->Slen; o->n_terms = c->T; o->n_free = c->N;
+    o->n_clusters = c->J; o->n_blocks = c->NB; o->reserved = 0;
+    return 0;
+}
+
+extern "C" int clrs_get_unique_counts(const clrs_ctx *c, int32_t b, int32_t r, int32_t *nr, int32_t *nl) {
+    if (!c || b < 0 || b >= c->NB) return fail(CLRS_ERR_INVALID, "block out of range");
+    const BlockInfo &k = c->blk[b];
+    if (k.kind != 0 || r < 0 || r >= k.m) return fail(CLRS_ERR_INVALID, "not a low-rank sub-block row");
+    if (nr) *nr = k.UR[r];
+    if (nl) *nl = k.UL[r];
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-iteration drivers
+// ------------------------------------------------------------------------------------------------
+static int read_info(clrs_ctx *c, int *status) {
+    int h = INFO_NONE;
+    HIPCHECK(hipMemcpyAsync(&h, c->d_info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    *status = (h == INFO_NONE) ? 0 : h;
+    return 0;
+}
+
+static int collect_times(clrs_ctx *c) {
+    if (c->times_pending) {
+        for (int i = 0; i < 5; i++) {
+            float ms = 0;
+            int a = (i == 0) ? 0 : i + 1, b = (i == 0) ? 1 : i + 2;   // ev0-1: schur; ev2..7: cholS,LinvB,Q,cholQ boundaries
+            if (hipEventElapsedTime(&ms, c->ev[a], c->ev[b]) == hipSuccess) c->times[i] = ms * 1e-3;
+        }
+        c->times_pending = false;
+    }
+    if (c->solve_time_pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, c->ev[7], c->ev[8]) == hipSuccess) c->times[5] = ms * 1e-3;
+        c->solve_time_pending = false;
+    }
+    return 0;
+}
+
+extern "C" int clrs_schur_assemble_dev(clrs_ctx *c, const double *d_Xchol, const double *d_Y) {
+    if (!c || !d_Xchol || !d_Y) return fail(CLRS_ERR_INVALID, "null argument");
+    HIPCHECK(hipSetDevice(c->device));
+    if (d_Xchol != c->d_Xc) HIPCHECK(hipMemcpyAsync(c->d_Xc, d_Xchol, sizeof(double) * c->xylen, hipMemcpyDeviceToDevice, c->stream));
+    if (d_Y != c->d_Y) HIPCHECK(hipMemcpyAsync(c->d_Y, d_Y, sizeof(double) * c->xylen, hipMemcpyDeviceToDevice, c->stream));
+    if (c->timing) HIPCHECK(hipEventRecord(c->ev[0], c->stream));
+    int rc = run_plan(c, c->p_assemble);
+    if (rc) return rc;
+    if (c->timing) HIPCHECK(hipEventRecord(c->ev[1], c->stream));
+    c->assembled = true; c->factored = false;
+    return 0;
+}
+
+extern "C" int clrs_schur_assemble(clrs_ctx *c, const double *Xchol, const double *Y, double *S_out, double *AY_out) {
+    if (!c || !Xchol || !Y) return fail(CLRS_ERR_INVALID, "null argument");
+    HIPCHECK(hipSetDevice(c->device));
+    HIPCHECK(hipMemcpyAsync(c->d_Xc, Xchol, sizeof(double) * c->xylen, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipMemcpyAsync(c->d_Y, Y, sizeof(double) * c->xylen, hipMemcpyHostToDevice, c->stream));
+    int rc = clrs_schur_assemble_dev(c, c->d_Xc, c->d_Y);
+    if (rc) return rc;
+    if (S_out) HIPCHECK(hipMemcpyAsync(S_out, c->d_S, sizeof(double) * c->Slen, hipMemcpyDeviceToHost, c->stream));
+    if (AY_out && c->T > 0) HIPCHECK(hipMemcpyAsync(AY_out, c->d_AY, sizeof(double) * c->T, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int clrs_schur_factor_local_dev(clrs_ctx *c) {
+    if (!c) return fail(CLRS_ERR_INVALID, "null argument");
+    if (!c->assembled) return fail(CLRS_ERR_STATE, "clrs_schur_factor called before clrs_schur_assemble");
+    HIPCHECK(hipSetDevice(c->device));
+    int rc;
+    if (c->timing) HIPCHECK(hipEventRecord(c->ev[2], c->stream));
+    if ((rc = run_plan(c, c->p_cholS))) return rc;
+    if (c->timing) HIPCHECK(hipEventRecord(c->ev[3], c->stream));
+    if ((rc = run_plan(c, c->p_linvB))) return rc;
+    if (c->timing) HIPCHECK(hipEventRecord(c->ev[4], c->stream));
+    if ((rc = run_plan(c, c->p_Q))) return rc;
+    if (c->timing) HIPCHECK(hipEventRecord(c->ev[5], c->stream));
+    c->assembled = false;  // S now holds L
+    return 0;
+}
+
+extern "C" int clrs_schur_factor_finish_dev(clrs_ctx *c) {
+    if (!c) return fail(CLRS_ERR_INVALID, "null argument");
+    HIPCHECK(hipSetDevice(c->device));
+    int rc;
+    if ((rc = run_plan(c, c->p_cholQ))) return rc;
+    if (c->timing) { HIPCHECK(hipEventRecord(c->ev[6], c->stream)); c->times_pending = true; }
+    c->factored = true;
+    return 0;
+}
+
+extern "C" int clrs_sync_status(clrs_ctx *c) {
+    if (!c) return fail(CLRS_ERR_INVALID, "null argument");
+    int st = 0;
+    int rc = read_info(c, &st);
+    if (rc) return rc;
+    if (c->timing) collect_times(c);
+    return st;
+}
+
+extern "C" int clrs_schur_factor(clrs_ctx *c) {
+    int rc = clrs_schur_factor_local_dev(c);
+    if (rc) return rc;
+    if ((rc = clrs_schur_factor_finish_dev(c))) return rc;
+    return clrs_sync_status(c);
+}
+
+extern "C" int clrs_get_factor(clrs_ctx *c, double *L, double *LinvB, double *LQ) {
+    if (!c) return fail(CLRS_ERR_INVALID, "null argument");
+    if (!c->factored) return fail(CLRS_ERR_STATE, "no factorisation available");
+    HIPCHECK(hipSetDevice(c->device));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    if (L) {
+        std::vector<double> h((size_t)c->Slen);
+        HIPCHECK(hipMemcpy(h.data(), c->d_S, sizeof(double) * c->Slen, hipMemcpyDeviceToHost));
+        for (int j = 0; j < c->J; j++) {
+            const int P = c->P[j];
+            double *Sj = h.data() + c->Soff[j];
+            for (int col = 0; col < P; col++)
+                for (int r = 0; r < col; r++) Sj[r + (i64)col * P] = 0.0;   // tools.jl:100-105
+        }
+        std::memcpy(L, h.data(), sizeof(double) * c->Slen);
+    }
+    if (LinvB && c->N > 0) {
+        std::vector<double> h((size_t)(c->xlen * c->N));
+        HIPCHECK(hipMemcpy(h.data(), c->d_LB, sizeof(double) * h.size(), hipMemcpyDeviceToHost));
+        i64 off = 0;
+        for (int j = 0; j < c->J; j++) {
+            for (int col = 0; col < c->N; col++)
+                for (int r = 0; r < c->P[j]; r++) LinvB[off + r + (i64)col * c->P[j]] = h[(size_t)(c->coff[j] + r + (i64)col * c->xlen)];
+            off += (i64)c->P[j] * c->N;
+        }
+    }
+    if (LQ && c->N > 0) {
+        HIPCHECK(hipMemcpy(LQ, c->d_Q, sizeof(double) * c->N * c->N, hipMemcpyDeviceToHost));
+        for (int col = 0; col < c->N; col++)
+            for (int r = 0; r < col; r++) LQ[r + (i64)col * c->N] = 0.0;
+    }
+    return 0;
+}
+
+extern "C" int clrs_schur_solve_fwd_dev(clrs_ctx *c, const double *d_rhs_x) {
+    if (!c || !d_rhs_x) return fail(CLRS_ERR_INVALID, "null argument");
+    if (!c->factored) return fail(CLRS_ERR_STATE, "clrs_schur_solve called before clrs_schur_factor");
+    HIPCHECK(hipSetDevice(c->device));
+    if (d_rhs_x != c->d_rhsx) HIPCHECK(hipMemcpyAsync(c->d_rhsx, d_rhs_x, sizeof(double) * c->xlen, hipMemcpyDeviceToDevice, c->stream));
+    if (c->timing) HIPCHECK(hipEventRecord(c->ev[7], c->stream));
+    return run_plan(c, c->p_fwd);
+}
+
+extern "C" int clrs_schur_solve_bwd_dev(clrs_ctx *c, const double *d_rhs_y, double *d_dx, double *d_dy) {
+    if (!c) return fail(CLRS_ERR_INVALID, "null argument");
+    if (!c->factored) return fail(CLRS_ERR_STATE, "clrs_schur_solve called before clrs_schur_factor");
+    HIPCHECK(hipSetDevice(c->device));
+    if (c->N > 0 && d_rhs_y && d_rhs_y != c->d_rhsy)
+        HIPCHECK(hipMemcpyAsync(c->d_rhsy, d_rhs_y, sizeof(double) * c->N, hipMemcpyDeviceToDevice, c->stream));
+    int rc = run_plan(c, c->p_bwd);
+    if (rc) return rc;
+    if (c->timing) { HIPCHECK(hipEventRecord(c->ev[8], c->stream)); c->solve_time_pending = true; }
+    if (d_dx && d_dx != c->d_t) HIPCHECK(hipMemcpyAsync(d_dx, c->d_t, sizeof(double) * c->xlen, hipMemcpyDeviceToDevice, c->stream));
+    if (d_dy && c->N > 0 && d_dy != c->d_dy) HIPCHECK(hipMemcpyAsync(d_dy, c->d_dy, sizeof(double) * c->N, hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+}
+
+extern "C" int clrs_schur_solve(clrs_ctx *c, const double *rhs_x, const double *rhs_y, double *dx, double *dy) {
+    if (!c || !rhs_x || !dx) return fail(CLRS_ERR_INVALID, "null argument");
+    if (!c->factored) return fail(CLRS_ERR_STATE, "clrs_schur_solve called before clrs_schur_factor");
+    HIPCHECK(hipSetDevice(c->device));
+    HIPCHECK(hipMemcpyAsync(c->d_rhsx, rhs_x, sizeof(double) * c->xlen, hipMemcpyHostToDevice, c->stream));
+    if (c->N > 0) {
+        if (!rhs_y || !dy) return fail(CLRS_ERR_INVALID, "null argument");
+        HIPCHECK(hipMemcpyAsync(c->d_rhsy, rhs_y, sizeof(double) * c->N, hipMemcpyHostToDevice, c->stream));
+    }
+    int rc;
+    if ((rc = clrs_schur_solve_fwd_dev(c, c->d_rhsx))) return rc;
+    if ((rc = clrs_schur_solve_bwd_dev(c, c->d_rhsy, nullptr, nullptr))) return rc;
+    HIPCHECK(hipMemcpyAsync(dx, c->d_t, sizeof(double) * c->xlen, hipMemcpyDeviceToHost, c->stream));
+    if (c->N > 0) HIPCHECK(hipMemcpyAsync(dy, c->d_dy, sizeof(double) * c->N, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int clrs_cholesky_blocks(clrs_ctx *c, const double *X, double *Xchol) {
+    if (!c || !X || !Xchol) return fail(CLRS_ERR_INVALID, "null argument");
+    HIPCHECK(hipSetDevice(c->device));
+    HIPCHECK(hipMemcpyAsync(c->d_X, X, sizeof(double) * c->xylen, hipMemcpyHostToDevice, c->stream));
+    int rc = run_plan(c, c->p_cholX);
+    if (rc) return rc;
+    int st = 0;
+    if ((rc = read_info(c, &st))) return rc;
+    HIPCHECK(hipMemcpy(Xchol, c->d_X, sizeof(double) * c->xylen, hipMemcpyDeviceToHost));
+    for (int b = 0; b < c->NB; b++) {
+        const int n = c->blk[b].n;
+        double *A = Xchol + c->blk[b].xyoff;
+        for (int col = 0; col < n; col++)
+            for (int r = 0; r < col; r++) A[r + (i64)col * n] = 0.0;
+    }
+    return st;
+}
+
+extern "C" double *clrs_q_buffer_dev(clrs_ctx *c) { return c ? c->d_Q : nullptr; }
+extern "C" double *clrs_u_buffer_dev(clrs_ctx *c) { return c ? c->d_u : nullptr; }
+extern "C" double *clrs_S_buffer_dev(clrs_ctx *c) { return c ? c->d_S : nullptr; }
+extern "C" double *clrs_AY_buffer_dev(clrs_ctx *c) { return c ? c->d_AY : nullptr; }
+extern "C" void *clrs_stream(clrs_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+extern "C" int clrs_set_timing(clrs_ctx *c, int enabled) {
+    if (!c) return fail(CLRS_ERR_INVALID, "null argument");
+    c->timing = enabled != 0;
+    return 0;
+}
+extern "C" int clrs_get_timings(clrs_ctx *c, double t[6]) {
+    if (!c || !t) return fail(CLRS_ERR_INVALID, "null argument");
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    collect_times(c);
+    for (int i = 0; i < 6; i++) t[i] = c->times[i];
+    return 0;
+}
+extern "C" int clrs_get_counters(const clrs_ctx *c, double *ab, double *af, double *ff, double *sf) {
+    if (!c) return fail(CLRS_ERR_INVALID, "null argument");
+    if (ab) *ab = c->cnt_bytes;
+    if (af) *af = c->cnt_flops;
+    if (ff) *ff = c->cnt_factor_flops;
+    if (sf) *sf = c->cnt_solve_flops;
+    return 0;
+}
+extern "C" int clrs_set_graph_mode(clrs_ctx *c, int enabled) {
+    if (!c) return fail(CLRS_ERR_INVALID, "null argument");
+    c->graph_mode = enabled != 0;
+    return 0;
+}
+extern "C" int clrs_plan_info(const clrs_ctx *c, int32_t *na, int32_t *nf, int32_t *ns) {
+    if (!c) return fail(CLRS_ERR_INVALID, "null argument");
+    if (na) *na = c->p_assemble.launches();
+    if (nf) *nf = c->p_cholS.launches() + c->p_linvB.launches() + c->p_Q.launches() + c->p_cholQ.launches();
+    if (ns) *ns = c->p_fwd.launches() + c->p_bwd.launches();
+    return 0;
+}
+
+extern "C" const char *clrs_strerror(int code) {
+    switch (code) {
+        case CLRS_OK: return "ok";
+        case CLRS_ERR_INVALID: return "invalid argument or malformed SDP description";
+        case CLRS_ERR_HIP: return "HIP runtime error";
+        case CLRS_ERR_NO_DEVICE: return "no usable HIP device";
+        case CLRS_ERR_STATE: return "call order violated";
+        default: return code > 0 ? "factorisation failure (non-positive pivot)" : "unknown error";
+    }
+}
+extern "C" const char *clrs_last_error(void) { return g_last_error.c_str(); }
+extern "C" const char *clrs_version(void) { return "clrs-hip 0.1.0 (gfx950)"; }
+
+// ------------------------------------------------------------------------------------------------
+// test hooks
+// ------------------------------------------------------------------------------------------------
+static clrs_ctx *mini_ctx(int device) {
+    clrs_ctx *c = new clrs_ctx();
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; }
+    std::vector<int> hi(1, INFO_NONE);
+    int *di;
+    if (upload(c, hi, &di)) { clrs_ctx_destroy(c); return nullptr; }
+    c->d_info = di;
+    return c;
+}
+
+extern "C" int clrs_test_gemm(int device, int ta, int tb, int M, int N, int K, double alpha, const double *A, int lda, const double *B,
+                              int ldb, double beta, double *C, int ldc) {
+    clrs_ctx *c = mini_ctx(device);
+    if (!c) return fail(CLRS_ERR_NO_DEVICE, "no device");
+    int rc = 0;
+    i64 na = (i64)lda * (ta ? M : K), nb = (i64)ldb * (tb ? K : N), nc = (i64)ldc * N;
+    std::vector<double> hA(A, A + na), hB(B, B + nb), hC(C, C + nc);
+    double *dA, *dB, *dC;
+    if ((rc = upload(c, hA, &dA)) || (rc = upload(c, hB, &dB)) || (rc = upload(c, hC, &dC))) { clrs_ctx_destroy(c); return rc; }
+    Plan pl;
+    std::vector<GemmDesc> g;
+    g.push_back(mk_gemm(ta, tb, M, N, K, alpha, dA, lda, dB, ldb, beta, dC, ldc));
+    if (!(rc = add_gemm_stage(c, pl, g)) && !(rc = run_steps(c, pl))) {
+        if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(C, dC, sizeof(double) * nc, hipMemcpyDeviceToHost) != hipSuccess)
+            rc = fail(CLRS_ERR_HIP, "copy back failed");
+    }
+    clrs_ctx_destroy(c);
+    return rc;
+}
+
+extern "C" int clrs_test_potrf(int device, int n, double *A, int lda) {
+    clrs_ctx *c = mini_ctx(device);
+    if (!c) return fail(CLRS_ERR_NO_DEVICE, "no device");
+    int rc = 0, st = 0;
+    std::vector<double> hA(A, A + (i64)lda * n);
+    double *dA;
+    if ((rc = upload(c, hA, &dA))) { clrs_ctx_destroy(c); return rc; }
+    Plan pl;
+    std::vector<PotrfJob> pj;
+    pj.push_back(PotrfJob{dA, lda, n, 1});
+    if (!(rc = plan_potrf(c, pl, pj)) && !(rc = run_steps(c, pl)) && !(rc = read_info(c, &st))) {
+        if (hipMemcpy(A, dA, sizeof(double) * (i64)lda * n, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(CLRS_ERR_HIP, "copy back failed");
+    }
+    clrs_ctx_destroy(c);
+    return rc ? rc : st;
+}
+
+extern "C" int clrs_test_trsm(int device, int trans, int n, int nrhs, const double *L, int ldl, double *B, int ldb) {
+    clrs_ctx *c = mini_ctx(device);
+    if (!c) return fail(CLRS_ERR_NO_DEVICE, "no device");
+    int rc = 0;
+    std::vector<double> hL(L, L + (i64)ldl * n), hB(B, B + (i64)ldb * nrhs);
+    double *dL, *dB;
+    if ((rc = upload(c, hL, &dL)) || (rc = upload(c, hB, &dB))) { clrs_ctx_destroy(c); return rc; }
+    Plan pl;
+    std::vector<TrsmJob> tj;
+    tj.push_back(TrsmJob{dL, ldl, n, dB, ldb, nrhs});
+    if (!(rc = plan_trsm(c, pl, tj, trans)) && !(rc = run_steps(c, pl))) {
+        if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(B, dB, sizeof(double) * (i64)ldb * nrhs, hipMemcpyDeviceToHost) != hipSuccess)
+            rc = fail(CLRS_ERR_HIP, "copy back failed");
+    }
+    clrs_ctx_destroy(c);
+    return rc;
+}

@@ -1,0 +1,6 @@
+"""Problem generators for the BASELINE configs, written from the mathematics
+of the reference's examples/ directory.  Each returns a `ClusteredLowRankSDP`."""
+from .polyopt import polyopt, polyopt_random, polyopt_scaled
+from .delsarte import delsarte
+from .spherepacking import cohnelkies, nsphere_packing, cohnelkies_multi
+from .sdpa import read_sdpa, sdpa_to_sdp, sdpa_scaled, write_sdpa

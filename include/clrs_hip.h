@@ -1,0 +1,187 @@
+/*
+ * clrs_hip.h -- C ABI of the MI355X-native interior-point hot path for clustered low-rank SDPs.
+ *
+ * This is the drop-in boundary for the ONE path of nanleij/ClusteredLowRankSolver.jl (v2.1.0) that
+ * this repository accelerates: per-iteration Schur-complement assembly from low-rank constraint
+ * matrices and the block-Cholesky factor/solve of the cluster-block-diagonal normal equations.
+ * The reference has no FFI seam for this path (it is plain Julia mutating preallocated Arb buffers);
+ * each entry point below names the reference function it replaces (paths relative to the reference
+ * repository).  INTEGRATION.md shows the Julia `ccall` shim a maintainer would add.
+ *
+ * Conventions
+ *   - plain C: pointers, sizes, int return codes; no C++/torch types.
+ *   - all matrices are COLUMN-MAJOR fp64 (Julia `Matrix{Float64}` layout).
+ *   - block-diagonal iterates X, Y (and the Cholesky factors of X) are passed as ONE array: the
+ *     blocks (j,l) in the order of `clrs_sdp_desc`, each n x n column-major, concatenated
+ *     ("xy layout", length sum n^2).
+ *   - S / L_j are passed as one array: per cluster P_j x P_j column-major, concatenated ("S layout").
+ *   - x-like vectors (rhs_x, dx) concatenate the clusters (length sum P_j).
+ *   - indices are 0-based; constraint indices are cluster-local (the reference's `cs_map`,
+ *     src/solver.jl:156-167, is applied by the caller).
+ *   - one context per GPU / per process; a context is not thread-safe (like the reference's shared
+ *     scratch `tempX`, `part_r`).
+ *   - return value: 0 ok; >0 factorisation failure (see clrs_schur_factor); <0 an error from
+ *     `clrs_strerror`.
+ *   - host entry points take host pointers and synchronise before returning; `_dev` entry points
+ *     take device pointers, enqueue on the context's stream and do NOT synchronise.
+ */
+#ifndef CLRS_HIP_H
+#define CLRS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CLRS_OK 0
+#define CLRS_ERR_INVALID (-1)      /* malformed description / argument */
+#define CLRS_ERR_HIP (-2)          /* a HIP runtime call failed (message via clrs_last_error) */
+#define CLRS_ERR_NO_DEVICE (-3)    /* no usable gfx950 device */
+#define CLRS_ERR_STATE (-4)        /* call order violated (e.g. solve before factor) */
+
+/*
+ * Numeric description of a ClusteredLowRankSDP restricted to what the hot path reads:
+ * replaces the traversal of `sdp.A[j][l][r,s][p]`, `sdp.B[j]` (src/interface.jl:807-819) done by
+ * precompute_matrices_bilinear_pairings (src/solver.jl:985-1059).
+ *
+ * Blocks are listed cluster by cluster.  A low-rank block (kind 0) is an m x m grid of delta x delta
+ * sub-blocks; each term t is one rank-1 piece lambda * vs * ws^T of A[j][l][r,s][p]
+ * (LowRankMat, src/interface.jl:759-763).  The convention A[r,s][p] = A[s,r][p]^T
+ * (src/solver.jl:1009) is required: for every term (p,r,s,rank) the term (p,s,r,rank) must exist.
+ * A dense ("high rank") block (kind 1) has m == 1 and lists its matrices A[j][l][1,1][p].
+ */
+typedef struct clrs_sdp_desc {
+    int32_t n_clusters;            /* J */
+    int32_t n_free;                /* N, number of free variables (columns of B) */
+    const int32_t *cluster_P;      /* [J] constraints per cluster */
+    const double *B;               /* per cluster P_j x N column-major, concatenated */
+    int32_t n_blocks;              /* total number of PSD blocks (j,l) */
+    const int32_t *block_cluster;  /* [NB] cluster of each block (non-decreasing) */
+    const int32_t *block_m;        /* [NB] sub-blocks per side */
+    const int32_t *block_delta;    /* [NB] sub-block size; block side n = m*delta */
+    const int32_t *block_kind;     /* [NB] 0 = low rank, 1 = dense */
+    const int64_t *term_ptr;       /* [NB+1] CSR: terms of block b are term_ptr[b]..term_ptr[b+1]-1 */
+    const int32_t *term_p;         /* [T] constraint index in the cluster */
+    const int32_t *term_r;         /* [T] sub-block row */
+    const int32_t *term_s;         /* [T] sub-block column */
+    const int32_t *term_rank;      /* [T] index of the rank-1 piece inside A[r,s][p] */
+    const double *term_lambda;     /* [T] */
+    const int64_t *term_vec_ptr;   /* [T+1] offsets of the term's vectors in term_vs / term_ws */
+    const double *term_vs;         /* delta doubles per term */
+    const double *term_ws;         /* delta doubles per term */
+    const int64_t *dense_ptr;      /* [NB+1] CSR over dense entries */
+    const int32_t *dense_p;        /* [D] constraint index in the cluster */
+    const int64_t *dense_A_ptr;    /* [D+1] offsets into dense_A */
+    const double *dense_A;         /* n x n column-major per entry */
+} clrs_sdp_desc;
+
+typedef struct clrs_ctx clrs_ctx;
+
+/* Sizes of the flat layouts, for buffer allocation by the caller. */
+typedef struct clrs_dims {
+    int64_t xy_len;    /* sum n^2 over blocks */
+    int64_t x_len;     /* sum P_j */
+    int64_t S_len;     /* sum P_j^2 */
+    int64_t n_terms;   /* T */
+    int32_t n_free;    /* N */
+    int32_t n_clusters;
+    int32_t n_blocks;
+    int32_t reserved;
+} clrs_dims;
+
+/* Create a context on HIP device `device`: de-duplicates the sampled vectors, builds the gather
+ * tables and the launch plan, uploads all static data and allocates every device buffer.
+ * Replaces: precompute_matrices_bilinear_pairings (src/solver.jl:985-1059), the preallocation
+ * block src/solver.jl:298-317 and ThreadingInfo (src/threadinginfo.jl:59-102). */
+int clrs_ctx_create(const clrs_sdp_desc *desc, int device, clrs_ctx **out);
+void clrs_ctx_destroy(clrs_ctx *ctx);
+int clrs_get_dims(const clrs_ctx *ctx, clrs_dims *dims);
+
+/* Number of unique right / left vectors of sub-block row r of block b after de-duplication
+ * (sizes of rightvecs[j][l][r] / leftvecs[j][l][r], src/solver.jl:1018-1051). */
+int clrs_get_unique_counts(const clrs_ctx *ctx, int32_t block, int32_t r, int32_t *n_right, int32_t *n_left);
+
+/* Cluster sharding across GPUs (one process per GPU) is done by the caller: each rank creates its
+ * context from the sub-description holding only ITS clusters (all N free variables), calls
+ * clrs_schur_factor_local_dev, sums the partial Q (clrs_q_buffer_dev) over ranks with one RCCL
+ * all-reduce and calls clrs_schur_factor_finish_dev; the solve is split the same way around the
+ * all-reduce of the partial u = LinvB^T t (clrs_u_buffer_dev). */
+
+/* Lower Cholesky factors of all X blocks: Xchol_blk = chol(X_blk).
+ * Replaces: the approx_cholesky!(X_inv_blk, X_blk) loop, src/solver.jl:388-399.
+ * Returns 0, or b+1 for the first block whose pivot is not positive. */
+int clrs_cholesky_blocks(clrs_ctx *ctx, const double *X, double *Xchol);
+
+/* Schur complement assembly S[j][p,q] = sum_l <A_p, X^-1 A_q Y> from the Cholesky factors of X
+ * (xy layout) and Y.  Optionally returns S (S layout, full symmetric) and the per-term bilinear
+ * pairings w^T Y v (A_Y, length T, in term order).
+ * Replaces: compute_S_integrated! (src/solver.jl:1062-1226). */
+int clrs_schur_assemble(clrs_ctx *ctx, const double *Xchol, const double *Y, double *S_out, double *AY_out);
+
+/* S_j = L_j L_j^T, LinvB_j = L_j^-1 B_j, Q = sum_j LinvB_j^T LinvB_j, Q = L_Q L_Q^T.
+ * Replaces: steps 3-4 of compute_T_decomposition! (src/solver.jl:1244-1279).
+ * Returns 0; j+1 if S_j is not positive definite ("S was not decomposed succesfully in block j",
+ * :1249); n_clusters+1 if Q is not ("Q was not decomposed correctly", :1277). */
+int clrs_schur_factor(clrs_ctx *ctx);
+
+/* Copies of the factors for inspection / for the caller's buffers `S` (holding L_j), `LinvB`, `Q`
+ * (holding L_Q) of compute_T_decomposition!.  Any pointer may be NULL.
+ * L: S layout (strict upper triangles zero); LinvB: per cluster P_j x N column-major, concatenated;
+ * LQ: N x N. */
+int clrs_get_factor(clrs_ctx *ctx, double *L, double *LinvB, double *LQ);
+
+/* Solve [S -B; B^T 0] (dx; dy) = (rhs_x; rhs_y) with the current factorisation.
+ * Replaces: the "solve system" stage of compute_search_direction! (src/solver.jl:1527-1582). */
+int clrs_schur_solve(clrs_ctx *ctx, const double *rhs_x, const double *rhs_y, double *dx, double *dy);
+
+/* --- device-pointer / sharded variants (enqueue on the context stream, no synchronisation) --- */
+int clrs_schur_assemble_dev(clrs_ctx *ctx, const double *d_Xchol, const double *d_Y);
+int clrs_schur_factor_local_dev(clrs_ctx *ctx);               /* up to the local partial Q */
+double *clrs_q_buffer_dev(clrs_ctx *ctx);                     /* N x N device buffer holding Q (partial, then total) */
+int clrs_schur_factor_finish_dev(clrs_ctx *ctx);              /* Cholesky of the (summed) Q */
+int clrs_schur_solve_fwd_dev(clrs_ctx *ctx, const double *d_rhs_x);   /* t = L^-1 rhs_x ; u = LinvB^T t (partial) */
+double *clrs_u_buffer_dev(clrs_ctx *ctx);                     /* N doubles: the partial u, to be summed over ranks */
+int clrs_schur_solve_bwd_dev(clrs_ctx *ctx, const double *d_rhs_y, double *d_dx, double *d_dy);
+double *clrs_S_buffer_dev(clrs_ctx *ctx);                     /* S layout; holds S after assemble, L_j after factor */
+double *clrs_AY_buffer_dev(clrs_ctx *ctx);                    /* [T] */
+/* Blocks until the stream is idle and returns the factorisation status of the last factor call
+ * (same codes as clrs_schur_factor). */
+int clrs_sync_status(clrs_ctx *ctx);
+void *clrs_stream(clrs_ctx *ctx);                             /* hipStream_t of the context */
+
+/* Timings of the last assemble/factor calls in seconds, measured with HIP events on the context
+ * stream: t[0..4] = schur, cholS, LinvB, Q, cholQ -- the 5-way split compute_T_decomposition!
+ * returns (src/solver.jl:1282-1286); t[5] = last solve.  Enabled by clrs_set_timing(ctx, 1). */
+int clrs_set_timing(clrs_ctx *ctx, int enabled);
+int clrs_get_timings(clrs_ctx *ctx, double t[6]);
+
+/* Algorithmic work of one Schur assembly (SURVEY.md section 8d formulas, with the de-duplicated
+ * vector counts): bytes and flops; and of one factor + one solve. */
+int clrs_get_counters(const clrs_ctx *ctx, double *assemble_bytes, double *assemble_flops,
+                      double *factor_flops, double *solve_flops);
+
+/* Capture the per-iteration launch sequences into hipGraphs (1) or launch kernels one by one (0). */
+int clrs_set_graph_mode(clrs_ctx *ctx, int enabled);
+
+/* Name of the kernel that dominates the assembly for this context and the number of launches of one
+ * assemble / factor / solve call (for profiling). */
+int clrs_plan_info(const clrs_ctx *ctx, int32_t *n_launch_assemble, int32_t *n_launch_factor, int32_t *n_launch_solve);
+
+const char *clrs_strerror(int code);
+const char *clrs_last_error(void);
+const char *clrs_version(void);
+
+/* Test hook: C = alpha * op(A) op(B) + beta * C through the grouped fp64 MFMA GEMM kernel
+ * (host pointers).  Used by tests/ to check the kernel in isolation. */
+int clrs_test_gemm(int device, int ta, int tb, int M, int N, int K, double alpha, const double *A, int lda,
+                   const double *B, int ldb, double beta, double *C, int ldc);
+/* Test hooks for the blocked dense kernels (host pointers, in place): lower Cholesky of an n x n
+ * matrix (returns 0 or 1 on a non-positive pivot), and B <- L^-1 B / L^-T B. */
+int clrs_test_potrf(int device, int n, double *A, int lda);
+int clrs_test_trsm(int device, int trans, int n, int nrhs, const double *L, int ldl, double *B, int ldb);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLRS_HIP_H */

@@ -1,0 +1,218 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Tolerances (fp64 path): S assembly is compared in the norm-wise sense |S_hip - S_ref| <= 1e-11 * max|S_ref|
+against the __float128 oracle (the fp64 oracle itself differs from quad by ~1e-13 on these instances);
+factor/solve outputs are compared through residuals and against the fp64 oracle where the problem is
+well conditioned."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from tests.util import chol_blocks_np, flat, spd_iterates  # noqa: E402
+
+
+def _lib():
+    from clrs_amd import _lib
+    return _lib.load()
+
+
+def _dp(a):
+    from clrs_amd import _lib
+    return a.ctypes.data_as(_lib.p_d)
+
+
+@pytest.mark.parametrize("ta,tb", [(0, 0), (1, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (16, 16, 4), (64, 64, 16), (37, 53, 29), (130, 70, 100), (3, 200, 65)])
+def test_gemm_kernel(ta, tb, M, N, K):
+    rng = np.random.default_rng(M * 1000 + N * 10 + K)
+    A = rng.standard_normal((K, M) if ta else (M, K))
+    B = rng.standard_normal((N, K) if tb else (K, N))
+    C = rng.standard_normal((M, N))
+    ref = 0.7 * (A.T if ta else A) @ (B.T if tb else B) - 0.3 * C
+    Af, Bf, Cf = np.asfortranarray(A), np.asfortranarray(B), np.asfortranarray(C)
+    rc = _lib().clrs_test_gemm(0, ta, tb, M, N, K, 0.7, _dp(Af), Af.shape[0], _dp(Bf), Bf.shape[0], -0.3, _dp(Cf), M)
+    assert rc == 0
+    assert np.max(np.abs(Cf - ref)) <= 1e-12 * max(1.0, np.max(np.abs(ref)))
+
+
+@pytest.mark.parametrize("n", [1, 2, 17, 64, 65, 150, 300])
+def test_potrf_and_trsm(n):
+    rng = np.random.default_rng(n)
+    G = rng.standard_normal((n, n))
+    A = np.asfortranarray(np.eye(n) + G @ G.T / n)
+    L = A.copy(order="F")
+    assert _lib().clrs_test_potrf(0, n, _dp(L), n) == 0
+    Lr = np.linalg.cholesky(A)
+    assert np.max(np.abs(np.tril(L) - Lr)) <= 1e-12 * np.max(np.abs(Lr))
+    Lf = np.asfortranarray(np.tril(L))
+    for trans in (0, 1):
+        for nrhs in (1, 70):
+            B = np.asfortranarray(rng.standard_normal((n, nrhs)))
+            Bs = B.copy(order="F")
+            assert _lib().clrs_test_trsm(0, trans, n, nrhs, _dp(Lf), n, _dp(Bs), n) == 0
+            ref = np.linalg.solve(Lf.T if trans else Lf, B)
+            assert np.max(np.abs(Bs - ref)) <= 1e-10 * max(1.0, np.max(np.abs(ref)))
+
+
+def test_potrf_reports_failure():
+    A = np.asfortranarray(np.array([[1.0, 2.0], [2.0, 1.0]]))
+    assert _lib().clrs_test_potrf(0, 2, _dp(A), 2) == 1
+
+
+ASSEMBLE_CASES = ["x2p1", "polyopt8", "polyopt40", "delsarte_3_10", "delsarte_8_3", "ce_8_15", "ce_8_3", "ns_8_3_2", "ns_8_15_2",
+                  "sdpa_small", "sdpa_mid", "polyopt_scaled_100"]
+
+
+@pytest.mark.parametrize("name", ASSEMBLE_CASES)
+def test_schur_assemble_matches_oracle(name, oracle_built):
+    from clrs_amd.solver import SchurContext
+    from oracle.oracle import Oracle
+    f = flat(name)
+    X, Y = spd_iterates(f, seed=1)
+    Xc = chol_blocks_np(f, X)
+    ctx = SchurContext(f)
+    S, AY = ctx.compute_S_integrated(Xc, Y)
+    o = Oracle(f, quad=True, use_lo=False)
+    S_ref, AY_ref = o.schur_assemble(Xc, Y)
+    scale = np.max(np.abs(S_ref))
+    assert np.max(np.abs(S - S_ref)) <= 1e-11 * scale
+    if f.n_terms:
+        assert np.max(np.abs(AY - AY_ref)) <= 1e-11 * max(1.0, np.max(np.abs(AY_ref)))
+    # exact symmetry, like symmetric! (src/tools.jl:43-57)
+    for j in range(f.n_clusters):
+        P = int(f.cluster_P[j])
+        Sj = S[f.S_off[j]:f.S_off[j + 1]].reshape(P, P, order="F")
+        assert np.array_equal(Sj, Sj.T)
+    ctx.close()
+
+
+def test_dedup_counts_match_oracle(oracle_built):
+    from clrs_amd.solver import SchurContext
+    from oracle.oracle import Oracle
+    f = flat("ns_8_15_2")
+    ctx = SchurContext(f)
+    o = Oracle(f)
+    for b in range(f.n_blocks):
+        if f.block_kind[b] == 0:
+            UR, UL = o.unique_counts(b)
+            assert ctx.unique_counts(b) == (list(UR), list(UL))
+    # the 96-constraint cluster collapses to 32 unique vectors per sub-block row (src/solver.jl:988)
+    big = [b for b in range(f.n_blocks) if f.block_n[b] == 32]
+    assert big and all(ctx.unique_counts(b)[0] == [32, 32] for b in big)
+    ctx.close()
+
+
+FACTOR_CASES = ["x2p1", "polyopt8", "polyopt40", "delsarte_3_10", "delsarte_8_3", "ns_8_3_2", "sdpa_small", "sdpa_mid", "polyopt_scaled_100"]
+
+
+@pytest.mark.parametrize("name", FACTOR_CASES)
+def test_factor_and_solve_match_oracle(name, oracle_built):
+    from clrs_amd.solver import SchurContext, compute_T_decomposition, solve_system
+    from oracle.oracle import Oracle
+    f = flat(name)
+    X, Y = spd_iterates(f, seed=2)
+    Xc = chol_blocks_np(f, X)
+    ctx = SchurContext(f)
+    _, S, _ = compute_T_decomposition(ctx, Xc, Y, want_S=True)
+    L, LinvB, LQ = ctx.get_factor()
+    o = Oracle(f, quad=False)
+    o.schur_assemble(Xc, Y)
+    assert o.schur_factor() == 0
+    L_ref, LinvB_ref, LQ_ref = o.get_factor()
+    tol = 1e-9
+    assert np.max(np.abs(L - L_ref)) <= tol * np.max(np.abs(L_ref))
+    if f.n_free:
+        assert np.max(np.abs(LinvB - LinvB_ref)) <= tol * max(1.0, np.max(np.abs(LinvB_ref)))
+        assert np.max(np.abs(LQ - LQ_ref)) <= tol * max(1.0, np.max(np.abs(LQ_ref)))
+    rng = np.random.default_rng(7)
+    rx, ry = rng.standard_normal(f.x_len), rng.standard_normal(f.n_free)
+    dx, dy = solve_system(ctx, rx, ry)
+    dx_ref, dy_ref = o.schur_solve(rx, ry)
+    assert np.max(np.abs(dx - dx_ref)) <= 1e-8 * max(1.0, np.max(np.abs(dx_ref)))
+    if f.n_free:
+        assert np.max(np.abs(dy - dy_ref)) <= 1e-8 * max(1.0, np.max(np.abs(dy_ref)))
+    # structural identity: S dx - B dy = rhs_x ; B^T dx = rhs_y   (src/solver.jl:1527)
+    N = f.n_free
+    bty = np.zeros(N)
+    for j in range(f.n_clusters):
+        P = int(f.cluster_P[j])
+        sl = slice(int(f.cluster_off[j]), int(f.cluster_off[j + 1]))
+        Sj = S[f.S_off[j]:f.S_off[j + 1]].reshape(P, P, order="F")
+        r = Sj @ dx[sl] - rx[sl]
+        if N:
+            Bj = f.B[int(f.cluster_off[j]) * N:int(f.cluster_off[j + 1]) * N].reshape(P, N, order="F")
+            r -= Bj @ dy
+            bty += Bj.T @ dx[sl]
+        assert np.max(np.abs(r)) <= 1e-8 * max(1.0, np.max(np.abs(Sj)) * np.max(np.abs(dx)))
+    if N:
+        assert np.max(np.abs(bty - ry)) <= 1e-8 * max(1.0, np.max(np.abs(dx)))
+    ctx.close()
+
+
+def test_factor_failure_is_reported_like_the_reference():
+    """cohnelkies(8,15) is not factorisable in fp64 (cond(S) ~ 1e30): the path must report it, not crash."""
+    from clrs_amd.solver import SchurContext, SolverFailure, compute_T_decomposition
+    f = flat("ce_8_15")
+    X, Y = spd_iterates(f, seed=3)
+    ctx = SchurContext(f)
+    with pytest.raises(SolverFailure, match="was not decomposed"):
+        compute_T_decomposition(ctx, chol_blocks_np(f, X), Y)
+    ctx.close()
+
+
+def test_cholesky_blocks(oracle_built):
+    from clrs_amd.solver import SchurContext, SolverFailure
+    f = flat("delsarte_3_10")
+    X, _ = spd_iterates(f, seed=4)
+    ctx = SchurContext(f)
+    Xc = ctx.cholesky_blocks(X)
+    assert np.max(np.abs(Xc - chol_blocks_np(f, X))) <= 1e-12 * np.max(np.abs(Xc))
+    X[f.block_off[3]] = -1.0
+    with pytest.raises(SolverFailure, match=r"block \(1,4\)"):
+        ctx.cholesky_blocks(X)
+    ctx.close()
+
+
+def test_graph_mode_matches_eager():
+    from clrs_amd.solver import SchurContext
+    f = flat("ns_8_3_2")
+    X, Y = spd_iterates(f, seed=5)
+    Xc = chol_blocks_np(f, X)
+    a = SchurContext(f)
+    b = SchurContext(f, graph=True)
+    Sa, _ = a.compute_S_integrated(Xc, Y)
+    for _ in range(3):
+        Sb, _ = b.compute_S_integrated(Xc, Y)
+    assert np.array_equal(Sa, Sb)
+    assert a.factor() == 0 and b.factor() == 0
+    rx, ry = np.ones(f.x_len), np.ones(f.n_free)
+    for u, v in zip(a.solve(rx, ry), b.solve(rx, ry)):
+        assert np.array_equal(u, v)
+    a.close(); b.close()
+
+
+@pytest.mark.parametrize("name,expected,tol", [("x2p1", 1.0, 1e-6), ("delsarte_3_10", 13.158314, 1e-5), ("delsarte_8_3", 240.0, 1e-4)])
+def test_solvesdp_known_answers(name, expected, tol):
+    """End-to-end through the path with the reference's pinned objectives (test/runtests_solver.jl:15,86-87; README.md:149)."""
+    from clrs_amd.solver import solvesdp
+    r = solvesdp(flat(name))
+    assert r.error_code == 0, (r.status, r.iterations)
+    assert abs(r.primal_objective - expected) <= tol * max(1.0, abs(expected))
+    assert abs(r.dual_objective - expected) <= tol * max(1.0, abs(expected))
+
+
+def test_solvesdp_matches_oracle_loop(oracle_built):
+    """Same fp64 algorithm, host+HIP vs the C oracle loop: objectives and iteration counts agree."""
+    from clrs_amd.solver import solvesdp
+    from oracle.oracle import Oracle
+    f = flat("polyopt40")
+    r = solvesdp(f)
+    o = Oracle(f, quad=False).solvesdp(omega_p=1e4, omega_d=1e4, duality_gap_threshold=1e-8, dual_error_threshold=1e-9,
+                                        primal_error_threshold=1e-9)
+    assert r.error_code == 0 and o["error_code"] == 0
+    assert abs(r.primal_objective - o["p_obj"]) <= 1e-6
+    assert abs(r.iterations - o["iterations"]) <= 2
+    n = min(3, len(r.history))
+    assert np.allclose(r.history[:n, 1], o["hist"][:n, 1], rtol=1e-6)      # mu trace
+    assert np.allclose(r.history[:n, 8:10], o["hist"][:n, 8:10], rtol=1e-3)  # step lengths
