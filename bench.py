@@ -1,0 +1,300 @@
+#!/usr/bin/env python3
+"""bench.py -- interior-point hot-path iterations/sec + Schur-assembly roofline on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+Workload (BASELINE.json: "SpherePacking d=8, 2d=30"): the Cohn-Elkies sphere-packing SDP
+cohnelkies(8, 15) of the reference's examples/SpherePacking.jl:117-185 -- 2 clusters of P = 32
+constraints, PSD blocks 16x16 (rank-1 constraint matrices) + one 1x1 dense block, N = 31 free variables.
+With N GPUs the problem is weak-scaled along the reference's own outer parallel axis (clusters): 2 clusters
+per GPU (cohnelkies_multi with 2N-1 sign-constraint clusters), sharded one shard per rank, coupled only by
+the RCCL all-reduce of Q (31 x 31) and of u (31) -- SURVEY.md section 8e.
+
+One step = one pass of the hot path of one interior-point iteration on device-resident iterates:
+    Cholesky of the X blocks            (src/solver.jl:388-399)
+    Schur assembly                      (compute_S_integrated!, :1062-1226)
+    chol S_j, L^-1 B, Q, chol Q         (compute_T_decomposition!, :1244-1279)
+    2 x system solve                    (predictor + corrector, compute_search_direction! :1527-1582)
+`value` = steps/s over all ranks' clusters (the iteration is one job; N GPUs hold N x the clusters).
+
+`roofline` is measured in the same process with HIP events around every launch (library-side, on the
+stream the kernels run on) for the Schur assembly of a many-cluster instance of the SAME block shapes
+(`roofline.workload`), where the launch moves enough bytes for a bandwidth figure to mean something;
+`roofline_named` is the same measurement on the 2-cluster problem itself (launch-latency bound: 41 KB
+per assembly).  `cpu_baseline` times the CPU oracle (oracle/clrs_oracle.c, fp64, OpenMP) on the same
+step on the host cores -- a port, not the reference (which needs Julia + Arb, absent here).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+FP64_PEAK_TFLOPS = 78.6      # MI355X fp64 vector = matrix peak (256 CU x 128 flop/clk x 2.4 GHz)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def seeded_iterates(flat, seed):
+    """X, Y = I + G G^T / n per block (SURVEY.md section 8d synthetic iterates), xy layout."""
+    rng = np.random.default_rng(seed)
+    X, Y = np.zeros(flat.xy_len), np.zeros(flat.xy_len)
+    for b in range(flat.n_blocks):
+        n = int(flat.block_n[b])
+        for M in (X, Y):
+            G = rng.standard_normal((n, n))
+            M[flat.block_off[b]:flat.block_off[b + 1]] = (np.eye(n) + G @ G.T / n).reshape(-1, order="F")
+    return X, Y
+
+
+def build_problem(n_pairs: int):
+    """cohnelkies(8,15) for n_pairs == 1; otherwise 2*n_pairs clusters (1 + (2 n_pairs - 1) radii)."""
+    import clrs_amd
+    from clrs_amd.problems import cohnelkies_multi
+    R = 2 * n_pairs - 1
+    radii = [1.0 + 0.125 * k for k in range(R)]
+    return clrs_amd.flatten(cohnelkies_multi(8, 15, radii))
+
+
+def replicate_clusters(flat, copies: int):
+    """A many-cluster instance with the block shapes of `flat`: the clusters of `flat` repeated `copies`
+    times (independent clusters with identical constraint data, distinct iterates).  Only used for the
+    roofline measurement of the assembly kernels."""
+    import copy
+    from clrs_amd.sdp import shard_clusters
+    J = flat.n_clusters
+    parts = [shard_clusters(flat, list(range(J))) for _ in range(copies)]
+    f = copy.copy(parts[0])
+    cat = np.concatenate
+    f.n_clusters = J * copies
+    f.n_blocks = flat.n_blocks * copies
+    for name in ("cluster_P", "B", "B_lo", "c", "c_lo", "C", "C_lo", "block_m", "block_delta", "block_kind", "term_p", "term_r",
+                 "term_s", "term_rank", "term_lambda", "term_lambda_lo", "term_vs", "term_vs_lo", "term_ws", "term_ws_lo",
+                 "dense_p", "dense_A", "dense_A_lo", "block_n"):
+        setattr(f, name, cat([getattr(p, name) for p in parts]))
+    f.block_cluster = cat([p.block_cluster + k * J for k, p in enumerate(parts)]).astype(np.int32)
+
+    def cat_ptr(name):
+        out, off = [np.zeros(1, np.int64)], 0
+        for p in parts:
+            a = getattr(p, name)
+            out.append(a[1:] + off)
+            off += int(a[-1])
+        return cat(out).astype(np.int64)
+
+    for name in ("term_ptr", "term_vec_ptr", "dense_ptr", "dense_A_ptr"):
+        setattr(f, name, cat_ptr(name))
+    f.block_off = np.concatenate([[0], np.cumsum(f.block_n.astype(np.int64) ** 2)]).astype(np.int64)
+    f.cluster_off = np.concatenate([[0], np.cumsum(f.cluster_P.astype(np.int64))]).astype(np.int64)
+    f.S_off = np.concatenate([[0], np.cumsum(f.cluster_P.astype(np.int64) ** 2)]).astype(np.int64)
+    return f
+
+
+def kernel_profile(ctx, run_once, reps):
+    """Per-kernel HIP-event timing of `reps` eager passes; returns {name: (avg seconds per launch, launches per pass)}."""
+    ctx.set_graph_mode(False)
+    ctx.set_kernel_timing(-1)
+    for _ in range(reps):
+        run_once()
+    kt = ctx.kernel_times()
+    ctx.set_kernel_timing(-2)
+    return {k: (sec / cnt, cnt / reps, sec / reps) for k, (_, sec, cnt) in kt.items()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-graph", action="store_true", help="launch kernels one by one instead of replaying hipGraphs")
+    ap.add_argument("--roofline-copies", type=int, default=512, help="cluster replication factor of the roofline instance")
+    ap.add_argument("--skip-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP library is the only compute path)")
+    torch.cuda.set_device(local_rank)
+    torch.cuda.set_stream(torch.cuda.Stream())      # a real (capturable) stream; the library runs on torch's current stream
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+
+    import clrs_amd  # noqa: F401
+    from clrs_amd.sharded import HipLocal, ShardedSchur
+
+    t0 = time.time()
+    flat = build_problem(world)
+    if rank == 0:
+        log(f"problem: {flat.n_clusters} clusters P={list(flat.cluster_P[:4])}.. N={flat.n_free} blocks n={list(flat.block_n[:4])}.. "
+            f"generated in {time.time() - t0:.1f}s")
+    parts = [[2 * r, 2 * r + 1] for r in range(world)]          # 2 clusters per GPU (identical weights)
+    use_graph = not args.no_graph
+    sh = ShardedSchur(flat, rank, world, lambda s: HipLocal(s, local_rank, graph=use_graph), parts=parts)
+    f = sh.shard
+    ctx = sh.local.ctx
+    dev = f"cuda:{local_rank}"
+    X, Y = seeded_iterates(flat, seed=1)
+    rng = np.random.default_rng(2)
+    rhs_x_full, rhs_y = rng.standard_normal(flat.x_len), rng.standard_normal(flat.n_free)
+    tX = torch.from_numpy(sh.take_xy(X)).to(dev)
+    tY = torch.from_numpy(sh.take_xy(Y)).to(dev)
+    tXc = torch.empty_like(tX)
+    trx = torch.from_numpy(sh.take_x(rhs_x_full)).to(dev)
+    tryy = torch.from_numpy(rhs_y).to(dev)
+    tdx = torch.empty_like(trx)
+    tdy = torch.empty_like(tryy)
+
+    def step():
+        sh.local.cholesky_blocks(tX, tXc)
+        sh.decompose(tXc, tY)
+        sh.solve(trx, tryy, tdx, tdy)      # predictor
+        sh.solve(trx, tryy, tdx, tdy)      # corrector
+
+    # ---- parity of this very configuration against the CPU oracle (checker only) ----
+    parity = {}
+    from oracle.oracle import Oracle
+    o = Oracle(f, quad=True, use_lo=False)
+    Xc_ref = np.concatenate([np.linalg.cholesky(sh.take_xy(X)[f.block_off[b]:f.block_off[b + 1]].reshape(int(f.block_n[b]), -1, order="F"))
+                             .reshape(-1, order="F") for b in range(f.n_blocks)])
+    S_ref, _ = o.schur_assemble(Xc_ref, sh.take_xy(Y))
+    sh.local.cholesky_blocks(tX, tXc)
+    sh.local.assemble(tXc, tY)
+    torch.cuda.synchronize()
+    from clrs_amd.sharded import _DevArray
+    S_dev = torch.as_tensor(_DevArray(ctx.S_buffer(), f.S_len), device=dev).cpu().numpy()
+    parity["S_rel_err_vs_f128_oracle"] = float(np.max(np.abs(S_dev - S_ref)) / np.max(np.abs(S_ref)))
+    parity["Xchol_rel_err"] = float(np.max(np.abs(tXc.cpu().numpy() - Xc_ref)) / np.max(np.abs(Xc_ref)))
+    assert parity["Xchol_rel_err"] < 1e-12, parity
+    assert parity["S_rel_err_vs_f128_oracle"] < 1e-11, parity
+    step()
+    torch.cuda.synchronize()
+    parity["factor_status"] = sh.status()      # cond(S) > 1/eps for 2d=30 in fp64: non-zero = the reference's SolverFailure
+
+    # ---- timed region: W warmup + exactly K steps, barrier + synchronize on both sides ----
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = args.steps / elapsed
+
+    out = {
+        "metric": "interior-point iterations/sec (hot path: chol X + Schur assembly + block-Cholesky factor + 2 solves)",
+        "value": value, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "SpherePacking cohnelkies(8,15): d=8, 2d=30; 2 clusters/GPU P=32, blocks 16x16 r1 + 1x1 dense, N=31",
+                   "clusters": int(flat.n_clusters), "clusters_per_gpu": 2, "n_free": int(flat.n_free),
+                   "launch": "hipGraph" if use_graph else "eager", "collective": "RCCL all-reduce Q(31x31)+2x u(31)" if world > 1 else "none"},
+        "parity": parity,
+    }
+
+    if rank == 0:
+        cnt = ctx.counters()
+        # ---- per-kernel profile of the named problem (eager, HIP events around each launch) ----
+        prof = kernel_profile(ctx, lambda: sh.local.assemble(tXc, tY), 50)
+        asm_s = sum(v[2] for v in prof.values())
+        dom = max(prof.items(), key=lambda kv: kv[1][2])
+        out["roofline_named"] = {"bound": "hbm", "phase": "schur_assemble", "kernel": dom[0], "kernel_avg_us": 1e6 * dom[1][0],
+                                 "kernel_launches_per_assembly": dom[1][1], "assembly_us": 1e6 * asm_s,
+                                 "achieved": cnt["assemble_bytes"] / asm_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": cnt["assemble_bytes"] / asm_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                 "algorithmic_bytes": cnt["assemble_bytes"], "algorithmic_flops": cnt["assemble_flops"],
+                                 "kernels_us": {k: round(1e6 * v[2], 3) for k, v in prof.items()}}
+        if use_graph:
+            ctx.set_graph_mode(True)
+
+        # ---- roofline instance: the same block shapes, many clusters per launch ----
+        big = replicate_clusters(f, args.roofline_copies)
+        from clrs_amd.solver import SchurContext
+        bctx = SchurContext(big, device=local_rank)
+        bctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        bX, bY = seeded_iterates(big, seed=3)
+        bXc = np.concatenate([np.linalg.cholesky(bX[big.block_off[b]:big.block_off[b + 1]].reshape(int(big.block_n[b]), -1, order="F"))
+                              .reshape(-1, order="F") for b in range(big.n_blocks)])
+        tbXc, tbY = torch.from_numpy(bXc).to(dev), torch.from_numpy(bY).to(dev)
+        for _ in range(5):
+            bctx.assemble_dev(tbXc.data_ptr(), tbY.data_ptr())
+        torch.cuda.synchronize()
+        bprof = kernel_profile(bctx, lambda: bctx.assemble_dev(tbXc.data_ptr(), tbY.data_ptr()), 20)
+        bcnt = bctx.counters()
+        basm = sum(v[2] for v in bprof.values())
+        bdom = max(bprof.items(), key=lambda kv: kv[1][2])
+        # spot-check the big instance too: first and last cluster against the oracle
+        Sb = torch.as_tensor(_DevArray(bctx.S_buffer(), big.S_len), device=dev).cpu().numpy()
+        ob = Oracle(f, quad=False)
+        nxy = f.xy_len
+        for k in (0, args.roofline_copies - 1):
+            Sk, _ = ob.schur_assemble(bXc[k * nxy:(k + 1) * nxy], bY[k * nxy:(k + 1) * nxy])
+            err = np.max(np.abs(Sb[k * f.S_len:(k + 1) * f.S_len] - Sk)) / np.max(np.abs(Sk))
+            assert err < 1e-10, ("roofline instance parity", k, err)
+        out["roofline"] = {"bound": "hbm", "phase": "schur_assemble", "kernel": bdom[0], "kernel_avg_us": 1e6 * bdom[1][0],
+                           "kernel_launches_per_assembly": bdom[1][1], "assembly_us": 1e6 * basm,
+                           "achieved": bcnt["assemble_bytes"] / basm / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": bcnt["assemble_bytes"] / basm / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                           "workload": f"{big.n_clusters} clusters / {big.n_blocks} PSD blocks of the cohnelkies(8,15) shapes in one assembly",
+                           "algorithmic_bytes": bcnt["assemble_bytes"], "algorithmic_flops": bcnt["assemble_flops"],
+                           "achieved_gflops": bcnt["assemble_flops"] / basm / 1e9,
+                           "kernels_us": {k: round(1e6 * v[2], 3) for k, v in bprof.items()}}
+        bctx.close()
+
+        # ---- CPU baseline: the fp64 OpenMP oracle on the same step, bounded sample ----
+        if not args.skip_cpu and world == 1:
+            oc = Oracle(f, quad=False)
+            Xs, Ys = sh.take_xy(X), sh.take_xy(Y)
+            rx = sh.take_x(rhs_x_full)
+            n_it, t_cpu = 0, 0.0
+            budget = 12.0
+            while t_cpu < budget and n_it < 20000:
+                t1 = time.perf_counter()
+                _, Lc, _ = oc.cholesky_blocks(Xs)
+                oc.schur_assemble(Lc, Ys)
+                oc.schur_factor()
+                oc.schur_solve(rx, rhs_y)
+                oc.schur_solve(rx, rhs_y)
+                t_cpu += time.perf_counter() - t1
+                n_it += 1
+            out["cpu_baseline"] = {"value": n_it / t_cpu, "unit": "iterations/s", "cores": oc.num_threads, "kind": "port",
+                                   "sample": f"{n_it} hot-path passes of the same 2-cluster problem in {t_cpu:.1f}s "
+                                             f"(oracle/clrs_oracle.c fp64 + OpenMP through ctypes)"}
+        print(json.dumps(out), flush=True)
+    sh.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -49,6 +49,7 @@ SYMBOLS = {
     "clrs_get_dims": (C.c_int, [C.c_void_p, C.POINTER(Dims)]),
     "clrs_get_unique_counts": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, p_i32, p_i32]),
     "clrs_cholesky_blocks": (C.c_int, [C.c_void_p, p_d, p_d]),
+    "clrs_cholesky_blocks_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "clrs_schur_assemble": (C.c_int, [C.c_void_p, p_d, p_d, p_d, p_d]),
     "clrs_schur_factor": (C.c_int, [C.c_void_p]),
     "clrs_get_factor": (C.c_int, [C.c_void_p, p_d, p_d, p_d]),
@@ -63,11 +64,16 @@ SYMBOLS = {
     "clrs_S_buffer_dev": (C.c_void_p, [C.c_void_p]),
     "clrs_AY_buffer_dev": (C.c_void_p, [C.c_void_p]),
     "clrs_sync_status": (C.c_int, [C.c_void_p]),
+    "clrs_sync_status_cholesky": (C.c_int, [C.c_void_p]),
     "clrs_stream": (C.c_void_p, [C.c_void_p]),
     "clrs_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "clrs_get_timings": (C.c_int, [C.c_void_p, p_d]),
     "clrs_get_counters": (C.c_int, [C.c_void_p, p_d, p_d, p_d, p_d]),
     "clrs_set_graph_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "clrs_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "clrs_set_kernel_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "clrs_get_kernel_times": (C.c_int, [C.c_void_p, C.c_int, p_d, p_i64]),
+    "clrs_kernel_name": (C.c_char_p, [C.c_int]),
     "clrs_plan_info": (C.c_int, [C.c_void_p, p_i32, p_i32, p_i32]),
     "clrs_strerror": (C.c_char_p, [C.c_int]),
     "clrs_last_error": (C.c_char_p, []),

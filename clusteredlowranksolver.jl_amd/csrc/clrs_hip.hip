@@ -44,7 +44,10 @@ static const int INFO_NONE = 0x7f7f7f7f;
 // ------------------------------------------------------------------------------------------------
 // launch plan
 // ------------------------------------------------------------------------------------------------
-enum StepKind { STEP_MEMCPY, STEP_GEMM, STEP_TRSM, STEP_POTRF, STEP_GATHER_S, STEP_GATHER_SCALAR, STEP_SUB, STEP_MEMSET_INFO };
+enum StepKind { STEP_MEMCPY, STEP_GEMM, STEP_TRSM, STEP_POTRF, STEP_GATHER_S, STEP_GATHER_SCALAR, STEP_SUB, STEP_MEMSET_INFO, STEP_ZERO_UPPER, STEP_NKINDS };
+static const char *const STEP_NAMES[STEP_NKINDS] = {"hipMemcpyAsync(D2D)", "k_gemm_f64", "k_trsm_diag", "k_potrf_diag", "k_schur_gather",
+                                                    "k_gather_scalar", "k_sub", "hipMemsetAsync", "k_zero_upper"};
+static const int KT_MAX_EVENTS = 8192;   // event pairs kept between two clrs_get_kernel_times calls
 
 struct Step {
     StepKind kind;
@@ -93,6 +96,13 @@ struct BlockInfo {
 struct clrs_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    bool own_stream = true;
+    // per-kernel HIP-event timing (clrs_set_kernel_timing): -2 off, -1 every step kind, k >= 0 only kind k
+    int kt_kind = -2;
+    std::vector<hipEvent_t> kt_ev;
+    std::vector<int> kt_kinds;
+    double kt_total[STEP_NKINDS] = {0};
+    long long kt_count[STEP_NKINDS] = {0};
     int J = 0, N = 0, NB = 0;
     i64 T = 0, D = 0;
     std::vector<int> P;
@@ -238,7 +248,7 @@ static int plan_trsm(clrs_ctx *c, Plan &pl, const std::vector<TrsmJob> &jobs, in
 }
 
 // in-place lower Cholesky of a list of independent matrices, blocked by POTRF_NB, level-synchronous.
-static int plan_potrf(clrs_ctx *c, Plan &pl, const std::vector<PotrfJob> &jobs) {
+static int plan_potrf(clrs_ctx *c, Plan &pl, const std::vector<PotrfJob> &jobs, int *info = nullptr) {
     int maxp = 0;
     for (const PotrfJob &j : jobs) maxp = std::max(maxp, (j.n + POTRF_NB - 1) / POTRF_NB);
     int rc;
@@ -265,6 +275,7 @@ static int plan_potrf(clrs_ctx *c, Plan &pl, const std::vector<PotrfJob> &jobs) 
         Step s;
         s.kind = STEP_POTRF;
         s.grid = (int)pd.size();
+        s.dst = info ? info : c->d_info;
         PotrfDesc *dd;
         if ((rc = upload(c, pd, &dd))) return rc;
         s.d0 = dd;
@@ -287,6 +298,16 @@ static void add_memcpy(Plan &pl, void *dst, const void *src, size_t bytes) {
 static int run_steps(clrs_ctx *c, const Plan &pl) {
     hipStream_t st = c->stream;
     for (const Step &s : pl.steps) {
+        const bool timed = !c->graph_mode && (c->kt_kind == -1 || c->kt_kind == (int)s.kind) && (int)c->kt_kinds.size() < KT_MAX_EVENTS;
+        if (timed) {
+            const size_t need = 2 * (c->kt_kinds.size() + 1);
+            while (c->kt_ev.size() < need) {
+                hipEvent_t e;
+                HIPCHECK(hipEventCreate(&e));
+                c->kt_ev.push_back(e);
+            }
+            HIPCHECK(hipEventRecord(c->kt_ev[need - 2], st));
+        }
         switch (s.kind) {
             case STEP_MEMCPY:
                 HIPCHECK(hipMemcpyAsync(s.dst, s.src, s.bytes, hipMemcpyDeviceToDevice, st));
@@ -298,7 +319,7 @@ static int run_steps(clrs_ctx *c, const Plan &pl) {
                 hipLaunchKernelGGL(k_trsm_diag, dim3(s.grid), dim3(64), 0, st, (const TrsmDesc *)s.d0, (const TrsmWork *)s.d1);
                 break;
             case STEP_POTRF:
-                hipLaunchKernelGGL(k_potrf_diag, dim3(s.grid), dim3(256), 0, st, (const PotrfDesc *)s.d0, c->d_info);
+                hipLaunchKernelGGL(k_potrf_diag, dim3(s.grid), dim3(256), 0, st, (const PotrfDesc *)s.d0, (int *)s.dst);
                 break;
             case STEP_GATHER_S:
                 hipLaunchKernelGGL(k_schur_gather, dim3(s.grid), dim3(256), 0, st, (const SClusterDesc *)s.d0, (const SBlockDesc *)s.d1,
@@ -313,8 +334,17 @@ static int run_steps(clrs_ctx *c, const Plan &pl) {
                                    (const double *)s.d0, (int)s.n);
                 break;
             case STEP_MEMSET_INFO:
-                HIPCHECK(hipMemsetAsync(c->d_info, 0x7f, sizeof(int), st));
+                HIPCHECK(hipMemsetAsync(s.dst ? s.dst : (void *)c->d_info, 0x7f, sizeof(int), st));
                 break;
+            case STEP_ZERO_UPPER:
+                hipLaunchKernelGGL(k_zero_upper, dim3((unsigned)((s.n + 255) / 256), (unsigned)s.grid), dim3(256), 0, st, (const PotrfDesc *)s.d0);
+                break;
+            default:
+                break;
+        }
+        if (timed) {
+            HIPCHECK(hipEventRecord(c->kt_ev[2 * c->kt_kinds.size() + 1], st));
+            c->kt_kinds.push_back((int)s.kind);
         }
     }
     HIPCHECK(hipGetLastError());
@@ -505,7 +535,7 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
     }
     {
         int *di;
-        std::vector<int> hi(1, INFO_NONE);
+        std::vector<int> hi(2, INFO_NONE);   // [0]: S_j / Q factorisations, [1]: Cholesky of the X blocks
         CK(upload(c, hi, &di));
         c->d_info = di;
     }
@@ -701,9 +731,22 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
     {
         std::vector<PotrfJob> pj;
         for (int b = 0; b < NB; b++) pj.push_back(PotrfJob{c->d_X + c->blk[b].xyoff, c->blk[b].n, c->blk[b].n, b + 1});
-        Step ms; ms.kind = STEP_MEMSET_INFO;
+        Step ms; ms.kind = STEP_MEMSET_INFO; ms.dst = c->d_info + 1;
         c->p_cholX.steps.push_back(ms);
-        CK(plan_potrf(c, c->p_cholX, pj));
+        CK(plan_potrf(c, c->p_cholX, pj, c->d_info + 1));
+        if (NB > 0) {   // strict upper triangles -> 0, the output format of approx_cholesky! (src/tools.jl:100-105)
+            std::vector<PotrfDesc> zd;
+            i64 maxnn = 0;
+            for (int b = 0; b < NB; b++) {
+                zd.push_back(PotrfDesc{c->d_X + c->blk[b].xyoff, c->blk[b].n, c->blk[b].n, 0, 0});
+                maxnn = std::max(maxnn, (i64)c->blk[b].n * c->blk[b].n);
+            }
+            PotrfDesc *dz;
+            CK(upload(c, zd, &dz));
+            Step zs;
+            zs.kind = STEP_ZERO_UPPER; zs.grid = NB; zs.d0 = dz; zs.n = maxnn;
+            c->p_cholX.steps.push_back(zs);
+        }
     }
 
     // ---- algorithmic work counters ----
@@ -745,7 +788,8 @@ extern "C" void clrs_ctx_destroy(clrs_ctx *c) {
     for (void *p : c->allocs) hipFree(p);
     for (int i = 0; i < 10; i++)
         if (c->ev[i]) hipEventDestroy(c->ev[i]);
-    if (c->stream) hipStreamDestroy(c->stream);
+    for (hipEvent_t e : c->kt_ev) hipEventDestroy(e);
+    if (c->stream && c->own_stream) hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -768,9 +812,9 @@ extern "C" int clrs_get_unique_counts(const clrs_ctx *c, int32_t b, int32_t r, i
 // ------------------------------------------------------------------------------------------------
 // per-iteration drivers
 // ------------------------------------------------------------------------------------------------
-static int read_info(clrs_ctx *c, int *status) {
+static int read_info(clrs_ctx *c, int *status, int which = 0) {
     int h = INFO_NONE;
-    HIPCHECK(hipMemcpyAsync(&h, c->d_info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipMemcpyAsync(&h, c->d_info + which, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(hipStreamSynchronize(c->stream));
     *status = (h == INFO_NONE) ? 0 : h;
     return 0;
@@ -852,6 +896,13 @@ extern "C" int clrs_sync_status(clrs_ctx *c) {
     if (rc) return rc;
     if (c->timing) collect_times(c);
     return st;
+}
+
+extern "C" int clrs_sync_status_cholesky(clrs_ctx *c) {
+    if (!c) return fail(CLRS_ERR_INVALID, "null argument");
+    int st = 0;
+    int rc = read_info(c, &st, 1);
+    return rc ? rc : st;
 }
 
 extern "C" int clrs_schur_factor(clrs_ctx *c) {
@@ -936,21 +987,25 @@ extern "C" int clrs_schur_solve(clrs_ctx *c, const double *rhs_x, const double *
     return 0;
 }
 
+extern "C" int clrs_cholesky_blocks_dev(clrs_ctx *c, const double *d_X, double *d_Xchol) {
+    if (!c || !d_X || !d_Xchol) return fail(CLRS_ERR_INVALID, "null argument");
+    HIPCHECK(hipSetDevice(c->device));
+    if (d_X != c->d_X) HIPCHECK(hipMemcpyAsync(c->d_X, d_X, sizeof(double) * c->xylen, hipMemcpyDeviceToDevice, c->stream));
+    int rc = run_plan(c, c->p_cholX);
+    if (rc) return rc;
+    if (d_Xchol != c->d_X) HIPCHECK(hipMemcpyAsync(d_Xchol, c->d_X, sizeof(double) * c->xylen, hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+}
+
 extern "C" int clrs_cholesky_blocks(clrs_ctx *c, const double *X, double *Xchol) {
     if (!c || !X || !Xchol) return fail(CLRS_ERR_INVALID, "null argument");
     HIPCHECK(hipSetDevice(c->device));
     HIPCHECK(hipMemcpyAsync(c->d_X, X, sizeof(double) * c->xylen, hipMemcpyHostToDevice, c->stream));
-    int rc = run_plan(c, c->p_cholX);
+    int rc = clrs_cholesky_blocks_dev(c, c->d_X, c->d_X);
     if (rc) return rc;
     int st = 0;
-    if ((rc = read_info(c, &st))) return rc;
+    if ((rc = read_info(c, &st, 1))) return rc;
     HIPCHECK(hipMemcpy(Xchol, c->d_X, sizeof(double) * c->xylen, hipMemcpyDeviceToHost));
-    for (int b = 0; b < c->NB; b++) {
-        const int n = c->blk[b].n;
-        double *A = Xchol + c->blk[b].xyoff;
-        for (int col = 0; col < n; col++)
-            for (int r = 0; r < col; r++) A[r + (i64)col * n] = 0.0;
-    }
     return st;
 }
 
@@ -992,6 +1047,53 @@ extern "C" int clrs_plan_info(const clrs_ctx *c, int32_t *na, int32_t *nf, int32
     if (ns) *ns = c->p_fwd.launches() + c->p_bwd.launches();
     return 0;
 }
+
+// ---- external stream / per-kernel timing -----------------------------------------------------------
+extern "C" int clrs_set_stream(clrs_ctx *c, void *stream) {
+    if (!c) return fail(CLRS_ERR_INVALID, "null argument");
+    HIPCHECK(hipSetDevice(c->device));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    Plan *plans[] = {&c->p_assemble, &c->p_cholS, &c->p_linvB, &c->p_Q, &c->p_cholQ, &c->p_fwd, &c->p_bwd, &c->p_cholX, &c->p_zeroL};
+    for (Plan *p : plans)
+        if (p->graph) { hipGraphExecDestroy(p->graph); p->graph = nullptr; }   // graphs are re-captured on the new stream
+    if (c->own_stream) HIPCHECK(hipStreamDestroy(c->stream));
+    c->stream = (hipStream_t)stream;
+    c->own_stream = false;
+    return 0;
+}
+
+static int kt_collect(clrs_ctx *c) {
+    if (c->kt_kinds.empty()) return 0;
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < c->kt_kinds.size(); i++) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, c->kt_ev[2 * i], c->kt_ev[2 * i + 1]) == hipSuccess) {
+            c->kt_total[c->kt_kinds[i]] += ms * 1e-3;
+            c->kt_count[c->kt_kinds[i]]++;
+        }
+    }
+    c->kt_kinds.clear();
+    return 0;
+}
+
+extern "C" int clrs_set_kernel_timing(clrs_ctx *c, int kind) {
+    if (!c || kind < -2 || kind >= STEP_NKINDS) return fail(CLRS_ERR_INVALID, "bad kernel kind");
+    int rc = kt_collect(c);
+    if (rc) return rc;
+    c->kt_kind = kind;
+    for (int k = 0; k < STEP_NKINDS; k++) { c->kt_total[k] = 0; c->kt_count[k] = 0; }
+    return 0;
+}
+
+extern "C" int clrs_get_kernel_times(clrs_ctx *c, int max_kinds, double *seconds, int64_t *launches) {
+    if (!c || !seconds || !launches) return fail(CLRS_ERR_INVALID, "null argument");
+    int rc = kt_collect(c);
+    if (rc) return rc;
+    for (int k = 0; k < max_kinds && k < STEP_NKINDS; k++) { seconds[k] = c->kt_total[k]; launches[k] = c->kt_count[k]; }
+    return STEP_NKINDS;
+}
+
+extern "C" const char *clrs_kernel_name(int kind) { return (kind >= 0 && kind < STEP_NKINDS) ? STEP_NAMES[kind] : ""; }
 
 extern "C" const char *clrs_strerror(int code) {
     switch (code) {

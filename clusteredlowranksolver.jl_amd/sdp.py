@@ -350,3 +350,64 @@ def S_unpack(flat: FlatSDP, v: np.ndarray) -> List[np.ndarray]:
         P = int(flat.cluster_P[j])
         res.append(np.asarray(v[flat.S_off[j]:flat.S_off[j + 1]]).reshape((P, P), order="F"))
     return res
+
+
+def shard_clusters(flat: FlatSDP, clusters) -> FlatSDP:
+    """The sub-problem holding only `clusters` (in the given, increasing order) and all N free
+    variables: what one rank of the cluster-sharded path owns (the clusters are
+    the reference's outer parallel axis, src/solver.jl:1245,1257,1537,1566)."""
+    clusters = [int(j) for j in clusters]
+    if sorted(set(clusters)) != clusters:
+        raise ValueError("clusters must be strictly increasing")
+    N = flat.n_free
+    newj = {j: i for i, j in enumerate(clusters)}
+    blocks = [b for b in range(flat.n_blocks) if int(flat.block_cluster[b]) in newj]
+
+    def cat(xs, dt=np.float64):
+        return np.concatenate(xs).astype(dt) if xs else np.zeros(0, dtype=dt)
+
+    def per_cluster(arr, width):
+        return cat([arr[int(flat.cluster_off[j]) * width:int(flat.cluster_off[j + 1]) * width] for j in clusters])
+
+    def per_block(arr):
+        return cat([arr[int(flat.block_off[b]):int(flat.block_off[b + 1])] for b in blocks])
+
+    term_ptr, dense_ptr, tsel, dsel = [0], [0], [], []
+    for b in blocks:
+        tsel.extend(range(int(flat.term_ptr[b]), int(flat.term_ptr[b + 1])))
+        dsel.extend(range(int(flat.dense_ptr[b]), int(flat.dense_ptr[b + 1])))
+        term_ptr.append(len(tsel)); dense_ptr.append(len(dsel))
+    tsel = np.array(tsel, dtype=np.int64); dsel = np.array(dsel, dtype=np.int64)
+
+    def vecs(arr):
+        return cat([arr[int(flat.term_vec_ptr[t]):int(flat.term_vec_ptr[t + 1])] for t in tsel])
+
+    def dmats(arr):
+        return cat([arr[int(flat.dense_A_ptr[e]):int(flat.dense_A_ptr[e + 1])] for e in dsel])
+
+    tlen = (flat.term_vec_ptr[tsel + 1] - flat.term_vec_ptr[tsel]) if len(tsel) else np.zeros(0, np.int64)
+    dlen = (flat.dense_A_ptr[dsel + 1] - flat.dense_A_ptr[dsel]) if len(dsel) else np.zeros(0, np.int64)
+    cluster_P = flat.cluster_P[clusters].astype(np.int32)
+    block_n = flat.block_n[blocks].astype(np.int32)
+    return FlatSDP(
+        n_clusters=len(clusters), n_free=N, cluster_P=cluster_P,
+        B=per_cluster(flat.B, N), B_lo=per_cluster(flat.B_lo, N), c=per_cluster(flat.c, 1), c_lo=per_cluster(flat.c_lo, 1),
+        b=flat.b.copy(), b_lo=flat.b_lo.copy(), C=per_block(flat.C), C_lo=per_block(flat.C_lo),
+        maximize=flat.maximize, constant=flat.constant, n_blocks=len(blocks),
+        block_cluster=np.array([newj[int(flat.block_cluster[b])] for b in blocks], dtype=np.int32),
+        block_m=flat.block_m[blocks].astype(np.int32), block_delta=flat.block_delta[blocks].astype(np.int32),
+        block_kind=flat.block_kind[blocks].astype(np.int32),
+        term_ptr=np.array(term_ptr, dtype=np.int64),
+        term_p=flat.term_p[tsel].astype(np.int32), term_r=flat.term_r[tsel].astype(np.int32),
+        term_s=flat.term_s[tsel].astype(np.int32), term_rank=flat.term_rank[tsel].astype(np.int32),
+        term_lambda=flat.term_lambda[tsel].astype(np.float64), term_lambda_lo=flat.term_lambda_lo[tsel].astype(np.float64),
+        term_vec_ptr=np.concatenate([[0], np.cumsum(tlen)]).astype(np.int64),
+        term_vs=vecs(flat.term_vs), term_vs_lo=vecs(flat.term_vs_lo), term_ws=vecs(flat.term_ws), term_ws_lo=vecs(flat.term_ws_lo),
+        dense_ptr=np.array(dense_ptr, dtype=np.int64), dense_p=flat.dense_p[dsel].astype(np.int32),
+        dense_A_ptr=np.concatenate([[0], np.cumsum(dlen)]).astype(np.int64),
+        dense_A=dmats(flat.dense_A), dense_A_lo=dmats(flat.dense_A_lo),
+        block_n=block_n,
+        block_off=np.concatenate([[0], np.cumsum(block_n.astype(np.int64) ** 2)]).astype(np.int64),
+        cluster_off=np.concatenate([[0], np.cumsum(cluster_P.astype(np.int64))]).astype(np.int64),
+        S_off=np.concatenate([[0], np.cumsum(cluster_P.astype(np.int64) ** 2)]).astype(np.int64),
+    )

@@ -121,6 +121,21 @@ class SchurContext:
         _lib.check(self.L.clrs_get_counters(self.h, *[C.byref(x) for x in v]))
         return dict(assemble_bytes=v[0].value, assemble_flops=v[1].value, factor_flops=v[2].value, solve_flops=v[3].value)
 
+    def set_stream(self, hip_stream: int):
+        """Run on the caller's hipStream_t (e.g. torch.cuda.current_stream().cuda_stream)."""
+        _lib.check(self.L.clrs_set_stream(self.h, C.c_void_p(hip_stream)))
+
+    def set_kernel_timing(self, kind: int):
+        """HIP-event timing around every launch of kernel `kind` (-1 all kinds, -2 off); eager mode only."""
+        _lib.check(self.L.clrs_set_kernel_timing(self.h, int(kind)))
+
+    def kernel_times(self) -> dict:
+        """{kernel name: (kind, total seconds, launches)} since the last set_kernel_timing."""
+        sec = np.zeros(32)
+        cnt = np.zeros(32, dtype=np.int64)
+        n = _lib.check(self.L.clrs_get_kernel_times(self.h, 32, _dp(sec), cnt.ctypes.data_as(_lib.p_i64)))
+        return {self.L.clrs_kernel_name(k).decode(): (k, float(sec[k]), int(cnt[k])) for k in range(n) if cnt[k]}
+
     def plan_info(self):
         v = [C.c_int32() for _ in range(3)]
         _lib.check(self.L.clrs_plan_info(self.h, *[C.byref(x) for x in v]))
@@ -167,6 +182,9 @@ class SchurContext:
         return dx, dy[:f.n_free]
 
     # -- device-pointer / split-phase API (used by bench.py and the sharded driver) ---------------
+    def cholesky_blocks_dev(self, d_X: int, d_Xchol: int):
+        _lib.check(self.L.clrs_cholesky_blocks_dev(self.h, C.c_void_p(d_X), C.c_void_p(d_Xchol)))
+
     def assemble_dev(self, d_Xchol: int, d_Y: int):
         _lib.check(self.L.clrs_schur_assemble_dev(self.h, C.c_void_p(d_Xchol), C.c_void_p(d_Y)))
 
@@ -186,11 +204,17 @@ class SchurContext:
     def sync_status(self) -> int:
         return _lib.check(self.L.clrs_sync_status(self.h))
 
+    def sync_status_cholesky(self) -> int:
+        return _lib.check(self.L.clrs_sync_status_cholesky(self.h))
+
     def q_buffer(self) -> int:
         return int(self.L.clrs_q_buffer_dev(self.h) or 0)
 
     def u_buffer(self) -> int:
         return int(self.L.clrs_u_buffer_dev(self.h) or 0)
+
+    def S_buffer(self) -> int:
+        return int(self.L.clrs_S_buffer_dev(self.h) or 0)
 
     def stream(self) -> int:
         return int(self.L.clrs_stream(self.h) or 0)

@@ -136,6 +136,8 @@ int clrs_get_factor(clrs_ctx *ctx, double *L, double *LinvB, double *LQ);
 int clrs_schur_solve(clrs_ctx *ctx, const double *rhs_x, const double *rhs_y, double *dx, double *dy);
 
 /* --- device-pointer / sharded variants (enqueue on the context stream, no synchronisation) --- */
+int clrs_cholesky_blocks_dev(clrs_ctx *ctx, const double *d_X, double *d_Xchol);
+int clrs_sync_status_cholesky(clrs_ctx *ctx);   /* blocks; status of the last clrs_cholesky_blocks_dev: 0 or block b+1 */
 int clrs_schur_assemble_dev(clrs_ctx *ctx, const double *d_Xchol, const double *d_Y);
 int clrs_schur_factor_local_dev(clrs_ctx *ctx);               /* up to the local partial Q */
 double *clrs_q_buffer_dev(clrs_ctx *ctx);                     /* N x N device buffer holding Q (partial, then total) */
@@ -160,6 +162,18 @@ int clrs_get_timings(clrs_ctx *ctx, double t[6]);
  * vector counts): bytes and flops; and of one factor + one solve. */
 int clrs_get_counters(const clrs_ctx *ctx, double *assemble_bytes, double *assemble_flops,
                       double *factor_flops, double *solve_flops);
+
+/* Run every later call on the caller's hipStream_t instead of the context's own stream (e.g. the
+ * stream a collective library orders itself against).  The caller keeps ownership of the stream. */
+int clrs_set_stream(clrs_ctx *ctx, void *hip_stream);
+
+/* Per-kernel timing with HIP events recorded on the context stream around every launch of kernel
+ * `kind` (-1: every kind, -2: off; resets the accumulators).  Only in eager (non-graph) mode.
+ * clrs_get_kernel_times synchronises, fills seconds[k] / launches[k] for k < max_kinds and returns
+ * the number of kinds; clrs_kernel_name(k) names them (the names rocprofv3 --kernel-trace shows). */
+int clrs_set_kernel_timing(clrs_ctx *ctx, int kind);
+int clrs_get_kernel_times(clrs_ctx *ctx, int max_kinds, double *seconds, int64_t *launches);
+const char *clrs_kernel_name(int kind);
 
 /* Capture the per-iteration launch sequences into hipGraphs (1) or launch kernels one by one (0). */
 int clrs_set_graph_mode(clrs_ctx *ctx, int enabled);
