@@ -216,3 +216,99 @@ def test_solvesdp_matches_oracle_loop(oracle_built):
     n = min(3, len(r.history))
     assert np.allclose(r.history[:n, 1], o["hist"][:n, 1], rtol=1e-6)      # mu trace
     assert np.allclose(r.history[:n, 8:10], o["hist"][:n, 8:10], rtol=1e-3)  # step lengths
+
+
+GOLDEN_FULL = ["x2p1", "polyopt8", "delsarte_8_3", "ce_8_3", "ns_8_3_2", "sdpa_small", "polyopt40", "delsarte_3_10"]
+
+
+@pytest.mark.parametrize("name", GOLDEN_FULL + ["ce_8_15", "ns_8_15_2"])
+def test_schur_assemble_matches_256bit_golden(name):
+    """HIP assembly against the committed 256-bit vectors (tests/golden/make_golden.py): 1e-12 * max|S|,
+    the same bar the fp64 oracle meets (tests/test_oracle_cpu.py)."""
+    import os
+    from clrs_amd.solver import SchurContext
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+    ctx = SchurContext(flat(name))
+    S, _ = ctx.compute_S_integrated(g["Xchol"], g["Y"], want_AY=False)
+    assert np.max(np.abs(S - g["S"])) <= 1e-12 * np.max(np.abs(g["S"]))
+    ctx.close()
+
+
+@pytest.mark.parametrize("name", GOLDEN_FULL)
+def test_factor_solve_matches_256bit_golden(name):
+    """(dx, dy) against the 256-bit LU solution of the full KKT system; 1e-7 relative (fp64 eps x cond ~1e8)."""
+    import os
+    from clrs_amd.solver import SchurContext, compute_T_decomposition, solve_system
+    f = flat(name)
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+    ctx = SchurContext(f)
+    compute_T_decomposition(ctx, g["Xchol"], g["Y"])
+    dx, dy = solve_system(ctx, g["rhs_x"], g["rhs_y"])
+    scale = max(1.0, np.max(np.abs(g["dx"])), np.max(np.abs(g["dy"])) if f.n_free else 0.0)
+    assert np.max(np.abs(dx - g["dx"])) <= 1e-7 * scale
+    if f.n_free:
+        assert np.max(np.abs(dy - g["dy"])) <= 1e-7 * scale
+    ctx.close()
+
+
+def test_split_phase_device_api_two_shards_on_one_gpu(oracle_built):
+    """The sharded protocol (clrs_schur_factor_local_dev / _finish_dev, clrs_schur_solve_fwd_dev / _bwd_dev) with two
+    'ranks' living in one process on one GPU: partial Q and u are summed by hand where RCCL would all-reduce."""
+    import torch
+    from clrs_amd.sharded import HipLocal, ShardedSchur
+    from oracle.oracle import Oracle
+    f = flat("ns_8_3_2")
+    X, Y = spd_iterates(f, seed=41)
+    Xc = chol_blocks_np(f, X)
+    rng = np.random.default_rng(42)
+    rx, ry = rng.standard_normal(f.x_len), rng.standard_normal(f.n_free)
+    torch.cuda.set_device(0)
+    ranks = [ShardedSchur(f, r, 2, lambda s: HipLocal(s, 0)) for r in range(2)]
+    for sh in ranks:
+        sh.world = 1                      # no process group here: the exchange is done below
+    dev = "cuda:0"
+    tx = [torch.from_numpy(sh.take_xy(Xc)).to(dev) for sh in ranks]
+    ty = [torch.from_numpy(sh.take_xy(Y)).to(dev) for sh in ranks]
+    qs = []
+    for sh, a, b in zip(ranks, tx, ty):
+        sh.local.assemble(a, b)
+        qs.append(sh.local.factor_local())
+    total = qs[0] + qs[1]
+    for q in qs:
+        q.copy_(total)
+    for sh in ranks:
+        sh.local.factor_finish()
+        assert sh.local.status() == 0
+    us = [sh.local.solve_fwd(torch.from_numpy(sh.take_x(rx)).to(dev)) for sh in ranks]
+    total = us[0] + us[1]
+    for u in us:
+        u.copy_(total)
+    o = Oracle(f)
+    o.schur_assemble(Xc, Y)
+    assert o.schur_factor() == 0
+    dx_ref, dy_ref = o.schur_solve(rx, ry)
+    try_y = torch.from_numpy(ry).to(dev)
+    for sh in ranks:
+        dx = torch.empty(sh.shard.x_len, dtype=torch.float64, device=dev)
+        dy = torch.empty(f.n_free, dtype=torch.float64, device=dev)
+        sh.local.solve_bwd(try_y, dx, dy)
+        torch.cuda.synchronize()
+        ref = np.concatenate([dx_ref[f.cluster_off[j]:f.cluster_off[j + 1]] for j in sh.clusters])
+        assert np.max(np.abs(dx.cpu().numpy() - ref)) <= 1e-7 * max(1.0, np.max(np.abs(dx_ref)))
+        assert np.max(np.abs(dy.cpu().numpy() - dy_ref)) <= 1e-7 * max(1.0, np.max(np.abs(dy_ref)))
+        sh.close()
+
+
+def test_cholesky_blocks_device_entry():
+    import torch
+    from clrs_amd.solver import SchurContext
+    f = flat("ns_8_3_2")
+    X, _ = spd_iterates(f, seed=6)
+    ctx = SchurContext(f)
+    tX = torch.from_numpy(X).to("cuda:0")
+    tL = torch.empty_like(tX)
+    torch.cuda.synchronize()
+    ctx.cholesky_blocks_dev(tX.data_ptr(), tL.data_ptr())
+    assert ctx.sync_status_cholesky() == 0
+    assert np.max(np.abs(tL.cpu().numpy() - chol_blocks_np(f, X))) <= 1e-13 * np.max(np.abs(X))
+    ctx.close()

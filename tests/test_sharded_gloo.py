@@ -1,0 +1,130 @@
+"""The cluster-sharded orchestration (clrs_amd/sharded.py) over torch.distributed `gloo`, world_size 2, on CPU.
+
+Each rank owns a subset of the clusters, computes with the numpy stand-in of tests/numpy_local.py and exchanges
+the partial Q / u with the same all-reduces the GPU path issues over RCCL.  The sharded result must equal the
+single-process result on the full problem."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, name, negate_block, ret):
+    sys.path.insert(0, ROOT)
+    import clrs_amd  # noqa: F401
+    from clrs_amd.sharded import ShardedSchur
+    from tests.numpy_local import NumpyLocal
+    from tests.util import chol_blocks_np, flat, spd_iterates
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        f = flat(name)
+        X, Y = spd_iterates(f, seed=31)
+        if negate_block is not None:
+            Y[f.block_off[negate_block]:f.block_off[negate_block + 1]] *= -1.0
+        Xc = chol_blocks_np(f, X)
+        rng = np.random.default_rng(32)
+        rx, ry = rng.standard_normal(f.x_len), rng.standard_normal(f.n_free)
+        sh = ShardedSchur(f, rank, world, NumpyLocal)
+        sh.decompose(torch.from_numpy(sh.take_xy(Xc)), torch.from_numpy(sh.take_xy(Y)))
+        dx = torch.zeros(sh.shard.x_len, dtype=torch.float64)
+        dy = torch.zeros(f.n_free, dtype=torch.float64)
+        st = sh.status()
+        if st == 0:
+            sh.solve(torch.from_numpy(sh.take_x(rx)), torch.from_numpy(ry), dx, dy)
+        ret[rank] = dict(clusters=sh.clusters, dx=dx.numpy().copy(), dy=dy.numpy().copy(), status=st)
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(name, world=2, negate_block=None):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        ret = mgr.dict()
+        procs = [ctx.Process(target=_worker, args=(r, world, port, name, negate_block, ret)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(180)
+            assert p.exitcode == 0
+        return {k: dict(v) for k, v in ret.items()}
+
+
+@pytest.mark.parametrize("name", ["ns_8_3_2", "ce_8_3"])
+def test_sharded_equals_single_process(name, oracle_built):
+    from oracle.oracle import Oracle
+    from tests.util import chol_blocks_np, flat, spd_iterates
+    f = flat(name)
+    X, Y = spd_iterates(f, seed=31)
+    Xc = chol_blocks_np(f, X)
+    rng = np.random.default_rng(32)
+    rx, ry = rng.standard_normal(f.x_len), rng.standard_normal(f.n_free)
+    o = Oracle(f)
+    o.schur_assemble(Xc, Y)
+    assert o.schur_factor() == 0
+    dx_ref, dy_ref = o.schur_solve(rx, ry)
+    res = _run(name)
+    seen = []
+    for r in range(2):
+        assert res[r]["status"] == 0
+        seen += res[r]["clusters"]
+        got = res[r]["dx"]      # tolerance 1e-7: the summation order of Q and u differs; cond of the KKT system ~1e7 here
+        ref = np.concatenate([dx_ref[f.cluster_off[j]:f.cluster_off[j + 1]] for j in res[r]["clusters"]])
+        assert np.max(np.abs(got - ref)) <= 1e-7 * max(1.0, np.max(np.abs(dx_ref)))
+        assert np.max(np.abs(res[r]["dy"] - dy_ref)) <= 1e-7 * max(1.0, np.max(np.abs(dy_ref)))   # dy replicated
+    assert sorted(seen) == list(range(f.n_clusters))
+    assert np.array_equal(res[0]["dy"], res[1]["dy"])
+
+
+def test_sharded_status_is_global_cluster_number(oracle_built):
+    """A non-PD S_j on one rank is reported by every rank with the GLOBAL cluster number (j+1), like
+    'S was not decomposed succesfully in block j' (src/solver.jl:1249)."""
+    from tests.util import flat
+    f = flat("ns_8_3_2")
+    b = int(np.nonzero(f.block_cluster == 3)[0][-1])      # the big block of cluster 3 (its 1x1 sibling cannot flip the sign)
+    res = _run("ns_8_3_2", negate_block=b)
+    assert res[0]["status"] == res[1]["status"] == 4
+
+
+def test_partition_is_balanced_and_complete():
+    from clrs_amd.sharded import cluster_weights, partition_clusters
+    from tests.util import flat
+    f = flat("ns_8_15_2")
+    w = cluster_weights(f)
+    for world in (1, 2, 4, 8):
+        parts = partition_clusters(f, world)
+        assert sorted(j for p in parts for j in p) == list(range(f.n_clusters))
+        loads = [sum(w[j] for j in p) for p in parts]
+        assert max(loads) <= max(w.max(), w.sum() / world * 4 / 3 + 1e-9)     # LPT bound
+    assert np.argmax(w) == 1                                                     # the 96-constraint cluster dominates
+
+
+def test_shard_clusters_roundtrip(oracle_built):
+    from clrs_amd.sdp import shard_clusters
+    from oracle.oracle import Oracle
+    from tests.util import chol_blocks_np, flat, spd_iterates
+    f = flat("ns_8_3_2")
+    X, Y = spd_iterates(f, seed=1)
+    Xc = chol_blocks_np(f, X)
+    S, AY = Oracle(f).schur_assemble(Xc, Y)
+    for cl in ([0, 2, 5], [1, 3, 4, 6], list(range(7))):
+        g = shard_clusters(f, cl)
+        bl = [b for b in range(f.n_blocks) if f.block_cluster[b] in cl]
+        Xs = np.concatenate([Xc[f.block_off[b]:f.block_off[b + 1]] for b in bl])
+        Ys = np.concatenate([Y[f.block_off[b]:f.block_off[b + 1]] for b in bl])
+        Sg, AYg = Oracle(g).schur_assemble(Xs, Ys)
+        assert np.array_equal(Sg, np.concatenate([S[f.S_off[j]:f.S_off[j + 1]] for j in cl]))
+        assert np.array_equal(AYg, np.concatenate([AY[f.term_ptr[b]:f.term_ptr[b + 1]] for b in bl]))
