@@ -276,20 +276,35 @@ def main():
             oc = Oracle(f, quad=False)
             Xs, Ys = sh.take_xy(X), sh.take_xy(Y)
             rx = sh.take_x(rhs_x_full)
-            n_it, t_cpu = 0, 0.0
-            budget = 12.0
-            while t_cpu < budget and n_it < 20000:
-                t1 = time.perf_counter()
+
+            def cpu_pass():
                 _, Lc, _ = oc.cholesky_blocks(Xs)
                 oc.schur_assemble(Lc, Ys)
                 oc.schur_factor()
                 oc.schur_solve(rx, rhs_y)
                 oc.schur_solve(rx, rhs_y)
-                t_cpu += time.perf_counter() - t1
-                n_it += 1
-            out["cpu_baseline"] = {"value": n_it / t_cpu, "unit": "iterations/s", "cores": oc.num_threads, "kind": "port",
+
+            def cpu_rate(budget):
+                n_it, t_cpu = 0, 0.0
+                while t_cpu < budget and n_it < 200000:
+                    t1 = time.perf_counter()
+                    cpu_pass()
+                    t_cpu += time.perf_counter() - t1
+                    n_it += 1
+                return n_it / t_cpu, n_it, t_cpu
+
+            ncpu = os.cpu_count() or 1
+            best = None
+            for thr in sorted({1, min(8, ncpu), ncpu}):      # these matrices are tiny: fewer threads is usually faster
+                oc.set_num_threads(thr)
+                rate, _, _ = cpu_rate(1.0)
+                if best is None or rate > best[0]:
+                    best = (rate, thr)
+            oc.set_num_threads(best[1])
+            rate, n_it, t_cpu = cpu_rate(10.0)
+            out["cpu_baseline"] = {"value": rate, "unit": "iterations/s", "cores": best[1], "kind": "port",
                                    "sample": f"{n_it} hot-path passes of the same 2-cluster problem in {t_cpu:.1f}s "
-                                             f"(oracle/clrs_oracle.c fp64 + OpenMP through ctypes)"}
+                                             f"(oracle/clrs_oracle.c fp64 + OpenMP through ctypes; best of 1/8/{ncpu} threads)"}
         print(json.dumps(out), flush=True)
     sh.close()
     if world > 1:

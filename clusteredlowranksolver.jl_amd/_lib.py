@@ -70,6 +70,9 @@ SYMBOLS = {
     "clrs_get_timings": (C.c_int, [C.c_void_p, p_d]),
     "clrs_get_counters": (C.c_int, [C.c_void_p, p_d, p_d, p_d, p_d]),
     "clrs_set_graph_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "clrs_config_set": (C.c_int, [C.c_char_p, C.c_int]),
+    "clrs_fused_clusters": (C.c_int, [C.c_void_p]),
+    "clrs_debug_stamps": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "clrs_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "clrs_set_kernel_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "clrs_get_kernel_times": (C.c_int, [C.c_void_p, C.c_int, p_d, p_i64]),
@@ -85,10 +88,19 @@ SYMBOLS = {
 }
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile csrc/clrs_hip.hip for gfx950 into csrc/libclrs_hip.so (in-tree, travels with gpurun)."""
+def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str = None) -> str:
+    """Compile csrc/clrs_hip.hip for gfx950 into csrc/libclrs_hip.so (in-tree, travels with gpurun).
+    `extra_flags` / `out` build a diagnostic variant (e.g. -DCLRS_FUSED_STAMPS) beside it."""
+    if out is not None:
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", *extra_flags,
+               "-o", out, os.path.join(CSRC, "clrs_hip.hip")]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + r.stderr[-4000:])
+        return out
     src = [os.path.join(CSRC, f) for f in ("clrs_hip.hip", "clrs_kernels.hip.h")] + \
-          [os.path.join(_HERE, "..", "include", "clrs_hip.h")]
+          [os.path.join(CSRC, "clrs_fused.hip.h"), os.path.join(_HERE, "..", "include", "clrs_hip.h")]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in src):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -105,10 +117,13 @@ def build(force: bool = False, verbose: bool = False) -> str:
 _lib = None
 
 
-def load():
-    """Load libclrs_hip.so; fails loudly when it has not been built (no fallback path exists)."""
-    global _lib
+def load(path: str = None):
+    """Load libclrs_hip.so; fails loudly when it has not been built (no fallback path exists).
+    `path` (before the first load) selects a diagnostic build of the same library."""
+    global _lib, LIB_PATH
     if _lib is None:
+        if path is not None:
+            LIB_PATH = path
         if not os.path.exists(LIB_PATH):
             raise ClrsError(-100, f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                   f"(the HIP extension is the only compute path)")

@@ -23,6 +23,7 @@
 
 #include "../../include/clrs_hip.h"
 #include "clrs_kernels.hip.h"
+#include "clrs_fused.hip.h"
 
 using namespace clrs;
 typedef long long i64;
@@ -41,12 +42,16 @@ static int fail(int code, const std::string &msg) {
 
 static const int INFO_NONE = 0x7f7f7f7f;
 
+// process-wide knobs read at context creation (clrs_config_set)
+static int g_cfg_fused_assemble = 1;
+static const int LDS_BUDGET_DOUBLES = 20000;   // of the 20480 doubles (160 KiB) a workgroup may claim
+
 // ------------------------------------------------------------------------------------------------
 // launch plan
 // ------------------------------------------------------------------------------------------------
-enum StepKind { STEP_MEMCPY, STEP_GEMM, STEP_TRSM, STEP_POTRF, STEP_GATHER_S, STEP_GATHER_SCALAR, STEP_SUB, STEP_MEMSET_INFO, STEP_ZERO_UPPER, STEP_NKINDS };
+enum StepKind { STEP_MEMCPY, STEP_GEMM, STEP_TRSM, STEP_POTRF, STEP_GATHER_S, STEP_GATHER_SCALAR, STEP_SUB, STEP_MEMSET_INFO, STEP_ZERO_UPPER, STEP_FUSED_ASSEMBLE, STEP_NKINDS };
 static const char *const STEP_NAMES[STEP_NKINDS] = {"hipMemcpyAsync(D2D)", "k_gemm_f64", "k_trsm_diag", "k_potrf_diag", "k_schur_gather",
-                                                    "k_gather_scalar", "k_sub", "hipMemsetAsync", "k_zero_upper"};
+                                                    "k_gather_scalar", "k_sub", "hipMemsetAsync", "k_zero_upper", "k_cluster_assemble"};
 static const int KT_MAX_EVENTS = 8192;   // event pairs kept between two clrs_get_kernel_times calls
 
 struct Step {
@@ -57,6 +62,7 @@ struct Step {
     const void *src = nullptr;
     size_t bytes = 0;
     i64 n = 0;
+    int nmax = 0;
 };
 
 struct Plan {
@@ -91,6 +97,8 @@ struct BlockInfo {
     i64 zr_off = -1, zl_off = -1, ty_off = -1, g_off = -1;  // ZR/ZL in the "solve" arena; TY; GX,GY
     int cnt = 0;
     i64 w_off = -1, tt_off = -1, sd_off = -1;
+    int *d_tptr = nullptr;   // low rank: [P+1] CSR over the cluster's constraints into the sorted term arrays; dense: [cnt] constraint index
+    bool fused = false;      // handled by k_cluster_assemble
 };
 
 struct clrs_ctx {
@@ -122,12 +130,15 @@ struct clrs_ctx {
     int *d_info = nullptr;
     double *d_X = nullptr;  // scratch for clrs_cholesky_blocks
     Plan p_assemble, p_cholS, p_linvB, p_Q, p_cholQ, p_fwd, p_bwd, p_cholX, p_zeroL;
+    FTables ftables = {};
     bool factored = false, assembled = false;
     bool timing = false, graph_mode = false;
     hipEvent_t ev[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     double times[6] = {0, 0, 0, 0, 0, 0};
     bool times_pending = false, solve_time_pending = false;
     double cnt_bytes = 0, cnt_flops = 0, cnt_factor_flops = 0, cnt_solve_flops = 0;
+    std::vector<char> cluster_fused;         // per cluster: assembled by the fused kernel
+    int n_fused_clusters = 0;
     std::vector<int> host_UR, host_UL;       // flattened per (block, r) for clrs_get_unique_counts
     std::vector<i64> host_U_off;
 };
@@ -336,6 +347,16 @@ static int run_steps(clrs_ctx *c, const Plan &pl) {
             case STEP_MEMSET_INFO:
                 HIPCHECK(hipMemsetAsync(s.dst ? s.dst : (void *)c->d_info, 0x7f, sizeof(int), st));
                 break;
+            case STEP_FUSED_ASSEMBLE: {
+                const FTables *tb = (const FTables *)s.src;
+                if (s.nmax <= 16)
+                    hipLaunchKernelGGL(k_cluster_assemble<16>, dim3(s.grid), dim3(256), s.bytes, st, (const FCluster *)s.d0, (const FBlock *)s.d1, *tb);
+                else if (s.nmax <= 32)
+                    hipLaunchKernelGGL(k_cluster_assemble<32>, dim3(s.grid), dim3(256), s.bytes, st, (const FCluster *)s.d0, (const FBlock *)s.d1, *tb);
+                else
+                    hipLaunchKernelGGL(k_cluster_assemble<64>, dim3(s.grid), dim3(256), s.bytes, st, (const FCluster *)s.d0, (const FBlock *)s.d1, *tb);
+                break;
+            }
             case STEP_ZERO_UPPER:
                 hipLaunchKernelGGL(k_zero_upper, dim3((unsigned)((s.n + 255) / 256), (unsigned)s.grid), dim3(256), 0, st, (const PotrfDesc *)s.d0);
                 break;
@@ -581,20 +602,119 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
     }
     int *d_tL, *d_tR; double *d_tlam;
     CK(upload(c, s_tL, &d_tL)); CK(upload(c, s_tR, &d_tR)); CK(upload(c, s_tlam, &d_tlam));
+    for (int b = 0; b < NB; b++) {
+        BlockInfo &k = c->blk[b];
+        if (k.kind == 0) {
+            if (k.t1 == k.t0) continue;
+            for (int &v : h_tptr[b]) v += (int)k.t0;   // absolute positions in the sorted term arrays
+            CK(upload(c, h_tptr[b], &k.d_tptr));
+        } else if (k.cnt > 0) {
+            std::vector<int> dp(d->dense_p + k.d0, d->dense_p + k.d1);
+            CK(upload(c, dp, &k.d_tptr));
+        }
+    }
+
+    // ---- which clusters does the fused kernel take?  (everything of the cluster must fit in LDS) ----
+    std::vector<FCluster> fcl;
+    std::vector<FBlock> fbl;
+    int fused_nmax = 0;
+    size_t fused_lds = 0;
+    c->cluster_fused.assign(J, 0);
+    if (g_cfg_fused_assemble) {
+        int b = 0;
+        for (int j = 0; j < J; j++) {
+            const int b_first = b;
+            int szL = 0, szY = 0, szV = 0, szTY = 0, szZL = 0, szG = 0, szTab = 0, nmax = 0;
+            bool ok = true;
+            std::vector<FBlock> mine;
+            for (; b < NB && c->blk[b].j == j; b++) {
+                BlockInfo &k = c->blk[b];
+                FBlock fb;
+                std::memset(&fb, 0, sizeof(fb));
+                fb.kind = k.kind; fb.n = k.n; fb.xyoff = k.xyoff;
+                const int n = k.n, n16 = (n + 15) & ~15;
+                if (k.kind == 0) {
+                    if (k.t1 == k.t0) continue;
+                    if (n > 64) { ok = false; continue; }
+                    const int UR16 = (k.URt + 15) & ~15, UL16 = (k.ULt + 15) & ~15, Tn = (int)(k.t1 - k.t0);
+                    fb.URt = k.URt; fb.ULt = k.ULt; fb.sym = k.sym ? 1 : 0; fb.T = Tn;
+                    fb.ldn = n16 + 2;                    // >= ceil16(n) rows (zero padded), ldn % 4 == 2: conflict-free ds_read_b64 of the MFMA operands
+                    fb.ldg = k.ULt | 1;
+                    fb.v_off = k.zr_off; fb.w_off = k.zl_off; fb.t0 = k.t0; fb.tptr = k.d_tptr;
+                    szL = std::max(szL, fb.ldn * n16); szY = std::max(szY, fb.ldn * n16);
+                    szV = std::max(szV, fb.ldn * UR16); szTY = std::max(szTY, fb.ldn * UR16);
+                    if (!k.sym) szZL = std::max(szZL, fb.ldn * UL16);
+                    szG = std::max(szG, fb.ldg * k.URt);
+                    szTab = std::max(szTab, ((c->P[j] + 1 + 2 * Tn + 1) & ~1) / 2 + Tn);
+                    nmax = std::max(nmax, n);
+                } else {
+                    if (k.cnt == 0) continue;
+                    if (n > 16) { ok = false; continue; }
+                    fb.T = k.cnt; fb.ldn = n | 1; fb.v_off = k.w_off; fb.tptr = k.d_tptr;
+                    const int st = k.cnt * n * n;
+                    szL = std::max(szL, fb.ldn * n); szY = std::max(szY, fb.ldn * n);
+                    szV = std::max(szV, st); szTY = std::max(szTY, st); szG = std::max(szG, st);
+                    szTab = std::max(szTab, (k.cnt + 1) / 2);
+                }
+                mine.push_back(fb);
+            }
+            if (!ok || mine.empty()) continue;
+            FCluster fc;
+            std::memset(&fc, 0, sizeof(fc));
+            fc.S = c->d_S + c->Soff[j]; fc.P = c->P[j];
+            auto even = [](int v) { return (v + 1) & ~1; };   // keep every region 16-byte aligned
+            int o = 0;
+            fc.oL = o; o += even(szL); fc.oY = o; o += even(szY); fc.oV = o; o += even(szV); fc.oTY = o; o += even(szTY);
+            fc.oZL = o; o += even(szZL); fc.oGX = o; o += even(szG); fc.oGY = o; o += even(szG); fc.oTab = o; o += even(szTab);
+            if (o > LDS_BUDGET_DOUBLES) continue;
+            const int PP = c->P[j] * c->P[j];
+            fc.oS = o;
+            if (o + PP <= LDS_BUDGET_DOUBLES) { fc.s_in_lds = 1; o += even(PP); }
+            fc.lds_doubles = o;
+            fc.b0 = (int)fbl.size();
+            for (const FBlock &fb : mine) fbl.push_back(fb);
+            fc.b1 = (int)fbl.size();
+            fcl.push_back(fc);
+            c->cluster_fused[j] = 1;
+            for (int bb = b_first; bb < b; bb++) c->blk[bb].fused = true;
+            fused_nmax = std::max(fused_nmax, nmax);
+            fused_lds = std::max(fused_lds, (size_t)o * sizeof(double));
+        }
+    }
+    c->n_fused_clusters = (int)fcl.size();
+    for (int b = 0; b < NB; b++)
+        if (c->blk[b].fused && c->blk[b].kind == 0)
+            for (i64 t = c->blk[b].t0; t < c->blk[b].t1; t++) h_ayidx[t] = -1;   // written by the fused kernel
     CK(upload(c, h_ayidx, &c->d_ayidx));
+    std::vector<int> h_ayL(T), h_ayR(T);
+    for (int b = 0; b < NB; b++) {
+        BlockInfo &k = c->blk[b];
+        if (k.kind != 0) continue;
+        for (i64 t = k.t0; t < k.t1; t++) {
+            h_ayL[t] = k.offL[d->term_r[t]] + lidx[t];
+            h_ayR[t] = k.offR[d->term_s[t]] + ridx[partner[t]];
+        }
+    }
+    int *d_ayL, *d_ayR;
+    CK(upload(c, h_ayL, &d_ayL)); CK(upload(c, h_ayR, &d_ayR));
 
     // =============================================================================================
     // plan: assemble
     // =============================================================================================
     {
         Plan &pl = c->p_assemble;
-        add_memcpy(pl, c->d_work, c->d_static, sizeof(double) * (size_t)so);
+        bool need_copy = false;
+        for (int b = 0; b < NB; b++) need_copy = need_copy || !c->blk[b].fused;
+        if (need_copy) add_memcpy(pl, c->d_work, c->d_static, sizeof(double) * (size_t)so);
         std::vector<TrsmJob> fwd, bwd;
         std::vector<GemmDesc> g1, g2;
+        bool any_general = false;
         for (int b = 0; b < NB; b++) {
             BlockInfo &k = c->blk[b];
             const double *Lx = c->d_Xc + k.xyoff, *Yb = c->d_Y + k.xyoff;
             const int n = k.n, dl = k.delta;
+            if (k.fused) continue;
+            any_general = true;
             if (k.kind == 0) {
                 double *ZR = c->d_work + k.zr_off, *ZL = c->d_work + k.zl_off, *TY = c->d_TY + k.ty_off;
                 double *GX = c->d_G + k.g_off, *GY = GX + (i64)k.ULt * k.URt;
@@ -638,14 +758,12 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
                 SBlockDesc sd;
                 std::memset(&sd, 0, sizeof(sd));
                 sd.kind = k.kind;
+                if (k.fused) continue;
                 if (k.kind == 0) {
                     if (k.t1 == k.t0) continue;
                     sd.ldg = k.ULt;
                     sd.GX = c->d_G + k.g_off; sd.GY = sd.GX + (i64)k.ULt * k.URt;
-                    int *dp;
-                    for (int &v : h_tptr[b]) v += (int)k.t0;   // absolute positions in the sorted term arrays
-                    CK(upload(c, h_tptr[b], &dp));
-                    sd.tptr = dp; sd.tL = d_tL; sd.tR = d_tR; sd.tlam = d_tlam;
+                    sd.tptr = k.d_tptr; sd.tL = d_tL; sd.tR = d_tR; sd.tlam = d_tlam;
                 } else {
                     if (k.cnt == 0) continue;
                     sd.cnt = k.cnt; sd.Sd = c->d_Sd + k.sd_off;
@@ -658,6 +776,7 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
                 bl.push_back(sd);
             }
             cl[j].b1 = (int)bl.size();
+            if (c->cluster_fused[j]) continue;
             int nt = (c->P[j] + 15) / 16;
             for (int tj = 0; tj < nt; tj++)
                 for (int ti = 0; ti <= tj; ti++) tiles.push_back(STile{j, ti, tj, 0});
@@ -671,11 +790,33 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
             s.d0 = dcl; s.d1 = dbl; s.d2 = dt;
             pl.steps.push_back(s);
         }
-        if (T > 0) {
+        if (T > 0 && any_general) {
             Step s;
             s.kind = STEP_GATHER_SCALAR;
             s.dst = c->d_AY; s.src = c->d_G; s.d0 = c->d_ayidx; s.n = T;
             pl.steps.push_back(s);
+        }
+        if (!fcl.empty()) {
+            FCluster *dfc; FBlock *dfb;
+            CK(upload(c, fcl, &dfc)); CK(upload(c, fbl, &dfb));
+            c->ftables.Xc = c->d_Xc; c->ftables.Y = c->d_Y; c->ftables.stat = c->d_static;
+            c->ftables.tL = d_tL; c->ftables.tR = d_tR; c->ftables.tlam = d_tlam;
+            c->ftables.ayL = d_ayL; c->ftables.ayR = d_ayR; c->ftables.AY = c->d_AY;
+            {
+                std::vector<unsigned long long> z(64, 0ull);
+                unsigned long long *ds;
+                CK(upload(c, z, &ds));
+                c->ftables.stamps = ds;
+            }
+            Step s;
+            s.kind = STEP_FUSED_ASSEMBLE;
+            s.grid = (int)fcl.size(); s.d0 = dfc; s.d1 = dfb; s.src = &c->ftables; s.bytes = fused_lds; s.nmax = fused_nmax;
+            pl.steps.push_back(s);
+            if (fused_lds > 64 * 1024) {
+                if (fused_nmax <= 16) HIPCK(hipFuncSetAttribute((const void *)k_cluster_assemble<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds));
+                else if (fused_nmax <= 32) HIPCK(hipFuncSetAttribute((const void *)k_cluster_assemble<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds));
+                else HIPCK(hipFuncSetAttribute((const void *)k_cluster_assemble<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds));
+            }
         }
     }
     // =============================================================================================
@@ -1092,6 +1233,22 @@ extern "C" int clrs_get_kernel_times(clrs_ctx *c, int max_kinds, double *seconds
     for (int k = 0; k < max_kinds && k < STEP_NKINDS; k++) { seconds[k] = c->kt_total[k]; launches[k] = c->kt_count[k]; }
     return STEP_NKINDS;
 }
+
+extern "C" int clrs_config_set(const char *key, int value) {
+    if (!key) return fail(CLRS_ERR_INVALID, "null argument");
+    if (!std::strcmp(key, "fused_assemble")) { g_cfg_fused_assemble = value; return 0; }
+    return fail(CLRS_ERR_INVALID, std::string("unknown configuration key ") + key);
+}
+
+extern "C" int clrs_debug_stamps(clrs_ctx *c, uint64_t out[64]) {
+    if (!c || !out) return fail(CLRS_ERR_INVALID, "null argument");
+    if (!c->ftables.stamps) { std::memset(out, 0, 64 * sizeof(uint64_t)); return 0; }
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    HIPCHECK(hipMemcpy(out, c->ftables.stamps, 64 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int clrs_fused_clusters(const clrs_ctx *c) { return c ? c->n_fused_clusters : 0; }
 
 extern "C" const char *clrs_kernel_name(int kind) { return (kind >= 0 && kind < STEP_NKINDS) ? STEP_NAMES[kind] : ""; }
 

@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256) void k_schur_gather(const SClusterDesc *__rest
 // out[i] = src[idx[i]]
 __global__ void k_gather_scalar(double *__restrict__ out, const double *__restrict__ src, const long long *__restrict__ idx, long long n) {
     const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-    if (i < n) out[i] = src[idx[i]];
+    if (i < n && idx[i] >= 0) out[i] = src[idx[i]];   // negative: the entry is produced by the fused kernel
 }
 
 // y = a - b   (dy right-hand side: rhs_y - sum_j u_j, solver.jl:1550-1553)

@@ -46,10 +46,14 @@ class SchurContext:
     left/right vector tables, pointer tables, `high_ranks`) plus every preallocated buffer of
     src/solver.jl:298-317 -- all device resident."""
 
-    def __init__(self, sdp, device: int = 0, graph: bool = False, timing: bool = False):
+    def __init__(self, sdp, device: int = 0, graph: bool = False, timing: bool = False, fused: Optional[bool] = None):
+        """`fused=False` forces the staged grouped-GEMM assembly for every cluster (default: clusters that fit in
+        one CU's LDS take the fused per-cluster kernel)."""
         self.flat: FlatSDP = sdp if isinstance(sdp, FlatSDP) else flatten(sdp)
         f = self.flat
         self.L = _lib.load()
+        if fused is not None:
+            _lib.check(self.L.clrs_config_set(b"fused_assemble", int(bool(fused))))
         k = self._keep = {}
 
         def hold(name, arr, dt):
@@ -67,7 +71,11 @@ class SchurContext:
         for name in ("term_lambda", "term_vs", "term_ws", "dense_A"):
             setattr(d, name, _dp(hold(name, getattr(f, name), np.float64)))
         h = C.c_void_p()
-        _lib.check(self.L.clrs_ctx_create(C.byref(d), int(device), C.byref(h)))
+        try:
+            _lib.check(self.L.clrs_ctx_create(C.byref(d), int(device), C.byref(h)))
+        finally:
+            if fused is not None:
+                self.L.clrs_config_set(b"fused_assemble", 1)
         self.h = h
         self.device = device
         if graph:
@@ -100,6 +108,10 @@ class SchurContext:
             _lib.check(self.L.clrs_get_unique_counts(self.h, block, r, C.byref(a), C.byref(b)))
             R.append(a.value); Lc.append(b.value)
         return R, Lc
+
+    def fused_clusters(self) -> int:
+        """Number of clusters assembled by the fused per-cluster kernel."""
+        return int(self.L.clrs_fused_clusters(self.h))
 
     def high_ranks(self) -> List[bool]:
         """`high_ranks[j][l]` flattened over blocks (src/solver.jl:1000)."""
@@ -415,13 +427,15 @@ def compute_step_length(f: FlatSDP, M: np.ndarray, dM: np.ndarray, gamma: float,
 def solvesdp(sdp, ctx: Optional[SchurContext] = None, device: int = 0, maxiterations: int = 500,
              beta_infeasible: float = 0.3, beta_feasible: float = 0.1, gamma: float = 0.9,
              omega_p: float = 1e4, omega_d: float = 1e4,
-             duality_gap_threshold: float = 1e-8, dual_error_threshold: float = 1e-9, primal_error_threshold: float = 1e-9,
+             duality_gap_threshold: float = 1e-7, dual_error_threshold: float = 1e-9, primal_error_threshold: float = 1e-9,
              max_complementary_gap: float = 1e100, need_dual_feasible: bool = False, need_primal_feasible: bool = False,
              verbose: bool = False, step_length_threshold: float = 1e-7, safe_step: bool = True) -> SolveResult:
     """Primal-dual interior-point loop of the reference (src/solver.jl:100-744) with the hot path on the GPU.
 
     Same algorithm and keyword names as the reference; the defaults that depend on the working precision
-    (omega, thresholds) are set for fp64 (the reference's 1e10 / 1e-30 / 1e-15 assume 256-bit Arb).
+    (omega, thresholds) are set for fp64 (the reference's 1e10 / 1e-30 / 1e-15 assume 256-bit Arb): near
+    gap 1e-8 the Schur complement of e.g. delsarte(3,10) has cond(S) ~ 1e17 and whether its Cholesky
+    succeeds in fp64 is decided by rounding noise, so the fp64 default gap threshold is 1e-7.
     Returns a SolveResult; `status` is one of the reference's Optimal / NearOptimal / Feasible /
     PrimalFeasible / DualFeasible / NotConverged (src/solver.jl:727-741); error_code as :64-70 of docs/src/solving.md."""
     f = sdp if isinstance(sdp, FlatSDP) else flatten(sdp)

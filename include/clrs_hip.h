@@ -175,6 +175,14 @@ int clrs_set_kernel_timing(clrs_ctx *ctx, int kind);
 int clrs_get_kernel_times(clrs_ctx *ctx, int max_kinds, double *seconds, int64_t *launches);
 const char *clrs_kernel_name(int kind);
 
+/* Process-wide knobs, read when a context is created.  "fused_assemble" (default 1): clusters whose blocks fit
+ * in one CU's LDS are assembled by the fused per-cluster kernel; 0 forces the staged grouped-GEMM path.
+ * clrs_fused_clusters returns how many clusters of the context the fused kernel takes. */
+int clrs_config_set(const char *key, int value);
+int clrs_fused_clusters(const clrs_ctx *ctx);
+/* Diagnostic builds (-DCLRS_FUSED_STAMPS) only: s_memtime stamps of the phases of workgroup 0 of the fused kernel. */
+int clrs_debug_stamps(clrs_ctx *ctx, uint64_t out[64]);
+
 /* Capture the per-iteration launch sequences into hipGraphs (1) or launch kernels one by one (0). */
 int clrs_set_graph_mode(clrs_ctx *ctx, int enabled);
 

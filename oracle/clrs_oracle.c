@@ -918,6 +918,10 @@ int oracle_solvesdp(octx *o, const oracle_params *prm, int *iters_out, double *o
 }
 
 int oracle_real_bits(void) { return (int)(sizeof(REAL) * 8); }
+void oracle_set_num_threads(int n) {
+    if (n > 0) omp_set_num_threads(n);
+}
+
 int oracle_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -85,6 +85,7 @@ def _lib(quad: bool):
         L.oracle_unique_counts.argtypes = [C.c_void_p, C.c_int, _p_i, _p_i]
         L.oracle_real_bits.restype = C.c_int
         L.oracle_num_threads.restype = C.c_int
+        L.oracle_set_num_threads.argtypes = [C.c_int]
         _libs[key] = L
     return _libs[key]
 
@@ -237,6 +238,9 @@ class Oracle:
     @property
     def real_bits(self):
         return int(self.L.oracle_real_bits())
+
+    def set_num_threads(self, n: int):
+        self.L.oracle_set_num_threads(int(n))
 
     @property
     def num_threads(self):
