@@ -21,9 +21,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-namespace clrs {
+#include "clrs_wave.hip.h"
 
-typedef double v4d_f __attribute__((ext_vector_type(4)));
+namespace clrs {
 
 struct FBlock {
     int kind;             // 0 low rank, 1 dense
@@ -71,108 +71,6 @@ struct FTables {
 #else
 #define CLRS_STAMP(i) do {} while (0)
 #endif
-
-// ---- small MFMA GEMM on LDS operands:  C[i,j] = sum_k A[k,i] B[k,j]  (i < M, j < N, k < K) -------------------------
-// A: K x M (ld lda), B: K x N (ld ldb), C: M x N (ld ldc), all column-major in LDS.  Rows k >= K of A/B up to
-// ceil4(K) and columns up to ceil16(M)/ceil16(N) must be readable and ZERO (the buffers are zero padded once).
-// Tiles of 16 x 16 are dealt to the waves of the workgroup; lower_only skips tiles strictly above the diagonal.
-__device__ __forceinline__ void lds_gemm_tn(const double *A, int lda, const double *B, int ldb, double *C, int ldc, int M, int N, int K,
-                                            int wave, int nwaves, int lane) {
-    const int tm = (M + 15) >> 4, tn = (N + 15) >> 4, K4 = (K + 3) & ~3;
-    const int l15 = lane & 15, l4 = lane >> 4;
-    for (int t = wave; t < tm * tn; t += nwaves) {
-        const int ti = t % tm, tj = t / tm;
-        const double *a = A + l4 + (ti * 16 + l15) * lda;   // A[k, i0 + c]
-        const double *b = B + l4 + (tj * 16 + l15) * ldb;   // B[k, j0 + r]
-        v4d_f acc = {0.0, 0.0, 0.0, 0.0};
-        int k = 0;
-        for (; k + 16 <= K4; k += 16) {   // 8 LDS reads in flight per 4 MFMAs
-            const double a0 = a[k], a1 = a[k + 4], a2 = a[k + 8], a3 = a[k + 12];
-            const double b0 = b[k], b1 = b[k + 4], b2 = b[k + 8], b3 = b[k + 12];
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a0, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a1, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b2, a2, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b3, a3, acc, 0, 0, 0);
-        }
-        for (; k < K4; k += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b[k], a[k], acc, 0, 0, 0);
-        // D[r][c] = C[i0 + c, j0 + r]; lane holds c = lane & 15, r = (lane >> 4) + 4 * reg
-        const int i = ti * 16 + l15;
-#pragma unroll
-        for (int reg = 0; reg < 4; reg++) {
-            const int j = tj * 16 + l4 + 4 * reg;
-            if (i < M && j < N) C[i + j * ldc] = acc[reg];
-        }
-    }
-}
-
-// ---- forward substitution Z <- L^-1 Z, blocked by 16 rows, wave-level -------------------------------------------------
-// Diagonal 16 x 16 solve: a wave holds 4 columns x 16 rows, one element per lane (row = lane & 15).  Step k broadcasts
-// the finished x_k across the 16 lanes of its column with a DPP row broadcast (no LDS round trip) and every lane
-// below row k eliminates it with one FMA: a chain of 16 x (mul, dpp, fma) instead of n^2/2 dependent LDS reads.
-template <int K>
-__device__ __forceinline__ double bcast16(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x150 + K, 0xf, 0xf, false);   // row_newbcast:K
-    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x150 + K, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-template <int K>
-struct Trsm16 {
-    static __device__ __forceinline__ void run(double &x0, double &x1, const double (&Lrow)[16], double dinv, int row) {
-        const double b0 = bcast16<K>(x0 * dinv), b1 = bcast16<K>(x1 * dinv);
-        x0 = (row == K) ? b0 : __builtin_fma(-Lrow[K], b0, x0);   // Lrow[K] == 0 above the diagonal: finished rows stay
-        x1 = (row == K) ? b1 : __builtin_fma(-Lrow[K], b1, x1);
-        Trsm16<K + 1>::run(x0, x1, Lrow, dinv, row);
-    }
-};
-template <>
-struct Trsm16<16> {
-    static __device__ __forceinline__ void run(double &, double &, const double (&)[16], double, int) {}
-};
-
-// L: lower triangular in LDS (ld ldl, zero above the diagonal and beyond n up to ceil16(n)); dinv[i] = 1 / L[i,i]
-// (0 for i >= n); Z: ceil16(n) x ncols in LDS (ld ldz), rows >= n zero.  Must be called by all `nwaves` waves.
-__device__ __forceinline__ void lds_trsm_lower(const double *L, int ldl, const double *dinv, double *Z, int ldz, int n, int ncols, int wave,
-                                               int nwaves, int lane) {
-    const int npan = (n + 15) >> 4, row16 = lane & 15, cg4 = lane >> 4;
-    const int ngroups = (ncols + 3) >> 2;
-    for (int pb = 0; pb < npan; pb++) {
-        const int r0 = pb * 16, row = r0 + row16;
-        double Lrow[16];
-#pragma unroll
-        for (int k = 0; k < 16; k++) Lrow[k] = L[row + (r0 + k) * ldl];
-        const double di = dinv[row];
-        for (int g = wave; g < ngroups; g += 2 * nwaves) {   // two column groups per pass: independent chains interleave
-            const int c0 = g * 4 + cg4, c1 = (g + nwaves) * 4 + cg4;
-            const bool v0 = c0 < ncols, v1 = c1 < ncols;
-            double x0 = v0 ? Z[row + c0 * ldz] : 0.0, x1 = v1 ? Z[row + c1 * ldz] : 0.0;
-            Trsm16<0>::run(x0, x1, Lrow, di, row16);
-            if (v0) Z[row + c0 * ldz] = x0;
-            if (v1) Z[row + c1 * ldz] = x1;
-        }
-        if (pb + 1 < npan) {
-            __syncthreads();
-            // trailing update  Z[r0+16:, :] -= L[r0+16:, r0:r0+16] Z[r0:r0+16, :]   (MFMA, 16 x 16 tiles)
-            const int tm = npan - pb - 1, tn = (ncols + 15) >> 4;
-            for (int t = wave; t < tm * tn; t += nwaves) {
-                const int i0 = r0 + 16 + (t % tm) * 16, j0 = (t / tm) * 16;
-                v4d_f acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int kk = 0; kk < 16; kk += 4) {
-                    const double zb = Z[(r0 + kk + cg4) + (j0 + row16) * ldz];    // a-operand: Z[k, j0 + r]
-                    const double la = L[(i0 + row16) + (r0 + kk + cg4) * ldl];    // b-operand: L[i0 + c, k]
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(zb, la, acc, 0, 0, 0);
-                }
-#pragma unroll
-                for (int reg = 0; reg < 4; reg++) {
-                    const int j = j0 + cg4 + 4 * reg;
-                    if (j < ncols) Z[(i0 + row16) + j * ldz] -= acc[reg];
-                }
-            }
-            __syncthreads();
-        }
-    }
-}
 
 template <int NMAX>
 __global__ __launch_bounds__(256) void k_cluster_assemble(const FCluster *__restrict__ clusters, const FBlock *__restrict__ blocks,
@@ -248,10 +146,10 @@ __global__ __launch_bounds__(256) void k_cluster_assemble(const FCluster *__rest
             double *dinv = TYs;
             if (tid < n16) dinv[tid] = (tid < n) ? 1.0 / Ls[tid + tid * ldn] : 0.0;
             __syncthreads();
-            lds_trsm_lower(Ls, ldn, dinv, Vs, ldn, n, UR, wave, 4, lane);
+            lds_trsm<false>(Ls, ldn, dinv, Vs, 1, ldn, n, UR, wave, 4, lane);
             if (!k.sym) {
                 __syncthreads();
-                lds_trsm_lower(Ls, ldn, dinv, ZLs, ldn, n, UL, wave, 4, lane);
+                lds_trsm<false>(Ls, ldn, dinv, ZLs, 1, ldn, n, UL, wave, 4, lane);
             }
             __syncthreads();
             CLRS_STAMP(sb + 4);
@@ -350,6 +248,193 @@ __global__ __launch_bounds__(256) void k_cluster_assemble(const FCluster *__rest
         }
     }
     CLRS_STAMP(61);
+}
+
+
+// =====================================================================================================================
+// fused factor / solve kernels for clusters with P <= 128 and N <= 128 (LDS resident; clrs_wave.hip.h does the work)
+// =====================================================================================================================
+
+// Cholesky of small matrices, one workgroup each: out = chol(in) with zeros above the diagonal.
+// Used for the X blocks (approx_cholesky!(X_inv_blk, X_blk), src/solver.jl:388-399) and for Q (src/solver.jl:1274).
+struct SmallPotrf {
+    long long in_off, out_off;   // offsets from the base pointers given at launch
+    double *dinv;                // optional: 1 / diag(L), n doubles
+    int n, ldin, ldout, code;
+};
+
+__device__ __forceinline__ void lds_load_lower_identity_padded(double *A, int lda, const double *G, int ldg, int n, int n16, int tid, int nthr) {
+    // 16 x 16 element tiles: (tid & 15) walks down a column (contiguous in memory), (tid >> 4) across columns
+    const int i16 = tid & 15, j16 = tid >> 4, jstep = nthr >> 4;
+    for (int j0 = 0; j0 < n16; j0 += jstep)
+        for (int i0 = 0; i0 < n16; i0 += 16) {
+            const int i = i0 + i16, j = j0 + j16;
+            if (j < n16) A[i + j * lda] = (i < n && j < n) ? ((i >= j) ? G[i + (long long)j * ldg] : 0.0) : ((i == j) ? 1.0 : 0.0);
+        }
+}
+
+__global__ __launch_bounds__(256) void k_small_potrf(const SmallPotrf *__restrict__ descs, const double *in_base, double *out_base,
+                                                     int *__restrict__ info) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const SmallPotrf d = descs[blockIdx.x];
+    const double *din = in_base + d.in_off;
+    double *dout = out_base + d.out_off;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int n = d.n, n16 = (n + 15) & ~15, lda = n16 + 2;
+    double *A = lds, *dinv = lds + lda * n16;
+    lds_load_lower_identity_padded(A, lda, din, d.ldin, n, n16, tid, 256);
+    __syncthreads();
+    const bool bad = lds_potrf(A, lda, dinv, n, wave, 4, lane);
+    if (bad && lane == 0) atomicMin(info, d.code);
+    __syncthreads();
+    const int i16 = tid & 15, j16 = tid >> 4;
+    for (int j0 = 0; j0 < n; j0 += 16)
+        for (int i0 = 0; i0 < n; i0 += 16) {
+            const int i = i0 + i16, j = j0 + j16;
+            if (i < n && j < n) dout[i + (long long)j * d.ldout] = (i >= j) ? A[i + j * lda] : 0.0;
+        }
+    if (d.dinv && tid < n) d.dinv[tid] = dinv[tid];
+}
+
+// Per cluster: L_j = chol(S_j) in place (zero upper), LinvB_j = L_j^-1 B_j   (src/solver.jl:1245-1261)
+struct CFactor {
+    double *S;         // P x P, in: S_j, out: L_j
+    const double *B;   // rows of the cluster in the stacked B (ld ldb)
+    double *LB;        // same layout, output
+    double *dinv;      // P doubles: 1 / diag(L_j), kept for the solves
+    int P, N, ldb, code;
+    int nc;            // columns of B processed per pass (LDS budget)
+};
+
+__global__ __launch_bounds__(256) void k_cluster_factor(const CFactor *__restrict__ descs, int *__restrict__ info) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const CFactor d = descs[blockIdx.x];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int P = d.P, P16 = (P + 15) & ~15, lda = P16 + 2;
+    double *A = lds, *dinv = lds + lda * P16, *Z = dinv + P16;
+    lds_load_lower_identity_padded(A, lda, d.S, P, P, P16, tid, 256);
+    __syncthreads();
+    const bool bad = lds_potrf(A, lda, dinv, P, wave, 4, lane);
+    if (bad && lane == 0) atomicMin(info, d.code);
+    __syncthreads();
+    const int i16 = tid & 15, j16 = tid >> 4;
+    for (int j0 = 0; j0 < P; j0 += 16)
+        for (int i0 = 0; i0 < P; i0 += 16) {
+            const int i = i0 + i16, j = j0 + j16;
+            if (i < P && j < P) d.S[i + (long long)j * P] = (i >= j) ? A[i + j * lda] : 0.0;
+        }
+    if (tid < P) d.dinv[tid] = dinv[tid];
+    for (int c0 = 0; c0 < d.N; c0 += d.nc) {
+        const int nc = min(d.nc, d.N - c0);
+        __syncthreads();
+        for (int j0 = 0; j0 < nc; j0 += 16)
+            for (int i0 = 0; i0 < P16; i0 += 16) {
+                const int i = i0 + i16, j = j0 + j16;
+                if (j < nc) Z[i + j * lda] = (i < P) ? d.B[i + (long long)(c0 + j) * d.ldb] : 0.0;
+            }
+        __syncthreads();
+        lds_trsm<false>(A, lda, dinv, Z, 1, lda, P, nc, wave, 4, lane);
+        __syncthreads();
+        for (int j0 = 0; j0 < nc; j0 += 16)
+            for (int i0 = 0; i0 < P; i0 += 16) {
+                const int i = i0 + i16, j = j0 + j16;
+                if (i < P && j < nc) d.LB[i + (long long)(c0 + j) * d.ldb] = Z[i + j * lda];
+            }
+    }
+}
+
+// u[k] = sum_i LB[i,k] t[i]  (approx_mul_transpose!, src/solver.jl:1546, summed over the clusters): one wave per column
+__global__ __launch_bounds__(256) void k_gemv_t(const double *__restrict__ LB, int ld, int rows, int N, const double *__restrict__ t,
+                                                double *__restrict__ u) {
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (k >= N) return;
+    const double *col = LB + (long long)k * ld;
+    double s = 0.0;
+    for (int i = lane; i < rows; i += 64) s += col[i] * t[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) u[k] = s;
+}
+
+// Per cluster: t_j = L_j^-1 rhs_x[j]   (src/solver.jl:1538)
+struct CSolve {
+    const double *L;      // P x P (ld P), lower
+    const double *dinv;   // P
+    const double *LB;     // rows of the cluster in the stacked LinvB (ld ldb)
+    long long off;        // offset of the cluster in x-like vectors (rhs_x, t, dx)
+    int P, N, ldb, pad;
+};
+
+__device__ __forceinline__ void lds_load_L_for_solve(double *A, int lda, double *dv, const CSolve &d, int P16, int tid) {
+    const int i16 = tid & 15, j16 = tid >> 4;
+    for (int j0 = 0; j0 < P16; j0 += 16)
+        for (int i0 = 0; i0 < P16; i0 += 16) {
+            const int i = i0 + i16, j = j0 + j16;
+            A[i + j * lda] = (i < d.P && j < d.P && i >= j) ? d.L[i + (long long)j * d.P] : 0.0;
+        }
+    if (tid < P16) dv[tid] = (tid < d.P) ? d.dinv[tid] : 0.0;
+}
+
+__global__ __launch_bounds__(256) void k_cluster_solve_fwd(const CSolve *__restrict__ descs, const double *__restrict__ rhs_x, double *__restrict__ t) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const CSolve d = descs[blockIdx.x];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int P = d.P, P16 = (P + 15) & ~15, lda = P16 + 2;
+    double *A = lds, *dv = lds + lda * P16, *z = dv + P16;
+    lds_load_L_for_solve(A, lda, dv, d, P16, tid);
+    if (tid < P16) z[tid] = (tid < P) ? rhs_x[d.off + tid] : 0.0;
+    __syncthreads();
+    lds_trsm<false>(A, lda, dv, z, 1, lda, P, 1, wave, 4, lane);
+    __syncthreads();
+    if (tid < P) t[d.off + tid] = z[tid];
+}
+
+// Per cluster: dx_j = L_j^-T (t_j + LinvB_j dy)   (src/solver.jl:1566-1573)
+__global__ __launch_bounds__(256) void k_cluster_solve_bwd(const CSolve *__restrict__ descs, const double *__restrict__ dy, const double *__restrict__ t,
+                                                           double *__restrict__ dx) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const CSolve d = descs[blockIdx.x];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int P = d.P, P16 = (P + 15) & ~15, lda = P16 + 2;
+    double *A = lds, *dv = lds + lda * P16, *z = dv + P16;
+    lds_load_L_for_solve(A, lda, dv, d, P16, tid);
+    if (tid < P16) {
+        double s = 0.0;
+        if (tid < P) {
+            s = t[d.off + tid];
+            for (int k = 0; k < d.N; k++) s += d.LB[tid + (long long)k * d.ldb] * dy[k];
+        }
+        z[tid] = s;
+    }
+    __syncthreads();
+    lds_trsm<true>(A, lda, dv, z, 1, lda, P, 1, wave, 4, lane);
+    __syncthreads();
+    if (tid < P) dx[d.off + tid] = z[tid];
+}
+
+// dy = Q^-1 (rhs_y - u) with Q = L_Q L_Q^T   (src/solver.jl:1550-1558)
+__global__ __launch_bounds__(256) void k_q_solve(const double *__restrict__ LQ, const double *__restrict__ dinvQ, int N, const double *__restrict__ rhs_y,
+                                                 const double *__restrict__ u, double *__restrict__ dy) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int N16 = (N + 15) & ~15, lda = N16 + 2;
+    double *A = lds, *dv = lds + lda * N16, *z = dv + N16;
+    const int i16 = tid & 15, j16 = tid >> 4;
+    for (int j0 = 0; j0 < N16; j0 += 16)
+        for (int i0 = 0; i0 < N16; i0 += 16) {
+            const int i = i0 + i16, j = j0 + j16;
+            A[i + j * lda] = (i < N && j < N && i >= j) ? LQ[i + (long long)j * N] : 0.0;
+        }
+    if (tid < N16) {
+        dv[tid] = (tid < N) ? dinvQ[tid] : 0.0;
+        z[tid] = (tid < N) ? rhs_y[tid] - u[tid] : 0.0;
+    }
+    __syncthreads();
+    lds_trsm<false>(A, lda, dv, z, 1, lda, N, 1, wave, 4, lane);
+    __syncthreads();
+    lds_trsm<true>(A, lda, dv, z, 1, lda, N, 1, wave, 4, lane);
+    __syncthreads();
+    if (tid < N) dy[tid] = z[tid];
 }
 
 }  // namespace clrs

@@ -44,14 +44,16 @@ static const int INFO_NONE = 0x7f7f7f7f;
 
 // process-wide knobs read at context creation (clrs_config_set)
 static int g_cfg_fused_assemble = 1;
+static int g_cfg_fused_factor = 1;
 static const int LDS_BUDGET_DOUBLES = 20000;   // of the 20480 doubles (160 KiB) a workgroup may claim
 
 // ------------------------------------------------------------------------------------------------
 // launch plan
 // ------------------------------------------------------------------------------------------------
-enum StepKind { STEP_MEMCPY, STEP_GEMM, STEP_TRSM, STEP_POTRF, STEP_GATHER_S, STEP_GATHER_SCALAR, STEP_SUB, STEP_MEMSET_INFO, STEP_ZERO_UPPER, STEP_FUSED_ASSEMBLE, STEP_NKINDS };
+enum StepKind { STEP_MEMCPY, STEP_GEMM, STEP_TRSM, STEP_POTRF, STEP_GATHER_S, STEP_GATHER_SCALAR, STEP_SUB, STEP_MEMSET_INFO, STEP_ZERO_UPPER, STEP_FUSED_ASSEMBLE, STEP_SMALL_POTRF, STEP_CLUSTER_FACTOR, STEP_GEMV_T, STEP_CSOLVE_FWD, STEP_Q_SOLVE, STEP_CSOLVE_BWD, STEP_NKINDS };
 static const char *const STEP_NAMES[STEP_NKINDS] = {"hipMemcpyAsync(D2D)", "k_gemm_f64", "k_trsm_diag", "k_potrf_diag", "k_schur_gather",
-                                                    "k_gather_scalar", "k_sub", "hipMemsetAsync", "k_zero_upper", "k_cluster_assemble"};
+                                                    "k_gather_scalar", "k_sub", "hipMemsetAsync", "k_zero_upper", "k_cluster_assemble", "k_small_potrf", "k_cluster_factor", "k_gemv_t",
+                                                    "k_cluster_solve_fwd", "k_q_solve", "k_cluster_solve_bwd"};
 static const int KT_MAX_EVENTS = 8192;   // event pairs kept between two clrs_get_kernel_times calls
 
 struct Step {
@@ -68,6 +70,7 @@ struct Step {
 struct Plan {
     std::vector<Step> steps;
     hipGraphExec_t graph = nullptr;
+    const void *captured[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // bindings baked into `graph`
     int launches() const { return (int)steps.size(); }
 };
 
@@ -131,6 +134,11 @@ struct clrs_ctx {
     double *d_X = nullptr;  // scratch for clrs_cholesky_blocks
     Plan p_assemble, p_cholS, p_linvB, p_Q, p_cholQ, p_fwd, p_bwd, p_cholX, p_zeroL;
     FTables ftables = {};
+    // caller-provided device pointers of the current call, read by the fused kernels at launch (no staging copies)
+    const double *bind_X = nullptr, *bind_rhsx = nullptr, *bind_rhsy = nullptr;
+    double *bind_Xchol = nullptr, *bind_dx = nullptr, *bind_dy = nullptr;
+    double *d_dinvS = nullptr, *d_dinvQ = nullptr;
+    bool fused_fs = false, fused_q = false, fused_x = false, all_assemble_fused = false;
     bool factored = false, assembled = false;
     bool timing = false, graph_mode = false;
     hipEvent_t ev[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -357,6 +365,27 @@ static int run_steps(clrs_ctx *c, const Plan &pl) {
                     hipLaunchKernelGGL(k_cluster_assemble<64>, dim3(s.grid), dim3(256), s.bytes, st, (const FCluster *)s.d0, (const FBlock *)s.d1, *tb);
                 break;
             }
+            case STEP_SMALL_POTRF:
+                if (s.n == 0)
+                    hipLaunchKernelGGL(k_small_potrf, dim3(s.grid), dim3(256), s.bytes, st, (const SmallPotrf *)s.d0, c->bind_X, c->bind_Xchol, (int *)s.dst);
+                else
+                    hipLaunchKernelGGL(k_small_potrf, dim3(s.grid), dim3(256), s.bytes, st, (const SmallPotrf *)s.d0, (const double *)c->d_Q, c->d_Q, (int *)s.dst);
+                break;
+            case STEP_CLUSTER_FACTOR:
+                hipLaunchKernelGGL(k_cluster_factor, dim3(s.grid), dim3(256), s.bytes, st, (const CFactor *)s.d0, (int *)s.dst);
+                break;
+            case STEP_GEMV_T:
+                hipLaunchKernelGGL(k_gemv_t, dim3((c->N + 3) / 4), dim3(256), 0, st, (const double *)c->d_LB, (int)c->xlen, (int)c->xlen, c->N, (const double *)c->d_t, c->d_u);
+                break;
+            case STEP_CSOLVE_FWD:
+                hipLaunchKernelGGL(k_cluster_solve_fwd, dim3(s.grid), dim3(256), s.bytes, st, (const CSolve *)s.d0, c->bind_rhsx, c->d_t);
+                break;
+            case STEP_Q_SOLVE:
+                hipLaunchKernelGGL(k_q_solve, dim3(1), dim3(256), s.bytes, st, (const double *)c->d_Q, (const double *)c->d_dinvQ, c->N, c->bind_rhsy, (const double *)c->d_u, c->bind_dy);
+                break;
+            case STEP_CSOLVE_BWD:
+                hipLaunchKernelGGL(k_cluster_solve_bwd, dim3(s.grid), dim3(256), s.bytes, st, (const CSolve *)s.d0, (const double *)c->bind_dy, (const double *)c->d_t, c->bind_dx);
+                break;
             case STEP_ZERO_UPPER:
                 hipLaunchKernelGGL(k_zero_upper, dim3((unsigned)((s.n + 255) / 256), (unsigned)s.grid), dim3(256), 0, st, (const PotrfDesc *)s.d0);
                 break;
@@ -375,7 +404,13 @@ static int run_steps(clrs_ctx *c, const Plan &pl) {
 static int run_plan(clrs_ctx *c, Plan &pl) {
     if (pl.steps.empty()) return 0;
     if (!c->graph_mode) return run_steps(c, pl);
+    const void *now[8] = {c->bind_X, c->bind_Xchol, c->bind_rhsx, c->bind_rhsy, c->bind_dx, c->bind_dy, c->ftables.Xc, c->ftables.Y};
+    if (pl.graph && std::memcmp(now, pl.captured, sizeof(now)) != 0) {   // the graph bakes the caller's pointers: re-capture
+        hipGraphExecDestroy(pl.graph);
+        pl.graph = nullptr;
+    }
     if (!pl.graph) {
+        std::memcpy(pl.captured, now, sizeof(now));
         hipGraph_t g;
         HIPCHECK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
         int rc = run_steps(c, pl);
@@ -705,6 +740,7 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
         Plan &pl = c->p_assemble;
         bool need_copy = false;
         for (int b = 0; b < NB; b++) need_copy = need_copy || !c->blk[b].fused;
+        c->all_assemble_fused = !need_copy;
         if (need_copy) add_memcpy(pl, c->d_work, c->d_static, sizeof(double) * (size_t)so);
         std::vector<TrsmJob> fwd, bwd;
         std::vector<GemmDesc> g1, g2;
@@ -822,25 +858,68 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
     // =============================================================================================
     // plan: factor (src/solver.jl:1244-1279), split like the reference's timings
     // =============================================================================================
+    auto lds_square = [](int n) { const int n16 = (n + 15) & ~15; return (n16 + 2) * n16 + n16; };   // matrix + dinv, in doubles
     {
-        std::vector<PotrfJob> pj;
-        std::vector<TrsmJob> tj;
-        for (int j = 0; j < J; j++) {
-            pj.push_back(PotrfJob{c->d_S + c->Soff[j], c->P[j], c->P[j], j + 1});
-            if (N > 0) tj.push_back(TrsmJob{c->d_S + c->Soff[j], c->P[j], c->P[j], c->d_LB + c->coff[j], (int)c->xlen, N});
-        }
+        int maxP = 0, maxn = 0;
+        for (int j = 0; j < J; j++) maxP = std::max(maxP, c->P[j]);
+        for (int b = 0; b < NB; b++) maxn = std::max(maxn, c->blk[b].n);
+        c->fused_fs = g_cfg_fused_factor && J > 0 && maxP <= 128;
+        c->fused_q = g_cfg_fused_factor && N > 0 && N <= 128;
+        c->fused_x = g_cfg_fused_factor && NB > 0 && maxn <= 128;
+        CK(dmalloc(c, &c->d_dinvS, c->xlen)); CK(dmalloc(c, &c->d_dinvQ, N));
+    }
+    {
         Step ms; ms.kind = STEP_MEMSET_INFO;
         c->p_cholS.steps.push_back(ms);
-        CK(plan_potrf(c, c->p_cholS, pj));
+        if (c->fused_fs) {
+            std::vector<CFactor> cf(J);
+            size_t lds = 0;
+            for (int j = 0; j < J; j++) {
+                const int P = c->P[j], P16 = (P + 15) & ~15, lda = P16 + 2;
+                CFactor &f = cf[j];
+                f.S = c->d_S + c->Soff[j]; f.B = c->d_B + c->coff[j]; f.LB = c->d_LB + c->coff[j]; f.dinv = c->d_dinvS + c->coff[j];
+                f.P = P; f.N = N; f.ldb = (int)c->xlen; f.code = j + 1;
+                const int room = (LDS_BUDGET_DOUBLES - lds_square(P)) / lda;      // columns of B that fit beside L
+                f.nc = std::max(1, std::min(std::max(N, 1), room));
+                lds = std::max(lds, (size_t)(lds_square(P) + lda * (N > 0 ? f.nc : 0)) * sizeof(double));
+            }
+            CFactor *dcf;
+            CK(upload(c, cf, &dcf));
+            Step s;
+            s.kind = STEP_CLUSTER_FACTOR; s.grid = J; s.d0 = dcf; s.dst = c->d_info; s.bytes = lds;
+            c->p_cholS.steps.push_back(s);      // Cholesky of S_j and L_j^-1 B_j in one launch: the LinvB timing slot stays 0
+            if (lds > 64 * 1024) HIPCK(hipFuncSetAttribute((const void *)k_cluster_factor, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        } else {
+            std::vector<PotrfJob> pj;
+            std::vector<TrsmJob> tj;
+            for (int j = 0; j < J; j++) {
+                pj.push_back(PotrfJob{c->d_S + c->Soff[j], c->P[j], c->P[j], j + 1});
+                if (N > 0) tj.push_back(TrsmJob{c->d_S + c->Soff[j], c->P[j], c->P[j], c->d_LB + c->coff[j], (int)c->xlen, N});
+            }
+            CK(plan_potrf(c, c->p_cholS, pj));
+            if (N > 0) {
+                add_memcpy(c->p_linvB, c->d_LB, c->d_B, sizeof(double) * (size_t)(c->xlen * N));
+                CK(plan_trsm(c, c->p_linvB, tj, 0));
+            }
+        }
         if (N > 0) {
-            add_memcpy(c->p_linvB, c->d_LB, c->d_B, sizeof(double) * (size_t)(c->xlen * N));
-            CK(plan_trsm(c, c->p_linvB, tj, 0));
             std::vector<GemmDesc> gq;   // Q = LB^T LB  (vcat + matmul, src/solver.jl:1268-1269)
             gq.push_back(mk_gemm(1, 0, N, N, (int)c->xlen, 1.0, c->d_LB, (int)c->xlen, c->d_LB, (int)c->xlen, 0.0, c->d_Q, N));
             CK(add_gemm_stage(c, c->p_Q, gq));
-            std::vector<PotrfJob> qj;
-            qj.push_back(PotrfJob{c->d_Q, N, N, J + 1});
-            CK(plan_potrf(c, c->p_cholQ, qj));
+            if (c->fused_q) {
+                std::vector<SmallPotrf> sp(1);
+                sp[0].in_off = 0; sp[0].out_off = 0; sp[0].dinv = c->d_dinvQ; sp[0].n = N; sp[0].ldin = N; sp[0].ldout = N; sp[0].code = J + 1;
+                SmallPotrf *dsp;
+                CK(upload(c, sp, &dsp));
+                Step s;
+                s.kind = STEP_SMALL_POTRF; s.grid = 1; s.d0 = dsp; s.dst = c->d_info; s.n = 1; s.bytes = (size_t)lds_square(N) * sizeof(double);
+                c->p_cholQ.steps.push_back(s);
+                if (s.bytes > 64 * 1024) HIPCK(hipFuncSetAttribute((const void *)k_small_potrf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_square(128) * sizeof(double))));
+            } else {
+                std::vector<PotrfJob> qj;
+                qj.push_back(PotrfJob{c->d_Q, N, N, J + 1});
+                CK(plan_potrf(c, c->p_cholQ, qj));
+            }
         }
     }
     // =============================================================================================
@@ -849,44 +928,100 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
     {
         std::vector<TrsmJob> tj;
         for (int j = 0; j < J; j++) tj.push_back(TrsmJob{c->d_S + c->Soff[j], c->P[j], c->P[j], c->d_t + c->coff[j], (int)c->xlen, 1});
-        add_memcpy(c->p_fwd, c->d_t, c->d_rhsx, sizeof(double) * (size_t)c->xlen);
-        CK(plan_trsm(c, c->p_fwd, tj, 0));                                                  // t_j = L_j^-1 rhs_x[j]   (:1538)
-        if (N > 0) {
-            std::vector<GemmDesc> g;                                                        // u = LB^T t             (:1546)
-            g.push_back(mk_gemm(1, 0, N, 1, (int)c->xlen, 1.0, c->d_LB, (int)c->xlen, c->d_t, (int)c->xlen, 0.0, c->d_u, N));
-            CK(add_gemm_stage(c, c->p_fwd, g));
-            Step s;                                                                         // dy = rhs_y - u         (:1550-1553)
-            s.kind = STEP_SUB; s.dst = c->d_dy; s.src = c->d_rhsy; s.d0 = c->d_u; s.n = N;
-            c->p_bwd.steps.push_back(s);
-            std::vector<TrsmJob> qj;
-            qj.push_back(TrsmJob{c->d_Q, N, N, c->d_dy, N, 1});
-            CK(plan_trsm(c, c->p_bwd, qj, 0));                                              // dy = Q^-1 dy           (:1557)
-            CK(plan_trsm(c, c->p_bwd, qj, 1));
-            std::vector<GemmDesc> g2;                                                       // t += LB dy             (:1568-1569)
-            g2.push_back(mk_gemm(0, 0, (int)c->xlen, 1, N, 1.0, c->d_LB, (int)c->xlen, c->d_dy, N, 1.0, c->d_t, (int)c->xlen));
-            CK(add_gemm_stage(c, c->p_bwd, g2));
+        CSolve *dcs = nullptr;
+        size_t lds_cs = 0;
+        if (c->fused_fs) {
+            std::vector<CSolve> cs(J);
+            for (int j = 0; j < J; j++) {
+                cs[j].L = c->d_S + c->Soff[j]; cs[j].dinv = c->d_dinvS + c->coff[j]; cs[j].LB = c->d_LB + c->coff[j];
+                cs[j].off = c->coff[j]; cs[j].P = c->P[j]; cs[j].N = N; cs[j].ldb = (int)c->xlen; cs[j].pad = 0;
+                lds_cs = std::max(lds_cs, (size_t)(lds_square(c->P[j]) + ((c->P[j] + 15) & ~15) + 2) * sizeof(double));
+            }
+            CK(upload(c, cs, &dcs));
+            if (lds_cs > 64 * 1024) {
+                HIPCK(hipFuncSetAttribute((const void *)k_cluster_solve_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cs));
+                HIPCK(hipFuncSetAttribute((const void *)k_cluster_solve_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cs));
+            }
+            Step s;
+            s.kind = STEP_CSOLVE_FWD; s.grid = J; s.d0 = dcs; s.bytes = lds_cs;
+            c->p_fwd.steps.push_back(s);                                                        // t_j = L_j^-1 rhs_x[j]   (:1538)
+        } else {
+            add_memcpy(c->p_fwd, c->d_t, c->d_rhsx, sizeof(double) * (size_t)c->xlen);
+            CK(plan_trsm(c, c->p_fwd, tj, 0));
         }
-        CK(plan_trsm(c, c->p_bwd, tj, 1));                                                  // dx_j = L_j^-T t_j      (:1571)
+        if (N > 0) {
+            if (c->fused_fs) {
+                Step s;
+                s.kind = STEP_GEMV_T;                                                           // u = LB^T t             (:1546)
+                c->p_fwd.steps.push_back(s);
+            } else {
+                std::vector<GemmDesc> g;
+                g.push_back(mk_gemm(1, 0, N, 1, (int)c->xlen, 1.0, c->d_LB, (int)c->xlen, c->d_t, (int)c->xlen, 0.0, c->d_u, N));
+                CK(add_gemm_stage(c, c->p_fwd, g));
+            }
+            if (c->fused_q) {
+                Step s;
+                s.kind = STEP_Q_SOLVE; s.bytes = (size_t)(lds_square(N) + ((N + 15) & ~15) + 2) * sizeof(double);   // dy = Q^-1 (rhs_y - u)  (:1550-1558)
+                c->p_bwd.steps.push_back(s);
+                if (s.bytes > 64 * 1024) HIPCK(hipFuncSetAttribute((const void *)k_q_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s.bytes));
+            } else {
+                Step s;
+                s.kind = STEP_SUB; s.dst = c->d_dy; s.src = c->d_rhsy; s.d0 = c->d_u; s.n = N;
+                c->p_bwd.steps.push_back(s);
+                std::vector<TrsmJob> qj;
+                qj.push_back(TrsmJob{c->d_Q, N, N, c->d_dy, N, 1});
+                CK(plan_trsm(c, c->p_bwd, qj, 0));
+                CK(plan_trsm(c, c->p_bwd, qj, 1));
+            }
+            if (!c->fused_fs) {
+                std::vector<GemmDesc> g2;                                                       // t += LB dy             (:1568-1569)
+                g2.push_back(mk_gemm(0, 0, (int)c->xlen, 1, N, 1.0, c->d_LB, (int)c->xlen, c->d_dy, N, 1.0, c->d_t, (int)c->xlen));
+                CK(add_gemm_stage(c, c->p_bwd, g2));
+            }
+        }
+        if (c->fused_fs) {
+            Step s;
+            s.kind = STEP_CSOLVE_BWD; s.grid = J; s.d0 = dcs; s.bytes = lds_cs;                 // dx_j = L_j^-T (t_j + LB_j dy)  (:1566-1573)
+            c->p_bwd.steps.push_back(s);
+        } else {
+            CK(plan_trsm(c, c->p_bwd, tj, 1));
+        }
     }
     // plan: Cholesky of X blocks (src/solver.jl:388-399)
     {
-        std::vector<PotrfJob> pj;
-        for (int b = 0; b < NB; b++) pj.push_back(PotrfJob{c->d_X + c->blk[b].xyoff, c->blk[b].n, c->blk[b].n, b + 1});
         Step ms; ms.kind = STEP_MEMSET_INFO; ms.dst = c->d_info + 1;
         c->p_cholX.steps.push_back(ms);
-        CK(plan_potrf(c, c->p_cholX, pj, c->d_info + 1));
-        if (NB > 0) {   // strict upper triangles -> 0, the output format of approx_cholesky! (src/tools.jl:100-105)
-            std::vector<PotrfDesc> zd;
-            i64 maxnn = 0;
+        if (c->fused_x) {
+            std::vector<SmallPotrf> sp(NB);
+            size_t lds = 0;
             for (int b = 0; b < NB; b++) {
-                zd.push_back(PotrfDesc{c->d_X + c->blk[b].xyoff, c->blk[b].n, c->blk[b].n, 0, 0});
-                maxnn = std::max(maxnn, (i64)c->blk[b].n * c->blk[b].n);
+                sp[b].in_off = c->blk[b].xyoff; sp[b].out_off = c->blk[b].xyoff; sp[b].dinv = nullptr;
+                sp[b].n = c->blk[b].n; sp[b].ldin = c->blk[b].n; sp[b].ldout = c->blk[b].n; sp[b].code = b + 1;
+                lds = std::max(lds, (size_t)lds_square(c->blk[b].n) * sizeof(double));
             }
-            PotrfDesc *dz;
-            CK(upload(c, zd, &dz));
-            Step zs;
-            zs.kind = STEP_ZERO_UPPER; zs.grid = NB; zs.d0 = dz; zs.n = maxnn;
-            c->p_cholX.steps.push_back(zs);
+            SmallPotrf *dsp;
+            CK(upload(c, sp, &dsp));
+            Step s;
+            s.kind = STEP_SMALL_POTRF; s.grid = NB; s.d0 = dsp; s.dst = c->d_info + 1; s.n = 0; s.bytes = lds;
+            c->p_cholX.steps.push_back(s);
+            if (lds > 64 * 1024) HIPCK(hipFuncSetAttribute((const void *)k_small_potrf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_square(128) * sizeof(double))));
+        } else {
+            std::vector<PotrfJob> pj;
+            for (int b = 0; b < NB; b++) pj.push_back(PotrfJob{c->d_X + c->blk[b].xyoff, c->blk[b].n, c->blk[b].n, b + 1});
+            CK(plan_potrf(c, c->p_cholX, pj, c->d_info + 1));
+            if (NB > 0) {   // strict upper triangles -> 0, the output format of approx_cholesky! (src/tools.jl:100-105)
+                std::vector<PotrfDesc> zd;
+                i64 maxnn = 0;
+                for (int b = 0; b < NB; b++) {
+                    zd.push_back(PotrfDesc{c->d_X + c->blk[b].xyoff, c->blk[b].n, c->blk[b].n, 0, 0});
+                    maxnn = std::max(maxnn, (i64)c->blk[b].n * c->blk[b].n);
+                }
+                PotrfDesc *dz;
+                CK(upload(c, zd, &dz));
+                Step zs;
+                zs.kind = STEP_ZERO_UPPER; zs.grid = NB; zs.d0 = dz; zs.n = maxnn;
+                c->p_cholX.steps.push_back(zs);
+            }
         }
     }
 
@@ -981,8 +1116,13 @@ static int collect_times(clrs_ctx *c) {
 extern "C" int clrs_schur_assemble_dev(clrs_ctx *c, const double *d_Xchol, const double *d_Y) {
     if (!c || !d_Xchol || !d_Y) return fail(CLRS_ERR_INVALID, "null argument");
     HIPCHECK(hipSetDevice(c->device));
-    if (d_Xchol != c->d_Xc) HIPCHECK(hipMemcpyAsync(c->d_Xc, d_Xchol, sizeof(double) * c->xylen, hipMemcpyDeviceToDevice, c->stream));
-    if (d_Y != c->d_Y) HIPCHECK(hipMemcpyAsync(c->d_Y, d_Y, sizeof(double) * c->xylen, hipMemcpyDeviceToDevice, c->stream));
+    if (c->all_assemble_fused) {   // the fused kernel reads the caller's buffers directly
+        c->ftables.Xc = d_Xchol; c->ftables.Y = d_Y;
+    } else {
+        c->ftables.Xc = c->d_Xc; c->ftables.Y = c->d_Y;
+        if (d_Xchol != c->d_Xc) HIPCHECK(hipMemcpyAsync(c->d_Xc, d_Xchol, sizeof(double) * c->xylen, hipMemcpyDeviceToDevice, c->stream));
+        if (d_Y != c->d_Y) HIPCHECK(hipMemcpyAsync(c->d_Y, d_Y, sizeof(double) * c->xylen, hipMemcpyDeviceToDevice, c->stream));
+    }
     if (c->timing) HIPCHECK(hipEventRecord(c->ev[0], c->stream));
     int rc = run_plan(c, c->p_assemble);
     if (rc) return rc;
@@ -1091,7 +1231,8 @@ extern "C" int clrs_schur_solve_fwd_dev(clrs_ctx *c, const double *d_rhs_x) {
     if (!c || !d_rhs_x) return fail(CLRS_ERR_INVALID, "null argument");
     if (!c->factored) return fail(CLRS_ERR_STATE, "clrs_schur_solve called before clrs_schur_factor");
     HIPCHECK(hipSetDevice(c->device));
-    if (d_rhs_x != c->d_rhsx) HIPCHECK(hipMemcpyAsync(c->d_rhsx, d_rhs_x, sizeof(double) * c->xlen, hipMemcpyDeviceToDevice, c->stream));
+    if (c->fused_fs) c->bind_rhsx = d_rhs_x;
+    else if (d_rhs_x != c->d_rhsx) HIPCHECK(hipMemcpyAsync(c->d_rhsx, d_rhs_x, sizeof(double) * c->xlen, hipMemcpyDeviceToDevice, c->stream));
     if (c->timing) HIPCHECK(hipEventRecord(c->ev[7], c->stream));
     return run_plan(c, c->p_fwd);
 }
@@ -1100,13 +1241,19 @@ extern "C" int clrs_schur_solve_bwd_dev(clrs_ctx *c, const double *d_rhs_y, doub
     if (!c) return fail(CLRS_ERR_INVALID, "null argument");
     if (!c->factored) return fail(CLRS_ERR_STATE, "clrs_schur_solve called before clrs_schur_factor");
     HIPCHECK(hipSetDevice(c->device));
-    if (c->N > 0 && d_rhs_y && d_rhs_y != c->d_rhsy)
+    if (c->N > 0 && !d_rhs_y) return fail(CLRS_ERR_INVALID, "rhs_y is required when there are free variables");
+    // the fused kernels read / write the caller's buffers; the staged ones work on the context's own
+    const bool q_direct = c->fused_q && c->N > 0, x_direct = c->fused_fs;
+    c->bind_rhsy = q_direct ? d_rhs_y : c->d_rhsy;
+    c->bind_dy = (c->fused_q && d_dy) ? d_dy : c->d_dy;
+    c->bind_dx = (x_direct && d_dx) ? d_dx : c->d_dx;
+    if (c->N > 0 && !q_direct && d_rhs_y != c->d_rhsy)
         HIPCHECK(hipMemcpyAsync(c->d_rhsy, d_rhs_y, sizeof(double) * c->N, hipMemcpyDeviceToDevice, c->stream));
     int rc = run_plan(c, c->p_bwd);
     if (rc) return rc;
     if (c->timing) { HIPCHECK(hipEventRecord(c->ev[8], c->stream)); c->solve_time_pending = true; }
-    if (d_dx && d_dx != c->d_t) HIPCHECK(hipMemcpyAsync(d_dx, c->d_t, sizeof(double) * c->xlen, hipMemcpyDeviceToDevice, c->stream));
-    if (d_dy && c->N > 0 && d_dy != c->d_dy) HIPCHECK(hipMemcpyAsync(d_dy, c->d_dy, sizeof(double) * c->N, hipMemcpyDeviceToDevice, c->stream));
+    if (!x_direct && d_dx && d_dx != c->d_t) HIPCHECK(hipMemcpyAsync(d_dx, c->d_t, sizeof(double) * c->xlen, hipMemcpyDeviceToDevice, c->stream));
+    if (!c->fused_q && d_dy && c->N > 0 && d_dy != c->d_dy) HIPCHECK(hipMemcpyAsync(d_dy, c->d_dy, sizeof(double) * c->N, hipMemcpyDeviceToDevice, c->stream));
     return 0;
 }
 
@@ -1121,8 +1268,8 @@ extern "C" int clrs_schur_solve(clrs_ctx *c, const double *rhs_x, const double *
     }
     int rc;
     if ((rc = clrs_schur_solve_fwd_dev(c, c->d_rhsx))) return rc;
-    if ((rc = clrs_schur_solve_bwd_dev(c, c->d_rhsy, nullptr, nullptr))) return rc;
-    HIPCHECK(hipMemcpyAsync(dx, c->d_t, sizeof(double) * c->xlen, hipMemcpyDeviceToHost, c->stream));
+    if ((rc = clrs_schur_solve_bwd_dev(c, c->d_rhsy, c->d_dx, c->d_dy))) return rc;
+    HIPCHECK(hipMemcpyAsync(dx, c->d_dx, sizeof(double) * c->xlen, hipMemcpyDeviceToHost, c->stream));
     if (c->N > 0) HIPCHECK(hipMemcpyAsync(dy, c->d_dy, sizeof(double) * c->N, hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(hipStreamSynchronize(c->stream));
     return 0;
@@ -1131,6 +1278,10 @@ extern "C" int clrs_schur_solve(clrs_ctx *c, const double *rhs_x, const double *
 extern "C" int clrs_cholesky_blocks_dev(clrs_ctx *c, const double *d_X, double *d_Xchol) {
     if (!c || !d_X || !d_Xchol) return fail(CLRS_ERR_INVALID, "null argument");
     HIPCHECK(hipSetDevice(c->device));
+    if (c->fused_x) {              // one launch, caller's buffers
+        c->bind_X = d_X; c->bind_Xchol = d_Xchol;
+        return run_plan(c, c->p_cholX);
+    }
     if (d_X != c->d_X) HIPCHECK(hipMemcpyAsync(c->d_X, d_X, sizeof(double) * c->xylen, hipMemcpyDeviceToDevice, c->stream));
     int rc = run_plan(c, c->p_cholX);
     if (rc) return rc;
@@ -1237,6 +1388,7 @@ extern "C" int clrs_get_kernel_times(clrs_ctx *c, int max_kinds, double *seconds
 extern "C" int clrs_config_set(const char *key, int value) {
     if (!key) return fail(CLRS_ERR_INVALID, "null argument");
     if (!std::strcmp(key, "fused_assemble")) { g_cfg_fused_assemble = value; return 0; }
+    if (!std::strcmp(key, "fused_factor")) { g_cfg_fused_factor = value; return 0; }
     return fail(CLRS_ERR_INVALID, std::string("unknown configuration key ") + key);
 }
 

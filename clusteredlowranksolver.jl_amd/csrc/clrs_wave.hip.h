@@ -1,0 +1,259 @@
+// clrs_wave.hip.h -- wave-level (64 lanes) dense building blocks on LDS-resident fp64 matrices, gfx950.
+//
+// The matrices of the named configurations are 16..128 wide: too small for tiled BLAS-3 kernels, too serial for
+// one-thread-per-column loops through LDS.  These routines keep the dependent chains of the triangular solves and
+// of the Cholesky factorisation inside ONE wave, with
+//   * one matrix element (or one matrix row) per lane,
+//   * DPP row broadcasts (row_newbcast, 16 lanes) to pass the pivot / the finished unknown -- no LDS round trip,
+//   * v_mfma_f64_16x16x4_f64 for every 16 x 16 x 16 trailing update,
+// and are blocked by 16 so that any n <= 128 is handled by the same code.  All matrices are column-major in LDS.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace clrs {
+
+typedef double v4d_f __attribute__((ext_vector_type(4)));
+
+// broadcast lane K of every 16-lane row to the whole row
+template <int K>
+__device__ __forceinline__ double bcast16(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x150 + K, 0xf, 0xf, false);   // row_newbcast:K
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x150 + K, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+// ---- small MFMA GEMM on LDS operands:  C[i,j] = sum_k A[k,i] B[k,j]  (i < M, j < N, k < K) -------------------------
+// A: K x M (ld lda), B: K x N (ld ldb), C: M x N (ld ldc).  Rows k >= K of A/B up to ceil4(K) and columns up to
+// ceil16(M)/ceil16(N) must be readable and ZERO.  Tiles of 16 x 16 are dealt to the waves of the workgroup.
+// lower_only: only tiles with ti >= tj (C symmetric, the caller mirrors).
+__device__ __forceinline__ void lds_gemm_tn(const double *A, int lda, const double *B, int ldb, double *C, int ldc, int M, int N, int K,
+                                            int wave, int nwaves, int lane, bool lower_only = false) {
+    const int tm = (M + 15) >> 4, tn = (N + 15) >> 4, K4 = (K + 3) & ~3;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    int t = wave, ti = wave, tj = 0;
+    while (ti >= tm) { ti -= tm; tj++; }
+    for (; t < tm * tn; t += nwaves) {
+        if (!lower_only || ti >= tj) {
+            const double *a = A + l4 + (ti * 16 + l15) * lda;   // A[k, i0 + c]
+            const double *b = B + l4 + (tj * 16 + l15) * ldb;   // B[k, j0 + r]
+            v4d_f acc = {0.0, 0.0, 0.0, 0.0};
+            int k = 0;
+            for (; k + 16 <= K4; k += 16) {   // 8 LDS reads in flight per 4 MFMAs
+                const double a0 = a[k], a1 = a[k + 4], a2 = a[k + 8], a3 = a[k + 12];
+                const double b0 = b[k], b1 = b[k + 4], b2 = b[k + 8], b3 = b[k + 12];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a1, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b2, a2, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b3, a3, acc, 0, 0, 0);
+            }
+            for (; k < K4; k += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b[k], a[k], acc, 0, 0, 0);
+            // D[r][c] = C[i0 + c, j0 + r]; lane holds c = lane & 15, r = (lane >> 4) + 4 * reg
+            const int i = ti * 16 + l15;
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+                const int j = tj * 16 + l4 + 4 * reg;
+                if (i < M && j < N) C[i + j * ldc] = acc[reg];
+            }
+        }
+        ti += nwaves;
+        while (ti >= tm) { ti -= tm; tj++; }
+    }
+}
+
+// ---- 16 x 16 triangular solves inside a wave ----------------------------------------------------------------------
+// A wave holds 4 right-hand sides x 16 unknowns, one element per lane (row = lane & 15).  Forward (L x = b): step K
+// broadcasts the finished x_K and every lane below eliminates it with one FMA.  Lrow[k] = L[row, k], zero above the
+// diagonal; dinv = 1 / L[row,row] (0 for padding rows).  Two independent right-hand-side sets are interleaved.
+template <int K>
+struct Trsm16 {
+    static __device__ __forceinline__ void run(double &x0, double &x1, const double (&Lrow)[16], double dinv, int row) {
+        const double b0 = bcast16<K>(x0 * dinv), b1 = bcast16<K>(x1 * dinv);
+        x0 = (row == K) ? b0 : __builtin_fma(-Lrow[K], b0, x0);   // Lrow[K] == 0 above the diagonal: finished rows stay
+        x1 = (row == K) ? b1 : __builtin_fma(-Lrow[K], b1, x1);
+        Trsm16<K + 1>::run(x0, x1, Lrow, dinv, row);
+    }
+};
+template <>
+struct Trsm16<16> {
+    static __device__ __forceinline__ void run(double &, double &, const double (&)[16], double, int) {}
+};
+// Backward (L^T x = b): Lcol[k] = L[k, row] (zero for k < row), steps K = 15 .. 0.
+template <int K>
+struct Trsm16T {
+    static __device__ __forceinline__ void run(double &x0, double &x1, const double (&Lcol)[16], double dinv, int row) {
+        const double b0 = bcast16<K>(x0 * dinv), b1 = bcast16<K>(x1 * dinv);
+        x0 = (row == K) ? b0 : __builtin_fma(-Lcol[K], b0, x0);
+        x1 = (row == K) ? b1 : __builtin_fma(-Lcol[K], b1, x1);
+        Trsm16T<K - 1>::run(x0, x1, Lcol, dinv, row);
+    }
+};
+template <>
+struct Trsm16T<-1> {
+    static __device__ __forceinline__ void run(double &, double &, const double (&)[16], double, int) {}
+};
+
+// Z <- L^-1 Z (TRANS = false) or Z <- L^-T Z (TRANS = true), blocked by 16.
+//   L: lower triangular, ld ldl, ZERO above the diagonal and in rows/columns n..ceil16(n)-1;
+//   dinv[i] = 1 / L[i,i] for i < n, 0 for n <= i < ceil16(n);
+//   Z element (row, col) at Z[row * rs + col * cs]; rows n..ceil16(n)-1 must be readable (any finite value) and are
+//   only written with values that do not matter.  Must be called by all `nwaves` waves of the workgroup (barriers).
+template <bool TRANS>
+__device__ __forceinline__ void lds_trsm(const double *L, int ldl, const double *dinv, double *Z, int rs, int cs, int n, int ncols, int wave,
+                                         int nwaves, int lane) {
+    const int npan = (n + 15) >> 4, row16 = lane & 15, cg4 = lane >> 4;
+    const int ngroups = (ncols + 3) >> 2;
+    for (int step = 0; step < npan; step++) {
+        const int pb = TRANS ? npan - 1 - step : step;
+        const int r0 = pb * 16, row = r0 + row16;
+        double Lr[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) Lr[k] = TRANS ? L[(r0 + k) + row * ldl] : L[row + (r0 + k) * ldl];
+        const double di = dinv[row];
+        for (int g = wave; g < ngroups; g += 2 * nwaves) {   // two column groups per pass: independent chains interleave
+            const int c0 = g * 4 + cg4, c1 = (g + nwaves) * 4 + cg4;
+            const bool v0 = c0 < ncols, v1 = c1 < ncols;
+            double x0 = v0 ? Z[row * rs + c0 * cs] : 0.0, x1 = v1 ? Z[row * rs + c1 * cs] : 0.0;
+            if (TRANS) Trsm16T<15>::run(x0, x1, Lr, di, row16);
+            else Trsm16<0>::run(x0, x1, Lr, di, row16);
+            if (v0) Z[row * rs + c0 * cs] = x0;
+            if (v1) Z[row * rs + c1 * cs] = x1;
+        }
+        if (step + 1 < npan) {
+            __syncthreads();
+            // remaining panels:  Z[i-panel, :] -= op(L)[i-panel, r0:r0+16] Z[r0:r0+16, :]   (MFMA, 16 x 16 tiles)
+            const int tm = npan - step - 1, tn = (ncols + 15) >> 4;
+            int ti = wave, tj = 0;
+            while (ti >= tm) { ti -= tm; tj++; }
+            for (int t = wave; t < tm * tn; t += nwaves) {
+                const int i0 = TRANS ? ti * 16 : r0 + 16 + ti * 16, j0 = tj * 16;
+                v4d_f acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kk = 0; kk < 16; kk += 4) {
+                    const double zb = (j0 + row16 < ncols) ? Z[(r0 + kk + cg4) * rs + (j0 + row16) * cs] : 0.0;    // a-operand: Z[k, j0 + r]
+                    const double la = TRANS ? L[(r0 + kk + cg4) + (i0 + row16) * ldl]  // b-operand: L[k, i0 + c]  (L^T[i0 + c, k])
+                                            : L[(i0 + row16) + (r0 + kk + cg4) * ldl]; //            L[i0 + c, k]
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(zb, la, acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++) {
+                    const int j = j0 + cg4 + 4 * reg;
+                    if (j < ncols) Z[(i0 + row16) * rs + j * cs] -= acc[reg];
+                }
+                ti += nwaves;
+                while (ti >= tm) { ti -= tm; tj++; }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ---- 16 x 16 Cholesky inside a wave: lane r (of every 16-lane row, redundantly) holds row r of the block ---------------
+// Right-looking: step K takes the square root of the pivot of lane K, scales column K, and eliminates it from the
+// trailing columns; l_JK of lane J reaches the others by DPP broadcast.  IEEE sqrt and division (parity with LAPACK-style
+// references).  Returns through `bad` whether a pivot of a row < nvalid was not positive (tools.jl:92-95).
+template <int K>
+struct Potrf16 {
+    static __device__ __forceinline__ void run(double (&a)[16], int row, int nvalid, bool &bad) {
+        const double akk = bcast16<K>(a[K]);
+        if (K < nvalid && !(akk > 0.0)) bad = true;
+        const double d = sqrt(akk);
+        const double lik = (row == K) ? d : a[K] / d;    // rows < K hold zeros in column K already
+        a[K] = (row >= K) ? lik : 0.0;
+        Elim<K + 1>::run(a, lik, row);
+        Potrf16<K + 1>::run(a, row, nvalid, bad);
+    }
+    template <int J, int DUMMY = 0>
+    struct Elim {
+        static __device__ __forceinline__ void run(double (&a)[16], double lik, int row) {
+            const double ljk = bcast16<J>(lik);          // l_JK lives in lane J
+            if (row >= J) a[J] = __builtin_fma(-lik, ljk, a[J]);
+            Elim<J + 1>::run(a, lik, row);
+        }
+    };
+    template <int DUMMY>
+    struct Elim<16, DUMMY> {
+        static __device__ __forceinline__ void run(double (&)[16], double, int) {}
+    };
+};
+template <>
+struct Potrf16<16> {
+    static __device__ __forceinline__ void run(double (&)[16], int, int, bool &) {}
+};
+
+// In-place lower Cholesky of the n x n matrix A in LDS (ld lda), blocked by 16.  Requirements: rows/columns
+// n..ceil16(n)-1 of A hold the identity (diagonal 1, rest 0); only the lower triangle is read.  On return the lower
+// triangle holds L, the diagonal blocks have zeros above the diagonal; the strictly upper off-diagonal blocks are
+// NOT touched (callers mask them when storing).  dinv (ceil16(n) doubles of LDS) receives 1 / L[i,i] (0 for i >= n).
+// Returns true in every thread of wave 0 .. (callers reduce) if a pivot was not positive.  All waves must call.
+__device__ __forceinline__ bool lds_potrf(double *A, int lda, double *dinv, int n, int wave, int nwaves, int lane) {
+    const int npan = (n + 15) >> 4, row16 = lane & 15, cg4 = lane >> 4;
+    bool bad = false;
+    for (int pb = 0; pb < npan; pb++) {
+        const int r0 = pb * 16;
+        if (wave == 0) {
+            double a[16];
+#pragma unroll
+            for (int c = 0; c < 16; c++) a[c] = A[(r0 + row16) + (r0 + c) * lda];
+#pragma unroll
+            for (int c = 1; c < 16; c++)
+                if (c > row16) a[c] = 0.0;
+            Potrf16<0>::run(a, row16, n - r0, bad);
+            if (cg4 == 0) {
+#pragma unroll
+                for (int c = 0; c < 16; c++) A[(r0 + row16) + (r0 + c) * lda] = a[c];
+                // a[row16] is the diagonal entry: select it without dynamic register indexing
+                double dg = a[0];
+#pragma unroll
+                for (int c = 1; c < 16; c++) dg = (row16 == c) ? a[c] : dg;
+                dinv[r0 + row16] = (r0 + row16 < n) ? 1.0 / dg : 0.0;
+            }
+        }
+        if (pb + 1 == npan) break;
+        __syncthreads();
+        // panel: rows below the diagonal block, X L_kk^T = A_panel  <=>  L_kk X^T = A_panel^T: the unknown index runs along
+        // the 16 columns of the panel (stride lda), the right-hand sides are the panel rows (stride 1)
+        {
+            const int M = (npan - pb - 1) * 16;
+            double Lr[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) Lr[k] = A[(r0 + row16) + (r0 + k) * lda];
+            const double di = dinv[r0 + row16];
+            const int ngroups = M >> 2;
+            for (int g = wave; g < ngroups; g += 2 * nwaves) {
+                const int c0 = g * 4 + cg4, c1 = (g + nwaves) * 4 + cg4;
+                const bool v1 = c1 < M;
+                double *p0 = A + (r0 + 16 + c0) + (r0 + row16) * lda, *p1 = A + (r0 + 16 + c1) + (r0 + row16) * lda;
+                double x0 = *p0, x1 = v1 ? *p1 : 0.0;
+                Trsm16<0>::run(x0, x1, Lr, di, row16);
+                *p0 = x0;
+                if (v1) *p1 = x1;
+            }
+        }
+        __syncthreads();
+        // trailing update (lower tiles): A[i-blk, j-blk] -= Lp_i Lp_j^T
+        {
+            const int tm = npan - pb - 1;
+            for (int t = wave; t < tm * (tm + 1) / 2; t += nwaves) {
+                int tj = 0, rem = t;
+                while (rem >= tm - tj) { rem -= tm - tj; tj++; }
+                const int ti = tj + rem;
+                const int i0 = r0 + 16 + ti * 16, j0 = r0 + 16 + tj * 16;
+                v4d_f acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kk = 0; kk < 16; kk += 4) {
+                    const double aj = A[(j0 + row16) + (r0 + kk + cg4) * lda];   // a-operand: Lp[j0 + r, k]
+                    const double ai = A[(i0 + row16) + (r0 + kk + cg4) * lda];   // b-operand: Lp[i0 + c, k]
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aj, ai, acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++) A[(i0 + row16) + (j0 + cg4 + 4 * reg) * lda] -= acc[reg];
+            }
+        }
+        __syncthreads();
+    }
+    return bad;
+}
+
+}  // namespace clrs

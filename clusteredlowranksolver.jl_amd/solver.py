@@ -47,13 +47,14 @@ class SchurContext:
     src/solver.jl:298-317 -- all device resident."""
 
     def __init__(self, sdp, device: int = 0, graph: bool = False, timing: bool = False, fused: Optional[bool] = None):
-        """`fused=False` forces the staged grouped-GEMM assembly for every cluster (default: clusters that fit in
-        one CU's LDS take the fused per-cluster kernel)."""
+        """`fused=False` forces the staged grouped-GEMM / blocked-BLAS path everywhere (default: clusters that fit in
+        one CU's LDS take the fused per-cluster assembly, factor and solve kernels)."""
         self.flat: FlatSDP = sdp if isinstance(sdp, FlatSDP) else flatten(sdp)
         f = self.flat
         self.L = _lib.load()
         if fused is not None:
             _lib.check(self.L.clrs_config_set(b"fused_assemble", int(bool(fused))))
+            _lib.check(self.L.clrs_config_set(b"fused_factor", int(bool(fused))))
         k = self._keep = {}
 
         def hold(name, arr, dt):
@@ -76,6 +77,7 @@ class SchurContext:
         finally:
             if fused is not None:
                 self.L.clrs_config_set(b"fused_assemble", 1)
+                self.L.clrs_config_set(b"fused_factor", 1)
         self.h = h
         self.device = device
         if graph:

@@ -108,14 +108,15 @@ def test_dedup_counts_match_oracle(oracle_built):
 FACTOR_CASES = ["x2p1", "polyopt8", "polyopt40", "delsarte_3_10", "delsarte_8_3", "ns_8_3_2", "sdpa_small", "sdpa_mid", "polyopt_scaled_100"]
 
 
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "staged"])
 @pytest.mark.parametrize("name", FACTOR_CASES)
-def test_factor_and_solve_match_oracle(name, oracle_built):
+def test_factor_and_solve_match_oracle(name, fused, oracle_built):
     from clrs_amd.solver import SchurContext, compute_T_decomposition, solve_system
     from oracle.oracle import Oracle
     f = flat(name)
     X, Y = spd_iterates(f, seed=2)
     Xc = chol_blocks_np(f, X)
-    ctx = SchurContext(f)
+    ctx = SchurContext(f, fused=fused)
     _, S, _ = compute_T_decomposition(ctx, Xc, Y, want_S=True)
     L, LinvB, LQ = ctx.get_factor()
     o = Oracle(f, quad=False)
@@ -163,11 +164,12 @@ def test_factor_failure_is_reported_like_the_reference():
     ctx.close()
 
 
-def test_cholesky_blocks(oracle_built):
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "staged"])
+def test_cholesky_blocks(fused, oracle_built):
     from clrs_amd.solver import SchurContext, SolverFailure
     f = flat("delsarte_3_10")
     X, _ = spd_iterates(f, seed=4)
-    ctx = SchurContext(f)
+    ctx = SchurContext(f, fused=fused)
     Xc = ctx.cholesky_blocks(X)
     assert np.max(np.abs(Xc - chol_blocks_np(f, X))) <= 1e-12 * np.max(np.abs(Xc))
     X[f.block_off[3]] = -1.0
@@ -237,14 +239,15 @@ def test_schur_assemble_matches_256bit_golden(name, fused):
     ctx.close()
 
 
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "staged"])
 @pytest.mark.parametrize("name", GOLDEN_FULL)
-def test_factor_solve_matches_256bit_golden(name):
+def test_factor_solve_matches_256bit_golden(name, fused):
     """(dx, dy) against the 256-bit LU solution of the full KKT system; 1e-7 relative (fp64 eps x cond ~1e8)."""
     import os
     from clrs_amd.solver import SchurContext, compute_T_decomposition, solve_system
     f = flat(name)
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
-    ctx = SchurContext(f)
+    ctx = SchurContext(f, fused=fused)
     compute_T_decomposition(ctx, g["Xchol"], g["Y"])
     dx, dy = solve_system(ctx, g["rhs_x"], g["rhs_y"])
     scale = max(1.0, np.max(np.abs(g["dx"])), np.max(np.abs(g["dy"])) if f.n_free else 0.0)
