@@ -118,7 +118,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--no-graph", action="store_true", help="launch kernels one by one instead of replaying hipGraphs")
+    ap.add_argument("--graph", action="store_true", help="replay one hipGraph per library call instead of launching kernels one by one "
+                    "(slower for this path: a call is 1-3 kernels and a graph replay costs 10-16 us of host time)")
     ap.add_argument("--roofline-copies", type=int, default=512, help="cluster replication factor of the roofline instance")
     ap.add_argument("--skip-cpu", action="store_true")
     args = ap.parse_args()
@@ -147,7 +148,7 @@ def main():
         log(f"problem: {flat.n_clusters} clusters P={list(flat.cluster_P[:4])}.. N={flat.n_free} blocks n={list(flat.block_n[:4])}.. "
             f"generated in {time.time() - t0:.1f}s")
     parts = [[2 * r, 2 * r + 1] for r in range(world)]          # 2 clusters per GPU (identical weights)
-    use_graph = not args.no_graph
+    use_graph = args.graph
     sh = ShardedSchur(flat, rank, world, lambda s: HipLocal(s, local_rank, graph=use_graph), parts=parts)
     f = sh.shard
     ctx = sh.local.ctx

@@ -55,6 +55,8 @@ SYMBOLS = {
     "clrs_get_factor": (C.c_int, [C.c_void_p, p_d, p_d, p_d]),
     "clrs_schur_solve": (C.c_int, [C.c_void_p, p_d, p_d, p_d, p_d]),
     "clrs_schur_assemble_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "clrs_schur_factor_dev": (C.c_int, [C.c_void_p]),
+    "clrs_schur_solve_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "clrs_schur_factor_local_dev": (C.c_int, [C.c_void_p]),
     "clrs_q_buffer_dev": (C.c_void_p, [C.c_void_p]),
     "clrs_schur_factor_finish_dev": (C.c_int, [C.c_void_p]),

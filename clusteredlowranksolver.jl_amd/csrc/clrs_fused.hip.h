@@ -261,15 +261,28 @@ struct SmallPotrf {
     long long in_off, out_off;   // offsets from the base pointers given at launch
     double *dinv;                // optional: 1 / diag(L), n doubles
     int n, ldin, ldout, code;
+    int nslabs;                  // > 1: the input is the sum of nslabs matrices, slab_stride apart (partial Q per cluster)
+    int pad;
+    long long slab_stride;
 };
 
-__device__ __forceinline__ void lds_load_lower_identity_padded(double *A, int lda, const double *G, int ldg, int n, int n16, int tid, int nthr) {
+__device__ __forceinline__ void lds_load_lower_identity_padded(double *A, int lda, const double *G, int ldg, int n, int n16, int tid, int nthr,
+                                                               int nslabs = 1, long long slab_stride = 0) {
     // 16 x 16 element tiles: (tid & 15) walks down a column (contiguous in memory), (tid >> 4) across columns
     const int i16 = tid & 15, j16 = tid >> 4, jstep = nthr >> 4;
     for (int j0 = 0; j0 < n16; j0 += jstep)
         for (int i0 = 0; i0 < n16; i0 += 16) {
             const int i = i0 + i16, j = j0 + j16;
-            if (j < n16) A[i + j * lda] = (i < n && j < n) ? ((i >= j) ? G[i + (long long)j * ldg] : 0.0) : ((i == j) ? 1.0 : 0.0);
+            if (j >= n16) continue;
+            double v = (i == j) ? 1.0 : 0.0;
+            if (i < n && j < n) {
+                v = 0.0;
+                if (i >= j) {
+                    const double *g = G + i + (long long)j * ldg;
+                    for (int sl = 0; sl < nslabs; sl++) v += g[sl * slab_stride];   // fixed order: deterministic
+                }
+            }
+            A[i + j * lda] = v;
         }
 }
 
@@ -282,7 +295,7 @@ __global__ __launch_bounds__(256) void k_small_potrf(const SmallPotrf *__restric
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int n = d.n, n16 = (n + 15) & ~15, lda = n16 + 2;
     double *A = lds, *dinv = lds + lda * n16;
-    lds_load_lower_identity_padded(A, lda, din, d.ldin, n, n16, tid, 256);
+    lds_load_lower_identity_padded(A, lda, din, d.ldin, n, n16, tid, 256, d.nslabs, d.slab_stride);
     __syncthreads();
     const bool bad = lds_potrf(A, lda, dinv, n, wave, 4, lane);
     if (bad && lane == 0) atomicMin(info, d.code);
@@ -304,6 +317,8 @@ struct CFactor {
     double *dinv;      // P doubles: 1 / diag(L_j), kept for the solves
     int P, N, ldb, code;
     int nc;            // columns of B processed per pass (LDS budget)
+    int pad;
+    double *Qslab;     // N x N partial Q_j = LinvB_j^T LinvB_j (only when nc >= N), or nullptr
 };
 
 __global__ __launch_bounds__(256) void k_cluster_factor(const CFactor *__restrict__ descs, int *__restrict__ info) {
@@ -340,7 +355,22 @@ __global__ __launch_bounds__(256) void k_cluster_factor(const CFactor *__restric
                 const int i = i0 + i16, j = j0 + j16;
                 if (i < P && j < nc) d.LB[i + (long long)(c0 + j) * d.ldb] = Z[i + j * lda];
             }
+        if (d.Qslab) {   // the whole LinvB_j is resident: its Gram matrix is this cluster's share of Q (src/solver.jl:1268-1269)
+            const int nc16 = (nc + 15) & ~15;
+            for (int e = tid; e < (nc16 - nc) * lda; e += 256) Z[nc * lda + e] = 0.0;   // zero the padding columns read by the MFMA tiles
+            __syncthreads();
+            lds_gemm_tn(Z, lda, Z, lda, d.Qslab, d.N, d.N, d.N, P, wave, 4, lane);
+        }
     }
+}
+
+// Q = sum of the per-cluster slabs (fixed order), for the split-phase path where Q is exchanged between ranks
+__global__ __launch_bounds__(256) void k_sum_slabs(const double *__restrict__ slabs, long long stride, int nslabs, long long len, double *__restrict__ out) {
+    const long long e = blockIdx.x * 256ll + threadIdx.x;
+    if (e >= len) return;
+    double v = 0.0;
+    for (int sl = 0; sl < nslabs; sl++) v += slabs[e + sl * stride];
+    out[e] = v;
 }
 
 // u[k] = sum_i LB[i,k] t[i]  (approx_mul_transpose!, src/solver.jl:1546, summed over the clusters): one wave per column
@@ -413,8 +443,10 @@ __global__ __launch_bounds__(256) void k_cluster_solve_bwd(const CSolve *__restr
 }
 
 // dy = Q^-1 (rhs_y - u) with Q = L_Q L_Q^T   (src/solver.jl:1550-1558)
+// With LB != nullptr the kernel first forms u = LinvB^T t itself (single-GPU path: saves the k_gemv_t launch).
 __global__ __launch_bounds__(256) void k_q_solve(const double *__restrict__ LQ, const double *__restrict__ dinvQ, int N, const double *__restrict__ rhs_y,
-                                                 const double *__restrict__ u, double *__restrict__ dy) {
+                                                 double *__restrict__ u, double *__restrict__ dy, const double *__restrict__ LB, int ldb, int rows,
+                                                 const double *__restrict__ t) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int N16 = (N + 15) & ~15, lda = N16 + 2;
@@ -425,6 +457,18 @@ __global__ __launch_bounds__(256) void k_q_solve(const double *__restrict__ LQ, 
             const int i = i0 + i16, j = j0 + j16;
             A[i + j * lda] = (i < N && j < N && i >= j) ? LQ[i + (long long)j * N] : 0.0;
         }
+    if (LB) {
+        for (int k = wave; k < N; k += 4) {
+            const double *col = LB + (long long)k * ldb;
+            double sacc = 0.0;
+            for (int i = lane; i < rows; i += 64) sacc += col[i] * t[i];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) sacc += __shfl_down(sacc, off, 64);
+            if (lane == 0) u[k] = sacc;
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
     if (tid < N16) {
         dv[tid] = (tid < N) ? dinvQ[tid] : 0.0;
         z[tid] = (tid < N) ? rhs_y[tid] - u[tid] : 0.0;

@@ -50,10 +50,10 @@ static const int LDS_BUDGET_DOUBLES = 20000;   // of the 20480 doubles (160 KiB)
 // ------------------------------------------------------------------------------------------------
 // launch plan
 // ------------------------------------------------------------------------------------------------
-enum StepKind { STEP_MEMCPY, STEP_GEMM, STEP_TRSM, STEP_POTRF, STEP_GATHER_S, STEP_GATHER_SCALAR, STEP_SUB, STEP_MEMSET_INFO, STEP_ZERO_UPPER, STEP_FUSED_ASSEMBLE, STEP_SMALL_POTRF, STEP_CLUSTER_FACTOR, STEP_GEMV_T, STEP_CSOLVE_FWD, STEP_Q_SOLVE, STEP_CSOLVE_BWD, STEP_NKINDS };
+enum StepKind { STEP_MEMCPY, STEP_GEMM, STEP_TRSM, STEP_POTRF, STEP_GATHER_S, STEP_GATHER_SCALAR, STEP_SUB, STEP_MEMSET_INFO, STEP_ZERO_UPPER, STEP_FUSED_ASSEMBLE, STEP_SMALL_POTRF, STEP_CLUSTER_FACTOR, STEP_GEMV_T, STEP_CSOLVE_FWD, STEP_Q_SOLVE, STEP_CSOLVE_BWD, STEP_SUM_SLABS, STEP_NKINDS };
 static const char *const STEP_NAMES[STEP_NKINDS] = {"hipMemcpyAsync(D2D)", "k_gemm_f64", "k_trsm_diag", "k_potrf_diag", "k_schur_gather",
                                                     "k_gather_scalar", "k_sub", "hipMemsetAsync", "k_zero_upper", "k_cluster_assemble", "k_small_potrf", "k_cluster_factor", "k_gemv_t",
-                                                    "k_cluster_solve_fwd", "k_q_solve", "k_cluster_solve_bwd"};
+                                                    "k_cluster_solve_fwd", "k_q_solve", "k_cluster_solve_bwd", "k_sum_slabs"};
 static const int KT_MAX_EVENTS = 8192;   // event pairs kept between two clrs_get_kernel_times calls
 
 struct Step {
@@ -137,7 +137,9 @@ struct clrs_ctx {
     // caller-provided device pointers of the current call, read by the fused kernels at launch (no staging copies)
     const double *bind_X = nullptr, *bind_rhsx = nullptr, *bind_rhsy = nullptr;
     double *bind_Xchol = nullptr, *bind_dx = nullptr, *bind_dy = nullptr;
-    double *d_dinvS = nullptr, *d_dinvQ = nullptr;
+    double *d_dinvS = nullptr, *d_dinvQ = nullptr, *d_Qslabs = nullptr;
+    bool q_slabs = false;     // k_cluster_factor leaves per-cluster partial Q slabs
+    Plan p_cholQ_slabs, p_solve_all;
     bool fused_fs = false, fused_q = false, fused_x = false, all_assemble_fused = false;
     bool factored = false, assembled = false;
     bool timing = false, graph_mode = false;
@@ -368,8 +370,14 @@ static int run_steps(clrs_ctx *c, const Plan &pl) {
             case STEP_SMALL_POTRF:
                 if (s.n == 0)
                     hipLaunchKernelGGL(k_small_potrf, dim3(s.grid), dim3(256), s.bytes, st, (const SmallPotrf *)s.d0, c->bind_X, c->bind_Xchol, (int *)s.dst);
-                else
+                else if (s.n == 1)
                     hipLaunchKernelGGL(k_small_potrf, dim3(s.grid), dim3(256), s.bytes, st, (const SmallPotrf *)s.d0, (const double *)c->d_Q, c->d_Q, (int *)s.dst);
+                else   // Q = sum of the per-cluster slabs, factored in the same launch
+                    hipLaunchKernelGGL(k_small_potrf, dim3(s.grid), dim3(256), s.bytes, st, (const SmallPotrf *)s.d0, (const double *)c->d_Qslabs, c->d_Q, (int *)s.dst);
+                break;
+            case STEP_SUM_SLABS:
+                hipLaunchKernelGGL(k_sum_slabs, dim3((unsigned)(((i64)c->N * c->N + 255) / 256)), dim3(256), 0, st, (const double *)c->d_Qslabs, (i64)c->N * c->N, c->J,
+                                   (i64)c->N * c->N, c->d_Q);
                 break;
             case STEP_CLUSTER_FACTOR:
                 hipLaunchKernelGGL(k_cluster_factor, dim3(s.grid), dim3(256), s.bytes, st, (const CFactor *)s.d0, (int *)s.dst);
@@ -381,7 +389,8 @@ static int run_steps(clrs_ctx *c, const Plan &pl) {
                 hipLaunchKernelGGL(k_cluster_solve_fwd, dim3(s.grid), dim3(256), s.bytes, st, (const CSolve *)s.d0, c->bind_rhsx, c->d_t);
                 break;
             case STEP_Q_SOLVE:
-                hipLaunchKernelGGL(k_q_solve, dim3(1), dim3(256), s.bytes, st, (const double *)c->d_Q, (const double *)c->d_dinvQ, c->N, c->bind_rhsy, (const double *)c->d_u, c->bind_dy);
+                hipLaunchKernelGGL(k_q_solve, dim3(1), dim3(256), s.bytes, st, (const double *)c->d_Q, (const double *)c->d_dinvQ, c->N, c->bind_rhsy, c->d_u, c->bind_dy,
+                                   s.n ? (const double *)c->d_LB : (const double *)nullptr, (int)c->xlen, (int)c->xlen, (const double *)c->d_t);
                 break;
             case STEP_CSOLVE_BWD:
                 hipLaunchKernelGGL(k_cluster_solve_bwd, dim3(s.grid), dim3(256), s.bytes, st, (const CSolve *)s.d0, (const double *)c->bind_dy, (const double *)c->d_t, c->bind_dx);
@@ -869,11 +878,10 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
         CK(dmalloc(c, &c->d_dinvS, c->xlen)); CK(dmalloc(c, &c->d_dinvQ, N));
     }
     {
-        Step ms; ms.kind = STEP_MEMSET_INFO;
-        c->p_cholS.steps.push_back(ms);
         if (c->fused_fs) {
             std::vector<CFactor> cf(J);
             size_t lds = 0;
+            c->q_slabs = c->fused_q && J <= 4096;
             for (int j = 0; j < J; j++) {
                 const int P = c->P[j], P16 = (P + 15) & ~15, lda = P16 + 2;
                 CFactor &f = cf[j];
@@ -881,8 +889,14 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
                 f.P = P; f.N = N; f.ldb = (int)c->xlen; f.code = j + 1;
                 const int room = (LDS_BUDGET_DOUBLES - lds_square(P)) / lda;      // columns of B that fit beside L
                 f.nc = std::max(1, std::min(std::max(N, 1), room));
-                lds = std::max(lds, (size_t)(lds_square(P) + lda * (N > 0 ? f.nc : 0)) * sizeof(double));
+                if (f.nc < N || room < ((N + 15) & ~15)) c->q_slabs = false;      // the Gram matrix needs all of LinvB_j (+ tile padding) resident
+                lds = std::max(lds, (size_t)(lds_square(P) + lda * (N > 0 ? std::max(f.nc, c->q_slabs ? ((N + 15) & ~15) : 0) : 0)) * sizeof(double));
             }
+            if (c->q_slabs) {
+                CK(dmalloc(c, &c->d_Qslabs, (i64)J * N * N));
+                for (int j = 0; j < J; j++) cf[j].Qslab = c->d_Qslabs + (i64)j * N * N;
+            } else
+                for (int j = 0; j < J; j++) cf[j].Qslab = nullptr;
             CFactor *dcf;
             CK(upload(c, cf, &dcf));
             Step s;
@@ -892,6 +906,8 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
         } else {
             std::vector<PotrfJob> pj;
             std::vector<TrsmJob> tj;
+            Step ms; ms.kind = STEP_MEMSET_INFO;
+            c->p_cholS.steps.push_back(ms);
             for (int j = 0; j < J; j++) {
                 pj.push_back(PotrfJob{c->d_S + c->Soff[j], c->P[j], c->P[j], j + 1});
                 if (N > 0) tj.push_back(TrsmJob{c->d_S + c->Soff[j], c->P[j], c->P[j], c->d_LB + c->coff[j], (int)c->xlen, N});
@@ -903,17 +919,31 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
             }
         }
         if (N > 0) {
-            std::vector<GemmDesc> gq;   // Q = LB^T LB  (vcat + matmul, src/solver.jl:1268-1269)
-            gq.push_back(mk_gemm(1, 0, N, N, (int)c->xlen, 1.0, c->d_LB, (int)c->xlen, c->d_LB, (int)c->xlen, 0.0, c->d_Q, N));
-            CK(add_gemm_stage(c, c->p_Q, gq));
+            if (c->q_slabs) {
+                Step s;
+                s.kind = STEP_SUM_SLABS;
+                c->p_Q.steps.push_back(s);
+            } else {
+                std::vector<GemmDesc> gq;   // Q = LB^T LB  (vcat + matmul, src/solver.jl:1268-1269)
+                gq.push_back(mk_gemm(1, 0, N, N, (int)c->xlen, 1.0, c->d_LB, (int)c->xlen, c->d_LB, (int)c->xlen, 0.0, c->d_Q, N));
+                CK(add_gemm_stage(c, c->p_Q, gq));
+            }
             if (c->fused_q) {
                 std::vector<SmallPotrf> sp(1);
+                std::memset(&sp[0], 0, sizeof(SmallPotrf));
                 sp[0].in_off = 0; sp[0].out_off = 0; sp[0].dinv = c->d_dinvQ; sp[0].n = N; sp[0].ldin = N; sp[0].ldout = N; sp[0].code = J + 1;
+                sp[0].nslabs = 1; sp[0].slab_stride = 0;
                 SmallPotrf *dsp;
                 CK(upload(c, sp, &dsp));
                 Step s;
                 s.kind = STEP_SMALL_POTRF; s.grid = 1; s.d0 = dsp; s.dst = c->d_info; s.n = 1; s.bytes = (size_t)lds_square(N) * sizeof(double);
                 c->p_cholQ.steps.push_back(s);
+                if (c->q_slabs) {   // single-GPU path: sum the slabs while loading Q, no separate reduction launch
+                    sp[0].nslabs = J; sp[0].slab_stride = (i64)N * N;
+                    CK(upload(c, sp, &dsp));
+                    s.d0 = dsp; s.n = 2;
+                    c->p_cholQ_slabs.steps.push_back(s);
+                }
                 if (s.bytes > 64 * 1024) HIPCK(hipFuncSetAttribute((const void *)k_small_potrf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_square(128) * sizeof(double))));
             } else {
                 std::vector<PotrfJob> qj;
@@ -987,16 +1017,23 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
             CK(plan_trsm(c, c->p_bwd, tj, 1));
         }
     }
+    // single-GPU solve in three launches: the u = LinvB^T t product moves into the Q-solve kernel
+    if (c->fused_fs && c->fused_q && c->xlen <= 4096) {
+        c->p_solve_all.steps.push_back(c->p_fwd.steps[0]);            // k_cluster_solve_fwd
+        Step q = c->p_bwd.steps[0];                                   // k_q_solve
+        q.n = 1;
+        c->p_solve_all.steps.push_back(q);
+        c->p_solve_all.steps.push_back(c->p_bwd.steps.back());        // k_cluster_solve_bwd
+    }
     // plan: Cholesky of X blocks (src/solver.jl:388-399)
     {
-        Step ms; ms.kind = STEP_MEMSET_INFO; ms.dst = c->d_info + 1;
-        c->p_cholX.steps.push_back(ms);
         if (c->fused_x) {
             std::vector<SmallPotrf> sp(NB);
             size_t lds = 0;
             for (int b = 0; b < NB; b++) {
+                std::memset(&sp[b], 0, sizeof(SmallPotrf));
                 sp[b].in_off = c->blk[b].xyoff; sp[b].out_off = c->blk[b].xyoff; sp[b].dinv = nullptr;
-                sp[b].n = c->blk[b].n; sp[b].ldin = c->blk[b].n; sp[b].ldout = c->blk[b].n; sp[b].code = b + 1;
+                sp[b].n = c->blk[b].n; sp[b].ldin = c->blk[b].n; sp[b].ldout = c->blk[b].n; sp[b].code = b + 1; sp[b].nslabs = 1;
                 lds = std::max(lds, (size_t)lds_square(c->blk[b].n) * sizeof(double));
             }
             SmallPotrf *dsp;
@@ -1007,6 +1044,8 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
             if (lds > 64 * 1024) HIPCK(hipFuncSetAttribute((const void *)k_small_potrf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_square(128) * sizeof(double))));
         } else {
             std::vector<PotrfJob> pj;
+            Step ms; ms.kind = STEP_MEMSET_INFO; ms.dst = c->d_info + 1;
+            c->p_cholX.steps.push_back(ms);
             for (int b = 0; b < NB; b++) pj.push_back(PotrfJob{c->d_X + c->blk[b].xyoff, c->blk[b].n, c->blk[b].n, b + 1});
             CK(plan_potrf(c, c->p_cholX, pj, c->d_info + 1));
             if (NB > 0) {   // strict upper triangles -> 0, the output format of approx_cholesky! (src/tools.jl:100-105)
@@ -1058,7 +1097,7 @@ extern "C" void clrs_ctx_destroy(clrs_ctx *c) {
     if (!c) return;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
-    Plan *plans[] = {&c->p_assemble, &c->p_cholS, &c->p_linvB, &c->p_Q, &c->p_cholQ, &c->p_fwd, &c->p_bwd, &c->p_cholX, &c->p_zeroL};
+    Plan *plans[] = {&c->p_assemble, &c->p_cholS, &c->p_linvB, &c->p_Q, &c->p_cholQ, &c->p_fwd, &c->p_bwd, &c->p_cholX, &c->p_zeroL, &c->p_cholQ_slabs, &c->p_solve_all};
     for (Plan *p : plans)
         if (p->graph) hipGraphExecDestroy(p->graph);
     for (void *p : c->allocs) hipFree(p);
@@ -1093,6 +1132,7 @@ static int read_info(clrs_ctx *c, int *status, int which = 0) {
     HIPCHECK(hipMemcpyAsync(&h, c->d_info + which, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(hipStreamSynchronize(c->stream));
     *status = (h == INFO_NONE) ? 0 : h;
+    if (h != INFO_NONE) HIPCHECK(hipMemsetAsync(c->d_info + which, 0x7f, sizeof(int), c->stream));   // re-arm: the status is "since the last query"
     return 0;
 }
 
@@ -1186,10 +1226,28 @@ extern "C" int clrs_sync_status_cholesky(clrs_ctx *c) {
     return rc ? rc : st;
 }
 
+extern "C" int clrs_schur_factor_dev(clrs_ctx *c) {
+    if (!c) return fail(CLRS_ERR_INVALID, "null argument");
+    if (c->p_cholQ_slabs.steps.empty()) {   // no fused single-GPU shortcut: the two split phases back to back
+        int rc = clrs_schur_factor_local_dev(c);
+        return rc ? rc : clrs_schur_factor_finish_dev(c);
+    }
+    if (!c->assembled) return fail(CLRS_ERR_STATE, "clrs_schur_factor called before clrs_schur_assemble");
+    HIPCHECK(hipSetDevice(c->device));
+    int rc;
+    if (c->timing) HIPCHECK(hipEventRecord(c->ev[2], c->stream));
+    if ((rc = run_plan(c, c->p_cholS))) return rc;                    // chol S_j, LinvB_j and the Q slabs: one launch
+    if (c->timing) { HIPCHECK(hipEventRecord(c->ev[3], c->stream)); HIPCHECK(hipEventRecord(c->ev[4], c->stream)); HIPCHECK(hipEventRecord(c->ev[5], c->stream)); }
+    if ((rc = run_plan(c, c->p_cholQ_slabs))) return rc;              // Q = sum of slabs, chol Q: one launch
+    if (c->timing) { HIPCHECK(hipEventRecord(c->ev[6], c->stream)); c->times_pending = true; }
+    c->assembled = false;
+    c->factored = true;
+    return 0;
+}
+
 extern "C" int clrs_schur_factor(clrs_ctx *c) {
-    int rc = clrs_schur_factor_local_dev(c);
+    int rc = clrs_schur_factor_dev(c);
     if (rc) return rc;
-    if ((rc = clrs_schur_factor_finish_dev(c))) return rc;
     return clrs_sync_status(c);
 }
 
@@ -1257,6 +1315,23 @@ extern "C" int clrs_schur_solve_bwd_dev(clrs_ctx *c, const double *d_rhs_y, doub
     return 0;
 }
 
+extern "C" int clrs_schur_solve_dev(clrs_ctx *c, const double *d_rhs_x, const double *d_rhs_y, double *d_dx, double *d_dy) {
+    if (!c || !d_rhs_x || !d_dx) return fail(CLRS_ERR_INVALID, "null argument");
+    if (c->p_solve_all.steps.empty()) {
+        int rc = clrs_schur_solve_fwd_dev(c, d_rhs_x);
+        return rc ? rc : clrs_schur_solve_bwd_dev(c, d_rhs_y, d_dx, d_dy);
+    }
+    if (!c->factored) return fail(CLRS_ERR_STATE, "clrs_schur_solve called before clrs_schur_factor");
+    if (!d_rhs_y || !d_dy) return fail(CLRS_ERR_INVALID, "rhs_y / dy are required when there are free variables");
+    HIPCHECK(hipSetDevice(c->device));
+    c->bind_rhsx = d_rhs_x; c->bind_rhsy = d_rhs_y; c->bind_dx = d_dx; c->bind_dy = d_dy;
+    if (c->timing) HIPCHECK(hipEventRecord(c->ev[7], c->stream));
+    int rc = run_plan(c, c->p_solve_all);
+    if (rc) return rc;
+    if (c->timing) { HIPCHECK(hipEventRecord(c->ev[8], c->stream)); c->solve_time_pending = true; }
+    return 0;
+}
+
 extern "C" int clrs_schur_solve(clrs_ctx *c, const double *rhs_x, const double *rhs_y, double *dx, double *dy) {
     if (!c || !rhs_x || !dx) return fail(CLRS_ERR_INVALID, "null argument");
     if (!c->factored) return fail(CLRS_ERR_STATE, "clrs_schur_solve called before clrs_schur_factor");
@@ -1267,8 +1342,7 @@ extern "C" int clrs_schur_solve(clrs_ctx *c, const double *rhs_x, const double *
         HIPCHECK(hipMemcpyAsync(c->d_rhsy, rhs_y, sizeof(double) * c->N, hipMemcpyHostToDevice, c->stream));
     }
     int rc;
-    if ((rc = clrs_schur_solve_fwd_dev(c, c->d_rhsx))) return rc;
-    if ((rc = clrs_schur_solve_bwd_dev(c, c->d_rhsy, c->d_dx, c->d_dy))) return rc;
+    if ((rc = clrs_schur_solve_dev(c, c->d_rhsx, c->d_rhsy, c->d_dx, c->d_dy))) return rc;
     HIPCHECK(hipMemcpyAsync(dx, c->d_dx, sizeof(double) * c->xlen, hipMemcpyDeviceToHost, c->stream));
     if (c->N > 0) HIPCHECK(hipMemcpyAsync(dy, c->d_dy, sizeof(double) * c->N, hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(hipStreamSynchronize(c->stream));
@@ -1345,7 +1419,7 @@ extern "C" int clrs_set_stream(clrs_ctx *c, void *stream) {
     if (!c) return fail(CLRS_ERR_INVALID, "null argument");
     HIPCHECK(hipSetDevice(c->device));
     HIPCHECK(hipStreamSynchronize(c->stream));
-    Plan *plans[] = {&c->p_assemble, &c->p_cholS, &c->p_linvB, &c->p_Q, &c->p_cholQ, &c->p_fwd, &c->p_bwd, &c->p_cholX, &c->p_zeroL};
+    Plan *plans[] = {&c->p_assemble, &c->p_cholS, &c->p_linvB, &c->p_Q, &c->p_cholQ, &c->p_fwd, &c->p_bwd, &c->p_cholX, &c->p_zeroL, &c->p_cholQ_slabs, &c->p_solve_all};
     for (Plan *p : plans)
         if (p->graph) { hipGraphExecDestroy(p->graph); p->graph = nullptr; }   // graphs are re-captured on the new stream
     if (c->own_stream) HIPCHECK(hipStreamDestroy(c->stream));

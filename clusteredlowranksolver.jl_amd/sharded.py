@@ -90,6 +90,14 @@ class HipLocal:
     def assemble(self, Xchol, Y):
         self.ctx.assemble_dev(Xchol.data_ptr(), Y.data_ptr())
 
+    def factor_all(self):
+        """Single-rank shortcut: no exchange needed, fewer launches."""
+        self.ctx.factor_dev()
+
+    def solve_all(self, rhs_x, rhs_y, dx, dy):
+        self.ctx.solve_dev(rhs_x.data_ptr(), rhs_y.data_ptr() if rhs_y is not None and rhs_y.numel() else 0,
+                           dx.data_ptr(), dy.data_ptr() if dy is not None and dy.numel() else 0)
+
     def factor_local(self):
         self.ctx.factor_local_dev()
         return self.q
@@ -159,12 +167,18 @@ class ShardedSchur:
     def decompose(self, Xchol, Y):
         """compute_T_decomposition! (src/solver.jl:1229-1287) on this rank's clusters + the one exchange."""
         self.local.assemble(Xchol, Y)
+        if self.world == 1 and hasattr(self.local, "factor_all"):
+            self.local.factor_all()
+            return
         q = self.local.factor_local()
         self._all_reduce(q)                      # Q = sum over ranks of the partial Q
         self.local.factor_finish()
 
     def solve(self, rhs_x, rhs_y, dx, dy):
         """Solve stage of compute_search_direction! (src/solver.jl:1527-1582): rhs_x, dx sharded; rhs_y, dy replicated."""
+        if self.world == 1 and hasattr(self.local, "solve_all"):
+            self.local.solve_all(rhs_x, rhs_y, dx, dy)
+            return
         u = self.local.solve_fwd(rhs_x)
         self._all_reduce(u)                      # u = sum over ranks of LinvB_j^T t_j
         self.local.solve_bwd(rhs_y, dx, dy)

@@ -202,6 +202,13 @@ class SchurContext:
     def assemble_dev(self, d_Xchol: int, d_Y: int):
         _lib.check(self.L.clrs_schur_assemble_dev(self.h, C.c_void_p(d_Xchol), C.c_void_p(d_Y)))
 
+    def factor_dev(self):
+        _lib.check(self.L.clrs_schur_factor_dev(self.h))
+
+    def solve_dev(self, d_rhs_x: int, d_rhs_y: int, d_dx: int, d_dy: int):
+        _lib.check(self.L.clrs_schur_solve_dev(self.h, C.c_void_p(d_rhs_x), C.c_void_p(d_rhs_y) if d_rhs_y else None,
+                                               C.c_void_p(d_dx), C.c_void_p(d_dy) if d_dy else None))
+
     def factor_local_dev(self):
         _lib.check(self.L.clrs_schur_factor_local_dev(self.h))
 

@@ -139,6 +139,8 @@ int clrs_schur_solve(clrs_ctx *ctx, const double *rhs_x, const double *rhs_y, do
 int clrs_cholesky_blocks_dev(clrs_ctx *ctx, const double *d_X, double *d_Xchol);
 int clrs_sync_status_cholesky(clrs_ctx *ctx);   /* blocks; status of the last clrs_cholesky_blocks_dev: 0 or block b+1 */
 int clrs_schur_assemble_dev(clrs_ctx *ctx, const double *d_Xchol, const double *d_Y);
+int clrs_schur_factor_dev(clrs_ctx *ctx);                     /* whole factorisation on one GPU (no exchange, no sync) */
+int clrs_schur_solve_dev(clrs_ctx *ctx, const double *d_rhs_x, const double *d_rhs_y, double *d_dx, double *d_dy);
 int clrs_schur_factor_local_dev(clrs_ctx *ctx);               /* up to the local partial Q */
 double *clrs_q_buffer_dev(clrs_ctx *ctx);                     /* N x N device buffer holding Q (partial, then total) */
 int clrs_schur_factor_finish_dev(clrs_ctx *ctx);              /* Cholesky of the (summed) Q */

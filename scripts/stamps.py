@@ -3,7 +3,7 @@ Build the stamped variant on the CPU box first:  python scripts/stamps.py build 
 import ctypes as C
 import os
 import sys
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import clrs_amd
 from clrs_amd import _lib

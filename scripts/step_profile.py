@@ -1,6 +1,6 @@
 """Per-kernel HIP-event times of one hot-path step (eager), and host-side issue time per step."""
 import sys, time
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import bench
 import clrs_amd
