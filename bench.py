@@ -122,6 +122,7 @@ def main():
                     "(slower for this path: a call is 1-3 kernels and a graph replay costs 10-16 us of host time)")
     ap.add_argument("--roofline-copies", type=int, default=512, help="cluster replication factor of the roofline instance")
     ap.add_argument("--skip-cpu", action="store_true")
+    ap.add_argument("--split", action="store_true", help="with one GPU: still run the split-phase calls and the RCCL all-reduces (1-rank group)")
     args = ap.parse_args()
 
     import torch
@@ -135,8 +136,13 @@ def main():
         raise SystemExit("bench.py needs a GPU (the HIP library is the only compute path)")
     torch.cuda.set_device(local_rank)
     torch.cuda.set_stream(torch.cuda.Stream())      # a real (capturable) stream; the library runs on torch's current stream
-    if world > 1:
+    if world > 1 or args.split:
+        if os.environ.get("NCCL_DEBUG", "VERSION").upper() == "VERSION":
+            os.environ["NCCL_DEBUG"] = "WARN"      # keep RCCL's version banner off stdout: rank 0 prints exactly one JSON line
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
 
     import clrs_amd  # noqa: F401
@@ -149,7 +155,7 @@ def main():
             f"generated in {time.time() - t0:.1f}s")
     parts = [[2 * r, 2 * r + 1] for r in range(world)]          # 2 clusters per GPU (identical weights)
     use_graph = args.graph
-    sh = ShardedSchur(flat, rank, world, lambda s: HipLocal(s, local_rank, graph=use_graph), parts=parts)
+    sh = ShardedSchur(flat, rank, world, lambda s: HipLocal(s, local_rank, graph=use_graph), parts=parts, force_split=args.split)
     f = sh.shard
     ctx = sh.local.ctx
     dev = f"cuda:{local_rank}"
@@ -190,6 +196,33 @@ def main():
     torch.cuda.synchronize()
     parity["factor_status"] = sh.status()      # cond(S) > 1/eps for 2d=30 in fp64: non-zero = the reference's SolverFailure
 
+    # the 2d=30 instance cannot be factored in fp64: check factor + solve through the very same calls
+    # on the 2d=6 instance of the same family, where fp64 carries the condition number
+    if rank == 0:
+        import clrs_amd as _c
+        from clrs_amd.problems import cohnelkies_multi
+        small = _c.flatten(cohnelkies_multi(8, 3, [1.0], orth_free=True))
+        sh2 = ShardedSchur(small, 0, 1, lambda s_: HipLocal(s_, local_rank, graph=False))
+        X2, Y2 = seeded_iterates(small, seed=5)
+        r2 = np.random.default_rng(6)
+        rx2, ry2 = r2.standard_normal(small.x_len), r2.standard_normal(small.n_free)
+        a = [torch.from_numpy(v).to(dev) for v in (X2, Y2, rx2, ry2)]
+        c2, dx2, dy2 = torch.empty_like(a[0]), torch.empty_like(a[2]), torch.empty_like(a[3])
+        sh2.local.cholesky_blocks(a[0], c2)
+        sh2.decompose(c2, a[1])
+        sh2.solve(a[2], a[3], dx2, dy2)
+        torch.cuda.synchronize()
+        assert sh2.status() == 0
+        o2 = Oracle(small, quad=True, use_lo=False)
+        _, L2, _ = o2.cholesky_blocks(X2)
+        o2.schur_assemble(L2, Y2)
+        assert o2.schur_factor() == 0
+        dxr, dyr = o2.schur_solve(rx2, ry2)
+        sc = max(1.0, np.max(np.abs(dxr)), np.max(np.abs(dyr)))
+        parity["solve_rel_err_2d6_vs_f128_oracle"] = float(max(np.max(np.abs(dx2.cpu().numpy() - dxr)), np.max(np.abs(dy2.cpu().numpy() - dyr))) / sc)
+        assert parity["solve_rel_err_2d6_vs_f128_oracle"] < 1e-7, parity
+        sh2.close()
+
     # ---- timed region: W warmup + exactly K steps, barrier + synchronize on both sides ----
     for _ in range(args.warmup):
         step()
@@ -219,7 +252,7 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "SpherePacking cohnelkies(8,15): d=8, 2d=30; 2 clusters/GPU P=32, blocks 16x16 r1 + 1x1 dense, N=31",
                    "clusters": int(flat.n_clusters), "clusters_per_gpu": 2, "n_free": int(flat.n_free),
-                   "launch": "hipGraph" if use_graph else "eager", "collective": "RCCL all-reduce Q(31x31)+2x u(31)" if world > 1 else "none"},
+                   "launch": "hipGraph" if use_graph else "eager", "collective": "RCCL all-reduce Q(31x31)+2x u(31)" if (world > 1 or args.split) else "none"},
         "parity": parity,
     }
 
@@ -271,6 +304,14 @@ def main():
                            "achieved_gflops": bcnt["assemble_flops"] / basm / 1e9,
                            "kernels_us": {k: round(1e6 * v[2], 3) for k, v in bprof.items()}}
         bctx.close()
+        # HBM traffic of that launch from the committed PMC passes (rocprofv3 cannot run inside this process)
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[bdom[0]]
+            if tr["workgroups"] == big.n_clusters:
+                out["roofline"]["traffic"] = tr["traffic_bytes"]
+                out["roofline"]["traffic_source"] = tr["source"]
+        except Exception:
+            pass
 
         # ---- CPU baseline: the fp64 OpenMP oracle on the same step, bounded sample ----
         if not args.skip_cpu and world == 1:
@@ -306,10 +347,16 @@ def main():
             out["cpu_baseline"] = {"value": rate, "unit": "iterations/s", "cores": best[1], "kind": "port",
                                    "sample": f"{n_it} hot-path passes of the same 2-cluster problem in {t_cpu:.1f}s "
                                              f"(oracle/clrs_oracle.c fp64 + OpenMP through ctypes; best of 1/8/{ncpu} threads)"}
-        print(json.dumps(out), flush=True)
-    sh.close()
     if world > 1:
+        dist.barrier()
+    sh.close()
+    if world > 1 or args.split:
         dist.destroy_process_group()
+    if rank == 0:
+        import ctypes
+        sys.stderr.flush()
+        ctypes.CDLL(None).fflush(None)             # anything native code buffered on stdout goes out before the JSON line
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

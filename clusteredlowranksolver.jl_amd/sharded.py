@@ -128,9 +128,10 @@ class ShardedSchur:
     process group (None = default group; with world == 1 no collective is issued)."""
 
     def __init__(self, flat: FlatSDP, rank: int, world: int, local_factory, group=None,
-                 parts: Optional[Sequence[Sequence[int]]] = None):
+                 parts: Optional[Sequence[Sequence[int]]] = None, force_split: bool = False):
         self.full = flat
         self.rank, self.world = rank, world
+        self.force_split = force_split      # exercise the split-phase calls + collectives even with one rank
         self.parts = [list(p) for p in (parts if parts is not None else partition_clusters(flat, world))]
         assert sorted(j for p in self.parts for j in p) == list(range(flat.n_clusters)), "partition must cover every cluster once"
         self.clusters = self.parts[rank]
@@ -160,14 +161,14 @@ class ShardedSchur:
 
     # -- the path --------------------------------------------------------------------------------
     def _all_reduce(self, t):
-        if self.world > 1 and t.numel():
+        if (self.world > 1 or self.force_split) and t.numel():
             import torch.distributed as dist
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
     def decompose(self, Xchol, Y):
         """compute_T_decomposition! (src/solver.jl:1229-1287) on this rank's clusters + the one exchange."""
         self.local.assemble(Xchol, Y)
-        if self.world == 1 and hasattr(self.local, "factor_all"):
+        if self.world == 1 and not self.force_split and hasattr(self.local, "factor_all"):
             self.local.factor_all()
             return
         q = self.local.factor_local()
@@ -176,7 +177,7 @@ class ShardedSchur:
 
     def solve(self, rhs_x, rhs_y, dx, dy):
         """Solve stage of compute_search_direction! (src/solver.jl:1527-1582): rhs_x, dx sharded; rhs_y, dy replicated."""
-        if self.world == 1 and hasattr(self.local, "solve_all"):
+        if self.world == 1 and not self.force_split and hasattr(self.local, "solve_all"):
             self.local.solve_all(rhs_x, rhs_y, dx, dy)
             return
         u = self.local.solve_fwd(rhs_x)

@@ -12,5 +12,6 @@ timeout 600 python bench.py > $OUT/bench_$TAG.json 2> $OUT/bench_$TAG.err; echo 
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -- python3 $R/bench.py --skip-cpu > $OUT/prof_$TAG.json 2> $OUT/prof_$TAG.err; echo "rocprof rc=$?"
 find $OUT/prof_$TAG -name '*kernel_stats*' | head; f=$(find $OUT/prof_$TAG -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && head -20 "$f"
+t=$(find $OUT/prof_$TAG -name '*kernel_trace.csv' | head -1); [ -n "$t" ] && python $R/scripts/trace_by_grid.py "$t" > $OUT/prof_${TAG}_by_grid.csv && head -12 $OUT/prof_${TAG}_by_grid.csv
 # keep only the small summaries (the raw trace can be large)
 find $OUT/prof_$TAG -name '*kernel_trace.csv' -size +8M -delete
