@@ -482,3 +482,290 @@ __global__ __launch_bounds__(256) void k_q_solve(const double *__restrict__ LQ, 
 }
 
 }  // namespace clrs
+
+namespace clrs {
+
+// =====================================================================================================================
+// k_cluster_assemble_w1: Schur assembly with ONE WAVE PER PSD BLOCK (no workgroup barriers inside a block)
+// =====================================================================================================================
+// For the dominant block shape of the named configurations -- n <= 16, rank-1 terms, one term per constraint, left and
+// right vectors identical and all distinct (Delsarte, PolyOpt with 2d <= 30, Cohn-Elkies) -- the pairing matrices never
+// need to exist in memory: with U = number of vectors of the block and pmap[u] the constraint of vector u,
+//
+//     S[pmap[u], pmap[v]] += lam_u lam_v * (Z^T Z)[u,v] * (V^T Y V)[u,v]          Z = L_X^-1 V
+//
+// is a Hadamard product of two MFMA output tiles that live in the same lanes.  A wave stages V (n x U) in LDS, keeps
+// Y and the row of L_X it needs in registers, computes T_Y = Y V, the lower tiles of G_Y = V^T T_Y (registers),
+// Z (DPP forward substitution in place of V), then tile by tile G_X = Z^T Z and the product, which it adds into its
+// own P x P slab in LDS.  The waves of a workgroup take the blocks of one cluster round-robin (dense blocks included);
+// one barrier, then the slabs are summed in a fixed order into S_j (symmetric by construction: only u >= v is
+// computed and mirrored).  Independent waves overlap each other's global-memory latency, so many clusters per launch
+// stream at HBM rate instead of paying every round trip in lock step.
+struct WBlock {
+    int kind;            // 0: simple low-rank block, 1: dense block
+    int n, U;            // side; number of vectors (= terms) / dense: number of matrices
+    int pad;
+    long long xyoff;     // offset of the block in the X/Y layout
+    long long v_off;     // static arena: vectors n x U (ld n) / dense: stack of n x n matrices
+    const int *pmap;     // [U] constraint index of vector u / dense: constraint index of matrix a
+    const double *lam;   // [U] lambda of the term of vector u
+    const int *ay;       // [U] position of the term in the A_Y output
+};
+struct WCluster {
+    double *S;
+    int P, nblk;         // blocks of the cluster: slots 0..nblk-1 of its row of the block table
+    int work_doubles;    // per-wave work area (after the slab)
+    int pad;
+};
+
+__device__ __forceinline__ void wave_sync() {
+    // LDS operations of one wave complete in issue order; this only stops the compiler from moving them across
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int UT>   // U <= 16 * UT
+__global__ __launch_bounds__(512) void k_cluster_assemble_w1(const WCluster *__restrict__ clusters, const WBlock *__restrict__ blocks, const FTables tb,
+                                                             int nwaves, int maxblk) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
+    // The block table has a fixed number of slots per cluster, so the descriptor of this wave's first block is fetched
+    // together with the cluster descriptor (one round trip to memory instead of two before the first data load).
+    const WBlock *myblocks = blocks + (size_t)blockIdx.x * maxblk;
+    WBlock k = myblocks[wave < maxblk ? wave : 0];
+    const WCluster cl = clusters[blockIdx.x];
+    const int P = cl.P, PS = P | 1, PP = P * PS;   // slab leading dimension odd: the mirrored (strided) accesses spread over the banks
+    constexpr int LD = 17;                       // leading dimension of the 16-row LDS buffers (one 2-way bank conflict per operand read)
+    double *slab = lds + (size_t)wave * (PP + cl.work_doubles);
+    double *work = slab + PP;
+    for (int e = lane; e < PP; e += 64) slab[e] = 0.0;
+    CLRS_STAMP(0);
+
+    for (int b = wave; b < cl.nblk; b += nwaves) {
+        wave_sync();
+        if (b != wave) k = myblocks[b];
+        const int sb = 1 + 10 * b;
+        (void)sb;
+        CLRS_STAMP(sb + 0);
+        const int n = k.n;
+        const double *Lg = tb.Xc + k.xyoff, *Yg = tb.Y + k.xyoff;
+        if (k.kind == 0) {
+            const int U = k.U;
+            double *Vs = work, *TYs = work + LD * 16 * UT;
+            const double *Vg = tb.stat + k.v_off;
+            // ---- every global load of the block is issued here, before any use ----
+            // (each element of L, Y, V and of the per-vector tables is fetched by exactly one lane; L and the tables are
+            // redistributed through LDS, which costs LDS latency once instead of 40 more global load instructions per lane)
+            double yop[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int kk = 4 * q + l4;
+                yop[q] = (kk < n && l15 < n) ? Yg[kk + l15 * n] : 0.0;          // MFMA operand Y[k, i]: k = 4q + (lane >> 4), i = lane & 15
+            }
+            double *Lt = TYs;                                                   // 16 x 16 staging of L_X (the T_Y buffer is free until T_Y is formed)
+            double *tl = TYs + LD * 16;                                         // lam[u], then pmap / ay as ints
+            int *tpm = (int *)(tl + 16 * UT), *tay = tpm + 16 * UT;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int col = 4 * q + l4;
+                Lt[l15 + col * LD] = (l15 < n && col < l15) ? Lg[l15 + col * n] : 0.0;            // strictly lower part
+            }
+            const double dg = (l15 < n) ? Lg[l15 * (n + 1)] : 1.0;
+            for (int u = lane; u < 16 * UT; u += 64) {
+                tl[u] = (u < U) ? k.lam[u] : 0.0;
+                tpm[u] = (u < U) ? k.pmap[u] : 0;
+                tay[u] = (u < U) ? k.ay[u] : 0;
+            }
+#pragma unroll
+            for (int c0 = 0; c0 < 16 * UT; c0 += 4) {
+                const int col = c0 + l4;
+                Vs[l15 + col * LD] = (l15 < n && col < U) ? Vg[l15 + col * n] : 0.0;
+            }
+            const double di = (l15 < n) ? 1.0 / dg : 0.0;
+            wave_sync();
+            double Lr[16], lam_r[UT], lam_c[UT * 4];
+            int pm_r[UT], pm_c[UT * 4], ay_r[UT];
+#pragma unroll
+            for (int c = 0; c < 16; c++) Lr[c] = Lt[l15 + c * LD];              // row (lane & 15) of L_X, zero on and above the diagonal
+#pragma unroll
+            for (int t = 0; t < UT; t++) {
+                const int u = t * 16 + l15;                                     // row index of the tiles in tile row t
+                lam_r[t] = tl[u];
+                pm_r[t] = tpm[u];
+                ay_r[t] = tay[u];
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++) {
+                    const int v = t * 16 + l4 + 4 * reg;                        // column index of the tiles in tile column t
+                    lam_c[t * 4 + reg] = tl[v];
+                    pm_c[t * 4 + reg] = tpm[v];
+                }
+            }
+            wave_sync();
+            CLRS_STAMP(sb + 1);
+            // ---- T_Y = Y V ----
+#pragma unroll
+            for (int tj = 0; tj < UT; tj++) {
+                if (tj * 16 < U) {
+                    v4d_f acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int q = 0; q < 4; q++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Vs[(4 * q + l4) + (tj * 16 + l15) * LD], yop[q], acc, 0, 0, 0);
+#pragma unroll
+                    for (int reg = 0; reg < 4; reg++) TYs[l15 + (tj * 16 + l4 + 4 * reg) * LD] = acc[reg];   // T_Y[i, j]
+                }
+            }
+            wave_sync();
+            CLRS_STAMP(sb + 2);
+            // ---- lower tiles of G_Y = V^T T_Y, kept in registers: lane holds G_Y[ti*16 + (lane&15), tj*16 + (lane>>4) + 4 reg] ----
+            v4d_f gy[UT * (UT + 1) / 2];
+#pragma unroll
+            for (int ti = 0; ti < UT; ti++)
+#pragma unroll
+                for (int tj = 0; tj <= ti; tj++) {
+                    v4d_f acc = {0.0, 0.0, 0.0, 0.0};
+                    if (ti * 16 < U) {
+#pragma unroll
+                        for (int q = 0; q < 4; q++)
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(TYs[(4 * q + l4) + (tj * 16 + l15) * LD], Vs[(4 * q + l4) + (ti * 16 + l15) * LD], acc, 0, 0, 0);
+                    }
+                    gy[ti * (ti + 1) / 2 + tj] = acc;
+                }
+            // A_Y[t] = w^T Y v of the term's own vector: the diagonal of G_Y
+#pragma unroll
+            for (int t = 0; t < UT; t++)
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++) {
+                    const int u = t * 16 + l15;
+                    if (l15 == l4 + 4 * reg && u < U) tb.AY[ay_r[t]] = gy[t * (t + 1) / 2 + t][reg];
+                }
+            wave_sync();
+            CLRS_STAMP(sb + 3);
+            // ---- Z = L_X^-1 V in place: 4 columns per 16-lane group pair, two groups interleaved ----
+#pragma unroll
+            for (int c0 = 0; c0 < 16 * UT; c0 += 8) {
+                if (c0 < U) {
+                    double x0 = Vs[l15 + (c0 + l4) * LD], x1 = Vs[l15 + (c0 + 4 + l4) * LD];
+                    Trsm16<0>::run(x0, x1, Lr, di);
+                    Vs[l15 + (c0 + l4) * LD] = x0 * di;
+                    Vs[l15 + (c0 + 4 + l4) * LD] = x1 * di;
+                }
+            }
+            wave_sync();
+            CLRS_STAMP(sb + 4);
+            // ---- G_X = Z^T Z for all lower tiles (independent MFMA chains back to back), Hadamard with G_Y, scale ----
+#pragma unroll
+            for (int ti = 0; ti < UT; ti++)
+#pragma unroll
+                for (int tj = 0; tj <= ti; tj++) {
+                    v4d_f acc = {0.0, 0.0, 0.0, 0.0};
+                    if (ti * 16 < U) {
+#pragma unroll
+                        for (int q = 0; q < 4; q++)
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Vs[(4 * q + l4) + (tj * 16 + l15) * LD], Vs[(4 * q + l4) + (ti * 16 + l15) * LD], acc, 0, 0, 0);
+                    }
+                    v4d_f &g = gy[ti * (ti + 1) / 2 + tj];
+#pragma unroll
+                    for (int reg = 0; reg < 4; reg++) g[reg] = (lam_r[ti] * lam_c[tj * 4 + reg]) * (acc[reg] * g[reg]);
+                }
+            // ---- add into the slab (u >= v only, mirrored).  The (p, q) of one block are all distinct: per tile the 8 slab
+            // entries are read first and written afterwards, so the LDS latency is paid once per tile ----
+#pragma unroll
+            for (int ti = 0; ti < UT; ti++)
+#pragma unroll
+                for (int tj = 0; tj <= ti; tj++) {
+                    if (ti * 16 < U) {
+                        const v4d_f sv = gy[ti * (ti + 1) / 2 + tj];
+                        double o1[4], o2[4];
+                        bool on[4];
+#pragma unroll
+                        for (int reg = 0; reg < 4; reg++) {
+                            const int u = ti * 16 + l15, v = tj * 16 + l4 + 4 * reg;
+                            on[reg] = u < U && v < U && u >= v;
+                            const int p = pm_r[ti], q2 = pm_c[tj * 4 + reg];
+                            o1[reg] = slab[p + q2 * PS];        // always a valid address (p = q2 = 0 for padding lanes): unconditional reads
+                            o2[reg] = slab[q2 + p * PS];
+                        }
+#pragma unroll
+                        for (int reg = 0; reg < 4; reg++) {
+                            const int u = ti * 16 + l15, v = tj * 16 + l4 + 4 * reg;
+                            const int p = pm_r[ti], q2 = pm_c[tj * 4 + reg];
+                            if (on[reg]) {
+                                slab[p + q2 * PS] = o1[reg] + sv[reg];
+                                if (u != v) slab[q2 + p * PS] = o2[reg] + sv[reg];
+                            }
+                        }
+                    }
+                }
+            CLRS_STAMP(sb + 5);
+        } else {
+            // ---- dense block (n <= 16): T_a = X^-1 A_a Y for every matrix, S[p_a, p_b] += <A_b, T_a>, all within the wave ----
+            const int cnt = k.U, nn = n * n;
+            const double *Ag = tb.stat + k.v_off;
+            double *Ls = work, *Ys = Ls + nn, *As = Ys + nn, *Ws = As + cnt * nn, *Tt = Ws + cnt * nn;
+            for (int e = lane; e < nn; e += 64) {
+                const int i = e % n, j = e / n;
+                Ls[e] = (i >= j) ? Lg[e] : 0.0;
+                Ys[e] = Yg[e];
+            }
+            for (int e = lane; e < cnt * nn; e += 64) As[e] = Ag[e];
+            wave_sync();
+            for (int c = lane; c < cnt * n; c += 64) {      // W_a = X^-1 A_a, one column per lane
+                const double *src = As + c * n;
+                double *w = Ws + c * n;
+                for (int i = 0; i < n; i++) {
+                    double s = src[i];
+                    for (int kk = 0; kk < i; kk++) s -= Ls[i + kk * n] * w[kk];
+                    w[i] = s / Ls[i + i * n];
+                }
+                for (int i = n - 1; i >= 0; i--) {
+                    double s = w[i];
+                    for (int kk = i + 1; kk < n; kk++) s -= Ls[kk + i * n] * w[kk];
+                    w[i] = s / Ls[i + i * n];
+                }
+            }
+            wave_sync();
+            for (int e = lane; e < cnt * nn; e += 64) {     // T_a = W_a Y
+                const int a = e / nn, r = e % nn, i = r % n, j = r / n;
+                const double *w = Ws + a * nn;
+                double s = 0.0;
+                for (int kk = 0; kk < n; kk++) s += w[i + kk * n] * Ys[kk + j * n];
+                Tt[e] = s;
+            }
+            wave_sync();
+            for (int e = lane; e < cnt * cnt; e += 64) {
+                const int a = e % cnt, bb = e / cnt;
+                if (a > bb) continue;
+                const double *A2 = As + bb * nn, *T1 = Tt + a * nn;
+                double s = 0.0;
+                for (int kk = 0; kk < nn; kk++) s += A2[kk] * T1[kk];
+                const int p = k.pmap[a], q2 = k.pmap[bb];
+                slab[p + q2 * PS] += s;
+                if (p != q2) slab[q2 + p * PS] += s;
+            }
+        }
+    }
+    __syncthreads();
+    CLRS_STAMP(60);
+    // ---- S_j = sum of the wave slabs, fixed order ----
+    const int stride = PP + cl.work_doubles;
+    const int i16 = threadIdx.x & 15, j16 = threadIdx.x >> 4, jstep = blockDim.x >> 4;
+    for (int j0 = 0; j0 < P; j0 += jstep)
+        for (int i0 = 0; i0 < P; i0 += 64) {                         // 4 independent sums per thread per pass
+            double s[4] = {0.0, 0.0, 0.0, 0.0};
+            const int j = j0 + j16;
+            for (int w = 0; w < nwaves; w++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int i = i0 + 16 * q + i16;
+                    if (i < P && j < P) s[q] += lds[w * stride + i + j * PS];
+                }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int i = i0 + 16 * q + i16;
+                if (i < P && j < P) cl.S[i + (long long)j * P] = s[q];
+            }
+        }
+    CLRS_STAMP(61);
+}
+
+}  // namespace clrs

@@ -45,15 +45,16 @@ static const int INFO_NONE = 0x7f7f7f7f;
 // process-wide knobs read at context creation (clrs_config_set)
 static int g_cfg_fused_assemble = 1;
 static int g_cfg_fused_factor = 1;
+static int g_cfg_wave_assemble = 1;
 static const int LDS_BUDGET_DOUBLES = 20000;   // of the 20480 doubles (160 KiB) a workgroup may claim
 
 // ------------------------------------------------------------------------------------------------
 // launch plan
 // ------------------------------------------------------------------------------------------------
-enum StepKind { STEP_MEMCPY, STEP_GEMM, STEP_TRSM, STEP_POTRF, STEP_GATHER_S, STEP_GATHER_SCALAR, STEP_SUB, STEP_MEMSET_INFO, STEP_ZERO_UPPER, STEP_FUSED_ASSEMBLE, STEP_SMALL_POTRF, STEP_CLUSTER_FACTOR, STEP_GEMV_T, STEP_CSOLVE_FWD, STEP_Q_SOLVE, STEP_CSOLVE_BWD, STEP_SUM_SLABS, STEP_NKINDS };
+enum StepKind { STEP_MEMCPY, STEP_GEMM, STEP_TRSM, STEP_POTRF, STEP_GATHER_S, STEP_GATHER_SCALAR, STEP_SUB, STEP_MEMSET_INFO, STEP_ZERO_UPPER, STEP_FUSED_ASSEMBLE, STEP_SMALL_POTRF, STEP_CLUSTER_FACTOR, STEP_GEMV_T, STEP_CSOLVE_FWD, STEP_Q_SOLVE, STEP_CSOLVE_BWD, STEP_SUM_SLABS, STEP_ASSEMBLE_W1, STEP_NKINDS };
 static const char *const STEP_NAMES[STEP_NKINDS] = {"hipMemcpyAsync(D2D)", "k_gemm_f64", "k_trsm_diag", "k_potrf_diag", "k_schur_gather",
                                                     "k_gather_scalar", "k_sub", "hipMemsetAsync", "k_zero_upper", "k_cluster_assemble", "k_small_potrf", "k_cluster_factor", "k_gemv_t",
-                                                    "k_cluster_solve_fwd", "k_q_solve", "k_cluster_solve_bwd", "k_sum_slabs"};
+                                                    "k_cluster_solve_fwd", "k_q_solve", "k_cluster_solve_bwd", "k_sum_slabs", "k_cluster_assemble_w1"};
 static const int KT_MAX_EVENTS = 8192;   // event pairs kept between two clrs_get_kernel_times calls
 
 struct Step {
@@ -148,7 +149,7 @@ struct clrs_ctx {
     bool times_pending = false, solve_time_pending = false;
     double cnt_bytes = 0, cnt_flops = 0, cnt_factor_flops = 0, cnt_solve_flops = 0;
     std::vector<char> cluster_fused;         // per cluster: assembled by the fused kernel
-    int n_fused_clusters = 0;
+    int n_fused_clusters = 0, n_wave_clusters = 0;
     std::vector<int> host_UR, host_UL;       // flattened per (block, r) for clrs_get_unique_counts
     std::vector<i64> host_U_off;
 };
@@ -365,6 +366,17 @@ static int run_steps(clrs_ctx *c, const Plan &pl) {
                     hipLaunchKernelGGL(k_cluster_assemble<32>, dim3(s.grid), dim3(256), s.bytes, st, (const FCluster *)s.d0, (const FBlock *)s.d1, *tb);
                 else
                     hipLaunchKernelGGL(k_cluster_assemble<64>, dim3(s.grid), dim3(256), s.bytes, st, (const FCluster *)s.d0, (const FBlock *)s.d1, *tb);
+                break;
+            }
+            case STEP_ASSEMBLE_W1: {
+                const FTables *tb = (const FTables *)s.src;
+                const int nw = (int)s.n, mb = (int)(intptr_t)s.dst;
+                if (s.nmax <= 2)
+                    hipLaunchKernelGGL(k_cluster_assemble_w1<2>, dim3(s.grid), dim3(64 * nw), s.bytes, st, (const WCluster *)s.d0, (const WBlock *)s.d1, *tb, nw, mb);
+                else if (s.nmax <= 4)
+                    hipLaunchKernelGGL(k_cluster_assemble_w1<4>, dim3(s.grid), dim3(64 * nw), s.bytes, st, (const WCluster *)s.d0, (const WBlock *)s.d1, *tb, nw, mb);
+                else
+                    hipLaunchKernelGGL(k_cluster_assemble_w1<8>, dim3(s.grid), dim3(64 * nw), s.bytes, st, (const WCluster *)s.d0, (const WBlock *)s.d1, *tb, nw, mb);
                 break;
             }
             case STEP_SMALL_POTRF:
@@ -659,20 +671,109 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
     }
 
     // ---- which clusters does the fused kernel take?  (everything of the cluster must fit in LDS) ----
+    c->cluster_fused.assign(J, 0);
+    // ---- wave-per-block assembly (k_cluster_assemble_w1): clusters made of "simple" rank-1 blocks with n <= 16 and small dense blocks ----
+    std::vector<WCluster> wcl;
+    std::vector<WBlock> wbl;
+    std::vector<int> w_pmap, w_ay;
+    std::vector<double> w_lam;
+    std::vector<size_t> w_ioff;       // per WBlock: offset of its pmap / lam / ay entries in the packed arrays
+    std::vector<size_t> w_cl_first;   // per WCluster: its first WBlock
+    int w_ut = 0, w_nwaves = 8, w_maxblocks = 0;
+    size_t w_cluster_doubles = 0;
+    if (g_cfg_fused_assemble && g_cfg_wave_assemble) {
+        int b = 0;
+        for (int j = 0; j < J; j++) {
+            const int b_first = b;
+            bool ok = true;
+            int work = 0, ut = 1, nblk = 0;
+            std::vector<WBlock> mine;
+            std::vector<size_t> mine_off;
+            const size_t keep_pm = w_pmap.size(), keep_lam = w_lam.size(), keep_ay = w_ay.size();
+            for (; b < NB && c->blk[b].j == j; b++) {
+                BlockInfo &k = c->blk[b];
+                if (!ok) continue;
+                WBlock wb;
+                std::memset(&wb, 0, sizeof(wb));
+                wb.kind = k.kind; wb.n = k.n; wb.xyoff = k.xyoff;
+                if (k.kind == 0) {
+                    const int Tn = (int)(k.t1 - k.t0);
+                    if (Tn == 0) continue;
+                    if (k.m != 1 || k.n > 16 || !k.sym || k.URt != Tn || Tn > 128) { ok = false; continue; }
+                    std::vector<int> pm(Tn, -1), ay(Tn, -1);
+                    std::vector<double> lam(Tn, 0.0);
+                    for (i64 q = k.t0; q < k.t1 && ok; q++) {
+                        const i64 t = perm[q];
+                        const int u = s_tR[q];
+                        if (s_tL[q] != u || u < 0 || u >= Tn || pm[u] >= 0) { ok = false; break; }
+                        pm[u] = d->term_p[t]; lam[u] = d->term_lambda[t]; ay[u] = (int)t;
+                    }
+                    if (ok) {   // one term per constraint
+                        std::vector<int> seen(pm);
+                        std::sort(seen.begin(), seen.end());
+                        for (int i2 = 1; i2 < Tn; i2++) if (seen[i2] == seen[i2 - 1]) ok = false;
+                    }
+                    if (!ok) continue;
+                    wb.U = Tn; wb.v_off = k.zr_off;
+                    mine_off.push_back(w_pmap.size());
+                    w_pmap.insert(w_pmap.end(), pm.begin(), pm.end());
+                    w_ay.insert(w_ay.end(), ay.begin(), ay.end());
+                    w_lam.resize(w_pmap.size(), 0.0);
+                    std::copy(lam.begin(), lam.end(), w_lam.end() - Tn);
+                    ut = std::max(ut, (Tn + 15) / 16);
+                } else {
+                    if (k.cnt == 0) continue;
+                    const int need = 2 * k.n * k.n + 3 * k.cnt * k.n * k.n;
+                    if (k.n > 16 || need > 4096) { ok = false; continue; }
+                    wb.U = k.cnt; wb.v_off = k.w_off;
+                    mine_off.push_back(w_pmap.size());
+                    for (i64 e = k.d0; e < k.d1; e++) { w_pmap.push_back(d->dense_p[e]); w_ay.push_back(0); }
+                    w_lam.resize(w_pmap.size(), 0.0);
+                    work = std::max(work, need);
+                }
+                mine.push_back(wb);
+                nblk++;
+            }
+            const int utr = ut <= 2 ? 2 : ut <= 4 ? 4 : 8;
+            work = std::max(work, 2 * 17 * 16 * utr);
+            const i64 per_wave = (i64)c->P[j] * (c->P[j] | 1) + work;     // slab (odd leading dimension) + work area
+            if (!ok || mine.empty() || per_wave > LDS_BUDGET_DOUBLES) {
+                w_pmap.resize(keep_pm); w_lam.resize(keep_lam); w_ay.resize(keep_ay);
+                continue;
+            }
+            WCluster wc;
+            std::memset(&wc, 0, sizeof(wc));
+            wc.S = c->d_S + c->Soff[j]; wc.P = c->P[j]; wc.nblk = (int)mine.size(); wc.work_doubles = work;
+            w_cl_first.push_back(wbl.size());
+            for (size_t i2 = 0; i2 < mine.size(); i2++) { wbl.push_back(mine[i2]); w_ioff.push_back(mine_off[i2]); }
+            wcl.push_back(wc);
+            c->cluster_fused[j] = 2;
+            for (int bb = b_first; bb < b; bb++) c->blk[bb].fused = true;
+            w_ut = std::max(w_ut, utr);
+            w_nwaves = std::min(w_nwaves, (int)(LDS_BUDGET_DOUBLES / per_wave));
+            w_maxblocks = std::max(w_maxblocks, nblk);
+            w_cluster_doubles = std::max(w_cluster_doubles, (size_t)per_wave);
+        }
+        w_nwaves = std::max(1, std::min(w_nwaves, w_maxblocks));
+        for (WCluster &wc : wcl) wc.work_doubles = (int)(w_cluster_doubles - (size_t)wc.P * (wc.P | 1));   // one slab + work stride for all clusters
+        // a cluster whose own P^2 + work is smaller still gets the common stride; re-check the budget with it
+        if ((i64)w_nwaves * (i64)w_cluster_doubles > LDS_BUDGET_DOUBLES) w_nwaves = std::max(1, (int)(LDS_BUDGET_DOUBLES / (i64)w_cluster_doubles));
+    }
+    c->n_wave_clusters = (int)wcl.size();
     std::vector<FCluster> fcl;
     std::vector<FBlock> fbl;
     int fused_nmax = 0;
     size_t fused_lds = 0;
-    c->cluster_fused.assign(J, 0);
     if (g_cfg_fused_assemble) {
         int b = 0;
         for (int j = 0; j < J; j++) {
             const int b_first = b;
             int szL = 0, szY = 0, szV = 0, szTY = 0, szZL = 0, szG = 0, szTab = 0, nmax = 0;
-            bool ok = true;
+            bool ok = c->cluster_fused[j] == 0;      // not already taken by the wave-per-block kernel
             std::vector<FBlock> mine;
             for (; b < NB && c->blk[b].j == j; b++) {
                 BlockInfo &k = c->blk[b];
+                if (!ok) continue;
                 FBlock fb;
                 std::memset(&fb, 0, sizeof(fb));
                 fb.kind = k.kind; fb.n = k.n; fb.xyoff = k.xyoff;
@@ -725,7 +826,7 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
             fused_lds = std::max(fused_lds, (size_t)o * sizeof(double));
         }
     }
-    c->n_fused_clusters = (int)fcl.size();
+    c->n_fused_clusters = (int)fcl.size() + (int)wcl.size();
     for (int b = 0; b < NB; b++)
         if (c->blk[b].fused && c->blk[b].kind == 0)
             for (i64 t = c->blk[b].t0; t < c->blk[b].t1; t++) h_ayidx[t] = -1;   // written by the fused kernel
@@ -841,13 +942,43 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
             s.dst = c->d_AY; s.src = c->d_G; s.d0 = c->d_ayidx; s.n = T;
             pl.steps.push_back(s);
         }
+        if (!wcl.empty()) {
+            int *dpm, *day; double *dlam;
+            CK(upload(c, w_pmap, &dpm)); CK(upload(c, w_ay, &day)); CK(upload(c, w_lam, &dlam));
+            for (size_t i2 = 0; i2 < wbl.size(); i2++) { wbl[i2].pmap = dpm + w_ioff[i2]; wbl[i2].ay = day + w_ioff[i2]; wbl[i2].lam = dlam + w_ioff[i2]; }
+            // block table with a fixed number of slots per cluster (the kernel fetches slot `wave` without knowing the cluster yet)
+            std::vector<WBlock> table(wcl.size() * (size_t)w_maxblocks);
+            std::memset(table.data(), 0, table.size() * sizeof(WBlock));
+            for (size_t ci = 0; ci < wcl.size(); ci++)
+                for (int sl = 0; sl < w_maxblocks; sl++)
+                    table[ci * w_maxblocks + sl] = wbl[w_cl_first[ci] + (sl < wcl[ci].nblk ? sl : 0)];
+            WCluster *dwc; WBlock *dwb;
+            CK(upload(c, wcl, &dwc)); CK(upload(c, table, &dwb));
+            c->ftables.Xc = c->d_Xc; c->ftables.Y = c->d_Y; c->ftables.stat = c->d_static; c->ftables.AY = c->d_AY;
+            if (!c->ftables.stamps) {
+                std::vector<unsigned long long> z(64, 0ull);
+                unsigned long long *ds;
+                CK(upload(c, z, &ds));
+                c->ftables.stamps = ds;
+            }
+            Step s;
+            s.kind = STEP_ASSEMBLE_W1;
+            s.grid = (int)wcl.size(); s.d0 = dwc; s.d1 = dwb; s.src = &c->ftables; s.n = w_nwaves; s.nmax = w_ut; s.dst = (void *)(intptr_t)w_maxblocks;
+            s.bytes = (size_t)w_nwaves * w_cluster_doubles * sizeof(double);
+            pl.steps.push_back(s);
+            if (s.bytes > 64 * 1024) {
+                if (w_ut <= 2) HIPCK(hipFuncSetAttribute((const void *)k_cluster_assemble_w1<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s.bytes));
+                else if (w_ut <= 4) HIPCK(hipFuncSetAttribute((const void *)k_cluster_assemble_w1<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s.bytes));
+                else HIPCK(hipFuncSetAttribute((const void *)k_cluster_assemble_w1<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s.bytes));
+            }
+        }
         if (!fcl.empty()) {
             FCluster *dfc; FBlock *dfb;
             CK(upload(c, fcl, &dfc)); CK(upload(c, fbl, &dfb));
             c->ftables.Xc = c->d_Xc; c->ftables.Y = c->d_Y; c->ftables.stat = c->d_static;
             c->ftables.tL = d_tL; c->ftables.tR = d_tR; c->ftables.tlam = d_tlam;
             c->ftables.ayL = d_ayL; c->ftables.ayR = d_ayR; c->ftables.AY = c->d_AY;
-            {
+            if (!c->ftables.stamps) {
                 std::vector<unsigned long long> z(64, 0ull);
                 unsigned long long *ds;
                 CK(upload(c, z, &ds));
@@ -1463,6 +1594,7 @@ extern "C" int clrs_config_set(const char *key, int value) {
     if (!key) return fail(CLRS_ERR_INVALID, "null argument");
     if (!std::strcmp(key, "fused_assemble")) { g_cfg_fused_assemble = value; return 0; }
     if (!std::strcmp(key, "fused_factor")) { g_cfg_fused_factor = value; return 0; }
+    if (!std::strcmp(key, "wave_assemble")) { g_cfg_wave_assemble = value; return 0; }
     return fail(CLRS_ERR_INVALID, std::string("unknown configuration key ") + key);
 }
 
@@ -1475,6 +1607,7 @@ extern "C" int clrs_debug_stamps(clrs_ctx *c, uint64_t out[64]) {
 }
 
 extern "C" int clrs_fused_clusters(const clrs_ctx *c) { return c ? c->n_fused_clusters : 0; }
+extern "C" int clrs_wave_clusters(const clrs_ctx *c) { return c ? c->n_wave_clusters : 0; }
 
 extern "C" const char *clrs_kernel_name(int kind) { return (kind >= 0 && kind < STEP_NKINDS) ? STEP_NAMES[kind] : ""; }
 

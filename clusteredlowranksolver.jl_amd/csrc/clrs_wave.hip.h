@@ -65,32 +65,35 @@ __device__ __forceinline__ void lds_gemm_tn(const double *A, int lda, const doub
 // A wave holds 4 right-hand sides x 16 unknowns, one element per lane (row = lane & 15).  Forward (L x = b): step K
 // broadcasts the finished x_K and every lane below eliminates it with one FMA.  Lrow[k] = L[row, k], zero above the
 // diagonal; dinv = 1 / L[row,row] (0 for padding rows).  Two independent right-hand-side sets are interleaved.
+// The lanes carry the UNSCALED partial results y (x = y * dinv): step K broadcasts x_K = y_K * dinv_K and every lane
+// subtracts L[row,K] x_K.  Lrow must be STRICTLY lower (the diagonal entry and everything above it zero), so that the
+// lanes whose unknown is finished are left alone without a compare/select; the caller multiplies by dinv at the end.
 template <int K>
 struct Trsm16 {
-    static __device__ __forceinline__ void run(double &x0, double &x1, const double (&Lrow)[16], double dinv, int row) {
-        const double b0 = bcast16<K>(x0 * dinv), b1 = bcast16<K>(x1 * dinv);
-        x0 = (row == K) ? b0 : __builtin_fma(-Lrow[K], b0, x0);   // Lrow[K] == 0 above the diagonal: finished rows stay
-        x1 = (row == K) ? b1 : __builtin_fma(-Lrow[K], b1, x1);
-        Trsm16<K + 1>::run(x0, x1, Lrow, dinv, row);
+    static __device__ __forceinline__ void run(double &y0, double &y1, const double (&Lrow)[16], double dinv) {
+        const double b0 = bcast16<K>(y0 * dinv), b1 = bcast16<K>(y1 * dinv);
+        y0 = __builtin_fma(-Lrow[K], b0, y0);
+        y1 = __builtin_fma(-Lrow[K], b1, y1);
+        Trsm16<K + 1>::run(y0, y1, Lrow, dinv);
     }
 };
 template <>
-struct Trsm16<16> {
-    static __device__ __forceinline__ void run(double &, double &, const double (&)[16], double, int) {}
+struct Trsm16<15> {     // the last unknown has nothing below it
+    static __device__ __forceinline__ void run(double &, double &, const double (&)[16], double) {}
 };
-// Backward (L^T x = b): Lcol[k] = L[k, row] (zero for k < row), steps K = 15 .. 0.
+// Backward (L^T x = b): Lcol[k] = L[k, row] for k > row (zero otherwise), steps K = 15 .. 1.
 template <int K>
 struct Trsm16T {
-    static __device__ __forceinline__ void run(double &x0, double &x1, const double (&Lcol)[16], double dinv, int row) {
-        const double b0 = bcast16<K>(x0 * dinv), b1 = bcast16<K>(x1 * dinv);
-        x0 = (row == K) ? b0 : __builtin_fma(-Lcol[K], b0, x0);
-        x1 = (row == K) ? b1 : __builtin_fma(-Lcol[K], b1, x1);
-        Trsm16T<K - 1>::run(x0, x1, Lcol, dinv, row);
+    static __device__ __forceinline__ void run(double &y0, double &y1, const double (&Lcol)[16], double dinv) {
+        const double b0 = bcast16<K>(y0 * dinv), b1 = bcast16<K>(y1 * dinv);
+        y0 = __builtin_fma(-Lcol[K], b0, y0);
+        y1 = __builtin_fma(-Lcol[K], b1, y1);
+        Trsm16T<K - 1>::run(y0, y1, Lcol, dinv);
     }
 };
 template <>
-struct Trsm16T<-1> {
-    static __device__ __forceinline__ void run(double &, double &, const double (&)[16], double, int) {}
+struct Trsm16T<0> {
+    static __device__ __forceinline__ void run(double &, double &, const double (&)[16], double) {}
 };
 
 // Z <- L^-1 Z (TRANS = false) or Z <- L^-T Z (TRANS = true), blocked by 16.
@@ -108,16 +111,19 @@ __device__ __forceinline__ void lds_trsm(const double *L, int ldl, const double 
         const int r0 = pb * 16, row = r0 + row16;
         double Lr[16];
 #pragma unroll
-        for (int k = 0; k < 16; k++) Lr[k] = TRANS ? L[(r0 + k) + row * ldl] : L[row + (r0 + k) * ldl];
+        for (int k = 0; k < 16; k++) {
+            const double v = TRANS ? L[(r0 + k) + row * ldl] : L[row + (r0 + k) * ldl];
+            Lr[k] = (k == row16) ? 0.0 : v;      // strictly triangular copy (L is zero on the other side already)
+        }
         const double di = dinv[row];
         for (int g = wave; g < ngroups; g += 2 * nwaves) {   // two column groups per pass: independent chains interleave
             const int c0 = g * 4 + cg4, c1 = (g + nwaves) * 4 + cg4;
             const bool v0 = c0 < ncols, v1 = c1 < ncols;
             double x0 = v0 ? Z[row * rs + c0 * cs] : 0.0, x1 = v1 ? Z[row * rs + c1 * cs] : 0.0;
-            if (TRANS) Trsm16T<15>::run(x0, x1, Lr, di, row16);
-            else Trsm16<0>::run(x0, x1, Lr, di, row16);
-            if (v0) Z[row * rs + c0 * cs] = x0;
-            if (v1) Z[row * rs + c1 * cs] = x1;
+            if (TRANS) Trsm16T<15>::run(x0, x1, Lr, di);
+            else Trsm16<0>::run(x0, x1, Lr, di);
+            if (v0) Z[row * rs + c0 * cs] = x0 * di;
+            if (v1) Z[row * rs + c1 * cs] = x1 * di;
         }
         if (step + 1 < npan) {
             __syncthreads();
@@ -241,7 +247,7 @@ __device__ __forceinline__ bool lds_potrf(double *A, int lda, double *dinv, int 
             const int M = (npan - pb - 1) * 16;
             double Lr[16];
 #pragma unroll
-            for (int k = 0; k < 16; k++) Lr[k] = A[(r0 + row16) + (r0 + k) * lda];
+            for (int k = 0; k < 16; k++) Lr[k] = (k == row16) ? 0.0 : A[(r0 + row16) + (r0 + k) * lda];
             const double di = dinv[r0 + row16];
             const int ngroups = M >> 2;
             for (int g = wave; g < ngroups; g += 2 * nwaves) {
@@ -249,9 +255,9 @@ __device__ __forceinline__ bool lds_potrf(double *A, int lda, double *dinv, int 
                 const bool v1 = c1 < M;
                 double *p0 = A + (r0 + 16 + c0) + (r0 + row16) * lda, *p1 = A + (r0 + 16 + c1) + (r0 + row16) * lda;
                 double x0 = *p0, x1 = v1 ? *p1 : 0.0;
-                Trsm16<0>::run(x0, x1, Lr, di, row16);
-                *p0 = x0;
-                if (v1) *p1 = x1;
+                Trsm16<0>::run(x0, x1, Lr, di);
+                *p0 = x0 * di;
+                if (v1) *p1 = x1 * di;
             }
         }
         __syncthreads();

@@ -46,15 +46,19 @@ class SchurContext:
     left/right vector tables, pointer tables, `high_ranks`) plus every preallocated buffer of
     src/solver.jl:298-317 -- all device resident."""
 
-    def __init__(self, sdp, device: int = 0, graph: bool = False, timing: bool = False, fused: Optional[bool] = None):
+    def __init__(self, sdp, device: int = 0, graph: bool = False, timing: bool = False, fused: Optional[bool] = None,
+                 wave: Optional[bool] = None):
         """`fused=False` forces the staged grouped-GEMM / blocked-BLAS path everywhere (default: clusters that fit in
-        one CU's LDS take the fused per-cluster assembly, factor and solve kernels)."""
+        one CU's LDS take the fused per-cluster assembly, factor and solve kernels).  `wave=False` keeps the
+        fused assembly on the 4-waves-per-block kernel even where the wave-per-block kernel applies."""
         self.flat: FlatSDP = sdp if isinstance(sdp, FlatSDP) else flatten(sdp)
         f = self.flat
         self.L = _lib.load()
         if fused is not None:
             _lib.check(self.L.clrs_config_set(b"fused_assemble", int(bool(fused))))
             _lib.check(self.L.clrs_config_set(b"fused_factor", int(bool(fused))))
+        if wave is not None:
+            _lib.check(self.L.clrs_config_set(b"wave_assemble", int(bool(wave))))
         k = self._keep = {}
 
         def hold(name, arr, dt):
@@ -78,6 +82,8 @@ class SchurContext:
             if fused is not None:
                 self.L.clrs_config_set(b"fused_assemble", 1)
                 self.L.clrs_config_set(b"fused_factor", 1)
+            if wave is not None:
+                self.L.clrs_config_set(b"wave_assemble", 1)
         self.h = h
         self.device = device
         if graph:
@@ -114,6 +120,10 @@ class SchurContext:
     def fused_clusters(self) -> int:
         """Number of clusters assembled by the fused per-cluster kernel."""
         return int(self.L.clrs_fused_clusters(self.h))
+
+    def wave_clusters(self) -> int:
+        """Number of clusters assembled with one wave per PSD block (k_cluster_assemble_w1)."""
+        return int(self.L.clrs_wave_clusters(self.h))
 
     def high_ranks(self) -> List[bool]:
         """`high_ranks[j][l]` flattened over blocks (src/solver.jl:1000)."""

@@ -182,6 +182,9 @@ const char *clrs_kernel_name(int kind);
  * clrs_fused_clusters returns how many clusters of the context the fused kernel takes. */
 int clrs_config_set(const char *key, int value);
 int clrs_fused_clusters(const clrs_ctx *ctx);
+/* "wave_assemble" (default 1): among those, clusters made only of simple rank-1 blocks with n <= 16 and small dense
+ * blocks are assembled with one wave per PSD block (k_cluster_assemble_w1); clrs_wave_clusters counts them. */
+int clrs_wave_clusters(const clrs_ctx *ctx);
 /* Diagnostic builds (-DCLRS_FUSED_STAMPS) only: s_memtime stamps of the phases of workgroup 0 of the fused kernel. */
 int clrs_debug_stamps(clrs_ctx *ctx, uint64_t out[64]);
 

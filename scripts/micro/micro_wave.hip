@@ -38,7 +38,7 @@ __global__ void k_micro(double *A, unsigned long long *out, int reps) {
     double x0 = Zs[row16 + (lane >> 4) * 18], x1 = Zs[row16 + (4 + (lane >> 4)) * 18];
     t0 = __builtin_amdgcn_s_memtime();
     for (int r = 0; r < reps; r++) {
-        Trsm16<0>::run(x0, x1, Lr, di, row16);
+        Trsm16<0>::run(x0, x1, Lr, di);
         x0 += 1.0; x1 += 1.0;
     }
     t1 = __builtin_amdgcn_s_memtime();

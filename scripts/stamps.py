@@ -16,6 +16,9 @@ from clrs_amd.solver import SchurContext
 from tests.util import flat, spd_iterates, chol_blocks_np
 name = sys.argv[1] if len(sys.argv) > 1 else "ce_8_15"
 f = flat(name)
+if len(sys.argv) > 2:
+    import bench
+    f = bench.replicate_clusters(f, int(sys.argv[2]))
 X, Y = spd_iterates(f, seed=1)
 Xc = chol_blocks_np(f, X)
 ctx = SchurContext(f)
@@ -25,8 +28,8 @@ st = (C.c_uint64 * 64)()
 ctx.L.clrs_debug_stamps(ctx.h, st)
 st = np.array(st, dtype=np.float64)
 t0 = st[0]
-names = ["stage", "TY", "GY", "trsm", "GX", "accum", ""]
-print("ticks are s_memtime (100 MHz => 10 ns each)")
+names = ["stage", "TY", "GY", "trsm", "GX", "accum", ""] if not ctx.wave_clusters() else ["loads", "TY", "GY+AY", "trsm", "GX+S", "", ""]
+print("values are shader cycles x10 (s_memtime ticks at the shader clock); wave-per-block kernel:", bool(ctx.wave_clusters()))
 prev = t0
 for b in range(6):
     base = 1 + 10 * b

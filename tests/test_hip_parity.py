@@ -64,16 +64,25 @@ ASSEMBLE_CASES = ["x2p1", "polyopt8", "polyopt40", "delsarte_3_10", "delsarte_8_
                   "sdpa_small", "sdpa_mid", "polyopt_scaled_100"]
 
 
-@pytest.mark.parametrize("fused", [True, False], ids=["fused", "staged"])
+PATHS = {"wave": dict(fused=True, wave=True), "fused": dict(fused=True, wave=False), "staged": dict(fused=False)}
+WAVE_CASES = {"x2p1", "polyopt8", "delsarte_3_10", "delsarte_8_3", "ce_8_15", "ce_8_3", "sdpa_small"}   # every cluster takes k_cluster_assemble_w1
+
+
+@pytest.mark.parametrize("path", list(PATHS))
 @pytest.mark.parametrize("name", ASSEMBLE_CASES)
-def test_schur_assemble_matches_oracle(name, fused, oracle_built):
+def test_schur_assemble_matches_oracle(name, path, oracle_built):
     from clrs_amd.solver import SchurContext
     from oracle.oracle import Oracle
     f = flat(name)
     X, Y = spd_iterates(f, seed=1)
     Xc = chol_blocks_np(f, X)
-    ctx = SchurContext(f, fused=fused)
+    ctx = SchurContext(f, **PATHS[path])
+    fused = path != "staged"
     assert (ctx.fused_clusters() > 0) == (fused and name not in ("sdpa_mid", "polyopt_scaled_100"))
+    if path == "wave" and name in WAVE_CASES:
+        assert ctx.wave_clusters() == f.n_clusters
+    if path != "wave":
+        assert ctx.wave_clusters() == 0
     S, AY = ctx.compute_S_integrated(Xc, Y)
     o = Oracle(f, quad=True, use_lo=False)
     S_ref, AY_ref = o.schur_assemble(Xc, Y)
@@ -225,15 +234,15 @@ def test_solvesdp_matches_oracle_loop(oracle_built):
 GOLDEN_FULL = ["x2p1", "polyopt8", "delsarte_8_3", "ce_8_3", "ns_8_3_2", "sdpa_small", "polyopt40", "delsarte_3_10"]
 
 
-@pytest.mark.parametrize("fused", [True, False], ids=["fused", "staged"])
+@pytest.mark.parametrize("path", list(PATHS))
 @pytest.mark.parametrize("name", GOLDEN_FULL + ["ce_8_15", "ns_8_15_2"])
-def test_schur_assemble_matches_256bit_golden(name, fused):
+def test_schur_assemble_matches_256bit_golden(name, path):
     """HIP assembly against the committed 256-bit vectors (tests/golden/make_golden.py): 1e-12 * max|S|,
     the same bar the fp64 oracle meets (tests/test_oracle_cpu.py)."""
     import os
     from clrs_amd.solver import SchurContext
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
-    ctx = SchurContext(flat(name), fused=fused)
+    ctx = SchurContext(flat(name), **PATHS[path])
     S, _ = ctx.compute_S_integrated(g["Xchol"], g["Y"], want_AY=False)
     assert np.max(np.abs(S - g["S"])) <= 1e-12 * np.max(np.abs(g["S"]))
     ctx.close()
