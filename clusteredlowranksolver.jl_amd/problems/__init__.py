@@ -4,3 +4,4 @@ from .polyopt import polyopt, polyopt_random, polyopt_scaled
 from .delsarte import delsarte
 from .spherepacking import cohnelkies, nsphere_packing, cohnelkies_multi
 from .sdpa import read_sdpa, sdpa_to_sdp, sdpa_scaled, write_sdpa
+from .threepoint import three_point_spherical_codes

@@ -69,6 +69,10 @@ def write_sdpa(path, data: SDPAData) -> None:
 
 def sdpa_to_sdp(data: SDPAData) -> ClusteredLowRankSDP:
     """One cluster, dense blocks, no free variables (reference src/SDPAtoCLRS.jl:51-83)."""
+    # constraints without any matrix are dropped, like the reference does (src/SDPAtoCLRS.jl:66-78)
+    keep = [k for k in range(1, data.m + 1) if any(np.any(M != 0.0) for M in data.F[k])]
+    if len(keep) != data.m:
+        data = SDPAData(len(keep), data.block_sizes, data.c[[k - 1 for k in keep]], [data.F[0]] + [data.F[k] for k in keep])
     blocks: List[Block] = []
     Cs = []
     for blk, s in enumerate(data.block_sizes):

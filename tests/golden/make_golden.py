@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 from tests.util import chol_blocks_np, flat, spd_iterates  # noqa: E402
 
 PREC = 256
-CASES = ["x2p1", "polyopt8", "delsarte_8_3", "ce_8_3", "ns_8_3_2", "sdpa_small", "polyopt40", "delsarte_3_10", "ce_8_15", "ns_8_15_2"]
+CASES = ["x2p1", "polyopt8", "delsarte_8_3", "ce_8_3", "ns_8_3_2", "sdpa_small", "polyopt40", "delsarte_3_10", "threepoint_4", "ce_8_15", "ns_8_15_2"]
 # 2d = 30 sphere packing: S is numerically singular in fp64 (cond > 1/eps), so only the assembly is pinned there
 S_ONLY = {"ce_8_15", "ns_8_15_2"}
 

@@ -61,7 +61,7 @@ def test_potrf_reports_failure():
 
 
 ASSEMBLE_CASES = ["x2p1", "polyopt8", "polyopt40", "delsarte_3_10", "delsarte_8_3", "ce_8_15", "ce_8_3", "ns_8_3_2", "ns_8_15_2",
-                  "sdpa_small", "sdpa_mid", "polyopt_scaled_100"]
+                  "threepoint_4", "sdpa_small", "sdpa_mid", "polyopt_scaled_100"]
 
 
 PATHS = {"wave": dict(fused=True, wave=True), "fused": dict(fused=True, wave=False), "staged": dict(fused=False)}
@@ -114,7 +114,8 @@ def test_dedup_counts_match_oracle(oracle_built):
     ctx.close()
 
 
-FACTOR_CASES = ["x2p1", "polyopt8", "polyopt40", "delsarte_3_10", "delsarte_8_3", "ns_8_3_2", "sdpa_small", "sdpa_mid", "polyopt_scaled_100"]
+FACTOR_CASES = ["x2p1", "polyopt8", "polyopt40", "delsarte_3_10", "delsarte_8_3", "ns_8_3_2", "threepoint_4", "sdpa_small", "sdpa_mid",
+                "polyopt_scaled_100"]
 
 
 @pytest.mark.parametrize("fused", [True, False], ids=["fused", "staged"])
@@ -132,7 +133,8 @@ def test_factor_and_solve_match_oracle(name, fused, oracle_built):
     o.schur_assemble(Xc, Y)
     assert o.schur_factor() == 0
     L_ref, LinvB_ref, LQ_ref = o.get_factor()
-    tol = 1e-9
+    amp = 1e3 if name == "threepoint_4" else 1.0          # cond(S) ~ 1e10 at these iterates for the three-point instance
+    tol = 1e-9 * amp
     assert np.max(np.abs(L - L_ref)) <= tol * np.max(np.abs(L_ref))
     if f.n_free:
         assert np.max(np.abs(LinvB - LinvB_ref)) <= tol * max(1.0, np.max(np.abs(LinvB_ref)))
@@ -141,9 +143,9 @@ def test_factor_and_solve_match_oracle(name, fused, oracle_built):
     rx, ry = rng.standard_normal(f.x_len), rng.standard_normal(f.n_free)
     dx, dy = solve_system(ctx, rx, ry)
     dx_ref, dy_ref = o.schur_solve(rx, ry)
-    assert np.max(np.abs(dx - dx_ref)) <= 1e-8 * max(1.0, np.max(np.abs(dx_ref)))
+    assert np.max(np.abs(dx - dx_ref)) <= 1e-8 * amp * max(1.0, np.max(np.abs(dx_ref)))
     if f.n_free:
-        assert np.max(np.abs(dy - dy_ref)) <= 1e-8 * max(1.0, np.max(np.abs(dy_ref)))
+        assert np.max(np.abs(dy - dy_ref)) <= 1e-8 * amp * max(1.0, np.max(np.abs(dy_ref)))
     # structural identity: S dx - B dy = rhs_x ; B^T dx = rhs_y   (src/solver.jl:1527)
     N = f.n_free
     bty = np.zeros(N)
@@ -156,7 +158,7 @@ def test_factor_and_solve_match_oracle(name, fused, oracle_built):
             Bj = f.B[int(f.cluster_off[j]) * N:int(f.cluster_off[j + 1]) * N].reshape(P, N, order="F")
             r -= Bj @ dy
             bty += Bj.T @ dx[sl]
-        assert np.max(np.abs(r)) <= 1e-8 * max(1.0, np.max(np.abs(Sj)) * np.max(np.abs(dx)))
+        assert np.max(np.abs(r)) <= 1e-8 * amp * max(1.0, np.max(np.abs(Sj)) * np.max(np.abs(dx)))
     if N:
         assert np.max(np.abs(bty - ry)) <= 1e-8 * max(1.0, np.max(np.abs(dx)))
     ctx.close()
@@ -231,7 +233,7 @@ def test_solvesdp_matches_oracle_loop(oracle_built):
     assert np.allclose(r.history[:n, 8:10], o["hist"][:n, 8:10], rtol=1e-3)  # step lengths
 
 
-GOLDEN_FULL = ["x2p1", "polyopt8", "delsarte_8_3", "ce_8_3", "ns_8_3_2", "sdpa_small", "polyopt40", "delsarte_3_10"]
+GOLDEN_FULL = ["x2p1", "polyopt8", "delsarte_8_3", "ce_8_3", "ns_8_3_2", "sdpa_small", "polyopt40", "delsarte_3_10", "threepoint_4"]
 
 
 @pytest.mark.parametrize("path", list(PATHS))
@@ -260,9 +262,10 @@ def test_factor_solve_matches_256bit_golden(name, fused):
     compute_T_decomposition(ctx, g["Xchol"], g["Y"])
     dx, dy = solve_system(ctx, g["rhs_x"], g["rhs_y"])
     scale = max(1.0, np.max(np.abs(g["dx"])), np.max(np.abs(g["dy"])) if f.n_free else 0.0)
-    assert np.max(np.abs(dx - g["dx"])) <= 1e-7 * scale
+    tol = 1e-5 if name == "threepoint_4" else 1e-7       # cond(S) ~ 1e10 at these iterates for the three-point instance
+    assert np.max(np.abs(dx - g["dx"])) <= tol * scale
     if f.n_free:
-        assert np.max(np.abs(dy - g["dy"])) <= 1e-7 * scale
+        assert np.max(np.abs(dy - g["dy"])) <= tol * scale
     ctx.close()
 
 
@@ -327,3 +330,25 @@ def test_cholesky_blocks_device_entry():
     assert ctx.sync_status_cholesky() == 0
     assert np.max(np.abs(tL.cpu().numpy() - chol_blocks_np(f, X))) <= 1e-13 * np.max(np.abs(X))
     ctx.close()
+
+
+def test_solvesdp_three_point_bound_config4():
+    """BASELINE config 4 end to end through the HIP path: three_point_spherical_codes(4, 1//6, -1, 4) = 10 +- 1e-5 with
+    omega = 1e3 as in the reference's test (test/runtests_solver.jl:26-27).  fp64 reaches the value; it may stop on a
+    failed Cholesky once the gap is below ~1e-7 (error_code 1, the reference's behaviour at too low a precision)."""
+    from clrs_amd.solver import solvesdp
+    r = solvesdp(flat("threepoint_4"), omega_p=1e3, omega_d=1e3, maxiterations=200)
+    assert r.error_code in (0, 1), (r.status, r.iterations)
+    assert abs(r.primal_objective - 10.0) <= 1e-5 and abs(r.dual_objective - 10.0) <= 1e-5, (r.primal_objective, r.dual_objective)
+
+
+def test_solvesdp_sdpa_example_config5(oracle_built):
+    """BASELINE config 5, test/example.dat-s: dense-constraint path, no free variables; objective 30 (oracle, unpinned by the reference)."""
+    from clrs_amd.solver import solvesdp
+    from oracle.oracle import Oracle
+    f = flat("sdpa_example")
+    r = solvesdp(f, omega_p=1e2, omega_d=1e2)
+    o = Oracle(f, quad=True).solvesdp(omega_p=1e2, omega_d=1e2, duality_gap_threshold=1e-7, dual_error_threshold=1e-9,
+                                      primal_error_threshold=1e-9)
+    assert r.error_code == 0 and o["error_code"] == 0
+    assert abs(r.primal_objective - o["p_obj"]) <= 1e-5 and abs(r.primal_objective - 30.0) <= 1e-4

@@ -56,6 +56,12 @@ def instance(name):
         return P.sdpa_to_sdp(P.sdpa_scaled(nb=4, bs=8, m=12, seed=5))
     if name == "sdpa_mid":
         return P.sdpa_to_sdp(P.sdpa_scaled(nb=8, bs=32, m=40, seed=6))
+    if name == "sdpa_example":
+        import os
+        return P.sdpa_to_sdp(P.read_sdpa(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "example.dat-s")))
+    if name == "threepoint_4":
+        import mpmath as mp
+        return P.three_point_spherical_codes(4, mp.mpf(1) / 6, -1, 4)
     if name == "polyopt_scaled_100":
         return P.polyopt_scaled(100)
     raise KeyError(name)
