@@ -51,10 +51,10 @@ static const int LDS_BUDGET_DOUBLES = 20000;   // of the 20480 doubles (160 KiB)
 // ------------------------------------------------------------------------------------------------
 // launch plan
 // ------------------------------------------------------------------------------------------------
-enum StepKind { STEP_MEMCPY, STEP_GEMM, STEP_TRSM, STEP_POTRF, STEP_GATHER_S, STEP_GATHER_SCALAR, STEP_SUB, STEP_MEMSET_INFO, STEP_ZERO_UPPER, STEP_FUSED_ASSEMBLE, STEP_SMALL_POTRF, STEP_CLUSTER_FACTOR, STEP_GEMV_T, STEP_CSOLVE_FWD, STEP_Q_SOLVE, STEP_CSOLVE_BWD, STEP_SUM_SLABS, STEP_ASSEMBLE_W1, STEP_NKINDS };
-static const char *const STEP_NAMES[STEP_NKINDS] = {"hipMemcpyAsync(D2D)", "k_gemm_f64", "k_trsm_diag", "k_potrf_diag", "k_schur_gather",
+enum StepKind { STEP_MEMCPY, STEP_GEMM, STEP_TRSM, STEP_POTRF, STEP_GATHER_S, STEP_GATHER_SCALAR, STEP_SUB, STEP_MEMSET_INFO, STEP_ZERO_UPPER, STEP_FUSED_ASSEMBLE, STEP_SMALL_POTRF, STEP_CLUSTER_FACTOR, STEP_GEMV_T, STEP_CSOLVE_FWD, STEP_Q_SOLVE, STEP_CSOLVE_BWD, STEP_SUM_SLABS, STEP_ASSEMBLE_W1, STEP_GRAM_SMALL, STEP_NKINDS };
+static const char *const STEP_NAMES[STEP_NKINDS] = {"hipMemcpyAsync(D2D)", "k_gemm_f64_t", "k_trsm_diag", "k_potrf_diag", "k_schur_gather",
                                                     "k_gather_scalar", "k_sub", "hipMemsetAsync", "k_zero_upper", "k_cluster_assemble", "k_small_potrf", "k_cluster_factor", "k_gemv_t",
-                                                    "k_cluster_solve_fwd", "k_q_solve", "k_cluster_solve_bwd", "k_sum_slabs", "k_cluster_assemble_w1"};
+                                                    "k_cluster_solve_fwd", "k_q_solve", "k_cluster_solve_bwd", "k_sum_slabs", "k_cluster_assemble_w1", "k_gram_small"};
 static const int KT_MAX_EVENTS = 8192;   // event pairs kept between two clrs_get_kernel_times calls
 
 struct Step {
@@ -173,33 +173,39 @@ static int dmalloc(clrs_ctx *c, double **d, i64 n) {
 
 // ---- stage builders -----------------------------------------------------------------------------
 static int add_gemm_stage(clrs_ctx *c, Plan &pl, const std::vector<GemmDesc> &descs) {
-    std::vector<GemmDesc> ds;
-    std::vector<GemmTile> tiles;
-    for (const GemmDesc &d : descs) {
-        if (d.M <= 0 || d.N <= 0) continue;
-        int id = (int)ds.size();
-        ds.push_back(d);
-        int tm = (d.M + GEMM_BM - 1) / GEMM_BM, tn = (d.N + GEMM_BN - 1) / GEMM_BN;
-        int batch = 1;
-        // batch count is encoded by the caller through pad0 (>=1)
-        batch = std::max(1, d.pad0);
-        for (int b = 0; b < batch; b++)
-            for (int j = 0; j < tn; j++)
-                for (int i = 0; i < tm; i++) {
-                    if (d.lower_only && (i + 1) * GEMM_BM <= j * GEMM_BN) continue;
-                    tiles.push_back(GemmTile{id, b, i, j});
-                }
+    // only products large enough to give every CU several 128 x 128 tiles take the large-tile kernel (it runs one workgroup
+    // per CU: 356 registers); everything else the 64 x 64 one, which fills the chip at smaller sizes
+    for (int big = 1; big >= 0; big--) {
+        const int BM = big ? 128 : GEMM_BM, BN = big ? 128 : GEMM_BN;
+        std::vector<GemmDesc> ds;
+        std::vector<GemmTile> tiles;
+        for (const GemmDesc &d : descs) {
+            if (d.M <= 0 || d.N <= 0) continue;
+            const bool is_big = d.M >= 256 && d.N >= 256 && (long long)d.M * d.N >= 128ll * 128 * 1024;
+            if (is_big != (big == 1)) continue;
+            int id = (int)ds.size();
+            ds.push_back(d);
+            int tm = (d.M + BM - 1) / BM, tn = (d.N + BN - 1) / BN;
+            int batch = std::max(1, d.pad0);   // batch count is encoded by the caller through pad0 (>=1)
+            for (int b = 0; b < batch; b++)
+                for (int j = 0; j < tn; j++)
+                    for (int i = 0; i < tm; i++) {
+                        if (d.lower_only && (i + 1) * BM <= j * BN) continue;
+                        tiles.push_back(GemmTile{id, b, i, j});
+                    }
+        }
+        if (tiles.empty()) continue;
+        Step s;
+        s.kind = STEP_GEMM;
+        s.grid = (int)tiles.size();
+        s.nmax = big;
+        GemmDesc *dd; GemmTile *dt;
+        int rc;
+        if ((rc = upload(c, ds, &dd))) return rc;
+        if ((rc = upload(c, tiles, &dt))) return rc;
+        s.d0 = dd; s.d1 = dt;
+        pl.steps.push_back(s);
     }
-    if (tiles.empty()) return 0;
-    Step s;
-    s.kind = STEP_GEMM;
-    s.grid = (int)tiles.size();
-    GemmDesc *dd; GemmTile *dt;
-    int rc;
-    if ((rc = upload(c, ds, &dd))) return rc;
-    if ((rc = upload(c, tiles, &dt))) return rc;
-    s.d0 = dd; s.d1 = dt;
-    pl.steps.push_back(s);
     return 0;
 }
 
@@ -335,10 +341,13 @@ static int run_steps(clrs_ctx *c, const Plan &pl) {
                 HIPCHECK(hipMemcpyAsync(s.dst, s.src, s.bytes, hipMemcpyDeviceToDevice, st));
                 break;
             case STEP_GEMM:
-                hipLaunchKernelGGL(k_gemm_f64, dim3(s.grid), dim3(256), 0, st, (const GemmDesc *)s.d0, (const GemmTile *)s.d1);
+                if (s.nmax)
+                    hipLaunchKernelGGL((k_gemm_f64_t<128, 128>), dim3(s.grid), dim3(256), gemm_lds_bytes(128, 128), st, (const GemmDesc *)s.d0, (const GemmTile *)s.d1);
+                else
+                    hipLaunchKernelGGL((k_gemm_f64_t<64, 64>), dim3(s.grid), dim3(256), gemm_lds_bytes(64, 64), st, (const GemmDesc *)s.d0, (const GemmTile *)s.d1);
                 break;
             case STEP_TRSM:
-                hipLaunchKernelGGL(k_trsm_diag, dim3(s.grid), dim3(64), 0, st, (const TrsmDesc *)s.d0, (const TrsmWork *)s.d1);
+                hipLaunchKernelGGL(k_trsm_diag, dim3(s.grid), dim3(256), 0, st, (const TrsmDesc *)s.d0, (const TrsmWork *)s.d1);
                 break;
             case STEP_POTRF:
                 hipLaunchKernelGGL(k_potrf_diag, dim3(s.grid), dim3(256), 0, st, (const PotrfDesc *)s.d0, (int *)s.dst);
@@ -386,6 +395,9 @@ static int run_steps(clrs_ctx *c, const Plan &pl) {
                     hipLaunchKernelGGL(k_small_potrf, dim3(s.grid), dim3(256), s.bytes, st, (const SmallPotrf *)s.d0, (const double *)c->d_Q, c->d_Q, (int *)s.dst);
                 else   // Q = sum of the per-cluster slabs, factored in the same launch
                     hipLaunchKernelGGL(k_small_potrf, dim3(s.grid), dim3(256), s.bytes, st, (const SmallPotrf *)s.d0, (const double *)c->d_Qslabs, c->d_Q, (int *)s.dst);
+                break;
+            case STEP_GRAM_SMALL:
+                hipLaunchKernelGGL(k_gram_small, dim3(c->N * c->N), dim3(256), 0, st, (const double *)c->d_LB, (int)c->xlen, (int)c->xlen, c->N, c->d_Q);
                 break;
             case STEP_SUM_SLABS:
                 hipLaunchKernelGGL(k_sum_slabs, dim3((unsigned)(((i64)c->N * c->N + 255) / 256)), dim3(256), 0, st, (const double *)c->d_Qslabs, (i64)c->N * c->N, c->J,
@@ -467,6 +479,7 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
 #define CK(x) do { rc = (x); if (rc) { clrs_ctx_destroy(c); return rc; } } while (0)
 #define HIPCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { clrs_ctx_destroy(c); return fail(CLRS_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } } while (0)
     HIPCK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIPCK(hipFuncSetAttribute((const void *)k_gemm_f64_t<128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes(128, 128)));
     for (int i = 0; i < 10; i++) HIPCK(hipEventCreate(&c->ev[i]));
     c->J = d->n_clusters; c->N = d->n_free; c->NB = d->n_blocks;
     if (c->J < 0 || c->N < 0 || c->NB < 0) { clrs_ctx_destroy(c); return fail(CLRS_ERR_INVALID, "negative sizes"); }
@@ -1054,6 +1067,10 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
                 Step s;
                 s.kind = STEP_SUM_SLABS;
                 c->p_Q.steps.push_back(s);
+            } else if (N <= 16 && c->xlen >= 512) {
+                Step s;
+                s.kind = STEP_GRAM_SMALL;   // few free variables, many constraints: one reduction per entry of Q
+                c->p_Q.steps.push_back(s);
             } else {
                 std::vector<GemmDesc> gq;   // Q = LB^T LB  (vcat + matmul, src/solver.jl:1268-1269)
                 gq.push_back(mk_gemm(1, 0, N, N, (int)c->xlen, 1.0, c->d_LB, (int)c->xlen, c->d_LB, (int)c->xlen, 0.0, c->d_Q, N));
@@ -1631,6 +1648,7 @@ static clrs_ctx *mini_ctx(int device) {
     clrs_ctx *c = new clrs_ctx();
     c->device = device;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; }
+    (void)hipFuncSetAttribute((const void *)k_gemm_f64_t<128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes(128, 128));
     std::vector<int> hi(1, INFO_NONE);
     int *di;
     if (upload(c, hi, &di)) { clrs_ctx_destroy(c); return nullptr; }

@@ -5,7 +5,7 @@
 // processes the same step of every PSD block / cluster ("grouped" kernels).
 //
 // Kernel            replaces (reference, src/...)                         bound
-// k_gemm_f64        matmul_threaded! tools.jl:175-266 (all GEMMs)         MFMA fp64
+// k_gemm_f64_t<BM,BN> matmul_threaded! tools.jl:175-266 (all GEMMs)       MFMA fp64
 // k_trsm_diag       Arblib.approx_solve_tril!/triu! solver.jl:1258,1538   latency / LDS
 // k_potrf_diag      approx_cholesky! tools.jl:75-107                      latency / LDS
 // k_schur_gather    S accumulation loops solver.jl:1176-1212 + symmetric! HBM / L2 gather
@@ -13,6 +13,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include "clrs_wave.hip.h"
 
 namespace clrs {
 
@@ -34,64 +36,111 @@ struct GemmDesc {
 };
 struct GemmTile { int desc, batch, tm, tn; };
 
-constexpr int GEMM_BM = 64, GEMM_BN = 64, GEMM_BK = 16, GEMM_LDS = 80;  // 80: conflict-free ds_read_b64 across the 4 k-rows
+constexpr int GEMM_BM = 64, GEMM_BN = 64, GEMM_BK = 16;   // small-tile kernel; the large-tile kernel is 128 x 128 x 16
 
-__global__ __launch_bounds__(256) void k_gemm_f64(const GemmDesc *__restrict__ descs, const GemmTile *__restrict__ tiles) {
+// Workgroup tile BM x BN, 4 waves in a 2 x 2 arrangement, each wave (BM/2) x (BN/2) = (BM/32) x (BN/32) MFMA tiles.
+// LDS rows are padded by 16 doubles: the four k-rows an MFMA operand read touches then fall into different banks.
+// Double buffered: the global loads of step k+1 are issued before the MFMAs of step k and written to the other
+// buffer after them, one barrier per step.  With 128 x 128 tiles a step is 64 MFMAs per wave (4096 cycles of the matrix
+// pipe) against 16 global loads per thread, which hides the load latency even with one workgroup per CU.
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void k_gemm_f64_t(const GemmDesc *__restrict__ descs, const GemmTile *__restrict__ tiles) {
+    constexpr int BK = GEMM_BK, LDA_S = BM + 16, LDB_S = BN + 16, MT = BM / 32, NT = BN / 32, EA = BM * BK / 256, EB = BN * BK / 256;
+    // Two LDS layouts per operand, chosen so that BOTH the staging writes and the MFMA operand reads are conflict free:
+    //   source contiguous along the tile row/column index (ta == 0 / tb == 1):  [k][i], row stride BM + 16
+    //   source contiguous along k               (ta == 1 / tb == 0):            [i][k], row stride BK + 2
+    constexpr int LDT = BK + 2;
+    static_assert(BK * (BM + 16) >= BM * LDT && BK * (BN + 16) >= BN * LDT, "both layouts must fit the same buffer");
     const GemmTile t = tiles[blockIdx.x];
     const GemmDesc d = descs[t.desc];
     const double *__restrict__ A = d.A + (long long)t.batch * d.sA;
     const double *__restrict__ B = d.B + (long long)t.batch * d.sB;
     double *__restrict__ C = d.C + (long long)t.batch * d.sC;
-    const int m0 = t.tm * GEMM_BM, n0 = t.tn * GEMM_BN;
-    __shared__ double As[GEMM_BK][GEMM_LDS];
-    __shared__ double Bs[GEMM_BK][GEMM_LDS];
+    const int m0 = t.tm * BM, n0 = t.tn * BN;
+    extern __shared__ __attribute__((aligned(16))) double gsm[];
+    double *As = gsm, *Bs = gsm + 2 * BK * LDA_S;             // As[buf][k][i], Bs[buf][k][j]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int wm = (wave & 1) * 32, wn = (wave >> 1) * 32;
+    const int wm = (wave & 1) * (BM / 2), wn = (wave >> 1) * (BN / 2);
     const int l15 = lane & 15, l4 = lane >> 4;
-    v4d acc[2][2];
+    v4d acc[MT][NT];
 #pragma unroll
-    for (int a = 0; a < 2; a++)
+    for (int a = 0; a < MT; a++)
 #pragma unroll
-        for (int b = 0; b < 2; b++) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
-
-    for (int k0 = 0; k0 < d.K; k0 += GEMM_BK) {
-        // stage op(A)[m0.., k0..] -> As[k][i] and op(B)[k0.., n0..] -> Bs[k][j]; 4 elements per thread each,
-        // consecutive lanes walk the contiguous dimension of the source.
+        for (int b = 0; b < NT; b++) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+    double ra[EA], rb[EB];
+    // staging map: consecutive lanes walk the contiguous dimension of the source
+    auto fetch = [&](int k0) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
+        for (int q = 0; q < EA; q++) {
             const int e = tid + 256 * q;
             int i, k;
-            if (d.ta == 0) { i = e & 63; k = e >> 6; } else { k = e & 15; i = e >> 4; }
+            if (d.ta == 0) { i = e % BM; k = e / BM; } else { k = e % BK; i = e / BK; }
             const int gi = m0 + i, gk = k0 + k;
-            double v = 0.0;
-            if (gi < d.M && gk < d.K) v = d.ta == 0 ? A[gi + (long long)gk * d.lda] : A[gk + (long long)gi * d.lda];
-            As[k][i] = v;
-            int j, kb;
-            if (d.tb == 0) { kb = e & 15; j = e >> 4; } else { j = e & 63; kb = e >> 6; }
-            const int gj = n0 + j, gkb = k0 + kb;
-            double w = 0.0;
-            if (gj < d.N && gkb < d.K) w = d.tb == 0 ? B[gkb + (long long)gj * d.ldb] : B[gj + (long long)gkb * d.ldb];
-            Bs[kb][j] = w;
+            ra[q] = (gi < d.M && gk < d.K) ? (d.ta == 0 ? A[gi + (long long)gk * d.lda] : A[gk + (long long)gi * d.lda]) : 0.0;
         }
-        __syncthreads();
 #pragma unroll
-        for (int kk = 0; kk < GEMM_BK; kk += 4) {
+        for (int q = 0; q < EB; q++) {
+            const int e = tid + 256 * q;
+            int j, k;
+            if (d.tb == 0) { k = e % BK; j = e / BK; } else { j = e % BN; k = e / BN; }
+            const int gj = n0 + j, gk = k0 + k;
+            rb[q] = (gj < d.N && gk < d.K) ? (d.tb == 0 ? B[gk + (long long)gj * d.ldb] : B[gj + (long long)gk * d.ldb]) : 0.0;
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < EA; q++) {
+            const int e = tid + 256 * q;
+            int i, k;
+            if (d.ta == 0) { i = e % BM; k = e / BM; } else { k = e % BK; i = e / BK; }
+            As[buf * BK * LDA_S + (d.ta == 0 ? k * LDA_S + i : i * LDT + k)] = ra[q];
+        }
+#pragma unroll
+        for (int q = 0; q < EB; q++) {
+            const int e = tid + 256 * q;
+            int j, k;
+            if (d.tb == 0) { k = e % BK; j = e / BK; } else { j = e % BN; k = e / BN; }
+            Bs[buf * BK * LDB_S + (d.tb == 0 ? j * LDT + k : k * LDB_S + j)] = rb[q];
+        }
+    };
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < d.K; k0 += BK) {
+        const bool more = k0 + BK < d.K;
+        if (more) fetch(k0 + BK);
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 4) {
             // The MFMA computes D[r][c] = sum_k Aop[r][k] Bop[k][c] with c on lane&15.  We feed Aop = op(B)^T and
             // Bop = op(A)^T so that c runs along the rows i of C (contiguous in memory) -> coalesced C stores.
-            const double a0 = As[kk + l4][wm + l15], a1 = As[kk + l4][wm + 16 + l15];
-            const double b0 = Bs[kk + l4][wn + l15], b1 = Bs[kk + l4][wn + 16 + l15];
-            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a0, acc[0][0], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a1, acc[1][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a0, acc[0][1], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a1, acc[1][1], 0, 0, 0);
+            double av[MT], bv[NT];
+#pragma unroll
+            for (int a = 0; a < MT; a++) {
+                const int i = wm + a * 16 + l15, k = kk + l4;
+                av[a] = As[buf * BK * LDA_S + (d.ta == 0 ? k * LDA_S + i : i * LDT + k)];
+            }
+#pragma unroll
+            for (int b = 0; b < NT; b++) {
+                const int j = wn + b * 16 + l15, k = kk + l4;
+                bv[b] = Bs[buf * BK * LDB_S + (d.tb == 0 ? j * LDT + k : k * LDB_S + j)];
+            }
+#pragma unroll
+            for (int a = 0; a < MT; a++)
+#pragma unroll
+                for (int b = 0; b < NT; b++) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[b], av[a], acc[a][b], 0, 0, 0);
         }
-        __syncthreads();
+        if (more) {
+            stash(buf ^ 1);       // the other buffer was last read before the previous barrier
+            __syncthreads();
+            buf ^= 1;
+        }
     }
     // D layout of v_mfma_f64_16x16x4_f64: c = lane & 15, r = (lane >> 4) + 4 * reg.  Here r indexes j, c indexes i.
 #pragma unroll
-    for (int mi = 0; mi < 2; mi++)
+    for (int mi = 0; mi < MT; mi++)
 #pragma unroll
-        for (int ni = 0; ni < 2; ni++)
+        for (int ni = 0; ni < NT; ni++)
 #pragma unroll
             for (int reg = 0; reg < 4; reg++) {
                 const int gi = m0 + wm + mi * 16 + l15;
@@ -103,6 +152,7 @@ __global__ __launch_bounds__(256) void k_gemm_f64(const GemmDesc *__restrict__ d
                 }
             }
 }
+constexpr size_t gemm_lds_bytes(int BM, int BN) { return (size_t)2 * GEMM_BK * ((BM + 16) + (BN + 16)) * sizeof(double); }
 
 // ------------------------------------------------------------------------------------------------
 // triangular solve with a diagonal block (n <= 64): one thread per right-hand-side vector.
@@ -119,44 +169,52 @@ struct TrsmDesc {
 struct TrsmWork { int desc, chunk; };
 constexpr int TRSM_NB = 64;
 
-__global__ __launch_bounds__(64) void k_trsm_diag(const TrsmDesc *__restrict__ descs, const TrsmWork *__restrict__ work) {
+__global__ __launch_bounds__(256) void k_trsm_diag(const TrsmDesc *__restrict__ descs, const TrsmWork *__restrict__ work) {
+    // One workgroup per (problem, chunk of 64 right-hand sides): L and the chunk live in LDS, the substitution itself is
+    // the wave-level DPP / MFMA routine of clrs_wave.hip.h (16-row panels, 4 right-hand sides per 16-lane group).
     const TrsmWork w = work[blockIdx.x];
     const TrsmDesc d = descs[w.desc];
-    __shared__ double Ls[TRSM_NB][TRSM_NB + 1];
-    __shared__ double xs[TRSM_NB][TRSM_NB];   // xs[i][v]
-    const int tid = threadIdx.x, n = d.n;
+    constexpr int LDL = TRSM_NB + 2;
+    __shared__ double Ls[LDL * TRSM_NB];
+    __shared__ double xs[LDL * 64];       // xs[i + v * LDL]
+    __shared__ double dinv[TRSM_NB];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = d.n, n16 = (n + 15) & ~15;
     const int v0 = w.chunk * 64;
     const int nv = min(64, d.nvec - v0);
-    for (int e = tid; e < n * n; e += 64) {
-        const int i = e % n, k = e / n;
-        Ls[i][k] = (k <= i) ? d.L[i + (long long)k * d.ldl] : 0.0;
-    }
-    if (d.es == 1) {
-        for (int e = tid; e < n * nv; e += 64) { const int i = e % n, v = e / n; xs[i][v] = d.B[(long long)(v0 + v) * d.vs + i]; }
-    } else {
-        for (int e = tid; e < n * nv; e += 64) { const int v = e % nv, i = e / nv; xs[i][v] = d.B[(long long)(v0 + v) * d.vs + (long long)i * d.es]; }
-    }
-    __syncthreads();
-    if (tid < nv) {
-        if (d.trans == 0) {
-            for (int i = 0; i < n; i++) {
-                double s = xs[i][tid];
-                for (int k = 0; k < i; k++) s -= Ls[i][k] * xs[k][tid];
-                xs[i][tid] = s / Ls[i][i];
+    const int i16 = tid & 15, j16 = tid >> 4;
+    for (int j0 = 0; j0 < n16; j0 += 16)
+        for (int i0 = 0; i0 < n16; i0 += 16) {
+            const int i = i0 + i16, j = j0 + j16;
+            Ls[i + j * LDL] = (i < n && j < n && i >= j) ? d.L[i + (long long)j * d.ldl] : 0.0;
+        }
+    if (tid < n16) dinv[tid] = (tid < n) ? 1.0 / d.L[tid + (long long)tid * d.ldl] : 0.0;
+    if (d.es == 1) {     // vectors are columns: consecutive threads walk down a column
+        for (int j0 = 0; j0 < nv; j0 += 16)
+            for (int i0 = 0; i0 < n16; i0 += 16) {
+                const int i = i0 + i16, v = j0 + j16;
+                if (v < nv) xs[i + v * LDL] = (i < n) ? d.B[(long long)(v0 + v) * d.vs + i] : 0.0;
             }
-        } else {
-            for (int i = n - 1; i >= 0; i--) {
-                double s = xs[i][tid];
-                for (int k = i + 1; k < n; k++) s -= Ls[k][i] * xs[k][tid];
-                xs[i][tid] = s / Ls[i][i];
-            }
+    } else {             // vectors are rows (vs == 1): consecutive threads walk along the vectors
+        for (int i0 = 0; i0 < n16; i0 += 4) {
+            const int v = tid & 63, i = i0 + (tid >> 6);
+            if (v < nv) xs[i + v * LDL] = (i < n) ? d.B[(long long)(v0 + v) * d.vs + (long long)i * d.es] : 0.0;
         }
     }
     __syncthreads();
+    if (d.trans == 0) lds_trsm<false>(Ls, LDL, dinv, xs, 1, LDL, n, nv, wave, 4, lane);
+    else lds_trsm<true>(Ls, LDL, dinv, xs, 1, LDL, n, nv, wave, 4, lane);
+    __syncthreads();
     if (d.es == 1) {
-        for (int e = tid; e < n * nv; e += 64) { const int i = e % n, v = e / n; d.B[(long long)(v0 + v) * d.vs + i] = xs[i][v]; }
+        for (int j0 = 0; j0 < nv; j0 += 16)
+            for (int i0 = 0; i0 < n; i0 += 16) {
+                const int i = i0 + i16, v = j0 + j16;
+                if (i < n && v < nv) d.B[(long long)(v0 + v) * d.vs + i] = xs[i + v * LDL];
+            }
     } else {
-        for (int e = tid; e < n * nv; e += 64) { const int v = e % nv, i = e / nv; d.B[(long long)(v0 + v) * d.vs + (long long)i * d.es] = xs[i][v]; }
+        for (int i0 = 0; i0 < n; i0 += 4) {
+            const int v = tid & 63, i = i0 + (tid >> 6);
+            if (i < n && v < nv) d.B[(long long)(v0 + v) * d.vs + (long long)i * d.es] = xs[i + v * LDL];
+        }
     }
 }
 
@@ -172,36 +230,25 @@ constexpr int POTRF_NB = 64;
 
 __global__ __launch_bounds__(256) void k_potrf_diag(const PotrfDesc *__restrict__ descs, int *__restrict__ info) {
     const PotrfDesc d = descs[blockIdx.x];
-    __shared__ double As[POTRF_NB][POTRF_NB + 1];
-    __shared__ int failed;
-    const int tid = threadIdx.x, n = d.n;
-    if (tid == 0) failed = 0;
-    for (int e = tid; e < n * n; e += 256) {
-        const int i = e % n, j = e / n;
-        if (i >= j) As[i][j] = d.A[i + (long long)j * d.lda];
-    }
+    constexpr int LDA = POTRF_NB + 2;
+    __shared__ double As[LDA * POTRF_NB];
+    __shared__ double dinv[POTRF_NB];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = d.n, n16 = (n + 15) & ~15;
+    const int i16 = tid & 15, j16 = tid >> 4;
+    for (int j0 = 0; j0 < n16; j0 += 16)
+        for (int i0 = 0; i0 < n16; i0 += 16) {
+            const int i = i0 + i16, j = j0 + j16;
+            As[i + j * LDA] = (i < n && j < n) ? ((i >= j) ? d.A[i + (long long)j * d.lda] : 0.0) : ((i == j) ? 1.0 : 0.0);
+        }
     __syncthreads();
-    for (int k = 0; k < n; k++) {
-        if (tid == 0) {
-            const double dk = As[k][k];
-            if (!(dk > 0.0)) failed = 1;
-            As[k][k] = sqrt(dk);
+    const bool bad = lds_potrf(As, LDA, dinv, n, wave, 4, lane);
+    if (bad && lane == 0) atomicMin(info, d.code);
+    __syncthreads();
+    for (int j0 = 0; j0 < n; j0 += 16)
+        for (int i0 = 0; i0 < n; i0 += 16) {
+            const int i = i0 + i16, j = j0 + j16;
+            if (i < n && j < n && i >= j) d.A[i + (long long)j * d.lda] = As[i + j * LDA];
         }
-        __syncthreads();
-        if (tid > k && tid < n) As[tid][k] /= As[k][k];
-        __syncthreads();
-        const int m = n - k - 1;
-        for (int e = tid; e < m * m; e += 256) {
-            const int i = k + 1 + e % m, j = k + 1 + e / m;
-            if (i >= j) As[i][j] -= As[i][k] * As[j][k];
-        }
-        __syncthreads();
-    }
-    if (tid == 0 && failed) atomicMin(info, d.code);
-    for (int e = tid; e < n * n; e += 256) {
-        const int i = e % n, j = e / n;
-        if (i >= j) d.A[i + (long long)j * d.lda] = As[i][j];
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -250,6 +297,26 @@ __global__ __launch_bounds__(256) void k_schur_gather(const SClusterDesc *__rest
     }
     c.S[p + (long long)q * c.P] = acc;
     c.S[q + (long long)p * c.P] = acc;
+}
+
+// Q[k,l] = sum_i LB[i,k] LB[i,l] for a handful of free variables (N <= 16) and many rows: one workgroup per entry,
+// fixed-shape tree reduction (deterministic).  Replaces a 1-tile GEMM whose K loop would run serially in one workgroup.
+__global__ __launch_bounds__(256) void k_gram_small(const double *__restrict__ LB, int ld, int rows, int N, double *__restrict__ Q) {
+    const int k = blockIdx.x % N, l = blockIdx.x / N;
+    if (k < l) return;                                   // lower triangle, mirrored below
+    const double *a = LB + (long long)k * ld, *b = LB + (long long)l * ld;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < rows; i += 256) s += a[i] * b[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    __shared__ double part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double v = (part[0] + part[1]) + (part[2] + part[3]);
+        Q[k + (long long)l * N] = v;
+        Q[l + (long long)k * N] = v;
+    }
 }
 
 // out[i] = src[idx[i]]

@@ -23,7 +23,8 @@ def _dp(a):
 
 
 @pytest.mark.parametrize("ta,tb", [(0, 0), (1, 0), (0, 1), (1, 1)])
-@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (16, 16, 4), (64, 64, 16), (37, 53, 29), (130, 70, 100), (3, 200, 65)])
+@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (16, 16, 4), (64, 64, 16), (37, 53, 29), (130, 70, 100), (3, 200, 65),
+                                   (256, 256, 16), (300, 260, 70), (513, 257, 33)])     # the last three take the 128 x 128 tile kernel
 def test_gemm_kernel(ta, tb, M, N, K):
     rng = np.random.default_rng(M * 1000 + N * 10 + K)
     A = rng.standard_normal((K, M) if ta else (M, K))
