@@ -36,6 +36,27 @@ class Dims(C.Structure):
                 ("n_free", C.c_int32), ("n_clusters", C.c_int32), ("n_blocks", C.c_int32), ("reserved", C.c_int32)]
 
 
+class IpmData(C.Structure):
+    """struct clrs_ipm_data"""
+    _fields_ = [("C", p_d), ("c", p_d), ("b", p_d), ("maximize", C.c_int32), ("reserved", C.c_int32), ("constant", C.c_double)]
+
+
+class IpmParams(C.Structure):
+    """struct clrs_ipm_params"""
+    _fields_ = [("beta_infeasible", C.c_double), ("beta_feasible", C.c_double), ("gamma", C.c_double),
+                ("dual_error_threshold", C.c_double), ("primal_error_threshold", C.c_double), ("max_complementary_gap", C.c_double),
+                ("step_length_threshold", C.c_double), ("safe_step", C.c_int32), ("reserved", C.c_int32)]
+
+
+class IpmRecord(C.Structure):
+    """struct clrs_ipm_record"""
+    _fields_ = [("iter", C.c_int32), ("pd_feas", C.c_int32), ("error_code", C.c_int32), ("factor_status", C.c_int32),
+                ("cholesky_status", C.c_int32), ("reserved", C.c_int32),
+                ("mu", C.c_double), ("d_obj", C.c_double), ("p_obj", C.c_double), ("gap", C.c_double), ("dual_error", C.c_double),
+                ("primal_error", C.c_double), ("alpha_d", C.c_double), ("alpha_p", C.c_double), ("beta_c", C.c_double),
+                ("max_P", C.c_double), ("max_p", C.c_double), ("max_d", C.c_double)]
+
+
 class ClrsError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"clrs error {code}: {msg}")
@@ -72,6 +93,11 @@ SYMBOLS = {
     "clrs_get_timings": (C.c_int, [C.c_void_p, p_d]),
     "clrs_get_counters": (C.c_int, [C.c_void_p, p_d, p_d, p_d, p_d]),
     "clrs_set_graph_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "clrs_ipm_create": (C.c_int, [C.c_void_p, C.POINTER(IpmData)]),
+    "clrs_ipm_set_params": (C.c_int, [C.c_void_p, C.POINTER(IpmParams)]),
+    "clrs_ipm_init": (C.c_int, [C.c_void_p, C.c_double, C.c_double]),
+    "clrs_ipm_iterate": (C.c_int, [C.c_void_p, C.POINTER(IpmRecord)]),
+    "clrs_ipm_get": (C.c_int, [C.c_void_p, p_d, p_d, p_d, p_d]),
     "clrs_config_set": (C.c_int, [C.c_char_p, C.c_int]),
     "clrs_fused_clusters": (C.c_int, [C.c_void_p]),
     "clrs_wave_clusters": (C.c_int, [C.c_void_p]),
@@ -103,7 +129,8 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str =
             raise RuntimeError("hipcc failed:\n" + r.stderr[-4000:])
         return out
     src = [os.path.join(CSRC, f) for f in ("clrs_hip.hip", "clrs_kernels.hip.h")] + \
-          [os.path.join(CSRC, "clrs_fused.hip.h"), os.path.join(CSRC, "clrs_wave.hip.h"), os.path.join(_HERE, "..", "include", "clrs_hip.h")]
+          [os.path.join(CSRC, "clrs_fused.hip.h"), os.path.join(CSRC, "clrs_wave.hip.h"), os.path.join(CSRC, "clrs_ipm.hip.h"),
+           os.path.join(CSRC, "clrs_ipm_host.inc"), os.path.join(_HERE, "..", "include", "clrs_hip.h")]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in src):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -24,6 +24,7 @@
 #include "../../include/clrs_hip.h"
 #include "clrs_kernels.hip.h"
 #include "clrs_fused.hip.h"
+#include "clrs_ipm.hip.h"
 
 using namespace clrs;
 typedef long long i64;
@@ -105,8 +106,14 @@ struct BlockInfo {
     bool fused = false;      // handled by k_cluster_assemble
 };
 
+struct IpmState;
+
 struct clrs_ctx {
     int device = 0;
+    IpmState *ipm = nullptr;                           // device-resident interior-point iteration (clrs_ipm_*), created on demand
+    std::vector<int> h_term_p, h_dense_p;              // host copies of the description arrays the IPM tables are built from
+    std::vector<double> h_term_lambda;
+    int *d_ayL = nullptr, *d_ayR = nullptr;            // per original term: left / right expanded vector index of its pairing
     hipStream_t stream = nullptr;
     bool own_stream = true;
     // per-kernel HIP-event timing (clrs_set_kernel_timing): -2 off, -1 every step kind, k >= 0 only kind k
@@ -855,6 +862,9 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
     }
     int *d_ayL, *d_ayR;
     CK(upload(c, h_ayL, &d_ayL)); CK(upload(c, h_ayR, &d_ayR));
+    c->d_ayL = d_ayL; c->d_ayR = d_ayR;
+    c->h_term_p.assign(d->term_p, d->term_p + T); c->h_term_lambda.assign(d->term_lambda, d->term_lambda + T);
+    c->h_dense_p.assign(d->dense_p, d->dense_p + c->D);
 
     // =============================================================================================
     // plan: assemble
@@ -1241,8 +1251,11 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
 #undef HIPCK
 }
 
+static void ipm_free(clrs_ctx *c);
+
 extern "C" void clrs_ctx_destroy(clrs_ctx *c) {
     if (!c) return;
+    ipm_free(c);
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     Plan *plans[] = {&c->p_assemble, &c->p_cholS, &c->p_linvB, &c->p_Q, &c->p_cholQ, &c->p_fwd, &c->p_bwd, &c->p_cholX, &c->p_zeroL, &c->p_cholQ_slabs, &c->p_solve_all};
@@ -1640,6 +1653,8 @@ extern "C" const char *clrs_strerror(int code) {
 }
 extern "C" const char *clrs_last_error(void) { return g_last_error.c_str(); }
 extern "C" const char *clrs_version(void) { return "clrs-hip 0.1.0 (gfx950)"; }
+
+#include "clrs_ipm_host.inc"
 
 // ------------------------------------------------------------------------------------------------
 // test hooks

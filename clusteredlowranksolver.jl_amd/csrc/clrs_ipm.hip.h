@@ -1,0 +1,640 @@
+// clrs_ipm.hip.h -- the interior-point iteration AROUND the hot path, device resident (gfx950).
+//
+// once Schur assembly / factor / solve run on the GPU, the per-block cubic work of the
+// iteration (residual R, the matrices Z and dY of the search direction, the step length) and the constraint-wise
+// traces <A_*, .> / weighted sums sum_i a_i A_i dominate and force the iterates through PCIe every iteration.  These
+// kernels keep x, y, X, Y and every intermediate in HBM; the host only sequences launches and reads one small record per
+// iteration.  One workgroup per PSD block, the block LDS resident (n <= 48 here; larger blocks keep the host loop).
+//
+//   k_ipm_pre        X Y product, tr(XY), chol(X)                 src/solver.jl:369, 961-970, 388-399
+//   k_ipm_weighted   sum_i a_i A_i (+ base) per block, max |P|     compute_weighted_A! :1410-1470, :882-893
+//   k_ipm_dense_dot  <A_e, M> for the dense constraint matrices    trace_A :1290-1366
+//   k_ipm_csum       per-constraint sums of the per-term traces    trace_A :1368-1407, residual d :863-879, rhs_x :1518-1523
+//   k_ipm_p          p = +-b - B^T x                               :899-916
+//   k_ipm_Z          Z = sym(X^-1 (P Y - R)), w^T Z v per term     compute_search_direction! :1501-1514
+//   k_ipm_dXdY       dX = P + sum dx_i A_i, dY = sym(X^-1 (R - dX Y))   :1585-1613
+//   k_ipm_step       min eig of L^-1 dM L^-T per block (Householder tridiagonalisation + Sturm multisection)  :1620-1693
+//   k_ipm_update     x, X += alpha_d (dx, dX); y, Y += alpha_p (dy, dY); objective dots   :485-495, 793-804
+//   k_ipm_scalars    the scalar control flow of the loop (mu, beta, step lengths, errors)  :369-374, 429-447, 470-483
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "clrs_wave.hip.h"
+
+namespace clrs {
+
+struct IBlock {
+    int n, kind;          // side; 0 low rank, 1 dense
+    int URt, ULt;         // expanded right / left unique vectors
+    int T, cnt;           // terms (low rank) / matrices (dense)
+    int xoff;             // offset of the block's cluster in the x layout
+    int pad;
+    long long xyoff;      // offset in the X/Y layout
+    long long vr_off, wl_off;   // static arena: V (n x URt), W (n x ULt), ld n (equal when the tables coincide)
+    long long t0;         // first term of the block (original term order)
+    long long a_off;      // dense: offset of the stack of matrices in the static arena
+    long long d0;         // dense: first dense entry of the block
+};
+
+// scalars living in device memory (index into IpmBuf::scal)
+enum {
+    SC_MU = 0, SC_MU_P, SC_MU_C, SC_BETA_C, SC_ALPHA_P, SC_ALPHA_D, SC_DOBJ, SC_POBJ, SC_GAP, SC_DUAL_ERR, SC_PRIMAL_ERR,
+    SC_PD_FEAS, SC_XY, SC_MAXP, SC_MAXp, SC_MAXd, SC_EIG_X, SC_EIG_Y, SC_ERRCODE, SC_K, SC_ITER, SC_COUNT = 32
+};
+
+struct IpmParams {
+    double beta_infeasible, beta_feasible, gamma, dual_error_threshold, primal_error_threshold, max_complementary_gap;
+    double sgn, constant;   // +1 maximise / -1 minimise; objective constant
+    double step_length_threshold;
+    int safe_step, K;       // K = sum of the block sides
+};
+
+struct IpmBuf {
+    // iterates and directions
+    double *x, *y, *X, *Y, *dx, *dy, *dX, *dY;
+    double *Xchol, *XY, *P, *Z;
+    double *d, *p, *rhs_x;
+    double *AZ;            // per term: lambda-free pairing w^T Z v
+    double *AY;            // per term: w^T Y v (from the assembly)
+    double *dtr;           // per dense entry: <A_e, M>
+    double *part;          // per block partial sums: [NB][8]
+    double *eig;           // per block: min eig for X part, Y part: [NB][2]
+    double *scal;          // SC_COUNT doubles
+    int *info;             // [2] factorisation status words of the context
+    // static problem data
+    const double *stat, *C, *c, *b, *B;
+    const int *ayL, *ayR, *term_p;      // per original term
+    const double *term_lam;
+    const int *crow_ptr, *crow_term;    // CSR: constraint (global x index) -> terms (original indices)
+    const int *drow_ptr, *drow_ent;     // CSR: constraint -> dense entries
+    const int *dense_p;                 // per dense entry: cluster-local constraint
+    const IBlock *blocks;
+    int NB, N, xlen;
+    long long xylen, T, D;
+};
+
+__device__ __forceinline__ double block_reduce_sum(double v, double *red) {   // 256 threads, deterministic tree
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+__device__ __forceinline__ double block_reduce_max(double v, double *red) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
+
+// load an n x n block (ld n in memory) into LDS (ld lda), zero padded to n16 x n16
+__device__ __forceinline__ void ipm_load(double *A, int lda, const double *G, int n, int n16, int tid) {
+    const int i16 = tid & 15, j16 = tid >> 4;
+    for (int j0 = 0; j0 < n16; j0 += 16)
+        for (int i0 = 0; i0 < n16; i0 += 16) {
+            const int i = i0 + i16, j = j0 + j16;
+            A[i + j * lda] = (i < n && j < n) ? G[i + (long long)j * n] : 0.0;
+        }
+}
+__device__ __forceinline__ void ipm_load_chol(double *A, int lda, double *dinv, const double *G, int n, int n16, int tid) {
+    const int i16 = tid & 15, j16 = tid >> 4;
+    for (int j0 = 0; j0 < n16; j0 += 16)
+        for (int i0 = 0; i0 < n16; i0 += 16) {
+            const int i = i0 + i16, j = j0 + j16;
+            A[i + j * lda] = (i < n && j < n && i >= j) ? G[i + (long long)j * n] : 0.0;
+        }
+    if (tid < n16) dinv[tid] = (tid < n) ? 1.0 / G[tid + (long long)tid * n] : 0.0;
+}
+// M <- (L L^T)^-1 M for an n x n matrix in LDS (columns as right-hand sides); all 256 threads
+__device__ __forceinline__ void ipm_potrs(const double *L, int lda, const double *dinv, double *M, int n, int wave, int lane) {
+    lds_trsm<false>(L, lda, dinv, M, 1, lda, n, n, wave, 4, lane);
+    __syncthreads();
+    lds_trsm<true>(L, lda, dinv, M, 1, lda, n, n, wave, 4, lane);
+    __syncthreads();
+}
+
+// ---- k_ipm_pre: XY = X Y, partial tr(XY), Xchol = chol(X) ---------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ipm_pre(const IpmBuf q) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    __shared__ double red[4];
+    const IBlock k = q.blocks[blockIdx.x];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = k.n, n16 = (n + 15) & ~15, lda = n16 + 2;
+    double *Xs = lds, *Ys = Xs + lda * n16, *Ps = Ys + lda * n16, *dinv = Ps + lda * n16;
+    ipm_load(Xs, lda, q.X + k.xyoff, n, n16, tid);
+    ipm_load(Ys, lda, q.Y + k.xyoff, n, n16, tid);
+    __syncthreads();
+    lds_gemm_tn(Xs, lda, Ys, lda, Ps, lda, n, n, n, wave, 4, lane);       // X symmetric: X^T Y = X Y
+    __syncthreads();
+    double tr = 0.0;
+    const int i16 = tid & 15, j16 = tid >> 4;
+    for (int j0 = 0; j0 < n; j0 += 16)
+        for (int i0 = 0; i0 < n; i0 += 16) {
+            const int i = i0 + i16, j = j0 + j16;
+            if (i < n && j < n) {
+                q.XY[k.xyoff + i + (long long)j * n] = Ps[i + j * lda];
+                if (i == j) tr += Ps[i + j * lda];
+            }
+        }
+    tr = block_reduce_sum(tr, red);
+    if (tid == 0) q.part[blockIdx.x * 8 + 0] = tr;
+    // Cholesky of X in place (identity padding)
+    for (int j0 = 0; j0 < n16; j0 += 16)
+        for (int i0 = 0; i0 < n16; i0 += 16) {
+            const int i = i0 + i16, j = j0 + j16;
+            if (i >= n || j >= n) Xs[i + j * lda] = (i == j) ? 1.0 : 0.0;
+        }
+    __syncthreads();
+    const bool bad = lds_potrf(Xs, lda, dinv, n, wave, 4, lane);
+    if (bad && lane == 0) atomicMin(q.info + 1, (int)blockIdx.x + 1);
+    __syncthreads();
+    for (int j0 = 0; j0 < n; j0 += 16)
+        for (int i0 = 0; i0 < n; i0 += 16) {
+            const int i = i0 + i16, j = j0 + j16;
+            if (i < n && j < n) q.Xchol[k.xyoff + i + (long long)j * n] = (i >= j) ? Xs[i + j * lda] : 0.0;
+        }
+}
+
+// ---- sum_i a_i A_i of one block into LDS matrix M (n x n, ld lda), a = coefficient vector in the x layout ------------------
+// low rank: M[i,j] = sum_t a_{p(t)} lam_t W[i, ayL_t] V[j, ayR_t] over all terms of the block (both (r,s) and (s,r) are
+// terms, so the result is the full symmetric matrix); dense: M = sum_e a_{p(e)} A_e.
+__device__ __forceinline__ void ipm_weighted(const IpmBuf &q, const IBlock &k, const double *a, double *M, int lda, double *work, int tid) {
+    const int n = k.n;
+    const int i16 = tid & 15, j16 = tid >> 4;
+    if (k.kind == 0) {
+        // stage V, W and the per-term coefficients
+        const double *Vg = q.stat + k.vr_off, *Wg = q.stat + k.wl_off;
+        double *Vs = work, *Ws = (k.wl_off == k.vr_off) ? Vs : Vs + n * k.URt;
+        double *coef = Vs + n * k.URt + ((k.wl_off == k.vr_off) ? 0 : n * k.ULt);
+        int *tl = (int *)(coef + k.T), *tr = tl + k.T;
+        for (int e = tid; e < n * k.URt; e += 256) Vs[e] = Vg[e];
+        if (Ws != Vs)
+            for (int e = tid; e < n * k.ULt; e += 256) Ws[e] = Wg[e];
+        for (int t = tid; t < k.T; t += 256) {
+            coef[t] = a[k.xoff + q.term_p[k.t0 + t]] * q.term_lam[k.t0 + t];
+            tl[t] = q.ayL[k.t0 + t];
+            tr[t] = q.ayR[k.t0 + t];
+        }
+        __syncthreads();
+        for (int j0 = 0; j0 < n; j0 += 16)
+            for (int i0 = 0; i0 < n; i0 += 16) {
+                const int i = i0 + i16, j = j0 + j16;
+                if (i < n && j < n) {
+                    double s = 0.0;
+                    for (int t = 0; t < k.T; t++) s += coef[t] * (Ws[i + tl[t] * n] * Vs[j + tr[t] * n]);
+                    M[i + j * lda] = s;
+                }
+            }
+    } else {
+        const double *Ag = q.stat + k.a_off;
+        for (int j0 = 0; j0 < n; j0 += 16)
+            for (int i0 = 0; i0 < n; i0 += 16) {
+                const int i = i0 + i16, j = j0 + j16;
+                if (i < n && j < n) {
+                    double s = 0.0;
+                    for (int e = 0; e < k.cnt; e++) s += a[k.xoff + q.dense_p[k.d0 + e]] * Ag[(long long)e * n * n + i + j * n];
+                    M[i + j * lda] = s;
+                }
+            }
+    }
+    __syncthreads();
+}
+
+// ---- k_ipm_P: P = sum x_i A_i - X -+ C, max |P| ----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ipm_P(const IpmBuf q, const IpmParams prm) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    __shared__ double red[4];
+    const IBlock k = q.blocks[blockIdx.x];
+    const int tid = threadIdx.x, n = k.n, lda = n;
+    double *M = lds, *work = M + n * n;
+    ipm_weighted(q, k, q.x, M, lda, work, tid);
+    double mx = 0.0;
+    for (int e = tid; e < n * n; e += 256) {
+        const double v = M[e] - q.X[k.xyoff + e] - prm.sgn * q.C[k.xyoff + e];
+        q.P[k.xyoff + e] = v;
+        mx = fmax(mx, fabs(v));
+    }
+    mx = block_reduce_max(mx, red);
+    if (tid == 0) q.part[blockIdx.x * 8 + 1] = mx;
+}
+
+// ---- k_ipm_dense_dot: dtr[e] = <A_e, M> for every dense entry (one wave per entry) --------------------------------------------
+__global__ __launch_bounds__(256) void k_ipm_dense_dot(const IpmBuf q, const double *__restrict__ Mxy, const int *__restrict__ ent_block) {
+    const long long e = blockIdx.x * 4ll + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (e >= q.D) return;
+    const IBlock k = q.blocks[ent_block[e]];
+    const int nn = k.n * k.n;
+    const double *A = q.stat + k.a_off + (e - k.d0) * (long long)nn, *M = Mxy + k.xyoff;
+    double s = 0.0;
+    for (int i = lane; i < nn; i += 64) s += A[i] * M[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) q.dtr[e] = s;
+}
+
+// ---- k_ipm_csum: out[i] = sign * (base[i] - sum_t lam_t val[t] - sum_e dtr[e] - with_By * (B y)_i), max |out| -----------------
+// one thread per constraint (global x index); fixed summation order
+__global__ __launch_bounds__(256) void k_ipm_csum(const IpmBuf q, const double *__restrict__ base, double base_sign, const double *__restrict__ val,
+                                                  int with_By, double *__restrict__ out, int part_slot) {
+    __shared__ double red[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    double r = 0.0;
+    if (i < q.xlen) {
+        double s = base_sign * base[i];
+        for (int u = q.crow_ptr[i]; u < q.crow_ptr[i + 1]; u++) {
+            const int t = q.crow_term[u];
+            s -= q.term_lam[t] * val[t];
+        }
+        for (int u = q.drow_ptr[i]; u < q.drow_ptr[i + 1]; u++) s -= q.dtr[q.drow_ent[u]];
+        if (with_By)
+            for (int kk = 0; kk < q.N; kk++) s -= q.B[i + (long long)kk * q.xlen] * q.y[kk];
+        out[i] = s;
+        r = fabs(s);
+    }
+    r = block_reduce_max(r, red);
+    if (threadIdx.x == 0 && part_slot >= 0) q.part[(long long)(q.NB + blockIdx.x) * 8 + part_slot] = r;
+}
+
+// ---- k_ipm_p: p = sgn b - B^T x (one wave per free variable), per-wave |p| ------------------------------------------------
+__global__ __launch_bounds__(256) void k_ipm_p(const IpmBuf q, const IpmParams prm) {
+    const int kk = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (kk >= q.N) return;
+    const double *col = q.B + (long long)kk * q.xlen;
+    double s = 0.0;
+    for (int i = lane; i < q.xlen; i += 64) s += col[i] * q.x[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) q.p[kk] = prm.sgn * q.b[kk] - s;
+}
+
+// ---- k_ipm_Z: Z = sym(X^-1 (P Y - R)), R = mu' I - XY [- dX dY]; per-term pairings w^T Z v ------------------------------------
+__global__ __launch_bounds__(256) void k_ipm_Z(const IpmBuf q, int corrector) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const IBlock k = q.blocks[blockIdx.x];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = k.n, n16 = (n + 15) & ~15, lda = n16 + 2;
+    double *Ls = lds, *As = Ls + lda * n16, *Bs = As + lda * n16, *Ts = Bs + lda * n16, *dinv = Ts + lda * n16, *work = dinv + n16;
+    const double mu = q.scal[corrector ? SC_MU_C : SC_MU_P];
+    const int i16 = tid & 15, j16 = tid >> 4;
+    ipm_load_chol(Ls, lda, dinv, q.Xchol + k.xyoff, n, n16, tid);
+    ipm_load(As, lda, q.P + k.xyoff, n, n16, tid);
+    ipm_load(Bs, lda, q.Y + k.xyoff, n, n16, tid);
+    __syncthreads();
+    lds_gemm_tn(As, lda, Bs, lda, Ts, lda, n, n, n, wave, 4, lane);       // P symmetric: P^T Y = P Y
+    __syncthreads();
+    if (corrector) {   // dX dY, both symmetric
+        ipm_load(As, lda, q.dX + k.xyoff, n, n16, tid);
+        ipm_load(Bs, lda, q.dY + k.xyoff, n, n16, tid);
+        __syncthreads();
+        // accumulate into a second product buffer: reuse work as n x n scratch through As after the product
+        double *Ds = work;     // lda * n16 doubles of scratch (sized by the host)
+        lds_gemm_tn(As, lda, Bs, lda, Ds, lda, n, n, n, wave, 4, lane);
+        __syncthreads();
+        for (int j0 = 0; j0 < n; j0 += 16)
+            for (int i0 = 0; i0 < n; i0 += 16) {
+                const int i = i0 + i16, j = j0 + j16;
+                if (i < n && j < n) Ts[i + j * lda] += Ds[i + j * lda];
+            }
+        __syncthreads();
+    }
+    // T = P Y - (mu I - XY - dX dY) = P Y + XY [+ dX dY] - mu I
+    for (int j0 = 0; j0 < n16; j0 += 16)
+        for (int i0 = 0; i0 < n16; i0 += 16) {
+            const int i = i0 + i16, j = j0 + j16;
+            double v = 0.0;
+            if (i < n && j < n) v = Ts[i + j * lda] + q.XY[k.xyoff + i + (long long)j * n] - ((i == j) ? mu : 0.0);
+            Ts[i + j * lda] = v;
+        }
+    __syncthreads();
+    ipm_potrs(Ls, lda, dinv, Ts, n, wave, lane);
+    // symmetrise into As (= Z), store
+    for (int j0 = 0; j0 < n16; j0 += 16)
+        for (int i0 = 0; i0 < n16; i0 += 16) {
+            const int i = i0 + i16, j = j0 + j16;
+            const double v = (i < n && j < n) ? 0.5 * (Ts[i + j * lda] + Ts[j + i * lda]) : 0.0;
+            As[i + j * lda] = v;
+            if (i < n && j < n) q.Z[k.xyoff + i + (long long)j * n] = v;
+        }
+    __syncthreads();
+    if (k.kind == 0) {
+        // pairings: AZ[t] = W[:, ayL_t]^T Z V[:, ayR_t]   (TZ = Z V column by column, then dots)
+        const double *Vg = q.stat + k.vr_off, *Wg = q.stat + k.wl_off;
+        double *TZ = work;                       // n x URt
+        for (int e = tid; e < n * k.URt; e += 256) {
+            const int i = e % n, u = e / n;
+            double s = 0.0;
+            for (int kk = 0; kk < n; kk++) s += As[i + kk * lda] * Vg[kk + (long long)u * n];
+            TZ[e] = s;
+        }
+        __syncthreads();
+        for (int t = tid; t < k.T; t += 256) {
+            const double *w = Wg + (long long)q.ayL[k.t0 + t] * n, *tz = TZ + q.ayR[k.t0 + t] * n;
+            double s = 0.0;
+            for (int i = 0; i < n; i++) s += w[i] * tz[i];
+            q.AZ[k.t0 + t] = s;
+        }
+    }
+}
+
+// ---- k_ipm_dXdY: dX = P + sum dx_i A_i; dY = sym(X^-1 (R - dX Y)); partial dots <X,dY>, <dX,Y>, <dX,dY> -----------------------
+__global__ __launch_bounds__(256) void k_ipm_dXdY(const IpmBuf q, int corrector) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    __shared__ double red[4];
+    const IBlock k = q.blocks[blockIdx.x];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = k.n, n16 = (n + 15) & ~15, lda = n16 + 2;
+    double *Ls = lds, *As = Ls + lda * n16, *Bs = As + lda * n16, *Ts = Bs + lda * n16, *dinv = Ts + lda * n16, *M = dinv + n16, *work = M + n * n;
+    const double mu = q.scal[corrector ? SC_MU_C : SC_MU_P];
+    const int i16 = tid & 15, j16 = tid >> 4;
+    ipm_weighted(q, k, q.dx, M, n, work, tid);
+    // dX (old dX / dY are still needed for the corrector's R: read them before overwriting)
+    double *Ds = work;   // product dXold dYold
+    if (corrector) {
+        ipm_load(As, lda, q.dX + k.xyoff, n, n16, tid);
+        ipm_load(Bs, lda, q.dY + k.xyoff, n, n16, tid);
+        __syncthreads();
+        lds_gemm_tn(As, lda, Bs, lda, Ds, lda, n, n, n, wave, 4, lane);
+        __syncthreads();
+    }
+    for (int j0 = 0; j0 < n16; j0 += 16)
+        for (int i0 = 0; i0 < n16; i0 += 16) {
+            const int i = i0 + i16, j = j0 + j16;
+            double v = 0.0;
+            if (i < n && j < n) {
+                v = q.P[k.xyoff + i + (long long)j * n] + M[i + j * n];
+                q.dX[k.xyoff + i + (long long)j * n] = v;
+            }
+            As[i + j * lda] = v;
+        }
+    ipm_load_chol(Ls, lda, dinv, q.Xchol + k.xyoff, n, n16, tid);
+    ipm_load(Bs, lda, q.Y + k.xyoff, n, n16, tid);
+    __syncthreads();
+    lds_gemm_tn(As, lda, Bs, lda, Ts, lda, n, n, n, wave, 4, lane);       // dX Y
+    __syncthreads();
+    // T = R - dX Y = mu I - XY [- dXold dYold] - dX Y
+    for (int j0 = 0; j0 < n16; j0 += 16)
+        for (int i0 = 0; i0 < n16; i0 += 16) {
+            const int i = i0 + i16, j = j0 + j16;
+            double v = 0.0;
+            if (i < n && j < n) {
+                v = ((i == j) ? mu : 0.0) - q.XY[k.xyoff + i + (long long)j * n] - Ts[i + j * lda];
+                if (corrector) v -= Ds[i + j * lda];
+            }
+            Ts[i + j * lda] = v;
+        }
+    __syncthreads();
+    ipm_potrs(Ls, lda, dinv, Ts, n, wave, lane);
+    double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (int j0 = 0; j0 < n; j0 += 16)
+        for (int i0 = 0; i0 < n; i0 += 16) {
+            const int i = i0 + i16, j = j0 + j16;
+            if (i < n && j < n) {
+                const double dy = 0.5 * (Ts[i + j * lda] + Ts[j + i * lda]);
+                const long long g = k.xyoff + i + (long long)j * n;
+                q.dY[g] = dy;
+                const double dxv = As[i + j * lda];
+                s1 += q.X[g] * dy;
+                s2 += dxv * Bs[i + j * lda];
+                s3 += dxv * dy;
+            }
+        }
+    s1 = block_reduce_sum(s1, red);
+    s2 = block_reduce_sum(s2, red);
+    s3 = block_reduce_sum(s3, red);
+    if (tid == 0) {
+        q.part[blockIdx.x * 8 + 2] = s1;
+        q.part[blockIdx.x * 8 + 3] = s2;
+        q.part[blockIdx.x * 8 + 4] = s3;
+    }
+}
+
+// ---- k_ipm_step: smallest eigenvalue of L^-1 dM L^-T, M in {X, Y} ---------------------------------------------------------------
+// grid = 2 NB: workgroup 2b handles (X, dX), 2b+1 handles (Y, dY).  Cholesky of M, two triangular solves, Householder
+// tridiagonalisation in LDS, Sturm-count multisection with one shift per thread (256-section per round).
+__global__ __launch_bounds__(256) void k_ipm_step(const IpmBuf q) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    __shared__ double red[4];
+    __shared__ double sh_lo, sh_hi;
+    __shared__ int cnts[257];
+    const int b = blockIdx.x >> 1, which = blockIdx.x & 1;
+    const IBlock k = q.blocks[b];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = k.n, n16 = (n + 15) & ~15, lda = n16 + 2;
+    double *Ls = lds, *Ws = Ls + lda * n16, *dinv = Ws + lda * n16, *dd = dinv + n16, *ee = dd + n16, *vv = ee + n16, *pp = vv + n16;
+    const double *Mg = (which ? q.Y : q.X) + k.xyoff, *dMg = (which ? q.dY : q.dX) + k.xyoff;
+    const int i16 = tid & 15, j16 = tid >> 4;
+    if (n == 1) {
+        if (tid == 0) q.eig[b * 2 + which] = dMg[0] / Mg[0];
+        return;
+    }
+    // L = chol(M)
+    for (int j0 = 0; j0 < n16; j0 += 16)
+        for (int i0 = 0; i0 < n16; i0 += 16) {
+            const int i = i0 + i16, j = j0 + j16;
+            Ls[i + j * lda] = (i < n && j < n) ? ((i >= j) ? Mg[i + (long long)j * n] : 0.0) : ((i == j) ? 1.0 : 0.0);
+        }
+    ipm_load(Ws, lda, dMg, n, n16, tid);
+    __syncthreads();
+    const bool bad = lds_potrf(Ls, lda, dinv, n, wave, 4, lane);
+    if (bad && lane == 0) atomicMin(q.info + 1, 1000000 + b);          // Cholesky failed in the step length computation
+    __syncthreads();
+    // W = L^-1 dM L^-T: solve on the columns, then on the rows
+    lds_trsm<false>(Ls, lda, dinv, Ws, 1, lda, n, n, wave, 4, lane);
+    __syncthreads();
+    lds_trsm<false>(Ls, lda, dinv, Ws, lda, 1, n, n, wave, 4, lane);
+    __syncthreads();
+    // symmetrise
+    for (int j0 = 0; j0 < n; j0 += 16)
+        for (int i0 = 0; i0 < n; i0 += 16) {
+            const int i = i0 + i16, j = j0 + j16;
+            if (i < n && j < n && i > j) {
+                const double v = 0.5 * (Ws[i + j * lda] + Ws[j + i * lda]);
+                Ws[i + j * lda] = v;
+                Ws[j + i * lda] = v;
+            }
+        }
+    __syncthreads();
+    // Householder tridiagonalisation (unblocked, lower part authoritative but both triangles kept equal)
+    for (int c = 0; c < n - 2; c++) {
+        const int m = n - c - 1;                    // length of the column below the diagonal
+        double *xcol = Ws + (c + 1) + c * lda;
+        double ss = 0.0;
+        for (int i = tid; i < m; i += 256) ss += xcol[i] * xcol[i];
+        ss = block_reduce_sum(ss, red);
+        const double x0 = xcol[0];
+        const double nrm = sqrt(ss);
+        if (nrm == 0.0) {
+            if (tid == 0) ee[c] = 0.0;
+            __syncthreads();
+            continue;
+        }
+        const double alpha = (x0 > 0.0) ? -nrm : nrm;
+        const double v0 = x0 - alpha;
+        const double vnorm2 = ss - x0 * x0 + v0 * v0;   // ||v||^2
+        __syncthreads();
+        for (int i = tid; i < m; i += 256) vv[i] = (i == 0) ? v0 : xcol[i];
+        if (tid == 0) ee[c] = alpha;
+        __syncthreads();
+        const double tau = 2.0 / vnorm2;
+        // p = tau * A22 v
+        for (int i = tid; i < m; i += 256) {
+            double s = 0.0;
+            const double *row = Ws + (c + 1 + i) + (c + 1) * lda;
+            for (int j = 0; j < m; j++) s += row[j * lda] * vv[j];
+            pp[i] = tau * s;
+        }
+        __syncthreads();
+        double kk = 0.0;
+        for (int i = tid; i < m; i += 256) kk += pp[i] * vv[i];
+        kk = block_reduce_sum(kk, red);
+        const double K2 = 0.5 * tau * kk;
+        __syncthreads();
+        for (int i = tid; i < m; i += 256) pp[i] -= K2 * vv[i];   // w
+        __syncthreads();
+        for (int e = tid; e < m * m; e += 256) {
+            const int i = e % m, j = e / m;
+            Ws[(c + 1 + i) + (c + 1 + j) * lda] -= vv[i] * pp[j] + pp[i] * vv[j];
+        }
+        __syncthreads();
+    }
+    if (tid < n) dd[tid] = Ws[tid + tid * lda];
+    if (tid == 0) ee[n - 2] = Ws[(n - 1) + (n - 2) * lda];
+    __syncthreads();
+    // Gershgorin interval
+    double lo = 1e300, hi = -1e300;
+    if (tid < n) {
+        const double r = ((tid > 0) ? fabs(ee[tid - 1]) : 0.0) + ((tid < n - 1) ? fabs(ee[tid]) : 0.0);
+        lo = dd[tid] - r;
+        hi = dd[tid] + r;
+    }
+    lo = -block_reduce_max(-lo, red);
+    hi = block_reduce_max(hi, red);
+    // multisection for the smallest eigenvalue: count(s) = number of eigenvalues < s
+    const double scale = fmax(fabs(lo), fabs(hi));
+    lo -= 1e-3 * scale + 1e-300;
+    hi += 1e-3 * scale + 1e-300;
+    for (int round = 0; round < 8; round++) {
+        const double h = (hi - lo) / 257.0;
+        const double sft = lo + h * (tid + 1);
+        int cnt = 0;
+        double qv = dd[0] - sft;
+        if (qv < 0.0) cnt++;
+        for (int i = 1; i < n; i++) {
+            const double e2 = ee[i - 1] * ee[i - 1];
+            if (qv == 0.0) qv = 1e-300 * (1.0 + fabs(sft));
+            qv = dd[i] - sft - e2 / qv;
+            if (qv < 0.0) cnt++;
+        }
+        cnts[tid + 1] = cnt;
+        if (tid == 0) cnts[0] = 0;
+        __syncthreads();
+        // the smallest eigenvalue lies in the first sub-interval whose upper end has count >= 1
+        if (cnts[tid + 1] >= 1 && cnts[tid] == 0) { sh_lo = lo + h * tid; sh_hi = sft; }
+        if (tid == 0 && cnts[256] == 0) { sh_lo = lo + h * 256; sh_hi = hi; }
+        __syncthreads();
+        lo = sh_lo;
+        hi = sh_hi;
+        __syncthreads();
+    }
+    if (tid == 0) q.eig[b * 2 + which] = 0.5 * (lo + hi);
+}
+
+// ---- k_ipm_update: iterate update + objective / complementarity dots ------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ipm_update(const IpmBuf q, int nblocks_grid, int row0) {
+    __shared__ double red[4];
+    // after a failed factorisation or a too short step the iterate is left as it is (the reference returns the current
+    // iterate, src/solver.jl:470-475, 594-623); the directions may then hold NaNs, so they are not even multiplied by 0
+    const bool skip = q.scal[SC_ERRCODE] != 0.0;
+    const double ap = q.scal[SC_ALPHA_P], ad = q.scal[SC_ALPHA_D];
+    double cy = 0.0, xy = 0.0, cx = 0.0, by = 0.0;
+    for (long long e = blockIdx.x * 256ll + threadIdx.x; e < q.xylen; e += 256ll * nblocks_grid) {
+        const double Xn = skip ? q.X[e] : q.X[e] + ad * q.dX[e], Yn = skip ? q.Y[e] : q.Y[e] + ap * q.dY[e];
+        q.X[e] = Xn;
+        q.Y[e] = Yn;
+        cy += q.C[e] * Yn;
+        xy += Xn * Yn;
+    }
+    for (long long e = blockIdx.x * 256ll + threadIdx.x; e < q.xlen; e += 256ll * nblocks_grid) {
+        const double xn = skip ? q.x[e] : q.x[e] + ad * q.dx[e];
+        q.x[e] = xn;
+        cx += q.c[e] * xn;
+    }
+    for (long long e = blockIdx.x * 256ll + threadIdx.x; e < q.N; e += 256ll * nblocks_grid) {
+        const double yn = skip ? q.y[e] : q.y[e] + ap * q.dy[e];
+        q.y[e] = yn;
+        by += q.b[e] * yn;
+    }
+    cy = block_reduce_sum(cy, red);
+    xy = block_reduce_sum(xy, red);
+    cx = block_reduce_sum(cx, red);
+    by = block_reduce_sum(by, red);
+    if (threadIdx.x == 0) {
+        double *pt = q.part + (long long)(row0 + blockIdx.x) * 8;
+        pt[5] = cy; pt[6] = cx; pt[7] = by; pt[0] = xy;
+    }
+}
+
+// ---- k_ipm_scalars: the scalar control flow, one thread -----------------------------------------------------------------------
+// stage 0: mu from tr(XY) partials; mu_p                                      (src/solver.jl:369-374)
+// stage 1: errors after the residuals; pd_feas                               (:441-447, computed before the predictor here)
+// stage 2: beta_c, mu_c after the predictor                                   (:429-434)
+// stage 3: step lengths from the eigenvalues                                  (:462-483, :1684-1692)
+// stage 4: objectives and gap after the update (grid partials of k_ipm_update) (:793-804, 844-847)
+__global__ void k_ipm_scalars(const IpmBuf q, const IpmParams prm, int stage, int ngrid, int ncsum_or_row0) {
+    const int ncsum = ncsum_or_row0, row0 = ncsum_or_row0;
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double *s = q.scal;
+    if (stage == 0) {
+        double xy = 0.0;
+        for (int b = 0; b < q.NB; b++) xy += q.part[b * 8 + 0];
+        s[SC_XY] = xy;
+        s[SC_MU] = xy / prm.K;
+        s[SC_MU_P] = (s[SC_PD_FEAS] != 0.0) ? 0.0 : prm.beta_infeasible * s[SC_MU];
+        if (s[SC_MU] > prm.max_complementary_gap) s[SC_ERRCODE] = 3.0;
+    } else if (stage == 1) {
+        double mP = 0.0, md = 0.0, mp = 0.0;
+        for (int b = 0; b < q.NB; b++) mP = fmax(mP, q.part[b * 8 + 1]);
+        for (int g = 0; g < ncsum; g++) md = fmax(md, q.part[(long long)(q.NB + g) * 8 + 0]);
+        for (int kk = 0; kk < q.N; kk++) mp = fmax(mp, fabs(q.p[kk]));
+        s[SC_MAXP] = mP; s[SC_MAXd] = md; s[SC_MAXp] = mp;
+        s[SC_DUAL_ERR] = fmax(mp, mP);
+        s[SC_PRIMAL_ERR] = md;
+    } else if (stage == 2) {
+        double a = 0.0, bb = 0.0, c = 0.0;
+        for (int b = 0; b < q.NB; b++) { a += q.part[b * 8 + 2]; bb += q.part[b * 8 + 3]; c += q.part[b * 8 + 4]; }
+        const double r = (s[SC_XY] + a + bb + c) / (s[SC_MU] * prm.K);
+        const double beta = (r < 1.0) ? r * r : r;
+        const bool feas = s[SC_DUAL_ERR] < prm.dual_error_threshold && s[SC_PRIMAL_ERR] < prm.primal_error_threshold;
+        s[SC_PD_FEAS] = feas ? 1.0 : 0.0;
+        s[SC_BETA_C] = feas ? fmin(fmax(prm.beta_feasible, beta), 1.0) : fmax(prm.beta_infeasible, beta);
+        s[SC_MU_C] = s[SC_BETA_C] * s[SC_MU];
+    } else if (stage == 3) {
+        double ex = 1e300, ey = 1e300;
+        for (int b = 0; b < q.NB; b++) {
+            const double fx = (q.blocks[b].n == 1) ? 0.0 : 1e-5;    // the reference subtracts 1e-5 from the Lanczos estimate (:1680)
+            ex = fmin(ex, q.eig[b * 2 + 0] - fx);
+            ey = fmin(ey, q.eig[b * 2 + 1] - fx);
+        }
+        s[SC_EIG_X] = ex; s[SC_EIG_Y] = ey;
+        const bool unsafe = (s[SC_PD_FEAS] != 0.0) && !prm.safe_step;
+        double ad = (ex > -prm.gamma && !unsafe) ? 1.0 : -prm.gamma / ex;
+        double ap = (ey > -prm.gamma && !unsafe) ? 1.0 : -prm.gamma / ey;
+        if (s[SC_PD_FEAS] != 0.0 && prm.safe_step) ad = ap = fmin(ad, ap);
+        s[SC_ALPHA_D] = ad; s[SC_ALPHA_P] = ap;
+        if (fmin(ad, ap) < prm.step_length_threshold || !(ad == ad) || !(ap == ap)) s[SC_ERRCODE] = 4.0;     // :470-475
+        if (q.info[0] != 0x7f7f7f7f || q.info[1] != 0x7f7f7f7f) s[SC_ERRCODE] = 1.0;                          // a Cholesky failed: SolverFailure
+    } else if (stage == 4) {
+        double cy = 0.0, cx = 0.0, by = 0.0, xy = 0.0;
+        for (int g = 0; g < ngrid; g++) {
+            const double *pt = q.part + (long long)(row0 + g) * 8;
+            cy += pt[5]; cx += pt[6]; by += pt[7]; xy += pt[0];
+        }
+        s[SC_DOBJ] = prm.sgn * cx + prm.constant;
+        s[SC_POBJ] = cy + by + prm.constant;
+        s[SC_GAP] = fabs(s[SC_DOBJ] - s[SC_POBJ]) / fmax(1.0, fabs(s[SC_DOBJ] + s[SC_POBJ]));
+        if (s[SC_ERRCODE] == 0.0) s[SC_ITER] += 1.0;
+    }
+}
+
+}  // namespace clrs

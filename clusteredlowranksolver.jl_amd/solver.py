@@ -585,3 +585,82 @@ def solvesdp(sdp, ctx: Optional[SchurContext] = None, device: int = 0, maxiterat
         ctx.close()
     return SolveResult(status, x, X, y, Y, t_total, error_code, it - 1, d_obj, p_obj, gap, dual_error, primal_error,
                        np.array(hist).reshape(-1, 11), tm)
+
+
+# ------------------------------------------------------------------------------------------------
+# device-resident loop: the same algorithm with every iterate in HBM (clrs_ipm_*)
+# ------------------------------------------------------------------------------------------------
+
+def solvesdp_device(sdp, ctx: Optional[SchurContext] = None, device: int = 0, maxiterations: int = 500,
+                    beta_infeasible: float = 0.3, beta_feasible: float = 0.1, gamma: float = 0.9,
+                    omega_p: float = 1e4, omega_d: float = 1e4,
+                    duality_gap_threshold: float = 1e-7, dual_error_threshold: float = 1e-9, primal_error_threshold: float = 1e-9,
+                    max_complementary_gap: float = 1e100, need_dual_feasible: bool = False, need_primal_feasible: bool = False,
+                    verbose: bool = False, step_length_threshold: float = 1e-7, safe_step: bool = True) -> SolveResult:
+    """`solvesdp` (src/solver.jl:100-744) with the whole loop body on the GPU: residuals, both search directions (through
+    the Schur assembly / factor / solve of the path), step lengths and the update never leave HBM; the host reads one record
+    per iteration and decides termination (src/solver.jl:921-950).  Same keywords and defaults as `solvesdp` above.
+    Raises ClrsError when a PSD block is too large for the LDS-resident kernels (use `solvesdp` then)."""
+    f = sdp if isinstance(sdp, FlatSDP) else flatten(sdp)
+    own_ctx = ctx is None
+    if ctx is None:
+        ctx = SchurContext(f, device=device)
+    L = ctx.L
+    keep = [_c(f.C), _c(f.c), _c(f.b if f.n_free else np.zeros(1))]
+    data = _lib.IpmData(_dp(keep[0]), _dp(keep[1]), _dp(keep[2]), int(f.maximize), 0, float(f.constant))
+    _lib.check(L.clrs_ipm_create(ctx.h, C.byref(data)))
+    prm = _lib.IpmParams(beta_infeasible, beta_feasible, gamma, dual_error_threshold, primal_error_threshold, max_complementary_gap,
+                         step_length_threshold, int(safe_step), 0)
+    _lib.check(L.clrs_ipm_set_params(ctx.h, C.byref(prm)))
+    _lib.check(L.clrs_ipm_init(ctx.h, float(omega_p), float(omega_d)))
+    rec = _lib.IpmRecord()
+    hist = []
+    t_start = time.time()
+    error_code, it = 0, 1
+    dual_error = primal_error = gap = np.inf
+    d_obj = p_obj = f.constant
+    pd_feas = False
+    while True:
+        dual_feas, primal_feas = dual_error < dual_error_threshold, primal_error < primal_error_threshold
+        if (need_dual_feasible and dual_feas) or (need_primal_feasible and primal_feas):          # :921-950
+            break
+        if dual_feas and primal_feas and gap < duality_gap_threshold:
+            break
+        if it > maxiterations:
+            error_code = 2
+            break
+        _lib.check(L.clrs_ipm_iterate(ctx.h, C.byref(rec)))
+        hist.append([it, rec.mu, d_obj, p_obj, gap, rec.max_P, rec.max_p, rec.max_d, rec.alpha_d, rec.alpha_p, rec.beta_c])
+        if verbose:
+            print("%5d %8.1f %11.3e %11.3e %11.3e %10.2e %10.2e %10.2e %10.2e %10.2e %10.2e %10.2e" %
+                  (it, time.time() - t_start, rec.mu, d_obj, p_obj, gap, rec.max_P, rec.max_p, rec.max_d, rec.alpha_d, rec.alpha_p, rec.beta_c))
+        # the errors of the record belong to the iterate BEFORE this update (like the table row of the reference); they
+        # are what the next termination test sees together with the new objectives
+        dual_error, primal_error, pd_feas = rec.dual_error, rec.primal_error, bool(rec.pd_feas)
+        if rec.error_code:
+            error_code = rec.error_code
+            if verbose and rec.error_code == 1:
+                print("SolverFailure: factor status %d, Cholesky status %d" % (rec.factor_status, rec.cholesky_status))
+            break
+        d_obj, p_obj, gap = rec.d_obj, rec.p_obj, rec.gap
+        it += 1
+    t_total = time.time() - t_start
+    x, y = np.zeros(f.x_len), np.zeros(max(f.n_free, 1))
+    X, Y = np.zeros(f.xy_len), np.zeros(f.xy_len)
+    _lib.check(L.clrs_ipm_get(ctx.h, _dp(x), _dp(y), _dp(X), _dp(Y)))
+    if pd_feas and gap < duality_gap_threshold:                                    # :727-741
+        status = "Optimal"
+    elif (pd_feas and gap < 1e-8) or (dual_error < 1e-15 and primal_error < 1e-15 and gap < 1e-8):
+        status = "NearOptimal"
+    elif pd_feas:
+        status = "Feasible"
+    elif primal_error < primal_error_threshold:
+        status = "PrimalFeasible"
+    elif dual_error < dual_error_threshold:
+        status = "DualFeasible"
+    else:
+        status = "NotConverged"
+    if own_ctx:
+        ctx.close()
+    return SolveResult(status, x, X, y[:f.n_free], Y, t_total, error_code, it - 1, d_obj, p_obj, gap, dual_error, primal_error,
+                       np.array(hist).reshape(-1, 11), dict(loop="device"))

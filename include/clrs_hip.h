@@ -154,6 +154,34 @@ double *clrs_AY_buffer_dev(clrs_ctx *ctx);                    /* [T] */
 int clrs_sync_status(clrs_ctx *ctx);
 void *clrs_stream(clrs_ctx *ctx);                             /* hipStream_t of the context */
 
+/* --- device-resident interior-point iteration around the path -------------------------
+ * The whole loop body of solvesdp (src/solver.jl:348-589) with x, y, X, Y and every intermediate in HBM: residuals
+ * (:863-918, 961-983), search directions (:1474-1616, with the solves of this library), step lengths (:1620-1693) and the
+ * update (:485-495).  The host sequences kernels and reads one record per iteration.  Available when every PSD block
+ * fits in LDS (n <= ~48); otherwise clrs_ipm_create returns CLRS_ERR_INVALID and the caller keeps its own loop. */
+typedef struct clrs_ipm_data {
+    const double *C;      /* objective matrices, xy layout (sdp.C) */
+    const double *c;      /* right-hand sides, x layout (sdp.c) */
+    const double *b;      /* objective of the free variables [N] (sdp.b) */
+    int32_t maximize;     /* sdp.maximize */
+    int32_t reserved;
+    double constant;      /* objective constant */
+} clrs_ipm_data;
+typedef struct clrs_ipm_params {   /* keyword arguments of solvesdp, src/solver.jl:100-127 */
+    double beta_infeasible, beta_feasible, gamma;
+    double dual_error_threshold, primal_error_threshold, max_complementary_gap, step_length_threshold;
+    int32_t safe_step, reserved;
+} clrs_ipm_params;
+typedef struct clrs_ipm_record {   /* one row of the reference's iteration table (:566-582) + status */
+    int32_t iter, pd_feas, error_code, factor_status, cholesky_status, reserved;
+    double mu, d_obj, p_obj, gap, dual_error, primal_error, alpha_d, alpha_p, beta_c, max_P, max_p, max_d;
+} clrs_ipm_record;
+int clrs_ipm_create(clrs_ctx *ctx, const clrs_ipm_data *data);
+int clrs_ipm_set_params(clrs_ctx *ctx, const clrs_ipm_params *params);
+int clrs_ipm_init(clrs_ctx *ctx, double omega_p, double omega_d);            /* x = y = 0, X = omega_p I, Y = omega_d I */
+int clrs_ipm_iterate(clrs_ctx *ctx, clrs_ipm_record *out);                   /* one iteration; error_code 0 / 1 / 3 / 4 as docs/src/solving.md:64-70 */
+int clrs_ipm_get(clrs_ctx *ctx, double *x, double *y, double *X, double *Y); /* copy the iterate to the host (any pointer may be NULL) */
+
 /* Timings of the last assemble/factor calls in seconds, measured with HIP events on the context
  * stream: t[0..4] = schur, cholS, LinvB, Q, cholQ -- the 5-way split compute_T_decomposition!
  * returns (src/solver.jl:1282-1286); t[5] = last solve.  Enabled by clrs_set_timing(ctx, 1). */

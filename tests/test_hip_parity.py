@@ -353,3 +353,58 @@ def test_solvesdp_sdpa_example_config5(oracle_built):
                                       primal_error_threshold=1e-9)
     assert r.error_code == 0 and o["error_code"] == 0
     assert abs(r.primal_objective - o["p_obj"]) <= 1e-5 and abs(r.primal_objective - 30.0) <= 1e-4
+
+
+# ---- device-resident interior-point loop (clrs_ipm_*) ------------------------------------------
+
+DEVICE_LOOP_CASES = [("x2p1", 1.0, 1e-6, {}), ("polyopt40", None, 1e-6, {}), ("delsarte_3_10", 13.158314, 1e-5, {}),
+                     ("delsarte_8_3", 240.0, 1e-6, {}), ("sdpa_example", 30.0, 1e-6, dict(omega_p=1e2, omega_d=1e2))]
+
+
+@pytest.mark.parametrize("name,expected,tol,kw", DEVICE_LOOP_CASES)
+def test_device_loop_reaches_the_pinned_objectives(name, expected, tol, kw, oracle_built):
+    """The whole iteration on the GPU: same answers as the reference pins (test/runtests_solver.jl:15,86-87; README.md:149);
+    polyopt 2d=40 (BASELINE config 2) against the quad-precision oracle loop."""
+    from clrs_amd.solver import solvesdp_device
+    from oracle.oracle import Oracle
+    f = flat(name)
+    r = solvesdp_device(f, **kw)
+    assert r.error_code == 0 and r.status == "Optimal", (r.status, r.error_code, r.iterations)
+    if expected is None:
+        expected = Oracle(f, quad=True).solvesdp(omega_p=1e4, omega_d=1e4, duality_gap_threshold=1e-9, dual_error_threshold=1e-9,
+                                                 primal_error_threshold=1e-9)["p_obj"]
+    assert abs(r.primal_objective - expected) <= tol * max(1.0, abs(expected))
+    assert abs(r.dual_objective - expected) <= tol * max(1.0, abs(expected))
+
+
+@pytest.mark.parametrize("name", ["polyopt8", "delsarte_3_10", "polyopt40"])
+def test_device_loop_follows_the_host_loop(name):
+    """Same algorithm, same fp64 arithmetic up to summation order: the iteration traces (mu, step lengths) of the device loop and
+    of the host-orchestrated loop agree to 1e-6 over the first iterations, and the iteration counts within 2."""
+    from clrs_amd.solver import solvesdp, solvesdp_device
+    f = flat(name)
+    rd, rh = solvesdp_device(f), solvesdp(f)
+    assert rd.error_code == 0 and rh.error_code == 0
+    assert abs(rd.iterations - rh.iterations) <= 2
+    n = min(6, len(rd.history), len(rh.history))
+    assert np.allclose(rd.history[:n, 1], rh.history[:n, 1], rtol=1e-6)          # mu
+    assert np.allclose(rd.history[:n, 8:10], rh.history[:n, 8:10], rtol=1e-5)    # alpha_d, alpha_p
+    assert abs(rd.primal_objective - rh.primal_objective) <= 1e-6 * max(1.0, abs(rh.primal_objective))
+
+
+def test_device_loop_three_point_bound():
+    """BASELINE config 4 on the device loop: 10 +- 1e-5 (fp64 stalls on the step length near gap 1e-8, like the fp64 oracle)."""
+    from clrs_amd.solver import solvesdp_device
+    r = solvesdp_device(flat("threepoint_4"), omega_p=1e3, omega_d=1e3, maxiterations=200)
+    assert r.error_code in (0, 1, 4)
+    assert abs(r.primal_objective - 10.0) <= 1e-5 and abs(r.dual_objective - 10.0) <= 1e-5
+
+
+def test_device_loop_reports_failure_like_the_reference():
+    """cohnelkies(8,15) cannot be factored in fp64: the device loop stops with error_code 1 at the first iteration and leaves the
+    starting point untouched (the reference returns the current iterate, src/solver.jl:594-623)."""
+    from clrs_amd.solver import solvesdp_device
+    f = flat("ce_8_15")
+    r = solvesdp_device(f)
+    assert r.error_code == 1 and r.iterations == 0
+    assert np.all(np.isfinite(r.X)) and np.all(np.isfinite(r.x)) and np.allclose(r.x, 0.0)
