@@ -98,6 +98,7 @@ SYMBOLS = {
     "clrs_ipm_init": (C.c_int, [C.c_void_p, C.c_double, C.c_double]),
     "clrs_ipm_iterate": (C.c_int, [C.c_void_p, C.POINTER(IpmRecord)]),
     "clrs_ipm_get": (C.c_int, [C.c_void_p, p_d, p_d, p_d, p_d]),
+    "clrs_ipm_debug": (C.c_int, [C.c_void_p, p_d]),
     "clrs_config_set": (C.c_int, [C.c_char_p, C.c_int]),
     "clrs_fused_clusters": (C.c_int, [C.c_void_p]),
     "clrs_wave_clusters": (C.c_int, [C.c_void_p]),

@@ -518,13 +518,6 @@ struct WCluster {
     int pad;
 };
 
-__device__ __forceinline__ void wave_sync() {
-    // LDS operations of one wave complete in issue order; this only stops the compiler from moving them across
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 template <int UT>   // U <= 16 * UT
 __global__ __launch_bounds__(512) void k_cluster_assemble_w1(const WCluster *__restrict__ clusters, const WBlock *__restrict__ blocks, const FTables tb,
                                                              int nwaves, int maxblk) {

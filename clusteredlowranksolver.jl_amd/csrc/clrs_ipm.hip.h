@@ -74,6 +74,19 @@ struct IpmBuf {
     long long xylen, T, D;
 };
 
+#ifdef CLRS_IPM_STAMPS
+#define IPM_STAMP(i)                                                                                            \
+    do {                                                                                                        \
+        if (blockIdx.x == 0 && threadIdx.x == 0) {                                                              \
+            unsigned long long t_;                                                                              \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                          \
+            q.eig[2 * q.NB + (i)] = (double)t_;                                                                 \
+        }                                                                                                       \
+    } while (0)
+#else
+#define IPM_STAMP(i) do {} while (0)
+#endif
+
 __device__ __forceinline__ double block_reduce_sum(double v, double *red) {   // 256 threads, deterministic tree
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -421,13 +434,15 @@ __global__ __launch_bounds__(256) void k_ipm_step(const IpmBuf q) {
     const int b = blockIdx.x >> 1, which = blockIdx.x & 1;
     const IBlock k = q.blocks[b];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = k.n, n16 = (n + 15) & ~15, lda = n16 + 2;
-    double *Ls = lds, *Ws = Ls + lda * n16, *dinv = Ws + lda * n16, *dd = dinv + n16, *ee = dd + n16, *vv = ee + n16, *pp = vv + n16;
+    // Ws carries 8 extra zero columns and vv / pp are 72 long: the Householder loops run in unguarded chunks of 8
+    double *Ls = lds, *Ws = Ls + lda * n16, *dinv = Ws + lda * (n16 + 8), *dd = dinv + n16, *ee = dd + n16, *vv = ee + n16, *pp = vv + 72;
     const double *Mg = (which ? q.Y : q.X) + k.xyoff, *dMg = (which ? q.dY : q.dX) + k.xyoff;
     const int i16 = tid & 15, j16 = tid >> 4;
     if (n == 1) {
         if (tid == 0) q.eig[b * 2 + which] = dMg[0] / Mg[0];
         return;
     }
+    IPM_STAMP(0);
     // L = chol(M)
     for (int j0 = 0; j0 < n16; j0 += 16)
         for (int i0 = 0; i0 < n16; i0 += 16) {
@@ -435,15 +450,19 @@ __global__ __launch_bounds__(256) void k_ipm_step(const IpmBuf q) {
             Ls[i + j * lda] = (i < n && j < n) ? ((i >= j) ? Mg[i + (long long)j * n] : 0.0) : ((i == j) ? 1.0 : 0.0);
         }
     ipm_load(Ws, lda, dMg, n, n16, tid);
+    for (int e = tid; e < 8 * lda; e += 256) Ws[n16 * lda + e] = 0.0;
     __syncthreads();
+    IPM_STAMP(1);
     const bool bad = lds_potrf(Ls, lda, dinv, n, wave, 4, lane);
     if (bad && lane == 0) atomicMin(q.info + 1, 1000000 + b);          // Cholesky failed in the step length computation
     __syncthreads();
+    IPM_STAMP(2);
     // W = L^-1 dM L^-T: solve on the columns, then on the rows
     lds_trsm<false>(Ls, lda, dinv, Ws, 1, lda, n, n, wave, 4, lane);
     __syncthreads();
     lds_trsm<false>(Ls, lda, dinv, Ws, lda, 1, n, n, wave, 4, lane);
     __syncthreads();
+    IPM_STAMP(3);
     // symmetrise
     for (int j0 = 0; j0 < n; j0 += 16)
         for (int i0 = 0; i0 < n; i0 += 16) {
@@ -455,51 +474,71 @@ __global__ __launch_bounds__(256) void k_ipm_step(const IpmBuf q) {
             }
         }
     __syncthreads();
-    // Householder tridiagonalisation (unblocked, lower part authoritative but both triangles kept equal)
-    for (int c = 0; c < n - 2; c++) {
-        const int m = n - c - 1;                    // length of the column below the diagonal
-        double *xcol = Ws + (c + 1) + c * lda;
-        double ss = 0.0;
-        for (int i = tid; i < m; i += 256) ss += xcol[i] * xcol[i];
-        ss = block_reduce_sum(ss, red);
-        const double x0 = xcol[0];
-        const double nrm = sqrt(ss);
-        if (nrm == 0.0) {
-            if (tid == 0) ee[c] = 0.0;
-            __syncthreads();
-            continue;
+    IPM_STAMP(4);
+    // Householder tridiagonalisation inside ONE wave (n <= 64): lane i owns row c+1+i of the trailing matrix, the vector v and
+    // w go through LDS as broadcasts, the norms and dot products through wave butterflies -- no workgroup barriers in the
+    // n-2 dependent steps.  Both triangles of the trailing matrix are kept.
+    if (wave == 0) {
+        for (int c = 0; c < n - 2; c++) {
+            const int m = n - c - 1;                    // rows c+1 .. n-1 <-> lanes 0 .. m-1
+            const double xi = (lane < m) ? Ws[(c + 1 + lane) + c * lda] : 0.0;
+            const double ss = wave_sum(xi * xi);
+            const double x0 = readlane_f64(xi, 0);
+            const double nrm = sqrt(ss);
+            if (nrm == 0.0) {
+                if (lane == 0) ee[c] = 0.0;
+                continue;
+            }
+            const double alpha = (x0 > 0.0) ? -nrm : nrm;
+            const double v0 = x0 - alpha;
+            const double vi = (lane == 0) ? v0 : xi;
+            const double tau = 2.0 / (ss - x0 * x0 + v0 * v0);
+            vv[lane] = (lane < m) ? vi : 0.0;           // zero padded: the loops below run in unguarded chunks of 8
+            wave_sync();
+            double pi = 0.0;
+            const int m8 = (m + 7) & ~7;
+            if (lane < m) {
+                const double *row = Ws + (c + 1 + lane) + (c + 1) * lda;
+                for (int j0 = 0; j0 < m8; j0 += 8) {    // 16 independent LDS reads in flight per chunk
+                    double a[8], v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) { a[u] = row[(j0 + u) * lda]; v[u] = vv[j0 + u]; }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) pi += a[u] * v[u];
+                }
+                pi *= tau;
+            }
+            const double kk = wave_sum(pi * vi);
+            const double wi = pi - 0.5 * tau * kk * vi;
+            pp[lane] = (lane < m) ? wi : 0.0;
+            wave_sync();
+            if (lane < m) {
+                double *row = Ws + (c + 1 + lane) + (c + 1) * lda;
+                for (int j0 = 0; j0 < m8; j0 += 8) {
+                    double a[8], v[8], w[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) { a[u] = row[(j0 + u) * lda]; v[u] = vv[j0 + u]; w[u] = pp[j0 + u]; }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) row[(j0 + u) * lda] = a[u] - (vi * w[u] + wi * v[u]);
+                }
+            }
+            if (lane == 0) ee[c] = alpha;
+            wave_sync();
         }
-        const double alpha = (x0 > 0.0) ? -nrm : nrm;
-        const double v0 = x0 - alpha;
-        const double vnorm2 = ss - x0 * x0 + v0 * v0;   // ||v||^2
-        __syncthreads();
-        for (int i = tid; i < m; i += 256) vv[i] = (i == 0) ? v0 : xcol[i];
-        if (tid == 0) ee[c] = alpha;
-        __syncthreads();
-        const double tau = 2.0 / vnorm2;
-        // p = tau * A22 v
-        for (int i = tid; i < m; i += 256) {
-            double s = 0.0;
-            const double *row = Ws + (c + 1 + i) + (c + 1) * lda;
-            for (int j = 0; j < m; j++) s += row[j * lda] * vv[j];
-            pp[i] = tau * s;
-        }
-        __syncthreads();
-        double kk = 0.0;
-        for (int i = tid; i < m; i += 256) kk += pp[i] * vv[i];
-        kk = block_reduce_sum(kk, red);
-        const double K2 = 0.5 * tau * kk;
-        __syncthreads();
-        for (int i = tid; i < m; i += 256) pp[i] -= K2 * vv[i];   // w
-        __syncthreads();
-        for (int e = tid; e < m * m; e += 256) {
-            const int i = e % m, j = e / m;
-            Ws[(c + 1 + i) + (c + 1 + j) * lda] -= vv[i] * pp[j] + pp[i] * vv[j];
-        }
-        __syncthreads();
     }
+    __syncthreads();
+    IPM_STAMP(5);
     if (tid < n) dd[tid] = Ws[tid + tid * lda];
     if (tid == 0) ee[n - 2] = Ws[(n - 1) + (n - 2) * lda];
+    __syncthreads();
+    // squared off-diagonals and padding for the Sturm recurrence: steps beyond n see d = +huge, e = 0 and count nothing
+    {
+        double *d2 = vv, *e2s = pp;           // 72 doubles each, free after the tridiagonalisation
+        if (tid < 72) {
+            d2[tid] = (tid < n) ? dd[tid] : 1e300;
+            e2s[tid] = (tid >= 1 && tid < n) ? ee[tid - 1] * ee[tid - 1] : 0.0;
+        }
+    }
     __syncthreads();
     // Gershgorin interval
     double lo = 1e300, hi = -1e300;
@@ -514,17 +553,25 @@ __global__ __launch_bounds__(256) void k_ipm_step(const IpmBuf q) {
     const double scale = fmax(fabs(lo), fabs(hi));
     lo -= 1e-3 * scale + 1e-300;
     hi += 1e-3 * scale + 1e-300;
-    for (int round = 0; round < 8; round++) {
+    for (int round = 0; round < 7; round++) {      // 257^7 > 1e16: the bracket shrinks to rounding level
         const double h = (hi - lo) / 257.0;
         const double sft = lo + h * (tid + 1);
         int cnt = 0;
-        double qv = dd[0] - sft;
-        if (qv < 0.0) cnt++;
-        for (int i = 1; i < n; i++) {
-            const double e2 = ee[i - 1] * ee[i - 1];
-            if (qv == 0.0) qv = 1e-300 * (1.0 + fabs(sft));
-            qv = dd[i] - sft - e2 / qv;
-            if (qv < 0.0) cnt++;
+        double qv = vv[0] - sft;
+        cnt += (qv < 0.0) ? 1 : 0;
+        const int n8 = 1 + ((n - 1 + 7) & ~7);
+        for (int i0 = 1; i0 < n8; i0 += 8) {      // d and e^2 of 8 steps are fetched together, then the dependent chain runs from registers
+            double dv[8], e2[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { dv[u] = vv[i0 + u]; e2[u] = pp[i0 + u]; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                qv = (qv == 0.0) ? 1e-300 : qv;
+                double rq = __builtin_amdgcn_rcp(qv);              // v_rcp_f64 + one Newton step: ~1e-16 relative, a fraction of the cost
+                rq = __builtin_fma(__builtin_fma(-qv, rq, 1.0), rq, rq);   // of an IEEE division; only the SIGN of the pivots is used
+                qv = dv[u] - sft - e2[u] * rq;
+                cnt += (qv < 0.0) ? 1 : 0;
+            }
         }
         cnts[tid + 1] = cnt;
         if (tid == 0) cnts[0] = 0;
@@ -537,6 +584,7 @@ __global__ __launch_bounds__(256) void k_ipm_step(const IpmBuf q) {
         hi = sh_hi;
         __syncthreads();
     }
+    IPM_STAMP(6);
     if (tid == 0) q.eig[b * 2 + which] = 0.5 * (lo + hi);
 }
 

@@ -23,6 +23,34 @@ __device__ __forceinline__ double bcast16(double v) {
     return __longlong_as_double(x);
 }
 
+// ordering point for the LDS traffic of ONE wave (no other wave involved): LDS operations of a wave complete in issue
+// order, this only stops the compiler from moving them across
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// Sum over the 64 lanes, the same value (bitwise) in every lane.  DPP row shifts inside the 16-lane rows (lanes shifted in
+// from outside a row read 0), then the four row totals through v_readlane: ~25 short instructions.  (__shfl_xor on a
+// double lowers to two ds_bpermute per step: ~700 cycles for the same reduction.)
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_zero(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+__device__ __forceinline__ double wave_sum(double v) {
+    v += dpp_mov_zero<0x111>(v);   // row_shr:1
+    v += dpp_mov_zero<0x112>(v);   // row_shr:2
+    v += dpp_mov_zero<0x114>(v);   // row_shr:4
+    v += dpp_mov_zero<0x118>(v);   // row_shr:8   -> lane 15 of every row holds the row total
+    return (readlane_f64(v, 15) + readlane_f64(v, 31)) + (readlane_f64(v, 47) + readlane_f64(v, 63));
+}
+
 // ---- small MFMA GEMM on LDS operands:  C[i,j] = sum_k A[k,i] B[k,j]  (i < M, j < N, k < K) -------------------------
 // A: K x M (ld lda), B: K x N (ld ldb), C: M x N (ld ldc).  Rows k >= K of A/B up to ceil4(K) and columns up to
 // ceil16(M)/ceil16(N) must be readable and ZERO.  Tiles of 16 x 16 are dealt to the waves of the workgroup.

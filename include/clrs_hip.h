@@ -181,6 +181,7 @@ int clrs_ipm_set_params(clrs_ctx *ctx, const clrs_ipm_params *params);
 int clrs_ipm_init(clrs_ctx *ctx, double omega_p, double omega_d);            /* x = y = 0, X = omega_p I, Y = omega_d I */
 int clrs_ipm_iterate(clrs_ctx *ctx, clrs_ipm_record *out);                   /* one iteration; error_code 0 / 1 / 3 / 4 as docs/src/solving.md:64-70 */
 int clrs_ipm_get(clrs_ctx *ctx, double *x, double *y, double *X, double *Y); /* copy the iterate to the host (any pointer may be NULL) */
+int clrs_ipm_debug(clrs_ctx *ctx, double out[32]);                           /* diagnostic builds only: kernel phase stamps */
 
 /* Timings of the last assemble/factor calls in seconds, measured with HIP events on the context
  * stream: t[0..4] = schur, cholS, LinvB, Q, cholQ -- the 5-way split compute_T_decomposition!
