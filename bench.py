@@ -307,7 +307,7 @@ def main():
         # HBM traffic of that launch from the committed PMC passes (rocprofv3 cannot run inside this process)
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[bdom[0]]
-            if tr["workgroups"] == big.n_clusters:
+            if tr.get("clusters") == big.n_clusters:
                 out["roofline"]["traffic"] = tr["traffic_bytes"]
                 out["roofline"]["traffic_source"] = tr["source"]
         except Exception:

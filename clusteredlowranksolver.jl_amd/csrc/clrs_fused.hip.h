@@ -762,3 +762,235 @@ __global__ __launch_bounds__(512) void k_cluster_assemble_w1(const WCluster *__r
 }
 
 }  // namespace clrs
+
+namespace clrs {
+
+// =====================================================================================================================
+// k_cluster_assemble_w2: ONE WAVE PER CLUSTER, S accumulated in registers
+// =====================================================================================================================
+// When every low-rank block of a cluster is "simple" (see k_cluster_assemble_w1) AND they all use the same constraint
+// order (vector u of every block belongs to constraint pmap[u], U = P) AND the dense blocks are 1 x 1 -- the Cohn-Elkies,
+// Delsarte and univariate polynomial-optimisation clusters -- the Hadamard products of all blocks land on the same lanes:
+// the S tiles stay in registers across the blocks, there is no slab, no barrier and no reduction, and LDS holds only V and
+// T_Y of the block in flight (8.7 KB per wave for U <= 32), so 12-16 waves per CU overlap each other's memory latency.
+// Z = L^-1 V is formed as (L^-1) V: the 16 x 16 inverse by the DPP substitution on the identity (two passes instead of
+// U/8), then MFMA.  S_j is staged through the (then free) LDS area for a coalesced store when it fits.
+struct W2Block {
+    int kind;            // 0: simple low-rank block, 1: dense 1 x 1 block
+    int n, pad0, pad1;
+    long long xyoff;     // offset of the block in the X/Y layout
+    long long v_off;     // static arena: vectors n x U (ld n)
+    const double *lam;   // [U] lambda of the term of vector u / dense: the 1 x 1 matrix entry of constraint pmap[u] (0 when absent)
+    const int *ay;       // [U] position of the term in the A_Y output (low rank only)
+};
+struct W2Cluster {
+    double *S;
+    const int *pmap;     // [U] constraint index of vector u, a permutation of 0..P-1
+    int P, nblk;
+    long long blk0;      // first block of the cluster in the block table
+};
+
+template <int UT>   // P = U <= 16 * UT
+__global__ __launch_bounds__(256) void k_cluster_assemble_w2(const W2Cluster *__restrict__ clusters, const W2Block *__restrict__ blocks, const FTables tb,
+                                                             int nclusters) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
+    const int ci = blockIdx.x * 4 + wave;
+    if (ci >= nclusters) return;                 // no workgroup barrier anywhere in this kernel
+    const W2Cluster cl = clusters[ci];
+    constexpr int LD = 17, WORK = 2 * LD * 16 * UT;
+    double *work = lds + (size_t)wave * WORK;
+    double *Vs = work, *TYs = work + LD * 16 * UT;
+    const int P = cl.P, U = P;
+    constexpr int NT = UT * (UT + 1) / 2;
+    v4d_f sacc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) sacc[t] = (v4d_f){0.0, 0.0, 0.0, 0.0};
+
+    for (int b = 0; b < cl.nblk; b++) {
+        wave_sync();
+        const W2Block k = blocks[cl.blk0 + b];
+        const double *Lg = tb.Xc + k.xyoff, *Yg = tb.Y + k.xyoff;
+        double lam_r[UT], lam_c[UT * 4];
+        if (k.kind == 1) {
+            // 1 x 1 dense block: S[p_u, p_v] += a_u a_v Y / X, X = L^2
+            const double Lx = Lg[0], ratio = Yg[0] / (Lx * Lx);
+#pragma unroll
+            for (int t = 0; t < UT; t++) {
+                const int u = t * 16 + l15;
+                lam_r[t] = (u < U) ? k.lam[u] : 0.0;
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++) {
+                    const int v = t * 16 + l4 + 4 * reg;
+                    lam_c[t * 4 + reg] = (v < U) ? k.lam[v] : 0.0;
+                }
+            }
+#pragma unroll
+            for (int ti = 0; ti < UT; ti++)
+#pragma unroll
+                for (int tj = 0; tj <= ti; tj++)
+#pragma unroll
+                    for (int reg = 0; reg < 4; reg++) sacc[ti * (ti + 1) / 2 + tj][reg] += (lam_r[ti] * lam_c[tj * 4 + reg]) * ratio;
+            continue;
+        }
+        const int n = k.n;
+        const double *Vg = tb.stat + k.v_off;
+        // ---- all global loads of the block ----
+        double yop[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int kk = 4 * q + l4;
+            yop[q] = (kk < n && l15 < n) ? Yg[kk + l15 * n] : 0.0;
+        }
+        double *Lt = TYs;                       // strictly lower part of L_X, staged for the row reads
+        double *tl = TYs + LD * 16;
+        int *tay = (int *)(tl + 16 * UT);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int col = 4 * q + l4;
+            Lt[l15 + col * LD] = (l15 < n && col < l15) ? Lg[l15 + col * n] : 0.0;
+        }
+        const double dg = (l15 < n) ? Lg[l15 * (n + 1)] : 1.0;
+        for (int u = lane; u < 16 * UT; u += 64) {
+            tl[u] = (u < U) ? k.lam[u] : 0.0;
+            tay[u] = (u < U) ? k.ay[u] : 0;
+        }
+#pragma unroll
+        for (int c0 = 0; c0 < 16 * UT; c0 += 4) {
+            const int col = c0 + l4;
+            Vs[l15 + col * LD] = (l15 < n && col < U) ? Vg[l15 + col * n] : 0.0;
+        }
+        const double di = (l15 < n) ? 1.0 / dg : 0.0;
+        wave_sync();
+        double Lr[16];
+        int ay_r[UT];
+#pragma unroll
+        for (int c = 0; c < 16; c++) Lr[c] = Lt[l15 + c * LD];
+#pragma unroll
+        for (int t = 0; t < UT; t++) {
+            const int u = t * 16 + l15;
+            lam_r[t] = tl[u];
+            ay_r[t] = tay[u];
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) lam_c[t * 4 + reg] = tl[t * 16 + l4 + 4 * reg];
+        }
+        wave_sync();
+        // ---- T_Y = Y V ----
+#pragma unroll
+        for (int tj = 0; tj < UT; tj++) {
+            v4d_f acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < 4; q++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Vs[(4 * q + l4) + (tj * 16 + l15) * LD], yop[q], acc, 0, 0, 0);
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) TYs[l15 + (tj * 16 + l4 + 4 * reg) * LD] = acc[reg];
+        }
+        wave_sync();
+        // ---- lower tiles of G_Y = V^T T_Y in registers ----
+        v4d_f gy[NT];
+#pragma unroll
+        for (int ti = 0; ti < UT; ti++)
+#pragma unroll
+            for (int tj = 0; tj <= ti; tj++) {
+                v4d_f acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(TYs[(4 * q + l4) + (tj * 16 + l15) * LD], Vs[(4 * q + l4) + (ti * 16 + l15) * LD], acc, 0, 0, 0);
+                gy[ti * (ti + 1) / 2 + tj] = acc;
+            }
+#pragma unroll
+        for (int t = 0; t < UT; t++)
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+                const int u = t * 16 + l15;
+                if (l15 == l4 + 4 * reg && u < U) tb.AY[ay_r[t]] = gy[t * (t + 1) / 2 + t][reg];
+            }
+        wave_sync();
+        // ---- W = L^-1 by substitution on the identity (16 columns = 4 groups = 2 passes), stored TRANSPOSED over T_Y ----
+        double *Wt = TYs;                        // Wt[k + i * LD] = W[i, k]
+        {
+            double x0 = (l15 == l4) ? 1.0 : 0.0, x1 = (l15 == 4 + l4) ? 1.0 : 0.0;       // columns l4 and 4 + l4 of I
+            Trsm16<0>::run(x0, x1, Lr, di);
+            Wt[l4 + l15 * LD] = x0 * di;
+            Wt[(4 + l4) + l15 * LD] = x1 * di;
+            x0 = (l15 == 8 + l4) ? 1.0 : 0.0;
+            x1 = (l15 == 12 + l4) ? 1.0 : 0.0;
+            Trsm16<0>::run(x0, x1, Lr, di);
+            Wt[(8 + l4) + l15 * LD] = x0 * di;
+            Wt[(12 + l4) + l15 * LD] = x1 * di;
+        }
+        wave_sync();
+        // ---- Z = W V (MFMA), in registers first (V is both source and destination) ----
+        v4d_f zt[UT];
+#pragma unroll
+        for (int tj = 0; tj < UT; tj++) {
+            v4d_f acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < 4; q++)   // Z[i, j] = sum_k Wt[k, i] V[k, j]
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Vs[(4 * q + l4) + (tj * 16 + l15) * LD], Wt[(4 * q + l4) + l15 * LD], acc, 0, 0, 0);
+            zt[tj] = acc;
+        }
+        wave_sync();
+#pragma unroll
+        for (int tj = 0; tj < UT; tj++)
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) Vs[l15 + (tj * 16 + l4 + 4 * reg) * LD] = zt[tj][reg];
+        wave_sync();
+        // ---- G_X = Z^T Z tile by tile, Hadamard with G_Y, scale, accumulate in registers ----
+#pragma unroll
+        for (int ti = 0; ti < UT; ti++)
+#pragma unroll
+            for (int tj = 0; tj <= ti; tj++) {
+                v4d_f acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Vs[(4 * q + l4) + (tj * 16 + l15) * LD], Vs[(4 * q + l4) + (ti * 16 + l15) * LD], acc, 0, 0, 0);
+                const v4d_f g = gy[ti * (ti + 1) / 2 + tj];
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++) sacc[ti * (ti + 1) / 2 + tj][reg] += (lam_r[ti] * lam_c[tj * 4 + reg]) * (acc[reg] * g[reg]);
+            }
+    }
+    wave_sync();
+    // ---- S_j: u >= v computed, mirrored.  Through LDS for coalesced stores when P (P|1) fits in the work area. ----
+    int pm_r[UT], pm_c[UT * 4];
+#pragma unroll
+    for (int t = 0; t < UT; t++) {
+        const int u = t * 16 + l15;
+        pm_r[t] = (u < U) ? cl.pmap[u] : 0;
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const int v = t * 16 + l4 + 4 * reg;
+            pm_c[t * 4 + reg] = (v < U) ? cl.pmap[v] : 0;
+        }
+    }
+    const int PS = P | 1;
+    const bool via_lds = P * PS <= WORK;
+#pragma unroll
+    for (int ti = 0; ti < UT; ti++)
+#pragma unroll
+        for (int tj = 0; tj <= ti; tj++)
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+                const int u = ti * 16 + l15, v = tj * 16 + l4 + 4 * reg;
+                if (u < U && v < U && u >= v) {
+                    const double s = sacc[ti * (ti + 1) / 2 + tj][reg];
+                    const int p = pm_r[ti], q2 = pm_c[tj * 4 + reg];
+                    if (via_lds) {
+                        work[p + q2 * PS] = s;
+                        work[q2 + p * PS] = s;
+                    } else {
+                        cl.S[p + (long long)q2 * P] = s;
+                        cl.S[q2 + (long long)p * P] = s;
+                    }
+                }
+            }
+    if (via_lds) {
+        wave_sync();
+        for (int j = l4; j < P; j += 4)
+            for (int i0 = 0; i0 < P; i0 += 16) {
+                const int i = i0 + l15;
+                if (i < P) cl.S[i + (long long)j * P] = work[i + j * PS];
+            }
+    }
+}
+
+}  // namespace clrs

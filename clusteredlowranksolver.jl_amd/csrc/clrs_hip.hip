@@ -47,15 +47,16 @@ static const int INFO_NONE = 0x7f7f7f7f;
 static int g_cfg_fused_assemble = 1;
 static int g_cfg_fused_factor = 1;
 static int g_cfg_wave_assemble = 1;
+static int g_cfg_wave2_assemble = 1;
 static const int LDS_BUDGET_DOUBLES = 20000;   // of the 20480 doubles (160 KiB) a workgroup may claim
 
 // ------------------------------------------------------------------------------------------------
 // launch plan
 // ------------------------------------------------------------------------------------------------
-enum StepKind { STEP_MEMCPY, STEP_GEMM, STEP_TRSM, STEP_POTRF, STEP_GATHER_S, STEP_GATHER_SCALAR, STEP_SUB, STEP_MEMSET_INFO, STEP_ZERO_UPPER, STEP_FUSED_ASSEMBLE, STEP_SMALL_POTRF, STEP_CLUSTER_FACTOR, STEP_GEMV_T, STEP_CSOLVE_FWD, STEP_Q_SOLVE, STEP_CSOLVE_BWD, STEP_SUM_SLABS, STEP_ASSEMBLE_W1, STEP_GRAM_SMALL, STEP_NKINDS };
+enum StepKind { STEP_MEMCPY, STEP_GEMM, STEP_TRSM, STEP_POTRF, STEP_GATHER_S, STEP_GATHER_SCALAR, STEP_SUB, STEP_MEMSET_INFO, STEP_ZERO_UPPER, STEP_FUSED_ASSEMBLE, STEP_SMALL_POTRF, STEP_CLUSTER_FACTOR, STEP_GEMV_T, STEP_CSOLVE_FWD, STEP_Q_SOLVE, STEP_CSOLVE_BWD, STEP_SUM_SLABS, STEP_ASSEMBLE_W1, STEP_GRAM_SMALL, STEP_ASSEMBLE_W2, STEP_NKINDS };
 static const char *const STEP_NAMES[STEP_NKINDS] = {"hipMemcpyAsync(D2D)", "k_gemm_f64_t", "k_trsm_diag", "k_potrf_diag", "k_schur_gather",
                                                     "k_gather_scalar", "k_sub", "hipMemsetAsync", "k_zero_upper", "k_cluster_assemble", "k_small_potrf", "k_cluster_factor", "k_gemv_t",
-                                                    "k_cluster_solve_fwd", "k_q_solve", "k_cluster_solve_bwd", "k_sum_slabs", "k_cluster_assemble_w1", "k_gram_small"};
+                                                    "k_cluster_solve_fwd", "k_q_solve", "k_cluster_solve_bwd", "k_sum_slabs", "k_cluster_assemble_w1", "k_gram_small", "k_cluster_assemble_w2"};
 static const int KT_MAX_EVENTS = 8192;   // event pairs kept between two clrs_get_kernel_times calls
 
 struct Step {
@@ -156,7 +157,7 @@ struct clrs_ctx {
     bool times_pending = false, solve_time_pending = false;
     double cnt_bytes = 0, cnt_flops = 0, cnt_factor_flops = 0, cnt_solve_flops = 0;
     std::vector<char> cluster_fused;         // per cluster: assembled by the fused kernel
-    int n_fused_clusters = 0, n_wave_clusters = 0;
+    int n_fused_clusters = 0, n_wave_clusters = 0, n_wave2_clusters = 0;
     std::vector<int> host_UR, host_UL;       // flattened per (block, r) for clrs_get_unique_counts
     std::vector<i64> host_U_off;
 };
@@ -382,6 +383,15 @@ static int run_steps(clrs_ctx *c, const Plan &pl) {
                     hipLaunchKernelGGL(k_cluster_assemble<32>, dim3(s.grid), dim3(256), s.bytes, st, (const FCluster *)s.d0, (const FBlock *)s.d1, *tb);
                 else
                     hipLaunchKernelGGL(k_cluster_assemble<64>, dim3(s.grid), dim3(256), s.bytes, st, (const FCluster *)s.d0, (const FBlock *)s.d1, *tb);
+                break;
+            }
+            case STEP_ASSEMBLE_W2: {
+                const FTables *tb = (const FTables *)s.src;
+                const int ncl = (int)s.n;
+                if (s.nmax <= 2)
+                    hipLaunchKernelGGL(k_cluster_assemble_w2<2>, dim3((ncl + 3) / 4), dim3(256), s.bytes, st, (const W2Cluster *)s.d0, (const W2Block *)s.d1, *tb, ncl);
+                else
+                    hipLaunchKernelGGL(k_cluster_assemble_w2<4>, dim3((ncl + 3) / 4), dim3(256), s.bytes, st, (const W2Cluster *)s.d0, (const W2Block *)s.d1, *tb, ncl);
                 break;
             }
             case STEP_ASSEMBLE_W1: {
@@ -699,6 +709,12 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
     std::vector<double> w_lam;
     std::vector<size_t> w_ioff;       // per WBlock: offset of its pmap / lam / ay entries in the packed arrays
     std::vector<size_t> w_cl_first;   // per WCluster: its first WBlock
+    std::vector<W2Cluster> w2cl;      // cluster-per-wave kernel
+    std::vector<W2Block> w2bl;
+    std::vector<int> w2_pmap, w2_ay;
+    std::vector<double> w2_lam;
+    std::vector<size_t> w2_cl_pm, w2_boff;
+    int w2_ut = 0;
     int w_ut = 0, w_nwaves = 8, w_maxblocks = 0;
     size_t w_cluster_doubles = 0;
     if (g_cfg_fused_assemble && g_cfg_wave_assemble) {
@@ -761,6 +777,59 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
                 w_pmap.resize(keep_pm); w_lam.resize(keep_lam); w_ay.resize(keep_ay);
                 continue;
             }
+            // cluster-per-wave kernel: every low-rank block uses the same constraint order (U = P) and the dense blocks are 1 x 1
+            // (throughput form: one wave walks the blocks of its cluster one after the other, so it is chosen when there are enough
+            // clusters to fill the chip -- "wave2_assemble" = 1: automatic (>= 64 clusters), 2: always, 0: never)
+            if ((g_cfg_wave2_assemble == 2 || (g_cfg_wave2_assemble == 1 && J >= 64)) && utr <= 4) {
+                const int Pj = c->P[j];
+                bool w2 = true;
+                const int *pm0 = nullptr;
+                for (size_t i2 = 0; i2 < mine.size() && w2; i2++) {
+                    const WBlock &wb = mine[i2];
+                    if (wb.kind == 0) {
+                        const int *pm = w_pmap.data() + mine_off[i2];
+                        if (wb.U != Pj) w2 = false;
+                        else if (!pm0) pm0 = pm;
+                        else if (std::memcmp(pm, pm0, sizeof(int) * Pj) != 0) w2 = false;
+                    } else if (wb.n != 1) w2 = false;
+                }
+                if (w2 && pm0) {
+                    std::vector<int> inv(Pj, -1);
+                    for (int u = 0; u < Pj; u++) inv[pm0[u]] = u;
+                    W2Cluster wc2;
+                    std::memset(&wc2, 0, sizeof(wc2));
+                    wc2.S = c->d_S + c->Soff[j]; wc2.P = Pj; wc2.nblk = (int)mine.size(); wc2.blk0 = (i64)w2bl.size();
+                    w2_cl_pm.push_back(w2_pmap.size());
+                    w2_pmap.insert(w2_pmap.end(), pm0, pm0 + Pj);
+                    int bsel = b_first;
+                    for (size_t i2 = 0; i2 < mine.size(); i2++) {
+                        const WBlock &wb = mine[i2];
+                        W2Block q2;
+                        std::memset(&q2, 0, sizeof(q2));
+                        q2.kind = wb.kind; q2.n = wb.n; q2.xyoff = wb.xyoff; q2.v_off = wb.v_off;
+                        w2_boff.push_back(w2_lam.size());
+                        if (wb.kind == 0) {
+                            w2_lam.insert(w2_lam.end(), w_lam.begin() + mine_off[i2], w_lam.begin() + mine_off[i2] + Pj);
+                            w2_ay.insert(w2_ay.end(), w_ay.begin() + mine_off[i2], w_ay.begin() + mine_off[i2] + Pj);
+                        } else {
+                            // locate the BlockInfo of this dense block to read its 1 x 1 matrices
+                            while (!(c->blk[bsel].kind != 0 && c->blk[bsel].xyoff == wb.xyoff)) bsel++;
+                            const BlockInfo &kb = c->blk[bsel];
+                            std::vector<double> a(Pj, 0.0);
+                            for (i64 e = kb.d0; e < kb.d1; e++) a[inv[d->dense_p[e]]] = d->dense_A[d->dense_A_ptr[e]];
+                            w2_lam.insert(w2_lam.end(), a.begin(), a.end());
+                            w2_ay.insert(w2_ay.end(), Pj, 0);
+                        }
+                        w2bl.push_back(q2);
+                    }
+                    w2cl.push_back(wc2);
+                    w2_ut = std::max(w2_ut, utr);
+                    c->cluster_fused[j] = 3;
+                    for (int bb = b_first; bb < b; bb++) c->blk[bb].fused = true;
+                    w_pmap.resize(keep_pm); w_lam.resize(keep_lam); w_ay.resize(keep_ay);
+                    continue;
+                }
+            }
             WCluster wc;
             std::memset(&wc, 0, sizeof(wc));
             wc.S = c->d_S + c->Soff[j]; wc.P = c->P[j]; wc.nblk = (int)mine.size(); wc.work_doubles = work;
@@ -774,12 +843,13 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
             w_maxblocks = std::max(w_maxblocks, nblk);
             w_cluster_doubles = std::max(w_cluster_doubles, (size_t)per_wave);
         }
-        w_nwaves = std::max(1, std::min(w_nwaves, w_maxblocks));
+        w_nwaves = std::max(1, std::min(w_nwaves, std::max(w_maxblocks, 1)));
         for (WCluster &wc : wcl) wc.work_doubles = (int)(w_cluster_doubles - (size_t)wc.P * (wc.P | 1));   // one slab + work stride for all clusters
         // a cluster whose own P^2 + work is smaller still gets the common stride; re-check the budget with it
         if ((i64)w_nwaves * (i64)w_cluster_doubles > LDS_BUDGET_DOUBLES) w_nwaves = std::max(1, (int)(LDS_BUDGET_DOUBLES / (i64)w_cluster_doubles));
     }
     c->n_wave_clusters = (int)wcl.size();
+    c->n_wave2_clusters = (int)w2cl.size();
     std::vector<FCluster> fcl;
     std::vector<FBlock> fbl;
     int fused_nmax = 0;
@@ -846,7 +916,7 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
             fused_lds = std::max(fused_lds, (size_t)o * sizeof(double));
         }
     }
-    c->n_fused_clusters = (int)fcl.size() + (int)wcl.size();
+    c->n_fused_clusters = (int)fcl.size() + (int)wcl.size() + (int)w2cl.size();
     for (int b = 0; b < NB; b++)
         if (c->blk[b].fused && c->blk[b].kind == 0)
             for (i64 t = c->blk[b].t0; t < c->blk[b].t1; t++) h_ayidx[t] = -1;   // written by the fused kernel
@@ -964,6 +1034,21 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
             s.kind = STEP_GATHER_SCALAR;
             s.dst = c->d_AY; s.src = c->d_G; s.d0 = c->d_ayidx; s.n = T;
             pl.steps.push_back(s);
+        }
+        if (!w2cl.empty()) {
+            int *dpm, *day; double *dlam;
+            CK(upload(c, w2_pmap, &dpm)); CK(upload(c, w2_ay, &day)); CK(upload(c, w2_lam, &dlam));
+            for (size_t i2 = 0; i2 < w2bl.size(); i2++) { w2bl[i2].lam = dlam + w2_boff[i2]; w2bl[i2].ay = day + w2_boff[i2]; }
+            for (size_t i2 = 0; i2 < w2cl.size(); i2++) w2cl[i2].pmap = dpm + w2_cl_pm[i2];
+            W2Cluster *dwc; W2Block *dwb;
+            CK(upload(c, w2cl, &dwc)); CK(upload(c, w2bl, &dwb));
+            c->ftables.Xc = c->d_Xc; c->ftables.Y = c->d_Y; c->ftables.stat = c->d_static; c->ftables.AY = c->d_AY;
+            Step s;
+            s.kind = STEP_ASSEMBLE_W2;
+            s.d0 = dwc; s.d1 = dwb; s.src = &c->ftables; s.n = (i64)w2cl.size(); s.nmax = w2_ut;
+            s.bytes = (size_t)4 * 2 * 17 * 16 * w2_ut * sizeof(double);
+            pl.steps.push_back(s);
+            if (s.bytes > 64 * 1024) HIPCK(hipFuncSetAttribute((const void *)k_cluster_assemble_w2<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s.bytes));
         }
         if (!wcl.empty()) {
             int *dpm, *day; double *dlam;
@@ -1625,6 +1710,7 @@ extern "C" int clrs_config_set(const char *key, int value) {
     if (!std::strcmp(key, "fused_assemble")) { g_cfg_fused_assemble = value; return 0; }
     if (!std::strcmp(key, "fused_factor")) { g_cfg_fused_factor = value; return 0; }
     if (!std::strcmp(key, "wave_assemble")) { g_cfg_wave_assemble = value; return 0; }
+    if (!std::strcmp(key, "wave2_assemble")) { g_cfg_wave2_assemble = value; return 0; }
     return fail(CLRS_ERR_INVALID, std::string("unknown configuration key ") + key);
 }
 
@@ -1637,7 +1723,8 @@ extern "C" int clrs_debug_stamps(clrs_ctx *c, uint64_t out[64]) {
 }
 
 extern "C" int clrs_fused_clusters(const clrs_ctx *c) { return c ? c->n_fused_clusters : 0; }
-extern "C" int clrs_wave_clusters(const clrs_ctx *c) { return c ? c->n_wave_clusters : 0; }
+extern "C" int clrs_wave_clusters(const clrs_ctx *c) { return c ? c->n_wave_clusters + c->n_wave2_clusters : 0; }
+extern "C" int clrs_wave2_clusters(const clrs_ctx *c) { return c ? c->n_wave2_clusters : 0; }
 
 extern "C" const char *clrs_kernel_name(int kind) { return (kind >= 0 && kind < STEP_NKINDS) ? STEP_NAMES[kind] : ""; }
 

@@ -47,7 +47,7 @@ class SchurContext:
     src/solver.jl:298-317 -- all device resident."""
 
     def __init__(self, sdp, device: int = 0, graph: bool = False, timing: bool = False, fused: Optional[bool] = None,
-                 wave: Optional[bool] = None):
+                 wave: Optional[bool] = None, wave2: Optional[bool] = None):
         """`fused=False` forces the staged grouped-GEMM / blocked-BLAS path everywhere (default: clusters that fit in
         one CU's LDS take the fused per-cluster assembly, factor and solve kernels).  `wave=False` keeps the
         fused assembly on the 4-waves-per-block kernel even where the wave-per-block kernel applies."""
@@ -59,6 +59,8 @@ class SchurContext:
             _lib.check(self.L.clrs_config_set(b"fused_factor", int(bool(fused))))
         if wave is not None:
             _lib.check(self.L.clrs_config_set(b"wave_assemble", int(bool(wave))))
+        if wave2 is not None:
+            _lib.check(self.L.clrs_config_set(b"wave2_assemble", 2 if wave2 else 0))
         k = self._keep = {}
 
         def hold(name, arr, dt):
@@ -84,6 +86,8 @@ class SchurContext:
                 self.L.clrs_config_set(b"fused_factor", 1)
             if wave is not None:
                 self.L.clrs_config_set(b"wave_assemble", 1)
+            if wave2 is not None:
+                self.L.clrs_config_set(b"wave2_assemble", 1)
         self.h = h
         self.device = device
         if graph:
@@ -124,6 +128,10 @@ class SchurContext:
     def wave_clusters(self) -> int:
         """Number of clusters assembled with one wave per PSD block (k_cluster_assemble_w1)."""
         return int(self.L.clrs_wave_clusters(self.h))
+
+    def wave2_clusters(self) -> int:
+        """Number of clusters assembled by one wave per cluster with S in registers (k_cluster_assemble_w2)."""
+        return int(self.L.clrs_wave2_clusters(self.h))
 
     def high_ranks(self) -> List[bool]:
         """`high_ranks[j][l]` flattened over blocks (src/solver.jl:1000)."""

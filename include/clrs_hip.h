@@ -214,6 +214,10 @@ int clrs_fused_clusters(const clrs_ctx *ctx);
 /* "wave_assemble" (default 1): among those, clusters made only of simple rank-1 blocks with n <= 16 and small dense
  * blocks are assembled with one wave per PSD block (k_cluster_assemble_w1); clrs_wave_clusters counts them. */
 int clrs_wave_clusters(const clrs_ctx *ctx);
+/* "wave2_assemble" (default 1 = automatic: contexts with >= 64 clusters; 2 = always; 0 = never): of those, clusters whose
+ * low-rank blocks all use the same constraint order (and whose dense blocks are 1 x 1) are assembled by ONE wave per cluster
+ * with S in registers (k_cluster_assemble_w2): higher throughput, but the blocks of a cluster are walked one after the other. */
+int clrs_wave2_clusters(const clrs_ctx *ctx);
 /* Diagnostic builds (-DCLRS_FUSED_STAMPS) only: s_memtime stamps of the phases of workgroup 0 of the fused kernel. */
 int clrs_debug_stamps(clrs_ctx *ctx, uint64_t out[64]);
 

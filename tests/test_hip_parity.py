@@ -65,7 +65,9 @@ ASSEMBLE_CASES = ["x2p1", "polyopt8", "polyopt40", "delsarte_3_10", "delsarte_8_
                   "threepoint_4", "sdpa_small", "sdpa_mid", "polyopt_scaled_100"]
 
 
-PATHS = {"wave": dict(fused=True, wave=True), "fused": dict(fused=True, wave=False), "staged": dict(fused=False)}
+PATHS = {"wave2": dict(fused=True, wave=True, wave2=True), "wave": dict(fused=True, wave=True, wave2=False), "fused": dict(fused=True, wave=False),
+         "staged": dict(fused=False)}
+WAVE2_CASES = {"x2p1": 1, "polyopt8": 1, "delsarte_8_3": 0, "ce_8_15": 2, "ce_8_3": 2}    # clusters taken by k_cluster_assemble_w2
 WAVE_CASES = {"x2p1", "polyopt8", "delsarte_3_10", "delsarte_8_3", "ce_8_15", "ce_8_3", "sdpa_small"}   # every cluster takes k_cluster_assemble_w1
 
 
@@ -80,9 +82,13 @@ def test_schur_assemble_matches_oracle(name, path, oracle_built):
     ctx = SchurContext(f, **PATHS[path])
     fused = path != "staged"
     assert (ctx.fused_clusters() > 0) == (fused and name not in ("sdpa_mid", "polyopt_scaled_100"))
-    if path == "wave" and name in WAVE_CASES:
+    if path in ("wave", "wave2") and name in WAVE_CASES:
         assert ctx.wave_clusters() == f.n_clusters
-    if path != "wave":
+    if path == "wave2" and name in WAVE2_CASES:
+        assert ctx.wave2_clusters() == WAVE2_CASES[name]
+    if path == "wave":
+        assert ctx.wave2_clusters() == 0
+    if path in ("fused", "staged"):
         assert ctx.wave_clusters() == 0
     S, AY = ctx.compute_S_integrated(Xc, Y)
     o = Oracle(f, quad=True, use_lo=False)
