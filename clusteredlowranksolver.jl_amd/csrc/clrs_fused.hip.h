@@ -790,7 +790,9 @@ struct W2Cluster {
     long long blk0;      // first block of the cluster in the block table
 };
 
-template <int UT>   // P = U <= 16 * UT
+// FULL: every low-rank block has n == 16 and U == 16 * UT exactly (Cohn-Elkies 2d = 30: n = 16, U = 32): no tile is partial, so
+// every bounds predicate folds away at compile time -- a third of the VALU / SALU instructions of the issue-bound loop.
+template <int UT, bool FULL>   // P = U <= 16 * UT
 __global__ __launch_bounds__(256) void k_cluster_assemble_w2(const W2Cluster *__restrict__ clusters, const W2Block *__restrict__ blocks, const FTables tb,
                                                              int nclusters) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -801,7 +803,7 @@ __global__ __launch_bounds__(256) void k_cluster_assemble_w2(const W2Cluster *__
     constexpr int LD = 17, WORK = 2 * LD * 16 * UT;
     double *work = lds + (size_t)wave * WORK;
     double *Vs = work, *TYs = work + LD * 16 * UT;
-    const int P = cl.P, U = P;
+    const int P = FULL ? 16 * UT : cl.P, U = P;
     constexpr int NT = UT * (UT + 1) / 2;
     v4d_f sacc[NT];
 #pragma unroll
@@ -833,7 +835,7 @@ __global__ __launch_bounds__(256) void k_cluster_assemble_w2(const W2Cluster *__
                     for (int reg = 0; reg < 4; reg++) sacc[ti * (ti + 1) / 2 + tj][reg] += (lam_r[ti] * lam_c[tj * 4 + reg]) * ratio;
             continue;
         }
-        const int n = k.n;
+        const int n = FULL ? 16 : k.n;
         const double *Vg = tb.stat + k.v_off;
         // ---- all global loads of the block ----
         double yop[4];

@@ -388,10 +388,13 @@ static int run_steps(clrs_ctx *c, const Plan &pl) {
             case STEP_ASSEMBLE_W2: {
                 const FTables *tb = (const FTables *)s.src;
                 const int ncl = (int)s.n;
-                if (s.nmax <= 2)
-                    hipLaunchKernelGGL(k_cluster_assemble_w2<2>, dim3((ncl + 3) / 4), dim3(256), s.bytes, st, (const W2Cluster *)s.d0, (const W2Block *)s.d1, *tb, ncl);
+                const bool full = s.grid != 0;      // every low-rank block is exactly 16 x (16 UT)
+                if (s.nmax <= 2 && full)
+                    hipLaunchKernelGGL((k_cluster_assemble_w2<2, true>), dim3((ncl + 3) / 4), dim3(256), s.bytes, st, (const W2Cluster *)s.d0, (const W2Block *)s.d1, *tb, ncl);
+                else if (s.nmax <= 2)
+                    hipLaunchKernelGGL((k_cluster_assemble_w2<2, false>), dim3((ncl + 3) / 4), dim3(256), s.bytes, st, (const W2Cluster *)s.d0, (const W2Block *)s.d1, *tb, ncl);
                 else
-                    hipLaunchKernelGGL(k_cluster_assemble_w2<4>, dim3((ncl + 3) / 4), dim3(256), s.bytes, st, (const W2Cluster *)s.d0, (const W2Block *)s.d1, *tb, ncl);
+                    hipLaunchKernelGGL((k_cluster_assemble_w2<4, false>), dim3((ncl + 3) / 4), dim3(256), s.bytes, st, (const W2Cluster *)s.d0, (const W2Block *)s.d1, *tb, ncl);
                 break;
             }
             case STEP_ASSEMBLE_W1: {
@@ -1046,9 +1049,13 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
             Step s;
             s.kind = STEP_ASSEMBLE_W2;
             s.d0 = dwc; s.d1 = dwb; s.src = &c->ftables; s.n = (i64)w2cl.size(); s.nmax = w2_ut;
+            bool full = w2_ut <= 2;
+            for (size_t i2 = 0; i2 < w2bl.size() && full; i2++) if (w2bl[i2].kind == 0 && w2bl[i2].n != 16) full = false;
+            for (size_t i2 = 0; i2 < w2cl.size() && full; i2++) if (w2cl[i2].P != 16 * w2_ut) full = false;
+            s.grid = full ? 1 : 0;
             s.bytes = (size_t)4 * 2 * 17 * 16 * w2_ut * sizeof(double);
             pl.steps.push_back(s);
-            if (s.bytes > 64 * 1024) HIPCK(hipFuncSetAttribute((const void *)k_cluster_assemble_w2<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s.bytes));
+            if (s.bytes > 64 * 1024) HIPCK(hipFuncSetAttribute((const void *)k_cluster_assemble_w2<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s.bytes));
         }
         if (!wcl.empty()) {
             int *dpm, *day; double *dlam;
