@@ -809,14 +809,46 @@ __global__ __launch_bounds__(256) void k_cluster_assemble_w2(const W2Cluster *__
 #pragma unroll
     for (int t = 0; t < NT; t++) sacc[t] = (v4d_f){0.0, 0.0, 0.0, 0.0};
 
+    // Software pipeline over the blocks of the cluster: the global loads of block b+1 are issued (into registers) before the
+    // arithmetic of block b and written to LDS when block b is done, so that the memory time of one block hides behind the
+    // arithmetic of the other instead of every wave of the chip loading, then computing, in lock step.
+    struct Pre {
+        double yop[4], lt[4], dg, lam, v[4 * UT];
+        int ay;
+    };
+    auto issue = [&](const W2Block &kb, Pre &r) {
+        const int n = FULL ? 16 : kb.n;
+        const double *Lg = tb.Xc + kb.xyoff, *Yg = tb.Y + kb.xyoff, *Vg = tb.stat + kb.v_off;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int kk = 4 * q + l4;
+            r.yop[q] = (kk < n && l15 < n) ? Yg[kk + l15 * n] : 0.0;        // MFMA operand Y[k, i]
+            r.lt[q] = (l15 < n && kk < l15) ? Lg[l15 + kk * n] : 0.0;       // strictly lower part of L_X
+        }
+        r.dg = (l15 < n) ? Lg[l15 * (n + 1)] : 1.0;
+        r.lam = (lane < U && lane < 16 * UT) ? kb.lam[lane] : 0.0;
+        r.ay = (lane < U && lane < 16 * UT) ? kb.ay[lane] : 0;
+#pragma unroll
+        for (int c = 0; c < 4 * UT; c++) {
+            const int col = 4 * c + l4;
+            r.v[c] = (l15 < n && col < U) ? Vg[l15 + col * n] : 0.0;
+        }
+    };
+    static_assert(UT <= 4, "the per-vector tables are fetched by one lane each");
+    W2Block k = blocks[cl.blk0];
+    Pre cur, nxt;
+    if (k.kind == 0) issue(k, cur);
     for (int b = 0; b < cl.nblk; b++) {
         wave_sync();
-        const W2Block k = blocks[cl.blk0 + b];
+        W2Block knext = k;
+        const bool have_next = b + 1 < cl.nblk;
+        if (have_next) knext = blocks[cl.blk0 + b + 1];
         const double *Lg = tb.Xc + k.xyoff, *Yg = tb.Y + k.xyoff;
         double lam_r[UT], lam_c[UT * 4];
         if (k.kind == 1) {
             // 1 x 1 dense block: S[p_u, p_v] += a_u a_v Y / X, X = L^2
             const double Lx = Lg[0], ratio = Yg[0] / (Lx * Lx);
+            if (have_next && knext.kind == 0) issue(knext, cur);
 #pragma unroll
             for (int t = 0; t < UT; t++) {
                 const int u = t * 16 + l15;
@@ -833,36 +865,25 @@ __global__ __launch_bounds__(256) void k_cluster_assemble_w2(const W2Cluster *__
                 for (int tj = 0; tj <= ti; tj++)
 #pragma unroll
                     for (int reg = 0; reg < 4; reg++) sacc[ti * (ti + 1) / 2 + tj][reg] += (lam_r[ti] * lam_c[tj * 4 + reg]) * ratio;
+            k = knext;
             continue;
         }
         const int n = FULL ? 16 : k.n;
-        const double *Vg = tb.stat + k.v_off;
-        // ---- all global loads of the block ----
+        // ---- the block's data is in `cur` (registers): commit to LDS, then start the loads of the next block ----
         double yop[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int kk = 4 * q + l4;
-            yop[q] = (kk < n && l15 < n) ? Yg[kk + l15 * n] : 0.0;
-        }
         double *Lt = TYs;                       // strictly lower part of L_X, staged for the row reads
         double *tl = TYs + LD * 16;
         int *tay = (int *)(tl + 16 * UT);
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const int col = 4 * q + l4;
-            Lt[l15 + col * LD] = (l15 < n && col < l15) ? Lg[l15 + col * n] : 0.0;
+            yop[q] = cur.yop[q];
+            Lt[l15 + (4 * q + l4) * LD] = cur.lt[q];
         }
-        const double dg = (l15 < n) ? Lg[l15 * (n + 1)] : 1.0;
-        for (int u = lane; u < 16 * UT; u += 64) {
-            tl[u] = (u < U) ? k.lam[u] : 0.0;
-            tay[u] = (u < U) ? k.ay[u] : 0;
-        }
+        if (lane < 16 * UT) { tl[lane] = cur.lam; tay[lane] = cur.ay; }
 #pragma unroll
-        for (int c0 = 0; c0 < 16 * UT; c0 += 4) {
-            const int col = c0 + l4;
-            Vs[l15 + col * LD] = (l15 < n && col < U) ? Vg[l15 + col * n] : 0.0;
-        }
-        const double di = (l15 < n) ? 1.0 / dg : 0.0;
+        for (int c = 0; c < 4 * UT; c++) Vs[l15 + (4 * c + l4) * LD] = cur.v[c];
+        const double di = (l15 < n) ? 1.0 / cur.dg : 0.0;
+        if (have_next && knext.kind == 0) issue(knext, nxt);
         wave_sync();
         double Lr[16];
         int ay_r[UT];
@@ -950,6 +971,8 @@ __global__ __launch_bounds__(256) void k_cluster_assemble_w2(const W2Cluster *__
 #pragma unroll
                 for (int reg = 0; reg < 4; reg++) sacc[ti * (ti + 1) / 2 + tj][reg] += (lam_r[ti] * lam_c[tj * 4 + reg]) * (acc[reg] * g[reg]);
             }
+        cur = nxt;
+        k = knext;
     }
     wave_sync();
     // ---- S_j: u >= v computed, mirrored.  Through LDS for coalesced stores when P (P|1) fits in the work area. ----
