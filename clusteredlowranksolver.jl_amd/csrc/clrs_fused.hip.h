@@ -381,8 +381,7 @@ __global__ __launch_bounds__(256) void k_gemv_t(const double *__restrict__ LB, i
     const double *col = LB + (long long)k * ld;
     double s = 0.0;
     for (int i = lane; i < rows; i += 64) s += col[i] * t[i];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    s = wave_sum(s);
     if (lane == 0) u[k] = s;
 }
 
@@ -462,8 +461,7 @@ __global__ __launch_bounds__(256) void k_q_solve(const double *__restrict__ LQ, 
             const double *col = LB + (long long)k * ldb;
             double sacc = 0.0;
             for (int i = lane; i < rows; i += 64) sacc += col[i] * t[i];
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) sacc += __shfl_down(sacc, off, 64);
+            sacc = wave_sum(sacc);
             if (lane == 0) u[k] = sacc;
         }
         __threadfence_block();
@@ -484,6 +482,74 @@ __global__ __launch_bounds__(256) void k_q_solve(const double *__restrict__ LQ, 
 }  // namespace clrs
 
 namespace clrs {
+
+// Whole solve stage in ONE workgroup, for problems with a handful of small clusters (the named configurations): the three
+// phases of src/solver.jl:1537-1573 are separated by workgroup barriers instead of kernel boundaries, t and u never leave LDS.
+__global__ __launch_bounds__(256) void k_solve_small(const CSolve *__restrict__ descs, int J, const double *__restrict__ LQ, const double *__restrict__ dinvQ,
+                                                     int N, int xlen, const double *__restrict__ rhs_x, const double *__restrict__ rhs_y,
+                                                     const double *__restrict__ LBall, double *__restrict__ dx, double *__restrict__ dy, int maxP16) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int lda = maxP16 + 2, xl16 = (xlen + 15) & ~15, N16 = (N + 15) & ~15;
+    double *A = lds, *dv = A + lda * maxP16, *z = dv + maxP16, *tt = z + maxP16 + 2, *uu = tt + xl16, *yy = uu + N16;
+    const int i16 = tid & 15, j16 = tid >> 4;
+    // ---- t_j = L_j^-1 rhs_x[j] ----
+    for (int j = 0; j < J; j++) {
+        const CSolve d = descs[j];
+        const int P16 = (d.P + 15) & ~15;
+        __syncthreads();
+        lds_load_L_for_solve(A, lda, dv, d, P16, tid);
+        if (tid < P16) z[tid] = (tid < d.P) ? rhs_x[d.off + tid] : 0.0;
+        __syncthreads();
+        lds_trsm<false>(A, lda, dv, z, 1, lda, d.P, 1, wave, 4, lane);
+        __syncthreads();
+        if (tid < d.P) tt[d.off + tid] = z[tid];
+    }
+    __syncthreads();
+    if (N > 0) {
+        // ---- u = LinvB^T t, dy = Q^-1 (rhs_y - u) ----
+        for (int k = wave; k < N; k += 4) {
+            const double *col = LBall + (long long)k * xlen;
+            double sacc = 0.0;
+            for (int i = lane; i < xlen; i += 64) sacc += col[i] * tt[i];
+            sacc = wave_sum(sacc);
+            if (lane == 0) uu[k] = sacc;
+        }
+        for (int j0 = 0; j0 < N16; j0 += 16)
+            for (int i0 = 0; i0 < N16; i0 += 16) {
+                const int i = i0 + i16, j = j0 + j16;
+                A[i + j * lda] = (i < N && j < N && i >= j) ? LQ[i + (long long)j * N] : 0.0;
+            }
+        if (tid < N16) dv[tid] = (tid < N) ? dinvQ[tid] : 0.0;
+        __syncthreads();
+        if (tid < N16) yy[tid] = (tid < N) ? rhs_y[tid] - uu[tid] : 0.0;
+        __syncthreads();
+        lds_trsm<false>(A, lda, dv, yy, 1, lda, N, 1, wave, 4, lane);
+        __syncthreads();
+        lds_trsm<true>(A, lda, dv, yy, 1, lda, N, 1, wave, 4, lane);
+        __syncthreads();
+        if (tid < N) dy[tid] = yy[tid];
+    }
+    // ---- dx_j = L_j^-T (t_j + LinvB_j dy) ----
+    for (int j = 0; j < J; j++) {
+        const CSolve d = descs[j];
+        const int P16 = (d.P + 15) & ~15;
+        __syncthreads();
+        lds_load_L_for_solve(A, lda, dv, d, P16, tid);
+        if (tid < P16) {
+            double sacc = 0.0;
+            if (tid < d.P) {
+                sacc = tt[d.off + tid];
+                for (int k = 0; k < N; k++) sacc += d.LB[tid + (long long)k * d.ldb] * yy[k];
+            }
+            z[tid] = sacc;
+        }
+        __syncthreads();
+        lds_trsm<true>(A, lda, dv, z, 1, lda, d.P, 1, wave, 4, lane);
+        __syncthreads();
+        if (tid < d.P) dx[d.off + tid] = z[tid];
+    }
+}
 
 // =====================================================================================================================
 // k_cluster_assemble_w1: Schur assembly with ONE WAVE PER PSD BLOCK (no workgroup barriers inside a block)

@@ -53,10 +53,10 @@ static const int LDS_BUDGET_DOUBLES = 20000;   // of the 20480 doubles (160 KiB)
 // ------------------------------------------------------------------------------------------------
 // launch plan
 // ------------------------------------------------------------------------------------------------
-enum StepKind { STEP_MEMCPY, STEP_GEMM, STEP_TRSM, STEP_POTRF, STEP_GATHER_S, STEP_GATHER_SCALAR, STEP_SUB, STEP_MEMSET_INFO, STEP_ZERO_UPPER, STEP_FUSED_ASSEMBLE, STEP_SMALL_POTRF, STEP_CLUSTER_FACTOR, STEP_GEMV_T, STEP_CSOLVE_FWD, STEP_Q_SOLVE, STEP_CSOLVE_BWD, STEP_SUM_SLABS, STEP_ASSEMBLE_W1, STEP_GRAM_SMALL, STEP_ASSEMBLE_W2, STEP_NKINDS };
+enum StepKind { STEP_MEMCPY, STEP_GEMM, STEP_TRSM, STEP_POTRF, STEP_GATHER_S, STEP_GATHER_SCALAR, STEP_SUB, STEP_MEMSET_INFO, STEP_ZERO_UPPER, STEP_FUSED_ASSEMBLE, STEP_SMALL_POTRF, STEP_CLUSTER_FACTOR, STEP_GEMV_T, STEP_CSOLVE_FWD, STEP_Q_SOLVE, STEP_CSOLVE_BWD, STEP_SUM_SLABS, STEP_ASSEMBLE_W1, STEP_GRAM_SMALL, STEP_ASSEMBLE_W2, STEP_SOLVE_SMALL, STEP_NKINDS };
 static const char *const STEP_NAMES[STEP_NKINDS] = {"hipMemcpyAsync(D2D)", "k_gemm_f64_t", "k_trsm_diag", "k_potrf_diag", "k_schur_gather",
                                                     "k_gather_scalar", "k_sub", "hipMemsetAsync", "k_zero_upper", "k_cluster_assemble", "k_small_potrf", "k_cluster_factor", "k_gemv_t",
-                                                    "k_cluster_solve_fwd", "k_q_solve", "k_cluster_solve_bwd", "k_sum_slabs", "k_cluster_assemble_w1", "k_gram_small", "k_cluster_assemble_w2"};
+                                                    "k_cluster_solve_fwd", "k_q_solve", "k_cluster_solve_bwd", "k_sum_slabs", "k_cluster_assemble_w1", "k_gram_small", "k_cluster_assemble_w2", "k_solve_small"};
 static const int KT_MAX_EVENTS = 8192;   // event pairs kept between two clrs_get_kernel_times calls
 
 struct Step {
@@ -385,6 +385,10 @@ static int run_steps(clrs_ctx *c, const Plan &pl) {
                     hipLaunchKernelGGL(k_cluster_assemble<64>, dim3(s.grid), dim3(256), s.bytes, st, (const FCluster *)s.d0, (const FBlock *)s.d1, *tb);
                 break;
             }
+            case STEP_SOLVE_SMALL:
+                hipLaunchKernelGGL(k_solve_small, dim3(1), dim3(256), s.bytes, st, (const CSolve *)s.d0, c->J, (const double *)c->d_Q, (const double *)c->d_dinvQ, c->N,
+                                   (int)c->xlen, c->bind_rhsx, c->bind_rhsy, (const double *)c->d_LB, c->bind_dx, c->bind_dy, (int)s.n);
+                break;
             case STEP_ASSEMBLE_W2: {
                 const FTables *tb = (const FTables *)s.src;
                 const int ncl = (int)s.n;
@@ -1267,6 +1271,16 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
             CK(plan_trsm(c, c->p_bwd, tj, 1));
         }
     }
+    // a handful of small clusters: the whole solve stage in one workgroup, one launch
+    if (c->fused_fs && (c->fused_q || N == 0) && J <= 8 && c->xlen <= 1024) {
+        int maxP16 = (N + 15) & ~15;
+        for (int j = 0; j < J; j++) maxP16 = std::max(maxP16, (c->P[j] + 15) & ~15);
+        Step s = c->p_fwd.steps[0];                                   // reuses the CSolve table
+        s.kind = STEP_SOLVE_SMALL; s.n = maxP16;
+        s.bytes = (size_t)((maxP16 + 2) * maxP16 + 2 * maxP16 + 2 + ((c->xlen + 15) & ~15) + 2 * ((N + 15) & ~15) + 16) * sizeof(double);
+        if (s.bytes > 64 * 1024) HIPCK(hipFuncSetAttribute((const void *)k_solve_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s.bytes));
+        c->p_solve_all.steps.push_back(s);
+    } else
     // single-GPU solve in three launches: the u = LinvB^T t product moves into the Q-solve kernel
     if (c->fused_fs && c->fused_q && c->xlen <= 4096) {
         c->p_solve_all.steps.push_back(c->p_fwd.steps[0]);            // k_cluster_solve_fwd
@@ -1575,7 +1589,7 @@ extern "C" int clrs_schur_solve_dev(clrs_ctx *c, const double *d_rhs_x, const do
         return rc ? rc : clrs_schur_solve_bwd_dev(c, d_rhs_y, d_dx, d_dy);
     }
     if (!c->factored) return fail(CLRS_ERR_STATE, "clrs_schur_solve called before clrs_schur_factor");
-    if (!d_rhs_y || !d_dy) return fail(CLRS_ERR_INVALID, "rhs_y / dy are required when there are free variables");
+    if (c->N > 0 && (!d_rhs_y || !d_dy)) return fail(CLRS_ERR_INVALID, "rhs_y / dy are required when there are free variables");
     HIPCHECK(hipSetDevice(c->device));
     c->bind_rhsx = d_rhs_x; c->bind_rhsy = d_rhs_y; c->bind_dx = d_dx; c->bind_dy = d_dy;
     if (c->timing) HIPCHECK(hipEventRecord(c->ev[7], c->stream));

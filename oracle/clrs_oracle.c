@@ -13,11 +13,17 @@
  *
  * PARITY PINNING: the reference (Julia + Arblib/FLINT, unpinned, absent from /root/reference) can
  * be neither built nor imported here, and its tests hold no kernel-level fixtures.  The oracle is
- * pinned end-to-end through the reference's own known answers (tests/test_oracle_pinned.py):
- * delsarte(3,10,1/2) = 13.158314 (test/runtests_solver.jl:15), delsarte(8,3,1/2) = 240,
- * cohnelkies(8,15) = pi^4/384 (:19-20), Nsphere_packing(8,15,[1/2,1/2]) (:21-22), x^2+1 -> 1
- * (README.md:149), and by structural identities (low-rank S == dense Tr(A_p X^-1 A_q Y)).
- * Kernel-level parity (S, L, Q, dx, dy) is otherwise "parity unpinned" by the reference.
+ * pinned (tests/test_oracle_cpu.py)
+ *   - end-to-end through the reference's own known answers that 113 bits can reach:
+ *     delsarte(3,10,1/2) = 13.158314 (test/runtests_solver.jl:15), delsarte(8,3,1/2) = 240 (:86-87),
+ *     three_point_spherical_codes(4,1//6,-1,4) = 10 (:26-27), x^2+1 -> 1 (README.md:149);
+ *     cohnelkies(8,15) / Nsphere_packing(8,15,...) = pi^4/384 (:19-22) need the reference's 256-300 bits
+ *     and are NOT reproduced;
+ *   - kernel level against tests/golden/*.npz: 256-bit answers from an independent mpmath
+ *     restatement of the definitions (dense trace formula for S, LU solve of the KKT system);
+ *   - by structural identities (low-rank S == dense Tr(A_p X^-1 A_q Y), symmetry, definiteness).
+ * Kernel-level parity (S, L, Q, dx, dy) against the reference's OWN intermediates stays "parity
+ * unpinned": the reference exposes none.
  *
  * Functions cite the reference lines they follow (paths relative to /root/reference).
  * Matrices are column-major.  Indices are 0-based.
