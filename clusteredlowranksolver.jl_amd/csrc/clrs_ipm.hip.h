@@ -284,13 +284,90 @@ __global__ __launch_bounds__(256) void k_ipm_p(const IpmBuf q, const IpmParams p
     if (lane == 0) q.p[kk] = prm.sgn * q.b[kk] - s;
 }
 
+// ---- k_ipm_scalars: the scalar control flow, one thread -----------------------------------------------------------------------
+// stage 0: mu from tr(XY) partials; mu_p                                      (src/solver.jl:369-374)
+// stage 1: errors after the residuals; pd_feas                               (:441-447, computed before the predictor here)
+// stage 2: beta_c, mu_c after the predictor                                   (:429-434)
+// stage 3: step lengths from the eigenvalues                                  (:462-483, :1684-1692)
+// stage 4: objectives and gap after the update (grid partials of k_ipm_update) (:793-804, 844-847)
+__device__ __forceinline__ void ipm_scalar_stage(const IpmBuf &q, const IpmParams &prm, int stage, int ngrid, int ncsum_or_row0) {
+    const int ncsum = ncsum_or_row0, row0 = ncsum_or_row0;
+    double *s = q.scal;
+    if (stage == 0) {
+        double xy = 0.0;
+        for (int b = 0; b < q.NB; b++) xy += q.part[b * 8 + 0];
+        s[SC_XY] = xy;
+        s[SC_MU] = xy / prm.K;
+        s[SC_MU_P] = (s[SC_PD_FEAS] != 0.0) ? 0.0 : prm.beta_infeasible * s[SC_MU];
+        if (s[SC_MU] > prm.max_complementary_gap) s[SC_ERRCODE] = 3.0;
+    } else if (stage == 1) {
+        double mP = 0.0, md = 0.0, mp = 0.0;
+        for (int b = 0; b < q.NB; b++) mP = fmax(mP, q.part[b * 8 + 1]);
+        for (int g = 0; g < ncsum; g++) md = fmax(md, q.part[(long long)(q.NB + g) * 8 + 0]);
+        for (int kk = 0; kk < q.N; kk++) mp = fmax(mp, fabs(q.p[kk]));
+        s[SC_MAXP] = mP; s[SC_MAXd] = md; s[SC_MAXp] = mp;
+        s[SC_DUAL_ERR] = fmax(mp, mP);
+        s[SC_PRIMAL_ERR] = md;
+    } else if (stage == 2) {
+        double a = 0.0, bb = 0.0, c = 0.0;
+        for (int b = 0; b < q.NB; b++) { a += q.part[b * 8 + 2]; bb += q.part[b * 8 + 3]; c += q.part[b * 8 + 4]; }
+        const double r = (s[SC_XY] + a + bb + c) / (s[SC_MU] * prm.K);
+        const double beta = (r < 1.0) ? r * r : r;
+        const bool feas = s[SC_DUAL_ERR] < prm.dual_error_threshold && s[SC_PRIMAL_ERR] < prm.primal_error_threshold;
+        s[SC_PD_FEAS] = feas ? 1.0 : 0.0;
+        s[SC_BETA_C] = feas ? fmin(fmax(prm.beta_feasible, beta), 1.0) : fmax(prm.beta_infeasible, beta);
+        s[SC_MU_C] = s[SC_BETA_C] * s[SC_MU];
+    } else if (stage == 3) {
+        double ex = 1e300, ey = 1e300;
+        for (int b = 0; b < q.NB; b++) {
+            const double fx = (q.blocks[b].n == 1) ? 0.0 : 1e-5;    // the reference subtracts 1e-5 from the Lanczos estimate (:1680)
+            ex = fmin(ex, q.eig[b * 2 + 0] - fx);
+            ey = fmin(ey, q.eig[b * 2 + 1] - fx);
+        }
+        s[SC_EIG_X] = ex; s[SC_EIG_Y] = ey;
+        const bool unsafe = (s[SC_PD_FEAS] != 0.0) && !prm.safe_step;
+        double ad = (ex > -prm.gamma && !unsafe) ? 1.0 : -prm.gamma / ex;
+        double ap = (ey > -prm.gamma && !unsafe) ? 1.0 : -prm.gamma / ey;
+        if (s[SC_PD_FEAS] != 0.0 && prm.safe_step) ad = ap = fmin(ad, ap);
+        s[SC_ALPHA_D] = ad; s[SC_ALPHA_P] = ap;
+        if (fmin(ad, ap) < prm.step_length_threshold || !(ad == ad) || !(ap == ap)) s[SC_ERRCODE] = 4.0;     // :470-475
+        if (q.info[0] != 0x7f7f7f7f || q.info[1] != 0x7f7f7f7f) s[SC_ERRCODE] = 1.0;                          // a Cholesky failed: SolverFailure
+    } else if (stage == 4) {
+        double cy = 0.0, cx = 0.0, by = 0.0, xy = 0.0;
+        for (int g = 0; g < ngrid; g++) {
+            const double *pt = q.part + (long long)(row0 + g) * 8;
+            cy += pt[5]; cx += pt[6]; by += pt[7]; xy += pt[0];
+        }
+        s[SC_DOBJ] = prm.sgn * cx + prm.constant;
+        s[SC_POBJ] = cy + by + prm.constant;
+        s[SC_GAP] = fabs(s[SC_DOBJ] - s[SC_POBJ]) / fmax(1.0, fabs(s[SC_DOBJ] + s[SC_POBJ]));
+        if (s[SC_ERRCODE] == 0.0) s[SC_ITER] += 1.0;
+    }
+}
+
+__global__ void k_ipm_scalars(const IpmBuf q, const IpmParams prm, int stage, int ngrid, int ncsum_or_row0) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    ipm_scalar_stage(q, prm, stage, ngrid, ncsum_or_row0);
+}
+
 // ---- k_ipm_Z: Z = sym(X^-1 (P Y - R)), R = mu' I - XY [- dX dY]; per-term pairings w^T Z v ------------------------------------
-__global__ __launch_bounds__(256) void k_ipm_Z(const IpmBuf q, int corrector) {
+// inl != 0 (few blocks): the scalar control flow that precedes this kernel (mu, errors / beta_c) is evaluated here by thread 0 of
+// every workgroup instead of in one-thread kernels of their own; all workgroups compute identical values.
+__global__ __launch_bounds__(256) void k_ipm_Z(const IpmBuf q, const IpmParams prm, int corrector, int inl, int ncsum) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    __shared__ double sh_mu;
     const IBlock k = q.blocks[blockIdx.x];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = k.n, n16 = (n + 15) & ~15, lda = n16 + 2;
     double *Ls = lds, *As = Ls + lda * n16, *Bs = As + lda * n16, *Ts = Bs + lda * n16, *dinv = Ts + lda * n16, *work = dinv + n16;
-    const double mu = q.scal[corrector ? SC_MU_C : SC_MU_P];
+    if (tid == 0) {
+        if (inl) {
+            if (!corrector) { ipm_scalar_stage(q, prm, 0, 0, 0); ipm_scalar_stage(q, prm, 1, 0, ncsum); }
+            else ipm_scalar_stage(q, prm, 2, 0, 0);
+        }
+        sh_mu = q.scal[corrector ? SC_MU_C : SC_MU_P];
+    }
+    __syncthreads();
+    const double mu = sh_mu;
     const int i16 = tid & 15, j16 = tid >> 4;
     ipm_load_chol(Ls, lda, dinv, q.Xchol + k.xyoff, n, n16, tid);
     ipm_load(As, lda, q.P + k.xyoff, n, n16, tid);
@@ -589,12 +666,18 @@ __global__ __launch_bounds__(256) void k_ipm_step(const IpmBuf q) {
 }
 
 // ---- k_ipm_update: iterate update + objective / complementarity dots ------------------------------------------------------
-__global__ __launch_bounds__(256) void k_ipm_update(const IpmBuf q, int nblocks_grid, int row0) {
+__global__ __launch_bounds__(256) void k_ipm_update(const IpmBuf q, const IpmParams prm, int nblocks_grid, int row0, int inl) {
     __shared__ double red[4];
+    __shared__ double sh_sc[3];
+    if (threadIdx.x == 0) {
+        if (inl) ipm_scalar_stage(q, prm, 3, 0, 0);      // step lengths from the eigenvalues, identical in every workgroup
+        sh_sc[0] = q.scal[SC_ERRCODE]; sh_sc[1] = q.scal[SC_ALPHA_P]; sh_sc[2] = q.scal[SC_ALPHA_D];
+    }
+    __syncthreads();
     // after a failed factorisation or a too short step the iterate is left as it is (the reference returns the current
     // iterate, src/solver.jl:470-475, 594-623); the directions may then hold NaNs, so they are not even multiplied by 0
-    const bool skip = q.scal[SC_ERRCODE] != 0.0;
-    const double ap = q.scal[SC_ALPHA_P], ad = q.scal[SC_ALPHA_D];
+    const bool skip = sh_sc[0] != 0.0;
+    const double ap = sh_sc[1], ad = sh_sc[2];
     double cy = 0.0, xy = 0.0, cx = 0.0, by = 0.0;
     for (long long e = blockIdx.x * 256ll + threadIdx.x; e < q.xylen; e += 256ll * nblocks_grid) {
         const double Xn = skip ? q.X[e] : q.X[e] + ad * q.dX[e], Yn = skip ? q.Y[e] : q.Y[e] + ap * q.dY[e];
@@ -620,68 +703,6 @@ __global__ __launch_bounds__(256) void k_ipm_update(const IpmBuf q, int nblocks_
     if (threadIdx.x == 0) {
         double *pt = q.part + (long long)(row0 + blockIdx.x) * 8;
         pt[5] = cy; pt[6] = cx; pt[7] = by; pt[0] = xy;
-    }
-}
-
-// ---- k_ipm_scalars: the scalar control flow, one thread -----------------------------------------------------------------------
-// stage 0: mu from tr(XY) partials; mu_p                                      (src/solver.jl:369-374)
-// stage 1: errors after the residuals; pd_feas                               (:441-447, computed before the predictor here)
-// stage 2: beta_c, mu_c after the predictor                                   (:429-434)
-// stage 3: step lengths from the eigenvalues                                  (:462-483, :1684-1692)
-// stage 4: objectives and gap after the update (grid partials of k_ipm_update) (:793-804, 844-847)
-__global__ void k_ipm_scalars(const IpmBuf q, const IpmParams prm, int stage, int ngrid, int ncsum_or_row0) {
-    const int ncsum = ncsum_or_row0, row0 = ncsum_or_row0;
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    double *s = q.scal;
-    if (stage == 0) {
-        double xy = 0.0;
-        for (int b = 0; b < q.NB; b++) xy += q.part[b * 8 + 0];
-        s[SC_XY] = xy;
-        s[SC_MU] = xy / prm.K;
-        s[SC_MU_P] = (s[SC_PD_FEAS] != 0.0) ? 0.0 : prm.beta_infeasible * s[SC_MU];
-        if (s[SC_MU] > prm.max_complementary_gap) s[SC_ERRCODE] = 3.0;
-    } else if (stage == 1) {
-        double mP = 0.0, md = 0.0, mp = 0.0;
-        for (int b = 0; b < q.NB; b++) mP = fmax(mP, q.part[b * 8 + 1]);
-        for (int g = 0; g < ncsum; g++) md = fmax(md, q.part[(long long)(q.NB + g) * 8 + 0]);
-        for (int kk = 0; kk < q.N; kk++) mp = fmax(mp, fabs(q.p[kk]));
-        s[SC_MAXP] = mP; s[SC_MAXd] = md; s[SC_MAXp] = mp;
-        s[SC_DUAL_ERR] = fmax(mp, mP);
-        s[SC_PRIMAL_ERR] = md;
-    } else if (stage == 2) {
-        double a = 0.0, bb = 0.0, c = 0.0;
-        for (int b = 0; b < q.NB; b++) { a += q.part[b * 8 + 2]; bb += q.part[b * 8 + 3]; c += q.part[b * 8 + 4]; }
-        const double r = (s[SC_XY] + a + bb + c) / (s[SC_MU] * prm.K);
-        const double beta = (r < 1.0) ? r * r : r;
-        const bool feas = s[SC_DUAL_ERR] < prm.dual_error_threshold && s[SC_PRIMAL_ERR] < prm.primal_error_threshold;
-        s[SC_PD_FEAS] = feas ? 1.0 : 0.0;
-        s[SC_BETA_C] = feas ? fmin(fmax(prm.beta_feasible, beta), 1.0) : fmax(prm.beta_infeasible, beta);
-        s[SC_MU_C] = s[SC_BETA_C] * s[SC_MU];
-    } else if (stage == 3) {
-        double ex = 1e300, ey = 1e300;
-        for (int b = 0; b < q.NB; b++) {
-            const double fx = (q.blocks[b].n == 1) ? 0.0 : 1e-5;    // the reference subtracts 1e-5 from the Lanczos estimate (:1680)
-            ex = fmin(ex, q.eig[b * 2 + 0] - fx);
-            ey = fmin(ey, q.eig[b * 2 + 1] - fx);
-        }
-        s[SC_EIG_X] = ex; s[SC_EIG_Y] = ey;
-        const bool unsafe = (s[SC_PD_FEAS] != 0.0) && !prm.safe_step;
-        double ad = (ex > -prm.gamma && !unsafe) ? 1.0 : -prm.gamma / ex;
-        double ap = (ey > -prm.gamma && !unsafe) ? 1.0 : -prm.gamma / ey;
-        if (s[SC_PD_FEAS] != 0.0 && prm.safe_step) ad = ap = fmin(ad, ap);
-        s[SC_ALPHA_D] = ad; s[SC_ALPHA_P] = ap;
-        if (fmin(ad, ap) < prm.step_length_threshold || !(ad == ad) || !(ap == ap)) s[SC_ERRCODE] = 4.0;     // :470-475
-        if (q.info[0] != 0x7f7f7f7f || q.info[1] != 0x7f7f7f7f) s[SC_ERRCODE] = 1.0;                          // a Cholesky failed: SolverFailure
-    } else if (stage == 4) {
-        double cy = 0.0, cx = 0.0, by = 0.0, xy = 0.0;
-        for (int g = 0; g < ngrid; g++) {
-            const double *pt = q.part + (long long)(row0 + g) * 8;
-            cy += pt[5]; cx += pt[6]; by += pt[7]; xy += pt[0];
-        }
-        s[SC_DOBJ] = prm.sgn * cx + prm.constant;
-        s[SC_POBJ] = cy + by + prm.constant;
-        s[SC_GAP] = fabs(s[SC_DOBJ] - s[SC_POBJ]) / fmax(1.0, fabs(s[SC_DOBJ] + s[SC_POBJ]));
-        if (s[SC_ERRCODE] == 0.0) s[SC_ITER] += 1.0;
     }
 }
 

@@ -414,3 +414,73 @@ def test_device_loop_reports_failure_like_the_reference():
     r = solvesdp_device(f)
     assert r.error_code == 1 and r.iterations == 0
     assert np.all(np.isfinite(r.X)) and np.all(np.isfinite(r.x)) and np.allclose(r.x, 0.0)
+
+
+# ---- malformed descriptions and edge shapes through the C ABI ------------------------------------------------------------------
+
+def _mini_sdp(rank2=False, drop_partner=False, m=1):
+    """One cluster, P = 3, N = 1, one low-rank block (optionally m = 2 sub-blocks), one 1 x 1 dense block."""
+    import clrs_amd
+    from clrs_amd.sdp import Block, ClusteredLowRankSDP, HiLo, LowRankMat
+    rng = np.random.default_rng(7)
+    dl = 3
+    ent = {}
+    for r in range(m):
+        for s in range(m):
+            if drop_partner and (r, s) == (1, 0):
+                continue
+            ent[(r, s)] = {}
+    for p in range(3):
+        v = rng.standard_normal((2 if rank2 else 1, dl))
+        lam = np.array([1.0, 0.5][: v.shape[0]])
+        for r in range(m):
+            for s in range(m):
+                if (r, s) in ent:
+                    ent[(r, s)][p] = LowRankMat(lam, v, v)
+    blocks = [Block(m, dl, ent, "lr"), Block(1, 1, {(0, 0): {0: HiLo.of(np.array([[2.0]])), 2: HiLo.of(np.array([[0.5]]))}}, "dense")]
+    sdp = ClusteredLowRankSDP(maximize=True, constant=0.0, blocks=[blocks], B=[rng.standard_normal((3, 1))], c=[np.ones(3)],
+                              C=[[np.zeros((m * dl, m * dl)), np.zeros((1, 1))]], b=np.ones(1))
+    return sdp
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(rank2=True), dict(m=2), dict(m=2, rank2=True)])
+def test_small_handmade_shapes_match_oracle(kw, oracle_built):
+    """rank-2 terms, sub-blocks (m = 2), a dense block touching only some constraints, de-duplicated vectors."""
+    import clrs_amd
+    from clrs_amd.solver import SchurContext, compute_T_decomposition, solve_system
+    from oracle.oracle import Oracle
+    f = clrs_amd.flatten(_mini_sdp(**kw))
+    X, Y = spd_iterates(f, seed=3)
+    Xc = chol_blocks_np(f, X)
+    o = Oracle(f, quad=True, use_lo=False)
+    S_ref, AY_ref = o.schur_assemble(Xc, Y)
+    assert o.schur_factor() == 0
+    dx_ref, dy_ref = o.schur_solve(np.ones(f.x_len), np.ones(f.n_free))
+    for path in PATHS.values():
+        ctx = SchurContext(f, **path)
+        _, S, AY = compute_T_decomposition(ctx, Xc, Y, want_S=True)
+        assert np.max(np.abs(S - S_ref)) <= 1e-12 * np.max(np.abs(S_ref))
+        assert np.max(np.abs(AY - AY_ref)) <= 1e-12 * max(1.0, np.max(np.abs(AY_ref)))
+        dx, dy = solve_system(ctx, np.ones(f.x_len), np.ones(f.n_free))
+        assert np.max(np.abs(dx - dx_ref)) <= 1e-9 * max(1.0, np.max(np.abs(dx_ref)))
+        assert np.max(np.abs(dy - dy_ref)) <= 1e-9 * max(1.0, np.max(np.abs(dy_ref)))
+        ctx.close()
+
+
+def test_malformed_descriptions_are_rejected():
+    """The ABI validates what it is given: a term without its transposed partner (the convention of src/solver.jl:1009), a solve
+    before a factorisation, wrong call order -- negative codes with a message, never a crash."""
+    import clrs_amd
+    from clrs_amd._lib import ClrsError
+    from clrs_amd.solver import SchurContext
+    sdp = _mini_sdp(m=2, drop_partner=True)
+    sdp.check = lambda: None                      # bypass the host-side check so that the C layer sees the malformed input
+    with pytest.raises(ClrsError, match="transposed partner"):
+        SchurContext(clrs_amd.flatten(sdp))
+    f = flat("polyopt8")
+    ctx = SchurContext(f)
+    with pytest.raises(ClrsError, match="before clrs_schur_factor"):
+        ctx.solve(np.ones(f.x_len), np.ones(f.n_free))
+    with pytest.raises(ClrsError, match="before clrs_schur_assemble"):
+        ctx.factor()
+    ctx.close()
