@@ -483,6 +483,75 @@ __global__ __launch_bounds__(256) void k_q_solve(const double *__restrict__ LQ, 
 
 namespace clrs {
 
+// =====================================================================================================================
+// k_dense_block: the dense ("high rank") branch of the assembly for one PSD block with n <= 64, LDS resident
+// =====================================================================================================================
+// Sd[x,y] = <A_x, X^-1 A_y Y> (src/solver.jl:1089-1104) for the cnt constraint matrices of the block:
+//   U_x = A_x Y (MFMA), W_y = X^-1 A_y (blocked DPP/MFMA triangular solves on all matrices at once, in place),
+//   Sd = <U_x, W_y> as one Gram contraction over the n^2 entries (MFMA, K split over the 4 waves).
+// One workgroup per block; every MOI/JuMP problem and the SDPA import land here (all their matrices are dense).
+struct DBlock {
+    int n, cnt;
+    long long xyoff;     // block in the X/Y layout
+    long long a_off;     // stack of cnt n x n matrices in the static arena
+    double *Sd;          // cnt x cnt output (column-major, ld cnt)
+};
+
+__global__ __launch_bounds__(256) void k_dense_block(const DBlock *__restrict__ blocks, const FTables tb) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const DBlock k = blocks[blockIdx.x];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = k.n, n16 = (n + 15) & ~15, lda = n16 + 2, cnt = k.cnt;
+    const int msz = lda * n16;                           // one matrix (zero padded columns up to n16)
+    double *Ls = lds, *Ys = Ls + msz, *dinv = Ys + msz, *Ws = dinv + n16, *Us = Ws + cnt * msz, *part = Us + cnt * msz;   // part: 4 x 256
+    const int i16 = tid & 15, j16 = tid >> 4;
+    for (int j0 = 0; j0 < n16; j0 += 16)
+        for (int i0 = 0; i0 < n16; i0 += 16) {
+            const int i = i0 + i16, j = j0 + j16;
+            const bool in = i < n && j < n;
+            Ls[i + j * lda] = (in && i >= j) ? tb.Xc[k.xyoff + i + (long long)j * n] : 0.0;
+            Ys[i + j * lda] = in ? tb.Y[k.xyoff + i + (long long)j * n] : 0.0;
+        }
+    if (tid < n16) dinv[tid] = (tid < n) ? 1.0 / tb.Xc[k.xyoff + tid + (long long)tid * n] : 0.0;
+    const double *Ag = tb.stat + k.a_off;
+    for (int a = 0; a < cnt; a++)
+        for (int j0 = 0; j0 < n16; j0 += 16)
+            for (int i0 = 0; i0 < n16; i0 += 16) {
+                const int i = i0 + i16, j = j0 + j16;
+                Ws[a * msz + i + j * lda] = (i < n && j < n) ? Ag[(long long)a * n * n + i + (long long)j * n] : 0.0;
+            }
+    // the two padding rows of every column (rows n16, n16+1 of the leading dimension) take part in the Gram contraction: zero them
+    for (int e = tid; e < cnt * n16; e += 256) {
+        Ws[e * lda + n16] = 0.0; Ws[e * lda + n16 + 1] = 0.0;
+        Us[e * lda + n16] = 0.0; Us[e * lda + n16 + 1] = 0.0;
+    }
+    __syncthreads();
+    // U_a = A_a Y  (A_a symmetric: A_a^T Y)
+    for (int a = 0; a < cnt; a++) lds_gemm_tn(Ws + a * msz, lda, Ys, lda, Us + a * msz, lda, n16, n16, n, wave, 4, lane);
+    __syncthreads();
+    // W = X^-1 [A_1 ... A_cnt]: all columns at once
+    lds_trsm<false>(Ls, lda, dinv, Ws, 1, lda, n, cnt * n16, wave, 4, lane);
+    __syncthreads();
+    lds_trsm<true>(Ls, lda, dinv, Ws, 1, lda, n, cnt * n16, wave, 4, lane);
+    __syncthreads();
+    // Sd[x,y] = sum_e U_x[e] W_y[e]: tiles of 16 x 16 outputs, the contraction (msz long) split over the 4 waves
+    const int ct = (cnt + 15) >> 4, l15 = lane & 15, l4 = lane >> 4;
+    const int kq = ((msz / 4 + 3) / 4) * 4;               // k range per wave, multiple of 4
+    for (int ty = 0; ty < ct; ty++)
+        for (int tx = 0; tx < ct; tx++) {
+            v4d_f acc = {0.0, 0.0, 0.0, 0.0};
+            const int k0 = wave * kq, k1 = min(msz, k0 + kq);
+            const int xa = min(tx * 16 + l15, cnt - 1), ya = min(ty * 16 + l15, cnt - 1);     // clamped: out-of-range columns are discarded below
+            const double *ux = Us + xa * msz + l4, *wy = Ws + ya * msz + l4;
+            for (int kk = k0; kk < k1; kk += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wy[kk], ux[kk], acc, 0, 0, 0);   // D[r][c]: c -> x, r -> y
+            __syncthreads();
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) part[wave * 256 + l15 + 16 * (l4 + 4 * reg)] = acc[reg];
+            __syncthreads();
+            const int x = tx * 16 + (tid & 15), y = ty * 16 + (tid >> 4);
+            if (x < cnt && y < cnt) k.Sd[x + (long long)y * cnt] = (part[tid] + part[256 + tid]) + (part[512 + tid] + part[768 + tid]);
+        }
+}
+
 // Whole solve stage in ONE workgroup, for problems with a handful of small clusters (the named configurations): the three
 // phases of src/solver.jl:1537-1573 are separated by workgroup barriers instead of kernel boundaries, t and u never leave LDS.
 __global__ __launch_bounds__(256) void k_solve_small(const CSolve *__restrict__ descs, int J, const double *__restrict__ LQ, const double *__restrict__ dinvQ,

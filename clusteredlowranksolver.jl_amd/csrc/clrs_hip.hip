@@ -49,15 +49,16 @@ static int g_cfg_fused_assemble = 1;
 static int g_cfg_fused_factor = 1;
 static int g_cfg_wave_assemble = 1;
 static int g_cfg_wave2_assemble = 1;
+static int g_cfg_dense_block = 1;
 static const int LDS_BUDGET_DOUBLES = 20000;   // of the 20480 doubles (160 KiB) a workgroup may claim
 
 // ------------------------------------------------------------------------------------------------
 // launch plan
 // ------------------------------------------------------------------------------------------------
-enum StepKind { STEP_MEMCPY, STEP_GEMM, STEP_TRSM, STEP_POTRF, STEP_GATHER_S, STEP_GATHER_SCALAR, STEP_SUB, STEP_MEMSET_INFO, STEP_ZERO_UPPER, STEP_FUSED_ASSEMBLE, STEP_SMALL_POTRF, STEP_CLUSTER_FACTOR, STEP_GEMV_T, STEP_CSOLVE_FWD, STEP_Q_SOLVE, STEP_CSOLVE_BWD, STEP_SUM_SLABS, STEP_ASSEMBLE_W1, STEP_GRAM_SMALL, STEP_ASSEMBLE_W2, STEP_SOLVE_SMALL, STEP_NKINDS };
+enum StepKind { STEP_MEMCPY, STEP_GEMM, STEP_TRSM, STEP_POTRF, STEP_GATHER_S, STEP_GATHER_SCALAR, STEP_SUB, STEP_MEMSET_INFO, STEP_ZERO_UPPER, STEP_FUSED_ASSEMBLE, STEP_SMALL_POTRF, STEP_CLUSTER_FACTOR, STEP_GEMV_T, STEP_CSOLVE_FWD, STEP_Q_SOLVE, STEP_CSOLVE_BWD, STEP_SUM_SLABS, STEP_ASSEMBLE_W1, STEP_GRAM_SMALL, STEP_ASSEMBLE_W2, STEP_SOLVE_SMALL, STEP_DENSE_BLOCK, STEP_NKINDS };
 static const char *const STEP_NAMES[STEP_NKINDS] = {"hipMemcpyAsync(D2D)", "k_gemm_f64_t", "k_trsm_diag", "k_potrf_diag", "k_schur_gather",
                                                     "k_gather_scalar", "k_sub", "hipMemsetAsync", "k_zero_upper", "k_cluster_assemble", "k_small_potrf", "k_cluster_factor", "k_gemv_t",
-                                                    "k_cluster_solve_fwd", "k_q_solve", "k_cluster_solve_bwd", "k_sum_slabs", "k_cluster_assemble_w1", "k_gram_small", "k_cluster_assemble_w2", "k_solve_small"};
+                                                    "k_cluster_solve_fwd", "k_q_solve", "k_cluster_solve_bwd", "k_sum_slabs", "k_cluster_assemble_w1", "k_gram_small", "k_cluster_assemble_w2", "k_solve_small", "k_dense_block"};
 static const int KT_MAX_EVENTS = 8192;   // event pairs kept between two clrs_get_kernel_times calls
 
 struct Step {
@@ -386,6 +387,9 @@ static int run_steps(clrs_ctx *c, const Plan &pl) {
                     hipLaunchKernelGGL(k_cluster_assemble<64>, dim3(s.grid), dim3(256), s.bytes, st, (const FCluster *)s.d0, (const FBlock *)s.d1, *tb);
                 break;
             }
+            case STEP_DENSE_BLOCK:
+                hipLaunchKernelGGL(k_dense_block, dim3(s.grid), dim3(256), s.bytes, st, (const DBlock *)s.d0, *(const FTables *)s.src);
+                break;
             case STEP_SOLVE_SMALL:
                 hipLaunchKernelGGL(k_solve_small, dim3(1), dim3(256), s.bytes, st, (const CSolve *)s.d0, c->J, (const double *)c->d_Q, (const double *)c->d_dinvQ, c->N,
                                    (int)c->xlen, c->bind_rhsx, c->bind_rhsy, (const double *)c->d_LB, c->bind_dx, c->bind_dy, (int)s.n);
@@ -952,6 +956,11 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
         bool need_copy = false;
         for (int b = 0; b < NB; b++) need_copy = need_copy || !c->blk[b].fused;
         c->all_assemble_fused = !need_copy;
+        // which of the non-fused blocks still need the work arena (a copy of the static arena that the staged solves overwrite)?
+        bool need_work_arena = false;
+        std::vector<DBlock> dblocks;
+        size_t dense_lds = 0;
+        const size_t copy_step_index = pl.steps.size();
         if (need_copy) add_memcpy(pl, c->d_work, c->d_static, sizeof(double) * (size_t)so);
         std::vector<TrsmJob> fwd, bwd;
         std::vector<GemmDesc> g1, g2;
@@ -963,6 +972,7 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
             if (k.fused) continue;
             any_general = true;
             if (k.kind == 0) {
+                need_work_arena = true;
                 double *ZR = c->d_work + k.zr_off, *ZL = c->d_work + k.zl_off, *TY = c->d_TY + k.ty_off;
                 double *GX = c->d_G + k.g_off, *GY = GX + (i64)k.ULt * k.URt;
                 const double *VR = c->d_static + k.zr_off, *WL = c->d_static + k.zl_off;
@@ -981,6 +991,17 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
                 // GX = ZL^T ZR = W^T X^-1 V       (replaces src/solver.jl:1117,1137-1143)
                 if (k.ULt > 0 && k.URt > 0) g2.push_back(mk_gemm(1, 0, k.ULt, k.URt, n, 1.0, ZL, n, ZR, n, 0.0, GX, k.ULt));
             } else if (k.cnt > 0) {
+                {   // dense block that fits in LDS: one fused launch for all such blocks
+                    const size_t n16 = (n + 15) & ~15, msz = (n16 + 2) * n16, need = 2 * msz + n16 + 2 * (size_t)k.cnt * msz + 1024;
+                    if (g_cfg_dense_block && g_cfg_fused_assemble && n <= 64 && need <= (size_t)LDS_BUDGET_DOUBLES) {
+                        DBlock db;
+                        db.n = n; db.cnt = k.cnt; db.xyoff = k.xyoff; db.a_off = k.w_off; db.Sd = c->d_Sd + k.sd_off;
+                        dblocks.push_back(db);
+                        dense_lds = std::max(dense_lds, need * sizeof(double));
+                        continue;
+                    }
+                }
+                need_work_arena = true;
                 double *W = c->d_work + k.w_off, *TT = c->d_TT + k.tt_off, *Sd = c->d_Sd + k.sd_off;
                 const double *Ast = c->d_static + k.w_off;
                 fwd.push_back(TrsmJob{Lx, n, n, W, n, n * k.cnt});      // X^-1 A_p for all p  (src/solver.jl:1095)
@@ -989,10 +1010,20 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
                 g2.push_back(mk_gemm(1, 0, k.cnt, k.cnt, n * n, 1.0, Ast, n * n, TT, n * n, 0.0, Sd, k.cnt));           // <A_i, T_k>   (:1102)
             }
         }
+        if (need_copy && !need_work_arena) pl.steps.erase(pl.steps.begin() + copy_step_index);   // nothing left that overwrites it
         CK(plan_trsm(c, pl, fwd, 0));
         CK(plan_trsm(c, pl, bwd, 1));
         CK(add_gemm_stage(c, pl, g1));
         CK(add_gemm_stage(c, pl, g2));
+        if (!dblocks.empty()) {
+            DBlock *ddb;
+            CK(upload(c, dblocks, &ddb));
+            c->ftables.Xc = c->d_Xc; c->ftables.Y = c->d_Y; c->ftables.stat = c->d_static;
+            Step s;
+            s.kind = STEP_DENSE_BLOCK; s.grid = (int)dblocks.size(); s.d0 = ddb; s.src = &c->ftables; s.bytes = dense_lds;
+            pl.steps.push_back(s);
+            if (dense_lds > 64 * 1024) HIPCK(hipFuncSetAttribute((const void *)k_dense_block, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dense_lds));
+        }
         // gather
         std::vector<SClusterDesc> cl(J);
         std::vector<SBlockDesc> bl;
@@ -1733,6 +1764,7 @@ extern "C" int clrs_config_set(const char *key, int value) {
     if (!std::strcmp(key, "fused_factor")) { g_cfg_fused_factor = value; return 0; }
     if (!std::strcmp(key, "wave_assemble")) { g_cfg_wave_assemble = value; return 0; }
     if (!std::strcmp(key, "wave2_assemble")) { g_cfg_wave2_assemble = value; return 0; }
+    if (!std::strcmp(key, "dense_block")) { g_cfg_dense_block = value; return 0; }
     return fail(CLRS_ERR_INVALID, std::string("unknown configuration key ") + key);
 }
 
