@@ -72,7 +72,6 @@ struct FTables {
 #define CLRS_STAMP(i) do {} while (0)
 #endif
 
-template <int NMAX>
 __global__ __launch_bounds__(256) void k_cluster_assemble(const FCluster *__restrict__ clusters, const FBlock *__restrict__ blocks,
                                                           const FTables tb) {
     extern __shared__ __attribute__((aligned(16))) double lds[];

@@ -143,7 +143,7 @@ struct clrs_ctx {
     i64 *d_ayidx = nullptr;
     int *d_info = nullptr;
     double *d_X = nullptr;  // scratch for clrs_cholesky_blocks
-    Plan p_assemble, p_cholS, p_linvB, p_Q, p_cholQ, p_fwd, p_bwd, p_cholX, p_zeroL;
+    Plan p_assemble, p_cholS, p_linvB, p_Q, p_cholQ, p_fwd, p_bwd, p_cholX;
     FTables ftables = {};
     // caller-provided device pointers of the current call, read by the fused kernels at launch (no staging copies)
     const double *bind_X = nullptr, *bind_rhsx = nullptr, *bind_rhsy = nullptr;
@@ -377,16 +377,9 @@ static int run_steps(clrs_ctx *c, const Plan &pl) {
             case STEP_MEMSET_INFO:
                 HIPCHECK(hipMemsetAsync(s.dst ? s.dst : (void *)c->d_info, 0x7f, sizeof(int), st));
                 break;
-            case STEP_FUSED_ASSEMBLE: {
-                const FTables *tb = (const FTables *)s.src;
-                if (s.nmax <= 16)
-                    hipLaunchKernelGGL(k_cluster_assemble<16>, dim3(s.grid), dim3(256), s.bytes, st, (const FCluster *)s.d0, (const FBlock *)s.d1, *tb);
-                else if (s.nmax <= 32)
-                    hipLaunchKernelGGL(k_cluster_assemble<32>, dim3(s.grid), dim3(256), s.bytes, st, (const FCluster *)s.d0, (const FBlock *)s.d1, *tb);
-                else
-                    hipLaunchKernelGGL(k_cluster_assemble<64>, dim3(s.grid), dim3(256), s.bytes, st, (const FCluster *)s.d0, (const FBlock *)s.d1, *tb);
+            case STEP_FUSED_ASSEMBLE:
+                hipLaunchKernelGGL(k_cluster_assemble, dim3(s.grid), dim3(256), s.bytes, st, (const FCluster *)s.d0, (const FBlock *)s.d1, *(const FTables *)s.src);
                 break;
-            }
             case STEP_DENSE_BLOCK:
                 hipLaunchKernelGGL(k_dense_block, dim3(s.grid), dim3(256), s.bytes, st, (const DBlock *)s.d0, *(const FTables *)s.src);
                 break;
@@ -1139,11 +1132,7 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
             s.kind = STEP_FUSED_ASSEMBLE;
             s.grid = (int)fcl.size(); s.d0 = dfc; s.d1 = dfb; s.src = &c->ftables; s.bytes = fused_lds; s.nmax = fused_nmax;
             pl.steps.push_back(s);
-            if (fused_lds > 64 * 1024) {
-                if (fused_nmax <= 16) HIPCK(hipFuncSetAttribute((const void *)k_cluster_assemble<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds));
-                else if (fused_nmax <= 32) HIPCK(hipFuncSetAttribute((const void *)k_cluster_assemble<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds));
-                else HIPCK(hipFuncSetAttribute((const void *)k_cluster_assemble<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds));
-            }
+            if (fused_lds > 64 * 1024) HIPCK(hipFuncSetAttribute((const void *)k_cluster_assemble, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds));
         }
     }
     // =============================================================================================
@@ -1396,7 +1385,7 @@ extern "C" void clrs_ctx_destroy(clrs_ctx *c) {
     ipm_free(c);
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
-    Plan *plans[] = {&c->p_assemble, &c->p_cholS, &c->p_linvB, &c->p_Q, &c->p_cholQ, &c->p_fwd, &c->p_bwd, &c->p_cholX, &c->p_zeroL, &c->p_cholQ_slabs, &c->p_solve_all};
+    Plan *plans[] = {&c->p_assemble, &c->p_cholS, &c->p_linvB, &c->p_Q, &c->p_cholQ, &c->p_fwd, &c->p_bwd, &c->p_cholX, &c->p_cholQ_slabs, &c->p_solve_all};
     for (Plan *p : plans)
         if (p->graph) hipGraphExecDestroy(p->graph);
     for (void *p : c->allocs) hipFree(p);
@@ -1718,7 +1707,7 @@ extern "C" int clrs_set_stream(clrs_ctx *c, void *stream) {
     if (!c) return fail(CLRS_ERR_INVALID, "null argument");
     HIPCHECK(hipSetDevice(c->device));
     HIPCHECK(hipStreamSynchronize(c->stream));
-    Plan *plans[] = {&c->p_assemble, &c->p_cholS, &c->p_linvB, &c->p_Q, &c->p_cholQ, &c->p_fwd, &c->p_bwd, &c->p_cholX, &c->p_zeroL, &c->p_cholQ_slabs, &c->p_solve_all};
+    Plan *plans[] = {&c->p_assemble, &c->p_cholS, &c->p_linvB, &c->p_Q, &c->p_cholQ, &c->p_fwd, &c->p_bwd, &c->p_cholX, &c->p_cholQ_slabs, &c->p_solve_all};
     for (Plan *p : plans)
         if (p->graph) { hipGraphExecDestroy(p->graph); p->graph = nullptr; }   // graphs are re-captured on the new stream
     if (c->own_stream) HIPCHECK(hipStreamDestroy(c->stream));
