@@ -69,40 +69,6 @@ def build_problem(n_pairs: int):
     return clrs_amd.flatten(cohnelkies_multi(8, 15, radii))
 
 
-def replicate_clusters(flat, copies: int):
-    """A many-cluster instance with the block shapes of `flat`: the clusters of `flat` repeated `copies`
-    times (independent clusters with identical constraint data, distinct iterates).  Only used for the
-    roofline measurement of the assembly kernels."""
-    import copy
-    from clrs_amd.sdp import shard_clusters
-    J = flat.n_clusters
-    parts = [shard_clusters(flat, list(range(J))) for _ in range(copies)]
-    f = copy.copy(parts[0])
-    cat = np.concatenate
-    f.n_clusters = J * copies
-    f.n_blocks = flat.n_blocks * copies
-    for name in ("cluster_P", "B", "B_lo", "c", "c_lo", "C", "C_lo", "block_m", "block_delta", "block_kind", "term_p", "term_r",
-                 "term_s", "term_rank", "term_lambda", "term_lambda_lo", "term_vs", "term_vs_lo", "term_ws", "term_ws_lo",
-                 "dense_p", "dense_A", "dense_A_lo", "block_n"):
-        setattr(f, name, cat([getattr(p, name) for p in parts]))
-    f.block_cluster = cat([p.block_cluster + k * J for k, p in enumerate(parts)]).astype(np.int32)
-
-    def cat_ptr(name):
-        out, off = [np.zeros(1, np.int64)], 0
-        for p in parts:
-            a = getattr(p, name)
-            out.append(a[1:] + off)
-            off += int(a[-1])
-        return cat(out).astype(np.int64)
-
-    for name in ("term_ptr", "term_vec_ptr", "dense_ptr", "dense_A_ptr"):
-        setattr(f, name, cat_ptr(name))
-    f.block_off = np.concatenate([[0], np.cumsum(f.block_n.astype(np.int64) ** 2)]).astype(np.int64)
-    f.cluster_off = np.concatenate([[0], np.cumsum(f.cluster_P.astype(np.int64))]).astype(np.int64)
-    f.S_off = np.concatenate([[0], np.cumsum(f.cluster_P.astype(np.int64) ** 2)]).astype(np.int64)
-    return f
-
-
 def kernel_profile(ctx, run_once, reps):
     """Per-kernel HIP-event timing of `reps` eager passes; returns {name: (avg seconds per launch, launches per pass)}."""
     ctx.set_graph_mode(False)
@@ -277,6 +243,7 @@ def main():
             ctx.set_graph_mode(True)
 
         # ---- roofline instance: the same block shapes, many clusters per launch ----
+        from clrs_amd.sdp import replicate_clusters
         big = replicate_clusters(f, args.roofline_copies)
         from clrs_amd.solver import SchurContext
         bctx = SchurContext(big, device=local_rank)

@@ -1,0 +1,301 @@
+// clrs_assemble_w3.hip.h -- k_cluster_assemble_w3: register-resident Schur assembly, one wave per run of clusters, gfx950.
+//
+// Same eligibility as k_cluster_assemble_w2 (clusters whose low-rank blocks are "simple": one sub-block, n <= 16, rank-1
+// symmetric terms, one term per constraint, the same constraint order in every block, U = P <= 32; dense blocks 1 x 1) --
+// the Cohn-Elkies / Delsarte / univariate-SOS shapes -- but the matrices never pass through LDS and nothing synchronises.
+//
+// The observation that makes this possible: for v_mfma_f64_16x16x4_f64 the A operand (lane (l15, l4) holds A[i = l15][k = l4])
+// and the B operand (lane holds B[k = l4][j = l15]) have the SAME lane <-> (free index, contraction index) map, and an
+// accumulator (lane holds D[4 reg + l4][l15], reg = 0..3) read as "k-step reg" is again an operand with contraction index
+// 4 reg + l4 and free index l15.  So the whole chain of src/solver.jl:1121-1212
+//     T_Y = Y V          (A = Y rows,    B = V)          ->  accumulators = operands with contraction index = row of T_Y
+//     G_Y = V^T T_Y      (A = V,         B = T_Y acc)
+//     Z   = L^-1 V       (A = L^-1 rows, B = V)          ->  accumulators = operands with contraction index = row of Z
+//     G_X = Z^T Z        (A = Z acc,     B = Z acc)      ( = V^T X^-1 V, no explicit inverse of X: src/solver.jl:1117)
+//     S  += (lambda lambda^T) o G_X o G_Y                (same lanes hold the same entry of G_X and G_Y)
+// runs from registers to registers.  V is static data: clrs_ctx_create stores it in MFMA-operand order
+// (vop[(t*4+q)*64 + lane] = V[4q + l4, 16t + l15], zero padded), so every load of it is one fully coalesced 512-byte
+// wave access; Y (column-major n x n, n = 16) is in operand order as it stands.  L^-1 comes from the DPP substitution on the
+// identity (clrs_wave.hip.h) with the structural zeros skipped, and runs on the VALU underneath the T_Y / G_Y MFMAs; the
+// row of L_X each lane needs for it is the only thing staged through LDS (2.3 KB per wave, written and read by the same
+// wave: in order, no barrier).  lambda is folded into Z (Z D), so the accumulation into S is one FMA per entry.
+// 1 x 1 dense blocks (Y / X scalars) are rank-1 MFMA steps into the same accumulators when their cluster ends.
+//
+// Work distribution: each wave owns a CONTIGUOUS range of clusters, i.e. a contiguous range of the block table, and walks
+// it with the loads of the next block (and the descriptor of the one after) in flight during the arithmetic of the
+// current one -- across cluster boundaries too, so only a wave's very first block waits for memory.
+#pragma once
+#include "clrs_fused.hip.h"
+
+namespace clrs {
+
+struct W3Block {               // one simple low-rank block (n <= 16, U <= 32) of the flat block sequence
+    long long xyoff;           // offset of the block in the X/Y layout
+    long long S_off;           // last block of a cluster: offset of S_j in the S layout
+    long long dxyoff;          // last block, ndense >= 1: X/Y offset of the cluster's first 1 x 1 dense block
+    int n, U;                  // block side; U = P of the cluster
+    int last;                  // 1: S_j is stored after this block
+    int vop_off;               // W3Tables::vop: the vectors in MFMA-operand order, in units of 512 doubles
+    int lam_off;               // W3Tables::lam / ay: [U] lambda of vector u / position of its term in the A_Y output
+    int pmap_off;              // W3Tables::pmap: [U] constraint of vector u (a permutation of 0..P-1)
+    int ndense, dense0;        // the cluster's 1 x 1 dense blocks: W3Tables::dense[dense0 .. dense0 + ndense)
+    int dlam_off;              // W3Tables::lam: [U] matrix entry of the first dense block for the constraint of vector u
+    int pad;
+};
+struct W3Dense {
+    long long xyoff;
+    int lam_off, pad;
+};
+struct W3Tables {
+    const double *Xc, *Y;      // iterates (xy layout): Cholesky factors of the X blocks, Y blocks
+    double *S, *AY;            // outputs: S layout, A_Y per term
+    const double *vop;         // vectors in MFMA-operand order: vop[(t*4+q)*64 + lane] = V[4q + (lane >> 4), 16t + (lane & 15)]
+    const double *lam;
+    const int *ay, *pmap;
+    const W3Dense *dense;
+};
+
+struct W3Pre {                 // what one PSD block needs from memory, as it arrives in registers
+    double y[4];               // Y[l15, 4q + l4]                       (A operand of T_Y = Y V)
+    double v[8];               // V[4q + l4, 16t + l15] at [t*4 + q]    (B operand of T_Y and Z, A operand of G_Y)
+    double lt[4];              // L[l15, 4q + l4]
+    double dg;                 // L[l15, l15]
+    double lam[2];             // lambda of vector 16t + l15
+    int ay[2];                 // position of the term of vector 16t + l15 in the A_Y output
+};
+
+template <int K, int Q>
+struct W3Sub {                 // substitution steps K.. for the chains whose first non-zero row is <= K
+    static __device__ __forceinline__ void chains(double (&x)[4], const double (&lr)[16], double di) {
+        if constexpr (Q < 4) {
+            if constexpr (4 * Q <= K) {
+                const double b = bcast16<K>(x[Q] * di);
+                x[Q] = __builtin_fma(-lr[K], b, x[Q]);
+            }
+            W3Sub<K, Q + 1>::chains(x, lr, di);
+        }
+    }
+    static __device__ __forceinline__ void run(double (&x)[4], const double (&lr)[16], double di) {
+        if constexpr (K < 15) {
+            chains(x, lr, di);
+            W3Sub<K + 1, 0>::run(x, lr, di);
+        }
+    }
+};
+
+typedef double v2d_f __attribute__((ext_vector_type(2)));
+
+template <bool FULL>           // FULL: every block has n == 16 and U == P == 32 exactly
+__global__ __launch_bounds__(256, 2) void k_cluster_assemble_w3(const int *__restrict__ cluster_blk0, const W3Block *__restrict__ blocks,
+                                                                const W3Tables tb, int nclusters, int nblocks) {
+    constexpr int LD = 18;                                       // doubles per row of the staged L: conflict-free ds_read_b128
+    __shared__ __attribute__((aligned(16))) double lds_all[4 * 16 * LD];
+    const int lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
+    double *Lt = lds_all + wave * 16 * LD;
+    // contiguous cluster range of this wave
+    const int c0 = (int)((long long)gw * nclusters / nw), c1 = (int)((long long)(gw + 1) * nclusters / nw);
+    if (c0 >= c1) return;
+    const int bbeg = cluster_blk0[c0], bend = (c1 < nclusters) ? cluster_blk0[c1] : nblocks;
+
+    auto issue = [&](const W3Block &kb, W3Pre &r) {
+        const double *Lg = tb.Xc + kb.xyoff, *Yg = tb.Y + kb.xyoff, *Vg = tb.vop + (long long)kb.vop_off * 512;
+        const int n = FULL ? 16 : kb.n, U = FULL ? 32 : kb.U;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const bool ok = FULL || (l15 < n && 4 * q + l4 < n);
+            const int idx = ok ? l15 + n * (4 * q + l4) : 0;
+            const double ty = Yg[idx], tl = Lg[idx];
+            r.y[q] = ok ? ty : 0.0;
+            r.lt[q] = ok ? tl : 0.0;
+        }
+#pragma unroll
+        for (int c = 0; c < 8; c++) r.v[c] = Vg[c * 64 + lane];
+        {
+            const bool ok = FULL || l15 < n;
+            const double t = Lg[ok ? l15 * (n + 1) : 0];
+            r.dg = ok ? t : 1.0;
+        }
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const bool ok = FULL || 16 * t + l15 < U;
+            const int idx = kb.lam_off + (ok ? 16 * t + l15 : 0);
+            const double tl = tb.lam[idx];
+            const int ta = tb.ay[idx];
+            r.lam[t] = ok ? tl : 0.0;
+            r.ay[t] = ok ? ta : -1;
+        }
+    };
+
+    v4d_f sacc[3];
+#pragma unroll
+    for (int t = 0; t < 3; t++) sacc[t] = (v4d_f){0.0, 0.0, 0.0, 0.0};
+    const int dreg = (l15 - l4) >> 2;                             // lanes with l15 = 4 dreg + l4 hold a diagonal entry of a diagonal tile
+    const bool on_diag = l15 >= l4 && ((l15 - l4) & 3) == 0;
+
+    // one block: consume `cur` (its loads were issued one block ago), start the loads of block bi + 1 into `nxt`
+    auto process = [&](int bi, const W3Block &k, const W3Block &kn, W3Pre &cur, W3Pre &nxt) {
+        if (bi + 1 < bend) issue(kn, nxt);
+        // ---- what the end of the cluster needs (addresses for S, the first 1 x 1 dense block) ----
+        int pm_v[2], pm_u[8];
+        double da[2], dy = 0.0, dl = 1.0;
+        if (k.last) {
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                const bool okv = FULL || 16 * t + l15 < k.U;
+                pm_v[t] = tb.pmap[k.pmap_off + (okv ? 16 * t + l15 : 0)];
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++) {
+                    const bool oku = FULL || 16 * t + 4 * reg + l4 < k.U;
+                    pm_u[t * 4 + reg] = tb.pmap[k.pmap_off + (oku ? 16 * t + 4 * reg + l4 : 0)];
+                }
+                da[t] = 0.0;
+            }
+            if (k.ndense > 0) {
+                dy = tb.Y[k.dxyoff];
+                dl = tb.Xc[k.dxyoff];
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    const bool ok = FULL || 16 * t + l15 < k.U;
+                    const double ta = tb.lam[k.dlam_off + (ok ? 16 * t + l15 : 0)];
+                    da[t] = ok ? ta : 0.0;
+                }
+            }
+        }
+        // ---- the strictly lower part of L_X through LDS: lane (l15, *) reads row l15 ----
+#pragma unroll
+        for (int q = 0; q < 4; q++) Lt[l15 * LD + 4 * q + l4] = (4 * q + l4 < l15) ? cur.lt[q] : 0.0;
+        double lr[16];
+#pragma unroll
+        for (int p = 0; p < 8; p++) {
+            const v2d_f t2 = *(const v2d_f *)(Lt + l15 * LD + 2 * p);
+            lr[2 * p] = t2[0];
+            lr[2 * p + 1] = t2[1];
+        }
+        // ---- T_Y = Y V: two tiles, accumulator reg = row 4 reg + l4 of T_Y, column 16 t + l15 ----
+        v4d_f ty[2];
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            v4d_f acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < 4; q++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.y[q], cur.v[t * 4 + q], acc, 0, 0, 0);
+            ty[t] = acc;
+        }
+        // ---- L^-1 by substitution on the identity: lane (l15, l4) gets W[l15, 4q + l4], q = 0..3 (VALU, under the MFMAs) ----
+        const double di = (FULL || l15 < k.n) ? 1.0 / cur.dg : 0.0;
+        double x[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) x[q] = (l15 == 4 * q + l4) ? 1.0 : 0.0;
+        W3Sub<0, 0>::run(x, lr, di);
+#pragma unroll
+        for (int q = 0; q < 4; q++) x[q] *= di;
+        // ---- G_Y = V^T T_Y, lower tiles: entry (16 ti + 4 reg + l4, 16 tj + l15) ----
+        v4d_f gy[3];
+#pragma unroll
+        for (int ti = 0; ti < 2; ti++)
+#pragma unroll
+            for (int tj = 0; tj <= ti; tj++) {
+                v4d_f acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int q = 0; q < 4; q++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.v[ti * 4 + q], ty[tj][q], acc, 0, 0, 0);
+                gy[ti * (ti + 1) / 2 + tj] = acc;
+            }
+        // A_Y: the diagonal of G_Y (src/solver.jl:1152-1170): one lane-select, one store per diagonal tile
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const v4d_f g = gy[t * (t + 1) / 2 + t];
+            double dv = g[0];
+            dv = (dreg == 1) ? g[1] : dv;
+            dv = (dreg == 2) ? g[2] : dv;
+            dv = (dreg == 3) ? g[3] : dv;
+            if (on_diag && cur.ay[t] >= 0) tb.AY[cur.ay[t]] = dv;
+        }
+        // ---- Z D = (L^-1 V) diag(lambda) ----
+        v4d_f z[2];
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            v4d_f acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < 4; q++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x[q], cur.v[t * 4 + q], acc, 0, 0, 0);
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) acc[reg] *= cur.lam[t];
+            z[t] = acc;
+        }
+        // ---- D G_X D = (Z D)^T (Z D) tile by tile, times G_Y, into S ----
+#pragma unroll
+        for (int ti = 0; ti < 2; ti++)
+#pragma unroll
+            for (int tj = 0; tj <= ti; tj++) {
+                v4d_f acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int q = 0; q < 4; q++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(z[ti][q], z[tj][q], acc, 0, 0, 0);
+                const int T = ti * (ti + 1) / 2 + tj;
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++) sacc[T][reg] = __builtin_fma(acc[reg], gy[T][reg], sacc[T][reg]);
+            }
+        if (k.last) {
+            // ---- 1 x 1 dense blocks: S[p_u, p_v] += a_u a_v Y / X, one rank-1 MFMA step per tile (k = 0 carries the data) ----
+            for (int e = 0; e < k.ndense; e++) {
+                if (e > 0) {                                        // further dense blocks of the cluster: loaded here (rare)
+                    const W3Dense de = tb.dense[k.dense0 + e];
+                    dy = tb.Y[de.xyoff];
+                    dl = tb.Xc[de.xyoff];
+#pragma unroll
+                    for (int t = 0; t < 2; t++) {
+                        const bool ok = FULL || 16 * t + l15 < k.U;
+                        const double ta = tb.lam[de.lam_off + (ok ? 16 * t + l15 : 0)];
+                        da[t] = ok ? ta : 0.0;
+                    }
+                }
+                const double ratio = dy / (dl * dl);
+                double a[2], ar[2];
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    a[t] = (l4 == 0) ? da[t] : 0.0;
+                    ar[t] = a[t] * ratio;
+                }
+                sacc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[0], a[0], sacc[0], 0, 0, 0);
+                sacc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[1], a[0], sacc[1], 0, 0, 0);
+                sacc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[1], a[1], sacc[2], 0, 0, 0);
+            }
+            // ---- S_j: entries u >= v are computed; both (u, v) and (v, u) are written (symmetric!, src/tools.jl:43-57) ----
+            const int P = FULL ? 32 : k.U;
+            double *Sg = tb.S + k.S_off;
+#pragma unroll
+            for (int ti = 0; ti < 2; ti++)
+#pragma unroll
+                for (int tj = 0; tj <= ti; tj++)
+#pragma unroll
+                    for (int reg = 0; reg < 4; reg++) {
+                        const int u = 16 * ti + 4 * reg + l4, v = 16 * tj + l15;
+                        if (u >= v && (FULL || u < P)) {
+                            const double s = sacc[ti * (ti + 1) / 2 + tj][reg];
+                            const int pu = pm_u[ti * 4 + reg], pv = pm_v[tj];
+                            Sg[pv + pu * P] = s;
+                            Sg[pu + pv * P] = s;
+                        }
+                    }
+#pragma unroll
+            for (int t = 0; t < 3; t++) sacc[t] = (v4d_f){0.0, 0.0, 0.0, 0.0};
+        }
+    };
+
+    W3Pre pa, pb;
+    // descriptors: k0 = current, k1 = next (its loads are issued at the start of the current block), k2 = the one after
+    // (its scalar loads are in flight during the current block)
+    W3Block k0 = blocks[bbeg], k1 = blocks[bbeg + 1 < bend ? bbeg + 1 : bbeg], k2;
+    issue(k0, pa);
+    for (int bi = bbeg;;) {
+        k2 = blocks[bi + 2 < bend ? bi + 2 : bi];
+        process(bi, k0, k1, pa, pb);
+        if (++bi >= bend) break;
+        k0 = k1; k1 = k2;
+        k2 = blocks[bi + 2 < bend ? bi + 2 : bi];
+        process(bi, k0, k1, pb, pa);
+        if (++bi >= bend) break;
+        k0 = k1; k1 = k2;
+    }
+}
+
+}  // namespace clrs

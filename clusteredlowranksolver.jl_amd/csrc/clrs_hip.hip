@@ -25,6 +25,7 @@
 #include "../../include/clrs_hip.h"
 #include "clrs_kernels.hip.h"
 #include "clrs_fused.hip.h"
+#include "clrs_assemble_w3.hip.h"
 #include "clrs_ipm.hip.h"
 
 using namespace clrs;
@@ -49,16 +50,17 @@ static int g_cfg_fused_assemble = 1;
 static int g_cfg_fused_factor = 1;
 static int g_cfg_wave_assemble = 1;
 static int g_cfg_wave2_assemble = 1;
+static int g_cfg_wave3_assemble = 1;   // register-resident form of the cluster-per-wave assembly (U <= 32); 0: k_cluster_assemble_w2
 static int g_cfg_dense_block = 1;
 static const int LDS_BUDGET_DOUBLES = 20000;   // of the 20480 doubles (160 KiB) a workgroup may claim
 
 // ------------------------------------------------------------------------------------------------
 // launch plan
 // ------------------------------------------------------------------------------------------------
-enum StepKind { STEP_MEMCPY, STEP_GEMM, STEP_TRSM, STEP_POTRF, STEP_GATHER_S, STEP_GATHER_SCALAR, STEP_SUB, STEP_MEMSET_INFO, STEP_ZERO_UPPER, STEP_FUSED_ASSEMBLE, STEP_SMALL_POTRF, STEP_CLUSTER_FACTOR, STEP_GEMV_T, STEP_CSOLVE_FWD, STEP_Q_SOLVE, STEP_CSOLVE_BWD, STEP_SUM_SLABS, STEP_ASSEMBLE_W1, STEP_GRAM_SMALL, STEP_ASSEMBLE_W2, STEP_SOLVE_SMALL, STEP_DENSE_BLOCK, STEP_NKINDS };
+enum StepKind { STEP_MEMCPY, STEP_GEMM, STEP_TRSM, STEP_POTRF, STEP_GATHER_S, STEP_GATHER_SCALAR, STEP_SUB, STEP_MEMSET_INFO, STEP_ZERO_UPPER, STEP_FUSED_ASSEMBLE, STEP_SMALL_POTRF, STEP_CLUSTER_FACTOR, STEP_GEMV_T, STEP_CSOLVE_FWD, STEP_Q_SOLVE, STEP_CSOLVE_BWD, STEP_SUM_SLABS, STEP_ASSEMBLE_W1, STEP_GRAM_SMALL, STEP_ASSEMBLE_W2, STEP_SOLVE_SMALL, STEP_DENSE_BLOCK, STEP_ASSEMBLE_W3, STEP_NKINDS };
 static const char *const STEP_NAMES[STEP_NKINDS] = {"hipMemcpyAsync(D2D)", "k_gemm_f64_t", "k_trsm_diag", "k_potrf_diag", "k_schur_gather",
                                                     "k_gather_scalar", "k_sub", "hipMemsetAsync", "k_zero_upper", "k_cluster_assemble", "k_small_potrf", "k_cluster_factor", "k_gemv_t",
-                                                    "k_cluster_solve_fwd", "k_q_solve", "k_cluster_solve_bwd", "k_sum_slabs", "k_cluster_assemble_w1", "k_gram_small", "k_cluster_assemble_w2", "k_solve_small", "k_dense_block"};
+                                                    "k_cluster_solve_fwd", "k_q_solve", "k_cluster_solve_bwd", "k_sum_slabs", "k_cluster_assemble_w1", "k_gram_small", "k_cluster_assemble_w2", "k_solve_small", "k_dense_block", "k_cluster_assemble_w3"};
 static const int KT_MAX_EVENTS = 8192;   // event pairs kept between two clrs_get_kernel_times calls
 
 struct Step {
@@ -70,6 +72,7 @@ struct Step {
     size_t bytes = 0;
     i64 n = 0;
     int nmax = 0;
+    int aux0 = 0, aux1 = 0;   // kind-specific (STEP_ASSEMBLE_W3: grid size, number of blocks)
 };
 
 struct Plan {
@@ -145,6 +148,7 @@ struct clrs_ctx {
     double *d_X = nullptr;  // scratch for clrs_cholesky_blocks
     Plan p_assemble, p_cholS, p_linvB, p_Q, p_cholQ, p_fwd, p_bwd, p_cholX;
     FTables ftables = {};
+    W3Tables w3tables = {};
     // caller-provided device pointers of the current call, read by the fused kernels at launch (no staging copies)
     const double *bind_X = nullptr, *bind_rhsx = nullptr, *bind_rhsy = nullptr;
     double *bind_Xchol = nullptr, *bind_dx = nullptr, *bind_dy = nullptr;
@@ -397,6 +401,15 @@ static int run_steps(clrs_ctx *c, const Plan &pl) {
                     hipLaunchKernelGGL((k_cluster_assemble_w2<2, false>), dim3((ncl + 3) / 4), dim3(256), s.bytes, st, (const W2Cluster *)s.d0, (const W2Block *)s.d1, *tb, ncl);
                 else
                     hipLaunchKernelGGL((k_cluster_assemble_w2<4, false>), dim3((ncl + 3) / 4), dim3(256), s.bytes, st, (const W2Cluster *)s.d0, (const W2Block *)s.d1, *tb, ncl);
+                break;
+            }
+            case STEP_ASSEMBLE_W3: {
+                W3Tables tb = *(const W3Tables *)s.src;
+                tb.Xc = c->ftables.Xc; tb.Y = c->ftables.Y;      // the iterates bound for this call (the caller's buffers or the context's)
+                if (s.grid != 0)
+                    hipLaunchKernelGGL((k_cluster_assemble_w3<true>), dim3(s.aux0), dim3(256), 0, st, (const int *)s.d0, (const W3Block *)s.d1, tb, (int)s.n, s.aux1);
+                else
+                    hipLaunchKernelGGL((k_cluster_assemble_w3<false>), dim3(s.aux0), dim3(256), 0, st, (const int *)s.d0, (const W3Block *)s.d1, tb, (int)s.n, s.aux1);
                 break;
             }
             case STEP_ASSEMBLE_W1: {
@@ -1077,12 +1090,66 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
             c->ftables.Xc = c->d_Xc; c->ftables.Y = c->d_Y; c->ftables.stat = c->d_static; c->ftables.AY = c->d_AY;
             Step s;
             s.kind = STEP_ASSEMBLE_W2;
+            const bool use_w3 = g_cfg_wave3_assemble && w2_ut <= 2;
             s.d0 = dwc; s.d1 = dwb; s.src = &c->ftables; s.n = (i64)w2cl.size(); s.nmax = w2_ut;
             bool full = w2_ut <= 2;
             for (size_t i2 = 0; i2 < w2bl.size() && full; i2++) if (w2bl[i2].kind == 0 && w2bl[i2].n != 16) full = false;
             for (size_t i2 = 0; i2 < w2cl.size() && full; i2++) if (w2cl[i2].P != 16 * w2_ut) full = false;
             s.grid = full ? 1 : 0;
             s.bytes = (size_t)4 * 2 * 17 * 16 * w2_ut * sizeof(double);
+            if (use_w3) {
+                // k_cluster_assemble_w3: flat sequence of the low-rank blocks, vectors in MFMA-operand order, the 1 x 1 dense
+                // blocks attached to the last low-rank block of their cluster
+                std::vector<W3Block> b3;
+                std::vector<W3Dense> d3;
+                std::vector<int> cl_blk0;
+                std::vector<double> h_vop;
+                for (size_t ci = 0; ci < w2cl.size(); ci++) {
+                    const W2Cluster &wc = w2cl[ci];
+                    cl_blk0.push_back((int)b3.size());
+                    const int dense0 = (int)d3.size();
+                    size_t last_lr = 0;
+                    for (int i2 = 0; i2 < wc.nblk; i2++) {
+                        const size_t bi2 = (size_t)wc.blk0 + i2;
+                        const W2Block &q2 = w2bl[bi2];
+                        if (q2.kind != 0) { W3Dense de; de.xyoff = q2.xyoff; de.lam_off = (int)w2_boff[bi2]; de.pad = 0; d3.push_back(de); continue; }
+                        W3Block k3;
+                        std::memset(&k3, 0, sizeof(k3));
+                        k3.xyoff = q2.xyoff; k3.n = q2.n; k3.U = wc.P; k3.lam_off = (int)w2_boff[bi2]; k3.pmap_off = (int)w2_cl_pm[ci];
+                        k3.vop_off = (int)(h_vop.size() / 512);
+                        h_vop.resize(h_vop.size() + 512, 0.0);
+                        double *dst = h_vop.data() + (size_t)k3.vop_off * 512;
+                        const double *V = h_static.data() + q2.v_off;
+                        for (int t = 0; t < 2; t++)
+                            for (int q = 0; q < 4; q++)
+                                for (int ln = 0; ln < 64; ln++) {
+                                    const int row = 4 * q + (ln >> 4), col = 16 * t + (ln & 15);
+                                    if (row < q2.n && col < wc.P) dst[(t * 4 + q) * 64 + ln] = V[row + (i64)col * q2.n];
+                                }
+                        last_lr = b3.size();
+                        b3.push_back(k3);
+                    }
+                    W3Block &kl = b3[last_lr];
+                    kl.last = 1; kl.S_off = (i64)(wc.S - c->d_S);
+                    kl.ndense = (int)d3.size() - dense0; kl.dense0 = dense0;
+                    if (kl.ndense > 0) { kl.dxyoff = d3[dense0].xyoff; kl.dlam_off = d3[dense0].lam_off; }
+                }
+                if (d3.empty()) { W3Dense de; std::memset(&de, 0, sizeof(de)); d3.push_back(de); }
+                int *dcb; W3Block *db3; W3Dense *dd3; double *dvop;
+                CK(upload(c, cl_blk0, &dcb)); CK(upload(c, b3, &db3)); CK(upload(c, d3, &dd3)); CK(upload(c, h_vop, &dvop));
+                c->w3tables.Xc = c->d_Xc; c->w3tables.Y = c->d_Y; c->w3tables.S = c->d_S; c->w3tables.AY = c->d_AY;
+                c->w3tables.vop = dvop; c->w3tables.lam = dlam; c->w3tables.ay = day; c->w3tables.pmap = dpm; c->w3tables.dense = dd3;
+                // persistent form: as many workgroups as are resident at once, each wave walks a contiguous range of clusters
+                int per_cu = 2, cus = 256, dev = 0;
+                hipDeviceProp_t prop;
+                if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+                if (full) { if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_cluster_assemble_w3<true>, 256, 0) != hipSuccess) per_cu = 2; }
+                else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_cluster_assemble_w3<false>, 256, 0) != hipSuccess) per_cu = 2;
+                s.kind = STEP_ASSEMBLE_W3;
+                s.d0 = dcb; s.d1 = db3; s.src = &c->w3tables; s.bytes = 0;
+                s.aux0 = (int)std::min<i64>(((i64)w2cl.size() + 3) / 4, (i64)std::max(per_cu, 1) * cus);
+                s.aux1 = (int)b3.size();
+            }
             pl.steps.push_back(s);
             if (s.bytes > 64 * 1024) HIPCK(hipFuncSetAttribute((const void *)k_cluster_assemble_w2<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s.bytes));
         }
@@ -1753,6 +1820,7 @@ extern "C" int clrs_config_set(const char *key, int value) {
     if (!std::strcmp(key, "fused_factor")) { g_cfg_fused_factor = value; return 0; }
     if (!std::strcmp(key, "wave_assemble")) { g_cfg_wave_assemble = value; return 0; }
     if (!std::strcmp(key, "wave2_assemble")) { g_cfg_wave2_assemble = value; return 0; }
+    if (!std::strcmp(key, "wave3_assemble")) { g_cfg_wave3_assemble = value; return 0; }
     if (!std::strcmp(key, "dense_block")) { g_cfg_dense_block = value; return 0; }
     return fail(CLRS_ERR_INVALID, std::string("unknown configuration key ") + key);
 }

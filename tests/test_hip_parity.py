@@ -65,8 +65,8 @@ ASSEMBLE_CASES = ["x2p1", "polyopt8", "polyopt40", "delsarte_3_10", "delsarte_8_
                   "threepoint_4", "sdpa_small", "sdpa_mid", "polyopt_scaled_100"]
 
 
-PATHS = {"wave2": dict(fused=True, wave=True, wave2=True), "wave": dict(fused=True, wave=True, wave2=False), "fused": dict(fused=True, wave=False),
-         "staged": dict(fused=False)}
+PATHS = {"wave3": dict(fused=True, wave=True, wave2=True, wave3=True), "wave2": dict(fused=True, wave=True, wave2=True, wave3=False),
+         "wave": dict(fused=True, wave=True, wave2=False), "fused": dict(fused=True, wave=False), "staged": dict(fused=False)}
 WAVE2_CASES = {"x2p1": 1, "polyopt8": 1, "delsarte_8_3": 0, "ce_8_15": 2, "ce_8_3": 2}    # clusters taken by k_cluster_assemble_w2
 WAVE_CASES = {"x2p1", "polyopt8", "delsarte_3_10", "delsarte_8_3", "ce_8_15", "ce_8_3", "sdpa_small"}   # every cluster takes k_cluster_assemble_w1
 
@@ -82,9 +82,9 @@ def test_schur_assemble_matches_oracle(name, path, oracle_built):
     ctx = SchurContext(f, **PATHS[path])
     fused = path != "staged"
     assert (ctx.fused_clusters() > 0) == (fused and name not in ("sdpa_mid", "polyopt_scaled_100"))
-    if path in ("wave", "wave2") and name in WAVE_CASES:
+    if path in ("wave", "wave2", "wave3") and name in WAVE_CASES:
         assert ctx.wave_clusters() == f.n_clusters
-    if path == "wave2" and name in WAVE2_CASES:
+    if path in ("wave2", "wave3") and name in WAVE2_CASES:
         assert ctx.wave2_clusters() == WAVE2_CASES[name]
     if path == "wave":
         assert ctx.wave2_clusters() == 0
@@ -103,6 +103,46 @@ def test_schur_assemble_matches_oracle(name, path, oracle_built):
         Sj = S[f.S_off[j]:f.S_off[j + 1]].reshape(P, P, order="F")
         assert np.array_equal(Sj, Sj.T)
     ctx.close()
+
+
+@pytest.mark.parametrize("name,copies", [("ce_8_15", 1100), ("ce_8_3", 1100), ("polyopt8", 2500)])
+def test_cluster_per_wave_assembly_many_clusters(name, copies, oracle_built):
+    """k_cluster_assemble_w3 with several clusters per wave (contiguous cluster ranges, loads of the next cluster's first block in
+    flight across the cluster boundary): more clusters than resident waves, every cluster checked against the oracle."""
+    import torch
+    torch.cuda.set_device(0)       # torch's HIP runtime first (as in bench.py); the library then shares the device with it
+    from clrs_amd.sdp import replicate_clusters
+    from clrs_amd.solver import SchurContext
+    from oracle.oracle import Oracle
+    f = flat(name)
+    big = replicate_clusters(f, copies)
+    X, Y = spd_iterates(big, seed=7)
+    Xc = chol_blocks_np(big, X)
+    ctx = SchurContext(big)
+    assert ctx.wave2_clusters() == big.n_clusters
+    S, AY = ctx.compute_S_integrated(Xc, Y)
+    # the device-pointer entry reads the caller's buffers directly: same result from other iterates held in torch tensors
+    from clrs_amd.sharded import _DevArray
+    X2, Y2 = spd_iterates(big, seed=8)
+    Xc2 = chol_blocks_np(big, X2)
+    tX, tY = torch.from_numpy(Xc2).to("cuda:0"), torch.from_numpy(Y2).to("cuda:0")
+    torch.cuda.synchronize()
+    ctx.assemble_dev(tX.data_ptr(), tY.data_ptr())
+    torch.cuda.synchronize()
+    S2 = torch.as_tensor(_DevArray(ctx.S_buffer(), big.S_len), device="cuda:0").cpu().numpy()
+    ctx.close()
+    o = Oracle(f, quad=False)
+    nxy, nS, nT = f.xy_len, f.S_len, f.n_terms
+    for k in (0, copies // 2, copies - 1):
+        Sk, _ = o.schur_assemble(Xc2[k * nxy:(k + 1) * nxy], Y2[k * nxy:(k + 1) * nxy])
+        assert np.max(np.abs(S2[k * nS:(k + 1) * nS] - Sk)) <= 1e-11 * np.max(np.abs(Sk))
+    worst = 0.0
+    for k in range(copies):
+        Sk, AYk = o.schur_assemble(Xc[k * nxy:(k + 1) * nxy], Y[k * nxy:(k + 1) * nxy])
+        worst = max(worst, np.max(np.abs(S[k * nS:(k + 1) * nS] - Sk)) / np.max(np.abs(Sk)))
+        if nT:
+            worst = max(worst, np.max(np.abs(AY[k * nT:(k + 1) * nT] - AYk)) / max(1.0, np.max(np.abs(AYk))))
+    assert worst <= 1e-11
 
 
 def test_dedup_counts_match_oracle(oracle_built):
