@@ -159,6 +159,13 @@ def load(path: str = None):
         if not os.path.exists(LIB_PATH):
             raise ClrsError(-100, f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                   f"(the HIP extension is the only compute path)")
+        # One HIP runtime per process: PyTorch bundles its own libamdhip64, and a process that loads /opt/rocm's copy first
+        # (through this library) and torch's afterwards ends up with two runtimes, the second of which sees no GPU.  Importing
+        # torch first makes its copy the one the dynamic linker binds this library to as well (import only: no GPU is touched).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)   # AttributeError here = header and library out of sync

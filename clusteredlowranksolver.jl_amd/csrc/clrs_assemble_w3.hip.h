@@ -40,7 +40,7 @@ struct W3Block {               // one simple low-rank block (n <= 16, U <= 32) o
     int pmap_off;              // W3Tables::pmap: [U] constraint of vector u (a permutation of 0..P-1)
     int ndense, dense0;        // the cluster's 1 x 1 dense blocks: W3Tables::dense[dense0 .. dense0 + ndense)
     int dlam_off;              // W3Tables::lam: [U] matrix entry of the first dense block for the constraint of vector u
-    int pad;
+    int pmap_identity;         // 1: pmap[u] == u (the usual case): the S store needs no table
 };
 struct W3Dense {
     long long xyoff;
@@ -62,26 +62,66 @@ struct W3Pre {                 // what one PSD block needs from memory, as it ar
     double dg;                 // L[l15, l15]
     double lam[2];             // lambda of vector 16t + l15
     int ay[2];                 // position of the term of vector 16t + l15 in the A_Y output
+    double da[2], dy, dl;      // the cluster's first 1 x 1 dense block (last block of a cluster only; harmless reads otherwise):
+                               // its entry for the constraint of vector 16t + l15, Y, chol X
 };
 
-template <int K, int Q>
-struct W3Sub {                 // substitution steps K.. for the chains whose first non-zero row is <= K
-    static __device__ __forceinline__ void chains(double (&x)[4], const double (&lr)[16], double di) {
-        if constexpr (Q < 4) {
-            if constexpr (4 * Q <= K) {
-                const double b = bcast16<K>(x[Q] * di);
-                x[Q] = __builtin_fma(-lr[K], b, x[Q]);
-            }
-            W3Sub<K, Q + 1>::chains(x, lr, di);
-        }
-    }
-    static __device__ __forceinline__ void run(double (&x)[4], const double (&lr)[16], double di) {
-        if constexpr (K < 15) {
-            chains(x, lr, di);
-            W3Sub<K + 1, 0>::run(x, lr, di);
-        }
-    }
-};
+// Forward substitution on four right-hand-side groups inside a wave, one instruction per elimination:
+//     x_q[i] += x_q[K] * m[K]      for the lanes i of every 16-lane row, x_q[K] read from lane K of the row by DPP
+// (v_fmac_f64_dpp with row_newbcast -- the only DPP control the 64-bit ALU has).  m[K] = -L[i,K] / L[i,i] for K < i and 0
+// otherwise (row-scaled, so the system is unit lower triangular and no step multiplies by a reciprocal), the right-hand
+// side is D^-1: the result is L^-1.  Lane (l15, l4) carries columns 4q + l4 of the right-hand side in x_q: column c is zero
+// above row c, so chain q starts at step 4q: 36 eliminations instead of 60.  The chains are independent of each other; they
+// are interleaved so that an instruction reads a register written at least three instructions earlier (a DPP read needs two
+// wait states after the VALU write); the tail of the longest chain is padded with s_nop.
+__device__ __forceinline__ void w3_substitute(double (&x)[4], const double (&m)[16]) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_fmac_f64_dpp %0, %0, %4 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %1, %8 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %2, %2, %12 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %0, %5 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %1, %9 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %2, %2, %13 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %0, %6 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %1, %10 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %2, %2, %14 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %0, %7 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %1, %11 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %2, %2, %15 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %0, %8 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %1, %12 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %2, %2, %16 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %0, %9 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %1, %13 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %3, %3, %16 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %0, %10 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %1, %14 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %2, %2, %17 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %0, %11 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %1, %15 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %3, %3, %17 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %0, %12 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %1, %16 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %2, %2, %18 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %0, %13 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %1, %17 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %3, %3, %18 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %0, %14 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %1, %18 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_fmac_f64_dpp %0, %0, %15 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_fmac_f64_dpp %0, %0, %16 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_fmac_f64_dpp %0, %0, %17 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_fmac_f64_dpp %0, %0, %18 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3])
+        : "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7]), "v"(m[8]), "v"(m[9]), "v"(m[10]), "v"(m[11]),
+          "v"(m[12]), "v"(m[13]), "v"(m[14]));
+}
 
 typedef double v2d_f __attribute__((ext_vector_type(2)));
 
@@ -126,6 +166,23 @@ __global__ __launch_bounds__(256, 2) void k_cluster_assemble_w3(const int *__res
             r.lam[t] = ok ? tl : 0.0;
             r.ay[t] = ok ? ta : -1;
         }
+        // first 1 x 1 dense block of the cluster, fetched with the cluster's last block.  These loads are issued for EVERY block (from
+        // addresses that are valid anyway when there is nothing to fetch): the number of vector-memory operations per block must not
+        // depend on the block, or the s_waitcnt vmcnt(N) the compiler places before the first use of this block's data would have to
+        // assume the smaller count and so also wait for the loads of the block after it.
+        {
+            const bool has = kb.last && kb.ndense > 0;
+            const long long dxy = has ? kb.dxyoff : kb.xyoff;
+            const int dlo = has ? kb.dlam_off : kb.lam_off;
+            r.dy = tb.Y[dxy];
+            r.dl = tb.Xc[dxy];
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                const bool ok = FULL || 16 * t + l15 < U;
+                const double ta = tb.lam[dlo + (ok ? 16 * t + l15 : 0)];
+                r.da[t] = ok ? ta : 0.0;
+            }
+        }
     };
 
     v4d_f sacc[3];
@@ -136,36 +193,14 @@ __global__ __launch_bounds__(256, 2) void k_cluster_assemble_w3(const int *__res
 
     // one block: consume `cur` (its loads were issued one block ago), start the loads of block bi + 1 into `nxt`
     auto process = [&](int bi, const W3Block &k, const W3Block &kn, W3Pre &cur, W3Pre &nxt) {
-        if (bi + 1 < bend) issue(kn, nxt);
-        // ---- what the end of the cluster needs (addresses for S, the first 1 x 1 dense block) ----
-        int pm_v[2], pm_u[8];
-        double da[2], dy = 0.0, dl = 1.0;
-        if (k.last) {
+        issue(kn, nxt);          // unconditional (the last block of the range re-reads itself): see the note on the dense loads in issue()
+        // ---- m = -D^-1 strict_lower(L_X) through LDS: lane (l15, *) reads row l15 ----
+        double di = __builtin_amdgcn_rcp(cur.dg);                   // 1 / L[l15,l15]: v_rcp_f64 + two Newton steps
+        di = __builtin_fma(__builtin_fma(-cur.dg, di, 1.0), di, di);
+        di = __builtin_fma(__builtin_fma(-cur.dg, di, 1.0), di, di);
+        if (!FULL) di = (l15 < k.n) ? di : 0.0;
 #pragma unroll
-            for (int t = 0; t < 2; t++) {
-                const bool okv = FULL || 16 * t + l15 < k.U;
-                pm_v[t] = tb.pmap[k.pmap_off + (okv ? 16 * t + l15 : 0)];
-#pragma unroll
-                for (int reg = 0; reg < 4; reg++) {
-                    const bool oku = FULL || 16 * t + 4 * reg + l4 < k.U;
-                    pm_u[t * 4 + reg] = tb.pmap[k.pmap_off + (oku ? 16 * t + 4 * reg + l4 : 0)];
-                }
-                da[t] = 0.0;
-            }
-            if (k.ndense > 0) {
-                dy = tb.Y[k.dxyoff];
-                dl = tb.Xc[k.dxyoff];
-#pragma unroll
-                for (int t = 0; t < 2; t++) {
-                    const bool ok = FULL || 16 * t + l15 < k.U;
-                    const double ta = tb.lam[k.dlam_off + (ok ? 16 * t + l15 : 0)];
-                    da[t] = ok ? ta : 0.0;
-                }
-            }
-        }
-        // ---- the strictly lower part of L_X through LDS: lane (l15, *) reads row l15 ----
-#pragma unroll
-        for (int q = 0; q < 4; q++) Lt[l15 * LD + 4 * q + l4] = (4 * q + l4 < l15) ? cur.lt[q] : 0.0;
+        for (int q = 0; q < 4; q++) Lt[l15 * LD + 4 * q + l4] = (4 * q + l4 < l15) ? -(cur.lt[q] * di) : 0.0;
         double lr[16];
 #pragma unroll
         for (int p = 0; p < 8; p++) {
@@ -182,14 +217,11 @@ __global__ __launch_bounds__(256, 2) void k_cluster_assemble_w3(const int *__res
             for (int q = 0; q < 4; q++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.y[q], cur.v[t * 4 + q], acc, 0, 0, 0);
             ty[t] = acc;
         }
-        // ---- L^-1 by substitution on the identity: lane (l15, l4) gets W[l15, 4q + l4], q = 0..3 (VALU, under the MFMAs) ----
-        const double di = (FULL || l15 < k.n) ? 1.0 / cur.dg : 0.0;
+        // ---- L^-1 = (D^-1 L)^-1 D^-1 by substitution: lane (l15, l4) gets W[l15, 4q + l4], q = 0..3 ----
         double x[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) x[q] = (l15 == 4 * q + l4) ? 1.0 : 0.0;
-        W3Sub<0, 0>::run(x, lr, di);
-#pragma unroll
-        for (int q = 0; q < 4; q++) x[q] *= di;
+        for (int q = 0; q < 4; q++) x[q] = (l15 == 4 * q + l4) ? di : 0.0;
+        w3_substitute(x, lr);
         // ---- G_Y = V^T T_Y, lower tiles: entry (16 ti + 4 reg + l4, 16 tj + l15) ----
         v4d_f gy[3];
 #pragma unroll
@@ -236,6 +268,7 @@ __global__ __launch_bounds__(256, 2) void k_cluster_assemble_w3(const int *__res
             }
         if (k.last) {
             // ---- 1 x 1 dense blocks: S[p_u, p_v] += a_u a_v Y / X, one rank-1 MFMA step per tile (k = 0 carries the data) ----
+            double da[2] = {cur.da[0], cur.da[1]}, dy = cur.dy, dl = cur.dl;
             for (int e = 0; e < k.ndense; e++) {
                 if (e > 0) {                                        // further dense blocks of the cluster: loaded here (rare)
                     const W3Dense de = tb.dense[k.dense0 + e];
@@ -258,6 +291,22 @@ __global__ __launch_bounds__(256, 2) void k_cluster_assemble_w3(const int *__res
                 sacc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[0], a[0], sacc[0], 0, 0, 0);
                 sacc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[1], a[0], sacc[1], 0, 0, 0);
                 sacc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[1], a[1], sacc[2], 0, 0, 0);
+            }
+            // the constraint of vector u: u itself unless the cluster carries a permutation (then read here: rare, waits for memory)
+            int pm_v[2], pm_u[8];
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                pm_v[t] = 16 * t + l15;
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++) pm_u[t * 4 + reg] = 16 * t + 4 * reg + l4;
+            }
+            if (!k.pmap_identity) {
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    pm_v[t] = tb.pmap[k.pmap_off + ((FULL || pm_v[t] < k.U) ? pm_v[t] : 0)];
+#pragma unroll
+                    for (int reg = 0; reg < 4; reg++) pm_u[t * 4 + reg] = tb.pmap[k.pmap_off + ((FULL || pm_u[t * 4 + reg] < k.U) ? pm_u[t * 4 + reg] : 0)];
+                }
             }
             // ---- S_j: entries u >= v are computed; both (u, v) and (v, u) are written (symmetric!, src/tools.jl:43-57) ----
             const int P = FULL ? 32 : k.U;

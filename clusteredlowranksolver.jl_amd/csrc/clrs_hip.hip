@@ -1131,6 +1131,8 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
                     }
                     W3Block &kl = b3[last_lr];
                     kl.last = 1; kl.S_off = (i64)(wc.S - c->d_S);
+                    kl.pmap_identity = 1;
+                    for (int u = 0; u < wc.P; u++) if (w2_pmap[w2_cl_pm[ci] + u] != u) kl.pmap_identity = 0;
                     kl.ndense = (int)d3.size() - dense0; kl.dense0 = dense0;
                     if (kl.ndense > 0) { kl.dxyoff = d3[dense0].xyoff; kl.dlam_off = d3[dense0].lam_off; }
                 }
