@@ -46,12 +46,18 @@ struct W3Dense {
     long long xyoff;
     int lam_off, pad;
 };
+struct W3LamAy {               // per vector of a low-rank block, one 16-byte load
+    double lam;                // lambda of its term
+    int ay, pad;               // position of the term in the A_Y output
+};
 struct W3Tables {
     const double *Xc, *Y;      // iterates (xy layout): Cholesky factors of the X blocks, Y blocks
     double *S, *AY;            // outputs: S layout, A_Y per term
-    const double *vop;         // vectors in MFMA-operand order: vop[(t*4+q)*64 + lane] = V[4q + (lane >> 4), 16t + (lane & 15)]
-    const double *lam;
-    const int *ay, *pmap;
+    const double *vop;         // vectors in MFMA-operand order, two k-steps per 16-byte lane element:
+                               // vop[((t*2+p)*64 + lane)*2 + e] = V[4(2p+e) + (lane >> 4), 16t + (lane & 15)], zero padded
+    const W3LamAy *lamay;      // [lam_off + u]
+    const double *lam;         // [dlam_off + u]: entries of the 1 x 1 dense blocks
+    const int *pmap;
     const W3Dense *dense;
 };
 
@@ -59,7 +65,6 @@ struct W3Pre {                 // what one PSD block needs from memory, as it ar
     double y[4];               // Y[l15, 4q + l4]                       (A operand of T_Y = Y V)
     double v[8];               // V[4q + l4, 16t + l15] at [t*4 + q]    (B operand of T_Y and Z, A operand of G_Y)
     double lt[4];              // L[l15, 4q + l4]
-    double dg;                 // L[l15, l15]
     double lam[2];             // lambda of vector 16t + l15
     int ay[2];                 // position of the term of vector 16t + l15 in the A_Y output
     double da[2], dy, dl;      // the cluster's first 1 x 1 dense block (last block of a cluster only; harmless reads otherwise):
@@ -125,15 +130,33 @@ __device__ __forceinline__ void w3_substitute(double (&x)[4], const double (&m)[
 
 typedef double v2d_f __attribute__((ext_vector_type(2)));
 
+// Diagnostic builds (-DCLRS_W3_STAMPS): wave 0 of workgroup 0 accumulates the shader cycles (s_memtime) it spends in each phase
+// of a block; read back with clrs_debug_w3_stamps.  The product build contains none of this.
+#ifdef CLRS_W3_STAMPS
+__device__ unsigned long long g_w3_stamps[16];
+#define W3_STAMP(i)                                                                  \
+    do {                                                                             \
+        if (gw == 0) {                                                               \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();              \
+            st_acc[i] += t_ - st_prev;                                               \
+            st_prev = t_;                                                            \
+        }                                                                            \
+    } while (0)
+#else
+#define W3_STAMP(i) do { } while (0)
+#endif
+
 template <bool FULL>           // FULL: every block has n == 16 and U == P == 32 exactly
 __global__ __launch_bounds__(256, 2) void k_cluster_assemble_w3(const int *__restrict__ cluster_blk0, const W3Block *__restrict__ blocks,
                                                                 const W3Tables tb, int nclusters, int nblocks) {
     constexpr int LD = 18;                                       // doubles per row of the staged L: conflict-free ds_read_b128
-    __shared__ __attribute__((aligned(16))) double lds_all[4 * 16 * LD];
+    constexpr int LDS_S = 34;                                    // leading dimension of the staged S_j (even: 16-byte aligned pairs)
+    constexpr int PER_WAVE = 16 * LD + 16 + 32 * LDS_S;          // L rows | diagonal of L | S_j
+    __shared__ __attribute__((aligned(16))) double lds_all[4 * PER_WAVE];
     const int lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
-    double *Lt = lds_all + wave * 16 * LD;
+    double *Lt = lds_all + wave * PER_WAVE, *Ld = Lt + 16 * LD, *Ss = Ld + 16;
     // contiguous cluster range of this wave
     const int c0 = (int)((long long)gw * nclusters / nw), c1 = (int)((long long)(gw + 1) * nclusters / nw);
     if (c0 >= c1) return;
@@ -151,20 +174,17 @@ __global__ __launch_bounds__(256, 2) void k_cluster_assemble_w3(const int *__res
             r.lt[q] = ok ? tl : 0.0;
         }
 #pragma unroll
-        for (int c = 0; c < 8; c++) r.v[c] = Vg[c * 64 + lane];
-        {
-            const bool ok = FULL || l15 < n;
-            const double t = Lg[ok ? l15 * (n + 1) : 0];
-            r.dg = ok ? t : 1.0;
+        for (int c = 0; c < 4; c++) {                               // 16 bytes per lane: k-steps 2p and 2p + 1 of tile t, c = 2t + p
+            const v2d_f w = ((const v2d_f *)Vg)[c * 64 + lane];
+            r.v[2 * c] = w[0];
+            r.v[2 * c + 1] = w[1];
         }
 #pragma unroll
         for (int t = 0; t < 2; t++) {
             const bool ok = FULL || 16 * t + l15 < U;
-            const int idx = kb.lam_off + (ok ? 16 * t + l15 : 0);
-            const double tl = tb.lam[idx];
-            const int ta = tb.ay[idx];
-            r.lam[t] = ok ? tl : 0.0;
-            r.ay[t] = ok ? ta : -1;
+            const W3LamAy la = tb.lamay[kb.lam_off + (ok ? 16 * t + l15 : 0)];
+            r.lam[t] = ok ? la.lam : 0.0;
+            r.ay[t] = ok ? la.ay : -1;
         }
         // first 1 x 1 dense block of the cluster, fetched with the cluster's last block.  These loads are issued for EVERY block (from
         // addresses that are valid anyway when there is nothing to fetch): the number of vector-memory operations per block must not
@@ -188,19 +208,34 @@ __global__ __launch_bounds__(256, 2) void k_cluster_assemble_w3(const int *__res
     v4d_f sacc[3];
 #pragma unroll
     for (int t = 0; t < 3; t++) sacc[t] = (v4d_f){0.0, 0.0, 0.0, 0.0};
+#ifdef CLRS_W3_STAMPS
+    unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_prev = __builtin_amdgcn_s_memtime();
+#endif
     const int dreg = (l15 - l4) >> 2;                             // lanes with l15 = 4 dreg + l4 hold a diagonal entry of a diagonal tile
     const bool on_diag = l15 >= l4 && ((l15 - l4) & 3) == 0;
 
     // one block: consume `cur` (its loads were issued one block ago), start the loads of block bi + 1 into `nxt`
     auto process = [&](int bi, const W3Block &k, const W3Block &kn, W3Pre &cur, W3Pre &nxt) {
+        W3_STAMP(0);
         issue(kn, nxt);          // unconditional (the last block of the range re-reads itself): see the note on the dense loads in issue()
+        // ---- the diagonal of L_X: the lane that holds L[l15,l15] in lt[] hands it to its row through LDS ----
+        {
+            double dsel = cur.lt[0];
+            dsel = (dreg == 1) ? cur.lt[1] : dsel;
+            dsel = (dreg == 2) ? cur.lt[2] : dsel;
+            dsel = (dreg == 3) ? cur.lt[3] : dsel;
+            if (on_diag) Ld[l15] = dsel;
+        }
+        wave_sync();             // LDS hand-offs between lanes of this wave: in order in hardware, this only pins the compiler's order
+        const double dg = Ld[l15];
         // ---- m = -D^-1 strict_lower(L_X) through LDS: lane (l15, *) reads row l15 ----
-        double di = __builtin_amdgcn_rcp(cur.dg);                   // 1 / L[l15,l15]: v_rcp_f64 + two Newton steps
-        di = __builtin_fma(__builtin_fma(-cur.dg, di, 1.0), di, di);
-        di = __builtin_fma(__builtin_fma(-cur.dg, di, 1.0), di, di);
+        double di = __builtin_amdgcn_rcp(dg);                       // 1 / L[l15,l15]: v_rcp_f64 + two Newton steps
+        di = __builtin_fma(__builtin_fma(-dg, di, 1.0), di, di);
+        di = __builtin_fma(__builtin_fma(-dg, di, 1.0), di, di);
         if (!FULL) di = (l15 < k.n) ? di : 0.0;
 #pragma unroll
         for (int q = 0; q < 4; q++) Lt[l15 * LD + 4 * q + l4] = (4 * q + l4 < l15) ? -(cur.lt[q] * di) : 0.0;
+        wave_sync();
         double lr[16];
 #pragma unroll
         for (int p = 0; p < 8; p++) {
@@ -208,6 +243,8 @@ __global__ __launch_bounds__(256, 2) void k_cluster_assemble_w3(const int *__res
             lr[2 * p] = t2[0];
             lr[2 * p + 1] = t2[1];
         }
+        wave_sync();
+        W3_STAMP(1);
         // ---- T_Y = Y V: two tiles, accumulator reg = row 4 reg + l4 of T_Y, column 16 t + l15 ----
         v4d_f ty[2];
 #pragma unroll
@@ -217,11 +254,16 @@ __global__ __launch_bounds__(256, 2) void k_cluster_assemble_w3(const int *__res
             for (int q = 0; q < 4; q++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.y[q], cur.v[t * 4 + q], acc, 0, 0, 0);
             ty[t] = acc;
         }
+#ifdef CLRS_W3_STAMPS
+        asm volatile("" :: "v"(ty[0][0]), "v"(ty[1][3]));
+#endif
+        W3_STAMP(2);
         // ---- L^-1 = (D^-1 L)^-1 D^-1 by substitution: lane (l15, l4) gets W[l15, 4q + l4], q = 0..3 ----
         double x[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) x[q] = (l15 == 4 * q + l4) ? di : 0.0;
         w3_substitute(x, lr);
+        W3_STAMP(3);
         // ---- G_Y = V^T T_Y, lower tiles: entry (16 ti + 4 reg + l4, 16 tj + l15) ----
         v4d_f gy[3];
 #pragma unroll
@@ -233,6 +275,10 @@ __global__ __launch_bounds__(256, 2) void k_cluster_assemble_w3(const int *__res
                 for (int q = 0; q < 4; q++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.v[ti * 4 + q], ty[tj][q], acc, 0, 0, 0);
                 gy[ti * (ti + 1) / 2 + tj] = acc;
             }
+#ifdef CLRS_W3_STAMPS
+        asm volatile("" :: "v"(gy[0][0]), "v"(gy[2][3]));
+#endif
+        W3_STAMP(4);
         // A_Y: the diagonal of G_Y (src/solver.jl:1152-1170): one lane-select, one store per diagonal tile
 #pragma unroll
         for (int t = 0; t < 2; t++) {
@@ -243,6 +289,7 @@ __global__ __launch_bounds__(256, 2) void k_cluster_assemble_w3(const int *__res
             dv = (dreg == 3) ? g[3] : dv;
             if (on_diag && cur.ay[t] >= 0) tb.AY[cur.ay[t]] = dv;
         }
+        W3_STAMP(5);
         // ---- Z D = (L^-1 V) diag(lambda) ----
         v4d_f z[2];
 #pragma unroll
@@ -254,6 +301,10 @@ __global__ __launch_bounds__(256, 2) void k_cluster_assemble_w3(const int *__res
             for (int reg = 0; reg < 4; reg++) acc[reg] *= cur.lam[t];
             z[t] = acc;
         }
+#ifdef CLRS_W3_STAMPS
+        asm volatile("" :: "v"(z[0][0]), "v"(z[1][3]));
+#endif
+        W3_STAMP(6);
         // ---- D G_X D = (Z D)^T (Z D) tile by tile, times G_Y, into S ----
 #pragma unroll
         for (int ti = 0; ti < 2; ti++)
@@ -266,6 +317,10 @@ __global__ __launch_bounds__(256, 2) void k_cluster_assemble_w3(const int *__res
 #pragma unroll
                 for (int reg = 0; reg < 4; reg++) sacc[T][reg] = __builtin_fma(acc[reg], gy[T][reg], sacc[T][reg]);
             }
+#ifdef CLRS_W3_STAMPS
+        asm volatile("" :: "v"(sacc[0][0]), "v"(sacc[2][3]));
+#endif
+        W3_STAMP(7);
         if (k.last) {
             // ---- 1 x 1 dense blocks: S[p_u, p_v] += a_u a_v Y / X, one rank-1 MFMA step per tile (k = 0 carries the data) ----
             double da[2] = {cur.da[0], cur.da[1]}, dy = cur.dy, dl = cur.dl;
@@ -311,6 +366,7 @@ __global__ __launch_bounds__(256, 2) void k_cluster_assemble_w3(const int *__res
             // ---- S_j: entries u >= v are computed; both (u, v) and (v, u) are written (symmetric!, src/tools.jl:43-57) ----
             const int P = FULL ? 32 : k.U;
             double *Sg = tb.S + k.S_off;
+            // through LDS, so that S_j leaves as whole consecutive 512-byte / 1-KB pieces (S_j is P x P contiguous)
 #pragma unroll
             for (int ti = 0; ti < 2; ti++)
 #pragma unroll
@@ -319,14 +375,27 @@ __global__ __launch_bounds__(256, 2) void k_cluster_assemble_w3(const int *__res
                     for (int reg = 0; reg < 4; reg++) {
                         const int u = 16 * ti + 4 * reg + l4, v = 16 * tj + l15;
                         if (u >= v && (FULL || u < P)) {
-                            const double s = sacc[ti * (ti + 1) / 2 + tj][reg];
+                            const double sv = sacc[ti * (ti + 1) / 2 + tj][reg];
                             const int pu = pm_u[ti * 4 + reg], pv = pm_v[tj];
-                            Sg[pv + pu * P] = s;
-                            Sg[pu + pv * P] = s;
+                            Ss[pv + pu * LDS_S] = sv;
+                            Ss[pu + pv * LDS_S] = sv;
                         }
                     }
+            wave_sync();
+            if (FULL) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) {                       // 16 bytes per lane, 1 KB per store
+                    const int m = 128 * i + 2 * lane;
+                    const v2d_f w = *(const v2d_f *)(Ss + (m >> 5) * LDS_S + (m & 31));
+                    __builtin_nontemporal_store(w, (v2d_f *)(Sg + m));
+                }
+            } else {
+                for (int m = lane; m < P * P; m += 64) Sg[m] = Ss[(m / P) * LDS_S + (m % P)];
+            }
+            wave_sync();
 #pragma unroll
             for (int t = 0; t < 3; t++) sacc[t] = (v4d_f){0.0, 0.0, 0.0, 0.0};
+            W3_STAMP(8);
         }
     };
 
@@ -345,6 +414,12 @@ __global__ __launch_bounds__(256, 2) void k_cluster_assemble_w3(const int *__res
         if (++bi >= bend) break;
         k0 = k1; k1 = k2;
     }
+#ifdef CLRS_W3_STAMPS
+    if (gw == 0 && lane == 0) {
+        for (int i = 0; i < 15; i++) g_w3_stamps[i] = st_acc[i];
+        g_w3_stamps[15] = (unsigned long long)(bend - bbeg);
+    }
+#endif
 }
 
 }  // namespace clrs

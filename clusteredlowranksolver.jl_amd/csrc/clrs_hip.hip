@@ -17,6 +17,7 @@
 #include <climits>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -1124,7 +1125,7 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
                             for (int q = 0; q < 4; q++)
                                 for (int ln = 0; ln < 64; ln++) {
                                     const int row = 4 * q + (ln >> 4), col = 16 * t + (ln & 15);
-                                    if (row < q2.n && col < wc.P) dst[(t * 4 + q) * 64 + ln] = V[row + (i64)col * q2.n];
+                                    if (row < q2.n && col < wc.P) dst[((t * 2 + (q >> 1)) * 64 + ln) * 2 + (q & 1)] = V[row + (i64)col * q2.n];
                                 }
                         last_lr = b3.size();
                         b3.push_back(k3);
@@ -1137,16 +1138,20 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
                     if (kl.ndense > 0) { kl.dxyoff = d3[dense0].xyoff; kl.dlam_off = d3[dense0].lam_off; }
                 }
                 if (d3.empty()) { W3Dense de; std::memset(&de, 0, sizeof(de)); d3.push_back(de); }
-                int *dcb; W3Block *db3; W3Dense *dd3; double *dvop;
-                CK(upload(c, cl_blk0, &dcb)); CK(upload(c, b3, &db3)); CK(upload(c, d3, &dd3)); CK(upload(c, h_vop, &dvop));
+                std::vector<W3LamAy> la(w2_lam.size());
+                for (size_t i2 = 0; i2 < la.size(); i2++) { la[i2].lam = w2_lam[i2]; la[i2].ay = w2_ay[i2]; la[i2].pad = 0; }
+                int *dcb; W3Block *db3; W3Dense *dd3; double *dvop; W3LamAy *dla;
+                CK(upload(c, cl_blk0, &dcb)); CK(upload(c, b3, &db3)); CK(upload(c, d3, &dd3)); CK(upload(c, h_vop, &dvop)); CK(upload(c, la, &dla));
                 c->w3tables.Xc = c->d_Xc; c->w3tables.Y = c->d_Y; c->w3tables.S = c->d_S; c->w3tables.AY = c->d_AY;
-                c->w3tables.vop = dvop; c->w3tables.lam = dlam; c->w3tables.ay = day; c->w3tables.pmap = dpm; c->w3tables.dense = dd3;
+                c->w3tables.vop = dvop; c->w3tables.lamay = dla; c->w3tables.lam = dlam; c->w3tables.pmap = dpm; c->w3tables.dense = dd3;
                 // persistent form: as many workgroups as are resident at once, each wave walks a contiguous range of clusters
                 int per_cu = 2, cus = 256, dev = 0;
                 hipDeviceProp_t prop;
                 if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
                 if (full) { if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_cluster_assemble_w3<true>, 256, 0) != hipSuccess) per_cu = 2; }
                 else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_cluster_assemble_w3<false>, 256, 0) != hipSuccess) per_cu = 2;
+                if (const char *e = std::getenv("CLRS_W3_WGS_PER_CU")) per_cu = std::max(1, std::atoi(e));     // diagnostic: waves per SIMD
+                if (std::getenv("CLRS_DEBUG")) std::fprintf(stderr, "[clrs] k_cluster_assemble_w3<%s>: %zu clusters, %zu blocks, %d workgroups per CU x %d CUs\n", full ? "full" : "general", w2cl.size(), b3.size(), per_cu, cus);
                 s.kind = STEP_ASSEMBLE_W3;
                 s.d0 = dcb; s.d1 = db3; s.src = &c->w3tables; s.bytes = 0;
                 s.aux0 = (int)std::min<i64>(((i64)w2cl.size() + 3) / 4, (i64)std::max(per_cu, 1) * cus);
@@ -1826,6 +1831,15 @@ extern "C" int clrs_config_set(const char *key, int value) {
     if (!std::strcmp(key, "dense_block")) { g_cfg_dense_block = value; return 0; }
     return fail(CLRS_ERR_INVALID, std::string("unknown configuration key ") + key);
 }
+
+#ifdef CLRS_W3_STAMPS
+extern "C" int clrs_debug_w3_stamps(clrs_ctx *c, uint64_t out[16]) {
+    if (!c || !out) return fail(CLRS_ERR_INVALID, "null argument");
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    HIPCHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_w3_stamps), 16 * sizeof(uint64_t)));
+    return 0;
+}
+#endif
 
 extern "C" int clrs_debug_stamps(clrs_ctx *c, uint64_t out[64]) {
     if (!c || !out) return fail(CLRS_ERR_INVALID, "null argument");
