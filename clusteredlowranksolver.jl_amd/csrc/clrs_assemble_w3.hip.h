@@ -36,27 +36,26 @@ struct W3Block {               // one simple low-rank block (n <= 16, U <= 32) o
     int n, U;                  // block side; U = P of the cluster
     int last;                  // 1: S_j is stored after this block
     int vop_off;               // W3Tables::vop: the vectors in MFMA-operand order, in units of 512 doubles
-    int lam_off;               // W3Tables::lam / ay: [U] lambda of vector u / position of its term in the A_Y output
+    int lam_off;               // W3Tables::lam: [U] lambda of vector u
+    int ay_base;               // the term of vector u is at ay_base + u of the A_Y output (clusters whose terms are not consecutive in
+                               // A_Y stay on k_cluster_assemble_w2: a table lookup here would be a vector load on a rarely taken path,
+                               // and the compiler then drains vmcnt on the common path too before reusing that load's register)
     int pmap_off;              // W3Tables::pmap: [U] constraint of vector u (a permutation of 0..P-1)
     int ndense, dense0;        // the cluster's 1 x 1 dense blocks: W3Tables::dense[dense0 .. dense0 + ndense)
     int dlam_off;              // W3Tables::lam: [U] matrix entry of the first dense block for the constraint of vector u
     int pmap_identity;         // 1: pmap[u] == u (the usual case): the S store needs no table
+    int pad[3];
 };
 struct W3Dense {
     long long xyoff;
     int lam_off, pad;
-};
-struct W3LamAy {               // per vector of a low-rank block, one 16-byte load
-    double lam;                // lambda of its term
-    int ay, pad;               // position of the term in the A_Y output
 };
 struct W3Tables {
     const double *Xc, *Y;      // iterates (xy layout): Cholesky factors of the X blocks, Y blocks
     double *S, *AY;            // outputs: S layout, A_Y per term
     const double *vop;         // vectors in MFMA-operand order, two k-steps per 16-byte lane element:
                                // vop[((t*2+p)*64 + lane)*2 + e] = V[4(2p+e) + (lane >> 4), 16t + (lane & 15)], zero padded
-    const W3LamAy *lamay;      // [lam_off + u]
-    const double *lam;         // [dlam_off + u]: entries of the 1 x 1 dense blocks
+    const double *lam;         // [lam_off + u]: lambda of the term of vector u; [dlam_off + u]: entries of the 1 x 1 dense blocks
     const int *pmap;
     const W3Dense *dense;
 };
@@ -66,7 +65,6 @@ struct W3Pre {                 // what one PSD block needs from memory, as it ar
     double v[8];               // V[4q + l4, 16t + l15] at [t*4 + q]    (B operand of T_Y and Z, A operand of G_Y)
     double lt[4];              // L[l15, 4q + l4]
     double lam[2];             // lambda of vector 16t + l15
-    int ay[2];                 // position of the term of vector 16t + l15 in the A_Y output
     double da[2], dy, dl;      // the cluster's first 1 x 1 dense block (last block of a cluster only; harmless reads otherwise):
                                // its entry for the constraint of vector 16t + l15, Y, chol X
 };
@@ -182,9 +180,8 @@ __global__ __launch_bounds__(256, 2) void k_cluster_assemble_w3(const int *__res
 #pragma unroll
         for (int t = 0; t < 2; t++) {
             const bool ok = FULL || 16 * t + l15 < U;
-            const W3LamAy la = tb.lamay[kb.lam_off + (ok ? 16 * t + l15 : 0)];
-            r.lam[t] = ok ? la.lam : 0.0;
-            r.ay[t] = ok ? la.ay : -1;
+            const double tl = tb.lam[kb.lam_off + (ok ? 16 * t + l15 : 0)];
+            r.lam[t] = ok ? tl : 0.0;
         }
         // first 1 x 1 dense block of the cluster, fetched with the cluster's last block.  These loads are issued for EVERY block (from
         // addresses that are valid anyway when there is nothing to fetch): the number of vector-memory operations per block must not
@@ -194,6 +191,7 @@ __global__ __launch_bounds__(256, 2) void k_cluster_assemble_w3(const int *__res
             const bool has = kb.last && kb.ndense > 0;
             const long long dxy = has ? kb.dxyoff : kb.xyoff;
             const int dlo = has ? kb.dlam_off : kb.lam_off;
+            // (vector loads on purpose: a scalar load would come back through lgkmcnt, which every LDS wait of the block drains)
             r.dy = tb.Y[dxy];
             r.dl = tb.Xc[dxy];
 #pragma unroll
@@ -287,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void k_cluster_assemble_w3(const int *__res
             dv = (dreg == 1) ? g[1] : dv;
             dv = (dreg == 2) ? g[2] : dv;
             dv = (dreg == 3) ? g[3] : dv;
-            if (on_diag && cur.ay[t] >= 0) tb.AY[cur.ay[t]] = dv;
+            if (on_diag && (FULL || 16 * t + l15 < k.U)) tb.AY[k.ay_base + 16 * t + l15] = dv;
         }
         W3_STAMP(5);
         // ---- Z D = (L^-1 V) diag(lambda) ----

@@ -732,7 +732,7 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
     std::vector<W2Block> w2bl;
     std::vector<int> w2_pmap, w2_ay;
     std::vector<double> w2_lam;
-    std::vector<size_t> w2_cl_pm, w2_boff;
+    std::vector<size_t> w2_cl_pm, w2_boff, w2_bl_cl;
     int w2_ut = 0;
     int w_ut = 0, w_nwaves = 8, w_maxblocks = 0;
     size_t w_cluster_doubles = 0;
@@ -827,6 +827,7 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
                         std::memset(&q2, 0, sizeof(q2));
                         q2.kind = wb.kind; q2.n = wb.n; q2.xyoff = wb.xyoff; q2.v_off = wb.v_off;
                         w2_boff.push_back(w2_lam.size());
+                        w2_bl_cl.push_back(w2cl.size());
                         if (wb.kind == 0) {
                             w2_lam.insert(w2_lam.end(), w_lam.begin() + mine_off[i2], w_lam.begin() + mine_off[i2] + Pj);
                             w2_ay.insert(w2_ay.end(), w_ay.begin() + mine_off[i2], w_ay.begin() + mine_off[i2] + Pj);
@@ -1091,7 +1092,12 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
             c->ftables.Xc = c->d_Xc; c->ftables.Y = c->d_Y; c->ftables.stat = c->d_static; c->ftables.AY = c->d_AY;
             Step s;
             s.kind = STEP_ASSEMBLE_W2;
-            const bool use_w3 = g_cfg_wave3_assemble && w2_ut <= 2;
+            bool use_w3 = g_cfg_wave3_assemble && w2_ut <= 2;
+            // k_cluster_assemble_w3 takes the A_Y position of vector u as ay_base + u (terms of a block consecutive in A_Y, in vector order)
+            for (size_t i2 = 0; i2 < w2bl.size() && use_w3; i2++)
+                if (w2bl[i2].kind == 0)
+                    for (int u = 0; u < w2cl[w2_bl_cl[i2]].P; u++)
+                        if (w2_ay[w2_boff[i2] + u] != w2_ay[w2_boff[i2]] + u) { use_w3 = false; break; }
             s.d0 = dwc; s.d1 = dwb; s.src = &c->ftables; s.n = (i64)w2cl.size(); s.nmax = w2_ut;
             bool full = w2_ut <= 2;
             for (size_t i2 = 0; i2 < w2bl.size() && full; i2++) if (w2bl[i2].kind == 0 && w2bl[i2].n != 16) full = false;
@@ -1117,6 +1123,7 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
                         W3Block k3;
                         std::memset(&k3, 0, sizeof(k3));
                         k3.xyoff = q2.xyoff; k3.n = q2.n; k3.U = wc.P; k3.lam_off = (int)w2_boff[bi2]; k3.pmap_off = (int)w2_cl_pm[ci];
+                        k3.ay_base = w2_ay[w2_boff[bi2]];
                         k3.vop_off = (int)(h_vop.size() / 512);
                         h_vop.resize(h_vop.size() + 512, 0.0);
                         double *dst = h_vop.data() + (size_t)k3.vop_off * 512;
@@ -1138,12 +1145,10 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
                     if (kl.ndense > 0) { kl.dxyoff = d3[dense0].xyoff; kl.dlam_off = d3[dense0].lam_off; }
                 }
                 if (d3.empty()) { W3Dense de; std::memset(&de, 0, sizeof(de)); d3.push_back(de); }
-                std::vector<W3LamAy> la(w2_lam.size());
-                for (size_t i2 = 0; i2 < la.size(); i2++) { la[i2].lam = w2_lam[i2]; la[i2].ay = w2_ay[i2]; la[i2].pad = 0; }
-                int *dcb; W3Block *db3; W3Dense *dd3; double *dvop; W3LamAy *dla;
-                CK(upload(c, cl_blk0, &dcb)); CK(upload(c, b3, &db3)); CK(upload(c, d3, &dd3)); CK(upload(c, h_vop, &dvop)); CK(upload(c, la, &dla));
+                int *dcb; W3Block *db3; W3Dense *dd3; double *dvop;
+                CK(upload(c, cl_blk0, &dcb)); CK(upload(c, b3, &db3)); CK(upload(c, d3, &dd3)); CK(upload(c, h_vop, &dvop));
                 c->w3tables.Xc = c->d_Xc; c->w3tables.Y = c->d_Y; c->w3tables.S = c->d_S; c->w3tables.AY = c->d_AY;
-                c->w3tables.vop = dvop; c->w3tables.lamay = dla; c->w3tables.lam = dlam; c->w3tables.pmap = dpm; c->w3tables.dense = dd3;
+                c->w3tables.vop = dvop; c->w3tables.lam = dlam; c->w3tables.pmap = dpm; c->w3tables.dense = dd3;
                 // persistent form: as many workgroups as are resident at once, each wave walks a contiguous range of clusters
                 int per_cu = 2, cus = 256, dev = 0;
                 hipDeviceProp_t prop;
