@@ -797,9 +797,11 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
                 continue;
             }
             // cluster-per-wave kernel: every low-rank block uses the same constraint order (U = P) and the dense blocks are 1 x 1
-            // (throughput form: one wave walks the blocks of its cluster one after the other, so it is chosen when there are enough
-            // clusters to fill the chip -- "wave2_assemble" = 1: automatic (>= 64 clusters), 2: always, 0: never)
-            if ((g_cfg_wave2_assemble == 2 || (g_cfg_wave2_assemble == 1 && J >= 64)) && utr <= 4) {
+            // ("wave2_assemble" = 1: automatic, 2: always, 0: never.  Automatic: always when the register-resident kernel
+            // k_cluster_assemble_w3 applies (U <= 32) -- it is also the fastest form for a handful of clusters, 8 us against 12.5 us of
+            // the wave-per-block kernel on cohnelkies(8,15) -- and from 64 clusters on for the LDS-staged k_cluster_assemble_w2,
+            // which walks the blocks of a cluster one after the other and needs enough clusters to fill the chip)
+            if ((g_cfg_wave2_assemble == 2 || (g_cfg_wave2_assemble == 1 && (J >= 64 || (g_cfg_wave3_assemble && utr <= 2)))) && utr <= 4) {
                 const int Pj = c->P[j];
                 bool w2 = true;
                 const int *pm0 = nullptr;

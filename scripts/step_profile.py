@@ -13,6 +13,11 @@ if name == "ce":
 else:
     from tests.util import flat as tf
     flat = tf(name)
+if len(sys.argv) > 2:      # e.g. "wave2_assemble=2": library configuration keys set before the context is created
+    from clrs_amd import _lib
+    for kv in sys.argv[2:]:
+        key, val = kv.split("=")
+        _lib.check(_lib.load().clrs_config_set(key.encode(), int(val)))
 sh = ShardedSchur(flat, 0, 1, lambda s: HipLocal(s, 0, graph=False))
 f, ctx, dev = sh.shard, sh.local.ctx, "cuda:0"
 X, Y = bench.seeded_iterates(flat, seed=1)
