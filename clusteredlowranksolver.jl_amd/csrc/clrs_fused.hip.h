@@ -265,23 +265,70 @@ struct SmallPotrf {
     long long slab_stride;
 };
 
+// Loads are issued in batches of eight 16 x 16 tiles (two tile columns x four tile rows) before any of them is stored: the
+// whole matrix of the named configurations (n <= 32) is ONE round trip to memory instead of one per tile (these kernels are a
+// chain of dependent steps on a few KB: every serial round trip is 0.5-2 us of a 5-15 us kernel).
 __device__ __forceinline__ void lds_load_lower_identity_padded(double *A, int lda, const double *G, int ldg, int n, int n16, int tid, int nthr,
                                                                int nslabs = 1, long long slab_stride = 0) {
-    // 16 x 16 element tiles: (tid & 15) walks down a column (contiguous in memory), (tid >> 4) across columns
-    const int i16 = tid & 15, j16 = tid >> 4, jstep = nthr >> 4;
-    for (int j0 = 0; j0 < n16; j0 += jstep)
-        for (int i0 = 0; i0 < n16; i0 += 16) {
-            const int i = i0 + i16, j = j0 + j16;
-            if (j >= n16) continue;
-            double v = (i == j) ? 1.0 : 0.0;
-            if (i < n && j < n) {
-                v = 0.0;
-                if (i >= j) {
-                    const double *g = G + i + (long long)j * ldg;
-                    for (int sl = 0; sl < nslabs; sl++) v += g[sl * slab_stride];   // fixed order: deterministic
+    // 16 x 16 element tiles: (tid & 15) walks down a column (contiguous in memory), (tid >> 4) across columns; nthr == 256
+    const int i16 = tid & 15, j16 = tid >> 4, nt = n16 >> 4;
+    (void)nthr;
+    for (int tj0 = 0; tj0 < nt; tj0 += 2)
+        for (int ti0 = 0; ti0 < nt; ti0 += 4) {
+            double v[8];
+            bool in[8];
+            long long off[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const int ti = ti0 + (e & 3), tj = tj0 + (e >> 2);
+                const int i = ti * 16 + i16, j = tj * 16 + j16;
+                in[e] = ti < nt && tj < nt && i < n && j < n && i >= j;
+                off[e] = in[e] ? i + (long long)j * ldg : 0;
+                v[e] = 0.0;
+            }
+            for (int sl = 0; sl < nslabs; sl += 2) {                 // fixed order: deterministic
+                const bool two = sl + 1 < nslabs;
+                double a[8], b[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    a[e] = G[off[e] + sl * slab_stride];
+                    b[e] = G[off[e] + (two ? sl + 1 : sl) * slab_stride];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    v[e] += a[e];
+                    if (two) v[e] += b[e];
                 }
             }
-            A[i + j * lda] = v;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const int ti = ti0 + (e & 3), tj = tj0 + (e >> 2);
+                const int i = ti * 16 + i16, j = tj * 16 + j16;
+                if (ti < nt && tj < nt) A[i + j * lda] = in[e] ? v[e] : ((i == j) ? 1.0 : 0.0);
+            }
+        }
+}
+
+// Z[i + j * ldz] = (i < rows) ? G[i + j * ldg] : 0 for i < rows16, j < cols: the same batching for a rectangular block (B_j)
+__device__ __forceinline__ void lds_load_rect_padded(double *Z, int ldz, const double *G, long long ldg, int rows, int rows16, int cols, int tid) {
+    const int i16 = tid & 15, j16 = tid >> 4, nti = rows16 >> 4, ntj = (cols + 15) >> 4;
+    for (int tj0 = 0; tj0 < ntj; tj0 += 2)
+        for (int ti0 = 0; ti0 < nti; ti0 += 4) {
+            double v[8];
+            bool in[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const int ti = ti0 + (e & 3), tj = tj0 + (e >> 2);
+                const int i = ti * 16 + i16, j = tj * 16 + j16;
+                in[e] = ti < nti && tj < ntj && i < rows && j < cols;
+                v[e] = G[in[e] ? i + (long long)j * ldg : 0];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const int ti = ti0 + (e & 3), tj = tj0 + (e >> 2);
+                const int i = ti * 16 + i16, j = tj * 16 + j16;
+                if (ti < nti && tj < ntj && j < cols) Z[i + j * ldz] = in[e] ? v[e] : 0.0;
+            }
         }
 }
 
@@ -327,6 +374,7 @@ __global__ __launch_bounds__(256) void k_cluster_factor(const CFactor *__restric
     const int P = d.P, P16 = (P + 15) & ~15, lda = P16 + 2;
     double *A = lds, *dinv = lds + lda * P16, *Z = dinv + P16;
     lds_load_lower_identity_padded(A, lda, d.S, P, P, P16, tid, 256);
+    if (d.N > 0) lds_load_rect_padded(Z, lda, d.B, d.ldb, P, P16, min(d.nc, d.N), tid);      // the first (usually only) pass of B_j: in flight with S_j
     __syncthreads();
     const bool bad = lds_potrf(A, lda, dinv, P, wave, 4, lane);
     if (bad && lane == 0) atomicMin(info, d.code);
@@ -341,11 +389,7 @@ __global__ __launch_bounds__(256) void k_cluster_factor(const CFactor *__restric
     for (int c0 = 0; c0 < d.N; c0 += d.nc) {
         const int nc = min(d.nc, d.N - c0);
         __syncthreads();
-        for (int j0 = 0; j0 < nc; j0 += 16)
-            for (int i0 = 0; i0 < P16; i0 += 16) {
-                const int i = i0 + i16, j = j0 + j16;
-                if (j < nc) Z[i + j * lda] = (i < P) ? d.B[i + (long long)(c0 + j) * d.ldb] : 0.0;
-            }
+        if (c0 > 0) lds_load_rect_padded(Z, lda, d.B + (long long)c0 * d.ldb, d.ldb, P, P16, nc, tid);
         __syncthreads();
         lds_trsm<false>(A, lda, dinv, Z, 1, lda, P, nc, wave, 4, lane);
         __syncthreads();

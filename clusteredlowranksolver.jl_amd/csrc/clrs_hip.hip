@@ -27,6 +27,7 @@
 #include "clrs_kernels.hip.h"
 #include "clrs_fused.hip.h"
 #include "clrs_assemble_w3.hip.h"
+#include "clrs_solve_small.hip.h"
 #include "clrs_ipm.hip.h"
 
 using namespace clrs;
@@ -53,6 +54,7 @@ static int g_cfg_wave_assemble = 1;
 static int g_cfg_wave2_assemble = 1;
 static int g_cfg_wave3_assemble = 1;   // register-resident form of the cluster-per-wave assembly (U <= 32); 0: k_cluster_assemble_w2
 static int g_cfg_dense_block = 1;
+static int g_cfg_solve_small2 = 1;     // one-workgroup solve stage with all loads up front and single-wave triangular solves (0: k_solve_small)
 static const int LDS_BUDGET_DOUBLES = 20000;   // of the 20480 doubles (160 KiB) a workgroup may claim
 
 // ------------------------------------------------------------------------------------------------
@@ -150,6 +152,9 @@ struct clrs_ctx {
     Plan p_assemble, p_cholS, p_linvB, p_Q, p_cholQ, p_fwd, p_bwd, p_cholX;
     FTables ftables = {};
     W3Tables w3tables = {};
+    CSolve8 solve8 = {};          // host copy of the (<= 8) CSolve descriptors: kernel argument of k_solve_small2
+    StageJobs solve_jobs = {};    // its staging job table
+    int solve_rx_job[8] = {0, 0, 0, 0, 0, 0, 0, 0}, solve_ry_job = -1;
     // caller-provided device pointers of the current call, read by the fused kernels at launch (no staging copies)
     const double *bind_X = nullptr, *bind_rhsx = nullptr, *bind_rhsy = nullptr;
     double *bind_Xchol = nullptr, *bind_dx = nullptr, *bind_dy = nullptr;
@@ -389,6 +394,18 @@ static int run_steps(clrs_ctx *c, const Plan &pl) {
                 hipLaunchKernelGGL(k_dense_block, dim3(s.grid), dim3(256), s.bytes, st, (const DBlock *)s.d0, *(const FTables *)s.src);
                 break;
             case STEP_SOLVE_SMALL:
+                if (s.aux0 == 2) {
+                    for (int j = 0; j < c->J; j++) c->solve_jobs.j[c->solve_rx_job[j]].src = c->bind_rhsx + c->solve8.d[j].off;     // right-hand sides bound for this call
+                    if (c->solve_ry_job >= 0) c->solve_jobs.j[c->solve_ry_job].src = c->bind_rhsy;
+#define CLRS_SS2(NJ) hipLaunchKernelGGL(k_solve_small2<NJ>, dim3(1), dim3(256), s.bytes, st, c->solve8, c->solve_jobs, c->J, (const double *)c->d_Q,          \
+                                        (const double *)c->d_dinvQ, c->N, (int)c->xlen, c->bind_rhsx, c->bind_rhsy, (const double *)c->d_LB, c->bind_dx, c->bind_dy)
+                    if (c->solve_jobs.n <= 8) CLRS_SS2(8);
+                    else if (c->solve_jobs.n <= 16) CLRS_SS2(16);
+                    else if (c->solve_jobs.n <= 24) CLRS_SS2(24);
+                    else CLRS_SS2(40);
+#undef CLRS_SS2
+                    break;
+                }
                 hipLaunchKernelGGL(k_solve_small, dim3(1), dim3(256), s.bytes, st, (const CSolve *)s.d0, c->J, (const double *)c->d_Q, (const double *)c->d_dinvQ, c->N,
                                    (int)c->xlen, c->bind_rhsx, c->bind_rhsy, (const double *)c->d_LB, c->bind_dx, c->bind_dy, (int)s.n);
                 break;
@@ -1381,6 +1398,21 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
         s.kind = STEP_SOLVE_SMALL; s.n = maxP16;
         s.bytes = (size_t)((maxP16 + 2) * maxP16 + 2 * maxP16 + 2 + ((c->xlen + 15) & ~15) + 2 * ((N + 15) & ~15) + 16) * sizeof(double);
         if (s.bytes > 64 * 1024) HIPCK(hipFuncSetAttribute((const void *)k_solve_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s.bytes));
+        const size_t need2 = solve_small2_lds_doubles(c->P.data(), J, N, c->xlen) * sizeof(double);
+        bool fits2 = g_cfg_solve_small2 && need2 <= 150 * 1024;
+        if (fits2) {
+            HIPCK(hipMemcpy(c->solve8.d, s.d0, sizeof(CSolve) * J, hipMemcpyDeviceToHost));
+            fits2 = solve_small2_jobs(c->solve_jobs, c->solve8.d, J, c->d_Q, c->d_dinvQ, N, c->xlen, c->d_LB, c->solve_rx_job, &c->solve_ry_job);
+        }
+        if (fits2) {                                                // everything resident at once: the latency-first variant
+            s.aux0 = 2; s.bytes = need2;
+            if (s.bytes > 64 * 1024) {
+                HIPCK(hipFuncSetAttribute((const void *)k_solve_small2<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s.bytes));
+                HIPCK(hipFuncSetAttribute((const void *)k_solve_small2<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s.bytes));
+                HIPCK(hipFuncSetAttribute((const void *)k_solve_small2<24>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s.bytes));
+                HIPCK(hipFuncSetAttribute((const void *)k_solve_small2<40>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s.bytes));
+            }
+        }
         c->p_solve_all.steps.push_back(s);
     } else
     // single-GPU solve in three launches: the u = LinvB^T t product moves into the Q-solve kernel
@@ -1836,10 +1868,17 @@ extern "C" int clrs_config_set(const char *key, int value) {
     if (!std::strcmp(key, "wave2_assemble")) { g_cfg_wave2_assemble = value; return 0; }
     if (!std::strcmp(key, "wave3_assemble")) { g_cfg_wave3_assemble = value; return 0; }
     if (!std::strcmp(key, "dense_block")) { g_cfg_dense_block = value; return 0; }
+    if (!std::strcmp(key, "solve_small2")) { g_cfg_solve_small2 = value; return 0; }
     return fail(CLRS_ERR_INVALID, std::string("unknown configuration key ") + key);
 }
 
 #ifdef CLRS_W3_STAMPS
+extern "C" int clrs_debug_ss2_stamps(clrs_ctx *c, uint64_t out[16]) {
+    if (!c || !out) return fail(CLRS_ERR_INVALID, "null argument");
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    HIPCHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ss2_stamps), 16 * sizeof(uint64_t)));
+    return 0;
+}
 extern "C" int clrs_debug_w3_stamps(clrs_ctx *c, uint64_t out[16]) {
     if (!c || !out) return fail(CLRS_ERR_INVALID, "null argument");
     HIPCHECK(hipStreamSynchronize(c->stream));

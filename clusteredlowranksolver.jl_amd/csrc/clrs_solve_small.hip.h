@@ -1,0 +1,342 @@
+// clrs_solve_small.hip.h -- k_solve_small2: the whole solve stage of compute_search_direction! (src/solver.jl:1527-1582) in one
+// workgroup, latency first.
+//
+// For the named configurations (a handful of clusters, P_j <= 128, N <= 128) the stage is a chain of dependent steps on ~40 KB
+// of factors: t_j = L_j^-1 rhs_x[j];  u = sum_j LinvB_j^T t_j;  dy = Q^-1 (rhs_y - u);  dx_j = L_j^-T (t_j + LinvB_j dy).
+// k_solve_small (clrs_fused.hip.h) walks it with one global -> LDS load phase per cluster and phase (five round trips to memory
+// on cohnelkies(8,15)) and all four waves on every triangular solve.  Here
+//   * every factor (L_j, L_Q, LinvB) and both right-hand sides are loaded ONCE, all loads in flight together;
+//   * a triangular solve with one right-hand side is a single-wave job: the clusters are dealt to the waves (they run
+//     concurrently), 16 unknowns at a time live in the 16 lanes of a DPP row, and one elimination is ONE instruction
+//     (v_fmac_f64_dpp row_newbcast on the row-scaled factor, see clrs_assemble_w3.hip.h); the rows below / above a finished
+//     panel are updated by the 64 lanes with 16 multiply-adds each;
+//   * the two matrix-vector products are split over all 256 threads with a fixed-order LDS reduction (deterministic).
+// Five workgroup barriers in all.
+#pragma once
+#include <algorithm>
+#include <cstring>
+#include <vector>
+#include "clrs_fused.hip.h"
+
+namespace clrs {
+
+// x += bcast_K(x) * m[K], K = 0 .. 14 (forward) / K = 15 .. 1 (backward); a DPP read needs two wait states after the write
+__device__ __forceinline__ void trsv16_chain_fwd(double &x, const double (&m)[16]) {
+    asm volatile(
+        "s_nop 1\n\tv_fmac_f64_dpp %0, %0, %1 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_fmac_f64_dpp %0, %0, %2 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_fmac_f64_dpp %0, %0, %3 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_fmac_f64_dpp %0, %0, %4 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_fmac_f64_dpp %0, %0, %5 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_fmac_f64_dpp %0, %0, %6 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_fmac_f64_dpp %0, %0, %7 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_fmac_f64_dpp %0, %0, %8 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_fmac_f64_dpp %0, %0, %9 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_fmac_f64_dpp %0, %0, %10 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_fmac_f64_dpp %0, %0, %11 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_fmac_f64_dpp %0, %0, %12 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_fmac_f64_dpp %0, %0, %13 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_fmac_f64_dpp %0, %0, %14 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_fmac_f64_dpp %0, %0, %15 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(x)
+        : "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7]), "v"(m[8]), "v"(m[9]), "v"(m[10]), "v"(m[11]),
+          "v"(m[12]), "v"(m[13]), "v"(m[14]));
+}
+__device__ __forceinline__ void trsv16_chain_bwd(double &x, const double (&m)[16]) {
+    asm volatile(
+        "s_nop 1\n\tv_fmac_f64_dpp %0, %0, %15 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_fmac_f64_dpp %0, %0, %14 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_fmac_f64_dpp %0, %0, %13 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_fmac_f64_dpp %0, %0, %12 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_fmac_f64_dpp %0, %0, %11 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_fmac_f64_dpp %0, %0, %10 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_fmac_f64_dpp %0, %0, %9 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_fmac_f64_dpp %0, %0, %8 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_fmac_f64_dpp %0, %0, %7 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_fmac_f64_dpp %0, %0, %6 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_fmac_f64_dpp %0, %0, %5 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_fmac_f64_dpp %0, %0, %4 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_fmac_f64_dpp %0, %0, %3 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_fmac_f64_dpp %0, %0, %2 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_fmac_f64_dpp %0, %0, %1 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(x)
+        : "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7]), "v"(m[8]), "v"(m[9]), "v"(m[10]), "v"(m[11]), "v"(m[12]),
+          "v"(m[13]), "v"(m[14]), "v"(m[15]));
+}
+
+// One wave: x <- L^-1 x.  A: n16 x n16 in LDS (ld lda), lower triangle of L, ZERO above the diagonal and in rows / columns >= n;
+// dinv: 1 / L[i,i] (0 for i >= n); x: n16 entries in LDS (entries >= n zero).
+__device__ __forceinline__ void wave_trsv_fwd(const double *A, int lda, const double *dinv, double *x, int n16, int lane) {
+    const int l15 = lane & 15;
+    for (int r0 = 0; r0 < n16; r0 += 16) {
+        const int row = r0 + l15;
+        const double di = dinv[row];
+        double m[16];
+#pragma unroll
+        for (int k = 0; k < 15; k++) m[k] = A[row + (r0 + k) * lda];            // all reads issued first (a select around a read is a branch)
+#pragma unroll
+        for (int k = 0; k < 15; k++) m[k] = (k < l15) ? -(m[k] * di) : 0.0;
+        double xr = x[row] * di;
+        trsv16_chain_fwd(xr, m);
+        if (lane < 16) x[row] = xr;
+        wave_sync();
+        for (int i = r0 + 16 + lane; i < n16; i += 64) {      // rows below the panel
+            double s = x[i];
+#pragma unroll
+            for (int k = 0; k < 16; k++) s = __builtin_fma(-A[i + (r0 + k) * lda], x[r0 + k], s);
+            x[i] = s;
+        }
+        wave_sync();
+    }
+}
+// One wave: x <- L^-T x (same storage of L).
+__device__ __forceinline__ void wave_trsv_bwd(const double *A, int lda, const double *dinv, double *x, int n16, int lane) {
+    const int l15 = lane & 15;
+    for (int r0 = n16 - 16; r0 >= 0; r0 -= 16) {
+        const int row = r0 + l15;
+        const double di = dinv[row];
+        double m[16];
+#pragma unroll
+        for (int k = 1; k < 16; k++) m[k] = A[(r0 + k) + row * lda];            // L^T[row, r0 + k] = L[r0 + k, row]
+#pragma unroll
+        for (int k = 1; k < 16; k++) m[k] = (k > l15) ? -(m[k] * di) : 0.0;
+        double xr = x[row] * di;
+        trsv16_chain_bwd(xr, m);
+        if (lane < 16) x[row] = xr;
+        wave_sync();
+        for (int i = lane; i < r0; i += 64) {                   // rows above the panel
+            double s = x[i];
+#pragma unroll
+            for (int k = 0; k < 16; k++) s = __builtin_fma(-A[(r0 + k) + i * lda], x[r0 + k], s);
+            x[i] = s;
+        }
+        wave_sync();
+    }
+}
+
+#ifdef CLRS_W3_STAMPS
+__device__ unsigned long long g_ss2_stamps[16];
+#define SS2_STAMP(i) do { if (tid == 0) g_ss2_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SS2_STAMP(i) do { } while (0)
+#endif
+
+// ---- one-round-trip staging of many small matrices: a job table in the kernel arguments ---------------------------------
+// A kernel that stages its operands matrix by matrix (load tile, store to LDS, next matrix) pays one trip to memory per
+// matrix: the stores of one matrix sit between its loads and the loads of the next.  Here the host lists every 16 x 16 tile /
+// 256-entry vector piece to stage as a job in the kernel arguments; all loads are issued (straight-line code, one register per
+// job and thread), then all stores.  Thread (r = tid & 15, c = tid >> 4) of the 256 moves entry (r, c) of a tile.
+struct StageJob {
+    const double *src;     // tile origin / first entry
+    unsigned dst_ldd;      // bits 0-15: destination offset in LDS (doubles); 16-24: destination leading dimension; 25-29: columns written
+    unsigned meta;         // bits 0-15: source leading dimension; 16-20: valid rows; 21-25: full valid columns; 26-30: valid rows of one more
+                           // (partial) column.  Entry (r, c) is loaded when (c < cols && r < rows) || (c == cols && r < rem); the destination
+                           // gets it, or zero, for every c < columns written (all 16 rows).  A 16 x 16 tile of a matrix: rem = 0, 16 columns
+                           // written; a piece of a vector: a "tile" with both leading dimensions 16 (entry index r + 16 c)
+};
+constexpr int STAGE_MAX_JOBS = 40;
+struct StageJobs {
+    StageJob j[STAGE_MAX_JOBS];
+    int n, pad;
+};
+static inline StageJob stage_rect(const double *src, int ldg, int rows, int cols, int dst, int ldd) {
+    StageJob b;
+    b.src = src; b.dst_ldd = (unsigned)dst | ((unsigned)ldd << 16) | (16u << 25); b.meta = (unsigned)ldg | ((unsigned)rows << 16) | ((unsigned)cols << 21);
+    return b;
+}
+static inline StageJob stage_flat(const double *src, int count, int write, int dst) {       // count <= 256 entries loaded, `write` (multiple of 16) written
+    StageJob b;
+    b.src = src; b.dst_ldd = (unsigned)dst | (16u << 16) | ((unsigned)(write / 16) << 25);
+    b.meta = 16u | (16u << 16) | ((unsigned)(count / 16) << 21) | ((unsigned)(count % 16) << 26);
+    return b;
+}
+// The table itself must not be read entry by entry (scalar loads from the kernel-argument segment, or LDS reads of a copy: each
+// entry's use then waits for its own fetch, 400 cycles per job measured): lane t of every wave fetches job t with ONE 16-byte
+// vector load from the kernel-argument segment, and the unrolled loops below pick job t out of lane t with v_readlane
+// (compile-time lane, a few cycles, no memory access).
+// NJ (compile time) jobs are processed without any branch: the host pads the table with empty jobs (nothing valid, nothing written).
+// A branch per job would make the compiler drain vmcnt before every v_readlane (it cannot see that the table's load, waited for
+// on the path through the previous job, is complete on every path) -- one trip to memory per job again.
+template <int NJ>
+__device__ __forceinline__ void stage_all(const StageJobs &kjobs, double *lds, int tid) {
+    const int r = tid & 15, c = tid >> 4, lane = tid & 63;
+    static_assert(NJ <= STAGE_MAX_JOBS && STAGE_MAX_JOBS <= 64, "one job per lane");
+    const StageJob mine = kjobs.j[lane < NJ ? lane : 0];
+    const unsigned long long msrc = (unsigned long long)mine.src;
+    const int m_lo = (int)(unsigned)msrc, m_hi = (int)(unsigned)(msrc >> 32), m_dl = (int)mine.dst_ldd, m_meta = (int)mine.meta;
+    double v[NJ];
+#pragma unroll
+    for (int t = 0; t < NJ; t++) {
+        const unsigned meta = (unsigned)__builtin_amdgcn_readlane(m_meta, t);
+        const unsigned long long sp = (unsigned long long)(unsigned)__builtin_amdgcn_readlane(m_lo, t) | ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(m_hi, t) << 32);
+        // a GLOBAL pointer (address space 1): through a generic pointer this would be a flat_load, which completes out of order, and the
+        // compiler would drain vmcnt AND lgkmcnt before every later v_readlane of the table -- one trip to memory per job again
+        const __attribute__((address_space(1))) double *src = (const __attribute__((address_space(1))) double *)sp;
+        const int rows = (meta >> 16) & 31, cols = (meta >> 21) & 31, rem = (meta >> 26) & 31;
+        const bool valid = (c < cols & r < rows) | (c == cols & r < rem);
+        v[t] = src[valid ? r + c * (int)(meta & 0xffff) : 0];
+    }
+#ifdef CLRS_W3_STAMPS
+    if (tid == 0) g_ss2_stamps[8] = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0) g_ss2_stamps[9] = __builtin_amdgcn_s_memtime();
+#endif
+#pragma unroll
+    for (int t = 0; t < NJ; t++) {
+        const unsigned meta = (unsigned)__builtin_amdgcn_readlane(m_meta, t), dl = (unsigned)__builtin_amdgcn_readlane(m_dl, t);
+        const int rows = (meta >> 16) & 31, cols = (meta >> 21) & 31, rem = (meta >> 26) & 31;
+        const bool valid = (c < cols & r < rows) | (c == cols & r < rem);
+        if (c < (int)((dl >> 25) & 31)) lds[(int)(dl & 0xffff) + r + c * (int)((dl >> 16) & 511)] = valid ? v[t] : 0.0;
+    }
+}
+
+// LDS doubles k_solve_small2 needs (the host uses the same formula to decide whether the kernel applies)
+static inline size_t solve_small2_lds_doubles(const int *P, int J, int N, long long xlen) {
+    size_t tot = 0;
+    for (int j = 0; j < J; j++) {
+        const size_t P16 = (size_t)((P[j] + 15) & ~15);
+        tot += (P16 + 2) * P16 + 2 * P16;          // L_j, 1 / diag, padded work vector
+    }
+    const size_t N16 = (size_t)((N + 15) & ~15), xl = (size_t)((xlen + 15) & ~15);
+    tot += (N16 + 2) * N16 + N16;                  // L_Q, 1 / diag
+    tot += (size_t)xlen * (size_t)N;               // LinvB
+    tot += xl + N16 + 8 * N16 + 4 * xl;            // t, dy work, partial sums of the two products
+    return tot + 16;
+}
+
+// The cluster descriptors travel BY VALUE in the kernel arguments (J <= 8): a descriptor fetched from memory is a dependent
+// round trip (~1 us) in front of every load that needs its pointers.
+struct CSolve8 {
+    CSolve d[8];
+};
+
+// The jobs of k_solve_small2, in the LDS layout the kernel carves (returns false when they do not fit the table: the caller keeps
+// k_solve_small).  rhs_x / rhs_y are bound per call: their jobs are listed in rx_job[j] / ry_job for patching at launch.
+static inline bool solve_small2_jobs(StageJobs &jb, const CSolve *cs, int J, const double *LQ, const double *dinvQ, int N, long long xlen,
+                                     const double *LBall, int *rx_job, int *ry_job) {
+    std::vector<StageJob> v;
+    int o = 0;
+    for (int j = 0; j < J; j++) {
+        const int P = cs[j].P, P16 = (P + 15) & ~15, lda = P16 + 2, nt = P16 / 16;
+        for (int tj = 0; tj < nt; tj++)
+            for (int ti = tj; ti < nt; ti++)       // lower tiles only: the solves never read above the diagonal tiles
+                v.push_back(stage_rect(cs[j].L + ti * 16 + (long long)tj * 16 * P, P, std::min(16, P - ti * 16), std::min(16, P - tj * 16), o + ti * 16 + tj * 16 * lda, lda));
+        for (int p0 = 0; p0 < P16; p0 += 256) {
+            v.push_back(stage_flat(cs[j].dinv + p0, std::min(256, P - p0), std::min(256, P16 - p0), o + lda * P16 + p0));
+            rx_job[j] = (int)v.size();               // (one piece: P16 <= 256 is checked below)
+            v.push_back(stage_flat(nullptr, std::min(256, P - p0), std::min(256, P16 - p0), o + lda * P16 + P16 + p0));
+        }
+        if (P16 > 256) return false;
+        o += lda * P16 + 2 * P16;
+    }
+    const int N16 = (N + 15) & ~15, ldq = N16 + 2, ntq = N16 / 16, xl = (int)((xlen + 15) & ~15);
+    if (N16 > 256) return false;
+    for (int tj = 0; tj < ntq; tj++)
+        for (int ti = tj; ti < ntq; ti++)
+            v.push_back(stage_rect(LQ + ti * 16 + (long long)tj * 16 * N, N, std::min(16, N - ti * 16), std::min(16, N - tj * 16), o + ti * 16 + tj * 16 * ldq, ldq));
+    *ry_job = -1;
+    if (N > 0) {
+        v.push_back(stage_flat(dinvQ, N, N16, o + ldq * N16));
+        const int oLB = o + ldq * N16 + N16, oyy = oLB + (int)(xlen * N) + xl;
+        *ry_job = (int)v.size();
+        v.push_back(stage_flat(nullptr, N, N16, oyy));
+        const long long tot = xlen * N;
+        for (long long e0 = 0; e0 < tot; e0 += 256) {      // whole 16-entry columns are written: the last piece may spill (zeros) into t, which is filled later
+            const int cnt = (int)std::min<long long>(256, tot - e0);
+            v.push_back(stage_flat(LBall + e0, cnt, (cnt + 15) & ~15, oLB + (int)e0));
+        }
+    }
+    if (v.size() > (size_t)STAGE_MAX_JOBS) return false;
+    std::memset(&jb, 0, sizeof(jb));
+    for (size_t i = 0; i < v.size(); i++) jb.j[i] = v[i];
+    jb.n = (int)v.size();
+    for (int i = jb.n; i < STAGE_MAX_JOBS; i++) jb.j[i] = stage_flat(LBall ? LBall : cs[0].L, 0, 0, 0);     // empty: reads one valid word, writes nothing
+    return true;
+}
+
+template <int NJ>      // number of staging jobs processed (the table is padded with empty jobs up to it)
+__global__ __launch_bounds__(256) void k_solve_small2(const CSolve8 descs8, const StageJobs jobs, int J, const double *__restrict__ LQ, const double *__restrict__ dinvQ,
+                                                      int N, int xlen, const double *__restrict__ rhs_x, const double *__restrict__ rhs_y,
+                                                      const double *__restrict__ LBall, double *__restrict__ dx, double *__restrict__ dy) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    __shared__ int offA[8], offZ[8];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int N16 = (N + 15) & ~15, ldq = N16 + 2, xl = (xlen + 15) & ~15;
+    SS2_STAMP(0);
+    // ---- LDS layout (same order as solve_small2_lds_doubles): the cluster part needs the descriptors, see below ----
+    // ---- every load of the stage in one trip to memory (job table built by the host: solve_small2_jobs) ----
+    __shared__ CSolve descs_lds[8];
+    if (tid >= 64 && tid < 64 + J) descs_lds[tid - 64] = descs8.d[tid - 64];
+    stage_all<NJ>(jobs, lds, tid);
+    __syncthreads();
+    int o = 0;
+    for (int j = 0; j < J; j++) {
+        const int P16 = (descs_lds[j].P + 15) & ~15;
+        if (tid == 0) { offA[j] = o; offZ[j] = o + (P16 + 2) * P16 + P16; }
+        o += (P16 + 2) * P16 + 2 * P16;
+    }
+    double *AQ = lds + o, *dvQ = AQ + ldq * N16, *LBs = dvQ + N16, *tt = LBs + (size_t)xlen * N, *yy = tt + xl, *pu = yy + N16, *pw = pu + 8 * N16;
+    __syncthreads();
+    SS2_STAMP(1);
+    // ---- t_j = L_j^-1 rhs_x[j]: one wave per cluster, concurrently (src/solver.jl:1537-1540) ----
+    for (int j = wave; j < J; j += 4) {
+        const CSolve d = descs_lds[j];
+        const int P16 = (d.P + 15) & ~15, lda = P16 + 2;
+        double *A = lds + offA[j], *dv = A + lda * P16, *z = lds + offZ[j];
+        wave_trsv_fwd(A, lda, dv, z, P16, lane);
+        for (int i = lane; i < d.P; i += 64) tt[d.off + i] = z[i];
+    }
+    __syncthreads();
+    SS2_STAMP(2);
+    if (N > 0) {
+        // ---- u = LinvB^T t (src/solver.jl:1546), 8 partial sums per column in a fixed order; dy = Q^-1 (rhs_y - u) (:1550-1558) ----
+        for (int k0 = 0; k0 < N; k0 += 32) {
+            const int k = k0 + (tid >> 3), part = tid & 7;
+            double s = 0.0;
+            if (k < N)
+                for (int i = part; i < xlen; i += 8) s = __builtin_fma(LBs[i + (size_t)k * xlen], tt[i], s);
+            if (k < N) pu[k * 8 + part] = s;
+        }
+        __syncthreads();
+        if (tid < N) {
+            const double *p = pu + tid * 8;
+            yy[tid] -= ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+        }
+        __syncthreads();
+        SS2_STAMP(3);
+        if (wave == 0) {
+            wave_trsv_fwd(AQ, ldq, dvQ, yy, N16, lane);
+            wave_trsv_bwd(AQ, ldq, dvQ, yy, N16, lane);
+            for (int k = lane; k < N; k += 64) dy[k] = yy[k];
+        }
+        __syncthreads();
+        SS2_STAMP(4);
+        // ---- t_j + LinvB_j dy (src/solver.jl:1567-1569): wave w sums the columns k = w mod 4, then a fixed-order sum of the four ----
+        for (int i = lane; i < xlen; i += 64) {
+            double s = 0.0;
+            for (int k = wave; k < N; k += 4) s = __builtin_fma(LBs[i + (size_t)k * xlen], yy[k], s);
+            pw[wave * xl + i] = s;
+        }
+        __syncthreads();
+    }
+    SS2_STAMP(5);
+    // ---- dx_j = L_j^-T (...) (src/solver.jl:1570-1573) ----
+    for (int j = wave; j < J; j += 4) {
+        const CSolve d = descs_lds[j];
+        const int P16 = (d.P + 15) & ~15, lda = P16 + 2;
+        double *A = lds + offA[j], *dv = A + lda * P16, *z = lds + offZ[j];
+        for (int i = lane; i < d.P; i += 64) {
+            double s = tt[d.off + i];
+            if (N > 0) s += (pw[d.off + i] + pw[xl + d.off + i]) + (pw[2 * xl + d.off + i] + pw[3 * xl + d.off + i]);
+            z[i] = s;
+        }
+        wave_sync();
+        wave_trsv_bwd(A, lda, dv, z, P16, lane);
+        for (int i = lane; i < d.P; i += 64) dx[d.off + i] = z[i];
+    }
+    SS2_STAMP(6);
+}
+
+}  // namespace clrs

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Diagnostic: shader cycles per phase of k_solve_small2 on cohnelkies(8,15) (s_memtime-stamped build: scripts/w3_stamps.py build)."""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+torch.cuda.set_device(0)
+import clrs_amd
+from clrs_amd import _lib
+L = _lib.load(os.path.join(_lib.CSRC, "libclrs_hip_w3stamps.so"))
+from clrs_amd.solver import SchurContext, compute_T_decomposition, solve_system
+from tests.util import chol_blocks_np, flat, spd_iterates
+f = flat(sys.argv[1] if len(sys.argv) > 1 else "ce_8_3")
+X, Y = spd_iterates(f, seed=2)
+ctx = SchurContext(f)
+Xc = ctx.cholesky_blocks(X)
+compute_T_decomposition(ctx, Xc, Y)
+for _ in range(5):
+    solve_system(ctx, np.ones(f.x_len), np.ones(f.n_free))
+st = (C.c_uint64 * 16)()
+L.clrs_debug_ss2_stamps.restype = C.c_int
+L.clrs_debug_ss2_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+assert L.clrs_debug_ss2_stamps(ctx.h, st) == 0
+st = np.array(st, dtype=np.float64)
+names = ["loads -> LDS", "forward solves (one wave per cluster)", "u = LinvB^T t", "Q forward + backward solve", "LinvB dy partial sums", "backward solves + store"]
+for i, n in enumerate(names):
+    print(f"  {n:40s} {st[i + 1] - st[i]:8.0f} cycles")
+print(f"  {'total':40s} {st[6] - st[0]:8.0f} cycles")
+print(f"  inside the staging: entry -> all loads issued {st[8] - st[0]:6.0f}, -> all loads landed {st[9] - st[8]:6.0f}, -> stored + barrier {st[1] - st[9]:6.0f}")
+ctx.close()
