@@ -367,8 +367,16 @@ struct CFactor {
     double *Qslab;     // N x N partial Q_j = LinvB_j^T LinvB_j (only when nc >= N), or nullptr
 };
 
+#ifdef CLRS_W3_STAMPS
+__device__ unsigned long long g_cf_stamps[16];
+#define CF_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_cf_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CF_STAMP(i) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(256) void k_cluster_factor(const CFactor *__restrict__ descs, int *__restrict__ info) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    CF_STAMP(0);
     const CFactor d = descs[blockIdx.x];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int P = d.P, P16 = (P + 15) & ~15, lda = P16 + 2;
@@ -376,9 +384,11 @@ __global__ __launch_bounds__(256) void k_cluster_factor(const CFactor *__restric
     lds_load_lower_identity_padded(A, lda, d.S, P, P, P16, tid, 256);
     if (d.N > 0) lds_load_rect_padded(Z, lda, d.B, d.ldb, P, P16, min(d.nc, d.N), tid);      // the first (usually only) pass of B_j: in flight with S_j
     __syncthreads();
+    CF_STAMP(1);
     const bool bad = lds_potrf(A, lda, dinv, P, wave, 4, lane);
     if (bad && lane == 0) atomicMin(info, d.code);
     __syncthreads();
+    CF_STAMP(2);
     const int i16 = tid & 15, j16 = tid >> 4;
     for (int j0 = 0; j0 < P; j0 += 16)
         for (int i0 = 0; i0 < P; i0 += 16) {
@@ -386,6 +396,7 @@ __global__ __launch_bounds__(256) void k_cluster_factor(const CFactor *__restric
             if (i < P && j < P) d.S[i + (long long)j * P] = (i >= j) ? A[i + j * lda] : 0.0;
         }
     if (tid < P) d.dinv[tid] = dinv[tid];
+    CF_STAMP(3);
     for (int c0 = 0; c0 < d.N; c0 += d.nc) {
         const int nc = min(d.nc, d.N - c0);
         __syncthreads();
@@ -393,11 +404,13 @@ __global__ __launch_bounds__(256) void k_cluster_factor(const CFactor *__restric
         __syncthreads();
         lds_trsm<false>(A, lda, dinv, Z, 1, lda, P, nc, wave, 4, lane);
         __syncthreads();
+        CF_STAMP(4);
         for (int j0 = 0; j0 < nc; j0 += 16)
             for (int i0 = 0; i0 < P; i0 += 16) {
                 const int i = i0 + i16, j = j0 + j16;
                 if (i < P && j < nc) d.LB[i + (long long)(c0 + j) * d.ldb] = Z[i + j * lda];
             }
+        CF_STAMP(5);
         if (d.Qslab) {   // the whole LinvB_j is resident: its Gram matrix is this cluster's share of Q (src/solver.jl:1268-1269)
             const int nc16 = (nc + 15) & ~15;
             for (int e = tid; e < (nc16 - nc) * lda; e += 256) Z[nc * lda + e] = 0.0;   // zero the padding columns read by the MFMA tiles
@@ -405,6 +418,7 @@ __global__ __launch_bounds__(256) void k_cluster_factor(const CFactor *__restric
             lds_gemm_tn(Z, lda, Z, lda, d.Qslab, d.N, d.N, d.N, P, wave, 4, lane);
         }
     }
+    CF_STAMP(6);
 }
 
 // Q = sum of the per-cluster slabs (fixed order), for the split-phase path where Q is exchanged between ranks

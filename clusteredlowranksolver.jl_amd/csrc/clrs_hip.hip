@@ -1873,6 +1873,12 @@ extern "C" int clrs_config_set(const char *key, int value) {
 }
 
 #ifdef CLRS_W3_STAMPS
+extern "C" int clrs_debug_cf_stamps(clrs_ctx *c, uint64_t out[16]) {
+    if (!c || !out) return fail(CLRS_ERR_INVALID, "null argument");
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    HIPCHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cf_stamps), 16 * sizeof(uint64_t)));
+    return 0;
+}
 extern "C" int clrs_debug_ss2_stamps(clrs_ctx *c, uint64_t out[16]) {
     if (!c || !out) return fail(CLRS_ERR_INVALID, "null argument");
     HIPCHECK(hipStreamSynchronize(c->stream));

@@ -220,17 +220,19 @@ struct Potrf16 {
         double r = __builtin_amdgcn_rcp(p);
         r = __builtin_fma(__builtin_fma(-p, r, 1.0), r, r);
         const double w = a[K];
-        const double t = w * r;
+        const double nt = -(w * r);
         // Entries above the diagonal are never read: the eliminations run unpredicated on all rows; whatever they leave above
         // the diagonal is zeroed by the final scaling pass.
-        Elim<K + 1>::run(a, t, w);
+        Elim<K + 1>::run(a, nt, w);
         Potrf16<K + 1>::run(a, row, nvalid, bad, dgn);
     }
     template <int J, int DUMMY = 0>
     struct Elim {
-        static __device__ __forceinline__ void run(double (&a)[16], double t, double w) {
-            a[J] = __builtin_fma(-t, bcast16<J>(w), a[J]);      // a_iJ -= w_iK w_JK / d_K
-            Elim<J + 1>::run(a, t, w);
+        static __device__ __forceinline__ void run(double (&a)[16], double nt, double w) {
+            // a_iJ -= w_iK w_JK / d_K as ONE instruction: w_JK is read from lane J of the row by DPP inside the multiply-add
+            // (v_fmac_f64_dpp; row_newbcast is the one DPP control the 64-bit ALU has) instead of a v_mov_b64_dpp + v_fma pair
+            asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(a[J]) : "v"(w), "v"(nt), "n"(J));
+            Elim<J + 1>::run(a, nt, w);
         }
     };
     template <int DUMMY>

@@ -30,4 +30,13 @@ for i, n in enumerate(names):
     print(f"  {n:40s} {st[i + 1] - st[i]:8.0f} cycles")
 print(f"  {'total':40s} {st[6] - st[0]:8.0f} cycles")
 print(f"  inside the staging: entry -> all loads issued {st[8] - st[0]:6.0f}, -> all loads landed {st[9] - st[8]:6.0f}, -> stored + barrier {st[1] - st[9]:6.0f}")
+L.clrs_debug_cf_stamps.restype = C.c_int
+L.clrs_debug_cf_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+st = (C.c_uint64 * 16)()
+assert L.clrs_debug_cf_stamps(ctx.h, st) == 0
+st = np.array(st, dtype=np.float64)
+print("k_cluster_factor (workgroup 0):")
+for i, n in enumerate(["descriptor + loads of S_j, B_j -> LDS", "Cholesky of S_j", "store L_j", "L_j^-1 B_j", "store LinvB_j", "partial Q_j"]):
+    print(f"  {n:40s} {st[i + 1] - st[i]:8.0f} cycles")
+print(f"  {'total':40s} {st[6] - st[0]:8.0f} cycles")
 ctx.close()
