@@ -154,7 +154,7 @@ struct clrs_ctx {
     W3Tables w3tables = {};
     CSolve8 solve8 = {};          // host copy of the (<= 8) CSolve descriptors: kernel argument of k_solve_small2
     StageJobs solve_jobs = {};    // its staging job table
-    int solve_rx_job[8] = {0, 0, 0, 0, 0, 0, 0, 0}, solve_ry_job = -1;
+    int solve_rx_job[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, solve_ry_job[2] = {-1, -1};     // [first, end) job ranges of rhs_x[j] / rhs_y
     // caller-provided device pointers of the current call, read by the fused kernels at launch (no staging copies)
     const double *bind_X = nullptr, *bind_rhsx = nullptr, *bind_rhsy = nullptr;
     double *bind_Xchol = nullptr, *bind_dx = nullptr, *bind_dy = nullptr;
@@ -395,14 +395,24 @@ static int run_steps(clrs_ctx *c, const Plan &pl) {
                 break;
             case STEP_SOLVE_SMALL:
                 if (s.aux0 == 2) {
-                    for (int j = 0; j < c->J; j++) c->solve_jobs.j[c->solve_rx_job[j]].src = c->bind_rhsx + c->solve8.d[j].off;     // right-hand sides bound for this call
-                    if (c->solve_ry_job >= 0) c->solve_jobs.j[c->solve_ry_job].src = c->bind_rhsy;
+                    // right-hand sides bound for this call: piece i of a vector starts 16 x (its destination offset - the first piece's) in
+                    // (a pure zero-fill piece -- no valid rows -- reads and ignores the first entry)
+                    auto piece_off = [&](int t, int first) -> long long {
+                        const StageJob &jb = c->solve_jobs.j[t];
+                        return ((jb.meta >> 16) & 31) ? (long long)(jb.dst_ldd & 0xffff) - (long long)(c->solve_jobs.j[first].dst_ldd & 0xffff) : 0;
+                    };
+                    for (int j = 0; j < c->J; j++)
+                        for (int t = c->solve_rx_job[j]; t < c->solve_rx_job[8 + j]; t++)
+                            c->solve_jobs.j[t].src = c->bind_rhsx + c->solve8.d[j].off + piece_off(t, c->solve_rx_job[j]);
+                    for (int t = c->solve_ry_job[0]; t >= 0 && t < c->solve_ry_job[1]; t++)
+                        c->solve_jobs.j[t].src = c->bind_rhsy + piece_off(t, c->solve_ry_job[0]);
 #define CLRS_SS2(NJ) hipLaunchKernelGGL(k_solve_small2<NJ>, dim3(1), dim3(256), s.bytes, st, c->solve8, c->solve_jobs, c->J, (const double *)c->d_Q,          \
                                         (const double *)c->d_dinvQ, c->N, (int)c->xlen, c->bind_rhsx, c->bind_rhsy, (const double *)c->d_LB, c->bind_dx, c->bind_dy)
                     if (c->solve_jobs.n <= 8) CLRS_SS2(8);
                     else if (c->solve_jobs.n <= 16) CLRS_SS2(16);
                     else if (c->solve_jobs.n <= 24) CLRS_SS2(24);
-                    else CLRS_SS2(40);
+                    else if (c->solve_jobs.n <= 32) CLRS_SS2(32);
+                    else CLRS_SS2(48);
 #undef CLRS_SS2
                     break;
                 }
@@ -1402,7 +1412,7 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
         bool fits2 = g_cfg_solve_small2 && need2 <= 150 * 1024;
         if (fits2) {
             HIPCK(hipMemcpy(c->solve8.d, s.d0, sizeof(CSolve) * J, hipMemcpyDeviceToHost));
-            fits2 = solve_small2_jobs(c->solve_jobs, c->solve8.d, J, c->d_Q, c->d_dinvQ, N, c->xlen, c->d_LB, c->solve_rx_job, &c->solve_ry_job);
+            fits2 = solve_small2_jobs(c->solve_jobs, c->solve8.d, J, c->d_Q, c->d_dinvQ, N, c->xlen, c->d_LB, c->solve_rx_job, c->solve_ry_job);
         }
         if (fits2) {                                                // everything resident at once: the latency-first variant
             s.aux0 = 2; s.bytes = need2;
@@ -1410,7 +1420,8 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
                 HIPCK(hipFuncSetAttribute((const void *)k_solve_small2<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s.bytes));
                 HIPCK(hipFuncSetAttribute((const void *)k_solve_small2<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s.bytes));
                 HIPCK(hipFuncSetAttribute((const void *)k_solve_small2<24>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s.bytes));
-                HIPCK(hipFuncSetAttribute((const void *)k_solve_small2<40>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s.bytes));
+                HIPCK(hipFuncSetAttribute((const void *)k_solve_small2<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s.bytes));
+                HIPCK(hipFuncSetAttribute((const void *)k_solve_small2<48>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s.bytes));
             }
         }
         c->p_solve_all.steps.push_back(s);

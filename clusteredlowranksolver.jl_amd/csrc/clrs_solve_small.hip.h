@@ -129,28 +129,35 @@ __device__ unsigned long long g_ss2_stamps[16];
 // 256-entry vector piece to stage as a job in the kernel arguments; all loads are issued (straight-line code, one register per
 // job and thread), then all stores.  Thread (r = tid & 15, c = tid >> 4) of the 256 moves entry (r, c) of a tile.
 struct StageJob {
-    const double *src;     // tile origin / first entry
+    const double *src;     // tile origin
     unsigned dst_ldd;      // bits 0-15: destination offset in LDS (doubles); 16-24: destination leading dimension; 25-29: columns written
-    unsigned meta;         // bits 0-15: source leading dimension; 16-20: valid rows; 21-25: full valid columns; 26-30: valid rows of one more
-                           // (partial) column.  Entry (r, c) is loaded when (c < cols && r < rows) || (c == cols && r < rem); the destination
-                           // gets it, or zero, for every c < columns written (all 16 rows).  A 16 x 16 tile of a matrix: rem = 0, 16 columns
-                           // written; a piece of a vector: a "tile" with both leading dimensions 16 (entry index r + 16 c)
+    unsigned meta;         // bits 0-15: source leading dimension; 16-20: valid rows; 21-25: valid columns.  Entry (r, c), r, c < 16, is loaded
+                           // when r < rows and c < cols; the destination gets it, or zero, for every c < columns written (all 16 rows).
+                           // A piece of a vector is a "tile" with both leading dimensions 16 (entry index r + 16 c)
 };
-constexpr int STAGE_MAX_JOBS = 40;
+constexpr int STAGE_MAX_JOBS = 48;
 struct StageJobs {
     StageJob j[STAGE_MAX_JOBS];
     int n, pad;
 };
-static inline StageJob stage_rect(const double *src, int ldg, int rows, int cols, int dst, int ldd) {
+static inline StageJob stage_rect(const double *src, int ldg, int rows, int cols, int dst, int ldd, int wcols = 16) {
     StageJob b;
-    b.src = src; b.dst_ldd = (unsigned)dst | ((unsigned)ldd << 16) | (16u << 25); b.meta = (unsigned)ldg | ((unsigned)rows << 16) | ((unsigned)cols << 21);
+    b.src = src; b.dst_ldd = (unsigned)dst | ((unsigned)ldd << 16) | ((unsigned)wcols << 25); b.meta = (unsigned)ldg | ((unsigned)rows << 16) | ((unsigned)cols << 21);
     return b;
 }
-static inline StageJob stage_flat(const double *src, int count, int write, int dst) {       // count <= 256 entries loaded, `write` (multiple of 16) written
-    StageJob b;
-    b.src = src; b.dst_ldd = (unsigned)dst | (16u << 16) | ((unsigned)(write / 16) << 25);
-    b.meta = 16u | (16u << 16) | ((unsigned)(count / 16) << 21) | ((unsigned)(count % 16) << 26);
-    return b;
+// `count` consecutive entries from src to LDS offset dst, zeros up to `write` (a multiple of 16) entries: whole 16-entry columns as
+// pieces of up to 256, the remainder (and the zero fill) as one more piece with a single partly valid column
+static inline void stage_flat(std::vector<StageJob> &v, const double *src, int count, int write, int dst) {
+    const int full = count / 16, rem = count % 16;
+    for (int c0 = 0; c0 < full; c0 += 16) {
+        const int nc = std::min(16, full - c0);
+        v.push_back(stage_rect(src ? src + 16 * c0 : nullptr, 16, 16, nc, dst + 16 * c0, 16, nc));
+    }
+    for (int c0 = full; c0 < write / 16; c0 += 16) {                 // at most the first of these has a valid (partial) column
+        const int nc = std::min(16, write / 16 - c0);
+        const bool part = c0 == full && rem > 0;                       // a pure zero-fill piece reads (and ignores) the first entry of the vector
+        v.push_back(stage_rect(src ? (part ? src + 16 * c0 : src) : nullptr, 16, part ? rem : 0, part ? 1 : 0, dst + 16 * c0, 16, nc));
+    }
 }
 // The table itself must not be read entry by entry (scalar loads from the kernel-argument segment, or LDS reads of a copy: each
 // entry's use then waits for its own fetch, 400 cycles per job measured): lane t of every wave fetches job t with ONE 16-byte
@@ -166,6 +173,8 @@ __device__ __forceinline__ void stage_all(const StageJobs &kjobs, double *lds, i
     const StageJob mine = kjobs.j[lane < NJ ? lane : 0];
     const unsigned long long msrc = (unsigned long long)mine.src;
     const int m_lo = (int)(unsigned)msrc, m_hi = (int)(unsigned)(msrc >> 32), m_dl = (int)mine.dst_ldd, m_meta = (int)mine.meta;
+    // validity as integer arithmetic on the VALU (sign bits), not compares: a compare writes an SGPR pair that the scalar unit then
+    // combines and hands back through VCC -- four VALU <-> SALU hand-offs per job were most of the 215 cycles a job cost
     double v[NJ];
 #pragma unroll
     for (int t = 0; t < NJ; t++) {
@@ -174,9 +183,9 @@ __device__ __forceinline__ void stage_all(const StageJobs &kjobs, double *lds, i
         // a GLOBAL pointer (address space 1): through a generic pointer this would be a flat_load, which completes out of order, and the
         // compiler would drain vmcnt AND lgkmcnt before every later v_readlane of the table -- one trip to memory per job again
         const __attribute__((address_space(1))) double *src = (const __attribute__((address_space(1))) double *)sp;
-        const int rows = (meta >> 16) & 31, cols = (meta >> 21) & 31, rem = (meta >> 26) & 31;
-        const bool valid = (c < cols & r < rows) | (c == cols & r < rem);
-        v[t] = src[valid ? r + c * (int)(meta & 0xffff) : 0];
+        const int rows = (meta >> 16) & 31, cols = (meta >> 21) & 31;
+        const int mask = ((r - rows) & (c - cols)) >> 31;                 // all ones: r < rows and c < cols
+        v[t] = src[(r + c * (int)(meta & 0xffff)) & mask];
     }
 #ifdef CLRS_W3_STAMPS
     if (tid == 0) g_ss2_stamps[8] = __builtin_amdgcn_s_memtime();
@@ -186,9 +195,10 @@ __device__ __forceinline__ void stage_all(const StageJobs &kjobs, double *lds, i
 #pragma unroll
     for (int t = 0; t < NJ; t++) {
         const unsigned meta = (unsigned)__builtin_amdgcn_readlane(m_meta, t), dl = (unsigned)__builtin_amdgcn_readlane(m_dl, t);
-        const int rows = (meta >> 16) & 31, cols = (meta >> 21) & 31, rem = (meta >> 26) & 31;
-        const bool valid = (c < cols & r < rows) | (c == cols & r < rem);
-        if (c < (int)((dl >> 25) & 31)) lds[(int)(dl & 0xffff) + r + c * (int)((dl >> 16) & 511)] = valid ? v[t] : 0.0;
+        const int rows = (meta >> 16) & 31, cols = (meta >> 21) & 31;
+        const long long mask = (long long)(((r - rows) & (c - cols)) >> 31);
+        const double val = __longlong_as_double(__double_as_longlong(v[t]) & mask);
+        if (c < (int)((dl >> 25) & 31)) lds[(int)(dl & 0xffff) + r + c * (int)((dl >> 16) & 511)] = val;
     }
 }
 
@@ -223,11 +233,10 @@ static inline bool solve_small2_jobs(StageJobs &jb, const CSolve *cs, int J, con
         for (int tj = 0; tj < nt; tj++)
             for (int ti = tj; ti < nt; ti++)       // lower tiles only: the solves never read above the diagonal tiles
                 v.push_back(stage_rect(cs[j].L + ti * 16 + (long long)tj * 16 * P, P, std::min(16, P - ti * 16), std::min(16, P - tj * 16), o + ti * 16 + tj * 16 * lda, lda));
-        for (int p0 = 0; p0 < P16; p0 += 256) {
-            v.push_back(stage_flat(cs[j].dinv + p0, std::min(256, P - p0), std::min(256, P16 - p0), o + lda * P16 + p0));
-            rx_job[j] = (int)v.size();               // (one piece: P16 <= 256 is checked below)
-            v.push_back(stage_flat(nullptr, std::min(256, P - p0), std::min(256, P16 - p0), o + lda * P16 + P16 + p0));
-        }
+        stage_flat(v, cs[j].dinv, P, P16, o + lda * P16);
+        rx_job[j] = (int)v.size();                   // the pieces of rhs_x[j] follow: sources patched per call (src = base + what stage_flat added)
+        stage_flat(v, nullptr, P, P16, o + lda * P16 + P16);
+        rx_job[8 + j] = (int)v.size();
         if (P16 > 256) return false;
         o += lda * P16 + 2 * P16;
     }
@@ -236,23 +245,21 @@ static inline bool solve_small2_jobs(StageJobs &jb, const CSolve *cs, int J, con
     for (int tj = 0; tj < ntq; tj++)
         for (int ti = tj; ti < ntq; ti++)
             v.push_back(stage_rect(LQ + ti * 16 + (long long)tj * 16 * N, N, std::min(16, N - ti * 16), std::min(16, N - tj * 16), o + ti * 16 + tj * 16 * ldq, ldq));
-    *ry_job = -1;
+    ry_job[0] = ry_job[1] = -1;
     if (N > 0) {
-        v.push_back(stage_flat(dinvQ, N, N16, o + ldq * N16));
+        stage_flat(v, dinvQ, N, N16, o + ldq * N16);
         const int oLB = o + ldq * N16 + N16, oyy = oLB + (int)(xlen * N) + xl;
-        *ry_job = (int)v.size();
-        v.push_back(stage_flat(nullptr, N, N16, oyy));
-        const long long tot = xlen * N;
-        for (long long e0 = 0; e0 < tot; e0 += 256) {      // whole 16-entry columns are written: the last piece may spill (zeros) into t, which is filled later
-            const int cnt = (int)std::min<long long>(256, tot - e0);
-            v.push_back(stage_flat(LBall + e0, cnt, (cnt + 15) & ~15, oLB + (int)e0));
-        }
+        ry_job[0] = (int)v.size();
+        stage_flat(v, nullptr, N, N16, oyy);
+        ry_job[1] = (int)v.size();
+        // LinvB: whole 16-entry columns are written, the last piece may spill (zeros) into t, which is filled later
+        stage_flat(v, LBall, (int)(xlen * N), (int)((xlen * N + 15) & ~15ll), oLB);
     }
     if (v.size() > (size_t)STAGE_MAX_JOBS) return false;
     std::memset(&jb, 0, sizeof(jb));
     for (size_t i = 0; i < v.size(); i++) jb.j[i] = v[i];
     jb.n = (int)v.size();
-    for (int i = jb.n; i < STAGE_MAX_JOBS; i++) jb.j[i] = stage_flat(LBall ? LBall : cs[0].L, 0, 0, 0);     // empty: reads one valid word, writes nothing
+    for (int i = jb.n; i < STAGE_MAX_JOBS; i++) jb.j[i] = stage_rect(cs[0].L, 16, 0, 0, 0, 16, 0);     // empty: reads one valid word, writes nothing
     return true;
 }
 
