@@ -94,6 +94,11 @@ def main():
     ap.add_argument("--split", action="store_true", help="with one GPU: still run the split-phase calls and the RCCL all-reduces (1-rank group)")
     args = ap.parse_args()
 
+    # stdout carries exactly one JSON line.  Native libraries write there too (RCCL prints its version banner and its "iommu=pt"
+    # warning to stdout when the process group comes up): keep the real stdout aside and point fd 1 at stderr for the whole run.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
@@ -367,8 +372,8 @@ def main():
     if rank == 0:
         import ctypes
         sys.stderr.flush()
-        ctypes.CDLL(None).fflush(None)             # anything native code buffered on stdout goes out before the JSON line
-        print(json.dumps(out), flush=True)
+        ctypes.CDLL(None).fflush(None)             # anything native code buffered goes out (to stderr) before the JSON line
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
 
 
 if __name__ == "__main__":
