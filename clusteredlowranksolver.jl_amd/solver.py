@@ -47,12 +47,14 @@ class SchurContext:
     src/solver.jl:298-317 -- all device resident."""
 
     def __init__(self, sdp, device: int = 0, graph: bool = False, timing: bool = False, fused: Optional[bool] = None,
-                 wave: Optional[bool] = None, wave2: Optional[bool] = None, wave3: Optional[bool] = None):
+                 wave: Optional[bool] = None, wave2: Optional[bool] = None, wave3: Optional[bool] = None,
+                 solve_small2: Optional[bool] = None):
         """`fused=False` forces the staged grouped-GEMM / blocked-BLAS path everywhere (default: clusters that fit in
         one CU's LDS take the fused per-cluster assembly, factor and solve kernels).  `wave=False` keeps the
         fused assembly on the 4-waves-per-block kernel even where the wave-per-block kernel applies.  `wave2=True`
         takes the cluster-per-wave assembly even for few clusters (default: from 64 clusters on); `wave3=False` keeps it on
-        the LDS-staged kernel (k_cluster_assemble_w2) instead of the register-resident one (k_cluster_assemble_w3)."""
+        the LDS-staged kernel (k_cluster_assemble_w2) instead of the register-resident one (k_cluster_assemble_w3);
+        `solve_small2=False` keeps the one-launch solve stage on k_solve_small instead of k_solve_small2."""
         self.flat: FlatSDP = sdp if isinstance(sdp, FlatSDP) else flatten(sdp)
         f = self.flat
         self.L = _lib.load()
@@ -65,6 +67,8 @@ class SchurContext:
             _lib.check(self.L.clrs_config_set(b"wave2_assemble", 2 if wave2 else 0))
         if wave3 is not None:
             _lib.check(self.L.clrs_config_set(b"wave3_assemble", int(bool(wave3))))
+        if solve_small2 is not None:
+            _lib.check(self.L.clrs_config_set(b"solve_small2", int(bool(solve_small2))))
         k = self._keep = {}
 
         def hold(name, arr, dt):
@@ -94,6 +98,8 @@ class SchurContext:
                 self.L.clrs_config_set(b"wave2_assemble", 1)
             if wave3 is not None:
                 self.L.clrs_config_set(b"wave3_assemble", 1)
+            if solve_small2 is not None:
+                self.L.clrs_config_set(b"solve_small2", 1)
         self.h = h
         self.device = device
         if graph:

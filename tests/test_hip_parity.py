@@ -145,6 +145,40 @@ def test_cluster_per_wave_assembly_many_clusters(name, copies, oracle_built):
     assert worst <= 1e-11
 
 
+@pytest.mark.parametrize("copies", [1, 700])
+@pytest.mark.parametrize("name", ["ce_8_15", "ce_8_3"])
+def test_cluster_per_wave_assembly_rare_paths(name, copies, oracle_built):
+    """The rarely taken paths of k_cluster_assemble_w3: constraints of a cluster in a permuted order (S_j stored through the
+    vector -> constraint table), two 1 x 1 dense blocks in one cluster (the second one is fetched at the cluster's end), three
+    low-rank blocks in one cluster -- alone and with several clusters per wave (the loads of the next block are in flight across
+    these paths)."""
+    from clrs_amd.sdp import replicate_clusters
+    from clrs_amd.solver import SchurContext
+    from oracle.oracle import Oracle
+    from tests.util import duplicate_block, permute_cluster_constraints
+    f = flat(name)
+    dense = [b for b in range(f.n_blocks) if f.block_kind[b] == 1]
+    assert len(dense) == 1
+    g = duplicate_block(f, dense[0], 0.5)                 # second 1 x 1 dense block in that cluster
+    g = duplicate_block(g, 0, -0.75)                      # third low-rank block in cluster 0 (negative lambdas too)
+    g = permute_cluster_constraints(g, seed=11)
+    big = replicate_clusters(g, copies) if copies > 1 else g
+    X, Y = spd_iterates(big, seed=9)
+    Xc = chol_blocks_np(big, X)
+    ctx = SchurContext(big, wave2=True)
+    assert ctx.wave2_clusters() == big.n_clusters
+    S, AY = ctx.compute_S_integrated(Xc, Y)
+    ctx.close()
+    o = Oracle(g, quad=False)
+    nxy, nS, nT = g.xy_len, g.S_len, g.n_terms
+    for k in range(copies):
+        Sk, AYk = o.schur_assemble(Xc[k * nxy:(k + 1) * nxy], Y[k * nxy:(k + 1) * nxy])
+        assert np.max(np.abs(S[k * nS:(k + 1) * nS] - Sk)) <= 1e-11 * np.max(np.abs(Sk))
+        assert np.max(np.abs(AY[k * nT:(k + 1) * nT] - AYk)) <= 1e-11 * max(1.0, np.max(np.abs(AYk)))
+        Sj = S[k * nS:k * nS + int(g.cluster_P[0]) ** 2].reshape(int(g.cluster_P[0]), -1, order="F")
+        assert np.array_equal(Sj, Sj.T)
+
+
 def test_dedup_counts_match_oracle(oracle_built):
     from clrs_amd.solver import SchurContext
     from oracle.oracle import Oracle
@@ -165,7 +199,7 @@ FACTOR_CASES = ["x2p1", "polyopt8", "polyopt40", "delsarte_3_10", "delsarte_8_3"
                 "polyopt_scaled_100"]
 
 
-@pytest.mark.parametrize("fused", [True, False], ids=["fused", "staged"])
+@pytest.mark.parametrize("fused", [True, "k_solve_small", False], ids=["fused", "fused_k_solve_small", "staged"])
 @pytest.mark.parametrize("name", FACTOR_CASES)
 def test_factor_and_solve_match_oracle(name, fused, oracle_built):
     from clrs_amd.solver import SchurContext, compute_T_decomposition, solve_system
@@ -173,7 +207,7 @@ def test_factor_and_solve_match_oracle(name, fused, oracle_built):
     f = flat(name)
     X, Y = spd_iterates(f, seed=2)
     Xc = chol_blocks_np(f, X)
-    ctx = SchurContext(f, fused=fused)
+    ctx = SchurContext(f, fused=bool(fused), solve_small2=(False if fused == "k_solve_small" else None))
     _, S, _ = compute_T_decomposition(ctx, Xc, Y, want_S=True)
     L, LinvB, LQ = ctx.get_factor()
     o = Oracle(f, quad=False)

@@ -70,3 +70,78 @@ def instance(name):
 @functools.lru_cache(maxsize=None)
 def flat(name):
     return clrs_amd.flatten(instance(name))
+
+
+def permute_cluster_constraints(f, seed=0):
+    """The same SDP with the constraints of every cluster relabelled by a random permutation (rows of B_j and c_j moved along):
+    the vector -> constraint map of the cluster-per-wave assembly kernels is then not the identity."""
+    import copy
+    rng = np.random.default_rng(seed)
+    g = copy.copy(f)
+    g.term_p, g.dense_p = f.term_p.copy(), f.dense_p.copy()
+    g.B, g.B_lo, g.c, g.c_lo = f.B.copy(), f.B_lo.copy(), f.c.copy(), f.c_lo.copy()
+    N = f.n_free
+    for j in range(f.n_clusters):
+        P = int(f.cluster_P[j])
+        perm = rng.permutation(P)                    # new index of old constraint p
+        for b in range(f.n_blocks):
+            if int(f.block_cluster[b]) != j:
+                continue
+            t0, t1 = int(f.term_ptr[b]), int(f.term_ptr[b + 1])
+            g.term_p[t0:t1] = perm[f.term_p[t0:t1]]
+            d0, d1 = int(f.dense_ptr[b]), int(f.dense_ptr[b + 1])
+            g.dense_p[d0:d1] = perm[f.dense_p[d0:d1]]
+        o = int(f.cluster_off[j])
+        for arr_new, arr_old in ((g.c, f.c), (g.c_lo, f.c_lo)):
+            arr_new[o + perm] = arr_old[o:o + P]
+        for arr_new, arr_old in ((g.B, f.B), (g.B_lo, f.B_lo)):
+            Bo = arr_old[o * N:(o + P) * N].reshape(P, N, order="F")
+            Bn = np.empty_like(Bo)
+            Bn[perm, :] = Bo
+            arr_new[o * N:(o + P) * N] = Bn.reshape(-1, order="F")
+    return g
+
+
+def duplicate_block(f, b, scale=0.5):
+    """The same SDP with a copy of PSD block b (its constraint matrices scaled) appended right after it in the same cluster:
+    gives a cluster a second 1 x 1 dense block, or one more low-rank block."""
+    import copy
+    g = copy.copy(f)
+    ins = b + 1
+
+    def ins1(a, val):
+        return np.insert(a, ins, val)
+
+    g.n_blocks = f.n_blocks + 1
+    for name in ("block_cluster", "block_m", "block_delta", "block_kind", "block_n"):
+        setattr(g, name, ins1(getattr(f, name), getattr(f, name)[b]))
+    t0, t1 = int(f.term_ptr[b]), int(f.term_ptr[b + 1])
+    d0, d1 = int(f.dense_ptr[b]), int(f.dense_ptr[b + 1])
+    nt, nd = t1 - t0, d1 - d0
+    g.term_ptr = np.concatenate([f.term_ptr[:ins + 1], f.term_ptr[ins:] + nt]).astype(np.int64)
+    g.dense_ptr = np.concatenate([f.dense_ptr[:ins + 1], f.dense_ptr[ins:] + nd]).astype(np.int64)
+    for name in ("term_p", "term_r", "term_s", "term_rank"):
+        a = getattr(f, name)
+        setattr(g, name, np.concatenate([a[:t1], a[t0:t1], a[t1:]]))
+    for name, s_ in (("term_lambda", scale), ("term_lambda_lo", scale)):
+        a = getattr(f, name)
+        setattr(g, name, np.concatenate([a[:t1], s_ * a[t0:t1], a[t1:]]))
+    v0, v1 = int(f.term_vec_ptr[t0]), int(f.term_vec_ptr[t1])
+    lens = np.diff(f.term_vec_ptr)
+    g.term_vec_ptr = np.concatenate([[0], np.cumsum(np.concatenate([lens[:t1], lens[t0:t1], lens[t1:]]))]).astype(np.int64)
+    for name in ("term_vs", "term_vs_lo", "term_ws", "term_ws_lo"):
+        a = getattr(f, name)
+        setattr(g, name, np.concatenate([a[:v1], a[v0:v1], a[v1:]]))
+    g.dense_p = np.concatenate([f.dense_p[:d1], f.dense_p[d0:d1], f.dense_p[d1:]])
+    a0, a1 = int(f.dense_A_ptr[d0]), int(f.dense_A_ptr[d1])
+    dl = np.diff(f.dense_A_ptr)
+    g.dense_A_ptr = np.concatenate([[0], np.cumsum(np.concatenate([dl[:d1], dl[d0:d1], dl[d1:]]))]).astype(np.int64)
+    for name in ("dense_A", "dense_A_lo"):
+        a = getattr(f, name)
+        setattr(g, name, np.concatenate([a[:a1], scale * a[a0:a1], a[a1:]]))
+    x0, x1 = int(f.block_off[b]), int(f.block_off[b + 1])
+    for name in ("C", "C_lo"):
+        a = getattr(f, name)
+        setattr(g, name, np.concatenate([a[:x1], a[x0:x1], a[x1:]]))
+    g.block_off = np.concatenate([[0], np.cumsum(g.block_n.astype(np.int64) ** 2)]).astype(np.int64)
+    return g
