@@ -214,10 +214,16 @@ int clrs_fused_clusters(const clrs_ctx *ctx);
 /* "wave_assemble" (default 1): among those, clusters made only of simple rank-1 blocks with n <= 16 and small dense
  * blocks are assembled with one wave per PSD block (k_cluster_assemble_w1); clrs_wave_clusters counts them. */
 int clrs_wave_clusters(const clrs_ctx *ctx);
-/* "wave2_assemble" (default 1 = automatic: contexts with >= 64 clusters; 2 = always; 0 = never): of those, clusters whose
- * low-rank blocks all use the same constraint order (and whose dense blocks are 1 x 1) are assembled by ONE wave per cluster
- * with S in registers (k_cluster_assemble_w2): higher throughput, but the blocks of a cluster are walked one after the other. */
+/* "wave2_assemble" (default 1 = automatic; 2 = always; 0 = never): of those, clusters whose low-rank blocks all use the same
+ * constraint order (and whose dense blocks are 1 x 1) are assembled by ONE wave per cluster with S in registers.
+ * "wave3_assemble" (default 1): with U = P <= 32 that wave is k_cluster_assemble_w3 -- MFMA accumulators reused as operands,
+ * nothing but the row of chol(X) and S_j on its way out touches LDS, each wave walks a contiguous run of clusters with the next
+ * block's loads in flight -- and "automatic" means always (it is also the fastest form for two clusters); otherwise
+ * (U <= 64, or "wave3_assemble" = 0) it is the LDS-staged k_cluster_assemble_w2 and "automatic" means >= 64 clusters.
+ * clrs_wave2_clusters counts the clusters either kernel takes. */
 int clrs_wave2_clusters(const clrs_ctx *ctx);
+/* "solve_small2" (default 1): contexts with <= 8 clusters whose factors fit in 150 KB of LDS run the solve stage as ONE launch
+ * of k_solve_small2 (every operand staged in one trip to memory, one wave per triangular solve); 0 keeps k_solve_small. */
 /* Diagnostic builds (-DCLRS_FUSED_STAMPS) only: s_memtime stamps of the phases of workgroup 0 of the fused kernel. */
 int clrs_debug_stamps(clrs_ctx *ctx, uint64_t out[64]);
 
