@@ -153,8 +153,12 @@ struct clrs_ctx {
     FTables ftables = {};
     W3Tables w3tables = {};
     CSolve8 solve8 = {};          // host copy of the (<= 8) CSolve descriptors: kernel argument of k_solve_small2
-    StageJobs solve_jobs = {};    // its staging job table
-    int solve_rx_job[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, solve_ry_job[2] = {-1, -1};     // [first, end) job ranges of rhs_x[j] / rhs_y
+    struct SolveSmall2 {          // its staging job table, per phase: 0 = whole stage, 1 / 2 = before / after the exchange of u (sharded path)
+        StageJobs jobs = {};
+        int rx_job[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ry_job[2] = {-1, -1};     // [first, end) job ranges of rhs_x[j] / rhs_y
+        bool ok = false;
+    } ss2[3];
+    Plan p_fwd_small, p_bwd_small;     // one-launch forms of p_fwd / p_bwd (k_solve_small2, phases 1 and 2)
     // caller-provided device pointers of the current call, read by the fused kernels at launch (no staging copies)
     const double *bind_X = nullptr, *bind_rhsx = nullptr, *bind_rhsy = nullptr;
     double *bind_Xchol = nullptr, *bind_dx = nullptr, *bind_dy = nullptr;
@@ -394,25 +398,31 @@ static int run_steps(clrs_ctx *c, const Plan &pl) {
                 hipLaunchKernelGGL(k_dense_block, dim3(s.grid), dim3(256), s.bytes, st, (const DBlock *)s.d0, *(const FTables *)s.src);
                 break;
             case STEP_SOLVE_SMALL:
-                if (s.aux0 == 2) {
+                if (s.aux0 >= 2) {
+                    const int ph = s.aux0 - 2;
+                    clrs_ctx::SolveSmall2 &q = c->ss2[ph];
                     // right-hand sides bound for this call: piece i of a vector starts 16 x (its destination offset - the first piece's) in
                     // (a pure zero-fill piece -- no valid rows -- reads and ignores the first entry)
                     auto piece_off = [&](int t, int first) -> long long {
-                        const StageJob &jb = c->solve_jobs.j[t];
-                        return ((jb.meta >> 16) & 31) ? (long long)(jb.dst_ldd & 0xffff) - (long long)(c->solve_jobs.j[first].dst_ldd & 0xffff) : 0;
+                        const StageJob &jb = q.jobs.j[t];
+                        return ((jb.meta >> 16) & 31) ? (long long)(jb.dst_ldd & 0xffff) - (long long)(q.jobs.j[first].dst_ldd & 0xffff) : 0;
                     };
                     for (int j = 0; j < c->J; j++)
-                        for (int t = c->solve_rx_job[j]; t < c->solve_rx_job[8 + j]; t++)
-                            c->solve_jobs.j[t].src = c->bind_rhsx + c->solve8.d[j].off + piece_off(t, c->solve_rx_job[j]);
-                    for (int t = c->solve_ry_job[0]; t >= 0 && t < c->solve_ry_job[1]; t++)
-                        c->solve_jobs.j[t].src = c->bind_rhsy + piece_off(t, c->solve_ry_job[0]);
-#define CLRS_SS2(NJ) hipLaunchKernelGGL(k_solve_small2<NJ>, dim3(1), dim3(256), s.bytes, st, c->solve8, c->solve_jobs, c->J, (const double *)c->d_Q,          \
-                                        (const double *)c->d_dinvQ, c->N, (int)c->xlen, c->bind_rhsx, c->bind_rhsy, (const double *)c->d_LB, c->bind_dx, c->bind_dy)
-                    if (c->solve_jobs.n <= 8) CLRS_SS2(8);
-                    else if (c->solve_jobs.n <= 16) CLRS_SS2(16);
-                    else if (c->solve_jobs.n <= 24) CLRS_SS2(24);
-                    else if (c->solve_jobs.n <= 32) CLRS_SS2(32);
-                    else CLRS_SS2(48);
+                        for (int t = q.rx_job[j]; t < q.rx_job[8 + j]; t++) q.jobs.j[t].src = c->bind_rhsx + c->solve8.d[j].off + piece_off(t, q.rx_job[j]);
+                    for (int t = q.ry_job[0]; t >= 0 && t < q.ry_job[1]; t++) q.jobs.j[t].src = c->bind_rhsy + piece_off(t, q.ry_job[0]);
+#define CLRS_SS2(NJ, PH) hipLaunchKernelGGL((k_solve_small2<NJ, PH>), dim3(1), dim3(256), s.bytes, st, c->solve8, q.jobs, c->J, c->N, (int)c->xlen, c->bind_dx, c->bind_dy, c->d_t, c->d_u)
+#define CLRS_SS2_NJ(PH)                                  \
+    do {                                                 \
+        if (q.jobs.n <= 8) CLRS_SS2(8, PH);              \
+        else if (q.jobs.n <= 16) CLRS_SS2(16, PH);       \
+        else if (q.jobs.n <= 24) CLRS_SS2(24, PH);       \
+        else if (q.jobs.n <= 32) CLRS_SS2(32, PH);       \
+        else CLRS_SS2(48, PH);                           \
+    } while (0)
+                    if (ph == 0) CLRS_SS2_NJ(0);
+                    else if (ph == 1) CLRS_SS2_NJ(1);
+                    else CLRS_SS2_NJ(2);
+#undef CLRS_SS2_NJ
 #undef CLRS_SS2
                     break;
                 }
@@ -1412,16 +1422,25 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
         bool fits2 = g_cfg_solve_small2 && need2 <= 150 * 1024;
         if (fits2) {
             HIPCK(hipMemcpy(c->solve8.d, s.d0, sizeof(CSolve) * J, hipMemcpyDeviceToHost));
-            fits2 = solve_small2_jobs(c->solve_jobs, c->solve8.d, J, c->d_Q, c->d_dinvQ, N, c->xlen, c->d_LB, c->solve_rx_job, c->solve_ry_job);
+            for (int ph = 0; ph < 3 && fits2; ph++) {
+                clrs_ctx::SolveSmall2 &q = c->ss2[ph];
+                q.ok = solve_small2_jobs(q.jobs, c->solve8.d, J, c->d_Q, c->d_dinvQ, N, c->xlen, c->d_LB, q.rx_job, q.ry_job, ph, c->d_t, c->d_u);
+                fits2 = q.ok;
+            }
         }
         if (fits2) {                                                // everything resident at once: the latency-first variant
+            Step s1 = s, s2 = s;
             s.aux0 = 2; s.bytes = need2;
+            s1.aux0 = 3; s1.bytes = need2; s2.aux0 = 4; s2.bytes = need2;
+            c->p_fwd_small.steps.push_back(s1);
+            c->p_bwd_small.steps.push_back(s2);
             if (s.bytes > 64 * 1024) {
-                HIPCK(hipFuncSetAttribute((const void *)k_solve_small2<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s.bytes));
-                HIPCK(hipFuncSetAttribute((const void *)k_solve_small2<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s.bytes));
-                HIPCK(hipFuncSetAttribute((const void *)k_solve_small2<24>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s.bytes));
-                HIPCK(hipFuncSetAttribute((const void *)k_solve_small2<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s.bytes));
-                HIPCK(hipFuncSetAttribute((const void *)k_solve_small2<48>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s.bytes));
+#define CLRS_SS2_ATTR(NJ)                                                                                                                   \
+    HIPCK(hipFuncSetAttribute((const void *)k_solve_small2<NJ, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s.bytes));               \
+    HIPCK(hipFuncSetAttribute((const void *)k_solve_small2<NJ, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s.bytes));               \
+    HIPCK(hipFuncSetAttribute((const void *)k_solve_small2<NJ, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s.bytes));
+                CLRS_SS2_ATTR(8) CLRS_SS2_ATTR(16) CLRS_SS2_ATTR(24) CLRS_SS2_ATTR(32) CLRS_SS2_ATTR(48)
+#undef CLRS_SS2_ATTR
             }
         }
         c->p_solve_all.steps.push_back(s);
@@ -1509,7 +1528,7 @@ extern "C" void clrs_ctx_destroy(clrs_ctx *c) {
     ipm_free(c);
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
-    Plan *plans[] = {&c->p_assemble, &c->p_cholS, &c->p_linvB, &c->p_Q, &c->p_cholQ, &c->p_fwd, &c->p_bwd, &c->p_cholX, &c->p_cholQ_slabs, &c->p_solve_all};
+    Plan *plans[] = {&c->p_assemble, &c->p_cholS, &c->p_linvB, &c->p_Q, &c->p_cholQ, &c->p_fwd, &c->p_bwd, &c->p_cholX, &c->p_cholQ_slabs, &c->p_solve_all, &c->p_fwd_small, &c->p_bwd_small};
     for (Plan *p : plans)
         if (p->graph) hipGraphExecDestroy(p->graph);
     for (void *p : c->allocs) hipFree(p);
@@ -1704,7 +1723,7 @@ extern "C" int clrs_schur_solve_fwd_dev(clrs_ctx *c, const double *d_rhs_x) {
     if (c->fused_fs) c->bind_rhsx = d_rhs_x;
     else if (d_rhs_x != c->d_rhsx) HIPCHECK(hipMemcpyAsync(c->d_rhsx, d_rhs_x, sizeof(double) * c->xlen, hipMemcpyDeviceToDevice, c->stream));
     if (c->timing) HIPCHECK(hipEventRecord(c->ev[7], c->stream));
-    return run_plan(c, c->p_fwd);
+    return run_plan(c, c->p_fwd_small.steps.empty() ? c->p_fwd : c->p_fwd_small);
 }
 
 extern "C" int clrs_schur_solve_bwd_dev(clrs_ctx *c, const double *d_rhs_y, double *d_dx, double *d_dy) {
@@ -1719,7 +1738,7 @@ extern "C" int clrs_schur_solve_bwd_dev(clrs_ctx *c, const double *d_rhs_y, doub
     c->bind_dx = (x_direct && d_dx) ? d_dx : c->d_dx;
     if (c->N > 0 && !q_direct && d_rhs_y != c->d_rhsy)
         HIPCHECK(hipMemcpyAsync(c->d_rhsy, d_rhs_y, sizeof(double) * c->N, hipMemcpyDeviceToDevice, c->stream));
-    int rc = run_plan(c, c->p_bwd);
+    int rc = run_plan(c, c->p_bwd_small.steps.empty() ? c->p_bwd : c->p_bwd_small);
     if (rc) return rc;
     if (c->timing) { HIPCHECK(hipEventRecord(c->ev[8], c->stream)); c->solve_time_pending = true; }
     if (!x_direct && d_dx && d_dx != c->d_t) HIPCHECK(hipMemcpyAsync(d_dx, c->d_t, sizeof(double) * c->xlen, hipMemcpyDeviceToDevice, c->stream));
@@ -1831,7 +1850,7 @@ extern "C" int clrs_set_stream(clrs_ctx *c, void *stream) {
     if (!c) return fail(CLRS_ERR_INVALID, "null argument");
     HIPCHECK(hipSetDevice(c->device));
     HIPCHECK(hipStreamSynchronize(c->stream));
-    Plan *plans[] = {&c->p_assemble, &c->p_cholS, &c->p_linvB, &c->p_Q, &c->p_cholQ, &c->p_fwd, &c->p_bwd, &c->p_cholX, &c->p_cholQ_slabs, &c->p_solve_all};
+    Plan *plans[] = {&c->p_assemble, &c->p_cholS, &c->p_linvB, &c->p_Q, &c->p_cholQ, &c->p_fwd, &c->p_bwd, &c->p_cholX, &c->p_cholQ_slabs, &c->p_solve_all, &c->p_fwd_small, &c->p_bwd_small};
     for (Plan *p : plans)
         if (p->graph) { hipGraphExecDestroy(p->graph); p->graph = nullptr; }   // graphs are re-captured on the new stream
     if (c->own_stream) HIPCHECK(hipStreamDestroy(c->stream));

@@ -224,8 +224,10 @@ struct CSolve8 {
 
 // The jobs of k_solve_small2, in the LDS layout the kernel carves (returns false when they do not fit the table: the caller keeps
 // k_solve_small).  rhs_x / rhs_y are bound per call: their jobs are listed in rx_job[j] / ry_job for patching at launch.
+// phase 0: the whole stage; 1: the part before the exchange of u (forward solves, partial u); 2: the part after it (Q solve, backward
+// solves), which takes t and the summed u back from the context's buffers d_t / d_u (the cluster-sharded path)
 static inline bool solve_small2_jobs(StageJobs &jb, const CSolve *cs, int J, const double *LQ, const double *dinvQ, int N, long long xlen,
-                                     const double *LBall, int *rx_job, int *ry_job) {
+                                     const double *LBall, int *rx_job, int *ry_job, int phase = 0, const double *d_t = nullptr, const double *d_u = nullptr) {
     std::vector<StageJob> v;
     int o = 0;
     for (int j = 0; j < J; j++) {
@@ -235,26 +237,33 @@ static inline bool solve_small2_jobs(StageJobs &jb, const CSolve *cs, int J, con
                 v.push_back(stage_rect(cs[j].L + ti * 16 + (long long)tj * 16 * P, P, std::min(16, P - ti * 16), std::min(16, P - tj * 16), o + ti * 16 + tj * 16 * lda, lda));
         stage_flat(v, cs[j].dinv, P, P16, o + lda * P16);
         rx_job[j] = (int)v.size();                   // the pieces of rhs_x[j] follow: sources patched per call (src = base + what stage_flat added)
-        stage_flat(v, nullptr, P, P16, o + lda * P16 + P16);
+        if (phase != 2) stage_flat(v, nullptr, P, P16, o + lda * P16 + P16);
         rx_job[8 + j] = (int)v.size();
         if (P16 > 256) return false;
         o += lda * P16 + 2 * P16;
     }
     const int N16 = (N + 15) & ~15, ldq = N16 + 2, ntq = N16 / 16, xl = (int)((xlen + 15) & ~15);
     if (N16 > 256) return false;
-    for (int tj = 0; tj < ntq; tj++)
-        for (int ti = tj; ti < ntq; ti++)
-            v.push_back(stage_rect(LQ + ti * 16 + (long long)tj * 16 * N, N, std::min(16, N - ti * 16), std::min(16, N - tj * 16), o + ti * 16 + tj * 16 * ldq, ldq));
+    if (phase != 1)
+        for (int tj = 0; tj < ntq; tj++)
+            for (int ti = tj; ti < ntq; ti++)
+                v.push_back(stage_rect(LQ + ti * 16 + (long long)tj * 16 * N, N, std::min(16, N - ti * 16), std::min(16, N - tj * 16), o + ti * 16 + tj * 16 * ldq, ldq));
     ry_job[0] = ry_job[1] = -1;
+    const int oLB = o + ldq * N16 + N16, ott = oLB + (int)(xlen * N), oyy = ott + xl, opu = oyy + N16;
     if (N > 0) {
-        stage_flat(v, dinvQ, N, N16, o + ldq * N16);
-        const int oLB = o + ldq * N16 + N16, oyy = oLB + (int)(xlen * N) + xl;
-        ry_job[0] = (int)v.size();
-        stage_flat(v, nullptr, N, N16, oyy);
-        ry_job[1] = (int)v.size();
+        if (phase != 1) {
+            stage_flat(v, dinvQ, N, N16, o + ldq * N16);
+            ry_job[0] = (int)v.size();
+            stage_flat(v, nullptr, N, N16, oyy);
+            ry_job[1] = (int)v.size();
+        }
+        if (phase == 2) stage_flat(v, d_u, N, N16, opu);             // the summed u, parked where the partial sums live in the other phases
         // LinvB: whole 16-entry columns are written, the last piece may spill (zeros) into t, which is filled later
         stage_flat(v, LBall, (int)(xlen * N), (int)((xlen * N + 15) & ~15ll), oLB);
     }
+    // t of the first part: AFTER the LinvB pieces, whose last one may spill zeros over the first entries of t (same threads of the
+    // same wave write both, in job order)
+    if (phase == 2) stage_flat(v, d_t, (int)xlen, xl, ott);
     if (v.size() > (size_t)STAGE_MAX_JOBS) return false;
     std::memset(&jb, 0, sizeof(jb));
     for (size_t i = 0; i < v.size(); i++) jb.j[i] = v[i];
@@ -263,10 +272,11 @@ static inline bool solve_small2_jobs(StageJobs &jb, const CSolve *cs, int J, con
     return true;
 }
 
-template <int NJ>      // number of staging jobs processed (the table is padded with empty jobs up to it)
-__global__ __launch_bounds__(256) void k_solve_small2(const CSolve8 descs8, const StageJobs jobs, int J, const double *__restrict__ LQ, const double *__restrict__ dinvQ,
-                                                      int N, int xlen, const double *__restrict__ rhs_x, const double *__restrict__ rhs_y,
-                                                      const double *__restrict__ LBall, double *__restrict__ dx, double *__restrict__ dy) {
+// NJ: number of staging jobs processed (the table is padded with empty jobs up to it).  PH: 0 = the whole stage; 1 / 2 = the parts
+// before / after the exchange of u between the ranks of the cluster-sharded path (t_out, u_out: the context's d_t, d_u buffers).
+template <int NJ, int PH>
+__global__ __launch_bounds__(256) void k_solve_small2(const CSolve8 descs8, const StageJobs jobs, int J, int N, int xlen, double *__restrict__ dx, double *__restrict__ dy,
+                                                      double *__restrict__ t_out, double *__restrict__ u_out) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ int offA[8], offZ[8];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -288,29 +298,39 @@ __global__ __launch_bounds__(256) void k_solve_small2(const CSolve8 descs8, cons
     __syncthreads();
     SS2_STAMP(1);
     // ---- t_j = L_j^-1 rhs_x[j]: one wave per cluster, concurrently (src/solver.jl:1537-1540) ----
-    for (int j = wave; j < J; j += 4) {
-        const CSolve d = descs_lds[j];
-        const int P16 = (d.P + 15) & ~15, lda = P16 + 2;
-        double *A = lds + offA[j], *dv = A + lda * P16, *z = lds + offZ[j];
-        wave_trsv_fwd(A, lda, dv, z, P16, lane);
-        for (int i = lane; i < d.P; i += 64) tt[d.off + i] = z[i];
+    if (PH != 2) {
+        for (int j = wave; j < J; j += 4) {
+            const CSolve d = descs_lds[j];
+            const int P16 = (d.P + 15) & ~15, lda = P16 + 2;
+            double *A = lds + offA[j], *dv = A + lda * P16, *z = lds + offZ[j];
+            wave_trsv_fwd(A, lda, dv, z, P16, lane);
+            for (int i = lane; i < d.P; i += 64) {
+                tt[d.off + i] = z[i];
+                if (PH == 1) t_out[d.off + i] = z[i];
+            }
+        }
+        __syncthreads();
     }
-    __syncthreads();
     SS2_STAMP(2);
     if (N > 0) {
         // ---- u = LinvB^T t (src/solver.jl:1546), 8 partial sums per column in a fixed order; dy = Q^-1 (rhs_y - u) (:1550-1558) ----
-        for (int k0 = 0; k0 < N; k0 += 32) {
-            const int k = k0 + (tid >> 3), part = tid & 7;
-            double s = 0.0;
-            if (k < N)
-                for (int i = part; i < xlen; i += 8) s = __builtin_fma(LBs[i + (size_t)k * xlen], tt[i], s);
-            if (k < N) pu[k * 8 + part] = s;
+        if (PH != 2) {
+            for (int k0 = 0; k0 < N; k0 += 32) {
+                const int k = k0 + (tid >> 3), part = tid & 7;
+                double s = 0.0;
+                if (k < N)
+                    for (int i = part; i < xlen; i += 8) s = __builtin_fma(LBs[i + (size_t)k * xlen], tt[i], s);
+                if (k < N) pu[k * 8 + part] = s;
+            }
+            __syncthreads();
         }
-        __syncthreads();
         if (tid < N) {
             const double *p = pu + tid * 8;
-            yy[tid] -= ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+            const double usum = (PH == 2) ? pu[tid] : ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+            if (PH == 1) u_out[tid] = usum;                        // this rank's share of u: summed over the ranks by the caller
+            else yy[tid] -= usum;
         }
+        if (PH == 1) return;
         __syncthreads();
         SS2_STAMP(3);
         if (wave == 0) {
@@ -329,6 +349,7 @@ __global__ __launch_bounds__(256) void k_solve_small2(const CSolve8 descs8, cons
         __syncthreads();
     }
     SS2_STAMP(5);
+    if (PH == 1) return;
     // ---- dx_j = L_j^-T (...) (src/solver.jl:1570-1573) ----
     for (int j = wave; j < J; j += 4) {
         const CSolve d = descs_lds[j];
