@@ -124,6 +124,26 @@ struct Trsm16T<0> {
     static __device__ __forceinline__ void run(double &, double &, const double (&)[16], double) {}
 };
 
+// The same substitutions with ONE instruction per elimination: on the row-scaled system (m[k] = -L[row,k] / L[row,row], right-hand
+// side scaled by 1 / L[row,row]) a step is y += y_K m[K], and v_fmac_f64_dpp reads y_K from lane K of the 16-lane row inside the
+// multiply-add (row_newbcast is the one DPP control the 64-bit ALU has).  Two right-hand-side sets are interleaved; with the s_nop
+// an instruction reads a register written three issue slots earlier (a DPP read needs two wait states after the VALU write).
+// 15 steps x 2 chains: 230-250 cycles against the 470 of Trsm16 (scripts/micro/micro_dppchain.hip).
+#define CLRS_FMAC2(K) "v_fmac_f64_dpp %0, %0, %2 row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %1, %1, %2 row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
+__device__ __forceinline__ void trsm16_fmac_fwd(double &y0, double &y1, const double (&m)[16]) {
+#define CLRS_STEP(K, R) asm volatile("v_fmac_f64_dpp %0, %0, %2 row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %1, %1, %2 row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n\ts_nop 0" : "+v"(y0), "+v"(y1) : "v"(m[R]))
+    asm volatile("s_nop 1");
+    CLRS_STEP(0, 0); CLRS_STEP(1, 1); CLRS_STEP(2, 2); CLRS_STEP(3, 3); CLRS_STEP(4, 4); CLRS_STEP(5, 5); CLRS_STEP(6, 6); CLRS_STEP(7, 7);
+    CLRS_STEP(8, 8); CLRS_STEP(9, 9); CLRS_STEP(10, 10); CLRS_STEP(11, 11); CLRS_STEP(12, 12); CLRS_STEP(13, 13); CLRS_STEP(14, 14);
+}
+__device__ __forceinline__ void trsm16_fmac_bwd(double &y0, double &y1, const double (&m)[16]) {
+    asm volatile("s_nop 1");
+    CLRS_STEP(15, 15); CLRS_STEP(14, 14); CLRS_STEP(13, 13); CLRS_STEP(12, 12); CLRS_STEP(11, 11); CLRS_STEP(10, 10); CLRS_STEP(9, 9); CLRS_STEP(8, 8);
+    CLRS_STEP(7, 7); CLRS_STEP(6, 6); CLRS_STEP(5, 5); CLRS_STEP(4, 4); CLRS_STEP(3, 3); CLRS_STEP(2, 2); CLRS_STEP(1, 1);
+#undef CLRS_STEP
+}
+#undef CLRS_FMAC2
+
 // Z <- L^-1 Z (TRANS = false) or Z <- L^-T Z (TRANS = true), blocked by 16.
 //   L: lower triangular, ld ldl, ZERO above the diagonal and in rows/columns n..ceil16(n)-1;
 //   dinv[i] = 1 / L[i,i] for i < n, 0 for n <= i < ceil16(n);
@@ -137,21 +157,21 @@ __device__ __forceinline__ void lds_trsm(const double *L, int ldl, const double 
     for (int step = 0; step < npan; step++) {
         const int pb = TRANS ? npan - 1 - step : step;
         const int r0 = pb * 16, row = r0 + row16;
+        const double di = dinv[row];
         double Lr[16];
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const double v = TRANS ? L[(r0 + k) + row * ldl] : L[row + (r0 + k) * ldl];
-            Lr[k] = (k == row16) ? 0.0 : v;      // strictly triangular copy (L is zero on the other side already)
-        }
-        const double di = dinv[row];
+        for (int k = 0; k < 16; k++) Lr[k] = TRANS ? L[(r0 + k) + row * ldl] : L[row + (r0 + k) * ldl];
+#pragma unroll
+        for (int k = 0; k < 16; k++) Lr[k] = (k == row16) ? 0.0 : -(Lr[k] * di);      // strictly triangular (L is zero on the other side already), row scaled
         for (int g = wave; g < ngroups; g += 2 * nwaves) {   // two column groups per pass: independent chains interleave
             const int c0 = g * 4 + cg4, c1 = (g + nwaves) * 4 + cg4;
             const bool v0 = c0 < ncols, v1 = c1 < ncols;
-            double x0 = v0 ? Z[row * rs + c0 * cs] : 0.0, x1 = v1 ? Z[row * rs + c1 * cs] : 0.0;
-            if (TRANS) Trsm16T<15>::run(x0, x1, Lr, di);
-            else Trsm16<0>::run(x0, x1, Lr, di);
-            if (v0) Z[row * rs + c0 * cs] = x0 * di;
-            if (v1) Z[row * rs + c1 * cs] = x1 * di;
+            const double z0 = Z[row * rs + (v0 ? c0 : 0) * cs], z1 = Z[row * rs + (v1 ? c1 : 0) * cs];
+            double x0 = v0 ? z0 * di : 0.0, x1 = v1 ? z1 * di : 0.0;
+            if (TRANS) trsm16_fmac_bwd(x0, x1, Lr);
+            else trsm16_fmac_fwd(x0, x1, Lr);
+            if (v0) Z[row * rs + c0 * cs] = x0;
+            if (v1) Z[row * rs + c1 * cs] = x1;
         }
         if (step + 1 < npan) {
             __syncthreads();
@@ -258,12 +278,18 @@ struct PotrfScale16<16> {
 };
 // lower Cholesky of the 16 x 16 matrix whose row `row` the lane holds in a[] (entries above the diagonal ignored);
 // on return a[] is row `row` of L with zeros above the diagonal.
-__device__ __forceinline__ void potrf16(double (&a)[16], int row, int nvalid, bool &bad) {
+// rdiag receives 1 / L[row,row] (the reciprocal square root of the row's pivot: what the triangular solves need)
+__device__ __forceinline__ void potrf16(double (&a)[16], int row, int nvalid, bool &bad, double &rdiag) {
     double dgn = 1.0;
     Potrf16<0>::run(a, row, nvalid, bad, dgn);
     double d, rs;
     sqrt_rsqrt(dgn, d, rs);                              // every lane: 1 / sqrt of its own pivot
     PotrfScale16<0>::run(a, row, rs);
+    rdiag = rs;
+}
+__device__ __forceinline__ void potrf16(double (&a)[16], int row, int nvalid, bool &bad) {
+    double rdiag;
+    potrf16(a, row, nvalid, bad, rdiag);
 }
 
 // In-place lower Cholesky of the n x n matrix A in LDS (ld lda), blocked by 16.  Requirements: rows/columns
@@ -283,15 +309,12 @@ __device__ __forceinline__ bool lds_potrf(double *A, int lda, double *dinv, int 
 #pragma unroll
             for (int c = 1; c < 16; c++)
                 if (c > row16) a[c] = 0.0;
-            potrf16(a, row16, n - r0, bad);
+            double rdiag;
+            potrf16(a, row16, n - r0, bad, rdiag);
             if (cg4 == 0) {
 #pragma unroll
                 for (int c = 0; c < 16; c++) A[(r0 + row16) + (r0 + c) * lda] = a[c];
-                // a[row16] is the diagonal entry: select it without dynamic register indexing
-                double dg = a[0];
-#pragma unroll
-                for (int c = 1; c < 16; c++) dg = (row16 == c) ? a[c] : dg;
-                dinv[r0 + row16] = (r0 + row16 < n) ? 1.0 / dg : 0.0;   // one IEEE division per row, off the dependent chain
+                dinv[r0 + row16] = (r0 + row16 < n) ? rdiag : 0.0;      // 1 / L[i,i] = the reciprocal square root of the pivot, already at hand
             }
         }
         if (pb + 1 == npan) break;
@@ -300,19 +323,22 @@ __device__ __forceinline__ bool lds_potrf(double *A, int lda, double *dinv, int 
         // the 16 columns of the panel (stride lda), the right-hand sides are the panel rows (stride 1)
         {
             const int M = (npan - pb - 1) * 16;
+            const double di = dinv[r0 + row16];
             double Lr[16];
 #pragma unroll
-            for (int k = 0; k < 16; k++) Lr[k] = (k == row16) ? 0.0 : A[(r0 + row16) + (r0 + k) * lda];
-            const double di = dinv[r0 + row16];
+            for (int k = 0; k < 16; k++) Lr[k] = A[(r0 + row16) + (r0 + k) * lda];
+#pragma unroll
+            for (int k = 0; k < 16; k++) Lr[k] = (k == row16) ? 0.0 : -(Lr[k] * di);
             const int ngroups = M >> 2;
             for (int g = wave; g < ngroups; g += 2 * nwaves) {
                 const int c0 = g * 4 + cg4, c1 = (g + nwaves) * 4 + cg4;
                 const bool v1 = c1 < M;
-                double *p0 = A + (r0 + 16 + c0) + (r0 + row16) * lda, *p1 = A + (r0 + 16 + c1) + (r0 + row16) * lda;
-                double x0 = *p0, x1 = v1 ? *p1 : 0.0;
-                Trsm16<0>::run(x0, x1, Lr, di);
-                *p0 = x0 * di;
-                if (v1) *p1 = x1 * di;
+                double *p0 = A + (r0 + 16 + c0) + (r0 + row16) * lda, *p1 = A + (r0 + 16 + (v1 ? c1 : c0)) + (r0 + row16) * lda;
+                const double z1 = *p1;
+                double x0 = *p0 * di, x1 = v1 ? z1 * di : 0.0;
+                trsm16_fmac_fwd(x0, x1, Lr);
+                *p0 = x0;
+                if (v1) *p1 = x1;
             }
         }
         __syncthreads();
