@@ -102,25 +102,51 @@ __global__ __launch_bounds__(256) void k_cluster_assemble(const FCluster *__rest
             const int UR = k.URt, UL = k.ULt, ldg = k.ldg;
             const int n4 = (n + 3) & ~3, UR16 = (UR + 15) & ~15, UL16 = (UL + 15) & ~15, n16 = (n + 15) & ~15;
             // ---- stage L (lower), Y, V [, W] zero padded; term tables ----
-            for (int e = tid; e < n16 * ldn; e += 256) {
-                const int i = e % ldn, j = e / ldn;
-                const bool in = i < n && j < n;
-                Ys[e] = in ? Yg[i + (long long)j * n] : 0.0;
-                Ls[e] = (in && i >= j) ? Lg[i + (long long)j * n] : 0.0;
-            }
-            const double *Vg = tb.stat + k.v_off;
-            for (int e = tid; e < UR16 * ldn; e += 256) {
-                const int i = e % ldn, j = e / ldn;
-                Vs[e] = (i < n && j < UR) ? Vg[i + (long long)j * n] : 0.0;
-                TYs[e] = 0.0;   // the padding rows / columns of T_Y are read by the next contraction
-            }
-            if (!k.sym) {
-                const double *Wg = tb.stat + k.w_off;
-                for (int e = tid; e < UL16 * ldn; e += 256) {
-                    const int i = e % ldn, j = e / ldn;
-                    ZLs[e] = (i < n && j < UL) ? Wg[i + (long long)j * n] : 0.0;
+            // Loads in batches of eight per thread, all of a batch issued (clamped address, select after the load) before the first
+            // store: a matrix is one trip to memory, not one per 256 entries (a select around a load is a branch)
+            for (int e0 = 0; e0 < n16 * ldn; e0 += 4 * 256) {
+                double vy[4], vl[4];
+                bool in[4], lo[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int e = e0 + u * 256 + tid, i = e % ldn, j = e / ldn;
+                    in[u] = e < n16 * ldn && i < n && j < n;
+                    lo[u] = in[u] && i >= j;
+                    const long long g = in[u] ? i + (long long)j * n : 0;
+                    vy[u] = Yg[g];
+                    vl[u] = Lg[g];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int e = e0 + u * 256 + tid;
+                    if (e < n16 * ldn) {
+                        Ys[e] = in[u] ? vy[u] : 0.0;
+                        Ls[e] = lo[u] ? vl[u] : 0.0;
+                    }
                 }
             }
+            auto stage_vectors = [&](double *dst, const double *src, int U, int U16, bool zero_ty) {
+                for (int e0 = 0; e0 < U16 * ldn; e0 += 8 * 256) {
+                    double vv[8];
+                    bool in[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const int e = e0 + u * 256 + tid, i = e % ldn, j = e / ldn;
+                        in[u] = e < U16 * ldn && i < n && j < U;
+                        vv[u] = src[in[u] ? i + (long long)j * n : 0];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const int e = e0 + u * 256 + tid;
+                        if (e < U16 * ldn) {
+                            dst[e] = in[u] ? vv[u] : 0.0;
+                            if (zero_ty) TYs[e] = 0.0;   // the padding rows / columns of T_Y are read by the next contraction
+                        }
+                    }
+                }
+            };
+            stage_vectors(Vs, tb.stat + k.v_off, UR, UR16, true);
+            if (!k.sym) stage_vectors(ZLs, tb.stat + k.w_off, UL, UL16, false);
             int *tp = tab, *sL = tab + (P + 1), *sR = sL + k.T;
             double *slam = (double *)(tab + ((P + 1 + 2 * k.T + 1) & ~1));
             for (int e = tid; e <= P; e += 256) tp[e] = k.tptr[e] - (int)k.t0;

@@ -104,23 +104,35 @@ __device__ __forceinline__ double block_reduce_max(double v, double *red) {
     return fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
 }
 
-// load an n x n block (ld n in memory) into LDS (ld lda), zero padded to n16 x n16
-__device__ __forceinline__ void ipm_load(double *A, int lda, const double *G, int n, int n16, int tid) {
-    const int i16 = tid & 15, j16 = tid >> 4;
-    for (int j0 = 0; j0 < n16; j0 += 16)
-        for (int i0 = 0; i0 < n16; i0 += 16) {
-            const int i = i0 + i16, j = j0 + j16;
-            A[i + j * lda] = (i < n && j < n) ? G[i + (long long)j * n] : 0.0;
+// load an n x n block (ld n in memory) into LDS (ld lda), zero padded to n16 x n16.  Eight 16 x 16 tiles per batch, every load of a
+// batch issued (from a clamped address, the select after the load) before any of them is stored: a block of the named configurations
+// is one trip to memory instead of one per tile (a select AROUND a load is a branch, and each tile then waits for its own trip).
+template <bool LOWER>
+__device__ __forceinline__ void ipm_load_tiles(double *A, int lda, const double *G, int n, int n16, int tid) {
+    const int i16 = tid & 15, j16 = tid >> 4, nt = n16 >> 4;
+    for (int tj0 = 0; tj0 < nt; tj0 += 2)
+        for (int ti0 = 0; ti0 < nt; ti0 += 4) {
+            double v[8];
+            bool in[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const int ti = ti0 + (e & 3), tj = tj0 + (e >> 2);
+                const int i = ti * 16 + i16, j = tj * 16 + j16;
+                in[e] = ti < nt && tj < nt && i < n && j < n && (!LOWER || i >= j);
+                v[e] = G[in[e] ? i + (long long)j * n : 0];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const int ti = ti0 + (e & 3), tj = tj0 + (e >> 2);
+                if (ti < nt && tj < nt) A[(ti * 16 + i16) + (tj * 16 + j16) * lda] = in[e] ? v[e] : 0.0;
+            }
         }
 }
+__device__ __forceinline__ void ipm_load(double *A, int lda, const double *G, int n, int n16, int tid) { ipm_load_tiles<false>(A, lda, G, n, n16, tid); }
 __device__ __forceinline__ void ipm_load_chol(double *A, int lda, double *dinv, const double *G, int n, int n16, int tid) {
-    const int i16 = tid & 15, j16 = tid >> 4;
-    for (int j0 = 0; j0 < n16; j0 += 16)
-        for (int i0 = 0; i0 < n16; i0 += 16) {
-            const int i = i0 + i16, j = j0 + j16;
-            A[i + j * lda] = (i < n && j < n && i >= j) ? G[i + (long long)j * n] : 0.0;
-        }
-    if (tid < n16) dinv[tid] = (tid < n) ? 1.0 / G[tid + (long long)tid * n] : 0.0;
+    const double dg = G[(tid < n) ? tid + (long long)tid * n : 0];          // in flight with the tiles
+    ipm_load_tiles<true>(A, lda, G, n, n16, tid);
+    if (tid < n16) dinv[tid] = (tid < n) ? 1.0 / dg : 0.0;
 }
 // M <- (L L^T)^-1 M for an n x n matrix in LDS (columns as right-hand sides); all 256 threads
 __device__ __forceinline__ void ipm_potrs(const double *L, int lda, const double *dinv, double *M, int n, int wave, int lane) {
