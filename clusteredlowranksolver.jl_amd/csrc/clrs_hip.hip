@@ -28,6 +28,7 @@
 #include "clrs_fused.hip.h"
 #include "clrs_assemble_w3.hip.h"
 #include "clrs_solve_small.hip.h"
+#include "clrs_factor_small.hip.h"
 #include "clrs_ipm.hip.h"
 
 using namespace clrs;
@@ -54,16 +55,17 @@ static int g_cfg_wave_assemble = 1;
 static int g_cfg_wave2_assemble = 1;
 static int g_cfg_wave3_assemble = 1;   // register-resident form of the cluster-per-wave assembly (U <= 32); 0: k_cluster_assemble_w2
 static int g_cfg_dense_block = 1;
+static int g_cfg_factor_small = 1;      // factor + Q in one launch of one workgroup for <= 4 small clusters (0: k_cluster_factor + k_small_potrf)
 static int g_cfg_solve_small2 = 1;     // one-workgroup solve stage with all loads up front and single-wave triangular solves (0: k_solve_small)
 static const int LDS_BUDGET_DOUBLES = 20000;   // of the 20480 doubles (160 KiB) a workgroup may claim
 
 // ------------------------------------------------------------------------------------------------
 // launch plan
 // ------------------------------------------------------------------------------------------------
-enum StepKind { STEP_MEMCPY, STEP_GEMM, STEP_TRSM, STEP_POTRF, STEP_GATHER_S, STEP_GATHER_SCALAR, STEP_SUB, STEP_MEMSET_INFO, STEP_ZERO_UPPER, STEP_FUSED_ASSEMBLE, STEP_SMALL_POTRF, STEP_CLUSTER_FACTOR, STEP_GEMV_T, STEP_CSOLVE_FWD, STEP_Q_SOLVE, STEP_CSOLVE_BWD, STEP_SUM_SLABS, STEP_ASSEMBLE_W1, STEP_GRAM_SMALL, STEP_ASSEMBLE_W2, STEP_SOLVE_SMALL, STEP_DENSE_BLOCK, STEP_ASSEMBLE_W3, STEP_NKINDS };
+enum StepKind { STEP_MEMCPY, STEP_GEMM, STEP_TRSM, STEP_POTRF, STEP_GATHER_S, STEP_GATHER_SCALAR, STEP_SUB, STEP_MEMSET_INFO, STEP_ZERO_UPPER, STEP_FUSED_ASSEMBLE, STEP_SMALL_POTRF, STEP_CLUSTER_FACTOR, STEP_GEMV_T, STEP_CSOLVE_FWD, STEP_Q_SOLVE, STEP_CSOLVE_BWD, STEP_SUM_SLABS, STEP_ASSEMBLE_W1, STEP_GRAM_SMALL, STEP_ASSEMBLE_W2, STEP_SOLVE_SMALL, STEP_DENSE_BLOCK, STEP_ASSEMBLE_W3, STEP_FACTOR_SMALL, STEP_NKINDS };
 static const char *const STEP_NAMES[STEP_NKINDS] = {"hipMemcpyAsync(D2D)", "k_gemm_f64_t", "k_trsm_diag", "k_potrf_diag", "k_schur_gather",
                                                     "k_gather_scalar", "k_sub", "hipMemsetAsync", "k_zero_upper", "k_cluster_assemble", "k_small_potrf", "k_cluster_factor", "k_gemv_t",
-                                                    "k_cluster_solve_fwd", "k_q_solve", "k_cluster_solve_bwd", "k_sum_slabs", "k_cluster_assemble_w1", "k_gram_small", "k_cluster_assemble_w2", "k_solve_small", "k_dense_block", "k_cluster_assemble_w3"};
+                                                    "k_cluster_solve_fwd", "k_q_solve", "k_cluster_solve_bwd", "k_sum_slabs", "k_cluster_assemble_w1", "k_gram_small", "k_cluster_assemble_w2", "k_solve_small", "k_dense_block", "k_cluster_assemble_w3", "k_factor_small"};
 static const int KT_MAX_EVENTS = 8192;   // event pairs kept between two clrs_get_kernel_times calls
 
 struct Step {
@@ -159,6 +161,9 @@ struct clrs_ctx {
         bool ok = false;
     } ss2[3];
     Plan p_fwd_small, p_bwd_small;     // one-launch forms of p_fwd / p_bwd (k_solve_small2, phases 1 and 2)
+    Plan p_factor_small;               // k_factor_small: the whole of clrs_schur_factor in one launch
+    FSmallArgs fsmall = {};
+    StageJobs fsmall_jobs = {};
     // caller-provided device pointers of the current call, read by the fused kernels at launch (no staging copies)
     const double *bind_X = nullptr, *bind_rhsx = nullptr, *bind_rhsy = nullptr;
     double *bind_Xchol = nullptr, *bind_dx = nullptr, *bind_dy = nullptr;
@@ -439,6 +444,16 @@ static int run_steps(clrs_ctx *c, const Plan &pl) {
                     hipLaunchKernelGGL((k_cluster_assemble_w2<2, false>), dim3((ncl + 3) / 4), dim3(256), s.bytes, st, (const W2Cluster *)s.d0, (const W2Block *)s.d1, *tb, ncl);
                 else
                     hipLaunchKernelGGL((k_cluster_assemble_w2<4, false>), dim3((ncl + 3) / 4), dim3(256), s.bytes, st, (const W2Cluster *)s.d0, (const W2Block *)s.d1, *tb, ncl);
+                break;
+            }
+            case STEP_FACTOR_SMALL: {
+#define CLRS_FS(NJ) hipLaunchKernelGGL(k_factor_small<NJ>, dim3(1), dim3(256), s.bytes, st, c->fsmall, c->fsmall_jobs, c->d_info)
+                if (c->fsmall_jobs.n <= 8) CLRS_FS(8);
+                else if (c->fsmall_jobs.n <= 16) CLRS_FS(16);
+                else if (c->fsmall_jobs.n <= 24) CLRS_FS(24);
+                else if (c->fsmall_jobs.n <= 32) CLRS_FS(32);
+                else CLRS_FS(48);
+#undef CLRS_FS
                 break;
             }
             case STEP_ASSEMBLE_W3: {
@@ -1345,6 +1360,37 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
             }
         }
     }
+    // ONE small cluster: the whole factorisation stage in one launch of one workgroup (measured: 1.6-1.9 us per step saved on
+    // polyopt 2d = 40 and delsarte(3,10)).  "factor_small" = 2 also takes 2-4 clusters, one wave per cluster -- slower than
+    // k_cluster_factor + k_small_potrf on cohnelkies(8,15) (23.4 us against 12.4 + 8.0): a single wave per 32 x 32 cluster is
+    // latency bound on its own dependent chains, the workgroup-per-cluster kernels overlap four waves on them.
+    if (g_cfg_factor_small && c->fused_fs && c->fused_q && N > 0 && (J == 1 || (g_cfg_factor_small == 2 && J <= 4)) && !c->p_cholQ_slabs.steps.empty()) {
+        bool ok = N <= 64;
+        for (int j = 0; j < J; j++) ok = ok && c->P[j] <= 64;
+        const size_t need = factor_small_lds_doubles(c->P.data(), J, N) * sizeof(double);
+        ok = ok && need <= 150 * 1024;
+        if (ok) {
+            std::memset(&c->fsmall, 0, sizeof(c->fsmall));
+            const double *Ssrc[4], *Bsrc[4];
+            for (int j = 0; j < J; j++) {
+                c->fsmall.c[j].S = c->d_S + c->Soff[j]; c->fsmall.c[j].LB = c->d_LB + c->coff[j]; c->fsmall.c[j].dinv = c->d_dinvS + c->coff[j];
+                c->fsmall.c[j].P = c->P[j]; c->fsmall.c[j].code = j + 1;
+                Ssrc[j] = c->d_S + c->Soff[j]; Bsrc[j] = c->d_B + c->coff[j];
+            }
+            c->fsmall.Q = c->d_Q; c->fsmall.dinvQ = c->d_dinvQ; c->fsmall.J = J; c->fsmall.N = N; c->fsmall.ldb = (int)c->xlen; c->fsmall.codeQ = J + 1;
+            ok = factor_small_jobs(c->fsmall_jobs, c->fsmall, Ssrc, Bsrc);
+        }
+        if (ok) {
+            Step s;
+            s.kind = STEP_FACTOR_SMALL; s.bytes = need;
+            c->p_factor_small.steps.push_back(s);
+            if (need > 64 * 1024) {
+#define CLRS_FS_ATTR(NJ) HIPCK(hipFuncSetAttribute((const void *)k_factor_small<NJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
+                CLRS_FS_ATTR(8) CLRS_FS_ATTR(16) CLRS_FS_ATTR(24) CLRS_FS_ATTR(32) CLRS_FS_ATTR(48)
+#undef CLRS_FS_ATTR
+            }
+        }
+    }
     // =============================================================================================
     // plan: solve (src/solver.jl:1527-1582)
     // =============================================================================================
@@ -1528,7 +1574,7 @@ extern "C" void clrs_ctx_destroy(clrs_ctx *c) {
     ipm_free(c);
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
-    Plan *plans[] = {&c->p_assemble, &c->p_cholS, &c->p_linvB, &c->p_Q, &c->p_cholQ, &c->p_fwd, &c->p_bwd, &c->p_cholX, &c->p_cholQ_slabs, &c->p_solve_all, &c->p_fwd_small, &c->p_bwd_small};
+    Plan *plans[] = {&c->p_assemble, &c->p_cholS, &c->p_linvB, &c->p_Q, &c->p_cholQ, &c->p_fwd, &c->p_bwd, &c->p_cholX, &c->p_cholQ_slabs, &c->p_solve_all, &c->p_fwd_small, &c->p_bwd_small, &c->p_factor_small};
     for (Plan *p : plans)
         if (p->graph) hipGraphExecDestroy(p->graph);
     for (void *p : c->allocs) hipFree(p);
@@ -1667,9 +1713,14 @@ extern "C" int clrs_schur_factor_dev(clrs_ctx *c) {
     HIPCHECK(hipSetDevice(c->device));
     int rc;
     if (c->timing) HIPCHECK(hipEventRecord(c->ev[2], c->stream));
+    if (!c->p_factor_small.steps.empty()) {                           // everything in one launch (k_factor_small)
+        if ((rc = run_plan(c, c->p_factor_small))) return rc;
+        if (c->timing) { HIPCHECK(hipEventRecord(c->ev[3], c->stream)); HIPCHECK(hipEventRecord(c->ev[4], c->stream)); HIPCHECK(hipEventRecord(c->ev[5], c->stream)); }
+    } else {
     if ((rc = run_plan(c, c->p_cholS))) return rc;                    // chol S_j, LinvB_j and the Q slabs: one launch
     if (c->timing) { HIPCHECK(hipEventRecord(c->ev[3], c->stream)); HIPCHECK(hipEventRecord(c->ev[4], c->stream)); HIPCHECK(hipEventRecord(c->ev[5], c->stream)); }
     if ((rc = run_plan(c, c->p_cholQ_slabs))) return rc;              // Q = sum of slabs, chol Q: one launch
+    }
     if (c->timing) { HIPCHECK(hipEventRecord(c->ev[6], c->stream)); c->times_pending = true; }
     c->assembled = false;
     c->factored = true;
@@ -1850,7 +1901,7 @@ extern "C" int clrs_set_stream(clrs_ctx *c, void *stream) {
     if (!c) return fail(CLRS_ERR_INVALID, "null argument");
     HIPCHECK(hipSetDevice(c->device));
     HIPCHECK(hipStreamSynchronize(c->stream));
-    Plan *plans[] = {&c->p_assemble, &c->p_cholS, &c->p_linvB, &c->p_Q, &c->p_cholQ, &c->p_fwd, &c->p_bwd, &c->p_cholX, &c->p_cholQ_slabs, &c->p_solve_all, &c->p_fwd_small, &c->p_bwd_small};
+    Plan *plans[] = {&c->p_assemble, &c->p_cholS, &c->p_linvB, &c->p_Q, &c->p_cholQ, &c->p_fwd, &c->p_bwd, &c->p_cholX, &c->p_cholQ_slabs, &c->p_solve_all, &c->p_fwd_small, &c->p_bwd_small, &c->p_factor_small};
     for (Plan *p : plans)
         if (p->graph) { hipGraphExecDestroy(p->graph); p->graph = nullptr; }   // graphs are re-captured on the new stream
     if (c->own_stream) HIPCHECK(hipStreamDestroy(c->stream));
@@ -1899,6 +1950,7 @@ extern "C" int clrs_config_set(const char *key, int value) {
     if (!std::strcmp(key, "wave3_assemble")) { g_cfg_wave3_assemble = value; return 0; }
     if (!std::strcmp(key, "dense_block")) { g_cfg_dense_block = value; return 0; }
     if (!std::strcmp(key, "solve_small2")) { g_cfg_solve_small2 = value; return 0; }
+    if (!std::strcmp(key, "factor_small")) { g_cfg_factor_small = value; return 0; }
     return fail(CLRS_ERR_INVALID, std::string("unknown configuration key ") + key);
 }
 

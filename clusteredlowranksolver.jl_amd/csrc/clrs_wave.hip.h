@@ -30,6 +30,13 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+// The blocked routines below synchronise the waves that share a matrix: the whole workgroup (WG = true, __syncthreads), or -- when ONE
+// wave runs the routine on its own matrix (wave = 0, nwaves = 1) -- only the compiler's ordering of that wave's LDS accesses.
+template <bool WG>
+__device__ __forceinline__ void lds_sync() {
+    if (WG) __syncthreads();
+    else wave_sync();
+}
 // Sum over the 64 lanes, the same value (bitwise) in every lane.  DPP row shifts inside the 16-lane rows (lanes shifted in
 // from outside a row read 0), then the four row totals through v_readlane: ~25 short instructions.  (__shfl_xor on a
 // double lowers to two ds_bpermute per step: ~700 cycles for the same reduction.)
@@ -149,7 +156,7 @@ __device__ __forceinline__ void trsm16_fmac_bwd(double &y0, double &y1, const do
 //   dinv[i] = 1 / L[i,i] for i < n, 0 for n <= i < ceil16(n);
 //   Z element (row, col) at Z[row * rs + col * cs]; rows n..ceil16(n)-1 must be readable (any finite value) and are
 //   only written with values that do not matter.  Must be called by all `nwaves` waves of the workgroup (barriers).
-template <bool TRANS>
+template <bool TRANS, bool WG = true>
 __device__ __forceinline__ void lds_trsm(const double *L, int ldl, const double *dinv, double *Z, int rs, int cs, int n, int ncols, int wave,
                                          int nwaves, int lane) {
     const int npan = (n + 15) >> 4, row16 = lane & 15, cg4 = lane >> 4;
@@ -174,7 +181,7 @@ __device__ __forceinline__ void lds_trsm(const double *L, int ldl, const double 
             if (v1) Z[row * rs + c1 * cs] = x1;
         }
         if (step + 1 < npan) {
-            __syncthreads();
+            lds_sync<WG>();
             // remaining panels:  Z[i-panel, :] -= op(L)[i-panel, r0:r0+16] Z[r0:r0+16, :]   (MFMA, 16 x 16 tiles)
             const int tm = npan - step - 1, tn = (ncols + 15) >> 4;
             int ti = wave, tj = 0;
@@ -197,7 +204,7 @@ __device__ __forceinline__ void lds_trsm(const double *L, int ldl, const double 
                 ti += nwaves;
                 while (ti >= tm) { ti -= tm; tj++; }
             }
-            __syncthreads();
+            lds_sync<WG>();
         }
     }
 }
@@ -297,6 +304,7 @@ __device__ __forceinline__ void potrf16(double (&a)[16], int row, int nvalid, bo
 // triangle holds L, the diagonal blocks have zeros above the diagonal; the strictly upper off-diagonal blocks are
 // NOT touched (callers mask them when storing).  dinv (ceil16(n) doubles of LDS) receives 1 / L[i,i] (0 for i >= n).
 // Returns true in every thread of wave 0 .. (callers reduce) if a pivot was not positive.  All waves must call.
+template <bool WG = true>
 __device__ __forceinline__ bool lds_potrf(double *A, int lda, double *dinv, int n, int wave, int nwaves, int lane) {
     const int npan = (n + 15) >> 4, row16 = lane & 15, cg4 = lane >> 4;
     bool bad = false;
@@ -318,7 +326,7 @@ __device__ __forceinline__ bool lds_potrf(double *A, int lda, double *dinv, int 
             }
         }
         if (pb + 1 == npan) break;
-        __syncthreads();
+        lds_sync<WG>();
         // panel: rows below the diagonal block, X L_kk^T = A_panel  <=>  L_kk X^T = A_panel^T: the unknown index runs along
         // the 16 columns of the panel (stride lda), the right-hand sides are the panel rows (stride 1)
         {
@@ -341,7 +349,7 @@ __device__ __forceinline__ bool lds_potrf(double *A, int lda, double *dinv, int 
                 if (v1) *p1 = x1;
             }
         }
-        __syncthreads();
+        lds_sync<WG>();
         // trailing update (lower tiles): A[i-blk, j-blk] -= Lp_i Lp_j^T
         {
             const int tm = npan - pb - 1;
@@ -361,7 +369,7 @@ __device__ __forceinline__ bool lds_potrf(double *A, int lda, double *dinv, int 
                 for (int reg = 0; reg < 4; reg++) A[(i0 + row16) + (j0 + cg4 + 4 * reg) * lda] -= acc[reg];
             }
         }
-        __syncthreads();
+        lds_sync<WG>();
     }
     return bad;
 }

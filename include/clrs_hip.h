@@ -222,7 +222,10 @@ int clrs_wave_clusters(const clrs_ctx *ctx);
  * (U <= 64, or "wave3_assemble" = 0) it is the LDS-staged k_cluster_assemble_w2 and "automatic" means >= 64 clusters.
  * clrs_wave2_clusters counts the clusters either kernel takes. */
 int clrs_wave2_clusters(const clrs_ctx *ctx);
-/* "solve_small2" (default 1): contexts with <= 8 clusters whose factors fit in 150 KB of LDS run the solve stage as ONE launch
+/* "factor_small" (default 1): a context with ONE cluster (P, N <= 64) runs clrs_schur_factor as one launch of k_factor_small
+ * (S_j and B_j staged in one trip, Q never leaves LDS before it is factored); 2 = also for 2-4 clusters, one wave per cluster
+ * (slower than the workgroup-per-cluster kernels on the named problems: kept for measurement); 0 = never.
+ * "solve_small2" (default 1): contexts with <= 8 clusters whose factors fit in 150 KB of LDS run the solve stage as ONE launch
  * of k_solve_small2 (every operand staged in one trip to memory, one wave per triangular solve); 0 keeps k_solve_small. */
 /* Diagnostic builds (-DCLRS_FUSED_STAMPS) only: s_memtime stamps of the phases of workgroup 0 of the fused kernel. */
 int clrs_debug_stamps(clrs_ctx *ctx, uint64_t out[64]);

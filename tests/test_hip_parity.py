@@ -199,7 +199,8 @@ FACTOR_CASES = ["x2p1", "polyopt8", "polyopt40", "delsarte_3_10", "delsarte_8_3"
                 "polyopt_scaled_100"]
 
 
-@pytest.mark.parametrize("fused", [True, "k_solve_small", False], ids=["fused", "fused_k_solve_small", "staged"])
+@pytest.mark.parametrize("fused", [True, "k_solve_small", "k_factor_small_waves", False],
+                         ids=["fused", "fused_k_solve_small", "fused_k_factor_small_wave_per_cluster", "staged"])
 @pytest.mark.parametrize("name", FACTOR_CASES)
 def test_factor_and_solve_match_oracle(name, fused, oracle_built):
     from clrs_amd.solver import SchurContext, compute_T_decomposition, solve_system
@@ -207,7 +208,8 @@ def test_factor_and_solve_match_oracle(name, fused, oracle_built):
     f = flat(name)
     X, Y = spd_iterates(f, seed=2)
     Xc = chol_blocks_np(f, X)
-    ctx = SchurContext(f, fused=bool(fused), solve_small2=(False if fused == "k_solve_small" else None))
+    ctx = SchurContext(f, fused=bool(fused), solve_small2=(False if fused == "k_solve_small" else None),
+                       factor_small=(2 if fused == "k_factor_small_waves" else None))
     _, S, _ = compute_T_decomposition(ctx, Xc, Y, want_S=True)
     L, LinvB, LQ = ctx.get_factor()
     o = Oracle(f, quad=False)
