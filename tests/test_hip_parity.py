@@ -179,6 +179,44 @@ def test_cluster_per_wave_assembly_rare_paths(name, copies, oracle_built):
         assert np.array_equal(Sj, Sj.T)
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_random_simple_structures(seed, oracle_built):
+    """Randomised structure for the general (partial-tile) paths of the wave kernels: clusters of different sizes P <= 32 in one
+    context, 1-3 low-rank blocks of different sides n <= 16 per cluster, 0-2 dense 1 x 1 blocks touching a subset of the constraints,
+    placed anywhere among them; a few free variables.  Assembly against the oracle on every wave path, then factor + solve."""
+    import clrs_amd
+    from clrs_amd.solver import SchurContext, compute_T_decomposition, solve_system
+    from oracle.oracle import Oracle
+    from tests.util import random_simple_sdp
+    f = clrs_amd.flatten(random_simple_sdp(seed, J=3 + seed % 3, n_free=seed % 4, definite=True))
+    X, Y = spd_iterates(f, seed=seed + 100)
+    Xc = chol_blocks_np(f, X)
+    o = Oracle(f, quad=False)
+    S_ref, AY_ref = o.schur_assemble(Xc, Y)
+    for kw in (dict(wave2=True, wave3=True), dict(wave2=True, wave3=False), dict(wave2=False), dict(wave=False)):
+        ctx = SchurContext(f, **kw)
+        if "wave3" in kw:
+            assert ctx.wave2_clusters() == f.n_clusters
+        S, AY = ctx.compute_S_integrated(Xc, Y)
+        for j in range(f.n_clusters):
+            sl = slice(int(f.S_off[j]), int(f.S_off[j + 1]))
+            assert np.max(np.abs(S[sl] - S_ref[sl])) <= 1e-11 * np.max(np.abs(S_ref[sl])), (kw, j)
+        assert np.max(np.abs(AY - AY_ref)) <= 1e-11 * max(1.0, np.max(np.abs(AY_ref))), kw
+        ctx.close()
+    assert o.schur_factor() == 0
+    rng = np.random.default_rng(seed)
+    rx, ry = rng.standard_normal(f.x_len), rng.standard_normal(f.n_free)
+    dx_ref, dy_ref = o.schur_solve(rx, ry)
+    for kw in (dict(), dict(solve_small2=False), dict(factor_small=2)):
+        ctx = SchurContext(f, **kw)
+        compute_T_decomposition(ctx, Xc, Y)
+        dx, dy = solve_system(ctx, rx, ry)
+        assert np.max(np.abs(dx - dx_ref)) <= 1e-7 * max(1.0, np.max(np.abs(dx_ref))), kw
+        if f.n_free:
+            assert np.max(np.abs(dy - dy_ref)) <= 1e-7 * max(1.0, np.max(np.abs(dy_ref))), kw
+        ctx.close()
+
+
 def test_dedup_counts_match_oracle(oracle_built):
     from clrs_amd.solver import SchurContext
     from oracle.oracle import Oracle

@@ -145,3 +145,38 @@ def duplicate_block(f, b, scale=0.5):
         setattr(g, name, np.concatenate([a[:x1], a[x0:x1], a[x1:]]))
     g.block_off = np.concatenate([[0], np.cumsum(g.block_n.astype(np.int64) ** 2)]).astype(np.int64)
     return g
+
+
+def random_simple_sdp(seed, J=5, n_free=3, max_P=32, max_n=16, definite=False):
+    """A random SDP of the shapes the cluster-per-wave assembly takes: per cluster P_j constraints, 1-3 low-rank blocks of side
+    n <= 16 with ONE rank-1 symmetric term per constraint (distinct vectors, the same constraint order in every block) and 0-2 dense
+    1 x 1 blocks that touch a random subset of the constraints; mixed sizes within one context.  `definite`: the first block of every
+    cluster has side >= 9 (45 independent pairings >= P), so that S_j is positive definite at generic iterates."""
+    from clrs_amd.sdp import Block, ClusteredLowRankSDP, HiLo, LowRankMat
+    rng = np.random.default_rng(seed)
+    blocks, B, c, C = [], [], [], []
+    for j in range(J):
+        P = int(rng.integers(1, max_P + 1))
+        cl, Cl = [], []
+        for bi in range(int(rng.integers(1, 4))):
+            n = int(rng.integers(1, max_n + 1))
+            if definite and bi == 0:
+                n = max(n, 9)
+            V = rng.standard_normal((P, n))
+            lam = rng.uniform(0.5, 1.5, P) * rng.choice([-1.0, 1.0], P)
+            ent = {(0, 0): {p: LowRankMat(np.array([lam[p]]), V[p:p + 1, :], V[p:p + 1, :]) for p in range(P)}}
+            cl.append(Block(m=1, delta=n, entries=ent, name="lr"))
+            Cl.append(np.zeros((n, n)))
+        for _ in range(int(rng.integers(0, 3))):
+            ps = [p for p in range(P) if rng.random() < 0.6] or [0]
+            ent = {(0, 0): {p: HiLo.of(rng.standard_normal((1, 1))) for p in ps}}
+            cl.append(Block(m=1, delta=1, entries=ent, name="dense"))
+            Cl.append(np.zeros((1, 1)))
+        order = rng.permutation(len(cl))          # dense blocks anywhere among the low-rank ones
+        blocks.append([cl[i] for i in order])
+        C.append([Cl[i] for i in order])
+        B.append(rng.standard_normal((P, n_free)))
+        c.append(rng.standard_normal(P))
+    sdp = ClusteredLowRankSDP(maximize=True, constant=0.0, blocks=blocks, B=B, c=c, C=C, b=rng.standard_normal(n_free), names={})
+    sdp.check()
+    return sdp
