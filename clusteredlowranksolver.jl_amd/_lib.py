@@ -130,9 +130,8 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str =
         if r.returncode != 0:
             raise RuntimeError("hipcc failed:\n" + r.stderr[-4000:])
         return out
-    src = [os.path.join(CSRC, f) for f in ("clrs_hip.hip", "clrs_kernels.hip.h")] + \
-          [os.path.join(CSRC, "clrs_fused.hip.h"), os.path.join(CSRC, "clrs_wave.hip.h"), os.path.join(CSRC, "clrs_ipm.hip.h"),
-           os.path.join(CSRC, "clrs_ipm_host.inc"), os.path.join(_HERE, "..", "include", "clrs_hip.h")]
+    src = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hip.h", ".inc"))] + \
+          [os.path.join(_HERE, "..", "include", "clrs_hip.h")]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in src):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
