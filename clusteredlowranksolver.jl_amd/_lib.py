@@ -153,6 +153,8 @@ def load(path: str = None):
     `path` (before the first load) selects a diagnostic build of the same library."""
     global _lib, LIB_PATH
     if _lib is None:
+        if path is None:
+            path = os.environ.get("CLRS_HIP_LIB") or None      # a diagnostic / experimental build of the same library
         if path is not None:
             LIB_PATH = path
         if not os.path.exists(LIB_PATH):

@@ -149,12 +149,12 @@ __global__ __launch_bounds__(256, 2) void k_cluster_assemble_w3(const int *__res
                                                                 const W3Tables tb, int nclusters, int nblocks) {
     constexpr int LD = 18;                                       // doubles per row of the staged L: conflict-free ds_read_b128
     constexpr int LDS_S = 34;                                    // leading dimension of the staged S_j (even: 16-byte aligned pairs)
-    constexpr int PER_WAVE = 16 * LD + 16 + 32 * LDS_S;          // L rows | diagonal of L | S_j
+    constexpr int PER_WAVE = 16 * LD + 16 + 32 + 32 * LDS_S;     // L rows | diagonal of L | A_Y of the block | S_j
     __shared__ __attribute__((aligned(16))) double lds_all[4 * PER_WAVE];
     const int lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
-    double *Lt = lds_all + wave * PER_WAVE, *Ld = Lt + 16 * LD, *Ss = Ld + 16;
+    double *Lt = lds_all + wave * PER_WAVE, *Ld = Lt + 16 * LD, *Ay = Ld + 16, *Ss = Ay + 32;
     // contiguous cluster range of this wave
     const int c0 = (int)((long long)gw * nclusters / nw), c1 = (int)((long long)(gw + 1) * nclusters / nw);
     if (c0 >= c1) return;
@@ -334,7 +334,11 @@ __global__ __launch_bounds__(256, 2) void k_cluster_assemble_w3(const int *__res
                         da[t] = ok ? ta : 0.0;
                     }
                 }
-                const double ratio = dy / (dl * dl);
+                const double xx = dl * dl;                          // Y / X with X = L^2: reciprocal + two Newton steps (an IEEE division is ~30 VALU)
+                double rx = __builtin_amdgcn_rcp(xx);
+                rx = __builtin_fma(__builtin_fma(-xx, rx, 1.0), rx, rx);
+                rx = __builtin_fma(__builtin_fma(-xx, rx, 1.0), rx, rx);
+                const double ratio = dy * rx;
                 double a[2], ar[2];
 #pragma unroll
                 for (int t = 0; t < 2; t++) {
@@ -365,20 +369,38 @@ __global__ __launch_bounds__(256, 2) void k_cluster_assemble_w3(const int *__res
             const int P = FULL ? 32 : k.U;
             double *Sg = tb.S + k.S_off;
             // through LDS, so that S_j leaves as whole consecutive 512-byte / 1-KB pieces (S_j is P x P contiguous)
+            if (k.pmap_identity) {
+                // (u, v) -> v + u LDS_S = [l15 + l4 LDS_S] + constant, mirror [l4 + l15 LDS_S] + constant: two lane offsets, immediates
+                double *s_uv = Ss + l15 + l4 * LDS_S, *s_vu = Ss + l4 + l15 * LDS_S;
 #pragma unroll
-            for (int ti = 0; ti < 2; ti++)
+                for (int ti = 0; ti < 2; ti++)
 #pragma unroll
-                for (int tj = 0; tj <= ti; tj++)
+                    for (int tj = 0; tj <= ti; tj++)
 #pragma unroll
-                    for (int reg = 0; reg < 4; reg++) {
-                        const int u = 16 * ti + 4 * reg + l4, v = 16 * tj + l15;
-                        if (u >= v && (FULL || u < P)) {
-                            const double sv = sacc[ti * (ti + 1) / 2 + tj][reg];
-                            const int pu = pm_u[ti * 4 + reg], pv = pm_v[tj];
-                            Ss[pv + pu * LDS_S] = sv;
-                            Ss[pu + pv * LDS_S] = sv;
+                        for (int reg = 0; reg < 4; reg++) {
+                            const int u = 16 * ti + 4 * reg + l4, v = 16 * tj + l15;
+                            if (u >= v && (FULL || u < P)) {
+                                const double sv = sacc[ti * (ti + 1) / 2 + tj][reg];
+                                s_uv[16 * tj + (16 * ti + 4 * reg) * LDS_S] = sv;
+                                s_vu[16 * ti + 4 * reg + 16 * tj * LDS_S] = sv;
+                            }
                         }
-                    }
+            } else {
+#pragma unroll
+                for (int ti = 0; ti < 2; ti++)
+#pragma unroll
+                    for (int tj = 0; tj <= ti; tj++)
+#pragma unroll
+                        for (int reg = 0; reg < 4; reg++) {
+                            const int u = 16 * ti + 4 * reg + l4, v = 16 * tj + l15;
+                            if (u >= v && (FULL || u < P)) {
+                                const double sv = sacc[ti * (ti + 1) / 2 + tj][reg];
+                                const int pu = pm_u[ti * 4 + reg], pv = pm_v[tj];
+                                Ss[pv + pu * LDS_S] = sv;
+                                Ss[pu + pv * LDS_S] = sv;
+                            }
+                        }
+            }
             wave_sync();
             if (FULL) {
 #pragma unroll
