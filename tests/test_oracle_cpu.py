@@ -180,3 +180,49 @@ def test_oracle_reports_nonpositive_pivot_like_the_reference(oracle_built):
     o = Oracle(f)
     o.schur_assemble(Xc, Y)
     assert o.schur_factor() == int(f.block_cluster[b]) + 1
+
+
+def test_sdp_variant_helpers_against_the_oracle(oracle_built):
+    """Host logic used by the GPU parity tests and by bench.py (cluster replication, constraint relabelling, block duplication),
+    checked on the CPU against the oracle's own algebra: relabelling the constraints permutes S_j, a duplicated dense 1 x 1 block with
+    half the entries adds a quarter of its contribution, replicated clusters assemble independently."""
+    from clrs_amd.sdp import replicate_clusters
+    from oracle.oracle import Oracle
+    from tests.util import chol_blocks_np, duplicate_block, flat, permute_cluster_constraints, spd_iterates
+    f = flat("ce_8_3")
+    X, Y = spd_iterates(f, seed=3)
+    Xc = chol_blocks_np(f, X)
+    S, _ = Oracle(f, quad=False).schur_assemble(Xc, Y)
+    # relabelled constraints: S'[perm p, perm q] = S[p, q]
+    g = permute_cluster_constraints(f, seed=5)
+    Sg, _ = Oracle(g, quad=False).schur_assemble(Xc, Y)
+    for j in range(f.n_clusters):
+        P = int(f.cluster_P[j])
+        a = S[f.S_off[j]:f.S_off[j + 1]].reshape(P, P, order="F")
+        b = Sg[g.S_off[j]:g.S_off[j + 1]].reshape(P, P, order="F")
+        assert np.allclose(np.sort(np.linalg.eigvalsh(a)), np.sort(np.linalg.eigvalsh(b)), rtol=1e-10, atol=1e-12 * np.max(np.abs(a)))
+        assert np.isclose(np.trace(a), np.trace(b), rtol=1e-12)
+    # duplicated dense 1 x 1 block (entries x 0.5): its contribution a a^T Y / X is added once more, scaled by 0.25, when the copy's
+    # iterates equal the original's
+    d = [b for b in range(f.n_blocks) if f.block_kind[b] == 1][0]
+    h = duplicate_block(f, d, 0.5)
+    x0, x1 = int(f.block_off[d]), int(f.block_off[d + 1])
+    Xc2 = np.concatenate([Xc[:x1], Xc[x0:x1], Xc[x1:]])
+    Y2 = np.concatenate([Y[:x1], Y[x0:x1], Y[x1:]])
+    Sh, _ = Oracle(h, quad=False).schur_assemble(Xc2, Y2)
+    # S without the dense block, from a copy whose dense entries are zero
+    import copy
+    z = copy.copy(f)
+    z.dense_A = f.dense_A.copy()
+    z.dense_A[int(f.dense_A_ptr[f.dense_ptr[d]]):int(f.dense_A_ptr[f.dense_ptr[d + 1]])] = 0.0
+    S0, _ = Oracle(z, quad=False).schur_assemble(Xc, Y)
+    assert np.allclose(Sh - S0, 1.25 * (S - S0), rtol=1e-10, atol=1e-13 * np.max(np.abs(S)))
+    # replication: cluster k of the big instance is the small problem at its own iterates
+    big = replicate_clusters(f, 3)
+    Xb, Yb = spd_iterates(big, seed=8)
+    Xcb = chol_blocks_np(big, Xb)
+    Sb, _ = Oracle(big, quad=False).schur_assemble(Xcb, Yb)
+    o = Oracle(f, quad=False)
+    for k in range(3):
+        Sk, _ = o.schur_assemble(Xcb[k * f.xy_len:(k + 1) * f.xy_len], Yb[k * f.xy_len:(k + 1) * f.xy_len])
+        assert np.array_equal(Sb[k * f.S_len:(k + 1) * f.S_len], Sk)
