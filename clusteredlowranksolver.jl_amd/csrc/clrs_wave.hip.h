@@ -138,16 +138,18 @@ struct Trsm16T<0> {
 // 15 steps x 2 chains: 230-250 cycles against the 470 of Trsm16 (scripts/micro/micro_dppchain.hip).
 #define CLRS_FMAC2(K) "v_fmac_f64_dpp %0, %0, %2 row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %1, %1, %2 row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
 __device__ __forceinline__ void trsm16_fmac_fwd(double &y0, double &y1, const double (&m)[16]) {
+// (the compiler's hazard recogniser does not look inside inline assembly: every DPP read here is kept two wait states behind the write
+// of its source by the s_nop INSIDE the same asm statement, which the scheduler cannot separate from it)
 #define CLRS_STEP(K, R) asm volatile("v_fmac_f64_dpp %0, %0, %2 row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %1, %1, %2 row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n\ts_nop 0" : "+v"(y0), "+v"(y1) : "v"(m[R]))
-    asm volatile("s_nop 1");
-    CLRS_STEP(0, 0); CLRS_STEP(1, 1); CLRS_STEP(2, 2); CLRS_STEP(3, 3); CLRS_STEP(4, 4); CLRS_STEP(5, 5); CLRS_STEP(6, 6); CLRS_STEP(7, 7);
+#define CLRS_STEP0(K, R) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %2 row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %1, %1, %2 row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n\ts_nop 0" : "+v"(y0), "+v"(y1) : "v"(m[R]))
+    CLRS_STEP0(0, 0); CLRS_STEP(1, 1); CLRS_STEP(2, 2); CLRS_STEP(3, 3); CLRS_STEP(4, 4); CLRS_STEP(5, 5); CLRS_STEP(6, 6); CLRS_STEP(7, 7);
     CLRS_STEP(8, 8); CLRS_STEP(9, 9); CLRS_STEP(10, 10); CLRS_STEP(11, 11); CLRS_STEP(12, 12); CLRS_STEP(13, 13); CLRS_STEP(14, 14);
 }
 __device__ __forceinline__ void trsm16_fmac_bwd(double &y0, double &y1, const double (&m)[16]) {
-    asm volatile("s_nop 1");
-    CLRS_STEP(15, 15); CLRS_STEP(14, 14); CLRS_STEP(13, 13); CLRS_STEP(12, 12); CLRS_STEP(11, 11); CLRS_STEP(10, 10); CLRS_STEP(9, 9); CLRS_STEP(8, 8);
+    CLRS_STEP0(15, 15); CLRS_STEP(14, 14); CLRS_STEP(13, 13); CLRS_STEP(12, 12); CLRS_STEP(11, 11); CLRS_STEP(10, 10); CLRS_STEP(9, 9); CLRS_STEP(8, 8);
     CLRS_STEP(7, 7); CLRS_STEP(6, 6); CLRS_STEP(5, 5); CLRS_STEP(4, 4); CLRS_STEP(3, 3); CLRS_STEP(2, 2); CLRS_STEP(1, 1);
 #undef CLRS_STEP
+#undef CLRS_STEP0
 }
 #undef CLRS_FMAC2
 
@@ -251,6 +253,9 @@ struct Potrf16 {
         // Entries above the diagonal are never read: the eliminations run unpredicated on all rows; whatever they leave above
         // the diagonal is zeroed by the final scaling pass.
         Elim<K + 1>::run(a, nt, w);
+        // the next pivot broadcast is a DPP read of a[K + 1] that the COMPILER emits: it cannot see the VALU write inside the inline
+        // assembly above, so the two wait states are put here, tied to that register so that they stay between the two
+        if constexpr (K + 1 < 16) asm volatile("s_nop 1" : "+v"(a[K + 1 < 16 ? K + 1 : 15]));
         Potrf16<K + 1>::run(a, row, nvalid, bad, dgn);
     }
     template <int J, int DUMMY = 0>

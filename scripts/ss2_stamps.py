@@ -13,7 +13,13 @@ from clrs_amd import _lib
 L = _lib.load(os.path.join(_lib.CSRC, "libclrs_hip_w3stamps.so"))
 from clrs_amd.solver import SchurContext, compute_T_decomposition, solve_system
 from tests.util import chol_blocks_np, flat, spd_iterates
-f = flat(sys.argv[1] if len(sys.argv) > 1 else "ce_8_3")
+name = sys.argv[1] if len(sys.argv) > 1 else "ce_8_3"
+if name == "synthetic_ce":      # the shapes of cohnelkies(8,15) (2 clusters, P = 32, N = 31) with random, well conditioned data
+    from tests.util import random_simple_sdp
+    import clrs_amd as _c
+    f = _c.flatten(random_simple_sdp(0, J=2, n_free=31, max_P=32, max_n=16, definite=True))
+else:
+    f = flat(name)
 X, Y = spd_iterates(f, seed=2)
 ctx = SchurContext(f)
 Xc = ctx.cholesky_blocks(X)
