@@ -83,13 +83,13 @@ def kernel_profile(ctx, run_once, reps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--graph", action="store_true", help="replay one hipGraph per library call instead of launching kernels one by one "
                     "(slower for this path: a call is 1-3 kernels and a graph replay costs 10-16 us of host time)")
     ap.add_argument("--roofline-copies", type=int, default=8192,
-                    help="cluster replication factor of the roofline instance (default: 16384 clusters, 0.54 GB touched per launch -- "
-                         "larger than the 256 MiB Infinity Cache, so that repeated launches really stream from HBM)")
+                    help="cluster replication factor of the roofline instance (default: 16384 clusters, 359 MB of traffic per launch -- "
+                         "more than the 256 MiB Infinity Cache holds; profiles/r01/o_size_sweep.txt has 4096 ... 131072 clusters)")
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--split", action="store_true", help="with one GPU: still run the split-phase calls and the RCCL all-reduces (1-rank group)")
     args = ap.parse_args()
@@ -287,8 +287,19 @@ def main():
             if tr.get("clusters") == big.n_clusters:
                 out["roofline"]["traffic"] = tr["traffic_bytes"]
                 out["roofline"]["traffic_source"] = tr["source"]
-        except Exception:
-            pass
+                # what a pure streaming kernel of the same footprint and read : write mix reaches on this device, measured now
+                # (include/clrs_hip.h: clrs_test_stream) -- the practical roof beside the data-sheet peak the fraction is quoted on
+                import ctypes as _ct
+                from clrs_amd._lib import load as _load, check as _check
+                rd, wr = int(2 * 1024 * tr["fetch_size_kib_raw"]), int(1024 * tr["write_size_kib"])
+                us = _ct.c_double(0.0)
+                _check(_load().clrs_test_stream(local_rank, rd, wr, 20, _ct.byref(us)))
+                copy_gbs = (rd + wr) / (us.value * 1e-6) / 1e9
+                traffic_gbs = tr["traffic_bytes"] / (out["roofline"]["kernel_avg_us"] * 1e-6) / 1e9
+                out["roofline"]["copy_roof"] = {"read_bytes": rd, "write_bytes": wr, "us": us.value, "GB/s": copy_gbs,
+                                                "kernel_traffic_GB/s": traffic_gbs, "kernel_vs_copy": traffic_gbs / copy_gbs}
+        except Exception as e:
+            out["roofline"]["copy_roof_error"] = repr(e)
 
         # ---- the complete interior-point method, device resident, on the instances fp64 can solve ----
         # every iteration = residuals + predictor + corrector + step lengths + update around the same hot path; one host sync per iteration

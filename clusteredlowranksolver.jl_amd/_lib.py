@@ -116,6 +116,7 @@ SYMBOLS = {
                                  C.c_double, p_d, C.c_int]),
     "clrs_test_potrf": (C.c_int, [C.c_int, C.c_int, p_d, C.c_int]),
     "clrs_test_trsm": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, p_d, C.c_int, p_d, C.c_int]),
+    "clrs_test_stream": (C.c_int, [C.c_int, C.c_longlong, C.c_longlong, C.c_int, p_d]),
 }
 
 

@@ -2056,6 +2056,62 @@ extern "C" int clrs_test_potrf(int device, int n, double *A, int lda) {
     return rc ? rc : st;
 }
 
+// ---- measurement hook: what a pure streaming kernel reaches at a given footprint and read : write mix -------------------------
+// (bench.py reports the assembly kernel's HBM traffic per second beside this rate: the 8 TB/s of the data sheet is not reachable by
+// any kernel -- beyond the 256 MiB Infinity Cache a plain copy runs at 5.0-5.8 TB/s on this part)
+typedef double v2d_stream __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void k_stream_probe(const v2d_stream *__restrict__ a, const v2d_stream *__restrict__ b, v2d_stream *__restrict__ w,
+                                                      long long nr, long long nw) {
+    const long long stride = (long long)gridDim.x * 256, n = nr > nw ? nr : nw;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += 4 * stride) {
+        v2d_stream x[4], y[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const long long k = i + u * stride;
+            x[u] = y[u] = (v2d_stream){0.0, 0.0};
+            if (k < nr) { x[u] = a[k]; y[u] = b[k]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const long long k = i + u * stride;
+            if (k < nw) __builtin_nontemporal_store(x[u] + y[u], w + k);
+        }
+    }
+}
+
+extern "C" int clrs_test_stream(int device, long long read_bytes, long long write_bytes, int reps, double *avg_us) {
+    if (read_bytes < 32 || write_bytes < 16 || reps < 1 || !avg_us) return fail(CLRS_ERR_INVALID, "clrs_test_stream: bad arguments");
+    if (hipSetDevice(device) != hipSuccess) return fail(CLRS_ERR_NO_DEVICE, "no device");
+    const long long nr = read_bytes / 32, nw = write_bytes / 16;        // 16-byte elements: two read streams of nr, one write stream of nw
+    v2d_stream *a = nullptr, *b = nullptr, *w = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipStream_t st = nullptr;
+    int rc = 0;
+    auto ok = [&](hipError_t e, const char *what) { if (e != hipSuccess && !rc) rc = fail(CLRS_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e)); return e == hipSuccess; };
+    if (ok(hipMalloc(&a, nr * 16), "hipMalloc") && ok(hipMalloc(&b, nr * 16), "hipMalloc") && ok(hipMalloc(&w, nw * 16), "hipMalloc") &&
+        ok(hipMemset(a, 0, nr * 16), "hipMemset") && ok(hipMemset(b, 0, nr * 16), "hipMemset") && ok(hipMemset(w, 0, nw * 16), "hipMemset") &&
+        ok(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "hipStreamCreate") && ok(hipEventCreate(&e0), "hipEventCreate") && ok(hipEventCreate(&e1), "hipEventCreate")) {
+        hipDeviceProp_t prop;
+        int cus = 256;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess) cus = prop.multiProcessorCount;
+        const int grid = 2 * cus;
+        for (int r = 0; r < 3; r++) hipLaunchKernelGGL(k_stream_probe, dim3(grid), dim3(256), 0, st, a, b, w, nr, nw);
+        ok(hipEventRecord(e0, st), "hipEventRecord");
+        for (int r = 0; r < reps; r++) hipLaunchKernelGGL(k_stream_probe, dim3(grid), dim3(256), 0, st, a, b, w, nr, nw);
+        ok(hipEventRecord(e1, st), "hipEventRecord");
+        ok(hipEventSynchronize(e1), "hipEventSynchronize");
+        float ms = 0.f;
+        if (ok(hipEventElapsedTime(&ms, e0, e1), "hipEventElapsedTime")) *avg_us = 1e3 * (double)ms / reps;
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (st) (void)hipStreamDestroy(st);
+    if (a) (void)hipFree(a);
+    if (b) (void)hipFree(b);
+    if (w) (void)hipFree(w);
+    return rc;
+}
+
 extern "C" int clrs_test_trsm(int device, int trans, int n, int nrhs, const double *L, int ldl, double *B, int ldb) {
     clrs_ctx *c = mini_ctx(device);
     if (!c) return fail(CLRS_ERR_NO_DEVICE, "no device");

@@ -250,6 +250,12 @@ int clrs_test_gemm(int device, int ta, int tb, int M, int N, int K, double alpha
 int clrs_test_potrf(int device, int n, double *A, int lda);
 int clrs_test_trsm(int device, int trans, int n, int nrhs, const double *L, int ldl, double *B, int ldb);
 
+/* Measurement hook: average duration (us, HIP events, `reps` back-to-back launches) of a pure streaming kernel that reads
+ * `read_bytes` (two streams) and writes `write_bytes` (one stream, non-temporal) of freshly allocated device memory: the rate a
+ * bandwidth-bound kernel of that footprint and read : write mix can reach on this device.  bench.py reports the assembly kernel's
+ * HBM traffic per second beside it (`roofline.copy_roof`). */
+int clrs_test_stream(int device, long long read_bytes, long long write_bytes, int reps, double *avg_us);
+
 #ifdef __cplusplus
 }
 #endif

@@ -51,6 +51,15 @@ def main():
     print(f"clusters {big.n_clusters} blocks {big.n_blocks}: {1e6 * dt:.1f} us per assembly (host clock, back to back), "
           f"{cnt['assemble_bytes'] / dt / 1e9:.0f} GB/s algorithmic, {cnt['assemble_flops'] / dt / 1e12:.2f} TFLOP/s")
     ctx.close()
+    # the streaming rate of this device at the same footprint and read : write mix (PMC traffic of the 16384-cluster launch, scaled)
+    import ctypes as C
+    from clrs_amd._lib import load, check
+    scale = big.n_clusters / 16384.0
+    rd, wr = int(218711490 * scale), int(140524523 * scale)
+    us = C.c_double(0.0)
+    check(load().clrs_test_stream(0, rd, wr, reps, C.byref(us)))
+    print(f"    traffic {1e-6 * (rd + wr):.0f} MB per launch -> kernel {(rd + wr) / dt / 1e9:.0f} GB/s; streaming probe of that footprint "
+          f"{us.value:.1f} us = {(rd + wr) / us.value / 1e3:.0f} GB/s; kernel / probe = {us.value * 1e-6 / dt:.2f}")
 
 
 if __name__ == "__main__":

@@ -56,6 +56,17 @@ def test_potrf_and_trsm(n):
             assert np.max(np.abs(Bs - ref)) <= 1e-10 * max(1.0, np.max(np.abs(ref)))
 
 
+def test_stream_probe_measures_a_plausible_rate():
+    """clrs_test_stream (the copy roof bench.py quotes beside the assembly kernel): runs, rejects bad sizes, and reports a rate
+    between 1 and 12 TB/s for a footprint of 96 MB."""
+    import ctypes as C
+    us = C.c_double(0.0)
+    assert _lib().clrs_test_stream(0, 64 << 20, 32 << 20, 5, C.byref(us)) == 0
+    rate = (96 << 20) / (us.value * 1e-6) / 1e12
+    assert 1.0 < rate < 12.0, (us.value, rate)
+    assert _lib().clrs_test_stream(0, 0, 0, 1, C.byref(us)) < 0
+
+
 def test_potrf_reports_failure():
     A = np.asfortranarray(np.array([[1.0, 2.0], [2.0, 1.0]]))
     assert _lib().clrs_test_potrf(0, 2, _dp(A), 2) == 1
