@@ -276,6 +276,49 @@ __global__ __launch_bounds__(256) void k_cluster_assemble(const FCluster *__rest
 }
 
 
+// S_j = sum of the per-block slabs written by k_cluster_assemble when the blocks of a cluster run in workgroups of their own
+// (host plan: "split_blocks"), added in block order starting from zero: bit-identical to the accumulation in one workgroup.
+struct SSlabSum {
+    double *out;              // S_j (P x P)
+    const double *slabs;      // nslabs slabs of len doubles
+    long long len;
+    int nslabs, pad;
+};
+
+// grid = (chunks of 1024 entries, clusters); the loads of eight slabs are in flight together, the additions stay in slab order
+__global__ __launch_bounds__(256) void k_sum_S_slabs(const SSlabSum *__restrict__ descs) {
+    const SSlabSum d = descs[blockIdx.y];
+    const long long e0 = (long long)blockIdx.x * 1024;
+    if (e0 >= d.len) return;
+    long long idx[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const long long e = e0 + u * 256 + threadIdx.x;
+        idx[u] = e < d.len ? e : 0;
+    }
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int s0 = 0; s0 < d.nslabs; s0 += 8) {
+        double v[8][4];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int sl = s0 + k < d.nslabs ? s0 + k : d.nslabs - 1;       // clamped: loaded, not added
+#pragma unroll
+            for (int u = 0; u < 4; u++) v[k][u] = d.slabs[idx[u] + sl * d.len];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (s0 + k < d.nslabs) {
+#pragma unroll
+                for (int u = 0; u < 4; u++) acc[u] += v[k][u];
+            }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const long long e = e0 + u * 256 + threadIdx.x;
+        if (e < d.len) d.out[e] = acc[u];
+    }
+}
+
 // =====================================================================================================================
 // fused factor / solve kernels for clusters with P <= 128 and N <= 128 (LDS resident; clrs_wave.hip.h does the work)
 // =====================================================================================================================

@@ -50,22 +50,24 @@ static const int INFO_NONE = 0x7f7f7f7f;
 
 // process-wide knobs read at context creation (clrs_config_set)
 static int g_cfg_fused_assemble = 1;
+static int g_cfg_split_blocks = 1;      // fused general assembly: one workgroup per PSD block (partial S_j slabs, summed in block order) when the launch is far from filling the chip
 static int g_cfg_fused_factor = 1;
 static int g_cfg_wave_assemble = 1;
 static int g_cfg_wave2_assemble = 1;
 static int g_cfg_wave3_assemble = 1;   // register-resident form of the cluster-per-wave assembly (U <= 32); 0: k_cluster_assemble_w2
 static int g_cfg_dense_block = 1;
 static int g_cfg_factor_small = 1;      // factor + Q in one launch of one workgroup for <= 4 small clusters (0: k_cluster_factor + k_small_potrf)
+static int g_cfg_solve_small_max = 32768;     // one-workgroup solve stage only up to this many doubles of operands (beyond: one workgroup per cluster, three launches)
 static int g_cfg_solve_small2 = 1;     // one-workgroup solve stage with all loads up front and single-wave triangular solves (0: k_solve_small)
 static const int LDS_BUDGET_DOUBLES = 20000;   // of the 20480 doubles (160 KiB) a workgroup may claim
 
 // ------------------------------------------------------------------------------------------------
 // launch plan
 // ------------------------------------------------------------------------------------------------
-enum StepKind { STEP_MEMCPY, STEP_GEMM, STEP_TRSM, STEP_POTRF, STEP_GATHER_S, STEP_GATHER_SCALAR, STEP_SUB, STEP_MEMSET_INFO, STEP_ZERO_UPPER, STEP_FUSED_ASSEMBLE, STEP_SMALL_POTRF, STEP_CLUSTER_FACTOR, STEP_GEMV_T, STEP_CSOLVE_FWD, STEP_Q_SOLVE, STEP_CSOLVE_BWD, STEP_SUM_SLABS, STEP_ASSEMBLE_W1, STEP_GRAM_SMALL, STEP_ASSEMBLE_W2, STEP_SOLVE_SMALL, STEP_DENSE_BLOCK, STEP_ASSEMBLE_W3, STEP_FACTOR_SMALL, STEP_NKINDS };
+enum StepKind { STEP_MEMCPY, STEP_GEMM, STEP_TRSM, STEP_POTRF, STEP_GATHER_S, STEP_GATHER_SCALAR, STEP_SUB, STEP_MEMSET_INFO, STEP_ZERO_UPPER, STEP_FUSED_ASSEMBLE, STEP_SMALL_POTRF, STEP_CLUSTER_FACTOR, STEP_GEMV_T, STEP_CSOLVE_FWD, STEP_Q_SOLVE, STEP_CSOLVE_BWD, STEP_SUM_SLABS, STEP_ASSEMBLE_W1, STEP_GRAM_SMALL, STEP_ASSEMBLE_W2, STEP_SOLVE_SMALL, STEP_DENSE_BLOCK, STEP_ASSEMBLE_W3, STEP_FACTOR_SMALL, STEP_SUM_S_SLABS, STEP_NKINDS };
 static const char *const STEP_NAMES[STEP_NKINDS] = {"hipMemcpyAsync(D2D)", "k_gemm_f64_t", "k_trsm_diag", "k_potrf_diag", "k_schur_gather",
                                                     "k_gather_scalar", "k_sub", "hipMemsetAsync", "k_zero_upper", "k_cluster_assemble", "k_small_potrf", "k_cluster_factor", "k_gemv_t",
-                                                    "k_cluster_solve_fwd", "k_q_solve", "k_cluster_solve_bwd", "k_sum_slabs", "k_cluster_assemble_w1", "k_gram_small", "k_cluster_assemble_w2", "k_solve_small", "k_dense_block", "k_cluster_assemble_w3", "k_factor_small"};
+                                                    "k_cluster_solve_fwd", "k_q_solve", "k_cluster_solve_bwd", "k_sum_slabs", "k_cluster_assemble_w1", "k_gram_small", "k_cluster_assemble_w2", "k_solve_small", "k_dense_block", "k_cluster_assemble_w3", "k_factor_small", "k_sum_S_slabs"};
 static const int KT_MAX_EVENTS = 8192;   // event pairs kept between two clrs_get_kernel_times calls
 
 struct Step {
@@ -486,6 +488,9 @@ static int run_steps(clrs_ctx *c, const Plan &pl) {
                 break;
             case STEP_GRAM_SMALL:
                 hipLaunchKernelGGL(k_gram_small, dim3(c->N * c->N), dim3(256), 0, st, (const double *)c->d_LB, (int)c->xlen, (int)c->xlen, c->N, c->d_Q);
+                break;
+            case STEP_SUM_S_SLABS:
+                hipLaunchKernelGGL(k_sum_S_slabs, dim3((unsigned)((s.n + 1023) / 1024), s.grid), dim3(256), 0, st, (const SSlabSum *)s.d0);
                 break;
             case STEP_SUM_SLABS:
                 hipLaunchKernelGGL(k_sum_slabs, dim3((unsigned)(((i64)c->N * c->N + 255) / 256)), dim3(256), 0, st, (const double *)c->d_Qslabs, (i64)c->N * c->N, c->J,
@@ -925,6 +930,8 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
     c->n_wave_clusters = (int)wcl.size();
     c->n_wave2_clusters = (int)w2cl.size();
     std::vector<FCluster> fcl;
+    std::vector<int> fcl_cluster;
+    std::vector<SSlabSum> fsum;
     std::vector<FBlock> fbl;
     int fused_nmax = 0;
     size_t fused_lds = 0;
@@ -984,6 +991,7 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
             for (const FBlock &fb : mine) fbl.push_back(fb);
             fc.b1 = (int)fbl.size();
             fcl.push_back(fc);
+            fcl_cluster.push_back(j);
             c->cluster_fused[j] = 1;
             for (int bb = b_first; bb < b; bb++) c->blk[bb].fused = true;
             fused_nmax = std::max(fused_nmax, nmax);
@@ -991,6 +999,43 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
         }
     }
     c->n_fused_clusters = (int)fcl.size() + (int)wcl.size() + (int)w2cl.size();
+    // Few clusters with several blocks each: the blocks of a cluster are independent until their contributions meet in S_j.  One
+    // workgroup per block (groups of blocks beyond 32 per cluster) writes its contribution as a P x P slab, k_sum_S_slabs adds
+    // the slabs in block order -- the same additions in the same order as the one-workgroup form, so S_j is bit-identical.
+    if (g_cfg_split_blocks && !fcl.empty() && fcl.size() <= 32) {
+        std::vector<FCluster> split;
+        std::vector<int> split_sum;                // per entry of `split`: its sum descriptor, or -1
+        i64 slab_doubles = 0;
+        for (size_t i = 0; i < fcl.size(); i++) {
+            const FCluster &fc = fcl[i];
+            const int nb = fc.b1 - fc.b0, groups = std::min(nb, 32);
+            if (nb < 2) { split.push_back(fc); split_sum.push_back(-1); continue; }
+            SSlabSum ss;
+            ss.out = fc.S; ss.slabs = nullptr; ss.len = (i64)fc.P * fc.P; ss.nslabs = groups; ss.pad = (int)slab_doubles;      // offset for now (fits: few small clusters)
+            for (int g = 0; g < groups; g++) {
+                FCluster part = fc;
+                part.b0 = fc.b0 + (int)((i64)g * nb / groups);
+                part.b1 = fc.b0 + (int)((i64)(g + 1) * nb / groups);
+                part.S = nullptr;                       // patched below: slab g of this cluster
+                split.push_back(part);
+                split_sum.push_back((int)fsum.size());
+            }
+            slab_doubles += ss.len * groups;
+            fsum.push_back(ss);
+        }
+        if (!fsum.empty()) {
+            double *dslabs;
+            CK(dmalloc(c, &dslabs, slab_doubles));
+            std::vector<int> used(fsum.size(), 0);
+            for (size_t i = 0; i < split.size(); i++)
+                if (split_sum[i] >= 0) {
+                    const int si = split_sum[i];
+                    split[i].S = dslabs + fsum[si].pad + fsum[si].len * used[si]++;
+                }
+            for (SSlabSum &ss : fsum) { ss.slabs = dslabs + ss.pad; ss.pad = 0; }
+            fcl.swap(split);
+        }
+    }
     for (int b = 0; b < NB; b++)
         if (c->blk[b].fused && c->blk[b].kind == 0)
             for (i64 t = c->blk[b].t0; t < c->blk[b].t1; t++) h_ayidx[t] = -1;   // written by the fused kernel
@@ -1266,6 +1311,14 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
             s.grid = (int)fcl.size(); s.d0 = dfc; s.d1 = dfb; s.src = &c->ftables; s.bytes = fused_lds; s.nmax = fused_nmax;
             pl.steps.push_back(s);
             if (fused_lds > 64 * 1024) HIPCK(hipFuncSetAttribute((const void *)k_cluster_assemble, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds));
+            if (!fsum.empty()) {
+                SSlabSum *dss;
+                CK(upload(c, fsum, &dss));
+                Step s2;
+                s2.kind = STEP_SUM_S_SLABS; s2.grid = (int)fsum.size(); s2.d0 = dss; s2.n = 0;
+                for (const SSlabSum &ss : fsum) s2.n = std::max<i64>(s2.n, ss.len);
+                pl.steps.push_back(s2);
+            }
         }
     }
     // =============================================================================================
@@ -1457,7 +1510,9 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
         }
     }
     // a handful of small clusters: the whole solve stage in one workgroup, one launch
-    if (c->fused_fs && (c->fused_q || N == 0) && J <= 8 && c->xlen <= 1024) {
+    i64 solve_doubles = (i64)N * N + c->xlen * N;                     // operands of one solve: L_j, LinvB, L_Q
+    for (int j = 0; j < J; j++) solve_doubles += (i64)c->P[j] * c->P[j];
+    if (c->fused_fs && (c->fused_q || N == 0) && J <= 8 && c->xlen <= 1024 && solve_doubles <= g_cfg_solve_small_max) {
         int maxP16 = (N + 15) & ~15;
         for (int j = 0; j < J; j++) maxP16 = std::max(maxP16, (c->P[j] + 15) & ~15);
         Step s = c->p_fwd.steps[0];                                   // reuses the CSolve table
@@ -1944,6 +1999,7 @@ extern "C" int clrs_get_kernel_times(clrs_ctx *c, int max_kinds, double *seconds
 extern "C" int clrs_config_set(const char *key, int value) {
     if (!key) return fail(CLRS_ERR_INVALID, "null argument");
     if (!std::strcmp(key, "fused_assemble")) { g_cfg_fused_assemble = value; return 0; }
+    if (!std::strcmp(key, "split_blocks")) { g_cfg_split_blocks = value; return 0; }
     if (!std::strcmp(key, "fused_factor")) { g_cfg_fused_factor = value; return 0; }
     if (!std::strcmp(key, "wave_assemble")) { g_cfg_wave_assemble = value; return 0; }
     if (!std::strcmp(key, "wave2_assemble")) { g_cfg_wave2_assemble = value; return 0; }
@@ -1951,6 +2007,7 @@ extern "C" int clrs_config_set(const char *key, int value) {
     if (!std::strcmp(key, "dense_block")) { g_cfg_dense_block = value; return 0; }
     if (!std::strcmp(key, "solve_small2")) { g_cfg_solve_small2 = value; return 0; }
     if (!std::strcmp(key, "factor_small")) { g_cfg_factor_small = value; return 0; }
+    if (!std::strcmp(key, "solve_small_max")) { g_cfg_solve_small_max = value; return 0; }
     return fail(CLRS_ERR_INVALID, std::string("unknown configuration key ") + key);
 }
 

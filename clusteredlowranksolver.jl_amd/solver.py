@@ -48,14 +48,17 @@ class SchurContext:
 
     def __init__(self, sdp, device: int = 0, graph: bool = False, timing: bool = False, fused: Optional[bool] = None,
                  wave: Optional[bool] = None, wave2: Optional[bool] = None, wave3: Optional[bool] = None,
-                 solve_small2: Optional[bool] = None, factor_small: Optional[int] = None):
+                 solve_small2: Optional[bool] = None, factor_small: Optional[int] = None,
+                 split_blocks: Optional[bool] = None):
         """`fused=False` forces the staged grouped-GEMM / blocked-BLAS path everywhere (default: clusters that fit in
         one CU's LDS take the fused per-cluster assembly, factor and solve kernels).  `wave=False` keeps the
         fused assembly on the 4-waves-per-block kernel even where the wave-per-block kernel applies.  `wave2=True`
         takes the cluster-per-wave assembly even for few clusters (default: from 64 clusters on); `wave3=False` keeps it on
         the LDS-staged kernel (k_cluster_assemble_w2) instead of the register-resident one (k_cluster_assemble_w3);
         `solve_small2=False` keeps the one-launch solve stage on k_solve_small instead of k_solve_small2; `factor_small`
-        (0 / 1 / 2) selects when the factorisation stage is the single launch k_factor_small (include/clrs_hip.h)."""
+        (0 / 1 / 2) selects when the factorisation stage is the single launch k_factor_small (include/clrs_hip.h);
+        `split_blocks=False` keeps the general fused assembly at one workgroup per cluster (default: one per PSD block when
+        there are few clusters)."""
         self.flat: FlatSDP = sdp if isinstance(sdp, FlatSDP) else flatten(sdp)
         f = self.flat
         self.L = _lib.load()
@@ -72,6 +75,8 @@ class SchurContext:
             _lib.check(self.L.clrs_config_set(b"solve_small2", int(bool(solve_small2))))
         if factor_small is not None:
             _lib.check(self.L.clrs_config_set(b"factor_small", int(factor_small)))
+        if split_blocks is not None:
+            _lib.check(self.L.clrs_config_set(b"split_blocks", int(bool(split_blocks))))
         k = self._keep = {}
 
         def hold(name, arr, dt):
@@ -105,6 +110,8 @@ class SchurContext:
                 self.L.clrs_config_set(b"solve_small2", 1)
             if factor_small is not None:
                 self.L.clrs_config_set(b"factor_small", 1)
+            if split_blocks is not None:
+                self.L.clrs_config_set(b"split_blocks", 1)
         self.h = h
         self.device = device
         if graph:

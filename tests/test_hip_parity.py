@@ -116,6 +116,24 @@ def test_schur_assemble_matches_oracle(name, path, oracle_built):
     ctx.close()
 
 
+@pytest.mark.parametrize("name", ["threepoint_4", "ns_8_15_2", "ns_8_3_2", "sdpa_small", "delsarte_8_3", "x2p1"])
+def test_block_split_assembly_is_bit_identical(name):
+    """General fused assembly with one workgroup per PSD block + k_sum_S_slabs (the default for few clusters) against one workgroup
+    per cluster: the same additions in the same order, so S and A_Y agree to the last bit."""
+    from clrs_amd.solver import SchurContext
+    f = flat(name)
+    X, Y = spd_iterates(f, seed=5)
+    Xc = chol_blocks_np(f, X)
+    out = []
+    for split in (True, False):
+        ctx = SchurContext(f, wave=False, split_blocks=split)
+        S, AY = ctx.compute_S_integrated(Xc, Y)
+        out.append((S.copy(), np.array(AY, copy=True)))
+        ctx.close()
+    assert np.array_equal(out[0][0], out[1][0])
+    assert np.array_equal(out[0][1], out[1][1])
+
+
 @pytest.mark.parametrize("name,copies", [("ce_8_15", 1100), ("ce_8_3", 1100), ("polyopt8", 2500)])
 def test_cluster_per_wave_assembly_many_clusters(name, copies, oracle_built):
     """k_cluster_assemble_w3 with several clusters per wave (contiguous cluster ranges, loads of the next cluster's first block in
