@@ -225,6 +225,12 @@ int clrs_wave2_clusters(const clrs_ctx *ctx);
 /* "factor_small" (default 1): a context with ONE cluster (P, N <= 64) runs clrs_schur_factor as one launch of k_factor_small
  * (S_j and B_j staged in one trip, Q never leaves LDS before it is factored); 2 = also for 2-4 clusters, one wave per cluster
  * (slower than the workgroup-per-cluster kernels on the named problems: kept for measurement); 0 = never.
+ * "split_blocks" (default 1): when at most 32 clusters take the general fused assembly (k_cluster_assemble), every PSD block
+ * of a cluster gets a workgroup of its own (groups of blocks beyond 32 per cluster) that writes its contribution to S_j as a
+ * slab; k_sum_S_slabs adds the slabs in block order, which reproduces the one-workgroup accumulation bit for bit; 0 = one
+ * workgroup per cluster.
+ * "solve_small_max" (default 32768): the one-workgroup solve stage (k_solve_small / k_solve_small2) is used while the operands
+ * of a solve (L_j, LinvB, L_Q) stay below this many doubles; beyond, one workgroup per cluster in three launches.
  * "solve_small2" (default 1): contexts with <= 8 clusters whose factors fit in 150 KB of LDS run the solve stage as ONE launch
  * of k_solve_small2 (every operand staged in one trip to memory, one wave per triangular solve); 0 keeps k_solve_small. */
 /* Diagnostic builds (-DCLRS_FUSED_STAMPS) only: s_memtime stamps of the phases of workgroup 0 of the fused kernel. */
