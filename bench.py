@@ -9,7 +9,8 @@ cohnelkies(8, 15) of the reference's examples/SpherePacking.jl:117-185 -- 2 clus
 constraints, PSD blocks 16x16 (rank-1 constraint matrices) + one 1x1 dense block, N = 31 free variables.
 With N GPUs the problem is weak-scaled along the reference's own outer parallel axis (clusters): 2 clusters
 per GPU (cohnelkies_multi with 2N-1 sign-constraint clusters), sharded one shard per rank, coupled only by
-the RCCL all-reduce of Q (31 x 31) and of u (31) -- SURVEY.md section 8e.
+the RCCL all-reduce of Q (31 x 31) and of u (31) -- SURVEY.md section 8e; the exchange of Q rides on the first solve's
+exchange of u (one all-reduce of the contiguous [Q | u]), so a step has two collectives.
 
 One step = one pass of the hot path of one interior-point iteration on device-resident iterates:
     Cholesky of the X blocks            (src/solver.jl:388-399)
@@ -228,7 +229,7 @@ def main():
         "config": {"workload": "SpherePacking cohnelkies(8,15): d=8, 2d=30; 2 clusters/GPU P=32, blocks 16x16 r1 + 1x1 dense, N=31",
                    "clusters": int(flat.n_clusters), "clusters_per_gpu": 2, "n_free": int(flat.n_free),
                    "unit_of_work": "one hot-path pass over one 2-cluster share; a step of the N-GPU job (one iteration of the 2N-cluster problem) = N units",
-                   "launch": "hipGraph" if use_graph else "eager", "collective": "RCCL all-reduce Q(31x31)+2x u(31)" if (world > 1 or args.split) else "none"},
+                   "launch": "hipGraph" if use_graph else "eager", "collective": "2 RCCL all-reduces per step: [Q(31x31) | u(31)] with the first solve, u(31) with the second" if (world > 1 or args.split) else "none"},
         "parity": parity,
     }
 
@@ -257,10 +258,10 @@ def main():
         bXc = np.concatenate([np.linalg.cholesky(bX[big.block_off[b]:big.block_off[b + 1]].reshape(int(big.block_n[b]), -1, order="F"))
                               .reshape(-1, order="F") for b in range(big.n_blocks)])
         tbXc, tbY = torch.from_numpy(bXc).to(dev), torch.from_numpy(bY).to(dev)
-        for _ in range(5):
+        for _ in range(50):      # clocks and caches in their steady state before the timed launches
             bctx.assemble_dev(tbXc.data_ptr(), tbY.data_ptr())
         torch.cuda.synchronize()
-        bprof = kernel_profile(bctx, lambda: bctx.assemble_dev(tbXc.data_ptr(), tbY.data_ptr()), 20)
+        bprof = kernel_profile(bctx, lambda: bctx.assemble_dev(tbXc.data_ptr(), tbY.data_ptr()), 100)
         bcnt = bctx.counters()
         basm = sum(v[2] for v in bprof.values())
         bdom = max(bprof.items(), key=lambda kv: kv[1][2])

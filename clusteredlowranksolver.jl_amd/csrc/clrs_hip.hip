@@ -173,7 +173,7 @@ struct clrs_ctx {
     bool q_slabs = false;     // k_cluster_factor leaves per-cluster partial Q slabs
     Plan p_cholQ_slabs, p_solve_all;
     bool fused_fs = false, fused_q = false, fused_x = false, all_assemble_fused = false;
-    bool factored = false, assembled = false;
+    bool factored = false, assembled = false, local_factored = false;
     bool timing = false, graph_mode = false;
     hipEvent_t ev[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     double times[6] = {0, 0, 0, 0, 0, 0};
@@ -702,8 +702,9 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
     CK(dmalloc(c, &c->d_Xc, c->xylen)); CK(dmalloc(c, &c->d_Y, c->xylen)); CK(dmalloc(c, &c->d_X, c->xylen));
     CK(dmalloc(c, &c->d_TY, tyo)); CK(dmalloc(c, &c->d_G, go)); CK(dmalloc(c, &c->d_TT, tto)); CK(dmalloc(c, &c->d_Sd, sdo));
     CK(dmalloc(c, &c->d_S, c->Slen));
-    CK(dmalloc(c, &c->d_LB, c->xlen * (i64)N)); CK(dmalloc(c, &c->d_Q, (i64)N * N));
-    CK(dmalloc(c, &c->d_t, c->xlen)); CK(dmalloc(c, &c->d_u, N)); CK(dmalloc(c, &c->d_dy, N)); CK(dmalloc(c, &c->d_rhsy, N));
+    CK(dmalloc(c, &c->d_LB, c->xlen * (i64)N)); CK(dmalloc(c, &c->d_Q, (i64)N * N + N));
+    c->d_u = c->d_Q + (i64)N * N;      // u directly behind Q: a sharded caller sums both partials over the ranks with ONE collective
+    CK(dmalloc(c, &c->d_t, c->xlen)); CK(dmalloc(c, &c->d_dy, N)); CK(dmalloc(c, &c->d_rhsy, N));
     CK(dmalloc(c, &c->d_dx, c->xlen)); CK(dmalloc(c, &c->d_rhsx, c->xlen));
     CK(dmalloc(c, &c->d_AY, T));
     {   // B stacked: rows = all constraints (cluster after cluster), columns = free variables; ld = xlen
@@ -1699,7 +1700,7 @@ extern "C" int clrs_schur_assemble_dev(clrs_ctx *c, const double *d_Xchol, const
     int rc = run_plan(c, c->p_assemble);
     if (rc) return rc;
     if (c->timing) HIPCHECK(hipEventRecord(c->ev[1], c->stream));
-    c->assembled = true; c->factored = false;
+    c->assembled = true; c->factored = false; c->local_factored = false;
     return 0;
 }
 
@@ -1729,6 +1730,8 @@ extern "C" int clrs_schur_factor_local_dev(clrs_ctx *c) {
     if ((rc = run_plan(c, c->p_Q))) return rc;
     if (c->timing) HIPCHECK(hipEventRecord(c->ev[5], c->stream));
     c->assembled = false;  // S now holds L
+    c->factored = false;
+    c->local_factored = true;      // L_j and LinvB_j are ready: clrs_schur_solve_fwd_dev may run before Q is summed and factored
     return 0;
 }
 
@@ -1824,7 +1827,7 @@ extern "C" int clrs_get_factor(clrs_ctx *c, double *L, double *LinvB, double *LQ
 
 extern "C" int clrs_schur_solve_fwd_dev(clrs_ctx *c, const double *d_rhs_x) {
     if (!c || !d_rhs_x) return fail(CLRS_ERR_INVALID, "null argument");
-    if (!c->factored) return fail(CLRS_ERR_STATE, "clrs_schur_solve called before clrs_schur_factor");
+    if (!c->factored && !c->local_factored) return fail(CLRS_ERR_STATE, "clrs_schur_solve called before clrs_schur_factor");
     HIPCHECK(hipSetDevice(c->device));
     if (c->fused_fs) c->bind_rhsx = d_rhs_x;
     else if (d_rhs_x != c->d_rhsx) HIPCHECK(hipMemcpyAsync(c->d_rhsx, d_rhs_x, sizeof(double) * c->xlen, hipMemcpyDeviceToDevice, c->stream));

@@ -81,8 +81,10 @@ class HipLocal:
             self.ctx.set_graph_mode(True)
         N = shard.n_free
         dev = f"cuda:{device}"
-        self.q = torch.as_tensor(_DevArray(self.ctx.q_buffer(), max(N * N, 1)), device=dev)[:N * N]
-        self.u = torch.as_tensor(_DevArray(self.ctx.u_buffer(), max(N, 1)), device=dev)[:N]
+        # Q (N x N) and u (N) are one device buffer (include/clrs_hip.h): `qu` is what a merged exchange reduces
+        self.qu = torch.as_tensor(_DevArray(self.ctx.q_buffer(), max(N * N + N, 1)), device=dev)[:N * N + N]
+        self.q, self.u = self.qu[:N * N], self.qu[N * N:]
+        assert N == 0 or self.ctx.u_buffer() == self.ctx.q_buffer() + 8 * N * N
 
     def cholesky_blocks(self, X, Xchol):
         self.ctx.cholesky_blocks_dev(X.data_ptr(), Xchol.data_ptr())
@@ -128,7 +130,7 @@ class ShardedSchur:
     process group (None = default group; with world == 1 no collective is issued)."""
 
     def __init__(self, flat: FlatSDP, rank: int, world: int, local_factory, group=None,
-                 parts: Optional[Sequence[Sequence[int]]] = None, force_split: bool = False):
+                 parts: Optional[Sequence[Sequence[int]]] = None, force_split: bool = False, defer_q: bool = True):
         self.full = flat
         self.rank, self.world = rank, world
         self.force_split = force_split      # exercise the split-phase calls + collectives even with one rank
@@ -139,6 +141,8 @@ class ShardedSchur:
         self.local = local_factory(self.shard)
         self.group = group
         self.N = flat.n_free
+        self.defer_q = defer_q
+        self._q = None                           # partial Q whose exchange is still pending
 
     # -- index helpers ---------------------------------------------------------------------------
     def xy_slices(self):
@@ -171,22 +175,37 @@ class ShardedSchur:
         if self.world == 1 and not self.force_split and hasattr(self.local, "factor_all"):
             self.local.factor_all()
             return
-        q = self.local.factor_local()
-        self._all_reduce(q)                      # Q = sum over ranks of the partial Q
-        self.local.factor_finish()
+        self._q = self.local.factor_local()      # partial Q of this rank; its exchange is deferred to the first solve (or to status())
+        if not self.defer_q:
+            self._finish_factor()
+
+    def _finish_factor(self):
+        if self._q is not None:
+            self._all_reduce(self._q)            # Q = sum over ranks of the partial Q
+            self.local.factor_finish()
+            self._q = None
 
     def solve(self, rhs_x, rhs_y, dx, dy):
-        """Solve stage of compute_search_direction! (src/solver.jl:1527-1582): rhs_x, dx sharded; rhs_y, dy replicated."""
+        """Solve stage of compute_search_direction! (src/solver.jl:1527-1582): rhs_x, dx sharded; rhs_y, dy replicated.
+        The first solve after a factorisation also carries the exchange of Q: both Q and u = sum_j LinvB_j^T t_j are needed at the
+        same point (dy = Q^-1 (rhs_y - u)), t_j needs only the cluster-local factors, so ONE all-reduce of [Q | u] replaces two."""
         if self.world == 1 and not self.force_split and hasattr(self.local, "solve_all"):
             self.local.solve_all(rhs_x, rhs_y, dx, dy)
             return
         u = self.local.solve_fwd(rhs_x)
-        self._all_reduce(u)                      # u = sum over ranks of LinvB_j^T t_j
+        if self._q is not None and getattr(self.local, "qu", None) is not None:
+            self._all_reduce(self.local.qu)      # [Q | u] in one collective
+            self.local.factor_finish()
+            self._q = None
+        else:
+            self._finish_factor()
+            self._all_reduce(u)                  # u = sum over ranks of LinvB_j^T t_j
         self.local.solve_bwd(rhs_y, dx, dy)
 
     def status(self) -> int:
         """Factorisation status over all ranks: 0, or the smallest failing code in GLOBAL cluster numbering
         (j+1 for S_j, n_clusters+1 for Q), like clrs_schur_factor."""
+        self._finish_factor()                    # a pending Q is exchanged and factored now
         st = self.local.status()
         J_local, J = self.shard.n_clusters, self.full.n_clusters
         if st > 0:

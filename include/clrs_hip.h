@@ -106,7 +106,11 @@ int clrs_get_unique_counts(const clrs_ctx *ctx, int32_t block, int32_t r, int32_
  * context from the sub-description holding only ITS clusters (all N free variables), calls
  * clrs_schur_factor_local_dev, sums the partial Q (clrs_q_buffer_dev) over ranks with one RCCL
  * all-reduce and calls clrs_schur_factor_finish_dev; the solve is split the same way around the
- * all-reduce of the partial u = LinvB^T t (clrs_u_buffer_dev). */
+ * all-reduce of the partial u = LinvB^T t (clrs_u_buffer_dev).  clrs_schur_solve_fwd_dev may be called right after
+ * clrs_schur_factor_local_dev (it needs only L_j and LinvB_j), and the u buffer lies directly behind the Q buffer
+ * (clrs_u_buffer_dev == clrs_q_buffer_dev + N * N): the exchange of Q can be deferred to the first solve after a
+ * factorisation and merged with that solve's exchange of u into ONE all-reduce of N * N + N doubles, followed by
+ * clrs_schur_factor_finish_dev and clrs_schur_solve_bwd_dev (clrs_amd.sharded.ShardedSchur does this). */
 
 /* Lower Cholesky factors of all X blocks: Xchol_blk = chol(X_blk).
  * Replaces: the approx_cholesky!(X_inv_blk, X_blk) loop, src/solver.jl:388-399.

@@ -14,8 +14,8 @@ class NumpyLocal:
         self.flat = shard
         self.o = Oracle(shard, quad=False)
         self.N = shard.n_free
-        self.q = torch.zeros(self.N * self.N, dtype=torch.float64)
-        self.u = torch.zeros(self.N, dtype=torch.float64)
+        self.qu = torch.zeros(self.N * self.N + self.N, dtype=torch.float64)      # [Q | u] in one buffer, like HipLocal
+        self.q, self.u = self.qu[:self.N * self.N], self.qu[self.N * self.N:]
         self.st = 0
 
     def _B(self, j):

@@ -467,6 +467,65 @@ def test_split_phase_device_api_two_shards_on_one_gpu(oracle_built):
         sh.close()
 
 
+@pytest.mark.parametrize("name", ["ns_8_3_2", "ce_8_15_well"])
+def test_merged_exchange_order_two_shards_on_one_gpu(name, oracle_built):
+    """The order ShardedSchur uses by default: factor_local, solve_fwd, ONE exchange of the contiguous [Q | u] buffer,
+    factor_finish, solve_bwd -- two 'ranks' in one process on one GPU, the all-reduce replaced by a sum by hand; then a second
+    solve (u alone) through the same objects."""
+    import torch
+    from clrs_amd.sharded import HipLocal, ShardedSchur
+    from oracle.oracle import Oracle
+    f = flat("ce_8_3" if name == "ce_8_15_well" else name)
+    X, Y = spd_iterates(f, seed=43)
+    Xc = chol_blocks_np(f, X)
+    rng = np.random.default_rng(44)
+    rx, ry = rng.standard_normal(f.x_len), rng.standard_normal(f.n_free)
+    torch.cuda.set_device(0)
+    dev = "cuda:0"
+    ranks = [ShardedSchur(f, r, 2, lambda s: HipLocal(s, 0)) for r in range(2)]
+    bufs = [sh.local.qu for sh in ranks]
+
+    def fake_all_reduce(t):                      # called by rank 1 last: every buffer becomes the sum
+        if t.data_ptr() == bufs[1].data_ptr() or t.data_ptr() == ranks[1].local.u.data_ptr():
+            n, off = t.numel(), (0 if t.data_ptr() == bufs[1].data_ptr() else f.n_free * f.n_free)
+            total = bufs[0][off:off + n] + bufs[1][off:off + n]
+            for b in bufs:
+                b[off:off + n].copy_(total)
+    for sh in ranks:
+        sh._all_reduce = fake_all_reduce
+        sh.force_split = True
+    o = Oracle(f)
+    o.schur_assemble(Xc, Y)
+    assert o.schur_factor() == 0
+    dx_ref, dy_ref = o.schur_solve(rx, ry)
+    txs = [torch.from_numpy(sh.take_x(rx)).to(dev) for sh in ranks]
+    t_y = torch.from_numpy(ry).to(dev)
+    for sh in ranks:
+        sh.local.assemble(torch.from_numpy(sh.take_xy(Xc)).to(dev), torch.from_numpy(sh.take_xy(Y)).to(dev))
+        sh._q = sh.local.factor_local()
+    for rep in range(2):
+        # the two ranks step through solve() in lock step: fwd on both, exchange, finish + bwd on both
+        us = [sh.local.solve_fwd(tx) for sh, tx in zip(ranks, txs)]
+        if rep == 0:
+            fake_all_reduce(bufs[1])
+            for sh in ranks:
+                sh.local.factor_finish()
+                sh._q = None
+                assert sh.local.status() == 0
+        else:
+            fake_all_reduce(us[1])
+        for sh in ranks:
+            dx = torch.empty(sh.shard.x_len, dtype=torch.float64, device=dev)
+            dy = torch.empty(f.n_free, dtype=torch.float64, device=dev)
+            sh.local.solve_bwd(t_y, dx, dy)
+            torch.cuda.synchronize()
+            ref = np.concatenate([dx_ref[f.cluster_off[j]:f.cluster_off[j + 1]] for j in sh.clusters])
+            assert np.max(np.abs(dx.cpu().numpy() - ref)) <= 1e-7 * max(1.0, np.max(np.abs(dx_ref))), rep
+            assert np.max(np.abs(dy.cpu().numpy() - dy_ref)) <= 1e-7 * max(1.0, np.max(np.abs(dy_ref))), rep
+    for sh in ranks:
+        sh.close()
+
+
 def test_cholesky_blocks_device_entry():
     import torch
     from clrs_amd.solver import SchurContext

@@ -22,7 +22,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, name, negate_block, ret):
+def _worker(rank, world, port, name, negate_block, ret, solve_first=False):
     sys.path.insert(0, ROOT)
     import clrs_amd  # noqa: F401
     from clrs_amd.sharded import ShardedSchur
@@ -41,20 +41,32 @@ def _worker(rank, world, port, name, negate_block, ret):
         sh.decompose(torch.from_numpy(sh.take_xy(Xc)), torch.from_numpy(sh.take_xy(Y)))
         dx = torch.zeros(sh.shard.x_len, dtype=torch.float64)
         dy = torch.zeros(f.n_free, dtype=torch.float64)
-        st = sh.status()
-        if st == 0:
+        if solve_first:      # the exchange of Q rides on the first solve's all-reduce of u (one collective for [Q | u])
+            calls = []
+            orig = sh._all_reduce
+            sh._all_reduce = lambda t: (calls.append(t.numel()), orig(t))[1]
             sh.solve(torch.from_numpy(sh.take_x(rx)), torch.from_numpy(ry), dx, dy)
+            assert calls == [f.n_free * f.n_free + f.n_free], calls
+            dx2, dy2 = torch.zeros_like(dx), torch.zeros_like(dy)
+            sh.solve(torch.from_numpy(sh.take_x(rx)), torch.from_numpy(ry), dx2, dy2)      # second solve: u alone
+            assert calls[1:] == [f.n_free], calls
+            assert torch.equal(dx, dx2) and torch.equal(dy, dy2)
+            st = sh.status()
+        else:
+            st = sh.status()
+            if st == 0:
+                sh.solve(torch.from_numpy(sh.take_x(rx)), torch.from_numpy(ry), dx, dy)
         ret[rank] = dict(clusters=sh.clusters, dx=dx.numpy().copy(), dy=dy.numpy().copy(), status=st)
     finally:
         dist.destroy_process_group()
 
 
-def _run(name, world=2, negate_block=None):
+def _run(name, world=2, negate_block=None, solve_first=False):
     port = _free_port()
     ctx = mp.get_context("spawn")
     with ctx.Manager() as mgr:
         ret = mgr.dict()
-        procs = [ctx.Process(target=_worker, args=(r, world, port, name, negate_block, ret)) for r in range(world)]
+        procs = [ctx.Process(target=_worker, args=(r, world, port, name, negate_block, ret, solve_first)) for r in range(world)]
         for p in procs:
             p.start()
         for p in procs:
@@ -63,8 +75,9 @@ def _run(name, world=2, negate_block=None):
         return {k: dict(v) for k, v in ret.items()}
 
 
+@pytest.mark.parametrize("solve_first", [False, True], ids=["status_then_solve", "merged_exchange"])
 @pytest.mark.parametrize("name", ["ns_8_3_2", "ce_8_3"])
-def test_sharded_equals_single_process(name, oracle_built):
+def test_sharded_equals_single_process(name, solve_first, oracle_built):
     from oracle.oracle import Oracle
     from tests.util import chol_blocks_np, flat, spd_iterates
     f = flat(name)
@@ -76,7 +89,7 @@ def test_sharded_equals_single_process(name, oracle_built):
     o.schur_assemble(Xc, Y)
     assert o.schur_factor() == 0
     dx_ref, dy_ref = o.schur_solve(rx, ry)
-    res = _run(name)
+    res = _run(name, solve_first=solve_first)
     seen = []
     for r in range(2):
         assert res[r]["status"] == 0
