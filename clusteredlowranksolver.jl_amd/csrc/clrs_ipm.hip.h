@@ -29,7 +29,7 @@ struct IBlock {
     int URt, ULt;         // expanded right / left unique vectors
     int T, cnt;           // terms (low rank) / matrices (dense)
     int xoff;             // offset of the block's cluster in the x layout
-    int pad;
+    int wmfma;            // low rank: sum_i a_i A_i as one MFMA contraction over the terms (its LDS operands fit: host plan)
     long long xyoff;      // offset in the X/Y layout
     long long vr_off, wl_off;   // static arena: V (n x URt), W (n x ULt), ld n (equal when the tables coincide)
     long long t0;         // first term of the block (original term order)
@@ -189,6 +189,47 @@ __global__ __launch_bounds__(256) void k_ipm_pre(const IpmBuf q) {
 __device__ __forceinline__ void ipm_weighted(const IpmBuf &q, const IBlock &k, const double *a, double *M, int lda, double *work, int tid) {
     const int n = k.n;
     const int i16 = tid & 15, j16 = tid >> 4;
+    if (k.kind == 0 && k.wmfma) {
+        // M = (W diag(coef))_gathered V_gathered^T as one contraction over the terms: A[t, i] = coef_t W[i, ayL_t], B[t, j] = V[j, ayR_t]
+        // (K x M operands of lds_gemm_tn, zero padded to 4 terms / 16 columns), 16 x 16 x 4 MFMA tiles instead of T FMAs per entry
+        const int T = k.T, T4 = (T + 3) & ~3, ldt = ((T + 15) & ~15) + 2, n16 = (n + 15) & ~15;
+        double *At = work, *Bt = At + ldt * n16, *coef = Bt + ldt * n16;
+        int *tl = (int *)(coef + T4), *tr = tl + T4;
+        for (int t = tid; t < T4; t += 256) {
+            const bool in = t < T;
+            const long long g = k.t0 + (in ? t : 0);
+            const double cf = a[k.xoff + q.term_p[g]] * q.term_lam[g];
+            const int l = q.ayL[g], r = q.ayR[g];
+            coef[t] = in ? cf : 0.0;
+            tl[t] = l;
+            tr[t] = r;
+        }
+        __syncthreads();
+        const double *Vg = q.stat + k.vr_off, *Wg = q.stat + k.wl_off;
+        for (int e0 = 0; e0 < T4 * n16; e0 += 4 * 256) {
+            double wv[4], vv[4];
+            bool in[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {          // i fastest: coalesced columns of W / V; all loads of a batch before the first store
+                const int e = e0 + u * 256 + tid, i = e % n16, t = min(e / n16, T4 - 1);
+                in[u] = e < T4 * n16 && i < n;
+                wv[u] = Wg[(in[u] ? i : 0) + (long long)tl[t] * n];
+                vv[u] = Vg[(in[u] ? i : 0) + (long long)tr[t] * n];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int e = e0 + u * 256 + tid, i = e % n16, t = e / n16;
+                if (e < T4 * n16) {
+                    At[t + i * ldt] = in[u] ? coef[t] * wv[u] : 0.0;
+                    Bt[t + i * ldt] = in[u] ? vv[u] : 0.0;
+                }
+            }
+        }
+        __syncthreads();
+        lds_gemm_tn(At, ldt, Bt, ldt, M, lda, n, n, T, tid >> 6, 4, tid & 63);
+        __syncthreads();
+        return;
+    }
     if (k.kind == 0) {
         // stage V, W and the per-term coefficients
         const double *Vg = q.stat + k.vr_off, *Wg = q.stat + k.wl_off;
