@@ -58,7 +58,7 @@ static int g_cfg_wave3_assemble = 1;   // register-resident form of the cluster-
 static int g_cfg_dense_block = 1;
 static int g_cfg_factor_small = 1;      // factor + Q in one launch of one workgroup for <= 4 small clusters (0: k_cluster_factor + k_small_potrf)
 static int g_cfg_solve_small_max = 32768;     // one-workgroup solve stage only up to this many doubles of operands (beyond: one workgroup per cluster, three launches)
-static int g_cfg_ipm_wmfma = 1;         // device interior-point loop: sum_i a_i A_i of a low-rank block as an MFMA contraction over its terms (0: per-entry loops)
+static int g_cfg_ipm_wmfma = 3;         // device interior-point loop, bit 0: sum_i a_i A_i of a low-rank block as an MFMA contraction over its terms; bit 1: Z V by MFMA (0: per-entry loops)
 static int g_cfg_solve_small2 = 1;     // one-workgroup solve stage with all loads up front and single-wave triangular solves (0: k_solve_small)
 static const int LDS_BUDGET_DOUBLES = 20000;   // of the 20480 doubles (160 KiB) a workgroup may claim
 

@@ -29,7 +29,7 @@ struct IBlock {
     int URt, ULt;         // expanded right / left unique vectors
     int T, cnt;           // terms (low rank) / matrices (dense)
     int xoff;             // offset of the block's cluster in the x layout
-    int wmfma;            // low rank: sum_i a_i A_i as one MFMA contraction over the terms (its LDS operands fit: host plan)
+    int wmfma;            // low rank, bit 0: sum_i a_i A_i as one MFMA contraction over the terms; bit 1: Z V by MFMA in k_ipm_Z (their LDS operands fit: host plan)
     long long xyoff;      // offset in the X/Y layout
     long long vr_off, wl_off;   // static arena: V (n x URt), W (n x ULt), ld n (equal when the tables coincide)
     long long t0;         // first term of the block (original term order)
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void k_ipm_pre(const IpmBuf q) {
 __device__ __forceinline__ void ipm_weighted(const IpmBuf &q, const IBlock &k, const double *a, double *M, int lda, double *work, int tid) {
     const int n = k.n;
     const int i16 = tid & 15, j16 = tid >> 4;
-    if (k.kind == 0 && k.wmfma) {
+    if (k.kind == 0 && (k.wmfma & 1)) {
         // M = (W diag(coef))_gathered V_gathered^T as one contraction over the terms: A[t, i] = coef_t W[i, ayL_t], B[t, j] = V[j, ayR_t]
         // (K x M operands of lds_gemm_tn, zero padded to 4 terms / 16 columns), 16 x 16 x 4 MFMA tiles instead of T FMAs per entry
         const int T = k.T, T4 = (T + 3) & ~3, ldt = ((T + 15) & ~15) + 2, n16 = (n + 15) & ~15;
@@ -465,6 +465,38 @@ __global__ __launch_bounds__(256) void k_ipm_Z(const IpmBuf q, const IpmParams p
     if (k.kind == 0) {
         // pairings: AZ[t] = W[:, ayL_t]^T Z V[:, ayR_t]   (TZ = Z V column by column, then dots)
         const double *Vg = q.stat + k.vr_off, *Wg = q.stat + k.wl_off;
+        if (k.wmfma & 2) {
+            // TZ = Z V as one MFMA product (Z symmetric and zero padded in As; V staged zero padded), then one dot product per term
+            const int UR16 = (k.URt + 15) & ~15;
+            double *Vs = work, *TZ = Vs + lda * UR16;
+            for (int e0 = 0; e0 < lda * UR16; e0 += 4 * 256) {
+                double vv4[4];
+                bool in[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int e = e0 + u * 256 + tid, i = e % lda, j = e / lda;
+                    in[u] = e < lda * UR16 && i < n && j < k.URt;
+                    vv4[u] = Vg[in[u] ? i + (long long)j * n : 0];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int e = e0 + u * 256 + tid;
+                    if (e < lda * UR16) Vs[e] = in[u] ? vv4[u] : 0.0;
+                }
+            }
+            __syncthreads();
+            lds_gemm_tn(As, lda, Vs, lda, TZ, lda, n, k.URt, n, wave, 4, lane);
+            __syncthreads();
+            for (int t = tid; t < k.T; t += 256) {
+                const double *w = Wg + (long long)q.ayL[k.t0 + t] * n, *tz = TZ + q.ayR[k.t0 + t] * lda;
+                double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+                int i = 0;
+                for (; i + 4 <= n; i += 4) { s0 += w[i] * tz[i]; s1 += w[i + 1] * tz[i + 1]; s2 += w[i + 2] * tz[i + 2]; s3 += w[i + 3] * tz[i + 3]; }
+                for (; i < n; i++) s0 += w[i] * tz[i];
+                q.AZ[k.t0 + t] = (s0 + s1) + (s2 + s3);
+            }
+            return;
+        }
         double *TZ = work;                       // n x URt
         for (int e = tid; e < n * k.URt; e += 256) {
             const int i = e % n, u = e / n;
@@ -553,14 +585,86 @@ __global__ __launch_bounds__(256) void k_ipm_dXdY(const IpmBuf q, int corrector)
     }
 }
 
+// Householder tridiagonalisation of a symmetric n x n matrix (n <= NC <= 32) inside ONE wave with the matrix in REGISTERS: lane r
+// holds row r (NC doubles, static indices: the loop over the columns is fully unrolled), the entries of v and w reach the other lanes
+// through v_readlane (SGPR operands of the FMAs), the norms and dot products through DPP butterflies.  Nothing goes through LDS in
+// the n - 2 dependent steps (the LDS form below, kept for n > 32, spends 2.4k cycles per step on its strided row reads: 46k of the
+// 97k cycles of k_ipm_step for n = 21).  d -> dd[0..n), e -> ee[0..n-1).
+typedef double v2d_ipm __attribute__((ext_vector_type(2)));
+template <int NC>
+__device__ __forceinline__ void ipm_householder_regs(const double *Ws, int lda, int n, double *dd, double *ee, int lane) {
+    double a[NC];
+    const int r = lane < NC ? lane : 0;
+#pragma unroll
+    for (int j = 0; j < NC; j += 2) {                      // row r = column r (both triangles are kept): contiguous, 16-byte aligned
+        const v2d_ipm t = *(const v2d_ipm *)(Ws + r * lda + j);
+        a[j] = t[0];
+        a[j + 1] = t[1];
+    }
+    const bool rowok = lane < n;
+#pragma unroll
+    for (int j = 0; j < NC; j++) a[j] = (rowok && j < n) ? a[j] : 0.0;
+#pragma unroll
+    for (int c = 0; c < NC - 2; c++) {
+        if (c < n - 2) {                                    // uniform
+            const double xi = (lane > c) ? a[c] : 0.0;      // column c below the diagonal (rows >= n hold zeros)
+            const double ss = wave_sum(xi * xi);
+            const double x0 = readlane_f64(xi, c + 1);
+            if (ss == 0.0) {
+                if (lane == 0) ee[c] = 0.0;
+            } else {
+                // |x| = ss * rsqrt(ss) with two Newton steps, tau = 2 / v^T v by reciprocal + Newton: the IEEE sqrt and division are ~60
+                // dependent instructions per step.  H = I - tau v v^T is orthogonal for ANY alpha as long as tau = 2 / v^T v for the v in
+                // use; an alpha that is |x| only to an ulp leaves an entry of that size where a zero is assumed, like rounding does.
+                double rs = __builtin_amdgcn_rsq(ss);
+                rs = rs * __builtin_fma(-0.5 * ss * rs, rs, 1.5);
+                rs = rs * __builtin_fma(-0.5 * ss * rs, rs, 1.5);
+                const double nrm = ss * rs;
+                const double alpha = (x0 > 0.0) ? -nrm : nrm;
+                const double v0 = x0 - alpha;
+                const double vi = (lane == c + 1) ? v0 : xi;
+                const double vtv = ss - x0 * x0 + v0 * v0;
+                double rt = __builtin_amdgcn_rcp(vtv);
+                rt = __builtin_fma(__builtin_fma(-vtv, rt, 1.0), rt, rt);
+                rt = __builtin_fma(__builtin_fma(-vtv, rt, 1.0), rt, rt);
+                const double tau = 2.0 * rt;
+                double pa = 0.0, pb = 0.0, pc2 = 0.0, pd = 0.0;          // four partial sums: the FMAs of one chain wait on each other
+#pragma unroll
+                for (int j = c + 1; j < NC; j++) {
+                    const double vj = readlane_f64(vi, j);
+                    if (((j - c - 1) & 3) == 0) pa = __builtin_fma(a[j], vj, pa);
+                    else if (((j - c - 1) & 3) == 1) pb = __builtin_fma(a[j], vj, pb);
+                    else if (((j - c - 1) & 3) == 2) pc2 = __builtin_fma(a[j], vj, pc2);
+                    else pd = __builtin_fma(a[j], vj, pd);
+                }
+                double pi = (pa + pb) + (pc2 + pd);
+                pi = (lane > c) ? pi * tau : 0.0;
+                const double kk = wave_sum(pi * vi);
+                const double wi = pi - 0.5 * tau * kk * vi;
+#pragma unroll
+                for (int j = c + 1; j < NC; j++) a[j] -= vi * readlane_f64(wi, j) + wi * readlane_f64(vi, j);
+                if (lane == 0) ee[c] = alpha;
+            }
+        }
+    }
+    double dv = 0.0, ev = 0.0;
+#pragma unroll
+    for (int j = 0; j < NC; j++) {
+        dv = (lane == j) ? a[j] : dv;
+        ev = (j == n - 2) ? a[j] : ev;
+    }
+    if (lane < n) dd[lane] = dv;
+    ev = readlane_f64(ev, n - 1);
+    if (lane == 0) ee[n - 2] = ev;
+}
+
 // ---- k_ipm_step: smallest eigenvalue of L^-1 dM L^-T, M in {X, Y} ---------------------------------------------------------------
 // grid = 2 NB: workgroup 2b handles (X, dX), 2b+1 handles (Y, dY).  Cholesky of M, two triangular solves, Householder
 // tridiagonalisation in LDS, Sturm-count multisection with one shift per thread (256-section per round).
 __global__ __launch_bounds__(256) void k_ipm_step(const IpmBuf q) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ double red[4];
-    __shared__ double sh_lo, sh_hi;
-    __shared__ int cnts[257];
+    __shared__ int zc[2][4];
     const int b = blockIdx.x >> 1, which = blockIdx.x & 1;
     const IBlock k = q.blocks[b];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = k.n, n16 = (n + 15) & ~15, lda = n16 + 2;
@@ -608,7 +712,13 @@ __global__ __launch_bounds__(256) void k_ipm_step(const IpmBuf q) {
     // Householder tridiagonalisation inside ONE wave (n <= 64): lane i owns row c+1+i of the trailing matrix, the vector v and
     // w go through LDS as broadcasts, the norms and dot products through wave butterflies -- no workgroup barriers in the
     // n-2 dependent steps.  Both triangles of the trailing matrix are kept.
-    if (wave == 0) {
+    const bool in_regs = n <= 32;
+    if (wave == 0 && in_regs) {
+        if (n <= 16) ipm_householder_regs<16>(Ws, lda, n, dd, ee, lane);
+        else if (n <= 24) ipm_householder_regs<24>(Ws, lda, n, dd, ee, lane);
+        else ipm_householder_regs<32>(Ws, lda, n, dd, ee, lane);
+    }
+    if (wave == 0 && !in_regs) {
         for (int c = 0; c < n - 2; c++) {
             const int m = n - c - 1;                    // rows c+1 .. n-1 <-> lanes 0 .. m-1
             const double xi = (lane < m) ? Ws[(c + 1 + lane) + c * lda] : 0.0;
@@ -658,16 +768,9 @@ __global__ __launch_bounds__(256) void k_ipm_step(const IpmBuf q) {
     }
     __syncthreads();
     IPM_STAMP(5);
-    if (tid < n) dd[tid] = Ws[tid + tid * lda];
-    if (tid == 0) ee[n - 2] = Ws[(n - 1) + (n - 2) * lda];
-    __syncthreads();
-    // squared off-diagonals and padding for the Sturm recurrence: steps beyond n see d = +huge, e = 0 and count nothing
-    {
-        double *d2 = vv, *e2s = pp;           // 72 doubles each, free after the tridiagonalisation
-        if (tid < 72) {
-            d2[tid] = (tid < n) ? dd[tid] : 1e300;
-            e2s[tid] = (tid >= 1 && tid < n) ? ee[tid - 1] * ee[tid - 1] : 0.0;
-        }
+    if (!in_regs) {
+        if (tid < n) dd[tid] = Ws[tid + tid * lda];
+        if (tid == 0) ee[n - 2] = Ws[(n - 1) + (n - 2) * lda];
     }
     __syncthreads();
     // Gershgorin interval
@@ -679,41 +782,72 @@ __global__ __launch_bounds__(256) void k_ipm_step(const IpmBuf q) {
     }
     lo = -block_reduce_max(-lo, red);
     hi = block_reduce_max(hi, red);
-    // multisection for the smallest eigenvalue: count(s) = number of eigenvalues < s
-    const double scale = fmax(fabs(lo), fabs(hi));
-    lo -= 1e-3 * scale + 1e-300;
-    hi += 1e-3 * scale + 1e-300;
-    for (int round = 0; round < 7; round++) {      // 257^7 > 1e16: the bracket shrinks to rounding level
-        const double h = (hi - lo) / 257.0;
-        const double sft = lo + h * (tid + 1);
-        int cnt = 0;
-        double qv = vv[0] - sft;
-        cnt += (qv < 0.0) ? 1 : 0;
-        const int n8 = 1 + ((n - 1 + 7) & ~7);
-        for (int i0 = 1; i0 < n8; i0 += 8) {      // d and e^2 of 8 steps are fetched together, then the dependent chain runs from registers
-            double dv[8], e2[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) { dv[u] = vv[i0 + u]; e2[u] = pp[i0 + u]; }
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                qv = (qv == 0.0) ? 1e-300 : qv;
-                double rq = __builtin_amdgcn_rcp(qv);              // v_rcp_f64 + one Newton step: ~1e-16 relative, a fraction of the cost
-                rq = __builtin_fma(__builtin_fma(-qv, rq, 1.0), rq, rq);   // of an IEEE division; only the SIGN of the pivots is used
-                qv = dv[u] - sft - e2[u] * rq;
-                cnt += (qv < 0.0) ? 1 : 0;
-            }
+    // Sturm sequence in product form, p_{i+1} = (d_i - s) p_i - e_{i-1}^2 p_{i-1}: the number of sign changes is the number of eigenvalues
+    // below s.  No division on the dependent chain (one FMA per step instead of reciprocal + Newton + FMA: 23k -> cycles of the
+    // seven rounds); d and e are scaled by a power of two (exact) so that |d - s| <= 2, e^2 <= 1, and the pair (p_i, p_{i-1}) is
+    // renormalised by a power of two every four steps, so nothing overflows or underflows for n <= 64.
+    const double scale = fmax(fmax(fabs(lo), fabs(hi)), 1e-290);
+    const int sexp = __builtin_amdgcn_frexp_exp(scale);           // scale < 2^sexp
+    {
+        double *d2 = vv, *e2s = pp;           // 72 doubles each, free after the tridiagonalisation
+        if (tid < 72) {
+            d2[tid] = (tid < n) ? ldexp(dd[tid], -sexp) : 0.0;
+            const double es = (tid >= 1 && tid < n) ? ldexp(ee[tid - 1], -sexp) : 0.0;
+            e2s[tid] = es * es;
         }
-        cnts[tid + 1] = cnt;
-        if (tid == 0) cnts[0] = 0;
-        __syncthreads();
-        // the smallest eigenvalue lies in the first sub-interval whose upper end has count >= 1
-        if (cnts[tid + 1] >= 1 && cnts[tid] == 0) { sh_lo = lo + h * tid; sh_hi = sft; }
-        if (tid == 0 && cnts[256] == 0) { sh_lo = lo + h * 256; sh_hi = hi; }
-        __syncthreads();
-        lo = sh_lo;
-        hi = sh_hi;
-        __syncthreads();
     }
+    lo = ldexp(lo, -sexp);
+    hi = ldexp(hi, -sexp);
+    __syncthreads();
+    // multisection for the smallest eigenvalue: count(s) = number of eigenvalues < s
+    lo -= 1e-3;
+    hi += 1e-3;
+    for (int round = 0; round < 7; round++) {      // 257^7 > 1e16: the bracket shrinks to rounding level
+        const double h = (hi - lo) * (1.0 / 257.0);      // (an IEEE division is ~35 dependent VALU operations)
+        const double sft = lo + h * (tid + 1);
+        double pm = 1.0, pc = (vv[0] - sft) + 1e-300;     // p_0, p_1
+        // sign changes counted on the sign bits with integer VALU operations (a compare pair per step would go through SGPR masks)
+        auto hi32 = [](double v) { return (unsigned)(__double_as_longlong(v) >> 32); };
+        unsigned cnt = hi32(pc) >> 31;
+        auto step = [&](double tvu, double e2u) {
+            // + 1e-300 (in the term that is off the dependent chain): an exact zero becomes a tiny positive p, from which the recurrence
+            // continues correctly whether or not the next e^2 is zero; for every other value (|p| >= 1e-70 between renormalisations) it is a no-op
+            const double pn = __builtin_fma(tvu, pc, __builtin_fma(-e2u, pm, 1e-300));
+            cnt += (hi32(pn) ^ hi32(pc)) >> 31;
+            pm = pc;
+            pc = pn;
+        };
+        int i0 = 1;
+        double dn[4], en[4];                        // the next chunk's d and e^2 (broadcast LDS reads) are in flight while this chunk's chain runs
+#pragma unroll
+        for (int u = 0; u < 4; u++) { dn[u] = vv[i0 + u]; en[u] = pp[i0 + u]; }
+        for (; i0 + 4 <= n; i0 += 4) {
+            double tv[4], e2[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { tv[u] = dn[u] - sft; e2[u] = en[u]; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) { dn[u] = vv[i0 + 4 + u]; en[u] = pp[i0 + 4 + u]; }    // 72-long buffers: no guard
+#pragma unroll
+            for (int u = 0; u < 4; u++) step(tv[u], e2[u]);
+            const int ex = __builtin_amdgcn_frexp_exp(pc);
+            pc = ldexp(pc, -ex);
+            pm = ldexp(pm, -ex);
+        }
+        if (i0 < n) step(dn[0] - sft, en[0]);          // at most three steps left (uniform)
+        if (i0 + 1 < n) step(dn[1] - sft, en[1]);
+        if (i0 + 2 < n) step(dn[2] - sft, en[2]);
+        // The counts are monotone in the shift, so the number of shifts with count 0 is the index of the sub-interval that holds the
+        // smallest eigenvalue: one ballot per wave, four numbers through LDS, ONE barrier per round (buffers alternate by round).
+        const unsigned long long zero = __ballot(cnt == 0u);
+        if (lane == 0) zc[round & 1][wave] = __popcll(zero);
+        __syncthreads();
+        const int idx = (zc[round & 1][0] + zc[round & 1][1]) + (zc[round & 1][2] + zc[round & 1][3]);
+        const double nlo = lo + h * idx;
+        hi = (idx == 256) ? hi : lo + h * (idx + 1);
+        lo = nlo;
+    }
+    lo = ldexp(lo, sexp);
+    hi = ldexp(hi, sexp);
     IPM_STAMP(6);
     if (tid == 0) q.eig[b * 2 + which] = 0.5 * (lo + hi);
 }

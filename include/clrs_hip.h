@@ -235,8 +235,9 @@ int clrs_wave2_clusters(const clrs_ctx *ctx);
  * workgroup per cluster.
  * "solve_small_max" (default 32768): the one-workgroup solve stage (k_solve_small / k_solve_small2) is used while the operands
  * of a solve (L_j, LinvB, L_Q) stay below this many doubles; beyond, one workgroup per cluster in three launches.
- * "ipm_wmfma" (default 1): the device-resident interior-point loop (clrs_ipm_*) forms sum_i a_i A_i of a low-rank block as one
- * MFMA contraction over the block's terms (operands gathered into LDS) when they fit; 0 = per-entry loops over the terms.
+ * "ipm_wmfma" (default 3): the device-resident interior-point loop (clrs_ipm_*) forms, for low-rank blocks that are large enough
+ * and whose operands fit in LDS, (bit 0) sum_i a_i A_i as one MFMA contraction over the block's terms and (bit 1) Z V for the
+ * per-term pairings as one MFMA product; 0 = per-entry loops.
  * "solve_small2" (default 1): contexts with <= 8 clusters whose factors fit in 150 KB of LDS run the solve stage as ONE launch
  * of k_solve_small2 (every operand staged in one trip to memory, one wave per triangular solve); 0 keeps k_solve_small. */
 /* Diagnostic builds (-DCLRS_FUSED_STAMPS) only: s_memtime stamps of the phases of workgroup 0 of the fused kernel. */

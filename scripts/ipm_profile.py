@@ -5,6 +5,10 @@ from tests.util import flat
 from clrs_amd.solver import solvesdp_device, SchurContext
 name = sys.argv[1] if len(sys.argv) > 1 else "polyopt40"
 f = flat(name)
+for kv in sys.argv[2:]:      # library configuration keys, e.g. ipm_wmfma=1
+    from clrs_amd import _lib
+    key, val = kv.split("=")
+    _lib.check(_lib.load().clrs_config_set(key.encode(), int(val)))
 ctx = SchurContext(f)
 solvesdp_device(f, ctx=ctx)
 t = time.time(); n = 0
