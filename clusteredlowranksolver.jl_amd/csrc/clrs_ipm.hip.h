@@ -40,7 +40,9 @@ struct IBlock {
 // scalars living in device memory (index into IpmBuf::scal)
 enum {
     SC_MU = 0, SC_MU_P, SC_MU_C, SC_BETA_C, SC_ALPHA_P, SC_ALPHA_D, SC_DOBJ, SC_POBJ, SC_GAP, SC_DUAL_ERR, SC_PRIMAL_ERR,
-    SC_PD_FEAS, SC_XY, SC_MAXP, SC_MAXp, SC_MAXd, SC_EIG_X, SC_EIG_Y, SC_ERRCODE, SC_K, SC_ITER, SC_COUNT = 32
+    SC_PD_FEAS, SC_XY, SC_MAXP, SC_MAXp, SC_MAXd, SC_EIG_X, SC_EIG_Y, SC_ERRCODE, SC_K, SC_ITER,
+    SC_INFO0 = 30, SC_INFO1 = 31,      // the library's two status words (factorisation, Cholesky of X), copied here for the host's single read
+    SC_COUNT = 32
 };
 
 struct IpmParams {
@@ -890,6 +892,7 @@ __global__ __launch_bounds__(256) void k_ipm_update(const IpmBuf q, const IpmPar
     if (threadIdx.x == 0) {
         double *pt = q.part + (long long)(row0 + blockIdx.x) * 8;
         pt[5] = cy; pt[6] = cx; pt[7] = by; pt[0] = xy;
+        if (blockIdx.x == 0) { q.scal[SC_INFO0] = (double)q.info[0]; q.scal[SC_INFO1] = (double)q.info[1]; }
     }
 }
 
