@@ -124,6 +124,13 @@ struct IpmState;
 
 struct clrs_ctx {
     int device = 0;
+    int *h_info = nullptr;                             // pinned host copy of the two status words
+    // pinned staging arena of the host-pointer entry points: a copy to or from pageable memory goes through the runtime's own
+    // staging with a synchronisation per call (10-20 us for a few KB); one memcpy into pinned memory and an async copy do not
+    char *pin = nullptr;
+    size_t pin_cap = 0, pin_used = 0, pin_demand = 0;
+    struct PinOut { void *user; const void *pinned; size_t bytes; };
+    std::vector<PinOut> pin_out;
     IpmState *ipm = nullptr;                           // device-resident interior-point iteration (clrs_ipm_*), created on demand
     std::vector<int> h_term_p, h_dense_p;              // host copies of the description arrays the IPM tables are built from
     std::vector<double> h_term_lambda;
@@ -1638,6 +1645,8 @@ extern "C" void clrs_ctx_destroy(clrs_ctx *c) {
     for (int i = 0; i < 10; i++)
         if (c->ev[i]) hipEventDestroy(c->ev[i]);
     for (hipEvent_t e : c->kt_ev) hipEventDestroy(e);
+    if (c->h_info) (void)hipHostFree(c->h_info);
+    if (c->pin) (void)hipHostFree(c->pin);
     if (c->stream && c->own_stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1661,10 +1670,57 @@ extern "C" int clrs_get_unique_counts(const clrs_ctx *c, int32_t b, int32_t r, i
 // ------------------------------------------------------------------------------------------------
 // per-iteration drivers
 // ------------------------------------------------------------------------------------------------
-static int read_info(clrs_ctx *c, int *status, int which = 0) {
-    int h = INFO_NONE;
-    HIPCHECK(hipMemcpyAsync(&h, c->d_info + which, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+static const size_t PIN_LIMIT = (size_t)64 << 20;      // beyond this the caller's buffers are copied directly (bandwidth, not latency, matters there)
+// start of a host-pointer call: the arena is empty again; it grows here (never while pointers are handed out) to what the
+// previous call asked for in total
+static void pin_reset(clrs_ctx *c) {
+    c->pin_used = 0;
+    c->pin_out.clear();
+    if (c->pin_demand > c->pin_cap && c->pin_demand <= PIN_LIMIT) {
+        const size_t cap = std::min(PIN_LIMIT, std::max<size_t>((size_t)1 << 20, 2 * c->pin_demand));
+        if (c->pin) { (void)hipHostFree(c->pin); c->pin = nullptr; c->pin_cap = 0; }
+        if (hipHostMalloc((void **)&c->pin, cap, hipHostMallocDefault) == hipSuccess) c->pin_cap = cap;
+        else c->pin = nullptr;
+    }
+    c->pin_demand = 0;
+}
+static void *pin_take(clrs_ctx *c, size_t bytes) {
+    bytes = (bytes + 63) & ~(size_t)63;
+    c->pin_demand += bytes;
+    if (c->pin_used + bytes > c->pin_cap) return nullptr;      // the caller copies directly; the next call finds a larger arena
+    void *p = c->pin + c->pin_used;
+    c->pin_used += bytes;
+    return p;
+}
+// host -> device through the arena (falls back to the direct copy when the arena cannot hold it)
+static int h2d_staged(clrs_ctx *c, void *dst, const void *src, size_t bytes) {
+    if (bytes == 0) return 0;
+    void *p = pin_take(c, bytes);
+    if (p) { std::memcpy(p, src, bytes); src = p; }
+    HIPCHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+// device -> host: lands in the arena, handed to the caller by d2h_finish after the stream has been synchronised
+static int d2h_staged(clrs_ctx *c, void *user, const void *src, size_t bytes) {
+    if (bytes == 0) return 0;
+    void *p = pin_take(c, bytes);
+    HIPCHECK(hipMemcpyAsync(p ? p : user, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    if (p) c->pin_out.push_back(clrs_ctx::PinOut{user, p, bytes});
+    return 0;
+}
+static int d2h_finish(clrs_ctx *c) {
     HIPCHECK(hipStreamSynchronize(c->stream));
+    for (const clrs_ctx::PinOut &o : c->pin_out) std::memcpy(o.user, o.pinned, o.bytes);
+    c->pin_out.clear();
+    return 0;
+}
+
+static int read_info(clrs_ctx *c, int *status, int which = 0) {
+    if (!c->h_info) HIPCHECK(hipHostMalloc((void **)&c->h_info, 2 * sizeof(int), hipHostMallocDefault));   // pinned: no staging copy behind the 4-byte read
+    c->h_info[which] = INFO_NONE;
+    HIPCHECK(hipMemcpyAsync(c->h_info + which, c->d_info + which, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    const int h = c->h_info[which];
     *status = (h == INFO_NONE) ? 0 : h;
     if (h != INFO_NONE) HIPCHECK(hipMemsetAsync(c->d_info + which, 0x7f, sizeof(int), c->stream));   // re-arm: the status is "since the last query"
     return 0;
@@ -1708,14 +1764,14 @@ extern "C" int clrs_schur_assemble_dev(clrs_ctx *c, const double *d_Xchol, const
 extern "C" int clrs_schur_assemble(clrs_ctx *c, const double *Xchol, const double *Y, double *S_out, double *AY_out) {
     if (!c || !Xchol || !Y) return fail(CLRS_ERR_INVALID, "null argument");
     HIPCHECK(hipSetDevice(c->device));
-    HIPCHECK(hipMemcpyAsync(c->d_Xc, Xchol, sizeof(double) * c->xylen, hipMemcpyHostToDevice, c->stream));
-    HIPCHECK(hipMemcpyAsync(c->d_Y, Y, sizeof(double) * c->xylen, hipMemcpyHostToDevice, c->stream));
-    int rc = clrs_schur_assemble_dev(c, c->d_Xc, c->d_Y);
-    if (rc) return rc;
-    if (S_out) HIPCHECK(hipMemcpyAsync(S_out, c->d_S, sizeof(double) * c->Slen, hipMemcpyDeviceToHost, c->stream));
-    if (AY_out && c->T > 0) HIPCHECK(hipMemcpyAsync(AY_out, c->d_AY, sizeof(double) * c->T, hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(hipStreamSynchronize(c->stream));
-    return 0;
+    int rc;
+    pin_reset(c);
+    if ((rc = h2d_staged(c, c->d_Xc, Xchol, sizeof(double) * c->xylen))) return rc;
+    if ((rc = h2d_staged(c, c->d_Y, Y, sizeof(double) * c->xylen))) return rc;
+    if ((rc = clrs_schur_assemble_dev(c, c->d_Xc, c->d_Y))) return rc;
+    if (S_out && (rc = d2h_staged(c, S_out, c->d_S, sizeof(double) * c->Slen))) return rc;
+    if (AY_out && c->T > 0 && (rc = d2h_staged(c, AY_out, c->d_AY, sizeof(double) * c->T))) return rc;
+    return d2h_finish(c);
 }
 
 extern "C" int clrs_schur_factor_local_dev(clrs_ctx *c) {
@@ -1877,17 +1933,17 @@ extern "C" int clrs_schur_solve(clrs_ctx *c, const double *rhs_x, const double *
     if (!c || !rhs_x || !dx) return fail(CLRS_ERR_INVALID, "null argument");
     if (!c->factored) return fail(CLRS_ERR_STATE, "clrs_schur_solve called before clrs_schur_factor");
     HIPCHECK(hipSetDevice(c->device));
-    HIPCHECK(hipMemcpyAsync(c->d_rhsx, rhs_x, sizeof(double) * c->xlen, hipMemcpyHostToDevice, c->stream));
+    int rc;
+    pin_reset(c);
+    if ((rc = h2d_staged(c, c->d_rhsx, rhs_x, sizeof(double) * c->xlen))) return rc;
     if (c->N > 0) {
         if (!rhs_y || !dy) return fail(CLRS_ERR_INVALID, "null argument");
-        HIPCHECK(hipMemcpyAsync(c->d_rhsy, rhs_y, sizeof(double) * c->N, hipMemcpyHostToDevice, c->stream));
+        if ((rc = h2d_staged(c, c->d_rhsy, rhs_y, sizeof(double) * c->N))) return rc;
     }
-    int rc;
     if ((rc = clrs_schur_solve_dev(c, c->d_rhsx, c->d_rhsy, c->d_dx, c->d_dy))) return rc;
-    HIPCHECK(hipMemcpyAsync(dx, c->d_dx, sizeof(double) * c->xlen, hipMemcpyDeviceToHost, c->stream));
-    if (c->N > 0) HIPCHECK(hipMemcpyAsync(dy, c->d_dy, sizeof(double) * c->N, hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(hipStreamSynchronize(c->stream));
-    return 0;
+    if ((rc = d2h_staged(c, dx, c->d_dx, sizeof(double) * c->xlen))) return rc;
+    if (c->N > 0 && (rc = d2h_staged(c, dy, c->d_dy, sizeof(double) * c->N))) return rc;
+    return d2h_finish(c);
 }
 
 extern "C" int clrs_cholesky_blocks_dev(clrs_ctx *c, const double *d_X, double *d_Xchol) {
@@ -1907,12 +1963,14 @@ extern "C" int clrs_cholesky_blocks_dev(clrs_ctx *c, const double *d_X, double *
 extern "C" int clrs_cholesky_blocks(clrs_ctx *c, const double *X, double *Xchol) {
     if (!c || !X || !Xchol) return fail(CLRS_ERR_INVALID, "null argument");
     HIPCHECK(hipSetDevice(c->device));
-    HIPCHECK(hipMemcpyAsync(c->d_X, X, sizeof(double) * c->xylen, hipMemcpyHostToDevice, c->stream));
-    int rc = clrs_cholesky_blocks_dev(c, c->d_X, c->d_X);
-    if (rc) return rc;
+    int rc;
+    pin_reset(c);
+    if ((rc = h2d_staged(c, c->d_X, X, sizeof(double) * c->xylen))) return rc;
+    if ((rc = clrs_cholesky_blocks_dev(c, c->d_X, c->d_X))) return rc;
+    if ((rc = d2h_staged(c, Xchol, c->d_X, sizeof(double) * c->xylen))) return rc;
     int st = 0;
-    if ((rc = read_info(c, &st, 1))) return rc;
-    HIPCHECK(hipMemcpy(Xchol, c->d_X, sizeof(double) * c->xylen, hipMemcpyDeviceToHost));
+    if ((rc = read_info(c, &st, 1))) return rc;          // synchronises the stream: the factors have landed as well
+    if ((rc = d2h_finish(c))) return rc;
     return st;
 }
 
