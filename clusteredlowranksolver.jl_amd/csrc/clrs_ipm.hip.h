@@ -6,11 +6,11 @@
 // kernels keep x, y, X, Y and every intermediate in HBM; the host only sequences launches and reads one small record per
 // iteration.  One workgroup per PSD block, the block LDS resident (n <= 48 here; larger blocks keep the host loop).
 //
-//   k_ipm_pre        X Y product, tr(XY), chol(X)                 src/solver.jl:369, 961-970, 388-399
-//   k_ipm_weighted   sum_i a_i A_i (+ base) per block, max |P|     compute_weighted_A! :1410-1470, :882-893
+//   k_ipm_pre        X Y product, tr(XY), chol(X); P = sum x_i A_i - X -+ C, max |P|   src/solver.jl:369, 961-970, 388-399, 882-893
+//   ipm_weighted     sum_i a_i A_i per block (device function of k_ipm_pre / k_ipm_dXdY)   compute_weighted_A! :1410-1470
 //   k_ipm_dense_dot  <A_e, M> for the dense constraint matrices    trace_A :1290-1366
-//   k_ipm_csum       per-constraint sums of the per-term traces    trace_A :1368-1407, residual d :863-879, rhs_x :1518-1523
-//   k_ipm_p          p = +-b - B^T x                               :899-916
+//   k_ipm_csum       per-constraint sums of the per-term traces    trace_A :1368-1407, residual d :863-879, rhs_x :1518-1523;
+//                    its first call of an iteration also forms p = +-b - B^T x   :899-916
 //   k_ipm_Z          Z = sym(X^-1 (P Y - R)), w^T Z v per term     compute_search_direction! :1501-1514
 //   k_ipm_dXdY       dX = P + sum dx_i A_i, dY = sym(X^-1 (R - dX Y))   :1585-1613
 //   k_ipm_step       min eig of L^-1 dM L^-T per block (Householder tridiagonalisation + Sturm multisection)  :1620-1693
@@ -144,8 +144,11 @@ __device__ __forceinline__ void ipm_potrs(const double *L, int lda, const double
     __syncthreads();
 }
 
-// ---- k_ipm_pre: XY = X Y, partial tr(XY), Xchol = chol(X) ---------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_ipm_pre(const IpmBuf q) {
+__device__ __forceinline__ void ipm_weighted(const IpmBuf &q, const IBlock &k, const double *a, double *M, int lda, double *work, int tid);
+
+// ---- k_ipm_pre: XY = X Y, partial tr(XY), Xchol = chol(X); then P = sum x_i A_i - X -+ C, max |P| (everything that depends on the
+// iterate alone: one launch; src/solver.jl:388-399, 961-983) -------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ipm_pre(const IpmBuf q, const IpmParams prm) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ double red[4];
     const IBlock k = q.blocks[blockIdx.x];
@@ -183,6 +186,18 @@ __global__ __launch_bounds__(256) void k_ipm_pre(const IpmBuf q) {
             const int i = i0 + i16, j = j0 + j16;
             if (i < n && j < n) q.Xchol[k.xyoff + i + (long long)j * n] = (i >= j) ? Xs[i + j * lda] : 0.0;
         }
+    __syncthreads();
+    // ---- P (the LDS is free again) ----
+    double *M = lds, *work = M + n * n;
+    ipm_weighted(q, k, q.x, M, n, work, tid);
+    double mx = 0.0;
+    for (int e = tid; e < n * n; e += 256) {
+        const double v = M[e] - q.X[k.xyoff + e] - prm.sgn * q.C[k.xyoff + e];
+        q.P[k.xyoff + e] = v;
+        mx = fmax(mx, fabs(v));
+    }
+    mx = block_reduce_max(mx, red);
+    if (tid == 0) q.part[blockIdx.x * 8 + 1] = mx;
 }
 
 // ---- sum_i a_i A_i of one block into LDS matrix M (n x n, ld lda), a = coefficient vector in the x layout ------------------
@@ -271,24 +286,6 @@ __device__ __forceinline__ void ipm_weighted(const IpmBuf &q, const IBlock &k, c
     __syncthreads();
 }
 
-// ---- k_ipm_P: P = sum x_i A_i - X -+ C, max |P| ----------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_ipm_P(const IpmBuf q, const IpmParams prm) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    __shared__ double red[4];
-    const IBlock k = q.blocks[blockIdx.x];
-    const int tid = threadIdx.x, n = k.n, lda = n;
-    double *M = lds, *work = M + n * n;
-    ipm_weighted(q, k, q.x, M, lda, work, tid);
-    double mx = 0.0;
-    for (int e = tid; e < n * n; e += 256) {
-        const double v = M[e] - q.X[k.xyoff + e] - prm.sgn * q.C[k.xyoff + e];
-        q.P[k.xyoff + e] = v;
-        mx = fmax(mx, fabs(v));
-    }
-    mx = block_reduce_max(mx, red);
-    if (tid == 0) q.part[blockIdx.x * 8 + 1] = mx;
-}
-
 // ---- k_ipm_dense_dot: dtr[e] = <A_e, M> for every dense entry (one wave per entry) --------------------------------------------
 __global__ __launch_bounds__(256) void k_ipm_dense_dot(const IpmBuf q, const double *__restrict__ Mxy, const int *__restrict__ ent_block) {
     const long long e = blockIdx.x * 4ll + (threadIdx.x >> 6);
@@ -306,9 +303,22 @@ __global__ __launch_bounds__(256) void k_ipm_dense_dot(const IpmBuf q, const dou
 
 // ---- k_ipm_csum: out[i] = sign * (base[i] - sum_t lam_t val[t] - sum_e dtr[e] - with_By * (B y)_i), max |out| -----------------
 // one thread per constraint (global x index); fixed summation order
+// Workgroups from p_from on (first call of an iteration only; -1: none) compute p = sgn b - B^T x instead, one wave per free variable
+// (src/solver.jl:961-983): two independent residuals, one launch.
 __global__ __launch_bounds__(256) void k_ipm_csum(const IpmBuf q, const double *__restrict__ base, double base_sign, const double *__restrict__ val,
-                                                  int with_By, double *__restrict__ out, int part_slot) {
+                                                  int with_By, double *__restrict__ out, int part_slot, int p_from, double sgn) {
     __shared__ double red[4];
+    if (p_from >= 0 && (int)blockIdx.x >= p_from) {
+        const int kk = ((int)blockIdx.x - p_from) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+        if (kk >= q.N) return;
+        const double *col = q.B + (long long)kk * q.xlen;
+        double s = 0.0;
+        for (int i = lane; i < q.xlen; i += 64) s += col[i] * q.x[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        if (lane == 0) q.p[kk] = sgn * q.b[kk] - s;
+        return;
+    }
     const int i = blockIdx.x * 256 + threadIdx.x;
     double r = 0.0;
     if (i < q.xlen) {
@@ -325,18 +335,6 @@ __global__ __launch_bounds__(256) void k_ipm_csum(const IpmBuf q, const double *
     }
     r = block_reduce_max(r, red);
     if (threadIdx.x == 0 && part_slot >= 0) q.part[(long long)(q.NB + blockIdx.x) * 8 + part_slot] = r;
-}
-
-// ---- k_ipm_p: p = sgn b - B^T x (one wave per free variable), per-wave |p| ------------------------------------------------
-__global__ __launch_bounds__(256) void k_ipm_p(const IpmBuf q, const IpmParams prm) {
-    const int kk = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (kk >= q.N) return;
-    const double *col = q.B + (long long)kk * q.xlen;
-    double s = 0.0;
-    for (int i = lane; i < q.xlen; i += 64) s += col[i] * q.x[i];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    if (lane == 0) q.p[kk] = prm.sgn * q.b[kk] - s;
 }
 
 // ---- k_ipm_scalars: the scalar control flow, one thread -----------------------------------------------------------------------
