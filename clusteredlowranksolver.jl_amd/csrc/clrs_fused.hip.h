@@ -520,14 +520,30 @@ struct CSolve {
     int P, N, ldb, pad;
 };
 
+// (batched: eight tiles in flight per trip to memory; a tile-by-tile loop with the select around the load is one trip per tile --
+// 36 trips for P = 96.  The padding carries an identity diagonal, which the solves never use: their 1 / diag entries are zero there.)
 __device__ __forceinline__ void lds_load_L_for_solve(double *A, int lda, double *dv, const CSolve &d, int P16, int tid) {
-    const int i16 = tid & 15, j16 = tid >> 4;
-    for (int j0 = 0; j0 < P16; j0 += 16)
-        for (int i0 = 0; i0 < P16; i0 += 16) {
-            const int i = i0 + i16, j = j0 + j16;
-            A[i + j * lda] = (i < d.P && j < d.P && i >= j) ? d.L[i + (long long)j * d.P] : 0.0;
-        }
-    if (tid < P16) dv[tid] = (tid < d.P) ? d.dinv[tid] : 0.0;
+    lds_load_lower_identity_padded(A, lda, d.L, d.P, d.P, P16, tid, 256);
+    if (tid < P16) dv[tid] = d.dinv[tid < d.P ? tid : 0] * ((tid < d.P) ? 1.0 : 0.0);
+}
+
+// partial[k] = sum_i LB[i, k] t[i] for the columns k0 .. k0 + 7 of one wave: the loads of eight columns are in flight together
+__device__ __forceinline__ void gemv_t_8cols(const double *__restrict__ LB, int ldb, int rows, int N, int k0, const double *__restrict__ t, int lane,
+                                             double *__restrict__ out) {
+    double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int i = lane; i < rows; i += 64) {
+        const double ti = t[i];
+        double v[8];
+#pragma unroll
+        for (int c = 0; c < 8; c++) v[c] = LB[i + (long long)min(k0 + c, N - 1) * ldb];
+#pragma unroll
+        for (int c = 0; c < 8; c++) acc[c] = __builtin_fma(v[c], ti, acc[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        const double sacc = wave_sum(acc[c]);
+        if (lane == 0 && k0 + c < N) out[k0 + c] = sacc;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_cluster_solve_fwd(const CSolve *__restrict__ descs, const double *__restrict__ rhs_x, double *__restrict__ t) {
@@ -539,7 +555,7 @@ __global__ __launch_bounds__(256) void k_cluster_solve_fwd(const CSolve *__restr
     lds_load_L_for_solve(A, lda, dv, d, P16, tid);
     if (tid < P16) z[tid] = (tid < P) ? rhs_x[d.off + tid] : 0.0;
     __syncthreads();
-    lds_trsm<false>(A, lda, dv, z, 1, lda, P, 1, wave, 4, lane);
+    if (wave == 0) wave_trsv_fwd(A, lda, dv, z, P16, lane);      // one right-hand side: a single-wave job, no barriers between its panels
     __syncthreads();
     if (tid < P) t[d.off + tid] = z[tid];
 }
@@ -555,14 +571,24 @@ __global__ __launch_bounds__(256) void k_cluster_solve_bwd(const CSolve *__restr
     lds_load_L_for_solve(A, lda, dv, d, P16, tid);
     if (tid < P16) {
         double s = 0.0;
-        if (tid < P) {
+        if (tid < P) {                     // t_j + LinvB_j dy: four partial sums, eight loads in flight
+            double s1 = 0.0, s2 = 0.0, s3 = 0.0;
             s = t[d.off + tid];
-            for (int k = 0; k < d.N; k++) s += d.LB[tid + (long long)k * d.ldb] * dy[k];
+            int k = 0;
+            for (; k + 8 <= d.N; k += 8) {
+                double v[8];
+#pragma unroll
+                for (int c = 0; c < 8; c++) v[c] = d.LB[tid + (long long)(k + c) * d.ldb];
+                s = __builtin_fma(v[0], dy[k], s); s1 = __builtin_fma(v[1], dy[k + 1], s1); s2 = __builtin_fma(v[2], dy[k + 2], s2); s3 = __builtin_fma(v[3], dy[k + 3], s3);
+                s = __builtin_fma(v[4], dy[k + 4], s); s1 = __builtin_fma(v[5], dy[k + 5], s1); s2 = __builtin_fma(v[6], dy[k + 6], s2); s3 = __builtin_fma(v[7], dy[k + 7], s3);
+            }
+            for (; k < d.N; k++) s = __builtin_fma(d.LB[tid + (long long)k * d.ldb], dy[k], s);
+            s = (s + s1) + (s2 + s3);
         }
         z[tid] = s;
     }
     __syncthreads();
-    lds_trsm<true>(A, lda, dv, z, 1, lda, P, 1, wave, 4, lane);
+    if (wave == 0) wave_trsv_bwd(A, lda, dv, z, P16, lane);
     __syncthreads();
     if (tid < P) dx[d.off + tid] = z[tid];
 }
@@ -576,20 +602,9 @@ __global__ __launch_bounds__(256) void k_q_solve(const double *__restrict__ LQ, 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int N16 = (N + 15) & ~15, lda = N16 + 2;
     double *A = lds, *dv = lds + lda * N16, *z = dv + N16;
-    const int i16 = tid & 15, j16 = tid >> 4;
-    for (int j0 = 0; j0 < N16; j0 += 16)
-        for (int i0 = 0; i0 < N16; i0 += 16) {
-            const int i = i0 + i16, j = j0 + j16;
-            A[i + j * lda] = (i < N && j < N && i >= j) ? LQ[i + (long long)j * N] : 0.0;
-        }
+    lds_load_lower_identity_padded(A, lda, LQ, N, N, N16, tid, 256);
     if (LB) {
-        for (int k = wave; k < N; k += 4) {
-            const double *col = LB + (long long)k * ldb;
-            double sacc = 0.0;
-            for (int i = lane; i < rows; i += 64) sacc += col[i] * t[i];
-            sacc = wave_sum(sacc);
-            if (lane == 0) u[k] = sacc;
-        }
+        for (int k0 = wave * 8; k0 < N; k0 += 32) gemv_t_8cols(LB, ldb, rows, N, k0, t, lane, u);
         __threadfence_block();
         __syncthreads();
     }
@@ -598,9 +613,10 @@ __global__ __launch_bounds__(256) void k_q_solve(const double *__restrict__ LQ, 
         z[tid] = (tid < N) ? rhs_y[tid] - u[tid] : 0.0;
     }
     __syncthreads();
-    lds_trsm<false>(A, lda, dv, z, 1, lda, N, 1, wave, 4, lane);
-    __syncthreads();
-    lds_trsm<true>(A, lda, dv, z, 1, lda, N, 1, wave, 4, lane);
+    if (wave == 0) {
+        wave_trsv_fwd(A, lda, dv, z, N16, lane);
+        wave_trsv_bwd(A, lda, dv, z, N16, lane);
+    }
     __syncthreads();
     if (tid < N) dy[tid] = z[tid];
 }

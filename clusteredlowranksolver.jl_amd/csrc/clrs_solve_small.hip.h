@@ -20,101 +20,7 @@
 
 namespace clrs {
 
-// x += bcast_K(x) * m[K], K = 0 .. 14 (forward) / K = 15 .. 1 (backward); a DPP read needs two wait states after the write
-__device__ __forceinline__ void trsv16_chain_fwd(double &x, const double (&m)[16]) {
-    asm volatile(
-        "s_nop 1\n\tv_fmac_f64_dpp %0, %0, %1 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_fmac_f64_dpp %0, %0, %2 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_fmac_f64_dpp %0, %0, %3 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_fmac_f64_dpp %0, %0, %4 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_fmac_f64_dpp %0, %0, %5 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_fmac_f64_dpp %0, %0, %6 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_fmac_f64_dpp %0, %0, %7 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_fmac_f64_dpp %0, %0, %8 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_fmac_f64_dpp %0, %0, %9 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_fmac_f64_dpp %0, %0, %10 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_fmac_f64_dpp %0, %0, %11 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_fmac_f64_dpp %0, %0, %12 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_fmac_f64_dpp %0, %0, %13 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_fmac_f64_dpp %0, %0, %14 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_fmac_f64_dpp %0, %0, %15 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1"
-        : "+v"(x)
-        : "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7]), "v"(m[8]), "v"(m[9]), "v"(m[10]), "v"(m[11]),
-          "v"(m[12]), "v"(m[13]), "v"(m[14]));
-}
-__device__ __forceinline__ void trsv16_chain_bwd(double &x, const double (&m)[16]) {
-    asm volatile(
-        "s_nop 1\n\tv_fmac_f64_dpp %0, %0, %15 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_fmac_f64_dpp %0, %0, %14 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_fmac_f64_dpp %0, %0, %13 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_fmac_f64_dpp %0, %0, %12 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_fmac_f64_dpp %0, %0, %11 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_fmac_f64_dpp %0, %0, %10 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_fmac_f64_dpp %0, %0, %9 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_fmac_f64_dpp %0, %0, %8 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_fmac_f64_dpp %0, %0, %7 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_fmac_f64_dpp %0, %0, %6 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_fmac_f64_dpp %0, %0, %5 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_fmac_f64_dpp %0, %0, %4 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_fmac_f64_dpp %0, %0, %3 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_fmac_f64_dpp %0, %0, %2 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_fmac_f64_dpp %0, %0, %1 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1"
-        : "+v"(x)
-        : "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7]), "v"(m[8]), "v"(m[9]), "v"(m[10]), "v"(m[11]), "v"(m[12]),
-          "v"(m[13]), "v"(m[14]), "v"(m[15]));
-}
-
-// One wave: x <- L^-1 x.  A: n16 x n16 in LDS (ld lda), lower triangle of L, ZERO above the diagonal and in rows / columns >= n;
-// dinv: 1 / L[i,i] (0 for i >= n); x: n16 entries in LDS (entries >= n zero).
-__device__ __forceinline__ void wave_trsv_fwd(const double *A, int lda, const double *dinv, double *x, int n16, int lane) {
-    const int l15 = lane & 15;
-    for (int r0 = 0; r0 < n16; r0 += 16) {
-        const int row = r0 + l15;
-        const double di = dinv[row];
-        double m[16];
-#pragma unroll
-        for (int k = 0; k < 15; k++) m[k] = A[row + (r0 + k) * lda];            // all reads issued first (a select around a read is a branch)
-#pragma unroll
-        for (int k = 0; k < 15; k++) m[k] = (k < l15) ? -(m[k] * di) : 0.0;
-        double xr = x[row] * di;
-        trsv16_chain_fwd(xr, m);
-        if (lane < 16) x[row] = xr;
-        wave_sync();
-        for (int i = r0 + 16 + lane; i < n16; i += 64) {      // rows below the panel
-            double s = x[i];
-#pragma unroll
-            for (int k = 0; k < 16; k++) s = __builtin_fma(-A[i + (r0 + k) * lda], x[r0 + k], s);
-            x[i] = s;
-        }
-        wave_sync();
-    }
-}
-// One wave: x <- L^-T x (same storage of L).
-__device__ __forceinline__ void wave_trsv_bwd(const double *A, int lda, const double *dinv, double *x, int n16, int lane) {
-    const int l15 = lane & 15;
-    for (int r0 = n16 - 16; r0 >= 0; r0 -= 16) {
-        const int row = r0 + l15;
-        const double di = dinv[row];
-        double m[16];
-#pragma unroll
-        for (int k = 1; k < 16; k++) m[k] = A[(r0 + k) + row * lda];            // L^T[row, r0 + k] = L[r0 + k, row]
-#pragma unroll
-        for (int k = 1; k < 16; k++) m[k] = (k > l15) ? -(m[k] * di) : 0.0;
-        double xr = x[row] * di;
-        trsv16_chain_bwd(xr, m);
-        if (lane < 16) x[row] = xr;
-        wave_sync();
-        for (int i = lane; i < r0; i += 64) {                   // rows above the panel
-            double s = x[i];
-#pragma unroll
-            for (int k = 0; k < 16; k++) s = __builtin_fma(-A[(r0 + k) + i * lda], x[r0 + k], s);
-            x[i] = s;
-        }
-        wave_sync();
-    }
-}
+// (trsv16_chain_fwd / _bwd and wave_trsv_fwd / _bwd, the single-wave triangular solves, live in clrs_wave.hip.h)
 
 #ifdef CLRS_W3_STAMPS
 __device__ unsigned long long g_ss2_stamps[16];
