@@ -1670,7 +1670,7 @@ extern "C" int clrs_get_unique_counts(const clrs_ctx *c, int32_t b, int32_t r, i
 // ------------------------------------------------------------------------------------------------
 // per-iteration drivers
 // ------------------------------------------------------------------------------------------------
-static const size_t PIN_LIMIT = (size_t)64 << 20;      // beyond this the caller's buffers are copied directly (bandwidth, not latency, matters there)
+static size_t PIN_LIMIT = (size_t)64 << 20;            // beyond this the caller's buffers are copied directly (bandwidth, not latency, matters there); "pin_limit" (tests)
 // start of a host-pointer call: the arena is empty again; it grows here (never while pointers are handed out) to what the
 // previous call asked for in total
 static void pin_reset(clrs_ctx *c) {
@@ -2069,6 +2069,7 @@ extern "C" int clrs_config_set(const char *key, int value) {
     if (!std::strcmp(key, "dense_block")) { g_cfg_dense_block = value; return 0; }
     if (!std::strcmp(key, "solve_small2")) { g_cfg_solve_small2 = value; return 0; }
     if (!std::strcmp(key, "factor_small")) { g_cfg_factor_small = value; return 0; }
+    if (!std::strcmp(key, "pin_limit")) { PIN_LIMIT = (size_t)std::max(value, 0); return 0; }
     if (!std::strcmp(key, "ipm_wmfma")) { g_cfg_ipm_wmfma = value; return 0; }
     if (!std::strcmp(key, "solve_small_max")) { g_cfg_solve_small_max = value; return 0; }
     return fail(CLRS_ERR_INVALID, std::string("unknown configuration key ") + key);

@@ -67,6 +67,35 @@ def test_stream_probe_measures_a_plausible_rate():
     assert _lib().clrs_test_stream(0, 0, 0, 1, C.byref(us)) < 0
 
 
+def test_host_pointer_entry_points_staged_and_direct_copies_agree():
+    """The host-pointer entry points stage the caller's buffers through a pinned arena (from the second call of a context on: the
+    arena is sized by what the first call asked for); "pin_limit" = 0 keeps the direct copies.  Same bits either way, call after call."""
+    from clrs_amd.solver import SchurContext, compute_T_decomposition, solve_system
+    f = flat("ce_8_3")
+    X, Y = spd_iterates(f, seed=9)
+    Xc = chol_blocks_np(f, X)
+    rng = np.random.default_rng(10)
+    rx, ry = rng.standard_normal(f.x_len), rng.standard_normal(f.n_free)
+    results = []
+    for limit in (None, 0):
+        if limit is not None:
+            assert _lib().clrs_config_set(b"pin_limit", limit) == 0
+        try:
+            ctx = SchurContext(f)
+            out = []
+            for _ in range(3):
+                _, S, AY = compute_T_decomposition(ctx, Xc, Y, want_S=True)
+                dx, dy = solve_system(ctx, rx, ry)
+                out.append((S.copy(), np.array(AY, copy=True), dx.copy(), dy.copy()))
+            ctx.close()
+        finally:
+            assert _lib().clrs_config_set(b"pin_limit", 64 << 20) == 0
+        for o in out[1:]:
+            assert all(np.array_equal(a, b) for a, b in zip(o, out[0]))
+        results.append(out[0])
+    assert all(np.array_equal(a, b) for a, b in zip(results[0], results[1]))
+
+
 def test_potrf_reports_failure():
     A = np.asfortranarray(np.array([[1.0, 2.0], [2.0, 1.0]]))
     assert _lib().clrs_test_potrf(0, 2, _dp(A), 2) == 1
