@@ -275,6 +275,35 @@ def test_random_simple_structures(seed, oracle_built):
         ctx.close()
 
 
+@pytest.mark.parametrize("P,N", [(127, 127), (128, 128), (129, 7), (80, 129), (128, 0)])
+def test_size_limits_of_the_fused_regime(P, N, oracle_built):
+    """Clusters and free-variable counts at the limits where the plan switches between the LDS-resident kernels (P, N <= 128) and the
+    staged ones: two clusters of exactly P constraints (four low-rank blocks of side 16 each, so S_j is definite), N free variables.
+    Assembly, factorisation and solve against the oracle."""
+    import clrs_amd
+    from clrs_amd.solver import SchurContext, compute_T_decomposition, solve_system
+    from oracle.oracle import Oracle
+    from tests.util import random_simple_sdp
+    f = clrs_amd.flatten(random_simple_sdp(1000 + P + N, J=2, n_free=N, fixed_P=P, max_n=16, lr_blocks=4))
+    X, Y = spd_iterates(f, seed=P + 2 * N)
+    Xc = chol_blocks_np(f, X)
+    o = Oracle(f, quad=False)
+    S_ref, AY_ref = o.schur_assemble(Xc, Y)
+    assert o.schur_factor() == 0
+    rng = np.random.default_rng(P * 131 + N)
+    rx, ry = rng.standard_normal(f.x_len), rng.standard_normal(f.n_free)
+    dx_ref, dy_ref = o.schur_solve(rx, ry)
+    ctx = SchurContext(f)
+    _, S, AY = compute_T_decomposition(ctx, Xc, Y, want_S=True)
+    assert np.max(np.abs(S - S_ref)) <= 1e-11 * np.max(np.abs(S_ref))
+    assert np.max(np.abs(AY - AY_ref)) <= 1e-11 * max(1.0, np.max(np.abs(AY_ref)))
+    dx, dy = solve_system(ctx, rx, ry)
+    assert np.max(np.abs(dx - dx_ref)) <= 1e-7 * max(1.0, np.max(np.abs(dx_ref)))
+    if N:
+        assert np.max(np.abs(dy - dy_ref)) <= 1e-7 * max(1.0, np.max(np.abs(dy_ref)))
+    ctx.close()
+
+
 def test_dedup_counts_match_oracle(oracle_built):
     from clrs_amd.solver import SchurContext
     from oracle.oracle import Oracle

@@ -147,7 +147,7 @@ def duplicate_block(f, b, scale=0.5):
     return g
 
 
-def random_simple_sdp(seed, J=5, n_free=3, max_P=32, max_n=16, definite=False):
+def random_simple_sdp(seed, J=5, n_free=3, max_P=32, max_n=16, definite=False, fixed_P=None, lr_blocks=None):
     """A random SDP of the shapes the cluster-per-wave assembly takes: per cluster P_j constraints, 1-3 low-rank blocks of side
     n <= 16 with ONE rank-1 symmetric term per constraint (distinct vectors, the same constraint order in every block) and 0-2 dense
     1 x 1 blocks that touch a random subset of the constraints; mixed sizes within one context.  `definite`: the first block of every
@@ -156,10 +156,10 @@ def random_simple_sdp(seed, J=5, n_free=3, max_P=32, max_n=16, definite=False):
     rng = np.random.default_rng(seed)
     blocks, B, c, C = [], [], [], []
     for j in range(J):
-        P = int(rng.integers(1, max_P + 1))
-        cl, Cl = [], []
-        for bi in range(int(rng.integers(1, 4))):
-            n = int(rng.integers(1, max_n + 1))
+        P = int(rng.integers(1, max_P + 1)) if fixed_P is None else int(fixed_P)      # fixed_P / lr_blocks: every cluster P constraints and
+        cl, Cl = [], []                                                                # lr_blocks low-rank blocks of side max_n (size-limit tests)
+        for bi in range(int(rng.integers(1, 4)) if lr_blocks is None else int(lr_blocks)):
+            n = int(rng.integers(1, max_n + 1)) if lr_blocks is None else int(max_n)
             if definite and bi == 0:
                 n = max(n, 9)
             V = rng.standard_normal((P, n))
