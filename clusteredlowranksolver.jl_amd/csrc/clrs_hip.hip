@@ -2211,6 +2211,7 @@ extern "C" int clrs_test_stream(int device, long long read_bytes, long long writ
     auto ok = [&](hipError_t e, const char *what) { if (e != hipSuccess && !rc) rc = fail(CLRS_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e)); return e == hipSuccess; };
     if (ok(hipMalloc(&a, nr * 16), "hipMalloc") && ok(hipMalloc(&b, nr * 16), "hipMalloc") && ok(hipMalloc(&w, nw * 16), "hipMalloc") &&
         ok(hipMemset(a, 0, nr * 16), "hipMemset") && ok(hipMemset(b, 0, nr * 16), "hipMemset") && ok(hipMemset(w, 0, nw * 16), "hipMemset") &&
+        ok(hipStreamSynchronize(nullptr), "hipStreamSynchronize") &&      // the fills (null stream) are done before the probe's own stream starts
         ok(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "hipStreamCreate") && ok(hipEventCreate(&e0), "hipEventCreate") && ok(hipEventCreate(&e1), "hipEventCreate")) {
         hipDeviceProp_t prop;
         int cus = 256;
