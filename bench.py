@@ -198,6 +198,12 @@ def main():
         assert parity["solve_rel_err_2d6_vs_f128_oracle"] < 1e-7, parity
         sh2.close()
 
+    # ---- device wake-up (untimed, before the W warmup steps): a process that starts on an idle box has been seen to run its first
+    # ~100 ms of launches several times slower (a 2000-step loop at 0.47 ms per step instead of 0.054) -- a fixed number of steps, the
+    # same on every rank (the steps of a sharded run contain collectives) ----
+    for _ in range(3000):
+        step()
+    torch.cuda.synchronize()
     # ---- timed region: W warmup + exactly K steps, barrier + synchronize on both sides ----
     for _ in range(args.warmup):
         step()
