@@ -36,7 +36,13 @@
 #include <omp.h>
 #endif
 
-#ifdef ORACLE_QUAD
+#if defined(ORACLE_MP)
+/* multi-limb build (oracle/clrs_oracle_mp.cpp includes mpx.hpp first and compiles this file as C++):
+ * the stand-in for the reference's Arb midpoints at `prec` bits (src/solver.jl:73,103) */
+typedef mpx<ORACLE_MP> REAL;
+#define RSQRT(x) mpx_sqrt(x)
+#define RABS(x) mpx_abs(x)
+#elif defined(ORACLE_QUAD)
 #include <quadmath.h>
 typedef __float128 REAL;
 #define RSQRT(x) sqrtq(x)
@@ -113,6 +119,11 @@ typedef struct {
     REAL *AY;             /* [T] w^T Y v per term */
     REAL *Xinv_tmp;       /* largest block scratch x3 */
     int maxn;
+    /* trajectory snapshots of oracle_solvesdp (oracle_set_snapshots): iterates at the top of the listed
+     * iterations and the predictor's right-hand sides, as k-limb planar arrays */
+    int snap_n, snap_k, snap_count;
+    const int *snap_it;
+    double *snap_X, *snap_Y, *snap_rx, *snap_ry;
 } octx;
 
 static REAL ld(const double *hi, const double *lo, i64 i) { return lo ? (REAL)hi[i] + (REAL)lo[i] : (REAL)hi[i]; }
@@ -126,6 +137,26 @@ static REAL *rload(const double *hi, const double *lo, i64 n) {
     REAL *p = ralloc(n);
     for (i64 i = 0; i < n; i++) p[i] = ld(hi, lo, i);
     return p;
+}
+
+/* k-limb planar arrays: value[i] = sum_l p[l * len + i] (limb 0 = the value rounded to fp64, then the
+ * rounded remainders): the interchange format of the multi-word HIP path (include/clrs_hip.h, clrs_mw_*) */
+static REAL ldk(const double *p, i64 len, int k, i64 i) {
+    REAL v = (REAL)p[i];
+    for (int l = 1; l < k; l++) v = v + (REAL)p[(i64)l * len + i];
+    return v;
+}
+static void stk(double *p, i64 len, int k, i64 i, REAL v) {
+    for (int l = 0; l < k; l++) {
+        double h = (double)v;
+        p[(i64)l * len + i] = h;
+        v = v - (REAL)h;
+    }
+}
+static REAL *rloadk(const double *p, i64 len, int k) {
+    REAL *r = ralloc(len);
+    for (i64 i = 0; i < len; i++) r[i] = ldk(p, len, k, i);
+    return r;
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -555,6 +586,57 @@ void oracle_schur_solve(octx *o, const double *rx, const double *rx_lo, const do
     free(a); free(b); free(x); free(y);
 }
 
+
+/* --- the same entry points on k-limb planar arrays (multi-word parity checks) ---------------- */
+int oracle_cholesky_blocks_mw(octx *o, int k, const double *X, double *L) {
+    REAL *W = rloadk(X, o->xylen, k);
+    int fail = 0;
+    for (int b = 0; b < o->NB && !fail; b++)
+        if (!cholesky_lower(o->blk[b].n, W + o->blk[b].off, o->blk[b].n)) fail = b + 1;
+    for (i64 i = 0; i < o->xylen; i++) stk(L, o->xylen, k, i, W[i]);
+    free(W);
+    return fail;
+}
+void oracle_schur_assemble_mw(octx *o, int k, const double *Xchol, const double *Y, double *S, double *AY) {
+    REAL *L = rloadk(Xchol, o->xylen, k), *Yr = rloadk(Y, o->xylen, k);
+    schur_assemble_real(o, L, Yr);
+    if (S) for (i64 i = 0; i < o->Slen; i++) stk(S, o->Slen, k, i, o->S[i]);
+    if (AY) for (i64 i = 0; i < o->T; i++) stk(AY, o->T, k, i, o->AY[i]);
+    free(L); free(Yr);
+}
+/* load S (S layout) into the context, e.g. to factor a matrix another implementation assembled */
+void oracle_set_S_mw(octx *o, int k, const double *S) {
+    for (i64 i = 0; i < o->Slen; i++) o->S[i] = ldk(S, o->Slen, k, i);
+}
+void oracle_get_factor_mw(octx *o, int k, double *L, double *LinvB, double *Q) {
+    if (L) for (i64 i = 0; i < o->Slen; i++) stk(L, o->Slen, k, i, o->S[i]);
+    if (LinvB) {
+        i64 off = 0, tot = (i64)o->xlen * o->N;
+        for (int j = 0; j < o->J; j++) {
+            i64 n = (i64)o->P[j] * o->N;
+            for (i64 i = 0; i < n; i++) stk(LinvB, tot, k, off + i, o->LinvB[j][i]);
+            off += n;
+        }
+    }
+    if (Q) for (i64 i = 0; i < (i64)o->N * o->N; i++) stk(Q, (i64)o->N * o->N, k, i, o->Q[i]);
+}
+void oracle_schur_solve_mw(octx *o, int k, const double *rx, const double *ry, double *dx, double *dy) {
+    REAL *a = rloadk(rx, o->xlen, k), *b = rloadk(ry, o->N, k);
+    REAL *x = ralloc(o->xlen), *y = ralloc(o->N);
+    schur_solve_real(o, a, b, x, y);
+    for (i64 i = 0; i < o->xlen; i++) stk(dx, o->xlen, k, i, x[i]);
+    for (i64 i = 0; i < o->N; i++) stk(dy, o->N, k, i, y[i]);
+    free(a); free(b); free(x); free(y);
+}
+/* snapshots of the next oracle_solvesdp: at the listed iterations (1-based, ascending) the iterate (X, Y) at the
+ * top of the iteration and the predictor's right-hand sides (rhs_x, rhs_y) are stored as k-limb planar arrays,
+ * snapshot s at offset s * k * len of each buffer.  n = 0 switches them off. */
+void oracle_set_snapshots(octx *o, int n, const int *iters, int k, double *X, double *Y, double *rx, double *ry) {
+    o->snap_n = n; o->snap_it = iters; o->snap_k = k; o->snap_count = 0;
+    o->snap_X = X; o->snap_Y = Y; o->snap_rx = rx; o->snap_ry = ry;
+}
+int oracle_snapshot_count(const octx *o) { return o->snap_count; }
+
 /* Dense restatement of S used as an independent structural check:
  * S[p,q] = sum_l Tr(A_p X^-1 A_q Y) with A_p = Matrix(::LowRankMat) (src/interface.jl:798-800). */
 void oracle_schur_dense_check(octx *o, const double *Xchol, const double *Xchol_lo, const double *Y, const double *Y_lo,
@@ -875,6 +957,12 @@ int oracle_solvesdp(octx *o, const oracle_params *prm, int *iters_out, double *o
             }
             trace_A(o, dY, tr);
             for (i64 i = 0; i < nx; i++) rhsx[i] = -d[i] - tr[i];                 /* :1522-1523 */
+            if (pass == 0 && o->snap_count < o->snap_n && o->snap_it[o->snap_count] == iter) {
+                int k_ = o->snap_k, s_ = o->snap_count++;
+                for (i64 i = 0; i < nxy; i++) { stk(o->snap_X + (i64)s_ * k_ * nxy, nxy, k_, i, X[i]); stk(o->snap_Y + (i64)s_ * k_ * nxy, nxy, k_, i, Y[i]); }
+                for (i64 i = 0; i < nx; i++) stk(o->snap_rx + (i64)s_ * k_ * nx, nx, k_, i, rhsx[i]);
+                for (int i = 0; i < N; i++) stk(o->snap_ry + (i64)s_ * k_ * (N > 0 ? N : 1), N, k_, i, pv[i]);
+            }
             schur_solve_real(o, rhsx, pv, dx, dy);                                /* :1527-1582 */
             weighted_A(o, dx, dX);                                                /* :1588 */
             for (i64 i = 0; i < nxy; i++) dX[i] += Pm[i];                         /* :1591 */
@@ -923,7 +1011,17 @@ int oracle_solvesdp(octx *o, const oracle_params *prm, int *iters_out, double *o
     return error_code;
 }
 
-int oracle_real_bits(void) { return (int)(sizeof(REAL) * 8); }
+#if defined(ORACLE_MP)
+int oracle_real_bits(void) { return mpx_prec_bits > 0 && mpx_prec_bits < 64 * ORACLE_MP ? mpx_prec_bits : 64 * ORACLE_MP; }
+/* working precision of every later operation (1..64*limbs bits; 0 = all limbs): the reference's `prec` */
+void oracle_set_precision_bits(int bits) { mpx_prec_bits = bits; }
+#elif defined(ORACLE_QUAD)
+int oracle_real_bits(void) { return 113; }
+void oracle_set_precision_bits(int bits) { (void)bits; }
+#else
+int oracle_real_bits(void) { return 53; }
+void oracle_set_precision_bits(int bits) { (void)bits; }
+#endif
 void oracle_set_num_threads(int n) {
     if (n > 0) omp_set_num_threads(n);
 }

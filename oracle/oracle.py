@@ -48,10 +48,11 @@ class OracleParams(C.Structure):
 
 def build(force: bool = False) -> None:
     """Compile the oracle shared libraries with the committed Makefile."""
-    need = force or not all(os.path.exists(os.path.join(_HERE, f)) for f in ("libclrs_oracle_f64.so", "libclrs_oracle_f128.so"))
+    libs = ("libclrs_oracle_f64.so", "libclrs_oracle_f128.so", "libclrs_oracle_mp.so")
+    need = force or not all(os.path.exists(os.path.join(_HERE, f)) for f in libs)
     if not need:
-        src = os.path.getmtime(os.path.join(_HERE, "clrs_oracle.c"))
-        need = any(os.path.getmtime(os.path.join(_HERE, f)) < src for f in ("libclrs_oracle_f64.so", "libclrs_oracle_f128.so"))
+        src = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("clrs_oracle.c", "clrs_oracle_mp.cpp", "mpx.hpp"))
+        need = any(os.path.getmtime(os.path.join(_HERE, f)) < src for f in libs)
     if need:
         subprocess.run(["make", "-C", _HERE, "-B"], check=True, capture_output=True)
 
@@ -59,8 +60,11 @@ def build(force: bool = False) -> None:
 _libs = {}
 
 
-def _lib(quad: bool):
-    key = "f128" if quad else "f64"
+MP_LIMB_BITS = 320   # mantissa bits of libclrs_oracle_mp.so (mpx<5>)
+
+
+def _lib(quad):
+    key = "mp" if quad == "mp" else ("f128" if quad else "f64")
     if key not in _libs:
         path = os.path.join(_HERE, f"libclrs_oracle_{key}.so")
         if not os.path.exists(path):
@@ -84,6 +88,16 @@ def _lib(quad: bool):
         L.oracle_unique_counts.restype = C.c_int
         L.oracle_unique_counts.argtypes = [C.c_void_p, C.c_int, _p_i, _p_i]
         L.oracle_real_bits.restype = C.c_int
+        L.oracle_set_precision_bits.argtypes = [C.c_int]
+        L.oracle_cholesky_blocks_mw.restype = C.c_int
+        L.oracle_cholesky_blocks_mw.argtypes = [C.c_void_p, C.c_int, _p_d, _p_d]
+        L.oracle_schur_assemble_mw.argtypes = [C.c_void_p, C.c_int, _p_d, _p_d, _p_d, _p_d]
+        L.oracle_set_S_mw.argtypes = [C.c_void_p, C.c_int, _p_d]
+        L.oracle_get_factor_mw.argtypes = [C.c_void_p, C.c_int, _p_d, _p_d, _p_d]
+        L.oracle_schur_solve_mw.argtypes = [C.c_void_p, C.c_int, _p_d, _p_d, _p_d, _p_d]
+        L.oracle_set_snapshots.argtypes = [C.c_void_p, C.c_int, _p_i, C.c_int, _p_d, _p_d, _p_d, _p_d]
+        L.oracle_snapshot_count.restype = C.c_int
+        L.oracle_snapshot_count.argtypes = [C.c_void_p]
         L.oracle_num_threads.restype = C.c_int
         L.oracle_set_num_threads.argtypes = [C.c_int]
         _libs[key] = L
@@ -113,12 +127,21 @@ def _c(a, dt=np.float64):
 
 class Oracle:
     """CPU oracle context for a FlatSDP.  `quad=True` computes in __float128 using the (hi, lo) inputs;
-    `use_lo=False` forces the fp64-rounded problem data (what the HIP path sees) even in quad."""
+    `use_lo=False` forces the fp64-rounded problem data (what the HIP path sees) even in quad.
+    `mp_bits=p` computes in the multi-limb type of mpx.hpp truncated to p bits per operation (p <= 320; the stand-in for
+    the reference's Arb midpoints at `prec=p`).  The precision is a property of the loaded library, not of the
+    context: it is re-applied by every method of a multi-precision context."""
 
-    def __init__(self, flat, quad: bool = False, use_lo: bool = True):
+    def __init__(self, flat, quad: bool = False, use_lo: bool = True, mp_bits: Optional[int] = None):
         self.flat = flat
+        self.mp_bits = mp_bits
+        if mp_bits is not None:
+            if not 1 <= mp_bits <= MP_LIMB_BITS:
+                raise ValueError("mp_bits must be within 1..%d" % MP_LIMB_BITS)
+            quad = "mp"
         self.quad = quad
         self.L = _lib(quad)
+        self._prec()
         f = flat
         keep = self._keep = {}
 
@@ -127,7 +150,7 @@ class Oracle:
             return keep[name]
 
         def lo(name, arr):
-            if not (quad and use_lo):
+            if not (quad and use_lo) or arr is None:
                 return None
             return _dp(hold(name, arr))
 
@@ -166,6 +189,48 @@ class Oracle:
                 self.ctx = None
         except Exception:
             pass
+
+    def _prec(self):
+        if self.mp_bits is not None:
+            self.L.oracle_set_precision_bits(int(self.mp_bits))
+
+    # -- hot path on k-limb planar arrays (shape (k, len); value = sum over axis 0) -----------------
+    def cholesky_blocks_mw(self, X):
+        self._prec()
+        X = _c(np.atleast_2d(X)); k = X.shape[0]
+        L = np.zeros_like(X)
+        st = self.L.oracle_cholesky_blocks_mw(self.ctx, k, _dp(X), _dp(L))
+        return int(st), L
+
+    def schur_assemble_mw(self, Xchol, Y):
+        self._prec()
+        f = self.flat
+        Xchol, Y = _c(np.atleast_2d(Xchol)), _c(np.atleast_2d(Y)); k = Xchol.shape[0]
+        assert Y.shape == Xchol.shape == (k, f.xy_len)
+        S, AY = np.zeros((k, f.S_len)), np.zeros((k, max(f.n_terms, 1)))
+        self.L.oracle_schur_assemble_mw(self.ctx, k, _dp(Xchol), _dp(Y), _dp(S), _dp(AY) if f.n_terms else None)
+        return S, AY[:, :f.n_terms]
+
+    def set_S_mw(self, S):
+        self._prec()
+        S = _c(np.atleast_2d(S))
+        self.L.oracle_set_S_mw(self.ctx, S.shape[0], _dp(S))
+
+    def get_factor_mw(self, k):
+        self._prec()
+        f = self.flat
+        L = np.zeros((k, f.S_len)); LinvB = np.zeros((k, max(f.x_len * f.n_free, 1))); Q = np.zeros((k, max(f.n_free * f.n_free, 1)))
+        self.L.oracle_get_factor_mw(self.ctx, k, _dp(L), _dp(LinvB) if f.n_free else None, _dp(Q) if f.n_free else None)
+        return L, LinvB[:, :f.x_len * f.n_free], Q[:, :f.n_free * f.n_free]
+
+    def schur_solve_mw(self, rhs_x, rhs_y):
+        self._prec()
+        f = self.flat
+        rx = _c(np.atleast_2d(rhs_x)); k = rx.shape[0]
+        ry = _c(np.atleast_2d(rhs_y)) if f.n_free else np.zeros((k, 1))
+        dx, dy = np.zeros((k, f.x_len)), np.zeros((k, max(f.n_free, 1)))
+        self.L.oracle_schur_solve_mw(self.ctx, k, _dp(rx), _dp(ry), _dp(dx), _dp(dy))
+        return dx, dy[:, :f.n_free]
 
     # -- hot path -------------------------------------------------------------------------------
     def cholesky_blocks(self, X, X_lo=None):
@@ -219,11 +284,22 @@ class Oracle:
         self.L.oracle_default_params(C.byref(p))
         return p
 
-    def solvesdp(self, params: Optional[OracleParams] = None, hist_rows: int = 600, **kw):
+    def solvesdp(self, params: Optional[OracleParams] = None, hist_rows: int = 600, snapshots=None, snapshot_limbs: int = 1, **kw):
+        """`snapshots`: ascending 1-based iteration numbers; the result then carries `snap` = dict(iters, X, Y, rhs_x, rhs_y)
+        with k-limb planar arrays of shape (n, k, len): the iterate at the top of those iterations and the predictor's
+        right-hand sides (trajectory fixtures)."""
+        self._prec()
         p = params or self.default_params()
         for k, v in kw.items():
             setattr(p, k, v)
         f = self.flat
+        snap = None
+        if snapshots is not None and len(snapshots):
+            its = _c(sorted(int(i) for i in snapshots), np.int32)
+            ns, kl = len(its), int(snapshot_limbs)
+            snap = dict(iters=its, X=np.zeros((ns, kl, f.xy_len)), Y=np.zeros((ns, kl, f.xy_len)),
+                        rhs_x=np.zeros((ns, kl, f.x_len)), rhs_y=np.zeros((ns, kl, max(f.n_free, 1))))
+            self.L.oracle_set_snapshots(self.ctx, ns, _ip(its), kl, _dp(snap["X"]), _dp(snap["Y"]), _dp(snap["rhs_x"]), _dp(snap["rhs_y"]))
         iters = C.c_int(0)
         out = np.zeros(6)
         hist = np.zeros((hist_rows, HIST_COLS))
@@ -231,7 +307,11 @@ class Oracle:
         X, Y = np.zeros(f.xy_len), np.zeros(f.xy_len)
         code = self.L.oracle_solvesdp(self.ctx, C.byref(p), C.byref(iters), _dp(out), _dp(hist), hist_rows, _dp(x), _dp(y), _dp(X), _dp(Y))
         n = min(iters.value, hist_rows)
-        return dict(error_code=int(code), iterations=int(iters.value), d_obj=out[0], p_obj=out[1], gap=out[2],
+        if snap is not None:
+            cnt = int(self.L.oracle_snapshot_count(self.ctx))
+            self.L.oracle_set_snapshots(self.ctx, 0, None, 1, None, None, None, None)
+            snap = {k_: (v[:cnt] if k_ != "rhs_y" else v[:cnt, :, :f.n_free]) for k_, v in snap.items()}
+        return dict(snap=snap, error_code=int(code), iterations=int(iters.value), d_obj=out[0], p_obj=out[1], gap=out[2],
                     dual_error=out[3], primal_error=out[4], pd_feas=bool(out[5]), hist=hist[:n],
                     x=x, y=y[:f.n_free], X=X, Y=Y)
 
