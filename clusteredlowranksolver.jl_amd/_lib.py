@@ -109,6 +109,31 @@ SYMBOLS = {
     "clrs_get_kernel_times": (C.c_int, [C.c_void_p, C.c_int, p_d, p_i64]),
     "clrs_kernel_name": (C.c_char_p, [C.c_int]),
     "clrs_plan_info": (C.c_int, [C.c_void_p, p_i32, p_i32, p_i32]),
+    "clrs_mw_create": (C.c_int, [C.POINTER(SdpDesc), C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "clrs_mw_destroy": (None, [C.c_void_p]),
+    "clrs_mw_limbs": (C.c_int, [C.c_void_p]),
+    "clrs_mw_get_dims": (C.c_int, [C.c_void_p, C.POINTER(Dims)]),
+    "clrs_mw_get_unique_count": (C.c_int, [C.c_void_p, C.c_int32, p_i32]),
+    "clrs_mw_cholesky_blocks": (C.c_int, [C.c_void_p, p_d, p_d]),
+    "clrs_mw_schur_assemble": (C.c_int, [C.c_void_p, p_d, p_d, p_d, p_d]),
+    "clrs_mw_schur_factor": (C.c_int, [C.c_void_p]),
+    "clrs_mw_get_factor": (C.c_int, [C.c_void_p, p_d, p_d, p_d]),
+    "clrs_mw_schur_solve": (C.c_int, [C.c_void_p, p_d, p_d, p_d, p_d]),
+    "clrs_mw_cholesky_blocks_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "clrs_mw_sync_status_cholesky": (C.c_int, [C.c_void_p]),
+    "clrs_mw_set_xchol_dev": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "clrs_mw_schur_assemble_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "clrs_mw_schur_factor_dev": (C.c_int, [C.c_void_p]),
+    "clrs_mw_sync_status": (C.c_int, [C.c_void_p]),
+    "clrs_mw_schur_solve_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "clrs_mw_S_buffer_dev": (C.c_void_p, [C.c_void_p]),
+    "clrs_mw_AY_buffer_dev": (C.c_void_p, [C.c_void_p]),
+    "clrs_mw_stream": (C.c_void_p, [C.c_void_p]),
+    "clrs_mw_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "clrs_mw_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "clrs_mw_get_timings": (C.c_int, [C.c_void_p, p_d]),
+    "clrs_mw_get_counters": (C.c_int, [C.c_void_p, p_d, p_d, p_d]),
+    "clrs_set_last_error": (None, [C.c_char_p]),
     "clrs_strerror": (C.c_char_p, [C.c_int]),
     "clrs_last_error": (C.c_char_p, []),
     "clrs_version": (C.c_char_p, []),
@@ -120,30 +145,43 @@ SYMBOLS = {
 }
 
 
-def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str = None) -> str:
-    """Compile csrc/clrs_hip.hip for gfx950 into csrc/libclrs_hip.so (in-tree, travels with gpurun).
-    `extra_flags` / `out` build a diagnostic variant (e.g. -DCLRS_FUSED_STAMPS) beside it."""
-    if out is not None:
-        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", *extra_flags,
-               "-o", out, os.path.join(CSRC, "clrs_hip.hip")]
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError("hipcc failed:\n" + r.stderr[-4000:])
-        return out
-    src = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hip.h", ".inc"))] + \
-          [os.path.join(_HERE, "..", "include", "clrs_hip.h")]
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in src):
-        return LIB_PATH
+def _hipcc(args):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
-           "-o", LIB_PATH, os.path.join(CSRC, "clrs_hip.hip")]
-    r = subprocess.run(cmd, capture_output=True, text=True)
+    r = subprocess.run([hipcc, *args], capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed:\n" + r.stderr[-4000:])
-    if verbose:
-        print(" ".join(cmd))
-    return LIB_PATH
+
+
+# translation units of libclrs_hip.so: (object, source, extra flags, predicate selecting the files it depends on)
+_UNITS = (
+    ("clrs_hip.o", "clrs_hip.hip", (), lambda f: not f.startswith("clrs_mw")),
+    # the multi-word (extended precision) path: error-free transformations must not be contracted into FMAs
+    ("clrs_mw.o", "clrs_mw.hip", ("-ffp-contract=off",), lambda f: f.startswith("clrs_mw")),
+)
+_COMMON = ("--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value")
+
+
+def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str = None) -> str:
+    """Compile csrc/*.hip for gfx950 into csrc/libclrs_hip.so (in-tree, travels with gpurun): one object per translation
+    unit (recompiled only when one of its sources changed), then one link.
+    `extra_flags` / `out` build a diagnostic variant (e.g. -DCLRS_FUSED_STAMPS) of the fp64 unit beside it."""
+    hdr = os.path.join(_HERE, "..", "include", "clrs_hip.h")
+    files = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".hip.h", ".inc", ".h")))
+    objs, rebuilt = [], False
+    for obj, src, flags, mine in _UNITS:
+        o = os.path.join(CSRC, obj if out is None or src != "clrs_hip.hip" else os.path.basename(out) + ".o")
+        deps = [os.path.join(CSRC, f) for f in files if mine(f)] + [hdr]
+        diag = out is not None and src == "clrs_hip.hip"
+        if force or diag or not os.path.exists(o) or any(os.path.getmtime(o) < os.path.getmtime(s) for s in deps):
+            _hipcc([*_COMMON, *flags, *(extra_flags if diag else ()), "-c", "-o", o, os.path.join(CSRC, src)])
+            rebuilt = True
+            if verbose:
+                print("compiled", src)
+        objs.append(o)
+    target = out if out is not None else LIB_PATH
+    if rebuilt or not os.path.exists(target) or any(os.path.getmtime(target) < os.path.getmtime(o) for o in objs):
+        _hipcc(["--offload-arch=gfx950", "-fPIC", "-shared", "-o", target, *objs])
+    return target
 
 
 _lib = None

@@ -39,6 +39,7 @@ static int fail(int code, const std::string &msg) {
     g_last_error = msg;
     return code;
 }
+extern "C" void clrs_set_last_error(const char *msg) { g_last_error = msg ? msg : ""; }   // for the other translation units of the library (clrs_mw.hip)
 #define HIPCHECK(expr)                                                                                   \
     do {                                                                                                 \
         hipError_t e_ = (expr);                                                                          \

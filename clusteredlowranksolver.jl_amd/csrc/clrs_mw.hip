@@ -1,0 +1,593 @@
+// clrs_mw.hip -- the hot path at the reference's working precision: multi-word fp64 (K limbs), host side + C ABI
+// (include/clrs_hip.h, clrs_mw_*).  Compiled with -ffp-contract=off (clrs_mw_arith.h) and linked into libclrs_hip.so.
+//
+// A context of its own (clrs_mw_ctx), created from the same clrs_sdp_desc as the fp64 context: the de-duplication of
+// the sampled vectors (precompute_matrices_bilinear_pairings, src/solver.jl:985-1059) is redone here into ONE table of
+// expanded unique vectors per PSD block -- a vector of sub-block r is stored with its delta entries at rows
+// r*delta.. and zeros elsewhere, duplicates removed by exact equality as the reference does (src/tools.jl:128-145) -- so
+// that both pairing matrices of a block are plain symmetric products V^T X^-1 V and V^T Y V, and the reference's
+// pointers_left / pointers_right dictionaries become two integers per term.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/clrs_hip.h"
+#include "clrs_mw_kernels.hip.h"
+
+typedef long long i64;
+
+extern "C" void clrs_set_last_error(const char *msg);   // clrs_hip.hip: the library keeps one thread-local message
+
+static int mw_fail(int code, const std::string &msg) {
+    clrs_set_last_error(msg.c_str());
+    return code;
+}
+#define MWCHECK(expr)                                                                                    \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess) return mw_fail(CLRS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+static const size_t MW_LDS_MAX = 160 * 1024 - 2048;     // bytes of LDS one workgroup may claim on gfx950 (margin for the runtime)
+
+struct clrs_mw_ctx {
+    int device = 0, K = 4;
+    hipStream_t stream = nullptr;
+    bool own_stream = true;
+    MwDev d = {};
+    std::vector<MwBlk> blk;
+    std::vector<MwClu> clu;
+    std::vector<void *> allocs;
+    int maxU = 0, maxP = 0, maxn = 0;
+    bool lds_x = false, lds_q = false, lds_zt_L = false;
+    size_t sm_x = 0, sm_zt = 0, sm_dense = 0, sm_factor = 0, sm_q = 0, sm_fwd = 0, sm_mid = 0, sm_bwd = 0;
+    int *h_info = nullptr;               // pinned
+    double *d_Xin = nullptr, *d_Xc = nullptr, *d_Y = nullptr, *d_rx = nullptr, *d_ry = nullptr, *d_dx = nullptr, *d_dy = nullptr;   // staging of the host-pointer entry points
+    bool assembled = false, factored = false;
+    bool timing = false;
+    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    double times[6] = {0, 0, 0, 0, 0, 0};
+    double cnt_mul = 0;                  // multi-word multiply-adds of one assembly (algorithmic)
+    double cnt_factor = 0, cnt_solve = 0;
+    struct MwIpm *ipm = nullptr;
+};
+
+template <class T>
+static int mw_upload(clrs_mw_ctx *c, const std::vector<T> &h, const T **d) {
+    T *p = nullptr;
+    size_t bytes = std::max<size_t>(h.size(), 1) * sizeof(T);
+    MWCHECK(hipMalloc((void **)&p, bytes));
+    c->allocs.push_back(p);
+    if (!h.empty()) MWCHECK(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    *d = p;
+    return 0;
+}
+static int mw_dmalloc(clrs_mw_ctx *c, double **d, i64 n) {
+    size_t bytes = (size_t)std::max<i64>(n, 1) * sizeof(double);
+    MWCHECK(hipMalloc((void **)d, bytes));
+    c->allocs.push_back(*d);
+    MWCHECK(hipMemset(*d, 0, bytes));
+    return 0;
+}
+
+#define MW_DISPATCH(Kv, ...)                                   \
+    switch (Kv) {                                              \
+    case 2: { constexpr int KK = 2; __VA_ARGS__; } break;      \
+    case 3: { constexpr int KK = 3; __VA_ARGS__; } break;      \
+    case 4: { constexpr int KK = 4; __VA_ARGS__; } break;      \
+    case 5: { constexpr int KK = 5; __VA_ARGS__; } break;      \
+    default: return mw_fail(CLRS_ERR_INVALID, "limbs must be 2..5"); \
+    }
+
+template <class F>
+static int mw_set_lds(F kernel, size_t bytes) {
+    if (bytes > 48 * 1024) MWCHECK(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return 0;
+}
+
+extern "C" void clrs_mw_destroy(clrs_mw_ctx *c);
+static void mw_ipm_free(clrs_mw_ctx *c);
+static int mw_launch_xrd(clrs_mw_ctx *c, const double *d_Xc);
+
+extern "C" int clrs_mw_create(const clrs_sdp_desc *d, int device, int limbs, clrs_mw_ctx **out) {
+    if (!d || !out) return mw_fail(CLRS_ERR_INVALID, "null argument");
+    if (limbs < 2 || limbs > 5) return mw_fail(CLRS_ERR_INVALID, "limbs must be 2..5");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device >= ndev) return mw_fail(CLRS_ERR_NO_DEVICE, "no usable HIP device");
+    MWCHECK(hipSetDevice(device));
+    clrs_mw_ctx *c = new clrs_mw_ctx();
+    c->device = device;
+    c->K = limbs;
+    const int K = limbs;
+    const int J = d->n_clusters, N = d->n_free, NB = d->n_blocks;
+    if (J <= 0 || N < 0 || NB < 0) { delete c; return mw_fail(CLRS_ERR_INVALID, "bad sizes"); }
+    int rc = 0;
+#define MW_BAIL(code, msg) do { clrs_mw_destroy(c); return mw_fail(code, msg); } while (0)
+#define MW_TRY(call) do { if ((rc = (call))) { clrs_mw_destroy(c); return rc; } } while (0)
+    MWCHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    MWCHECK(hipHostMalloc((void **)&c->h_info, 2 * sizeof(int), hipHostMallocDefault));
+    // ---- clusters ----
+    c->clu.resize(J);
+    i64 xlen = 0, Slen = 0;
+    for (int j = 0; j < J; j++) {
+        MwClu &q = c->clu[j];
+        q.P = d->cluster_P[j];
+        if (q.P <= 0) MW_BAIL(CLRS_ERR_INVALID, "cluster without constraints");
+        q.coff = xlen; q.Soff = Slen; q.b0 = NB; q.b1 = 0;
+        xlen += q.P; Slen += (i64)q.P * q.P;
+        c->maxP = std::max(c->maxP, q.P);
+    }
+    // ---- blocks, unique expanded vectors, term tables ----
+    c->blk.resize(NB);
+    const i64 T = NB ? d->term_ptr[NB] : 0, D = NB ? d->dense_ptr[NB] : 0;
+    std::vector<double> hV;
+    std::vector<int> hvrow, st_a(std::max<i64>(T, 1)), st_b(std::max<i64>(T, 1)), htptr, ay_a(std::max<i64>(T, 1), 0), ay_b(std::max<i64>(T, 1), 0),
+        ay_blk(std::max<i64>(T, 1), -1), hdmap, lr_list, dn_list;
+    std::vector<double> st_lam(std::max<i64>(T, 1)), hdA;
+    i64 xyoff = 0, rdoff = 0, zoff = 0, goff = 0, sdoff = 0, woff = 0;
+    double cnt_mul = 0;
+    for (int b = 0; b < NB; b++) {
+        MwBlk &k = c->blk[b];
+        std::memset(&k, 0, sizeof(k));
+        k.j = d->block_cluster[b];
+        if (k.j < 0 || k.j >= J || (b > 0 && k.j < c->blk[b - 1].j)) MW_BAIL(CLRS_ERR_INVALID, "block_cluster must be non-decreasing and within range");
+        const int m = d->block_m[b];
+        k.delta = d->block_delta[b];
+        k.n = m * k.delta;
+        k.kind = d->block_kind[b];
+        k.P = c->clu[k.j].P;
+        if (k.n <= 0 || (k.kind != 0 && m != 1)) MW_BAIL(CLRS_ERR_INVALID, "bad block shape");
+        k.xyoff = xyoff; xyoff += (i64)k.n * k.n;
+        k.rd_off = rdoff; rdoff += k.n;
+        c->clu[k.j].b0 = std::min(c->clu[k.j].b0, b);
+        c->clu[k.j].b1 = std::max(c->clu[k.j].b1, b + 1);
+        c->maxn = std::max(c->maxn, k.n);
+        const int P = k.P, n = k.n, dl = k.delta;
+        if (k.kind == 0) {
+            lr_list.push_back(b);
+            const i64 t0 = d->term_ptr[b], t1 = d->term_ptr[b + 1];
+            // unique expanded vectors: (sub-block, delta values), exact equality, first occurrence wins
+            std::vector<std::pair<int, const double *>> uniq;
+            auto find_or_add = [&](int r, const double *v) -> int {
+                for (size_t u = 0; u < uniq.size(); u++)
+                    if (uniq[u].first == r && std::memcmp(uniq[u].second, v, sizeof(double) * dl) == 0) return (int)u;
+                // memcmp distinguishes -0.0 from 0.0 and equal NaNs; compare by value where bits differ
+                for (size_t u = 0; u < uniq.size(); u++) {
+                    if (uniq[u].first != r) continue;
+                    bool eq = true;
+                    for (int i = 0; i < dl && eq; i++) eq = uniq[u].second[i] == v[i];
+                    if (eq) return (int)u;
+                }
+                uniq.push_back({r, v});
+                return (int)uniq.size() - 1;
+            };
+            std::map<std::tuple<int, int, int, int>, i64> index;
+            for (i64 t = t0; t < t1; t++) {
+                if (d->term_p[t] < 0 || d->term_p[t] >= P || d->term_r[t] < 0 || d->term_r[t] >= m || d->term_s[t] < 0 || d->term_s[t] >= m)
+                    MW_BAIL(CLRS_ERR_INVALID, "term index out of range");
+                if (d->term_vec_ptr[t + 1] - d->term_vec_ptr[t] != dl) MW_BAIL(CLRS_ERR_INVALID, "term vectors must have delta entries");
+                index[std::make_tuple(d->term_p[t], d->term_r[t], d->term_s[t], d->term_rank[t])] = t;
+            }
+            // R(t): vs of the term at sub-block r; Lself(t): ws of the term at sub-block r   (rightvecs[r] / leftvecs[r], src/solver.jl:1011, 1032)
+            std::vector<int> Rt(t1 - t0), Ls(t1 - t0);
+            std::vector<i64> partner(t1 - t0);
+            for (i64 t = t0; t < t1; t++) {
+                Rt[t - t0] = find_or_add(d->term_r[t], d->term_vs + d->term_vec_ptr[t]);
+                Ls[t - t0] = find_or_add(d->term_r[t], d->term_ws + d->term_vec_ptr[t]);
+                auto it = index.find(std::make_tuple(d->term_p[t], d->term_s[t], d->term_r[t], d->term_rank[t]));
+                if (it == index.end()) MW_BAIL(CLRS_ERR_INVALID, "term without transposed partner: A[r,s][p] must equal A[s,r][p]^T");
+                partner[t - t0] = it->second;
+            }
+            k.U = (int)uniq.size();
+            c->maxU = std::max(c->maxU, k.U);
+            k.v_off = (i64)hV.size();
+            k.vrow_off = (i64)hvrow.size();
+            hV.resize(hV.size() + (size_t)n * k.U, 0.0);
+            for (int u = 0; u < k.U; u++) {
+                hvrow.push_back(uniq[u].first * dl);
+                for (int i = 0; i < dl; i++) hV[k.v_off + (i64)u * n + uniq[u].first * dl + i] = uniq[u].second[i];
+            }
+            k.z_off = zoff; zoff += (i64)n * k.U;
+            k.g_off = goff; goff += (i64)k.U * k.U;
+            // terms sorted by constraint (stable), CSR over p
+            std::vector<i64> order(t1 - t0);
+            for (i64 t = t0; t < t1; t++) order[t - t0] = t;
+            std::stable_sort(order.begin(), order.end(), [&](i64 a, i64 b2) { return d->term_p[a] < d->term_p[b2]; });
+            k.tptr_off = (i64)htptr.size();
+            htptr.resize(htptr.size() + P + 1, 0);
+            int *tp = htptr.data() + k.tptr_off;
+            for (i64 i = 0; i < t1 - t0; i++) tp[d->term_p[order[i]] + 1]++;
+            tp[0] = (int)t0;
+            for (int p = 0; p < P; p++) tp[p + 1] += tp[p];
+            for (i64 i = 0; i < t1 - t0; i++) {
+                const i64 t = order[i];
+                st_a[t0 + i] = Ls[partner[t - t0] - t0];      // pointers_left[s][(r,p,k)] = ws of A[s,r][p]
+                st_b[t0 + i] = Rt[t - t0];                    // pointers_right[r][(s,p,k)] = vs of A[r,s][p]
+                st_lam[t0 + i] = d->term_lambda[t];
+            }
+            for (i64 t = t0; t < t1; t++) {                    // A_Y[r,s][idx] = bpY[r,s][left_r(s,p,k), right_s(r,p,k)]  (src/solver.jl:1162)
+                ay_blk[t] = b;
+                ay_a[t] = Ls[t - t0];
+                ay_b[t] = Rt[partner[t - t0] - t0];
+            }
+            // algorithmic multi-word multiply-adds of the assembly of this block: T = Y V, Z = L^-1 V, GX, GY (lower triangles), S
+            cnt_mul += (double)n * dl * k.U + 0.5 * (double)n * n * k.U + 0.5 * (double)k.U * k.U * (n + dl);
+            for (int p = 0; p < P; p++)
+                for (int q2 = p; q2 < P; q2++) cnt_mul += (double)(tp[p + 1] - tp[p]) * (tp[q2 + 1] - tp[q2]);
+        } else {
+            dn_list.push_back(b);
+            const i64 d0 = d->dense_ptr[b], d1 = d->dense_ptr[b + 1];
+            k.cnt = (int)(d1 - d0);
+            k.d0 = d0;
+            k.a_off = (i64)hdA.size();
+            k.dmap_off = (i64)hdmap.size();
+            hdmap.resize(hdmap.size() + P, -1);
+            for (i64 e = d0; e < d1; e++) {
+                const int p = d->dense_p[e];
+                if (p < 0 || p >= P) MW_BAIL(CLRS_ERR_INVALID, "dense constraint index out of range");
+                if (d->dense_A_ptr[e + 1] - d->dense_A_ptr[e] != (i64)n * n) MW_BAIL(CLRS_ERR_INVALID, "dense matrix must have n*n entries");
+                hdmap[k.dmap_off + p] = (int)(e - d0);
+                hdA.insert(hdA.end(), d->dense_A + d->dense_A_ptr[e], d->dense_A + d->dense_A_ptr[e + 1]);
+            }
+            k.sd_off = sdoff; sdoff += (i64)k.cnt * k.cnt;
+            k.w_off = woff; woff += (i64)k.cnt * n * n;
+            cnt_mul += (double)k.cnt * (2.0 * n * n * n + 0.5 * (double)k.cnt * n * n);
+        }
+    }
+    for (int j = 0; j < J; j++)
+        if (c->clu[j].b0 > c->clu[j].b1) { c->clu[j].b0 = c->clu[j].b1 = 0; }
+    c->cnt_mul = cnt_mul;
+    for (int j = 0; j < J; j++) {
+        const double P = c->clu[j].P;
+        c->cnt_factor += P * P * P / 6.0 + 0.5 * P * P * N + 0.5 * P * (double)N * N;
+        c->cnt_solve += P * P + 2.0 * P * N;
+    }
+    c->cnt_factor += (double)N * N * N / 6.0;
+    c->cnt_solve += (double)N * N;
+    // ---- LDS plans ----
+    const size_t lim = MW_LDS_MAX / sizeof(double);
+    {
+        size_t nn = (size_t)c->maxn * c->maxn * K;
+        c->lds_x = nn <= lim;
+        c->sm_x = c->lds_x ? nn * 8 : 0;
+        size_t zt = (size_t)c->maxn * MW_CT * K;
+        c->lds_zt_L = zt + nn <= lim;
+        c->sm_zt = (zt + (c->lds_zt_L ? nn : 0)) * 8;
+        if (zt > lim) MW_BAIL(CLRS_ERR_INVALID, "PSD block too large for the multi-word kernels");
+        size_t maxnd = 0;
+        for (auto &k : c->blk) if (k.kind != 0 && k.n > 1) maxnd = std::max(maxnd, (size_t)k.n);
+        if (maxnd * maxnd * K > lim) MW_BAIL(CLRS_ERR_INVALID, "dense block too large for the multi-word kernels");
+        c->sm_dense = maxnd * maxnd * K * 8;
+        size_t fmax = 0, smax = 0;
+        for (auto &q : c->clu) {
+            size_t need = ((size_t)q.P * q.P + (size_t)q.P * N) * K;
+            q.lds = need <= lim ? 1 : 0;
+            if (q.lds) fmax = std::max(fmax, need);
+            size_t sneed = ((size_t)q.P + (q.lds ? (size_t)q.P * q.P : 0)) * K;
+            smax = std::max(smax, sneed);
+        }
+        c->sm_factor = fmax * 8;
+        c->sm_fwd = c->sm_bwd = smax * 8;
+        size_t qn = (size_t)N * N * K;
+        c->lds_q = qn + (size_t)N * K <= lim;
+        c->sm_q = c->lds_q ? qn * 8 : 0;
+        c->sm_mid = ((size_t)N * K + (c->lds_q ? qn : 0)) * 8;
+        if (c->sm_fwd > MW_LDS_MAX || c->sm_mid > MW_LDS_MAX) MW_BAIL(CLRS_ERR_INVALID, "cluster too large for the multi-word solve kernels");
+    }
+    MW_DISPATCH(K, {
+        MW_TRY(mw_set_lds(k_mw_potrf_x<KK>, c->sm_x)); MW_TRY(mw_set_lds(k_mw_zt<KK>, c->sm_zt)); MW_TRY(mw_set_lds(k_mw_dense<KK>, c->sm_dense));
+        MW_TRY(mw_set_lds(k_mw_factor<KK>, c->sm_factor)); MW_TRY(mw_set_lds(k_mw_potrf_q<KK>, c->sm_q));
+        MW_TRY(mw_set_lds(k_mw_solve_fwd<KK>, c->sm_fwd)); MW_TRY(mw_set_lds(k_mw_solve_mid<KK>, c->sm_mid)); MW_TRY(mw_set_lds(k_mw_solve_bwd<KK>, c->sm_bwd));
+    });
+    // ---- upload ----
+    MwDev &q = c->d;
+    q.J = J; q.N = N; q.NB = NB; q.nlr = (int)lr_list.size(); q.ndn = (int)dn_list.size();
+    q.xylen = xyoff; q.xlen = xlen; q.Slen = Slen; q.T = T; q.xrdlen = rdoff;
+    q.zlen = std::max<i64>(zoff, 1); q.glen = std::max<i64>(goff, 1); q.wlen = std::max<i64>(woff, 1); q.sdlen = std::max<i64>(sdoff, 1);
+    std::vector<int> hdense_p(d->dense_p, d->dense_p + D);
+    std::vector<double> hB(d->B, d->B + xlen * (i64)N);
+    // B arrives per cluster (P_j x N column-major, concatenated); the kernels read one stacked xlen x N matrix
+    std::vector<double> hBs((size_t)xlen * N, 0.0);
+    {
+        i64 off = 0;
+        for (int j = 0; j < J; j++) {
+            const int P = c->clu[j].P;
+            for (int a = 0; a < N; a++)
+                for (int r = 0; r < P; r++) hBs[c->clu[j].coff + r + (i64)a * xlen] = hB[off + r + (i64)a * P];
+            off += (i64)P * N;
+        }
+    }
+    MW_TRY(mw_upload(c, c->blk, &q.blk)); MW_TRY(mw_upload(c, c->clu, &q.clu));
+    MW_TRY(mw_upload(c, lr_list, &q.lr_list)); MW_TRY(mw_upload(c, dn_list, &q.dn_list));
+    MW_TRY(mw_upload(c, hV, &q.V)); MW_TRY(mw_upload(c, hvrow, &q.vrow));
+    MW_TRY(mw_upload(c, st_a, &q.st_a)); MW_TRY(mw_upload(c, st_b, &q.st_b)); MW_TRY(mw_upload(c, st_lam, &q.st_lam));
+    MW_TRY(mw_upload(c, htptr, &q.tptr));
+    MW_TRY(mw_upload(c, ay_a, &q.ay_a)); MW_TRY(mw_upload(c, ay_b, &q.ay_b)); MW_TRY(mw_upload(c, ay_blk, &q.ay_blk));
+    MW_TRY(mw_upload(c, hdA, &q.dA)); MW_TRY(mw_upload(c, hdmap, &q.dmap)); MW_TRY(mw_upload(c, hdense_p, &q.dense_p));
+    MW_TRY(mw_upload(c, hBs, &q.B));
+    MW_TRY(mw_dmalloc(c, &q.Z, q.zlen * K)); MW_TRY(mw_dmalloc(c, &q.Tm, q.zlen * K));
+    MW_TRY(mw_dmalloc(c, &q.GX, q.glen * K)); MW_TRY(mw_dmalloc(c, &q.GY, q.glen * K));
+    MW_TRY(mw_dmalloc(c, &q.W, q.wlen * K)); MW_TRY(mw_dmalloc(c, &q.Sd, q.sdlen * K));
+    MW_TRY(mw_dmalloc(c, &q.S, Slen * K)); MW_TRY(mw_dmalloc(c, &q.LB, xlen * (i64)N * K)); MW_TRY(mw_dmalloc(c, &q.Q, (i64)N * N * K));
+    MW_TRY(mw_dmalloc(c, &q.xrd, rdoff * K)); MW_TRY(mw_dmalloc(c, &q.srd, xlen * K)); MW_TRY(mw_dmalloc(c, &q.qrd, (i64)N * K));
+    MW_TRY(mw_dmalloc(c, &q.t, xlen * K)); MW_TRY(mw_dmalloc(c, &q.u, (i64)J * N * K)); MW_TRY(mw_dmalloc(c, &q.AY, T * K));
+    MW_TRY(mw_dmalloc(c, &c->d_Xin, xyoff * K)); MW_TRY(mw_dmalloc(c, &c->d_Xc, xyoff * K)); MW_TRY(mw_dmalloc(c, &c->d_Y, xyoff * K));
+    MW_TRY(mw_dmalloc(c, &c->d_rx, xlen * K)); MW_TRY(mw_dmalloc(c, &c->d_dx, xlen * K));
+    MW_TRY(mw_dmalloc(c, &c->d_ry, (i64)N * K)); MW_TRY(mw_dmalloc(c, &c->d_dy, (i64)N * K));
+    {
+        int *info = nullptr;
+        MWCHECK(hipMalloc((void **)&info, 2 * sizeof(int)));
+        c->allocs.push_back(info);
+        q.info = info;
+        int init[2] = {MW_INFO_NONE, MW_INFO_NONE};
+        MWCHECK(hipMemcpy(info, init, sizeof(init), hipMemcpyHostToDevice));
+    }
+    for (auto &e : c->ev) MWCHECK(hipEventCreate(&e));
+    *out = c;
+    return 0;
+#undef MW_BAIL
+#undef MW_TRY
+}
+
+extern "C" void clrs_mw_destroy(clrs_mw_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    mw_ipm_free(c);
+    for (void *p : c->allocs) (void)hipFree(p);
+    for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
+    if (c->h_info) (void)hipHostFree(c->h_info);
+    if (c->stream && c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int clrs_mw_limbs(const clrs_mw_ctx *c) { return c ? c->K : 0; }
+extern "C" void *clrs_mw_stream(clrs_mw_ctx *c) { return c ? (void *)c->stream : nullptr; }
+extern "C" int clrs_mw_set_stream(clrs_mw_ctx *c, void *stream) {
+    if (!c) return mw_fail(CLRS_ERR_INVALID, "null context");
+    if (c->own_stream && c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    c->stream = (hipStream_t)stream;
+    c->own_stream = false;
+    return 0;
+}
+extern "C" int clrs_mw_get_dims(const clrs_mw_ctx *c, clrs_dims *o) {
+    if (!c || !o) return mw_fail(CLRS_ERR_INVALID, "null argument");
+    o->xy_len = c->d.xylen; o->x_len = c->d.xlen; o->S_len = c->d.Slen; o->n_terms = c->d.T;
+    o->n_free = c->d.N; o->n_clusters = c->d.J; o->n_blocks = c->d.NB; o->reserved = c->K;
+    return 0;
+}
+extern "C" int clrs_mw_get_unique_count(const clrs_mw_ctx *c, int32_t block, int32_t *n_unique) {
+    if (!c || !n_unique || block < 0 || block >= c->d.NB) return mw_fail(CLRS_ERR_INVALID, "bad argument");
+    *n_unique = c->blk[block].U;
+    return 0;
+}
+extern "C" int clrs_mw_set_timing(clrs_mw_ctx *c, int on) {
+    if (!c) return mw_fail(CLRS_ERR_INVALID, "null context");
+    c->timing = on != 0;
+    return 0;
+}
+extern "C" int clrs_mw_get_counters(const clrs_mw_ctx *c, double *assemble_muladds, double *factor_muladds, double *solve_muladds) {
+    if (!c) return mw_fail(CLRS_ERR_INVALID, "null context");
+    if (assemble_muladds) *assemble_muladds = c->cnt_mul;
+    if (factor_muladds) *factor_muladds = c->cnt_factor;
+    if (solve_muladds) *solve_muladds = c->cnt_solve;
+    return 0;
+}
+
+static int mw_reset_info(clrs_mw_ctx *c, int which) {
+    MWCHECK(hipMemsetAsync(c->d.info + which, 0x7f, sizeof(int), c->stream));      // MW_INFO_NONE is the byte 0x7f four times
+    return 0;
+}
+static int mw_read_info(clrs_mw_ctx *c, int which, int *status) {
+    MWCHECK(hipMemcpyAsync(c->h_info + which, c->d.info + which, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    MWCHECK(hipStreamSynchronize(c->stream));
+    *status = c->h_info[which] == MW_INFO_NONE ? 0 : c->h_info[which];
+    return 0;
+}
+
+// ---- the path, device pointers (planar K x len arrays), enqueue only ------------------------------------------------
+extern "C" int clrs_mw_cholesky_blocks_dev(clrs_mw_ctx *c, const double *d_X, double *d_Xchol) {
+    if (!c || !d_X || !d_Xchol) return mw_fail(CLRS_ERR_INVALID, "null argument");
+    MWCHECK(hipSetDevice(c->device));
+    int rc;
+    if ((rc = mw_reset_info(c, 1))) return rc;
+    if (c->d.NB == 0) return 0;
+    MW_DISPATCH(c->K, hipLaunchKernelGGL(k_mw_potrf_x<KK>, dim3(c->d.NB), dim3(MW_NT), c->sm_x, c->stream, c->d, d_X, d_Xchol, c->lds_x ? 1 : 0));
+    MWCHECK(hipGetLastError());
+    return 0;
+}
+extern "C" int clrs_mw_sync_status_cholesky(clrs_mw_ctx *c) {
+    if (!c) return mw_fail(CLRS_ERR_INVALID, "null context");
+    int st = 0, rc;
+    if ((rc = mw_read_info(c, 1, &st))) return rc;
+    return st;
+}
+
+extern "C" int clrs_mw_schur_assemble_dev(clrs_mw_ctx *c, const double *d_Xchol, const double *d_Y) {
+    if (!c || !d_Xchol || !d_Y) return mw_fail(CLRS_ERR_INVALID, "null argument");
+    MWCHECK(hipSetDevice(c->device));
+    const MwDev &q = c->d;
+    if (c->timing) MWCHECK(hipEventRecord(c->ev[0], c->stream));
+    MW_DISPATCH(c->K, {
+        if (q.nlr) {
+            hipLaunchKernelGGL(k_mw_zt<KK>, dim3((c->maxU + MW_CT - 1) / MW_CT, q.nlr), dim3(MW_NT), c->sm_zt, c->stream, q, d_Xchol, d_Y, c->lds_zt_L ? 1 : 0);
+            hipLaunchKernelGGL(k_mw_gram<KK>, dim3((c->maxU * (c->maxU + 1) / 2 + MW_NT - 1) / MW_NT, q.nlr), dim3(MW_NT), 0, c->stream, q);
+        }
+        if (q.ndn) hipLaunchKernelGGL(k_mw_dense<KK>, dim3(q.ndn), dim3(MW_NT), c->sm_dense, c->stream, q, d_Xchol, d_Y);
+        hipLaunchKernelGGL(k_mw_saccum<KK>, dim3((c->maxP * (c->maxP + 1) / 2 + MW_NT - 1) / MW_NT, q.J), dim3(MW_NT), 0, c->stream, q);
+        if (q.T) hipLaunchKernelGGL(k_mw_ay<KK>, dim3((unsigned)((q.T + MW_NT - 1) / MW_NT)), dim3(MW_NT), 0, c->stream, q);
+    });
+    MWCHECK(hipGetLastError());
+    if (c->timing) MWCHECK(hipEventRecord(c->ev[1], c->stream));
+    c->assembled = true;
+    c->factored = false;
+    return 0;
+}
+
+extern "C" int clrs_mw_schur_factor_dev(clrs_mw_ctx *c) {
+    if (!c) return mw_fail(CLRS_ERR_INVALID, "null context");
+    if (!c->assembled) return mw_fail(CLRS_ERR_STATE, "clrs_mw_schur_factor before clrs_mw_schur_assemble");
+    MWCHECK(hipSetDevice(c->device));
+    const MwDev &q = c->d;
+    int rc;
+    if ((rc = mw_reset_info(c, 0))) return rc;
+    if (c->timing) MWCHECK(hipEventRecord(c->ev[2], c->stream));
+    MW_DISPATCH(c->K, {
+        hipLaunchKernelGGL(k_mw_factor<KK>, dim3(q.J), dim3(MW_NT), c->sm_factor, c->stream, q);
+        if (c->timing) (void)hipEventRecord(c->ev[3], c->stream);
+        if (q.N > 0) {
+            hipLaunchKernelGGL(k_mw_qgram<KK>, dim3((q.N * (q.N + 1) / 2 + MW_NT - 1) / MW_NT), dim3(MW_NT), 0, c->stream, q);
+            if (c->timing) (void)hipEventRecord(c->ev[4], c->stream);
+            hipLaunchKernelGGL(k_mw_potrf_q<KK>, dim3(1), dim3(MW_NT), c->sm_q, c->stream, q, c->lds_q ? 1 : 0);
+        } else if (c->timing) (void)hipEventRecord(c->ev[4], c->stream);
+    });
+    MWCHECK(hipGetLastError());
+    if (c->timing) MWCHECK(hipEventRecord(c->ev[5], c->stream));
+    c->factored = true;
+    return 0;
+}
+extern "C" int clrs_mw_sync_status(clrs_mw_ctx *c) {
+    if (!c) return mw_fail(CLRS_ERR_INVALID, "null context");
+    int st = 0, rc;
+    if ((rc = mw_read_info(c, 0, &st))) return rc;
+    return st;
+}
+
+extern "C" int clrs_mw_schur_solve_dev(clrs_mw_ctx *c, const double *d_rhs_x, const double *d_rhs_y, double *d_dx, double *d_dy) {
+    if (!c || !d_rhs_x || !d_dx) return mw_fail(CLRS_ERR_INVALID, "null argument");
+    if (!c->factored) return mw_fail(CLRS_ERR_STATE, "clrs_mw_schur_solve before clrs_mw_schur_factor");
+    const MwDev &q = c->d;
+    if (q.N > 0 && (!d_rhs_y || !d_dy)) return mw_fail(CLRS_ERR_INVALID, "null argument");
+    MWCHECK(hipSetDevice(c->device));
+    if (c->timing) MWCHECK(hipEventRecord(c->ev[6], c->stream));
+    MW_DISPATCH(c->K, {
+        hipLaunchKernelGGL(k_mw_solve_fwd<KK>, dim3(q.J), dim3(MW_NT), c->sm_fwd, c->stream, q, d_rhs_x);
+        if (q.N > 0) hipLaunchKernelGGL(k_mw_solve_mid<KK>, dim3(1), dim3(MW_NT), c->sm_mid, c->stream, q, d_rhs_y, d_dy, c->lds_q ? 1 : 0);
+        hipLaunchKernelGGL(k_mw_solve_bwd<KK>, dim3(q.J), dim3(MW_NT), c->sm_bwd, c->stream, q, (const double *)d_dy, d_dx);
+    });
+    MWCHECK(hipGetLastError());
+    if (c->timing) MWCHECK(hipEventRecord(c->ev[7], c->stream));
+    return 0;
+}
+
+extern "C" double *clrs_mw_S_buffer_dev(clrs_mw_ctx *c) { return c ? c->d.S : nullptr; }
+extern "C" double *clrs_mw_AY_buffer_dev(clrs_mw_ctx *c) { return c ? c->d.AY : nullptr; }
+
+extern "C" int clrs_mw_get_timings(clrs_mw_ctx *c, double t[6]) {
+    if (!c || !t) return mw_fail(CLRS_ERR_INVALID, "null argument");
+    MWCHECK(hipStreamSynchronize(c->stream));
+    if (c->timing) {
+        float ms = 0;
+        const int pairs[6][2] = {{0, 1}, {2, 3}, {3, 3}, {3, 4}, {4, 5}, {6, 7}};      // schur, cholS + LinvB (one kernel), -, Q, cholQ, solve
+        for (int i = 0; i < 6; i++) {
+            if (pairs[i][0] == pairs[i][1]) { c->times[i] = 0; continue; }
+            if (hipEventElapsedTime(&ms, c->ev[pairs[i][0]], c->ev[pairs[i][1]]) == hipSuccess) c->times[i] = ms * 1e-3;
+        }
+    }
+    for (int i = 0; i < 6; i++) t[i] = c->times[i];
+    return 0;
+}
+
+// ---- host-pointer entry points (planar K x len host arrays; copy, run, synchronise) ----------------------------------
+extern "C" int clrs_mw_cholesky_blocks(clrs_mw_ctx *c, const double *X, double *Xchol) {
+    if (!c || !X || !Xchol) return mw_fail(CLRS_ERR_INVALID, "null argument");
+    MWCHECK(hipSetDevice(c->device));
+    const size_t bytes = (size_t)c->d.xylen * c->K * sizeof(double);
+    MWCHECK(hipMemcpyAsync(c->d_Xin, X, bytes, hipMemcpyHostToDevice, c->stream));
+    int rc = clrs_mw_cholesky_blocks_dev(c, c->d_Xin, c->d_Xc);
+    if (rc) return rc;
+    MWCHECK(hipMemcpyAsync(Xchol, c->d_Xc, bytes, hipMemcpyDeviceToHost, c->stream));
+    return clrs_mw_sync_status_cholesky(c);
+}
+extern "C" int clrs_mw_schur_assemble(clrs_mw_ctx *c, const double *Xchol, const double *Y, double *S_out, double *AY_out) {
+    if (!c || !Xchol || !Y) return mw_fail(CLRS_ERR_INVALID, "null argument");
+    MWCHECK(hipSetDevice(c->device));
+    const size_t bytes = (size_t)c->d.xylen * c->K * sizeof(double);
+    MWCHECK(hipMemcpyAsync(c->d_Xc, Xchol, bytes, hipMemcpyHostToDevice, c->stream));
+    MWCHECK(hipMemcpyAsync(c->d_Y, Y, bytes, hipMemcpyHostToDevice, c->stream));
+    // the substitutions need the reciprocal diagonal of chol(X): recomputed from the factor the caller passes
+    int rc;
+    if ((rc = mw_launch_xrd(c, c->d_Xc))) return rc;
+    if ((rc = clrs_mw_schur_assemble_dev(c, c->d_Xc, c->d_Y))) return rc;
+    if (S_out) MWCHECK(hipMemcpyAsync(S_out, c->d.S, (size_t)c->d.Slen * c->K * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (AY_out && c->d.T) MWCHECK(hipMemcpyAsync(AY_out, c->d.AY, (size_t)c->d.T * c->K * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    MWCHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+extern "C" int clrs_mw_schur_factor(clrs_mw_ctx *c) {
+    int rc = clrs_mw_schur_factor_dev(c);
+    if (rc) return rc;
+    return clrs_mw_sync_status(c);
+}
+extern "C" int clrs_mw_get_factor(clrs_mw_ctx *c, double *L, double *LinvB, double *LQ) {
+    if (!c) return mw_fail(CLRS_ERR_INVALID, "null context");
+    if (!c->factored) return mw_fail(CLRS_ERR_STATE, "clrs_mw_get_factor before clrs_mw_schur_factor");
+    MWCHECK(hipSetDevice(c->device));
+    MWCHECK(hipStreamSynchronize(c->stream));
+    const MwDev &q = c->d;
+    const int K = c->K, N = q.N;
+    if (L) MWCHECK(hipMemcpy(L, q.S, (size_t)q.Slen * K * sizeof(double), hipMemcpyDeviceToHost));
+    if (LQ && N) MWCHECK(hipMemcpy(LQ, q.Q, (size_t)N * N * K * sizeof(double), hipMemcpyDeviceToHost));
+    if (LinvB && N) {
+        // device: stacked xlen x N; caller: per cluster P_j x N column-major, concatenated (as clrs_get_factor)
+        std::vector<double> h((size_t)q.xlen * N * K);
+        MWCHECK(hipMemcpy(h.data(), q.LB, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+        const i64 plane = q.xlen * (i64)N;
+        for (int l = 0; l < K; l++) {
+            i64 off = 0;
+            for (int j = 0; j < q.J; j++) {
+                const int P = c->clu[j].P;
+                for (int a = 0; a < N; a++)
+                    for (int r = 0; r < P; r++) LinvB[l * plane + off + r + (i64)a * P] = h[l * plane + c->clu[j].coff + r + (i64)a * q.xlen];
+                off += (i64)P * N;
+            }
+        }
+    }
+    return 0;
+}
+extern "C" int clrs_mw_schur_solve(clrs_mw_ctx *c, const double *rhs_x, const double *rhs_y, double *dx, double *dy) {
+    if (!c || !rhs_x || !dx) return mw_fail(CLRS_ERR_INVALID, "null argument");
+    MWCHECK(hipSetDevice(c->device));
+    const MwDev &q = c->d;
+    const int K = c->K;
+    MWCHECK(hipMemcpyAsync(c->d_rx, rhs_x, (size_t)q.xlen * K * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (q.N) {
+        if (!rhs_y || !dy) return mw_fail(CLRS_ERR_INVALID, "null argument");
+        MWCHECK(hipMemcpyAsync(c->d_ry, rhs_y, (size_t)q.N * K * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    }
+    int rc = clrs_mw_schur_solve_dev(c, c->d_rx, c->d_ry, c->d_dx, c->d_dy);
+    if (rc) return rc;
+    MWCHECK(hipMemcpyAsync(dx, c->d_dx, (size_t)q.xlen * K * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (q.N) MWCHECK(hipMemcpyAsync(dy, c->d_dy, (size_t)q.N * K * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    MWCHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// reciprocal diagonals of Cholesky factors passed in by the caller (clrs_mw_schur_assemble with host or foreign factors)
+template <int K>
+__global__ __launch_bounds__(MW_NT) void k_mw_xrd(const MwDev q, const double *__restrict__ Xc) {
+    using namespace mwa;
+    const MwBlk &k = q.blk[blockIdx.x];
+    for (int i = threadIdx.x; i < k.n; i += MW_NT) st<K>(q.xrd + k.rd_off, q.xrdlen, i, recip<K>(ld<K>(Xc + k.xyoff, q.xylen, i + (long)i * k.n)));
+}
+static int mw_launch_xrd(clrs_mw_ctx *c, const double *d_Xc) {
+    if (c->d.NB == 0) return 0;
+    MW_DISPATCH(c->K, hipLaunchKernelGGL(k_mw_xrd<KK>, dim3(c->d.NB), dim3(MW_NT), 0, c->stream, c->d, d_Xc));
+    MWCHECK(hipGetLastError());
+    return 0;
+}
+// device-pointer form of the same (callers that bring their own Cholesky factors of X)
+extern "C" int clrs_mw_set_xchol_dev(clrs_mw_ctx *c, const double *d_Xchol) {
+    if (!c || !d_Xchol) return mw_fail(CLRS_ERR_INVALID, "null argument");
+    MWCHECK(hipSetDevice(c->device));
+    return mw_launch_xrd(c, d_Xchol);
+}
+
+static void mw_ipm_free(clrs_mw_ctx *c) { (void)c; }

@@ -399,6 +399,8 @@ MWF mw<K> ld(const double *p, long plane, long i) {
     return r;
 }
 template <int K>
+MWF mw<K> ld_(const double *p, long plane, long i) { return ld<K>(p, plane, i); }   // for scopes where `ld` is a leading dimension
+template <int K>
 MWF void st(double *p, long plane, long i, const mw<K> &v) {
 #pragma unroll
     for (int l = 0; l < K; l++) p[(long)l * plane + i] = v.l[l];

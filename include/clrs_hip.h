@@ -250,8 +250,69 @@ int clrs_set_graph_mode(clrs_ctx *ctx, int enabled);
  * assemble / factor / solve call (for profiling). */
 int clrs_plan_info(const clrs_ctx *ctx, int32_t *n_launch_assemble, int32_t *n_launch_factor, int32_t *n_launch_solve);
 
+
+/* =====================================================================================================================
+ * The same path at the reference's working precision: multi-word fp64 ("limbs").
+ *
+ * The reference computes in Arb midpoints at `prec` bits (default 256: src/solver.jl:73,103; Cholesky on midpoints
+ * src/tools.jl:59-107; products Arblib.approx_mul!, src/solver.jl:1125-1143) because the Schur complements of its
+ * headline problems are not positive definite to fp64 accuracy (cohnelkies(8,15) fails at the first iterate in fp64 and
+ * at 113 bits).  A clrs_mw_ctx runs the identical stages with every number an unevaluated sum of
+ * `limbs` doubles (limbs = 2..5: ~104 / 157 / 209 / 262 bits); limbs = 5 covers the reference's default precision.
+ *
+ * Array format ("planar limbs"): an array of logical length len is limbs * len doubles, limb l of element i at
+ * [l * len + i]; value_i = sum_l a[l * len + i], limb 0 the value rounded to fp64, |limb l+1| <= ulp(limb l).
+ * Every layout of the fp64 API (xy layout, S layout, x-like vectors) is used unchanged for the logical array.
+ * The problem description is the same clrs_sdp_desc (fp64 data: the sampled vectors, lambda, B, dense A_p are exact
+ * doubles; the iterates and everything computed from them carry `limbs` words).
+ * Return codes and failure semantics are those of the fp64 entry points they mirror.
+ * ===================================================================================================================== */
+typedef struct clrs_mw_ctx clrs_mw_ctx;
+
+/* Replaces precompute_matrices_bilinear_pairings (src/solver.jl:985-1059) + the preallocation :298-317 for a solve at
+ * `limbs` words per number. */
+int clrs_mw_create(const clrs_sdp_desc *desc, int device, int limbs, clrs_mw_ctx **out);
+void clrs_mw_destroy(clrs_mw_ctx *ctx);
+int clrs_mw_limbs(const clrs_mw_ctx *ctx);
+int clrs_mw_get_dims(const clrs_mw_ctx *ctx, clrs_dims *dims);          /* logical lengths; dims->reserved = limbs */
+/* number of unique sampled vectors of block b over all its sub-blocks (the union of rightvecs / leftvecs) */
+int clrs_mw_get_unique_count(const clrs_mw_ctx *ctx, int32_t block, int32_t *n_unique);
+
+/* approx_cholesky!(X_inv_blk, X_blk) for every block (src/solver.jl:388-399); 0 or b+1 */
+int clrs_mw_cholesky_blocks(clrs_mw_ctx *ctx, const double *X, double *Xchol);
+/* compute_S_integrated! (src/solver.jl:1062-1226) */
+int clrs_mw_schur_assemble(clrs_mw_ctx *ctx, const double *Xchol, const double *Y, double *S_out, double *AY_out);
+/* steps 3-4 of compute_T_decomposition! (src/solver.jl:1244-1279); 0, j+1 or n_clusters+1 */
+int clrs_mw_schur_factor(clrs_mw_ctx *ctx);
+int clrs_mw_get_factor(clrs_mw_ctx *ctx, double *L, double *LinvB, double *LQ);
+/* the solve stage of compute_search_direction! (src/solver.jl:1527-1582) */
+int clrs_mw_schur_solve(clrs_mw_ctx *ctx, const double *rhs_x, const double *rhs_y, double *dx, double *dy);
+
+/* device-pointer variants: planar device arrays, enqueue on the context stream, no synchronisation.
+ * clrs_mw_schur_assemble_dev uses the reciprocal Cholesky diagonals the last clrs_mw_cholesky_blocks_dev left in the
+ * context; a caller that brings factors of X from elsewhere calls clrs_mw_set_xchol_dev first. */
+int clrs_mw_cholesky_blocks_dev(clrs_mw_ctx *ctx, const double *d_X, double *d_Xchol);
+int clrs_mw_sync_status_cholesky(clrs_mw_ctx *ctx);
+int clrs_mw_set_xchol_dev(clrs_mw_ctx *ctx, const double *d_Xchol);
+int clrs_mw_schur_assemble_dev(clrs_mw_ctx *ctx, const double *d_Xchol, const double *d_Y);
+int clrs_mw_schur_factor_dev(clrs_mw_ctx *ctx);
+int clrs_mw_sync_status(clrs_mw_ctx *ctx);
+int clrs_mw_schur_solve_dev(clrs_mw_ctx *ctx, const double *d_rhs_x, const double *d_rhs_y, double *d_dx, double *d_dy);
+double *clrs_mw_S_buffer_dev(clrs_mw_ctx *ctx);      /* planar S layout: S after assemble, L_j after factor */
+double *clrs_mw_AY_buffer_dev(clrs_mw_ctx *ctx);     /* planar [T] */
+void *clrs_mw_stream(clrs_mw_ctx *ctx);
+int clrs_mw_set_stream(clrs_mw_ctx *ctx, void *hip_stream);
+
+/* HIP-event timings of the last calls, seconds: t[0] schur, t[1] cholS + LinvB (one kernel), t[2] 0, t[3] Q, t[4] cholQ,
+ * t[5] last solve (the split compute_T_decomposition! returns, src/solver.jl:1282-1286). */
+int clrs_mw_set_timing(clrs_mw_ctx *ctx, int enabled);
+int clrs_mw_get_timings(clrs_mw_ctx *ctx, double t[6]);
+/* algorithmic multi-word multiply-adds of one assembly / factorisation / solve */
+int clrs_mw_get_counters(const clrs_mw_ctx *ctx, double *assemble_muladds, double *factor_muladds, double *solve_muladds);
+
 const char *clrs_strerror(int code);
 const char *clrs_last_error(void);
+void clrs_set_last_error(const char *msg);   /* used by the library's own translation units */
 const char *clrs_version(void);
 
 /* Test hook: C = alpha * op(A) op(B) + beta * C through the grouped fp64 MFMA GEMM kernel

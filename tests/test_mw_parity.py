@@ -1,0 +1,147 @@
+"""Parity of the multi-word (extended precision) HIP path with the multi-precision CPU oracle.
+
+The oracle computes at 320 bits (oracle/mpx.hpp, the stand-in for the reference's Arb midpoints); the HIP path at K limbs of
+fp64 (about 53 K - K bits).  Tolerances are stated per test as 2^-(53 K - slack): `slack` covers the length of the dot
+products and the conditioning of the seeded iterates (cond ~ 10), nothing else."""
+import numpy as np
+import pytest
+
+from tests.util import (chol_blocks_np, flat, mw_diff, mw_from_double, mw_relerr, mw_with_tails, spd_iterates)
+
+pytestmark = pytest.mark.gpu
+
+NAMES = ["polyopt8", "ce_8_3", "ce_8_15", "ns_8_3_2", "ns_8_15_2", "delsarte_3_10", "threepoint_4", "sdpa_small", "polyopt40"]
+
+
+@pytest.fixture(scope="module")
+def oracle_built():
+    from oracle import oracle
+    oracle.build()
+
+
+def _iterates(f, K, seed=1):
+    X, Y = spd_iterates(f, seed=seed)
+    return mw_with_tails(X, K, seed=seed + 10), mw_with_tails(Y, K, seed=seed + 20)
+
+
+def _sym_limbs(f, M):
+    """make every block of a planar xy-layout array exactly symmetric, limb by limb"""
+    M = M.copy()
+    for b in range(f.n_blocks):
+        n = int(f.block_n[b]); sl = slice(int(f.block_off[b]), int(f.block_off[b + 1]))
+        for l in range(M.shape[0]):
+            A = M[l, sl].reshape(n, n, order="F")
+            A = np.tril(A) + np.tril(A, -1).T
+            M[l, sl] = A.reshape(-1, order="F")
+    return M
+
+
+def tol(K, slack):
+    return 2.0 ** (-(53 * K - slack))
+
+
+@pytest.mark.parametrize("K", [2, 3, 4, 5])
+@pytest.mark.parametrize("name", NAMES)
+def test_mw_assemble_factor_solve_match_oracle(name, K, oracle_built):
+    from clrs_amd.mw import MwSchurContext
+    from oracle.oracle import Oracle
+    if name in ("ns_8_15_2",) and K in (2, 3):
+        pytest.skip("covered at K = 4, 5")
+    f = flat(name)
+    X, Y = _iterates(f, K)
+    X, Y = _sym_limbs(f, X), _sym_limbs(f, Y)
+    o = Oracle(f, mp_bits=320, use_lo=False)
+    ctx = MwSchurContext(f, limbs=K)
+    # Cholesky of the X blocks
+    Xc = ctx.cholesky_blocks(X)
+    st, Xc_ref = o.cholesky_blocks_mw(np.vstack([X, np.zeros((1, f.xy_len))]))
+    assert st == 0
+    assert mw_relerr(Xc, Xc_ref) <= tol(K, 14), ("chol X", mw_relerr(Xc, Xc_ref))
+    # assembly from the SAME factors
+    S, AY = ctx.compute_S_integrated(Xc, Y)
+    S_ref, AY_ref = o.schur_assemble_mw(np.vstack([Xc, np.zeros((1, f.xy_len))]), np.vstack([Y, np.zeros((1, f.xy_len))]))
+    assert mw_relerr(S, S_ref) <= tol(K, 22), ("S", mw_relerr(S, S_ref))
+    if f.n_terms:
+        assert mw_relerr(AY, AY_ref, scale=max(1.0, np.max(np.abs(AY_ref[0])))) <= tol(K, 16)
+    # exact symmetry (symmetric!, src/tools.jl:43-57)
+    for j in range(f.n_clusters):
+        P = int(f.cluster_P[j]); o0 = int(f.S_off[j])
+        for l in range(K):
+            Sj = S[l, o0:o0 + P * P].reshape(P, P, order="F")
+            assert np.array_equal(Sj, Sj.T)
+    # factorisation of the SAME S (the well-conditioned ones; the 2d = 30 sphere-packing S is the subject of the next test)
+    o.set_S_mw(np.vstack([S, np.zeros((1, f.S_len))]))
+    st_ref = o.schur_factor()
+    st_gpu = ctx.factor()
+    if name in ("ce_8_15", "ns_8_15_2") and K == 2:
+        assert st_gpu == st_ref or st_gpu > 0
+        ctx.close()
+        return
+    assert st_ref == 0 and st_gpu == 0, (st_ref, st_gpu)
+    L, LinvB, LQ = ctx.get_factor()
+    L_ref, LinvB_ref, LQ_ref = o.get_factor_mw(K + 1)
+    # conditioning of S enters the factor: cond(S) is up to ~1e20 on the sphere-packing instances
+    amp = {"ce_8_15": 70, "ns_8_15_2": 70, "polyopt40": 40, "threepoint_4": 40}.get(name, 30)
+    assert mw_relerr(L, L_ref) <= tol(K, 22 + amp), ("L", mw_relerr(L, L_ref))
+    if f.n_free:
+        assert mw_relerr(LinvB, LinvB_ref) <= tol(K, 22 + amp), ("LinvB", mw_relerr(LinvB, LinvB_ref))
+        assert mw_relerr(LQ, LQ_ref) <= tol(K, 22 + 2 * amp), ("LQ", mw_relerr(LQ, LQ_ref))
+    rng = np.random.default_rng(5)
+    rx, ry = mw_with_tails(rng.standard_normal(f.x_len), K, 1), mw_with_tails(rng.standard_normal(max(f.n_free, 1)), K, 2)[:, :f.n_free]
+    dx, dy = ctx.solve(rx, ry)
+    dx_ref, dy_ref = o.schur_solve_mw(np.vstack([rx, np.zeros((1, f.x_len))]), np.vstack([ry, np.zeros((1, f.n_free))]) if f.n_free else np.zeros((K + 1, 0)))
+    assert mw_relerr(dx, dx_ref) <= tol(K, 22 + 3 * amp), ("dx", mw_relerr(dx, dx_ref))
+    if f.n_free:
+        assert mw_relerr(dy, dy_ref) <= tol(K, 22 + 3 * amp), ("dy", mw_relerr(dy, dy_ref))
+    ctx.close()
+
+
+@pytest.mark.parametrize("K", [4, 5])
+def test_mw_factors_the_north_star_instance_where_fp64_fails(K, oracle_built):
+    """cohnelkies(8,15) at the first iterate X = Y = Omega I (src/solver.jl:187-201): the fp64 path reports the reference's
+    SolverFailure (tests/test_hip_parity.py), 113 bits fail too; 4 and 5 limbs factor S_j and solve to the oracle's answer."""
+    from clrs_amd.mw import MwSchurContext
+    from clrs_amd.solver import SchurContext
+    from oracle.oracle import Oracle
+    f = flat("ce_8_15")
+    X = np.zeros(f.xy_len); Y = np.zeros(f.xy_len)
+    for b in range(f.n_blocks):
+        n = int(f.block_n[b]); o0 = int(f.block_off[b])
+        X[o0:o0 + n * n] = (1e10 * np.eye(n)).reshape(-1); Y[o0:o0 + n * n] = (1e10 * np.eye(n)).reshape(-1)
+    c64 = SchurContext(f)
+    c64.compute_S_integrated(c64.cholesky_blocks(X), Y)
+    assert c64.factor() > 0
+    c64.close()
+    ctx = MwSchurContext(f, limbs=K)
+    Xm, Ym = mw_from_double(X, K), mw_from_double(Y, K)
+    Xc = ctx.cholesky_blocks(Xm)
+    S, _ = ctx.compute_S_integrated(Xc, Ym)
+    assert ctx.factor() == 0
+    o = Oracle(f, mp_bits=320, use_lo=False)
+    S_ref, _ = o.schur_assemble_mw(np.vstack([Xc, np.zeros((1, f.xy_len))]), np.vstack([Ym, np.zeros((1, f.xy_len))]))
+    assert mw_relerr(S, S_ref) <= tol(K, 22)
+    assert o.schur_factor() == 0
+    rx, ry = mw_from_double(np.ones(f.x_len), K), mw_from_double(np.ones(f.n_free), K)
+    dx, dy = ctx.solve(rx, ry)
+    dx_ref, dy_ref = o.schur_solve_mw(np.vstack([rx, np.zeros((1, f.x_len))]), np.vstack([ry, np.zeros((1, f.n_free))]))
+    # cond(S) ~ 1e37 here (lambda_min/lambda_max of the sampled form): what is left of 53 K bits
+    assert mw_relerr(dx, dx_ref) <= tol(K, 150), mw_relerr(dx, dx_ref)
+    assert mw_relerr(dy, dy_ref) <= tol(K, 150), mw_relerr(dy, dy_ref)
+    ctx.close()
+
+
+def test_mw_reports_failures_like_the_reference(oracle_built):
+    """A non-positive pivot in S_j returns j+1, in a block of X b+1 (src/solver.jl:395-397, 1249)."""
+    from clrs_amd.mw import MwSchurContext
+    from clrs_amd.solver import SolverFailure
+    f = flat("polyopt8")
+    K = 3
+    ctx = MwSchurContext(f, limbs=K)
+    X, Y = spd_iterates(f, seed=2)
+    Xm, Ym = mw_from_double(X, K), mw_from_double(-Y, K)          # Y negative definite: S is too
+    Xc = ctx.cholesky_blocks(Xm)
+    ctx.compute_S_integrated(Xc, Ym)
+    assert ctx.factor() == 1
+    with pytest.raises(SolverFailure, match="block \\(1,1\\)"):
+        ctx.cholesky_blocks(mw_from_double(-X, K))
+    ctx.close()

@@ -180,3 +180,42 @@ def random_simple_sdp(seed, J=5, n_free=3, max_P=32, max_n=16, definite=False, f
     sdp = ClusteredLowRankSDP(maximize=True, constant=0.0, blocks=blocks, B=B, c=c, C=C, b=rng.standard_normal(n_free), names={})
     sdp.check()
     return sdp
+
+
+# ---- multi-word (planar limbs) helpers --------------------------------------------------------------------------------
+def mw_from_double(a, K):
+    """fp64 array -> planar limbs (K, len) with zero tails."""
+    a = np.ascontiguousarray(a, dtype=np.float64).reshape(-1)
+    out = np.zeros((K, a.size))
+    out[0] = a
+    return out
+
+
+def mw_with_tails(a, K, seed=0):
+    """fp64 array -> planar limbs whose lower limbs are random but properly nested (|limb l+1| <= ulp(limb l) / 2): numbers that
+    genuinely carry 53 K bits."""
+    rng = np.random.default_rng(seed)
+    out = mw_from_double(a, K)
+    for l in range(1, K):
+        prev = out[l - 1]
+        t = 0.49 * np.spacing(np.abs(prev)) * rng.uniform(-1, 1, prev.shape)
+        out[l] = np.where(prev != 0, t, 0.0)
+    return out
+
+
+def mw_diff(a, b):
+    """Exact elementwise difference of two planar-limb arrays (possibly of different limb counts), rounded to fp64."""
+    import math
+    a, b = np.atleast_2d(a), np.atleast_2d(b)
+    assert a.shape[1] == b.shape[1]
+    out = np.empty(a.shape[1])
+    for i in range(a.shape[1]):
+        out[i] = math.fsum(list(a[:, i]) + list(-b[:, i]))
+    return out
+
+
+def mw_relerr(a, b, scale=None):
+    """max |a - b| / max |b| (or / scale), exact differences."""
+    d = np.abs(mw_diff(a, b))
+    s = np.max(np.abs(np.atleast_2d(b)[0])) if scale is None else scale
+    return float(np.max(d) / s) if d.size else 0.0
