@@ -110,6 +110,7 @@ SYMBOLS = {
     "clrs_kernel_name": (C.c_char_p, [C.c_int]),
     "clrs_plan_info": (C.c_int, [C.c_void_p, p_i32, p_i32, p_i32]),
     "clrs_mw_create": (C.c_int, [C.POINTER(SdpDesc), C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "clrs_mw_create_ex": (C.c_int, [C.POINTER(SdpDesc), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "clrs_mw_destroy": (None, [C.c_void_p]),
     "clrs_mw_limbs": (C.c_int, [C.c_void_p]),
     "clrs_mw_get_dims": (C.c_int, [C.c_void_p, C.POINTER(Dims)]),
@@ -133,6 +134,14 @@ SYMBOLS = {
     "clrs_mw_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "clrs_mw_get_timings": (C.c_int, [C.c_void_p, p_d]),
     "clrs_mw_get_counters": (C.c_int, [C.c_void_p, p_d, p_d, p_d]),
+    "clrs_mw_ipm_create": (C.c_int, [C.c_void_p, C.POINTER(IpmData)]),
+    "clrs_mw_ipm_create_ex": (C.c_int, [C.c_void_p, C.POINTER(IpmData), C.c_int]),
+    "clrs_mw_ipm_set_params": (C.c_int, [C.c_void_p, C.POINTER(IpmParams)]),
+    "clrs_mw_ipm_init": (C.c_int, [C.c_void_p, C.c_double, C.c_double]),
+    "clrs_mw_ipm_set": (C.c_int, [C.c_void_p, p_d, p_d, p_d, p_d]),
+    "clrs_mw_ipm_iterate": (C.c_int, [C.c_void_p, C.POINTER(IpmRecord)]),
+    "clrs_mw_ipm_get": (C.c_int, [C.c_void_p, p_d, p_d, p_d, p_d]),
+    "clrs_mw_ipm_objectives": (C.c_int, [C.c_void_p, p_d]),
     "clrs_set_last_error": (None, [C.c_char_p]),
     "clrs_strerror": (C.c_char_p, [C.c_int]),
     "clrs_last_error": (C.c_char_p, []),

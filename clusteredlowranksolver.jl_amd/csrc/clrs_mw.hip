@@ -37,7 +37,7 @@ static int mw_fail(int code, const std::string &msg) {
 static const size_t MW_LDS_MAX = 160 * 1024 - 2048;     // bytes of LDS one workgroup may claim on gfx950 (margin for the runtime)
 
 struct clrs_mw_ctx {
-    int device = 0, K = 4;
+    int device = 0, K = 4, DK = 1;
     hipStream_t stream = nullptr;
     bool own_stream = true;
     MwDev d = {};
@@ -76,14 +76,15 @@ static int mw_dmalloc(clrs_mw_ctx *c, double **d, i64 n) {
     return 0;
 }
 
-#define MW_DISPATCH(Kv, ...)                                   \
-    switch (Kv) {                                              \
-    case 2: { constexpr int KK = 2; __VA_ARGS__; } break;      \
-    case 3: { constexpr int KK = 3; __VA_ARGS__; } break;      \
-    case 4: { constexpr int KK = 4; __VA_ARGS__; } break;      \
-    case 5: { constexpr int KK = 5; __VA_ARGS__; } break;      \
-    default: return mw_fail(CLRS_ERR_INVALID, "limbs must be 2..5"); \
-    }
+// dispatch over the limb count K of the computed numbers and DK of the problem data (1: fp64, 2: double-double)
+#define MW_CASE(Kc, Dc, ...) if (c_K_ == Kc && c_D_ == Dc) { constexpr int KK = Kc; constexpr int DD = Dc; __VA_ARGS__; } else
+#define MW_DISPATCH(ctx, ...)                                                                                       \
+    do {                                                                                                            \
+        const int c_K_ = (ctx)->K, c_D_ = (ctx)->DK;                                                                \
+        MW_CASE(2, 1, __VA_ARGS__) MW_CASE(2, 2, __VA_ARGS__) MW_CASE(3, 1, __VA_ARGS__) MW_CASE(3, 2, __VA_ARGS__)  \
+        MW_CASE(4, 1, __VA_ARGS__) MW_CASE(4, 2, __VA_ARGS__) MW_CASE(5, 1, __VA_ARGS__) MW_CASE(5, 2, __VA_ARGS__)  \
+        return mw_fail(CLRS_ERR_INVALID, "limbs must be 2..5 and data limbs 1 or 2");                               \
+    } while (0)
 
 template <class F>
 static int mw_set_lds(F kernel, size_t bytes) {
@@ -95,9 +96,15 @@ extern "C" void clrs_mw_destroy(clrs_mw_ctx *c);
 static void mw_ipm_free(clrs_mw_ctx *c);
 static int mw_launch_xrd(clrs_mw_ctx *c, const double *d_Xc);
 
+extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int device, int limbs, clrs_mw_ctx **out);
 extern "C" int clrs_mw_create(const clrs_sdp_desc *d, int device, int limbs, clrs_mw_ctx **out) {
+    return clrs_mw_create_ex(d, 1, device, limbs, out);
+}
+
+extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int device, int limbs, clrs_mw_ctx **out) {
     if (!d || !out) return mw_fail(CLRS_ERR_INVALID, "null argument");
     if (limbs < 2 || limbs > 5) return mw_fail(CLRS_ERR_INVALID, "limbs must be 2..5");
+    if (data_limbs < 1 || data_limbs > 2 || data_limbs > limbs) return mw_fail(CLRS_ERR_INVALID, "data limbs must be 1 or 2 (and at most limbs)");
     *out = nullptr;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device >= ndev) return mw_fail(CLRS_ERR_NO_DEVICE, "no usable HIP device");
@@ -105,7 +112,8 @@ extern "C" int clrs_mw_create(const clrs_sdp_desc *d, int device, int limbs, clr
     clrs_mw_ctx *c = new clrs_mw_ctx();
     c->device = device;
     c->K = limbs;
-    const int K = limbs;
+    c->DK = data_limbs;
+    const int K = limbs, DK = data_limbs;
     const int J = d->n_clusters, N = d->n_free, NB = d->n_blocks;
     if (J <= 0 || N < 0 || NB < 0) { delete c; return mw_fail(CLRS_ERR_INVALID, "bad sizes"); }
     int rc = 0;
@@ -127,10 +135,17 @@ extern "C" int clrs_mw_create(const clrs_sdp_desc *d, int device, int limbs, clr
     // ---- blocks, unique expanded vectors, term tables ----
     c->blk.resize(NB);
     const i64 T = NB ? d->term_ptr[NB] : 0, D = NB ? d->dense_ptr[NB] : 0;
-    std::vector<double> hV;
+    // planes of the description's data arrays (data_limbs planes each)
+    const i64 vec_plane = T ? d->term_vec_ptr[T] : 0, dA_plane = D ? d->dense_A_ptr[D] : 0;
+    std::vector<double> hV;          // limb 0 while the tables are built; the other limbs follow below
     std::vector<int> hvrow, st_a(std::max<i64>(T, 1)), st_b(std::max<i64>(T, 1)), htptr, ay_a(std::max<i64>(T, 1), 0), ay_b(std::max<i64>(T, 1), 0),
         ay_blk(std::max<i64>(T, 1), -1), hdmap, lr_list, dn_list;
-    std::vector<double> st_lam(std::max<i64>(T, 1)), hdA;
+    std::vector<double> st_lam((size_t)std::max<i64>(T, 1) * DK), hdA;
+    std::vector<std::vector<double>> hVl(DK), hdAl(DK);     // per limb
+    // for the interior-point iteration around the path (clrs_mw_ipm.hip.h), sorted term order: original term, vs at sub-block r / ws at
+    // sub-block s (compute_weighted_A!, src/solver.jl:1433-1459), ws at r / vs at s (trace_A, :1334-1341), and the flags s <= r, r != s
+    std::vector<int> st_orig(std::max<i64>(T, 1)), st_war(std::max<i64>(T, 1)), st_wac(std::max<i64>(T, 1)), st_trl(std::max<i64>(T, 1)),
+        st_trd(std::max<i64>(T, 1)), st_flag(std::max<i64>(T, 1)), st_p(std::max<i64>(T, 1));
     i64 xyoff = 0, rdoff = 0, zoff = 0, goff = 0, sdoff = 0, woff = 0;
     double cnt_mul = 0;
     for (int b = 0; b < NB; b++) {
@@ -142,6 +157,7 @@ extern "C" int clrs_mw_create(const clrs_sdp_desc *d, int device, int limbs, clr
         k.delta = d->block_delta[b];
         k.n = m * k.delta;
         k.kind = d->block_kind[b];
+        k.m = m;
         k.P = c->clu[k.j].P;
         if (k.n <= 0 || (k.kind != 0 && m != 1)) MW_BAIL(CLRS_ERR_INVALID, "bad block shape");
         k.xyoff = xyoff; xyoff += (i64)k.n * k.n;
@@ -153,16 +169,15 @@ extern "C" int clrs_mw_create(const clrs_sdp_desc *d, int device, int limbs, clr
         if (k.kind == 0) {
             lr_list.push_back(b);
             const i64 t0 = d->term_ptr[b], t1 = d->term_ptr[b + 1];
+            k.t0 = t0;
             // unique expanded vectors: (sub-block, delta values), exact equality, first occurrence wins
-            std::vector<std::pair<int, const double *>> uniq;
+            std::vector<std::pair<int, const double *>> uniq;      // (sub-block, pointer to limb 0 of the vector inside term_vs / term_ws)
             auto find_or_add = [&](int r, const double *v) -> int {
-                for (size_t u = 0; u < uniq.size(); u++)
-                    if (uniq[u].first == r && std::memcmp(uniq[u].second, v, sizeof(double) * dl) == 0) return (int)u;
-                // memcmp distinguishes -0.0 from 0.0 and equal NaNs; compare by value where bits differ
                 for (size_t u = 0; u < uniq.size(); u++) {
                     if (uniq[u].first != r) continue;
                     bool eq = true;
-                    for (int i = 0; i < dl && eq; i++) eq = uniq[u].second[i] == v[i];
+                    for (int l = 0; l < DK && eq; l++)
+                        for (int i = 0; i < dl && eq; i++) eq = uniq[u].second[(i64)l * vec_plane + i] == v[(i64)l * vec_plane + i];
                     if (eq) return (int)u;
                 }
                 uniq.push_back({r, v});
@@ -176,23 +191,26 @@ extern "C" int clrs_mw_create(const clrs_sdp_desc *d, int device, int limbs, clr
                 index[std::make_tuple(d->term_p[t], d->term_r[t], d->term_s[t], d->term_rank[t])] = t;
             }
             // R(t): vs of the term at sub-block r; Lself(t): ws of the term at sub-block r   (rightvecs[r] / leftvecs[r], src/solver.jl:1011, 1032)
-            std::vector<int> Rt(t1 - t0), Ls(t1 - t0);
+            std::vector<int> Rt(t1 - t0), Ls(t1 - t0), Cs(t1 - t0), Ds(t1 - t0);
             std::vector<i64> partner(t1 - t0);
             for (i64 t = t0; t < t1; t++) {
                 Rt[t - t0] = find_or_add(d->term_r[t], d->term_vs + d->term_vec_ptr[t]);
                 Ls[t - t0] = find_or_add(d->term_r[t], d->term_ws + d->term_vec_ptr[t]);
+                Cs[t - t0] = find_or_add(d->term_s[t], d->term_ws + d->term_vec_ptr[t]);
+                Ds[t - t0] = find_or_add(d->term_s[t], d->term_vs + d->term_vec_ptr[t]);
                 auto it = index.find(std::make_tuple(d->term_p[t], d->term_s[t], d->term_r[t], d->term_rank[t]));
                 if (it == index.end()) MW_BAIL(CLRS_ERR_INVALID, "term without transposed partner: A[r,s][p] must equal A[s,r][p]^T");
                 partner[t - t0] = it->second;
             }
             k.U = (int)uniq.size();
             c->maxU = std::max(c->maxU, k.U);
-            k.v_off = (i64)hV.size();
+            k.v_off = (i64)hVl[0].size();
             k.vrow_off = (i64)hvrow.size();
-            hV.resize(hV.size() + (size_t)n * k.U, 0.0);
+            for (int l = 0; l < DK; l++) hVl[l].resize(hVl[l].size() + (size_t)n * k.U, 0.0);
             for (int u = 0; u < k.U; u++) {
                 hvrow.push_back(uniq[u].first * dl);
-                for (int i = 0; i < dl; i++) hV[k.v_off + (i64)u * n + uniq[u].first * dl + i] = uniq[u].second[i];
+                for (int l = 0; l < DK; l++)
+                    for (int i = 0; i < dl; i++) hVl[l][k.v_off + (i64)u * n + uniq[u].first * dl + i] = uniq[u].second[(i64)l * vec_plane + i];
             }
             k.z_off = zoff; zoff += (i64)n * k.U;
             k.g_off = goff; goff += (i64)k.U * k.U;
@@ -210,7 +228,12 @@ extern "C" int clrs_mw_create(const clrs_sdp_desc *d, int device, int limbs, clr
                 const i64 t = order[i];
                 st_a[t0 + i] = Ls[partner[t - t0] - t0];      // pointers_left[s][(r,p,k)] = ws of A[s,r][p]
                 st_b[t0 + i] = Rt[t - t0];                    // pointers_right[r][(s,p,k)] = vs of A[r,s][p]
-                st_lam[t0 + i] = d->term_lambda[t];
+                for (int l = 0; l < DK; l++) st_lam[(size_t)l * std::max<i64>(T, 1) + t0 + i] = d->term_lambda[(i64)l * T + t];
+                st_orig[t0 + i] = (int)t;
+                st_p[t0 + i] = d->term_p[t];
+                st_war[t0 + i] = Rt[t - t0]; st_wac[t0 + i] = Cs[t - t0];
+                st_trl[t0 + i] = Ls[t - t0]; st_trd[t0 + i] = Ds[t - t0];
+                st_flag[t0 + i] = (d->term_s[t] <= d->term_r[t] ? 1 : 0) | (d->term_s[t] != d->term_r[t] ? 2 : 0);
             }
             for (i64 t = t0; t < t1; t++) {                    // A_Y[r,s][idx] = bpY[r,s][left_r(s,p,k), right_s(r,p,k)]  (src/solver.jl:1162)
                 ay_blk[t] = b;
@@ -226,7 +249,7 @@ extern "C" int clrs_mw_create(const clrs_sdp_desc *d, int device, int limbs, clr
             const i64 d0 = d->dense_ptr[b], d1 = d->dense_ptr[b + 1];
             k.cnt = (int)(d1 - d0);
             k.d0 = d0;
-            k.a_off = (i64)hdA.size();
+            k.a_off = (i64)hdAl[0].size();
             k.dmap_off = (i64)hdmap.size();
             hdmap.resize(hdmap.size() + P, -1);
             for (i64 e = d0; e < d1; e++) {
@@ -234,7 +257,8 @@ extern "C" int clrs_mw_create(const clrs_sdp_desc *d, int device, int limbs, clr
                 if (p < 0 || p >= P) MW_BAIL(CLRS_ERR_INVALID, "dense constraint index out of range");
                 if (d->dense_A_ptr[e + 1] - d->dense_A_ptr[e] != (i64)n * n) MW_BAIL(CLRS_ERR_INVALID, "dense matrix must have n*n entries");
                 hdmap[k.dmap_off + p] = (int)(e - d0);
-                hdA.insert(hdA.end(), d->dense_A + d->dense_A_ptr[e], d->dense_A + d->dense_A_ptr[e + 1]);
+                for (int l = 0; l < DK; l++)
+                    hdAl[l].insert(hdAl[l].end(), d->dense_A + (i64)l * dA_plane + d->dense_A_ptr[e], d->dense_A + (i64)l * dA_plane + d->dense_A_ptr[e + 1]);
             }
             k.sd_off = sdoff; sdoff += (i64)k.cnt * k.cnt;
             k.w_off = woff; woff += (i64)k.cnt * n * n;
@@ -281,9 +305,9 @@ extern "C" int clrs_mw_create(const clrs_sdp_desc *d, int device, int limbs, clr
         c->sm_mid = ((size_t)N * K + (c->lds_q ? qn : 0)) * 8;
         if (c->sm_fwd > MW_LDS_MAX || c->sm_mid > MW_LDS_MAX) MW_BAIL(CLRS_ERR_INVALID, "cluster too large for the multi-word solve kernels");
     }
-    MW_DISPATCH(K, {
-        MW_TRY(mw_set_lds(k_mw_potrf_x<KK>, c->sm_x)); MW_TRY(mw_set_lds(k_mw_zt<KK>, c->sm_zt)); MW_TRY(mw_set_lds(k_mw_dense<KK>, c->sm_dense));
-        MW_TRY(mw_set_lds(k_mw_factor<KK>, c->sm_factor)); MW_TRY(mw_set_lds(k_mw_potrf_q<KK>, c->sm_q));
+    MW_DISPATCH(c, {
+        MW_TRY(mw_set_lds(k_mw_potrf_x<KK>, c->sm_x)); MW_TRY(mw_set_lds(k_mw_zt<KK, DD>, c->sm_zt)); MW_TRY(mw_set_lds(k_mw_dense<KK, DD>, c->sm_dense));
+        MW_TRY(mw_set_lds(k_mw_factor<KK, DD>, c->sm_factor)); MW_TRY(mw_set_lds(k_mw_potrf_q<KK>, c->sm_q));
         MW_TRY(mw_set_lds(k_mw_solve_fwd<KK>, c->sm_fwd)); MW_TRY(mw_set_lds(k_mw_solve_mid<KK>, c->sm_mid)); MW_TRY(mw_set_lds(k_mw_solve_bwd<KK>, c->sm_bwd));
     });
     // ---- upload ----
@@ -292,23 +316,32 @@ extern "C" int clrs_mw_create(const clrs_sdp_desc *d, int device, int limbs, clr
     q.xylen = xyoff; q.xlen = xlen; q.Slen = Slen; q.T = T; q.xrdlen = rdoff;
     q.zlen = std::max<i64>(zoff, 1); q.glen = std::max<i64>(goff, 1); q.wlen = std::max<i64>(woff, 1); q.sdlen = std::max<i64>(sdoff, 1);
     std::vector<int> hdense_p(d->dense_p, d->dense_p + D);
-    std::vector<double> hB(d->B, d->B + xlen * (i64)N);
     // B arrives per cluster (P_j x N column-major, concatenated); the kernels read one stacked xlen x N matrix
-    std::vector<double> hBs((size_t)xlen * N, 0.0);
-    {
+    const i64 Bp = xlen * (i64)N;
+    std::vector<double> hBs((size_t)std::max<i64>(Bp, 1) * DK, 0.0);
+    for (int l = 0; l < DK; l++) {
         i64 off = 0;
         for (int j = 0; j < J; j++) {
             const int P = c->clu[j].P;
             for (int a = 0; a < N; a++)
-                for (int r = 0; r < P; r++) hBs[c->clu[j].coff + r + (i64)a * xlen] = hB[off + r + (i64)a * P];
+                for (int r = 0; r < P; r++) hBs[(size_t)l * std::max<i64>(Bp, 1) + c->clu[j].coff + r + (i64)a * xlen] = d->B[(i64)l * Bp + off + r + (i64)a * P];
             off += (i64)P * N;
         }
+    }
+    q.Vp = std::max<i64>((i64)hVl[0].size(), 1); q.dAp = std::max<i64>((i64)hdAl[0].size(), 1); q.lamp = std::max<i64>(T, 1); q.Bp = std::max<i64>(Bp, 1);
+    hV.assign((size_t)q.Vp * DK, 0.0);
+    hdA.assign((size_t)q.dAp * DK, 0.0);
+    for (int l = 0; l < DK; l++) {
+        std::copy(hVl[l].begin(), hVl[l].end(), hV.begin() + (size_t)l * q.Vp);
+        std::copy(hdAl[l].begin(), hdAl[l].end(), hdA.begin() + (size_t)l * q.dAp);
     }
     MW_TRY(mw_upload(c, c->blk, &q.blk)); MW_TRY(mw_upload(c, c->clu, &q.clu));
     MW_TRY(mw_upload(c, lr_list, &q.lr_list)); MW_TRY(mw_upload(c, dn_list, &q.dn_list));
     MW_TRY(mw_upload(c, hV, &q.V)); MW_TRY(mw_upload(c, hvrow, &q.vrow));
     MW_TRY(mw_upload(c, st_a, &q.st_a)); MW_TRY(mw_upload(c, st_b, &q.st_b)); MW_TRY(mw_upload(c, st_lam, &q.st_lam));
     MW_TRY(mw_upload(c, htptr, &q.tptr));
+    MW_TRY(mw_upload(c, st_orig, &q.st_orig)); MW_TRY(mw_upload(c, st_p, &q.st_p)); MW_TRY(mw_upload(c, st_war, &q.st_war)); MW_TRY(mw_upload(c, st_wac, &q.st_wac));
+    MW_TRY(mw_upload(c, st_trl, &q.st_trl)); MW_TRY(mw_upload(c, st_trd, &q.st_trd)); MW_TRY(mw_upload(c, st_flag, &q.st_flag));
     MW_TRY(mw_upload(c, ay_a, &q.ay_a)); MW_TRY(mw_upload(c, ay_b, &q.ay_b)); MW_TRY(mw_upload(c, ay_blk, &q.ay_blk));
     MW_TRY(mw_upload(c, hdA, &q.dA)); MW_TRY(mw_upload(c, hdmap, &q.dmap)); MW_TRY(mw_upload(c, hdense_p, &q.dense_p));
     MW_TRY(mw_upload(c, hBs, &q.B));
@@ -399,7 +432,7 @@ extern "C" int clrs_mw_cholesky_blocks_dev(clrs_mw_ctx *c, const double *d_X, do
     int rc;
     if ((rc = mw_reset_info(c, 1))) return rc;
     if (c->d.NB == 0) return 0;
-    MW_DISPATCH(c->K, hipLaunchKernelGGL(k_mw_potrf_x<KK>, dim3(c->d.NB), dim3(MW_NT), c->sm_x, c->stream, c->d, d_X, d_Xchol, c->lds_x ? 1 : 0));
+    MW_DISPATCH(c, hipLaunchKernelGGL(k_mw_potrf_x<KK>, dim3(c->d.NB), dim3(MW_NT), c->sm_x, c->stream, c->d, d_X, d_Xchol, c->lds_x ? 1 : 0));
     MWCHECK(hipGetLastError());
     return 0;
 }
@@ -415,13 +448,13 @@ extern "C" int clrs_mw_schur_assemble_dev(clrs_mw_ctx *c, const double *d_Xchol,
     MWCHECK(hipSetDevice(c->device));
     const MwDev &q = c->d;
     if (c->timing) MWCHECK(hipEventRecord(c->ev[0], c->stream));
-    MW_DISPATCH(c->K, {
+    MW_DISPATCH(c, {
         if (q.nlr) {
-            hipLaunchKernelGGL(k_mw_zt<KK>, dim3((c->maxU + MW_CT - 1) / MW_CT, q.nlr), dim3(MW_NT), c->sm_zt, c->stream, q, d_Xchol, d_Y, c->lds_zt_L ? 1 : 0);
-            hipLaunchKernelGGL(k_mw_gram<KK>, dim3((c->maxU * (c->maxU + 1) / 2 + MW_NT - 1) / MW_NT, q.nlr), dim3(MW_NT), 0, c->stream, q);
+            hipLaunchKernelGGL((k_mw_zt<KK, DD>), dim3((c->maxU + MW_CT - 1) / MW_CT, q.nlr), dim3(MW_NT), c->sm_zt, c->stream, q, d_Xchol, d_Y, c->lds_zt_L ? 1 : 0);
+            hipLaunchKernelGGL((k_mw_gram<KK, DD>), dim3((c->maxU * (c->maxU + 1) / 2 + MW_NT - 1) / MW_NT, q.nlr), dim3(MW_NT), 0, c->stream, q);
         }
-        if (q.ndn) hipLaunchKernelGGL(k_mw_dense<KK>, dim3(q.ndn), dim3(MW_NT), c->sm_dense, c->stream, q, d_Xchol, d_Y);
-        hipLaunchKernelGGL(k_mw_saccum<KK>, dim3((c->maxP * (c->maxP + 1) / 2 + MW_NT - 1) / MW_NT, q.J), dim3(MW_NT), 0, c->stream, q);
+        if (q.ndn) hipLaunchKernelGGL((k_mw_dense<KK, DD>), dim3(q.ndn), dim3(MW_NT), c->sm_dense, c->stream, q, d_Xchol, d_Y);
+        hipLaunchKernelGGL((k_mw_saccum<KK, DD>), dim3((c->maxP * (c->maxP + 1) / 2 + MW_NT - 1) / MW_NT, q.J), dim3(MW_NT), 0, c->stream, q);
         if (q.T) hipLaunchKernelGGL(k_mw_ay<KK>, dim3((unsigned)((q.T + MW_NT - 1) / MW_NT)), dim3(MW_NT), 0, c->stream, q);
     });
     MWCHECK(hipGetLastError());
@@ -439,8 +472,8 @@ extern "C" int clrs_mw_schur_factor_dev(clrs_mw_ctx *c) {
     int rc;
     if ((rc = mw_reset_info(c, 0))) return rc;
     if (c->timing) MWCHECK(hipEventRecord(c->ev[2], c->stream));
-    MW_DISPATCH(c->K, {
-        hipLaunchKernelGGL(k_mw_factor<KK>, dim3(q.J), dim3(MW_NT), c->sm_factor, c->stream, q);
+    MW_DISPATCH(c, {
+        hipLaunchKernelGGL((k_mw_factor<KK, DD>), dim3(q.J), dim3(MW_NT), c->sm_factor, c->stream, q);
         if (c->timing) (void)hipEventRecord(c->ev[3], c->stream);
         if (q.N > 0) {
             hipLaunchKernelGGL(k_mw_qgram<KK>, dim3((q.N * (q.N + 1) / 2 + MW_NT - 1) / MW_NT), dim3(MW_NT), 0, c->stream, q);
@@ -467,7 +500,7 @@ extern "C" int clrs_mw_schur_solve_dev(clrs_mw_ctx *c, const double *d_rhs_x, co
     if (q.N > 0 && (!d_rhs_y || !d_dy)) return mw_fail(CLRS_ERR_INVALID, "null argument");
     MWCHECK(hipSetDevice(c->device));
     if (c->timing) MWCHECK(hipEventRecord(c->ev[6], c->stream));
-    MW_DISPATCH(c->K, {
+    MW_DISPATCH(c, {
         hipLaunchKernelGGL(k_mw_solve_fwd<KK>, dim3(q.J), dim3(MW_NT), c->sm_fwd, c->stream, q, d_rhs_x);
         if (q.N > 0) hipLaunchKernelGGL(k_mw_solve_mid<KK>, dim3(1), dim3(MW_NT), c->sm_mid, c->stream, q, d_rhs_y, d_dy, c->lds_q ? 1 : 0);
         hipLaunchKernelGGL(k_mw_solve_bwd<KK>, dim3(q.J), dim3(MW_NT), c->sm_bwd, c->stream, q, (const double *)d_dy, d_dx);
@@ -579,7 +612,7 @@ __global__ __launch_bounds__(MW_NT) void k_mw_xrd(const MwDev q, const double *_
 }
 static int mw_launch_xrd(clrs_mw_ctx *c, const double *d_Xc) {
     if (c->d.NB == 0) return 0;
-    MW_DISPATCH(c->K, hipLaunchKernelGGL(k_mw_xrd<KK>, dim3(c->d.NB), dim3(MW_NT), 0, c->stream, c->d, d_Xc));
+    MW_DISPATCH(c, hipLaunchKernelGGL(k_mw_xrd<KK>, dim3(c->d.NB), dim3(MW_NT), 0, c->stream, c->d, d_Xc));
     MWCHECK(hipGetLastError());
     return 0;
 }
@@ -590,4 +623,4 @@ extern "C" int clrs_mw_set_xchol_dev(clrs_mw_ctx *c, const double *d_Xchol) {
     return mw_launch_xrd(c, d_Xchol);
 }
 
-static void mw_ipm_free(clrs_mw_ctx *c) { (void)c; }
+#include "clrs_mw_ipm.hip.h"

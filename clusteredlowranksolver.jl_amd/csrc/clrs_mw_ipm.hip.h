@@ -1,0 +1,828 @@
+// clrs_mw_ipm.hip.h -- the interior-point iteration around the path at the reference's working precision (included by
+// clrs_mw.hip).  SURVEY.md section 8f rows 1-2 in multi-word fp64: x, y, X, Y and every intermediate stay in HBM as planar
+// limbs; one iteration is the loop body of solvesdp (src/solver.jl:348-589):
+//   mu (:369) -> R = mu_p I - X Y (:961-970) -> chol X (:388-399) -> decomposition (:406-408, the path) -> residuals P, p, d
+//   (:863-918) -> predictor (:423) -> beta_c, mu_c (:429-434) -> R (:972-983) -> corrector (:454) -> step lengths (:462-463,
+//   1620-1693) -> update (:485-495) -> objectives (:793-804, 844-847).
+// The scalar control flow runs in one-thread kernels between the stages; the host reads one record per iteration and decides
+// termination (src/solver.jl:921-950).  The smallest eigenvalue of L^-1 dM L^-T is taken in fp64 (Householder + Sturm
+// multisection) from the multi-word congruence rounded to fp64 -- the reference, too, hands a Float64 matrix to its Lanczos
+// (KrylovKit, tol 1e-5, src/solver.jl:1659) -- everything else carries K limbs.
+
+enum { MSC_MU = 0, MSC_MUS, MSC_XY, MSC_XdY, MSC_dXY, MSC_dXdY, MSC_CY, MSC_DOBJ, MSC_POBJ, MSC_GAP, MSC_COUNT = 16 };
+enum { MREC_ITER = 0, MREC_MU, MREC_DOBJ, MREC_POBJ, MREC_GAP, MREC_DERR, MREC_PERR, MREC_AD, MREC_AP, MREC_BETA, MREC_MAXP, MREC_MAXp, MREC_MAXd,
+       MREC_PDFEAS, MREC_ERR, MREC_FSTAT, MREC_XSTAT, MREC_COUNT = 24 };
+
+struct MwIpmDev {
+    double *x, *y, *X, *Y, *dx, *dy, *dX, *dY, *R, *Xc, *Pm, *d, *rhsx, *pv, *coef;   // planar limbs
+    double *sc, *part;                 // planar scalars [MSC_COUNT]; partial dot products [5][NB]
+    unsigned long long *fmax;          // bit patterns of non-negative doubles: [0] max|P|, [1] max|d|, [2] max|p|
+    double *eig;                       // fp64 [2][NB]: smallest eigenvalue of L^-1 dM L^-T per block (X then Y)
+    double *rec;                       // fp64 record of the iteration
+    int *flags;                        // [0] pd_feas, [1] error_code, [2] Cholesky failure inside the step length
+    const double *C, *c, *b;           // problem data, DK limbs planar (sdp.C xy layout, sdp.c x layout, sdp.b [N])
+    const int *row_clu;                // [xlen] cluster of each constraint row
+    double sgn, constant;
+    int Ktot, pad;
+    double beta_infeasible, beta_feasible, gamma, dual_thr, primal_thr, max_gap, step_thr;
+    int safe_step, pad2;
+};
+
+namespace mwk {
+
+// sum over the workgroup (256 threads) of one multi-word value per thread; red: LDS, K * 256 doubles; result in every thread
+template <int K>
+__device__ mw<K> wg_reduce_sum(const mw<K> &v, double *red, int tid) {
+    st<K>(red, MW_NT, tid, v);
+    __syncthreads();
+    for (int s = MW_NT / 2; s > 0; s >>= 1) {
+        if (tid < s) st<K>(red, MW_NT, tid, add<K>(ld_<K>(red, MW_NT, tid), ld_<K>(red, MW_NT, tid + s)));
+        __syncthreads();
+    }
+    mw<K> r = ld_<K>(red, MW_NT, 0);
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ void atomic_max_abs(unsigned long long *slot, double v) {
+    atomicMax(slot, (unsigned long long)__double_as_longlong(__builtin_fabs(v)));
+}
+
+// Smallest eigenvalue of the symmetric n x n fp64 matrix A (LDS, full storage, leading dimension n; destroyed).
+// Householder tridiagonalisation by the workgroup, then Sturm-count multisection (256 shifts per round).
+// work: LDS, at least 3 n + 2 * MW_NT doubles.
+__device__ double wg_min_eig(double *A, int n, double *work, int tid) {
+    if (n == 1) return A[0];
+    double *dd = work, *ee = work + n, *v = work + 2 * n, *red = work + 3 * n, *pq = work + 3 * n + MW_NT;   // pq: n doubles inside the second MW_NT chunk
+    for (int k = 0; k < n - 2; k++) {
+        const int m = n - k - 1;           // x = A[k+1 .. n-1, k]
+        double part = 0;
+        for (int i = tid; i < m; i += MW_NT) { double t = A[(k + 1 + i) + k * n]; part += t * t; }
+        red[tid] = part;
+        __syncthreads();
+        for (int s = MW_NT / 2; s > 0; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
+        const double nrm2 = red[0];
+        __syncthreads();
+        const double x0 = A[(k + 1) + k * n];
+        const double alpha = (x0 > 0 ? -1.0 : 1.0) * __builtin_sqrt(nrm2);
+        if (tid == 0) { dd[k] = A[k + k * n]; ee[k] = (nrm2 == 0.0) ? 0.0 : alpha; }
+        if (nrm2 == 0.0 || nrm2 == x0 * x0) {            // column already tridiagonal
+            if (tid == 0) ee[k] = x0;
+            __syncthreads();
+            continue;
+        }
+        for (int i = tid; i < m; i += MW_NT) v[i] = A[(k + 1 + i) + k * n] - (i == 0 ? alpha : 0.0);
+        __syncthreads();
+        const double vtv = nrm2 - 2.0 * alpha * x0 + alpha * alpha;   // |x - alpha e1|^2
+        const double beta = 2.0 / vtv;
+        // p = beta * A22 v
+        for (int i = tid; i < m; i += MW_NT) {
+            double s = 0;
+            for (int j = 0; j < m; j++) s += A[(k + 1 + i) + (k + 1 + j) * n] * v[j];
+            pq[i] = beta * s;
+        }
+        __syncthreads();
+        part = 0;
+        for (int i = tid; i < m; i += MW_NT) part += v[i] * pq[i];
+        red[tid] = part;
+        __syncthreads();
+        for (int s = MW_NT / 2; s > 0; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
+        const double Kc = 0.5 * beta * red[0];
+        __syncthreads();
+        for (int i = tid; i < m; i += MW_NT) pq[i] -= Kc * v[i];
+        __syncthreads();
+        for (int e = tid; e < m * m; e += MW_NT) {
+            const int i = e % m, j = e / m;
+            A[(k + 1 + i) + (k + 1 + j) * n] -= v[i] * pq[j] + pq[i] * v[j];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        dd[n - 2] = A[(n - 2) + (n - 2) * n];
+        ee[n - 2] = A[(n - 1) + (n - 2) * n];
+        dd[n - 1] = A[(n - 1) + (n - 1) * n];
+    }
+    __syncthreads();
+    // Gershgorin interval
+    double lo = dd[0], hi = dd[0];
+    for (int i = 0; i < n; i++) {
+        const double r = (i > 0 ? __builtin_fabs(ee[i - 1]) : 0.0) + (i < n - 1 ? __builtin_fabs(ee[i]) : 0.0);
+        lo = fmin(lo, dd[i] - r);
+        hi = fmax(hi, dd[i] + r);
+    }
+    const double scale = fmax(__builtin_fabs(lo), __builtin_fabs(hi));
+    if (scale == 0.0) return 0.0;
+    lo -= 1e-14 * scale;
+    hi += 1e-14 * scale;
+    int *first = (int *)red;
+    for (int round = 0; round < 8; round++) {
+        // shift of thread t: lo + (t + 1) * h; count the eigenvalues below it
+        const double h = (hi - lo) / MW_NT;
+        const double sg = lo + (tid + 1) * h;
+        int cnt = 0;
+        double qv = dd[0] - sg;
+        if (qv < 0) cnt++;
+        for (int i = 1; i < n; i++) {
+            if (qv == 0.0) qv = 1e-300;
+            qv = dd[i] - sg - ee[i - 1] * ee[i - 1] / qv;
+            if (qv < 0) cnt++;
+        }
+        if (tid == 0) *first = MW_NT - 1;
+        __syncthreads();
+        if (cnt >= 1) atomicMin(first, tid);
+        __syncthreads();
+        const int f = *first;
+        __syncthreads();
+        const double nlo = lo + f * h, nhi = lo + (f + 1) * h;
+        lo = nlo;
+        hi = nhi;
+        if (hi - lo <= 4e-16 * scale) break;
+    }
+    return 0.5 * (lo + hi);
+}
+
+}  // namespace mwk
+
+// ---- block dot products: partial sums per PSD block ------------------------------------------------------------------
+// sel bit 0: <X,Y>; bit 1: <X,dY>, <dX,Y>, <dX,dY>; bit 2: <C,Y>
+template <int K, int DK>
+__global__ __launch_bounds__(MW_NT) void k_mwi_dots(const MwDev q, const MwIpmDev p, int sel) {
+    using namespace mwk;
+    const MwBlk &k = q.blk[blockIdx.x];
+    const int tid = threadIdx.x;
+    const long nn = (long)k.n * k.n;
+    acc<K> a0, a1, a2, a3, a4;
+    acc_zero<K>(a0); acc_zero<K>(a1); acc_zero<K>(a2); acc_zero<K>(a3); acc_zero<K>(a4);
+    for (long i = tid; i < nn; i += MW_NT) {
+        const long e = k.xyoff + i;
+        mw<K> Y = ld_<K>(p.Y, q.xylen, e);
+        if (sel & 1) acc_fma<K, K, K>(a0, ld_<K>(p.X, q.xylen, e), Y);
+        if (sel & 2) {
+            mw<K> X = ld_<K>(p.X, q.xylen, e), dX = ld_<K>(p.dX, q.xylen, e), dY = ld_<K>(p.dY, q.xylen, e);
+            acc_fma<K, K, K>(a1, X, dY);
+            acc_fma<K, K, K>(a2, dX, Y);
+            acc_fma<K, K, K>(a3, dX, dY);
+        }
+        if (sel & 4) acc_fma<K, K, DK>(a4, Y, ld_<DK>(p.C, q.xylen, e));
+    }
+    double *red = mw_lds;
+    if (sel & 1) { mw<K> r = wg_reduce_sum<K>(acc_result<K>(a0), red, tid); if (tid == 0) st<K>(p.part, 5L * q.NB, 0L * q.NB + blockIdx.x, r); }
+    if (sel & 2) {
+        mw<K> r = wg_reduce_sum<K>(acc_result<K>(a1), red, tid); if (tid == 0) st<K>(p.part, 5L * q.NB, 1L * q.NB + blockIdx.x, r);
+        r = wg_reduce_sum<K>(acc_result<K>(a2), red, tid); if (tid == 0) st<K>(p.part, 5L * q.NB, 2L * q.NB + blockIdx.x, r);
+        r = wg_reduce_sum<K>(acc_result<K>(a3), red, tid); if (tid == 0) st<K>(p.part, 5L * q.NB, 3L * q.NB + blockIdx.x, r);
+    }
+    if (sel & 4) { mw<K> r = wg_reduce_sum<K>(acc_result<K>(a4), red, tid); if (tid == 0) st<K>(p.part, 5L * q.NB, 4L * q.NB + blockIdx.x, r); }
+}
+
+// ---- scalar stages (one thread) ------------------------------------------------------------------------------------
+template <int K>
+__device__ mwa::mw<K> mwi_sum_part(const MwDev &q, const MwIpmDev &p, int slot) {
+    using namespace mwa;
+    acc<K> s;
+    acc_zero<K>(s);
+    for (int b = 0; b < q.NB; b++) acc_add<K, K>(s, ld_<K>(p.part, 5L * q.NB, (long)slot * q.NB + b));
+    return acc_result<K>(s);
+}
+template <int K, int DK>
+__global__ void k_mwi_scalar(const MwDev q, const MwIpmDev p, int stage, int iter) {
+    using namespace mwa;
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const long SP = MSC_COUNT;
+    if (stage == 0) {                              // start of the iteration: mu, mu_p  (src/solver.jl:369-380)
+        mw<K> xy = mwi_sum_part<K>(q, p, 0);
+        mw<K> mu = div<K>(xy, from_double<K>((double)p.Ktot));
+        st<K>(p.sc, SP, MSC_XY, xy);
+        st<K>(p.sc, SP, MSC_MU, mu);
+        st<K>(p.sc, SP, MSC_MUS, p.flags[0] ? zero<K>() : mul_d<K>(mu, p.beta_infeasible));
+        p.flags[1] = 0;
+        p.flags[2] = 0;
+        p.fmax[0] = p.fmax[1] = p.fmax[2] = 0ull;
+        for (int i = 0; i < MREC_COUNT; i++) p.rec[i] = 0.0;
+        p.rec[MREC_ITER] = iter;
+        p.rec[MREC_MU] = mu.l[0];
+        if (mu.l[0] > p.max_gap) p.flags[1] = 3;
+    } else if (stage == 1) {                       // after the residuals: errors (:441-447 use them), failures of the decomposition
+        const double maxP = __longlong_as_double((long long)p.fmax[0]), maxd = __longlong_as_double((long long)p.fmax[1]),
+                     maxp = __longlong_as_double((long long)p.fmax[2]);
+        p.rec[MREC_MAXP] = maxP; p.rec[MREC_MAXd] = maxd; p.rec[MREC_MAXp] = maxp;
+        p.rec[MREC_DERR] = fmax(maxp, maxP);       // :828-832
+        p.rec[MREC_PERR] = maxd;
+        const int fs = q.info[0], xs = q.info[1];
+        p.rec[MREC_FSTAT] = fs == MW_INFO_NONE ? 0 : fs;
+        p.rec[MREC_XSTAT] = xs == MW_INFO_NONE ? 0 : xs;
+        if ((fs != MW_INFO_NONE || xs != MW_INFO_NONE) && p.flags[1] == 0) p.flags[1] = 1;
+    } else if (stage == 2) {                       // between predictor and corrector: beta_c, mu_c (:429-434), then pd_feas (:441-447)
+        acc<K> s;
+        acc_zero<K>(s);
+        acc_add<K, K>(s, ld_<K>(p.sc, SP, MSC_XY));
+        acc_add<K, K>(s, mwi_sum_part<K>(q, p, 1));
+        acc_add<K, K>(s, mwi_sum_part<K>(q, p, 2));
+        acc_add<K, K>(s, mwi_sum_part<K>(q, p, 3));
+        mw<K> mu = ld_<K>(p.sc, SP, MSC_MU);
+        mw<K> r = div<K>(acc_result<K>(s), mul_d<K>(mu, (double)p.Ktot));
+        mw<K> beta = less<K>(r, from_double<K>(1.0)) ? mul<K>(r, r) : r;
+        mw<K> beta_c;
+        if (p.flags[0]) {                          // the feasibility of the PREVIOUS iteration decides (:429-434 come before :441-447)
+            beta_c = less<K>(from_double<K>(p.beta_feasible), beta) ? beta : from_double<K>(p.beta_feasible);
+            if (less<K>(from_double<K>(1.0), beta_c)) beta_c = from_double<K>(1.0);
+        } else {
+            beta_c = less<K>(from_double<K>(p.beta_infeasible), beta) ? beta : from_double<K>(p.beta_infeasible);
+        }
+        st<K>(p.sc, SP, MSC_MUS, mul<K>(beta_c, mu));
+        p.rec[MREC_BETA] = beta_c.l[0];
+        p.flags[0] = (p.rec[MREC_DERR] < p.dual_thr && p.rec[MREC_PERR] < p.primal_thr) ? 1 : 0;
+        p.rec[MREC_PDFEAS] = p.flags[0];
+    } else if (stage == 3) {                       // step lengths (:1684-1691, 470-483)
+        double al[2];
+        for (int w = 0; w < 2; w++) {
+            double mn = p.eig[(long)w * q.NB];
+            for (int b = 1; b < q.NB; b++) mn = fmin(mn, p.eig[(long)w * q.NB + b]);
+            const bool unsafe = p.flags[0] && !p.safe_step;
+            al[w] = (mn > -p.gamma && !unsafe) ? 1.0 : -p.gamma / mn;
+        }
+        if (p.flags[2] && p.flags[1] == 0) p.flags[1] = 1;
+        double amin = fmin(al[0], al[1]);
+        if (!(amin >= p.step_thr) && p.flags[1] == 0) p.flags[1] = 4;
+        p.rec[MREC_AD] = al[0]; p.rec[MREC_AP] = al[1];           // the table row shows the values before they are equalised
+        if (p.flags[0] && p.safe_step) al[0] = al[1] = amin;
+        p.sc[MSC_COUNT * 0 + 10] = al[0];                          // slots 10 / 11 of limb plane 0: alpha_d / alpha_p as plain doubles
+        p.sc[MSC_COUNT * 0 + 11] = al[1];
+        p.rec[MREC_ERR] = p.flags[1];
+    } else if (stage == 4) {                       // objectives of the new iterate (:793-804, 844-847)
+        acc<K> s;
+        acc_zero<K>(s);
+        for (long i = 0; i < q.xlen; i++) acc_fma<K, K, DK>(s, ld_<K>(p.x, q.xlen, i), ld_<DK>(p.c, q.xlen, i), p.sgn);
+        acc_add_d<K>(s, p.constant);
+        mw<K> dobj = acc_result<K>(s);
+        acc_zero<K>(s);
+        acc_add<K, K>(s, mwi_sum_part<K>(q, p, 4));
+        for (int a = 0; a < q.N; a++) acc_fma<K, K, DK>(s, ld_<K>(p.y, q.N, a), ld_<DK>(p.b, q.N, a));
+        acc_add_d<K>(s, p.constant);
+        mw<K> pobj = acc_result<K>(s);
+        mw<K> den = abs<K>(add<K>(dobj, pobj));
+        if (less<K>(den, from_double<K>(1.0))) den = from_double<K>(1.0);
+        mw<K> gap = div<K>(abs<K>(sub<K>(dobj, pobj)), den);
+        st<K>(p.sc, SP, MSC_DOBJ, dobj); st<K>(p.sc, SP, MSC_POBJ, pobj); st<K>(p.sc, SP, MSC_GAP, gap);
+        p.rec[MREC_DOBJ] = dobj.l[0]; p.rec[MREC_POBJ] = pobj.l[0]; p.rec[MREC_GAP] = gap.l[0];
+        p.rec[MREC_ERR] = p.flags[1];
+        p.rec[MREC_PDFEAS] = p.flags[0];
+    }
+}
+
+// ---- R = mu_s I - X Y [- dX dY]  (compute_residual_R!, src/solver.jl:961-983) ------------------------------------------
+template <int K>
+__global__ __launch_bounds__(MW_NT) void k_mwi_R(const MwDev q, const MwIpmDev p, int corrector) {
+    using namespace mwk;
+    const MwBlk &k = q.blk[blockIdx.y];
+    const int n = k.n;
+    const int e = blockIdx.x * MW_NT + threadIdx.x;
+    if (e >= n * n) return;
+    const int i = e % n, c = e / n;
+    acc<K> s;
+    acc_zero<K>(s);
+    for (int kk = 0; kk < n; kk++) acc_fma<K, K, K>(s, ld_<K>(p.X + k.xyoff, q.xylen, i + (long)kk * n), ld_<K>(p.Y + k.xyoff, q.xylen, kk + (long)c * n), -1.0);
+    if (corrector)
+        for (int kk = 0; kk < n; kk++) acc_fma<K, K, K>(s, ld_<K>(p.dX + k.xyoff, q.xylen, i + (long)kk * n), ld_<K>(p.dY + k.xyoff, q.xylen, kk + (long)c * n), -1.0);
+    if (i == c) acc_add<K, K>(s, ld_<K>(p.sc, MSC_COUNT, MSC_MUS));
+    st<K>(p.R + k.xyoff, q.xylen, e, acc_result<K>(s));
+}
+
+// ---- coefficients a_p * lambda_t of the sorted terms -------------------------------------------------------------------
+template <int K, int DK>
+__global__ __launch_bounds__(MW_NT) void k_mwi_coef(const MwDev q, const MwIpmDev p, const double *__restrict__ a) {
+    using namespace mwk;
+    const mwi64 t = (mwi64)blockIdx.x * MW_NT + threadIdx.x;
+    if (t >= q.T) return;
+    const int b = q.ay_blk[t];           // block of the term range (sorted and original order share it)
+    if (b < 0) return;
+    const MwClu &c = q.clu[q.blk[b].j];
+    st<K>(p.coef, q.T, t, mulx<K, K, DK>(ld_<K>(a, q.xlen, c.coff + q.st_p[t]), ld_<DK>(q.st_lam, q.lamp, t)));
+}
+
+// ---- sum_i a_i A_i per block (compute_weighted_A!, src/solver.jl:1410-1470) plus the rest of P or dX -------------------
+// mode 0: P = sum x_i A_i - X -+ C (:882-893), max|P|;  mode 1: dX = sum dx_i A_i + P (:1585-1594)
+template <int K, int DK>
+__global__ __launch_bounds__(MW_NT) void k_mwi_wA(const MwDev q, const MwIpmDev p, int mode) {
+    using namespace mwk;
+    const MwBlk &k = q.blk[blockIdx.y];
+    const int n = k.n;
+    const int e = blockIdx.x * MW_NT + threadIdx.x;
+    if (e >= n * n) return;
+    const int i = e % n, c = e / n;
+    const double *a = mode == 0 ? p.x : p.dx;
+    const bool mirror = (k.kind == 0 && k.m > 1);
+    if (mirror && c > i) return;                   // the lower triangle is computed and mirrored (symmetric!(:L), :1462-1465)
+    acc<K> s;
+    acc_zero<K>(s);
+    if (k.kind == 0) {
+        const double *V = q.V + k.v_off;
+        const int *tp = q.tptr + k.tptr_off;
+        for (int t = tp[0]; t < tp[k.P]; t++) {
+            if (!(q.st_flag[t] & 1)) continue;     // s <= r only (:1433)
+            const mw<DK> vi = ld_<DK>(V, q.Vp, i + (long)q.st_war[t] * n), vc = ld_<DK>(V, q.Vp, c + (long)q.st_wac[t] * n);
+            if (vi.l[0] == 0.0 || vc.l[0] == 0.0) continue;
+            constexpr int LL = (2 * DK + 1 < K) ? 2 * DK + 1 : K;
+            acc_fma<K, K, LL>(s, ld_<K>(p.coef, q.T, t), mulx<LL, DK, DK>(vi, vc));
+        }
+    } else {
+        const MwClu &cl = q.clu[k.j];
+        const long nn = (long)n * n;
+        for (int en = 0; en < k.cnt; en++)
+            acc_fma<K, K, DK>(s, ld_<K>(a, q.xlen, cl.coff + q.dense_p[k.d0 + en]), ld_<DK>(q.dA, q.dAp, k.a_off + en * nn + e));
+    }
+    mw<K> v;
+    if (mode == 0) {
+        acc_add<K, K>(s, ld_<K>(p.X + k.xyoff, q.xylen, e), -1.0);
+        acc_add<K, DK>(s, ld_<DK>(p.C, q.xylen, k.xyoff + e), -p.sgn);
+        v = acc_result<K>(s);
+        atomic_max_abs(&p.fmax[0], v.l[0]);
+        st<K>(p.Pm + k.xyoff, q.xylen, e, v);
+        if (mirror && c != i) {
+            // P is symmetric as a whole: -X -+ C are, and the weighted sum is mirrored
+            st<K>(p.Pm + k.xyoff, q.xylen, c + (long)i * n, v);
+        }
+    } else {
+        acc_add<K, K>(s, ld_<K>(p.Pm + k.xyoff, q.xylen, e));
+        v = acc_result<K>(s);
+        st<K>(p.dX + k.xyoff, q.xylen, e, v);
+        if (mirror && c != i) st<K>(p.dX + k.xyoff, q.xylen, c + (long)i * n, v);
+    }
+}
+
+// ---- T = M V for the low-rank blocks (first half of trace_A, src/solver.jl:1334-1341) -----------------------------------
+template <int K, int DK>
+__global__ __launch_bounds__(MW_NT) void k_mwi_MV(const MwDev q, const double *__restrict__ M) {
+    using namespace mwk;
+    const MwBlk &k = q.blk[q.lr_list[blockIdx.y]];
+    const int n = k.n, dl = k.delta;
+    const int e = blockIdx.x * MW_NT + threadIdx.x;
+    if (e >= n * k.U) return;
+    const int i = e % n, c = e / n;
+    const double *V = q.V + k.v_off;
+    const int r0 = q.vrow[k.vrow_off + c];
+    acc<K> s;
+    acc_zero<K>(s);
+    for (int kk = r0; kk < r0 + dl; kk++) acc_fma<K, K, DK>(s, ld_<K>(M + k.xyoff, q.xylen, i + (long)kk * n), ld_<DK>(V, q.Vp, kk + (long)c * n));
+    st<K>(q.Tm + k.z_off, q.zlen, e, acc_result<K>(s));
+}
+
+// ---- per constraint row: d = c - <A_*,Y> - B y (:863-879) or rhs_x = -d - <A_*,Z> (:1518-1523) --------------------------
+template <int K, int DK>
+__global__ __launch_bounds__(MW_NT) void k_mwi_rows(const MwDev q, const MwIpmDev p, int mode) {
+    using namespace mwk;
+    const mwi64 g = (mwi64)blockIdx.x * MW_NT + threadIdx.x;
+    if (g >= q.xlen) return;
+    const int j = p.row_clu[g];
+    const MwClu &cl = q.clu[j];
+    const int pp = (int)(g - cl.coff);
+    const double *M = mode == 0 ? p.Y : p.dY;        // Z is kept in the dY buffer, as the reference does (:1501-1514)
+    acc<K> s;
+    acc_zero<K>(s);
+    for (int b = cl.b0; b < cl.b1; b++) {
+        const MwBlk &k = q.blk[b];
+        const int n = k.n;
+        if (k.kind == 0) {
+            const int *tp = q.tptr + k.tptr_off;
+            for (int t = tp[pp]; t < tp[pp + 1]; t++) {
+                const int fl = q.st_flag[t];
+                if (!(fl & 1)) continue;                                           // s <= r (:1310)
+                const mw<DK> w = mul_pow2<DK>(ld_<DK>(q.st_lam, q.lamp, t), (fl & 2) ? 2.0 : 1.0);      // off-diagonal sub-blocks count twice (:1354-1356)
+                if (mode == 0) {
+                    acc_fma<K, K, DK>(s, ld_<K>(q.AY, q.T, q.st_orig[t]), w);      // trace_A with (Y, A_Y), :1368-1407
+                } else {
+                    const double *V = q.V + k.v_off;
+                    const int l = q.st_trl[t], dcol = q.st_trd[t], r0 = q.vrow[k.vrow_off + l];
+                    acc<K> z;
+                    acc_zero<K>(z);
+                    for (int ii = r0; ii < r0 + k.delta; ii++) acc_fma<K, K, DK>(z, ld_<K>(q.Tm + k.z_off, q.zlen, ii + (long)dcol * n), ld_<DK>(V, q.Vp, ii + (long)l * n));
+                    acc_fma<K, K, DK>(s, acc_result<K>(z), w);
+                }
+            }
+        } else {
+            const int en = q.dmap[k.dmap_off + pp];
+            if (en >= 0) {
+                const long nn = (long)n * n;
+                for (long i = 0; i < nn; i++) acc_fma<K, K, DK>(s, ld_<K>(M + k.xyoff, q.xylen, i), ld_<DK>(q.dA, q.dAp, k.a_off + en * nn + i));
+            }
+        }
+    }
+    mw<K> tr = acc_result<K>(s);
+    if (mode == 0) {
+        acc<K> r;
+        acc_zero<K>(r);
+        acc_add<K, DK>(r, ld_<DK>(p.c, q.xlen, g));
+        acc_add<K, K>(r, tr, -1.0);
+        for (int a = 0; a < q.N; a++) acc_fma<K, K, DK>(r, ld_<K>(p.y, q.N, a), ld_<DK>(q.B, q.Bp, g + (long)a * q.xlen), -1.0);
+        mw<K> dv = acc_result<K>(r);
+        atomic_max_abs(&p.fmax[1], dv.l[0]);
+        st<K>(p.d, q.xlen, g, dv);
+    } else {
+        acc<K> r;
+        acc_zero<K>(r);
+        acc_add<K, K>(r, ld_<K>(p.d, q.xlen, g), -1.0);
+        acc_add<K, K>(r, tr, -1.0);
+        st<K>(p.rhsx, q.xlen, g, acc_result<K>(r));
+    }
+}
+
+// p = +-b - B^T x  (:899-916)
+template <int K, int DK>
+__global__ __launch_bounds__(MW_NT) void k_mwi_pv(const MwDev q, const MwIpmDev p) {
+    using namespace mwk;
+    const int a = blockIdx.x * MW_NT + threadIdx.x;
+    if (a >= q.N) return;
+    acc<K> s;
+    acc_zero<K>(s);
+    acc_add<K, DK>(s, ld_<DK>(p.b, q.N, a), p.sgn);
+    for (long g = 0; g < q.xlen; g++) acc_fma<K, K, DK>(s, ld_<K>(p.x, q.xlen, g), ld_<DK>(q.B, q.Bp, g + (long)a * q.xlen), -1.0);
+    mw<K> v = acc_result<K>(s);
+    atomic_max_abs(&p.fmax[2], v.l[0]);
+    st<K>(p.pv, q.N, a, v);
+}
+
+// ---- which 0: Z = sym(X^-1 (P Y - R)) (:1501-1514);  which 1: dY = sym(X^-1 (R - dX Y)) (:1597-1613); both into dY --------
+template <int K>
+__global__ __launch_bounds__(MW_NT) void k_mwi_Z(const MwDev q, const MwIpmDev p, int which, int lds_L) {
+    using namespace mwk;
+    const MwBlk &k = q.blk[blockIdx.x];
+    const int n = k.n, tid = threadIdx.x;
+    const long nn = (long)n * n;
+    double *M = mw_lds;
+    const double *A = (which == 0 ? p.Pm : p.dX) + k.xyoff;
+    const double sg = which == 0 ? 1.0 : -1.0;
+    for (int e = tid; e < nn; e += MW_NT) {
+        const int i = e % n, c = e / n;
+        acc<K> s;
+        acc_zero<K>(s);
+        for (int kk = 0; kk < n; kk++) acc_fma<K, K, K>(s, ld_<K>(A, q.xylen, i + (long)kk * n), ld_<K>(p.Y + k.xyoff, q.xylen, kk + (long)c * n), sg);
+        acc_add<K, K>(s, ld_<K>(p.R + k.xyoff, q.xylen, e), -sg);
+        st<K>(M, nn, e, acc_result<K>(s));
+    }
+    const double *L = p.Xc + k.xyoff;
+    long lplane = q.xylen;
+    if (lds_L) {
+        double *Ls = mw_lds + (long)K * nn;
+        wg_copy<K>(Ls, nn, n, p.Xc + k.xyoff, q.xylen, n, n, n, tid);
+        L = Ls;
+        lplane = nn;
+    }
+    __syncthreads();
+    wg_trsm_lower<K>(L, lplane, n, q.xrd + k.rd_off, q.xrdlen, n, M, nn, n, n, tid);
+    wg_trsm_lower_t<K>(L, lplane, n, q.xrd + k.rd_off, q.xrdlen, n, M, nn, n, n, tid);
+    for (int e = tid; e < nn; e += MW_NT) {
+        const int i = e % n, c = e / n;
+        if (c > i) continue;
+        mw<K> v = mul_pow2<K>(add<K>(ld_<K>(M, nn, i + (long)c * n), ld_<K>(M, nn, c + (long)i * n)), 0.5);
+        st<K>(p.dY + k.xyoff, q.xylen, i + (long)c * n, v);
+        st<K>(p.dY + k.xyoff, q.xylen, c + (long)i * n, v);
+    }
+}
+
+// ---- compute_step_length (:1620-1693) per block: smallest eigenvalue of L^-1 dM L^-T, L = chol(M) -----------------------
+// which 0: (X, dX) with the factors of this iteration; which 1: (Y, dY), factored here
+template <int K>
+__global__ __launch_bounds__(MW_NT) void k_mwi_step(const MwDev q, const MwIpmDev p, int which) {
+    using namespace mwk;
+    const MwBlk &k = q.blk[blockIdx.x];
+    const int n = k.n, tid = threadIdx.x;
+    const long nn = (long)n * n;
+    const double *Mg = (which == 0 ? p.X : p.Y) + k.xyoff, *dMg = (which == 0 ? p.dX : p.dY) + k.xyoff;
+    if (n == 1) {
+        if (tid == 0) {
+            mw<K> m = ld_<K>(Mg, q.xylen, 0);
+            if (!(m.l[0] > 0.0)) { p.flags[2] = 1; p.eig[(long)which * q.NB + blockIdx.x] = 0.0; }
+            else p.eig[(long)which * q.NB + blockIdx.x] = div<K>(ld_<K>(dMg, q.xylen, 0), m).l[0] ;     // :1637-1641
+        }
+        return;
+    }
+    double *L = mw_lds, *W = mw_lds + (long)K * nn, *rd = W + (long)K * nn, *Wd = rd + (long)K * n, *work = Wd + nn;
+    if (which == 0) {
+        wg_copy<K>(L, nn, n, p.Xc + k.xyoff, q.xylen, n, n, n, tid);
+        for (int i = tid; i < n; i += MW_NT) st<K>(rd, n, i, ld_<K>(q.xrd + k.rd_off, q.xrdlen, i));
+        __syncthreads();
+    } else {
+        wg_copy<K>(L, nn, n, Mg, q.xylen, n, n, n, tid);
+        __syncthreads();
+        if (!wg_potrf<K>(L, nn, n, n, rd, n, tid)) {                                    // :1644-1646
+            if (tid == 0) { p.flags[2] = 1; p.eig[(long)which * q.NB + blockIdx.x] = 0.0; }
+            return;
+        }
+    }
+    wg_copy<K>(W, nn, n, dMg, q.xylen, n, n, n, tid);
+    __syncthreads();
+    wg_trsm_lower<K>(L, nn, n, rd, n, n, W, nn, n, n, tid);                              // :1651
+    for (int e = tid; e < nn; e += MW_NT) {                                              // transpose :1652
+        const int i = e % n, c = e / n;
+        if (c >= i) continue;
+        mw<K> a = ld_<K>(W, nn, i + (long)c * n), b2 = ld_<K>(W, nn, c + (long)i * n);
+        st<K>(W, nn, i + (long)c * n, b2);
+        st<K>(W, nn, c + (long)i * n, a);
+    }
+    __syncthreads();
+    wg_trsm_lower<K>(L, nn, n, rd, n, n, W, nn, n, n, tid);                              // :1655
+    for (int e = tid; e < nn; e += MW_NT) {
+        const int i = e % n, c = e / n;
+        Wd[e] = 0.5 * (W[i + (long)c * n] + W[c + (long)i * n]);                         // heads of the limbs: the Float64 matrix of :1659
+    }
+    __syncthreads();
+    const double ev = wg_min_eig(Wd, n, work, tid);
+    if (tid == 0) p.eig[(long)which * q.NB + blockIdx.x] = ev - 1e-5;                    // :1662
+}
+
+// ---- x, X += alpha_d (dx, dX); y, Y += alpha_p (dy, dY)  (:485-495); skipped when the iteration ended with an error ------
+template <int K>
+__global__ __launch_bounds__(MW_NT) void k_mwi_update(const MwDev q, const MwIpmDev p) {
+    using namespace mwk;
+    if (p.flags[1] != 0) return;
+    const double ad = p.sc[10], ap = p.sc[11];
+    const mwi64 tot = q.xylen + q.xlen + q.N;
+    for (mwi64 i = (mwi64)blockIdx.x * MW_NT + threadIdx.x; i < tot; i += (mwi64)gridDim.x * MW_NT) {
+        if (i < q.xylen) {
+            acc<K> s;
+            acc_zero<K>(s);
+            acc_add<K, K>(s, ld_<K>(p.X, q.xylen, i));
+            acc_fma_d<K, K>(s, ld_<K>(p.dX, q.xylen, i), ad);
+            st<K>(p.X, q.xylen, i, acc_result<K>(s));
+            acc_zero<K>(s);
+            acc_add<K, K>(s, ld_<K>(p.Y, q.xylen, i));
+            acc_fma_d<K, K>(s, ld_<K>(p.dY, q.xylen, i), ap);
+            st<K>(p.Y, q.xylen, i, acc_result<K>(s));
+        } else if (i < q.xylen + q.xlen) {
+            const mwi64 g = i - q.xylen;
+            acc<K> s;
+            acc_zero<K>(s);
+            acc_add<K, K>(s, ld_<K>(p.x, q.xlen, g));
+            acc_fma_d<K, K>(s, ld_<K>(p.dx, q.xlen, g), ad);
+            st<K>(p.x, q.xlen, g, acc_result<K>(s));
+        } else {
+            const mwi64 a = i - q.xylen - q.xlen;
+            acc<K> s;
+            acc_zero<K>(s);
+            acc_add<K, K>(s, ld_<K>(p.y, q.N, a));
+            acc_fma_d<K, K>(s, ld_<K>(p.dy, q.N, a), ap);
+            st<K>(p.y, q.N, a, acc_result<K>(s));
+        }
+    }
+}
+
+// X = omega_p I, Y = omega_d I, x = y = 0 (:187-201)
+template <int K>
+__global__ __launch_bounds__(MW_NT) void k_mwi_init(const MwDev q, const MwIpmDev p, double omega_p, double omega_d) {
+    const MwBlk &k = q.blk[blockIdx.x];
+    const int n = k.n;
+    for (int e = threadIdx.x; e < n * n; e += MW_NT) {
+        const int i = e % n, c = e / n;
+        for (int l = 0; l < K; l++) {
+            p.X[(long)l * q.xylen + k.xyoff + e] = (l == 0 && i == c) ? omega_p : 0.0;
+            p.Y[(long)l * q.xylen + k.xyoff + e] = (l == 0 && i == c) ? omega_d : 0.0;
+        }
+    }
+}
+
+// =====================================================================================================================
+// host
+// =====================================================================================================================
+struct MwIpm {
+    MwIpmDev d = {};
+    bool ready = false;
+    int iter = 0;
+    double *h_rec = nullptr;      // pinned
+    size_t sm_Z = 0, sm_step = 0;
+    bool lds_ZL = false;
+    ~MwIpm() { if (h_rec) (void)hipHostFree(h_rec); }
+};
+
+static void mw_ipm_free(clrs_mw_ctx *c) {
+    delete c->ipm;
+    c->ipm = nullptr;
+}
+
+extern "C" int clrs_mw_ipm_create_ex(clrs_mw_ctx *c, const clrs_ipm_data *data, int data_limbs);
+extern "C" int clrs_mw_ipm_create(clrs_mw_ctx *c, const clrs_ipm_data *data) { return clrs_mw_ipm_create_ex(c, data, 1); }
+
+// data->C, c, b planar with `data_limbs` planes (at most the data limbs the context was created with)
+extern "C" int clrs_mw_ipm_create_ex(clrs_mw_ctx *c, const clrs_ipm_data *data, int data_limbs) {
+    if (!c || !data) return mw_fail(CLRS_ERR_INVALID, "null argument");
+    if (data_limbs < 1 || data_limbs > c->DK) return mw_fail(CLRS_ERR_INVALID, "data limbs of the objective exceed those of the context");
+    MWCHECK(hipSetDevice(c->device));
+    const MwDev &q = c->d;
+    const int K = c->K, N = q.N, NB = q.NB;
+    if (NB == 0) return mw_fail(CLRS_ERR_INVALID, "no PSD blocks");
+    if (!c->ipm) c->ipm = new MwIpm();
+    MwIpm *st = c->ipm;
+    MwIpmDev &p = st->d;
+    int rc;
+    if (!st->ready) {
+        double **xy[] = {&p.X, &p.Y, &p.dX, &p.dY, &p.R, &p.Xc, &p.Pm};
+        for (double **b : xy) if ((rc = mw_dmalloc(c, b, q.xylen * K))) return rc;
+        double **xs[] = {&p.x, &p.dx, &p.d, &p.rhsx};
+        for (double **b : xs) if ((rc = mw_dmalloc(c, b, q.xlen * K))) return rc;
+        double **ys[] = {&p.y, &p.dy, &p.pv};
+        for (double **b : ys) if ((rc = mw_dmalloc(c, b, (i64)N * K))) return rc;
+        if ((rc = mw_dmalloc(c, &p.coef, q.T * K))) return rc;
+        if ((rc = mw_dmalloc(c, &p.sc, (i64)MSC_COUNT * K))) return rc;
+        if ((rc = mw_dmalloc(c, &p.part, 5LL * NB * K))) return rc;
+        if ((rc = mw_dmalloc(c, &p.eig, 2LL * NB))) return rc;
+        if ((rc = mw_dmalloc(c, &p.rec, MREC_COUNT))) return rc;
+        double *tmp = nullptr;
+        if ((rc = mw_dmalloc(c, &tmp, 4))) return rc;
+        p.fmax = (unsigned long long *)tmp;
+        if ((rc = mw_dmalloc(c, &tmp, 4))) return rc;
+        p.flags = (int *)tmp;
+        std::vector<int> row_clu((size_t)q.xlen);
+        for (int j = 0; j < q.J; j++)
+            for (int r = 0; r < c->clu[j].P; r++) row_clu[c->clu[j].coff + r] = j;
+        if ((rc = mw_upload(c, row_clu, &p.row_clu))) return rc;
+        double *dC, *dc, *db;
+        if ((rc = mw_dmalloc(c, &dC, q.xylen * c->DK)) || (rc = mw_dmalloc(c, &dc, q.xlen * c->DK)) || (rc = mw_dmalloc(c, &db, (i64)N * c->DK))) return rc;
+        p.C = dC; p.c = dc; p.b = db;
+        MWCHECK(hipHostMalloc((void **)&st->h_rec, sizeof(double) * MREC_COUNT, hipHostMallocDefault));
+        p.Ktot = 0;
+        size_t maxn = 0;
+        for (auto &k : c->blk) { p.Ktot += k.n; maxn = std::max(maxn, (size_t)k.n); }
+        const size_t lim = MW_LDS_MAX / sizeof(double), nnK = maxn * maxn * K;
+        if (nnK > lim) return mw_fail(CLRS_ERR_INVALID, "device-resident multi-word iteration needs PSD blocks that fit in LDS");
+        st->lds_ZL = 2 * nnK <= lim;
+        st->sm_Z = (st->lds_ZL ? 2 : 1) * nnK * 8;
+        const size_t stepd = 2 * nnK + (size_t)K * maxn + maxn * maxn + 3 * maxn + 2 * MW_NT + 8;
+        if (stepd > lim) return mw_fail(CLRS_ERR_INVALID, "device-resident multi-word iteration needs PSD blocks that fit in LDS");
+        st->sm_step = stepd * 8;
+        MW_DISPATCH(c, {
+            if ((rc = mw_set_lds(k_mwi_Z<KK>, st->sm_Z))) return rc;
+            if ((rc = mw_set_lds(k_mwi_step<KK>, st->sm_step))) return rc;
+        });
+        // default parameters (src/solver.jl:103-126)
+        p.beta_infeasible = 0.3; p.beta_feasible = 0.1; p.gamma = 0.9; p.dual_thr = 1e-30; p.primal_thr = 1e-30;
+        p.max_gap = 1e100; p.step_thr = 1e-7; p.safe_step = 1;
+        st->ready = true;
+    }
+    // (re)load the objective data: a context may be reused for another right-hand side / objective
+    MWCHECK(hipMemset((void *)p.C, 0, sizeof(double) * q.xylen * c->DK));
+    MWCHECK(hipMemset((void *)p.c, 0, sizeof(double) * q.xlen * c->DK));
+    if (N) MWCHECK(hipMemset((void *)p.b, 0, sizeof(double) * N * c->DK));
+    MWCHECK(hipMemcpy((void *)p.C, data->C, sizeof(double) * q.xylen * data_limbs, hipMemcpyHostToDevice));
+    MWCHECK(hipMemcpy((void *)p.c, data->c, sizeof(double) * q.xlen * data_limbs, hipMemcpyHostToDevice));
+    if (N) MWCHECK(hipMemcpy((void *)p.b, data->b, sizeof(double) * N * data_limbs, hipMemcpyHostToDevice));
+    p.sgn = data->maximize ? 1.0 : -1.0;
+    p.constant = data->constant;
+    return 0;
+}
+
+extern "C" int clrs_mw_ipm_set_params(clrs_mw_ctx *c, const clrs_ipm_params *prm) {
+    if (!c || !prm || !c->ipm || !c->ipm->ready) return mw_fail(CLRS_ERR_STATE, "clrs_mw_ipm_create first");
+    MwIpmDev &p = c->ipm->d;
+    p.beta_infeasible = prm->beta_infeasible; p.beta_feasible = prm->beta_feasible; p.gamma = prm->gamma;
+    p.dual_thr = prm->dual_error_threshold; p.primal_thr = prm->primal_error_threshold; p.max_gap = prm->max_complementary_gap;
+    p.step_thr = prm->step_length_threshold; p.safe_step = prm->safe_step;
+    return 0;
+}
+
+static int mw_ipm_objectives(clrs_mw_ctx *c) {
+    const MwDev &q = c->d;
+    const MwIpmDev &p = c->ipm->d;
+    MW_DISPATCH(c, {
+        hipLaunchKernelGGL((k_mwi_dots<KK, DD>), dim3(q.NB), dim3(MW_NT), (size_t)KK * MW_NT * 8, c->stream, q, p, 4);
+        hipLaunchKernelGGL((k_mwi_scalar<KK, DD>), dim3(1), dim3(1), 0, c->stream, q, p, 4, c->ipm->iter);
+    });
+    MWCHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int clrs_mw_ipm_init(clrs_mw_ctx *c, double omega_p, double omega_d) {
+    if (!c || !c->ipm || !c->ipm->ready) return mw_fail(CLRS_ERR_STATE, "clrs_mw_ipm_create first");
+    MWCHECK(hipSetDevice(c->device));
+    const MwDev &q = c->d;
+    MwIpm *st = c->ipm;
+    const MwIpmDev &p = st->d;
+    const int K = c->K;
+    MWCHECK(hipMemsetAsync(p.x, 0, sizeof(double) * q.xlen * K, c->stream));
+    if (q.N) MWCHECK(hipMemsetAsync(p.y, 0, sizeof(double) * q.N * K, c->stream));
+    MWCHECK(hipMemsetAsync(p.flags, 0, 4 * sizeof(double), c->stream));
+    MWCHECK(hipMemsetAsync(p.sc, 0, sizeof(double) * MSC_COUNT * K, c->stream));
+    MW_DISPATCH(c, hipLaunchKernelGGL(k_mwi_init<KK>, dim3(q.NB), dim3(MW_NT), 0, c->stream, q, p, omega_p, omega_d));
+    MWCHECK(hipGetLastError());
+    st->iter = 0;
+    int rc;
+    if ((rc = mw_ipm_objectives(c))) return rc;
+    MWCHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// warm start (dualsol / primalsol keywords, src/solver.jl:202-239): planar limbs; any pointer may be NULL (kept)
+extern "C" int clrs_mw_ipm_set(clrs_mw_ctx *c, const double *x, const double *y, const double *X, const double *Y) {
+    if (!c || !c->ipm || !c->ipm->ready) return mw_fail(CLRS_ERR_STATE, "clrs_mw_ipm_create first");
+    MWCHECK(hipSetDevice(c->device));
+    const MwDev &q = c->d;
+    const MwIpmDev &p = c->ipm->d;
+    const int K = c->K;
+    if (x) MWCHECK(hipMemcpy(p.x, x, sizeof(double) * q.xlen * K, hipMemcpyHostToDevice));
+    if (y && q.N) MWCHECK(hipMemcpy(p.y, y, sizeof(double) * q.N * K, hipMemcpyHostToDevice));
+    if (X) MWCHECK(hipMemcpy(p.X, X, sizeof(double) * q.xylen * K, hipMemcpyHostToDevice));
+    if (Y) MWCHECK(hipMemcpy(p.Y, Y, sizeof(double) * q.xylen * K, hipMemcpyHostToDevice));
+    int rc;
+    if ((rc = mw_ipm_objectives(c))) return rc;
+    MWCHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+static int mw_ipm_direction(clrs_mw_ctx *c, int corrector) {
+    const MwDev &q = c->d;
+    MwIpm *st = c->ipm;
+    const MwIpmDev &p = st->d;
+    const int maxnn = c->maxn * c->maxn;
+    int rc;
+    MW_DISPATCH(c, {
+        hipLaunchKernelGGL(k_mwi_R<KK>, dim3((maxnn + MW_NT - 1) / MW_NT, q.NB), dim3(MW_NT), 0, c->stream, q, p, corrector);
+        hipLaunchKernelGGL(k_mwi_Z<KK>, dim3(q.NB), dim3(MW_NT), st->sm_Z, c->stream, q, p, 0, st->lds_ZL ? 1 : 0);
+        if (q.nlr) hipLaunchKernelGGL((k_mwi_MV<KK, DD>), dim3((c->maxn * c->maxU + MW_NT - 1) / MW_NT, q.nlr), dim3(MW_NT), 0, c->stream, q, (const double *)p.dY);
+        hipLaunchKernelGGL((k_mwi_rows<KK, DD>), dim3((unsigned)((q.xlen + MW_NT - 1) / MW_NT)), dim3(MW_NT), 0, c->stream, q, p, 1);
+    });
+    MWCHECK(hipGetLastError());
+    if ((rc = clrs_mw_schur_solve_dev(c, p.rhsx, p.pv, p.dx, p.dy))) return rc;
+    MW_DISPATCH(c, {
+        if (q.T) hipLaunchKernelGGL((k_mwi_coef<KK, DD>), dim3((unsigned)((q.T + MW_NT - 1) / MW_NT)), dim3(MW_NT), 0, c->stream, q, p, (const double *)p.dx);
+        hipLaunchKernelGGL((k_mwi_wA<KK, DD>), dim3((maxnn + MW_NT - 1) / MW_NT, q.NB), dim3(MW_NT), 0, c->stream, q, p, 1);
+        hipLaunchKernelGGL(k_mwi_Z<KK>, dim3(q.NB), dim3(MW_NT), st->sm_Z, c->stream, q, p, 1, st->lds_ZL ? 1 : 0);
+    });
+    MWCHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int clrs_mw_ipm_iterate(clrs_mw_ctx *c, clrs_ipm_record *out) {
+    if (!c || !out || !c->ipm || !c->ipm->ready) return mw_fail(CLRS_ERR_STATE, "clrs_mw_ipm_create first");
+    MWCHECK(hipSetDevice(c->device));
+    const MwDev &q = c->d;
+    MwIpm *st = c->ipm;
+    const MwIpmDev &p = st->d;
+    const int maxnn = c->maxn * c->maxn;
+    const size_t sm_red = (size_t)c->K * MW_NT * 8;
+    int rc;
+    st->iter++;
+    MW_DISPATCH(c, {
+        hipLaunchKernelGGL((k_mwi_dots<KK, DD>), dim3(q.NB), dim3(MW_NT), sm_red, c->stream, q, p, 1);
+        hipLaunchKernelGGL((k_mwi_scalar<KK, DD>), dim3(1), dim3(1), 0, c->stream, q, p, 0, st->iter);
+    });
+    if ((rc = clrs_mw_cholesky_blocks_dev(c, p.X, p.Xc))) return rc;
+    if ((rc = clrs_mw_schur_assemble_dev(c, p.Xc, p.Y))) return rc;
+    if ((rc = clrs_mw_schur_factor_dev(c))) return rc;
+    MW_DISPATCH(c, {
+        if (q.T) hipLaunchKernelGGL((k_mwi_coef<KK, DD>), dim3((unsigned)((q.T + MW_NT - 1) / MW_NT)), dim3(MW_NT), 0, c->stream, q, p, (const double *)p.x);
+        hipLaunchKernelGGL((k_mwi_wA<KK, DD>), dim3((maxnn + MW_NT - 1) / MW_NT, q.NB), dim3(MW_NT), 0, c->stream, q, p, 0);
+        hipLaunchKernelGGL((k_mwi_rows<KK, DD>), dim3((unsigned)((q.xlen + MW_NT - 1) / MW_NT)), dim3(MW_NT), 0, c->stream, q, p, 0);
+        if (q.N) hipLaunchKernelGGL((k_mwi_pv<KK, DD>), dim3((q.N + MW_NT - 1) / MW_NT), dim3(MW_NT), 0, c->stream, q, p);
+        hipLaunchKernelGGL((k_mwi_scalar<KK, DD>), dim3(1), dim3(1), 0, c->stream, q, p, 1, st->iter);
+    });
+    MWCHECK(hipGetLastError());
+    if ((rc = mw_ipm_direction(c, 0))) return rc;
+    MW_DISPATCH(c, {
+        hipLaunchKernelGGL((k_mwi_dots<KK, DD>), dim3(q.NB), dim3(MW_NT), sm_red, c->stream, q, p, 2);
+        hipLaunchKernelGGL((k_mwi_scalar<KK, DD>), dim3(1), dim3(1), 0, c->stream, q, p, 2, st->iter);
+    });
+    if ((rc = mw_ipm_direction(c, 1))) return rc;
+    MW_DISPATCH(c, {
+        hipLaunchKernelGGL(k_mwi_step<KK>, dim3(q.NB), dim3(MW_NT), st->sm_step, c->stream, q, p, 0);
+        hipLaunchKernelGGL(k_mwi_step<KK>, dim3(q.NB), dim3(MW_NT), st->sm_step, c->stream, q, p, 1);
+        hipLaunchKernelGGL((k_mwi_scalar<KK, DD>), dim3(1), dim3(1), 0, c->stream, q, p, 3, st->iter);
+        hipLaunchKernelGGL(k_mwi_update<KK>, dim3((unsigned)std::min<i64>(1024, (q.xylen + q.xlen + q.N + MW_NT - 1) / MW_NT)), dim3(MW_NT), 0, c->stream, q, p);
+    });
+    MWCHECK(hipGetLastError());
+    if ((rc = mw_ipm_objectives(c))) return rc;
+    MWCHECK(hipMemcpyAsync(st->h_rec, p.rec, sizeof(double) * MREC_COUNT, hipMemcpyDeviceToHost, c->stream));
+    MWCHECK(hipStreamSynchronize(c->stream));
+    const double *r = st->h_rec;
+    out->iter = (int)r[MREC_ITER]; out->pd_feas = (int)r[MREC_PDFEAS]; out->error_code = (int)r[MREC_ERR];
+    out->factor_status = (int)r[MREC_FSTAT]; out->cholesky_status = (int)r[MREC_XSTAT]; out->reserved = 0;
+    out->mu = r[MREC_MU]; out->d_obj = r[MREC_DOBJ]; out->p_obj = r[MREC_POBJ]; out->gap = r[MREC_GAP];
+    out->dual_error = r[MREC_DERR]; out->primal_error = r[MREC_PERR]; out->alpha_d = r[MREC_AD]; out->alpha_p = r[MREC_AP];
+    out->beta_c = r[MREC_BETA]; out->max_P = r[MREC_MAXP]; out->max_p = r[MREC_MAXp]; out->max_d = r[MREC_MAXd];
+    return 0;
+}
+
+extern "C" int clrs_mw_ipm_get(clrs_mw_ctx *c, double *x, double *y, double *X, double *Y) {
+    if (!c || !c->ipm || !c->ipm->ready) return mw_fail(CLRS_ERR_STATE, "clrs_mw_ipm_create first");
+    MWCHECK(hipSetDevice(c->device));
+    MWCHECK(hipStreamSynchronize(c->stream));
+    const MwDev &q = c->d;
+    const MwIpmDev &p = c->ipm->d;
+    const int K = c->K;
+    if (x) MWCHECK(hipMemcpy(x, p.x, sizeof(double) * q.xlen * K, hipMemcpyDeviceToHost));
+    if (y && q.N) MWCHECK(hipMemcpy(y, p.y, sizeof(double) * q.N * K, hipMemcpyDeviceToHost));
+    if (X) MWCHECK(hipMemcpy(X, p.X, sizeof(double) * q.xylen * K, hipMemcpyDeviceToHost));
+    if (Y) MWCHECK(hipMemcpy(Y, p.Y, sizeof(double) * q.xylen * K, hipMemcpyDeviceToHost));
+    return 0;
+}
+// objectives and gap of the current iterate, K limbs each: out[0..K-1] d_obj, [K..2K-1] p_obj, [2K..3K-1] gap
+extern "C" int clrs_mw_ipm_objectives(clrs_mw_ctx *c, double *out) {
+    if (!c || !out || !c->ipm || !c->ipm->ready) return mw_fail(CLRS_ERR_STATE, "clrs_mw_ipm_create first");
+    MWCHECK(hipSetDevice(c->device));
+    MWCHECK(hipStreamSynchronize(c->stream));
+    const int K = c->K;
+    std::vector<double> h((size_t)MSC_COUNT * K);
+    MWCHECK(hipMemcpy(h.data(), c->ipm->d.sc, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int l = 0; l < K; l++) {
+        out[l] = h[(size_t)l * MSC_COUNT + MSC_DOBJ];
+        out[K + l] = h[(size_t)l * MSC_COUNT + MSC_POBJ];
+        out[2 * K + l] = h[(size_t)l * MSC_COUNT + MSC_GAP];
+    }
+    return 0;
+}

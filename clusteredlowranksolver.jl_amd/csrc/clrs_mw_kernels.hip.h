@@ -19,6 +19,8 @@
 
 #include "clrs_mw_arith.h"
 
+// Template parameters: K = limbs of every computed number, DK = limbs of the problem data (sampled vectors, lambda, dense
+// A_p, B; the reference holds them at `prec` bits too, src/interface.jl:1078-1112).  DK = 1 is plain fp64 data.
 #define MW_NT 256            // threads per workgroup, every kernel
 #define MW_CT 8              // columns of V per workgroup in k_mw_zt
 #define MW_INFO_NONE 0x7f7f7f7f
@@ -39,6 +41,8 @@ struct MwBlk {               // one PSD block (j, l)
     mwi64 w_off;             // dense: T_e = X^-1 A_e Y, cnt matrices n x n
     mwi64 dmap_off;          // dense: constraint -> entry (or -1) [P]
     mwi64 d0;                // dense: first entry in dense_p
+    mwi64 t0;                // low rank: first term (sorted arrays and original order share the range)
+    int m, pad2;
 };
 struct MwClu {               // one cluster j
     int P, b0, b1, lds;      // constraints; block range; 1 = S_j (and B_j) fit in LDS
@@ -50,15 +54,17 @@ struct MwDev {
     const MwBlk *blk;
     const MwClu *clu;
     const int *lr_list, *dn_list;       // indices of the low-rank / dense blocks
-    const double *V;
+    const double *V;                    // problem data are planar with DK limbs (DK = 1: plain fp64, DK = 2: double-double, ...)
     const int *vrow;
     const int *st_a, *st_b;             // sorted terms: unique-vector index of pointers_left[s][(r,p,k)] / pointers_right[r][(s,p,k)]
     const double *st_lam;
     const int *tptr;
+    const int *st_orig, *st_p, *st_war, *st_wac, *st_trl, *st_trd, *st_flag;   // sorted terms, for the iteration around the path (clrs_mw_ipm.hip.h)
     const int *ay_a, *ay_b, *ay_blk;    // original term order: pairing of the term
     const double *dA;
     const int *dmap, *dense_p;
-    const double *B;                    // stacked B, xlen x N column-major fp64
+    const double *B;                    // stacked B, xlen x N column-major
+    mwi64 Vp, lamp, dAp, Bp;            // plane lengths of the problem data V, st_lam, dA, B (DK limbs each, planar)
     double *Z, *Tm, *GX, *GY, *W, *Sd;  // scratch, planar
     mwi64 zlen, glen, wlen, sdlen;
     double *S, *LB, *Q, *Qs;            // S layout; stacked L^-1 B (xlen x N); Q (N x N); (unused)
@@ -200,7 +206,7 @@ __global__ __launch_bounds__(MW_NT) void k_mw_potrf_x(const MwDev q, const doubl
 // These are the reference's part_r products (src/solver.jl:1125, 1137) with X^-1 = L^-T L^-1 split over the two sides
 // of the pairing: V^T X^-1 V = Z^T Z, so the explicit inverse (inv_cho_precomp!, :1117) is never formed.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int K>
+template <int K, int DK>
 __global__ __launch_bounds__(MW_NT) void k_mw_zt(const MwDev q, const double *__restrict__ Xc, const double *__restrict__ Y, int lds_L) {
     using namespace mwk;
     const MwBlk &k = q.blk[q.lr_list[blockIdx.y]];
@@ -215,7 +221,7 @@ __global__ __launch_bounds__(MW_NT) void k_mw_zt(const MwDev q, const double *__
         const int i = e % n, c = c0 + e / n, r0 = vrow[c];
         acc<K> s;
         acc_zero<K>(s);
-        for (int kk = r0; kk < r0 + dl; kk++) acc_fma_d<K, K>(s, ld_<K>(Y + k.xyoff, q.xylen, i + (long)kk * n), V[kk + (long)c * n]);
+        for (int kk = r0; kk < r0 + dl; kk++) acc_fma<K, K, DK>(s, ld_<K>(Y + k.xyoff, q.xylen, i + (long)kk * n), ld_<DK>(V, q.Vp, kk + (long)c * n));
         st<K>(q.Tm + k.z_off, q.zlen, i + (long)c * n, acc_result<K>(s));
     }
     // Z tile in LDS: forward substitution with L
@@ -231,9 +237,8 @@ __global__ __launch_bounds__(MW_NT) void k_mw_zt(const MwDev q, const double *__
     }
     for (int e = tid; e < n * nc; e += MW_NT) {
         const int i = e % n, c = e / n;
-        Zt[e] = V[i + (long)(c0 + c) * n];
 #pragma unroll
-        for (int l = 1; l < K; l++) Zt[(long)l * zp + e] = 0.0;
+        for (int l = 0; l < K; l++) Zt[(long)l * zp + e] = l < DK ? V[(long)l * q.Vp + i + (long)(c0 + c) * n] : 0.0;
     }
     __syncthreads();
     wg_trsm_lower<K>(L, lplane, n, q.xrd + k.rd_off, q.xrdlen, n, Zt, zp, n, nc, tid);
@@ -247,7 +252,7 @@ __global__ __launch_bounds__(MW_NT) void k_mw_zt(const MwDev q, const double *__
 // Pairing matrices of a low-rank block: GX = Z^T Z = V^T X^-1 V, GY = V^T T = V^T Y V (U x U, symmetric; the
 // reference's bilinear_pairings_Xinv / _Y, src/solver.jl:1131, 1143).  One thread per entry of the lower triangle.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int K>
+template <int K, int DK>
 __global__ __launch_bounds__(MW_NT) void k_mw_gram(const MwDev q) {
     using namespace mwk;
     const MwBlk &k = q.blk[q.lr_list[blockIdx.y]];
@@ -267,7 +272,7 @@ __global__ __launch_bounds__(MW_NT) void k_mw_gram(const MwDev q) {
     mw<K> gx = acc_result<K>(s);
     acc_zero<K>(s);
     const int r0 = vrow[a];
-    for (int i = r0; i < r0 + dl; i++) acc_fma_d<K, K>(s, ld_<K>(T, q.zlen, i + (long)b * n), V[i + (long)a * n]);
+    for (int i = r0; i < r0 + dl; i++) acc_fma<K, K, DK>(s, ld_<K>(T, q.zlen, i + (long)b * n), ld_<DK>(V, q.Vp, i + (long)a * n));
     mw<K> gy = acc_result<K>(s);
     st<K>(q.GX + k.g_off, q.glen, a + (long)b * U, gx);
     st<K>(q.GX + k.g_off, q.glen, b + (long)a * U, gx);
@@ -279,7 +284,7 @@ __global__ __launch_bounds__(MW_NT) void k_mw_gram(const MwDev q) {
 // Dense ("high rank") block: T_e = X^-1 A_e Y for every matrix of the block, then the table Sd[e, e'] = <A_e', T_e>
 // (src/solver.jl:1089-1104).  One workgroup per block; n = 1 blocks take one thread per entry.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int K>
+template <int K, int DK>
 __global__ __launch_bounds__(MW_NT) void k_mw_dense(const MwDev q, const double *__restrict__ Xc, const double *__restrict__ Y) {
     using namespace mwk;
     const MwBlk &k = q.blk[q.dn_list[blockIdx.x]];
@@ -290,15 +295,14 @@ __global__ __launch_bounds__(MW_NT) void k_mw_dense(const MwDev q, const double 
     if (n == 1) {
         mw<K> rd = ld_<K>(q.xrd + k.rd_off, q.xrdlen, 0);
         mw<K> yx = mul<K>(ld_<K>(Y + k.xyoff, q.xylen, 0), mul<K>(rd, rd));      // Y / X
-        for (int e = tid; e < cnt; e += MW_NT) st<K>(W, q.wlen, e, mul_d<K>(yx, A[e]));
+        for (int e = tid; e < cnt; e += MW_NT) st<K>(W, q.wlen, e, mulx<K, K, DK>(yx, ld_<DK>(A, q.dAp, e)));
     } else {
         for (int e = 0; e < cnt; e++) {
             // M = A_e; M <- L^-1 M; M <- L^-T M; T_e = M Y
             double *M = mw_lds;
             for (int i = tid; i < nn; i += MW_NT) {
-                M[i] = A[(long)e * nn + i];
 #pragma unroll
-                for (int l = 1; l < K; l++) M[(long)l * nn + i] = 0.0;
+                for (int l = 0; l < K; l++) M[(long)l * nn + i] = l < DK ? A[(long)l * q.dAp + (long)e * nn + i] : 0.0;
             }
             __syncthreads();
             wg_trsm_lower<K>(Xc + k.xyoff, q.xylen, n, q.xrd + k.rd_off, q.xrdlen, n, M, nn, n, n, tid);
@@ -320,7 +324,7 @@ __global__ __launch_bounds__(MW_NT) void k_mw_dense(const MwDev q, const double 
         tri_index(o, e2, e1);       // e2 >= e1
         acc<K> s;
         acc_zero<K>(s);
-        for (long i = 0; i < nn; i++) acc_fma_d<K, K>(s, ld_<K>(W, q.wlen, (long)e1 * nn + i), A[(long)e2 * nn + i]);
+        for (long i = 0; i < nn; i++) acc_fma<K, K, DK>(s, ld_<K>(W, q.wlen, (long)e1 * nn + i), ld_<DK>(A, q.dAp, (long)e2 * nn + i));
         mw<K> v = acc_result<K>(s);
         st<K>(q.Sd + k.sd_off, q.sdlen, e1 + (long)e2 * cnt, v);
         st<K>(q.Sd + k.sd_off, q.sdlen, e2 + (long)e1 * cnt, v);
@@ -333,7 +337,7 @@ __global__ __launch_bounds__(MW_NT) void k_mw_dense(const MwDev q, const double 
 // (the accumulation loops src/solver.jl:1176-1212 with the four Dict lookups replaced by the sorted term table),
 // dense  Sd[e_p, e_q].  One thread per entry q >= p, mirrored write (symmetric!, src/tools.jl:43-57).
 // ---------------------------------------------------------------------------------------------------------------------
-template <int K>
+template <int K, int DK>
 __global__ __launch_bounds__(MW_NT) void k_mw_saccum(const MwDev q) {
     using namespace mwk;
     const MwClu &c = q.clu[blockIdx.y];
@@ -354,9 +358,9 @@ __global__ __launch_bounds__(MW_NT) void k_mw_saccum(const MwDev q) {
                     mw<K> gx = ld_<K>(q.GX + k.g_off, q.glen, q.st_a[t] + (long)q.st_b[t2] * U);
                     mw<K> gy = ld_<K>(q.GY + k.g_off, q.glen, q.st_a[t2] + (long)q.st_b[t] * U);
                     mw<K> w = mul<K>(gx, gy);
-                    mw<2> ll;
-                    two_prod(q.st_lam[t], q.st_lam[t2], ll.l[0], ll.l[1]);
-                    acc_fma<K, K, 2>(s, w, ll);
+                    constexpr int LL = (2 * DK + 1 < K) ? 2 * DK + 1 : K;   // lambda lambda' is exact in 2 DK limbs; one more bin so that none of them rounds
+                    mw<LL> ll = mulx<LL, DK, DK>(ld_<DK>(q.st_lam, q.lamp, t), ld_<DK>(q.st_lam, q.lamp, t2));
+                    acc_fma<K, K, LL>(s, w, ll);
                 }
             }
         } else {
@@ -385,7 +389,7 @@ __global__ __launch_bounds__(MW_NT) void k_mw_ay(const MwDev q) {
 // ---------------------------------------------------------------------------------------------------------------------
 // Factorisation of a cluster: L_j = chol(S_j) (in place in the S buffer), LinvB_j = L_j^-1 B_j.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int K>
+template <int K, int DK>
 __global__ __launch_bounds__(MW_NT) void k_mw_factor(const MwDev q) {
     using namespace mwk;
     const int j = blockIdx.x, tid = threadIdx.x;
@@ -412,9 +416,8 @@ __global__ __launch_bounds__(MW_NT) void k_mw_factor(const MwDev q) {
     // B_j (fp64) -> multi-word
     for (int e = tid; e < P * N; e += MW_NT) {
         const int i = e % P, cc = e / P;
-        Bm[i + (long)cc * ldb] = q.B[c.coff + i + (long)cc * q.xlen];
 #pragma unroll
-        for (int l = 1; l < K; l++) Bm[(long)l * bplane + i + (long)cc * ldb] = 0.0;
+        for (int l = 0; l < K; l++) Bm[(long)l * bplane + i + (long)cc * ldb] = l < DK ? q.B[(long)l * q.Bp + c.coff + i + (long)cc * q.xlen] : 0.0;
     }
     __syncthreads();
     const bool ok = wg_potrf<K>(M, mplane, P, P, q.srd + c.coff, q.xlen, tid);

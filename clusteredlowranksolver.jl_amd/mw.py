@@ -82,10 +82,15 @@ def _c(a):
 class MwSchurContext:
     """Device context of the hot path for one SDP at `limbs` words per number (see module docstring)."""
 
-    def __init__(self, sdp, limbs: int = 4, device: int = 0, timing: bool = False):
+    def __init__(self, sdp, limbs: int = 4, device: int = 0, timing: bool = False, data_limbs: int = 2):
+        """`data_limbs` = 2 (default): the problem data (sampled vectors, lambda, dense A_p, B and, in `solvesdp_mw`, C, c, b) are
+        passed as double-double, the (hi, lo) pairs a FlatSDP carries; 1: the fp64 roundings only."""
         self.flat: FlatSDP = sdp if isinstance(sdp, FlatSDP) else flatten(sdp)
         f = self.flat
         self.limbs = int(limbs)
+        self.data_limbs = int(data_limbs)
+        if self.data_limbs not in (1, 2):
+            raise ValueError("data_limbs must be 1 or 2")
         self.L = _lib.load()
         k = self._keep = {}
 
@@ -93,18 +98,28 @@ class MwSchurContext:
             k[name] = np.ascontiguousarray(arr, dtype=dt)
             return k[name]
 
+        def data(name):
+            """planar (data_limbs, len) copy of a data array of the FlatSDP: hi [, lo]"""
+            hi = np.ascontiguousarray(getattr(f, name), dtype=np.float64).reshape(-1)
+            if self.data_limbs == 1:
+                return hold(name, hi, np.float64)
+            lo = getattr(f, name + "_lo", None)
+            lo = np.zeros_like(hi) if lo is None else np.ascontiguousarray(lo, dtype=np.float64).reshape(-1)
+            return hold(name, np.vstack([hi, lo]), np.float64)
+
+        self._data = data
         d = _lib.SdpDesc()
         d.n_clusters, d.n_free, d.n_blocks = f.n_clusters, f.n_free, f.n_blocks
         d.cluster_P = hold("cluster_P", f.cluster_P, np.int32).ctypes.data_as(_lib.p_i32)
-        d.B = _dp(hold("B", f.B, np.float64))
+        d.B = _dp(data("B"))
         for name in ("block_cluster", "block_m", "block_delta", "block_kind", "term_p", "term_r", "term_s", "term_rank", "dense_p"):
             setattr(d, name, hold(name, getattr(f, name), np.int32).ctypes.data_as(_lib.p_i32))
         for name in ("term_ptr", "term_vec_ptr", "dense_ptr", "dense_A_ptr"):
             setattr(d, name, hold(name, getattr(f, name), np.int64).ctypes.data_as(_lib.p_i64))
         for name in ("term_lambda", "term_vs", "term_ws", "dense_A"):
-            setattr(d, name, _dp(hold(name, getattr(f, name), np.float64)))
+            setattr(d, name, _dp(data(name)))
         h = C.c_void_p()
-        _lib.check(self.L.clrs_mw_create(C.byref(d), int(device), self.limbs, C.byref(h)))
+        _lib.check(self.L.clrs_mw_create_ex(C.byref(d), self.data_limbs, int(device), self.limbs, C.byref(h)))
         self.h = h
         self.device = device
         if timing:
@@ -212,3 +227,91 @@ class MwSchurContext:
 
     def set_stream(self, hip_stream: int):
         _lib.check(self.L.clrs_mw_set_stream(self.h, C.c_void_p(hip_stream)))
+
+
+# ------------------------------------------------------------------------------------------------
+# solvesdp at the reference's precision, device resident (clrs_mw_ipm_*)
+# ------------------------------------------------------------------------------------------------
+
+def solvesdp_mw(sdp, limbs: Optional[int] = None, prec: Optional[int] = None, ctx: Optional[MwSchurContext] = None, device: int = 0, data_limbs: int = 2,
+                maxiterations: int = 500, beta_infeasible: float = 0.3, beta_feasible: float = 0.1, gamma: float = 0.9,
+                omega_p: float = 1e10, omega_d: float = 1e10, duality_gap_threshold: float = 1e-15,
+                dual_error_threshold: float = 1e-30, primal_error_threshold: float = 1e-30, max_complementary_gap: float = 1e100,
+                need_dual_feasible: bool = False, need_primal_feasible: bool = False, verbose: bool = False,
+                step_length_threshold: float = 1e-7, safe_step: bool = True):
+    """`solvesdp(sdp; prec, ...)` (src/solver.jl:71-127) with the whole loop body on the GPU in multi-word fp64.
+
+    Keywords and DEFAULTS are the reference's (omega = 1e10, gap 1e-15, errors 1e-30: they assume its 256-bit arithmetic):
+    `prec` bits select the limb count (`limbs_for_precision`), or pass `limbs` directly; the default is limbs = 5, which
+    covers prec = 256.  The result's x, y, X, Y are planar limbs; objectives are fp64 heads plus `objectives_limbs`.
+    Termination (src/solver.jl:921-950) is decided on the host from one record per iteration."""
+    import time
+    from .solver import SolveResult
+    f = sdp if isinstance(sdp, FlatSDP) else flatten(sdp)
+    if limbs is None:
+        limbs = limbs_for_precision(prec) if prec is not None else 5
+    own_ctx = ctx is None
+    if ctx is None:
+        ctx = MwSchurContext(f, limbs=limbs, device=device, data_limbs=data_limbs)
+    K = ctx.limbs
+    L = ctx.L
+    keep = [ctx._data("C"), ctx._data("c"), ctx._data("b") if f.n_free else np.zeros((ctx.data_limbs, 1))]
+    data = _lib.IpmData(_dp(keep[0]), _dp(keep[1]), _dp(keep[2]), int(f.maximize), 0, float(f.constant))
+    _lib.check(L.clrs_mw_ipm_create_ex(ctx.h, C.byref(data), ctx.data_limbs))
+    prm = _lib.IpmParams(beta_infeasible, beta_feasible, gamma, dual_error_threshold, primal_error_threshold, max_complementary_gap,
+                         step_length_threshold, int(safe_step), 0)
+    _lib.check(L.clrs_mw_ipm_set_params(ctx.h, C.byref(prm)))
+    _lib.check(L.clrs_mw_ipm_init(ctx.h, float(omega_p), float(omega_d)))
+    rec = _lib.IpmRecord()
+    hist = []
+    t_start = time.time()
+    error_code, it = 0, 1
+    dual_error = primal_error = gap = np.inf
+    d_obj = p_obj = f.constant
+    pd_feas = False
+    while True:
+        dual_feas, primal_feas = dual_error < dual_error_threshold, primal_error < primal_error_threshold
+        if (need_dual_feasible and dual_feas) or (need_primal_feasible and primal_feas):          # src/solver.jl:921-950
+            break
+        if dual_feas and primal_feas and gap < duality_gap_threshold:
+            break
+        if it > maxiterations:
+            error_code = 2
+            break
+        _lib.check(L.clrs_mw_ipm_iterate(ctx.h, C.byref(rec)))
+        hist.append([it, rec.mu, d_obj, p_obj, gap, rec.max_P, rec.max_p, rec.max_d, rec.alpha_d, rec.alpha_p, rec.beta_c])
+        if verbose:
+            print("%5d %8.1f %11.3e %11.3e %11.3e %10.2e %10.2e %10.2e %10.2e %10.2e %10.2e %10.2e" %
+                  (it, time.time() - t_start, rec.mu, d_obj, p_obj, gap, rec.max_P, rec.max_p, rec.max_d, rec.alpha_d, rec.alpha_p, rec.beta_c))
+        dual_error, primal_error, pd_feas = rec.dual_error, rec.primal_error, bool(rec.pd_feas)
+        if rec.error_code:
+            error_code = rec.error_code
+            if verbose and rec.error_code == 1:
+                print("SolverFailure: factor status %d, Cholesky status %d" % (rec.factor_status, rec.cholesky_status))
+            break
+        d_obj, p_obj, gap = rec.d_obj, rec.p_obj, rec.gap
+        it += 1
+    t_total = time.time() - t_start
+    x, y = np.zeros((K, f.x_len)), np.zeros((K, max(f.n_free, 1)))
+    X, Y = np.zeros((K, f.xy_len)), np.zeros((K, f.xy_len))
+    _lib.check(L.clrs_mw_ipm_get(ctx.h, _dp(x), _dp(y), _dp(X), _dp(Y)))
+    obj = np.zeros(3 * K)
+    _lib.check(L.clrs_mw_ipm_objectives(ctx.h, _dp(obj)))
+    if pd_feas and gap < duality_gap_threshold:                                    # src/solver.jl:727-741
+        status = "Optimal"
+    elif (pd_feas and gap < 1e-8) or (dual_error < 1e-15 and primal_error < 1e-15 and gap < 1e-8):
+        status = "NearOptimal"
+    elif pd_feas:
+        status = "Feasible"
+    elif primal_error < primal_error_threshold:
+        status = "PrimalFeasible"
+    elif dual_error < dual_error_threshold:
+        status = "DualFeasible"
+    else:
+        status = "NotConverged"
+    if own_ctx:
+        ctx.close()
+    res = SolveResult(status, x, X, y[:, :f.n_free], Y, t_total, error_code, it - 1, d_obj, p_obj, gap, dual_error, primal_error,
+                      np.array(hist).reshape(-1, 11), dict(loop="device", limbs=K))
+    res.timings["objectives_limbs"] = obj.reshape(3, K)
+    return res

@@ -272,6 +272,11 @@ typedef struct clrs_mw_ctx clrs_mw_ctx;
 /* Replaces precompute_matrices_bilinear_pairings (src/solver.jl:985-1059) + the preallocation :298-317 for a solve at
  * `limbs` words per number. */
 int clrs_mw_create(const clrs_sdp_desc *desc, int device, int limbs, clrs_mw_ctx **out);
+/* The same with problem data beyond fp64: every `const double *` array of `desc` (B, term_lambda, term_vs, term_ws, dense_A)
+ * is planar with `data_limbs` planes (1 or 2; plane length = the array's fp64 length).  The reference holds the sampled
+ * problem at `prec` bits as well (convert_to_prec, src/interface.jl:1078-1112), and its headline problems need it: the
+ * cohnelkies(8,15) SDP whose data are rounded to fp64 is a different, dual-infeasible problem. */
+int clrs_mw_create_ex(const clrs_sdp_desc *desc, int data_limbs, int device, int limbs, clrs_mw_ctx **out);
 void clrs_mw_destroy(clrs_mw_ctx *ctx);
 int clrs_mw_limbs(const clrs_mw_ctx *ctx);
 int clrs_mw_get_dims(const clrs_mw_ctx *ctx, clrs_dims *dims);          /* logical lengths; dims->reserved = limbs */
@@ -309,6 +314,20 @@ int clrs_mw_set_timing(clrs_mw_ctx *ctx, int enabled);
 int clrs_mw_get_timings(clrs_mw_ctx *ctx, double t[6]);
 /* algorithmic multi-word multiply-adds of one assembly / factorisation / solve */
 int clrs_mw_get_counters(const clrs_mw_ctx *ctx, double *assemble_muladds, double *factor_muladds, double *solve_muladds);
+
+/* The interior-point iteration around the path at the same precision (the loop body of solvesdp, src/solver.jl:348-589, as
+ * clrs_ipm_* above but with every iterate and intermediate in `limbs` words; the step-length eigenvalue alone is taken in
+ * fp64, as the reference's Float64 Lanczos does, src/solver.jl:1659).  C, c, b are fp64; x, y, X, Y of clrs_mw_ipm_get / _set
+ * are planar limbs.  clrs_mw_ipm_create may be called again on the same context with other objective data.
+ * Available when every PSD block fits in LDS at this limb count. */
+int clrs_mw_ipm_create(clrs_mw_ctx *ctx, const clrs_ipm_data *data);
+int clrs_mw_ipm_create_ex(clrs_mw_ctx *ctx, const clrs_ipm_data *data, int data_limbs);   /* C, c, b planar with data_limbs planes */
+int clrs_mw_ipm_set_params(clrs_mw_ctx *ctx, const clrs_ipm_params *params);
+int clrs_mw_ipm_init(clrs_mw_ctx *ctx, double omega_p, double omega_d);
+int clrs_mw_ipm_set(clrs_mw_ctx *ctx, const double *x, const double *y, const double *X, const double *Y);   /* warm start, src/solver.jl:202-239 */
+int clrs_mw_ipm_iterate(clrs_mw_ctx *ctx, clrs_ipm_record *out);
+int clrs_mw_ipm_get(clrs_mw_ctx *ctx, double *x, double *y, double *X, double *Y);
+int clrs_mw_ipm_objectives(clrs_mw_ctx *ctx, double *out /* [3 * limbs]: d_obj, p_obj, gap */);
 
 const char *clrs_strerror(int code);
 const char *clrs_last_error(void);

@@ -40,9 +40,10 @@ def tol(K, slack):
     return 2.0 ** (-(53 * K - slack))
 
 
-@pytest.mark.parametrize("K", [2, 3, 4, 5])
+@pytest.mark.parametrize("K,DL", [(2, 1), (2, 2), (3, 2), (4, 1), (4, 2), (5, 2)])
 @pytest.mark.parametrize("name", NAMES)
-def test_mw_assemble_factor_solve_match_oracle(name, K, oracle_built):
+def test_mw_assemble_factor_solve_match_oracle(name, K, DL, oracle_built):
+    """K limbs per computed number; DL limbs of problem data (1: the fp64 roundings, 2: the (hi, lo) pairs of the FlatSDP)."""
     from clrs_amd.mw import MwSchurContext
     from oracle.oracle import Oracle
     if name in ("ns_8_15_2",) and K in (2, 3):
@@ -50,8 +51,8 @@ def test_mw_assemble_factor_solve_match_oracle(name, K, oracle_built):
     f = flat(name)
     X, Y = _iterates(f, K)
     X, Y = _sym_limbs(f, X), _sym_limbs(f, Y)
-    o = Oracle(f, mp_bits=320, use_lo=False)
-    ctx = MwSchurContext(f, limbs=K)
+    o = Oracle(f, mp_bits=320, use_lo=(DL == 2))
+    ctx = MwSchurContext(f, limbs=K, data_limbs=DL)
     # Cholesky of the X blocks
     Xc = ctx.cholesky_blocks(X)
     st, Xc_ref = o.cholesky_blocks_mw(np.vstack([X, np.zeros((1, f.xy_len))]))
@@ -117,7 +118,7 @@ def test_mw_factors_the_north_star_instance_where_fp64_fails(K, oracle_built):
     Xc = ctx.cholesky_blocks(Xm)
     S, _ = ctx.compute_S_integrated(Xc, Ym)
     assert ctx.factor() == 0
-    o = Oracle(f, mp_bits=320, use_lo=False)
+    o = Oracle(f, mp_bits=320)
     S_ref, _ = o.schur_assemble_mw(np.vstack([Xc, np.zeros((1, f.xy_len))]), np.vstack([Ym, np.zeros((1, f.xy_len))]))
     assert mw_relerr(S, S_ref) <= tol(K, 22)
     assert o.schur_factor() == 0
@@ -145,3 +146,100 @@ def test_mw_reports_failures_like_the_reference(oracle_built):
     with pytest.raises(SolverFailure, match="block \\(1,1\\)"):
         ctx.cholesky_blocks(mw_from_double(-X, K))
     ctx.close()
+
+
+# ---- the whole interior-point loop at the reference's precision ------------------------------------------------------
+PI4_384 = 0.25366950790104804          # pi^4 / 384, test/runtests_solver.jl:20,22
+
+
+def test_north_star_instance_solves_to_the_pinned_objective(oracle_built):
+    """cohnelkies(8,15) with the reference's DEFAULT options (Omega = 1e10, gap 1e-15, errors 1e-30; prec = 256 -> 5 limbs):
+    test/runtests_solver.jl:19-20 pins the objective to pi^4/384 within 1e-4.  The oracle at 256 bits takes 56 iterations."""
+    from clrs_amd.mw import solvesdp_mw
+    from oracle.oracle import Oracle
+    f = flat("ce_8_15")
+    r = solvesdp_mw(f, prec=256)
+    assert r.error_code == 0 and r.status == "Optimal", (r.status, r.error_code, r.iterations)
+    assert abs(r.primal_objective - PI4_384) <= 1e-4 and abs(r.dual_objective - PI4_384) <= 1e-4
+    ro = Oracle(f, mp_bits=256).solvesdp()
+    assert ro["error_code"] == 0
+    assert abs(r.primal_objective - ro["p_obj"]) <= 1e-12 and abs(r.dual_objective - ro["d_obj"]) <= 1e-12
+    assert abs(r.iterations - ro["iterations"]) <= 2, (r.iterations, ro["iterations"])
+    # the early iterations follow the oracle's trace to the digits the step-length eigenvalue (fp64, -1e-5) leaves
+    h, ho = r.history, ro["hist"]
+    for it in range(5):
+        assert abs(h[it, 1] - ho[it, 1]) <= 1e-6 * ho[it, 1]              # mu
+        assert abs(h[it, 8] - ho[it, 8]) <= 1e-6 and abs(h[it, 9] - ho[it, 9]) <= 1e-6   # alpha_d, alpha_p
+
+
+def test_four_limbs_reach_the_objective_with_thresholds_for_209_bits(oracle_built):
+    """4 limbs (~209 bits): the oracle's sweep reaches gap 1e-14 and errors 5e-29 / 5e-38 at 212 bits, so the
+    error thresholds are set to 1e-25 instead of the 256-bit defaults 1e-30."""
+    from clrs_amd.mw import solvesdp_mw
+    r = solvesdp_mw(flat("ce_8_15"), limbs=4, dual_error_threshold=1e-25, primal_error_threshold=1e-25, duality_gap_threshold=1e-12)
+    assert r.error_code == 0 and r.status == "Optimal", (r.status, r.error_code, r.iterations)
+    assert abs(r.primal_objective - PI4_384) <= 1e-4
+
+
+def test_fp64_rounded_problem_data_is_a_different_problem(oracle_built):
+    """Why the ABI takes multi-word problem DATA too (clrs_mw_create_ex): with B, c, the sampled vectors rounded to fp64 the
+    cohnelkies(8,15) SDP is no longer the same problem -- p = b - B^T x stalls near 1e9 and mu blows up (error code 3, "mu too
+    large") at 5 limbs, in the oracle at 256 bits exactly as on the GPU."""
+    from clrs_amd.mw import solvesdp_mw
+    from oracle.oracle import Oracle
+    f = flat("ce_8_15")
+    r = solvesdp_mw(f, limbs=5, data_limbs=1)
+    ro = Oracle(f, mp_bits=256, use_lo=False).solvesdp()
+    assert r.error_code == 3 and ro["error_code"] == 3
+    assert abs(r.iterations - ro["iterations"]) <= 1
+
+
+def test_nsphere_packing_prec_300_instance(oracle_built):
+    """Nsphere_packing(8,15,[1/2,1/2],2) (test/runtests_solver.jl:21-22, prec = 300 there; 5 limbs = 262 bits here): 7 clusters,
+    m = 2 sub-blocks, P = 96; same pinned value."""
+    from clrs_amd.mw import solvesdp_mw
+    r = solvesdp_mw(flat("ns_8_15_2"), limbs=5)
+    assert r.error_code == 0, (r.status, r.error_code, r.iterations)
+    assert abs(r.primal_objective - PI4_384) <= 1e-4, r.primal_objective
+
+
+@pytest.mark.parametrize("name,expected,tol_,kw", [
+    ("x2p1", 1.0, 1e-10, {}),
+    ("delsarte_3_10", 13.158314, 1e-5, {}),
+    ("delsarte_8_3", 240.0, 1e-8, {}),
+    ("threepoint_4", 10.0, 1e-5, dict(omega_p=1e3, omega_d=1e3)),
+    ("polyopt40", None, 1e-10, {}),
+    ("sdpa_example", None, 1e-10, {}),
+])
+def test_mw_loop_reaches_the_pinned_objectives(name, expected, tol_, kw, oracle_built):
+    """The reference's own known answers (test/runtests_solver.jl:15, 86-87, 26-27; README.md:149) with its default options,
+    and agreement with the 256-bit oracle loop on the rest."""
+    from clrs_amd.mw import solvesdp_mw
+    from oracle.oracle import Oracle
+    f = flat(name)
+    r = solvesdp_mw(f, limbs=5, **kw)
+    assert r.error_code == 0 and r.status == "Optimal", (name, r.status, r.error_code)
+    if expected is not None:
+        assert abs(r.primal_objective - expected) <= tol_, (name, r.primal_objective)
+    ro = Oracle(f, mp_bits=256).solvesdp(**kw)
+    assert ro["error_code"] == 0
+    assert abs(r.primal_objective - ro["p_obj"]) <= 1e-10 * max(1.0, abs(ro["p_obj"]))
+    assert abs(r.iterations - ro["iterations"]) <= 2
+
+
+def test_mw_loop_beta_follows_the_reference_order_across_the_feasibility_flip(oracle_built):
+    """beta_c of the iteration in which the iterate becomes feasible is still chosen with the PREVIOUS feasibility
+    (src/solver.jl:429-434 before :441-447): the per-iteration beta_c column agrees with the oracle's."""
+    from clrs_amd.mw import solvesdp_mw
+    from oracle.oracle import Oracle
+    f = flat("delsarte_3_10")
+    r = solvesdp_mw(f, limbs=5)
+    ro = Oracle(f, mp_bits=256).solvesdp()
+    n = min(len(r.history), len(ro["hist"]))
+    assert n > 10
+    flips = 0
+    for it in range(n):
+        assert abs(r.history[it, 10] - ro["hist"][it, 10]) <= 1e-6 * max(1.0, ro["hist"][it, 10]), (it, r.history[it, 10], ro["hist"][it, 10])
+        if it and (r.history[it, 10] == 0.1) != (r.history[it - 1, 10] == 0.1):
+            flips += 1
+    assert flips >= 1
