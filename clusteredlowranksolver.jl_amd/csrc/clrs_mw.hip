@@ -279,8 +279,9 @@ extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int dev
     const size_t lim = MW_LDS_MAX / sizeof(double);
     {
         size_t nn = (size_t)c->maxn * c->maxn * K;
-        c->lds_x = nn <= lim;
-        c->sm_x = c->lds_x ? nn * 8 : 0;
+        const size_t bcw = K + 1;                       // broadcast slot of wg_potrf
+        c->lds_x = nn + bcw <= lim;
+        c->sm_x = ((c->lds_x ? nn : 0) + bcw) * 8;
         size_t zt = (size_t)c->maxn * MW_CT * K;
         c->lds_zt_L = zt + nn <= lim;
         c->sm_zt = (zt + (c->lds_zt_L ? nn : 0)) * 8;
@@ -291,23 +292,25 @@ extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int dev
         c->sm_dense = maxnd * maxnd * K * 8;
         size_t fmax = 0, smax = 0;
         for (auto &q : c->clu) {
-            size_t need = ((size_t)q.P * q.P + (size_t)q.P * N) * K;
+            size_t need = std::max((size_t)q.P * q.P * K + bcw, ((size_t)q.P * q.P + (size_t)q.P * MW_BT) * K);     // k_mw_factor; k_mw_linvb
             q.lds = need <= lim ? 1 : 0;
+            if (!q.lds && (size_t)q.P * MW_BT * K > lim) MW_BAIL(CLRS_ERR_INVALID, "cluster too large for the multi-word kernels");
+            if (!q.lds) fmax = std::max(fmax, (size_t)q.P * MW_BT * K);
             if (q.lds) fmax = std::max(fmax, need);
             size_t sneed = ((size_t)q.P + (q.lds ? (size_t)q.P * q.P : 0)) * K;
             smax = std::max(smax, sneed);
         }
-        c->sm_factor = fmax * 8;
+        c->sm_factor = std::max(fmax, bcw) * 8;
         c->sm_fwd = c->sm_bwd = smax * 8;
         size_t qn = (size_t)N * N * K;
-        c->lds_q = qn + (size_t)N * K <= lim;
-        c->sm_q = c->lds_q ? qn * 8 : 0;
-        c->sm_mid = ((size_t)N * K + (c->lds_q ? qn : 0)) * 8;
+        c->lds_q = 2 * qn + (size_t)N * K <= lim;
+        c->sm_q = ((c->lds_q ? qn : 0) + bcw) * 8;
+        c->sm_mid = ((size_t)N * K + (c->lds_q ? 2 * qn : 0)) * 8;
         if (c->sm_fwd > MW_LDS_MAX || c->sm_mid > MW_LDS_MAX) MW_BAIL(CLRS_ERR_INVALID, "cluster too large for the multi-word solve kernels");
     }
     MW_DISPATCH(c, {
         MW_TRY(mw_set_lds(k_mw_potrf_x<KK>, c->sm_x)); MW_TRY(mw_set_lds(k_mw_zt<KK, DD>, c->sm_zt)); MW_TRY(mw_set_lds(k_mw_dense<KK, DD>, c->sm_dense));
-        MW_TRY(mw_set_lds(k_mw_factor<KK, DD>, c->sm_factor)); MW_TRY(mw_set_lds(k_mw_potrf_q<KK>, c->sm_q));
+        MW_TRY(mw_set_lds(k_mw_factor<KK>, c->sm_factor)); MW_TRY(mw_set_lds((k_mw_linvb<KK, DD>), c->sm_factor)); MW_TRY(mw_set_lds(k_mw_potrf_q<KK>, c->sm_q));
         MW_TRY(mw_set_lds(k_mw_solve_fwd<KK>, c->sm_fwd)); MW_TRY(mw_set_lds(k_mw_solve_mid<KK>, c->sm_mid)); MW_TRY(mw_set_lds(k_mw_solve_bwd<KK>, c->sm_bwd));
     });
     // ---- upload ----
@@ -349,6 +352,9 @@ extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int dev
     MW_TRY(mw_dmalloc(c, &q.GX, q.glen * K)); MW_TRY(mw_dmalloc(c, &q.GY, q.glen * K));
     MW_TRY(mw_dmalloc(c, &q.W, q.wlen * K)); MW_TRY(mw_dmalloc(c, &q.Sd, q.sdlen * K));
     MW_TRY(mw_dmalloc(c, &q.S, Slen * K)); MW_TRY(mw_dmalloc(c, &q.LB, xlen * (i64)N * K)); MW_TRY(mw_dmalloc(c, &q.Q, (i64)N * N * K));
+    MW_TRY(mw_dmalloc(c, &q.Sf, Slen * K)); MW_TRY(mw_dmalloc(c, &q.Sb, Slen * K));
+    MW_TRY(mw_dmalloc(c, &q.Qf, (i64)N * N * K)); MW_TRY(mw_dmalloc(c, &q.Qb, (i64)N * N * K));
+    MW_TRY(mw_dmalloc(c, &q.Xf, xyoff * K)); MW_TRY(mw_dmalloc(c, &q.Xb, xyoff * K));
     MW_TRY(mw_dmalloc(c, &q.xrd, rdoff * K)); MW_TRY(mw_dmalloc(c, &q.srd, xlen * K)); MW_TRY(mw_dmalloc(c, &q.qrd, (i64)N * K));
     MW_TRY(mw_dmalloc(c, &q.t, xlen * K)); MW_TRY(mw_dmalloc(c, &q.u, (i64)J * N * K)); MW_TRY(mw_dmalloc(c, &q.AY, T * K));
     MW_TRY(mw_dmalloc(c, &c->d_Xin, xyoff * K)); MW_TRY(mw_dmalloc(c, &c->d_Xc, xyoff * K)); MW_TRY(mw_dmalloc(c, &c->d_Y, xyoff * K));
@@ -450,12 +456,12 @@ extern "C" int clrs_mw_schur_assemble_dev(clrs_mw_ctx *c, const double *d_Xchol,
     if (c->timing) MWCHECK(hipEventRecord(c->ev[0], c->stream));
     MW_DISPATCH(c, {
         if (q.nlr) {
-            hipLaunchKernelGGL((k_mw_zt<KK, DD>), dim3((c->maxU + MW_CT - 1) / MW_CT, q.nlr), dim3(MW_NT), c->sm_zt, c->stream, q, d_Xchol, d_Y, c->lds_zt_L ? 1 : 0);
-            hipLaunchKernelGGL((k_mw_gram<KK, DD>), dim3((c->maxU * (c->maxU + 1) / 2 + MW_NT - 1) / MW_NT, q.nlr), dim3(MW_NT), 0, c->stream, q);
+            const int gper = MW_NT / MW_GRAM_W;
+            hipLaunchKernelGGL((k_mw_zt<KK, DD>), dim3((c->maxU + MW_CT - 1) / MW_CT, q.nlr), dim3(MW_NT), c->sm_zt, c->stream, q, d_Y, c->lds_zt_L ? 1 : 0);
+            hipLaunchKernelGGL((k_mw_gram<KK, DD>), dim3((c->maxU * (c->maxU + 1) / 2 + gper - 1) / gper, q.nlr), dim3(MW_NT), 0, c->stream, q);
         }
-        if (q.ndn) hipLaunchKernelGGL((k_mw_dense<KK, DD>), dim3(q.ndn), dim3(MW_NT), c->sm_dense, c->stream, q, d_Xchol, d_Y);
+        if (q.ndn) hipLaunchKernelGGL((k_mw_dense<KK, DD>), dim3(q.ndn), dim3(MW_NT), c->sm_dense, c->stream, q, d_Y);
         hipLaunchKernelGGL((k_mw_saccum<KK, DD>), dim3((c->maxP * (c->maxP + 1) / 2 + MW_NT - 1) / MW_NT, q.J), dim3(MW_NT), 0, c->stream, q);
-        if (q.T) hipLaunchKernelGGL(k_mw_ay<KK>, dim3((unsigned)((q.T + MW_NT - 1) / MW_NT)), dim3(MW_NT), 0, c->stream, q);
     });
     MWCHECK(hipGetLastError());
     if (c->timing) MWCHECK(hipEventRecord(c->ev[1], c->stream));
@@ -473,10 +479,11 @@ extern "C" int clrs_mw_schur_factor_dev(clrs_mw_ctx *c) {
     if ((rc = mw_reset_info(c, 0))) return rc;
     if (c->timing) MWCHECK(hipEventRecord(c->ev[2], c->stream));
     MW_DISPATCH(c, {
-        hipLaunchKernelGGL((k_mw_factor<KK, DD>), dim3(q.J), dim3(MW_NT), c->sm_factor, c->stream, q);
+        hipLaunchKernelGGL(k_mw_factor<KK>, dim3(q.J), dim3(MW_NT), c->sm_factor, c->stream, q);
+        if (q.N > 0) hipLaunchKernelGGL((k_mw_linvb<KK, DD>), dim3((q.N + MW_BT - 1) / MW_BT, q.J), dim3(MW_NT), c->sm_factor, c->stream, q);
         if (c->timing) (void)hipEventRecord(c->ev[3], c->stream);
         if (q.N > 0) {
-            hipLaunchKernelGGL(k_mw_qgram<KK>, dim3((q.N * (q.N + 1) / 2 + MW_NT - 1) / MW_NT), dim3(MW_NT), 0, c->stream, q);
+            hipLaunchKernelGGL(k_mw_qgram<KK>, dim3((q.N * (q.N + 1) / 2 + MW_NT / MW_Q_W - 1) / (MW_NT / MW_Q_W)), dim3(MW_NT), 0, c->stream, q);
             if (c->timing) (void)hipEventRecord(c->ev[4], c->stream);
             hipLaunchKernelGGL(k_mw_potrf_q<KK>, dim3(1), dim3(MW_NT), c->sm_q, c->stream, q, c->lds_q ? 1 : 0);
         } else if (c->timing) (void)hipEventRecord(c->ev[4], c->stream);
@@ -606,9 +613,12 @@ extern "C" int clrs_mw_schur_solve(clrs_mw_ctx *c, const double *rhs_x, const do
 // reciprocal diagonals of Cholesky factors passed in by the caller (clrs_mw_schur_assemble with host or foreign factors)
 template <int K>
 __global__ __launch_bounds__(MW_NT) void k_mw_xrd(const MwDev q, const double *__restrict__ Xc) {
-    using namespace mwa;
+    using namespace mwk;
     const MwBlk &k = q.blk[blockIdx.x];
-    for (int i = threadIdx.x; i < k.n; i += MW_NT) st<K>(q.xrd + k.rd_off, q.xrdlen, i, recip<K>(ld<K>(Xc + k.xyoff, q.xylen, i + (long)i * k.n)));
+    for (int i = threadIdx.x; i < k.n; i += MW_NT) stx<K>(q.xrd + k.rd_off, q.xrdlen, i, recip<K>(ldx<K>(Xc + k.xyoff, q.xylen, i + (long)i * k.n)));
+    __threadfence_block();
+    __syncthreads();
+    wg_scaled_factors<K>(Xc + k.xyoff, q.xylen, k.n, q.xrd + k.rd_off, q.xrdlen, k.n, q.Xf + k.xyoff, q.xylen, k.n, q.Xb + k.xyoff, q.xylen, k.n, threadIdx.x);
 }
 static int mw_launch_xrd(clrs_mw_ctx *c, const double *d_Xc) {
     if (c->d.NB == 0) return 0;

@@ -32,16 +32,16 @@ namespace mwk {
 
 // sum over the workgroup (256 threads) of one multi-word value per thread; red: LDS, K * 256 doubles; result in every thread
 template <int K>
-__device__ mw<K> wg_reduce_sum(const mw<K> &v, double *red, int tid) {
-    st<K>(red, MW_NT, tid, v);
+__device__ mw<K> wg_reduce_sum(const mw<K> &v, lds_d *red, int tid) {
+    mw<K> w = lanes_sum<K, 64>(v);                     // within the wave by shuffles, across the four waves through LDS
+    if ((tid & 63) == 0) stx<K>(red, MW_NT / 64, tid >> 6, w);
     __syncthreads();
-    for (int s = MW_NT / 2; s > 0; s >>= 1) {
-        if (tid < s) st<K>(red, MW_NT, tid, add<K>(ld_<K>(red, MW_NT, tid), ld_<K>(red, MW_NT, tid + s)));
-        __syncthreads();
-    }
-    mw<K> r = ld_<K>(red, MW_NT, 0);
+    acc<K> s;
+    acc_zero<K>(s);
+#pragma unroll
+    for (int i = 0; i < MW_NT / 64; i++) acc_add<K, K>(s, ldx<K>(red, MW_NT / 64, i));
     __syncthreads();
-    return r;
+    return acc_result<K>(s);
 }
 __device__ __forceinline__ void atomic_max_abs(unsigned long long *slot, double v) {
     atomicMax(slot, (unsigned long long)__double_as_longlong(__builtin_fabs(v)));
@@ -50,9 +50,9 @@ __device__ __forceinline__ void atomic_max_abs(unsigned long long *slot, double 
 // Smallest eigenvalue of the symmetric n x n fp64 matrix A (LDS, full storage, leading dimension n; destroyed).
 // Householder tridiagonalisation by the workgroup, then Sturm-count multisection (256 shifts per round).
 // work: LDS, at least 3 n + 2 * MW_NT doubles.
-__device__ double wg_min_eig(double *A, int n, double *work, int tid) {
+__device__ double wg_min_eig(lds_d *A, int n, lds_d *work, int tid) {
     if (n == 1) return A[0];
-    double *dd = work, *ee = work + n, *v = work + 2 * n, *red = work + 3 * n, *pq = work + 3 * n + MW_NT;   // pq: n doubles inside the second MW_NT chunk
+    lds_d *dd = work, *ee = work + n, *v = work + 2 * n, *red = work + 3 * n, *pq = work + 3 * n + MW_NT;   // pq: n doubles inside the second MW_NT chunk
     for (int k = 0; k < n - 2; k++) {
         const int m = n - k - 1;           // x = A[k+1 .. n-1, k]
         double part = 0;
@@ -113,7 +113,7 @@ __device__ double wg_min_eig(double *A, int n, double *work, int tid) {
     if (scale == 0.0) return 0.0;
     lo -= 1e-14 * scale;
     hi += 1e-14 * scale;
-    int *first = (int *)red;
+    int *first = (int *)(double *)red;               // generic pointer: atomicMin has no overload for address-space-qualified ones
     for (int round = 0; round < 8; round++) {
         // shift of thread t: lo + (t + 1) * h; count the eigenvalues below it
         const double h = (hi - lo) / MW_NT;
@@ -154,46 +154,46 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_dots(const MwDev q, const MwIpmDe
     acc_zero<K>(a0); acc_zero<K>(a1); acc_zero<K>(a2); acc_zero<K>(a3); acc_zero<K>(a4);
     for (long i = tid; i < nn; i += MW_NT) {
         const long e = k.xyoff + i;
-        mw<K> Y = ld_<K>(p.Y, q.xylen, e);
-        if (sel & 1) acc_fma<K, K, K>(a0, ld_<K>(p.X, q.xylen, e), Y);
+        mw<K> Y = ldx<K>(p.Y, q.xylen, e);
+        if (sel & 1) acc_fma<K, K, K>(a0, ldx<K>(p.X, q.xylen, e), Y);
         if (sel & 2) {
-            mw<K> X = ld_<K>(p.X, q.xylen, e), dX = ld_<K>(p.dX, q.xylen, e), dY = ld_<K>(p.dY, q.xylen, e);
+            mw<K> X = ldx<K>(p.X, q.xylen, e), dX = ldx<K>(p.dX, q.xylen, e), dY = ldx<K>(p.dY, q.xylen, e);
             acc_fma<K, K, K>(a1, X, dY);
             acc_fma<K, K, K>(a2, dX, Y);
             acc_fma<K, K, K>(a3, dX, dY);
         }
-        if (sel & 4) acc_fma<K, K, DK>(a4, Y, ld_<DK>(p.C, q.xylen, e));
+        if (sel & 4) acc_fma<K, K, DK>(a4, Y, ldx<DK>(p.C, q.xylen, e));
     }
-    double *red = mw_lds;
-    if (sel & 1) { mw<K> r = wg_reduce_sum<K>(acc_result<K>(a0), red, tid); if (tid == 0) st<K>(p.part, 5L * q.NB, 0L * q.NB + blockIdx.x, r); }
+    lds_d *red = MW_LDS;
+    if (sel & 1) { mw<K> r = wg_reduce_sum<K>(acc_result<K>(a0), red, tid); if (tid == 0) stx<K>(p.part, 5L * q.NB, 0L * q.NB + blockIdx.x, r); }
     if (sel & 2) {
-        mw<K> r = wg_reduce_sum<K>(acc_result<K>(a1), red, tid); if (tid == 0) st<K>(p.part, 5L * q.NB, 1L * q.NB + blockIdx.x, r);
-        r = wg_reduce_sum<K>(acc_result<K>(a2), red, tid); if (tid == 0) st<K>(p.part, 5L * q.NB, 2L * q.NB + blockIdx.x, r);
-        r = wg_reduce_sum<K>(acc_result<K>(a3), red, tid); if (tid == 0) st<K>(p.part, 5L * q.NB, 3L * q.NB + blockIdx.x, r);
+        mw<K> r = wg_reduce_sum<K>(acc_result<K>(a1), red, tid); if (tid == 0) stx<K>(p.part, 5L * q.NB, 1L * q.NB + blockIdx.x, r);
+        r = wg_reduce_sum<K>(acc_result<K>(a2), red, tid); if (tid == 0) stx<K>(p.part, 5L * q.NB, 2L * q.NB + blockIdx.x, r);
+        r = wg_reduce_sum<K>(acc_result<K>(a3), red, tid); if (tid == 0) stx<K>(p.part, 5L * q.NB, 3L * q.NB + blockIdx.x, r);
     }
-    if (sel & 4) { mw<K> r = wg_reduce_sum<K>(acc_result<K>(a4), red, tid); if (tid == 0) st<K>(p.part, 5L * q.NB, 4L * q.NB + blockIdx.x, r); }
+    if (sel & 4) { mw<K> r = wg_reduce_sum<K>(acc_result<K>(a4), red, tid); if (tid == 0) stx<K>(p.part, 5L * q.NB, 4L * q.NB + blockIdx.x, r); }
 }
 
 // ---- scalar stages (one thread) ------------------------------------------------------------------------------------
 template <int K>
 __device__ mwa::mw<K> mwi_sum_part(const MwDev &q, const MwIpmDev &p, int slot) {
-    using namespace mwa;
+    using namespace mwk;
     acc<K> s;
     acc_zero<K>(s);
-    for (int b = 0; b < q.NB; b++) acc_add<K, K>(s, ld_<K>(p.part, 5L * q.NB, (long)slot * q.NB + b));
+    for (int b = 0; b < q.NB; b++) acc_add<K, K>(s, ldx<K>(p.part, 5L * q.NB, (long)slot * q.NB + b));
     return acc_result<K>(s);
 }
 template <int K, int DK>
 __global__ void k_mwi_scalar(const MwDev q, const MwIpmDev p, int stage, int iter) {
-    using namespace mwa;
+    using namespace mwk;
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const long SP = MSC_COUNT;
     if (stage == 0) {                              // start of the iteration: mu, mu_p  (src/solver.jl:369-380)
         mw<K> xy = mwi_sum_part<K>(q, p, 0);
         mw<K> mu = div<K>(xy, from_double<K>((double)p.Ktot));
-        st<K>(p.sc, SP, MSC_XY, xy);
-        st<K>(p.sc, SP, MSC_MU, mu);
-        st<K>(p.sc, SP, MSC_MUS, p.flags[0] ? zero<K>() : mul_d<K>(mu, p.beta_infeasible));
+        stx<K>(p.sc, SP, MSC_XY, xy);
+        stx<K>(p.sc, SP, MSC_MU, mu);
+        stx<K>(p.sc, SP, MSC_MUS, p.flags[0] ? zero<K>() : mul_d<K>(mu, p.beta_infeasible));
         p.flags[1] = 0;
         p.flags[2] = 0;
         p.fmax[0] = p.fmax[1] = p.fmax[2] = 0ull;
@@ -214,11 +214,11 @@ __global__ void k_mwi_scalar(const MwDev q, const MwIpmDev p, int stage, int ite
     } else if (stage == 2) {                       // between predictor and corrector: beta_c, mu_c (:429-434), then pd_feas (:441-447)
         acc<K> s;
         acc_zero<K>(s);
-        acc_add<K, K>(s, ld_<K>(p.sc, SP, MSC_XY));
+        acc_add<K, K>(s, ldx<K>(p.sc, SP, MSC_XY));
         acc_add<K, K>(s, mwi_sum_part<K>(q, p, 1));
         acc_add<K, K>(s, mwi_sum_part<K>(q, p, 2));
         acc_add<K, K>(s, mwi_sum_part<K>(q, p, 3));
-        mw<K> mu = ld_<K>(p.sc, SP, MSC_MU);
+        mw<K> mu = ldx<K>(p.sc, SP, MSC_MU);
         mw<K> r = div<K>(acc_result<K>(s), mul_d<K>(mu, (double)p.Ktot));
         mw<K> beta = less<K>(r, from_double<K>(1.0)) ? mul<K>(r, r) : r;
         mw<K> beta_c;
@@ -228,7 +228,7 @@ __global__ void k_mwi_scalar(const MwDev q, const MwIpmDev p, int stage, int ite
         } else {
             beta_c = less<K>(from_double<K>(p.beta_infeasible), beta) ? beta : from_double<K>(p.beta_infeasible);
         }
-        st<K>(p.sc, SP, MSC_MUS, mul<K>(beta_c, mu));
+        stx<K>(p.sc, SP, MSC_MUS, mul<K>(beta_c, mu));
         p.rec[MREC_BETA] = beta_c.l[0];
         p.flags[0] = (p.rec[MREC_DERR] < p.dual_thr && p.rec[MREC_PERR] < p.primal_thr) ? 1 : 0;
         p.rec[MREC_PDFEAS] = p.flags[0];
@@ -251,18 +251,18 @@ __global__ void k_mwi_scalar(const MwDev q, const MwIpmDev p, int stage, int ite
     } else if (stage == 4) {                       // objectives of the new iterate (:793-804, 844-847)
         acc<K> s;
         acc_zero<K>(s);
-        for (long i = 0; i < q.xlen; i++) acc_fma<K, K, DK>(s, ld_<K>(p.x, q.xlen, i), ld_<DK>(p.c, q.xlen, i), p.sgn);
+        for (long i = 0; i < q.xlen; i++) acc_fma<K, K, DK>(s, ldx<K>(p.x, q.xlen, i), ldx<DK>(p.c, q.xlen, i), p.sgn);
         acc_add_d<K>(s, p.constant);
         mw<K> dobj = acc_result<K>(s);
         acc_zero<K>(s);
         acc_add<K, K>(s, mwi_sum_part<K>(q, p, 4));
-        for (int a = 0; a < q.N; a++) acc_fma<K, K, DK>(s, ld_<K>(p.y, q.N, a), ld_<DK>(p.b, q.N, a));
+        for (int a = 0; a < q.N; a++) acc_fma<K, K, DK>(s, ldx<K>(p.y, q.N, a), ldx<DK>(p.b, q.N, a));
         acc_add_d<K>(s, p.constant);
         mw<K> pobj = acc_result<K>(s);
         mw<K> den = abs<K>(add<K>(dobj, pobj));
         if (less<K>(den, from_double<K>(1.0))) den = from_double<K>(1.0);
         mw<K> gap = div<K>(abs<K>(sub<K>(dobj, pobj)), den);
-        st<K>(p.sc, SP, MSC_DOBJ, dobj); st<K>(p.sc, SP, MSC_POBJ, pobj); st<K>(p.sc, SP, MSC_GAP, gap);
+        stx<K>(p.sc, SP, MSC_DOBJ, dobj); stx<K>(p.sc, SP, MSC_POBJ, pobj); stx<K>(p.sc, SP, MSC_GAP, gap);
         p.rec[MREC_DOBJ] = dobj.l[0]; p.rec[MREC_POBJ] = pobj.l[0]; p.rec[MREC_GAP] = gap.l[0];
         p.rec[MREC_ERR] = p.flags[1];
         p.rec[MREC_PDFEAS] = p.flags[0];
@@ -280,11 +280,11 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_R(const MwDev q, const MwIpmDev p
     const int i = e % n, c = e / n;
     acc<K> s;
     acc_zero<K>(s);
-    for (int kk = 0; kk < n; kk++) acc_fma<K, K, K>(s, ld_<K>(p.X + k.xyoff, q.xylen, i + (long)kk * n), ld_<K>(p.Y + k.xyoff, q.xylen, kk + (long)c * n), -1.0);
+    for (int kk = 0; kk < n; kk++) acc_fma<K, K, K>(s, ldx<K>(p.X + k.xyoff, q.xylen, i + (long)kk * n), ldx<K>(p.Y + k.xyoff, q.xylen, kk + (long)c * n), -1.0);
     if (corrector)
-        for (int kk = 0; kk < n; kk++) acc_fma<K, K, K>(s, ld_<K>(p.dX + k.xyoff, q.xylen, i + (long)kk * n), ld_<K>(p.dY + k.xyoff, q.xylen, kk + (long)c * n), -1.0);
-    if (i == c) acc_add<K, K>(s, ld_<K>(p.sc, MSC_COUNT, MSC_MUS));
-    st<K>(p.R + k.xyoff, q.xylen, e, acc_result<K>(s));
+        for (int kk = 0; kk < n; kk++) acc_fma<K, K, K>(s, ldx<K>(p.dX + k.xyoff, q.xylen, i + (long)kk * n), ldx<K>(p.dY + k.xyoff, q.xylen, kk + (long)c * n), -1.0);
+    if (i == c) acc_add<K, K>(s, ldx<K>(p.sc, MSC_COUNT, MSC_MUS));
+    stx<K>(p.R + k.xyoff, q.xylen, e, acc_result<K>(s));
 }
 
 // ---- coefficients a_p * lambda_t of the sorted terms -------------------------------------------------------------------
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_coef(const MwDev q, const MwIpmDe
     const int b = q.ay_blk[t];           // block of the term range (sorted and original order share it)
     if (b < 0) return;
     const MwClu &c = q.clu[q.blk[b].j];
-    st<K>(p.coef, q.T, t, mulx<K, K, DK>(ld_<K>(a, q.xlen, c.coff + q.st_p[t]), ld_<DK>(q.st_lam, q.lamp, t)));
+    stx<K>(p.coef, q.T, t, mulx<K, K, DK>(ldx<K>(a, q.xlen, c.coff + q.st_p[t]), ldx<DK>(q.st_lam, q.lamp, t)));
 }
 
 // ---- sum_i a_i A_i per block (compute_weighted_A!, src/solver.jl:1410-1470) plus the rest of P or dX -------------------
@@ -319,33 +319,33 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_wA(const MwDev q, const MwIpmDev 
         const int *tp = q.tptr + k.tptr_off;
         for (int t = tp[0]; t < tp[k.P]; t++) {
             if (!(q.st_flag[t] & 1)) continue;     // s <= r only (:1433)
-            const mw<DK> vi = ld_<DK>(V, q.Vp, i + (long)q.st_war[t] * n), vc = ld_<DK>(V, q.Vp, c + (long)q.st_wac[t] * n);
+            const mw<DK> vi = ldx<DK>(V, q.Vp, i + (long)q.st_war[t] * n), vc = ldx<DK>(V, q.Vp, c + (long)q.st_wac[t] * n);
             if (vi.l[0] == 0.0 || vc.l[0] == 0.0) continue;
             constexpr int LL = (2 * DK + 1 < K) ? 2 * DK + 1 : K;
-            acc_fma<K, K, LL>(s, ld_<K>(p.coef, q.T, t), mulx<LL, DK, DK>(vi, vc));
+            acc_fma<K, K, LL>(s, ldx<K>(p.coef, q.T, t), mulx<LL, DK, DK>(vi, vc));
         }
     } else {
         const MwClu &cl = q.clu[k.j];
         const long nn = (long)n * n;
         for (int en = 0; en < k.cnt; en++)
-            acc_fma<K, K, DK>(s, ld_<K>(a, q.xlen, cl.coff + q.dense_p[k.d0 + en]), ld_<DK>(q.dA, q.dAp, k.a_off + en * nn + e));
+            acc_fma<K, K, DK>(s, ldx<K>(a, q.xlen, cl.coff + q.dense_p[k.d0 + en]), ldx<DK>(q.dA, q.dAp, k.a_off + en * nn + e));
     }
     mw<K> v;
     if (mode == 0) {
-        acc_add<K, K>(s, ld_<K>(p.X + k.xyoff, q.xylen, e), -1.0);
-        acc_add<K, DK>(s, ld_<DK>(p.C, q.xylen, k.xyoff + e), -p.sgn);
+        acc_add<K, K>(s, ldx<K>(p.X + k.xyoff, q.xylen, e), -1.0);
+        acc_add<K, DK>(s, ldx<DK>(p.C, q.xylen, k.xyoff + e), -p.sgn);
         v = acc_result<K>(s);
         atomic_max_abs(&p.fmax[0], v.l[0]);
-        st<K>(p.Pm + k.xyoff, q.xylen, e, v);
+        stx<K>(p.Pm + k.xyoff, q.xylen, e, v);
         if (mirror && c != i) {
             // P is symmetric as a whole: -X -+ C are, and the weighted sum is mirrored
-            st<K>(p.Pm + k.xyoff, q.xylen, c + (long)i * n, v);
+            stx<K>(p.Pm + k.xyoff, q.xylen, c + (long)i * n, v);
         }
     } else {
-        acc_add<K, K>(s, ld_<K>(p.Pm + k.xyoff, q.xylen, e));
+        acc_add<K, K>(s, ldx<K>(p.Pm + k.xyoff, q.xylen, e));
         v = acc_result<K>(s);
-        st<K>(p.dX + k.xyoff, q.xylen, e, v);
-        if (mirror && c != i) st<K>(p.dX + k.xyoff, q.xylen, c + (long)i * n, v);
+        stx<K>(p.dX + k.xyoff, q.xylen, e, v);
+        if (mirror && c != i) stx<K>(p.dX + k.xyoff, q.xylen, c + (long)i * n, v);
     }
 }
 
@@ -362,8 +362,8 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_MV(const MwDev q, const double *_
     const int r0 = q.vrow[k.vrow_off + c];
     acc<K> s;
     acc_zero<K>(s);
-    for (int kk = r0; kk < r0 + dl; kk++) acc_fma<K, K, DK>(s, ld_<K>(M + k.xyoff, q.xylen, i + (long)kk * n), ld_<DK>(V, q.Vp, kk + (long)c * n));
-    st<K>(q.Tm + k.z_off, q.zlen, e, acc_result<K>(s));
+    for (int kk = r0; kk < r0 + dl; kk++) acc_fma<K, K, DK>(s, ldx<K>(M + k.xyoff, q.xylen, i + (long)kk * n), ldx<DK>(V, q.Vp, kk + (long)c * n));
+    stx<K>(q.Tm + k.z_off, q.zlen, e, acc_result<K>(s));
 }
 
 // ---- per constraint row: d = c - <A_*,Y> - B y (:863-879) or rhs_x = -d - <A_*,Z> (:1518-1523) --------------------------
@@ -386,15 +386,15 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_rows(const MwDev q, const MwIpmDe
             for (int t = tp[pp]; t < tp[pp + 1]; t++) {
                 const int fl = q.st_flag[t];
                 if (!(fl & 1)) continue;                                           // s <= r (:1310)
-                const mw<DK> w = mul_pow2<DK>(ld_<DK>(q.st_lam, q.lamp, t), (fl & 2) ? 2.0 : 1.0);      // off-diagonal sub-blocks count twice (:1354-1356)
+                const mw<DK> w = mul_pow2<DK>(ldx<DK>(q.st_lam, q.lamp, t), (fl & 2) ? 2.0 : 1.0);      // off-diagonal sub-blocks count twice (:1354-1356)
                 if (mode == 0) {
-                    acc_fma<K, K, DK>(s, ld_<K>(q.AY, q.T, q.st_orig[t]), w);      // trace_A with (Y, A_Y), :1368-1407
+                    acc_fma<K, K, DK>(s, ldx<K>(q.AY, q.T, q.st_orig[t]), w);      // trace_A with (Y, A_Y), :1368-1407
                 } else {
                     const double *V = q.V + k.v_off;
                     const int l = q.st_trl[t], dcol = q.st_trd[t], r0 = q.vrow[k.vrow_off + l];
                     acc<K> z;
                     acc_zero<K>(z);
-                    for (int ii = r0; ii < r0 + k.delta; ii++) acc_fma<K, K, DK>(z, ld_<K>(q.Tm + k.z_off, q.zlen, ii + (long)dcol * n), ld_<DK>(V, q.Vp, ii + (long)l * n));
+                    for (int ii = r0; ii < r0 + k.delta; ii++) acc_fma<K, K, DK>(z, ldx<K>(q.Tm + k.z_off, q.zlen, ii + (long)dcol * n), ldx<DK>(V, q.Vp, ii + (long)l * n));
                     acc_fma<K, K, DK>(s, acc_result<K>(z), w);
                 }
             }
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_rows(const MwDev q, const MwIpmDe
             const int en = q.dmap[k.dmap_off + pp];
             if (en >= 0) {
                 const long nn = (long)n * n;
-                for (long i = 0; i < nn; i++) acc_fma<K, K, DK>(s, ld_<K>(M + k.xyoff, q.xylen, i), ld_<DK>(q.dA, q.dAp, k.a_off + en * nn + i));
+                for (long i = 0; i < nn; i++) acc_fma<K, K, DK>(s, ldx<K>(M + k.xyoff, q.xylen, i), ldx<DK>(q.dA, q.dAp, k.a_off + en * nn + i));
             }
         }
     }
@@ -410,18 +410,18 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_rows(const MwDev q, const MwIpmDe
     if (mode == 0) {
         acc<K> r;
         acc_zero<K>(r);
-        acc_add<K, DK>(r, ld_<DK>(p.c, q.xlen, g));
+        acc_add<K, DK>(r, ldx<DK>(p.c, q.xlen, g));
         acc_add<K, K>(r, tr, -1.0);
-        for (int a = 0; a < q.N; a++) acc_fma<K, K, DK>(r, ld_<K>(p.y, q.N, a), ld_<DK>(q.B, q.Bp, g + (long)a * q.xlen), -1.0);
+        for (int a = 0; a < q.N; a++) acc_fma<K, K, DK>(r, ldx<K>(p.y, q.N, a), ldx<DK>(q.B, q.Bp, g + (long)a * q.xlen), -1.0);
         mw<K> dv = acc_result<K>(r);
         atomic_max_abs(&p.fmax[1], dv.l[0]);
-        st<K>(p.d, q.xlen, g, dv);
+        stx<K>(p.d, q.xlen, g, dv);
     } else {
         acc<K> r;
         acc_zero<K>(r);
-        acc_add<K, K>(r, ld_<K>(p.d, q.xlen, g), -1.0);
+        acc_add<K, K>(r, ldx<K>(p.d, q.xlen, g), -1.0);
         acc_add<K, K>(r, tr, -1.0);
-        st<K>(p.rhsx, q.xlen, g, acc_result<K>(r));
+        stx<K>(p.rhsx, q.xlen, g, acc_result<K>(r));
     }
 }
 
@@ -433,11 +433,11 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_pv(const MwDev q, const MwIpmDev 
     if (a >= q.N) return;
     acc<K> s;
     acc_zero<K>(s);
-    acc_add<K, DK>(s, ld_<DK>(p.b, q.N, a), p.sgn);
-    for (long g = 0; g < q.xlen; g++) acc_fma<K, K, DK>(s, ld_<K>(p.x, q.xlen, g), ld_<DK>(q.B, q.Bp, g + (long)a * q.xlen), -1.0);
+    acc_add<K, DK>(s, ldx<DK>(p.b, q.N, a), p.sgn);
+    for (long g = 0; g < q.xlen; g++) acc_fma<K, K, DK>(s, ldx<K>(p.x, q.xlen, g), ldx<DK>(q.B, q.Bp, g + (long)a * q.xlen), -1.0);
     mw<K> v = acc_result<K>(s);
     atomic_max_abs(&p.fmax[2], v.l[0]);
-    st<K>(p.pv, q.N, a, v);
+    stx<K>(p.pv, q.N, a, v);
 }
 
 // ---- which 0: Z = sym(X^-1 (P Y - R)) (:1501-1514);  which 1: dY = sym(X^-1 (R - dX Y)) (:1597-1613); both into dY --------
@@ -447,34 +447,36 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_Z(const MwDev q, const MwIpmDev p
     const MwBlk &k = q.blk[blockIdx.x];
     const int n = k.n, tid = threadIdx.x;
     const long nn = (long)n * n;
-    double *M = mw_lds;
+    lds_d *M = MW_LDS;
     const double *A = (which == 0 ? p.Pm : p.dX) + k.xyoff;
     const double sg = which == 0 ? 1.0 : -1.0;
     for (int e = tid; e < nn; e += MW_NT) {
         const int i = e % n, c = e / n;
         acc<K> s;
         acc_zero<K>(s);
-        for (int kk = 0; kk < n; kk++) acc_fma<K, K, K>(s, ld_<K>(A, q.xylen, i + (long)kk * n), ld_<K>(p.Y + k.xyoff, q.xylen, kk + (long)c * n), sg);
-        acc_add<K, K>(s, ld_<K>(p.R + k.xyoff, q.xylen, e), -sg);
-        st<K>(M, nn, e, acc_result<K>(s));
+        for (int kk = 0; kk < n; kk++) acc_fma<K, K, K>(s, ldx<K>(A, q.xylen, i + (long)kk * n), ldx<K>(p.Y + k.xyoff, q.xylen, kk + (long)c * n), sg);
+        acc_add<K, K>(s, ldx<K>(p.R + k.xyoff, q.xylen, e), -sg);
+        stx<K>(M, nn, e, acc_result<K>(s));
     }
-    const double *L = p.Xc + k.xyoff;
-    long lplane = q.xylen;
+    // X^-1 M with the scaled triangles of chol(X) (this iteration's k_mw_potrf_x left them in the context)
     if (lds_L) {
-        double *Ls = mw_lds + (long)K * nn;
-        wg_copy<K>(Ls, nn, n, p.Xc + k.xyoff, q.xylen, n, n, n, tid);
-        L = Ls;
-        lplane = nn;
+        lds_d *Lf = MW_LDS + (long)K * nn, *Lb = Lf + (long)K * nn;
+        wg_copy<K>(Lf, nn, n, q.Xf + k.xyoff, q.xylen, n, n, n, tid);
+        wg_copy<K>(Lb, nn, n, q.Xb + k.xyoff, q.xylen, n, n, n, tid);
+        __syncthreads();
+        wg_trsm_f<K>(Lf, nn, n, q.xrd + k.rd_off, q.xrdlen, n, M, nn, n, n, tid);
+        wg_trsm_b<K>(Lb, nn, n, q.xrd + k.rd_off, q.xrdlen, n, M, nn, n, n, tid);
+    } else {
+        __syncthreads();
+        wg_trsm_f<K>(q.Xf + k.xyoff, q.xylen, n, q.xrd + k.rd_off, q.xrdlen, n, M, nn, n, n, tid);
+        wg_trsm_b<K>(q.Xb + k.xyoff, q.xylen, n, q.xrd + k.rd_off, q.xrdlen, n, M, nn, n, n, tid);
     }
-    __syncthreads();
-    wg_trsm_lower<K>(L, lplane, n, q.xrd + k.rd_off, q.xrdlen, n, M, nn, n, n, tid);
-    wg_trsm_lower_t<K>(L, lplane, n, q.xrd + k.rd_off, q.xrdlen, n, M, nn, n, n, tid);
     for (int e = tid; e < nn; e += MW_NT) {
         const int i = e % n, c = e / n;
         if (c > i) continue;
-        mw<K> v = mul_pow2<K>(add<K>(ld_<K>(M, nn, i + (long)c * n), ld_<K>(M, nn, c + (long)i * n)), 0.5);
-        st<K>(p.dY + k.xyoff, q.xylen, i + (long)c * n, v);
-        st<K>(p.dY + k.xyoff, q.xylen, c + (long)i * n, v);
+        mw<K> v = mul_pow2<K>(add<K>(ldx<K>(M, nn, i + (long)c * n), ldx<K>(M, nn, c + (long)i * n)), 0.5);
+        stx<K>(p.dY + k.xyoff, q.xylen, i + (long)c * n, v);
+        stx<K>(p.dY + k.xyoff, q.xylen, c + (long)i * n, v);
     }
 }
 
@@ -489,37 +491,43 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_step(const MwDev q, const MwIpmDe
     const double *Mg = (which == 0 ? p.X : p.Y) + k.xyoff, *dMg = (which == 0 ? p.dX : p.dY) + k.xyoff;
     if (n == 1) {
         if (tid == 0) {
-            mw<K> m = ld_<K>(Mg, q.xylen, 0);
+            mw<K> m = ldx<K>(Mg, q.xylen, 0);
             if (!(m.l[0] > 0.0)) { p.flags[2] = 1; p.eig[(long)which * q.NB + blockIdx.x] = 0.0; }
-            else p.eig[(long)which * q.NB + blockIdx.x] = div<K>(ld_<K>(dMg, q.xylen, 0), m).l[0] ;     // :1637-1641
+            else p.eig[(long)which * q.NB + blockIdx.x] = div<K>(ldx<K>(dMg, q.xylen, 0), m).l[0];     // :1637-1641
         }
         return;
     }
-    double *L = mw_lds, *W = mw_lds + (long)K * nn, *rd = W + (long)K * nn, *Wd = rd + (long)K * n, *work = Wd + nn;
+    // LDS: F (row-scaled factor), W, rd, the fp64 matrix and the eigenvalue work space, the broadcast slot of the factorisation
+    lds_d *F = MW_LDS, *W = F + (long)K * nn, *rd = W + (long)K * nn, *Wd = rd + (long)K * n, *work = Wd + nn, *bc = work + 3 * n + 2 * MW_NT;
     if (which == 0) {
-        wg_copy<K>(L, nn, n, p.Xc + k.xyoff, q.xylen, n, n, n, tid);
-        for (int i = tid; i < n; i += MW_NT) st<K>(rd, n, i, ld_<K>(q.xrd + k.rd_off, q.xrdlen, i));
+        wg_copy<K>(F, nn, n, q.Xf + k.xyoff, q.xylen, n, n, n, tid);
+        for (int i = tid; i < n; i += MW_NT) stx<K>(rd, n, i, ldx<K>(q.xrd + k.rd_off, q.xrdlen, i));
         __syncthreads();
     } else {
-        wg_copy<K>(L, nn, n, Mg, q.xylen, n, n, n, tid);
+        wg_copy<K>(F, nn, n, Mg, q.xylen, n, n, n, tid);
         __syncthreads();
-        if (!wg_potrf<K>(L, nn, n, n, rd, n, tid)) {                                    // :1644-1646
+        if (!wg_potrf<K>(F, nn, n, n, rd, n, bc, tid)) {                                 // :1644-1646
             if (tid == 0) { p.flags[2] = 1; p.eig[(long)which * q.NB + blockIdx.x] = 0.0; }
             return;
         }
+        for (int e = tid; e < nn; e += MW_NT) {                                          // row-scaled strict lower triangle, in place
+            const int i = e % n, c = e / n;
+            if (i > c) stx<K>(F, nn, e, mul<K>(ldx<K>(F, nn, e), ldx<K>(rd, n, i)));
+        }
+        __syncthreads();
     }
     wg_copy<K>(W, nn, n, dMg, q.xylen, n, n, n, tid);
     __syncthreads();
-    wg_trsm_lower<K>(L, nn, n, rd, n, n, W, nn, n, n, tid);                              // :1651
+    wg_trsm_f<K>(F, nn, n, rd, n, n, W, nn, n, n, tid);                                  // :1651
     for (int e = tid; e < nn; e += MW_NT) {                                              // transpose :1652
         const int i = e % n, c = e / n;
         if (c >= i) continue;
-        mw<K> a = ld_<K>(W, nn, i + (long)c * n), b2 = ld_<K>(W, nn, c + (long)i * n);
-        st<K>(W, nn, i + (long)c * n, b2);
-        st<K>(W, nn, c + (long)i * n, a);
+        mw<K> a = ldx<K>(W, nn, i + (long)c * n), b2 = ldx<K>(W, nn, c + (long)i * n);
+        stx<K>(W, nn, i + (long)c * n, b2);
+        stx<K>(W, nn, c + (long)i * n, a);
     }
     __syncthreads();
-    wg_trsm_lower<K>(L, nn, n, rd, n, n, W, nn, n, n, tid);                              // :1655
+    wg_trsm_f<K>(F, nn, n, rd, n, n, W, nn, n, n, tid);                                  // :1655
     for (int e = tid; e < nn; e += MW_NT) {
         const int i = e % n, c = e / n;
         Wd[e] = 0.5 * (W[i + (long)c * n] + W[c + (long)i * n]);                         // heads of the limbs: the Float64 matrix of :1659
@@ -540,27 +548,27 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_update(const MwDev q, const MwIpm
         if (i < q.xylen) {
             acc<K> s;
             acc_zero<K>(s);
-            acc_add<K, K>(s, ld_<K>(p.X, q.xylen, i));
-            acc_fma_d<K, K>(s, ld_<K>(p.dX, q.xylen, i), ad);
-            st<K>(p.X, q.xylen, i, acc_result<K>(s));
+            acc_add<K, K>(s, ldx<K>(p.X, q.xylen, i));
+            acc_fma_d<K, K>(s, ldx<K>(p.dX, q.xylen, i), ad);
+            stx<K>(p.X, q.xylen, i, acc_result<K>(s));
             acc_zero<K>(s);
-            acc_add<K, K>(s, ld_<K>(p.Y, q.xylen, i));
-            acc_fma_d<K, K>(s, ld_<K>(p.dY, q.xylen, i), ap);
-            st<K>(p.Y, q.xylen, i, acc_result<K>(s));
+            acc_add<K, K>(s, ldx<K>(p.Y, q.xylen, i));
+            acc_fma_d<K, K>(s, ldx<K>(p.dY, q.xylen, i), ap);
+            stx<K>(p.Y, q.xylen, i, acc_result<K>(s));
         } else if (i < q.xylen + q.xlen) {
             const mwi64 g = i - q.xylen;
             acc<K> s;
             acc_zero<K>(s);
-            acc_add<K, K>(s, ld_<K>(p.x, q.xlen, g));
-            acc_fma_d<K, K>(s, ld_<K>(p.dx, q.xlen, g), ad);
-            st<K>(p.x, q.xlen, g, acc_result<K>(s));
+            acc_add<K, K>(s, ldx<K>(p.x, q.xlen, g));
+            acc_fma_d<K, K>(s, ldx<K>(p.dx, q.xlen, g), ad);
+            stx<K>(p.x, q.xlen, g, acc_result<K>(s));
         } else {
             const mwi64 a = i - q.xylen - q.xlen;
             acc<K> s;
             acc_zero<K>(s);
-            acc_add<K, K>(s, ld_<K>(p.y, q.N, a));
-            acc_fma_d<K, K>(s, ld_<K>(p.dy, q.N, a), ap);
-            st<K>(p.y, q.N, a, acc_result<K>(s));
+            acc_add<K, K>(s, ldx<K>(p.y, q.N, a));
+            acc_fma_d<K, K>(s, ldx<K>(p.dy, q.N, a), ap);
+            stx<K>(p.y, q.N, a, acc_result<K>(s));
         }
     }
 }
@@ -642,9 +650,9 @@ extern "C" int clrs_mw_ipm_create_ex(clrs_mw_ctx *c, const clrs_ipm_data *data, 
         for (auto &k : c->blk) { p.Ktot += k.n; maxn = std::max(maxn, (size_t)k.n); }
         const size_t lim = MW_LDS_MAX / sizeof(double), nnK = maxn * maxn * K;
         if (nnK > lim) return mw_fail(CLRS_ERR_INVALID, "device-resident multi-word iteration needs PSD blocks that fit in LDS");
-        st->lds_ZL = 2 * nnK <= lim;
-        st->sm_Z = (st->lds_ZL ? 2 : 1) * nnK * 8;
-        const size_t stepd = 2 * nnK + (size_t)K * maxn + maxn * maxn + 3 * maxn + 2 * MW_NT + 8;
+        st->lds_ZL = 3 * nnK <= lim;
+        st->sm_Z = (st->lds_ZL ? 3 : 1) * nnK * 8;
+        const size_t stepd = 2 * nnK + (size_t)K * maxn + maxn * maxn + 3 * maxn + 2 * MW_NT + K + 1 + 8;
         if (stepd > lim) return mw_fail(CLRS_ERR_INVALID, "device-resident multi-word iteration needs PSD blocks that fit in LDS");
         st->sm_step = stepd * 8;
         MW_DISPATCH(c, {
@@ -681,7 +689,7 @@ static int mw_ipm_objectives(clrs_mw_ctx *c) {
     const MwDev &q = c->d;
     const MwIpmDev &p = c->ipm->d;
     MW_DISPATCH(c, {
-        hipLaunchKernelGGL((k_mwi_dots<KK, DD>), dim3(q.NB), dim3(MW_NT), (size_t)KK * MW_NT * 8, c->stream, q, p, 4);
+        hipLaunchKernelGGL((k_mwi_dots<KK, DD>), dim3(q.NB), dim3(MW_NT), (size_t)KK * 8 * 8, c->stream, q, p, 4);
         hipLaunchKernelGGL((k_mwi_scalar<KK, DD>), dim3(1), dim3(1), 0, c->stream, q, p, 4, c->ipm->iter);
     });
     MWCHECK(hipGetLastError());
@@ -755,7 +763,7 @@ extern "C" int clrs_mw_ipm_iterate(clrs_mw_ctx *c, clrs_ipm_record *out) {
     MwIpm *st = c->ipm;
     const MwIpmDev &p = st->d;
     const int maxnn = c->maxn * c->maxn;
-    const size_t sm_red = (size_t)c->K * MW_NT * 8;
+    const size_t sm_red = (size_t)c->K * 8 * 8;
     int rc;
     st->iter++;
     MW_DISPATCH(c, {

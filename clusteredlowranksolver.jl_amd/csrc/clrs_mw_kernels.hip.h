@@ -68,6 +68,8 @@ struct MwDev {
     double *Z, *Tm, *GX, *GY, *W, *Sd;  // scratch, planar
     mwi64 zlen, glen, wlen, sdlen;
     double *S, *LB, *Q, *Qs;            // S layout; stacked L^-1 B (xlen x N); Q (N x N); (unused)
+    double *Sf, *Sb, *Qf, *Qb;          // row- / column-scaled strict lower triangles of L_j and L_Q (unit-diagonal substitutions)
+    double *Xf, *Xb;                    // the same for the Cholesky factors of the X blocks (xy layout)
     double *xrd, *srd, *qrd;            // reciprocal diagonals of chol(X_b), L_j, L_Q
     double *t, *u, *AY;                 // t = L^-1 rhs_x (xlen); u slabs (J x N); pairings per term
     int *info;                          // [0] factor status, [1] Cholesky-of-X status
@@ -76,6 +78,23 @@ struct MwDev {
 namespace mwk {
 using namespace mwa;
 
+// LDS pointers carry their address space so that the accesses are ds_read / ds_write (a generic pointer makes every access a
+// flat_load with its longer latency and its wait on both memory counters); the primitives are templates over the pointer types
+typedef __attribute__((address_space(3))) double lds_d;
+
+template <int K, class P>
+__device__ __forceinline__ mw<K> ldx(P p, long plane, long i) {
+    mw<K> r;
+#pragma unroll
+    for (int l = 0; l < K; l++) r.l[l] = p[(long)l * plane + i];
+    return r;
+}
+template <int K, class P>
+__device__ __forceinline__ void stx(P p, long plane, long i, const mw<K> &v) {
+#pragma unroll
+    for (int l = 0; l < K; l++) p[(long)l * plane + i] = v.l[l];
+}
+
 __device__ __forceinline__ void tri_index(int e, int &ii, int &jj) {      // e -> (ii >= jj) of a packed lower triangle
     ii = (int)((__builtin_sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
     while ((ii + 1) * (ii + 2) / 2 <= e) ii++;
@@ -83,82 +102,134 @@ __device__ __forceinline__ void tri_index(int e, int &ii, int &jj) {      // e -
     jj = e - ii * (ii + 1) / 2;
 }
 
+// sum over groups of W consecutive lanes (W a power of two <= 64); every lane of the group gets the result
+template <int K, int W>
+__device__ __forceinline__ mw<K> lanes_sum(mw<K> v) {
+#pragma unroll
+    for (int off = W / 2; off > 0; off >>= 1) {
+        mw<K> o;
+#pragma unroll
+        for (int l = 0; l < K; l++) o.l[l] = __shfl_xor(v.l[l], off, 64);
+        v = add<K>(v, o);
+    }
+    return v;
+}
+
 // In-place lower Cholesky of the n x n matrix M (planar, leading dimension ld), reciprocal diagonal to rd.
-// approx_cholesky! (src/tools.jl:69-107): returns false at the first non-positive pivot (the strict upper triangle is
-// left to the caller).  Right-looking: per pivot one Newton rsqrt (every thread, redundantly), the column scaling and
-// the rank-1 update of the trailing triangle spread over the workgroup; two barriers per pivot.
-template <int K>
-__device__ bool wg_potrf(double *M, long plane, int n, int ld, double *rd, long rdplane, int tid) {
+// approx_cholesky! (src/tools.jl:69-107): returns false at the first non-positive pivot.
+// The dependent chain per pivot is  d_k -> 1/sqrt(d_k) -> l_(k+1,k) -> d_(k+1): ONE wave evaluates the Newton rsqrt while
+// the other waves apply the part of the previous rank-1 update that the chain does not need yet (columns > k: look-ahead);
+// then the column is scaled and only the next pivot column is updated before the next rsqrt starts.
+// `bc`: LDS, K + 1 doubles (the reciprocal square root and the status of the pivot, for the other waves).
+template <int K, class PM, class PR>
+__device__ __forceinline__ bool wg_potrf(PM M, long plane, int n, int ld, PR rd, long rdplane, lds_d *bc, int tid) {
+    const int wave = tid >> 6;
     for (int k = 0; k < n; k++) {
         const long kk = k + (long)k * ld;
-        mw<K> d = ld_<K>(M, plane, kk);
-        if (!(d.l[0] > 0.0)) return false;
-        mw<K> rs = rsqrt<K>(d);
-        for (int i = k + 1 + tid; i < n; i += MW_NT) {
-            const long idx = i + (long)k * ld;
-            st<K>(M, plane, idx, mul<K>(ld_<K>(M, plane, idx), rs));
+        if (wave == 0) {
+            mw<K> d = ldx<K>(M, plane, kk);
+            const bool ok = d.l[0] > 0.0;
+            mw<K> rs = ok ? rsqrt<K>(d) : zero<K>();
+            if (tid == 0) {                                              // M[k,k] keeps d_k until the end: nothing reads it again
+                stx<K>(bc, 1, 0, rs);
+                bc[K] = ok ? 1.0 : 0.0;
+                stx<K>(rd, rdplane, k, rs);
+            }
+        } else if (k > 0) {
+            const int m = n - k - 1, cnt = m * (m + 1) / 2;            // rest of update k-1: columns k+1 .. n-1
+            for (int e = tid - 64; e < cnt; e += MW_NT - 64) {
+                int ii, jj;
+                tri_index(e, ii, jj);
+                const int i = k + 1 + ii, j = k + 1 + jj;
+                const long idx = i + (long)j * ld;
+                stx<K>(M, plane, idx, fnma<K>(ldx<K>(M, plane, idx), ldx<K>(M, plane, i + (long)(k - 1) * ld), ldx<K>(M, plane, j + (long)(k - 1) * ld)));
+            }
         }
         __syncthreads();
-        if (tid == 0) {
-            st<K>(M, plane, kk, sqrt_with_rsqrt<K>(d, rs));
-            st<K>(rd, rdplane, k, rs);
+        if (bc[K] == 0.0) return false;
+        const mw<K> rs = ldx<K>(bc, 1, 0);
+        for (int i = k + 1 + tid; i < n; i += MW_NT) {
+            const long idx = i + (long)k * ld;
+            stx<K>(M, plane, idx, mul<K>(ldx<K>(M, plane, idx), rs));
         }
-        const int m = n - k - 1, cnt = m * (m + 1) / 2;
-        for (int e = tid; e < cnt; e += MW_NT) {
-            int ii, jj;
-            tri_index(e, ii, jj);
-            const int i = k + 1 + ii, j = k + 1 + jj;
-            const long idx = i + (long)j * ld;
-            st<K>(M, plane, idx, fnma<K>(ld_<K>(M, plane, idx), ld_<K>(M, plane, i + (long)k * ld), ld_<K>(M, plane, j + (long)k * ld)));
+        __syncthreads();
+        if (k + 1 < n) {
+            const mw<K> lk = ldx<K>(M, plane, (k + 1) + (long)k * ld);
+            for (int i = k + 1 + tid; i < n; i += MW_NT) {
+                const long idx = i + (long)(k + 1) * ld;
+                stx<K>(M, plane, idx, fnma<K>(ldx<K>(M, plane, idx), ldx<K>(M, plane, i + (long)k * ld), lk));
+            }
         }
         __syncthreads();
     }
+    for (int k = tid; k < n; k += MW_NT) {                               // L_kk = sqrt(d_k), off the dependent chain
+        const long kk = k + (long)k * ld;
+        stx<K>(M, plane, kk, sqrt_with_rsqrt<K>(ldx<K>(M, plane, kk), ldx<K>(rd, rdplane, k)));
+    }
+    __syncthreads();
     return true;
 }
 
-// B <- L^-1 B (n x nrhs, planar), L lower with reciprocal diagonal rd
-template <int K>
-__device__ void wg_trsm_lower(const double *L, long lplane, int ldl, const double *rd, long rdplane, int n, double *B, long bplane,
-                              int ldb, int nrhs, int tid) {
-    for (int k = 0; k < n; k++) {
-        mw<K> r = ld_<K>(rd, rdplane, k);
-        for (int c = tid; c < nrhs; c += MW_NT) {
-            const long idx = k + (long)c * ldb;
-            st<K>(B, bplane, idx, mul<K>(ld_<K>(B, bplane, idx), r));
+// Scaled strict lower triangles of a Cholesky factor: F[i,k] = L[i,k] / L[i,i] (forward substitution with a unit diagonal:
+// x_i = b_i / L_ii - sum_k F[i,k] x_k) and Bk[i,k] = L[i,k] / L[k,k] (backward: x_k = b_k / L_kk - sum_i Bk[i,k] x_i), i > k.
+template <int K, class PL, class PR, class PF, class PB>
+__device__ __forceinline__ void wg_scaled_factors(PL L, long lplane, int ldl, PR rd, long rdplane, int n, PF F, long fplane, int ldf, PB Bk,
+                                                  long bplane, int ldb, int tid) {
+    for (int e = tid; e < n * n; e += MW_NT) {
+        const int i = e % n, k = e / n;
+        if (i > k) {
+            const mw<K> l = ldx<K>(L, lplane, i + (long)k * ldl);
+            stx<K>(F, fplane, i + (long)k * ldf, mul<K>(l, ldx<K>(rd, rdplane, i)));
+            stx<K>(Bk, bplane, i + (long)k * ldb, mul<K>(l, ldx<K>(rd, rdplane, k)));
+        } else {
+            stx<K>(F, fplane, i + (long)k * ldf, zero<K>());
+            stx<K>(Bk, bplane, i + (long)k * ldb, zero<K>());
         }
-        __syncthreads();
+    }
+}
+
+// B <- L^-1 B with the row-scaled factor F (n x nrhs, planar): rows scaled by 1/L_ii first, then one multiply-add per
+// entry and ONE barrier per column of the factor
+template <int K, class PF, class PR, class PB>
+__device__ __forceinline__ void wg_trsm_f(PF F, long fplane, int ldf, PR rd, long rdplane, int n, PB B, long bplane, int ldb, int nrhs, int tid) {
+    for (int e = tid; e < n * nrhs; e += MW_NT) {
+        const int i = e % n, c = e / n;
+        const long idx = i + (long)c * ldb;
+        stx<K>(B, bplane, idx, mul<K>(ldx<K>(B, bplane, idx), ldx<K>(rd, rdplane, i)));
+    }
+    __syncthreads();
+    for (int k = 0; k < n - 1; k++) {
         const int m = n - k - 1;
         for (int e = tid; e < m * nrhs; e += MW_NT) {
             const int i = k + 1 + e % m, c = e / m;
             const long idx = i + (long)c * ldb;
-            st<K>(B, bplane, idx, fnma<K>(ld_<K>(B, bplane, idx), ld_<K>(L, lplane, i + (long)k * ldl), ld_<K>(B, bplane, k + (long)c * ldb)));
+            stx<K>(B, bplane, idx, fnma<K>(ldx<K>(B, bplane, idx), ldx<K>(F, fplane, i + (long)k * ldf), ldx<K>(B, bplane, k + (long)c * ldb)));
         }
         __syncthreads();
     }
 }
-// B <- L^-T B
-template <int K>
-__device__ void wg_trsm_lower_t(const double *L, long lplane, int ldl, const double *rd, long rdplane, int n, double *B, long bplane,
-                                int ldb, int nrhs, int tid) {
-    for (int k = n - 1; k >= 0; k--) {
-        mw<K> r = ld_<K>(rd, rdplane, k);
-        for (int c = tid; c < nrhs; c += MW_NT) {
-            const long idx = k + (long)c * ldb;
-            st<K>(B, bplane, idx, mul<K>(ld_<K>(B, bplane, idx), r));
-        }
-        __syncthreads();
+// B <- L^-T B with the column-scaled factor Bk
+template <int K, class PF, class PR, class PB>
+__device__ __forceinline__ void wg_trsm_b(PF Bk, long fplane, int ldf, PR rd, long rdplane, int n, PB B, long bplane, int ldb, int nrhs, int tid) {
+    for (int e = tid; e < n * nrhs; e += MW_NT) {
+        const int i = e % n, c = e / n;
+        const long idx = i + (long)c * ldb;
+        stx<K>(B, bplane, idx, mul<K>(ldx<K>(B, bplane, idx), ldx<K>(rd, rdplane, i)));
+    }
+    __syncthreads();
+    for (int k = n - 1; k > 0; k--) {
         for (int e = tid; e < k * nrhs; e += MW_NT) {
             const int i = e % k, c = e / k;
             const long idx = i + (long)c * ldb;
-            st<K>(B, bplane, idx, fnma<K>(ld_<K>(B, bplane, idx), ld_<K>(L, lplane, k + (long)i * ldl), ld_<K>(B, bplane, k + (long)c * ldb)));
+            stx<K>(B, bplane, idx, fnma<K>(ldx<K>(B, bplane, idx), ldx<K>(Bk, fplane, k + (long)i * ldf), ldx<K>(B, bplane, k + (long)c * ldb)));
         }
         __syncthreads();
     }
 }
 
-// copy an n x n (or rows x cols) planar matrix between a strided global array and a packed LDS array
-template <int K>
-__device__ void wg_copy(double *dst, long dplane, int ldd, const double *src, long splane, int lds_, int rows, int cols, int tid) {
+// copy a rows x cols planar matrix between two arrays (any address spaces)
+template <int K, class PD, class PS>
+__device__ __forceinline__ void wg_copy(PD dst, long dplane, int ldd, PS src, long splane, int lds_, int rows, int cols, int tid) {
     for (int e = tid; e < rows * cols; e += MW_NT) {
         const int i = e % rows, c = e / rows;
 #pragma unroll
@@ -169,35 +240,42 @@ __device__ void wg_copy(double *dst, long dplane, int ldd, const double *src, lo
 }  // namespace mwk
 
 extern __shared__ double mw_lds[];
+#define MW_LDS ((mwk::lds_d *)mw_lds)
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Cholesky of every X block: Xchol_b = chol(X_b), strict upper zero, reciprocal diagonal kept.
-// One workgroup per block; `lds` = 1: the block is factored in LDS.
+// Cholesky of every X block: Xchol_b = chol(X_b), strict upper zero; reciprocal diagonal and the two scaled triangles kept
+// for the substitutions that follow.  One workgroup per block; `lds` = 1: the block is factored in LDS.
 // ---------------------------------------------------------------------------------------------------------------------
+template <int K, class PM>
+__device__ __forceinline__ void mw_potrf_x_body(const MwDev &q, const MwBlk &k, PM M, long plane, double *__restrict__ Xc, mwk::lds_d *bc, int tid, int bid) {
+    using namespace mwk;
+    const int n = k.n;
+    const bool ok = wg_potrf<K>(M, plane, n, n, q.xrd + k.rd_off, q.xrdlen, bc, tid);
+    if (!ok && tid == 0) atomicMin(&q.info[1], bid + 1);
+    __syncthreads();
+    wg_scaled_factors<K>(M, plane, n, q.xrd + k.rd_off, q.xrdlen, n, q.Xf + k.xyoff, q.xylen, n, q.Xb + k.xyoff, q.xylen, n, tid);
+    for (int e = tid; e < n * n; e += MW_NT) {
+        const int i = e % n, c = e / n;
+#pragma unroll
+        for (int l = 0; l < K; l++) Xc[(long)l * q.xylen + k.xyoff + e] = (i >= c) ? (double)M[(long)l * plane + e] : 0.0;
+    }
+}
 template <int K>
 __global__ __launch_bounds__(MW_NT) void k_mw_potrf_x(const MwDev q, const double *__restrict__ X, double *__restrict__ Xc, int lds) {
     using namespace mwk;
     const MwBlk &k = q.blk[blockIdx.x];
     const int n = k.n, tid = threadIdx.x;
-    double *M;
-    long plane;
+    lds_d *bc = MW_LDS;                                   // K + 1 doubles, in front of the matrix
     if (lds) {
-        M = mw_lds;
-        plane = (long)n * n;
-        wg_copy<K>(M, plane, n, X + k.xyoff, q.xylen, n, n, n, tid);
+        lds_d *M = MW_LDS + (K + 1);
+        wg_copy<K>(M, (long)n * n, n, X + k.xyoff, q.xylen, n, n, n, tid);
+        __syncthreads();
+        mw_potrf_x_body<K>(q, k, M, (long)n * n, Xc, bc, tid, blockIdx.x);
     } else {
-        M = Xc + k.xyoff;
-        plane = q.xylen;
-        wg_copy<K>(M, plane, n, X + k.xyoff, q.xylen, n, n, n, tid);
-    }
-    __syncthreads();
-    const bool ok = wg_potrf<K>(M, plane, n, n, q.xrd + k.rd_off, q.xrdlen, tid);
-    if (!ok && tid == 0) atomicMin(&q.info[1], (int)blockIdx.x + 1);
-    __syncthreads();
-    for (int e = tid; e < n * n; e += MW_NT) {
-        const int i = e % n, c = e / n;
-#pragma unroll
-        for (int l = 0; l < K; l++) Xc[(long)l * q.xylen + k.xyoff + e] = (i >= c) ? M[(long)l * plane + e] : 0.0;
+        double *M = Xc + k.xyoff;
+        wg_copy<K>(M, q.xylen, n, X + k.xyoff, q.xylen, n, n, n, tid);
+        __syncthreads();
+        mw_potrf_x_body<K>(q, k, M, q.xylen, Xc, bc, tid, blockIdx.x);
     }
 }
 
@@ -207,7 +285,7 @@ __global__ __launch_bounds__(MW_NT) void k_mw_potrf_x(const MwDev q, const doubl
 // of the pairing: V^T X^-1 V = Z^T Z, so the explicit inverse (inv_cho_precomp!, :1117) is never formed.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int K, int DK>
-__global__ __launch_bounds__(MW_NT) void k_mw_zt(const MwDev q, const double *__restrict__ Xc, const double *__restrict__ Y, int lds_L) {
+__global__ __launch_bounds__(MW_NT) void k_mw_zt(const MwDev q, const double *__restrict__ Y, int lds_L) {
     using namespace mwk;
     const MwBlk &k = q.blk[q.lr_list[blockIdx.y]];
     const int n = k.n, U = k.U, tid = threadIdx.x, dl = k.delta;
@@ -216,32 +294,38 @@ __global__ __launch_bounds__(MW_NT) void k_mw_zt(const MwDev q, const double *__
     const int nc = min(MW_CT, U - c0);
     const double *V = q.V + k.v_off;
     const int *vrow = q.vrow + k.vrow_off;
-    // T[:, c] = Y[:, rows(c)] V[rows(c), c]
-    for (int e = tid; e < n * nc; e += MW_NT) {
-        const int i = e % n, c = c0 + e / n, r0 = vrow[c];
-        acc<K> s;
-        acc_zero<K>(s);
-        for (int kk = r0; kk < r0 + dl; kk++) acc_fma<K, K, DK>(s, ld_<K>(Y + k.xyoff, q.xylen, i + (long)kk * n), ld_<DK>(V, q.Vp, kk + (long)c * n));
-        st<K>(q.Tm + k.z_off, q.zlen, i + (long)c * n, acc_result<K>(s));
+    // T[:, c] = Y[:, rows(c)] V[rows(c), c]: two lanes per entry
+    {
+        const int sub = tid & 1;
+        for (int e0 = 0; e0 < n * nc; e0 += MW_NT / 2) {
+            const int e = e0 + (tid >> 1);
+            const bool live = e < n * nc;
+            const int ee = live ? e : 0;
+            const int i = ee % n, c = c0 + ee / n, r0 = vrow[c];
+            acc<K> s;
+            acc_zero<K>(s);
+            for (int kk = r0 + sub; kk < r0 + dl; kk += 2) acc_fma<K, K, DK>(s, ldx<K>(Y + k.xyoff, q.xylen, i + (long)kk * n), ldx<DK>(V, q.Vp, kk + (long)c * n));
+            mw<K> v = lanes_sum<K, 2>(acc_result<K>(s));
+            if (live && sub == 0) stx<K>(q.Tm + k.z_off, q.zlen, i + (long)c * n, v);
+        }
     }
-    // Z tile in LDS: forward substitution with L
-    double *Zt = mw_lds;
+    // Z tile in LDS: forward substitution with the row-scaled factor of X_b
+    lds_d *Zt = MW_LDS;
     const long zp = (long)n * MW_CT;
-    const double *L = Xc + k.xyoff;
-    long lplane = q.xylen;
-    if (lds_L) {
-        double *Ls = mw_lds + (long)K * zp;
-        wg_copy<K>(Ls, (long)n * n, n, Xc + k.xyoff, q.xylen, n, n, n, tid);
-        L = Ls;
-        lplane = (long)n * n;
-    }
     for (int e = tid; e < n * nc; e += MW_NT) {
         const int i = e % n, c = e / n;
 #pragma unroll
         for (int l = 0; l < K; l++) Zt[(long)l * zp + e] = l < DK ? V[(long)l * q.Vp + i + (long)(c0 + c) * n] : 0.0;
     }
-    __syncthreads();
-    wg_trsm_lower<K>(L, lplane, n, q.xrd + k.rd_off, q.xrdlen, n, Zt, zp, n, nc, tid);
+    if (lds_L) {
+        lds_d *Ls = MW_LDS + (long)K * zp;
+        wg_copy<K>(Ls, (long)n * n, n, q.Xf + k.xyoff, q.xylen, n, n, n, tid);
+        __syncthreads();
+        wg_trsm_f<K>(Ls, (long)n * n, n, q.xrd + k.rd_off, q.xrdlen, n, Zt, zp, n, nc, tid);
+    } else {
+        __syncthreads();
+        wg_trsm_f<K>(q.Xf + k.xyoff, q.xylen, n, q.xrd + k.rd_off, q.xrdlen, n, Zt, zp, n, nc, tid);
+    }
     for (int e = tid; e < n * nc; e += MW_NT) {
 #pragma unroll
         for (int l = 0; l < K; l++) q.Z[(long)l * q.zlen + k.z_off + (long)c0 * n + e] = Zt[(long)l * zp + e];
@@ -250,17 +334,20 @@ __global__ __launch_bounds__(MW_NT) void k_mw_zt(const MwDev q, const double *__
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Pairing matrices of a low-rank block: GX = Z^T Z = V^T X^-1 V, GY = V^T T = V^T Y V (U x U, symmetric; the
-// reference's bilinear_pairings_Xinv / _Y, src/solver.jl:1131, 1143).  One thread per entry of the lower triangle.
+// reference's bilinear_pairings_Xinv / _Y, src/solver.jl:1131, 1143).  Four lanes per entry of the lower triangle.
 // ---------------------------------------------------------------------------------------------------------------------
+#define MW_GRAM_W 4
 template <int K, int DK>
 __global__ __launch_bounds__(MW_NT) void k_mw_gram(const MwDev q) {
     using namespace mwk;
     const MwBlk &k = q.blk[q.lr_list[blockIdx.y]];
     const int n = k.n, U = k.U, dl = k.delta;
-    const int e = blockIdx.x * MW_NT + threadIdx.x;
-    if (e >= U * (U + 1) / 2) return;
+    const int e = blockIdx.x * (MW_NT / MW_GRAM_W) + threadIdx.x / MW_GRAM_W, sub = threadIdx.x % MW_GRAM_W;
+    const int tot = U * (U + 1) / 2;
+    if (blockIdx.x * (MW_NT / MW_GRAM_W) >= tot) return;
+    const bool live = e < tot;
     int a, b;
-    tri_index(e, a, b);
+    tri_index(live ? e : 0, a, b);
     const double *V = q.V + k.v_off;
     const int *vrow = q.vrow + k.vrow_off;
     const double *Z = q.Z + k.z_off, *T = q.Tm + k.z_off;
@@ -268,16 +355,18 @@ __global__ __launch_bounds__(MW_NT) void k_mw_gram(const MwDev q) {
     acc_zero<K>(s);
     // rows above the first nonzero row of either vector are zero in Z = L^-1 V
     const int i0 = max(vrow[a], vrow[b]);
-    for (int i = i0; i < n; i++) acc_fma<K, K, K>(s, ld_<K>(Z, q.zlen, i + (long)a * n), ld_<K>(Z, q.zlen, i + (long)b * n));
-    mw<K> gx = acc_result<K>(s);
+    for (int i = i0 + sub; i < n; i += MW_GRAM_W) acc_fma<K, K, K>(s, ldx<K>(Z, q.zlen, i + (long)a * n), ldx<K>(Z, q.zlen, i + (long)b * n));
+    mw<K> gx = lanes_sum<K, MW_GRAM_W>(acc_result<K>(s));
     acc_zero<K>(s);
     const int r0 = vrow[a];
-    for (int i = r0; i < r0 + dl; i++) acc_fma<K, K, DK>(s, ld_<K>(T, q.zlen, i + (long)b * n), ld_<DK>(V, q.Vp, i + (long)a * n));
-    mw<K> gy = acc_result<K>(s);
-    st<K>(q.GX + k.g_off, q.glen, a + (long)b * U, gx);
-    st<K>(q.GX + k.g_off, q.glen, b + (long)a * U, gx);
-    st<K>(q.GY + k.g_off, q.glen, a + (long)b * U, gy);
-    st<K>(q.GY + k.g_off, q.glen, b + (long)a * U, gy);
+    for (int i = r0 + sub; i < r0 + dl; i += MW_GRAM_W) acc_fma<K, K, DK>(s, ldx<K>(T, q.zlen, i + (long)b * n), ldx<DK>(V, q.Vp, i + (long)a * n));
+    mw<K> gy = lanes_sum<K, MW_GRAM_W>(acc_result<K>(s));
+    if (live && sub == 0) {
+        stx<K>(q.GX + k.g_off, q.glen, a + (long)b * U, gx);
+        stx<K>(q.GX + k.g_off, q.glen, b + (long)a * U, gx);
+        stx<K>(q.GY + k.g_off, q.glen, a + (long)b * U, gy);
+        stx<K>(q.GY + k.g_off, q.glen, b + (long)a * U, gy);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -285,7 +374,7 @@ __global__ __launch_bounds__(MW_NT) void k_mw_gram(const MwDev q) {
 // (src/solver.jl:1089-1104).  One workgroup per block; n = 1 blocks take one thread per entry.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int K, int DK>
-__global__ __launch_bounds__(MW_NT) void k_mw_dense(const MwDev q, const double *__restrict__ Xc, const double *__restrict__ Y) {
+__global__ __launch_bounds__(MW_NT) void k_mw_dense(const MwDev q, const double *__restrict__ Y) {
     using namespace mwk;
     const MwBlk &k = q.blk[q.dn_list[blockIdx.x]];
     const int n = k.n, cnt = k.cnt, tid = threadIdx.x;
@@ -293,26 +382,26 @@ __global__ __launch_bounds__(MW_NT) void k_mw_dense(const MwDev q, const double 
     double *W = q.W + k.w_off;
     const long nn = (long)n * n;
     if (n == 1) {
-        mw<K> rd = ld_<K>(q.xrd + k.rd_off, q.xrdlen, 0);
-        mw<K> yx = mul<K>(ld_<K>(Y + k.xyoff, q.xylen, 0), mul<K>(rd, rd));      // Y / X
-        for (int e = tid; e < cnt; e += MW_NT) st<K>(W, q.wlen, e, mulx<K, K, DK>(yx, ld_<DK>(A, q.dAp, e)));
+        mw<K> rd = ldx<K>(q.xrd + k.rd_off, q.xrdlen, 0);
+        mw<K> yx = mul<K>(ldx<K>(Y + k.xyoff, q.xylen, 0), mul<K>(rd, rd));      // Y / X
+        for (int e = tid; e < cnt; e += MW_NT) stx<K>(W, q.wlen, e, mulx<K, K, DK>(yx, ldx<DK>(A, q.dAp, e)));
     } else {
+        lds_d *M = MW_LDS;
         for (int e = 0; e < cnt; e++) {
             // M = A_e; M <- L^-1 M; M <- L^-T M; T_e = M Y
-            double *M = mw_lds;
             for (int i = tid; i < nn; i += MW_NT) {
 #pragma unroll
                 for (int l = 0; l < K; l++) M[(long)l * nn + i] = l < DK ? A[(long)l * q.dAp + (long)e * nn + i] : 0.0;
             }
             __syncthreads();
-            wg_trsm_lower<K>(Xc + k.xyoff, q.xylen, n, q.xrd + k.rd_off, q.xrdlen, n, M, nn, n, n, tid);
-            wg_trsm_lower_t<K>(Xc + k.xyoff, q.xylen, n, q.xrd + k.rd_off, q.xrdlen, n, M, nn, n, n, tid);
+            wg_trsm_f<K>(q.Xf + k.xyoff, q.xylen, n, q.xrd + k.rd_off, q.xrdlen, n, M, nn, n, n, tid);
+            wg_trsm_b<K>(q.Xb + k.xyoff, q.xylen, n, q.xrd + k.rd_off, q.xrdlen, n, M, nn, n, n, tid);
             for (int o = tid; o < nn; o += MW_NT) {
                 const int i = o % n, c = o / n;
                 acc<K> s;
                 acc_zero<K>(s);
-                for (int kk = 0; kk < n; kk++) acc_fma<K, K, K>(s, ld_<K>(M, nn, i + (long)kk * n), ld_<K>(Y + k.xyoff, q.xylen, kk + (long)c * n));
-                st<K>(W, q.wlen, (long)e * nn + o, acc_result<K>(s));
+                for (int kk = 0; kk < n; kk++) acc_fma<K, K, K>(s, ldx<K>(M, nn, i + (long)kk * n), ldx<K>(Y + k.xyoff, q.xylen, kk + (long)c * n));
+                stx<K>(W, q.wlen, (long)e * nn + o, acc_result<K>(s));
             }
             __syncthreads();
         }
@@ -324,10 +413,10 @@ __global__ __launch_bounds__(MW_NT) void k_mw_dense(const MwDev q, const double 
         tri_index(o, e2, e1);       // e2 >= e1
         acc<K> s;
         acc_zero<K>(s);
-        for (long i = 0; i < nn; i++) acc_fma<K, K, DK>(s, ld_<K>(W, q.wlen, (long)e1 * nn + i), ld_<DK>(A, q.dAp, (long)e2 * nn + i));
+        for (long i = 0; i < nn; i++) acc_fma<K, K, DK>(s, ldx<K>(W, q.wlen, (long)e1 * nn + i), ldx<DK>(A, q.dAp, (long)e2 * nn + i));
         mw<K> v = acc_result<K>(s);
-        st<K>(q.Sd + k.sd_off, q.sdlen, e1 + (long)e2 * cnt, v);
-        st<K>(q.Sd + k.sd_off, q.sdlen, e2 + (long)e1 * cnt, v);
+        stx<K>(q.Sd + k.sd_off, q.sdlen, e1 + (long)e2 * cnt, v);
+        stx<K>(q.Sd + k.sd_off, q.sdlen, e2 + (long)e1 * cnt, v);
     }
 }
 
@@ -335,11 +424,20 @@ __global__ __launch_bounds__(MW_NT) void k_mw_dense(const MwDev q, const double 
 // S_j[p, q] = sum over the blocks of the cluster: low rank  sum_{t in p, t' in q} lam_t lam_t' GX[a_t, b_t'] GY[a_t', b_t]
 // with a_t = pointers_left[s][(r,p,k)], b_t = pointers_right[r][(s,p,k)] of the term t = (p,r,s,k) (src/solver.jl:1198-1203)
 // (the accumulation loops src/solver.jl:1176-1212 with the four Dict lookups replaced by the sorted term table),
-// dense  Sd[e_p, e_q].  One thread per entry q >= p, mirrored write (symmetric!, src/tools.jl:43-57).
+// dense  Sd[e_p, e_q].  One thread per entry q >= p, mirrored write (symmetric!, src/tools.jl:43-57); the per-term pairings
+// A_Y (src/solver.jl:1152-1170) are written by the first workgroups of the same launch.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int K, int DK>
 __global__ __launch_bounds__(MW_NT) void k_mw_saccum(const MwDev q) {
     using namespace mwk;
+    if (blockIdx.y == 0) {                               // A_Y per term: w^T Y v
+        for (mwi64 t = (mwi64)blockIdx.x * MW_NT + threadIdx.x; t < q.T; t += (mwi64)gridDim.x * MW_NT) {
+            const int b = q.ay_blk[t];
+            if (b < 0) continue;
+            const MwBlk &k = q.blk[b];
+            stx<K>(q.AY, q.T, t, ldx<K>(q.GY + k.g_off, q.glen, q.ay_a[t] + (long)q.ay_b[t] * k.U));
+        }
+    }
     const MwClu &c = q.clu[blockIdx.y];
     const int P = c.P;
     const int e = blockIdx.x * MW_NT + threadIdx.x;
@@ -355,163 +453,202 @@ __global__ __launch_bounds__(MW_NT) void k_mw_saccum(const MwDev q) {
             const int U = k.U;
             for (int t = tp[pp]; t < tp[pp + 1]; t++) {
                 for (int t2 = tp[qq]; t2 < tp[qq + 1]; t2++) {
-                    mw<K> gx = ld_<K>(q.GX + k.g_off, q.glen, q.st_a[t] + (long)q.st_b[t2] * U);
-                    mw<K> gy = ld_<K>(q.GY + k.g_off, q.glen, q.st_a[t2] + (long)q.st_b[t] * U);
+                    mw<K> gx = ldx<K>(q.GX + k.g_off, q.glen, q.st_a[t] + (long)q.st_b[t2] * U);
+                    mw<K> gy = ldx<K>(q.GY + k.g_off, q.glen, q.st_a[t2] + (long)q.st_b[t] * U);
                     mw<K> w = mul<K>(gx, gy);
                     constexpr int LL = (2 * DK + 1 < K) ? 2 * DK + 1 : K;   // lambda lambda' is exact in 2 DK limbs; one more bin so that none of them rounds
-                    mw<LL> ll = mulx<LL, DK, DK>(ld_<DK>(q.st_lam, q.lamp, t), ld_<DK>(q.st_lam, q.lamp, t2));
+                    mw<LL> ll = mulx<LL, DK, DK>(ldx<DK>(q.st_lam, q.lamp, t), ldx<DK>(q.st_lam, q.lamp, t2));
                     acc_fma<K, K, LL>(s, w, ll);
                 }
             }
         } else {
             const int *dm = q.dmap + k.dmap_off;
             const int e1 = dm[pp], e2 = dm[qq];
-            if (e1 >= 0 && e2 >= 0) acc_add<K, K>(s, ld_<K>(q.Sd + k.sd_off, q.sdlen, e1 + (long)e2 * k.cnt));
+            if (e1 >= 0 && e2 >= 0) acc_add<K, K>(s, ldx<K>(q.Sd + k.sd_off, q.sdlen, e1 + (long)e2 * k.cnt));
         }
     }
     mw<K> v = acc_result<K>(s);
-    st<K>(q.S + c.Soff, q.Slen, pp + (long)qq * P, v);
-    st<K>(q.S + c.Soff, q.Slen, qq + (long)pp * P, v);
+    stx<K>(q.S + c.Soff, q.Slen, pp + (long)qq * P, v);
+    stx<K>(q.S + c.Soff, q.Slen, qq + (long)pp * P, v);
 }
 
-// A_Y per term: w^T Y v (src/solver.jl:1152-1170)
-template <int K>
-__global__ __launch_bounds__(MW_NT) void k_mw_ay(const MwDev q) {
+// ---------------------------------------------------------------------------------------------------------------------
+// Factorisation of a cluster: L_j = chol(S_j) (in place in the S buffer), LinvB_j = L_j^-1 B_j; the scaled triangles of L_j
+// for the solve stage.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int K, class PM>
+__device__ __forceinline__ bool mw_factor_body(const MwDev &q, const MwClu &c, int j, PM M, long mplane, mwk::lds_d *bc, int tid) {
     using namespace mwk;
-    const mwi64 t = (mwi64)blockIdx.x * MW_NT + threadIdx.x;
-    if (t >= q.T) return;
-    const int b = q.ay_blk[t];
-    if (b < 0) return;
-    const MwBlk &k = q.blk[b];
-    st<K>(q.AY, q.T, t, ld_<K>(q.GY + k.g_off, q.glen, q.ay_a[t] + (long)q.ay_b[t] * k.U));
+    const int P = c.P;
+    const bool ok = wg_potrf<K>(M, mplane, P, P, q.srd + c.coff, q.xlen, bc, tid);
+    if (!ok) {
+        if (tid == 0) atomicMin(&q.info[0], j + 1);
+        return false;
+    }
+    double *Sg = q.S + c.Soff;
+    wg_scaled_factors<K>(M, mplane, P, q.srd + c.coff, q.xlen, P, q.Sf + c.Soff, q.Slen, P, q.Sb + c.Soff, q.Slen, P, tid);
+    for (int e = tid; e < P * P; e += MW_NT) {            // L_j back to the S buffer with a zero strict upper triangle
+        const int i = e % P, cc = e / P;
+#pragma unroll
+        for (int l = 0; l < K; l++) Sg[(long)l * q.Slen + e] = (i >= cc) ? (double)M[(long)l * mplane + e] : 0.0;
+    }
+    return true;
 }
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Factorisation of a cluster: L_j = chol(S_j) (in place in the S buffer), LinvB_j = L_j^-1 B_j.
-// ---------------------------------------------------------------------------------------------------------------------
-template <int K, int DK>
+template <int K>
 __global__ __launch_bounds__(MW_NT) void k_mw_factor(const MwDev q) {
     using namespace mwk;
     const int j = blockIdx.x, tid = threadIdx.x;
     const MwClu &c = q.clu[j];
-    const int P = c.P, N = q.N;
-    double *Sg = q.S + c.Soff;
-    double *M, *Bm;
-    long mplane, bplane;
-    int ldb;
+    const int P = c.P;
+    lds_d *bc = MW_LDS;
     if (c.lds) {
-        M = mw_lds;
-        mplane = (long)P * P;
-        Bm = mw_lds + (long)K * mplane;
-        bplane = (long)P * N;
-        ldb = P;
-        wg_copy<K>(M, mplane, P, Sg, q.Slen, P, P, P, tid);
+        lds_d *M = MW_LDS + (K + 1);
+        wg_copy<K>(M, (long)P * P, P, q.S + c.Soff, q.Slen, P, P, P, tid);
+        __syncthreads();
+        mw_factor_body<K>(q, c, j, M, (long)P * P, bc, tid);
     } else {
-        M = Sg;
-        mplane = q.Slen;
-        Bm = q.LB + c.coff;
-        bplane = q.xlen * (long)N;
-        ldb = (int)q.xlen;
+        mw_factor_body<K>(q, c, j, q.S + c.Soff, q.Slen, bc, tid);       // too large for LDS: in place in global memory
     }
-    // B_j (fp64) -> multi-word
-    for (int e = tid; e < P * N; e += MW_NT) {
-        const int i = e % P, cc = e / P;
-#pragma unroll
-        for (int l = 0; l < K; l++) Bm[(long)l * bplane + i + (long)cc * ldb] = l < DK ? q.B[(long)l * q.Bp + c.coff + i + (long)cc * q.xlen] : 0.0;
-    }
-    __syncthreads();
-    const bool ok = wg_potrf<K>(M, mplane, P, P, q.srd + c.coff, q.xlen, tid);
-    if (!ok) {
-        if (tid == 0) atomicMin(&q.info[0], j + 1);
-        return;
-    }
-    if (N > 0) wg_trsm_lower<K>(M, mplane, P, q.srd + c.coff, q.xlen, P, Bm, bplane, ldb, N, tid);
-    __syncthreads();
-    // L_j back to the S buffer with a zero strict upper triangle; LinvB to the stacked buffer
-    for (int e = tid; e < P * P; e += MW_NT) {
-        const int i = e % P, cc = e / P;
-#pragma unroll
-        for (int l = 0; l < K; l++) Sg[(long)l * q.Slen + e] = (i >= cc) ? M[(long)l * mplane + e] : 0.0;
-    }
-    if (c.lds) wg_copy<K>(q.LB + c.coff, q.xlen * (long)N, (int)q.xlen, Bm, bplane, ldb, P, N, tid);
 }
 
-// Q = sum_j LinvB_j^T LinvB_j = LB^T LB over the stacked rows (src/solver.jl:1264-1271): one thread per entry a >= b
+// LinvB_j = L_j^-1 B_j (src/solver.jl:1256-1261): the columns of B_j are independent, one workgroup per tile of MW_BT of them
+#define MW_BT 8
+template <int K, int DK>
+__global__ __launch_bounds__(MW_NT) void k_mw_linvb(const MwDev q) {
+    using namespace mwk;
+    const int j = blockIdx.y, tid = threadIdx.x;
+    const MwClu &c = q.clu[j];
+    const int P = c.P, N = q.N;
+    const int a0 = blockIdx.x * MW_BT;
+    if (a0 >= N) return;
+    if (q.info[0] != MW_INFO_NONE && q.info[0] <= j + 1) return;        // this cluster (or an earlier one) failed
+    const int nc = min(MW_BT, N - a0);
+    lds_d *Bt = MW_LDS;                                   // P x MW_BT tile
+    const long bp = (long)P * MW_BT;
+    for (int e = tid; e < P * nc; e += MW_NT) {            // B_j (DK limbs) -> multi-word
+        const int i = e % P, cc = e / P;
+#pragma unroll
+        for (int l = 0; l < K; l++) Bt[(long)l * bp + e] = l < DK ? q.B[(long)l * q.Bp + c.coff + i + (long)(a0 + cc) * q.xlen] : 0.0;
+    }
+    if (c.lds) {
+        lds_d *F = MW_LDS + (long)K * bp;
+        wg_copy<K>(F, (long)P * P, P, q.Sf + c.Soff, q.Slen, P, P, P, tid);
+        __syncthreads();
+        wg_trsm_f<K>(F, (long)P * P, P, q.srd + c.coff, q.xlen, P, Bt, bp, P, nc, tid);
+    } else {
+        __syncthreads();
+        wg_trsm_f<K>(q.Sf + c.Soff, q.Slen, P, q.srd + c.coff, q.xlen, P, Bt, bp, P, nc, tid);
+    }
+    for (int e = tid; e < P * nc; e += MW_NT) {
+        const int i = e % P, cc = e / P;
+#pragma unroll
+        for (int l = 0; l < K; l++) q.LB[(long)l * q.xlen * N + c.coff + i + (long)(a0 + cc) * q.xlen] = Bt[(long)l * bp + e];
+    }
+}
+
+// Q = sum_j LinvB_j^T LinvB_j = LB^T LB over the stacked rows (src/solver.jl:1264-1271): eight lanes per entry a >= b
+#define MW_Q_W 8
 template <int K>
 __global__ __launch_bounds__(MW_NT) void k_mw_qgram(const MwDev q) {
     using namespace mwk;
     const int N = q.N;
-    const int e = blockIdx.x * MW_NT + threadIdx.x;
-    if (e >= N * (N + 1) / 2) return;
+    const int e = blockIdx.x * (MW_NT / MW_Q_W) + threadIdx.x / MW_Q_W, sub = threadIdx.x % MW_Q_W;
+    const int tot = N * (N + 1) / 2;
+    const bool live = e < tot;
     int a, b;
-    tri_index(e, a, b);
+    tri_index(live ? e : 0, a, b);
     const long plane = q.xlen * (long)N;
     acc<K> s;
     acc_zero<K>(s);
-    for (long r = 0; r < q.xlen; r++) acc_fma<K, K, K>(s, ld_<K>(q.LB, plane, r + a * q.xlen), ld_<K>(q.LB, plane, r + b * q.xlen));
-    mw<K> v = acc_result<K>(s);
-    st<K>(q.Q, (long)N * N, a + (long)b * N, v);
-    st<K>(q.Q, (long)N * N, b + (long)a * N, v);
+    for (long r = sub; r < q.xlen; r += MW_Q_W) acc_fma<K, K, K>(s, ldx<K>(q.LB, plane, r + a * q.xlen), ldx<K>(q.LB, plane, r + b * q.xlen));
+    mw<K> v = lanes_sum<K, MW_Q_W>(acc_result<K>(s));
+    if (live && sub == 0) {
+        stx<K>(q.Q, (long)N * N, a + (long)b * N, v);
+        stx<K>(q.Q, (long)N * N, b + (long)a * N, v);
+    }
 }
 
-// Cholesky of Q (src/solver.jl:1274)
+// Cholesky of Q (src/solver.jl:1274) and its scaled triangles
+template <int K, class PM>
+__device__ __forceinline__ void mw_potrf_q_body(const MwDev &q, PM M, long plane, mwk::lds_d *bc, int tid) {
+    using namespace mwk;
+    const int N = q.N;
+    const bool ok = wg_potrf<K>(M, plane, N, N, q.qrd, N, bc, tid);
+    if (!ok) {
+        if (tid == 0) atomicMin(&q.info[0], q.J + 1);
+        return;
+    }
+    wg_scaled_factors<K>(M, plane, N, q.qrd, N, N, q.Qf, (long)N * N, N, q.Qb, (long)N * N, N, tid);
+    __syncthreads();
+    for (int e = tid; e < N * N; e += MW_NT) {
+        const int i = e % N, cc = e / N;
+#pragma unroll
+        for (int l = 0; l < K; l++) q.Q[(long)l * N * N + e] = (i >= cc) ? (double)M[(long)l * plane + e] : 0.0;
+    }
+}
 template <int K>
 __global__ __launch_bounds__(MW_NT) void k_mw_potrf_q(const MwDev q, int lds) {
     using namespace mwk;
     const int N = q.N, tid = threadIdx.x;
     if (q.info[0] != MW_INFO_NONE) return;           // a cluster failed: the reference throws before reaching Q
-    double *M = q.Q;
-    long plane = (long)N * N;
+    lds_d *bc = MW_LDS;
     if (lds) {
-        M = mw_lds;
-        wg_copy<K>(M, plane, N, q.Q, plane, N, N, N, tid);
+        lds_d *M = MW_LDS + (K + 1);
+        wg_copy<K>(M, (long)N * N, N, q.Q, (long)N * N, N, N, N, tid);
         __syncthreads();
-    }
-    const bool ok = wg_potrf<K>(M, plane, N, N, q.qrd, N, tid);
-    if (!ok && tid == 0) atomicMin(&q.info[0], q.J + 1);
-    __syncthreads();
-    for (int e = tid; e < N * N; e += MW_NT) {
-        const int i = e % N, cc = e / N;
-#pragma unroll
-        for (int l = 0; l < K; l++) q.Q[(long)l * plane + e] = (i >= cc) ? M[(long)l * plane + e] : 0.0;
+        mw_potrf_q_body<K>(q, M, (long)N * N, bc, tid);
+    } else {
+        mw_potrf_q_body<K>(q, q.Q, (long)N * N, bc, tid);
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Solve stage (src/solver.jl:1527-1582), three launches: per cluster t_j = L_j^-1 rhs_x[j], u_j = LinvB_j^T t_j;
-// dy = Q^-1 (rhs_y - sum_j u_j); per cluster dx_j = L_j^-T (t_j + LinvB_j dy).
+// dy = Q^-1 (rhs_y - sum_j u_j); per cluster dx_j = L_j^-T (t_j + LinvB_j dy).  Substitutions with the scaled factors
+// (one multiply-add and one barrier per unknown), dot products over eight lanes.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int K>
-__global__ __launch_bounds__(MW_NT) void k_mw_solve_fwd(const MwDev q, const double *__restrict__ rhs_x) {
+#define MW_S_W 8
+template <int K, class PF>
+__device__ __forceinline__ void mw_solve_fwd_body(const MwDev &q, const MwClu &c, int j, PF F, long fplane, mwk::lds_d *tv, int tid) {
     using namespace mwk;
-    const int j = blockIdx.x, tid = threadIdx.x;
-    const MwClu &c = q.clu[j];
     const int P = c.P, N = q.N;
-    const double *L = q.S + c.Soff;
-    long lplane = q.Slen;
-    double *tv = mw_lds;                     // t: P numbers, planar with plane P
-    if (c.lds) {
-        double *Ls = mw_lds + (long)K * P;
-        wg_copy<K>(Ls, (long)P * P, P, q.S + c.Soff, q.Slen, P, P, P, tid);
-        L = Ls;
-        lplane = (long)P * P;
-    }
-    for (int i = tid; i < P; i += MW_NT) {
-#pragma unroll
-        for (int l = 0; l < K; l++) tv[(long)l * P + i] = rhs_x[(long)l * q.xlen + c.coff + i];
-    }
-    __syncthreads();
-    wg_trsm_lower<K>(L, lplane, P, q.srd + c.coff, q.xlen, P, tv, P, P, 1, tid);
+    wg_trsm_f<K>(F, fplane, P, q.srd + c.coff, q.xlen, P, tv, P, P, 1, tid);
     for (int i = tid; i < P; i += MW_NT) {
 #pragma unroll
         for (int l = 0; l < K; l++) q.t[(long)l * q.xlen + c.coff + i] = tv[(long)l * P + i];
     }
     const long plane = q.xlen * (long)N;
-    for (int a = tid; a < N; a += MW_NT) {
+    const int sub = tid % MW_S_W;
+    for (int a0 = 0; a0 < N; a0 += MW_NT / MW_S_W) {
+        const int a = a0 + tid / MW_S_W;
+        const bool live = a < N;
+        const int aa = live ? a : 0;
         acc<K> s;
         acc_zero<K>(s);
-        for (int r = 0; r < P; r++) acc_fma<K, K, K>(s, ld_<K>(q.LB, plane, c.coff + r + a * q.xlen), ld_<K>(tv, P, r));
-        st<K>(q.u, (long)q.J * N, (long)j * N + a, acc_result<K>(s));
+        for (int r = sub; r < P; r += MW_S_W) acc_fma<K, K, K>(s, ldx<K>(q.LB, plane, c.coff + r + aa * q.xlen), ldx<K>(tv, P, r));
+        mw<K> v = lanes_sum<K, MW_S_W>(acc_result<K>(s));
+        if (live && sub == 0) stx<K>(q.u, (long)q.J * N, (long)j * N + a, v);
+    }
+}
+template <int K>
+__global__ __launch_bounds__(MW_NT) void k_mw_solve_fwd(const MwDev q, const double *__restrict__ rhs_x) {
+    using namespace mwk;
+    const int j = blockIdx.x, tid = threadIdx.x;
+    const MwClu &c = q.clu[j];
+    const int P = c.P;
+    lds_d *tv = MW_LDS;                       // t: P numbers, planar with plane P
+    for (int i = tid; i < P; i += MW_NT) {
+#pragma unroll
+        for (int l = 0; l < K; l++) tv[(long)l * P + i] = rhs_x[(long)l * q.xlen + c.coff + i];
+    }
+    if (c.lds) {
+        lds_d *Ls = MW_LDS + (long)K * P;
+        wg_copy<K>(Ls, (long)P * P, P, q.Sf + c.Soff, q.Slen, P, P, P, tid);
+        __syncthreads();
+        mw_solve_fwd_body<K>(q, c, j, Ls, (long)P * P, tv, tid);
+    } else {
+        __syncthreads();
+        mw_solve_fwd_body<K>(q, c, j, q.Sf + c.Soff, q.Slen, tv, tid);
     }
 }
 
@@ -519,24 +656,27 @@ template <int K>
 __global__ __launch_bounds__(MW_NT) void k_mw_solve_mid(const MwDev q, const double *__restrict__ rhs_y, double *__restrict__ dy, int lds) {
     using namespace mwk;
     const int N = q.N, tid = threadIdx.x;
-    double *v = mw_lds;                      // N numbers, plane N
-    const double *L = q.Q;
-    long lplane = (long)N * N;
-    if (lds) {
-        double *Ls = mw_lds + (long)K * N;
-        wg_copy<K>(Ls, lplane, N, q.Q, lplane, N, N, N, tid);
-        L = Ls;
-    }
+    lds_d *v = MW_LDS;                        // N numbers, plane N
+    const long lplane = (long)N * N;
     for (int a = tid; a < N; a += MW_NT) {
         acc<K> s;
         acc_zero<K>(s);
-        acc_add<K, K>(s, ld_<K>(rhs_y, N, a));
-        for (int j = 0; j < q.J; j++) acc_add<K, K>(s, ld_<K>(q.u, (long)q.J * N, (long)j * N + a), -1.0);
-        st<K>(v, N, a, acc_result<K>(s));
+        acc_add<K, K>(s, ldx<K>(rhs_y, N, a));
+        for (int j = 0; j < q.J; j++) acc_add<K, K>(s, ldx<K>(q.u, (long)q.J * N, (long)j * N + a), -1.0);
+        stx<K>(v, N, a, acc_result<K>(s));
     }
-    __syncthreads();
-    wg_trsm_lower<K>(L, lplane, N, q.qrd, N, N, v, N, N, 1, tid);
-    wg_trsm_lower_t<K>(L, lplane, N, q.qrd, N, N, v, N, N, 1, tid);
+    if (lds) {
+        lds_d *Lf = MW_LDS + (long)K * N, *Lb = Lf + (long)K * lplane;
+        wg_copy<K>(Lf, lplane, N, q.Qf, lplane, N, N, N, tid);
+        wg_copy<K>(Lb, lplane, N, q.Qb, lplane, N, N, N, tid);
+        __syncthreads();
+        wg_trsm_f<K>(Lf, lplane, N, q.qrd, N, N, v, N, N, 1, tid);
+        wg_trsm_b<K>(Lb, lplane, N, q.qrd, N, N, v, N, N, 1, tid);
+    } else {
+        __syncthreads();
+        wg_trsm_f<K>(q.Qf, lplane, N, q.qrd, N, N, v, N, N, 1, tid);
+        wg_trsm_b<K>(q.Qb, lplane, N, q.qrd, N, N, v, N, N, 1, tid);
+    }
     for (int a = tid; a < N; a += MW_NT) {
 #pragma unroll
         for (int l = 0; l < K; l++) dy[(long)l * N + a] = v[(long)l * N + a];
@@ -549,25 +689,29 @@ __global__ __launch_bounds__(MW_NT) void k_mw_solve_bwd(const MwDev q, const dou
     const int j = blockIdx.x, tid = threadIdx.x;
     const MwClu &c = q.clu[j];
     const int P = c.P, N = q.N;
-    const double *L = q.S + c.Soff;
-    long lplane = q.Slen;
-    double *w = mw_lds;
-    if (c.lds) {
-        double *Ls = mw_lds + (long)K * P;
-        wg_copy<K>(Ls, (long)P * P, P, q.S + c.Soff, q.Slen, P, P, P, tid);
-        L = Ls;
-        lplane = (long)P * P;
-    }
+    lds_d *w = MW_LDS;
     const long plane = q.xlen * (long)N;
-    for (int r = tid; r < P; r += MW_NT) {
+    const int sub = tid % MW_S_W;
+    for (int r0 = 0; r0 < P; r0 += MW_NT / MW_S_W) {
+        const int r = r0 + tid / MW_S_W;
+        const bool live = r < P;
+        const int rr = live ? r : 0;
         acc<K> s;
         acc_zero<K>(s);
-        acc_add<K, K>(s, ld_<K>(q.t, q.xlen, c.coff + r));
-        for (int a = 0; a < N; a++) acc_fma<K, K, K>(s, ld_<K>(q.LB, plane, c.coff + r + a * q.xlen), ld_<K>(dy, N, a));
-        st<K>(w, P, r, acc_result<K>(s));
+        if (sub == 0) acc_add<K, K>(s, ldx<K>(q.t, q.xlen, c.coff + rr));
+        for (int a = sub; a < N; a += MW_S_W) acc_fma<K, K, K>(s, ldx<K>(q.LB, plane, c.coff + rr + a * q.xlen), ldx<K>(dy, N, a));
+        mw<K> v = lanes_sum<K, MW_S_W>(acc_result<K>(s));
+        if (live && sub == 0) stx<K>(w, P, r, v);
     }
-    __syncthreads();
-    wg_trsm_lower_t<K>(L, lplane, P, q.srd + c.coff, q.xlen, P, w, P, P, 1, tid);
+    if (c.lds) {
+        lds_d *Ls = MW_LDS + (long)K * P;
+        wg_copy<K>(Ls, (long)P * P, P, q.Sb + c.Soff, q.Slen, P, P, P, tid);
+        __syncthreads();
+        wg_trsm_b<K>(Ls, (long)P * P, P, q.srd + c.coff, q.xlen, P, w, P, P, 1, tid);
+    } else {
+        __syncthreads();
+        wg_trsm_b<K>(q.Sb + c.Soff, q.Slen, P, q.srd + c.coff, q.xlen, P, w, P, P, 1, tid);
+    }
     for (int i = tid; i < P; i += MW_NT) {
 #pragma unroll
         for (int l = 0; l < K; l++) dx[(long)l * q.xlen + c.coff + i] = w[(long)l * P + i];
