@@ -40,7 +40,7 @@ struct IBlock {
 // scalars living in device memory (index into IpmBuf::scal)
 enum {
     SC_MU = 0, SC_MU_P, SC_MU_C, SC_BETA_C, SC_ALPHA_P, SC_ALPHA_D, SC_DOBJ, SC_POBJ, SC_GAP, SC_DUAL_ERR, SC_PRIMAL_ERR,
-    SC_PD_FEAS, SC_XY, SC_MAXP, SC_MAXp, SC_MAXd, SC_EIG_X, SC_EIG_Y, SC_ERRCODE, SC_K, SC_ITER,
+    SC_PD_FEAS, SC_XY, SC_MAXP, SC_MAXp, SC_MAXd, SC_EIG_X, SC_EIG_Y, SC_ERRCODE, SC_K, SC_ITER, SC_PD_PREV,
     SC_INFO0 = 30, SC_INFO1 = 31,      // the library's two status words (factorisation, Cholesky of X), copied here for the host's single read
     SC_COUNT = 32
 };
@@ -352,6 +352,7 @@ __device__ __forceinline__ void ipm_scalar_stage(const IpmBuf &q, const IpmParam
         s[SC_XY] = xy;
         s[SC_MU] = xy / prm.K;
         s[SC_MU_P] = (s[SC_PD_FEAS] != 0.0) ? 0.0 : prm.beta_infeasible * s[SC_MU];
+        s[SC_PD_PREV] = s[SC_PD_FEAS];      // the feasibility the previous iteration found: beta_c is chosen with it (src/solver.jl:429-434 precede :441-447)
         if (s[SC_MU] > prm.max_complementary_gap) s[SC_ERRCODE] = 3.0;
     } else if (stage == 1) {
         double mP = 0.0, md = 0.0, mp = 0.0;
@@ -366,9 +367,12 @@ __device__ __forceinline__ void ipm_scalar_stage(const IpmBuf &q, const IpmParam
         for (int b = 0; b < q.NB; b++) { a += q.part[b * 8 + 2]; bb += q.part[b * 8 + 3]; c += q.part[b * 8 + 4]; }
         const double r = (s[SC_XY] + a + bb + c) / (s[SC_MU] * prm.K);
         const double beta = (r < 1.0) ? r * r : r;
+        // beta_c with the feasibility of the PREVIOUS iteration (kept by stage 0: this stage may run once per workgroup and all of
+        // them must read the same value), only then the new feasibility -- the order of the reference
+        const bool was_feas = s[SC_PD_PREV] != 0.0;
+        s[SC_BETA_C] = was_feas ? fmin(fmax(prm.beta_feasible, beta), 1.0) : fmax(prm.beta_infeasible, beta);
         const bool feas = s[SC_DUAL_ERR] < prm.dual_error_threshold && s[SC_PRIMAL_ERR] < prm.primal_error_threshold;
         s[SC_PD_FEAS] = feas ? 1.0 : 0.0;
-        s[SC_BETA_C] = feas ? fmin(fmax(prm.beta_feasible, beta), 1.0) : fmax(prm.beta_infeasible, beta);
         s[SC_MU_C] = s[SC_BETA_C] * s[SC_MU];
     } else if (stage == 3) {
         double ex = 1e300, ey = 1e300;

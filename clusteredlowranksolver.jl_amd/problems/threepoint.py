@@ -74,10 +74,20 @@ def three_point_spherical_codes(n, costheta, d2, d3, seed=1935, prec=DEFAULT_PRE
         for attempt in range(50):
             pick = sorted(rng.permutation(len(grid))[:n3])
             s3 = sorted([tuple(_floor4(x) for x in grid[i]) for i in pick])
-            E = np.array([[float((u + v + t) ** (deg - 3 * k - 2 * j) * (u * v + v * t + u * t) ** j * (u * v * t) ** k) for (deg, k, j) in inv]
-                          for (u, v, t) in s3])
+            Em = [[(u + v + t) ** (deg - 3 * k - 2 * j) * (u * v + v * t + u * t) ** j * (u * v * t) ** k for (deg, k, j) in inv] for (u, v, t) in s3]
+            E = np.array([[float(x) for x in row] for row in Em])
             if np.linalg.cond(E) < 1e13:      # unisolvent for the invariant polynomials of degree <= 2 N3
                 break
+            if n3 > 60:
+                # the invariant monomials are too ill-conditioned for an fp64 test at this degree: unisolvence is decided by an LU
+                # decomposition at the working precision (the reference takes the shuffled subset unchecked, examples/ThreePointBound.jl:101-105)
+                try:
+                    LU, _ = mp.mp.LU_decomp(mp.matrix(Em))
+                    piv = [abs(LU[i, i]) for i in range(n3)]
+                    if min(piv) > mp.mpf(2) ** (-prec // 2) * max(piv):
+                        break
+                except ZeroDivisionError:
+                    pass
         else:
             raise RuntimeError("no unisolvent sample subset found")
         P = n1 + n3

@@ -76,6 +76,10 @@ class HipLocal:
         self.device = device
         torch.cuda.set_device(device)
         self.ctx = SchurContext(shard, device=device)
+        if graph and torch.cuda.current_stream().cuda_stream == 0:
+            # the legacy (null) stream cannot be captured: hipStreamBeginCapture fails on it
+            raise ValueError("HipLocal(graph=True) needs a non-default current stream: wrap the calls in "
+                             "`with torch.cuda.stream(torch.cuda.Stream()):` or call torch.cuda.set_stream first")
         self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
         if graph:
             self.ctx.set_graph_mode(True)

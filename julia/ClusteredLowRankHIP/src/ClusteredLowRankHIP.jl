@@ -7,9 +7,14 @@
 #     compute_T_decomposition!(sdp, S, A_Y, X_inv, Y, ..., cs_map; prec)        (src/solver.jl:1229-1287)
 #     the "solve system" stage of compute_search_direction!                     (src/solver.jl:1527-1582)
 #
-# Host orchestration stays in Julia (Arb); at the boundary the iterates are rounded to Float64 column-major
-# arrays (`Float64.(...)`), the results come back as Float64 and are written into the caller's Arb buffers.
-# This file cannot be executed in the build container (no Julia there); INTEGRATION.md is the contract.
+# Host orchestration stays in Julia (Arb).  The device computes in multi-word fp64: a number is `limbs` doubles
+# (limbs = 5 covers the reference's default prec = 256; include/clrs_hip.h, clrs_mw_*), an array is PLANAR,
+# limb l of element i at [l * len + i].  At the boundary every Arb midpoint is split into its limbs (`limbs_of`),
+# results come back as limbs and are summed into the caller's Arb buffers (`arb_of`); the problem data cross the
+# boundary as 2 limbs (double-double).  `limbs = 1` selects the plain fp64 entry points (clrs_*), which cannot factor
+# the 2d = 30 sphere-packing problems (DESIGN.md section 2).
+# This file cannot be executed in the build container (no Julia there); INTEGRATION.md is the contract and
+# tests/test_abi_cpu.py checks the struct below against include/clrs_hip.h.
 module ClusteredLowRankHIP
 
 using Libdl
@@ -45,13 +50,17 @@ struct SdpDesc
     dense_A::Ptr{Float64}
 end
 
+const DATA_LIMBS = 2
+
 """Device context + the host arrays that back the description (kept alive for the lifetime of the context)."""
 mutable struct HipContext
     handle::Ptr{Cvoid}
+    limbs::Int                  # 1: fp64 entry points (clrs_*); 2..5: multi-word entry points (clrs_mw_*)
     keep::Vector{Any}
     block_off::Vector{Int}      # offsets of the blocks (j,l) in the xy layout
     block_n::Vector{Int}
     jl::Vector{Tuple{Int,Int}}  # (j,l) of every block in description order
+    cluster_P::Vector{Int}
     cluster_off::Vector{Int}
     S_off::Vector{Int}
     term_map::Vector{NTuple{5,Int}}   # (j,l,r,s,idx-in-A_Y[j][l][r,s]) of every term, in term order
@@ -63,25 +72,51 @@ check(code::Integer) = code < 0 ? error("clrs-hip: " * unsafe_string(ccall((:clr
 
 f64(x) = Float64(Arblib.midref(x))
 
+"""Limbs of the midpoint of `x`: successive roundings to Float64 (the subtraction is exact at the working precision)."""
+function limbs_of!(out::AbstractMatrix{Float64}, i::Int, x, K::Int)
+    r = Arb(x; prec=max(precision(x), 64 * K + 64))
+    Arblib.get_mid!(r, r)
+    for l in 1:K
+        h = Float64(Arblib.midref(r))
+        out[i, l] = h                      # column l of a (len x K) Julia matrix = limb plane l of the planar C array
+        h == 0 && break
+        Arblib.sub!(r, r, Arb(h; prec=precision(r)))
+    end
+    return out
+end
+
+"""Sum of the limbs of element `i` of a planar array as an Arb midpoint at precision `prec`."""
+function arb_of(a::AbstractMatrix{Float64}, i::Int, prec::Int)
+    r = Arb(0; prec=max(prec, 64 * size(a, 2) + 64))
+    for l in size(a, 2):-1:1
+        Arblib.add!(r, r, Arb(a[i, l]; prec=precision(r)))
+    end
+    out = Arb(r; prec)
+    Arblib.get_mid!(out, out)
+    return out
+end
+
 """
-    HipContext(sdp, cs_map; device=0)
+    HipContext(sdp, cs_map; device=0, limbs=5)
 
 Replaces `precompute_matrices_bilinear_pairings` (src/solver.jl:985-1059) and the preallocation block
 (src/solver.jl:298-317): flattens `sdp.A[j][l][r,s][p]` (cluster-local constraint indices through `cs_map[j]`,
-0-based) and `sdp.B[j]` into `clrs_sdp_desc` and creates the device context.
+0-based) and `sdp.B[j]` into `clrs_sdp_desc` and creates the device context.  `limbs = limbs_for(prec)`.
 """
-function HipContext(sdp::CLRS.ClusteredLowRankSDP, cs_map; device::Integer=0)
+function HipContext(sdp::CLRS.ClusteredLowRankSDP, cs_map; device::Integer=0, limbs::Integer=5)
     J = length(sdp.A)
+    DL = limbs == 1 ? 1 : DATA_LIMBS
     cluster_P = Int32[size(sdp.c[j], 1) for j in 1:J]
     N = size(sdp.B[1], 2)
-    Bflat = Float64[]
+    # data arrays are collected as Arb and split into DL limb planes at the end
+    Bv = Any[]
     for j in 1:J, k in 1:N, p in 1:cluster_P[j]
-        push!(Bflat, f64(sdp.B[j][p, k]))
+        push!(Bv, sdp.B[j][p, k])
     end
     bc = Int32[]; bm = Int32[]; bd = Int32[]; bk = Int32[]
-    term_ptr = Int64[0]; tp = Int32[]; tr = Int32[]; ts = Int32[]; tk = Int32[]; tl = Float64[]
-    tvp = Int64[0]; tvs = Float64[]; tws = Float64[]
-    dense_ptr = Int64[0]; dp = Int32[]; dAp = Int64[0]; dA = Float64[]
+    term_ptr = Int64[0]; tp = Int32[]; tr = Int32[]; ts = Int32[]; tk = Int32[]; tl = Any[]
+    tvp = Int64[0]; tvs = Any[]; tws = Any[]
+    dense_ptr = Int64[0]; dp = Int32[]; dAp = Int64[0]; dA = Any[]
     jl = Tuple{Int,Int}[]; block_n = Int[]; term_map = NTuple{5,Int}[]
     for j in 1:J, l in 1:length(sdp.A[j])
         Ajl = sdp.A[j][l]
@@ -94,7 +129,7 @@ function HipContext(sdp::CLRS.ClusteredLowRankSDP, cs_map; device::Integer=0)
                 M = Ajl[1, 1][p]
                 delta = size(M, 1)
                 push!(dp, cs_map[j][p] - 1)
-                append!(dA, [f64(M[a, b]) for b in 1:delta for a in 1:delta])
+                append!(dA, [M[a, b] for b in 1:delta for a in 1:delta])
                 push!(dAp, length(dA))
             end
             m = 1
@@ -105,85 +140,147 @@ function HipContext(sdp::CLRS.ClusteredLowRankSDP, cs_map; device::Integer=0)
             end
             sort!(items)
             inv_cs = Dict(v => k for (k, v) in cs_map[j])
+            # position of a term's pairing in A_Y[j][l][r,s] (src/solver.jl:1152-1170): A_Y is filled in the order
+            # `for p in keys(A[r,s]) for rnk`, so the index is the rank of (p, rnk) in that iteration order
+            ay_pos = Dict{NTuple{4,Int},Int}()
+            for r in 1:m, s in 1:m
+                idx = 0
+                for p in keys(Ajl[r, s]), k in 1:length(Ajl[r, s][p].lambda)
+                    idx += 1
+                    ay_pos[(r, s, cs_map[j][p], k)] = idx
+                end
+            end
             for (p0, r0, s0, k0) in items
                 A = Ajl[r0+1, s0+1][inv_cs[p0+1]]
                 delta = length(A.vs[k0+1])
-                push!(tp, p0); push!(tr, r0); push!(ts, s0); push!(tk, k0); push!(tl, f64(A.lambda[k0+1]))
-                append!(tvs, f64.(A.vs[k0+1])); append!(tws, f64.(A.ws[k0+1]))     # Matrix(::LowRankMat) = sum lam * vs * ws' (src/interface.jl:798-800)
+                push!(tp, p0); push!(tr, r0); push!(ts, s0); push!(tk, k0); push!(tl, A.lambda[k0+1])
+                append!(tvs, A.vs[k0+1]); append!(tws, A.ws[k0+1])     # Matrix(::LowRankMat) = sum lam * vs * ws' (src/interface.jl:798-800)
                 push!(tvp, length(tvs))
-                # position of this term's pairing in A_Y[j][l][r,s] (src/solver.jl:1152-1170): running index per (r,s)
-                push!(term_map, (j, l, r0 + 1, s0 + 1, count(t -> t[1] == j && t[2] == l && t[3] == r0 + 1 && t[4] == s0 + 1, term_map) + 1))
+                push!(term_map, (j, l, r0 + 1, s0 + 1, ay_pos[(r0 + 1, s0 + 1, p0 + 1, k0 + 1)]))
             end
         end
         push!(bm, m); push!(bd, delta); push!(block_n, m * delta)
         push!(term_ptr, length(tp)); push!(dense_ptr, length(dp))
     end
-    keep = Any[cluster_P, Bflat, bc, bm, bd, bk, term_ptr, tp, tr, ts, tk, tl, tvp, tvs, tws, dense_ptr, dp, dAp, dA]
+    planar(v) = (a = zeros(Float64, max(length(v), 1), DL); foreach(i -> limbs_of!(a, i, v[i], DL), eachindex(v)); a)
+    Bflat, tlf, tvsf, twsf, dAf = planar(Bv), planar(tl), planar(tvs), planar(tws), planar(dA)
+    keep = Any[cluster_P, Bflat, bc, bm, bd, bk, term_ptr, tp, tr, ts, tk, tlf, tvp, tvsf, twsf, dense_ptr, dp, dAp, dAf]
     desc = Ref(SdpDesc(J, N, pointer(cluster_P), pointer(Bflat), length(bc), pointer(bc), pointer(bm), pointer(bd), pointer(bk),
-                       pointer(term_ptr), pointer(tp), pointer(tr), pointer(ts), pointer(tk), pointer(tl), pointer(tvp),
-                       pointer(tvs), pointer(tws), pointer(dense_ptr), pointer(dp), pointer(dAp), pointer(dA)))
+                       pointer(term_ptr), pointer(tp), pointer(tr), pointer(ts), pointer(tk), pointer(tlf), pointer(tvp),
+                       pointer(tvsf), pointer(twsf), pointer(dense_ptr), pointer(dp), pointer(dAp), pointer(dAf)))
     h = Ref{Ptr{Cvoid}}(C_NULL)
-    GC.@preserve keep check(ccall((:clrs_ctx_create, libclrs[]), Cint, (Ref{SdpDesc}, Cint, Ref{Ptr{Cvoid}}), desc, device, h))
-    ctx = HipContext(h[], keep, cumsum([0; block_n .^ 2]), block_n, jl, cumsum([0; Int.(cluster_P)]), cumsum([0; Int.(cluster_P) .^ 2]),
-                     term_map, N)
-    finalizer(c -> ccall((:clrs_ctx_destroy, libclrs[]), Cvoid, (Ptr{Cvoid},), c.handle), ctx)
+    GC.@preserve keep begin
+        if limbs == 1
+            check(ccall((:clrs_ctx_create, libclrs[]), Cint, (Ref{SdpDesc}, Cint, Ref{Ptr{Cvoid}}), desc, device, h))
+        else
+            check(ccall((:clrs_mw_create_ex, libclrs[]), Cint, (Ref{SdpDesc}, Cint, Cint, Cint, Ref{Ptr{Cvoid}}), desc, DL, device, limbs, h))
+        end
+    end
+    ctx = HipContext(h[], limbs, keep, cumsum([0; block_n .^ 2]), block_n, jl, Int.(cluster_P), cumsum([0; Int.(cluster_P)]),
+                     cumsum([0; Int.(cluster_P) .^ 2]), term_map, N)
+    finalizer(c -> ccall((c.limbs == 1 ? :clrs_ctx_destroy : :clrs_mw_destroy, libclrs[]), Cvoid, (Ptr{Cvoid},), c.handle), ctx)
     return ctx
 end
 
-"""Pack a BlockDiagonal of BlockDiagonals of ArbRefMatrix into the xy layout (Float64, column-major per block)."""
+"""Smallest limb count whose operations carry `prec` bits (about 53 K - K bits for K limbs)."""
+limbs_for(prec::Integer) = prec <= 53 ? 1 : prec <= 104 ? 2 : prec <= 157 ? 3 : prec <= 209 ? 4 : prec <= 262 ? 5 :
+                           error("prec = $prec needs more than 5 limbs")
+
+"""Pack a BlockDiagonal of BlockDiagonals of ArbRefMatrix into the planar xy layout (len x limbs, column-major per block)."""
 function pack_xy(ctx::HipContext, M)
-    out = Vector{Float64}(undef, ctx.block_off[end])
+    out = zeros(Float64, ctx.block_off[end], ctx.limbs)
     for (b, (j, l)) in enumerate(ctx.jl)
         blk = M.blocks[j].blocks[l]
         n = ctx.block_n[b]
-        @inbounds for c in 1:n, r in 1:n
-            out[ctx.block_off[b]+r+(c-1)*n] = f64(blk[r, c])
+        for c in 1:n, r in 1:n
+            limbs_of!(out, ctx.block_off[b] + r + (c - 1) * n, blk[r, c], ctx.limbs)
         end
     end
     return out
 end
 
+sym(ctx::HipContext, fp64::Symbol, mw::Symbol) = ctx.limbs == 1 ? fp64 : mw
+
 """
 Drop-in for `compute_T_decomposition!` (src/solver.jl:1229-1287).  Same arguments; the Arb scratch arguments
-(`bilinear_pairings_*`, `tempX`, `leftvecs`, ..., `part_r`) are accepted and ignored.  Mutates `S` (-> L_j),
-`A_Y`, `LinvB`, `Q` (-> L_Q) exactly like the reference and throws the reference's `SolverFailure`s.
+(`bilinear_pairings_*`, `tempX`, `leftvecs`, ..., `part_r`) are accepted and ignored.  Writes `A_Y`, and -- so that a caller
+who keeps the reference's own `compute_search_direction!` finds what it reads there (src/solver.jl:1537-1571) -- copies the
+factors back into `S` (-> L_j), `LinvB` and `Q` (-> L_Q).  Callers that use `solve_system!` below can pass
+`copy_factors=false` and leave the factors on the device.  Throws the reference's `SolverFailure`s.
 """
-function compute_T_decomposition!(ctx::HipContext, sdp, S, A_Y, X_inv, Y, args...; prec=precision(S[1]))
+function compute_T_decomposition!(ctx::HipContext, sdp, S, A_Y, X_inv, Y, bilinear_pairings_Y=nothing, bilinear_pairings_Xinv=nothing,
+                                  LinvB=nothing, Q=nothing, args...; prec=precision(S[1]), copy_factors::Bool=true)
+    K = ctx.limbs
     Xc, Yf = pack_xy(ctx, X_inv), pack_xy(ctx, Y)
-    Sout = Vector{Float64}(undef, ctx.S_off[end])
-    AY = Vector{Float64}(undef, length(ctx.term_map))
-    check(ccall((:clrs_set_timing, libclrs[]), Cint, (Ptr{Cvoid}, Cint), ctx.handle, 1))
-    check(ccall((:clrs_schur_assemble, libclrs[]), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
-                ctx.handle, Xc, Yf, Sout, AY))
+    T = length(ctx.term_map)
+    AY = zeros(Float64, max(T, 1), K)
+    lib = libclrs[]
+    check(ccall((sym(ctx, :clrs_set_timing, :clrs_mw_set_timing), lib), Cint, (Ptr{Cvoid}, Cint), ctx.handle, 1))
+    check(ccall((sym(ctx, :clrs_schur_assemble, :clrs_mw_schur_assemble), lib), Cint,
+                (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), ctx.handle, Xc, Yf, C_NULL, AY))
     for (t, (j, l, r, s, idx)) in enumerate(ctx.term_map)
-        A_Y[j][l][r, s][idx, 1] = Arb(AY[t]; prec)
+        A_Y[j][l][r, s][idx, 1] = arb_of(AY, t, prec)
     end
-    st = check(ccall((:clrs_schur_factor, libclrs[]), Cint, (Ptr{Cvoid},), ctx.handle))
+    st = check(ccall((sym(ctx, :clrs_schur_factor, :clrs_mw_schur_factor), lib), Cint, (Ptr{Cvoid},), ctx.handle))
     J = length(S)
     if 0 < st <= J
         throw(CLRS.SolverFailure("S was not decomposed succesfully in block $st, try again with higher precision. If this occurred in the first iteration, remove linear dependencies in the PSD part of the constraints or turn preprocessing on."))
     elseif st == J + 1
         throw(CLRS.SolverFailure("Q was not decomposed correctly. Try restarting with a higher precision. If this occurred in the first iteration, remove linear dependencies between free variables or turn preprocessing on."))
     end
-    # The factors stay on the device for the solves; copy them back only if the caller inspects S / LinvB / Q.
+    if copy_factors
+        N = ctx.n_free
+        Lf = zeros(Float64, ctx.S_off[end], K)
+        LBf = zeros(Float64, max(ctx.cluster_off[end] * N, 1), K)
+        LQf = zeros(Float64, max(N * N, 1), K)
+        check(ccall((sym(ctx, :clrs_get_factor, :clrs_mw_get_factor), lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+                    ctx.handle, Lf, N > 0 ? pointer(LBf) : C_NULL, N > 0 ? pointer(LQf) : C_NULL))
+        lb_off = 0
+        for j in 1:J
+            P = ctx.cluster_P[j]
+            for q in 1:P, p in 1:P
+                S[j][p, q] = arb_of(Lf, ctx.S_off[j] + p + (q - 1) * P, prec)
+            end
+            if LinvB !== nothing
+                for k in 1:N, p in 1:P
+                    LinvB[j][p, k] = arb_of(LBf, lb_off + p + (k - 1) * P, prec)
+                end
+            end
+            lb_off += P * N
+        end
+        if Q !== nothing
+            for b in 1:N, a in 1:N
+                Q[a, b] = arb_of(LQf, a + (b - 1) * N, prec)
+            end
+        end
+    end
     t = zeros(Float64, 6)
-    check(ccall((:clrs_get_timings, libclrs[]), Cint, (Ptr{Cvoid}, Ptr{Float64}), ctx.handle, t))
+    check(ccall((sym(ctx, :clrs_get_timings, :clrs_mw_get_timings), lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), ctx.handle, t))
     return t[1], t[2], t[3], t[4], t[5]
 end
 
 """
-Drop-in for the "solve system" stage of `compute_search_direction!` (src/solver.jl:1527-1582):
-`dx`, `dy` are overwritten; `rhs_x` is the vector `-d - <A_*, Z>` (`:1518-1523`), `rhs_y` is `p`.
+Drop-in for the "solve system" stage of `compute_search_direction!` (src/solver.jl:1527-1582): `dx` (the flat
+`ArbRefMatrix(sum P_j, 1)` of src/solver.jl:187,310) and `dy` (`N x 1`) are overwritten; `rhs_x` is the vector
+`-d - <A_*, Z>` (`:1518-1523`, length sum P_j), `rhs_y` is `p` -- both Arb column matrices.
 """
-function solve_system!(ctx::HipContext, dx, dy, rhs_x::Vector{Float64}, rhs_y::Vector{Float64}; prec=precision(dx.blocks[1]))
-    dxf = Vector{Float64}(undef, ctx.cluster_off[end]); dyf = Vector{Float64}(undef, max(ctx.n_free, 1))
-    check(ccall((:clrs_schur_solve, libclrs[]), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
-                ctx.handle, rhs_x, rhs_y, dxf, dyf))
-    for j in 1:length(dx.blocks), p in 1:size(dx.blocks[j], 1)
-        dx.blocks[j][p, 1] = Arb(dxf[ctx.cluster_off[j]+p]; prec)
+function solve_system!(ctx::HipContext, dx, dy, rhs_x, rhs_y; prec=precision(dx))
+    K, N, nx = ctx.limbs, ctx.n_free, ctx.cluster_off[end]
+    rx = zeros(Float64, nx, K); ry = zeros(Float64, max(N, 1), K)
+    for i in 1:nx
+        limbs_of!(rx, i, rhs_x[i, 1], K)
     end
-    for k in 1:ctx.n_free
-        dy[k, 1] = Arb(dyf[k]; prec)
+    for k in 1:N
+        limbs_of!(ry, k, rhs_y[k, 1], K)
+    end
+    dxf = zeros(Float64, nx, K); dyf = zeros(Float64, max(N, 1), K)
+    check(ccall((sym(ctx, :clrs_schur_solve, :clrs_mw_schur_solve), libclrs[]), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+                ctx.handle, rx, ry, dxf, dyf))
+    for i in 1:nx
+        dx[i, 1] = arb_of(dxf, i, prec)
+    end
+    for k in 1:N
+        dy[k, 1] = arb_of(dyf, k, prec)
     end
     return nothing
 end

@@ -1011,6 +1011,22 @@ int oracle_solvesdp(octx *o, const oracle_params *prm, int *iters_out, double *o
     return error_code;
 }
 
+/* one scalar operation of the oracle's arithmetic on k-limb operands (unit tests of REAL itself, tests/test_oracle_cpu.py):
+ * op 0 add, 1 sub, 2 mul, 3 div, 4 sqrt(a) */
+void oracle_real_op(int op, int k, i64 n, const double *a, const double *b, double *out) {
+    for (i64 i = 0; i < n; i++) {
+        REAL x = ldk(a, n, k, i), y = ldk(b, n, k, i), r;
+        switch (op) {
+        case 0: r = x + y; break;
+        case 1: r = x - y; break;
+        case 2: r = x * y; break;
+        case 3: r = x / y; break;
+        default: r = RSQRT(x); break;
+        }
+        stk(out, n, k, i, r);
+    }
+}
+
 #if defined(ORACLE_MP)
 int oracle_real_bits(void) { return mpx_prec_bits > 0 && mpx_prec_bits < 64 * ORACLE_MP ? mpx_prec_bits : 64 * ORACLE_MP; }
 /* working precision of every later operation (1..64*limbs bits; 0 = all limbs): the reference's `prec` */

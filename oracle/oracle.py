@@ -89,6 +89,7 @@ def _lib(quad):
         L.oracle_unique_counts.argtypes = [C.c_void_p, C.c_int, _p_i, _p_i]
         L.oracle_real_bits.restype = C.c_int
         L.oracle_set_precision_bits.argtypes = [C.c_int]
+        L.oracle_real_op.argtypes = [C.c_int, C.c_int, C.c_longlong, _p_d, _p_d, _p_d]
         L.oracle_cholesky_blocks_mw.restype = C.c_int
         L.oracle_cholesky_blocks_mw.argtypes = [C.c_void_p, C.c_int, _p_d, _p_d]
         L.oracle_schur_assemble_mw.argtypes = [C.c_void_p, C.c_int, _p_d, _p_d, _p_d, _p_d]
@@ -123,6 +124,17 @@ def _lp(a):
 
 def _c(a, dt=np.float64):
     return np.ascontiguousarray(a, dtype=dt)
+
+
+def real_op(op: str, a: np.ndarray, b: np.ndarray, mp_bits: int = MP_LIMB_BITS) -> np.ndarray:
+    """One elementwise operation ('add', 'sub', 'mul', 'div', 'sqrt') of the multi-precision oracle's arithmetic on planar k-limb
+    arrays of shape (k, n), truncated to `mp_bits` bits -- for unit tests of oracle/mpx.hpp."""
+    L = _lib("mp")
+    L.oracle_set_precision_bits(int(mp_bits))
+    a, b = _c(a), _c(b)
+    out = np.zeros_like(a)
+    L.oracle_real_op({"add": 0, "sub": 1, "mul": 2, "div": 3, "sqrt": 4}[op], a.shape[0], a.shape[1], _dp(a), _dp(b), _dp(out))
+    return out
 
 
 class Oracle:

@@ -77,3 +77,31 @@ def test_flatten_layout_is_the_abi_layout():
         assert keys == sorted(keys)
         ks = set(keys)
         assert all((p, s, r, k) in ks for (p, r, s, k) in ks)
+
+
+def test_julia_shim_struct_and_symbols_match_the_header():
+    """The Julia shim cannot run here (no Julia): at least its `SdpDesc` must list the fields of `struct clrs_sdp_desc` in the same
+    order with matching widths, and every C symbol it binds must be declared in include/clrs_hip.h."""
+    hdr = open(os.path.join(ROOT, "include", "clrs_hip.h")).read()
+    jl = open(os.path.join(ROOT, "julia", "ClusteredLowRankHIP", "src", "ClusteredLowRankHIP.jl")).read()
+    body = re.search(r"typedef struct clrs_sdp_desc \{(.*?)\} clrs_sdp_desc;", hdr, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    c_fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        m = re.match(r"(const\s+)?(int32_t|int64_t|double)\s*(\*)?\s*(\w+)$", decl)
+        assert m, decl
+        c_fields.append((m.group(4), m.group(2), bool(m.group(3))))
+    jbody = re.search(r"struct SdpDesc\n(.*?)\nend", jl, flags=re.S).group(1)
+    j_fields = []
+    for line in jbody.strip().splitlines():
+        name, typ = [t.strip() for t in line.split("::")]
+        ptr = typ.startswith("Ptr{")
+        base = typ[4:-1] if ptr else typ
+        j_fields.append((name, {"Int32": "int32_t", "Int64": "int64_t", "Float64": "double"}[base], ptr))
+    assert j_fields == c_fields
+    declared = set(header_symbols())
+    used = set(re.findall(r":(clrs_[a-zA-Z0-9_]+)", jl))
+    assert used and used <= declared, used - declared

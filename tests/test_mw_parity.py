@@ -243,3 +243,32 @@ def test_mw_loop_beta_follows_the_reference_order_across_the_feasibility_flip(or
         if it and (r.history[it, 10] == 0.1) != (r.history[it - 1, 10] == 0.1):
             flips += 1
     assert flips >= 1
+
+
+# ---- kernel-level parity on real interior-point iterates ---------------------------------------------
+@pytest.mark.parametrize("K", [4, 5])
+def test_mw_path_on_the_trajectory_fixture(K):
+    """tests/golden/ce_8_15_traj.npz: (X, Y, rhs) at iterations 1, 2, K/2, K-1 of the mpmath restatement of the whole loop on
+    cohnelkies(8,15) (mu from 1e20 down to 2e-16), with S from the dense trace formula and (dx, dy) from an LU solve of the KKT matrix
+    at 456 bits -- an answer that shares neither arithmetic nor algorithm with the HIP path.
+    Tolerances: S carries cond(X) of the iterate, (dx, dy) carry cond(S) (up to ~1e37 on this problem, which is why it needs
+    the precision it needs): 2^-(53 K - slack) with the slack stated per quantity."""
+    import os
+    from clrs_amd.mw import MwSchurContext
+    f = flat("ce_8_15")
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ce_8_15_traj.npz"))
+    ctx = MwSchurContext(f, limbs=K)
+    worst = {}
+    for s, it in enumerate(g["iters"]):
+        X, Y = np.ascontiguousarray(g["X"][s][:K]), np.ascontiguousarray(g["Y"][s][:K])
+        Xc = ctx.cholesky_blocks(X)
+        S, _ = ctx.compute_S_integrated(Xc, Y)
+        eS = mw_relerr(S, g["S"][s])
+        assert ctx.factor() == 0, it
+        dx, dy = ctx.solve(np.ascontiguousarray(g["rhs_x"][s][:K]), np.ascontiguousarray(g["rhs_y"][s][:K]))
+        edx, edy = mw_relerr(dx, g["dx"][s]), mw_relerr(dy, g["dy"][s])
+        worst[int(it)] = (np.log2(eS), np.log2(max(edx, 1e-300)), np.log2(max(edy, 1e-300)))
+        assert eS <= 2.0 ** -(53 * K - 45), (it, worst)
+        assert edx <= 2.0 ** -(53 * K - 140) and edy <= 2.0 ** -(53 * K - 140), (it, worst)
+    print("log2 relative errors (S, dx, dy) per iteration:", worst)
+    ctx.close()

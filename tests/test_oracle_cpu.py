@@ -226,3 +226,126 @@ def test_sdp_variant_helpers_against_the_oracle(oracle_built):
     for k in range(3):
         Sk, _ = o.schur_assemble(Xcb[k * f.xy_len:(k + 1) * f.xy_len], Yb[k * f.xy_len:(k + 1) * f.xy_len])
         assert np.array_equal(Sb[k * f.S_len:(k + 1) * f.S_len], Sk)
+
+
+# ---- the multi-precision oracle (oracle/mpx.hpp): the stand-in for the reference's Arb arithmetic --------------------------
+PI4_384 = 0.25366950790104804          # pi^4 / 384 (test/runtests_solver.jl:19-22)
+
+
+def _limbs(vals, K):
+    import mpmath as mp
+    out = np.zeros((K, len(vals)))
+    for i, v in enumerate(vals):
+        r = mp.mpf(v)
+        for l in range(K):
+            h = float(r); out[l, i] = h; r -= mp.mpf(h)
+    return out
+
+
+def _vals(a):
+    import mpmath as mp
+    return [mp.fsum(mp.mpf(float(a[l, i])) for l in range(a.shape[0])) for i in range(a.shape[1])]
+
+
+@pytest.mark.parametrize("bits", [128, 256, 320])
+def test_mpx_arithmetic_against_mpmath(bits, oracle_built):
+    """add / sub / mul / div / sqrt of oracle/mpx.hpp, truncated to `bits` bits: within 2 units of 2^-bits of the exact result
+    (truncation, like Arb's approx_* functions), including near-cancelling subtractions."""
+    import mpmath as mp
+    from oracle.oracle import real_op
+    mp.mp.prec = 1200
+    rng = np.random.default_rng(bits)
+    K, n = 7, 200
+    av, bv = [], []
+    for i in range(n):
+        a = mp.fsum(mp.mpf(float(rng.standard_normal())) * mp.mpf(2) ** (int(rng.integers(-30, 30)) - 50 * l) for l in range(K))
+        b = mp.fsum(mp.mpf(float(rng.standard_normal())) * mp.mpf(2) ** (int(rng.integers(-30, 30)) - 50 * l) for l in range(K))
+        if i % 5 == 0:
+            b = a * (1 + mp.mpf(2) ** -int(rng.integers(20, bits - 20)))
+        av.append(a); bv.append(b)
+    A, B = _limbs(av, K), _limbs(bv, K)
+    # the oracle reads the limbs exactly when they fit: keep operands of at most `bits` bits
+    def trunc(vals):
+        out = []
+        for v in vals:
+            m, e = mp.frexp(v)
+            out.append(mp.ldexp(mp.floor(abs(m) * mp.mpf(2) ** bits), e - bits) * (1 if v >= 0 else -1))
+        return out
+    av, bv = trunc(_vals(A)), trunc(_vals(B))
+    A, B = _limbs(av, K), _limbs(bv, K)
+    unit = mp.mpf(2) ** -bits
+    for op, ex in (("add", [x + y for x, y in zip(av, bv)]), ("sub", [x - y for x, y in zip(av, bv)]), ("mul", [x * y for x, y in zip(av, bv)]),
+                   ("div", [x / y for x, y in zip(av, bv)]), ("sqrt", [mp.sqrt(abs(x)) for x in av])):
+        a_in = _limbs([abs(x) for x in av], K) if op == "sqrt" else A
+        got = _vals(real_op(op, a_in, B, mp_bits=bits))
+        for g, e, x, y in zip(got, ex, av, bv):
+            scale = abs(e) if op not in ("add", "sub") else max(abs(x), abs(y))
+            assert abs(g - e) <= 2.5 * unit * scale, (op, float(abs(g - e) / scale / unit))
+
+
+def test_mp_oracle_reproduces_the_reference_pinned_objective_of_the_north_star_config(oracle_built):
+    """cohnelkies(8,15) at 256 bits with the reference's default options: test/runtests_solver.jl:19-20 pins pi^4/384 +- 1e-4."""
+    from oracle.oracle import Oracle
+    r = Oracle(flat("ce_8_15"), mp_bits=256).solvesdp()
+    assert r["error_code"] == 0 and r["pd_feas"]
+    assert abs(r["p_obj"] - PI4_384) <= 1e-4 and abs(r["d_obj"] - PI4_384) <= 1e-4
+    assert r["gap"] < 1e-15 and r["dual_error"] < 1e-30 and r["primal_error"] < 1e-30
+    assert 50 <= r["iterations"] <= 62
+
+
+def test_precision_sweep_of_the_north_star_config(oracle_built):
+    """What working precision this problem needs: 106 and 113 bits lose positive definiteness of S at once,
+    160 bits reach the pinned objective but not feasibility, 212 bits reach gap 1e-12, 256 bits the reference's default thresholds."""
+    from oracle.oracle import Oracle
+    f = flat("ce_8_15")
+    for bits in (106, 113):
+        r = Oracle(f, mp_bits=bits).solvesdp()
+        assert r["error_code"] == 1 and r["iterations"] <= 2
+    r = Oracle(f, mp_bits=160).solvesdp()
+    assert abs(r["p_obj"] - PI4_384) <= 1e-4 and r["error_code"] == 1          # SolverFailure later on: current iterate returned
+    r = Oracle(f, mp_bits=212).solvesdp(dual_error_threshold=1e-25, primal_error_threshold=1e-25, duality_gap_threshold=1e-12)
+    assert r["error_code"] == 0 and abs(r["p_obj"] - PI4_384) <= 1e-4
+
+
+def test_fp64_rounded_data_is_a_different_problem(oracle_built):
+    """The same SDP with B, c, vectors rounded to fp64 diverges (mu too large, code 3): the problem data need more than fp64 too."""
+    from oracle.oracle import Oracle
+    r = Oracle(flat("ce_8_15"), mp_bits=256, use_lo=False).solvesdp()
+    assert r["error_code"] == 3
+
+
+def test_mp_oracle_loop_follows_the_independent_mpmath_loop(oracle_built):
+    """tests/golden/ce_8_15_ipm.npz: the whole interior-point loop restated in mpmath (dense trace formula, LU of the KKT matrix)
+    at 256 bits.  The oracle (bilinear pairings, block Cholesky, its own arithmetic) takes the same number of iterations to the same
+    objective and follows its mu / step-length trace (the step lengths go through an fp64 eigenvalue in both: 1e-6)."""
+    from oracle.oracle import Oracle
+    g = np.load(os.path.join(GOLD, "ce_8_15_ipm.npz"))
+    r = Oracle(flat("ce_8_15"), mp_bits=256).solvesdp()
+    assert r["iterations"] == int(g["iterations"][0])
+    assert abs(r["p_obj"] - float(np.sum(g["p_obj"]))) <= 1e-13 and abs(r["d_obj"] - float(np.sum(g["d_obj"]))) <= 1e-13
+    assert abs(float(np.sum(g["p_obj"])) - PI4_384) <= 1e-4
+    h, hg = r["hist"], g["hist"]
+    for it in range(min(len(h), len(hg))):
+        assert abs(h[it, 1] - hg[it, 1]) <= 1e-6 * hg[it, 1], (it, h[it, 1], hg[it, 1])                 # mu
+        assert abs(h[it, 8] - hg[it, 8]) <= 1e-6 and abs(h[it, 9] - hg[it, 9]) <= 1e-6, it             # alpha_d, alpha_p
+
+
+def test_mp_oracle_on_the_trajectory_fixture(oracle_built):
+    """tests/golden/ce_8_15_traj.npz: (X, Y, rhs) at iterations 1, 2, K/2, K-1 of that mpmath run (mu from 1e20 to 1e-15) with S from
+    the dense definition and (dx, dy) from an LU solve of the KKT matrix at 456 bits.  The oracle at 320 bits: S to 2^-250 relative (2^-316 on the first iterate);
+    dx, dy to what cond(S) leaves (stated per iterate)."""
+    from oracle.oracle import Oracle
+    from tests.util import mw_relerr
+    f = flat("ce_8_15")
+    g = np.load(os.path.join(GOLD, "ce_8_15_traj.npz"))
+    o = Oracle(f, mp_bits=320)
+    for s, it in enumerate(g["iters"]):
+        X, Y = g["X"][s], g["Y"][s]
+        st, Xc = o.cholesky_blocks_mw(X)
+        assert st == 0
+        S, _ = o.schur_assemble_mw(Xc, Y)
+        assert mw_relerr(S, g["S"][s]) <= 2.0 ** -250, (it, mw_relerr(S, g["S"][s]))      # cond(X) of the late iterates: 2^-316 at iteration 1, 2^-263 at 55
+        assert o.schur_factor() == 0
+        dx, dy = o.schur_solve_mw(g["rhs_x"][s], g["rhs_y"][s])
+        assert mw_relerr(dx, g["dx"][s]) <= 2.0 ** -150, (it, mw_relerr(dx, g["dx"][s]))
+        assert mw_relerr(dy, g["dy"][s]) <= 2.0 ** -150, (it, mw_relerr(dy, g["dy"][s]))
