@@ -127,6 +127,16 @@ SYMBOLS = {
     "clrs_mw_schur_factor_dev": (C.c_int, [C.c_void_p]),
     "clrs_mw_sync_status": (C.c_int, [C.c_void_p]),
     "clrs_mw_schur_solve_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "clrs_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "clrs_mw_set_shard": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "clrs_mw_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "clrs_mw_comm_destroy": (C.c_int, [C.c_void_p]),
+    "clrs_mw_schur_factor_local_dev": (C.c_int, [C.c_void_p]),
+    "clrs_mw_q_gather_dev": (C.c_void_p, [C.c_void_p]),
+    "clrs_mw_schur_factor_finish_dev": (C.c_int, [C.c_void_p]),
+    "clrs_mw_schur_solve_fwd_dev": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "clrs_mw_u_gather_dev": (C.c_void_p, [C.c_void_p]),
+    "clrs_mw_schur_solve_bwd_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "clrs_mw_S_buffer_dev": (C.c_void_p, [C.c_void_p]),
     "clrs_mw_AY_buffer_dev": (C.c_void_p, [C.c_void_p]),
     "clrs_mw_stream": (C.c_void_p, [C.c_void_p]),

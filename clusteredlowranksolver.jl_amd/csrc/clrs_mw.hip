@@ -9,6 +9,8 @@
 // pointers_left / pointers_right dictionaries become two integers per term.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
@@ -34,6 +36,41 @@ static int mw_fail(int code, const std::string &msg) {
         if (e_ != hipSuccess) return mw_fail(CLRS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
+// RCCL is bound at run time (dlopen): a process that already holds a copy (PyTorch ships one) keeps using that copy, and the
+// library loads on machines without RCCL.
+typedef struct { char internal[128]; } mw_nccl_id;
+struct MwNccl {
+    void *lib = nullptr;
+    int (*GetUniqueId)(mw_nccl_id *) = nullptr;
+    int (*CommInitRank)(void **, int, mw_nccl_id, int) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+static MwNccl g_nccl;
+static int mw_nccl_load() {
+    if (g_nccl.lib) return 0;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *h = nullptr;
+    for (const char *n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;      // a copy the process already has
+    for (const char *n : names) { if (h) break; h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); }
+    if (!h) return mw_fail(CLRS_ERR_INVALID, std::string("RCCL is not available: ") + dlerror());
+    g_nccl.GetUniqueId = (int (*)(mw_nccl_id *))dlsym(h, "ncclGetUniqueId");
+    g_nccl.CommInitRank = (int (*)(void **, int, mw_nccl_id, int))dlsym(h, "ncclCommInitRank");
+    g_nccl.CommDestroy = (int (*)(void *))dlsym(h, "ncclCommDestroy");
+    g_nccl.AllGather = (int (*)(const void *, void *, size_t, int, void *, hipStream_t))dlsym(h, "ncclAllGather");
+    g_nccl.GetErrorString = (const char *(*)(int))dlsym(h, "ncclGetErrorString");
+    if (!g_nccl.GetUniqueId || !g_nccl.CommInitRank || !g_nccl.CommDestroy || !g_nccl.AllGather) return mw_fail(CLRS_ERR_INVALID, "RCCL symbols missing");
+    g_nccl.lib = h;
+    return 0;
+}
+#define NCCLCHECK(expr)                                                                                                          \
+    do {                                                                                                                         \
+        int r_ = (expr);                                                                                                         \
+        if (r_ != 0) return mw_fail(CLRS_ERR_HIP, std::string(#expr) + ": " + (g_nccl.GetErrorString ? g_nccl.GetErrorString(r_) : "RCCL error")); \
+    } while (0)
+static const int MW_NCCL_FLOAT64 = 8;      // ncclFloat64 / ncclDouble
+
 static const size_t MW_LDS_MAX = 160 * 1024 - 2048;     // bytes of LDS one workgroup may claim on gfx950 (margin for the runtime)
 
 struct clrs_mw_ctx {
@@ -56,6 +93,8 @@ struct clrs_mw_ctx {
     double cnt_mul = 0;                  // multi-word multiply-adds of one assembly (algorithmic)
     double cnt_factor = 0, cnt_solve = 0;
     struct MwIpm *ipm = nullptr;
+    void *comm = nullptr;                // ncclComm_t when the library does the exchanges itself (clrs_mw_comm_init)
+    bool local_factored = false, fwd_done = false;
 };
 
 template <class T>
@@ -368,6 +407,8 @@ extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int dev
         int init[2] = {MW_INFO_NONE, MW_INFO_NONE};
         MWCHECK(hipMemcpy(info, init, sizeof(init), hipMemcpyHostToDevice));
     }
+    q.rank = 0; q.world = 1; q.gathered = 0;
+    MW_TRY(mw_dmalloc(c, &q.Qg, (i64)N * N * K)); MW_TRY(mw_dmalloc(c, &q.ug, (i64)N * K));
     for (auto &e : c->ev) MWCHECK(hipEventCreate(&e));
     *out = c;
     return 0;
@@ -380,6 +421,7 @@ extern "C" void clrs_mw_destroy(clrs_mw_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     mw_ipm_free(c);
+    if (c->comm && g_nccl.CommDestroy) { (void)g_nccl.CommDestroy(c->comm); c->comm = nullptr; }
     for (void *p : c->allocs) (void)hipFree(p);
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->h_info) (void)hipHostFree(c->h_info);
@@ -467,10 +509,64 @@ extern "C" int clrs_mw_schur_assemble_dev(clrs_mw_ctx *c, const double *d_Xchol,
     if (c->timing) MWCHECK(hipEventRecord(c->ev[1], c->stream));
     c->assembled = true;
     c->factored = false;
+    c->local_factored = false;
     return 0;
 }
 
-extern "C" int clrs_mw_schur_factor_dev(clrs_mw_ctx *c) {
+// ---- cluster sharding: split-phase entry points and the RCCL exchange ---------------------------------------------------
+
+extern "C" int clrs_comm_unique_id(void *id128) {
+    if (!id128) return mw_fail(CLRS_ERR_INVALID, "null argument");
+    int rc = mw_nccl_load();
+    if (rc) return rc;
+    NCCLCHECK(g_nccl.GetUniqueId((mw_nccl_id *)id128));
+    return 0;
+}
+
+// This context holds the clusters of rank `rank` of `world` (the description it was created from lists only those clusters, with
+// all N free variables).  world = 1 restores the unsharded behaviour.
+extern "C" int clrs_mw_set_shard(clrs_mw_ctx *c, int rank, int world) {
+    if (!c || world < 1 || rank < 0 || rank >= world) return mw_fail(CLRS_ERR_INVALID, "bad rank / world");
+    MWCHECK(hipSetDevice(c->device));
+    MWCHECK(hipStreamSynchronize(c->stream));
+    MwDev &q = c->d;
+    if (world != q.world) {
+        int rc;
+        if ((rc = mw_dmalloc(c, &q.Qg, (i64)world * q.N * q.N * c->K))) return rc;       // (the previous buffers stay in `allocs` until destroy)
+        if ((rc = mw_dmalloc(c, &q.ug, (i64)world * q.N * c->K))) return rc;
+    }
+    q.rank = rank; q.world = world;
+    q.gathered = (world > 1 || c->comm) ? 1 : 0;
+    return 0;
+}
+// The library performs the two exchanges itself with RCCL all-gathers on the context stream (one of limbs*N*N doubles per
+// factorisation, one of limbs*N per solve): clrs_mw_schur_factor_dev / _solve_dev then are collective calls.
+extern "C" int clrs_mw_comm_init(clrs_mw_ctx *c, const void *id128, int rank, int world) {
+    if (!c || !id128) return mw_fail(CLRS_ERR_INVALID, "null argument");
+    int rc = mw_nccl_load();
+    if (rc) return rc;
+    if ((rc = clrs_mw_set_shard(c, rank, world))) return rc;
+    mw_nccl_id id;
+    std::memcpy(&id, id128, sizeof(id));
+    NCCLCHECK(g_nccl.CommInitRank(&c->comm, world, id, rank));
+    c->d.gathered = 1;
+    return 0;
+}
+extern "C" int clrs_mw_comm_destroy(clrs_mw_ctx *c) {
+    if (!c) return mw_fail(CLRS_ERR_INVALID, "null context");
+    if (c->comm) {
+        (void)hipStreamSynchronize(c->stream);
+        NCCLCHECK(g_nccl.CommDestroy(c->comm));
+        c->comm = nullptr;
+        c->d.gathered = c->d.world > 1 ? 1 : 0;
+    }
+    return 0;
+}
+extern "C" double *clrs_mw_q_gather_dev(clrs_mw_ctx *c) { return c ? c->d.Qg : nullptr; }
+extern "C" double *clrs_mw_u_gather_dev(clrs_mw_ctx *c) { return c ? c->d.ug : nullptr; }
+
+// L_j, LinvB_j of this rank's clusters and its partial Q into slot `rank` of the gather buffer
+extern "C" int clrs_mw_schur_factor_local_dev(clrs_mw_ctx *c) {
     if (!c) return mw_fail(CLRS_ERR_INVALID, "null context");
     if (!c->assembled) return mw_fail(CLRS_ERR_STATE, "clrs_mw_schur_factor before clrs_mw_schur_assemble");
     MWCHECK(hipSetDevice(c->device));
@@ -482,16 +578,36 @@ extern "C" int clrs_mw_schur_factor_dev(clrs_mw_ctx *c) {
         hipLaunchKernelGGL(k_mw_factor<KK>, dim3(q.J), dim3(MW_NT), c->sm_factor, c->stream, q);
         if (q.N > 0) hipLaunchKernelGGL((k_mw_linvb<KK, DD>), dim3((q.N + MW_BT - 1) / MW_BT, q.J), dim3(MW_NT), c->sm_factor, c->stream, q);
         if (c->timing) (void)hipEventRecord(c->ev[3], c->stream);
-        if (q.N > 0) {
-            hipLaunchKernelGGL(k_mw_qgram<KK>, dim3((q.N * (q.N + 1) / 2 + MW_NT / MW_Q_W - 1) / (MW_NT / MW_Q_W)), dim3(MW_NT), 0, c->stream, q);
-            if (c->timing) (void)hipEventRecord(c->ev[4], c->stream);
-            hipLaunchKernelGGL(k_mw_potrf_q<KK>, dim3(1), dim3(MW_NT), c->sm_q, c->stream, q, c->lds_q ? 1 : 0);
-        } else if (c->timing) (void)hipEventRecord(c->ev[4], c->stream);
+        if (q.N > 0) hipLaunchKernelGGL(k_mw_qgram<KK>, dim3((q.N * (q.N + 1) / 2 + MW_NT / MW_Q_W - 1) / (MW_NT / MW_Q_W)), dim3(MW_NT), 0, c->stream, q);
+        if (c->timing) (void)hipEventRecord(c->ev[4], c->stream);
     });
+    MWCHECK(hipGetLastError());
+    c->local_factored = true;
+    c->factored = false;
+    return 0;
+}
+// after the gather buffer holds every rank's partial Q: Q = their sum, Cholesky of Q (redundantly on every rank)
+extern "C" int clrs_mw_schur_factor_finish_dev(clrs_mw_ctx *c) {
+    if (!c) return mw_fail(CLRS_ERR_INVALID, "null context");
+    if (!c->local_factored) return mw_fail(CLRS_ERR_STATE, "clrs_mw_schur_factor_finish before clrs_mw_schur_factor_local");
+    MWCHECK(hipSetDevice(c->device));
+    const MwDev &q = c->d;
+    MW_DISPATCH(c, { if (q.N > 0) hipLaunchKernelGGL(k_mw_potrf_q<KK>, dim3(1), dim3(MW_NT), c->sm_q, c->stream, q, c->lds_q ? 1 : 0); });
     MWCHECK(hipGetLastError());
     if (c->timing) MWCHECK(hipEventRecord(c->ev[5], c->stream));
     c->factored = true;
     return 0;
+}
+extern "C" int clrs_mw_schur_factor_dev(clrs_mw_ctx *c) {
+    int rc = clrs_mw_schur_factor_local_dev(c);
+    if (rc) return rc;
+    const MwDev &q = c->d;
+    if (q.gathered && q.N > 0) {
+        if (!c->comm) return mw_fail(CLRS_ERR_STATE, "sharded context without a communicator: use the split-phase entry points or clrs_mw_comm_init");
+        const size_t cnt = (size_t)q.N * q.N * c->K;
+        NCCLCHECK(g_nccl.AllGather(q.Qg + (size_t)q.rank * cnt, q.Qg, cnt, MW_NCCL_FLOAT64, c->comm, c->stream));
+    }
+    return clrs_mw_schur_factor_finish_dev(c);
 }
 extern "C" int clrs_mw_sync_status(clrs_mw_ctx *c) {
     if (!c) return mw_fail(CLRS_ERR_INVALID, "null context");
@@ -500,21 +616,48 @@ extern "C" int clrs_mw_sync_status(clrs_mw_ctx *c) {
     return st;
 }
 
-extern "C" int clrs_mw_schur_solve_dev(clrs_mw_ctx *c, const double *d_rhs_x, const double *d_rhs_y, double *d_dx, double *d_dy) {
-    if (!c || !d_rhs_x || !d_dx) return mw_fail(CLRS_ERR_INVALID, "null argument");
-    if (!c->factored) return mw_fail(CLRS_ERR_STATE, "clrs_mw_schur_solve before clrs_mw_schur_factor");
-    const MwDev &q = c->d;
-    if (q.N > 0 && (!d_rhs_y || !d_dy)) return mw_fail(CLRS_ERR_INVALID, "null argument");
+// t_j = L_j^-1 rhs_x[j] and this rank's partial u (slot `rank` of the u gather buffer when sharded)
+extern "C" int clrs_mw_schur_solve_fwd_dev(clrs_mw_ctx *c, const double *d_rhs_x) {
+    if (!c || !d_rhs_x) return mw_fail(CLRS_ERR_INVALID, "null argument");
+    if (!c->local_factored) return mw_fail(CLRS_ERR_STATE, "clrs_mw_schur_solve before clrs_mw_schur_factor");
     MWCHECK(hipSetDevice(c->device));
+    const MwDev &q = c->d;
     if (c->timing) MWCHECK(hipEventRecord(c->ev[6], c->stream));
     MW_DISPATCH(c, {
         hipLaunchKernelGGL(k_mw_solve_fwd<KK>, dim3(q.J), dim3(MW_NT), c->sm_fwd, c->stream, q, d_rhs_x);
+        if (q.gathered && q.N > 0) hipLaunchKernelGGL(k_mw_usum<KK>, dim3(1), dim3(MW_NT), 0, c->stream, q);
+    });
+    MWCHECK(hipGetLastError());
+    c->fwd_done = true;
+    return 0;
+}
+extern "C" int clrs_mw_schur_solve_bwd_dev(clrs_mw_ctx *c, const double *d_rhs_y, double *d_dx, double *d_dy) {
+    if (!c || !d_dx) return mw_fail(CLRS_ERR_INVALID, "null argument");
+    if (!c->factored || !c->fwd_done) return mw_fail(CLRS_ERR_STATE, "clrs_mw_schur_solve_bwd before clrs_mw_schur_factor_finish / clrs_mw_schur_solve_fwd");
+    const MwDev &q = c->d;
+    if (q.N > 0 && (!d_rhs_y || !d_dy)) return mw_fail(CLRS_ERR_INVALID, "null argument");
+    MWCHECK(hipSetDevice(c->device));
+    MW_DISPATCH(c, {
         if (q.N > 0) hipLaunchKernelGGL(k_mw_solve_mid<KK>, dim3(1), dim3(MW_NT), c->sm_mid, c->stream, q, d_rhs_y, d_dy, c->lds_q ? 1 : 0);
         hipLaunchKernelGGL(k_mw_solve_bwd<KK>, dim3(q.J), dim3(MW_NT), c->sm_bwd, c->stream, q, (const double *)d_dy, d_dx);
     });
     MWCHECK(hipGetLastError());
     if (c->timing) MWCHECK(hipEventRecord(c->ev[7], c->stream));
+    c->fwd_done = false;
     return 0;
+}
+extern "C" int clrs_mw_schur_solve_dev(clrs_mw_ctx *c, const double *d_rhs_x, const double *d_rhs_y, double *d_dx, double *d_dy) {
+    if (!c || !d_rhs_x || !d_dx) return mw_fail(CLRS_ERR_INVALID, "null argument");
+    if (!c->factored) return mw_fail(CLRS_ERR_STATE, "clrs_mw_schur_solve before clrs_mw_schur_factor");
+    int rc = clrs_mw_schur_solve_fwd_dev(c, d_rhs_x);
+    if (rc) return rc;
+    const MwDev &q = c->d;
+    if (q.gathered && q.N > 0) {
+        if (!c->comm) return mw_fail(CLRS_ERR_STATE, "sharded context without a communicator: use the split-phase entry points or clrs_mw_comm_init");
+        const size_t cnt = (size_t)q.N * c->K;
+        NCCLCHECK(g_nccl.AllGather(q.ug + (size_t)q.rank * cnt, q.ug, cnt, MW_NCCL_FLOAT64, c->comm, c->stream));
+    }
+    return clrs_mw_schur_solve_bwd_dev(c, d_rhs_y, d_dx, d_dy);
 }
 
 extern "C" double *clrs_mw_S_buffer_dev(clrs_mw_ctx *c) { return c ? c->d.S : nullptr; }

@@ -73,6 +73,10 @@ struct MwDev {
     double *xrd, *srd, *qrd;            // reciprocal diagonals of chol(X_b), L_j, L_Q
     double *t, *u, *AY;                 // t = L^-1 rhs_x (xlen); u slabs (J x N); pairings per term
     int *info;                          // [0] factor status, [1] Cholesky-of-X status
+    // cluster sharding over ranks (one process per GPU): this context holds the clusters of rank `rank`; the partial Q and the
+    // partial u of every rank are gathered into world slots and summed in rank order by every rank (src/solver.jl:1268-1269, 1550-1553)
+    int rank, world, gathered, pad3;    // gathered: u comes from the gather slots (world > 1, or a communicator is attached)
+    double *Qg, *ug;                    // [world][limbs * N * N], [world][limbs * N]
 };
 
 namespace mwk {
@@ -563,8 +567,9 @@ __global__ __launch_bounds__(MW_NT) void k_mw_qgram(const MwDev q) {
     for (long r = sub; r < q.xlen; r += MW_Q_W) acc_fma<K, K, K>(s, ldx<K>(q.LB, plane, r + a * q.xlen), ldx<K>(q.LB, plane, r + b * q.xlen));
     mw<K> v = lanes_sum<K, MW_Q_W>(acc_result<K>(s));
     if (live && sub == 0) {
-        stx<K>(q.Q, (long)N * N, a + (long)b * N, v);
-        stx<K>(q.Q, (long)N * N, b + (long)a * N, v);
+        double *Qp = q.Qg + (long)q.rank * K * N * N;                 // this rank's partial sum over its clusters
+        stx<K>(Qp, (long)N * N, a + (long)b * N, v);
+        stx<K>(Qp, (long)N * N, b + (long)a * N, v);
     }
 }
 
@@ -592,13 +597,39 @@ __global__ __launch_bounds__(MW_NT) void k_mw_potrf_q(const MwDev q, int lds) {
     const int N = q.N, tid = threadIdx.x;
     if (q.info[0] != MW_INFO_NONE) return;           // a cluster failed: the reference throws before reaching Q
     lds_d *bc = MW_LDS;
+    const long nn = (long)N * N;
     if (lds) {
         lds_d *M = MW_LDS + (K + 1);
-        wg_copy<K>(M, (long)N * N, N, q.Q, (long)N * N, N, N, N, tid);
+        for (int e = tid; e < nn; e += MW_NT) {            // Q = sum over the ranks' partial sums, in rank order on every rank
+            acc<K> s;
+            acc_zero<K>(s);
+            for (int r = 0; r < q.world; r++) acc_add<K, K>(s, ldx<K>(q.Qg + (long)r * K * nn, nn, e));
+            stx<K>(M, nn, e, acc_result<K>(s));
+        }
         __syncthreads();
-        mw_potrf_q_body<K>(q, M, (long)N * N, bc, tid);
+        mw_potrf_q_body<K>(q, M, nn, bc, tid);
     } else {
-        mw_potrf_q_body<K>(q, q.Q, (long)N * N, bc, tid);
+        for (int e = tid; e < nn; e += MW_NT) {
+            acc<K> s;
+            acc_zero<K>(s);
+            for (int r = 0; r < q.world; r++) acc_add<K, K>(s, ldx<K>(q.Qg + (long)r * K * nn, nn, e));
+            stx<K>(q.Q, nn, e, acc_result<K>(s));
+        }
+        __syncthreads();
+        mw_potrf_q_body<K>(q, q.Q, nn, bc, tid);
+    }
+}
+
+// partial u of this rank: sum of its clusters' u_j into its gather slot (sharded solve only)
+template <int K>
+__global__ __launch_bounds__(MW_NT) void k_mw_usum(const MwDev q) {
+    using namespace mwk;
+    const int N = q.N;
+    for (int a = blockIdx.x * MW_NT + threadIdx.x; a < N; a += gridDim.x * MW_NT) {
+        acc<K> s;
+        acc_zero<K>(s);
+        for (int j = 0; j < q.J; j++) acc_add<K, K>(s, ldx<K>(q.u, (long)q.J * N, (long)j * N + a));
+        stx<K>(q.ug + (long)q.rank * K * N, N, a, acc_result<K>(s));
     }
 }
 
@@ -662,7 +693,11 @@ __global__ __launch_bounds__(MW_NT) void k_mw_solve_mid(const MwDev q, const dou
         acc<K> s;
         acc_zero<K>(s);
         acc_add<K, K>(s, ldx<K>(rhs_y, N, a));
-        for (int j = 0; j < q.J; j++) acc_add<K, K>(s, ldx<K>(q.u, (long)q.J * N, (long)j * N + a), -1.0);
+        if (q.gathered) {
+            for (int r = 0; r < q.world; r++) acc_add<K, K>(s, ldx<K>(q.ug + (long)r * K * N, N, a), -1.0);
+        } else {
+            for (int j = 0; j < q.J; j++) acc_add<K, K>(s, ldx<K>(q.u, (long)q.J * N, (long)j * N + a), -1.0);
+        }
         stx<K>(v, N, a, acc_result<K>(s));
     }
     if (lds) {

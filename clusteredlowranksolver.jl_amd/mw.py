@@ -216,6 +216,44 @@ class MwSchurContext:
         _lib.check(self.L.clrs_mw_schur_solve_dev(self.h, C.c_void_p(d_rhs_x), C.c_void_p(d_rhs_y) if d_rhs_y else None,
                                                   C.c_void_p(d_dx), C.c_void_p(d_dy) if d_dy else None))
 
+    # -- cluster sharding (one process per GPU): this context holds the clusters of one rank -----------------
+    def set_shard(self, rank: int, world: int):
+        _lib.check(self.L.clrs_mw_set_shard(self.h, int(rank), int(world)))
+
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """ncclGetUniqueId (128 bytes): created on one rank, distributed by the caller, passed to comm_init on every rank."""
+        buf = C.create_string_buffer(128)
+        _lib.check(_lib.load().clrs_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, unique_id: bytes, rank: int, world: int):
+        """After this call factor_dev / solve_dev are collective: the library all-gathers the partial Q and u itself (RCCL)."""
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        _lib.check(self.L.clrs_mw_comm_init(self.h, buf, int(rank), int(world)))
+
+    def comm_destroy(self):
+        _lib.check(self.L.clrs_mw_comm_destroy(self.h))
+
+    def factor_local_dev(self):
+        _lib.check(self.L.clrs_mw_schur_factor_local_dev(self.h))
+
+    def factor_finish_dev(self):
+        _lib.check(self.L.clrs_mw_schur_factor_finish_dev(self.h))
+
+    def solve_fwd_dev(self, d_rhs_x: int):
+        _lib.check(self.L.clrs_mw_schur_solve_fwd_dev(self.h, C.c_void_p(d_rhs_x)))
+
+    def solve_bwd_dev(self, d_rhs_y: int, d_dx: int, d_dy: int):
+        _lib.check(self.L.clrs_mw_schur_solve_bwd_dev(self.h, C.c_void_p(d_rhs_y) if d_rhs_y else None, C.c_void_p(d_dx),
+                                                      C.c_void_p(d_dy) if d_dy else None))
+
+    def q_gather(self) -> int:
+        return int(self.L.clrs_mw_q_gather_dev(self.h) or 0)
+
+    def u_gather(self) -> int:
+        return int(self.L.clrs_mw_u_gather_dev(self.h) or 0)
+
     def sync_status(self) -> int:
         return _lib.check(self.L.clrs_mw_sync_status(self.h))
 

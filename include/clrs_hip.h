@@ -308,6 +308,24 @@ double *clrs_mw_AY_buffer_dev(clrs_mw_ctx *ctx);     /* planar [T] */
 void *clrs_mw_stream(clrs_mw_ctx *ctx);
 int clrs_mw_set_stream(clrs_mw_ctx *ctx, void *hip_stream);
 
+/* Cluster sharding (one process per GPU): a context created from the description of ITS clusters only (all N
+ * free variables) is told its place with clrs_mw_set_shard.  The two sums over all clusters, Q = sum_j LinvB_j^T LinvB_j
+ * (src/solver.jl:1268-1269) and u = sum_j LinvB_j^T t_j (:1550-1553), are formed from per-rank partial sums that are ALL-GATHERED
+ * (limb planes cannot be all-reduced: a sum of limbs is not the limbs of the sum) and added in rank order by every rank, so all
+ * ranks hold bit-identical Q, L_Q, dy.  Either the caller moves the slots (split-phase entry points; any transport), or the
+ * library does it with RCCL on the context stream after clrs_mw_comm_init, in which case clrs_mw_schur_factor_dev and
+ * clrs_mw_schur_solve_dev are collective calls: one all-gather of limbs*N*N doubles per factorisation, one of limbs*N per solve. */
+int clrs_comm_unique_id(void *id128);                                     /* ncclGetUniqueId: 128 bytes, to be distributed by the caller */
+int clrs_mw_set_shard(clrs_mw_ctx *ctx, int rank, int world);
+int clrs_mw_comm_init(clrs_mw_ctx *ctx, const void *id128, int rank, int world);   /* clrs_mw_set_shard + ncclCommInitRank */
+int clrs_mw_comm_destroy(clrs_mw_ctx *ctx);
+int clrs_mw_schur_factor_local_dev(clrs_mw_ctx *ctx);                     /* L_j, LinvB_j, partial Q into slot `rank` */
+double *clrs_mw_q_gather_dev(clrs_mw_ctx *ctx);                           /* [world][limbs * N * N] */
+int clrs_mw_schur_factor_finish_dev(clrs_mw_ctx *ctx);                    /* Q = sum of the slots, Cholesky of Q */
+int clrs_mw_schur_solve_fwd_dev(clrs_mw_ctx *ctx, const double *d_rhs_x);  /* t = L^-1 rhs_x, partial u into slot `rank` */
+double *clrs_mw_u_gather_dev(clrs_mw_ctx *ctx);                           /* [world][limbs * N] */
+int clrs_mw_schur_solve_bwd_dev(clrs_mw_ctx *ctx, const double *d_rhs_y, double *d_dx, double *d_dy);
+
 /* HIP-event timings of the last calls, seconds: t[0] schur, t[1] cholS + LinvB (one kernel), t[2] 0, t[3] Q, t[4] cholQ,
  * t[5] last solve (the split compute_T_decomposition! returns, src/solver.jl:1282-1286). */
 int clrs_mw_set_timing(clrs_mw_ctx *ctx, int enabled);

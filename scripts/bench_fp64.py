@@ -331,6 +331,40 @@ def main(argv=None, emit=True):
         except Exception as e:
             out["roofline"]["copy_roof_error"] = repr(e)
 
+        # ---- dense ("high rank") branch at BASELINE config 5's stated scale: SDPA import x64 blocks ----
+        try:
+            from clrs_amd.problems import sdpa_scaled, sdpa_to_sdp
+            import clrs_amd as _cc
+            fd = _cc.flatten(sdpa_to_sdp(sdpa_scaled(nb=64, bs=32, m=256, seed=64)))
+            dctx = SchurContext(fd, device=local_rank)
+            dctx.set_stream(torch.cuda.current_stream().cuda_stream)
+            dXd, dYd = seeded_iterates(fd, seed=7)
+            dXc = np.concatenate([np.linalg.cholesky(dXd[fd.block_off[b]:fd.block_off[b + 1]].reshape(int(fd.block_n[b]), -1, order="F"))
+                                  .reshape(-1, order="F") for b in range(fd.n_blocks)])
+            tdXc, tdY = torch.from_numpy(dXc).to(dev), torch.from_numpy(dYd).to(dev)
+            for _ in range(20):
+                dctx.assemble_dev(tdXc.data_ptr(), tdY.data_ptr())
+            torch.cuda.synchronize()
+            dprof = kernel_profile(dctx, lambda: dctx.assemble_dev(tdXc.data_ptr(), tdY.data_ptr()), 20)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(50):
+                dctx.assemble_dev(tdXc.data_ptr(), tdY.data_ptr())
+            e1.record(); e1.synchronize()
+            d_s = 1e-3 * e0.elapsed_time(e1) / 50
+            dcnt = dctx.counters()
+            ddom = max(dprof.items(), key=lambda kv: kv[1][2])
+            out["roofline_dense"] = {"bound": "mfma", "phase": "schur_assemble, dense branch (src/solver.jl:1089-1104)", "kernel": ddom[0],
+                                     "assembly_us": 1e6 * d_s, "achieved": dcnt["assemble_flops"] / d_s / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                     "frac": dcnt["assemble_flops"] / d_s / 1e12 / FP64_PEAK_TFLOPS, "traffic": None,
+                                     "workload": "sdpa_scaled(nb=64, bs=32, m=256): 64 dense 32x32 blocks, P = 256 (BASELINE config 5 as named)",
+                                     "algorithmic_flops": dcnt["assemble_flops"], "algorithmic_bytes": dcnt["assemble_bytes"],
+                                     "flops_model": "P (6 n^3) + P^2 n^2 per block over the constraints present in it (SURVEY.md section 8d)",
+                                     "kernels_us": {k: round(1e6 * v[2], 3) for k, v in dprof.items()}}
+            dctx.close()
+        except Exception as e:
+            out["roofline_dense"] = {"error": repr(e)}
+
         # ---- the complete interior-point method, device resident, on the instances fp64 can solve ----
         # every iteration = residuals + predictor + corrector + step lengths + update around the same hot path; one host sync per iteration
         try:

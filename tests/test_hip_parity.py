@@ -747,3 +747,85 @@ def test_malformed_descriptions_are_rejected():
     with pytest.raises(ClrsError, match="before clrs_schur_assemble"):
         ctx.factor()
     ctx.close()
+
+
+# ---- BASELINE configs 4 and 5 at their named sizes ---------------------------------------------------------------------------
+def test_three_point_bound_n3_2d16_config4_as_named(oracle_built):
+    """BASELINE config 4 as named ("ThreePointBound spherical code n=3, 2d=16": three_point_spherical_codes(3, 1/2, 8, 8),
+    examples/ThreePointBound.jl:45-160): one cluster of P = 221 constraints, 9 dense blocks (sides 9..1), 17 rank-1 1x1 blocks and
+    17 low-rank blocks up to 54 x 54 with rank-1 and rank-2 terms, N = 0.  The reference pins no answer for this instance (its test
+    runs (4, 1/6, -1, 4)); parity is against the oracle on seeded iterates plus the structural identities.
+    Like the 2d = 30 sphere-packing problems, S of this instance is not positive definite to fp64 accuracy even on well-conditioned
+    iterates: the fp64 path assembles it (checked) and reports the reference's SolverFailure; factor and solve are checked on the
+    multi-word path (4 limbs) against the 320-bit oracle."""
+    from clrs_amd.mw import MwSchurContext
+    from clrs_amd.solver import SchurContext
+    from oracle.oracle import Oracle
+    from tests.util import mw_from_double, mw_relerr
+    f = flat("threepoint_3_8_8")
+    P = 221
+    assert f.n_clusters == 1 and int(f.cluster_P[0]) == P and f.n_free == 0 and int(np.max(f.block_n)) == 54
+    X, Y = spd_iterates(f, seed=4)
+    Xc = chol_blocks_np(f, X)
+    o64 = Oracle(f, quad=False)
+    S64, _ = o64.schur_assemble(Xc, Y)
+    S_dense = o64.schur_dense_check(Xc, Y)                    # low-rank branch == dense trace formula (src/interface.jl:798-800)
+    assert np.max(np.abs(S64 - S_dense)) <= 1e-10 * np.max(np.abs(S64))
+    o = Oracle(f, quad=True, use_lo=False)
+    S_ref, AY_ref = o.schur_assemble(Xc, Y)
+    ctx = SchurContext(f)
+    S, AY = ctx.compute_S_integrated(Xc, Y)
+    Sm = S.reshape(P, P, order="F")
+    assert np.array_equal(Sm, Sm.T)
+    assert np.max(np.abs(S - S_ref)) <= 1e-11 * np.max(np.abs(S_ref)), np.max(np.abs(S - S_ref)) / np.max(np.abs(S_ref))
+    assert np.max(np.abs(AY - AY_ref)) <= 1e-11 * max(1.0, np.max(np.abs(AY_ref)))
+    assert ctx.factor() == 1                                  # "S was not decomposed succesfully in block 1" (src/solver.jl:1249)
+    ctx.close()
+    # factor + solve at 4 limbs
+    K = 4
+    om = Oracle(f, mp_bits=320)
+    mctx = MwSchurContext(f, limbs=K)
+    Xm, Ym = mw_from_double(X, K), mw_from_double(Y, K)
+    Xcm = mctx.cholesky_blocks(Xm)
+    Sm4, _ = mctx.compute_S_integrated(Xcm, Ym)
+    pad = lambda a: np.vstack([a, np.zeros((1, a.shape[1]))])
+    S_mp, _ = om.schur_assemble_mw(pad(Xcm), pad(Ym))
+    assert mw_relerr(Sm4, S_mp) <= 2.0 ** -(53 * K - 24), mw_relerr(Sm4, S_mp)
+    assert mctx.factor() == 0 and om.schur_factor() == 0
+    rhs = mw_from_double(np.random.default_rng(9).standard_normal(f.x_len), K)
+    dx, _ = mctx.solve(rhs, None)
+    dx_ref, _ = om.schur_solve_mw(pad(rhs), np.zeros((K + 1, 0)))
+    # cond(S) of this instance on these iterates is ~1e20 (why fp64 fails): what is left of 4 limbs
+    assert mw_relerr(dx, dx_ref) <= 2.0 ** -(53 * K - 110), mw_relerr(dx, dx_ref)
+    mctx.close()
+
+
+def test_sdpa_x64_config5_as_named(oracle_built):
+    """BASELINE config 5 as named ("SDPA .dat-s import scaled x64 blocks": sdpa_scaled(nb=64, bs=32, m=256), SURVEY.md section 8d
+    row 5; reader semantics of src/SDPAtoCLRS.jl:3-83): 64 dense 32 x 32 blocks, P = 256, no low-rank structure, N = 0 -- the dense
+    ("high rank") branch of compute_S_integrated! (src/solver.jl:1089-1104) on every block."""
+    from clrs_amd.solver import SchurContext, compute_T_decomposition, solve_system, solvesdp_device
+    from oracle.oracle import Oracle
+    f = flat("sdpa_x64")
+    assert f.n_blocks == 64 and int(f.cluster_P[0]) == 256 and np.all(f.block_kind == 1) and np.all(f.block_n == 32)
+    X, Y = spd_iterates(f, seed=6)
+    Xc = chol_blocks_np(f, X)
+    o = Oracle(f, quad=True, use_lo=False)
+    S_ref, _ = o.schur_assemble(Xc, Y)
+    assert o.schur_factor() == 0
+    rhs = np.random.default_rng(10).standard_normal(f.x_len)
+    dx_ref, _ = o.schur_solve(rhs, np.zeros(0))
+    for kw in (dict(), dict(fused=False)):
+        ctx = SchurContext(f, **kw)
+        _, S, _ = compute_T_decomposition(ctx, Xc, Y, want_S=True)
+        assert np.max(np.abs(S - S_ref)) <= 1e-11 * np.max(np.abs(S_ref)), (kw, np.max(np.abs(S - S_ref)) / np.max(np.abs(S_ref)))
+        Sm = S.reshape(256, 256, order="F")
+        assert np.array_equal(Sm, Sm.T)
+        dx, _ = solve_system(ctx, rhs, np.zeros(0))
+        assert np.max(np.abs(dx - dx_ref)) <= 1e-8 * max(1.0, np.max(np.abs(dx_ref)))
+        ctx.close()
+    # the whole solve, device resident, against the oracle loop (the reference pins no objective for a generated SDPA instance)
+    r = solvesdp_device(f)
+    ro = Oracle(f, quad=False).solvesdp(omega_p=1e4, omega_d=1e4, duality_gap_threshold=1e-7, dual_error_threshold=1e-9, primal_error_threshold=1e-9)
+    assert r.error_code == 0 and ro["error_code"] == 0, (r.status, r.error_code, ro["error_code"])
+    assert abs(r.primal_objective - ro["p_obj"]) <= 1e-6 * max(1.0, abs(ro["p_obj"]))

@@ -62,6 +62,11 @@ def instance(name):
     if name == "threepoint_4":
         import mpmath as mp
         return P.three_point_spherical_codes(4, mp.mpf(1) / 6, -1, 4)
+    if name == "threepoint_3_8_8":      # BASELINE config 4 as named: "ThreePointBound n=3, 2d=16" (examples/ThreePointBound.jl:45-160 with d2 = d3 = 8)
+        import mpmath as mp
+        return P.three_point_spherical_codes(3, mp.mpf(1) / 2, 8, 8)
+    if name == "sdpa_x64":              # BASELINE config 5 as named: SDPA dense-constraint import scaled to 64 blocks
+        return P.sdpa_to_sdp(P.sdpa_scaled(nb=64, bs=32, m=256, seed=64))
     if name == "polyopt_scaled_100":
         return P.polyopt_scaled(100)
     raise KeyError(name)
