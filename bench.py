@@ -16,8 +16,11 @@ One step = one pass of the hot path of one interior-point iteration on device-re
     chol S_j, L^-1 B, Q, chol Q         (compute_T_decomposition!, :1244-1279)
     2 x system solve                    (predictor + corrector, compute_search_direction! :1527-1582)
 on the iterate (X, Y) of iteration ceil(K/2) of the solve itself (trajectory iterates, not synthetic ones),
-with `parity.factor_status == 0` asserted.  `value` = steps/s.  With N GPUs: N independent replicas of the step ("replicas
-only": the multi-word path has no cluster-sharded form yet; the fp64 path's RCCL sharding is measured by scripts/bench_fp64.py).
+with `parity.factor_status == 0` asserted.  `value` = units/s, one unit = one hot-path pass over one 2-cluster share.
+With N GPUs the problem is weak-scaled along the reference's own outer parallel axis (clusters): cohnelkies_multi with 2N clusters
+(2N - 1 sign-constraint clusters at different radii), 2 clusters per rank, coupled by the two sums over all clusters -- RCCL
+all-gathers of the partial Q (limbs x 31 x 31) per factorisation and of the partial u (limbs x 31) per solve, issued by the library
+itself on its stream (clrs_mw_comm_init): a step of the N-GPU job counts as N units.
 
 `cpu_baseline`: the same step in the multi-precision CPU oracle (oracle/mpx.hpp, 256-bit truncation, the stand-in for the
 reference's Arb arithmetic: kind "port") on the host cores; `cpu_baseline_fp64`: the fp64 port on the same shapes.
@@ -56,6 +59,7 @@ def main():
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--skip-fp64", action="store_true", help="skip the fp64 measurements (Schur-assembly HBM roofline, fp64 step on the problem's shapes)")
     ap.add_argument("--mw-copies", type=int, default=128, help="replication factor of the multi-word roofline instance")
+    ap.add_argument("--split", action="store_true", help="with one GPU: still take the sharded code path (1-rank process group, RCCL all-gathers inside the library)")
     args = ap.parse_args()
 
     # stdout carries exactly one JSON line; native libraries write there too: keep the real stdout aside, point fd 1 at stderr
@@ -71,9 +75,14 @@ def main():
         raise SystemExit("bench.py needs a GPU (the HIP library is the only compute path)")
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
-    if world > 1:
+    sharded = world > 1 or args.split
+    if sharded:
         if os.environ.get("NCCL_DEBUG", "VERSION").upper() == "VERSION":
             os.environ["NCCL_DEBUG"] = "WARN"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device(dev))
 
     import clrs_amd
@@ -105,6 +114,26 @@ def main():
                   "what": "whole interior-point iterations (residuals, predictor, corrector, step lengths, update around the hot path), device resident, "
                           "one host synchronisation per iteration; first_solve_s includes context warm-up on a cold device"}
 
+    if sharded:
+        # weak scaling: 2 clusters per rank of the 2N-cluster problem; the iterate of a sign-constraint cluster is that of the solved one
+        from clrs_amd.problems import cohnelkies_multi
+        from clrs_amd.sdp import shard_clusters
+        full = clrs_amd.flatten(cohnelkies_multi(8, 15, [1.0 + 0.125 * k for k in range(2 * world - 1)]))
+        mine = [2 * rank, 2 * rank + 1]
+        shard = shard_clusters(full, mine)
+        blk = lambda M, b: M[:, int(flat.block_off[b]):int(flat.block_off[b + 1])]
+        per_cluster = {0: [0, 1], 1: [2, 3]}                                   # blocks of the f^ cluster / of a sign cluster in the solved problem
+        cols = [b for j in mine for b in per_cluster[0 if j == 0 else 1]]
+        X = np.ascontiguousarray(np.concatenate([blk(X, b) for b in cols], axis=1))
+        Y = np.ascontiguousarray(np.concatenate([blk(Y, b) for b in cols], axis=1))
+        ctx.close()
+        flat = shard
+        ctx = MwSchurContext(shard, limbs=K, device=local_rank)
+        uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            uid = torch.tensor(list(MwSchurContext.comm_unique_id()), dtype=torch.uint8, device=dev)
+        dist.broadcast(uid, 0)
+        ctx.comm_init(bytes(uid.cpu().tolist()), rank, world)
     dX, dY = torch.tensor(X, device=dev), torch.tensor(Y, device=dev)
     dXc = torch.empty_like(dX)
     rx, ry = np.zeros((K, flat.x_len)), np.zeros((K, flat.n_free))
@@ -126,7 +155,14 @@ def main():
     parity["factor_status"] = ctx.sync_status()
     parity["cholesky_status"] = ctx.sync_status_cholesky()
     assert parity["factor_status"] == 0 and parity["cholesky_status"] == 0, parity
-    if rank == 0:
+    if sharded:
+        # every rank must hold the same dy bit for bit (the gathered partial sums are added in rank order everywhere)
+        mine_dy = ddy.clone()
+        ref_dy = ddy.clone()
+        dist.broadcast(ref_dy, 0)
+        assert torch.equal(mine_dy, ref_dy), "dy differs between ranks"
+        parity["dy_identical_on_all_ranks"] = True
+    if rank == 0 and not sharded:
         import math as _m
         from oracle.oracle import Oracle
 
@@ -156,7 +192,7 @@ def main():
         step()
     ctx.sync_status()
     torch.cuda.synchronize()
-    if world > 1:
+    if sharded:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -164,11 +200,11 @@ def main():
         step()
     ctx.sync_status()
     torch.cuda.synchronize()
-    if world > 1:
+    if sharded:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if sharded:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -183,14 +219,16 @@ def main():
         "config": {"workload": "SpherePacking cohnelkies(8,15): d=8, 2d=30; 2 clusters P=32, blocks 16x16 r1 + 1x1 dense, N=31; "
                                f"iterate of iteration {mid + 1} of {n_it} of the solve at the reference's precision (prec=256 -> {K} limbs)",
                    "clusters": int(flat.n_clusters), "n_free": int(flat.n_free), "limbs": K, "data_limbs": 2,
-                   "unit_of_work": "one hot-path pass (chol X, assembly, factorisation, predictor + corrector solve) over the 2-cluster problem",
-                   "multi_gpu": "replicas only (N independent copies of the step, no collective)" if world > 1 else "single GPU",
-                   "launch": "eager, 13 kernels per step"},
+                   "unit_of_work": "one hot-path pass (chol X, assembly, factorisation, predictor + corrector solve) over one 2-cluster share; "
+                                   "a step of the N-GPU job (one iteration of the 2N-cluster problem) = N units",
+                   "multi_gpu": (f"{2 * world} clusters sharded 2 per rank; RCCL all-gather of the partial Q (per factorisation) and u (per solve) "
+                                 "inside the C ABI (clrs_mw_comm_init)") if sharded else "single GPU",
+                   "launch": "eager, 14 kernels per step"},
         "parity": parity,
         "full_solve": full_solve,
     }
 
-    if rank == 0:
+    if rank == 0 and not sharded:
         ctx.set_timing(True)
         for _ in range(3):
             step()
@@ -297,9 +335,11 @@ def main():
                                "cpu_baseline_fp64": f64.get("cpu_baseline"), "full_ipm_device_resident": f64.get("full_ipm_device_resident")}
             except Exception as e:
                 out["fp64"] = {"error": repr(e)}
-    ctx.close()
-    if world > 1:
+    if sharded:
         dist.barrier()
+        ctx.comm_destroy()
+    ctx.close()
+    if sharded:
         dist.destroy_process_group()
     if rank == 0:
         import ctypes

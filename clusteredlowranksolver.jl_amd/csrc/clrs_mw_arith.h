@@ -298,6 +298,15 @@ MWF bool less(const mw<K> &a, const mw<K> &b) {           // a < b
 // reciprocal, reciprocal square root: Newton's iteration with the working precision doubled per step
 // (53 -> 106 -> 212 -> 424 bits), each step evaluating its residual with just the limbs it needs.
 // ---------------------------------------------------------------------------------------------------------------------
+// precision schedule of the Newton iterations: the last step should start from ceil(K/2) limbs (not from the largest power of
+// two below K), the one before from ceil(K/4), ...: for K = 5 the chain is 1 -> 2 -> 3 -> 5 instead of 1 -> 2 -> 4 -> 5, and
+// the steps before the last run in cheaper arithmetic
+constexpr int newton_next(int K, int KX) {
+    int t = K;
+    while ((t + 1) / 2 > KX) t = (t + 1) / 2;
+    return t;
+}
+
 template <int K, int KX>
 struct NewtonRecip {
     // x (KX limbs, accurate to ~53 KX bits) -> K limbs
@@ -305,7 +314,7 @@ struct NewtonRecip {
         if constexpr (KX >= K) {
             return cvt<K, KX>(x);
         } else {
-            constexpr int KN = (2 * KX < K) ? 2 * KX : K;
+            constexpr int KN = newton_next(K, KX);
             // r = 1 - a x  to KN limbs (its leading KX limbs cancel)
             acc<KN> c;
             acc_zero<KN>(c);
@@ -346,7 +355,7 @@ struct NewtonRsqrt {
         if constexpr (KX >= K) {
             return cvt<K, KX>(y);
         } else {
-            constexpr int KN = (2 * KX < K) ? 2 * KX : K;
+            constexpr int KN = newton_next(K, KX);
             constexpr int KA = (KN < K ? KN : K);
             // r = 1 - a y^2 to KN limbs
             mw<KN> y2 = mulx<KN, KX, KX>(y, y);

@@ -135,9 +135,12 @@ __device__ __forceinline__ bool wg_potrf(PM M, long plane, int n, int ld, PR rd,
             const bool ok = d.l[0] > 0.0;
             mw<K> rs = ok ? rsqrt<K>(d) : zero<K>();
             if (tid == 0) {                                              // M[k,k] keeps d_k until the end: nothing reads it again
-                stx<K>(bc, 1, 0, rs);
                 bc[K] = ok ? 1.0 : 0.0;
                 stx<K>(rd, rdplane, k, rs);
+            }
+            for (int i = k + 1 + tid; i < n; i += 64) {                  // the column is scaled by the same wave, no barrier in between
+                const long idx = i + (long)k * ld;
+                stx<K>(M, plane, idx, mul<K>(ldx<K>(M, plane, idx), rs));
             }
         } else if (k > 0) {
             const int m = n - k - 1, cnt = m * (m + 1) / 2;            // rest of update k-1: columns k+1 .. n-1
@@ -151,12 +154,6 @@ __device__ __forceinline__ bool wg_potrf(PM M, long plane, int n, int ld, PR rd,
         }
         __syncthreads();
         if (bc[K] == 0.0) return false;
-        const mw<K> rs = ldx<K>(bc, 1, 0);
-        for (int i = k + 1 + tid; i < n; i += MW_NT) {
-            const long idx = i + (long)k * ld;
-            stx<K>(M, plane, idx, mul<K>(ldx<K>(M, plane, idx), rs));
-        }
-        __syncthreads();
         if (k + 1 < n) {
             const mw<K> lk = ldx<K>(M, plane, (k + 1) + (long)k * ld);
             for (int i = k + 1 + tid; i < n; i += MW_NT) {
@@ -174,8 +171,9 @@ __device__ __forceinline__ bool wg_potrf(PM M, long plane, int n, int ld, PR rd,
     return true;
 }
 
-// Scaled strict lower triangles of a Cholesky factor: F[i,k] = L[i,k] / L[i,i] (forward substitution with a unit diagonal:
-// x_i = b_i / L_ii - sum_k F[i,k] x_k) and Bk[i,k] = L[i,k] / L[k,k] (backward: x_k = b_k / L_kk - sum_i Bk[i,k] x_i), i > k.
+// Scaled strict triangles of a Cholesky factor: F[i,k] = L[i,k] / L[i,i], i > k (forward substitution with a unit diagonal:
+// x_i = b_i / L_ii - sum_k F[i,k] x_k) and, stored TRANSPOSED so that a substitution step reads a contiguous column,
+// Bk[i,k] = L[k,i] / L[i,i], i < k (backward: x_i = b_i / L_ii - sum_{k>i} Bk[i,k] x_k).
 template <int K, class PL, class PR, class PF, class PB>
 __device__ __forceinline__ void wg_scaled_factors(PL L, long lplane, int ldl, PR rd, long rdplane, int n, PF F, long fplane, int ldf, PB Bk,
                                                   long bplane, int ldb, int tid) {
@@ -184,10 +182,10 @@ __device__ __forceinline__ void wg_scaled_factors(PL L, long lplane, int ldl, PR
         if (i > k) {
             const mw<K> l = ldx<K>(L, lplane, i + (long)k * ldl);
             stx<K>(F, fplane, i + (long)k * ldf, mul<K>(l, ldx<K>(rd, rdplane, i)));
-            stx<K>(Bk, bplane, i + (long)k * ldb, mul<K>(l, ldx<K>(rd, rdplane, k)));
+            stx<K>(Bk, bplane, k + (long)i * ldb, mul<K>(l, ldx<K>(rd, rdplane, k)));      // entry (k, i) of the transposed factor
         } else {
             stx<K>(F, fplane, i + (long)k * ldf, zero<K>());
-            stx<K>(Bk, bplane, i + (long)k * ldb, zero<K>());
+            if (i == k) stx<K>(Bk, bplane, i + (long)k * ldb, zero<K>());
         }
     }
 }
@@ -225,10 +223,40 @@ __device__ __forceinline__ void wg_trsm_b(PF Bk, long fplane, int ldf, PR rd, lo
         for (int e = tid; e < k * nrhs; e += MW_NT) {
             const int i = e % k, c = e / k;
             const long idx = i + (long)c * ldb;
-            stx<K>(B, bplane, idx, fnma<K>(ldx<K>(B, bplane, idx), ldx<K>(Bk, fplane, k + (long)i * ldf), ldx<K>(B, bplane, k + (long)c * ldb)));
+            stx<K>(B, bplane, idx, fnma<K>(ldx<K>(B, bplane, idx), ldx<K>(Bk, fplane, i + (long)k * ldf), ldx<K>(B, bplane, k + (long)c * ldb)));
         }
         __syncthreads();
     }
+}
+
+// ---- substitutions with ONE right-hand side and n <= 64 unknowns: one wave, the vector in registers (lane i holds b_i, already
+// divided by L_ii), the finished unknown broadcast with v_readlane, the factor column read from LDS: no barrier, no LDS write, one
+// multiply-add on the dependent chain per unknown.
+__device__ __forceinline__ double readlane_d(double v, int k) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, k);
+    hi = __builtin_amdgcn_readlane(hi, k);
+    return __hiloint2double(hi, lo);
+}
+template <int K, class PF>
+__device__ __forceinline__ mw<K> wave_trsv_f(PF F, long fplane, int ldf, int n, mw<K> b, int lane) {
+    for (int k = 0; k < n - 1; k++) {
+        mw<K> xk;
+#pragma unroll
+        for (int l = 0; l < K; l++) xk.l[l] = readlane_d(b.l[l], k);
+        if (lane > k && lane < n) b = fnma<K>(b, ldx<K>(F, fplane, lane + (long)k * ldf), xk);
+    }
+    return b;
+}
+template <int K, class PF>
+__device__ __forceinline__ mw<K> wave_trsv_b(PF Bk, long fplane, int ldf, int n, mw<K> b, int lane) {
+    for (int k = n - 1; k > 0; k--) {
+        mw<K> xk;
+#pragma unroll
+        for (int l = 0; l < K; l++) xk.l[l] = readlane_d(b.l[l], k);
+        if (lane < k) b = fnma<K>(b, ldx<K>(Bk, fplane, lane + (long)k * ldf), xk);
+    }
+    return b;
 }
 
 // copy a rows x cols planar matrix between two arrays (any address spaces)
@@ -643,7 +671,16 @@ template <int K, class PF>
 __device__ __forceinline__ void mw_solve_fwd_body(const MwDev &q, const MwClu &c, int j, PF F, long fplane, mwk::lds_d *tv, int tid) {
     using namespace mwk;
     const int P = c.P, N = q.N;
-    wg_trsm_f<K>(F, fplane, P, q.srd + c.coff, q.xlen, P, tv, P, P, 1, tid);
+    if (P <= 64) {
+        if (tid < 64) {
+            mw<K> b = tid < P ? mul<K>(ldx<K>(tv, P, tid), ldx<K>(q.srd + c.coff, q.xlen, tid)) : zero<K>();
+            b = wave_trsv_f<K>(F, fplane, P, P, b, tid);
+            if (tid < P) stx<K>(tv, P, tid, b);
+        }
+        __syncthreads();
+    } else {
+        wg_trsm_f<K>(F, fplane, P, q.srd + c.coff, q.xlen, P, tv, P, P, 1, tid);
+    }
     for (int i = tid; i < P; i += MW_NT) {
 #pragma unroll
         for (int l = 0; l < K; l++) q.t[(long)l * q.xlen + c.coff + i] = tv[(long)l * P + i];
@@ -705,8 +742,19 @@ __global__ __launch_bounds__(MW_NT) void k_mw_solve_mid(const MwDev q, const dou
         wg_copy<K>(Lf, lplane, N, q.Qf, lplane, N, N, N, tid);
         wg_copy<K>(Lb, lplane, N, q.Qb, lplane, N, N, N, tid);
         __syncthreads();
-        wg_trsm_f<K>(Lf, lplane, N, q.qrd, N, N, v, N, N, 1, tid);
-        wg_trsm_b<K>(Lb, lplane, N, q.qrd, N, N, v, N, N, 1, tid);
+        if (N <= 64) {
+            if (tid < 64) {
+                mw<K> b = tid < N ? mul<K>(ldx<K>(v, N, tid), ldx<K>(q.qrd, N, tid)) : zero<K>();
+                b = wave_trsv_f<K>(Lf, lplane, N, N, b, tid);
+                if (tid < N) b = mul<K>(b, ldx<K>(q.qrd, N, tid));
+                b = wave_trsv_b<K>(Lb, lplane, N, N, b, tid);
+                if (tid < N) stx<K>(v, N, tid, b);
+            }
+            __syncthreads();
+        } else {
+            wg_trsm_f<K>(Lf, lplane, N, q.qrd, N, N, v, N, N, 1, tid);
+            wg_trsm_b<K>(Lb, lplane, N, q.qrd, N, N, v, N, N, 1, tid);
+        }
     } else {
         __syncthreads();
         wg_trsm_f<K>(q.Qf, lplane, N, q.qrd, N, N, v, N, N, 1, tid);
@@ -742,7 +790,16 @@ __global__ __launch_bounds__(MW_NT) void k_mw_solve_bwd(const MwDev q, const dou
         lds_d *Ls = MW_LDS + (long)K * P;
         wg_copy<K>(Ls, (long)P * P, P, q.Sb + c.Soff, q.Slen, P, P, P, tid);
         __syncthreads();
-        wg_trsm_b<K>(Ls, (long)P * P, P, q.srd + c.coff, q.xlen, P, w, P, P, 1, tid);
+        if (P <= 64) {
+            if (tid < 64) {
+                mw<K> b = tid < P ? mul<K>(ldx<K>(w, P, tid), ldx<K>(q.srd + c.coff, q.xlen, tid)) : zero<K>();
+                b = wave_trsv_b<K>(Ls, (long)P * P, P, P, b, tid);
+                if (tid < P) stx<K>(w, P, tid, b);
+            }
+            __syncthreads();
+        } else {
+            wg_trsm_b<K>(Ls, (long)P * P, P, q.srd + c.coff, q.xlen, P, w, P, P, 1, tid);
+        }
     } else {
         __syncthreads();
         wg_trsm_b<K>(q.Sb + c.Soff, q.Slen, P, q.srd + c.coff, q.xlen, P, w, P, P, 1, tid);
