@@ -186,8 +186,33 @@ __device__ mwa::mw<K> mwi_sum_part(const MwDev &q, const MwIpmDev &p, int slot) 
 template <int K, int DK>
 __global__ void k_mwi_scalar(const MwDev q, const MwIpmDev p, int stage, int iter) {
     using namespace mwk;
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const long SP = MSC_COUNT;
+    if (stage == 4) {                              // objectives of the new iterate (:793-804, 844-847): the two dot products over one wave
+        const int lane = threadIdx.x;
+        acc<K> s;
+        acc_zero<K>(s);
+        for (long i = lane; i < q.xlen; i += 64) acc_fma<K, K, DK>(s, ldx<K>(p.x, q.xlen, i), ldx<DK>(p.c, q.xlen, i), p.sgn);
+        mw<K> cx = lanes_sum<K, 64>(acc_result<K>(s));
+        acc_zero<K>(s);
+        for (int a = lane; a < q.N; a += 64) acc_fma<K, K, DK>(s, ldx<K>(p.y, q.N, a), ldx<DK>(p.b, q.N, a));
+        mw<K> by = lanes_sum<K, 64>(acc_result<K>(s));
+        if (lane != 0) return;
+        mw<K> dobj = add_d<K>(cx, p.constant);
+        acc_zero<K>(s);
+        acc_add<K, K>(s, mwi_sum_part<K>(q, p, 4));
+        acc_add<K, K>(s, by);
+        acc_add_d<K>(s, p.constant);
+        mw<K> pobj = acc_result<K>(s);
+        mw<K> den = abs<K>(add<K>(dobj, pobj));
+        if (less<K>(den, from_double<K>(1.0))) den = from_double<K>(1.0);
+        mw<K> gap = div<K>(abs<K>(sub<K>(dobj, pobj)), den);
+        stx<K>(p.sc, SP, MSC_DOBJ, dobj); stx<K>(p.sc, SP, MSC_POBJ, pobj); stx<K>(p.sc, SP, MSC_GAP, gap);
+        p.rec[MREC_DOBJ] = dobj.l[0]; p.rec[MREC_POBJ] = pobj.l[0]; p.rec[MREC_GAP] = gap.l[0];
+        p.rec[MREC_ERR] = p.flags[1];
+        p.rec[MREC_PDFEAS] = p.flags[0];
+        return;
+    }
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (stage == 0) {                              // start of the iteration: mu, mu_p  (src/solver.jl:369-380)
         mw<K> xy = mwi_sum_part<K>(q, p, 0);
         mw<K> mu = div<K>(xy, from_double<K>((double)p.Ktot));
@@ -248,26 +273,9 @@ __global__ void k_mwi_scalar(const MwDev q, const MwIpmDev p, int stage, int ite
         p.sc[MSC_COUNT * 0 + 10] = al[0];                          // slots 10 / 11 of limb plane 0: alpha_d / alpha_p as plain doubles
         p.sc[MSC_COUNT * 0 + 11] = al[1];
         p.rec[MREC_ERR] = p.flags[1];
-    } else if (stage == 4) {                       // objectives of the new iterate (:793-804, 844-847)
-        acc<K> s;
-        acc_zero<K>(s);
-        for (long i = 0; i < q.xlen; i++) acc_fma<K, K, DK>(s, ldx<K>(p.x, q.xlen, i), ldx<DK>(p.c, q.xlen, i), p.sgn);
-        acc_add_d<K>(s, p.constant);
-        mw<K> dobj = acc_result<K>(s);
-        acc_zero<K>(s);
-        acc_add<K, K>(s, mwi_sum_part<K>(q, p, 4));
-        for (int a = 0; a < q.N; a++) acc_fma<K, K, DK>(s, ldx<K>(p.y, q.N, a), ldx<DK>(p.b, q.N, a));
-        acc_add_d<K>(s, p.constant);
-        mw<K> pobj = acc_result<K>(s);
-        mw<K> den = abs<K>(add<K>(dobj, pobj));
-        if (less<K>(den, from_double<K>(1.0))) den = from_double<K>(1.0);
-        mw<K> gap = div<K>(abs<K>(sub<K>(dobj, pobj)), den);
-        stx<K>(p.sc, SP, MSC_DOBJ, dobj); stx<K>(p.sc, SP, MSC_POBJ, pobj); stx<K>(p.sc, SP, MSC_GAP, gap);
-        p.rec[MREC_DOBJ] = dobj.l[0]; p.rec[MREC_POBJ] = pobj.l[0]; p.rec[MREC_GAP] = gap.l[0];
-        p.rec[MREC_ERR] = p.flags[1];
-        p.rec[MREC_PDFEAS] = p.flags[0];
     }
 }
+
 
 // ---- R = mu_s I - X Y [- dX dY]  (compute_residual_R!, src/solver.jl:961-983) ------------------------------------------
 template <int K>
@@ -429,15 +437,18 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_rows(const MwDev q, const MwIpmDe
 template <int K, int DK>
 __global__ __launch_bounds__(MW_NT) void k_mwi_pv(const MwDev q, const MwIpmDev p) {
     using namespace mwk;
-    const int a = blockIdx.x * MW_NT + threadIdx.x;
-    if (a >= q.N) return;
+    const int a = blockIdx.x * (MW_NT / 8) + threadIdx.x / 8, sub = threadIdx.x % 8;      // eight lanes per free variable
+    const bool live = a < q.N;
+    const int aa = live ? a : 0;
     acc<K> s;
     acc_zero<K>(s);
-    acc_add<K, DK>(s, ldx<DK>(p.b, q.N, a), p.sgn);
-    for (long g = 0; g < q.xlen; g++) acc_fma<K, K, DK>(s, ldx<K>(p.x, q.xlen, g), ldx<DK>(q.B, q.Bp, g + (long)a * q.xlen), -1.0);
-    mw<K> v = acc_result<K>(s);
-    atomic_max_abs(&p.fmax[2], v.l[0]);
-    stx<K>(p.pv, q.N, a, v);
+    if (sub == 0) acc_add<K, DK>(s, ldx<DK>(p.b, q.N, aa), p.sgn);
+    for (long g = sub; g < q.xlen; g += 8) acc_fma<K, K, DK>(s, ldx<K>(p.x, q.xlen, g), ldx<DK>(q.B, q.Bp, g + (long)aa * q.xlen), -1.0);
+    mw<K> v = lanes_sum<K, 8>(acc_result<K>(s));
+    if (live && sub == 0) {
+        atomic_max_abs(&p.fmax[2], v.l[0]);
+        stx<K>(p.pv, q.N, a, v);
+    }
 }
 
 // ---- which 0: Z = sym(X^-1 (P Y - R)) (:1501-1514);  which 1: dY = sym(X^-1 (R - dX Y)) (:1597-1613); both into dY --------
@@ -483,8 +494,9 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_Z(const MwDev q, const MwIpmDev p
 // ---- compute_step_length (:1620-1693) per block: smallest eigenvalue of L^-1 dM L^-T, L = chol(M) -----------------------
 // which 0: (X, dX) with the factors of this iteration; which 1: (Y, dY), factored here
 template <int K>
-__global__ __launch_bounds__(MW_NT) void k_mwi_step(const MwDev q, const MwIpmDev p, int which) {
+__global__ __launch_bounds__(MW_NT) void k_mwi_step(const MwDev q, const MwIpmDev p) {
     using namespace mwk;
+    const int which = blockIdx.y;                       // both step lengths in one launch
     const MwBlk &k = q.blk[blockIdx.x];
     const int n = k.n, tid = threadIdx.x;
     const long nn = (long)n * n;
@@ -690,7 +702,7 @@ static int mw_ipm_objectives(clrs_mw_ctx *c) {
     const MwIpmDev &p = c->ipm->d;
     MW_DISPATCH(c, {
         hipLaunchKernelGGL((k_mwi_dots<KK, DD>), dim3(q.NB), dim3(MW_NT), (size_t)KK * 8 * 8, c->stream, q, p, 4);
-        hipLaunchKernelGGL((k_mwi_scalar<KK, DD>), dim3(1), dim3(1), 0, c->stream, q, p, 4, c->ipm->iter);
+        hipLaunchKernelGGL((k_mwi_scalar<KK, DD>), dim3(1), dim3(64), 0, c->stream, q, p, 4, c->ipm->iter);
     });
     MWCHECK(hipGetLastError());
     return 0;
@@ -777,7 +789,7 @@ extern "C" int clrs_mw_ipm_iterate(clrs_mw_ctx *c, clrs_ipm_record *out) {
         if (q.T) hipLaunchKernelGGL((k_mwi_coef<KK, DD>), dim3((unsigned)((q.T + MW_NT - 1) / MW_NT)), dim3(MW_NT), 0, c->stream, q, p, (const double *)p.x);
         hipLaunchKernelGGL((k_mwi_wA<KK, DD>), dim3((maxnn + MW_NT - 1) / MW_NT, q.NB), dim3(MW_NT), 0, c->stream, q, p, 0);
         hipLaunchKernelGGL((k_mwi_rows<KK, DD>), dim3((unsigned)((q.xlen + MW_NT - 1) / MW_NT)), dim3(MW_NT), 0, c->stream, q, p, 0);
-        if (q.N) hipLaunchKernelGGL((k_mwi_pv<KK, DD>), dim3((q.N + MW_NT - 1) / MW_NT), dim3(MW_NT), 0, c->stream, q, p);
+        if (q.N) hipLaunchKernelGGL((k_mwi_pv<KK, DD>), dim3((q.N + MW_NT / 8 - 1) / (MW_NT / 8)), dim3(MW_NT), 0, c->stream, q, p);
         hipLaunchKernelGGL((k_mwi_scalar<KK, DD>), dim3(1), dim3(1), 0, c->stream, q, p, 1, st->iter);
     });
     MWCHECK(hipGetLastError());
@@ -788,8 +800,7 @@ extern "C" int clrs_mw_ipm_iterate(clrs_mw_ctx *c, clrs_ipm_record *out) {
     });
     if ((rc = mw_ipm_direction(c, 1))) return rc;
     MW_DISPATCH(c, {
-        hipLaunchKernelGGL(k_mwi_step<KK>, dim3(q.NB), dim3(MW_NT), st->sm_step, c->stream, q, p, 0);
-        hipLaunchKernelGGL(k_mwi_step<KK>, dim3(q.NB), dim3(MW_NT), st->sm_step, c->stream, q, p, 1);
+        hipLaunchKernelGGL(k_mwi_step<KK>, dim3(q.NB, 2), dim3(MW_NT), st->sm_step, c->stream, q, p);
         hipLaunchKernelGGL((k_mwi_scalar<KK, DD>), dim3(1), dim3(1), 0, c->stream, q, p, 3, st->iter);
         hipLaunchKernelGGL(k_mwi_update<KK>, dim3((unsigned)std::min<i64>(1024, (q.xylen + q.xlen + q.N + MW_NT - 1) / MW_NT)), dim3(MW_NT), 0, c->stream, q, p);
     });

@@ -628,11 +628,26 @@ def solvesdp_device(sdp, ctx: Optional[SchurContext] = None, device: int = 0, ma
                     omega_p: float = 1e4, omega_d: float = 1e4,
                     duality_gap_threshold: float = 1e-7, dual_error_threshold: float = 1e-9, primal_error_threshold: float = 1e-9,
                     max_complementary_gap: float = 1e100, need_dual_feasible: bool = False, need_primal_feasible: bool = False,
-                    verbose: bool = False, step_length_threshold: float = 1e-7, safe_step: bool = True) -> SolveResult:
+                    verbose: bool = False, step_length_threshold: float = 1e-7, safe_step: bool = True,
+                    prec: Optional[int] = None, limbs: Optional[int] = None) -> SolveResult:
     """`solvesdp` (src/solver.jl:100-744) with the whole loop body on the GPU: residuals, both search directions (through
     the Schur assembly / factor / solve of the path), step lengths and the update never leave HBM; the host reads one record
     per iteration and decides termination (src/solver.jl:921-950).  Same keywords and defaults as `solvesdp` above.
-    Raises ClrsError when a PSD block is too large for the LDS-resident kernels (use `solvesdp` then)."""
+    Raises ClrsError when a PSD block is too large for the LDS-resident kernels (use `solvesdp` then).
+
+    `prec` (bits, the reference's keyword, src/solver.jl:73) or `limbs` selects the multi-word path (`mw.solvesdp_mw`): the same loop
+    with every number `limbs` fp64 words (prec = 256 -> 5).  The fp64 defaults above (omega 1e4, gap 1e-7, errors 1e-9) are then
+    replaced by the reference's own (1e10, 1e-15, 1e-30) unless given explicitly."""
+    if prec is not None or limbs is not None:
+        from .mw import solvesdp_mw
+        kw = dict(maxiterations=maxiterations, beta_infeasible=beta_infeasible, beta_feasible=beta_feasible, gamma=gamma,
+                  max_complementary_gap=max_complementary_gap, need_dual_feasible=need_dual_feasible,
+                  need_primal_feasible=need_primal_feasible, verbose=verbose, step_length_threshold=step_length_threshold, safe_step=safe_step)
+        if (omega_p, omega_d) != (1e4, 1e4):
+            kw.update(omega_p=omega_p, omega_d=omega_d)
+        if (duality_gap_threshold, dual_error_threshold, primal_error_threshold) != (1e-7, 1e-9, 1e-9):
+            kw.update(duality_gap_threshold=duality_gap_threshold, dual_error_threshold=dual_error_threshold, primal_error_threshold=primal_error_threshold)
+        return solvesdp_mw(sdp, limbs=limbs, prec=prec, device=device, **kw)
     f = sdp if isinstance(sdp, FlatSDP) else flatten(sdp)
     own_ctx = ctx is None
     if ctx is None:

@@ -829,3 +829,41 @@ def test_sdpa_x64_config5_as_named(oracle_built):
     ro = Oracle(f, quad=False).solvesdp(omega_p=1e4, omega_d=1e4, duality_gap_threshold=1e-7, dual_error_threshold=1e-9, primal_error_threshold=1e-9)
     assert r.error_code == 0 and ro["error_code"] == 0, (r.status, r.error_code, ro["error_code"])
     assert abs(r.primal_objective - ro["p_obj"]) <= 1e-6 * max(1.0, abs(ro["p_obj"]))
+
+
+def test_device_loop_beta_follows_the_reference_order_across_the_feasibility_flip(oracle_built):
+    """beta_c of the iteration in which the iterate becomes feasible is chosen with the PREVIOUS feasibility
+    (src/solver.jl:429-434 before :441-447).  The per-iteration (mu, beta_c) columns of the fp64 device loop agree with the oracle's."""
+    from clrs_amd.solver import solvesdp_device
+    from oracle.oracle import Oracle
+    f = flat("delsarte_3_10")
+    r = solvesdp_device(f)
+    ro = Oracle(f, quad=False).solvesdp(omega_p=1e4, omega_d=1e4, duality_gap_threshold=1e-7, dual_error_threshold=1e-9, primal_error_threshold=1e-9)
+    assert r.iterations == ro["iterations"]
+    flips = 0
+    for it in range(r.iterations):
+        assert abs(r.history[it, 10] - ro["hist"][it, 10]) <= 1e-6 * max(1.0, ro["hist"][it, 10]), (it, r.history[it, 10], ro["hist"][it, 10])
+        assert abs(r.history[it, 1] - ro["hist"][it, 1]) <= 1e-5 * ro["hist"][it, 1]
+        if it and (r.history[it, 10] == 0.1) != (r.history[it - 1, 10] == 0.1):
+            flips += 1
+    assert flips >= 1
+
+
+def test_ipm_context_reused_for_another_objective(oracle_built):
+    """clrs_ipm_create on a context that already holds an iteration state loads the new C, c, b (it used to solve the first
+    problem again)."""
+    import copy
+    from clrs_amd.solver import SchurContext, solvesdp_device
+    from oracle.oracle import Oracle
+    f = flat("polyopt8")
+    g = copy.copy(f)
+    g.c = f.c * 2.0
+    g.c_lo = f.c_lo * 2.0
+    ctx = SchurContext(f)
+    r1 = solvesdp_device(f, ctx=ctx)
+    r2 = solvesdp_device(g, ctx=ctx)
+    ro2 = Oracle(g, quad=False).solvesdp(omega_p=1e4, omega_d=1e4, duality_gap_threshold=1e-7, dual_error_threshold=1e-9, primal_error_threshold=1e-9)
+    assert r1.error_code == 0 and r2.error_code == 0
+    assert abs(r2.primal_objective - ro2["p_obj"]) <= 1e-6 * max(1.0, abs(ro2["p_obj"]))
+    assert abs(r2.primal_objective - r1.primal_objective) > 1e-3 * max(1.0, abs(r1.primal_objective))
+    ctx.close()

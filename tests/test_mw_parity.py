@@ -396,3 +396,36 @@ def test_mw_rccl_exchange_inside_the_c_abi_one_rank(oracle_built):
     assert np.array_equal(dx0, dx1) and np.array_equal(dy0, dy1)
     c.comm_destroy()
     c.close()
+
+
+def test_solvesdp_device_with_the_reference_prec_keyword():
+    """`solvesdp_device(sdp, prec=256)`: the reference's `prec` keyword (src/solver.jl:73) selects the limb count; the north-star
+    instance ends Optimal at the pinned objective (test/runtests_solver.jl:19-20)."""
+    from clrs_amd.solver import solvesdp_device
+    r = solvesdp_device(flat("ce_8_15"), prec=256)
+    assert r.error_code == 0 and r.status == "Optimal" and r.timings["limbs"] == 5
+    assert abs(r.primal_objective - PI4_384) <= 1e-4
+
+
+def test_fp64_assembly_paths_on_the_trajectory_fixture():
+    """The fp64 assembly kernels (every path) on the fp64 heads of the trajectory iterates against the fixture's S: fp64 accuracy times
+    cond(X) of the iterate (1, 4, 2^38, 2^52 at iterations 1, 2, 28, 55) -- the late iterates are beyond fp64 by their conditioning
+    alone, which is the reason for the multi-word path; the factorisation of that S fails in fp64 at every iterate."""
+    import os
+    from clrs_amd.solver import SchurContext, SolverFailure
+    f = flat("ce_8_15")
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ce_8_15_traj.npz"))
+    for kw in (dict(), dict(wave3=False, wave2=True), dict(wave2=False), dict(wave=False), dict(fused=False)):
+        ctx = SchurContext(f, **kw)
+        for s, it in enumerate(g["iters"]):
+            X, Y = g["X"][s][0].copy(), g["Y"][s][0].copy()
+            try:
+                Xc = ctx.cholesky_blocks(X)
+            except SolverFailure:
+                assert COND_X_BITS[int(it)] >= 38, it        # X itself is not positive definite to fp64 accuracy on the late iterates
+                continue
+            S, _ = ctx.compute_S_integrated(Xc, Y)
+            err = np.max(np.abs(S - g["S"][s][0])) / np.max(np.abs(g["S"][s][0]))
+            assert err <= 2.0 ** -(53 - 10 - COND_X_BITS[int(it)]) or COND_X_BITS[int(it)] >= 43, (kw, it, err)
+            assert ctx.factor() > 0
+        ctx.close()
