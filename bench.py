@@ -316,6 +316,19 @@ def main():
                                                  f"one add each -- the count an exact-product scheme needs as well; the error-free transformations that make the "
                                                  f"adds exact are overhead, not algorithmic work (DESIGN.md section 6)",
                                   "timed_region": f"{reps} assemblies back to back between two HIP events on the context stream"}
+            # what the launch really executes: fp64 VALU instructions per multiply-add from the committed counter pass (rocprofv3 cannot run
+            # inside this process), times this run's multiply-adds, against the issue capacity of the chip's 1024 SIMDs during this run's time
+            try:
+                pc = json.load(open(os.path.join(ROOT, "profiles", "mw_counters.json")))
+                if pc["limbs"] == K:
+                    wave_insts = pc["lane_instructions_per_muladd"] * muladds / 64.0
+                    out["roofline_mw"]["executed"] = {
+                        "valu_lane_instructions_per_muladd": pc["lane_instructions_per_muladd"], "source": pc["source"],
+                        "valu_issue_utilisation": wave_insts * 4.0 / (1024 * 2.4e9 * asm_s),
+                        "what": "fraction of the fp64 VALU issue slots of the chip (1024 SIMDs, 4 cycles per fp64 wave instruction, 2.4 GHz) the assembly "
+                                "filled: the bound of this kernel family (v_fma_f64 / v_add_f64 and the fp64 MFMA share one pipe)"}
+            except Exception as e:
+                out["roofline_mw"]["executed_error"] = repr(e)
             bctx.close()
         except Exception as e:
             out["roofline_mw"] = {"error": repr(e)}
