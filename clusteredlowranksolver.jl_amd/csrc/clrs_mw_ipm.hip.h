@@ -491,10 +491,32 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_Z(const MwDev q, const MwIpmDev p
     }
 }
 
+// W = L^-1 dM L^-T through two forward substitutions and a transposition (:1651-1655), then its fp64 symmetrisation
+template <int K, class PF, class PR, class PW>
+__device__ __forceinline__ void mwi_step_congruence(PF F, PR rd, PW W, long wplane, long nn, int n, const double *dMg, long gplane, mwk::lds_d *Wd, int tid) {
+    using namespace mwk;
+    wg_copy<K>(W, wplane, n, dMg, gplane, n, n, n, tid);
+    __syncthreads();
+    wg_trsm_f<K>(F, nn, n, rd, n, n, W, wplane, n, n, tid);                              // :1651
+    for (int e = tid; e < nn; e += MW_NT) {                                              // transpose :1652
+        const int i = e % n, c = e / n;
+        if (c >= i) continue;
+        mw<K> a = ldx<K>(W, wplane, i + (long)c * n), b2 = ldx<K>(W, wplane, c + (long)i * n);
+        stx<K>(W, wplane, i + (long)c * n, b2);
+        stx<K>(W, wplane, c + (long)i * n, a);
+    }
+    __syncthreads();
+    wg_trsm_f<K>(F, nn, n, rd, n, n, W, wplane, n, n, tid);                              // :1655
+    for (int e = tid; e < nn; e += MW_NT) {
+        const int i = e % n, c = e / n;
+        Wd[e] = 0.5 * ((double)W[i + (long)c * n] + (double)W[c + (long)i * n]);         // heads of the limbs: the Float64 matrix of :1659
+    }
+}
+
 // ---- compute_step_length (:1620-1693) per block: smallest eigenvalue of L^-1 dM L^-T, L = chol(M) -----------------------
 // which 0: (X, dX) with the factors of this iteration; which 1: (Y, dY), factored here
 template <int K>
-__global__ __launch_bounds__(MW_NT) void k_mwi_step(const MwDev q, const MwIpmDev p) {
+__global__ __launch_bounds__(MW_NT) void k_mwi_step(const MwDev q, const MwIpmDev p, int w_in_lds) {
     using namespace mwk;
     const int which = blockIdx.y;                       // both step lengths in one launch
     const MwBlk &k = q.blk[blockIdx.x];
@@ -509,8 +531,12 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_step(const MwDev q, const MwIpmDe
         }
         return;
     }
-    // LDS: F (row-scaled factor), W, rd, the fp64 matrix and the eigenvalue work space, the broadcast slot of the factorisation
-    lds_d *F = MW_LDS, *W = F + (long)K * nn, *rd = W + (long)K * nn, *Wd = rd + (long)K * n, *work = Wd + nn, *bc = work + 3 * n + 2 * MW_NT;
+    // LDS: F (row-scaled factor), [W], rd, the fp64 matrix and the eigenvalue work space, the broadcast slot of the factorisation.
+    // Blocks too large for two multi-word matrices in LDS keep W in global memory (the R and P buffers are dead at this point of the iteration).
+    lds_d *F = MW_LDS;
+    lds_d *Wl = F + (long)K * nn;
+    lds_d *rd = w_in_lds ? Wl + (long)K * nn : Wl;
+    lds_d *Wd = rd + (long)K * n, *work = Wd + nn, *bc = work + 3 * n + 2 * MW_NT;
     if (which == 0) {
         wg_copy<K>(F, nn, n, q.Xf + k.xyoff, q.xylen, n, n, n, tid);
         for (int i = tid; i < n; i += MW_NT) stx<K>(rd, n, i, ldx<K>(q.xrd + k.rd_off, q.xrdlen, i));
@@ -528,22 +554,8 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_step(const MwDev q, const MwIpmDe
         }
         __syncthreads();
     }
-    wg_copy<K>(W, nn, n, dMg, q.xylen, n, n, n, tid);
-    __syncthreads();
-    wg_trsm_f<K>(F, nn, n, rd, n, n, W, nn, n, n, tid);                                  // :1651
-    for (int e = tid; e < nn; e += MW_NT) {                                              // transpose :1652
-        const int i = e % n, c = e / n;
-        if (c >= i) continue;
-        mw<K> a = ldx<K>(W, nn, i + (long)c * n), b2 = ldx<K>(W, nn, c + (long)i * n);
-        stx<K>(W, nn, i + (long)c * n, b2);
-        stx<K>(W, nn, c + (long)i * n, a);
-    }
-    __syncthreads();
-    wg_trsm_f<K>(F, nn, n, rd, n, n, W, nn, n, n, tid);                                  // :1655
-    for (int e = tid; e < nn; e += MW_NT) {
-        const int i = e % n, c = e / n;
-        Wd[e] = 0.5 * (W[i + (long)c * n] + W[c + (long)i * n]);                         // heads of the limbs: the Float64 matrix of :1659
-    }
+    if (w_in_lds) mwi_step_congruence<K>(F, rd, Wl, nn, nn, n, dMg, q.xylen, Wd, tid);
+    else mwi_step_congruence<K>(F, rd, (which == 0 ? p.R : p.Pm) + k.xyoff, q.xylen, nn, n, dMg, q.xylen, Wd, tid);    // R and P are dead here; one each
     __syncthreads();
     const double ev = wg_min_eig(Wd, n, work, tid);
     if (tid == 0) p.eig[(long)which * q.NB + blockIdx.x] = ev - 1e-5;                    // :1662
@@ -608,7 +620,7 @@ struct MwIpm {
     int iter = 0;
     double *h_rec = nullptr;      // pinned
     size_t sm_Z = 0, sm_step = 0;
-    bool lds_ZL = false;
+    bool lds_ZL = false, step_w_lds = true;
     ~MwIpm() { if (h_rec) (void)hipHostFree(h_rec); }
 };
 
@@ -664,7 +676,9 @@ extern "C" int clrs_mw_ipm_create_ex(clrs_mw_ctx *c, const clrs_ipm_data *data, 
         if (nnK > lim) return mw_fail(CLRS_ERR_INVALID, "device-resident multi-word iteration needs PSD blocks that fit in LDS");
         st->lds_ZL = 3 * nnK <= lim;
         st->sm_Z = (st->lds_ZL ? 3 : 1) * nnK * 8;
-        const size_t stepd = 2 * nnK + (size_t)K * maxn + maxn * maxn + 3 * maxn + 2 * MW_NT + K + 1 + 8;
+        const size_t step_rest = (size_t)K * maxn + maxn * maxn + 3 * maxn + 2 * MW_NT + K + 1 + 8;
+        st->step_w_lds = 2 * nnK + step_rest <= lim;
+        const size_t stepd = (st->step_w_lds ? 2 : 1) * nnK + step_rest;
         if (stepd > lim) return mw_fail(CLRS_ERR_INVALID, "device-resident multi-word iteration needs PSD blocks that fit in LDS");
         st->sm_step = stepd * 8;
         MW_DISPATCH(c, {
@@ -800,7 +814,7 @@ extern "C" int clrs_mw_ipm_iterate(clrs_mw_ctx *c, clrs_ipm_record *out) {
     });
     if ((rc = mw_ipm_direction(c, 1))) return rc;
     MW_DISPATCH(c, {
-        hipLaunchKernelGGL(k_mwi_step<KK>, dim3(q.NB, 2), dim3(MW_NT), st->sm_step, c->stream, q, p);
+        hipLaunchKernelGGL(k_mwi_step<KK>, dim3(q.NB, 2), dim3(MW_NT), st->sm_step, c->stream, q, p, st->step_w_lds ? 1 : 0);
         hipLaunchKernelGGL((k_mwi_scalar<KK, DD>), dim3(1), dim3(1), 0, c->stream, q, p, 3, st->iter);
         hipLaunchKernelGGL(k_mwi_update<KK>, dim3((unsigned)std::min<i64>(1024, (q.xylen + q.xlen + q.N + MW_NT - 1) / MW_NT)), dim3(MW_NT), 0, c->stream, q, p);
     });

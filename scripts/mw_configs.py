@@ -1,0 +1,37 @@
+"""Every BASELINE configuration solved at the reference's precision (prec = 256 -> 5 limbs, the reference's default options unless
+its own test sets others) on the GPU, against the CPU oracle at 256 bits on the same host.  usage: mw_configs.py [names...]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from tests.util import flat
+from clrs_amd.mw import solvesdp_mw
+from oracle.oracle import Oracle
+
+CASES = [("delsarte_8_3", "config 1: delsarte(8,3,1/2)", 240.0, {}),
+         ("delsarte_3_10", "config 1: delsarte(3,10,1/2)", 13.158314, {}),
+         ("polyopt40", "config 2: polyopt 2d=40", None, {}),
+         ("ce_8_15", "config 3: cohnelkies(8,15)", 0.25366950790104804, {}),
+         ("ns_8_15_2", "config 3: Nsphere_packing(8,15,[1/2,1/2],2)", 0.25366950790104804, {}),
+         ("threepoint_4", "config 4 (reference's test): three_point_spherical_codes(4,1/6,-1,4)", 10.0, dict(omega_p=1e3, omega_d=1e3)),
+         ("threepoint_3_8_8", "config 4 as named: three_point_spherical_codes(3,1/2,8,8)", None, dict(omega_p=1e3, omega_d=1e3)),
+         ("sdpa_example", "config 5: example.dat-s", 30.0, {}),
+         ("sdpa_x64", "config 5 as named: sdpa_scaled(64,32,256)", None, {})]
+names = sys.argv[1:]
+print("%-72s %5s %6s %22s %10s %10s %8s" % ("instance", "limbs", "iters", "primal objective", "GPU s", "CPU s", "speedup"))
+for name, label, expect, kw in CASES:
+    if names and name not in names:
+        continue
+    f = flat(name)
+    solvesdp_mw(f, limbs=5, maxiterations=2, **kw)          # context / code warm-up
+    r = solvesdp_mw(f, limbs=5, **kw)
+    cpu = ""
+    sp = ""
+    if name not in ("threepoint_3_8_8",) or "--cpu-all" in sys.argv:
+        o = Oracle(f, mp_bits=256)
+        o.set_num_threads(1)
+        t0 = time.time(); ro = o.solvesdp(**kw); tc = time.time() - t0
+        cpu = "%.2f" % tc
+        sp = "%.1fx" % (tc / r.time_total)
+        assert abs(ro["p_obj"] - r.primal_objective) <= 1e-9 * max(1.0, abs(ro["p_obj"])), (name, ro["p_obj"], r.primal_objective)
+    ok = "" if expect is None else (" (pinned %.8g: %s)" % (expect, "ok" if abs(r.primal_objective - expect) <= 1e-4 * max(1, abs(expect)) else "MISMATCH"))
+    print("%-72s %5d %6d %22.15g %10.3f %10s %8s  %s code %d%s" % (label, 5, r.iterations, r.primal_objective, r.time_total, cpu, sp, r.status, r.error_code, ok), flush=True)

@@ -798,6 +798,12 @@ def test_three_point_bound_n3_2d16_config4_as_named(oracle_built):
     # cond(S) of this instance on these iterates is ~1e20 (why fp64 fails): what is left of 4 limbs
     assert mw_relerr(dx, dx_ref) <= 2.0 ** -(53 * K - 110), mw_relerr(dx, dx_ref)
     mctx.close()
+    # the whole solve at the reference's precision (5 limbs), omega = 1e3 as in the reference's three-point test: a valid three-point
+    # bound on the kissing number in dimension 3 (12 <= bound < 13; profiles/r02/c_configs_at_256_bits.txt: 12.5228 in 42 iterations)
+    from clrs_amd.mw import solvesdp_mw
+    r = solvesdp_mw(f, limbs=5, omega_p=1e3, omega_d=1e3)
+    assert r.error_code == 0 and r.status == "Optimal", (r.status, r.error_code, r.iterations)
+    assert 12.0 <= r.primal_objective < 13.0 and r.duality_gap < 1e-15
 
 
 def test_sdpa_x64_config5_as_named(oracle_built):
