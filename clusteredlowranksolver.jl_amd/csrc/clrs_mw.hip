@@ -93,6 +93,8 @@ struct clrs_mw_ctx {
     double cnt_mul = 0;                  // multi-word multiply-adds of one assembly (algorithmic)
     double cnt_factor = 0, cnt_solve = 0;
     struct MwIpm *ipm = nullptr;
+    double *d_bpFd = nullptr;            // scratch of the blocked factorisation (k_mw_bp_*)
+    size_t sm_bp_diag = 0, sm_bp_panel = 0;
     void *comm = nullptr;                // ncclComm_t when the library does the exchanges itself (clrs_mw_comm_init)
     bool local_factored = false, fwd_done = false;
 };
@@ -407,6 +409,10 @@ extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int dev
         int init[2] = {MW_INFO_NONE, MW_INFO_NONE};
         MWCHECK(hipMemcpy(info, init, sizeof(init), hipMemcpyHostToDevice));
     }
+    MW_TRY(mw_dmalloc(c, &c->d_bpFd, (i64)MW_PB * MW_PB * K));
+    c->sm_bp_diag = ((size_t)(K + 1) + (size_t)K * MW_PB * MW_PB + (size_t)K * MW_PB) * 8;
+    c->sm_bp_panel = ((size_t)K * MW_PB * MW_PB + (size_t)K * MW_PB * 32 + (size_t)K * MW_PB) * 8;
+    MW_DISPATCH(c, { MW_TRY(mw_set_lds(k_mw_bp_diag<KK>, c->sm_bp_diag)); MW_TRY(mw_set_lds(k_mw_bp_panel<KK>, c->sm_bp_panel)); });
     q.rank = 0; q.world = 1; q.gathered = 0;
     MW_TRY(mw_dmalloc(c, &q.Qg, (i64)N * N * K)); MW_TRY(mw_dmalloc(c, &q.ug, (i64)N * K));
     for (auto &e : c->ev) MWCHECK(hipEventCreate(&e));
@@ -565,6 +571,24 @@ extern "C" int clrs_mw_comm_destroy(clrs_mw_ctx *c) {
 extern "C" double *clrs_mw_q_gather_dev(clrs_mw_ctx *c) { return c ? c->d.Qg : nullptr; }
 extern "C" double *clrs_mw_u_gather_dev(clrs_mw_ctx *c) { return c ? c->d.ug : nullptr; }
 
+// blocked Cholesky of one matrix in global memory over many workgroups (clrs_mw_kernels.hip.h, k_mw_bp_*)
+static int mw_potrf_blocked(clrs_mw_ctx *c, const MwBp &m) {
+    const MwDev &q = c->d;
+    MW_DISPATCH(c, {
+        for (int j0 = 0; j0 < m.n; j0 += MW_PB) {
+            const int nb = std::min(MW_PB, m.n - j0), mm = m.n - j0 - nb;
+            hipLaunchKernelGGL(k_mw_bp_diag<KK>, dim3(1), dim3(MW_NT), c->sm_bp_diag, c->stream, q, m, j0);
+            if (mm > 0) {
+                hipLaunchKernelGGL(k_mw_bp_panel<KK>, dim3((mm + 31) / 32), dim3(MW_NT), c->sm_bp_panel, c->stream, q, m, j0);
+                hipLaunchKernelGGL(k_mw_bp_syrk<KK>, dim3((unsigned)(((i64)mm * (mm + 1) / 2 + MW_NT - 1) / MW_NT)), dim3(MW_NT), 0, c->stream, q, m, j0);
+            }
+        }
+        hipLaunchKernelGGL(k_mw_bp_finish<KK>, dim3((unsigned)std::min<i64>(1024, ((i64)m.n * m.n + MW_NT - 1) / MW_NT)), dim3(MW_NT), 0, c->stream, q, m);
+    });
+    MWCHECK(hipGetLastError());
+    return 0;
+}
+
 // L_j, LinvB_j of this rank's clusters and its partial Q into slot `rank` of the gather buffer
 extern "C" int clrs_mw_schur_factor_local_dev(clrs_mw_ctx *c) {
     if (!c) return mw_fail(CLRS_ERR_INVALID, "null context");
@@ -574,8 +598,14 @@ extern "C" int clrs_mw_schur_factor_local_dev(clrs_mw_ctx *c) {
     int rc;
     if ((rc = mw_reset_info(c, 0))) return rc;
     if (c->timing) MWCHECK(hipEventRecord(c->ev[2], c->stream));
+    MW_DISPATCH(c, { hipLaunchKernelGGL(k_mw_factor<KK>, dim3(q.J), dim3(MW_NT), c->sm_factor, c->stream, q); });
+    for (int j = 0; j < q.J; j++) {                     // clusters that do not fit in LDS: blocked over many workgroups
+        const MwClu &cl = c->clu[j];
+        if (cl.lds) continue;
+        MwBp m = {q.S + cl.Soff, q.srd + cl.coff, q.Sf + cl.Soff, q.Sb + cl.Soff, c->d_bpFd, q.Slen, q.xlen, q.Slen, cl.P, cl.P, j + 1, 0};
+        if ((rc = mw_potrf_blocked(c, m))) return rc;
+    }
     MW_DISPATCH(c, {
-        hipLaunchKernelGGL(k_mw_factor<KK>, dim3(q.J), dim3(MW_NT), c->sm_factor, c->stream, q);
         if (q.N > 0) hipLaunchKernelGGL((k_mw_linvb<KK, DD>), dim3((q.N + MW_BT - 1) / MW_BT, q.J), dim3(MW_NT), c->sm_factor, c->stream, q);
         if (c->timing) (void)hipEventRecord(c->ev[3], c->stream);
         if (q.N > 0) hipLaunchKernelGGL(k_mw_qgram<KK>, dim3((q.N * (q.N + 1) / 2 + MW_NT / MW_Q_W - 1) / (MW_NT / MW_Q_W)), dim3(MW_NT), 0, c->stream, q);
@@ -592,7 +622,14 @@ extern "C" int clrs_mw_schur_factor_finish_dev(clrs_mw_ctx *c) {
     if (!c->local_factored) return mw_fail(CLRS_ERR_STATE, "clrs_mw_schur_factor_finish before clrs_mw_schur_factor_local");
     MWCHECK(hipSetDevice(c->device));
     const MwDev &q = c->d;
-    MW_DISPATCH(c, { if (q.N > 0) hipLaunchKernelGGL(k_mw_potrf_q<KK>, dim3(1), dim3(MW_NT), c->sm_q, c->stream, q, c->lds_q ? 1 : 0); });
+    if (q.N > 0 && c->lds_q) {
+        MW_DISPATCH(c, { hipLaunchKernelGGL(k_mw_potrf_q<KK>, dim3(1), dim3(MW_NT), c->sm_q, c->stream, q, 1); });
+    } else if (q.N > 0) {
+        MW_DISPATCH(c, { hipLaunchKernelGGL(k_mw_qsum<KK>, dim3((unsigned)std::min<i64>(256, ((i64)q.N * q.N + MW_NT - 1) / MW_NT)), dim3(MW_NT), 0, c->stream, q); });
+        MwBp m = {q.Q, q.qrd, q.Qf, q.Qb, c->d_bpFd, (i64)q.N * q.N, (i64)q.N, (i64)q.N * q.N, q.N, q.N, q.J + 1, 0};
+        int rc = mw_potrf_blocked(c, m);
+        if (rc) return rc;
+    }
     MWCHECK(hipGetLastError());
     if (c->timing) MWCHECK(hipEventRecord(c->ev[5], c->stream));
     c->factored = true;

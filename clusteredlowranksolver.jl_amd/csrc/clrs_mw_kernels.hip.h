@@ -538,9 +538,8 @@ __global__ __launch_bounds__(MW_NT) void k_mw_factor(const MwDev q) {
         wg_copy<K>(M, (long)P * P, P, q.S + c.Soff, q.Slen, P, P, P, tid);
         __syncthreads();
         mw_factor_body<K>(q, c, j, M, (long)P * P, bc, tid);
-    } else {
-        mw_factor_body<K>(q, c, j, q.S + c.Soff, q.Slen, bc, tid);       // too large for LDS: in place in global memory
     }
+    // clusters too large for LDS are factored by the blocked, multi-workgroup path (k_mw_bp_*, driven by the host)
 }
 
 // LinvB_j = L_j^-1 B_j (src/solver.jl:1256-1261): the columns of B_j are independent, one workgroup per tile of MW_BT of them
@@ -636,15 +635,114 @@ __global__ __launch_bounds__(MW_NT) void k_mw_potrf_q(const MwDev q, int lds) {
         }
         __syncthreads();
         mw_potrf_q_body<K>(q, M, nn, bc, tid);
-    } else {
-        for (int e = tid; e < nn; e += MW_NT) {
-            acc<K> s;
-            acc_zero<K>(s);
-            for (int r = 0; r < q.world; r++) acc_add<K, K>(s, ldx<K>(q.Qg + (long)r * K * nn, nn, e));
-            stx<K>(q.Q, nn, e, acc_result<K>(s));
+    }
+    // a Q too large for LDS: k_mw_qsum + the blocked path (k_mw_bp_*)
+}
+
+// Q = sum over the ranks' partial sums (rank order), for the blocked factorisation of a Q that does not fit in LDS
+template <int K>
+__global__ __launch_bounds__(MW_NT) void k_mw_qsum(const MwDev q) {
+    using namespace mwk;
+    const long nn = (long)q.N * q.N;
+    for (long e = (long)blockIdx.x * MW_NT + threadIdx.x; e < nn; e += (long)gridDim.x * MW_NT) {
+        acc<K> s;
+        acc_zero<K>(s);
+        for (int r = 0; r < q.world; r++) acc_add<K, K>(s, ldx<K>(q.Qg + (long)r * K * nn, nn, e));
+        stx<K>(q.Q, nn, e, acc_result<K>(s));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Blocked Cholesky of a matrix that does not fit in LDS (clusters with P > ~60 at 5 limbs, Q with N > ~60), in place in
+// global memory, panel width MW_PB: per block column the diagonal block is factored by one workgroup in LDS (wg_potrf), the
+// panel below it is solved by one workgroup per 32 rows (the rows are independent), the trailing matrix is updated by
+// one thread per entry of its lower triangle (MW_PB-term dot products through the unnormalised accumulator) over as many
+// workgroups as it has entries / 256.  What a single workgroup spent on the rank-1 updates of a 256 x 256 matrix
+// (P^3/6 multiply-adds behind global-memory latency) is spread over the chip.
+// ---------------------------------------------------------------------------------------------------------------------
+#define MW_PB 32
+struct MwBp {                // one matrix being factored: planar M (leading dimension ld), reciprocal diagonal rd, scaled copies F, Bk
+    double *M, *rd, *F, *Bk, *Fd;      // Fd: scratch nb x nb, the row-scaled diagonal block of the current block column
+    mwi64 plane, rdplane, fplane;
+    int n, ld, code, which;            // info[which] = code on failure
+};
+template <int K>
+__global__ __launch_bounds__(MW_NT) void k_mw_bp_diag(const MwDev q, const MwBp m, int j0) {
+    using namespace mwk;
+    if (q.info[m.which] != MW_INFO_NONE) return;
+    const int nb = min(MW_PB, m.n - j0), tid = threadIdx.x;
+    lds_d *bc = MW_LDS, *D = MW_LDS + (K + 1), *rdl = D + (long)K * MW_PB * MW_PB;
+    wg_copy<K>(D, (long)nb * nb, nb, m.M + j0 + (long)j0 * m.ld, m.plane, m.ld, nb, nb, tid);
+    __syncthreads();
+    if (!wg_potrf<K>(D, (long)nb * nb, nb, nb, rdl, nb, bc, tid)) {
+        if (tid == 0) atomicMin(&q.info[m.which], m.code);
+        return;
+    }
+    for (int e = tid; e < nb * nb; e += MW_NT) {
+        const int i = e % nb, c = e / nb;
+        mw<K> v = ldx<K>(D, (long)nb * nb, e);
+        stx<K>(m.M, m.plane, (j0 + i) + (long)(j0 + c) * m.ld, i >= c ? v : zero<K>());
+        stx<K>(m.Fd, (long)MW_PB * MW_PB, i + (long)c * MW_PB, i > c ? mul<K>(v, ldx<K>(rdl, nb, i)) : zero<K>());
+    }
+    for (int i = tid; i < nb; i += MW_NT) stx<K>(m.rd, m.rdplane, j0 + i, ldx<K>(rdl, nb, i));
+}
+// rows below the diagonal block: X L_d^T = A_panel, 32 rows per workgroup
+template <int K>
+__global__ __launch_bounds__(MW_NT) void k_mw_bp_panel(const MwDev q, const MwBp m, int j0) {
+    using namespace mwk;
+    if (q.info[m.which] != MW_INFO_NONE) return;
+    const int nb = min(MW_PB, m.n - j0), tid = threadIdx.x;
+    const int r0 = j0 + nb + blockIdx.x * 32;
+    if (r0 >= m.n) return;
+    const int nr = min(32, m.n - r0);
+    lds_d *Fd = MW_LDS, *Bt = Fd + (long)K * MW_PB * MW_PB, *rdl = Bt + (long)K * MW_PB * 32;   // Bt: nb x nr, the tile transposed
+    wg_copy<K>(Fd, (long)MW_PB * MW_PB, MW_PB, m.Fd, (long)MW_PB * MW_PB, MW_PB, nb, nb, tid);
+    for (int i = tid; i < nb; i += MW_NT) stx<K>(rdl, nb, i, ldx<K>(m.rd, m.rdplane, j0 + i));
+    for (int e = tid; e < nb * nr; e += MW_NT) {
+        const int kcol = e % nb, r = e / nb;
+        stx<K>(Bt, (long)MW_PB * 32, kcol + (long)r * MW_PB, ldx<K>(m.M, m.plane, (r0 + r) + (long)(j0 + kcol) * m.ld));
+    }
+    __syncthreads();
+    wg_trsm_f<K>(Fd, (long)MW_PB * MW_PB, MW_PB, rdl, nb, nb, Bt, (long)MW_PB * 32, MW_PB, nr, tid);
+    for (int e = tid; e < nb * nr; e += MW_NT) {
+        const int kcol = e % nb, r = e / nb;
+        stx<K>(m.M, m.plane, (r0 + r) + (long)(j0 + kcol) * m.ld, ldx<K>(Bt, (long)MW_PB * 32, kcol + (long)r * MW_PB));
+    }
+}
+// trailing update: A[i, j] -= sum_c L[i, j0 + c] L[j, j0 + c], i >= j >= j0 + nb
+template <int K>
+__global__ __launch_bounds__(MW_NT) void k_mw_bp_syrk(const MwDev q, const MwBp m, int j0) {
+    using namespace mwk;
+    if (q.info[m.which] != MW_INFO_NONE) return;
+    const int nb = min(MW_PB, m.n - j0), t0 = j0 + nb, mm = m.n - t0;
+    const long e = (long)blockIdx.x * MW_NT + threadIdx.x;
+    if (e >= (long)mm * (mm + 1) / 2) return;
+    int ii, jj;
+    tri_index((int)e, ii, jj);
+    const int i = t0 + ii, j = t0 + jj;
+    acc<K> s;
+    acc_zero<K>(s);
+    acc_add<K, K>(s, ldx<K>(m.M, m.plane, i + (long)j * m.ld));
+    for (int c = 0; c < nb; c++) acc_fma<K, K, K>(s, ldx<K>(m.M, m.plane, i + (long)(j0 + c) * m.ld), ldx<K>(m.M, m.plane, j + (long)(j0 + c) * m.ld), -1.0);
+    stx<K>(m.M, m.plane, i + (long)j * m.ld, acc_result<K>(s));
+}
+// zero strict upper triangle and the scaled copies of the finished factor
+template <int K>
+__global__ __launch_bounds__(MW_NT) void k_mw_bp_finish(const MwDev q, const MwBp m) {
+    using namespace mwk;
+    if (q.info[m.which] != MW_INFO_NONE) return;
+    const long nn = (long)m.n * m.n;
+    for (long e = (long)blockIdx.x * MW_NT + threadIdx.x; e < nn; e += (long)gridDim.x * MW_NT) {
+        const int i = (int)(e % m.n), k = (int)(e / m.n);
+        if (i > k) {
+            const mw<K> l = ldx<K>(m.M, m.plane, i + (long)k * m.ld);
+            stx<K>(m.F, m.fplane, i + (long)k * m.ld, mul<K>(l, ldx<K>(m.rd, m.rdplane, i)));
+            stx<K>(m.Bk, m.fplane, k + (long)i * m.ld, mul<K>(l, ldx<K>(m.rd, m.rdplane, k)));
+        } else {
+            stx<K>(m.F, m.fplane, i + (long)k * m.ld, zero<K>());
+            if (i == k) stx<K>(m.Bk, m.fplane, i + (long)k * m.ld, zero<K>());
+            else stx<K>(m.M, m.plane, i + (long)k * m.ld, zero<K>());
         }
-        __syncthreads();
-        mw_potrf_q_body<K>(q, q.Q, nn, bc, tid);
     }
 }
 
