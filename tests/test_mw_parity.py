@@ -429,3 +429,86 @@ def test_fp64_assembly_paths_on_the_trajectory_fixture():
             assert err <= 2.0 ** -(53 - 10 - COND_X_BITS[int(it)]) or COND_X_BITS[int(it)] >= 43, (kw, it, err)
             assert ctx.factor() > 0
         ctx.close()
+
+
+# ---- breadth: random structures, handmade shapes, size limits, malformed input -------------------------------------------------
+def _check_mw_against_oracle(f, K, seed, amp=40, DL=2):
+    from clrs_amd.mw import MwSchurContext
+    from oracle.oracle import Oracle
+    X, Y = _iterates(f, K, seed=seed)
+    X, Y = _sym_limbs(f, X), _sym_limbs(f, Y)
+    o = Oracle(f, mp_bits=320, use_lo=(DL == 2))
+    ctx = MwSchurContext(f, limbs=K, data_limbs=DL)
+    pad = lambda a: np.vstack([a, np.zeros((1, a.shape[1]))])
+    Xc = ctx.cholesky_blocks(X)
+    S, AY = ctx.compute_S_integrated(Xc, Y)
+    S_ref, AY_ref = o.schur_assemble_mw(pad(Xc), pad(Y))
+    assert mw_relerr(S, S_ref) <= tol(K, 22), mw_relerr(S, S_ref)
+    if f.n_terms:
+        assert mw_relerr(AY, AY_ref, scale=max(1.0, np.max(np.abs(AY_ref[0])))) <= tol(K, 16)
+    o.set_S_mw(pad(S))
+    assert o.schur_factor() == 0 and ctx.factor() == 0
+    rng = np.random.default_rng(seed)
+    rx = mw_with_tails(rng.standard_normal(f.x_len), K, 1)
+    ry = mw_with_tails(rng.standard_normal(max(f.n_free, 1)), K, 2)[:, :f.n_free]
+    dx, dy = ctx.solve(rx, ry)
+    dx_ref, dy_ref = o.schur_solve_mw(pad(rx), pad(ry) if f.n_free else np.zeros((K + 1, 0)))
+    assert mw_relerr(dx, dx_ref) <= tol(K, 22 + 3 * amp), mw_relerr(dx, dx_ref)
+    if f.n_free:
+        assert mw_relerr(dy, dy_ref) <= tol(K, 22 + 3 * amp), mw_relerr(dy, dy_ref)
+    ctx.close()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_mw_random_structures(seed, oracle_built):
+    """Clusters of different sizes P <= 32 in one context, 1-3 low-rank blocks of different sides n <= 16 per cluster, 0-2 dense 1 x 1 blocks
+    touching a subset of the constraints, placed anywhere among them; 0-3 free variables (tests/util.py::random_simple_sdp)."""
+    import clrs_amd
+    from tests.util import random_simple_sdp
+    f = clrs_amd.flatten(random_simple_sdp(seed, J=3 + seed % 3, n_free=seed % 4, definite=True))
+    _check_mw_against_oracle(f, K=3 + seed % 3, seed=seed + 100)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(rank2=True), dict(m=2), dict(m=2, rank2=True)])
+def test_mw_handmade_shapes(kw, oracle_built):
+    """rank-2 terms, sub-blocks (m = 2), a dense block touching only some constraints, de-duplicated vectors (the shapes of
+    tests/test_hip_parity.py::_mini_sdp)."""
+    import clrs_amd
+    from tests.test_hip_parity import _mini_sdp
+    _check_mw_against_oracle(clrs_amd.flatten(_mini_sdp(**kw)), K=4, seed=3)
+
+
+@pytest.mark.parametrize("P,N", [(64, 64), (65, 7), (33, 65), (70, 0)])
+def test_mw_size_limits(P, N, oracle_built):
+    """The limits where the solve stage switches between the single-wave register form (P, N <= 64) and the workgroup form, and where
+    clusters leave LDS (4 limbs: P > ~68) for the blocked multi-workgroup factorisation: two clusters of exactly P constraints (four
+    low-rank blocks of side 16), N free variables."""
+    import clrs_amd
+    from tests.util import random_simple_sdp
+    f = clrs_amd.flatten(random_simple_sdp(2000 + P + N, J=2, n_free=N, fixed_P=P, max_n=16, lr_blocks=4))
+    _check_mw_against_oracle(f, K=4, seed=P + 2 * N, amp=50)
+
+
+def test_mw_malformed_descriptions_and_call_order():
+    """The multi-word ABI validates like the fp64 one: a term without its transposed partner (src/solver.jl:1009), calls out of order,
+    unsupported limb counts -- negative codes with a message, never a crash."""
+    import clrs_amd
+    from clrs_amd._lib import ClrsError
+    from clrs_amd.mw import MwSchurContext
+    from tests.test_hip_parity import _mini_sdp
+    sdp = _mini_sdp(m=2, drop_partner=True)
+    sdp.check = lambda: None
+    with pytest.raises(ClrsError, match="transposed partner"):
+        MwSchurContext(clrs_amd.flatten(sdp), limbs=4)
+    f = flat("polyopt8")
+    with pytest.raises(ClrsError, match="limbs"):
+        MwSchurContext(f, limbs=7)
+    ctx = MwSchurContext(f, limbs=3)
+    K = 3
+    with pytest.raises(ClrsError, match="before clrs_mw_schur_factor"):
+        ctx.solve(np.zeros((K, f.x_len)), np.zeros((K, f.n_free)))
+    with pytest.raises(ClrsError, match="before clrs_mw_schur_assemble"):
+        ctx.factor()
+    with pytest.raises(ValueError, match="planar limbs"):
+        ctx.cholesky_blocks(np.zeros(f.xy_len))
+    ctx.close()
