@@ -90,10 +90,12 @@ def sdpa_to_sdp(data: SDPAData) -> ClusteredLowRankSDP:
                                c=[data.c.copy()], C=[Cs], b=np.zeros(0))
 
 
-def sdpa_scaled(nb=64, bs=32, m=256, seed=64) -> SDPAData:
+def sdpa_scaled(nb=64, bs=32, m=256, seed=64, blocks_per_constraint=2) -> SDPAData:
     """BASELINE config 5 synthetic: m constraints, each a symmetric Gaussian
-    matrix on two random blocks; c_i = <A_i, I> so that Y = I is feasible; objective -(I + G G^T / bs)
-    so that the problem is bounded."""
+    matrix on `blocks_per_constraint` random blocks; c_i = <A_i, I> so that Y = I is feasible; objective -(I + G G^T / bs)
+    so that the problem is bounded.  `blocks_per_constraint = nb` makes every constraint matrix full block diagonal, like the
+    two constraints of test/example.dat-s (both touch both blocks): P dense matrices in EVERY block, the 7.5 GFLOP / 134 MB
+    assembly SURVEY.md section 8d quotes for (64, 32, 256)."""
     rng = np.random.default_rng(seed)
     sizes = [bs] * nb
     F = [[np.zeros((bs, bs)) for _ in range(nb)] for _ in range(m + 1)]
@@ -102,7 +104,7 @@ def sdpa_scaled(nb=64, bs=32, m=256, seed=64) -> SDPAData:
         F[0][blk] = -(np.eye(bs) + G @ G.T / bs)
     c = np.zeros(m)
     for i in range(1, m + 1):
-        for blk in rng.choice(nb, size=2, replace=False):
+        for blk in rng.choice(nb, size=min(blocks_per_constraint, nb), replace=False):
             G = rng.standard_normal((bs, bs))
             F[i][blk] = (G + G.T) / 2
             c[i - 1] += np.trace(F[i][blk])

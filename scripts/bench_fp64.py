@@ -335,7 +335,7 @@ def main(argv=None, emit=True):
         try:
             from clrs_amd.problems import sdpa_scaled, sdpa_to_sdp
             import clrs_amd as _cc
-            fd = _cc.flatten(sdpa_to_sdp(sdpa_scaled(nb=64, bs=32, m=256, seed=64)))
+            fd = _cc.flatten(sdpa_to_sdp(sdpa_scaled(nb=64, bs=32, m=256, seed=64, blocks_per_constraint=64)))
             dctx = SchurContext(fd, device=local_rank)
             dctx.set_stream(torch.cuda.current_stream().cuda_stream)
             dXd, dYd = seeded_iterates(fd, seed=7)
@@ -357,7 +357,8 @@ def main(argv=None, emit=True):
             out["roofline_dense"] = {"bound": "mfma", "phase": "schur_assemble, dense branch (src/solver.jl:1089-1104)", "kernel": ddom[0],
                                      "assembly_us": 1e6 * d_s, "achieved": dcnt["assemble_flops"] / d_s / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                                      "frac": dcnt["assemble_flops"] / d_s / 1e12 / FP64_PEAK_TFLOPS, "traffic": None,
-                                     "workload": "sdpa_scaled(nb=64, bs=32, m=256): 64 dense 32x32 blocks, P = 256 (BASELINE config 5 as named)",
+                                     "workload": "sdpa_scaled(nb=64, bs=32, m=256, blocks_per_constraint=64): 64 dense 32x32 blocks, P = 256 constraint matrices in EVERY block, like "
+                                                 "the two constraints of test/example.dat-s (BASELINE config 5 scaled x64; SURVEY.md section 8d: 7.5 GFLOP / 134 MB)",
                                      "algorithmic_flops": dcnt["assemble_flops"], "algorithmic_bytes": dcnt["assemble_bytes"],
                                      "flops_model": "P (6 n^3) + P^2 n^2 per block over the constraints present in it (SURVEY.md section 8d)",
                                      "kernels_us": {k: round(1e6 * v[2], 3) for k, v in dprof.items()}}

@@ -873,3 +873,28 @@ def test_ipm_context_reused_for_another_objective(oracle_built):
     assert abs(r2.primal_objective - ro2["p_obj"]) <= 1e-6 * max(1.0, abs(ro2["p_obj"]))
     assert abs(r2.primal_objective - r1.primal_objective) > 1e-3 * max(1.0, abs(r1.primal_objective))
     ctx.close()
+
+
+def test_sdpa_x64_full_block_diagonal_constraints(oracle_built):
+    """Config 5 with every constraint matrix full block diagonal (both constraints of test/example.dat-s touch both blocks): P = 256 dense
+    matrices in each of the 64 blocks -- the 7.5 GFLOP / 134 MB assembly of SURVEY.md section 8d, the instance `roofline_dense` of the bench
+    line is measured on.  Assembly against the fp64 oracle, symmetry, factor + solve."""
+    from clrs_amd.solver import SchurContext, compute_T_decomposition, solve_system
+    from oracle.oracle import Oracle
+    f = flat("sdpa_x64_full")
+    assert int(f.dense_ptr[-1]) == 64 * 256
+    X, Y = spd_iterates(f, seed=8)
+    Xc = chol_blocks_np(f, X)
+    o = Oracle(f, quad=False)
+    S_ref, _ = o.schur_assemble(Xc, Y)
+    assert o.schur_factor() == 0
+    rhs = np.random.default_rng(11).standard_normal(f.x_len)
+    dx_ref, _ = o.schur_solve(rhs, np.zeros(0))
+    ctx = SchurContext(f)
+    _, S, _ = compute_T_decomposition(ctx, Xc, Y, want_S=True)
+    assert np.max(np.abs(S - S_ref)) <= 1e-12 * np.max(np.abs(S_ref))
+    Sm = S.reshape(256, 256, order="F")
+    assert np.array_equal(Sm, Sm.T)
+    dx, _ = solve_system(ctx, rhs, np.zeros(0))
+    assert np.max(np.abs(dx - dx_ref)) <= 1e-9 * max(1.0, np.max(np.abs(dx_ref)))
+    ctx.close()

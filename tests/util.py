@@ -67,6 +67,8 @@ def instance(name):
         return P.three_point_spherical_codes(3, mp.mpf(1) / 2, 8, 8)
     if name == "sdpa_x64":              # BASELINE config 5 as named: SDPA dense-constraint import scaled to 64 blocks
         return P.sdpa_to_sdp(P.sdpa_scaled(nb=64, bs=32, m=256, seed=64))
+    if name == "sdpa_x64_full":         # the same with every constraint matrix full block diagonal (as in test/example.dat-s): 7.5 GFLOP per assembly
+        return P.sdpa_to_sdp(P.sdpa_scaled(nb=64, bs=32, m=256, seed=64, blocks_per_constraint=64))
     if name == "polyopt_scaled_100":
         return P.polyopt_scaled(100)
     raise KeyError(name)
