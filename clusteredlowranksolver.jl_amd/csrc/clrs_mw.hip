@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -81,8 +82,8 @@ struct clrs_mw_ctx {
     std::vector<MwBlk> blk;
     std::vector<MwClu> clu;
     std::vector<void *> allocs;
-    int maxU = 0, maxP = 0, maxn = 0;
-    bool lds_x = false, lds_q = false, lds_zt_L = false;
+    int maxU = 0, maxP = 0, maxn = 0, maxP_inv = 0;
+    bool lds_x = false, lds_q = false, lds_zt_L = false, qinv = false, any_inv = false, any_sub = false;
     size_t sm_x = 0, sm_zt = 0, sm_dense = 0, sm_factor = 0, sm_q = 0, sm_fwd = 0, sm_mid = 0, sm_bwd = 0;
     int *h_info = nullptr;               // pinned
     double *d_Xin = nullptr, *d_Xc = nullptr, *d_Y = nullptr, *d_rx = nullptr, *d_ry = nullptr, *d_dx = nullptr, *d_dy = nullptr;   // staging of the host-pointer entry points
@@ -318,6 +319,8 @@ extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int dev
     c->cnt_solve += (double)N * N;
     // ---- LDS plans ----
     const size_t lim = MW_LDS_MAX / sizeof(double);
+    const char *no_inv = getenv("CLRS_MW_NO_INVERSE");          // diagnostic: substitutions everywhere, as for matrices beyond LDS
+    const bool use_inv = !(no_inv && no_inv[0] == '1');
     {
         size_t nn = (size_t)c->maxn * c->maxn * K;
         const size_t bcw = K + 1;                       // broadcast slot of wg_potrf
@@ -335,6 +338,11 @@ extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int dev
         for (auto &q : c->clu) {
             size_t need = std::max((size_t)q.P * q.P * K + bcw, ((size_t)q.P * q.P + (size_t)q.P * MW_BT) * K);     // k_mw_factor; k_mw_linvb
             q.lds = need <= lim ? 1 : 0;
+            q.inv = (use_inv && q.lds && 2 * (size_t)q.P * q.P * K + bcw <= lim) ? 1 : 0;      // S_j and the inverse of its factor side by side
+            if (q.inv) need = std::max(need, 2 * (size_t)q.P * q.P * K + bcw);
+            c->any_inv |= q.inv != 0;
+            if (q.inv) c->maxP_inv = std::max(c->maxP_inv, q.P);
+            c->any_sub |= q.inv == 0;
             if (!q.lds && (size_t)q.P * MW_BT * K > lim) MW_BAIL(CLRS_ERR_INVALID, "cluster too large for the multi-word kernels");
             if (!q.lds) fmax = std::max(fmax, (size_t)q.P * MW_BT * K);
             if (q.lds) fmax = std::max(fmax, need);
@@ -345,7 +353,8 @@ extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int dev
         c->sm_fwd = c->sm_bwd = smax * 8;
         size_t qn = (size_t)N * N * K;
         c->lds_q = 2 * qn + (size_t)N * K <= lim;
-        c->sm_q = ((c->lds_q ? qn : 0) + bcw) * 8;
+        c->qinv = use_inv && c->lds_q && 2 * qn + bcw <= lim;
+        c->sm_q = ((c->qinv ? 2 * qn : c->lds_q ? qn : 0) + bcw) * 8;
         c->sm_mid = ((size_t)N * K + (c->lds_q ? 2 * qn : 0)) * 8;
         if (c->sm_fwd > MW_LDS_MAX || c->sm_mid > MW_LDS_MAX) MW_BAIL(CLRS_ERR_INVALID, "cluster too large for the multi-word solve kernels");
     }
@@ -394,6 +403,8 @@ extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int dev
     MW_TRY(mw_dmalloc(c, &q.W, q.wlen * K)); MW_TRY(mw_dmalloc(c, &q.Sd, q.sdlen * K));
     MW_TRY(mw_dmalloc(c, &q.S, Slen * K)); MW_TRY(mw_dmalloc(c, &q.LB, xlen * (i64)N * K)); MW_TRY(mw_dmalloc(c, &q.Q, (i64)N * N * K));
     MW_TRY(mw_dmalloc(c, &q.Sf, Slen * K)); MW_TRY(mw_dmalloc(c, &q.Sb, Slen * K));
+    MW_TRY(mw_dmalloc(c, &q.Si, Slen * K)); MW_TRY(mw_dmalloc(c, &q.Qi, (i64)N * N * K));
+    q.qinv = c->qinv ? 1 : 0;
     MW_TRY(mw_dmalloc(c, &q.Qf, (i64)N * N * K)); MW_TRY(mw_dmalloc(c, &q.Qb, (i64)N * N * K));
     MW_TRY(mw_dmalloc(c, &q.Xf, xyoff * K)); MW_TRY(mw_dmalloc(c, &q.Xb, xyoff * K));
     MW_TRY(mw_dmalloc(c, &q.xrd, rdoff * K)); MW_TRY(mw_dmalloc(c, &q.srd, xlen * K)); MW_TRY(mw_dmalloc(c, &q.qrd, (i64)N * K));
@@ -606,7 +617,9 @@ extern "C" int clrs_mw_schur_factor_local_dev(clrs_mw_ctx *c) {
         if ((rc = mw_potrf_blocked(c, m))) return rc;
     }
     MW_DISPATCH(c, {
-        if (q.N > 0) hipLaunchKernelGGL((k_mw_linvb<KK, DD>), dim3((q.N + MW_BT - 1) / MW_BT, q.J), dim3(MW_NT), c->sm_factor, c->stream, q);
+        if (q.N > 0 && c->any_sub) hipLaunchKernelGGL((k_mw_linvb<KK, DD>), dim3((q.N + MW_BT - 1) / MW_BT, q.J), dim3(MW_NT), c->sm_factor, c->stream, q);
+        if (q.N > 0 && c->any_inv)
+            hipLaunchKernelGGL((k_mw_linvb_inv<KK, DD>), dim3((c->maxP_inv * q.N + MW_NT / MW_LBI_W - 1) / (MW_NT / MW_LBI_W), q.J), dim3(MW_NT), 0, c->stream, q);
         if (c->timing) (void)hipEventRecord(c->ev[3], c->stream);
         if (q.N > 0) hipLaunchKernelGGL(k_mw_qgram<KK>, dim3((q.N * (q.N + 1) / 2 + MW_NT / MW_Q_W - 1) / (MW_NT / MW_Q_W)), dim3(MW_NT), 0, c->stream, q);
         if (c->timing) (void)hipEventRecord(c->ev[4], c->stream);

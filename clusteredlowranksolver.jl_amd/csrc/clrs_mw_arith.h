@@ -349,6 +349,31 @@ MWF mw<K> div(const mw<K> &a, const mw<K> &b) {
     return fma<K>(q, rem, r);
 }
 
+// a / b on a dependent chain: x ~ 1/b to KH = ceil(K/2) limbs (a reciprocal shared by every quotient with this divisor),
+// q0 = a x to KH limbs, q = q0 + x (a - b q0): the last Newton step of the reciprocal merged with the multiplication by a,
+// so that the full-precision work is one K x KH product for the remainder (its leading KH limbs cancel) and one short
+// product for the correction.  Error ~ eps_KH^2 + eps_K, as for recip<K> followed by mul<K> at 0.75 of the latency.
+template <int K>
+MWF mw<K> div_hr(const mw<K> &a, const mw<K> &b, const mw<(K + 1) / 2> &x) {
+    constexpr int KH = (K + 1) / 2;
+    constexpr int KR = (K - KH + 1 < K) ? K - KH + 1 : K;
+    mw<KH> q0 = mulx<KH, KH, KH>(cvt<KH, K>(a), x);
+    acc<K> c;
+#pragma unroll
+    for (int i = 0; i < K; i++) c.s[i] = a.l[i];
+    acc_fma<K, K, KH>(c, b, q0, -1.0);
+    mw<K> rem = acc_result<K>(c);
+    mw<KR> corr = mulx<KR, KR, KH>(cvt<KR, K>(rem), x);
+    acc<K> d;
+    acc_zero<K>(d);
+#pragma unroll
+    for (int i = 0; i < KH; i++) d.s[i] = q0.l[i];
+    acc_add<K, KR>(d, corr);
+    return acc_result<K>(d);
+}
+template <int K>
+MWF mw<K> div_fast(const mw<K> &a, const mw<K> &b) { return div_hr<K>(a, b, recip<(K + 1) / 2>(cvt<(K + 1) / 2, K>(b))); }
+
 template <int K, int KX>
 struct NewtonRsqrt {
     static MWF mw<K> run(const mw<K> &a, const mw<KX> &y) {

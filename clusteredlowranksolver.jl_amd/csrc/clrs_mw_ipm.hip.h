@@ -544,7 +544,7 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_step(const MwDev q, const MwIpmDe
     } else {
         wg_copy<K>(F, nn, n, Mg, q.xylen, n, n, n, tid);
         __syncthreads();
-        if (!wg_potrf<K>(F, nn, n, n, rd, n, bc, tid)) {                                 // :1644-1646
+        if (!wg_potrf<K, false>(F, nn, n, n, rd, n, F, 0, 0, bc, tid)) {                                 // :1644-1646
             if (tid == 0) { p.flags[2] = 1; p.eig[(long)which * q.NB + blockIdx.x] = 0.0; }
             return;
         }

@@ -47,6 +47,7 @@ struct MwBlk {               // one PSD block (j, l)
 struct MwClu {               // one cluster j
     int P, b0, b1, lds;      // constraints; block range; 1 = S_j (and B_j) fit in LDS
     mwi64 coff, Soff;
+    int inv, pad;            // 1 = S_j and the inverse of its factor fit in LDS together: L_j^-1 is formed (Si), the solves are products
 };
 struct MwDev {
     int J, N, NB, nlr, ndn, pad0;
@@ -71,6 +72,8 @@ struct MwDev {
     double *Sf, *Sb, *Qf, *Qb;          // row- / column-scaled strict lower triangles of L_j and L_Q (unit-diagonal substitutions)
     double *Xf, *Xb;                    // the same for the Cholesky factors of the X blocks (xy layout)
     double *xrd, *srd, *qrd;            // reciprocal diagonals of chol(X_b), L_j, L_Q
+    double *Si, *Qi;                    // explicit inverses L_j^-1 (S layout, clusters with inv = 1) and L_Q^-1 (qinv = 1), lower triangular
+    int qinv, pad4;
     double *t, *u, *AY;                 // t = L^-1 rhs_x (xlen); u slabs (J x N); pairings per term
     int *info;                          // [0] factor status, [1] Cholesky-of-X status
     // cluster sharding over ranks (one process per GPU): this context holds the clusters of rank `rank`; the partial Q and the
@@ -119,56 +122,141 @@ __device__ __forceinline__ mw<K> lanes_sum(mw<K> v) {
     return v;
 }
 
-// In-place lower Cholesky of the n x n matrix M (planar, leading dimension ld), reciprocal diagonal to rd.
-// approx_cholesky! (src/tools.jl:69-107): returns false at the first non-positive pivot.
-// The dependent chain per pivot is  d_k -> 1/sqrt(d_k) -> l_(k+1,k) -> d_(k+1): ONE wave evaluates the Newton rsqrt while
-// the other waves apply the part of the previous rank-1 update that the chain does not need yet (columns > k: look-ahead);
-// then the column is scaled and only the next pivot column is updated before the next rsqrt starts.
-// `bc`: LDS, K + 1 doubles (the reciprocal square root and the status of the pivot, for the other waves).
-template <int K, class PM, class PR>
-__device__ __forceinline__ bool wg_potrf(PM M, long plane, int n, int ld, PR rd, long rdplane, lds_d *bc, int tid) {
+// In-place lower Cholesky of the n x n matrix M (planar, leading dimension ld; only the lower triangle is read), reciprocal
+// diagonal to rd.  approx_cholesky! (src/tools.jl:69-107): returns false at the first non-positive pivot.
+// The factorisation is carried as an LDL^T elimination, because its dependent chain per pivot is shorter:
+//     d_k  ->  u_ik = a_ik / d_k  ->  a_(i,k+1) -= u_ik a_(k+1,k)  ->  d_(k+1)
+// (one division by a shared divisor, div_hr, and one multiply-add; the Cholesky form needs 1/sqrt(d_k), a product and a
+// multiply-add).  ONE wave evaluates the division of the pivot column, keeping the undivided column a_(.,k) in row k of the
+// upper triangle; meanwhile the other waves apply the part of the previous rank-1 update that the chain does not need yet
+// (columns > k: look-ahead) and, with INV, the same elimination step to a unit matrix W, which turns it into U^-1 behind the
+// chain at no cost to it.  After the loop, off the chain and in parallel: sqrt(d_k), L = U sqrt(D), W <- L^-1 = D^-1/2 U^-1;
+// the strict upper triangle of M is left holding U^T (= the column-scaled factor the backward substitutions use).
+// `bc`: LDS, K + 1 doubles (status of the pivot, for the other waves).
+template <int K, bool INV, class PM, class PR, class PW>
+__device__ __forceinline__ bool wg_potrf(PM M, long plane, int n, int ld, PR rd, long rdplane, PW W, long wplane, int ldw, lds_d *bc, int tid) {
+    constexpr int KH = (K + 1) / 2;
     const int wave = tid >> 6;
+    if (INV) {
+        for (int e = tid; e < n * n; e += MW_NT) {
+            const int i = e % n, c = e / n;
+            stx<K>(W, wplane, i + (long)c * ldw, i == c ? from_double<K>(1.0) : zero<K>());
+        }
+    }
     for (int k = 0; k < n; k++) {
         const long kk = k + (long)k * ld;
         if (wave == 0) {
-            mw<K> d = ldx<K>(M, plane, kk);
+            const mw<K> d = ldx<K>(M, plane, kk);
             const bool ok = d.l[0] > 0.0;
-            mw<K> rs = ok ? rsqrt<K>(d) : zero<K>();
-            if (tid == 0) {                                              // M[k,k] keeps d_k until the end: nothing reads it again
-                bc[K] = ok ? 1.0 : 0.0;
-                stx<K>(rd, rdplane, k, rs);
-            }
-            for (int i = k + 1 + tid; i < n; i += 64) {                  // the column is scaled by the same wave, no barrier in between
-                const long idx = i + (long)k * ld;
-                stx<K>(M, plane, idx, mul<K>(ldx<K>(M, plane, idx), rs));
+            if (tid == 0) bc[K] = ok ? 1.0 : 0.0;
+            if (ok && k + 1 < n) {
+                const mw<KH> x = recip<KH>(cvt<KH, K>(d));
+                for (int i = k + 1 + tid; i < n; i += 64) {
+                    const long idx = i + (long)k * ld;
+                    const mw<K> a = ldx<K>(M, plane, idx);
+                    stx<K>(M, plane, k + (long)i * ld, a);
+                    stx<K>(M, plane, idx, div_hr<K>(a, d, x));
+                }
             }
         } else if (k > 0) {
             const int m = n - k - 1, cnt = m * (m + 1) / 2;            // rest of update k-1: columns k+1 .. n-1
-            for (int e = tid - 64; e < cnt; e += MW_NT - 64) {
-                int ii, jj;
-                tri_index(e, ii, jj);
-                const int i = k + 1 + ii, j = k + 1 + jj;
-                const long idx = i + (long)j * ld;
-                stx<K>(M, plane, idx, fnma<K>(ldx<K>(M, plane, idx), ldx<K>(M, plane, i + (long)(k - 1) * ld), ldx<K>(M, plane, j + (long)(k - 1) * ld)));
+            const int mi = n - k, cnt2 = INV ? mi * k : 0;             // step k-1 of the inverse: rows k .. n-1, columns 0 .. k-1
+            for (int e = tid - 64; e < cnt + cnt2; e += MW_NT - 64) {
+                if (e < cnt) {
+                    int ii, jj;
+                    tri_index(e, ii, jj);
+                    const int i = k + 1 + ii, j = k + 1 + jj;
+                    const long idx = i + (long)j * ld;
+                    stx<K>(M, plane, idx, fnma<K>(ldx<K>(M, plane, idx), ldx<K>(M, plane, i + (long)(k - 1) * ld), ldx<K>(M, plane, (k - 1) + (long)j * ld)));
+                } else {
+                    const int e2 = e - cnt, i = k + e2 % mi, j = e2 / mi;
+                    const long idx = i + (long)j * ldw;
+                    stx<K>(W, wplane, idx, fnma<K>(ldx<K>(W, wplane, idx), ldx<K>(M, plane, i + (long)(k - 1) * ld), ldx<K>(W, wplane, (k - 1) + (long)j * ldw)));
+                }
             }
         }
         __syncthreads();
         if (bc[K] == 0.0) return false;
         if (k + 1 < n) {
-            const mw<K> lk = ldx<K>(M, plane, (k + 1) + (long)k * ld);
+            const mw<K> ak = ldx<K>(M, plane, k + (long)(k + 1) * ld);   // a_(k+1,k), undivided
             for (int i = k + 1 + tid; i < n; i += MW_NT) {
                 const long idx = i + (long)(k + 1) * ld;
-                stx<K>(M, plane, idx, fnma<K>(ldx<K>(M, plane, idx), ldx<K>(M, plane, i + (long)k * ld), lk));
+                stx<K>(M, plane, idx, fnma<K>(ldx<K>(M, plane, idx), ldx<K>(M, plane, i + (long)k * ld), ak));
             }
         }
         __syncthreads();
     }
-    for (int k = tid; k < n; k += MW_NT) {                               // L_kk = sqrt(d_k), off the dependent chain
+    for (int k = tid; k < n; k += MW_NT) {                               // L_kk = sqrt(d_k), 1 / L_kk
         const long kk = k + (long)k * ld;
-        stx<K>(M, plane, kk, sqrt_with_rsqrt<K>(ldx<K>(M, plane, kk), ldx<K>(rd, rdplane, k)));
+        const mw<K> d = ldx<K>(M, plane, kk), rs = rsqrt<K>(d);
+        stx<K>(rd, rdplane, k, rs);
+        stx<K>(M, plane, kk, sqrt_with_rsqrt<K>(d, rs));
+    }
+    __syncthreads();
+    for (int e = tid; e < n * n; e += MW_NT) {
+        const int i = e % n, c = e / n;
+        if (i > c) {
+            const mw<K> u = ldx<K>(M, plane, i + (long)c * ld);
+            stx<K>(M, plane, c + (long)i * ld, u);
+            stx<K>(M, plane, i + (long)c * ld, mul<K>(u, ldx<K>(M, plane, c + (long)c * ld)));
+        }
+        if (INV && i >= c) {
+            const long idx = i + (long)c * ldw;
+            const mw<K> ri = ldx<K>(rd, rdplane, i);
+            stx<K>(W, wplane, idx, i == c ? ri : mul<K>(ldx<K>(W, wplane, idx), ri));
+        }
     }
     __syncthreads();
     return true;
+}
+
+// The same two scaled triangles after wg_potrf, whose strict upper triangle already holds U^T = Bk: F[i,k] = L[i,k] / L[i,i].
+template <int K, class PL, class PR, class PF, class PB>
+__device__ __forceinline__ void wg_scaled_factors_u(PL L, long lplane, int ldl, PR rd, long rdplane, int n, PF F, long fplane, int ldf, PB Bk,
+                                                    long bplane, int ldb, int tid) {
+    for (int e = tid; e < n * n; e += MW_NT) {
+        const int i = e % n, k = e / n;
+        if (i > k) {
+            stx<K>(F, fplane, i + (long)k * ldf, mul<K>(ldx<K>(L, lplane, i + (long)k * ldl), ldx<K>(rd, rdplane, i)));
+        } else {
+            stx<K>(F, fplane, i + (long)k * ldf, zero<K>());
+            stx<K>(Bk, bplane, i + (long)k * ldb, i == k ? zero<K>() : ldx<K>(L, lplane, i + (long)k * ldl));
+        }
+    }
+}
+
+// y = T v and y = T^T v for a lower triangular n x n matrix T (an explicit inverse factor), v and y planar vectors in LDS
+// (y != v): eight lanes per row, the partial sums joined by shuffles.  Ends with a barrier.
+#define MW_TV_W 8
+template <int K, class PT, class PV>
+__device__ __forceinline__ void wg_trmv_n(PT T, long tplane, int ldt, int n, PV v, long vplane, PV y, long yplane, int tid) {
+    const int sub = tid % MW_TV_W;
+    for (int i0 = 0; i0 < n; i0 += MW_NT / MW_TV_W) {
+        const int i = i0 + tid / MW_TV_W;
+        const bool live = i < n;
+        const int ii = live ? i : 0;
+        acc<K> s;
+        acc_zero<K>(s);
+        for (int c = sub; c <= ii; c += MW_TV_W) acc_fma<K, K, K>(s, ldx<K>(T, tplane, ii + (long)c * ldt), ldx<K>(v, vplane, c));
+        const mw<K> r = lanes_sum<K, MW_TV_W>(acc_result<K>(s));
+        if (live && sub == 0) stx<K>(y, yplane, i, r);
+    }
+    __syncthreads();
+}
+template <int K, class PT, class PV>
+__device__ __forceinline__ void wg_trmv_t(PT T, long tplane, int ldt, int n, PV v, long vplane, PV y, long yplane, int tid) {
+    const int sub = tid % MW_TV_W;
+    for (int i0 = 0; i0 < n; i0 += MW_NT / MW_TV_W) {
+        const int i = i0 + tid / MW_TV_W;
+        const bool live = i < n;
+        const int ii = live ? i : 0;
+        acc<K> s;
+        acc_zero<K>(s);
+        for (int r = ii + sub; r < n; r += MW_TV_W) acc_fma<K, K, K>(s, ldx<K>(T, tplane, r + (long)ii * ldt), ldx<K>(v, vplane, r));
+        const mw<K> w = lanes_sum<K, MW_TV_W>(acc_result<K>(s));
+        if (live && sub == 0) stx<K>(y, yplane, i, w);
+    }
+    __syncthreads();
 }
 
 // Scaled strict triangles of a Cholesky factor: F[i,k] = L[i,k] / L[i,i], i > k (forward substitution with a unit diagonal:
@@ -282,10 +370,10 @@ template <int K, class PM>
 __device__ __forceinline__ void mw_potrf_x_body(const MwDev &q, const MwBlk &k, PM M, long plane, double *__restrict__ Xc, mwk::lds_d *bc, int tid, int bid) {
     using namespace mwk;
     const int n = k.n;
-    const bool ok = wg_potrf<K>(M, plane, n, n, q.xrd + k.rd_off, q.xrdlen, bc, tid);
+    const bool ok = wg_potrf<K, false>(M, plane, n, n, q.xrd + k.rd_off, q.xrdlen, M, 0, 0, bc, tid);
     if (!ok && tid == 0) atomicMin(&q.info[1], bid + 1);
     __syncthreads();
-    wg_scaled_factors<K>(M, plane, n, q.xrd + k.rd_off, q.xrdlen, n, q.Xf + k.xyoff, q.xylen, n, q.Xb + k.xyoff, q.xylen, n, tid);
+    if (ok) wg_scaled_factors_u<K>(M, plane, n, q.xrd + k.rd_off, q.xrdlen, n, q.Xf + k.xyoff, q.xylen, n, q.Xb + k.xyoff, q.xylen, n, tid);
     for (int e = tid; e < n * n; e += MW_NT) {
         const int i = e % n, c = e / n;
 #pragma unroll
@@ -508,21 +596,24 @@ __global__ __launch_bounds__(MW_NT) void k_mw_saccum(const MwDev q) {
 // Factorisation of a cluster: L_j = chol(S_j) (in place in the S buffer), LinvB_j = L_j^-1 B_j; the scaled triangles of L_j
 // for the solve stage.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int K, class PM>
-__device__ __forceinline__ bool mw_factor_body(const MwDev &q, const MwClu &c, int j, PM M, long mplane, mwk::lds_d *bc, int tid) {
+template <int K, bool INV, class PM, class PW>
+__device__ __forceinline__ bool mw_factor_body(const MwDev &q, const MwClu &c, int j, PM M, long mplane, PW W, mwk::lds_d *bc, int tid) {
     using namespace mwk;
     const int P = c.P;
-    const bool ok = wg_potrf<K>(M, mplane, P, P, q.srd + c.coff, q.xlen, bc, tid);
+    const bool ok = wg_potrf<K, INV>(M, mplane, P, P, q.srd + c.coff, q.xlen, W, mplane, P, bc, tid);
     if (!ok) {
         if (tid == 0) atomicMin(&q.info[0], j + 1);
         return false;
     }
     double *Sg = q.S + c.Soff;
-    wg_scaled_factors<K>(M, mplane, P, q.srd + c.coff, q.xlen, P, q.Sf + c.Soff, q.Slen, P, q.Sb + c.Soff, q.Slen, P, tid);
+    wg_scaled_factors_u<K>(M, mplane, P, q.srd + c.coff, q.xlen, P, q.Sf + c.Soff, q.Slen, P, q.Sb + c.Soff, q.Slen, P, tid);
     for (int e = tid; e < P * P; e += MW_NT) {            // L_j back to the S buffer with a zero strict upper triangle
         const int i = e % P, cc = e / P;
 #pragma unroll
-        for (int l = 0; l < K; l++) Sg[(long)l * q.Slen + e] = (i >= cc) ? (double)M[(long)l * mplane + e] : 0.0;
+        for (int l = 0; l < K; l++) {
+            Sg[(long)l * q.Slen + e] = (i >= cc) ? (double)M[(long)l * mplane + e] : 0.0;
+            if (INV) q.Si[(long)l * q.Slen + c.Soff + e] = (i >= cc) ? (double)W[(long)l * mplane + e] : 0.0;
+        }
     }
     return true;
 }
@@ -537,7 +628,8 @@ __global__ __launch_bounds__(MW_NT) void k_mw_factor(const MwDev q) {
         lds_d *M = MW_LDS + (K + 1);
         wg_copy<K>(M, (long)P * P, P, q.S + c.Soff, q.Slen, P, P, P, tid);
         __syncthreads();
-        mw_factor_body<K>(q, c, j, M, (long)P * P, bc, tid);
+        if (c.inv) mw_factor_body<K, true>(q, c, j, M, (long)P * P, M + (long)K * P * P, bc, tid);
+        else mw_factor_body<K, false>(q, c, j, M, (long)P * P, M, bc, tid);
     }
     // clusters too large for LDS are factored by the blocked, multi-workgroup path (k_mw_bp_*, driven by the host)
 }
@@ -551,7 +643,7 @@ __global__ __launch_bounds__(MW_NT) void k_mw_linvb(const MwDev q) {
     const MwClu &c = q.clu[j];
     const int P = c.P, N = q.N;
     const int a0 = blockIdx.x * MW_BT;
-    if (a0 >= N) return;
+    if (a0 >= N || c.inv) return;                                        // clusters with an explicit inverse: k_mw_linvb_inv
     if (q.info[0] != MW_INFO_NONE && q.info[0] <= j + 1) return;        // this cluster (or an earlier one) failed
     const int nc = min(MW_BT, N - a0);
     lds_d *Bt = MW_LDS;                                   // P x MW_BT tile
@@ -575,6 +667,27 @@ __global__ __launch_bounds__(MW_NT) void k_mw_linvb(const MwDev q) {
 #pragma unroll
         for (int l = 0; l < K; l++) q.LB[(long)l * q.xlen * N + c.coff + i + (long)(a0 + cc) * q.xlen] = Bt[(long)l * bp + e];
     }
+}
+
+// The same product for the clusters whose L_j^-1 is explicit: LinvB_j = Si_j B_j, four lanes per entry
+#define MW_LBI_W 4
+template <int K, int DK>
+__global__ __launch_bounds__(MW_NT) void k_mw_linvb_inv(const MwDev q) {
+    using namespace mwk;
+    const int j = blockIdx.y;
+    const MwClu &c = q.clu[j];
+    const int P = c.P, N = q.N;
+    if (!c.inv || blockIdx.x * (MW_NT / MW_LBI_W) >= P * N) return;
+    if (q.info[0] != MW_INFO_NONE && q.info[0] <= j + 1) return;
+    const int e = blockIdx.x * (MW_NT / MW_LBI_W) + threadIdx.x / MW_LBI_W, sub = threadIdx.x % MW_LBI_W;
+    const bool live = e < P * N;
+    const int ee = live ? e : 0, i = ee % P, a = ee / P;
+    const double *Ti = q.Si + c.Soff;
+    acc<K> s;
+    acc_zero<K>(s);
+    for (int r = sub; r <= i; r += MW_LBI_W) acc_fma<K, K, DK>(s, ldx<K>(Ti, q.Slen, i + (long)r * P), ldx<DK>(q.B, q.Bp, c.coff + r + (long)a * q.xlen));
+    const mw<K> v = lanes_sum<K, MW_LBI_W>(acc_result<K>(s));
+    if (live && sub == 0) stx<K>(q.LB, q.xlen * (long)N, c.coff + i + (long)a * q.xlen, v);
 }
 
 // Q = sum_j LinvB_j^T LinvB_j = LB^T LB over the stacked rows (src/solver.jl:1264-1271): eight lanes per entry a >= b
@@ -601,21 +714,24 @@ __global__ __launch_bounds__(MW_NT) void k_mw_qgram(const MwDev q) {
 }
 
 // Cholesky of Q (src/solver.jl:1274) and its scaled triangles
-template <int K, class PM>
-__device__ __forceinline__ void mw_potrf_q_body(const MwDev &q, PM M, long plane, mwk::lds_d *bc, int tid) {
+template <int K, bool INV, class PM, class PW>
+__device__ __forceinline__ void mw_potrf_q_body(const MwDev &q, PM M, long plane, PW W, mwk::lds_d *bc, int tid) {
     using namespace mwk;
     const int N = q.N;
-    const bool ok = wg_potrf<K>(M, plane, N, N, q.qrd, N, bc, tid);
+    const bool ok = wg_potrf<K, INV>(M, plane, N, N, q.qrd, N, W, plane, N, bc, tid);
     if (!ok) {
         if (tid == 0) atomicMin(&q.info[0], q.J + 1);
         return;
     }
-    wg_scaled_factors<K>(M, plane, N, q.qrd, N, N, q.Qf, (long)N * N, N, q.Qb, (long)N * N, N, tid);
+    wg_scaled_factors_u<K>(M, plane, N, q.qrd, N, N, q.Qf, (long)N * N, N, q.Qb, (long)N * N, N, tid);
     __syncthreads();
     for (int e = tid; e < N * N; e += MW_NT) {
         const int i = e % N, cc = e / N;
 #pragma unroll
-        for (int l = 0; l < K; l++) q.Q[(long)l * N * N + e] = (i >= cc) ? (double)M[(long)l * plane + e] : 0.0;
+        for (int l = 0; l < K; l++) {
+            q.Q[(long)l * N * N + e] = (i >= cc) ? (double)M[(long)l * plane + e] : 0.0;
+            if (INV) q.Qi[(long)l * N * N + e] = (i >= cc) ? (double)W[(long)l * plane + e] : 0.0;
+        }
     }
 }
 template <int K>
@@ -634,7 +750,8 @@ __global__ __launch_bounds__(MW_NT) void k_mw_potrf_q(const MwDev q, int lds) {
             stx<K>(M, nn, e, acc_result<K>(s));
         }
         __syncthreads();
-        mw_potrf_q_body<K>(q, M, nn, bc, tid);
+        if (q.qinv) mw_potrf_q_body<K, true>(q, M, nn, M + (long)K * nn, bc, tid);
+        else mw_potrf_q_body<K, false>(q, M, nn, M, bc, tid);
     }
     // a Q too large for LDS: k_mw_qsum + the blocked path (k_mw_bp_*)
 }
@@ -674,7 +791,7 @@ __global__ __launch_bounds__(MW_NT) void k_mw_bp_diag(const MwDev q, const MwBp 
     lds_d *bc = MW_LDS, *D = MW_LDS + (K + 1), *rdl = D + (long)K * MW_PB * MW_PB;
     wg_copy<K>(D, (long)nb * nb, nb, m.M + j0 + (long)j0 * m.ld, m.plane, m.ld, nb, nb, tid);
     __syncthreads();
-    if (!wg_potrf<K>(D, (long)nb * nb, nb, nb, rdl, nb, bc, tid)) {
+    if (!wg_potrf<K, false>(D, (long)nb * nb, nb, nb, rdl, nb, D, 0, 0, bc, tid)) {
         if (tid == 0) atomicMin(&q.info[m.which], m.code);
         return;
     }
@@ -765,10 +882,28 @@ __global__ __launch_bounds__(MW_NT) void k_mw_usum(const MwDev q) {
 // (one multiply-add and one barrier per unknown), dot products over eight lanes.
 // ---------------------------------------------------------------------------------------------------------------------
 #define MW_S_W 8
+// u_j = LinvB_j^T t_j (t in LDS, planar with plane P)
+template <int K>
+__device__ __forceinline__ void mw_solve_u(const MwDev &q, const MwClu &c, int j, mwk::lds_d *tv, int tid) {
+    using namespace mwk;
+    const int P = c.P, N = q.N;
+    const long plane = q.xlen * (long)N;
+    const int sub = tid % MW_S_W;
+    for (int a0 = 0; a0 < N; a0 += MW_NT / MW_S_W) {
+        const int a = a0 + tid / MW_S_W;
+        const bool live = a < N;
+        const int aa = live ? a : 0;
+        acc<K> s;
+        acc_zero<K>(s);
+        for (int r = sub; r < P; r += MW_S_W) acc_fma<K, K, K>(s, ldx<K>(q.LB, plane, c.coff + r + aa * q.xlen), ldx<K>(tv, P, r));
+        mw<K> v = lanes_sum<K, MW_S_W>(acc_result<K>(s));
+        if (live && sub == 0) stx<K>(q.u, (long)q.J * N, (long)j * N + a, v);
+    }
+}
 template <int K, class PF>
 __device__ __forceinline__ void mw_solve_fwd_body(const MwDev &q, const MwClu &c, int j, PF F, long fplane, mwk::lds_d *tv, int tid) {
     using namespace mwk;
-    const int P = c.P, N = q.N;
+    const int P = c.P;
     if (P <= 64) {
         if (tid < 64) {
             mw<K> b = tid < P ? mul<K>(ldx<K>(tv, P, tid), ldx<K>(q.srd + c.coff, q.xlen, tid)) : zero<K>();
@@ -783,18 +918,7 @@ __device__ __forceinline__ void mw_solve_fwd_body(const MwDev &q, const MwClu &c
 #pragma unroll
         for (int l = 0; l < K; l++) q.t[(long)l * q.xlen + c.coff + i] = tv[(long)l * P + i];
     }
-    const long plane = q.xlen * (long)N;
-    const int sub = tid % MW_S_W;
-    for (int a0 = 0; a0 < N; a0 += MW_NT / MW_S_W) {
-        const int a = a0 + tid / MW_S_W;
-        const bool live = a < N;
-        const int aa = live ? a : 0;
-        acc<K> s;
-        acc_zero<K>(s);
-        for (int r = sub; r < P; r += MW_S_W) acc_fma<K, K, K>(s, ldx<K>(q.LB, plane, c.coff + r + aa * q.xlen), ldx<K>(tv, P, r));
-        mw<K> v = lanes_sum<K, MW_S_W>(acc_result<K>(s));
-        if (live && sub == 0) stx<K>(q.u, (long)q.J * N, (long)j * N + a, v);
-    }
+    mw_solve_u<K>(q, c, j, tv, tid);
 }
 template <int K>
 __global__ __launch_bounds__(MW_NT) void k_mw_solve_fwd(const MwDev q, const double *__restrict__ rhs_x) {
@@ -807,7 +931,16 @@ __global__ __launch_bounds__(MW_NT) void k_mw_solve_fwd(const MwDev q, const dou
 #pragma unroll
         for (int l = 0; l < K; l++) tv[(long)l * P + i] = rhs_x[(long)l * q.xlen + c.coff + i];
     }
-    if (c.lds) {
+    if (c.inv) {                              // t_j = Si_j rhs_j: a product with the explicit inverse
+        lds_d *t2 = tv + (long)K * P;
+        __syncthreads();
+        wg_trmv_n<K>(q.Si + c.Soff, q.Slen, P, P, tv, P, t2, P, tid);
+        for (int i = tid; i < P; i += MW_NT) {
+#pragma unroll
+            for (int l = 0; l < K; l++) q.t[(long)l * q.xlen + c.coff + i] = t2[(long)l * P + i];
+        }
+        mw_solve_u<K>(q, c, j, t2, tid);
+    } else if (c.lds) {
         lds_d *Ls = MW_LDS + (long)K * P;
         wg_copy<K>(Ls, (long)P * P, P, q.Sf + c.Soff, q.Slen, P, P, P, tid);
         __syncthreads();
@@ -835,7 +968,12 @@ __global__ __launch_bounds__(MW_NT) void k_mw_solve_mid(const MwDev q, const dou
         }
         stx<K>(v, N, a, acc_result<K>(s));
     }
-    if (lds) {
+    if (q.qinv) {                             // dy = Qi^T (Qi v): two products with the explicit inverse of L_Q
+        lds_d *y = v + (long)K * N;
+        __syncthreads();
+        wg_trmv_n<K>(q.Qi, lplane, N, N, v, N, y, N, tid);
+        wg_trmv_t<K>(q.Qi, lplane, N, N, y, N, v, N, tid);
+    } else if (lds) {
         lds_d *Lf = MW_LDS + (long)K * N, *Lb = Lf + (long)K * lplane;
         wg_copy<K>(Lf, lplane, N, q.Qf, lplane, N, N, N, tid);
         wg_copy<K>(Lb, lplane, N, q.Qb, lplane, N, N, N, tid);
@@ -883,6 +1021,16 @@ __global__ __launch_bounds__(MW_NT) void k_mw_solve_bwd(const MwDev q, const dou
         for (int a = sub; a < N; a += MW_S_W) acc_fma<K, K, K>(s, ldx<K>(q.LB, plane, c.coff + rr + a * q.xlen), ldx<K>(dy, N, a));
         mw<K> v = lanes_sum<K, MW_S_W>(acc_result<K>(s));
         if (live && sub == 0) stx<K>(w, P, r, v);
+    }
+    if (c.inv) {                              // dx_j = Si_j^T w
+        lds_d *w2 = w + (long)K * P;
+        __syncthreads();
+        wg_trmv_t<K>(q.Si + c.Soff, q.Slen, P, P, w, P, w2, P, tid);
+        for (int i = tid; i < P; i += MW_NT) {
+#pragma unroll
+            for (int l = 0; l < K; l++) dx[(long)l * q.xlen + c.coff + i] = w2[(long)l * P + i];
+        }
+        return;
     }
     if (c.lds) {
         lds_d *Ls = MW_LDS + (long)K * P;

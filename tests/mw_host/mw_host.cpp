@@ -17,6 +17,7 @@ static void run(int op, long n, const double *a, const double *b, double *c) {
         case 6: r = rsqrt<K>(x); break;
         case 7: r = fnma<K>(x, y, y); break;            // x - y*y
         case 8: r = mul_d<K>(x, y.l[0]); break;
+        case 9: r = div_fast<K>(x, y); break;
         default: r = zero<K>();
         }
         st<K>(c, n, i, r);

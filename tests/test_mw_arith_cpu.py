@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SRC = os.path.join(_HERE, "mw_host", "mw_host.cpp")
 _LIB = os.path.join(_HERE, "mw_host", "libmw_host.so")
 _HDR = os.path.join(_HERE, "..", "clusteredlowranksolver.jl_amd", "csrc", "clrs_mw_arith.h")
-OPS = dict(add=0, sub=1, mul=2, div=3, sqrt=4, recip=5, rsqrt=6, fnma=7, mul_d=8)
+OPS = dict(add=0, sub=1, mul=2, div=3, sqrt=4, recip=5, rsqrt=6, fnma=7, mul_d=8, div_fast=9)
 
 
 @pytest.fixture(scope="module")
@@ -92,7 +92,7 @@ def test_mw_operations_against_mpmath(lib, K):
             got = from_limbs(call(lib, K, op, aa, b))
             ex = [1 / x for x in xs]
             scale = [abs(e) for e in ex]
-        elif op == "div":
+        elif op in ("div", "div_fast"):
             bb = to_limbs([v if v != 0 else mp.mpf(1) for v in bv], K)
             ys = from_limbs(bb)
             got = from_limbs(call(lib, K, op, a, bb))
