@@ -323,7 +323,7 @@ extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int dev
     const bool use_inv = !(no_inv && no_inv[0] == '1');
     {
         size_t nn = (size_t)c->maxn * c->maxn * K;
-        const size_t bcw = K + 1;                       // broadcast slot of wg_potrf
+        size_t bcw = MW_POTRF_SCR(K, (size_t)c->maxn);       // scratch of wg_potrf
         c->lds_x = nn + bcw <= lim;
         c->sm_x = ((c->lds_x ? nn : 0) + bcw) * 8;
         size_t zt = (size_t)c->maxn * MW_CT * K;
@@ -335,7 +335,10 @@ extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int dev
         if (maxnd * maxnd * K > lim) MW_BAIL(CLRS_ERR_INVALID, "dense block too large for the multi-word kernels");
         c->sm_dense = maxnd * maxnd * K * 8;
         size_t fmax = 0, smax = 0;
+        size_t bcw_max = bcw;
         for (auto &q : c->clu) {
+            bcw = MW_POTRF_SCR(K, (size_t)q.P);
+            bcw_max = std::max(bcw_max, bcw);
             size_t need = std::max((size_t)q.P * q.P * K + bcw, ((size_t)q.P * q.P + (size_t)q.P * MW_BT) * K);     // k_mw_factor; k_mw_linvb
             q.lds = need <= lim ? 1 : 0;
             q.inv = (use_inv && q.lds && 2 * (size_t)q.P * q.P * K + bcw <= lim) ? 1 : 0;      // S_j and the inverse of its factor side by side
@@ -349,9 +352,10 @@ extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int dev
             size_t sneed = ((size_t)q.P + (q.lds ? (size_t)q.P * q.P : 0)) * K;
             smax = std::max(smax, sneed);
         }
-        c->sm_factor = std::max(fmax, bcw) * 8;
+        c->sm_factor = std::max(fmax, bcw_max) * 8;
         c->sm_fwd = c->sm_bwd = smax * 8;
         size_t qn = (size_t)N * N * K;
+        bcw = MW_POTRF_SCR(K, (size_t)N);
         c->lds_q = 2 * qn + (size_t)N * K <= lim;
         c->qinv = use_inv && c->lds_q && 2 * qn + bcw <= lim;
         c->sm_q = ((c->qinv ? 2 * qn : c->lds_q ? qn : 0) + bcw) * 8;
@@ -421,7 +425,7 @@ extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int dev
         MWCHECK(hipMemcpy(info, init, sizeof(init), hipMemcpyHostToDevice));
     }
     MW_TRY(mw_dmalloc(c, &c->d_bpFd, (i64)MW_PB * MW_PB * K));
-    c->sm_bp_diag = ((size_t)(K + 1) + (size_t)K * MW_PB * MW_PB + (size_t)K * MW_PB) * 8;
+    c->sm_bp_diag = ((size_t)MW_POTRF_SCR(K, MW_PB) + (size_t)K * MW_PB * MW_PB + (size_t)K * MW_PB) * 8;
     c->sm_bp_panel = ((size_t)K * MW_PB * MW_PB + (size_t)K * MW_PB * 32 + (size_t)K * MW_PB) * 8;
     MW_DISPATCH(c, { MW_TRY(mw_set_lds(k_mw_bp_diag<KK>, c->sm_bp_diag)); MW_TRY(mw_set_lds(k_mw_bp_panel<KK>, c->sm_bp_panel)); });
     q.rank = 0; q.world = 1; q.gathered = 0;
@@ -497,7 +501,7 @@ extern "C" int clrs_mw_cholesky_blocks_dev(clrs_mw_ctx *c, const double *d_X, do
     int rc;
     if ((rc = mw_reset_info(c, 1))) return rc;
     if (c->d.NB == 0) return 0;
-    MW_DISPATCH(c, hipLaunchKernelGGL(k_mw_potrf_x<KK>, dim3(c->d.NB), dim3(MW_NT), c->sm_x, c->stream, c->d, d_X, d_Xchol, c->lds_x ? 1 : 0));
+    MW_DISPATCH(c, hipLaunchKernelGGL(k_mw_potrf_x<KK>, dim3(c->d.NB), dim3(MW_PT), c->sm_x, c->stream, c->d, d_X, d_Xchol, c->lds_x ? 1 : 0));
     MWCHECK(hipGetLastError());
     return 0;
 }
@@ -609,7 +613,7 @@ extern "C" int clrs_mw_schur_factor_local_dev(clrs_mw_ctx *c) {
     int rc;
     if ((rc = mw_reset_info(c, 0))) return rc;
     if (c->timing) MWCHECK(hipEventRecord(c->ev[2], c->stream));
-    MW_DISPATCH(c, { hipLaunchKernelGGL(k_mw_factor<KK>, dim3(q.J), dim3(MW_NT), c->sm_factor, c->stream, q); });
+    MW_DISPATCH(c, { hipLaunchKernelGGL(k_mw_factor<KK>, dim3(q.J), dim3(MW_PT), c->sm_factor, c->stream, q); });
     for (int j = 0; j < q.J; j++) {                     // clusters that do not fit in LDS: blocked over many workgroups
         const MwClu &cl = c->clu[j];
         if (cl.lds) continue;
@@ -636,7 +640,7 @@ extern "C" int clrs_mw_schur_factor_finish_dev(clrs_mw_ctx *c) {
     MWCHECK(hipSetDevice(c->device));
     const MwDev &q = c->d;
     if (q.N > 0 && c->lds_q) {
-        MW_DISPATCH(c, { hipLaunchKernelGGL(k_mw_potrf_q<KK>, dim3(1), dim3(MW_NT), c->sm_q, c->stream, q, 1); });
+        MW_DISPATCH(c, { hipLaunchKernelGGL(k_mw_potrf_q<KK>, dim3(1), dim3(MW_PT), c->sm_q, c->stream, q, 1); });
     } else if (q.N > 0) {
         MW_DISPATCH(c, { hipLaunchKernelGGL(k_mw_qsum<KK>, dim3((unsigned)std::min<i64>(256, ((i64)q.N * q.N + MW_NT - 1) / MW_NT)), dim3(MW_NT), 0, c->stream, q); });
         MwBp m = {q.Q, q.qrd, q.Qf, q.Qb, c->d_bpFd, (i64)q.N * q.N, (i64)q.N, (i64)q.N * q.N, q.N, q.N, q.J + 1, 0};

@@ -676,7 +676,7 @@ extern "C" int clrs_mw_ipm_create_ex(clrs_mw_ctx *c, const clrs_ipm_data *data, 
         if (nnK > lim) return mw_fail(CLRS_ERR_INVALID, "device-resident multi-word iteration needs PSD blocks that fit in LDS");
         st->lds_ZL = 3 * nnK <= lim;
         st->sm_Z = (st->lds_ZL ? 3 : 1) * nnK * 8;
-        const size_t step_rest = (size_t)K * maxn + maxn * maxn + 3 * maxn + 2 * MW_NT + K + 1 + 8;
+        const size_t step_rest = (size_t)K * maxn + maxn * maxn + 3 * maxn + 2 * MW_NT + MW_POTRF_SCR(K, maxn) + 8;
         st->step_w_lds = 2 * nnK + step_rest <= lim;
         const size_t stepd = (st->step_w_lds ? 2 : 1) * nnK + step_rest;
         if (stepd > lim) return mw_fail(CLRS_ERR_INVALID, "device-resident multi-word iteration needs PSD blocks that fit in LDS");

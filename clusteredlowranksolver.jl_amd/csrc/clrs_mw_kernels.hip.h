@@ -21,7 +21,8 @@
 
 // Template parameters: K = limbs of every computed number, DK = limbs of the problem data (sampled vectors, lambda, dense
 // A_p, B; the reference holds them at `prec` bits too, src/interface.jl:1078-1112).  DK = 1 is plain fp64 data.
-#define MW_NT 256            // threads per workgroup, every kernel
+#define MW_NT 256            // threads per workgroup, every kernel but the three factorisations
+#define MW_PT 512            // threads per workgroup of k_mw_potrf_x, k_mw_factor, k_mw_potrf_q: one wave on the dependent chain, seven behind it
 #define MW_CT 8              // columns of V per workgroup in k_mw_zt
 #define MW_INFO_NONE 0x7f7f7f7f
 
@@ -122,88 +123,98 @@ __device__ __forceinline__ mw<K> lanes_sum(mw<K> v) {
     return v;
 }
 
+// Exact scaling of one elimination step: ex even with d 2^-ex in [1/2, 2); p1 = 2^-ex, ph = 2^(-ex/2)  (d > 0, normal)
+__device__ __forceinline__ void pivot_scale(double head, double &p1, double &ph) {
+    int ex = ((__double2hiint(head) >> 20) & 0x7ff) - 1023;
+    ex += ex & 1;
+    p1 = __hiloint2double((1023 - ex) << 20, 0);
+    ph = __hiloint2double((1023 - ex / 2) << 20, 0);
+}
+#define MW_POTRF_SCR(K, n) (2 * (K) * (n))      // doubles of LDS scratch wg_potrf needs for an n x n matrix
+
 // In-place lower Cholesky of the n x n matrix M (planar, leading dimension ld; only the lower triangle is read), reciprocal
 // diagonal to rd.  approx_cholesky! (src/tools.jl:69-107): returns false at the first non-positive pivot.
-// The factorisation is carried as an LDL^T elimination, because its dependent chain per pivot is shorter:
-//     d_k  ->  u_ik = a_ik / d_k  ->  a_(i,k+1) -= u_ik a_(k+1,k)  ->  d_(k+1)
-// (one division by a shared divisor, div_hr, and one multiply-add; the Cholesky form needs 1/sqrt(d_k), a product and a
-// multiply-add).  ONE wave evaluates the division of the pivot column, keeping the undivided column a_(.,k) in row k of the
-// upper triangle; meanwhile the other waves apply the part of the previous rank-1 update that the chain does not need yet
-// (columns > k: look-ahead) and, with INV, the same elimination step to a unit matrix W, which turns it into U^-1 behind the
-// chain at no cost to it.  After the loop, off the chain and in parallel: sqrt(d_k), L = U sqrt(D), W <- L^-1 = D^-1/2 U^-1;
-// the strict upper triangle of M is left holding U^T (= the column-scaled factor the backward substitutions use).
-// `bc`: LDS, K + 1 doubles (status of the pivot, for the other waves).
-template <int K, bool INV, class PM, class PR, class PW>
-__device__ __forceinline__ bool wg_potrf(PM M, long plane, int n, int ld, PR rd, long rdplane, PW W, long wplane, int ldw, lds_d *bc, int tid) {
-    constexpr int KH = (K + 1) / 2;
-    const int wave = tid >> 6;
+//
+// A K-limb reciprocal or reciprocal square root costs three to four K-limb products, and a Cholesky (or LDL^T) elimination has
+// one of them on the dependent chain of every pivot.  The elimination is therefore carried in FRACTION-FREE form: with
+// a~ = s_k a (s_k the product of the scaled pivots so far) one step is
+//     a~_ij  <-  (d~_k a~_ij - a~_ik a~_jk) 2^-ex_k ,      s_(k+1) = s_k d~_k 2^-ex_k ,
+// two products into one accumulator and an exact power of two that keeps s_k near 1: no division, no square root, no
+// look-ahead, every entry of the trailing matrix equally cheap and ONE barrier per pivot.  The pivots keep their sign
+// (s_k > 0), so the failure test is unchanged.  With INV the same step is applied to a unit matrix W beside M ([M | I]
+// elimination), which leaves s_i (U^-1)_ij in row i.  What the chain no longer does happens once, for all pivots in parallel,
+// after the loop:  d_k = d~_k / s_k,  1/sqrt(d_k),  L_kk = sqrt(d_k),  f_k = 1 / (s_k sqrt(d_k));  L_ik = a~_ik f_k,
+// (L^-1)_ij = W_ij f_i.  The rounding errors are those of the classical elimination (each step rounds its entry once, relative
+// to the larger of its two terms); the scaling is exact.
+// Without INV the strict upper triangle of M is left holding U^T (u_ik = a~_ik / d~_k, the column-scaled factor of the backward
+// substitutions); with INV the triangular solves are products with W and U is not formed.
+// `scr`: LDS, MW_POTRF_SCR(K, n) doubles.
+template <int K, bool INV, int NT = MW_NT, class PM, class PR, class PW>
+__device__ __forceinline__ bool wg_potrf(PM M, long plane, int n, int ld, PR rd, long rdplane, PW W, long wplane, int ldw, lds_d *scr, int tid) {
     if (INV) {
-        for (int e = tid; e < n * n; e += MW_NT) {
+        for (int e = tid; e < n * n; e += NT) {
             const int i = e % n, c = e / n;
             stx<K>(W, wplane, i + (long)c * ldw, i == c ? from_double<K>(1.0) : zero<K>());
         }
+        __syncthreads();
     }
+    mw<K> srun = from_double<K>(1.0);                                   // s_k, carried by the last thread (idle in most tail rounds)
+    if (tid == NT - 1) stx<K>(rd, rdplane, 0, srun);
     for (int k = 0; k < n; k++) {
-        const long kk = k + (long)k * ld;
-        if (wave == 0) {
-            const mw<K> d = ldx<K>(M, plane, kk);
-            const bool ok = d.l[0] > 0.0;
-            if (tid == 0) bc[K] = ok ? 1.0 : 0.0;
-            if (ok && k + 1 < n) {
-                const mw<KH> x = recip<KH>(cvt<KH, K>(d));
-                for (int i = k + 1 + tid; i < n; i += 64) {
-                    const long idx = i + (long)k * ld;
-                    const mw<K> a = ldx<K>(M, plane, idx);
-                    stx<K>(M, plane, k + (long)i * ld, a);
-                    stx<K>(M, plane, idx, div_hr<K>(a, d, x));
-                }
-            }
-        } else if (k > 0) {
-            const int m = n - k - 1, cnt = m * (m + 1) / 2;            // rest of update k-1: columns k+1 .. n-1
-            const int mi = n - k, cnt2 = INV ? mi * k : 0;             // step k-1 of the inverse: rows k .. n-1, columns 0 .. k-1
-            for (int e = tid - 64; e < cnt + cnt2; e += MW_NT - 64) {
-                if (e < cnt) {
-                    int ii, jj;
-                    tri_index(e, ii, jj);
-                    const int i = k + 1 + ii, j = k + 1 + jj;
-                    const long idx = i + (long)j * ld;
-                    stx<K>(M, plane, idx, fnma<K>(ldx<K>(M, plane, idx), ldx<K>(M, plane, i + (long)(k - 1) * ld), ldx<K>(M, plane, (k - 1) + (long)j * ld)));
-                } else {
-                    const int e2 = e - cnt, i = k + e2 % mi, j = e2 / mi;
-                    const long idx = i + (long)j * ldw;
-                    stx<K>(W, wplane, idx, fnma<K>(ldx<K>(W, wplane, idx), ldx<K>(M, plane, i + (long)(k - 1) * ld), ldx<K>(W, wplane, (k - 1) + (long)j * ldw)));
-                }
-            }
-        }
-        __syncthreads();
-        if (bc[K] == 0.0) return false;
+        const mw<K> d = ldx<K>(M, plane, k + (long)k * ld);
+        if (!(d.l[0] > 0.0)) return false;                              // every thread reads the same pivot: uniform exit
         if (k + 1 < n) {
-            const mw<K> ak = ldx<K>(M, plane, k + (long)(k + 1) * ld);   // a_(k+1,k), undivided
-            for (int i = k + 1 + tid; i < n; i += MW_NT) {
-                const long idx = i + (long)(k + 1) * ld;
-                stx<K>(M, plane, idx, fnma<K>(ldx<K>(M, plane, idx), ldx<K>(M, plane, i + (long)k * ld), ak));
+            double p1, ph;
+            pivot_scale(d.l[0], p1, ph);
+            const mw<K> dh = mul_pow2<K>(d, p1);
+            const int m = n - k - 1, base = (k + 1) * (k + 2) / 2;
+            const int total = INV ? n * (n + 1) / 2 - base : m * (m + 1) / 2;    // INV: rows k+1.., columns 0..i of [W | M]; else the trailing triangle
+            for (int e = tid; e < total; e += NT) {
+                int i, c;
+                if (INV) tri_index(e + base, i, c);
+                else { tri_index(e, i, c); i += k + 1; c += k + 1; }
+                const mw<K> ci = mul_pow2<K>(ldx<K>(M, plane, i + (long)k * ld), ph);
+                const bool tr = !INV || c > k;
+                const mw<K> cj = mul_pow2<K>(tr ? ldx<K>(M, plane, c + (long)k * ld) : ldx<K>(W, wplane, k + (long)c * ldw), ph);
+                const mw<K> v = tr ? ldx<K>(M, plane, i + (long)c * ld) : ldx<K>(W, wplane, i + (long)c * ldw);
+                acc<K> s;
+                acc_zero<K>(s);
+                acc_fma<K, K, K>(s, dh, v);
+                acc_fma<K, K, K>(s, ci, cj, -1.0);
+                const mw<K> r = acc_result<K>(s);
+                if (tr) stx<K>(M, plane, i + (long)c * ld, r);
+                else stx<K>(W, wplane, i + (long)c * ldw, r);
+            }
+            if (tid == NT - 1) {
+                srun = mul<K>(srun, dh);
+                stx<K>(rd, rdplane, k + 1, srun);
+                if (INV) stx<K>(W, wplane, (k + 1) + (long)(k + 1) * ldw, srun);
             }
         }
         __syncthreads();
     }
-    for (int k = tid; k < n; k += MW_NT) {                               // L_kk = sqrt(d_k), 1 / L_kk
+    lds_d *fs = scr, *us = scr + (long)K * n;
+    for (int k = tid; k < n; k += NT) {
         const long kk = k + (long)k * ld;
-        const mw<K> d = ldx<K>(M, plane, kk), rs = rsqrt<K>(d);
+        const mw<K> is = recip<K>(ldx<K>(rd, rdplane, k));
+        const mw<K> d = mul<K>(ldx<K>(M, plane, kk), is), rs = rsqrt<K>(d);
         stx<K>(rd, rdplane, k, rs);
         stx<K>(M, plane, kk, sqrt_with_rsqrt<K>(d, rs));
+        const mw<K> f = mul<K>(rs, is);
+        stx<K>(fs, n, k, f);
+        if (!INV) stx<K>(us, n, k, mul<K>(f, rs));
     }
     __syncthreads();
-    for (int e = tid; e < n * n; e += MW_NT) {
+    for (int e = tid; e < n * n; e += NT) {
         const int i = e % n, c = e / n;
         if (i > c) {
-            const mw<K> u = ldx<K>(M, plane, i + (long)c * ld);
-            stx<K>(M, plane, c + (long)i * ld, u);
-            stx<K>(M, plane, i + (long)c * ld, mul<K>(u, ldx<K>(M, plane, c + (long)c * ld)));
+            const mw<K> a = ldx<K>(M, plane, i + (long)c * ld);
+            if (!INV) stx<K>(M, plane, c + (long)i * ld, mul<K>(a, ldx<K>(us, n, c)));
+            stx<K>(M, plane, i + (long)c * ld, mul<K>(a, ldx<K>(fs, n, c)));
         }
         if (INV && i >= c) {
             const long idx = i + (long)c * ldw;
-            const mw<K> ri = ldx<K>(rd, rdplane, i);
-            stx<K>(W, wplane, idx, i == c ? ri : mul<K>(ldx<K>(W, wplane, idx), ri));
+            stx<K>(W, wplane, idx, i == c ? ldx<K>(rd, rdplane, i) : mul<K>(ldx<K>(W, wplane, idx), ldx<K>(fs, n, i)));
         }
     }
     __syncthreads();
@@ -211,10 +222,10 @@ __device__ __forceinline__ bool wg_potrf(PM M, long plane, int n, int ld, PR rd,
 }
 
 // The same two scaled triangles after wg_potrf, whose strict upper triangle already holds U^T = Bk: F[i,k] = L[i,k] / L[i,i].
-template <int K, class PL, class PR, class PF, class PB>
+template <int K, int NT = MW_NT, class PL, class PR, class PF, class PB>
 __device__ __forceinline__ void wg_scaled_factors_u(PL L, long lplane, int ldl, PR rd, long rdplane, int n, PF F, long fplane, int ldf, PB Bk,
                                                     long bplane, int ldb, int tid) {
-    for (int e = tid; e < n * n; e += MW_NT) {
+    for (int e = tid; e < n * n; e += NT) {
         const int i = e % n, k = e / n;
         if (i > k) {
             stx<K>(F, fplane, i + (long)k * ldf, mul<K>(ldx<K>(L, lplane, i + (long)k * ldl), ldx<K>(rd, rdplane, i)));
@@ -348,9 +359,9 @@ __device__ __forceinline__ mw<K> wave_trsv_b(PF Bk, long fplane, int ldf, int n,
 }
 
 // copy a rows x cols planar matrix between two arrays (any address spaces)
-template <int K, class PD, class PS>
+template <int K, int NT = MW_NT, class PD, class PS>
 __device__ __forceinline__ void wg_copy(PD dst, long dplane, int ldd, PS src, long splane, int lds_, int rows, int cols, int tid) {
-    for (int e = tid; e < rows * cols; e += MW_NT) {
+    for (int e = tid; e < rows * cols; e += NT) {
         const int i = e % rows, c = e / rows;
 #pragma unroll
         for (int l = 0; l < K; l++) dst[(long)l * dplane + i + (long)c * ldd] = src[(long)l * splane + i + (long)c * lds_];
@@ -370,30 +381,30 @@ template <int K, class PM>
 __device__ __forceinline__ void mw_potrf_x_body(const MwDev &q, const MwBlk &k, PM M, long plane, double *__restrict__ Xc, mwk::lds_d *bc, int tid, int bid) {
     using namespace mwk;
     const int n = k.n;
-    const bool ok = wg_potrf<K, false>(M, plane, n, n, q.xrd + k.rd_off, q.xrdlen, M, 0, 0, bc, tid);
+    const bool ok = wg_potrf<K, false, MW_PT>(M, plane, n, n, q.xrd + k.rd_off, q.xrdlen, M, 0, 0, bc, tid);
     if (!ok && tid == 0) atomicMin(&q.info[1], bid + 1);
     __syncthreads();
-    if (ok) wg_scaled_factors_u<K>(M, plane, n, q.xrd + k.rd_off, q.xrdlen, n, q.Xf + k.xyoff, q.xylen, n, q.Xb + k.xyoff, q.xylen, n, tid);
-    for (int e = tid; e < n * n; e += MW_NT) {
+    if (ok) wg_scaled_factors_u<K, MW_PT>(M, plane, n, q.xrd + k.rd_off, q.xrdlen, n, q.Xf + k.xyoff, q.xylen, n, q.Xb + k.xyoff, q.xylen, n, tid);
+    for (int e = tid; e < n * n; e += MW_PT) {
         const int i = e % n, c = e / n;
 #pragma unroll
         for (int l = 0; l < K; l++) Xc[(long)l * q.xylen + k.xyoff + e] = (i >= c) ? (double)M[(long)l * plane + e] : 0.0;
     }
 }
 template <int K>
-__global__ __launch_bounds__(MW_NT) void k_mw_potrf_x(const MwDev q, const double *__restrict__ X, double *__restrict__ Xc, int lds) {
+__global__ __launch_bounds__(MW_PT) void k_mw_potrf_x(const MwDev q, const double *__restrict__ X, double *__restrict__ Xc, int lds) {
     using namespace mwk;
     const MwBlk &k = q.blk[blockIdx.x];
     const int n = k.n, tid = threadIdx.x;
-    lds_d *bc = MW_LDS;                                   // K + 1 doubles, in front of the matrix
+    lds_d *bc = MW_LDS;                                   // scratch of wg_potrf, in front of the matrix
     if (lds) {
-        lds_d *M = MW_LDS + (K + 1);
-        wg_copy<K>(M, (long)n * n, n, X + k.xyoff, q.xylen, n, n, n, tid);
+        lds_d *M = MW_LDS + MW_POTRF_SCR(K, n);
+        wg_copy<K, MW_PT>(M, (long)n * n, n, X + k.xyoff, q.xylen, n, n, n, tid);
         __syncthreads();
         mw_potrf_x_body<K>(q, k, M, (long)n * n, Xc, bc, tid, blockIdx.x);
     } else {
         double *M = Xc + k.xyoff;
-        wg_copy<K>(M, q.xylen, n, X + k.xyoff, q.xylen, n, n, n, tid);
+        wg_copy<K, MW_PT>(M, q.xylen, n, X + k.xyoff, q.xylen, n, n, n, tid);
         __syncthreads();
         mw_potrf_x_body<K>(q, k, M, q.xylen, Xc, bc, tid, blockIdx.x);
     }
@@ -600,14 +611,14 @@ template <int K, bool INV, class PM, class PW>
 __device__ __forceinline__ bool mw_factor_body(const MwDev &q, const MwClu &c, int j, PM M, long mplane, PW W, mwk::lds_d *bc, int tid) {
     using namespace mwk;
     const int P = c.P;
-    const bool ok = wg_potrf<K, INV>(M, mplane, P, P, q.srd + c.coff, q.xlen, W, mplane, P, bc, tid);
+    const bool ok = wg_potrf<K, INV, MW_PT>(M, mplane, P, P, q.srd + c.coff, q.xlen, W, mplane, P, bc, tid);
     if (!ok) {
         if (tid == 0) atomicMin(&q.info[0], j + 1);
         return false;
     }
     double *Sg = q.S + c.Soff;
-    wg_scaled_factors_u<K>(M, mplane, P, q.srd + c.coff, q.xlen, P, q.Sf + c.Soff, q.Slen, P, q.Sb + c.Soff, q.Slen, P, tid);
-    for (int e = tid; e < P * P; e += MW_NT) {            // L_j back to the S buffer with a zero strict upper triangle
+    if (!INV) wg_scaled_factors_u<K, MW_PT>(M, mplane, P, q.srd + c.coff, q.xlen, P, q.Sf + c.Soff, q.Slen, P, q.Sb + c.Soff, q.Slen, P, tid);
+    for (int e = tid; e < P * P; e += MW_PT) {            // L_j back to the S buffer with a zero strict upper triangle
         const int i = e % P, cc = e / P;
 #pragma unroll
         for (int l = 0; l < K; l++) {
@@ -618,15 +629,15 @@ __device__ __forceinline__ bool mw_factor_body(const MwDev &q, const MwClu &c, i
     return true;
 }
 template <int K>
-__global__ __launch_bounds__(MW_NT) void k_mw_factor(const MwDev q) {
+__global__ __launch_bounds__(MW_PT) void k_mw_factor(const MwDev q) {
     using namespace mwk;
     const int j = blockIdx.x, tid = threadIdx.x;
     const MwClu &c = q.clu[j];
     const int P = c.P;
     lds_d *bc = MW_LDS;
     if (c.lds) {
-        lds_d *M = MW_LDS + (K + 1);
-        wg_copy<K>(M, (long)P * P, P, q.S + c.Soff, q.Slen, P, P, P, tid);
+        lds_d *M = MW_LDS + MW_POTRF_SCR(K, P);
+        wg_copy<K, MW_PT>(M, (long)P * P, P, q.S + c.Soff, q.Slen, P, P, P, tid);
         __syncthreads();
         if (c.inv) mw_factor_body<K, true>(q, c, j, M, (long)P * P, M + (long)K * P * P, bc, tid);
         else mw_factor_body<K, false>(q, c, j, M, (long)P * P, M, bc, tid);
@@ -718,14 +729,14 @@ template <int K, bool INV, class PM, class PW>
 __device__ __forceinline__ void mw_potrf_q_body(const MwDev &q, PM M, long plane, PW W, mwk::lds_d *bc, int tid) {
     using namespace mwk;
     const int N = q.N;
-    const bool ok = wg_potrf<K, INV>(M, plane, N, N, q.qrd, N, W, plane, N, bc, tid);
+    const bool ok = wg_potrf<K, INV, MW_PT>(M, plane, N, N, q.qrd, N, W, plane, N, bc, tid);
     if (!ok) {
         if (tid == 0) atomicMin(&q.info[0], q.J + 1);
         return;
     }
-    wg_scaled_factors_u<K>(M, plane, N, q.qrd, N, N, q.Qf, (long)N * N, N, q.Qb, (long)N * N, N, tid);
+    if (!INV) wg_scaled_factors_u<K, MW_PT>(M, plane, N, q.qrd, N, N, q.Qf, (long)N * N, N, q.Qb, (long)N * N, N, tid);
     __syncthreads();
-    for (int e = tid; e < N * N; e += MW_NT) {
+    for (int e = tid; e < N * N; e += MW_PT) {
         const int i = e % N, cc = e / N;
 #pragma unroll
         for (int l = 0; l < K; l++) {
@@ -735,15 +746,15 @@ __device__ __forceinline__ void mw_potrf_q_body(const MwDev &q, PM M, long plane
     }
 }
 template <int K>
-__global__ __launch_bounds__(MW_NT) void k_mw_potrf_q(const MwDev q, int lds) {
+__global__ __launch_bounds__(MW_PT) void k_mw_potrf_q(const MwDev q, int lds) {
     using namespace mwk;
     const int N = q.N, tid = threadIdx.x;
     if (q.info[0] != MW_INFO_NONE) return;           // a cluster failed: the reference throws before reaching Q
     lds_d *bc = MW_LDS;
     const long nn = (long)N * N;
     if (lds) {
-        lds_d *M = MW_LDS + (K + 1);
-        for (int e = tid; e < nn; e += MW_NT) {            // Q = sum over the ranks' partial sums, in rank order on every rank
+        lds_d *M = MW_LDS + MW_POTRF_SCR(K, N);
+        for (int e = tid; e < nn; e += MW_PT) {            // Q = sum over the ranks' partial sums, in rank order on every rank
             acc<K> s;
             acc_zero<K>(s);
             for (int r = 0; r < q.world; r++) acc_add<K, K>(s, ldx<K>(q.Qg + (long)r * K * nn, nn, e));
@@ -788,7 +799,7 @@ __global__ __launch_bounds__(MW_NT) void k_mw_bp_diag(const MwDev q, const MwBp 
     using namespace mwk;
     if (q.info[m.which] != MW_INFO_NONE) return;
     const int nb = min(MW_PB, m.n - j0), tid = threadIdx.x;
-    lds_d *bc = MW_LDS, *D = MW_LDS + (K + 1), *rdl = D + (long)K * MW_PB * MW_PB;
+    lds_d *bc = MW_LDS, *D = MW_LDS + MW_POTRF_SCR(K, MW_PB), *rdl = D + (long)K * MW_PB * MW_PB;
     wg_copy<K>(D, (long)nb * nb, nb, m.M + j0 + (long)j0 * m.ld, m.plane, m.ld, nb, nb, tid);
     __syncthreads();
     if (!wg_potrf<K, false>(D, (long)nb * nb, nb, nb, rdl, nb, D, 0, 0, bc, tid)) {

@@ -16,6 +16,9 @@ __global__ void k(double *out, int n, double seed) {
         if (OP == 4) { a = recip<K>(a); a.l[0] += 1.0; }
         if (OP == 5) { acc<K> s; acc_zero<K>(s); for (int j = 0; j < 16; j++) { acc_fma<K, K, K>(s, a, b); b.l[0] += 1e-9; } a = acc_result<K>(s); a = mul_pow2<K>(a, 1.0 / 16); }
         if (OP == 6) a = mul_d<K>(a, 1.0000001);
+        if (OP == 7) { a = div_hr<K>(a, b, recip<(K + 1) / 2>(cvt<(K + 1) / 2, K>(b))); b.l[0] += 1e-9; }     // shared-divisor division with its half-precision reciprocal
+        if (OP == 8) { mw<(K + 1) / 2> x = recip<(K + 1) / 2>(cvt<(K + 1) / 2, K>(a)); a.l[0] = x.l[0] + 1.0; a.l[1] = x.l[1] * 1e-3; }
+        if (OP == 9) { mw<(K + 1) / 2> x; x.l[0] = 1.0 / b.l[0]; for (int l = 1; l < (K + 1) / 2; l++) x.l[l] = 1e-17 * x.l[l - 1]; a = div_hr<K>(a, b, x); }   // div_hr alone
     }
     double s = 0;
     for (int l = 0; l < K; l++) s += a.l[l];
@@ -37,6 +40,7 @@ void run(const char *name, int n, int per) {
 }
 int main() {
     run<5, 0>("mul", 2000, 1); run<5, 1>("fnma", 2000, 1); run<5, 2>("add", 2000, 1); run<5, 6>("mul_d", 2000, 1); run<5, 3>("rsqrt", 500, 1); run<5, 4>("recip", 500, 1); run<5, 5>("dot16/term", 200, 16);
-    run<4, 0>("mul", 2000, 1); run<4, 1>("fnma", 2000, 1); run<4, 3>("rsqrt", 500, 1); run<4, 5>("dot16/term", 200, 16);
+    run<5, 7>("div_fast", 500, 1); run<5, 8>("recip<KH>", 500, 1); run<5, 9>("div_hr", 500, 1);
+    run<4, 0>("mul", 2000, 1); run<4, 1>("fnma", 2000, 1); run<4, 3>("rsqrt", 500, 1); run<4, 5>("dot16/term", 200, 16); run<4, 7>("div_fast", 500, 1); run<4, 9>("div_hr", 500, 1);
     return 0;
 }
