@@ -161,6 +161,9 @@ __device__ __forceinline__ bool wg_potrf(PM M, long plane, int n, int ld, PR rd,
     mw<K> srun = from_double<K>(1.0);                                   // s_k, carried by the last thread (idle in most tail rounds)
     if (tid == NT - 1) stx<K>(rd, rdplane, 0, srun);
     for (int k = 0; k < n; k++) {
+#ifdef MW_STAMPS
+        if (tid == 0 && k > 0) g_stamps[k] = wall_clock64();
+#endif
         const mw<K> d = ldx<K>(M, plane, k + (long)k * ld);
         if (!(d.l[0] > 0.0)) return false;                              // every thread reads the same pivot: uniform exit
         if (k + 1 < n) {
@@ -194,30 +197,44 @@ __device__ __forceinline__ bool wg_potrf(PM M, long plane, int n, int ld, PR rd,
         __syncthreads();
     }
     lds_d *fs = scr, *us = scr + (long)K * n;
+#ifdef MW_STAMPS
+    if (tid == 0) g_stamps[n] = wall_clock64();
+#endif
+    // per pivot, in parallel: f_k = 1 / sqrt(s_k d~_k) = 1 / (s_k sqrt(d_k)), then 1/sqrt(d_k) = f_k s_k, sqrt(d_k) = d~_k f_k,
+    // 1/d~_k = f_k^2 s_k: one reciprocal square root and products
     for (int k = tid; k < n; k += NT) {
         const long kk = k + (long)k * ld;
-        const mw<K> is = recip<K>(ldx<K>(rd, rdplane, k));
-        const mw<K> d = mul<K>(ldx<K>(M, plane, kk), is), rs = rsqrt<K>(d);
+        const mw<K> sk = ldx<K>(rd, rdplane, k), dt = ldx<K>(M, plane, kk);
+        const mw<K> f = rsqrt<K>(mul<K>(sk, dt)), rs = mul<K>(f, sk);
         stx<K>(rd, rdplane, k, rs);
-        stx<K>(M, plane, kk, sqrt_with_rsqrt<K>(d, rs));
-        const mw<K> f = mul<K>(rs, is);
+        stx<K>(M, plane, kk, mul<K>(dt, f));
         stx<K>(fs, n, k, f);
         if (!INV) stx<K>(us, n, k, mul<K>(f, rs));
     }
     __syncthreads();
-    for (int e = tid; e < n * n; e += NT) {
-        const int i = e % n, c = e / n;
-        if (i > c) {
+#ifdef MW_STAMPS
+    if (tid == 0) g_stamps[100] = wall_clock64();
+#endif
+    // one product per task: L_ik = a~_ik f_k; without INV also U^T into the upper triangle, with INV (L^-1)_ij = W_ij f_i
+    const int T = n * (n - 1) / 2;
+    for (int e = tid; e < (INV ? 2 * T : T); e += NT) {
+        int i, c;
+        tri_index(e < T ? e : e - T, i, c);
+        i += 1;                                                          // strict lower triangle: i > c
+        if (e < T) {
             const mw<K> a = ldx<K>(M, plane, i + (long)c * ld);
             if (!INV) stx<K>(M, plane, c + (long)i * ld, mul<K>(a, ldx<K>(us, n, c)));
             stx<K>(M, plane, i + (long)c * ld, mul<K>(a, ldx<K>(fs, n, c)));
-        }
-        if (INV && i >= c) {
+        } else {
             const long idx = i + (long)c * ldw;
-            stx<K>(W, wplane, idx, i == c ? ldx<K>(rd, rdplane, i) : mul<K>(ldx<K>(W, wplane, idx), ldx<K>(fs, n, i)));
+            stx<K>(W, wplane, idx, mul<K>(ldx<K>(W, wplane, idx), ldx<K>(fs, n, i)));
         }
     }
+    if (INV) for (int i = tid; i < n; i += NT) stx<K>(W, wplane, i + (long)i * ldw, ldx<K>(rd, rdplane, i));
     __syncthreads();
+#ifdef MW_STAMPS
+    if (tid == 0) g_stamps[101] = wall_clock64();
+#endif
     return true;
 }
 
