@@ -83,6 +83,7 @@ struct clrs_mw_ctx {
     std::vector<MwClu> clu;
     std::vector<void *> allocs;
     int maxU = 0, maxP = 0, maxn = 0, maxP_inv = 0;
+    bool xinv_valid = false;            // Xi holds the inverses of the current Cholesky factors (they come from k_mw_potrf_x, not from the caller)
     bool lds_x = false, lds_q = false, lds_zt_L = false, qinv = false, any_inv = false, any_sub = false;
     size_t sm_x = 0, sm_zt = 0, sm_dense = 0, sm_factor = 0, sm_q = 0, sm_fwd = 0, sm_mid = 0, sm_bwd = 0;
     int *h_info = nullptr;               // pinned
@@ -325,7 +326,13 @@ extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int dev
         size_t nn = (size_t)c->maxn * c->maxn * K;
         size_t bcw = MW_POTRF_SCR(K, (size_t)c->maxn);       // scratch of wg_potrf
         c->lds_x = nn + bcw <= lim;
-        c->sm_x = ((c->lds_x ? nn : 0) + bcw) * 8;
+        size_t xneed = (c->lds_x ? nn : 0) + bcw;
+        for (auto &k : c->blk) {                            // X blocks whose factor and its inverse fit side by side: Xi is formed
+            const size_t two = 2 * (size_t)k.n * k.n * K + MW_POTRF_SCR(K, (size_t)k.n);
+            k.inv = (use_inv && c->lds_x && two <= lim) ? 1 : 0;
+            if (k.inv) xneed = std::max(xneed, two);
+        }
+        c->sm_x = xneed * 8;
         size_t zt = (size_t)c->maxn * MW_CT * K;
         c->lds_zt_L = zt + nn <= lim;
         c->sm_zt = (zt + (c->lds_zt_L ? nn : 0)) * 8;
@@ -410,7 +417,7 @@ extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int dev
     MW_TRY(mw_dmalloc(c, &q.Si, Slen * K)); MW_TRY(mw_dmalloc(c, &q.Qi, (i64)N * N * K));
     q.qinv = c->qinv ? 1 : 0;
     MW_TRY(mw_dmalloc(c, &q.Qf, (i64)N * N * K)); MW_TRY(mw_dmalloc(c, &q.Qb, (i64)N * N * K));
-    MW_TRY(mw_dmalloc(c, &q.Xf, xyoff * K)); MW_TRY(mw_dmalloc(c, &q.Xb, xyoff * K));
+    MW_TRY(mw_dmalloc(c, &q.Xf, xyoff * K)); MW_TRY(mw_dmalloc(c, &q.Xb, xyoff * K)); MW_TRY(mw_dmalloc(c, &q.Xi, xyoff * K));
     MW_TRY(mw_dmalloc(c, &q.xrd, rdoff * K)); MW_TRY(mw_dmalloc(c, &q.srd, xlen * K)); MW_TRY(mw_dmalloc(c, &q.qrd, (i64)N * K));
     MW_TRY(mw_dmalloc(c, &q.t, xlen * K)); MW_TRY(mw_dmalloc(c, &q.u, (i64)J * N * K)); MW_TRY(mw_dmalloc(c, &q.AY, T * K));
     MW_TRY(mw_dmalloc(c, &c->d_Xin, xyoff * K)); MW_TRY(mw_dmalloc(c, &c->d_Xc, xyoff * K)); MW_TRY(mw_dmalloc(c, &c->d_Y, xyoff * K));
@@ -503,6 +510,7 @@ extern "C" int clrs_mw_cholesky_blocks_dev(clrs_mw_ctx *c, const double *d_X, do
     if (c->d.NB == 0) return 0;
     MW_DISPATCH(c, hipLaunchKernelGGL(k_mw_potrf_x<KK>, dim3(c->d.NB), dim3(MW_PT), c->sm_x, c->stream, c->d, d_X, d_Xchol, c->lds_x ? 1 : 0));
     MWCHECK(hipGetLastError());
+    c->xinv_valid = true;
     return 0;
 }
 extern "C" int clrs_mw_sync_status_cholesky(clrs_mw_ctx *c) {
@@ -520,7 +528,7 @@ extern "C" int clrs_mw_schur_assemble_dev(clrs_mw_ctx *c, const double *d_Xchol,
     MW_DISPATCH(c, {
         if (q.nlr) {
             const int gper = MW_NT / MW_GRAM_W;
-            hipLaunchKernelGGL((k_mw_zt<KK, DD>), dim3((c->maxU + MW_CT - 1) / MW_CT, q.nlr), dim3(MW_NT), c->sm_zt, c->stream, q, d_Y, c->lds_zt_L ? 1 : 0);
+            hipLaunchKernelGGL((k_mw_zt<KK, DD>), dim3((c->maxU + MW_CT - 1) / MW_CT, q.nlr), dim3(MW_NT), c->sm_zt, c->stream, q, d_Y, c->lds_zt_L ? 1 : 0, c->xinv_valid ? 1 : 0);
             hipLaunchKernelGGL((k_mw_gram<KK, DD>), dim3((c->maxU * (c->maxU + 1) / 2 + gper - 1) / gper, q.nlr), dim3(MW_NT), 0, c->stream, q);
         }
         if (q.ndn) hipLaunchKernelGGL((k_mw_dense<KK, DD>), dim3(q.ndn), dim3(MW_NT), c->sm_dense, c->stream, q, d_Y);
@@ -821,6 +829,7 @@ static int mw_launch_xrd(clrs_mw_ctx *c, const double *d_Xc) {
     if (c->d.NB == 0) return 0;
     MW_DISPATCH(c, hipLaunchKernelGGL(k_mw_xrd<KK>, dim3(c->d.NB), dim3(MW_NT), 0, c->stream, c->d, d_Xc));
     MWCHECK(hipGetLastError());
+    c->xinv_valid = false;                  // the caller's factors: no inverse beside them, the assembly substitutes
     return 0;
 }
 // device-pointer form of the same (callers that bring their own Cholesky factors of X)

@@ -29,7 +29,7 @@
 typedef long long mwi64;
 
 struct MwBlk {               // one PSD block (j, l)
-    int j, n, kind, delta, U, cnt, P, pad;
+    int j, n, kind, delta, U, cnt, P, inv;   // inv: chol(X_b)^-1 is formed beside the factor (Xi)
     mwi64 xyoff;             // offset in the xy layout
     mwi64 rd_off;            // offset of its reciprocal Cholesky diagonal in xrd (sum of n over earlier blocks)
     mwi64 v_off;             // low rank: V, n x U column-major fp64 (expanded unique vectors)
@@ -74,6 +74,7 @@ struct MwDev {
     double *Xf, *Xb;                    // the same for the Cholesky factors of the X blocks (xy layout)
     double *xrd, *srd, *qrd;            // reciprocal diagonals of chol(X_b), L_j, L_Q
     double *Si, *Qi;                    // explicit inverses L_j^-1 (S layout, clusters with inv = 1) and L_Q^-1 (qinv = 1), lower triangular
+    double *Xi;                         // chol(X_b)^-1 of the blocks with inv = 1 (xy layout)
     int qinv, pad4;
     double *t, *u, *AY;                 // t = L^-1 rhs_x (xlen); u slabs (J x N); pairings per term
     int *info;                          // [0] factor status, [1] Cholesky-of-X status
@@ -146,10 +147,10 @@ __device__ __forceinline__ void pivot_scale(double head, double &p1, double &ph)
 // after the loop:  d_k = d~_k / s_k,  1/sqrt(d_k),  L_kk = sqrt(d_k),  f_k = 1 / (s_k sqrt(d_k));  L_ik = a~_ik f_k,
 // (L^-1)_ij = W_ij f_i.  The rounding errors are those of the classical elimination (each step rounds its entry once, relative
 // to the larger of its two terms); the scaling is exact.
-// Without INV the strict upper triangle of M is left holding U^T (u_ik = a~_ik / d~_k, the column-scaled factor of the backward
-// substitutions); with INV the triangular solves are products with W and U is not formed.
+// With UT (default: without INV) the strict upper triangle of M is left holding U^T (u_ik = a~_ik / d~_k, the column-scaled
+// factor of the backward substitutions); with INV the triangular solves are products with W and U is formed only on request.
 // `scr`: LDS, MW_POTRF_SCR(K, n) doubles.
-template <int K, bool INV, int NT = MW_NT, class PM, class PR, class PW>
+template <int K, bool INV, int NT = MW_NT, bool UT = !INV, class PM, class PR, class PW>
 __device__ __forceinline__ bool wg_potrf(PM M, long plane, int n, int ld, PR rd, long rdplane, PW W, long wplane, int ldw, lds_d *scr, int tid) {
     if (INV) {
         for (int e = tid; e < n * n; e += NT) {
@@ -209,7 +210,7 @@ __device__ __forceinline__ bool wg_potrf(PM M, long plane, int n, int ld, PR rd,
         stx<K>(rd, rdplane, k, rs);
         stx<K>(M, plane, kk, mul<K>(dt, f));
         stx<K>(fs, n, k, f);
-        if (!INV) stx<K>(us, n, k, mul<K>(f, rs));
+        if (UT) stx<K>(us, n, k, mul<K>(f, rs));
     }
     __syncthreads();
 #ifdef MW_STAMPS
@@ -223,7 +224,7 @@ __device__ __forceinline__ bool wg_potrf(PM M, long plane, int n, int ld, PR rd,
         i += 1;                                                          // strict lower triangle: i > c
         if (e < T) {
             const mw<K> a = ldx<K>(M, plane, i + (long)c * ld);
-            if (!INV) stx<K>(M, plane, c + (long)i * ld, mul<K>(a, ldx<K>(us, n, c)));
+            if (UT) stx<K>(M, plane, c + (long)i * ld, mul<K>(a, ldx<K>(us, n, c)));
             stx<K>(M, plane, i + (long)c * ld, mul<K>(a, ldx<K>(fs, n, c)));
         } else {
             const long idx = i + (long)c * ldw;
@@ -394,18 +395,21 @@ extern __shared__ double mw_lds[];
 // Cholesky of every X block: Xchol_b = chol(X_b), strict upper zero; reciprocal diagonal and the two scaled triangles kept
 // for the substitutions that follow.  One workgroup per block; `lds` = 1: the block is factored in LDS.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int K, class PM>
-__device__ __forceinline__ void mw_potrf_x_body(const MwDev &q, const MwBlk &k, PM M, long plane, double *__restrict__ Xc, mwk::lds_d *bc, int tid, int bid) {
+template <int K, bool INV, class PM, class PW>
+__device__ __forceinline__ void mw_potrf_x_body(const MwDev &q, const MwBlk &k, PM M, long plane, PW W, double *__restrict__ Xc, mwk::lds_d *bc, int tid, int bid) {
     using namespace mwk;
     const int n = k.n;
-    const bool ok = wg_potrf<K, false, MW_PT>(M, plane, n, n, q.xrd + k.rd_off, q.xrdlen, M, 0, 0, bc, tid);
+    const bool ok = wg_potrf<K, INV, MW_PT, true>(M, plane, n, n, q.xrd + k.rd_off, q.xrdlen, W, plane, n, bc, tid);
     if (!ok && tid == 0) atomicMin(&q.info[1], bid + 1);
     __syncthreads();
     if (ok) wg_scaled_factors_u<K, MW_PT>(M, plane, n, q.xrd + k.rd_off, q.xrdlen, n, q.Xf + k.xyoff, q.xylen, n, q.Xb + k.xyoff, q.xylen, n, tid);
     for (int e = tid; e < n * n; e += MW_PT) {
         const int i = e % n, c = e / n;
 #pragma unroll
-        for (int l = 0; l < K; l++) Xc[(long)l * q.xylen + k.xyoff + e] = (i >= c) ? (double)M[(long)l * plane + e] : 0.0;
+        for (int l = 0; l < K; l++) {
+            Xc[(long)l * q.xylen + k.xyoff + e] = (i >= c) ? (double)M[(long)l * plane + e] : 0.0;
+            if (INV) q.Xi[(long)l * q.xylen + k.xyoff + e] = (ok && i >= c) ? (double)W[(long)l * plane + e] : 0.0;
+        }
     }
 }
 template <int K>
@@ -418,12 +422,13 @@ __global__ __launch_bounds__(MW_PT) void k_mw_potrf_x(const MwDev q, const doubl
         lds_d *M = MW_LDS + MW_POTRF_SCR(K, n);
         wg_copy<K, MW_PT>(M, (long)n * n, n, X + k.xyoff, q.xylen, n, n, n, tid);
         __syncthreads();
-        mw_potrf_x_body<K>(q, k, M, (long)n * n, Xc, bc, tid, blockIdx.x);
+        if (k.inv) mw_potrf_x_body<K, true>(q, k, M, (long)n * n, M + (long)K * n * n, Xc, bc, tid, blockIdx.x);
+        else mw_potrf_x_body<K, false>(q, k, M, (long)n * n, M, Xc, bc, tid, blockIdx.x);
     } else {
         double *M = Xc + k.xyoff;
         wg_copy<K, MW_PT>(M, q.xylen, n, X + k.xyoff, q.xylen, n, n, n, tid);
         __syncthreads();
-        mw_potrf_x_body<K>(q, k, M, q.xylen, Xc, bc, tid, blockIdx.x);
+        mw_potrf_x_body<K, false>(q, k, M, q.xylen, M, Xc, bc, tid, blockIdx.x);
     }
 }
 
@@ -433,7 +438,7 @@ __global__ __launch_bounds__(MW_PT) void k_mw_potrf_x(const MwDev q, const doubl
 // of the pairing: V^T X^-1 V = Z^T Z, so the explicit inverse (inv_cho_precomp!, :1117) is never formed.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int K, int DK>
-__global__ __launch_bounds__(MW_NT) void k_mw_zt(const MwDev q, const double *__restrict__ Y, int lds_L) {
+__global__ __launch_bounds__(MW_NT) void k_mw_zt(const MwDev q, const double *__restrict__ Y, int lds_L, int use_inv) {
     using namespace mwk;
     const MwBlk &k = q.blk[q.lr_list[blockIdx.y]];
     const int n = k.n, U = k.U, tid = threadIdx.x, dl = k.delta;
@@ -456,6 +461,22 @@ __global__ __launch_bounds__(MW_NT) void k_mw_zt(const MwDev q, const double *__
             mw<K> v = lanes_sum<K, 2>(acc_result<K>(s));
             if (live && sub == 0) stx<K>(q.Tm + k.z_off, q.zlen, i + (long)c * n, v);
         }
+    }
+    if (use_inv && k.inv) {                 // Z[:, c] = Xi V[:, c]: rows above the first nonzero row of the vector are zero
+        const double *Xi = q.Xi + k.xyoff;
+        const int sub = tid & 1;
+        for (int e0 = 0; e0 < n * nc; e0 += MW_NT / 2) {
+            const int e = e0 + (tid >> 1);
+            const bool live = e < n * nc;
+            const int ee = live ? e : 0;
+            const int i = ee % n, c = c0 + ee / n, r0 = vrow[c];
+            acc<K> s;
+            acc_zero<K>(s);
+            for (int kk = r0 + sub; kk <= i; kk += 2) acc_fma<K, K, DK>(s, ldx<K>(Xi, q.xylen, i + (long)kk * n), ldx<DK>(V, q.Vp, kk + (long)c * n));
+            mw<K> v = lanes_sum<K, 2>(acc_result<K>(s));
+            if (live && sub == 0) stx<K>(q.Z + k.z_off, q.zlen, i + (long)c * n, v);
+        }
+        return;
     }
     // Z tile in LDS: forward substitution with the row-scaled factor of X_b
     lds_d *Zt = MW_LDS;
