@@ -278,21 +278,24 @@ __global__ void k_mwi_scalar(const MwDev q, const MwIpmDev p, int stage, int ite
 
 
 // ---- R = mu_s I - X Y [- dX dY]  (compute_residual_R!, src/solver.jl:961-983) ------------------------------------------
+#define MWI_EW 4              // lanes per matrix entry in the block products of the iteration
 template <int K>
 __global__ __launch_bounds__(MW_NT) void k_mwi_R(const MwDev q, const MwIpmDev p, int corrector) {
     using namespace mwk;
     const MwBlk &k = q.blk[blockIdx.y];
     const int n = k.n;
-    const int e = blockIdx.x * MW_NT + threadIdx.x;
-    if (e >= n * n) return;
-    const int i = e % n, c = e / n;
+    if (blockIdx.x * (MW_NT / MWI_EW) >= n * n) return;
+    const int e = blockIdx.x * (MW_NT / MWI_EW) + threadIdx.x / MWI_EW, sub = threadIdx.x % MWI_EW;
+    const bool live = e < n * n;
+    const int ee = live ? e : 0, i = ee % n, c = ee / n;
     acc<K> s;
     acc_zero<K>(s);
-    for (int kk = 0; kk < n; kk++) acc_fma<K, K, K>(s, ldx<K>(p.X + k.xyoff, q.xylen, i + (long)kk * n), ldx<K>(p.Y + k.xyoff, q.xylen, kk + (long)c * n), -1.0);
+    for (int kk = sub; kk < n; kk += MWI_EW) acc_fma<K, K, K>(s, ldx<K>(p.X + k.xyoff, q.xylen, i + (long)kk * n), ldx<K>(p.Y + k.xyoff, q.xylen, kk + (long)c * n), -1.0);
     if (corrector)
-        for (int kk = 0; kk < n; kk++) acc_fma<K, K, K>(s, ldx<K>(p.dX + k.xyoff, q.xylen, i + (long)kk * n), ldx<K>(p.dY + k.xyoff, q.xylen, kk + (long)c * n), -1.0);
-    if (i == c) acc_add<K, K>(s, ldx<K>(p.sc, MSC_COUNT, MSC_MUS));
-    stx<K>(p.R + k.xyoff, q.xylen, e, acc_result<K>(s));
+        for (int kk = sub; kk < n; kk += MWI_EW) acc_fma<K, K, K>(s, ldx<K>(p.dX + k.xyoff, q.xylen, i + (long)kk * n), ldx<K>(p.dY + k.xyoff, q.xylen, kk + (long)c * n), -1.0);
+    if (i == c && sub == 0) acc_add<K, K>(s, ldx<K>(p.sc, MSC_COUNT, MSC_MUS));
+    const mw<K> v = lanes_sum<K, MWI_EW>(acc_result<K>(s));
+    if (live && sub == 0) stx<K>(p.R + k.xyoff, q.xylen, e, v);
 }
 
 // ---- coefficients a_p * lambda_t of the sorted terms -------------------------------------------------------------------
@@ -314,18 +317,18 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_wA(const MwDev q, const MwIpmDev 
     using namespace mwk;
     const MwBlk &k = q.blk[blockIdx.y];
     const int n = k.n;
-    const int e = blockIdx.x * MW_NT + threadIdx.x;
-    if (e >= n * n) return;
-    const int i = e % n, c = e / n;
+    if (blockIdx.x * (MW_NT / MWI_EW) >= n * n) return;
+    const int e = blockIdx.x * (MW_NT / MWI_EW) + threadIdx.x / MWI_EW, sub = threadIdx.x % MWI_EW;
+    const int ee = e < n * n ? e : 0, i = ee % n, c = ee / n;
     const double *a = mode == 0 ? p.x : p.dx;
     const bool mirror = (k.kind == 0 && k.m > 1);
-    if (mirror && c > i) return;                   // the lower triangle is computed and mirrored (symmetric!(:L), :1462-1465)
+    const bool live = e < n * n && !(mirror && c > i);     // the lower triangle is computed and mirrored (symmetric!(:L), :1462-1465)
     acc<K> s;
     acc_zero<K>(s);
     if (k.kind == 0) {
         const double *V = q.V + k.v_off;
         const int *tp = q.tptr + k.tptr_off;
-        for (int t = tp[0]; t < tp[k.P]; t++) {
+        for (int t = tp[0] + sub; t < tp[k.P]; t += MWI_EW) {
             if (!(q.st_flag[t] & 1)) continue;     // s <= r only (:1433)
             const mw<DK> vi = ldx<DK>(V, q.Vp, i + (long)q.st_war[t] * n), vc = ldx<DK>(V, q.Vp, c + (long)q.st_wac[t] * n);
             if (vi.l[0] == 0.0 || vc.l[0] == 0.0) continue;
@@ -335,23 +338,25 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_wA(const MwDev q, const MwIpmDev 
     } else {
         const MwClu &cl = q.clu[k.j];
         const long nn = (long)n * n;
-        for (int en = 0; en < k.cnt; en++)
-            acc_fma<K, K, DK>(s, ldx<K>(a, q.xlen, cl.coff + q.dense_p[k.d0 + en]), ldx<DK>(q.dA, q.dAp, k.a_off + en * nn + e));
+        for (int en = sub; en < k.cnt; en += MWI_EW)
+            acc_fma<K, K, DK>(s, ldx<K>(a, q.xlen, cl.coff + q.dense_p[k.d0 + en]), ldx<DK>(q.dA, q.dAp, k.a_off + en * nn + ee));
     }
-    mw<K> v;
+    if (sub == 0) {
+        if (mode == 0) {
+            acc_add<K, K>(s, ldx<K>(p.X + k.xyoff, q.xylen, ee), -1.0);
+            acc_add<K, DK>(s, ldx<DK>(p.C, q.xylen, k.xyoff + ee), -p.sgn);
+        } else {
+            acc_add<K, K>(s, ldx<K>(p.Pm + k.xyoff, q.xylen, ee));
+        }
+    }
+    const mw<K> v = lanes_sum<K, MWI_EW>(acc_result<K>(s));
+    if (!live || sub != 0) return;
     if (mode == 0) {
-        acc_add<K, K>(s, ldx<K>(p.X + k.xyoff, q.xylen, e), -1.0);
-        acc_add<K, DK>(s, ldx<DK>(p.C, q.xylen, k.xyoff + e), -p.sgn);
-        v = acc_result<K>(s);
         atomic_max_abs(&p.fmax[0], v.l[0]);
         stx<K>(p.Pm + k.xyoff, q.xylen, e, v);
-        if (mirror && c != i) {
-            // P is symmetric as a whole: -X -+ C are, and the weighted sum is mirrored
-            stx<K>(p.Pm + k.xyoff, q.xylen, c + (long)i * n, v);
-        }
+        // P is symmetric as a whole: -X -+ C are, and the weighted sum is mirrored
+        if (mirror && c != i) stx<K>(p.Pm + k.xyoff, q.xylen, c + (long)i * n, v);
     } else {
-        acc_add<K, K>(s, ldx<K>(p.Pm + k.xyoff, q.xylen, e));
-        v = acc_result<K>(s);
         stx<K>(p.dX + k.xyoff, q.xylen, e, v);
         if (mirror && c != i) stx<K>(p.dX + k.xyoff, q.xylen, c + (long)i * n, v);
     }
@@ -363,27 +368,33 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_MV(const MwDev q, const double *_
     using namespace mwk;
     const MwBlk &k = q.blk[q.lr_list[blockIdx.y]];
     const int n = k.n, dl = k.delta;
-    const int e = blockIdx.x * MW_NT + threadIdx.x;
-    if (e >= n * k.U) return;
-    const int i = e % n, c = e / n;
+    if (blockIdx.x * (MW_NT / MWI_EW) >= n * k.U) return;
+    const int e = blockIdx.x * (MW_NT / MWI_EW) + threadIdx.x / MWI_EW, sub = threadIdx.x % MWI_EW;
+    const bool live = e < n * k.U;
+    const int ee = live ? e : 0, i = ee % n, c = ee / n;
     const double *V = q.V + k.v_off;
     const int r0 = q.vrow[k.vrow_off + c];
     acc<K> s;
     acc_zero<K>(s);
-    for (int kk = r0; kk < r0 + dl; kk++) acc_fma<K, K, DK>(s, ldx<K>(M + k.xyoff, q.xylen, i + (long)kk * n), ldx<DK>(V, q.Vp, kk + (long)c * n));
-    stx<K>(q.Tm + k.z_off, q.zlen, e, acc_result<K>(s));
+    for (int kk = r0 + sub; kk < r0 + dl; kk += MWI_EW) acc_fma<K, K, DK>(s, ldx<K>(M + k.xyoff, q.xylen, i + (long)kk * n), ldx<DK>(V, q.Vp, kk + (long)c * n));
+    const mw<K> v = lanes_sum<K, MWI_EW>(acc_result<K>(s));
+    if (live && sub == 0) stx<K>(q.Tm + k.z_off, q.zlen, e, v);
 }
 
 // ---- per constraint row: d = c - <A_*,Y> - B y (:863-879) or rhs_x = -d - <A_*,Z> (:1518-1523) --------------------------
+#define MWI_RW 8              // lanes per constraint row
 template <int K, int DK>
 __global__ __launch_bounds__(MW_NT) void k_mwi_rows(const MwDev q, const MwIpmDev p, int mode) {
     using namespace mwk;
-    const mwi64 g = (mwi64)blockIdx.x * MW_NT + threadIdx.x;
-    if (g >= q.xlen) return;
+    const mwi64 g0 = (mwi64)blockIdx.x * (MW_NT / MWI_RW) + threadIdx.x / MWI_RW;
+    const int sub = threadIdx.x % MWI_RW;
+    const bool live = g0 < q.xlen;
+    const mwi64 g = live ? g0 : 0;
     const int j = p.row_clu[g];
     const MwClu &cl = q.clu[j];
     const int pp = (int)(g - cl.coff);
     const double *M = mode == 0 ? p.Y : p.dY;        // Z is kept in the dY buffer, as the reference does (:1501-1514)
+    // every lane accumulates its share of  -(trace term) [- (B y)_g] ; the lanes are summed at the end
     acc<K> s;
     acc_zero<K>(s);
     for (int b = cl.b0; b < cl.b1; b++) {
@@ -391,45 +402,46 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_rows(const MwDev q, const MwIpmDe
         const int n = k.n;
         if (k.kind == 0) {
             const int *tp = q.tptr + k.tptr_off;
-            for (int t = tp[pp]; t < tp[pp + 1]; t++) {
-                const int fl = q.st_flag[t];
-                if (!(fl & 1)) continue;                                           // s <= r (:1310)
-                const mw<DK> w = mul_pow2<DK>(ldx<DK>(q.st_lam, q.lamp, t), (fl & 2) ? 2.0 : 1.0);      // off-diagonal sub-blocks count twice (:1354-1356)
-                if (mode == 0) {
-                    acc_fma<K, K, DK>(s, ldx<K>(q.AY, q.T, q.st_orig[t]), w);      // trace_A with (Y, A_Y), :1368-1407
-                } else {
-                    const double *V = q.V + k.v_off;
+            if (mode == 0) {
+                for (int t = tp[pp] + sub; t < tp[pp + 1]; t += MWI_RW) {
+                    const int fl = q.st_flag[t];
+                    if (!(fl & 1)) continue;                                           // s <= r (:1310)
+                    const mw<DK> w = mul_pow2<DK>(ldx<DK>(q.st_lam, q.lamp, t), (fl & 2) ? 2.0 : 1.0);      // off-diagonal sub-blocks count twice (:1354-1356)
+                    acc_fma<K, K, DK>(s, ldx<K>(q.AY, q.T, q.st_orig[t]), w, -1.0);     // trace_A with (Y, A_Y), :1368-1407
+                }
+            } else {
+                const double *V = q.V + k.v_off;
+                for (int t = tp[pp]; t < tp[pp + 1]; t++) {
+                    const int fl = q.st_flag[t];
+                    if (!(fl & 1)) continue;
+                    const mw<DK> w = mul_pow2<DK>(ldx<DK>(q.st_lam, q.lamp, t), (fl & 2) ? 2.0 : 1.0);
                     const int l = q.st_trl[t], dcol = q.st_trd[t], r0 = q.vrow[k.vrow_off + l];
                     acc<K> z;
                     acc_zero<K>(z);
-                    for (int ii = r0; ii < r0 + k.delta; ii++) acc_fma<K, K, DK>(z, ldx<K>(q.Tm + k.z_off, q.zlen, ii + (long)dcol * n), ldx<DK>(V, q.Vp, ii + (long)l * n));
-                    acc_fma<K, K, DK>(s, acc_result<K>(z), w);
+                    for (int ii = r0 + sub; ii < r0 + k.delta; ii += MWI_RW) acc_fma<K, K, DK>(z, ldx<K>(q.Tm + k.z_off, q.zlen, ii + (long)dcol * n), ldx<DK>(V, q.Vp, ii + (long)l * n));
+                    acc_fma<K, K, DK>(s, acc_result<K>(z), w, -1.0);
                 }
             }
         } else {
             const int en = q.dmap[k.dmap_off + pp];
             if (en >= 0) {
                 const long nn = (long)n * n;
-                for (long i = 0; i < nn; i++) acc_fma<K, K, DK>(s, ldx<K>(M + k.xyoff, q.xylen, i), ldx<DK>(q.dA, q.dAp, k.a_off + en * nn + i));
+                for (long i = sub; i < nn; i += MWI_RW) acc_fma<K, K, DK>(s, ldx<K>(M + k.xyoff, q.xylen, i), ldx<DK>(q.dA, q.dAp, k.a_off + en * nn + i), -1.0);
             }
         }
     }
-    mw<K> tr = acc_result<K>(s);
     if (mode == 0) {
-        acc<K> r;
-        acc_zero<K>(r);
-        acc_add<K, DK>(r, ldx<DK>(p.c, q.xlen, g));
-        acc_add<K, K>(r, tr, -1.0);
-        for (int a = 0; a < q.N; a++) acc_fma<K, K, DK>(r, ldx<K>(p.y, q.N, a), ldx<DK>(q.B, q.Bp, g + (long)a * q.xlen), -1.0);
-        mw<K> dv = acc_result<K>(r);
-        atomic_max_abs(&p.fmax[1], dv.l[0]);
-        stx<K>(p.d, q.xlen, g, dv);
+        if (sub == 0) acc_add<K, DK>(s, ldx<DK>(p.c, q.xlen, g));
+        for (int a = sub; a < q.N; a += MWI_RW) acc_fma<K, K, DK>(s, ldx<K>(p.y, q.N, a), ldx<DK>(q.B, q.Bp, g + (long)a * q.xlen), -1.0);
+        const mw<K> dv = lanes_sum<K, MWI_RW>(acc_result<K>(s));
+        if (live && sub == 0) {
+            atomic_max_abs(&p.fmax[1], dv.l[0]);
+            stx<K>(p.d, q.xlen, g, dv);
+        }
     } else {
-        acc<K> r;
-        acc_zero<K>(r);
-        acc_add<K, K>(r, ldx<K>(p.d, q.xlen, g), -1.0);
-        acc_add<K, K>(r, tr, -1.0);
-        stx<K>(p.rhsx, q.xlen, g, acc_result<K>(r));
+        if (sub == 0) acc_add<K, K>(s, ldx<K>(p.d, q.xlen, g), -1.0);
+        const mw<K> r = lanes_sum<K, MWI_RW>(acc_result<K>(s));
+        if (live && sub == 0) stx<K>(p.rhsx, q.xlen, g, r);
     }
 }
 
@@ -456,6 +468,7 @@ template <int K>
 __global__ __launch_bounds__(MW_NT) void k_mwi_Z(const MwDev q, const MwIpmDev p, int which, int lds_L) {
     using namespace mwk;
     const MwBlk &k = q.blk[blockIdx.x];
+    if (k.inv) return;                                  // k_mwi_Zi
     const int n = k.n, tid = threadIdx.x;
     const long nn = (long)n * n;
     lds_d *M = MW_LDS;
@@ -491,6 +504,86 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_Z(const MwDev q, const MwIpmDev p
     }
 }
 
+// The same with the explicit inverse Xi = chol(X)^-1 that k_mw_potrf_x leaves beside the factor: X^-1 M = Xi^T (Xi M), three
+// block products, two lanes per entry (MW_PT threads)
+template <int K>
+__global__ __launch_bounds__(MW_PT) void k_mwi_Zi(const MwDev q, const MwIpmDev p, int which) {
+    using namespace mwk;
+    const MwBlk &k = q.blk[blockIdx.x];
+    if (!k.inv) return;
+    const int n = k.n, tid = threadIdx.x, sub = tid & 1;
+    const long nn = (long)n * n;
+    lds_d *M = MW_LDS, *M2 = M + (long)K * nn;
+    const double *A = (which == 0 ? p.Pm : p.dX) + k.xyoff, *Xi = q.Xi + k.xyoff;
+    const double sg = which == 0 ? 1.0 : -1.0;
+    for (int e0 = 0; e0 < nn; e0 += MW_PT / 2) {           // M = sg (A Y - R)
+        const int e = e0 + (tid >> 1);
+        const bool live = e < nn;
+        const int ee = live ? e : 0, i = ee % n, c = ee / n;
+        acc<K> s;
+        acc_zero<K>(s);
+        for (int kk = sub; kk < n; kk += 2) acc_fma<K, K, K>(s, ldx<K>(A, q.xylen, i + (long)kk * n), ldx<K>(p.Y + k.xyoff, q.xylen, kk + (long)c * n), sg);
+        if (sub == 0) acc_add<K, K>(s, ldx<K>(p.R + k.xyoff, q.xylen, ee), -sg);
+        const mw<K> v = lanes_sum<K, 2>(acc_result<K>(s));
+        if (live && sub == 0) stx<K>(M, nn, e, v);
+    }
+    __syncthreads();
+    for (int e0 = 0; e0 < nn; e0 += MW_PT / 2) {           // M2 = Xi M
+        const int e = e0 + (tid >> 1);
+        const bool live = e < nn;
+        const int ee = live ? e : 0, i = ee % n, c = ee / n;
+        acc<K> s;
+        acc_zero<K>(s);
+        for (int r = sub; r <= i; r += 2) acc_fma<K, K, K>(s, ldx<K>(Xi, q.xylen, i + (long)r * n), ldx<K>(M, nn, r + (long)c * n));
+        const mw<K> v = lanes_sum<K, 2>(acc_result<K>(s));
+        if (live && sub == 0) stx<K>(M2, nn, e, v);
+    }
+    __syncthreads();
+    for (int e0 = 0; e0 < nn; e0 += MW_PT / 2) {           // M = Xi^T M2
+        const int e = e0 + (tid >> 1);
+        const bool live = e < nn;
+        const int ee = live ? e : 0, i = ee % n, c = ee / n;
+        acc<K> s;
+        acc_zero<K>(s);
+        for (int r = i + sub; r < n; r += 2) acc_fma<K, K, K>(s, ldx<K>(Xi, q.xylen, r + (long)i * n), ldx<K>(M2, nn, r + (long)c * n));
+        const mw<K> v = lanes_sum<K, 2>(acc_result<K>(s));
+        if (live && sub == 0) stx<K>(M, nn, e, v);
+    }
+    __syncthreads();
+    for (int e = tid; e < nn; e += MW_PT) {
+        const int i = e % n, c = e / n;
+        if (c > i) continue;
+        mw<K> v = mul_pow2<K>(add<K>(ldx<K>(M, nn, i + (long)c * n), ldx<K>(M, nn, c + (long)i * n)), 0.5);
+        stx<K>(p.dY + k.xyoff, q.xylen, i + (long)c * n, v);
+        stx<K>(p.dY + k.xyoff, q.xylen, c + (long)i * n, v);
+    }
+}
+
+// W = Li dM Li^T with the explicit inverse Li of the factor (two block products), symmetrised and rounded to fp64: the matrix of :1659
+template <int K, class PI>
+__device__ __forceinline__ void mwi_step_congruence_inv(PI Li, long iplane, int n, const double *dMg, long gplane, mwk::lds_d *T1, mwk::lds_d *Wd, int tid) {
+    using namespace mwk;
+    const long nn = (long)n * n;
+    for (int e = tid; e < nn; e += MW_NT) {                // T1 = Li dM
+        const int i = e % n, c = e / n;
+        acc<K> s;
+        acc_zero<K>(s);
+        for (int r = 0; r <= i; r++) acc_fma<K, K, K>(s, ldx<K>(Li, iplane, i + (long)r * n), ldx<K>(dMg, gplane, r + (long)c * n));
+        stx<K>(T1, nn, e, acc_result<K>(s));
+    }
+    __syncthreads();
+    for (int e = tid; e < nn; e += MW_NT) {                // W = T1 Li^T, lower triangle, mirrored
+        const int i = e % n, c = e / n;
+        if (c > i) continue;
+        acc<K> s;
+        acc_zero<K>(s);
+        for (int r = 0; r <= c; r++) acc_fma<K, K, K>(s, ldx<K>(T1, nn, i + (long)r * n), ldx<K>(Li, iplane, c + (long)r * n));
+        const double w = acc_result<K>(s).l[0];
+        Wd[i + (long)c * n] = w;
+        Wd[c + (long)i * n] = w;
+    }
+}
+
 // W = L^-1 dM L^-T through two forward substitutions and a transposition (:1651-1655), then its fp64 symmetrisation
 template <int K, class PF, class PR, class PW>
 __device__ __forceinline__ void mwi_step_congruence(PF F, PR rd, PW W, long wplane, long nn, int n, const double *dMg, long gplane, mwk::lds_d *Wd, int tid) {
@@ -516,7 +609,7 @@ __device__ __forceinline__ void mwi_step_congruence(PF F, PR rd, PW W, long wpla
 // ---- compute_step_length (:1620-1693) per block: smallest eigenvalue of L^-1 dM L^-T, L = chol(M) -----------------------
 // which 0: (X, dX) with the factors of this iteration; which 1: (Y, dY), factored here
 template <int K>
-__global__ __launch_bounds__(MW_NT) void k_mwi_step(const MwDev q, const MwIpmDev p, int w_in_lds) {
+__global__ __launch_bounds__(MW_NT) void k_mwi_step(const MwDev q, const MwIpmDev p, int w_in_lds, int inv_path) {
     using namespace mwk;
     const int which = blockIdx.y;                       // both step lengths in one launch
     const MwBlk &k = q.blk[blockIdx.x];
@@ -529,6 +622,26 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_step(const MwDev q, const MwIpmDe
             if (!(m.l[0] > 0.0)) { p.flags[2] = 1; p.eig[(long)which * q.NB + blockIdx.x] = 0.0; }
             else p.eig[(long)which * q.NB + blockIdx.x] = div<K>(ldx<K>(dMg, q.xylen, 0), m).l[0];     // :1637-1641
         }
+        return;
+    }
+    if (inv_path && k.inv) {
+        // LDS: Li (inverse factor; which 0 reads Xi from memory instead), T1, [Y and its factor], rd, the fp64 matrix, eigenvalue work space, scratch
+        lds_d *Li = MW_LDS, *T1 = Li + (long)K * nn, *Mf = T1 + (long)K * nn;
+        lds_d *rd = Mf + (long)K * nn, *Wd = rd + (long)K * n, *work = Wd + nn, *scr = work + 3 * n + 2 * MW_NT;
+        if (which == 0) {
+            mwi_step_congruence_inv<K>(q.Xi + k.xyoff, q.xylen, n, dMg, q.xylen, T1, Wd, tid);
+        } else {
+            wg_copy<K>(Mf, nn, n, Mg, q.xylen, n, n, n, tid);
+            __syncthreads();
+            if (!wg_potrf<K, true, MW_NT, false>(Mf, nn, n, n, rd, n, Li, nn, n, scr, tid)) {                // :1644-1646
+                if (tid == 0) { p.flags[2] = 1; p.eig[(long)which * q.NB + blockIdx.x] = 0.0; }
+                return;
+            }
+            mwi_step_congruence_inv<K>(Li, nn, n, dMg, q.xylen, T1, Wd, tid);
+        }
+        __syncthreads();
+        const double ev = wg_min_eig(Wd, n, work, tid);
+        if (tid == 0) p.eig[(long)which * q.NB + blockIdx.x] = ev - 1e-5;                // :1662
         return;
     }
     // LDS: F (row-scaled factor), [W], rd, the fp64 matrix and the eigenvalue work space, the broadcast slot of the factorisation.
@@ -619,8 +732,8 @@ struct MwIpm {
     bool ready = false;
     int iter = 0;
     double *h_rec = nullptr;      // pinned
-    size_t sm_Z = 0, sm_step = 0;
-    bool lds_ZL = false, step_w_lds = true;
+    size_t sm_Z = 0, sm_Zi = 0, sm_step = 0;
+    bool lds_ZL = false, step_w_lds = true, step_inv = false, any_xinv = false, any_xsub = false;
     ~MwIpm() { if (h_rec) (void)hipHostFree(h_rec); }
 };
 
@@ -681,7 +794,18 @@ extern "C" int clrs_mw_ipm_create_ex(clrs_mw_ctx *c, const clrs_ipm_data *data, 
         const size_t stepd = (st->step_w_lds ? 2 : 1) * nnK + step_rest;
         if (stepd > lim) return mw_fail(CLRS_ERR_INVALID, "device-resident multi-word iteration needs PSD blocks that fit in LDS");
         st->sm_step = stepd * 8;
+        // blocks whose inverse factor exists (k_mw_potrf_x): products instead of substitutions in Z and in the step length
+        size_t maxn_inv = 0;
+        for (auto &k : c->blk) {
+            if (k.inv) { st->any_xinv = true; maxn_inv = std::max(maxn_inv, (size_t)k.n); }
+            else st->any_xsub = true;
+        }
+        st->sm_Zi = 2 * maxn_inv * maxn_inv * K * 8;
+        const size_t step_inv_need = 3 * maxn_inv * maxn_inv * K + step_rest;
+        st->step_inv = st->any_xinv && step_inv_need <= lim;
+        if (st->step_inv) st->sm_step = std::max(st->sm_step, step_inv_need * 8);
         MW_DISPATCH(c, {
+            if ((rc = mw_set_lds(k_mwi_Zi<KK>, st->sm_Zi))) return rc;
             if ((rc = mw_set_lds(k_mwi_Z<KK>, st->sm_Z))) return rc;
             if ((rc = mw_set_lds(k_mwi_step<KK>, st->sm_step))) return rc;
         });
@@ -766,17 +890,19 @@ static int mw_ipm_direction(clrs_mw_ctx *c, int corrector) {
     const int maxnn = c->maxn * c->maxn;
     int rc;
     MW_DISPATCH(c, {
-        hipLaunchKernelGGL(k_mwi_R<KK>, dim3((maxnn + MW_NT - 1) / MW_NT, q.NB), dim3(MW_NT), 0, c->stream, q, p, corrector);
-        hipLaunchKernelGGL(k_mwi_Z<KK>, dim3(q.NB), dim3(MW_NT), st->sm_Z, c->stream, q, p, 0, st->lds_ZL ? 1 : 0);
-        if (q.nlr) hipLaunchKernelGGL((k_mwi_MV<KK, DD>), dim3((c->maxn * c->maxU + MW_NT - 1) / MW_NT, q.nlr), dim3(MW_NT), 0, c->stream, q, (const double *)p.dY);
-        hipLaunchKernelGGL((k_mwi_rows<KK, DD>), dim3((unsigned)((q.xlen + MW_NT - 1) / MW_NT)), dim3(MW_NT), 0, c->stream, q, p, 1);
+        hipLaunchKernelGGL(k_mwi_R<KK>, dim3((maxnn * MWI_EW + MW_NT - 1) / MW_NT, q.NB), dim3(MW_NT), 0, c->stream, q, p, corrector);
+        if (st->any_xinv) hipLaunchKernelGGL(k_mwi_Zi<KK>, dim3(q.NB), dim3(MW_PT), st->sm_Zi, c->stream, q, p, 0);
+        if (st->any_xsub) hipLaunchKernelGGL(k_mwi_Z<KK>, dim3(q.NB), dim3(MW_NT), st->sm_Z, c->stream, q, p, 0, st->lds_ZL ? 1 : 0);
+        if (q.nlr) hipLaunchKernelGGL((k_mwi_MV<KK, DD>), dim3((c->maxn * c->maxU * MWI_EW + MW_NT - 1) / MW_NT, q.nlr), dim3(MW_NT), 0, c->stream, q, (const double *)p.dY);
+        hipLaunchKernelGGL((k_mwi_rows<KK, DD>), dim3((unsigned)((q.xlen * MWI_RW + MW_NT - 1) / MW_NT)), dim3(MW_NT), 0, c->stream, q, p, 1);
     });
     MWCHECK(hipGetLastError());
     if ((rc = clrs_mw_schur_solve_dev(c, p.rhsx, p.pv, p.dx, p.dy))) return rc;
     MW_DISPATCH(c, {
         if (q.T) hipLaunchKernelGGL((k_mwi_coef<KK, DD>), dim3((unsigned)((q.T + MW_NT - 1) / MW_NT)), dim3(MW_NT), 0, c->stream, q, p, (const double *)p.dx);
-        hipLaunchKernelGGL((k_mwi_wA<KK, DD>), dim3((maxnn + MW_NT - 1) / MW_NT, q.NB), dim3(MW_NT), 0, c->stream, q, p, 1);
-        hipLaunchKernelGGL(k_mwi_Z<KK>, dim3(q.NB), dim3(MW_NT), st->sm_Z, c->stream, q, p, 1, st->lds_ZL ? 1 : 0);
+        hipLaunchKernelGGL((k_mwi_wA<KK, DD>), dim3((maxnn * MWI_EW + MW_NT - 1) / MW_NT, q.NB), dim3(MW_NT), 0, c->stream, q, p, 1);
+        if (st->any_xinv) hipLaunchKernelGGL(k_mwi_Zi<KK>, dim3(q.NB), dim3(MW_PT), st->sm_Zi, c->stream, q, p, 1);
+        if (st->any_xsub) hipLaunchKernelGGL(k_mwi_Z<KK>, dim3(q.NB), dim3(MW_NT), st->sm_Z, c->stream, q, p, 1, st->lds_ZL ? 1 : 0);
     });
     MWCHECK(hipGetLastError());
     return 0;
@@ -801,8 +927,8 @@ extern "C" int clrs_mw_ipm_iterate(clrs_mw_ctx *c, clrs_ipm_record *out) {
     if ((rc = clrs_mw_schur_factor_dev(c))) return rc;
     MW_DISPATCH(c, {
         if (q.T) hipLaunchKernelGGL((k_mwi_coef<KK, DD>), dim3((unsigned)((q.T + MW_NT - 1) / MW_NT)), dim3(MW_NT), 0, c->stream, q, p, (const double *)p.x);
-        hipLaunchKernelGGL((k_mwi_wA<KK, DD>), dim3((maxnn + MW_NT - 1) / MW_NT, q.NB), dim3(MW_NT), 0, c->stream, q, p, 0);
-        hipLaunchKernelGGL((k_mwi_rows<KK, DD>), dim3((unsigned)((q.xlen + MW_NT - 1) / MW_NT)), dim3(MW_NT), 0, c->stream, q, p, 0);
+        hipLaunchKernelGGL((k_mwi_wA<KK, DD>), dim3((maxnn * MWI_EW + MW_NT - 1) / MW_NT, q.NB), dim3(MW_NT), 0, c->stream, q, p, 0);
+        hipLaunchKernelGGL((k_mwi_rows<KK, DD>), dim3((unsigned)((q.xlen * MWI_RW + MW_NT - 1) / MW_NT)), dim3(MW_NT), 0, c->stream, q, p, 0);
         if (q.N) hipLaunchKernelGGL((k_mwi_pv<KK, DD>), dim3((q.N + MW_NT / 8 - 1) / (MW_NT / 8)), dim3(MW_NT), 0, c->stream, q, p);
         hipLaunchKernelGGL((k_mwi_scalar<KK, DD>), dim3(1), dim3(1), 0, c->stream, q, p, 1, st->iter);
     });
@@ -814,7 +940,7 @@ extern "C" int clrs_mw_ipm_iterate(clrs_mw_ctx *c, clrs_ipm_record *out) {
     });
     if ((rc = mw_ipm_direction(c, 1))) return rc;
     MW_DISPATCH(c, {
-        hipLaunchKernelGGL(k_mwi_step<KK>, dim3(q.NB, 2), dim3(MW_NT), st->sm_step, c->stream, q, p, st->step_w_lds ? 1 : 0);
+        hipLaunchKernelGGL(k_mwi_step<KK>, dim3(q.NB, 2), dim3(MW_NT), st->sm_step, c->stream, q, p, st->step_w_lds ? 1 : 0, st->step_inv ? 1 : 0);
         hipLaunchKernelGGL((k_mwi_scalar<KK, DD>), dim3(1), dim3(1), 0, c->stream, q, p, 3, st->iter);
         hipLaunchKernelGGL(k_mwi_update<KK>, dim3((unsigned)std::min<i64>(1024, (q.xylen + q.xlen + q.N + MW_NT - 1) / MW_NT)), dim3(MW_NT), 0, c->stream, q, p);
     });
