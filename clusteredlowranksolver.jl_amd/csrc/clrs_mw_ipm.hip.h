@@ -47,6 +47,18 @@ __device__ __forceinline__ void atomic_max_abs(unsigned long long *slot, double 
     atomicMax(slot, (unsigned long long)__double_as_longlong(__builtin_fabs(v)));
 }
 
+// sum of one double per thread over the workgroup: shuffles inside the waves, one LDS slot per wave, one barrier
+__device__ __forceinline__ double wg_sum_d(double v, lds_d *red, int tid) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    double s = 0;
+#pragma unroll
+    for (int w = 0; w < MW_NT / 64; w++) s += red[w];
+    return s;
+}
+
 // Smallest eigenvalue of the symmetric n x n fp64 matrix A (LDS, full storage, leading dimension n; destroyed).
 // Householder tridiagonalisation by the workgroup, then Sturm-count multisection (256 shifts per round).
 // work: LDS, at least 3 n + 2 * MW_NT doubles.
@@ -57,11 +69,7 @@ __device__ double wg_min_eig(lds_d *A, int n, lds_d *work, int tid) {
         const int m = n - k - 1;           // x = A[k+1 .. n-1, k]
         double part = 0;
         for (int i = tid; i < m; i += MW_NT) { double t = A[(k + 1 + i) + k * n]; part += t * t; }
-        red[tid] = part;
-        __syncthreads();
-        for (int s = MW_NT / 2; s > 0; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
-        const double nrm2 = red[0];
-        __syncthreads();
+        const double nrm2 = wg_sum_d(part, red, tid);
         const double x0 = A[(k + 1) + k * n];
         const double alpha = (x0 > 0 ? -1.0 : 1.0) * __builtin_sqrt(nrm2);
         if (tid == 0) { dd[k] = A[k + k * n]; ee[k] = (nrm2 == 0.0) ? 0.0 : alpha; }
@@ -74,25 +82,21 @@ __device__ double wg_min_eig(lds_d *A, int n, lds_d *work, int tid) {
         __syncthreads();
         const double vtv = nrm2 - 2.0 * alpha * x0 + alpha * alpha;   // |x - alpha e1|^2
         const double beta = 2.0 / vtv;
-        // p = beta * A22 v
-        for (int i = tid; i < m; i += MW_NT) {
-            double s = 0;
-            for (int j = 0; j < m; j++) s += A[(k + 1 + i) + (k + 1 + j) * n] * v[j];
-            pq[i] = beta * s;
-        }
-        __syncthreads();
+        // p = beta * A22 v, four lanes per row
         part = 0;
-        for (int i = tid; i < m; i += MW_NT) part += v[i] * pq[i];
-        red[tid] = part;
-        __syncthreads();
-        for (int s = MW_NT / 2; s > 0; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
-        const double Kc = 0.5 * beta * red[0];
-        __syncthreads();
-        for (int i = tid; i < m; i += MW_NT) pq[i] -= Kc * v[i];
-        __syncthreads();
+        for (int i0 = 0; i0 < m; i0 += MW_NT / 4) {
+            const int i = i0 + (tid >> 2);
+            double sm = 0;
+            if (i < m)
+                for (int j = tid & 3; j < m; j += 4) sm += A[(k + 1 + i) + (k + 1 + j) * n] * v[j];
+            sm += __shfl_xor(sm, 1, 64);
+            sm += __shfl_xor(sm, 2, 64);
+            if (i < m && (tid & 3) == 0) { pq[i] = beta * sm; part += v[i] * beta * sm; }
+        }
+        const double Kc = 0.5 * beta * wg_sum_d(part, red + MW_NT / 64, tid);      // its own slots: the first reduction may still be read
         for (int e = tid; e < m * m; e += MW_NT) {
             const int i = e % m, j = e / m;
-            A[(k + 1 + i) + (k + 1 + j) * n] -= v[i] * pq[j] + pq[i] * v[j];
+            A[(k + 1 + i) + (k + 1 + j) * n] -= v[i] * (pq[j] - Kc * v[j]) + (pq[i] - Kc * v[i]) * v[j];
         }
         __syncthreads();
     }
@@ -142,38 +146,6 @@ __device__ double wg_min_eig(lds_d *A, int n, lds_d *work, int tid) {
 
 }  // namespace mwk
 
-// ---- block dot products: partial sums per PSD block ------------------------------------------------------------------
-// sel bit 0: <X,Y>; bit 1: <X,dY>, <dX,Y>, <dX,dY>; bit 2: <C,Y>
-template <int K, int DK>
-__global__ __launch_bounds__(MW_NT) void k_mwi_dots(const MwDev q, const MwIpmDev p, int sel) {
-    using namespace mwk;
-    const MwBlk &k = q.blk[blockIdx.x];
-    const int tid = threadIdx.x;
-    const long nn = (long)k.n * k.n;
-    acc<K> a0, a1, a2, a3, a4;
-    acc_zero<K>(a0); acc_zero<K>(a1); acc_zero<K>(a2); acc_zero<K>(a3); acc_zero<K>(a4);
-    for (long i = tid; i < nn; i += MW_NT) {
-        const long e = k.xyoff + i;
-        mw<K> Y = ldx<K>(p.Y, q.xylen, e);
-        if (sel & 1) acc_fma<K, K, K>(a0, ldx<K>(p.X, q.xylen, e), Y);
-        if (sel & 2) {
-            mw<K> X = ldx<K>(p.X, q.xylen, e), dX = ldx<K>(p.dX, q.xylen, e), dY = ldx<K>(p.dY, q.xylen, e);
-            acc_fma<K, K, K>(a1, X, dY);
-            acc_fma<K, K, K>(a2, dX, Y);
-            acc_fma<K, K, K>(a3, dX, dY);
-        }
-        if (sel & 4) acc_fma<K, K, DK>(a4, Y, ldx<DK>(p.C, q.xylen, e));
-    }
-    lds_d *red = MW_LDS;
-    if (sel & 1) { mw<K> r = wg_reduce_sum<K>(acc_result<K>(a0), red, tid); if (tid == 0) stx<K>(p.part, 5L * q.NB, 0L * q.NB + blockIdx.x, r); }
-    if (sel & 2) {
-        mw<K> r = wg_reduce_sum<K>(acc_result<K>(a1), red, tid); if (tid == 0) stx<K>(p.part, 5L * q.NB, 1L * q.NB + blockIdx.x, r);
-        r = wg_reduce_sum<K>(acc_result<K>(a2), red, tid); if (tid == 0) stx<K>(p.part, 5L * q.NB, 2L * q.NB + blockIdx.x, r);
-        r = wg_reduce_sum<K>(acc_result<K>(a3), red, tid); if (tid == 0) stx<K>(p.part, 5L * q.NB, 3L * q.NB + blockIdx.x, r);
-    }
-    if (sel & 4) { mw<K> r = wg_reduce_sum<K>(acc_result<K>(a4), red, tid); if (tid == 0) stx<K>(p.part, 5L * q.NB, 4L * q.NB + blockIdx.x, r); }
-}
-
 // ---- scalar stages (one thread) ------------------------------------------------------------------------------------
 template <int K>
 __device__ mwa::mw<K> mwi_sum_part(const MwDev &q, const MwIpmDev &p, int slot) {
@@ -183,8 +155,26 @@ __device__ mwa::mw<K> mwi_sum_part(const MwDev &q, const MwIpmDev &p, int slot) 
     for (int b = 0; b < q.NB; b++) acc_add<K, K>(s, ldx<K>(p.part, 5L * q.NB, (long)slot * q.NB + b));
     return acc_result<K>(s);
 }
+// Two scalar stages (1: errors, 3: step lengths) run at the tail of the kernel that produces their inputs: the workgroup that
+// finishes last (a counter in flags[4]; every workgroup publishes its results with a fence before it counts itself) executes
+// the stage.  (The stages behind the block dot products stay separate launches: the fences cost those kernels more than the
+// launch saves -- measured 31 us against 10 + 9.5.)  `mwi_last_block` is uniform over the workgroup.
+__device__ __forceinline__ bool mwi_last_block(int *counter, unsigned total) {
+    __shared__ int last;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned old = atomicAdd((unsigned *)counter, 1u);
+        last = (old == total - 1) ? 1 : 0;
+        if (last) *counter = 0;
+    }
+    __syncthreads();
+    if (last) __threadfence();
+    return last != 0;
+}
+// called by the first wave of a workgroup (threadIdx.x < 64); stages 0-3 use its first lane only
 template <int K, int DK>
-__global__ void k_mwi_scalar(const MwDev q, const MwIpmDev p, int stage, int iter) {
+__device__ void mwi_scalar_stage(const MwDev &q, const MwIpmDev &p, int stage, int iter) {
     using namespace mwk;
     const long SP = MSC_COUNT;
     if (stage == 4) {                              // objectives of the new iterate (:793-804, 844-847): the two dot products over one wave
@@ -212,7 +202,7 @@ __global__ void k_mwi_scalar(const MwDev q, const MwIpmDev p, int stage, int ite
         p.rec[MREC_PDFEAS] = p.flags[0];
         return;
     }
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (threadIdx.x != 0) return;
     if (stage == 0) {                              // start of the iteration: mu, mu_p  (src/solver.jl:369-380)
         mw<K> xy = mwi_sum_part<K>(q, p, 0);
         mw<K> mu = div<K>(xy, from_double<K>((double)p.Ktot));
@@ -274,6 +264,44 @@ __global__ void k_mwi_scalar(const MwDev q, const MwIpmDev p, int stage, int ite
         p.sc[MSC_COUNT * 0 + 11] = al[1];
         p.rec[MREC_ERR] = p.flags[1];
     }
+}
+template <int K, int DK>
+__global__ void k_mwi_scalar(const MwDev q, const MwIpmDev p, int stage, int iter) {
+    if (blockIdx.x == 0 && threadIdx.x < 64) mwi_scalar_stage<K, DK>(q, p, stage, iter);
+}
+
+
+// ---- block dot products: partial sums per PSD block ------------------------------------------------------------------
+// sel bit 0: <X,Y>; bit 1: <X,dY>, <dX,Y>, <dX,dY>; bit 2: <C,Y>
+template <int K, int DK>
+__global__ __launch_bounds__(MW_NT) void k_mwi_dots(const MwDev q, const MwIpmDev p, int sel, int stage, int iter) {
+    using namespace mwk;
+    const MwBlk &k = q.blk[blockIdx.x];
+    const int tid = threadIdx.x;
+    const long nn = (long)k.n * k.n;
+    acc<K> a0, a1, a2, a3, a4;
+    acc_zero<K>(a0); acc_zero<K>(a1); acc_zero<K>(a2); acc_zero<K>(a3); acc_zero<K>(a4);
+    for (long i = tid; i < nn; i += MW_NT) {
+        const long e = k.xyoff + i;
+        mw<K> Y = ldx<K>(p.Y, q.xylen, e);
+        if (sel & 1) acc_fma<K, K, K>(a0, ldx<K>(p.X, q.xylen, e), Y);
+        if (sel & 2) {
+            mw<K> X = ldx<K>(p.X, q.xylen, e), dX = ldx<K>(p.dX, q.xylen, e), dY = ldx<K>(p.dY, q.xylen, e);
+            acc_fma<K, K, K>(a1, X, dY);
+            acc_fma<K, K, K>(a2, dX, Y);
+            acc_fma<K, K, K>(a3, dX, dY);
+        }
+        if (sel & 4) acc_fma<K, K, DK>(a4, Y, ldx<DK>(p.C, q.xylen, e));
+    }
+    lds_d *red = MW_LDS;
+    if (sel & 1) { mw<K> r = wg_reduce_sum<K>(acc_result<K>(a0), red, tid); if (tid == 0) stx<K>(p.part, 5L * q.NB, 0L * q.NB + blockIdx.x, r); }
+    if (sel & 2) {
+        mw<K> r = wg_reduce_sum<K>(acc_result<K>(a1), red, tid); if (tid == 0) stx<K>(p.part, 5L * q.NB, 1L * q.NB + blockIdx.x, r);
+        r = wg_reduce_sum<K>(acc_result<K>(a2), red, tid); if (tid == 0) stx<K>(p.part, 5L * q.NB, 2L * q.NB + blockIdx.x, r);
+        r = wg_reduce_sum<K>(acc_result<K>(a3), red, tid); if (tid == 0) stx<K>(p.part, 5L * q.NB, 3L * q.NB + blockIdx.x, r);
+    }
+    if (sel & 4) { mw<K> r = wg_reduce_sum<K>(acc_result<K>(a4), red, tid); if (tid == 0) stx<K>(p.part, 5L * q.NB, 4L * q.NB + blockIdx.x, r); }
+    if (stage >= 0 && mwi_last_block(&p.flags[4], gridDim.x) && tid < 64) mwi_scalar_stage<K, DK>(q, p, stage, iter);
 }
 
 
@@ -447,7 +475,7 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_rows(const MwDev q, const MwIpmDe
 
 // p = +-b - B^T x  (:899-916)
 template <int K, int DK>
-__global__ __launch_bounds__(MW_NT) void k_mwi_pv(const MwDev q, const MwIpmDev p) {
+__global__ __launch_bounds__(MW_NT) void k_mwi_pv(const MwDev q, const MwIpmDev p, int iter) {
     using namespace mwk;
     const int a = blockIdx.x * (MW_NT / 8) + threadIdx.x / 8, sub = threadIdx.x % 8;      // eight lanes per free variable
     const bool live = a < q.N;
@@ -461,6 +489,7 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_pv(const MwDev q, const MwIpmDev 
         atomic_max_abs(&p.fmax[2], v.l[0]);
         stx<K>(p.pv, q.N, a, v);
     }
+    if (mwi_last_block(&p.flags[4], gridDim.x) && threadIdx.x < 64) mwi_scalar_stage<K, DK>(q, p, 1, iter);      // errors of the residuals
 }
 
 // ---- which 0: Z = sym(X^-1 (P Y - R)) (:1501-1514);  which 1: dY = sym(X^-1 (R - dX Y)) (:1597-1613); both into dY --------
@@ -609,7 +638,7 @@ __device__ __forceinline__ void mwi_step_congruence(PF F, PR rd, PW W, long wpla
 // ---- compute_step_length (:1620-1693) per block: smallest eigenvalue of L^-1 dM L^-T, L = chol(M) -----------------------
 // which 0: (X, dX) with the factors of this iteration; which 1: (Y, dY), factored here
 template <int K>
-__global__ __launch_bounds__(MW_NT) void k_mwi_step(const MwDev q, const MwIpmDev p, int w_in_lds, int inv_path) {
+__device__ __forceinline__ void mwi_step_body(const MwDev &q, const MwIpmDev &p, int w_in_lds, int inv_path) {
     using namespace mwk;
     const int which = blockIdx.y;                       // both step lengths in one launch
     const MwBlk &k = q.blk[blockIdx.x];
@@ -672,6 +701,11 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_step(const MwDev q, const MwIpmDe
     __syncthreads();
     const double ev = wg_min_eig(Wd, n, work, tid);
     if (tid == 0) p.eig[(long)which * q.NB + blockIdx.x] = ev - 1e-5;                    // :1662
+}
+template <int K, int DK>
+__global__ __launch_bounds__(MW_NT) void k_mwi_step(const MwDev q, const MwIpmDev p, int w_in_lds, int inv_path, int iter) {
+    mwi_step_body<K>(q, p, w_in_lds, inv_path);
+    if (mwi_last_block(&p.flags[4], gridDim.x * gridDim.y) && threadIdx.x < 64) mwi_scalar_stage<K, DK>(q, p, 3, iter);   // step lengths
 }
 
 // ---- x, X += alpha_d (dx, dX); y, Y += alpha_p (dy, dY)  (:485-495); skipped when the iteration ended with an error ------
@@ -807,7 +841,7 @@ extern "C" int clrs_mw_ipm_create_ex(clrs_mw_ctx *c, const clrs_ipm_data *data, 
         MW_DISPATCH(c, {
             if ((rc = mw_set_lds(k_mwi_Zi<KK>, st->sm_Zi))) return rc;
             if ((rc = mw_set_lds(k_mwi_Z<KK>, st->sm_Z))) return rc;
-            if ((rc = mw_set_lds(k_mwi_step<KK>, st->sm_step))) return rc;
+            if ((rc = mw_set_lds((k_mwi_step<KK, DD>), st->sm_step))) return rc;
         });
         // default parameters (src/solver.jl:103-126)
         p.beta_infeasible = 0.3; p.beta_feasible = 0.1; p.gamma = 0.9; p.dual_thr = 1e-30; p.primal_thr = 1e-30;
@@ -839,7 +873,7 @@ static int mw_ipm_objectives(clrs_mw_ctx *c) {
     const MwDev &q = c->d;
     const MwIpmDev &p = c->ipm->d;
     MW_DISPATCH(c, {
-        hipLaunchKernelGGL((k_mwi_dots<KK, DD>), dim3(q.NB), dim3(MW_NT), (size_t)KK * 8 * 8, c->stream, q, p, 4);
+        hipLaunchKernelGGL((k_mwi_dots<KK, DD>), dim3(q.NB), dim3(MW_NT), (size_t)KK * 8 * 8, c->stream, q, p, 4, -1, c->ipm->iter);
         hipLaunchKernelGGL((k_mwi_scalar<KK, DD>), dim3(1), dim3(64), 0, c->stream, q, p, 4, c->ipm->iter);
     });
     MWCHECK(hipGetLastError());
@@ -919,8 +953,8 @@ extern "C" int clrs_mw_ipm_iterate(clrs_mw_ctx *c, clrs_ipm_record *out) {
     int rc;
     st->iter++;
     MW_DISPATCH(c, {
-        hipLaunchKernelGGL((k_mwi_dots<KK, DD>), dim3(q.NB), dim3(MW_NT), sm_red, c->stream, q, p, 1);
-        hipLaunchKernelGGL((k_mwi_scalar<KK, DD>), dim3(1), dim3(1), 0, c->stream, q, p, 0, st->iter);
+        hipLaunchKernelGGL((k_mwi_dots<KK, DD>), dim3(q.NB), dim3(MW_NT), sm_red, c->stream, q, p, 1, -1, st->iter);
+        hipLaunchKernelGGL((k_mwi_scalar<KK, DD>), dim3(1), dim3(64), 0, c->stream, q, p, 0, st->iter);
     });
     if ((rc = clrs_mw_cholesky_blocks_dev(c, p.X, p.Xc))) return rc;
     if ((rc = clrs_mw_schur_assemble_dev(c, p.Xc, p.Y))) return rc;
@@ -929,19 +963,18 @@ extern "C" int clrs_mw_ipm_iterate(clrs_mw_ctx *c, clrs_ipm_record *out) {
         if (q.T) hipLaunchKernelGGL((k_mwi_coef<KK, DD>), dim3((unsigned)((q.T + MW_NT - 1) / MW_NT)), dim3(MW_NT), 0, c->stream, q, p, (const double *)p.x);
         hipLaunchKernelGGL((k_mwi_wA<KK, DD>), dim3((maxnn * MWI_EW + MW_NT - 1) / MW_NT, q.NB), dim3(MW_NT), 0, c->stream, q, p, 0);
         hipLaunchKernelGGL((k_mwi_rows<KK, DD>), dim3((unsigned)((q.xlen * MWI_RW + MW_NT - 1) / MW_NT)), dim3(MW_NT), 0, c->stream, q, p, 0);
-        if (q.N) hipLaunchKernelGGL((k_mwi_pv<KK, DD>), dim3((q.N + MW_NT / 8 - 1) / (MW_NT / 8)), dim3(MW_NT), 0, c->stream, q, p);
-        hipLaunchKernelGGL((k_mwi_scalar<KK, DD>), dim3(1), dim3(1), 0, c->stream, q, p, 1, st->iter);
+        if (q.N) hipLaunchKernelGGL((k_mwi_pv<KK, DD>), dim3((q.N + MW_NT / 8 - 1) / (MW_NT / 8)), dim3(MW_NT), 0, c->stream, q, p, st->iter);
+        else hipLaunchKernelGGL((k_mwi_scalar<KK, DD>), dim3(1), dim3(64), 0, c->stream, q, p, 1, st->iter);
     });
     MWCHECK(hipGetLastError());
     if ((rc = mw_ipm_direction(c, 0))) return rc;
     MW_DISPATCH(c, {
-        hipLaunchKernelGGL((k_mwi_dots<KK, DD>), dim3(q.NB), dim3(MW_NT), sm_red, c->stream, q, p, 2);
-        hipLaunchKernelGGL((k_mwi_scalar<KK, DD>), dim3(1), dim3(1), 0, c->stream, q, p, 2, st->iter);
+        hipLaunchKernelGGL((k_mwi_dots<KK, DD>), dim3(q.NB), dim3(MW_NT), sm_red, c->stream, q, p, 2, -1, st->iter);
+        hipLaunchKernelGGL((k_mwi_scalar<KK, DD>), dim3(1), dim3(64), 0, c->stream, q, p, 2, st->iter);
     });
     if ((rc = mw_ipm_direction(c, 1))) return rc;
     MW_DISPATCH(c, {
-        hipLaunchKernelGGL(k_mwi_step<KK>, dim3(q.NB, 2), dim3(MW_NT), st->sm_step, c->stream, q, p, st->step_w_lds ? 1 : 0, st->step_inv ? 1 : 0);
-        hipLaunchKernelGGL((k_mwi_scalar<KK, DD>), dim3(1), dim3(1), 0, c->stream, q, p, 3, st->iter);
+        hipLaunchKernelGGL((k_mwi_step<KK, DD>), dim3(q.NB, 2), dim3(MW_NT), st->sm_step, c->stream, q, p, st->step_w_lds ? 1 : 0, st->step_inv ? 1 : 0, st->iter);
         hipLaunchKernelGGL(k_mwi_update<KK>, dim3((unsigned)std::min<i64>(1024, (q.xylen + q.xlen + q.N + MW_NT - 1) / MW_NT)), dim3(MW_NT), 0, c->stream, q, p);
     });
     MWCHECK(hipGetLastError());
