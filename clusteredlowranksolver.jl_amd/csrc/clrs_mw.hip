@@ -328,7 +328,7 @@ extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int dev
         c->lds_x = nn + bcw <= lim;
         size_t xneed = (c->lds_x ? nn : 0) + bcw;
         for (auto &k : c->blk) {                            // X blocks whose factor and its inverse fit side by side: Xi is formed
-            const size_t two = 2 * (size_t)k.n * k.n * K + MW_POTRF_SCR(K, (size_t)k.n);
+            const size_t two = 2 * (size_t)k.n * k.n * K + MW_POTRF_SCR(K, (size_t)k.n) + (size_t)K * k.n;   // + a reciprocal diagonal (the Y workgroups of the iteration)
             k.inv = (use_inv && c->lds_x && two <= lim) ? 1 : 0;
             if (k.inv) xneed = std::max(xneed, two);
         }
@@ -502,17 +502,20 @@ static int mw_read_info(clrs_mw_ctx *c, int which, int *status) {
 }
 
 // ---- the path, device pointers (planar K x len arrays), enqueue only ------------------------------------------------
-extern "C" int clrs_mw_cholesky_blocks_dev(clrs_mw_ctx *c, const double *d_X, double *d_Xchol) {
+// d_Y2 (optional): a second block-diagonal matrix whose inverse Cholesky factors go to d_Yi, failures per block to d_yfail
+static int mw_cholesky_blocks_dev2(clrs_mw_ctx *c, const double *d_X, double *d_Xchol, const double *d_Y2, double *d_Yi, int *d_yfail) {
     if (!c || !d_X || !d_Xchol) return mw_fail(CLRS_ERR_INVALID, "null argument");
     MWCHECK(hipSetDevice(c->device));
     int rc;
     if ((rc = mw_reset_info(c, 1))) return rc;
     if (c->d.NB == 0) return 0;
-    MW_DISPATCH(c, hipLaunchKernelGGL(k_mw_potrf_x<KK>, dim3(c->d.NB), dim3(MW_PT), c->sm_x, c->stream, c->d, d_X, d_Xchol, c->lds_x ? 1 : 0));
+    const int grid = d_Y2 ? 2 * c->d.NB : c->d.NB;
+    MW_DISPATCH(c, hipLaunchKernelGGL(k_mw_potrf_x<KK>, dim3(grid), dim3(MW_PT), c->sm_x, c->stream, c->d, d_X, d_Xchol, c->lds_x ? 1 : 0, d_Y2, d_Yi, d_yfail));
     MWCHECK(hipGetLastError());
     c->xinv_valid = true;
     return 0;
 }
+extern "C" int clrs_mw_cholesky_blocks_dev(clrs_mw_ctx *c, const double *d_X, double *d_Xchol) { return mw_cholesky_blocks_dev2(c, d_X, d_Xchol, nullptr, nullptr, nullptr); }
 extern "C" int clrs_mw_sync_status_cholesky(clrs_mw_ctx *c) {
     if (!c) return mw_fail(CLRS_ERR_INVALID, "null context");
     int st = 0, rc;

@@ -15,6 +15,10 @@ enum { MREC_ITER = 0, MREC_MU, MREC_DOBJ, MREC_POBJ, MREC_GAP, MREC_DERR, MREC_P
 
 struct MwIpmDev {
     double *x, *y, *X, *Y, *dx, *dy, *dX, *dY, *R, *Xc, *Pm, *d, *rhsx, *pv, *coef;   // planar limbs
+    double *Yi;                        // chol(Y)^-1 per block (xy layout), formed beside chol(X) at the start of the iteration
+    int *yfail;                        // [NB] 1 = Y_b is not positive definite
+    double *Zs;                        // unsymmetrised X^-1 (...) of k_mwi_Zi (xy layout)
+    int *zcnt;                         // [NB] workgroups of a block that have delivered their panel
     double *sc, *part;                 // planar scalars [MSC_COUNT]; partial dot products [5][NB]
     unsigned long long *fmax;          // bit patterns of non-negative doubles: [0] max|P|, [1] max|d|, [2] max|p|
     double *eig;                       // fp64 [2][NB]: smallest eigenvalue of L^-1 dM L^-T per block (X then Y)
@@ -534,55 +538,60 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_Z(const MwDev q, const MwIpmDev p
 }
 
 // The same with the explicit inverse Xi = chol(X)^-1 that k_mw_potrf_x leaves beside the factor: X^-1 M = Xi^T (Xi M), three
-// block products, two lanes per entry (MW_PT threads)
+// block products.  They are independent column by column, and one compute unit issues them no faster than its four SIMDs
+// allow, so a block is split over MWI_ZS workgroups by column panels (eight lanes per entry, MW_PT threads); the panels go to
+// a scratch matrix and the workgroup of a block that finishes last symmetrises it (a counter per block).
+#define MWI_ZS 4
+#define MWI_ZL 8
 template <int K>
 __global__ __launch_bounds__(MW_PT) void k_mwi_Zi(const MwDev q, const MwIpmDev p, int which) {
     using namespace mwk;
     const MwBlk &k = q.blk[blockIdx.x];
     if (!k.inv) return;
-    const int n = k.n, tid = threadIdx.x, sub = tid & 1;
-    const long nn = (long)n * n;
-    lds_d *M = MW_LDS, *M2 = M + (long)K * nn;
+    const int n = k.n, tid = threadIdx.x, sub = tid % MWI_ZL;
+    const int pc0 = (n + MWI_ZS - 1) / MWI_ZS, c0 = blockIdx.y * pc0, pc = max(0, min(pc0, n - c0));     // this workgroup's columns
+    const long np = (long)n * pc0;
+    lds_d *M = MW_LDS, *M2 = M + (long)K * np;
     const double *A = (which == 0 ? p.Pm : p.dX) + k.xyoff, *Xi = q.Xi + k.xyoff;
     const double sg = which == 0 ? 1.0 : -1.0;
-    for (int e0 = 0; e0 < nn; e0 += MW_PT / 2) {           // M = sg (A Y - R)
-        const int e = e0 + (tid >> 1);
-        const bool live = e < nn;
-        const int ee = live ? e : 0, i = ee % n, c = ee / n;
+    for (int e0 = 0; e0 < n * pc; e0 += MW_PT / MWI_ZL) {  // M = sg (A Y - R)
+        const int e = e0 + tid / MWI_ZL;
+        const bool live = e < n * pc;
+        const int ee = live ? e : 0, i = ee % n, c = c0 + ee / n;
         acc<K> s;
         acc_zero<K>(s);
-        for (int kk = sub; kk < n; kk += 2) acc_fma<K, K, K>(s, ldx<K>(A, q.xylen, i + (long)kk * n), ldx<K>(p.Y + k.xyoff, q.xylen, kk + (long)c * n), sg);
-        if (sub == 0) acc_add<K, K>(s, ldx<K>(p.R + k.xyoff, q.xylen, ee), -sg);
-        const mw<K> v = lanes_sum<K, 2>(acc_result<K>(s));
-        if (live && sub == 0) stx<K>(M, nn, e, v);
+        for (int kk = sub; kk < n; kk += MWI_ZL) acc_fma<K, K, K>(s, ldx<K>(A, q.xylen, i + (long)kk * n), ldx<K>(p.Y + k.xyoff, q.xylen, kk + (long)c * n), sg);
+        if (sub == 0) acc_add<K, K>(s, ldx<K>(p.R + k.xyoff, q.xylen, i + (long)c * n), -sg);
+        const mw<K> v = lanes_sum<K, MWI_ZL>(acc_result<K>(s));
+        if (live && sub == 0) stx<K>(M, np, ee, v);
     }
     __syncthreads();
-    for (int e0 = 0; e0 < nn; e0 += MW_PT / 2) {           // M2 = Xi M
-        const int e = e0 + (tid >> 1);
-        const bool live = e < nn;
-        const int ee = live ? e : 0, i = ee % n, c = ee / n;
+    for (int e0 = 0; e0 < n * pc; e0 += MW_PT / MWI_ZL) {  // M2 = Xi M
+        const int e = e0 + tid / MWI_ZL;
+        const bool live = e < n * pc;
+        const int ee = live ? e : 0, i = ee % n, cl = ee / n;
         acc<K> s;
         acc_zero<K>(s);
-        for (int r = sub; r <= i; r += 2) acc_fma<K, K, K>(s, ldx<K>(Xi, q.xylen, i + (long)r * n), ldx<K>(M, nn, r + (long)c * n));
-        const mw<K> v = lanes_sum<K, 2>(acc_result<K>(s));
-        if (live && sub == 0) stx<K>(M2, nn, e, v);
+        for (int r = sub; r <= i; r += MWI_ZL) acc_fma<K, K, K>(s, ldx<K>(Xi, q.xylen, i + (long)r * n), ldx<K>(M, np, r + (long)cl * n));
+        const mw<K> v = lanes_sum<K, MWI_ZL>(acc_result<K>(s));
+        if (live && sub == 0) stx<K>(M2, np, ee, v);
     }
     __syncthreads();
-    for (int e0 = 0; e0 < nn; e0 += MW_PT / 2) {           // M = Xi^T M2
-        const int e = e0 + (tid >> 1);
-        const bool live = e < nn;
-        const int ee = live ? e : 0, i = ee % n, c = ee / n;
+    for (int e0 = 0; e0 < n * pc; e0 += MW_PT / MWI_ZL) {  // Xi^T M2 -> scratch
+        const int e = e0 + tid / MWI_ZL;
+        const bool live = e < n * pc;
+        const int ee = live ? e : 0, i = ee % n, cl = ee / n;
         acc<K> s;
         acc_zero<K>(s);
-        for (int r = i + sub; r < n; r += 2) acc_fma<K, K, K>(s, ldx<K>(Xi, q.xylen, r + (long)i * n), ldx<K>(M2, nn, r + (long)c * n));
-        const mw<K> v = lanes_sum<K, 2>(acc_result<K>(s));
-        if (live && sub == 0) stx<K>(M, nn, e, v);
+        for (int r = i + sub; r < n; r += MWI_ZL) acc_fma<K, K, K>(s, ldx<K>(Xi, q.xylen, r + (long)i * n), ldx<K>(M2, np, r + (long)cl * n));
+        const mw<K> v = lanes_sum<K, MWI_ZL>(acc_result<K>(s));
+        if (live && sub == 0) stx<K>(p.Zs + k.xyoff, q.xylen, i + (long)(c0 + cl) * n, v);
     }
-    __syncthreads();
-    for (int e = tid; e < nn; e += MW_PT) {
+    if (!mwi_last_block(&p.zcnt[blockIdx.x], MWI_ZS)) return;
+    for (int e = tid; e < n * n; e += MW_PT) {
         const int i = e % n, c = e / n;
         if (c > i) continue;
-        mw<K> v = mul_pow2<K>(add<K>(ldx<K>(M, nn, i + (long)c * n), ldx<K>(M, nn, c + (long)i * n)), 0.5);
+        mw<K> v = mul_pow2<K>(add<K>(ldx<K>(p.Zs + k.xyoff, q.xylen, i + (long)c * n), ldx<K>(p.Zs + k.xyoff, q.xylen, c + (long)i * n)), 0.5);
         stx<K>(p.dY + k.xyoff, q.xylen, i + (long)c * n, v);
         stx<K>(p.dY + k.xyoff, q.xylen, c + (long)i * n, v);
     }
@@ -659,6 +668,12 @@ __device__ __forceinline__ void mwi_step_body(const MwDev &q, const MwIpmDev &p,
         lds_d *rd = Mf + (long)K * nn, *Wd = rd + (long)K * n, *work = Wd + nn, *scr = work + 3 * n + 2 * MW_NT;
         if (which == 0) {
             mwi_step_congruence_inv<K>(q.Xi + k.xyoff, q.xylen, n, dMg, q.xylen, T1, Wd, tid);
+        } else if (inv_path == 2) {                     // chol(Y)^-1 came with this iteration's chol(X)
+            if (p.yfail[blockIdx.x]) {                                                   // :1644-1646
+                if (tid == 0) { p.flags[2] = 1; p.eig[(long)which * q.NB + blockIdx.x] = 0.0; }
+                return;
+            }
+            mwi_step_congruence_inv<K>(p.Yi + k.xyoff, q.xylen, n, dMg, q.xylen, T1, Wd, tid);
         } else {
             wg_copy<K>(Mf, nn, n, Mg, q.xylen, n, n, n, tid);
             __syncthreads();
@@ -767,7 +782,7 @@ struct MwIpm {
     int iter = 0;
     double *h_rec = nullptr;      // pinned
     size_t sm_Z = 0, sm_Zi = 0, sm_step = 0;
-    bool lds_ZL = false, step_w_lds = true, step_inv = false, any_xinv = false, any_xsub = false;
+    bool lds_ZL = false, step_w_lds = true, step_inv = false, y_with_x = false, any_xinv = false, any_xsub = false;
     ~MwIpm() { if (h_rec) (void)hipHostFree(h_rec); }
 };
 
@@ -799,6 +814,9 @@ extern "C" int clrs_mw_ipm_create_ex(clrs_mw_ctx *c, const clrs_ipm_data *data, 
         double **ys[] = {&p.y, &p.dy, &p.pv};
         for (double **b : ys) if ((rc = mw_dmalloc(c, b, (i64)N * K))) return rc;
         if ((rc = mw_dmalloc(c, &p.coef, q.T * K))) return rc;
+        if ((rc = mw_dmalloc(c, &p.Yi, q.xylen * K)) || (rc = mw_dmalloc(c, &p.Zs, q.xylen * K))) return rc;
+        { double *t3 = nullptr; if ((rc = mw_dmalloc(c, &t3, (NB + 1) / 2 + 1))) return rc; p.zcnt = (int *)t3; }
+        { double *t2 = nullptr; if ((rc = mw_dmalloc(c, &t2, (NB + 1) / 2 + 1))) return rc; p.yfail = (int *)t2; }
         if ((rc = mw_dmalloc(c, &p.sc, (i64)MSC_COUNT * K))) return rc;
         if ((rc = mw_dmalloc(c, &p.part, 5LL * NB * K))) return rc;
         if ((rc = mw_dmalloc(c, &p.eig, 2LL * NB))) return rc;
@@ -834,9 +852,10 @@ extern "C" int clrs_mw_ipm_create_ex(clrs_mw_ctx *c, const clrs_ipm_data *data, 
             if (k.inv) { st->any_xinv = true; maxn_inv = std::max(maxn_inv, (size_t)k.n); }
             else st->any_xsub = true;
         }
-        st->sm_Zi = 2 * maxn_inv * maxn_inv * K * 8;
+        st->sm_Zi = 2 * maxn_inv * ((maxn_inv + MWI_ZS - 1) / MWI_ZS) * K * 8;
         const size_t step_inv_need = 3 * maxn_inv * maxn_inv * K + step_rest;
         st->step_inv = st->any_xinv && step_inv_need <= lim;
+        st->y_with_x = st->step_inv && !st->any_xsub;      // every block has its inverse factor: chol(Y)^-1 rides on the chol(X) launch
         if (st->step_inv) st->sm_step = std::max(st->sm_step, step_inv_need * 8);
         MW_DISPATCH(c, {
             if ((rc = mw_set_lds(k_mwi_Zi<KK>, st->sm_Zi))) return rc;
@@ -925,7 +944,7 @@ static int mw_ipm_direction(clrs_mw_ctx *c, int corrector) {
     int rc;
     MW_DISPATCH(c, {
         hipLaunchKernelGGL(k_mwi_R<KK>, dim3((maxnn * MWI_EW + MW_NT - 1) / MW_NT, q.NB), dim3(MW_NT), 0, c->stream, q, p, corrector);
-        if (st->any_xinv) hipLaunchKernelGGL(k_mwi_Zi<KK>, dim3(q.NB), dim3(MW_PT), st->sm_Zi, c->stream, q, p, 0);
+        if (st->any_xinv) hipLaunchKernelGGL(k_mwi_Zi<KK>, dim3(q.NB, MWI_ZS), dim3(MW_PT), st->sm_Zi, c->stream, q, p, 0);
         if (st->any_xsub) hipLaunchKernelGGL(k_mwi_Z<KK>, dim3(q.NB), dim3(MW_NT), st->sm_Z, c->stream, q, p, 0, st->lds_ZL ? 1 : 0);
         if (q.nlr) hipLaunchKernelGGL((k_mwi_MV<KK, DD>), dim3((c->maxn * c->maxU * MWI_EW + MW_NT - 1) / MW_NT, q.nlr), dim3(MW_NT), 0, c->stream, q, (const double *)p.dY);
         hipLaunchKernelGGL((k_mwi_rows<KK, DD>), dim3((unsigned)((q.xlen * MWI_RW + MW_NT - 1) / MW_NT)), dim3(MW_NT), 0, c->stream, q, p, 1);
@@ -935,7 +954,7 @@ static int mw_ipm_direction(clrs_mw_ctx *c, int corrector) {
     MW_DISPATCH(c, {
         if (q.T) hipLaunchKernelGGL((k_mwi_coef<KK, DD>), dim3((unsigned)((q.T + MW_NT - 1) / MW_NT)), dim3(MW_NT), 0, c->stream, q, p, (const double *)p.dx);
         hipLaunchKernelGGL((k_mwi_wA<KK, DD>), dim3((maxnn * MWI_EW + MW_NT - 1) / MW_NT, q.NB), dim3(MW_NT), 0, c->stream, q, p, 1);
-        if (st->any_xinv) hipLaunchKernelGGL(k_mwi_Zi<KK>, dim3(q.NB), dim3(MW_PT), st->sm_Zi, c->stream, q, p, 1);
+        if (st->any_xinv) hipLaunchKernelGGL(k_mwi_Zi<KK>, dim3(q.NB, MWI_ZS), dim3(MW_PT), st->sm_Zi, c->stream, q, p, 1);
         if (st->any_xsub) hipLaunchKernelGGL(k_mwi_Z<KK>, dim3(q.NB), dim3(MW_NT), st->sm_Z, c->stream, q, p, 1, st->lds_ZL ? 1 : 0);
     });
     MWCHECK(hipGetLastError());
@@ -956,7 +975,7 @@ extern "C" int clrs_mw_ipm_iterate(clrs_mw_ctx *c, clrs_ipm_record *out) {
         hipLaunchKernelGGL((k_mwi_dots<KK, DD>), dim3(q.NB), dim3(MW_NT), sm_red, c->stream, q, p, 1, -1, st->iter);
         hipLaunchKernelGGL((k_mwi_scalar<KK, DD>), dim3(1), dim3(64), 0, c->stream, q, p, 0, st->iter);
     });
-    if ((rc = clrs_mw_cholesky_blocks_dev(c, p.X, p.Xc))) return rc;
+    if ((rc = mw_cholesky_blocks_dev2(c, p.X, p.Xc, st->y_with_x ? p.Y : nullptr, p.Yi, p.yfail))) return rc;
     if ((rc = clrs_mw_schur_assemble_dev(c, p.Xc, p.Y))) return rc;
     if ((rc = clrs_mw_schur_factor_dev(c))) return rc;
     MW_DISPATCH(c, {
@@ -974,7 +993,7 @@ extern "C" int clrs_mw_ipm_iterate(clrs_mw_ctx *c, clrs_ipm_record *out) {
     });
     if ((rc = mw_ipm_direction(c, 1))) return rc;
     MW_DISPATCH(c, {
-        hipLaunchKernelGGL((k_mwi_step<KK, DD>), dim3(q.NB, 2), dim3(MW_NT), st->sm_step, c->stream, q, p, st->step_w_lds ? 1 : 0, st->step_inv ? 1 : 0, st->iter);
+        hipLaunchKernelGGL((k_mwi_step<KK, DD>), dim3(q.NB, 2), dim3(MW_NT), st->sm_step, c->stream, q, p, st->step_w_lds ? 1 : 0, st->y_with_x ? 2 : st->step_inv ? 1 : 0, st->iter);
         hipLaunchKernelGGL(k_mwi_update<KK>, dim3((unsigned)std::min<i64>(1024, (q.xylen + q.xlen + q.N + MW_NT - 1) / MW_NT)), dim3(MW_NT), 0, c->stream, q, p);
     });
     MWCHECK(hipGetLastError());

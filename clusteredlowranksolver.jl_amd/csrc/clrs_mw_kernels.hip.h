@@ -412,12 +412,33 @@ __device__ __forceinline__ void mw_potrf_x_body(const MwDev &q, const MwBlk &k, 
         }
     }
 }
+// Workgroups NB .. 2 NB - 1 (launched by the interior-point iteration only, when every block has inv = 1) factor a SECOND
+// block-diagonal matrix, Y, and keep just the inverse of its factor (Yi) and a failure flag per block: the step length of Y
+// (src/solver.jl:1644-1655) needs chol(Y)^-1, which depends on nothing computed during the iteration, so it rides along on
+// compute units the launch would leave idle.
 template <int K>
-__global__ __launch_bounds__(MW_PT) void k_mw_potrf_x(const MwDev q, const double *__restrict__ X, double *__restrict__ Xc, int lds) {
+__global__ __launch_bounds__(MW_PT) void k_mw_potrf_x(const MwDev q, const double *__restrict__ X, double *__restrict__ Xc, int lds, const double *__restrict__ Y2,
+                                                      double *__restrict__ Yi, int *__restrict__ yfail) {
     using namespace mwk;
-    const MwBlk &k = q.blk[blockIdx.x];
+    const bool second = (int)blockIdx.x >= q.NB;
+    const MwBlk &k = q.blk[second ? blockIdx.x - q.NB : blockIdx.x];
     const int n = k.n, tid = threadIdx.x;
     lds_d *bc = MW_LDS;                                   // scratch of wg_potrf, in front of the matrix
+    if (second) {
+        lds_d *M = MW_LDS + MW_POTRF_SCR(K, n), *W = M + (long)K * n * n, *rdl = W + (long)K * n * n;
+        wg_copy<K, MW_PT>(M, (long)n * n, n, Y2 + k.xyoff, q.xylen, n, n, n, tid);
+        __syncthreads();
+        const bool ok = wg_potrf<K, true, MW_PT, false>(M, (long)n * n, n, n, rdl, n, W, (long)n * n, n, bc, tid);
+        if (tid == 0) yfail[blockIdx.x - q.NB] = ok ? 0 : 1;
+        if (ok) {
+            for (int e = tid; e < n * n; e += MW_PT) {
+                const int i = e % n, c = e / n;
+#pragma unroll
+                for (int l = 0; l < K; l++) Yi[(long)l * q.xylen + k.xyoff + e] = (i >= c) ? (double)W[(long)l * n * n + e] : 0.0;
+            }
+        }
+        return;
+    }
     if (lds) {
         lds_d *M = MW_LDS + MW_POTRF_SCR(K, n);
         wg_copy<K, MW_PT>(M, (long)n * n, n, X + k.xyoff, q.xylen, n, n, n, tid);
