@@ -13,7 +13,6 @@
 
 #include <algorithm>
 #include <cstdio>
-#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -82,9 +81,9 @@ struct clrs_mw_ctx {
     std::vector<MwBlk> blk;
     std::vector<MwClu> clu;
     std::vector<void *> allocs;
-    int maxU = 0, maxP = 0, maxn = 0, maxP_inv = 0;
+    int maxU = 0, maxP = 0, maxn = 0;
     bool xinv_valid = false;            // Xi holds the inverses of the current Cholesky factors (they come from k_mw_potrf_x, not from the caller)
-    bool lds_x = false, lds_q = false, lds_zt_L = false, qinv = false, any_inv = false, any_sub = false;
+    bool lds_x = false, lds_q = false, lds_zt_L = false;
     size_t sm_x = 0, sm_zt = 0, sm_dense = 0, sm_factor = 0, sm_q = 0, sm_fwd = 0, sm_mid = 0, sm_bwd = 0;
     int *h_info = nullptr;               // pinned
     double *d_Xin = nullptr, *d_Xc = nullptr, *d_Y = nullptr, *d_rx = nullptr, *d_ry = nullptr, *d_dx = nullptr, *d_dy = nullptr;   // staging of the host-pointer entry points
@@ -95,8 +94,7 @@ struct clrs_mw_ctx {
     double cnt_mul = 0;                  // multi-word multiply-adds of one assembly (algorithmic)
     double cnt_factor = 0, cnt_solve = 0;
     struct MwIpm *ipm = nullptr;
-    double *d_bpFd = nullptr;            // scratch of the blocked factorisation (k_mw_bp_*)
-    size_t sm_bp_diag = 0, sm_bp_panel = 0;
+    size_t sm_bp_diag = 0, sm_bp_panel = 0, sm_bp_inv = 0;   // LDS of the blocked factorisation (k_mw_bp_*)
     void *comm = nullptr;                // ncclComm_t when the library does the exchanges itself (clrs_mw_comm_init)
     bool local_factored = false, fwd_done = false;
 };
@@ -320,8 +318,6 @@ extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int dev
     c->cnt_solve += (double)N * N;
     // ---- LDS plans ----
     const size_t lim = MW_LDS_MAX / sizeof(double);
-    const char *no_inv = getenv("CLRS_MW_NO_INVERSE");          // diagnostic: substitutions everywhere, as for matrices beyond LDS
-    const bool use_inv = !(no_inv && no_inv[0] == '1');
     {
         size_t nn = (size_t)c->maxn * c->maxn * K;
         size_t bcw = MW_POTRF_SCR(K, (size_t)c->maxn);       // scratch of wg_potrf
@@ -329,7 +325,7 @@ extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int dev
         size_t xneed = (c->lds_x ? nn : 0) + bcw;
         for (auto &k : c->blk) {                            // X blocks whose factor and its inverse fit side by side: Xi is formed
             const size_t two = 2 * (size_t)k.n * k.n * K + MW_POTRF_SCR(K, (size_t)k.n) + (size_t)K * k.n;   // + a reciprocal diagonal (the Y workgroups of the iteration)
-            k.inv = (use_inv && c->lds_x && two <= lim) ? 1 : 0;
+            k.inv = (c->lds_x && two <= lim) ? 1 : 0;
             if (k.inv) xneed = std::max(xneed, two);
         }
         c->sm_x = xneed * 8;
@@ -341,37 +337,23 @@ extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int dev
         for (auto &k : c->blk) if (k.kind != 0 && k.n > 1) maxnd = std::max(maxnd, (size_t)k.n);
         if (maxnd * maxnd * K > lim) MW_BAIL(CLRS_ERR_INVALID, "dense block too large for the multi-word kernels");
         c->sm_dense = maxnd * maxnd * K * 8;
-        size_t fmax = 0, smax = 0;
-        size_t bcw_max = bcw;
-        for (auto &q : c->clu) {
-            bcw = MW_POTRF_SCR(K, (size_t)q.P);
-            bcw_max = std::max(bcw_max, bcw);
-            size_t need = std::max((size_t)q.P * q.P * K + bcw, ((size_t)q.P * q.P + (size_t)q.P * MW_BT) * K);     // k_mw_factor; k_mw_linvb
+        size_t fmax = 0;
+        for (auto &q : c->clu) {                        // S_j and the inverse of its factor side by side in LDS, or the blocked path
+            const size_t need = 2 * (size_t)q.P * q.P * K + MW_POTRF_SCR(K, (size_t)q.P);
             q.lds = need <= lim ? 1 : 0;
-            q.inv = (use_inv && q.lds && 2 * (size_t)q.P * q.P * K + bcw <= lim) ? 1 : 0;      // S_j and the inverse of its factor side by side
-            if (q.inv) need = std::max(need, 2 * (size_t)q.P * q.P * K + bcw);
-            c->any_inv |= q.inv != 0;
-            if (q.inv) c->maxP_inv = std::max(c->maxP_inv, q.P);
-            c->any_sub |= q.inv == 0;
-            if (!q.lds && (size_t)q.P * MW_BT * K > lim) MW_BAIL(CLRS_ERR_INVALID, "cluster too large for the multi-word kernels");
-            if (!q.lds) fmax = std::max(fmax, (size_t)q.P * MW_BT * K);
             if (q.lds) fmax = std::max(fmax, need);
-            size_t sneed = ((size_t)q.P + (q.lds ? (size_t)q.P * q.P : 0)) * K;
-            smax = std::max(smax, sneed);
         }
-        c->sm_factor = std::max(fmax, bcw_max) * 8;
-        c->sm_fwd = c->sm_bwd = smax * 8;
-        size_t qn = (size_t)N * N * K;
-        bcw = MW_POTRF_SCR(K, (size_t)N);
-        c->lds_q = 2 * qn + (size_t)N * K <= lim;
-        c->qinv = use_inv && c->lds_q && 2 * qn + bcw <= lim;
-        c->sm_q = ((c->qinv ? 2 * qn : c->lds_q ? qn : 0) + bcw) * 8;
-        c->sm_mid = ((size_t)N * K + (c->lds_q ? 2 * qn : 0)) * 8;
+        c->sm_factor = std::max<size_t>(fmax, 1) * 8;
+        c->sm_fwd = c->sm_bwd = 2 * (size_t)c->maxP * K * 8;
+        const size_t qn = (size_t)N * N * K;
+        c->lds_q = 2 * qn + MW_POTRF_SCR(K, (size_t)N) <= lim;
+        c->sm_q = (c->lds_q ? 2 * qn + MW_POTRF_SCR(K, (size_t)N) : 1) * 8;
+        c->sm_mid = 2 * (size_t)std::max(N, 1) * K * 8;
         if (c->sm_fwd > MW_LDS_MAX || c->sm_mid > MW_LDS_MAX) MW_BAIL(CLRS_ERR_INVALID, "cluster too large for the multi-word solve kernels");
     }
     MW_DISPATCH(c, {
         MW_TRY(mw_set_lds(k_mw_potrf_x<KK>, c->sm_x)); MW_TRY(mw_set_lds(k_mw_zt<KK, DD>, c->sm_zt)); MW_TRY(mw_set_lds(k_mw_dense<KK, DD>, c->sm_dense));
-        MW_TRY(mw_set_lds(k_mw_factor<KK>, c->sm_factor)); MW_TRY(mw_set_lds((k_mw_linvb<KK, DD>), c->sm_factor)); MW_TRY(mw_set_lds(k_mw_potrf_q<KK>, c->sm_q));
+        MW_TRY(mw_set_lds(k_mw_factor<KK>, c->sm_factor)); MW_TRY(mw_set_lds(k_mw_potrf_q<KK>, c->sm_q));
         MW_TRY(mw_set_lds(k_mw_solve_fwd<KK>, c->sm_fwd)); MW_TRY(mw_set_lds(k_mw_solve_mid<KK>, c->sm_mid)); MW_TRY(mw_set_lds(k_mw_solve_bwd<KK>, c->sm_bwd));
     });
     // ---- upload ----
@@ -413,10 +395,8 @@ extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int dev
     MW_TRY(mw_dmalloc(c, &q.GX, q.glen * K)); MW_TRY(mw_dmalloc(c, &q.GY, q.glen * K));
     MW_TRY(mw_dmalloc(c, &q.W, q.wlen * K)); MW_TRY(mw_dmalloc(c, &q.Sd, q.sdlen * K));
     MW_TRY(mw_dmalloc(c, &q.S, Slen * K)); MW_TRY(mw_dmalloc(c, &q.LB, xlen * (i64)N * K)); MW_TRY(mw_dmalloc(c, &q.Q, (i64)N * N * K));
-    MW_TRY(mw_dmalloc(c, &q.Sf, Slen * K)); MW_TRY(mw_dmalloc(c, &q.Sb, Slen * K));
     MW_TRY(mw_dmalloc(c, &q.Si, Slen * K)); MW_TRY(mw_dmalloc(c, &q.Qi, (i64)N * N * K));
-    q.qinv = c->qinv ? 1 : 0;
-    MW_TRY(mw_dmalloc(c, &q.Qf, (i64)N * N * K)); MW_TRY(mw_dmalloc(c, &q.Qb, (i64)N * N * K));
+
     MW_TRY(mw_dmalloc(c, &q.Xf, xyoff * K)); MW_TRY(mw_dmalloc(c, &q.Xb, xyoff * K)); MW_TRY(mw_dmalloc(c, &q.Xi, xyoff * K));
     MW_TRY(mw_dmalloc(c, &q.xrd, rdoff * K)); MW_TRY(mw_dmalloc(c, &q.srd, xlen * K)); MW_TRY(mw_dmalloc(c, &q.qrd, (i64)N * K));
     MW_TRY(mw_dmalloc(c, &q.t, xlen * K)); MW_TRY(mw_dmalloc(c, &q.u, (i64)J * N * K)); MW_TRY(mw_dmalloc(c, &q.AY, T * K));
@@ -431,10 +411,10 @@ extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int dev
         int init[2] = {MW_INFO_NONE, MW_INFO_NONE};
         MWCHECK(hipMemcpy(info, init, sizeof(init), hipMemcpyHostToDevice));
     }
-    MW_TRY(mw_dmalloc(c, &c->d_bpFd, (i64)MW_PB * MW_PB * K));
-    c->sm_bp_diag = ((size_t)MW_POTRF_SCR(K, MW_PB) + (size_t)K * MW_PB * MW_PB + (size_t)K * MW_PB) * 8;
-    c->sm_bp_panel = ((size_t)K * MW_PB * MW_PB + (size_t)K * MW_PB * 32 + (size_t)K * MW_PB) * 8;
-    MW_DISPATCH(c, { MW_TRY(mw_set_lds(k_mw_bp_diag<KK>, c->sm_bp_diag)); MW_TRY(mw_set_lds(k_mw_bp_panel<KK>, c->sm_bp_panel)); });
+    c->sm_bp_diag = ((size_t)MW_POTRF_SCR(K, MW_PB) + 2 * (size_t)K * MW_PB * MW_PB + (size_t)K * MW_PB) * 8;
+    c->sm_bp_panel = (size_t)K * MW_BP_PR * MW_PB * 8;
+    c->sm_bp_inv = (size_t)K * MW_PB * MW_BP_IC * 8;
+    MW_DISPATCH(c, { MW_TRY(mw_set_lds(k_mw_bp_diag<KK>, c->sm_bp_diag)); MW_TRY(mw_set_lds(k_mw_bp_panel<KK>, c->sm_bp_panel)); MW_TRY(mw_set_lds(k_mw_bp_inv<KK>, c->sm_bp_inv)); });
     q.rank = 0; q.world = 1; q.gathered = 0;
     MW_TRY(mw_dmalloc(c, &q.Qg, (i64)N * N * K)); MW_TRY(mw_dmalloc(c, &q.ug, (i64)N * K));
     for (auto &e : c->ev) MWCHECK(hipEventCreate(&e));
@@ -597,18 +577,21 @@ extern "C" int clrs_mw_comm_destroy(clrs_mw_ctx *c) {
 extern "C" double *clrs_mw_q_gather_dev(clrs_mw_ctx *c) { return c ? c->d.Qg : nullptr; }
 extern "C" double *clrs_mw_u_gather_dev(clrs_mw_ctx *c) { return c ? c->d.ug : nullptr; }
 
-// blocked Cholesky of one matrix in global memory over many workgroups (clrs_mw_kernels.hip.h, k_mw_bp_*)
+// blocked Cholesky and inverse factor of one matrix in global memory over many workgroups (clrs_mw_kernels.hip.h, k_mw_bp_*)
 static int mw_potrf_blocked(clrs_mw_ctx *c, const MwBp &m) {
     const MwDev &q = c->d;
+    const int nbk = (m.n + MW_PB - 1) / MW_PB;
     MW_DISPATCH(c, {
         for (int j0 = 0; j0 < m.n; j0 += MW_PB) {
             const int nb = std::min(MW_PB, m.n - j0), mm = m.n - j0 - nb;
-            hipLaunchKernelGGL(k_mw_bp_diag<KK>, dim3(1), dim3(MW_NT), c->sm_bp_diag, c->stream, q, m, j0);
+            hipLaunchKernelGGL(k_mw_bp_diag<KK>, dim3(1), dim3(MW_PT), c->sm_bp_diag, c->stream, q, m, j0);
             if (mm > 0) {
-                hipLaunchKernelGGL(k_mw_bp_panel<KK>, dim3((mm + 31) / 32), dim3(MW_NT), c->sm_bp_panel, c->stream, q, m, j0);
+                hipLaunchKernelGGL(k_mw_bp_panel<KK>, dim3((mm + MW_BP_PR - 1) / MW_BP_PR), dim3(MW_PT), c->sm_bp_panel, c->stream, q, m, j0);
                 hipLaunchKernelGGL(k_mw_bp_syrk<KK>, dim3((unsigned)(((i64)mm * (mm + 1) / 2 + MW_NT - 1) / MW_NT)), dim3(MW_NT), 0, c->stream, q, m, j0);
             }
         }
+        for (int d = 1; d < nbk; d++)
+            hipLaunchKernelGGL(k_mw_bp_inv<KK>, dim3(nbk - d, MW_PB / MW_BP_IC), dim3(MW_PT), c->sm_bp_inv, c->stream, q, m, d);
         hipLaunchKernelGGL(k_mw_bp_finish<KK>, dim3((unsigned)std::min<i64>(1024, ((i64)m.n * m.n + MW_NT - 1) / MW_NT)), dim3(MW_NT), 0, c->stream, q, m);
     });
     MWCHECK(hipGetLastError());
@@ -628,13 +611,12 @@ extern "C" int clrs_mw_schur_factor_local_dev(clrs_mw_ctx *c) {
     for (int j = 0; j < q.J; j++) {                     // clusters that do not fit in LDS: blocked over many workgroups
         const MwClu &cl = c->clu[j];
         if (cl.lds) continue;
-        MwBp m = {q.S + cl.Soff, q.srd + cl.coff, q.Sf + cl.Soff, q.Sb + cl.Soff, c->d_bpFd, q.Slen, q.xlen, q.Slen, cl.P, cl.P, j + 1, 0};
+        MwBp m = {q.S + cl.Soff, q.Si + cl.Soff, q.srd + cl.coff, q.Slen, q.xlen, cl.P, cl.P, j + 1, 0};
         if ((rc = mw_potrf_blocked(c, m))) return rc;
     }
     MW_DISPATCH(c, {
-        if (q.N > 0 && c->any_sub) hipLaunchKernelGGL((k_mw_linvb<KK, DD>), dim3((q.N + MW_BT - 1) / MW_BT, q.J), dim3(MW_NT), c->sm_factor, c->stream, q);
-        if (q.N > 0 && c->any_inv)
-            hipLaunchKernelGGL((k_mw_linvb_inv<KK, DD>), dim3((c->maxP_inv * q.N + MW_NT / MW_LBI_W - 1) / (MW_NT / MW_LBI_W), q.J), dim3(MW_NT), 0, c->stream, q);
+        if (q.N > 0)
+            hipLaunchKernelGGL((k_mw_linvb<KK, DD>), dim3((c->maxP * q.N + MW_NT / MW_LBI_W - 1) / (MW_NT / MW_LBI_W), q.J), dim3(MW_NT), 0, c->stream, q);
         if (c->timing) (void)hipEventRecord(c->ev[3], c->stream);
         if (q.N > 0) hipLaunchKernelGGL(k_mw_qgram<KK>, dim3((q.N * (q.N + 1) / 2 + MW_NT / MW_Q_W - 1) / (MW_NT / MW_Q_W)), dim3(MW_NT), 0, c->stream, q);
         if (c->timing) (void)hipEventRecord(c->ev[4], c->stream);
@@ -651,10 +633,10 @@ extern "C" int clrs_mw_schur_factor_finish_dev(clrs_mw_ctx *c) {
     MWCHECK(hipSetDevice(c->device));
     const MwDev &q = c->d;
     if (q.N > 0 && c->lds_q) {
-        MW_DISPATCH(c, { hipLaunchKernelGGL(k_mw_potrf_q<KK>, dim3(1), dim3(MW_PT), c->sm_q, c->stream, q, 1); });
+        MW_DISPATCH(c, { hipLaunchKernelGGL(k_mw_potrf_q<KK>, dim3(1), dim3(MW_PT), c->sm_q, c->stream, q); });
     } else if (q.N > 0) {
         MW_DISPATCH(c, { hipLaunchKernelGGL(k_mw_qsum<KK>, dim3((unsigned)std::min<i64>(256, ((i64)q.N * q.N + MW_NT - 1) / MW_NT)), dim3(MW_NT), 0, c->stream, q); });
-        MwBp m = {q.Q, q.qrd, q.Qf, q.Qb, c->d_bpFd, (i64)q.N * q.N, (i64)q.N, (i64)q.N * q.N, q.N, q.N, q.J + 1, 0};
+        MwBp m = {q.Q, q.Qi, q.qrd, (i64)q.N * q.N, (i64)q.N, q.N, q.N, q.J + 1, 0};
         int rc = mw_potrf_blocked(c, m);
         if (rc) return rc;
     }
@@ -703,7 +685,7 @@ extern "C" int clrs_mw_schur_solve_bwd_dev(clrs_mw_ctx *c, const double *d_rhs_y
     if (q.N > 0 && (!d_rhs_y || !d_dy)) return mw_fail(CLRS_ERR_INVALID, "null argument");
     MWCHECK(hipSetDevice(c->device));
     MW_DISPATCH(c, {
-        if (q.N > 0) hipLaunchKernelGGL(k_mw_solve_mid<KK>, dim3(1), dim3(MW_NT), c->sm_mid, c->stream, q, d_rhs_y, d_dy, c->lds_q ? 1 : 0);
+        if (q.N > 0) hipLaunchKernelGGL(k_mw_solve_mid<KK>, dim3(1), dim3(MW_NT), c->sm_mid, c->stream, q, d_rhs_y, d_dy);
         hipLaunchKernelGGL(k_mw_solve_bwd<KK>, dim3(q.J), dim3(MW_NT), c->sm_bwd, c->stream, q, (const double *)d_dy, d_dx);
     });
     MWCHECK(hipGetLastError());

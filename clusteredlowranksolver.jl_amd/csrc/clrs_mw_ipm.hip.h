@@ -278,7 +278,7 @@ __global__ void k_mwi_scalar(const MwDev q, const MwIpmDev p, int stage, int ite
 // ---- block dot products: partial sums per PSD block ------------------------------------------------------------------
 // sel bit 0: <X,Y>; bit 1: <X,dY>, <dX,Y>, <dX,dY>; bit 2: <C,Y>
 template <int K, int DK>
-__global__ __launch_bounds__(MW_NT) void k_mwi_dots(const MwDev q, const MwIpmDev p, int sel, int stage, int iter) {
+__global__ __launch_bounds__(MW_NT) void k_mwi_dots(const MwDev q, const MwIpmDev p, int sel) {
     using namespace mwk;
     const MwBlk &k = q.blk[blockIdx.x];
     const int tid = threadIdx.x;
@@ -305,7 +305,6 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_dots(const MwDev q, const MwIpmDe
         r = wg_reduce_sum<K>(acc_result<K>(a3), red, tid); if (tid == 0) stx<K>(p.part, 5L * q.NB, 3L * q.NB + blockIdx.x, r);
     }
     if (sel & 4) { mw<K> r = wg_reduce_sum<K>(acc_result<K>(a4), red, tid); if (tid == 0) stx<K>(p.part, 5L * q.NB, 4L * q.NB + blockIdx.x, r); }
-    if (stage >= 0 && mwi_last_block(&p.flags[4], gridDim.x) && tid < 64) mwi_scalar_stage<K, DK>(q, p, stage, iter);
 }
 
 
@@ -892,7 +891,7 @@ static int mw_ipm_objectives(clrs_mw_ctx *c) {
     const MwDev &q = c->d;
     const MwIpmDev &p = c->ipm->d;
     MW_DISPATCH(c, {
-        hipLaunchKernelGGL((k_mwi_dots<KK, DD>), dim3(q.NB), dim3(MW_NT), (size_t)KK * 8 * 8, c->stream, q, p, 4, -1, c->ipm->iter);
+        hipLaunchKernelGGL((k_mwi_dots<KK, DD>), dim3(q.NB), dim3(MW_NT), (size_t)KK * 8 * 8, c->stream, q, p, 4);
         hipLaunchKernelGGL((k_mwi_scalar<KK, DD>), dim3(1), dim3(64), 0, c->stream, q, p, 4, c->ipm->iter);
     });
     MWCHECK(hipGetLastError());
@@ -972,8 +971,8 @@ extern "C" int clrs_mw_ipm_iterate(clrs_mw_ctx *c, clrs_ipm_record *out) {
     int rc;
     st->iter++;
     MW_DISPATCH(c, {
-        hipLaunchKernelGGL((k_mwi_dots<KK, DD>), dim3(q.NB), dim3(MW_NT), sm_red, c->stream, q, p, 1, -1, st->iter);
-        hipLaunchKernelGGL((k_mwi_scalar<KK, DD>), dim3(1), dim3(64), 0, c->stream, q, p, 0, st->iter);
+        hipLaunchKernelGGL((k_mwi_dots<KK, DD>), dim3(q.NB), dim3(MW_NT), sm_red, c->stream, q, p, 1);
+        hipLaunchKernelGGL((k_mwi_scalar<KK, DD>), dim3(1), dim3(1), 0, c->stream, q, p, 0, st->iter);
     });
     if ((rc = mw_cholesky_blocks_dev2(c, p.X, p.Xc, st->y_with_x ? p.Y : nullptr, p.Yi, p.yfail))) return rc;
     if ((rc = clrs_mw_schur_assemble_dev(c, p.Xc, p.Y))) return rc;
@@ -988,8 +987,8 @@ extern "C" int clrs_mw_ipm_iterate(clrs_mw_ctx *c, clrs_ipm_record *out) {
     MWCHECK(hipGetLastError());
     if ((rc = mw_ipm_direction(c, 0))) return rc;
     MW_DISPATCH(c, {
-        hipLaunchKernelGGL((k_mwi_dots<KK, DD>), dim3(q.NB), dim3(MW_NT), sm_red, c->stream, q, p, 2, -1, st->iter);
-        hipLaunchKernelGGL((k_mwi_scalar<KK, DD>), dim3(1), dim3(64), 0, c->stream, q, p, 2, st->iter);
+        hipLaunchKernelGGL((k_mwi_dots<KK, DD>), dim3(q.NB), dim3(MW_NT), sm_red, c->stream, q, p, 2);
+        hipLaunchKernelGGL((k_mwi_scalar<KK, DD>), dim3(1), dim3(1), 0, c->stream, q, p, 2, st->iter);
     });
     if ((rc = mw_ipm_direction(c, 1))) return rc;
     MW_DISPATCH(c, {

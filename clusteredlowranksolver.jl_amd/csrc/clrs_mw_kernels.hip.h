@@ -46,9 +46,8 @@ struct MwBlk {               // one PSD block (j, l)
     int m, pad2;
 };
 struct MwClu {               // one cluster j
-    int P, b0, b1, lds;      // constraints; block range; 1 = S_j (and B_j) fit in LDS
+    int P, b0, b1, lds;      // constraints; block range; 1 = S_j and the inverse of its factor fit in LDS side by side (k_mw_factor), 0 = blocked path
     mwi64 coff, Soff;
-    int inv, pad;            // 1 = S_j and the inverse of its factor fit in LDS together: L_j^-1 is formed (Si), the solves are products
 };
 struct MwDev {
     int J, N, NB, nlr, ndn, pad0;
@@ -70,12 +69,10 @@ struct MwDev {
     double *Z, *Tm, *GX, *GY, *W, *Sd;  // scratch, planar
     mwi64 zlen, glen, wlen, sdlen;
     double *S, *LB, *Q, *Qs;            // S layout; stacked L^-1 B (xlen x N); Q (N x N); (unused)
-    double *Sf, *Sb, *Qf, *Qb;          // row- / column-scaled strict lower triangles of L_j and L_Q (unit-diagonal substitutions)
-    double *Xf, *Xb;                    // the same for the Cholesky factors of the X blocks (xy layout)
+    double *Xf, *Xb;                    // row- / column-scaled strict triangles of the Cholesky factors of the X blocks (xy layout; unit-diagonal substitutions)
     double *xrd, *srd, *qrd;            // reciprocal diagonals of chol(X_b), L_j, L_Q
-    double *Si, *Qi;                    // explicit inverses L_j^-1 (S layout, clusters with inv = 1) and L_Q^-1 (qinv = 1), lower triangular
+    double *Si, *Qi;                    // explicit inverses L_j^-1 (S layout) and L_Q^-1, lower triangular: every triangular solve with them is a product
     double *Xi;                         // chol(X_b)^-1 of the blocks with inv = 1 (xy layout)
-    int qinv, pad4;
     double *t, *u, *AY;                 // t = L^-1 rhs_x (xlen); u slabs (J x N); pairings per term
     int *info;                          // [0] factor status, [1] Cholesky-of-X status
     // cluster sharding over ranks (one process per GPU): this context holds the clusters of rank `rank`; the partial Q and the
@@ -344,36 +341,6 @@ __device__ __forceinline__ void wg_trsm_b(PF Bk, long fplane, int ldf, PR rd, lo
         }
         __syncthreads();
     }
-}
-
-// ---- substitutions with ONE right-hand side and n <= 64 unknowns: one wave, the vector in registers (lane i holds b_i, already
-// divided by L_ii), the finished unknown broadcast with v_readlane, the factor column read from LDS: no barrier, no LDS write, one
-// multiply-add on the dependent chain per unknown.
-__device__ __forceinline__ double readlane_d(double v, int k) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_readlane(lo, k);
-    hi = __builtin_amdgcn_readlane(hi, k);
-    return __hiloint2double(hi, lo);
-}
-template <int K, class PF>
-__device__ __forceinline__ mw<K> wave_trsv_f(PF F, long fplane, int ldf, int n, mw<K> b, int lane) {
-    for (int k = 0; k < n - 1; k++) {
-        mw<K> xk;
-#pragma unroll
-        for (int l = 0; l < K; l++) xk.l[l] = readlane_d(b.l[l], k);
-        if (lane > k && lane < n) b = fnma<K>(b, ldx<K>(F, fplane, lane + (long)k * ldf), xk);
-    }
-    return b;
-}
-template <int K, class PF>
-__device__ __forceinline__ mw<K> wave_trsv_b(PF Bk, long fplane, int ldf, int n, mw<K> b, int lane) {
-    for (int k = n - 1; k > 0; k--) {
-        mw<K> xk;
-#pragma unroll
-        for (int l = 0; l < K; l++) xk.l[l] = readlane_d(b.l[l], k);
-        if (lane < k) b = fnma<K>(b, ldx<K>(Bk, fplane, lane + (long)k * ldf), xk);
-    }
-    return b;
 }
 
 // copy a rows x cols planar matrix between two arrays (any address spaces)
@@ -666,23 +633,22 @@ __global__ __launch_bounds__(MW_NT) void k_mw_saccum(const MwDev q) {
 // Factorisation of a cluster: L_j = chol(S_j) (in place in the S buffer), LinvB_j = L_j^-1 B_j; the scaled triangles of L_j
 // for the solve stage.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int K, bool INV, class PM, class PW>
+template <int K, class PM, class PW>
 __device__ __forceinline__ bool mw_factor_body(const MwDev &q, const MwClu &c, int j, PM M, long mplane, PW W, mwk::lds_d *bc, int tid) {
     using namespace mwk;
     const int P = c.P;
-    const bool ok = wg_potrf<K, INV, MW_PT>(M, mplane, P, P, q.srd + c.coff, q.xlen, W, mplane, P, bc, tid);
+    const bool ok = wg_potrf<K, true, MW_PT>(M, mplane, P, P, q.srd + c.coff, q.xlen, W, mplane, P, bc, tid);
     if (!ok) {
         if (tid == 0) atomicMin(&q.info[0], j + 1);
         return false;
     }
     double *Sg = q.S + c.Soff;
-    if (!INV) wg_scaled_factors_u<K, MW_PT>(M, mplane, P, q.srd + c.coff, q.xlen, P, q.Sf + c.Soff, q.Slen, P, q.Sb + c.Soff, q.Slen, P, tid);
-    for (int e = tid; e < P * P; e += MW_PT) {            // L_j back to the S buffer with a zero strict upper triangle
+    for (int e = tid; e < P * P; e += MW_PT) {            // L_j back to the S buffer with a zero strict upper triangle; L_j^-1 beside it
         const int i = e % P, cc = e / P;
 #pragma unroll
         for (int l = 0; l < K; l++) {
             Sg[(long)l * q.Slen + e] = (i >= cc) ? (double)M[(long)l * mplane + e] : 0.0;
-            if (INV) q.Si[(long)l * q.Slen + c.Soff + e] = (i >= cc) ? (double)W[(long)l * mplane + e] : 0.0;
+            q.Si[(long)l * q.Slen + c.Soff + e] = (i >= cc) ? (double)W[(long)l * mplane + e] : 0.0;
         }
     }
     return true;
@@ -698,57 +664,21 @@ __global__ __launch_bounds__(MW_PT) void k_mw_factor(const MwDev q) {
         lds_d *M = MW_LDS + MW_POTRF_SCR(K, P);
         wg_copy<K, MW_PT>(M, (long)P * P, P, q.S + c.Soff, q.Slen, P, P, P, tid);
         __syncthreads();
-        if (c.inv) mw_factor_body<K, true>(q, c, j, M, (long)P * P, M + (long)K * P * P, bc, tid);
-        else mw_factor_body<K, false>(q, c, j, M, (long)P * P, M, bc, tid);
+        mw_factor_body<K>(q, c, j, M, (long)P * P, M + (long)K * P * P, bc, tid);
     }
     // clusters too large for LDS are factored by the blocked, multi-workgroup path (k_mw_bp_*, driven by the host)
 }
 
-// LinvB_j = L_j^-1 B_j (src/solver.jl:1256-1261): the columns of B_j are independent, one workgroup per tile of MW_BT of them
-#define MW_BT 8
-template <int K, int DK>
-__global__ __launch_bounds__(MW_NT) void k_mw_linvb(const MwDev q) {
-    using namespace mwk;
-    const int j = blockIdx.y, tid = threadIdx.x;
-    const MwClu &c = q.clu[j];
-    const int P = c.P, N = q.N;
-    const int a0 = blockIdx.x * MW_BT;
-    if (a0 >= N || c.inv) return;                                        // clusters with an explicit inverse: k_mw_linvb_inv
-    if (q.info[0] != MW_INFO_NONE && q.info[0] <= j + 1) return;        // this cluster (or an earlier one) failed
-    const int nc = min(MW_BT, N - a0);
-    lds_d *Bt = MW_LDS;                                   // P x MW_BT tile
-    const long bp = (long)P * MW_BT;
-    for (int e = tid; e < P * nc; e += MW_NT) {            // B_j (DK limbs) -> multi-word
-        const int i = e % P, cc = e / P;
-#pragma unroll
-        for (int l = 0; l < K; l++) Bt[(long)l * bp + e] = l < DK ? q.B[(long)l * q.Bp + c.coff + i + (long)(a0 + cc) * q.xlen] : 0.0;
-    }
-    if (c.lds) {
-        lds_d *F = MW_LDS + (long)K * bp;
-        wg_copy<K>(F, (long)P * P, P, q.Sf + c.Soff, q.Slen, P, P, P, tid);
-        __syncthreads();
-        wg_trsm_f<K>(F, (long)P * P, P, q.srd + c.coff, q.xlen, P, Bt, bp, P, nc, tid);
-    } else {
-        __syncthreads();
-        wg_trsm_f<K>(q.Sf + c.Soff, q.Slen, P, q.srd + c.coff, q.xlen, P, Bt, bp, P, nc, tid);
-    }
-    for (int e = tid; e < P * nc; e += MW_NT) {
-        const int i = e % P, cc = e / P;
-#pragma unroll
-        for (int l = 0; l < K; l++) q.LB[(long)l * q.xlen * N + c.coff + i + (long)(a0 + cc) * q.xlen] = Bt[(long)l * bp + e];
-    }
-}
-
-// The same product for the clusters whose L_j^-1 is explicit: LinvB_j = Si_j B_j, four lanes per entry
+// LinvB_j = L_j^-1 B_j (src/solver.jl:1256-1261) = Si_j B_j: a product with the explicit inverse, four lanes per entry
 #define MW_LBI_W 4
 template <int K, int DK>
-__global__ __launch_bounds__(MW_NT) void k_mw_linvb_inv(const MwDev q) {
+__global__ __launch_bounds__(MW_NT) void k_mw_linvb(const MwDev q) {
     using namespace mwk;
     const int j = blockIdx.y;
     const MwClu &c = q.clu[j];
     const int P = c.P, N = q.N;
-    if (!c.inv || blockIdx.x * (MW_NT / MW_LBI_W) >= P * N) return;
-    if (q.info[0] != MW_INFO_NONE && q.info[0] <= j + 1) return;
+    if (blockIdx.x * (MW_NT / MW_LBI_W) >= P * N) return;
+    if (q.info[0] != MW_INFO_NONE && q.info[0] <= j + 1) return;        // this cluster (or an earlier one) failed
     const int e = blockIdx.x * (MW_NT / MW_LBI_W) + threadIdx.x / MW_LBI_W, sub = threadIdx.x % MW_LBI_W;
     const bool live = e < P * N;
     const int ee = live ? e : 0, i = ee % P, a = ee / P;
@@ -784,45 +714,40 @@ __global__ __launch_bounds__(MW_NT) void k_mw_qgram(const MwDev q) {
 }
 
 // Cholesky of Q (src/solver.jl:1274) and its scaled triangles
-template <int K, bool INV, class PM, class PW>
+template <int K, class PM, class PW>
 __device__ __forceinline__ void mw_potrf_q_body(const MwDev &q, PM M, long plane, PW W, mwk::lds_d *bc, int tid) {
     using namespace mwk;
     const int N = q.N;
-    const bool ok = wg_potrf<K, INV, MW_PT>(M, plane, N, N, q.qrd, N, W, plane, N, bc, tid);
+    const bool ok = wg_potrf<K, true, MW_PT>(M, plane, N, N, q.qrd, N, W, plane, N, bc, tid);
     if (!ok) {
         if (tid == 0) atomicMin(&q.info[0], q.J + 1);
         return;
     }
-    if (!INV) wg_scaled_factors_u<K, MW_PT>(M, plane, N, q.qrd, N, N, q.Qf, (long)N * N, N, q.Qb, (long)N * N, N, tid);
-    __syncthreads();
     for (int e = tid; e < N * N; e += MW_PT) {
         const int i = e % N, cc = e / N;
 #pragma unroll
         for (int l = 0; l < K; l++) {
             q.Q[(long)l * N * N + e] = (i >= cc) ? (double)M[(long)l * plane + e] : 0.0;
-            if (INV) q.Qi[(long)l * N * N + e] = (i >= cc) ? (double)W[(long)l * plane + e] : 0.0;
+            q.Qi[(long)l * N * N + e] = (i >= cc) ? (double)W[(long)l * plane + e] : 0.0;
         }
     }
 }
 template <int K>
-__global__ __launch_bounds__(MW_PT) void k_mw_potrf_q(const MwDev q, int lds) {
+__global__ __launch_bounds__(MW_PT) void k_mw_potrf_q(const MwDev q) {
     using namespace mwk;
     const int N = q.N, tid = threadIdx.x;
     if (q.info[0] != MW_INFO_NONE) return;           // a cluster failed: the reference throws before reaching Q
     lds_d *bc = MW_LDS;
     const long nn = (long)N * N;
-    if (lds) {
-        lds_d *M = MW_LDS + MW_POTRF_SCR(K, N);
-        for (int e = tid; e < nn; e += MW_PT) {            // Q = sum over the ranks' partial sums, in rank order on every rank
-            acc<K> s;
-            acc_zero<K>(s);
-            for (int r = 0; r < q.world; r++) acc_add<K, K>(s, ldx<K>(q.Qg + (long)r * K * nn, nn, e));
-            stx<K>(M, nn, e, acc_result<K>(s));
-        }
-        __syncthreads();
-        if (q.qinv) mw_potrf_q_body<K, true>(q, M, nn, M + (long)K * nn, bc, tid);
-        else mw_potrf_q_body<K, false>(q, M, nn, M, bc, tid);
+    lds_d *M = MW_LDS + MW_POTRF_SCR(K, N);
+    for (int e = tid; e < nn; e += MW_PT) {                // Q = sum over the ranks' partial sums, in rank order on every rank
+        acc<K> s;
+        acc_zero<K>(s);
+        for (int r = 0; r < q.world; r++) acc_add<K, K>(s, ldx<K>(q.Qg + (long)r * K * nn, nn, e));
+        stx<K>(M, nn, e, acc_result<K>(s));
     }
+    __syncthreads();
+    mw_potrf_q_body<K>(q, M, nn, M + (long)K * nn, bc, tid);
     // a Q too large for LDS: k_mw_qsum + the blocked path (k_mw_bp_*)
 }
 
@@ -840,60 +765,72 @@ __global__ __launch_bounds__(MW_NT) void k_mw_qsum(const MwDev q) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Blocked Cholesky of a matrix that does not fit in LDS (clusters with P > ~60 at 5 limbs, Q with N > ~60), in place in
-// global memory, panel width MW_PB: per block column the diagonal block is factored by one workgroup in LDS (wg_potrf), the
-// panel below it is solved by one workgroup per 32 rows (the rows are independent), the trailing matrix is updated by
-// one thread per entry of its lower triangle (MW_PB-term dot products through the unnormalised accumulator) over as many
-// workgroups as it has entries / 256.  What a single workgroup spent on the rank-1 updates of a 256 x 256 matrix
-// (P^3/6 multiply-adds behind global-memory latency) is spread over the chip.
+// Blocked Cholesky AND inverse factor of a matrix that does not fit twice in LDS (clusters with P > 44 at 5 limbs, Q with
+// N > 44), in place in global memory, panel width MW_PB, over many workgroups:
+//   k_mw_bp_diag   the diagonal block and its inverse by one workgroup in LDS (wg_potrf with the [M | I] elimination);
+//   k_mw_bp_panel  the rows below it, L_panel = A_panel M_d^T: a product with the inverse of the diagonal block, eight rows
+//                  per workgroup, two lanes per entry (the rows are independent);
+//   k_mw_bp_syrk   the trailing matrix, one thread per entry of its lower triangle (MW_PB-term accumulator dot products);
+//   k_mw_bp_inv    after the last block column: the off-diagonal blocks of L^-1 by block distance d = 1, 2, ...:
+//                  (L^-1)_ji = -(L^-1)_jj sum_{i <= k < j} L_jk (L^-1)_ki, independent column by column: one workgroup
+//                  per pair (j, i) and panel of four columns, four lanes per entry;
+//   k_mw_bp_finish zero strict upper triangle of L.
+// With L^-1 explicit, LinvB and every solve of a large cluster are products over many lanes, like those of a small one.
 // ---------------------------------------------------------------------------------------------------------------------
 #define MW_PB 32
-struct MwBp {                // one matrix being factored: planar M (leading dimension ld), reciprocal diagonal rd, scaled copies F, Bk
-    double *M, *rd, *F, *Bk, *Fd;      // Fd: scratch nb x nb, the row-scaled diagonal block of the current block column
-    mwi64 plane, rdplane, fplane;
+#define MW_BP_PR 8           // rows of the panel per workgroup
+#define MW_BP_IC 4           // columns of an inverse block per workgroup
+struct MwBp {                // one matrix being factored: planar M and its inverse factor Mi (same plane length and leading dimension), reciprocal diagonal rd
+    double *M, *Mi, *rd;
+    mwi64 plane, rdplane;
     int n, ld, code, which;            // info[which] = code on failure
 };
 template <int K>
-__global__ __launch_bounds__(MW_NT) void k_mw_bp_diag(const MwDev q, const MwBp m, int j0) {
+__global__ __launch_bounds__(MW_PT) void k_mw_bp_diag(const MwDev q, const MwBp m, int j0) {
     using namespace mwk;
     if (q.info[m.which] != MW_INFO_NONE) return;
     const int nb = min(MW_PB, m.n - j0), tid = threadIdx.x;
-    lds_d *bc = MW_LDS, *D = MW_LDS + MW_POTRF_SCR(K, MW_PB), *rdl = D + (long)K * MW_PB * MW_PB;
-    wg_copy<K>(D, (long)nb * nb, nb, m.M + j0 + (long)j0 * m.ld, m.plane, m.ld, nb, nb, tid);
+    lds_d *scr = MW_LDS, *D = MW_LDS + MW_POTRF_SCR(K, MW_PB), *W = D + (long)K * MW_PB * MW_PB, *rdl = W + (long)K * MW_PB * MW_PB;
+    wg_copy<K, MW_PT>(D, (long)nb * nb, nb, m.M + j0 + (long)j0 * m.ld, m.plane, m.ld, nb, nb, tid);
     __syncthreads();
-    if (!wg_potrf<K, false>(D, (long)nb * nb, nb, nb, rdl, nb, D, 0, 0, bc, tid)) {
+    if (!wg_potrf<K, true, MW_PT>(D, (long)nb * nb, nb, nb, rdl, nb, W, (long)nb * nb, nb, scr, tid)) {
         if (tid == 0) atomicMin(&q.info[m.which], m.code);
         return;
     }
-    for (int e = tid; e < nb * nb; e += MW_NT) {
+    for (int e = tid; e < nb * nb; e += MW_PT) {
         const int i = e % nb, c = e / nb;
-        mw<K> v = ldx<K>(D, (long)nb * nb, e);
-        stx<K>(m.M, m.plane, (j0 + i) + (long)(j0 + c) * m.ld, i >= c ? v : zero<K>());
-        stx<K>(m.Fd, (long)MW_PB * MW_PB, i + (long)c * MW_PB, i > c ? mul<K>(v, ldx<K>(rdl, nb, i)) : zero<K>());
+        const long g = (j0 + i) + (long)(j0 + c) * m.ld;
+        stx<K>(m.M, m.plane, g, i >= c ? ldx<K>(D, (long)nb * nb, e) : zero<K>());
+        stx<K>(m.Mi, m.plane, g, i >= c ? ldx<K>(W, (long)nb * nb, e) : zero<K>());
     }
-    for (int i = tid; i < nb; i += MW_NT) stx<K>(m.rd, m.rdplane, j0 + i, ldx<K>(rdl, nb, i));
+    for (int i = tid; i < nb; i += MW_PT) stx<K>(m.rd, m.rdplane, j0 + i, ldx<K>(rdl, nb, i));
 }
-// rows below the diagonal block: X L_d^T = A_panel, 32 rows per workgroup
+// rows below the diagonal block: L[r, c] = sum_{k <= c} A[r, k] M_d[c, k]
 template <int K>
-__global__ __launch_bounds__(MW_NT) void k_mw_bp_panel(const MwDev q, const MwBp m, int j0) {
+__global__ __launch_bounds__(MW_PT) void k_mw_bp_panel(const MwDev q, const MwBp m, int j0) {
     using namespace mwk;
     if (q.info[m.which] != MW_INFO_NONE) return;
     const int nb = min(MW_PB, m.n - j0), tid = threadIdx.x;
-    const int r0 = j0 + nb + blockIdx.x * 32;
+    const int r0 = j0 + nb + blockIdx.x * MW_BP_PR;
     if (r0 >= m.n) return;
-    const int nr = min(32, m.n - r0);
-    lds_d *Fd = MW_LDS, *Bt = Fd + (long)K * MW_PB * MW_PB, *rdl = Bt + (long)K * MW_PB * 32;   // Bt: nb x nr, the tile transposed
-    wg_copy<K>(Fd, (long)MW_PB * MW_PB, MW_PB, m.Fd, (long)MW_PB * MW_PB, MW_PB, nb, nb, tid);
-    for (int i = tid; i < nb; i += MW_NT) stx<K>(rdl, nb, i, ldx<K>(m.rd, m.rdplane, j0 + i));
-    for (int e = tid; e < nb * nr; e += MW_NT) {
-        const int kcol = e % nb, r = e / nb;
-        stx<K>(Bt, (long)MW_PB * 32, kcol + (long)r * MW_PB, ldx<K>(m.M, m.plane, (r0 + r) + (long)(j0 + kcol) * m.ld));
+    const int nr = min(MW_BP_PR, m.n - r0);
+    lds_d *At = MW_LDS;                                     // the MW_BP_PR x nb tile of A, read before any of it is overwritten
+    const long ap = (long)MW_BP_PR * MW_PB;
+    for (int e = tid; e < MW_BP_PR * nb; e += MW_PT) {
+        const int r = e % MW_BP_PR, c = e / MW_BP_PR;
+        if (r < nr) stx<K>(At, ap, e, ldx<K>(m.M, m.plane, (r0 + r) + (long)(j0 + c) * m.ld));
     }
     __syncthreads();
-    wg_trsm_f<K>(Fd, (long)MW_PB * MW_PB, MW_PB, rdl, nb, nb, Bt, (long)MW_PB * 32, MW_PB, nr, tid);
-    for (int e = tid; e < nb * nr; e += MW_NT) {
-        const int kcol = e % nb, r = e / nb;
-        stx<K>(m.M, m.plane, (r0 + r) + (long)(j0 + kcol) * m.ld, ldx<K>(Bt, (long)MW_PB * 32, kcol + (long)r * MW_PB));
+    const int sub = tid & 1;
+    for (int e0 = 0; e0 < MW_BP_PR * nb; e0 += MW_PT / 2) {
+        const int e = e0 + (tid >> 1);
+        const bool live = e < MW_BP_PR * nb && (e % MW_BP_PR) < nr;
+        const int ee = live ? e : 0, r = ee % MW_BP_PR, c = ee / MW_BP_PR;
+        acc<K> s;
+        acc_zero<K>(s);
+        for (int kk = sub; kk <= c; kk += 2) acc_fma<K, K, K>(s, ldx<K>(At, ap, r + (long)kk * MW_BP_PR), ldx<K>(m.Mi, m.plane, (j0 + c) + (long)(j0 + kk) * m.ld));
+        const mw<K> v = lanes_sum<K, 2>(acc_result<K>(s));
+        if (live && sub == 0) stx<K>(m.M, m.plane, (r0 + r) + (long)(j0 + c) * m.ld, v);
     }
 }
 // trailing update: A[i, j] -= sum_c L[i, j0 + c] L[j, j0 + c], i >= j >= j0 + nb
@@ -913,7 +850,41 @@ __global__ __launch_bounds__(MW_NT) void k_mw_bp_syrk(const MwDev q, const MwBp 
     for (int c = 0; c < nb; c++) acc_fma<K, K, K>(s, ldx<K>(m.M, m.plane, i + (long)(j0 + c) * m.ld), ldx<K>(m.M, m.plane, j + (long)(j0 + c) * m.ld), -1.0);
     stx<K>(m.M, m.plane, i + (long)j * m.ld, acc_result<K>(s));
 }
-// zero strict upper triangle and the scaled copies of the finished factor
+// blocks (j, i) of L^-1 with j - i = d: T = sum_{i <= k < j} L_jk (L^-1)_ki (the block columns between are contiguous: one
+// sum over the rows i MW_PB .. j MW_PB - 1), then (L^-1)_ji = -(L^-1)_jj T
+template <int K>
+__global__ __launch_bounds__(MW_PT) void k_mw_bp_inv(const MwDev q, const MwBp m, int d) {
+    using namespace mwk;
+    if (q.info[m.which] != MW_INFO_NONE) return;
+    const int bi = blockIdx.x, bj = bi + d, tid = threadIdx.x;
+    const int ci0 = bi * MW_PB, ni = min(MW_PB, m.n - ci0), rj0 = bj * MW_PB, nj = min(MW_PB, m.n - rj0);
+    const int c0 = blockIdx.y * MW_BP_IC;
+    if (c0 >= ni) return;
+    const int pc = min(MW_BP_IC, ni - c0);
+    lds_d *T = MW_LDS;
+    const long tp = (long)MW_PB * MW_BP_IC;
+    constexpr int LW = MW_PT / (MW_PB * MW_BP_IC);             // lanes per entry: 4
+    const int e = tid / LW, sub = tid % LW, r = e % MW_PB, cl = e / MW_PB;
+    const bool live = r < nj && cl < pc;
+    const int rr = live ? r : 0, col = ci0 + c0 + (live ? cl : 0);
+    {
+        acc<K> s;
+        acc_zero<K>(s);
+        for (int t = col + sub; t < rj0; t += LW)              // rows of (L^-1)[:, col] above its diagonal are zero
+            acc_fma<K, K, K>(s, ldx<K>(m.M, m.plane, (rj0 + rr) + (long)t * m.ld), ldx<K>(m.Mi, m.plane, t + (long)col * m.ld));
+        const mw<K> v = lanes_sum<K, LW>(acc_result<K>(s));
+        if (sub == 0) stx<K>(T, tp, e, live ? v : zero<K>());
+    }
+    __syncthreads();
+    {
+        acc<K> s;
+        acc_zero<K>(s);
+        for (int t = sub; t <= rr; t += LW) acc_fma<K, K, K>(s, ldx<K>(m.Mi, m.plane, (rj0 + rr) + (long)(rj0 + t) * m.ld), ldx<K>(T, tp, t + (long)(live ? cl : 0) * MW_PB), -1.0);
+        const mw<K> v = lanes_sum<K, LW>(acc_result<K>(s));
+        if (live && sub == 0) stx<K>(m.Mi, m.plane, (rj0 + r) + (long)col * m.ld, v);
+    }
+}
+// zero strict upper triangle of L (the blocks above the diagonal still hold the symmetric input)
 template <int K>
 __global__ __launch_bounds__(MW_NT) void k_mw_bp_finish(const MwDev q, const MwBp m) {
     using namespace mwk;
@@ -921,15 +892,7 @@ __global__ __launch_bounds__(MW_NT) void k_mw_bp_finish(const MwDev q, const MwB
     const long nn = (long)m.n * m.n;
     for (long e = (long)blockIdx.x * MW_NT + threadIdx.x; e < nn; e += (long)gridDim.x * MW_NT) {
         const int i = (int)(e % m.n), k = (int)(e / m.n);
-        if (i > k) {
-            const mw<K> l = ldx<K>(m.M, m.plane, i + (long)k * m.ld);
-            stx<K>(m.F, m.fplane, i + (long)k * m.ld, mul<K>(l, ldx<K>(m.rd, m.rdplane, i)));
-            stx<K>(m.Bk, m.fplane, k + (long)i * m.ld, mul<K>(l, ldx<K>(m.rd, m.rdplane, k)));
-        } else {
-            stx<K>(m.F, m.fplane, i + (long)k * m.ld, zero<K>());
-            if (i == k) stx<K>(m.Bk, m.fplane, i + (long)k * m.ld, zero<K>());
-            else stx<K>(m.M, m.plane, i + (long)k * m.ld, zero<K>());
-        }
+        if (i / MW_PB < k / MW_PB) stx<K>(m.M, m.plane, i + (long)k * m.ld, zero<K>());
     }
 }
 
@@ -948,8 +911,8 @@ __global__ __launch_bounds__(MW_NT) void k_mw_usum(const MwDev q) {
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Solve stage (src/solver.jl:1527-1582), three launches: per cluster t_j = L_j^-1 rhs_x[j], u_j = LinvB_j^T t_j;
-// dy = Q^-1 (rhs_y - sum_j u_j); per cluster dx_j = L_j^-T (t_j + LinvB_j dy).  Substitutions with the scaled factors
-// (one multiply-add and one barrier per unknown), dot products over eight lanes.
+// dy = Q^-1 (rhs_y - sum_j u_j); per cluster dx_j = L_j^-T (t_j + LinvB_j dy).  Every triangular solve is a product with
+// the explicit inverse factor (wg_trmv_n / _t), every dot product runs over eight lanes.
 // ---------------------------------------------------------------------------------------------------------------------
 #define MW_S_W 8
 // u_j = LinvB_j^T t_j (t in LDS, planar with plane P)
@@ -970,62 +933,31 @@ __device__ __forceinline__ void mw_solve_u(const MwDev &q, const MwClu &c, int j
         if (live && sub == 0) stx<K>(q.u, (long)q.J * N, (long)j * N + a, v);
     }
 }
-template <int K, class PF>
-__device__ __forceinline__ void mw_solve_fwd_body(const MwDev &q, const MwClu &c, int j, PF F, long fplane, mwk::lds_d *tv, int tid) {
-    using namespace mwk;
-    const int P = c.P;
-    if (P <= 64) {
-        if (tid < 64) {
-            mw<K> b = tid < P ? mul<K>(ldx<K>(tv, P, tid), ldx<K>(q.srd + c.coff, q.xlen, tid)) : zero<K>();
-            b = wave_trsv_f<K>(F, fplane, P, P, b, tid);
-            if (tid < P) stx<K>(tv, P, tid, b);
-        }
-        __syncthreads();
-    } else {
-        wg_trsm_f<K>(F, fplane, P, q.srd + c.coff, q.xlen, P, tv, P, P, 1, tid);
-    }
-    for (int i = tid; i < P; i += MW_NT) {
-#pragma unroll
-        for (int l = 0; l < K; l++) q.t[(long)l * q.xlen + c.coff + i] = tv[(long)l * P + i];
-    }
-    mw_solve_u<K>(q, c, j, tv, tid);
-}
 template <int K>
 __global__ __launch_bounds__(MW_NT) void k_mw_solve_fwd(const MwDev q, const double *__restrict__ rhs_x) {
     using namespace mwk;
     const int j = blockIdx.x, tid = threadIdx.x;
     const MwClu &c = q.clu[j];
     const int P = c.P;
-    lds_d *tv = MW_LDS;                       // t: P numbers, planar with plane P
+    lds_d *tv = MW_LDS, *t2 = tv + (long)K * P;            // rhs_j and t_j, planar with plane P
     for (int i = tid; i < P; i += MW_NT) {
 #pragma unroll
         for (int l = 0; l < K; l++) tv[(long)l * P + i] = rhs_x[(long)l * q.xlen + c.coff + i];
     }
-    if (c.inv) {                              // t_j = Si_j rhs_j: a product with the explicit inverse
-        lds_d *t2 = tv + (long)K * P;
-        __syncthreads();
-        wg_trmv_n<K>(q.Si + c.Soff, q.Slen, P, P, tv, P, t2, P, tid);
-        for (int i = tid; i < P; i += MW_NT) {
+    __syncthreads();
+    wg_trmv_n<K>(q.Si + c.Soff, q.Slen, P, P, tv, P, t2, P, tid);      // t_j = Si_j rhs_j
+    for (int i = tid; i < P; i += MW_NT) {
 #pragma unroll
-            for (int l = 0; l < K; l++) q.t[(long)l * q.xlen + c.coff + i] = t2[(long)l * P + i];
-        }
-        mw_solve_u<K>(q, c, j, t2, tid);
-    } else if (c.lds) {
-        lds_d *Ls = MW_LDS + (long)K * P;
-        wg_copy<K>(Ls, (long)P * P, P, q.Sf + c.Soff, q.Slen, P, P, P, tid);
-        __syncthreads();
-        mw_solve_fwd_body<K>(q, c, j, Ls, (long)P * P, tv, tid);
-    } else {
-        __syncthreads();
-        mw_solve_fwd_body<K>(q, c, j, q.Sf + c.Soff, q.Slen, tv, tid);
+        for (int l = 0; l < K; l++) q.t[(long)l * q.xlen + c.coff + i] = t2[(long)l * P + i];
     }
+    mw_solve_u<K>(q, c, j, t2, tid);
 }
 
 template <int K>
-__global__ __launch_bounds__(MW_NT) void k_mw_solve_mid(const MwDev q, const double *__restrict__ rhs_y, double *__restrict__ dy, int lds) {
+__global__ __launch_bounds__(MW_NT) void k_mw_solve_mid(const MwDev q, const double *__restrict__ rhs_y, double *__restrict__ dy) {
     using namespace mwk;
     const int N = q.N, tid = threadIdx.x;
-    lds_d *v = MW_LDS;                        // N numbers, plane N
+    lds_d *v = MW_LDS, *y = v + (long)K * N;  // N numbers each, plane N
     const long lplane = (long)N * N;
     for (int a = tid; a < N; a += MW_NT) {
         acc<K> s;
@@ -1038,34 +970,9 @@ __global__ __launch_bounds__(MW_NT) void k_mw_solve_mid(const MwDev q, const dou
         }
         stx<K>(v, N, a, acc_result<K>(s));
     }
-    if (q.qinv) {                             // dy = Qi^T (Qi v): two products with the explicit inverse of L_Q
-        lds_d *y = v + (long)K * N;
-        __syncthreads();
-        wg_trmv_n<K>(q.Qi, lplane, N, N, v, N, y, N, tid);
-        wg_trmv_t<K>(q.Qi, lplane, N, N, y, N, v, N, tid);
-    } else if (lds) {
-        lds_d *Lf = MW_LDS + (long)K * N, *Lb = Lf + (long)K * lplane;
-        wg_copy<K>(Lf, lplane, N, q.Qf, lplane, N, N, N, tid);
-        wg_copy<K>(Lb, lplane, N, q.Qb, lplane, N, N, N, tid);
-        __syncthreads();
-        if (N <= 64) {
-            if (tid < 64) {
-                mw<K> b = tid < N ? mul<K>(ldx<K>(v, N, tid), ldx<K>(q.qrd, N, tid)) : zero<K>();
-                b = wave_trsv_f<K>(Lf, lplane, N, N, b, tid);
-                if (tid < N) b = mul<K>(b, ldx<K>(q.qrd, N, tid));
-                b = wave_trsv_b<K>(Lb, lplane, N, N, b, tid);
-                if (tid < N) stx<K>(v, N, tid, b);
-            }
-            __syncthreads();
-        } else {
-            wg_trsm_f<K>(Lf, lplane, N, q.qrd, N, N, v, N, N, 1, tid);
-            wg_trsm_b<K>(Lb, lplane, N, q.qrd, N, N, v, N, N, 1, tid);
-        }
-    } else {
-        __syncthreads();
-        wg_trsm_f<K>(q.Qf, lplane, N, q.qrd, N, N, v, N, N, 1, tid);
-        wg_trsm_b<K>(q.Qb, lplane, N, q.qrd, N, N, v, N, N, 1, tid);
-    }
+    __syncthreads();
+    wg_trmv_n<K>(q.Qi, lplane, N, N, v, N, y, N, tid);     // dy = Qi^T (Qi v): two products with the explicit inverse of L_Q
+    wg_trmv_t<K>(q.Qi, lplane, N, N, y, N, v, N, tid);
     for (int a = tid; a < N; a += MW_NT) {
 #pragma unroll
         for (int l = 0; l < K; l++) dy[(long)l * N + a] = v[(long)l * N + a];
@@ -1078,7 +985,7 @@ __global__ __launch_bounds__(MW_NT) void k_mw_solve_bwd(const MwDev q, const dou
     const int j = blockIdx.x, tid = threadIdx.x;
     const MwClu &c = q.clu[j];
     const int P = c.P, N = q.N;
-    lds_d *w = MW_LDS;
+    lds_d *w = MW_LDS, *w2 = w + (long)K * P;
     const long plane = q.xlen * (long)N;
     const int sub = tid % MW_S_W;
     for (int r0 = 0; r0 < P; r0 += MW_NT / MW_S_W) {
@@ -1092,37 +999,11 @@ __global__ __launch_bounds__(MW_NT) void k_mw_solve_bwd(const MwDev q, const dou
         mw<K> v = lanes_sum<K, MW_S_W>(acc_result<K>(s));
         if (live && sub == 0) stx<K>(w, P, r, v);
     }
-    if (c.inv) {                              // dx_j = Si_j^T w
-        lds_d *w2 = w + (long)K * P;
-        __syncthreads();
-        wg_trmv_t<K>(q.Si + c.Soff, q.Slen, P, P, w, P, w2, P, tid);
-        for (int i = tid; i < P; i += MW_NT) {
-#pragma unroll
-            for (int l = 0; l < K; l++) dx[(long)l * q.xlen + c.coff + i] = w2[(long)l * P + i];
-        }
-        return;
-    }
-    if (c.lds) {
-        lds_d *Ls = MW_LDS + (long)K * P;
-        wg_copy<K>(Ls, (long)P * P, P, q.Sb + c.Soff, q.Slen, P, P, P, tid);
-        __syncthreads();
-        if (P <= 64) {
-            if (tid < 64) {
-                mw<K> b = tid < P ? mul<K>(ldx<K>(w, P, tid), ldx<K>(q.srd + c.coff, q.xlen, tid)) : zero<K>();
-                b = wave_trsv_b<K>(Ls, (long)P * P, P, P, b, tid);
-                if (tid < P) stx<K>(w, P, tid, b);
-            }
-            __syncthreads();
-        } else {
-            wg_trsm_b<K>(Ls, (long)P * P, P, q.srd + c.coff, q.xlen, P, w, P, P, 1, tid);
-        }
-    } else {
-        __syncthreads();
-        wg_trsm_b<K>(q.Sb + c.Soff, q.Slen, P, q.srd + c.coff, q.xlen, P, w, P, P, 1, tid);
-    }
+    __syncthreads();
+    wg_trmv_t<K>(q.Si + c.Soff, q.Slen, P, P, w, P, w2, P, tid);       // dx_j = Si_j^T w
     for (int i = tid; i < P; i += MW_NT) {
 #pragma unroll
-        for (int l = 0; l < K; l++) dx[(long)l * q.xlen + c.coff + i] = w[(long)l * P + i];
+        for (int l = 0; l < K; l++) dx[(long)l * q.xlen + c.coff + i] = w2[(long)l * P + i];
     }
 }
 
