@@ -223,7 +223,7 @@ def main():
                                    "a step of the N-GPU job (one iteration of the 2N-cluster problem) = N units",
                    "multi_gpu": (f"{2 * world} clusters sharded 2 per rank; RCCL all-gather of the partial Q (per factorisation) and u (per solve) "
                                  "inside the C ABI (clrs_mw_comm_init)") if sharded else "single GPU",
-                   "launch": "eager, 14 kernels per step"},
+                   "launch": "eager, 15 kernels per step"},
         "parity": parity,
         "full_solve": full_solve,
     }

@@ -1,8 +1,10 @@
 """Staged (large-block) regime: per-kernel times of one Schur assembly + factorisation on the roofline instances R."""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np, torch
-import bench, clrs_amd
+import clrs_amd
+import bench_fp64 as bench
 from clrs_amd import problems as P
 from clrs_amd.solver import SchurContext
 which = sys.argv[1] if len(sys.argv) > 1 else "polyopt512"
