@@ -83,7 +83,8 @@ struct clrs_mw_ctx {
     std::vector<void *> allocs;
     int maxU = 0, maxP = 0, maxn = 0;
     bool xinv_valid = false;            // Xi holds the inverses of the current Cholesky factors (they come from k_mw_potrf_x, not from the caller)
-    bool lds_x = false, lds_q = false, lds_zt_L = false;
+    bool lds_x = false, lds_q = false, lds_zt_L = false, dense_two = false;
+    int maxcnt = 0;
     size_t sm_x = 0, sm_zt = 0, sm_dense = 0, sm_factor = 0, sm_q = 0, sm_fwd = 0, sm_mid = 0, sm_bwd = 0;
     int *h_info = nullptr;               // pinned
     double *d_Xin = nullptr, *d_Xc = nullptr, *d_Y = nullptr, *d_rx = nullptr, *d_ry = nullptr, *d_dx = nullptr, *d_dy = nullptr;   // staging of the host-pointer entry points
@@ -181,6 +182,7 @@ extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int dev
     std::vector<double> hV;          // limb 0 while the tables are built; the other limbs follow below
     std::vector<int> hvrow, st_a(std::max<i64>(T, 1)), st_b(std::max<i64>(T, 1)), htptr, ay_a(std::max<i64>(T, 1), 0), ay_b(std::max<i64>(T, 1), 0),
         ay_blk(std::max<i64>(T, 1), -1), hdmap, lr_list, dn_list;
+    std::vector<std::tuple<i64, int, int>> drow_pairs;       // (stacked row, block, entry) of every dense matrix
     std::vector<double> st_lam((size_t)std::max<i64>(T, 1) * DK), hdA;
     std::vector<std::vector<double>> hVl(DK), hdAl(DK);     // per limb
     // for the interior-point iteration around the path (clrs_mw_ipm.hip.h), sorted term order: original term, vs at sub-block r / ws at
@@ -298,6 +300,7 @@ extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int dev
                 if (p < 0 || p >= P) MW_BAIL(CLRS_ERR_INVALID, "dense constraint index out of range");
                 if (d->dense_A_ptr[e + 1] - d->dense_A_ptr[e] != (i64)n * n) MW_BAIL(CLRS_ERR_INVALID, "dense matrix must have n*n entries");
                 hdmap[k.dmap_off + p] = (int)(e - d0);
+                drow_pairs.push_back(std::make_tuple(c->clu[k.j].coff + p, b, (int)(e - d0)));
                 for (int l = 0; l < DK; l++)
                     hdAl[l].insert(hdAl[l].end(), d->dense_A + (i64)l * dA_plane + d->dense_A_ptr[e], d->dense_A + (i64)l * dA_plane + d->dense_A_ptr[e + 1]);
             }
@@ -336,7 +339,8 @@ extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int dev
         size_t maxnd = 0;
         for (auto &k : c->blk) if (k.kind != 0 && k.n > 1) maxnd = std::max(maxnd, (size_t)k.n);
         if (maxnd * maxnd * K > lim) MW_BAIL(CLRS_ERR_INVALID, "dense block too large for the multi-word kernels");
-        c->sm_dense = maxnd * maxnd * K * 8;
+        c->dense_two = 2 * maxnd * maxnd * K <= lim;        // room for the two buffers of the product form of X^-1 A
+        c->sm_dense = (c->dense_two ? 2 : 1) * maxnd * maxnd * K * 8;
         size_t fmax = 0;
         for (auto &q : c->clu) {                        // S_j and the inverse of its factor side by side in LDS, or the blocked path
             const size_t need = 2 * (size_t)q.P * q.P * K + MW_POTRF_SCR(K, (size_t)q.P);
@@ -352,7 +356,7 @@ extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int dev
         if (c->sm_fwd > MW_LDS_MAX || c->sm_mid > MW_LDS_MAX) MW_BAIL(CLRS_ERR_INVALID, "cluster too large for the multi-word solve kernels");
     }
     MW_DISPATCH(c, {
-        MW_TRY(mw_set_lds(k_mw_potrf_x<KK>, c->sm_x)); MW_TRY(mw_set_lds(k_mw_zt<KK, DD>, c->sm_zt)); MW_TRY(mw_set_lds(k_mw_dense<KK, DD>, c->sm_dense));
+        MW_TRY(mw_set_lds(k_mw_potrf_x<KK>, c->sm_x)); MW_TRY(mw_set_lds(k_mw_zt<KK, DD>, c->sm_zt)); MW_TRY(mw_set_lds((k_mw_dense_t<KK, DD>), c->sm_dense));
         MW_TRY(mw_set_lds(k_mw_factor<KK>, c->sm_factor)); MW_TRY(mw_set_lds(k_mw_potrf_q<KK>, c->sm_q));
         MW_TRY(mw_set_lds(k_mw_solve_fwd<KK>, c->sm_fwd)); MW_TRY(mw_set_lds(k_mw_solve_mid<KK>, c->sm_mid)); MW_TRY(mw_set_lds(k_mw_solve_bwd<KK>, c->sm_bwd));
     });
@@ -390,6 +394,17 @@ extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int dev
     MW_TRY(mw_upload(c, st_trl, &q.st_trl)); MW_TRY(mw_upload(c, st_trd, &q.st_trd)); MW_TRY(mw_upload(c, st_flag, &q.st_flag));
     MW_TRY(mw_upload(c, ay_a, &q.ay_a)); MW_TRY(mw_upload(c, ay_b, &q.ay_b)); MW_TRY(mw_upload(c, ay_blk, &q.ay_blk));
     MW_TRY(mw_upload(c, hdA, &q.dA)); MW_TRY(mw_upload(c, hdmap, &q.dmap)); MW_TRY(mw_upload(c, hdense_p, &q.dense_p));
+    {
+        std::sort(drow_pairs.begin(), drow_pairs.end());
+        std::vector<int> hptr((size_t)xlen + 1, 0), hblk, hen;
+        for (auto &t : drow_pairs) hptr[(size_t)std::get<0>(t) + 1]++;
+        for (i64 g = 0; g < xlen; g++) hptr[(size_t)g + 1] += hptr[(size_t)g];
+        for (auto &t : drow_pairs) { hblk.push_back(std::get<1>(t)); hen.push_back(std::get<2>(t)); }
+        MW_TRY(mw_upload(c, hptr, &q.drow_ptr)); MW_TRY(mw_upload(c, hblk, &q.drow_blk)); MW_TRY(mw_upload(c, hen, &q.drow_en));
+        q.dn_big = 0;
+        for (auto &k : c->blk) if (k.kind != 0) { c->maxcnt = std::max(c->maxcnt, k.cnt); if (k.n > 1) q.dn_big = 1; }
+        q.maxcnt = c->maxcnt;
+    }
     MW_TRY(mw_upload(c, hBs, &q.B));
     MW_TRY(mw_dmalloc(c, &q.Z, q.zlen * K)); MW_TRY(mw_dmalloc(c, &q.Tm, q.zlen * K));
     MW_TRY(mw_dmalloc(c, &q.GX, q.glen * K)); MW_TRY(mw_dmalloc(c, &q.GY, q.glen * K));
@@ -514,7 +529,11 @@ extern "C" int clrs_mw_schur_assemble_dev(clrs_mw_ctx *c, const double *d_Xchol,
             hipLaunchKernelGGL((k_mw_zt<KK, DD>), dim3((c->maxU + MW_CT - 1) / MW_CT, q.nlr), dim3(MW_NT), c->sm_zt, c->stream, q, d_Y, c->lds_zt_L ? 1 : 0, c->xinv_valid ? 1 : 0);
             hipLaunchKernelGGL((k_mw_gram<KK, DD>), dim3((c->maxU * (c->maxU + 1) / 2 + gper - 1) / gper, q.nlr), dim3(MW_NT), 0, c->stream, q);
         }
-        if (q.ndn) hipLaunchKernelGGL((k_mw_dense<KK, DD>), dim3(q.ndn), dim3(MW_NT), c->sm_dense, c->stream, q, d_Y);
+        if (q.ndn) {
+            hipLaunchKernelGGL((k_mw_dense_t<KK, DD>), dim3(q.ndn, q.dn_big ? c->maxcnt : 1), dim3(MW_NT), c->sm_dense, c->stream, q, d_Y, c->xinv_valid ? 1 : 0, c->dense_two ? 1 : 0);
+            const int pairs = c->maxcnt * (c->maxcnt + 1) / 2;
+            hipLaunchKernelGGL((k_mw_dense_s<KK, DD>), dim3(q.ndn, (pairs + MW_NT / 64 - 1) / (MW_NT / 64)), dim3(MW_NT), 0, c->stream, q);
+        }
         hipLaunchKernelGGL((k_mw_saccum<KK, DD>), dim3((c->maxP * (c->maxP + 1) / 2 + MW_NT - 1) / MW_NT, q.J), dim3(MW_NT), 0, c->stream, q);
     });
     MWCHECK(hipGetLastError());

@@ -19,6 +19,7 @@ struct MwIpmDev {
     int *yfail;                        // [NB] 1 = Y_b is not positive definite
     double *Zs;                        // unsymmetrised X^-1 (...) of k_mwi_Zi (xy layout)
     int *zcnt;                         // [NB] workgroups of a block that have delivered their panel
+    double *dtr;                       // [xlen] dense part of the row traces <A_*, M> (k_mwi_rows_dn), when some dense block has n > 1
     double *sc, *part;                 // planar scalars [MSC_COUNT]; partial dot products [5][NB]
     unsigned long long *fmax;          // bit patterns of non-negative doubles: [0] max|P|, [1] max|d|, [2] max|p|
     double *eig;                       // fp64 [2][NB]: smallest eigenvalue of L^-1 dM L^-T per block (X then Y)
@@ -413,6 +414,26 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_MV(const MwDev q, const double *_
 }
 
 // ---- per constraint row: d = c - <A_*,Y> - B y (:863-879) or rhs_x = -d - <A_*,Z> (:1518-1523) --------------------------
+// Dense part of the row traces, <A_g, M> summed over the dense matrices of constraint row g: nn-term dot products, ONE WAVE per
+// row (the per-row lane group of k_mwi_rows would walk them with eight lanes, and rows of one wave touch different blocks).
+template <int K, int DK>
+__global__ __launch_bounds__(MW_NT) void k_mwi_rows_dn(const MwDev q, const MwIpmDev p, int mode) {
+    using namespace mwk;
+    const mwi64 g = (mwi64)blockIdx.x * (MW_NT / 64) + (threadIdx.x >> 6);
+    if (g >= q.xlen) return;                            // uniform over the wave
+    const int lane = threadIdx.x & 63;
+    const double *M = mode == 0 ? p.Y : p.dY;
+    acc<K> s;
+    acc_zero<K>(s);
+    for (int t = q.drow_ptr[g]; t < q.drow_ptr[g + 1]; t++) {
+        const MwBlk &k = q.blk[q.drow_blk[t]];
+        const long nn = (long)k.n * k.n, a0 = k.a_off + (long)q.drow_en[t] * nn;
+        for (long i = lane; i < nn; i += 64) acc_fma<K, K, DK>(s, ldx<K>(M + k.xyoff, q.xylen, i), ldx<DK>(q.dA, q.dAp, a0 + i));
+    }
+    const mw<K> v = lanes_sum<K, 64>(acc_result<K>(s));
+    if (lane == 0) stx<K>(p.dtr, q.xlen, g, v);
+}
+
 #define MWI_RW 8              // lanes per constraint row
 template <int K, int DK>
 __global__ __launch_bounds__(MW_NT) void k_mwi_rows(const MwDev q, const MwIpmDev p, int mode) {
@@ -453,7 +474,7 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_rows(const MwDev q, const MwIpmDe
                     acc_fma<K, K, DK>(s, acc_result<K>(z), w, -1.0);
                 }
             }
-        } else {
+        } else if (!q.dn_big) {
             const int en = q.dmap[k.dmap_off + pp];
             if (en >= 0) {
                 const long nn = (long)n * n;
@@ -461,6 +482,7 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_rows(const MwDev q, const MwIpmDe
             }
         }
     }
+    if (q.dn_big && sub == 0) acc_add<K, K>(s, ldx<K>(p.dtr, q.xlen, g), -1.0);      // the dense matrices of the row: k_mwi_rows_dn
     if (mode == 0) {
         if (sub == 0) acc_add<K, DK>(s, ldx<DK>(p.c, q.xlen, g));
         for (int a = sub; a < q.N; a += MWI_RW) acc_fma<K, K, DK>(s, ldx<K>(p.y, q.N, a), ldx<DK>(q.B, q.Bp, g + (long)a * q.xlen), -1.0);
@@ -812,7 +834,7 @@ extern "C" int clrs_mw_ipm_create_ex(clrs_mw_ctx *c, const clrs_ipm_data *data, 
         for (double **b : xs) if ((rc = mw_dmalloc(c, b, q.xlen * K))) return rc;
         double **ys[] = {&p.y, &p.dy, &p.pv};
         for (double **b : ys) if ((rc = mw_dmalloc(c, b, (i64)N * K))) return rc;
-        if ((rc = mw_dmalloc(c, &p.coef, q.T * K))) return rc;
+        if ((rc = mw_dmalloc(c, &p.coef, q.T * K)) || (rc = mw_dmalloc(c, &p.dtr, q.xlen * K))) return rc;
         if ((rc = mw_dmalloc(c, &p.Yi, q.xylen * K)) || (rc = mw_dmalloc(c, &p.Zs, q.xylen * K))) return rc;
         { double *t3 = nullptr; if ((rc = mw_dmalloc(c, &t3, (NB + 1) / 2 + 1))) return rc; p.zcnt = (int *)t3; }
         { double *t2 = nullptr; if ((rc = mw_dmalloc(c, &t2, (NB + 1) / 2 + 1))) return rc; p.yfail = (int *)t2; }
@@ -946,6 +968,7 @@ static int mw_ipm_direction(clrs_mw_ctx *c, int corrector) {
         if (st->any_xinv) hipLaunchKernelGGL(k_mwi_Zi<KK>, dim3(q.NB, MWI_ZS), dim3(MW_PT), st->sm_Zi, c->stream, q, p, 0);
         if (st->any_xsub) hipLaunchKernelGGL(k_mwi_Z<KK>, dim3(q.NB), dim3(MW_NT), st->sm_Z, c->stream, q, p, 0, st->lds_ZL ? 1 : 0);
         if (q.nlr) hipLaunchKernelGGL((k_mwi_MV<KK, DD>), dim3((c->maxn * c->maxU * MWI_EW + MW_NT - 1) / MW_NT, q.nlr), dim3(MW_NT), 0, c->stream, q, (const double *)p.dY);
+        if (q.dn_big) hipLaunchKernelGGL((k_mwi_rows_dn<KK, DD>), dim3((unsigned)((q.xlen + MW_NT / 64 - 1) / (MW_NT / 64))), dim3(MW_NT), 0, c->stream, q, p, 1);
         hipLaunchKernelGGL((k_mwi_rows<KK, DD>), dim3((unsigned)((q.xlen * MWI_RW + MW_NT - 1) / MW_NT)), dim3(MW_NT), 0, c->stream, q, p, 1);
     });
     MWCHECK(hipGetLastError());
@@ -980,6 +1003,7 @@ extern "C" int clrs_mw_ipm_iterate(clrs_mw_ctx *c, clrs_ipm_record *out) {
     MW_DISPATCH(c, {
         if (q.T) hipLaunchKernelGGL((k_mwi_coef<KK, DD>), dim3((unsigned)((q.T + MW_NT - 1) / MW_NT)), dim3(MW_NT), 0, c->stream, q, p, (const double *)p.x);
         hipLaunchKernelGGL((k_mwi_wA<KK, DD>), dim3((maxnn * MWI_EW + MW_NT - 1) / MW_NT, q.NB), dim3(MW_NT), 0, c->stream, q, p, 0);
+        if (q.dn_big) hipLaunchKernelGGL((k_mwi_rows_dn<KK, DD>), dim3((unsigned)((q.xlen + MW_NT / 64 - 1) / (MW_NT / 64))), dim3(MW_NT), 0, c->stream, q, p, 0);
         hipLaunchKernelGGL((k_mwi_rows<KK, DD>), dim3((unsigned)((q.xlen * MWI_RW + MW_NT - 1) / MW_NT)), dim3(MW_NT), 0, c->stream, q, p, 0);
         if (q.N) hipLaunchKernelGGL((k_mwi_pv<KK, DD>), dim3((q.N + MW_NT / 8 - 1) / (MW_NT / 8)), dim3(MW_NT), 0, c->stream, q, p, st->iter);
         else hipLaunchKernelGGL((k_mwi_scalar<KK, DD>), dim3(1), dim3(64), 0, c->stream, q, p, 1, st->iter);

@@ -64,6 +64,8 @@ struct MwDev {
     const int *ay_a, *ay_b, *ay_blk;    // original term order: pairing of the term
     const double *dA;
     const int *dmap, *dense_p;
+    const int *drow_ptr, *drow_blk, *drow_en;   // per constraint row (stacked, xlen + 1): its dense entries as (block, entry) pairs
+    int dn_big, maxcnt;                 // some dense block has n > 1 (the dense branch then runs one workgroup per matrix); largest cnt of a dense block
     const double *B;                    // stacked B, xlen x N column-major
     mwi64 Vp, lamp, dAp, Bp;            // plane lengths of the problem data V, st_lam, dA, B (DK limbs each, planar)
     double *Z, *Tm, *GX, *GY, *W, *Sd;  // scratch, planar
@@ -528,50 +530,80 @@ __global__ __launch_bounds__(MW_NT) void k_mw_gram(const MwDev q) {
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Dense ("high rank") block: T_e = X^-1 A_e Y for every matrix of the block, then the table Sd[e, e'] = <A_e', T_e>
-// (src/solver.jl:1089-1104).  One workgroup per block; n = 1 blocks take one thread per entry.
+// (src/solver.jl:1089-1104).  k_mw_dense_t: one workgroup per (block, matrix) -- the matrices are independent -- with
+// X^-1 A = Xi^T (Xi A) as products when the inverse factor of the block exists and two buffers fit in LDS (`prod`), by the
+// two substitutions otherwise; n = 1 blocks take one thread per matrix.  k_mw_dense_s: one wave per pair (e, e') of the table.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int K, int DK>
-__global__ __launch_bounds__(MW_NT) void k_mw_dense(const MwDev q, const double *__restrict__ Y) {
+__global__ __launch_bounds__(MW_NT) void k_mw_dense_t(const MwDev q, const double *__restrict__ Y, int use_inv, int two_buffers) {
     using namespace mwk;
     const MwBlk &k = q.blk[q.dn_list[blockIdx.x]];
-    const int n = k.n, cnt = k.cnt, tid = threadIdx.x;
+    const int n = k.n, cnt = k.cnt, tid = threadIdx.x, e = blockIdx.y;
     const double *A = q.dA + k.a_off;
     double *W = q.W + k.w_off;
     const long nn = (long)n * n;
     if (n == 1) {
+        if (e != 0) return;
         mw<K> rd = ldx<K>(q.xrd + k.rd_off, q.xrdlen, 0);
         mw<K> yx = mul<K>(ldx<K>(Y + k.xyoff, q.xylen, 0), mul<K>(rd, rd));      // Y / X
-        for (int e = tid; e < cnt; e += MW_NT) stx<K>(W, q.wlen, e, mulx<K, K, DK>(yx, ldx<DK>(A, q.dAp, e)));
-    } else {
-        lds_d *M = MW_LDS;
-        for (int e = 0; e < cnt; e++) {
-            // M = A_e; M <- L^-1 M; M <- L^-T M; T_e = M Y
-            for (int i = tid; i < nn; i += MW_NT) {
-#pragma unroll
-                for (int l = 0; l < K; l++) M[(long)l * nn + i] = l < DK ? A[(long)l * q.dAp + (long)e * nn + i] : 0.0;
-            }
-            __syncthreads();
-            wg_trsm_f<K>(q.Xf + k.xyoff, q.xylen, n, q.xrd + k.rd_off, q.xrdlen, n, M, nn, n, n, tid);
-            wg_trsm_b<K>(q.Xb + k.xyoff, q.xylen, n, q.xrd + k.rd_off, q.xrdlen, n, M, nn, n, n, tid);
-            for (int o = tid; o < nn; o += MW_NT) {
-                const int i = o % n, c = o / n;
-                acc<K> s;
-                acc_zero<K>(s);
-                for (int kk = 0; kk < n; kk++) acc_fma<K, K, K>(s, ldx<K>(M, nn, i + (long)kk * n), ldx<K>(Y + k.xyoff, q.xylen, kk + (long)c * n));
-                stx<K>(W, q.wlen, (long)e * nn + o, acc_result<K>(s));
-            }
-            __syncthreads();
-        }
+        for (int ee = tid; ee < cnt; ee += MW_NT) stx<K>(W, q.wlen, ee, mulx<K, K, DK>(yx, ldx<DK>(A, q.dAp, ee)));
+        return;
     }
-    __syncthreads();
-    // Sd[e, e'] = <A_e', T_e>, e <= e' computed, mirrored
-    for (int o = tid; o < cnt * (cnt + 1) / 2; o += MW_NT) {
-        int e2, e1;
-        tri_index(o, e2, e1);       // e2 >= e1
+    if (e >= cnt) return;
+    lds_d *M = MW_LDS, *M2 = M + (long)K * nn;
+    if (use_inv && k.inv && two_buffers) {
+        const double *Xi = q.Xi + k.xyoff;
+        for (int o = tid; o < nn; o += MW_NT) {            // M = Xi A_e
+            const int i = o % n, c = o / n;
+            acc<K> s;
+            acc_zero<K>(s);
+            for (int r = 0; r <= i; r++) acc_fma<K, K, DK>(s, ldx<K>(Xi, q.xylen, i + (long)r * n), ldx<DK>(A, q.dAp, (long)e * nn + r + (long)c * n));
+            stx<K>(M, nn, o, acc_result<K>(s));
+        }
+        __syncthreads();
+        for (int o = tid; o < nn; o += MW_NT) {            // M2 = Xi^T M
+            const int i = o % n, c = o / n;
+            acc<K> s;
+            acc_zero<K>(s);
+            for (int r = i; r < n; r++) acc_fma<K, K, K>(s, ldx<K>(Xi, q.xylen, r + (long)i * n), ldx<K>(M, nn, r + (long)c * n));
+            stx<K>(M2, nn, o, acc_result<K>(s));
+        }
+        __syncthreads();
+        M = M2;
+    } else {
+        for (int i = tid; i < nn; i += MW_NT) {
+#pragma unroll
+            for (int l = 0; l < K; l++) M[(long)l * nn + i] = l < DK ? A[(long)l * q.dAp + (long)e * nn + i] : 0.0;
+        }
+        __syncthreads();
+        wg_trsm_f<K>(q.Xf + k.xyoff, q.xylen, n, q.xrd + k.rd_off, q.xrdlen, n, M, nn, n, n, tid);
+        wg_trsm_b<K>(q.Xb + k.xyoff, q.xylen, n, q.xrd + k.rd_off, q.xrdlen, n, M, nn, n, n, tid);
+    }
+    for (int o = tid; o < nn; o += MW_NT) {                // T_e = (X^-1 A_e) Y
+        const int i = o % n, c = o / n;
         acc<K> s;
         acc_zero<K>(s);
-        for (long i = 0; i < nn; i++) acc_fma<K, K, DK>(s, ldx<K>(W, q.wlen, (long)e1 * nn + i), ldx<DK>(A, q.dAp, (long)e2 * nn + i));
-        mw<K> v = acc_result<K>(s);
+        for (int kk = 0; kk < n; kk++) acc_fma<K, K, K>(s, ldx<K>(M, nn, i + (long)kk * n), ldx<K>(Y + k.xyoff, q.xylen, kk + (long)c * n));
+        stx<K>(W, q.wlen, (long)e * nn + o, acc_result<K>(s));
+    }
+}
+// Sd[e, e'] = <A_e', T_e>, e <= e' computed, mirrored: one wave per pair
+template <int K, int DK>
+__global__ __launch_bounds__(MW_NT) void k_mw_dense_s(const MwDev q) {
+    using namespace mwk;
+    const MwBlk &k = q.blk[q.dn_list[blockIdx.x]];
+    const int cnt = k.cnt, lane = threadIdx.x & 63;
+    const int o = blockIdx.y * (MW_NT / 64) + (threadIdx.x >> 6);
+    if (o >= cnt * (cnt + 1) / 2) return;                  // uniform over the wave
+    const long nn = (long)k.n * k.n;
+    const double *A = q.dA + k.a_off, *W = q.W + k.w_off;
+    int e2, e1;
+    tri_index(o, e2, e1);       // e2 >= e1
+    acc<K> s;
+    acc_zero<K>(s);
+    for (long i = lane; i < nn; i += 64) acc_fma<K, K, DK>(s, ldx<K>(W, q.wlen, (long)e1 * nn + i), ldx<DK>(A, q.dAp, (long)e2 * nn + i));
+    const mw<K> v = lanes_sum<K, 64>(acc_result<K>(s));
+    if (lane == 0) {
         stx<K>(q.Sd + k.sd_off, q.sdlen, e1 + (long)e2 * cnt, v);
         stx<K>(q.Sd + k.sd_off, q.sdlen, e2 + (long)e1 * cnt, v);
     }
