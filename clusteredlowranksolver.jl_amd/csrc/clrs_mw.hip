@@ -327,9 +327,10 @@ extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int dev
         c->lds_x = nn + bcw <= lim;
         size_t xneed = (c->lds_x ? nn : 0) + bcw;
         for (auto &k : c->blk) {                            // X blocks whose factor and its inverse fit side by side: Xi is formed
-            const size_t two = 2 * (size_t)k.n * k.n * K + MW_POTRF_SCR(K, (size_t)k.n) + (size_t)K * k.n;   // + a reciprocal diagonal (the Y workgroups of the iteration)
-            k.inv = (c->lds_x && two <= lim) ? 1 : 0;
-            if (k.inv) xneed = std::max(xneed, two);
+            const size_t one = (size_t)k.n * k.n * K + MW_POTRF_SCR(K, (size_t)k.n) + (size_t)K * k.n;   // + a reciprocal diagonal (the Y workgroups of the iteration)
+            const size_t two = one + (size_t)k.n * k.n * K;
+            k.inv = !c->lds_x ? 0 : two <= lim ? 1 : one <= lim ? 2 : 0;       // the inverse in LDS beside the factor, or in place in memory
+            if (k.inv) xneed = std::max(xneed, k.inv == 1 ? two : one);
         }
         c->sm_x = xneed * 8;
         size_t zt = (size_t)c->maxn * MW_CT * K;

@@ -683,18 +683,25 @@ __device__ __forceinline__ void mwi_step_body(const MwDev &q, const MwIpmDev &p,
         }
         return;
     }
-    if (inv_path && k.inv) {
+    if (inv_path == 2) {
+        // both inverse factors are in memory (Xi from k_mw_potrf_x, Yi from its second half): LDS holds T1, the fp64 matrix, the eigenvalue work space
+        lds_d *T1 = MW_LDS, *Wd = T1 + (long)K * nn, *work = Wd + nn;
+        if (which == 1 && p.yfail[blockIdx.x]) {                                         // :1644-1646
+            if (tid == 0) { p.flags[2] = 1; p.eig[(long)which * q.NB + blockIdx.x] = 0.0; }
+            return;
+        }
+        mwi_step_congruence_inv<K>((which == 0 ? q.Xi : p.Yi) + k.xyoff, q.xylen, n, dMg, q.xylen, T1, Wd, tid);
+        __syncthreads();
+        const double ev = wg_min_eig(Wd, n, work, tid);
+        if (tid == 0) p.eig[(long)which * q.NB + blockIdx.x] = ev - 1e-5;                // :1662
+        return;
+    }
+    if (inv_path && k.inv == 1) {
         // LDS: Li (inverse factor; which 0 reads Xi from memory instead), T1, [Y and its factor], rd, the fp64 matrix, eigenvalue work space, scratch
         lds_d *Li = MW_LDS, *T1 = Li + (long)K * nn, *Mf = T1 + (long)K * nn;
         lds_d *rd = Mf + (long)K * nn, *Wd = rd + (long)K * n, *work = Wd + nn, *scr = work + 3 * n + 2 * MW_NT;
         if (which == 0) {
             mwi_step_congruence_inv<K>(q.Xi + k.xyoff, q.xylen, n, dMg, q.xylen, T1, Wd, tid);
-        } else if (inv_path == 2) {                     // chol(Y)^-1 came with this iteration's chol(X)
-            if (p.yfail[blockIdx.x]) {                                                   // :1644-1646
-                if (tid == 0) { p.flags[2] = 1; p.eig[(long)which * q.NB + blockIdx.x] = 0.0; }
-                return;
-            }
-            mwi_step_congruence_inv<K>(p.Yi + k.xyoff, q.xylen, n, dMg, q.xylen, T1, Wd, tid);
         } else {
             wg_copy<K>(Mf, nn, n, Mg, q.xylen, n, n, n, tid);
             __syncthreads();
@@ -875,9 +882,13 @@ extern "C" int clrs_mw_ipm_create_ex(clrs_mw_ctx *c, const clrs_ipm_data *data, 
         }
         st->sm_Zi = 2 * maxn_inv * ((maxn_inv + MWI_ZS - 1) / MWI_ZS) * K * 8;
         const size_t step_inv_need = 3 * maxn_inv * maxn_inv * K + step_rest;
-        st->step_inv = st->any_xinv && step_inv_need <= lim;
-        st->y_with_x = st->step_inv && !st->any_xsub;      // every block has its inverse factor: chol(Y)^-1 rides on the chol(X) launch
+        bool all_lds_inv = st->any_xinv;
+        for (auto &k : c->blk) all_lds_inv = all_lds_inv && k.inv == 1;
+        st->step_inv = all_lds_inv && step_inv_need <= lim;      // the step length factors Y itself, everything in LDS
+        const size_t step_need2 = nnK + maxn * maxn + 3 * maxn + 2 * MW_NT + 8;
+        st->y_with_x = st->any_xinv && !st->any_xsub && step_need2 <= lim;      // every block has its inverse factor: chol(Y)^-1 rides on the chol(X) launch
         if (st->step_inv) st->sm_step = std::max(st->sm_step, step_inv_need * 8);
+        if (st->y_with_x) st->sm_step = std::max(st->sm_step, step_need2 * 8);
         MW_DISPATCH(c, {
             if ((rc = mw_set_lds(k_mwi_Zi<KK>, st->sm_Zi))) return rc;
             if ((rc = mw_set_lds(k_mwi_Z<KK>, st->sm_Z))) return rc;

@@ -29,7 +29,7 @@
 typedef long long mwi64;
 
 struct MwBlk {               // one PSD block (j, l)
-    int j, n, kind, delta, U, cnt, P, inv;   // inv: chol(X_b)^-1 is formed beside the factor (Xi)
+    int j, n, kind, delta, U, cnt, P, inv;   // chol(X_b)^-1 is formed beside the factor (Xi): 1 = in LDS, 2 = in place in memory (the block fits in LDS once, not twice), 0 = not
     mwi64 xyoff;             // offset in the xy layout
     mwi64 rd_off;            // offset of its reciprocal Cholesky diagonal in xrd (sum of n over earlier blocks)
     mwi64 v_off;             // low rank: V, n x U column-major fp64 (expanded unique vectors)
@@ -365,10 +365,11 @@ extern __shared__ double mw_lds[];
 // for the substitutions that follow.  One workgroup per block; `lds` = 1: the block is factored in LDS.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int K, bool INV, class PM, class PW>
-__device__ __forceinline__ void mw_potrf_x_body(const MwDev &q, const MwBlk &k, PM M, long plane, PW W, double *__restrict__ Xc, mwk::lds_d *bc, int tid, int bid) {
+__device__ __forceinline__ void mw_potrf_x_body(const MwDev &q, const MwBlk &k, PM M, long plane, PW W, long wplane, bool w_in_place, double *__restrict__ Xc, mwk::lds_d *bc,
+                                                int tid, int bid) {
     using namespace mwk;
     const int n = k.n;
-    const bool ok = wg_potrf<K, INV, MW_PT, true>(M, plane, n, n, q.xrd + k.rd_off, q.xrdlen, W, plane, n, bc, tid);
+    const bool ok = wg_potrf<K, INV, MW_PT, true>(M, plane, n, n, q.xrd + k.rd_off, q.xrdlen, W, wplane, n, bc, tid);
     if (!ok && tid == 0) atomicMin(&q.info[1], bid + 1);
     __syncthreads();
     if (ok) wg_scaled_factors_u<K, MW_PT>(M, plane, n, q.xrd + k.rd_off, q.xrdlen, n, q.Xf + k.xyoff, q.xylen, n, q.Xb + k.xyoff, q.xylen, n, tid);
@@ -377,7 +378,7 @@ __device__ __forceinline__ void mw_potrf_x_body(const MwDev &q, const MwBlk &k, 
 #pragma unroll
         for (int l = 0; l < K; l++) {
             Xc[(long)l * q.xylen + k.xyoff + e] = (i >= c) ? (double)M[(long)l * plane + e] : 0.0;
-            if (INV) q.Xi[(long)l * q.xylen + k.xyoff + e] = (ok && i >= c) ? (double)W[(long)l * plane + e] : 0.0;
+            if (INV && !w_in_place) q.Xi[(long)l * q.xylen + k.xyoff + e] = (ok && i >= c) ? (double)W[(long)l * wplane + e] : 0.0;
         }
     }
 }
@@ -394,31 +395,39 @@ __global__ __launch_bounds__(MW_PT) void k_mw_potrf_x(const MwDev q, const doubl
     const int n = k.n, tid = threadIdx.x;
     lds_d *bc = MW_LDS;                                   // scratch of wg_potrf, in front of the matrix
     if (second) {
-        lds_d *M = MW_LDS + MW_POTRF_SCR(K, n), *W = M + (long)K * n * n, *rdl = W + (long)K * n * n;
+        lds_d *M = MW_LDS + MW_POTRF_SCR(K, n);
         wg_copy<K, MW_PT>(M, (long)n * n, n, Y2 + k.xyoff, q.xylen, n, n, n, tid);
         __syncthreads();
-        const bool ok = wg_potrf<K, true, MW_PT, false>(M, (long)n * n, n, n, rdl, n, W, (long)n * n, n, bc, tid);
-        if (tid == 0) yfail[blockIdx.x - q.NB] = ok ? 0 : 1;
-        if (ok) {
-            for (int e = tid; e < n * n; e += MW_PT) {
-                const int i = e % n, c = e / n;
+        bool ok;
+        if (k.inv == 1) {
+            lds_d *W = M + (long)K * n * n, *rdl = W + (long)K * n * n;
+            ok = wg_potrf<K, true, MW_PT, false>(M, (long)n * n, n, n, rdl, n, W, (long)n * n, n, bc, tid);
+            if (ok) {
+                for (int e = tid; e < n * n; e += MW_PT) {
+                    const int i = e % n, c = e / n;
 #pragma unroll
-                for (int l = 0; l < K; l++) Yi[(long)l * q.xylen + k.xyoff + e] = (i >= c) ? (double)W[(long)l * n * n + e] : 0.0;
+                    for (int l = 0; l < K; l++) Yi[(long)l * q.xylen + k.xyoff + e] = (i >= c) ? (double)W[(long)l * n * n + e] : 0.0;
+                }
             }
+        } else {                                        // the inverse in place in memory
+            lds_d *rdl = M + (long)K * n * n;
+            ok = wg_potrf<K, true, MW_PT, false>(M, (long)n * n, n, n, rdl, n, Yi + k.xyoff, q.xylen, n, bc, tid);
         }
+        if (tid == 0) yfail[blockIdx.x - q.NB] = ok ? 0 : 1;
         return;
     }
     if (lds) {
         lds_d *M = MW_LDS + MW_POTRF_SCR(K, n);
         wg_copy<K, MW_PT>(M, (long)n * n, n, X + k.xyoff, q.xylen, n, n, n, tid);
         __syncthreads();
-        if (k.inv) mw_potrf_x_body<K, true>(q, k, M, (long)n * n, M + (long)K * n * n, Xc, bc, tid, blockIdx.x);
-        else mw_potrf_x_body<K, false>(q, k, M, (long)n * n, M, Xc, bc, tid, blockIdx.x);
+        if (k.inv == 1) mw_potrf_x_body<K, true>(q, k, M, (long)n * n, M + (long)K * n * n, (long)n * n, false, Xc, bc, tid, blockIdx.x);
+        else if (k.inv == 2) mw_potrf_x_body<K, true>(q, k, M, (long)n * n, q.Xi + k.xyoff, q.xylen, true, Xc, bc, tid, blockIdx.x);
+        else mw_potrf_x_body<K, false>(q, k, M, (long)n * n, M, 0, false, Xc, bc, tid, blockIdx.x);
     } else {
         double *M = Xc + k.xyoff;
         wg_copy<K, MW_PT>(M, q.xylen, n, X + k.xyoff, q.xylen, n, n, n, tid);
         __syncthreads();
-        mw_potrf_x_body<K, false>(q, k, M, q.xylen, M, Xc, bc, tid, blockIdx.x);
+        mw_potrf_x_body<K, false>(q, k, M, q.xylen, M, 0, false, Xc, bc, tid, blockIdx.x);
     }
 }
 
