@@ -560,7 +560,7 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_Z(const MwDev q, const MwIpmDev p
 
 // The same with the explicit inverse Xi = chol(X)^-1 that k_mw_potrf_x leaves beside the factor: X^-1 M = Xi^T (Xi M), three
 // block products.  They are independent column by column, and one compute unit issues them no faster than its four SIMDs
-// allow, so a block is split over MWI_ZS workgroups by column panels (eight lanes per entry, MW_PT threads); the panels go to
+// allow, so a block is split over MWI_ZS or more workgroups (panels of at most eight columns) by column panels (eight lanes per entry, MW_PT threads); the panels go to
 // a scratch matrix and the workgroup of a block that finishes last symmetrises it (a counter per block).
 #define MWI_ZS 4
 #define MWI_ZL 8
@@ -570,7 +570,7 @@ __global__ __launch_bounds__(MW_PT) void k_mwi_Zi(const MwDev q, const MwIpmDev 
     const MwBlk &k = q.blk[blockIdx.x];
     if (!k.inv) return;
     const int n = k.n, tid = threadIdx.x, sub = tid % MWI_ZL;
-    const int pc0 = (n + MWI_ZS - 1) / MWI_ZS, c0 = blockIdx.y * pc0, pc = max(0, min(pc0, n - c0));     // this workgroup's columns
+    const int zs = gridDim.y, pc0 = (n + zs - 1) / zs, c0 = blockIdx.y * pc0, pc = max(0, min(pc0, n - c0));     // this workgroup's columns
     const long np = (long)n * pc0;
     lds_d *M = MW_LDS, *M2 = M + (long)K * np;
     const double *A = (which == 0 ? p.Pm : p.dX) + k.xyoff, *Xi = q.Xi + k.xyoff;
@@ -608,7 +608,7 @@ __global__ __launch_bounds__(MW_PT) void k_mwi_Zi(const MwDev q, const MwIpmDev 
         const mw<K> v = lanes_sum<K, MWI_ZL>(acc_result<K>(s));
         if (live && sub == 0) stx<K>(p.Zs + k.xyoff, q.xylen, i + (long)(c0 + cl) * n, v);
     }
-    if (!mwi_last_block(&p.zcnt[blockIdx.x], MWI_ZS)) return;
+    if (!mwi_last_block(&p.zcnt[blockIdx.x], zs)) return;
     for (int e = tid; e < n * n; e += MW_PT) {
         const int i = e % n, c = e / n;
         if (c > i) continue;
@@ -810,6 +810,7 @@ struct MwIpm {
     int iter = 0;
     double *h_rec = nullptr;      // pinned
     size_t sm_Z = 0, sm_Zi = 0, sm_step = 0;
+    int zs = MWI_ZS;              // workgroups per block of k_mwi_Zi
     bool lds_ZL = false, step_w_lds = true, step_inv = false, y_with_x = false, any_xinv = false, any_xsub = false;
     ~MwIpm() { if (h_rec) (void)hipHostFree(h_rec); }
 };
@@ -880,7 +881,8 @@ extern "C" int clrs_mw_ipm_create_ex(clrs_mw_ctx *c, const clrs_ipm_data *data, 
             if (k.inv) { st->any_xinv = true; maxn_inv = std::max(maxn_inv, (size_t)k.n); }
             else st->any_xsub = true;
         }
-        st->sm_Zi = 2 * maxn_inv * ((maxn_inv + MWI_ZS - 1) / MWI_ZS) * K * 8;
+        st->zs = std::max<int>(MWI_ZS, (int)((maxn_inv + 7) / 8));
+        st->sm_Zi = 2 * maxn_inv * ((maxn_inv + st->zs - 1) / st->zs) * K * 8;
         const size_t step_inv_need = 3 * maxn_inv * maxn_inv * K + step_rest;
         bool all_lds_inv = st->any_xinv;
         for (auto &k : c->blk) all_lds_inv = all_lds_inv && k.inv == 1;
@@ -976,7 +978,7 @@ static int mw_ipm_direction(clrs_mw_ctx *c, int corrector) {
     int rc;
     MW_DISPATCH(c, {
         hipLaunchKernelGGL(k_mwi_R<KK>, dim3((maxnn * MWI_EW + MW_NT - 1) / MW_NT, q.NB), dim3(MW_NT), 0, c->stream, q, p, corrector);
-        if (st->any_xinv) hipLaunchKernelGGL(k_mwi_Zi<KK>, dim3(q.NB, MWI_ZS), dim3(MW_PT), st->sm_Zi, c->stream, q, p, 0);
+        if (st->any_xinv) hipLaunchKernelGGL(k_mwi_Zi<KK>, dim3(q.NB, st->zs), dim3(MW_PT), st->sm_Zi, c->stream, q, p, 0);
         if (st->any_xsub) hipLaunchKernelGGL(k_mwi_Z<KK>, dim3(q.NB), dim3(MW_NT), st->sm_Z, c->stream, q, p, 0, st->lds_ZL ? 1 : 0);
         if (q.nlr) hipLaunchKernelGGL((k_mwi_MV<KK, DD>), dim3((c->maxn * c->maxU * MWI_EW + MW_NT - 1) / MW_NT, q.nlr), dim3(MW_NT), 0, c->stream, q, (const double *)p.dY);
         if (q.dn_big) hipLaunchKernelGGL((k_mwi_rows_dn<KK, DD>), dim3((unsigned)((q.xlen + MW_NT / 64 - 1) / (MW_NT / 64))), dim3(MW_NT), 0, c->stream, q, p, 1);
@@ -987,7 +989,7 @@ static int mw_ipm_direction(clrs_mw_ctx *c, int corrector) {
     MW_DISPATCH(c, {
         if (q.T) hipLaunchKernelGGL((k_mwi_coef<KK, DD>), dim3((unsigned)((q.T + MW_NT - 1) / MW_NT)), dim3(MW_NT), 0, c->stream, q, p, (const double *)p.dx);
         hipLaunchKernelGGL((k_mwi_wA<KK, DD>), dim3((maxnn * MWI_EW + MW_NT - 1) / MW_NT, q.NB), dim3(MW_NT), 0, c->stream, q, p, 1);
-        if (st->any_xinv) hipLaunchKernelGGL(k_mwi_Zi<KK>, dim3(q.NB, MWI_ZS), dim3(MW_PT), st->sm_Zi, c->stream, q, p, 1);
+        if (st->any_xinv) hipLaunchKernelGGL(k_mwi_Zi<KK>, dim3(q.NB, st->zs), dim3(MW_PT), st->sm_Zi, c->stream, q, p, 1);
         if (st->any_xsub) hipLaunchKernelGGL(k_mwi_Z<KK>, dim3(q.NB), dim3(MW_NT), st->sm_Z, c->stream, q, p, 1, st->lds_ZL ? 1 : 0);
     });
     MWCHECK(hipGetLastError());
