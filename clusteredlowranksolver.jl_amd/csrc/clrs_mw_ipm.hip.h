@@ -812,7 +812,15 @@ struct MwIpm {
     size_t sm_Z = 0, sm_Zi = 0, sm_step = 0;
     int zs = MWI_ZS;              // workgroups per block of k_mwi_Zi
     bool lds_ZL = false, step_w_lds = true, step_inv = false, y_with_x = false, any_xinv = false, any_xsub = false;
-    ~MwIpm() { if (h_rec) (void)hipHostFree(h_rec); }
+    // side stream: mu, the residual P and the predictor's R depend on (x, X, Y) only and run beside the decomposition
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    ~MwIpm() {
+        if (h_rec) (void)hipHostFree(h_rec);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+        if (side) (void)hipStreamDestroy(side);
+    }
 };
 
 static void mw_ipm_free(clrs_mw_ctx *c) {
@@ -863,6 +871,9 @@ extern "C" int clrs_mw_ipm_create_ex(clrs_mw_ctx *c, const clrs_ipm_data *data, 
         if ((rc = mw_dmalloc(c, &dC, q.xylen * c->DK)) || (rc = mw_dmalloc(c, &dc, q.xlen * c->DK)) || (rc = mw_dmalloc(c, &db, (i64)N * c->DK))) return rc;
         p.C = dC; p.c = dc; p.b = db;
         MWCHECK(hipHostMalloc((void **)&st->h_rec, sizeof(double) * MREC_COUNT, hipHostMallocDefault));
+        MWCHECK(hipStreamCreateWithFlags(&st->side, hipStreamNonBlocking));
+        MWCHECK(hipEventCreateWithFlags(&st->ev_fork, hipEventDisableTiming));
+        MWCHECK(hipEventCreateWithFlags(&st->ev_join, hipEventDisableTiming));
         p.Ktot = 0;
         size_t maxn = 0;
         for (auto &k : c->blk) { p.Ktot += k.n; maxn = std::max(maxn, (size_t)k.n); }
@@ -970,14 +981,14 @@ extern "C" int clrs_mw_ipm_set(clrs_mw_ctx *c, const double *x, const double *y,
     return 0;
 }
 
-static int mw_ipm_direction(clrs_mw_ctx *c, int corrector) {
+static int mw_ipm_direction(clrs_mw_ctx *c, int corrector, bool r_done = false) {
     const MwDev &q = c->d;
     MwIpm *st = c->ipm;
     const MwIpmDev &p = st->d;
     const int maxnn = c->maxn * c->maxn;
     int rc;
     MW_DISPATCH(c, {
-        hipLaunchKernelGGL(k_mwi_R<KK>, dim3((maxnn * MWI_EW + MW_NT - 1) / MW_NT, q.NB), dim3(MW_NT), 0, c->stream, q, p, corrector);
+        if (!r_done) hipLaunchKernelGGL(k_mwi_R<KK>, dim3((maxnn * MWI_EW + MW_NT - 1) / MW_NT, q.NB), dim3(MW_NT), 0, c->stream, q, p, corrector);
         if (st->any_xinv) hipLaunchKernelGGL(k_mwi_Zi<KK>, dim3(q.NB, st->zs), dim3(MW_PT), st->sm_Zi, c->stream, q, p, 0);
         if (st->any_xsub) hipLaunchKernelGGL(k_mwi_Z<KK>, dim3(q.NB), dim3(MW_NT), st->sm_Z, c->stream, q, p, 0, st->lds_ZL ? 1 : 0);
         if (q.nlr) hipLaunchKernelGGL((k_mwi_MV<KK, DD>), dim3((c->maxn * c->maxU * MWI_EW + MW_NT - 1) / MW_NT, q.nlr), dim3(MW_NT), 0, c->stream, q, (const double *)p.dY);
@@ -1006,23 +1017,32 @@ extern "C" int clrs_mw_ipm_iterate(clrs_mw_ctx *c, clrs_ipm_record *out) {
     const size_t sm_red = (size_t)c->K * 8 * 8;
     int rc;
     st->iter++;
+    // fork: mu (dot products + scalar stage 0), P = sum x_i A_i - X -+ C and the predictor's R on the side stream, the decomposition
+    // (chol X [and chol Y^-1], assembly, factorisation) on the context's stream; joined before the residual d needs A_Y and the
+    // errors need both
+    MWCHECK(hipEventRecord(st->ev_fork, c->stream));
+    MWCHECK(hipStreamWaitEvent(st->side, st->ev_fork, 0));
     MW_DISPATCH(c, {
-        hipLaunchKernelGGL((k_mwi_dots<KK, DD>), dim3(q.NB), dim3(MW_NT), sm_red, c->stream, q, p, 1);
-        hipLaunchKernelGGL((k_mwi_scalar<KK, DD>), dim3(1), dim3(1), 0, c->stream, q, p, 0, st->iter);
+        hipLaunchKernelGGL((k_mwi_dots<KK, DD>), dim3(q.NB), dim3(MW_NT), sm_red, st->side, q, p, 1);
+        hipLaunchKernelGGL((k_mwi_scalar<KK, DD>), dim3(1), dim3(1), 0, st->side, q, p, 0, st->iter);
+        if (q.T) hipLaunchKernelGGL((k_mwi_coef<KK, DD>), dim3((unsigned)((q.T + MW_NT - 1) / MW_NT)), dim3(MW_NT), 0, st->side, q, p, (const double *)p.x);
+        hipLaunchKernelGGL((k_mwi_wA<KK, DD>), dim3((maxnn * MWI_EW + MW_NT - 1) / MW_NT, q.NB), dim3(MW_NT), 0, st->side, q, p, 0);
+        hipLaunchKernelGGL(k_mwi_R<KK>, dim3((maxnn * MWI_EW + MW_NT - 1) / MW_NT, q.NB), dim3(MW_NT), 0, st->side, q, p, 0);
     });
+    MWCHECK(hipGetLastError());
+    MWCHECK(hipEventRecord(st->ev_join, st->side));
     if ((rc = mw_cholesky_blocks_dev2(c, p.X, p.Xc, st->y_with_x ? p.Y : nullptr, p.Yi, p.yfail))) return rc;
     if ((rc = clrs_mw_schur_assemble_dev(c, p.Xc, p.Y))) return rc;
     if ((rc = clrs_mw_schur_factor_dev(c))) return rc;
+    MWCHECK(hipStreamWaitEvent(c->stream, st->ev_join, 0));
     MW_DISPATCH(c, {
-        if (q.T) hipLaunchKernelGGL((k_mwi_coef<KK, DD>), dim3((unsigned)((q.T + MW_NT - 1) / MW_NT)), dim3(MW_NT), 0, c->stream, q, p, (const double *)p.x);
-        hipLaunchKernelGGL((k_mwi_wA<KK, DD>), dim3((maxnn * MWI_EW + MW_NT - 1) / MW_NT, q.NB), dim3(MW_NT), 0, c->stream, q, p, 0);
         if (q.dn_big) hipLaunchKernelGGL((k_mwi_rows_dn<KK, DD>), dim3((unsigned)((q.xlen + MW_NT / 64 - 1) / (MW_NT / 64))), dim3(MW_NT), 0, c->stream, q, p, 0);
         hipLaunchKernelGGL((k_mwi_rows<KK, DD>), dim3((unsigned)((q.xlen * MWI_RW + MW_NT - 1) / MW_NT)), dim3(MW_NT), 0, c->stream, q, p, 0);
         if (q.N) hipLaunchKernelGGL((k_mwi_pv<KK, DD>), dim3((q.N + MW_NT / 8 - 1) / (MW_NT / 8)), dim3(MW_NT), 0, c->stream, q, p, st->iter);
         else hipLaunchKernelGGL((k_mwi_scalar<KK, DD>), dim3(1), dim3(64), 0, c->stream, q, p, 1, st->iter);
     });
     MWCHECK(hipGetLastError());
-    if ((rc = mw_ipm_direction(c, 0))) return rc;
+    if ((rc = mw_ipm_direction(c, 0, true))) return rc;
     MW_DISPATCH(c, {
         hipLaunchKernelGGL((k_mwi_dots<KK, DD>), dim3(q.NB), dim3(MW_NT), sm_red, c->stream, q, p, 2);
         hipLaunchKernelGGL((k_mwi_scalar<KK, DD>), dim3(1), dim3(1), 0, c->stream, q, p, 2, st->iter);
