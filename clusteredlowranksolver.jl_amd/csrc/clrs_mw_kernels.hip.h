@@ -541,7 +541,8 @@ __global__ __launch_bounds__(MW_NT) void k_mw_gram(const MwDev q) {
 // Dense ("high rank") block: T_e = X^-1 A_e Y for every matrix of the block, then the table Sd[e, e'] = <A_e', T_e>
 // (src/solver.jl:1089-1104).  k_mw_dense_t: one workgroup per (block, matrix) -- the matrices are independent -- with
 // X^-1 A = Xi^T (Xi A) as products when the inverse factor of the block exists and two buffers fit in LDS (`prod`), by the
-// two substitutions otherwise; n = 1 blocks take one thread per matrix.  k_mw_dense_s: one wave per pair (e, e') of the table.
+// two substitutions otherwise; n = 1 blocks take one thread per matrix and per pair in the same launch.  k_mw_dense_s (blocks
+// with n > 1): one wave per pair (e, e') of the table.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int K, int DK>
 __global__ __launch_bounds__(MW_NT) void k_mw_dense_t(const MwDev q, const double *__restrict__ Y, int use_inv, int two_buffers) {
@@ -556,6 +557,14 @@ __global__ __launch_bounds__(MW_NT) void k_mw_dense_t(const MwDev q, const doubl
         mw<K> rd = ldx<K>(q.xrd + k.rd_off, q.xrdlen, 0);
         mw<K> yx = mul<K>(ldx<K>(Y + k.xyoff, q.xylen, 0), mul<K>(rd, rd));      // Y / X
         for (int ee = tid; ee < cnt; ee += MW_NT) stx<K>(W, q.wlen, ee, mulx<K, K, DK>(yx, ldx<DK>(A, q.dAp, ee)));
+        __syncthreads();                                   // the table of a 1 x 1 block right here: one thread per pair
+        for (int o = tid; o < cnt * (cnt + 1) / 2; o += MW_NT) {
+            int e2, e1;
+            tri_index(o, e2, e1);
+            const mw<K> v = mulx<K, K, DK>(ldx<K>(W, q.wlen, e1), ldx<DK>(A, q.dAp, e2));
+            stx<K>(q.Sd + k.sd_off, q.sdlen, e1 + (long)e2 * cnt, v);
+            stx<K>(q.Sd + k.sd_off, q.sdlen, e2 + (long)e1 * cnt, v);
+        }
         return;
     }
     if (e >= cnt) return;
@@ -601,6 +610,7 @@ template <int K, int DK>
 __global__ __launch_bounds__(MW_NT) void k_mw_dense_s(const MwDev q) {
     using namespace mwk;
     const MwBlk &k = q.blk[q.dn_list[blockIdx.x]];
+    if (k.n == 1) return;                                  // done by k_mw_dense_t
     const int cnt = k.cnt, lane = threadIdx.x & 63;
     const int o = blockIdx.y * (MW_NT / 64) + (threadIdx.x >> 6);
     if (o >= cnt * (cnt + 1) / 2) return;                  // uniform over the wave
