@@ -186,17 +186,21 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str =
     `extra_flags` / `out` build a diagnostic variant (e.g. -DCLRS_FUSED_STAMPS) of the fp64 unit beside it."""
     hdr = os.path.join(_HERE, "..", "include", "clrs_hip.h")
     files = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".hip.h", ".inc", ".h")))
-    objs, rebuilt = [], False
+    objs, jobs = [], []
     for obj, src, flags, mine in _UNITS:
         o = os.path.join(CSRC, obj if out is None or src != "clrs_hip.hip" else os.path.basename(out) + ".o")
         deps = [os.path.join(CSRC, f) for f in files if mine(f)] + [hdr]
         diag = out is not None and src == "clrs_hip.hip"
         if force or diag or not os.path.exists(o) or any(os.path.getmtime(o) < os.path.getmtime(s) for s in deps):
-            _hipcc([*_COMMON, *flags, *(extra_flags if diag else ()), "-c", "-o", o, os.path.join(CSRC, src)])
-            rebuilt = True
-            if verbose:
-                print("compiled", src)
+            jobs.append((src, [*_COMMON, *flags, *(extra_flags if diag else ()), "-c", "-o", o, os.path.join(CSRC, src)]))
         objs.append(o)
+    rebuilt = bool(jobs)
+    if jobs:                                                # the units compile side by side (the multi-word one takes minutes)
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=len(jobs)) as pool:
+            for src, _ in zip((j[0] for j in jobs), pool.map(lambda j: _hipcc(j[1]), jobs)):
+                if verbose:
+                    print("compiled", src)
     target = out if out is not None else LIB_PATH
     if rebuilt or not os.path.exists(target) or any(os.path.getmtime(target) < os.path.getmtime(o) for o in objs):
         _hipcc(["--offload-arch=gfx950", "-fPIC", "-shared", "-o", target, *objs])

@@ -48,7 +48,7 @@ class OracleParams(C.Structure):
 
 def build(force: bool = False) -> None:
     """Compile the oracle shared libraries with the committed Makefile."""
-    libs = ("libclrs_oracle_f64.so", "libclrs_oracle_f128.so", "libclrs_oracle_mp.so")
+    libs = ("libclrs_oracle_f64.so", "libclrs_oracle_f128.so", "libclrs_oracle_mp.so", "libclrs_oracle_mp10.so")
     need = force or not all(os.path.exists(os.path.join(_HERE, f)) for f in libs)
     if not need:
         src = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("clrs_oracle.c", "clrs_oracle_mp.cpp", "mpx.hpp"))
@@ -61,10 +61,11 @@ _libs = {}
 
 
 MP_LIMB_BITS = 320   # mantissa bits of libclrs_oracle_mp.so (mpx<5>)
+MP10_LIMB_BITS = 640 # mantissa bits of libclrs_oracle_mp10.so (mpx<10>), the checker of the 6- and 8-limb GPU paths
 
 
 def _lib(quad):
-    key = "mp" if quad == "mp" else ("f128" if quad else "f64")
+    key = quad if quad in ("mp", "mp10") else ("f128" if quad else "f64")
     if key not in _libs:
         path = os.path.join(_HERE, f"libclrs_oracle_{key}.so")
         if not os.path.exists(path):
@@ -129,7 +130,7 @@ def _c(a, dt=np.float64):
 def real_op(op: str, a: np.ndarray, b: np.ndarray, mp_bits: int = MP_LIMB_BITS) -> np.ndarray:
     """One elementwise operation ('add', 'sub', 'mul', 'div', 'sqrt') of the multi-precision oracle's arithmetic on planar k-limb
     arrays of shape (k, n), truncated to `mp_bits` bits -- for unit tests of oracle/mpx.hpp."""
-    L = _lib("mp")
+    L = _lib("mp" if mp_bits <= MP_LIMB_BITS else "mp10")
     L.oracle_set_precision_bits(int(mp_bits))
     a, b = _c(a), _c(b)
     out = np.zeros_like(a)
@@ -140,7 +141,7 @@ def real_op(op: str, a: np.ndarray, b: np.ndarray, mp_bits: int = MP_LIMB_BITS) 
 class Oracle:
     """CPU oracle context for a FlatSDP.  `quad=True` computes in __float128 using the (hi, lo) inputs;
     `use_lo=False` forces the fp64-rounded problem data (what the HIP path sees) even in quad.
-    `mp_bits=p` computes in the multi-limb type of mpx.hpp truncated to p bits per operation (p <= 320; the stand-in for
+    `mp_bits=p` computes in the multi-limb type of mpx.hpp truncated to p bits per operation (p <= 320, or <= 640 with the mpx<10> build; the stand-in for
     the reference's Arb midpoints at `prec=p`).  The precision is a property of the loaded library, not of the
     context: it is re-applied by every method of a multi-precision context."""
 
@@ -148,9 +149,9 @@ class Oracle:
         self.flat = flat
         self.mp_bits = mp_bits
         if mp_bits is not None:
-            if not 1 <= mp_bits <= MP_LIMB_BITS:
-                raise ValueError("mp_bits must be within 1..%d" % MP_LIMB_BITS)
-            quad = "mp"
+            if not 1 <= mp_bits <= MP10_LIMB_BITS:
+                raise ValueError("mp_bits must be within 1..%d" % MP10_LIMB_BITS)
+            quad = "mp" if mp_bits <= MP_LIMB_BITS else "mp10"
         self.quad = quad
         self.L = _lib(quad)
         self._prec()

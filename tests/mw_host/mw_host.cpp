@@ -38,6 +38,7 @@ extern "C" int mw_host_op(int K, int op, long n, const double *a, const double *
     case 4: run<4>(op, n, a, b, c); return 0;
     case 5: run<5>(op, n, a, b, c); return 0;
     case 6: run<6>(op, n, a, b, c); return 0;
+    case 8: run<8>(op, n, a, b, c); return 0;
     }
     return -1;
 }
@@ -48,6 +49,7 @@ extern "C" int mw_host_dot(int K, long n, const double *a, const double *b, doub
     case 4: dot<4>(n, a, b, c); return 0;
     case 5: dot<5>(n, a, b, c); return 0;
     case 6: dot<6>(n, a, b, c); return 0;
+    case 8: dot<8>(n, a, b, c); return 0;
     }
     return -1;
 }

@@ -64,7 +64,7 @@ def call(lib, K, op, a, b):
     return c
 
 
-@pytest.mark.parametrize("K", [2, 3, 4, 5, 6])
+@pytest.mark.parametrize("K", [2, 3, 4, 5, 6, 8])
 def test_mw_operations_against_mpmath(lib, K):
     mp.mp.prec = 53 * K + 200
     rng = np.random.default_rng(K)
@@ -121,7 +121,7 @@ def test_mw_operations_against_mpmath(lib, K):
     print(K, {k: round(v, 3) for k, v in worst.items()})
 
 
-@pytest.mark.parametrize("K", [2, 4, 5])
+@pytest.mark.parametrize("K", [2, 4, 5, 8])
 def test_mw_dot_accumulator(lib, K):
     """Sum a_i b_i through the unnormalised accumulator: error relative to sum |a_i b_i|, including heavy cancellation."""
     mp.mp.prec = 53 * K + 200

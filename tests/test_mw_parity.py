@@ -37,10 +37,11 @@ def _sym_limbs(f, M):
 
 
 def tol(K, slack):
-    return 2.0 ** (-(53 * K - slack))
+    # an operation carries about 53 K - K bits: the slacks below were set at K <= 5; one more bit per limb beyond that
+    return 2.0 ** (-(53 * K - slack - max(0, K - 5)))
 
 
-@pytest.mark.parametrize("K,DL", [(2, 1), (2, 2), (3, 2), (4, 1), (4, 2), (5, 2)])
+@pytest.mark.parametrize("K,DL", [(2, 1), (2, 2), (3, 2), (4, 1), (4, 2), (5, 2), (6, 2), (8, 2)])
 @pytest.mark.parametrize("name", NAMES)
 def test_mw_assemble_factor_solve_match_oracle(name, K, DL, oracle_built):
     """K limbs per computed number; DL limbs of problem data (1: the fp64 roundings, 2: the (hi, lo) pairs of the FlatSDP)."""
@@ -48,10 +49,12 @@ def test_mw_assemble_factor_solve_match_oracle(name, K, DL, oracle_built):
     from oracle.oracle import Oracle
     if name in ("ns_8_15_2",) and K in (2, 3):
         pytest.skip("covered at K = 4, 5")
+    if K > 5 and name not in ("ce_8_15", "threepoint_4", "sdpa_small", "ns_8_15_2"):
+        pytest.skip("6 and 8 limbs (checked against the 640-bit build of the oracle): the north-star shapes, a mixed and a dense instance, the blocked path")
     f = flat(name)
     X, Y = _iterates(f, K)
     X, Y = _sym_limbs(f, X), _sym_limbs(f, Y)
-    o = Oracle(f, mp_bits=320, use_lo=(DL == 2))
+    o = Oracle(f, mp_bits=320 if K <= 5 else 640, use_lo=(DL == 2))
     ctx = MwSchurContext(f, limbs=K, data_limbs=DL)
     # Cholesky of the X blocks
     Xc = ctx.cholesky_blocks(X)
@@ -195,12 +198,29 @@ def test_fp64_rounded_problem_data_is_a_different_problem(oracle_built):
 
 
 def test_nsphere_packing_prec_300_instance(oracle_built):
-    """Nsphere_packing(8,15,[1/2,1/2],2) (test/runtests_solver.jl:21-22, prec = 300 there; 5 limbs = 262 bits here): 7 clusters,
-    m = 2 sub-blocks, P = 96; same pinned value."""
-    from clrs_amd.mw import solvesdp_mw
-    r = solvesdp_mw(flat("ns_8_15_2"), limbs=5)
-    assert r.error_code == 0, (r.status, r.error_code, r.iterations)
+    """Nsphere_packing(8,15,[1/2,1/2],2) (test/runtests_solver.jl:21-22) at the reference's prec = 300 -> 6 limbs (315 bits):
+    7 clusters, m = 2 sub-blocks, P = 96 (blocked path); same pinned value, and the same objective as the 5-limb solve."""
+    from clrs_amd.mw import solvesdp_mw, limbs_for_precision
+    assert limbs_for_precision(300) == 6 and limbs_for_precision(256) == 5 and limbs_for_precision(400) == 8
+    r = solvesdp_mw(flat("ns_8_15_2"), prec=300)
+    assert r.error_code == 0 and r.timings["limbs"] == 6, (r.status, r.error_code, r.iterations)
     assert abs(r.primal_objective - PI4_384) <= 1e-4, r.primal_objective
+    r5 = solvesdp_mw(flat("ns_8_15_2"), limbs=5)
+    assert r5.error_code == 0 and abs(r5.primal_objective - r.primal_objective) <= 1e-12
+
+
+def test_duality_gap_1e30_as_in_the_reference_rounding_test(oracle_built):
+    """test/runtests_solver.jl:90: three_point_spherical_codes(4, 1//6, -1, 4, prec=256, duality_gap_threshold=1e-30, omega=10^3)
+    -- the solve the reference rounds to the exact optimum 10.  5 limbs reach the 1e-30 gap; 8 limbs (420 bits) reach 1e-45 and
+    agree with the 5-limb solution to the accuracy of the latter."""
+    from clrs_amd.mw import solvesdp_mw
+    kw = dict(omega_p=1e3, omega_d=1e3)
+    r = solvesdp_mw(flat("threepoint_4"), prec=256, duality_gap_threshold=1e-30, **kw)
+    assert r.error_code == 0 and r.status == "Optimal" and r.duality_gap <= 1e-30, (r.status, r.duality_gap)
+    assert abs(r.primal_objective - 10.0) <= 1e-12
+    r8 = solvesdp_mw(flat("threepoint_4"), limbs=8, duality_gap_threshold=1e-45, primal_error_threshold=1e-50, dual_error_threshold=1e-50, **kw)
+    assert r8.error_code == 0 and r8.status == "Optimal" and r8.duality_gap <= 1e-45, (r8.status, r8.duality_gap)
+    assert abs(r8.primal_objective - 10.0) <= 1e-12
 
 
 @pytest.mark.parametrize("name,expected,tol_,kw", [
