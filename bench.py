@@ -236,6 +236,35 @@ def main():
         out["stage_us"] = {"schur_assemble": 1e6 * tm[0], "cholS_and_LinvB": 1e6 * tm[1], "Q": 1e6 * tm[3], "cholQ": 1e6 * tm[4], "one_solve": 1e6 * tm[5]}
         ctx.set_timing(False)
 
+        # ---- the same step at the other supported limb counts (the iterate truncated / zero-extended): precision against time ----
+        sweep = {str(K): ms_per_step}
+        for Kx in (4, 6, 8):
+            if Kx == K:
+                continue
+            cx = MwSchurContext(flat, limbs=Kx, device=local_rank)
+            cut = lambda a: np.ascontiguousarray(np.vstack([a[:min(K, Kx)], np.zeros((max(0, Kx - K), a.shape[1]))]))
+            eX, eY, erx, ery = (torch.tensor(cut(a), device=dev) for a in (X, Y, rx, ry))
+            eXc, edx, edy = torch.empty_like(eX), torch.empty_like(erx), torch.empty_like(ery)
+
+            def xstep():
+                cx.cholesky_blocks_dev(eX.data_ptr(), eXc.data_ptr())
+                cx.assemble_dev(eXc.data_ptr(), eY.data_ptr())
+                cx.factor_dev()
+                cx.solve_dev(erx.data_ptr(), ery.data_ptr(), edx.data_ptr(), edy.data_ptr())
+                cx.solve_dev(erx.data_ptr(), ery.data_ptr(), edx.data_ptr(), edy.data_ptr())
+            for _ in range(10):
+                xstep()
+            ok = cx.sync_status() == 0 and cx.sync_status_cholesky() == 0
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(100):
+                xstep()
+            cx.sync_status()
+            torch.cuda.synchronize()
+            sweep[str(Kx)] = 1e3 * (time.perf_counter() - t0) / 100 if ok else None
+            cx.close()
+        out["ms_per_step_by_limbs"] = dict(sorted(sweep.items(), key=lambda kv: int(kv[0])))
+
         # ---- CPU baseline: the multi-precision oracle on the same step, same iterate, bounded sample ----
         if not args.skip_cpu and world == 1:
             from oracle.oracle import Oracle
