@@ -175,7 +175,10 @@ def _hipcc(args):
 _UNITS = (
     ("clrs_hip.o", "clrs_hip.hip", (), lambda f: not f.startswith("clrs_mw")),
     # the multi-word (extended precision) path: error-free transformations must not be contracted into FMAs
-    ("clrs_mw.o", "clrs_mw.hip", ("-ffp-contract=off",), lambda f: f.startswith("clrs_mw")),
+    ("clrs_mw.o", "clrs_mw.hip", ("-ffp-contract=off", "-DMW_SPLIT_UNITS"), lambda f: f.startswith("clrs_mw")),
+    # the device code of the larger limb counts, one unit each (explicit instantiations: clrs_mw_inst.h), compiled side by side
+    *((f"clrs_mw_k{k}.o", "clrs_mw_inst.hip", ("-ffp-contract=off", f"-DMW_INST_K={k}"),
+       lambda f: f.startswith("clrs_mw") and f not in ("clrs_mw.hip", "clrs_mw_ipm_host.inc")) for k in (4, 5, 6, 8)),
 )
 _COMMON = ("--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value")
 

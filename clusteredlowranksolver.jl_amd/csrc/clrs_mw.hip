@@ -21,6 +21,14 @@
 
 #include "../../include/clrs_hip.h"
 #include "clrs_mw_kernels.hip.h"
+#include "clrs_mw_ipm.hip.h"
+#include "clrs_mw_inst.h"
+#ifdef MW_SPLIT_UNITS        // the kernels of these limb counts are compiled in units of their own (clrs_mw_inst.hip)
+MW_KERNELS_ALL(extern template, 4)
+MW_KERNELS_ALL(extern template, 5)
+MW_KERNELS_ALL(extern template, 6)
+MW_KERNELS_ALL(extern template, 8)
+#endif
 
 typedef long long i64;
 
@@ -821,16 +829,6 @@ extern "C" int clrs_mw_schur_solve(clrs_mw_ctx *c, const double *rhs_x, const do
     return 0;
 }
 
-// reciprocal diagonals of Cholesky factors passed in by the caller (clrs_mw_schur_assemble with host or foreign factors)
-template <int K>
-__global__ __launch_bounds__(MW_NT) void k_mw_xrd(const MwDev q, const double *__restrict__ Xc) {
-    using namespace mwk;
-    const MwBlk &k = q.blk[blockIdx.x];
-    for (int i = threadIdx.x; i < k.n; i += MW_NT) stx<K>(q.xrd + k.rd_off, q.xrdlen, i, recip<K>(ldx<K>(Xc + k.xyoff, q.xylen, i + (long)i * k.n)));
-    __threadfence_block();
-    __syncthreads();
-    wg_scaled_factors<K>(Xc + k.xyoff, q.xylen, k.n, q.xrd + k.rd_off, q.xrdlen, k.n, q.Xf + k.xyoff, q.xylen, k.n, q.Xb + k.xyoff, q.xylen, k.n, threadIdx.x);
-}
 static int mw_launch_xrd(clrs_mw_ctx *c, const double *d_Xc) {
     if (c->d.NB == 0) return 0;
     MW_DISPATCH(c, hipLaunchKernelGGL(k_mw_xrd<KK>, dim3(c->d.NB), dim3(MW_NT), 0, c->stream, c->d, d_Xc));
@@ -845,4 +843,4 @@ extern "C" int clrs_mw_set_xchol_dev(clrs_mw_ctx *c, const double *d_Xchol) {
     return mw_launch_xrd(c, d_Xchol);
 }
 
-#include "clrs_mw_ipm.hip.h"
+#include "clrs_mw_ipm_host.inc"

@@ -800,296 +800,3 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_init(const MwDev q, const MwIpmDe
         }
     }
 }
-
-// =====================================================================================================================
-// host
-// =====================================================================================================================
-struct MwIpm {
-    MwIpmDev d = {};
-    bool ready = false;
-    int iter = 0;
-    double *h_rec = nullptr;      // pinned
-    size_t sm_Z = 0, sm_Zi = 0, sm_step = 0;
-    int zs = MWI_ZS;              // workgroups per block of k_mwi_Zi
-    bool lds_ZL = false, step_w_lds = true, step_inv = false, y_with_x = false, any_xinv = false, any_xsub = false;
-    // side stream: mu, the residual P and the predictor's R depend on (x, X, Y) only and run beside the decomposition
-    hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    ~MwIpm() {
-        if (h_rec) (void)hipHostFree(h_rec);
-        if (ev_fork) (void)hipEventDestroy(ev_fork);
-        if (ev_join) (void)hipEventDestroy(ev_join);
-        if (side) (void)hipStreamDestroy(side);
-    }
-};
-
-static void mw_ipm_free(clrs_mw_ctx *c) {
-    delete c->ipm;
-    c->ipm = nullptr;
-}
-
-extern "C" int clrs_mw_ipm_create_ex(clrs_mw_ctx *c, const clrs_ipm_data *data, int data_limbs);
-extern "C" int clrs_mw_ipm_create(clrs_mw_ctx *c, const clrs_ipm_data *data) { return clrs_mw_ipm_create_ex(c, data, 1); }
-
-// data->C, c, b planar with `data_limbs` planes (at most the data limbs the context was created with)
-extern "C" int clrs_mw_ipm_create_ex(clrs_mw_ctx *c, const clrs_ipm_data *data, int data_limbs) {
-    if (!c || !data) return mw_fail(CLRS_ERR_INVALID, "null argument");
-    if (data_limbs < 1 || data_limbs > c->DK) return mw_fail(CLRS_ERR_INVALID, "data limbs of the objective exceed those of the context");
-    MWCHECK(hipSetDevice(c->device));
-    const MwDev &q = c->d;
-    const int K = c->K, N = q.N, NB = q.NB;
-    if (NB == 0) return mw_fail(CLRS_ERR_INVALID, "no PSD blocks");
-    if (!c->ipm) c->ipm = new MwIpm();
-    MwIpm *st = c->ipm;
-    MwIpmDev &p = st->d;
-    int rc;
-    if (!st->ready) {
-        double **xy[] = {&p.X, &p.Y, &p.dX, &p.dY, &p.R, &p.Xc, &p.Pm};
-        for (double **b : xy) if ((rc = mw_dmalloc(c, b, q.xylen * K))) return rc;
-        double **xs[] = {&p.x, &p.dx, &p.d, &p.rhsx};
-        for (double **b : xs) if ((rc = mw_dmalloc(c, b, q.xlen * K))) return rc;
-        double **ys[] = {&p.y, &p.dy, &p.pv};
-        for (double **b : ys) if ((rc = mw_dmalloc(c, b, (i64)N * K))) return rc;
-        if ((rc = mw_dmalloc(c, &p.coef, q.T * K)) || (rc = mw_dmalloc(c, &p.dtr, q.xlen * K))) return rc;
-        if ((rc = mw_dmalloc(c, &p.Yi, q.xylen * K)) || (rc = mw_dmalloc(c, &p.Zs, q.xylen * K))) return rc;
-        { double *t3 = nullptr; if ((rc = mw_dmalloc(c, &t3, (NB + 1) / 2 + 1))) return rc; p.zcnt = (int *)t3; }
-        { double *t2 = nullptr; if ((rc = mw_dmalloc(c, &t2, (NB + 1) / 2 + 1))) return rc; p.yfail = (int *)t2; }
-        if ((rc = mw_dmalloc(c, &p.sc, (i64)MSC_COUNT * K))) return rc;
-        if ((rc = mw_dmalloc(c, &p.part, 5LL * NB * K))) return rc;
-        if ((rc = mw_dmalloc(c, &p.eig, 2LL * NB))) return rc;
-        if ((rc = mw_dmalloc(c, &p.rec, MREC_COUNT))) return rc;
-        double *tmp = nullptr;
-        if ((rc = mw_dmalloc(c, &tmp, 4))) return rc;
-        p.fmax = (unsigned long long *)tmp;
-        if ((rc = mw_dmalloc(c, &tmp, 4))) return rc;
-        p.flags = (int *)tmp;
-        std::vector<int> row_clu((size_t)q.xlen);
-        for (int j = 0; j < q.J; j++)
-            for (int r = 0; r < c->clu[j].P; r++) row_clu[c->clu[j].coff + r] = j;
-        if ((rc = mw_upload(c, row_clu, &p.row_clu))) return rc;
-        double *dC, *dc, *db;
-        if ((rc = mw_dmalloc(c, &dC, q.xylen * c->DK)) || (rc = mw_dmalloc(c, &dc, q.xlen * c->DK)) || (rc = mw_dmalloc(c, &db, (i64)N * c->DK))) return rc;
-        p.C = dC; p.c = dc; p.b = db;
-        MWCHECK(hipHostMalloc((void **)&st->h_rec, sizeof(double) * MREC_COUNT, hipHostMallocDefault));
-        MWCHECK(hipStreamCreateWithFlags(&st->side, hipStreamNonBlocking));
-        MWCHECK(hipEventCreateWithFlags(&st->ev_fork, hipEventDisableTiming));
-        MWCHECK(hipEventCreateWithFlags(&st->ev_join, hipEventDisableTiming));
-        p.Ktot = 0;
-        size_t maxn = 0;
-        for (auto &k : c->blk) { p.Ktot += k.n; maxn = std::max(maxn, (size_t)k.n); }
-        const size_t lim = MW_LDS_MAX / sizeof(double), nnK = maxn * maxn * K;
-        if (nnK > lim) return mw_fail(CLRS_ERR_INVALID, "device-resident multi-word iteration needs PSD blocks that fit in LDS");
-        st->lds_ZL = 3 * nnK <= lim;
-        st->sm_Z = (st->lds_ZL ? 3 : 1) * nnK * 8;
-        const size_t step_rest = (size_t)K * maxn + maxn * maxn + 3 * maxn + 2 * MW_NT + MW_POTRF_SCR(K, maxn) + 8;
-        st->step_w_lds = 2 * nnK + step_rest <= lim;
-        const size_t stepd = (st->step_w_lds ? 2 : 1) * nnK + step_rest;
-        if (stepd > lim) return mw_fail(CLRS_ERR_INVALID, "device-resident multi-word iteration needs PSD blocks that fit in LDS");
-        st->sm_step = stepd * 8;
-        // blocks whose inverse factor exists (k_mw_potrf_x): products instead of substitutions in Z and in the step length
-        size_t maxn_inv = 0;
-        for (auto &k : c->blk) {
-            if (k.inv) { st->any_xinv = true; maxn_inv = std::max(maxn_inv, (size_t)k.n); }
-            else st->any_xsub = true;
-        }
-        st->zs = std::max<int>(MWI_ZS, (int)((maxn_inv + 7) / 8));
-        st->sm_Zi = 2 * maxn_inv * ((maxn_inv + st->zs - 1) / st->zs) * K * 8;
-        const size_t step_inv_need = 3 * maxn_inv * maxn_inv * K + step_rest;
-        bool all_lds_inv = st->any_xinv;
-        for (auto &k : c->blk) all_lds_inv = all_lds_inv && k.inv == 1;
-        st->step_inv = all_lds_inv && step_inv_need <= lim;      // the step length factors Y itself, everything in LDS
-        const size_t step_need2 = nnK + maxn * maxn + 3 * maxn + 2 * MW_NT + 8;
-        st->y_with_x = st->any_xinv && !st->any_xsub && step_need2 <= lim;      // every block has its inverse factor: chol(Y)^-1 rides on the chol(X) launch
-        if (st->step_inv) st->sm_step = std::max(st->sm_step, step_inv_need * 8);
-        if (st->y_with_x) st->sm_step = std::max(st->sm_step, step_need2 * 8);
-        MW_DISPATCH(c, {
-            if ((rc = mw_set_lds(k_mwi_Zi<KK>, st->sm_Zi))) return rc;
-            if ((rc = mw_set_lds(k_mwi_Z<KK>, st->sm_Z))) return rc;
-            if ((rc = mw_set_lds((k_mwi_step<KK, DD>), st->sm_step))) return rc;
-        });
-        // default parameters (src/solver.jl:103-126)
-        p.beta_infeasible = 0.3; p.beta_feasible = 0.1; p.gamma = 0.9; p.dual_thr = 1e-30; p.primal_thr = 1e-30;
-        p.max_gap = 1e100; p.step_thr = 1e-7; p.safe_step = 1;
-        st->ready = true;
-    }
-    // (re)load the objective data: a context may be reused for another right-hand side / objective
-    MWCHECK(hipMemset((void *)p.C, 0, sizeof(double) * q.xylen * c->DK));
-    MWCHECK(hipMemset((void *)p.c, 0, sizeof(double) * q.xlen * c->DK));
-    if (N) MWCHECK(hipMemset((void *)p.b, 0, sizeof(double) * N * c->DK));
-    MWCHECK(hipMemcpy((void *)p.C, data->C, sizeof(double) * q.xylen * data_limbs, hipMemcpyHostToDevice));
-    MWCHECK(hipMemcpy((void *)p.c, data->c, sizeof(double) * q.xlen * data_limbs, hipMemcpyHostToDevice));
-    if (N) MWCHECK(hipMemcpy((void *)p.b, data->b, sizeof(double) * N * data_limbs, hipMemcpyHostToDevice));
-    p.sgn = data->maximize ? 1.0 : -1.0;
-    p.constant = data->constant;
-    return 0;
-}
-
-extern "C" int clrs_mw_ipm_set_params(clrs_mw_ctx *c, const clrs_ipm_params *prm) {
-    if (!c || !prm || !c->ipm || !c->ipm->ready) return mw_fail(CLRS_ERR_STATE, "clrs_mw_ipm_create first");
-    MwIpmDev &p = c->ipm->d;
-    p.beta_infeasible = prm->beta_infeasible; p.beta_feasible = prm->beta_feasible; p.gamma = prm->gamma;
-    p.dual_thr = prm->dual_error_threshold; p.primal_thr = prm->primal_error_threshold; p.max_gap = prm->max_complementary_gap;
-    p.step_thr = prm->step_length_threshold; p.safe_step = prm->safe_step;
-    return 0;
-}
-
-static int mw_ipm_objectives(clrs_mw_ctx *c) {
-    const MwDev &q = c->d;
-    const MwIpmDev &p = c->ipm->d;
-    MW_DISPATCH(c, {
-        hipLaunchKernelGGL((k_mwi_dots<KK, DD>), dim3(q.NB), dim3(MW_NT), (size_t)KK * 8 * 8, c->stream, q, p, 4);
-        hipLaunchKernelGGL((k_mwi_scalar<KK, DD>), dim3(1), dim3(64), 0, c->stream, q, p, 4, c->ipm->iter);
-    });
-    MWCHECK(hipGetLastError());
-    return 0;
-}
-
-extern "C" int clrs_mw_ipm_init(clrs_mw_ctx *c, double omega_p, double omega_d) {
-    if (!c || !c->ipm || !c->ipm->ready) return mw_fail(CLRS_ERR_STATE, "clrs_mw_ipm_create first");
-    MWCHECK(hipSetDevice(c->device));
-    const MwDev &q = c->d;
-    MwIpm *st = c->ipm;
-    const MwIpmDev &p = st->d;
-    const int K = c->K;
-    MWCHECK(hipMemsetAsync(p.x, 0, sizeof(double) * q.xlen * K, c->stream));
-    if (q.N) MWCHECK(hipMemsetAsync(p.y, 0, sizeof(double) * q.N * K, c->stream));
-    MWCHECK(hipMemsetAsync(p.flags, 0, 4 * sizeof(double), c->stream));
-    MWCHECK(hipMemsetAsync(p.sc, 0, sizeof(double) * MSC_COUNT * K, c->stream));
-    MW_DISPATCH(c, hipLaunchKernelGGL(k_mwi_init<KK>, dim3(q.NB), dim3(MW_NT), 0, c->stream, q, p, omega_p, omega_d));
-    MWCHECK(hipGetLastError());
-    st->iter = 0;
-    int rc;
-    if ((rc = mw_ipm_objectives(c))) return rc;
-    MWCHECK(hipStreamSynchronize(c->stream));
-    return 0;
-}
-
-// warm start (dualsol / primalsol keywords, src/solver.jl:202-239): planar limbs; any pointer may be NULL (kept)
-extern "C" int clrs_mw_ipm_set(clrs_mw_ctx *c, const double *x, const double *y, const double *X, const double *Y) {
-    if (!c || !c->ipm || !c->ipm->ready) return mw_fail(CLRS_ERR_STATE, "clrs_mw_ipm_create first");
-    MWCHECK(hipSetDevice(c->device));
-    const MwDev &q = c->d;
-    const MwIpmDev &p = c->ipm->d;
-    const int K = c->K;
-    if (x) MWCHECK(hipMemcpy(p.x, x, sizeof(double) * q.xlen * K, hipMemcpyHostToDevice));
-    if (y && q.N) MWCHECK(hipMemcpy(p.y, y, sizeof(double) * q.N * K, hipMemcpyHostToDevice));
-    if (X) MWCHECK(hipMemcpy(p.X, X, sizeof(double) * q.xylen * K, hipMemcpyHostToDevice));
-    if (Y) MWCHECK(hipMemcpy(p.Y, Y, sizeof(double) * q.xylen * K, hipMemcpyHostToDevice));
-    int rc;
-    if ((rc = mw_ipm_objectives(c))) return rc;
-    MWCHECK(hipStreamSynchronize(c->stream));
-    return 0;
-}
-
-static int mw_ipm_direction(clrs_mw_ctx *c, int corrector, bool r_done = false) {
-    const MwDev &q = c->d;
-    MwIpm *st = c->ipm;
-    const MwIpmDev &p = st->d;
-    const int maxnn = c->maxn * c->maxn;
-    int rc;
-    MW_DISPATCH(c, {
-        if (!r_done) hipLaunchKernelGGL(k_mwi_R<KK>, dim3((maxnn * MWI_EW + MW_NT - 1) / MW_NT, q.NB), dim3(MW_NT), 0, c->stream, q, p, corrector);
-        if (st->any_xinv) hipLaunchKernelGGL(k_mwi_Zi<KK>, dim3(q.NB, st->zs), dim3(MW_PT), st->sm_Zi, c->stream, q, p, 0);
-        if (st->any_xsub) hipLaunchKernelGGL(k_mwi_Z<KK>, dim3(q.NB), dim3(MW_NT), st->sm_Z, c->stream, q, p, 0, st->lds_ZL ? 1 : 0);
-        if (q.nlr) hipLaunchKernelGGL((k_mwi_MV<KK, DD>), dim3((c->maxn * c->maxU * MWI_EW + MW_NT - 1) / MW_NT, q.nlr), dim3(MW_NT), 0, c->stream, q, (const double *)p.dY);
-        if (q.dn_big) hipLaunchKernelGGL((k_mwi_rows_dn<KK, DD>), dim3((unsigned)((q.xlen + MW_NT / 64 - 1) / (MW_NT / 64))), dim3(MW_NT), 0, c->stream, q, p, 1);
-        hipLaunchKernelGGL((k_mwi_rows<KK, DD>), dim3((unsigned)((q.xlen * MWI_RW + MW_NT - 1) / MW_NT)), dim3(MW_NT), 0, c->stream, q, p, 1);
-    });
-    MWCHECK(hipGetLastError());
-    if ((rc = clrs_mw_schur_solve_dev(c, p.rhsx, p.pv, p.dx, p.dy))) return rc;
-    MW_DISPATCH(c, {
-        if (q.T) hipLaunchKernelGGL((k_mwi_coef<KK, DD>), dim3((unsigned)((q.T + MW_NT - 1) / MW_NT)), dim3(MW_NT), 0, c->stream, q, p, (const double *)p.dx);
-        hipLaunchKernelGGL((k_mwi_wA<KK, DD>), dim3((maxnn * MWI_EW + MW_NT - 1) / MW_NT, q.NB), dim3(MW_NT), 0, c->stream, q, p, 1);
-        if (st->any_xinv) hipLaunchKernelGGL(k_mwi_Zi<KK>, dim3(q.NB, st->zs), dim3(MW_PT), st->sm_Zi, c->stream, q, p, 1);
-        if (st->any_xsub) hipLaunchKernelGGL(k_mwi_Z<KK>, dim3(q.NB), dim3(MW_NT), st->sm_Z, c->stream, q, p, 1, st->lds_ZL ? 1 : 0);
-    });
-    MWCHECK(hipGetLastError());
-    return 0;
-}
-
-extern "C" int clrs_mw_ipm_iterate(clrs_mw_ctx *c, clrs_ipm_record *out) {
-    if (!c || !out || !c->ipm || !c->ipm->ready) return mw_fail(CLRS_ERR_STATE, "clrs_mw_ipm_create first");
-    MWCHECK(hipSetDevice(c->device));
-    const MwDev &q = c->d;
-    MwIpm *st = c->ipm;
-    const MwIpmDev &p = st->d;
-    const int maxnn = c->maxn * c->maxn;
-    const size_t sm_red = (size_t)c->K * 8 * 8;
-    int rc;
-    st->iter++;
-    // fork: mu (dot products + scalar stage 0), P = sum x_i A_i - X -+ C and the predictor's R on the side stream, the decomposition
-    // (chol X [and chol Y^-1], assembly, factorisation) on the context's stream; joined before the residual d needs A_Y and the
-    // errors need both
-    MWCHECK(hipEventRecord(st->ev_fork, c->stream));
-    MWCHECK(hipStreamWaitEvent(st->side, st->ev_fork, 0));
-    MW_DISPATCH(c, {
-        hipLaunchKernelGGL((k_mwi_dots<KK, DD>), dim3(q.NB), dim3(MW_NT), sm_red, st->side, q, p, 1);
-        hipLaunchKernelGGL((k_mwi_scalar<KK, DD>), dim3(1), dim3(1), 0, st->side, q, p, 0, st->iter);
-        if (q.T) hipLaunchKernelGGL((k_mwi_coef<KK, DD>), dim3((unsigned)((q.T + MW_NT - 1) / MW_NT)), dim3(MW_NT), 0, st->side, q, p, (const double *)p.x);
-        hipLaunchKernelGGL((k_mwi_wA<KK, DD>), dim3((maxnn * MWI_EW + MW_NT - 1) / MW_NT, q.NB), dim3(MW_NT), 0, st->side, q, p, 0);
-        hipLaunchKernelGGL(k_mwi_R<KK>, dim3((maxnn * MWI_EW + MW_NT - 1) / MW_NT, q.NB), dim3(MW_NT), 0, st->side, q, p, 0);
-    });
-    MWCHECK(hipGetLastError());
-    MWCHECK(hipEventRecord(st->ev_join, st->side));
-    if ((rc = mw_cholesky_blocks_dev2(c, p.X, p.Xc, st->y_with_x ? p.Y : nullptr, p.Yi, p.yfail))) return rc;
-    if ((rc = clrs_mw_schur_assemble_dev(c, p.Xc, p.Y))) return rc;
-    if ((rc = clrs_mw_schur_factor_dev(c))) return rc;
-    MWCHECK(hipStreamWaitEvent(c->stream, st->ev_join, 0));
-    MW_DISPATCH(c, {
-        if (q.dn_big) hipLaunchKernelGGL((k_mwi_rows_dn<KK, DD>), dim3((unsigned)((q.xlen + MW_NT / 64 - 1) / (MW_NT / 64))), dim3(MW_NT), 0, c->stream, q, p, 0);
-        hipLaunchKernelGGL((k_mwi_rows<KK, DD>), dim3((unsigned)((q.xlen * MWI_RW + MW_NT - 1) / MW_NT)), dim3(MW_NT), 0, c->stream, q, p, 0);
-        if (q.N) hipLaunchKernelGGL((k_mwi_pv<KK, DD>), dim3((q.N + MW_NT / 8 - 1) / (MW_NT / 8)), dim3(MW_NT), 0, c->stream, q, p, st->iter);
-        else hipLaunchKernelGGL((k_mwi_scalar<KK, DD>), dim3(1), dim3(64), 0, c->stream, q, p, 1, st->iter);
-    });
-    MWCHECK(hipGetLastError());
-    if ((rc = mw_ipm_direction(c, 0, true))) return rc;
-    MW_DISPATCH(c, {
-        hipLaunchKernelGGL((k_mwi_dots<KK, DD>), dim3(q.NB), dim3(MW_NT), sm_red, c->stream, q, p, 2);
-        hipLaunchKernelGGL((k_mwi_scalar<KK, DD>), dim3(1), dim3(1), 0, c->stream, q, p, 2, st->iter);
-    });
-    if ((rc = mw_ipm_direction(c, 1))) return rc;
-    MW_DISPATCH(c, {
-        hipLaunchKernelGGL((k_mwi_step<KK, DD>), dim3(q.NB, 2), dim3(MW_NT), st->sm_step, c->stream, q, p, st->step_w_lds ? 1 : 0, st->y_with_x ? 2 : st->step_inv ? 1 : 0, st->iter);
-        hipLaunchKernelGGL(k_mwi_update<KK>, dim3((unsigned)std::min<i64>(1024, (q.xylen + q.xlen + q.N + MW_NT - 1) / MW_NT)), dim3(MW_NT), 0, c->stream, q, p);
-    });
-    MWCHECK(hipGetLastError());
-    if ((rc = mw_ipm_objectives(c))) return rc;
-    MWCHECK(hipMemcpyAsync(st->h_rec, p.rec, sizeof(double) * MREC_COUNT, hipMemcpyDeviceToHost, c->stream));
-    MWCHECK(hipStreamSynchronize(c->stream));
-    const double *r = st->h_rec;
-    out->iter = (int)r[MREC_ITER]; out->pd_feas = (int)r[MREC_PDFEAS]; out->error_code = (int)r[MREC_ERR];
-    out->factor_status = (int)r[MREC_FSTAT]; out->cholesky_status = (int)r[MREC_XSTAT]; out->reserved = 0;
-    out->mu = r[MREC_MU]; out->d_obj = r[MREC_DOBJ]; out->p_obj = r[MREC_POBJ]; out->gap = r[MREC_GAP];
-    out->dual_error = r[MREC_DERR]; out->primal_error = r[MREC_PERR]; out->alpha_d = r[MREC_AD]; out->alpha_p = r[MREC_AP];
-    out->beta_c = r[MREC_BETA]; out->max_P = r[MREC_MAXP]; out->max_p = r[MREC_MAXp]; out->max_d = r[MREC_MAXd];
-    return 0;
-}
-
-extern "C" int clrs_mw_ipm_get(clrs_mw_ctx *c, double *x, double *y, double *X, double *Y) {
-    if (!c || !c->ipm || !c->ipm->ready) return mw_fail(CLRS_ERR_STATE, "clrs_mw_ipm_create first");
-    MWCHECK(hipSetDevice(c->device));
-    MWCHECK(hipStreamSynchronize(c->stream));
-    const MwDev &q = c->d;
-    const MwIpmDev &p = c->ipm->d;
-    const int K = c->K;
-    if (x) MWCHECK(hipMemcpy(x, p.x, sizeof(double) * q.xlen * K, hipMemcpyDeviceToHost));
-    if (y && q.N) MWCHECK(hipMemcpy(y, p.y, sizeof(double) * q.N * K, hipMemcpyDeviceToHost));
-    if (X) MWCHECK(hipMemcpy(X, p.X, sizeof(double) * q.xylen * K, hipMemcpyDeviceToHost));
-    if (Y) MWCHECK(hipMemcpy(Y, p.Y, sizeof(double) * q.xylen * K, hipMemcpyDeviceToHost));
-    return 0;
-}
-// objectives and gap of the current iterate, K limbs each: out[0..K-1] d_obj, [K..2K-1] p_obj, [2K..3K-1] gap
-extern "C" int clrs_mw_ipm_objectives(clrs_mw_ctx *c, double *out) {
-    if (!c || !out || !c->ipm || !c->ipm->ready) return mw_fail(CLRS_ERR_STATE, "clrs_mw_ipm_create first");
-    MWCHECK(hipSetDevice(c->device));
-    MWCHECK(hipStreamSynchronize(c->stream));
-    const int K = c->K;
-    std::vector<double> h((size_t)MSC_COUNT * K);
-    MWCHECK(hipMemcpy(h.data(), c->ipm->d.sc, h.size() * sizeof(double), hipMemcpyDeviceToHost));
-    for (int l = 0; l < K; l++) {
-        out[l] = h[(size_t)l * MSC_COUNT + MSC_DOBJ];
-        out[K + l] = h[(size_t)l * MSC_COUNT + MSC_POBJ];
-        out[2 * K + l] = h[(size_t)l * MSC_COUNT + MSC_GAP];
-    }
-    return 0;
-}

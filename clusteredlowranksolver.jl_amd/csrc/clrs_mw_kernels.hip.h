@@ -1058,4 +1058,15 @@ __global__ __launch_bounds__(MW_NT) void k_mw_solve_bwd(const MwDev q, const dou
     }
 }
 
+// reciprocal diagonals of Cholesky factors passed in by the caller (clrs_mw_schur_assemble with host or foreign factors)
+template <int K>
+__global__ __launch_bounds__(MW_NT) void k_mw_xrd(const MwDev q, const double *__restrict__ Xc) {
+    using namespace mwk;
+    const MwBlk &k = q.blk[blockIdx.x];
+    for (int i = threadIdx.x; i < k.n; i += MW_NT) stx<K>(q.xrd + k.rd_off, q.xrdlen, i, recip<K>(ldx<K>(Xc + k.xyoff, q.xylen, i + (long)i * k.n)));
+    __threadfence_block();
+    __syncthreads();
+    wg_scaled_factors<K>(Xc + k.xyoff, q.xylen, k.n, q.xrd + k.rd_off, q.xrdlen, k.n, q.Xf + k.xyoff, q.xylen, k.n, q.Xb + k.xyoff, q.xylen, k.n, threadIdx.x);
+}
+
 #endif
