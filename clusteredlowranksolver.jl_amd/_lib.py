@@ -178,7 +178,9 @@ _UNITS = (
     ("clrs_mw.o", "clrs_mw.hip", ("-ffp-contract=off", "-DMW_SPLIT_UNITS"), lambda f: f.startswith("clrs_mw")),
     # the device code of the larger limb counts, one unit each (explicit instantiations: clrs_mw_inst.h), compiled side by side
     *((f"clrs_mw_k{k}.o", "clrs_mw_inst.hip", ("-ffp-contract=off", f"-DMW_INST_K={k}"),
-       lambda f: f.startswith("clrs_mw") and f not in ("clrs_mw.hip", "clrs_mw_ipm_host.inc")) for k in (4, 5, 6, 8)),
+       lambda f: f.startswith("clrs_mw") and f not in ("clrs_mw.hip", "clrs_mw_ipm_host.inc")) for k in (4, 5, 6)),
+    *((f"clrs_mw_k{k}p{part}.o", "clrs_mw_inst.hip", ("-ffp-contract=off", f"-DMW_INST_K={k}", f"-DMW_INST_PART={part}"),
+       lambda f: f.startswith("clrs_mw") and f not in ("clrs_mw.hip", "clrs_mw_ipm_host.inc")) for k in (8,) for part in (1, 2, 3)),
 )
 _COMMON = ("--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value")
 

@@ -436,6 +436,7 @@ extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int dev
         int init[2] = {MW_INFO_NONE, MW_INFO_NONE};
         MWCHECK(hipMemcpy(info, init, sizeof(init), hipMemcpyHostToDevice));
     }
+    const int MW_PB = MW_PB_OF(K);
     c->sm_bp_diag = ((size_t)MW_POTRF_SCR(K, MW_PB) + 2 * (size_t)K * MW_PB * MW_PB + (size_t)K * MW_PB) * 8;
     c->sm_bp_panel = (size_t)K * MW_BP_PR * MW_PB * 8;
     c->sm_bp_inv = (size_t)K * MW_PB * MW_BP_IC * 8;
@@ -609,6 +610,7 @@ extern "C" double *clrs_mw_u_gather_dev(clrs_mw_ctx *c) { return c ? c->d.ug : n
 // blocked Cholesky and inverse factor of one matrix in global memory over many workgroups (clrs_mw_kernels.hip.h, k_mw_bp_*)
 static int mw_potrf_blocked(clrs_mw_ctx *c, const MwBp &m) {
     const MwDev &q = c->d;
+    const int MW_PB = MW_PB_OF(c->K);
     const int nbk = (m.n + MW_PB - 1) / MW_PB;
     MW_DISPATCH(c, {
         for (int j0 = 0; j0 < m.n; j0 += MW_PB) {

@@ -10,4 +10,15 @@
 #ifndef MW_INST_K
 #define MW_INST_K 5          // the build (clusteredlowranksolver.jl_amd/_lib.py) compiles this unit once per limb count 4, 5, 6, 8
 #endif
+#ifndef MW_INST_PART
+#define MW_INST_PART 0       // 0: every kernel of this limb count; 1 / 2 / 3: those without data limbs / with 1 / with 2 (the largest counts are split further)
+#endif
+#if MW_INST_PART == 0
 MW_KERNELS_ALL(template, MW_INST_K)
+#elif MW_INST_PART == 1
+MW_KERNELS_K(template, MW_INST_K)
+#elif MW_INST_PART == 2
+MW_KERNELS_KD(template, MW_INST_K, 1)
+#else
+MW_KERNELS_KD(template, MW_INST_K, 2)
+#endif

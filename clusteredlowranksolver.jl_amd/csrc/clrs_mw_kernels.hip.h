@@ -828,7 +828,7 @@ __global__ __launch_bounds__(MW_NT) void k_mw_qsum(const MwDev q) {
 //   k_mw_bp_finish zero strict upper triangle of L.
 // With L^-1 explicit, LinvB and every solve of a large cluster are products over many lanes, like those of a small one.
 // ---------------------------------------------------------------------------------------------------------------------
-#define MW_PB 32
+#define MW_PB_OF(K) ((K) <= 8 ? 32 : 16)     // panel width: two MW_PB x MW_PB matrices of K limbs must fit in LDS (k_mw_bp_diag)
 #define MW_BP_PR 8           // rows of the panel per workgroup
 #define MW_BP_IC 4           // columns of an inverse block per workgroup
 struct MwBp {                // one matrix being factored: planar M and its inverse factor Mi (same plane length and leading dimension), reciprocal diagonal rd
@@ -839,6 +839,7 @@ struct MwBp {                // one matrix being factored: planar M and its inve
 template <int K>
 __global__ __launch_bounds__(MW_PT) void k_mw_bp_diag(const MwDev q, const MwBp m, int j0) {
     using namespace mwk;
+    constexpr int MW_PB = MW_PB_OF(K);
     if (q.info[m.which] != MW_INFO_NONE) return;
     const int nb = min(MW_PB, m.n - j0), tid = threadIdx.x;
     lds_d *scr = MW_LDS, *D = MW_LDS + MW_POTRF_SCR(K, MW_PB), *W = D + (long)K * MW_PB * MW_PB, *rdl = W + (long)K * MW_PB * MW_PB;
@@ -860,6 +861,7 @@ __global__ __launch_bounds__(MW_PT) void k_mw_bp_diag(const MwDev q, const MwBp 
 template <int K>
 __global__ __launch_bounds__(MW_PT) void k_mw_bp_panel(const MwDev q, const MwBp m, int j0) {
     using namespace mwk;
+    constexpr int MW_PB = MW_PB_OF(K);
     if (q.info[m.which] != MW_INFO_NONE) return;
     const int nb = min(MW_PB, m.n - j0), tid = threadIdx.x;
     const int r0 = j0 + nb + blockIdx.x * MW_BP_PR;
@@ -888,6 +890,7 @@ __global__ __launch_bounds__(MW_PT) void k_mw_bp_panel(const MwDev q, const MwBp
 template <int K>
 __global__ __launch_bounds__(MW_NT) void k_mw_bp_syrk(const MwDev q, const MwBp m, int j0) {
     using namespace mwk;
+    constexpr int MW_PB = MW_PB_OF(K);
     if (q.info[m.which] != MW_INFO_NONE) return;
     const int nb = min(MW_PB, m.n - j0), t0 = j0 + nb, mm = m.n - t0;
     const long e = (long)blockIdx.x * MW_NT + threadIdx.x;
@@ -906,6 +909,7 @@ __global__ __launch_bounds__(MW_NT) void k_mw_bp_syrk(const MwDev q, const MwBp 
 template <int K>
 __global__ __launch_bounds__(MW_PT) void k_mw_bp_inv(const MwDev q, const MwBp m, int d) {
     using namespace mwk;
+    constexpr int MW_PB = MW_PB_OF(K);
     if (q.info[m.which] != MW_INFO_NONE) return;
     const int bi = blockIdx.x, bj = bi + d, tid = threadIdx.x;
     const int ci0 = bi * MW_PB, ni = min(MW_PB, m.n - ci0), rj0 = bj * MW_PB, nj = min(MW_PB, m.n - rj0);
@@ -939,6 +943,7 @@ __global__ __launch_bounds__(MW_PT) void k_mw_bp_inv(const MwDev q, const MwBp m
 template <int K>
 __global__ __launch_bounds__(MW_NT) void k_mw_bp_finish(const MwDev q, const MwBp m) {
     using namespace mwk;
+    constexpr int MW_PB = MW_PB_OF(K);
     if (q.info[m.which] != MW_INFO_NONE) return;
     const long nn = (long)m.n * m.n;
     for (long e = (long)blockIdx.x * MW_NT + threadIdx.x; e < nn; e += (long)gridDim.x * MW_NT) {

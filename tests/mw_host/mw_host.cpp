@@ -39,6 +39,7 @@ extern "C" int mw_host_op(int K, int op, long n, const double *a, const double *
     case 5: run<5>(op, n, a, b, c); return 0;
     case 6: run<6>(op, n, a, b, c); return 0;
     case 8: run<8>(op, n, a, b, c); return 0;
+    case 10: run<10>(op, n, a, b, c); return 0;
     }
     return -1;
 }
@@ -50,6 +51,7 @@ extern "C" int mw_host_dot(int K, long n, const double *a, const double *b, doub
     case 5: dot<5>(n, a, b, c); return 0;
     case 6: dot<6>(n, a, b, c); return 0;
     case 8: dot<8>(n, a, b, c); return 0;
+    case 10: dot<10>(n, a, b, c); return 0;
     }
     return -1;
 }

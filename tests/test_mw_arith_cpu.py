@@ -64,7 +64,7 @@ def call(lib, K, op, a, b):
     return c
 
 
-@pytest.mark.parametrize("K", [2, 3, 4, 5, 6, 8])
+@pytest.mark.parametrize("K", [2, 3, 4, 5, 6, 8, 10])
 def test_mw_operations_against_mpmath(lib, K):
     mp.mp.prec = 53 * K + 200
     rng = np.random.default_rng(K)
