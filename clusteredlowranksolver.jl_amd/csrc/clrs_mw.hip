@@ -92,6 +92,7 @@ struct clrs_mw_ctx {
     int maxU = 0, maxP = 0, maxn = 0;
     bool xinv_valid = false;            // Xi holds the inverses of the current Cholesky factors (they come from k_mw_potrf_x, not from the caller)
     bool lds_x = false, lds_q = false, lds_zt_L = false, dense_two = false;
+    int nw_factor = 1;                  // workgroups per cluster in k_mw_factor (they share out the columns of the inverse factor)
     int maxcnt = 0;
     size_t sm_x = 0, sm_zt = 0, sm_dense = 0, sm_factor = 0, sm_q = 0, sm_fwd = 0, sm_mid = 0, sm_bwd = 0;
     int *h_info = nullptr;               // pinned
@@ -358,6 +359,7 @@ extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int dev
             if (q.lds) fmax = std::max(fmax, need);
         }
         c->sm_factor = std::max<size_t>(fmax, 1) * 8;
+        c->nw_factor = std::max(1, std::min(MW_INV_WG, 256 / std::max(J, 1)));     // only while the clusters leave compute units idle
         c->sm_fwd = c->sm_bwd = 2 * (size_t)c->maxP * K * 8;
         const size_t qn = (size_t)N * N * K;
         c->lds_q = 2 * qn + MW_POTRF_SCR(K, (size_t)N) <= lim;
@@ -435,6 +437,11 @@ extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int dev
         q.info = info;
         int init[2] = {MW_INFO_NONE, MW_INFO_NONE};
         MWCHECK(hipMemcpy(info, init, sizeof(init), hipMemcpyHostToDevice));
+        int *pc = nullptr;
+        MWCHECK(hipMalloc((void **)&pc, (size_t)(J + 2) * sizeof(int)));
+        c->allocs.push_back(pc);
+        MWCHECK(hipMemset(pc, 0, (size_t)(J + 2) * sizeof(int)));
+        q.pcnt = pc;
     }
     const int MW_PB = MW_PB_OF(K);
     c->sm_bp_diag = ((size_t)MW_POTRF_SCR(K, MW_PB) + 2 * (size_t)K * MW_PB * MW_PB + (size_t)K * MW_PB) * 8;
@@ -615,7 +622,7 @@ static int mw_potrf_blocked(clrs_mw_ctx *c, const MwBp &m) {
     MW_DISPATCH(c, {
         for (int j0 = 0; j0 < m.n; j0 += MW_PB) {
             const int nb = std::min(MW_PB, m.n - j0), mm = m.n - j0 - nb;
-            hipLaunchKernelGGL(k_mw_bp_diag<KK>, dim3(1), dim3(MW_PT), c->sm_bp_diag, c->stream, q, m, j0);
+            hipLaunchKernelGGL(k_mw_bp_diag<KK>, dim3(MW_INV_WG), dim3(MW_PT), c->sm_bp_diag, c->stream, q, m, j0);
             if (mm > 0) {
                 hipLaunchKernelGGL(k_mw_bp_panel<KK>, dim3((mm + MW_BP_PR - 1) / MW_BP_PR), dim3(MW_PT), c->sm_bp_panel, c->stream, q, m, j0);
                 hipLaunchKernelGGL(k_mw_bp_syrk<KK>, dim3((unsigned)(((i64)mm * (mm + 1) / 2 + MW_NT - 1) / MW_NT)), dim3(MW_NT), 0, c->stream, q, m, j0);
@@ -638,7 +645,7 @@ extern "C" int clrs_mw_schur_factor_local_dev(clrs_mw_ctx *c) {
     int rc;
     if ((rc = mw_reset_info(c, 0))) return rc;
     if (c->timing) MWCHECK(hipEventRecord(c->ev[2], c->stream));
-    MW_DISPATCH(c, { hipLaunchKernelGGL(k_mw_factor<KK>, dim3(q.J), dim3(MW_PT), c->sm_factor, c->stream, q); });
+    MW_DISPATCH(c, { hipLaunchKernelGGL(k_mw_factor<KK>, dim3(q.J, c->nw_factor), dim3(MW_PT), c->sm_factor, c->stream, q); });
     for (int j = 0; j < q.J; j++) {                     // clusters that do not fit in LDS: blocked over many workgroups
         const MwClu &cl = c->clu[j];
         if (cl.lds) continue;
@@ -664,7 +671,7 @@ extern "C" int clrs_mw_schur_factor_finish_dev(clrs_mw_ctx *c) {
     MWCHECK(hipSetDevice(c->device));
     const MwDev &q = c->d;
     if (q.N > 0 && c->lds_q) {
-        MW_DISPATCH(c, { hipLaunchKernelGGL(k_mw_potrf_q<KK>, dim3(1), dim3(MW_PT), c->sm_q, c->stream, q); });
+        MW_DISPATCH(c, { hipLaunchKernelGGL(k_mw_potrf_q<KK>, dim3(MW_INV_WG), dim3(MW_PT), c->sm_q, c->stream, q); });
     } else if (q.N > 0) {
         MW_DISPATCH(c, { hipLaunchKernelGGL(k_mw_qsum<KK>, dim3((unsigned)std::min<i64>(256, ((i64)q.N * q.N + MW_NT - 1) / MW_NT)), dim3(MW_NT), 0, c->stream, q); });
         MwBp m = {q.Q, q.Qi, q.qrd, (i64)q.N * q.N, (i64)q.N, q.N, q.N, q.J + 1, 0};

@@ -164,19 +164,7 @@ __device__ mwa::mw<K> mwi_sum_part(const MwDev &q, const MwIpmDev &p, int slot) 
 // finishes last (a counter in flags[4]; every workgroup publishes its results with a fence before it counts itself) executes
 // the stage.  (The stages behind the block dot products stay separate launches: the fences cost those kernels more than the
 // launch saves -- measured 31 us against 10 + 9.5.)  `mwi_last_block` is uniform over the workgroup.
-__device__ __forceinline__ bool mwi_last_block(int *counter, unsigned total) {
-    __shared__ int last;
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned old = atomicAdd((unsigned *)counter, 1u);
-        last = (old == total - 1) ? 1 : 0;
-        if (last) *counter = 0;
-    }
-    __syncthreads();
-    if (last) __threadfence();
-    return last != 0;
-}
+__device__ __forceinline__ bool mwi_last_block(int *counter, unsigned total) { return mwk::wg_last_block(counter, total); }
 // called by the first wave of a workgroup (threadIdx.x < 64); stages 0-3 use its first lane only
 template <int K, int DK>
 __device__ void mwi_scalar_stage(const MwDev &q, const MwIpmDev &p, int stage, int iter) {

@@ -25,6 +25,7 @@
 #define MW_PT 512            // threads per workgroup of k_mw_potrf_x, k_mw_factor, k_mw_potrf_q: one wave on the dependent chain, seven behind it
 #define MW_CT 8              // columns of V per workgroup in k_mw_zt
 #define MW_INFO_NONE 0x7f7f7f7f
+#define MW_INV_WG 4          // workgroups that share the columns of an inverse factor (k_mw_factor, k_mw_potrf_q, k_mw_bp_diag)
 
 typedef long long mwi64;
 
@@ -77,6 +78,7 @@ struct MwDev {
     double *Xi;                         // chol(X_b)^-1 of the blocks with inv = 1 (xy layout)
     double *t, *u, *AY;                 // t = L^-1 rhs_x (xlen); u slabs (J x N); pairings per term
     int *info;                          // [0] factor status, [1] Cholesky-of-X status
+    int *pcnt;                          // [J + 2] arrival counters of the workgroups that share one factorisation (cluster j; J: Q; J + 1: blocked path)
     // cluster sharding over ranks (one process per GPU): this context holds the clusters of rank `rank`; the partial Q and the
     // partial u of every rank are gathered into world slots and summed in rank order by every rank (src/solver.jl:1268-1269, 1550-1553)
     int rank, world, gathered, pad3;    // gathered: u comes from the gather slots (world > 1, or a communicator is attached)
@@ -149,8 +151,12 @@ __device__ __forceinline__ void pivot_scale(double head, double &p1, double &ph)
 // With UT (default: without INV) the strict upper triangle of M is left holding U^T (u_ik = a~_ik / d~_k, the column-scaled
 // factor of the backward substitutions); with INV the triangular solves are products with W and U is formed only on request.
 // `scr`: LDS, MW_POTRF_SCR(K, n) doubles.
+// `cw`, `cnw`: this workgroup forms the columns c = cw (mod cnw) of W only.  The elimination of M cannot be split without
+// exchanging pivot columns, but the columns of W are independent of each other given M's: cnw workgroups that each repeat
+// the elimination of M (bit for bit the same) and share out the columns of W finish in the time of M plus a cnw-th of W.
 template <int K, bool INV, int NT = MW_NT, bool UT = !INV, class PM, class PR, class PW>
-__device__ __forceinline__ bool wg_potrf(PM M, long plane, int n, int ld, PR rd, long rdplane, PW W, long wplane, int ldw, lds_d *scr, int tid) {
+__device__ __forceinline__ bool wg_potrf(PM M, long plane, int n, int ld, PR rd, long rdplane, PW W, long wplane, int ldw, lds_d *scr, int tid, int cw = 0,
+                                         int cnw = 1) {
     if (INV) {
         for (int e = tid; e < n * n; e += NT) {
             const int i = e % n, c = e / n;
@@ -158,8 +164,9 @@ __device__ __forceinline__ bool wg_potrf(PM M, long plane, int n, int ld, PR rd,
         }
         __syncthreads();
     }
+    lds_d *fs = scr, *us = scr + (long)K * n;                           // us holds s_k until the pivot's post-processing replaces it
     mw<K> srun = from_double<K>(1.0);                                   // s_k, carried by the last thread (idle in most tail rounds)
-    if (tid == NT - 1) stx<K>(rd, rdplane, 0, srun);
+    if (tid == NT - 1) stx<K>(us, n, 0, srun);
     for (int k = 0; k < n; k++) {
 #ifdef MW_STAMPS
         if (tid == 0 && k > 0) g_stamps[k] = wall_clock64();
@@ -170,14 +177,15 @@ __device__ __forceinline__ bool wg_potrf(PM M, long plane, int n, int ld, PR rd,
             double p1, ph;
             pivot_scale(d.l[0], p1, ph);
             const mw<K> dh = mul_pow2<K>(d, p1);
-            const int m = n - k - 1, base = (k + 1) * (k + 2) / 2;
-            const int total = INV ? n * (n + 1) / 2 - base : m * (m + 1) / 2;    // INV: rows k+1.., columns 0..i of [W | M]; else the trailing triangle
+            const int m = n - k - 1, trail = m * (m + 1) / 2;                    // the trailing triangle of M ...
+            const int wcols = !INV || k < cw ? 0 : (k - cw) / cnw + 1;           // ... and rows k+1.. of this workgroup's columns <= k of W
+            const int total = trail + m * wcols;
             for (int e = tid; e < total; e += NT) {
                 int i, c;
-                if (INV) tri_index(e + base, i, c);
-                else { tri_index(e, i, c); i += k + 1; c += k + 1; }
+                const bool tr = e < trail;
+                if (tr) { tri_index(e, i, c); i += k + 1; c += k + 1; }
+                else { const int e2 = e - trail; i = k + 1 + e2 % m; c = cw + cnw * (e2 / m); }
                 const mw<K> ci = mul_pow2<K>(ldx<K>(M, plane, i + (long)k * ld), ph);
-                const bool tr = !INV || c > k;
                 const mw<K> cj = mul_pow2<K>(tr ? ldx<K>(M, plane, c + (long)k * ld) : ldx<K>(W, wplane, k + (long)c * ldw), ph);
                 const mw<K> v = tr ? ldx<K>(M, plane, i + (long)c * ld) : ldx<K>(W, wplane, i + (long)c * ldw);
                 acc<K> s;
@@ -190,13 +198,12 @@ __device__ __forceinline__ bool wg_potrf(PM M, long plane, int n, int ld, PR rd,
             }
             if (tid == NT - 1) {
                 srun = mul<K>(srun, dh);
-                stx<K>(rd, rdplane, k + 1, srun);
+                stx<K>(us, n, k + 1, srun);
                 if (INV) stx<K>(W, wplane, (k + 1) + (long)(k + 1) * ldw, srun);
             }
         }
         __syncthreads();
     }
-    lds_d *fs = scr, *us = scr + (long)K * n;
 #ifdef MW_STAMPS
     if (tid == 0) g_stamps[n] = wall_clock64();
 #endif
@@ -204,7 +211,7 @@ __device__ __forceinline__ bool wg_potrf(PM M, long plane, int n, int ld, PR rd,
     // 1/d~_k = f_k^2 s_k: one reciprocal square root and products
     for (int k = tid; k < n; k += NT) {
         const long kk = k + (long)k * ld;
-        const mw<K> sk = ldx<K>(rd, rdplane, k), dt = ldx<K>(M, plane, kk);
+        const mw<K> sk = ldx<K>(us, n, k), dt = ldx<K>(M, plane, kk);
         const mw<K> f = rsqrt<K>(mul<K>(sk, dt)), rs = mul<K>(f, sk);
         stx<K>(rd, rdplane, k, rs);
         stx<K>(M, plane, kk, mul<K>(dt, f));
@@ -225,7 +232,7 @@ __device__ __forceinline__ bool wg_potrf(PM M, long plane, int n, int ld, PR rd,
             const mw<K> a = ldx<K>(M, plane, i + (long)c * ld);
             if (UT) stx<K>(M, plane, c + (long)i * ld, mul<K>(a, ldx<K>(us, n, c)));
             stx<K>(M, plane, i + (long)c * ld, mul<K>(a, ldx<K>(fs, n, c)));
-        } else {
+        } else if (c % cnw == cw) {
             const long idx = i + (long)c * ldw;
             stx<K>(W, wplane, idx, mul<K>(ldx<K>(W, wplane, idx), ldx<K>(fs, n, i)));
         }
@@ -343,6 +350,22 @@ __device__ __forceinline__ void wg_trsm_b(PF Bk, long fplane, int ldf, PR rd, lo
         }
         __syncthreads();
     }
+}
+
+// true (uniformly over the workgroup) in the workgroup that arrives last at `counter` out of `total`; every workgroup publishes
+// its global writes before it counts itself, the last one resets the counter for the next launch
+__device__ __forceinline__ bool wg_last_block(int *counter, unsigned total) {
+    __shared__ int last;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned old = atomicAdd((unsigned *)counter, 1u);
+        last = (old == total - 1) ? 1 : 0;
+        if (last) *counter = 0;
+    }
+    __syncthreads();
+    if (last) __threadfence();
+    return last != 0;
 }
 
 // copy a rows x cols planar matrix between two arrays (any address spaces)
@@ -688,19 +711,24 @@ template <int K, class PM, class PW>
 __device__ __forceinline__ bool mw_factor_body(const MwDev &q, const MwClu &c, int j, PM M, long mplane, PW W, mwk::lds_d *bc, int tid) {
     using namespace mwk;
     const int P = c.P;
-    const bool ok = wg_potrf<K, true, MW_PT>(M, mplane, P, P, q.srd + c.coff, q.xlen, W, mplane, P, bc, tid);
-    if (!ok) {
-        if (tid == 0) atomicMin(&q.info[0], j + 1);
-        return false;
+    const int cw = blockIdx.y, cnw = gridDim.y;         // the workgroups of a cluster share out the columns of L_j^-1
+    const bool ok = wg_potrf<K, true, MW_PT>(M, mplane, P, P, q.srd + c.coff, q.xlen, W, mplane, P, bc, tid, cw, cnw);
+    if (!ok && tid == 0) atomicMin(&q.info[0], j + 1);
+    if (ok) {
+        for (int e = tid; e < P * P; e += MW_PT) {        // this workgroup's columns of L_j^-1, zero above the diagonal
+            const int i = e % P, cc = e / P;
+            if (cc % cnw != cw) continue;
+#pragma unroll
+            for (int l = 0; l < K; l++) q.Si[(long)l * q.Slen + c.Soff + e] = (i >= cc) ? (double)W[(long)l * mplane + e] : 0.0;
+        }
     }
+    // L_j goes back to the S buffer, which is also the input: only once every workgroup of the cluster has read it, i.e. by the last one
+    if (!wg_last_block(&q.pcnt[j], cnw) || !ok) return ok;
     double *Sg = q.S + c.Soff;
-    for (int e = tid; e < P * P; e += MW_PT) {            // L_j back to the S buffer with a zero strict upper triangle; L_j^-1 beside it
+    for (int e = tid; e < P * P; e += MW_PT) {
         const int i = e % P, cc = e / P;
 #pragma unroll
-        for (int l = 0; l < K; l++) {
-            Sg[(long)l * q.Slen + e] = (i >= cc) ? (double)M[(long)l * mplane + e] : 0.0;
-            q.Si[(long)l * q.Slen + c.Soff + e] = (i >= cc) ? (double)W[(long)l * mplane + e] : 0.0;
-        }
+        for (int l = 0; l < K; l++) Sg[(long)l * q.Slen + e] = (i >= cc) ? (double)M[(long)l * mplane + e] : 0.0;
     }
     return true;
 }
@@ -769,7 +797,8 @@ template <int K, class PM, class PW>
 __device__ __forceinline__ void mw_potrf_q_body(const MwDev &q, PM M, long plane, PW W, mwk::lds_d *bc, int tid) {
     using namespace mwk;
     const int N = q.N;
-    const bool ok = wg_potrf<K, true, MW_PT>(M, plane, N, N, q.qrd, N, W, plane, N, bc, tid);
+    const int cw = blockIdx.x, cnw = gridDim.x;         // the workgroups share out the columns of L_Q^-1; the first one also writes L_Q
+    const bool ok = wg_potrf<K, true, MW_PT>(M, plane, N, N, q.qrd, N, W, plane, N, bc, tid, cw, cnw);
     if (!ok) {
         if (tid == 0) atomicMin(&q.info[0], q.J + 1);
         return;
@@ -778,8 +807,8 @@ __device__ __forceinline__ void mw_potrf_q_body(const MwDev &q, PM M, long plane
         const int i = e % N, cc = e / N;
 #pragma unroll
         for (int l = 0; l < K; l++) {
-            q.Q[(long)l * N * N + e] = (i >= cc) ? (double)M[(long)l * plane + e] : 0.0;
-            q.Qi[(long)l * N * N + e] = (i >= cc) ? (double)W[(long)l * plane + e] : 0.0;
+            if (cw == 0) q.Q[(long)l * N * N + e] = (i >= cc) ? (double)M[(long)l * plane + e] : 0.0;
+            if (cc % cnw == cw) q.Qi[(long)l * N * N + e] = (i >= cc) ? (double)W[(long)l * plane + e] : 0.0;
         }
     }
 }
@@ -840,20 +869,29 @@ template <int K>
 __global__ __launch_bounds__(MW_PT) void k_mw_bp_diag(const MwDev q, const MwBp m, int j0) {
     using namespace mwk;
     constexpr int MW_PB = MW_PB_OF(K);
-    if (q.info[m.which] != MW_INFO_NONE) return;
     const int nb = min(MW_PB, m.n - j0), tid = threadIdx.x;
     lds_d *scr = MW_LDS, *D = MW_LDS + MW_POTRF_SCR(K, MW_PB), *W = D + (long)K * MW_PB * MW_PB, *rdl = W + (long)K * MW_PB * MW_PB;
-    wg_copy<K, MW_PT>(D, (long)nb * nb, nb, m.M + j0 + (long)j0 * m.ld, m.plane, m.ld, nb, nb, tid);
-    __syncthreads();
-    if (!wg_potrf<K, true, MW_PT>(D, (long)nb * nb, nb, nb, rdl, nb, W, (long)nb * nb, nb, scr, tid)) {
-        if (tid == 0) atomicMin(&q.info[m.which], m.code);
-        return;
+    const int cw = blockIdx.x, cnw = gridDim.x;         // the workgroups share out the columns of the inverse of the diagonal block
+    // a failure recorded earlier (an earlier block column, or a sibling workgroup of this one that ran first) skips the work but not
+    // the arrival count below, which every workgroup of the launch must reach
+    bool ok = false;
+    if (q.info[m.which] == MW_INFO_NONE) {
+        wg_copy<K, MW_PT>(D, (long)nb * nb, nb, m.M + j0 + (long)j0 * m.ld, m.plane, m.ld, nb, nb, tid);
+        __syncthreads();
+        ok = wg_potrf<K, true, MW_PT>(D, (long)nb * nb, nb, nb, rdl, nb, W, (long)nb * nb, nb, scr, tid, cw, cnw);
+        if (!ok && tid == 0) atomicMin(&q.info[m.which], m.code);
     }
+    if (ok) {
+        for (int e = tid; e < nb * nb; e += MW_PT) {
+            const int i = e % nb, c = e / nb;
+            if (c % cnw == cw) stx<K>(m.Mi, m.plane, (j0 + i) + (long)(j0 + c) * m.ld, i >= c ? ldx<K>(W, (long)nb * nb, e) : zero<K>());
+        }
+    }
+    // the factor overwrites its input: by the workgroup that finishes last, when all have read it
+    if (!wg_last_block(&q.pcnt[q.J + 1], cnw) || !ok) return;
     for (int e = tid; e < nb * nb; e += MW_PT) {
         const int i = e % nb, c = e / nb;
-        const long g = (j0 + i) + (long)(j0 + c) * m.ld;
-        stx<K>(m.M, m.plane, g, i >= c ? ldx<K>(D, (long)nb * nb, e) : zero<K>());
-        stx<K>(m.Mi, m.plane, g, i >= c ? ldx<K>(W, (long)nb * nb, e) : zero<K>());
+        stx<K>(m.M, m.plane, (j0 + i) + (long)(j0 + c) * m.ld, i >= c ? ldx<K>(D, (long)nb * nb, e) : zero<K>());
     }
     for (int i = tid; i < nb; i += MW_PT) stx<K>(m.rd, m.rdplane, j0 + i, ldx<K>(rdl, nb, i));
 }
