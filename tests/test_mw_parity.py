@@ -526,6 +526,16 @@ def test_mw_size_limits(P, N, oracle_built):
     _check_mw_against_oracle(f, K=4, seed=P + 2 * N, amp=50)
 
 
+@pytest.mark.parametrize("J", [90, 200])
+def test_mw_many_clusters(J, oracle_built):
+    """Many small clusters in one context: the workgroups that share the columns of an inverse factor are 4 per cluster only while
+    4 J <= 256 compute units (J = 90: 2 per cluster, J = 200: 1), and every per-cluster kernel runs with a grid of J."""
+    import clrs_amd
+    from tests.util import random_simple_sdp
+    f = clrs_amd.flatten(random_simple_sdp(4000 + J, J=J, n_free=3, fixed_P=6, max_n=4, lr_blocks=2))
+    _check_mw_against_oracle(f, K=5, seed=J, amp=40)
+
+
 def test_mw_malformed_descriptions_and_call_order():
     """The multi-word ABI validates like the fp64 one: a term without its transposed partner (src/solver.jl:1009), calls out of order,
     unsupported limb counts -- negative codes with a message, never a crash."""
