@@ -238,7 +238,7 @@ def main():
 
         # ---- the same step at the other supported limb counts (the iterate truncated / zero-extended): precision against time ----
         sweep = {str(K): ms_per_step}
-        for Kx in (4, 6, 8):
+        for Kx in (4, 6, 8, 10):
             if Kx == K:
                 continue
             cx = MwSchurContext(flat, limbs=Kx, device=local_rank)

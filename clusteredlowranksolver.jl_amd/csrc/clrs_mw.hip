@@ -28,6 +28,7 @@ MW_KERNELS_ALL(extern template, 4)
 MW_KERNELS_ALL(extern template, 5)
 MW_KERNELS_ALL(extern template, 6)
 MW_KERNELS_ALL(extern template, 8)
+MW_KERNELS_ALL(extern template, 10)
 #endif
 
 typedef long long i64;
@@ -135,7 +136,8 @@ static int mw_dmalloc(clrs_mw_ctx *c, double **d, i64 n) {
         MW_CASE(2, 1, __VA_ARGS__) MW_CASE(2, 2, __VA_ARGS__) MW_CASE(3, 1, __VA_ARGS__) MW_CASE(3, 2, __VA_ARGS__)  \
         MW_CASE(4, 1, __VA_ARGS__) MW_CASE(4, 2, __VA_ARGS__) MW_CASE(5, 1, __VA_ARGS__) MW_CASE(5, 2, __VA_ARGS__)  \
         MW_CASE(6, 1, __VA_ARGS__) MW_CASE(6, 2, __VA_ARGS__) MW_CASE(8, 1, __VA_ARGS__) MW_CASE(8, 2, __VA_ARGS__)  \
-        return mw_fail(CLRS_ERR_INVALID, "limbs must be 2..6 or 8 and data limbs 1 or 2");                          \
+        MW_CASE(10, 1, __VA_ARGS__) MW_CASE(10, 2, __VA_ARGS__)                                                      \
+        return mw_fail(CLRS_ERR_INVALID, "limbs must be 2..6, 8 or 10 and data limbs 1 or 2");                      \
     } while (0)
 
 template <class F>
@@ -155,7 +157,7 @@ extern "C" int clrs_mw_create(const clrs_sdp_desc *d, int device, int limbs, clr
 
 extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int device, int limbs, clrs_mw_ctx **out) {
     if (!d || !out) return mw_fail(CLRS_ERR_INVALID, "null argument");
-    if (limbs < 2 || limbs > 8 || limbs == 7) return mw_fail(CLRS_ERR_INVALID, "limbs must be 2..6 or 8");
+    if (limbs < 2 || limbs > 10 || limbs == 7 || limbs == 9) return mw_fail(CLRS_ERR_INVALID, "limbs must be 2..6, 8 or 10");
     if (data_limbs < 1 || data_limbs > 2 || data_limbs > limbs) return mw_fail(CLRS_ERR_INVALID, "data limbs must be 1 or 2 (and at most limbs)");
     *out = nullptr;
     int ndev = 0;

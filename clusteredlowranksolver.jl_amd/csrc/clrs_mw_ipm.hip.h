@@ -35,9 +35,21 @@ struct MwIpmDev {
 
 namespace mwk {
 
+// The scalar stages are control flow between a handful of K-limb operations; inlined, every division is thousands of instructions
+// and a stage function grows to hundreds of kilobytes (585 KB at 10 limbs, where the device then hangs in it).  Their arithmetic
+// goes through calls instead: one copy of each operation per K.
+template <int K> __device__ __noinline__ mw<K> s_div(const mw<K> a, const mw<K> b) { return div<K>(a, b); }
+template <int K> __device__ __noinline__ mw<K> s_mul(const mw<K> a, const mw<K> b) { return mul<K>(a, b); }
+template <int K> __device__ __noinline__ mw<K> s_mul_d(const mw<K> a, double b) { return mul_d<K>(a, b); }
+template <int K> __device__ __noinline__ mw<K> s_add(const mw<K> a, const mw<K> b) { return add<K>(a, b); }
+template <int K> __device__ __noinline__ mw<K> s_sub(const mw<K> a, const mw<K> b) { return sub<K>(a, b); }
+template <int K> __device__ __noinline__ mw<K> s_result(const acc<K> s) { return acc_result<K>(s); }
+template <int K> __device__ __noinline__ mw<K> s_lanes64(const mw<K> v) { return lanes_sum<K, 64>(v); }
+template <int K> __device__ __forceinline__ bool s_less(const mw<K> &a, const mw<K> &b) { return s_sub<K>(a, b).l[0] < 0.0; }
+
 // sum over the workgroup (256 threads) of one multi-word value per thread; red: LDS, K * 256 doubles; result in every thread
 template <int K>
-__device__ mw<K> wg_reduce_sum(const mw<K> &v, lds_d *red, int tid) {
+__device__ __noinline__ mw<K> wg_reduce_sum(const mw<K> &v, lds_d *red, int tid) {
     mw<K> w = lanes_sum<K, 64>(v);                     // within the wave by shuffles, across the four waves through LDS
     if ((tid & 63) == 0) stx<K>(red, MW_NT / 64, tid >> 6, w);
     __syncthreads();
@@ -153,7 +165,7 @@ __device__ double wg_min_eig(lds_d *A, int n, lds_d *work, int tid) {
 
 // ---- scalar stages (one thread) ------------------------------------------------------------------------------------
 template <int K>
-__device__ mwa::mw<K> mwi_sum_part(const MwDev &q, const MwIpmDev &p, int slot) {
+__device__ __noinline__ mwa::mw<K> mwi_sum_part(const MwDev &q, const MwIpmDev &p, int slot) {
     using namespace mwk;
     acc<K> s;
     acc_zero<K>(s);
@@ -175,20 +187,20 @@ __device__ void mwi_scalar_stage(const MwDev &q, const MwIpmDev &p, int stage, i
         acc<K> s;
         acc_zero<K>(s);
         for (long i = lane; i < q.xlen; i += 64) acc_fma<K, K, DK>(s, ldx<K>(p.x, q.xlen, i), ldx<DK>(p.c, q.xlen, i), p.sgn);
-        mw<K> cx = lanes_sum<K, 64>(acc_result<K>(s));
+        mw<K> cx = s_lanes64<K>(s_result<K>(s));
         acc_zero<K>(s);
         for (int a = lane; a < q.N; a += 64) acc_fma<K, K, DK>(s, ldx<K>(p.y, q.N, a), ldx<DK>(p.b, q.N, a));
-        mw<K> by = lanes_sum<K, 64>(acc_result<K>(s));
+        mw<K> by = s_lanes64<K>(s_result<K>(s));
         if (lane != 0) return;
-        mw<K> dobj = add_d<K>(cx, p.constant);
+        mw<K> dobj = s_add<K>(cx, from_double<K>(p.constant));
         acc_zero<K>(s);
         acc_add<K, K>(s, mwi_sum_part<K>(q, p, 4));
         acc_add<K, K>(s, by);
         acc_add_d<K>(s, p.constant);
-        mw<K> pobj = acc_result<K>(s);
-        mw<K> den = abs<K>(add<K>(dobj, pobj));
-        if (less<K>(den, from_double<K>(1.0))) den = from_double<K>(1.0);
-        mw<K> gap = div<K>(abs<K>(sub<K>(dobj, pobj)), den);
+        mw<K> pobj = s_result<K>(s);
+        mw<K> den = abs<K>(s_add<K>(dobj, pobj));
+        if (s_less<K>(den, from_double<K>(1.0))) den = from_double<K>(1.0);
+        mw<K> gap = s_div<K>(abs<K>(s_sub<K>(dobj, pobj)), den);
         stx<K>(p.sc, SP, MSC_DOBJ, dobj); stx<K>(p.sc, SP, MSC_POBJ, pobj); stx<K>(p.sc, SP, MSC_GAP, gap);
         p.rec[MREC_DOBJ] = dobj.l[0]; p.rec[MREC_POBJ] = pobj.l[0]; p.rec[MREC_GAP] = gap.l[0];
         p.rec[MREC_ERR] = p.flags[1];
@@ -198,10 +210,10 @@ __device__ void mwi_scalar_stage(const MwDev &q, const MwIpmDev &p, int stage, i
     if (threadIdx.x != 0) return;
     if (stage == 0) {                              // start of the iteration: mu, mu_p  (src/solver.jl:369-380)
         mw<K> xy = mwi_sum_part<K>(q, p, 0);
-        mw<K> mu = div<K>(xy, from_double<K>((double)p.Ktot));
+        mw<K> mu = s_div<K>(xy, from_double<K>((double)p.Ktot));
         stx<K>(p.sc, SP, MSC_XY, xy);
         stx<K>(p.sc, SP, MSC_MU, mu);
-        stx<K>(p.sc, SP, MSC_MUS, p.flags[0] ? zero<K>() : mul_d<K>(mu, p.beta_infeasible));
+        stx<K>(p.sc, SP, MSC_MUS, p.flags[0] ? zero<K>() : s_mul_d<K>(mu, p.beta_infeasible));
         p.flags[1] = 0;
         p.flags[2] = 0;
         p.fmax[0] = p.fmax[1] = p.fmax[2] = 0ull;
@@ -227,16 +239,16 @@ __device__ void mwi_scalar_stage(const MwDev &q, const MwIpmDev &p, int stage, i
         acc_add<K, K>(s, mwi_sum_part<K>(q, p, 2));
         acc_add<K, K>(s, mwi_sum_part<K>(q, p, 3));
         mw<K> mu = ldx<K>(p.sc, SP, MSC_MU);
-        mw<K> r = div<K>(acc_result<K>(s), mul_d<K>(mu, (double)p.Ktot));
-        mw<K> beta = less<K>(r, from_double<K>(1.0)) ? mul<K>(r, r) : r;
+        mw<K> r = s_div<K>(s_result<K>(s), s_mul_d<K>(mu, (double)p.Ktot));
+        mw<K> beta = s_less<K>(r, from_double<K>(1.0)) ? s_mul<K>(r, r) : r;
         mw<K> beta_c;
         if (p.flags[0]) {                          // the feasibility of the PREVIOUS iteration decides (:429-434 come before :441-447)
-            beta_c = less<K>(from_double<K>(p.beta_feasible), beta) ? beta : from_double<K>(p.beta_feasible);
-            if (less<K>(from_double<K>(1.0), beta_c)) beta_c = from_double<K>(1.0);
+            beta_c = s_less<K>(from_double<K>(p.beta_feasible), beta) ? beta : from_double<K>(p.beta_feasible);
+            if (s_less<K>(from_double<K>(1.0), beta_c)) beta_c = from_double<K>(1.0);
         } else {
-            beta_c = less<K>(from_double<K>(p.beta_infeasible), beta) ? beta : from_double<K>(p.beta_infeasible);
+            beta_c = s_less<K>(from_double<K>(p.beta_infeasible), beta) ? beta : from_double<K>(p.beta_infeasible);
         }
-        stx<K>(p.sc, SP, MSC_MUS, mul<K>(beta_c, mu));
+        stx<K>(p.sc, SP, MSC_MUS, s_mul<K>(beta_c, mu));
         p.rec[MREC_BETA] = beta_c.l[0];
         p.flags[0] = (p.rec[MREC_DERR] < p.dual_thr && p.rec[MREC_PERR] < p.primal_thr) ? 1 : 0;
         p.rec[MREC_PDFEAS] = p.flags[0];

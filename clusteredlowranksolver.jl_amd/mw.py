@@ -24,7 +24,7 @@ from . import _lib
 from .sdp import FlatSDP, flatten
 from .solver import SolverFailure
 
-LIMB_BITS = {2: 104, 3: 157, 4: 209, 5: 262, 6: 315, 8: 420}     # guaranteed bits of an operation's result, about 53 K - K
+LIMB_BITS = {2: 104, 3: 157, 4: 209, 5: 262, 6: 315, 8: 420, 10: 525}     # guaranteed bits of an operation's result, about 53 K - K
 
 
 def limbs_for_precision(prec: int) -> int:
@@ -32,7 +32,7 @@ def limbs_for_precision(prec: int) -> int:
     for k in sorted(LIMB_BITS):
         if LIMB_BITS[k] >= prec:
             return k
-    raise ValueError(f"prec = {prec} bits needs more than 8 limbs")
+    raise ValueError(f"prec = {prec} bits needs more than 10 limbs")
 
 
 def to_limbs(values, limbs: int) -> np.ndarray:

@@ -258,8 +258,8 @@ int clrs_plan_info(const clrs_ctx *ctx, int32_t *n_launch_assemble, int32_t *n_l
  * src/tools.jl:59-107; products Arblib.approx_mul!, src/solver.jl:1125-1143) because the Schur complements of its
  * headline problems are not positive definite to fp64 accuracy (cohnelkies(8,15) fails at the first iterate in fp64 and
  * at 113 bits).  A clrs_mw_ctx runs the identical stages with every number an unevaluated sum of
- * `limbs` doubles (limbs = 2..6, 8: ~104 / 157 / 209 / 262 / 315 / 420 bits); limbs = 5 covers the reference's default precision (256),
- * 6 its test at prec = 300, 8 goes to 420 bits.
+ * `limbs` doubles (limbs = 2..6, 8, 10: ~104 / 157 / 209 / 262 / 315 / 420 / 525 bits); limbs = 5 covers the reference's default precision
+ * (256), 6 its test at prec = 300, 10 the prec = 512 of its tutorial and example generators.
  *
  * Array format ("planar limbs"): an array of logical length len is limbs * len doubles, limb l of element i at
  * [l * len + i]; value_i = sum_l a[l * len + i], limb 0 the value rounded to fp64, |limb l+1| <= ulp(limb l).

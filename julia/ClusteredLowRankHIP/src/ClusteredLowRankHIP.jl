@@ -55,7 +55,7 @@ const DATA_LIMBS = 2
 """Device context + the host arrays that back the description (kept alive for the lifetime of the context)."""
 mutable struct HipContext
     handle::Ptr{Cvoid}
-    limbs::Int                  # 1: fp64 entry points (clrs_*); 2..6, 8: multi-word entry points (clrs_mw_*)
+    limbs::Int                  # 1: fp64 entry points (clrs_*); 2..6, 8, 10: multi-word entry points (clrs_mw_*)
     keep::Vector{Any}
     block_off::Vector{Int}      # offsets of the blocks (j,l) in the xy layout
     block_n::Vector{Int}
@@ -183,8 +183,8 @@ function HipContext(sdp::CLRS.ClusteredLowRankSDP, cs_map; device::Integer=0, li
 end
 
 """Smallest limb count whose operations carry `prec` bits (about 53 K - K bits for K limbs)."""
-limbs_for(prec::Integer) = prec <= 53 ? 1 : prec <= 104 ? 2 : prec <= 157 ? 3 : prec <= 209 ? 4 : prec <= 262 ? 5 : prec <= 315 ? 6 : prec <= 420 ? 8 :
-                           error("prec = $prec needs more than 8 limbs")
+limbs_for(prec::Integer) = prec <= 53 ? 1 : prec <= 104 ? 2 : prec <= 157 ? 3 : prec <= 209 ? 4 : prec <= 262 ? 5 : prec <= 315 ? 6 : prec <= 420 ? 8 : prec <= 525 ? 10 :
+                           error("prec = $prec needs more than 10 limbs")
 
 """Pack a BlockDiagonal of BlockDiagonals of ArbRefMatrix into the planar xy layout (len x limbs, column-major per block)."""
 function pack_xy(ctx::HipContext, M)

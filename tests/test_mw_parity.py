@@ -41,7 +41,7 @@ def tol(K, slack):
     return 2.0 ** (-(53 * K - slack - max(0, K - 5)))
 
 
-@pytest.mark.parametrize("K,DL", [(2, 1), (2, 2), (3, 2), (4, 1), (4, 2), (5, 2), (6, 2), (8, 2)])
+@pytest.mark.parametrize("K,DL", [(2, 1), (2, 2), (3, 2), (4, 1), (4, 2), (5, 2), (6, 2), (8, 2), (10, 2)])
 @pytest.mark.parametrize("name", NAMES)
 def test_mw_assemble_factor_solve_match_oracle(name, K, DL, oracle_built):
     """K limbs per computed number; DL limbs of problem data (1: the fp64 roundings, 2: the (hi, lo) pairs of the FlatSDP)."""
@@ -50,7 +50,7 @@ def test_mw_assemble_factor_solve_match_oracle(name, K, DL, oracle_built):
     if name in ("ns_8_15_2",) and K in (2, 3):
         pytest.skip("covered at K = 4, 5")
     if K > 5 and name not in ("ce_8_15", "threepoint_4", "sdpa_small", "ns_8_15_2"):
-        pytest.skip("6 and 8 limbs (checked against the 640-bit build of the oracle): the north-star shapes, a mixed and a dense instance, the blocked path")
+        pytest.skip("6, 8 and 10 limbs (checked against the 640-bit build of the oracle): the north-star shapes, a mixed and a dense instance, the blocked path")
     f = flat(name)
     X, Y = _iterates(f, K)
     X, Y = _sym_limbs(f, X), _sym_limbs(f, Y)
@@ -201,12 +201,26 @@ def test_nsphere_packing_prec_300_instance(oracle_built):
     """Nsphere_packing(8,15,[1/2,1/2],2) (test/runtests_solver.jl:21-22) at the reference's prec = 300 -> 6 limbs (315 bits):
     7 clusters, m = 2 sub-blocks, P = 96 (blocked path); same pinned value, and the same objective as the 5-limb solve."""
     from clrs_amd.mw import solvesdp_mw, limbs_for_precision
-    assert limbs_for_precision(300) == 6 and limbs_for_precision(256) == 5 and limbs_for_precision(400) == 8
+    assert limbs_for_precision(300) == 6 and limbs_for_precision(256) == 5 and limbs_for_precision(400) == 8 and limbs_for_precision(512) == 10
     r = solvesdp_mw(flat("ns_8_15_2"), prec=300)
     assert r.error_code == 0 and r.timings["limbs"] == 6, (r.status, r.error_code, r.iterations)
     assert abs(r.primal_objective - PI4_384) <= 1e-4, r.primal_objective
     r5 = solvesdp_mw(flat("ns_8_15_2"), limbs=5)
     assert r5.error_code == 0 and abs(r5.primal_objective - r.primal_objective) <= 1e-12
+
+
+def test_prec_512_and_gap_1e60_as_in_the_reference_tutorial():
+    """docs/src/tutorial.md:169: solvesdp(problem; prec=512, duality_gap_threshold=1e-60) -- prec = 512 maps to 10 limbs (525 bits).  On
+    the north-star instance (whose generator defaults to prec = 512 in examples/SpherePacking.jl:117; at 10 limbs its 32 x 32
+    clusters take the blocked path with 16-wide panels) the loop reaches the 1e-60 gap and the pinned objective.  The problem DATA
+    stay double-double (106 bits), so digits beyond ~1e-30 describe that problem, not the exact one."""
+    from clrs_amd.mw import solvesdp_mw
+    r = solvesdp_mw(flat("ce_8_15"), prec=512, duality_gap_threshold=1e-60, primal_error_threshold=1e-60, dual_error_threshold=1e-60)
+    assert r.timings["limbs"] == 10
+    assert r.error_code == 0 and r.status == "Optimal" and r.duality_gap <= 1e-60, (r.status, r.error_code, r.duality_gap, r.iterations)
+    assert abs(r.primal_objective - PI4_384) <= 1e-4
+    r5 = solvesdp_mw(flat("ce_8_15"), limbs=5)
+    assert abs(r.primal_objective - r5.primal_objective) <= 1e-13
 
 
 def test_duality_gap_1e30_as_in_the_reference_rounding_test(oracle_built):
