@@ -340,7 +340,7 @@ extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int dev
         size_t xneed = (c->lds_x ? nn : 0) + bcw;
         for (auto &k : c->blk) {                            // X blocks whose factor and its inverse fit side by side: Xi is formed
             const size_t one = (size_t)k.n * k.n * K + MW_POTRF_SCR(K, (size_t)k.n) + (size_t)K * k.n;   // + a reciprocal diagonal (the Y workgroups of the iteration)
-            const size_t two = one + (size_t)k.n * k.n * K;
+            const size_t two = one + (size_t)MW_TRI(k.n) * K;                // + the packed inverse factor
             k.inv = !c->lds_x ? 0 : two <= lim ? 1 : one <= lim ? 2 : 0;       // the inverse in LDS beside the factor, or in place in memory
             if (k.inv) xneed = std::max(xneed, k.inv == 1 ? two : one);
         }
@@ -356,7 +356,7 @@ extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int dev
         c->sm_dense = (c->dense_two ? 2 : 1) * maxnd * maxnd * K * 8;
         size_t fmax = 0;
         for (auto &q : c->clu) {                        // S_j and the inverse of its factor side by side in LDS, or the blocked path
-            const size_t need = 2 * (size_t)q.P * q.P * K + MW_POTRF_SCR(K, (size_t)q.P);
+            const size_t need = ((size_t)q.P * q.P + (size_t)MW_TRI(q.P)) * K + MW_POTRF_SCR(K, (size_t)q.P);
             q.lds = need <= lim ? 1 : 0;
             if (q.lds) fmax = std::max(fmax, need);
         }
@@ -364,8 +364,9 @@ extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int dev
         c->nw_factor = std::max(1, std::min(MW_INV_WG, 256 / std::max(J, 1)));     // only while the clusters leave compute units idle
         c->sm_fwd = c->sm_bwd = 2 * (size_t)c->maxP * K * 8;
         const size_t qn = (size_t)N * N * K;
-        c->lds_q = 2 * qn + MW_POTRF_SCR(K, (size_t)N) <= lim;
-        c->sm_q = (c->lds_q ? 2 * qn + MW_POTRF_SCR(K, (size_t)N) : 1) * 8;
+        const size_t qneed = qn + (size_t)MW_TRI(N) * K + MW_POTRF_SCR(K, (size_t)N);
+        c->lds_q = qneed <= lim;
+        c->sm_q = (c->lds_q ? qneed : 1) * 8;
         c->sm_mid = 2 * (size_t)std::max(N, 1) * K * 8;
         if (c->sm_fwd > MW_LDS_MAX || c->sm_mid > MW_LDS_MAX) MW_BAIL(CLRS_ERR_INVALID, "cluster too large for the multi-word solve kernels");
     }
@@ -446,7 +447,7 @@ extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int dev
         q.pcnt = pc;
     }
     const int MW_PB = MW_PB_OF(K);
-    c->sm_bp_diag = ((size_t)MW_POTRF_SCR(K, MW_PB) + 2 * (size_t)K * MW_PB * MW_PB + (size_t)K * MW_PB) * 8;
+    c->sm_bp_diag = ((size_t)MW_POTRF_SCR(K, MW_PB) + (size_t)K * MW_PB * MW_PB + (size_t)K * MW_TRI(MW_PB) + (size_t)K * MW_PB) * 8;
     c->sm_bp_panel = (size_t)K * MW_BP_PR * MW_PB * 8;
     c->sm_bp_inv = (size_t)K * MW_PB * MW_BP_IC * 8;
     MW_DISPATCH(c, { MW_TRY(mw_set_lds(k_mw_bp_diag<KK>, c->sm_bp_diag)); MW_TRY(mw_set_lds(k_mw_bp_panel<KK>, c->sm_bp_panel)); MW_TRY(mw_set_lds(k_mw_bp_inv<KK>, c->sm_bp_inv)); });

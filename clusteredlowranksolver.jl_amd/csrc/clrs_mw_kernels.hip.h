@@ -125,6 +125,12 @@ __device__ __forceinline__ mw<K> lanes_sum(mw<K> v) {
     return v;
 }
 
+// Position of entry (i, c), i >= c, of the lower triangular W of wg_potrf: full column-major storage with leading dimension ldw, or
+// (ldw = 0) packed by columns, n (n + 1) / 2 entries -- the form the LDS copies take, so that a matrix and the inverse of its
+// factor fit side by side up to n = 52 at 5 limbs (and n = 32 at 10)
+__device__ __forceinline__ long w_index(int i, int c, int n, int ldw) { return ldw ? i + (long)c * ldw : (long)c * n - (long)c * (c - 1) / 2 + (i - c); }
+#define MW_TRI(n) ((long)(n) * ((n) + 1) / 2)
+
 // Exact scaling of one elimination step: ex even with d 2^-ex in [1/2, 2); p1 = 2^-ex, ph = 2^(-ex/2)  (d > 0, normal)
 __device__ __forceinline__ void pivot_scale(double head, double &p1, double &ph) {
     int ex = ((__double2hiint(head) >> 20) & 0x7ff) - 1023;
@@ -160,7 +166,7 @@ __device__ __forceinline__ bool wg_potrf(PM M, long plane, int n, int ld, PR rd,
     if (INV) {
         for (int e = tid; e < n * n; e += NT) {
             const int i = e % n, c = e / n;
-            stx<K>(W, wplane, i + (long)c * ldw, i == c ? from_double<K>(1.0) : zero<K>());
+            if (ldw || i >= c) stx<K>(W, wplane, ldw ? i + (long)c * ldw : w_index(i, c, n, 0), i == c ? from_double<K>(1.0) : zero<K>());
         }
         __syncthreads();
     }
@@ -186,20 +192,20 @@ __device__ __forceinline__ bool wg_potrf(PM M, long plane, int n, int ld, PR rd,
                 if (tr) { tri_index(e, i, c); i += k + 1; c += k + 1; }
                 else { const int e2 = e - trail; i = k + 1 + e2 % m; c = cw + cnw * (e2 / m); }
                 const mw<K> ci = mul_pow2<K>(ldx<K>(M, plane, i + (long)k * ld), ph);
-                const mw<K> cj = mul_pow2<K>(tr ? ldx<K>(M, plane, c + (long)k * ld) : ldx<K>(W, wplane, k + (long)c * ldw), ph);
-                const mw<K> v = tr ? ldx<K>(M, plane, i + (long)c * ld) : ldx<K>(W, wplane, i + (long)c * ldw);
+                const mw<K> cj = mul_pow2<K>(tr ? ldx<K>(M, plane, c + (long)k * ld) : ldx<K>(W, wplane, w_index(k, c, n, ldw)), ph);
+                const mw<K> v = tr ? ldx<K>(M, plane, i + (long)c * ld) : ldx<K>(W, wplane, w_index(i, c, n, ldw));
                 acc<K> s;
                 acc_zero<K>(s);
                 acc_fma<K, K, K>(s, dh, v);
                 acc_fma<K, K, K>(s, ci, cj, -1.0);
                 const mw<K> r = acc_result<K>(s);
                 if (tr) stx<K>(M, plane, i + (long)c * ld, r);
-                else stx<K>(W, wplane, i + (long)c * ldw, r);
+                else stx<K>(W, wplane, w_index(i, c, n, ldw), r);
             }
             if (tid == NT - 1) {
                 srun = mul<K>(srun, dh);
                 stx<K>(us, n, k + 1, srun);
-                if (INV) stx<K>(W, wplane, (k + 1) + (long)(k + 1) * ldw, srun);
+                if (INV) stx<K>(W, wplane, w_index(k + 1, k + 1, n, ldw), srun);
             }
         }
         __syncthreads();
@@ -233,11 +239,11 @@ __device__ __forceinline__ bool wg_potrf(PM M, long plane, int n, int ld, PR rd,
             if (UT) stx<K>(M, plane, c + (long)i * ld, mul<K>(a, ldx<K>(us, n, c)));
             stx<K>(M, plane, i + (long)c * ld, mul<K>(a, ldx<K>(fs, n, c)));
         } else if (c % cnw == cw) {
-            const long idx = i + (long)c * ldw;
+            const long idx = w_index(i, c, n, ldw);
             stx<K>(W, wplane, idx, mul<K>(ldx<K>(W, wplane, idx), ldx<K>(fs, n, i)));
         }
     }
-    if (INV) for (int i = tid; i < n; i += NT) stx<K>(W, wplane, i + (long)i * ldw, ldx<K>(rd, rdplane, i));
+    if (INV) for (int i = tid; i < n; i += NT) stx<K>(W, wplane, w_index(i, i, n, ldw), ldx<K>(rd, rdplane, i));
     __syncthreads();
 #ifdef MW_STAMPS
     if (tid == 0) g_stamps[101] = wall_clock64();
@@ -392,7 +398,7 @@ __device__ __forceinline__ void mw_potrf_x_body(const MwDev &q, const MwBlk &k, 
                                                 int tid, int bid) {
     using namespace mwk;
     const int n = k.n;
-    const bool ok = wg_potrf<K, INV, MW_PT, true>(M, plane, n, n, q.xrd + k.rd_off, q.xrdlen, W, wplane, n, bc, tid);
+    const bool ok = wg_potrf<K, INV, MW_PT, true>(M, plane, n, n, q.xrd + k.rd_off, q.xrdlen, W, wplane, w_in_place ? n : 0, bc, tid);   // the LDS copy of W is packed
     if (!ok && tid == 0) atomicMin(&q.info[1], bid + 1);
     __syncthreads();
     if (ok) wg_scaled_factors_u<K, MW_PT>(M, plane, n, q.xrd + k.rd_off, q.xrdlen, n, q.Xf + k.xyoff, q.xylen, n, q.Xb + k.xyoff, q.xylen, n, tid);
@@ -401,7 +407,7 @@ __device__ __forceinline__ void mw_potrf_x_body(const MwDev &q, const MwBlk &k, 
 #pragma unroll
         for (int l = 0; l < K; l++) {
             Xc[(long)l * q.xylen + k.xyoff + e] = (i >= c) ? (double)M[(long)l * plane + e] : 0.0;
-            if (INV && !w_in_place) q.Xi[(long)l * q.xylen + k.xyoff + e] = (ok && i >= c) ? (double)W[(long)l * wplane + e] : 0.0;
+            if (INV && !w_in_place) q.Xi[(long)l * q.xylen + k.xyoff + e] = (ok && i >= c) ? (double)W[(long)l * wplane + w_index(i, c, n, 0)] : 0.0;
         }
     }
 }
@@ -423,13 +429,13 @@ __global__ __launch_bounds__(MW_PT) void k_mw_potrf_x(const MwDev q, const doubl
         __syncthreads();
         bool ok;
         if (k.inv == 1) {
-            lds_d *W = M + (long)K * n * n, *rdl = W + (long)K * n * n;
-            ok = wg_potrf<K, true, MW_PT, false>(M, (long)n * n, n, n, rdl, n, W, (long)n * n, n, bc, tid);
+            lds_d *W = M + (long)K * n * n, *rdl = W + (long)K * MW_TRI(n);
+            ok = wg_potrf<K, true, MW_PT, false>(M, (long)n * n, n, n, rdl, n, W, MW_TRI(n), 0, bc, tid);
             if (ok) {
                 for (int e = tid; e < n * n; e += MW_PT) {
                     const int i = e % n, c = e / n;
 #pragma unroll
-                    for (int l = 0; l < K; l++) Yi[(long)l * q.xylen + k.xyoff + e] = (i >= c) ? (double)W[(long)l * n * n + e] : 0.0;
+                    for (int l = 0; l < K; l++) Yi[(long)l * q.xylen + k.xyoff + e] = (i >= c) ? (double)W[(long)l * MW_TRI(n) + w_index(i, c, n, 0)] : 0.0;
                 }
             }
         } else {                                        // the inverse in place in memory
@@ -443,7 +449,7 @@ __global__ __launch_bounds__(MW_PT) void k_mw_potrf_x(const MwDev q, const doubl
         lds_d *M = MW_LDS + MW_POTRF_SCR(K, n);
         wg_copy<K, MW_PT>(M, (long)n * n, n, X + k.xyoff, q.xylen, n, n, n, tid);
         __syncthreads();
-        if (k.inv == 1) mw_potrf_x_body<K, true>(q, k, M, (long)n * n, M + (long)K * n * n, (long)n * n, false, Xc, bc, tid, blockIdx.x);
+        if (k.inv == 1) mw_potrf_x_body<K, true>(q, k, M, (long)n * n, M + (long)K * n * n, MW_TRI(n), false, Xc, bc, tid, blockIdx.x);
         else if (k.inv == 2) mw_potrf_x_body<K, true>(q, k, M, (long)n * n, q.Xi + k.xyoff, q.xylen, true, Xc, bc, tid, blockIdx.x);
         else mw_potrf_x_body<K, false>(q, k, M, (long)n * n, M, 0, false, Xc, bc, tid, blockIdx.x);
     } else {
@@ -712,14 +718,14 @@ __device__ __forceinline__ bool mw_factor_body(const MwDev &q, const MwClu &c, i
     using namespace mwk;
     const int P = c.P;
     const int cw = blockIdx.y, cnw = gridDim.y;         // the workgroups of a cluster share out the columns of L_j^-1
-    const bool ok = wg_potrf<K, true, MW_PT>(M, mplane, P, P, q.srd + c.coff, q.xlen, W, mplane, P, bc, tid, cw, cnw);
+    const bool ok = wg_potrf<K, true, MW_PT>(M, mplane, P, P, q.srd + c.coff, q.xlen, W, MW_TRI(P), 0, bc, tid, cw, cnw);     // W packed
     if (!ok && tid == 0) atomicMin(&q.info[0], j + 1);
     if (ok) {
         for (int e = tid; e < P * P; e += MW_PT) {        // this workgroup's columns of L_j^-1, zero above the diagonal
             const int i = e % P, cc = e / P;
             if (cc % cnw != cw) continue;
 #pragma unroll
-            for (int l = 0; l < K; l++) q.Si[(long)l * q.Slen + c.Soff + e] = (i >= cc) ? (double)W[(long)l * mplane + e] : 0.0;
+            for (int l = 0; l < K; l++) q.Si[(long)l * q.Slen + c.Soff + e] = (i >= cc) ? (double)W[(long)l * MW_TRI(P) + w_index(i, cc, P, 0)] : 0.0;
         }
     }
     // L_j goes back to the S buffer, which is also the input: only once every workgroup of the cluster has read it, i.e. by the last one
@@ -798,7 +804,7 @@ __device__ __forceinline__ void mw_potrf_q_body(const MwDev &q, PM M, long plane
     using namespace mwk;
     const int N = q.N;
     const int cw = blockIdx.x, cnw = gridDim.x;         // the workgroups share out the columns of L_Q^-1; the first one also writes L_Q
-    const bool ok = wg_potrf<K, true, MW_PT>(M, plane, N, N, q.qrd, N, W, plane, N, bc, tid, cw, cnw);
+    const bool ok = wg_potrf<K, true, MW_PT>(M, plane, N, N, q.qrd, N, W, MW_TRI(N), 0, bc, tid, cw, cnw);     // W packed
     if (!ok) {
         if (tid == 0) atomicMin(&q.info[0], q.J + 1);
         return;
@@ -808,7 +814,7 @@ __device__ __forceinline__ void mw_potrf_q_body(const MwDev &q, PM M, long plane
 #pragma unroll
         for (int l = 0; l < K; l++) {
             if (cw == 0) q.Q[(long)l * N * N + e] = (i >= cc) ? (double)M[(long)l * plane + e] : 0.0;
-            if (cc % cnw == cw) q.Qi[(long)l * N * N + e] = (i >= cc) ? (double)W[(long)l * plane + e] : 0.0;
+            if (cc % cnw == cw) q.Qi[(long)l * N * N + e] = (i >= cc) ? (double)W[(long)l * MW_TRI(N) + w_index(i, cc, N, 0)] : 0.0;
         }
     }
 }
@@ -857,7 +863,7 @@ __global__ __launch_bounds__(MW_NT) void k_mw_qsum(const MwDev q) {
 //   k_mw_bp_finish zero strict upper triangle of L.
 // With L^-1 explicit, LinvB and every solve of a large cluster are products over many lanes, like those of a small one.
 // ---------------------------------------------------------------------------------------------------------------------
-#define MW_PB_OF(K) ((K) <= 8 ? 32 : 16)     // panel width: two MW_PB x MW_PB matrices of K limbs must fit in LDS (k_mw_bp_diag)
+#define MW_PB_OF(K) 32       // panel width: a MW_PB x MW_PB matrix and the packed inverse of its factor, K limbs each, fit in LDS up to K = 10 (k_mw_bp_diag)
 #define MW_BP_PR 8           // rows of the panel per workgroup
 #define MW_BP_IC 4           // columns of an inverse block per workgroup
 struct MwBp {                // one matrix being factored: planar M and its inverse factor Mi (same plane length and leading dimension), reciprocal diagonal rd
@@ -870,7 +876,7 @@ __global__ __launch_bounds__(MW_PT) void k_mw_bp_diag(const MwDev q, const MwBp 
     using namespace mwk;
     constexpr int MW_PB = MW_PB_OF(K);
     const int nb = min(MW_PB, m.n - j0), tid = threadIdx.x;
-    lds_d *scr = MW_LDS, *D = MW_LDS + MW_POTRF_SCR(K, MW_PB), *W = D + (long)K * MW_PB * MW_PB, *rdl = W + (long)K * MW_PB * MW_PB;
+    lds_d *scr = MW_LDS, *D = MW_LDS + MW_POTRF_SCR(K, MW_PB), *W = D + (long)K * MW_PB * MW_PB, *rdl = W + (long)K * MW_TRI(MW_PB);
     const int cw = blockIdx.x, cnw = gridDim.x;         // the workgroups share out the columns of the inverse of the diagonal block
     // a failure recorded earlier (an earlier block column, or a sibling workgroup of this one that ran first) skips the work but not
     // the arrival count below, which every workgroup of the launch must reach
@@ -878,13 +884,13 @@ __global__ __launch_bounds__(MW_PT) void k_mw_bp_diag(const MwDev q, const MwBp 
     if (q.info[m.which] == MW_INFO_NONE) {
         wg_copy<K, MW_PT>(D, (long)nb * nb, nb, m.M + j0 + (long)j0 * m.ld, m.plane, m.ld, nb, nb, tid);
         __syncthreads();
-        ok = wg_potrf<K, true, MW_PT>(D, (long)nb * nb, nb, nb, rdl, nb, W, (long)nb * nb, nb, scr, tid, cw, cnw);
+        ok = wg_potrf<K, true, MW_PT>(D, (long)nb * nb, nb, nb, rdl, nb, W, MW_TRI(nb), 0, scr, tid, cw, cnw);     // W packed
         if (!ok && tid == 0) atomicMin(&q.info[m.which], m.code);
     }
     if (ok) {
         for (int e = tid; e < nb * nb; e += MW_PT) {
             const int i = e % nb, c = e / nb;
-            if (c % cnw == cw) stx<K>(m.Mi, m.plane, (j0 + i) + (long)(j0 + c) * m.ld, i >= c ? ldx<K>(W, (long)nb * nb, e) : zero<K>());
+            if (c % cnw == cw) stx<K>(m.Mi, m.plane, (j0 + i) + (long)(j0 + c) * m.ld, i >= c ? ldx<K>(W, MW_TRI(nb), w_index(i, c, nb, 0)) : zero<K>());
         }
     }
     // the factor overwrites its input: by the workgroup that finishes last, when all have read it
