@@ -128,7 +128,8 @@ __device__ __forceinline__ mw<K> lanes_sum(mw<K> v) {
 // Position of entry (i, c), i >= c, of the lower triangular W of wg_potrf: full column-major storage with leading dimension ldw, or
 // (ldw = 0) packed by columns, n (n + 1) / 2 entries -- the form the LDS copies take, so that a matrix and the inverse of its
 // factor fit side by side up to n = 52 at 5 limbs (and n = 32 at 10)
-__device__ __forceinline__ long w_index(int i, int c, int n, int ldw) { return ldw ? i + (long)c * ldw : (long)c * n - (long)c * (c - 1) / 2 + (i - c); }
+__device__ __forceinline__ int w_col(int c, int n, int ldw) { return ldw ? c * ldw : c * n - c * (c + 1) / 2; }      // entry (i, c) is at w_col(c) + i (32-bit: the matrices of one workgroup are small)
+__device__ __forceinline__ long w_index(int i, int c, int n, int ldw) { return w_col(c, n, ldw) + i; }
 #define MW_TRI(n) ((long)(n) * ((n) + 1) / 2)
 
 // Exact scaling of one elimination step: ex even with d 2^-ex in [1/2, 2); p1 = 2^-ex, ph = 2^(-ex/2)  (d > 0, normal)
@@ -191,16 +192,17 @@ __device__ __forceinline__ bool wg_potrf(PM M, long plane, int n, int ld, PR rd,
                 const bool tr = e < trail;
                 if (tr) { tri_index(e, i, c); i += k + 1; c += k + 1; }
                 else { const int e2 = e - trail; i = k + 1 + e2 % m; c = cw + cnw * (e2 / m); }
-                const mw<K> ci = mul_pow2<K>(ldx<K>(M, plane, i + (long)k * ld), ph);
-                const mw<K> cj = mul_pow2<K>(tr ? ldx<K>(M, plane, c + (long)k * ld) : ldx<K>(W, wplane, w_index(k, c, n, ldw)), ph);
-                const mw<K> v = tr ? ldx<K>(M, plane, i + (long)c * ld) : ldx<K>(W, wplane, w_index(i, c, n, ldw));
+                const mw<K> ci = mul_pow2<K>(ldx<K>(M, plane, i + k * ld), ph);
+                const int cb = tr ? c * ld : w_col(c, n, ldw);               // column base of the entry in M or in W
+                const mw<K> cj = mul_pow2<K>(tr ? ldx<K>(M, plane, c + k * ld) : ldx<K>(W, wplane, cb + k), ph);
+                const mw<K> v = tr ? ldx<K>(M, plane, cb + i) : ldx<K>(W, wplane, cb + i);
                 acc<K> s;
                 acc_zero<K>(s);
                 acc_fma<K, K, K>(s, dh, v);
                 acc_fma<K, K, K>(s, ci, cj, -1.0);
                 const mw<K> r = acc_result<K>(s);
-                if (tr) stx<K>(M, plane, i + (long)c * ld, r);
-                else stx<K>(W, wplane, w_index(i, c, n, ldw), r);
+                if (tr) stx<K>(M, plane, cb + i, r);
+                else stx<K>(W, wplane, cb + i, r);
             }
             if (tid == NT - 1) {
                 srun = mul<K>(srun, dh);
