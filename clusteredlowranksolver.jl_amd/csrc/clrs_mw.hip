@@ -555,7 +555,7 @@ extern "C" int clrs_mw_schur_assemble_dev(clrs_mw_ctx *c, const double *d_Xchol,
             const int pairs = c->maxcnt * (c->maxcnt + 1) / 2;
             if (q.dn_big) hipLaunchKernelGGL((k_mw_dense_s<KK, DD>), dim3(q.ndn, (pairs + MW_NT / 64 - 1) / (MW_NT / 64)), dim3(MW_NT), 0, c->stream, q);
         }
-        hipLaunchKernelGGL((k_mw_saccum<KK, DD>), dim3((c->maxP * (c->maxP + 1) / 2 + MW_NT - 1) / MW_NT, q.J), dim3(MW_NT), 0, c->stream, q);
+        hipLaunchKernelGGL((k_mw_saccum<KK, DD>), dim3((c->maxP * (c->maxP + 1) / 2 * MW_SA_W + MW_NT - 1) / MW_NT, q.J), dim3(MW_NT), 0, c->stream, q);
     });
     MWCHECK(hipGetLastError());
     if (c->timing) MWCHECK(hipEventRecord(c->ev[1], c->stream));

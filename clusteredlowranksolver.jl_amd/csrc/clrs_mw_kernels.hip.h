@@ -666,6 +666,7 @@ __global__ __launch_bounds__(MW_NT) void k_mw_dense_s(const MwDev q) {
 // dense  Sd[e_p, e_q].  One thread per entry q >= p, mirrored write (symmetric!, src/tools.jl:43-57); the per-term pairings
 // A_Y (src/solver.jl:1152-1170) are written by the first workgroups of the same launch.
 // ---------------------------------------------------------------------------------------------------------------------
+#define MW_SA_W 4
 template <int K, int DK>
 __global__ __launch_bounds__(MW_NT) void k_mw_saccum(const MwDev q) {
     using namespace mwk;
@@ -679,13 +680,16 @@ __global__ __launch_bounds__(MW_NT) void k_mw_saccum(const MwDev q) {
     }
     const MwClu &c = q.clu[blockIdx.y];
     const int P = c.P;
-    const int e = blockIdx.x * MW_NT + threadIdx.x;
-    if (e >= P * (P + 1) / 2) return;
+    if (blockIdx.x * (MW_NT / MW_SA_W) >= P * (P + 1) / 2) return;
+    // MW_SA_W lanes per entry, one block of the cluster each: the chains of dependent loads (block -> term range -> pointers ->
+    // pairings) of the blocks run side by side instead of one after the other
+    const int e = blockIdx.x * (MW_NT / MW_SA_W) + threadIdx.x / MW_SA_W, sub = threadIdx.x % MW_SA_W;
+    const bool live = e < P * (P + 1) / 2;
     int qq, pp;
-    tri_index(e, qq, pp);           // qq >= pp
+    tri_index(live ? e : 0, qq, pp);           // qq >= pp
     acc<K> s;
     acc_zero<K>(s);
-    for (int b = c.b0; b < c.b1; b++) {
+    for (int b = c.b0 + sub; b < c.b1; b += MW_SA_W) {
         const MwBlk &k = q.blk[b];
         if (k.kind == 0) {
             const int *tp = q.tptr + k.tptr_off;
@@ -706,9 +710,11 @@ __global__ __launch_bounds__(MW_NT) void k_mw_saccum(const MwDev q) {
             if (e1 >= 0 && e2 >= 0) acc_add<K, K>(s, ldx<K>(q.Sd + k.sd_off, q.sdlen, e1 + (long)e2 * k.cnt));
         }
     }
-    mw<K> v = acc_result<K>(s);
-    stx<K>(q.S + c.Soff, q.Slen, pp + (long)qq * P, v);
-    stx<K>(q.S + c.Soff, q.Slen, qq + (long)pp * P, v);
+    const mw<K> v = lanes_sum<K, MW_SA_W>(acc_result<K>(s));
+    if (live && sub == 0) {
+        stx<K>(q.S + c.Soff, q.Slen, pp + (long)qq * P, v);
+        stx<K>(q.S + c.Soff, q.Slen, qq + (long)pp * P, v);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
