@@ -57,6 +57,7 @@ static int g_cfg_wave_assemble = 1;
 static int g_cfg_wave2_assemble = 1;
 static int g_cfg_wave3_assemble = 1;   // register-resident form of the cluster-per-wave assembly (U <= 32); 0: k_cluster_assemble_w2
 static int g_cfg_dense_block = 1;
+static int g_cfg_dense_wave = 1;      // dense blocks with n <= 32 beyond k_dense_block: one wave per (block, matrix), k_dense_T32
 static int g_cfg_factor_small = 1;      // factor + Q in one launch of one workgroup for <= 4 small clusters (0: k_cluster_factor + k_small_potrf)
 static int g_cfg_solve_small_max = 32768;     // one-workgroup solve stage only up to this many doubles of operands (beyond: one workgroup per cluster, three launches)
 static int g_cfg_ipm_wmfma = 3;         // device interior-point loop, bit 0: sum_i a_i A_i of a low-rank block as an MFMA contraction over its terms; bit 1: Z V by MFMA (0: per-entry loops)
@@ -66,10 +67,10 @@ static const int LDS_BUDGET_DOUBLES = 20000;   // of the 20480 doubles (160 KiB)
 // ------------------------------------------------------------------------------------------------
 // launch plan
 // ------------------------------------------------------------------------------------------------
-enum StepKind { STEP_MEMCPY, STEP_GEMM, STEP_TRSM, STEP_POTRF, STEP_GATHER_S, STEP_GATHER_SCALAR, STEP_SUB, STEP_MEMSET_INFO, STEP_ZERO_UPPER, STEP_FUSED_ASSEMBLE, STEP_SMALL_POTRF, STEP_CLUSTER_FACTOR, STEP_GEMV_T, STEP_CSOLVE_FWD, STEP_Q_SOLVE, STEP_CSOLVE_BWD, STEP_SUM_SLABS, STEP_ASSEMBLE_W1, STEP_GRAM_SMALL, STEP_ASSEMBLE_W2, STEP_SOLVE_SMALL, STEP_DENSE_BLOCK, STEP_ASSEMBLE_W3, STEP_FACTOR_SMALL, STEP_SUM_S_SLABS, STEP_NKINDS };
+enum StepKind { STEP_MEMCPY, STEP_GEMM, STEP_TRSM, STEP_POTRF, STEP_GATHER_S, STEP_GATHER_SCALAR, STEP_SUB, STEP_MEMSET_INFO, STEP_ZERO_UPPER, STEP_FUSED_ASSEMBLE, STEP_SMALL_POTRF, STEP_CLUSTER_FACTOR, STEP_GEMV_T, STEP_CSOLVE_FWD, STEP_Q_SOLVE, STEP_CSOLVE_BWD, STEP_SUM_SLABS, STEP_ASSEMBLE_W1, STEP_GRAM_SMALL, STEP_ASSEMBLE_W2, STEP_SOLVE_SMALL, STEP_DENSE_BLOCK, STEP_ASSEMBLE_W3, STEP_FACTOR_SMALL, STEP_SUM_S_SLABS, STEP_TRTRI32, STEP_DENSE_T32, STEP_NKINDS };
 static const char *const STEP_NAMES[STEP_NKINDS] = {"hipMemcpyAsync(D2D)", "k_gemm_f64_t", "k_trsm_diag", "k_potrf_diag", "k_schur_gather",
                                                     "k_gather_scalar", "k_sub", "hipMemsetAsync", "k_zero_upper", "k_cluster_assemble", "k_small_potrf", "k_cluster_factor", "k_gemv_t",
-                                                    "k_cluster_solve_fwd", "k_q_solve", "k_cluster_solve_bwd", "k_sum_slabs", "k_cluster_assemble_w1", "k_gram_small", "k_cluster_assemble_w2", "k_solve_small", "k_dense_block", "k_cluster_assemble_w3", "k_factor_small", "k_sum_S_slabs"};
+                                                    "k_cluster_solve_fwd", "k_q_solve", "k_cluster_solve_bwd", "k_sum_slabs", "k_cluster_assemble_w1", "k_gram_small", "k_cluster_assemble_w2", "k_solve_small", "k_dense_block", "k_cluster_assemble_w3", "k_factor_small", "k_sum_S_slabs", "k_trtri32", "k_dense_T32"};
 static const int KT_MAX_EVENTS = 8192;   // event pairs kept between two clrs_get_kernel_times calls
 
 struct Step {
@@ -393,7 +394,7 @@ static int run_steps(clrs_ctx *c, const Plan &pl) {
                 hipLaunchKernelGGL(k_potrf_diag, dim3(s.grid), dim3(256), 0, st, (const PotrfDesc *)s.d0, (int *)s.dst);
                 break;
             case STEP_GATHER_S:
-                hipLaunchKernelGGL(k_schur_gather, dim3(s.grid), dim3(256), 0, st, (const SClusterDesc *)s.d0, (const SBlockDesc *)s.d1,
+                hipLaunchKernelGGL(k_schur_gather, dim3(s.grid), dim3(256 * SG_W), 0, st, (const SClusterDesc *)s.d0, (const SBlockDesc *)s.d1,
                                    (const STile *)s.d2);
                 break;
             case STEP_GATHER_SCALAR:
@@ -412,6 +413,12 @@ static int run_steps(clrs_ctx *c, const Plan &pl) {
                 break;
             case STEP_DENSE_BLOCK:
                 hipLaunchKernelGGL(k_dense_block, dim3(s.grid), dim3(256), s.bytes, st, (const DBlock *)s.d0, *(const FTables *)s.src);
+                break;
+            case STEP_TRTRI32:
+                hipLaunchKernelGGL(k_trtri32, dim3(s.grid), dim3(64), 0, st, (const DenseTBlock *)s.d0);
+                break;
+            case STEP_DENSE_T32:
+                hipLaunchKernelGGL(k_dense_T32, dim3(s.grid), dim3(64 * DT32_WAVES), dense_T32_lds_bytes(), st, (const DenseTBlock *)s.d0, (const DenseTPair *)s.d1);
                 break;
             case STEP_SOLVE_SMALL:
                 if (s.aux0 >= 2) {
@@ -1080,6 +1087,8 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
         const size_t copy_step_index = pl.steps.size();
         if (need_copy) add_memcpy(pl, c->d_work, c->d_static, sizeof(double) * (size_t)so);
         std::vector<TrsmJob> fwd, bwd;
+        std::vector<DenseTBlock> dtb;                       // dense blocks taken by k_dense_T32
+        std::vector<DenseTPair> dtp;
         std::vector<GemmDesc> g1, g2;
         bool any_general = false;
         for (int b = 0; b < NB; b++) {
@@ -1118,6 +1127,15 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
                         continue;
                     }
                 }
+                if (g_cfg_dense_wave && n <= 32) {      // T_e = X^-1 A_e Y by one wave per matrix (k_dense_T32), then the same Gram GEMM
+                    double *TT = c->d_TT + k.tt_off, *Sd = c->d_Sd + k.sd_off;
+                    const double *Ast = c->d_static + k.w_off;
+                    const int bi = (int)dtb.size();
+                    dtb.push_back(DenseTBlock{Lx, Yb, Ast, nullptr, TT, n, k.cnt});
+                    for (int e0 = 0; e0 < k.cnt; e0 += DT32_WAVES) dtp.push_back(DenseTPair{bi, e0});
+                    g2.push_back(mk_gemm(1, 0, k.cnt, k.cnt, n * n, 1.0, Ast, n * n, TT, n * n, 0.0, Sd, k.cnt));           // <A_i, T_k>   (:1102)
+                    continue;
+                }
                 need_work_arena = true;
                 double *W = c->d_work + k.w_off, *TT = c->d_TT + k.tt_off, *Sd = c->d_Sd + k.sd_off;
                 const double *Ast = c->d_static + k.w_off;
@@ -1131,6 +1149,21 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
         CK(plan_trsm(c, pl, fwd, 0));
         CK(plan_trsm(c, pl, bwd, 1));
         CK(add_gemm_stage(c, pl, g1));
+        if (!dtb.empty()) {
+            double *linv = nullptr;
+            CK(dmalloc(c, &linv, (i64)dtb.size() * 1024));
+            for (size_t i = 0; i < dtb.size(); i++) dtb[i].Linv = linv + i * 1024;
+            DenseTBlock *dblk; DenseTPair *dpr;
+            CK(upload(c, dtb, &dblk));
+            CK(upload(c, dtp, &dpr));
+            Step s1;
+            s1.kind = STEP_TRTRI32; s1.grid = (int)dtb.size(); s1.d0 = dblk;
+            pl.steps.push_back(s1);
+            Step s2;
+            s2.kind = STEP_DENSE_T32; s2.grid = (int)dtp.size(); s2.d0 = dblk; s2.d1 = dpr;
+            pl.steps.push_back(s2);
+            HIPCK(hipFuncSetAttribute((const void *)k_dense_T32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dense_T32_lds_bytes()));
+        }
         CK(add_gemm_stage(c, pl, g2));
         if (!dblocks.empty()) {
             DBlock *ddb;
@@ -2068,6 +2101,7 @@ extern "C" int clrs_config_set(const char *key, int value) {
     if (!std::strcmp(key, "wave2_assemble")) { g_cfg_wave2_assemble = value; return 0; }
     if (!std::strcmp(key, "wave3_assemble")) { g_cfg_wave3_assemble = value; return 0; }
     if (!std::strcmp(key, "dense_block")) { g_cfg_dense_block = value; return 0; }
+    if (!std::strcmp(key, "dense_wave")) { g_cfg_dense_wave = value; return 0; }
     if (!std::strcmp(key, "solve_small2")) { g_cfg_solve_small2 = value; return 0; }
     if (!std::strcmp(key, "factor_small")) { g_cfg_factor_small = value; return 0; }
     if (!std::strcmp(key, "pin_limit")) { PIN_LIMIT = (size_t)std::max(value, 0); return 0; }

@@ -155,6 +155,132 @@ __global__ __launch_bounds__(256) void k_gemm_f64_t(const GemmDesc *__restrict__
 constexpr size_t gemm_lds_bytes(int BM, int BN) { return (size_t)2 * GEMM_BK * ((BM + 16) + (BN + 16)) * sizeof(double); }
 
 // ------------------------------------------------------------------------------------------------
+// Dense ("high rank") branch for blocks with n <= 32 and MANY matrices (SDPA-type problems; src/solver.jl:1089-1097):
+// T_e = X^-1 A_e Y = Linv^T (Linv (A_e Y)) with Linv = chol(X_b)^-1, three 32 x 32 x 32 products per (block, matrix) through
+// v_mfma_f64_16x16x4 by ONE WAVE: A_e, Y, Linv staged in LDS (zero padded to 32 x 32), each result chained into the next product
+// as right operand in its accumulator registers, the last one copied out coalesced.  The staged
+// form spent two launches of one-thread-per-column substitutions (k_trsm_diag) and a batched GEMM with 32 x 32 tiles on it.
+//   k_trtri32     Linv per block (one wave: lane c owns column c of the inverse), padded to 32 x 32 with leading dimension 32
+//   k_dense_T32   DT32_WAVES consecutive matrices of one block per workgroup; Linv and Y of the block shared in LDS
+// ------------------------------------------------------------------------------------------------
+struct DenseTBlock {
+    const double *L, *Y, *A;     // chol(X_b) and Y_b (n x n, column-major), the stack of cnt matrices A_e (n x n each)
+    double *Linv, *TT;           // 32 x 32 scratch of the block; output stack T_e (n x n each)
+    int n, cnt;
+};
+struct DenseTPair { int blk, e0; };
+#define DT32_WAVES 4
+#define DT32_LD 34
+#define DT32_MS (32 * DT32_LD)
+__global__ __launch_bounds__(64) void k_trtri32(const DenseTBlock *__restrict__ blocks) {
+    __shared__ double Ls[32 * 33], Xs[32 * 33];
+    const DenseTBlock b = blocks[blockIdx.x];
+    const int n = b.n, lane = threadIdx.x;
+    for (int e = lane; e < 32 * 32; e += 64) {
+        const int i = e % 32, c = e / 32;
+        Ls[i + 33 * c] = (i < n && c < n) ? b.L[i + (long long)c * n] : (i == c ? 1.0 : 0.0);
+        Xs[i + 33 * c] = 0.0;
+    }
+    __syncthreads();
+    if (lane < 32) {                                        // column c = lane of the inverse by forward substitution
+        const int c = lane;
+        for (int i = c; i < 32; i++) {
+            double s = i == c ? 1.0 : 0.0;
+            for (int k = c; k < i; k++) s -= Ls[i + 33 * k] * Xs[k + 33 * c];
+            Xs[i + 33 * c] = s / Ls[i + 33 * i];
+        }
+    }
+    __syncthreads();
+    for (int e = lane; e < 32 * 32; e += 64) {
+        const int i = e % 32, c = e / 32;
+        b.Linv[e] = (i < n && c < n) ? Xs[i + 33 * c] : 0.0;
+    }
+}
+// D = X Y for 32 x 32 operands in LDS (leading dimension DT32_LD).  acc[ti][tj]: lane holds column tj*16 + (lane & 15), rows
+// ti*16 + (lane >> 4) + 4 reg -- which is exactly the B-operand layout of the next product's k-step (tile ti, reg), so that a
+// result is chained into the next MFMA as RIGHT operand without leaving the registers (dt32_mm_chain).
+__device__ __forceinline__ void dt32_mm(const double *X, const double *Yb, v4d (&acc)[2][2], int l15, int l4) {
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 32; kk += 4) {
+        double xv[2], yv[2];
+#pragma unroll
+        for (int a = 0; a < 2; a++) xv[a] = X[(a * 16 + l15) + DT32_LD * (kk + l4)];
+#pragma unroll
+        for (int b = 0; b < 2; b++) yv[b] = Yb[(kk + l4) + DT32_LD * (b * 16 + l15)];
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[a], yv[b], acc[a][b], 0, 0, 0);
+    }
+}
+// out = op(Li) yin with Li lower triangular in LDS and yin in accumulator layout; XT: op = transpose.  The zero tile of the
+// triangle (k > row for Li, k < row for Li^T) is skipped.
+template <bool XT>
+__device__ __forceinline__ void dt32_mm_chain(const double *Li, const v4d (&yin)[2][2], v4d (&out)[2][2], int l15, int l4) {
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) out[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kt = 0; kt < 2; kt++)
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const int k = kt * 16 + 4 * reg + l4;
+#pragma unroll
+            for (int a = 0; a < 2; a++) {
+                if ((!XT && kt > a) || (XT && kt < a)) continue;
+                const double xv = XT ? Li[k + DT32_LD * (a * 16 + l15)] : Li[(a * 16 + l15) + DT32_LD * k];
+#pragma unroll
+                for (int b = 0; b < 2; b++) out[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(xv, yin[kt][b][reg], out[a][b], 0, 0, 0);
+            }
+        }
+}
+__device__ __forceinline__ void dt32_store(double *B, const v4d (&acc)[2][2], int l15, int l4) {
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) B[(a * 16 + l4 + 4 * reg) + DT32_LD * (b * 16 + l15)] = acc[a][b][reg];
+}
+__global__ __launch_bounds__(64 * DT32_WAVES) void k_dense_T32(const DenseTBlock *__restrict__ blocks, const DenseTPair *__restrict__ pairs) {
+    extern __shared__ __attribute__((aligned(16))) double dts[];
+    const DenseTPair pr = pairs[blockIdx.x];
+    const DenseTBlock b = blocks[pr.blk];
+    const int n = b.n, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
+    double *Li = dts, *Ys = dts + DT32_MS, *B0 = dts + 2 * DT32_MS + wave * DT32_MS;
+    for (int e = tid; e < 32 * 32; e += 64 * DT32_WAVES) {
+        const int i = e % 32, c = e / 32;
+        Li[i + DT32_LD * c] = b.Linv[e];
+        Ys[i + DT32_LD * c] = (i < n && c < n) ? b.Y[i + (long long)c * n] : 0.0;
+    }
+    const int e = pr.e0 + wave;
+    const bool live = e < b.cnt;
+    const double *A = b.A + (long long)(live ? e : 0) * n * n;
+    for (int o = lane; o < 32 * 32; o += 64) {
+        const int i = o % 32, c = o / 32;
+        B0[i + DT32_LD * c] = (live && i < n && c < n) ? A[i + (long long)c * n] : 0.0;
+    }
+    __syncthreads();
+    v4d q1[2][2], q2[2][2];
+    dt32_mm(B0, Ys, q1, l15, l4);                           // A Y
+    dt32_mm_chain<false>(Li, q1, q2, l15, l4);              // Linv (A Y)
+    dt32_mm_chain<true>(Li, q2, q1, l15, l4);               // Linv^T Linv A Y = X^-1 A Y
+    __syncthreads();                                        // every wave is done reading its A before the result takes its place
+    dt32_store(B0, q1, l15, l4);
+    __syncthreads();
+    if (live) {
+        double *T = b.TT + (long long)e * n * n;
+        for (int o = lane; o < n * n; o += 64) T[o] = B0[(o % n) + DT32_LD * (o / n)];
+    }
+}
+constexpr size_t dense_T32_lds_bytes() { return (size_t)(2 + DT32_WAVES) * DT32_MS * sizeof(double); }
+
+// ------------------------------------------------------------------------------------------------
 // triangular solve with a diagonal block (n <= 64): one thread per right-hand-side vector.
 //   trans == 0:  L x = b (forward)      trans == 1:  L^T x = b (backward)
 // element i of vector v lives at B[v * vs + i * es]  (es = 1, vs = ldb: columns of B, "left" solve;
@@ -271,14 +397,18 @@ struct SClusterDesc {
 };
 struct STile { int cluster, ti, tj, pad; };
 
-__global__ __launch_bounds__(256) void k_schur_gather(const SClusterDesc *__restrict__ cl, const SBlockDesc *__restrict__ bl,
-                                                      const STile *__restrict__ tiles) {
+// SG_W lanes per entry, each walking every SG_W-th block of the cluster (a cluster of an SDPA-type problem has tens of blocks, and a
+// thread's walk over them is a chain of dependent loads), joined in a fixed order by shuffles
+#define SG_W 4
+__global__ __launch_bounds__(256 * SG_W) void k_schur_gather(const SClusterDesc *__restrict__ cl, const SBlockDesc *__restrict__ bl,
+                                                             const STile *__restrict__ tiles) {
     const STile t = tiles[blockIdx.x];
     const SClusterDesc c = cl[t.cluster];
-    const int p = t.ti * 16 + (threadIdx.x & 15), q = t.tj * 16 + (threadIdx.x >> 4);
-    if (p >= c.P || q >= c.P || p > q) return;
+    const int ent = threadIdx.x / SG_W, sub = threadIdx.x % SG_W;
+    const int p = t.ti * 16 + (ent & 15), q = t.tj * 16 + (ent >> 4);
+    if (p >= c.P || q >= c.P || p > q) return;             // uniform over the SG_W lanes of an entry
     double acc = 0.0;
-    for (int b = c.b0; b < c.b1; b++) {
+    for (int b = c.b0 + sub; b < c.b1; b += SG_W) {
         const SBlockDesc d = bl[b];
         if (d.kind == 0) {
             const int a0 = d.tptr[p], a1 = d.tptr[p + 1], b0 = d.tptr[q], b1 = d.tptr[q + 1];
@@ -295,8 +425,12 @@ __global__ __launch_bounds__(256) void k_schur_gather(const SClusterDesc *__rest
             if (i >= 0 && k >= 0) acc += d.Sd[k + (long long)i * d.cnt];
         }
     }
-    c.S[p + (long long)q * c.P] = acc;
-    c.S[q + (long long)p * c.P] = acc;
+#pragma unroll
+    for (int off = SG_W / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (sub == 0) {
+        c.S[p + (long long)q * c.P] = acc;
+        c.S[q + (long long)p * c.P] = acc;
+    }
 }
 
 // Q[k,l] = sum_i LB[i,k] LB[i,l] for a handful of free variables (N <= 16) and many rows: one workgroup per entry,
