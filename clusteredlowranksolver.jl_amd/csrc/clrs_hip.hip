@@ -1132,7 +1132,7 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
                     const double *Ast = c->d_static + k.w_off;
                     const int bi = (int)dtb.size();
                     dtb.push_back(DenseTBlock{Lx, Yb, Ast, nullptr, TT, n, k.cnt});
-                    for (int e0 = 0; e0 < k.cnt; e0 += DT32_WAVES) dtp.push_back(DenseTPair{bi, e0});
+                    for (int e0 = 0; e0 < k.cnt; e0 += DT32_WAVES * DT32_ITER) dtp.push_back(DenseTPair{bi, e0});
                     g2.push_back(mk_gemm(1, 0, k.cnt, k.cnt, n * n, 1.0, Ast, n * n, TT, n * n, 0.0, Sd, k.cnt));           // <A_i, T_k>   (:1102)
                     continue;
                 }

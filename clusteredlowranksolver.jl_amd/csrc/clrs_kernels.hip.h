@@ -170,30 +170,32 @@ struct DenseTBlock {
 };
 struct DenseTPair { int blk, e0; };
 #define DT32_WAVES 4
+#define DT32_ITER 2          // matrices per wave
 #define DT32_LD 34
 #define DT32_MS (32 * DT32_LD)
 __global__ __launch_bounds__(64) void k_trtri32(const DenseTBlock *__restrict__ blocks) {
-    __shared__ double Ls[32 * 33], Xs[32 * 33];
+    __shared__ double Ls[32 * 33];
     const DenseTBlock b = blocks[blockIdx.x];
     const int n = b.n, lane = threadIdx.x;
     for (int e = lane; e < 32 * 32; e += 64) {
         const int i = e % 32, c = e / 32;
         Ls[i + 33 * c] = (i < n && c < n) ? b.L[i + (long long)c * n] : (i == c ? 1.0 : 0.0);
-        Xs[i + 33 * c] = 0.0;
     }
     __syncthreads();
-    if (lane < 32) {                                        // column c = lane of the inverse by forward substitution
-        const int c = lane;
-        for (int i = c; i < 32; i++) {
-            double s = i == c ? 1.0 : 0.0;
-            for (int k = c; k < i; k++) s -= Ls[i + 33 * k] * Xs[k + 33 * c];
-            Xs[i + 33 * c] = s / Ls[i + 33 * i];
-        }
+    // column c = lane & 31 of the inverse by forward substitution, the column in registers: the reads of L are broadcasts that do
+    // not depend on the chain, which leaves one FMA per (row, k) on it
+    const int c = lane & 31;
+    double x[32];
+#pragma unroll
+    for (int i = 0; i < 32; i++) {
+        double s = i == c ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < i; k++) s -= Ls[i + 33 * k] * x[k];         // x[k] = 0 for k < c
+        x[i] = i < c ? 0.0 : s / Ls[i + 33 * i];
     }
-    __syncthreads();
-    for (int e = lane; e < 32 * 32; e += 64) {
-        const int i = e % 32, c = e / 32;
-        b.Linv[e] = (i < n && c < n) ? Xs[i + 33 * c] : 0.0;
+    if (lane < 32) {
+#pragma unroll
+        for (int i = 0; i < 32; i++) b.Linv[i + 32 * c] = (i < n && c < n) ? x[i] : 0.0;
     }
 }
 // D = X Y for 32 x 32 operands in LDS (leading dimension DT32_LD).  acc[ti][tj]: lane holds column tj*16 + (lane & 15), rows
@@ -252,30 +254,42 @@ __global__ __launch_bounds__(64 * DT32_WAVES) void k_dense_T32(const DenseTBlock
     const DenseTPair pr = pairs[blockIdx.x];
     const DenseTBlock b = blocks[pr.blk];
     const int n = b.n, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
-    double *Li = dts, *Ys = dts + DT32_MS, *B0 = dts + 2 * DT32_MS + wave * DT32_MS;
+    double *Li = dts, *Ys = dts + DT32_MS, *B0 = dts + 2 * DT32_MS + wave * DT32_MS;     // B0: this wave's matrix, then its result
     for (int e = tid; e < 32 * 32; e += 64 * DT32_WAVES) {
         const int i = e % 32, c = e / 32;
         Li[i + DT32_LD * c] = b.Linv[e];
         Ys[i + DT32_LD * c] = (i < n && c < n) ? b.Y[i + (long long)c * n] : 0.0;
     }
-    const int e = pr.e0 + wave;
-    const bool live = e < b.cnt;
-    const double *A = b.A + (long long)(live ? e : 0) * n * n;
-    for (int o = lane; o < 32 * 32; o += 64) {
-        const int i = o % 32, c = o / 32;
-        B0[i + DT32_LD * c] = (live && i < n && c < n) ? A[i + (long long)c * n] : 0.0;
-    }
-    __syncthreads();
-    v4d q1[2][2], q2[2][2];
-    dt32_mm(B0, Ys, q1, l15, l4);                           // A Y
-    dt32_mm_chain<false>(Li, q1, q2, l15, l4);              // Linv (A Y)
-    dt32_mm_chain<true>(Li, q2, q1, l15, l4);               // Linv^T Linv A Y = X^-1 A Y
-    __syncthreads();                                        // every wave is done reading its A before the result takes its place
-    dt32_store(B0, q1, l15, l4);
-    __syncthreads();
-    if (live) {
-        double *T = b.TT + (long long)e * n * n;
-        for (int o = lane; o < n * n; o += 64) T[o] = B0[(o % n) + DT32_LD * (o / n)];
+    // DT32_ITER matrices per wave, the next one fetched into registers while the products of the current one run
+    double areg[16];
+    auto fetch = [&](int e) {
+        const bool live = e < b.cnt;
+        const double *A = b.A + (long long)(live ? e : 0) * n * n;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int o = lane + 64 * r, i = o % 32, c = o / 32;
+            areg[r] = (live && i < n && c < n) ? A[i + (long long)c * n] : 0.0;
+        }
+    };
+    fetch(pr.e0 + wave);
+    __syncthreads();                                        // Linv, Y staged
+    for (int it = 0; it < DT32_ITER; it++) {
+        const int e = pr.e0 + it * DT32_WAVES + wave;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int o = lane + 64 * r;
+            B0[(o % 32) + DT32_LD * (o / 32)] = areg[r];
+        }
+        if (it + 1 < DT32_ITER) fetch(e + DT32_WAVES);
+        v4d q1[2][2], q2[2][2];
+        dt32_mm(B0, Ys, q1, l15, l4);                       // A Y
+        dt32_mm_chain<false>(Li, q1, q2, l15, l4);          // Linv (A Y)
+        dt32_mm_chain<true>(Li, q2, q1, l15, l4);           // Linv^T Linv A Y = X^-1 A Y
+        dt32_store(B0, q1, l15, l4);                        // B0 belongs to this wave alone: LDS operations of one wave keep their order
+        if (e < b.cnt) {
+            double *T = b.TT + (long long)e * n * n;
+            for (int o = lane; o < n * n; o += 64) T[o] = B0[(o % n) + DT32_LD * (o / n)];
+        }
     }
 }
 constexpr size_t dense_T32_lds_bytes() { return (size_t)(2 + DT32_WAVES) * DT32_MS * sizeof(double); }
