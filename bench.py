@@ -370,6 +370,7 @@ def main():
                 f64 = bench_fp64.main(["--steps", "500", "--warmup", "100"] + (["--skip-cpu"] if args.skip_cpu else []), emit=False)
                 out["roofline"] = f64.get("roofline")
                 out["roofline_named"] = f64.get("roofline_named")
+                out["roofline_R"] = f64.get("roofline_R")
                 out["roofline_dense"] = f64.get("roofline_dense")
                 out["fp64"] = {"what": "the fp64 kernels on the same problem SHAPES with synthetic well-conditioned iterates; the factorisation of S_j fails in fp64 "
                                        "(factor_status != 0 = the reference's SolverFailure, src/solver.jl:1249), so this is a kernel cost, not a rate of solvable iterations",

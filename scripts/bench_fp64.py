@@ -366,6 +366,43 @@ def main(argv=None, emit=True):
         except Exception as e:
             out["roofline_dense"] = {"error": repr(e)}
 
+        # ---- staged (large-block) regime on roofline instance R: config-2 structure at n = 1025, P = 2049 ----
+        try:
+            from clrs_amd.problems import polyopt_scaled
+            import clrs_amd as _cc
+            fr = _cc.flatten(polyopt_scaled(1024))
+            rctx = SchurContext(fr, device=local_rank)
+            rctx.set_stream(torch.cuda.current_stream().cuda_stream)
+            rX, rY = seeded_iterates(fr, seed=1)
+            trX, trY = torch.from_numpy(rX).to(dev), torch.from_numpy(rY).to(dev)
+            trXc = torch.empty_like(trX)
+
+            def rstep():
+                rctx.cholesky_blocks_dev(trX.data_ptr(), trXc.data_ptr())
+                rctx.assemble_dev(trXc.data_ptr(), trY.data_ptr())
+                rctx.factor_dev()
+            for _ in range(2):
+                rstep()
+            torch.cuda.synchronize()
+            assert rctx.sync_status() == 0
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                rstep()
+            e1.record(); e1.synchronize()
+            r_s = 1e-3 * e0.elapsed_time(e1) / 5
+            rcnt = rctx.counters()
+            rfl = rcnt["assemble_flops"] + rcnt["factor_flops"]
+            out["roofline_R"] = {"bound": "mfma", "phase": "chol X + schur_assemble + factor, staged (large-block) kernels", "kernel": "k_gemm_f64_t + k_trsm_diag + k_potrf_diag",
+                                 "ms": 1e3 * r_s, "achieved": rfl / r_s / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": rfl / r_s / 1e12 / FP64_PEAK_TFLOPS,
+                                 "traffic": None, "algorithmic_flops": rfl,
+                                 "workload": "polyopt_scaled(1024): one cluster, one PSD block n = 1025, P = 2049 rank-1 constraints (SURVEY.md section 8d, roofline "
+                                             "instance R; polyopt_scaled(2048): profiles/r02/g_staged_polyopt2048.txt)",
+                                 "launches": rctx.plan_info()}
+            rctx.close()
+        except Exception as e:
+            out["roofline_R"] = {"error": repr(e)}
+
         # ---- the complete interior-point method, device resident, on the instances fp64 can solve ----
         # every iteration = residuals + predictor + corrector + step lengths + update around the same hot path; one host sync per iteration
         try:
