@@ -394,8 +394,10 @@ static int run_steps(clrs_ctx *c, const Plan &pl) {
                 hipLaunchKernelGGL(k_potrf_diag, dim3(s.grid), dim3(256), 0, st, (const PotrfDesc *)s.d0, (int *)s.dst);
                 break;
             case STEP_GATHER_S:
-                hipLaunchKernelGGL(k_schur_gather, dim3(s.grid), dim3(256 * SG_W), 0, st, (const SClusterDesc *)s.d0, (const SBlockDesc *)s.d1,
-                                   (const STile *)s.d2);
+                if (s.aux0 >= 4)       // some cluster has four blocks or more: four lanes per entry walk them
+                    hipLaunchKernelGGL(k_schur_gather<4>, dim3(s.grid), dim3(1024), 0, st, (const SClusterDesc *)s.d0, (const SBlockDesc *)s.d1, (const STile *)s.d2);
+                else
+                    hipLaunchKernelGGL(k_schur_gather<1>, dim3(s.grid), dim3(256), 0, st, (const SClusterDesc *)s.d0, (const SBlockDesc *)s.d1, (const STile *)s.d2);
                 break;
             case STEP_GATHER_SCALAR:
                 hipLaunchKernelGGL(k_gather_scalar, dim3((unsigned)((s.n + 255) / 256)), dim3(256), 0, st, (double *)s.dst, (const double *)s.src,
@@ -1213,6 +1215,7 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
             Step s;
             s.kind = STEP_GATHER_S;
             s.grid = (int)tiles.size();
+            for (const SClusterDesc &cd : cl) s.aux0 = std::max(s.aux0, cd.b1 - cd.b0);      // most blocks in one cluster
             SClusterDesc *dcl; SBlockDesc *dbl; STile *dt;
             CK(upload(c, cl, &dcl)); CK(upload(c, bl, &dbl)); CK(upload(c, tiles, &dt));
             s.d0 = dcl; s.d1 = dbl; s.d2 = dt;

@@ -412,8 +412,8 @@ struct SClusterDesc {
 struct STile { int cluster, ti, tj, pad; };
 
 // SG_W lanes per entry, each walking every SG_W-th block of the cluster (a cluster of an SDPA-type problem has tens of blocks, and a
-// thread's walk over them is a chain of dependent loads), joined in a fixed order by shuffles
-#define SG_W 4
+// thread's walk over them is a chain of dependent loads), joined in a fixed order by shuffles; SG_W = 1 when no cluster has four blocks
+template <int SG_W>
 __global__ __launch_bounds__(256 * SG_W) void k_schur_gather(const SClusterDesc *__restrict__ cl, const SBlockDesc *__restrict__ bl,
                                                              const STile *__restrict__ tiles) {
     const STile t = tiles[blockIdx.x];

@@ -105,7 +105,7 @@ def test_potrf_reports_failure():
 
 
 ASSEMBLE_CASES = ["x2p1", "polyopt8", "polyopt40", "delsarte_3_10", "delsarte_8_3", "ce_8_15", "ce_8_3", "ns_8_3_2", "ns_8_15_2",
-                  "threepoint_4", "sdpa_small", "sdpa_mid", "polyopt_scaled_100"]
+                  "threepoint_4", "sdpa_small", "sdpa_mid", "polyopt_scaled_100", "polyopt_scaled_300"]
 
 
 PATHS = {"wave3": dict(fused=True, wave=True, wave2=True, wave3=True), "wave2": dict(fused=True, wave=True, wave2=True, wave3=False),
@@ -124,7 +124,7 @@ def test_schur_assemble_matches_oracle(name, path, oracle_built):
     Xc = chol_blocks_np(f, X)
     ctx = SchurContext(f, **PATHS[path])
     fused = path != "staged"
-    assert (ctx.fused_clusters() > 0) == (fused and name not in ("sdpa_mid", "polyopt_scaled_100"))
+    assert (ctx.fused_clusters() > 0) == (fused and name not in ("sdpa_mid", "polyopt_scaled_100", "polyopt_scaled_300"))
     if path in ("wave", "wave2", "wave3") and name in WAVE_CASES:
         assert ctx.wave_clusters() == f.n_clusters
     if path in ("wave2", "wave3") and name in WAVE2_CASES:
@@ -324,7 +324,7 @@ def test_dedup_counts_match_oracle(oracle_built):
 
 
 FACTOR_CASES = ["x2p1", "polyopt8", "polyopt40", "delsarte_3_10", "delsarte_8_3", "ns_8_3_2", "threepoint_4", "sdpa_small", "sdpa_mid",
-                "polyopt_scaled_100"]
+                "polyopt_scaled_100", "polyopt_scaled_300"]
 
 
 @pytest.mark.parametrize("fused", [True, "k_solve_small", "k_factor_small_waves", False],

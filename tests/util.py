@@ -69,6 +69,8 @@ def instance(name):
         return P.sdpa_to_sdp(P.sdpa_scaled(nb=64, bs=32, m=256, seed=64))
     if name == "sdpa_x64_full":         # the same with every constraint matrix full block diagonal (as in test/example.dat-s): 7.5 GFLOP per assembly
         return P.sdpa_to_sdp(P.sdpa_scaled(nb=64, bs=32, m=256, seed=64, blocks_per_constraint=64))
+    if name == "polyopt_scaled_300":      # n = 301, P = 601: beyond one outer block (256) of the staged TRSM / Cholesky plans
+        return P.polyopt_scaled(300)
     if name == "polyopt_scaled_100":
         return P.polyopt_scaled(100)
     raise KeyError(name)
