@@ -37,6 +37,7 @@ struct GemmDesc {
 struct GemmTile { int desc, batch, tm, tn; };
 
 constexpr int GEMM_BM = 64, GEMM_BN = 64, GEMM_BK = 16;   // small-tile kernel; the large-tile kernel is 128 x 128 x 16
+constexpr int gemm_padk(int BM) { return BM <= 64 ? 8 : 16; }
 
 // Workgroup tile BM x BN, 4 waves in a 2 x 2 arrangement, each wave (BM/2) x (BN/2) = (BM/32) x (BN/32) MFMA tiles.
 // LDS rows are padded by 16 doubles: the four k-rows an MFMA operand read touches then fall into different banks.
@@ -44,13 +45,15 @@ constexpr int GEMM_BM = 64, GEMM_BN = 64, GEMM_BK = 16;   // small-tile kernel; 
 // buffer after them, one barrier per step.  With 128 x 128 tiles a step is 64 MFMAs per wave (4096 cycles of the matrix
 // pipe) against 16 global loads per thread, which hides the load latency even with one workgroup per CU.
 template <int BM, int BN>
-__global__ __launch_bounds__(256) void k_gemm_f64_t(const GemmDesc *__restrict__ descs, const GemmTile *__restrict__ tiles) {
-    constexpr int BK = GEMM_BK, LDA_S = BM + 16, LDB_S = BN + 16, MT = BM / 32, NT = BN / 32, EA = BM * BK / 256, EB = BN * BK / 256;
+__global__ __launch_bounds__(256, (BM <= 64 ? 4 : 1)) void k_gemm_f64_t(const GemmDesc *__restrict__ descs, const GemmTile *__restrict__ tiles) {
+    // small tiles: a [k][i] stride of BM + 8 keeps a workgroup at 36 KB of LDS, so that FOUR of them share a compute unit: a grouped
+    // launch of 1024 tiles (the Gram contractions of the dense branch) then runs in one round instead of one and a third
+    constexpr int BK = GEMM_BK, PADK = gemm_padk(BM), LDA_S = BM + PADK, LDB_S = BN + PADK, MT = BM / 32, NT = BN / 32, EA = BM * BK / 256, EB = BN * BK / 256;
     // Two LDS layouts per operand, chosen so that BOTH the staging writes and the MFMA operand reads are conflict free:
     //   source contiguous along the tile row/column index (ta == 0 / tb == 1):  [k][i], row stride BM + 16
     //   source contiguous along k               (ta == 1 / tb == 0):            [i][k], row stride BK + 2
     constexpr int LDT = BK + 2;
-    static_assert(BK * (BM + 16) >= BM * LDT && BK * (BN + 16) >= BN * LDT, "both layouts must fit the same buffer");
+    static_assert(BK * LDA_S >= BM * LDT && BK * LDB_S >= BN * LDT, "both layouts must fit the same buffer");
     const GemmTile t = tiles[blockIdx.x];
     const GemmDesc d = descs[t.desc];
     const double *__restrict__ A = d.A + (long long)t.batch * d.sA;
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(256) void k_gemm_f64_t(const GemmDesc *__restrict__
                 }
             }
 }
-constexpr size_t gemm_lds_bytes(int BM, int BN) { return (size_t)2 * GEMM_BK * ((BM + 16) + (BN + 16)) * sizeof(double); }
+constexpr size_t gemm_lds_bytes(int BM, int BN) { return (size_t)2 * GEMM_BK * ((BM + gemm_padk(BM)) + (BN + gemm_padk(BM))) * sizeof(double); }
 
 // ------------------------------------------------------------------------------------------------
 // Dense ("high rank") branch for blocks with n <= 32 and MANY matrices (SDPA-type problems; src/solver.jl:1089-1097):
