@@ -57,6 +57,7 @@ static int g_cfg_wave_assemble = 1;
 static int g_cfg_wave2_assemble = 1;
 static int g_cfg_wave3_assemble = 1;   // register-resident form of the cluster-per-wave assembly (U <= 32); 0: k_cluster_assemble_w2
 static int g_cfg_dense_block = 1;
+static int g_cfg_trsm_blockinv = 1;  // triangular solves with n > TRSM_IB through inverted diagonal blocks (plan_trsm_blockinv)
 static int g_cfg_dense_wave = 1;      // dense blocks with n <= 32 beyond k_dense_block: one wave per (block, matrix), k_dense_T32
 static int g_cfg_factor_small = 1;      // factor + Q in one launch of one workgroup for <= 4 small clusters (0: k_cluster_factor + k_small_potrf)
 static int g_cfg_solve_small_max = 32768;     // one-workgroup solve stage only up to this many doubles of operands (beyond: one workgroup per cluster, three launches)
@@ -67,10 +68,10 @@ static const int LDS_BUDGET_DOUBLES = 20000;   // of the 20480 doubles (160 KiB)
 // ------------------------------------------------------------------------------------------------
 // launch plan
 // ------------------------------------------------------------------------------------------------
-enum StepKind { STEP_MEMCPY, STEP_GEMM, STEP_TRSM, STEP_POTRF, STEP_GATHER_S, STEP_GATHER_SCALAR, STEP_SUB, STEP_MEMSET_INFO, STEP_ZERO_UPPER, STEP_FUSED_ASSEMBLE, STEP_SMALL_POTRF, STEP_CLUSTER_FACTOR, STEP_GEMV_T, STEP_CSOLVE_FWD, STEP_Q_SOLVE, STEP_CSOLVE_BWD, STEP_SUM_SLABS, STEP_ASSEMBLE_W1, STEP_GRAM_SMALL, STEP_ASSEMBLE_W2, STEP_SOLVE_SMALL, STEP_DENSE_BLOCK, STEP_ASSEMBLE_W3, STEP_FACTOR_SMALL, STEP_SUM_S_SLABS, STEP_TRTRI32, STEP_DENSE_T32, STEP_NKINDS };
+enum StepKind { STEP_MEMCPY, STEP_GEMM, STEP_TRSM, STEP_POTRF, STEP_GATHER_S, STEP_GATHER_SCALAR, STEP_SUB, STEP_MEMSET_INFO, STEP_ZERO_UPPER, STEP_FUSED_ASSEMBLE, STEP_SMALL_POTRF, STEP_CLUSTER_FACTOR, STEP_GEMV_T, STEP_CSOLVE_FWD, STEP_Q_SOLVE, STEP_CSOLVE_BWD, STEP_SUM_SLABS, STEP_ASSEMBLE_W1, STEP_GRAM_SMALL, STEP_ASSEMBLE_W2, STEP_SOLVE_SMALL, STEP_DENSE_BLOCK, STEP_ASSEMBLE_W3, STEP_FACTOR_SMALL, STEP_SUM_S_SLABS, STEP_TRTRI32, STEP_DENSE_T32, STEP_TRTRI_DIAG, STEP_COPY2D, STEP_NKINDS };
 static const char *const STEP_NAMES[STEP_NKINDS] = {"hipMemcpyAsync(D2D)", "k_gemm_f64_t", "k_trsm_diag", "k_potrf_diag", "k_schur_gather",
                                                     "k_gather_scalar", "k_sub", "hipMemsetAsync", "k_zero_upper", "k_cluster_assemble", "k_small_potrf", "k_cluster_factor", "k_gemv_t",
-                                                    "k_cluster_solve_fwd", "k_q_solve", "k_cluster_solve_bwd", "k_sum_slabs", "k_cluster_assemble_w1", "k_gram_small", "k_cluster_assemble_w2", "k_solve_small", "k_dense_block", "k_cluster_assemble_w3", "k_factor_small", "k_sum_S_slabs", "k_trtri32", "k_dense_T32"};
+                                                    "k_cluster_solve_fwd", "k_q_solve", "k_cluster_solve_bwd", "k_sum_slabs", "k_cluster_assemble_w1", "k_gram_small", "k_cluster_assemble_w2", "k_solve_small", "k_dense_block", "k_cluster_assemble_w3", "k_factor_small", "k_sum_S_slabs", "k_trtri32", "k_dense_T32", "k_trtri_diag", "k_copy2d"};
 static const int KT_MAX_EVENTS = 8192;   // event pairs kept between two clrs_get_kernel_times calls
 
 struct Step {
@@ -281,9 +282,118 @@ static int add_trsm_stage(clrs_ctx *c, Plan &pl, const std::vector<TrsmDesc> &de
     return 0;
 }
 
+// Large triangles (n > TRSM_IB): the same solves through explicit inverses of the TRSM_IB x TRSM_IB diagonal blocks of L.
+//   1. every 64 x 64 leaf of L inverted, all leaves of all problems in one launch (k_trtri_diag);
+//   2. pairs of inverses joined, log2(TRSM_IB / 64) levels of two GEMM stages:  T = B A^-1,  off-diagonal block = -C^-1 T;
+//   3. per TRSM_IB rows:  Y_k = op(Inv_k) B_k  (into a scratch copy of B),  B_rest -= op(L_rest,k) Y_k;  then Y copied back over B.
+// n / TRSM_IB levels of two launches instead of n / 64: the level-synchronous chain of plan_trsm_chain is what bounds the staged regime
+// (profiles/r02/g_staged_polyopt2048*), not its flops.  The products with the triangular inverse blocks run as full GEMMs
+// (2 TRSM_IB n nrhs flops on top of the n^2 nrhs of the substitution).
+static int plan_trsm_blockinv(clrs_ctx *c, Plan &pl, const std::vector<TrsmJob> &jobs, int trans) {
+    constexpr int IB = TRSM_IB;
+    int rc, maxob = 0;
+    struct Aux { double *inv, *T, *Y; int nob; };
+    std::vector<Aux> aux(jobs.size());
+    std::vector<TrtriDesc> leaves;
+    for (size_t q = 0; q < jobs.size(); q++) {
+        const TrsmJob &j = jobs[q];
+        Aux &a = aux[q];
+        a.nob = (j.n + IB - 1) / IB;
+        maxob = std::max(maxob, a.nob);
+        if ((rc = dmalloc(c, &a.inv, (i64)a.nob * IB * IB))) return rc;
+        if ((rc = dmalloc(c, &a.T, (i64)j.n * (IB / 2)))) return rc;
+        if ((rc = dmalloc(c, &a.Y, (i64)j.n * j.nrhs))) return rc;
+        HIPCHECK(hipMemset(a.inv, 0, sizeof(double) * (size_t)a.nob * IB * IB));      // the strict upper triangles stay zero
+        for (int o = 0; o < a.nob; o++) {
+            const int r0 = o * IB, nb = std::min(IB, j.n - r0);
+            for (int l0 = 0; l0 < nb; l0 += TRSM_NB) {
+                TrtriDesc d;
+                d.L = j.L + (r0 + l0) + (i64)(r0 + l0) * j.ldl; d.ldl = j.ldl; d.n = std::min(TRSM_NB, nb - l0); d.pad = 0;
+                d.out = a.inv + (i64)o * IB * IB + l0 + (i64)l0 * IB; d.ldo = IB;
+                leaves.push_back(d);
+            }
+        }
+    }
+    {
+        Step s;
+        s.kind = STEP_TRTRI_DIAG; s.grid = (int)leaves.size();
+        TrtriDesc *dl;
+        if ((rc = upload(c, leaves, &dl))) return rc;
+        s.d0 = dl;
+        pl.steps.push_back(s);
+        HIPCHECK(hipFuncSetAttribute((const void *)k_trtri_diag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)trtri_diag_lds_bytes()));
+    }
+    for (int b = TRSM_NB; b < IB; b *= 2) {
+        std::vector<GemmDesc> ga, gb;
+        for (size_t q = 0; q < jobs.size(); q++) {
+            const TrsmJob &j = jobs[q];
+            const Aux &a = aux[q];
+            i64 toff = 0;
+            for (int o = 0; o < a.nob; o++) {
+                const int r0 = o * IB, nb = std::min(IB, j.n - r0);
+                double *inv = a.inv + (i64)o * IB * IB;
+                for (int lo = 0; lo + b < nb; lo += 2 * b) {
+                    const int mid = lo + b, hi = std::min(lo + 2 * b, nb), rows = hi - mid;
+                    double *T = a.T + toff;
+                    toff += (i64)rows * b;
+                    ga.push_back(mk_gemm(0, 0, rows, b, b, 1.0, j.L + (r0 + mid) + (i64)(r0 + lo) * j.ldl, j.ldl, inv + lo + (i64)lo * IB, IB, 0.0, T, rows));
+                    gb.push_back(mk_gemm(0, 0, rows, b, rows, -1.0, inv + mid + (i64)mid * IB, IB, T, rows, 0.0, inv + mid + (i64)lo * IB, IB));
+                }
+            }
+        }
+        if ((rc = add_gemm_stage(c, pl, ga))) return rc;
+        if ((rc = add_gemm_stage(c, pl, gb))) return rc;
+    }
+    for (int step = 0; step < maxob; step++) {
+        std::vector<GemmDesc> gy, gu;
+        for (size_t q = 0; q < jobs.size(); q++) {
+            const TrsmJob &j = jobs[q];
+            const Aux &a = aux[q];
+            if (step >= a.nob) continue;
+            const int k = trans ? a.nob - 1 - step : step, r0 = k * IB, nk = std::min(IB, j.n - r0);
+            const double *inv = a.inv + (i64)k * IB * IB;
+            gy.push_back(mk_gemm(trans ? 1 : 0, 0, nk, j.nrhs, nk, 1.0, inv, IB, j.B + r0, j.ldb, 0.0, a.Y + r0, j.n));
+            if (!trans) {
+                const int rem = j.n - (r0 + nk);
+                if (rem > 0) gu.push_back(mk_gemm(0, 0, rem, j.nrhs, nk, -1.0, j.L + (r0 + nk) + (i64)r0 * j.ldl, j.ldl, a.Y + r0, j.n, 1.0, j.B + r0 + nk, j.ldb));
+            } else if (r0 > 0)
+                gu.push_back(mk_gemm(1, 0, r0, j.nrhs, nk, -1.0, j.L + r0, j.ldl, a.Y + r0, j.n, 1.0, j.B, j.ldb));
+        }
+        if ((rc = add_gemm_stage(c, pl, gy))) return rc;
+        if ((rc = add_gemm_stage(c, pl, gu))) return rc;
+    }
+    std::vector<Copy2dDesc> cp;
+    i64 most = 0;
+    for (size_t q = 0; q < jobs.size(); q++) {
+        const TrsmJob &j = jobs[q];
+        cp.push_back(Copy2dDesc{aux[q].Y, j.B, j.n, j.ldb, j.n, j.nrhs});
+        most = std::max(most, (i64)j.n * j.nrhs);
+    }
+    Step s;
+    s.kind = STEP_COPY2D; s.grid = (int)cp.size(); s.aux0 = (int)std::min<i64>((most + 1023) / 1024, 4096);
+    Copy2dDesc *dc;
+    if ((rc = upload(c, cp, &dc))) return rc;
+    s.d0 = dc;
+    pl.steps.push_back(s);
+    return 0;
+}
+
 // B <- L^-1 B (trans = 0) or L^-T B (trans = 1) for a list of independent problems, blocked by
 // TRSM_NB, level-synchronous over the problems.
+static int plan_trsm_chain(clrs_ctx *c, Plan &pl, const std::vector<TrsmJob> &jobs, int trans);
 static int plan_trsm(clrs_ctx *c, Plan &pl, const std::vector<TrsmJob> &jobs, int trans) {
+    std::vector<TrsmJob> chain, big;
+    for (const TrsmJob &j : jobs) {
+        if (j.n <= 0 || j.nrhs <= 0) continue;
+        const bool inv = g_cfg_trsm_blockinv && j.n > TRSM_IB && (i64)j.n * j.nrhs <= (i64)1 << 31;       // scratch copy of B: 16 GB at most
+        (inv ? big : chain).push_back(j);
+    }
+    int rc;
+    if (!chain.empty() && (rc = plan_trsm_chain(c, pl, chain, trans))) return rc;
+    if (!big.empty() && (rc = plan_trsm_blockinv(c, pl, big, trans))) return rc;
+    return 0;
+}
+static int plan_trsm_chain(clrs_ctx *c, Plan &pl, const std::vector<TrsmJob> &jobs, int trans) {
     int maxp = 0;
     for (const TrsmJob &j : jobs) maxp = std::max(maxp, (j.n + TRSM_NB - 1) / TRSM_NB);
     int rc;
@@ -421,6 +531,12 @@ static int run_steps(clrs_ctx *c, const Plan &pl) {
                 break;
             case STEP_DENSE_T32:
                 hipLaunchKernelGGL(k_dense_T32, dim3(s.grid), dim3(64 * DT32_WAVES), dense_T32_lds_bytes(), st, (const DenseTBlock *)s.d0, (const DenseTPair *)s.d1);
+                break;
+            case STEP_TRTRI_DIAG:
+                hipLaunchKernelGGL(k_trtri_diag, dim3(s.grid), dim3(256), trtri_diag_lds_bytes(), st, (const TrtriDesc *)s.d0);
+                break;
+            case STEP_COPY2D:
+                hipLaunchKernelGGL(k_copy2d, dim3(s.aux0, s.grid), dim3(256), 0, st, (const Copy2dDesc *)s.d0);
                 break;
             case STEP_SOLVE_SMALL:
                 if (s.aux0 >= 2) {
@@ -2105,6 +2221,7 @@ extern "C" int clrs_config_set(const char *key, int value) {
     if (!std::strcmp(key, "wave3_assemble")) { g_cfg_wave3_assemble = value; return 0; }
     if (!std::strcmp(key, "dense_block")) { g_cfg_dense_block = value; return 0; }
     if (!std::strcmp(key, "dense_wave")) { g_cfg_dense_wave = value; return 0; }
+    if (!std::strcmp(key, "trsm_blockinv")) { g_cfg_trsm_blockinv = value; return 0; }
     if (!std::strcmp(key, "solve_small2")) { g_cfg_solve_small2 = value; return 0; }
     if (!std::strcmp(key, "factor_small")) { g_cfg_factor_small = value; return 0; }
     if (!std::strcmp(key, "pin_limit")) { PIN_LIMIT = (size_t)std::max(value, 0); return 0; }

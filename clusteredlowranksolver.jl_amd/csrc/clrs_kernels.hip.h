@@ -362,6 +362,58 @@ __global__ __launch_bounds__(256) void k_trsm_diag(const TrsmDesc *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Inverse of a lower triangular diagonal block (n <= 64): out = L^-1 (lower triangle; the strict upper triangle is written as zero).
+// Every 64 x 64 leaf of a large triangular factor is independent of the others, so ONE launch inverts them all; the host then joins
+// pairs of inverses by two GEMMs per doubling ([[A,0],[B,C]]^-1 = [[A^-1,0],[-C^-1 B A^-1, C^-1]]) up to blocks of TRSM_IB, and a
+// triangular solve with many right-hand sides becomes n / TRSM_IB levels of GEMMs instead of n / 64 levels of substitutions.
+// ------------------------------------------------------------------------------------------------
+struct TrtriDesc {
+    const double *L;
+    double *out;
+    int ldl, ldo, n, pad;
+};
+constexpr int TRSM_IB = 512;
+constexpr size_t trtri_diag_lds_bytes() { return (size_t)(2 * (TRSM_NB + 2) * TRSM_NB + TRSM_NB) * sizeof(double); }
+__global__ __launch_bounds__(256) void k_trtri_diag(const TrtriDesc *__restrict__ descs) {
+    extern __shared__ __attribute__((aligned(16))) double tts[];
+    const TrtriDesc d = descs[blockIdx.x];
+    constexpr int LDL = TRSM_NB + 2;
+    double *Ls = tts, *Zs = tts + LDL * TRSM_NB, *dinv = Zs + LDL * TRSM_NB;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = d.n, n16 = (n + 15) & ~15;
+    const int i16 = tid & 15, j16 = tid >> 4;
+    for (int j0 = 0; j0 < n16; j0 += 16)
+        for (int i0 = 0; i0 < n16; i0 += 16) {
+            const int i = i0 + i16, j = j0 + j16;
+            Ls[i + j * LDL] = (i < n && j < n && i >= j) ? d.L[i + (long long)j * d.ldl] : 0.0;
+            Zs[i + j * LDL] = (i == j && i < n) ? 1.0 : 0.0;
+        }
+    if (tid < n16) dinv[tid] = (tid < n) ? 1.0 / d.L[tid + (long long)tid * d.ldl] : 0.0;
+    __syncthreads();
+    lds_trsm<false>(Ls, LDL, dinv, Zs, 1, LDL, n, n, wave, 4, lane);
+    __syncthreads();
+    for (int j0 = 0; j0 < n; j0 += 16)
+        for (int i0 = 0; i0 < n; i0 += 16) {
+            const int i = i0 + i16, j = j0 + j16;
+            if (i < n && j < n) d.out[i + (long long)j * d.ldo] = (i >= j) ? Zs[i + j * LDL] : 0.0;
+        }
+}
+// rows x cols copy between two column-major arrays (the solved right-hand sides back into the caller's array)
+struct Copy2dDesc {
+    const double *src;
+    double *dst;
+    long long lds, ldd;
+    int rows, cols;
+};
+__global__ __launch_bounds__(256) void k_copy2d(const Copy2dDesc *__restrict__ descs) {
+    const Copy2dDesc d = descs[blockIdx.y];
+    const long long total = (long long)d.rows * d.cols;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long i = e % d.rows, j = e / d.rows;
+        d.dst[i + j * d.ldd] = d.src[i + j * d.lds];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Cholesky of a diagonal block (n <= 64), one workgroup per matrix, LDS resident, right-looking.
 // On a non-positive pivot records `code` (atomicMin) in *info; the lower triangle is overwritten by L.
 // ------------------------------------------------------------------------------------------------

@@ -38,3 +38,10 @@ for _ in range(3): step()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / 3
 print("wall per (cholX + assemble + factor): %.2f ms -> %.2f TFLOP/s overall" % (1e3*dt, (cnt["assemble_flops"]+cnt["factor_flops"])/dt/1e12))
+for name, fn in (("cholX", lambda: ctx.cholesky_blocks_dev(tX.data_ptr(), tXc.data_ptr())), ("assemble", lambda: ctx.assemble_dev(tXc.data_ptr(), tY.data_ptr())),
+                 ("assemble + factor", lambda: (ctx.assemble_dev(tXc.data_ptr(), tY.data_ptr()), ctx.factor_dev()))):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    print("  phase %-18s %.2f ms" % (name, 1e3 * (time.perf_counter() - t0) / 3))

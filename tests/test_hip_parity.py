@@ -37,8 +37,9 @@ def test_gemm_kernel(ta, tb, M, N, K):
     assert np.max(np.abs(Cf - ref)) <= 1e-12 * max(1.0, np.max(np.abs(ref)))
 
 
-@pytest.mark.parametrize("n", [1, 2, 17, 64, 65, 150, 300])
+@pytest.mark.parametrize("n", [1, 2, 17, 64, 65, 150, 300, 513, 600, 1100])
 def test_potrf_and_trsm(n):
+    """n > 512: the triangular solves run through inverted 512 x 512 diagonal blocks (plan_trsm_blockinv), with ragged last blocks."""
     rng = np.random.default_rng(n)
     G = rng.standard_normal((n, n))
     A = np.asfortranarray(np.eye(n) + G @ G.T / n)
