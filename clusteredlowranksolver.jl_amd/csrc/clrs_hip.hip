@@ -58,6 +58,7 @@ static int g_cfg_wave2_assemble = 1;
 static int g_cfg_wave3_assemble = 1;   // register-resident form of the cluster-per-wave assembly (U <= 32); 0: k_cluster_assemble_w2
 static int g_cfg_dense_block = 1;
 static int g_cfg_trsm_blockinv = 1;  // triangular solves with n > TRSM_IB through inverted diagonal blocks (plan_trsm_blockinv)
+static int g_cfg_potrf_levels = 1;   // Cholesky of matrices beyond one block: one launch per block column (plan_potrf_levels)
 static int g_cfg_dense_wave = 1;      // dense blocks with n <= 32 beyond k_dense_block: one wave per (block, matrix), k_dense_T32
 static int g_cfg_factor_small = 1;      // factor + Q in one launch of one workgroup for <= 4 small clusters (0: k_cluster_factor + k_small_potrf)
 static int g_cfg_solve_small_max = 32768;     // one-workgroup solve stage only up to this many doubles of operands (beyond: one workgroup per cluster, three launches)
@@ -68,10 +69,10 @@ static const int LDS_BUDGET_DOUBLES = 20000;   // of the 20480 doubles (160 KiB)
 // ------------------------------------------------------------------------------------------------
 // launch plan
 // ------------------------------------------------------------------------------------------------
-enum StepKind { STEP_MEMCPY, STEP_GEMM, STEP_TRSM, STEP_POTRF, STEP_GATHER_S, STEP_GATHER_SCALAR, STEP_SUB, STEP_MEMSET_INFO, STEP_ZERO_UPPER, STEP_FUSED_ASSEMBLE, STEP_SMALL_POTRF, STEP_CLUSTER_FACTOR, STEP_GEMV_T, STEP_CSOLVE_FWD, STEP_Q_SOLVE, STEP_CSOLVE_BWD, STEP_SUM_SLABS, STEP_ASSEMBLE_W1, STEP_GRAM_SMALL, STEP_ASSEMBLE_W2, STEP_SOLVE_SMALL, STEP_DENSE_BLOCK, STEP_ASSEMBLE_W3, STEP_FACTOR_SMALL, STEP_SUM_S_SLABS, STEP_TRTRI32, STEP_DENSE_T32, STEP_TRTRI_DIAG, STEP_COPY2D, STEP_NKINDS };
+enum StepKind { STEP_MEMCPY, STEP_GEMM, STEP_TRSM, STEP_POTRF, STEP_GATHER_S, STEP_GATHER_SCALAR, STEP_SUB, STEP_MEMSET_INFO, STEP_ZERO_UPPER, STEP_FUSED_ASSEMBLE, STEP_SMALL_POTRF, STEP_CLUSTER_FACTOR, STEP_GEMV_T, STEP_CSOLVE_FWD, STEP_Q_SOLVE, STEP_CSOLVE_BWD, STEP_SUM_SLABS, STEP_ASSEMBLE_W1, STEP_GRAM_SMALL, STEP_ASSEMBLE_W2, STEP_SOLVE_SMALL, STEP_DENSE_BLOCK, STEP_ASSEMBLE_W3, STEP_FACTOR_SMALL, STEP_SUM_S_SLABS, STEP_TRTRI32, STEP_DENSE_T32, STEP_TRTRI_DIAG, STEP_COPY2D, STEP_CHOL_LEVEL, STEP_NKINDS };
 static const char *const STEP_NAMES[STEP_NKINDS] = {"hipMemcpyAsync(D2D)", "k_gemm_f64_t", "k_trsm_diag", "k_potrf_diag", "k_schur_gather",
                                                     "k_gather_scalar", "k_sub", "hipMemsetAsync", "k_zero_upper", "k_cluster_assemble", "k_small_potrf", "k_cluster_factor", "k_gemv_t",
-                                                    "k_cluster_solve_fwd", "k_q_solve", "k_cluster_solve_bwd", "k_sum_slabs", "k_cluster_assemble_w1", "k_gram_small", "k_cluster_assemble_w2", "k_solve_small", "k_dense_block", "k_cluster_assemble_w3", "k_factor_small", "k_sum_S_slabs", "k_trtri32", "k_dense_T32", "k_trtri_diag", "k_copy2d"};
+                                                    "k_cluster_solve_fwd", "k_q_solve", "k_cluster_solve_bwd", "k_sum_slabs", "k_cluster_assemble_w1", "k_gram_small", "k_cluster_assemble_w2", "k_solve_small", "k_dense_block", "k_cluster_assemble_w3", "k_factor_small", "k_sum_S_slabs", "k_trtri32", "k_dense_T32", "k_trtri_diag", "k_copy2d", "k_chol_level"};
 static const int KT_MAX_EVENTS = 8192;   // event pairs kept between two clrs_get_kernel_times calls
 
 struct Step {
@@ -154,6 +155,7 @@ struct clrs_ctx {
     std::vector<BlockInfo> blk;
     std::vector<void *> allocs;  // every hipMalloc, for destroy
     // device buffers
+    std::vector<CholLevelJob> chol_jobs;           // jobs of the single-matrix k_chol_level launches (passed by value)
     double *d_Xc = nullptr, *d_Y = nullptr;        // inputs (xy layout)
     double *d_static = nullptr, *d_work = nullptr; // [Vexp | Astack] and [Z | W] (identical layouts: one memcpy)
     i64 solve_arena_len = 0;
@@ -426,8 +428,78 @@ static int plan_trsm_chain(clrs_ctx *c, Plan &pl, const std::vector<TrsmJob> &jo
     return 0;
 }
 
+// Matrices beyond one block: one launch per block column (k_chol_level) instead of the three of plan_potrf_chain, then the diagonal
+// factors copied from their side buffer into the matrices.
+static int plan_potrf_levels(clrs_ctx *c, Plan &pl, const std::vector<PotrfJob> &jobs, int *info) {
+    int rc, maxp = 0;
+    std::vector<double *> dbuf(jobs.size());
+    for (size_t q = 0; q < jobs.size(); q++) {
+        const int np = (jobs[q].n + 63) / 64;
+        maxp = std::max(maxp, np);
+        if ((rc = dmalloc(c, &dbuf[q], (i64)np * 4096))) return rc;
+    }
+    HIPCHECK(hipFuncSetAttribute((const void *)k_chol_level, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol_level_lds_bytes()));
+    for (int lvl = -1; lvl <= maxp - 2; lvl++) {
+        std::vector<CholLevelJob> cj;
+        std::vector<CholLevelWork> col, bulk;
+        for (size_t q = 0; q < jobs.size(); q++) {
+            const PotrfJob &j = jobs[q];
+            const int np = (j.n + 63) / 64, cb = lvl + 1;
+            if (cb >= np) continue;
+            const int id = (int)cj.size();
+            cj.push_back(CholLevelJob{j.A, dbuf[q], j.lda, j.n, lvl, j.code});
+            for (int i = cb; i < np; i++) col.push_back(CholLevelWork{id, 0, i, 0});
+            const int rb = (lvl + 2) * 64;
+            if (lvl >= 0 && rb < j.n) {
+                const int nt = (j.n - rb + 127) / 128;
+                for (int tj = 0; tj < nt; tj++)
+                    for (int ti = tj; ti < nt; ti++) bulk.push_back(CholLevelWork{id, 1, ti, tj});
+            }
+        }
+        if (col.empty()) continue;
+        const int ncol = (int)col.size();
+        col.insert(col.end(), bulk.begin(), bulk.end());       // the column workgroups (the critical path) are dispatched first
+        Step s;
+        s.kind = STEP_CHOL_LEVEL; s.grid = (int)col.size(); s.dst = info ? info : c->d_info;
+        if (cj.size() == 1) {                                  // the kernel derives the same order from blockIdx.x
+            c->chol_jobs.push_back(cj[0]);
+            s.aux1 = 1; s.aux0 = ncol; s.n = (i64)c->chol_jobs.size() - 1;
+        } else {
+            CholLevelJob *dj; CholLevelWork *dw;
+            if ((rc = upload(c, cj, &dj))) return rc;
+            if ((rc = upload(c, col, &dw))) return rc;
+            s.d0 = dj; s.d1 = dw;
+        }
+        pl.steps.push_back(s);
+    }
+    std::vector<Copy2dDesc> cp;
+    for (size_t q = 0; q < jobs.size(); q++) {
+        const PotrfJob &j = jobs[q];
+        for (int r0 = 0, b = 0; r0 < j.n; r0 += 64, b++) {
+            const int m = std::min(64, j.n - r0);
+            cp.push_back(Copy2dDesc{dbuf[q] + (i64)b * 4096, j.A + r0 + (i64)r0 * j.lda, 64, j.lda, m, m});
+        }
+    }
+    Step s;
+    s.kind = STEP_COPY2D; s.grid = (int)cp.size(); s.aux0 = 4;
+    Copy2dDesc *dc;
+    if ((rc = upload(c, cp, &dc))) return rc;
+    s.d0 = dc;
+    pl.steps.push_back(s);
+    return 0;
+}
+
 // in-place lower Cholesky of a list of independent matrices, blocked by POTRF_NB, level-synchronous.
+static int plan_potrf_chain(clrs_ctx *c, Plan &pl, const std::vector<PotrfJob> &jobs, int *info);
 static int plan_potrf(clrs_ctx *c, Plan &pl, const std::vector<PotrfJob> &jobs, int *info = nullptr) {
+    std::vector<PotrfJob> chain, big;
+    for (const PotrfJob &j : jobs) ((g_cfg_potrf_levels && j.n > POTRF_NB) ? big : chain).push_back(j);
+    int rc;
+    if (!chain.empty() && (rc = plan_potrf_chain(c, pl, chain, info))) return rc;
+    if (!big.empty() && (rc = plan_potrf_levels(c, pl, big, info))) return rc;
+    return 0;
+}
+static int plan_potrf_chain(clrs_ctx *c, Plan &pl, const std::vector<PotrfJob> &jobs, int *info) {
     int maxp = 0;
     for (const PotrfJob &j : jobs) maxp = std::max(maxp, (j.n + POTRF_NB - 1) / POTRF_NB);
     int rc;
@@ -534,6 +606,14 @@ static int run_steps(clrs_ctx *c, const Plan &pl) {
                 break;
             case STEP_TRTRI_DIAG:
                 hipLaunchKernelGGL(k_trtri_diag, dim3(s.grid), dim3(256), trtri_diag_lds_bytes(), st, (const TrtriDesc *)s.d0);
+                break;
+            case STEP_CHOL_LEVEL:
+                if (s.aux1 == 1) {       // one matrix: job by value (kept in the context), no tables
+                    hipLaunchKernelGGL(k_chol_level, dim3(s.grid), dim3(256), chol_level_lds_bytes(), st, c->chol_jobs[(size_t)s.n], s.aux0,
+                                       (const CholLevelJob *)nullptr, (const CholLevelWork *)nullptr, (int *)s.dst);
+                } else
+                    hipLaunchKernelGGL(k_chol_level, dim3(s.grid), dim3(256), chol_level_lds_bytes(), st, CholLevelJob{}, 0, (const CholLevelJob *)s.d0,
+                                       (const CholLevelWork *)s.d1, (int *)s.dst);
                 break;
             case STEP_COPY2D:
                 hipLaunchKernelGGL(k_copy2d, dim3(s.aux0, s.grid), dim3(256), 0, st, (const Copy2dDesc *)s.d0);
@@ -2221,6 +2301,7 @@ extern "C" int clrs_config_set(const char *key, int value) {
     if (!std::strcmp(key, "wave3_assemble")) { g_cfg_wave3_assemble = value; return 0; }
     if (!std::strcmp(key, "dense_block")) { g_cfg_dense_block = value; return 0; }
     if (!std::strcmp(key, "dense_wave")) { g_cfg_dense_wave = value; return 0; }
+    if (!std::strcmp(key, "potrf_levels")) { g_cfg_potrf_levels = value; return 0; }
     if (!std::strcmp(key, "trsm_blockinv")) { g_cfg_trsm_blockinv = value; return 0; }
     if (!std::strcmp(key, "solve_small2")) { g_cfg_solve_small2 = value; return 0; }
     if (!std::strcmp(key, "factor_small")) { g_cfg_factor_small = value; return 0; }

@@ -534,6 +534,194 @@ __global__ void k_sub(double *__restrict__ y, const double *__restrict__ a, cons
     if (i < n) y[i] = a[i] - b[i];
 }
 
+// ------------------------------------------------------------------------------------------------
+// Blocked Cholesky of a large matrix (n > 64), ONE launch per block column instead of three (k_potrf_diag, k_trsm_diag, k_gemm_f64_t): what
+// bounds the staged regime is the chain of dependent launches, n / 64 levels long (profiles/r02/g_staged_polyopt2048*), not its flops.
+// Launch k (k = -1 .. np - 2) finds the panel of block column k final (L_ik, i > k) and does, with c = k + 1:
+//   kind 0, one workgroup per block row i >= c ("column" workgroups, the critical path):
+//       D = A_cc - L_ck L_ck^T;  T = A_ic - L_ik L_ck^T;  D = chol(D) (every workgroup for itself: no workgroup waits for another);
+//       i == c: L_cc -> the side buffer J.D (the others still read the raw A_cc; copied into A after the last launch);
+//       i >  c: L_ic = T L_cc^-T as a product with the inverse of L_cc (lds_trsm on the identity) -> A_ic;
+//   kind 1, one workgroup per 128 x 128 tile of the rest of the trailing matrix (block columns >= c + 1, lower tiles only):
+//       A_ij -= L_ik L_jk^T, both panels of the tile loaded at once (K = 64: one round trip to memory, no k-loop).
+// All operand tiles are column-major in LDS with leading dimension CL_LD.
+// ------------------------------------------------------------------------------------------------
+struct CholLevelJob {
+    double *A, *D;               // matrix (lower triangle), side buffer of np diagonal factors (64 x 64 each, ld 64)
+    int lda, n, k, code;
+};
+struct CholLevelWork { int job, kind, ti, tj; };
+constexpr int CL_LD = 136, CL_TS = CL_LD * 64;       // one 128 x 64 panel in LDS
+constexpr size_t chol_level_lds_bytes() { return (size_t)(2 * CL_TS + 64) * sizeof(double); }
+
+// acc[a][b] = sum_k X[i][k] Y[j][k], k < 64, over NA x NB subtiles of 16 x 16: rows i of X from X[0], rows j of Y from Y[0]; the lane
+// holds i = 16 a + (lane & 15), j = 16 b + (lane >> 4) + 4 reg
+template <int NA, int NB>
+__device__ __forceinline__ void cl_mm(const double *X, const double *Y, v4d (&acc)[NA][NB], int l15, int l4) {
+#pragma unroll
+    for (int a = 0; a < NA; a++)
+#pragma unroll
+        for (int b = 0; b < NB; b++) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 64; kk += 4) {
+        double av[NA], bv[NB];
+#pragma unroll
+        for (int a = 0; a < NA; a++) av[a] = X[(a * 16 + l15) + (kk + l4) * CL_LD];
+#pragma unroll
+        for (int b = 0; b < NB; b++) bv[b] = Y[(b * 16 + l15) + (kk + l4) * CL_LD];
+#pragma unroll
+        for (int a = 0; a < NA; a++)
+#pragma unroll
+            for (int b = 0; b < NB; b++) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[b], av[a], acc[a][b], 0, 0, 0);
+    }
+}
+// rows x cols (<= 128 x 64) of a column-major array into a panel, zero filled.  The addresses are clamped into the valid part instead
+// of guarded: a guarded load is a branch, and the loads of a thread then wait for each other (15 us for four 64 x 64 tiles against 3).
+__device__ __forceinline__ void cl_load(double *dst, const double *src, long long ld, int rows, int cols, int tid) {
+    if (rows <= 0 || cols <= 0) {
+        for (int e = tid; e < 128 * 64; e += 256) dst[(e & 127) + (e >> 7) * CL_LD] = 0.0;
+        return;
+    }
+    double v[32];
+#pragma unroll
+    for (int q = 0; q < 32; q++) {
+        const int e = tid + 256 * q, i = e & 127, j = e >> 7;
+        v[q] = src[min(i, rows - 1) + min(j, cols - 1) * ld];
+    }
+#pragma unroll
+    for (int q = 0; q < 32; q++) {
+        const int e = tid + 256 * q, i = e & 127, j = e >> 7;
+        dst[i + j * CL_LD] = (i < rows && j < cols) ? v[q] : 0.0;
+    }
+}
+#ifdef CL_STAMPS
+#define CL_STAMP(i) do { if (blockIdx.x == 1 && threadIdx.x == 0) g_cl_stamps[i] = wall_clock64(); } while (0)
+#else
+#define CL_STAMP(i)
+#endif
+// One matrix (the usual case): the job rides in the kernel arguments and the work item follows from blockIdx.x (column workgroups
+// first, then the lower 128 x 128 tiles column by column) -- two dependent trips to memory less on every level; several matrices: tables.
+__global__ __launch_bounds__(256) void k_chol_level(const CholLevelJob J0, const int ncol, const CholLevelJob *__restrict__ jobs,
+                                                    const CholLevelWork *__restrict__ work, int *__restrict__ info) {
+    extern __shared__ __attribute__((aligned(16))) double cls[];
+    CholLevelWork w;
+    if (jobs) w = work[blockIdx.x];
+    else if ((int)blockIdx.x < ncol) w = CholLevelWork{0, 0, J0.k + 1 + (int)blockIdx.x, 0};
+    else {
+        const int nt = (J0.n - (J0.k + 2) * 64 + 127) / 128;
+        int t = (int)blockIdx.x - ncol, tj = 0;
+        while (t >= nt - tj) { t -= nt - tj; tj++; }
+        w = CholLevelWork{0, 1, tj + t, tj};
+    }
+    const CholLevelJob J = jobs ? jobs[w.job] : J0;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
+    double *P0 = cls, *P1 = cls + CL_TS, *dinv = cls + 2 * CL_TS;
+    const long long lda = J.lda;
+    const int rk = J.k * 64, wi = wave & 1, wj = wave >> 1;
+    if (w.kind == 1) {
+        const int rb = (J.k + 2) * 64, r0 = rb + 128 * w.ti, c0 = rb + 128 * w.tj;
+        cl_load(P0, J.A + r0 + rk * lda, lda, min(128, J.n - r0), 64, tid);
+        if (w.ti != w.tj) cl_load(P1, J.A + c0 + rk * lda, lda, min(128, J.n - c0), 64, tid);
+        __syncthreads();
+        if (w.ti == w.tj && wi == 0 && wj == 1) return;          // strictly upper quadrant of a diagonal tile
+        v4d acc[4][4];
+        cl_mm<4, 4>(P0 + wi * 64, (w.ti != w.tj ? P1 : P0) + wj * 64, acc, l15, l4);
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++) {
+                    const int gi = r0 + wi * 64 + a * 16 + l15, gj = c0 + wj * 64 + b * 16 + l4 + 4 * reg;
+                    if (gi < J.n && gj < J.n) J.A[gi + gj * lda] -= acc[a][b][reg];
+                }
+        return;
+    }
+    // column workgroup: the panel [D; T] = [A_cc; A_ic] in P0 (128 x 64), [L_ck; L_ik] in P1
+    const int c = J.k + 1, rc = c * 64, mc = min(64, J.n - rc), ri = w.ti * 64, mi = min(64, J.n - ri);
+    const bool diag = w.ti == c;
+    CL_STAMP(0);
+    {
+        double v[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int e = tid + 256 * q, i = e & 63, j = e >> 6;
+            v[q] = J.A[(rc + min(i, mc - 1)) + (rc + min(j, mc - 1)) * lda];
+        }
+        double vt[16];
+        if (!diag) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int e = tid + 256 * q, i = e & 63, j = e >> 6;
+                vt[q] = J.A[(ri + min(i, mi - 1)) + (rc + min(j, mc - 1)) * lda];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int e = tid + 256 * q, i = e & 63, j = e >> 6;
+            P0[i + j * CL_LD] = (i < mc && j < mc) ? (i >= j ? v[q] : 0.0) : (i == j ? 1.0 : 0.0);
+            P0[64 + i + j * CL_LD] = (!diag && i < mi && j < mc) ? vt[q] : 0.0;
+        }
+    }
+    if (J.k >= 0) {
+        double v[16], vt[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int e = tid + 256 * q, i = e & 63, j = e >> 6;
+            v[q] = J.A[(rc + min(i, mc - 1)) + (rk + j) * lda];
+        }
+        if (!diag) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int e = tid + 256 * q, i = e & 63, j = e >> 6;
+                vt[q] = J.A[(ri + min(i, mi - 1)) + (rk + j) * lda];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int e = tid + 256 * q, i = e & 63, j = e >> 6;
+            P1[i + j * CL_LD] = i < mc ? v[q] : 0.0;
+            P1[64 + i + j * CL_LD] = (!diag && i < mi) ? vt[q] : 0.0;
+        }
+    }
+    __syncthreads();
+    CL_STAMP(1);
+    if (J.k >= 0 && !(diag && wi == 1)) {
+        // [D; T] -= [L_ck; L_ik] L_ck^T: wave (wi, wj) rows 64 wi .., columns 32 wj ..
+        v4d acc[4][2];
+        cl_mm<4, 2>(P1 + wi * 64, P1 + wj * 32, acc, l15, l4);
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++)
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++) {
+                    const int i = wi * 64 + a * 16 + l15, j = wj * 32 + b * 16 + l4 + 4 * reg;
+                    if (i >= j) P0[i + j * CL_LD] -= acc[a][b][reg];        // rows >= 64 (T) always, D in its lower triangle
+                }
+    }
+    __syncthreads();
+    CL_STAMP(2);
+    // chol(D), and T L^-T in the same sweep (the rows of T ride along as rows below every diagonal block)
+    const bool bad = lds_potrf(P0, CL_LD, dinv, mc, wave, 4, lane, diag ? 0 : 64);
+    if (diag && bad && lane == 0) atomicMin(info, J.code);
+    __syncthreads();
+    CL_STAMP(3);
+    if (diag) {
+        double *out = J.D + (long long)c * 4096;
+        for (int e = tid; e < 64 * 64; e += 256) {
+            const int i = e & 63, j = e >> 6;
+            out[e] = (i >= j && i < mc) ? P0[i + j * CL_LD] : 0.0;
+        }
+        return;
+    }
+    for (int e = tid; e < 64 * 64; e += 256) {
+        const int i = e & 63, j = e >> 6;
+        if (i < mi && j < mc) J.A[(ri + i) + (rc + j) * lda] = P0[64 + i + j * CL_LD];
+    }
+    CL_STAMP(4);
+}
+
 // zero the strict upper triangles of the matrices listed in descs (output formatting of L, tools.jl:100-105)
 __global__ void k_zero_upper(const PotrfDesc *__restrict__ descs) {
     const PotrfDesc d = descs[blockIdx.y];

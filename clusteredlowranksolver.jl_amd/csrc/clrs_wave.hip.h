@@ -309,8 +309,10 @@ __device__ __forceinline__ void potrf16(double (&a)[16], int row, int nvalid, bo
 // triangle holds L, the diagonal blocks have zeros above the diagonal; the strictly upper off-diagonal blocks are
 // NOT touched (callers mask them when storing).  dinv (ceil16(n) doubles of LDS) receives 1 / L[i,i] (0 for i >= n).
 // Returns true in every thread of wave 0 .. (callers reduce) if a pivot was not positive.  All waves must call.
+// extra (a multiple of 16): rows n16 .. n16 + extra - 1 of the same array hold a panel B below the square; on return they hold
+// B L^-T (the panel of a blocked factorisation solved in the same sweep: its rows ride along as rows below every diagonal block).
 template <bool WG = true>
-__device__ __forceinline__ bool lds_potrf(double *A, int lda, double *dinv, int n, int wave, int nwaves, int lane) {
+__device__ __forceinline__ bool lds_potrf(double *A, int lda, double *dinv, int n, int wave, int nwaves, int lane, int extra = 0) {
     const int npan = (n + 15) >> 4, row16 = lane & 15, cg4 = lane >> 4;
     bool bad = false;
     for (int pb = 0; pb < npan; pb++) {
@@ -330,12 +332,12 @@ __device__ __forceinline__ bool lds_potrf(double *A, int lda, double *dinv, int 
                 dinv[r0 + row16] = (r0 + row16 < n) ? rdiag : 0.0;      // 1 / L[i,i] = the reciprocal square root of the pivot, already at hand
             }
         }
-        if (pb + 1 == npan) break;
+        if (pb + 1 == npan && extra == 0) break;
         lds_sync<WG>();
         // panel: rows below the diagonal block, X L_kk^T = A_panel  <=>  L_kk X^T = A_panel^T: the unknown index runs along
         // the 16 columns of the panel (stride lda), the right-hand sides are the panel rows (stride 1)
         {
-            const int M = (npan - pb - 1) * 16;
+            const int M = (npan - pb - 1) * 16 + extra;
             const double di = dinv[r0 + row16];
             double Lr[16];
 #pragma unroll
@@ -357,11 +359,17 @@ __device__ __forceinline__ bool lds_potrf(double *A, int lda, double *dinv, int 
         lds_sync<WG>();
         // trailing update (lower tiles): A[i-blk, j-blk] -= Lp_i Lp_j^T
         {
-            const int tm = npan - pb - 1;
-            for (int t = wave; t < tm * (tm + 1) / 2; t += nwaves) {
-                int tj = 0, rem = t;
-                while (rem >= tm - tj) { rem -= tm - tj; tj++; }
-                const int ti = tj + rem;
+            const int tm = npan - pb - 1, tri = tm * (tm + 1) / 2;
+            for (int t = wave; t < tri + (extra >> 4) * tm; t += nwaves) {
+                int ti, tj = 0;
+                if (t < tri) {
+                    int rem = t;
+                    while (rem >= tm - tj) { rem -= tm - tj; tj++; }
+                    ti = tj + rem;
+                } else {                                                 // rows of the extra panel against every remaining column block
+                    ti = tm + (t - tri) / tm;
+                    tj = (t - tri) % tm;
+                }
                 const int i0 = r0 + 16 + ti * 16, j0 = r0 + 16 + tj * 16;
                 v4d_f acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
