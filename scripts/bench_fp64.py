@@ -393,7 +393,7 @@ def main(argv=None, emit=True):
             r_s = 1e-3 * e0.elapsed_time(e1) / 5
             rcnt = rctx.counters()
             rfl = rcnt["assemble_flops"] + rcnt["factor_flops"]
-            out["roofline_R"] = {"bound": "mfma", "phase": "chol X + schur_assemble + factor, staged (large-block) kernels", "kernel": "k_gemm_f64_t + k_trsm_diag + k_potrf_diag",
+            out["roofline_R"] = {"bound": "mfma", "phase": "chol X + schur_assemble + factor, staged (large-block) kernels", "kernel": "k_gemm_f64_t + k_chol_level + k_trtri_diag",
                                  "ms": 1e3 * r_s, "achieved": rfl / r_s / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": rfl / r_s / 1e12 / FP64_PEAK_TFLOPS,
                                  "traffic": None, "algorithmic_flops": rfl,
                                  "workload": "polyopt_scaled(1024): one cluster, one PSD block n = 1025, P = 2049 rank-1 constraints (SURVEY.md section 8d, roofline "

@@ -33,6 +33,8 @@ tot = 0
 for k, v in sorted(prof.items(), key=lambda kv: -kv[1][2]):
     print(f"{k:24s} avg {1e6*v[0]:9.1f} us  x{v[1]:6.1f}/step  = {1e6*v[2]:10.1f} us/step"); tot += v[2]
 print("sum %.1f us;  assembly algorithmic %.2f GFLOP, %.1f MB; factor %.2f GFLOP" % (1e6*tot, cnt["assemble_flops"]/1e9, cnt["assemble_bytes"]/1e6, cnt["factor_flops"]/1e9))
+step()                       # the launch graphs are captured again after the per-kernel timing above
+torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(3): step()
 torch.cuda.synchronize()
