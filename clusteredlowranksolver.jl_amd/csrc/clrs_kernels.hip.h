@@ -297,6 +297,26 @@ __global__ __launch_bounds__(64 * DT32_WAVES) void k_dense_T32(const DenseTBlock
 }
 constexpr size_t dense_T32_lds_bytes() { return (size_t)(2 + DT32_WAVES) * DT32_MS * sizeof(double); }
 
+// Up to 64 x 64 elements G[i si + j sj] (i < rows, j < cols) into Z[i + j ldz] over the frame i < fr, j < fc, zero outside the
+// valid part (MODE 1: and above the diagonal; MODE 2: and ones on the diagonal of the padding).  All sixteen loads of a thread are
+// issued before the first store (addresses clamped into the valid part, not guarded): one round trip to memory instead of one per
+// 16 x 16 tile -- these kernels are links of a chain of dependent launches.  JFAST: consecutive threads walk j (sj == 1).
+template <int MODE, bool JFAST = false>
+__device__ __forceinline__ void tile64_load(double *Z, int ldz, const double *G, long long si, long long sj, int rows, int cols, int fr, int fc, int tid) {
+    double v[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        const int e = tid + 256 * q, i = JFAST ? e >> 6 : e & 63, j = JFAST ? e & 63 : e >> 6;
+        v[q] = G[min(i, rows - 1) * si + min(j, cols - 1) * sj];
+    }
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        const int e = tid + 256 * q, i = JFAST ? e >> 6 : e & 63, j = JFAST ? e & 63 : e >> 6;
+        const bool in = i < rows && j < cols && (MODE == 0 || i >= j);
+        if (i < fr && j < fc) Z[i + j * ldz] = in ? v[q] : ((MODE == 2 && i == j && i >= rows) ? 1.0 : 0.0);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // triangular solve with a diagonal block (n <= 64): one thread per right-hand-side vector.
 //   trans == 0:  L x = b (forward)      trans == 1:  L^T x = b (backward)
@@ -325,24 +345,10 @@ __global__ __launch_bounds__(256) void k_trsm_diag(const TrsmDesc *__restrict__ 
     const int v0 = w.chunk * 64;
     const int nv = min(64, d.nvec - v0);
     const int i16 = tid & 15, j16 = tid >> 4;
-    for (int j0 = 0; j0 < n16; j0 += 16)
-        for (int i0 = 0; i0 < n16; i0 += 16) {
-            const int i = i0 + i16, j = j0 + j16;
-            Ls[i + j * LDL] = (i < n && j < n && i >= j) ? d.L[i + (long long)j * d.ldl] : 0.0;
-        }
+    tile64_load<1>(Ls, LDL, d.L, 1, d.ldl, n, n, n16, n16, tid);
     if (tid < n16) dinv[tid] = (tid < n) ? 1.0 / d.L[tid + (long long)tid * d.ldl] : 0.0;
-    if (d.es == 1) {     // vectors are columns: consecutive threads walk down a column
-        for (int j0 = 0; j0 < nv; j0 += 16)
-            for (int i0 = 0; i0 < n16; i0 += 16) {
-                const int i = i0 + i16, v = j0 + j16;
-                if (v < nv) xs[i + v * LDL] = (i < n) ? d.B[(long long)(v0 + v) * d.vs + i] : 0.0;
-            }
-    } else {             // vectors are rows (vs == 1): consecutive threads walk along the vectors
-        for (int i0 = 0; i0 < n16; i0 += 4) {
-            const int v = tid & 63, i = i0 + (tid >> 6);
-            if (v < nv) xs[i + v * LDL] = (i < n) ? d.B[(long long)(v0 + v) * d.vs + (long long)i * d.es] : 0.0;
-        }
-    }
+    if (d.es == 1) tile64_load<0>(xs, LDL, d.B + (long long)v0 * d.vs, 1, d.vs, n, nv, n16, nv, tid);            // vectors are columns
+    else tile64_load<0, true>(xs, LDL, d.B + (long long)v0 * d.vs, d.es, d.vs, n, nv, n16, nv, tid);              // vectors are rows (vs == 1)
     __syncthreads();
     if (d.trans == 0) lds_trsm<false>(Ls, LDL, dinv, xs, 1, LDL, n, nv, wave, 4, lane);
     else lds_trsm<true>(Ls, LDL, dinv, xs, 1, LDL, n, nv, wave, 4, lane);
@@ -381,10 +387,10 @@ __global__ __launch_bounds__(256) void k_trtri_diag(const TrtriDesc *__restrict_
     double *Ls = tts, *Zs = tts + LDL * TRSM_NB, *dinv = Zs + LDL * TRSM_NB;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = d.n, n16 = (n + 15) & ~15;
     const int i16 = tid & 15, j16 = tid >> 4;
+    tile64_load<1>(Ls, LDL, d.L, 1, d.ldl, n, n, n16, n16, tid);
     for (int j0 = 0; j0 < n16; j0 += 16)
         for (int i0 = 0; i0 < n16; i0 += 16) {
             const int i = i0 + i16, j = j0 + j16;
-            Ls[i + j * LDL] = (i < n && j < n && i >= j) ? d.L[i + (long long)j * d.ldl] : 0.0;
             Zs[i + j * LDL] = (i == j && i < n) ? 1.0 : 0.0;
         }
     if (tid < n16) dinv[tid] = (tid < n) ? 1.0 / d.L[tid + (long long)tid * d.ldl] : 0.0;
@@ -430,11 +436,7 @@ __global__ __launch_bounds__(256) void k_potrf_diag(const PotrfDesc *__restrict_
     __shared__ double dinv[POTRF_NB];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = d.n, n16 = (n + 15) & ~15;
     const int i16 = tid & 15, j16 = tid >> 4;
-    for (int j0 = 0; j0 < n16; j0 += 16)
-        for (int i0 = 0; i0 < n16; i0 += 16) {
-            const int i = i0 + i16, j = j0 + j16;
-            As[i + j * LDA] = (i < n && j < n) ? ((i >= j) ? d.A[i + (long long)j * d.lda] : 0.0) : ((i == j) ? 1.0 : 0.0);
-        }
+    tile64_load<2>(As, LDA, d.A, 1, d.lda, n, n, n16, n16, tid);
     __syncthreads();
     const bool bad = lds_potrf(As, LDA, dinv, n, wave, 4, lane);
     if (bad && lane == 0) atomicMin(info, d.code);
