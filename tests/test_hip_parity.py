@@ -103,6 +103,37 @@ def test_host_pointer_entry_points_staged_and_direct_copies_agree():
 def test_potrf_reports_failure():
     A = np.asfortranarray(np.array([[1.0, 2.0], [2.0, 1.0]]))
     assert _lib().clrs_test_potrf(0, 2, _dp(A), 2) == 1
+    # beyond one block (k_chol_level): a pivot that turns negative in the third block column
+    n = 200
+    B = np.asfortranarray(np.eye(n) * 4.0)
+    B[150, 150] = -1.0
+    assert _lib().clrs_test_potrf(0, n, _dp(B), n) == 1
+
+
+def test_several_large_matrices_per_level_launch(oracle_built):
+    """Three clusters whose X blocks (101 x 101) and Schur blocks (201 x 201) are all beyond one 64-wide block: the per-column launches
+    of k_chol_level then carry several matrices (work tables instead of the single job in the kernel arguments)."""
+    from clrs_amd.sdp import replicate_clusters
+    from clrs_amd.solver import SchurContext, compute_T_decomposition
+    from oracle.oracle import Oracle
+    f = flat("polyopt_scaled_100")
+    big = replicate_clusters(f, 3)
+    X, Y = spd_iterates(big, seed=5)
+    ctx = SchurContext(big, fused=False)
+    Xc = ctx.cholesky_blocks(X)
+    assert np.max(np.abs(Xc - chol_blocks_np(big, X))) <= 1e-12 * np.max(np.abs(Xc))
+    _, S, _ = compute_T_decomposition(ctx, Xc, Y, want_S=True)
+    L, LinvB, LQ = ctx.get_factor()
+    ctx.close()
+    nxy, nS = f.xy_len, f.S_len
+    P = int(f.cluster_P[0])
+    for k in range(3):
+        o = Oracle(f, quad=False)
+        Sk, _ = o.schur_assemble(Xc[k * nxy:(k + 1) * nxy], Y[k * nxy:(k + 1) * nxy])
+        assert np.max(np.abs(S[k * nS:(k + 1) * nS] - Sk)) <= 1e-10 * np.max(np.abs(Sk))
+        Lk = np.linalg.cholesky(Sk.reshape(P, P, order="F"))
+        got = np.tril(L[k * nS:(k + 1) * nS].reshape(P, P, order="F"))
+        assert np.max(np.abs(got - Lk)) <= 1e-9 * np.max(np.abs(Lk))
 
 
 ASSEMBLE_CASES = ["x2p1", "polyopt8", "polyopt40", "delsarte_3_10", "delsarte_8_3", "ce_8_15", "ce_8_3", "ns_8_3_2", "ns_8_15_2",
