@@ -302,10 +302,9 @@ static int plan_trsm_blockinv(clrs_ctx *c, Plan &pl, const std::vector<TrsmJob> 
         Aux &a = aux[q];
         a.nob = (j.n + IB - 1) / IB;
         maxob = std::max(maxob, a.nob);
-        if ((rc = dmalloc(c, &a.inv, (i64)a.nob * IB * IB))) return rc;
+        if ((rc = dmalloc(c, &a.inv, (i64)a.nob * IB * IB))) return rc;      // zeroed: the strict upper triangles stay zero
         if ((rc = dmalloc(c, &a.T, (i64)j.n * (IB / 2)))) return rc;
         if ((rc = dmalloc(c, &a.Y, (i64)j.n * j.nrhs))) return rc;
-        HIPCHECK(hipMemset(a.inv, 0, sizeof(double) * (size_t)a.nob * IB * IB));      // the strict upper triangles stay zero
         for (int o = 0; o < a.nob; o++) {
             const int r0 = o * IB, nb = std::min(IB, j.n - r0);
             for (int l0 = 0; l0 < nb; l0 += TRSM_NB) {

@@ -239,7 +239,13 @@ int clrs_wave2_clusters(const clrs_ctx *ctx);
  * and whose operands fit in LDS, (bit 0) sum_i a_i A_i as one MFMA contraction over the block's terms and (bit 1) Z V for the
  * per-term pairings as one MFMA product; 0 = per-entry loops.
  * "solve_small2" (default 1): contexts with <= 8 clusters whose factors fit in 150 KB of LDS run the solve stage as ONE launch
- * of k_solve_small2 (every operand staged in one trip to memory, one wave per triangular solve); 0 keeps k_solve_small. */
+ * of k_solve_small2 (every operand staged in one trip to memory, one wave per triangular solve); 0 keeps k_solve_small.
+ * "dense_wave" (default 1): dense blocks with n <= 32 beyond the LDS-resident kernel form X^-1 A Y with one wave per matrix
+ * (k_trtri32 + k_dense_T32); 0 = two substitution launches and a batched GEMM.
+ * "potrf_levels" (default 1): the staged Cholesky of a matrix beyond one 64-wide block runs ONE launch per block column
+ * (k_chol_level); 0 = k_potrf_diag + k_trsm_diag + k_gemm_f64_t per block column.
+ * "trsm_blockinv" (default 1): staged triangular solves with n > 512 go through inverted 512 x 512 diagonal blocks (k_trtri_diag
+ * and GEMMs, n / 512 levels); 0 = 64-wide substitutions (n / 64 levels of k_trsm_diag + k_gemm_f64_t). */
 /* Diagnostic builds (-DCLRS_FUSED_STAMPS) only: s_memtime stamps of the phases of workgroup 0 of the fused kernel. */
 int clrs_debug_stamps(clrs_ctx *ctx, uint64_t out[64]);
 
