@@ -216,17 +216,30 @@ static int dmalloc(clrs_ctx *c, double **d, i64 n) {
 }
 
 // ---- stage builders -----------------------------------------------------------------------------
+// 128 x 128 or 64 x 64 tiles for one product: whichever leaves the busiest compute unit with less to do.  A CU works through
+// ceil(tiles / 256) tiles of either size; a large tile is four small ones of work and runs the matrix pipe at 0.72 of its peak
+// against 0.63 (scripts/gemm_probe.py).  2048 x 2048: 256 large tiles, one per CU; 2049 x 2049: 289 large tiles would give 33 CUs two.
+static bool gemm_prefers_large_tiles(const GemmDesc &d) {
+    if (d.M < 256 || d.N < 256) return false;
+    auto tiles = [&](int B) {
+        const long long tm = (d.M + B - 1) / B, tn = (d.N + B - 1) / B;
+        return (d.lower_only ? tm * (tn + 1) / 2 : tm * tn) * std::max(1, d.pad0);
+    };
+    // (a lone large tile on a CU -- one wave per SIMD -- reaches about 0.60)
+    const double large = (double)((tiles(128) + 255) / 256) * 4.0 / (tiles(128) >= 512 ? 0.72 : 0.60), small = (double)((tiles(64) + 255) / 256) / 0.63;
+    return large < small;
+}
 static int add_gemm_stage(clrs_ctx *c, Plan &pl, const std::vector<GemmDesc> &descs) {
-    // only products large enough to give every CU several 128 x 128 tiles take the large-tile kernel (it runs one workgroup
-    // per CU: 356 registers); everything else the 64 x 64 one, which fills the chip at smaller sizes
-    for (int big = 1; big >= 0; big--) {
+    // tile size per product: gemm_prefers_large_tiles
+    for (int var = 7; var >= 0; var--) {                       // one launch per (tile size, transposes): template parameters of the kernel
+        const int big = var >> 2, vta = (var >> 1) & 1, vtb = var & 1;
         const int BM = big ? 128 : GEMM_BM, BN = big ? 128 : GEMM_BN;
         std::vector<GemmDesc> ds;
         std::vector<GemmTile> tiles;
         for (const GemmDesc &d : descs) {
             if (d.M <= 0 || d.N <= 0) continue;
-            const bool is_big = d.M >= 256 && d.N >= 256 && (long long)d.M * d.N >= 128ll * 128 * 1024;
-            if (is_big != (big == 1)) continue;
+            const bool is_big = gemm_prefers_large_tiles(d);
+            if (is_big != (big == 1) || (d.ta != 0) != (vta == 1) || (d.tb != 0) != (vtb == 1)) continue;
             int id = (int)ds.size();
             ds.push_back(d);
             int tm = (d.M + BM - 1) / BM, tn = (d.N + BN - 1) / BN;
@@ -242,7 +255,7 @@ static int add_gemm_stage(clrs_ctx *c, Plan &pl, const std::vector<GemmDesc> &de
         Step s;
         s.kind = STEP_GEMM;
         s.grid = (int)tiles.size();
-        s.nmax = big;
+        s.nmax = big; s.aux0 = vta * 2 + vtb;
         GemmDesc *dd; GemmTile *dt;
         int rc;
         if ((rc = upload(c, ds, &dd))) return rc;
@@ -563,10 +576,19 @@ static int run_steps(clrs_ctx *c, const Plan &pl) {
                 HIPCHECK(hipMemcpyAsync(s.dst, s.src, s.bytes, hipMemcpyDeviceToDevice, st));
                 break;
             case STEP_GEMM:
-                if (s.nmax)
-                    hipLaunchKernelGGL((k_gemm_f64_t<128, 128>), dim3(s.grid), dim3(256), gemm_lds_bytes(128, 128), st, (const GemmDesc *)s.d0, (const GemmTile *)s.d1);
-                else
-                    hipLaunchKernelGGL((k_gemm_f64_t<64, 64>), dim3(s.grid), dim3(256), gemm_lds_bytes(64, 64), st, (const GemmDesc *)s.d0, (const GemmTile *)s.d1);
+#define CLRS_GEMM_LAUNCH(BMN, TA, TB) \
+    hipLaunchKernelGGL((k_gemm_f64_t<BMN, BMN, TA, TB>), dim3(s.grid), dim3(256), gemm_lds_bytes(BMN, BMN), st, (const GemmDesc *)s.d0, (const GemmTile *)s.d1)
+                switch ((s.nmax ? 4 : 0) + s.aux0) {
+                    case 0: CLRS_GEMM_LAUNCH(64, 0, 0); break;
+                    case 1: CLRS_GEMM_LAUNCH(64, 0, 1); break;
+                    case 2: CLRS_GEMM_LAUNCH(64, 1, 0); break;
+                    case 3: CLRS_GEMM_LAUNCH(64, 1, 1); break;
+                    case 4: CLRS_GEMM_LAUNCH(128, 0, 0); break;
+                    case 5: CLRS_GEMM_LAUNCH(128, 0, 1); break;
+                    case 6: CLRS_GEMM_LAUNCH(128, 1, 0); break;
+                    default: CLRS_GEMM_LAUNCH(128, 1, 1); break;
+                }
+#undef CLRS_GEMM_LAUNCH
                 break;
             case STEP_TRSM:
                 hipLaunchKernelGGL(k_trsm_diag, dim3(s.grid), dim3(256), 0, st, (const TrsmDesc *)s.d0, (const TrsmWork *)s.d1);
@@ -785,7 +807,10 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
 #define CK(x) do { rc = (x); if (rc) { clrs_ctx_destroy(c); return rc; } } while (0)
 #define HIPCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { clrs_ctx_destroy(c); return fail(CLRS_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } } while (0)
     HIPCK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    HIPCK(hipFuncSetAttribute((const void *)k_gemm_f64_t<128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes(128, 128)));
+    HIPCK(hipFuncSetAttribute((const void *)k_gemm_f64_t<128, 128, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes(128, 128)));
+    HIPCK(hipFuncSetAttribute((const void *)k_gemm_f64_t<128, 128, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes(128, 128)));
+    HIPCK(hipFuncSetAttribute((const void *)k_gemm_f64_t<128, 128, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes(128, 128)));
+    HIPCK(hipFuncSetAttribute((const void *)k_gemm_f64_t<128, 128, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes(128, 128)));
     for (int i = 0; i < 10; i++) HIPCK(hipEventCreate(&c->ev[i]));
     c->J = d->n_clusters; c->N = d->n_free; c->NB = d->n_blocks;
     if (c->J < 0 || c->N < 0 || c->NB < 0) { clrs_ctx_destroy(c); return fail(CLRS_ERR_INVALID, "negative sizes"); }
@@ -2367,7 +2392,10 @@ static clrs_ctx *mini_ctx(int device) {
     clrs_ctx *c = new clrs_ctx();
     c->device = device;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; }
-    (void)hipFuncSetAttribute((const void *)k_gemm_f64_t<128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes(128, 128));
+    (void)hipFuncSetAttribute((const void *)k_gemm_f64_t<128, 128, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes(128, 128));
+    (void)hipFuncSetAttribute((const void *)k_gemm_f64_t<128, 128, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes(128, 128));
+    (void)hipFuncSetAttribute((const void *)k_gemm_f64_t<128, 128, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes(128, 128));
+    (void)hipFuncSetAttribute((const void *)k_gemm_f64_t<128, 128, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes(128, 128));
     std::vector<int> hi(1, INFO_NONE);
     int *di;
     if (upload(c, hi, &di)) { clrs_ctx_destroy(c); return nullptr; }

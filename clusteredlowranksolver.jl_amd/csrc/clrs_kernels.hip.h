@@ -13,6 +13,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "clrs_wave.hip.h"
 
@@ -44,15 +45,22 @@ constexpr int gemm_padk(int BM) { return BM <= 64 ? 8 : 16; }
 // Double buffered: the global loads of step k+1 are issued before the MFMAs of step k and written to the other
 // buffer after them, one barrier per step.  With 128 x 128 tiles a step is 64 MFMAs per wave (4096 cycles of the matrix
 // pipe) against 16 global loads per thread, which hides the load latency even with one workgroup per CU.
-template <int BM, int BN>
-__global__ __launch_bounds__(256, (BM <= 64 ? 4 : 1)) void k_gemm_f64_t(const GemmDesc *__restrict__ descs, const GemmTile *__restrict__ tiles) {
+//
+// The transposes are template parameters and the k-loop is unrolled over the two buffers, so that every LDS address of the loop is a
+// per-lane base plus an immediate and every global address a per-lane offset (computed once) plus a uniform base that advances with
+// k.  With run-time transposes the SQ counters of this kernel showed SEVEN vector ALU instructions per MFMA (index arithmetic and
+// selects of the staging maps) and the matrix pipe busy 48 % of the time: one wave per SIMD issues in order, so whatever it spends on
+// address arithmetic the matrix pipe waits.  Rows / columns beyond M / N are read from a clamped address and never stored; only the
+// last, partial chunk of k is zero filled.
+template <int BM, int BN, int TA, int TB>
+__global__ __launch_bounds__(256, (BM <= 64 ? 4 : 2)) void k_gemm_f64_t(const GemmDesc *__restrict__ descs, const GemmTile *__restrict__ tiles) {
     // small tiles: a [k][i] stride of BM + 8 keeps a workgroup at 36 KB of LDS, so that FOUR of them share a compute unit: a grouped
     // launch of 1024 tiles (the Gram contractions of the dense branch) then runs in one round instead of one and a third
     constexpr int BK = GEMM_BK, PADK = gemm_padk(BM), LDA_S = BM + PADK, LDB_S = BN + PADK, MT = BM / 32, NT = BN / 32, EA = BM * BK / 256, EB = BN * BK / 256;
     // Two LDS layouts per operand, chosen so that BOTH the staging writes and the MFMA operand reads are conflict free:
     //   source contiguous along the tile row/column index (ta == 0 / tb == 1):  [k][i], row stride BM + 16
     //   source contiguous along k               (ta == 1 / tb == 0):            [i][k], row stride BK + 2
-    constexpr int LDT = BK + 2;
+    constexpr int LDT = BK + 2, ABUF = BK * LDA_S, BBUF = BK * LDB_S;
     static_assert(BK * LDA_S >= BM * LDT && BK * LDB_S >= BN * LDT, "both layouts must fit the same buffer");
     const GemmTile t = tiles[blockIdx.x];
     const GemmDesc d = descs[t.desc];
@@ -61,7 +69,7 @@ __global__ __launch_bounds__(256, (BM <= 64 ? 4 : 1)) void k_gemm_f64_t(const Ge
     double *__restrict__ C = d.C + (long long)t.batch * d.sC;
     const int m0 = t.tm * BM, n0 = t.tn * BN;
     extern __shared__ __attribute__((aligned(16))) double gsm[];
-    double *As = gsm, *Bs = gsm + 2 * BK * LDA_S;             // As[buf][k][i], Bs[buf][k][j]
+    double *As = gsm, *Bs = gsm + 2 * ABUF;                   // As[buf][k][i], Bs[buf][k][j]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = (wave & 1) * (BM / 2), wn = (wave >> 1) * (BN / 2);
     const int l15 = lane & 15, l4 = lane >> 4;
@@ -70,75 +78,100 @@ __global__ __launch_bounds__(256, (BM <= 64 ? 4 : 1)) void k_gemm_f64_t(const Ge
     for (int a = 0; a < MT; a++)
 #pragma unroll
         for (int b = 0; b < NT; b++) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+    // staging map: consecutive lanes walk the contiguous dimension of the source.  Element q of a thread: e = tid + 256 q,
+    //   TA == 0: (i, k) = (e % BM, e / BM) -> LDS [k][i];   TA == 1: (k, i) = (e % BK, e / BK) -> LDS [i][k]       (B alike with j)
+    // Byte offsets from the tile's first row / column, 32 bits (at most 128 lda doubles), on top of a uniform base: the loads take the
+    // scalar-base + vector-offset form and cost no vector ALU instruction.  The bases are cast to the GLOBAL address space: a pointer
+    // read from a descriptor in memory is a generic one, its loads are flat_load -- which also count as LDS operations, so that every
+    // wait for an MFMA operand read waited for the prefetch of the next chunk as well.
+    typedef const char __attribute__((address_space(1))) *gbytes_t;
+    typedef const double __attribute__((address_space(1))) *gdouble_t;
+    unsigned oa[EA], ob[EB];
+    const long long lda = d.lda, ldb = d.ldb;
+#pragma unroll
+    for (int q = 0; q < EA; q++) {
+        const int e = tid + 256 * q, i = TA == 0 ? e % BM : e / BK, k = TA == 0 ? e / BM : e % BK, ic = min(i, d.M - 1 - m0);
+        oa[q] = (unsigned)(TA == 0 ? ic + k * lda : k + ic * lda) * 8u;
+    }
+#pragma unroll
+    for (int q = 0; q < EB; q++) {
+        const int e = tid + 256 * q, j = TB == 0 ? e / BK : e % BN, k = TB == 0 ? e % BK : e / BN, jc = min(j, d.N - 1 - n0);
+        ob[q] = (unsigned)(TB == 0 ? k + jc * ldb : jc + k * ldb) * 8u;
+    }
+    const gbytes_t Ag = (gbytes_t)(A + (TA == 0 ? (long long)m0 : m0 * lda)), Bg = (gbytes_t)(B + (TB == 0 ? n0 * ldb : (long long)n0));
+    double *const sa = As + (TA == 0 ? (tid / BM) * LDA_S + tid % BM : (tid / BK) * LDT + tid % BK);     // element q: + q * SQA
+    double *const sb = Bs + (TB == 0 ? (tid / BK) * LDT + tid % BK : (tid / BN) * LDB_S + tid % BN);
+    constexpr int SQA = TA == 0 ? (256 / BM) * LDA_S : (256 / BK) * LDT, SQB = TB == 0 ? (256 / BK) * LDT : (256 / BN) * LDB_S;
+    const double *const ra_ = As + (TA == 0 ? l4 * LDA_S + wm + l15 : (wm + l15) * LDT + l4);              // operand reads: + immediates
+    const double *const rb_ = Bs + (TB == 0 ? (wn + l15) * LDT + l4 : l4 * LDB_S + wn + l15);
     double ra[EA], rb[EB];
-    // staging map: consecutive lanes walk the contiguous dimension of the source
-    auto fetch = [&](int k0) {
+    auto fetch = [&](int k0, auto tail) {
+        const gbytes_t Ak = Ag + (TA == 0 ? k0 * lda : (long long)k0) * 8, Bk = Bg + (TB == 0 ? (long long)k0 : k0 * ldb) * 8;
+        if constexpr (!decltype(tail)::value) {
 #pragma unroll
-        for (int q = 0; q < EA; q++) {
-            const int e = tid + 256 * q;
-            int i, k;
-            if (d.ta == 0) { i = e % BM; k = e / BM; } else { k = e % BK; i = e / BK; }
-            const int gi = m0 + i, gk = k0 + k;
-            ra[q] = (gi < d.M && gk < d.K) ? (d.ta == 0 ? A[gi + (long long)gk * d.lda] : A[gk + (long long)gi * d.lda]) : 0.0;
-        }
+            for (int q = 0; q < EA; q++) ra[q] = *(gdouble_t)(Ak + oa[q]);
 #pragma unroll
-        for (int q = 0; q < EB; q++) {
-            const int e = tid + 256 * q;
-            int j, k;
-            if (d.tb == 0) { k = e % BK; j = e / BK; } else { j = e % BN; k = e / BN; }
-            const int gj = n0 + j, gk = k0 + k;
-            rb[q] = (gj < d.N && gk < d.K) ? (d.tb == 0 ? B[gk + (long long)gj * d.ldb] : B[gj + (long long)gk * d.ldb]) : 0.0;
-        }
-    };
-    auto stash = [&](int buf) {
+            for (int q = 0; q < EB; q++) rb[q] = *(gdouble_t)(Bk + ob[q]);
+        } else {                                              // the last chunk of k: rows k >= K are zero
 #pragma unroll
-        for (int q = 0; q < EA; q++) {
-            const int e = tid + 256 * q;
-            int i, k;
-            if (d.ta == 0) { i = e % BM; k = e / BM; } else { k = e % BK; i = e / BK; }
-            As[buf * BK * LDA_S + (d.ta == 0 ? k * LDA_S + i : i * LDT + k)] = ra[q];
-        }
+            for (int q = 0; q < EA; q++) {
+                const int e = tid + 256 * q, k = TA == 0 ? e / BM : e % BK;
+                ra[q] = k0 + k < d.K ? *(gdouble_t)(Ak + oa[q]) : 0.0;
+            }
 #pragma unroll
-        for (int q = 0; q < EB; q++) {
-            const int e = tid + 256 * q;
-            int j, k;
-            if (d.tb == 0) { k = e % BK; j = e / BK; } else { j = e % BN; k = e / BN; }
-            Bs[buf * BK * LDB_S + (d.tb == 0 ? j * LDT + k : k * LDB_S + j)] = rb[q];
+            for (int q = 0; q < EB; q++) {
+                const int e = tid + 256 * q, k = TB == 0 ? e % BK : e / BN;
+                rb[q] = k0 + k < d.K ? *(gdouble_t)(Bk + ob[q]) : 0.0;
+            }
         }
     };
-    fetch(0);
-    stash(0);
-    __syncthreads();
-    int buf = 0;
-    for (int k0 = 0; k0 < d.K; k0 += BK) {
-        const bool more = k0 + BK < d.K;
-        if (more) fetch(k0 + BK);
+    // `cur` (0 / ABUF doubles): the buffer the MFMAs read; the staging writes go to the other one
+    auto stash = [&](int wo) {
+#pragma unroll
+        for (int q = 0; q < EA; q++) sa[wo + q * SQA] = ra[q];
+#pragma unroll
+        for (int q = 0; q < EB; q++) sb[wo + q * SQB] = rb[q];
+    };
+    auto mma = [&](int ro) {
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 4) {
             // The MFMA computes D[r][c] = sum_k Aop[r][k] Bop[k][c] with c on lane&15.  We feed Aop = op(B)^T and
             // Bop = op(A)^T so that c runs along the rows i of C (contiguous in memory) -> coalesced C stores.
             double av[MT], bv[NT];
 #pragma unroll
-            for (int a = 0; a < MT; a++) {
-                const int i = wm + a * 16 + l15, k = kk + l4;
-                av[a] = As[buf * BK * LDA_S + (d.ta == 0 ? k * LDA_S + i : i * LDT + k)];
-            }
+            for (int a = 0; a < MT; a++) av[a] = ra_[ro + (TA == 0 ? kk * LDA_S + a * 16 : a * 16 * LDT + kk)];
 #pragma unroll
-            for (int b = 0; b < NT; b++) {
-                const int j = wn + b * 16 + l15, k = kk + l4;
-                bv[b] = Bs[buf * BK * LDB_S + (d.tb == 0 ? j * LDT + k : k * LDB_S + j)];
-            }
+            for (int b = 0; b < NT; b++) bv[b] = rb_[ro + (TB == 0 ? b * 16 * LDT + kk : kk * LDB_S + b * 16)];
 #pragma unroll
             for (int a = 0; a < MT; a++)
 #pragma unroll
                 for (int b = 0; b < NT; b++) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[b], av[a], acc[a][b], 0, 0, 0);
         }
-        if (more) {
-            stash(buf ^ 1);       // the other buffer was last read before the previous barrier
-            __syncthreads();
-            buf ^= 1;
-        }
+    };
+    static_assert(ABUF == BBUF, "one buffer offset for both operands");
+    // chunks of BK: nfull whole ones, then a partial one (zero filled) if K is not a multiple.  The loop over the whole chunks has
+    // no branch in it: loads of chunk c + 1 in flight during the MFMAs of chunk c, written to the other buffer after them.
+    const int nfull = d.K / BK, rem = d.K % BK;
+    int cur = 0;
+    if (nfull > 0) fetch(0, std::false_type{});
+    else fetch(0, std::true_type{});
+    stash(0);
+    __syncthreads();
+    for (int c = 0; c + 1 < nfull; c++) {
+        fetch((c + 1) * BK, std::false_type{});
+        mma(cur);
+        stash(cur ^ ABUF);
+        __syncthreads();
+        cur ^= ABUF;
     }
+    if (nfull > 0 && rem > 0) {
+        fetch(nfull * BK, std::true_type{});
+        mma(cur);
+        stash(cur ^ ABUF);
+        __syncthreads();
+        cur ^= ABUF;
+    }
+    mma(cur);
     // D layout of v_mfma_f64_16x16x4_f64: c = lane & 15, r = (lane >> 4) + 4 * reg.  Here r indexes j, c indexes i.
 #pragma unroll
     for (int mi = 0; mi < MT; mi++)
@@ -149,7 +182,7 @@ __global__ __launch_bounds__(256, (BM <= 64 ? 4 : 1)) void k_gemm_f64_t(const Ge
                 const int gi = m0 + wm + mi * 16 + l15;
                 const int gj = n0 + wn + ni * 16 + l4 + 4 * reg;
                 if (gi < d.M && gj < d.N) {
-                    double *p = C + gi + (long long)gj * d.ldc;
+                    double __attribute__((address_space(1))) *p = (double __attribute__((address_space(1))) *)(C + gi + (long long)gj * d.ldc);
                     const double v = d.alpha * acc[mi][ni][reg];
                     *p = d.beta == 0.0 ? v : v + d.beta * *p;
                 }
