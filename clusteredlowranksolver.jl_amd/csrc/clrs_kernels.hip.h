@@ -21,6 +21,12 @@ namespace clrs {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
+// A pointer read from a descriptor table in memory is a GENERIC pointer: its loads are flat_load, which the hardware also counts as
+// LDS operations -- a wait for an LDS read then waits for every global prefetch in flight as well.  as_global() states what the
+// host knows (every table entry points into device memory) and turns them into global_load / global_store.
+template <class T> using gptr = T __attribute__((address_space(1))) *;
+template <class T> __device__ __forceinline__ gptr<T> as_global(T *p) { return (gptr<T>)p; }
+
 // ------------------------------------------------------------------------------------------------
 // grouped GEMM:  C = alpha * op(A) op(B) + beta * C   (column-major, fp64, MFMA 16x16x4)
 // ------------------------------------------------------------------------------------------------
@@ -213,9 +219,20 @@ __global__ __launch_bounds__(64) void k_trtri32(const DenseTBlock *__restrict__ 
     __shared__ double Ls[32 * 33];
     const DenseTBlock b = blocks[blockIdx.x];
     const int n = b.n, lane = threadIdx.x;
-    for (int e = lane; e < 32 * 32; e += 64) {
-        const int i = e % 32, c = e / 32;
-        Ls[i + 33 * c] = (i < n && c < n) ? b.L[i + (long long)c * n] : (i == c ? 1.0 : 0.0);
+    const gptr<const double> gL = as_global(b.L);
+    const gptr<double> gLinv = as_global(b.Linv);
+    {
+        double v[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int e = lane + 64 * q, i = e % 32, c = e / 32;
+            v[q] = gL[min(i, n - 1) + (long long)min(c, n - 1) * n];
+        }
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int e = lane + 64 * q, i = e % 32, c = e / 32;
+            Ls[i + 33 * c] = (i < n && c < n) ? v[q] : (i == c ? 1.0 : 0.0);
+        }
     }
     __syncthreads();
     // column c = lane & 31 of the inverse by forward substitution, the column in registers: the reads of L are broadcasts that do
@@ -231,7 +248,7 @@ __global__ __launch_bounds__(64) void k_trtri32(const DenseTBlock *__restrict__ 
     }
     if (lane < 32) {
 #pragma unroll
-        for (int i = 0; i < 32; i++) b.Linv[i + 32 * c] = (i < n && c < n) ? x[i] : 0.0;
+        for (int i = 0; i < 32; i++) gLinv[i + 32 * c] = (i < n && c < n) ? x[i] : 0.0;
     }
 }
 // D = X Y for 32 x 32 operands in LDS (leading dimension DT32_LD).  acc[ti][tj]: lane holds column tj*16 + (lane & 15), rows
@@ -291,16 +308,18 @@ __global__ __launch_bounds__(64 * DT32_WAVES) void k_dense_T32(const DenseTBlock
     const DenseTBlock b = blocks[pr.blk];
     const int n = b.n, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
     double *Li = dts, *Ys = dts + DT32_MS, *B0 = dts + 2 * DT32_MS + wave * DT32_MS;     // B0: this wave's matrix, then its result
+    const gptr<const double> gLinv = as_global((const double *)b.Linv), gY = as_global(b.Y), gA = as_global(b.A);
+    const gptr<double> gTT = as_global(b.TT);
     for (int e = tid; e < 32 * 32; e += 64 * DT32_WAVES) {
         const int i = e % 32, c = e / 32;
-        Li[i + DT32_LD * c] = b.Linv[e];
-        Ys[i + DT32_LD * c] = (i < n && c < n) ? b.Y[i + (long long)c * n] : 0.0;
+        Li[i + DT32_LD * c] = gLinv[e];
+        Ys[i + DT32_LD * c] = (i < n && c < n) ? gY[i + (long long)c * n] : 0.0;
     }
     // DT32_ITER matrices per wave, the next one fetched into registers while the products of the current one run
     double areg[16];
     auto fetch = [&](int e) {
         const bool live = e < b.cnt;
-        const double *A = b.A + (long long)(live ? e : 0) * n * n;
+        const gptr<const double> A = gA + (long long)(live ? e : 0) * n * n;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int o = lane + 64 * r, i = o % 32, c = o / 32;
@@ -323,7 +342,7 @@ __global__ __launch_bounds__(64 * DT32_WAVES) void k_dense_T32(const DenseTBlock
         dt32_mm_chain<true>(Li, q2, q1, l15, l4);           // Linv^T Linv A Y = X^-1 A Y
         dt32_store(B0, q1, l15, l4);                        // B0 belongs to this wave alone: LDS operations of one wave keep their order
         if (e < b.cnt) {
-            double *T = b.TT + (long long)e * n * n;
+            const gptr<double> T = gTT + (long long)e * n * n;
             for (int o = lane; o < n * n; o += 64) T[o] = B0[(o % n) + DT32_LD * (o / n)];
         }
     }
@@ -612,7 +631,7 @@ __device__ __forceinline__ void cl_mm(const double *X, const double *Y, v4d (&ac
 }
 // rows x cols (<= 128 x 64) of a column-major array into a panel, zero filled.  The addresses are clamped into the valid part instead
 // of guarded: a guarded load is a branch, and the loads of a thread then wait for each other (15 us for four 64 x 64 tiles against 3).
-__device__ __forceinline__ void cl_load(double *dst, const double *src, long long ld, int rows, int cols, int tid) {
+__device__ __forceinline__ void cl_load(double *dst, gptr<const double> src, long long ld, int rows, int cols, int tid) {
     if (rows <= 0 || cols <= 0) {
         for (int e = tid; e < 128 * 64; e += 256) dst[(e & 127) + (e >> 7) * CL_LD] = 0.0;
         return;
@@ -652,11 +671,13 @@ __global__ __launch_bounds__(256) void k_chol_level(const CholLevelJob J0, const
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
     double *P0 = cls, *P1 = cls + CL_TS, *dinv = cls + 2 * CL_TS;
     const long long lda = J.lda;
+    const gptr<double> GA = as_global(J.A);
+    const gptr<double> GD = as_global(J.D);
     const int rk = J.k * 64, wi = wave & 1, wj = wave >> 1;
     if (w.kind == 1) {
         const int rb = (J.k + 2) * 64, r0 = rb + 128 * w.ti, c0 = rb + 128 * w.tj;
-        cl_load(P0, J.A + r0 + rk * lda, lda, min(128, J.n - r0), 64, tid);
-        if (w.ti != w.tj) cl_load(P1, J.A + c0 + rk * lda, lda, min(128, J.n - c0), 64, tid);
+        cl_load(P0, (gptr<const double>)GA + r0 + rk * lda, lda, min(128, J.n - r0), 64, tid);
+        if (w.ti != w.tj) cl_load(P1, (gptr<const double>)GA + c0 + rk * lda, lda, min(128, J.n - c0), 64, tid);
         __syncthreads();
         if (w.ti == w.tj && wi == 0 && wj == 1) return;          // strictly upper quadrant of a diagonal tile
         v4d acc[4][4];
@@ -668,7 +689,7 @@ __global__ __launch_bounds__(256) void k_chol_level(const CholLevelJob J0, const
 #pragma unroll
                 for (int reg = 0; reg < 4; reg++) {
                     const int gi = r0 + wi * 64 + a * 16 + l15, gj = c0 + wj * 64 + b * 16 + l4 + 4 * reg;
-                    if (gi < J.n && gj < J.n) J.A[gi + gj * lda] -= acc[a][b][reg];
+                    if (gi < J.n && gj < J.n) GA[gi + gj * lda] -= acc[a][b][reg];
                 }
         return;
     }
@@ -681,14 +702,14 @@ __global__ __launch_bounds__(256) void k_chol_level(const CholLevelJob J0, const
 #pragma unroll
         for (int q = 0; q < 16; q++) {
             const int e = tid + 256 * q, i = e & 63, j = e >> 6;
-            v[q] = J.A[(rc + min(i, mc - 1)) + (rc + min(j, mc - 1)) * lda];
+            v[q] = GA[(rc + min(i, mc - 1)) + (rc + min(j, mc - 1)) * lda];
         }
         double vt[16];
         if (!diag) {
 #pragma unroll
             for (int q = 0; q < 16; q++) {
                 const int e = tid + 256 * q, i = e & 63, j = e >> 6;
-                vt[q] = J.A[(ri + min(i, mi - 1)) + (rc + min(j, mc - 1)) * lda];
+                vt[q] = GA[(ri + min(i, mi - 1)) + (rc + min(j, mc - 1)) * lda];
             }
         }
 #pragma unroll
@@ -703,13 +724,13 @@ __global__ __launch_bounds__(256) void k_chol_level(const CholLevelJob J0, const
 #pragma unroll
         for (int q = 0; q < 16; q++) {
             const int e = tid + 256 * q, i = e & 63, j = e >> 6;
-            v[q] = J.A[(rc + min(i, mc - 1)) + (rk + j) * lda];
+            v[q] = GA[(rc + min(i, mc - 1)) + (rk + j) * lda];
         }
         if (!diag) {
 #pragma unroll
             for (int q = 0; q < 16; q++) {
                 const int e = tid + 256 * q, i = e & 63, j = e >> 6;
-                vt[q] = J.A[(ri + min(i, mi - 1)) + (rk + j) * lda];
+                vt[q] = GA[(ri + min(i, mi - 1)) + (rk + j) * lda];
             }
         }
 #pragma unroll
@@ -743,7 +764,7 @@ __global__ __launch_bounds__(256) void k_chol_level(const CholLevelJob J0, const
     __syncthreads();
     CL_STAMP(3);
     if (diag) {
-        double *out = J.D + (long long)c * 4096;
+        const gptr<double> out = GD + (long long)c * 4096;
         for (int e = tid; e < 64 * 64; e += 256) {
             const int i = e & 63, j = e >> 6;
             out[e] = (i >= j && i < mc) ? P0[i + j * CL_LD] : 0.0;
@@ -752,7 +773,7 @@ __global__ __launch_bounds__(256) void k_chol_level(const CholLevelJob J0, const
     }
     for (int e = tid; e < 64 * 64; e += 256) {
         const int i = e & 63, j = e >> 6;
-        if (i < mi && j < mc) J.A[(ri + i) + (rc + j) * lda] = P0[64 + i + j * CL_LD];
+        if (i < mi && j < mc) GA[(ri + i) + (rc + j) * lda] = P0[64 + i + j * CL_LD];
     }
     CL_STAMP(4);
 }
