@@ -354,7 +354,7 @@ constexpr size_t dense_T32_lds_bytes() { return (size_t)(2 + DT32_WAVES) * DT32_
 // issued before the first store (addresses clamped into the valid part, not guarded): one round trip to memory instead of one per
 // 16 x 16 tile -- these kernels are links of a chain of dependent launches.  JFAST: consecutive threads walk j (sj == 1).
 template <int MODE, bool JFAST = false>
-__device__ __forceinline__ void tile64_load(double *Z, int ldz, const double *G, long long si, long long sj, int rows, int cols, int fr, int fc, int tid) {
+__device__ __forceinline__ void tile64_load(double *Z, int ldz, gptr<const double> G, long long si, long long sj, int rows, int cols, int fr, int fc, int tid) {
     double v[16];
 #pragma unroll
     for (int q = 0; q < 16; q++) {
@@ -397,10 +397,12 @@ __global__ __launch_bounds__(256) void k_trsm_diag(const TrsmDesc *__restrict__ 
     const int v0 = w.chunk * 64;
     const int nv = min(64, d.nvec - v0);
     const int i16 = tid & 15, j16 = tid >> 4;
-    tile64_load<1>(Ls, LDL, d.L, 1, d.ldl, n, n, n16, n16, tid);
-    if (tid < n16) dinv[tid] = (tid < n) ? 1.0 / d.L[tid + (long long)tid * d.ldl] : 0.0;
-    if (d.es == 1) tile64_load<0>(xs, LDL, d.B + (long long)v0 * d.vs, 1, d.vs, n, nv, n16, nv, tid);            // vectors are columns
-    else tile64_load<0, true>(xs, LDL, d.B + (long long)v0 * d.vs, d.es, d.vs, n, nv, n16, nv, tid);              // vectors are rows (vs == 1)
+    const gptr<const double> gL = as_global(d.L);
+    const gptr<double> gB = as_global(d.B);
+    tile64_load<1>(Ls, LDL, gL, 1, d.ldl, n, n, n16, n16, tid);
+    if (tid < n16) dinv[tid] = (tid < n) ? 1.0 / gL[tid + (long long)tid * d.ldl] : 0.0;
+    if (d.es == 1) tile64_load<0>(xs, LDL, (gptr<const double>)gB + (long long)v0 * d.vs, 1, d.vs, n, nv, n16, nv, tid);            // vectors are columns
+    else tile64_load<0, true>(xs, LDL, (gptr<const double>)gB + (long long)v0 * d.vs, d.es, d.vs, n, nv, n16, nv, tid);              // vectors are rows (vs == 1)
     __syncthreads();
     if (d.trans == 0) lds_trsm<false>(Ls, LDL, dinv, xs, 1, LDL, n, nv, wave, 4, lane);
     else lds_trsm<true>(Ls, LDL, dinv, xs, 1, LDL, n, nv, wave, 4, lane);
@@ -409,12 +411,12 @@ __global__ __launch_bounds__(256) void k_trsm_diag(const TrsmDesc *__restrict__ 
         for (int j0 = 0; j0 < nv; j0 += 16)
             for (int i0 = 0; i0 < n; i0 += 16) {
                 const int i = i0 + i16, v = j0 + j16;
-                if (i < n && v < nv) d.B[(long long)(v0 + v) * d.vs + i] = xs[i + v * LDL];
+                if (i < n && v < nv) gB[(long long)(v0 + v) * d.vs + i] = xs[i + v * LDL];
             }
     } else {
         for (int i0 = 0; i0 < n; i0 += 4) {
             const int v = tid & 63, i = i0 + (tid >> 6);
-            if (i < n && v < nv) d.B[(long long)(v0 + v) * d.vs + (long long)i * d.es] = xs[i + v * LDL];
+            if (i < n && v < nv) gB[(long long)(v0 + v) * d.vs + (long long)i * d.es] = xs[i + v * LDL];
         }
     }
 }
@@ -439,20 +441,22 @@ __global__ __launch_bounds__(256) void k_trtri_diag(const TrtriDesc *__restrict_
     double *Ls = tts, *Zs = tts + LDL * TRSM_NB, *dinv = Zs + LDL * TRSM_NB;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = d.n, n16 = (n + 15) & ~15;
     const int i16 = tid & 15, j16 = tid >> 4;
-    tile64_load<1>(Ls, LDL, d.L, 1, d.ldl, n, n, n16, n16, tid);
+    const gptr<const double> gL = as_global(d.L);
+    const gptr<double> gout = as_global(d.out);
+    tile64_load<1>(Ls, LDL, gL, 1, d.ldl, n, n, n16, n16, tid);
     for (int j0 = 0; j0 < n16; j0 += 16)
         for (int i0 = 0; i0 < n16; i0 += 16) {
             const int i = i0 + i16, j = j0 + j16;
             Zs[i + j * LDL] = (i == j && i < n) ? 1.0 : 0.0;
         }
-    if (tid < n16) dinv[tid] = (tid < n) ? 1.0 / d.L[tid + (long long)tid * d.ldl] : 0.0;
+    if (tid < n16) dinv[tid] = (tid < n) ? 1.0 / gL[tid + (long long)tid * d.ldl] : 0.0;
     __syncthreads();
     lds_trsm<false>(Ls, LDL, dinv, Zs, 1, LDL, n, n, wave, 4, lane);
     __syncthreads();
     for (int j0 = 0; j0 < n; j0 += 16)
         for (int i0 = 0; i0 < n; i0 += 16) {
             const int i = i0 + i16, j = j0 + j16;
-            if (i < n && j < n) d.out[i + (long long)j * d.ldo] = (i >= j) ? Zs[i + j * LDL] : 0.0;
+            if (i < n && j < n) gout[i + (long long)j * d.ldo] = (i >= j) ? Zs[i + j * LDL] : 0.0;
         }
 }
 // rows x cols copy between two column-major arrays (the solved right-hand sides back into the caller's array)
@@ -488,7 +492,8 @@ __global__ __launch_bounds__(256) void k_potrf_diag(const PotrfDesc *__restrict_
     __shared__ double dinv[POTRF_NB];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = d.n, n16 = (n + 15) & ~15;
     const int i16 = tid & 15, j16 = tid >> 4;
-    tile64_load<2>(As, LDA, d.A, 1, d.lda, n, n, n16, n16, tid);
+    const gptr<double> gA = as_global(d.A);
+    tile64_load<2>(As, LDA, (gptr<const double>)gA, 1, d.lda, n, n, n16, n16, tid);
     __syncthreads();
     const bool bad = lds_potrf(As, LDA, dinv, n, wave, 4, lane);
     if (bad && lane == 0) atomicMin(info, d.code);
@@ -496,7 +501,7 @@ __global__ __launch_bounds__(256) void k_potrf_diag(const PotrfDesc *__restrict_
     for (int j0 = 0; j0 < n; j0 += 16)
         for (int i0 = 0; i0 < n; i0 += 16) {
             const int i = i0 + i16, j = j0 + j16;
-            if (i < n && j < n && i >= j) d.A[i + (long long)j * d.lda] = As[i + j * LDA];
+            if (i < n && j < n && i >= j) gA[i + (long long)j * d.lda] = As[i + j * LDA];
         }
 }
 
