@@ -302,20 +302,30 @@ __device__ __forceinline__ void dt32_store(double *B, const v4d (&acc)[2][2], in
 #pragma unroll
             for (int reg = 0; reg < 4; reg++) B[(a * 16 + l4 + 4 * reg) + DT32_LD * (b * 16 + l15)] = acc[a][b][reg];
 }
-__global__ __launch_bounds__(64 * DT32_WAVES) void k_dense_T32(const DenseTBlock *__restrict__ blocks, const DenseTPair *__restrict__ pairs) {
-    extern __shared__ __attribute__((aligned(16))) double dts[];
-    const DenseTPair pr = pairs[blockIdx.x];
-    const DenseTBlock b = blocks[pr.blk];
-    const int n = b.n, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
+// FULL: n == 32, the usual case -- no guards on the loads, shifts instead of divisions by n in the copy-out
+template <bool FULL>
+__device__ __forceinline__ void dense_T32_body(const DenseTBlock &b, const DenseTPair &pr, double *dts) {
+    const int n = FULL ? 32 : b.n, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
     double *Li = dts, *Ys = dts + DT32_MS, *B0 = dts + 2 * DT32_MS + wave * DT32_MS;     // B0: this wave's matrix, then its result
     const gptr<const double> gLinv = as_global((const double *)b.Linv), gY = as_global(b.Y), gA = as_global(b.A);
     const gptr<double> gTT = as_global(b.TT);
-    for (int e = tid; e < 32 * 32; e += 64 * DT32_WAVES) {
-        const int i = e % 32, c = e / 32;
-        Li[i + DT32_LD * c] = gLinv[e];
-        Ys[i + DT32_LD * c] = (i < n && c < n) ? gY[i + (long long)c * n] : 0.0;
+    {
+        double vl[4], vy[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int e = tid + 64 * DT32_WAVES * q, i = e % 32, c = e / 32;
+            vl[q] = gLinv[e];
+            vy[q] = gY[min(i, n - 1) + (long long)min(c, n - 1) * n];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int e = tid + 64 * DT32_WAVES * q, i = e % 32, c = e / 32;
+            Li[i + DT32_LD * c] = vl[q];
+            Ys[i + DT32_LD * c] = (FULL || (i < n && c < n)) ? vy[q] : 0.0;
+        }
     }
-    // DT32_ITER matrices per wave, the next one fetched into registers while the products of the current one run
+    // DT32_ITER matrices per wave, the next one fetched into registers while the products of the current one run.  The addresses are
+    // clamped into the matrix (and a wave beyond the last matrix re-reads the first): no branch around any load
     double areg[16];
     auto fetch = [&](int e) {
         const bool live = e < b.cnt;
@@ -323,7 +333,14 @@ __global__ __launch_bounds__(64 * DT32_WAVES) void k_dense_T32(const DenseTBlock
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int o = lane + 64 * r, i = o % 32, c = o / 32;
-            areg[r] = (live && i < n && c < n) ? A[i + (long long)c * n] : 0.0;
+            areg[r] = FULL ? A[o] : A[min(i, n - 1) + (long long)min(c, n - 1) * n];
+        }
+        if (!FULL) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int o = lane + 64 * r, i = o % 32, c = o / 32;
+                areg[r] = (i < n && c < n) ? areg[r] : 0.0;
+            }
         }
     };
     fetch(pr.e0 + wave);
@@ -343,9 +360,23 @@ __global__ __launch_bounds__(64 * DT32_WAVES) void k_dense_T32(const DenseTBlock
         dt32_store(B0, q1, l15, l4);                        // B0 belongs to this wave alone: LDS operations of one wave keep their order
         if (e < b.cnt) {
             const gptr<double> T = gTT + (long long)e * n * n;
-            for (int o = lane; o < n * n; o += 64) T[o] = B0[(o % n) + DT32_LD * (o / n)];
+            if (FULL) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int o = lane + 64 * r;
+                    T[o] = B0[(o % 32) + DT32_LD * (o / 32)];
+                }
+            } else
+                for (int o = lane; o < n * n; o += 64) T[o] = B0[(o % n) + DT32_LD * (o / n)];
         }
     }
+}
+__global__ __launch_bounds__(64 * DT32_WAVES) void k_dense_T32(const DenseTBlock *__restrict__ blocks, const DenseTPair *__restrict__ pairs) {
+    extern __shared__ __attribute__((aligned(16))) double dts[];
+    const DenseTPair pr = pairs[blockIdx.x];
+    const DenseTBlock b = blocks[pr.blk];
+    if (b.n == 32) dense_T32_body<true>(b, pr, dts);
+    else dense_T32_body<false>(b, pr, dts);
 }
 constexpr size_t dense_T32_lds_bytes() { return (size_t)(2 + DT32_WAVES) * DT32_MS * sizeof(double); }
 
