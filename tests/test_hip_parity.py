@@ -930,3 +930,25 @@ def test_sdpa_x64_full_block_diagonal_constraints(oracle_built):
     dx, _ = solve_system(ctx, rhs, np.zeros(0))
     assert np.max(np.abs(dx - dx_ref)) <= 1e-9 * max(1.0, np.max(np.abs(dx_ref)))
     ctx.close()
+
+
+def test_dense_blocks_below_32_with_a_ragged_matrix_count(oracle_built):
+    """k_dense_T32 off its 32 x 32 fast path: 8 blocks of 24 x 24 with 100 dense matrices each (not a multiple of the 8 matrices a
+    workgroup takes), assembly against the fp64 oracle."""
+    import clrs_amd
+    from clrs_amd import problems as P
+    from clrs_amd.solver import SchurContext, compute_T_decomposition
+    from oracle.oracle import Oracle
+    f = clrs_amd.flatten(P.sdpa_to_sdp(P.sdpa_scaled(nb=8, bs=24, m=100, seed=3, blocks_per_constraint=8)))
+    assert int(f.dense_ptr[-1]) == 8 * 100
+    X, Y = spd_iterates(f, seed=4)
+    Xc = chol_blocks_np(f, X)
+    S_ref, _ = Oracle(f, quad=False).schur_assemble(Xc, Y)
+    ctx = SchurContext(f)
+    ctx.set_graph_mode(False)
+    ctx.set_kernel_timing(-1)
+    _, S, _ = compute_T_decomposition(ctx, Xc, Y, want_S=True)
+    assert "k_dense_T32" in ctx.kernel_times()
+    ctx.close()
+    assert np.max(np.abs(S - S_ref)) <= 1e-12 * np.max(np.abs(S_ref))
+
