@@ -216,17 +216,19 @@ static int dmalloc(clrs_ctx *c, double **d, i64 n) {
 }
 
 // ---- stage builders -----------------------------------------------------------------------------
-// 128 x 128 or 64 x 64 tiles for one product: whichever leaves the busiest compute unit with less to do.  A CU works through
-// ceil(tiles / 256) tiles of either size; a large tile is four small ones of work and runs the matrix pipe at 0.72 of its peak
-// against 0.63 (scripts/gemm_probe.py).  2048 x 2048: 256 large tiles, one per CU; 2049 x 2049: 289 large tiles would give 33 CUs two.
+// 128 x 128 or 64 x 64 tiles for one product: whichever finishes its last round of workgroups first, in units of one 64 x 64 tile on a
+// CU of its own (scripts/gemm_probe.py).  Small tiles: 1024 resident (four per CU), the matrix pipe at 0.63 of its peak; a tile on
+// the edge of C skips the MFMAs outside C and, dispatched first, hides behind the whole tiles on its CU (about 0.3 of a tile).
+// Large tiles: 512 resident (two per CU, four units each) at 0.72, a lone one on a CU at 0.60; an edge tile is bound by the latency
+// of its loads and takes as long as a whole one.  4096 x 4096: two rounds of large tiles; 4097 x 4097 (1089 large tiles: a third
+// round) and 2049 x 2049 (289: 33 CUs with two) are faster with small ones.
 static bool gemm_prefers_large_tiles(const GemmDesc &d) {
     if (d.M < 256 || d.N < 256) return false;
-    auto tiles = [&](int B) {
-        const long long tm = (d.M + B - 1) / B, tn = (d.N + B - 1) / B;
-        return (d.lower_only ? tm * (tn + 1) / 2 : tm * tn) * std::max(1, d.pad0);
-    };
-    // (a lone large tile on a CU -- one wave per SIMD -- reaches about 0.60)
-    const double large = (double)((tiles(128) + 255) / 256) * 4.0 / (tiles(128) >= 512 ? 0.72 : 0.60), small = (double)((tiles(64) + 255) / 256) / 0.63;
+    const long long batch = std::max(1, d.pad0);
+    auto count = [&](long long tm, long long tn) { return (d.lower_only ? tm * (tn + 1) / 2 : tm * tn) * batch; };
+    const long long all64 = count((d.M + 63) / 64, (d.N + 63) / 64), full64 = count(d.M / 64, d.N / 64), all128 = count((d.M + 127) / 128, (d.N + 127) / 128);
+    const double small = ((double)((full64 + 1023) / 1024) * 4.0 + 0.3 * 4.0 * (double)(all64 - full64) / 1024.0) / 0.63;
+    const double large = all128 > 256 ? (double)((all128 + 511) / 512) * 8.0 / 0.72 : 4.0 / 0.60;
     return large < small;
 }
 static int add_gemm_stage(clrs_ctx *c, Plan &pl, const std::vector<GemmDesc> &descs) {
@@ -244,12 +246,17 @@ static int add_gemm_stage(clrs_ctx *c, Plan &pl, const std::vector<GemmDesc> &de
             ds.push_back(d);
             int tm = (d.M + BM - 1) / BM, tn = (d.N + BN - 1) / BN;
             int batch = std::max(1, d.pad0);   // batch count is encoded by the caller through pad0 (>=1)
-            for (int b = 0; b < batch; b++)
-                for (int j = 0; j < tn; j++)
-                    for (int i = 0; i < tm; i++) {
-                        if (d.lower_only && (i + 1) * BM <= j * BN) continue;
-                        tiles.push_back(GemmTile{id, b, i, j});
-                    }
+            // tiles on the edge of C first: they skip most of their MFMAs and are bound by the latency of their loads, which costs nothing
+            // while whole tiles share their CUs -- and a full tile's time at the tail of the launch when they come last
+            const bool ragged_m = d.M % BM != 0, ragged_n = d.N % BN != 0;
+            for (int edge = 1; edge >= 0; edge--)
+                for (int b = 0; b < batch; b++)
+                    for (int j = 0; j < tn; j++)
+                        for (int i = 0; i < tm; i++) {
+                            if (d.lower_only && (i + 1) * BM <= j * BN) continue;
+                            const bool is_edge = (ragged_m && i == tm - 1) || (ragged_n && j == tn - 1);
+                            if (is_edge == (edge == 1)) tiles.push_back(GemmTile{id, b, i, j});
+                        }
         }
         if (tiles.empty()) continue;
         Step s;

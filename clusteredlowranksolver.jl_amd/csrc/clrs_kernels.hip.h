@@ -138,20 +138,40 @@ __global__ __launch_bounds__(256, (BM <= 64 ? 4 : 2)) void k_gemm_f64_t(const Ge
 #pragma unroll
         for (int q = 0; q < EB; q++) sb[wo + q * SQB] = rb[q];
     };
+    // 16-row / 16-column pieces of this wave's quarter that lie inside C: a tile on the edge of C (the roofline instances are one row
+    // and column beyond a multiple of the tile: 65 of 1089 tiles) skips the MFMAs of the pieces outside, instead of costing a full tile
+    const int na = min(MT, max(0, (d.M - m0 - wm + 15) >> 4)), nb = min(NT, max(0, (d.N - n0 - wn + 15) >> 4));
+    const bool inner = na == MT && nb == NT;
     auto mma = [&](int ro) {
+        if (inner) {
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 4) {
-            // The MFMA computes D[r][c] = sum_k Aop[r][k] Bop[k][c] with c on lane&15.  We feed Aop = op(B)^T and
-            // Bop = op(A)^T so that c runs along the rows i of C (contiguous in memory) -> coalesced C stores.
-            double av[MT], bv[NT];
+            for (int kk = 0; kk < BK; kk += 4) {
+                // The MFMA computes D[r][c] = sum_k Aop[r][k] Bop[k][c] with c on lane&15.  We feed Aop = op(B)^T and
+                // Bop = op(A)^T so that c runs along the rows i of C (contiguous in memory) -> coalesced C stores.
+                double av[MT], bv[NT];
 #pragma unroll
-            for (int a = 0; a < MT; a++) av[a] = ra_[ro + (TA == 0 ? kk * LDA_S + a * 16 : a * 16 * LDT + kk)];
+                for (int a = 0; a < MT; a++) av[a] = ra_[ro + (TA == 0 ? kk * LDA_S + a * 16 : a * 16 * LDT + kk)];
 #pragma unroll
-            for (int b = 0; b < NT; b++) bv[b] = rb_[ro + (TB == 0 ? b * 16 * LDT + kk : kk * LDB_S + b * 16)];
+                for (int b = 0; b < NT; b++) bv[b] = rb_[ro + (TB == 0 ? b * 16 * LDT + kk : kk * LDB_S + b * 16)];
 #pragma unroll
-            for (int a = 0; a < MT; a++)
+                for (int a = 0; a < MT; a++)
 #pragma unroll
-                for (int b = 0; b < NT; b++) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[b], av[a], acc[a][b], 0, 0, 0);
+                    for (int b = 0; b < NT; b++) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[b], av[a], acc[a][b], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < BK; kk += 4) {
+                double av[MT], bv[NT];
+#pragma unroll
+                for (int a = 0; a < MT; a++) av[a] = ra_[ro + (TA == 0 ? kk * LDA_S + a * 16 : a * 16 * LDT + kk)];
+#pragma unroll
+                for (int b = 0; b < NT; b++) bv[b] = rb_[ro + (TB == 0 ? b * 16 * LDT + kk : kk * LDB_S + b * 16)];
+#pragma unroll
+                for (int a = 0; a < MT; a++)
+#pragma unroll
+                    for (int b = 0; b < NT; b++)
+                        if (a < na && b < nb) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[b], av[a], acc[a][b], 0, 0, 0);
+            }
         }
     };
     static_assert(ABUF == BBUF, "one buffer offset for both operands");
