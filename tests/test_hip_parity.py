@@ -24,7 +24,10 @@ def _dp(a):
 
 @pytest.mark.parametrize("ta,tb", [(0, 0), (1, 0), (0, 1), (1, 1)])
 @pytest.mark.parametrize("M,N,K", [(1, 1, 1), (16, 16, 4), (64, 64, 16), (37, 53, 29), (130, 70, 100), (3, 200, 65),
-                                   (256, 256, 16), (300, 260, 70), (513, 257, 33)])     # the last three take the 128 x 128 tile kernel
+                                   (256, 256, 16), (300, 260, 70), (513, 257, 33),
+                                   # two rounds of 128 x 128 tiles against four of 64 x 64: these take the large tile (gemm_prefers_large_tiles),
+                                   # with a ragged last tile column / row and a partial last chunk of k
+                                   (4096, 4000, 40), (4000, 4096, 19)])
 def test_gemm_kernel(ta, tb, M, N, K):
     rng = np.random.default_rng(M * 1000 + N * 10 + K)
     A = rng.standard_normal((K, M) if ta else (M, K))
