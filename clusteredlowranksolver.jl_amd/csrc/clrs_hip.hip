@@ -59,6 +59,7 @@ static int g_cfg_wave3_assemble = 1;   // register-resident form of the cluster-
 static int g_cfg_dense_block = 1;
 static int g_cfg_trsm_blockinv = 1;  // triangular solves with n > TRSM_IB through inverted diagonal blocks (plan_trsm_blockinv)
 static int g_cfg_potrf_levels = 1;   // Cholesky of matrices beyond one block: one launch per block column (plan_potrf_levels)
+static int g_cfg_pairing_tri = 1;    // staged low-rank blocks with W = V: lower triangles of the pairing matrices only
 static int g_cfg_dense_wave = 1;      // dense blocks with n <= 32 beyond k_dense_block: one wave per (block, matrix), k_dense_T32
 static int g_cfg_factor_small = 1;      // factor + Q in one launch of one workgroup for <= 4 small clusters (0: k_cluster_factor + k_small_potrf)
 static int g_cfg_solve_small_max = 32768;     // one-workgroup solve stage only up to this many doubles of operands (beyond: one workgroup per cluster, three launches)
@@ -993,7 +994,9 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
         for (i64 t = k.t0; t < k.t1; t++) {
             int r = d->term_r[t], s = d->term_s[t];
             // A_Y[t] = bpY[r,s][pointers_left[r][(s,p,k)], pointers_right[s][(r,p,k)]]  (src/solver.jl:1163)
-            h_ayidx[t] = k.g_off + (i64)k.ULt * k.URt + (k.offL[r] + lidx[t]) + (i64)(k.offR[s] + ridx[partner[t]]) * k.ULt;
+            i64 gl = k.offL[r] + lidx[t], gr = k.offR[s] + ridx[partner[t]];
+            if (g_cfg_pairing_tri && k.sym && k.m == 1 && k.ULt == k.URt && gl < gr) std::swap(gl, gr);   // only the lower triangle of the symmetric GY is formed
+            h_ayidx[t] = k.g_off + (i64)k.ULt * k.URt + gl + gr * k.ULt;
         }
     }
     std::vector<int> s_tL(T), s_tR(T);
@@ -1340,11 +1343,13 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
                     if (k.UR[r] > 0)
                         g1.push_back(mk_gemm(0, 0, n, k.UR[r], dl, 1.0, Yb + (i64)r0 * n, n, VR + r0 + (i64)k.offR[r] * n, n, 0.0, TY + (i64)k.offR[r] * n, n));
                 }
+                // W = V in one sub-block: GX = V^T X^-1 V and GY = V^T Y V are symmetric -- lower tiles only, the gather mirrors its reads
+                const int tri = g_cfg_pairing_tri && k.sym && k.m == 1 && k.ULt == k.URt ? 1 : 0;
                 for (int s = 0; s < k.m; s++)  // GY[rows s, :] = W_s^T T_Y[s-block, :]   (src/solver.jl:1131)
                     if (k.UL[s] > 0 && k.URt > 0)
-                        g2.push_back(mk_gemm(1, 0, k.UL[s], k.URt, dl, 1.0, WL + s * dl + (i64)k.offL[s] * n, n, TY + s * dl, n, 0.0, GY + k.offL[s], k.ULt));
+                        g2.push_back(mk_gemm(1, 0, k.UL[s], k.URt, dl, 1.0, WL + s * dl + (i64)k.offL[s] * n, n, TY + s * dl, n, 0.0, GY + k.offL[s], k.ULt, 1, 0, 0, 0, tri));
                 // GX = ZL^T ZR = W^T X^-1 V       (replaces src/solver.jl:1117,1137-1143)
-                if (k.ULt > 0 && k.URt > 0) g2.push_back(mk_gemm(1, 0, k.ULt, k.URt, n, 1.0, ZL, n, ZR, n, 0.0, GX, k.ULt));
+                if (k.ULt > 0 && k.URt > 0) g2.push_back(mk_gemm(1, 0, k.ULt, k.URt, n, 1.0, ZL, n, ZR, n, 0.0, GX, k.ULt, 1, 0, 0, 0, tri));
             } else if (k.cnt > 0) {
                 {   // dense block that fits in LDS: one fused launch for all such blocks
                     const size_t n16 = (n + 15) & ~15, msz = (n16 + 2) * n16, need = 2 * msz + n16 + 2 * (size_t)k.cnt * msz + 1024;
@@ -1419,6 +1424,7 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
                 if (k.kind == 0) {
                     if (k.t1 == k.t0) continue;
                     sd.ldg = k.ULt;
+                    sd.tri = g_cfg_pairing_tri && k.sym && k.m == 1 && k.ULt == k.URt ? 1 : 0;
                     sd.GX = c->d_G + k.g_off; sd.GY = sd.GX + (i64)k.ULt * k.URt;
                     sd.tptr = k.d_tptr; sd.tL = d_tL; sd.tR = d_tR; sd.tlam = d_tlam;
                 } else {
@@ -2332,6 +2338,7 @@ extern "C" int clrs_config_set(const char *key, int value) {
     if (!std::strcmp(key, "wave3_assemble")) { g_cfg_wave3_assemble = value; return 0; }
     if (!std::strcmp(key, "dense_block")) { g_cfg_dense_block = value; return 0; }
     if (!std::strcmp(key, "dense_wave")) { g_cfg_dense_wave = value; return 0; }
+    if (!std::strcmp(key, "pairing_tri")) { g_cfg_pairing_tri = value; return 0; }
     if (!std::strcmp(key, "potrf_levels")) { g_cfg_potrf_levels = value; return 0; }
     if (!std::strcmp(key, "trsm_blockinv")) { g_cfg_trsm_blockinv = value; return 0; }
     if (!std::strcmp(key, "solve_small2")) { g_cfg_solve_small2 = value; return 0; }

@@ -562,7 +562,7 @@ __global__ __launch_bounds__(256) void k_potrf_diag(const PotrfDesc *__restrict_
 // One thread per (p,q); each S entry is written exactly once (deterministic, no atomics).
 // ------------------------------------------------------------------------------------------------
 struct SBlockDesc {
-    int kind, ldg, cnt, pad;
+    int kind, ldg, cnt, tri;   // tri: GX and GY are symmetric and only their lower triangles were computed (W = V, one sub-block)
     const double *GX, *GY;     // low rank: UL x UR pairing matrices
     const int *tptr;           // [P+1] CSR of this block's terms over the cluster's constraint index
     const int *tL, *tR;        // per term: global left / right unique-vector index
@@ -596,7 +596,8 @@ __global__ __launch_bounds__(256 * SG_W) void k_schur_gather(const SClusterDesc 
                 const double l1 = d.tlam[t1];
                 for (int t2 = b0; t2 < b1; t2++) {
                     const int L2 = d.tL[t2], R2 = d.tR[t2];
-                    acc += (l1 * d.tlam[t2]) * (d.GX[L1 + (long long)R2 * d.ldg] * d.GY[L2 + (long long)R1 * d.ldg]);
+                    const bool sx = d.tri && L1 < R2, sy = d.tri && L2 < R1;
+                    acc += (l1 * d.tlam[t2]) * (d.GX[(sx ? R2 : L1) + (long long)(sx ? L1 : R2) * d.ldg] * d.GY[(sy ? R1 : L2) + (long long)(sy ? L2 : R1) * d.ldg]);
                 }
             }
         } else {

@@ -242,6 +242,8 @@ int clrs_wave2_clusters(const clrs_ctx *ctx);
  * of k_solve_small2 (every operand staged in one trip to memory, one wave per triangular solve); 0 keeps k_solve_small.
  * "dense_wave" (default 1): dense blocks with n <= 32 beyond the LDS-resident kernel form X^-1 A Y with one wave per matrix
  * (k_trtri32 + k_dense_T32); 0 = two substitution launches and a batched GEMM.
+ * "pairing_tri" (default 1): staged low-rank blocks whose left and right vectors coincide (W = V, one sub-block) compute only the
+ * lower tiles of the symmetric pairing matrices V^T X^-1 V and V^T Y V; k_schur_gather mirrors its reads; 0 = full matrices.
  * "potrf_levels" (default 1): the staged Cholesky of a matrix beyond one 64-wide block runs ONE launch per block column
  * (k_chol_level); 0 = k_potrf_diag + k_trsm_diag + k_gemm_f64_t per block column.
  * "trsm_blockinv" (default 1): staged triangular solves with n > 512 go through inverted 512 x 512 diagonal blocks (k_trtri_diag
