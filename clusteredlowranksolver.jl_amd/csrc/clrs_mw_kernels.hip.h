@@ -377,12 +377,28 @@ __device__ __forceinline__ bool wg_last_block(int *counter, unsigned total) {
 }
 
 // copy a rows x cols planar matrix between two arrays (any address spaces)
+// Four elements per thread and pass, every load of a pass issued before its first store (the index of a thread past the end is clamped
+// instead of guarded): a pass is one round trip to the source instead of four, and a 96 x 96 block is 5 passes instead of 18.
 template <int K, int NT = MW_NT, class PD, class PS>
 __device__ __forceinline__ void wg_copy(PD dst, long dplane, int ldd, PS src, long splane, int lds_, int rows, int cols, int tid) {
-    for (int e = tid; e < rows * cols; e += NT) {
-        const int i = e % rows, c = e / rows;
+    constexpr int U = K <= 6 ? 4 : 2;
+    const int total = rows * cols;
+    for (int e0 = tid; e0 < total; e0 += U * NT) {
+        double v[U][K];
 #pragma unroll
-        for (int l = 0; l < K; l++) dst[(long)l * dplane + i + (long)c * ldd] = src[(long)l * splane + i + (long)c * lds_];
+        for (int u = 0; u < U; u++) {
+            const int e = min(e0 + u * NT, total - 1), i = e % rows, c = e / rows;
+#pragma unroll
+            for (int l = 0; l < K; l++) v[u][l] = src[(long)l * splane + i + (long)c * lds_];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int e = e0 + u * NT, i = e % rows, c = e / rows;
+            if (e < total) {
+#pragma unroll
+                for (int l = 0; l < K; l++) dst[(long)l * dplane + i + (long)c * ldd] = v[u][l];
+            }
+        }
     }
 }
 
