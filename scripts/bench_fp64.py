@@ -391,13 +391,23 @@ def main(argv=None, emit=True):
                 rstep()
             e1.record(); e1.synchronize()
             r_s = 1e-3 * e0.elapsed_time(e1) / 5
+            # the Schur assembly alone (the phase SURVEY.md section 8d's 25.8 GFLOP / 67 MB are quoted for), same iterates
+            e0.record()
+            for _ in range(5):
+                rctx.assemble_dev(trXc.data_ptr(), trY.data_ptr())
+            e1.record(); e1.synchronize()
+            ra_s = 1e-3 * e0.elapsed_time(e1) / 5
             rcnt = rctx.counters()
             rfl = rcnt["assemble_flops"] + rcnt["factor_flops"]
             out["roofline_R"] = {"bound": "mfma", "phase": "chol X + schur_assemble + factor, staged (large-block) kernels", "kernel": "k_gemm_f64_t + k_chol_level + k_trtri_diag",
                                  "ms": 1e3 * r_s, "achieved": rfl / r_s / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": rfl / r_s / 1e12 / FP64_PEAK_TFLOPS,
                                  "traffic": None, "algorithmic_flops": rfl,
+                                 "assembly": {"ms": 1e3 * ra_s, "algorithmic_flops": rcnt["assemble_flops"], "achieved": rcnt["assemble_flops"] / ra_s / 1e12,
+                                              "frac": rcnt["assemble_flops"] / ra_s / 1e12 / FP64_PEAK_TFLOPS,
+                                              "note": "schur_assemble alone; the symmetric pairing matrices of W = V blocks are formed as lower tiles only, "
+                                                      "the flop count is SURVEY.md section 8d's 2 (2 n^2 U + 2 n U^2) + U^2 per block all the same"},
                                  "workload": "polyopt_scaled(1024): one cluster, one PSD block n = 1025, P = 2049 rank-1 constraints (SURVEY.md section 8d, roofline "
-                                             "instance R; polyopt_scaled(2048): profiles/r02/g_staged_polyopt2048.txt)",
+                                             "instance R; polyopt_scaled(2048): profiles/r02/u_staged_polyopt2048.txt)",
                                  "launches": rctx.plan_info()}
             rctx.close()
         except Exception as e:
