@@ -638,10 +638,10 @@ static int run_steps(clrs_ctx *c, const Plan &pl) {
                 break;
             case STEP_CHOL_LEVEL:
                 if (s.aux1 == 1) {       // one matrix: job by value (kept in the context), no tables
-                    hipLaunchKernelGGL(k_chol_level, dim3(s.grid), dim3(256), chol_level_lds_bytes(), st, c->chol_jobs[(size_t)s.n], s.aux0,
+                    hipLaunchKernelGGL(k_chol_level, dim3(s.grid), dim3(CL_NT), chol_level_lds_bytes(), st, c->chol_jobs[(size_t)s.n], s.aux0,
                                        (const CholLevelJob *)nullptr, (const CholLevelWork *)nullptr, (int *)s.dst);
                 } else
-                    hipLaunchKernelGGL(k_chol_level, dim3(s.grid), dim3(256), chol_level_lds_bytes(), st, CholLevelJob{}, 0, (const CholLevelJob *)s.d0,
+                    hipLaunchKernelGGL(k_chol_level, dim3(s.grid), dim3(CL_NT), chol_level_lds_bytes(), st, CholLevelJob{}, 0, (const CholLevelJob *)s.d0,
                                        (const CholLevelWork *)s.d1, (int *)s.dst);
                 break;
             case STEP_COPY2D:

@@ -663,6 +663,8 @@ struct CholLevelJob {
 };
 struct CholLevelWork { int job, kind, ti, tj; };
 constexpr int CL_LD = 136, CL_TS = CL_LD * 64;       // one 128 x 64 panel in LDS
+constexpr int CL_NT = 1024, CL_WAVES = CL_NT / 64;   // sixteen waves: the update, the panel solves and the trailing tiles of the diagonal block spread over all of them
+constexpr int CL_WR = CL_WAVES / 4, CL_RPW = 128 / CL_WR, CL_NA = CL_RPW / 16;   // waves along the 128 rows of a panel (four groups along its columns), rows and 16-row pieces per wave
 constexpr size_t chol_level_lds_bytes() { return (size_t)(2 * CL_TS + 64) * sizeof(double); }
 
 // acc[a][b] = sum_k X[i][k] Y[j][k], k < 64, over NA x NB subtiles of 16 x 16: rows i of X from X[0], rows j of Y from Y[0]; the lane
@@ -690,18 +692,19 @@ __device__ __forceinline__ void cl_mm(const double *X, const double *Y, v4d (&ac
 // of guarded: a guarded load is a branch, and the loads of a thread then wait for each other (15 us for four 64 x 64 tiles against 3).
 __device__ __forceinline__ void cl_load(double *dst, gptr<const double> src, long long ld, int rows, int cols, int tid) {
     if (rows <= 0 || cols <= 0) {
-        for (int e = tid; e < 128 * 64; e += 256) dst[(e & 127) + (e >> 7) * CL_LD] = 0.0;
+        for (int e = tid; e < 128 * 64; e += CL_NT) dst[(e & 127) + (e >> 7) * CL_LD] = 0.0;
         return;
     }
-    double v[32];
+    constexpr int Q = 128 * 64 / CL_NT;
+    double v[Q];
 #pragma unroll
-    for (int q = 0; q < 32; q++) {
-        const int e = tid + 256 * q, i = e & 127, j = e >> 7;
+    for (int q = 0; q < Q; q++) {
+        const int e = tid + CL_NT * q, i = e & 127, j = e >> 7;
         v[q] = src[min(i, rows - 1) + min(j, cols - 1) * ld];
     }
 #pragma unroll
-    for (int q = 0; q < 32; q++) {
-        const int e = tid + 256 * q, i = e & 127, j = e >> 7;
+    for (int q = 0; q < Q; q++) {
+        const int e = tid + CL_NT * q, i = e & 127, j = e >> 7;
         dst[i + j * CL_LD] = (i < rows && j < cols) ? v[q] : 0.0;
     }
 }
@@ -712,7 +715,7 @@ __device__ __forceinline__ void cl_load(double *dst, gptr<const double> src, lon
 #endif
 // One matrix (the usual case): the job rides in the kernel arguments and the work item follows from blockIdx.x (column workgroups
 // first, then the lower 128 x 128 tiles column by column) -- two dependent trips to memory less on every level; several matrices: tables.
-__global__ __launch_bounds__(256) void k_chol_level(const CholLevelJob J0, const int ncol, const CholLevelJob *__restrict__ jobs,
+__global__ __launch_bounds__(CL_NT) void k_chol_level(const CholLevelJob J0, const int ncol, const CholLevelJob *__restrict__ jobs,
                                                     const CholLevelWork *__restrict__ work, int *__restrict__ info) {
     extern __shared__ __attribute__((aligned(16))) double cls[];
     CholLevelWork w;
@@ -730,22 +733,22 @@ __global__ __launch_bounds__(256) void k_chol_level(const CholLevelJob J0, const
     const long long lda = J.lda;
     const gptr<double> GA = as_global(J.A);
     const gptr<double> GD = as_global(J.D);
-    const int rk = J.k * 64, wi = wave & 1, wj = wave >> 1;
+    const int rk = J.k * 64, wi = wave % CL_WR, wj = wave / CL_WR;      // wave (wi, wj): rows CL_RPW wi .., one of four column groups
     if (w.kind == 1) {
         const int rb = (J.k + 2) * 64, r0 = rb + 128 * w.ti, c0 = rb + 128 * w.tj;
         cl_load(P0, (gptr<const double>)GA + r0 + rk * lda, lda, min(128, J.n - r0), 64, tid);
         if (w.ti != w.tj) cl_load(P1, (gptr<const double>)GA + c0 + rk * lda, lda, min(128, J.n - c0), 64, tid);
         __syncthreads();
-        if (w.ti == w.tj && wi == 0 && wj == 1) return;          // strictly upper quadrant of a diagonal tile
-        v4d acc[4][4];
-        cl_mm<4, 4>(P0 + wi * 64, (w.ti != w.tj ? P1 : P0) + wj * 64, acc, l15, l4);
+        if (w.ti == w.tj && (wi + 1) * CL_RPW <= wj * 32) return;          // strictly above the diagonal of a diagonal tile
+        v4d acc[CL_NA][2];
+        cl_mm<CL_NA, 2>(P0 + wi * CL_RPW, (w.ti != w.tj ? P1 : P0) + wj * 32, acc, l15, l4);
 #pragma unroll
-        for (int a = 0; a < 4; a++)
+        for (int a = 0; a < CL_NA; a++)
 #pragma unroll
-            for (int b = 0; b < 4; b++)
+            for (int b = 0; b < 2; b++)
 #pragma unroll
                 for (int reg = 0; reg < 4; reg++) {
-                    const int gi = r0 + wi * 64 + a * 16 + l15, gj = c0 + wj * 64 + b * 16 + l4 + 4 * reg;
+                    const int gi = r0 + wi * CL_RPW + a * 16 + l15, gj = c0 + wj * 32 + b * 16 + l4 + 4 * reg;
                     if (gi < J.n && gj < J.n) GA[gi + gj * lda] -= acc[a][b][reg];
                 }
         return;
@@ -755,80 +758,80 @@ __global__ __launch_bounds__(256) void k_chol_level(const CholLevelJob J0, const
     const bool diag = w.ti == c;
     CL_STAMP(0);
     {
-        double v[16];
+        double v[4096 / CL_NT];
 #pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const int e = tid + 256 * q, i = e & 63, j = e >> 6;
+        for (int q = 0; q < 4096 / CL_NT; q++) {
+            const int e = tid + CL_NT * q, i = e & 63, j = e >> 6;
             v[q] = GA[(rc + min(i, mc - 1)) + (rc + min(j, mc - 1)) * lda];
         }
-        double vt[16];
+        double vt[4096 / CL_NT];
         if (!diag) {
 #pragma unroll
-            for (int q = 0; q < 16; q++) {
-                const int e = tid + 256 * q, i = e & 63, j = e >> 6;
+            for (int q = 0; q < 4096 / CL_NT; q++) {
+                const int e = tid + CL_NT * q, i = e & 63, j = e >> 6;
                 vt[q] = GA[(ri + min(i, mi - 1)) + (rc + min(j, mc - 1)) * lda];
             }
         }
 #pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const int e = tid + 256 * q, i = e & 63, j = e >> 6;
+        for (int q = 0; q < 4096 / CL_NT; q++) {
+            const int e = tid + CL_NT * q, i = e & 63, j = e >> 6;
             P0[i + j * CL_LD] = (i < mc && j < mc) ? (i >= j ? v[q] : 0.0) : (i == j ? 1.0 : 0.0);
             P0[64 + i + j * CL_LD] = (!diag && i < mi && j < mc) ? vt[q] : 0.0;
         }
     }
     if (J.k >= 0) {
-        double v[16], vt[16];
+        double v[4096 / CL_NT], vt[4096 / CL_NT];
 #pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const int e = tid + 256 * q, i = e & 63, j = e >> 6;
+        for (int q = 0; q < 4096 / CL_NT; q++) {
+            const int e = tid + CL_NT * q, i = e & 63, j = e >> 6;
             v[q] = GA[(rc + min(i, mc - 1)) + (rk + j) * lda];
         }
         if (!diag) {
 #pragma unroll
-            for (int q = 0; q < 16; q++) {
-                const int e = tid + 256 * q, i = e & 63, j = e >> 6;
+            for (int q = 0; q < 4096 / CL_NT; q++) {
+                const int e = tid + CL_NT * q, i = e & 63, j = e >> 6;
                 vt[q] = GA[(ri + min(i, mi - 1)) + (rk + j) * lda];
             }
         }
 #pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const int e = tid + 256 * q, i = e & 63, j = e >> 6;
+        for (int q = 0; q < 4096 / CL_NT; q++) {
+            const int e = tid + CL_NT * q, i = e & 63, j = e >> 6;
             P1[i + j * CL_LD] = i < mc ? v[q] : 0.0;
             P1[64 + i + j * CL_LD] = (!diag && i < mi) ? vt[q] : 0.0;
         }
     }
     __syncthreads();
     CL_STAMP(1);
-    if (J.k >= 0 && !(diag && wi == 1)) {
-        // [D; T] -= [L_ck; L_ik] L_ck^T: wave (wi, wj) rows 64 wi .., columns 32 wj ..
-        v4d acc[4][2];
-        cl_mm<4, 2>(P1 + wi * 64, P1 + wj * 32, acc, l15, l4);
+    if (J.k >= 0 && !(diag && wi * CL_RPW >= 64)) {
+        // [D; T] -= [L_ck; L_ik] L_ck^T: wave (wi, wj) rows CL_RPW wi .., columns 16 wj ..
+        v4d acc[CL_NA][1];
+        cl_mm<CL_NA, 1>(P1 + wi * CL_RPW, P1 + wj * 16, acc, l15, l4);
 #pragma unroll
-        for (int a = 0; a < 4; a++)
+        for (int a = 0; a < CL_NA; a++)
 #pragma unroll
-            for (int b = 0; b < 2; b++)
+            for (int b = 0; b < 1; b++)
 #pragma unroll
                 for (int reg = 0; reg < 4; reg++) {
-                    const int i = wi * 64 + a * 16 + l15, j = wj * 32 + b * 16 + l4 + 4 * reg;
+                    const int i = wi * CL_RPW + a * 16 + l15, j = wj * 16 + b * 16 + l4 + 4 * reg;
                     if (i >= j) P0[i + j * CL_LD] -= acc[a][b][reg];        // rows >= 64 (T) always, D in its lower triangle
                 }
     }
     __syncthreads();
     CL_STAMP(2);
     // chol(D), and T L^-T in the same sweep (the rows of T ride along as rows below every diagonal block)
-    const bool bad = lds_potrf(P0, CL_LD, dinv, mc, wave, 4, lane, diag ? 0 : 64);
+    const bool bad = lds_potrf(P0, CL_LD, dinv, mc, wave, CL_WAVES, lane, diag ? 0 : 64);
     if (diag && bad && lane == 0) atomicMin(info, J.code);
     __syncthreads();
     CL_STAMP(3);
     if (diag) {
         const gptr<double> out = GD + (long long)c * 4096;
-        for (int e = tid; e < 64 * 64; e += 256) {
+        for (int e = tid; e < 64 * 64; e += CL_NT) {
             const int i = e & 63, j = e >> 6;
             out[e] = (i >= j && i < mc) ? P0[i + j * CL_LD] : 0.0;
         }
         return;
     }
-    for (int e = tid; e < 64 * 64; e += 256) {
+    for (int e = tid; e < 64 * 64; e += CL_NT) {
         const int i = e & 63, j = e >> 6;
         if (i < mi && j < mc) GA[(ri + i) + (rc + j) * lda] = P0[64 + i + j * CL_LD];
     }

@@ -41,7 +41,7 @@ int main(int argc, char **argv) {
         hipMemcpy(dw, w.data(), w.size() * sizeof(CholLevelWork), hipMemcpyHostToDevice);
         hipDeviceSynchronize();
         hipEventRecord(e0);
-        hipLaunchKernelGGL(k_chol_level, dim3((unsigned)w.size()), dim3(256), chol_level_lds_bytes(), 0, J, ncol, (const CholLevelJob *)nullptr, (const CholLevelWork *)nullptr, dinfo);
+        hipLaunchKernelGGL(k_chol_level, dim3((unsigned)w.size()), dim3(CL_NT), chol_level_lds_bytes(), 0, J, ncol, (const CholLevelJob *)nullptr, (const CholLevelWork *)nullptr, dinfo);
         hipEventRecord(e1);
         hipDeviceSynchronize();
         float ms;
