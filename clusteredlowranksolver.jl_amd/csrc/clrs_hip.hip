@@ -60,6 +60,7 @@ static int g_cfg_dense_block = 1;
 static int g_cfg_trsm_blockinv = 1;  // triangular solves with n > TRSM_IB through inverted diagonal blocks (plan_trsm_blockinv)
 static int g_cfg_potrf_levels = 1;   // Cholesky of matrices beyond one block: one launch per block column (plan_potrf_levels)
 static int g_cfg_pairing_tri = 1;    // staged low-rank blocks with W = V: lower triangles of the pairing matrices only
+static int g_cfg_factor_aug = 1;     // one large cluster with <= 64 free variables: L, L^-1 B and Q from one factorisation of [S .; B^T 0]
 static int g_cfg_dense_wave = 1;      // dense blocks with n <= 32 beyond k_dense_block: one wave per (block, matrix), k_dense_T32
 static int g_cfg_factor_small = 1;      // factor + Q in one launch of one workgroup for <= 4 small clusters (0: k_cluster_factor + k_small_potrf)
 static int g_cfg_solve_small_max = 32768;     // one-workgroup solve stage only up to this many doubles of operands (beyond: one workgroup per cluster, three launches)
@@ -70,10 +71,10 @@ static const int LDS_BUDGET_DOUBLES = 20000;   // of the 20480 doubles (160 KiB)
 // ------------------------------------------------------------------------------------------------
 // launch plan
 // ------------------------------------------------------------------------------------------------
-enum StepKind { STEP_MEMCPY, STEP_GEMM, STEP_TRSM, STEP_POTRF, STEP_GATHER_S, STEP_GATHER_SCALAR, STEP_SUB, STEP_MEMSET_INFO, STEP_ZERO_UPPER, STEP_FUSED_ASSEMBLE, STEP_SMALL_POTRF, STEP_CLUSTER_FACTOR, STEP_GEMV_T, STEP_CSOLVE_FWD, STEP_Q_SOLVE, STEP_CSOLVE_BWD, STEP_SUM_SLABS, STEP_ASSEMBLE_W1, STEP_GRAM_SMALL, STEP_ASSEMBLE_W2, STEP_SOLVE_SMALL, STEP_DENSE_BLOCK, STEP_ASSEMBLE_W3, STEP_FACTOR_SMALL, STEP_SUM_S_SLABS, STEP_TRTRI32, STEP_DENSE_T32, STEP_TRTRI_DIAG, STEP_COPY2D, STEP_CHOL_LEVEL, STEP_NKINDS };
+enum StepKind { STEP_MEMCPY, STEP_GEMM, STEP_TRSM, STEP_POTRF, STEP_GATHER_S, STEP_GATHER_SCALAR, STEP_SUB, STEP_MEMSET_INFO, STEP_ZERO_UPPER, STEP_FUSED_ASSEMBLE, STEP_SMALL_POTRF, STEP_CLUSTER_FACTOR, STEP_GEMV_T, STEP_CSOLVE_FWD, STEP_Q_SOLVE, STEP_CSOLVE_BWD, STEP_SUM_SLABS, STEP_ASSEMBLE_W1, STEP_GRAM_SMALL, STEP_ASSEMBLE_W2, STEP_SOLVE_SMALL, STEP_DENSE_BLOCK, STEP_ASSEMBLE_W3, STEP_FACTOR_SMALL, STEP_SUM_S_SLABS, STEP_TRTRI32, STEP_DENSE_T32, STEP_TRTRI_DIAG, STEP_COPY2D, STEP_CHOL_LEVEL, STEP_CHOL_PACK, STEP_CHOL_UNPACK, STEP_NKINDS };
 static const char *const STEP_NAMES[STEP_NKINDS] = {"hipMemcpyAsync(D2D)", "k_gemm_f64_t", "k_trsm_diag", "k_potrf_diag", "k_schur_gather",
                                                     "k_gather_scalar", "k_sub", "hipMemsetAsync", "k_zero_upper", "k_cluster_assemble", "k_small_potrf", "k_cluster_factor", "k_gemv_t",
-                                                    "k_cluster_solve_fwd", "k_q_solve", "k_cluster_solve_bwd", "k_sum_slabs", "k_cluster_assemble_w1", "k_gram_small", "k_cluster_assemble_w2", "k_solve_small", "k_dense_block", "k_cluster_assemble_w3", "k_factor_small", "k_sum_S_slabs", "k_trtri32", "k_dense_T32", "k_trtri_diag", "k_copy2d", "k_chol_level"};
+                                                    "k_cluster_solve_fwd", "k_q_solve", "k_cluster_solve_bwd", "k_sum_slabs", "k_cluster_assemble_w1", "k_gram_small", "k_cluster_assemble_w2", "k_solve_small", "k_dense_block", "k_cluster_assemble_w3", "k_factor_small", "k_sum_S_slabs", "k_trtri32", "k_dense_T32", "k_trtri_diag", "k_copy2d", "k_chol_level", "k_chol_pack", "k_chol_unpack"};
 static const int KT_MAX_EVENTS = 8192;   // event pairs kept between two clrs_get_kernel_times calls
 
 struct Step {
@@ -109,6 +110,7 @@ struct TrsmJob {
 struct PotrfJob {
     double *A;
     int lda, n, code;
+    int stop = 0;     // > 0: factor the first `stop` block columns only (the trailing updates still reach the rest: a Schur complement)
 };
 
 struct BlockInfo {
@@ -157,6 +159,7 @@ struct clrs_ctx {
     std::vector<void *> allocs;  // every hipMalloc, for destroy
     // device buffers
     std::vector<CholLevelJob> chol_jobs;           // jobs of the single-matrix k_chol_level launches (passed by value)
+    std::vector<CholAugDesc> chol_aug;             // augmented factorisations [S; B^T] (k_chol_pack / k_chol_unpack, passed by value)
     double *d_Xc = nullptr, *d_Y = nullptr;        // inputs (xy layout)
     double *d_static = nullptr, *d_work = nullptr; // [Vexp | Astack] and [Z | W] (identical layouts: one memcpy)
     i64 solve_arena_len = 0;
@@ -453,30 +456,34 @@ static int plan_trsm_chain(clrs_ctx *c, Plan &pl, const std::vector<TrsmJob> &jo
 static int plan_potrf_levels(clrs_ctx *c, Plan &pl, const std::vector<PotrfJob> &jobs, int *info) {
     int rc, maxp = 0;
     std::vector<double *> dbuf(jobs.size());
+    auto stop_of = [](const PotrfJob &j) { const int np = (j.n + 63) / 64; return j.stop > 0 ? std::min(j.stop, np) : np; };
     for (size_t q = 0; q < jobs.size(); q++) {
         const int np = (jobs[q].n + 63) / 64;
         maxp = std::max(maxp, np);
         if ((rc = dmalloc(c, &dbuf[q], (i64)np * 4096))) return rc;
     }
     HIPCHECK(hipFuncSetAttribute((const void *)k_chol_level, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol_level_lds_bytes()));
+    // launch lvl: block column lvl final; column workgroups for block column lvl + 1 (while it is to be factored), trailing tiles beyond
     for (int lvl = -1; lvl <= maxp - 2; lvl++) {
         std::vector<CholLevelJob> cj;
         std::vector<CholLevelWork> col, bulk;
         for (size_t q = 0; q < jobs.size(); q++) {
             const PotrfJob &j = jobs[q];
-            const int np = (j.n + 63) / 64, cb = lvl + 1;
-            if (cb >= np) continue;
-            const int id = (int)cj.size();
-            cj.push_back(CholLevelJob{j.A, dbuf[q], j.lda, j.n, lvl, j.code});
-            for (int i = cb; i < np; i++) col.push_back(CholLevelWork{id, 0, i, 0});
-            const int rb = (lvl + 2) * 64;
+            const int np = (j.n + 63) / 64, cb = lvl + 1, stop = stop_of(j);
+            if (cb >= np || cb > stop) continue;
+            const bool closing = cb == stop;                       // nothing left to factor: the trailing update of block column lvl alone
+            const int id = (int)cj.size(), bulk0 = closing ? cb : cb + 1;
+            cj.push_back(CholLevelJob{j.A, dbuf[q], j.lda, j.n, lvl, j.code, bulk0, 0});
+            if (!closing)
+                for (int i = cb; i < np; i++) col.push_back(CholLevelWork{id, 0, i, 0});
+            const int rb = bulk0 * 64;
             if (lvl >= 0 && rb < j.n) {
                 const int nt = (j.n - rb + 127) / 128;
                 for (int tj = 0; tj < nt; tj++)
                     for (int ti = tj; ti < nt; ti++) bulk.push_back(CholLevelWork{id, 1, ti, tj});
             }
         }
-        if (col.empty()) continue;
+        if (col.empty() && bulk.empty()) continue;
         const int ncol = (int)col.size();
         col.insert(col.end(), bulk.begin(), bulk.end());       // the column workgroups (the critical path) are dispatched first
         Step s;
@@ -495,7 +502,8 @@ static int plan_potrf_levels(clrs_ctx *c, Plan &pl, const std::vector<PotrfJob> 
     std::vector<Copy2dDesc> cp;
     for (size_t q = 0; q < jobs.size(); q++) {
         const PotrfJob &j = jobs[q];
-        for (int r0 = 0, b = 0; r0 < j.n; r0 += 64, b++) {
+        const int stop = stop_of(j);
+        for (int r0 = 0, b = 0; r0 < j.n && b < stop; r0 += 64, b++) {
             const int m = std::min(64, j.n - r0);
             cp.push_back(Copy2dDesc{dbuf[q] + (i64)b * 4096, j.A + r0 + (i64)r0 * j.lda, 64, j.lda, m, m});
         }
@@ -643,6 +651,12 @@ static int run_steps(clrs_ctx *c, const Plan &pl) {
                 } else
                     hipLaunchKernelGGL(k_chol_level, dim3(s.grid), dim3(CL_NT), chol_level_lds_bytes(), st, CholLevelJob{}, 0, (const CholLevelJob *)s.d0,
                                        (const CholLevelWork *)s.d1, (int *)s.dst);
+                break;
+            case STEP_CHOL_PACK:
+                hipLaunchKernelGGL(k_chol_pack, dim3(s.grid), dim3(256), 0, st, c->chol_aug[(size_t)s.n]);
+                break;
+            case STEP_CHOL_UNPACK:
+                hipLaunchKernelGGL(k_chol_unpack, dim3(s.grid), dim3(256), 0, st, c->chol_aug[(size_t)s.n]);
                 break;
             case STEP_COPY2D:
                 hipLaunchKernelGGL(k_copy2d, dim3(s.aux0, s.grid), dim3(256), 0, st, (const Copy2dDesc *)s.d0);
@@ -1613,6 +1627,7 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
         c->fused_x = g_cfg_fused_factor && NB > 0 && maxn <= 128;
         CK(dmalloc(c, &c->d_dinvS, c->xlen)); CK(dmalloc(c, &c->d_dinvQ, N));
     }
+    bool q_from_factor = false;
     {
         if (c->fused_fs) {
             std::vector<CFactor> cf(J);
@@ -1639,6 +1654,29 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
             s.kind = STEP_CLUSTER_FACTOR; s.grid = J; s.d0 = dcf; s.dst = c->d_info; s.bytes = lds;
             c->p_cholS.steps.push_back(s);      // Cholesky of S_j and L_j^-1 B_j in one launch: the LinvB timing slot stays 0
             if (lds > 64 * 1024) HIPCK(hipFuncSetAttribute((const void *)k_cluster_factor, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        } else if (g_cfg_factor_aug && g_cfg_potrf_levels && J == 1 && N > 0 && N <= 64 && c->P[0] > POTRF_NB) {
+            // one large cluster, a few free variables: L, L^-1 B and Q from ONE blocked factorisation of [S .; B^T 0] (k_chol_pack)
+            const int P = c->P[0], P64 = (P + 63) & ~63, na = P64 + N;
+            CholAugDesc ad;
+            std::memset(&ad, 0, sizeof(ad));
+            CK(dmalloc(c, &ad.Aug, (i64)na * na));
+            ad.S = c->d_S + c->Soff[0]; ad.B = c->d_B + c->coff[0]; ad.LB = c->d_LB + c->coff[0]; ad.Q = c->d_Q;
+            ad.P = P; ad.P64 = P64; ad.N = N; ad.ldb = (int)c->xlen;
+            c->chol_aug.push_back(ad);
+            Step ms; ms.kind = STEP_MEMSET_INFO;
+            c->p_cholS.steps.push_back(ms);
+            Step ps;
+            ps.kind = STEP_CHOL_PACK; ps.n = (i64)c->chol_aug.size() - 1; ps.grid = (int)std::min<i64>(((i64)na * na + 255) / 256, 8192);
+            c->p_cholS.steps.push_back(ps);
+            std::vector<PotrfJob> pj;
+            PotrfJob job{ad.Aug, na, na, 1};
+            job.stop = P64 / 64;
+            pj.push_back(job);
+            CK(plan_potrf(c, c->p_cholS, pj));
+            Step us = ps;
+            us.kind = STEP_CHOL_UNPACK; us.grid = (int)std::min<i64>(((i64)P * P + (i64)P * N + (i64)N * N + 255) / 256, 8192);
+            c->p_cholS.steps.push_back(us);
+            q_from_factor = true;
         } else {
             std::vector<PotrfJob> pj;
             std::vector<TrsmJob> tj;
@@ -1655,7 +1693,9 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
             }
         }
         if (N > 0) {
-            if (c->q_slabs) {
+            if (q_from_factor) {
+                // Q came out of the factorisation of S (k_chol_unpack)
+            } else if (c->q_slabs) {
                 Step s;
                 s.kind = STEP_SUM_SLABS;
                 c->p_Q.steps.push_back(s);
@@ -2338,6 +2378,7 @@ extern "C" int clrs_config_set(const char *key, int value) {
     if (!std::strcmp(key, "wave3_assemble")) { g_cfg_wave3_assemble = value; return 0; }
     if (!std::strcmp(key, "dense_block")) { g_cfg_dense_block = value; return 0; }
     if (!std::strcmp(key, "dense_wave")) { g_cfg_dense_wave = value; return 0; }
+    if (!std::strcmp(key, "factor_aug")) { g_cfg_factor_aug = value; return 0; }
     if (!std::strcmp(key, "pairing_tri")) { g_cfg_pairing_tri = value; return 0; }
     if (!std::strcmp(key, "potrf_levels")) { g_cfg_potrf_levels = value; return 0; }
     if (!std::strcmp(key, "trsm_blockinv")) { g_cfg_trsm_blockinv = value; return 0; }

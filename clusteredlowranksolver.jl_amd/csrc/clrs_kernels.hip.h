@@ -660,6 +660,8 @@ __global__ void k_sub(double *__restrict__ y, const double *__restrict__ a, cons
 struct CholLevelJob {
     double *A, *D;               // matrix (lower triangle), side buffer of np diagonal factors (64 x 64 each, ld 64)
     int lda, n, k, code;
+    int bulk0, pad;              // first block row / column of the 128 x 128 trailing tiles: k + 2, or k + 1 in the closing launch of a
+                                 // factorisation that stops early (no column workgroups left to take block column k + 1)
 };
 struct CholLevelWork { int job, kind, ti, tj; };
 constexpr int CL_LD = 136, CL_TS = CL_LD * 64;       // one 128 x 64 panel in LDS
@@ -722,7 +724,7 @@ __global__ __launch_bounds__(CL_NT) void k_chol_level(const CholLevelJob J0, con
     if (jobs) w = work[blockIdx.x];
     else if ((int)blockIdx.x < ncol) w = CholLevelWork{0, 0, J0.k + 1 + (int)blockIdx.x, 0};
     else {
-        const int nt = (J0.n - (J0.k + 2) * 64 + 127) / 128;
+        const int nt = (J0.n - J0.bulk0 * 64 + 127) / 128;
         int t = (int)blockIdx.x - ncol, tj = 0;
         while (t >= nt - tj) { t -= nt - tj; tj++; }
         w = CholLevelWork{0, 1, tj + t, tj};
@@ -735,7 +737,7 @@ __global__ __launch_bounds__(CL_NT) void k_chol_level(const CholLevelJob J0, con
     const gptr<double> GD = as_global(J.D);
     const int rk = J.k * 64, wi = wave % CL_WR, wj = wave / CL_WR;      // wave (wi, wj): rows CL_RPW wi .., one of four column groups
     if (w.kind == 1) {
-        const int rb = (J.k + 2) * 64, r0 = rb + 128 * w.ti, c0 = rb + 128 * w.tj;
+        const int rb = J.bulk0 * 64, r0 = rb + 128 * w.ti, c0 = rb + 128 * w.tj;
         cl_load(P0, (gptr<const double>)GA + r0 + rk * lda, lda, min(128, J.n - r0), 64, tid);
         if (w.ti != w.tj) cl_load(P1, (gptr<const double>)GA + c0 + rk * lda, lda, min(128, J.n - c0), 64, tid);
         __syncthreads();
@@ -836,6 +838,54 @@ __global__ __launch_bounds__(CL_NT) void k_chol_level(const CholLevelJob J0, con
         if (i < mi && j < mc) GA[(ri + i) + (rc + j) * lda] = P0[64 + i + j * CL_LD];
     }
     CL_STAMP(4);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Factorisation stage of ONE large cluster with a few free variables as ONE blocked factorisation (src/solver.jl:1245-1269): with B^T
+// appended to S as one more block row,
+//        [ S    .  ]   [ L        .  ] [ L^T  L^-1 B ]
+//        [ B^T  0  ] = [ B^T L^-T  I ] [ .    -Q     ],      Q = (L^-1 B)^T (L^-1 B),
+// the column workgroups of k_chol_level return B^T L^-T = (L^-1 B)^T as that row's panels and its trailing tiles leave -Q in the
+// corner: L^-1 B (a chain of its own of 18 launches through inverted diagonal blocks) and the Gram product cost nothing.  The
+// factorisation stops before the corner (PotrfJob::stop).  k_chol_pack lays the augmented matrix out (rows P .. P64 - 1 pad S to a
+// multiple of the block size with an identity), k_chol_unpack hands L, L^-1 B and Q back in the layouts of the rest of the library.
+// ------------------------------------------------------------------------------------------------
+struct CholAugDesc {
+    double *S, *LB, *Q, *Aug;     // S: P x P (ld P), in: S_j, out: L_j;  LB: P x N (ld ldb);  Q: N x N;  Aug: (P64 + N)^2 (ld P64 + N)
+    const double *B;              // P x N (ld ldb)
+    int P, P64, N, ldb;
+};
+__global__ __launch_bounds__(256) void k_chol_pack(const CholAugDesc d) {
+    const gptr<const double> S = as_global((const double *)d.S), B = as_global(d.B);
+    const gptr<double> A = as_global(d.Aug);
+    const long long na = d.P64 + d.N, total = na * na;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int i = (int)(e % na), j = (int)(e / na);
+        if (i < j) continue;
+        double v = 0.0;
+        if (j < d.P) v = i < d.P ? S[i + (long long)j * d.P] : (i >= d.P64 ? B[j + (long long)(i - d.P64) * d.ldb] : 0.0);
+        else if (j < d.P64) v = i == j ? 1.0 : 0.0;
+        A[e] = v;
+    }
+}
+__global__ __launch_bounds__(256) void k_chol_unpack(const CholAugDesc d) {
+    const gptr<const double> A = as_global((const double *)d.Aug);
+    const gptr<double> S = as_global(d.S), LB = as_global(d.LB), Q = as_global(d.Q);
+    const long long na = d.P64 + d.N, PP = (long long)d.P * d.P, total = PP + (long long)d.P * d.N + (long long)d.N * d.N;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        if (e < PP) {
+            const int i = (int)(e % d.P), j = (int)(e / d.P);
+            S[e] = i >= j ? A[i + j * na] : 0.0;
+        } else if (e < PP + (long long)d.P * d.N) {
+            const long long f = e - PP;
+            const int c = (int)(f % d.P), r = (int)(f / d.P);
+            LB[c + (long long)r * d.ldb] = A[(d.P64 + r) + c * na];
+        } else {
+            const long long f = e - PP - (long long)d.P * d.N;
+            const int a = (int)(f % d.N), b = (int)(f / d.N), hi = max(a, b), lo = min(a, b);
+            Q[f] = -A[(d.P64 + hi) + (d.P64 + lo) * na];
+        }
+    }
 }
 
 // zero the strict upper triangles of the matrices listed in descs (output formatting of L, tools.jl:100-105)

@@ -27,7 +27,7 @@ int main(int argc, char **argv) {
     hipEventCreate(&e0); hipEventCreate(&e1);
     for (int lvl = -1; lvl <= np - 2; lvl++) {
         std::vector<CholLevelWork> w;
-        CholLevelJob J{dA, dD, n, n, lvl, 1};
+        CholLevelJob J{dA, dD, n, n, lvl, 1, lvl + 2, 0};
         for (int i = lvl + 1; i < np; i++) w.push_back(CholLevelWork{0, 0, i, 0});
         const int ncol = (int)w.size(), rb = (lvl + 2) * 64;
         if (lvl >= 0 && rb < n) {
