@@ -955,3 +955,46 @@ def test_dense_blocks_below_32_with_a_ragged_matrix_count(oracle_built):
     ctx.close()
     assert np.max(np.abs(S - S_ref)) <= 1e-12 * np.max(np.abs(S_ref))
 
+
+@pytest.mark.parametrize("P,N", [(129, 1), (150, 20), (200, 64), (321, 33)])
+def test_one_large_cluster_factor_with_free_variables_in_one_factorisation(P, N, oracle_built):
+    """One cluster beyond one 64-wide block with 1 .. 64 free variables: L, L^-1 B and Q come out of ONE blocked factorisation of
+    [S .; B^T 0] that stops before the corner ("factor_aug": k_chol_pack, k_chol_level, k_chol_unpack), here with ragged last blocks and
+    32 < N <= 64 (the corner's upper half is mirrored from the lower).  Against the oracle, and against the three-stage plan."""
+    import clrs_amd
+    from clrs_amd import _lib
+    from clrs_amd.solver import SchurContext, compute_T_decomposition, solve_system
+    from oracle.oracle import Oracle
+    from tests.util import random_simple_sdp
+    lr = (P + 119) // 120                       # sides 16: 136 independent pairings per block
+    f = clrs_amd.flatten(random_simple_sdp(3000 + P + N, J=1, n_free=N, fixed_P=P, max_n=16, lr_blocks=lr))
+    X, Y = spd_iterates(f, seed=P + 3 * N)
+    Xc = chol_blocks_np(f, X)
+    o = Oracle(f, quad=False)
+    o.schur_assemble(Xc, Y)
+    assert o.schur_factor() == 0
+    L_ref, LinvB_ref, LQ_ref = o.get_factor()
+    rng = np.random.default_rng(P * 7 + N)
+    rx, ry = rng.standard_normal(f.x_len), rng.standard_normal(f.n_free)
+    dx_ref, dy_ref = o.schur_solve(rx, ry)
+    got = {}
+    for aug in (1, 0):
+        assert _lib.load().clrs_config_set(b"factor_aug", aug) == 0
+        try:
+            ctx = SchurContext(f, fused=False)
+            ctx.set_graph_mode(False)
+            ctx.set_kernel_timing(-1)
+            compute_T_decomposition(ctx, Xc, Y, want_S=False)
+            assert ("k_chol_pack" in ctx.kernel_times()) == (aug == 1)
+            got[aug] = ctx.get_factor() + solve_system(ctx, rx, ry)
+            ctx.close()
+        finally:
+            _lib.load().clrs_config_set(b"factor_aug", 1)
+    for aug in (1, 0):
+        L, LinvB, LQ, dx, dy = got[aug]
+        assert np.max(np.abs(L - L_ref)) <= 1e-9 * np.max(np.abs(L_ref))
+        assert np.max(np.abs(LinvB - LinvB_ref)) <= 1e-9 * max(1.0, np.max(np.abs(LinvB_ref)))
+        assert np.max(np.abs(LQ - LQ_ref)) <= 1e-9 * max(1.0, np.max(np.abs(LQ_ref)))
+        assert np.max(np.abs(dx - dx_ref)) <= 1e-7 * max(1.0, np.max(np.abs(dx_ref)))
+        assert np.max(np.abs(dy - dy_ref)) <= 1e-7 * max(1.0, np.max(np.abs(dy_ref)))
+
