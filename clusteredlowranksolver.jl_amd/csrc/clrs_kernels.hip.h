@@ -5,9 +5,13 @@
 // processes the same step of every PSD block / cluster ("grouped" kernels).
 //
 // Kernel            replaces (reference, src/...)                         bound
-// k_gemm_f64_t<BM,BN> matmul_threaded! tools.jl:175-266 (all GEMMs)       MFMA fp64
-// k_trsm_diag       Arblib.approx_solve_tril!/triu! solver.jl:1258,1538   latency / LDS
-// k_potrf_diag      approx_cholesky! tools.jl:75-107                      latency / LDS
+// k_gemm_f64_t<BM,BN,TA,TB> matmul_threaded! tools.jl:175-266 (all GEMMs)  MFMA fp64
+// k_trsm_diag       Arblib.approx_solve_tril!/triu! solver.jl:1258,1538   latency / LDS   (triangles within one 64-wide block)
+// k_trtri_diag      the same for n > 512: inverses of the 64 x 64 leaves, joined and applied by GEMMs (plan_trsm_blockinv)
+// k_potrf_diag      approx_cholesky! tools.jl:75-107                      latency / LDS   (matrices within one 64-wide block)
+// k_chol_level      the same beyond one block: ONE launch per block column (column workgroups + 128 x 128 trailing tiles)
+// k_chol_pack / k_chol_unpack   solver.jl:1245-1269 as one factorisation of [S .; B^T 0]: L, L^-1 B and Q together
+// k_trtri32 / k_dense_T32       X^-1 A Y of the dense branch, solver.jl:1089-1097, one wave per matrix    MFMA fp64 / HBM
 // k_schur_gather    S accumulation loops solver.jl:1176-1212 + symmetric! HBM / L2 gather
 // k_gather_scalar   A_Y extraction solver.jl:1152-1170                    HBM
 #pragma once
