@@ -119,6 +119,7 @@ struct BlockInfo {
     std::vector<int> UR, UL, offR, offL;
     int URt = 0, ULt = 0;
     bool sym = false;
+    bool sd_tri = false;      // dense block: only the lower tiles of the symmetric Sd = <A_i, X^-1 A_k Y> are formed (staged Gram GEMM)
     // offsets (in doubles) inside the work / static arenas
     i64 zr_off = -1, zl_off = -1, ty_off = -1, g_off = -1;  // ZR/ZL in the "solve" arena; TY; GX,GY
     int cnt = 0;
@@ -1381,7 +1382,8 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
                     const int bi = (int)dtb.size();
                     dtb.push_back(DenseTBlock{Lx, Yb, Ast, nullptr, TT, n, k.cnt});
                     for (int e0 = 0; e0 < k.cnt; e0 += DT32_WAVES * DT32_ITER) dtp.push_back(DenseTPair{bi, e0});
-                    g2.push_back(mk_gemm(1, 0, k.cnt, k.cnt, n * n, 1.0, Ast, n * n, TT, n * n, 0.0, Sd, k.cnt));           // <A_i, T_k>   (:1102)
+                    k.sd_tri = g_cfg_pairing_tri != 0;      // <A_i, X^-1 A_k Y> = tr(A_i X^-1 A_k Y) is symmetric in (i, k): lower tiles, mirrored reads
+                    g2.push_back(mk_gemm(1, 0, k.cnt, k.cnt, n * n, 1.0, Ast, n * n, TT, n * n, 0.0, Sd, k.cnt, 1, 0, 0, 0, k.sd_tri ? 1 : 0));           // <A_i, T_k>   (:1102)
                     continue;
                 }
                 need_work_arena = true;
@@ -1390,7 +1392,8 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
                 fwd.push_back(TrsmJob{Lx, n, n, W, n, n * k.cnt});      // X^-1 A_p for all p  (src/solver.jl:1095)
                 bwd.push_back(TrsmJob{Lx, n, n, W, n, n * k.cnt});
                 g1.push_back(mk_gemm(0, 0, n, n, n, 1.0, W, n, Yb, n, 0.0, TT, n, k.cnt, (i64)n * n, 0, (i64)n * n));  // (X^-1 A_p) Y  (:1097)
-                g2.push_back(mk_gemm(1, 0, k.cnt, k.cnt, n * n, 1.0, Ast, n * n, TT, n * n, 0.0, Sd, k.cnt));           // <A_i, T_k>   (:1102)
+                k.sd_tri = g_cfg_pairing_tri != 0;
+                g2.push_back(mk_gemm(1, 0, k.cnt, k.cnt, n * n, 1.0, Ast, n * n, TT, n * n, 0.0, Sd, k.cnt, 1, 0, 0, 0, k.sd_tri ? 1 : 0));           // <A_i, T_k>   (:1102)
             }
         }
         if (need_copy && !need_work_arena) pl.steps.erase(pl.steps.begin() + copy_step_index);   // nothing left that overwrites it
@@ -1443,7 +1446,7 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
                     sd.tptr = k.d_tptr; sd.tL = d_tL; sd.tR = d_tR; sd.tlam = d_tlam;
                 } else {
                     if (k.cnt == 0) continue;
-                    sd.cnt = k.cnt; sd.Sd = c->d_Sd + k.sd_off;
+                    sd.cnt = k.cnt; sd.Sd = c->d_Sd + k.sd_off; sd.tri = k.sd_tri ? 1 : 0;
                     std::vector<int> inv(c->P[j], -1);
                     for (i64 e = k.d0; e < k.d1; e++) inv[d->dense_p[e]] = (int)(e - k.d0);
                     int *dinv;

@@ -566,7 +566,7 @@ __global__ __launch_bounds__(256) void k_potrf_diag(const PotrfDesc *__restrict_
 // One thread per (p,q); each S entry is written exactly once (deterministic, no atomics).
 // ------------------------------------------------------------------------------------------------
 struct SBlockDesc {
-    int kind, ldg, cnt, tri;   // tri: GX and GY are symmetric and only their lower triangles were computed (W = V, one sub-block)
+    int kind, ldg, cnt, tri;   // tri: GX and GY (low rank: W = V, one sub-block) / Sd (dense) are symmetric and only their lower tiles were formed
     const double *GX, *GY;     // low rank: UL x UR pairing matrices
     const int *tptr;           // [P+1] CSR of this block's terms over the cluster's constraint index
     const int *tL, *tR;        // per term: global left / right unique-vector index
@@ -606,7 +606,7 @@ __global__ __launch_bounds__(256 * SG_W) void k_schur_gather(const SClusterDesc 
             }
         } else {
             const int i = d.inv[p], k = d.inv[q];
-            if (i >= 0 && k >= 0) acc += d.Sd[k + (long long)i * d.cnt];
+            if (i >= 0 && k >= 0) acc += d.tri && k < i ? d.Sd[i + (long long)k * d.cnt] : d.Sd[k + (long long)i * d.cnt];
         }
     }
 #pragma unroll

@@ -246,7 +246,8 @@ int clrs_wave2_clusters(const clrs_ctx *ctx);
  * blocked factorisation that stops before the corner: L^-1 B comes out as the panels of the appended block row, -Q as its Schur
  * complement (k_chol_pack, k_chol_level, k_chol_unpack); 0 = Cholesky of S, the substitution for L^-1 B and the Gram product apart.
  * "pairing_tri" (default 1): staged low-rank blocks whose left and right vectors coincide (W = V, one sub-block) compute only the
- * lower tiles of the symmetric pairing matrices V^T X^-1 V and V^T Y V; k_schur_gather mirrors its reads; 0 = full matrices.
+ * lower tiles of the symmetric pairing matrices V^T X^-1 V and V^T Y V, and staged dense blocks only the lower tiles of
+ * <A_i, X^-1 A_k Y>; k_schur_gather mirrors its reads; 0 = full matrices.
  * "potrf_levels" (default 1): the staged Cholesky of a matrix beyond one 64-wide block runs ONE launch per block column
  * (k_chol_level); 0 = k_potrf_diag + k_trsm_diag + k_gemm_f64_t per block column.
  * "trsm_blockinv" (default 1): staged triangular solves with n > 512 go through inverted 512 x 512 diagonal blocks (k_trtri_diag
