@@ -435,9 +435,12 @@ def test_cholesky_blocks(fused, oracle_built):
     ctx.close()
 
 
-def test_graph_mode_matches_eager():
+@pytest.mark.parametrize("name", ["ns_8_3_2", "polyopt_scaled_300"])
+def test_graph_mode_matches_eager(name):
+    """polyopt_scaled_300: the staged plans (one launch per block column of the factorisations, the factor stage as one factorisation,
+    substitutions through inverted diagonal blocks) replayed as hipGraphs."""
     from clrs_amd.solver import SchurContext
-    f = flat("ns_8_3_2")
+    f = flat(name)
     X, Y = spd_iterates(f, seed=5)
     Xc = chol_blocks_np(f, X)
     a = SchurContext(f)
