@@ -788,6 +788,7 @@ static int run_steps(clrs_ctx *c, const Plan &pl) {
 static int run_plan(clrs_ctx *c, Plan &pl) {
     if (pl.steps.empty()) return 0;
     if (!c->graph_mode) return run_steps(c, pl);
+    if (!c->stream) return fail(CLRS_ERR_STATE, "graph mode cannot capture the default (null) stream: pass a stream of its own to clrs_set_stream");
     const void *now[8] = {c->bind_X, c->bind_Xchol, c->bind_rhsx, c->bind_rhsy, c->bind_dx, c->bind_dy, c->ftables.Xc, c->ftables.Y};
     if (pl.graph && std::memcmp(now, pl.captured, sizeof(now)) != 0) {   // the graph bakes the caller's pointers: re-capture
         hipGraphExecDestroy(pl.graph);

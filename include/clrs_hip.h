@@ -255,7 +255,8 @@ int clrs_wave2_clusters(const clrs_ctx *ctx);
 /* Diagnostic builds (-DCLRS_FUSED_STAMPS) only: s_memtime stamps of the phases of workgroup 0 of the fused kernel. */
 int clrs_debug_stamps(clrs_ctx *ctx, uint64_t out[64]);
 
-/* Capture the per-iteration launch sequences into hipGraphs (1) or launch kernels one by one (0). */
+/* Capture the per-iteration launch sequences into hipGraphs (1) or launch kernels one by one (0).  The default (null) stream cannot
+ * be captured: with a caller's stream (clrs_set_stream) graph mode needs a stream of its own; calls fail with CLRS_ERR_STATE otherwise. */
 int clrs_set_graph_mode(clrs_ctx *ctx, int enabled);
 
 /* Name of the kernel that dominates the assembly for this context and the number of launches of one

@@ -47,3 +47,14 @@ for name, fn in (("cholX", lambda: ctx.cholesky_blocks_dev(tX.data_ptr(), tXc.da
     for _ in range(3): fn()
     torch.cuda.synchronize()
     print("  phase %-18s %.2f ms" % (name, 1e3 * (time.perf_counter() - t0) / 3))
+if "--graph" in sys.argv:       # the same step with every library call replayed as one hipGraph (on a stream of its own: the null stream cannot be captured)
+    gs = torch.cuda.Stream()
+    ctx.set_stream(gs.cuda_stream)
+    ctx.set_graph_mode(True)
+    for _ in range(2): step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5): step()
+    torch.cuda.synchronize()
+    print("  hipGraph replay: %.2f ms per (cholX + assemble + factor)" % (1e3 * (time.perf_counter() - t0) / 5))
+
