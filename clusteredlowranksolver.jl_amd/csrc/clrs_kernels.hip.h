@@ -591,7 +591,29 @@ __global__ __launch_bounds__(256 * SG_W) void k_schur_gather(const SClusterDesc 
     const int p = t.ti * 16 + (ent & 15), q = t.tj * 16 + (ent >> 4);
     if (p >= c.P || q >= c.P || p > q) return;             // uniform over the SG_W lanes of an entry
     double acc = 0.0;
-    for (int b = c.b0 + sub; b < c.b1; b += SG_W) {
+    // a cluster of dense blocks only (an SDPA-type problem: tens of blocks per entry): four blocks of a lane per pass, the four
+    // descriptors, then the eight index look-ups, then the four values in flight together instead of three dependent loads per block
+    // one block after the other.  Same order of the additions.
+    int b = c.b0 + sub;
+    for (; b + 3 * SG_W < c.b1; b += 4 * SG_W) {
+        SBlockDesc d4[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) d4[u] = bl[b + u * SG_W];
+        if (d4[0].kind == 0 || d4[1].kind == 0 || d4[2].kind == 0 || d4[3].kind == 0) break;          // a low-rank block: one by one below
+        int i4[4], k4[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { i4[u] = d4[u].inv[p]; k4[u] = d4[u].inv[q]; }
+        double v4[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = max(i4[u], 0), k = max(k4[u], 0);
+            v4[u] = d4[u].tri && k < i ? d4[u].Sd[i + (long long)k * d4[u].cnt] : d4[u].Sd[k + (long long)i * d4[u].cnt];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (i4[u] >= 0 && k4[u] >= 0) acc += v4[u];
+    }
+    for (; b < c.b1; b += SG_W) {
         const SBlockDesc d = bl[b];
         if (d.kind == 0) {
             const int a0 = d.tptr[p], a1 = d.tptr[p + 1], b0 = d.tptr[q], b1 = d.tptr[q + 1];
