@@ -87,6 +87,7 @@ struct Step {
     i64 n = 0;
     int nmax = 0;
     int aux0 = 0, aux1 = 0;   // kind-specific (STEP_ASSEMBLE_W3: grid size, number of blocks)
+    bool s_inverse = false;   // forms the inverted diagonal blocks of the factors L_j of S: skipped while those of the current factorisation exist
 };
 
 struct Plan {
@@ -160,6 +161,8 @@ struct clrs_ctx {
     std::vector<void *> allocs;  // every hipMalloc, for destroy
     // device buffers
     std::vector<CholLevelJob> chol_jobs;           // jobs of the single-matrix k_chol_level launches (passed by value)
+    std::map<const double *, std::pair<double *, double *>> s_inv;   // factor L_j of S -> its inverted diagonal blocks and their scratch (shared by the solve plans)
+    bool s_inv_valid = false;                      // ... formed since the last factorisation (eager mode skips forming them again)
     std::vector<CholAugDesc> chol_aug;             // augmented factorisations [S; B^T] (k_chol_pack / k_chol_unpack, passed by value)
     double *d_Xc = nullptr, *d_Y = nullptr;        // inputs (xy layout)
     double *d_static = nullptr, *d_work = nullptr; // [Vexp | Astack] and [Z | W] (identical layouts: one memcpy)
@@ -316,7 +319,10 @@ static int add_trsm_stage(clrs_ctx *c, Plan &pl, const std::vector<TrsmDesc> &de
 // n / TRSM_IB levels of two launches instead of n / 64: the level-synchronous chain of plan_trsm_chain is what bounds the staged regime
 // (profiles/r02/g_staged_polyopt2048*), not its flops.  The products with the triangular inverse blocks run as full GEMMs
 // (2 TRSM_IB n nrhs flops on top of the n^2 nrhs of the substitution).
-static int plan_trsm_blockinv(clrs_ctx *c, Plan &pl, const std::vector<TrsmJob> &jobs, int trans) {
+// share: the triangles are the factors of S, solved with several times per factorisation -- their inverse blocks live in the context
+// (one buffer per factor for all the solve plans) and the steps that form them are marked, so that only the first solve after a
+// factorisation runs them.
+static int plan_trsm_blockinv(clrs_ctx *c, Plan &pl, const std::vector<TrsmJob> &jobs, int trans, bool share) {
     constexpr int IB = TRSM_IB;
     int rc, maxob = 0;
     struct Aux { double *inv, *T, *Y; int nob; };
@@ -327,8 +333,13 @@ static int plan_trsm_blockinv(clrs_ctx *c, Plan &pl, const std::vector<TrsmJob> 
         Aux &a = aux[q];
         a.nob = (j.n + IB - 1) / IB;
         maxob = std::max(maxob, a.nob);
-        if ((rc = dmalloc(c, &a.inv, (i64)a.nob * IB * IB))) return rc;      // zeroed: the strict upper triangles stay zero
-        if ((rc = dmalloc(c, &a.T, (i64)j.n * (IB / 2)))) return rc;
+        auto hit = share ? c->s_inv.find(j.L) : c->s_inv.end();
+        if (hit != c->s_inv.end()) { a.inv = hit->second.first; a.T = hit->second.second; }
+        else {
+            if ((rc = dmalloc(c, &a.inv, (i64)a.nob * IB * IB))) return rc;      // zeroed: the strict upper triangles stay zero
+            if ((rc = dmalloc(c, &a.T, (i64)j.n * (IB / 2)))) return rc;
+            if (share) c->s_inv[j.L] = {a.inv, a.T};
+        }
         if ((rc = dmalloc(c, &a.Y, (i64)j.n * j.nrhs))) return rc;
         for (int o = 0; o < a.nob; o++) {
             const int r0 = o * IB, nb = std::min(IB, j.n - r0);
@@ -345,7 +356,7 @@ static int plan_trsm_blockinv(clrs_ctx *c, Plan &pl, const std::vector<TrsmJob> 
         s.kind = STEP_TRTRI_DIAG; s.grid = (int)leaves.size();
         TrtriDesc *dl;
         if ((rc = upload(c, leaves, &dl))) return rc;
-        s.d0 = dl;
+        s.d0 = dl; s.s_inverse = share;
         pl.steps.push_back(s);
         HIPCHECK(hipFuncSetAttribute((const void *)k_trtri_diag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)trtri_diag_lds_bytes()));
     }
@@ -367,8 +378,10 @@ static int plan_trsm_blockinv(clrs_ctx *c, Plan &pl, const std::vector<TrsmJob> 
                 }
             }
         }
+        const size_t first = pl.steps.size();
         if ((rc = add_gemm_stage(c, pl, ga))) return rc;
         if ((rc = add_gemm_stage(c, pl, gb))) return rc;
+        for (size_t i = first; i < pl.steps.size(); i++) pl.steps[i].s_inverse = share;
     }
     for (int step = 0; step < maxob; step++) {
         std::vector<GemmDesc> gy, gu;
@@ -407,7 +420,7 @@ static int plan_trsm_blockinv(clrs_ctx *c, Plan &pl, const std::vector<TrsmJob> 
 // B <- L^-1 B (trans = 0) or L^-T B (trans = 1) for a list of independent problems, blocked by
 // TRSM_NB, level-synchronous over the problems.
 static int plan_trsm_chain(clrs_ctx *c, Plan &pl, const std::vector<TrsmJob> &jobs, int trans);
-static int plan_trsm(clrs_ctx *c, Plan &pl, const std::vector<TrsmJob> &jobs, int trans) {
+static int plan_trsm(clrs_ctx *c, Plan &pl, const std::vector<TrsmJob> &jobs, int trans, bool factors_of_S = false) {
     std::vector<TrsmJob> chain, big;
     for (const TrsmJob &j : jobs) {
         if (j.n <= 0 || j.nrhs <= 0) continue;
@@ -416,7 +429,7 @@ static int plan_trsm(clrs_ctx *c, Plan &pl, const std::vector<TrsmJob> &jobs, in
     }
     int rc;
     if (!chain.empty() && (rc = plan_trsm_chain(c, pl, chain, trans))) return rc;
-    if (!big.empty() && (rc = plan_trsm_blockinv(c, pl, big, trans))) return rc;
+    if (!big.empty() && (rc = plan_trsm_blockinv(c, pl, big, trans, factors_of_S))) return rc;
     return 0;
 }
 static int plan_trsm_chain(clrs_ctx *c, Plan &pl, const std::vector<TrsmJob> &jobs, int trans) {
@@ -578,6 +591,7 @@ static void add_memcpy(Plan &pl, void *dst, const void *src, size_t bytes) {
 static int run_steps(clrs_ctx *c, const Plan &pl) {
     hipStream_t st = c->stream;
     for (const Step &s : pl.steps) {
+        if (s.s_inverse && c->s_inv_valid && !c->graph_mode) continue;       // (a captured graph replays all of its steps)
         const bool timed = !c->graph_mode && (c->kt_kind == -1 || c->kt_kind == (int)s.kind) && (int)c->kt_kinds.size() < KT_MAX_EVENTS;
         if (timed) {
             const size_t need = 2 * (c->kt_kinds.size() + 1);
@@ -1792,7 +1806,7 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
             c->p_fwd.steps.push_back(s);                                                        // t_j = L_j^-1 rhs_x[j]   (:1538)
         } else {
             add_memcpy(c->p_fwd, c->d_t, c->d_rhsx, sizeof(double) * (size_t)c->xlen);
-            CK(plan_trsm(c, c->p_fwd, tj, 0));
+            CK(plan_trsm(c, c->p_fwd, tj, 0, true));
         }
         if (N > 0) {
             if (c->fused_fs) {
@@ -1829,7 +1843,7 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
             s.kind = STEP_CSOLVE_BWD; s.grid = J; s.d0 = dcs; s.bytes = lds_cs;                 // dx_j = L_j^-T (t_j + LB_j dy)  (:1566-1573)
             c->p_bwd.steps.push_back(s);
         } else {
-            CK(plan_trsm(c, c->p_bwd, tj, 1));
+            CK(plan_trsm(c, c->p_bwd, tj, 1, true));
         }
     }
     // a handful of small clusters: the whole solve stage in one workgroup, one launch
@@ -2071,7 +2085,7 @@ extern "C" int clrs_schur_assemble_dev(clrs_ctx *c, const double *d_Xchol, const
     int rc = run_plan(c, c->p_assemble);
     if (rc) return rc;
     if (c->timing) HIPCHECK(hipEventRecord(c->ev[1], c->stream));
-    c->assembled = true; c->factored = false; c->local_factored = false;
+    c->assembled = true; c->factored = false; c->local_factored = false; c->s_inv_valid = false;
     return 0;
 }
 
@@ -2094,6 +2108,7 @@ extern "C" int clrs_schur_factor_local_dev(clrs_ctx *c) {
     HIPCHECK(hipSetDevice(c->device));
     int rc;
     if (c->timing) HIPCHECK(hipEventRecord(c->ev[2], c->stream));
+    c->s_inv_valid = false;
     if ((rc = run_plan(c, c->p_cholS))) return rc;
     if (c->timing) HIPCHECK(hipEventRecord(c->ev[3], c->stream));
     if ((rc = run_plan(c, c->p_linvB))) return rc;
@@ -2146,6 +2161,7 @@ extern "C" int clrs_schur_factor_dev(clrs_ctx *c) {
         if ((rc = run_plan(c, c->p_factor_small))) return rc;
         if (c->timing) { HIPCHECK(hipEventRecord(c->ev[3], c->stream)); HIPCHECK(hipEventRecord(c->ev[4], c->stream)); HIPCHECK(hipEventRecord(c->ev[5], c->stream)); }
     } else {
+    c->s_inv_valid = false;
     if ((rc = run_plan(c, c->p_cholS))) return rc;                    // chol S_j, LinvB_j and the Q slabs: one launch
     if (c->timing) { HIPCHECK(hipEventRecord(c->ev[3], c->stream)); HIPCHECK(hipEventRecord(c->ev[4], c->stream)); HIPCHECK(hipEventRecord(c->ev[5], c->stream)); }
     if ((rc = run_plan(c, c->p_cholQ_slabs))) return rc;              // Q = sum of slabs, chol Q: one launch
@@ -2203,7 +2219,9 @@ extern "C" int clrs_schur_solve_fwd_dev(clrs_ctx *c, const double *d_rhs_x) {
     if (c->fused_fs) c->bind_rhsx = d_rhs_x;
     else if (d_rhs_x != c->d_rhsx) HIPCHECK(hipMemcpyAsync(c->d_rhsx, d_rhs_x, sizeof(double) * c->xlen, hipMemcpyDeviceToDevice, c->stream));
     if (c->timing) HIPCHECK(hipEventRecord(c->ev[7], c->stream));
-    return run_plan(c, c->p_fwd_small.steps.empty() ? c->p_fwd : c->p_fwd_small);
+    const int rc = run_plan(c, c->p_fwd_small.steps.empty() ? c->p_fwd : c->p_fwd_small);
+    if (!rc && !c->s_inv.empty()) c->s_inv_valid = true;
+    return rc;
 }
 
 extern "C" int clrs_schur_solve_bwd_dev(clrs_ctx *c, const double *d_rhs_y, double *d_dx, double *d_dy) {
@@ -2220,6 +2238,7 @@ extern "C" int clrs_schur_solve_bwd_dev(clrs_ctx *c, const double *d_rhs_y, doub
         HIPCHECK(hipMemcpyAsync(c->d_rhsy, d_rhs_y, sizeof(double) * c->N, hipMemcpyDeviceToDevice, c->stream));
     int rc = run_plan(c, c->p_bwd_small.steps.empty() ? c->p_bwd : c->p_bwd_small);
     if (rc) return rc;
+    if (!c->s_inv.empty()) c->s_inv_valid = true;
     if (c->timing) { HIPCHECK(hipEventRecord(c->ev[8], c->stream)); c->solve_time_pending = true; }
     if (!x_direct && d_dx && d_dx != c->d_t) HIPCHECK(hipMemcpyAsync(d_dx, c->d_t, sizeof(double) * c->xlen, hipMemcpyDeviceToDevice, c->stream));
     if (!c->fused_q && d_dy && c->N > 0 && d_dy != c->d_dy) HIPCHECK(hipMemcpyAsync(d_dy, c->d_dy, sizeof(double) * c->N, hipMemcpyDeviceToDevice, c->stream));

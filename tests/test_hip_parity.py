@@ -1001,3 +1001,32 @@ def test_one_large_cluster_factor_with_free_variables_in_one_factorisation(P, N,
         assert np.max(np.abs(dx - dx_ref)) <= 1e-7 * max(1.0, np.max(np.abs(dx_ref)))
         assert np.max(np.abs(dy - dy_ref)) <= 1e-7 * max(1.0, np.max(np.abs(dy_ref)))
 
+
+def test_inverse_blocks_of_S_are_formed_once_per_factorisation(oracle_built):
+    """polyopt_scaled_300 (P = 601 > 512): the staged solves go through the inverted 512 x 512 diagonal blocks of L; the first solve after a
+    factorisation forms them (k_trtri_diag), the second solve and both backward substitutions reuse them, and a new factorisation forms
+    them again.  Every solve against the oracle."""
+    from clrs_amd.solver import SchurContext, compute_T_decomposition, solve_system
+    from oracle.oracle import Oracle
+    f = flat("polyopt_scaled_300")
+    ctx = SchurContext(f, fused=False)
+    ctx.set_graph_mode(False)
+    o = Oracle(f, quad=False)
+    rng = np.random.default_rng(3)
+    for round_ in range(2):
+        X, Y = spd_iterates(f, seed=20 + round_)
+        Xc = chol_blocks_np(f, X)
+        compute_T_decomposition(ctx, Xc, Y)
+        o.schur_assemble(Xc, Y)
+        assert o.schur_factor() == 0
+        ctx.set_kernel_timing(-1)
+        for solve in range(2):
+            rx, ry = rng.standard_normal(f.x_len), rng.standard_normal(f.n_free)
+            dx, dy = solve_system(ctx, rx, ry)
+            dx_ref, dy_ref = o.schur_solve(rx, ry)
+            assert np.max(np.abs(dx - dx_ref)) <= 1e-8 * max(1.0, np.max(np.abs(dx_ref)))
+            assert np.max(np.abs(dy - dy_ref)) <= 1e-8 * max(1.0, np.max(np.abs(dy_ref)))
+            assert ctx.kernel_times()["k_trtri_diag"][2] == 1          # one launch per factorisation, by the first forward substitution
+        ctx.set_kernel_timing(-2)
+    ctx.close()
+
