@@ -602,12 +602,13 @@ __global__ __launch_bounds__(256 * SG_W) void k_schur_gather(const SClusterDesc 
         if (d4[0].kind == 0 || d4[1].kind == 0 || d4[2].kind == 0 || d4[3].kind == 0) break;          // a low-rank block: one by one below
         int i4[4], k4[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) { i4[u] = d4[u].inv[p]; k4[u] = d4[u].inv[q]; }
+        for (int u = 0; u < 4; u++) { i4[u] = as_global(d4[u].inv)[p]; k4[u] = as_global(d4[u].inv)[q]; }
         double v4[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int i = max(i4[u], 0), k = max(k4[u], 0);
-            v4[u] = d4[u].tri && k < i ? d4[u].Sd[i + (long long)k * d4[u].cnt] : d4[u].Sd[k + (long long)i * d4[u].cnt];
+            const gptr<const double> Sd = as_global(d4[u].Sd);
+            v4[u] = d4[u].tri && k < i ? Sd[i + (long long)k * d4[u].cnt] : Sd[k + (long long)i * d4[u].cnt];
         }
 #pragma unroll
         for (int u = 0; u < 4; u++)
@@ -634,8 +635,9 @@ __global__ __launch_bounds__(256 * SG_W) void k_schur_gather(const SClusterDesc 
 #pragma unroll
     for (int off = SG_W / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
     if (sub == 0) {
-        c.S[p + (long long)q * c.P] = acc;
-        c.S[q + (long long)p * c.P] = acc;
+        const gptr<double> S = as_global(c.S);
+        S[p + (long long)q * c.P] = acc;
+        S[q + (long long)p * c.P] = acc;
     }
 }
 
