@@ -224,10 +224,11 @@ constexpr size_t gemm_lds_bytes(int BM, int BN) { return (size_t)2 * GEMM_BK * (
 // Dense ("high rank") branch for blocks with n <= 32 and MANY matrices (SDPA-type problems; src/solver.jl:1089-1097):
 // T_e = X^-1 A_e Y = Linv^T (Linv (A_e Y)) with Linv = chol(X_b)^-1, three 32 x 32 x 32 products per (block, matrix) through
 // v_mfma_f64_16x16x4 by ONE WAVE: A_e, Y, Linv staged in LDS (zero padded to 32 x 32), each result chained into the next product
-// as right operand in its accumulator registers, the last one copied out coalesced.  The staged
+// as right operand in its accumulator registers, the last one stored from them.  The staged
 // form spent two launches of one-thread-per-column substitutions (k_trsm_diag) and a batched GEMM with 32 x 32 tiles on it.
 //   k_trtri32     Linv per block (one wave: lane c owns column c of the inverse), padded to 32 x 32 with leading dimension 32
-//   k_dense_T32   DT32_WAVES consecutive matrices of one block per workgroup; Linv and Y of the block shared in LDS
+//   k_dense_T32   DT32_WAVES consecutive matrices of one block per workgroup; Linv and Y of the block shared in LDS; T_e is written
+//                 transposed (its only reader pairs it with a symmetric A_i)
 // ------------------------------------------------------------------------------------------------
 struct DenseTBlock {
     const double *L, *Y, *A;     // chol(X_b) and Y_b (n x n, column-major), the stack of cnt matrices A_e (n x n each)
@@ -318,14 +319,6 @@ __device__ __forceinline__ void dt32_mm_chain(const double *Li, const v4d (&yin)
             }
         }
 }
-__device__ __forceinline__ void dt32_store(double *B, const v4d (&acc)[2][2], int l15, int l4) {
-#pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-        for (int b = 0; b < 2; b++)
-#pragma unroll
-            for (int reg = 0; reg < 4; reg++) B[(a * 16 + l4 + 4 * reg) + DT32_LD * (b * 16 + l15)] = acc[a][b][reg];
-}
 // FULL: n == 32, the usual case -- no guards on the loads, shifts instead of divisions by n in the copy-out
 template <bool FULL>
 __device__ __forceinline__ void dense_T32_body(const DenseTBlock &b, const DenseTPair &pr, double *dts) {
@@ -381,17 +374,19 @@ __device__ __forceinline__ void dense_T32_body(const DenseTBlock &b, const Dense
         dt32_mm(B0, Ys, q1, l15, l4);                       // A Y
         dt32_mm_chain<false>(Li, q1, q2, l15, l4);          // Linv (A Y)
         dt32_mm_chain<true>(Li, q2, q1, l15, l4);           // Linv^T Linv A Y = X^-1 A Y
-        dt32_store(B0, q1, l15, l4);                        // B0 belongs to this wave alone: LDS operations of one wave keep their order
+        // T_e goes out TRANSPOSED, straight from the accumulators (lane & 15 runs along a row of T: 128-byte pieces): its only reader is
+        // the Gram product <A_i, T_e>, and A_i is symmetric -- <A_i, T_e> = <A_i^T, T_e^T> = <A_i, T_e^T>.  No trip through LDS.
         if (e < b.cnt) {
             const gptr<double> T = gTT + (long long)e * n * n;
-            if (FULL) {
 #pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int o = lane + 64 * r;
-                    T[o] = B0[(o % 32) + DT32_LD * (o / 32)];
-                }
-            } else
-                for (int o = lane; o < n * n; o += 64) T[o] = B0[(o % n) + DT32_LD * (o / n)];
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int bb = 0; bb < 2; bb++)
+#pragma unroll
+                    for (int reg = 0; reg < 4; reg++) {
+                        const int r = a * 16 + l4 + 4 * reg, cc = bb * 16 + l15;
+                        if (FULL || (r < n && cc < n)) T[cc + n * r] = q1[a][bb][reg];
+                    }
         }
     }
 }
