@@ -248,6 +248,8 @@ static int add_gemm_stage(clrs_ctx *c, Plan &pl, const std::vector<GemmDesc> &de
         std::vector<GemmTile> tiles;
         for (const GemmDesc &d : descs) {
             if (d.M <= 0 || d.N <= 0) continue;
+            // the kernel addresses a tile's operands by 32-bit byte offsets from the tile's origin: at most 128 leading dimensions
+            if ((long long)std::max(d.lda, d.ldb) * 128 * 8 >= (1ll << 32)) return fail(CLRS_ERR_INVALID, "leading dimension beyond 4 M doubles in a staged product");
             const bool is_big = gemm_prefers_large_tiles(d);
             if (is_big != (big == 1) || (d.ta != 0) != (vta == 1) || (d.tb != 0) != (vtb == 1)) continue;
             int id = (int)ds.size();
