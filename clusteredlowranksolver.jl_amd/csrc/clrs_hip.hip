@@ -60,7 +60,7 @@ static int g_cfg_dense_block = 1;
 static int g_cfg_trsm_blockinv = 1;  // triangular solves with n > TRSM_IB through inverted diagonal blocks (plan_trsm_blockinv)
 static int g_cfg_potrf_levels = 1;   // Cholesky of matrices beyond one block: one launch per block column (plan_potrf_levels)
 static int g_cfg_pairing_tri = 1;    // staged low-rank blocks with W = V: lower triangles of the pairing matrices only
-static int g_cfg_factor_aug = 1;     // one large cluster with <= 64 free variables: L, L^-1 B and Q from one factorisation of [S .; B^T 0]
+static int g_cfg_factor_aug = 1;     // one large cluster with <= 512 free variables: L, L^-1 B and Q from one factorisation of [S .; B^T 0]
 static int g_cfg_dense_wave = 1;      // dense blocks with n <= 32 beyond k_dense_block: one wave per (block, matrix), k_dense_T32
 static int g_cfg_factor_small = 1;      // factor + Q in one launch of one workgroup for <= 4 small clusters (0: k_cluster_factor + k_small_potrf)
 static int g_cfg_solve_small_max = 32768;     // one-workgroup solve stage only up to this many doubles of operands (beyond: one workgroup per cluster, three launches)
@@ -1674,7 +1674,7 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
             s.kind = STEP_CLUSTER_FACTOR; s.grid = J; s.d0 = dcf; s.dst = c->d_info; s.bytes = lds;
             c->p_cholS.steps.push_back(s);      // Cholesky of S_j and L_j^-1 B_j in one launch: the LinvB timing slot stays 0
             if (lds > 64 * 1024) HIPCK(hipFuncSetAttribute((const void *)k_cluster_factor, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        } else if (g_cfg_factor_aug && g_cfg_potrf_levels && J == 1 && N > 0 && N <= 64 && c->P[0] > POTRF_NB) {
+        } else if (g_cfg_factor_aug && g_cfg_potrf_levels && J == 1 && N > 0 && N <= 512 && c->P[0] > POTRF_NB) {
             // one large cluster, a few free variables: L, L^-1 B and Q from ONE blocked factorisation of [S .; B^T 0] (k_chol_pack)
             const int P = c->P[0], P64 = (P + 63) & ~63, na = P64 + N;
             CholAugDesc ad;

@@ -864,7 +864,7 @@ __global__ __launch_bounds__(CL_NT) void k_chol_level(const CholLevelJob J0, con
 }
 
 // ------------------------------------------------------------------------------------------------
-// Factorisation stage of ONE large cluster with a few free variables as ONE blocked factorisation (src/solver.jl:1245-1269): with B^T
+// Factorisation stage of ONE large cluster with free variables as ONE blocked factorisation (src/solver.jl:1245-1269): with B^T
 // appended to S as one more block row,
 //        [ S    .  ]   [ L        .  ] [ L^T  L^-1 B ]
 //        [ B^T  0  ] = [ B^T L^-T  I ] [ .    -Q     ],      Q = (L^-1 B)^T (L^-1 B),

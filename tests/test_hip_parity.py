@@ -959,11 +959,12 @@ def test_dense_blocks_below_32_with_a_ragged_matrix_count(oracle_built):
     assert np.max(np.abs(S - S_ref)) <= 1e-12 * np.max(np.abs(S_ref))
 
 
-@pytest.mark.parametrize("P,N", [(129, 1), (150, 20), (200, 64), (321, 33)])
+@pytest.mark.parametrize("P,N", [(129, 1), (150, 20), (200, 64), (321, 33), (260, 100), (200, 150)])
 def test_one_large_cluster_factor_with_free_variables_in_one_factorisation(P, N, oracle_built):
-    """One cluster beyond one 64-wide block with 1 .. 64 free variables: L, L^-1 B and Q come out of ONE blocked factorisation of
-    [S .; B^T 0] that stops before the corner ("factor_aug": k_chol_pack, k_chol_level, k_chol_unpack), here with ragged last blocks and
-    32 < N <= 64 (the corner's upper half is mirrored from the lower).  Against the oracle, and against the three-stage plan."""
+    """One cluster beyond one 64-wide block with free variables: L, L^-1 B and Q come out of ONE blocked factorisation of
+    [S .; B^T 0] that stops before the corner ("factor_aug": k_chol_pack, k_chol_level, k_chol_unpack), here with ragged last blocks,
+    32 < N <= 64 (the corner's upper half is mirrored from the lower) and N beyond one block (several appended block rows).  Against
+    the oracle, and against the three-stage plan."""
     import clrs_amd
     from clrs_amd import _lib
     from clrs_amd.solver import SchurContext, compute_T_decomposition, solve_system
