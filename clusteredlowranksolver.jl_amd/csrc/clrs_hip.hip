@@ -60,7 +60,7 @@ static int g_cfg_dense_block = 1;
 static int g_cfg_trsm_blockinv = 1;  // triangular solves with n > TRSM_IB through inverted diagonal blocks (plan_trsm_blockinv)
 static int g_cfg_potrf_levels = 1;   // Cholesky of matrices beyond one block: one launch per block column (plan_potrf_levels)
 static int g_cfg_pairing_tri = 1;    // staged low-rank blocks with W = V: lower triangles of the pairing matrices only
-static int g_cfg_factor_aug = 1;     // one large cluster with <= 512 free variables: L, L^-1 B and Q from one factorisation of [S .; B^T 0]
+static int g_cfg_factor_aug = 1;     // clusters beyond one block, <= 512 free variables: L_j, L_j^-1 B_j and Q from one factorisation of [S_j .; B_j^T 0] each
 static int g_cfg_dense_wave = 1;      // dense blocks with n <= 32 beyond k_dense_block: one wave per (block, matrix), k_dense_T32
 static int g_cfg_factor_small = 1;      // factor + Q in one launch of one workgroup for <= 4 small clusters (0: k_cluster_factor + k_small_potrf)
 static int g_cfg_solve_small_max = 32768;     // one-workgroup solve stage only up to this many doubles of operands (beyond: one workgroup per cluster, three launches)
@@ -1674,28 +1674,35 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
             s.kind = STEP_CLUSTER_FACTOR; s.grid = J; s.d0 = dcf; s.dst = c->d_info; s.bytes = lds;
             c->p_cholS.steps.push_back(s);      // Cholesky of S_j and L_j^-1 B_j in one launch: the LinvB timing slot stays 0
             if (lds > 64 * 1024) HIPCK(hipFuncSetAttribute((const void *)k_cluster_factor, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        } else if (g_cfg_factor_aug && g_cfg_potrf_levels && J == 1 && N > 0 && N <= 512 && c->P[0] > POTRF_NB) {
-            // one large cluster, a few free variables: L, L^-1 B and Q from ONE blocked factorisation of [S .; B^T 0] (k_chol_pack)
-            const int P = c->P[0], P64 = (P + 63) & ~63, na = P64 + N;
-            CholAugDesc ad;
-            std::memset(&ad, 0, sizeof(ad));
-            CK(dmalloc(c, &ad.Aug, (i64)na * na));
-            ad.S = c->d_S + c->Soff[0]; ad.B = c->d_B + c->coff[0]; ad.LB = c->d_LB + c->coff[0]; ad.Q = c->d_Q;
-            ad.P = P; ad.P64 = P64; ad.N = N; ad.ldb = (int)c->xlen;
-            c->chol_aug.push_back(ad);
+        } else if (g_cfg_factor_aug && g_cfg_potrf_levels && J >= 1 && N > 0 && N <= 512 && *std::min_element(c->P.begin(), c->P.end()) > POTRF_NB) {
+            // large clusters, a few free variables: L_j, L_j^-1 B_j and the cluster's share of Q from ONE blocked factorisation of
+            // [S_j .; B_j^T 0] each (k_chol_pack), all clusters in the same launches; several clusters: the shares summed in cluster order
+            if (J > 1) CK(dmalloc(c, &c->d_Qslabs, (i64)J * N * N));
             Step ms; ms.kind = STEP_MEMSET_INFO;
             c->p_cholS.steps.push_back(ms);
-            Step ps;
-            ps.kind = STEP_CHOL_PACK; ps.n = (i64)c->chol_aug.size() - 1; ps.grid = (int)std::min<i64>(((i64)na * na + 255) / 256, 8192);
-            c->p_cholS.steps.push_back(ps);
             std::vector<PotrfJob> pj;
-            PotrfJob job{ad.Aug, na, na, 1};
-            job.stop = P64 / 64;
-            pj.push_back(job);
+            std::vector<Step> unpack;
+            for (int j = 0; j < J; j++) {
+                const int P = c->P[j], P64 = (P + 63) & ~63, na = P64 + N;
+                CholAugDesc ad;
+                std::memset(&ad, 0, sizeof(ad));
+                CK(dmalloc(c, &ad.Aug, (i64)na * na));
+                ad.S = c->d_S + c->Soff[j]; ad.B = c->d_B + c->coff[j]; ad.LB = c->d_LB + c->coff[j];
+                ad.Q = J > 1 ? c->d_Qslabs + (i64)j * N * N : c->d_Q;
+                ad.P = P; ad.P64 = P64; ad.N = N; ad.ldb = (int)c->xlen;
+                c->chol_aug.push_back(ad);
+                Step ps;
+                ps.kind = STEP_CHOL_PACK; ps.n = (i64)c->chol_aug.size() - 1; ps.grid = (int)std::min<i64>(((i64)na * na + 255) / 256, 8192);
+                c->p_cholS.steps.push_back(ps);
+                PotrfJob job{ad.Aug, na, na, j + 1};
+                job.stop = P64 / 64;
+                pj.push_back(job);
+                Step us = ps;
+                us.kind = STEP_CHOL_UNPACK; us.grid = (int)std::min<i64>(((i64)P * P + (i64)P * N + (i64)N * N + 255) / 256, 8192);
+                unpack.push_back(us);
+            }
             CK(plan_potrf(c, c->p_cholS, pj));
-            Step us = ps;
-            us.kind = STEP_CHOL_UNPACK; us.grid = (int)std::min<i64>(((i64)P * P + (i64)P * N + (i64)N * N + 255) / 256, 8192);
-            c->p_cholS.steps.push_back(us);
+            for (const Step &us : unpack) c->p_cholS.steps.push_back(us);
             q_from_factor = true;
         } else {
             std::vector<PotrfJob> pj;
@@ -1714,7 +1721,12 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
         }
         if (N > 0) {
             if (q_from_factor) {
-                // Q came out of the factorisation of S (k_chol_unpack)
+                // Q came out of the factorisation of S (k_chol_unpack); several clusters: their shares are added up in cluster order
+                if (J > 1) {
+                    Step s;
+                    s.kind = STEP_SUM_SLABS;
+                    c->p_Q.steps.push_back(s);
+                }
             } else if (c->q_slabs) {
                 Step s;
                 s.kind = STEP_SUM_SLABS;

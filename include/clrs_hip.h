@@ -242,7 +242,7 @@ int clrs_wave2_clusters(const clrs_ctx *ctx);
  * of k_solve_small2 (every operand staged in one trip to memory, one wave per triangular solve); 0 keeps k_solve_small.
  * "dense_wave" (default 1): dense blocks with n <= 32 beyond the LDS-resident kernel form X^-1 A Y with one wave per matrix
  * (k_trtri32 + k_dense_T32); 0 = two substitution launches and a batched GEMM.
- * "factor_aug" (default 1): a context of ONE cluster beyond one 64-wide block with 1 .. 512 free variables factors [S .; B^T 0] in one
+ * "factor_aug" (default 1): a context whose clusters are all beyond one 64-wide block, with 1 .. 512 free variables, factors [S_j .; B_j^T 0] in one
  * blocked factorisation that stops before the corner: L^-1 B comes out as the panels of the appended block row, -Q as its Schur
  * complement (k_chol_pack, k_chol_level, k_chol_unpack); 0 = Cholesky of S, the substitution for L^-1 B and the Gram product apart.
  * "pairing_tri" (default 1): staged low-rank blocks whose left and right vectors coincide (W = V, one sub-block) compute only the

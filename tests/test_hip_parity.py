@@ -127,6 +127,21 @@ def test_several_large_matrices_per_level_launch(oracle_built):
     assert np.max(np.abs(Xc - chol_blocks_np(big, X))) <= 1e-12 * np.max(np.abs(Xc))
     _, S, _ = compute_T_decomposition(ctx, Xc, Y, want_S=True)
     L, LinvB, LQ = ctx.get_factor()
+    # the factor stage of the three clusters is one augmented factorisation each, their shares of Q summed: against the oracle on the
+    # replicated problem, with a solve
+    ob = Oracle(big, quad=False)
+    ob.schur_assemble(Xc, Y)
+    assert ob.schur_factor() == 0
+    _, LinvB_ref, LQ_ref = ob.get_factor()
+    assert np.max(np.abs(LinvB - LinvB_ref)) <= 1e-9 * max(1.0, np.max(np.abs(LinvB_ref)))
+    assert np.max(np.abs(LQ - LQ_ref)) <= 1e-9 * max(1.0, np.max(np.abs(LQ_ref)))
+    rng = np.random.default_rng(9)
+    rx, ry = rng.standard_normal(big.x_len), rng.standard_normal(big.n_free)
+    from clrs_amd.solver import solve_system
+    dx, dy = solve_system(ctx, rx, ry)
+    dx_ref, dy_ref = ob.schur_solve(rx, ry)
+    assert np.max(np.abs(dx - dx_ref)) <= 1e-8 * max(1.0, np.max(np.abs(dx_ref)))
+    assert np.max(np.abs(dy - dy_ref)) <= 1e-8 * max(1.0, np.max(np.abs(dy_ref)))
     ctx.close()
     nxy, nS = f.xy_len, f.S_len
     P = int(f.cluster_P[0])
