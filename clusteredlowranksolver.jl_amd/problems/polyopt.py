@@ -62,3 +62,63 @@ def polyopt_scaled(d, seed=0) -> ClusteredLowRankSDP:
     return ClusteredLowRankSDP(
         maximize=True, constant=0.0, blocks=[[blk]], B=[np.ones((P, 1))], c=[rng.uniform(-1, 1, P)],
         C=[[np.zeros((d + 1, d + 1))]], b=np.ones(1), names={"free": ["lambda"], "blocks": [["sos"]]})
+
+
+def invariant_basis(d):
+    """Exponents (a, i, j) of the S_3-invariant monomials (x+y+z)^a (xy+yz+zx)^i (xyz)^j of degree <= d, ordered by degree
+    (reference examples/PolyOpt.jl:33-37: `for deg = 0:d for j = 0:div(deg,3) for i = 0:div(deg-3j,2)`)."""
+    return [(deg - 2 * i - 3 * j, i, j) for deg in range(d + 1) for j in range(deg // 3 + 1) for i in range((deg - 3 * j) // 2 + 1)]
+
+
+def min_f(d=2, prec=DEFAULT_PREC) -> ClusteredLowRankSDP:
+    """S_3-invariant polynomial optimisation (reference examples/PolyOpt.jl:40-86, docs/src/examples/poly_opt.md):
+
+        maximise M  s.t.  f - M = <Y_1, w w^T> + <Y_2, Pi_2 (x) w w^T> + <Y_3, Pi_3 (x) w w^T>,
+        f = x^4 + y^4 + z^4 - 4xyz + x + y + z,
+
+    sampled at the approximate Fekete points of the (2d+1)(2d+2)(2d+3) Chebyshev grid for the invariant polynomials of degree
+    <= 2d.  `min_f(2)`: one cluster, P = 11, one 4x4 rank-1 block and one 3x3 rank-2 block (Pi_3 = v_1 v_1^T/2 + 3 v_2 v_2^T/2),
+    N = 1.  The block of Pi_2 = ((x-y)(y-z)(z-x))^2 appears from d = 3 on."""
+    from .polytools import approximate_fekete
+    with mp.workprec(prec):
+        inv = invariant_basis(2 * d)
+        degrees = [a + 2 * i + 3 * j for (a, i, j) in inv]
+
+        def ev(e, x, y, z):
+            a, i, j = e
+            return (x + y + z) ** a * (x * y + y * z + z * x) ** i * (x * y * z) ** j
+
+        cheb = [sample_points_chebyshev(2 * d + k) for k in range(3)]
+        grid = [(cheb[0][i], cheb[1][j], cheb[2][k]) for i in range(2 * d + 1) for j in range(2 * d + 2) for k in range(2 * d + 3)]
+        V0 = np.array([[ev(e, *pt) for e in inv] for pt in grid], dtype=object)
+        V, samples = approximate_fekete(V0, grid)       # V[p, k] = (new basis element k)(sample p); degree order preserved
+        P = len(samples)
+        equivariants = [
+            [[(0, lambda x, y, z: mp.mpf(1))]],
+            [[(3, lambda x, y, z: (x - y) * (y - z) * (z - x))]],
+            [[(1, lambda x, y, z: 2 * x - y - z), (2, lambda x, y, z: 2 * y * z - x * z - x * y)],
+             [(1, lambda x, y, z: y - z), (2, lambda x, y, z: x * z - x * y)]],
+        ]
+        factors = [[mp.mpf(1)], [mp.mpf(1)], [mp.mpf(1) / 2, mp.mpf(3) / 2]]
+        blocks, Cs, names = [], [], []
+        for eqi, rows in enumerate(equivariants):
+            sel = []        # per rank-one term: list of (equivariant, basis index)
+            for row in rows:
+                items = [(ef, k) for (edeg, ef) in row for k, qdeg in enumerate(degrees) if 2 * edeg + 2 * qdeg <= 2 * d]
+                if items:
+                    sel.append(items)
+            if not sel:
+                continue
+            side = len(sel[0])
+            ent = {}
+            for p, pt in enumerate(samples):
+                vs = np.array([[ef(*pt) * V[p, k] for (ef, k) in row] for row in sel], dtype=object)
+                lam = np.array(factors[eqi][:len(sel)], dtype=object)
+                ent[p] = LowRankMat(HiLo.of(lam), HiLo.of(vs), HiLo.of(vs))
+            blocks.append(Block(m=1, delta=side, entries={(0, 0): ent}, name=("trivariatesos", eqi + 1)))
+            Cs.append(HiLo.of(np.zeros((side, side))))
+            names.append(("trivariatesos", eqi + 1))
+        c = np.array([x ** 4 + y ** 4 + z ** 4 - 4 * x * y * z + x + y + z for (x, y, z) in samples], dtype=object)
+        return ClusteredLowRankSDP(
+            maximize=True, constant=0.0, blocks=[blocks], B=[HiLo.of(np.ones((P, 1)))], c=[HiLo.of(c)], C=[Cs], b=HiLo.of(np.ones(1)),
+            names={"free": ["M"], "blocks": [names], "samples": samples})

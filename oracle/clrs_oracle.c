@@ -124,6 +124,7 @@ typedef struct {
     int snap_n, snap_k, snap_count;
     const int *snap_it;
     double *snap_X, *snap_Y, *snap_rx, *snap_ry;
+    REAL last_obj[3];     /* dual objective, primal objective, duality gap of the last oracle_solvesdp at full working precision */
 } octx;
 
 static REAL ld(const double *hi, const double *lo, i64 i) { return lo ? (REAL)hi[i] + (REAL)lo[i] : (REAL)hi[i]; }
@@ -636,6 +637,10 @@ void oracle_set_snapshots(octx *o, int n, const int *iters, int k, double *X, do
     o->snap_X = X; o->snap_Y = Y; o->snap_rx = rx; o->snap_ry = ry;
 }
 int oracle_snapshot_count(const octx *o) { return o->snap_count; }
+/* dual objective, primal objective and duality gap the last oracle_solvesdp ended with, as k-limb planar numbers (out[l * 3 + i]) */
+void oracle_last_objectives_mw(octx *o, int k, double *out) {
+    for (int i = 0; i < 3; i++) stk(out, 3, k, i, o->last_obj[i]);
+}
 
 /* Dense restatement of S used as an independent structural check:
  * S[p,q] = sum_l Tr(A_p X^-1 A_q Y) with A_p = Matrix(::LowRankMat) (src/interface.jl:798-800). */
@@ -1002,6 +1007,7 @@ int oracle_solvesdp(octx *o, const oracle_params *prm, int *iters_out, double *o
     *iters_out = iter - 1;
     out[0] = (double)d_obj; out[1] = (double)p_obj; out[2] = (double)gap; out[3] = (double)dual_error;
     out[4] = (double)primal_error; out[5] = pd_feas;
+    o->last_obj[0] = d_obj; o->last_obj[1] = p_obj; o->last_obj[2] = gap;
     if (x_out) for (i64 i = 0; i < nx; i++) x_out[i] = (double)x[i];
     if (y_out) for (int i = 0; i < N; i++) y_out[i] = (double)y[i];
     if (X_out) for (i64 i = 0; i < nxy; i++) X_out[i] = (double)X[i];

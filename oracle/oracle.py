@@ -98,6 +98,7 @@ def _lib(quad):
         L.oracle_get_factor_mw.argtypes = [C.c_void_p, C.c_int, _p_d, _p_d, _p_d]
         L.oracle_schur_solve_mw.argtypes = [C.c_void_p, C.c_int, _p_d, _p_d, _p_d, _p_d]
         L.oracle_set_snapshots.argtypes = [C.c_void_p, C.c_int, _p_i, C.c_int, _p_d, _p_d, _p_d, _p_d]
+        L.oracle_last_objectives_mw.argtypes = [C.c_void_p, C.c_int, _p_d]
         L.oracle_snapshot_count.restype = C.c_int
         L.oracle_snapshot_count.argtypes = [C.c_void_p]
         L.oracle_num_threads.restype = C.c_int
@@ -324,7 +325,9 @@ class Oracle:
             cnt = int(self.L.oracle_snapshot_count(self.ctx))
             self.L.oracle_set_snapshots(self.ctx, 0, None, 1, None, None, None, None)
             snap = {k_: (v[:cnt] if k_ != "rhs_y" else v[:cnt, :, :f.n_free]) for k_, v in snap.items()}
-        return dict(snap=snap, error_code=int(code), iterations=int(iters.value), d_obj=out[0], p_obj=out[1], gap=out[2],
+        obj_limbs = np.zeros((6, 3))
+        self.L.oracle_last_objectives_mw(self.ctx, 6, _dp(obj_limbs))
+        return dict(snap=snap, objectives_limbs=obj_limbs.T.copy(), error_code=int(code), iterations=int(iters.value), d_obj=out[0], p_obj=out[1], gap=out[2],
                     dual_error=out[3], primal_error=out[4], pd_feas=bool(out[5]), hist=hist[:n],
                     x=x, y=y[:f.n_free], X=X, Y=Y)
 

@@ -228,3 +228,20 @@ def mw_relerr(a, b, scale=None):
     d = np.abs(mw_diff(a, b))
     s = np.max(np.abs(np.atleast_2d(b)[0])) if scale is None else scale
     return float(np.max(d) / s) if d.size else 0.0
+
+
+# ---- FlatSDP <-> .npz (fixtures of generated instances) ------------------------------------------------------------------
+def save_flat(path, f, **extra):
+    import dataclasses
+    arrs = {k: np.asarray(getattr(f, k)) for k in (fl.name for fl in dataclasses.fields(f))}
+    np.savez_compressed(path, **arrs, **extra)
+
+
+def load_flat(path):
+    import dataclasses
+    z = np.load(path, allow_pickle=False)
+    kw = {}
+    for fl in dataclasses.fields(sdpmod.FlatSDP):
+        v = z[fl.name]
+        kw[fl.name] = v if v.ndim else v.item()
+    return sdpmod.FlatSDP(**kw), {k: z[k] for k in z.files if k not in kw}
