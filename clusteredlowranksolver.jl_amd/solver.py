@@ -664,7 +664,8 @@ def solvesdp_device(sdp, ctx: Optional[SchurContext] = None, device: int = 0, ma
     hist = []
     t_start = time.time()
     error_code, it = 0, 1
-    dual_error = primal_error = gap = np.inf
+    dual_error = primal_error = np.inf      # computed by the first iteration; no termination test can pass before
+    gap = 0.0                               # x = 0, y = 0: both objectives equal the constant (src/solver.jl:319-321)
     d_obj = p_obj = f.constant
     pd_feas = False
     while True:

@@ -285,4 +285,230 @@ function solve_system!(ctx::HipContext, dx, dy, rhs_x, rhs_y; prec=precision(dx)
     return nothing
 end
 
+
+# =====================================================================================================================
+# Drop-in front end: `solvesdp` with the reference's signature and 5-tuple return, no patch to the reference needed.
+#
+# The reference's `solvesdp(problem; prec, kwargs...)` (src/solver.jl:71-99) builds the ClusteredLowRankSDP, converts it to
+# `prec`, and `solvesdp(sdp; ...)` (:100-744) preprocesses, runs the loop and post-processes.  Here the same steps run with the
+# reference's own functions for everything outside the loop (ClusteredLowRankSDP, convert_to_prec, preprocess!, postprocess,
+# solution_to_bigfloat) and with the device-resident loop of the library (clrs_mw_ipm_*) in place of :348-589.
+# =====================================================================================================================
+
+# struct clrs_ipm_data / clrs_ipm_params / clrs_ipm_record (include/clrs_hip.h) -- field order and types must match the header
+struct IpmData
+    C::Ptr{Float64}
+    c::Ptr{Float64}
+    b::Ptr{Float64}
+    maximize::Int32
+    reserved::Int32
+    constant::Float64
+end
+struct IpmParams
+    beta_infeasible::Float64
+    beta_feasible::Float64
+    gamma::Float64
+    dual_error_threshold::Float64
+    primal_error_threshold::Float64
+    max_complementary_gap::Float64
+    step_length_threshold::Float64
+    safe_step::Int32
+    reserved::Int32
+end
+struct IpmRecord
+    iter::Int32
+    pd_feas::Int32
+    error_code::Int32
+    factor_status::Int32
+    cholesky_status::Int32
+    reserved::Int32
+    mu::Float64
+    d_obj::Float64
+    p_obj::Float64
+    gap::Float64
+    dual_error::Float64
+    primal_error::Float64
+    alpha_d::Float64
+    alpha_p::Float64
+    beta_c::Float64
+    max_P::Float64
+    max_p::Float64
+    max_d::Float64
+end
+
+"""
+    solvesdp(problem::Problem; prec=precision(BigFloat), device=0, kwargs...)
+    solvesdp(sdp::ClusteredLowRankSDP; prec=precision(BigFloat), device=0, kwargs...)
+
+The reference's `solvesdp` (src/solver.jl:42-127: same keywords, same defaults, same return
+`status, dualsol, primalsol, solve_time, errorcode`) with the interior-point loop on the GPU at `limbs_for(prec)` words per number.
+Keywords without a device counterpart (`save_settings`, `correctoronly`, `matmul_prec`, `testing`) are accepted; a non-default
+value raises an `ArgumentError`, so that a caller never silently gets something else than it asked for.
+"""
+function solvesdp(problem::CLRS.Problem; prec=precision(BigFloat), kwargs...)
+    sdp = CLRS.ClusteredLowRankSDP(problem, prec=prec)          # src/solver.jl:96-98
+    sdp = CLRS.convert_to_prec(sdp, prec)
+    return solvesdp(sdp; prec=prec, kwargs...)
+end
+
+function solvesdp(sdp::CLRS.ClusteredLowRankSDP;
+        prec=precision(BigFloat), device::Integer=0,
+        maxiterations=500, beta_infeasible=3//10, beta_feasible=1//10, gamma=9//10,
+        omega_p=big(10)^10, omega_d=big(10)^10,
+        duality_gap_threshold=1e-15, dual_error_threshold=1e-30, primal_error_threshold=1e-30,
+        max_complementary_gap=big(10)^100, need_dual_feasible=false, need_primal_feasible=false,
+        verbose=true, step_length_threshold=1e-7,
+        dualsol::Union{Nothing,CLRS.DualSolution}=nothing, primalsol::Union{Nothing,CLRS.PrimalSolution}=nothing,
+        safe_step::Bool=true, correctoronly=false, save_settings=nothing, preprocess=true, matmul_prec=prec, testing=false)
+    correctoronly && throw(ArgumentError("correctoronly is not available with the HIP backend"))
+    (save_settings === nothing || (save_settings.iter_interval === nothing && save_settings.time_interval === nothing && save_settings.callback === nothing)) ||
+        throw(ArgumentError("save_settings is not available with the HIP backend"))
+    matmul_prec == prec || throw(ArgumentError("matmul_prec is not available with the HIP backend"))
+    (dualsol === nothing) == (primalsol === nothing) || throw(ArgumentError("pass both dualsol and primalsol, or neither"))
+    (dualsol === nothing) || throw(ArgumentError("warm starts are not wired through this front end yet (clrs_mw_ipm_set takes the iterate)"))
+    lib = libclrs[]
+    K = limbs_for(prec)
+    K >= 2 || throw(ArgumentError("the device-resident loop runs at 2 or more limbs (prec > 53)"))
+    # preprocessing with the reference's own code (src/solver.jl:156-167)
+    if preprocess
+        num_constr = [size(sdp.B[j], 1) for j in eachindex(sdp.B)]
+        cs, var_rels = CLRS.preprocess!(sdp)
+        c_removed = [Int[] for _ in eachindex(sdp.B)]
+        for (_, j, p) in cs
+            push!(c_removed[j], p)
+        end
+        cs_leftover = [[pi for pi in 1:num_constr[j] if !(pi in c_removed[j])] for j in eachindex(sdp.B)]
+        cs_map = [Dict(v => k for (k, v) in enumerate(cs_leftover[j])) for j in eachindex(sdp.B)]
+    else
+        cs_map = [Dict(i => i for i in 1:size(sdp.B[j], 1)) for j in eachindex(sdp.B)]
+    end
+    ctx = HipContext(sdp, cs_map; device=device, limbs=K)
+    DL = DATA_LIMBS
+    nxy, nx, N = ctx.block_off[end], ctx.cluster_off[end], ctx.n_free
+    # objective data as DL limb planes: C in the xy layout, c in the x layout, b
+    Cf = zeros(Float64, max(nxy, 1), DL); cf = zeros(Float64, max(nx, 1), DL); bf = zeros(Float64, max(N, 1), DL)
+    for (b, (j, l)) in enumerate(ctx.jl)
+        blk = sdp.C.blocks[j].blocks[l]
+        n = ctx.block_n[b]
+        for cc in 1:n, r in 1:n
+            limbs_of!(Cf, ctx.block_off[b] + r + (cc - 1) * n, blk[r, cc], DL)
+        end
+    end
+    for j in eachindex(sdp.c), p in 1:ctx.cluster_P[j]
+        limbs_of!(cf, ctx.cluster_off[j] + p, sdp.c[j][p, 1], DL)
+    end
+    for k in 1:N
+        limbs_of!(bf, k, sdp.b[k, 1], DL)
+    end
+    data = Ref(IpmData(pointer(Cf), pointer(cf), pointer(bf), sdp.maximize ? 1 : 0, 0, f64(sdp.constant)))
+    prm = Ref(IpmParams(Float64(beta_infeasible), Float64(beta_feasible), Float64(gamma), Float64(dual_error_threshold),
+                        Float64(primal_error_threshold), Float64(max_complementary_gap), Float64(step_length_threshold), safe_step ? 1 : 0, 0))
+    rec = Ref(IpmRecord(0, 0, 0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0))
+    GC.@preserve Cf cf bf begin
+        check(ccall((:clrs_mw_ipm_create_ex, lib), Cint, (Ptr{Cvoid}, Ref{IpmData}, Cint), ctx.handle, data, DL))
+    end
+    check(ccall((:clrs_mw_ipm_set_params, lib), Cint, (Ptr{Cvoid}, Ref{IpmParams}), ctx.handle, prm))
+    check(ccall((:clrs_mw_ipm_init, lib), Cint, (Ptr{Cvoid}, Cdouble, Cdouble), ctx.handle, Float64(omega_p), Float64(omega_d)))
+    if verbose
+        CLRS.@printf("%5s %8s %11s %11s %11s %10s %10s %10s %10s %10s %10s %10s\n", "iter", "time(s)", "μ", "D-obj", "P-obj", "gap",
+                     "D-error", "d-error", "p-error", "α_d", "α_p", "beta")
+    end
+    time_start = time()
+    iter, error_code = 1, 0
+    dual_error = primal_error = Inf
+    gap, d_obj, p_obj, pd_feas = 0.0, f64(sdp.constant), f64(sdp.constant), false
+    while true                                                     # termination: src/solver.jl:921-950
+        dual_feas, primal_feas = dual_error < dual_error_threshold, primal_error < primal_error_threshold
+        ((need_dual_feasible && dual_feas) || (need_primal_feasible && primal_feas)) && break
+        (dual_feas && primal_feas && gap < duality_gap_threshold) && (verbose && println("Optimal solution found"); break)
+        if iter > maxiterations                                    # :362-366
+            verbose && println("The maximum number of iterations has been reached.")
+            error_code = 2
+            break
+        end
+        check(ccall((:clrs_mw_ipm_iterate, lib), Cint, (Ptr{Cvoid}, Ref{IpmRecord}), ctx.handle, rec))
+        r = rec[]
+        if verbose                                                 # the row of :566-582: values from the start of the iteration, step lengths from its end
+            CLRS.@printf("%5d %8.1f %11.3e %11.3e %11.3e %10.2e %10.2e %10.2e %10.2e %10.2e %10.2e %10.2e\n", iter, time() - time_start,
+                         r.mu, d_obj, p_obj, gap, r.max_P, r.max_p, r.max_d, r.alpha_d, r.alpha_p, r.beta_c)
+        end
+        dual_error, primal_error, pd_feas = r.dual_error, r.primal_error, r.pd_feas != 0
+        if r.error_code != 0                                       # 1 SolverFailure, 3 mu too large, 4 step too short (docs/src/solving.md:64-70)
+            error_code = Int(r.error_code)
+            if verbose && error_code == 1
+                J = length(sdp.A)
+                if r.cholesky_status > 0
+                    j, l = ctx.jl[r.cholesky_status]
+                    println("The cholesky decomposition of X was not computed correctly in block ($j,$l). Try again with higher precision")
+                elseif 0 < r.factor_status <= J
+                    println("S was not decomposed succesfully in block $(r.factor_status), try again with higher precision. If this occurred in the first iteration, remove linear dependencies in the PSD part of the constraints or turn preprocessing on.")
+                elseif r.factor_status == J + 1
+                    println("Q was not decomposed correctly. Try restarting with a higher precision. If this occurred in the first iteration, remove linear dependencies between free variables or turn preprocessing on.")
+                end
+                println("We return the current solution and optimality status.")
+            end
+            break
+        end
+        d_obj, p_obj, gap = r.d_obj, r.p_obj, r.gap
+        iter += 1
+    end
+    time_total = time() - time_start
+    # the iterate back as Arb midpoints in the reference's containers
+    xf = zeros(Float64, max(nx, 1), K); yf = zeros(Float64, max(N, 1), K); Xf = zeros(Float64, max(nxy, 1), K); Yf = zeros(Float64, max(nxy, 1), K)
+    check(ccall((:clrs_mw_ipm_get, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), ctx.handle, xf, yf, Xf, Yf))
+    x = Arblib.ArbRefMatrix(nx, 1; prec=prec); y = Arblib.ArbRefMatrix(N, 1; prec=prec)
+    for i in 1:nx
+        x[i, 1] = arb_of(xf, i, prec)
+    end
+    for k in 1:N
+        y[k, 1] = arb_of(yf, k, prec)
+    end
+    unpack(Mf) = CLRS.BlockDiagonal([CLRS.BlockDiagonal([begin
+                b = findfirst(==((j, l)), ctx.jl); n = ctx.block_n[b]
+                M = Arblib.ArbRefMatrix(n, n; prec=prec)
+                for cc in 1:n, r in 1:n
+                    M[r, cc] = arb_of(Mf, ctx.block_off[b] + r + (cc - 1) * n, prec)
+                end
+                M
+            end for l in eachindex(sdp.A[j])]) for j in eachindex(sdp.A)])
+    X, Y = unpack(Xf), unpack(Yf)
+    if preprocess
+        x, y = CLRS.postprocess(x, y, cs, var_rels)                # src/solver.jl:630-632
+    end
+    dsol, psol = CLRS.solution_to_bigfloat(X, x, Y, y, sdp)
+    status = if pd_feas && gap < duality_gap_threshold              # src/solver.jl:727-741
+        CLRS.Optimal()
+    elseif (pd_feas && gap < 1e-8) || (dual_error < 1e-15 && primal_error < 1e-15 && gap < 1e-8)
+        CLRS.NearOptimal()
+    elseif pd_feas
+        CLRS.Feasible()
+    elseif primal_error < primal_error_threshold
+        CLRS.PrimalFeasible()
+    elseif dual_error < dual_error_threshold
+        CLRS.DualFeasible()
+    else
+        CLRS.NotConverged()
+    end
+    return status, dsol, psol, time_total, error_code
+end
+
+"""
+    ClusteredLowRankHIP.optimize!(opt)
+
+`MOI.optimize!` for the reference's `ClusteredLowRankSolver.Optimizer` (ext/MOIExt.jl:395-407) with this package's `solvesdp`: reads
+`opt.problem` and `opt.options`, fills `opt.result_data` under the keys the reference's result getters read (`:primalsol`, `:dualsol`,
+`:status`, `:errorcode`; ext/MOIExt.jl:417-566).  `ext/ClusteredLowRankHIPMOIExt.jl` wraps it in an `Optimizer` for JuMP.
+"""
+function optimize!(opt; device::Integer=0)
+    opts = Dict{Symbol,Any}(k => v for (k, v) in opt.options if k != :save_settings)
+    status, dualsol, primalsol, t, e = solvesdp(opt.problem; device=device, opts...)
+    opt.optimized = true
+    opt.result_data[:primalsol] = primalsol
+    opt.result_data[:dualsol] = dualsol
+    opt.result_data[:status] = status
+    opt.result_data[:errorcode] = e
+    opt.result_data[:solve_time] = t
+    return status, dualsol, primalsol, t, e
+end
+
 end # module

@@ -629,6 +629,43 @@ void oracle_schur_solve_mw(octx *o, int k, const double *rx, const double *ry, d
     for (i64 i = 0; i < o->N; i++) stk(dy, o->N, k, i, y[i]);
     free(a); free(b); free(x); free(y);
 }
+/* Backward error of a candidate solution (dx, dy) of the Newton system written at src/solver.jl:1527,
+ *     [S -B; B^T 0] (dx; dy) = (rhs_x; rhs_y),
+ * evaluated at the oracle's working precision from S given as k-limb planes (S layout; the matrix BEFORE its factorisation):
+ *     out[0] = max_i |S dx - B dy - rhs_x|_i / max_i (|S| |dx| + |B| |dy| + |rhs_x|)_i
+ *     out[1] = max_j |B^T dx - rhs_y|_j     / max_j (|B^T| |dx| + |rhs_y|)_j          (0 when N = 0)
+ * Normwise and free of the conditioning of S: a forward-error comparison of (dx, dy) loses log2 cond(S) bits, this does not. */
+void oracle_kkt_backward_error_mw(octx *o, int k, const double *S, const double *dx, const double *dy, const double *rx,
+                                  const double *ry, double *out) {
+    int N = o->N;
+    REAL *Sr = rloadk(S, o->Slen, k), *x = rloadk(dx, o->xlen, k), *y = rloadk(dy, N, k);
+    REAL *a = rloadk(rx, o->xlen, k), *b = rloadk(ry, N, k);
+    REAL num_x = 0, den_x = 0, num_y = 0, den_y = 0;
+    REAL *ry_acc = ralloc(N), *ry_abs = ralloc(N);
+    for (int j = 0; j < o->J; j++) {
+        int P = o->P[j];
+        const REAL *Sj = Sr + o->Soff[j], *Bj = o->B[j], *xj = x + o->coff[j], *aj = a + o->coff[j];
+        for (int i = 0; i < P; i++) {
+            REAL r = 0, m = 0;
+            for (int q = 0; q < P; q++) { REAL t = Sj[i + (i64)q * P] * xj[q]; r = r + t; m = m + RABS(t); }
+            for (int c = 0; c < N; c++) { REAL t = Bj[i + (i64)c * P] * y[c]; r = r - t; m = m + RABS(t); }
+            r = r - aj[i]; m = m + RABS(aj[i]);
+            r = RABS(r);
+            if (r > num_x) num_x = r;
+            if (m > den_x) den_x = m;
+        }
+        for (int c = 0; c < N; c++)
+            for (int i = 0; i < P; i++) { REAL t = Bj[i + (i64)c * P] * xj[i]; ry_acc[c] = ry_acc[c] + t; ry_abs[c] = ry_abs[c] + RABS(t); }
+    }
+    for (int c = 0; c < N; c++) {
+        REAL r = RABS(ry_acc[c] - b[c]), m = ry_abs[c] + RABS(b[c]);
+        if (r > num_y) num_y = r;
+        if (m > den_y) den_y = m;
+    }
+    out[0] = den_x > (REAL)0 ? (double)(num_x / den_x) : 0.0;
+    out[1] = den_y > (REAL)0 ? (double)(num_y / den_y) : 0.0;
+    free(Sr); free(x); free(y); free(a); free(b); free(ry_acc); free(ry_abs);
+}
 /* snapshots of the next oracle_solvesdp: at the listed iterations (1-based, ascending) the iterate (X, Y) at the
  * top of the iteration and the predictor's right-hand sides (rhs_x, rhs_y) are stored as k-limb planar arrays,
  * snapshot s at offset s * k * len of each buffer.  n = 0 switches them off. */

@@ -98,6 +98,7 @@ def _lib(quad):
         L.oracle_get_factor_mw.argtypes = [C.c_void_p, C.c_int, _p_d, _p_d, _p_d]
         L.oracle_schur_solve_mw.argtypes = [C.c_void_p, C.c_int, _p_d, _p_d, _p_d, _p_d]
         L.oracle_set_snapshots.argtypes = [C.c_void_p, C.c_int, _p_i, C.c_int, _p_d, _p_d, _p_d, _p_d]
+        L.oracle_kkt_backward_error_mw.argtypes = [C.c_void_p, C.c_int] + [_p_d] * 6
         L.oracle_last_objectives_mw.argtypes = [C.c_void_p, C.c_int, _p_d]
         L.oracle_snapshot_count.restype = C.c_int
         L.oracle_snapshot_count.argtypes = [C.c_void_p]
@@ -245,6 +246,22 @@ class Oracle:
         dx, dy = np.zeros((k, f.x_len)), np.zeros((k, max(f.n_free, 1)))
         self.L.oracle_schur_solve_mw(self.ctx, k, _dp(rx), _dp(ry), _dp(dx), _dp(dy))
         return dx, dy[:, :f.n_free]
+
+    def kkt_backward_error_mw(self, S, dx, dy, rhs_x, rhs_y):
+        """Normwise backward errors (x rows, y rows) of (dx, dy) as a solution of [S -B; B^T 0](dx; dy) = (rhs_x; rhs_y)
+        (src/solver.jl:1527), evaluated at the oracle's working precision; all arguments planar limbs, S the unfactored matrix."""
+        self._prec()
+        f = self.flat
+        k = max(np.atleast_2d(a).shape[0] for a in (S, dx, rhs_x))
+
+        def pad(a, n):
+            a = _c(np.atleast_2d(a)) if n else np.zeros((k, 1))
+            return _c(np.vstack([a, np.zeros((k - a.shape[0], a.shape[1]))])) if a.shape[0] < k else a
+        S, dx, rx = pad(S, f.S_len), pad(dx, f.x_len), pad(rhs_x, f.x_len)
+        dy, ry = pad(dy, f.n_free), pad(rhs_y, f.n_free)
+        out = np.zeros(2)
+        self.L.oracle_kkt_backward_error_mw(self.ctx, k, _dp(S), _dp(dx), _dp(dy), _dp(rx), _dp(ry), _dp(out))
+        return float(out[0]), float(out[1])
 
     # -- hot path -------------------------------------------------------------------------------
     def cholesky_blocks(self, X, X_lo=None):
