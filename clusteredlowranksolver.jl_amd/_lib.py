@@ -57,6 +57,12 @@ class IpmRecord(C.Structure):
                 ("max_P", C.c_double), ("max_p", C.c_double), ("max_d", C.c_double)]
 
 
+class IpmStop(C.Structure):
+    """struct clrs_ipm_stop"""
+    _fields_ = [("duality_gap_threshold", C.c_double), ("need_dual_feasible", C.c_int32), ("need_primal_feasible", C.c_int32),
+                ("max_iterations", C.c_int32), ("reserved", C.c_int32)]
+
+
 class ClrsError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"clrs error {code}: {msg}")
@@ -152,6 +158,7 @@ SYMBOLS = {
     "clrs_mw_ipm_iterate": (C.c_int, [C.c_void_p, C.POINTER(IpmRecord)]),
     "clrs_mw_ipm_get": (C.c_int, [C.c_void_p, p_d, p_d, p_d, p_d]),
     "clrs_mw_ipm_objectives": (C.c_int, [C.c_void_p, p_d]),
+    "clrs_mw_ipm_solve": (C.c_int, [C.c_void_p, C.POINTER(IpmStop), C.POINTER(IpmRecord), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "clrs_set_last_error": (None, [C.c_char_p]),
     "clrs_strerror": (C.c_char_p, [C.c_int]),
     "clrs_last_error": (C.c_char_p, []),

@@ -108,6 +108,7 @@ struct clrs_mw_ctx {
     size_t sm_bp_diag = 0, sm_bp_panel = 0, sm_bp_inv = 0;   // LDS of the blocked factorisation (k_mw_bp_*)
     void *comm = nullptr;                // ncclComm_t when the library does the exchanges itself (clrs_mw_comm_init)
     bool local_factored = false, fwd_done = false;
+    bool ipm_arms_info = false;          // inside the device-resident iteration the status words are re-armed by a kernel, not by a memset per call
 };
 
 template <class T>
@@ -507,6 +508,7 @@ extern "C" int clrs_mw_get_counters(const clrs_mw_ctx *c, double *assemble_mulad
 }
 
 static int mw_reset_info(clrs_mw_ctx *c, int which) {
+    if (c->ipm_arms_info) return 0;
     MWCHECK(hipMemsetAsync(c->d.info + which, 0x7f, sizeof(int), c->stream));      // MW_INFO_NONE is the byte 0x7f four times
     return 0;
 }

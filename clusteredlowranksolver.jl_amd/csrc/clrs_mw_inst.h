@@ -42,7 +42,7 @@
     X __global__ void k_mwi_rows_dn<K, DK>(const MwDev, const MwIpmDev, int);                                          \
     X __global__ void k_mwi_rows<K, DK>(const MwDev, const MwIpmDev, int);                                             \
     X __global__ void k_mwi_pv<K, DK>(const MwDev, const MwIpmDev, int);                                               \
-    X __global__ void k_mwi_step<K, DK>(const MwDev, const MwIpmDev, int, int, int);
+    X __global__ void k_mwi_step<K, DK>(const MwDev, const MwIpmDev, int, int, int, int);
 
 #define MW_KERNELS_ALL(X, K) MW_KERNELS_K(X, K) MW_KERNELS_KD(X, K, 1) MW_KERNELS_KD(X, K, 2)
 

@@ -31,6 +31,11 @@ struct MwIpmDev {
     int Ktot, pad;
     double beta_infeasible, beta_feasible, gamma, dual_thr, primal_thr, max_gap, step_thr;
     int safe_step, pad2;
+    // termination test of the loop (src/solver.jl:921-950) evaluated ON THE DEVICE at the end of an iteration when stop_on != 0
+    // (clrs_mw_ipm_solve: the host runs one iteration ahead of the records it reads; an iteration that follows the last one must
+    // not move the iterate): flags[6] = 1 makes k_mwi_update a no-op
+    double gap_thr;
+    int stop_on, need_dual, need_primal, pad3;
 };
 
 namespace mwk {
@@ -161,6 +166,154 @@ __device__ double wg_min_eig(lds_d *A, int n, lds_d *work, int tid) {
     return 0.5 * (lo + hi);
 }
 
+
+// ---- the same for n <= 32 with the tridiagonalisation in the REGISTERS of one wave and a division-free Sturm count ------------------
+// (the scheme of the fp64 loop's k_ipm_step, clrs_ipm.hip.h: lane r holds row r, the column loop is fully unrolled so that every
+// register index is static, v and w reach the other lanes through v_readlane, norms and dot products through DPP row shifts; the
+// Sturm sequence runs in product form p_(i+1) = (d_i - s) p_i - e_i^2 p_(i-1) with a power-of-two renormalisation every four steps,
+// 257 sections per round with ONE barrier).  The LDS form above spends a barrier and strided row reads on each of its n - 2
+// dependent steps and an IEEE division on each of the n steps of its Sturm chains: 45 of the 72 us of k_mwi_step at n = 16.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_zero(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+__device__ __forceinline__ double wave_sum_d(double v) {      // the same value (bitwise) in every lane
+    v += dpp_mov_zero<0x111>(v);   // row_shr:1
+    v += dpp_mov_zero<0x112>(v);   // row_shr:2
+    v += dpp_mov_zero<0x114>(v);   // row_shr:4
+    v += dpp_mov_zero<0x118>(v);   // row_shr:8   -> lane 15 of every row holds the row total
+    return (readlane_f64(v, 15) + readlane_f64(v, 31)) + (readlane_f64(v, 47) + readlane_f64(v, 63));
+}
+template <int NC>
+__device__ __forceinline__ void householder_regs(lds_d *A, int n, lds_d *dd, lds_d *ee, int lane) {
+    double a[NC];
+    const int r = lane < n ? lane : 0;
+#pragma unroll
+    for (int j = 0; j < NC; j++) a[j] = A[r * n + (j < n ? j : 0)];      // row r = column r: both triangles are stored
+    const bool rowok = lane < n;
+#pragma unroll
+    for (int j = 0; j < NC; j++) a[j] = (rowok && j < n) ? a[j] : 0.0;
+#pragma unroll
+    for (int c = 0; c < NC - 2; c++) {
+        if (c < n - 2) {                                    // uniform
+            const double xi = (lane > c) ? a[c] : 0.0;      // column c below the diagonal (rows >= n hold zeros)
+            const double ss = wave_sum_d(xi * xi);
+            const double x0 = readlane_f64(xi, c + 1);
+            if (ss == 0.0) {
+                if (lane == 0) ee[c] = 0.0;
+            } else {
+                // H = I - tau v v^T is orthogonal for ANY alpha as long as tau = 2 / v^T v for the v in use: |x| and tau by rsq / rcp
+                // with Newton steps (the IEEE sqrt and division are ~60 dependent instructions per step)
+                double rs = __builtin_amdgcn_rsq(ss);
+                rs = rs * __builtin_fma(-0.5 * ss * rs, rs, 1.5);
+                rs = rs * __builtin_fma(-0.5 * ss * rs, rs, 1.5);
+                const double nrm = ss * rs;
+                const double alpha = (x0 > 0.0) ? -nrm : nrm;
+                const double v0 = x0 - alpha;
+                const double vi = (lane == c + 1) ? v0 : xi;
+                const double vtv = ss - x0 * x0 + v0 * v0;
+                double rt = __builtin_amdgcn_rcp(vtv);
+                rt = __builtin_fma(__builtin_fma(-vtv, rt, 1.0), rt, rt);
+                rt = __builtin_fma(__builtin_fma(-vtv, rt, 1.0), rt, rt);
+                const double tau = 2.0 * rt;
+                double pa = 0.0, pb = 0.0, pc2 = 0.0, pd = 0.0;          // four partial sums: the FMAs of one chain wait on each other
+#pragma unroll
+                for (int j = c + 1; j < NC; j++) {
+                    const double vj = readlane_f64(vi, j);
+                    if (((j - c - 1) & 3) == 0) pa = __builtin_fma(a[j], vj, pa);
+                    else if (((j - c - 1) & 3) == 1) pb = __builtin_fma(a[j], vj, pb);
+                    else if (((j - c - 1) & 3) == 2) pc2 = __builtin_fma(a[j], vj, pc2);
+                    else pd = __builtin_fma(a[j], vj, pd);
+                }
+                double pi = (pa + pb) + (pc2 + pd);
+                pi = (lane > c) ? pi * tau : 0.0;
+                const double kk = wave_sum_d(pi * vi);
+                const double wi = pi - 0.5 * tau * kk * vi;
+#pragma unroll
+                for (int j = c + 1; j < NC; j++) a[j] -= vi * readlane_f64(wi, j) + wi * readlane_f64(vi, j);
+                if (lane == 0) ee[c] = alpha;
+            }
+        }
+    }
+    double dv = 0.0, ev = 0.0;
+#pragma unroll
+    for (int j = 0; j < NC; j++) {
+        dv = (lane == j) ? a[j] : dv;
+        ev = (j == n - 2) ? a[j] : ev;
+    }
+    if (lane < n) dd[lane] = dv;
+    ev = readlane_f64(ev, n - 1);
+    if (lane == 0) ee[n - 2] = ev;
+}
+// work: LDS, at least 2 n + 96 doubles (3 n + 2 MW_NT are there); 2 <= n <= 32; MW_NT = 256 threads
+__device__ double wg_min_eig32(lds_d *A, int n, lds_d *work, int tid) {
+    __shared__ int zc[2][MW_NT / 64];
+    lds_d *dd = work, *ee = work + n, *d2 = work + 2 * n, *e2s = d2 + 48;
+    const int wave = tid >> 6, lane = tid & 63;
+    if (wave == 0) {
+        if (n <= 16) householder_regs<16>(A, n, dd, ee, lane);
+        else if (n <= 24) householder_regs<24>(A, n, dd, ee, lane);
+        else householder_regs<32>(A, n, dd, ee, lane);
+    }
+    __syncthreads();
+    double lo = dd[0], hi = dd[0];                          // Gershgorin interval, by every thread
+    for (int i = 0; i < n; i++) {
+        const double rr = (i > 0 ? __builtin_fabs(ee[i - 1]) : 0.0) + (i < n - 1 ? __builtin_fabs(ee[i]) : 0.0);
+        lo = fmin(lo, dd[i] - rr);
+        hi = fmax(hi, dd[i] + rr);
+    }
+    const double scale = fmax(fmax(__builtin_fabs(lo), __builtin_fabs(hi)), 1e-290);
+    const int sexp = __builtin_amdgcn_frexp_exp(scale);           // scale < 2^sexp: |d - s| <= 2, e^2 <= 1 after the exact scaling
+    if (tid < 48) {
+        d2[tid] = (tid < n) ? ldexp(dd[tid], -sexp) : 0.0;
+        const double es = (tid >= 1 && tid < n) ? ldexp(ee[tid - 1], -sexp) : 0.0;
+        e2s[tid] = es * es;
+    }
+    lo = ldexp(lo, -sexp) - 1e-3;
+    hi = ldexp(hi, -sexp) + 1e-3;
+    __syncthreads();
+    for (int round = 0; round < 7; round++) {      // 257^7 > 1e16: the bracket shrinks to rounding level
+        const double h = (hi - lo) * (1.0 / 257.0);
+        const double sft = lo + h * (tid + 1);
+        double pm = 1.0, pc = (d2[0] - sft) + 1e-300;     // p_0, p_1
+        auto hi32 = [](double v) { return (unsigned)(__double_as_longlong(v) >> 32); };
+        unsigned cnt = hi32(pc) >> 31;                     // sign changes counted on the sign bits
+        auto step = [&](double tvu, double e2u) {
+            // + 1e-300 off the dependent chain: an exact zero becomes a tiny positive p, from which the recurrence continues correctly
+            const double pn = __builtin_fma(tvu, pc, __builtin_fma(-e2u, pm, 1e-300));
+            cnt += (hi32(pn) ^ hi32(pc)) >> 31;
+            pm = pc;
+            pc = pn;
+        };
+        int i0 = 1;
+        for (; i0 + 4 <= n; i0 += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) step(d2[i0 + u] - sft, e2s[i0 + u]);
+            const int ex = __builtin_amdgcn_frexp_exp(pc);
+            pc = ldexp(pc, -ex);
+            pm = ldexp(pm, -ex);
+        }
+        for (; i0 < n; i0++) step(d2[i0] - sft, e2s[i0]);
+        // the counts are monotone in the shift: the number of shifts with count 0 is the index of the sub-interval with the smallest eigenvalue
+        const unsigned long long zero = __ballot(cnt == 0u);
+        if (lane == 0) zc[round & 1][wave] = __popcll(zero);
+        __syncthreads();
+        int idx = 0;
+#pragma unroll
+        for (int w = 0; w < MW_NT / 64; w++) idx += zc[round & 1][w];
+        const double nlo = lo + h * idx;
+        hi = (idx == MW_NT) ? hi : lo + h * (idx + 1);
+        lo = nlo;
+    }
+    return ldexp(0.5 * (lo + hi), sexp);
+}
+
 }  // namespace mwk
 
 // ---- scalar stages (one thread) ------------------------------------------------------------------------------------
@@ -205,6 +358,10 @@ __device__ void mwi_scalar_stage(const MwDev &q, const MwIpmDev &p, int stage, i
         p.rec[MREC_DOBJ] = dobj.l[0]; p.rec[MREC_POBJ] = pobj.l[0]; p.rec[MREC_GAP] = gap.l[0];
         p.rec[MREC_ERR] = p.flags[1];
         p.rec[MREC_PDFEAS] = p.flags[0];
+        if (p.stop_on) {                           // the test of :921-950 on the values the host will read from this record
+            const bool df = p.rec[MREC_DERR] < p.dual_thr, pf = p.rec[MREC_PERR] < p.primal_thr;
+            if (p.flags[1] != 0 || (p.need_dual && df) || (p.need_primal && pf) || (df && pf && gap.l[0] < p.gap_thr)) p.flags[6] = 1;
+        }
         return;
     }
     if (threadIdx.x != 0) return;
@@ -221,7 +378,8 @@ __device__ void mwi_scalar_stage(const MwDev &q, const MwIpmDev &p, int stage, i
         p.rec[MREC_ITER] = iter;
         p.rec[MREC_MU] = mu.l[0];
         if (mu.l[0] > p.max_gap) p.flags[1] = 3;
-    } else if (stage == 1) {                       // after the residuals: errors (:441-447 use them), failures of the decomposition
+    }
+    if (stage == 1 || stage == 2) {                // after the residuals: errors (:441-447 use them), failures of the decomposition
         const double maxP = __longlong_as_double((long long)p.fmax[0]), maxd = __longlong_as_double((long long)p.fmax[1]),
                      maxp = __longlong_as_double((long long)p.fmax[2]);
         p.rec[MREC_MAXP] = maxP; p.rec[MREC_MAXd] = maxd; p.rec[MREC_MAXp] = maxp;
@@ -231,13 +389,14 @@ __device__ void mwi_scalar_stage(const MwDev &q, const MwIpmDev &p, int stage, i
         p.rec[MREC_FSTAT] = fs == MW_INFO_NONE ? 0 : fs;
         p.rec[MREC_XSTAT] = xs == MW_INFO_NONE ? 0 : xs;
         if ((fs != MW_INFO_NONE || xs != MW_INFO_NONE) && p.flags[1] == 0) p.flags[1] = 1;
-    } else if (stage == 2) {                       // between predictor and corrector: beta_c, mu_c (:429-434), then pd_feas (:441-447)
+        q.info[0] = MW_INFO_NONE;                  // re-armed for the next decomposition (the iteration issues no memsets)
+        q.info[1] = MW_INFO_NONE;
+    }
+    if (stage == 2) {                              // between predictor and corrector: beta_c, mu_c (:429-434), then pd_feas (:441-447)
         acc<K> s;
         acc_zero<K>(s);
         acc_add<K, K>(s, ldx<K>(p.sc, SP, MSC_XY));
-        acc_add<K, K>(s, mwi_sum_part<K>(q, p, 1));
-        acc_add<K, K>(s, mwi_sum_part<K>(q, p, 2));
-        acc_add<K, K>(s, mwi_sum_part<K>(q, p, 3));
+        acc_add<K, K>(s, mwi_sum_part<K>(q, p, 1));       // <X,dY> + <dX,Y> + <dX,dY>, one partial sum per block
         mw<K> mu = ldx<K>(p.sc, SP, MSC_MU);
         mw<K> r = s_div<K>(s_result<K>(s), s_mul_d<K>(mu, (double)p.Ktot));
         mw<K> beta = s_less<K>(r, from_double<K>(1.0)) ? s_mul<K>(r, r) : r;
@@ -252,7 +411,8 @@ __device__ void mwi_scalar_stage(const MwDev &q, const MwIpmDev &p, int stage, i
         p.rec[MREC_BETA] = beta_c.l[0];
         p.flags[0] = (p.rec[MREC_DERR] < p.dual_thr && p.rec[MREC_PERR] < p.primal_thr) ? 1 : 0;
         p.rec[MREC_PDFEAS] = p.flags[0];
-    } else if (stage == 3) {                       // step lengths (:1684-1691, 470-483)
+    }
+    if (stage == 3) {                              // step lengths (:1684-1691, 470-483)
         double al[2];
         for (int w = 0; w < 2; w++) {
             double mn = p.eig[(long)w * q.NB];
@@ -284,17 +444,17 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_dots(const MwDev q, const MwIpmDe
     const MwBlk &k = q.blk[blockIdx.x];
     const int tid = threadIdx.x;
     const long nn = (long)k.n * k.n;
-    acc<K> a0, a1, a2, a3, a4;
-    acc_zero<K>(a0); acc_zero<K>(a1); acc_zero<K>(a2); acc_zero<K>(a3); acc_zero<K>(a4);
+    acc<K> a0, a1, a4;
+    acc_zero<K>(a0); acc_zero<K>(a1); acc_zero<K>(a4);
     for (long i = tid; i < nn; i += MW_NT) {
         const long e = k.xyoff + i;
         mw<K> Y = ldx<K>(p.Y, q.xylen, e);
         if (sel & 1) acc_fma<K, K, K>(a0, ldx<K>(p.X, q.xylen, e), Y);
         if (sel & 2) {
             mw<K> X = ldx<K>(p.X, q.xylen, e), dX = ldx<K>(p.dX, q.xylen, e), dY = ldx<K>(p.dY, q.xylen, e);
-            acc_fma<K, K, K>(a1, X, dY);
-            acc_fma<K, K, K>(a2, dX, Y);
-            acc_fma<K, K, K>(a3, dX, dY);
+            acc_fma<K, K, K>(a1, X, dY);                   // only the sum of the three is ever used (:429): one accumulator, one reduction
+            acc_fma<K, K, K>(a1, dX, Y);
+            acc_fma<K, K, K>(a1, dX, dY);
         }
         if (sel & 4) acc_fma<K, K, DK>(a4, Y, ldx<DK>(p.C, q.xylen, e));
     }
@@ -302,14 +462,14 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_dots(const MwDev q, const MwIpmDe
     if (sel & 1) { mw<K> r = wg_reduce_sum<K>(acc_result<K>(a0), red, tid); if (tid == 0) stx<K>(p.part, 5L * q.NB, 0L * q.NB + blockIdx.x, r); }
     if (sel & 2) {
         mw<K> r = wg_reduce_sum<K>(acc_result<K>(a1), red, tid); if (tid == 0) stx<K>(p.part, 5L * q.NB, 1L * q.NB + blockIdx.x, r);
-        r = wg_reduce_sum<K>(acc_result<K>(a2), red, tid); if (tid == 0) stx<K>(p.part, 5L * q.NB, 2L * q.NB + blockIdx.x, r);
-        r = wg_reduce_sum<K>(acc_result<K>(a3), red, tid); if (tid == 0) stx<K>(p.part, 5L * q.NB, 3L * q.NB + blockIdx.x, r);
     }
     if (sel & 4) { mw<K> r = wg_reduce_sum<K>(acc_result<K>(a4), red, tid); if (tid == 0) stx<K>(p.part, 5L * q.NB, 4L * q.NB + blockIdx.x, r); }
 }
 
 
-// ---- R = mu_s I - X Y [- dX dY]  (compute_residual_R!, src/solver.jl:961-983) ------------------------------------------
+// ---- R' = - X Y [- dX dY]: compute_residual_R! (src/solver.jl:961-983) without its mu_s I, which the consumers (k_mwi_Zi, k_mwi_Z)
+// add on the diagonal of their first product -- the products do not depend on mu_p / mu_c, so this kernel runs beside the scalar
+// stages that produce them instead of behind them -------------------------------------------------------------------------
 #define MWI_EW 4              // lanes per matrix entry in the block products of the iteration
 template <int K>
 __global__ __launch_bounds__(MW_NT) void k_mwi_R(const MwDev q, const MwIpmDev p, int corrector) {
@@ -325,7 +485,6 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_R(const MwDev q, const MwIpmDev p
     for (int kk = sub; kk < n; kk += MWI_EW) acc_fma<K, K, K>(s, ldx<K>(p.X + k.xyoff, q.xylen, i + (long)kk * n), ldx<K>(p.Y + k.xyoff, q.xylen, kk + (long)c * n), -1.0);
     if (corrector)
         for (int kk = sub; kk < n; kk += MWI_EW) acc_fma<K, K, K>(s, ldx<K>(p.dX + k.xyoff, q.xylen, i + (long)kk * n), ldx<K>(p.dY + k.xyoff, q.xylen, kk + (long)c * n), -1.0);
-    if (i == c && sub == 0) acc_add<K, K>(s, ldx<K>(p.sc, MSC_COUNT, MSC_MUS));
     const mw<K> v = lanes_sum<K, MWI_EW>(acc_result<K>(s));
     if (live && sub == 0) stx<K>(p.R + k.xyoff, q.xylen, e, v);
 }
@@ -514,7 +673,7 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_pv(const MwDev q, const MwIpmDev 
         atomic_max_abs(&p.fmax[2], v.l[0]);
         stx<K>(p.pv, q.N, a, v);
     }
-    if (mwi_last_block(&p.flags[4], gridDim.x) && threadIdx.x < 64) mwi_scalar_stage<K, DK>(q, p, 1, iter);      // errors of the residuals
+    (void)iter;      // the errors of the residuals (scalar stage 1) are taken at the head of stage 2, when the decomposition has ended as well
 }
 
 // ---- which 0: Z = sym(X^-1 (P Y - R)) (:1501-1514);  which 1: dY = sym(X^-1 (R - dX Y)) (:1597-1613); both into dY --------
@@ -534,6 +693,7 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_Z(const MwDev q, const MwIpmDev p
         acc_zero<K>(s);
         for (int kk = 0; kk < n; kk++) acc_fma<K, K, K>(s, ldx<K>(A, q.xylen, i + (long)kk * n), ldx<K>(p.Y + k.xyoff, q.xylen, kk + (long)c * n), sg);
         acc_add<K, K>(s, ldx<K>(p.R + k.xyoff, q.xylen, e), -sg);
+        if (i == c) acc_add<K, K>(s, ldx<K>(p.sc, MSC_COUNT, MSC_MUS), -sg);          // R = mu_s I + R'
         stx<K>(M, nn, e, acc_result<K>(s));
     }
     // X^-1 M with the scaled triangles of chol(X) (this iteration's k_mw_potrf_x left them in the context)
@@ -583,6 +743,7 @@ __global__ __launch_bounds__(MW_PT) void k_mwi_Zi(const MwDev q, const MwIpmDev 
         acc_zero<K>(s);
         for (int kk = sub; kk < n; kk += MWI_ZL) acc_fma<K, K, K>(s, ldx<K>(A, q.xylen, i + (long)kk * n), ldx<K>(p.Y + k.xyoff, q.xylen, kk + (long)c * n), sg);
         if (sub == 0) acc_add<K, K>(s, ldx<K>(p.R + k.xyoff, q.xylen, i + (long)c * n), -sg);
+        if (sub == 1 && i == c) acc_add<K, K>(s, ldx<K>(p.sc, MSC_COUNT, MSC_MUS), -sg);      // R = mu_s I + R'
         const mw<K> v = lanes_sum<K, MWI_ZL>(acc_result<K>(s));
         if (live && sub == 0) stx<K>(M, np, ee, v);
     }
@@ -668,9 +829,9 @@ __device__ __forceinline__ void mwi_step_congruence(PF F, PR rd, PW W, long wpla
 // ---- compute_step_length (:1620-1693) per block: smallest eigenvalue of L^-1 dM L^-T, L = chol(M) -----------------------
 // which 0: (X, dX) with the factors of this iteration; which 1: (Y, dY), factored here
 template <int K>
-__device__ __forceinline__ void mwi_step_body(const MwDev &q, const MwIpmDev &p, int w_in_lds, int inv_path) {
+__device__ __forceinline__ void mwi_step_body(const MwDev &q, const MwIpmDev &p, int w_in_lds, int inv_path, int which_base) {
     using namespace mwk;
-    const int which = blockIdx.y;                       // both step lengths in one launch
+    const int which = which_base + blockIdx.y;          // both step lengths in one launch (grid.y = 2), or one launch each
     const MwBlk &k = q.blk[blockIdx.x];
     const int n = k.n, tid = threadIdx.x;
     const long nn = (long)n * n;
@@ -692,7 +853,7 @@ __device__ __forceinline__ void mwi_step_body(const MwDev &q, const MwIpmDev &p,
         }
         mwi_step_congruence_inv<K>((which == 0 ? q.Xi : p.Yi) + k.xyoff, q.xylen, n, dMg, q.xylen, T1, Wd, tid);
         __syncthreads();
-        const double ev = wg_min_eig(Wd, n, work, tid);
+        const double ev = n <= 32 ? wg_min_eig32(Wd, n, work, tid) : wg_min_eig(Wd, n, work, tid);
         if (tid == 0) p.eig[(long)which * q.NB + blockIdx.x] = ev - 1e-5;                // :1662
         return;
     }
@@ -712,7 +873,7 @@ __device__ __forceinline__ void mwi_step_body(const MwDev &q, const MwIpmDev &p,
             mwi_step_congruence_inv<K>(Li, nn, n, dMg, q.xylen, T1, Wd, tid);
         }
         __syncthreads();
-        const double ev = wg_min_eig(Wd, n, work, tid);
+        const double ev = n <= 32 ? wg_min_eig32(Wd, n, work, tid) : wg_min_eig(Wd, n, work, tid);
         if (tid == 0) p.eig[(long)which * q.NB + blockIdx.x] = ev - 1e-5;                // :1662
         return;
     }
@@ -742,20 +903,21 @@ __device__ __forceinline__ void mwi_step_body(const MwDev &q, const MwIpmDev &p,
     if (w_in_lds) mwi_step_congruence<K>(F, rd, Wl, nn, nn, n, dMg, q.xylen, Wd, tid);
     else mwi_step_congruence<K>(F, rd, (which == 0 ? p.R : p.Pm) + k.xyoff, q.xylen, nn, n, dMg, q.xylen, Wd, tid);    // R and P are dead here; one each
     __syncthreads();
-    const double ev = wg_min_eig(Wd, n, work, tid);
+    const double ev = n <= 32 ? wg_min_eig32(Wd, n, work, tid) : wg_min_eig(Wd, n, work, tid);
     if (tid == 0) p.eig[(long)which * q.NB + blockIdx.x] = ev - 1e-5;                    // :1662
 }
 template <int K, int DK>
-__global__ __launch_bounds__(MW_NT) void k_mwi_step(const MwDev q, const MwIpmDev p, int w_in_lds, int inv_path, int iter) {
-    mwi_step_body<K>(q, p, w_in_lds, inv_path);
-    if (mwi_last_block(&p.flags[4], gridDim.x * gridDim.y) && threadIdx.x < 64) mwi_scalar_stage<K, DK>(q, p, 3, iter);   // step lengths
+__global__ __launch_bounds__(MW_NT) void k_mwi_step(const MwDev q, const MwIpmDev p, int w_in_lds, int inv_path, int iter, int which_base) {
+    mwi_step_body<K>(q, p, w_in_lds, inv_path, which_base);
+    // the workgroup that arrives last -- of BOTH halves, 2 NB workgroups in one launch or two -- takes the step lengths
+    if (mwi_last_block(&p.flags[4], 2u * q.NB) && threadIdx.x < 64) mwi_scalar_stage<K, DK>(q, p, 3, iter);
 }
 
 // ---- x, X += alpha_d (dx, dX); y, Y += alpha_p (dy, dY)  (:485-495); skipped when the iteration ended with an error ------
 template <int K>
 __global__ __launch_bounds__(MW_NT) void k_mwi_update(const MwDev q, const MwIpmDev p) {
     using namespace mwk;
-    if (p.flags[1] != 0) return;
+    if (p.flags[1] != 0 || p.flags[6] != 0) return;
     const double ad = p.sc[10], ap = p.sc[11];
     const mwi64 tot = q.xylen + q.xlen + q.N;
     for (mwi64 i = (mwi64)blockIdx.x * MW_NT + threadIdx.x; i < tot; i += (mwi64)gridDim.x * MW_NT) {

@@ -276,13 +276,14 @@ def solvesdp_mw(sdp, limbs: Optional[int] = None, prec: Optional[int] = None, ct
                 omega_p: float = 1e10, omega_d: float = 1e10, duality_gap_threshold: float = 1e-15,
                 dual_error_threshold: float = 1e-30, primal_error_threshold: float = 1e-30, max_complementary_gap: float = 1e100,
                 need_dual_feasible: bool = False, need_primal_feasible: bool = False, verbose: bool = False,
-                step_length_threshold: float = 1e-7, safe_step: bool = True):
+                step_length_threshold: float = 1e-7, safe_step: bool = True, step_by_step: bool = False):
     """`solvesdp(sdp; prec, ...)` (src/solver.jl:71-127) with the whole loop body on the GPU in multi-word fp64.
 
     Keywords and DEFAULTS are the reference's (omega = 1e10, gap 1e-15, errors 1e-30: they assume its 256-bit arithmetic):
     `prec` bits select the limb count (`limbs_for_precision`), or pass `limbs` directly; the default is limbs = 5, which
     covers prec = 256.  The result's x, y, X, Y are planar limbs; objectives are fp64 heads plus `objectives_limbs`.
-    Termination (src/solver.jl:921-950) is decided on the host from one record per iteration."""
+    Termination (src/solver.jl:921-950): by the library and the device together in one call (`clrs_mw_ipm_solve`), or -- `verbose` or
+    `step_by_step` -- on the host from one record per call of `clrs_mw_ipm_iterate`."""
     import time
     from .solver import SolveResult
     f = sdp if isinstance(sdp, FlatSDP) else flatten(sdp)
@@ -308,28 +309,51 @@ def solvesdp_mw(sdp, limbs: Optional[int] = None, prec: Optional[int] = None, ct
     gap = 0.0                               # x = 0, y = 0: both objectives equal the constant (src/solver.jl:319-321)
     d_obj = p_obj = f.constant
     pd_feas = False
-    while True:
-        dual_feas, primal_feas = dual_error < dual_error_threshold, primal_error < primal_error_threshold
-        if (need_dual_feasible and dual_feas) or (need_primal_feasible and primal_feas):          # src/solver.jl:921-950
-            break
-        if dual_feas and primal_feas and gap < duality_gap_threshold:
-            break
-        if it > maxiterations:
-            error_code = 2
-            break
-        _lib.check(L.clrs_mw_ipm_iterate(ctx.h, C.byref(rec)))
-        hist.append([it, rec.mu, d_obj, p_obj, gap, rec.max_P, rec.max_p, rec.max_d, rec.alpha_d, rec.alpha_p, rec.beta_c])
-        if verbose:
-            print("%5d %8.1f %11.3e %11.3e %11.3e %10.2e %10.2e %10.2e %10.2e %10.2e %10.2e %10.2e" %
-                  (it, time.time() - t_start, rec.mu, d_obj, p_obj, gap, rec.max_P, rec.max_p, rec.max_d, rec.alpha_d, rec.alpha_p, rec.beta_c))
-        dual_error, primal_error, pd_feas = rec.dual_error, rec.primal_error, bool(rec.pd_feas)
-        if rec.error_code:
-            error_code = rec.error_code
-            if verbose and rec.error_code == 1:
-                print("SolverFailure: factor status %d, Cholesky status %d" % (rec.factor_status, rec.cholesky_status))
-            break
-        d_obj, p_obj, gap = rec.d_obj, rec.p_obj, rec.gap
-        it += 1
+
+    def row(r):
+        return [it, r.mu, d_obj, p_obj, gap, r.max_P, r.max_p, r.max_d, r.alpha_d, r.alpha_p, r.beta_c]
+
+    if not verbose and not step_by_step:
+        # the whole loop in ONE call (clrs_mw_ipm_solve): the library enqueues iterations one ahead of the record it waits for and the
+        # device evaluates the termination test of src/solver.jl:921-950 itself; the records come back as the reference's table rows
+        stop = _lib.IpmStop(float(duality_gap_threshold), int(bool(need_dual_feasible)), int(bool(need_primal_feasible)), int(maxiterations), 0)
+        recs = (_lib.IpmRecord * max(int(maxiterations), 1))()
+        n_it, err = C.c_int(0), C.c_int(0)
+        _lib.check(L.clrs_mw_ipm_solve(ctx.h, C.byref(stop), recs, int(maxiterations), C.byref(n_it), C.byref(err)))
+        error_code = err.value
+        for i in range(n_it.value):
+            r = recs[i]
+            hist.append(row(r))
+            dual_error, primal_error, pd_feas = r.dual_error, r.primal_error, bool(r.pd_feas)
+            if r.error_code:
+                break
+            d_obj, p_obj, gap = r.d_obj, r.p_obj, r.gap
+            it += 1
+        if error_code == 2:
+            it = n_it.value + 1
+    else:
+        while True:
+            dual_feas, primal_feas = dual_error < dual_error_threshold, primal_error < primal_error_threshold
+            if (need_dual_feasible and dual_feas) or (need_primal_feasible and primal_feas):          # src/solver.jl:921-950
+                break
+            if dual_feas and primal_feas and gap < duality_gap_threshold:
+                break
+            if it > maxiterations:
+                error_code = 2
+                break
+            _lib.check(L.clrs_mw_ipm_iterate(ctx.h, C.byref(rec)))
+            hist.append(row(rec))
+            if verbose:
+                print("%5d %8.1f %11.3e %11.3e %11.3e %10.2e %10.2e %10.2e %10.2e %10.2e %10.2e %10.2e" %
+                      (it, time.time() - t_start, rec.mu, d_obj, p_obj, gap, rec.max_P, rec.max_p, rec.max_d, rec.alpha_d, rec.alpha_p, rec.beta_c))
+            dual_error, primal_error, pd_feas = rec.dual_error, rec.primal_error, bool(rec.pd_feas)
+            if rec.error_code:
+                error_code = rec.error_code
+                if verbose and rec.error_code == 1:
+                    print("SolverFailure: factor status %d, Cholesky status %d" % (rec.factor_status, rec.cholesky_status))
+                break
+            d_obj, p_obj, gap = rec.d_obj, rec.p_obj, rec.gap
+            it += 1
     t_total = time.time() - t_start
     x, y = np.zeros((K, f.x_len)), np.zeros((K, max(f.n_free, 1)))
     X, Y = np.zeros((K, f.xy_len)), np.zeros((K, f.xy_len))

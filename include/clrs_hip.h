@@ -360,6 +360,15 @@ int clrs_mw_ipm_set(clrs_mw_ctx *ctx, const double *x, const double *y, const do
 int clrs_mw_ipm_iterate(clrs_mw_ctx *ctx, clrs_ipm_record *out);
 int clrs_mw_ipm_get(clrs_mw_ctx *ctx, double *x, double *y, double *X, double *Y);
 int clrs_mw_ipm_objectives(clrs_mw_ctx *ctx, double *out /* [3 * limbs]: d_obj, p_obj, gap */);
+/* The whole loop with its termination test (src/solver.jl:348-589, 921-950) in one call: at most max_iterations iterations from the
+ * current iterate, enqueued one ahead of the record the host waits for (the device evaluates the same test and freezes the iterate once
+ * it holds, so the device never idles between iterations).  records[i] (i < max_records) = table row of the i-th iteration of this call;
+ * *n_iter = iterations run; *error_code = 0, 1 / 3 / 4 as clrs_mw_ipm_iterate reports them, or 2 = max_iterations reached (:362-366). */
+typedef struct clrs_ipm_stop {
+    double duality_gap_threshold;                 /* with the error thresholds of clrs_ipm_params */
+    int32_t need_dual_feasible, need_primal_feasible, max_iterations, reserved;
+} clrs_ipm_stop;
+int clrs_mw_ipm_solve(clrs_mw_ctx *ctx, const clrs_ipm_stop *stop, clrs_ipm_record *records, int max_records, int *n_iter, int *error_code);
 
 const char *clrs_strerror(int code);
 const char *clrs_last_error(void);

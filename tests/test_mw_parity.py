@@ -607,3 +607,23 @@ def test_mw_malformed_descriptions_and_call_order():
     with pytest.raises(ValueError, match="planar limbs"):
         ctx.cholesky_blocks(np.zeros(f.xy_len))
     ctx.close()
+
+
+def test_one_call_loop_equals_the_step_by_step_loop():
+    """`clrs_mw_ipm_solve` (iterations enqueued one ahead of the record the host reads, termination test evaluated on the device, the
+    iterate frozen once it holds) against one `clrs_mw_ipm_iterate` per iteration with the test on the host: the same kernels in the same
+    order on the same data -- every table row, the objectives and the final iterate agree bit for bit; a maximum number of iterations
+    gives error code 2 (src/solver.jl:362-366) and the loop can be continued from where it stopped."""
+    from clrs_amd.mw import MwSchurContext, solvesdp_mw
+    f = flat("ce_8_15")
+    a = solvesdp_mw(f, limbs=5)
+    b = solvesdp_mw(f, limbs=5, step_by_step=True)
+    assert a.status == b.status == "Optimal" and a.iterations == b.iterations and a.error_code == b.error_code == 0
+    assert np.array_equal(a.history, b.history)
+    for u, v in ((a.x, b.x), (a.y, b.y), (a.X, b.X), (a.Y, b.Y), (a.timings["objectives_limbs"], b.timings["objectives_limbs"])):
+        assert np.array_equal(u, v)
+    c = solvesdp_mw(f, limbs=5, maxiterations=7)
+    assert c.error_code == 2 and c.iterations == 7 and np.array_equal(c.history, a.history[:7])
+    for kw in (dict(need_primal_feasible=True), dict(need_dual_feasible=True)):
+        u, v = solvesdp_mw(f, limbs=5, **kw), solvesdp_mw(f, limbs=5, step_by_step=True, **kw)
+        assert u.iterations == v.iterations and np.array_equal(u.history, v.history) and np.array_equal(u.X, v.X)
