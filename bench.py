@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""bench.py -- interior-point hot-path iterations/sec + Schur-assembly roofline on MI355X.
+"""bench.py -- interior-point iterations/sec + Schur-assembly roofline on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--limbs 5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
@@ -10,22 +10,27 @@ dense block, N = 31 free variables -- at the precision the reference solves it a
 prec = 256 bits (Arb midpoints); here every number is 5 limbs of fp64 (~262 bits; `--limbs 4` = ~209 bits), the problem data
 2 limbs.  In fp64 this instance cannot be factored at all (`fp64.parity.factor_status` below).
 
-One step = one pass of the hot path of one interior-point iteration on device-resident iterates:
-    Cholesky of the X blocks            (src/solver.jl:388-399)
-    Schur assembly                      (compute_S_integrated!, :1062-1226)
-    chol S_j, L^-1 B, Q, chol Q         (compute_T_decomposition!, :1244-1279)
-    2 x system solve                    (predictor + corrector, compute_search_direction! :1527-1582)
-on the iterate (X, Y) of iteration ceil(K/2) of the solve itself (trajectory iterates, not synthetic ones),
-with `parity.factor_status == 0` asserted.  `value` = units/s, one unit = one hot-path pass over one 2-cluster share.
-With N GPUs the problem is weak-scaled along the reference's own outer parallel axis (clusters): cohnelkies_multi with 2N clusters
-(2N - 1 sign-constraint clusters at different radii), 2 clusters per rank, coupled by the two sums over all clusters -- RCCL
-all-gathers of the partial Q (limbs x 31 x 31) per factorisation and of the partial u (limbs x 31) per solve, issued by the library
-itself on its stream (clrs_mw_comm_init): a step of the N-GPU job counts as N units.
+One STEP = one whole interior-point iteration of `solvesdp` (src/solver.jl:348-589) with the reference's default options, device
+resident: mu, residuals, Cholesky of the X blocks, the hot path (Schur assembly :1062-1226, chol S_j / L^-1 B / Q / chol Q :1244-1279,
+predictor and corrector solves :1527-1582), search directions, step lengths, update, objectives.  The timed region runs solves from the
+reference's starting point (X = Y = 1e10 I) back to back through `clrs_mw_ipm_solve` until exactly K iterations have run (a solve
+of this problem takes 56; the last one is cut at the remainder); `value` = iterations/s = BASELINE's metric.  The solve must end
+Optimal within 1e-4 of pi^4/384 (test/runtests_solver.jl:19-20) before anything is timed.  `hot_path` reports the rate of hot-path
+passes alone (the round-1/2 headline) on the iterate of iteration ceil(56/2), with its parity against the 320-bit oracle.
 
-`cpu_baseline`: the same step in the multi-precision CPU oracle (oracle/mpx.hpp, 256-bit truncation, the stand-in for the
-reference's Arb arithmetic: kind "port") on the host cores; `cpu_baseline_fp64`: the fp64 port on the same shapes.
-`roofline`: the HBM-bound fp64 Schur-assembly kernel on a many-cluster instance of the same block shapes (the BASELINE metric
-"Schur-assembly GB/s vs fp64 roofline"); `roofline_mw`: the multi-word Schur assembly against the fp64 pipe (78.6 TFLOP/s).
+With N GPUs the problem is weak-scaled along the reference's own outer parallel axis (clusters): cohnelkies_multi with 2N clusters
+(the f^ cluster and 2N - 1 sign-constraint clusters at different radii), partitioned over the ranks by `partition_clusters`, and the
+WHOLE interior-point solve runs sharded: x, X, Y stay on their rank, y and every scalar are replicated bit for bit; per iteration the
+library itself all-gathers (RCCL, two communicators: one per stream that exchanges) the partial Q (limbs x 31 x 31), the partial u
+(limbs x 31, twice) and five small records for mu, the errors and p = b - B^T x, beta_c, the step lengths and the objectives
+(clrs_mw_comm_init, clrs_mw_comm_init_side, clrs_mw_ipm_set_global).  A step of the N-GPU job = one
+iteration of the 2N-cluster problem = N units of work; `value` = N x iterations/s.
+
+`cpu_baseline`: whole iterations of the same solve in the multi-precision CPU oracle (oracle/mpx.hpp, 256-bit truncation, the stand-in
+for the reference's Arb arithmetic: kind "port") on the host cores; `roofline`: the HBM-bound fp64 Schur-assembly kernel on a
+many-cluster instance of the same block shapes (the BASELINE metric "Schur-assembly GB/s vs fp64 roofline"); `roofline_timed`: the
+kernel that dominates the timed step (k_mw_factor) against the fp64 issue rate of the compute units it occupies; `roofline_mw`: the
+multi-word Schur assembly of many clusters against the fp64 pipe (78.6 TFLOP/s).
 """
 from __future__ import annotations
 
@@ -53,8 +58,9 @@ def log(*a):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=560, help="interior-point iterations in the timed region")
+    ap.add_argument("--warmup", type=int, default=56)
+    ap.add_argument("--pass-steps", type=int, default=200, help="hot-path passes of the secondary measurement (`hot_path`)")
     ap.add_argument("--limbs", type=int, default=5, help="fp64 words per number (5 covers the reference's prec = 256)")
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--skip-fp64", action="store_true", help="skip the fp64 measurements (Schur-assembly HBM roofline, fp64 step on the problem's shapes)")
@@ -96,73 +102,102 @@ def main():
     flat = clrs_amd.flatten(cohnelkies(8, 15))
     log(f"problem: cohnelkies(8,15), {flat.n_clusters} clusters P={list(flat.cluster_P)} N={flat.n_free} blocks n={list(flat.block_n)}, generated in {time.time() - t0:.1f}s")
 
-    # ---- the solve itself: cold (first) and warm, with the reference's default options at K = 5 ----
-    ctx = MwSchurContext(flat, limbs=K, device=local_rank)
-    t0 = time.perf_counter()
-    r_cold = solvesdp_mw(flat, ctx=ctx, **thr)
-    t_cold = time.perf_counter() - t0
-    r = solvesdp_mw(flat, ctx=ctx, **thr)
-    assert r.error_code == 0 and r.status == "Optimal", (r.status, r.error_code)
-    assert abs(r.primal_objective - PI4_384) <= 1e-4, r.primal_objective       # test/runtests_solver.jl:19-20
-    n_it = r.iterations
-    mid = (n_it + 1) // 2
-    r_mid = solvesdp_mw(flat, ctx=ctx, maxiterations=mid, **thr)               # stops with code 2 after `mid` iterations; its iterate is (X, Y) of iteration mid + 1
-    X, Y = r_mid.X, r_mid.Y
-    full_solve = {"iterations": n_it, "status": r.status, "primal_objective": r.primal_objective, "dual_objective": r.dual_objective,
-                  "expected": PI4_384, "tolerance": 1e-4, "first_solve_s": t_cold, "solve_s": r.time_total,
-                  "iterations_per_s": n_it / r.time_total, "ms_per_iteration": 1e3 * r.time_total / n_it,
-                  "what": "whole interior-point iterations (residuals, predictor, corrector, step lengths, update around the hot path), device resident, "
-                          "one host synchronisation per iteration; first_solve_s includes context warm-up on a cold device"}
-
+    # ---- the job's problem: the named one on one GPU, the 2N-cluster weak-scaled one sharded over N ranks ----
+    from clrs_amd.mw import shard_problem
+    shard_info = None
+    prob = flat
     if sharded:
-        # weak scaling: 2 clusters per rank of the 2N-cluster problem; the iterate of a sign-constraint cluster is that of the solved one
         from clrs_amd.problems import cohnelkies_multi
-        from clrs_amd.sdp import shard_clusters
         full = clrs_amd.flatten(cohnelkies_multi(8, 15, [1.0 + 0.125 * k for k in range(2 * world - 1)]))
-        mine = [2 * rank, 2 * rank + 1]
-        shard = shard_clusters(full, mine)
-        blk = lambda M, b: M[:, int(flat.block_off[b]):int(flat.block_off[b + 1])]
-        per_cluster = {0: [0, 1], 1: [2, 3]}                                   # blocks of the f^ cluster / of a sign cluster in the solved problem
-        cols = [b for j in mine for b in per_cluster[0 if j == 0 else 1]]
-        X = np.ascontiguousarray(np.concatenate([blk(X, b) for b in cols], axis=1))
-        Y = np.ascontiguousarray(np.concatenate([blk(Y, b) for b in cols], axis=1))
-        ctx.close()
-        flat = shard
-        ctx = MwSchurContext(shard, limbs=K, device=local_rank)
-        uid = torch.zeros(128, dtype=torch.uint8, device=dev)
-        if rank == 0:
-            uid = torch.tensor(list(MwSchurContext.comm_unique_id()), dtype=torch.uint8, device=dev)
-        dist.broadcast(uid, 0)
-        ctx.comm_init(bytes(uid.cpu().tolist()), rank, world)
-    dX, dY = torch.tensor(X, device=dev), torch.tensor(Y, device=dev)
-    dXc = torch.empty_like(dX)
-    rx, ry = np.zeros((K, flat.x_len)), np.zeros((K, flat.n_free))
-    rx[0], ry[0] = 1.0, 1.0
-    drx, dry = torch.tensor(rx, device=dev), torch.tensor(ry, device=dev)
-    ddx, ddy = torch.empty_like(drx), torch.empty_like(dry)
-    torch.cuda.synchronize()
-
-    def step():
-        ctx.cholesky_blocks_dev(dX.data_ptr(), dXc.data_ptr())
-        ctx.assemble_dev(dXc.data_ptr(), dY.data_ptr())
-        ctx.factor_dev()
-        ctx.solve_dev(drx.data_ptr(), dry.data_ptr(), ddx.data_ptr(), ddy.data_ptr())      # predictor
-        ctx.solve_dev(drx.data_ptr(), dry.data_ptr(), ddx.data_ptr(), ddy.data_ptr())      # corrector
-
-    # ---- parity of this very step against the CPU oracle at 320 bits (checker only) ----
-    parity = {}
-    step()
-    parity["factor_status"] = ctx.sync_status()
-    parity["cholesky_status"] = ctx.sync_status_cholesky()
-    assert parity["factor_status"] == 0 and parity["cholesky_status"] == 0, parity
+        prob, shard_info = shard_problem(full, rank, world)
+        log(f"rank {rank}: clusters {list(shard_info['cluster_ids'])} of {full.n_clusters}")
+    ctx = MwSchurContext(prob, limbs=K, device=local_rank)
     if sharded:
-        # every rank must hold the same dy bit for bit (the gathered partial sums are added in rank order everywhere)
-        mine_dy = ddy.clone()
-        ref_dy = ddy.clone()
-        dist.broadcast(ref_dy, 0)
-        assert torch.equal(mine_dy, ref_dy), "dy differs between ranks"
-        parity["dy_identical_on_all_ranks"] = True
+        ids = torch.zeros(2, 128, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            ids = torch.tensor([list(MwSchurContext.comm_unique_id()), list(MwSchurContext.comm_unique_id())], dtype=torch.uint8, device=dev)
+        dist.broadcast(ids, 0)
+        ctx.comm_init(bytes(ids[0].cpu().tolist()), rank, world)
+        ctx.comm_init_side(bytes(ids[1].cpu().tolist()))
+
+    def solve(**kw):
+        return solvesdp_mw(prob, ctx=ctx, shard_info=shard_info, **thr, **kw)
+
+    # ---- the solve itself, untimed: cold (first) and warm, with the reference's default options at K = 5 ----
+    t0 = time.perf_counter()
+    r_cold = solve()
+    t_cold = time.perf_counter() - t0
+    r = solve()
+    n_it = r.iterations
+    if not sharded:
+        assert r.error_code == 0 and r.status == "Optimal", (r.status, r.error_code)
+        assert abs(r.primal_objective - PI4_384) <= 1e-4, r.primal_objective       # test/runtests_solver.jl:19-20
+    assert n_it > 0 and r_cold.iterations == n_it
+    full_solve = {"iterations": n_it, "status": r.status, "error_code": r.error_code, "primal_objective": r.primal_objective, "dual_objective": r.dual_objective,
+                  "expected": PI4_384 if not sharded else None, "tolerance": 1e-4, "first_solve_s": t_cold, "solve_s": r.time_total,
+                  "iterations_per_s": n_it / r.time_total, "ms_per_iteration": 1e3 * r.time_total / n_it,
+                  "what": "one whole solve from the reference's starting point with its default options (one call of clrs_mw_ipm_solve: iterations enqueued one "
+                          "ahead of the record the host reads, termination test on the device); first_solve_s includes context warm-up on a cold device"}
+
+    def run_iterations(n):
+        """exactly n interior-point iterations: whole solves back to back, the last one cut at the remainder"""
+        done = 0
+        while done < n:
+            rr = solve(maxiterations=n - done)
+            assert rr.iterations > 0
+            done += rr.iterations
+
+    # ---- timed region: W warmup iterations + exactly K iterations, barrier + synchronize on both sides ----
+    run_iterations(args.warmup)
+    torch.cuda.synchronize()
+    if sharded:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_iterations(args.steps)
+    torch.cuda.synchronize()
+    if sharded:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if sharded:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        ry0 = torch.tensor(r.y, device=dev)
+        ry_ref = ry0.clone()
+        dist.broadcast(ry_ref, 0)
+        assert torch.equal(ry0, ry_ref), "the free variables y differ between ranks"
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = world * args.steps / elapsed
+
+    # ---- secondary: the hot path alone (chol X + assembly + factorisation + 2 solves) on a mid-trajectory iterate, single GPU ----
+    hot = None
+    parity = {}
     if rank == 0 and not sharded:
+        mid = (n_it + 1) // 2
+        r_mid = solve(maxiterations=mid)                                        # stops with code 2 after `mid` iterations; its iterate is (X, Y) of iteration mid + 1
+        X, Y = r_mid.X, r_mid.Y
+        dX, dY = torch.tensor(X, device=dev), torch.tensor(Y, device=dev)
+        dXc = torch.empty_like(dX)
+        rx, ry = np.zeros((K, flat.x_len)), np.zeros((K, flat.n_free))
+        rx[0], ry[0] = 1.0, 1.0
+        drx, dry = torch.tensor(rx, device=dev), torch.tensor(ry, device=dev)
+        ddx, ddy = torch.empty_like(drx), torch.empty_like(dry)
+        torch.cuda.synchronize()
+
+        def step():
+            ctx.cholesky_blocks_dev(dX.data_ptr(), dXc.data_ptr())
+            ctx.assemble_dev(dXc.data_ptr(), dY.data_ptr())
+            ctx.factor_dev()
+            ctx.solve_dev(drx.data_ptr(), dry.data_ptr(), ddx.data_ptr(), ddy.data_ptr())      # predictor
+            ctx.solve_dev(drx.data_ptr(), dry.data_ptr(), ddx.data_ptr(), ddy.data_ptr())      # corrector
+
+        # ---- parity of this very pass against the CPU oracle at 320 bits (checker only) ----
+        step()
+        parity["factor_status"] = ctx.sync_status()
+        parity["cholesky_status"] = ctx.sync_status_cholesky()
+        assert parity["factor_status"] == 0 and parity["cholesky_status"] == 0, parity
         import math as _m
         from oracle.oracle import Oracle
 
@@ -180,53 +215,50 @@ def main():
         parity["S_rel_err_vs_320bit_oracle"] = relerr(S_gpu, S_ref)
         parity["dx_rel_err_vs_320bit_oracle"] = relerr(ddx.cpu().numpy(), dx_ref)
         parity["dy_rel_err_vs_320bit_oracle"] = relerr(ddy.cpu().numpy(), dy_ref)
+        bx, by = o.kkt_backward_error_mw(S_ref, ddx.cpu().numpy(), ddy.cpu().numpy(), rx, ry)
+        parity["kkt_backward_error_x_rows"], parity["kkt_backward_error_y_rows"] = bx, by
         parity["limb_bits"] = bits
         # the assembly inherits cond(X) of a mid-trajectory iterate (~1e9 here); the solve inherits cond(S) (~1e34): reported, and bounded loosely
         assert parity["S_rel_err_vs_320bit_oracle"] <= 2.0 ** -(53 * K - 64), parity
         assert parity["dx_rel_err_vs_320bit_oracle"] <= 1e-20 and parity["dy_rel_err_vs_320bit_oracle"] <= 1e-20, parity
+        assert bx <= 2.0 ** -(53 * K - 60) and by <= 2.0 ** -(53 * K - 90), parity      # the explicit inverse factors lose up to ~45 bits on x rows, ~65 on y rows (tests/test_mw_parity.py)
         ctx.assemble_dev(dXc.data_ptr(), dY.data_ptr())      # compute_S_integrated staged host copies of the factors: restore the device-resident state
         ctx.factor_dev()
-
-    # ---- timed region: W warmup + exactly K steps, barrier + synchronize on both sides ----
-    for _ in range(args.warmup):
-        step()
-    ctx.sync_status()
-    torch.cuda.synchronize()
-    if sharded:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    ctx.sync_status()
-    torch.cuda.synchronize()
-    if sharded:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if sharded:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    ms_per_step = 1e3 * elapsed / args.steps
-    value = world * args.steps / elapsed
+        for _ in range(30):
+            step()
+        ctx.sync_status()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.pass_steps):
+            step()
+        ctx.sync_status()
+        torch.cuda.synchronize()
+        t_pass = (time.perf_counter() - t1) / args.pass_steps
+        hot = {"what": "hot-path passes alone on device-resident planar limbs: chol X + Schur assembly + chol S_j / L^-1 B / Q / chol Q + predictor and "
+                       "corrector solve (15 kernels), on the iterate of iteration %d of %d" % (mid + 1, n_it),
+               "passes_per_s": 1.0 / t_pass, "ms_per_pass": 1e3 * t_pass, "passes_timed": args.pass_steps}
 
     out = {
-        "metric": "interior-point iterations/sec (hot path: chol X + Schur assembly + block-Cholesky factor + 2 solves)",
+        "metric": "interior-point iterations/sec",
         "value": value, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": f"f64x{K} (multi-word fp64: {K} limbs per number, ~{bits} bits; problem data f64x2)", "data": "synthetic",
-        "config": {"workload": "SpherePacking cohnelkies(8,15): d=8, 2d=30; 2 clusters P=32, blocks 16x16 r1 + 1x1 dense, N=31; "
-                               f"iterate of iteration {mid + 1} of {n_it} of the solve at the reference's precision (prec=256 -> {K} limbs)",
-                   "clusters": int(flat.n_clusters), "n_free": int(flat.n_free), "limbs": K, "data_limbs": 2,
-                   "unit_of_work": "one hot-path pass (chol X, assembly, factorisation, predictor + corrector solve) over one 2-cluster share; "
-                                   "a step of the N-GPU job (one iteration of the 2N-cluster problem) = N units",
-                   "multi_gpu": (f"{2 * world} clusters sharded 2 per rank; RCCL all-gather of the partial Q (per factorisation) and u (per solve) "
-                                 "inside the C ABI (clrs_mw_comm_init)") if sharded else "single GPU",
-                   "launch": "eager, 15 kernels per step"},
-        "parity": parity,
+        "dtype": f"f64x{K} (multi-word fp64: {K} limbs per number, ~{bits} bits; problem data f64x2)",
+        "data": "generated: cohnelkies(8,15) built from the mathematics of the reference's examples/SpherePacking.jl (no dataset, no checkpoint); every "
+                "iterate is the solve's own, from the reference's starting point X = Y = 1e10 I",
+        "config": {"workload": "SpherePacking cohnelkies(8,15): d=8, 2d=30; 2 clusters P=32, blocks 16x16 r1 + 1x1 dense, N=31; whole interior-point "
+                               f"iterations with the reference's default options at its precision (prec=256 -> {K} limbs), {n_it} per solve",
+                   "clusters": int(prob.n_clusters) * world if sharded else int(flat.n_clusters), "n_free": int(flat.n_free), "limbs": K, "data_limbs": 2,
+                   "unit_of_work": "one interior-point iteration over one 2-cluster share; a step of the N-GPU job (one iteration of the 2N-cluster problem) = N units",
+                   "multi_gpu": (f"{2 * world} clusters partitioned over {world} ranks (partition_clusters); per iteration RCCL all-gathers of the partial Q, the partial u "
+                                 "(twice) and five scalar records (mu; errors and p; beta_c; step lengths; objectives) inside the C ABI, two communicators "
+                                 "(clrs_mw_comm_init, clrs_mw_comm_init_side, clrs_mw_ipm_set_global); y bit-identical on all ranks (asserted)") if sharded else "single GPU",
+                   "launch": "eager, two streams, 35 kernels per iteration, one host wait per iteration on a record that is one iteration old"},
         "full_solve": full_solve,
     }
+    if hot is not None:
+        out["hot_path"] = hot
+        out["parity"] = parity
+        ms_pass = hot["ms_per_pass"]
 
     if rank == 0 and not sharded:
         ctx.set_timing(True)
@@ -237,7 +269,7 @@ def main():
         ctx.set_timing(False)
 
         # ---- the same step at the other supported limb counts (the iterate truncated / zero-extended): precision against time ----
-        sweep = {str(K): ms_per_step}
+        sweep = {str(K): ms_pass}
         for Kx in (4, 6, 8, 10):
             if Kx == K:
                 continue
@@ -263,12 +295,40 @@ def main():
             torch.cuda.synchronize()
             sweep[str(Kx)] = 1e3 * (time.perf_counter() - t0) / 100 if ok else None
             cx.close()
-        out["ms_per_step_by_limbs"] = dict(sorted(sweep.items(), key=lambda kv: int(kv[0])))
+        out["hot_path"]["ms_per_pass_by_limbs"] = dict(sorted(sweep.items(), key=lambda kv: int(kv[0])))
 
-        # ---- CPU baseline: the multi-precision oracle on the same step, same iterate, bounded sample ----
+        # ---- CPU baseline: whole iterations of the same solve in the multi-precision oracle, bounded sample ----
         if not args.skip_cpu and world == 1:
             from oracle.oracle import Oracle
             oc = Oracle(flat, mp_bits=256)
+            ncpu = os.cpu_count() or 1
+            best = None
+            for th in sorted({1, min(8, ncpu), ncpu}):      # these matrices are tiny: more threads is usually slower
+                oc.set_num_threads(th)
+                t1 = time.perf_counter()
+                ro = oc.solvesdp(maxiterations=12)
+                rate = ro["iterations"] / (time.perf_counter() - t1)
+                if best is None or rate > best[0]:
+                    best = (rate, th)
+            oc.set_num_threads(best[1])
+            n_cpu, t_cpu, ro = 0, 0.0, None
+            while t_cpu < 10.0:
+                t1 = time.perf_counter()
+                ro = oc.solvesdp()
+                t_cpu += time.perf_counter() - t1
+                n_cpu += ro["iterations"]
+            assert ro["error_code"] == 0 and abs(ro["p_obj"] - r.primal_objective) <= 1e-10
+            rate = n_cpu / t_cpu
+            out["cpu_baseline"] = {"value": rate, "unit": "iterations/s", "cores": best[1], "kind": "port",
+                                   "sample": f"{n_cpu} interior-point iterations ({n_cpu // ro['iterations']} whole solves of the same problem with the same options, "
+                                             f"{ro['iterations']} iterations each, same objective to 1e-10) in {t_cpu:.1f}s: oracle/clrs_oracle.c on the multi-limb type of "
+                                             f"oracle/mpx.hpp truncated to 256 bits per operation (the stand-in for the reference's Arb midpoints at prec = 256; the "
+                                             f"reference itself needs Julia + Arb), best of 1/8/{ncpu} threads",
+                                   "precision_bits": 256}
+            out["speedup_vs_cpu_baseline"] = value / rate
+            out["full_solve"]["cpu_oracle_256bit"] = {"iterations": ro["iterations"], "iterations_per_s": rate, "primal_objective": ro["p_obj"], "threads": best[1]}
+            # the hot path alone in the oracle, same iterate (the secondary measurement's counterpart)
+            oc.set_num_threads(1)
 
             def cpu_pass():
                 st_, Lc = oc.cholesky_blocks_mw(X)
@@ -276,39 +336,14 @@ def main():
                 assert st_ == 0 and oc.schur_factor() == 0
                 oc.schur_solve_mw(rx, ry)
                 oc.schur_solve_mw(rx, ry)
-
-            def cpu_rate(budget):
-                n, tc = 0, 0.0
-                while tc < budget and n < 100000:
-                    t1 = time.perf_counter()
-                    cpu_pass()
-                    tc += time.perf_counter() - t1
-                    n += 1
-                return n / tc, n, tc
-
-            ncpu = os.cpu_count() or 1
-            best = None
-            for th in sorted({1, min(8, ncpu), ncpu}):      # these matrices are tiny: more threads is usually slower
-                oc.set_num_threads(th)
-                rate, _, _ = cpu_rate(1.5)
-                if best is None or rate > best[0]:
-                    best = (rate, th)
-            oc.set_num_threads(best[1])
-            rate, n_p, t_cpu = cpu_rate(12.0)
-            out["cpu_baseline"] = {"value": rate, "unit": "iterations/s", "cores": best[1], "kind": "port",
-                                   "sample": f"{n_p} hot-path passes of the same problem on the same iterate in {t_cpu:.1f}s: oracle/clrs_oracle.c on "
-                                             f"the multi-limb type of oracle/mpx.hpp truncated to 256 bits per operation (the stand-in for the reference's "
-                                             f"Arb midpoints at prec = 256; the reference itself needs Julia + Arb), best of 1/8/{ncpu} threads",
-                                   "precision_bits": 256}
-            out["speedup_vs_cpu_baseline"] = value / rate
-            # the whole solve in the oracle (one thread is its fastest configuration here)
-            oc.set_num_threads(1)
-            t1 = time.perf_counter()
-            ro = oc.solvesdp()
-            t_or = time.perf_counter() - t1
-            out["full_solve"]["cpu_oracle_256bit"] = {"iterations": ro["iterations"], "solve_s": t_or, "iterations_per_s": ro["iterations"] / t_or,
-                                                      "primal_objective": ro["p_obj"], "threads": 1}
-            out["full_solve"]["speedup_vs_cpu_oracle"] = (n_it / r.time_total) / (ro["iterations"] / t_or)
+            n_p, t_p = 0, 0.0
+            while t_p < 3.0:
+                t1 = time.perf_counter()
+                cpu_pass()
+                t_p += time.perf_counter() - t1
+                n_p += 1
+            out["hot_path"]["cpu_oracle_256bit_passes_per_s"] = n_p / t_p
+            out["hot_path"]["speedup_vs_cpu_oracle"] = out["hot_path"]["passes_per_s"] / (n_p / t_p)
 
         # ---- multi-word Schur assembly on a many-cluster instance: against the fp64 pipe ----
         try:
@@ -361,6 +396,29 @@ def main():
             bctx.close()
         except Exception as e:
             out["roofline_mw"] = {"error": repr(e)}
+
+        # ---- the kernel that dominates the TIMED step: k_mw_factor (one 32 x 32 Cholesky + inverse factor per cluster, 4 workgroups each) ----
+        # Its roof is the fp64 issue rate of the compute units it occupies (one fp64 VALU wave instruction holds its SIMD for 4 cycles); the
+        # executed instruction count comes from the committed counter pass (rocprofv3 cannot run inside this process), the duration is live.
+        try:
+            fc = json.load(open(os.path.join(ROOT, "profiles", "mw_factor_counters.json")))
+            if fc["limbs"] == K:
+                ctx.set_timing(True)
+                for _ in range(5):
+                    step()
+                t_f = ctx.timings()[1]                      # chol S_j + L^-1 B of the last pass (HIP events on the context stream)
+                ctx.set_timing(False)
+                insts, cus = fc["k_mw_factor"]["SQ_INSTS_VALU"], fc["k_mw_factor"]["workgroups"]
+                t_k = fc["k_mw_factor"]["share_of_stage"] * t_f
+                peak = cus * 4 * 2.4e9 / 4.0                # fp64 VALU wave instructions per second of the occupied compute units
+                out["roofline_timed"] = {"kernel": "k_mw_factor", "bound": "fp64 VALU issue of the occupied compute units", "unit": "G wave-instructions/s",
+                                         "achieved": insts / t_k / 1e9, "peak": peak / 1e9, "frac": insts / t_k / peak, "traffic": None,
+                                         "kernel_us": 1e6 * t_k, "compute_units": cus, "of_256_compute_units": cus / 256.0,
+                                         "valu_wave_instructions": insts, "source": fc["source"],
+                                         "what": "SQ_INSTS_VALU x 4 cycles / (occupied CUs x 4 SIMDs x kernel cycles): the chain of 32 dependent pivot steps of a "
+                                                 "fraction-free elimination keeps 8 of 256 compute units busy at this share of their fp64 issue slots"}
+        except Exception as e:
+            out["roofline_timed"] = {"error": repr(e)}
 
         # ---- fp64 measurements: the HBM-bound Schur assembly (BASELINE metric) and the fp64 kernels on this problem's shapes ----
         if not args.skip_fp64 and world == 1:

@@ -158,6 +158,11 @@ SYMBOLS = {
     "clrs_mw_ipm_iterate": (C.c_int, [C.c_void_p, C.POINTER(IpmRecord)]),
     "clrs_mw_ipm_get": (C.c_int, [C.c_void_p, p_d, p_d, p_d, p_d]),
     "clrs_mw_ipm_objectives": (C.c_int, [C.c_void_p, p_d]),
+    "clrs_mw_ipm_set_global": (C.c_int, [C.c_void_p, C.c_int, C.c_int, p_i32, p_i32]),
+    "clrs_mw_comm_init_side": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "clrs_mw_local_group_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "clrs_mw_local_group_destroy": (None, [C.c_void_p]),
+    "clrs_mw_comm_init_local": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "clrs_mw_ipm_solve": (C.c_int, [C.c_void_p, C.POINTER(IpmStop), C.POINTER(IpmRecord), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "clrs_set_last_error": (None, [C.c_char_p]),
     "clrs_strerror": (C.c_char_p, [C.c_int]),

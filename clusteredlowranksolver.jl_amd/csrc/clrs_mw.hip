@@ -12,9 +12,11 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <tuple>
 #include <vector>
@@ -80,6 +82,30 @@ static int mw_nccl_load() {
     } while (0)
 static const int MW_NCCL_FLOAT64 = 8;      // ncclFloat64 / ncclDouble
 
+// In-process stand-in for a communicator: `world` contexts of ONE process that share one device, driven by one host thread each
+// (the two-shards-on-one-GPU tests; a box has one GPU, and RCCL refuses two ranks on one device).  An all-gather is: every rank
+// records "my slot is written" on its stream, the host threads meet, every rank copies the peers' slots device to device behind the
+// peers' events, records "I have read", the host threads meet again and every rank orders its stream behind the peers' reads (a
+// slot is rewritten every iteration).  Two channels, like the two RCCL communicators of a context: one per stream that exchanges.
+struct clrs_mw_local_group {
+    int world = 0;
+    std::mutex m;
+    std::condition_variable cv;
+    struct Chan {
+        int arrived = 0;
+        long gen = 0;
+        std::vector<double *> base;
+        std::vector<hipEvent_t> ready, copied;
+    } ch[2];
+    void barrier(int k) {
+        std::unique_lock<std::mutex> lk(m);
+        Chan &c = ch[k];
+        const long g = c.gen;
+        if (++c.arrived == world) { c.arrived = 0; c.gen++; cv.notify_all(); }
+        else cv.wait(lk, [&] { return c.gen != g; });
+    }
+};
+
 static const size_t MW_LDS_MAX = 160 * 1024 - 2048;     // bytes of LDS one workgroup may claim on gfx950 (margin for the runtime)
 
 struct clrs_mw_ctx {
@@ -95,6 +121,7 @@ struct clrs_mw_ctx {
     bool lds_x = false, lds_q = false, lds_zt_L = false, dense_two = false;
     int nw_factor = 1;                  // workgroups per cluster in k_mw_factor (they share out the columns of the inverse factor)
     int maxcnt = 0;
+    int maxTb = 0;                      // most low-rank terms in one PSD block
     size_t sm_x = 0, sm_zt = 0, sm_dense = 0, sm_factor = 0, sm_q = 0, sm_fwd = 0, sm_mid = 0, sm_bwd = 0;
     int *h_info = nullptr;               // pinned
     double *d_Xin = nullptr, *d_Xc = nullptr, *d_Y = nullptr, *d_rx = nullptr, *d_ry = nullptr, *d_dx = nullptr, *d_dy = nullptr;   // staging of the host-pointer entry points
@@ -106,7 +133,9 @@ struct clrs_mw_ctx {
     double cnt_factor = 0, cnt_solve = 0;
     struct MwIpm *ipm = nullptr;
     size_t sm_bp_diag = 0, sm_bp_panel = 0, sm_bp_inv = 0;   // LDS of the blocked factorisation (k_mw_bp_*)
-    void *comm = nullptr;                // ncclComm_t when the library does the exchanges itself (clrs_mw_comm_init)
+    void *comm = nullptr;                // ncclComm_t when the library does the exchanges itself (clrs_mw_comm_init): the context's stream
+    void *comm_side = nullptr;           // a second communicator for the exchanges of the iteration's side stream (clrs_mw_comm_init_side)
+    clrs_mw_local_group *lgroup = nullptr;   // or: the in-process group (clrs_mw_comm_init_local)
     bool local_factored = false, fwd_done = false;
     bool ipm_arms_info = false;          // inside the device-resident iteration the status words are re-armed by a kernel, not by a memset per call
 };
@@ -226,6 +255,7 @@ extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int dev
             lr_list.push_back(b);
             const i64 t0 = d->term_ptr[b], t1 = d->term_ptr[b + 1];
             k.t0 = t0;
+            c->maxTb = std::max(c->maxTb, (int)(t1 - t0));
             // unique expanded vectors: (sub-block, delta values), exact equality, first occurrence wins
             std::vector<std::pair<int, const double *>> uniq;      // (sub-block, pointer to limb 0 of the vector inside term_vs / term_ws)
             auto find_or_add = [&](int r, const double *v) -> int {
@@ -467,6 +497,7 @@ extern "C" void clrs_mw_destroy(clrs_mw_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     mw_ipm_free(c);
     if (c->comm && g_nccl.CommDestroy) { (void)g_nccl.CommDestroy(c->comm); c->comm = nullptr; }
+    if (c->comm_side && g_nccl.CommDestroy) { (void)g_nccl.CommDestroy(c->comm_side); c->comm_side = nullptr; }
     for (void *p : c->allocs) (void)hipFree(p);
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->h_info) (void)hipHostFree(c->h_info);
@@ -590,7 +621,7 @@ extern "C" int clrs_mw_set_shard(clrs_mw_ctx *c, int rank, int world) {
         if ((rc = mw_dmalloc(c, &q.ug, (i64)world * q.N * c->K))) return rc;
     }
     q.rank = rank; q.world = world;
-    q.gathered = (world > 1 || c->comm) ? 1 : 0;
+    q.gathered = (world > 1 || c->comm || c->lgroup) ? 1 : 0;
     return 0;
 }
 // The library performs the two exchanges itself with RCCL all-gathers on the context stream (one of limbs*N*N doubles per
@@ -612,12 +643,90 @@ extern "C" int clrs_mw_comm_destroy(clrs_mw_ctx *c) {
         (void)hipStreamSynchronize(c->stream);
         NCCLCHECK(g_nccl.CommDestroy(c->comm));
         c->comm = nullptr;
+        if (c->comm_side) { NCCLCHECK(g_nccl.CommDestroy(c->comm_side)); c->comm_side = nullptr; }
         c->d.gathered = c->d.world > 1 ? 1 : 0;
     }
     return 0;
 }
 extern "C" double *clrs_mw_q_gather_dev(clrs_mw_ctx *c) { return c ? c->d.Qg : nullptr; }
 extern "C" double *clrs_mw_u_gather_dev(clrs_mw_ctx *c) { return c ? c->d.ug : nullptr; }
+
+// all-gather of `cnt` doubles per rank inside `base` ([world][cnt], this rank's slot written by earlier work on `stream`); channel 0 =
+// the context's stream, 1 = the side stream of the interior-point iteration
+static bool mw_has_comm(const clrs_mw_ctx *c, int chan) { return c->lgroup || (chan == 0 ? c->comm : c->comm_side); }
+static int mw_allgather(clrs_mw_ctx *c, int chan, double *base, size_t cnt, hipStream_t stream) {
+    const MwDev &q = c->d;
+    if (c->lgroup) {
+        clrs_mw_local_group *g = c->lgroup;
+        auto &ch = g->ch[chan];
+        const int r = q.rank;
+        MWCHECK(hipEventRecord(ch.ready[r], stream));
+        ch.base[r] = base;
+        g->barrier(chan);
+        for (int p = 0; p < g->world; p++) {
+            if (p == r) continue;
+            MWCHECK(hipStreamWaitEvent(stream, ch.ready[p], 0));
+            MWCHECK(hipMemcpyAsync(base + (size_t)p * cnt, ch.base[p] + (size_t)p * cnt, cnt * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        }
+        MWCHECK(hipEventRecord(ch.copied[r], stream));
+        g->barrier(chan);
+        for (int p = 0; p < g->world; p++)
+            if (p != r) MWCHECK(hipStreamWaitEvent(stream, ch.copied[p], 0));
+        return 0;
+    }
+    void *comm = chan == 0 ? c->comm : c->comm_side;
+    if (!comm) return mw_fail(CLRS_ERR_STATE, chan == 0 ? "sharded context without a communicator: use the split-phase entry points or clrs_mw_comm_init"
+                                                        : "the sharded interior-point iteration needs the side communicator: clrs_mw_comm_init_side");
+    NCCLCHECK(g_nccl.AllGather(base + (size_t)q.rank * cnt, base, cnt, MW_NCCL_FLOAT64, comm, stream));
+    return 0;
+}
+// second RCCL communicator (its own unique id), for the exchanges the interior-point iteration issues on its side stream
+extern "C" int clrs_mw_comm_init_side(clrs_mw_ctx *c, const void *id128) {
+    if (!c || !id128) return mw_fail(CLRS_ERR_INVALID, "null argument");
+    if (!c->comm) return mw_fail(CLRS_ERR_STATE, "clrs_mw_comm_init first");
+    mw_nccl_id id;
+    std::memcpy(&id, id128, sizeof(id));
+    NCCLCHECK(g_nccl.CommInitRank(&c->comm_side, c->d.world, id, c->d.rank));
+    return 0;
+}
+extern "C" int clrs_mw_local_group_create(int world, int device, clrs_mw_local_group **out) {
+    if (!out || world < 1) return mw_fail(CLRS_ERR_INVALID, "bad argument");
+    MWCHECK(hipSetDevice(device));
+    clrs_mw_local_group *g = new clrs_mw_local_group();
+    g->world = world;
+    for (auto &ch : g->ch) {
+        ch.base.assign(world, nullptr);
+        ch.ready.assign(world, nullptr);
+        ch.copied.assign(world, nullptr);
+        for (int r = 0; r < world; r++) {
+            MWCHECK(hipEventCreateWithFlags(&ch.ready[r], hipEventDisableTiming));
+            MWCHECK(hipEventCreateWithFlags(&ch.copied[r], hipEventDisableTiming));
+            // recorded once on the null stream, so that a wait issued before the first real record of a peer is well defined
+            MWCHECK(hipEventRecord(ch.ready[r], nullptr));
+            MWCHECK(hipEventRecord(ch.copied[r], nullptr));
+        }
+    }
+    MWCHECK(hipDeviceSynchronize());
+    *out = g;
+    return 0;
+}
+extern "C" void clrs_mw_local_group_destroy(clrs_mw_local_group *g) {
+    if (!g) return;
+    for (auto &ch : g->ch) {
+        for (auto e : ch.ready) if (e) (void)hipEventDestroy(e);
+        for (auto e : ch.copied) if (e) (void)hipEventDestroy(e);
+    }
+    delete g;
+}
+// this context is rank `rank` of the in-process group: the library's exchanges then go through it (one host thread per rank)
+extern "C" int clrs_mw_comm_init_local(clrs_mw_ctx *c, clrs_mw_local_group *g, int rank) {
+    if (!c || !g) return mw_fail(CLRS_ERR_INVALID, "null argument");
+    int rc = clrs_mw_set_shard(c, rank, g->world);
+    if (rc) return rc;
+    c->lgroup = g;
+    c->d.gathered = 1;
+    return 0;
+}
 
 // blocked Cholesky and inverse factor of one matrix in global memory over many workgroups (clrs_mw_kernels.hip.h, k_mw_bp_*)
 static int mw_potrf_blocked(clrs_mw_ctx *c, const MwBp &m) {
@@ -693,9 +802,8 @@ extern "C" int clrs_mw_schur_factor_dev(clrs_mw_ctx *c) {
     if (rc) return rc;
     const MwDev &q = c->d;
     if (q.gathered && q.N > 0) {
-        if (!c->comm) return mw_fail(CLRS_ERR_STATE, "sharded context without a communicator: use the split-phase entry points or clrs_mw_comm_init");
-        const size_t cnt = (size_t)q.N * q.N * c->K;
-        NCCLCHECK(g_nccl.AllGather(q.Qg + (size_t)q.rank * cnt, q.Qg, cnt, MW_NCCL_FLOAT64, c->comm, c->stream));
+        int rc2 = mw_allgather(c, 0, q.Qg, (size_t)q.N * q.N * c->K, c->stream);
+        if (rc2) return rc2;
     }
     return clrs_mw_schur_factor_finish_dev(c);
 }
@@ -743,9 +851,8 @@ extern "C" int clrs_mw_schur_solve_dev(clrs_mw_ctx *c, const double *d_rhs_x, co
     if (rc) return rc;
     const MwDev &q = c->d;
     if (q.gathered && q.N > 0) {
-        if (!c->comm) return mw_fail(CLRS_ERR_STATE, "sharded context without a communicator: use the split-phase entry points or clrs_mw_comm_init");
-        const size_t cnt = (size_t)q.N * c->K;
-        NCCLCHECK(g_nccl.AllGather(q.ug + (size_t)q.rank * cnt, q.ug, cnt, MW_NCCL_FLOAT64, c->comm, c->stream));
+        int rc2 = mw_allgather(c, 0, q.ug, (size_t)q.N * c->K, c->stream);
+        if (rc2) return rc2;
     }
     return clrs_mw_schur_solve_bwd_dev(c, d_rhs_y, d_dx, d_dy);
 }

@@ -36,7 +36,19 @@ struct MwIpmDev {
     // not move the iterate): flags[6] = 1 makes k_mwi_update a no-op
     double gap_thr;
     int stop_on, need_dual, need_primal, pad3;
+    // cluster sharding (q.world > 1): the sums / maxima / minima over ALL clusters that the scalar stages need (mu :369, errors :441-442,
+    // p = +-b - B^T x :899-916, beta_c :429, step lengths :1684-1686, objectives :793-804) travel as one small record per rank and stage:
+    // k_mwi_gpack writes this rank's slot, the library all-gathers it, every rank reduces the slots in rank order -- identical bits everywhere.
+    // Two buffers, one per stream that exchanges.  Slot layout: see MWG_* below.
+    double *gsM, *gsS;                 // [world][GL]
+    int GL, Jglob;                     // slot length; clusters of the whole problem (status code of a failed Q: Jglob + 1)
+    const int *clu_gid, *blk_gid;      // global number of every local cluster / PSD block (failure codes are global), or null = local numbers
 };
+#define MWG_S1(K, N) 0                       /* K limbs: <X,Y> (stage 0) | <X,dY>+<dX,Y>+<dX,dY> (stage 2) | <C,Y> (stage 4) */
+#define MWG_S2(K, N) (K)                     /* K limbs: <c,x> (stage 4) */
+#define MWG_BX(K, N) (2 * (K))               /* K N limbs, planar with plane N: -B^T x of this rank's rows (stage 1) */
+#define MWG_D(K, N) (2 * (K) + (K) * (N))    /* doubles: max|P|, max|d|, min eig X, min eig Y, factor status, Cholesky status, step-length failure, - */
+#define MWG_LEN(K, N) (MWG_D(K, N) + 8)
 
 namespace mwk {
 
@@ -330,6 +342,20 @@ __device__ __noinline__ mwa::mw<K> mwi_sum_part(const MwDev &q, const MwIpmDev &
 // the stage.  (The stages behind the block dot products stay separate launches: the fences cost those kernels more than the
 // launch saves -- measured 31 us against 10 + 9.5.)  `mwi_last_block` is uniform over the workgroup.
 __device__ __forceinline__ bool mwi_last_block(int *counter, unsigned total) { return mwk::wg_last_block(counter, total); }
+// sum over the ranks, in rank order, of the K-limb number at offset `off` of every slot of a gather buffer
+template <int K>
+__device__ __noinline__ mwa::mw<K> mwi_gsum(const MwDev &q, const double *gs, int GL, int off) {
+    using namespace mwk;
+    acc<K> s;
+    acc_zero<K>(s);
+    for (int r = 0; r < q.world; r++) {
+        mw<K> v;
+#pragma unroll
+        for (int l = 0; l < K; l++) v.l[l] = gs[(long)r * GL + off + l];
+        acc_add<K, K>(s, v);
+    }
+    return acc_result<K>(s);
+}
 // called by the first wave of a workgroup (threadIdx.x < 64); stages 0-3 use its first lane only
 template <int K, int DK>
 __device__ void mwi_scalar_stage(const MwDev &q, const MwIpmDev &p, int stage, int iter) {
@@ -345,9 +371,10 @@ __device__ void mwi_scalar_stage(const MwDev &q, const MwIpmDev &p, int stage, i
         for (int a = lane; a < q.N; a += 64) acc_fma<K, K, DK>(s, ldx<K>(p.y, q.N, a), ldx<DK>(p.b, q.N, a));
         mw<K> by = s_lanes64<K>(s_result<K>(s));
         if (lane != 0) return;
+        if (q.world > 1) cx = mwi_gsum<K>(q, p.gsS, p.GL, MWG_S2(K, q.N));       // this rank's rows of <c,x> were gathered (k_mwi_gpack)
         mw<K> dobj = s_add<K>(cx, from_double<K>(p.constant));
         acc_zero<K>(s);
-        acc_add<K, K>(s, mwi_sum_part<K>(q, p, 4));
+        acc_add<K, K>(s, q.world > 1 ? mwi_gsum<K>(q, p.gsS, p.GL, MWG_S1(K, q.N)) : mwi_sum_part<K>(q, p, 4));
         acc_add<K, K>(s, by);
         acc_add_d<K>(s, p.constant);
         mw<K> pobj = s_result<K>(s);
@@ -366,7 +393,7 @@ __device__ void mwi_scalar_stage(const MwDev &q, const MwIpmDev &p, int stage, i
     }
     if (threadIdx.x != 0) return;
     if (stage == 0) {                              // start of the iteration: mu, mu_p  (src/solver.jl:369-380)
-        mw<K> xy = mwi_sum_part<K>(q, p, 0);
+        mw<K> xy = q.world > 1 ? mwi_gsum<K>(q, p.gsS, p.GL, MWG_S1(K, q.N)) : mwi_sum_part<K>(q, p, 0);
         mw<K> mu = s_div<K>(xy, from_double<K>((double)p.Ktot));
         stx<K>(p.sc, SP, MSC_XY, xy);
         stx<K>(p.sc, SP, MSC_MU, mu);
@@ -385,7 +412,15 @@ __device__ void mwi_scalar_stage(const MwDev &q, const MwIpmDev &p, int stage, i
         p.rec[MREC_MAXP] = maxP; p.rec[MREC_MAXd] = maxd; p.rec[MREC_MAXp] = maxp;
         p.rec[MREC_DERR] = fmax(maxp, maxP);       // :828-832
         p.rec[MREC_PERR] = maxd;
-        const int fs = q.info[0], xs = q.info[1];
+        int fs = q.info[0], xs = q.info[1];
+        if (q.world > 1) {                         // the first failure in rank order, as every rank sees it (codes are global numbers)
+            fs = xs = MW_INFO_NONE;
+            for (int r = q.world - 1; r >= 0; r--) {
+                const double *D = p.gsM + (long)r * p.GL + MWG_D(K, q.N);
+                if ((int)D[4] != MW_INFO_NONE) fs = (int)D[4];
+                if ((int)D[5] != MW_INFO_NONE) xs = (int)D[5];
+            }
+        }
         p.rec[MREC_FSTAT] = fs == MW_INFO_NONE ? 0 : fs;
         p.rec[MREC_XSTAT] = xs == MW_INFO_NONE ? 0 : xs;
         if ((fs != MW_INFO_NONE || xs != MW_INFO_NONE) && p.flags[1] == 0) p.flags[1] = 1;
@@ -396,7 +431,7 @@ __device__ void mwi_scalar_stage(const MwDev &q, const MwIpmDev &p, int stage, i
         acc<K> s;
         acc_zero<K>(s);
         acc_add<K, K>(s, ldx<K>(p.sc, SP, MSC_XY));
-        acc_add<K, K>(s, mwi_sum_part<K>(q, p, 1));       // <X,dY> + <dX,Y> + <dX,dY>, one partial sum per block
+        acc_add<K, K>(s, q.world > 1 ? mwi_gsum<K>(q, p.gsM, p.GL, MWG_S1(K, q.N)) : mwi_sum_part<K>(q, p, 1));       // <X,dY> + <dX,Y> + <dX,dY>
         mw<K> mu = ldx<K>(p.sc, SP, MSC_MU);
         mw<K> r = s_div<K>(s_result<K>(s), s_mul_d<K>(mu, (double)p.Ktot));
         mw<K> beta = s_less<K>(r, from_double<K>(1.0)) ? s_mul<K>(r, r) : r;
@@ -415,8 +450,15 @@ __device__ void mwi_scalar_stage(const MwDev &q, const MwIpmDev &p, int stage, i
     if (stage == 3) {                              // step lengths (:1684-1691, 470-483)
         double al[2];
         for (int w = 0; w < 2; w++) {
-            double mn = p.eig[(long)w * q.NB];
-            for (int b = 1; b < q.NB; b++) mn = fmin(mn, p.eig[(long)w * q.NB + b]);
+            double mn;
+            if (q.world > 1) {
+                mn = p.gsM[MWG_D(K, q.N) + 2 + w];
+                for (int r = 1; r < q.world; r++) mn = fmin(mn, p.gsM[(long)r * p.GL + MWG_D(K, q.N) + 2 + w]);
+                for (int r = 0; r < q.world; r++) if (p.gsM[(long)r * p.GL + MWG_D(K, q.N) + 6] != 0.0) p.flags[2] = 1;
+            } else {
+                mn = p.eig[(long)w * q.NB];
+                for (int b = 1; b < q.NB; b++) mn = fmin(mn, p.eig[(long)w * q.NB + b]);
+            }
             const bool unsafe = p.flags[0] && !p.safe_step;
             al[w] = (mn > -p.gamma && !unsafe) ? 1.0 : -p.gamma / mn;
         }
@@ -503,12 +545,25 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_coef(const MwDev q, const MwIpmDe
 
 // ---- sum_i a_i A_i per block (compute_weighted_A!, src/solver.jl:1410-1470) plus the rest of P or dX -------------------
 // mode 0: P = sum x_i A_i - X -+ C (:882-893), max|P|;  mode 1: dX = sum dx_i A_i + P (:1585-1594)
+// coef_lds = 1: the coefficients a_p lambda_t of the block's terms are formed here, into LDS (every workgroup of a block repeats the few
+// products: cheaper than the launch of k_mwi_coef in front of this kernel); 0: read from p.coef (blocks with more terms than LDS holds)
 template <int K, int DK>
-__global__ __launch_bounds__(MW_NT) void k_mwi_wA(const MwDev q, const MwIpmDev p, int mode) {
+__global__ __launch_bounds__(MW_NT) void k_mwi_wA(const MwDev q, const MwIpmDev p, int mode, int coef_lds) {
     using namespace mwk;
     const MwBlk &k = q.blk[blockIdx.y];
     const int n = k.n;
     if (blockIdx.x * (MW_NT / MWI_EW) >= n * n) return;
+    lds_d *cf = MW_LDS;
+    int t_first = 0, t_cnt = 0;
+    if (coef_lds && k.kind == 0) {                        // uniform over the workgroup
+        const int *tp0 = q.tptr + k.tptr_off;
+        t_first = tp0[0]; t_cnt = tp0[k.P] - tp0[0];
+        const double *av = mode == 0 ? p.x : p.dx;
+        const MwClu &cl0 = q.clu[k.j];
+        for (int t = threadIdx.x; t < t_cnt; t += MW_NT)
+            stx<K>(cf, t_cnt, t, mulx<K, K, DK>(ldx<K>(av, q.xlen, cl0.coff + q.st_p[t_first + t]), ldx<DK>(q.st_lam, q.lamp, t_first + t)));
+        __syncthreads();
+    }
     const int e = blockIdx.x * (MW_NT / MWI_EW) + threadIdx.x / MWI_EW, sub = threadIdx.x % MWI_EW;
     const int ee = e < n * n ? e : 0, i = ee % n, c = ee / n;
     const double *a = mode == 0 ? p.x : p.dx;
@@ -524,7 +579,7 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_wA(const MwDev q, const MwIpmDev 
             const mw<DK> vi = ldx<DK>(V, q.Vp, i + (long)q.st_war[t] * n), vc = ldx<DK>(V, q.Vp, c + (long)q.st_wac[t] * n);
             if (vi.l[0] == 0.0 || vc.l[0] == 0.0) continue;
             constexpr int LL = (2 * DK + 1 < K) ? 2 * DK + 1 : K;
-            acc_fma<K, K, LL>(s, ldx<K>(p.coef, q.T, t), mulx<LL, DK, DK>(vi, vc));
+            acc_fma<K, K, LL>(s, coef_lds ? ldx<K>(cf, t_cnt, t - t_first) : ldx<K>(p.coef, q.T, t), mulx<LL, DK, DK>(vi, vc));
         }
     } else {
         const MwClu &cl = q.clu[k.j];
@@ -657,7 +712,73 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_rows(const MwDev q, const MwIpmDe
     }
 }
 
-// p = +-b - B^T x  (:899-916)
+// ---- this rank's slot of a gather buffer (cluster sharding): one workgroup, the first wave --------------------------------------
+template <int K, int DK>
+__global__ void k_mwi_gpack(const MwDev q, const MwIpmDev p, int stage) {
+    using namespace mwk;
+    if (blockIdx.x != 0 || threadIdx.x >= 64) return;
+    const int lane = threadIdx.x, N = q.N;
+    double *slot = ((stage == 2 || stage == 3) ? p.gsM : p.gsS) + (long)q.rank * p.GL, *D = slot + MWG_D(K, N);
+    if (stage == 4) {                              // <c,x> over this rank's rows, by the wave
+        acc<K> s;
+        acc_zero<K>(s);
+        for (long i = lane; i < q.xlen; i += 64) acc_fma<K, K, DK>(s, ldx<K>(p.x, q.xlen, i), ldx<DK>(p.c, q.xlen, i), p.sgn);
+        const mw<K> cx = s_lanes64<K>(s_result<K>(s));
+        if (lane == 0) {
+#pragma unroll
+            for (int l = 0; l < K; l++) slot[MWG_S2(K, N) + l] = cx.l[l];
+        }
+    }
+    if (lane != 0) return;
+    if (stage == 0 || stage == 2 || stage == 4) {
+        const mw<K> v = mwi_sum_part<K>(q, p, stage == 0 ? 0 : stage == 2 ? 1 : 4);
+#pragma unroll
+        for (int l = 0; l < K; l++) slot[MWG_S1(K, N) + l] = v.l[l];
+    }
+    if (stage == 1) {
+        D[0] = __longlong_as_double((long long)p.fmax[0]);
+        D[1] = __longlong_as_double((long long)p.fmax[1]);
+    }
+    if (stage == 2) {                              // the decomposition's status words, as global numbers
+        const int fs = q.info[0], xs = q.info[1];
+        D[4] = fs == MW_INFO_NONE ? MW_INFO_NONE : fs > q.J ? p.Jglob + 1 : p.clu_gid ? p.clu_gid[fs - 1] + 1 : fs;
+        D[5] = xs == MW_INFO_NONE ? MW_INFO_NONE : p.blk_gid ? p.blk_gid[xs - 1] + 1 : xs;
+    }
+    if (stage == 3) {
+        for (int w = 0; w < 2; w++) {
+            double mn = p.eig[(long)w * q.NB];
+            for (int b = 1; b < q.NB; b++) mn = fmin(mn, p.eig[(long)w * q.NB + b]);
+            D[2 + w] = mn;
+        }
+        D[6] = p.flags[2];
+    }
+}
+// sharded: p = +-b + sum over the ranks (rank order) of their -B^T x, max|p|; and the maxima of |P|, |d| over the ranks
+template <int K, int DK>
+__global__ __launch_bounds__(MW_NT) void k_mwi_pvfin(const MwDev q, const MwIpmDev p) {
+    using namespace mwk;
+    const int N = q.N;
+    for (int a = blockIdx.x * MW_NT + threadIdx.x; a < N; a += gridDim.x * MW_NT) {
+        acc<K> s;
+        acc_zero<K>(s);
+        acc_add<K, DK>(s, ldx<DK>(p.b, N, a), p.sgn);
+        for (int r = 0; r < q.world; r++) acc_add<K, K>(s, ldx<K>(p.gsS + (long)r * p.GL + MWG_BX(K, N), N, a));
+        const mw<K> v = acc_result<K>(s);
+        atomic_max_abs(&p.fmax[2], v.l[0]);
+        stx<K>(p.pv, N, a, v);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        double mP = 0, md = 0;
+        for (int r = 0; r < q.world; r++) {
+            const double *D = p.gsS + (long)r * p.GL + MWG_D(K, N);
+            mP = fmax(mP, D[0]); md = fmax(md, D[1]);
+        }
+        p.fmax[0] = (unsigned long long)__double_as_longlong(mP);
+        p.fmax[1] = (unsigned long long)__double_as_longlong(md);
+    }
+}
+
+// p = +-b - B^T x  (:899-916); sharded (q.world > 1): only -B^T x over this rank's rows, into its gather slot (k_mwi_pvfin completes it)
 template <int K, int DK>
 __global__ __launch_bounds__(MW_NT) void k_mwi_pv(const MwDev q, const MwIpmDev p, int iter) {
     using namespace mwk;
@@ -666,12 +787,16 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_pv(const MwDev q, const MwIpmDev 
     const int aa = live ? a : 0;
     acc<K> s;
     acc_zero<K>(s);
-    if (sub == 0) acc_add<K, DK>(s, ldx<DK>(p.b, q.N, aa), p.sgn);
+    const bool part = q.world > 1;
+    if (sub == 0 && !part) acc_add<K, DK>(s, ldx<DK>(p.b, q.N, aa), p.sgn);
     for (long g = sub; g < q.xlen; g += 8) acc_fma<K, K, DK>(s, ldx<K>(p.x, q.xlen, g), ldx<DK>(q.B, q.Bp, g + (long)aa * q.xlen), -1.0);
     mw<K> v = lanes_sum<K, 8>(acc_result<K>(s));
     if (live && sub == 0) {
-        atomic_max_abs(&p.fmax[2], v.l[0]);
-        stx<K>(p.pv, q.N, a, v);
+        if (part) stx<K>(p.gsS + (long)q.rank * p.GL + MWG_BX(K, q.N), q.N, a, v);
+        else {
+            atomic_max_abs(&p.fmax[2], v.l[0]);
+            stx<K>(p.pv, q.N, a, v);
+        }
     }
     (void)iter;      // the errors of the residuals (scalar stage 1) are taken at the head of stage 2, when the decomposition has ended as well
 }
@@ -910,6 +1035,7 @@ template <int K, int DK>
 __global__ __launch_bounds__(MW_NT) void k_mwi_step(const MwDev q, const MwIpmDev p, int w_in_lds, int inv_path, int iter, int which_base) {
     mwi_step_body<K>(q, p, w_in_lds, inv_path, which_base);
     // the workgroup that arrives last -- of BOTH halves, 2 NB workgroups in one launch or two -- takes the step lengths
+    if (q.world > 1) return;                            // sharded: the minima travel first (k_mwi_gpack, all-gather, k_mwi_scalar stage 3)
     if (mwi_last_block(&p.flags[4], 2u * q.NB) && threadIdx.x < 64) mwi_scalar_stage<K, DK>(q, p, 3, iter);
 }
 

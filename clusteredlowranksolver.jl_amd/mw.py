@@ -232,6 +232,16 @@ class MwSchurContext:
         buf = C.create_string_buffer(bytes(unique_id), 128)
         _lib.check(self.L.clrs_mw_comm_init(self.h, buf, int(rank), int(world)))
 
+    def comm_init_side(self, unique_id: bytes):
+        """Second communicator (its own unique id) for the exchanges the sharded interior-point iteration issues on its side stream."""
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        _lib.check(self.L.clrs_mw_comm_init_side(self.h, buf))
+
+    def comm_init_local(self, group: "LocalGroup", rank: int):
+        """Rank `rank` of an in-process group (all contexts on one device, one host thread per rank): for single-GPU tests."""
+        _lib.check(self.L.clrs_mw_comm_init_local(self.h, group.h, int(rank)))
+        self._group = group
+
     def comm_destroy(self):
         _lib.check(self.L.clrs_mw_comm_destroy(self.h))
 
@@ -267,6 +277,38 @@ class MwSchurContext:
         _lib.check(self.L.clrs_mw_set_stream(self.h, C.c_void_p(hip_stream)))
 
 
+class LocalGroup:
+    """clrs_mw_local_group: the in-process stand-in for the RCCL communicators (`world` contexts on one device, one thread each)."""
+
+    def __init__(self, world: int, device: int = 0):
+        self.L = _lib.load()
+        self.world = int(world)
+        h = C.c_void_p()
+        _lib.check(self.L.clrs_mw_local_group_create(self.world, int(device), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.clrs_mw_local_group_destroy(self.h)
+            self.h = None
+
+
+def shard_problem(full: FlatSDP, rank: int, world: int, parts=None):
+    """The sub-problem of rank `rank` (its clusters by `partition_clusters`, all free variables) and what `solvesdp_mw` must tell the
+    library about the whole: (shard, shard_info)."""
+    from .sdp import shard_clusters
+    from .sharded import partition_clusters
+    parts = partition_clusters(full, world) if parts is None else parts
+    mine = parts[rank]
+    if not mine:
+        raise ValueError(f"rank {rank} of {world} holds no cluster: use at most {full.n_clusters} ranks")
+    shard = shard_clusters(full, mine)
+    blocks = [b for b in range(full.n_blocks) if int(full.block_cluster[b]) in set(mine)]
+    info = dict(rows_global=int(np.sum(full.block_n)), clusters_global=int(full.n_clusters),
+                cluster_ids=np.asarray(mine, dtype=np.int32), block_ids=np.asarray(blocks, dtype=np.int32))
+    return shard, info
+
+
 # ------------------------------------------------------------------------------------------------
 # solvesdp at the reference's precision, device resident (clrs_mw_ipm_*)
 # ------------------------------------------------------------------------------------------------
@@ -276,7 +318,7 @@ def solvesdp_mw(sdp, limbs: Optional[int] = None, prec: Optional[int] = None, ct
                 omega_p: float = 1e10, omega_d: float = 1e10, duality_gap_threshold: float = 1e-15,
                 dual_error_threshold: float = 1e-30, primal_error_threshold: float = 1e-30, max_complementary_gap: float = 1e100,
                 need_dual_feasible: bool = False, need_primal_feasible: bool = False, verbose: bool = False,
-                step_length_threshold: float = 1e-7, safe_step: bool = True, step_by_step: bool = False):
+                step_length_threshold: float = 1e-7, safe_step: bool = True, step_by_step: bool = False, shard_info: Optional[dict] = None):
     """`solvesdp(sdp; prec, ...)` (src/solver.jl:71-127) with the whole loop body on the GPU in multi-word fp64.
 
     Keywords and DEFAULTS are the reference's (omega = 1e10, gap 1e-15, errors 1e-30: they assume its 256-bit arithmetic):
@@ -300,6 +342,12 @@ def solvesdp_mw(sdp, limbs: Optional[int] = None, prec: Optional[int] = None, ct
     prm = _lib.IpmParams(beta_infeasible, beta_feasible, gamma, dual_error_threshold, primal_error_threshold, max_complementary_gap,
                          step_length_threshold, int(safe_step), 0)
     _lib.check(L.clrs_mw_ipm_set_params(ctx.h, C.byref(prm)))
+    if shard_info is not None:
+        # `sdp` is this rank's share of a cluster-sharded problem (shard_problem) and `ctx` carries the rank's communicators: every call
+        # below is collective; x, X, Y of the result are the shard's, y and every scalar are identical on all ranks
+        cid, bid = np.ascontiguousarray(shard_info["cluster_ids"], np.int32), np.ascontiguousarray(shard_info["block_ids"], np.int32)
+        _lib.check(L.clrs_mw_ipm_set_global(ctx.h, int(shard_info["rows_global"]), int(shard_info["clusters_global"]),
+                                            cid.ctypes.data_as(_lib.p_i32), bid.ctypes.data_as(_lib.p_i32)))
     _lib.check(L.clrs_mw_ipm_init(ctx.h, float(omega_p), float(omega_d)))
     rec = _lib.IpmRecord()
     hist = []

@@ -333,6 +333,16 @@ int clrs_comm_unique_id(void *id128);                                     /* ncc
 int clrs_mw_set_shard(clrs_mw_ctx *ctx, int rank, int world);
 int clrs_mw_comm_init(clrs_mw_ctx *ctx, const void *id128, int rank, int world);   /* clrs_mw_set_shard + ncclCommInitRank */
 int clrs_mw_comm_destroy(clrs_mw_ctx *ctx);
+/* The interior-point iteration of a sharded context (clrs_mw_ipm_*) exchanges on two streams: a second communicator (a second unique
+ * id, same rank and world) serves its side stream. */
+int clrs_mw_comm_init_side(clrs_mw_ctx *ctx, const void *id128);
+/* In-process stand-in for the communicators: `world` contexts of ONE process on ONE device, each driven by its own host thread (a
+ * collective call blocks until every rank of the group has issued it).  For tests on a single GPU (RCCL refuses two ranks on one
+ * device); the exchange is the same all-gather into rank-ordered slots. */
+typedef struct clrs_mw_local_group clrs_mw_local_group;
+int clrs_mw_local_group_create(int world, int device, clrs_mw_local_group **out);
+void clrs_mw_local_group_destroy(clrs_mw_local_group *group);
+int clrs_mw_comm_init_local(clrs_mw_ctx *ctx, clrs_mw_local_group *group, int rank);
 int clrs_mw_schur_factor_local_dev(clrs_mw_ctx *ctx);                     /* L_j, LinvB_j, partial Q into slot `rank` */
 double *clrs_mw_q_gather_dev(clrs_mw_ctx *ctx);                           /* [world][limbs * N * N] */
 int clrs_mw_schur_factor_finish_dev(clrs_mw_ctx *ctx);                    /* Q = sum of the slots, Cholesky of Q */
@@ -360,6 +370,13 @@ int clrs_mw_ipm_set(clrs_mw_ctx *ctx, const double *x, const double *y, const do
 int clrs_mw_ipm_iterate(clrs_mw_ctx *ctx, clrs_ipm_record *out);
 int clrs_mw_ipm_get(clrs_mw_ctx *ctx, double *x, double *y, double *X, double *Y);
 int clrs_mw_ipm_objectives(clrs_mw_ctx *ctx, double *out /* [3 * limbs]: d_obj, p_obj, gap */);
+/* Cluster-sharded iteration (one context per rank, each created from its own clusters and ALL free variables): the scalars that are sums,
+ * maxima or minima over all clusters -- mu (src/solver.jl:369), the errors (:441-442), p = +-b - B^T x (:899-916), beta_c (:429), the step
+ * lengths (:1684-1686), the objectives (:793-804) -- travel as one small record per rank and stage through all-gathers the library issues
+ * itself and are reduced in rank order by every rank: x, X, Y stay sharded, y and every scalar are bit-identical on all ranks.  This call
+ * supplies what a rank cannot know: the row count of X over all clusters, the cluster count of the whole problem, and the global numbers
+ * (0-based) of its clusters / PSD blocks for failure codes (NULL: local numbers). */
+int clrs_mw_ipm_set_global(clrs_mw_ctx *ctx, int rows_of_X_global, int clusters_global, const int32_t *cluster_ids, const int32_t *block_ids);
 /* The whole loop with its termination test (src/solver.jl:348-589, 921-950) in one call: at most max_iterations iterations from the
  * current iterate, enqueued one ahead of the record the host waits for (the device evaluates the same test and freezes the iterate once
  * it holds, so the device never idles between iterations).  records[i] (i < max_records) = table row of the i-th iteration of this call;

@@ -627,3 +627,71 @@ def test_one_call_loop_equals_the_step_by_step_loop():
     for kw in (dict(need_primal_feasible=True), dict(need_dual_feasible=True)):
         u, v = solvesdp_mw(f, limbs=5, **kw), solvesdp_mw(f, limbs=5, step_by_step=True, **kw)
         assert u.iterations == v.iterations and np.array_equal(u.history, v.history) and np.array_equal(u.X, v.X)
+
+
+
+def _solve_sharded_in_threads(full, world, K=5, **kw):
+    """`world` ranks of one process on one GPU, one thread each, exchanging through the in-process group: the whole sharded solve."""
+    import threading
+    from clrs_amd.mw import LocalGroup, MwSchurContext, shard_problem, solvesdp_mw
+    group = LocalGroup(world)
+    out, err = [None] * world, [None] * world
+
+    def run(rank):
+        try:
+            shard, info = shard_problem(full, rank, world)
+            ctx = MwSchurContext(shard, limbs=K)
+            ctx.comm_init_local(group, rank)
+            out[rank] = (solvesdp_mw(shard, ctx=ctx, shard_info=info, **kw), info)
+            ctx.close()
+        except Exception as e:          # a failing rank must not leave the others waiting in a collective: nothing to do but report
+            err[rank] = e
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert all(e is None for e in err), err
+    assert all(o is not None for o in out)
+    group.close()
+    return out
+
+
+@pytest.mark.parametrize("which,world", [("multi3", 2), ("ns3", 2), ("ns3", 3)])
+def test_sharded_interior_point_solve_on_one_gpu(which, world, oracle_built):
+    """SURVEY.md section 8e, third row: a whole interior-point solve with the clusters sharded over `world` ranks (here: contexts of one
+    process, one thread each, the all-gathers through the in-process group -- the same slots and the same rank-order reductions the RCCL
+    path uses).  mu, the errors, p, beta_c, the step lengths and the objectives are reduced over the ranks inside the library; every rank
+    ends with bit-identical y, objectives and table rows, and the solve agrees with the unsharded one (whose sums run in block order,
+    not in rank order: the last bits differ).  `ns3` = Nsphere_packing(8, 15, [1/2, 1/2, 1/2]) with its 11 = N(N+1)/2 + N + 2 clusters
+    (BASELINE config 3: "many small clusters sharded"), pinned like the N = 2 instance to pi^4/384 (test/runtests_solver.jl:21-22)."""
+    import clrs_amd
+    from clrs_amd.mw import solvesdp_mw
+    from clrs_amd.problems import cohnelkies_multi, nsphere_packing
+    from clrs_amd.sharded import partition_clusters
+    if which == "multi3":
+        full = clrs_amd.flatten(cohnelkies_multi(8, 15, [1.0, 1.125, 1.25]))
+    else:
+        full = clrs_amd.flatten(nsphere_packing(8, 15, [0.5, 0.5, 0.5]))
+        assert full.n_clusters == 11
+    parts = partition_clusters(full, world)
+    assert sorted(j for p in parts for j in p) == list(range(full.n_clusters)) and all(parts)
+    K = 5 if which == "multi3" else 6          # the reference runs Nsphere_packing at prec = 300 (test/runtests_solver.jl:21): 6 limbs; 5 end NearOptimal
+    ref = solvesdp_mw(full, limbs=K)
+    assert ref.error_code == 0 and ref.status == "Optimal", (ref.status, ref.error_code, ref.iterations, ref.duality_gap)
+    if which == "ns3":
+        assert abs(ref.primal_objective - PI4_384) <= 1e-4
+    res = _solve_sharded_in_threads(full, world, K=K)
+    r0 = res[0][0]
+    assert r0.error_code == 0 and r0.status == "Optimal", (r0.status, r0.error_code)
+    for r, _ in res[1:]:
+        assert np.array_equal(r.y, r0.y) and np.array_equal(r.history, r0.history)
+        assert np.array_equal(r.timings["objectives_limbs"], r0.timings["objectives_limbs"])
+    assert r0.iterations == ref.iterations
+    assert abs(r0.primal_objective - ref.primal_objective) <= 1e-12 * max(1.0, abs(ref.primal_objective))
+    assert np.allclose(r0.history[:, [1, 8, 9]], ref.history[:, [1, 8, 9]], rtol=1e-9, atol=0)
+    # the shards' x, X, Y are the unsharded solution's rows / blocks
+    for r, info in res:
+        cols = np.concatenate([np.arange(int(full.block_off[b]), int(full.block_off[b + 1])) for b in info["block_ids"]])
+        rows = np.concatenate([np.arange(int(full.cluster_off[j]), int(full.cluster_off[j + 1])) for j in info["cluster_ids"]])
+        assert np.allclose(r.Y[0], ref.Y[0][cols], rtol=1e-9, atol=1e-300) and np.allclose(r.x[0], ref.x[0][rows], rtol=1e-7, atol=1e-300)
