@@ -241,17 +241,20 @@ static bool gemm_prefers_large_tiles(const GemmDesc &d) {
 }
 static int add_gemm_stage(clrs_ctx *c, Plan &pl, const std::vector<GemmDesc> &descs) {
     // tile size per product: gemm_prefers_large_tiles
-    for (int var = 7; var >= 0; var--) {                       // one launch per (tile size, transposes): template parameters of the kernel
-        const int big = var >> 2, vta = (var >> 1) & 1, vtb = var & 1;
+    for (int var = 11; var >= 0; var--) {                      // one launch per (tile size / offset width, transposes): template parameters of the kernel
+        const int cls = var >> 2, vta = (var >> 1) & 1, vtb = var & 1;          // class 0: 64 x 64 tiles, 1: 128 x 128, 2: 64 x 64 with 64-bit offsets
+        const int big = cls == 1;
         const int BM = big ? 128 : GEMM_BM, BN = big ? 128 : GEMM_BN;
         std::vector<GemmDesc> ds;
         std::vector<GemmTile> tiles;
         for (const GemmDesc &d : descs) {
             if (d.M <= 0 || d.N <= 0) continue;
-            // the kernel addresses a tile's operands by 32-bit byte offsets from the tile's origin: at most 128 leading dimensions
-            if ((long long)std::max(d.lda, d.ldb) * 128 * 8 >= (1ll << 32)) return fail(CLRS_ERR_INVALID, "leading dimension beyond 4 M doubles in a staged product");
-            const bool is_big = gemm_prefers_large_tiles(d);
-            if (is_big != (big == 1) || (d.ta != 0) != (vta == 1) || (d.tb != 0) != (vtb == 1)) continue;
+            // the kernel addresses a tile's operands by 32-bit byte offsets from the tile's origin (gemm_offsets_reach): a product whose
+            // leading dimensions are beyond the reach of the large tile takes the small one, beyond that the 64-bit instantiation
+            int want = gemm_prefers_large_tiles(d) ? 1 : 0;
+            if (want == 1 && !gemm_offsets_reach(d, 128)) want = 0;
+            if (want == 0 && !gemm_offsets_reach(d, 64)) want = 2;
+            if (want != cls || (d.ta != 0) != (vta == 1) || (d.tb != 0) != (vtb == 1)) continue;
             int id = (int)ds.size();
             ds.push_back(d);
             int tm = (d.M + BM - 1) / BM, tn = (d.N + BN - 1) / BN;
@@ -272,7 +275,7 @@ static int add_gemm_stage(clrs_ctx *c, Plan &pl, const std::vector<GemmDesc> &de
         Step s;
         s.kind = STEP_GEMM;
         s.grid = (int)tiles.size();
-        s.nmax = big; s.aux0 = vta * 2 + vtb;
+        s.nmax = cls; s.aux0 = vta * 2 + vtb;
         GemmDesc *dd; GemmTile *dt;
         int rc;
         if ((rc = upload(c, ds, &dd))) return rc;
@@ -611,7 +614,13 @@ static int run_steps(clrs_ctx *c, const Plan &pl) {
             case STEP_GEMM:
 #define CLRS_GEMM_LAUNCH(BMN, TA, TB) \
     hipLaunchKernelGGL((k_gemm_f64_t<BMN, BMN, TA, TB>), dim3(s.grid), dim3(256), gemm_lds_bytes(BMN, BMN), st, (const GemmDesc *)s.d0, (const GemmTile *)s.d1)
-                switch ((s.nmax ? 4 : 0) + s.aux0) {
+#define CLRS_GEMM_LAUNCH_WIDE(TA, TB) \
+    hipLaunchKernelGGL((k_gemm_f64_t<64, 64, TA, TB, unsigned long long>), dim3(s.grid), dim3(256), gemm_lds_bytes(64, 64), st, (const GemmDesc *)s.d0, (const GemmTile *)s.d1)
+                switch (s.nmax * 4 + s.aux0) {
+                    case 8: CLRS_GEMM_LAUNCH_WIDE(0, 0); break;
+                    case 9: CLRS_GEMM_LAUNCH_WIDE(0, 1); break;
+                    case 10: CLRS_GEMM_LAUNCH_WIDE(1, 0); break;
+                    case 11: CLRS_GEMM_LAUNCH_WIDE(1, 1); break;
                     case 0: CLRS_GEMM_LAUNCH(64, 0, 0); break;
                     case 1: CLRS_GEMM_LAUNCH(64, 0, 1); break;
                     case 2: CLRS_GEMM_LAUNCH(64, 1, 0); break;
@@ -622,6 +631,7 @@ static int run_steps(clrs_ctx *c, const Plan &pl) {
                     default: CLRS_GEMM_LAUNCH(128, 1, 1); break;
                 }
 #undef CLRS_GEMM_LAUNCH
+#undef CLRS_GEMM_LAUNCH_WIDE
                 break;
             case STEP_TRSM:
                 hipLaunchKernelGGL(k_trsm_diag, dim3(s.grid), dim3(256), 0, st, (const TrsmDesc *)s.d0, (const TrsmWork *)s.d1);
@@ -971,6 +981,13 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
         } else {
             for (i64 e = k.d0; e < k.d1; e++) {
                 if (d->dense_A_ptr[e + 1] - d->dense_A_ptr[e] != (i64)k.n * k.n) { clrs_ctx_destroy(c); return fail(CLRS_ERR_INVALID, "dense matrix has the wrong size"); }
+                {   // the dense branch forms <A_i, X^-1 A_k Y> from lower tiles and transposed stores (k_dense_T32, pairing_tri): A_p must be
+                    // symmetric, as the reference's constructor makes it (src/interface.jl:1010-1017 symmetrises a non-symmetric entry)
+                    const double *Ae = d->dense_A + d->dense_A_ptr[e];
+                    for (int cc = 0; cc < k.n; cc++)
+                        for (int rr = cc + 1; rr < k.n; rr++)
+                            if (Ae[rr + (i64)cc * k.n] != Ae[cc + (i64)rr * k.n]) { clrs_ctx_destroy(c); return fail(CLRS_ERR_INVALID, "dense constraint matrices must be symmetric"); }
+                }
                 std::memcpy(h_static.data() + k.w_off + (e - k.d0) * (i64)k.n * k.n, d->dense_A + d->dense_A_ptr[e], sizeof(double) * k.n * k.n);
             }
         }

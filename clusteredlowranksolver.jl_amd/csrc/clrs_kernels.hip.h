@@ -62,7 +62,10 @@ constexpr int gemm_padk(int BM) { return BM <= 64 ? 8 : 16; }
 // selects of the staging maps) and the matrix pipe busy 48 % of the time: one wave per SIMD issues in order, so whatever it spends on
 // address arithmetic the matrix pipe waits.  Rows / columns beyond M / N are read from a clamped address and never stored; only the
 // last, partial chunk of k is zero filled.
-template <int BM, int BN, int TA, int TB>
+// OFF = unsigned: the 32-bit per-lane byte offsets described below (every product whose operands they reach: gemm_offsets_reach);
+// OFF = unsigned long long: the same kernel with 64-bit offsets (a vector add per load) for leading dimensions beyond that -- the Gram
+// product of a dense block with n >= 2048 has lda = ldb = n^2.
+template <int BM, int BN, int TA, int TB, typename OFF = unsigned>
 __global__ __launch_bounds__(256, (BM <= 64 ? 4 : 2)) void k_gemm_f64_t(const GemmDesc *__restrict__ descs, const GemmTile *__restrict__ tiles) {
     // small tiles: a [k][i] stride of BM + 8 keeps a workgroup at 36 KB of LDS, so that FOUR of them share a compute unit: a grouped
     // launch of 1024 tiles (the Gram contractions of the dense branch) then runs in one round instead of one and a third
@@ -96,17 +99,17 @@ __global__ __launch_bounds__(256, (BM <= 64 ? 4 : 2)) void k_gemm_f64_t(const Ge
     // wait for an MFMA operand read waited for the prefetch of the next chunk as well.
     typedef const char __attribute__((address_space(1))) *gbytes_t;
     typedef const double __attribute__((address_space(1))) *gdouble_t;
-    unsigned oa[EA], ob[EB];
+    OFF oa[EA], ob[EB];
     const long long lda = d.lda, ldb = d.ldb;
 #pragma unroll
     for (int q = 0; q < EA; q++) {
         const int e = tid + 256 * q, i = TA == 0 ? e % BM : e / BK, k = TA == 0 ? e / BM : e % BK, ic = min(i, d.M - 1 - m0);
-        oa[q] = (unsigned)(TA == 0 ? ic + k * lda : k + ic * lda) * 8u;
+        oa[q] = (OFF)(TA == 0 ? ic + k * lda : k + ic * lda) * (OFF)8;
     }
 #pragma unroll
     for (int q = 0; q < EB; q++) {
         const int e = tid + 256 * q, j = TB == 0 ? e / BK : e % BN, k = TB == 0 ? e % BK : e / BN, jc = min(j, d.N - 1 - n0);
-        ob[q] = (unsigned)(TB == 0 ? k + jc * ldb : jc + k * ldb) * 8u;
+        ob[q] = (OFF)(TB == 0 ? k + jc * ldb : jc + k * ldb) * (OFF)8;
     }
     const gbytes_t Ag = (gbytes_t)(A + (TA == 0 ? (long long)m0 : m0 * lda)), Bg = (gbytes_t)(B + (TB == 0 ? n0 * ldb : (long long)n0));
     double *const sa = As + (TA == 0 ? (tid / BM) * LDA_S + tid % BM : (tid / BK) * LDT + tid % BK);     // element q: + q * SQA
@@ -217,6 +220,12 @@ __global__ __launch_bounds__(256, (BM <= 64 ? 4 : 2)) void k_gemm_f64_t(const Ge
                     *p = d.beta == 0.0 ? v : v + d.beta * *p;
                 }
             }
+}
+// true if the 32-bit byte offsets of a BM x BN tile reach every element of both operands: an operand walked along k inside the tile spans
+// BK leading dimensions, one walked along the tile's rows / columns BM (BN) of them
+static inline bool gemm_offsets_reach(const GemmDesc &d, int BMN) {
+    const long long ra = (d.ta == 0 ? (long long)GEMM_BK : (long long)BMN) * d.lda, rb = (d.tb == 0 ? (long long)BMN : (long long)GEMM_BK) * d.ldb;
+    return (ra + BMN) * 8 < (1ll << 32) && (rb + BMN) * 8 < (1ll << 32);
 }
 constexpr size_t gemm_lds_bytes(int BM, int BN) { return (size_t)2 * GEMM_BK * ((BM + gemm_padk(BM)) + (BN + gemm_padk(BM))) * sizeof(double); }
 

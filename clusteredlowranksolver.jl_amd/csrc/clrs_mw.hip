@@ -203,8 +203,8 @@ extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int dev
     int rc = 0;
 #define MW_BAIL(code, msg) do { clrs_mw_destroy(c); return mw_fail(code, msg); } while (0)
 #define MW_TRY(call) do { if ((rc = (call))) { clrs_mw_destroy(c); return rc; } } while (0)
-    MWCHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    MWCHECK(hipHostMalloc((void **)&c->h_info, 2 * sizeof(int), hipHostMallocDefault));
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) MW_BAIL(CLRS_ERR_HIP, "hipStreamCreateWithFlags failed");
+    if (hipHostMalloc((void **)&c->h_info, 2 * sizeof(int), hipHostMallocDefault) != hipSuccess) MW_BAIL(CLRS_ERR_HIP, "hipHostMalloc failed");
     // ---- clusters ----
     c->clu.resize(J);
     i64 xlen = 0, Slen = 0;
@@ -342,6 +342,12 @@ extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int dev
                 const int p = d->dense_p[e];
                 if (p < 0 || p >= P) MW_BAIL(CLRS_ERR_INVALID, "dense constraint index out of range");
                 if (d->dense_A_ptr[e + 1] - d->dense_A_ptr[e] != (i64)n * n) MW_BAIL(CLRS_ERR_INVALID, "dense matrix must have n*n entries");
+                for (int l = 0; l < DK; l++) {          // symmetric, as the reference's constructor makes them (src/interface.jl:1010-1017)
+                    const double *Ae = d->dense_A + (i64)l * dA_plane + d->dense_A_ptr[e];
+                    for (int cc = 0; cc < n; cc++)
+                        for (int rr = cc + 1; rr < n; rr++)
+                            if (Ae[rr + (i64)cc * n] != Ae[cc + (i64)rr * n]) MW_BAIL(CLRS_ERR_INVALID, "dense constraint matrices must be symmetric");
+                }
                 hdmap[k.dmap_off + p] = (int)(e - d0);
                 drow_pairs.push_back(std::make_tuple(c->clu[k.j].coff + p, b, (int)(e - d0)));
                 for (int l = 0; l < DK; l++)
@@ -776,6 +782,7 @@ extern "C" int clrs_mw_schur_factor_local_dev(clrs_mw_ctx *c) {
     MWCHECK(hipGetLastError());
     c->local_factored = true;
     c->factored = false;
+    c->assembled = false;                       // S now holds L_j: a second factorisation needs a new assembly (as the fp64 entry point)
     return 0;
 }
 // after the gather buffer holds every rank's partial Q: Q = their sum, Cholesky of Q (redundantly on every rank)

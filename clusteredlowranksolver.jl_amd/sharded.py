@@ -230,3 +230,68 @@ class ShardedSchur:
     def close(self):
         if hasattr(self.local, "close"):
             self.local.close()
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# Host-side mirror of the scalar exchanges of the sharded interior-point iteration (csrc/clrs_mw_ipm.hip.h: MWG_*, k_mwi_gpack, mwi_gsum;
+# csrc/clrs_mw_ipm_host.inc: mw_ipm_exchange).  The product runs them inside the C ABI on RCCL (or its in-process group); this mirror
+# states the protocol -- slot layout, which stream's channel carries which stage, all-gather into rank-ordered slots, reduction in rank
+# order -- in a form the CPU tests can drive over `gloo` and check against the C++ sources.
+# ------------------------------------------------------------------------------------------------------------------------------------
+IPM_EXCHANGE_SCHEDULE = (            # (scalar stage, stream) in issue order within one iteration; "S" = side stream, "M" = the context's stream
+    (4, "S"),                        # objectives of the previous iterate (the tail of the previous iteration leads this one's side work)
+    (0, "S"),                        # <X,Y> -> mu                                                  src/solver.jl:369
+    (1, "S"),                        # -B^T x, max|P|, max|d| -> p, errors                          :899-916, 441-442
+    (2, "M"),                        # <X,dY> + <dX,Y> + <dX,dY>, status words -> beta_c            :429-434
+    (3, "M"),                        # smallest eigenvalues -> step lengths                         :1684-1686
+)
+
+
+def ipm_slot_layout(K: int, N: int) -> dict:
+    """Offsets (in doubles) of one rank's record: S1, S2 K-limb sums, BX = K x N planar limbs, D = 8 plain doubles; LEN = slot length."""
+    return dict(S1=0, S2=K, BX=2 * K, D=2 * K + K * N, LEN=2 * K + K * N + 8)
+
+
+class ScalarExchange:
+    """One rank's view of the exchange: `gather(slot)` all-gathers the rank's record into rank-ordered slots (torch.distributed on the
+    given group, any backend), the `reduce_*` functions fold the slots in RANK ORDER, so every rank computes identical bits."""
+
+    def __init__(self, K: int, N: int, rank: int, world: int, group=None):
+        self.K, self.N, self.rank, self.world, self.group = K, N, rank, world, group
+        self.lay = ipm_slot_layout(K, N)
+
+    def new_slot(self) -> np.ndarray:
+        return np.zeros(self.lay["LEN"])
+
+    def gather(self, slot: np.ndarray) -> np.ndarray:
+        import torch
+        import torch.distributed as dist
+        mine = torch.from_numpy(np.ascontiguousarray(slot, dtype=np.float64))
+        out = [torch.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(out, mine, group=self.group)
+        return np.stack([t.numpy() for t in out])
+
+    def reduce_sum(self, slots: np.ndarray, field: str, count: int = 1) -> np.ndarray:
+        """Sum over the ranks, in rank order, of `count` K-limb numbers stored planar at `field` (limb l of number i at off + l * count + i);
+        returned as exact sums of the limbs rounded once to fp64 per number (the device keeps K limbs; the order is what matters here)."""
+        import math
+        off, K = self.lay[field], self.K
+        out = np.zeros(count)
+        for i in range(count):
+            terms = []
+            for r in range(self.world):                      # rank order
+                terms += [slots[r, off + l * count + i] for l in range(K)]
+            out[i] = math.fsum(terms)
+        return out
+
+    def reduce_max(self, slots: np.ndarray, index: int) -> float:
+        v = 0.0
+        for r in range(self.world):
+            v = max(v, float(slots[r, self.lay["D"] + index]))
+        return v
+
+    def reduce_min(self, slots: np.ndarray, index: int) -> float:
+        v = float(slots[0, self.lay["D"] + index])
+        for r in range(1, self.world):
+            v = min(v, float(slots[r, self.lay["D"] + index]))
+        return v

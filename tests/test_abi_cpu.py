@@ -105,3 +105,80 @@ def test_julia_shim_struct_and_symbols_match_the_header():
     declared = set(header_symbols())
     used = set(re.findall(r":(clrs_[a-zA-Z0-9_]+)", jl))
     assert used and used <= declared, used - declared
+
+
+# ---- every ccall of the Julia package against the C prototypes of include/clrs_hip.h ------------------------------------------------
+def _c_prototypes():
+    txt = open(os.path.join(ROOT, "include", "clrs_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    protos = {}
+    for ret, name, args in re.findall(r"^\s*((?:const\s+)?\w+\s*\*?)\s*(clrs_\w+)\s*\(([^;{]*?)\)\s*;", txt, flags=re.M):
+        args = [a.strip() for a in args.split(",")] if args.strip() not in ("", "void") else []
+        protos[name] = (ret.strip(), args)
+    return protos
+
+
+def _julia_type_of(ctype):
+    """the Julia ccall type(s) a C parameter type may be bound with"""
+    t = re.sub(r"\b\w+\s*(\[\d*\])?$", lambda m: "*" if m.group(1) else "", ctype.strip()) if not ctype.strip().endswith("*") else ctype.strip()
+    t = re.sub(r"\s+", " ", t.replace("const ", "")).strip()
+    t = t.replace(" *", "*")
+    table = {
+        "int": {"Cint"}, "int32_t": {"Cint", "Int32"}, "double": {"Cdouble", "Float64"}, "void": {"Cvoid"},
+        "double*": {"Ptr{Float64}"}, "int*": {"Ptr{Cint}", "Ref{Cint}"}, "int32_t*": {"Ptr{Int32}", "Ptr{Cint}"}, "void*": {"Ptr{Cvoid}", "Ptr{UInt8}"},
+        "char*": {"Cstring"}, "clrs_ctx*": {"Ptr{Cvoid}"}, "clrs_mw_ctx*": {"Ptr{Cvoid}"}, "clrs_ctx**": {"Ref{Ptr{Cvoid}}"}, "clrs_mw_ctx**": {"Ref{Ptr{Cvoid}}"},
+        "clrs_sdp_desc*": {"Ref{SdpDesc}"}, "clrs_ipm_data*": {"Ref{IpmData}"}, "clrs_ipm_params*": {"Ref{IpmParams}"}, "clrs_ipm_record*": {"Ref{IpmRecord}"},
+    }
+    return table.get(t)
+
+
+def test_every_julia_ccall_matches_its_c_prototype():
+    """Argument count, argument types and return type of every `ccall` in julia/ClusteredLowRankHIP against the prototype of the symbol in
+    include/clrs_hip.h (the Julia package cannot be executed here: this is what keeps it from drifting)."""
+    protos = _c_prototypes()
+    jl = open(os.path.join(ROOT, "julia", "ClusteredLowRankHIP", "src", "ClusteredLowRankHIP.jl")).read()
+    calls = re.findall(r"ccall\(\(([^\n]*?),\s*lib(?:clrs\[\])?\),\s*(\w+),\s*\(([^()]*)\)", jl, flags=re.S)
+    assert len(calls) >= 15
+    checked = set()
+    for symexpr, ret, argt in calls:
+        syms = re.findall(r":(clrs_\w+)", symexpr)
+        assert syms, symexpr
+        jargs = [a.strip() for a in re.split(r",\s*(?![^{]*\})", argt.strip().rstrip(",")) if a.strip()]
+        for name in syms:
+            assert name in protos, name
+            cret, cargs = protos[name]
+            assert ret in (_julia_type_of(cret + " x") or _julia_type_of(cret) or set()), (name, ret, cret)
+            assert len(jargs) == len(cargs), (name, jargs, cargs)
+            for ja, ca in zip(jargs, cargs):
+                allowed = _julia_type_of(ca)
+                assert allowed is not None, (name, ca)
+                assert ja in allowed, (name, ja, ca)
+            checked.add(name)
+    for must in ("clrs_mw_create_ex", "clrs_mw_schur_assemble", "clrs_mw_schur_factor", "clrs_mw_get_factor", "clrs_mw_schur_solve", "clrs_mw_ipm_create_ex",
+                 "clrs_mw_ipm_set_params", "clrs_mw_ipm_init", "clrs_mw_ipm_iterate", "clrs_mw_ipm_get"):
+        assert must in checked, must
+
+
+def test_julia_ipm_structs_match_the_header():
+    hdr = open(os.path.join(ROOT, "include", "clrs_hip.h")).read()
+    jl = open(os.path.join(ROOT, "julia", "ClusteredLowRankHIP", "src", "ClusteredLowRankHIP.jl")).read()
+    for cname, jname in (("clrs_ipm_data", "IpmData"), ("clrs_ipm_params", "IpmParams"), ("clrs_ipm_record", "IpmRecord")):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), hdr, flags=re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        c_fields = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            m = re.match(r"(const\s+)?(int32_t|int64_t|double)\s*(\*)?\s*(.*)$", decl, flags=re.S)
+            assert m, decl
+            for nm in m.group(4).split(","):
+                c_fields.append((nm.strip().lstrip("*").strip(), m.group(2), bool(m.group(3)) or nm.strip().startswith("*")))
+        jbody = re.search(r"struct %s\n(.*?)\nend" % jname, jl, flags=re.S).group(1)
+        j_fields = []
+        for line in jbody.strip().splitlines():
+            name, typ = [t.strip() for t in line.split("::")]
+            ptr = typ.startswith("Ptr{")
+            base = typ[4:-1] if ptr else typ
+            j_fields.append((name, {"Int32": "int32_t", "Int64": "int64_t", "Float64": "double"}[base], ptr))
+        assert j_fields == c_fields, (cname, j_fields, c_fields)

@@ -40,6 +40,32 @@ def test_gemm_kernel(ta, tb, M, N, K):
     assert np.max(np.abs(Cf - ref)) <= 1e-12 * max(1.0, np.max(np.abs(ref)))
 
 
+@pytest.mark.parametrize("which", ["A", "B"])
+def test_gemm_kernel_with_a_leading_dimension_beyond_32_bit_offsets(which):
+    """The staged GEMM addresses a tile's operands by 32-bit byte offsets (64 or 128 leading dimensions of reach); the Gram product of a
+    dense block with n >= 2048 has lda = ldb = n^2 >= 2^22.  Products beyond the reach of the large tile take the small one, beyond that
+    the 64-bit-offset instantiation -- instead of failing the whole context (round-2 behaviour).  Here ld = 2^23 + 16 on the operand that
+    is walked along the tile (A transposed: K x M; B as stored: K x N), 64 ld doubles = 4.3 GB of reach needed."""
+    ld = (1 << 23) + 16
+    M, N, K = 5, 7, 100
+    rng = np.random.default_rng(11 + (which == "B"))
+    ta = 1 if which == "A" else 0
+    if which == "A":
+        Af = np.zeros((ld, M), order="F"); Af[:K, :] = rng.standard_normal((K, M))
+        opA = Af[:K, :].T
+        Bf = np.asfortranarray(rng.standard_normal((K, N))); opB = Bf
+    else:
+        Af = np.asfortranarray(rng.standard_normal((M, K))); opA = Af
+        Bf = np.zeros((ld, N), order="F"); Bf[:K, :] = rng.standard_normal((K, N))
+        opB = Bf[:K, :]
+    C = rng.standard_normal((M, N))
+    ref = 0.7 * opA @ opB - 0.3 * C
+    Cf = np.asfortranarray(C)
+    rc = _lib().clrs_test_gemm(0, ta, 0, M, N, K, 0.7, _dp(Af), Af.shape[0], _dp(Bf), Bf.shape[0], -0.3, _dp(Cf), M)
+    assert rc == 0
+    assert np.max(np.abs(Cf - ref)) <= 1e-12 * max(1.0, np.max(np.abs(ref)))
+
+
 @pytest.mark.parametrize("n", [1, 2, 17, 64, 65, 150, 300, 513, 600, 1100])
 def test_potrf_and_trsm(n):
     """n > 512: the triangular solves run through inverted 512 x 512 diagonal blocks (plan_trsm_blockinv), with ragged last blocks."""
@@ -800,6 +826,18 @@ def test_malformed_descriptions_are_rejected():
     with pytest.raises(ClrsError, match="before clrs_schur_assemble"):
         ctx.factor()
     ctx.close()
+    # a dense constraint matrix that is not symmetric: the dense branch forms lower tiles and transposed stores only (both paths)
+    import copy
+    from clrs_amd.mw import MwSchurContext
+    g = copy.copy(flat("sdpa_small"))
+    g.dense_A = g.dense_A.copy()
+    n = int(g.block_n[0])
+    g.dense_A[1] += 0.5                            # entry (1, 0) of the first matrix, not its mirror
+    assert n > 1
+    with pytest.raises(ClrsError, match="must be symmetric"):
+        SchurContext(g)
+    with pytest.raises(ClrsError, match="must be symmetric"):
+        MwSchurContext(g, limbs=3)
 
 
 # ---- BASELINE configs 4 and 5 at their named sizes ---------------------------------------------------------------------------

@@ -141,3 +141,94 @@ def test_shard_clusters_roundtrip(oracle_built):
         Sg, AYg = Oracle(g).schur_assemble(Xs, Ys)
         assert np.array_equal(Sg, np.concatenate([S[f.S_off[j]:f.S_off[j + 1]] for j in cl]))
         assert np.array_equal(AYg, np.concatenate([AY[f.term_ptr[b]:f.term_ptr[b + 1]] for b in bl]))
+
+
+# ---- the scalar exchanges of the sharded interior-point iteration (clrs_mw_ipm_*): protocol mirror over gloo -------------------------
+def test_exchange_mirror_matches_the_cpp_sources():
+    """The slot layout and the issue order of clrs_amd.sharded.ScalarExchange / IPM_EXCHANGE_SCHEDULE are those of the C++ path: the MWG_*
+    macros of clrs_mw_ipm.hip.h and the mw_ipm_exchange calls of clrs_mw_ipm_host.inc (stage, stream) in source order."""
+    import re
+    from clrs_amd.sharded import IPM_EXCHANGE_SCHEDULE, ipm_slot_layout
+    csrc = os.path.join(ROOT, "clusteredlowranksolver.jl_amd", "csrc")
+    hdr = open(os.path.join(csrc, "clrs_mw_ipm.hip.h")).read()
+    mac = dict(re.findall(r"#define MWG_(\w+)\(K, N\) (.*?)\s+/\*", hdr))
+    mac["LEN"] = re.search(r"#define MWG_LEN\(K, N\) (.*)", hdr).group(1)
+    for K, N in ((5, 31), (6, 193), (2, 0)):
+        lay = ipm_slot_layout(K, N)
+        env = {"K": K, "N": N}
+        env["MWG_D"] = lambda k, n: eval(mac["D"].replace("(K)", str(k)).replace("(N)", str(n)))
+        for name in ("S1", "S2", "BX", "D"):
+            assert eval(mac[name].replace("(K)", str(K)).replace("(N)", str(N))) == lay[name], name
+        assert eval(mac["LEN"].replace("MWG_D(K, N)", str(lay["D"]))) == lay["LEN"]
+    inc = open(os.path.join(csrc, "clrs_mw_ipm_host.inc")).read()
+    body = inc[inc.index("static int mw_ipm_enqueue"):inc.index("static int mw_ipm_finish")]
+    calls = [(int(s_), st) for st, s_ in re.findall(r"mw_ipm_exchange\(c, (S|M), (\d)\)", body)]
+    # the objectives' exchange (stage 4) is issued by mw_ipm_objectives on the stream of mw_ipm_tail: the side stream, at the head of enqueue
+    assert "mw_ipm_exchange(c, stream, 4)" in inc and "mw_ipm_objectives(c, st->side)" in inc
+    assert [(4, "S")] + calls == list(IPM_EXCHANGE_SCHEDULE)
+
+
+def _exchange_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    import clrs_amd  # noqa: F401
+    from clrs_amd.sharded import IPM_EXCHANGE_SCHEDULE, ScalarExchange, partition_clusters
+    from tests.util import flat, mw_with_tails, spd_iterates
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        f = flat("ns_8_3_2")
+        K, N = 3, f.n_free
+        mine = partition_clusters(f, world)[rank]
+        X, Y = spd_iterates(f, seed=5)
+        x = np.random.default_rng(6).standard_normal(f.x_len)
+        B = np.zeros((f.x_len, N))
+        for j in range(f.n_clusters):
+            P = int(f.cluster_P[j]); o = int(f.cluster_off[j])
+            B[o:o + P] = f.B[o * N:(o + P) * N].reshape(P, N, order="F")
+        ex = ScalarExchange(K, N, rank, world)
+        got = {}
+        for stage, stream in IPM_EXCHANGE_SCHEDULE:          # both channels are one gloo group here; the ORDER is what is exercised
+            slot = ex.new_slot()
+            if stage == 0:                                   # <X,Y> over this rank's blocks, as K limbs
+                s = sum(float(X[f.block_off[b]:f.block_off[b + 1]] @ Y[f.block_off[b]:f.block_off[b + 1]]) for b in range(f.n_blocks) if int(f.block_cluster[b]) in mine)
+                slot[ex.lay["S1"]:ex.lay["S1"] + K] = mw_with_tails(np.array([s]), K, seed=rank)[:, 0]
+            if stage == 1:                                   # -B^T x over this rank's rows (planar limbs), max|P| stand-in
+                rows = np.concatenate([np.arange(int(f.cluster_off[j]), int(f.cluster_off[j + 1])) for j in mine])
+                part = -(B[rows].T @ x[rows])
+                slot[ex.lay["BX"]:ex.lay["BX"] + K * N] = mw_with_tails(part, K, seed=10 + rank).reshape(-1)
+                slot[ex.lay["D"] + 0] = float(np.max(np.abs(x[rows])))
+            if stage == 3:
+                slot[ex.lay["D"] + 2] = -0.25 - rank
+            slots = ex.gather(slot)
+            assert slots.shape == (world, ex.lay["LEN"]) and np.array_equal(slots[rank], slot)
+            if stage == 0:
+                got["xy"] = ex.reduce_sum(slots, "S1")[0]
+            if stage == 1:
+                got["btx"] = ex.reduce_sum(slots, "BX", N)
+                got["maxP"] = ex.reduce_max(slots, 0)
+            if stage == 3:
+                got["eig"] = ex.reduce_min(slots, 2)
+        got["ref_xy"] = float(X @ Y)
+        got["ref_btx"] = -(B.T @ x)
+        ret[rank] = got
+    finally:
+        dist.destroy_process_group()
+
+
+def test_scalar_exchange_over_gloo_gives_identical_bits_on_every_rank():
+    """World size 2 over gloo: every rank packs its record of a stage, all-gathers, reduces the slots in rank order -- the values of mu's
+    numerator, of -B^T x and of the maxima / minima are bit-identical on both ranks and equal the single-process values to rounding."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        ret = mgr.dict()
+        procs = [ctx.Process(target=_exchange_worker, args=(r, 2, port, ret)) for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(180)
+            assert p.exitcode == 0
+        res = {k: dict(v) for k, v in ret.items()}
+    a, b = res[0], res[1]
+    assert a["xy"] == b["xy"] and np.array_equal(a["btx"], b["btx"]) and a["maxP"] == b["maxP"] and a["eig"] == b["eig"] == -1.25
+    assert abs(a["xy"] - a["ref_xy"]) <= 1e-12 * abs(a["ref_xy"])
+    assert np.allclose(a["btx"], a["ref_btx"], rtol=1e-12, atol=1e-12)
