@@ -370,7 +370,7 @@ def main():
             asm_s = 1e-3 * ev0.elapsed_time(ev1) / reps
             muladds = bctx.counters()["assemble_muladds"]
             flops_alg = muladds * K * (K + 1)
-            out["roofline_mw"] = {"bound": "mfma", "phase": "schur_assemble (multi-word)", "kernel": "k_mw_zt + k_mw_gram + k_mw_dense + k_mw_saccum + k_mw_ay",
+            out["roofline_mw"] = {"bound": "mfma", "phase": "schur_assemble (multi-word)", "kernel": "k_mws_pair (exact slice products, v_mfma_f64_16x16x4) + k_mw_dense_t + k_mw_saccum",
                                   "assembly_us": 1e6 * asm_s, "achieved": flops_alg / asm_s / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                                   "frac": flops_alg / asm_s / 1e12 / FP64_PEAK_TFLOPS, "traffic": None,
                                   "workload": f"{big.n_clusters} clusters / {big.n_blocks} PSD blocks of the cohnelkies(8,15) shapes in one assembly, {K} limbs",
@@ -385,12 +385,17 @@ def main():
             try:
                 pc = json.load(open(os.path.join(ROOT, "profiles", "mw_counters.json")))
                 if pc["limbs"] == K:
-                    wave_insts = pc["lane_instructions_per_muladd"] * muladds / 64.0
+                    scale = muladds / pc["algorithmic_muladds"]
+                    wave_insts = pc["valu_wave_instructions_total"] * scale
+                    mfma = sum(pc.get("mfma_wave_instructions", {}).values()) * scale
+                    pipe_cycles = (wave_insts - mfma) * 4.0 + mfma * 64.0        # an fp64 MFMA 16x16x4 holds the pipe for 16 passes, any other fp64 VALU instruction for one
                     out["roofline_mw"]["executed"] = {
                         "valu_lane_instructions_per_muladd": pc["lane_instructions_per_muladd"], "source": pc["source"],
-                        "valu_issue_utilisation": wave_insts * 4.0 / (1024 * 2.4e9 * asm_s),
-                        "what": "fraction of the fp64 VALU issue slots of the chip (1024 SIMDs, 4 cycles per fp64 wave instruction, 2.4 GHz) the assembly "
-                                "filled: the bound of this kernel family (v_fma_f64 / v_add_f64 and the fp64 MFMA share one pipe)"}
+                        "before_exact_products": pc.get("before_exact_products"),
+                        "fp64_pipe_utilisation": pipe_cycles / (1024 * 2.4e9 * asm_s),
+                        "what": "wave instructions per multiply-add from the committed counter pass (MFMAs included, one instruction each); share of the fp64 pipe "
+                                "cycles of the chip's 1024 SIMDs (4 per fp64 VALU instruction, 64 per v_mfma_f64_16x16x4, 2.4 GHz) the assembly filled -- the pairing "
+                                "matrices come from exact 23-bit slice products on the matrix cores (k_mws_pair), S_j from K-limb expansions (k_mw_saccum)"}
             except Exception as e:
                 out["roofline_mw"]["executed_error"] = repr(e)
             bctx.close()

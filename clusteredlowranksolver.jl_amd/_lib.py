@@ -124,6 +124,8 @@ SYMBOLS = {
     "clrs_mw_cholesky_blocks": (C.c_int, [C.c_void_p, p_d, p_d]),
     "clrs_mw_schur_assemble": (C.c_int, [C.c_void_p, p_d, p_d, p_d, p_d]),
     "clrs_mw_schur_factor": (C.c_int, [C.c_void_p]),
+    "clrs_mw_get_S": (C.c_int, [C.c_void_p, p_d, p_d]),
+    "clrs_mw_debug_exact_stamps": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "clrs_mw_get_factor": (C.c_int, [C.c_void_p, p_d, p_d, p_d]),
     "clrs_mw_schur_solve": (C.c_int, [C.c_void_p, p_d, p_d, p_d, p_d]),
     "clrs_mw_cholesky_blocks_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

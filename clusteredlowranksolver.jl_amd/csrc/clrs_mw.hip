@@ -23,6 +23,7 @@
 
 #include "../../include/clrs_hip.h"
 #include "clrs_mw_kernels.hip.h"
+#include "clrs_mw_exact.hip.h"
 #include "clrs_mw_ipm.hip.h"
 #include "clrs_mw_inst.h"
 #ifdef MW_SPLIT_UNITS        // the kernels of these limb counts are compiled in units of their own (clrs_mw_inst.hip)
@@ -35,6 +36,7 @@ MW_KERNELS_ALL(extern template, 10)
 
 typedef long long i64;
 
+extern int g_cfg_mw_exact_products;                      // clrs_hip.hip, clrs_config_set("mw_exact_products", 0 / 1 / 2): read at context creation
 extern "C" void clrs_set_last_error(const char *msg);   // clrs_hip.hip: the library keeps one thread-local message
 
 static int mw_fail(int code, const std::string &msg) {
@@ -121,6 +123,7 @@ struct clrs_mw_ctx {
     bool lds_x = false, lds_q = false, lds_zt_L = false, dense_two = false;
     int nw_factor = 1;                  // workgroups per cluster in k_mw_factor (they share out the columns of the inverse factor)
     int maxcnt = 0;
+    int sa_lanes = MW_SA_W;             // lanes per entry of k_mw_saccum: 1, 2 or 4 by the largest block count of a cluster
     int maxTb = 0;                      // most low-rank terms in one PSD block
     size_t sm_x = 0, sm_zt = 0, sm_dense = 0, sm_factor = 0, sm_q = 0, sm_fwd = 0, sm_mid = 0, sm_bwd = 0;
     int *h_info = nullptr;               // pinned
@@ -137,6 +140,10 @@ struct clrs_mw_ctx {
     void *comm_side = nullptr;           // a second communicator for the exchanges of the iteration's side stream (clrs_mw_comm_init_side)
     clrs_mw_local_group *lgroup = nullptr;   // or: the in-process group (clrs_mw_comm_init_local)
     bool local_factored = false, fwd_done = false;
+    MwsDev mws = {};                     // static V slices of the blocks the exact-product kernel takes
+    int mws_blocks = 0;                  // how many
+    int mws_turns = 1;                   // 2: some eligible block has more than four T / Z tiles
+    size_t sm_mws = 0;
     bool ipm_arms_info = false;          // inside the device-resident iteration the status words are re-armed by a kernel, not by a memset per call
 };
 
@@ -360,6 +367,11 @@ extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int dev
     }
     for (int j = 0; j < J; j++)
         if (c->clu[j].b0 > c->clu[j].b1) { c->clu[j].b0 = c->clu[j].b1 = 0; }
+    {
+        int mostb = 1;
+        for (int j = 0; j < J; j++) mostb = std::max(mostb, c->clu[j].b1 - c->clu[j].b0);
+        c->sa_lanes = mostb >= 3 ? 4 : mostb;
+    }
     c->cnt_mul = cnt_mul;
     for (int j = 0; j < J; j++) {
         const double P = c->clu[j].P;
@@ -412,8 +424,64 @@ extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int dev
         MW_TRY(mw_set_lds(k_mw_factor<KK>, c->sm_factor)); MW_TRY(mw_set_lds(k_mw_potrf_q<KK>, c->sm_q));
         MW_TRY(mw_set_lds(k_mw_solve_fwd<KK>, c->sm_fwd)); MW_TRY(mw_set_lds(k_mw_solve_mid<KK>, c->sm_mid)); MW_TRY(mw_set_lds(k_mw_solve_bwd<KK>, c->sm_bwd));
     });
+    // ---- exact-product path (clrs_mw_exact.hip.h): static slices of V of the eligible blocks ----
+    std::vector<long long> mws_off((size_t)std::max(NB, 1), -1);
+    {
+        const int S = mws_slices(K);
+        std::vector<float> hVs;
+        std::vector<int> hVe, hve_off((size_t)std::max(NB, 1), 0), hsv((size_t)std::max(NB, 1), 0);
+        for (int b = 0; b < NB; b++) {
+            const MwBlk &k = c->blk[b];
+            if (k.kind != 0 || !k.inv || k.n > 32) continue;
+            const int n = k.n, U = k.U, np = (n + 3) & ~3, n16 = (n + 15) & ~15, U16 = (U + 15) & ~15, rV = MWS_ROWPAD(U16);
+            if ((n16 / 16) * (U16 / 16) > 4 || mws_lds_bytes(S, n, U) > MW_LDS_MAX) continue;
+            if (2 * (n16 / 16) * (U16 / 16) > 4) c->mws_turns = 2;
+            mws_off[b] = (long long)hVs.size();
+            hve_off[b] = (int)hVe.size();
+            hVs.resize(hVs.size() + (size_t)S * np * rV, 0.0f);
+            hVe.resize(hVe.size() + U16, 0);
+            float *dst = hVs.data() + mws_off[b];
+            int sv = 0;
+            for (int u = 0; u < U; u++) {
+                double mx = 0;
+                for (int i = 0; i < n; i++) mx = std::max(mx, std::fabs(hVl[0][k.v_off + (i64)u * n + i]));
+                const int e = mwk::mws_exponent(mx);
+                hVe[hve_off[b] + u] = e;
+                for (int i = 0; i < n; i++) {
+                    mwa::mw<2> x;
+                    x.l[0] = hVl[0][k.v_off + (i64)u * n + i];
+                    x.l[1] = DK > 1 ? hVl[1][k.v_off + (i64)u * n + i] : 0.0;
+                    double r0 = std::ldexp(x.l[0], -e), r1 = std::ldexp(x.l[1], -e);
+                    for (int s = 0; s < S; s++) {
+                        const double g = std::ldexp(1.0, -(s + 1) * MWS_BETA), C = 0x1.8p52 * g;
+                        volatile double tv = r0 + C;               // (no contraction or reassociation of the rounding trick on the host)
+                        const double t = tv - C;
+                        const float dgt = (float)(t * std::ldexp(1.0, (s + 1) * MWS_BETA));
+                        dst[(size_t)s * np * rV + (size_t)i * rV + u] = dgt;      // [s][k = row i of V][col = u]
+                        if (dgt != 0.0f) sv = std::max(sv, s + 1);
+                        r0 -= t;
+                        double sm, er;
+                        mwa::two_sum(r0, r1, sm, er);
+                        r0 = sm; r1 = er;
+                    }
+                }
+            }
+            hsv[b] = sv;
+            c->mws_blocks++;
+            c->sm_mws = std::max(c->sm_mws, mws_lds_bytes(S, n, U));
+        }
+        const bool on = g_cfg_mw_exact_products == 2 ? c->mws_blocks > 0 : (g_cfg_mw_exact_products == 1 && c->mws_blocks >= 256);
+        if (!on) { c->mws_blocks = 0; std::fill(mws_off.begin(), mws_off.end(), -1); }
+        else {
+            MW_TRY(mw_upload(c, hVs, &c->mws.Vs)); MW_TRY(mw_upload(c, hVe, &c->mws.Vexp));
+            MW_TRY(mw_upload(c, hve_off, &c->mws.ve_off)); MW_TRY(mw_upload(c, hsv, &c->mws.sv));
+            MW_DISPATCH(c, { MW_TRY(mw_set_lds((k_mws_pair<KK, DD, 1>), c->sm_mws)); MW_TRY(mw_set_lds((k_mws_pair<KK, DD, 2>), c->sm_mws)); });
+        }
+        MW_TRY(mw_upload(c, mws_off, &c->mws.vs_off));
+    }
     // ---- upload ----
     MwDev &q = c->d;
+    q.mws_off = c->mws.vs_off; q.mws_on = c->mws_blocks > 0 ? 1 : 0;
     q.J = J; q.N = N; q.NB = NB; q.nlr = (int)lr_list.size(); q.ndn = (int)dn_list.size();
     q.xylen = xyoff; q.xlen = xlen; q.Slen = Slen; q.T = T; q.xrdlen = rdoff;
     q.zlen = std::max<i64>(zoff, 1); q.glen = std::max<i64>(goff, 1); q.wlen = std::max<i64>(woff, 1); q.sdlen = std::max<i64>(sdoff, 1);
@@ -584,17 +652,22 @@ extern "C" int clrs_mw_schur_assemble_dev(clrs_mw_ctx *c, const double *d_Xchol,
     const MwDev &q = c->d;
     if (c->timing) MWCHECK(hipEventRecord(c->ev[0], c->stream));
     MW_DISPATCH(c, {
-        if (q.nlr) {
+        const bool exact = c->mws_blocks > 0 && c->xinv_valid;      // the exact-product kernel needs chol(X)^-1 (k_mw_potrf_x of this context)
+        if (exact && c->mws_turns == 1) hipLaunchKernelGGL((k_mws_pair<KK, DD, 1>), dim3(q.nlr), dim3(MWS_NT), c->sm_mws, c->stream, q, c->mws, d_Y);
+        else if (exact) hipLaunchKernelGGL((k_mws_pair<KK, DD, 2>), dim3(q.nlr), dim3(MWS_NT), c->sm_mws, c->stream, q, c->mws, d_Y);
+        if (q.nlr && !(exact && c->mws_blocks == q.nlr)) {
+            MwDev q2 = q;
+            q2.mws_on = exact ? 1 : 0;
             const int gper = MW_NT / MW_GRAM_W;
-            hipLaunchKernelGGL((k_mw_zt<KK, DD>), dim3((c->maxU + MW_CT - 1) / MW_CT, q.nlr), dim3(MW_NT), c->sm_zt, c->stream, q, d_Y, c->lds_zt_L ? 1 : 0, c->xinv_valid ? 1 : 0);
-            hipLaunchKernelGGL((k_mw_gram<KK, DD>), dim3((c->maxU * (c->maxU + 1) / 2 + gper - 1) / gper, q.nlr), dim3(MW_NT), 0, c->stream, q);
+            hipLaunchKernelGGL((k_mw_zt<KK, DD>), dim3((c->maxU + MW_CT - 1) / MW_CT, q.nlr), dim3(MW_NT), c->sm_zt, c->stream, q2, d_Y, c->lds_zt_L ? 1 : 0, c->xinv_valid ? 1 : 0);
+            hipLaunchKernelGGL((k_mw_gram<KK, DD>), dim3((c->maxU * (c->maxU + 1) / 2 + gper - 1) / gper, q.nlr), dim3(MW_NT), 0, c->stream, q2);
         }
         if (q.ndn) {
             hipLaunchKernelGGL((k_mw_dense_t<KK, DD>), dim3(q.ndn, q.dn_big ? c->maxcnt : 1), dim3(MW_NT), c->sm_dense, c->stream, q, d_Y, c->xinv_valid ? 1 : 0, c->dense_two ? 1 : 0);
             const int pairs = c->maxcnt * (c->maxcnt + 1) / 2;
             if (q.dn_big) hipLaunchKernelGGL((k_mw_dense_s<KK, DD>), dim3(q.ndn, (pairs + MW_NT / 64 - 1) / (MW_NT / 64)), dim3(MW_NT), 0, c->stream, q);
         }
-        hipLaunchKernelGGL((k_mw_saccum<KK, DD>), dim3((c->maxP * (c->maxP + 1) / 2 * MW_SA_W + MW_NT - 1) / MW_NT, q.J), dim3(MW_NT), 0, c->stream, q);
+        hipLaunchKernelGGL((k_mw_saccum<KK, DD>), dim3((c->maxP * (c->maxP + 1) / 2 * c->sa_lanes + MW_NT - 1) / MW_NT, q.J), dim3(MW_NT), 0, c->stream, q, c->sa_lanes);
     });
     MWCHECK(hipGetLastError());
     if (c->timing) MWCHECK(hipEventRecord(c->ev[1], c->stream));
@@ -866,6 +939,32 @@ extern "C" int clrs_mw_schur_solve_dev(clrs_mw_ctx *c, const double *d_rhs_x, co
 
 extern "C" double *clrs_mw_S_buffer_dev(clrs_mw_ctx *c) { return c ? c->d.S : nullptr; }
 extern "C" double *clrs_mw_AY_buffer_dev(clrs_mw_ctx *c) { return c ? c->d.AY : nullptr; }
+
+// S_j (S layout) and the per-term pairings A_Y of the last assembly, planar limbs, to host memory (either pointer may be NULL): for
+// callers of the device-pointer entry points (clrs_mw_schur_assemble_dev) that want to look at what was assembled
+extern "C" int clrs_mw_get_S(clrs_mw_ctx *c, double *S_out, double *AY_out) {
+    if (!c) return mw_fail(CLRS_ERR_INVALID, "null context");
+    if (!c->assembled) return mw_fail(CLRS_ERR_STATE, "clrs_mw_get_S before clrs_mw_schur_assemble (or after the factorisation has overwritten S)");
+    MWCHECK(hipSetDevice(c->device));
+    MWCHECK(hipStreamSynchronize(c->stream));
+    if (S_out) MWCHECK(hipMemcpy(S_out, c->d.S, (size_t)c->d.Slen * c->K * sizeof(double), hipMemcpyDeviceToHost));
+    if (AY_out && c->d.T) MWCHECK(hipMemcpy(AY_out, c->d.AY, (size_t)c->d.T * c->K * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// diagnostic: phase stamps (100 MHz wall clock) of wave 0 of the first workgroup of the next k_mws_pair launches; out[16] = the last ones
+extern "C" int clrs_mw_debug_exact_stamps(clrs_mw_ctx *c, unsigned long long *out) {
+    if (!c) return mw_fail(CLRS_ERR_INVALID, "null context");
+    MWCHECK(hipSetDevice(c->device));
+    MWCHECK(hipStreamSynchronize(c->stream));
+    if (!c->mws.stamps) {
+        double *p = nullptr;
+        int rc = mw_dmalloc(c, &p, 16);
+        if (rc) return rc;
+        c->mws.stamps = (unsigned long long *)p;
+    } else if (out) MWCHECK(hipMemcpy(out, c->mws.stamps, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return 0;
+}
 
 extern "C" int clrs_mw_get_timings(clrs_mw_ctx *c, double t[6]) {
     if (!c || !t) return mw_fail(CLRS_ERR_INVALID, "null argument");

@@ -1,0 +1,301 @@
+// clrs_mw_exact.hip.h -- the pairing matrices of a low-rank block through EXACT slice products on the fp64 matrix cores.
+//
+// The multi-word contractions of the Schur assembly (the four GEMMs of src/solver.jl:1121-1147: T = Y V, Z = X^-1/2 V, GY = V^T T,
+// GX = Z^T Z) cost 345 fp64 lane instructions per 5-limb multiply-add in k_mw_zt / k_mw_gram: 30 flops of limb products, the rest
+// are the error-free transformations that keep the ADDITIONS exact (profiles/r02/m_pmc_mw_assembly_sq_counters.csv).  Here the
+// operands are cut into slices whose products and k-sums are exact in an fp64 accumulator by construction, so the additions need no
+// transformation at all and the inner loop is v_mfma_f64_16x16x4:
+//
+//   x_ik = 2^e_i  sum_s d_s(i,k) 2^-(s+1)B ,   d_s integers, |d_s| <= 2^(B-1) + 1,   e_i one exponent per ROW of the left operand
+//   y_kj = 2^f_j  sum_t d'_t(k,j) 2^-(t+1)B ,                                       f_j one exponent per COLUMN of the right operand
+//   sum_k x_ik y_kj = 2^(e_i + f_j)  sum_o 2^-(o+2)B  [ sum_{s+t=o} sum_k d_s(i,k) d'_t(k,j) ]        (orders o >= S dropped)
+//
+// With B = 23 the bracket is an integer below (o+1) k 2^(2B-2) <= 2^52 for k <= 32 and o < 16: every MFMA accumulation is exact, in any
+// order.  S = ceil((52 K + 16) / B) slices (12 at K = 5: 276 bits below the row's largest entry).  Dropping the orders o >= S and cutting
+// every entry at 2^-SB relative to its row / column maximum are the only roundings: a normwise error of k 2^-(SB-9) relative to
+// max|row| max|column|, which is what the backward-error analysis of a GEMM asks for (measured on the trajectory iterates of
+// cohnelkies(8,15), mu from 1e20 to 2e-16: 2^-273 of max|GY|, against 2^-262 for the 5-limb expansions).  An entry far below its row's
+// maximum keeps fewer bits of its own -- unlike the expansions, which round every product relative to itself.
+//
+// The digits are stored as fp32 (exact: 23 bits and a sign), half the LDS of doubles, converted by one v_cvt_f64_f32 per operand.
+// One workgroup of four waves per PSD block; every slice array has the layout [slice][k][col] (k = contraction index, col = the free
+// index, contiguous): the MFMA A operand (lane (l15, l4) holds A[i = l15][k = l4]) and B operand (B[k = l4][j = l15]) read it alike.
+//   phase A  slice Y and Xi = chol(X)^-1 by rows (dynamic); the slices of V by columns are static data (context creation)
+//   phase B  T = Y V and Z = Xi V: one 16 x 16 output tile per wave and turn; recombine the order sums to K limbs, slice by columns
+//   phase D  GY = V^T T, GX = Z^T Z, lower tiles only, recombined to K limbs and written mirrored like k_mw_gram does
+// The per-term pairings A_Y and the accumulation into S_j stay with k_mw_saccum.
+#ifndef CLRS_MW_EXACT_HIP_H
+#define CLRS_MW_EXACT_HIP_H
+
+#include "clrs_mw_kernels.hip.h"
+
+#define MWS_BETA 23
+#define MWS_NT 256
+constexpr int mws_slices(int K) { return (52 * K + 16 + MWS_BETA - 1) / MWS_BETA; }
+
+namespace mwk {
+
+typedef double v4d_mw __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) float lds_f;
+
+// exponent e with |x| < 2^(e-2) for a renormalised expansion with head h (0 for h = 0: the slices of a zero are zeros)
+__device__ __host__ __forceinline__ int mws_exponent(double h) {
+    if (h == 0.0) return 0;
+    int ex;
+    (void)frexp(h, &ex);                    // |h| < 2^ex
+    return ex + 2;
+}
+
+// Digits of x relative to the window exponent e (|x| < 2^(e-2)): x = 2^e sum_s d[s] 2^-(s+1)B + O(2^(e-SB-1)).  Each digit is the head of
+// the remainder rounded to the grid 2^-(s+1)B by the add-and-subtract of 1.5 * 2^52 * grid (exact for |head| < 2^51 grid); the remainder
+// is then swept once top-down with two_sum, which leaves a head within 2^-53 of the remainder's value whatever the order of its terms.
+template <int K, int S, class OUT>
+MWF void mws_slice(const mwa::mw<K> &x, int e, OUT &&put) {
+    double r[K];
+#pragma unroll
+    for (int l = 0; l < K; l++) r[l] = ldexp(x.l[l], -e);
+#pragma unroll
+    for (int s = 0; s < S; s++) {
+        const double g = ldexp(1.0, -(s + 1) * MWS_BETA), C = 0x1.8p52 * g;
+        const double t = (r[0] + C) - C;
+        put(s, (float)(t * ldexp(1.0, (s + 1) * MWS_BETA)));
+        r[0] -= t;
+#pragma unroll
+        for (int l = 0; l + 1 < K; l++) {
+            double sm, er;
+            mwa::two_sum(r[l], r[l + 1], sm, er);
+            r[l] = sm;
+            r[l + 1] = er;
+        }
+    }
+}
+
+// sum_o acc[o] 2^-(o+2)B as K limbs (acc[o] exact integers below 2^53): every term enters the unnormalised accumulator in a bin its
+// magnitude allows (|acc[o]| 2^-(o+2)B <= 2^(7 - o B)), then one renormalisation
+template <int K, int S, int O>
+struct MwsPush {
+    static __device__ __forceinline__ void run(mwa::acc<K> &a, const v4d_mw (&acc)[S], int reg) {
+        constexpr int raw = (O * MWS_BETA - 8) / 53, bin = raw < 0 ? 0 : (raw > K - 1 ? K - 1 : raw);
+        const double v = ldexp(acc[O][reg], -(O + 2) * MWS_BETA);
+        mwa::acc_push<K, bin>(a, v);
+        if constexpr (O + 1 < S) MwsPush<K, S, O + 1>::run(a, acc, reg);
+    }
+};
+template <int K, int S>
+__device__ __forceinline__ mwa::mw<K> mws_recombine(const v4d_mw (&acc)[S], int reg, int escale) {
+    mwa::acc<K> a;
+    mwa::acc_zero<K>(a);
+    MwsPush<K, S, 0>::run(a, acc, reg);
+    mwa::mw<K> r = mwa::acc_result<K>(a);
+#pragma unroll
+    for (int l = 0; l < K; l++) r.l[l] = ldexp(r.l[l], escale);
+    return r;
+}
+
+// one 16 x 16 output tile: acc[o] += sum over the pairs s + t = o, s < SA, t < SB, and the k-steps, of A_s^T-style products
+//   A operand: As[s][k][i0 + l15], B operand: Bs[t][k][j0 + l15]; strides in floats: slice strides sa / sb, row (k) strides ra / rb
+// SA, SB are compile-time: every digit of a k-step is in registers before its first MFMA and the MFMA sequence has no branch in it.
+template <int S, int SA, int SB>
+__device__ __forceinline__ void mws_tile(v4d_mw (&acc)[S], const lds_f *As, int sa, int ra, const lds_f *Bs, int sb, int rb, int ksteps, int l15, int l4) {
+#pragma unroll
+    for (int o = 0; o < S; o++) acc[o] = (v4d_mw){0.0, 0.0, 0.0, 0.0};
+    const lds_f *ap = As + l4 * ra + l15, *bp = Bs + l4 * rb + l15;
+    for (int ks = 0; ks < ksteps; ks++) {
+        float af[SA], bf[SB];
+#pragma unroll
+        for (int s = 0; s < SA; s++) af[s] = ap[s * sa + ks * 4 * ra];
+#pragma unroll
+        for (int t = 0; t < SB; t++) bf[t] = bp[t * sb + ks * 4 * rb];
+        double bv[SB];
+#pragma unroll
+        for (int t = 0; t < SB; t++) bv[t] = (double)bf[t];
+#pragma unroll
+        for (int s = 0; s < SA; s++) {
+            const double av = (double)af[s];
+#pragma unroll
+            for (int t = 0; t < SB; t++)
+                if (s + t < S) acc[s + t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[t], acc[s + t], 0, 0, 0);
+        }
+    }
+}
+// the static operand (V) has SV <= S slices that are not all zero: instantiations for SV rounded up to S/2, 3S/4, S
+template <int S, bool V_IS_A>
+__device__ __forceinline__ void mws_tile_v(v4d_mw (&acc)[S], int SV, const lds_f *As, int sa, int ra, const lds_f *Bs, int sb, int rb, int ksteps, int l15, int l4) {
+    constexpr int S1 = (S + 1) / 2, S2 = (3 * S + 3) / 4;
+    if (V_IS_A) {
+        if (SV <= S1) mws_tile<S, S1, S>(acc, As, sa, ra, Bs, sb, rb, ksteps, l15, l4);
+        else if (SV <= S2) mws_tile<S, S2, S>(acc, As, sa, ra, Bs, sb, rb, ksteps, l15, l4);
+        else mws_tile<S, S, S>(acc, As, sa, ra, Bs, sb, rb, ksteps, l15, l4);
+    } else {
+        if (SV <= S1) mws_tile<S, S, S1>(acc, As, sa, ra, Bs, sb, rb, ksteps, l15, l4);
+        else if (SV <= S2) mws_tile<S, S, S2>(acc, As, sa, ra, Bs, sb, rb, ksteps, l15, l4);
+        else mws_tile<S, S, S>(acc, As, sa, ra, Bs, sb, rb, ksteps, l15, l4);
+    }
+}
+
+}  // namespace mwk
+
+// static slices of V of every eligible block: digits [S][np][Up] (np = n rounded up to 4, Up = U rounded up to 16, + 16 floats of padding
+// per row so that the four k-rows of an operand read fall into different banks), column exponents [Up]
+struct MwsDev {
+    const float *Vs;         // digits, per block at vs_off
+    const int *Vexp;         // per block at ve_off
+    const long long *vs_off; // [NB] (-1: the block is not eligible)
+    const int *ve_off;       // [NB]
+    const int *sv;           // [NB] slices of V that are not all zero
+    unsigned long long *stamps;   // diagnostic: wall_clock64 at the phase boundaries of wave 0 of workgroup 0 (or null)
+};
+
+#define MWS_ROWPAD(cols) ((cols) + 16)
+// LDS of one workgroup in floats: V slices, the Y / Xi slices (later: the T slices), the Z slices, + exponents
+static inline size_t mws_lds_bytes(int S, int n, int U) {
+    const int np = (n + 3) & ~3, n16 = (n + 15) & ~15, U16 = (U + 15) & ~15;
+    const size_t vsl = (size_t)S * np * MWS_ROWPAD(U16), yx = (size_t)2 * S * np * MWS_ROWPAD(n16), tz = (size_t)S * np * MWS_ROWPAD(U16);
+    return (vsl + (yx > tz ? yx : tz) + tz) * sizeof(float) + (size_t)(2 * n16 + 3 * U16 + 8 * U16) * sizeof(int);
+}
+
+// TURNS = 1: every block of the launch has at most four T / Z tiles (n <= 16 with U <= 32, the named shapes), one per wave; 2: up to eight
+template <int K, int DK, int TURNS>
+__global__ __launch_bounds__(MWS_NT, 2) void k_mws_pair(const MwDev q, const MwsDev w, const double *__restrict__ Y) {
+    using namespace mwk;
+    constexpr int S = mws_slices(K);
+    const int b = q.lr_list[blockIdx.x];
+    if (w.vs_off[b] < 0) return;
+    const MwBlk &k = q.blk[b];
+    const int n = k.n, U = k.U, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
+    const int np = (n + 3) & ~3, n16 = (n + 15) & ~15, U16 = (U + 15) & ~15, ksteps = np / 4;
+    const int rV = MWS_ROWPAD(U16), rY = MWS_ROWPAD(n16), sV = np * rV, sY = np * rY;
+    const int SV = w.sv[b];
+    extern __shared__ __attribute__((aligned(16))) float mws_lds[];
+    const bool stamp = w.stamps && blockIdx.x == 0 && tid == 0;
+    int nst = 0;
+#define MWS_STAMP() do { if (stamp) w.stamps[nst++] = wall_clock64(); } while (0)
+    MWS_STAMP();
+    lds_f *Vsl = (lds_f *)mws_lds;                              // [S][np][rV]
+    const size_t yx = (size_t)2 * S * sY, tz = (size_t)S * sV;
+    lds_f *Ysl = Vsl + (size_t)S * sV, *Xsl = Ysl + (size_t)S * sY;      // [S][np][rY] each; the T slices overlay them later
+    lds_f *Tsl = Ysl, *Zsl = Ysl + (yx > tz ? yx : tz);         // [S][np][rV] each
+    int *eY = (int *)(Zsl + tz), *eX = eY + n16, *fV = eX + n16, *fT = fV + U16, *fZ = fT + U16, *part = fZ + U16;      // part: [2][4][U16] column maxima per row tile
+    // ---- phase A: V slices (static), row exponents of Y and Xi, their slices ----
+    {
+        typedef float v4f_mw __attribute__((ext_vector_type(4)));
+        const v4f_mw *gv = (const v4f_mw *)(w.Vs + w.vs_off[b]);
+        v4f_mw __attribute__((address_space(3))) *lv = (v4f_mw __attribute__((address_space(3))) *)Vsl;
+        const int nq = S * sV / 4, nv = SV * sV / 4;          // sV is a multiple of 4 (rows of U16 + 16 floats)
+        for (int e0 = 0; e0 < nq; e0 += 4 * MWS_NT) {          // four 16-byte loads in flight per thread and pass
+            v4f_mw v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int e = e0 + tid + u * MWS_NT; v[u] = e < nv ? gv[e] : (v4f_mw){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int e = e0 + tid + u * MWS_NT; if (e < nq) lv[e] = v[u]; }
+        }
+        for (int u = tid; u < U16; u += MWS_NT) fV[u] = w.Vexp[w.ve_off[b] + u];
+        if (n != n16 || np != n) {                             // padding rows / columns of the Y and Xi slices are zero digits
+            for (int e = tid; e < 2 * S * sY; e += MWS_NT) Ysl[e] = 0.0f;
+        }
+        for (int i = tid; i < 2 * n16; i += MWS_NT) eY[i] = 0;                    // (eY and eX are adjacent)
+    }
+    __syncthreads();
+    MWS_STAMP();
+    const double *Yg = Y + k.xyoff, *Xig = q.Xi + k.xyoff;
+    // row exponents: every thread takes the heads of its entries (coalesced loads) to an integer maximum per row in LDS
+    for (int e = tid; e < 2 * n * n; e += MWS_NT) {
+        const int which = e / (n * n), ee = e % (n * n), i = ee % n, c = ee / n;
+        if (which == 1 && c > i) continue;
+        const double h = (which == 0 ? Yg : Xig)[i + (long)c * n];
+        if (h != 0.0) atomicMax(&(which == 0 ? eY : eX)[i], mws_exponent(h) + 4096);      // biased: the initial 0 is below every real exponent
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * n16; i += MWS_NT) eY[i] = eY[i] == 0 ? 0 : eY[i] - 4096;
+    __syncthreads();
+    for (int e = tid; e < 2 * n * n; e += MWS_NT) {
+        const int which = e / (n * n), ee = e % (n * n), i = ee % n, c = ee / n;        // entry (row i, column c): A operand [k = c][col = i]
+        lds_f *dst = (which == 0 ? Ysl : Xsl) + c * rY + i;
+        if (which == 1 && c > i) {                           // Xi is lower triangular
+#pragma unroll
+            for (int sl = 0; sl < S; sl++) dst[sl * sY] = 0.0f;
+            continue;
+        }
+        const mw<K> x = ldx<K>(which == 0 ? Yg : Xig, q.xylen, i + (long)c * n);
+        mws_slice<K, S>(x, (which == 0 ? eY : eX)[i], [&](int sl, float d) { dst[sl * sY] = d; });
+    }
+    __syncthreads();
+    MWS_STAMP();
+    // ---- phase B: T = Y V, Z = Xi V; tasks = (which, row tile, column tile), one per wave and turn ----
+    const int ntn = n16 / 16, ntu = U16 / 16, ntask = 2 * ntn * ntu;
+    v4d_mw acc[S];
+    // the results stay in registers across the barrier that frees the Y / Xi slices: at most two turns are supported (ntask <= 8)
+    mw<K> res[TURNS][4];
+    int tsk[TURNS];
+#pragma unroll
+    for (int turn = 0; turn < TURNS; turn++) tsk[turn] = -1;
+#pragma unroll
+    for (int turn = 0; turn < TURNS; turn++) {
+        const int task = wave + 4 * turn;
+        if (task >= ntask) break;
+        tsk[turn] = task;
+        const int which = task / (ntn * ntu), ti = (task / ntu) % ntn, tj = task % ntu;
+        mws_tile_v<S, false>(acc, SV, (which == 0 ? Ysl : Xsl) + ti * 16, sY, rY, Vsl + tj * 16, sV, rV, ksteps, l15, l4);
+        MWS_STAMP();
+        int cmax = -100000;
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const int i = ti * 16 + 4 * reg + l4, j = tj * 16 + l15;
+            res[turn][reg] = mws_recombine<K, S>(acc, reg, (which == 0 ? eY : eX)[min(i, n16 - 1)] + fV[j]);
+            if (i < n && j < U && res[turn][reg].l[0] != 0.0) cmax = max(cmax, mws_exponent(res[turn][reg].l[0]));
+        }
+        cmax = max(cmax, __shfl_xor(cmax, 16, 64));
+        cmax = max(cmax, __shfl_xor(cmax, 32, 64));
+        if (l4 == 0) part[(which * 4 + ti) * U16 + tj * 16 + l15] = cmax;
+    }
+    MWS_STAMP();
+    __syncthreads();                                            // every wave is done with the Y / Xi slices; the partial column maxima are written
+    for (int u = tid; u < 2 * U16; u += MWS_NT) {
+        const int which = u / U16, j = u % U16;
+        int m = -100000;
+        for (int ti = 0; ti < ntn; ti++) m = max(m, part[(which * 4 + ti) * U16 + j]);
+        (which == 0 ? fT : fZ)[j] = m == -100000 ? 0 : m;
+    }
+    if (n != np || U != U16) {                                  // padding rows / columns of the T and Z slices
+        for (int e = tid; e < (int)(2 * tz); e += MWS_NT) (e < (int)tz ? Tsl[e] : Zsl[e - tz]) = 0.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int turn = 0; turn < TURNS; turn++) {
+        const int task = tsk[turn];
+        if (task < 0) break;
+        const int which = task / (ntn * ntu), ti = (task / ntu) % ntn, tj = task % ntu;
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const int i = ti * 16 + 4 * reg + l4, j = tj * 16 + l15;        // entry (row i, column j) of T / Z: operand [k = i][col = j]
+            if (i >= n || j >= U) continue;
+            lds_f *dst = (which == 0 ? Tsl : Zsl) + i * rV + j;
+            mws_slice<K, S>(res[turn][reg], (which == 0 ? fT : fZ)[j], [&](int s, float d) { dst[s * sV] = d; });
+        }
+    }
+    __syncthreads();
+    MWS_STAMP();
+    // ---- phase D: GX = Z^T Z, GY = V^T T, lower tiles; GX tiles first (they are the longer tasks: all S slices on both sides) ----
+    const int ntri = ntu * (ntu + 1) / 2;
+    for (int task = wave; task < 2 * ntri; task += 4) {
+        const int which = task / ntri;                      // 0: GX, 1: GY
+        int ti, tj;
+        tri_index(task % ntri, ti, tj);                     // ti >= tj
+        if (which == 0) mws_tile<S, S, S>(acc, Zsl + ti * 16, sV, rV, Zsl + tj * 16, sV, rV, ksteps, l15, l4);
+        else mws_tile_v<S, true>(acc, SV, Vsl + ti * 16, sV, rV, Tsl + tj * 16, sV, rV, ksteps, l15, l4);
+        MWS_STAMP();
+        double *G = (which == 0 ? q.GX : q.GY) + k.g_off;
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const int a = ti * 16 + 4 * reg + l4, c = tj * 16 + l15;        // entry (a, c), a >= c kept
+            if (a >= U || c >= U || c > a) continue;
+            const mw<K> v = mws_recombine<K, S>(acc, reg, which == 0 ? fZ[a] + fZ[c] : fV[a] + fT[c]);
+            stx<K>(G, q.glen, a + (long)c * U, v);
+            stx<K>(G, q.glen, c + (long)a * U, v);
+        }
+        MWS_STAMP();
+    }
+#undef MWS_STAMP
+}
+
+#endif

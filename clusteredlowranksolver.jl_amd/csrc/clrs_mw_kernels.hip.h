@@ -83,6 +83,9 @@ struct MwDev {
     // partial u of every rank are gathered into world slots and summed in rank order by every rank (src/solver.jl:1268-1269, 1550-1553)
     int rank, world, gathered, pad3;    // gathered: u comes from the gather slots (world > 1, or a communicator is attached)
     double *Qg, *ug;                    // [world][limbs * N * N], [world][limbs * N]
+    // exact-product path of the pairing matrices (clrs_mw_exact.hip.h): blocks with mws_off[b] >= 0 are taken by k_mws_pair when mws_on
+    const long long *mws_off;
+    int mws_on, pad4;
 };
 
 namespace mwk {
@@ -486,6 +489,7 @@ __global__ __launch_bounds__(MW_PT) void k_mw_potrf_x(const MwDev q, const doubl
 template <int K, int DK>
 __global__ __launch_bounds__(MW_NT) void k_mw_zt(const MwDev q, const double *__restrict__ Y, int lds_L, int use_inv) {
     using namespace mwk;
+    if (q.mws_on && q.mws_off[q.lr_list[blockIdx.y]] >= 0) return;      // k_mws_pair forms the pairing matrices of this block
     const MwBlk &k = q.blk[q.lr_list[blockIdx.y]];
     const int n = k.n, U = k.U, tid = threadIdx.x, dl = k.delta;
     const int c0 = blockIdx.x * MW_CT;
@@ -555,6 +559,7 @@ __global__ __launch_bounds__(MW_NT) void k_mw_zt(const MwDev q, const double *__
 template <int K, int DK>
 __global__ __launch_bounds__(MW_NT) void k_mw_gram(const MwDev q) {
     using namespace mwk;
+    if (q.mws_on && q.mws_off[q.lr_list[blockIdx.y]] >= 0) return;
     const MwBlk &k = q.blk[q.lr_list[blockIdx.y]];
     const int n = k.n, U = k.U, dl = k.delta;
     const int e = blockIdx.x * (MW_NT / MW_GRAM_W) + threadIdx.x / MW_GRAM_W, sub = threadIdx.x % MW_GRAM_W;
@@ -682,30 +687,22 @@ __global__ __launch_bounds__(MW_NT) void k_mw_dense_s(const MwDev q) {
 // dense  Sd[e_p, e_q].  One thread per entry q >= p, mirrored write (symmetric!, src/tools.jl:43-57); the per-term pairings
 // A_Y (src/solver.jl:1152-1170) are written by the first workgroups of the same launch.
 // ---------------------------------------------------------------------------------------------------------------------
-#define MW_SA_W 4
-template <int K, int DK>
-__global__ __launch_bounds__(MW_NT) void k_mw_saccum(const MwDev q) {
+#define MW_SA_W 4            // most lanes per entry; the launch takes 1, 2 or 4 (the largest number of PSD blocks of a cluster, rounded up)
+template <int K, int DK, int W>
+__device__ __forceinline__ void mw_saccum_body(const MwDev &q) {
     using namespace mwk;
-    if (blockIdx.y == 0) {                               // A_Y per term: w^T Y v
-        for (mwi64 t = (mwi64)blockIdx.x * MW_NT + threadIdx.x; t < q.T; t += (mwi64)gridDim.x * MW_NT) {
-            const int b = q.ay_blk[t];
-            if (b < 0) continue;
-            const MwBlk &k = q.blk[b];
-            stx<K>(q.AY, q.T, t, ldx<K>(q.GY + k.g_off, q.glen, q.ay_a[t] + (long)q.ay_b[t] * k.U));
-        }
-    }
     const MwClu &c = q.clu[blockIdx.y];
     const int P = c.P;
-    if (blockIdx.x * (MW_NT / MW_SA_W) >= P * (P + 1) / 2) return;
-    // MW_SA_W lanes per entry, one block of the cluster each: the chains of dependent loads (block -> term range -> pointers ->
+    if (blockIdx.x * (MW_NT / W) >= P * (P + 1) / 2) return;
+    // W lanes per entry, one block of the cluster each: the chains of dependent loads (block -> term range -> pointers ->
     // pairings) of the blocks run side by side instead of one after the other
-    const int e = blockIdx.x * (MW_NT / MW_SA_W) + threadIdx.x / MW_SA_W, sub = threadIdx.x % MW_SA_W;
+    const int e = blockIdx.x * (MW_NT / W) + threadIdx.x / W, sub = threadIdx.x % W;
     const bool live = e < P * (P + 1) / 2;
     int qq, pp;
     tri_index(live ? e : 0, qq, pp);           // qq >= pp
     acc<K> s;
     acc_zero<K>(s);
-    for (int b = c.b0 + sub; b < c.b1; b += MW_SA_W) {
+    for (int b = c.b0 + sub; b < c.b1; b += W) {
         const MwBlk &k = q.blk[b];
         if (k.kind == 0) {
             const int *tp = q.tptr + k.tptr_off;
@@ -726,11 +723,26 @@ __global__ __launch_bounds__(MW_NT) void k_mw_saccum(const MwDev q) {
             if (e1 >= 0 && e2 >= 0) acc_add<K, K>(s, ldx<K>(q.Sd + k.sd_off, q.sdlen, e1 + (long)e2 * k.cnt));
         }
     }
-    const mw<K> v = lanes_sum<K, MW_SA_W>(acc_result<K>(s));
+    const mw<K> v = lanes_sum<K, W>(acc_result<K>(s));
     if (live && sub == 0) {
         stx<K>(q.S + c.Soff, q.Slen, pp + (long)qq * P, v);
         stx<K>(q.S + c.Soff, q.Slen, qq + (long)pp * P, v);
     }
+}
+template <int K, int DK>
+__global__ __launch_bounds__(MW_NT) void k_mw_saccum(const MwDev q, int lanes) {
+    using namespace mwk;
+    if (blockIdx.y == 0) {                               // A_Y per term: w^T Y v
+        for (mwi64 t = (mwi64)blockIdx.x * MW_NT + threadIdx.x; t < q.T; t += (mwi64)gridDim.x * MW_NT) {
+            const int b = q.ay_blk[t];
+            if (b < 0) continue;
+            const MwBlk &k = q.blk[b];
+            stx<K>(q.AY, q.T, t, ldx<K>(q.GY + k.g_off, q.glen, q.ay_a[t] + (long)q.ay_b[t] * k.U));
+        }
+    }
+    if (lanes == 1) mw_saccum_body<K, DK, 1>(q);
+    else if (lanes == 2) mw_saccum_body<K, DK, 2>(q);
+    else mw_saccum_body<K, DK, 4>(q);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -82,8 +82,10 @@ def _c(a):
 class MwSchurContext:
     """Device context of the hot path for one SDP at `limbs` words per number (see module docstring)."""
 
-    def __init__(self, sdp, limbs: int = 4, device: int = 0, timing: bool = False, data_limbs: int = 2):
-        """`data_limbs` = 2 (default): the problem data (sampled vectors, lambda, dense A_p, B and, in `solvesdp_mw`, C, c, b) are
+    def __init__(self, sdp, limbs: int = 4, device: int = 0, timing: bool = False, data_limbs: int = 2, exact_products: Optional[bool] = None):
+        """`exact_products`: the pairing matrices through exact slice products on the matrix cores (k_mws_pair, csrc/clrs_mw_exact.hip.h):
+        None = automatic (contexts with >= 256 eligible PSD blocks), True = always, False = never.
+        `data_limbs` = 2 (default): the problem data (sampled vectors, lambda, dense A_p, B and, in `solvesdp_mw`, C, c, b) are
         passed as double-double, the (hi, lo) pairs a FlatSDP carries; 1: the fp64 roundings only."""
         self.flat: FlatSDP = sdp if isinstance(sdp, FlatSDP) else flatten(sdp)
         f = self.flat
@@ -119,7 +121,11 @@ class MwSchurContext:
         for name in ("term_lambda", "term_vs", "term_ws", "dense_A"):
             setattr(d, name, _dp(data(name)))
         h = C.c_void_p()
-        _lib.check(self.L.clrs_mw_create_ex(C.byref(d), self.data_limbs, int(device), self.limbs, C.byref(h)))
+        _lib.check(self.L.clrs_config_set(b"mw_exact_products", 1 if exact_products is None else (2 if exact_products else 0)))
+        try:
+            _lib.check(self.L.clrs_mw_create_ex(C.byref(d), self.data_limbs, int(device), self.limbs, C.byref(h)))
+        finally:
+            self.L.clrs_config_set(b"mw_exact_products", 1)
         self.h = h
         self.device = device
         if timing:
@@ -181,6 +187,14 @@ class MwSchurContext:
         S = np.empty((self.limbs, f.S_len)) if want_S else None
         AY = np.empty((self.limbs, f.n_terms)) if (want_AY and f.n_terms) else None
         _lib.check(self.L.clrs_mw_schur_assemble(self.h, _dp(Xc), _dp(Y), _dp(S) if S is not None else None, _dp(AY) if AY is not None else None))
+        return S, AY
+
+    def get_S(self):
+        """S_j and A_Y of the last assembly (also after the device-pointer entry points), planar limbs."""
+        f = self.flat
+        S = np.empty((self.limbs, f.S_len))
+        AY = np.empty((self.limbs, f.n_terms)) if f.n_terms else None
+        _lib.check(self.L.clrs_mw_get_S(self.h, _dp(S), _dp(AY) if AY is not None else None))
         return S, AY
 
     def factor(self) -> int:

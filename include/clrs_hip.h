@@ -304,6 +304,8 @@ int clrs_mw_schur_assemble(clrs_mw_ctx *ctx, const double *Xchol, const double *
 /* steps 3-4 of compute_T_decomposition! (src/solver.jl:1244-1279); 0, j+1 or n_clusters+1 */
 int clrs_mw_schur_factor(clrs_mw_ctx *ctx);
 int clrs_mw_get_factor(clrs_mw_ctx *ctx, double *L, double *LinvB, double *LQ);
+int clrs_mw_debug_exact_stamps(clrs_mw_ctx *ctx, unsigned long long *out /* [16] */);   /* diagnostic: first call arms, later calls read the phase stamps of k_mws_pair */
+int clrs_mw_get_S(clrs_mw_ctx *ctx, double *S_out, double *AY_out);   /* S_j and A_Y of the last (device-pointer) assembly -> host; NULL pointers are skipped */
 /* the solve stage of compute_search_direction! (src/solver.jl:1527-1582) */
 int clrs_mw_schur_solve(clrs_mw_ctx *ctx, const double *rhs_x, const double *rhs_y, double *dx, double *dy);
 

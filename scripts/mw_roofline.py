@@ -13,9 +13,10 @@ from clrs_amd.sdp import replicate_clusters
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 copies = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+exact = {"auto": None, "on": True, "off": False}[sys.argv[4]] if len(sys.argv) > 4 else None      # exact slice products on the matrix cores (k_mws_pair)
 flat = clrs_amd.flatten(cohnelkies(8, 15))
 big = replicate_clusters(flat, copies)
-ctx = MwSchurContext(big, limbs=K)
+ctx = MwSchurContext(big, limbs=K, exact_products=exact)
 rng = np.random.default_rng(1)
 X, Y = np.zeros((K, big.xy_len)), np.zeros((K, big.xy_len))
 for b in range(big.n_blocks):
@@ -38,5 +39,13 @@ with torch.cuda.stream(s_):
 ev1.synchronize()
 t = 1e-3 * ev0.elapsed_time(ev1) / reps
 m = ctx.counters()["assemble_muladds"]
-print("limbs %d, %d clusters: assembly %.1f us, %.3g multiply-adds -> %.2f TFLOP/s at K(K+1) flops each" % (K, big.n_clusters, 1e6 * t, m, m * K * (K + 1) / t / 1e12))
+print("exact products %s: limbs %d, %d clusters: assembly %.1f us, %.3g multiply-adds -> %.2f TFLOP/s at K(K+1) flops each" % (sys.argv[4] if len(sys.argv) > 4 else "auto", K, big.n_clusters, 1e6 * t, m, m * K * (K + 1) / t / 1e12))
+if exact:
+    import ctypes as C
+    st = (C.c_uint64 * 16)()
+    ctx.L.clrs_mw_debug_exact_stamps(ctx.h, None)
+    ctx.assemble_dev(tXc.data_ptr(), tY.data_ptr())
+    ctx.L.clrs_mw_debug_exact_stamps(ctx.h, st)
+    v = [int(x) for x in st]
+    print("k_mws_pair phase stamps of wave 0, workgroup 0 (us from start, 100 MHz clock):", ["%.1f" % ((x - v[0]) / 100.0) for x in v if x])
 ctx.close()

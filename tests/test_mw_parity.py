@@ -695,3 +695,60 @@ def test_sharded_interior_point_solve_on_one_gpu(which, world, oracle_built):
         cols = np.concatenate([np.arange(int(full.block_off[b]), int(full.block_off[b + 1])) for b in info["block_ids"]])
         rows = np.concatenate([np.arange(int(full.cluster_off[j]), int(full.cluster_off[j + 1])) for j in info["cluster_ids"]])
         assert np.allclose(r.Y[0], ref.Y[0][cols], rtol=1e-9, atol=1e-300) and np.allclose(r.x[0], ref.x[0][rows], rtol=1e-7, atol=1e-300)
+
+
+@pytest.mark.parametrize("K", [3, 4, 5, 6])
+@pytest.mark.parametrize("name", ["ce_8_15", "ns_8_15_2", "polyopt8", "delsarte_3_10", "threepoint_4", "polyopt40"])
+def test_exact_product_pairings_match_the_oracle(name, K, oracle_built):
+    """k_mws_pair (csrc/clrs_mw_exact.hip.h): the pairing matrices V^T X^-1 V and V^T Y V through 23-bit slices whose products and k-sums
+    are exact in the fp64 MFMA accumulators, instead of K-limb expansions -- the same S_j and A_Y as the oracle to the same tolerance as the
+    expansion kernels (the scheme cuts at 2^-(23 S) relative to row / column maxima, S = 8 / 10 / 12 / 15 slices for K = 3 / 4 / 5 / 6: below
+    the expansions' own rounding), on blocks of sides 1 ... 32 with and without sub-blocks, rank-1 and rank-2 terms."""
+    import torch
+    from clrs_amd.mw import MwSchurContext
+    from oracle.oracle import Oracle
+    f = flat(name)
+    X, Y = _iterates(f, K)
+    X, Y = _sym_limbs(f, X), _sym_limbs(f, Y)
+    ctx = MwSchurContext(f, limbs=K, exact_products=True)
+    dX, dY = torch.tensor(X, device="cuda:0"), torch.tensor(Y, device="cuda:0")
+    dXc = torch.empty_like(dX)
+    ctx.cholesky_blocks_dev(dX.data_ptr(), dXc.data_ptr())        # the exact-product kernel uses the inverse factors this call leaves in the context
+    ctx.assemble_dev(dXc.data_ptr(), dY.data_ptr())
+    S, AY = ctx.get_S()
+    Xc = dXc.cpu().numpy()
+    o = Oracle(f, mp_bits=320 if K <= 5 else 640)
+    pad = lambda a: np.vstack([a, np.zeros((1, a.shape[1]))])
+    S_ref, AY_ref = o.schur_assemble_mw(pad(Xc), pad(Y))
+    assert mw_relerr(S, S_ref) <= tol(K, 22), ("S", np.log2(mw_relerr(S, S_ref)))
+    if f.n_terms:
+        assert mw_relerr(AY, AY_ref, scale=max(1.0, np.max(np.abs(AY_ref[0])))) <= tol(K, 16)
+    for j in range(f.n_clusters):
+        P = int(f.cluster_P[j]); o0 = int(f.S_off[j])
+        for l in range(K):
+            Sj = S[l, o0:o0 + P * P].reshape(P, P, order="F")
+            assert np.array_equal(Sj, Sj.T)
+    assert ctx.factor() == (0 if not (name in ("ce_8_15", "ns_8_15_2") and K <= 3) else ctx.sync_status())
+    ctx.close()
+
+
+@pytest.mark.parametrize("K", [4, 5])
+def test_exact_product_pairings_on_the_trajectory_fixture(K):
+    """The same on real interior-point iterates (tests/golden/ce_8_15_traj.npz, mu from 1e20 to 2e-16, cond(X) up to 2^56): S against the
+    456-bit dense trace formula within the bound of the expansion kernels."""
+    import os
+    import torch
+    from clrs_amd.mw import MwSchurContext
+    f = flat("ce_8_15")
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ce_8_15_traj.npz"))
+    ctx = MwSchurContext(f, limbs=K, exact_products=True)
+    for s, it in enumerate(g["iters"]):
+        X, Y = np.ascontiguousarray(g["X"][s][:K]), np.ascontiguousarray(g["Y"][s][:K])
+        dX, dY = torch.tensor(X, device="cuda:0"), torch.tensor(Y, device="cuda:0")
+        dXc = torch.empty_like(dX)
+        ctx.cholesky_blocks_dev(dX.data_ptr(), dXc.data_ptr())
+        ctx.assemble_dev(dXc.data_ptr(), dY.data_ptr())
+        S, _ = ctx.get_S()
+        eS = mw_relerr(S, g["S"][s])
+        assert eS <= 2.0 ** -(53 * K - 6 - COND_X_BITS[int(it)]), (it, np.log2(eS))
+    ctx.close()
