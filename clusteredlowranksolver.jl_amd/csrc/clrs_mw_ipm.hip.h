@@ -23,6 +23,8 @@ struct MwIpmDev {
     double *sc, *part;                 // planar scalars [MSC_COUNT]; partial dot products [5][NB]
     unsigned long long *fmax;          // bit patterns of non-negative doubles: [0] max|P|, [1] max|d|, [2] max|p|
     double *eig;                       // fp64 [2][NB]: smallest eigenvalue of L^-1 dM L^-T per block (X then Y)
+    double *Wd;                        // fp64 [2][xylen]: the congruences L^-1 dM L^-T rounded to fp64, written by column panels (k_mwi_step)
+    int *wcnt;                         // [2 NB] workgroups of a (block, which) that have delivered their panel
     double *rec;                       // fp64 record of the iteration
     int *flags;                        // [0] pd_feas, [1] error_code, [2] Cholesky failure inside the step length
     const double *C, *c, *b;           // problem data, DK limbs planar (sdp.C xy layout, sdp.c x layout, sdp.b [N])
@@ -951,36 +953,89 @@ __device__ __forceinline__ void mwi_step_congruence(PF F, PR rd, PW W, long wpla
     }
 }
 
+// The congruence by COLUMN PANELS over gridDim.z workgroups per (block, which), for blocks whose inverse factors are both in memory:
+// W[:, c] = Li (dM Li^T[:, c]) is independent column by column (two products, four lanes per entry, rows i >= c only: the lower triangle);
+// the panels go to p.Wd as fp64 heads, the workgroup of a (block, which) that arrives last mirrors them in LDS and takes the eigenvalue.
+// One workgroup issues the two 16-term products of a 16 x 16 block no faster than its four SIMDs allow (14 us); four share them.
+#define MWI_SW 4
+template <int K>
+__device__ __forceinline__ bool mwi_step_panels(const MwDev &q, const MwIpmDev &p, const MwBlk &k, int which, const double *Li, const double *dMg) {
+    using namespace mwk;
+    const int n = k.n, tid = threadIdx.x, sub = tid % MWI_SW;
+    const int zs = gridDim.z, pc0 = (n + zs - 1) / zs, c0 = blockIdx.z * pc0, pc = max(0, min(pc0, n - c0));
+    const long np = (long)n * pc0;
+    lds_d *Us = MW_LDS;                                   // U = dM Li^T[:, panel], n x pc0, K limbs planar
+    for (int e0 = 0; e0 < n * pc; e0 += MW_NT / MWI_SW) {
+        const int e = e0 + tid / MWI_SW;
+        const bool live = e < n * pc;
+        const int ee = live ? e : 0, r = ee % n, c = c0 + ee / n;
+        acc<K> s;
+        acc_zero<K>(s);
+        for (int t = sub; t <= c; t += MWI_SW) acc_fma<K, K, K>(s, ldx<K>(dMg, q.xylen, r + (long)t * n), ldx<K>(Li, q.xylen, c + (long)t * n));
+        const mw<K> v = lanes_sum<K, MWI_SW>(acc_result<K>(s));
+        if (live && sub == 0) stx<K>(Us, np, ee, v);
+    }
+    __syncthreads();
+    double *Wg = p.Wd + (long)which * q.xylen + k.xyoff;
+    for (int e0 = 0; e0 < n * pc; e0 += MW_NT / MWI_SW) {
+        const int e = e0 + tid / MWI_SW;
+        const bool live = e < n * pc;
+        const int ee = live ? e : 0, i = ee % n, cl = ee / n, c = c0 + cl;
+        acc<K> s;
+        acc_zero<K>(s);
+        if (i >= c)
+            for (int r = sub; r <= i; r += MWI_SW) acc_fma<K, K, K>(s, ldx<K>(Li, q.xylen, i + (long)r * n), ldx<K>(Us, np, r + (long)cl * n));
+        const mw<K> v = lanes_sum<K, MWI_SW>(acc_result<K>(s));
+        if (live && sub == 0 && i >= c) Wg[i + (long)c * n] = v.l[0];
+    }
+    return mwi_last_block(&p.wcnt[which * q.NB + blockIdx.x], zs);
+}
+
 // ---- compute_step_length (:1620-1693) per block: smallest eigenvalue of L^-1 dM L^-T, L = chol(M) -----------------------
 // which 0: (X, dX) with the factors of this iteration; which 1: (Y, dY), factored here
 template <int K>
-__device__ __forceinline__ void mwi_step_body(const MwDev &q, const MwIpmDev &p, int w_in_lds, int inv_path, int which_base) {
+__device__ __forceinline__ bool mwi_step_body(const MwDev &q, const MwIpmDev &p, int w_in_lds, int inv_path, int which_base) {
     using namespace mwk;
     const int which = which_base + blockIdx.y;          // both step lengths in one launch (grid.y = 2), or one launch each
     const MwBlk &k = q.blk[blockIdx.x];
     const int n = k.n, tid = threadIdx.x;
     const long nn = (long)n * n;
     const double *Mg = (which == 0 ? p.X : p.Y) + k.xyoff, *dMg = (which == 0 ? p.dX : p.dY) + k.xyoff;
+    // launched with column panels (gridDim.z > 1): only the inverse-factor path of blocks with n > 1 is split; everything else is workgroup z = 0's
+    if (blockIdx.z != 0 && (n == 1 || inv_path != 2 || (which == 1 && p.yfail[blockIdx.x]))) return false;
     if (n == 1) {
         if (tid == 0) {
             mw<K> m = ldx<K>(Mg, q.xylen, 0);
             if (!(m.l[0] > 0.0)) { p.flags[2] = 1; p.eig[(long)which * q.NB + blockIdx.x] = 0.0; }
             else p.eig[(long)which * q.NB + blockIdx.x] = div<K>(ldx<K>(dMg, q.xylen, 0), m).l[0];     // :1637-1641
         }
-        return;
+        return true;
     }
     if (inv_path == 2) {
         // both inverse factors are in memory (Xi from k_mw_potrf_x, Yi from its second half): LDS holds T1, the fp64 matrix, the eigenvalue work space
         lds_d *T1 = MW_LDS, *Wd = T1 + (long)K * nn, *work = Wd + nn;
         if (which == 1 && p.yfail[blockIdx.x]) {                                         // :1644-1646
             if (tid == 0) { p.flags[2] = 1; p.eig[(long)which * q.NB + blockIdx.x] = 0.0; }
-            return;
+            return true;
+        }
+        if (gridDim.z > 1) {
+            if (!mwi_step_panels<K>(q, p, k, which, (which == 0 ? q.Xi : p.Yi) + k.xyoff, dMg)) return false;      // not the last workgroup of this (block, which)
+            lds_d *Wl = MW_LDS, *wk = Wl + nn;
+            const double *Wg = p.Wd + (long)which * q.xylen + k.xyoff;
+            for (int e = tid; e < nn; e += MW_NT) {
+                const int i = e % n, c = e / n;
+                Wl[e] = i >= c ? Wg[e] : Wg[c + (long)i * n];
+            }
+            __syncthreads();
+            const double ev = n <= 32 ? wg_min_eig32(Wl, n, wk, tid) : wg_min_eig(Wl, n, wk, tid);
+            if (tid == 0) p.eig[(long)which * q.NB + blockIdx.x] = ev - 1e-5;            // :1662
+            return true;
         }
         mwi_step_congruence_inv<K>((which == 0 ? q.Xi : p.Yi) + k.xyoff, q.xylen, n, dMg, q.xylen, T1, Wd, tid);
         __syncthreads();
         const double ev = n <= 32 ? wg_min_eig32(Wd, n, work, tid) : wg_min_eig(Wd, n, work, tid);
         if (tid == 0) p.eig[(long)which * q.NB + blockIdx.x] = ev - 1e-5;                // :1662
-        return;
+        return true;
     }
     if (inv_path && k.inv == 1) {
         // LDS: Li (inverse factor; which 0 reads Xi from memory instead), T1, [Y and its factor], rd, the fp64 matrix, eigenvalue work space, scratch
@@ -993,14 +1048,14 @@ __device__ __forceinline__ void mwi_step_body(const MwDev &q, const MwIpmDev &p,
             __syncthreads();
             if (!wg_potrf<K, true, MW_NT, false>(Mf, nn, n, n, rd, n, Li, nn, n, scr, tid)) {                // :1644-1646
                 if (tid == 0) { p.flags[2] = 1; p.eig[(long)which * q.NB + blockIdx.x] = 0.0; }
-                return;
+                return true;
             }
             mwi_step_congruence_inv<K>(Li, nn, n, dMg, q.xylen, T1, Wd, tid);
         }
         __syncthreads();
         const double ev = n <= 32 ? wg_min_eig32(Wd, n, work, tid) : wg_min_eig(Wd, n, work, tid);
         if (tid == 0) p.eig[(long)which * q.NB + blockIdx.x] = ev - 1e-5;                // :1662
-        return;
+        return true;
     }
     // LDS: F (row-scaled factor), [W], rd, the fp64 matrix and the eigenvalue work space, the broadcast slot of the factorisation.
     // Blocks too large for two multi-word matrices in LDS keep W in global memory (the R and P buffers are dead at this point of the iteration).
@@ -1017,7 +1072,7 @@ __device__ __forceinline__ void mwi_step_body(const MwDev &q, const MwIpmDev &p,
         __syncthreads();
         if (!wg_potrf<K, false>(F, nn, n, n, rd, n, F, 0, 0, bc, tid)) {                                 // :1644-1646
             if (tid == 0) { p.flags[2] = 1; p.eig[(long)which * q.NB + blockIdx.x] = 0.0; }
-            return;
+            return true;
         }
         for (int e = tid; e < nn; e += MW_NT) {                                          // row-scaled strict lower triangle, in place
             const int i = e % n, c = e / n;
@@ -1030,11 +1085,13 @@ __device__ __forceinline__ void mwi_step_body(const MwDev &q, const MwIpmDev &p,
     __syncthreads();
     const double ev = n <= 32 ? wg_min_eig32(Wd, n, work, tid) : wg_min_eig(Wd, n, work, tid);
     if (tid == 0) p.eig[(long)which * q.NB + blockIdx.x] = ev - 1e-5;                    // :1662
+    return true;
 }
+
 template <int K, int DK>
 __global__ __launch_bounds__(MW_NT) void k_mwi_step(const MwDev q, const MwIpmDev p, int w_in_lds, int inv_path, int iter, int which_base) {
-    mwi_step_body<K>(q, p, w_in_lds, inv_path, which_base);
-    // the workgroup that arrives last -- of BOTH halves, 2 NB workgroups in one launch or two -- takes the step lengths
+    if (!mwi_step_body<K>(q, p, w_in_lds, inv_path, which_base)) return;      // a column panel that was not the last one of its (block, which)
+    // the workgroup that arrives last -- of the 2 NB that end a (block, which), in one launch or two -- takes the step lengths
     if (q.world > 1) return;                            // sharded: the minima travel first (k_mwi_gpack, all-gather, k_mwi_scalar stage 3)
     if (mwi_last_block(&p.flags[4], 2u * q.NB) && threadIdx.x < 64) mwi_scalar_stage<K, DK>(q, p, 3, iter);
 }
