@@ -64,7 +64,7 @@ def main():
     ap.add_argument("--limbs", type=int, default=5, help="fp64 words per number (5 covers the reference's prec = 256)")
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--skip-fp64", action="store_true", help="skip the fp64 measurements (Schur-assembly HBM roofline, fp64 step on the problem's shapes)")
-    ap.add_argument("--mw-copies", type=int, default=128, help="replication factor of the multi-word roofline instance")
+    ap.add_argument("--mw-copies", type=int, default=1024, help="replication factor of the multi-word roofline instance (2 clusters each)")
     ap.add_argument("--split", action="store_true", help="with one GPU: still take the sharded code path (1-rank process group, RCCL all-gathers inside the library)")
     args = ap.parse_args()
 
@@ -348,26 +348,29 @@ def main():
         # ---- multi-word Schur assembly on a many-cluster instance: against the fp64 pipe ----
         try:
             from clrs_amd.sdp import replicate_clusters
-            big = replicate_clusters(flat, args.mw_copies)
-            bctx = MwSchurContext(big, limbs=K, device=local_rank, timing=True)
-            bX, bY = np.tile(X, (1, args.mw_copies)), np.tile(Y, (1, args.mw_copies))
-            tbX, tbY = torch.tensor(bX, device=dev), torch.tensor(bY, device=dev)
-            tbXc = torch.empty_like(tbX)
-            bctx.cholesky_blocks_dev(tbX.data_ptr(), tbXc.data_ptr())
-            for _ in range(3):
-                bctx.assemble_dev(tbXc.data_ptr(), tbY.data_ptr())
-            reps = 10
-            bctx.set_timing(False)
-            torch.cuda.synchronize()
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s_ = torch.cuda.ExternalStream(bctx.stream())
-            with torch.cuda.stream(s_):
-                ev0.record()
-                for _ in range(reps):
-                    bctx.assemble_dev(tbXc.data_ptr(), tbY.data_ptr())
-                ev1.record()
-            ev1.synchronize()
-            asm_s = 1e-3 * ev0.elapsed_time(ev1) / reps
+
+            def mw_assembly(copies, reps=10):
+                big_ = replicate_clusters(flat, copies)
+                bctx_ = MwSchurContext(big_, limbs=K, device=local_rank, timing=True)
+                tbX, tbY = torch.tensor(np.tile(X, (1, copies)), device=dev), torch.tensor(np.tile(Y, (1, copies)), device=dev)
+                tbXc = torch.empty_like(tbX)
+                bctx_.cholesky_blocks_dev(tbX.data_ptr(), tbXc.data_ptr())
+                for _ in range(3):
+                    bctx_.assemble_dev(tbXc.data_ptr(), tbY.data_ptr())
+                bctx_.set_timing(False)
+                torch.cuda.synchronize()
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s_ = torch.cuda.ExternalStream(bctx_.stream())
+                with torch.cuda.stream(s_):
+                    ev0.record()
+                    for _ in range(reps):
+                        bctx_.assemble_dev(tbXc.data_ptr(), tbY.data_ptr())
+                    ev1.record()
+                ev1.synchronize()
+                return big_, bctx_, 1e-3 * ev0.elapsed_time(ev1) / reps, reps
+
+            # the instance that fills the chip (two workgroups of k_mws_pair per compute unit: 512 at a time, 3072 low-rank blocks here) ...
+            big, bctx, asm_s, reps = mw_assembly(args.mw_copies)
             muladds = bctx.counters()["assemble_muladds"]
             flops_alg = muladds * K * (K + 1)
             out["roofline_mw"] = {"bound": "mfma", "phase": "schur_assemble (multi-word)", "kernel": "k_mws_pair (exact slice products, v_mfma_f64_16x16x4) + k_mw_dense_t + k_mw_saccum",
@@ -399,8 +402,15 @@ def main():
             except Exception as e:
                 out["roofline_mw"]["executed_error"] = repr(e)
             bctx.close()
+            # ... and the 256-cluster instance of rounds 1-2 (384 low-rank blocks: less than one round of workgroups, the launch is bound by the
+            # latency of one workgroup, not by the pipe)
+            big2, bctx2, asm2, _ = mw_assembly(128)
+            m2 = bctx2.counters()["assemble_muladds"]
+            out["roofline_mw"]["instance_of_rounds_1_2"] = {"workload": f"{big2.n_clusters} clusters / {big2.n_blocks} PSD blocks", "assembly_us": 1e6 * asm2,
+                                                            "achieved": m2 * K * (K + 1) / asm2 / 1e12, "frac": m2 * K * (K + 1) / asm2 / 1e12 / FP64_PEAK_TFLOPS}
+            bctx2.close()
         except Exception as e:
-            out["roofline_mw"] = {"error": repr(e)}
+            out.setdefault("roofline_mw", {})["error"] = repr(e)
 
         # ---- the kernel that dominates the TIMED step: k_mw_factor (one 32 x 32 Cholesky + inverse factor per cluster, 4 workgroups each) ----
         # Its roof is the fp64 issue rate of the compute units it occupies (one fp64 VALU wave instruction holds its SIMD for 4 cycles); the

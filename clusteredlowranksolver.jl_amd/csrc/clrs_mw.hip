@@ -371,6 +371,8 @@ extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int dev
         int mostb = 1;
         for (int j = 0; j < J; j++) mostb = std::max(mostb, c->clu[j].b1 - c->clu[j].b0);
         c->sa_lanes = mostb >= 3 ? 4 : mostb;
+        // (one lane per entry when the launch fills the chip anyway was tried at 2048 clusters: 30 M wave instructions instead of 90 M, and
+        // 390 us instead of 245: the chains of dependent loads of a cluster's blocks, one after the other, cost more than the idle lanes)
     }
     c->cnt_mul = cnt_mul;
     for (int j = 0; j < J; j++) {
@@ -433,8 +435,8 @@ extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int dev
         for (int b = 0; b < NB; b++) {
             const MwBlk &k = c->blk[b];
             if (k.kind != 0 || !k.inv || k.n > 32) continue;
-            const int n = k.n, U = k.U, np = (n + 3) & ~3, n16 = (n + 15) & ~15, U16 = (U + 15) & ~15, rV = MWS_ROWPAD(U16);
-            if ((n16 / 16) * (U16 / 16) > 4 || mws_lds_bytes(S, n, U) > MW_LDS_MAX) continue;
+            const int n = k.n, U = k.U, np = (n + 3) & ~3, n16 = (n + 15) & ~15, U16 = (U + 15) & ~15, rV = mws_rowstride(U16);
+            if ((n16 / 16) * (U16 / 16) > 4 || mws_lds_bytes(S, mws_sv_class(S, 1), n, U) > MW_LDS_MAX) continue;
             if (2 * (n16 / 16) * (U16 / 16) > 4) c->mws_turns = 2;
             mws_off[b] = (long long)hVs.size();
             hve_off[b] = (int)hVe.size();
@@ -457,7 +459,7 @@ extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int dev
                         volatile double tv = r0 + C;               // (no contraction or reassociation of the rounding trick on the host)
                         const double t = tv - C;
                         const float dgt = (float)(t * std::ldexp(1.0, (s + 1) * MWS_BETA));
-                        dst[(size_t)s * np * rV + (size_t)i * rV + u] = dgt;      // [s][k = row i of V][col = u]
+                        dst[(size_t)s * np * rV + (size_t)i * rV + mws_col(i, u, U16)] = dgt;      // [s][k = row i of V][col = u]
                         if (dgt != 0.0f) sv = std::max(sv, s + 1);
                         r0 -= t;
                         double sm, er;
@@ -466,9 +468,14 @@ extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int dev
                     }
                 }
             }
+            if (mws_lds_bytes(S, mws_sv_class(S, sv), n, U) > MW_LDS_MAX) {      // (the test above assumed the fewest slices of V)
+                hVs.resize((size_t)mws_off[b]); hVe.resize((size_t)hve_off[b]);
+                mws_off[b] = -1;
+                continue;
+            }
             hsv[b] = sv;
             c->mws_blocks++;
-            c->sm_mws = std::max(c->sm_mws, mws_lds_bytes(S, n, U));
+            c->sm_mws = std::max(c->sm_mws, mws_lds_bytes(S, mws_sv_class(S, sv), n, U));
         }
         const bool on = g_cfg_mw_exact_products == 2 ? c->mws_blocks > 0 : (g_cfg_mw_exact_products == 1 && c->mws_blocks >= 256);
         if (!on) { c->mws_blocks = 0; std::fill(mws_off.begin(), mws_off.end(), -1); }

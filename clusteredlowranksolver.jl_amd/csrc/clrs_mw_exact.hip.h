@@ -93,13 +93,14 @@ __device__ __forceinline__ mwa::mw<K> mws_recombine(const v4d_mw (&acc)[S], int 
 }
 
 // one 16 x 16 output tile: acc[o] += sum over the pairs s + t = o, s < SA, t < SB, and the k-steps, of A_s^T-style products
-//   A operand: As[s][k][i0 + l15], B operand: Bs[t][k][j0 + l15]; strides in floats: slice strides sa / sb, row (k) strides ra / rb
+//   A operand: As[s][k][ca + l15], B operand: Bs[t][k][cb + l15]; strides in floats: slice strides sa / sb, row (k) strides ra / rb; ca, cb: the
+//   tile's first column as this lane's k-rows hold it (mws_tilecol)
 // SA, SB are compile-time: every digit of a k-step is in registers before its first MFMA and the MFMA sequence has no branch in it.
 template <int S, int SA, int SB>
-__device__ __forceinline__ void mws_tile(v4d_mw (&acc)[S], const lds_f *As, int sa, int ra, const lds_f *Bs, int sb, int rb, int ksteps, int l15, int l4) {
+__device__ __forceinline__ void mws_tile(v4d_mw (&acc)[S], const lds_f *As, int sa, int ra, int ca, const lds_f *Bs, int sb, int rb, int cb, int ksteps, int l15, int l4) {
 #pragma unroll
     for (int o = 0; o < S; o++) acc[o] = (v4d_mw){0.0, 0.0, 0.0, 0.0};
-    const lds_f *ap = As + l4 * ra + l15, *bp = Bs + l4 * rb + l15;
+    const lds_f *ap = As + l4 * ra + ca + l15, *bp = Bs + l4 * rb + cb + l15;
     for (int ks = 0; ks < ksteps; ks++) {
         float af[SA], bf[SB];
 #pragma unroll
@@ -118,25 +119,25 @@ __device__ __forceinline__ void mws_tile(v4d_mw (&acc)[S], const lds_f *As, int 
         }
     }
 }
-// the static operand (V) has SV <= S slices that are not all zero: instantiations for SV rounded up to S/2, 3S/4, S
+// the static operand (V) has SV <= S slices that are not all zero: instantiations for SV rounded up to S/2, 3S/4, S (mws_sv_class)
 template <int S, bool V_IS_A>
-__device__ __forceinline__ void mws_tile_v(v4d_mw (&acc)[S], int SV, const lds_f *As, int sa, int ra, const lds_f *Bs, int sb, int rb, int ksteps, int l15, int l4) {
+__device__ __forceinline__ void mws_tile_v(v4d_mw (&acc)[S], int SV, const lds_f *As, int sa, int ra, int ca, const lds_f *Bs, int sb, int rb, int cb, int ksteps, int l15, int l4) {
     constexpr int S1 = (S + 1) / 2, S2 = (3 * S + 3) / 4;
     if (V_IS_A) {
-        if (SV <= S1) mws_tile<S, S1, S>(acc, As, sa, ra, Bs, sb, rb, ksteps, l15, l4);
-        else if (SV <= S2) mws_tile<S, S2, S>(acc, As, sa, ra, Bs, sb, rb, ksteps, l15, l4);
-        else mws_tile<S, S, S>(acc, As, sa, ra, Bs, sb, rb, ksteps, l15, l4);
+        if (SV <= S1) mws_tile<S, S1, S>(acc, As, sa, ra, ca, Bs, sb, rb, cb, ksteps, l15, l4);
+        else if (SV <= S2) mws_tile<S, S2, S>(acc, As, sa, ra, ca, Bs, sb, rb, cb, ksteps, l15, l4);
+        else mws_tile<S, S, S>(acc, As, sa, ra, ca, Bs, sb, rb, cb, ksteps, l15, l4);
     } else {
-        if (SV <= S1) mws_tile<S, S, S1>(acc, As, sa, ra, Bs, sb, rb, ksteps, l15, l4);
-        else if (SV <= S2) mws_tile<S, S, S2>(acc, As, sa, ra, Bs, sb, rb, ksteps, l15, l4);
-        else mws_tile<S, S, S>(acc, As, sa, ra, Bs, sb, rb, ksteps, l15, l4);
+        if (SV <= S1) mws_tile<S, S, S1>(acc, As, sa, ra, ca, Bs, sb, rb, cb, ksteps, l15, l4);
+        else if (SV <= S2) mws_tile<S, S, S2>(acc, As, sa, ra, ca, Bs, sb, rb, cb, ksteps, l15, l4);
+        else mws_tile<S, S, S>(acc, As, sa, ra, ca, Bs, sb, rb, cb, ksteps, l15, l4);
     }
 }
 
 }  // namespace mwk
 
-// static slices of V of every eligible block: digits [S][np][Up] (np = n rounded up to 4, Up = U rounded up to 16, + 16 floats of padding
-// per row so that the four k-rows of an operand read fall into different banks), column exponents [Up]
+// static slices of V of every eligible block: digits [S][np][mws_rowstride(Up)] in the column order of mws_col (np = n rounded up to 4,
+// Up = U rounded up to 16), column exponents [Up]
 struct MwsDev {
     const float *Vs;         // digits, per block at vs_off
     const int *Vexp;         // per block at ve_off
@@ -146,11 +147,19 @@ struct MwsDev {
     unsigned long long *stamps;   // diagnostic: wall_clock64 at the phase boundaries of wave 0 of workgroup 0 (or null)
 };
 
-#define MWS_ROWPAD(cols) ((cols) + 16)
+// Layout of a slice array [slice][k][col] with c16 columns (a multiple of 16).  A wave reads four consecutive k-rows of one 16-column tile at
+// once; the four rows must fall into different quarters of the 64 banks.  An odd number of tiles per row does that by itself; two tiles per row
+// (32 columns, the named shapes) by exchanging the two tiles in the rows with bit 1 of k set; other even counts by one tile of padding.
+// (Half the LDS of the padded form of the first version: two workgroups per compute unit instead of one.)
+__host__ __device__ __forceinline__ int mws_rowstride(int c16) { const int m = c16 / 16; return ((m & 1) || m == 2) ? c16 : c16 + 16; }
+__host__ __device__ __forceinline__ int mws_col(int k, int col, int c16) { return c16 == 32 ? col ^ (((k >> 1) & 1) << 4) : col; }
+__device__ __forceinline__ int mws_tilecol(int tile, int l4, int c16) { return c16 == 32 ? (tile ^ (l4 >> 1)) * 16 : tile * 16; }     // k = 4 ks + l4
+// slices of V kept in LDS: the class of mws_tile_v its count of non-zero slices falls into
+__host__ __device__ __forceinline__ int mws_sv_class(int S, int SV) { const int S1 = (S + 1) / 2, S2 = (3 * S + 3) / 4; return SV <= S1 ? S1 : SV <= S2 ? S2 : S; }
 // LDS of one workgroup in floats: V slices, the Y / Xi slices (later: the T slices), the Z slices, + exponents
-static inline size_t mws_lds_bytes(int S, int n, int U) {
+static inline size_t mws_lds_bytes(int S, int SVc, int n, int U) {
     const int np = (n + 3) & ~3, n16 = (n + 15) & ~15, U16 = (U + 15) & ~15;
-    const size_t vsl = (size_t)S * np * MWS_ROWPAD(U16), yx = (size_t)2 * S * np * MWS_ROWPAD(n16), tz = (size_t)S * np * MWS_ROWPAD(U16);
+    const size_t vsl = (size_t)SVc * np * mws_rowstride(U16), yx = (size_t)2 * S * np * mws_rowstride(n16), tz = (size_t)S * np * mws_rowstride(U16);
     return (vsl + (yx > tz ? yx : tz) + tz) * sizeof(float) + (size_t)(2 * n16 + 3 * U16 + 8 * U16) * sizeof(int);
 }
 
@@ -164,16 +173,16 @@ __global__ __launch_bounds__(MWS_NT, 2) void k_mws_pair(const MwDev q, const Mws
     const MwBlk &k = q.blk[b];
     const int n = k.n, U = k.U, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
     const int np = (n + 3) & ~3, n16 = (n + 15) & ~15, U16 = (U + 15) & ~15, ksteps = np / 4;
-    const int rV = MWS_ROWPAD(U16), rY = MWS_ROWPAD(n16), sV = np * rV, sY = np * rY;
-    const int SV = w.sv[b];
+    const int rV = mws_rowstride(U16), rY = mws_rowstride(n16), sV = np * rV, sY = np * rY;
+    const int SV = w.sv[b], SVc = mws_sv_class(S, SV);
     extern __shared__ __attribute__((aligned(16))) float mws_lds[];
     const bool stamp = w.stamps && blockIdx.x == 0 && tid == 0;
     int nst = 0;
 #define MWS_STAMP() do { if (stamp) w.stamps[nst++] = wall_clock64(); } while (0)
     MWS_STAMP();
-    lds_f *Vsl = (lds_f *)mws_lds;                              // [S][np][rV]
+    lds_f *Vsl = (lds_f *)mws_lds;                              // [SVc][np][rV]
     const size_t yx = (size_t)2 * S * sY, tz = (size_t)S * sV;
-    lds_f *Ysl = Vsl + (size_t)S * sV, *Xsl = Ysl + (size_t)S * sY;      // [S][np][rY] each; the T slices overlay them later
+    lds_f *Ysl = Vsl + (size_t)SVc * sV, *Xsl = Ysl + (size_t)S * sY;      // [S][np][rY] each; the T slices overlay them later
     lds_f *Tsl = Ysl, *Zsl = Ysl + (yx > tz ? yx : tz);         // [S][np][rV] each
     int *eY = (int *)(Zsl + tz), *eX = eY + n16, *fV = eX + n16, *fT = fV + U16, *fZ = fT + U16, *part = fZ + U16;      // part: [2][4][U16] column maxima per row tile
     // ---- phase A: V slices (static), row exponents of Y and Xi, their slices ----
@@ -181,7 +190,7 @@ __global__ __launch_bounds__(MWS_NT, 2) void k_mws_pair(const MwDev q, const Mws
         typedef float v4f_mw __attribute__((ext_vector_type(4)));
         const v4f_mw *gv = (const v4f_mw *)(w.Vs + w.vs_off[b]);
         v4f_mw __attribute__((address_space(3))) *lv = (v4f_mw __attribute__((address_space(3))) *)Vsl;
-        const int nq = S * sV / 4, nv = SV * sV / 4;          // sV is a multiple of 4 (rows of U16 + 16 floats)
+        const int nq = SVc * sV / 4, nv = SV * sV / 4;          // sV is a multiple of 4 (rows of U16 + 16 floats)
         for (int e0 = 0; e0 < nq; e0 += 4 * MWS_NT) {          // four 16-byte loads in flight per thread and pass
             v4f_mw v[4];
 #pragma unroll
@@ -210,7 +219,7 @@ __global__ __launch_bounds__(MWS_NT, 2) void k_mws_pair(const MwDev q, const Mws
     __syncthreads();
     for (int e = tid; e < 2 * n * n; e += MWS_NT) {
         const int which = e / (n * n), ee = e % (n * n), i = ee % n, c = ee / n;        // entry (row i, column c): A operand [k = c][col = i]
-        lds_f *dst = (which == 0 ? Ysl : Xsl) + c * rY + i;
+        lds_f *dst = (which == 0 ? Ysl : Xsl) + c * rY + mws_col(c, i, n16);
         if (which == 1 && c > i) {                           // Xi is lower triangular
 #pragma unroll
             for (int sl = 0; sl < S; sl++) dst[sl * sY] = 0.0f;
@@ -235,7 +244,7 @@ __global__ __launch_bounds__(MWS_NT, 2) void k_mws_pair(const MwDev q, const Mws
         if (task >= ntask) break;
         tsk[turn] = task;
         const int which = task / (ntn * ntu), ti = (task / ntu) % ntn, tj = task % ntu;
-        mws_tile_v<S, false>(acc, SV, (which == 0 ? Ysl : Xsl) + ti * 16, sY, rY, Vsl + tj * 16, sV, rV, ksteps, l15, l4);
+        mws_tile_v<S, false>(acc, SV, which == 0 ? Ysl : Xsl, sY, rY, mws_tilecol(ti, l4, n16), Vsl, sV, rV, mws_tilecol(tj, l4, U16), ksteps, l15, l4);
         MWS_STAMP();
         int cmax = -100000;
 #pragma unroll
@@ -269,20 +278,22 @@ __global__ __launch_bounds__(MWS_NT, 2) void k_mws_pair(const MwDev q, const Mws
         for (int reg = 0; reg < 4; reg++) {
             const int i = ti * 16 + 4 * reg + l4, j = tj * 16 + l15;        // entry (row i, column j) of T / Z: operand [k = i][col = j]
             if (i >= n || j >= U) continue;
-            lds_f *dst = (which == 0 ? Tsl : Zsl) + i * rV + j;
+            lds_f *dst = (which == 0 ? Tsl : Zsl) + i * rV + mws_col(i, j, U16);
             mws_slice<K, S>(res[turn][reg], (which == 0 ? fT : fZ)[j], [&](int s, float d) { dst[s * sV] = d; });
         }
     }
     __syncthreads();
     MWS_STAMP();
     // ---- phase D: GX = Z^T Z, GY = V^T T, lower tiles; GX tiles first (they are the longer tasks: all S slices on both sides) ----
+    // (six tiles on four waves at the named shapes: waves 0, 1 get two.  Workgroups of odd index deal the tiles in the opposite wave order, so
+    // that two workgroups that share a compute unit do not leave the same SIMDs idle.)
     const int ntri = ntu * (ntu + 1) / 2;
-    for (int task = wave; task < 2 * ntri; task += 4) {
+    for (int task = (blockIdx.x & 1) ? 3 - wave : wave; task < 2 * ntri; task += 4) {
         const int which = task / ntri;                      // 0: GX, 1: GY
         int ti, tj;
         tri_index(task % ntri, ti, tj);                     // ti >= tj
-        if (which == 0) mws_tile<S, S, S>(acc, Zsl + ti * 16, sV, rV, Zsl + tj * 16, sV, rV, ksteps, l15, l4);
-        else mws_tile_v<S, true>(acc, SV, Vsl + ti * 16, sV, rV, Tsl + tj * 16, sV, rV, ksteps, l15, l4);
+        if (which == 0) mws_tile<S, S, S>(acc, Zsl, sV, rV, mws_tilecol(ti, l4, U16), Zsl, sV, rV, mws_tilecol(tj, l4, U16), ksteps, l15, l4);
+        else mws_tile_v<S, true>(acc, SV, Vsl, sV, rV, mws_tilecol(ti, l4, U16), Tsl, sV, rV, mws_tilecol(tj, l4, U16), ksteps, l15, l4);
         MWS_STAMP();
         double *G = (which == 0 ? q.GX : q.GY) + k.g_off;
 #pragma unroll

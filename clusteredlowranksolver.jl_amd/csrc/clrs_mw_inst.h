@@ -37,7 +37,7 @@
     X __global__ void k_mw_saccum<K, DK>(const MwDev, int);                                                                 \
     X __global__ void k_mw_linvb<K, DK>(const MwDev);                                                                  \
     X __global__ void k_mwi_scalar<K, DK>(const MwDev, const MwIpmDev, int, int);                                      \
-    X __global__ void k_mwi_dots<K, DK>(const MwDev, const MwIpmDev, int);                                             \
+    X __global__ void k_mwi_dots<K, DK>(const MwDev, const MwIpmDev, int, int);                                             \
     X __global__ void k_mwi_coef<K, DK>(const MwDev, const MwIpmDev, const double *);                                  \
     X __global__ void k_mwi_wA<K, DK>(const MwDev, const MwIpmDev, int, int);                                               \
     X __global__ void k_mwi_MV<K, DK>(const MwDev, const double *);                                                    \

@@ -480,11 +480,42 @@ __global__ void k_mwi_scalar(const MwDev q, const MwIpmDev p, int stage, int ite
 }
 
 
+// ---- R' = - X Y [- dX dY]: compute_residual_R! (src/solver.jl:961-983) without its mu_s I, which the consumers (k_mwi_Zi, k_mwi_Z)
+// add on the diagonal of their first product -- the products do not depend on mu_p / mu_c, so this kernel runs beside the scalar
+// stages that produce them instead of behind them -------------------------------------------------------------------------
+#define MWI_EW 4              // lanes per matrix entry in the block products of the iteration
+template <int K>
+__device__ __forceinline__ void mwi_R_body(const MwDev &q, const MwIpmDev &p, int corrector, int bx, int by) {
+    using namespace mwk;
+    const MwBlk &k = q.blk[by];
+    const int n = k.n;
+    if (bx * (MW_NT / MWI_EW) >= n * n) return;
+    const int e = bx * (MW_NT / MWI_EW) + threadIdx.x / MWI_EW, sub = threadIdx.x % MWI_EW;
+    const bool live = e < n * n;
+    const int ee = live ? e : 0, i = ee % n, c = ee / n;
+    acc<K> s;
+    acc_zero<K>(s);
+    for (int kk = sub; kk < n; kk += MWI_EW) acc_fma<K, K, K>(s, ldx<K>(p.X + k.xyoff, q.xylen, i + (long)kk * n), ldx<K>(p.Y + k.xyoff, q.xylen, kk + (long)c * n), -1.0);
+    if (corrector)
+        for (int kk = sub; kk < n; kk += MWI_EW) acc_fma<K, K, K>(s, ldx<K>(p.dX + k.xyoff, q.xylen, i + (long)kk * n), ldx<K>(p.dY + k.xyoff, q.xylen, kk + (long)c * n), -1.0);
+    const mw<K> v = lanes_sum<K, MWI_EW>(acc_result<K>(s));
+    if (live && sub == 0) stx<K>(p.R + k.xyoff, q.xylen, e, v);
+}
+template <int K>
+__global__ __launch_bounds__(MW_NT) void k_mwi_R(const MwDev q, const MwIpmDev p, int corrector) { mwi_R_body<K>(q, p, corrector, blockIdx.x, blockIdx.y); }
+
 // ---- block dot products: partial sums per PSD block ------------------------------------------------------------------
 // sel bit 0: <X,Y>; bit 1: <X,dY>, <dX,Y>, <dX,dY>; bit 2: <C,Y>
+// r_tiles > 0: the launch carries r_tiles * NB more workgroups that form the corrector's R' = -XY - dX dY (mwi_R_body): it depends on the
+// predictor's dX, dY only, like the dot products, and not on the beta_c they lead to -- one launch, side by side, instead of two in a row
 template <int K, int DK>
-__global__ __launch_bounds__(MW_NT) void k_mwi_dots(const MwDev q, const MwIpmDev p, int sel) {
+__global__ __launch_bounds__(MW_NT) void k_mwi_dots(const MwDev q, const MwIpmDev p, int sel, int r_tiles) {
     using namespace mwk;
+    if ((int)blockIdx.x >= q.NB) {
+        const int w = blockIdx.x - q.NB;
+        mwi_R_body<K>(q, p, 1, w % r_tiles, w / r_tiles);
+        return;
+    }
     const MwBlk &k = q.blk[blockIdx.x];
     const int tid = threadIdx.x;
     const long nn = (long)k.n * k.n;
@@ -510,28 +541,6 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_dots(const MwDev q, const MwIpmDe
     if (sel & 4) { mw<K> r = wg_reduce_sum<K>(acc_result<K>(a4), red, tid); if (tid == 0) stx<K>(p.part, 5L * q.NB, 4L * q.NB + blockIdx.x, r); }
 }
 
-
-// ---- R' = - X Y [- dX dY]: compute_residual_R! (src/solver.jl:961-983) without its mu_s I, which the consumers (k_mwi_Zi, k_mwi_Z)
-// add on the diagonal of their first product -- the products do not depend on mu_p / mu_c, so this kernel runs beside the scalar
-// stages that produce them instead of behind them -------------------------------------------------------------------------
-#define MWI_EW 4              // lanes per matrix entry in the block products of the iteration
-template <int K>
-__global__ __launch_bounds__(MW_NT) void k_mwi_R(const MwDev q, const MwIpmDev p, int corrector) {
-    using namespace mwk;
-    const MwBlk &k = q.blk[blockIdx.y];
-    const int n = k.n;
-    if (blockIdx.x * (MW_NT / MWI_EW) >= n * n) return;
-    const int e = blockIdx.x * (MW_NT / MWI_EW) + threadIdx.x / MWI_EW, sub = threadIdx.x % MWI_EW;
-    const bool live = e < n * n;
-    const int ee = live ? e : 0, i = ee % n, c = ee / n;
-    acc<K> s;
-    acc_zero<K>(s);
-    for (int kk = sub; kk < n; kk += MWI_EW) acc_fma<K, K, K>(s, ldx<K>(p.X + k.xyoff, q.xylen, i + (long)kk * n), ldx<K>(p.Y + k.xyoff, q.xylen, kk + (long)c * n), -1.0);
-    if (corrector)
-        for (int kk = sub; kk < n; kk += MWI_EW) acc_fma<K, K, K>(s, ldx<K>(p.dX + k.xyoff, q.xylen, i + (long)kk * n), ldx<K>(p.dY + k.xyoff, q.xylen, kk + (long)c * n), -1.0);
-    const mw<K> v = lanes_sum<K, MWI_EW>(acc_result<K>(s));
-    if (live && sub == 0) stx<K>(p.R + k.xyoff, q.xylen, e, v);
-}
 
 // ---- coefficients a_p * lambda_t of the sorted terms -------------------------------------------------------------------
 template <int K, int DK>
@@ -1088,14 +1097,6 @@ __device__ __forceinline__ bool mwi_step_body(const MwDev &q, const MwIpmDev &p,
     return true;
 }
 
-template <int K, int DK>
-__global__ __launch_bounds__(MW_NT) void k_mwi_step(const MwDev q, const MwIpmDev p, int w_in_lds, int inv_path, int iter, int which_base) {
-    if (!mwi_step_body<K>(q, p, w_in_lds, inv_path, which_base)) return;      // a column panel that was not the last one of its (block, which)
-    // the workgroup that arrives last -- of the 2 NB that end a (block, which), in one launch or two -- takes the step lengths
-    if (q.world > 1) return;                            // sharded: the minima travel first (k_mwi_gpack, all-gather, k_mwi_scalar stage 3)
-    if (mwi_last_block(&p.flags[4], 2u * q.NB) && threadIdx.x < 64) mwi_scalar_stage<K, DK>(q, p, 3, iter);
-}
-
 // ---- x, X += alpha_d (dx, dX); y, Y += alpha_p (dy, dY)  (:485-495); skipped when the iteration ended with an error ------
 template <int K>
 __global__ __launch_bounds__(MW_NT) void k_mwi_update(const MwDev q, const MwIpmDev p) {
@@ -1130,6 +1131,15 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_update(const MwDev q, const MwIpm
             stx<K>(p.y, q.N, a, acc_result<K>(s));
         }
     }
+}
+
+template <int K, int DK>
+__global__ __launch_bounds__(MW_NT) void k_mwi_step(const MwDev q, const MwIpmDev p, int w_in_lds, int inv_path, int iter, int which_base) {
+    if (!mwi_step_body<K>(q, p, w_in_lds, inv_path, which_base)) return;      // a column panel that was not the last one of its (block, which)
+    // the workgroup that arrives last -- of the 2 NB that end a (block, which), in one launch or two -- takes the step lengths
+    // (moving the iterate here as well, by this one workgroup, is slower than the launch of k_mwi_update it saves: 45 against 35 + 6 us)
+    if (q.world > 1) return;                            // sharded: the minima travel first (k_mwi_gpack, all-gather, k_mwi_scalar stage 3)
+    if (mwi_last_block(&p.flags[4], 2u * q.NB) && threadIdx.x < 64) mwi_scalar_stage<K, DK>(q, p, 3, iter);
 }
 
 // X = omega_p I, Y = omega_d I, x = y = 0 (:187-201)
