@@ -662,14 +662,16 @@ extern "C" int clrs_mw_schur_assemble_dev(clrs_mw_ctx *c, const double *d_Xchol,
         const bool exact = c->mws_blocks > 0 && c->xinv_valid;      // the exact-product kernel needs chol(X)^-1 (k_mw_potrf_x of this context)
         if (exact && c->mws_turns == 1) hipLaunchKernelGGL((k_mws_pair<KK, DD, 1>), dim3(q.nlr), dim3(MWS_NT), c->sm_mws, c->stream, q, c->mws, d_Y);
         else if (exact) hipLaunchKernelGGL((k_mws_pair<KK, DD, 2>), dim3(q.nlr), dim3(MWS_NT), c->sm_mws, c->stream, q, c->mws, d_Y);
+        bool dense_done = false;
         if (q.nlr && !(exact && c->mws_blocks == q.nlr)) {
             MwDev q2 = q;
             q2.mws_on = exact ? 1 : 0;
             const int gper = MW_NT / MW_GRAM_W;
             hipLaunchKernelGGL((k_mw_zt<KK, DD>), dim3((c->maxU + MW_CT - 1) / MW_CT, q.nlr), dim3(MW_NT), c->sm_zt, c->stream, q2, d_Y, c->lds_zt_L ? 1 : 0, c->xinv_valid ? 1 : 0);
-            hipLaunchKernelGGL((k_mw_gram<KK, DD>), dim3((c->maxU * (c->maxU + 1) / 2 + gper - 1) / gper, q.nlr), dim3(MW_NT), 0, c->stream, q2);
+            dense_done = q.ndn && !q.dn_big;                // 1 x 1 dense blocks ride on this launch
+            hipLaunchKernelGGL((k_mw_gram<KK, DD>), dim3((c->maxU * (c->maxU + 1) / 2 + gper - 1) / gper, q.nlr + (dense_done ? q.ndn : 0)), dim3(MW_NT), 0, c->stream, q2, d_Y);
         }
-        if (q.ndn) {
+        if (q.ndn && !dense_done) {
             hipLaunchKernelGGL((k_mw_dense_t<KK, DD>), dim3(q.ndn, q.dn_big ? c->maxcnt : 1), dim3(MW_NT), c->sm_dense, c->stream, q, d_Y, c->xinv_valid ? 1 : 0, c->dense_two ? 1 : 0);
             const int pairs = c->maxcnt * (c->maxcnt + 1) / 2;
             if (q.dn_big) hipLaunchKernelGGL((k_mw_dense_s<KK, DD>), dim3(q.ndn, (pairs + MW_NT / 64 - 1) / (MW_NT / 64)), dim3(MW_NT), 0, c->stream, q);

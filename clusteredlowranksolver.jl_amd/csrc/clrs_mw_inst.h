@@ -29,7 +29,7 @@
 
 #define MW_KERNELS_KD(X, K, DK)                                                                                        \
     X __global__ void k_mw_zt<K, DK>(const MwDev, const double *, int, int);                                           \
-    X __global__ void k_mw_gram<K, DK>(const MwDev);                                                                   \
+    X __global__ void k_mw_gram<K, DK>(const MwDev, const double *);                                                                   \
     X __global__ void k_mws_pair<K, DK, 1>(const MwDev, const MwsDev, const double *);                                 \
     X __global__ void k_mws_pair<K, DK, 2>(const MwDev, const MwsDev, const double *);                                                                   \
     X __global__ void k_mw_dense_t<K, DK>(const MwDev, const double *, int, int);                                      \

@@ -556,9 +556,34 @@ __global__ __launch_bounds__(MW_NT) void k_mw_zt(const MwDev q, const double *__
 // reference's bilinear_pairings_Xinv / _Y, src/solver.jl:1131, 1143).  Four lanes per entry of the lower triangle.
 // ---------------------------------------------------------------------------------------------------------------------
 #define MW_GRAM_W 4
+// a 1 x 1 dense block: T_e = (Y / X) a_e and the table Sd[e, e'] = a_e' T_e right behind it, one thread per matrix, then per pair
 template <int K, int DK>
-__global__ __launch_bounds__(MW_NT) void k_mw_gram(const MwDev q) {
+__device__ __forceinline__ void mw_dense_1x1(const MwDev &q, const MwBlk &k, const double *__restrict__ Y, int tid) {
     using namespace mwk;
+    const int cnt = k.cnt;
+    const double *A = q.dA + k.a_off;
+    double *W = q.W + k.w_off;
+    mw<K> rd = ldx<K>(q.xrd + k.rd_off, q.xrdlen, 0);
+    mw<K> yx = mul<K>(ldx<K>(Y + k.xyoff, q.xylen, 0), mul<K>(rd, rd));      // Y / X
+    for (int ee = tid; ee < cnt; ee += MW_NT) stx<K>(W, q.wlen, ee, mulx<K, K, DK>(yx, ldx<DK>(A, q.dAp, ee)));
+    __syncthreads();
+    for (int o = tid; o < cnt * (cnt + 1) / 2; o += MW_NT) {
+        int e2, e1;
+        tri_index(o, e2, e1);
+        const mw<K> v = mulx<K, K, DK>(ldx<K>(W, q.wlen, e1), ldx<DK>(A, q.dAp, e2));
+        stx<K>(q.Sd + k.sd_off, q.sdlen, e1 + (long)e2 * cnt, v);
+        stx<K>(q.Sd + k.sd_off, q.sdlen, e2 + (long)e1 * cnt, v);
+    }
+}
+template <int K, int DK>
+__global__ __launch_bounds__(MW_NT) void k_mw_gram(const MwDev q, const double *__restrict__ Y) {
+    using namespace mwk;
+    // rows of the grid beyond the low-rank blocks (the launch adds them when every dense block is 1 x 1): the dense blocks' tables, which depend on
+    // X and Y only -- beside the pairing matrices instead of a launch of their own behind them (k_mw_dense_t)
+    if ((int)blockIdx.y >= q.nlr) {
+        if (blockIdx.x == 0) mw_dense_1x1<K, DK>(q, q.blk[q.dn_list[blockIdx.y - q.nlr]], Y, threadIdx.x);
+        return;
+    }
     if (q.mws_on && q.mws_off[q.lr_list[blockIdx.y]] >= 0) return;
     const MwBlk &k = q.blk[q.lr_list[blockIdx.y]];
     const int n = k.n, U = k.U, dl = k.delta;
@@ -605,18 +630,7 @@ __global__ __launch_bounds__(MW_NT) void k_mw_dense_t(const MwDev q, const doubl
     double *W = q.W + k.w_off;
     const long nn = (long)n * n;
     if (n == 1) {
-        if (e != 0) return;
-        mw<K> rd = ldx<K>(q.xrd + k.rd_off, q.xrdlen, 0);
-        mw<K> yx = mul<K>(ldx<K>(Y + k.xyoff, q.xylen, 0), mul<K>(rd, rd));      // Y / X
-        for (int ee = tid; ee < cnt; ee += MW_NT) stx<K>(W, q.wlen, ee, mulx<K, K, DK>(yx, ldx<DK>(A, q.dAp, ee)));
-        __syncthreads();                                   // the table of a 1 x 1 block right here: one thread per pair
-        for (int o = tid; o < cnt * (cnt + 1) / 2; o += MW_NT) {
-            int e2, e1;
-            tri_index(o, e2, e1);
-            const mw<K> v = mulx<K, K, DK>(ldx<K>(W, q.wlen, e1), ldx<DK>(A, q.dAp, e2));
-            stx<K>(q.Sd + k.sd_off, q.sdlen, e1 + (long)e2 * cnt, v);
-            stx<K>(q.Sd + k.sd_off, q.sdlen, e2 + (long)e1 * cnt, v);
-        }
+        if (e == 0) mw_dense_1x1<K, DK>(q, k, Y, tid);
         return;
     }
     if (e >= cnt) return;
