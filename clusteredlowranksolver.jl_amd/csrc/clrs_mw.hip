@@ -123,6 +123,8 @@ struct clrs_mw_ctx {
     bool lds_x = false, lds_q = false, lds_zt_L = false, dense_two = false;
     int nw_factor = 1;                  // workgroups per cluster in k_mw_factor (they share out the columns of the inverse factor)
     int maxcnt = 0;
+    double *vz = nullptr;               // 2 N numbers of scratch of the solve stage over many workgroups (k_mw_solve_wide)
+    bool wide_solve = false;            // some cluster or Q has more than 64 rows: the products of the solve stage are launches of their own
     int sa_lanes = MW_SA_W;             // lanes per entry of k_mw_saccum: 1, 2 or 4 by the largest block count of a cluster
     int maxTb = 0;                      // most low-rank terms in one PSD block
     size_t sm_x = 0, sm_zt = 0, sm_dense = 0, sm_factor = 0, sm_q = 0, sm_fwd = 0, sm_mid = 0, sm_bwd = 0;
@@ -542,6 +544,8 @@ extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int dev
     MW_TRY(mw_dmalloc(c, &q.Xf, xyoff * K)); MW_TRY(mw_dmalloc(c, &q.Xb, xyoff * K)); MW_TRY(mw_dmalloc(c, &q.Xi, xyoff * K));
     MW_TRY(mw_dmalloc(c, &q.xrd, rdoff * K)); MW_TRY(mw_dmalloc(c, &q.srd, xlen * K)); MW_TRY(mw_dmalloc(c, &q.qrd, (i64)N * K));
     MW_TRY(mw_dmalloc(c, &q.t, xlen * K)); MW_TRY(mw_dmalloc(c, &q.u, (i64)J * N * K)); MW_TRY(mw_dmalloc(c, &q.AY, T * K));
+    MW_TRY(mw_dmalloc(c, &c->vz, 2 * (i64)N * K));
+    c->wide_solve = c->maxP > 64 || N > 64;
     MW_TRY(mw_dmalloc(c, &c->d_Xin, xyoff * K)); MW_TRY(mw_dmalloc(c, &c->d_Xc, xyoff * K)); MW_TRY(mw_dmalloc(c, &c->d_Y, xyoff * K));
     MW_TRY(mw_dmalloc(c, &c->d_rx, xlen * K)); MW_TRY(mw_dmalloc(c, &c->d_dx, xlen * K));
     MW_TRY(mw_dmalloc(c, &c->d_ry, (i64)N * K)); MW_TRY(mw_dmalloc(c, &c->d_dy, (i64)N * K));
@@ -936,9 +940,29 @@ extern "C" int clrs_mw_schur_solve_bwd_dev(clrs_mw_ctx *c, const double *d_rhs_y
 extern "C" int clrs_mw_schur_solve_dev(clrs_mw_ctx *c, const double *d_rhs_x, const double *d_rhs_y, double *d_dx, double *d_dy) {
     if (!c || !d_rhs_x || !d_dx) return mw_fail(CLRS_ERR_INVALID, "null argument");
     if (!c->factored) return mw_fail(CLRS_ERR_STATE, "clrs_mw_schur_solve before clrs_mw_schur_factor");
+    const MwDev &q = c->d;
+    if (c->wide_solve && !q.gathered) {                  // large clusters or a large Q: one launch per product, rows over many workgroups
+        if (q.N > 0 && (!d_rhs_y || !d_dy)) return mw_fail(CLRS_ERR_INVALID, "null argument");
+        MWCHECK(hipSetDevice(c->device));
+        if (c->timing) MWCHECK(hipEventRecord(c->ev[6], c->stream));
+        constexpr int RPW = MW_NT / MW_SW_L;
+        const dim3 gP((c->maxP + RPW - 1) / RPW, q.J), gN((q.N + RPW - 1) / RPW), gX((unsigned)((q.xlen + RPW - 1) / RPW));
+        MW_DISPATCH(c, {
+            hipLaunchKernelGGL(k_mw_solve_wide<KK>, gP, dim3(MW_NT), 0, c->stream, q, 1, d_rhs_x, d_rhs_y, d_dx, d_dy, c->vz);
+            if (q.N > 0) {
+                hipLaunchKernelGGL(k_mw_solve_wide<KK>, gN, dim3(MW_NT), 0, c->stream, q, 2, d_rhs_x, d_rhs_y, d_dx, d_dy, c->vz);
+                hipLaunchKernelGGL(k_mw_solve_wide<KK>, gN, dim3(MW_NT), 0, c->stream, q, 3, d_rhs_x, d_rhs_y, d_dx, d_dy, c->vz);
+                hipLaunchKernelGGL(k_mw_solve_wide<KK>, gN, dim3(MW_NT), 0, c->stream, q, 4, d_rhs_x, d_rhs_y, d_dx, d_dy, c->vz);
+                hipLaunchKernelGGL(k_mw_solve_wide<KK>, gX, dim3(MW_NT), 0, c->stream, q, 5, d_rhs_x, d_rhs_y, d_dx, d_dy, c->vz);
+            }
+            hipLaunchKernelGGL(k_mw_solve_wide<KK>, gP, dim3(MW_NT), 0, c->stream, q, 6, d_rhs_x, d_rhs_y, d_dx, d_dy, c->vz);
+        });
+        MWCHECK(hipGetLastError());
+        if (c->timing) MWCHECK(hipEventRecord(c->ev[7], c->stream));
+        return 0;
+    }
     int rc = clrs_mw_schur_solve_fwd_dev(c, d_rhs_x);
     if (rc) return rc;
-    const MwDev &q = c->d;
     if (q.gathered && q.N > 0) {
         int rc2 = mw_allgather(c, 0, q.ug, (size_t)q.N * c->K, c->stream);
         if (rc2) return rc2;

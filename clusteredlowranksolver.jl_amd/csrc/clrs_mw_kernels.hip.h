@@ -1157,6 +1157,67 @@ __global__ __launch_bounds__(MW_NT) void k_mw_solve_bwd(const MwDev q, const dou
     }
 }
 
+// The same solve for clusters or a Q of more than ~64 rows: with one workgroup per cluster (and one for Q) the six products of the stage run one
+// after the other on one compute unit each (55 us per launch at P = 96, N = 97).  Here every product is a launch of its own whose ROWS are
+// spread over workgroups, sixteen lanes per row:
+//   1  t = Si rhs_x (per cluster)          2  v = rhs_y - LB^T t (one dot product over all rows of all clusters)     3  z = Qi v
+//   4  dy = Qi^T z                         5  t <- t + LB dy                                                          6  dx = Si^T t (per cluster)
+// vz: 2 N numbers of scratch (v, then z), planar with plane 2 N.  Unsharded contexts only (the sharded solve exchanges the partial u_j).
+#define MW_SW_L 16
+template <int K>
+__global__ __launch_bounds__(MW_NT) void k_mw_solve_wide(const MwDev q, int stage, const double *__restrict__ rhs_x, const double *__restrict__ rhs_y,
+                                                         double *__restrict__ dx, double *__restrict__ dy, double *__restrict__ vz) {
+    using namespace mwk;
+    constexpr int RPW = MW_NT / MW_SW_L;
+    const int sub = threadIdx.x % MW_SW_L, row = blockIdx.x * RPW + threadIdx.x / MW_SW_L, N = q.N;
+    const long lbp = q.xlen * (long)N, qp = (long)N * N, vp = 2L * N;
+    acc<K> s;
+    acc_zero<K>(s);
+    if (stage == 1 || stage == 6) {
+        const MwClu &c = q.clu[blockIdx.y];
+        const int P = c.P;
+        if (blockIdx.x * RPW >= P) return;                  // uniform over the workgroup
+        const bool live = row < P;
+        const int i = live ? row : 0;
+        const double *Si = q.Si + c.Soff;
+        if (stage == 1) {
+            for (int cc = sub; cc <= i; cc += MW_SW_L) acc_fma<K, K, K>(s, ldx<K>(Si, q.Slen, i + (long)cc * P), ldx<K>(rhs_x, q.xlen, c.coff + cc));
+        } else {
+            for (int cc = i + sub; cc < P; cc += MW_SW_L) acc_fma<K, K, K>(s, ldx<K>(Si, q.Slen, cc + (long)i * P), ldx<K>(q.t, q.xlen, c.coff + cc));
+        }
+        const mw<K> v = lanes_sum<K, MW_SW_L>(acc_result<K>(s));
+        if (live && sub == 0) stx<K>(stage == 1 ? q.t : dx, q.xlen, c.coff + i, v);
+        return;
+    }
+    if (stage == 5) {
+        if ((long)blockIdx.x * RPW >= q.xlen) return;
+        const bool live = row < q.xlen;
+        const long g = live ? row : 0;
+        if (sub == 0) acc_add<K, K>(s, ldx<K>(q.t, q.xlen, g));
+        for (int a = sub; a < N; a += MW_SW_L) acc_fma<K, K, K>(s, ldx<K>(q.LB, lbp, g + a * q.xlen), ldx<K>(dy, N, a));
+        const mw<K> v = lanes_sum<K, MW_SW_L>(acc_result<K>(s));
+        if (live && sub == 0) stx<K>(q.t, q.xlen, g, v);
+        return;
+    }
+    if (blockIdx.x * RPW >= N) return;
+    const bool live = row < N;
+    const int a = live ? row : 0;
+    if (stage == 2) {
+        if (sub == 0) acc_add<K, K>(s, ldx<K>(rhs_y, N, a));
+        for (long g = sub; g < q.xlen; g += MW_SW_L) acc_fma<K, K, K>(s, ldx<K>(q.LB, lbp, g + a * q.xlen), ldx<K>(q.t, q.xlen, g), -1.0);
+    } else if (stage == 3) {
+        for (int cc = sub; cc <= a; cc += MW_SW_L) acc_fma<K, K, K>(s, ldx<K>(q.Qi, qp, a + (long)cc * N), ldx<K>(vz, vp, cc));
+    } else {
+        for (int cc = a + sub; cc < N; cc += MW_SW_L) acc_fma<K, K, K>(s, ldx<K>(q.Qi, qp, cc + (long)a * N), ldx<K>(vz, vp, N + cc));
+    }
+    const mw<K> v = lanes_sum<K, MW_SW_L>(acc_result<K>(s));
+    if (live && sub == 0) {
+        if (stage == 2) stx<K>(vz, vp, a, v);
+        else if (stage == 3) stx<K>(vz, vp, N + a, v);
+        else stx<K>(dy, N, a, v);
+    }
+}
+
 // reciprocal diagonals of Cholesky factors passed in by the caller (clrs_mw_schur_assemble with host or foreign factors)
 template <int K>
 __global__ __launch_bounds__(MW_NT) void k_mw_xrd(const MwDev q, const double *__restrict__ Xc) {
