@@ -831,7 +831,7 @@ static int mw_potrf_blocked(clrs_mw_ctx *c, const MwBp &m) {
             hipLaunchKernelGGL(k_mw_bp_diag<KK>, dim3(MW_INV_WG), dim3(MW_PT), c->sm_bp_diag, c->stream, q, m, j0);
             if (mm > 0) {
                 hipLaunchKernelGGL(k_mw_bp_panel<KK>, dim3((mm + MW_BP_PR - 1) / MW_BP_PR), dim3(MW_PT), c->sm_bp_panel, c->stream, q, m, j0);
-                hipLaunchKernelGGL(k_mw_bp_syrk<KK>, dim3((unsigned)(((i64)mm * (mm + 1) / 2 + MW_NT - 1) / MW_NT)), dim3(MW_NT), 0, c->stream, q, m, j0);
+                hipLaunchKernelGGL(k_mw_bp_syrk<KK>, dim3((unsigned)(((i64)mm * (mm + 1) / 2 * MW_BP_SW + MW_NT - 1) / MW_NT)), dim3(MW_NT), 0, c->stream, q, m, j0);
             }
         }
         for (int d = 1; d < nbk; d++)

@@ -904,18 +904,20 @@ __global__ __launch_bounds__(MW_NT) void k_mw_qsum(const MwDev q) {
 // Blocked Cholesky AND inverse factor of a matrix that does not fit twice in LDS (clusters with P > 44 at 5 limbs, Q with
 // N > 44), in place in global memory, panel width MW_PB, over many workgroups:
 //   k_mw_bp_diag   the diagonal block and its inverse by one workgroup in LDS (wg_potrf with the [M | I] elimination);
-//   k_mw_bp_panel  the rows below it, L_panel = A_panel M_d^T: a product with the inverse of the diagonal block, eight rows
-//                  per workgroup, two lanes per entry (the rows are independent);
-//   k_mw_bp_syrk   the trailing matrix, one thread per entry of its lower triangle (MW_PB-term accumulator dot products);
+//   k_mw_bp_panel  the rows below it, L_panel = A_panel M_d^T: a product with the inverse of the diagonal block, MW_BP_PR rows
+//                  per workgroup, eight lanes per entry (the rows are independent);
+//   k_mw_bp_syrk   the trailing matrix, MW_BP_SW lanes per entry of its lower triangle (MW_PB-term accumulator dot products);
 //   k_mw_bp_inv    after the last block column: the off-diagonal blocks of L^-1 by block distance d = 1, 2, ...:
 //                  (L^-1)_ji = -(L^-1)_jj sum_{i <= k < j} L_jk (L^-1)_ki, independent column by column: one workgroup
-//                  per pair (j, i) and panel of four columns, four lanes per entry;
+//                  per pair (j, i) and column, sixteen lanes per entry;
 //   k_mw_bp_finish zero strict upper triangle of L.
 // With L^-1 explicit, LinvB and every solve of a large cluster are products over many lanes, like those of a small one.
 // ---------------------------------------------------------------------------------------------------------------------
 #define MW_PB_OF(K) 32       // panel width: a MW_PB x MW_PB matrix and the packed inverse of its factor, K limbs each, fit in LDS up to K = 10 (k_mw_bp_diag)
-#define MW_BP_PR 8           // rows of the panel per workgroup
-#define MW_BP_IC 4           // columns of an inverse block per workgroup
+#define MW_BP_PR 2           // rows of the panel per workgroup: eight lanes per entry (the chain of 5 - 7 launches per block column is latency bound: few
+                             // multiply-adds per lane matter more than full lanes)
+#define MW_BP_IC 1           // columns of an inverse block per workgroup: sixteen lanes per entry
+#define MW_BP_SW 4           // lanes per entry of the trailing update
 struct MwBp {                // one matrix being factored: planar M and its inverse factor Mi (same plane length and leading dimension), reciprocal diagonal rd
     double *M, *Mi, *rd;
     mwi64 plane, rdplane;
@@ -968,15 +970,16 @@ __global__ __launch_bounds__(MW_PT) void k_mw_bp_panel(const MwDev q, const MwBp
         if (r < nr) stx<K>(At, ap, e, ldx<K>(m.M, m.plane, (r0 + r) + (long)(j0 + c) * m.ld));
     }
     __syncthreads();
-    const int sub = tid & 1;
-    for (int e0 = 0; e0 < MW_BP_PR * nb; e0 += MW_PT / 2) {
-        const int e = e0 + (tid >> 1);
+    constexpr int LP = MW_PT / (MW_BP_PR * MW_PB);          // lanes per entry
+    const int sub = tid % LP;
+    for (int e0 = 0; e0 < MW_BP_PR * nb; e0 += MW_PT / LP) {
+        const int e = e0 + tid / LP;
         const bool live = e < MW_BP_PR * nb && (e % MW_BP_PR) < nr;
         const int ee = live ? e : 0, r = ee % MW_BP_PR, c = ee / MW_BP_PR;
         acc<K> s;
         acc_zero<K>(s);
-        for (int kk = sub; kk <= c; kk += 2) acc_fma<K, K, K>(s, ldx<K>(At, ap, r + (long)kk * MW_BP_PR), ldx<K>(m.Mi, m.plane, (j0 + c) + (long)(j0 + kk) * m.ld));
-        const mw<K> v = lanes_sum<K, 2>(acc_result<K>(s));
+        for (int kk = sub; kk <= c; kk += LP) acc_fma<K, K, K>(s, ldx<K>(At, ap, r + (long)kk * MW_BP_PR), ldx<K>(m.Mi, m.plane, (j0 + c) + (long)(j0 + kk) * m.ld));
+        const mw<K> v = lanes_sum<K, LP>(acc_result<K>(s));
         if (live && sub == 0) stx<K>(m.M, m.plane, (r0 + r) + (long)(j0 + c) * m.ld, v);
     }
 }
@@ -987,16 +990,20 @@ __global__ __launch_bounds__(MW_NT) void k_mw_bp_syrk(const MwDev q, const MwBp 
     constexpr int MW_PB = MW_PB_OF(K);
     if (q.info[m.which] != MW_INFO_NONE) return;
     const int nb = min(MW_PB, m.n - j0), t0 = j0 + nb, mm = m.n - t0;
-    const long e = (long)blockIdx.x * MW_NT + threadIdx.x;
-    if (e >= (long)mm * (mm + 1) / 2) return;
+    const long tot = (long)mm * (mm + 1) / 2;
+    if ((long)blockIdx.x * (MW_NT / MW_BP_SW) >= tot) return;      // uniform over the workgroup
+    const long e = (long)blockIdx.x * (MW_NT / MW_BP_SW) + threadIdx.x / MW_BP_SW;
+    const int sub = threadIdx.x % MW_BP_SW;
+    const bool live = e < tot;
     int ii, jj;
-    tri_index((int)e, ii, jj);
+    tri_index(live ? (int)e : 0, ii, jj);
     const int i = t0 + ii, j = t0 + jj;
     acc<K> s;
     acc_zero<K>(s);
-    acc_add<K, K>(s, ldx<K>(m.M, m.plane, i + (long)j * m.ld));
-    for (int c = 0; c < nb; c++) acc_fma<K, K, K>(s, ldx<K>(m.M, m.plane, i + (long)(j0 + c) * m.ld), ldx<K>(m.M, m.plane, j + (long)(j0 + c) * m.ld), -1.0);
-    stx<K>(m.M, m.plane, i + (long)j * m.ld, acc_result<K>(s));
+    if (sub == 0) acc_add<K, K>(s, ldx<K>(m.M, m.plane, i + (long)j * m.ld));
+    for (int c = sub; c < nb; c += MW_BP_SW) acc_fma<K, K, K>(s, ldx<K>(m.M, m.plane, i + (long)(j0 + c) * m.ld), ldx<K>(m.M, m.plane, j + (long)(j0 + c) * m.ld), -1.0);
+    const mw<K> v = lanes_sum<K, MW_BP_SW>(acc_result<K>(s));
+    if (live && sub == 0) stx<K>(m.M, m.plane, i + (long)j * m.ld, v);
 }
 // blocks (j, i) of L^-1 with j - i = d: T = sum_{i <= k < j} L_jk (L^-1)_ki (the block columns between are contiguous: one
 // sum over the rows i MW_PB .. j MW_PB - 1), then (L^-1)_ji = -(L^-1)_jj T
