@@ -18,6 +18,7 @@ struct MwIpmDev {
     double *Yi;                        // chol(Y)^-1 per block (xy layout), formed beside chol(X) at the start of the iteration
     int *yfail;                        // [NB] 1 = Y_b is not positive definite
     double *Zs;                        // unsymmetrised X^-1 (...) of k_mwi_Zi (xy layout)
+    double *Zt;                        // second scratch of the tiled form of the same products (k_mwi_bmm; xy layout)
     int *zcnt;                         // [NB] workgroups of a block that have delivered their panel
     double *dtr;                       // [xlen] dense part of the row traces <A_*, M> (k_mwi_rows_dn), when some dense block has n > 1
     double *sc, *part;                 // planar scalars [MSC_COUNT]; partial dot products [5][NB]
@@ -913,6 +914,53 @@ __global__ __launch_bounds__(MW_PT) void k_mwi_Zi(const MwDev q, const MwIpmDev 
         stx<K>(p.dY + k.xyoff, q.xylen, i + (long)c * n, v);
         stx<K>(p.dY + k.xyoff, q.xylen, c + (long)i * n, v);
     }
+}
+
+// The same three products for LARGE blocks (sides beyond ~24), as launches of their own over 8 x 8 output tiles, four lanes per entry: a column panel
+// of k_mwi_Zi walks whole matrices with 64 entries at a time (21 passes of seven multiply-adds per lane at n = 54, every workgroup reading all of A
+// and Xi), a tile reads eight rows and eight columns and its lanes take n / 4 multiply-adds.  op 0: Zt = sg (A Y - R' - mu_s I); 1: Zs = Xi Zt;
+// 2: Zt = Xi^T Zs; 3: dY = sym(Zt).  Blocks without an inverse factor stay with k_mwi_Z.
+#define MWI_BT 8
+template <int K>
+__global__ __launch_bounds__(MW_NT) void k_mwi_bmm(const MwDev q, const MwIpmDev p, int op, int which) {
+    using namespace mwk;
+    const MwBlk &k = q.blk[blockIdx.y];
+    if (!k.inv) return;
+    const int n = k.n, nt = (n + MWI_BT - 1) / MWI_BT;
+    if ((int)blockIdx.x >= nt * nt) return;
+    const int ti = blockIdx.x % nt, tj = blockIdx.x / nt;
+    if (op == 3) {
+        if (tj > ti) return;
+        const int e = threadIdx.x;
+        if (e >= MWI_BT * MWI_BT) return;
+        const int i = ti * MWI_BT + e % MWI_BT, c = tj * MWI_BT + e / MWI_BT;
+        if (i >= n || c > i) return;
+        mw<K> v = mul_pow2<K>(add<K>(ldx<K>(p.Zt + k.xyoff, q.xylen, i + (long)c * n), ldx<K>(p.Zt + k.xyoff, q.xylen, c + (long)i * n)), 0.5);
+        stx<K>(p.dY + k.xyoff, q.xylen, i + (long)c * n, v);
+        stx<K>(p.dY + k.xyoff, q.xylen, c + (long)i * n, v);
+        return;
+    }
+    constexpr int LW = MW_NT / (MWI_BT * MWI_BT);          // lanes per entry: 4
+    const int e = threadIdx.x / LW, sub = threadIdx.x % LW;
+    const int i0 = ti * MWI_BT + e % MWI_BT, c0 = tj * MWI_BT + e / MWI_BT;
+    const bool live = i0 < n && c0 < n;
+    const int i = live ? i0 : 0, c = live ? c0 : 0;
+    const double *Xi = q.Xi + k.xyoff;
+    acc<K> s;
+    acc_zero<K>(s);
+    if (op == 0) {
+        const double *A = (which == 0 ? p.Pm : p.dX) + k.xyoff;
+        const double sg = which == 0 ? 1.0 : -1.0;
+        for (int kk = sub; kk < n; kk += LW) acc_fma<K, K, K>(s, ldx<K>(A, q.xylen, i + (long)kk * n), ldx<K>(p.Y + k.xyoff, q.xylen, kk + (long)c * n), sg);
+        if (sub == 0) acc_add<K, K>(s, ldx<K>(p.R + k.xyoff, q.xylen, i + (long)c * n), -sg);
+        if (sub == 1 && i == c) acc_add<K, K>(s, ldx<K>(p.sc, MSC_COUNT, MSC_MUS), -sg);      // R = mu_s I + R'
+    } else if (op == 1) {
+        for (int r = sub; r <= i; r += LW) acc_fma<K, K, K>(s, ldx<K>(Xi, q.xylen, i + (long)r * n), ldx<K>(p.Zt + k.xyoff, q.xylen, r + (long)c * n));
+    } else {
+        for (int r = i + sub; r < n; r += LW) acc_fma<K, K, K>(s, ldx<K>(Xi, q.xylen, r + (long)i * n), ldx<K>(p.Zs + k.xyoff, q.xylen, r + (long)c * n));
+    }
+    const mw<K> v = lanes_sum<K, LW>(acc_result<K>(s));
+    if (live && sub == 0) stx<K>((op == 1 ? p.Zs : p.Zt) + k.xyoff, q.xylen, i + (long)c * n, v);
 }
 
 // W = Li dM Li^T with the explicit inverse Li of the factor (two block products), symmetrised and rounded to fp64: the matrix of :1659
