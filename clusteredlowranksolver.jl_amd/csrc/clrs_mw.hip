@@ -118,7 +118,7 @@ struct clrs_mw_ctx {
     std::vector<MwBlk> blk;
     std::vector<MwClu> clu;
     std::vector<void *> allocs;
-    int maxU = 0, maxP = 0, maxn = 0;
+    int maxU = 0, maxP = 0, maxn = 0, maxn_dense = 0;
     bool xinv_valid = false;            // Xi holds the inverses of the current Cholesky factors (they come from k_mw_potrf_x, not from the caller)
     bool lds_x = false, lds_q = false, lds_zt_L = false, dense_two = false;
     int nw_factor = 1;                  // workgroups per cluster in k_mw_factor (they share out the columns of the inverse factor)
@@ -259,6 +259,7 @@ extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int dev
         c->clu[k.j].b0 = std::min(c->clu[k.j].b0, b);
         c->clu[k.j].b1 = std::max(c->clu[k.j].b1, b + 1);
         c->maxn = std::max(c->maxn, k.n);
+        if (k.kind != 0) c->maxn_dense = std::max(c->maxn_dense, k.n);
         const int P = k.P, n = k.n, dl = k.delta;
         if (k.kind == 0) {
             lr_list.push_back(b);
@@ -678,7 +679,8 @@ extern "C" int clrs_mw_schur_assemble_dev(clrs_mw_ctx *c, const double *d_Xchol,
         if (q.ndn && !dense_done) {
             hipLaunchKernelGGL((k_mw_dense_t<KK, DD>), dim3(q.ndn, q.dn_big ? c->maxcnt : 1), dim3(MW_NT), c->sm_dense, c->stream, q, d_Y, c->xinv_valid ? 1 : 0, c->dense_two ? 1 : 0);
             const int pairs = c->maxcnt * (c->maxcnt + 1) / 2;
-            if (q.dn_big) hipLaunchKernelGGL((k_mw_dense_s<KK, DD>), dim3(q.ndn, (pairs + MW_NT / 64 - 1) / (MW_NT / 64)), dim3(MW_NT), 0, c->stream, q);
+            const int ds_lanes = c->maxn_dense * c->maxn_dense <= 128 ? 8 : c->maxn_dense * c->maxn_dense <= 512 ? 16 : 64;      // per pair of the table
+            if (q.dn_big) hipLaunchKernelGGL((k_mw_dense_s<KK, DD>), dim3(q.ndn, (pairs + MW_NT / ds_lanes - 1) / (MW_NT / ds_lanes)), dim3(MW_NT), 0, c->stream, q, ds_lanes);
         }
         hipLaunchKernelGGL((k_mw_saccum<KK, DD>), dim3((c->maxP * (c->maxP + 1) / 2 * c->sa_lanes + MW_NT - 1) / MW_NT, q.J), dim3(MW_NT), 0, c->stream, q, c->sa_lanes);
     });

@@ -35,7 +35,7 @@
     X __global__ void k_mws_pair<K, DK, 1>(const MwDev, const MwsDev, const double *);                                 \
     X __global__ void k_mws_pair<K, DK, 2>(const MwDev, const MwsDev, const double *);                                                                   \
     X __global__ void k_mw_dense_t<K, DK>(const MwDev, const double *, int, int);                                      \
-    X __global__ void k_mw_dense_s<K, DK>(const MwDev);                                                                \
+    X __global__ void k_mw_dense_s<K, DK>(const MwDev, int);                                                           \
     X __global__ void k_mw_saccum<K, DK>(const MwDev, int);                                                                 \
     X __global__ void k_mw_linvb<K, DK>(const MwDev);                                                                  \
     X __global__ void k_mwi_scalar<K, DK>(const MwDev, const MwIpmDev, int, int);                                      \

@@ -948,6 +948,26 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_bmm(const MwDev q, const MwIpmDev
     const double *Xi = q.Xi + k.xyoff;
     acc<K> s;
     acc_zero<K>(s);
+    if (op >= 4) {
+        // the congruences of the step lengths (compute_step_length, :1647-1659), both matrices in one launch (blockIdx.z: 0 = X, 1 = Y):
+        // 4: U = dM Li^T into Zs / Zt;  5: W = Li U, lower triangle, rounded to fp64 into Wd -- the matrix k_mwi_step (inv_path 3) takes the eigenvalue of
+        const int wh = blockIdx.z;
+        if (n == 1 || (wh == 1 && p.yfail[blockIdx.y])) return;
+        if (op == 5 && tj > ti) return;
+        const double *Li = (wh == 0 ? q.Xi : p.Yi) + k.xyoff, *dMg = (wh == 0 ? p.dX : p.dY) + k.xyoff;
+        double *U = (wh == 0 ? p.Zs : p.Zt) + k.xyoff;
+        if (op == 4) {
+            for (int t = sub; t <= c; t += LW) acc_fma<K, K, K>(s, ldx<K>(dMg, q.xylen, i + (long)t * n), ldx<K>(Li, q.xylen, c + (long)t * n));
+        } else if (i >= c) {
+            for (int r = sub; r <= i; r += LW) acc_fma<K, K, K>(s, ldx<K>(Li, q.xylen, i + (long)r * n), ldx<K>(U, q.xylen, r + (long)c * n));
+        }
+        const mw<K> v = lanes_sum<K, LW>(acc_result<K>(s));
+        if (live && sub == 0) {
+            if (op == 4) stx<K>(U, q.xylen, i + (long)c * n, v);
+            else if (i >= c) p.Wd[(long)wh * q.xylen + k.xyoff + i + (long)c * n] = v.l[0];
+        }
+        return;
+    }
     if (op == 0) {
         const double *A = (which == 0 ? p.Pm : p.dX) + k.xyoff;
         const double sg = which == 0 ? 1.0 : -1.0;
@@ -1068,15 +1088,15 @@ __device__ __forceinline__ bool mwi_step_body(const MwDev &q, const MwIpmDev &p,
         }
         return true;
     }
-    if (inv_path == 2) {
+    if (inv_path >= 2) {
         // both inverse factors are in memory (Xi from k_mw_potrf_x, Yi from its second half): LDS holds T1, the fp64 matrix, the eigenvalue work space
         lds_d *T1 = MW_LDS, *Wd = T1 + (long)K * nn, *work = Wd + nn;
         if (which == 1 && p.yfail[blockIdx.x]) {                                         // :1644-1646
             if (tid == 0) { p.flags[2] = 1; p.eig[(long)which * q.NB + blockIdx.x] = 0.0; }
             return true;
         }
-        if (gridDim.z > 1) {
-            if (!mwi_step_panels<K>(q, p, k, which, (which == 0 ? q.Xi : p.Yi) + k.xyoff, dMg)) return false;      // not the last workgroup of this (block, which)
+        if (gridDim.z > 1 || inv_path == 3) {             // 3: the congruence is in Wd already (tiled launches of k_mwi_bmm, large blocks)
+            if (inv_path == 2 && !mwi_step_panels<K>(q, p, k, which, (which == 0 ? q.Xi : p.Yi) + k.xyoff, dMg)) return false;      // not the last workgroup of this (block, which)
             lds_d *Wl = MW_LDS, *wk = Wl + nn;
             const double *Wg = p.Wd + (long)which * q.xylen + k.xyoff;
             for (int e = tid; e < nn; e += MW_NT) {

@@ -671,27 +671,36 @@ __global__ __launch_bounds__(MW_NT) void k_mw_dense_t(const MwDev q, const doubl
         stx<K>(W, q.wlen, (long)e * nn + o, acc_result<K>(s));
     }
 }
-// Sd[e, e'] = <A_e', T_e>, e <= e' computed, mirrored: one wave per pair
-template <int K, int DK>
-__global__ __launch_bounds__(MW_NT) void k_mw_dense_s(const MwDev q) {
+// Sd[e, e'] = <A_e', T_e>, e <= e' computed, mirrored: W lanes per pair -- a wave for large blocks, eight lanes for blocks of a few dozen entries
+// (the three-point bound has 9 dense blocks of sides <= 9 with up to 221 matrices each: 24 000 pairs of 81-term dot products, for which the six
+// rounds of a wave-wide sum were five times the work)
+template <int K, int DK, int W>
+__device__ __forceinline__ void mw_dense_s_body(const MwDev &q) {
     using namespace mwk;
     const MwBlk &k = q.blk[q.dn_list[blockIdx.x]];
     if (k.n == 1) return;                                  // done by k_mw_dense_t
-    const int cnt = k.cnt, lane = threadIdx.x & 63;
-    const int o = blockIdx.y * (MW_NT / 64) + (threadIdx.x >> 6);
-    if (o >= cnt * (cnt + 1) / 2) return;                  // uniform over the wave
+    const int cnt = k.cnt, lane = threadIdx.x % W;
+    const int o0 = blockIdx.y * (MW_NT / W) + threadIdx.x / W, tot = cnt * (cnt + 1) / 2;
+    if ((int)(blockIdx.y * (MW_NT / W)) >= tot) return;    // uniform over the workgroup
+    const bool live = o0 < tot;
     const long nn = (long)k.n * k.n;
-    const double *A = q.dA + k.a_off, *W = q.W + k.w_off;
+    const double *A = q.dA + k.a_off, *Wt = q.W + k.w_off;
     int e2, e1;
-    tri_index(o, e2, e1);       // e2 >= e1
+    tri_index(live ? o0 : 0, e2, e1);       // e2 >= e1
     acc<K> s;
     acc_zero<K>(s);
-    for (long i = lane; i < nn; i += 64) acc_fma<K, K, DK>(s, ldx<K>(W, q.wlen, (long)e1 * nn + i), ldx<DK>(A, q.dAp, (long)e2 * nn + i));
-    const mw<K> v = lanes_sum<K, 64>(acc_result<K>(s));
-    if (lane == 0) {
+    for (long i = lane; i < nn; i += W) acc_fma<K, K, DK>(s, ldx<K>(Wt, q.wlen, (long)e1 * nn + i), ldx<DK>(A, q.dAp, (long)e2 * nn + i));
+    const mw<K> v = lanes_sum<K, W>(acc_result<K>(s));
+    if (live && lane == 0) {
         stx<K>(q.Sd + k.sd_off, q.sdlen, e1 + (long)e2 * cnt, v);
         stx<K>(q.Sd + k.sd_off, q.sdlen, e2 + (long)e1 * cnt, v);
     }
+}
+template <int K, int DK>
+__global__ __launch_bounds__(MW_NT) void k_mw_dense_s(const MwDev q, int lanes) {
+    if (lanes == 8) mw_dense_s_body<K, DK, 8>(q);
+    else if (lanes == 16) mw_dense_s_body<K, DK, 16>(q);
+    else mw_dense_s_body<K, DK, 64>(q);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
