@@ -41,10 +41,10 @@
     X __global__ void k_mwi_scalar<K, DK>(const MwDev, const MwIpmDev, int, int);                                      \
     X __global__ void k_mwi_dots<K, DK>(const MwDev, const MwIpmDev, int, int);                                             \
     X __global__ void k_mwi_coef<K, DK>(const MwDev, const MwIpmDev, const double *);                                  \
-    X __global__ void k_mwi_wA<K, DK>(const MwDev, const MwIpmDev, int, int);                                               \
+    X __global__ void k_mwi_wA<K, DK>(const MwDev, const MwIpmDev, int, int, int);                                          \
     X __global__ void k_mwi_MV<K, DK>(const MwDev, const double *);                                                    \
     X __global__ void k_mwi_rows_dn<K, DK>(const MwDev, const MwIpmDev, int);                                          \
-    X __global__ void k_mwi_rows<K, DK>(const MwDev, const MwIpmDev, int);                                             \
+    X __global__ void k_mwi_rows<K, DK>(const MwDev, const MwIpmDev, int, int);                                        \
     X __global__ void k_mwi_pv<K, DK>(const MwDev, const MwIpmDev, int);                                               \
     X __global__ void k_mwi_pvfin<K, DK>(const MwDev, const MwIpmDev);                                                 \
     X __global__ void k_mwi_gpack<K, DK>(const MwDev, const MwIpmDev, int);                                               \

@@ -559,12 +559,14 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_coef(const MwDev q, const MwIpmDe
 // mode 0: P = sum x_i A_i - X -+ C (:882-893), max|P|;  mode 1: dX = sum dx_i A_i + P (:1585-1594)
 // coef_lds = 1: the coefficients a_p lambda_t of the block's terms are formed here, into LDS (every workgroup of a block repeats the few
 // products: cheaper than the launch of k_mwi_coef in front of this kernel); 0: read from p.coef (blocks with more terms than LDS holds)
-template <int K, int DK>
-__global__ __launch_bounds__(MW_NT) void k_mwi_wA(const MwDev q, const MwIpmDev p, int mode, int coef_lds) {
+// EW lanes per entry: four, or sixteen for blocks with hundreds of terms (every term is a chain of dependent gathers: its flag, its two vector
+// indices, the vectors' entries -- the lanes of an entry walk their share of the terms one after the other)
+template <int K, int DK, int EW>
+__device__ __forceinline__ void mwi_wA_body(const MwDev &q, const MwIpmDev &p, int mode, int coef_lds) {
     using namespace mwk;
     const MwBlk &k = q.blk[blockIdx.y];
     const int n = k.n;
-    if (blockIdx.x * (MW_NT / MWI_EW) >= n * n) return;
+    if (blockIdx.x * (MW_NT / EW) >= n * n) return;
     lds_d *cf = MW_LDS;
     int t_first = 0, t_cnt = 0;
     if (coef_lds && k.kind == 0) {                        // uniform over the workgroup
@@ -576,7 +578,7 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_wA(const MwDev q, const MwIpmDev 
             stx<K>(cf, t_cnt, t, mulx<K, K, DK>(ldx<K>(av, q.xlen, cl0.coff + q.st_p[t_first + t]), ldx<DK>(q.st_lam, q.lamp, t_first + t)));
         __syncthreads();
     }
-    const int e = blockIdx.x * (MW_NT / MWI_EW) + threadIdx.x / MWI_EW, sub = threadIdx.x % MWI_EW;
+    const int e = blockIdx.x * (MW_NT / EW) + threadIdx.x / EW, sub = threadIdx.x % EW;
     const int ee = e < n * n ? e : 0, i = ee % n, c = ee / n;
     const double *a = mode == 0 ? p.x : p.dx;
     const bool mirror = (k.kind == 0 && k.m > 1);
@@ -586,7 +588,7 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_wA(const MwDev q, const MwIpmDev 
     if (k.kind == 0) {
         const double *V = q.V + k.v_off;
         const int *tp = q.tptr + k.tptr_off;
-        for (int t = tp[0] + sub; t < tp[k.P]; t += MWI_EW) {
+        for (int t = tp[0] + sub; t < tp[k.P]; t += EW) {
             if (!(q.st_flag[t] & 1)) continue;     // s <= r only (:1433)
             const mw<DK> vi = ldx<DK>(V, q.Vp, i + (long)q.st_war[t] * n), vc = ldx<DK>(V, q.Vp, c + (long)q.st_wac[t] * n);
             if (vi.l[0] == 0.0 || vc.l[0] == 0.0) continue;
@@ -596,7 +598,7 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_wA(const MwDev q, const MwIpmDev 
     } else {
         const MwClu &cl = q.clu[k.j];
         const long nn = (long)n * n;
-        for (int en = sub; en < k.cnt; en += MWI_EW)
+        for (int en = sub; en < k.cnt; en += EW)
             acc_fma<K, K, DK>(s, ldx<K>(a, q.xlen, cl.coff + q.dense_p[k.d0 + en]), ldx<DK>(q.dA, q.dAp, k.a_off + en * nn + ee));
     }
     if (sub == 0) {
@@ -607,7 +609,7 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_wA(const MwDev q, const MwIpmDev 
             acc_add<K, K>(s, ldx<K>(p.Pm + k.xyoff, q.xylen, ee));
         }
     }
-    const mw<K> v = lanes_sum<K, MWI_EW>(acc_result<K>(s));
+    const mw<K> v = lanes_sum<K, EW>(acc_result<K>(s));
     if (!live || sub != 0) return;
     if (mode == 0) {
         atomic_max_abs(&p.fmax[0], v.l[0]);
@@ -618,6 +620,11 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_wA(const MwDev q, const MwIpmDev 
         stx<K>(p.dX + k.xyoff, q.xylen, e, v);
         if (mirror && c != i) stx<K>(p.dX + k.xyoff, q.xylen, c + (long)i * n, v);
     }
+}
+template <int K, int DK>
+__global__ __launch_bounds__(MW_NT) void k_mwi_wA(const MwDev q, const MwIpmDev p, int mode, int coef_lds, int ew) {
+    if (ew == 16) mwi_wA_body<K, DK, 16>(q, p, mode, coef_lds);
+    else mwi_wA_body<K, DK, MWI_EW>(q, p, mode, coef_lds);
 }
 
 // ---- T = M V for the low-rank blocks (first half of trace_A, src/solver.jl:1334-1341) -----------------------------------
@@ -661,11 +668,14 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_rows_dn(const MwDev q, const MwIp
 }
 
 #define MWI_RW 8              // lanes per constraint row
-template <int K, int DK>
-__global__ __launch_bounds__(MW_NT) void k_mwi_rows(const MwDev q, const MwIpmDev p, int mode) {
+// BG groups of MWI_RW lanes per row, each group taking every BG-th PSD block of the row's cluster: a cluster of dozens of blocks (the three-point
+// bound: 43) is otherwise a chain of as many dependent dot products per row, on seven workgroups
+template <int K, int DK, int BG>
+__device__ __forceinline__ void mwi_rows_body(const MwDev &q, const MwIpmDev &p, int mode) {
     using namespace mwk;
-    const mwi64 g0 = (mwi64)blockIdx.x * (MW_NT / MWI_RW) + threadIdx.x / MWI_RW;
-    const int sub = threadIdx.x % MWI_RW;
+    constexpr int RWT = MWI_RW * BG;                        // lanes per row
+    const mwi64 g0 = (mwi64)blockIdx.x * (MW_NT / RWT) + threadIdx.x / RWT;
+    const int sub = threadIdx.x % MWI_RW, grp = (threadIdx.x % RWT) / MWI_RW, sub_all = threadIdx.x % RWT;
     const bool live = g0 < q.xlen;
     const mwi64 g = live ? g0 : 0;
     const int j = p.row_clu[g];
@@ -675,7 +685,7 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_rows(const MwDev q, const MwIpmDe
     // every lane accumulates its share of  -(trace term) [- (B y)_g] ; the lanes are summed at the end
     acc<K> s;
     acc_zero<K>(s);
-    for (int b = cl.b0; b < cl.b1; b++) {
+    for (int b = cl.b0 + grp; b < cl.b1; b += BG) {
         const MwBlk &k = q.blk[b];
         const int n = k.n;
         if (k.kind == 0) {
@@ -708,20 +718,25 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_rows(const MwDev q, const MwIpmDe
             }
         }
     }
-    if (q.dn_big && sub == 0) acc_add<K, K>(s, ldx<K>(p.dtr, q.xlen, g), -1.0);      // the dense matrices of the row: k_mwi_rows_dn
+    if (q.dn_big && sub_all == 0) acc_add<K, K>(s, ldx<K>(p.dtr, q.xlen, g), -1.0);      // the dense matrices of the row: k_mwi_rows_dn
     if (mode == 0) {
-        if (sub == 0) acc_add<K, DK>(s, ldx<DK>(p.c, q.xlen, g));
-        for (int a = sub; a < q.N; a += MWI_RW) acc_fma<K, K, DK>(s, ldx<K>(p.y, q.N, a), ldx<DK>(q.B, q.Bp, g + (long)a * q.xlen), -1.0);
-        const mw<K> dv = lanes_sum<K, MWI_RW>(acc_result<K>(s));
-        if (live && sub == 0) {
+        if (sub_all == 0) acc_add<K, DK>(s, ldx<DK>(p.c, q.xlen, g));
+        for (int a = sub_all; a < q.N; a += RWT) acc_fma<K, K, DK>(s, ldx<K>(p.y, q.N, a), ldx<DK>(q.B, q.Bp, g + (long)a * q.xlen), -1.0);
+        const mw<K> dv = lanes_sum<K, RWT>(acc_result<K>(s));
+        if (live && sub_all == 0) {
             atomic_max_abs(&p.fmax[1], dv.l[0]);
             stx<K>(p.d, q.xlen, g, dv);
         }
     } else {
-        if (sub == 0) acc_add<K, K>(s, ldx<K>(p.d, q.xlen, g), -1.0);
-        const mw<K> r = lanes_sum<K, MWI_RW>(acc_result<K>(s));
-        if (live && sub == 0) stx<K>(p.rhsx, q.xlen, g, r);
+        if (sub_all == 0) acc_add<K, K>(s, ldx<K>(p.d, q.xlen, g), -1.0);
+        const mw<K> r = lanes_sum<K, RWT>(acc_result<K>(s));
+        if (live && sub_all == 0) stx<K>(p.rhsx, q.xlen, g, r);
     }
+}
+template <int K, int DK>
+__global__ __launch_bounds__(MW_NT) void k_mwi_rows(const MwDev q, const MwIpmDev p, int mode, int groups) {
+    if (groups == 8) mwi_rows_body<K, DK, 8>(q, p, mode);
+    else mwi_rows_body<K, DK, 1>(q, p, mode);
 }
 
 // ---- this rank's slot of a gather buffer (cluster sharding): one workgroup, the first wave --------------------------------------
