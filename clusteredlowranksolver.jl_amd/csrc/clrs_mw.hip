@@ -677,7 +677,12 @@ extern "C" int clrs_mw_schur_assemble_dev(clrs_mw_ctx *c, const double *d_Xchol,
             hipLaunchKernelGGL((k_mw_gram<KK, DD>), dim3((c->maxU * (c->maxU + 1) / 2 + gper - 1) / gper, q.nlr + (dense_done ? q.ndn : 0)), dim3(MW_NT), 0, c->stream, q2, d_Y);
         }
         if (q.ndn && !dense_done) {
-            hipLaunchKernelGGL((k_mw_dense_t<KK, DD>), dim3(q.ndn, q.dn_big ? c->maxcnt : 1), dim3(MW_NT), c->sm_dense, c->stream, q, d_Y, c->xinv_valid ? 1 : 0, c->dense_two ? 1 : 0);
+            const bool panels = c->xinv_valid && c->maxn_dense > 16 && c->maxn_dense <= MW_NT;      // dense blocks of side > 16 with inverse factors: column panels (k_mw_dense_tp)
+            hipLaunchKernelGGL((k_mw_dense_t<KK, DD>), dim3(q.ndn, q.dn_big ? c->maxcnt : 1), dim3(MW_NT), c->sm_dense, c->stream, q, d_Y, c->xinv_valid ? 1 : 0, c->dense_two ? 1 : 0, panels ? 1 : 0);
+            if (panels) {
+                const int pcmin = std::max(1, MW_NT / c->maxn_dense);
+                hipLaunchKernelGGL((k_mw_dense_tp<KK, DD>), dim3(q.ndn, c->maxcnt, (c->maxn_dense + pcmin - 1) / pcmin), dim3(MW_NT), (size_t)2 * KK * MW_NT * 8, c->stream, q, d_Y);
+            }
             const int pairs = c->maxcnt * (c->maxcnt + 1) / 2;
             const int ds_lanes = c->maxn_dense * c->maxn_dense <= 128 ? 8 : c->maxn_dense * c->maxn_dense <= 512 ? 16 : 64;      // per pair of the table
             if (q.dn_big) hipLaunchKernelGGL((k_mw_dense_s<KK, DD>), dim3(q.ndn, (pairs + MW_NT / ds_lanes - 1) / (MW_NT / ds_lanes)), dim3(MW_NT), 0, c->stream, q, ds_lanes);

@@ -34,7 +34,8 @@
     X __global__ void k_mw_gram<K, DK>(const MwDev, const double *);                                                                   \
     X __global__ void k_mws_pair<K, DK, 1>(const MwDev, const MwsDev, const double *);                                 \
     X __global__ void k_mws_pair<K, DK, 2>(const MwDev, const MwsDev, const double *);                                                                   \
-    X __global__ void k_mw_dense_t<K, DK>(const MwDev, const double *, int, int);                                      \
+    X __global__ void k_mw_dense_t<K, DK>(const MwDev, const double *, int, int, int);                                 \
+    X __global__ void k_mw_dense_tp<K, DK>(const MwDev, const double *);                                               \
     X __global__ void k_mw_dense_s<K, DK>(const MwDev, int);                                                           \
     X __global__ void k_mw_saccum<K, DK>(const MwDev, int);                                                                 \
     X __global__ void k_mw_linvb<K, DK>(const MwDev);                                                                  \

@@ -622,7 +622,7 @@ __global__ __launch_bounds__(MW_NT) void k_mw_gram(const MwDev q, const double *
 // with n > 1): one wave per pair (e, e') of the table.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int K, int DK>
-__global__ __launch_bounds__(MW_NT) void k_mw_dense_t(const MwDev q, const double *__restrict__ Y, int use_inv, int two_buffers) {
+__global__ __launch_bounds__(MW_NT) void k_mw_dense_t(const MwDev q, const double *__restrict__ Y, int use_inv, int two_buffers, int panels) {
     using namespace mwk;
     const MwBlk &k = q.blk[q.dn_list[blockIdx.x]];
     const int n = k.n, cnt = k.cnt, tid = threadIdx.x, e = blockIdx.y;
@@ -633,7 +633,7 @@ __global__ __launch_bounds__(MW_NT) void k_mw_dense_t(const MwDev q, const doubl
         if (e == 0) mw_dense_1x1<K, DK>(q, k, Y, tid);
         return;
     }
-    if (e >= cnt) return;
+    if (e >= cnt || (panels && use_inv && k.inv && n > 16)) return;          // the latter: k_mw_dense_tp
     lds_d *M = MW_LDS, *M2 = M + (long)K * nn;
     if (use_inv && k.inv && two_buffers) {
         const double *Xi = q.Xi + k.xyoff;
@@ -669,6 +669,47 @@ __global__ __launch_bounds__(MW_NT) void k_mw_dense_t(const MwDev q, const doubl
         acc_zero<K>(s);
         for (int kk = 0; kk < n; kk++) acc_fma<K, K, K>(s, ldx<K>(M, nn, i + (long)kk * n), ldx<K>(Y + k.xyoff, q.xylen, kk + (long)c * n));
         stx<K>(W, q.wlen, (long)e * nn + o, acc_result<K>(s));
+    }
+}
+// T_e = X^-1 (A_e Y) for the blocks of side > 16 that have an inverse factor, by COLUMN PANELS: associated this way every product is independent
+// column by column, so a matrix is shared by n / pc workgroups (pc = 256 / n columns: one entry per thread) instead of one workgroup walking
+// four entries per thread through three products (SDPA x64: 512 matrices of 32 x 32 on 256 compute units, 2 waves per SIMD: 42 % of the pipe).
+// k_mw_dense_t skips these blocks (`panels` = 1).
+template <int K, int DK>
+__global__ __launch_bounds__(MW_NT) void k_mw_dense_tp(const MwDev q, const double *__restrict__ Y) {
+    using namespace mwk;
+    const MwBlk &k = q.blk[q.dn_list[blockIdx.x]];
+    const int n = k.n, tid = threadIdx.x, e = blockIdx.y;
+    if (n <= 16 || !k.inv || e >= k.cnt) return;
+    const int pc = max(1, MW_NT / n), c0 = blockIdx.z * pc;
+    if (c0 >= n) return;
+    const int pw = min(pc, n - c0);
+    const long nn = (long)n * n, np = (long)n * pc;
+    const double *A = q.dA + k.a_off, *Xi = q.Xi + k.xyoff;
+    lds_d *M1 = MW_LDS, *M2 = M1 + (long)K * np;
+    for (int o = tid; o < n * pw; o += MW_NT) {            // M1 = A_e Y[:, panel]
+        const int i = o % n, cl = o / n;
+        acc<K> s;
+        acc_zero<K>(s);
+        for (int kk = 0; kk < n; kk++) acc_fma<K, K, DK>(s, ldx<K>(Y + k.xyoff, q.xylen, kk + (long)(c0 + cl) * n), ldx<DK>(A, q.dAp, (long)e * nn + i + (long)kk * n));
+        stx<K>(M1, np, o, acc_result<K>(s));
+    }
+    __syncthreads();
+    for (int o = tid; o < n * pw; o += MW_NT) {            // M2 = Xi M1
+        const int i = o % n, cl = o / n;
+        acc<K> s;
+        acc_zero<K>(s);
+        for (int r = 0; r <= i; r++) acc_fma<K, K, K>(s, ldx<K>(Xi, q.xylen, i + (long)r * n), ldx<K>(M1, np, r + (long)cl * n));
+        stx<K>(M2, np, o, acc_result<K>(s));
+    }
+    __syncthreads();
+    double *W = q.W + k.w_off;
+    for (int o = tid; o < n * pw; o += MW_NT) {            // T_e[:, panel] = Xi^T M2
+        const int i = o % n, cl = o / n;
+        acc<K> s;
+        acc_zero<K>(s);
+        for (int r = i; r < n; r++) acc_fma<K, K, K>(s, ldx<K>(Xi, q.xylen, r + (long)i * n), ldx<K>(M2, np, r + (long)cl * n));
+        stx<K>(W, q.wlen, (long)e * nn + i + (long)(c0 + cl) * n, acc_result<K>(s));
     }
 }
 // Sd[e, e'] = <A_e', T_e>, e <= e' computed, mirrored: W lanes per pair -- a wave for large blocks, eight lanes for blocks of a few dozen entries
