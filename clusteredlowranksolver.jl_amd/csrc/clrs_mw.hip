@@ -142,6 +142,8 @@ struct clrs_mw_ctx {
     void *comm_side = nullptr;           // a second communicator for the exchanges of the iteration's side stream (clrs_mw_comm_init_side)
     clrs_mw_local_group *lgroup = nullptr;   // or: the in-process group (clrs_mw_comm_init_local)
     bool local_factored = false, fwd_done = false;
+    MwxDev mwx = {};                     // digits of V (static), Z, T of the blocks whose pairing matrices go through k_mwx_slice / k_mwx_gram
+    int mwx_blocks = 0, mwx_maxU16 = 0;
     MwsDev mws = {};                     // static V slices of the blocks the exact-product kernel takes
     int mws_blocks = 0;                  // how many
     int mws_turns = 1;                   // 2: some eligible block has more than four T / Z tiles
@@ -489,9 +491,67 @@ extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int dev
         }
         MW_TRY(mw_upload(c, mws_off, &c->mws.vs_off));
     }
+    // ---- pairing matrices of blocks of any size through digits in global memory (k_mwx_slice, k_mwx_gram): blocks without sub-blocks that
+    // k_mws_pair does not take and that have enough unique vectors for their U x U Gram products to matter ----
+    std::vector<long long> mwx_off((size_t)std::max(NB, 1), -1);
+    if (g_cfg_mw_exact_products != 0) {
+        const int S = mws_slices(K);
+        std::vector<float> hVd;
+        std::vector<int> heV, he_off((size_t)std::max(NB, 1), 0), hsv((size_t)std::max(NB, 1), 0);
+        for (int b = 0; b < NB; b++) {
+            const MwBlk &k = c->blk[b];
+            if (k.kind != 0 || k.m != 1 || mws_off[b] >= 0) continue;
+            if (k.U < (g_cfg_mw_exact_products == 2 ? 16 : 64) || k.n < 8) continue;
+            const int n = k.n, U = k.U, np = (n + 3) & ~3, U16 = (U + 15) & ~15;
+            mwx_off[b] = (long long)hVd.size();
+            he_off[b] = (int)heV.size();
+            hVd.resize(hVd.size() + (size_t)S * np * U16, 0.0f);
+            heV.resize(heV.size() + U16, 0);
+            float *dst = hVd.data() + mwx_off[b];
+            int sv = 0;
+            for (int u = 0; u < U; u++) {
+                double mx = 0;
+                for (int i = 0; i < n; i++) mx = std::max(mx, std::fabs(hVl[0][k.v_off + (i64)u * n + i]));
+                const int e = mwk::mws_exponent(mx);
+                heV[he_off[b] + u] = e;
+                for (int i = 0; i < n; i++) {
+                    double r0 = std::ldexp(hVl[0][k.v_off + (i64)u * n + i], -e), r1 = DK > 1 ? std::ldexp(hVl[1][k.v_off + (i64)u * n + i], -e) : 0.0;
+                    for (int s2 = 0; s2 < S; s2++) {
+                        const double g = std::ldexp(1.0, -(s2 + 1) * MWS_BETA), C = 0x1.8p52 * g;
+                        volatile double tv = r0 + C;
+                        const double t = tv - C;
+                        const float dgt = (float)(t * std::ldexp(1.0, (s2 + 1) * MWS_BETA));
+                        dst[(size_t)s2 * np * U16 + (size_t)i * U16 + u] = dgt;
+                        if (dgt != 0.0f) sv = std::max(sv, s2 + 1);
+                        r0 -= t;
+                        double sm, er;
+                        mwa::two_sum(r0, r1, sm, er);
+                        r0 = sm; r1 = er;
+                    }
+                }
+            }
+            hsv[b] = sv;
+            c->mwx_blocks++;
+            c->mwx_maxU16 = std::max(c->mwx_maxU16, U16);
+        }
+        if (c->mwx_blocks > 0) {
+            MW_TRY(mw_upload(c, hVd, &c->mwx.Vd)); MW_TRY(mw_upload(c, heV, &c->mwx.eV));
+            MW_TRY(mw_upload(c, he_off, &c->mwx.e_off)); MW_TRY(mw_upload(c, hsv, &c->mwx.sv));
+            double *zd = nullptr, *td = nullptr, *ez = nullptr, *et = nullptr;      // (the allocator counts doubles)
+            MW_TRY(mw_dmalloc(c, &zd, (i64)(hVd.size() + 1) / 2)); MW_TRY(mw_dmalloc(c, &td, (i64)(hVd.size() + 1) / 2));
+            MW_TRY(mw_dmalloc(c, &ez, (i64)(heV.size() + 1) / 2)); MW_TRY(mw_dmalloc(c, &et, (i64)(heV.size() + 1) / 2));
+            c->mwx.Zd = (float *)zd; c->mwx.Td = (float *)td; c->mwx.eZ = (int *)ez; c->mwx.eT = (int *)et;
+            MWCHECK(hipMemset(zd, 0, hVd.size() * sizeof(float))); MWCHECK(hipMemset(td, 0, hVd.size() * sizeof(float)));      // the padding rows and columns stay zero
+            MWCHECK(hipMemset(ez, 0, heV.size() * sizeof(int))); MWCHECK(hipMemset(et, 0, heV.size() * sizeof(int)));
+        }
+        MW_TRY(mw_upload(c, mwx_off, &c->mwx.d_off));
+    } else {
+        MW_TRY(mw_upload(c, mwx_off, &c->mwx.d_off));
+    }
     // ---- upload ----
     MwDev &q = c->d;
     q.mws_off = c->mws.vs_off; q.mws_on = c->mws_blocks > 0 ? 1 : 0;
+    q.mwx_off = c->mwx.d_off; q.mwx_on = c->mwx_blocks > 0 ? 1 : 0;
     q.J = J; q.N = N; q.NB = NB; q.nlr = (int)lr_list.size(); q.ndn = (int)dn_list.size();
     q.xylen = xyoff; q.xlen = xlen; q.Slen = Slen; q.T = T; q.xrdlen = rdoff;
     q.zlen = std::max<i64>(zoff, 1); q.glen = std::max<i64>(goff, 1); q.wlen = std::max<i64>(woff, 1); q.sdlen = std::max<i64>(sdoff, 1);
@@ -674,7 +734,13 @@ extern "C" int clrs_mw_schur_assemble_dev(clrs_mw_ctx *c, const double *d_Xchol,
             const int gper = MW_NT / MW_GRAM_W;
             hipLaunchKernelGGL((k_mw_zt<KK, DD>), dim3((c->maxU + MW_CT - 1) / MW_CT, q.nlr), dim3(MW_NT), c->sm_zt, c->stream, q2, d_Y, c->lds_zt_L ? 1 : 0, c->xinv_valid ? 1 : 0);
             dense_done = q.ndn && !q.dn_big;                // 1 x 1 dense blocks ride on this launch
+            q2.mwx_on = c->mwx_blocks > 0 ? 1 : 0;
             hipLaunchKernelGGL((k_mw_gram<KK, DD>), dim3((c->maxU * (c->maxU + 1) / 2 + gper - 1) / gper, q.nlr + (dense_done ? q.ndn : 0)), dim3(MW_NT), 0, c->stream, q2, d_Y);
+            if (q2.mwx_on) {                                 // the large pairing matrices: digits of Z and T, then 16 x 16 tiles on the matrix cores
+                const int nt = c->mwx_maxU16 / 16;
+                hipLaunchKernelGGL(k_mwx_slice<KK>, dim3(nt, 2, q.nlr), dim3(MWS_NT), 0, c->stream, q2, c->mwx);
+                hipLaunchKernelGGL(k_mwx_gram<KK>, dim3((nt * (nt + 1) / 2 + MWS_NT / 64 - 1) / (MWS_NT / 64), 2, q.nlr), dim3(MWS_NT), 0, c->stream, q2, c->mwx);
+            }
         }
         if (q.ndn && !dense_done) {
             const bool panels = c->xinv_valid && c->maxn_dense > 16 && c->maxn_dense <= MW_NT;      // dense blocks of side > 16 with inverse factors: column panels (k_mw_dense_tp)

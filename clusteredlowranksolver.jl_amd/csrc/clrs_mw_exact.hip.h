@@ -309,4 +309,143 @@ __global__ __launch_bounds__(MWS_NT, 2) void k_mws_pair(const MwDev q, const Mws
 #undef MWS_STAMP
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// Pairing matrices of blocks of ANY size (many unique vectors: the three-point bound has blocks of side 54 with 408 of them) through the same
+// exact slice products: GX = Z^T Z and GY = V^T T are U x U Gram products of n-row operands, 83 000 entries of 54-term K-limb dot products for
+// such a block in k_mw_gram.  Here k_mw_zt leaves Z and T as K-limb matrices as before, k_mwx_slice cuts them into digits by columns ([slice][k][col]
+// in global memory, one exponent per column; the digits of V are static), and k_mwx_gram gives every wave one 16 x 16 tile of the lower triangle:
+// operands straight from memory (L2), 32 rows of k per exact accumulation, the order sums pushed into one K-limb accumulator per entry across the
+// chunks of k.  Blocks with sub-blocks (m > 1) and the small shapes of k_mws_pair are not taken.
+// ---------------------------------------------------------------------------------------------------------------------------------------
+struct MwxDev {
+    const float *Vd;         // static digits of V, [S][np][U16] per block at d_off (np = n rounded up to 4, U16 = U rounded up to 16; padding zero)
+    float *Zd, *Td;          // digits of Z and T of the current assembly, same shape and offsets
+    const int *eV;           // column exponents, [U16] per block at e_off
+    int *eZ, *eT;
+    const long long *d_off;  // [NB], -1: not taken
+    const int *e_off;        // [NB]
+    const int *sv;           // [NB] slices of V that are not all zero
+};
+
+// digits and column exponents of Z (blockIdx.y = 0) and T (1) of one block: sixteen columns per workgroup
+template <int K>
+__global__ __launch_bounds__(MWS_NT) void k_mwx_slice(const MwDev q, const MwxDev w) {
+    using namespace mwk;
+    constexpr int S = mws_slices(K);
+    const int b = q.lr_list[blockIdx.z];
+    if (w.d_off[b] < 0) return;
+    const MwBlk &k = q.blk[b];
+    const int n = k.n, U = k.U, tid = threadIdx.x, np = (n + 3) & ~3, U16 = (U + 15) & ~15;
+    const int c0 = blockIdx.x * 16;
+    if (c0 >= U16) return;
+    const int nc = min(16, U - c0);                         // live columns of this chunk (<= 0: padding only)
+    const double *src = (blockIdx.y == 0 ? q.Z : q.Tm) + k.z_off;
+    float *D = (blockIdx.y == 0 ? w.Zd : w.Td) + w.d_off[b];
+    int *E = (blockIdx.y == 0 ? w.eZ : w.eT) + w.e_off[b];
+    __shared__ int emax[16];
+    if (tid < 16) emax[tid] = 0;
+    __syncthreads();
+    for (int e = tid; e < n * nc; e += MWS_NT) {            // heads, coalesced along the columns' rows
+        const int i = e % n, cl = e / n;
+        const double h = src[i + (long)(c0 + cl) * n];
+        if (h != 0.0) atomicMax(&emax[cl], mws_exponent(h) + 4096);
+    }
+    __syncthreads();
+    if (tid < 16) {
+        const int ev = emax[tid] == 0 ? 0 : emax[tid] - 4096;
+        emax[tid] = ev;
+        E[c0 + tid] = ev;
+    }
+    __syncthreads();
+    const long sD = (long)np * U16;
+    for (int e = tid; e < n * nc; e += MWS_NT) {            // digits: the column runs fastest, so that the sixteen floats of a (slice, row) are one store
+        const int cl = e % nc, i = e / nc;
+        const mw<K> x = ldx<K>(src, q.zlen, i + (long)(c0 + cl) * n);
+        float *dst = D + (long)i * U16 + c0 + cl;
+        mws_slice<K, S>(x, emax[cl], [&](int sl, float d) { dst[sl * sD] = d; });
+    }
+}
+
+namespace mwk {
+// acc[o] += the pairs s + t = o of the k-steps ks0 .. ks0 + nks - 1, operands in global memory: A[s][k][ca + l15], B[t][k][cb + l15]
+template <int S, int SA, int SB>
+__device__ __forceinline__ void mwx_tile(v4d_mw (&acc)[S], const float *__restrict__ Ag, long sa, int ra, const float *__restrict__ Bg, long sb, int rb, int ks0, int nks, int l15,
+                                         int l4) {
+    const float *ap = Ag + (long)(4 * ks0 + l4) * ra + l15, *bp = Bg + (long)(4 * ks0 + l4) * rb + l15;
+    float af[SA], bf[SB];
+#pragma unroll
+    for (int s = 0; s < SA; s++) af[s] = ap[s * sa];
+#pragma unroll
+    for (int t = 0; t < SB; t++) bf[t] = bp[t * sb];
+    for (int ks = 0; ks < nks; ks++) {
+        double av[SA], bv[SB];
+#pragma unroll
+        for (int s = 0; s < SA; s++) av[s] = (double)af[s];
+#pragma unroll
+        for (int t = 0; t < SB; t++) bv[t] = (double)bf[t];
+        if (ks + 1 < nks) {                                 // the next k-step's digits are on their way while this one's products run
+            ap += 4 * ra; bp += 4 * rb;
+#pragma unroll
+            for (int s = 0; s < SA; s++) af[s] = ap[s * sa];
+#pragma unroll
+            for (int t = 0; t < SB; t++) bf[t] = bp[t * sb];
+        }
+#pragma unroll
+        for (int s = 0; s < SA; s++)
+#pragma unroll
+            for (int t = 0; t < SB; t++)
+                if (s + t < S) acc[s + t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], bv[t], acc[s + t], 0, 0, 0);
+    }
+}
+
+}  // namespace mwk
+
+// one 16 x 16 tile (ta >= tb) of GX (blockIdx.y = 0) or GY (1) per wave
+template <int K>
+__global__ __launch_bounds__(MWS_NT, 2) void k_mwx_gram(const MwDev q, const MwxDev w) {
+    using namespace mwk;
+    constexpr int S = mws_slices(K), S1 = (S + 1) / 2, S2 = (3 * S + 3) / 4;
+    const int b = q.lr_list[blockIdx.z];
+    if (w.d_off[b] < 0) return;
+    const MwBlk &k = q.blk[b];
+    const int n = k.n, U = k.U, np = (n + 3) & ~3, U16 = (U + 15) & ~15, nt = U16 / 16;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
+    const int task = blockIdx.x * (MWS_NT / 64) + wave;
+    if (task >= nt * (nt + 1) / 2) return;                  // (uniform over the wave; no barrier below)
+    int ta, tb;
+    tri_index(task, ta, tb);                                // ta >= tb
+    const bool gy = blockIdx.y == 1;
+    const long sD = (long)np * U16, off = w.d_off[b];
+    const float *Lg = (gy ? w.Vd : (const float *)w.Zd) + off + ta * 16, *Rg = (gy ? (const float *)w.Td : (const float *)w.Zd) + off + tb * 16;
+    const int *eL = (gy ? w.eV : (const int *)w.eZ) + w.e_off[b], *eR = (gy ? (const int *)w.eT : (const int *)w.eZ) + w.e_off[b];
+    const int SV = w.sv[b], ksteps = np / 4;
+    acc<K> a4[4];
+#pragma unroll
+    for (int reg = 0; reg < 4; reg++) acc_zero<K>(a4[reg]);
+    v4d_mw acc[S];
+    for (int ks0 = 0; ks0 < ksteps; ks0 += 8) {             // 32 rows of k: the order sums stay below 2^53
+        const int nks = min(8, ksteps - ks0);
+#pragma unroll
+        for (int o = 0; o < S; o++) acc[o] = (v4d_mw){0.0, 0.0, 0.0, 0.0};
+        if (!gy) mwx_tile<S, S, S>(acc, Lg, sD, U16, Rg, sD, U16, ks0, nks, l15, l4);
+        else if (SV <= S1) mwx_tile<S, S1, S>(acc, Lg, sD, U16, Rg, sD, U16, ks0, nks, l15, l4);
+        else if (SV <= S2) mwx_tile<S, S2, S>(acc, Lg, sD, U16, Rg, sD, U16, ks0, nks, l15, l4);
+        else mwx_tile<S, S, S>(acc, Lg, sD, U16, Rg, sD, U16, ks0, nks, l15, l4);
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) MwsPush<K, S, 0>::run(a4[reg], acc, reg);
+    }
+    double *G = (gy ? q.GY : q.GX) + k.g_off;
+#pragma unroll
+    for (int reg = 0; reg < 4; reg++) {
+        const int a = ta * 16 + 4 * reg + l4, c = tb * 16 + l15;        // entry (a, c), a >= c kept and mirrored
+        if (a >= U || c >= U || c > a) continue;
+        mw<K> v = acc_result<K>(a4[reg]);
+        const int es = eL[a] + eR[c];
+#pragma unroll
+        for (int l = 0; l < K; l++) v.l[l] = ldexp(v.l[l], es);
+        stx<K>(G, q.glen, a + (long)c * U, v);
+        stx<K>(G, q.glen, c + (long)a * U, v);
+    }
+}
+
 #endif

@@ -26,6 +26,8 @@
     X __global__ void k_mwi_Z<K>(const MwDev, const MwIpmDev, int, int);                                               \
     X __global__ void k_mwi_Zi<K>(const MwDev, const MwIpmDev, int);                                                   \
     X __global__ void k_mwi_bmm<K>(const MwDev, const MwIpmDev, int, int);                                             \
+    X __global__ void k_mwx_slice<K>(const MwDev, const MwxDev);                                                       \
+    X __global__ void k_mwx_gram<K>(const MwDev, const MwxDev);                                                        \
     X __global__ void k_mwi_update<K>(const MwDev, const MwIpmDev);                                                    \
     X __global__ void k_mwi_init<K>(const MwDev, const MwIpmDev, double, double);
 

@@ -85,7 +85,8 @@ struct MwDev {
     double *Qg, *ug;                    // [world][limbs * N * N], [world][limbs * N]
     // exact-product path of the pairing matrices (clrs_mw_exact.hip.h): blocks with mws_off[b] >= 0 are taken by k_mws_pair when mws_on
     const long long *mws_off;
-    int mws_on, pad4;
+    int mws_on, mwx_on;
+    const long long *mwx_off;           // blocks with mwx_off[b] >= 0: pairing matrices of ANY size from the digits of Z, T, V (k_mwx_slice, k_mwx_gram) when mwx_on
 };
 
 namespace mwk {
@@ -585,6 +586,7 @@ __global__ __launch_bounds__(MW_NT) void k_mw_gram(const MwDev q, const double *
         return;
     }
     if (q.mws_on && q.mws_off[q.lr_list[blockIdx.y]] >= 0) return;
+    if (q.mwx_on && q.mwx_off[q.lr_list[blockIdx.y]] >= 0) return;      // k_mwx_gram
     const MwBlk &k = q.blk[q.lr_list[blockIdx.y]];
     const int n = k.n, U = k.U, dl = k.delta;
     const int e = blockIdx.x * (MW_NT / MW_GRAM_W) + threadIdx.x / MW_GRAM_W, sub = threadIdx.x % MW_GRAM_W;
