@@ -732,6 +732,37 @@ def test_exact_product_pairings_match_the_oracle(name, K, oracle_built):
     ctx.close()
 
 
+@pytest.mark.parametrize("K", [4, 5, 6])
+def test_exact_product_pairings_of_a_large_block(K, oracle_built):
+    """k_mwx_slice / k_mwx_gram (csrc/clrs_mw_exact.hip.h): the pairing matrices of a block beyond the shapes of k_mws_pair -- 41 x 41 with 81 unique
+    vectors: digits of Z and T in global memory, 6 x 6 tiles of 16 x 16 per matrix, 44 rows of k in two exact accumulations of at most 32 -- against
+    the oracle like the expansion kernels; the same context with the exact products switched off gives the same S to the tolerance of either."""
+    import torch
+    from clrs_amd.mw import MwSchurContext
+    from oracle.oracle import Oracle
+    f = flat("polyopt80")
+    X, Y = _iterates(f, K)
+    X, Y = _sym_limbs(f, X), _sym_limbs(f, Y)
+    o = Oracle(f, mp_bits=320 if K <= 5 else 640)
+    pad = lambda a: np.vstack([a, np.zeros((1, a.shape[1]))])
+    res = {}
+    for exact in (True, False):
+        ctx = MwSchurContext(f, limbs=K, exact_products=exact)
+        dX, dY = torch.tensor(X, device="cuda:0"), torch.tensor(Y, device="cuda:0")
+        dXc = torch.empty_like(dX)
+        ctx.cholesky_blocks_dev(dX.data_ptr(), dXc.data_ptr())
+        ctx.assemble_dev(dXc.data_ptr(), dY.data_ptr())
+        S, AY = ctx.get_S()
+        if exact:
+            S_ref, AY_ref = o.schur_assemble_mw(pad(dXc.cpu().numpy()), pad(Y))
+        assert mw_relerr(S, S_ref) <= tol(K, 22), (exact, np.log2(mw_relerr(S, S_ref)))
+        assert mw_relerr(AY, AY_ref, scale=max(1.0, np.max(np.abs(AY_ref[0])))) <= tol(K, 16), exact
+        res[exact] = S
+        ctx.close()
+    assert not np.array_equal(res[True], res[False])        # two different arithmetics (the exact path was taken), one answer
+    assert mw_relerr(res[True], res[False]) <= tol(K, 22)
+
+
 @pytest.mark.parametrize("K", [4, 5])
 def test_exact_product_pairings_on_the_trajectory_fixture(K):
     """The same on real interior-point iterates (tests/golden/ce_8_15_traj.npz, mu from 1e20 to 2e-16, cond(X) up to 2^56): S against the

@@ -36,6 +36,8 @@ def instance(name):
         return P.polyopt(lambda x: x * x + 1, 1)
     if name == "polyopt40":
         return P.polyopt_random(20, seed=0)[0]
+    if name == "polyopt80":     # one 41 x 41 block with 81 unique vectors: beyond the shapes of k_mws_pair, two chunks of k in k_mwx_gram
+        return P.polyopt_random(40, seed=1)[0]
     if name == "polyopt8":
         return P.polyopt_random(4, seed=3)[0]
     if name == "delsarte_3_10":
