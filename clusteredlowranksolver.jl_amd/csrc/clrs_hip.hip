@@ -163,6 +163,8 @@ struct clrs_ctx {
     // device buffers
     std::vector<CholLevelJob> chol_jobs;           // jobs of the single-matrix k_chol_level launches (passed by value)
     std::map<const double *, std::pair<double *, double *>> s_inv;   // factor L_j of S -> its inverted diagonal blocks and their scratch (shared by the solve plans)
+    std::vector<std::pair<i64, double *>> trsm_y_pool;               // scratch copies of the right-hand sides of plan_trsm_blockinv, by job position: the plans of a
+                                                                    // context run one after the other on one stream, so the forward and the backward solve of a triangle share them
     bool s_inv_valid = false;                      // ... formed since the last factorisation (eager mode skips forming them again)
     std::vector<CholAugDesc> chol_aug;             // augmented factorisations [S; B^T] (k_chol_pack / k_chol_unpack, passed by value)
     double *d_Xc = nullptr, *d_Y = nullptr;        // inputs (xy layout)
@@ -346,7 +348,15 @@ static int plan_trsm_blockinv(clrs_ctx *c, Plan &pl, const std::vector<TrsmJob> 
             if ((rc = dmalloc(c, &a.T, (i64)j.n * (IB / 2)))) return rc;
             if (share) c->s_inv[j.L] = {a.inv, a.T};
         }
-        if ((rc = dmalloc(c, &a.Y, (i64)j.n * j.nrhs))) return rc;
+        {   // the q-th job of every plan uses the q-th scratch of the context (jobs of ONE plan run side by side and need one each)
+            const i64 need = (i64)j.n * j.nrhs;
+            if (c->trsm_y_pool.size() <= q) c->trsm_y_pool.resize(q + 1, {0, nullptr});
+            if (c->trsm_y_pool[q].first < need) {
+                if ((rc = dmalloc(c, &c->trsm_y_pool[q].second, need))) return rc;
+                c->trsm_y_pool[q].first = need;
+            }
+            a.Y = c->trsm_y_pool[q].second;
+        }
         for (int o = 0; o < a.nob; o++) {
             const int r0 = o * IB, nb = std::min(IB, j.n - r0);
             for (int l0 = 0; l0 < nb; l0 += TRSM_NB) {
