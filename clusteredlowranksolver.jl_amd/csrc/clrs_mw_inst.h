@@ -45,6 +45,7 @@
     X __global__ void k_mwi_dots<K, DK>(const MwDev, const MwIpmDev, int, int);                                             \
     X __global__ void k_mwi_coef<K, DK>(const MwDev, const MwIpmDev, const double *);                                  \
     X __global__ void k_mwi_wA<K, DK>(const MwDev, const MwIpmDev, int, int, int);                                          \
+    X __global__ void k_mwi_wB<K, DK>(const MwDev, const MwIpmDev, int);                                                    \
     X __global__ void k_mwi_MV<K, DK>(const MwDev, const double *);                                                    \
     X __global__ void k_mwi_rows_dn<K, DK>(const MwDev, const MwIpmDev, int);                                          \
     X __global__ void k_mwi_rows<K, DK>(const MwDev, const MwIpmDev, int, int);                                        \

@@ -17,8 +17,10 @@ struct MwIpmDev {
     double *x, *y, *X, *Y, *dx, *dy, *dX, *dY, *R, *Xc, *Pm, *d, *rhsx, *pv, *coef;   // planar limbs
     double *Yi;                        // chol(Y)^-1 per block (xy layout), formed beside chol(X) at the start of the iteration
     int *yfail;                        // [NB] 1 = Y_b is not positive definite
+    int wBn;                           // leading dimension of wB: the largest side of a low-rank block (0: not used)
     double *Zs;                        // unsymmetrised X^-1 (...) of k_mwi_Zi (xy layout)
     double *Zt;                        // second scratch of the tiled form of the same products (k_mwi_bmm; xy layout)
+    double *wB;                        // [T * wBn] K limbs: coefficient times right vector of every term, for blocks with many terms (k_mwi_wB)
     int *zcnt;                         // [NB] workgroups of a block that have delivered their panel
     double *dtr;                       // [xlen] dense part of the row traces <A_*, M> (k_mwi_rows_dn), when some dense block has n > 1
     double *sc, *part;                 // planar scalars [MSC_COUNT]; partial dot products [5][NB]
@@ -562,7 +564,7 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_coef(const MwDev q, const MwIpmDe
 // EW lanes per entry: four, or sixteen for blocks with hundreds of terms (every term is a chain of dependent gathers: its flag, its two vector
 // indices, the vectors' entries -- the lanes of an entry walk their share of the terms one after the other)
 template <int K, int DK, int EW>
-__device__ __forceinline__ void mwi_wA_body(const MwDev &q, const MwIpmDev &p, int mode, int coef_lds) {
+__device__ __forceinline__ void mwi_wA_body(const MwDev &q, const MwIpmDev &p, int mode, int coef_lds, int use_B) {
     using namespace mwk;
     const MwBlk &k = q.blk[blockIdx.y];
     const int n = k.n;
@@ -590,6 +592,12 @@ __device__ __forceinline__ void mwi_wA_body(const MwDev &q, const MwIpmDev &p, i
         const int *tp = q.tptr + k.tptr_off;
         for (int t = tp[0] + sub; t < tp[k.P]; t += EW) {
             if (!(q.st_flag[t] & 1)) continue;     // s <= r only (:1433)
+            if (use_B) {                           // coefficient times right vector formed once per term and column (k_mwi_wB): a K x DK product per entry is left
+                const mw<DK> vi = ldx<DK>(V, q.Vp, i + (long)q.st_war[t] * n);
+                if (vi.l[0] == 0.0) continue;
+                acc_fma<K, K, DK>(s, ldx<K>(p.wB, q.T * (long)p.wBn, (long)t * p.wBn + c), vi);
+                continue;
+            }
             const mw<DK> vi = ldx<DK>(V, q.Vp, i + (long)q.st_war[t] * n), vc = ldx<DK>(V, q.Vp, c + (long)q.st_wac[t] * n);
             if (vi.l[0] == 0.0 || vc.l[0] == 0.0) continue;
             constexpr int LL = (2 * DK + 1 < K) ? 2 * DK + 1 : K;
@@ -623,8 +631,28 @@ __device__ __forceinline__ void mwi_wA_body(const MwDev &q, const MwIpmDev &p, i
 }
 template <int K, int DK>
 __global__ __launch_bounds__(MW_NT) void k_mwi_wA(const MwDev q, const MwIpmDev p, int mode, int coef_lds, int ew) {
-    if (ew == 16) mwi_wA_body<K, DK, 16>(q, p, mode, coef_lds);
-    else mwi_wA_body<K, DK, MWI_EW>(q, p, mode, coef_lds);
+    if (ew == 17) mwi_wA_body<K, DK, 16>(q, p, mode, 0, 1);       // sixteen lanes per entry, products with the vectors' right halves from k_mwi_wB
+    else if (ew == 16) mwi_wA_body<K, DK, 16>(q, p, mode, coef_lds, 0);
+    else mwi_wA_body<K, DK, MWI_EW>(q, p, mode, coef_lds, 0);
+}
+// wB[t][c] = a_p(t) lambda_t V[c, wac(t)] for every term (s <= r) of every low-rank block: with hundreds of terms per block (the three-point bound:
+// 204-408) forming this once per term and column leaves sum a_i A_i a K x DK product per term and entry instead of a DK x DK and a K x (2 DK + 1) one
+template <int K, int DK>
+__global__ __launch_bounds__(MW_NT) void k_mwi_wB(const MwDev q, const MwIpmDev p, int mode) {
+    using namespace mwk;
+    const mwi64 e = (mwi64)blockIdx.x * MW_NT + threadIdx.x;
+    const mwi64 t = e / p.wBn;
+    const int c = (int)(e % p.wBn);
+    if (t >= q.T) return;
+    const int b = q.ay_blk[t];
+    if (b < 0 || !(q.st_flag[t] & 1)) return;
+    const MwBlk &k = q.blk[b];
+    if (c >= k.n) return;
+    const MwClu &cl = q.clu[k.j];
+    const double *a = mode == 0 ? p.x : p.dx;
+    const mw<K> cf = mulx<K, K, DK>(ldx<K>(a, q.xlen, cl.coff + q.st_p[t]), ldx<DK>(q.st_lam, q.lamp, t));
+    const mw<DK> vc = ldx<DK>(q.V + k.v_off, q.Vp, c + (long)q.st_wac[t] * k.n);
+    stx<K>(p.wB, q.T * (long)p.wBn, t * p.wBn + c, mulx<K, K, DK>(cf, vc));
 }
 
 // ---- T = M V for the low-rank blocks (first half of trace_A, src/solver.jl:1334-1341) -----------------------------------
