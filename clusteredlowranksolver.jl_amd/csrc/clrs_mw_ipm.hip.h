@@ -184,7 +184,7 @@ __device__ double wg_min_eig(lds_d *A, int n, lds_d *work, int tid) {
 }
 
 
-// ---- the same for n <= 32 with the tridiagonalisation in the REGISTERS of one wave and a division-free Sturm count ------------------
+// ---- the same for n <= 64 (wg_min_eig32: named after its first version) with the tridiagonalisation in the REGISTERS of one wave and a division-free Sturm count ------------------
 // (the scheme of the fp64 loop's k_ipm_step, clrs_ipm.hip.h: lane r holds row r, the column loop is fully unrolled so that every
 // register index is static, v and w reach the other lanes through v_readlane, norms and dot products through DPP row shifts; the
 // Sturm sequence runs in product form p_(i+1) = (d_i - s) p_i - e_i^2 p_(i-1) with a power-of-two renormalisation every four steps,
@@ -268,15 +268,22 @@ __device__ __forceinline__ void householder_regs(lds_d *A, int n, lds_d *dd, lds
     ev = readlane_f64(ev, n - 1);
     if (lane == 0) ee[n - 2] = ev;
 }
-// work: LDS, at least 2 n + 96 doubles (3 n + 2 MW_NT are there); 2 <= n <= 32; MW_NT = 256 threads
+// n = 33 .. 64 (a wave has 64 lanes: one row each; 96-128 VGPRs of matrix): a call, not inlined -- inlined, the register allocation of the whole
+// step kernel followed this path and the n <= 32 path of the named problems paid for it (34.5 -> 37.4 us)
+__device__ __noinline__ void householder_regs_big(lds_d *A, int n, lds_d *dd, lds_d *ee, int lane) {
+    if (n <= 48) householder_regs<48>(A, n, dd, ee, lane);
+    else householder_regs<64>(A, n, dd, ee, lane);
+}
+// work: LDS, at least 2 n + 160 doubles (3 n + 2 MW_NT are there); 2 <= n <= 64; MW_NT = 256 threads
 __device__ double wg_min_eig32(lds_d *A, int n, lds_d *work, int tid) {
     __shared__ int zc[2][MW_NT / 64];
-    lds_d *dd = work, *ee = work + n, *d2 = work + 2 * n, *e2s = d2 + 48;
+    lds_d *dd = work, *ee = work + n, *d2 = work + 2 * n, *e2s = d2 + 80;
     const int wave = tid >> 6, lane = tid & 63;
     if (wave == 0) {
         if (n <= 16) householder_regs<16>(A, n, dd, ee, lane);
         else if (n <= 24) householder_regs<24>(A, n, dd, ee, lane);
-        else householder_regs<32>(A, n, dd, ee, lane);
+        else if (n <= 32) householder_regs<32>(A, n, dd, ee, lane);
+        else householder_regs_big(A, n, dd, ee, lane);
     }
     __syncthreads();
     double lo = dd[0], hi = dd[0];                          // Gershgorin interval, by every thread
@@ -287,7 +294,7 @@ __device__ double wg_min_eig32(lds_d *A, int n, lds_d *work, int tid) {
     }
     const double scale = fmax(fmax(__builtin_fabs(lo), __builtin_fabs(hi)), 1e-290);
     const int sexp = __builtin_amdgcn_frexp_exp(scale);           // scale < 2^sexp: |d - s| <= 2, e^2 <= 1 after the exact scaling
-    if (tid < 48) {
+    if (tid < 80) {
         d2[tid] = (tid < n) ? ldexp(dd[tid], -sexp) : 0.0;
         const double es = (tid >= 1 && tid < n) ? ldexp(ee[tid - 1], -sexp) : 0.0;
         e2s[tid] = es * es;
@@ -1147,13 +1154,13 @@ __device__ __forceinline__ bool mwi_step_body(const MwDev &q, const MwIpmDev &p,
                 Wl[e] = i >= c ? Wg[e] : Wg[c + (long)i * n];
             }
             __syncthreads();
-            const double ev = n <= 32 ? wg_min_eig32(Wl, n, wk, tid) : wg_min_eig(Wl, n, wk, tid);
+            const double ev = n <= 64 ? wg_min_eig32(Wl, n, wk, tid) : wg_min_eig(Wl, n, wk, tid);
             if (tid == 0) p.eig[(long)which * q.NB + blockIdx.x] = ev - 1e-5;            // :1662
             return true;
         }
         mwi_step_congruence_inv<K>((which == 0 ? q.Xi : p.Yi) + k.xyoff, q.xylen, n, dMg, q.xylen, T1, Wd, tid);
         __syncthreads();
-        const double ev = n <= 32 ? wg_min_eig32(Wd, n, work, tid) : wg_min_eig(Wd, n, work, tid);
+        const double ev = n <= 64 ? wg_min_eig32(Wd, n, work, tid) : wg_min_eig(Wd, n, work, tid);
         if (tid == 0) p.eig[(long)which * q.NB + blockIdx.x] = ev - 1e-5;                // :1662
         return true;
     }
@@ -1173,7 +1180,7 @@ __device__ __forceinline__ bool mwi_step_body(const MwDev &q, const MwIpmDev &p,
             mwi_step_congruence_inv<K>(Li, nn, n, dMg, q.xylen, T1, Wd, tid);
         }
         __syncthreads();
-        const double ev = n <= 32 ? wg_min_eig32(Wd, n, work, tid) : wg_min_eig(Wd, n, work, tid);
+        const double ev = n <= 64 ? wg_min_eig32(Wd, n, work, tid) : wg_min_eig(Wd, n, work, tid);
         if (tid == 0) p.eig[(long)which * q.NB + blockIdx.x] = ev - 1e-5;                // :1662
         return true;
     }
@@ -1203,7 +1210,7 @@ __device__ __forceinline__ bool mwi_step_body(const MwDev &q, const MwIpmDev &p,
     if (w_in_lds) mwi_step_congruence<K>(F, rd, Wl, nn, nn, n, dMg, q.xylen, Wd, tid);
     else mwi_step_congruence<K>(F, rd, (which == 0 ? p.R : p.Pm) + k.xyoff, q.xylen, nn, n, dMg, q.xylen, Wd, tid);    // R and P are dead here; one each
     __syncthreads();
-    const double ev = n <= 32 ? wg_min_eig32(Wd, n, work, tid) : wg_min_eig(Wd, n, work, tid);
+    const double ev = n <= 64 ? wg_min_eig32(Wd, n, work, tid) : wg_min_eig(Wd, n, work, tid);
     if (tid == 0) p.eig[(long)which * q.NB + blockIdx.x] = ev - 1e-5;                    // :1662
     return true;
 }
