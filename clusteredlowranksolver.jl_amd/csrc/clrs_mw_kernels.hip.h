@@ -171,6 +171,7 @@ __device__ __forceinline__ bool wg_potrf(PM M, long plane, int n, int ld, PR rd,
     if (INV) {
         for (int e = tid; e < n * n; e += NT) {
             const int i = e % n, c = e / n;
+            if (ldw && cnw > 1 && c % cnw != cw) continue;      // W in memory, shared with other workgroups: the columns of this one only
             if (ldw || i >= c) stx<K>(W, wplane, ldw ? i + (long)c * ldw : w_index(i, c, n, 0), i == c ? from_double<K>(1.0) : zero<K>());
         }
         __syncthreads();
@@ -211,7 +212,7 @@ __device__ __forceinline__ bool wg_potrf(PM M, long plane, int n, int ld, PR rd,
             if (tid == NT - 1) {
                 srun = mul<K>(srun, dh);
                 stx<K>(us, n, k + 1, srun);
-                if (INV) stx<K>(W, wplane, w_index(k + 1, k + 1, n, ldw), srun);
+                if (INV && (!ldw || cnw == 1 || (k + 1) % cnw == cw)) stx<K>(W, wplane, w_index(k + 1, k + 1, n, ldw), srun);
             }
         }
         __syncthreads();
@@ -249,7 +250,7 @@ __device__ __forceinline__ bool wg_potrf(PM M, long plane, int n, int ld, PR rd,
             stx<K>(W, wplane, idx, mul<K>(ldx<K>(W, wplane, idx), ldx<K>(fs, n, i)));
         }
     }
-    if (INV) for (int i = tid; i < n; i += NT) stx<K>(W, wplane, w_index(i, i, n, ldw), ldx<K>(rd, rdplane, i));
+    if (INV) for (int i = tid; i < n; i += NT) if (!ldw || cnw == 1 || i % cnw == cw) stx<K>(W, wplane, w_index(i, i, n, ldw), ldx<K>(rd, rdplane, i));
     __syncthreads();
 #ifdef MW_STAMPS
     if (tid == 0) g_stamps[101] = wall_clock64();
@@ -420,9 +421,13 @@ __device__ __forceinline__ void mw_potrf_x_body(const MwDev &q, const MwBlk &k, 
                                                 int tid, int bid) {
     using namespace mwk;
     const int n = k.n;
-    const bool ok = wg_potrf<K, INV, MW_PT, true>(M, plane, n, n, q.xrd + k.rd_off, q.xrdlen, W, wplane, w_in_place ? n : 0, bc, tid);   // the LDS copy of W is packed
+    // W in memory (blocks whose factor and inverse do not fit in LDS side by side): gridDim.y workgroups repeat the elimination of M in their own
+    // LDS and share out the columns of W, like the factorisations of S_j and Q; the first one writes the factor
+    const int cw = w_in_place ? blockIdx.y : 0, cnw = w_in_place ? gridDim.y : 1;
+    const bool ok = wg_potrf<K, INV, MW_PT, true>(M, plane, n, n, q.xrd + k.rd_off, q.xrdlen, W, wplane, w_in_place ? n : 0, bc, tid, cw, cnw);   // the LDS copy of W is packed
     if (!ok && tid == 0) atomicMin(&q.info[1], bid + 1);
     __syncthreads();
+    if (cw != 0) return;
     if (ok) wg_scaled_factors_u<K, MW_PT>(M, plane, n, q.xrd + k.rd_off, q.xrdlen, n, q.Xf + k.xyoff, q.xylen, n, q.Xb + k.xyoff, q.xylen, n, tid);
     for (int e = tid; e < n * n; e += MW_PT) {
         const int i = e % n, c = e / n;
@@ -444,6 +449,7 @@ __global__ __launch_bounds__(MW_PT) void k_mw_potrf_x(const MwDev q, const doubl
     const bool second = (int)blockIdx.x >= q.NB;
     const MwBlk &k = q.blk[second ? blockIdx.x - q.NB : blockIdx.x];
     const int n = k.n, tid = threadIdx.x;
+    if (blockIdx.y != 0 && !(lds && k.inv == 2)) return;   // more than one workgroup per matrix only where the inverse is formed in memory
     lds_d *bc = MW_LDS;                                   // scratch of wg_potrf, in front of the matrix
     if (second) {
         lds_d *M = MW_LDS + MW_POTRF_SCR(K, n);
@@ -462,9 +468,9 @@ __global__ __launch_bounds__(MW_PT) void k_mw_potrf_x(const MwDev q, const doubl
             }
         } else {                                        // the inverse in place in memory
             lds_d *rdl = M + (long)K * n * n;
-            ok = wg_potrf<K, true, MW_PT, false>(M, (long)n * n, n, n, rdl, n, Yi + k.xyoff, q.xylen, n, bc, tid);
+            ok = wg_potrf<K, true, MW_PT, false>(M, (long)n * n, n, n, rdl, n, Yi + k.xyoff, q.xylen, n, bc, tid, blockIdx.y, gridDim.y);
         }
-        if (tid == 0) yfail[blockIdx.x - q.NB] = ok ? 0 : 1;
+        if (tid == 0 && blockIdx.y == 0) yfail[blockIdx.x - q.NB] = ok ? 0 : 1;
         return;
     }
     if (lds) {
