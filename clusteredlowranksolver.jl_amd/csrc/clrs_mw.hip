@@ -138,6 +138,9 @@ struct clrs_mw_ctx {
     double cnt_factor = 0, cnt_solve = 0;
     struct MwIpm *ipm = nullptr;
     size_t sm_bp_diag = 0, sm_bp_panel = 0, sm_bp_inv = 0;   // LDS of the blocked factorisation (k_mw_bp_*)
+    std::vector<MwBp> bp_S, bp_Q;       // the matrices of the blocked path: the clusters beyond LDS, and Q (when it is)
+    const MwBp *d_bp = nullptr;         // both lists on the device, bp_S first
+    bool any_lds_cluster = false;
     void *comm = nullptr;                // ncclComm_t when the library does the exchanges itself (clrs_mw_comm_init): the context's stream
     void *comm_side = nullptr;           // a second communicator for the exchanges of the iteration's side stream (clrs_mw_comm_init_side)
     clrs_mw_local_group *lgroup = nullptr;   // or: the in-process group (clrs_mw_comm_init_local)
@@ -618,16 +621,27 @@ extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int dev
         int init[2] = {MW_INFO_NONE, MW_INFO_NONE};
         MWCHECK(hipMemcpy(info, init, sizeof(init), hipMemcpyHostToDevice));
         int *pc = nullptr;
-        MWCHECK(hipMalloc((void **)&pc, (size_t)(J + 2) * sizeof(int)));
+        MWCHECK(hipMalloc((void **)&pc, (size_t)(2 * J + 3) * sizeof(int)));
         c->allocs.push_back(pc);
-        MWCHECK(hipMemset(pc, 0, (size_t)(J + 2) * sizeof(int)));
+        MWCHECK(hipMemset(pc, 0, (size_t)(2 * J + 3) * sizeof(int)));
         q.pcnt = pc;
+    }
+    {   // matrices of the blocked path (k_mw_bp_*)
+        for (int j = 0; j < J; j++) {
+            const MwClu &cl = c->clu[j];
+            if (cl.lds) { c->any_lds_cluster = true; continue; }
+            c->bp_S.push_back(MwBp{q.S + cl.Soff, q.Si + cl.Soff, q.srd + cl.coff, q.Slen, q.xlen, cl.P, cl.P, j + 1, 0, (int)c->bp_S.size(), 0});
+        }
+        if (N > 0) c->bp_Q.push_back(MwBp{q.Q, q.Qi, q.qrd, (i64)N * N, (i64)N, N, N, J + 1, 0, (int)c->bp_S.size(), 0});
+        std::vector<MwBp> all = c->bp_S;
+        all.insert(all.end(), c->bp_Q.begin(), c->bp_Q.end());
+        MW_TRY(mw_upload(c, all, &c->d_bp));
     }
     const int MW_PB = MW_PB_OF(K);
     c->sm_bp_diag = ((size_t)MW_POTRF_SCR(K, MW_PB) + (size_t)K * MW_PB * MW_PB + (size_t)K * MW_TRI(MW_PB) + (size_t)K * MW_PB) * 8;
     c->sm_bp_panel = (size_t)K * MW_BP_PR * MW_PB * 8;
     c->sm_bp_inv = (size_t)K * MW_PB * MW_BP_IC * 8;
-    MW_DISPATCH(c, { MW_TRY(mw_set_lds(k_mw_bp_diag<KK>, c->sm_bp_diag)); MW_TRY(mw_set_lds(k_mw_bp_panel<KK>, c->sm_bp_panel)); MW_TRY(mw_set_lds(k_mw_bp_inv<KK>, c->sm_bp_inv)); });
+    MW_DISPATCH(c, { MW_TRY(mw_set_lds(k_mw_bp_diag<KK>, std::max(c->sm_bp_diag, c->sm_factor))); MW_TRY(mw_set_lds(k_mw_bp_panel<KK>, c->sm_bp_panel)); MW_TRY(mw_set_lds(k_mw_bp_inv<KK>, c->sm_bp_inv)); });
     q.rank = 0; q.world = 1; q.gathered = 0;
     MW_TRY(mw_dmalloc(c, &q.Qg, (i64)N * N * K)); MW_TRY(mw_dmalloc(c, &q.ug, (i64)N * K));
     for (auto &e : c->ev) MWCHECK(hipEventCreate(&e));
@@ -895,23 +909,28 @@ extern "C" int clrs_mw_comm_init_local(clrs_mw_ctx *c, clrs_mw_local_group *g, i
     return 0;
 }
 
-// blocked Cholesky and inverse factor of one matrix in global memory over many workgroups (clrs_mw_kernels.hip.h, k_mw_bp_*)
-static int mw_potrf_blocked(clrs_mw_ctx *c, const MwBp &m) {
+// blocked Cholesky and inverse factor of matrices in global memory over many workgroups (clrs_mw_kernels.hip.h, k_mw_bp_*): all matrices of the
+// list side by side in every launch (their block columns are chains of five launches each: the clusters of Nsphere_packing with N = 3 wait
+// for nothing but their own).  ride_factor: the first launch also carries the clusters that fit in LDS (k_mw_factor's work).
+static int mw_potrf_blocked(clrs_mw_ctx *c, const std::vector<MwBp> &hm, const MwBp *d_ms, bool ride_factor) {
     const MwDev &q = c->d;
-    const int MW_PB = MW_PB_OF(c->K);
-    const int nbk = (m.n + MW_PB - 1) / MW_PB;
+    const int MW_PB = MW_PB_OF(c->K), nm = (int)hm.size();
+    int nmax = 0;
+    for (auto &m : hm) nmax = std::max(nmax, m.n);
+    const int nbk = (nmax + MW_PB - 1) / MW_PB;
     MW_DISPATCH(c, {
-        for (int j0 = 0; j0 < m.n; j0 += MW_PB) {
-            const int nb = std::min(MW_PB, m.n - j0), mm = m.n - j0 - nb;
-            hipLaunchKernelGGL(k_mw_bp_diag<KK>, dim3(MW_INV_WG), dim3(MW_PT), c->sm_bp_diag, c->stream, q, m, j0);
+        for (int j0 = 0; j0 < nmax; j0 += MW_PB) {
+            const int nb = std::min(MW_PB, nmax - j0), mm = nmax - j0 - nb;
+            const bool ride = ride_factor && j0 == 0;
+            hipLaunchKernelGGL(k_mw_bp_diag<KK>, dim3(MW_INV_WG, nm + (ride ? q.J : 0)), dim3(MW_PT), ride ? std::max(c->sm_bp_diag, c->sm_factor) : c->sm_bp_diag, c->stream, q, d_ms, nm, j0);
             if (mm > 0) {
-                hipLaunchKernelGGL(k_mw_bp_panel<KK>, dim3((mm + MW_BP_PR - 1) / MW_BP_PR), dim3(MW_PT), c->sm_bp_panel, c->stream, q, m, j0);
-                hipLaunchKernelGGL(k_mw_bp_syrk<KK>, dim3((unsigned)(((i64)mm * (mm + 1) / 2 * MW_BP_SW + MW_NT - 1) / MW_NT)), dim3(MW_NT), 0, c->stream, q, m, j0);
+                hipLaunchKernelGGL(k_mw_bp_panel<KK>, dim3((mm + MW_BP_PR - 1) / MW_BP_PR, nm), dim3(MW_PT), c->sm_bp_panel, c->stream, q, d_ms, j0);
+                hipLaunchKernelGGL(k_mw_bp_syrk<KK>, dim3((unsigned)(((i64)mm * (mm + 1) / 2 * MW_BP_SW + MW_NT - 1) / MW_NT), nm), dim3(MW_NT), 0, c->stream, q, d_ms, j0);
             }
         }
         for (int d = 1; d < nbk; d++)
-            hipLaunchKernelGGL(k_mw_bp_inv<KK>, dim3(nbk - d, MW_PB / MW_BP_IC), dim3(MW_PT), c->sm_bp_inv, c->stream, q, m, d);
-        hipLaunchKernelGGL(k_mw_bp_finish<KK>, dim3((unsigned)std::min<i64>(1024, ((i64)m.n * m.n + MW_NT - 1) / MW_NT)), dim3(MW_NT), 0, c->stream, q, m);
+            hipLaunchKernelGGL(k_mw_bp_inv<KK>, dim3(nbk - d, MW_PB / MW_BP_IC, nm), dim3(MW_PT), c->sm_bp_inv, c->stream, q, d_ms, d);
+        hipLaunchKernelGGL(k_mw_bp_finish<KK>, dim3((unsigned)std::min<i64>(1024, ((i64)nmax * nmax + MW_NT - 1) / MW_NT), nm), dim3(MW_NT), 0, c->stream, q, d_ms);
     });
     MWCHECK(hipGetLastError());
     return 0;
@@ -926,13 +945,11 @@ extern "C" int clrs_mw_schur_factor_local_dev(clrs_mw_ctx *c) {
     int rc;
     if ((rc = mw_reset_info(c, 0))) return rc;
     if (c->timing) MWCHECK(hipEventRecord(c->ev[2], c->stream));
-    MW_DISPATCH(c, { hipLaunchKernelGGL(k_mw_factor<KK>, dim3(q.J, c->nw_factor), dim3(MW_PT), c->sm_factor, c->stream, q); });
-    for (int j = 0; j < q.J; j++) {                     // clusters that do not fit in LDS: blocked over many workgroups
-        const MwClu &cl = c->clu[j];
-        if (cl.lds) continue;
-        MwBp m = {q.S + cl.Soff, q.Si + cl.Soff, q.srd + cl.coff, q.Slen, q.xlen, cl.P, cl.P, j + 1, 0};
-        if ((rc = mw_potrf_blocked(c, m))) return rc;
-    }
+    // clusters that do not fit in LDS: blocked over many workgroups, all of them side by side; the others ride on the first of those launches
+    // when they take the same number of workgroups per matrix, else they have their launch (k_mw_factor)
+    const bool ride = !c->bp_S.empty() && c->nw_factor == MW_INV_WG && c->any_lds_cluster;
+    if (!ride && c->any_lds_cluster) MW_DISPATCH(c, { hipLaunchKernelGGL(k_mw_factor<KK>, dim3(q.J, c->nw_factor), dim3(MW_PT), c->sm_factor, c->stream, q); });
+    if (!c->bp_S.empty() && (rc = mw_potrf_blocked(c, c->bp_S, c->d_bp, ride))) return rc;
     MW_DISPATCH(c, {
         if (q.N > 0)
             hipLaunchKernelGGL((k_mw_linvb<KK, DD>), dim3((c->maxP * q.N + MW_NT / MW_LBI_W - 1) / (MW_NT / MW_LBI_W), q.J), dim3(MW_NT), 0, c->stream, q);
@@ -956,8 +973,7 @@ extern "C" int clrs_mw_schur_factor_finish_dev(clrs_mw_ctx *c) {
         MW_DISPATCH(c, { hipLaunchKernelGGL(k_mw_potrf_q<KK>, dim3(MW_INV_WG), dim3(MW_PT), c->sm_q, c->stream, q); });
     } else if (q.N > 0) {
         MW_DISPATCH(c, { hipLaunchKernelGGL(k_mw_qsum<KK>, dim3((unsigned)std::min<i64>(256, ((i64)q.N * q.N + MW_NT - 1) / MW_NT)), dim3(MW_NT), 0, c->stream, q); });
-        MwBp m = {q.Q, q.Qi, q.qrd, (i64)q.N * q.N, (i64)q.N, q.N, q.N, q.J + 1, 0};
-        int rc = mw_potrf_blocked(c, m);
+        int rc = mw_potrf_blocked(c, c->bp_Q, c->d_bp + c->bp_S.size(), false);
         if (rc) return rc;
     }
     MWCHECK(hipGetLastError());

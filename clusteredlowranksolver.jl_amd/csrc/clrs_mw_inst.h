@@ -11,11 +11,11 @@
     X __global__ void k_mw_qgram<K>(const MwDev);                                                                      \
     X __global__ void k_mw_potrf_q<K>(const MwDev);                                                                    \
     X __global__ void k_mw_qsum<K>(const MwDev);                                                                       \
-    X __global__ void k_mw_bp_diag<K>(const MwDev, const MwBp, int);                                                   \
-    X __global__ void k_mw_bp_panel<K>(const MwDev, const MwBp, int);                                                  \
-    X __global__ void k_mw_bp_syrk<K>(const MwDev, const MwBp, int);                                                   \
-    X __global__ void k_mw_bp_inv<K>(const MwDev, const MwBp, int);                                                    \
-    X __global__ void k_mw_bp_finish<K>(const MwDev, const MwBp);                                                      \
+    X __global__ void k_mw_bp_diag<K>(const MwDev, const MwBp *, int, int);                                             \
+    X __global__ void k_mw_bp_panel<K>(const MwDev, const MwBp *, int);                                                \
+    X __global__ void k_mw_bp_syrk<K>(const MwDev, const MwBp *, int);                                                 \
+    X __global__ void k_mw_bp_inv<K>(const MwDev, const MwBp *, int);                                                  \
+    X __global__ void k_mw_bp_finish<K>(const MwDev, const MwBp *);                                                    \
     X __global__ void k_mw_usum<K>(const MwDev);                                                                       \
     X __global__ void k_mw_solve_fwd<K>(const MwDev, const double *);                                                  \
     X __global__ void k_mw_solve_mid<K>(const MwDev, const double *, double *);                                        \

@@ -78,7 +78,7 @@ struct MwDev {
     double *Xi;                         // chol(X_b)^-1 of the blocks with inv = 1 (xy layout)
     double *t, *u, *AY;                 // t = L^-1 rhs_x (xlen); u slabs (J x N); pairings per term
     int *info;                          // [0] factor status, [1] Cholesky-of-X status
-    int *pcnt;                          // [J + 2] arrival counters of the workgroups that share one factorisation (cluster j; J: Q; J + 1: blocked path)
+    int *pcnt;                          // [2 J + 3] arrival counters of the workgroups that share one factorisation (cluster j; J: Q; J + 1 + slot: matrices of the blocked path)
     // cluster sharding over ranks (one process per GPU): this context holds the clusters of rank `rank`; the partial Q and the
     // partial u of every rank are gathered into world slots and summed in rank order by every rank (src/solver.jl:1268-1269, 1550-1553)
     int rank, world, gathered, pad3;    // gathered: u comes from the gather slots (world > 1, or a communicator is attached)
@@ -822,10 +822,10 @@ __global__ __launch_bounds__(MW_NT) void k_mw_saccum(const MwDev q, int lanes) {
 // for the solve stage.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int K, class PM, class PW>
-__device__ __forceinline__ bool mw_factor_body(const MwDev &q, const MwClu &c, int j, PM M, long mplane, PW W, mwk::lds_d *bc, int tid) {
+__device__ __forceinline__ bool mw_factor_body(const MwDev &q, const MwClu &c, int j, PM M, long mplane, PW W, mwk::lds_d *bc, int tid, int cw, int cnw) {
     using namespace mwk;
     const int P = c.P;
-    const int cw = blockIdx.y, cnw = gridDim.y;         // the workgroups of a cluster share out the columns of L_j^-1
+    // (cw of cnw: the workgroups of a cluster share out the columns of L_j^-1)
     const bool ok = wg_potrf<K, true, MW_PT>(M, mplane, P, P, q.srd + c.coff, q.xlen, W, MW_TRI(P), 0, bc, tid, cw, cnw);     // W packed
     if (!ok && tid == 0) atomicMin(&q.info[0], j + 1);
     if (ok) {
@@ -847,9 +847,9 @@ __device__ __forceinline__ bool mw_factor_body(const MwDev &q, const MwClu &c, i
     return true;
 }
 template <int K>
-__global__ __launch_bounds__(MW_PT) void k_mw_factor(const MwDev q) {
+__device__ __forceinline__ void mw_factor_cluster(const MwDev &q, int j, int cw, int cnw) {
     using namespace mwk;
-    const int j = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     const MwClu &c = q.clu[j];
     const int P = c.P;
     lds_d *bc = MW_LDS;
@@ -857,10 +857,12 @@ __global__ __launch_bounds__(MW_PT) void k_mw_factor(const MwDev q) {
         lds_d *M = MW_LDS + MW_POTRF_SCR(K, P);
         wg_copy<K, MW_PT>(M, (long)P * P, P, q.S + c.Soff, q.Slen, P, P, P, tid);
         __syncthreads();
-        mw_factor_body<K>(q, c, j, M, (long)P * P, M + (long)K * P * P, bc, tid);
+        mw_factor_body<K>(q, c, j, M, (long)P * P, M + (long)K * P * P, bc, tid, cw, cnw);
     }
     // clusters too large for LDS are factored by the blocked, multi-workgroup path (k_mw_bp_*, driven by the host)
 }
+template <int K>
+__global__ __launch_bounds__(MW_PT) void k_mw_factor(const MwDev q) { mw_factor_cluster<K>(q, blockIdx.x, blockIdx.y, gridDim.y); }
 
 // LinvB_j = L_j^-1 B_j (src/solver.jl:1256-1261) = Si_j B_j: a product with the explicit inverse, four lanes per entry
 #define MW_LBI_W 4
@@ -980,11 +982,17 @@ struct MwBp {                // one matrix being factored: planar M and its inve
     double *M, *Mi, *rd;
     mwi64 plane, rdplane;
     int n, ld, code, which;            // info[which] = code on failure
+    int slot, pad;                     // arrival counter pcnt[J + 1 + slot] of the workgroups that share a diagonal block
 };
 template <int K>
-__global__ __launch_bounds__(MW_PT) void k_mw_bp_diag(const MwDev q, const MwBp m, int j0) {
+__global__ __launch_bounds__(MW_PT) void k_mw_bp_diag(const MwDev q, const MwBp *__restrict__ ms, int nm, int j0) {
     using namespace mwk;
     constexpr int MW_PB = MW_PB_OF(K);
+    // rows of the grid beyond the nm matrices of this launch (the first launch of the factorisation of the S_j adds them): the clusters that fit
+    // in LDS, factored beside the first diagonal block of the large ones instead of in a launch of their own in front of it
+    if ((int)blockIdx.y >= nm) { mw_factor_cluster<K>(q, blockIdx.y - nm, blockIdx.x, gridDim.x); return; }
+    const MwBp m = ms[blockIdx.y];
+    if (j0 >= m.n) return;
     const int nb = min(MW_PB, m.n - j0), tid = threadIdx.x;
     lds_d *scr = MW_LDS, *D = MW_LDS + MW_POTRF_SCR(K, MW_PB), *W = D + (long)K * MW_PB * MW_PB, *rdl = W + (long)K * MW_TRI(MW_PB);
     const int cw = blockIdx.x, cnw = gridDim.x;         // the workgroups share out the columns of the inverse of the diagonal block
@@ -1004,7 +1012,7 @@ __global__ __launch_bounds__(MW_PT) void k_mw_bp_diag(const MwDev q, const MwBp 
         }
     }
     // the factor overwrites its input: by the workgroup that finishes last, when all have read it
-    if (!wg_last_block(&q.pcnt[q.J + 1], cnw) || !ok) return;
+    if (!wg_last_block(&q.pcnt[q.J + 1 + m.slot], cnw) || !ok) return;
     for (int e = tid; e < nb * nb; e += MW_PT) {
         const int i = e % nb, c = e / nb;
         stx<K>(m.M, m.plane, (j0 + i) + (long)(j0 + c) * m.ld, i >= c ? ldx<K>(D, (long)nb * nb, e) : zero<K>());
@@ -1013,10 +1021,11 @@ __global__ __launch_bounds__(MW_PT) void k_mw_bp_diag(const MwDev q, const MwBp 
 }
 // rows below the diagonal block: L[r, c] = sum_{k <= c} A[r, k] M_d[c, k]
 template <int K>
-__global__ __launch_bounds__(MW_PT) void k_mw_bp_panel(const MwDev q, const MwBp m, int j0) {
+__global__ __launch_bounds__(MW_PT) void k_mw_bp_panel(const MwDev q, const MwBp *__restrict__ ms, int j0) {
     using namespace mwk;
     constexpr int MW_PB = MW_PB_OF(K);
-    if (q.info[m.which] != MW_INFO_NONE) return;
+    const MwBp m = ms[blockIdx.y];
+    if (j0 >= m.n || q.info[m.which] != MW_INFO_NONE) return;
     const int nb = min(MW_PB, m.n - j0), tid = threadIdx.x;
     const int r0 = j0 + nb + blockIdx.x * MW_BP_PR;
     if (r0 >= m.n) return;
@@ -1043,10 +1052,11 @@ __global__ __launch_bounds__(MW_PT) void k_mw_bp_panel(const MwDev q, const MwBp
 }
 // trailing update: A[i, j] -= sum_c L[i, j0 + c] L[j, j0 + c], i >= j >= j0 + nb
 template <int K>
-__global__ __launch_bounds__(MW_NT) void k_mw_bp_syrk(const MwDev q, const MwBp m, int j0) {
+__global__ __launch_bounds__(MW_NT) void k_mw_bp_syrk(const MwDev q, const MwBp *__restrict__ ms, int j0) {
     using namespace mwk;
     constexpr int MW_PB = MW_PB_OF(K);
-    if (q.info[m.which] != MW_INFO_NONE) return;
+    const MwBp m = ms[blockIdx.y];
+    if (j0 >= m.n || q.info[m.which] != MW_INFO_NONE) return;
     const int nb = min(MW_PB, m.n - j0), t0 = j0 + nb, mm = m.n - t0;
     const long tot = (long)mm * (mm + 1) / 2;
     if ((long)blockIdx.x * (MW_NT / MW_BP_SW) >= tot) return;      // uniform over the workgroup
@@ -1066,11 +1076,13 @@ __global__ __launch_bounds__(MW_NT) void k_mw_bp_syrk(const MwDev q, const MwBp 
 // blocks (j, i) of L^-1 with j - i = d: T = sum_{i <= k < j} L_jk (L^-1)_ki (the block columns between are contiguous: one
 // sum over the rows i MW_PB .. j MW_PB - 1), then (L^-1)_ji = -(L^-1)_jj T
 template <int K>
-__global__ __launch_bounds__(MW_PT) void k_mw_bp_inv(const MwDev q, const MwBp m, int d) {
+__global__ __launch_bounds__(MW_PT) void k_mw_bp_inv(const MwDev q, const MwBp *__restrict__ ms, int d) {
     using namespace mwk;
     constexpr int MW_PB = MW_PB_OF(K);
+    const MwBp m = ms[blockIdx.z];
     if (q.info[m.which] != MW_INFO_NONE) return;
     const int bi = blockIdx.x, bj = bi + d, tid = threadIdx.x;
+    if (bj * MW_PB >= m.n) return;                          // (a matrix with fewer block columns than the largest of the launch)
     const int ci0 = bi * MW_PB, ni = min(MW_PB, m.n - ci0), rj0 = bj * MW_PB, nj = min(MW_PB, m.n - rj0);
     const int c0 = blockIdx.y * MW_BP_IC;
     if (c0 >= ni) return;
@@ -1100,9 +1112,10 @@ __global__ __launch_bounds__(MW_PT) void k_mw_bp_inv(const MwDev q, const MwBp m
 }
 // zero strict upper triangle of L (the blocks above the diagonal still hold the symmetric input)
 template <int K>
-__global__ __launch_bounds__(MW_NT) void k_mw_bp_finish(const MwDev q, const MwBp m) {
+__global__ __launch_bounds__(MW_NT) void k_mw_bp_finish(const MwDev q, const MwBp *__restrict__ ms) {
     using namespace mwk;
     constexpr int MW_PB = MW_PB_OF(K);
+    const MwBp m = ms[blockIdx.y];
     if (q.info[m.which] != MW_INFO_NONE) return;
     const long nn = (long)m.n * m.n;
     for (long e = (long)blockIdx.x * MW_NT + threadIdx.x; e < nn; e += (long)gridDim.x * MW_NT) {
