@@ -145,6 +145,9 @@ struct clrs_mw_ctx {
     void *comm_side = nullptr;           // a second communicator for the exchanges of the iteration's side stream (clrs_mw_comm_init_side)
     clrs_mw_local_group *lgroup = nullptr;   // or: the in-process group (clrs_mw_comm_init_local)
     bool local_factored = false, fwd_done = false;
+    MwdDev mwd = {};                     // static digits of the dense matrices of the blocks k_mwx_dense takes
+    int mwd_blocks = 0, mwd_tasks = 0;
+    size_t sm_mwd = 0;
     MwxDev mwx = {};                     // digits of V (static), Z, T of the blocks whose pairing matrices go through k_mwx_slice / k_mwx_gram
     int mwx_blocks = 0, mwx_maxU16 = 0;
     MwsDev mws = {};                     // static V slices of the blocks the exact-product kernel takes
@@ -551,10 +554,70 @@ extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int dev
     } else {
         MW_TRY(mw_upload(c, mwx_off, &c->mwx.d_off));
     }
+    // ---- dense blocks with 16 < n <= 32 and inverse factors: X^-1 (A_e Y) through exact slice products (k_mwx_dense), static digits of the A_e ----
+    std::vector<long long> mwd_off((size_t)std::max(NB, 1), -1);
+    if (g_cfg_mw_exact_products != 0 && K <= 6) {
+        const int S = mws_slices(K), S1 = (S + 1) / 2, sN = 32 * 32;
+        std::vector<float> hAd;
+        std::vector<int> heA, he_off((size_t)std::max(NB, 1), 0);
+        for (int b = 0; b < NB; b++) {
+            const MwBlk &k = c->blk[b];
+            if (k.kind == 0 || !k.inv || k.n <= 16 || k.n > 32 || k.cnt <= 0) continue;
+            const int n = k.n;
+            const size_t base = hAd.size(), ebase = heA.size();
+            hAd.resize(base + (size_t)k.cnt * S1 * sN, 0.0f);
+            heA.resize(ebase + (size_t)k.cnt * 32, 0);
+            bool fits = true;
+            for (int e = 0; e < k.cnt && fits; e++) {
+                float *dst = hAd.data() + base + (size_t)e * S1 * sN;
+                const i64 a0 = k.a_off + (i64)e * n * n;
+                for (int col = 0; col < n; col++) {
+                    double mx = 0;
+                    for (int kk = 0; kk < n; kk++) mx = std::max(mx, std::fabs(hdAl[0][a0 + kk + (i64)col * n]));
+                    const int ex = mwk::mws_exponent(mx);
+                    heA[ebase + (size_t)e * 32 + col] = ex;
+                    for (int kk = 0; kk < n; kk++) {
+                        double r0 = std::ldexp(hdAl[0][a0 + kk + (i64)col * n], -ex), r1 = DK > 1 ? std::ldexp(hdAl[1][a0 + kk + (i64)col * n], -ex) : 0.0;
+                        for (int s2 = 0; s2 < S; s2++) {
+                            const double g = std::ldexp(1.0, -(s2 + 1) * MWS_BETA), C = 0x1.8p52 * g;
+                            volatile double tv = r0 + C;
+                            const double t = tv - C;
+                            const float dgt = (float)(t * std::ldexp(1.0, (s2 + 1) * MWS_BETA));
+                            if (s2 < S1) dst[(size_t)s2 * sN + (size_t)kk * 32 + mws_col(kk, col, 32)] = dgt;
+                            else if (dgt != 0.0f) fits = false;      // data beyond the slices kept: leave the block to the expansion kernels
+                            r0 -= t;
+                            double sm, er;
+                            mwa::two_sum(r0, r1, sm, er);
+                            r0 = sm; r1 = er;
+                        }
+                    }
+                }
+            }
+            if (!fits) { hAd.resize(base); heA.resize(ebase); continue; }
+            mwd_off[b] = (long long)base;
+            he_off[b] = (int)ebase;
+            c->mwd_blocks++;
+        }
+        if (c->mwd_blocks > 0) {
+            std::vector<int> tasks;
+            for (size_t di = 0; di < dn_list.size(); di++) {
+                const int b = dn_list[di];
+                if (mwd_off[b] < 0) continue;
+                for (int e = 0; e < c->blk[b].cnt; e++) { tasks.push_back((int)di); tasks.push_back(e); }
+            }
+            c->mwd_tasks = (int)tasks.size() / 2;
+            MW_TRY(mw_upload(c, tasks, &c->mwd.tasks));
+            MW_TRY(mw_upload(c, hAd, &c->mwd.Ad)); MW_TRY(mw_upload(c, heA, &c->mwd.eA)); MW_TRY(mw_upload(c, he_off, &c->mwd.e_off));
+            c->sm_mwd = (size_t)2 * S * sN * sizeof(float) + 128 * sizeof(int);
+            MW_DISPATCH(c, { MW_TRY(mw_set_lds((k_mwx_dense<KK, DD>), c->sm_mwd)); });
+        }
+    }
+    MW_TRY(mw_upload(c, mwd_off, &c->mwd.a_off));
     // ---- upload ----
     MwDev &q = c->d;
     q.mws_off = c->mws.vs_off; q.mws_on = c->mws_blocks > 0 ? 1 : 0;
     q.mwx_off = c->mwx.d_off; q.mwx_on = c->mwx_blocks > 0 ? 1 : 0;
+    q.mwd_off = c->mwd.a_off; q.mwd_on = 0;            // (switched on per assembly: the kernel needs the inverse factors of this context's chol X)
     q.J = J; q.N = N; q.NB = NB; q.nlr = (int)lr_list.size(); q.ndn = (int)dn_list.size();
     q.xylen = xyoff; q.xlen = xlen; q.Slen = Slen; q.T = T; q.xrdlen = rdoff;
     q.zlen = std::max<i64>(zoff, 1); q.glen = std::max<i64>(goff, 1); q.wlen = std::max<i64>(woff, 1); q.sdlen = std::max<i64>(sdoff, 1);
@@ -760,10 +823,15 @@ extern "C" int clrs_mw_schur_assemble_dev(clrs_mw_ctx *c, const double *d_Xchol,
         }
         if (q.ndn && !dense_done) {
             const bool panels = c->xinv_valid && c->maxn_dense > 16 && c->maxn_dense <= MW_NT;      // dense blocks of side > 16 with inverse factors: column panels (k_mw_dense_tp)
-            hipLaunchKernelGGL((k_mw_dense_t<KK, DD>), dim3(q.ndn, q.dn_big ? c->maxcnt : 1), dim3(MW_NT), c->sm_dense, c->stream, q, d_Y, c->xinv_valid ? 1 : 0, c->dense_two ? 1 : 0, panels ? 1 : 0);
+            MwDev q3 = q;
+            q3.mwd_on = (panels && c->mwd_blocks > 0) ? 1 : 0;     // ... or exact slice products for sides up to 32 (k_mwx_dense)
+            hipLaunchKernelGGL((k_mw_dense_t<KK, DD>), dim3(q.ndn, q.dn_big ? c->maxcnt : 1), dim3(MW_NT), c->sm_dense, c->stream, q3, d_Y, c->xinv_valid ? 1 : 0, c->dense_two ? 1 : 0, panels ? 1 : 0);
             if (panels) {
                 const int pcmin = std::max(1, MW_NT / c->maxn_dense);
-                hipLaunchKernelGGL((k_mw_dense_tp<KK, DD>), dim3(q.ndn, c->maxcnt, (c->maxn_dense + pcmin - 1) / pcmin), dim3(MW_NT), (size_t)2 * KK * MW_NT * 8, c->stream, q, d_Y);
+                if (c->mwd_blocks < q.ndn)
+                    hipLaunchKernelGGL((k_mw_dense_tp<KK, DD>), dim3(q.ndn, c->maxcnt, (c->maxn_dense + pcmin - 1) / pcmin), dim3(MW_NT), (size_t)2 * KK * MW_NT * 8, c->stream, q3, d_Y);
+                c->mwd.stamps = c->mws.stamps;
+                if (q3.mwd_on) hipLaunchKernelGGL((k_mwx_dense<KK, DD>), dim3(c->mwd_tasks), dim3(MWS_NT), c->sm_mwd, c->stream, q3, c->mwd, d_Y);
             }
             const int pairs = c->maxcnt * (c->maxcnt + 1) / 2;
             const int ds_lanes = c->maxn_dense * c->maxn_dense <= 128 ? 8 : c->maxn_dense * c->maxn_dense <= 512 ? 16 : 64;      // per pair of the table

@@ -448,4 +448,152 @@ __global__ __launch_bounds__(MWS_NT, 2) void k_mwx_gram(const MwDev q, const Mwx
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// T_e = X^-1 (A_e Y) = Xi^T (Xi (A_e Y)) of the dense blocks with 16 < n <= 32 (SDPA x64: 512 matrices of 32 x 32) through the same exact slice
+// products: three chained 32 x 32 x 32 products per matrix, 2 x 2 output tiles = the four waves of one workgroup, every operand as digits in LDS
+// ([slice][k][32 columns], tile-exchange layout).  Two regions of S 32 x 32 digit arrays: X holds the left operand of the product at hand (the
+// static digits of A_e, then Xi^T by its rows' exponents, then Xi by its columns'), R the right one (Y by columns, then the K-limb result of the
+// previous product cut again by columns).  The expansion form of the same (k_mw_dense_tp) runs at twice the fp64 pipe's bound; this one does a
+// fifth of its work.  Limb counts up to 6 (the two regions need 2 S 4 KB of LDS).
+// ---------------------------------------------------------------------------------------------------------------------------------------
+struct MwdDev {
+    const float *Ad;         // static digits of the dense matrices: [S1][32][32] per matrix (S1 = (S + 1) / 2 slices: 106-bit data), matrix e of block b at a_off[b] + e S1 1024
+    const int *eA;           // column exponents, [32] per matrix at e_off[b] + 32 e
+    const long long *a_off;  // [NB], -1: not taken
+    const int *e_off;        // [NB]
+    const int *tasks;        // [2 ntasks]: (index into dn_list, matrix) of every matrix of every block taken -- a dense list: with one workgroup per compute unit
+                             // (98 KB of LDS) a grid over (block, most matrices of a block) ran four rounds of workgroups, the last two mostly empty
+    unsigned long long *stamps;   // diagnostic (clrs_mw_debug_exact_stamps): wall_clock64 at the phase boundaries of wave 0 of the first workgroup, or null
+};
+template <int K, int DK>
+__global__ __launch_bounds__(MWS_NT) void k_mwx_dense(const MwDev q, const MwdDev w, const double *__restrict__ Y) {
+    using namespace mwk;
+    constexpr int S = mws_slices(K), S1 = (S + 1) / 2, sN = 32 * 32;
+    const int b = q.dn_list[w.tasks[2 * blockIdx.x]], e = w.tasks[2 * blockIdx.x + 1];
+    const MwBlk &k = q.blk[b];
+    const int n = k.n, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
+    const int np = (n + 3) & ~3, ksteps = np / 4;
+    extern __shared__ __attribute__((aligned(16))) float mwd_lds[];
+    lds_f *RX = (lds_f *)mwd_lds, *RR = RX + (size_t)S * sN;
+    int *eL = (int *)(RR + (size_t)S * sN), *eR = eL + 32, *part = eR + 32;      // part: [2][32] column maxima per row tile
+    const double *Yg = Y + k.xyoff, *Xig = q.Xi + k.xyoff;
+    const long nn = (long)n * n;
+    const bool stamp = w.stamps && blockIdx.x == 0 && tid == 0;
+    int nst = 0;
+#define MWD_STAMP() do { if (stamp) w.stamps[nst++] = wall_clock64(); } while (0)
+    MWD_STAMP();
+    // ---- operands of product 1: A_e (static digits, by columns; A_e is symmetric) and Y by columns ----
+    {
+        typedef float v4f_mw __attribute__((ext_vector_type(4)));
+        const v4f_mw *ga = (const v4f_mw *)(w.Ad + w.a_off[b] + (long)e * S1 * sN);
+        v4f_mw __attribute__((address_space(3))) *lx = (v4f_mw __attribute__((address_space(3))) *)RX;
+        for (int o = tid; o < S1 * sN / 4; o += MWS_NT) lx[o] = ga[o];
+        if (n != 32) for (int o = tid; o < S * sN; o += MWS_NT) RR[o] = 0.0f;      // padding rows / columns are zero digits
+        if (tid < 32) { eL[tid] = w.eA[w.e_off[b] + 32 * e + tid]; eR[tid] = 0; }
+    }
+    __syncthreads();
+    for (int o = tid; o < n * n; o += MWS_NT) {
+        const double h = Yg[o];
+        if (h != 0.0) atomicMax(&eR[o / n], mws_exponent(h) + 4096);
+    }
+    __syncthreads();
+    if (tid < 32) eR[tid] = eR[tid] == 0 ? 0 : eR[tid] - 4096;
+    __syncthreads();
+    for (int o = tid; o < n * n; o += MWS_NT) {
+        const int kk = o % n, c = o / n;                  // entry (row kk, column c): operand [k = kk][col = c]
+        lds_f *dst = RR + kk * 32 + mws_col(kk, c, 32);
+        mws_slice<K, S>(ldx<K>(Yg, q.xylen, kk + (long)c * n), eR[c], [&](int sl, float d) { dst[sl * sN] = d; });
+    }
+    __syncthreads();
+    const int ti = wave & 1, tj = wave >> 1;              // output tile: rows 16 ti .., columns 16 tj ..
+    v4d_mw acc[S];
+    mw<K> res[4];
+    // the result of a product as the right operand of the next one: column maxima over both row tiles, then digits by columns into RR
+    auto publish = [&](const int *ex) {
+        int cmax = -100000;
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const int i = ti * 16 + 4 * reg + l4, c = tj * 16 + l15;
+            res[reg] = mws_recombine<K, S>(acc, reg, ex[i] + eR[c]);
+            if (i < n && c < n && res[reg].l[0] != 0.0) cmax = max(cmax, mws_exponent(res[reg].l[0]));
+        }
+        cmax = max(cmax, __shfl_xor(cmax, 16, 64));
+        cmax = max(cmax, __shfl_xor(cmax, 32, 64));
+        if (l4 == 0) part[ti * 32 + tj * 16 + l15] = cmax;
+        __syncthreads();                                   // every wave is done with both regions; the partial maxima are written
+        if (tid < 32) { const int m2 = max(part[tid], part[32 + tid]); eR[tid] = m2 == -100000 ? 0 : m2; }
+        __syncthreads();
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const int i = ti * 16 + 4 * reg + l4, c = tj * 16 + l15;
+            if (i >= n || c >= n) continue;
+            lds_f *dst = RR + i * 32 + mws_col(i, c, 32);
+            mws_slice<K, S>(res[reg], eR[c], [&](int sl, float d) { dst[sl * sN] = d; });
+        }
+    };
+    // digits of Xi into RX as the left operand [k][col = i]: transposed = 1: element Xi[i, k] (product Xi M), exponents by rows of Xi;
+    // transposed = 0: element Xi[k, i] (product Xi^T M), exponents by columns.  Xi is lower triangular.
+    auto load_xi = [&](bool transposed) {
+        if (tid < 32) eL[tid] = 0;
+        if (n != 32) for (int o = tid; o < S * sN; o += MWS_NT) RX[o] = 0.0f;
+        __syncthreads();
+        for (int o = tid; o < n * n; o += MWS_NT) {
+            const int r = o % n, c = o / n;               // Xi[r, c], r >= c
+            if (c > r) continue;
+            const double h = Xig[o];
+            if (h != 0.0) atomicMax(&eL[transposed ? r : c], mws_exponent(h) + 4096);
+        }
+        __syncthreads();
+        if (tid < 32) eL[tid] = eL[tid] == 0 ? 0 : eL[tid] - 4096;
+        __syncthreads();
+        for (int o = tid; o < n * n; o += MWS_NT) {
+            const int r = o % n, c = o / n;
+            const int kk = transposed ? c : r, col = transposed ? r : c;
+            lds_f *dst = RX + kk * 32 + mws_col(kk, col, 32);
+            if (c > r) {
+#pragma unroll
+                for (int sl = 0; sl < S; sl++) dst[sl * sN] = 0.0f;
+                continue;
+            }
+            mws_slice<K, S>(ldx<K>(Xig, q.xylen, o), eL[col], [&](int sl, float d) { dst[sl * sN] = d; });
+        }
+    };
+    MWD_STAMP();
+    // ---- product 1: M1 = A_e Y ----
+    mws_tile<S, S1, S>(acc, RX, sN, 32, mws_tilecol(ti, l4, 32), RR, sN, 32, mws_tilecol(tj, l4, 32), ksteps, l15, l4);
+    MWD_STAMP();
+    publish(eL);
+    MWD_STAMP();
+    load_xi(true);
+    __syncthreads();
+    MWD_STAMP();
+    // ---- product 2: M2 = Xi M1 (k <= i: the first row tile needs the first four k-steps only) ----
+    mws_tile<S, S, S>(acc, RX, sN, 32, mws_tilecol(ti, l4, 32), RR, sN, 32, mws_tilecol(tj, l4, 32), ti == 0 ? min(ksteps, 4) : ksteps, l15, l4);
+    MWD_STAMP();
+    publish(eL);
+    MWD_STAMP();
+    load_xi(false);
+    __syncthreads();
+    MWD_STAMP();
+    // ---- product 3: T_e = Xi^T M2 (k >= i: the second row tile starts at k = 16) ----
+    {
+        const int ks0 = ti == 0 ? 0 : 4;
+        if (ks0 < ksteps) mws_tile<S, S, S>(acc, RX + ks0 * 4 * 32, sN, 32, mws_tilecol(ti, l4, 32), RR + ks0 * 4 * 32, sN, 32, mws_tilecol(tj, l4, 32), ksteps - ks0, l15, l4);
+        else {
+#pragma unroll
+            for (int o = 0; o < S; o++) acc[o] = (v4d_mw){0.0, 0.0, 0.0, 0.0};
+        }
+    }
+    MWD_STAMP();
+    double *W = q.W + k.w_off;
+#pragma unroll
+    for (int reg = 0; reg < 4; reg++) {
+        const int i = ti * 16 + 4 * reg + l4, c = tj * 16 + l15;
+        if (i >= n || c >= n) continue;
+        stx<K>(W, q.wlen, (long)e * nn + i + (long)c * n, mws_recombine<K, S>(acc, reg, eL[i] + eR[c]));
+    }
+    MWD_STAMP();
+#undef MWD_STAMP
+}
+
 #endif

@@ -38,6 +38,7 @@
     X __global__ void k_mws_pair<K, DK, 2>(const MwDev, const MwsDev, const double *);                                                                   \
     X __global__ void k_mw_dense_t<K, DK>(const MwDev, const double *, int, int, int);                                 \
     X __global__ void k_mw_dense_tp<K, DK>(const MwDev, const double *);                                               \
+    X __global__ void k_mwx_dense<K, DK>(const MwDev, const MwdDev, const double *);                                   \
     X __global__ void k_mw_dense_s<K, DK>(const MwDev, int);                                                           \
     X __global__ void k_mw_saccum<K, DK>(const MwDev, int);                                                                 \
     X __global__ void k_mw_linvb<K, DK>(const MwDev);                                                                  \

@@ -86,6 +86,8 @@ struct MwDev {
     // exact-product path of the pairing matrices (clrs_mw_exact.hip.h): blocks with mws_off[b] >= 0 are taken by k_mws_pair when mws_on
     const long long *mws_off;
     int mws_on, mwx_on;
+    const long long *mwd_off;           // dense blocks with mwd_off[b] >= 0: X^-1 (A_e Y) by k_mwx_dense when mwd_on
+    int mwd_on, pad5;
     const long long *mwx_off;           // blocks with mwx_off[b] >= 0: pairing matrices of ANY size from the digits of Z, T, V (k_mwx_slice, k_mwx_gram) when mwx_on
 };
 
@@ -641,7 +643,7 @@ __global__ __launch_bounds__(MW_NT) void k_mw_dense_t(const MwDev q, const doubl
         if (e == 0) mw_dense_1x1<K, DK>(q, k, Y, tid);
         return;
     }
-    if (e >= cnt || (panels && use_inv && k.inv && n > 16)) return;          // the latter: k_mw_dense_tp
+    if (e >= cnt || (panels && use_inv && k.inv && n > 16)) return;          // the latter: k_mw_dense_tp or k_mwx_dense
     lds_d *M = MW_LDS, *M2 = M + (long)K * nn;
     if (use_inv && k.inv && two_buffers) {
         const double *Xi = q.Xi + k.xyoff;
@@ -689,6 +691,7 @@ __global__ __launch_bounds__(MW_NT) void k_mw_dense_tp(const MwDev q, const doub
     const MwBlk &k = q.blk[q.dn_list[blockIdx.x]];
     const int n = k.n, tid = threadIdx.x, e = blockIdx.y;
     if (n <= 16 || !k.inv || e >= k.cnt) return;
+    if (q.mwd_on && q.mwd_off[q.dn_list[blockIdx.x]] >= 0) return;      // k_mwx_dense
     const int pc = max(1, MW_NT / n), c0 = blockIdx.z * pc;
     if (c0 >= n) return;
     const int pw = min(pc, n - c0);

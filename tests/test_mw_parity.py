@@ -763,6 +763,36 @@ def test_exact_product_pairings_of_a_large_block(K, oracle_built):
     assert mw_relerr(res[True], res[False]) <= tol(K, 22)
 
 
+@pytest.mark.parametrize("K", [4, 5, 6])
+def test_exact_products_of_dense_blocks(K, oracle_built):
+    """k_mwx_dense (csrc/clrs_mw_exact.hip.h): T_e = X^-1 (A_e Y) of dense 32 x 32 blocks as three chained exact slice products per matrix (static
+    digits of A_e, digits of Y, Xi^T, Xi and of the intermediate results in LDS) -- S_j against the oracle within the tolerance of the expansion
+    kernels, and against the expansion kernels themselves (sdpa_scaled(8, 32, 40): 8 dense blocks, 40 constraints on random block pairs)."""
+    import torch
+    from clrs_amd.mw import MwSchurContext
+    from oracle.oracle import Oracle
+    f = flat("sdpa_mid")
+    X, Y = _iterates(f, K)
+    X, Y = _sym_limbs(f, X), _sym_limbs(f, Y)
+    o = Oracle(f, mp_bits=320 if K <= 5 else 640)
+    pad = lambda a: np.vstack([a, np.zeros((1, a.shape[1]))])
+    res = {}
+    for exact in (True, False):
+        ctx = MwSchurContext(f, limbs=K, exact_products=exact)
+        dX, dY = torch.tensor(X, device="cuda:0"), torch.tensor(Y, device="cuda:0")
+        dXc = torch.empty_like(dX)
+        ctx.cholesky_blocks_dev(dX.data_ptr(), dXc.data_ptr())
+        ctx.assemble_dev(dXc.data_ptr(), dY.data_ptr())
+        S, _ = ctx.get_S()
+        if exact:
+            S_ref, _ = o.schur_assemble_mw(pad(dXc.cpu().numpy()), pad(Y))
+        assert mw_relerr(S, S_ref) <= tol(K, 22), (exact, np.log2(mw_relerr(S, S_ref)))
+        res[exact] = S
+        ctx.close()
+    assert not np.array_equal(res[True], res[False])        # two different arithmetics (the exact path was taken), one answer
+    assert mw_relerr(res[True], res[False]) <= tol(K, 22)
+
+
 @pytest.mark.parametrize("K", [4, 5])
 def test_exact_product_pairings_on_the_trajectory_fixture(K):
     """The same on real interior-point iterates (tests/golden/ce_8_15_traj.npz, mu from 1e20 to 2e-16, cond(X) up to 2^56): S against the
