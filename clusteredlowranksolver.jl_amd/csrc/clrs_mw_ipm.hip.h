@@ -994,43 +994,55 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_bmm(const MwDev q, const MwIpmDev
     const int e = threadIdx.x / LW, sub = threadIdx.x % LW;
     const int i0 = ti * MWI_BT + e % MWI_BT, c0 = tj * MWI_BT + e / MWI_BT;
     const bool live = i0 < n && c0 < n;
-    const int i = live ? i0 : 0, c = live ? c0 : 0;
-    const double *Xi = q.Xi + k.xyoff;
-    acc<K> s;
-    acc_zero<K>(s);
+    const int wh = blockIdx.z;
     if (op >= 4) {
         // the congruences of the step lengths (compute_step_length, :1647-1659), both matrices in one launch (blockIdx.z: 0 = X, 1 = Y):
         // 4: U = dM Li^T into Zs / Zt;  5: W = Li U, lower triangle, rounded to fp64 into Wd -- the matrix k_mwi_step (inv_path 3) takes the eigenvalue of
-        const int wh = blockIdx.z;
         if (n == 1 || (wh == 1 && p.yfail[blockIdx.y])) return;
         if (op == 5 && tj > ti) return;
-        const double *Li = (wh == 0 ? q.Xi : p.Yi) + k.xyoff, *dMg = (wh == 0 ? p.dX : p.dY) + k.xyoff;
-        double *U = (wh == 0 ? p.Zs : p.Zt) + k.xyoff;
-        if (op == 4) {
-            for (int t = sub; t <= c; t += LW) acc_fma<K, K, K>(s, ldx<K>(dMg, q.xylen, i + (long)t * n), ldx<K>(Li, q.xylen, c + (long)t * n));
-        } else if (i >= c) {
-            for (int r = sub; r <= i; r += LW) acc_fma<K, K, K>(s, ldx<K>(Li, q.xylen, i + (long)r * n), ldx<K>(U, q.xylen, r + (long)c * n));
-        }
-        const mw<K> v = lanes_sum<K, LW>(acc_result<K>(s));
-        if (live && sub == 0) {
-            if (op == 4) stx<K>(U, q.xylen, i + (long)c * n, v);
-            else if (i >= c) p.Wd[(long)wh * q.xylen + k.xyoff + i + (long)c * n] = v.l[0];
-        }
-        return;
     }
+    // The operands of the tile through LDS: eight rows of the left matrix and eight columns of the right one over the tile's range of k
+    // (read straight from memory, every lane fetched its own two K-limb numbers per multiply-add: 164 KB per workgroup, 170 MB per launch
+    // at 64 blocks of 32 x 32 -- the launches ran at the L2's bandwidth, not at the pipe's).  Triangular factors are stored with their zeros,
+    // so the range of k is the tile's, not the entry's.
+    const double *Lp, *Rp;
+    int l_si, l_sk, r_sk, r_sc, k_lo = 0, k_hi = n;
+    const double *Xi = q.Xi + k.xyoff;
+    if (op == 0) { Lp = (which == 0 ? p.Pm : p.dX) + k.xyoff; l_si = 1; l_sk = n; Rp = p.Y + k.xyoff; r_sk = 1; r_sc = n; }
+    else if (op == 1) { Lp = Xi; l_si = 1; l_sk = n; Rp = p.Zt + k.xyoff; r_sk = 1; r_sc = n; k_hi = min(n, ti * MWI_BT + MWI_BT); }
+    else if (op == 2) { Lp = Xi; l_si = n; l_sk = 1; Rp = p.Zs + k.xyoff; r_sk = 1; r_sc = n; k_lo = ti * MWI_BT; }
+    else if (op == 4) { Lp = (wh == 0 ? p.dX : p.dY) + k.xyoff; l_si = 1; l_sk = n; Rp = (wh == 0 ? q.Xi : p.Yi) + k.xyoff; r_sk = n; r_sc = 1; k_hi = min(n, tj * MWI_BT + MWI_BT); }
+    else { Lp = (wh == 0 ? q.Xi : p.Yi) + k.xyoff; l_si = 1; l_sk = n; Rp = (wh == 0 ? p.Zs : p.Zt) + k.xyoff; r_sk = 1; r_sc = n; k_hi = min(n, ti * MWI_BT + MWI_BT); }
+    const int klen = k_hi - k_lo;
+    const long lp = (long)MWI_BT * n;                       // plane of the staged operands (klen <= n)
+    lds_d *Ls = MW_LDS, *Rs = Ls + (long)K * lp;
+    for (int idx = threadIdx.x; idx < MWI_BT * klen; idx += MW_NT) {
+        const int ii = l_si == 1 ? idx % MWI_BT : idx / klen, kk = l_si == 1 ? idx / MWI_BT : idx % klen;     // the contiguous index runs fastest
+        const int gi = ti * MWI_BT + ii;
+        stx<K>(Ls, lp, kk * MWI_BT + ii, gi < n ? ldx<K>(Lp, q.xylen, (long)gi * l_si + (long)(k_lo + kk) * l_sk) : zero<K>());
+    }
+    for (int idx = threadIdx.x; idx < MWI_BT * klen; idx += MW_NT) {
+        const int cc = r_sc == 1 ? idx % MWI_BT : idx / klen, kk = r_sc == 1 ? idx / MWI_BT : idx % klen;
+        const int gc = tj * MWI_BT + cc;
+        stx<K>(Rs, lp, kk * MWI_BT + cc, gc < n ? ldx<K>(Rp, q.xylen, (long)(k_lo + kk) * r_sk + (long)gc * r_sc) : zero<K>());
+    }
+    __syncthreads();
+    const int i = live ? i0 : 0, c = live ? c0 : 0, ii = e % MWI_BT, cc = e / MWI_BT;
+    acc<K> s;
+    acc_zero<K>(s);
+    const double sg = (op == 0 && which != 0) ? -1.0 : 1.0;
+    if (op != 5 || i >= c)
+        for (int kk = sub; kk < klen; kk += LW) acc_fma<K, K, K>(s, ldx<K>(Ls, lp, kk * MWI_BT + ii), ldx<K>(Rs, lp, kk * MWI_BT + cc), sg);
     if (op == 0) {
-        const double *A = (which == 0 ? p.Pm : p.dX) + k.xyoff;
-        const double sg = which == 0 ? 1.0 : -1.0;
-        for (int kk = sub; kk < n; kk += LW) acc_fma<K, K, K>(s, ldx<K>(A, q.xylen, i + (long)kk * n), ldx<K>(p.Y + k.xyoff, q.xylen, kk + (long)c * n), sg);
         if (sub == 0) acc_add<K, K>(s, ldx<K>(p.R + k.xyoff, q.xylen, i + (long)c * n), -sg);
         if (sub == 1 && i == c) acc_add<K, K>(s, ldx<K>(p.sc, MSC_COUNT, MSC_MUS), -sg);      // R = mu_s I + R'
-    } else if (op == 1) {
-        for (int r = sub; r <= i; r += LW) acc_fma<K, K, K>(s, ldx<K>(Xi, q.xylen, i + (long)r * n), ldx<K>(p.Zt + k.xyoff, q.xylen, r + (long)c * n));
-    } else {
-        for (int r = i + sub; r < n; r += LW) acc_fma<K, K, K>(s, ldx<K>(Xi, q.xylen, r + (long)i * n), ldx<K>(p.Zs + k.xyoff, q.xylen, r + (long)c * n));
     }
     const mw<K> v = lanes_sum<K, LW>(acc_result<K>(s));
-    if (live && sub == 0) stx<K>((op == 1 ? p.Zs : p.Zt) + k.xyoff, q.xylen, i + (long)c * n, v);
+    if (!live || sub != 0) return;
+    if (op == 5) {
+        if (i >= c) p.Wd[(long)wh * q.xylen + k.xyoff + i + (long)c * n] = v.l[0];
+    } else if (op == 4) stx<K>((wh == 0 ? p.Zs : p.Zt) + k.xyoff, q.xylen, i + (long)c * n, v);
+    else stx<K>((op == 1 ? p.Zs : p.Zt) + k.xyoff, q.xylen, i + (long)c * n, v);
 }
 
 // W = Li dM Li^T with the explicit inverse Li of the factor (two block products), symmetrised and rounded to fp64: the matrix of :1659
