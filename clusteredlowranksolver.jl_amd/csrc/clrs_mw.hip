@@ -125,6 +125,7 @@ struct clrs_mw_ctx {
     int maxcnt = 0;
     double *vz = nullptr;               // 2 N numbers of scratch of the solve stage over many workgroups (k_mw_solve_wide)
     bool wide_solve = false;            // some cluster or Q has more than 64 rows: the products of the solve stage are launches of their own
+    int n_one_term = 0, n_many_term = 0;   // clusters whose S_j goes through k_mw_saccum_one / through the general k_mw_saccum
     int sa_lanes = MW_SA_W;             // lanes per entry of k_mw_saccum: 1, 2 or 4 by the largest block count of a cluster
     int maxTb = 0;                      // most low-rank terms in one PSD block
     size_t sm_x = 0, sm_zt = 0, sm_dense = 0, sm_factor = 0, sm_q = 0, sm_fwd = 0, sm_mid = 0, sm_bwd = 0;
@@ -384,6 +385,19 @@ extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int dev
         c->sa_lanes = mostb >= 3 ? 4 : mostb;
         // (one lane per entry when the launch fills the chip anyway was tried at 2048 clusters: 30 M wave instructions instead of 90 M, and
         // 390 us instead of 245: the chains of dependent loads of a cluster's blocks, one after the other, cost more than the idle lanes)
+        // clusters with at most four blocks and at most one low-rank term per (constraint, block): k_mw_saccum_one
+        for (int j = 0; j < J; j++) {
+            MwClu &cl = c->clu[j];
+            bool one = cl.b1 - cl.b0 >= 1 && cl.b1 - cl.b0 <= 4;
+            for (int b = cl.b0; b < cl.b1 && one; b++) {
+                const MwBlk &k = c->blk[b];
+                if (k.kind != 0) continue;
+                const int *tp = htptr.data() + k.tptr_off;
+                for (int p = 0; p < cl.P && one; p++) one = tp[p + 1] - tp[p] <= 1;
+            }
+            cl.one_term = one ? 1 : 0;
+            (one ? c->n_one_term : c->n_many_term)++;
+        }
     }
     c->cnt_mul = cnt_mul;
     for (int j = 0; j < J; j++) {
@@ -837,7 +851,10 @@ extern "C" int clrs_mw_schur_assemble_dev(clrs_mw_ctx *c, const double *d_Xchol,
             const int ds_lanes = c->maxn_dense * c->maxn_dense <= 128 ? 8 : c->maxn_dense * c->maxn_dense <= 512 ? 16 : 64;      // per pair of the table
             if (q.dn_big) hipLaunchKernelGGL((k_mw_dense_s<KK, DD>), dim3(q.ndn, (pairs + MW_NT / ds_lanes - 1) / (MW_NT / ds_lanes)), dim3(MW_NT), 0, c->stream, q, ds_lanes);
         }
-        hipLaunchKernelGGL((k_mw_saccum<KK, DD>), dim3((c->maxP * (c->maxP + 1) / 2 * c->sa_lanes + MW_NT - 1) / MW_NT, q.J), dim3(MW_NT), 0, c->stream, q, c->sa_lanes);
+        // (k_mw_saccum also writes the per-term pairings A_Y: launched in any case, its grid shrunk to their share when every cluster is k_mw_saccum_one's)
+        const int sa_x = c->n_many_term ? (c->maxP * (c->maxP + 1) / 2 * c->sa_lanes + MW_NT - 1) / MW_NT : (int)std::min<i64>(2048, (q.T + MW_NT - 1) / MW_NT + 1);
+        hipLaunchKernelGGL((k_mw_saccum<KK, DD>), dim3(sa_x, c->n_many_term ? q.J : 1), dim3(MW_NT), 0, c->stream, q, c->sa_lanes);
+        if (c->n_one_term) hipLaunchKernelGGL((k_mw_saccum_one<KK, DD>), dim3((c->maxP * (c->maxP + 1) / 2 + MW_NT - 1) / MW_NT, q.J), dim3(MW_NT), 0, c->stream, q);
     });
     MWCHECK(hipGetLastError());
     if (c->timing) MWCHECK(hipEventRecord(c->ev[1], c->stream));

@@ -49,6 +49,7 @@ struct MwBlk {               // one PSD block (j, l)
 struct MwClu {               // one cluster j
     int P, b0, b1, lds;      // constraints; block range; 1 = S_j and the inverse of its factor fit in LDS side by side (k_mw_factor), 0 = blocked path
     mwi64 coff, Soff;
+    int one_term, pad;       // 1 = at most four PSD blocks and at most one low-rank term per (constraint, block): S_j by k_mw_saccum_one
 };
 struct MwDev {
     int J, N, NB, nlr, ndn, pad0;
@@ -767,6 +768,7 @@ template <int K, int DK, int W>
 __device__ __forceinline__ void mw_saccum_body(const MwDev &q) {
     using namespace mwk;
     const MwClu &c = q.clu[blockIdx.y];
+    if (c.one_term) return;                              // k_mw_saccum_one
     const int P = c.P;
     if (blockIdx.x * (MW_NT / W) >= P * (P + 1) / 2) return;
     // W lanes per entry, one block of the cluster each: the chains of dependent loads (block -> term range -> pointers ->
@@ -818,6 +820,84 @@ __global__ __launch_bounds__(MW_NT) void k_mw_saccum(const MwDev q, int lanes) {
     if (lanes == 1) mw_saccum_body<K, DK, 1>(q);
     else if (lanes == 2) mw_saccum_body<K, DK, 2>(q);
     else mw_saccum_body<K, DK, 4>(q);
+}
+
+// The same for clusters with at most four PSD blocks and at most ONE low-rank term per (constraint, block) -- every sampled problem whose
+// constraint matrices are rank one per block (the sphere-packing and polynomial-optimisation families).  One lane per entry, and the blocks
+// of the cluster UNROLLED: the term of the row and of the column in every block first, then their vector indices, then the pairings and
+// weights of all blocks, then the arithmetic -- four rounds of independent loads instead of one chain of dependent ones per block and lane
+// (k_mw_saccum with one lane per entry walks the blocks one after the other: 390 us on 2048 clusters; with a lane per block it pays
+// for the sums across lanes: 245 us; this kernel: 108 us).  Folding the eigenvalues lambda lambda' into the columns of Z (so that GX carries
+// them and an entry is one K x K multiply-add per block) was tried on top: 92 us here, but +24 us in k_mws_pair, whose VALU phases are on its
+// critical path -- not kept.
+template <int K, int DK>
+__global__ __launch_bounds__(MW_NT) void k_mw_saccum_one(const MwDev q) {
+    using namespace mwk;
+    const MwClu &c = q.clu[blockIdx.y];
+    if (!c.one_term) return;
+    const int P = c.P;
+    const int e = blockIdx.x * MW_NT + threadIdx.x;
+    if (e >= P * (P + 1) / 2) return;
+    int qq, pp;
+    tri_index(e, qq, pp);           // qq >= pp
+    constexpr int MB = 4;
+    int tA[MB], tB[MB], kind[MB];
+    bool has[MB];
+    const MwBlk *kb[MB];
+#pragma unroll
+    for (int bi = 0; bi < MB; bi++) {
+        const int b = min(c.b0 + bi, c.b1 - 1);
+        kb[bi] = &q.blk[b];
+        kind[bi] = kb[bi]->kind;
+        has[bi] = c.b0 + bi < c.b1;
+        tA[bi] = tB[bi] = 0;
+        if (kind[bi] == 0) {
+            const int *tp = q.tptr + kb[bi]->tptr_off;
+            const int a0 = tp[pp], a1 = tp[pp + 1], b0 = tp[qq], b1 = tp[qq + 1];
+            has[bi] = has[bi] && a1 > a0 && b1 > b0;
+            tA[bi] = a0; tB[bi] = b0;
+        } else {
+            const int *dm = q.dmap + kb[bi]->dmap_off;
+            tA[bi] = dm[pp]; tB[bi] = dm[qq];
+            has[bi] = has[bi] && tA[bi] >= 0 && tB[bi] >= 0;
+        }
+    }
+    long ix[MB], iy[MB];
+#pragma unroll
+    for (int bi = 0; bi < MB; bi++) {
+        ix[bi] = iy[bi] = 0;
+        if (kind[bi] == 0 && has[bi]) {
+            const int U = kb[bi]->U;
+            ix[bi] = q.st_a[tA[bi]] + (long)q.st_b[tB[bi]] * U;
+            iy[bi] = q.st_a[tB[bi]] + (long)q.st_b[tA[bi]] * U;
+        }
+    }
+    mw<K> gx[MB], gy[MB];
+    mw<DK> l1[MB], l2[MB];
+#pragma unroll
+    for (int bi = 0; bi < MB; bi++) {
+        if (kind[bi] == 0 && has[bi]) {
+            gx[bi] = ldx<K>(q.GX + kb[bi]->g_off, q.glen, ix[bi]);
+            gy[bi] = ldx<K>(q.GY + kb[bi]->g_off, q.glen, iy[bi]);
+            l1[bi] = ldx<DK>(q.st_lam, q.lamp, tA[bi]);
+            l2[bi] = ldx<DK>(q.st_lam, q.lamp, tB[bi]);
+        } else if (has[bi]) {
+            gx[bi] = ldx<K>(q.Sd + kb[bi]->sd_off, q.sdlen, tA[bi] + (long)tB[bi] * kb[bi]->cnt);
+        }
+    }
+    acc<K> s;
+    acc_zero<K>(s);
+#pragma unroll
+    for (int bi = 0; bi < MB; bi++) {
+        if (!has[bi]) continue;
+        if (kind[bi] == 0) {
+            constexpr int LL = (2 * DK + 1 < K) ? 2 * DK + 1 : K;
+            acc_fma<K, K, LL>(s, mul<K>(gx[bi], gy[bi]), mulx<LL, DK, DK>(l1[bi], l2[bi]));
+        } else acc_add<K, K>(s, gx[bi]);
+    }
+    const mw<K> v = acc_result<K>(s);
+    stx<K>(q.S + c.Soff, q.Slen, pp + (long)qq * P, v);
+    stx<K>(q.S + c.Soff, q.Slen, qq + (long)pp * P, v);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
