@@ -818,17 +818,19 @@ extern "C" int clrs_mw_schur_assemble_dev(clrs_mw_ctx *c, const double *d_Xchol,
     if (c->timing) MWCHECK(hipEventRecord(c->ev[0], c->stream));
     MW_DISPATCH(c, {
         const bool exact = c->mws_blocks > 0 && c->xinv_valid;      // the exact-product kernel needs chol(X)^-1 (k_mw_potrf_x of this context)
-        if (exact && c->mws_turns == 1) hipLaunchKernelGGL((k_mws_pair<KK, DD, 1>), dim3(q.nlr), dim3(MWS_NT), c->sm_mws, c->stream, q, c->mws, d_Y);
-        else if (exact) hipLaunchKernelGGL((k_mws_pair<KK, DD, 2>), dim3(q.nlr), dim3(MWS_NT), c->sm_mws, c->stream, q, c->mws, d_Y);
-        bool dense_done = false;
+        bool dense_done = exact && q.ndn && !q.dn_big;          // 1 x 1 dense blocks ride on the launch of the exact pairing matrices ...
+        const int pair_grid = q.nlr + (dense_done ? q.ndn : 0);
+        if (exact && c->mws_turns == 1) hipLaunchKernelGGL((k_mws_pair<KK, DD, 1>), dim3(pair_grid), dim3(MWS_NT), c->sm_mws, c->stream, q, c->mws, d_Y);
+        else if (exact) hipLaunchKernelGGL((k_mws_pair<KK, DD, 2>), dim3(pair_grid), dim3(MWS_NT), c->sm_mws, c->stream, q, c->mws, d_Y);
         if (q.nlr && !(exact && c->mws_blocks == q.nlr)) {
             MwDev q2 = q;
             q2.mws_on = exact ? 1 : 0;
             const int gper = MW_NT / MW_GRAM_W;
             hipLaunchKernelGGL((k_mw_zt<KK, DD>), dim3((c->maxU + MW_CT - 1) / MW_CT, q.nlr), dim3(MW_NT), c->sm_zt, c->stream, q2, d_Y, c->lds_zt_L ? 1 : 0, c->xinv_valid ? 1 : 0);
-            dense_done = q.ndn && !q.dn_big;                // 1 x 1 dense blocks ride on this launch
+            const bool ride_gram = !dense_done && q.ndn && !q.dn_big;      // ... or on that of the expansion kernel
+            dense_done = dense_done || ride_gram;
             q2.mwx_on = c->mwx_blocks > 0 ? 1 : 0;
-            hipLaunchKernelGGL((k_mw_gram<KK, DD>), dim3((c->maxU * (c->maxU + 1) / 2 + gper - 1) / gper, q.nlr + (dense_done ? q.ndn : 0)), dim3(MW_NT), 0, c->stream, q2, d_Y);
+            hipLaunchKernelGGL((k_mw_gram<KK, DD>), dim3((c->maxU * (c->maxU + 1) / 2 + gper - 1) / gper, q.nlr + (ride_gram ? q.ndn : 0)), dim3(MW_NT), 0, c->stream, q2, d_Y);
             if (q2.mwx_on) {                                 // the large pairing matrices: digits of Z and T, then 16 x 16 tiles on the matrix cores
                 const int nt = c->mwx_maxU16 / 16;
                 hipLaunchKernelGGL(k_mwx_slice<KK>, dim3(nt, 2, q.nlr), dim3(MWS_NT), 0, c->stream, q2, c->mwx);
@@ -851,10 +853,9 @@ extern "C" int clrs_mw_schur_assemble_dev(clrs_mw_ctx *c, const double *d_Xchol,
             const int ds_lanes = c->maxn_dense * c->maxn_dense <= 128 ? 8 : c->maxn_dense * c->maxn_dense <= 512 ? 16 : 64;      // per pair of the table
             if (q.dn_big) hipLaunchKernelGGL((k_mw_dense_s<KK, DD>), dim3(q.ndn, (pairs + MW_NT / ds_lanes - 1) / (MW_NT / ds_lanes)), dim3(MW_NT), 0, c->stream, q, ds_lanes);
         }
-        // (k_mw_saccum also writes the per-term pairings A_Y: launched in any case, its grid shrunk to their share when every cluster is k_mw_saccum_one's)
-        const int sa_x = c->n_many_term ? (c->maxP * (c->maxP + 1) / 2 * c->sa_lanes + MW_NT - 1) / MW_NT : (int)std::min<i64>(2048, (q.T + MW_NT - 1) / MW_NT + 1);
-        hipLaunchKernelGGL((k_mw_saccum<KK, DD>), dim3(sa_x, c->n_many_term ? q.J : 1), dim3(MW_NT), 0, c->stream, q, c->sa_lanes);
-        if (c->n_one_term) hipLaunchKernelGGL((k_mw_saccum_one<KK, DD>), dim3((c->maxP * (c->maxP + 1) / 2 + MW_NT - 1) / MW_NT, q.J), dim3(MW_NT), 0, c->stream, q);
+        // (the per-term pairings A_Y are written by k_mw_saccum, or by k_mw_saccum_one cluster by cluster when no cluster is left to k_mw_saccum)
+        if (c->n_many_term) hipLaunchKernelGGL((k_mw_saccum<KK, DD>), dim3((c->maxP * (c->maxP + 1) / 2 * c->sa_lanes + MW_NT - 1) / MW_NT, q.J), dim3(MW_NT), 0, c->stream, q, c->sa_lanes);
+        if (c->n_one_term) hipLaunchKernelGGL((k_mw_saccum_one<KK, DD>), dim3((c->maxP * (c->maxP + 1) / 2 + MW_NT - 1) / MW_NT, q.J), dim3(MW_NT), 0, c->stream, q, c->n_many_term ? 0 : 1);
     });
     MWCHECK(hipGetLastError());
     if (c->timing) MWCHECK(hipEventRecord(c->ev[1], c->stream));

@@ -168,6 +168,9 @@ template <int K, int DK, int TURNS>
 __global__ __launch_bounds__(MWS_NT, 2) void k_mws_pair(const MwDev q, const MwsDev w, const double *__restrict__ Y) {
     using namespace mwk;
     constexpr int S = mws_slices(K);
+    // workgroups beyond the low-rank blocks (the launch adds them when every dense block is 1 x 1): the dense blocks' tables, beside the pairing
+    // matrices instead of in a launch of their own behind them
+    if ((int)blockIdx.x >= q.nlr) { mw_dense_1x1<K, DK>(q, q.blk[q.dn_list[blockIdx.x - q.nlr]], Y, threadIdx.x); return; }
     const int b = q.lr_list[blockIdx.x];
     if (w.vs_off[b] < 0) return;
     const MwBlk &k = q.blk[b];

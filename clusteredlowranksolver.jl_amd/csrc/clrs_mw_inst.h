@@ -41,7 +41,7 @@
     X __global__ void k_mwx_dense<K, DK>(const MwDev, const MwdDev, const double *);                                   \
     X __global__ void k_mw_dense_s<K, DK>(const MwDev, int);                                                           \
     X __global__ void k_mw_saccum<K, DK>(const MwDev, int);                                                                 \
-    X __global__ void k_mw_saccum_one<K, DK>(const MwDev);                                                                  \
+    X __global__ void k_mw_saccum_one<K, DK>(const MwDev, int);                                                             \
     X __global__ void k_mw_linvb<K, DK>(const MwDev);                                                                  \
     X __global__ void k_mwi_scalar<K, DK>(const MwDev, const MwIpmDev, int, int);                                      \
     X __global__ void k_mwi_dots<K, DK>(const MwDev, const MwIpmDev, int, int);                                             \

@@ -831,12 +831,21 @@ __global__ __launch_bounds__(MW_NT) void k_mw_saccum(const MwDev q, int lanes) {
 // them and an entry is one K x K multiply-add per block) was tried on top: 92 us here, but +24 us in k_mws_pair, whose VALU phases are on its
 // critical path -- not kept.
 template <int K, int DK>
-__global__ __launch_bounds__(MW_NT) void k_mw_saccum_one(const MwDev q) {
+__global__ __launch_bounds__(MW_NT) void k_mw_saccum_one(const MwDev q, int do_ay) {
     using namespace mwk;
     const MwClu &c = q.clu[blockIdx.y];
     if (!c.one_term) return;
     const int P = c.P;
     const int e = blockIdx.x * MW_NT + threadIdx.x;
+    if (do_ay) {                                         // A_Y per term, w^T Y v, of this cluster's blocks (when no cluster is left to k_mw_saccum, which writes them all)
+        for (int b = c.b0; b < c.b1; b++) {
+            const MwBlk &k = q.blk[b];
+            if (k.kind != 0) continue;
+            const int *tp = q.tptr + k.tptr_off;
+            for (int t = tp[0] + e; t < tp[P]; t += gridDim.x * MW_NT)
+                stx<K>(q.AY, q.T, t, ldx<K>(q.GY + k.g_off, q.glen, q.ay_a[t] + (long)q.ay_b[t] * k.U));
+        }
+    }
     if (e >= P * (P + 1) / 2) return;
     int qq, pp;
     tri_index(e, qq, pp);           // qq >= pp
