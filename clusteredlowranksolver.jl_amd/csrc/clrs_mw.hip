@@ -125,6 +125,8 @@ struct clrs_mw_ctx {
     int maxcnt = 0;
     double *vz = nullptr;               // 2 N numbers of scratch of the solve stage over many workgroups (k_mw_solve_wide)
     bool wide_solve = false;            // some cluster or Q has more than 64 rows: the products of the solve stage are launches of their own
+    const double *ride_fwd = nullptr;   // set by the iteration around clrs_mw_schur_factor_finish_dev: rhs_x of the solve that follows
+    bool fwd_rode = false;              // ... and its first product pair (k_mw_solve_fwd's work) was done on the launch of k_mw_potrf_q
     int n_one_term = 0, n_many_term = 0;   // clusters whose S_j goes through k_mw_saccum_one / through the general k_mw_saccum
     int sa_lanes = MW_SA_W;             // lanes per entry of k_mw_saccum: 1, 2 or 4 by the largest block count of a cluster
     int maxTb = 0;                      // most low-rank terms in one PSD block
@@ -448,7 +450,7 @@ extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int dev
     }
     MW_DISPATCH(c, {
         MW_TRY(mw_set_lds(k_mw_potrf_x<KK>, c->sm_x)); MW_TRY(mw_set_lds(k_mw_zt<KK, DD>, c->sm_zt)); MW_TRY(mw_set_lds((k_mw_dense_t<KK, DD>), c->sm_dense));
-        MW_TRY(mw_set_lds(k_mw_factor<KK>, c->sm_factor)); MW_TRY(mw_set_lds(k_mw_potrf_q<KK>, c->sm_q));
+        MW_TRY(mw_set_lds(k_mw_factor<KK>, c->sm_factor)); MW_TRY(mw_set_lds(k_mw_potrf_q<KK>, std::max(c->sm_q, c->sm_fwd)));
         MW_TRY(mw_set_lds(k_mw_solve_fwd<KK>, c->sm_fwd)); MW_TRY(mw_set_lds(k_mw_solve_mid<KK>, c->sm_mid)); MW_TRY(mw_set_lds(k_mw_solve_bwd<KK>, c->sm_bwd));
     });
     // ---- exact-product path (clrs_mw_exact.hip.h): static slices of V of the eligible blocks ----
@@ -1056,7 +1058,10 @@ extern "C" int clrs_mw_schur_factor_finish_dev(clrs_mw_ctx *c) {
     MWCHECK(hipSetDevice(c->device));
     const MwDev &q = c->d;
     if (q.N > 0 && c->lds_q) {
-        MW_DISPATCH(c, { hipLaunchKernelGGL(k_mw_potrf_q<KK>, dim3(MW_INV_WG), dim3(MW_PT), c->sm_q, c->stream, q); });
+        // the interior-point iteration hands over the right-hand side of its next solve: the solve's first product pair rides on this launch
+        const bool ride = c->ride_fwd != nullptr && !q.gathered && !c->wide_solve;
+        MW_DISPATCH(c, { hipLaunchKernelGGL(k_mw_potrf_q<KK>, dim3(MW_INV_WG + (ride ? q.J : 0)), dim3(MW_PT), ride ? std::max(c->sm_q, c->sm_fwd) : c->sm_q, c->stream, q, MW_INV_WG, c->ride_fwd); });
+        c->fwd_rode = ride;
     } else if (q.N > 0) {
         MW_DISPATCH(c, { hipLaunchKernelGGL(k_mw_qsum<KK>, dim3((unsigned)std::min<i64>(256, ((i64)q.N * q.N + MW_NT - 1) / MW_NT)), dim3(MW_NT), 0, c->stream, q); });
         int rc = mw_potrf_blocked(c, c->bp_Q, c->d_bp + c->bp_S.size(), false);
@@ -1138,7 +1143,9 @@ extern "C" int clrs_mw_schur_solve_dev(clrs_mw_ctx *c, const double *d_rhs_x, co
         if (c->timing) MWCHECK(hipEventRecord(c->ev[7], c->stream));
         return 0;
     }
-    int rc = clrs_mw_schur_solve_fwd_dev(c, d_rhs_x);
+    int rc = 0;
+    if (c->fwd_rode) { c->fwd_rode = false; c->fwd_done = true; }      // t_j, u_j of this right-hand side are there already (k_mw_potrf_q's launch)
+    else rc = clrs_mw_schur_solve_fwd_dev(c, d_rhs_x);
     if (rc) return rc;
     if (q.gathered && q.N > 0) {
         int rc2 = mw_allgather(c, 0, q.ug, (size_t)q.N * c->K, c->stream);

@@ -1000,12 +1000,14 @@ __global__ __launch_bounds__(MW_NT) void k_mw_qgram(const MwDev q) {
     }
 }
 
+template <int K>
+__device__ __forceinline__ void mw_solve_fwd_cluster(const MwDev &q, int j, const double *__restrict__ rhs_x);      // (solve stage, below)
 // Cholesky of Q (src/solver.jl:1274) and its scaled triangles
 template <int K, class PM, class PW>
-__device__ __forceinline__ void mw_potrf_q_body(const MwDev &q, PM M, long plane, PW W, mwk::lds_d *bc, int tid) {
+__device__ __forceinline__ void mw_potrf_q_body(const MwDev &q, PM M, long plane, PW W, mwk::lds_d *bc, int tid, int cw, int cnw) {
     using namespace mwk;
     const int N = q.N;
-    const int cw = blockIdx.x, cnw = gridDim.x;         // the workgroups share out the columns of L_Q^-1; the first one also writes L_Q
+    // (cw of cnw: the workgroups share out the columns of L_Q^-1; the first one also writes L_Q)
     const bool ok = wg_potrf<K, true, MW_PT>(M, plane, N, N, q.qrd, N, W, MW_TRI(N), 0, bc, tid, cw, cnw);     // W packed
     if (!ok) {
         if (tid == 0) atomicMin(&q.info[0], q.J + 1);
@@ -1021,9 +1023,12 @@ __device__ __forceinline__ void mw_potrf_q_body(const MwDev &q, PM M, long plane
     }
 }
 template <int K>
-__global__ __launch_bounds__(MW_PT) void k_mw_potrf_q(const MwDev q) {
+__global__ __launch_bounds__(MW_PT) void k_mw_potrf_q(const MwDev q, int nq, const double *__restrict__ fwd_rhs) {
     using namespace mwk;
     const int N = q.N, tid = threadIdx.x;
+    // workgroups behind the nq of Q (the interior-point iteration adds them): the first product pair of the next solve, t_j = L_j^-1 rhs_x[j] and
+    // u_j = LinvB_j^T t_j per cluster, which needs the clusters' factors only -- beside the 31 pivots of Q instead of behind them
+    if ((int)blockIdx.x >= nq) { mw_solve_fwd_cluster<K>(q, blockIdx.x - nq, fwd_rhs); return; }
     if (q.info[0] != MW_INFO_NONE) return;           // a cluster failed: the reference throws before reaching Q
     lds_d *bc = MW_LDS;
     const long nn = (long)N * N;
@@ -1035,7 +1040,7 @@ __global__ __launch_bounds__(MW_PT) void k_mw_potrf_q(const MwDev q) {
         stx<K>(M, nn, e, acc_result<K>(s));
     }
     __syncthreads();
-    mw_potrf_q_body<K>(q, M, nn, M + (long)K * nn, bc, tid);
+    mw_potrf_q_body<K>(q, M, nn, M + (long)K * nn, bc, tid, blockIdx.x, nq);
     // a Q too large for LDS: k_mw_qsum + the blocked path (k_mw_bp_*)
 }
 
@@ -1254,9 +1259,10 @@ __device__ __forceinline__ void mw_solve_u(const MwDev &q, const MwClu &c, int j
     }
 }
 template <int K>
-__global__ __launch_bounds__(MW_NT) void k_mw_solve_fwd(const MwDev q, const double *__restrict__ rhs_x) {
+__device__ __forceinline__ void mw_solve_fwd_cluster(const MwDev &q, int j, const double *__restrict__ rhs_x) {
     using namespace mwk;
-    const int j = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
+    if (tid >= MW_NT) return;                              // (called from a launch with more threads: the other waves leave; barriers count the rest)
     const MwClu &c = q.clu[j];
     const int P = c.P;
     lds_d *tv = MW_LDS, *t2 = tv + (long)K * P;            // rhs_j and t_j, planar with plane P
@@ -1272,6 +1278,8 @@ __global__ __launch_bounds__(MW_NT) void k_mw_solve_fwd(const MwDev q, const dou
     }
     mw_solve_u<K>(q, c, j, t2, tid);
 }
+template <int K>
+__global__ __launch_bounds__(MW_NT) void k_mw_solve_fwd(const MwDev q, const double *__restrict__ rhs_x) { mw_solve_fwd_cluster<K>(q, blockIdx.x, rhs_x); }
 
 template <int K>
 __global__ __launch_bounds__(MW_NT) void k_mw_solve_mid(const MwDev q, const double *__restrict__ rhs_y, double *__restrict__ dy) {
