@@ -451,7 +451,7 @@ extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int dev
     MW_DISPATCH(c, {
         MW_TRY(mw_set_lds(k_mw_potrf_x<KK>, c->sm_x)); MW_TRY(mw_set_lds(k_mw_zt<KK, DD>, c->sm_zt)); MW_TRY(mw_set_lds((k_mw_dense_t<KK, DD>), c->sm_dense));
         MW_TRY(mw_set_lds(k_mw_factor<KK>, c->sm_factor)); MW_TRY(mw_set_lds(k_mw_potrf_q<KK>, std::max(c->sm_q, c->sm_fwd)));
-        MW_TRY(mw_set_lds(k_mw_solve_fwd<KK>, c->sm_fwd)); MW_TRY(mw_set_lds(k_mw_solve_mid<KK>, c->sm_mid)); MW_TRY(mw_set_lds(k_mw_solve_bwd<KK>, c->sm_bwd));
+        MW_TRY(mw_set_lds(k_mw_solve_fwd<KK>, c->sm_fwd)); MW_TRY(mw_set_lds(k_mw_solve_mid<KK>, c->sm_mid)); MW_TRY(mw_set_lds(k_mw_solve_bwd<KK>, c->sm_mid + c->sm_bwd));
     });
     // ---- exact-product path (clrs_mw_exact.hip.h): static slices of V of the eligible blocks ----
     std::vector<long long> mws_off((size_t)std::max(NB, 1), -1);
@@ -1111,8 +1111,11 @@ extern "C" int clrs_mw_schur_solve_bwd_dev(clrs_mw_ctx *c, const double *d_rhs_y
     if (q.N > 0 && (!d_rhs_y || !d_dy)) return mw_fail(CLRS_ERR_INVALID, "null argument");
     MWCHECK(hipSetDevice(c->device));
     MW_DISPATCH(c, {
-        if (q.N > 0) hipLaunchKernelGGL(k_mw_solve_mid<KK>, dim3(1), dim3(MW_NT), c->sm_mid, c->stream, q, d_rhs_y, d_dy);
-        hipLaunchKernelGGL(k_mw_solve_bwd<KK>, dim3(q.J), dim3(MW_NT), c->sm_bwd, c->stream, q, (const double *)d_dy, d_dx);
+        // few clusters, one rank: dy is formed by every workgroup of the backward launch itself (one launch less on the chain of the iteration)
+        const bool mid_in_bwd = q.N > 0 && !q.gathered && q.J <= 4 && c->sm_mid + c->sm_bwd <= MW_LDS_MAX;
+        if (q.N > 0 && !mid_in_bwd) hipLaunchKernelGGL(k_mw_solve_mid<KK>, dim3(1), dim3(MW_NT), c->sm_mid, c->stream, q, d_rhs_y, d_dy);
+        hipLaunchKernelGGL(k_mw_solve_bwd<KK>, dim3(q.J), dim3(MW_NT), mid_in_bwd ? c->sm_mid + c->sm_bwd : c->sm_bwd, c->stream, q, (const double *)d_dy, d_dx,
+                           mid_in_bwd ? d_rhs_y : (const double *)nullptr, d_dy);
     });
     MWCHECK(hipGetLastError());
     if (c->timing) MWCHECK(hipEventRecord(c->ev[7], c->stream));

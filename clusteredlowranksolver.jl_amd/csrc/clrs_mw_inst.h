@@ -19,7 +19,7 @@
     X __global__ void k_mw_usum<K>(const MwDev);                                                                       \
     X __global__ void k_mw_solve_fwd<K>(const MwDev, const double *);                                                  \
     X __global__ void k_mw_solve_mid<K>(const MwDev, const double *, double *);                                        \
-    X __global__ void k_mw_solve_bwd<K>(const MwDev, const double *, double *);                                        \
+    X __global__ void k_mw_solve_bwd<K>(const MwDev, const double *, double *, const double *, double *);                    \
     X __global__ void k_mw_solve_wide<K>(const MwDev, int, const double *, const double *, double *, double *, double *);\
     X __global__ void k_mw_xrd<K>(const MwDev, const double *);                                                        \
     X __global__ void k_mwi_R<K>(const MwDev, const MwIpmDev, int);                                                    \

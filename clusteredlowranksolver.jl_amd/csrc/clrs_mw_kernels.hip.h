@@ -1281,11 +1281,11 @@ __device__ __forceinline__ void mw_solve_fwd_cluster(const MwDev &q, int j, cons
 template <int K>
 __global__ __launch_bounds__(MW_NT) void k_mw_solve_fwd(const MwDev q, const double *__restrict__ rhs_x) { mw_solve_fwd_cluster<K>(q, blockIdx.x, rhs_x); }
 
+// dy = Q^-1 (rhs_y - sum_j u_j) into v (LDS, plane N; y: N more numbers of scratch)
 template <int K>
-__global__ __launch_bounds__(MW_NT) void k_mw_solve_mid(const MwDev q, const double *__restrict__ rhs_y, double *__restrict__ dy) {
+__device__ __forceinline__ void mw_solve_mid_body(const MwDev &q, const double *__restrict__ rhs_y, mwk::lds_d *v, mwk::lds_d *y, int tid) {
     using namespace mwk;
-    const int N = q.N, tid = threadIdx.x;
-    lds_d *v = MW_LDS, *y = v + (long)K * N;  // N numbers each, plane N
+    const int N = q.N;
     const long lplane = (long)N * N;
     for (int a = tid; a < N; a += MW_NT) {
         acc<K> s;
@@ -1301,21 +1301,39 @@ __global__ __launch_bounds__(MW_NT) void k_mw_solve_mid(const MwDev q, const dou
     __syncthreads();
     wg_trmv_n<K>(q.Qi, lplane, N, N, v, N, y, N, tid);     // dy = Qi^T (Qi v): two products with the explicit inverse of L_Q
     wg_trmv_t<K>(q.Qi, lplane, N, N, y, N, v, N, tid);
+}
+template <int K>
+__global__ __launch_bounds__(MW_NT) void k_mw_solve_mid(const MwDev q, const double *__restrict__ rhs_y, double *__restrict__ dy) {
+    using namespace mwk;
+    const int N = q.N, tid = threadIdx.x;
+    lds_d *v = MW_LDS, *y = v + (long)K * N;  // N numbers each, plane N
+    mw_solve_mid_body<K>(q, rhs_y, v, y, tid);
     for (int a = tid; a < N; a += MW_NT) {
 #pragma unroll
         for (int l = 0; l < K; l++) dy[(long)l * N + a] = v[(long)l * N + a];
     }
 }
 
+// mid_rhs_y != null (small unsharded systems): every workgroup forms dy = Q^-1 (rhs_y - sum u_j) itself first (two 31-row products: cheaper than the
+// launch of k_mw_solve_mid in front of this kernel); the first one writes it to dy
 template <int K>
-__global__ __launch_bounds__(MW_NT) void k_mw_solve_bwd(const MwDev q, const double *__restrict__ dy, double *__restrict__ dx) {
+__global__ __launch_bounds__(MW_NT) void k_mw_solve_bwd(const MwDev q, const double *__restrict__ dy_in, double *__restrict__ dx, const double *__restrict__ mid_rhs_y,
+                                                        double *__restrict__ dy_out) {
     using namespace mwk;
     const int j = blockIdx.x, tid = threadIdx.x;
     const MwClu &c = q.clu[j];
     const int P = c.P, N = q.N;
-    lds_d *w = MW_LDS, *w2 = w + (long)K * P;
+    lds_d *dyl = MW_LDS, *w = MW_LDS + (mid_rhs_y ? 2L * K * N : 0L), *w2 = w + (long)K * P;
     const long plane = q.xlen * (long)N;
     const int sub = tid % MW_S_W;
+    if (mid_rhs_y) {
+        mw_solve_mid_body<K>(q, mid_rhs_y, dyl, dyl + (long)K * N, tid);      // (ends with a barrier)
+        if (j == 0)
+            for (int a = tid; a < N; a += MW_NT) {
+#pragma unroll
+                for (int l = 0; l < K; l++) dy_out[(long)l * N + a] = dyl[(long)l * N + a];
+            }
+    }
     for (int r0 = 0; r0 < P; r0 += MW_NT / MW_S_W) {
         const int r = r0 + tid / MW_S_W;
         const bool live = r < P;
@@ -1323,7 +1341,11 @@ __global__ __launch_bounds__(MW_NT) void k_mw_solve_bwd(const MwDev q, const dou
         acc<K> s;
         acc_zero<K>(s);
         if (sub == 0) acc_add<K, K>(s, ldx<K>(q.t, q.xlen, c.coff + rr));
-        for (int a = sub; a < N; a += MW_S_W) acc_fma<K, K, K>(s, ldx<K>(q.LB, plane, c.coff + rr + a * q.xlen), ldx<K>(dy, N, a));
+        if (mid_rhs_y) {
+            for (int a = sub; a < N; a += MW_S_W) acc_fma<K, K, K>(s, ldx<K>(q.LB, plane, c.coff + rr + a * q.xlen), ldx<K>(dyl, N, a));
+        } else {
+            for (int a = sub; a < N; a += MW_S_W) acc_fma<K, K, K>(s, ldx<K>(q.LB, plane, c.coff + rr + a * q.xlen), ldx<K>(dy_in, N, a));
+        }
         mw<K> v = lanes_sum<K, MW_S_W>(acc_result<K>(s));
         if (live && sub == 0) stx<K>(w, P, r, v);
     }
