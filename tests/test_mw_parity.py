@@ -732,6 +732,30 @@ def test_exact_product_pairings_match_the_oracle(name, K, oracle_built):
     ctx.close()
 
 
+@pytest.mark.parametrize("kw", [
+    dict(seed=1, J=3, n_free=1, definite=True),                              # the shapes of the named problems
+    dict(seed=10, J=2, n_free=5, fixed_P=70, max_n=40, lr_blocks=2),         # tiled block products (n = 40), blocked factorisation (P = 70), row-parallel solve
+    dict(seed=11, J=1, n_free=0, fixed_P=60, max_n=33, lr_blocks=3),         # no free variables, one cluster beyond LDS
+    dict(seed=12, J=40, n_free=2, fixed_P=6, max_n=4, lr_blocks=2),          # many small clusters (k_mw_saccum_one)
+    dict(seed=13, J=2, n_free=70, fixed_P=40, max_n=20, lr_blocks=2),        # Q larger than the clusters (blocked Q, N = 70)
+])
+def test_device_loop_follows_the_oracle_on_random_sdps(kw, oracle_built):
+    """The device-resident loop against the 256-bit oracle on random SDPs of awkward shapes -- most are infeasible or unbounded, and both must
+    walk the same trajectory: mu, both step lengths and beta_c of the first 12 iterations to 1e-8, the same error code at the end."""
+    import clrs_amd
+    from tests.util import random_simple_sdp
+    from clrs_amd.mw import solvesdp_mw
+    from oracle.oracle import Oracle
+    f = clrs_amd.flatten(random_simple_sdp(**kw))
+    r = solvesdp_mw(f, limbs=5, maxiterations=12)
+    ro = Oracle(f, mp_bits=256).solvesdp(maxiterations=12)
+    assert r.error_code == ro["error_code"] and r.iterations == ro["iterations"]
+    for it in range(len(ro["hist"])):
+        for col in (1, 8, 9, 10):
+            a, b = r.history[it, col], ro["hist"][it, col]
+            assert abs(a - b) <= 1e-8 * max(abs(b), 1e-300), (it, col, a, b)
+
+
 @pytest.mark.parametrize("K", [4, 5, 6])
 def test_exact_product_pairings_of_a_large_block(K, oracle_built):
     """k_mwx_slice / k_mwx_gram (csrc/clrs_mw_exact.hip.h): the pairing matrices of a block beyond the shapes of k_mws_pair -- 41 x 41 with 81 unique
