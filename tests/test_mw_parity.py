@@ -746,14 +746,20 @@ def test_device_loop_follows_the_oracle_on_random_sdps(kw, oracle_built):
     from tests.util import random_simple_sdp
     from clrs_amd.mw import solvesdp_mw
     from oracle.oracle import Oracle
+    from clrs_amd.mw import MwSchurContext
     f = clrs_amd.flatten(random_simple_sdp(**kw))
-    r = solvesdp_mw(f, limbs=5, maxiterations=12)
-    ro = Oracle(f, mp_bits=256).solvesdp(maxiterations=12)
-    assert r.error_code == ro["error_code"] and r.iterations == ro["iterations"]
-    for it in range(len(ro["hist"])):
-        for col in (1, 8, 9, 10):
-            a, b = r.history[it, col], ro["hist"][it, col]
-            assert abs(a - b) <= 1e-8 * max(abs(b), 1e-300), (it, col, a, b)
+    o = Oracle(f, mp_bits=256)
+    o.set_num_threads(8)
+    ro = o.solvesdp(maxiterations=12)
+    for exact in ((None, True) if kw["seed"] in (1, 12) else (None,)):        # also with the pairing matrices forced through the exact slice products
+        ctx = MwSchurContext(f, limbs=5, exact_products=exact)
+        r = solvesdp_mw(f, limbs=5, maxiterations=12, ctx=ctx)
+        ctx.close()
+        assert r.error_code == ro["error_code"] and r.iterations == ro["iterations"], exact
+        for it in range(len(ro["hist"])):
+            for col in (1, 8, 9, 10):
+                a, b = r.history[it, col], ro["hist"][it, col]
+                assert abs(a - b) <= 1e-8 * max(abs(b), 1e-300), (exact, it, col, a, b)
 
 
 @pytest.mark.parametrize("K", [4, 5, 6])
