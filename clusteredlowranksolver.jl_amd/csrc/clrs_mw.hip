@@ -119,6 +119,7 @@ struct clrs_mw_ctx {
     std::vector<MwClu> clu;
     std::vector<void *> allocs;
     int maxU = 0, maxP = 0, maxn = 0, maxn_dense = 0;
+    bool all_inv = false;               // every low-rank block has its inverse factor (k.inv != 0)
     bool xinv_valid = false;            // Xi holds the inverses of the current Cholesky factors (they come from k_mw_potrf_x, not from the caller)
     bool lds_x = false, lds_q = false, lds_zt_L = false, dense_two = false;
     int nw_factor = 1;                  // workgroups per cluster in k_mw_factor (they share out the columns of the inverse factor)
@@ -422,6 +423,8 @@ extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int dev
             k.inv = !c->lds_x ? 0 : two <= lim ? 1 : one <= lim ? 2 : 0;       // the inverse in LDS beside the factor, or in place in memory
             if (k.inv) xneed = std::max(xneed, k.inv == 1 ? two : one);
         }
+        c->all_inv = !c->blk.empty();
+        for (auto &k : c->blk) c->all_inv = c->all_inv && (k.kind != 0 || k.inv != 0);
         c->sm_x = xneed * 8;
         size_t zt = (size_t)c->maxn * MW_CT * K;
         c->lds_zt_L = zt + nn <= lim;
@@ -828,7 +831,9 @@ extern "C" int clrs_mw_schur_assemble_dev(clrs_mw_ctx *c, const double *d_Xchol,
             MwDev q2 = q;
             q2.mws_on = exact ? 1 : 0;
             const int gper = MW_NT / MW_GRAM_W;
-            hipLaunchKernelGGL((k_mw_zt<KK, DD>), dim3((c->maxU + MW_CT - 1) / MW_CT, q.nlr), dim3(MW_NT), c->sm_zt, c->stream, q2, d_Y, c->lds_zt_L ? 1 : 0, c->xinv_valid ? 1 : 0);
+            // few blocks, every one with its inverse factor: two columns per workgroup and eight lanes per entry
+            const int zt_ct = (c->xinv_valid && c->all_inv && (i64)q.nlr * c->maxU <= 2048 && c->maxn <= 32) ? 2 : MW_CT;
+            hipLaunchKernelGGL((k_mw_zt<KK, DD>), dim3((c->maxU + zt_ct - 1) / zt_ct, q.nlr), dim3(MW_NT), c->sm_zt, c->stream, q2, d_Y, c->lds_zt_L ? 1 : 0, c->xinv_valid ? 1 : 0, zt_ct);
             const bool ride_gram = !dense_done && q.ndn && !q.dn_big;      // ... or on that of the expansion kernel
             dense_done = dense_done || ride_gram;
             q2.mwx_on = c->mwx_blocks > 0 ? 1 : 0;

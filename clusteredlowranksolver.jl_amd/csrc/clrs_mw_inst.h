@@ -32,7 +32,7 @@
     X __global__ void k_mwi_init<K>(const MwDev, const MwIpmDev, double, double);
 
 #define MW_KERNELS_KD(X, K, DK)                                                                                        \
-    X __global__ void k_mw_zt<K, DK>(const MwDev, const double *, int, int);                                           \
+    X __global__ void k_mw_zt<K, DK>(const MwDev, const double *, int, int, int);                                      \
     X __global__ void k_mw_gram<K, DK>(const MwDev, const double *);                                                                   \
     X __global__ void k_mws_pair<K, DK, 1>(const MwDev, const MwsDev, const double *);                                 \
     X __global__ void k_mws_pair<K, DK, 2>(const MwDev, const MwsDev, const double *);                                                                   \

@@ -494,25 +494,25 @@ __global__ void k_mwi_scalar(const MwDev q, const MwIpmDev p, int stage, int ite
 // add on the diagonal of their first product -- the products do not depend on mu_p / mu_c, so this kernel runs beside the scalar
 // stages that produce them instead of behind them -------------------------------------------------------------------------
 #define MWI_EW 4              // lanes per matrix entry in the block products of the iteration
-template <int K>
+template <int K, int EW>
 __device__ __forceinline__ void mwi_R_body(const MwDev &q, const MwIpmDev &p, int corrector, int bx, int by) {
     using namespace mwk;
     const MwBlk &k = q.blk[by];
     const int n = k.n;
-    if (bx * (MW_NT / MWI_EW) >= n * n) return;
-    const int e = bx * (MW_NT / MWI_EW) + threadIdx.x / MWI_EW, sub = threadIdx.x % MWI_EW;
+    if (bx * (MW_NT / EW) >= n * n) return;
+    const int e = bx * (MW_NT / EW) + threadIdx.x / EW, sub = threadIdx.x % EW;
     const bool live = e < n * n;
     const int ee = live ? e : 0, i = ee % n, c = ee / n;
     acc<K> s;
     acc_zero<K>(s);
-    for (int kk = sub; kk < n; kk += MWI_EW) acc_fma<K, K, K>(s, ldx<K>(p.X + k.xyoff, q.xylen, i + (long)kk * n), ldx<K>(p.Y + k.xyoff, q.xylen, kk + (long)c * n), -1.0);
+    for (int kk = sub; kk < n; kk += EW) acc_fma<K, K, K>(s, ldx<K>(p.X + k.xyoff, q.xylen, i + (long)kk * n), ldx<K>(p.Y + k.xyoff, q.xylen, kk + (long)c * n), -1.0);
     if (corrector)
-        for (int kk = sub; kk < n; kk += MWI_EW) acc_fma<K, K, K>(s, ldx<K>(p.dX + k.xyoff, q.xylen, i + (long)kk * n), ldx<K>(p.dY + k.xyoff, q.xylen, kk + (long)c * n), -1.0);
-    const mw<K> v = lanes_sum<K, MWI_EW>(acc_result<K>(s));
+        for (int kk = sub; kk < n; kk += EW) acc_fma<K, K, K>(s, ldx<K>(p.dX + k.xyoff, q.xylen, i + (long)kk * n), ldx<K>(p.dY + k.xyoff, q.xylen, kk + (long)c * n), -1.0);
+    const mw<K> v = lanes_sum<K, EW>(acc_result<K>(s));
     if (live && sub == 0) stx<K>(p.R + k.xyoff, q.xylen, e, v);
 }
 template <int K>
-__global__ __launch_bounds__(MW_NT) void k_mwi_R(const MwDev q, const MwIpmDev p, int corrector) { mwi_R_body<K>(q, p, corrector, blockIdx.x, blockIdx.y); }
+__global__ __launch_bounds__(MW_NT) void k_mwi_R(const MwDev q, const MwIpmDev p, int corrector) { mwi_R_body<K, MWI_EW>(q, p, corrector, blockIdx.x, blockIdx.y); }
 
 // ---- block dot products: partial sums per PSD block ------------------------------------------------------------------
 // sel bit 0: <X,Y>; bit 1: <X,dY>, <dX,Y>, <dX,dY>; bit 2: <C,Y>
@@ -523,7 +523,8 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_dots(const MwDev q, const MwIpmDe
     using namespace mwk;
     if ((int)blockIdx.x >= q.NB) {
         const int w = blockIdx.x - q.NB;
-        mwi_R_body<K>(q, p, 1, w % r_tiles, w / r_tiles);
+        if (r_tiles < 0) mwi_R_body<K, 16>(q, p, 1, w % (-r_tiles), w / (-r_tiles));      // (negative: sixteen lanes per entry, small problems)
+        else mwi_R_body<K, MWI_EW>(q, p, 1, w % r_tiles, w / r_tiles);
         return;
     }
     const MwBlk &k = q.blk[blockIdx.x];

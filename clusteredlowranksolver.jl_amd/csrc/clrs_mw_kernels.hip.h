@@ -496,48 +496,53 @@ __global__ __launch_bounds__(MW_PT) void k_mw_potrf_x(const MwDev q, const doubl
 // These are the reference's part_r products (src/solver.jl:1125, 1137) with X^-1 = L^-T L^-1 split over the two sides
 // of the pairing: V^T X^-1 V = Z^T Z, so the explicit inverse (inv_cho_precomp!, :1117) is never formed.
 // ---------------------------------------------------------------------------------------------------------------------
+// T[:, c] = Y[:, rows(c)] V[rows(c), c] and (inverse factors) Z[:, c] = Xi V[:, c] for the columns c0 .. c0 + nc - 1: ZW lanes per entry
+template <int K, int DK, int ZW>
+__device__ __forceinline__ void mw_zt_products(const MwDev &q, const MwBlk &k, const double *__restrict__ Y, int c0, int nc, bool with_z) {
+    using namespace mwk;
+    const int n = k.n, tid = threadIdx.x, dl = k.delta, sub = tid % ZW;
+    const double *V = q.V + k.v_off;
+    const int *vrow = q.vrow + k.vrow_off;
+    for (int e0 = 0; e0 < n * nc; e0 += MW_NT / ZW) {
+        const int e = e0 + tid / ZW;
+        const bool live = e < n * nc;
+        const int ee = live ? e : 0;
+        const int i = ee % n, c = c0 + ee / n, r0 = vrow[c];
+        acc<K> s;
+        acc_zero<K>(s);
+        for (int kk = r0 + sub; kk < r0 + dl; kk += ZW) acc_fma<K, K, DK>(s, ldx<K>(Y + k.xyoff, q.xylen, i + (long)kk * n), ldx<DK>(V, q.Vp, kk + (long)c * n));
+        mw<K> v = lanes_sum<K, ZW>(acc_result<K>(s));
+        if (live && sub == 0) stx<K>(q.Tm + k.z_off, q.zlen, i + (long)c * n, v);
+    }
+    if (!with_z) return;
+    const double *Xi = q.Xi + k.xyoff;                 // rows above the first nonzero row of the vector are zero
+    for (int e0 = 0; e0 < n * nc; e0 += MW_NT / ZW) {
+        const int e = e0 + tid / ZW;
+        const bool live = e < n * nc;
+        const int ee = live ? e : 0;
+        const int i = ee % n, c = c0 + ee / n, r0 = vrow[c];
+        acc<K> s;
+        acc_zero<K>(s);
+        for (int kk = r0 + sub; kk <= i; kk += ZW) acc_fma<K, K, DK>(s, ldx<K>(Xi, q.xylen, i + (long)kk * n), ldx<DK>(V, q.Vp, kk + (long)c * n));
+        mw<K> v = lanes_sum<K, ZW>(acc_result<K>(s));
+        if (live && sub == 0) stx<K>(q.Z + k.z_off, q.zlen, i + (long)c * n, v);
+    }
+}
+// ct: columns of V per workgroup -- MW_CT with two lanes per entry, or (ct = 2, small launches with inverse factors: the named problems have twelve
+// workgroups of eight columns) two columns with eight lanes per entry: a quarter of the multiply-adds per lane
 template <int K, int DK>
-__global__ __launch_bounds__(MW_NT) void k_mw_zt(const MwDev q, const double *__restrict__ Y, int lds_L, int use_inv) {
+__global__ __launch_bounds__(MW_NT) void k_mw_zt(const MwDev q, const double *__restrict__ Y, int lds_L, int use_inv, int ct) {
     using namespace mwk;
     if (q.mws_on && q.mws_off[q.lr_list[blockIdx.y]] >= 0) return;      // k_mws_pair forms the pairing matrices of this block
     const MwBlk &k = q.blk[q.lr_list[blockIdx.y]];
-    const int n = k.n, U = k.U, tid = threadIdx.x, dl = k.delta;
-    const int c0 = blockIdx.x * MW_CT;
+    const int n = k.n, U = k.U, tid = threadIdx.x;
+    const int c0 = blockIdx.x * ct;
     if (c0 >= U) return;
-    const int nc = min(MW_CT, U - c0);
+    const int nc = min(ct, U - c0);
     const double *V = q.V + k.v_off;
-    const int *vrow = q.vrow + k.vrow_off;
-    // T[:, c] = Y[:, rows(c)] V[rows(c), c]: two lanes per entry
-    {
-        const int sub = tid & 1;
-        for (int e0 = 0; e0 < n * nc; e0 += MW_NT / 2) {
-            const int e = e0 + (tid >> 1);
-            const bool live = e < n * nc;
-            const int ee = live ? e : 0;
-            const int i = ee % n, c = c0 + ee / n, r0 = vrow[c];
-            acc<K> s;
-            acc_zero<K>(s);
-            for (int kk = r0 + sub; kk < r0 + dl; kk += 2) acc_fma<K, K, DK>(s, ldx<K>(Y + k.xyoff, q.xylen, i + (long)kk * n), ldx<DK>(V, q.Vp, kk + (long)c * n));
-            mw<K> v = lanes_sum<K, 2>(acc_result<K>(s));
-            if (live && sub == 0) stx<K>(q.Tm + k.z_off, q.zlen, i + (long)c * n, v);
-        }
-    }
-    if (use_inv && k.inv) {                 // Z[:, c] = Xi V[:, c]: rows above the first nonzero row of the vector are zero
-        const double *Xi = q.Xi + k.xyoff;
-        const int sub = tid & 1;
-        for (int e0 = 0; e0 < n * nc; e0 += MW_NT / 2) {
-            const int e = e0 + (tid >> 1);
-            const bool live = e < n * nc;
-            const int ee = live ? e : 0;
-            const int i = ee % n, c = c0 + ee / n, r0 = vrow[c];
-            acc<K> s;
-            acc_zero<K>(s);
-            for (int kk = r0 + sub; kk <= i; kk += 2) acc_fma<K, K, DK>(s, ldx<K>(Xi, q.xylen, i + (long)kk * n), ldx<DK>(V, q.Vp, kk + (long)c * n));
-            mw<K> v = lanes_sum<K, 2>(acc_result<K>(s));
-            if (live && sub == 0) stx<K>(q.Z + k.z_off, q.zlen, i + (long)c * n, v);
-        }
-        return;
-    }
+    if (ct != MW_CT) { mw_zt_products<K, DK, 8>(q, k, Y, c0, nc, true); return; }      // (launched so only when every block has its inverse factor)
+    mw_zt_products<K, DK, 2>(q, k, Y, c0, nc, use_inv && k.inv);
+    if (use_inv && k.inv) return;
     // Z tile in LDS: forward substitution with the row-scaled factor of X_b
     lds_d *Zt = MW_LDS;
     const long zp = (long)n * MW_CT;
