@@ -1047,7 +1047,8 @@ extern "C" int clrs_mw_schur_factor_local_dev(clrs_mw_ctx *c) {
         if (q.N > 0)
             hipLaunchKernelGGL((k_mw_linvb<KK, DD>), dim3((c->maxP * q.N + MW_NT / MW_LBI_W - 1) / (MW_NT / MW_LBI_W), q.J), dim3(MW_NT), 0, c->stream, q);
         if (c->timing) (void)hipEventRecord(c->ev[3], c->stream);
-        if (q.N > 0) hipLaunchKernelGGL(k_mw_qgram<KK>, dim3((q.N * (q.N + 1) / 2 + MW_NT / MW_Q_W - 1) / (MW_NT / MW_Q_W)), dim3(MW_NT), 0, c->stream, q);
+        const int qw = (i64)q.N * (q.N + 1) / 2 * 32 <= 32768 && q.xlen >= 32 ? 32 : MW_Q_W;      // lanes per entry of Q
+        if (q.N > 0) hipLaunchKernelGGL(k_mw_qgram<KK>, dim3((q.N * (q.N + 1) / 2 + MW_NT / qw - 1) / (MW_NT / qw)), dim3(MW_NT), 0, c->stream, q, qw);
         if (c->timing) (void)hipEventRecord(c->ev[4], c->stream);
     });
     MWCHECK(hipGetLastError());

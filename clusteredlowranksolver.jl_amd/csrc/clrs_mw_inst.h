@@ -8,7 +8,7 @@
 #define MW_KERNELS_K(X, K)                                                                                             \
     X __global__ void k_mw_potrf_x<K>(const MwDev, const double *, double *, int, const double *, double *, int *);    \
     X __global__ void k_mw_factor<K>(const MwDev);                                                                     \
-    X __global__ void k_mw_qgram<K>(const MwDev);                                                                      \
+    X __global__ void k_mw_qgram<K>(const MwDev, int);                                                                 \
     X __global__ void k_mw_potrf_q<K>(const MwDev, int, const double *);                                                               \
     X __global__ void k_mw_qsum<K>(const MwDev);                                                                       \
     X __global__ void k_mw_bp_diag<K>(const MwDev, const MwBp *, int, int);                                             \

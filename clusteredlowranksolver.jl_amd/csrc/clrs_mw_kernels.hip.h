@@ -984,25 +984,32 @@ __global__ __launch_bounds__(MW_NT) void k_mw_linvb(const MwDev q) {
 
 // Q = sum_j LinvB_j^T LinvB_j = LB^T LB over the stacked rows (src/solver.jl:1264-1271): eight lanes per entry a >= b
 #define MW_Q_W 8
-template <int K>
-__global__ __launch_bounds__(MW_NT) void k_mw_qgram(const MwDev q) {
+template <int K, int W>
+__device__ __forceinline__ void mw_qgram_body(const MwDev &q) {
     using namespace mwk;
     const int N = q.N;
-    const int e = blockIdx.x * (MW_NT / MW_Q_W) + threadIdx.x / MW_Q_W, sub = threadIdx.x % MW_Q_W;
+    const int e = blockIdx.x * (MW_NT / W) + threadIdx.x / W, sub = threadIdx.x % W;
     const int tot = N * (N + 1) / 2;
+    if (blockIdx.x * (MW_NT / W) >= tot) return;
     const bool live = e < tot;
     int a, b;
     tri_index(live ? e : 0, a, b);
     const long plane = q.xlen * (long)N;
     acc<K> s;
     acc_zero<K>(s);
-    for (long r = sub; r < q.xlen; r += MW_Q_W) acc_fma<K, K, K>(s, ldx<K>(q.LB, plane, r + a * q.xlen), ldx<K>(q.LB, plane, r + b * q.xlen));
-    mw<K> v = lanes_sum<K, MW_Q_W>(acc_result<K>(s));
+    for (long r = sub; r < q.xlen; r += W) acc_fma<K, K, K>(s, ldx<K>(q.LB, plane, r + a * q.xlen), ldx<K>(q.LB, plane, r + b * q.xlen));
+    mw<K> v = lanes_sum<K, W>(acc_result<K>(s));
     if (live && sub == 0) {
         double *Qp = q.Qg + (long)q.rank * K * N * N;                 // this rank's partial sum over its clusters
         stx<K>(Qp, (long)N * N, a + (long)b * N, v);
         stx<K>(Qp, (long)N * N, b + (long)a * N, v);
     }
+}
+// lanes: 8, or 32 while the launch stays small (a few hundred entries: more workgroups with a quarter of the multiply-adds per lane)
+template <int K>
+__global__ __launch_bounds__(MW_NT) void k_mw_qgram(const MwDev q, int lanes) {
+    if (lanes == 32) mw_qgram_body<K, 32>(q);
+    else mw_qgram_body<K, MW_Q_W>(q);
 }
 
 template <int K>
