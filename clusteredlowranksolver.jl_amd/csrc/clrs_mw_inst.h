@@ -51,6 +51,7 @@
     X __global__ void k_mwi_MV<K, DK>(const MwDev, const double *);                                                    \
     X __global__ void k_mwi_rows_dn<K, DK>(const MwDev, const MwIpmDev, int);                                          \
     X __global__ void k_mwi_rows<K, DK>(const MwDev, const MwIpmDev, int, int);                                        \
+    X __global__ void k_mwi_rows_fwd<K, DK>(const MwDev, const MwIpmDev);                                              \
     X __global__ void k_mwi_pv<K, DK>(const MwDev, const MwIpmDev, int);                                               \
     X __global__ void k_mwi_pvfin<K, DK>(const MwDev, const MwIpmDev);                                                 \
     X __global__ void k_mwi_gpack<K, DK>(const MwDev, const MwIpmDev, int);                                               \

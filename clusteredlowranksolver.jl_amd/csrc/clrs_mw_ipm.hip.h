@@ -707,12 +707,10 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_rows_dn(const MwDev q, const MwIp
 // BG groups of MWI_RW lanes per row, each group taking every BG-th PSD block of the row's cluster: a cluster of dozens of blocks (the three-point
 // bound: 43) is otherwise a chain of as many dependent dot products per row, on seven workgroups
 template <int K, int DK, int BG>
-__device__ __forceinline__ void mwi_rows_body(const MwDev &q, const MwIpmDev &p, int mode) {
+__device__ __forceinline__ void mwi_rows_body(const MwDev &q, const MwIpmDev &p, int mode, mwi64 g0, bool live) {
     using namespace mwk;
     constexpr int RWT = MWI_RW * BG;                        // lanes per row
-    const mwi64 g0 = (mwi64)blockIdx.x * (MW_NT / RWT) + threadIdx.x / RWT;
     const int sub = threadIdx.x % MWI_RW, grp = (threadIdx.x % RWT) / MWI_RW, sub_all = threadIdx.x % RWT;
-    const bool live = g0 < q.xlen;
     const mwi64 g = live ? g0 : 0;
     const int j = p.row_clu[g];
     const MwClu &cl = q.clu[j];
@@ -771,8 +769,21 @@ __device__ __forceinline__ void mwi_rows_body(const MwDev &q, const MwIpmDev &p,
 }
 template <int K, int DK>
 __global__ __launch_bounds__(MW_NT) void k_mwi_rows(const MwDev q, const MwIpmDev p, int mode, int groups) {
-    if (groups == 8) mwi_rows_body<K, DK, 8>(q, p, mode);
-    else mwi_rows_body<K, DK, 1>(q, p, mode);
+    if (groups == 8) { const mwi64 g0 = (mwi64)blockIdx.x * (MW_NT / (MWI_RW * 8)) + threadIdx.x / (MWI_RW * 8); mwi_rows_body<K, DK, 8>(q, p, mode, g0, g0 < q.xlen); }
+    else { const mwi64 g0 = (mwi64)blockIdx.x * (MW_NT / MWI_RW) + threadIdx.x / MWI_RW; mwi_rows_body<K, DK, 1>(q, p, mode, g0, g0 < q.xlen); }
+}
+// rhs_x of the corrector and the first product pair of its solve in one launch, per cluster: the rows of a cluster are all its workgroup of the
+// solve needs (small unsharded systems; one launch less on the chain of the iteration)
+template <int K, int DK>
+__global__ __launch_bounds__(MW_NT) void k_mwi_rows_fwd(const MwDev q, const MwIpmDev p) {
+    const MwClu &c = q.clu[blockIdx.x];
+    for (int r0 = 0; r0 < c.P; r0 += MW_NT / MWI_RW) {
+        const int r = r0 + threadIdx.x / MWI_RW;
+        mwi_rows_body<K, DK, 1>(q, p, 1, c.coff + r, r < c.P);
+    }
+    __threadfence_block();
+    __syncthreads();
+    mw_solve_fwd_cluster<K>(q, blockIdx.x, p.rhsx);
 }
 
 // ---- this rank's slot of a gather buffer (cluster sharding): one workgroup, the first wave --------------------------------------
