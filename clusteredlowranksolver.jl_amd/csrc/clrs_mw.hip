@@ -1065,7 +1065,7 @@ extern "C" int clrs_mw_schur_factor_finish_dev(clrs_mw_ctx *c) {
     const MwDev &q = c->d;
     if (q.N > 0 && c->lds_q) {
         // the interior-point iteration hands over the right-hand side of its next solve: the solve's first product pair rides on this launch
-        const bool ride = c->ride_fwd != nullptr && !q.gathered && !c->wide_solve;
+        const bool ride = c->ride_fwd != nullptr && !c->wide_solve;
         MW_DISPATCH(c, { hipLaunchKernelGGL(k_mw_potrf_q<KK>, dim3(MW_INV_WG + (ride ? q.J : 0)), dim3(MW_PT), ride ? std::max(c->sm_q, c->sm_fwd) : c->sm_q, c->stream, q, MW_INV_WG, c->ride_fwd); });
         c->fwd_rode = ride;
     } else if (q.N > 0) {
@@ -1153,8 +1153,14 @@ extern "C" int clrs_mw_schur_solve_dev(clrs_mw_ctx *c, const double *d_rhs_x, co
         return 0;
     }
     int rc = 0;
-    if (c->fwd_rode) { c->fwd_rode = false; c->fwd_done = true; }      // t_j, u_j of this right-hand side are there already (k_mw_potrf_q's launch)
-    else rc = clrs_mw_schur_solve_fwd_dev(c, d_rhs_x);
+    if (c->fwd_rode) {                                   // t_j, u_j of this right-hand side are there already (k_mw_potrf_q's launch, or k_mwi_rows_fwd)
+        c->fwd_rode = false;
+        c->fwd_done = true;
+        if (q.gathered && q.N > 0) {                     // sharded: this rank's partial u into its gather slot, as clrs_mw_schur_solve_fwd_dev does behind its launch
+            MW_DISPATCH(c, hipLaunchKernelGGL(k_mw_usum<KK>, dim3(1), dim3(MW_NT), 0, c->stream, q));
+            MWCHECK(hipGetLastError());
+        }
+    } else rc = clrs_mw_schur_solve_fwd_dev(c, d_rhs_x);
     if (rc) return rc;
     if (q.gathered && q.N > 0) {
         int rc2 = mw_allgather(c, 0, q.ug, (size_t)q.N * c->K, c->stream);
