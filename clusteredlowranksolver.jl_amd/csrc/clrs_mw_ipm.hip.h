@@ -22,6 +22,7 @@ struct MwIpmDev {
     double *Zt;                        // second scratch of the tiled form of the same products (k_mwi_bmm; xy layout)
     double *wB;                        // [T * wBn] K limbs: coefficient times right vector of every term, for blocks with many terms (k_mwi_wB)
     int *zcnt;                         // [NB] workgroups of a block that have delivered their panel
+    unsigned long long *stamps;        // diagnostic (clrs_mw_debug_exact_stamps): wall_clock64 at the phase boundaries of k_mwi_Zi, wave 0 of the first workgroup, or null
     double *dtr;                       // [xlen] dense part of the row traces <A_*, M> (k_mwi_rows_dn), when some dense block has n > 1
     double *sc, *part;                 // planar scalars [MSC_COUNT]; partial dot products [5][NB]
     unsigned long long *fmax;          // bit patterns of non-negative doubles: [0] max|P|, [1] max|d|, [2] max|p|
@@ -934,6 +935,10 @@ __global__ __launch_bounds__(MW_PT) void k_mwi_Zi(const MwDev q, const MwIpmDev 
     lds_d *M = MW_LDS, *M2 = M + (long)K * np;
     const double *A = (which == 0 ? p.Pm : p.dX) + k.xyoff, *Xi = q.Xi + k.xyoff;
     const double sg = which == 0 ? 1.0 : -1.0;
+    const bool stamp = p.stamps && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0;
+    int nst = 0;
+#define MWZ_STAMP() do { if (stamp) p.stamps[nst++] = wall_clock64(); } while (0)
+    MWZ_STAMP();
     for (int e0 = 0; e0 < n * pc; e0 += MW_PT / MWI_ZL) {  // M = sg (A Y - R)
         const int e = e0 + tid / MWI_ZL;
         const bool live = e < n * pc;
@@ -947,6 +952,7 @@ __global__ __launch_bounds__(MW_PT) void k_mwi_Zi(const MwDev q, const MwIpmDev 
         if (live && sub == 0) stx<K>(M, np, ee, v);
     }
     __syncthreads();
+    MWZ_STAMP();
     for (int e0 = 0; e0 < n * pc; e0 += MW_PT / MWI_ZL) {  // M2 = Xi M
         const int e = e0 + tid / MWI_ZL;
         const bool live = e < n * pc;
@@ -958,6 +964,7 @@ __global__ __launch_bounds__(MW_PT) void k_mwi_Zi(const MwDev q, const MwIpmDev 
         if (live && sub == 0) stx<K>(M2, np, ee, v);
     }
     __syncthreads();
+    MWZ_STAMP();
     for (int e0 = 0; e0 < n * pc; e0 += MW_PT / MWI_ZL) {  // Xi^T M2 -> scratch
         const int e = e0 + tid / MWI_ZL;
         const bool live = e < n * pc;
@@ -968,7 +975,9 @@ __global__ __launch_bounds__(MW_PT) void k_mwi_Zi(const MwDev q, const MwIpmDev 
         const mw<K> v = lanes_sum<K, MWI_ZL>(acc_result<K>(s));
         if (live && sub == 0) stx<K>(p.Zs + k.xyoff, q.xylen, i + (long)(c0 + cl) * n, v);
     }
+    MWZ_STAMP();
     if (!mwi_last_block(&p.zcnt[blockIdx.x], zs)) return;
+    MWZ_STAMP();
     for (int e = tid; e < n * n; e += MW_PT) {
         const int i = e % n, c = e / n;
         if (c > i) continue;
@@ -976,6 +985,8 @@ __global__ __launch_bounds__(MW_PT) void k_mwi_Zi(const MwDev q, const MwIpmDev 
         stx<K>(p.dY + k.xyoff, q.xylen, i + (long)c * n, v);
         stx<K>(p.dY + k.xyoff, q.xylen, c + (long)i * n, v);
     }
+    MWZ_STAMP();
+#undef MWZ_STAMP
 }
 
 // The same three products for LARGE blocks (sides beyond ~24), as launches of their own over 8 x 8 output tiles, four lanes per entry: a column panel
