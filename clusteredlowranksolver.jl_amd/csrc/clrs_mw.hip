@@ -36,6 +36,7 @@ MW_KERNELS_ALL(extern template, 10)
 
 typedef long long i64;
 
+extern int g_cfg_mw_refine;                              // clrs_hip.hip, clrs_config_set("mw_refine", 0 / 1): read at context creation
 extern int g_cfg_mw_exact_products;                      // clrs_hip.hip, clrs_config_set("mw_exact_products", 0 / 1 / 2): read at context creation
 extern "C" void clrs_set_last_error(const char *msg);   // clrs_hip.hip: the library keeps one thread-local message
 
@@ -158,6 +159,7 @@ struct clrs_mw_ctx {
     int mws_blocks = 0;                  // how many
     int mws_turns = 1;                   // 2: some eligible block has more than four T / Z tiles
     size_t sm_mws = 0;
+    int refine = 1;                      // steps of iterative refinement of the solve stage (clrs_config_set("mw_refine", 0 / 1))
     bool ipm_arms_info = false;          // inside the device-resident iteration the status words are re-armed by a kernel, not by a memset per call
 };
 
@@ -443,7 +445,8 @@ extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int dev
         }
         c->sm_factor = std::max<size_t>(fmax, 1) * 8;
         c->nw_factor = std::max(1, std::min(MW_INV_WG, 256 / std::max(J, 1)));     // only while the clusters leave compute units idle
-        c->sm_fwd = c->sm_bwd = 2 * (size_t)c->maxP * K * 8;
+        c->sm_fwd = 2 * (size_t)c->maxP * K * 8;
+        c->sm_bwd = 3 * (size_t)c->maxP * K * 8;              // (three vectors: the refinement's first half rides on the backward launch)
         const size_t qn = (size_t)N * N * K;
         const size_t qneed = qn + (size_t)MW_TRI(N) * K + MW_POTRF_SCR(K, (size_t)N);
         c->lds_q = qneed <= lim;
@@ -453,8 +456,14 @@ extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int dev
     }
     MW_DISPATCH(c, {
         MW_TRY(mw_set_lds(k_mw_potrf_x<KK>, c->sm_x)); MW_TRY(mw_set_lds(k_mw_zt<KK, DD>, c->sm_zt)); MW_TRY(mw_set_lds((k_mw_dense_t<KK, DD>), c->sm_dense));
-        MW_TRY(mw_set_lds(k_mw_factor<KK>, c->sm_factor)); MW_TRY(mw_set_lds(k_mw_potrf_q<KK>, std::max(c->sm_q, c->sm_fwd)));
-        MW_TRY(mw_set_lds(k_mw_solve_fwd<KK>, c->sm_fwd)); MW_TRY(mw_set_lds(k_mw_solve_mid<KK>, c->sm_mid)); MW_TRY(mw_set_lds(k_mw_solve_bwd<KK>, c->sm_mid + c->sm_bwd));
+        // (only what can be launched: Q beyond LDS never rides k_mw_potrf_q, and systems whose dy and three cluster vectors exceed LDS take the
+        // row-parallel solve (k_mw_solve_wide) -- sharded, they are refused at the launch, not here)
+        constexpr int KC = mw_kc(KK);
+        const size_t bw = std::min(c->sm_mid + c->sm_bwd, MW_LDS_MAX);
+        MW_TRY(mw_set_lds(k_mw_factor<KK>, c->sm_factor)); MW_TRY(mw_set_lds(k_mw_potrf_q<KK>, c->lds_q ? std::max(c->sm_q, c->sm_fwd) : c->sm_fwd));
+        MW_TRY(mw_set_lds(k_mw_solve_fwd<KK>, c->sm_fwd)); MW_TRY(mw_set_lds((k_mw_solve_mid<KK, KK>), c->sm_mid)); MW_TRY(mw_set_lds((k_mw_solve_mid<KK, KC>), c->sm_mid));
+        MW_TRY(mw_set_lds((k_mw_solve_bwd<KK, KK, DD, 0>), bw)); MW_TRY(mw_set_lds((k_mw_solve_bwd<KK, KK, DD, 1>), bw)); MW_TRY(mw_set_lds((k_mw_solve_bwd<KK, KK, DD, 2>), bw));
+        MW_TRY(mw_set_lds((k_mw_solve_bwd<KK, KC, DD, 1>), bw)); MW_TRY(mw_set_lds((k_mw_solve_bwd<KK, KC, DD, 2>), bw));
     });
     // ---- exact-product path (clrs_mw_exact.hip.h): static slices of V of the eligible blocks ----
     std::vector<long long> mws_off((size_t)std::max(NB, 1), -1);
@@ -691,6 +700,11 @@ extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int dev
     MW_TRY(mw_dmalloc(c, &q.xrd, rdoff * K)); MW_TRY(mw_dmalloc(c, &q.srd, xlen * K)); MW_TRY(mw_dmalloc(c, &q.qrd, (i64)N * K));
     MW_TRY(mw_dmalloc(c, &q.t, xlen * K)); MW_TRY(mw_dmalloc(c, &q.u, (i64)J * N * K)); MW_TRY(mw_dmalloc(c, &q.AY, T * K));
     MW_TRY(mw_dmalloc(c, &c->vz, 2 * (i64)N * K));
+    MW_TRY(mw_dmalloc(c, &q.S0, Slen * K)); MW_TRY(mw_dmalloc(c, &q.ub, (i64)J * N * K));
+    MW_TRY(mw_dmalloc(c, &q.rx2, xlen * K)); MW_TRY(mw_dmalloc(c, &q.dx2, xlen * K));
+    MW_TRY(mw_dmalloc(c, &q.u2, (i64)N * K)); MW_TRY(mw_dmalloc(c, &q.dy2, (i64)N * K));
+    q.uadd = nullptr;
+    c->refine = g_cfg_mw_refine;
     c->wide_solve = c->maxP > 64 || N > 64;
     MW_TRY(mw_dmalloc(c, &c->d_Xin, xyoff * K)); MW_TRY(mw_dmalloc(c, &c->d_Xc, xyoff * K)); MW_TRY(mw_dmalloc(c, &c->d_Y, xyoff * K));
     MW_TRY(mw_dmalloc(c, &c->d_rx, xlen * K)); MW_TRY(mw_dmalloc(c, &c->d_dx, xlen * K));
@@ -1110,49 +1124,89 @@ extern "C" int clrs_mw_schur_solve_fwd_dev(clrs_mw_ctx *c, const double *d_rhs_x
     c->fwd_done = true;
     return 0;
 }
+// the backward half: dy = Q^-1 (rhs_y - sum u), dx_j = L_j^-T (t_j + LinvB_j dy).  mode 0: plain; 1: followed by the first half of the refinement step
+// (residuals, t', u' into q.t, q.ub); 2: the correction's backward half, added to dx, dy (k_mw_solve_bwd).  full_kc: the correction in all K limbs.
+#define MW_BWD(KCC, MODE) hipLaunchKernelGGL((k_mw_solve_bwd<KK, KCC, DD, MODE>), dim3(q.J), dim3(MW_NT), lds, c->stream, q, (const double *)dy_mid, d_dx, mid, d_dy, d_rhs_x)
+static int mw_solve_bwd(clrs_mw_ctx *c, const MwDev &q, const double *d_rhs_x, const double *d_rhs_y, double *d_dx, double *d_dy, int mode, bool full_kc) {
+    if (c->sm_mid + c->sm_bwd > MW_LDS_MAX) return mw_fail(CLRS_ERR_INVALID, "system too large for the one-workgroup-per-cluster solve kernels (a sharded solve with clusters + free variables beyond LDS)");
+    const size_t lds = c->sm_mid + c->sm_bwd;
+    MW_DISPATCH(c, {
+        constexpr int KC = mw_kc(KK);
+        // few clusters, one rank: dy is formed by every workgroup of the backward launch itself (one launch less on the chain of the iteration)
+        const bool mid_in_bwd = q.N > 0 && !q.gathered && q.J <= 4;
+        double *dy_mid = mode == 2 ? q.dy2 : d_dy;          // (the correction dy' has a buffer of its own; the backward launch adds it)
+        if (q.N > 0 && !mid_in_bwd) {
+            if (mode == 2 && !full_kc) hipLaunchKernelGGL((k_mw_solve_mid<KK, KC>), dim3(1), dim3(MW_NT), c->sm_mid, c->stream, q, d_rhs_y, dy_mid);
+            else hipLaunchKernelGGL((k_mw_solve_mid<KK, KK>), dim3(1), dim3(MW_NT), c->sm_mid, c->stream, q, d_rhs_y, dy_mid);
+        }
+        const double *mid = mid_in_bwd ? d_rhs_y : (const double *)nullptr;
+        if (mode == 0) MW_BWD(KK, 0);
+        else if (mode == 1) { if (full_kc) MW_BWD(KK, 1); else MW_BWD(KC, 1); }
+        else { if (full_kc) MW_BWD(KK, 2); else MW_BWD(KC, 2); }
+    });
+#undef MW_BWD
+    MWCHECK(hipGetLastError());
+    return 0;
+}
 extern "C" int clrs_mw_schur_solve_bwd_dev(clrs_mw_ctx *c, const double *d_rhs_y, double *d_dx, double *d_dy) {
     if (!c || !d_dx) return mw_fail(CLRS_ERR_INVALID, "null argument");
     if (!c->factored || !c->fwd_done) return mw_fail(CLRS_ERR_STATE, "clrs_mw_schur_solve_bwd before clrs_mw_schur_factor_finish / clrs_mw_schur_solve_fwd");
     const MwDev &q = c->d;
     if (q.N > 0 && (!d_rhs_y || !d_dy)) return mw_fail(CLRS_ERR_INVALID, "null argument");
     MWCHECK(hipSetDevice(c->device));
-    MW_DISPATCH(c, {
-        // few clusters, one rank: dy is formed by every workgroup of the backward launch itself (one launch less on the chain of the iteration)
-        const bool mid_in_bwd = q.N > 0 && !q.gathered && q.J <= 4 && c->sm_mid + c->sm_bwd <= MW_LDS_MAX;
-        if (q.N > 0 && !mid_in_bwd) hipLaunchKernelGGL(k_mw_solve_mid<KK>, dim3(1), dim3(MW_NT), c->sm_mid, c->stream, q, d_rhs_y, d_dy);
-        hipLaunchKernelGGL(k_mw_solve_bwd<KK>, dim3(q.J), dim3(MW_NT), mid_in_bwd ? c->sm_mid + c->sm_bwd : c->sm_bwd, c->stream, q, (const double *)d_dy, d_dx,
-                           mid_in_bwd ? d_rhs_y : (const double *)nullptr, d_dy);
-    });
-    MWCHECK(hipGetLastError());
+    int rc = mw_solve_bwd(c, q, nullptr, d_rhs_y, d_dx, d_dy, 0, false);
+    if (rc) return rc;
     if (c->timing) MWCHECK(hipEventRecord(c->ev[7], c->stream));
     c->fwd_done = false;
     return 0;
 }
+// one pass of the row-parallel solve (clusters or a Q beyond 64 rows, one rank): a launch per product
+static int mw_solve_wide_once(clrs_mw_ctx *c, const double *d_rhs_x, const double *d_rhs_y, double *d_dx, double *d_dy) {
+    const MwDev &q = c->d;
+    constexpr int RPW = MW_NT / MW_SW_L;
+    const dim3 gP((c->maxP + RPW - 1) / RPW, q.J), gN((q.N + RPW - 1) / RPW), gX((unsigned)((q.xlen + RPW - 1) / RPW));
+    MW_DISPATCH(c, {
+        hipLaunchKernelGGL(k_mw_solve_wide<KK>, gP, dim3(MW_NT), 0, c->stream, q, 1, d_rhs_x, d_rhs_y, d_dx, d_dy, c->vz);
+        if (q.N > 0) {
+            hipLaunchKernelGGL(k_mw_solve_wide<KK>, gN, dim3(MW_NT), 0, c->stream, q, 2, d_rhs_x, d_rhs_y, d_dx, d_dy, c->vz);
+            hipLaunchKernelGGL(k_mw_solve_wide<KK>, gN, dim3(MW_NT), 0, c->stream, q, 3, d_rhs_x, d_rhs_y, d_dx, d_dy, c->vz);
+            hipLaunchKernelGGL(k_mw_solve_wide<KK>, gN, dim3(MW_NT), 0, c->stream, q, 4, d_rhs_x, d_rhs_y, d_dx, d_dy, c->vz);
+            hipLaunchKernelGGL(k_mw_solve_wide<KK>, gX, dim3(MW_NT), 0, c->stream, q, 5, d_rhs_x, d_rhs_y, d_dx, d_dy, c->vz);
+        }
+        hipLaunchKernelGGL(k_mw_solve_wide<KK>, gP, dim3(MW_NT), 0, c->stream, q, 6, d_rhs_x, d_rhs_y, d_dx, d_dy, c->vz);
+    });
+    MWCHECK(hipGetLastError());
+    return 0;
+}
+// The solve stage (src/solver.jl:1527-1582): one pass of products with the inverse factors, then (c->refine, the default) one step of iterative
+// refinement against the assembled S_j and B (k_mw_refine's header): the backward error of the reference's substitutions at the latency of products.
 extern "C" int clrs_mw_schur_solve_dev(clrs_mw_ctx *c, const double *d_rhs_x, const double *d_rhs_y, double *d_dx, double *d_dy) {
     if (!c || !d_rhs_x || !d_dx) return mw_fail(CLRS_ERR_INVALID, "null argument");
     if (!c->factored) return mw_fail(CLRS_ERR_STATE, "clrs_mw_schur_solve before clrs_mw_schur_factor");
-    const MwDev &q = c->d;
+    MwDev &q = c->d;
+    if (q.N > 0 && (!d_rhs_y || !d_dy)) return mw_fail(CLRS_ERR_INVALID, "null argument");
+    MWCHECK(hipSetDevice(c->device));
+    int rc = 0;
     if (c->wide_solve && !q.gathered) {                  // large clusters or a large Q: one launch per product, rows over many workgroups
-        if (q.N > 0 && (!d_rhs_y || !d_dy)) return mw_fail(CLRS_ERR_INVALID, "null argument");
-        MWCHECK(hipSetDevice(c->device));
         if (c->timing) MWCHECK(hipEventRecord(c->ev[6], c->stream));
-        constexpr int RPW = MW_NT / MW_SW_L;
-        const dim3 gP((c->maxP + RPW - 1) / RPW, q.J), gN((q.N + RPW - 1) / RPW), gX((unsigned)((q.xlen + RPW - 1) / RPW));
-        MW_DISPATCH(c, {
-            hipLaunchKernelGGL(k_mw_solve_wide<KK>, gP, dim3(MW_NT), 0, c->stream, q, 1, d_rhs_x, d_rhs_y, d_dx, d_dy, c->vz);
-            if (q.N > 0) {
-                hipLaunchKernelGGL(k_mw_solve_wide<KK>, gN, dim3(MW_NT), 0, c->stream, q, 2, d_rhs_x, d_rhs_y, d_dx, d_dy, c->vz);
-                hipLaunchKernelGGL(k_mw_solve_wide<KK>, gN, dim3(MW_NT), 0, c->stream, q, 3, d_rhs_x, d_rhs_y, d_dx, d_dy, c->vz);
-                hipLaunchKernelGGL(k_mw_solve_wide<KK>, gN, dim3(MW_NT), 0, c->stream, q, 4, d_rhs_x, d_rhs_y, d_dx, d_dy, c->vz);
-                hipLaunchKernelGGL(k_mw_solve_wide<KK>, gX, dim3(MW_NT), 0, c->stream, q, 5, d_rhs_x, d_rhs_y, d_dx, d_dy, c->vz);
-            }
-            hipLaunchKernelGGL(k_mw_solve_wide<KK>, gP, dim3(MW_NT), 0, c->stream, q, 6, d_rhs_x, d_rhs_y, d_dx, d_dy, c->vz);
-        });
-        MWCHECK(hipGetLastError());
+        if ((rc = mw_solve_wide_once(c, d_rhs_x, d_rhs_y, d_dx, d_dy))) return rc;
+        if (c->refine) {
+            constexpr int RPW = MW_NT / MW_SW_L;
+            const int rowsP = (c->maxP + RPW - 1) / RPW, rowsN = (q.N + RPW - 1) / RPW;
+            MW_DISPATCH(c, hipLaunchKernelGGL((k_mw_refine<KK, DD>), dim3(std::max(rowsP, rowsN), q.J + (q.N > 0 ? 1 : 0)), dim3(MW_NT), 0, c->stream, q, 1, d_rhs_x, d_dx, d_dy));
+            MWCHECK(hipGetLastError());
+            q.uadd = q.N > 0 ? q.u2 : nullptr;
+            rc = mw_solve_wide_once(c, q.rx2, d_rhs_y, q.dx2, q.dy2);
+            q.uadd = nullptr;
+            if (rc) return rc;
+            MW_DISPATCH(c, hipLaunchKernelGGL((k_mw_refine<KK, DD>), dim3((unsigned)std::min<i64>(256, (q.xlen + q.N + MW_NT - 1) / MW_NT)), dim3(MW_NT), 0, c->stream, q, 3, d_rhs_x, d_dx, d_dy));
+            MWCHECK(hipGetLastError());
+        }
         if (c->timing) MWCHECK(hipEventRecord(c->ev[7], c->stream));
         return 0;
     }
-    int rc = 0;
+    // one workgroup per cluster: forward half (unless it rode on an earlier launch), [exchange of the partial u], backward half; the refinement's
+    // residuals and forward half ride on the backward launch, its backward half is one more launch [and one more exchange]
     if (c->fwd_rode) {                                   // t_j, u_j of this right-hand side are there already (k_mw_potrf_q's launch, or k_mwi_rows_fwd)
         c->fwd_rode = false;
         c->fwd_done = true;
@@ -1162,11 +1216,21 @@ extern "C" int clrs_mw_schur_solve_dev(clrs_mw_ctx *c, const double *d_rhs_x, co
         }
     } else rc = clrs_mw_schur_solve_fwd_dev(c, d_rhs_x);
     if (rc) return rc;
+    if (q.gathered && q.N > 0 && (rc = mw_allgather(c, 0, q.ug, (size_t)q.N * c->K, c->stream))) return rc;
+    if (!c->refine) return clrs_mw_schur_solve_bwd_dev(c, d_rhs_y, d_dx, d_dy);
+    const bool full_kc = c->refine >= 2;
+    if ((rc = mw_solve_bwd(c, q, d_rhs_x, d_rhs_y, d_dx, d_dy, 1, full_kc))) return rc;
+    MwDev q2 = q;
+    q2.u = q.ub;                                         // (the first half of the step wrote its u' beside the u the other workgroups were still reading)
     if (q.gathered && q.N > 0) {
-        int rc2 = mw_allgather(c, 0, q.ug, (size_t)q.N * c->K, c->stream);
-        if (rc2) return rc2;
+        MW_DISPATCH(c, hipLaunchKernelGGL(k_mw_usum<KK>, dim3(1), dim3(MW_NT), 0, c->stream, q2));
+        MWCHECK(hipGetLastError());
+        if ((rc = mw_allgather(c, 0, q.ug, (size_t)q.N * c->K, c->stream))) return rc;
     }
-    return clrs_mw_schur_solve_bwd_dev(c, d_rhs_y, d_dx, d_dy);
+    if ((rc = mw_solve_bwd(c, q2, d_rhs_x, d_rhs_y, d_dx, d_dy, 2, full_kc))) return rc;
+    if (c->timing) MWCHECK(hipEventRecord(c->ev[7], c->stream));
+    c->fwd_done = false;
+    return 0;
 }
 
 extern "C" double *clrs_mw_S_buffer_dev(clrs_mw_ctx *c) { return c ? c->d.S : nullptr; }

@@ -18,8 +18,8 @@
     X __global__ void k_mw_bp_finish<K>(const MwDev, const MwBp *);                                                    \
     X __global__ void k_mw_usum<K>(const MwDev);                                                                       \
     X __global__ void k_mw_solve_fwd<K>(const MwDev, const double *);                                                  \
-    X __global__ void k_mw_solve_mid<K>(const MwDev, const double *, double *);                                        \
-    X __global__ void k_mw_solve_bwd<K>(const MwDev, const double *, double *, const double *, double *);                    \
+    X __global__ void k_mw_solve_mid<K, K>(const MwDev, const double *, double *);                                     \
+    X __global__ void k_mw_solve_mid<K, mw_kc(K)>(const MwDev, const double *, double *);                              \
     X __global__ void k_mw_solve_wide<K>(const MwDev, int, const double *, const double *, double *, double *, double *);\
     X __global__ void k_mw_xrd<K>(const MwDev, const double *);                                                        \
     X __global__ void k_mwi_R<K>(const MwDev, const MwIpmDev, int);                                                    \
@@ -43,6 +43,12 @@
     X __global__ void k_mw_saccum<K, DK>(const MwDev, int);                                                                 \
     X __global__ void k_mw_saccum_one<K, DK>(const MwDev, int);                                                             \
     X __global__ void k_mw_linvb<K, DK>(const MwDev);                                                                  \
+    X __global__ void k_mw_refine<K, DK>(const MwDev, int, const double *, double *, double *);                        \
+    X __global__ void k_mw_solve_bwd<K, K, DK, 0>(const MwDev, const double *, double *, const double *, double *, const double *);        \
+    X __global__ void k_mw_solve_bwd<K, K, DK, 1>(const MwDev, const double *, double *, const double *, double *, const double *);        \
+    X __global__ void k_mw_solve_bwd<K, K, DK, 2>(const MwDev, const double *, double *, const double *, double *, const double *);        \
+    X __global__ void k_mw_solve_bwd<K, mw_kc(K), DK, 1>(const MwDev, const double *, double *, const double *, double *, const double *); \
+    X __global__ void k_mw_solve_bwd<K, mw_kc(K), DK, 2>(const MwDev, const double *, double *, const double *, double *, const double *); \
     X __global__ void k_mwi_scalar<K, DK>(const MwDev, const MwIpmDev, int, int);                                      \
     X __global__ void k_mwi_dots<K, DK>(const MwDev, const MwIpmDev, int, int);                                             \
     X __global__ void k_mwi_coef<K, DK>(const MwDev, const MwIpmDev, const double *);                                  \

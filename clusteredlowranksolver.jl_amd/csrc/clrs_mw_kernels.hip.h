@@ -78,6 +78,12 @@ struct MwDev {
     double *Si, *Qi;                    // explicit inverses L_j^-1 (S layout) and L_Q^-1, lower triangular: every triangular solve with them is a product
     double *Xi;                         // chol(X_b)^-1 of the blocks with inv = 1 (xy layout)
     double *t, *u, *AY;                 // t = L^-1 rhs_x (xlen); u slabs (J x N); pairings per term
+    // iterative refinement of the solve stage over many workgroups (k_mw_refine): the residual r_x (xlen), B^T dx of this rank's rows (N), the
+    // correction (xlen, N); uadd: while the correction is solved, the vector subtracted from rhs_y beside sum_j u_j (= u2), else null
+    double *S0;                         // S_j as assembled (S layout): the factorisation overwrites S with L_j, the residuals of the refinement need S_j
+    double *ub;                         // u' slabs of the refinement step (J x N; k_mw_solve_bwd MODE 1 writes them while other workgroups read u)
+    double *rx2, *u2, *dx2, *dy2;
+    const double *uadd;
     int *info;                          // [0] factor status, [1] Cholesky-of-X status
     int *pcnt;                          // [2 J + 3] arrival counters of the workgroups that share one factorisation (cluster j; J: Q; J + 1 + slot: matrices of the blocked path)
     // cluster sharding over ranks (one process per GPU): this context holds the clusters of rank `rank`; the partial Q and the
@@ -809,6 +815,8 @@ __device__ __forceinline__ void mw_saccum_body(const MwDev &q) {
     if (live && sub == 0) {
         stx<K>(q.S + c.Soff, q.Slen, pp + (long)qq * P, v);
         stx<K>(q.S + c.Soff, q.Slen, qq + (long)pp * P, v);
+        stx<K>(q.S0 + c.Soff, q.Slen, pp + (long)qq * P, v);      // (the copy the factorisation leaves alone: residuals of the refined solve)
+        stx<K>(q.S0 + c.Soff, q.Slen, qq + (long)pp * P, v);
     }
 }
 template <int K, int DK>
@@ -912,6 +920,8 @@ __global__ __launch_bounds__(MW_NT) void k_mw_saccum_one(const MwDev q, int do_a
     const mw<K> v = acc_result<K>(s);
     stx<K>(q.S + c.Soff, q.Slen, pp + (long)qq * P, v);
     stx<K>(q.S + c.Soff, q.Slen, qq + (long)pp * P, v);
+    stx<K>(q.S0 + c.Soff, q.Slen, pp + (long)qq * P, v);
+    stx<K>(q.S0 + c.Soff, q.Slen, qq + (long)pp * P, v);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1242,6 +1252,7 @@ __global__ __launch_bounds__(MW_NT) void k_mw_usum(const MwDev q) {
         acc<K> s;
         acc_zero<K>(s);
         for (int j = 0; j < q.J; j++) acc_add<K, K>(s, ldx<K>(q.u, (long)q.J * N, (long)j * N + a));
+        if (q.uadd) acc_add<K, K>(s, ldx<K>(q.uadd, N, a));
         stx<K>(q.ug + (long)q.rank * K * N, N, a, acc_result<K>(s));
     }
 }
@@ -1293,8 +1304,14 @@ __device__ __forceinline__ void mw_solve_fwd_cluster(const MwDev &q, int j, cons
 template <int K>
 __global__ __launch_bounds__(MW_NT) void k_mw_solve_fwd(const MwDev q, const double *__restrict__ rhs_x) { mw_solve_fwd_cluster<K>(q, blockIdx.x, rhs_x); }
 
-// dy = Q^-1 (rhs_y - sum_j u_j) into v (LDS, plane N; y: N more numbers of scratch)
-template <int K>
+// Limbs of the CORRECTION of the refined solve (MODE 1 / 2 below; clrs_config_set("mw_refine", 2): all K).  The correction is smaller than the
+// solution by the backward error of the first pass, 2^(lam - 53 K) with lam the bits the inverse-factor products lose (cohnelkies(8,15): 57,
+// Nsphere_packing(8,15): 82), and is itself computed to 2^(lam - 52 KC) of its size: the sum is good to the working precision while 2 lam <= 52 KC.
+__host__ __device__ constexpr int mw_kc(int K) { return K <= 3 ? K : K <= 6 ? 3 : K / 2; }
+
+// dy = Q^-1 (rhs_y - sum_j u_j) into v (LDS, plane N; y: N more numbers of scratch).  The difference in K limbs (with the u_j of the refinement it
+// cancels to the size of the residual), the two products with the explicit inverse of L_Q in KC.
+template <int K, int KC>
 __device__ __forceinline__ void mw_solve_mid_body(const MwDev &q, const double *__restrict__ rhs_y, mwk::lds_d *v, mwk::lds_d *y, int tid) {
     using namespace mwk;
     const int N = q.N;
@@ -1307,65 +1324,109 @@ __device__ __forceinline__ void mw_solve_mid_body(const MwDev &q, const double *
             for (int r = 0; r < q.world; r++) acc_add<K, K>(s, ldx<K>(q.ug + (long)r * K * N, N, a), -1.0);
         } else {
             for (int j = 0; j < q.J; j++) acc_add<K, K>(s, ldx<K>(q.u, (long)q.J * N, (long)j * N + a), -1.0);
+            if (q.uadd) acc_add<K, K>(s, ldx<K>(q.uadd, N, a), -1.0);
         }
         stx<K>(v, N, a, acc_result<K>(s));
     }
     __syncthreads();
-    wg_trmv_n<K>(q.Qi, lplane, N, N, v, N, y, N, tid);     // dy = Qi^T (Qi v): two products with the explicit inverse of L_Q
-    wg_trmv_t<K>(q.Qi, lplane, N, N, y, N, v, N, tid);
+    wg_trmv_n<KC>(q.Qi, lplane, N, N, v, N, y, N, tid);     // dy = Qi^T (Qi v): two products with the explicit inverse of L_Q
+    wg_trmv_t<KC>(q.Qi, lplane, N, N, y, N, v, N, tid);
 }
-template <int K>
+// KC < K: the correction dy' of the refined solve, to dy (a buffer of its own: k_mw_solve_bwd<.., 2> adds it)
+template <int K, int KC>
 __global__ __launch_bounds__(MW_NT) void k_mw_solve_mid(const MwDev q, const double *__restrict__ rhs_y, double *__restrict__ dy) {
     using namespace mwk;
     const int N = q.N, tid = threadIdx.x;
     lds_d *v = MW_LDS, *y = v + (long)K * N;  // N numbers each, plane N
-    mw_solve_mid_body<K>(q, rhs_y, v, y, tid);
+    mw_solve_mid_body<K, KC>(q, rhs_y, v, y, tid);
     for (int a = tid; a < N; a += MW_NT) {
 #pragma unroll
-        for (int l = 0; l < K; l++) dy[(long)l * N + a] = v[(long)l * N + a];
+        for (int l = 0; l < K; l++) dy[(long)l * N + a] = l < KC ? (double)v[(long)l * N + a] : 0.0;
     }
 }
 
 // mid_rhs_y != null (small unsharded systems): every workgroup forms dy = Q^-1 (rhs_y - sum u_j) itself first (two 31-row products: cheaper than the
-// launch of k_mw_solve_mid in front of this kernel); the first one writes it to dy
-template <int K>
+// launch of k_mw_solve_mid in front of this kernel); the first one writes it to dy.
+// MODE 0: the plain backward half.
+// MODE 1: ... followed by the first half of the refinement step (k_mw_refine's header) for this cluster: r_j = rhs_x[j] - S_j dx_j + B_j dy (K limbs: it
+//         cancels), t'_j = Si_j r_j (KC limbs) and u'_j = LinvB_j^T t'_j + B_j^T dx_j (the second term is this cluster's share of -r_y, in K limbs) into
+//         q.t, q.u, where the plain forward half would have left them.
+// MODE 2: the backward half of the correction in KC limbs, added to what dx, dy hold.
+template <int K, int KC, int DK, int MODE>
 __global__ __launch_bounds__(MW_NT) void k_mw_solve_bwd(const MwDev q, const double *__restrict__ dy_in, double *__restrict__ dx, const double *__restrict__ mid_rhs_y,
-                                                        double *__restrict__ dy_out) {
+                                                        double *__restrict__ dy_out, const double *__restrict__ rhs_x) {
     using namespace mwk;
+    constexpr int KB = MODE == 2 ? KC : K;                 // limbs of this pass's products
     const int j = blockIdx.x, tid = threadIdx.x;
     const MwClu &c = q.clu[j];
     const int P = c.P, N = q.N;
-    lds_d *dyl = MW_LDS, *w = MW_LDS + (mid_rhs_y ? 2L * K * N : 0L), *w2 = w + (long)K * P;
+    lds_d *dyl = MW_LDS, *w = MW_LDS + 2L * K * N, *w2 = w + (long)K * P, *w3 = w2 + (long)K * P;
     const long plane = q.xlen * (long)N;
     const int sub = tid % MW_S_W;
     if (mid_rhs_y) {
-        mw_solve_mid_body<K>(q, mid_rhs_y, dyl, dyl + (long)K * N, tid);      // (ends with a barrier)
-        if (j == 0)
-            for (int a = tid; a < N; a += MW_NT) {
+        mw_solve_mid_body<K, KB>(q, mid_rhs_y, dyl, dyl + (long)K * N, tid);      // (ends with a barrier)
+    } else if (N > 0) {
+        for (int a = tid; a < N; a += MW_NT) {
 #pragma unroll
-                for (int l = 0; l < K; l++) dy_out[(long)l * N + a] = dyl[(long)l * N + a];
-            }
+            for (int l = 0; l < KB; l++) dyl[(long)l * N + a] = dy_in[(long)l * N + a];
+        }
+        __syncthreads();
     }
+    if (j == 0 && (mid_rhs_y || MODE == 2))
+        for (int a = tid; a < N; a += MW_NT) {
+            if (MODE == 2) stx<K>(dy_out, N, a, add<K>(ldx<K>(dy_out, N, a), cvt<K, KB>(ldx<KB>(dyl, N, a))));
+            else stx<K>(dy_out, N, a, ldx<K>(dyl, N, a));
+        }
+    for (int r0 = 0; r0 < P; r0 += MW_NT / MW_S_W) {
+        const int r = r0 + tid / MW_S_W;
+        const bool live = r < P;
+        const int rr = live ? r : 0;
+        acc<KB> s;
+        acc_zero<KB>(s);
+        if (sub == 0) acc_add<KB, KB>(s, ldx<KB>(q.t, q.xlen, c.coff + rr));
+        for (int a = sub; a < N; a += MW_S_W) acc_fma<KB, KB, KB>(s, ldx<KB>(q.LB, plane, c.coff + rr + a * q.xlen), ldx<KB>(dyl, N, a));
+        mw<KB> v = lanes_sum<KB, MW_S_W>(acc_result<KB>(s));
+        if (live && sub == 0) stx<KB>(w, P, r, v);
+    }
+    __syncthreads();
+    wg_trmv_t<KB>(q.Si + c.Soff, q.Slen, P, P, w, P, w2, P, tid);       // dx_j = Si_j^T w
+    for (int i = tid; i < P; i += MW_NT) {
+        if (MODE == 2) stx<K>(dx, q.xlen, c.coff + i, add<K>(ldx<K>(dx, q.xlen, c.coff + i), cvt<K, KB>(ldx<KB>(w2, P, i))));
+        else stx<K>(dx, q.xlen, c.coff + i, ldx<K>(w2, P, i));
+    }
+    if (MODE != 1) return;
+    // r_j = rhs_x[j] - S_j dx_j + B_j dy into w
+    const double *S0 = q.S0 + c.Soff;
     for (int r0 = 0; r0 < P; r0 += MW_NT / MW_S_W) {
         const int r = r0 + tid / MW_S_W;
         const bool live = r < P;
         const int rr = live ? r : 0;
         acc<K> s;
         acc_zero<K>(s);
-        if (sub == 0) acc_add<K, K>(s, ldx<K>(q.t, q.xlen, c.coff + rr));
-        if (mid_rhs_y) {
-            for (int a = sub; a < N; a += MW_S_W) acc_fma<K, K, K>(s, ldx<K>(q.LB, plane, c.coff + rr + a * q.xlen), ldx<K>(dyl, N, a));
-        } else {
-            for (int a = sub; a < N; a += MW_S_W) acc_fma<K, K, K>(s, ldx<K>(q.LB, plane, c.coff + rr + a * q.xlen), ldx<K>(dy_in, N, a));
-        }
+        if (sub == 0) acc_add<K, K>(s, ldx<K>(rhs_x, q.xlen, c.coff + rr));
+        for (int cc = sub; cc < P; cc += MW_S_W) acc_fma<K, K, K>(s, ldx<K>(S0, q.Slen, cc + (long)rr * P), ldx<K>(w2, P, cc), -1.0);      // row rr = column rr (symmetric!)
+        for (int a = sub; a < N; a += MW_S_W) acc_fma<K, DK, K>(s, ldx<DK>(q.B, q.Bp, c.coff + rr + a * q.xlen), ldx<K>(dyl, N, a));
         mw<K> v = lanes_sum<K, MW_S_W>(acc_result<K>(s));
         if (live && sub == 0) stx<K>(w, P, r, v);
     }
     __syncthreads();
-    wg_trmv_t<K>(q.Si + c.Soff, q.Slen, P, P, w, P, w2, P, tid);       // dx_j = Si_j^T w
+    wg_trmv_n<KC>(q.Si + c.Soff, q.Slen, P, P, w, P, w3, P, tid);      // t'_j = Si_j r_j
     for (int i = tid; i < P; i += MW_NT) {
 #pragma unroll
-        for (int l = 0; l < K; l++) dx[(long)l * q.xlen + c.coff + i] = w2[(long)l * P + i];
+        for (int l = 0; l < K; l++) q.t[(long)l * q.xlen + c.coff + i] = l < KC ? (double)w3[(long)l * P + i] : 0.0;
+    }
+    for (int a0 = 0; a0 < N; a0 += MW_NT / MW_S_W) {                     // u'_j = LinvB_j^T t'_j + B_j^T dx_j
+        const int a = a0 + tid / MW_S_W;
+        const bool live = a < N;
+        const int aa = live ? a : 0;
+        acc<K> s;
+        acc_zero<K>(s);
+        for (int r = sub; r < P; r += MW_S_W) {
+            acc_fma<K, KC, KC>(s, ldx<KC>(q.LB, plane, c.coff + r + aa * q.xlen), ldx<KC>(w3, P, r));
+            acc_fma<K, DK, K>(s, ldx<DK>(q.B, q.Bp, c.coff + r + aa * q.xlen), ldx<K>(w2, P, r));
+        }
+        mw<K> v = lanes_sum<K, MW_S_W>(acc_result<K>(s));
+        if (live && sub == 0) stx<K>(q.ub, (long)q.J * N, (long)j * N + a, v);
     }
 }
 
@@ -1415,7 +1476,10 @@ __global__ __launch_bounds__(MW_NT) void k_mw_solve_wide(const MwDev q, int stag
     const bool live = row < N;
     const int a = live ? row : 0;
     if (stage == 2) {
-        if (sub == 0) acc_add<K, K>(s, ldx<K>(rhs_y, N, a));
+        if (sub == 0) {
+            acc_add<K, K>(s, ldx<K>(rhs_y, N, a));
+            if (q.uadd) acc_add<K, K>(s, ldx<K>(q.uadd, N, a), -1.0);
+        }
         for (long g = sub; g < q.xlen; g += MW_SW_L) acc_fma<K, K, K>(s, ldx<K>(q.LB, lbp, g + a * q.xlen), ldx<K>(q.t, q.xlen, g), -1.0);
     } else if (stage == 3) {
         for (int cc = sub; cc <= a; cc += MW_SW_L) acc_fma<K, K, K>(s, ldx<K>(q.Qi, qp, a + (long)cc * N), ldx<K>(vz, vp, cc));
@@ -1428,6 +1492,54 @@ __global__ __launch_bounds__(MW_NT) void k_mw_solve_wide(const MwDev q, int stag
         else if (stage == 3) stx<K>(vz, vp, N + a, v);
         else stx<K>(dy, N, a, v);
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// One step of iterative refinement of the solve stage.  The reference solves with substitutions (approx_solve_tril! / solve_cho_precomp! /
+// approx_solve_triu!, src/solver.jl:1538, 1557, 1567-1572), whose residuals stay at the working accuracy whatever cond(L_j), cond(L_Q) are;
+// a product with an explicit inverse factor has a residual of cond(L) eps instead.  The residuals of the computed (dx, dy),
+//     r_x = rhs_x - S dx + B dy,        r_y = rhs_y - B^T dx,
+// are formed in K limbs from the matrices as ASSEMBLED (S0) and solved for with the same inverse-factor products: the sum has the backward
+// error of the working precision (measured: scripts/refine_check.py; cohnelkies(8,15) y rows 2^-208 -> 2^-268 at 5 limbs).
+// This kernel is the form with rows over many workgroups, sixteen lanes per row, beside k_mw_solve_wide (clusters or Q beyond 64 rows):
+//   stage 1   rx2 = rhs_x - S_j dx_j + B_j dy (grid.y = cluster)   and, in the workgroups with blockIdx.y = J,   u2 = B^T dx over this rank's rows
+//   stage 3   dx += dx2, dy += dy2
+// The small systems take the same step inside the launches of the solve itself (k_mw_solve_bwd, MODE 1 / 2).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int K, int DK>
+__global__ __launch_bounds__(MW_NT) void k_mw_refine(const MwDev q, int stage, const double *__restrict__ rhs_x, double *__restrict__ dx, double *__restrict__ dy) {
+    using namespace mwk;
+    constexpr int RPW = MW_NT / MW_SW_L;
+    const int sub = threadIdx.x % MW_SW_L, row = blockIdx.x * RPW + threadIdx.x / MW_SW_L, N = q.N;
+    if (stage == 3) {
+        for (long i = (long)blockIdx.x * MW_NT + threadIdx.x; i < q.xlen + N; i += (long)gridDim.x * MW_NT) {
+            if (i < q.xlen) stx<K>(dx, q.xlen, i, add<K>(ldx<K>(dx, q.xlen, i), ldx<K>(q.dx2, q.xlen, i)));
+            else stx<K>(dy, N, i - q.xlen, add<K>(ldx<K>(dy, N, i - q.xlen), ldx<K>(q.dy2, N, i - q.xlen)));
+        }
+        return;
+    }
+    acc<K> s;
+    acc_zero<K>(s);
+    if ((int)blockIdx.y == q.J) {                           // u2[a] = sum_g B[g, a] dx[g]
+        if (blockIdx.x * RPW >= N) return;
+        const bool live = row < N;
+        const int a = live ? row : 0;
+        for (long g = sub; g < q.xlen; g += MW_SW_L) acc_fma<K, DK, K>(s, ldx<DK>(q.B, q.Bp, g + a * q.xlen), ldx<K>(dx, q.xlen, g));
+        const mw<K> v = lanes_sum<K, MW_SW_L>(acc_result<K>(s));
+        if (live && sub == 0) stx<K>(q.u2, N, a, v);
+        return;
+    }
+    const MwClu &c = q.clu[blockIdx.y];
+    const int P = c.P;
+    if (blockIdx.x * RPW >= P) return;                      // uniform over the workgroup
+    const bool live = row < P;
+    const int i = live ? row : 0;
+    const double *S0 = q.S0 + c.Soff;
+    if (sub == 0) acc_add<K, K>(s, ldx<K>(rhs_x, q.xlen, c.coff + i));
+    for (int cc = sub; cc < P; cc += MW_SW_L) acc_fma<K, K, K>(s, ldx<K>(S0, q.Slen, cc + (long)i * P), ldx<K>(dx, q.xlen, c.coff + cc), -1.0);      // row i = column i (symmetric!)
+    for (int a = sub; a < N; a += MW_SW_L) acc_fma<K, DK, K>(s, ldx<DK>(q.B, q.Bp, c.coff + i + a * q.xlen), ldx<K>(dy, N, a));
+    const mw<K> v = lanes_sum<K, MW_SW_L>(acc_result<K>(s));
+    if (live && sub == 0) stx<K>(q.rx2, q.xlen, c.coff + i, v);
 }
 
 // reciprocal diagonals of Cholesky factors passed in by the caller (clrs_mw_schur_assemble with host or foreign factors)
