@@ -63,6 +63,11 @@ class IpmStop(C.Structure):
                 ("max_iterations", C.c_int32), ("reserved", C.c_int32)]
 
 
+class MwOptions(C.Structure):
+    """struct clrs_mw_options"""
+    _fields_ = [("exact_products", C.c_int32), ("refine", C.c_int32), ("reserved", C.c_int32 * 6)]
+
+
 class ClrsError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"clrs error {code}: {msg}")
@@ -117,6 +122,7 @@ SYMBOLS = {
     "clrs_plan_info": (C.c_int, [C.c_void_p, p_i32, p_i32, p_i32]),
     "clrs_mw_create": (C.c_int, [C.POINTER(SdpDesc), C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "clrs_mw_create_ex": (C.c_int, [C.POINTER(SdpDesc), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "clrs_mw_create_opts": (C.c_int, [C.POINTER(SdpDesc), C.c_int, C.c_int, C.c_int, C.POINTER(MwOptions), C.POINTER(C.c_void_p)]),
     "clrs_mw_destroy": (None, [C.c_void_p]),
     "clrs_mw_limbs": (C.c_int, [C.c_void_p]),
     "clrs_mw_get_dims": (C.c_int, [C.c_void_p, C.POINTER(Dims)]),
@@ -139,12 +145,14 @@ SYMBOLS = {
     "clrs_mw_set_shard": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "clrs_mw_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "clrs_mw_comm_destroy": (C.c_int, [C.c_void_p]),
+    "clrs_mw_comm_probe": (C.c_int, [C.c_void_p, C.c_int, p_d, p_i32]),
     "clrs_mw_schur_factor_local_dev": (C.c_int, [C.c_void_p]),
     "clrs_mw_q_gather_dev": (C.c_void_p, [C.c_void_p]),
     "clrs_mw_schur_factor_finish_dev": (C.c_int, [C.c_void_p]),
     "clrs_mw_schur_solve_fwd_dev": (C.c_int, [C.c_void_p, C.c_void_p]),
     "clrs_mw_u_gather_dev": (C.c_void_p, [C.c_void_p]),
     "clrs_mw_schur_solve_bwd_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "clrs_mw_schur_solve_refine_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "clrs_mw_S_buffer_dev": (C.c_void_p, [C.c_void_p]),
     "clrs_mw_AY_buffer_dev": (C.c_void_p, [C.c_void_p]),
     "clrs_mw_stream": (C.c_void_p, [C.c_void_p]),
@@ -206,10 +214,20 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str =
     hdr = os.path.join(_HERE, "..", "include", "clrs_hip.h")
     files = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".hip.h", ".inc", ".h")))
     objs, jobs = [], []
+    # CLRS_MW_STAMPS=1: the diagnostic variant of the multi-word units with phase stamps in k_mwi_Zi / k_mws_pair / k_mwx_dense (compile-time: the
+    # product library carries none), built beside the product as csrc/_diag/libclrs_hip_mwstamps.so (objects there too; load it with CLRS_HIP_LIB=...)
+    mw_stamps = bool(os.environ.get("CLRS_MW_STAMPS")) and out is None
+    if mw_stamps:
+        os.makedirs(os.path.join(CSRC, "_diag"), exist_ok=True)
+        out = os.path.join(CSRC, "_diag", "libclrs_hip_mwstamps.so")
     for obj, src, flags, mine in _UNITS:
-        o = os.path.join(CSRC, obj if out is None or src != "clrs_hip.hip" else os.path.basename(out) + ".o")
+        if mw_stamps:
+            flags = (*flags, "-DCLRS_MW_STAMPS") if src != "clrs_hip.hip" else flags
+            obj = os.path.join("_diag", obj) if src != "clrs_hip.hip" else obj
+        o = os.path.join(CSRC, obj if out is None or src != "clrs_hip.hip" or mw_stamps else os.path.join("_diag", os.path.basename(out) + ".o"))
+        os.makedirs(os.path.dirname(o), exist_ok=True)
         deps = [os.path.join(CSRC, f) for f in files if mine(f)] + [hdr]
-        diag = out is not None and src == "clrs_hip.hip"
+        diag = out is not None and src == "clrs_hip.hip" and not mw_stamps
         if force or diag or not os.path.exists(o) or any(os.path.getmtime(o) < os.path.getmtime(s) for s in deps):
             jobs.append((src, [*_COMMON, *flags, *(extra_flags if diag else ()), "-c", "-o", o, os.path.join(CSRC, src)]))
         objs.append(o)
@@ -221,6 +239,7 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str =
                 if verbose:
                     print("compiled", src)
     target = out if out is not None else LIB_PATH
+    os.makedirs(os.path.dirname(target), exist_ok=True)       # (diagnostic variants live in csrc/_diag/: delete the directory when done, it ships with gpurun)
     if rebuilt or not os.path.exists(target) or any(os.path.getmtime(target) < os.path.getmtime(o) for o in objs):
         _hipcc(["--offload-arch=gfx950", "-fPIC", "-shared", "-o", target, *objs])
     return target

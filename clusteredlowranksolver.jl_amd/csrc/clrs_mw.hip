@@ -92,6 +92,7 @@ static const int MW_NCCL_FLOAT64 = 8;      // ncclFloat64 / ncclDouble
 // slot is rewritten every iteration).  Two channels, like the two RCCL communicators of a context: one per stream that exchanges.
 struct clrs_mw_local_group {
     int world = 0;
+    int attached = 0;                   // contexts that point to this group (clrs_mw_comm_init_local / clrs_mw_comm_destroy, clrs_mw_destroy)
     std::mutex m;
     std::condition_variable cv;
     struct Chan {
@@ -150,6 +151,8 @@ struct clrs_mw_ctx {
     void *comm_side = nullptr;           // a second communicator for the exchanges of the iteration's side stream (clrs_mw_comm_init_side)
     clrs_mw_local_group *lgroup = nullptr;   // or: the in-process group (clrs_mw_comm_init_local)
     bool local_factored = false, fwd_done = false;
+    const double *split_rhs_x = nullptr;   // right-hand side of the last clrs_mw_schur_solve_fwd_dev (the refinement's residual needs it)
+    bool refine_ready = false;             // clrs_mw_schur_solve_bwd_dev left the first half of a refinement step behind
     MwdDev mwd = {};                     // static digits of the dense matrices of the blocks k_mwx_dense takes
     int mwd_blocks = 0, mwd_tasks = 0;
     size_t sm_mwd = 0;
@@ -159,7 +162,7 @@ struct clrs_mw_ctx {
     int mws_blocks = 0;                  // how many
     int mws_turns = 1;                   // 2: some eligible block has more than four T / Z tiles
     size_t sm_mws = 0;
-    int refine = 1;                      // steps of iterative refinement of the solve stage (clrs_config_set("mw_refine", 0 / 1))
+    int refine = 1;                      // iterative refinement of the solve stage (clrs_mw_options / clrs_config_set("mw_refine")): 0 off, 1 one step with the correction in all K limbs, 2 ... in mw_kc(K) limbs
     bool ipm_arms_info = false;          // inside the device-resident iteration the status words are re-armed by a kernel, not by a memset per call
 };
 
@@ -203,13 +206,21 @@ extern "C" void clrs_mw_destroy(clrs_mw_ctx *c);
 static void mw_ipm_free(clrs_mw_ctx *c);
 static int mw_launch_xrd(clrs_mw_ctx *c, const double *d_Xc);
 
-extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int device, int limbs, clrs_mw_ctx **out);
+extern "C" int clrs_mw_create_opts(const clrs_sdp_desc *d, int data_limbs, int device, int limbs, const clrs_mw_options *opts, clrs_mw_ctx **out);
 extern "C" int clrs_mw_create(const clrs_sdp_desc *d, int device, int limbs, clrs_mw_ctx **out) {
-    return clrs_mw_create_ex(d, 1, device, limbs, out);
+    return clrs_mw_create_opts(d, 1, device, limbs, nullptr, out);
+}
+extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int device, int limbs, clrs_mw_ctx **out) {
+    return clrs_mw_create_opts(d, data_limbs, device, limbs, nullptr, out);
 }
 
-extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int device, int limbs, clrs_mw_ctx **out) {
+// opts: per-context choices (a field < 0, or opts == NULL: the process-wide default of clrs_config_set) -- contexts created side by side from
+// several threads do not share a knob this way
+extern "C" int clrs_mw_create_opts(const clrs_sdp_desc *d, int data_limbs, int device, int limbs, const clrs_mw_options *opts, clrs_mw_ctx **out) {
     if (!d || !out) return mw_fail(CLRS_ERR_INVALID, "null argument");
+    const int cfg_exact = opts && opts->exact_products >= 0 ? opts->exact_products : g_cfg_mw_exact_products;
+    const int cfg_refine = opts && opts->refine >= 0 ? opts->refine : g_cfg_mw_refine;
+    if (cfg_exact > 2 || cfg_refine > 2) return mw_fail(CLRS_ERR_INVALID, "clrs_mw_options: exact_products and refine are 0, 1 or 2 (or < 0 for the default)");
     if (limbs < 2 || limbs > 10 || limbs == 7 || limbs == 9) return mw_fail(CLRS_ERR_INVALID, "limbs must be 2..6, 8 or 10");
     if (data_limbs < 1 || data_limbs > 2 || data_limbs > limbs) return mw_fail(CLRS_ERR_INVALID, "data limbs must be 1 or 2 (and at most limbs)");
     *out = nullptr;
@@ -516,7 +527,7 @@ extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int dev
             c->mws_blocks++;
             c->sm_mws = std::max(c->sm_mws, mws_lds_bytes(S, mws_sv_class(S, sv), n, U));
         }
-        const bool on = g_cfg_mw_exact_products == 2 ? c->mws_blocks > 0 : (g_cfg_mw_exact_products == 1 && c->mws_blocks >= 256);
+        const bool on = cfg_exact == 2 ? c->mws_blocks > 0 : (cfg_exact == 1 && c->mws_blocks >= 256);
         if (!on) { c->mws_blocks = 0; std::fill(mws_off.begin(), mws_off.end(), -1); }
         else {
             MW_TRY(mw_upload(c, hVs, &c->mws.Vs)); MW_TRY(mw_upload(c, hVe, &c->mws.Vexp));
@@ -528,14 +539,14 @@ extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int dev
     // ---- pairing matrices of blocks of any size through digits in global memory (k_mwx_slice, k_mwx_gram): blocks without sub-blocks that
     // k_mws_pair does not take and that have enough unique vectors for their U x U Gram products to matter ----
     std::vector<long long> mwx_off((size_t)std::max(NB, 1), -1);
-    if (g_cfg_mw_exact_products != 0) {
+    if (cfg_exact != 0) {
         const int S = mws_slices(K);
         std::vector<float> hVd;
         std::vector<int> heV, he_off((size_t)std::max(NB, 1), 0), hsv((size_t)std::max(NB, 1), 0);
         for (int b = 0; b < NB; b++) {
             const MwBlk &k = c->blk[b];
             if (k.kind != 0 || k.m != 1 || mws_off[b] >= 0) continue;
-            if (k.U < (g_cfg_mw_exact_products == 2 ? 16 : 64) || k.n < 8) continue;
+            if (k.U < (cfg_exact == 2 ? 16 : 64) || k.n < 8) continue;
             const int n = k.n, U = k.U, np = (n + 3) & ~3, U16 = (U + 15) & ~15;
             mwx_off[b] = (long long)hVd.size();
             he_off[b] = (int)heV.size();
@@ -584,7 +595,7 @@ extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int dev
     }
     // ---- dense blocks with 16 < n <= 32 and inverse factors: X^-1 (A_e Y) through exact slice products (k_mwx_dense), static digits of the A_e ----
     std::vector<long long> mwd_off((size_t)std::max(NB, 1), -1);
-    if (g_cfg_mw_exact_products != 0 && K <= 6) {
+    if (cfg_exact != 0 && K <= 6) {
         const int S = mws_slices(K), S1 = (S + 1) / 2, sN = 32 * 32;
         std::vector<float> hAd;
         std::vector<int> heA, he_off((size_t)std::max(NB, 1), 0);
@@ -704,7 +715,7 @@ extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int dev
     MW_TRY(mw_dmalloc(c, &q.rx2, xlen * K)); MW_TRY(mw_dmalloc(c, &q.dx2, xlen * K));
     MW_TRY(mw_dmalloc(c, &q.u2, (i64)N * K)); MW_TRY(mw_dmalloc(c, &q.dy2, (i64)N * K));
     q.uadd = nullptr;
-    c->refine = g_cfg_mw_refine;
+    c->refine = cfg_refine;
     c->wide_solve = c->maxP > 64 || N > 64;
     MW_TRY(mw_dmalloc(c, &c->d_Xin, xyoff * K)); MW_TRY(mw_dmalloc(c, &c->d_Xc, xyoff * K)); MW_TRY(mw_dmalloc(c, &c->d_Y, xyoff * K));
     MW_TRY(mw_dmalloc(c, &c->d_rx, xlen * K)); MW_TRY(mw_dmalloc(c, &c->d_dx, xlen * K));
@@ -754,6 +765,7 @@ extern "C" void clrs_mw_destroy(clrs_mw_ctx *c) {
     mw_ipm_free(c);
     if (c->comm && g_nccl.CommDestroy) { (void)g_nccl.CommDestroy(c->comm); c->comm = nullptr; }
     if (c->comm_side && g_nccl.CommDestroy) { (void)g_nccl.CommDestroy(c->comm_side); c->comm_side = nullptr; }
+    if (c->lgroup) { std::lock_guard<std::mutex> lk(c->lgroup->m); c->lgroup->attached--; c->lgroup = nullptr; }
     for (void *p : c->allocs) (void)hipFree(p);
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->h_info) (void)hipHostFree(c->h_info);
@@ -932,8 +944,14 @@ extern "C" int clrs_mw_comm_destroy(clrs_mw_ctx *c) {
         NCCLCHECK(g_nccl.CommDestroy(c->comm));
         c->comm = nullptr;
         if (c->comm_side) { NCCLCHECK(g_nccl.CommDestroy(c->comm_side)); c->comm_side = nullptr; }
-        c->d.gathered = c->d.world > 1 ? 1 : 0;
     }
+    if (c->lgroup) {                                     // detach from the in-process group (which counts its attached ranks)
+        (void)hipStreamSynchronize(c->stream);
+        std::lock_guard<std::mutex> lk(c->lgroup->m);
+        c->lgroup->attached--;
+        c->lgroup = nullptr;
+    }
+    c->d.gathered = c->d.world > 1 ? 1 : 0;
     return 0;
 }
 extern "C" double *clrs_mw_q_gather_dev(clrs_mw_ctx *c) { return c ? c->d.Qg : nullptr; }
@@ -968,6 +986,40 @@ static int mw_allgather(clrs_mw_ctx *c, int chan, double *base, size_t cnt, hipS
     NCCLCHECK(g_nccl.AllGather(base + (size_t)q.rank * cnt, base, cnt, MW_NCCL_FLOAT64, comm, stream));
     return 0;
 }
+// Diagnostic for the multi-GPU bench: the cost of the exchanges of one sharded interior-point iteration on this context's communicator, measured with
+// HIP events on the context's stream around `reps` all-gathers of each size, back to back: us[0] the partial Q (limbs N^2 doubles per rank), us[1] the
+// partial u (limbs N), us[2] a scalar record (MWG_LEN).  Collective: every rank of the communicator must call it.  info[0..2] = rank, world, backend
+// (0 none, 1 RCCL, 2 in-process group).
+extern "C" int clrs_mw_comm_probe(clrs_mw_ctx *c, int reps, double us[3], int info[3]) {
+    if (!c || !us || !info || reps < 1) return mw_fail(CLRS_ERR_INVALID, "bad argument");
+    MWCHECK(hipSetDevice(c->device));
+    const MwDev &q = c->d;
+    info[0] = q.rank; info[1] = q.world; info[2] = c->comm ? 1 : c->lgroup ? 2 : 0;
+    us[0] = us[1] = us[2] = 0.0;
+    if (!mw_has_comm(c, 0) || q.N <= 0) return 0;
+    const size_t cnt[3] = {(size_t)q.N * q.N * c->K, (size_t)q.N * c->K, (size_t)(2 * c->K + c->K * q.N + 8)};
+    double *scratch = nullptr;                                       // (a buffer of its own: the exchanges must not disturb Qg / ug)
+    MWCHECK(hipMalloc((void **)&scratch, cnt[0] * q.world * sizeof(double)));
+    MWCHECK(hipMemsetAsync(scratch, 0, cnt[0] * q.world * sizeof(double), c->stream));
+    hipEvent_t e0, e1;
+    MWCHECK(hipEventCreate(&e0)); MWCHECK(hipEventCreate(&e1));
+    int rc = 0;
+    for (int k = 0; k < 3 && !rc; k++) {
+        for (int w = 0; w < 3 && !rc; w++) rc = mw_allgather(c, 0, scratch, cnt[k], c->stream);          // warm-up
+        if (rc) break;
+        (void)hipEventRecord(e0, c->stream);
+        for (int i = 0; i < reps && !rc; i++) rc = mw_allgather(c, 0, scratch, cnt[k], c->stream);
+        (void)hipEventRecord(e1, c->stream);
+        if (hipEventSynchronize(e1) != hipSuccess) rc = mw_fail(CLRS_ERR_HIP, "hipEventSynchronize failed");
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        us[k] = 1e3 * ms / reps;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(scratch);
+    return rc;
+}
 // second RCCL communicator (its own unique id), for the exchanges the interior-point iteration issues on its side stream
 extern "C" int clrs_mw_comm_init_side(clrs_mw_ctx *c, const void *id128) {
     if (!c || !id128) return mw_fail(CLRS_ERR_INVALID, "null argument");
@@ -998,8 +1050,14 @@ extern "C" int clrs_mw_local_group_create(int world, int device, clrs_mw_local_g
     *out = g;
     return 0;
 }
+// (refused -- the group is leaked and the last error set -- while contexts are attached: they would dereference freed events in their next exchange;
+// clrs_mw_comm_destroy or clrs_mw_destroy on each rank first)
 extern "C" void clrs_mw_local_group_destroy(clrs_mw_local_group *g) {
     if (!g) return;
+    {
+        std::lock_guard<std::mutex> lk(g->m);
+        if (g->attached > 0) { (void)mw_fail(CLRS_ERR_STATE, "clrs_mw_local_group_destroy: contexts are still attached (clrs_mw_comm_destroy them first)"); return; }
+    }
     for (auto &ch : g->ch) {
         for (auto e : ch.ready) if (e) (void)hipEventDestroy(e);
         for (auto e : ch.copied) if (e) (void)hipEventDestroy(e);
@@ -1011,6 +1069,11 @@ extern "C" int clrs_mw_comm_init_local(clrs_mw_ctx *c, clrs_mw_local_group *g, i
     if (!c || !g) return mw_fail(CLRS_ERR_INVALID, "null argument");
     int rc = clrs_mw_set_shard(c, rank, g->world);
     if (rc) return rc;
+    if (c->lgroup != g) {
+        if (c->lgroup) { std::lock_guard<std::mutex> lk(c->lgroup->m); c->lgroup->attached--; }
+        std::lock_guard<std::mutex> lk(g->m);
+        g->attached++;
+    }
     c->lgroup = g;
     c->d.gathered = 1;
     return 0;
@@ -1122,6 +1185,7 @@ extern "C" int clrs_mw_schur_solve_fwd_dev(clrs_mw_ctx *c, const double *d_rhs_x
     });
     MWCHECK(hipGetLastError());
     c->fwd_done = true;
+    c->split_rhs_x = d_rhs_x;
     return 0;
 }
 // the backward half: dy = Q^-1 (rhs_y - sum u), dx_j = L_j^-T (t_j + LinvB_j dy).  mode 0: plain; 1: followed by the first half of the refinement step
@@ -1154,12 +1218,38 @@ extern "C" int clrs_mw_schur_solve_bwd_dev(clrs_mw_ctx *c, const double *d_rhs_y
     const MwDev &q = c->d;
     if (q.N > 0 && (!d_rhs_y || !d_dy)) return mw_fail(CLRS_ERR_INVALID, "null argument");
     MWCHECK(hipSetDevice(c->device));
-    int rc = mw_solve_bwd(c, q, nullptr, d_rhs_y, d_dx, d_dy, 0, false);
+    // split-phase callers with the refinement on: the launch also forms the residuals and the forward half of the correction, and leaves this rank's
+    // partial u' in its gather slot -- after one more exchange of the u slots clrs_mw_schur_solve_refine_dev adds the correction (optional: without
+    // that call (dx, dy) are the plain products' solution)
+    const bool first_half = c->refine && c->split_rhs_x != nullptr;
+    int rc = mw_solve_bwd(c, q, c->split_rhs_x, d_rhs_y, d_dx, d_dy, first_half ? 1 : 0, c->refine != 2);
     if (rc) return rc;
+    if (first_half && q.gathered && q.N > 0) {
+        MwDev q2 = q;
+        q2.u = q.ub;
+        MW_DISPATCH(c, hipLaunchKernelGGL(k_mw_usum<KK>, dim3(1), dim3(MW_NT), 0, c->stream, q2));
+        MWCHECK(hipGetLastError());
+    }
+    c->refine_ready = first_half;
+    c->split_rhs_x = nullptr;
     if (c->timing) MWCHECK(hipEventRecord(c->ev[7], c->stream));
     c->fwd_done = false;
     return 0;
 }
+// second half of the refinement step for split-phase callers: after clrs_mw_schur_solve_bwd_dev and one more exchange of the u gather slots
+extern "C" int clrs_mw_schur_solve_refine_dev(clrs_mw_ctx *c, const double *d_rhs_y, double *d_dx, double *d_dy) {
+    if (!c || !d_dx) return mw_fail(CLRS_ERR_INVALID, "null argument");
+    if (!c->refine) return 0;                             // clrs_config_set("mw_refine", 0): nothing to add
+    if (!c->refine_ready) return mw_fail(CLRS_ERR_STATE, "clrs_mw_schur_solve_refine before clrs_mw_schur_solve_fwd / clrs_mw_schur_solve_bwd");
+    const MwDev &q = c->d;
+    if (q.N > 0 && (!d_rhs_y || !d_dy)) return mw_fail(CLRS_ERR_INVALID, "null argument");
+    MWCHECK(hipSetDevice(c->device));
+    MwDev q2 = q;
+    q2.u = q.ub;
+    c->refine_ready = false;
+    return mw_solve_bwd(c, q2, nullptr, d_rhs_y, d_dx, d_dy, 2, c->refine != 2);
+}
+
 // one pass of the row-parallel solve (clusters or a Q beyond 64 rows, one rank): a launch per product
 static int mw_solve_wide_once(clrs_mw_ctx *c, const double *d_rhs_x, const double *d_rhs_y, double *d_dx, double *d_dy) {
     const MwDev &q = c->d;
@@ -1217,8 +1307,9 @@ extern "C" int clrs_mw_schur_solve_dev(clrs_mw_ctx *c, const double *d_rhs_x, co
     } else rc = clrs_mw_schur_solve_fwd_dev(c, d_rhs_x);
     if (rc) return rc;
     if (q.gathered && q.N > 0 && (rc = mw_allgather(c, 0, q.ug, (size_t)q.N * c->K, c->stream))) return rc;
+    c->split_rhs_x = nullptr;
     if (!c->refine) return clrs_mw_schur_solve_bwd_dev(c, d_rhs_y, d_dx, d_dy);
-    const bool full_kc = c->refine >= 2;
+    const bool full_kc = c->refine != 2;                  // 2: the correction in mw_kc(K) limbs (opt-in: valid while twice the lost bits fit in them)
     if ((rc = mw_solve_bwd(c, q, d_rhs_x, d_rhs_y, d_dx, d_dy, 1, full_kc))) return rc;
     MwDev q2 = q;
     q2.u = q.ub;                                         // (the first half of the step wrote its u' beside the u the other workgroups were still reading)
@@ -1251,6 +1342,9 @@ extern "C" int clrs_mw_get_S(clrs_mw_ctx *c, double *S_out, double *AY_out) {
 // diagnostic: phase stamps (100 MHz wall clock) of wave 0 of the first workgroup of the next k_mws_pair launches; out[16] = the last ones
 extern "C" int clrs_mw_debug_exact_stamps(clrs_mw_ctx *c, unsigned long long *out) {
     if (!c) return mw_fail(CLRS_ERR_INVALID, "null context");
+#ifndef CLRS_MW_STAMPS
+    return mw_fail(CLRS_ERR_STATE, "this library was built without -DCLRS_MW_STAMPS (the product kernels carry no phase stamps): CLRS_MW_STAMPS=1 builds the diagnostic variant");
+#endif
     MWCHECK(hipSetDevice(c->device));
     MWCHECK(hipStreamSynchronize(c->stream));
     if (!c->mws.stamps) {

@@ -179,9 +179,13 @@ __global__ __launch_bounds__(MWS_NT, 2) void k_mws_pair(const MwDev q, const Mws
     const int rV = mws_rowstride(U16), rY = mws_rowstride(n16), sV = np * rV, sY = np * rY;
     const int SV = w.sv[b], SVc = mws_sv_class(S, SV);
     extern __shared__ __attribute__((aligned(16))) float mws_lds[];
+#ifdef CLRS_MW_STAMPS            // diagnostic builds only (scripts/mw_pmc.sh, scripts/dense_stamps.py): the product carries no run-time probe
     const bool stamp = w.stamps && blockIdx.x == 0 && tid == 0;
     int nst = 0;
 #define MWS_STAMP() do { if (stamp) w.stamps[nst++] = wall_clock64(); } while (0)
+#else
+#define MWS_STAMP() do { } while (0)
+#endif
     MWS_STAMP();
     lds_f *Vsl = (lds_f *)mws_lds;                              // [SVc][np][rV]
     const size_t yx = (size_t)2 * S * sY, tz = (size_t)S * sV;
@@ -481,9 +485,13 @@ __global__ __launch_bounds__(MWS_NT) void k_mwx_dense(const MwDev q, const MwdDe
     int *eL = (int *)(RR + (size_t)S * sN), *eR = eL + 32, *part = eR + 32;      // part: [2][32] column maxima per row tile
     const double *Yg = Y + k.xyoff, *Xig = q.Xi + k.xyoff;
     const long nn = (long)n * n;
+#ifdef CLRS_MW_STAMPS
     const bool stamp = w.stamps && blockIdx.x == 0 && tid == 0;
     int nst = 0;
 #define MWD_STAMP() do { if (stamp) w.stamps[nst++] = wall_clock64(); } while (0)
+#else
+#define MWD_STAMP() do { } while (0)
+#endif
     MWD_STAMP();
     // ---- operands of product 1: A_e (static digits, by columns; A_e is symmetric) and Y by columns ----
     {

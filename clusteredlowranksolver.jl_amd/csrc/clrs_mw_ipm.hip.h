@@ -405,6 +405,15 @@ __device__ void mwi_scalar_stage(const MwDev &q, const MwIpmDev &p, int stage, i
         return;
     }
     if (threadIdx.x != 0) return;
+    if (stage == 5) {                              // warm start (clrs_mw_ipm_set): the feasibility of the STARTING iterate, which the reference knows before its
+        const double maxP = __longlong_as_double((long long)p.fmax[0]), maxd = __longlong_as_double((long long)p.fmax[1]),      // loop (src/solver.jl:322-333)
+                     maxp = __longlong_as_double((long long)p.fmax[2]);      // and which decides mu_p and beta_c of the first iteration (:373, :429-434)
+        p.flags[0] = (q.info[1] == MW_INFO_NONE && fmax(maxp, maxP) < p.dual_thr && maxd < p.primal_thr) ? 1 : 0;
+        p.fmax[0] = p.fmax[1] = p.fmax[2] = 0ull;
+        q.info[0] = MW_INFO_NONE;
+        q.info[1] = MW_INFO_NONE;
+        return;
+    }
     if (stage == 0) {                              // start of the iteration: mu, mu_p  (src/solver.jl:369-380)
         mw<K> xy = q.world > 1 ? mwi_gsum<K>(q, p.gsS, p.GL, MWG_S1(K, q.N)) : mwi_sum_part<K>(q, p, 0);
         mw<K> mu = s_div<K>(xy, from_double<K>((double)p.Ktot));
@@ -935,9 +944,13 @@ __global__ __launch_bounds__(MW_PT) void k_mwi_Zi(const MwDev q, const MwIpmDev 
     lds_d *M = MW_LDS, *M2 = M + (long)K * np;
     const double *A = (which == 0 ? p.Pm : p.dX) + k.xyoff, *Xi = q.Xi + k.xyoff;
     const double sg = which == 0 ? 1.0 : -1.0;
+#ifdef CLRS_MW_STAMPS            // diagnostic builds only (CLRS_MW_STAMPS=1 python -c "... _lib.build()": scripts/zi_stamps.py): the product carries no run-time probe
     const bool stamp = p.stamps && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0;
     int nst = 0;
 #define MWZ_STAMP() do { if (stamp) p.stamps[nst++] = wall_clock64(); } while (0)
+#else
+#define MWZ_STAMP() do { } while (0)
+#endif
     MWZ_STAMP();
     for (int e0 = 0; e0 < n * pc; e0 += MW_PT / MWI_ZL) {  // M = sg (A Y - R)
         const int e = e0 + tid / MWI_ZL;

@@ -1304,9 +1304,11 @@ __device__ __forceinline__ void mw_solve_fwd_cluster(const MwDev &q, int j, cons
 template <int K>
 __global__ __launch_bounds__(MW_NT) void k_mw_solve_fwd(const MwDev q, const double *__restrict__ rhs_x) { mw_solve_fwd_cluster<K>(q, blockIdx.x, rhs_x); }
 
-// Limbs of the CORRECTION of the refined solve (MODE 1 / 2 below; clrs_config_set("mw_refine", 2): all K).  The correction is smaller than the
+// Limbs of the CORRECTION of the refined solve when the caller opts for fewer than K (MODE 1 / 2 below; refine = 2).  The correction is smaller than the
 // solution by the backward error of the first pass, 2^(lam - 53 K) with lam the bits the inverse-factor products lose (cohnelkies(8,15): 57,
-// Nsphere_packing(8,15): 82), and is itself computed to 2^(lam - 52 KC) of its size: the sum is good to the working precision while 2 lam <= 52 KC.
+// Nsphere_packing(8,15): 82 on mid-trajectory iterates), and is itself computed to 2^(lam - 52 KC) of its size: the sum is good to the working precision
+// while 2 lam <= 52 KC.  NOT the default: on the last iterates of Nsphere_packing(8,15,[1/2,1/2,1/2]) lam exceeds 100 bits and a 3-limb correction is
+// worse than none (measured, scripts/sharded_debug.py) -- the default correction carries all K limbs (-25 us per iteration on the named problem otherwise).
 __host__ __device__ constexpr int mw_kc(int K) { return K <= 3 ? K : K <= 6 ? 3 : K / 2; }
 
 // dy = Q^-1 (rhs_y - sum_j u_j) into v (LDS, plane N; y: N more numbers of scratch).  The difference in K limbs (with the u_j of the refinement it

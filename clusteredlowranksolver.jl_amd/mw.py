@@ -82,9 +82,12 @@ def _c(a):
 class MwSchurContext:
     """Device context of the hot path for one SDP at `limbs` words per number (see module docstring)."""
 
-    def __init__(self, sdp, limbs: int = 4, device: int = 0, timing: bool = False, data_limbs: int = 2, exact_products: Optional[bool] = None):
+    def __init__(self, sdp, limbs: int = 4, device: int = 0, timing: bool = False, data_limbs: int = 2, exact_products: Optional[bool] = None,
+                 refine: Optional[int] = None):
         """`exact_products`: the pairing matrices through exact slice products on the matrix cores (k_mws_pair, csrc/clrs_mw_exact.hip.h):
         None = automatic (contexts with >= 256 eligible PSD blocks), True = always, False = never.
+        `refine`: iterative refinement of the solve stage (k_mw_refine): None = the library default (one step), 0 = none (products with the inverse
+        factors only), 1 = the default, 2 = one step with the correction in fewer limbs (cheaper; as good while twice the lost bits fit in them).
         `data_limbs` = 2 (default): the problem data (sampled vectors, lambda, dense A_p, B and, in `solvesdp_mw`, C, c, b) are
         passed as double-double, the (hi, lo) pairs a FlatSDP carries; 1: the fp64 roundings only."""
         self.flat: FlatSDP = sdp if isinstance(sdp, FlatSDP) else flatten(sdp)
@@ -121,11 +124,8 @@ class MwSchurContext:
         for name in ("term_lambda", "term_vs", "term_ws", "dense_A"):
             setattr(d, name, _dp(data(name)))
         h = C.c_void_p()
-        _lib.check(self.L.clrs_config_set(b"mw_exact_products", 1 if exact_products is None else (2 if exact_products else 0)))
-        try:
-            _lib.check(self.L.clrs_mw_create_ex(C.byref(d), self.data_limbs, int(device), self.limbs, C.byref(h)))
-        finally:
-            self.L.clrs_config_set(b"mw_exact_products", 1)
+        opts = _lib.MwOptions(-1 if exact_products is None else (2 if exact_products else 0), -1 if refine is None else int(refine))
+        _lib.check(self.L.clrs_mw_create_opts(C.byref(d), self.data_limbs, int(device), self.limbs, C.byref(opts), C.byref(h)))
         self.h = h
         self.device = device
         if timing:
@@ -256,6 +256,13 @@ class MwSchurContext:
         _lib.check(self.L.clrs_mw_comm_init_local(self.h, group.h, int(rank)))
         self._group = group
 
+    def comm_probe(self, reps: int = 50):
+        """microseconds per all-gather of (partial Q, partial u, scalar record) on this context's communicator, and (rank, world, backend): collective"""
+        us, info = np.zeros(3), np.zeros(3, dtype=np.int32)
+        _lib.check(self.L.clrs_mw_comm_probe(self.h, int(reps), _dp(us), info.ctypes.data_as(_lib.p_i32)))
+        return dict(q_us=float(us[0]), u_us=float(us[1]), record_us=float(us[2]), rank=int(info[0]), world=int(info[1]),
+                    backend={0: "none", 1: "rccl", 2: "in-process group"}[int(info[2])])
+
     def comm_destroy(self):
         _lib.check(self.L.clrs_mw_comm_destroy(self.h))
 
@@ -271,6 +278,11 @@ class MwSchurContext:
     def solve_bwd_dev(self, d_rhs_y: int, d_dx: int, d_dy: int):
         _lib.check(self.L.clrs_mw_schur_solve_bwd_dev(self.h, C.c_void_p(d_rhs_y) if d_rhs_y else None, C.c_void_p(d_dx),
                                                       C.c_void_p(d_dy) if d_dy else None))
+
+    def solve_refine_dev(self, d_rhs_y: int, d_dx: int, d_dy: int):
+        """second half of the refinement step of a split-phase solve: after solve_bwd_dev and one more exchange of the u gather slots"""
+        _lib.check(self.L.clrs_mw_schur_solve_refine_dev(self.h, C.c_void_p(d_rhs_y) if d_rhs_y else None, C.c_void_p(d_dx),
+                                                         C.c_void_p(d_dy) if d_dy else None))
 
     def q_gather(self) -> int:
         return int(self.L.clrs_mw_q_gather_dev(self.h) or 0)
@@ -332,12 +344,16 @@ def solvesdp_mw(sdp, limbs: Optional[int] = None, prec: Optional[int] = None, ct
                 omega_p: float = 1e10, omega_d: float = 1e10, duality_gap_threshold: float = 1e-15,
                 dual_error_threshold: float = 1e-30, primal_error_threshold: float = 1e-30, max_complementary_gap: float = 1e100,
                 need_dual_feasible: bool = False, need_primal_feasible: bool = False, verbose: bool = False,
-                step_length_threshold: float = 1e-7, safe_step: bool = True, step_by_step: bool = False, shard_info: Optional[dict] = None):
+                step_length_threshold: float = 1e-7, safe_step: bool = True, step_by_step: bool = False, shard_info: Optional[dict] = None,
+                dualsol=None, primalsol=None):
     """`solvesdp(sdp; prec, ...)` (src/solver.jl:71-127) with the whole loop body on the GPU in multi-word fp64.
 
     Keywords and DEFAULTS are the reference's (omega = 1e10, gap 1e-15, errors 1e-30: they assume its 256-bit arithmetic):
     `prec` bits select the limb count (`limbs_for_precision`), or pass `limbs` directly; the default is limbs = 5, which
     covers prec = 256.  The result's x, y, X, Y are planar limbs; objectives are fp64 heads plus `objectives_limbs`.
+    `dualsol` / `primalsol`: the warm start of src/solver.jl:202-239 (applied, as there, only when BOTH are given): `dualsol` supplies x and X,
+    `primalsol` y and Y -- a previous `SolveResult` (or anything with those attributes), fp64 or planar limbs; through `clrs_mw_ipm_set`.  The errors of
+    the starting iterate are known after the first iteration (the reference computes them before its loop): a warm-started solve runs at least one.
     Termination (src/solver.jl:921-950): by the library and the device together in one call (`clrs_mw_ipm_solve`), or -- `verbose` or
     `step_by_step` -- on the host from one record per call of `clrs_mw_ipm_iterate`."""
     import time
@@ -363,6 +379,20 @@ def solvesdp_mw(sdp, limbs: Optional[int] = None, prec: Optional[int] = None, ct
         _lib.check(L.clrs_mw_ipm_set_global(ctx.h, int(shard_info["rows_global"]), int(shard_info["clusters_global"]),
                                             cid.ctypes.data_as(_lib.p_i32), bid.ctypes.data_as(_lib.p_i32)))
     _lib.check(L.clrs_mw_ipm_init(ctx.h, float(omega_p), float(omega_d)))
+    warm = dualsol is not None and primalsol is not None
+
+    def _limbs_of(a, n):
+        a = np.asarray(a, dtype=np.float64)
+        a = a.reshape(1, -1) if a.ndim == 1 else a
+        if a.shape[1] != n:
+            raise ValueError(f"warm start: expected {n} numbers per limb plane, got {a.shape}")
+        out = np.zeros((K, max(n, 1)))
+        out[:min(K, a.shape[0]), :n] = a[:K]
+        return out
+
+    if warm:
+        ws = [_limbs_of(dualsol.x, f.x_len), _limbs_of(primalsol.y, f.n_free), _limbs_of(dualsol.X, f.xy_len), _limbs_of(primalsol.Y, f.xy_len)]
+        _lib.check(L.clrs_mw_ipm_set(ctx.h, _dp(ws[0]), _dp(ws[1]) if f.n_free else None, _dp(ws[2]), _dp(ws[3])))
     rec = _lib.IpmRecord()
     hist = []
     t_start = time.time()
@@ -370,6 +400,10 @@ def solvesdp_mw(sdp, limbs: Optional[int] = None, prec: Optional[int] = None, ct
     dual_error = primal_error = np.inf      # computed by the first iteration; no termination test can pass before
     gap = 0.0                               # x = 0, y = 0: both objectives equal the constant (src/solver.jl:319-321)
     d_obj = p_obj = f.constant
+    if warm:                                # objectives of the starting iterate (src/solver.jl:319-321)
+        o3 = np.zeros(3 * K)
+        _lib.check(L.clrs_mw_ipm_objectives(ctx.h, _dp(o3)))
+        d_obj, p_obj, gap = float(o3[0]), float(o3[K]), float(o3[2 * K])
     pd_feas = False
 
     def row(r):

@@ -291,6 +291,15 @@ int clrs_mw_create(const clrs_sdp_desc *desc, int device, int limbs, clrs_mw_ctx
  * problem at `prec` bits as well (convert_to_prec, src/interface.jl:1078-1112), and its headline problems need it: the
  * cohnelkies(8,15) SDP whose data are rounded to fp64 is a different, dual-infeasible problem. */
 int clrs_mw_create_ex(const clrs_sdp_desc *desc, int data_limbs, int device, int limbs, clrs_mw_ctx **out);
+/* The same with per-context choices instead of the process-wide clrs_config_set knobs (a field < 0, or opts == NULL: the knob's value):
+ * exact_products 0 / 1 / 2 = pairing matrices through exact slice products on the matrix cores never / from 256 eligible blocks on / always;
+ * refine 0 / 1 / 2 = iterative refinement of the solve stage off / one step (default) / one step with the correction in fewer limbs. */
+typedef struct clrs_mw_options {
+    int32_t exact_products;
+    int32_t refine;
+    int32_t reserved[6];
+} clrs_mw_options;
+int clrs_mw_create_opts(const clrs_sdp_desc *desc, int data_limbs, int device, int limbs, const clrs_mw_options *opts, clrs_mw_ctx **out);
 void clrs_mw_destroy(clrs_mw_ctx *ctx);
 int clrs_mw_limbs(const clrs_mw_ctx *ctx);
 int clrs_mw_get_dims(const clrs_mw_ctx *ctx, clrs_dims *dims);          /* logical lengths; dims->reserved = limbs */
@@ -335,6 +344,10 @@ int clrs_comm_unique_id(void *id128);                                     /* ncc
 int clrs_mw_set_shard(clrs_mw_ctx *ctx, int rank, int world);
 int clrs_mw_comm_init(clrs_mw_ctx *ctx, const void *id128, int rank, int world);   /* clrs_mw_set_shard + ncclCommInitRank */
 int clrs_mw_comm_destroy(clrs_mw_ctx *ctx);
+/* Diagnostic (collective over the communicator): microseconds per all-gather of the three message sizes of one sharded iteration -- us[0] partial Q,
+ * us[1] partial u, us[2] one scalar record -- from HIP events around `reps` exchanges back to back on the context's stream; info = rank, world, backend
+ * (0 none, 1 RCCL, 2 in-process group).  bench.py reports them beside the N-GPU rate. */
+int clrs_mw_comm_probe(clrs_mw_ctx *ctx, int reps, double us[3], int info[3]);
 /* The interior-point iteration of a sharded context (clrs_mw_ipm_*) exchanges on two streams: a second communicator (a second unique
  * id, same rank and world) serves its side stream. */
 int clrs_mw_comm_init_side(clrs_mw_ctx *ctx, const void *id128);
@@ -351,6 +364,13 @@ int clrs_mw_schur_factor_finish_dev(clrs_mw_ctx *ctx);                    /* Q =
 int clrs_mw_schur_solve_fwd_dev(clrs_mw_ctx *ctx, const double *d_rhs_x);  /* t = L^-1 rhs_x, partial u into slot `rank` */
 double *clrs_mw_u_gather_dev(clrs_mw_ctx *ctx);                           /* [world][limbs * N] */
 int clrs_mw_schur_solve_bwd_dev(clrs_mw_ctx *ctx, const double *d_rhs_y, double *d_dx, double *d_dy);
+/* The solve stage multiplies with explicit inverse factors and then takes one step of iterative refinement against the assembled S_j and B,
+ * which gives (dx, dy) the backward error of the reference's substitutions (src/solver.jl:1538, 1557, 1567-1572) -- clrs_mw_schur_solve[_dev] do
+ * both (clrs_mw_options.refine, or clrs_config_set("mw_refine", 0 / 1 / 2) before the context is created: no step / one step, the default / one step
+ * with the correction in fewer limbs -- cheaper, and as good while twice the bits the products lose fit in those limbs: DESIGN.md section 5.5).
+ * Split-phase callers: clrs_mw_schur_solve_bwd_dev leaves this rank's partial u' of the correction in slot `rank` of the u gather buffer; after ONE
+ * MORE exchange of that buffer this call adds the correction to dx, dy (without it they are the plain products' solution). */
+int clrs_mw_schur_solve_refine_dev(clrs_mw_ctx *ctx, const double *d_rhs_y, double *d_dx, double *d_dy);
 
 /* HIP-event timings of the last calls, seconds: t[0] schur, t[1] cholS + LinvB (one kernel), t[2] 0, t[3] Q, t[4] cholQ,
  * t[5] last solve (the split compute_T_decomposition! returns, src/solver.jl:1282-1286). */

@@ -19,7 +19,7 @@ mutable struct Optimizer <: MOI.AbstractOptimizer
 end
 
 function __init__()
-    setglobal!(ClusteredLowRankHIP, :Optimizer, Optimizer)
+    ClusteredLowRankHIP.OPTIMIZER_TYPE[] = Optimizer      # (a Ref the parent declares: extensions may not create bindings in their parent)
     return
 end
 

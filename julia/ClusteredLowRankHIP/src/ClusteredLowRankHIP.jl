@@ -336,14 +336,58 @@ struct IpmRecord
     max_d::Float64
 end
 
+"""Cluster-local renumbering of the constraints preprocessing kept: `original row => position among the kept rows` (what `cs_map[j]` is)."""
+function renumber_kept(nrows::Integer, removed)
+    gone = Set{Int}(removed)
+    out = Dict{Int,Int}()
+    for p in 1:nrows
+        p in gone || (out[p] = length(out) + 1)
+    end
+    return out
+end
+
+"""
+Limb planes (len x K) of the warm-start iterate: x and X from `dualsol`, y and Y from `primalsol` (the meaning of src/solver.jl:202-239), in the
+layouts of the device loop (x: constraints stacked by cluster; X, Y: blocks in description order, column-major).
+"""
+function warm_start_planes(sdp, ctx::HipContext, dualsol, primalsol, K::Int)
+    nxy, nx, N = ctx.block_off[end], ctx.cluster_off[end], ctx.n_free
+    xw = zeros(Float64, max(nx, 1), K); yw = zeros(Float64, max(N, 1), K)
+    Xw = zeros(Float64, max(nxy, 1), K); Yw = zeros(Float64, max(nxy, 1), K)
+    for ((con, smp), row) in sdp.order_c                             # (constraint of the Problem, sample) -> row of x
+        limbs_of!(xw, row, dualsol.x[con][smp], K)
+    end
+    for (k, name) in enumerate(sdp.free_coeff_names)
+        limbs_of!(yw, k, primalsol.freevars[name], K)
+    end
+    for (b, (j, l)) in enumerate(ctx.jl)
+        name = sdp.matrix_coeff_names[j][l]
+        m = size(sdp.A[j][l], 1)
+        n = ctx.block_n[b]
+        dl = div(n, m)
+        whole = !(CLRS.Block(name, 1, 1) in sdp.matrix_coeff_blocks)  # a variable without sub-blocks is stored under its bare name
+        for r in 1:m, s in 1:r
+            key = (whole && r == 1 && s == 1) ? name : CLRS.Block(name, r, s)
+            for (sol, W) in ((dualsol, Xw), (primalsol, Yw))
+                M = sol.matrixvars[key]
+                for cc in 1:dl, rr in 1:dl
+                    limbs_of!(W, ctx.block_off[b] + (r - 1) * dl + rr + ((s - 1) * dl + cc - 1) * n, M[rr, cc], K)
+                    r == s || limbs_of!(W, ctx.block_off[b] + (s - 1) * dl + cc + ((r - 1) * dl + rr - 1) * n, M[rr, cc], K)   # the mirrored sub-block: the iterate is symmetric
+                end
+            end
+        end
+    end
+    return xw, yw, Xw, Yw
+end
+
 """
     solvesdp(problem::Problem; prec=precision(BigFloat), device=0, kwargs...)
     solvesdp(sdp::ClusteredLowRankSDP; prec=precision(BigFloat), device=0, kwargs...)
 
 The reference's `solvesdp` (src/solver.jl:42-127: same keywords, same defaults, same return
 `status, dualsol, primalsol, solve_time, errorcode`) with the interior-point loop on the GPU at `limbs_for(prec)` words per number.
-Keywords without a device counterpart (`save_settings`, `correctoronly`, `matmul_prec`, `testing`) are accepted; a non-default
-value raises an `ArgumentError`, so that a caller never silently gets something else than it asked for.
+`dualsol` / `primalsol` warm-start the device loop (`clrs_mw_ipm_set`).  Keywords without a device counterpart (`save_settings`, `correctoronly`,
+`matmul_prec`, `testing`) are accepted; a non-default value raises an `ArgumentError`, so that a caller never silently gets something else than it asked for.
 """
 function solvesdp(problem::CLRS.Problem; prec=precision(BigFloat), kwargs...)
     sdp = CLRS.ClusteredLowRankSDP(problem, prec=prec)          # src/solver.jl:96-98
@@ -364,24 +408,14 @@ function solvesdp(sdp::CLRS.ClusteredLowRankSDP;
     (save_settings === nothing || (save_settings.iter_interval === nothing && save_settings.time_interval === nothing && save_settings.callback === nothing)) ||
         throw(ArgumentError("save_settings is not available with the HIP backend"))
     matmul_prec == prec || throw(ArgumentError("matmul_prec is not available with the HIP backend"))
-    (dualsol === nothing) == (primalsol === nothing) || throw(ArgumentError("pass both dualsol and primalsol, or neither"))
-    (dualsol === nothing) || throw(ArgumentError("warm starts are not wired through this front end yet (clrs_mw_ipm_set takes the iterate)"))
+    warm = dualsol !== nothing && primalsol !== nothing               # src/solver.jl:202: only both together are used
     lib = libclrs[]
     K = limbs_for(prec)
     K >= 2 || throw(ArgumentError("the device-resident loop runs at 2 or more limbs (prec > 53)"))
-    # preprocessing with the reference's own code (src/solver.jl:156-167)
-    if preprocess
-        num_constr = [size(sdp.B[j], 1) for j in eachindex(sdp.B)]
-        cs, var_rels = CLRS.preprocess!(sdp)
-        c_removed = [Int[] for _ in eachindex(sdp.B)]
-        for (_, j, p) in cs
-            push!(c_removed[j], p)
-        end
-        cs_leftover = [[pi for pi in 1:num_constr[j] if !(pi in c_removed[j])] for j in eachindex(sdp.B)]
-        cs_map = [Dict(v => k for (k, v) in enumerate(cs_leftover[j])) for j in eachindex(sdp.B)]
-    else
-        cs_map = [Dict(i => i for i in 1:size(sdp.B[j], 1)) for j in eachindex(sdp.B)]
-    end
+    # preprocessing with the reference's own code (CLRS.preprocess!, src/pre_postprocessing.jl); the constraints it leaves are renumbered per cluster
+    rows_before = [size(sdp.B[j], 1) for j in eachindex(sdp.B)]
+    cs, var_rels = preprocess ? CLRS.preprocess!(sdp) : ((), nothing)
+    cs_map = [renumber_kept(rows_before[j], (t[3] for t in cs if t[2] == j)) for j in eachindex(sdp.B)]
     ctx = HipContext(sdp, cs_map; device=device, limbs=K)
     DL = DATA_LIMBS
     nxy, nx, N = ctx.block_off[end], ctx.cluster_off[end], ctx.n_free
@@ -409,6 +443,19 @@ function solvesdp(sdp::CLRS.ClusteredLowRankSDP;
     end
     check(ccall((:clrs_mw_ipm_set_params, lib), Cint, (Ptr{Cvoid}, Ref{IpmParams}), ctx.handle, prm))
     check(ccall((:clrs_mw_ipm_init, lib), Cint, (Ptr{Cvoid}, Cdouble, Cdouble), ctx.handle, Float64(omega_p), Float64(omega_d)))
+    d_obj0, p_obj0, gap0 = f64(sdp.constant), f64(sdp.constant), 0.0
+    if warm
+        # the iterate of a previous solve (src/solver.jl:202-239) as limb planes through clrs_mw_ipm_set.  The reference leaves the case of
+        # constraints removed by preprocessing open (its TODO at :203: x is indexed by the ORIGINAL constraints); refused here instead of guessed
+        isempty(cs) || throw(ArgumentError("warm start of a problem from which preprocessing removed constraints: pass preprocess=false"))
+        xw, yw, Xw, Yw = warm_start_planes(sdp, ctx, dualsol, primalsol, K)
+        GC.@preserve xw yw Xw Yw begin
+            check(ccall((:clrs_mw_ipm_set, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), ctx.handle, xw, N > 0 ? pointer(yw) : Ptr{Float64}(C_NULL), Xw, Yw))
+        end
+        obj3 = zeros(Float64, 3 * K)                               # objectives of the starting iterate (src/solver.jl:319-321)
+        check(ccall((:clrs_mw_ipm_objectives, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), ctx.handle, obj3))
+        d_obj0, p_obj0, gap0 = obj3[1], obj3[K + 1], obj3[2 * K + 1]
+    end
     if verbose
         CLRS.@printf("%5s %8s %11s %11s %11s %10s %10s %10s %10s %10s %10s %10s\n", "iter", "time(s)", "μ", "D-obj", "P-obj", "gap",
                      "D-error", "d-error", "p-error", "α_d", "α_p", "beta")
@@ -416,7 +463,7 @@ function solvesdp(sdp::CLRS.ClusteredLowRankSDP;
     time_start = time()
     iter, error_code = 1, 0
     dual_error = primal_error = Inf
-    gap, d_obj, p_obj, pd_feas = 0.0, f64(sdp.constant), f64(sdp.constant), false
+    gap, d_obj, p_obj, pd_feas = gap0, d_obj0, p_obj0, false
     while true                                                     # termination: src/solver.jl:921-950
         dual_feas, primal_feas = dual_error < dual_error_threshold, primal_error < primal_error_threshold
         ((need_dual_feasible && dual_feas) || (need_primal_feasible && primal_feas)) && break
@@ -500,7 +547,7 @@ end
 `:status`, `:errorcode`; ext/MOIExt.jl:417-566).  `ext/ClusteredLowRankHIPMOIExt.jl` wraps it in an `Optimizer` for JuMP.
 """
 function optimize!(opt; device::Integer=0)
-    opts = Dict{Symbol,Any}(k => v for (k, v) in opt.options if k != :save_settings)
+    opts = Dict{Symbol,Any}(k => v for (k, v) in opt.options)      # (save_settings included: solvesdp raises for what the device loop cannot do)
     status, dualsol, primalsol, t, e = solvesdp(opt.problem; device=device, opts...)
     opt.optimized = true
     opt.result_data[:primalsol] = primalsol
@@ -509,6 +556,14 @@ function optimize!(opt; device::Integer=0)
     opt.result_data[:errorcode] = e
     opt.result_data[:solve_time] = t
     return status, dualsol, primalsol, t, e
+end
+
+# `ClusteredLowRankHIP.Optimizer`: the MOI optimizer type lives in the package extension (ext/ClusteredLowRankHIPMOIExt.jl, loaded with
+# MathOptInterface), which registers it here; JuMP takes any callable that returns an optimizer: `GenericModel{BigFloat}(ClusteredLowRankHIP.Optimizer)`
+const OPTIMIZER_TYPE = Ref{Any}(nothing)
+function Optimizer(; kwargs...)
+    OPTIMIZER_TYPE[] === nothing && error("ClusteredLowRankHIP.Optimizer needs MathOptInterface (or JuMP) to be loaded")
+    return OPTIMIZER_TYPE[](; kwargs...)
 end
 
 end # module

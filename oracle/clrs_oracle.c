@@ -125,6 +125,9 @@ typedef struct {
     const int *snap_it;
     double *snap_X, *snap_Y, *snap_rx, *snap_ry;
     REAL last_obj[3];     /* dual objective, primal objective, duality gap of the last oracle_solvesdp at full working precision */
+    /* starting iterate of the next oracle_solvesdp (oracle_set_start; the dualsol / primalsol keywords, src/solver.jl:202-239) */
+    int start_k;
+    const double *start_x, *start_y, *start_X, *start_Y;
 } octx;
 
 static REAL ld(const double *hi, const double *lo, i64 i) { return lo ? (REAL)hi[i] + (REAL)lo[i] : (REAL)hi[i]; }
@@ -674,6 +677,11 @@ void oracle_set_snapshots(octx *o, int n, const int *iters, int k, double *X, do
     o->snap_X = X; o->snap_Y = Y; o->snap_rx = rx; o->snap_ry = ry;
 }
 int oracle_snapshot_count(const octx *o) { return o->snap_count; }
+/* warm start (src/solver.jl:202-239: x, X from dualsol, y, Y from primalsol): the next oracle_solvesdp starts from these k-limb planar arrays
+ * instead of x = 0, y = 0, X = omega_p I, Y = omega_d I.  k = 0 switches it off. */
+void oracle_set_start(octx *o, int k, const double *x, const double *y, const double *X, const double *Y) {
+    o->start_k = k; o->start_x = x; o->start_y = y; o->start_X = X; o->start_Y = Y;
+}
 /* dual objective, primal objective and duality gap the last oracle_solvesdp ended with, as k-limb planar numbers (out[l * 3 + i]) */
 void oracle_last_objectives_mw(octx *o, int k, double *out) {
     for (int i = 0; i < 3; i++) stk(out, 3, k, i, o->last_obj[i]);
@@ -911,6 +919,11 @@ int oracle_solvesdp(octx *o, const oracle_params *prm, int *iters_out, double *o
         oblock *k = &o->blk[b];
         K += k->n;
         for (int i = 0; i < k->n; i++) { X[k->off + i + (i64)i * k->n] = (REAL)prm->omega_p; Y[k->off + i + (i64)i * k->n] = (REAL)prm->omega_d; }
+    }
+    if (o->start_k > 0) {                                                         /* :202-239 */
+        for (i64 i = 0; i < nx; i++) x[i] = ldk(o->start_x, nx, o->start_k, i);
+        for (int i = 0; i < N; i++) y[i] = ldk(o->start_y, N, o->start_k, i);
+        for (i64 i = 0; i < nxy; i++) { X[i] = ldk(o->start_X, nxy, o->start_k, i); Y[i] = ldk(o->start_Y, nxy, o->start_k, i); }
     }
     int iter = 1, error_code = 0, pd_feas = 0;
     REAL d_obj, p_obj, gap, dual_error, primal_error, mu = 0, alpha_p = 0, alpha_d = 0, beta_c = 0;

@@ -98,6 +98,7 @@ def _lib(quad):
         L.oracle_get_factor_mw.argtypes = [C.c_void_p, C.c_int, _p_d, _p_d, _p_d]
         L.oracle_schur_solve_mw.argtypes = [C.c_void_p, C.c_int, _p_d, _p_d, _p_d, _p_d]
         L.oracle_set_snapshots.argtypes = [C.c_void_p, C.c_int, _p_i, C.c_int, _p_d, _p_d, _p_d, _p_d]
+        L.oracle_set_start.argtypes = [C.c_void_p, C.c_int, _p_d, _p_d, _p_d, _p_d]
         L.oracle_kkt_backward_error_mw.argtypes = [C.c_void_p, C.c_int] + [_p_d] * 6
         L.oracle_last_objectives_mw.argtypes = [C.c_void_p, C.c_int, _p_d]
         L.oracle_snapshot_count.restype = C.c_int
@@ -315,8 +316,9 @@ class Oracle:
         self.L.oracle_default_params(C.byref(p))
         return p
 
-    def solvesdp(self, params: Optional[OracleParams] = None, hist_rows: int = 600, snapshots=None, snapshot_limbs: int = 1, **kw):
-        """`snapshots`: ascending 1-based iteration numbers; the result then carries `snap` = dict(iters, X, Y, rhs_x, rhs_y)
+    def solvesdp(self, params: Optional[OracleParams] = None, hist_rows: int = 600, snapshots=None, snapshot_limbs: int = 1, start=None, **kw):
+        """`start`: (x, y, X, Y) as k-limb planar arrays -- the dualsol / primalsol warm start of src/solver.jl:202-239.
+        `snapshots`: ascending 1-based iteration numbers; the result then carries `snap` = dict(iters, X, Y, rhs_x, rhs_y)
         with k-limb planar arrays of shape (n, k, len): the iterate at the top of those iterations and the predictor's
         right-hand sides (trajectory fixtures)."""
         self._prec()
@@ -331,6 +333,12 @@ class Oracle:
             snap = dict(iters=its, X=np.zeros((ns, kl, f.xy_len)), Y=np.zeros((ns, kl, f.xy_len)),
                         rhs_x=np.zeros((ns, kl, f.x_len)), rhs_y=np.zeros((ns, kl, max(f.n_free, 1))))
             self.L.oracle_set_snapshots(self.ctx, ns, _ip(its), kl, _dp(snap["X"]), _dp(snap["Y"]), _dp(snap["rhs_x"]), _dp(snap["rhs_y"]))
+        if start is not None:
+            st_ = [np.ascontiguousarray(np.atleast_2d(a), dtype=np.float64) for a in start]
+            if f.n_free == 0:
+                st_[1] = np.zeros((st_[0].shape[0], 1))
+            assert len({a.shape[0] for a in st_}) == 1 and st_[0].shape[1] == f.x_len and st_[2].shape[1] == f.xy_len and st_[3].shape[1] == f.xy_len
+            self.L.oracle_set_start(self.ctx, st_[0].shape[0], _dp(st_[0]), _dp(st_[1]), _dp(st_[2]), _dp(st_[3]))
         iters = C.c_int(0)
         out = np.zeros(6)
         hist = np.zeros((hist_rows, HIST_COLS))
@@ -338,6 +346,8 @@ class Oracle:
         X, Y = np.zeros(f.xy_len), np.zeros(f.xy_len)
         code = self.L.oracle_solvesdp(self.ctx, C.byref(p), C.byref(iters), _dp(out), _dp(hist), hist_rows, _dp(x), _dp(y), _dp(X), _dp(Y))
         n = min(iters.value, hist_rows)
+        if start is not None:
+            self.L.oracle_set_start(self.ctx, 0, None, None, None, None)
         if snap is not None:
             cnt = int(self.L.oracle_snapshot_count(self.ctx))
             self.L.oracle_set_snapshots(self.ctx, 0, None, 1, None, None, None, None)

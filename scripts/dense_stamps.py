@@ -1,4 +1,6 @@
-"""phase stamps of k_mwx_dense (wave 0 of the first workgroup) on the SDPA x64 instance"""
+"""phase stamps of k_mwx_dense (wave 0 of the first workgroup) on the SDPA x64 instance
+(diagnostic build: `CLRS_MW_STAMPS=1 python -c "from clrs_amd import _lib; _lib.build()"` here, then run with
+CLRS_HIP_LIB=clusteredlowranksolver.jl_amd/csrc/_diag/libclrs_hip_mwstamps.so; the product library carries no stamps)"""
 import os, sys, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

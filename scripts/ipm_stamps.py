@@ -2,7 +2,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, clrs_amd
 from clrs_amd import _lib
-OUT = os.path.join(_lib.CSRC, "libclrs_hip_stamps.so")
+OUT = os.path.join(_lib.CSRC, "_diag", "libclrs_hip_stamps.so")
 if len(sys.argv) > 1 and sys.argv[1] == "build":
     print(_lib.build(extra_flags=["-DCLRS_FUSED_STAMPS", "-DCLRS_IPM_STAMPS"], out=OUT)); sys.exit(0)
 _lib.load(OUT)

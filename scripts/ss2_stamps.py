@@ -10,7 +10,7 @@ import torch
 torch.cuda.set_device(0)
 import clrs_amd
 from clrs_amd import _lib
-L = _lib.load(os.path.join(_lib.CSRC, "libclrs_hip_w3stamps.so"))
+L = _lib.load(os.path.join(_lib.CSRC, "_diag", "libclrs_hip_w3stamps.so"))
 from clrs_amd.solver import SchurContext, compute_T_decomposition, solve_system
 from tests.util import chol_blocks_np, flat, spd_iterates
 name = sys.argv[1] if len(sys.argv) > 1 else "ce_8_3"

@@ -12,7 +12,7 @@ import numpy as np
 import clrs_amd
 from clrs_amd import _lib
 
-OUT = os.path.join(_lib.CSRC, "libclrs_hip_w3stamps.so")
+OUT = os.path.join(_lib.CSRC, "_diag", "libclrs_hip_w3stamps.so")
 if len(sys.argv) > 1 and sys.argv[1] == "build":
     print(_lib.build(extra_flags=["-DCLRS_W3_STAMPS"], out=OUT))
     sys.exit(0)

@@ -1,4 +1,6 @@
-"""phase stamps of k_mwi_Zi (first workgroup) during a solve of the named problem: products, arrival at the counter, symmetrisation"""
+"""phase stamps of k_mwi_Zi (first workgroup) during a solve of the named problem: products, arrival at the counter, symmetrisation
+(diagnostic build: `CLRS_MW_STAMPS=1 python -c "from clrs_amd import _lib; _lib.build()"` here, then run with
+CLRS_HIP_LIB=clusteredlowranksolver.jl_amd/csrc/_diag/libclrs_hip_mwstamps.so; the product library carries no stamps)"""
 import os, sys, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tests.util import flat

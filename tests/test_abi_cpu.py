@@ -155,7 +155,7 @@ def test_every_julia_ccall_matches_its_c_prototype():
                 assert ja in allowed, (name, ja, ca)
             checked.add(name)
     for must in ("clrs_mw_create_ex", "clrs_mw_schur_assemble", "clrs_mw_schur_factor", "clrs_mw_get_factor", "clrs_mw_schur_solve", "clrs_mw_ipm_create_ex",
-                 "clrs_mw_ipm_set_params", "clrs_mw_ipm_init", "clrs_mw_ipm_iterate", "clrs_mw_ipm_get"):
+                 "clrs_mw_ipm_set_params", "clrs_mw_ipm_init", "clrs_mw_ipm_iterate", "clrs_mw_ipm_get", "clrs_mw_ipm_set", "clrs_mw_ipm_objectives"):
         assert must in checked, must
 
 
@@ -182,3 +182,17 @@ def test_julia_ipm_structs_match_the_header():
             base = typ[4:-1] if ptr else typ
             j_fields.append((name, {"Int32": "int32_t", "Int64": "int64_t", "Float64": "double"}[base], ptr))
         assert j_fields == c_fields, (cname, j_fields, c_fields)
+
+
+def test_julia_front_end_forwards_warm_starts_and_declares_its_optimizer():
+    """Round-3 review: `solvesdp(...; dualsol, primalsol)` must reach clrs_mw_ipm_set instead of raising, the constraint renumbering must be the
+    package's own helper, and the MOI extension may only assign to a binding its parent declares (Julia >= 1.11 refuses anything else)."""
+    jl = open(os.path.join(ROOT, "julia", "ClusteredLowRankHIP", "src", "ClusteredLowRankHIP.jl")).read()
+    ext = open(os.path.join(ROOT, "julia", "ClusteredLowRankHIP", "ext", "ClusteredLowRankHIPMOIExt.jl")).read()
+    assert "warm starts are not wired" not in jl and ":clrs_mw_ipm_set," in jl and "warm_start_planes" in jl
+    assert "function renumber_kept" in jl and "c_removed" not in jl and "cs_leftover" not in jl
+    assert "const OPTIMIZER_TYPE" in jl and "function Optimizer(" in jl
+    assert "setglobal!" not in ext and "ClusteredLowRankHIP.OPTIMIZER_TYPE[] = Optimizer" in ext
+    assert "k != :save_settings" not in jl                      # optimize! passes save_settings on, solvesdp raises for what it cannot do
+    proj = open(os.path.join(ROOT, "julia", "ClusteredLowRankHIP", "Project.toml")).read()
+    assert "[compat]" in proj and "julia" in proj.split("[compat]")[1]

@@ -182,3 +182,54 @@ def test_hip_path_solves_the_toy_problem(name):
     assert r.primal_error < 1e-30
     r = solvesdp_mw(f, prec=256, need_dual_feasible=True)
     assert r.dual_error < 1e-30
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# warm start (dualsol / primalsol, src/solver.jl:202-239; the reference's test: test/runtests_solver.jl:166-173)
+# ------------------------------------------------------------------------------------------------------------------------------------
+
+def test_oracle_warm_start_continues_from_the_given_iterate(oracle_built):
+    import clrs_amd
+    from clrs_amd import problems
+    from oracle.oracle import Oracle
+    f = clrs_amd.flatten(problems.toy_z())
+    o = Oracle(f, mp_bits=256)
+    r1 = o.solvesdp(duality_gap_threshold=1e-5)
+    cold = o.solvesdp(duality_gap_threshold=1e-10)
+    r2 = o.solvesdp(duality_gap_threshold=1e-10, start=(r1["x"], r1["y"], r1["X"], r1["Y"]))
+    assert r1["error_code"] == 0 and r2["error_code"] == 0 and r2["gap"] < 1e-10
+    assert abs(r1["p_obj"] - r2["p_obj"]) <= 1e-4                                 # test/runtests_solver.jl:172
+    assert 0 < r2["iterations"] < cold["iterations"] - r1["iterations"] + 4        # it continues, it does not start over
+    again = o.solvesdp(duality_gap_threshold=1e-10)                                 # the start is used once
+    assert again["iterations"] == cold["iterations"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["toy_z", "ce_8_3"])
+def test_hip_path_warm_start_matches_the_oracle_started_from_the_same_iterate(name, oracle_built):
+    """solve to gap 1e-5, restart from the returned iterate (clrs_mw_ipm_set) to 1e-10: the reference's warm-start test on its own toy, and on a
+    sampled sphere-packing instance with free variables; the 320-bit oracle loop started from the SAME K-limb iterate takes the same iterations to
+    the same objectives, step lengths and mu."""
+    import clrs_amd
+    from clrs_amd import problems
+    from clrs_amd.mw import solvesdp_mw
+    from oracle.oracle import Oracle
+    from tests.util import flat
+    f = clrs_amd.flatten(problems.toy_z()) if name == "toy_z" else flat(name)
+    r1 = solvesdp_mw(f, limbs=5, duality_gap_threshold=1e-5)
+    assert r1.error_code == 0 and r1.duality_gap < 1e-5
+    r2 = solvesdp_mw(f, limbs=5, dualsol=r1, primalsol=r1, duality_gap_threshold=1e-10)
+    assert r2.error_code == 0 and r2.status in ("Optimal", "NearOptimal") and r2.duality_gap < 1e-10, (r2.status, r2.duality_gap)
+    assert abs(r1.primal_objective - r2.primal_objective) <= 1e-4                 # test/runtests_solver.jl:172
+    cold = solvesdp_mw(f, limbs=5, duality_gap_threshold=1e-10)
+    assert 0 < r2.iterations < cold.iterations
+    y1 = r1.y if f.n_free else np.zeros((5, 1))
+    ro = Oracle(f, mp_bits=320).solvesdp(duality_gap_threshold=1e-10, start=(r1.x, y1, r1.X, r1.Y))
+    assert ro["error_code"] == 0 and ro["iterations"] == r2.iterations, (ro["iterations"], r2.iterations)
+    assert abs(ro["p_obj"] - r2.primal_objective) <= 1e-12 * max(1.0, abs(ro["p_obj"])) and abs(ro["d_obj"] - r2.dual_objective) <= 1e-12 * max(1.0, abs(ro["d_obj"]))
+    n = r2.iterations
+    for col in (1, 2, 3, 8, 9):                                                    # mu, objectives of the iterate at the top of each iteration, step lengths
+        assert np.allclose(r2.history[:n, col], ro["hist"][:n, col], rtol=1e-6, atol=1e-12), (col, r2.history[:n, col], ro["hist"][:n, col])
+    # only one of the two given: ignored, as in the reference (`if !isnothing(dualsol) && !isnothing(primalsol)`, src/solver.jl:202)
+    half = solvesdp_mw(f, limbs=5, dualsol=r1, duality_gap_threshold=1e-10)
+    assert half.iterations == cold.iterations

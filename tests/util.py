@@ -52,6 +52,8 @@ def instance(name):
         return P.cohnelkies(8, 3, orth_free=True)
     if name == "ns_8_15_2":
         return P.nsphere_packing(8, 15, [0.5, 0.5])
+    if name == "ns_8_15_3":     # Nsphere_packing(8, 15, [1/2, 1/2, 1/2]): 11 clusters, P = 192, 193 free variables (BASELINE config 3's many-cluster instance)
+        return P.nsphere_packing(8, 15, [0.5, 0.5, 0.5])
     if name == "ns_8_3_2":
         return P.nsphere_packing(8, 3, [0.5, 0.5])
     if name == "sdpa_small":
