@@ -65,7 +65,7 @@ class IpmStop(C.Structure):
 
 class MwOptions(C.Structure):
     """struct clrs_mw_options"""
-    _fields_ = [("exact_products", C.c_int32), ("refine", C.c_int32), ("reserved", C.c_int32 * 6)]
+    _fields_ = [("exact_products", C.c_int32), ("refine", C.c_int32), ("pipeline", C.c_int32), ("reserved", C.c_int32 * 5)]
 
 
 class ClrsError(RuntimeError):
@@ -132,6 +132,7 @@ SYMBOLS = {
     "clrs_mw_schur_factor": (C.c_int, [C.c_void_p]),
     "clrs_mw_get_S": (C.c_int, [C.c_void_p, p_d, p_d]),
     "clrs_mw_debug_exact_stamps": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "clrs_mw_debug_pipe_stamps": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "clrs_mw_get_factor": (C.c_int, [C.c_void_p, p_d, p_d, p_d]),
     "clrs_mw_schur_solve": (C.c_int, [C.c_void_p, p_d, p_d, p_d, p_d]),
     "clrs_mw_cholesky_blocks_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

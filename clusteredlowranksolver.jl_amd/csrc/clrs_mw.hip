@@ -23,6 +23,7 @@
 
 #include "../../include/clrs_hip.h"
 #include "clrs_mw_kernels.hip.h"
+#include "clrs_mw_pipe.hip.h"
 #include "clrs_mw_exact.hip.h"
 #include "clrs_mw_ipm.hip.h"
 #include "clrs_mw_inst.h"
@@ -36,6 +37,7 @@ MW_KERNELS_ALL(extern template, 10)
 
 typedef long long i64;
 
+extern int g_cfg_mw_pipeline;                            // clrs_hip.hip, clrs_config_set("mw_pipeline", 0 / 1): read at context creation
 extern int g_cfg_mw_refine;                              // clrs_hip.hip, clrs_config_set("mw_refine", 0 / 1): read at context creation
 extern int g_cfg_mw_exact_products;                      // clrs_hip.hip, clrs_config_set("mw_exact_products", 0 / 1 / 2): read at context creation
 extern "C" void clrs_set_last_error(const char *msg);   // clrs_hip.hip: the library keeps one thread-local message
@@ -162,6 +164,9 @@ struct clrs_mw_ctx {
     int mws_blocks = 0;                  // how many
     int mws_turns = 1;                   // 2: some eligible block has more than four T / Z tiles
     size_t sm_mws = 0;
+    bool pipe_S = false, pipe_Q = false;  // the factorisations of the clusters / of Q as pipelines of workgroups (clrs_mw_pipe.hip.h): every matrix <= 32 rows, few clusters
+    int pipe_pcQ = 0;                    // index of Q's hand-off region in pipe_pc
+    unsigned pipe_epoch = 0;             // launch counter: the tag of the hand-off granules
     int refine = 1;                      // iterative refinement of the solve stage (clrs_mw_options / clrs_config_set("mw_refine")): 0 off, 1 one step with the correction in all K limbs, 2 ... in mw_kc(K) limbs
     bool ipm_arms_info = false;          // inside the device-resident iteration the status words are re-armed by a kernel, not by a memset per call
 };
@@ -220,6 +225,7 @@ extern "C" int clrs_mw_create_opts(const clrs_sdp_desc *d, int data_limbs, int d
     if (!d || !out) return mw_fail(CLRS_ERR_INVALID, "null argument");
     const int cfg_exact = opts && opts->exact_products >= 0 ? opts->exact_products : g_cfg_mw_exact_products;
     const int cfg_refine = opts && opts->refine >= 0 ? opts->refine : g_cfg_mw_refine;
+    const int cfg_pipe = opts && opts->pipeline >= 0 ? opts->pipeline : g_cfg_mw_pipeline;
     if (cfg_exact > 2 || cfg_refine > 2) return mw_fail(CLRS_ERR_INVALID, "clrs_mw_options: exact_products and refine are 0, 1 or 2 (or < 0 for the default)");
     if (limbs < 2 || limbs > 10 || limbs == 7 || limbs == 9) return mw_fail(CLRS_ERR_INVALID, "limbs must be 2..6, 8 or 10");
     if (data_limbs < 1 || data_limbs > 2 || data_limbs > limbs) return mw_fail(CLRS_ERR_INVALID, "data limbs must be 1 or 2 (and at most limbs)");
@@ -717,6 +723,28 @@ extern "C" int clrs_mw_create_opts(const clrs_sdp_desc *d, int data_limbs, int d
     q.uadd = nullptr;
     c->refine = cfg_refine;
     c->wide_solve = c->maxP > 64 || N > 64;
+    {   // pipelined factorisations (clrs_mw_pipe.hip.h): matrices of at most 32 rows, while stages + W workgroups of every matrix can be resident side by side
+        bool small = c->maxP <= MWP_N;
+        for (auto &cl : c->clu) small = small && cl.lds;
+        c->pipe_S = cfg_pipe != 0 && small && (i64)J * ((MWP_N / MWP_W) + MWP_WW) <= 256;
+        c->pipe_Q = cfg_pipe >= 2 && N > 0 && N <= MWP_N;      // (Q: slower than the one-workgroup kernel on the named problem, 83 against 80 us: opt-in)
+        q.pipe_pc = nullptr;
+        q.pipe_stamps = nullptr;
+        if (c->pipe_S || c->pipe_Q) {
+            const size_t words = (size_t)((c->pipe_S ? J : 0) + 1) * MWP_PC_WORDS(K);
+            unsigned long long *pc = nullptr;
+            if (hipMalloc((void **)&pc, words * sizeof(unsigned long long)) != hipSuccess) MW_BAIL(CLRS_ERR_HIP, "hipMalloc failed");
+            c->allocs.push_back(pc);
+            if (hipMemset(pc, 0xff, words * sizeof(unsigned long long)) != hipSuccess) MW_BAIL(CLRS_ERR_HIP, "hipMemset failed");      // no launch epoch has this tag
+            q.pipe_pc = pc;
+            c->pipe_pcQ = c->pipe_S ? J : 0;
+            q.pipe_q = c->pipe_pcQ;
+            MW_DISPATCH(c, {
+                MW_TRY(mw_set_lds(k_mw_factor_pipe<KK>, MWP_LDS_ALONE));
+                MW_TRY(mw_set_lds(k_mw_potrf_q_pipe<KK>, std::max<size_t>(MWP_LDS_ALONE, c->sm_fwd)));
+            });
+        }
+    }
     MW_TRY(mw_dmalloc(c, &c->d_Xin, xyoff * K)); MW_TRY(mw_dmalloc(c, &c->d_Xc, xyoff * K)); MW_TRY(mw_dmalloc(c, &c->d_Y, xyoff * K));
     MW_TRY(mw_dmalloc(c, &c->d_rx, xlen * K)); MW_TRY(mw_dmalloc(c, &c->d_dx, xlen * K));
     MW_TRY(mw_dmalloc(c, &c->d_ry, (i64)N * K)); MW_TRY(mw_dmalloc(c, &c->d_dy, (i64)N * K));
@@ -1118,7 +1146,10 @@ extern "C" int clrs_mw_schur_factor_local_dev(clrs_mw_ctx *c) {
     // clusters that do not fit in LDS: blocked over many workgroups, all of them side by side; the others ride on the first of those launches
     // when they take the same number of workgroups per matrix, else they have their launch (k_mw_factor)
     const bool ride = !c->bp_S.empty() && c->nw_factor == MW_INV_WG && c->any_lds_cluster;
-    if (!ride && c->any_lds_cluster) MW_DISPATCH(c, { hipLaunchKernelGGL(k_mw_factor<KK>, dim3(q.J, c->nw_factor), dim3(MW_PT), c->sm_factor, c->stream, q); });
+    if (c->pipe_S) {
+        c->pipe_epoch = (c->pipe_epoch + 1) & 0x3ffffff;
+        MW_DISPATCH(c, { hipLaunchKernelGGL(k_mw_factor_pipe<KK>, dim3(mwp_blocks(q.J)), dim3(MWP_NT), MWP_LDS_ALONE, c->stream, q, c->pipe_epoch); });
+    } else if (!ride && c->any_lds_cluster) MW_DISPATCH(c, { hipLaunchKernelGGL(k_mw_factor<KK>, dim3(q.J, c->nw_factor), dim3(MW_PT), c->sm_factor, c->stream, q); });
     if (!c->bp_S.empty() && (rc = mw_potrf_blocked(c, c->bp_S, c->d_bp, ride))) return rc;
     MW_DISPATCH(c, {
         if (q.N > 0)
@@ -1140,7 +1171,13 @@ extern "C" int clrs_mw_schur_factor_finish_dev(clrs_mw_ctx *c) {
     if (!c->local_factored) return mw_fail(CLRS_ERR_STATE, "clrs_mw_schur_factor_finish before clrs_mw_schur_factor_local");
     MWCHECK(hipSetDevice(c->device));
     const MwDev &q = c->d;
-    if (q.N > 0 && c->lds_q) {
+    if (q.N > 0 && c->pipe_Q) {
+        const bool ride = c->ride_fwd != nullptr && !c->wide_solve;
+        c->pipe_epoch = (c->pipe_epoch + 1) & 0x3ffffff;
+        MW_DISPATCH(c, { hipLaunchKernelGGL(k_mw_potrf_q_pipe<KK>, dim3(64 + (ride ? q.J : 0)), dim3(MWP_NT), std::max<size_t>(MWP_LDS_ALONE, ride ? c->sm_fwd : 0),
+                                            c->stream, q, c->pipe_epoch, c->ride_fwd); });
+        c->fwd_rode = ride;
+    } else if (q.N > 0 && c->lds_q) {
         // the interior-point iteration hands over the right-hand side of its next solve: the solve's first product pair rides on this launch
         const bool ride = c->ride_fwd != nullptr && !c->wide_solve;
         MW_DISPATCH(c, { hipLaunchKernelGGL(k_mw_potrf_q<KK>, dim3(MW_INV_WG + (ride ? q.J : 0)), dim3(MW_PT), ride ? std::max(c->sm_q, c->sm_fwd) : c->sm_q, c->stream, q, MW_INV_WG, c->ride_fwd); });
@@ -1339,6 +1376,23 @@ extern "C" int clrs_mw_get_S(clrs_mw_ctx *c, double *S_out, double *AY_out) {
     return 0;
 }
 
+// diagnostic (-DCLRS_MW_STAMPS builds): step stamps of the pipelined factorisations, [16 roles][40]: rows 0-7 the workgroups of cluster 0 in
+// k_mw_factor_pipe, rows 8-15 those of Q in k_mw_potrf_q_pipe; columns 0..n-1 the top of step k, 39 start, 38 end (100 MHz wall clock)
+extern "C" int clrs_mw_debug_pipe_stamps(clrs_mw_ctx *c, unsigned long long *out) {
+    if (!c) return mw_fail(CLRS_ERR_INVALID, "null context");
+#ifndef CLRS_MW_STAMPS
+    return mw_fail(CLRS_ERR_STATE, "this library was built without -DCLRS_MW_STAMPS");
+#endif
+    MWCHECK(hipSetDevice(c->device));
+    MWCHECK(hipStreamSynchronize(c->stream));
+    if (!c->d.pipe_stamps) {
+        double *p = nullptr;
+        int rc = mw_dmalloc(c, &p, 16 * 40);
+        if (rc) return rc;
+        c->d.pipe_stamps = (unsigned long long *)p;
+    } else if (out) MWCHECK(hipMemcpy(out, c->d.pipe_stamps, 16 * 40 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return 0;
+}
 // diagnostic: phase stamps (100 MHz wall clock) of wave 0 of the first workgroup of the next k_mws_pair launches; out[16] = the last ones
 extern "C" int clrs_mw_debug_exact_stamps(clrs_mw_ctx *c, unsigned long long *out) {
     if (!c) return mw_fail(CLRS_ERR_INVALID, "null context");

@@ -4,6 +4,7 @@
 
 #include "../../include/clrs_hip.h"
 #include "clrs_mw_kernels.hip.h"
+#include "clrs_mw_pipe.hip.h"
 #include "clrs_mw_exact.hip.h"
 #include "clrs_mw_ipm.hip.h"
 #include "clrs_mw_inst.h"

@@ -81,6 +81,9 @@ struct MwDev {
     // iterative refinement of the solve stage over many workgroups (k_mw_refine): the residual r_x (xlen), B^T dx of this rank's rows (N), the
     // correction (xlen, N); uadd: while the correction is solved, the vector subtracted from rhs_y beside sum_j u_j (= u2), else null
     double *S0;                         // S_j as assembled (S layout): the factorisation overwrites S with L_j, the residuals of the refinement need S_j
+    int pipe_q, pad6;                   // index of Q's region in pipe_pc
+    unsigned long long *pipe_stamps;    // diagnostic builds: [16][40] step stamps of the pipelined factorisations (clrs_mw_debug_pipe_stamps), or null
+    unsigned long long *pipe_pc;        // hand-off granules of the pipelined factorisations (clrs_mw_pipe.hip.h): [J + 1][MWP_PC_WORDS], or null
     double *ub;                         // u' slabs of the refinement step (J x N; k_mw_solve_bwd MODE 1 writes them while other workgroups read u)
     double *rx2, *u2, *dx2, *dy2;
     const double *uadd;

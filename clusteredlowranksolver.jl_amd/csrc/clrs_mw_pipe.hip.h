@@ -1,0 +1,352 @@
+// clrs_mw_pipe.hip.h -- Cholesky AND inverse factor of one small matrix (n <= 32: a cluster's S_j, or Q) as a PIPELINE of workgroups, gfx950.
+//
+// The elimination of wg_potrf (clrs_mw_kernels.hip.h: fraction-free, [M | I], one barrier per pivot) is a chain of n dependent pivot steps, and in
+// one workgroup a step costs 1.0 us + 0.65 us per wave-round of entries: the 32 x 32 matrices of the named problem start with nine wave-rounds on
+// four SIMDs (3.3 us per pivot) and average 2.5 us (k_mw_factor 93 us, k_mw_potrf_q 80 us: DESIGN.md section 5.5).  The trailing update cannot be
+// split over compute units without exchanging pivot columns -- but the exchange only ever runs ONE WAY when the matrix is split by COLUMN BLOCKS:
+//
+//   stage g (one workgroup, 256 entry threads with one entry each IN REGISTERS, and four loader waves) owns columns [8 g, 8 g + 8) of the lower triangle.  Pivot column k is
+//   final once pivots 0 .. k-1 have been applied to it; its owner publishes it the moment that is so.  A stage first applies the pivot columns of
+//   the stages before it, as they arrive (each is one step of at most 256 entry updates: ONE wave per SIMD), then runs its own eight pivots.  Nothing
+//   ever flows back, so a stage never waits for a later one: the chain is n steps of the cheapest kind (1.4-1.6 us) plus one hand-off per stage.
+//   The columns of W = [I] (the inverse factor) need every pivot column and nothing else: four more workgroups consume the same stream, each with
+//   a quarter of W's columns, again one entry per thread.
+//
+// Hand-off: a pivot column is <= 32 K-limb numbers = 1.3 KB at K = 5.  It travels as 8-byte {32 data bits, 32-bit tag} granules written with
+// agent-scope relaxed (sc1, write-through) stores and read with sc1 loads by ONE loader wave per consumer, which retries a granule until its tag
+// (launch epoch, pivot) matches -- MI355X_MICROARCH.md, "handoff-1to1": no flag, no fence, no ordering between granules is needed because every granule
+// carries its own validity; 0.8-1.0 us per hop, hidden behind the consumer's current step (the loader fetches column k + 1 while step k runs).
+// A consumer that reads a non-positive pivot stops exactly like its producer did (approx_cholesky!'s failure test, src/tools.jl:92-95); a loader
+// that never sees its tag gives up after a bounded number of polls and reports the failure instead of hanging.
+//
+// Measured (cohnelkies(8,15), 5 limbs, scripts/pipe_stamps.py, profiles/r04): a stage's own steps 1.45 us, steps that apply an incoming column 1.9 us, a
+// hop 4 us (not the 1 us of an idle hand-off: the column is asked for before it exists and found by polling); k_mw_factor 93 -> 85 us, k_mw_potrf_q
+// 80 -> 83 us (its launch also carries the first products of the next solve): the default (clrs_mw_options.pipeline = 1) pipelines the clusters only.
+//
+// The arithmetic per entry and pivot is wg_potrf's, in the same order: the factor, its reciprocal diagonal and the inverse are bit for bit those of
+// the one-workgroup kernels (tests/test_mw_parity.py::test_pipelined_factorisation_is_bit_identical).
+#ifndef CLRS_MW_PIPE_HIP_H
+#define CLRS_MW_PIPE_HIP_H
+
+#define MWP_N 32             // largest matrix side
+#define MWP_W 8              // columns per stage
+#define MWP_WW 4             // workgroups that share the columns of W
+#define MWP_ET 256           // entry threads per workgroup: MWP_W columns x MWP_N rows
+#define MWP_NL 4             // LOADER waves: each fetches every MWP_NL-th pivot column, MWP_NL steps ahead of the entry waves (the first one also publishes this stage's own)
+#define MWP_NT (MWP_ET + 64 * MWP_NL)
+#define MWP_SPIN_LIMIT (1 << 22)
+#define MWP_GRANULES(K) ((K) * MWP_N * 2)                 // granules of one published pivot column
+#define MWP_PC_WORDS(K) ((long)MWP_N * MWP_GRANULES(K))    // ... of one matrix (MWP_N pivots)
+
+struct MwPipeMat {           // one matrix of a pipelined factorisation
+    const double *in;        // input: planar n x n (leading dimension n), lower triangle read; in_slots > 1: the sum of that many arrays, in order
+    long inplane, in_stride;
+    int in_slots, n;
+    double *L, *rd, *Inv;    // outputs: factor (strict upper triangle zeroed), reciprocal diagonal, inverse factor (upper triangle zeroed)
+    long lplane, rdplane, invplane;
+    unsigned long long *pc;  // MWP_PC_WORDS granules: the published pivot columns
+    int fail_code;           // atomicMin'ed into info[0] at a non-positive pivot
+    unsigned long long *stamps;   // diagnostic builds (-DCLRS_MW_STAMPS): [roles][40] time stamps, or null
+};
+
+namespace mwk {
+
+__device__ __forceinline__ void mwp_store(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long mwp_load(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// publish entry (i, k) of pivot column k: 2 K granules
+template <int K>
+__device__ __forceinline__ void mwp_publish(unsigned long long *pcol, unsigned tag, int i, const mw<K> &v) {
+#pragma unroll
+    for (int l = 0; l < K; l++) {
+        const unsigned long long b = (unsigned long long)__double_as_longlong(v.l[l]), t = (unsigned long long)tag << 32;
+        mwp_store(pcol + ((long)l * MWP_N + i) * 2, t | (b & 0xffffffffull));
+        mwp_store(pcol + ((long)l * MWP_N + i) * 2 + 1, t | (b >> 32));
+    }
+}
+// the loader wave (64 lanes) publishes rows r0 .. n-1 of a pivot column held in LDS (planar, plane MWP_N)
+template <int K>
+__device__ __forceinline__ void mwp_publish_column(unsigned long long *pcol, unsigned tag, int r0, int n, const lds_d *buf, int lane) {
+    const int rows = n - r0, cnt = rows * K;
+    const unsigned long long t = (unsigned long long)tag << 32;
+    for (int e = lane; e < cnt; e += 64) {
+        const int l = e / rows, i = r0 + e % rows;
+        const unsigned long long b = (unsigned long long)__double_as_longlong((double)buf[(long)l * MWP_N + i]);
+        unsigned long long *g = pcol + ((long)l * MWP_N + i) * 2;
+        const unsigned long long g0 = t | (b & 0xffffffffull), g1 = t | (b >> 32);
+#ifdef MWP_PLAIN_PUBLISH
+        *(volatile unsigned long long *)g = g0;
+        *(volatile unsigned long long *)(g + 1) = g1;
+#else
+        mwp_store(g, g0);
+        mwp_store(g + 1, g1);
+#endif
+    }
+#ifdef MWP_PLAIN_PUBLISH
+    // Tried and NOT used (-DMWP_PLAIN_PUBLISH): plain stores, which leave the lines in this XCD's L2 where the sc1 loads of a consumer on the same XCD would
+    // find them (the kernels' block map puts the workgroups of a matrix on one XCD), and one agent-scope write-back of the L2 behind them for consumers
+    // elsewhere.  The wait for the stores and the write-back hold the publishing wave for ~2 us, and with it the barrier of every one of this stage's own
+    // steps: 3.3 us per step instead of 1.45, kernel 103 us instead of 86 (measured).  Plain stores ON TOP of the sc1 stores: the same.
+    asm volatile("s_waitcnt vmcnt(0)\n\tbuffer_wbl2 sc1" ::: "memory");
+#endif
+}
+// A loader wave (64 lanes) fetches row `prow` (the pivot) and rows r0 .. n-1 of a pivot column in two halves: `issue` sends every load of the column
+// at once, `complete` -- a step later -- looks at the tags, polls the granules that were not there yet one by one and writes the numbers to LDS
+// (planar, plane MWP_N); it returns false when a granule never arrived.  A hop is ~2.5 us (measured, scripts/pipe_stamps.py: the producer's sc1
+// stores drop the line from its L2, the consumer's sc1 loads go to memory; 4-5 us when the first poll comes too early), the producers publish a column
+// every 1.5 us: with ONE column in flight a consumer ran at 2.6 us per step, with two at 2.1.  So MWP_NL loader waves take turns: wave p fetches the
+// columns j = p (mod MWP_NL), sends for column j + MWP_NL the moment it has delivered column j, and so has MWP_NL steps per column.
+template <int K>
+struct MwpFetch {
+    static constexpr int R = (K * MWP_N + 63) / 64;            // passes of the wave over the K MWP_N numbers of a whole column
+    unsigned long long a[R], b[R];
+    int off[R];                                                 // (l MWP_N + i) of this lane's numbers: the same for every column (no index arithmetic per step)
+    bool want[R];                                               // of the column in flight: the rows this workgroup reads (the pivot, and rows r0 ..)
+    const unsigned long long *col;
+    __device__ __forceinline__ void init(int n, int lane) {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int t = lane + 64 * r, l = t / MWP_N, i = t % MWP_N;
+            off[r] = (l < K && i < n) ? l * MWP_N + i : -1;
+            want[r] = false; a[r] = b[r] = 0;
+        }
+        col = nullptr;
+    }
+    __device__ __forceinline__ void issue(const unsigned long long *pcol, int prow, int r0) {
+        col = pcol;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int i = off[r] & (MWP_N - 1);
+            want[r] = off[r] >= 0 && (i == prow || i >= r0);
+            if (want[r]) {
+                const unsigned long long *g = pcol + (long)off[r] * 2;
+                a[r] = mwp_load(g);
+                b[r] = mwp_load(g + 1);
+            }
+        }
+    }
+    // `sentinel`: the granule the publisher stores LAST (limb K - 1 of row n - 1, second half).  A column that was not there when `issue` ran is not
+    // polled granule by granule -- the waves of the workgroups behind one producer would hammer the lines its stores are queued at (measured: the
+    // producer's own steps 2.5 us instead of 1.45, in both forms: whole columns and only the rows read) -- but by ONE address per wave; when its tag
+    // is there, the rows are loaded again, and any granule that still is not is polled like that again.
+    __device__ __forceinline__ bool complete(unsigned tag, lds_d *buf, const unsigned long long *sentinel) {
+        int spins = 0;
+        for (;;) {
+            bool mine = true;
+#pragma unroll
+            for (int r = 0; r < R; r++) mine = mine && (!want[r] || ((unsigned)(a[r] >> 32) == tag && (unsigned)(b[r] >> 32) == tag));
+            if (__all(mine)) break;
+            while ((unsigned)(mwp_load(sentinel) >> 32) != tag && spins < MWP_SPIN_LIMIT) {
+                __builtin_amdgcn_s_sleep(2);
+                spins++;
+            }
+            if (++spins >= MWP_SPIN_LIMIT) break;
+#pragma unroll
+            for (int r = 0; r < R; r++)
+                if (want[r]) {
+                    const unsigned long long *g = col + (long)off[r] * 2;
+                    a[r] = mwp_load(g); b[r] = mwp_load(g + 1);
+                }
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++)
+            if (want[r]) buf[off[r]] = __longlong_as_double((long long)((a[r] & 0xffffffffull) | (b[r] << 32)));
+        return spins < MWP_SPIN_LIMIT;
+    }
+};
+
+// The barrier of a pivot step: LDS traffic only.  __syncthreads() also waits for the vector-memory counter, i.e. for the write-through (sc1) stores of
+// the pivot column this step has just published -- a fabric round trip on the dependent chain of every pivot (measured: 3 us per step instead of 1.5).
+// The published granules need no ordering (each carries its tag); what the next step reads comes from LDS.
+__device__ __forceinline__ void mwp_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// one elimination step on one entry: v <- (dh v - (ci ph)(cj ph)) with dh = d 2^-ex, ph = 2^(-ex/2)  (wg_potrf's step)
+template <int K>
+__device__ __forceinline__ mw<K> mwp_step(const mw<K> &dh, double ph, const mw<K> &v, const mw<K> &ci, const mw<K> &cj) {
+    acc<K> s;
+    acc_zero<K>(s);
+    acc_fma<K, K, K>(s, dh, v);
+    acc_fma<K, K, K>(s, mul_pow2<K>(ci, ph), mul_pow2<K>(cj, ph), -1.0);
+    return acc_result<K>(s);
+}
+
+// LDS of one workgroup: two pivot-column buffers, the products s_k of the scaled pivots, the pivots, the post-processing factors, W's row k
+template <int K>
+struct MwpLds {                                      // (no arrays of pointers: indexing one with k & 1 would put it in scratch memory, a round trip per pivot)
+    lds_d *col0, *us, *dd, *fs, *rs, *wrow0;
+    int *flag;
+    __device__ __forceinline__ MwpLds(lds_d *base) {
+        col0 = base;
+        us = col0 + 2L * K * MWP_N; dd = us + (long)K * (MWP_N + 1); fs = dd + (long)K * MWP_N; rs = fs + (long)K * MWP_N;
+        wrow0 = rs + (long)K * MWP_N;
+        flag = (int *)(wrow0 + 2L * K * MWP_W);
+    }
+    __device__ __forceinline__ lds_d *col(int k) const { return col0 + (long)(k & 1) * K * MWP_N; }
+    __device__ __forceinline__ lds_d *wrow(int k) const { return wrow0 + (long)(k & 1) * K * MWP_W; }
+};
+// LDS a workgroup ASKS for: more than half of a compute unit's 160 KB, so that no two workgroups of these kernels share a compute unit (with the
+// workgroups of a matrix on one XCD the dispatcher packed several per compute unit: their steps took 3.5 us instead of 1.45, measured)
+#define MWP_LDS_ALONE ((size_t)84 * 1024)
+#define MWP_LDS_DOUBLES(K) ((K) * (6 * MWP_N + 1 + 2 * MWP_W) + 2)
+
+// role < stages: stage `role` of the elimination of M; role >= stages: workgroup role - stages of the MWP_WW that form W.  Returns false at a
+// non-positive pivot (or a hand-off that never arrived); every workgroup of the matrix then stops at the same pivot.
+template <int K>
+__device__ __forceinline__ bool mwp_run(const MwPipeMat &m, int role, unsigned epoch, int *info, int tid) {
+    const int n = m.n, stages = (n + MWP_W - 1) / MWP_W;
+    MwpLds<K> S(MW_LDS);
+    const bool loader = tid >= MWP_ET;                                       // waves 4 ..: hand-offs and the running product s_k
+    const int lw = (tid - MWP_ET) >> 6, lane = (tid - MWP_ET) & 63;          // (loader waves only)
+    const int cc = (tid >> 5) & 7, i = tid & 31;
+    const bool is_w = role >= stages;
+    const int c0 = is_w ? 0 : role * MWP_W, c1 = is_w ? n : min(c0 + MWP_W, n);
+    const int c = is_w ? (role - stages) + MWP_WW * cc : c0 + cc;            // my column
+    const bool live = !loader && c < c1 && i >= c && i < n;
+    const int nfetch = is_w ? n : c0;                                        // columns 0 .. nfetch - 1 come from other workgroups
+    mw<K> v = zero<K>();
+    if (!is_w && live) {
+        if (m.in_slots > 1) {
+            acc<K> s;
+            acc_zero<K>(s);
+            for (int r = 0; r < m.in_slots; r++) acc_add<K, K>(s, ldx<K>(m.in + (long)r * m.in_stride, m.inplane, i + (long)c * n));
+            v = acc_result<K>(s);
+        } else v = ldx<K>(m.in, m.inplane, i + (long)c * n);
+    }
+    if (tid == MWP_ET) { stx<K>(S.us, MWP_N + 1, 0, from_double<K>(1.0)); *S.flag = 1; }
+    MwpFetch<K> F;
+    F.init(n, lane);
+    const unsigned tag0 = epoch << 5;
+    // column 0: stage 0 owns it, everybody else fetches it; columns 1 .. MWP_NL are on their way when step 0 begins
+    if (!is_w && c0 == 0) {
+        if (live && c == 0) stx<K>(S.col(0), MWP_N, i, v);
+    } else if (loader && lw == 0) {
+        F.issue(m.pc, 0, is_w ? 0 : c0);
+        if (!F.complete(tag0, S.col(0), m.pc + ((long)(K - 1) * MWP_N + n - 1) * 2 + 1)) *S.flag = 0;
+    }
+    if (loader) {
+        const int j = lw == 0 ? MWP_NL : lw;
+        if (j < nfetch) F.issue(m.pc + (long)j * MWP_GRANULES(K), j, is_w ? j : c0);
+    }
+    __syncthreads();
+    const int kend = is_w ? n : c1;                                          // pivots this workgroup looks at: 0 .. kend - 1
+#ifdef CLRS_MW_STAMPS            // diagnostic builds: wall clock (100 MHz) of thread 0 at the top of every step, per role, for the matrix with m.stamps != null
+    unsigned long long *stamps = m.stamps ? m.stamps + (long)role * 40 : nullptr;
+    if (stamps && tid == 0) stamps[39] = wall_clock64();
+#endif
+    for (int k = 0; k < kend; k++) {
+#ifdef CLRS_MW_STAMPS
+        if (stamps && tid == 0) stamps[k] = wall_clock64();
+#endif
+        lds_d *cur = S.col(k), *nxt = S.col(k + 1);
+        const mw<K> d = ldx<K>(cur, MWP_N, k);
+        if (!(*S.flag) || !(d.l[0] > 0.0)) {                                 // uniform: every thread reads the same words
+            if (tid == 0) atomicMin(info, m.fail_code);
+            return false;
+        }
+        if (is_w && tid == MWP_ET) stx<K>(S.dd, MWP_N, k, d);
+        // a column this stage owns goes to the stages and the W workgroups behind it from HERE, out of LDS, by a loader wave: a store of the entry waves
+        // would put its wait for the write-through on the dependent chain (the compiler guards the stored registers with s_waitcnt vmcnt)
+        if (loader && lw == 0 && !is_w && k >= c0) mwp_publish_column<K>(m.pc + (long)k * MWP_GRANULES(K), tag0 | (unsigned)k, k, n, cur, lane);
+        if (k + 1 >= kend) break;
+        double p1, ph;
+        pivot_scale(d.l[0], p1, ph);
+        const mw<K> dh = mul_pow2<K>(d, p1);
+        if (loader) {
+            if ((k + 1) % MWP_NL == lw) {                                    // my turn: deliver column k + 1 (sent for MWP_NL steps ago), send for the next of mine
+                if (k + 1 < nfetch && !F.complete(tag0 | (unsigned)(k + 1), nxt, m.pc + (long)(k + 1) * MWP_GRANULES(K) + ((long)(K - 1) * MWP_N + n - 1) * 2 + 1)) *S.flag = 0;
+                const int j = k + 1 + MWP_NL;
+                if (j < nfetch) F.issue(m.pc + (long)j * MWP_GRANULES(K), j, is_w ? j : c0);
+            }
+            // s_(k+1) = s_k dh_k: one K-limb product per step, off the chain, on the first loader wave: it shares its SIMD with entry wave 0, which in a
+            // stage's own steps is the first to run out of live columns (moving it to another SIMD made those steps 1.9-2.9 us instead of 1.45: measured)
+            if (tid == MWP_ET) stx<K>(S.us, MWP_N + 1, k + 1, mul<K>(ldx<K>(S.us, MWP_N + 1, k), dh));
+        } else if (!is_w) {
+            if (live && c > k) v = mwp_step<K>(dh, ph, v, ldx<K>(cur, MWP_N, i), ldx<K>(cur, MWP_N, c));
+            if (k + 1 >= c0 && live && c == k + 1) stx<K>(nxt, MWP_N, i, v);      // my stage's column k + 1 is final now: to this stage's next step
+        } else {
+            // W: entries (i, c) with c <= k < i; row k of W comes from the thread that owns (k, c), through LDS; w_kk = s_k
+            if (live && c <= k && i > k) {
+                const mw<K> wk = c == k ? ldx<K>(S.us, MWP_N + 1, k) : ldx<K>(S.wrow(k), MWP_W, cc);
+                v = mwp_step<K>(dh, ph, v, ldx<K>(cur, MWP_N, i), wk);
+            }
+            if (live && i == k + 1 && c <= k) stx<K>(S.wrow(k + 1), MWP_W, cc, v);
+        }
+        mwp_barrier();
+    }
+    __syncthreads();
+    // post-processing (wg_potrf's): f_k = 1 / sqrt(s_k d~_k); L_kk = d~_k f_k, 1 / L_kk = f_k s_k; L_ik = a~_ik f_k; (L^-1)_ij = W_ij f_i
+    if (!is_w) {
+        if (live && i == c) {
+            const mw<K> sk = ldx<K>(S.us, MWP_N + 1, c), f = rsqrt<K>(mul<K>(sk, v)), r = mul<K>(f, sk);
+            stx<K>(S.fs, MWP_N, cc, f);
+            stx<K>(m.rd, m.rdplane, c, r);
+        }
+        __syncthreads();
+        if (!loader && c < c1 && i < n) stx<K>(m.L, m.lplane, i + (long)c * n, i >= c ? mul<K>(v, ldx<K>(S.fs, MWP_N, cc)) : zero<K>());
+    } else {
+        if (tid < n) {                                                       // (every W workgroup needs every f_i: n reciprocal square roots side by side)
+            const mw<K> sk = ldx<K>(S.us, MWP_N + 1, tid), dt = ldx<K>(S.dd, MWP_N, tid), f = rsqrt<K>(mul<K>(sk, dt));
+            stx<K>(S.fs, MWP_N, tid, f);
+            stx<K>(S.rs, MWP_N, tid, mul<K>(f, sk));
+        }
+        __syncthreads();
+        if (!loader && c < n && i < n) stx<K>(m.Inv, m.invplane, i + (long)c * n, i > c ? mul<K>(v, ldx<K>(S.fs, MWP_N, i)) : i == c ? ldx<K>(S.rs, MWP_N, i) : zero<K>());
+    }
+#ifdef CLRS_MW_STAMPS
+    if (stamps && tid == 0) stamps[38] = wall_clock64();
+#endif
+    return true;
+}
+
+}  // namespace mwk
+
+// Block index -> (matrix, role): blocks are dealt to the 8 XCDs round-robin (observed, not promised: MI355X_MICROARCH.md), so the 8 workgroups of a matrix
+// (up to 4 stages + 4 for W) get block indices that agree modulo 8 -- matrix j of a group of 8 matrices has the blocks 64 (j / 8) + (j % 8) + 8 role.
+// Earlier stages have lower block indices.  Placement is a speed matter only: the hand-off is correct anywhere.
+#define MWP_ROLES 8
+__device__ __forceinline__ void mwp_block_map(int b, int &matrix, int &role) {
+    matrix = (b & 7) + 8 * (b >> 6);
+    role = (b >> 3) & 7;
+}
+static inline int mwp_blocks(int matrices) { return 64 * ((matrices + 7) / 8); }
+
+// L_j = chol(S_j) and L_j^-1 of every cluster with P <= MWP_N: mwp_blocks(J) workgroups
+template <int K>
+__global__ __launch_bounds__(MWP_NT) void k_mw_factor_pipe(const MwDev q, unsigned epoch) {
+    using namespace mwk;
+    int j, role;
+    mwp_block_map(blockIdx.x, j, role);
+    if (j >= q.J) return;
+    const MwClu &c = q.clu[j];
+    const int P = c.P, stages = (P + MWP_W - 1) / MWP_W;
+    if (role >= stages + MWP_WW) return;
+    MwPipeMat m;
+    m.in = q.S + c.Soff; m.inplane = q.Slen; m.in_stride = 0; m.in_slots = 1; m.n = P;
+    m.L = q.S + c.Soff; m.lplane = q.Slen; m.rd = q.srd + c.coff; m.rdplane = q.xlen; m.Inv = q.Si + c.Soff; m.invplane = q.Slen;
+    m.pc = q.pipe_pc + (long)j * MWP_PC_WORDS(K);
+    m.fail_code = j + 1;
+    m.stamps = j == 0 && q.pipe_stamps ? q.pipe_stamps : nullptr;
+    mwp_run<K>(m, role, epoch, &q.info[0], threadIdx.x);
+}
+
+// L_Q = chol(Q), Q = the sum of the ranks' partial sums, and L_Q^-1: the blocks 0, 8, 16, ... of the first 64 (one XCD); the blocks from 64 on carry the
+// first product pair of the next solve (as in k_mw_potrf_q), one cluster each
+template <int K>
+__global__ __launch_bounds__(MWP_NT) void k_mw_potrf_q_pipe(const MwDev q, unsigned epoch, const double *__restrict__ fwd_rhs) {
+    using namespace mwk;
+    if (blockIdx.x >= 64) { mw_solve_fwd_cluster<K>(q, blockIdx.x - 64, fwd_rhs); return; }
+    int mtx, role;
+    mwp_block_map(blockIdx.x, mtx, role);
+    const int N = q.N;
+    if (mtx != 0 || role >= (N + MWP_W - 1) / MWP_W + MWP_WW) return;
+    if (q.info[0] != MW_INFO_NONE) return;                          // a cluster failed: the reference throws before reaching Q
+    MwPipeMat m;
+    m.in = q.Qg; m.inplane = (long)N * N; m.in_stride = (long)K * N * N; m.in_slots = q.world; m.n = N;
+    m.L = q.Q; m.lplane = (long)N * N; m.rd = q.qrd; m.rdplane = N; m.Inv = q.Qi; m.invplane = (long)N * N;
+    m.pc = q.pipe_pc + (long)q.pipe_q * MWP_PC_WORDS(K);
+    m.fail_code = q.J + 1;
+    m.stamps = q.pipe_stamps ? q.pipe_stamps + 8 * 40 : nullptr;
+    mwp_run<K>(m, role, epoch, &q.info[0], threadIdx.x);
+}
+
+#endif

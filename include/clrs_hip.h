@@ -297,7 +297,8 @@ int clrs_mw_create_ex(const clrs_sdp_desc *desc, int data_limbs, int device, int
 typedef struct clrs_mw_options {
     int32_t exact_products;
     int32_t refine;
-    int32_t reserved[6];
+    int32_t pipeline;        /* factorisations of matrices of at most 32 rows as a pipeline of workgroups: 0 never / 1 the clusters' S_j (default) / 2 and Q */
+    int32_t reserved[5];
 } clrs_mw_options;
 int clrs_mw_create_opts(const clrs_sdp_desc *desc, int data_limbs, int device, int limbs, const clrs_mw_options *opts, clrs_mw_ctx **out);
 void clrs_mw_destroy(clrs_mw_ctx *ctx);
@@ -314,6 +315,7 @@ int clrs_mw_schur_assemble(clrs_mw_ctx *ctx, const double *Xchol, const double *
 int clrs_mw_schur_factor(clrs_mw_ctx *ctx);
 int clrs_mw_get_factor(clrs_mw_ctx *ctx, double *L, double *LinvB, double *LQ);
 int clrs_mw_debug_exact_stamps(clrs_mw_ctx *ctx, unsigned long long *out /* [16] */);   /* diagnostic: first call arms, later calls read the phase stamps of k_mws_pair */
+int clrs_mw_debug_pipe_stamps(clrs_mw_ctx *ctx, unsigned long long *out /* [16 * 40] */);   /* diagnostic builds (-DCLRS_MW_STAMPS) only: DESIGN.md section 5.5 */
 int clrs_mw_get_S(clrs_mw_ctx *ctx, double *S_out, double *AY_out);   /* S_j and A_Y of the last (device-pointer) assembly -> host; NULL pointers are skipped */
 /* the solve stage of compute_search_direction! (src/solver.jl:1527-1582) */
 int clrs_mw_schur_solve(clrs_mw_ctx *ctx, const double *rhs_x, const double *rhs_y, double *dx, double *dy);
