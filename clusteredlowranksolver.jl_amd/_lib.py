@@ -65,7 +65,7 @@ class IpmStop(C.Structure):
 
 class MwOptions(C.Structure):
     """struct clrs_mw_options"""
-    _fields_ = [("exact_products", C.c_int32), ("refine", C.c_int32), ("pipeline", C.c_int32), ("reserved", C.c_int32 * 5)]
+    _fields_ = [("exact_products", C.c_int32), ("refine", C.c_int32), ("pipeline", C.c_int32), ("refine_predictor", C.c_int32), ("reserved", C.c_int32 * 4)]
 
 
 class ClrsError(RuntimeError):

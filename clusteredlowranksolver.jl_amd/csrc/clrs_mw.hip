@@ -38,6 +38,7 @@ MW_KERNELS_ALL(extern template, 10)
 typedef long long i64;
 
 extern int g_cfg_mw_pipeline;                            // clrs_hip.hip, clrs_config_set("mw_pipeline", 0 / 1): read at context creation
+extern int g_cfg_mw_refine_predictor;                    // clrs_hip.hip, clrs_config_set("mw_refine_predictor", 0 / 1)
 extern int g_cfg_mw_refine;                              // clrs_hip.hip, clrs_config_set("mw_refine", 0 / 1): read at context creation
 extern int g_cfg_mw_exact_products;                      // clrs_hip.hip, clrs_config_set("mw_exact_products", 0 / 1 / 2): read at context creation
 extern "C" void clrs_set_last_error(const char *msg);   // clrs_hip.hip: the library keeps one thread-local message
@@ -167,6 +168,8 @@ struct clrs_mw_ctx {
     bool pipe_S = false, pipe_Q = false;  // the factorisations of the clusters / of Q as pipelines of workgroups (clrs_mw_pipe.hip.h): every matrix <= 32 rows, few clusters
     int pipe_pcQ = 0;                    // index of Q's hand-off region in pipe_pc
     unsigned pipe_epoch = 0;             // launch counter: the tag of the hand-off granules
+    bool refine_skip_next = false;       // the interior-point iteration's PREDICTOR solve: one pass (set by clrs_mw_ipm_host.inc for the next clrs_mw_schur_solve_dev only)
+    int refine_predictor = 0;            // clrs_mw_options.refine_predictor: 1 = the predictor's solve is refined like every other
     int refine = 1;                      // iterative refinement of the solve stage (clrs_mw_options / clrs_config_set("mw_refine")): 0 off, 1 one step with the correction in all K limbs, 2 ... in mw_kc(K) limbs
     bool ipm_arms_info = false;          // inside the device-resident iteration the status words are re-armed by a kernel, not by a memset per call
 };
@@ -226,6 +229,7 @@ extern "C" int clrs_mw_create_opts(const clrs_sdp_desc *d, int data_limbs, int d
     const int cfg_exact = opts && opts->exact_products >= 0 ? opts->exact_products : g_cfg_mw_exact_products;
     const int cfg_refine = opts && opts->refine >= 0 ? opts->refine : g_cfg_mw_refine;
     const int cfg_pipe = opts && opts->pipeline >= 0 ? opts->pipeline : g_cfg_mw_pipeline;
+    const int cfg_refine_pred = opts && opts->refine_predictor >= 0 ? opts->refine_predictor : g_cfg_mw_refine_predictor;
     if (cfg_exact > 2 || cfg_refine > 2) return mw_fail(CLRS_ERR_INVALID, "clrs_mw_options: exact_products and refine are 0, 1 or 2 (or < 0 for the default)");
     if (limbs < 2 || limbs > 10 || limbs == 7 || limbs == 9) return mw_fail(CLRS_ERR_INVALID, "limbs must be 2..6, 8 or 10");
     if (data_limbs < 1 || data_limbs > 2 || data_limbs > limbs) return mw_fail(CLRS_ERR_INVALID, "data limbs must be 1 or 2 (and at most limbs)");
@@ -722,11 +726,12 @@ extern "C" int clrs_mw_create_opts(const clrs_sdp_desc *d, int data_limbs, int d
     MW_TRY(mw_dmalloc(c, &q.u2, (i64)N * K)); MW_TRY(mw_dmalloc(c, &q.dy2, (i64)N * K));
     q.uadd = nullptr;
     c->refine = cfg_refine;
+    c->refine_predictor = cfg_refine_pred;
     c->wide_solve = c->maxP > 64 || N > 64;
     {   // pipelined factorisations (clrs_mw_pipe.hip.h): matrices of at most 32 rows, while stages + W workgroups of every matrix can be resident side by side
         bool small = c->maxP <= MWP_N;
         for (auto &cl : c->clu) small = small && cl.lds;
-        c->pipe_S = cfg_pipe != 0 && small && (i64)J * ((MWP_N / MWP_W) + MWP_WW) <= 256;
+        c->pipe_S = cfg_pipe != 0 && (K <= 6 || cfg_pipe >= 2) && small && (i64)J * ((MWP_N / MWP_W) + MWP_WW) <= 256;      // (8, 10 limbs: measured slower than one workgroup, 2.42 against 2.34 ms per iteration: opt-in)
         c->pipe_Q = cfg_pipe >= 2 && N > 0 && N <= MWP_N;      // (Q: slower than the one-workgroup kernel on the named problem, 83 against 80 us: opt-in)
         q.pipe_pc = nullptr;
         q.pipe_stamps = nullptr;
@@ -1314,10 +1319,12 @@ extern "C" int clrs_mw_schur_solve_dev(clrs_mw_ctx *c, const double *d_rhs_x, co
     if (q.N > 0 && (!d_rhs_y || !d_dy)) return mw_fail(CLRS_ERR_INVALID, "null argument");
     MWCHECK(hipSetDevice(c->device));
     int rc = 0;
+    const int refine = c->refine_skip_next ? 0 : c->refine;
+    c->refine_skip_next = false;
     if (c->wide_solve && !q.gathered) {                  // large clusters or a large Q: one launch per product, rows over many workgroups
         if (c->timing) MWCHECK(hipEventRecord(c->ev[6], c->stream));
         if ((rc = mw_solve_wide_once(c, d_rhs_x, d_rhs_y, d_dx, d_dy))) return rc;
-        if (c->refine) {
+        if (refine) {
             constexpr int RPW = MW_NT / MW_SW_L;
             const int rowsP = (c->maxP + RPW - 1) / RPW, rowsN = (q.N + RPW - 1) / RPW;
             MW_DISPATCH(c, hipLaunchKernelGGL((k_mw_refine<KK, DD>), dim3(std::max(rowsP, rowsN), q.J + (q.N > 0 ? 1 : 0)), dim3(MW_NT), 0, c->stream, q, 1, d_rhs_x, d_dx, d_dy));
@@ -1345,8 +1352,8 @@ extern "C" int clrs_mw_schur_solve_dev(clrs_mw_ctx *c, const double *d_rhs_x, co
     if (rc) return rc;
     if (q.gathered && q.N > 0 && (rc = mw_allgather(c, 0, q.ug, (size_t)q.N * c->K, c->stream))) return rc;
     c->split_rhs_x = nullptr;
-    if (!c->refine) return clrs_mw_schur_solve_bwd_dev(c, d_rhs_y, d_dx, d_dy);
-    const bool full_kc = c->refine != 2;                  // 2: the correction in mw_kc(K) limbs (opt-in: valid while twice the lost bits fit in them)
+    if (!refine) { const int keep = c->refine; c->refine = 0; rc = clrs_mw_schur_solve_bwd_dev(c, d_rhs_y, d_dx, d_dy); c->refine = keep; return rc; }
+    const bool full_kc = refine != 2;                  // 2: the correction in mw_kc(K) limbs (opt-in: valid while twice the lost bits fit in them)
     if ((rc = mw_solve_bwd(c, q, d_rhs_x, d_rhs_y, d_dx, d_dy, 1, full_kc))) return rc;
     MwDev q2 = q;
     q2.u = q.ub;                                         // (the first half of the step wrote its u' beside the u the other workgroups were still reading)

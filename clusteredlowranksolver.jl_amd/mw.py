@@ -83,11 +83,12 @@ class MwSchurContext:
     """Device context of the hot path for one SDP at `limbs` words per number (see module docstring)."""
 
     def __init__(self, sdp, limbs: int = 4, device: int = 0, timing: bool = False, data_limbs: int = 2, exact_products: Optional[bool] = None,
-                 refine: Optional[int] = None, pipeline=None):
+                 refine: Optional[int] = None, pipeline=None, refine_predictor: Optional[bool] = None):
         """`exact_products`: the pairing matrices through exact slice products on the matrix cores (k_mws_pair, csrc/clrs_mw_exact.hip.h):
         None = automatic (contexts with >= 256 eligible PSD blocks), True = always, False = never.
         `refine`: iterative refinement of the solve stage (k_mw_refine): None = the library default (one step), 0 = none (products with the inverse
         factors only), 1 = the default, 2 = one step with the correction in fewer limbs (cheaper; as good while twice the lost bits fit in them).
+        `refine_predictor`: in `solvesdp_mw`, whether the predictor's solve takes the refinement step too (None / False: the corrector's only).
         `pipeline`: Cholesky + inverse factor of matrices of at most 32 rows as a pipeline of workgroups (csrc/clrs_mw_pipe.hip.h): None = the library
         default (the clusters' S_j), False / 0 = never, 1 = S_j, True / 2 = S_j and Q.
         `data_limbs` = 2 (default): the problem data (sampled vectors, lambda, dense A_p, B and, in `solvesdp_mw`, C, c, b) are
@@ -127,7 +128,7 @@ class MwSchurContext:
             setattr(d, name, _dp(data(name)))
         h = C.c_void_p()
         opts = _lib.MwOptions(-1 if exact_products is None else (2 if exact_products else 0), -1 if refine is None else int(refine),
-                              -1 if pipeline is None else (2 if pipeline is True else int(pipeline)))
+                              -1 if pipeline is None else (2 if pipeline is True else int(pipeline)), -1 if refine_predictor is None else int(bool(refine_predictor)))
         _lib.check(self.L.clrs_mw_create_opts(C.byref(d), self.data_limbs, int(device), self.limbs, C.byref(opts), C.byref(h)))
         self.h = h
         self.device = device

@@ -298,7 +298,8 @@ typedef struct clrs_mw_options {
     int32_t exact_products;
     int32_t refine;
     int32_t pipeline;        /* factorisations of matrices of at most 32 rows as a pipeline of workgroups: 0 never / 1 the clusters' S_j (default) / 2 and Q */
-    int32_t reserved[5];
+    int32_t refine_predictor; /* clrs_mw_ipm_*: 0 (default) the predictor's solve is one pass of products, the corrector's is refined; 1 both are refined */
+    int32_t reserved[4];
 } clrs_mw_options;
 int clrs_mw_create_opts(const clrs_sdp_desc *desc, int data_limbs, int device, int limbs, const clrs_mw_options *opts, clrs_mw_ctx **out);
 void clrs_mw_destroy(clrs_mw_ctx *ctx);
