@@ -528,15 +528,27 @@ def main():
                     step()
                 t_f = ctx.timings()[1]                      # chol S_j + L^-1 B of the last pass (HIP events on the context stream)
                 ctx.set_timing(False)
+                tm5 = ctx.timings()
                 insts, cus = fc["k_mw_factor"]["SQ_INSTS_VALU"], fc["k_mw_factor"]["workgroups"]
                 t_k = fc["k_mw_factor"]["share_of_stage"] * t_f
                 peak = cus * 4 * 2.4e9 / 4.0                # fp64 VALU wave instructions per second of the occupied compute units
-                out["roofline_timed"] = {"kernel": "k_mw_factor", "bound": "fp64 VALU issue of the occupied compute units", "unit": "G wave-instructions/s",
+                kname = fc["k_mw_factor"].get("kernel", "k_mw_factor")
+                out["roofline_timed"] = {"kernel": kname, "bound": "fp64 VALU issue of the occupied compute units", "unit": "G wave-instructions/s",
                                          "achieved": insts / t_k / 1e9, "peak": peak / 1e9, "frac": insts / t_k / peak, "traffic": None,
                                          "kernel_us": 1e6 * t_k, "compute_units": cus, "of_256_compute_units": cus / 256.0,
                                          "valu_wave_instructions": insts, "source": fc["source"],
                                          "what": "SQ_INSTS_VALU x 4 cycles / (occupied CUs x 4 SIMDs x kernel cycles): the chain of 32 dependent pivot steps of a "
-                                                 "fraction-free elimination keeps 8 of 256 compute units busy at this share of their fp64 issue slots"}
+                                                 "fraction-free elimination -- since round 4 a pipeline of column-block stages over workgroups (clrs_mw_pipe.hip.h) -- "
+                                                 "keeps this many of 256 compute units busy at this share of their fp64 issue slots",
+                                         "other_chains": {}}
+                # the two other pivot chains of the timed step: Cholesky of Q (duration live: HIP events of the context), Cholesky of the X blocks (duration of the counter pass)
+                for key, t_live in (("k_mw_potrf_q", tm5[4]), ("k_mw_potrf_x", None)):
+                    if key in fc:
+                        e = fc[key]
+                        t_c = t_live if t_live else 1e-6 * e["duration_us"]
+                        pk = e["workgroups"] * 4 * 2.4e9 / 4.0
+                        out["roofline_timed"]["other_chains"][key] = {"kernel_us": 1e6 * t_c, "duration": "live (HIP events)" if t_live else "counter pass", "compute_units": e["workgroups"],
+                                                                      "valu_wave_instructions": e["SQ_INSTS_VALU"], "frac": e["SQ_INSTS_VALU"] / t_c / pk}
         except Exception as e:
             out["roofline_timed"] = {"error": repr(e)}
 

@@ -17,6 +17,8 @@ for k in sorted(cnt, key=lambda k: -sum(dur.get(k, [0]))):
     c = cnt[k]
     m = {n: sum(v) / len(v) for n, v in c.items()}
     d = sum(dur[k]) / max(len(dur[k]), 1) / 1e3 if k in dur else float("nan")
+    if k.startswith("k_mw_factor_pipe"):      # grid of 64 blocks per 8 clusters, of which 8 per cluster work (4 stages + 4 for the inverse; the others return at once): 2 clusters here
+        wgs[k] = 16
     cus = min(wgs.get(k, 0), 256)
     # share of the fp64 VALU issue slots (4 cycles per wave instruction, 4 SIMDs per CU) of the compute units the kernel occupies, over its duration at 2.4 GHz
     util = m.get("SQ_INSTS_VALU", 0) * 4.0 / (max(cus, 1) * 4 * d * 1e-6 * 2.4e9) if d == d and d > 0 else float("nan")
@@ -29,9 +31,11 @@ with open(out_csv, "w") as fh:
     for r in rows:
         w.writerow([r[0], r[1], r[2], round(r[3], 1), round(r[4], 1), round(r[5], 1), round(r[6], 2), round(r[7], 4)])
 d = {r[0]: r for r in rows}
-f, l = d["k_mw_factor<5>"], d["k_mw_linvb<5, 2>"]
-json.dump({"source": f"profiles/r03/{tag}_pmc_iter_sq_counters.csv (rocprofv3 --pmc SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES -- python3 scripts/mw_iter_profile.py ce_8_15 2; durations from --kernel-trace of the same command)",
-           "limbs": 5, "k_mw_factor": {"SQ_INSTS_VALU": f[3], "SQ_BUSY_CYCLES": f[4], "workgroups": f[2], "duration_us": f[6], "issue_utilisation": f[7],
-                                       "share_of_stage": f[6] / (f[6] + l[6])},
-           "k_mw_potrf_q": {"SQ_INSTS_VALU": d["k_mw_potrf_q<5>"][3], "workgroups": d["k_mw_potrf_q<5>"][2], "duration_us": d["k_mw_potrf_q<5>"][6], "issue_utilisation": d["k_mw_potrf_q<5>"][7]}},
+fk = "k_mw_factor_pipe<5>" if "k_mw_factor_pipe<5>" in d else "k_mw_factor<5>"
+f, l = d[fk], d["k_mw_linvb<5, 2>"]
+ent = lambda r: {"SQ_INSTS_VALU": r[3], "SQ_BUSY_CYCLES": r[4], "workgroups": r[2], "duration_us": r[6], "issue_utilisation": r[7]}
+json.dump({"source": f"profiles/r04/{tag}_pmc_iter_sq_counters.csv (rocprofv3 --pmc SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES -- python3 scripts/mw_iter_profile.py ce_8_15 2; durations from --kernel-trace of the same command)",
+           "limbs": 5, "k_mw_factor": dict(ent(f), kernel=fk.split("<")[0], share_of_stage=f[6] / (f[6] + l[6])),
+           "k_mw_potrf_q": ent(d["k_mw_potrf_q<5>"]) if "k_mw_potrf_q<5>" in d else ent(d["k_mw_potrf_q_pipe<5>"]),
+           "k_mw_potrf_x": ent(d["k_mw_potrf_x<5>"])},
           open(out_json, "w"), indent=1)
