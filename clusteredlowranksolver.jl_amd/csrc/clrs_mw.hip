@@ -1155,6 +1155,7 @@ extern "C" int clrs_mw_schur_factor_local_dev(clrs_mw_ctx *c) {
         c->pipe_epoch = (c->pipe_epoch + 1) & 0x3ffffff;
         MW_DISPATCH(c, { hipLaunchKernelGGL(k_mw_factor_pipe<KK>, dim3(mwp_blocks(q.J)), dim3(MWP_NT), MWP_LDS_ALONE, c->stream, q, c->pipe_epoch); });
     } else if (!ride && c->any_lds_cluster) MW_DISPATCH(c, { hipLaunchKernelGGL(k_mw_factor<KK>, dim3(q.J, c->nw_factor), dim3(MW_PT), c->sm_factor, c->stream, q); });
+    if (!c->bp_S.empty()) MW_DISPATCH(c, hipLaunchKernelGGL(k_mw_keep_S<KK>, dim3((unsigned)std::min<i64>(64, ((i64)c->maxP * c->maxP + MW_NT - 1) / MW_NT), q.J), dim3(MW_NT), 0, c->stream, q));
     if (!c->bp_S.empty() && (rc = mw_potrf_blocked(c, c->bp_S, c->d_bp, ride))) return rc;
     MW_DISPATCH(c, {
         if (q.N > 0)

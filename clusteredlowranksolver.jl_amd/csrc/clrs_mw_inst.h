@@ -19,6 +19,7 @@
     X __global__ void k_mw_bp_inv<K>(const MwDev, const MwBp *, int);                                                  \
     X __global__ void k_mw_bp_finish<K>(const MwDev, const MwBp *);                                                    \
     X __global__ void k_mw_usum<K>(const MwDev);                                                                       \
+    X __global__ void k_mw_keep_S<K>(const MwDev);                                                                     \
     X __global__ void k_mw_solve_fwd<K>(const MwDev, const double *);                                                  \
     X __global__ void k_mw_solve_mid<K, K>(const MwDev, const double *, double *);                                     \
     X __global__ void k_mw_solve_mid<K, mw_kc(K)>(const MwDev, const double *, double *);                              \

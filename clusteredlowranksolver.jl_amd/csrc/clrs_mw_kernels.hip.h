@@ -80,7 +80,7 @@ struct MwDev {
     double *t, *u, *AY;                 // t = L^-1 rhs_x (xlen); u slabs (J x N); pairings per term
     // iterative refinement of the solve stage over many workgroups (k_mw_refine): the residual r_x (xlen), B^T dx of this rank's rows (N), the
     // correction (xlen, N); uadd: while the correction is solved, the vector subtracted from rhs_y beside sum_j u_j (= u2), else null
-    double *S0;                         // S_j as assembled (S layout): the factorisation overwrites S with L_j, the residuals of the refinement need S_j
+    double *S0;                         // S_j as assembled (S layout; written by the FACTOR stage as it reads S_j, which it overwrites with L_j): the residuals of the refinement need S_j
     int pipe_q, pad6;                   // index of Q's region in pipe_pc
     unsigned long long *pipe_stamps;    // diagnostic builds: [16][40] step stamps of the pipelined factorisations (clrs_mw_debug_pipe_stamps), or null
     unsigned long long *pipe_pc;        // hand-off granules of the pipelined factorisations (clrs_mw_pipe.hip.h): [J + 1][MWP_PC_WORDS], or null
@@ -818,8 +818,6 @@ __device__ __forceinline__ void mw_saccum_body(const MwDev &q) {
     if (live && sub == 0) {
         stx<K>(q.S + c.Soff, q.Slen, pp + (long)qq * P, v);
         stx<K>(q.S + c.Soff, q.Slen, qq + (long)pp * P, v);
-        stx<K>(q.S0 + c.Soff, q.Slen, pp + (long)qq * P, v);      // (the copy the factorisation leaves alone: residuals of the refined solve)
-        stx<K>(q.S0 + c.Soff, q.Slen, qq + (long)pp * P, v);
     }
 }
 template <int K, int DK>
@@ -923,8 +921,7 @@ __global__ __launch_bounds__(MW_NT) void k_mw_saccum_one(const MwDev q, int do_a
     const mw<K> v = acc_result<K>(s);
     stx<K>(q.S + c.Soff, q.Slen, pp + (long)qq * P, v);
     stx<K>(q.S + c.Soff, q.Slen, qq + (long)pp * P, v);
-    stx<K>(q.S0 + c.Soff, q.Slen, pp + (long)qq * P, v);
-    stx<K>(q.S0 + c.Soff, q.Slen, qq + (long)pp * P, v);
+
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -967,12 +964,25 @@ __device__ __forceinline__ void mw_factor_cluster(const MwDev &q, int j, int cw,
         lds_d *M = MW_LDS + MW_POTRF_SCR(K, P);
         wg_copy<K, MW_PT>(M, (long)P * P, P, q.S + c.Soff, q.Slen, P, P, P, tid);
         __syncthreads();
+        if (cw == 0) wg_copy<K, MW_PT>(q.S0 + c.Soff, q.Slen, P, M, (long)P * P, P, P, P, tid);      // S_j as assembled, for the residuals of the refined solve
         mw_factor_body<K>(q, c, j, M, (long)P * P, M + (long)K * P * P, bc, tid, cw, cnw);
     }
     // clusters too large for LDS are factored by the blocked, multi-workgroup path (k_mw_bp_*, driven by the host)
 }
 template <int K>
 __global__ __launch_bounds__(MW_PT) void k_mw_factor(const MwDev q) { mw_factor_cluster<K>(q, blockIdx.x, blockIdx.y, gridDim.y); }
+
+// S0_j = S_j for the clusters factored by the blocked path (the LDS kernels copy as they load): grid (tiles, J)
+template <int K>
+__global__ __launch_bounds__(MW_NT) void k_mw_keep_S(const MwDev q) {
+    const MwClu &c = q.clu[blockIdx.y];
+    if (c.lds) return;
+    const long nn = (long)c.P * c.P;
+    for (long e = (long)blockIdx.x * MW_NT + threadIdx.x; e < nn; e += (long)gridDim.x * MW_NT) {
+#pragma unroll
+        for (int l = 0; l < K; l++) q.S0[(long)l * q.Slen + c.Soff + e] = q.S[(long)l * q.Slen + c.Soff + e];
+    }
+}
 
 // LinvB_j = L_j^-1 B_j (src/solver.jl:1256-1261) = Si_j B_j: a product with the explicit inverse, four lanes per entry
 #define MW_LBI_W 4

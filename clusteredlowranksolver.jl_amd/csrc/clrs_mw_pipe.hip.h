@@ -39,6 +39,7 @@
 #define MWP_PC_WORDS(K) ((long)MWP_N * MWP_GRANULES(K))    // ... of one matrix (MWP_N pivots)
 
 struct MwPipeMat {           // one matrix of a pipelined factorisation
+    double *keep;            // null, or where a copy of the input goes (same layout as `in`)
     const double *in;        // input: planar n x n (leading dimension n), lower triangle read; in_slots > 1: the sum of that many arrays, in order
     long inplane, in_stride;
     int in_slots, n;
@@ -211,6 +212,10 @@ __device__ __forceinline__ bool mwp_run(const MwPipeMat &m, int role, unsigned e
             for (int r = 0; r < m.in_slots; r++) acc_add<K, K>(s, ldx<K>(m.in + (long)r * m.in_stride, m.inplane, i + (long)c * n));
             v = acc_result<K>(s);
         } else v = ldx<K>(m.in, m.inplane, i + (long)c * n);
+        if (m.keep) {                                                        // the matrix as it came in (both triangles), for the residuals of the refined solve
+            stx<K>(m.keep, m.inplane, i + (long)c * n, v);
+            stx<K>(m.keep, m.inplane, c + (long)i * n, v);
+        }
     }
     if (tid == MWP_ET) { stx<K>(S.us, MWP_N + 1, 0, from_double<K>(1.0)); *S.flag = 1; }
     MwpFetch<K> F;
@@ -321,7 +326,7 @@ __global__ __launch_bounds__(MWP_NT) void k_mw_factor_pipe(const MwDev q, unsign
     const int P = c.P, stages = (P + MWP_W - 1) / MWP_W;
     if (role >= stages + MWP_WW) return;
     MwPipeMat m;
-    m.in = q.S + c.Soff; m.inplane = q.Slen; m.in_stride = 0; m.in_slots = 1; m.n = P;
+    m.in = q.S + c.Soff; m.inplane = q.Slen; m.in_stride = 0; m.in_slots = 1; m.n = P; m.keep = q.S0 + c.Soff;
     m.L = q.S + c.Soff; m.lplane = q.Slen; m.rd = q.srd + c.coff; m.rdplane = q.xlen; m.Inv = q.Si + c.Soff; m.invplane = q.Slen;
     m.pc = q.pipe_pc + (long)j * MWP_PC_WORDS(K);
     m.fail_code = j + 1;
@@ -341,7 +346,7 @@ __global__ __launch_bounds__(MWP_NT) void k_mw_potrf_q_pipe(const MwDev q, unsig
     if (mtx != 0 || role >= (N + MWP_W - 1) / MWP_W + MWP_WW) return;
     if (q.info[0] != MW_INFO_NONE) return;                          // a cluster failed: the reference throws before reaching Q
     MwPipeMat m;
-    m.in = q.Qg; m.inplane = (long)N * N; m.in_stride = (long)K * N * N; m.in_slots = q.world; m.n = N;
+    m.in = q.Qg; m.inplane = (long)N * N; m.in_stride = (long)K * N * N; m.in_slots = q.world; m.n = N; m.keep = nullptr;
     m.L = q.Q; m.lplane = (long)N * N; m.rd = q.qrd; m.rdplane = N; m.Inv = q.Qi; m.invplane = (long)N * N;
     m.pc = q.pipe_pc + (long)q.pipe_q * MWP_PC_WORDS(K);
     m.fail_code = q.J + 1;
