@@ -132,6 +132,8 @@ struct clrs_mw_ctx {
     double *vz = nullptr;               // 2 N numbers of scratch of the solve stage over many workgroups (k_mw_solve_wide)
     bool wide_solve = false;            // some cluster or Q has more than 64 rows: the products of the solve stage are launches of their own
     const double *ride_fwd = nullptr;   // set by the iteration around clrs_mw_schur_factor_finish_dev: rhs_x of the solve that follows
+    const int *ride_wait = nullptr;     // ... and, with it, the word its workgroups wait for inside the launch (>= ride_wait_value) instead of an event in front of it
+    int ride_wait_value = 0;
     bool fwd_rode = false;              // ... and its first product pair (k_mw_solve_fwd's work) was done on the launch of k_mw_potrf_q
     int n_one_term = 0, n_many_term = 0;   // clusters whose S_j goes through k_mw_saccum_one / through the general k_mw_saccum
     int sa_lanes = MW_SA_W;             // lanes per entry of k_mw_saccum: 1, 2 or 4 by the largest block count of a cluster
@@ -1181,12 +1183,12 @@ extern "C" int clrs_mw_schur_factor_finish_dev(clrs_mw_ctx *c) {
         const bool ride = c->ride_fwd != nullptr && !c->wide_solve;
         c->pipe_epoch = (c->pipe_epoch + 1) & 0x3ffffff;
         MW_DISPATCH(c, { hipLaunchKernelGGL(k_mw_potrf_q_pipe<KK>, dim3(64 + (ride ? q.J : 0)), dim3(MWP_NT), std::max<size_t>(MWP_LDS_ALONE, ride ? c->sm_fwd : 0),
-                                            c->stream, q, c->pipe_epoch, c->ride_fwd); });
+                                            c->stream, q, c->pipe_epoch, c->ride_fwd, ride ? c->ride_wait : (const int *)nullptr, c->ride_wait_value); });
         c->fwd_rode = ride;
     } else if (q.N > 0 && c->lds_q) {
         // the interior-point iteration hands over the right-hand side of its next solve: the solve's first product pair rides on this launch
         const bool ride = c->ride_fwd != nullptr && !c->wide_solve;
-        MW_DISPATCH(c, { hipLaunchKernelGGL(k_mw_potrf_q<KK>, dim3(MW_INV_WG + (ride ? q.J : 0)), dim3(MW_PT), ride ? std::max(c->sm_q, c->sm_fwd) : c->sm_q, c->stream, q, MW_INV_WG, c->ride_fwd); });
+        MW_DISPATCH(c, { hipLaunchKernelGGL(k_mw_potrf_q<KK>, dim3(MW_INV_WG + (ride ? q.J : 0)), dim3(MW_PT), ride ? std::max(c->sm_q, c->sm_fwd) : c->sm_q, c->stream, q, MW_INV_WG, c->ride_fwd, ride ? c->ride_wait : (const int *)nullptr, c->ride_wait_value); });
         c->fwd_rode = ride;
     } else if (q.N > 0) {
         MW_DISPATCH(c, { hipLaunchKernelGGL(k_mw_qsum<KK>, dim3((unsigned)std::min<i64>(256, ((i64)q.N * q.N + MW_NT - 1) / MW_NT)), dim3(MW_NT), 0, c->stream, q); });

@@ -31,6 +31,7 @@ struct MwIpmDev {
     int *wcnt;                         // [2 NB] workgroups of a (block, which) that have delivered their panel
     double *rec;                       // fp64 record of the iteration
     int *flags;                        // [0] pd_feas, [1] error_code, [2] Cholesky failure inside the step length
+    int *sync;                         // [0] the number of the last iteration whose side-stream work (everything the predictor's solve reads) is complete (k_mwi_mark)
     const double *C, *c, *b;           // problem data, DK limbs planar (sdp.C xy layout, sdp.c x layout, sdp.b [N])
     const int *row_clu;                // [xlen] cluster of each constraint row
     double sgn, constant;
@@ -794,6 +795,17 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_rows_fwd(const MwDev q, const MwI
     __threadfence_block();
     __syncthreads();
     mw_solve_fwd_cluster<K>(q, blockIdx.x, p.rhsx);
+}
+
+// ---- "the side stream's work of iteration `iter` is done": one thread, behind that work in stream order.  The workgroups that ride on the Cholesky of Q
+// (the first products of the predictor's solve) wait for this word INSIDE their launch instead of the main stream waiting for an event in front of it:
+// an event awaited on the main stream costs it a bubble of 6-15 us (measured, profiles/r03, r04), while those workgroups have the 80 us of the launch.
+template <int UNIT>      // (a template only so that the units that include this header do not each define the symbol)
+__global__ void k_mwi_mark(int *word, int iter) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __hip_atomic_store(word, iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // ---- this rank's slot of a gather buffer (cluster sharding): one workgroup, the first wave --------------------------------------

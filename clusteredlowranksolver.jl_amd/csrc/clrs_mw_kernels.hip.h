@@ -1057,13 +1057,30 @@ __device__ __forceinline__ void mw_potrf_q_body(const MwDev &q, PM M, long plane
         }
     }
 }
+// wait (one lane polls, bounded) until *word >= value, then make what the signalling stream wrote before it visible to this workgroup
+// (a mark that never comes -- it cannot, the marking kernel is enqueued first -- ends the wait after ~seconds and reports a failed factorisation: *info)
+__device__ __forceinline__ void mw_wait_word(const int *word, int value, int *info, int code) {
+    if (threadIdx.x == 0) {
+        int spins = 0;
+        while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < value && ++spins < (1 << 24)) __builtin_amdgcn_s_sleep(8);
+        if (spins >= (1 << 24)) atomicMin(info, code);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+}
 template <int K>
-__global__ __launch_bounds__(MW_PT) void k_mw_potrf_q(const MwDev q, int nq, const double *__restrict__ fwd_rhs) {
+__global__ __launch_bounds__(MW_PT) void k_mw_potrf_q(const MwDev q, int nq, const double *__restrict__ fwd_rhs, const int *__restrict__ wait_word, int wait_value) {
     using namespace mwk;
     const int N = q.N, tid = threadIdx.x;
     // workgroups behind the nq of Q (the interior-point iteration adds them): the first product pair of the next solve, t_j = L_j^-1 rhs_x[j] and
-    // u_j = LinvB_j^T t_j per cluster, which needs the clusters' factors only -- beside the 31 pivots of Q instead of behind them
-    if ((int)blockIdx.x >= nq) { mw_solve_fwd_cluster<K>(q, blockIdx.x - nq, fwd_rhs); return; }
+    // u_j = LinvB_j^T t_j per cluster, which needs the clusters' factors only -- beside the 31 pivots of Q instead of behind them.  Their right-hand
+    // side comes from another stream: they wait for its mark here (wait_word), not the whole launch in front of an event
+    if ((int)blockIdx.x >= nq) {
+        if (wait_word) mw_wait_word(wait_word, wait_value, &q.info[0], q.J + 1);
+        mw_solve_fwd_cluster<K>(q, blockIdx.x - nq, fwd_rhs);
+        return;
+    }
     if (q.info[0] != MW_INFO_NONE) return;           // a cluster failed: the reference throws before reaching Q
     lds_d *bc = MW_LDS;
     const long nn = (long)N * N;

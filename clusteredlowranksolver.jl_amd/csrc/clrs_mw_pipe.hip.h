@@ -337,9 +337,13 @@ __global__ __launch_bounds__(MWP_NT) void k_mw_factor_pipe(const MwDev q, unsign
 // L_Q = chol(Q), Q = the sum of the ranks' partial sums, and L_Q^-1: the blocks 0, 8, 16, ... of the first 64 (one XCD); the blocks from 64 on carry the
 // first product pair of the next solve (as in k_mw_potrf_q), one cluster each
 template <int K>
-__global__ __launch_bounds__(MWP_NT) void k_mw_potrf_q_pipe(const MwDev q, unsigned epoch, const double *__restrict__ fwd_rhs) {
+__global__ __launch_bounds__(MWP_NT) void k_mw_potrf_q_pipe(const MwDev q, unsigned epoch, const double *__restrict__ fwd_rhs, const int *__restrict__ wait_word, int wait_value) {
     using namespace mwk;
-    if (blockIdx.x >= 64) { mw_solve_fwd_cluster<K>(q, blockIdx.x - 64, fwd_rhs); return; }
+    if (blockIdx.x >= 64) {
+        if (wait_word) mw_wait_word(wait_word, wait_value, &q.info[0], q.J + 1);
+        mw_solve_fwd_cluster<K>(q, blockIdx.x - 64, fwd_rhs);
+        return;
+    }
     int mtx, role;
     mwp_block_map(blockIdx.x, mtx, role);
     const int N = q.N;
