@@ -808,6 +808,16 @@ __global__ void k_mwi_mark(int *word, int iter) {
     }
 }
 
+// ---- the other direction: the side stream waits, in a kernel of its own (one wave, bounded polling), for a word that a launch of the main stream stores
+// as it starts (MwDev::mark_word) -- an event RECORDED on the main stream costs it a bubble of ~5 us (measured: profiles/r04/r4_host_vs_gpu), a word costs it nothing
+template <int UNIT>
+__global__ void k_mwi_wait(const int *word, int value) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        int spins = 0;
+        while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < value && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(32);      // (it may wait half an iteration: a poll per ~1 us)
+    }
+}
+
 // ---- this rank's slot of a gather buffer (cluster sharding): one workgroup, the first wave --------------------------------------
 template <int K, int DK>
 __global__ void k_mwi_gpack(const MwDev q, const MwIpmDev p, int stage) {

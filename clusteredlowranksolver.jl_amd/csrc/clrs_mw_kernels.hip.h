@@ -81,6 +81,8 @@ struct MwDev {
     // iterative refinement of the solve stage over many workgroups (k_mw_refine): the residual r_x (xlen), B^T dx of this rank's rows (N), the
     // correction (xlen, N); uadd: while the correction is solved, the vector subtracted from rhs_y beside sum_j u_j (= u2), else null
     double *S0;                         // S_j as assembled (S layout; written by the FACTOR stage as it reads S_j, which it overwrites with L_j): the residuals of the refinement need S_j
+    int *mark_word;                     // null, or a word the FIRST workgroup of the next Cholesky / factor launch stores mark_value to as it starts: "everything in front of
+    int mark_value, pad7;               // this launch on its stream is complete", for kernels of another stream that wait inside their launch (mw_wait_word) instead of for an event
     int pipe_q, pad6;                   // index of Q's region in pipe_pc
     unsigned long long *pipe_stamps;    // diagnostic builds: [16][40] step stamps of the pipelined factorisations (clrs_mw_debug_pipe_stamps), or null
     unsigned long long *pipe_pc;        // hand-off granules of the pipelined factorisations (clrs_mw_pipe.hip.h): [J + 1][MWP_PC_WORDS], or null
@@ -101,6 +103,7 @@ struct MwDev {
     const long long *mwx_off;           // blocks with mwx_off[b] >= 0: pairing matrices of ANY size from the digits of Z, T, V (k_mwx_slice, k_mwx_gram) when mwx_on
 };
 
+__device__ __forceinline__ void mw_mark(const MwDev &q);
 namespace mwk {
 using namespace mwa;
 
@@ -458,6 +461,7 @@ template <int K>
 __global__ __launch_bounds__(MW_PT) void k_mw_potrf_x(const MwDev q, const double *__restrict__ X, double *__restrict__ Xc, int lds, const double *__restrict__ Y2,
                                                       double *__restrict__ Yi, int *__restrict__ yfail) {
     using namespace mwk;
+    mw_mark(q);
     const bool second = (int)blockIdx.x >= q.NB;
     const MwBlk &k = q.blk[second ? blockIdx.x - q.NB : blockIdx.x];
     const int n = k.n, tid = threadIdx.x;
@@ -970,7 +974,7 @@ __device__ __forceinline__ void mw_factor_cluster(const MwDev &q, int j, int cw,
     // clusters too large for LDS are factored by the blocked, multi-workgroup path (k_mw_bp_*, driven by the host)
 }
 template <int K>
-__global__ __launch_bounds__(MW_PT) void k_mw_factor(const MwDev q) { mw_factor_cluster<K>(q, blockIdx.x, blockIdx.y, gridDim.y); }
+__global__ __launch_bounds__(MW_PT) void k_mw_factor(const MwDev q) { mw_mark(q); mw_factor_cluster<K>(q, blockIdx.x, blockIdx.y, gridDim.y); }
 
 // S0_j = S_j for the clusters factored by the blocked path (the LDS kernels copy as they load): grid (tiles, J)
 template <int K>
@@ -1058,6 +1062,11 @@ __device__ __forceinline__ void mw_potrf_q_body(const MwDev &q, PM M, long plane
     }
 }
 // wait (one lane polls, bounded) until *word >= value, then make what the signalling stream wrote before it visible to this workgroup
+// store q.mark_value to q.mark_word (first thread of the launch): see MwDev::mark_word
+__device__ __forceinline__ void mw_mark(const MwDev &q) {
+    if (q.mark_word && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0)
+        __hip_atomic_store(q.mark_word, q.mark_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 // (a mark that never comes -- it cannot, the marking kernel is enqueued first -- ends the wait after ~seconds and reports a failed factorisation: *info)
 __device__ __forceinline__ void mw_wait_word(const int *word, int value, int *info, int code) {
     if (threadIdx.x == 0) {
@@ -1135,6 +1144,7 @@ struct MwBp {                // one matrix being factored: planar M and its inve
 };
 template <int K>
 __global__ __launch_bounds__(MW_PT) void k_mw_bp_diag(const MwDev q, const MwBp *__restrict__ ms, int nm, int j0) {
+    mw_mark(q);
     using namespace mwk;
     constexpr int MW_PB = MW_PB_OF(K);
     // rows of the grid beyond the nm matrices of this launch (the first launch of the factorisation of the S_j adds them): the clusters that fit

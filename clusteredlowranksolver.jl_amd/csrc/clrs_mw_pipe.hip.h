@@ -185,9 +185,9 @@ struct MwpLds {                                      // (no arrays of pointers: 
     __device__ __forceinline__ lds_d *col(int k) const { return col0 + (long)(k & 1) * K * MWP_N; }
     __device__ __forceinline__ lds_d *wrow(int k) const { return wrow0 + (long)(k & 1) * K * MWP_W; }
 };
-// LDS a workgroup ASKS for: more than half of a compute unit's 160 KB, so that no two workgroups of these kernels share a compute unit (with the
-// workgroups of a matrix on one XCD the dispatcher packed several per compute unit: their steps took 3.5 us instead of 1.45, measured)
-#define MWP_LDS_ALONE ((size_t)84 * 1024)
+// LDS a workgroup asks for.  (Asking for more than half of a compute unit's 160 KB, so that no two workgroups share a compute unit, was tried with the
+// plain-store hand-offs below and changed nothing: their 3.5 us steps came from the stores, not from sharing.)
+#define MWP_LDS_ALONE (MWP_LDS_DOUBLES(10) * sizeof(double))
 #define MWP_LDS_DOUBLES(K) ((K) * (6 * MWP_N + 1 + 2 * MWP_W) + 2)
 
 // role < stages: stage `role` of the elimination of M; role >= stages: workgroup role - stages of the MWP_WW that form W.  Returns false at a
@@ -319,6 +319,7 @@ static inline int mwp_blocks(int matrices) { return 64 * ((matrices + 7) / 8); }
 template <int K>
 __global__ __launch_bounds__(MWP_NT) void k_mw_factor_pipe(const MwDev q, unsigned epoch) {
     using namespace mwk;
+    mw_mark(q);
     int j, role;
     mwp_block_map(blockIdx.x, j, role);
     if (j >= q.J) return;

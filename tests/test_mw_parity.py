@@ -158,6 +158,32 @@ def test_refinement_gives_the_solve_stage_the_backward_error_of_substitutions(na
     assert max(lost[1]) <= 12 and max(lost[2]) <= 12, lost
 
 
+def test_stream_words_make_progress_when_streams_share_hardware_queues(oracle_built):
+    """The two streams of the interior-point iteration synchronise through words that kernels store and await (clrs_mw_ipm_host.inc) instead of events
+    where a launch exists to do it.  HIP may map several streams onto one hardware queue; the rule that keeps that safe -- a waiting launch is submitted
+    after the launch that stores its word -- is exercised here with enough live contexts (two streams each) that streams must share queues: every solve
+    must finish at its usual speed (a wait whose producer sat behind it in the same queue would take seconds per iteration: bench.py met exactly that
+    before the rule)."""
+    import time
+    from clrs_amd.mw import MwSchurContext, solvesdp_mw
+    f = flat("ce_8_3")
+    ctxs = [MwSchurContext(f, limbs=4) for _ in range(10)]
+    try:
+        for c in ctxs:                       # every context creates its side stream (clrs_mw_ipm_create) and runs the loop
+            r = solvesdp_mw(f, ctx=c, limbs=4, duality_gap_threshold=1e-10, dual_error_threshold=1e-20, primal_error_threshold=1e-20)
+            assert r.error_code == 0
+        t0 = time.time()
+        its = 0
+        for c in ctxs:
+            r = solvesdp_mw(f, ctx=c, limbs=4, duality_gap_threshold=1e-10, dual_error_threshold=1e-20, primal_error_threshold=1e-20)
+            assert r.error_code == 0 and r.status == "Optimal"
+            its += r.iterations
+        assert (time.time() - t0) / its < 5e-3, ("seconds per iteration", (time.time() - t0) / its)
+    finally:
+        for c in ctxs:
+            c.close()
+
+
 @pytest.mark.parametrize("K", [3, 5, 6, 10])
 @pytest.mark.parametrize("name", ["ce_8_15", "ce_8_3", "polyopt8", "delsarte_3_10", "polyopt40", "sdpa_small"])
 def test_pipelined_factorisation_is_bit_identical(name, K, oracle_built):
