@@ -37,6 +37,7 @@ MW_KERNELS_ALL(extern template, 10)
 
 typedef long long i64;
 
+extern int g_cfg_mw_stream_words;                        // clrs_hip.hip, clrs_config_set("mw_stream_words", 0 / 1); env CLRS_MW_STREAM_WORDS
 extern int g_cfg_mw_pipeline;                            // clrs_hip.hip, clrs_config_set("mw_pipeline", 0 / 1): read at context creation
 extern int g_cfg_mw_refine_predictor;                    // clrs_hip.hip, clrs_config_set("mw_refine_predictor", 0 / 1)
 extern int g_cfg_mw_refine;                              // clrs_hip.hip, clrs_config_set("mw_refine", 0 / 1): read at context creation
@@ -170,6 +171,7 @@ struct clrs_mw_ctx {
     bool pipe_S = false, pipe_Q = false;  // the factorisations of the clusters / of Q as pipelines of workgroups (clrs_mw_pipe.hip.h): every matrix <= 32 rows, few clusters
     int pipe_pcQ = 0;                    // index of Q's hand-off region in pipe_pc
     unsigned pipe_epoch = 0;             // launch counter: the tag of the hand-off granules
+    bool stream_words = true;            // the interior-point iteration synchronises its two streams through words (clrs_mw_ipm_host.inc) where it can; false: events only
     bool refine_skip_next = false;       // the interior-point iteration's PREDICTOR solve: one pass (set by clrs_mw_ipm_host.inc for the next clrs_mw_schur_solve_dev only)
     int refine_predictor = 0;            // clrs_mw_options.refine_predictor: 1 = the predictor's solve is refined like every other
     int refine = 1;                      // iterative refinement of the solve stage (clrs_mw_options / clrs_config_set("mw_refine")): 0 off, 1 one step with the correction in all K limbs, 2 ... in mw_kc(K) limbs
@@ -729,6 +731,10 @@ extern "C" int clrs_mw_create_opts(const clrs_sdp_desc *d, int data_limbs, int d
     q.uadd = nullptr;
     c->refine = cfg_refine;
     c->refine_predictor = cfg_refine_pred;
+    {
+        const char *e = std::getenv("CLRS_MW_STREAM_WORDS");
+        c->stream_words = e && *e ? std::atoi(e) != 0 : g_cfg_mw_stream_words != 0;
+    }
     c->wide_solve = c->maxP > 64 || N > 64;
     {   // pipelined factorisations (clrs_mw_pipe.hip.h): matrices of at most 32 rows, while stages + W workgroups of every matrix can be resident side by side
         bool small = c->maxP <= MWP_N;

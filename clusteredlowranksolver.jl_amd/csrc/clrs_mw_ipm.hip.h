@@ -830,10 +830,11 @@ __global__ void k_mwi_mark(int *word, int iter) {
 // ---- the other direction: the side stream waits, in a kernel of its own (one wave, bounded polling), for a word that a launch of the main stream stores
 // as it starts (MwDev::mark_word) -- an event RECORDED on the main stream costs it a bubble of ~5 us (measured: profiles/r04/r4_host_vs_gpu), a word costs it nothing
 template <int UNIT>
-__global__ void k_mwi_wait(const int *word, int value) {
+__global__ void k_mwi_wait(const int *word, int value, int *info, int code) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         int spins = 0;
-        while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < value && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(32);      // (it may wait half an iteration: a poll per ~1 us)
+        while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < value && ++spins < (1 << 20)) __builtin_amdgcn_s_sleep(32);      // (it may wait half an iteration: a poll per ~1 us)
+        if (spins >= (1 << 20)) atomicMin(info, code);          // never in a run whose queues run side by side; then: the iteration reports a failed factorisation, not numbers
     }
 }
 

@@ -1067,12 +1067,13 @@ __device__ __forceinline__ void mw_mark(const MwDev &q) {
     if (q.mark_word && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0)
         __hip_atomic_store(q.mark_word, q.mark_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// (a mark that never comes -- it cannot, the marking kernel is enqueued first -- ends the wait after ~seconds and reports a failed factorisation: *info)
+// (a mark that never comes -- it cannot while kernels of different queues may run side by side: the marking kernel is enqueued first; a profiler that
+// serialises kernels, e.g. rocprofv3 --pmc, breaks that: use CLRS_MW_STREAM_WORDS=0 there -- ends the wait after ~0.5 s and reports a failed factorisation: *info)
 __device__ __forceinline__ void mw_wait_word(const int *word, int value, int *info, int code) {
     if (threadIdx.x == 0) {
         int spins = 0;
-        while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < value && ++spins < (1 << 24)) __builtin_amdgcn_s_sleep(8);
-        if (spins >= (1 << 24)) atomicMin(info, code);
+        while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < value && ++spins < (1 << 21)) __builtin_amdgcn_s_sleep(8);
+        if (spins >= (1 << 21)) atomicMin(info, code);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }

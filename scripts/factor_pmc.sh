@@ -7,6 +7,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+export CLRS_MW_STREAM_WORDS=0      # counter collection serialises kernels: the iteration's streams synchronise through events only
 timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES --output-format csv -d $OUT/pmc_iter_$TAG -- python3 $R/scripts/mw_iter_profile.py ce_8_15 2 > $OUT/pmc_iter_$TAG.log 2>&1; echo "pmc rc=$?"
 timeout 600 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_iter_$TAG -- python3 $R/scripts/mw_iter_profile.py ce_8_15 2 > $OUT/trace_iter_$TAG.log 2>&1; echo "trace rc=$?"
 cd $R

@@ -6,6 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+export CLRS_MW_STREAM_WORDS=0      # counter collection serialises kernels: the iteration's streams synchronise through events only
 timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc_mw_$TAG -- python3 $R/scripts/mw_roofline.py 5 1024 2 on > $OUT/pmc_mw_$TAG.log 2>&1; echo "pmc rc=$?"
 cd $R
 f=$(find $OUT/pmc_mw_$TAG -name '*counter_collection.csv' | head -1)
