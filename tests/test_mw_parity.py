@@ -158,6 +158,47 @@ def test_refinement_gives_the_solve_stage_the_backward_error_of_substitutions(na
     assert max(lost[1]) <= 12 and max(lost[2]) <= 12, lost
 
 
+def test_stream_words_and_events_give_the_same_solve(oracle_built):
+    """clrs_config_set("mw_stream_words", 0): the two streams of the iteration synchronise through events only (what counter-collection runs use, and what
+    sharded contexts always do).  Same kernels, same order of operations: histories and iterates are bit-identical to the default (words)."""
+    from clrs_amd import _lib
+    from clrs_amd.mw import MwSchurContext, solvesdp_mw
+    L = _lib.load()
+    f = flat("ce_8_3")
+    out = []
+    for words in (1, 0):
+        _lib.check(L.clrs_config_set(b"mw_stream_words", words))
+        try:
+            ctx = MwSchurContext(f, limbs=4)
+        finally:
+            L.clrs_config_set(b"mw_stream_words", 1)
+        r = solvesdp_mw(f, ctx=ctx, limbs=4, duality_gap_threshold=1e-10, dual_error_threshold=1e-20, primal_error_threshold=1e-20)
+        ctx.close()
+        assert r.error_code == 0 and r.status == "Optimal"
+        out.append(r)
+    a, b = out
+    assert a.iterations == b.iterations and np.array_equal(a.history, b.history)
+    assert np.array_equal(a.x, b.x) and np.array_equal(a.y, b.y) and np.array_equal(a.X, b.X) and np.array_equal(a.Y, b.Y)
+
+
+def test_refined_predictor_option_and_comm_probe_without_communicator(oracle_built):
+    """clrs_mw_options.refine_predictor = 1: both solves of an iteration take the refinement step (the default refines the corrector's only): same
+    iteration count, objectives equal far inside the tolerances of the solve.  clrs_mw_comm_probe on a context without a communicator reports that."""
+    from clrs_amd.mw import MwSchurContext, solvesdp_mw
+    f = flat("ce_8_15")
+    rs = []
+    for rp in (False, True):
+        ctx = MwSchurContext(f, limbs=5, refine_predictor=rp)
+        if not rp:
+            pr = ctx.comm_probe(2)
+            assert pr["backend"] == "none" and pr["world"] == 1 and pr["q_us"] == 0.0
+        rs.append(solvesdp_mw(f, ctx=ctx))
+        ctx.close()
+    a, b = rs
+    assert a.status == b.status == "Optimal" and a.iterations == b.iterations == 56
+    assert abs(a.primal_objective - b.primal_objective) <= 1e-20 and abs(a.duality_gap - b.duality_gap) <= 1e-6 * a.duality_gap
+
+
 def test_stream_words_make_progress_when_streams_share_hardware_queues(oracle_built):
     """The two streams of the interior-point iteration synchronise through words that kernels store and await (clrs_mw_ipm_host.inc) instead of events
     where a launch exists to do it.  HIP may map several streams onto one hardware queue; the rule that keeps that safe -- a waiting launch is submitted
