@@ -415,8 +415,10 @@ __device__ void mwi_scalar_stage(const MwDev &q, const MwIpmDev &p, int stage, i
         q.info[1] = MW_INFO_NONE;
         return;
     }
+    const bool xy_merged = stage == 10;            // stage 0 whose <X,Y> travelled with the previous iteration's objectives (k_mwi_gpack stage 14)
+    if (xy_merged) stage = 0;
     if (stage == 0) {                              // start of the iteration: mu, mu_p  (src/solver.jl:369-380)
-        mw<K> xy = q.world > 1 ? mwi_gsum<K>(q, p.gsS, p.GL, MWG_S1(K, q.N)) : mwi_sum_part<K>(q, p, 0);
+        mw<K> xy = q.world > 1 ? mwi_gsum<K>(q, p.gsS, p.GL, xy_merged ? MWG_BX(K, q.N) : MWG_S1(K, q.N)) : mwi_sum_part<K>(q, p, 0);
         mw<K> mu = s_div<K>(xy, from_double<K>((double)p.Ktot));
         stx<K>(p.sc, SP, MSC_XY, xy);
         stx<K>(p.sc, SP, MSC_MU, mu);
@@ -845,6 +847,8 @@ __global__ void k_mwi_gpack(const MwDev q, const MwIpmDev p, int stage) {
     if (blockIdx.x != 0 || threadIdx.x >= 64) return;
     const int lane = threadIdx.x, N = q.N;
     double *slot = ((stage == 2 || stage == 3) ? p.gsM : p.gsS) + (long)q.rank * p.GL, *D = slot + MWG_D(K, N);
+    const bool with_xy = stage == 14;              // stage 4 whose record also carries <X,Y> (first K doubles of the -B^T x area, unused by stages 0 and 4)
+    if (with_xy) stage = 4;
     if (stage == 4) {                              // <c,x> over this rank's rows, by the wave
         acc<K> s;
         acc_zero<K>(s);
@@ -860,6 +864,11 @@ __global__ void k_mwi_gpack(const MwDev q, const MwIpmDev p, int stage) {
         const mw<K> v = mwi_sum_part<K>(q, p, stage == 0 ? 0 : stage == 2 ? 1 : 4);
 #pragma unroll
         for (int l = 0; l < K; l++) slot[MWG_S1(K, N) + l] = v.l[l];
+    }
+    if (with_xy) {
+        const mw<K> v = mwi_sum_part<K>(q, p, 0);
+#pragma unroll
+        for (int l = 0; l < K; l++) slot[MWG_BX(K, N) + l] = v.l[l];
     }
     if (stage == 1) {
         D[0] = __longlong_as_double((long long)p.fmax[0]);

@@ -148,7 +148,7 @@ def test_exchange_mirror_matches_the_cpp_sources():
     """The slot layout and the issue order of clrs_amd.sharded.ScalarExchange / IPM_EXCHANGE_SCHEDULE are those of the C++ path: the MWG_*
     macros of clrs_mw_ipm.hip.h and the mw_ipm_exchange calls of clrs_mw_ipm_host.inc (stage, stream) in source order."""
     import re
-    from clrs_amd.sharded import IPM_EXCHANGE_SCHEDULE, ipm_slot_layout
+    from clrs_amd.sharded import IPM_EXCHANGE_FIRST, IPM_EXCHANGE_LAST, IPM_EXCHANGE_SCHEDULE, ipm_slot_layout
     csrc = os.path.join(ROOT, "clusteredlowranksolver.jl_amd", "csrc")
     hdr = open(os.path.join(csrc, "clrs_mw_ipm.hip.h")).read()
     mac = dict(re.findall(r"#define MWG_(\w+)\(K, N\) (.*?)\s+/\*", hdr))
@@ -163,9 +163,12 @@ def test_exchange_mirror_matches_the_cpp_sources():
     inc = open(os.path.join(csrc, "clrs_mw_ipm_host.inc")).read()
     body = inc[inc.index("static int mw_ipm_enqueue"):inc.index("static int mw_ipm_finish")]
     calls = [(int(s_), st) for st, s_ in re.findall(r"mw_ipm_exchange\(c, (S|M), (\d)\)", body)]
-    # the objectives' exchange (stage 4) is issued by mw_ipm_objectives on the stream of mw_ipm_tail: the side stream, at the head of enqueue
-    assert "mw_ipm_exchange(c, stream, 4)" in inc and "mw_ipm_objectives(c, st->side)" in inc
-    assert [(4, "S")] + calls == list(IPM_EXCHANGE_SCHEDULE)
+    # the objectives' exchange is issued by mw_ipm_objectives on the stream of mw_ipm_tail -- the side stream, at the head of enqueue --: stage 14 (objectives
+    # and <X,Y> in one record) when an iteration follows, stage 4 alone from mw_ipm_finish; the separate stage 0 of enqueue is then skipped (xy_with_tail)
+    assert "mw_ipm_exchange(c, stream, with_xy ? 14 : 4)" in inc and "mw_ipm_objectives(c, st->side, word_value != 0 || with_next)" in inc
+    assert "if (!st->xy_with_tail) {" in body and calls[0] == IPM_EXCHANGE_FIRST and IPM_EXCHANGE_LAST == (4, "S")
+    assert [(14, "S")] + calls[1:] == list(IPM_EXCHANGE_SCHEDULE)
+    assert "slot[MWG_BX(K, N) + l] = v.l[l]" in hdr and "xy_merged ? MWG_BX(K, q.N) : MWG_S1(K, q.N)" in hdr
 
 
 def _exchange_worker(rank, world, port, ret):
@@ -188,9 +191,10 @@ def _exchange_worker(rank, world, port, ret):
         got = {}
         for stage, stream in IPM_EXCHANGE_SCHEDULE:          # both channels are one gloo group here; the ORDER is what is exercised
             slot = ex.new_slot()
-            if stage == 0:                                   # <X,Y> over this rank's blocks, as K limbs
+            if stage in (0, 14):                             # <X,Y> over this rank's blocks, as K limbs (stage 14: in the first K doubles of the BX area)
                 s = sum(float(X[f.block_off[b]:f.block_off[b + 1]] @ Y[f.block_off[b]:f.block_off[b + 1]]) for b in range(f.n_blocks) if int(f.block_cluster[b]) in mine)
-                slot[ex.lay["S1"]:ex.lay["S1"] + K] = mw_with_tails(np.array([s]), K, seed=rank)[:, 0]
+                o = ex.lay["S1"] if stage == 0 else ex.lay["BX"]
+                slot[o:o + K] = mw_with_tails(np.array([s]), K, seed=rank)[:, 0]
             if stage == 1:                                   # -B^T x over this rank's rows (planar limbs), max|P| stand-in
                 rows = np.concatenate([np.arange(int(f.cluster_off[j]), int(f.cluster_off[j + 1])) for j in mine])
                 part = -(B[rows].T @ x[rows])
@@ -202,6 +206,10 @@ def _exchange_worker(rank, world, port, ret):
             assert slots.shape == (world, ex.lay["LEN"]) and np.array_equal(slots[rank], slot)
             if stage == 0:
                 got["xy"] = ex.reduce_sum(slots, "S1")[0]
+            if stage == 14:                                  # the K limbs of <X,Y> sit at BX + l (count = 1 in the layout of reduce_sum)
+                lay_xy = dict(ex.lay, XY=ex.lay["BX"])
+                ex.lay = lay_xy
+                got["xy"] = ex.reduce_sum(slots, "XY")[0]
             if stage == 1:
                 got["btx"] = ex.reduce_sum(slots, "BX", N)
                 got["maxP"] = ex.reduce_max(slots, 0)
