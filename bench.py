@@ -225,8 +225,8 @@ def main():
                  "exchanges_per_iteration": {"partial_Q": 1, "partial_u": 3, "scalar_record": 4},
                  "exchange_us_per_iteration_back_to_back": per_iter,
                  "what": "all-gathers of one sharded iteration: the partial Q once, the partial u three times (the predictor's solve; the corrector's and "
-                         "its refinement step's), five scalar records, on two communicators (main / side stream); the sum is what they cost "
-                         "issued back to back on one stream -- inside the iteration the side stream's five overlap the factorisations"}
+                         "its refinement step's), four scalar records (objectives + <X,Y>; errors and p; beta_c; step lengths), on two communicators (main / side stream); "
+                         "the sum is what they cost issued back to back on one stream -- inside the iteration the side stream's two overlap the factorisations"}
         if rank == 0:
             c1 = MwSchurContext(flat, limbs=K, device=local_rank)
             solvesdp_mw(flat, ctx=c1, **thr)
