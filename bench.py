@@ -22,7 +22,7 @@ With N GPUs the problem is weak-scaled along the reference's own outer parallel 
 (the f^ cluster and 2N - 1 sign-constraint clusters at different radii), partitioned over the ranks by `partition_clusters`, and the
 WHOLE interior-point solve runs sharded: x, X, Y stay on their rank, y and every scalar are replicated bit for bit; per iteration the
 library itself all-gathers (RCCL, two communicators: one per stream that exchanges) the partial Q (limbs x 31 x 31), the partial u
-(limbs x 31, three times: the predictor's solve, the corrector's solve and its refinement step) and four small records for mu, the errors and p = b - B^T x, beta_c, the step lengths and the objectives
+(limbs x 31, three times: the predictor's solve, the corrector's solve and its refinement step) and three small records (objectives + mu + p = b - B^T x and the primal-residual error; beta_c and the dual-residual error; the step lengths)
 (clrs_mw_comm_init, clrs_mw_comm_init_side, clrs_mw_ipm_set_global).  A step of the N-GPU job = one
 iteration of the 2N-cluster problem = N units of work; `value` = N x iterations/s.
 
@@ -222,10 +222,10 @@ def main():
         per_iter = probe["q_us"] + 3 * probe["u_us"] + 4 * probe["record_us"]
         multi = {"ranks_in_process_group": dist.get_world_size(), "ranks_in_library_communicator": probe["world"], "backend": probe["backend"],
                  "allgather_us": {"partial_Q": probe["q_us"], "partial_u": probe["u_us"], "scalar_record": probe["record_us"]},
-                 "exchanges_per_iteration": {"partial_Q": 1, "partial_u": 3, "scalar_record": 4},
+                 "exchanges_per_iteration": {"partial_Q": 1, "partial_u": 3, "scalar_record": 3},
                  "exchange_us_per_iteration_back_to_back": per_iter,
                  "what": "all-gathers of one sharded iteration: the partial Q once, the partial u three times (the predictor's solve; the corrector's and "
-                         "its refinement step's), four scalar records (objectives + <X,Y>; errors and p; beta_c; step lengths), on two communicators (main / side stream); "
+                         "its refinement step's), three scalar records (objectives + <X,Y> + p; beta_c and errors; step lengths), on two communicators (main / side stream); "
                          "the sum is what they cost issued back to back on one stream -- inside the iteration the side stream's two overlap the factorisations"}
         if rank == 0:
             c1 = MwSchurContext(flat, limbs=K, device=local_rank)
@@ -320,7 +320,7 @@ def main():
                    "clusters": int(prob.n_clusters) * world if sharded else int(flat.n_clusters), "n_free": int(flat.n_free), "limbs": K, "data_limbs": 2,
                    "unit_of_work": "one interior-point iteration over one 2-cluster share; a step of the N-GPU job (one iteration of the 2N-cluster problem) = N units",
                    "multi_gpu": (f"{2 * world} clusters partitioned over {world} ranks (partition_clusters); per iteration RCCL all-gathers of the partial Q, the partial u "
-                                 "(three times: predictor, corrector and its refinement step) and four scalar records (objectives + mu; errors and p; beta_c; step lengths) inside the C ABI, two communicators "
+                                 "(three times: predictor, corrector and its refinement step) and three scalar records (objectives + mu + p; beta_c and errors; step lengths) inside the C ABI, two communicators "
                                  "(clrs_mw_comm_init, clrs_mw_comm_init_side, clrs_mw_ipm_set_global); y bit-identical on all ranks (asserted); hardware scaling curve: unmeasured by the builder (one-GPU boxes)") if sharded else "single GPU",
                    "launch": "eager, two streams, 35 kernels per iteration, one host wait per iteration on a record that is one iteration old"},
         "full_solve": full_solve,

@@ -55,7 +55,8 @@ struct MwIpmDev {
 #define MWG_S2(K, N) (K)                     /* K limbs: <c,x> (stage 4) */
 #define MWG_BX(K, N) (2 * (K))               /* K N limbs, planar with plane N: -B^T x of this rank's rows (stage 1) */
 #define MWG_D(K, N) (2 * (K) + (K) * (N))    /* doubles: max|P|, max|d|, min eig X, min eig Y, factor status, Cholesky status, step-length failure, - */
-#define MWG_LEN(K, N) (MWG_D(K, N) + 8)
+#define MWG_XY(K, N) (MWG_D(K, N) + 8)        /* K limbs: <X,Y> of the iterate the last update produced (stage 15) */
+#define MWG_LEN(K, N) (MWG_D(K, N) + 8 + (K))
 
 namespace mwk {
 
@@ -415,10 +416,10 @@ __device__ void mwi_scalar_stage(const MwDev &q, const MwIpmDev &p, int stage, i
         q.info[1] = MW_INFO_NONE;
         return;
     }
-    const bool xy_merged = stage == 10;            // stage 0 whose <X,Y> travelled with the previous iteration's objectives (k_mwi_gpack stage 14)
+    const bool xy_merged = stage == 10;            // stage 0 whose <X,Y> travelled with the previous iteration's objectives (k_mwi_gpack stage 15: MWG_XY)
     if (xy_merged) stage = 0;
     if (stage == 0) {                              // start of the iteration: mu, mu_p  (src/solver.jl:369-380)
-        mw<K> xy = q.world > 1 ? mwi_gsum<K>(q, p.gsS, p.GL, xy_merged ? MWG_BX(K, q.N) : MWG_S1(K, q.N)) : mwi_sum_part<K>(q, p, 0);
+        mw<K> xy = q.world > 1 ? mwi_gsum<K>(q, p.gsS, p.GL, xy_merged ? MWG_XY(K, q.N) : MWG_S1(K, q.N)) : mwi_sum_part<K>(q, p, 0);
         mw<K> mu = s_div<K>(xy, from_double<K>((double)p.Ktot));
         stx<K>(p.sc, SP, MSC_XY, xy);
         stx<K>(p.sc, SP, MSC_MU, mu);
@@ -451,8 +452,13 @@ __device__ void mwi_scalar_stage(const MwDev &q, const MwIpmDev &p, int stage, i
         }
     }
     if (stage == 1 || stage == 2) {                // after the residuals: errors (:441-447 use them), failures of the decomposition
-        const double maxP = __longlong_as_double((long long)p.fmax[0]), maxd = __longlong_as_double((long long)p.fmax[1]),
-                     maxp = __longlong_as_double((long long)p.fmax[2]);
+        const double maxP = __longlong_as_double((long long)p.fmax[0]), maxp = __longlong_as_double((long long)p.fmax[2]);
+        double maxd = __longlong_as_double((long long)p.fmax[1]);
+        if (q.world > 1 && stage == 2) {           // max|d| over the ranks (their stage-2 records)
+            for (int r = 0; r < q.world; r++) maxd = fmax(maxd, p.gsM[(long)r * p.GL + MWG_D(K, q.N) + 1]);
+        }
+        // max|P| of the NEXT iterate is accumulated by the tail of this iteration when the solve is sharded (stage 15), before the next stage 0 runs
+        p.fmax[0] = 0ull;
         p.rec[MREC_MAXP] = maxP; p.rec[MREC_MAXd] = maxd; p.rec[MREC_MAXp] = maxp;
         p.rec[MREC_DERR] = fmax(maxp, maxP);       // :828-832
         p.rec[MREC_PERR] = maxd;
@@ -847,7 +853,10 @@ __global__ void k_mwi_gpack(const MwDev q, const MwIpmDev p, int stage) {
     if (blockIdx.x != 0 || threadIdx.x >= 64) return;
     const int lane = threadIdx.x, N = q.N;
     double *slot = ((stage == 2 || stage == 3) ? p.gsM : p.gsS) + (long)q.rank * p.GL, *D = slot + MWG_D(K, N);
-    const bool with_xy = stage == 14;              // stage 4 whose record also carries <X,Y> (first K doubles of the -B^T x area, unused by stages 0 and 4)
+    // stage 15: ONE record for everything the side stream needs of the iterate the last update produced -- the objectives (stage 4), <X,Y> (stage 0 of the
+    // next iteration) and what depends on the iterate alone among the residuals (stage 1: -B^T x, which k_mwi_pv has written to the slot, and max|P|; max|d|
+    // needs the pairings of the next assembly and travels with stage 2)
+    const bool with_xy = stage == 15;
     if (with_xy) stage = 4;
     if (stage == 4) {                              // <c,x> over this rank's rows, by the wave
         acc<K> s;
@@ -868,13 +877,16 @@ __global__ void k_mwi_gpack(const MwDev q, const MwIpmDev p, int stage) {
     if (with_xy) {
         const mw<K> v = mwi_sum_part<K>(q, p, 0);
 #pragma unroll
-        for (int l = 0; l < K; l++) slot[MWG_BX(K, N) + l] = v.l[l];
+        for (int l = 0; l < K; l++) slot[MWG_XY(K, N) + l] = v.l[l];
+        D[0] = __longlong_as_double((long long)p.fmax[0]);
+        D[1] = 0.0;
     }
     if (stage == 1) {
         D[0] = __longlong_as_double((long long)p.fmax[0]);
         D[1] = __longlong_as_double((long long)p.fmax[1]);
     }
-    if (stage == 2) {                              // the decomposition's status words, as global numbers
+    if (stage == 2) {                              // max|d| of this rank's rows; the decomposition's status words, as global numbers
+        D[1] = __longlong_as_double((long long)p.fmax[1]);
         const int fs = q.info[0], xs = q.info[1];
         D[4] = fs == MW_INFO_NONE ? MW_INFO_NONE : fs > q.J ? p.Jglob + 1 : p.clu_gid ? p.clu_gid[fs - 1] + 1 : fs;
         D[5] = xs == MW_INFO_NONE ? MW_INFO_NONE : p.blk_gid ? p.blk_gid[xs - 1] + 1 : xs;

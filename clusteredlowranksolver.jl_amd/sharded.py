@@ -239,20 +239,21 @@ class ShardedSchur:
 # order -- in a form the CPU tests can drive over `gloo` and check against the C++ sources.
 # ------------------------------------------------------------------------------------------------------------------------------------
 IPM_EXCHANGE_SCHEDULE = (            # (scalar stage, stream) in issue order within one iteration of a running solve; "S" = side stream, "M" = the context's stream
-    (14, "S"),                       # objectives of the iterate the last update produced (the tail of the previous iteration leads this one's side work) AND, in the
-                                     # same record, <X,Y> of that iterate -> mu of this iteration (stage 4 + stage 0: one exchange since round 4)  src/solver.jl:793-804, 369
-    (1, "S"),                        # -B^T x, max|P|, max|d| -> p, errors                          :899-916, 441-442
-    (2, "M"),                        # <X,dY> + <dX,Y> + <dX,dY>, status words -> beta_c            :429-434
+    (15, "S"),                       # objectives of the iterate the last update produced (the tail of the previous iteration leads this one's side work) AND, in the
+                                     # same record, <X,Y> of that iterate -> mu of this iteration, AND this rank's -B^T x and max|P| of that iterate -> p, errors
+                                     # (stages 4 + 0 + 1: one exchange on the side stream since round 4)          src/solver.jl:793-804, 369, 899-916
+    (2, "M"),                        # <X,dY> + <dX,Y> + <dX,dY>, max|d|, status words -> beta_c, errors           :429-434, 441-442
     (3, "M"),                        # smallest eigenvalues -> step lengths                         :1684-1686
 )
-# the first iteration of a solve has no tail in front of it: its <X,Y> travels alone (stage 0); the last tail (mw_ipm_finish) has no iteration behind it: stage 4 alone
-IPM_EXCHANGE_FIRST, IPM_EXCHANGE_LAST = (0, "S"), (4, "S")
+# the first iteration of a solve has no tail in front of it: its <X,Y> travels alone (stage 0) and so do its residuals (stage 1: -B^T x, max|P|, max|d|);
+# the last tail (mw_ipm_finish) has no iteration behind it: stage 4 alone
+IPM_EXCHANGE_FIRST, IPM_EXCHANGE_LAST = ((0, "S"), (1, "S")), (4, "S")
 
 
 def ipm_slot_layout(K: int, N: int) -> dict:
-    """Offsets (in doubles) of one rank's record: S1, S2 K-limb sums, BX = K x N planar limbs (stage 14: its first K doubles carry <X,Y>), D = 8 plain
-    doubles; LEN = slot length."""
-    return dict(S1=0, S2=K, BX=2 * K, D=2 * K + K * N, LEN=2 * K + K * N + 8)
+    """Offsets (in doubles) of one rank's record: S1, S2 K-limb sums, BX = K x N planar limbs, D = 8 plain doubles, XY = K limbs (<X,Y> of stage 15);
+    LEN = slot length."""
+    return dict(S1=0, S2=K, BX=2 * K, D=2 * K + K * N, XY=2 * K + K * N + 8, LEN=3 * K + K * N + 8)
 
 
 class ScalarExchange:

@@ -157,18 +157,20 @@ def test_exchange_mirror_matches_the_cpp_sources():
         lay = ipm_slot_layout(K, N)
         env = {"K": K, "N": N}
         env["MWG_D"] = lambda k, n: eval(mac["D"].replace("(K)", str(k)).replace("(N)", str(n)))
-        for name in ("S1", "S2", "BX", "D"):
-            assert eval(mac[name].replace("(K)", str(K)).replace("(N)", str(N))) == lay[name], name
-        assert eval(mac["LEN"].replace("MWG_D(K, N)", str(lay["D"]))) == lay["LEN"]
+        for name in ("S1", "S2", "BX", "D", "XY"):
+            assert eval(mac[name].replace("MWG_D(K, N)", str(lay["D"])).replace("(K)", str(K)).replace("(N)", str(N))) == lay[name], name
+        assert eval(mac["LEN"].replace("MWG_D(K, N)", str(lay["D"])).replace("(K)", str(K))) == lay["LEN"]
     inc = open(os.path.join(csrc, "clrs_mw_ipm_host.inc")).read()
     body = inc[inc.index("static int mw_ipm_enqueue"):inc.index("static int mw_ipm_finish")]
     calls = [(int(s_), st) for st, s_ in re.findall(r"mw_ipm_exchange\(c, (S|M), (\d)\)", body)]
-    # the objectives' exchange is issued by mw_ipm_objectives on the stream of mw_ipm_tail -- the side stream, at the head of enqueue --: stage 14 (objectives
-    # and <X,Y> in one record) when an iteration follows, stage 4 alone from mw_ipm_finish; the separate stage 0 of enqueue is then skipped (xy_with_tail)
-    assert "mw_ipm_exchange(c, stream, with_xy ? 14 : 4)" in inc and "mw_ipm_objectives(c, st->side, word_value != 0 || with_next)" in inc
-    assert "if (!st->xy_with_tail) {" in body and calls[0] == IPM_EXCHANGE_FIRST and IPM_EXCHANGE_LAST == (4, "S")
-    assert [(14, "S")] + calls[1:] == list(IPM_EXCHANGE_SCHEDULE)
-    assert "slot[MWG_BX(K, N) + l] = v.l[l]" in hdr and "xy_merged ? MWG_BX(K, q.N) : MWG_S1(K, q.N)" in hdr
+    # the objectives' exchange is issued by mw_ipm_objectives on the stream of mw_ipm_tail -- the side stream, at the head of enqueue --: stage 15 (objectives,
+    # <X,Y> and the iterate's share of the residuals in one record) when an iteration follows, stage 4 alone from mw_ipm_finish; the separate stages 0 and 1 of
+    # enqueue are then skipped (xy_with_tail, res_with_tail)
+    assert "mw_ipm_exchange(c, stream, with_xy ? 15 : 4)" in inc and "mw_ipm_objectives(c, st->side, word_value != 0 || with_next)" in inc
+    assert "if (!st->xy_with_tail) {" in body and "if (!res_with_tail) {" in body and "res_with_tail = st->xy_with_tail && q.world > 1" in body
+    assert tuple(calls[:2]) == IPM_EXCHANGE_FIRST and IPM_EXCHANGE_LAST == (4, "S")
+    assert [(15, "S")] + calls[2:] == list(IPM_EXCHANGE_SCHEDULE)
+    assert "slot[MWG_XY(K, N) + l] = v.l[l]" in hdr and "xy_merged ? MWG_XY(K, q.N) : MWG_S1(K, q.N)" in hdr
 
 
 def _exchange_worker(rank, world, port, ret):
@@ -191,11 +193,11 @@ def _exchange_worker(rank, world, port, ret):
         got = {}
         for stage, stream in IPM_EXCHANGE_SCHEDULE:          # both channels are one gloo group here; the ORDER is what is exercised
             slot = ex.new_slot()
-            if stage in (0, 14):                             # <X,Y> over this rank's blocks, as K limbs (stage 14: in the first K doubles of the BX area)
+            if stage in (0, 15):                             # <X,Y> over this rank's blocks, as K limbs (stage 15: in the XY field behind the plain doubles)
                 s = sum(float(X[f.block_off[b]:f.block_off[b + 1]] @ Y[f.block_off[b]:f.block_off[b + 1]]) for b in range(f.n_blocks) if int(f.block_cluster[b]) in mine)
-                o = ex.lay["S1"] if stage == 0 else ex.lay["BX"]
+                o = ex.lay["S1"] if stage == 0 else ex.lay["XY"]
                 slot[o:o + K] = mw_with_tails(np.array([s]), K, seed=rank)[:, 0]
-            if stage == 1:                                   # -B^T x over this rank's rows (planar limbs), max|P| stand-in
+            if stage in (1, 15):                             # -B^T x over this rank's rows (planar limbs), max|P| stand-in
                 rows = np.concatenate([np.arange(int(f.cluster_off[j]), int(f.cluster_off[j + 1])) for j in mine])
                 part = -(B[rows].T @ x[rows])
                 slot[ex.lay["BX"]:ex.lay["BX"] + K * N] = mw_with_tails(part, K, seed=10 + rank).reshape(-1)
@@ -206,11 +208,9 @@ def _exchange_worker(rank, world, port, ret):
             assert slots.shape == (world, ex.lay["LEN"]) and np.array_equal(slots[rank], slot)
             if stage == 0:
                 got["xy"] = ex.reduce_sum(slots, "S1")[0]
-            if stage == 14:                                  # the K limbs of <X,Y> sit at BX + l (count = 1 in the layout of reduce_sum)
-                lay_xy = dict(ex.lay, XY=ex.lay["BX"])
-                ex.lay = lay_xy
+            if stage == 15:
                 got["xy"] = ex.reduce_sum(slots, "XY")[0]
-            if stage == 1:
+            if stage in (1, 15):
                 got["btx"] = ex.reduce_sum(slots, "BX", N)
                 got["maxP"] = ex.reduce_max(slots, 0)
             if stage == 3:
