@@ -20,6 +20,7 @@
 // The digits are stored as fp32 (exact: 23 bits and a sign), half the LDS of doubles, converted by one v_cvt_f64_f32 per operand.
 // One workgroup of four waves per PSD block; every slice array has the layout [slice][k][col] (k = contraction index, col = the free
 // index, contiguous): the MFMA A operand (lane (l15, l4) holds A[i = l15][k = l4]) and B operand (B[k = l4][j = l15]) read it alike.
+// The two conversions -- K limbs -> digits, order sums -> K limbs -- are in clrs_mw_slices.h (host + device).
 //   phase A  slice Y and Xi = chol(X)^-1 by rows (dynamic); the slices of V by columns are static data (context creation)
 //   phase B  T = Y V and Z = Xi V: one 16 x 16 output tile per wave and turn; recombine the order sums to K limbs, slice by columns
 //   phase D  GY = V^T T, GX = Z^T Z, lower tiles only, recombined to K limbs and written mirrored like k_mw_gram does
@@ -29,67 +30,22 @@
 
 #include "clrs_mw_kernels.hip.h"
 
-#define MWS_BETA 23
+#include "clrs_mw_slices.h"       // MWS_BETA, mws_slices, mws_exponent, mws_slice, mws_recombine_orders (host + device; tests/mw_host checks them against mpmath)
+
 #define MWS_NT 256
-constexpr int mws_slices(int K) { return (52 * K + 16 + MWS_BETA - 1) / MWS_BETA; }
 
 namespace mwk {
 
 typedef double v4d_mw __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) float lds_f;
 
-// exponent e with |x| < 2^(e-2) for a renormalised expansion with head h (0 for h = 0: the slices of a zero are zeros)
-__device__ __host__ __forceinline__ int mws_exponent(double h) {
-    if (h == 0.0) return 0;
-    int ex;
-    (void)frexp(h, &ex);                    // |h| < 2^ex
-    return ex + 2;
-}
-
-// Digits of x relative to the window exponent e (|x| < 2^(e-2)): x = 2^e sum_s d[s] 2^-(s+1)B + O(2^(e-SB-1)).  Each digit is the head of
-// the remainder rounded to the grid 2^-(s+1)B by the add-and-subtract of 1.5 * 2^52 * grid (exact for |head| < 2^51 grid); the remainder
-// is then swept once top-down with two_sum, which leaves a head within 2^-53 of the remainder's value whatever the order of its terms.
-template <int K, int S, class OUT>
-MWF void mws_slice(const mwa::mw<K> &x, int e, OUT &&put) {
-    double r[K];
-#pragma unroll
-    for (int l = 0; l < K; l++) r[l] = ldexp(x.l[l], -e);
-#pragma unroll
-    for (int s = 0; s < S; s++) {
-        const double g = ldexp(1.0, -(s + 1) * MWS_BETA), C = 0x1.8p52 * g;
-        const double t = (r[0] + C) - C;
-        put(s, (float)(t * ldexp(1.0, (s + 1) * MWS_BETA)));
-        r[0] -= t;
-#pragma unroll
-        for (int l = 0; l + 1 < K; l++) {
-            double sm, er;
-            mwa::two_sum(r[l], r[l + 1], sm, er);
-            r[l] = sm;
-            r[l + 1] = er;
-        }
-    }
-}
-
-// sum_o acc[o] 2^-(o+2)B as K limbs (acc[o] exact integers below 2^53): every term enters the unnormalised accumulator in a bin its
-// magnitude allows (|acc[o]| 2^-(o+2)B <= 2^(7 - o B)), then one renormalisation
-template <int K, int S, int O>
-struct MwsPush {
-    static __device__ __forceinline__ void run(mwa::acc<K> &a, const v4d_mw (&acc)[S], int reg) {
-        constexpr int raw = (O * MWS_BETA - 8) / 53, bin = raw < 0 ? 0 : (raw > K - 1 ? K - 1 : raw);
-        const double v = ldexp(acc[O][reg], -(O + 2) * MWS_BETA);
-        mwa::acc_push<K, bin>(a, v);
-        if constexpr (O + 1 < S) MwsPush<K, S, O + 1>::run(a, acc, reg);
-    }
-};
+// register `reg` of the S order accumulators of a tile -> K limbs (clrs_mw_slices.h)
 template <int K, int S>
 __device__ __forceinline__ mwa::mw<K> mws_recombine(const v4d_mw (&acc)[S], int reg, int escale) {
-    mwa::acc<K> a;
-    mwa::acc_zero<K>(a);
-    MwsPush<K, S, 0>::run(a, acc, reg);
-    mwa::mw<K> r = mwa::acc_result<K>(a);
+    double a[S];
 #pragma unroll
-    for (int l = 0; l < K; l++) r.l[l] = ldexp(r.l[l], escale);
-    return r;
+    for (int o = 0; o < S; o++) a[o] = acc[o][reg];
+    return mws_recombine_orders<K, S>(a, escale);
 }
 
 // one 16 x 16 output tile: acc[o] += sum over the pairs s + t = o, s < SA, t < SB, and the k-steps, of A_s^T-style products
@@ -426,9 +382,9 @@ __global__ __launch_bounds__(MWS_NT, 2) void k_mwx_gram(const MwDev q, const Mwx
     const float *Lg = (gy ? w.Vd : (const float *)w.Zd) + off + ta * 16, *Rg = (gy ? (const float *)w.Td : (const float *)w.Zd) + off + tb * 16;
     const int *eL = (gy ? w.eV : (const int *)w.eZ) + w.e_off[b], *eR = (gy ? (const int *)w.eT : (const int *)w.eZ) + w.e_off[b];
     const int SV = w.sv[b], ksteps = np / 4;
-    acc<K> a4[4];
+    double bins[4][mws_bins(S)];                           // (clrs_mw_slices.h: the chunks' order sums add up exactly in the bins)
 #pragma unroll
-    for (int reg = 0; reg < 4; reg++) acc_zero<K>(a4[reg]);
+    for (int reg = 0; reg < 4; reg++) mws_bins_zero<S>(bins[reg]);
     v4d_mw acc[S];
     for (int ks0 = 0; ks0 < ksteps; ks0 += 8) {             // 32 rows of k: the order sums stay below 2^53
         const int nks = min(8, ksteps - ks0);
@@ -439,17 +395,19 @@ __global__ __launch_bounds__(MWS_NT, 2) void k_mwx_gram(const MwDev q, const Mwx
         else if (SV <= S2) mwx_tile<S, S2, S>(acc, Lg, sD, U16, Rg, sD, U16, ks0, nks, l15, l4);
         else mwx_tile<S, S, S>(acc, Lg, sD, U16, Rg, sD, U16, ks0, nks, l15, l4);
 #pragma unroll
-        for (int reg = 0; reg < 4; reg++) MwsPush<K, S, 0>::run(a4[reg], acc, reg);
+        for (int reg = 0; reg < 4; reg++) {
+            double a[S];
+#pragma unroll
+            for (int o = 0; o < S; o++) a[o] = acc[o][reg];
+            mws_bins_add<S>(bins[reg], a);
+        }
     }
     double *G = (gy ? q.GY : q.GX) + k.g_off;
 #pragma unroll
     for (int reg = 0; reg < 4; reg++) {
         const int a = ta * 16 + 4 * reg + l4, c = tb * 16 + l15;        // entry (a, c), a >= c kept and mirrored
         if (a >= U || c >= U || c > a) continue;
-        mw<K> v = acc_result<K>(a4[reg]);
-        const int es = eL[a] + eR[c];
-#pragma unroll
-        for (int l = 0; l < K; l++) v.l[l] = ldexp(v.l[l], es);
+        const mw<K> v = mws_bins_result<K, S>(bins[reg], eL[a] + eR[c]);
         stx<K>(G, q.glen, a + (long)c * U, v);
         stx<K>(G, q.glen, c + (long)a * U, v);
     }
