@@ -219,14 +219,14 @@ def main():
         # what the exchanges of one iteration cost on this job's communicator (HIP events around all-gathers of the three message sizes, back to back:
         # clrs_mw_comm_probe), and the one-GPU rate of the named problem measured by rank 0 in this same job for comparison
         probe = ctx.comm_probe(50)
-        per_iter = probe["q_us"] + 3 * probe["u_us"] + 4 * probe["record_us"]
+        per_iter = probe["q_us"] + 3 * probe["u_us"] + 3 * probe["record_us"]
         multi = {"ranks_in_process_group": dist.get_world_size(), "ranks_in_library_communicator": probe["world"], "backend": probe["backend"],
                  "allgather_us": {"partial_Q": probe["q_us"], "partial_u": probe["u_us"], "scalar_record": probe["record_us"]},
                  "exchanges_per_iteration": {"partial_Q": 1, "partial_u": 3, "scalar_record": 3},
                  "exchange_us_per_iteration_back_to_back": per_iter,
                  "what": "all-gathers of one sharded iteration: the partial Q once, the partial u three times (the predictor's solve; the corrector's and "
                          "its refinement step's), three scalar records (objectives + <X,Y> + p; beta_c and errors; step lengths), on two communicators (main / side stream); "
-                         "the sum is what they cost issued back to back on one stream -- inside the iteration the side stream's two overlap the factorisations"}
+                         "the sum is what they cost issued back to back on one stream -- inside the iteration the side stream's one overlaps the factorisations"}
         if rank == 0:
             c1 = MwSchurContext(flat, limbs=K, device=local_rank)
             solvesdp_mw(flat, ctx=c1, **thr)
