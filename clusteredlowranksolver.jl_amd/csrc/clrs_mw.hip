@@ -168,6 +168,7 @@ struct clrs_mw_ctx {
     int mws_blocks = 0;                  // how many
     int mws_turns = 1;                   // 2: some eligible block has more than four T / Z tiles
     size_t sm_mws = 0;
+    bool pipe_bp = false;                // the diagonal blocks of the blocked factorisation as pipelines (k_mw_bp_diag_pipe)
     bool pipe_S = false, pipe_Q = false;  // the factorisations of the clusters / of Q as pipelines of workgroups (clrs_mw_pipe.hip.h): every matrix <= 32 rows, few clusters
     int pipe_pcQ = 0;                    // index of Q's hand-off region in pipe_pc
     unsigned pipe_epoch = 0;             // launch counter: the tag of the hand-off granules
@@ -736,28 +737,6 @@ extern "C" int clrs_mw_create_opts(const clrs_sdp_desc *d, int data_limbs, int d
         c->stream_words = e && *e ? std::atoi(e) != 0 : g_cfg_mw_stream_words != 0;
     }
     c->wide_solve = c->maxP > 64 || N > 64;
-    {   // pipelined factorisations (clrs_mw_pipe.hip.h): matrices of at most 32 rows, while stages + W workgroups of every matrix can be resident side by side
-        bool small = c->maxP <= MWP_N;
-        for (auto &cl : c->clu) small = small && cl.lds;
-        c->pipe_S = cfg_pipe != 0 && (K <= 6 || cfg_pipe >= 2) && small && (i64)J * ((MWP_N / MWP_W) + MWP_WW) <= 256;      // (8, 10 limbs: measured slower than one workgroup, 2.42 against 2.34 ms per iteration: opt-in)
-        c->pipe_Q = cfg_pipe >= 2 && N > 0 && N <= MWP_N;      // (Q: slower than the one-workgroup kernel on the named problem, 83 against 80 us: opt-in)
-        q.pipe_pc = nullptr;
-        q.pipe_stamps = nullptr;
-        if (c->pipe_S || c->pipe_Q) {
-            const size_t words = (size_t)((c->pipe_S ? J : 0) + 1) * MWP_PC_WORDS(K);
-            unsigned long long *pc = nullptr;
-            if (hipMalloc((void **)&pc, words * sizeof(unsigned long long)) != hipSuccess) MW_BAIL(CLRS_ERR_HIP, "hipMalloc failed");
-            c->allocs.push_back(pc);
-            if (hipMemset(pc, 0xff, words * sizeof(unsigned long long)) != hipSuccess) MW_BAIL(CLRS_ERR_HIP, "hipMemset failed");      // no launch epoch has this tag
-            q.pipe_pc = pc;
-            c->pipe_pcQ = c->pipe_S ? J : 0;
-            q.pipe_q = c->pipe_pcQ;
-            MW_DISPATCH(c, {
-                MW_TRY(mw_set_lds(k_mw_factor_pipe<KK>, MWP_LDS_ALONE));
-                MW_TRY(mw_set_lds(k_mw_potrf_q_pipe<KK>, std::max<size_t>(MWP_LDS_ALONE, c->sm_fwd)));
-            });
-        }
-    }
     MW_TRY(mw_dmalloc(c, &c->d_Xin, xyoff * K)); MW_TRY(mw_dmalloc(c, &c->d_Xc, xyoff * K)); MW_TRY(mw_dmalloc(c, &c->d_Y, xyoff * K));
     MW_TRY(mw_dmalloc(c, &c->d_rx, xlen * K)); MW_TRY(mw_dmalloc(c, &c->d_dx, xlen * K));
     MW_TRY(mw_dmalloc(c, &c->d_ry, (i64)N * K)); MW_TRY(mw_dmalloc(c, &c->d_dy, (i64)N * K));
@@ -785,11 +764,41 @@ extern "C" int clrs_mw_create_opts(const clrs_sdp_desc *d, int data_limbs, int d
         all.insert(all.end(), c->bp_Q.begin(), c->bp_Q.end());
         MW_TRY(mw_upload(c, all, &c->d_bp));
     }
+    {   // pipelined factorisations (clrs_mw_pipe.hip.h): matrices of at most 32 rows, while stages + W workgroups of every matrix can be resident side by side
+        bool small = c->maxP <= MWP_N;
+        for (auto &cl : c->clu) small = small && cl.lds;
+        c->pipe_S = cfg_pipe != 0 && (K <= 6 || cfg_pipe >= 2) && small && (i64)J * ((MWP_N / MWP_W) + MWP_WW) <= 256;      // (8, 10 limbs: measured slower than one workgroup, 2.42 against 2.34 ms per iteration: opt-in)
+        c->pipe_Q = cfg_pipe >= 2 && N > 0 && N <= MWP_N;      // (Q: slower than the one-workgroup kernel on the named problem, 83 against 80 us: opt-in)
+        // the diagonal blocks of the blocked factorisation (k_mw_bp_diag_pipe): the same pipeline per 32-column block of every matrix beyond LDS
+        const size_t nbp = c->bp_S.size() + c->bp_Q.size();
+        const bool any_bp = !c->bp_S.empty() || (N > 0 && !c->lds_q);
+        c->pipe_bp = cfg_pipe != 0 && (K <= 6 || cfg_pipe >= 2) && any_bp && (i64)std::max<size_t>(c->bp_S.size(), 1) * ((MWP_N / MWP_W) + MWP_WW) <= 256;
+        q.pipe_pc = nullptr;
+        q.pipe_stamps = nullptr;
+        q.pipe_bp = 0;
+        if (c->pipe_S || c->pipe_Q || c->pipe_bp) {
+            const size_t own = (size_t)(c->pipe_S ? J : 0) + 1;
+            const size_t words = (own + (c->pipe_bp ? nbp : 0)) * MWP_PC_WORDS(K);
+            unsigned long long *pc = nullptr;
+            if (hipMalloc((void **)&pc, words * sizeof(unsigned long long)) != hipSuccess) MW_BAIL(CLRS_ERR_HIP, "hipMalloc failed");
+            c->allocs.push_back(pc);
+            if (hipMemset(pc, 0xff, words * sizeof(unsigned long long)) != hipSuccess) MW_BAIL(CLRS_ERR_HIP, "hipMemset failed");      // no launch epoch has this tag
+            q.pipe_pc = pc;
+            c->pipe_pcQ = c->pipe_S ? J : 0;
+            q.pipe_q = c->pipe_pcQ;
+            q.pipe_bp = (int)own;
+            MW_DISPATCH(c, {
+                MW_TRY(mw_set_lds(k_mw_factor_pipe<KK>, MWP_LDS_ALONE));
+                MW_TRY(mw_set_lds(k_mw_potrf_q_pipe<KK>, std::max<size_t>(MWP_LDS_ALONE, c->sm_fwd)));
+                MW_TRY(mw_set_lds(k_mw_bp_diag_pipe<KK>, std::max<size_t>(MWP_LDS_ALONE, c->sm_factor)));
+            });
+        }
+    }
     const int MW_PB = MW_PB_OF(K);
     c->sm_bp_diag = ((size_t)MW_POTRF_SCR(K, MW_PB) + (size_t)K * MW_PB * MW_PB + (size_t)K * MW_TRI(MW_PB) + (size_t)K * MW_PB) * 8;
     c->sm_bp_panel = (size_t)K * MW_BP_PR * MW_PB * 8;
     c->sm_bp_inv = (size_t)K * MW_PB * MW_BP_IC * 8;
-    MW_DISPATCH(c, { MW_TRY(mw_set_lds(k_mw_bp_diag<KK>, std::max(c->sm_bp_diag, c->sm_factor))); MW_TRY(mw_set_lds(k_mw_bp_panel<KK>, c->sm_bp_panel)); MW_TRY(mw_set_lds(k_mw_bp_inv<KK>, c->sm_bp_inv)); });
+    MW_DISPATCH(c, { MW_TRY(mw_set_lds(k_mw_bp_diag<KK>, std::max(c->sm_bp_diag, c->sm_factor))); MW_TRY(mw_set_lds(k_mw_bp_panel<KK>, c->sm_bp_panel)); MW_TRY(mw_set_lds(k_mw_bp_inv<KK>, c->sm_bp_inv)); MW_TRY(mw_set_lds(k_mw_bp_inv_row<KK>, c->sm_bp_inv)); });
     q.rank = 0; q.world = 1; q.gathered = 0;
     MW_TRY(mw_dmalloc(c, &q.Qg, (i64)N * N * K)); MW_TRY(mw_dmalloc(c, &q.ug, (i64)N * K));
     for (auto &e : c->ev) MWCHECK(hipEventCreate(&e));
@@ -1133,12 +1142,23 @@ static int mw_potrf_blocked(clrs_mw_ctx *c, const std::vector<MwBp> &hm, const M
         for (int j0 = 0; j0 < nmax; j0 += MW_PB) {
             const int nb = std::min(MW_PB, nmax - j0), mm = nmax - j0 - nb;
             const bool ride = ride_factor && j0 == 0;
+            if (c->pipe_bp) {
+                // block row j0 / MW_PB - 1 of the inverse factors rides on this launch (its diagonal block was the previous launch's)
+                const int inv_row = j0 / MW_PB - 1 >= 1 ? j0 / MW_PB - 1 : 0;
+                c->pipe_epoch = (c->pipe_epoch + 1) & 0x3ffffff;
+                hipLaunchKernelGGL(k_mw_bp_diag_pipe<KK>, dim3(mwp_blocks(nm) + (ride ? q.J * MW_INV_WG : 0) + inv_row * (MW_PB / MW_BP_IC) * nm), dim3(MWP_NT),
+                                   ride ? std::max<size_t>(MWP_LDS_ALONE, c->sm_factor) : std::max<size_t>(MWP_LDS_ALONE, c->sm_bp_inv),
+                                   c->stream, q, d_ms, nm, j0, c->pipe_epoch, ride ? q.J : 0, inv_row);
+            } else
             hipLaunchKernelGGL(k_mw_bp_diag<KK>, dim3(MW_INV_WG, nm + (ride ? q.J : 0)), dim3(MW_PT), ride ? std::max(c->sm_bp_diag, c->sm_factor) : c->sm_bp_diag, c->stream, q, d_ms, nm, j0);
             if (mm > 0) {
                 hipLaunchKernelGGL(k_mw_bp_panel<KK>, dim3((mm + MW_BP_PR - 1) / MW_BP_PR, nm), dim3(MW_PT), c->sm_bp_panel, c->stream, q, d_ms, j0);
                 hipLaunchKernelGGL(k_mw_bp_syrk<KK>, dim3((unsigned)(((i64)mm * (mm + 1) / 2 * MW_BP_SW + MW_NT - 1) / MW_NT), nm), dim3(MW_NT), 0, c->stream, q, d_ms, j0);
             }
         }
+        if (c->pipe_bp) {                // the rows 1 .. nbk - 2 rode on the launches of the diagonal blocks; the last row has none to ride on
+            if (nbk >= 2) hipLaunchKernelGGL(k_mw_bp_inv_row<KK>, dim3(nbk - 1, MW_PB / MW_BP_IC, nm), dim3(MW_PT), c->sm_bp_inv, c->stream, q, d_ms, nbk - 1);
+        } else
         for (int d = 1; d < nbk; d++)
             hipLaunchKernelGGL(k_mw_bp_inv<KK>, dim3(nbk - d, MW_PB / MW_BP_IC, nm), dim3(MW_PT), c->sm_bp_inv, c->stream, q, d_ms, d);
         hipLaunchKernelGGL(k_mw_bp_finish<KK>, dim3((unsigned)std::min<i64>(1024, ((i64)nmax * nmax + MW_NT - 1) / MW_NT), nm), dim3(MW_NT), 0, c->stream, q, d_ms);

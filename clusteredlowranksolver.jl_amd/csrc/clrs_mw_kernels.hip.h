@@ -83,7 +83,7 @@ struct MwDev {
     double *S0;                         // S_j as assembled (S layout; written by the FACTOR stage as it reads S_j, which it overwrites with L_j): the residuals of the refinement need S_j
     int *mark_word;                     // null, or a word the FIRST workgroup of the next Cholesky / factor launch stores mark_value to as it starts: "everything in front of
     int mark_value, pad7;               // this launch on its stream is complete", for kernels of another stream that wait inside their launch (mw_wait_word) instead of for an event
-    int pipe_q, pad6;                   // index of Q's region in pipe_pc
+    int pipe_q, pipe_bp;                // index of Q's region in pipe_pc; of the first matrix of the blocked path (k_mw_bp_diag_pipe: region pipe_bp + MwBp::slot)
     unsigned long long *pipe_stamps;    // diagnostic builds: [16][40] step stamps of the pipelined factorisations (clrs_mw_debug_pipe_stamps), or null
     unsigned long long *pipe_pc;        // hand-off granules of the pipelined factorisations (clrs_mw_pipe.hip.h): [J + 1][MWP_PC_WORDS], or null
     double *ub;                         // u' slabs of the refinement step (J x N; k_mw_solve_bwd MODE 1 writes them while other workgroups read u)
@@ -1211,6 +1211,8 @@ __global__ __launch_bounds__(MW_PT) void k_mw_bp_panel(const MwDev q, const MwBp
     }
 }
 // trailing update: A[i, j] -= sum_c L[i, j0 + c] L[j, j0 + c], i >= j >= j0 + nb
+// (split into the first MW_PB columns -- all the next diagonal block and panel need -- and a rest that rides on the next diagonal block's launch: measured,
+// no gain: the launch of the first columns takes what the whole update takes, a 32-term dot product over four lanes per entry, whatever the entry count)
 template <int K>
 __global__ __launch_bounds__(MW_NT) void k_mw_bp_syrk(const MwDev q, const MwBp *__restrict__ ms, int j0) {
     using namespace mwk;
@@ -1236,15 +1238,14 @@ __global__ __launch_bounds__(MW_NT) void k_mw_bp_syrk(const MwDev q, const MwBp 
 // blocks (j, i) of L^-1 with j - i = d: T = sum_{i <= k < j} L_jk (L^-1)_ki (the block columns between are contiguous: one
 // sum over the rows i MW_PB .. j MW_PB - 1), then (L^-1)_ji = -(L^-1)_jj T
 template <int K>
-__global__ __launch_bounds__(MW_PT) void k_mw_bp_inv(const MwDev q, const MwBp *__restrict__ ms, int d) {
+__device__ __forceinline__ void mw_bp_inv_block(const MwDev &q, const MwBp &m, int bi, int bj, int cblk) {
     using namespace mwk;
     constexpr int MW_PB = MW_PB_OF(K);
-    const MwBp m = ms[blockIdx.z];
     if (q.info[m.which] != MW_INFO_NONE) return;
-    const int bi = blockIdx.x, bj = bi + d, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     if (bj * MW_PB >= m.n) return;                          // (a matrix with fewer block columns than the largest of the launch)
     const int ci0 = bi * MW_PB, ni = min(MW_PB, m.n - ci0), rj0 = bj * MW_PB, nj = min(MW_PB, m.n - rj0);
-    const int c0 = blockIdx.y * MW_BP_IC;
+    const int c0 = cblk * MW_BP_IC;
     if (c0 >= ni) return;
     const int pc = min(MW_BP_IC, ni - c0);
     lds_d *T = MW_LDS;
@@ -1270,6 +1271,12 @@ __global__ __launch_bounds__(MW_PT) void k_mw_bp_inv(const MwDev q, const MwBp *
         if (live && sub == 0) stx<K>(m.Mi, m.plane, (rj0 + r) + (long)col * m.ld, v);
     }
 }
+template <int K>
+__global__ __launch_bounds__(MW_PT) void k_mw_bp_inv(const MwDev q, const MwBp *__restrict__ ms, int d) { mw_bp_inv_block<K>(q, ms[blockIdx.z], blockIdx.x, blockIdx.x + d, blockIdx.y); }
+// the same by block ROWS: the blocks (row, i), i < row, need the rows above (and the inverse of the row's diagonal block): row j can be formed as soon as the
+// diagonal block j is, beside the rest of the factorisation -- k_mw_bp_diag_pipe carries row j on the launch of diagonal block j + 1, this kernel takes the last row
+template <int K>
+__global__ __launch_bounds__(MW_PT) void k_mw_bp_inv_row(const MwDev q, const MwBp *__restrict__ ms, int row) { mw_bp_inv_block<K>(q, ms[blockIdx.z], blockIdx.x, row, blockIdx.y); }
 // zero strict upper triangle of L (the blocks above the diagonal still hold the symmetric input)
 template <int K>
 __global__ __launch_bounds__(MW_NT) void k_mw_bp_finish(const MwDev q, const MwBp *__restrict__ ms) {

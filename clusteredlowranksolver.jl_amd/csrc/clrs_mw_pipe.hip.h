@@ -40,10 +40,12 @@
 
 struct MwPipeMat {           // one matrix of a pipelined factorisation
     double *keep;            // null, or where a copy of the input goes (same layout as `in`)
-    const double *in;        // input: planar n x n (leading dimension n), lower triangle read; in_slots > 1: the sum of that many arrays, in order
+    const double *in;        // input: planar n x n (leading dimension in_ld), lower triangle read; in_slots > 1: the sum of that many arrays, in order
     long inplane, in_stride;
     int in_slots, n;
-    double *L, *rd, *Inv;    // outputs: factor (strict upper triangle zeroed), reciprocal diagonal, inverse factor (upper triangle zeroed)
+    int in_ld, l_ld, inv_ld, pad;      // leading dimensions of in (and keep), L, Inv: n for a matrix of its own, more for a diagonal block of a larger one (k_mw_bp_diag_pipe)
+    double *L, *rd, *Inv;    // outputs: factor (strict upper triangle zeroed), reciprocal diagonal, inverse factor (upper triangle zeroed); L may be `in` (every entry
+                             // is read by the one thread that owns it, before anything is written)
     long lplane, rdplane, invplane;
     unsigned long long *pc;  // MWP_PC_WORDS granules: the published pivot columns
     int fail_code;           // atomicMin'ed into info[0] at a non-positive pivot
@@ -209,12 +211,12 @@ __device__ __forceinline__ bool mwp_run(const MwPipeMat &m, int role, unsigned e
         if (m.in_slots > 1) {
             acc<K> s;
             acc_zero<K>(s);
-            for (int r = 0; r < m.in_slots; r++) acc_add<K, K>(s, ldx<K>(m.in + (long)r * m.in_stride, m.inplane, i + (long)c * n));
+            for (int r = 0; r < m.in_slots; r++) acc_add<K, K>(s, ldx<K>(m.in + (long)r * m.in_stride, m.inplane, i + (long)c * m.in_ld));
             v = acc_result<K>(s);
-        } else v = ldx<K>(m.in, m.inplane, i + (long)c * n);
+        } else v = ldx<K>(m.in, m.inplane, i + (long)c * m.in_ld);
         if (m.keep) {                                                        // the matrix as it came in (both triangles), for the residuals of the refined solve
-            stx<K>(m.keep, m.inplane, i + (long)c * n, v);
-            stx<K>(m.keep, m.inplane, c + (long)i * n, v);
+            stx<K>(m.keep, m.inplane, i + (long)c * m.in_ld, v);
+            stx<K>(m.keep, m.inplane, c + (long)i * m.in_ld, v);
         }
     }
     if (tid == MWP_ET) { stx<K>(S.us, MWP_N + 1, 0, from_double<K>(1.0)); *S.flag = 1; }
@@ -287,7 +289,7 @@ __device__ __forceinline__ bool mwp_run(const MwPipeMat &m, int role, unsigned e
             stx<K>(m.rd, m.rdplane, c, r);
         }
         __syncthreads();
-        if (!loader && c < c1 && i < n) stx<K>(m.L, m.lplane, i + (long)c * n, i >= c ? mul<K>(v, ldx<K>(S.fs, MWP_N, cc)) : zero<K>());
+        if (!loader && c < c1 && i < n) stx<K>(m.L, m.lplane, i + (long)c * m.l_ld, i >= c ? mul<K>(v, ldx<K>(S.fs, MWP_N, cc)) : zero<K>());
     } else {
         if (tid < n) {                                                       // (every W workgroup needs every f_i: n reciprocal square roots side by side)
             const mw<K> sk = ldx<K>(S.us, MWP_N + 1, tid), dt = ldx<K>(S.dd, MWP_N, tid), f = rsqrt<K>(mul<K>(sk, dt));
@@ -295,7 +297,7 @@ __device__ __forceinline__ bool mwp_run(const MwPipeMat &m, int role, unsigned e
             stx<K>(S.rs, MWP_N, tid, mul<K>(f, sk));
         }
         __syncthreads();
-        if (!loader && c < n && i < n) stx<K>(m.Inv, m.invplane, i + (long)c * n, i > c ? mul<K>(v, ldx<K>(S.fs, MWP_N, i)) : i == c ? ldx<K>(S.rs, MWP_N, i) : zero<K>());
+        if (!loader && c < n && i < n) stx<K>(m.Inv, m.invplane, i + (long)c * m.inv_ld, i > c ? mul<K>(v, ldx<K>(S.fs, MWP_N, i)) : i == c ? ldx<K>(S.rs, MWP_N, i) : zero<K>());
     }
 #ifdef CLRS_MW_STAMPS
     if (stamps && tid == 0) stamps[38] = wall_clock64();
@@ -313,7 +315,7 @@ __device__ __forceinline__ void mwp_block_map(int b, int &matrix, int &role) {
     matrix = (b & 7) + 8 * (b >> 6);
     role = (b >> 3) & 7;
 }
-static inline int mwp_blocks(int matrices) { return 64 * ((matrices + 7) / 8); }
+__host__ __device__ static inline int mwp_blocks(int matrices) { return 64 * ((matrices + 7) / 8); }
 
 // L_j = chol(S_j) and L_j^-1 of every cluster with P <= MWP_N: mwp_blocks(J) workgroups
 template <int K>
@@ -328,6 +330,7 @@ __global__ __launch_bounds__(MWP_NT) void k_mw_factor_pipe(const MwDev q, unsign
     if (role >= stages + MWP_WW) return;
     MwPipeMat m;
     m.in = q.S + c.Soff; m.inplane = q.Slen; m.in_stride = 0; m.in_slots = 1; m.n = P; m.keep = q.S0 + c.Soff;
+    m.in_ld = m.l_ld = m.inv_ld = P;
     m.L = q.S + c.Soff; m.lplane = q.Slen; m.rd = q.srd + c.coff; m.rdplane = q.xlen; m.Inv = q.Si + c.Soff; m.invplane = q.Slen;
     m.pc = q.pipe_pc + (long)j * MWP_PC_WORDS(K);
     m.fail_code = j + 1;
@@ -352,11 +355,54 @@ __global__ __launch_bounds__(MWP_NT) void k_mw_potrf_q_pipe(const MwDev q, unsig
     if (q.info[0] != MW_INFO_NONE) return;                          // a cluster failed: the reference throws before reaching Q
     MwPipeMat m;
     m.in = q.Qg; m.inplane = (long)N * N; m.in_stride = (long)K * N * N; m.in_slots = q.world; m.n = N; m.keep = nullptr;
+    m.in_ld = m.l_ld = m.inv_ld = N;
     m.L = q.Q; m.lplane = (long)N * N; m.rd = q.qrd; m.rdplane = N; m.Inv = q.Qi; m.invplane = (long)N * N;
     m.pc = q.pipe_pc + (long)q.pipe_q * MWP_PC_WORDS(K);
     m.fail_code = q.J + 1;
     m.stamps = q.pipe_stamps ? q.pipe_stamps + 8 * 40 : nullptr;
     mwp_run<K>(m, role, epoch, &q.info[0], threadIdx.x);
+}
+
+// The diagonal block of one block column of the blocked factorisation (k_mw_bp_diag's work: Cholesky of the MW_PB x MW_PB block at (j0, j0) of every matrix
+// of the list and the inverse of its factor, both in place in the matrices' M / Mi) as the same pipeline: a 32-column block is four stages of eight columns
+// plus four workgroups for the inverse instead of four workgroups that each repeat the whole elimination -- the diagonal blocks are the serial part of the
+// blocked path (13 of them per iteration on Nsphere_packing(8,15,[1/2,1/2,1/2]): 40 % of its time).  Bit for bit the results of k_mw_bp_diag.
+// A matrix whose earlier block column failed is eliminated all the same (its workgroups cannot agree on a status word that changes while they run): it fails
+// again, with the same code.  Blocks beyond mwp_blocks(nm): first the clusters that fit in LDS (k_mw_bp_diag's ride; `ride` of them, MW_INV_WG workgroups
+// each), then block row `inv_row` of the inverse factors (>= 1, or 0 for none: the blocks (inv_row, i), i < inv_row, of L^-1 -- k_mw_bp_inv_row's work; the row's
+// own diagonal block was finished by an earlier launch), inv_row x MW_PB / MW_BP_IC workgroups per matrix: what was a chain of launches behind the last block
+// column (one per block distance: 11 launches, 200 us per iteration on Nsphere_packing(8,15,[1/2,1/2,1/2])) runs beside the diagonal blocks, on other compute units.
+template <int K>
+__global__ __launch_bounds__(MWP_NT) void k_mw_bp_diag_pipe(const MwDev q, const MwBp *__restrict__ ms, int nm, int j0, unsigned epoch, int ride, int inv_row) {
+    using namespace mwk;
+    static_assert(MWP_NT == MW_PT && MWP_N == MW_PB_OF(K), "the ride of the LDS clusters and the panel width assume the blocked path's shapes");
+    mw_mark(q);
+    const int nbp = mwp_blocks(nm);
+    if ((int)blockIdx.x >= nbp) {
+        int r = (int)blockIdx.x - nbp;
+        if (r < ride * MW_INV_WG) { mw_factor_cluster<K>(q, r / MW_INV_WG, r % MW_INV_WG, MW_INV_WG); return; }
+        r -= ride * MW_INV_WG;
+        constexpr int CB = MW_PB_OF(K) / MW_BP_IC;                   // column workgroups per block
+        const int per = inv_row * CB;
+        mw_bp_inv_block<K>(q, ms[r / per], (r % per) / CB, inv_row, r % CB);
+        return;
+    }
+    int mtx, role;
+    mwp_block_map(blockIdx.x, mtx, role);
+    if (mtx >= nm) return;
+    const MwBp b = ms[mtx];
+    if (j0 >= b.n) return;
+    const int nb = min(MWP_N, b.n - j0);
+    if (role >= (nb + MWP_W - 1) / MWP_W + MWP_WW) return;
+    const long at = j0 + (long)j0 * b.ld;
+    MwPipeMat m;
+    m.in = b.M + at; m.inplane = b.plane; m.in_stride = 0; m.in_slots = 1; m.n = nb; m.keep = nullptr;
+    m.in_ld = m.l_ld = m.inv_ld = b.ld;
+    m.L = b.M + at; m.lplane = b.plane; m.rd = b.rd + j0; m.rdplane = b.rdplane; m.Inv = b.Mi + at; m.invplane = b.plane;
+    m.pc = q.pipe_pc + (long)(q.pipe_bp + b.slot) * MWP_PC_WORDS(K);
+    m.fail_code = b.code;
+    m.stamps = nullptr;
+    mwp_run<K>(m, role, epoch, &q.info[b.which], threadIdx.x);
 }
 
 #endif

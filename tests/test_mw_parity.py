@@ -226,12 +226,14 @@ def test_stream_words_make_progress_when_streams_share_hardware_queues(oracle_bu
 
 
 @pytest.mark.parametrize("K", [3, 5, 6, 10])
-@pytest.mark.parametrize("name", ["ce_8_15", "ce_8_3", "polyopt8", "delsarte_3_10", "polyopt40", "sdpa_small"])
+@pytest.mark.parametrize("name", ["ce_8_15", "ce_8_3", "polyopt8", "delsarte_3_10", "polyopt40", "sdpa_small", "ns_8_15_2", "polyopt_scaled_100"])
 def test_pipelined_factorisation_is_bit_identical(name, K, oracle_built):
     """csrc/clrs_mw_pipe.hip.h: chol(S_j), chol(Q) and their inverse factors as pipelines of workgroups (column blocks of eight as stages, four more
     workgroups for the inverse, pivot columns handed on as tagged granules) do the arithmetic of the one-workgroup elimination entry by entry and
     pivot by pivot: factors, reciprocal diagonals (through LinvB and the solves) and solutions agree BIT FOR BIT with `pipeline=False`, on matrix sides
-    1 ... 32 including sides that are no multiple of the stage width (31, 22, 9), with and without free variables."""
+    1 ... 32 including sides that are no multiple of the stage width (31, 22, 9), with and without free variables.  Matrices beyond LDS (the last two
+    instances: P = 96 with N = 97 free variables beside clusters that ride on the first launch; P = 201): the diagonal blocks of the blocked factorisation
+    go through the same pipeline (k_mw_bp_diag_pipe), last blocks of 1 and 9 columns included."""
     from clrs_amd.mw import MwSchurContext
     f = flat(name)
     if K == 3 and name == "ce_8_15":
