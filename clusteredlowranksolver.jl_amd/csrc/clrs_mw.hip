@@ -877,8 +877,8 @@ static int mw_cholesky_blocks_dev2(clrs_mw_ctx *c, const double *d_X, double *d_
     if ((rc = mw_reset_info(c, 1))) return rc;
     if (c->d.NB == 0) return 0;
     const int grid = d_Y2 ? 2 * c->d.NB : c->d.NB;
-    bool in_mem = false;                                  // some block forms its inverse factor in memory: four workgroups share its columns
-    for (auto &k : c->blk) in_mem = in_mem || k.inv == 2;
+    bool in_mem = false;                                  // some block forms its inverse factor in memory, or in LDS beside a large block: four workgroups share its columns
+    for (auto &k : c->blk) in_mem = in_mem || k.inv == 2 || mw_x_shares(k);
     MW_DISPATCH(c, hipLaunchKernelGGL(k_mw_potrf_x<KK>, dim3(grid, in_mem && c->lds_x ? MW_INV_WG : 1), dim3(MW_PT), c->sm_x, c->stream, c->d, d_X, d_Xchol, c->lds_x ? 1 : 0, d_Y2, d_Yi, d_yfail));
     MWCHECK(hipGetLastError());
     c->xinv_valid = true;

@@ -431,17 +431,30 @@ extern __shared__ double mw_lds[];
 // Cholesky of every X block: Xchol_b = chol(X_b), strict upper zero; reciprocal diagonal and the two scaled triangles kept
 // for the substitutions that follow.  One workgroup per block; `lds` = 1: the block is factored in LDS.
 // ---------------------------------------------------------------------------------------------------------------------
+#define MW_X_SHARE 32        // PSD blocks of more rows whose inverse factor is formed in LDS: MW_INV_WG workgroups share its columns (k_mw_potrf_x)
+__host__ __device__ __forceinline__ bool mw_x_shares(const MwBlk &k) { return k.inv == 1 && k.n > MW_X_SHARE; }
 template <int K, bool INV, class PM, class PW>
 __device__ __forceinline__ void mw_potrf_x_body(const MwDev &q, const MwBlk &k, PM M, long plane, PW W, long wplane, bool w_in_place, double *__restrict__ Xc, mwk::lds_d *bc,
                                                 int tid, int bid) {
     using namespace mwk;
     const int n = k.n;
-    // W in memory (blocks whose factor and inverse do not fit in LDS side by side): gridDim.y workgroups repeat the elimination of M in their own
-    // LDS and share out the columns of W, like the factorisations of S_j and Q; the first one writes the factor
-    const int cw = w_in_place ? blockIdx.y : 0, cnw = w_in_place ? gridDim.y : 1;
+    // W in memory (blocks whose factor and inverse do not fit in LDS side by side), or W in LDS beside a block of more than MW_X_SHARE rows (the
+    // elimination of [M | I] is then bound by the instruction rate of one compute unit: 244 us for the 48 x 48 blocks of Nsphere_packing N = 3):
+    // gridDim.y workgroups repeat the elimination of M in their own LDS and share out the columns of W, like the factorisations of S_j and Q; the
+    // first one writes the factor, each its columns of the inverse
+    const bool share = w_in_place || (INV && mw_x_shares(k));
+    const int cw = share ? blockIdx.y : 0, cnw = share ? gridDim.y : 1;
     const bool ok = wg_potrf<K, INV, MW_PT, true>(M, plane, n, n, q.xrd + k.rd_off, q.xrdlen, W, wplane, w_in_place ? n : 0, bc, tid, cw, cnw);   // the LDS copy of W is packed
     if (!ok && tid == 0) atomicMin(&q.info[1], bid + 1);
     __syncthreads();
+    if (INV && !w_in_place && cnw > 1) {                  // this workgroup's columns of the inverse, out of its LDS
+        for (int e = tid; e < n * n; e += MW_PT) {
+            const int i = e % n, c = e / n;
+            if (c % cnw != cw) continue;
+#pragma unroll
+            for (int l = 0; l < K; l++) q.Xi[(long)l * q.xylen + k.xyoff + e] = (ok && i >= c) ? (double)W[(long)l * wplane + w_index(i, c, n, 0)] : 0.0;
+        }
+    }
     if (cw != 0) return;
     if (ok) wg_scaled_factors_u<K, MW_PT>(M, plane, n, q.xrd + k.rd_off, q.xrdlen, n, q.Xf + k.xyoff, q.xylen, n, q.Xb + k.xyoff, q.xylen, n, tid);
     for (int e = tid; e < n * n; e += MW_PT) {
@@ -449,7 +462,7 @@ __device__ __forceinline__ void mw_potrf_x_body(const MwDev &q, const MwBlk &k, 
 #pragma unroll
         for (int l = 0; l < K; l++) {
             Xc[(long)l * q.xylen + k.xyoff + e] = (i >= c) ? (double)M[(long)l * plane + e] : 0.0;
-            if (INV && !w_in_place) q.Xi[(long)l * q.xylen + k.xyoff + e] = (ok && i >= c) ? (double)W[(long)l * wplane + w_index(i, c, n, 0)] : 0.0;
+            if (INV && !w_in_place && cnw == 1) q.Xi[(long)l * q.xylen + k.xyoff + e] = (ok && i >= c) ? (double)W[(long)l * wplane + w_index(i, c, n, 0)] : 0.0;
         }
     }
 }
@@ -465,7 +478,7 @@ __global__ __launch_bounds__(MW_PT) void k_mw_potrf_x(const MwDev q, const doubl
     const bool second = (int)blockIdx.x >= q.NB;
     const MwBlk &k = q.blk[second ? blockIdx.x - q.NB : blockIdx.x];
     const int n = k.n, tid = threadIdx.x;
-    if (blockIdx.y != 0 && !(lds && k.inv == 2)) return;   // more than one workgroup per matrix only where the inverse is formed in memory
+    if (blockIdx.y != 0 && !(lds && (k.inv == 2 || mw_x_shares(k)))) return;   // more than one workgroup per matrix only where the inverse is formed in memory, or beside a large block
     lds_d *bc = MW_LDS;                                   // scratch of wg_potrf, in front of the matrix
     if (second) {
         lds_d *M = MW_LDS + MW_POTRF_SCR(K, n);
@@ -474,10 +487,12 @@ __global__ __launch_bounds__(MW_PT) void k_mw_potrf_x(const MwDev q, const doubl
         bool ok;
         if (k.inv == 1) {
             lds_d *W = M + (long)K * n * n, *rdl = W + (long)K * MW_TRI(n);
-            ok = wg_potrf<K, true, MW_PT, false>(M, (long)n * n, n, n, rdl, n, W, MW_TRI(n), 0, bc, tid);
+            const int cw = mw_x_shares(k) ? blockIdx.y : 0, cnw = mw_x_shares(k) ? gridDim.y : 1;
+            ok = wg_potrf<K, true, MW_PT, false>(M, (long)n * n, n, n, rdl, n, W, MW_TRI(n), 0, bc, tid, cw, cnw);
             if (ok) {
                 for (int e = tid; e < n * n; e += MW_PT) {
                     const int i = e % n, c = e / n;
+                    if (c % cnw != cw) continue;
 #pragma unroll
                     for (int l = 0; l < K; l++) Yi[(long)l * q.xylen + k.xyoff + e] = (i >= c) ? (double)W[(long)l * MW_TRI(n) + w_index(i, c, n, 0)] : 0.0;
                 }
