@@ -772,7 +772,8 @@ extern "C" int clrs_mw_create_opts(const clrs_sdp_desc *d, int data_limbs, int d
         // the diagonal blocks of the blocked factorisation (k_mw_bp_diag_pipe): the same pipeline per 32-column block of every matrix beyond LDS
         const size_t nbp = c->bp_S.size() + c->bp_Q.size();
         const bool any_bp = !c->bp_S.empty() || (N > 0 && !c->lds_q);
-        c->pipe_bp = cfg_pipe != 0 && (K <= 6 || cfg_pipe >= 2) && any_bp && (i64)std::max<size_t>(c->bp_S.size(), 1) * ((MWP_N / MWP_W) + MWP_WW) <= 256;
+        // (at every limb count: 8 and 10 limbs gain 2-4 % per iteration as well -- scripts/blocked_pipe_limbs.py -- unlike the clusters that fit in LDS)
+        c->pipe_bp = cfg_pipe != 0 && any_bp && (i64)std::max<size_t>(c->bp_S.size(), 1) * ((MWP_N / MWP_W) + MWP_WW) <= 256;
         q.pipe_pc = nullptr;
         q.pipe_stamps = nullptr;
         q.pipe_bp = 0;
