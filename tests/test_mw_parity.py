@@ -225,6 +225,29 @@ def test_stream_words_make_progress_when_streams_share_hardware_queues(oracle_bu
             c.close()
 
 
+@pytest.mark.parametrize("K", [4, 5, 6])
+def test_inverse_factor_columns_of_a_large_block_are_shared(K, oracle_built):
+    """k_mw_potrf_x: a PSD block of more than 32 rows whose inverse factor still fits in LDS beside it (48 x 48 in Nsphere_packing(8,15,[1/2,1/2,1/2]) at
+    4-6 limbs) is eliminated by four workgroups that share out the columns of the inverse: factor against the oracle's, and the assembly that reads the
+    inverse factors (Z = Xi V) against the oracle's from the same factors -- every column of every inverse must have been written, by its own workgroup."""
+    from clrs_amd.mw import MwSchurContext
+    from oracle.oracle import Oracle
+    f = flat("ns_8_15_3")
+    assert int(max(f.block_n)) == 48
+    X, Y = _iterates(f, K)
+    X, Y = _sym_limbs(f, X), _sym_limbs(f, Y)
+    o = Oracle(f, mp_bits=320 if K <= 5 else 640)
+    ctx = MwSchurContext(f, limbs=K)
+    Xc = ctx.cholesky_blocks(X)
+    st, Xc_ref = o.cholesky_blocks_mw(np.vstack([X, np.zeros((1, f.xy_len))]))
+    assert st == 0
+    assert mw_relerr(Xc, Xc_ref) <= tol(K, 14), ("chol X", mw_relerr(Xc, Xc_ref))
+    S, AY = ctx.compute_S_integrated(Xc, Y)
+    S_ref, AY_ref = o.schur_assemble_mw(np.vstack([Xc, np.zeros((1, f.xy_len))]), np.vstack([Y, np.zeros((1, f.xy_len))]))
+    assert mw_relerr(S, S_ref) <= tol(K, 22), ("S", mw_relerr(S, S_ref))
+    ctx.close()
+
+
 @pytest.mark.parametrize("K", [3, 5, 6, 10])
 @pytest.mark.parametrize("name", ["ce_8_15", "ce_8_3", "polyopt8", "delsarte_3_10", "polyopt40", "sdpa_small", "ns_8_15_2", "polyopt_scaled_100"])
 def test_pipelined_factorisation_is_bit_identical(name, K, oracle_built):
