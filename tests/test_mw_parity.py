@@ -894,6 +894,11 @@ def test_sharded_interior_point_solve_on_one_gpu(which, world, oracle_built):
     assert r0.iterations == ref.iterations
     assert abs(r0.primal_objective - ref.primal_objective) <= 1e-12 * max(1.0, abs(ref.primal_objective))
     assert np.allclose(r0.history[:, [1, 8, 9]], ref.history[:, [1, 8, 9]], rtol=1e-9, atol=0)
+    # max|P|, max|p|, max|d| of every iteration: maxima over the ranks' records (stage 15: -B^T x and max|P| with the objectives; stage 2: max|d|)
+    # (above the rounding floor of the residuals, where sums in rank order and sums in block order differ by factors)
+    he, hr = r0.history[:, [5, 6, 7]], ref.history[:, [5, 6, 7]]
+    big = hr > 1e-30 * np.max(hr, axis=0)
+    assert big.sum() > 3 * 10 and np.allclose(he[big], hr[big], rtol=1e-6, atol=0)
     # the shards' x, X, Y are the unsharded solution's rows / blocks
     for r, info in res:
         cols = np.concatenate([np.arange(int(full.block_off[b]), int(full.block_off[b + 1])) for b in info["block_ids"]])
