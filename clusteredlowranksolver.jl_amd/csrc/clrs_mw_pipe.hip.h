@@ -247,6 +247,10 @@ __device__ __forceinline__ bool mwp_run(const MwPipeMat &m, int role, unsigned e
         lds_d *cur = S.col(k), *nxt = S.col(k + 1);
         const mw<K> d = ldx<K>(cur, MWP_N, k);
         if (!(*S.flag) || !(d.l[0] > 0.0)) {                                 // uniform: every thread reads the same words
+            // the owner of a column with a non-positive pivot publishes it all the same: the workgroups behind it read the pivot there and stop at the same
+            // step -- without it they would poll for the column until their bound (1.3 s: found on the 16-cluster weak-scaling instance, whose solve ends
+            // with a failed factorisation)
+            if (loader && lw == 0 && !is_w && k >= c0) mwp_publish_column<K>(m.pc + (long)k * MWP_GRANULES(K), tag0 | (unsigned)k, k, n, cur, lane);
             if (tid == 0) atomicMin(info, m.fail_code);
             return false;
         }
