@@ -10,7 +10,7 @@ from clrs_amd.sharded import partition_clusters
 thr = dict(dual_error_threshold=1e-30, primal_error_threshold=1e-30, duality_gap_threshold=1e-15)
 for world in (1, 2, 4, 8):
     t0 = time.time()
-    full = clrs_amd.flatten(cohnelkies_multi(8, 15, [1.0 + 0.125 * k for k in range(2 * world - 1)]))
+    full = clrs_amd.flatten(cohnelkies_multi(8, 15, [1.0 + 0.0625 * k for k in range(2 * world - 1)]))
     tg = time.time() - t0
     parts = partition_clusters(full, world)
     r = solvesdp_mw(full, limbs=5, **thr)
