@@ -284,9 +284,12 @@ def test_pipelined_factorisation_reports_a_nonpositive_pivot_and_does_not_hang(o
     """every workgroup of a matrix stops at the pivot its producer found non-positive (approx_cholesky!'s test, src/tools.jl:92-95): the status is the
     one-workgroup kernel's, and it comes at once: the stage that owns the failing column publishes it before it stops (without that its consumers polled
     for the column until their bound, 1.3 s -- found on the 16-cluster weak-scaling instance of bench.py, whose solve ends with a failed factorisation)."""
-    f = flat("ce_8_15")
     import time
-    for K, flip in ((2, False), (5, True)):                   # S_j not positive definite: at 2 limbs by rounding (a pivot in the middle); Y negated (the first pivot)
+    # S_j not positive definite: at 2 limbs by rounding (a pivot in the middle of a cluster); Y negated (the first pivot of every cluster); the same on the
+    # instance whose large cluster and Q go through the blocked path (k_mw_bp_diag_pipe: a matrix that failed is eliminated again in every later block
+    # column, and fails again with the same code)
+    for name, K, flip in (("ce_8_15", 2, False), ("ce_8_15", 5, True), ("ns_8_15_2", 2, False), ("ns_8_15_2", 5, True)):
+        f = flat(name)
         X, Y = _iterates(f, K)
         X, Y = _sym_limbs(f, X), _sym_limbs(f, Y)
         if flip:
