@@ -297,6 +297,19 @@ def test_pipelined_factorisation_reports_a_nonpositive_pivot_and_does_not_hang(o
         _pivot_failure_case(f, K, X, Y, time)
 
 
+def test_a_solve_that_ends_with_a_failed_factorisation_does_not_stall():
+    """cohnelkies_multi(8, 15) with 15 radius scalings in steps of 1/8 (16 clusters: the first form of bench.py's eight-rank instance) ends at 5 limbs with a
+    factorisation that fails at mu = 6e-15 (the reference's SolverFailure inside the loop, src/solver.jl:1249: status by the gap reached, code 1).  Through
+    the pipelined factorisation that last iteration took 1.3 s -- 18.7 ms per iteration over the solve -- before the owner of a failing column published it."""
+    import clrs_amd
+    from clrs_amd.mw import solvesdp_mw
+    from clrs_amd.problems import cohnelkies_multi
+    full = clrs_amd.flatten(cohnelkies_multi(8, 15, [1.0 + 0.125 * k for k in range(15)]))
+    r = solvesdp_mw(full, limbs=5, dual_error_threshold=1e-30, primal_error_threshold=1e-30, duality_gap_threshold=1e-15)
+    assert r.error_code == 1 and r.status == "NearOptimal" and 70 <= r.iterations <= 80, (r.status, r.error_code, r.iterations)
+    assert r.time_total / r.iterations < 3e-3, r.time_total / r.iterations
+
+
 def _pivot_failure_case(f, K, X, Y, time):
     from clrs_amd.mw import MwSchurContext
     st = []
