@@ -426,6 +426,12 @@ __device__ __forceinline__ void wg_copy(PD dst, long dplane, int ldd, PS src, lo
 
 extern __shared__ double mw_lds[];
 #define MW_LDS ((mwk::lds_d *)mw_lds)
+// diagnostic builds (-DCLRS_MW_STAMPS): launch-boundary stamps of the factorisation's chain into rows 8.. of the pipeline's stamp buffer (scripts/chain_stamps.py)
+#ifdef CLRS_MW_STAMPS
+#define MW_CHAIN_STAMP(q, idx, cond) do { if ((q).pipe_stamps && (cond)) (q).pipe_stamps[8 * 40 + (idx)] = wall_clock64(); } while (0)
+#else
+#define MW_CHAIN_STAMP(q, idx, cond) do { } while (0)
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Cholesky of every X block: Xchol_b = chol(X_b), strict upper zero; reciprocal diagonal and the two scaled triangles kept
@@ -1007,6 +1013,7 @@ __global__ __launch_bounds__(MW_NT) void k_mw_keep_S(const MwDev q) {
 #define MW_LBI_W 4
 template <int K, int DK>
 __global__ __launch_bounds__(MW_NT) void k_mw_linvb(const MwDev q) {
+    MW_CHAIN_STAMP(q, 0, blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0);
     using namespace mwk;
     const int j = blockIdx.y;
     const MwClu &c = q.clu[j];
@@ -1050,8 +1057,11 @@ __device__ __forceinline__ void mw_qgram_body(const MwDev &q) {
 // lanes: 8, or 32 while the launch stays small (a few hundred entries: more workgroups with a quarter of the multiply-adds per lane)
 template <int K>
 __global__ __launch_bounds__(MW_NT) void k_mw_qgram(const MwDev q, int lanes) {
+    MW_CHAIN_STAMP(q, 1, blockIdx.x == 0 && threadIdx.x == 0);
+    MW_CHAIN_STAMP(q, 2, blockIdx.x == gridDim.x - 1 && threadIdx.x == 0);
     if (lanes == 32) mw_qgram_body<K, 32>(q);
     else mw_qgram_body<K, MW_Q_W>(q);
+    MW_CHAIN_STAMP(q, 5, blockIdx.x == gridDim.x - 1 && threadIdx.x == 0);       // (end of the last workgroup)
 }
 
 template <int K>
@@ -1098,6 +1108,8 @@ template <int K>
 __global__ __launch_bounds__(MW_PT) void k_mw_potrf_q(const MwDev q, int nq, const double *__restrict__ fwd_rhs, const int *__restrict__ wait_word, int wait_value) {
     using namespace mwk;
     const int N = q.N, tid = threadIdx.x;
+    MW_CHAIN_STAMP(q, 3, blockIdx.x == 0 && threadIdx.x == 0);
+    MW_CHAIN_STAMP(q, 4, (int)blockIdx.x == nq && threadIdx.x == 0);
     // workgroups behind the nq of Q (the interior-point iteration adds them): the first product pair of the next solve, t_j = L_j^-1 rhs_x[j] and
     // u_j = LinvB_j^T t_j per cluster, which needs the clusters' factors only -- beside the 31 pivots of Q instead of behind them.  Their right-hand
     // side comes from another stream: they wait for its mark here (wait_word), not the whole launch in front of an event
