@@ -23,6 +23,14 @@
 // hop 4 us (not the 1 us of an idle hand-off: the column is asked for before it exists and found by polling); k_mw_factor 93 -> 85 us, k_mw_potrf_q
 // 80 -> 83 us (its launch also carries the first products of the next solve): the default (clrs_mw_options.pipeline = 1) pipelines the clusters only.
 //
+// The tail (scripts/pipe_stamps.py at the end of round 4): a consumer that runs less than MWP_NL steps behind its producer sends for every column before it
+// exists and finds it at its turn only -- one sc1 round trip (2-3.5 us) on its step instead of the step's arithmetic.  The workgroups of W catch up with the
+// last stage, and two of the four take 3-3.5 us for each of the last four columns: the kernel ends at 84-86 us where the other two are done at 78.  Tried
+// against it, none kept: one workgroup per compute unit (86 KB of LDS asked for: no change -- it is not sharing); at a miss the rows at once before the
+// sentinel (no change); every lane polling its own granules for the last four columns (no change: the loads themselves take that long); every loader asking
+// again once per step for what came back stale (cures the tail of the workgroups it hits, but all cadences go from 1.9 to 2.0 us: 0.526 against 0.522 ms
+// per iteration, Nsphere_packing N = 3 2.54 against 2.51).
+//
 // The arithmetic per entry and pivot is wg_potrf's, in the same order: the factor, its reciprocal diagonal and the inverse are bit for bit those of
 // the one-workgroup kernels (tests/test_mw_parity.py::test_pipelined_factorisation_is_bit_identical).
 #ifndef CLRS_MW_PIPE_HIP_H
