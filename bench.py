@@ -379,7 +379,10 @@ def main():
         if not args.skip_cpu and world == 1:
             from oracle.oracle import Oracle
             oc = Oracle(flat, mp_bits=256)
-            ncpu = os.cpu_count() or 1
+            # (threads: 1, 8, and the host's count capped at 32 -- a box gives one GPU's job 16 cores; a team of os.cpu_count() = 256 OpenMP threads never won
+            # and left a pool of idle threads behind that slowed every host-driven GPU loop measured after it in this process: the fp64 device loop on
+            # PolyOpt 2d = 40 showed 3.2k iterations/s behind it and 5.2k without)
+            ncpu = min(os.cpu_count() or 1, 32)
             best = None
             for th in sorted({1, min(8, ncpu), ncpu}):      # these matrices are tiny: more threads is usually slower
                 oc.set_num_threads(th)
@@ -423,6 +426,11 @@ def main():
                 n_p += 1
             out["hot_path"]["cpu_oracle_256bit_passes_per_s"] = n_p / t_p
             out["hot_path"]["speedup_vs_cpu_oracle"] = out["hot_path"]["passes_per_s"] / (n_p / t_p)
+            # the OpenMP pool goes back to two threads (a team of two makes libgomp release the others): idle pool threads take cores from the host
+            # thread of the host-driven GPU loops measured below (fp64 device loop on PolyOpt 2d = 40: 4.5k iterations/s behind a pool of 32, 5.2k without)
+            oc.set_num_threads(2)
+            oc.solvesdp(maxiterations=1)
+            oc.set_num_threads(1)
 
         # ---- the one rate the reference documents: the solver log of min_f(2) (docs/src/solving.md:38-46) ----
         # iterations 3 -> 56 between log times 13.4 s and 13.9 s at 0.1 s resolution: ~100 iterations/s (+-20 %), hardware and thread count not stated.

@@ -424,14 +424,19 @@ def main(argv=None, emit=True):
                 ff = sdp_f()
                 cx = SchurContext(ff, device=local_rank)
                 solvesdp_device(ff, ctx=cx)                                   # warm up
-                t1 = time.perf_counter()
-                reps, its = 5, 0
-                for _ in range(reps):
-                    rr = solvesdp_device(ff, ctx=cx)
-                    its += rr.iterations
-                dt = time.perf_counter() - t1
+                # the loop synchronises with the host once per iteration: its rate follows whatever else runs on the host's cores (boxes share a host;
+                # 2.4k-5.3k iterations/s were seen for the same build on PolyOpt 2d = 40) -- the best of three rounds of five solves is reported, all three kept
+                rounds = []
+                for _round in range(3):
+                    t1 = time.perf_counter()
+                    reps, its = 5, 0
+                    for _ in range(reps):
+                        rr = solvesdp_device(ff, ctx=cx)
+                        its += rr.iterations
+                    rounds.append((time.perf_counter() - t1) / its)
+                dt, its = min(rounds), 1
                 ent = {"iterations_per_s": its / dt, "iterations": rr.iterations, "status": rr.status, "primal_objective": rr.primal_objective,
-                       "dual_objective": rr.dual_objective, "us_per_iteration": 1e6 * dt / its}
+                       "dual_objective": rr.dual_objective, "us_per_iteration": 1e6 * dt / its, "us_per_iteration_rounds": [1e6 * x for x in rounds]}
                 if expect is not None:
                     ent["expected"] = expect
                     assert abs(rr.primal_objective - expect) <= 1e-5 * abs(expect), ent
@@ -475,7 +480,7 @@ def main(argv=None, emit=True):
                     n_it += 1
                 return n_it / t_cpu, n_it, t_cpu
 
-            ncpu = os.cpu_count() or 1
+            ncpu = min(os.cpu_count() or 1, 32)      # (a team of 256 threads never wins and leaves an idle pool behind: see bench.py)
             best = None
             for thr in sorted({1, min(8, ncpu), ncpu}):      # these matrices are tiny: fewer threads is usually faster
                 oc.set_num_threads(thr)
