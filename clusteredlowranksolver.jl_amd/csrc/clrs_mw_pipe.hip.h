@@ -29,7 +29,8 @@
 // against it, none kept: one workgroup per compute unit (86 KB of LDS asked for: no change -- it is not sharing); at a miss the rows at once before the
 // sentinel (no change); every lane polling its own granules for the last four columns (no change: the loads themselves take that long); every loader asking
 // again once per step for what came back stale (cures the tail of the workgroups it hits, but all cadences go from 1.9 to 2.0 us: 0.526 against 0.522 ms
-// per iteration, Nsphere_packing N = 3 2.54 against 2.51).
+// per iteration, Nsphere_packing N = 3 2.54 against 2.51); the same in the last eight steps of the W workgroups only (they end at 77-81 us instead of
+// 84-86, and the iteration does not move: 0.521-0.522 ms, 2.50 against 2.51).
 //
 // The arithmetic per entry and pivot is wg_potrf's, in the same order: the factor, its reciprocal diagonal and the inverse are bit for bit those of
 // the one-workgroup kernels (tests/test_mw_parity.py::test_pipelined_factorisation_is_bit_identical).
