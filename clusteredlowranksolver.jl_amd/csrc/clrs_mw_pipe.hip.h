@@ -397,6 +397,7 @@ __global__ __launch_bounds__(MWP_NT) void k_mw_bp_diag_pipe(const MwDev q, const
         r -= ride * MW_INV_WG;
         constexpr int CB = MW_PB_OF(K) / MW_BP_IC;                   // column workgroups per block
         const int per = inv_row * CB;
+        if (per == 0 || r >= per * nm) return;                       // (the launch has no such blocks)
         mw_bp_inv_block<K>(q, ms[r / per], (r % per) / CB, inv_row, r % CB);
         return;
     }
