@@ -51,7 +51,7 @@ class IpmParams(C.Structure):
 class IpmRecord(C.Structure):
     """struct clrs_ipm_record"""
     _fields_ = [("iter", C.c_int32), ("pd_feas", C.c_int32), ("error_code", C.c_int32), ("factor_status", C.c_int32),
-                ("cholesky_status", C.c_int32), ("reserved", C.c_int32),
+                ("cholesky_status", C.c_int32), ("refine_bits", C.c_int32),
                 ("mu", C.c_double), ("d_obj", C.c_double), ("p_obj", C.c_double), ("gap", C.c_double), ("dual_error", C.c_double),
                 ("primal_error", C.c_double), ("alpha_d", C.c_double), ("alpha_p", C.c_double), ("beta_c", C.c_double),
                 ("max_P", C.c_double), ("max_p", C.c_double), ("max_d", C.c_double)]
@@ -65,7 +65,8 @@ class IpmStop(C.Structure):
 
 class MwOptions(C.Structure):
     """struct clrs_mw_options"""
-    _fields_ = [("exact_products", C.c_int32), ("refine", C.c_int32), ("pipeline", C.c_int32), ("refine_predictor", C.c_int32), ("reserved", C.c_int32 * 4)]
+    _fields_ = [("exact_products", C.c_int32), ("refine", C.c_int32), ("pipeline", C.c_int32), ("refine_predictor", C.c_int32), ("factor_limbs", C.c_int32),
+                ("reserved", C.c_int32 * 3)]
 
 
 class ClrsError(RuntimeError):

@@ -42,6 +42,7 @@ extern int g_cfg_mw_pipeline;                            // clrs_hip.hip, clrs_c
 extern int g_cfg_mw_refine_predictor;                    // clrs_hip.hip, clrs_config_set("mw_refine_predictor", 0 / 1)
 extern int g_cfg_mw_refine;                              // clrs_hip.hip, clrs_config_set("mw_refine", 0 / 1): read at context creation
 extern int g_cfg_mw_exact_products;                      // clrs_hip.hip, clrs_config_set("mw_exact_products", 0 / 1 / 2): read at context creation
+extern int g_cfg_mw_factor_limbs;                        // clrs_hip.hip, clrs_config_set("mw_factor_limbs", 0 / limbs): read at context creation
 extern "C" void clrs_set_last_error(const char *msg);   // clrs_hip.hip: the library keeps one thread-local message
 
 static int mw_fail(int code, const std::string &msg) {
@@ -177,6 +178,10 @@ struct clrs_mw_ctx {
     int refine_predictor = 0;            // clrs_mw_options.refine_predictor: 1 = the predictor's solve is refined like every other
     int refine = 1;                      // iterative refinement of the solve stage (clrs_mw_options / clrs_config_set("mw_refine")): 0 off, 1 one step with the correction in all K limbs, 2 ... in mw_kc(K) limbs
     bool ipm_arms_info = false;          // inside the device-resident iteration the status words are re-armed by a kernel, not by a memset per call
+    // Mixed-precision refinement (MwDev::kf, mw_kf_of): kf_low = the reduced limb count this context may run its factor stage and the products of its solve
+    // stage in (K: it may not -- limb counts without a reduced form, refinement off or in fewer limbs, blocked / row-parallel paths); kf_entry = what the
+    // stand-alone entry points use (clrs_mw_options.factor_limbs: 0 = K there and kf_low, adaptively, inside clrs_mw_ipm_*; explicit: that count everywhere)
+    int kf_low = 0, kf_entry = 0;
 };
 
 template <class T>
@@ -235,6 +240,7 @@ extern "C" int clrs_mw_create_opts(const clrs_sdp_desc *d, int data_limbs, int d
     const int cfg_refine = opts && opts->refine >= 0 ? opts->refine : g_cfg_mw_refine;
     const int cfg_pipe = opts && opts->pipeline >= 0 ? opts->pipeline : g_cfg_mw_pipeline;
     const int cfg_refine_pred = opts && opts->refine_predictor >= 0 ? opts->refine_predictor : g_cfg_mw_refine_predictor;
+    const int cfg_factor_limbs = opts && opts->factor_limbs >= 0 ? opts->factor_limbs : g_cfg_mw_factor_limbs;
     if (cfg_exact > 2 || cfg_refine > 2) return mw_fail(CLRS_ERR_INVALID, "clrs_mw_options: exact_products and refine are 0, 1 or 2 (or < 0 for the default)");
     if (limbs < 2 || limbs > 10 || limbs == 7 || limbs == 9) return mw_fail(CLRS_ERR_INVALID, "limbs must be 2..6, 8 or 10");
     if (data_limbs < 1 || data_limbs > 2 || data_limbs > limbs) return mw_fail(CLRS_ERR_INVALID, "data limbs must be 1 or 2 (and at most limbs)");
@@ -802,6 +808,21 @@ extern "C" int clrs_mw_create_opts(const clrs_sdp_desc *d, int data_limbs, int d
     MW_DISPATCH(c, { MW_TRY(mw_set_lds(k_mw_bp_diag<KK>, std::max(c->sm_bp_diag, c->sm_factor))); MW_TRY(mw_set_lds(k_mw_bp_panel<KK>, c->sm_bp_panel)); MW_TRY(mw_set_lds(k_mw_bp_inv<KK>, c->sm_bp_inv)); MW_TRY(mw_set_lds(k_mw_bp_inv_row<KK>, c->sm_bp_inv)); });
     q.rank = 0; q.world = 1; q.gathered = 0;
     MW_TRY(mw_dmalloc(c, &q.Qg, (i64)N * N * K)); MW_TRY(mw_dmalloc(c, &q.ug, (i64)N * K));
+    {   // factor stage and solve products in fewer limbs, residuals and iterate in K (mw_kf_of): the LDS-resident paths with the full-limb refinement step
+        bool all_lds = true;
+        for (auto &cl : c->clu) all_lds = all_lds && cl.lds;
+        const bool may = mw_kf_of(K) < K && c->refine == 1 && !c->wide_solve && all_lds && (N == 0 || c->lds_q || c->pipe_Q);
+        c->kf_low = may ? mw_kf_of(K) : K;
+        if (cfg_factor_limbs != 0 && cfg_factor_limbs != K && cfg_factor_limbs != c->kf_low) MW_BAIL(CLRS_ERR_INVALID, "factor_limbs: 0 (automatic), the context's limbs, or the reduced count of this limb count where the LDS-resident refined solve runs");
+        if (cfg_factor_limbs == K) c->kf_low = K;
+        c->kf_entry = cfg_factor_limbs == 0 ? K : cfg_factor_limbs;
+        q.kf = c->kf_entry;
+        unsigned long long *rs = nullptr;
+        if (hipMalloc((void **)&rs, 4 * sizeof(unsigned long long)) != hipSuccess) MW_BAIL(CLRS_ERR_HIP, "hipMalloc failed");
+        c->allocs.push_back(rs);
+        if (hipMemset(rs, 0, 4 * sizeof(unsigned long long)) != hipSuccess) MW_BAIL(CLRS_ERR_HIP, "hipMemset failed");
+        q.refstat = rs;
+    }
     for (auto &e : c->ev) MWCHECK(hipEventCreate(&e));
     *out = c;
     return 0;

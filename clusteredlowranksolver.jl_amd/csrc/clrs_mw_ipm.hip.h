@@ -11,7 +11,7 @@
 
 enum { MSC_MU = 0, MSC_MUS, MSC_XY, MSC_XdY, MSC_dXY, MSC_dXdY, MSC_CY, MSC_DOBJ, MSC_POBJ, MSC_GAP, MSC_COUNT = 16 };
 enum { MREC_ITER = 0, MREC_MU, MREC_DOBJ, MREC_POBJ, MREC_GAP, MREC_DERR, MREC_PERR, MREC_AD, MREC_AP, MREC_BETA, MREC_MAXP, MREC_MAXp, MREC_MAXd,
-       MREC_PDFEAS, MREC_ERR, MREC_FSTAT, MREC_XSTAT, MREC_COUNT = 24 };
+       MREC_PDFEAS, MREC_ERR, MREC_FSTAT, MREC_XSTAT, MREC_REFB, MREC_COUNT = 24 };
 
 struct MwIpmDev {
     double *x, *y, *X, *Y, *dx, *dy, *dX, *dY, *R, *Xc, *Pm, *d, *rhsx, *pv, *coef;   // planar limbs
@@ -520,6 +520,17 @@ __device__ void mwi_scalar_stage(const MwDev &q, const MwIpmDev &p, int stage, i
         p.sc[MSC_COUNT * 0 + 10] = al[0];                          // slots 10 / 11 of limb plane 0: alpha_d / alpha_p as plain doubles
         p.sc[MSC_COUNT * 0 + 11] = al[1];
         p.rec[MREC_ERR] = p.flags[1];
+        // how good the first pass of the corrector's refined solve was: -log2(max|correction| / max|solution|) over dx and dy (k_mw_solve_bwd MODE 2 left the
+        // four maxima in q.refstat).  The host returns the factor stage to all K limbs when this falls to one limb plus a margin (mw_kf_of, clrs_mw_ipm_host.inc).
+        if (q.refstat) {
+            const double c0 = __longlong_as_double((long long)q.refstat[0]), v0 = __longlong_as_double((long long)q.refstat[1]);
+            const double c1 = __longlong_as_double((long long)q.refstat[2]), v1 = __longlong_as_double((long long)q.refstat[3]);
+            double ratio = 0.0;
+            if (v0 > 0.0) ratio = fmax(ratio, c0 / v0);
+            if (v1 > 0.0) ratio = fmax(ratio, c1 / v1);
+            p.rec[MREC_REFB] = (v0 > 0.0 || v1 > 0.0) ? (ratio > 0.0 ? fmin(1023.0, fmax(1.0, -log2(ratio))) : 1023.0) : 0.0;
+            q.refstat[0] = q.refstat[1] = q.refstat[2] = q.refstat[3] = 0ull;
+        }
     }
 }
 template <int K, int DK>

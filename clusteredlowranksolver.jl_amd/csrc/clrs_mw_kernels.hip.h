@@ -51,8 +51,16 @@ struct MwClu {               // one cluster j
     mwi64 coff, Soff;
     int one_term, pad;       // 1 = at most four PSD blocks and at most one low-rank term per (constraint, block): S_j by k_mw_saccum_one
 };
+// Limbs of the FACTOR stage and of the products of the solve stage when the context runs them in fewer limbs than its K (MwDev::kf < K; clrs_mw_options.factor_limbs):
+// mixed-precision iterative refinement.  L_j, L_j^-1, L^-1 B, Q, L_Q, L_Q^-1 and both passes of inverse-factor products carry mw_kf_of(K) limbs (their upper
+// planes are stored as zeros, so that every K-limb reader stays valid), the residuals r_x = rhs_x - S dx + B dy, r_y = rhs_y - B^T dx of the refinement step
+// and the sum dx + dx' carry K.  One K-1 limb pass has a forward error of cond 2^(-53 (K - 1)); the correction squares it.  The refined solution is as good as
+// that of K-limb factors while the first pass alone is good to 2^-53 (one limb): k_mw_solve_bwd MODE 2 measures max|dx'| / max|dx| (MwDev::refstat) and the
+// caller returns to K limbs when it is not (prototype numbers: cohnelkies(8,15) iterations 1 / 28 / 55 first pass 2^-123 / 2^-99 / 2^-45).
+__host__ __device__ constexpr int mw_kf_of(int K) { return (K == 5 || K == 6) ? K - 1 : K; }
+
 struct MwDev {
-    int J, N, NB, nlr, ndn, pad0;
+    int J, N, NB, nlr, ndn, kf;         // kf: limbs of the factor stage and of the solve's products (K, or mw_kf_of(K))
     mwi64 xylen, xlen, Slen, T, xrdlen;
     const MwBlk *blk;
     const MwClu *clu;
@@ -87,6 +95,7 @@ struct MwDev {
     unsigned long long *pipe_stamps;    // diagnostic builds: [16][40] step stamps of the pipelined factorisations (clrs_mw_debug_pipe_stamps), or null
     unsigned long long *pipe_pc;        // hand-off granules of the pipelined factorisations (clrs_mw_pipe.hip.h): [J + 1][MWP_PC_WORDS], or null
     double *ub;                         // u' slabs of the refinement step (J x N; k_mw_solve_bwd MODE 1 writes them while other workgroups read u)
+    unsigned long long *refstat;        // bit patterns of non-negative doubles, atomicMax'ed by the correction's backward half (MODE 2): [0] max|dx'|, [1] max|dx|, [2] max|dy'|, [3] max|dy|
     double *rx2, *u2, *dx2, *dy2;
     const double *uadd;
     int *info;                          // [0] factor status, [1] Cholesky-of-X status
@@ -953,19 +962,25 @@ __global__ __launch_bounds__(MW_NT) void k_mw_saccum_one(const MwDev q, int do_a
 // Factorisation of a cluster: L_j = chol(S_j) (in place in the S buffer), LinvB_j = L_j^-1 B_j; the scaled triangles of L_j
 // for the solve stage.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int K, class PM, class PW>
+// KS: limbs of the arrays (S, S0, Si and the LDS copies M, W, whose planes are laid out for KS); K <= KS: limbs of the elimination (MwDev::kf) -- the upper
+// KS - K planes of L_j, 1 / diag and L_j^-1 are stored as zeros
+template <int KS, int K, class PM, class PW>
 __device__ __forceinline__ bool mw_factor_body(const MwDev &q, const MwClu &c, int j, PM M, long mplane, PW W, mwk::lds_d *bc, int tid, int cw, int cnw) {
     using namespace mwk;
     const int P = c.P;
     // (cw of cnw: the workgroups of a cluster share out the columns of L_j^-1)
     const bool ok = wg_potrf<K, true, MW_PT>(M, mplane, P, P, q.srd + c.coff, q.xlen, W, MW_TRI(P), 0, bc, tid, cw, cnw);     // W packed
     if (!ok && tid == 0) atomicMin(&q.info[0], j + 1);
+    if (K < KS && ok && cw == 0) for (int i = tid; i < P; i += MW_PT) {
+#pragma unroll
+        for (int l = K; l < KS; l++) q.srd[(long)l * q.xlen + c.coff + i] = 0.0;
+    }
     if (ok) {
         for (int e = tid; e < P * P; e += MW_PT) {        // this workgroup's columns of L_j^-1, zero above the diagonal
             const int i = e % P, cc = e / P;
             if (cc % cnw != cw) continue;
 #pragma unroll
-            for (int l = 0; l < K; l++) q.Si[(long)l * q.Slen + c.Soff + e] = (i >= cc) ? (double)W[(long)l * MW_TRI(P) + w_index(i, cc, P, 0)] : 0.0;
+            for (int l = 0; l < KS; l++) q.Si[(long)l * q.Slen + c.Soff + e] = (i >= cc && l < K) ? (double)W[(long)l * MW_TRI(P) + w_index(i, cc, P, 0)] : 0.0;
         }
     }
     // L_j goes back to the S buffer, which is also the input: only once every workgroup of the cluster has read it, i.e. by the last one
@@ -974,7 +989,7 @@ __device__ __forceinline__ bool mw_factor_body(const MwDev &q, const MwClu &c, i
     for (int e = tid; e < P * P; e += MW_PT) {
         const int i = e % P, cc = e / P;
 #pragma unroll
-        for (int l = 0; l < K; l++) Sg[(long)l * q.Slen + e] = (i >= cc) ? (double)M[(long)l * mplane + e] : 0.0;
+        for (int l = 0; l < KS; l++) Sg[(long)l * q.Slen + e] = (i >= cc && l < K) ? (double)M[(long)l * mplane + e] : 0.0;
     }
     return true;
 }
@@ -990,7 +1005,10 @@ __device__ __forceinline__ void mw_factor_cluster(const MwDev &q, int j, int cw,
         wg_copy<K, MW_PT>(M, (long)P * P, P, q.S + c.Soff, q.Slen, P, P, P, tid);
         __syncthreads();
         if (cw == 0) wg_copy<K, MW_PT>(q.S0 + c.Soff, q.Slen, P, M, (long)P * P, P, P, P, tid);      // S_j as assembled, for the residuals of the refined solve
-        mw_factor_body<K>(q, c, j, M, (long)P * P, M + (long)K * P * P, bc, tid, cw, cnw);
+        if constexpr (mw_kf_of(K) < K) {
+            if (q.kf < K) { mw_factor_body<K, mw_kf_of(K)>(q, c, j, M, (long)P * P, M + (long)K * P * P, bc, tid, cw, cnw); return; }
+        }
+        mw_factor_body<K, K>(q, c, j, M, (long)P * P, M + (long)K * P * P, bc, tid, cw, cnw);
     }
     // clusters too large for LDS are factored by the blocked, multi-workgroup path (k_mw_bp_*, driven by the host)
 }
@@ -1009,11 +1027,10 @@ __global__ __launch_bounds__(MW_NT) void k_mw_keep_S(const MwDev q) {
     }
 }
 
-// LinvB_j = L_j^-1 B_j (src/solver.jl:1256-1261) = Si_j B_j: a product with the explicit inverse, four lanes per entry
+// LinvB_j = L_j^-1 B_j (src/solver.jl:1256-1261) = Si_j B_j: a product with the explicit inverse, four lanes per entry.  KA <= K: limbs of the product (MwDev::kf)
 #define MW_LBI_W 4
-template <int K, int DK>
-__global__ __launch_bounds__(MW_NT) void k_mw_linvb(const MwDev q) {
-    MW_CHAIN_STAMP(q, 0, blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0);
+template <int K, int KA, int DK>
+__device__ __forceinline__ void mw_linvb_body(const MwDev &q) {
     using namespace mwk;
     const int j = blockIdx.y;
     const MwClu &c = q.clu[j];
@@ -1024,16 +1041,22 @@ __global__ __launch_bounds__(MW_NT) void k_mw_linvb(const MwDev q) {
     const bool live = e < P * N;
     const int ee = live ? e : 0, i = ee % P, a = ee / P;
     const double *Ti = q.Si + c.Soff;
-    acc<K> s;
-    acc_zero<K>(s);
-    for (int r = sub; r <= i; r += MW_LBI_W) acc_fma<K, K, DK>(s, ldx<K>(Ti, q.Slen, i + (long)r * P), ldx<DK>(q.B, q.Bp, c.coff + r + (long)a * q.xlen));
-    const mw<K> v = lanes_sum<K, MW_LBI_W>(acc_result<K>(s));
-    if (live && sub == 0) stx<K>(q.LB, q.xlen * (long)N, c.coff + i + (long)a * q.xlen, v);
+    acc<KA> s;
+    acc_zero<KA>(s);
+    for (int r = sub; r <= i; r += MW_LBI_W) acc_fma<KA, KA, DK>(s, ldx<KA>(Ti, q.Slen, i + (long)r * P), ldx<DK>(q.B, q.Bp, c.coff + r + (long)a * q.xlen));
+    const mw<KA> v = lanes_sum<KA, MW_LBI_W>(acc_result<KA>(s));
+    if (live && sub == 0) stx<K>(q.LB, q.xlen * (long)N, c.coff + i + (long)a * q.xlen, cvt<K, KA>(v));
+}
+template <int K, int DK>
+__global__ __launch_bounds__(MW_NT) void k_mw_linvb(const MwDev q) {
+    MW_CHAIN_STAMP(q, 0, blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0);
+    if constexpr (mw_kf_of(K) < K) { if (q.kf < K) { mw_linvb_body<K, mw_kf_of(K), DK>(q); return; } }
+    mw_linvb_body<K, K, DK>(q);
 }
 
 // Q = sum_j LinvB_j^T LinvB_j = LB^T LB over the stacked rows (src/solver.jl:1264-1271): eight lanes per entry a >= b
 #define MW_Q_W 8
-template <int K, int W>
+template <int K, int KA, int W>
 __device__ __forceinline__ void mw_qgram_body(const MwDev &q) {
     using namespace mwk;
     const int N = q.N;
@@ -1044,10 +1067,10 @@ __device__ __forceinline__ void mw_qgram_body(const MwDev &q) {
     int a, b;
     tri_index(live ? e : 0, a, b);
     const long plane = q.xlen * (long)N;
-    acc<K> s;
-    acc_zero<K>(s);
-    for (long r = sub; r < q.xlen; r += W) acc_fma<K, K, K>(s, ldx<K>(q.LB, plane, r + a * q.xlen), ldx<K>(q.LB, plane, r + b * q.xlen));
-    mw<K> v = lanes_sum<K, W>(acc_result<K>(s));
+    acc<KA> s;
+    acc_zero<KA>(s);
+    for (long r = sub; r < q.xlen; r += W) acc_fma<KA, KA, KA>(s, ldx<KA>(q.LB, plane, r + a * q.xlen), ldx<KA>(q.LB, plane, r + b * q.xlen));
+    const mw<K> v = cvt<K, KA>(lanes_sum<KA, W>(acc_result<KA>(s)));
     if (live && sub == 0) {
         double *Qp = q.Qg + (long)q.rank * K * N * N;                 // this rank's partial sum over its clusters
         stx<K>(Qp, (long)N * N, a + (long)b * N, v);
@@ -1059,15 +1082,25 @@ template <int K>
 __global__ __launch_bounds__(MW_NT) void k_mw_qgram(const MwDev q, int lanes) {
     MW_CHAIN_STAMP(q, 1, blockIdx.x == 0 && threadIdx.x == 0);
     MW_CHAIN_STAMP(q, 2, blockIdx.x == gridDim.x - 1 && threadIdx.x == 0);
-    if (lanes == 32) mw_qgram_body<K, 32>(q);
-    else mw_qgram_body<K, MW_Q_W>(q);
+    bool done = false;
+    if constexpr (mw_kf_of(K) < K) {
+        if (q.kf < K) {
+            if (lanes == 32) mw_qgram_body<K, mw_kf_of(K), 32>(q);
+            else mw_qgram_body<K, mw_kf_of(K), MW_Q_W>(q);
+            done = true;
+        }
+    }
+    if (!done) {
+        if (lanes == 32) mw_qgram_body<K, K, 32>(q);
+        else mw_qgram_body<K, K, MW_Q_W>(q);
+    }
     MW_CHAIN_STAMP(q, 5, blockIdx.x == gridDim.x - 1 && threadIdx.x == 0);       // (end of the last workgroup)
 }
 
 template <int K>
 __device__ __forceinline__ void mw_solve_fwd_cluster(const MwDev &q, int j, const double *__restrict__ rhs_x);      // (solve stage, below)
-// Cholesky of Q (src/solver.jl:1274) and its scaled triangles
-template <int K, class PM, class PW>
+// Cholesky of Q (src/solver.jl:1274) and its scaled triangles.  KS / K: limbs of the arrays / of the elimination, as mw_factor_body
+template <int KS, int K, class PM, class PW>
 __device__ __forceinline__ void mw_potrf_q_body(const MwDev &q, PM M, long plane, PW W, mwk::lds_d *bc, int tid, int cw, int cnw) {
     using namespace mwk;
     const int N = q.N;
@@ -1077,12 +1110,16 @@ __device__ __forceinline__ void mw_potrf_q_body(const MwDev &q, PM M, long plane
         if (tid == 0) atomicMin(&q.info[0], q.J + 1);
         return;
     }
+    if (K < KS && cw == 0) for (int i = tid; i < N; i += MW_PT) {
+#pragma unroll
+        for (int l = K; l < KS; l++) q.qrd[(long)l * N + i] = 0.0;
+    }
     for (int e = tid; e < N * N; e += MW_PT) {
         const int i = e % N, cc = e / N;
 #pragma unroll
-        for (int l = 0; l < K; l++) {
-            if (cw == 0) q.Q[(long)l * N * N + e] = (i >= cc) ? (double)M[(long)l * plane + e] : 0.0;
-            if (cc % cnw == cw) q.Qi[(long)l * N * N + e] = (i >= cc) ? (double)W[(long)l * MW_TRI(N) + w_index(i, cc, N, 0)] : 0.0;
+        for (int l = 0; l < KS; l++) {
+            if (cw == 0) q.Q[(long)l * N * N + e] = (i >= cc && l < K) ? (double)M[(long)l * plane + e] : 0.0;
+            if (cc % cnw == cw) q.Qi[(long)l * N * N + e] = (i >= cc && l < K) ? (double)W[(long)l * MW_TRI(N) + w_index(i, cc, N, 0)] : 0.0;
         }
     }
 }
@@ -1129,7 +1166,10 @@ __global__ __launch_bounds__(MW_PT) void k_mw_potrf_q(const MwDev q, int nq, con
         stx<K>(M, nn, e, acc_result<K>(s));
     }
     __syncthreads();
-    mw_potrf_q_body<K>(q, M, nn, M + (long)K * nn, bc, tid, blockIdx.x, nq);
+    if constexpr (mw_kf_of(K) < K) {
+        if (q.kf < K) { mw_potrf_q_body<K, mw_kf_of(K)>(q, M, nn, M + (long)K * nn, bc, tid, blockIdx.x, nq); return; }
+    }
+    mw_potrf_q_body<K, K>(q, M, nn, M + (long)K * nn, bc, tid, blockIdx.x, nq);
     // a Q too large for LDS: k_mw_qsum + the blocked path (k_mw_bp_*)
 }
 
@@ -1338,8 +1378,8 @@ __global__ __launch_bounds__(MW_NT) void k_mw_usum(const MwDev q) {
 // the explicit inverse factor (wg_trmv_n / _t), every dot product runs over eight lanes.
 // ---------------------------------------------------------------------------------------------------------------------
 #define MW_S_W 8
-// u_j = LinvB_j^T t_j (t in LDS, planar with plane P)
-template <int K>
+// u_j = LinvB_j^T t_j (t in LDS, planar with plane P).  KA <= K: limbs of the products (MwDev::kf); what is stored carries K planes, the upper ones zero
+template <int K, int KA>
 __device__ __forceinline__ void mw_solve_u(const MwDev &q, const MwClu &c, int j, mwk::lds_d *tv, int tid) {
     using namespace mwk;
     const int P = c.P, N = q.N;
@@ -1349,15 +1389,15 @@ __device__ __forceinline__ void mw_solve_u(const MwDev &q, const MwClu &c, int j
         const int a = a0 + tid / MW_S_W;
         const bool live = a < N;
         const int aa = live ? a : 0;
-        acc<K> s;
-        acc_zero<K>(s);
-        for (int r = sub; r < P; r += MW_S_W) acc_fma<K, K, K>(s, ldx<K>(q.LB, plane, c.coff + r + aa * q.xlen), ldx<K>(tv, P, r));
-        mw<K> v = lanes_sum<K, MW_S_W>(acc_result<K>(s));
-        if (live && sub == 0) stx<K>(q.u, (long)q.J * N, (long)j * N + a, v);
+        acc<KA> s;
+        acc_zero<KA>(s);
+        for (int r = sub; r < P; r += MW_S_W) acc_fma<KA, KA, KA>(s, ldx<KA>(q.LB, plane, c.coff + r + aa * q.xlen), ldx<KA>(tv, P, r));
+        mw<KA> v = lanes_sum<KA, MW_S_W>(acc_result<KA>(s));
+        if (live && sub == 0) stx<K>(q.u, (long)q.J * N, (long)j * N + a, cvt<K, KA>(v));
     }
 }
-template <int K>
-__device__ __forceinline__ void mw_solve_fwd_cluster(const MwDev &q, int j, const double *__restrict__ rhs_x) {
+template <int K, int KA>
+__device__ __forceinline__ void mw_solve_fwd_cluster_ka(const MwDev &q, int j, const double *__restrict__ rhs_x) {
     using namespace mwk;
     const int tid = threadIdx.x;
     if (tid >= MW_NT) return;                              // (called from a launch with more threads: the other waves leave; barriers count the rest)
@@ -1366,15 +1406,20 @@ __device__ __forceinline__ void mw_solve_fwd_cluster(const MwDev &q, int j, cons
     lds_d *tv = MW_LDS, *t2 = tv + (long)K * P;            // rhs_j and t_j, planar with plane P
     for (int i = tid; i < P; i += MW_NT) {
 #pragma unroll
-        for (int l = 0; l < K; l++) tv[(long)l * P + i] = rhs_x[(long)l * q.xlen + c.coff + i];
+        for (int l = 0; l < KA; l++) tv[(long)l * P + i] = rhs_x[(long)l * q.xlen + c.coff + i];
     }
     __syncthreads();
-    wg_trmv_n<K>(q.Si + c.Soff, q.Slen, P, P, tv, P, t2, P, tid);      // t_j = Si_j rhs_j
+    wg_trmv_n<KA>(q.Si + c.Soff, q.Slen, P, P, tv, P, t2, P, tid);      // t_j = Si_j rhs_j
     for (int i = tid; i < P; i += MW_NT) {
 #pragma unroll
-        for (int l = 0; l < K; l++) q.t[(long)l * q.xlen + c.coff + i] = t2[(long)l * P + i];
+        for (int l = 0; l < K; l++) q.t[(long)l * q.xlen + c.coff + i] = l < KA ? (double)t2[(long)l * P + i] : 0.0;
     }
-    mw_solve_u<K>(q, c, j, t2, tid);
+    mw_solve_u<K, KA>(q, c, j, t2, tid);
+}
+template <int K>
+__device__ __forceinline__ void mw_solve_fwd_cluster(const MwDev &q, int j, const double *__restrict__ rhs_x) {
+    if constexpr (mw_kf_of(K) < K) { if (q.kf < K) { mw_solve_fwd_cluster_ka<K, mw_kf_of(K)>(q, j, rhs_x); return; } }
+    mw_solve_fwd_cluster_ka<K, K>(q, j, rhs_x);
 }
 template <int K>
 __global__ __launch_bounds__(MW_NT) void k_mw_solve_fwd(const MwDev q, const double *__restrict__ rhs_x) { mw_solve_fwd_cluster<K>(q, blockIdx.x, rhs_x); }
@@ -1411,7 +1456,7 @@ __device__ __forceinline__ void mw_solve_mid_body(const MwDev &q, const double *
 }
 // KC < K: the correction dy' of the refined solve, to dy (a buffer of its own: k_mw_solve_bwd<.., 2> adds it)
 template <int K, int KC>
-__global__ __launch_bounds__(MW_NT) void k_mw_solve_mid(const MwDev q, const double *__restrict__ rhs_y, double *__restrict__ dy) {
+__device__ __forceinline__ void mw_solve_mid_kernel_body(const MwDev &q, const double *__restrict__ rhs_y, double *__restrict__ dy) {
     using namespace mwk;
     const int N = q.N, tid = threadIdx.x;
     lds_d *v = MW_LDS, *y = v + (long)K * N;  // N numbers each, plane N
@@ -1421,6 +1466,11 @@ __global__ __launch_bounds__(MW_NT) void k_mw_solve_mid(const MwDev q, const dou
         for (int l = 0; l < K; l++) dy[(long)l * N + a] = l < KC ? (double)v[(long)l * N + a] : 0.0;
     }
 }
+template <int K, int KC>
+__global__ __launch_bounds__(MW_NT) void k_mw_solve_mid(const MwDev q, const double *__restrict__ rhs_y, double *__restrict__ dy) {
+    if constexpr (KC == K && mw_kf_of(K) < K) { if (q.kf < K) { mw_solve_mid_kernel_body<K, mw_kf_of(K)>(q, rhs_y, dy); return; } }
+    mw_solve_mid_kernel_body<K, KC>(q, rhs_y, dy);
+}
 
 // mid_rhs_y != null (small unsharded systems): every workgroup forms dy = Q^-1 (rhs_y - sum u_j) itself first (two 31-row products: cheaper than the
 // launch of k_mw_solve_mid in front of this kernel); the first one writes it to dy.
@@ -1429,11 +1479,12 @@ __global__ __launch_bounds__(MW_NT) void k_mw_solve_mid(const MwDev q, const dou
 //         cancels), t'_j = Si_j r_j (KC limbs) and u'_j = LinvB_j^T t'_j + B_j^T dx_j (the second term is this cluster's share of -r_y, in K limbs) into
 //         q.t, q.u, where the plain forward half would have left them.
 // MODE 2: the backward half of the correction in KC limbs, added to what dx, dy hold.
-template <int K, int KC, int DK, int MODE>
-__global__ __launch_bounds__(MW_NT) void k_mw_solve_bwd(const MwDev q, const double *__restrict__ dy_in, double *__restrict__ dx, const double *__restrict__ mid_rhs_y,
-                                                        double *__restrict__ dy_out, const double *__restrict__ rhs_x) {
+// KP: limbs of the products of the first pass (MODE 0, 1) -- K, or MwDev::kf with factors of fewer limbs, in which case KC = KP as well
+template <int K, int KP, int KC, int DK, int MODE>
+__device__ __forceinline__ void mw_solve_bwd_body(const MwDev &q, const double *__restrict__ dy_in, double *__restrict__ dx, const double *__restrict__ mid_rhs_y,
+                                                  double *__restrict__ dy_out, const double *__restrict__ rhs_x) {
     using namespace mwk;
-    constexpr int KB = MODE == 2 ? KC : K;                 // limbs of this pass's products
+    constexpr int KB = MODE == 2 ? KC : KP;                // limbs of this pass's products
     const int j = blockIdx.x, tid = threadIdx.x;
     const MwClu &c = q.clu[j];
     const int P = c.P, N = q.N;
@@ -1449,11 +1500,21 @@ __global__ __launch_bounds__(MW_NT) void k_mw_solve_bwd(const MwDev q, const dou
         }
         __syncthreads();
     }
+    double mx_c = 0.0, mx_v = 0.0;                          // MODE 2: largest |correction|, |value| this thread has seen (heads)
     if (j == 0 && (mid_rhs_y || MODE == 2))
         for (int a = tid; a < N; a += MW_NT) {
-            if (MODE == 2) stx<K>(dy_out, N, a, add<K>(ldx<K>(dy_out, N, a), cvt<K, KB>(ldx<KB>(dyl, N, a))));
-            else stx<K>(dy_out, N, a, ldx<K>(dyl, N, a));
+            if (MODE == 2) {
+                const mw<K> old = ldx<K>(dy_out, N, a), cor = cvt<K, KB>(ldx<KB>(dyl, N, a));
+                mx_c = fmax(mx_c, __builtin_fabs(cor.l[0])); mx_v = fmax(mx_v, __builtin_fabs(old.l[0]));
+                stx<K>(dy_out, N, a, add<K>(old, cor));
+            } else stx<K>(dy_out, N, a, cvt<K, KB>(ldx<KB>(dyl, N, a)));
         }
+    if (MODE == 2 && q.refstat && j == 0) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { mx_c = fmax(mx_c, __shfl_xor(mx_c, off, 64)); mx_v = fmax(mx_v, __shfl_xor(mx_v, off, 64)); }
+        if ((tid & 63) == 0 && tid < N) { atomicMax(q.refstat + 2, (unsigned long long)__double_as_longlong(mx_c)); atomicMax(q.refstat + 3, (unsigned long long)__double_as_longlong(mx_v)); }
+    }
+    mx_c = mx_v = 0.0;
     for (int r0 = 0; r0 < P; r0 += MW_NT / MW_S_W) {
         const int r = r0 + tid / MW_S_W;
         const bool live = r < P;
@@ -1468,8 +1529,16 @@ __global__ __launch_bounds__(MW_NT) void k_mw_solve_bwd(const MwDev q, const dou
     __syncthreads();
     wg_trmv_t<KB>(q.Si + c.Soff, q.Slen, P, P, w, P, w2, P, tid);       // dx_j = Si_j^T w
     for (int i = tid; i < P; i += MW_NT) {
-        if (MODE == 2) stx<K>(dx, q.xlen, c.coff + i, add<K>(ldx<K>(dx, q.xlen, c.coff + i), cvt<K, KB>(ldx<KB>(w2, P, i))));
-        else stx<K>(dx, q.xlen, c.coff + i, ldx<K>(w2, P, i));
+        if (MODE == 2) {
+            const mw<K> old = ldx<K>(dx, q.xlen, c.coff + i), cor = cvt<K, KB>(ldx<KB>(w2, P, i));
+            mx_c = fmax(mx_c, __builtin_fabs(cor.l[0])); mx_v = fmax(mx_v, __builtin_fabs(old.l[0]));
+            stx<K>(dx, q.xlen, c.coff + i, add<K>(old, cor));
+        } else stx<K>(dx, q.xlen, c.coff + i, cvt<K, KB>(ldx<KB>(w2, P, i)));
+    }
+    if (MODE == 2 && q.refstat) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { mx_c = fmax(mx_c, __shfl_xor(mx_c, off, 64)); mx_v = fmax(mx_v, __shfl_xor(mx_v, off, 64)); }
+        if ((tid & 63) == 0 && tid < P) { atomicMax(q.refstat + 0, (unsigned long long)__double_as_longlong(mx_c)); atomicMax(q.refstat + 1, (unsigned long long)__double_as_longlong(mx_v)); }
     }
     if (MODE != 1) return;
     // r_j = rhs_x[j] - S_j dx_j + B_j dy into w
@@ -1481,8 +1550,8 @@ __global__ __launch_bounds__(MW_NT) void k_mw_solve_bwd(const MwDev q, const dou
         acc<K> s;
         acc_zero<K>(s);
         if (sub == 0) acc_add<K, K>(s, ldx<K>(rhs_x, q.xlen, c.coff + rr));
-        for (int cc = sub; cc < P; cc += MW_S_W) acc_fma<K, K, K>(s, ldx<K>(S0, q.Slen, cc + (long)rr * P), ldx<K>(w2, P, cc), -1.0);      // row rr = column rr (symmetric!)
-        for (int a = sub; a < N; a += MW_S_W) acc_fma<K, DK, K>(s, ldx<DK>(q.B, q.Bp, c.coff + rr + a * q.xlen), ldx<K>(dyl, N, a));
+        for (int cc = sub; cc < P; cc += MW_S_W) acc_fma<K, K, KB>(s, ldx<K>(S0, q.Slen, cc + (long)rr * P), ldx<KB>(w2, P, cc), -1.0);      // row rr = column rr (symmetric!)
+        for (int a = sub; a < N; a += MW_S_W) acc_fma<K, DK, KB>(s, ldx<DK>(q.B, q.Bp, c.coff + rr + a * q.xlen), ldx<KB>(dyl, N, a));
         mw<K> v = lanes_sum<K, MW_S_W>(acc_result<K>(s));
         if (live && sub == 0) stx<K>(w, P, r, v);
     }
@@ -1500,11 +1569,19 @@ __global__ __launch_bounds__(MW_NT) void k_mw_solve_bwd(const MwDev q, const dou
         acc_zero<K>(s);
         for (int r = sub; r < P; r += MW_S_W) {
             acc_fma<K, KC, KC>(s, ldx<KC>(q.LB, plane, c.coff + r + aa * q.xlen), ldx<KC>(w3, P, r));
-            acc_fma<K, DK, K>(s, ldx<DK>(q.B, q.Bp, c.coff + r + aa * q.xlen), ldx<K>(w2, P, r));
+            acc_fma<K, DK, KB>(s, ldx<DK>(q.B, q.Bp, c.coff + r + aa * q.xlen), ldx<KB>(w2, P, r));
         }
         mw<K> v = lanes_sum<K, MW_S_W>(acc_result<K>(s));
         if (live && sub == 0) stx<K>(q.ub, (long)q.J * N, (long)j * N + a, v);
     }
+}
+template <int K, int KC, int DK, int MODE>
+__global__ __launch_bounds__(MW_NT) void k_mw_solve_bwd(const MwDev q, const double *__restrict__ dy_in, double *__restrict__ dx, const double *__restrict__ mid_rhs_y,
+                                                        double *__restrict__ dy_out, const double *__restrict__ rhs_x) {
+    if constexpr (KC == K && mw_kf_of(K) < K) {
+        if (q.kf < K) { mw_solve_bwd_body<K, mw_kf_of(K), mw_kf_of(K), DK, MODE>(q, dy_in, dx, mid_rhs_y, dy_out, rhs_x); return; }
+    }
+    mw_solve_bwd_body<K, K, KC, DK, MODE>(q, dy_in, dx, mid_rhs_y, dy_out, rhs_x);
 }
 
 // The same solve for clusters or a Q of more than ~64 rows: with one workgroup per cluster (and one for Q) the six products of the stage run one

@@ -203,7 +203,9 @@ struct MwpLds {                                      // (no arrays of pointers: 
 
 // role < stages: stage `role` of the elimination of M; role >= stages: workgroup role - stages of the MWP_WW that form W.  Returns false at a
 // non-positive pivot (or a hand-off that never arrived); every workgroup of the matrix then stops at the same pivot.
-template <int K>
+// KS: limbs of the arrays in memory (input, keep, L, rd, Inv); K <= KS: limbs of the elimination (MwDev::kf).  K < KS: the input is truncated to K limbs
+// (the copy `keep` carries all KS), the results are stored with their upper KS - K planes zero.
+template <int KS, int K>
 __device__ __forceinline__ bool mwp_run(const MwPipeMat &m, int role, unsigned epoch, int *info, int tid) {
     const int n = m.n, stages = (n + MWP_W - 1) / MWP_W;
     MwpLds<K> S(MW_LDS);
@@ -217,16 +219,18 @@ __device__ __forceinline__ bool mwp_run(const MwPipeMat &m, int role, unsigned e
     const int nfetch = is_w ? n : c0;                                        // columns 0 .. nfetch - 1 come from other workgroups
     mw<K> v = zero<K>();
     if (!is_w && live) {
+        mw<KS> vin;
         if (m.in_slots > 1) {
-            acc<K> s;
-            acc_zero<K>(s);
-            for (int r = 0; r < m.in_slots; r++) acc_add<K, K>(s, ldx<K>(m.in + (long)r * m.in_stride, m.inplane, i + (long)c * m.in_ld));
-            v = acc_result<K>(s);
-        } else v = ldx<K>(m.in, m.inplane, i + (long)c * m.in_ld);
+            acc<KS> s;
+            acc_zero<KS>(s);
+            for (int r = 0; r < m.in_slots; r++) acc_add<KS, KS>(s, ldx<KS>(m.in + (long)r * m.in_stride, m.inplane, i + (long)c * m.in_ld));
+            vin = acc_result<KS>(s);
+        } else vin = ldx<KS>(m.in, m.inplane, i + (long)c * m.in_ld);
         if (m.keep) {                                                        // the matrix as it came in (both triangles), for the residuals of the refined solve
-            stx<K>(m.keep, m.inplane, i + (long)c * m.in_ld, v);
-            stx<K>(m.keep, m.inplane, c + (long)i * m.in_ld, v);
+            stx<KS>(m.keep, m.inplane, i + (long)c * m.in_ld, vin);
+            stx<KS>(m.keep, m.inplane, c + (long)i * m.in_ld, vin);
         }
+        v = cvt<K, KS>(vin);
     }
     if (tid == MWP_ET) { stx<K>(S.us, MWP_N + 1, 0, from_double<K>(1.0)); *S.flag = 1; }
     MwpFetch<K> F;
@@ -299,10 +303,10 @@ __device__ __forceinline__ bool mwp_run(const MwPipeMat &m, int role, unsigned e
         if (live && i == c) {
             const mw<K> sk = ldx<K>(S.us, MWP_N + 1, c), f = rsqrt<K>(mul<K>(sk, v)), r = mul<K>(f, sk);
             stx<K>(S.fs, MWP_N, cc, f);
-            stx<K>(m.rd, m.rdplane, c, r);
+            stx<KS>(m.rd, m.rdplane, c, cvt<KS, K>(r));
         }
         __syncthreads();
-        if (!loader && c < c1 && i < n) stx<K>(m.L, m.lplane, i + (long)c * m.l_ld, i >= c ? mul<K>(v, ldx<K>(S.fs, MWP_N, cc)) : zero<K>());
+        if (!loader && c < c1 && i < n) stx<KS>(m.L, m.lplane, i + (long)c * m.l_ld, i >= c ? cvt<KS, K>(mul<K>(v, ldx<K>(S.fs, MWP_N, cc))) : zero<KS>());
     } else {
         if (tid < n) {                                                       // (every W workgroup needs every f_i: n reciprocal square roots side by side)
             const mw<K> sk = ldx<K>(S.us, MWP_N + 1, tid), dt = ldx<K>(S.dd, MWP_N, tid), f = rsqrt<K>(mul<K>(sk, dt));
@@ -310,7 +314,7 @@ __device__ __forceinline__ bool mwp_run(const MwPipeMat &m, int role, unsigned e
             stx<K>(S.rs, MWP_N, tid, mul<K>(f, sk));
         }
         __syncthreads();
-        if (!loader && c < n && i < n) stx<K>(m.Inv, m.invplane, i + (long)c * m.inv_ld, i > c ? mul<K>(v, ldx<K>(S.fs, MWP_N, i)) : i == c ? ldx<K>(S.rs, MWP_N, i) : zero<K>());
+        if (!loader && c < n && i < n) stx<KS>(m.Inv, m.invplane, i + (long)c * m.inv_ld, cvt<KS, K>(i > c ? mul<K>(v, ldx<K>(S.fs, MWP_N, i)) : i == c ? ldx<K>(S.rs, MWP_N, i) : zero<K>()));
     }
 #ifdef CLRS_MW_STAMPS
     if (stamps && tid == 0) stamps[38] = wall_clock64();
@@ -348,7 +352,8 @@ __global__ __launch_bounds__(MWP_NT) void k_mw_factor_pipe(const MwDev q, unsign
     m.pc = q.pipe_pc + (long)j * MWP_PC_WORDS(K);
     m.fail_code = j + 1;
     m.stamps = j == 0 && q.pipe_stamps ? q.pipe_stamps : nullptr;
-    mwp_run<K>(m, role, epoch, &q.info[0], threadIdx.x);
+    if constexpr (mw_kf_of(K) < K) { if (q.kf < K) { mwp_run<K, mw_kf_of(K)>(m, role, epoch, &q.info[0], threadIdx.x); return; } }
+    mwp_run<K, K>(m, role, epoch, &q.info[0], threadIdx.x);
 }
 
 // L_Q = chol(Q), Q = the sum of the ranks' partial sums, and L_Q^-1: the blocks 0, 8, 16, ... of the first 64 (one XCD); the blocks from 64 on carry the
@@ -373,7 +378,8 @@ __global__ __launch_bounds__(MWP_NT) void k_mw_potrf_q_pipe(const MwDev q, unsig
     m.pc = q.pipe_pc + (long)q.pipe_q * MWP_PC_WORDS(K);
     m.fail_code = q.J + 1;
     m.stamps = q.pipe_stamps ? q.pipe_stamps + 8 * 40 : nullptr;
-    mwp_run<K>(m, role, epoch, &q.info[0], threadIdx.x);
+    if constexpr (mw_kf_of(K) < K) { if (q.kf < K) { mwp_run<K, mw_kf_of(K)>(m, role, epoch, &q.info[0], threadIdx.x); return; } }
+    mwp_run<K, K>(m, role, epoch, &q.info[0], threadIdx.x);
 }
 
 // The diagonal block of one block column of the blocked factorisation (k_mw_bp_diag's work: Cholesky of the MW_PB x MW_PB block at (j0, j0) of every matrix
@@ -416,7 +422,7 @@ __global__ __launch_bounds__(MWP_NT) void k_mw_bp_diag_pipe(const MwDev q, const
     m.pc = q.pipe_pc + (long)(q.pipe_bp + b.slot) * MWP_PC_WORDS(K);
     m.fail_code = b.code;
     m.stamps = nullptr;
-    mwp_run<K>(m, role, epoch, &q.info[b.which], threadIdx.x);
+    mwp_run<K, K>(m, role, epoch, &q.info[b.which], threadIdx.x);      // (the blocked path keeps all K limbs)
 }
 
 #endif

@@ -83,8 +83,12 @@ class MwSchurContext:
     """Device context of the hot path for one SDP at `limbs` words per number (see module docstring)."""
 
     def __init__(self, sdp, limbs: int = 4, device: int = 0, timing: bool = False, data_limbs: int = 2, exact_products: Optional[bool] = None,
-                 refine: Optional[int] = None, pipeline=None, refine_predictor: Optional[bool] = None):
-        """`exact_products`: the pairing matrices through exact slice products on the matrix cores (k_mws_pair, csrc/clrs_mw_exact.hip.h):
+                 refine: Optional[int] = None, pipeline=None, refine_predictor: Optional[bool] = None, factor_limbs: Optional[int] = None):
+        """`factor_limbs`: mixed-precision iterative refinement (csrc/clrs_mw_kernels.hip.h::mw_kf_of) -- limbs of the factor stage and of the solve
+        stage's inverse-factor products, the residuals of the refinement step and the solution keep all `limbs`: None / 0 = automatic (`limbs - 1` for
+        5 and 6 limbs inside `solvesdp_mw` while the measured first-pass accuracy allows, all limbs in `factor()` / `solve()`), `limbs` = never reduce,
+        `limbs - 1` = reduced in `factor()` / `solve()` too.
+        `exact_products`: the pairing matrices through exact slice products on the matrix cores (k_mws_pair, csrc/clrs_mw_exact.hip.h):
         None = automatic (contexts with >= 256 eligible PSD blocks), True = always, False = never.
         `refine`: iterative refinement of the solve stage (k_mw_refine): None = the library default (one step), 0 = none (products with the inverse
         factors only), 1 = the default, 2 = one step with the correction in fewer limbs (cheaper; as good while twice the lost bits fit in them).
@@ -128,7 +132,8 @@ class MwSchurContext:
             setattr(d, name, _dp(data(name)))
         h = C.c_void_p()
         opts = _lib.MwOptions(-1 if exact_products is None else (2 if exact_products else 0), -1 if refine is None else int(refine),
-                              -1 if pipeline is None else (2 if pipeline is True else int(pipeline)), -1 if refine_predictor is None else int(bool(refine_predictor)))
+                              -1 if pipeline is None else (2 if pipeline is True else int(pipeline)), -1 if refine_predictor is None else int(bool(refine_predictor)),
+                              -1 if factor_limbs is None else int(factor_limbs))
         _lib.check(self.L.clrs_mw_create_opts(C.byref(d), self.data_limbs, int(device), self.limbs, C.byref(opts), C.byref(h)))
         self.h = h
         self.device = device
@@ -349,8 +354,10 @@ def solvesdp_mw(sdp, limbs: Optional[int] = None, prec: Optional[int] = None, ct
                 dual_error_threshold: float = 1e-30, primal_error_threshold: float = 1e-30, max_complementary_gap: float = 1e100,
                 need_dual_feasible: bool = False, need_primal_feasible: bool = False, verbose: bool = False,
                 step_length_threshold: float = 1e-7, safe_step: bool = True, step_by_step: bool = False, shard_info: Optional[dict] = None,
-                dualsol=None, primalsol=None):
+                dualsol=None, primalsol=None, factor_limbs: Optional[int] = None):
     """`solvesdp(sdp; prec, ...)` (src/solver.jl:71-127) with the whole loop body on the GPU in multi-word fp64.
+    `factor_limbs`: see `MwSchurContext` (ignored when `ctx` is given); `timings["refine_bits"]` of the result lists, per iteration, the bits the first
+    pass of the corrector's refined solve was good to.
 
     Keywords and DEFAULTS are the reference's (omega = 1e10, gap 1e-15, errors 1e-30: they assume its 256-bit arithmetic):
     `prec` bits select the limb count (`limbs_for_precision`), or pass `limbs` directly; the default is limbs = 5, which
@@ -367,7 +374,7 @@ def solvesdp_mw(sdp, limbs: Optional[int] = None, prec: Optional[int] = None, ct
         limbs = limbs_for_precision(prec) if prec is not None else 5
     own_ctx = ctx is None
     if ctx is None:
-        ctx = MwSchurContext(f, limbs=limbs, device=device, data_limbs=data_limbs)
+        ctx = MwSchurContext(f, limbs=limbs, device=device, data_limbs=data_limbs, factor_limbs=factor_limbs)
     K = ctx.limbs
     L = ctx.L
     keep = [ctx._data("C"), ctx._data("c"), ctx._data("b") if f.n_free else np.zeros((ctx.data_limbs, 1))]
@@ -399,6 +406,7 @@ def solvesdp_mw(sdp, limbs: Optional[int] = None, prec: Optional[int] = None, ct
         _lib.check(L.clrs_mw_ipm_set(ctx.h, _dp(ws[0]), _dp(ws[1]) if f.n_free else None, _dp(ws[2]), _dp(ws[3])))
     rec = _lib.IpmRecord()
     hist = []
+    refine_bits = []
     t_start = time.time()
     error_code, it = 0, 1
     dual_error = primal_error = np.inf      # computed by the first iteration; no termination test can pass before
@@ -424,6 +432,7 @@ def solvesdp_mw(sdp, limbs: Optional[int] = None, prec: Optional[int] = None, ct
         for i in range(n_it.value):
             r = recs[i]
             hist.append(row(r))
+            refine_bits.append(int(r.refine_bits))
             dual_error, primal_error, pd_feas = r.dual_error, r.primal_error, bool(r.pd_feas)
             if r.error_code:
                 break
@@ -443,6 +452,7 @@ def solvesdp_mw(sdp, limbs: Optional[int] = None, prec: Optional[int] = None, ct
                 break
             _lib.check(L.clrs_mw_ipm_iterate(ctx.h, C.byref(rec)))
             hist.append(row(rec))
+            refine_bits.append(int(rec.refine_bits))
             if verbose:
                 print("%5d %8.1f %11.3e %11.3e %11.3e %10.2e %10.2e %10.2e %10.2e %10.2e %10.2e %10.2e" %
                       (it, time.time() - t_start, rec.mu, d_obj, p_obj, gap, rec.max_P, rec.max_p, rec.max_d, rec.alpha_d, rec.alpha_p, rec.beta_c))
@@ -477,4 +487,5 @@ def solvesdp_mw(sdp, limbs: Optional[int] = None, prec: Optional[int] = None, ct
     res = SolveResult(status, x, X, y[:, :f.n_free], Y, t_total, error_code, it - 1, d_obj, p_obj, gap, dual_error, primal_error,
                       np.array(hist).reshape(-1, 11), dict(loop="device", limbs=K))
     res.timings["objectives_limbs"] = obj.reshape(3, K)
+    res.timings["refine_bits"] = refine_bits
     return res

@@ -177,7 +177,10 @@ typedef struct clrs_ipm_params {   /* keyword arguments of solvesdp, src/solver.
     int32_t safe_step, reserved;
 } clrs_ipm_params;
 typedef struct clrs_ipm_record {   /* one row of the reference's iteration table (:566-582) + status */
-    int32_t iter, pd_feas, error_code, factor_status, cholesky_status, reserved;
+    int32_t iter, pd_feas, error_code, factor_status, cholesky_status;
+    int32_t refine_bits;   /* clrs_mw_ipm_*: bits the FIRST pass of the corrector's refined solve was good to, -log2(max|correction| / max|solution|) over dx and dy
+                            * (0: no refinement step ran).  With factors in fewer limbs (clrs_mw_options.factor_limbs) the library returns to all limbs when this
+                            * falls below one limb plus a margin */
     double mu, d_obj, p_obj, gap, dual_error, primal_error, alpha_d, alpha_p, beta_c, max_P, max_p, max_d;
 } clrs_ipm_record;
 int clrs_ipm_create(clrs_ctx *ctx, const clrs_ipm_data *data);
@@ -299,7 +302,12 @@ typedef struct clrs_mw_options {
     int32_t refine;
     int32_t pipeline;        /* factorisations of matrices of at most 32 rows as a pipeline of workgroups: 0 never / 1 the clusters' S_j (default) / 2 and Q */
     int32_t refine_predictor; /* clrs_mw_ipm_*: 0 (default) the predictor's solve is one pass of products, the corrector's is refined; 1 both are refined */
-    int32_t reserved[4];
+    int32_t factor_limbs;    /* Mixed-precision iterative refinement: limbs of the FACTOR stage (L_j, L_j^-1, L^-1 B, Q, L_Q, L_Q^-1) and of the inverse-factor products of
+                              * the solve stage; the residuals of the refinement step, S_j itself and the solution carry all `limbs`.  0 (default) = automatic: inside
+                              * clrs_mw_ipm_* limbs - 1 for limbs = 5, 6 on the LDS-resident paths, while the measured first-pass accuracy (clrs_ipm_record.refine_bits)
+                              * stays above one limb plus a margin, then all limbs; the stand-alone entry points (clrs_mw_schur_factor / _solve) use all limbs.
+                              * `limbs` = never reduce; limbs - 1 (5, 6 limbs) = the reduced count in the stand-alone entry points as well */
+    int32_t reserved[3];
 } clrs_mw_options;
 int clrs_mw_create_opts(const clrs_sdp_desc *desc, int data_limbs, int device, int limbs, const clrs_mw_options *opts, clrs_mw_ctx **out);
 void clrs_mw_destroy(clrs_mw_ctx *ctx);

@@ -321,7 +321,7 @@ struct IpmRecord
     error_code::Int32
     factor_status::Int32
     cholesky_status::Int32
-    reserved::Int32
+    refine_bits::Int32
     mu::Float64
     d_obj::Float64
     p_obj::Float64
