@@ -69,6 +69,7 @@ int g_cfg_mw_stream_words = 1;        // multi-word interior-point iteration: it
 int g_cfg_mw_pipeline = 1;            // multi-word path: Cholesky + inverse factor of matrices <= 32 rows as a pipeline of workgroups (clrs_mw_pipe.hip.h); 0: one workgroup chain per matrix
 int g_cfg_mw_refine_predictor = 0;    // multi-word interior-point iteration: 1 = the PREDICTOR's solve takes the refinement step too (default: the corrector's only -- the predictor's direction sets beta_c and the second-order term, nothing that moves the iterate)
 int g_cfg_mw_refine = 1;              // multi-word path: one step of iterative refinement of the solve stage (k_mw_refine); 0: products with the inverse factors only; 2: the correction in fewer limbs
+int g_cfg_mw_affine_corrector = 1;    // multi-word interior-point iteration: the corrector's right-hand side as rhs0 + mu_c tau, with beta_c / mu_c formed on the side stream beside Z0 and its traces (clrs_mw_ipm_host.inc); 0: the corrector waits for mu_c
 int g_cfg_mw_factor_limbs = 0;        // multi-word path: limbs of the factor stage and of the solve stage's products (mixed-precision refinement, clrs_mw_kernels.hip.h::mw_kf_of): 0 = automatic (reduced inside clrs_mw_ipm_* while the measured contraction allows, all limbs in the stand-alone entry points); a limb count = that count everywhere
 int g_cfg_mw_exact_products = 1;      // multi-word path: pairing matrices through exact slice products on the matrix cores (k_mws_pair): 0 never, 1 when >= 256 blocks are eligible (one per compute unit: below, the chip is not full and the latency-oriented kernels win), 2 always
 static int g_cfg_solve_small2 = 1;     // one-workgroup solve stage with all loads up front and single-wave triangular solves (0: k_solve_small)
@@ -2460,6 +2461,7 @@ extern "C" int clrs_config_set(const char *key, int value) {
     if (!std::strcmp(key, "mw_exact_products")) { g_cfg_mw_exact_products = value; return 0; }
     if (!std::strcmp(key, "mw_refine")) { g_cfg_mw_refine = value; return 0; }
     if (!std::strcmp(key, "mw_factor_limbs")) { g_cfg_mw_factor_limbs = value; return 0; }
+    if (!std::strcmp(key, "mw_affine_corrector")) { g_cfg_mw_affine_corrector = value; return 0; }
     if (!std::strcmp(key, "mw_pipeline")) { g_cfg_mw_pipeline = value; return 0; }
     if (!std::strcmp(key, "mw_stream_words")) { g_cfg_mw_stream_words = value; return 0; }
     if (!std::strcmp(key, "mw_refine_predictor")) { g_cfg_mw_refine_predictor = value; return 0; }

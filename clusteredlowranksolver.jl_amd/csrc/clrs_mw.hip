@@ -42,6 +42,7 @@ extern int g_cfg_mw_pipeline;                            // clrs_hip.hip, clrs_c
 extern int g_cfg_mw_refine_predictor;                    // clrs_hip.hip, clrs_config_set("mw_refine_predictor", 0 / 1)
 extern int g_cfg_mw_refine;                              // clrs_hip.hip, clrs_config_set("mw_refine", 0 / 1): read at context creation
 extern int g_cfg_mw_exact_products;                      // clrs_hip.hip, clrs_config_set("mw_exact_products", 0 / 1 / 2): read at context creation
+extern int g_cfg_mw_affine_corrector;                    // clrs_hip.hip, clrs_config_set("mw_affine_corrector", 0 / 1): read by clrs_mw_ipm_create
 extern int g_cfg_mw_factor_limbs;                        // clrs_hip.hip, clrs_config_set("mw_factor_limbs", 0 / limbs): read at context creation
 extern "C" void clrs_set_last_error(const char *msg);   // clrs_hip.hip: the library keeps one thread-local message
 
@@ -258,7 +259,14 @@ extern "C" int clrs_mw_create_opts(const clrs_sdp_desc *d, int data_limbs, int d
     int rc = 0;
 #define MW_BAIL(code, msg) do { clrs_mw_destroy(c); return mw_fail(code, msg); } while (0)
 #define MW_TRY(call) do { if ((rc = (call))) { clrs_mw_destroy(c); return rc; } } while (0)
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) MW_BAIL(CLRS_ERR_HIP, "hipStreamCreateWithFlags failed");
+    {   // The context's stream at the HIGHEST priority, the side stream of the interior-point iteration (clrs_mw_ipm_host.inc) at the default one: the runtime
+        // maps streams onto a few hardware queues PER PRIORITY (GPU_MAX_HW_QUEUES, 4 by default), and two streams of one iteration that land on one queue run
+        // its packets in submission order -- measured: the second context of a process, whose side stream shared a queue, 0.58 ms per iteration against
+        // 0.45 (profiles/r05).  Different priorities never share; and the main stream carries the longest chain of the iteration.
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { least = greatest = 0; (void)hipGetLastError(); }
+        if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, greatest) != hipSuccess) MW_BAIL(CLRS_ERR_HIP, "hipStreamCreateWithPriority failed");
+    }
     if (hipHostMalloc((void **)&c->h_info, 2 * sizeof(int), hipHostMallocDefault) != hipSuccess) MW_BAIL(CLRS_ERR_HIP, "hipHostMalloc failed");
     // ---- clusters ----
     c->clu.resize(J);
@@ -731,6 +739,8 @@ extern "C" int clrs_mw_create_opts(const clrs_sdp_desc *d, int data_limbs, int d
     MW_TRY(mw_dmalloc(c, &q.Xf, xyoff * K)); MW_TRY(mw_dmalloc(c, &q.Xb, xyoff * K)); MW_TRY(mw_dmalloc(c, &q.Xi, xyoff * K));
     MW_TRY(mw_dmalloc(c, &q.xrd, rdoff * K)); MW_TRY(mw_dmalloc(c, &q.srd, xlen * K)); MW_TRY(mw_dmalloc(c, &q.qrd, (i64)N * K));
     MW_TRY(mw_dmalloc(c, &q.t, xlen * K)); MW_TRY(mw_dmalloc(c, &q.u, (i64)J * N * K)); MW_TRY(mw_dmalloc(c, &q.AY, T * K));
+    q.AX = nullptr;                      // (the interior-point iteration asks for it: clrs_mw_ipm_create)
+    q.aff_mu = q.aff_rhs = q.aff_t = q.aff_u = nullptr; q.aff_wait = nullptr; q.ride2_rhs = nullptr; q.ride2_t = q.ride2_u = nullptr;
     MW_TRY(mw_dmalloc(c, &c->vz, 2 * (i64)N * K));
     MW_TRY(mw_dmalloc(c, &q.S0, Slen * K)); MW_TRY(mw_dmalloc(c, &q.ub, (i64)J * N * K));
     MW_TRY(mw_dmalloc(c, &q.rx2, xlen * K)); MW_TRY(mw_dmalloc(c, &q.dx2, xlen * K));
@@ -1230,13 +1240,13 @@ extern "C" int clrs_mw_schur_factor_finish_dev(clrs_mw_ctx *c) {
     if (q.N > 0 && c->pipe_Q) {
         const bool ride = c->ride_fwd != nullptr && !c->wide_solve;
         c->pipe_epoch = (c->pipe_epoch + 1) & 0x3ffffff;
-        MW_DISPATCH(c, { hipLaunchKernelGGL(k_mw_potrf_q_pipe<KK>, dim3(64 + (ride ? q.J : 0)), dim3(MWP_NT), std::max<size_t>(MWP_LDS_ALONE, ride ? c->sm_fwd : 0),
+        MW_DISPATCH(c, { hipLaunchKernelGGL(k_mw_potrf_q_pipe<KK>, dim3(64 + (ride ? q.J * (q.ride2_rhs ? 2 : 1) : 0)), dim3(MWP_NT), std::max<size_t>(MWP_LDS_ALONE, ride ? c->sm_fwd : 0),
                                             c->stream, q, c->pipe_epoch, c->ride_fwd, ride ? c->ride_wait : (const int *)nullptr, c->ride_wait_value); });
         c->fwd_rode = ride;
     } else if (q.N > 0 && c->lds_q) {
         // the interior-point iteration hands over the right-hand side of its next solve: the solve's first product pair rides on this launch
         const bool ride = c->ride_fwd != nullptr && !c->wide_solve;
-        MW_DISPATCH(c, { hipLaunchKernelGGL(k_mw_potrf_q<KK>, dim3(MW_INV_WG + (ride ? q.J : 0)), dim3(MW_PT), ride ? std::max(c->sm_q, c->sm_fwd) : c->sm_q, c->stream, q, MW_INV_WG, c->ride_fwd, ride ? c->ride_wait : (const int *)nullptr, c->ride_wait_value); });
+        MW_DISPATCH(c, { hipLaunchKernelGGL(k_mw_potrf_q<KK>, dim3(MW_INV_WG + (ride ? q.J * (q.ride2_rhs ? 2 : 1) : 0)), dim3(MW_PT), ride ? std::max(c->sm_q, c->sm_fwd) : c->sm_q, c->stream, q, MW_INV_WG, c->ride_fwd, ride ? c->ride_wait : (const int *)nullptr, c->ride_wait_value); });
         c->fwd_rode = ride;
     } else if (q.N > 0) {
         MW_DISPATCH(c, { hipLaunchKernelGGL(k_mw_qsum<KK>, dim3((unsigned)std::min<i64>(256, ((i64)q.N * q.N + MW_NT - 1) / MW_NT)), dim3(MW_NT), 0, c->stream, q); });

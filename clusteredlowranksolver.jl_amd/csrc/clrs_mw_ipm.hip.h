@@ -31,7 +31,9 @@ struct MwIpmDev {
     int *wcnt;                         // [2 NB] workgroups of a (block, which) that have delivered their panel
     double *rec;                       // fp64 record of the iteration
     int *flags;                        // [0] pd_feas, [1] error_code, [2] Cholesky failure inside the step length
-    int *sync;                         // [0] the number of the last iteration whose side-stream work (everything the predictor's solve reads) is complete (k_mwi_mark)
+    double *tau, *ttau, *utau;         // the corrector's right-hand side is affine in mu_c (mw_ipm_enqueue): tau_g = <A_g, X^-1> (xlen; k_mwi_rows mode 0 forms it beside d),
+                                       // t_tau = Si tau (xlen), u_tau = LB^T t_tau (J x N slabs; both ride on the Cholesky of Q); null: the corrector waits for mu_c
+    int *sync;                         // [3] "the dot products behind the predictor are complete" (stored by the corrector's first launch), [4] "mu_c is there" (side stream); [0] the number of the last iteration whose side-stream work (everything the predictor's solve reads) is complete (k_mwi_mark)
     const double *C, *c, *b;           // problem data, DK limbs planar (sdp.C xy layout, sdp.c x layout, sdp.b [N])
     const int *row_clu;                // [xlen] cluster of each constraint row
     double sgn, constant;
@@ -768,6 +770,11 @@ __device__ __forceinline__ void mwi_rows_body(const MwDev &q, const MwIpmDev &p,
     // every lane accumulates its share of  -(trace term) [- (B y)_g] ; the lanes are summed at the end
     acc<K> s;
     acc_zero<K>(s);
+    // mode 0 with p.tau: tau_g = <A_g, X^-1> beside d_g -- the same sums with the pairings w^T X^-1 v of the assembly (q.AX) in place of w^T Y v: what mu_c
+    // multiplies in the corrector's right-hand side (Z = sym(X^-1 (P Y - R)) = Z0 - mu_c X^-1, rhs_x = -d - <A, Z>)
+    const bool with_tau = mode == 0 && p.tau != nullptr && q.AX != nullptr;
+    acc<K> st;
+    acc_zero<K>(st);
     for (int b = cl.b0 + grp; b < cl.b1; b += BG) {
         const MwBlk &k = q.blk[b];
         const int n = k.n;
@@ -779,6 +786,7 @@ __device__ __forceinline__ void mwi_rows_body(const MwDev &q, const MwIpmDev &p,
                     if (!(fl & 1)) continue;                                           // s <= r (:1310)
                     const mw<DK> w = mul_pow2<DK>(ldx<DK>(q.st_lam, q.lamp, t), (fl & 2) ? 2.0 : 1.0);      // off-diagonal sub-blocks count twice (:1354-1356)
                     acc_fma<K, K, DK>(s, ldx<K>(q.AY, q.T, q.st_orig[t]), w, -1.0);     // trace_A with (Y, A_Y), :1368-1407
+                    if (with_tau) acc_fma<K, K, DK>(st, ldx<K>(q.AX, q.T, q.st_orig[t]), w);
                 }
             } else {
                 const double *V = q.V + k.v_off;
@@ -798,6 +806,10 @@ __device__ __forceinline__ void mwi_rows_body(const MwDev &q, const MwIpmDev &p,
             if (en >= 0) {
                 const long nn = (long)n * n;
                 for (long i = sub; i < nn; i += MWI_RW) acc_fma<K, K, DK>(s, ldx<K>(M + k.xyoff, q.xylen, i), ldx<DK>(q.dA, q.dAp, k.a_off + en * nn + i), -1.0);
+                if (with_tau && sub == 0) {                                              // (1 x 1 dense blocks only: the host asks for tau only then) X^-1 = Xi^2
+                    const mw<K> xi = ldx<K>(q.Xi + k.xyoff, q.xylen, 0);
+                    acc_fma<K, K, DK>(st, mul<K>(xi, xi), ldx<DK>(q.dA, q.dAp, k.a_off + en * nn));
+                }
             }
         }
     }
@@ -809,6 +821,10 @@ __device__ __forceinline__ void mwi_rows_body(const MwDev &q, const MwIpmDev &p,
         if (live && sub_all == 0) {
             atomic_max_abs(&p.fmax[1], dv.l[0]);
             stx<K>(p.d, q.xlen, g, dv);
+        }
+        if (with_tau) {
+            const mw<K> tv = lanes_sum<K, RWT>(acc_result<K>(st));
+            if (live && sub_all == 0) stx<K>(p.tau, q.xlen, g, tv);
         }
     } else {
         if (sub_all == 0) acc_add<K, K>(s, ldx<K>(p.d, q.xlen, g), -1.0);
@@ -1010,6 +1026,9 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_Z(const MwDev q, const MwIpmDev p
 template <int K>
 __global__ __launch_bounds__(MW_PT) void k_mwi_Zi(const MwDev q, const MwIpmDev p, int which) {
     using namespace mwk;
+    mw_mark(q);
+    const bool nomu = which == 2;                        // which 2: which 0 without the mu_s I of R (the corrector's Z0: mw_ipm_enqueue adds mu_c <A, X^-1> to the traces instead)
+    if (nomu) which = 0;
     const MwBlk &k = q.blk[blockIdx.x];
     if (!k.inv) return;
     const int n = k.n, tid = threadIdx.x, sub = tid % MWI_ZL;
@@ -1034,7 +1053,7 @@ __global__ __launch_bounds__(MW_PT) void k_mwi_Zi(const MwDev q, const MwIpmDev 
         acc_zero<K>(s);
         for (int kk = sub; kk < n; kk += MWI_ZL) acc_fma<K, K, K>(s, ldx<K>(A, q.xylen, i + (long)kk * n), ldx<K>(p.Y + k.xyoff, q.xylen, kk + (long)c * n), sg);
         if (sub == 0) acc_add<K, K>(s, ldx<K>(p.R + k.xyoff, q.xylen, i + (long)c * n), -sg);
-        if (sub == 1 && i == c) acc_add<K, K>(s, ldx<K>(p.sc, MSC_COUNT, MSC_MUS), -sg);      // R = mu_s I + R'
+        if (sub == 1 && i == c && !nomu) acc_add<K, K>(s, ldx<K>(p.sc, MSC_COUNT, MSC_MUS), -sg);      // R = mu_s I + R'
         const mw<K> v = lanes_sum<K, MWI_ZL>(acc_result<K>(s));
         if (live && sub == 0) stx<K>(M, np, ee, v);
     }

@@ -95,6 +95,16 @@ struct MwDev {
     unsigned long long *pipe_stamps;    // diagnostic builds: [16][40] step stamps of the pipelined factorisations (clrs_mw_debug_pipe_stamps), or null
     unsigned long long *pipe_pc;        // hand-off granules of the pipelined factorisations (clrs_mw_pipe.hip.h): [J + 1][MWP_PC_WORDS], or null
     double *ub;                         // u' slabs of the refinement step (J x N; k_mw_solve_bwd MODE 1 writes them while other workgroups read u)
+    // A right-hand side that is AFFINE in a scalar known late (the corrector of the interior-point iteration: rhs_x = rhs0 + mu_c tau, clrs_mw_ipm_host.inc): the
+    // forward half ran on rhs0 (q.t, q.u) and, once per iteration, on tau (aff_t, aff_u); k_mw_solve_bwd MODE 1 waits for aff_wait >= aff_wait_value, reads
+    // the K-limb scalar at aff_mu (planar, plane aff_mu_plane) and uses t + mu aff_t, u_j + mu aff_u_j, rhs_x + mu aff_rhs wherever it reads t, u_j, rhs_x.  null: off
+    const double *aff_mu, *aff_rhs, *aff_t, *aff_u;
+    const int *aff_wait;
+    int aff_wait_value, aff_mu_plane;
+    // a second right-hand side whose forward half rides on the launch of k_mw_potrf_q behind the first one's (workgroups nq + J ..): t = Si rhs into ride2_t, u_j into ride2_u
+    const double *ride2_rhs;
+    double *ride2_t, *ride2_u;
+    double *AX;                         // per-term pairings w^T X^-1 v, beside AY (k_mw_saccum[_one]); null: not kept
     unsigned long long *refstat;        // bit patterns of non-negative doubles, atomicMax'ed by the correction's backward half (MODE 2): [0] max|dx'|, [1] max|dx|, [2] max|dy'|, [3] max|dy|
     double *rx2, *u2, *dx2, *dy2;
     const double *uadd;
@@ -863,6 +873,7 @@ __global__ __launch_bounds__(MW_NT) void k_mw_saccum(const MwDev q, int lanes) {
             if (b < 0) continue;
             const MwBlk &k = q.blk[b];
             stx<K>(q.AY, q.T, t, ldx<K>(q.GY + k.g_off, q.glen, q.ay_a[t] + (long)q.ay_b[t] * k.U));
+            if (q.AX) stx<K>(q.AX, q.T, t, ldx<K>(q.GX + k.g_off, q.glen, q.ay_a[t] + (long)q.ay_b[t] * k.U));
         }
     }
     if (lanes == 1) mw_saccum_body<K, DK, 1>(q);
@@ -890,8 +901,10 @@ __global__ __launch_bounds__(MW_NT) void k_mw_saccum_one(const MwDev q, int do_a
             const MwBlk &k = q.blk[b];
             if (k.kind != 0) continue;
             const int *tp = q.tptr + k.tptr_off;
-            for (int t = tp[0] + e; t < tp[P]; t += gridDim.x * MW_NT)
+            for (int t = tp[0] + e; t < tp[P]; t += gridDim.x * MW_NT) {
                 stx<K>(q.AY, q.T, t, ldx<K>(q.GY + k.g_off, q.glen, q.ay_a[t] + (long)q.ay_b[t] * k.U));
+                if (q.AX) stx<K>(q.AX, q.T, t, ldx<K>(q.GX + k.g_off, q.glen, q.ay_a[t] + (long)q.ay_b[t] * k.U));
+            }
         }
     }
     if (e >= P * (P + 1) / 2) return;
@@ -1152,7 +1165,11 @@ __global__ __launch_bounds__(MW_PT) void k_mw_potrf_q(const MwDev q, int nq, con
     // side comes from another stream: they wait for its mark here (wait_word), not the whole launch in front of an event
     if ((int)blockIdx.x >= nq) {
         if (wait_word) mw_wait_word(wait_word, wait_value, &q.info[0], q.J + 1);
-        mw_solve_fwd_cluster<K>(q, blockIdx.x - nq, fwd_rhs);
+        if ((int)blockIdx.x >= nq + q.J) {           // the second right-hand side (MwDev::ride2_rhs)
+            MwDev q2 = q;
+            q2.t = q.ride2_t; q2.u = q.ride2_u;
+            mw_solve_fwd_cluster<K>(q2, blockIdx.x - nq - q.J, q.ride2_rhs);
+        } else mw_solve_fwd_cluster<K>(q, blockIdx.x - nq, fwd_rhs);
         return;
     }
     if (q.info[0] != MW_INFO_NONE) return;           // a cluster failed: the reference throws before reaching Q
@@ -1434,7 +1451,7 @@ __host__ __device__ constexpr int mw_kc(int K) { return K <= 3 ? K : K <= 6 ? 3 
 // dy = Q^-1 (rhs_y - sum_j u_j) into v (LDS, plane N; y: N more numbers of scratch).  The difference in K limbs (with the u_j of the refinement it
 // cancels to the size of the residual), the two products with the explicit inverse of L_Q in KC.
 template <int K, int KC>
-__device__ __forceinline__ void mw_solve_mid_body(const MwDev &q, const double *__restrict__ rhs_y, mwk::lds_d *v, mwk::lds_d *y, int tid) {
+__device__ __forceinline__ void mw_solve_mid_body(const MwDev &q, const double *__restrict__ rhs_y, mwk::lds_d *v, mwk::lds_d *y, int tid, const mwa::mw<K> *aff_mu = nullptr) {
     using namespace mwk;
     const int N = q.N;
     const long lplane = (long)N * N;
@@ -1446,6 +1463,7 @@ __device__ __forceinline__ void mw_solve_mid_body(const MwDev &q, const double *
             for (int r = 0; r < q.world; r++) acc_add<K, K>(s, ldx<K>(q.ug + (long)r * K * N, N, a), -1.0);
         } else {
             for (int j = 0; j < q.J; j++) acc_add<K, K>(s, ldx<K>(q.u, (long)q.J * N, (long)j * N + a), -1.0);
+            if (aff_mu) for (int j = 0; j < q.J; j++) acc_fma<K, K, K>(s, ldx<K>(q.aff_u, (long)q.J * N, (long)j * N + a), *aff_mu, -1.0);
             if (q.uadd) acc_add<K, K>(s, ldx<K>(q.uadd, N, a), -1.0);
         }
         stx<K>(v, N, a, acc_result<K>(s));
@@ -1491,8 +1509,15 @@ __device__ __forceinline__ void mw_solve_bwd_body(const MwDev &q, const double *
     lds_d *dyl = MW_LDS, *w = MW_LDS + 2L * K * N, *w2 = w + (long)K * P, *w3 = w2 + (long)K * P;
     const long plane = q.xlen * (long)N;
     const int sub = tid % MW_S_W;
+    // MODE 1 with a right-hand side affine in a scalar that another stream produces (MwDev::aff_mu): wait for it here, behind the launch, then read it
+    const bool aff = MODE == 1 && q.aff_mu != nullptr;
+    mw<K> amu = zero<K>();
+    if (aff) {
+        if (q.aff_wait) mw_wait_word(q.aff_wait, q.aff_wait_value, &q.info[0], q.J + 1);
+        amu = ldx<K>(q.aff_mu, q.aff_mu_plane, 0);
+    }
     if (mid_rhs_y) {
-        mw_solve_mid_body<K, KB>(q, mid_rhs_y, dyl, dyl + (long)K * N, tid);      // (ends with a barrier)
+        mw_solve_mid_body<K, KB>(q, mid_rhs_y, dyl, dyl + (long)K * N, tid, aff ? &amu : nullptr);      // (ends with a barrier)
     } else if (N > 0) {
         for (int a = tid; a < N; a += MW_NT) {
 #pragma unroll
@@ -1522,6 +1547,7 @@ __device__ __forceinline__ void mw_solve_bwd_body(const MwDev &q, const double *
         acc<KB> s;
         acc_zero<KB>(s);
         if (sub == 0) acc_add<KB, KB>(s, ldx<KB>(q.t, q.xlen, c.coff + rr));
+        if (aff && sub == 1) acc_fma<KB, KB, KB>(s, ldx<KB>(q.aff_t, q.xlen, c.coff + rr), cvt<KB, K>(amu));
         for (int a = sub; a < N; a += MW_S_W) acc_fma<KB, KB, KB>(s, ldx<KB>(q.LB, plane, c.coff + rr + a * q.xlen), ldx<KB>(dyl, N, a));
         mw<KB> v = lanes_sum<KB, MW_S_W>(acc_result<KB>(s));
         if (live && sub == 0) stx<KB>(w, P, r, v);
@@ -1550,6 +1576,7 @@ __device__ __forceinline__ void mw_solve_bwd_body(const MwDev &q, const double *
         acc<K> s;
         acc_zero<K>(s);
         if (sub == 0) acc_add<K, K>(s, ldx<K>(rhs_x, q.xlen, c.coff + rr));
+        if (aff && sub == 1) acc_fma<K, K, K>(s, ldx<K>(q.aff_rhs, q.xlen, c.coff + rr), amu);
         for (int cc = sub; cc < P; cc += MW_S_W) acc_fma<K, K, KB>(s, ldx<K>(S0, q.Slen, cc + (long)rr * P), ldx<KB>(w2, P, cc), -1.0);      // row rr = column rr (symmetric!)
         for (int a = sub; a < N; a += MW_S_W) acc_fma<K, DK, KB>(s, ldx<DK>(q.B, q.Bp, c.coff + rr + a * q.xlen), ldx<KB>(dyl, N, a));
         mw<K> v = lanes_sum<K, MW_S_W>(acc_result<K>(s));

@@ -363,7 +363,11 @@ __global__ __launch_bounds__(MWP_NT) void k_mw_potrf_q_pipe(const MwDev q, unsig
     using namespace mwk;
     if (blockIdx.x >= 64) {
         if (wait_word) mw_wait_word(wait_word, wait_value, &q.info[0], q.J + 1);
-        mw_solve_fwd_cluster<K>(q, blockIdx.x - 64, fwd_rhs);
+        if ((int)blockIdx.x >= 64 + q.J) {           // the second right-hand side (MwDev::ride2_rhs)
+            MwDev q2 = q;
+            q2.t = q.ride2_t; q2.u = q.ride2_u;
+            mw_solve_fwd_cluster<K>(q2, blockIdx.x - 64 - q.J, q.ride2_rhs);
+        } else mw_solve_fwd_cluster<K>(q, blockIdx.x - 64, fwd_rhs);
         return;
     }
     int mtx, role;
