@@ -24,7 +24,11 @@ WHOLE interior-point solve runs sharded: x, X, Y stay on their rank, y and every
 library itself all-gathers (RCCL, two communicators: one per stream that exchanges) the partial Q (limbs x 31 x 31), the partial u
 (limbs x 31, three times: the predictor's solve, the corrector's solve and its refinement step) and three small records (objectives + mu + p = b - B^T x and the primal-residual error; beta_c and the dual-residual error; the step lengths)
 (clrs_mw_comm_init, clrs_mw_comm_init_side, clrs_mw_ipm_set_global).  A step of the N-GPU job = one
-iteration of the 2N-cluster problem = N units of work; `value` = N x iterations/s.
+iteration of the 2N-cluster problem = N units of work; `value` = N x iterations/s.  That number alone would flatter: ONE GPU solves the same
+2N-cluster problem unsharded in little more than the time of the 2-cluster one (the instance is latency bound at two clusters per rank).  So
+rank 0 also times that SAME problem unsharded on its one GPU in the same job and the line carries `multi_gpu.speedup_vs_one_gpu_same_problem`;
+and a second regime -- `--filled-clusters-per-rank` clusters per rank (default 32: a rank's share fills its chip), the same comparison -- is
+measured and reported beside it (`multi_gpu.filled_regime`).  `--clusters-per-rank C` makes C the primary regime's share.
 
 `cpu_baseline`: whole iterations of the same solve in the multi-precision CPU oracle (oracle/mpx.hpp, 256-bit truncation, the stand-in
 for the reference's Arb arithmetic: kind "port") on the host cores; `roofline`: the HBM-bound fp64 Schur-assembly kernel on a
@@ -55,13 +59,47 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def visible_gpus():
+    """GPUs of this node as the kernel driver lists them (KFD topology nodes with SIMDs; CPU nodes have none), narrowed by HIP_VISIBLE_DEVICES /
+    ROCR_VISIBLE_DEVICES when set -- read from sysfs, so that the launcher never initialises HIP in the process that starts the ranks."""
+    n, base = 0, "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        for node in os.listdir(base):
+            try:
+                props = dict(line.split()[:2] for line in open(os.path.join(base, node, "properties")) if len(line.split()) >= 2)
+            except OSError:
+                continue
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+    except OSError:
+        n = 0
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([t for t in v.split(",") if t.strip() != ""]))
+    return n
+
+
+def weak_scaling_instance(world, clusters_per_rank=2):
+    """The problem of the N-rank job: cohnelkies_multi(8, 15) with 2 `world` clusters (the f^ cluster and 2 `world` - 1 sign-constraint clusters at radius
+    scalings 1, 1 + 1/16, ...: with steps of 1/8 the 16-cluster instance ends NearOptimal at 5 limbs, with 1/16 every instance up to eight ranks ends
+    Optimal -- scripts/multi_instances_check.py), its clusters repeated clusters_per_rank / 2 times (identical, redundant constraints: the same optimum;
+    `replicate_clusters`) so that `partition_clusters` hands every rank `clusters_per_rank` clusters."""
+    import clrs_amd
+    from clrs_amd.problems import cohnelkies_multi
+    from clrs_amd.sdp import replicate_clusters
+    if clusters_per_rank < 2 or clusters_per_rank % 2:
+        raise ValueError("clusters per rank: an even number >= 2")
+    full = clrs_amd.flatten(cohnelkies_multi(8, 15, [1.0 + 0.0625 * k for k in range(2 * world - 1)]))
+    return full if clusters_per_rank == 2 else replicate_clusters(full, clusters_per_rank // 2)
+
+
 def launch_ranks(n, cmd=None, check_devices=True):
     """Start n copies of this script (or of `cmd`) as ranks 0..n-1 of one job (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as torch.distributed.run sets them),
     wait for all of them and return the worst exit code; a rank that dies takes the others down instead of leaving them in a collective."""
     import socket
     import subprocess
-    import torch                                   # device_count() does not initialise the GPU (no HIP context is created in this process)
-    have = torch.cuda.device_count() if check_devices else n
+    have = visible_gpus() if check_devices else n   # (from sysfs: nothing in the launcher touches HIP before the ranks exist)
     if have < n:
         log(f"bench.py: --gpus {n} needs {n} GPUs on this node, {have} visible")
         return 2
@@ -102,6 +140,8 @@ def main():
     ap.add_argument("--skip-fp64", action="store_true", help="skip the fp64 measurements (Schur-assembly HBM roofline, fp64 step on the problem's shapes)")
     ap.add_argument("--mw-copies", type=int, default=1024, help="replication factor of the multi-word roofline instance (2 clusters each)")
     ap.add_argument("--split", action="store_true", help="with one GPU: still take the sharded code path (1-rank process group, RCCL all-gathers inside the library)")
+    ap.add_argument("--clusters-per-rank", type=int, default=2, help="N-rank job: clusters a rank holds in the PRIMARY regime (2 = the named problem's share: `value` stays comparable with N = 1)")
+    ap.add_argument("--filled-clusters-per-rank", type=int, default=32, help="N-rank job: clusters per rank of the second regime reported under multi_gpu.filled_regime (0: skip it)")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -150,21 +190,25 @@ def main():
     from clrs_amd.mw import shard_problem
     shard_info = None
     prob = flat
-    if sharded:
-        from clrs_amd.problems import cohnelkies_multi
-        # (radius scalings 1, 1.0625, ...: with steps of 1/8 the 16-cluster instance of eight ranks ends NearOptimal at 5 limbs -- a factorisation fails at
-        # mu = 6e-15 --, with steps of 1/16 every instance up to eight ranks ends Optimal: scripts/multi_instances_check.py)
-        full = clrs_amd.flatten(cohnelkies_multi(8, 15, [1.0 + 0.0625 * k for k in range(2 * world - 1)]))
-        prob, shard_info = shard_problem(full, rank, world)
-        log(f"rank {rank}: clusters {list(shard_info['cluster_ids'])} of {full.n_clusters}")
-    ctx = MwSchurContext(prob, limbs=K, device=local_rank)
-    if sharded:
+    def sharded_context(full_problem):
+        """this rank's share of `full_problem` on a context with the library's two communicators (collective: every rank calls it)"""
+        prob_, info_ = shard_problem(full_problem, rank, world)
+        c_ = MwSchurContext(prob_, limbs=K, device=local_rank)
         ids = torch.zeros(2, 128, dtype=torch.uint8, device=dev)
         if rank == 0:
             ids = torch.tensor([list(MwSchurContext.comm_unique_id()), list(MwSchurContext.comm_unique_id())], dtype=torch.uint8, device=dev)
         dist.broadcast(ids, 0)
-        ctx.comm_init(bytes(ids[0].cpu().tolist()), rank, world)
-        ctx.comm_init_side(bytes(ids[1].cpu().tolist()))
+        c_.comm_init(bytes(ids[0].cpu().tolist()), rank, world)
+        c_.comm_init_side(bytes(ids[1].cpu().tolist()))
+        return prob_, info_, c_
+
+    full = None
+    if sharded:
+        full = weak_scaling_instance(world, args.clusters_per_rank)
+        prob, shard_info, ctx = sharded_context(full)
+        log(f"rank {rank}: clusters {list(shard_info['cluster_ids'])} of {full.n_clusters}")
+    else:
+        ctx = MwSchurContext(prob, limbs=K, device=local_rank)
 
     def solve(**kw):
         return solvesdp_mw(prob, ctx=ctx, shard_info=shard_info, **thr, **kw)
@@ -179,9 +223,9 @@ def main():
         assert r.error_code == 0 and r.status == "Optimal", (r.status, r.error_code)
         assert abs(r.primal_objective - PI4_384) <= 1e-4, r.primal_objective       # test/runtests_solver.jl:19-20
     elif not (r.error_code == 0 and r.status == "Optimal"):
-        # the weak-scaled instances end Optimal unsharded and through the in-process rehearsal of 2, 4 and 8 ranks (profiles/r04/j_*, k_*); a run that does not
-        # is still timed -- its iterations are whole iterations -- and says so in `full_solve`
-        log(f"rank {rank}: WARNING: the sharded solve ended {r.status} (code {r.error_code}) after {r.iterations} iterations")
+        # the weak-scaled instances end Optimal unsharded and through the in-process rehearsal of 2, 4 and 8 ranks (profiles/r04/j_*, k_*): a job whose solve
+        # does not is not a measurement of this workload -- no JSON line, non-zero exit
+        raise SystemExit(f"bench.py: rank {rank}: the sharded solve ended {r.status} (code {r.error_code}) after {r.iterations} iterations: nothing is reported")
     assert n_it > 0 and r_cold.iterations == n_it
     full_solve = {"iterations": n_it, "status": r.status, "error_code": r.error_code, "primal_objective": r.primal_objective, "dual_objective": r.dual_objective,
                   "expected": PI4_384 if not sharded else None, "tolerance": 1e-4, "first_solve_s": t_cold, "solve_s": r.time_total,
@@ -233,19 +277,65 @@ def main():
                  "what": "all-gathers of one sharded iteration: the partial Q once, the partial u three times (the predictor's solve; the corrector's and "
                          "its refinement step's), three scalar records (objectives + <X,Y> + p; beta_c and errors; step lengths), on two communicators (main / side stream); "
                          "the sum is what they cost issued back to back on one stream -- inside the iteration the side stream's one overlaps the factorisations"}
-        if rank == 0:
-            c1 = MwSchurContext(flat, limbs=K, device=local_rank)
-            solvesdp_mw(flat, ctx=c1, **thr)
+        def time_unsharded(problem, steps):
+            """rank 0's one GPU alone on `problem`: (status, iterations per solve, seconds per iteration) over `steps` iterations"""
+            c1 = MwSchurContext(problem, limbs=K, device=local_rank)
+            r1 = solvesdp_mw(problem, ctx=c1, **thr)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             done = 0
-            while done < args.steps:
-                done += solvesdp_mw(flat, ctx=c1, maxiterations=args.steps - done, **thr).iterations
+            while done < steps:
+                done += solvesdp_mw(problem, ctx=c1, maxiterations=steps - done, **thr).iterations
             torch.cuda.synchronize()
             t_single = time.perf_counter() - t1
             c1.close()
-            multi["single_gpu_iterations_per_s_same_job"] = args.steps / t_single
-            multi["single_gpu_ms_per_iteration_same_job"] = 1e3 * t_single / args.steps
+            return r1, t_single / steps
+
+        if rank == 0:
+            r1, s1 = time_unsharded(flat, args.steps)
+            multi["single_gpu_iterations_per_s_named_problem"] = 1.0 / s1
+            multi["single_gpu_ms_per_iteration_named_problem"] = 1e3 * s1
+            # the honest comparison: the SAME problem the N ranks share, unsharded on one GPU
+            r_same, s_same = time_unsharded(full, args.steps)
+            multi["clusters_per_rank"] = args.clusters_per_rank
+            multi["problem_clusters"] = int(full.n_clusters)
+            multi["sharded_ms_per_iteration"] = ms_per_step
+            multi["one_gpu_same_problem"] = {"status": r_same.status, "iterations": r_same.iterations, "ms_per_iteration": 1e3 * s_same,
+                                             "primal_objective": r_same.primal_objective, "sharded_primal_objective": r.primal_objective}
+            multi["speedup_vs_one_gpu_same_problem"] = 1e3 * s_same / ms_per_step
+            multi["speedup_what"] = ("time per iteration of ONE GPU on the whole %d-cluster problem, unsharded, divided by the time per iteration of the %d-rank job on "
+                                     "that same problem: below 1 the sharding loses (the instance is latency bound at %d clusters per rank: seven dependent all-gathers "
+                                     "per iteration against kernels that use a few per cent of a chip)" % (full.n_clusters, world, args.clusters_per_rank))
+        dist.barrier()
+        # ---- second regime: a share that fills a rank's chip ----
+        if args.filled_clusters_per_rank and args.filled_clusters_per_rank != args.clusters_per_rank:
+            Cf = args.filled_clusters_per_rank
+            full_f = weak_scaling_instance(world, Cf)
+            prob_f, info_f, ctx_f = sharded_context(full_f)
+            steps_f = min(args.steps, 112)
+            rf = solvesdp_mw(prob_f, ctx=ctx_f, shard_info=info_f, **thr)
+            torch.cuda.synchronize()
+            dist.barrier()
+            t1 = time.perf_counter()
+            done = 0
+            while done < steps_f:
+                done += solvesdp_mw(prob_f, ctx=ctx_f, shard_info=info_f, maxiterations=steps_f - done, **thr).iterations
+            torch.cuda.synchronize()
+            dist.barrier()
+            tf = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+            dist.all_reduce(tf, op=dist.ReduceOp.MAX)
+            ms_f = 1e3 * float(tf.item()) / steps_f
+            filled = {"clusters_per_rank": Cf, "problem_clusters": int(full_f.n_clusters), "status": rf.status, "error_code": rf.error_code, "iterations": rf.iterations,
+                      "primal_objective": rf.primal_objective, "sharded_ms_per_iteration": ms_f, "iterations_timed": steps_f,
+                      "valid": bool(rf.error_code == 0 and rf.status == "Optimal")}
+            if rank == 0:
+                r_same, s_same = time_unsharded(full_f, steps_f)
+                filled["one_gpu_same_problem"] = {"status": r_same.status, "iterations": r_same.iterations, "ms_per_iteration": 1e3 * s_same, "primal_objective": r_same.primal_objective}
+                filled["speedup_vs_one_gpu_same_problem"] = 1e3 * s_same / ms_f
+            dist.barrier()
+            ctx_f.comm_destroy()
+            ctx_f.close()
+            multi["filled_regime"] = filled
 
     # ---- secondary: the hot path alone (chol X + assembly + factorisation + 2 solves) on a mid-trajectory iterate, single GPU ----
     hot = None
@@ -317,15 +407,15 @@ def main():
     out = {
         "metric": "interior-point iterations/sec",
         "value": value, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,      # (BASELINE.json publishes no number for this workload)
         "dtype": f"f64x{K} (multi-word fp64: {K} limbs per number, ~{bits} bits; problem data f64x2)",
         "data": "generated: cohnelkies(8,15) built from the mathematics of the reference's examples/SpherePacking.jl (no dataset, no checkpoint); every "
                 "iterate is the solve's own, from the reference's starting point X = Y = 1e10 I",
         "config": {"workload": "SpherePacking cohnelkies(8,15): d=8, 2d=30; 2 clusters P=32, blocks 16x16 r1 + 1x1 dense, N=31; whole interior-point "
                                f"iterations with the reference's default options at its precision (prec=256 -> {K} limbs), {n_it} per solve",
-                   "clusters": int(prob.n_clusters) * world if sharded else int(flat.n_clusters), "n_free": int(flat.n_free), "limbs": K, "data_limbs": 2,
+                   "clusters": int(full.n_clusters) if sharded else int(flat.n_clusters), "n_free": int(flat.n_free), "limbs": K, "data_limbs": 2,
                    "unit_of_work": "one interior-point iteration over one 2-cluster share; a step of the N-GPU job (one iteration of the 2N-cluster problem) = N units",
-                   "multi_gpu": (f"{2 * world} clusters partitioned over {world} ranks (partition_clusters); per iteration RCCL all-gathers of the partial Q, the partial u "
+                   "multi_gpu": (f"{int(full.n_clusters)} clusters partitioned over {world} ranks (partition_clusters); per iteration RCCL all-gathers of the partial Q, the partial u "
                                  "(three times: predictor, corrector and its refinement step) and three scalar records (objectives + mu + p; beta_c and errors; step lengths) inside the C ABI, two communicators "
                                  "(clrs_mw_comm_init, clrs_mw_comm_init_side, clrs_mw_ipm_set_global); y bit-identical on all ranks (asserted); hardware scaling curve: unmeasured by the builder (one-GPU boxes)") if sharded else "single GPU",
                    "launch": "eager, two streams, 35 kernels per iteration, one host wait per iteration on a record that is one iteration old"},
@@ -457,10 +547,6 @@ def main():
                 "~100 iterations/s +-20 %; hardware and thread count not stated; the only timing the reference publishes (BASELINE.md section 1)",
                 "gpu_iterations_per_s": rate_m, "gpu_iterations": rm.iterations, "gpu_primal_objective": rm.primal_objective,
                 "ratio": rate_m / 100.0}
-            out["vs_baseline"] = rate_m / 100.0
-            out["vs_baseline_what"] = ("NOT value / a published number for the headline workload (none exists: BASELINE.json `published` is empty): the ratio of this GPU's "
-                                       "iterations/s on min_f(2) at 5 limbs to the ~100 iterations/s the reference's documented solver log of the same instance implies "
-                                       "(docs/src/solving.md:38-46; unknown hardware) -- see `reference_documented_rate`")
         except Exception as e:
             out["reference_documented_rate"] = {"error": repr(e)}
 

@@ -1079,7 +1079,7 @@ extern "C" int clrs_mw_comm_probe(clrs_mw_ctx *c, int reps, double us[3], int in
     info[0] = q.rank; info[1] = q.world; info[2] = c->comm ? 1 : c->lgroup ? 2 : 0;
     us[0] = us[1] = us[2] = 0.0;
     if (!mw_has_comm(c, 0) || q.N <= 0) return 0;
-    const size_t cnt[3] = {(size_t)q.N * q.N * c->K, (size_t)q.N * c->K, (size_t)(2 * c->K + c->K * q.N + 8)};
+    const size_t cnt[3] = {(size_t)q.N * q.N * c->K, (size_t)q.N * c->K, (size_t)MWG_LEN(c->K, q.N)};      // (the record as the iteration exchanges it: clrs_mw_ipm.hip.h)
     double *scratch = nullptr;                                       // (a buffer of its own: the exchanges must not disturb Qg / ug)
     MWCHECK(hipMalloc((void **)&scratch, cnt[0] * q.world * sizeof(double)));
     MWCHECK(hipMemsetAsync(scratch, 0, cnt[0] * q.world * sizeof(double), c->stream));

@@ -475,7 +475,7 @@ __device__ void mwi_scalar_stage(const MwDev &q, const MwIpmDev &p, int stage, i
         }
         p.rec[MREC_FSTAT] = fs == MW_INFO_NONE ? 0 : fs;
         p.rec[MREC_XSTAT] = xs == MW_INFO_NONE ? 0 : xs;
-        if ((fs != MW_INFO_NONE || xs != MW_INFO_NONE) && p.flags[1] == 0) p.flags[1] = 1;
+        if ((fs != MW_INFO_NONE || xs != MW_INFO_NONE) && p.flags[1] == 0) p.flags[1] = (fs == MW_INFO_TIMEOUT || xs == MW_INFO_TIMEOUT) ? 5 : 1;      // 5: a wait between the two streams timed out
         q.info[0] = MW_INFO_NONE;                  // re-armed for the next decomposition (the iteration issues no memsets)
         q.info[1] = MW_INFO_NONE;
     }
@@ -866,10 +866,18 @@ __global__ void k_mwi_mark(int *word, int iter) {
 // as it starts (MwDev::mark_word) -- an event RECORDED on the main stream costs it a bubble of ~5 us (measured: profiles/r04/r4_host_vs_gpu), a word costs it nothing
 template <int UNIT>
 __global__ void k_mwi_wait(const int *word, int value, int *info, int code) {
+    (void)code;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        int spins = 0;
-        while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < value && ++spins < (1 << 20)) __builtin_amdgcn_s_sleep(32);      // (it may wait half an iteration: a poll per ~1 us)
-        if (spins >= (1 << 20)) atomicMin(info, code);          // never in a run whose queues run side by side; then: the iteration reports a failed factorisation, not numbers
+        unsigned spins = 0;
+        unsigned long long t0 = 0;
+        while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < value) {      // (it may wait half an iteration: a poll per ~1 us)
+            __builtin_amdgcn_s_sleep(32);
+            if ((++spins & 1023u) == 0) {                      // bounded by WALL CLOCK (MW_WAIT_TICKS), not by a poll count: a long wait is not a failure
+                const unsigned long long now = wall_clock64();
+                if (t0 == 0) t0 = now;
+                else if (now - t0 > MW_WAIT_TICKS) { atomicMin(info, MW_INFO_TIMEOUT); break; }      // the iteration reports error code 5, never numbers
+            }
+        }
     }
 }
 

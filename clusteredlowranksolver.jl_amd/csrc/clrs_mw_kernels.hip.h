@@ -25,6 +25,9 @@
 #define MW_PT 512            // threads per workgroup of k_mw_potrf_x, k_mw_factor, k_mw_potrf_q: one wave on the dependent chain, seven behind it
 #define MW_CT 8              // columns of V per workgroup in k_mw_zt
 #define MW_INFO_NONE 0x7f7f7f7f
+#define MW_INFO_TIMEOUT 0x7f7f7f00   // status word of a launch that waited for a word of another stream (mw_wait_word, k_mwi_wait) longer than MW_WAIT_TICKS: larger than every
+                                     // block number, so a real failure of the same decomposition wins the atomicMin; the iteration reports error code 5, not a failed block
+#define MW_WAIT_TICKS 3000000000ull  // 30 s of wall_clock64 (100 MHz): a bound against hangs only -- a long wait (a large instance, a GPU shared with other work) is not a failure
 #define MW_INV_WG 4          // workgroups that share the columns of an inverse factor (k_mw_factor, k_mw_potrf_q, k_mw_bp_diag)
 
 typedef long long mwi64;
@@ -1143,12 +1146,23 @@ __device__ __forceinline__ void mw_mark(const MwDev &q) {
         __hip_atomic_store(q.mark_word, q.mark_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // (a mark that never comes -- it cannot while kernels of different queues may run side by side: the marking kernel is enqueued first; a profiler that
-// serialises kernels, e.g. rocprofv3 --pmc, breaks that: use CLRS_MW_STREAM_WORDS=0 there -- ends the wait after ~0.5 s and reports a failed factorisation: *info)
+// serialises kernels, e.g. rocprofv3 --pmc, breaks that: use CLRS_MW_STREAM_WORDS=0 there -- ends the wait after MW_WAIT_TICKS of WALL CLOCK, however long the
+// polls take, and leaves MW_INFO_TIMEOUT in *info: the iteration then reports error code 5 (stream synchronisation timed out), not a failed block)
 __device__ __forceinline__ void mw_wait_word(const int *word, int value, int *info, int code) {
+    (void)code;
     if (threadIdx.x == 0) {
-        int spins = 0;
-        while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < value && ++spins < (1 << 21)) __builtin_amdgcn_s_sleep(8);
-        if (spins >= (1 << 21)) atomicMin(info, code);
+        unsigned spins = 0;
+        unsigned long long t0 = 0;
+        bool late = false;
+        while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < value) {
+            __builtin_amdgcn_s_sleep(8);
+            if ((++spins & 4095u) == 0) {                      // the clock is looked at every few thousand polls only
+                const unsigned long long now = wall_clock64();
+                if (t0 == 0) t0 = now;
+                else if (now - t0 > MW_WAIT_TICKS) { late = true; break; }
+            }
+        }
+        if (late) atomicMin(info, MW_INFO_TIMEOUT);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }

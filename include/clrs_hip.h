@@ -419,6 +419,9 @@ typedef struct clrs_ipm_stop {
     int32_t need_dual_feasible, need_primal_feasible, max_iterations, reserved;
 } clrs_ipm_stop;
 int clrs_mw_ipm_solve(clrs_mw_ctx *ctx, const clrs_ipm_stop *stop, clrs_ipm_record *records, int max_records, int *n_iter, int *error_code);
+/* error_code of clrs_mw_ipm_iterate / clrs_mw_ipm_solve: 0; 1 / 3 / 4 as the reference's (docs/src/solving.md:64-70); 2 = max_iterations; and 5 = a wait
+ * between the two streams of the iteration ran past its wall-clock bound (30 s: a hang, e.g. under a profiler that serialises kernels -- there, or to rule
+ * it out, clrs_config_set("mw_stream_words", 0) / CLRS_MW_STREAM_WORDS=0 makes new contexts synchronise through events only); the iterate is not moved. */
 
 const char *clrs_strerror(int code);
 const char *clrs_last_error(void);

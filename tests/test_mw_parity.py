@@ -215,11 +215,18 @@ def test_stream_words_make_progress_when_streams_share_hardware_queues(oracle_bu
             assert r.error_code == 0
         t0 = time.time()
         its = 0
+        first = None
         for c in ctxs:
             r = solvesdp_mw(f, ctx=c, limbs=4, duality_gap_threshold=1e-10, dual_error_threshold=1e-20, primal_error_threshold=1e-20)
+            # the functional signal: a wait that ran out of polls reports a failed factorisation (error code 1), never numbers -- and every context must
+            # produce the SAME solve, whatever queue its streams landed on
             assert r.error_code == 0 and r.status == "Optimal"
+            first = first or r
+            assert r.iterations == first.iterations and np.array_equal(r.history, first.history) and np.array_equal(r.y, first.y)
             its += r.iterations
-        assert (time.time() - t0) / its < 5e-3, ("seconds per iteration", (time.time() - t0) / its)
+        # (a loose clock on top: a wait whose producer sat behind it in the same queue costs its whole bound, seconds per iteration; an ordinary solve on a
+        # shared host stays orders of magnitude below this)
+        assert (time.time() - t0) / its < 0.25, ("seconds per iteration", (time.time() - t0) / its)
     finally:
         for c in ctxs:
             c.close()
