@@ -63,10 +63,13 @@ class IpmStop(C.Structure):
                 ("max_iterations", C.c_int32), ("reserved", C.c_int32)]
 
 
+RecordFn = C.CFUNCTYPE(None, C.POINTER(IpmRecord), C.c_void_p)      # clrs_ipm_record_fn
+
+
 class MwOptions(C.Structure):
     """struct clrs_mw_options"""
     _fields_ = [("exact_products", C.c_int32), ("refine", C.c_int32), ("pipeline", C.c_int32), ("refine_predictor", C.c_int32), ("factor_limbs", C.c_int32),
-                ("reserved", C.c_int32 * 3)]
+                ("matmul_limbs", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
 class ClrsError(RuntimeError):
@@ -176,6 +179,7 @@ SYMBOLS = {
     "clrs_mw_local_group_destroy": (None, [C.c_void_p]),
     "clrs_mw_comm_init_local": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "clrs_mw_ipm_solve": (C.c_int, [C.c_void_p, C.POINTER(IpmStop), C.POINTER(IpmRecord), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "clrs_mw_ipm_solve_cb": (C.c_int, [C.c_void_p, C.POINTER(IpmStop), RecordFn, C.c_void_p, C.POINTER(IpmRecord), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "clrs_set_last_error": (None, [C.c_char_p]),
     "clrs_strerror": (C.c_char_p, [C.c_int]),
     "clrs_last_error": (C.c_char_p, []),

@@ -237,11 +237,16 @@ extern "C" int clrs_mw_create_ex(const clrs_sdp_desc *d, int data_limbs, int dev
 // several threads do not share a knob this way
 extern "C" int clrs_mw_create_opts(const clrs_sdp_desc *d, int data_limbs, int device, int limbs, const clrs_mw_options *opts, clrs_mw_ctx **out) {
     if (!d || !out) return mw_fail(CLRS_ERR_INVALID, "null argument");
-    const int cfg_exact = opts && opts->exact_products >= 0 ? opts->exact_products : g_cfg_mw_exact_products;
+    int cfg_exact = opts && opts->exact_products >= 0 ? opts->exact_products : g_cfg_mw_exact_products;
     const int cfg_refine = opts && opts->refine >= 0 ? opts->refine : g_cfg_mw_refine;
     const int cfg_pipe = opts && opts->pipeline >= 0 ? opts->pipeline : g_cfg_mw_pipeline;
     const int cfg_refine_pred = opts && opts->refine_predictor >= 0 ? opts->refine_predictor : g_cfg_mw_refine_predictor;
     const int cfg_factor_limbs = opts && opts->factor_limbs >= 0 ? opts->factor_limbs : g_cfg_mw_factor_limbs;
+    // matmul_prec of the reference (src/solver.jl:125): limbs of the pairing products, rounded UP to the next count on offer (mw_km_ok); 0 = the context's limbs
+    int cfg_km = opts && opts->matmul_limbs > 0 ? opts->matmul_limbs : limbs;
+    if (cfg_km > limbs) cfg_km = limbs;
+    while (cfg_km < limbs && !mw_km_ok(limbs, cfg_km)) cfg_km++;
+    if (cfg_km < limbs) cfg_exact = 0;                     // (the exact slice products have one slice count per limb count: the expansion kernels take the reduced products)
     if (cfg_exact > 2 || cfg_refine > 2) return mw_fail(CLRS_ERR_INVALID, "clrs_mw_options: exact_products and refine are 0, 1 or 2 (or < 0 for the default)");
     if (limbs < 2 || limbs > 10 || limbs == 7 || limbs == 9) return mw_fail(CLRS_ERR_INVALID, "limbs must be 2..6, 8 or 10");
     if (data_limbs < 1 || data_limbs > 2 || data_limbs > limbs) return mw_fail(CLRS_ERR_INVALID, "data limbs must be 1 or 2 (and at most limbs)");
@@ -827,6 +832,7 @@ extern "C" int clrs_mw_create_opts(const clrs_sdp_desc *d, int data_limbs, int d
         if (cfg_factor_limbs == K) c->kf_low = K;
         c->kf_entry = cfg_factor_limbs == 0 ? K : cfg_factor_limbs;
         q.kf = c->kf_entry;
+        q.km = cfg_km;
         unsigned long long *rs = nullptr;
         if (hipMalloc((void **)&rs, 4 * sizeof(unsigned long long)) != hipSuccess) MW_BAIL(CLRS_ERR_HIP, "hipMalloc failed");
         c->allocs.push_back(rs);

@@ -17,6 +17,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "clrs_mw_arith.h"
 
 // Template parameters: K = limbs of every computed number, DK = limbs of the problem data (sampled vectors, lambda, dense
@@ -62,6 +64,18 @@ struct MwClu {               // one cluster j
 // caller returns to K limbs when it is not (prototype numbers: cohnelkies(8,15) iterations 1 / 28 / 55 first pass 2^-123 / 2^-99 / 2^-45).
 __host__ __device__ constexpr int mw_kf_of(int K) { return (K == 5 || K == 6) ? K - 1 : K; }
 
+// The reference's `matmul_prec` (src/solver.jl:125, 304, 312-313, 1125-1143): the products that lead to the pairing matrices (part_r = Y V, X^-1 V and
+// bilinear_pairings = W^T part_r) at fewer bits than the rest.  Here: T = Y V, Z = chol(X)^-1 V, GX = Z^T Z, GY = V^T T in MwDev::km limbs (stored with the upper
+// K - km planes zero; S_j is accumulated from them in K limbs, as the reference does at `prec`).  Limb counts on offer: the instantiated ones from K / 2 up;
+// the host rounds a request up to the next of them.
+__host__ __device__ constexpr bool mw_km_ok(int K, int KM) { return KM == K || (KM < K && 2 * KM >= K && (KM <= 6 || KM == 8)); }
+#define MW_KM_CASE(KMc) if constexpr (mw_km_ok(K, KMc) && KMc < K) { if (km == KMc) { f(std::integral_constant<int, KMc>{}); return; } }
+template <int K, class F>
+__device__ __forceinline__ void mw_km_switch(int km, F f) {
+    MW_KM_CASE(2) MW_KM_CASE(3) MW_KM_CASE(4) MW_KM_CASE(5) MW_KM_CASE(6) MW_KM_CASE(8)
+    f(std::integral_constant<int, K>{});
+}
+
 struct MwDev {
     int J, N, NB, nlr, ndn, kf;         // kf: limbs of the factor stage and of the solve's products (K, or mw_kf_of(K))
     mwi64 xylen, xlen, Slen, T, xrdlen;
@@ -93,7 +107,7 @@ struct MwDev {
     // correction (xlen, N); uadd: while the correction is solved, the vector subtracted from rhs_y beside sum_j u_j (= u2), else null
     double *S0;                         // S_j as assembled (S layout; written by the FACTOR stage as it reads S_j, which it overwrites with L_j): the residuals of the refinement need S_j
     int *mark_word;                     // null, or a word the FIRST workgroup of the next Cholesky / factor launch stores mark_value to as it starts: "everything in front of
-    int mark_value, pad7;               // this launch on its stream is complete", for kernels of another stream that wait inside their launch (mw_wait_word) instead of for an event
+    int mark_value, km;                 // (km: limbs of the pairing products -- the reference's matmul_prec, src/solver.jl:125, 1125-1143 -- K by default; mw_km_switch)  this launch on its stream is complete", for kernels of another stream that wait inside their launch (mw_wait_word) instead of for an event
     int pipe_q, pipe_bp;                // index of Q's region in pipe_pc; of the first matrix of the blocked path (k_mw_bp_diag_pipe: region pipe_bp + MwBp::slot)
     unsigned long long *pipe_stamps;    // diagnostic builds: [16][40] step stamps of the pipelined factorisations (clrs_mw_debug_pipe_stamps), or null
     unsigned long long *pipe_pc;        // hand-off granules of the pipelined factorisations (clrs_mw_pipe.hip.h): [J + 1][MWP_PC_WORDS], or null
@@ -553,8 +567,8 @@ __global__ __launch_bounds__(MW_PT) void k_mw_potrf_x(const MwDev q, const doubl
 // of the pairing: V^T X^-1 V = Z^T Z, so the explicit inverse (inv_cho_precomp!, :1117) is never formed.
 // ---------------------------------------------------------------------------------------------------------------------
 // T[:, c] = Y[:, rows(c)] V[rows(c), c] and (inverse factors) Z[:, c] = Xi V[:, c] for the columns c0 .. c0 + nc - 1: ZW lanes per entry
-template <int K, int DK, int ZW>
-__device__ __forceinline__ void mw_zt_products(const MwDev &q, const MwBlk &k, const double *__restrict__ Y, int c0, int nc, bool with_z) {
+template <int K, int KM, int DK, int ZW>
+__device__ __forceinline__ void mw_zt_products_km(const MwDev &q, const MwBlk &k, const double *__restrict__ Y, int c0, int nc, bool with_z) {
     using namespace mwk;
     const int n = k.n, tid = threadIdx.x, dl = k.delta, sub = tid % ZW;
     const double *V = q.V + k.v_off;
@@ -564,11 +578,11 @@ __device__ __forceinline__ void mw_zt_products(const MwDev &q, const MwBlk &k, c
         const bool live = e < n * nc;
         const int ee = live ? e : 0;
         const int i = ee % n, c = c0 + ee / n, r0 = vrow[c];
-        acc<K> s;
-        acc_zero<K>(s);
-        for (int kk = r0 + sub; kk < r0 + dl; kk += ZW) acc_fma<K, K, DK>(s, ldx<K>(Y + k.xyoff, q.xylen, i + (long)kk * n), ldx<DK>(V, q.Vp, kk + (long)c * n));
-        mw<K> v = lanes_sum<K, ZW>(acc_result<K>(s));
-        if (live && sub == 0) stx<K>(q.Tm + k.z_off, q.zlen, i + (long)c * n, v);
+        acc<KM> s;
+        acc_zero<KM>(s);
+        for (int kk = r0 + sub; kk < r0 + dl; kk += ZW) acc_fma<KM, KM, DK>(s, ldx<KM>(Y + k.xyoff, q.xylen, i + (long)kk * n), ldx<DK>(V, q.Vp, kk + (long)c * n));
+        mw<KM> v = lanes_sum<KM, ZW>(acc_result<KM>(s));
+        if (live && sub == 0) stx<K>(q.Tm + k.z_off, q.zlen, i + (long)c * n, cvt<K, KM>(v));
     }
     if (!with_z) return;
     const double *Xi = q.Xi + k.xyoff;                 // rows above the first nonzero row of the vector are zero
@@ -577,12 +591,16 @@ __device__ __forceinline__ void mw_zt_products(const MwDev &q, const MwBlk &k, c
         const bool live = e < n * nc;
         const int ee = live ? e : 0;
         const int i = ee % n, c = c0 + ee / n, r0 = vrow[c];
-        acc<K> s;
-        acc_zero<K>(s);
-        for (int kk = r0 + sub; kk <= i; kk += ZW) acc_fma<K, K, DK>(s, ldx<K>(Xi, q.xylen, i + (long)kk * n), ldx<DK>(V, q.Vp, kk + (long)c * n));
-        mw<K> v = lanes_sum<K, ZW>(acc_result<K>(s));
-        if (live && sub == 0) stx<K>(q.Z + k.z_off, q.zlen, i + (long)c * n, v);
+        acc<KM> s;
+        acc_zero<KM>(s);
+        for (int kk = r0 + sub; kk <= i; kk += ZW) acc_fma<KM, KM, DK>(s, ldx<KM>(Xi, q.xylen, i + (long)kk * n), ldx<DK>(V, q.Vp, kk + (long)c * n));
+        mw<KM> v = lanes_sum<KM, ZW>(acc_result<KM>(s));
+        if (live && sub == 0) stx<K>(q.Z + k.z_off, q.zlen, i + (long)c * n, cvt<K, KM>(v));
     }
+}
+template <int K, int DK, int ZW>
+__device__ __forceinline__ void mw_zt_products(const MwDev &q, const MwBlk &k, const double *__restrict__ Y, int c0, int nc, bool with_z) {
+    mw_km_switch<K>(q.km, [&](auto kmc) { mw_zt_products_km<K, decltype(kmc)::value, DK, ZW>(q, k, Y, c0, nc, with_z); });
 }
 // ct: columns of V per workgroup -- MW_CT with two lanes per entry, or (ct = 2, small launches with inverse factors: the named problems have twelve
 // workgroups of eight columns) two columns with eight lanes per entry: a quarter of the multiply-adds per lane
@@ -646,17 +664,9 @@ __device__ __forceinline__ void mw_dense_1x1(const MwDev &q, const MwBlk &k, con
         stx<K>(q.Sd + k.sd_off, q.sdlen, e2 + (long)e1 * cnt, v);
     }
 }
-template <int K, int DK>
-__global__ __launch_bounds__(MW_NT) void k_mw_gram(const MwDev q, const double *__restrict__ Y) {
+template <int K, int KM, int DK>
+__device__ __forceinline__ void mw_gram_km(const MwDev &q) {
     using namespace mwk;
-    // rows of the grid beyond the low-rank blocks (the launch adds them when every dense block is 1 x 1): the dense blocks' tables, which depend on
-    // X and Y only -- beside the pairing matrices instead of a launch of their own behind them (k_mw_dense_t)
-    if ((int)blockIdx.y >= q.nlr) {
-        if (blockIdx.x == 0) mw_dense_1x1<K, DK>(q, q.blk[q.dn_list[blockIdx.y - q.nlr]], Y, threadIdx.x);
-        return;
-    }
-    if (q.mws_on && q.mws_off[q.lr_list[blockIdx.y]] >= 0) return;
-    if (q.mwx_on && q.mwx_off[q.lr_list[blockIdx.y]] >= 0) return;      // k_mwx_gram
     const MwBlk &k = q.blk[q.lr_list[blockIdx.y]];
     const int n = k.n, U = k.U, dl = k.delta;
     const int e = blockIdx.x * (MW_NT / MW_GRAM_W) + threadIdx.x / MW_GRAM_W, sub = threadIdx.x % MW_GRAM_W;
@@ -668,22 +678,35 @@ __global__ __launch_bounds__(MW_NT) void k_mw_gram(const MwDev q, const double *
     const double *V = q.V + k.v_off;
     const int *vrow = q.vrow + k.vrow_off;
     const double *Z = q.Z + k.z_off, *T = q.Tm + k.z_off;
-    acc<K> s;
-    acc_zero<K>(s);
+    acc<KM> s;
+    acc_zero<KM>(s);
     // rows above the first nonzero row of either vector are zero in Z = L^-1 V
     const int i0 = max(vrow[a], vrow[b]);
-    for (int i = i0 + sub; i < n; i += MW_GRAM_W) acc_fma<K, K, K>(s, ldx<K>(Z, q.zlen, i + (long)a * n), ldx<K>(Z, q.zlen, i + (long)b * n));
-    mw<K> gx = lanes_sum<K, MW_GRAM_W>(acc_result<K>(s));
-    acc_zero<K>(s);
+    for (int i = i0 + sub; i < n; i += MW_GRAM_W) acc_fma<KM, KM, KM>(s, ldx<KM>(Z, q.zlen, i + (long)a * n), ldx<KM>(Z, q.zlen, i + (long)b * n));
+    const mw<K> gx = cvt<K, KM>(lanes_sum<KM, MW_GRAM_W>(acc_result<KM>(s)));
+    acc_zero<KM>(s);
     const int r0 = vrow[a];
-    for (int i = r0 + sub; i < r0 + dl; i += MW_GRAM_W) acc_fma<K, K, DK>(s, ldx<K>(T, q.zlen, i + (long)b * n), ldx<DK>(V, q.Vp, i + (long)a * n));
-    mw<K> gy = lanes_sum<K, MW_GRAM_W>(acc_result<K>(s));
+    for (int i = r0 + sub; i < r0 + dl; i += MW_GRAM_W) acc_fma<KM, KM, DK>(s, ldx<KM>(T, q.zlen, i + (long)b * n), ldx<DK>(V, q.Vp, i + (long)a * n));
+    const mw<K> gy = cvt<K, KM>(lanes_sum<KM, MW_GRAM_W>(acc_result<KM>(s)));
     if (live && sub == 0) {
         stx<K>(q.GX + k.g_off, q.glen, a + (long)b * U, gx);
         stx<K>(q.GX + k.g_off, q.glen, b + (long)a * U, gx);
         stx<K>(q.GY + k.g_off, q.glen, a + (long)b * U, gy);
         stx<K>(q.GY + k.g_off, q.glen, b + (long)a * U, gy);
     }
+}
+template <int K, int DK>
+__global__ __launch_bounds__(MW_NT) void k_mw_gram(const MwDev q, const double *__restrict__ Y) {
+    using namespace mwk;
+    // rows of the grid beyond the low-rank blocks (the launch adds them when every dense block is 1 x 1): the dense blocks' tables, which depend on
+    // X and Y only -- beside the pairing matrices instead of a launch of their own behind them (k_mw_dense_t)
+    if ((int)blockIdx.y >= q.nlr) {
+        if (blockIdx.x == 0) mw_dense_1x1<K, DK>(q, q.blk[q.dn_list[blockIdx.y - q.nlr]], Y, threadIdx.x);
+        return;
+    }
+    if (q.mws_on && q.mws_off[q.lr_list[blockIdx.y]] >= 0) return;
+    if (q.mwx_on && q.mwx_off[q.lr_list[blockIdx.y]] >= 0) return;      // k_mwx_gram
+    mw_km_switch<K>(q.km, [&](auto kmc) { mw_gram_km<K, decltype(kmc)::value, DK>(q); });
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

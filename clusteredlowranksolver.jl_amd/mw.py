@@ -83,8 +83,11 @@ class MwSchurContext:
     """Device context of the hot path for one SDP at `limbs` words per number (see module docstring)."""
 
     def __init__(self, sdp, limbs: int = 4, device: int = 0, timing: bool = False, data_limbs: int = 2, exact_products: Optional[bool] = None,
-                 refine: Optional[int] = None, pipeline=None, refine_predictor: Optional[bool] = None, factor_limbs: Optional[int] = None):
-        """`factor_limbs`: mixed-precision iterative refinement (csrc/clrs_mw_kernels.hip.h::mw_kf_of) -- limbs of the factor stage and of the solve
+                 refine: Optional[int] = None, pipeline=None, refine_predictor: Optional[bool] = None, factor_limbs: Optional[int] = None,
+                 matmul_limbs: Optional[int] = None):
+        """`matmul_limbs`: the reference's `matmul_prec` (src/solver.jl:125) as a limb count (`limbs_for_precision(matmul_prec)`): the products that form the
+        pairing matrices in fewer limbs than the rest; None / 0 = `limbs`.
+        `factor_limbs`: mixed-precision iterative refinement (csrc/clrs_mw_kernels.hip.h::mw_kf_of) -- limbs of the factor stage and of the solve
         stage's inverse-factor products, the residuals of the refinement step and the solution keep all `limbs`: None / 0 = automatic (`limbs - 1` for
         5 and 6 limbs inside `solvesdp_mw` while the measured first-pass accuracy allows, all limbs in `factor()` / `solve()`), `limbs` = never reduce,
         `limbs - 1` = reduced in `factor()` / `solve()` too.
@@ -133,7 +136,7 @@ class MwSchurContext:
         h = C.c_void_p()
         opts = _lib.MwOptions(-1 if exact_products is None else (2 if exact_products else 0), -1 if refine is None else int(refine),
                               -1 if pipeline is None else (2 if pipeline is True else int(pipeline)), -1 if refine_predictor is None else int(bool(refine_predictor)),
-                              -1 if factor_limbs is None else int(factor_limbs))
+                              -1 if factor_limbs is None else int(factor_limbs), 0 if matmul_limbs is None else int(matmul_limbs))
         _lib.check(self.L.clrs_mw_create_opts(C.byref(d), self.data_limbs, int(device), self.limbs, C.byref(opts), C.byref(h)))
         self.h = h
         self.device = device
@@ -354,8 +357,10 @@ def solvesdp_mw(sdp, limbs: Optional[int] = None, prec: Optional[int] = None, ct
                 dual_error_threshold: float = 1e-30, primal_error_threshold: float = 1e-30, max_complementary_gap: float = 1e100,
                 need_dual_feasible: bool = False, need_primal_feasible: bool = False, verbose: bool = False,
                 step_length_threshold: float = 1e-7, safe_step: bool = True, step_by_step: bool = False, shard_info: Optional[dict] = None,
-                dualsol=None, primalsol=None, factor_limbs: Optional[int] = None):
+                dualsol=None, primalsol=None, factor_limbs: Optional[int] = None, matmul_prec: Optional[int] = None):
     """`solvesdp(sdp; prec, ...)` (src/solver.jl:71-127) with the whole loop body on the GPU in multi-word fp64.
+    `matmul_prec`: the reference's keyword (src/solver.jl:125): bits of the products that form the pairing matrices (rounded up to whole limbs; ignored when
+    `ctx` is given -- create it with `matmul_limbs`).
     `factor_limbs`: see `MwSchurContext` (ignored when `ctx` is given); `timings["refine_bits"]` of the result lists, per iteration, the bits the first
     pass of the corrector's refined solve was good to.
 
@@ -365,8 +370,8 @@ def solvesdp_mw(sdp, limbs: Optional[int] = None, prec: Optional[int] = None, ct
     `dualsol` / `primalsol`: the warm start of src/solver.jl:202-239 (applied, as there, only when BOTH are given): `dualsol` supplies x and X,
     `primalsol` y and Y -- a previous `SolveResult` (or anything with those attributes), fp64 or planar limbs; through `clrs_mw_ipm_set`.  The errors of
     the starting iterate are known after the first iteration (the reference computes them before its loop): a warm-started solve runs at least one.
-    Termination (src/solver.jl:921-950): by the library and the device together in one call (`clrs_mw_ipm_solve`), or -- `verbose` or
-    `step_by_step` -- on the host from one record per call of `clrs_mw_ipm_iterate`."""
+    Termination (src/solver.jl:921-950): by the library and the device together in one call (`clrs_mw_ipm_solve_cb`; `verbose` prints the table rows
+    from its callback), or -- `step_by_step` -- on the host from one record per call of `clrs_mw_ipm_iterate`."""
     import time
     from .solver import SolveResult
     f = sdp if isinstance(sdp, FlatSDP) else flatten(sdp)
@@ -374,7 +379,8 @@ def solvesdp_mw(sdp, limbs: Optional[int] = None, prec: Optional[int] = None, ct
         limbs = limbs_for_precision(prec) if prec is not None else 5
     own_ctx = ctx is None
     if ctx is None:
-        ctx = MwSchurContext(f, limbs=limbs, device=device, data_limbs=data_limbs, factor_limbs=factor_limbs)
+        ctx = MwSchurContext(f, limbs=limbs, device=device, data_limbs=data_limbs, factor_limbs=factor_limbs,
+                             matmul_limbs=None if matmul_prec is None else min(limbs, limbs_for_precision(matmul_prec)))
     K = ctx.limbs
     L = ctx.L
     keep = [ctx._data("C"), ctx._data("c"), ctx._data("b") if f.n_free else np.zeros((ctx.data_limbs, 1))]
@@ -421,13 +427,24 @@ def solvesdp_mw(sdp, limbs: Optional[int] = None, prec: Optional[int] = None, ct
     def row(r):
         return [it, r.mu, d_obj, p_obj, gap, r.max_P, r.max_p, r.max_d, r.alpha_d, r.alpha_p, r.beta_c]
 
-    if not verbose and not step_by_step:
-        # the whole loop in ONE call (clrs_mw_ipm_solve): the library enqueues iterations one ahead of the record it waits for and the
-        # device evaluates the termination test of src/solver.jl:921-950 itself; the records come back as the reference's table rows
+    if not step_by_step:
+        # the whole loop in ONE call (clrs_mw_ipm_solve_cb): the library enqueues iterations one ahead of the record it waits for and the
+        # device evaluates the termination test of src/solver.jl:921-950 itself; the records come back as the reference's table rows, and with
+        # `verbose` a callback prints each row (:566-582) as the host reads it
         stop = _lib.IpmStop(float(duality_gap_threshold), int(bool(need_dual_feasible)), int(bool(need_primal_feasible)), int(maxiterations), 0)
         recs = (_lib.IpmRecord * max(int(maxiterations), 1))()
         n_it, err = C.c_int(0), C.c_int(0)
-        _lib.check(L.clrs_mw_ipm_solve(ctx.h, C.byref(stop), recs, int(maxiterations), C.byref(n_it), C.byref(err)))
+        shown = dict(it=1, d=d_obj, p=p_obj, g=gap)
+
+        def _row(recp, _user):
+            q = recp.contents
+            print("%5d %8.1f %11.3e %11.3e %11.3e %10.2e %10.2e %10.2e %10.2e %10.2e %10.2e %10.2e" %
+                  (shown["it"], time.time() - t_start, q.mu, shown["d"], shown["p"], shown["g"], q.max_P, q.max_p, q.max_d, q.alpha_d, q.alpha_p, q.beta_c), flush=True)
+            if not q.error_code:
+                shown.update(d=q.d_obj, p=q.p_obj, g=q.gap)
+            shown["it"] += 1
+        cb = _lib.RecordFn(_row) if verbose else _lib.RecordFn()
+        _lib.check(L.clrs_mw_ipm_solve_cb(ctx.h, C.byref(stop), cb, None, recs, int(maxiterations), C.byref(n_it), C.byref(err)))
         error_code = err.value
         for i in range(n_it.value):
             r = recs[i]

@@ -307,7 +307,11 @@ typedef struct clrs_mw_options {
                               * clrs_mw_ipm_* limbs - 1 for limbs = 5, 6 on the LDS-resident paths, while the measured first-pass accuracy (clrs_ipm_record.refine_bits)
                               * stays above one limb plus a margin, then all limbs; the stand-alone entry points (clrs_mw_schur_factor / _solve) use all limbs.
                               * `limbs` = never reduce; limbs - 1 (5, 6 limbs) = the reduced count in the stand-alone entry points as well */
-    int32_t reserved[3];
+    int32_t matmul_limbs;    /* The reference's `matmul_prec` keyword (src/solver.jl:125, 304, 312-313, 1125-1143): limbs of the products that form the pairing matrices
+                              * (part_r = Y V, X^-1 V and bilinear_pairings = W^T part_r; here T = Y V, Z = chol(X)^-1 V, Z^T Z, V^T T) -- S_j is accumulated from them in all
+                              * `limbs`, as the reference does at `prec`.  0 (default) = `limbs`; a smaller count is rounded up to the next on offer (from limbs / 2 up).
+                              * With fewer limbs than `limbs` the exact slice products (exact_products) are off. */
+    int32_t reserved[2];
 } clrs_mw_options;
 int clrs_mw_create_opts(const clrs_sdp_desc *desc, int data_limbs, int device, int limbs, const clrs_mw_options *opts, clrs_mw_ctx **out);
 void clrs_mw_destroy(clrs_mw_ctx *ctx);
@@ -419,6 +423,11 @@ typedef struct clrs_ipm_stop {
     int32_t need_dual_feasible, need_primal_feasible, max_iterations, reserved;
 } clrs_ipm_stop;
 int clrs_mw_ipm_solve(clrs_mw_ctx *ctx, const clrs_ipm_stop *stop, clrs_ipm_record *records, int max_records, int *n_iter, int *error_code);
+/* The same loop with a callback per record: `on_record(record, user)` runs on the calling thread as the host reads the record of an iteration (the device
+ * is one iteration further by then) -- the live iteration table of `verbose = true` (src/solver.jl:566-582) without giving up the one-call loop.  The
+ * callback must not call into this context.  on_record and records may be NULL. */
+typedef void (*clrs_ipm_record_fn)(const clrs_ipm_record *record, void *user);
+int clrs_mw_ipm_solve_cb(clrs_mw_ctx *ctx, const clrs_ipm_stop *stop, clrs_ipm_record_fn on_record, void *user, clrs_ipm_record *records, int max_records, int *n_iter, int *error_code);
 /* error_code of clrs_mw_ipm_iterate / clrs_mw_ipm_solve: 0; 1 / 3 / 4 as the reference's (docs/src/solving.md:64-70); 2 = max_iterations; and 5 = a wait
  * between the two streams of the iteration ran past its wall-clock bound (30 s: a hang, e.g. under a profiler that serialises kernels -- there, or to rule
  * it out, clrs_config_set("mw_stream_words", 0) / CLRS_MW_STREAM_WORDS=0 makes new contexts synchronise through events only); the iterate is not moved. */

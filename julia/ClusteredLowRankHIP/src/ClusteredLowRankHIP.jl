@@ -96,14 +96,27 @@ function arb_of(a::AbstractMatrix{Float64}, i::Int, prec::Int)
     return out
 end
 
+# struct clrs_mw_options (include/clrs_hip.h): a field < 0 = the library's process-wide default; matmul_limbs 0 = the context's limbs
+struct MwOptions
+    exact_products::Int32
+    refine::Int32
+    pipeline::Int32
+    refine_predictor::Int32
+    factor_limbs::Int32
+    matmul_limbs::Int32
+    reserved1::Int32
+    reserved2::Int32
+end
+
 """
-    HipContext(sdp, cs_map; device=0, limbs=5)
+    HipContext(sdp, cs_map; device=0, limbs=5, matmul_limbs=0)
 
 Replaces `precompute_matrices_bilinear_pairings` (src/solver.jl:985-1059) and the preallocation block
 (src/solver.jl:298-317): flattens `sdp.A[j][l][r,s][p]` (cluster-local constraint indices through `cs_map[j]`,
-0-based) and `sdp.B[j]` into `clrs_sdp_desc` and creates the device context.  `limbs = limbs_for(prec)`.
+0-based) and `sdp.B[j]` into `clrs_sdp_desc` and creates the device context.  `limbs = limbs_for(prec)`; `matmul_limbs = limbs_for(matmul_prec)`
+(the reference's keyword, src/solver.jl:125: the products that form the pairing matrices in fewer bits; 0 = `limbs`).
 """
-function HipContext(sdp::CLRS.ClusteredLowRankSDP, cs_map; device::Integer=0, limbs::Integer=5)
+function HipContext(sdp::CLRS.ClusteredLowRankSDP, cs_map; device::Integer=0, limbs::Integer=5, matmul_limbs::Integer=0)
     J = length(sdp.A)
     DL = limbs == 1 ? 1 : DATA_LIMBS
     cluster_P = Int32[size(sdp.c[j], 1) for j in 1:J]
@@ -173,7 +186,8 @@ function HipContext(sdp::CLRS.ClusteredLowRankSDP, cs_map; device::Integer=0, li
         if limbs == 1
             check(ccall((:clrs_ctx_create, libclrs[]), Cint, (Ref{SdpDesc}, Cint, Ref{Ptr{Cvoid}}), desc, device, h))
         else
-            check(ccall((:clrs_mw_create_ex, libclrs[]), Cint, (Ref{SdpDesc}, Cint, Cint, Cint, Ref{Ptr{Cvoid}}), desc, DL, device, limbs, h))
+            opts = Ref(MwOptions(-1, -1, -1, -1, -1, Int32(matmul_limbs), 0, 0))
+            check(ccall((:clrs_mw_create_opts, libclrs[]), Cint, (Ref{SdpDesc}, Cint, Cint, Cint, Ref{MwOptions}, Ref{Ptr{Cvoid}}), desc, DL, device, limbs, opts, h))
         end
     end
     ctx = HipContext(h[], limbs, keep, cumsum([0; block_n .^ 2]), block_n, jl, Int.(cluster_P), cumsum([0; Int.(cluster_P)]),
@@ -335,6 +349,34 @@ struct IpmRecord
     max_p::Float64
     max_d::Float64
 end
+struct IpmStop
+    duality_gap_threshold::Float64
+    need_dual_feasible::Int32
+    need_primal_feasible::Int32
+    max_iterations::Int32
+    reserved::Int32
+end
+
+# What the per-record callback of clrs_mw_ipm_solve_cb needs between two rows of the iteration table: the reference prints, in the row of an
+# iteration, the objectives and the gap of the iterate the iteration STARTED from (src/solver.jl:566-582)
+mutable struct TableState
+    iter::Int
+    t0::Float64
+    d_obj::Float64
+    p_obj::Float64
+    gap::Float64
+end
+function print_row(recp::Ptr{IpmRecord}, user::Ptr{Cvoid})::Cvoid
+    st = unsafe_pointer_to_objref(user)::TableState
+    r = unsafe_load(recp)
+    CLRS.@printf("%5d %8.1f %11.3e %11.3e %11.3e %10.2e %10.2e %10.2e %10.2e %10.2e %10.2e %10.2e\n", st.iter, time() - st.t0,
+                 r.mu, st.d_obj, st.p_obj, st.gap, r.max_P, r.max_p, r.max_d, r.alpha_d, r.alpha_p, r.beta_c)
+    if r.error_code == 0
+        st.d_obj, st.p_obj, st.gap = r.d_obj, r.p_obj, r.gap
+    end
+    st.iter += 1
+    return nothing
+end
 
 """Cluster-local renumbering of the constraints preprocessing kept: `original row => position among the kept rows` (what `cs_map[j]` is)."""
 function renumber_kept(nrows::Integer, removed)
@@ -386,8 +428,8 @@ end
 
 The reference's `solvesdp` (src/solver.jl:42-127: same keywords, same defaults, same return
 `status, dualsol, primalsol, solve_time, errorcode`) with the interior-point loop on the GPU at `limbs_for(prec)` words per number.
-`dualsol` / `primalsol` warm-start the device loop (`clrs_mw_ipm_set`).  Keywords without a device counterpart (`save_settings`, `correctoronly`,
-`matmul_prec`, `testing`) are accepted; a non-default value raises an `ArgumentError`, so that a caller never silently gets something else than it asked for.
+`dualsol` / `primalsol` warm-start the device loop (`clrs_mw_ipm_set`).  `matmul_prec` selects the limbs of the pairing products (`clrs_mw_options.matmul_limbs`).  Keywords without a device counterpart (`save_settings`,
+`correctoronly`, `testing`) are accepted; a non-default value raises an `ArgumentError`, so that a caller never silently gets something else than it asked for.
 """
 function solvesdp(problem::CLRS.Problem; prec=precision(BigFloat), kwargs...)
     sdp = CLRS.ClusteredLowRankSDP(problem, prec=prec)          # src/solver.jl:96-98
@@ -407,7 +449,7 @@ function solvesdp(sdp::CLRS.ClusteredLowRankSDP;
     correctoronly && throw(ArgumentError("correctoronly is not available with the HIP backend"))
     (save_settings === nothing || (save_settings.iter_interval === nothing && save_settings.time_interval === nothing && save_settings.callback === nothing)) ||
         throw(ArgumentError("save_settings is not available with the HIP backend"))
-    matmul_prec == prec || throw(ArgumentError("matmul_prec is not available with the HIP backend"))
+    matmul_prec <= prec || throw(ArgumentError("matmul_prec must not exceed prec"))
     warm = dualsol !== nothing && primalsol !== nothing               # src/solver.jl:202: only both together are used
     lib = libclrs[]
     K = limbs_for(prec)
@@ -416,7 +458,7 @@ function solvesdp(sdp::CLRS.ClusteredLowRankSDP;
     rows_before = [size(sdp.B[j], 1) for j in eachindex(sdp.B)]
     cs, var_rels = preprocess ? CLRS.preprocess!(sdp) : ((), nothing)
     cs_map = [renumber_kept(rows_before[j], (t[3] for t in cs if t[2] == j)) for j in eachindex(sdp.B)]
-    ctx = HipContext(sdp, cs_map; device=device, limbs=K)
+    ctx = HipContext(sdp, cs_map; device=device, limbs=K, matmul_limbs=(matmul_prec == prec ? 0 : min(K, limbs_for(matmul_prec))))
     DL = DATA_LIMBS
     nxy, nx, N = ctx.block_off[end], ctx.cluster_off[end], ctx.n_free
     # objective data as DL limb planes: C in the xy layout, c in the x layout, b
@@ -437,7 +479,6 @@ function solvesdp(sdp::CLRS.ClusteredLowRankSDP;
     data = Ref(IpmData(pointer(Cf), pointer(cf), pointer(bf), sdp.maximize ? 1 : 0, 0, f64(sdp.constant)))
     prm = Ref(IpmParams(Float64(beta_infeasible), Float64(beta_feasible), Float64(gamma), Float64(dual_error_threshold),
                         Float64(primal_error_threshold), Float64(max_complementary_gap), Float64(step_length_threshold), safe_step ? 1 : 0, 0))
-    rec = Ref(IpmRecord(0, 0, 0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0))
     GC.@preserve Cf cf bf begin
         check(ccall((:clrs_mw_ipm_create_ex, lib), Cint, (Ptr{Cvoid}, Ref{IpmData}, Cint), ctx.handle, data, DL))
     end
@@ -464,25 +505,25 @@ function solvesdp(sdp::CLRS.ClusteredLowRankSDP;
     iter, error_code = 1, 0
     dual_error = primal_error = Inf
     gap, d_obj, p_obj, pd_feas = gap0, d_obj0, p_obj0, false
-    while true                                                     # termination: src/solver.jl:921-950
-        dual_feas, primal_feas = dual_error < dual_error_threshold, primal_error < primal_error_threshold
-        ((need_dual_feasible && dual_feas) || (need_primal_feasible && primal_feas)) && break
-        (dual_feas && primal_feas && gap < duality_gap_threshold) && (verbose && println("Optimal solution found"); break)
-        if iter > maxiterations                                    # :362-366
-            verbose && println("The maximum number of iterations has been reached.")
-            error_code = 2
-            break
-        end
-        check(ccall((:clrs_mw_ipm_iterate, lib), Cint, (Ptr{Cvoid}, Ref{IpmRecord}), ctx.handle, rec))
-        r = rec[]
-        if verbose                                                 # the row of :566-582: values from the start of the iteration, step lengths from its end
-            CLRS.@printf("%5d %8.1f %11.3e %11.3e %11.3e %10.2e %10.2e %10.2e %10.2e %10.2e %10.2e %10.2e\n", iter, time() - time_start,
-                         r.mu, d_obj, p_obj, gap, r.max_P, r.max_p, r.max_d, r.alpha_d, r.alpha_p, r.beta_c)
-        end
+    # The whole loop in ONE call (clrs_mw_ipm_solve_cb): the library enqueues iterations one ahead of the record it waits for and the device evaluates the
+    # termination test of src/solver.jl:921-950 itself -- the path bench.py measures.  The rows of the iteration table (:566-582) are printed by a callback as
+    # the host reads each record; the records come back as well.
+    table = TableState(1, time_start, d_obj0, p_obj0, gap0)
+    row_cb = @cfunction(print_row, Cvoid, (Ptr{IpmRecord}, Ptr{Cvoid}))
+    nrec = max(Int(maxiterations), 1)
+    recs = Vector{IpmRecord}(undef, nrec)
+    n_it, err = Ref{Cint}(0), Ref{Cint}(0)
+    stop = Ref(IpmStop(Float64(duality_gap_threshold), need_dual_feasible ? 1 : 0, need_primal_feasible ? 1 : 0, Int32(maxiterations), 0))
+    GC.@preserve table recs begin
+        check(ccall((:clrs_mw_ipm_solve_cb, lib), Cint, (Ptr{Cvoid}, Ref{IpmStop}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{IpmRecord}, Cint, Ref{Cint}, Ref{Cint}),
+                    ctx.handle, stop, verbose ? row_cb : C_NULL, pointer_from_objref(table), recs, nrec, n_it, err))
+    end
+    error_code = Int(err[])
+    for i in 1:min(Int(n_it[]), nrec)
+        r = recs[i]
         dual_error, primal_error, pd_feas = r.dual_error, r.primal_error, r.pd_feas != 0
-        if r.error_code != 0                                       # 1 SolverFailure, 3 mu too large, 4 step too short (docs/src/solving.md:64-70)
-            error_code = Int(r.error_code)
-            if verbose && error_code == 1
+        if r.error_code != 0                                       # 1 SolverFailure, 3 mu too large, 4 step too short (docs/src/solving.md:64-70); 5: clrs_hip.h
+            if verbose && r.error_code == 1
                 J = length(sdp.A)
                 if r.cholesky_status > 0
                     j, l = ctx.jl[r.cholesky_status]
@@ -498,6 +539,13 @@ function solvesdp(sdp::CLRS.ClusteredLowRankSDP;
         end
         d_obj, p_obj, gap = r.d_obj, r.p_obj, r.gap
         iter += 1
+    end
+    if verbose
+        if error_code == 2                                         # src/solver.jl:362-366
+            println("The maximum number of iterations has been reached.")
+        elseif error_code == 0 && dual_error < dual_error_threshold && primal_error < primal_error_threshold && gap < duality_gap_threshold
+            println("Optimal solution found")
+        end
     end
     time_total = time() - time_start
     # the iterate back as Arb midpoints in the reference's containers

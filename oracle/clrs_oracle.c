@@ -400,6 +400,16 @@ int oracle_unique_counts(const octx *o, int b, int *UR, int *UL) {
 /* ------------------------------------------------------------------------------------------ */
 /* compute_S_integrated!  (src/solver.jl:1062-1226), REAL version on internal buffers          */
 /* ------------------------------------------------------------------------------------------ */
+/* The reference's `matmul_prec` (src/solver.jl:125, 304, 312-313): part_r and the bilinear pairings are matrices of matmul_prec bits and their products
+ * run at matmul_prec (:1125-1143).  Here: while the pairing products run, the working precision of the multi-limb type is oracle_matmul_bits_ (0 = no change). */
+static int oracle_matmul_bits_ = 0;
+#if defined(ORACLE_MP)
+#define MATMUL_PREC_BEGIN const int matmul_save_ = mpx_prec_bits; if (oracle_matmul_bits_ > 0) mpx_prec_bits = oracle_matmul_bits_;
+#define MATMUL_PREC_END mpx_prec_bits = matmul_save_;
+#else
+#define MATMUL_PREC_BEGIN
+#define MATMUL_PREC_END
+#endif
 static void schur_assemble_real(octx *o, const REAL *Xchol, const REAL *Y) {
     REAL *Xinv = o->Xinv_tmp, *T1 = Xinv + (i64)o->maxn * o->maxn, *T2 = T1 + (i64)o->maxn * o->maxn;
     memset(o->S, 0, sizeof(REAL) * o->Slen);                          /* :1082 */
@@ -427,6 +437,7 @@ static void schur_assemble_real(octx *o, const REAL *Xchol, const REAL *Y) {
             int UR = k->UR[r];
             if (UR == 0) continue;
             REAL *part = ralloc((i64)n * UR);
+            MATMUL_PREC_BEGIN
             for (int which = 0; which < 2; which++) {
                 const REAL *M = which == 0 ? Yb : Xinv;
                 gemm_nn(n, UR, dl, M + (i64)r * dl * n, n, k->rightvecs[r], dl, part, n);       /* :1125 / :1137 */
@@ -437,6 +448,7 @@ static void schur_assemble_real(octx *o, const REAL *Xchol, const REAL *Y) {
                     gemm_nn(UL, UR, dl, k->leftvecs[s], UL, part + (i64)s * dl, n, bp, UL);     /* :1131 / :1143 */
                 }
             }
+            MATMUL_PREC_END
             free(part);
         }
         /* A_Y: w^T Y v per term (:1152-1170; here for every (r,s), the reference keeps s <= r) */
@@ -1094,6 +1106,8 @@ void oracle_set_precision_bits(int bits) { (void)bits; }
 int oracle_real_bits(void) { return 53; }
 void oracle_set_precision_bits(int bits) { (void)bits; }
 #endif
+/* the reference's matmul_prec (bits; 0 = the working precision); effective in the multi-limb builds */
+void oracle_set_matmul_precision_bits(int bits) { oracle_matmul_bits_ = bits; }
 void oracle_set_num_threads(int n) {
     if (n > 0) omp_set_num_threads(n);
 }

@@ -90,6 +90,7 @@ def _lib(quad):
         L.oracle_unique_counts.argtypes = [C.c_void_p, C.c_int, _p_i, _p_i]
         L.oracle_real_bits.restype = C.c_int
         L.oracle_set_precision_bits.argtypes = [C.c_int]
+        L.oracle_set_matmul_precision_bits.argtypes = [C.c_int]
         L.oracle_real_op.argtypes = [C.c_int, C.c_int, C.c_longlong, _p_d, _p_d, _p_d]
         L.oracle_cholesky_blocks_mw.restype = C.c_int
         L.oracle_cholesky_blocks_mw.argtypes = [C.c_void_p, C.c_int, _p_d, _p_d]
@@ -148,9 +149,10 @@ class Oracle:
     the reference's Arb midpoints at `prec=p`).  The precision is a property of the loaded library, not of the
     context: it is re-applied by every method of a multi-precision context."""
 
-    def __init__(self, flat, quad: bool = False, use_lo: bool = True, mp_bits: Optional[int] = None):
+    def __init__(self, flat, quad: bool = False, use_lo: bool = True, mp_bits: Optional[int] = None, matmul_bits: Optional[int] = None):
         self.flat = flat
         self.mp_bits = mp_bits
+        self.matmul_bits = matmul_bits      # the reference's matmul_prec (src/solver.jl:125): bits of the pairing products; None = the working precision
         if mp_bits is not None:
             if not 1 <= mp_bits <= MP10_LIMB_BITS:
                 raise ValueError("mp_bits must be within 1..%d" % MP10_LIMB_BITS)
@@ -209,6 +211,7 @@ class Oracle:
     def _prec(self):
         if self.mp_bits is not None:
             self.L.oracle_set_precision_bits(int(self.mp_bits))
+            self.L.oracle_set_matmul_precision_bits(int(self.matmul_bits or 0))
 
     # -- hot path on k-limb planar arrays (shape (k, len); value = sum over axis 0) -----------------
     def cholesky_blocks_mw(self, X):

@@ -127,7 +127,7 @@ def _julia_type_of(ctype):
         "int": {"Cint"}, "int32_t": {"Cint", "Int32"}, "double": {"Cdouble", "Float64"}, "void": {"Cvoid"},
         "double*": {"Ptr{Float64}"}, "int*": {"Ptr{Cint}", "Ref{Cint}"}, "int32_t*": {"Ptr{Int32}", "Ptr{Cint}"}, "void*": {"Ptr{Cvoid}", "Ptr{UInt8}"},
         "char*": {"Cstring"}, "clrs_ctx*": {"Ptr{Cvoid}"}, "clrs_mw_ctx*": {"Ptr{Cvoid}"}, "clrs_ctx**": {"Ref{Ptr{Cvoid}}"}, "clrs_mw_ctx**": {"Ref{Ptr{Cvoid}}"},
-        "clrs_sdp_desc*": {"Ref{SdpDesc}"}, "clrs_ipm_data*": {"Ref{IpmData}"}, "clrs_ipm_params*": {"Ref{IpmParams}"}, "clrs_ipm_record*": {"Ref{IpmRecord}"},
+        "clrs_sdp_desc*": {"Ref{SdpDesc}"}, "clrs_ipm_data*": {"Ref{IpmData}"}, "clrs_ipm_params*": {"Ref{IpmParams}"}, "clrs_ipm_record*": {"Ref{IpmRecord}", "Ptr{IpmRecord}"}, "clrs_ipm_stop*": {"Ref{IpmStop}"}, "clrs_mw_options*": {"Ref{MwOptions}"}, "clrs_ipm_record_fn": {"Ptr{Cvoid}"},
     }
     return table.get(t)
 
@@ -154,15 +154,15 @@ def test_every_julia_ccall_matches_its_c_prototype():
                 assert allowed is not None, (name, ca)
                 assert ja in allowed, (name, ja, ca)
             checked.add(name)
-    for must in ("clrs_mw_create_ex", "clrs_mw_schur_assemble", "clrs_mw_schur_factor", "clrs_mw_get_factor", "clrs_mw_schur_solve", "clrs_mw_ipm_create_ex",
-                 "clrs_mw_ipm_set_params", "clrs_mw_ipm_init", "clrs_mw_ipm_iterate", "clrs_mw_ipm_get", "clrs_mw_ipm_set", "clrs_mw_ipm_objectives"):
+    for must in ("clrs_mw_create_opts", "clrs_mw_schur_assemble", "clrs_mw_schur_factor", "clrs_mw_get_factor", "clrs_mw_schur_solve", "clrs_mw_ipm_create_ex",
+                 "clrs_mw_ipm_set_params", "clrs_mw_ipm_init", "clrs_mw_ipm_solve_cb", "clrs_mw_ipm_get", "clrs_mw_ipm_set", "clrs_mw_ipm_objectives"):
         assert must in checked, must
 
 
 def test_julia_ipm_structs_match_the_header():
     hdr = open(os.path.join(ROOT, "include", "clrs_hip.h")).read()
     jl = open(os.path.join(ROOT, "julia", "ClusteredLowRankHIP", "src", "ClusteredLowRankHIP.jl")).read()
-    for cname, jname in (("clrs_ipm_data", "IpmData"), ("clrs_ipm_params", "IpmParams"), ("clrs_ipm_record", "IpmRecord")):
+    for cname, jname in (("clrs_ipm_data", "IpmData"), ("clrs_ipm_params", "IpmParams"), ("clrs_ipm_record", "IpmRecord"), ("clrs_ipm_stop", "IpmStop")):
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), hdr, flags=re.S).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         c_fields = []
@@ -182,6 +182,36 @@ def test_julia_ipm_structs_match_the_header():
             base = typ[4:-1] if ptr else typ
             j_fields.append((name, {"Int32": "int32_t", "Int64": "int64_t", "Float64": "double"}[base], ptr))
         assert j_fields == c_fields, (cname, j_fields, c_fields)
+
+
+def test_julia_options_struct_and_matmul_prec():
+    """`struct MwOptions` of the Julia package is `clrs_mw_options` field for field (eight int32), and `matmul_prec` is forwarded, not refused."""
+    hdr = open(os.path.join(ROOT, "include", "clrs_hip.h")).read()
+    jl = open(os.path.join(ROOT, "julia", "ClusteredLowRankHIP", "src", "ClusteredLowRankHIP.jl")).read()
+    body = re.sub(r"/\*.*?\*/", "", re.search(r"typedef struct clrs_mw_options \{(.*?)\} clrs_mw_options;", hdr, flags=re.S).group(1), flags=re.S)
+    c_names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if decl:
+            m = re.match(r"int32_t\s+(\w+)(\[(\d+)\])?$", decl)
+            assert m, decl
+            c_names += [m.group(1)] if not m.group(3) else [m.group(1) + str(i + 1) for i in range(int(m.group(3)))]
+    jbody = re.search(r"struct MwOptions\n(.*?)\nend", jl, flags=re.S).group(1)
+    j_fields = [tuple(t.strip() for t in line.split("::")) for line in jbody.strip().splitlines()]
+    assert [n for n, _ in j_fields] == c_names and all(t == "Int32" for _, t in j_fields) and len(c_names) == 8
+    from clrs_amd import _lib
+    import ctypes
+    assert ctypes.sizeof(_lib.MwOptions) == 32 and [n for n, _ in _lib.MwOptions._fields_][:6] == c_names[:6]
+    assert "matmul_prec is not available" not in jl and "matmul_limbs=(matmul_prec == prec ? 0 : min(K, limbs_for(matmul_prec)))" in jl
+
+
+def test_julia_front_end_runs_the_one_call_loop():
+    """Round-4 review: the drop-in front end must be the measured path -- `solvesdp` calls clrs_mw_ipm_solve_cb (iterations enqueued one ahead, termination
+    on the device) once, prints the table rows from a callback, and no longer loops over clrs_mw_ipm_iterate."""
+    jl = open(os.path.join(ROOT, "julia", "ClusteredLowRankHIP", "src", "ClusteredLowRankHIP.jl")).read()
+    body = jl[jl.index("function solvesdp(sdp::CLRS.ClusteredLowRankSDP;"):jl.index("function optimize!(")]
+    assert ":clrs_mw_ipm_solve_cb" in body and ":clrs_mw_ipm_iterate" not in body and "while true" not in body
+    assert "@cfunction(print_row, Cvoid, (Ptr{IpmRecord}, Ptr{Cvoid}))" in body and "function print_row(recp::Ptr{IpmRecord}, user::Ptr{Cvoid})::Cvoid" in jl
 
 
 def test_julia_front_end_forwards_warm_starts_and_declares_its_optimizer():

@@ -3,6 +3,8 @@
 The oracle computes at 320 bits (oracle/mpx.hpp, the stand-in for the reference's Arb midpoints); the HIP path at K limbs of
 fp64 (about 53 K - K bits).  Tolerances are stated per test as 2^-(53 K - slack): `slack` covers the length of the dot
 products and the conditioning of the seeded iterates (cond ~ 10), nothing else."""
+import os
+
 import numpy as np
 import pytest
 
@@ -179,6 +181,58 @@ def test_stream_words_and_events_give_the_same_solve(oracle_built):
     a, b = out
     assert a.iterations == b.iterations and np.array_equal(a.history, b.history)
     assert np.array_equal(a.x, b.x) and np.array_equal(a.y, b.y) and np.array_equal(a.X, b.X) and np.array_equal(a.Y, b.Y)
+
+
+def test_verbose_table_rows_come_from_the_callback_of_the_one_call_loop(capsys, oracle_built):
+    """clrs_mw_ipm_solve_cb: `verbose` prints the reference's table rows (src/solver.jl:566-582) from a callback per record while the loop stays the
+    one-call loop (iterations enqueued one ahead, termination on the device): as many rows as iterations, the row of iteration k carrying the objectives
+    of the iterate it started from, and bit for bit the solve of the silent call."""
+    from clrs_amd.mw import MwSchurContext, solvesdp_mw
+    f = flat("ce_8_3")
+    kw = dict(limbs=4, duality_gap_threshold=1e-10, dual_error_threshold=1e-20, primal_error_threshold=1e-20)
+    ctx = MwSchurContext(f, limbs=4)
+    a = solvesdp_mw(f, ctx=ctx, **kw)
+    capsys.readouterr()
+    b = solvesdp_mw(f, ctx=ctx, verbose=True, **kw)
+    out = [l for l in capsys.readouterr().out.splitlines() if l.strip() and l.split()[0].isdigit()]
+    ctx.close()
+    assert a.status == b.status == "Optimal" and np.array_equal(a.history, b.history) and np.array_equal(a.y, b.y)
+    assert len(out) == b.iterations and [int(l.split()[0]) for l in out] == list(range(1, b.iterations + 1))
+    for k, l in enumerate(out):
+        cols = l.split()
+        assert abs(float(cols[2]) - b.history[k, 1]) <= 1e-3 * abs(b.history[k, 1])                       # mu
+        assert abs(float(cols[3]) - b.history[k, 2]) <= 1e-3 * abs(b.history[k, 2]) + 1e-300             # D-obj of the iterate the iteration started from
+
+
+def test_matmul_prec_reduces_the_pairing_products_as_the_oracle_does(oracle_built):
+    """The reference's `matmul_prec` keyword (src/solver.jl:125, 304, 312-313, 1125-1143): the products that form the pairing matrices at fewer bits than the
+    rest.  clrs_mw_options.matmul_limbs = 4 at 5 limbs (~209 bits): S_j agrees with the oracle whose pairing products run at 212 bits as closely as two
+    209-bit computations can, and is measurably further from the oracle at full precision; a whole solve with the reference's default thresholds gets at least as far as the
+    oracle's with the same matmul_prec (which ends in a SolverFailure near gap 1e-14 where its full-precision solve ends Optimal)."""
+    from clrs_amd.mw import MwSchurContext, solvesdp_mw
+    from oracle.oracle import Oracle
+    f = flat("ce_8_15")
+    K = 5
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "ce_8_15_traj.npz"))
+    X, Y = z["X"][2][:K], z["Y"][2][:K]                       # iterate of iteration 28
+    pad = lambda a: np.vstack([a, np.zeros((1, a.shape[1]))])
+    ctx = MwSchurContext(f, limbs=K, matmul_limbs=4)
+    Xc = ctx.cholesky_blocks(X)
+    S, _ = ctx.compute_S_integrated(Xc, Y)
+    ctx.close()
+    S_red, _ = Oracle(f, mp_bits=320, matmul_bits=212).schur_assemble_mw(pad(Xc), pad(Y))
+    S_full, _ = Oracle(f, mp_bits=320).schur_assemble_mw(pad(Xc), pad(Y))
+    e_red, e_full, e_orc = mw_relerr(S, S_red), mw_relerr(S, S_full), mw_relerr(S_red[:K], S_full)
+    assert e_orc > 2.0 ** -225, np.log2(e_orc)                     # the oracle's own reduction is visible at this iterate ...
+    assert 2.0 ** -225 < e_full < 2.0 ** -150, np.log2(e_full)     # ... and so is the GPU's, at the same order
+    assert e_red < 2.0 ** -150 and abs(np.log2(e_full) - np.log2(e_orc)) < 30, (np.log2(e_red), np.log2(e_full), np.log2(e_orc))
+    ro = Oracle(f, mp_bits=256, matmul_bits=212).solvesdp()
+    rg = solvesdp_mw(f, limbs=K, matmul_prec=212)
+    # the oracle forms X^-1 explicitly and rounds X^-1 V to matmul_prec (the reference's method 3, :1117-1143: errors relative to |X^-1| |V|); the HIP path
+    # rounds Z = chol(X)^-1 V and takes V^T X^-1 V = Z^T Z (errors relative to the Gram matrix itself), so at the same matmul_prec its S_j is at least as
+    # good: the oracle ends with a failed factorisation at gap 4e-14, the HIP solve goes at least as far
+    assert ro["error_code"] == 1 and ro["gap"] < 1e-9
+    assert rg.duality_gap <= 10 * ro["gap"] and abs(rg.primal_objective - ro["p_obj"]) <= 1e-9, (rg.status, rg.error_code, rg.duality_gap, ro["gap"])
 
 
 def test_refined_predictor_option_and_comm_probe_without_communicator(oracle_built):
