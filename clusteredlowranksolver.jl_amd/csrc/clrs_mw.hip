@@ -826,7 +826,8 @@ extern "C" int clrs_mw_create_opts(const clrs_sdp_desc *d, int data_limbs, int d
     {   // factor stage and solve products in fewer limbs, residuals and iterate in K (mw_kf_of): the LDS-resident paths with the full-limb refinement step
         bool all_lds = true;
         for (auto &cl : c->clu) all_lds = all_lds && cl.lds;
-        const bool may = mw_kf_of(K) < K && c->refine == 1 && !c->wide_solve && all_lds && (N == 0 || c->lds_q || c->pipe_Q);
+        (void)all_lds;
+        const bool may = mw_kf_of(K) < K && c->refine == 1;      // (every factorisation and solve path carries the reduced form: LDS-resident, pipelined, blocked, row-parallel)
         c->kf_low = may ? mw_kf_of(K) : K;
         if (cfg_factor_limbs != 0 && cfg_factor_limbs != K && cfg_factor_limbs != c->kf_low) MW_BAIL(CLRS_ERR_INVALID, "factor_limbs: 0 (automatic), the context's limbs, or the reduced count of this limb count where the LDS-resident refined solve runs");
         if (cfg_factor_limbs == K) c->kf_low = K;

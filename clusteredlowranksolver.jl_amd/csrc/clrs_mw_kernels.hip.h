@@ -1264,16 +1264,12 @@ struct MwBp {                // one matrix being factored: planar M and its inve
     int n, ld, code, which;            // info[which] = code on failure
     int slot, pad;                     // arrival counter pcnt[J + 1 + slot] of the workgroups that share a diagonal block
 };
-template <int K>
-__global__ __launch_bounds__(MW_PT) void k_mw_bp_diag(const MwDev q, const MwBp *__restrict__ ms, int nm, int j0) {
-    mw_mark(q);
+// (the blocked path with MwDev::kf < K: every kernel below reads KA = kf planes of the matrices it works on, in place, and stores its results with the upper
+// K - KA planes zero -- what the trailing matrix has not been through yet still holds the K-limb input, read as its truncation)
+template <int K, int KA>
+__device__ __forceinline__ void mw_bp_diag_body(const MwDev &q, const MwBp &m, int j0) {
     using namespace mwk;
     constexpr int MW_PB = MW_PB_OF(K);
-    // rows of the grid beyond the nm matrices of this launch (the first launch of the factorisation of the S_j adds them): the clusters that fit
-    // in LDS, factored beside the first diagonal block of the large ones instead of in a launch of their own in front of it
-    if ((int)blockIdx.y >= nm) { mw_factor_cluster<K>(q, blockIdx.y - nm, blockIdx.x, gridDim.x); return; }
-    const MwBp m = ms[blockIdx.y];
-    if (j0 >= m.n) return;
     const int nb = min(MW_PB, m.n - j0), tid = threadIdx.x;
     lds_d *scr = MW_LDS, *D = MW_LDS + MW_POTRF_SCR(K, MW_PB), *W = D + (long)K * MW_PB * MW_PB, *rdl = W + (long)K * MW_TRI(MW_PB);
     const int cw = blockIdx.x, cnw = gridDim.x;         // the workgroups share out the columns of the inverse of the diagonal block
@@ -1281,31 +1277,42 @@ __global__ __launch_bounds__(MW_PT) void k_mw_bp_diag(const MwDev q, const MwBp 
     // the arrival count below, which every workgroup of the launch must reach
     bool ok = false;
     if (q.info[m.which] == MW_INFO_NONE) {
-        wg_copy<K, MW_PT>(D, (long)nb * nb, nb, m.M + j0 + (long)j0 * m.ld, m.plane, m.ld, nb, nb, tid);
+        wg_copy<KA, MW_PT>(D, (long)nb * nb, nb, m.M + j0 + (long)j0 * m.ld, m.plane, m.ld, nb, nb, tid);
         __syncthreads();
-        ok = wg_potrf<K, true, MW_PT>(D, (long)nb * nb, nb, nb, rdl, nb, W, MW_TRI(nb), 0, scr, tid, cw, cnw);     // W packed
+        ok = wg_potrf<KA, true, MW_PT>(D, (long)nb * nb, nb, nb, rdl, nb, W, MW_TRI(nb), 0, scr, tid, cw, cnw);     // W packed
         if (!ok && tid == 0) atomicMin(&q.info[m.which], m.code);
     }
     if (ok) {
         for (int e = tid; e < nb * nb; e += MW_PT) {
             const int i = e % nb, c = e / nb;
-            if (c % cnw == cw) stx<K>(m.Mi, m.plane, (j0 + i) + (long)(j0 + c) * m.ld, i >= c ? ldx<K>(W, MW_TRI(nb), w_index(i, c, nb, 0)) : zero<K>());
+            if (c % cnw == cw) stx<K>(m.Mi, m.plane, (j0 + i) + (long)(j0 + c) * m.ld, i >= c ? cvt<K, KA>(ldx<KA>(W, MW_TRI(nb), w_index(i, c, nb, 0))) : zero<K>());
         }
     }
     // the factor overwrites its input: by the workgroup that finishes last, when all have read it
     if (!wg_last_block(&q.pcnt[q.J + 1 + m.slot], cnw) || !ok) return;
     for (int e = tid; e < nb * nb; e += MW_PT) {
         const int i = e % nb, c = e / nb;
-        stx<K>(m.M, m.plane, (j0 + i) + (long)(j0 + c) * m.ld, i >= c ? ldx<K>(D, (long)nb * nb, e) : zero<K>());
+        stx<K>(m.M, m.plane, (j0 + i) + (long)(j0 + c) * m.ld, i >= c ? cvt<K, KA>(ldx<KA>(D, (long)nb * nb, e)) : zero<K>());
     }
-    for (int i = tid; i < nb; i += MW_PT) stx<K>(m.rd, m.rdplane, j0 + i, ldx<K>(rdl, nb, i));
+    for (int i = tid; i < nb; i += MW_PT) stx<K>(m.rd, m.rdplane, j0 + i, cvt<K, KA>(ldx<KA>(rdl, nb, i)));
+}
+template <int K>
+__global__ __launch_bounds__(MW_PT) void k_mw_bp_diag(const MwDev q, const MwBp *__restrict__ ms, int nm, int j0) {
+    mw_mark(q);
+    using namespace mwk;
+    // rows of the grid beyond the nm matrices of this launch (the first launch of the factorisation of the S_j adds them): the clusters that fit
+    // in LDS, factored beside the first diagonal block of the large ones instead of in a launch of their own in front of it
+    if ((int)blockIdx.y >= nm) { mw_factor_cluster<K>(q, blockIdx.y - nm, blockIdx.x, gridDim.x); return; }
+    const MwBp m = ms[blockIdx.y];
+    if (j0 >= m.n) return;
+    if constexpr (mw_kf_of(K) < K) { if (q.kf < K) { mw_bp_diag_body<K, mw_kf_of(K)>(q, m, j0); return; } }
+    mw_bp_diag_body<K, K>(q, m, j0);
 }
 // rows below the diagonal block: L[r, c] = sum_{k <= c} A[r, k] M_d[c, k]
-template <int K>
-__global__ __launch_bounds__(MW_PT) void k_mw_bp_panel(const MwDev q, const MwBp *__restrict__ ms, int j0) {
+template <int K, int KA>
+__device__ __forceinline__ void mw_bp_panel_body(const MwDev &q, const MwBp &m, int j0) {
     using namespace mwk;
     constexpr int MW_PB = MW_PB_OF(K);
-    const MwBp m = ms[blockIdx.y];
     if (j0 >= m.n || q.info[m.which] != MW_INFO_NONE) return;
     const int nb = min(MW_PB, m.n - j0), tid = threadIdx.x;
     const int r0 = j0 + nb + blockIdx.x * MW_BP_PR;
@@ -1315,7 +1322,7 @@ __global__ __launch_bounds__(MW_PT) void k_mw_bp_panel(const MwDev q, const MwBp
     const long ap = (long)MW_BP_PR * MW_PB;
     for (int e = tid; e < MW_BP_PR * nb; e += MW_PT) {
         const int r = e % MW_BP_PR, c = e / MW_BP_PR;
-        if (r < nr) stx<K>(At, ap, e, ldx<K>(m.M, m.plane, (r0 + r) + (long)(j0 + c) * m.ld));
+        if (r < nr) stx<KA>(At, ap, e, ldx<KA>(m.M, m.plane, (r0 + r) + (long)(j0 + c) * m.ld));
     }
     __syncthreads();
     constexpr int LP = MW_PT / (MW_BP_PR * MW_PB);          // lanes per entry
@@ -1324,21 +1331,26 @@ __global__ __launch_bounds__(MW_PT) void k_mw_bp_panel(const MwDev q, const MwBp
         const int e = e0 + tid / LP;
         const bool live = e < MW_BP_PR * nb && (e % MW_BP_PR) < nr;
         const int ee = live ? e : 0, r = ee % MW_BP_PR, c = ee / MW_BP_PR;
-        acc<K> s;
-        acc_zero<K>(s);
-        for (int kk = sub; kk <= c; kk += LP) acc_fma<K, K, K>(s, ldx<K>(At, ap, r + (long)kk * MW_BP_PR), ldx<K>(m.Mi, m.plane, (j0 + c) + (long)(j0 + kk) * m.ld));
-        const mw<K> v = lanes_sum<K, LP>(acc_result<K>(s));
-        if (live && sub == 0) stx<K>(m.M, m.plane, (r0 + r) + (long)(j0 + c) * m.ld, v);
+        acc<KA> s;
+        acc_zero<KA>(s);
+        for (int kk = sub; kk <= c; kk += LP) acc_fma<KA, KA, KA>(s, ldx<KA>(At, ap, r + (long)kk * MW_BP_PR), ldx<KA>(m.Mi, m.plane, (j0 + c) + (long)(j0 + kk) * m.ld));
+        const mw<KA> v = lanes_sum<KA, LP>(acc_result<KA>(s));
+        if (live && sub == 0) stx<K>(m.M, m.plane, (r0 + r) + (long)(j0 + c) * m.ld, cvt<K, KA>(v));
     }
+}
+template <int K>
+__global__ __launch_bounds__(MW_PT) void k_mw_bp_panel(const MwDev q, const MwBp *__restrict__ ms, int j0) {
+    const MwBp m = ms[blockIdx.y];
+    if constexpr (mw_kf_of(K) < K) { if (q.kf < K) { mw_bp_panel_body<K, mw_kf_of(K)>(q, m, j0); return; } }
+    mw_bp_panel_body<K, K>(q, m, j0);
 }
 // trailing update: A[i, j] -= sum_c L[i, j0 + c] L[j, j0 + c], i >= j >= j0 + nb
 // (split into the first MW_PB columns -- all the next diagonal block and panel need -- and a rest that rides on the next diagonal block's launch: measured,
 // no gain: the launch of the first columns takes what the whole update takes, a 32-term dot product over four lanes per entry, whatever the entry count)
-template <int K>
-__global__ __launch_bounds__(MW_NT) void k_mw_bp_syrk(const MwDev q, const MwBp *__restrict__ ms, int j0) {
+template <int K, int KA>
+__device__ __forceinline__ void mw_bp_syrk_body(const MwDev &q, const MwBp &m, int j0) {
     using namespace mwk;
     constexpr int MW_PB = MW_PB_OF(K);
-    const MwBp m = ms[blockIdx.y];
     if (j0 >= m.n || q.info[m.which] != MW_INFO_NONE) return;
     const int nb = min(MW_PB, m.n - j0), t0 = j0 + nb, mm = m.n - t0;
     const long tot = (long)mm * (mm + 1) / 2;
@@ -1349,17 +1361,23 @@ __global__ __launch_bounds__(MW_NT) void k_mw_bp_syrk(const MwDev q, const MwBp 
     int ii, jj;
     tri_index(live ? (int)e : 0, ii, jj);
     const int i = t0 + ii, j = t0 + jj;
-    acc<K> s;
-    acc_zero<K>(s);
-    if (sub == 0) acc_add<K, K>(s, ldx<K>(m.M, m.plane, i + (long)j * m.ld));
-    for (int c = sub; c < nb; c += MW_BP_SW) acc_fma<K, K, K>(s, ldx<K>(m.M, m.plane, i + (long)(j0 + c) * m.ld), ldx<K>(m.M, m.plane, j + (long)(j0 + c) * m.ld), -1.0);
-    const mw<K> v = lanes_sum<K, MW_BP_SW>(acc_result<K>(s));
-    if (live && sub == 0) stx<K>(m.M, m.plane, i + (long)j * m.ld, v);
+    acc<KA> s;
+    acc_zero<KA>(s);
+    if (sub == 0) acc_add<KA, KA>(s, ldx<KA>(m.M, m.plane, i + (long)j * m.ld));
+    for (int c = sub; c < nb; c += MW_BP_SW) acc_fma<KA, KA, KA>(s, ldx<KA>(m.M, m.plane, i + (long)(j0 + c) * m.ld), ldx<KA>(m.M, m.plane, j + (long)(j0 + c) * m.ld), -1.0);
+    const mw<KA> v = lanes_sum<KA, MW_BP_SW>(acc_result<KA>(s));
+    if (live && sub == 0) stx<K>(m.M, m.plane, i + (long)j * m.ld, cvt<K, KA>(v));
+}
+template <int K>
+__global__ __launch_bounds__(MW_NT) void k_mw_bp_syrk(const MwDev q, const MwBp *__restrict__ ms, int j0) {
+    const MwBp m = ms[blockIdx.y];
+    if constexpr (mw_kf_of(K) < K) { if (q.kf < K) { mw_bp_syrk_body<K, mw_kf_of(K)>(q, m, j0); return; } }
+    mw_bp_syrk_body<K, K>(q, m, j0);
 }
 // blocks (j, i) of L^-1 with j - i = d: T = sum_{i <= k < j} L_jk (L^-1)_ki (the block columns between are contiguous: one
 // sum over the rows i MW_PB .. j MW_PB - 1), then (L^-1)_ji = -(L^-1)_jj T
-template <int K>
-__device__ __forceinline__ void mw_bp_inv_block(const MwDev &q, const MwBp &m, int bi, int bj, int cblk) {
+template <int K, int KA>
+__device__ __forceinline__ void mw_bp_inv_block_ka(const MwDev &q, const MwBp &m, int bi, int bj, int cblk) {
     using namespace mwk;
     constexpr int MW_PB = MW_PB_OF(K);
     if (q.info[m.which] != MW_INFO_NONE) return;
@@ -1376,21 +1394,26 @@ __device__ __forceinline__ void mw_bp_inv_block(const MwDev &q, const MwBp &m, i
     const bool live = r < nj && cl < pc;
     const int rr = live ? r : 0, col = ci0 + c0 + (live ? cl : 0);
     {
-        acc<K> s;
-        acc_zero<K>(s);
+        acc<KA> s;
+        acc_zero<KA>(s);
         for (int t = col + sub; t < rj0; t += LW)              // rows of (L^-1)[:, col] above its diagonal are zero
-            acc_fma<K, K, K>(s, ldx<K>(m.M, m.plane, (rj0 + rr) + (long)t * m.ld), ldx<K>(m.Mi, m.plane, t + (long)col * m.ld));
-        const mw<K> v = lanes_sum<K, LW>(acc_result<K>(s));
-        if (sub == 0) stx<K>(T, tp, e, live ? v : zero<K>());
+            acc_fma<KA, KA, KA>(s, ldx<KA>(m.M, m.plane, (rj0 + rr) + (long)t * m.ld), ldx<KA>(m.Mi, m.plane, t + (long)col * m.ld));
+        const mw<KA> v = lanes_sum<KA, LW>(acc_result<KA>(s));
+        if (sub == 0) stx<KA>(T, tp, e, live ? v : zero<KA>());
     }
     __syncthreads();
     {
-        acc<K> s;
-        acc_zero<K>(s);
-        for (int t = sub; t <= rr; t += LW) acc_fma<K, K, K>(s, ldx<K>(m.Mi, m.plane, (rj0 + rr) + (long)(rj0 + t) * m.ld), ldx<K>(T, tp, t + (long)(live ? cl : 0) * MW_PB), -1.0);
-        const mw<K> v = lanes_sum<K, LW>(acc_result<K>(s));
-        if (live && sub == 0) stx<K>(m.Mi, m.plane, (rj0 + r) + (long)col * m.ld, v);
+        acc<KA> s;
+        acc_zero<KA>(s);
+        for (int t = sub; t <= rr; t += LW) acc_fma<KA, KA, KA>(s, ldx<KA>(m.Mi, m.plane, (rj0 + rr) + (long)(rj0 + t) * m.ld), ldx<KA>(T, tp, t + (long)(live ? cl : 0) * MW_PB), -1.0);
+        const mw<KA> v = lanes_sum<KA, LW>(acc_result<KA>(s));
+        if (live && sub == 0) stx<K>(m.Mi, m.plane, (rj0 + r) + (long)col * m.ld, cvt<K, KA>(v));
     }
+}
+template <int K>
+__device__ __forceinline__ void mw_bp_inv_block(const MwDev &q, const MwBp &m, int bi, int bj, int cblk) {
+    if constexpr (mw_kf_of(K) < K) { if (q.kf < K) { mw_bp_inv_block_ka<K, mw_kf_of(K)>(q, m, bi, bj, cblk); return; } }
+    mw_bp_inv_block_ka<K, K>(q, m, bi, bj, cblk);
 }
 template <int K>
 __global__ __launch_bounds__(MW_PT) void k_mw_bp_inv(const MwDev q, const MwBp *__restrict__ ms, int d) { mw_bp_inv_block<K>(q, ms[blockIdx.z], blockIdx.x, blockIdx.x + d, blockIdx.y); }
@@ -1655,15 +1678,17 @@ __global__ __launch_bounds__(MW_NT) void k_mw_solve_bwd(const MwDev q, const dou
 //   4  dy = Qi^T z                         5  t <- t + LB dy                                                          6  dx = Si^T t (per cluster)
 // vz: 2 N numbers of scratch (v, then z), planar with plane 2 N.  Unsharded contexts only (the sharded solve exchanges the partial u_j).
 #define MW_SW_L 16
-template <int K>
-__global__ __launch_bounds__(MW_NT) void k_mw_solve_wide(const MwDev q, int stage, const double *__restrict__ rhs_x, const double *__restrict__ rhs_y,
-                                                         double *__restrict__ dx, double *__restrict__ dy, double *__restrict__ vz) {
+// KA <= K: limbs of the products (MwDev::kf); the difference rhs_y - [uadd] - LB^T t of stage 2 -- which cancels to the size of a residual in the refinement's
+// second pass -- is accumulated in K limbs from KA-limb operands; what is stored carries K planes, the upper ones zero
+template <int K, int KA>
+__device__ __forceinline__ void mw_solve_wide_body(const MwDev &q, int stage, const double *__restrict__ rhs_x, const double *__restrict__ rhs_y,
+                                                   double *__restrict__ dx, double *__restrict__ dy, double *__restrict__ vz) {
     using namespace mwk;
     constexpr int RPW = MW_NT / MW_SW_L;
     const int sub = threadIdx.x % MW_SW_L, row = blockIdx.x * RPW + threadIdx.x / MW_SW_L, N = q.N;
     const long lbp = q.xlen * (long)N, qp = (long)N * N, vp = 2L * N;
-    acc<K> s;
-    acc_zero<K>(s);
+    acc<KA> s;
+    acc_zero<KA>(s);
     if (stage == 1 || stage == 6) {
         const MwClu &c = q.clu[blockIdx.y];
         const int P = c.P;
@@ -1672,44 +1697,54 @@ __global__ __launch_bounds__(MW_NT) void k_mw_solve_wide(const MwDev q, int stag
         const int i = live ? row : 0;
         const double *Si = q.Si + c.Soff;
         if (stage == 1) {
-            for (int cc = sub; cc <= i; cc += MW_SW_L) acc_fma<K, K, K>(s, ldx<K>(Si, q.Slen, i + (long)cc * P), ldx<K>(rhs_x, q.xlen, c.coff + cc));
+            for (int cc = sub; cc <= i; cc += MW_SW_L) acc_fma<KA, KA, KA>(s, ldx<KA>(Si, q.Slen, i + (long)cc * P), ldx<KA>(rhs_x, q.xlen, c.coff + cc));
         } else {
-            for (int cc = i + sub; cc < P; cc += MW_SW_L) acc_fma<K, K, K>(s, ldx<K>(Si, q.Slen, cc + (long)i * P), ldx<K>(q.t, q.xlen, c.coff + cc));
+            for (int cc = i + sub; cc < P; cc += MW_SW_L) acc_fma<KA, KA, KA>(s, ldx<KA>(Si, q.Slen, cc + (long)i * P), ldx<KA>(q.t, q.xlen, c.coff + cc));
         }
-        const mw<K> v = lanes_sum<K, MW_SW_L>(acc_result<K>(s));
-        if (live && sub == 0) stx<K>(stage == 1 ? q.t : dx, q.xlen, c.coff + i, v);
+        const mw<KA> v = lanes_sum<KA, MW_SW_L>(acc_result<KA>(s));
+        if (live && sub == 0) stx<K>(stage == 1 ? q.t : dx, q.xlen, c.coff + i, cvt<K, KA>(v));
         return;
     }
     if (stage == 5) {
         if ((long)blockIdx.x * RPW >= q.xlen) return;
         const bool live = row < q.xlen;
         const long g = live ? row : 0;
-        if (sub == 0) acc_add<K, K>(s, ldx<K>(q.t, q.xlen, g));
-        for (int a = sub; a < N; a += MW_SW_L) acc_fma<K, K, K>(s, ldx<K>(q.LB, lbp, g + a * q.xlen), ldx<K>(dy, N, a));
-        const mw<K> v = lanes_sum<K, MW_SW_L>(acc_result<K>(s));
-        if (live && sub == 0) stx<K>(q.t, q.xlen, g, v);
+        if (sub == 0) acc_add<KA, KA>(s, ldx<KA>(q.t, q.xlen, g));
+        for (int a = sub; a < N; a += MW_SW_L) acc_fma<KA, KA, KA>(s, ldx<KA>(q.LB, lbp, g + a * q.xlen), ldx<KA>(dy, N, a));
+        const mw<KA> v = lanes_sum<KA, MW_SW_L>(acc_result<KA>(s));
+        if (live && sub == 0) stx<K>(q.t, q.xlen, g, cvt<K, KA>(v));
         return;
     }
     if (blockIdx.x * RPW >= N) return;
     const bool live = row < N;
     const int a = live ? row : 0;
     if (stage == 2) {
+        acc<K> sk;
+        acc_zero<K>(sk);
         if (sub == 0) {
-            acc_add<K, K>(s, ldx<K>(rhs_y, N, a));
-            if (q.uadd) acc_add<K, K>(s, ldx<K>(q.uadd, N, a), -1.0);
+            acc_add<K, K>(sk, ldx<K>(rhs_y, N, a));
+            if (q.uadd) acc_add<K, K>(sk, ldx<K>(q.uadd, N, a), -1.0);
         }
-        for (long g = sub; g < q.xlen; g += MW_SW_L) acc_fma<K, K, K>(s, ldx<K>(q.LB, lbp, g + a * q.xlen), ldx<K>(q.t, q.xlen, g), -1.0);
+        for (long g = sub; g < q.xlen; g += MW_SW_L) acc_fma<K, KA, KA>(sk, ldx<KA>(q.LB, lbp, g + a * q.xlen), ldx<KA>(q.t, q.xlen, g), -1.0);
+        const mw<K> v = lanes_sum<K, MW_SW_L>(acc_result<K>(sk));
+        if (live && sub == 0) stx<K>(vz, vp, a, v);
+        return;
     } else if (stage == 3) {
-        for (int cc = sub; cc <= a; cc += MW_SW_L) acc_fma<K, K, K>(s, ldx<K>(q.Qi, qp, a + (long)cc * N), ldx<K>(vz, vp, cc));
+        for (int cc = sub; cc <= a; cc += MW_SW_L) acc_fma<KA, KA, KA>(s, ldx<KA>(q.Qi, qp, a + (long)cc * N), ldx<KA>(vz, vp, cc));
     } else {
-        for (int cc = a + sub; cc < N; cc += MW_SW_L) acc_fma<K, K, K>(s, ldx<K>(q.Qi, qp, cc + (long)a * N), ldx<K>(vz, vp, N + cc));
+        for (int cc = a + sub; cc < N; cc += MW_SW_L) acc_fma<KA, KA, KA>(s, ldx<KA>(q.Qi, qp, cc + (long)a * N), ldx<KA>(vz, vp, N + cc));
     }
-    const mw<K> v = lanes_sum<K, MW_SW_L>(acc_result<K>(s));
+    const mw<KA> v = lanes_sum<KA, MW_SW_L>(acc_result<KA>(s));
     if (live && sub == 0) {
-        if (stage == 2) stx<K>(vz, vp, a, v);
-        else if (stage == 3) stx<K>(vz, vp, N + a, v);
-        else stx<K>(dy, N, a, v);
+        if (stage == 3) stx<K>(vz, vp, N + a, cvt<K, KA>(v));
+        else stx<K>(dy, N, a, cvt<K, KA>(v));
     }
+}
+template <int K>
+__global__ __launch_bounds__(MW_NT) void k_mw_solve_wide(const MwDev q, int stage, const double *__restrict__ rhs_x, const double *__restrict__ rhs_y,
+                                                         double *__restrict__ dx, double *__restrict__ dy, double *__restrict__ vz) {
+    if constexpr (mw_kf_of(K) < K) { if (q.kf < K) { mw_solve_wide_body<K, mw_kf_of(K)>(q, stage, rhs_x, rhs_y, dx, dy, vz); return; } }
+    mw_solve_wide_body<K, K>(q, stage, rhs_x, rhs_y, dx, dy, vz);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1730,9 +1765,26 @@ __global__ __launch_bounds__(MW_NT) void k_mw_refine(const MwDev q, int stage, c
     constexpr int RPW = MW_NT / MW_SW_L;
     const int sub = threadIdx.x % MW_SW_L, row = blockIdx.x * RPW + threadIdx.x / MW_SW_L, N = q.N;
     if (stage == 3) {
+        double mc[2] = {0.0, 0.0}, mv[2] = {0.0, 0.0};      // largest |correction| and |value| of dx, dy this thread has seen: MwDev::refstat
         for (long i = (long)blockIdx.x * MW_NT + threadIdx.x; i < q.xlen + N; i += (long)gridDim.x * MW_NT) {
-            if (i < q.xlen) stx<K>(dx, q.xlen, i, add<K>(ldx<K>(dx, q.xlen, i), ldx<K>(q.dx2, q.xlen, i)));
-            else stx<K>(dy, N, i - q.xlen, add<K>(ldx<K>(dy, N, i - q.xlen), ldx<K>(q.dy2, N, i - q.xlen)));
+            const bool isx = i < q.xlen;
+            double *v = isx ? dx : dy;
+            const double *cr = isx ? q.dx2 : q.dy2;
+            const long pl = isx ? (long)q.xlen : (long)N, at = isx ? i : i - q.xlen;
+            const mw<K> old = ldx<K>(v, pl, at), cor = ldx<K>(cr, pl, at);
+            mc[isx ? 0 : 1] = fmax(mc[isx ? 0 : 1], __builtin_fabs(cor.l[0])); mv[isx ? 0 : 1] = fmax(mv[isx ? 0 : 1], __builtin_fabs(old.l[0]));
+            stx<K>(v, pl, at, add<K>(old, cor));
+        }
+        if (q.refstat) {
+#pragma unroll
+            for (int w = 0; w < 2; w++) {
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) { mc[w] = fmax(mc[w], __shfl_xor(mc[w], off, 64)); mv[w] = fmax(mv[w], __shfl_xor(mv[w], off, 64)); }
+                if ((threadIdx.x & 63) == 0 && mv[w] > 0.0) {
+                    atomicMax(q.refstat + 2 * w, (unsigned long long)__double_as_longlong(mc[w]));
+                    atomicMax(q.refstat + 2 * w + 1, (unsigned long long)__double_as_longlong(mv[w]));
+                }
+            }
         }
         return;
     }

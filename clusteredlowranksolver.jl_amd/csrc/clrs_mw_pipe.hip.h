@@ -426,7 +426,8 @@ __global__ __launch_bounds__(MWP_NT) void k_mw_bp_diag_pipe(const MwDev q, const
     m.pc = q.pipe_pc + (long)(q.pipe_bp + b.slot) * MWP_PC_WORDS(K);
     m.fail_code = b.code;
     m.stamps = nullptr;
-    mwp_run<K, K>(m, role, epoch, &q.info[b.which], threadIdx.x);      // (the blocked path keeps all K limbs)
+    if constexpr (mw_kf_of(K) < K) { if (q.kf < K) { mwp_run<K, mw_kf_of(K)>(m, role, epoch, &q.info[b.which], threadIdx.x); return; } }
+    mwp_run<K, K>(m, role, epoch, &q.info[b.which], threadIdx.x);
 }
 
 #endif
