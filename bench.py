@@ -623,12 +623,25 @@ def main():
         try:
             fc = json.load(open(os.path.join(ROOT, "profiles", "mw_factor_counters.json")))
             if fc["limbs"] == K:
-                ctx.set_timing(True)
+                # the factor stage as the TIMED loop runs it: in the reduced limb count of the mixed-precision refinement (clrs_mw_options.factor_limbs; inside
+                # clrs_mw_ipm_* that is automatic, the stand-alone entry points this measurement goes through take it on request)
+                kf = K - 1 if K in (5, 6) else K
+                cf = MwSchurContext(flat, limbs=K, device=local_rank, factor_limbs=kf)
+
+                def fstep():
+                    cf.cholesky_blocks_dev(dX.data_ptr(), dXc.data_ptr())
+                    cf.assemble_dev(dXc.data_ptr(), dY.data_ptr())
+                    cf.factor_dev()
+                    cf.solve_dev(drx.data_ptr(), dry.data_ptr(), ddx.data_ptr(), ddy.data_ptr())
                 for _ in range(5):
-                    step()
-                t_f = ctx.timings()[1]                      # chol S_j + L^-1 B of the last pass (HIP events on the context stream)
-                ctx.set_timing(False)
-                tm5 = ctx.timings()
+                    fstep()
+                cf.set_timing(True)
+                for _ in range(5):
+                    fstep()
+                t_f = cf.timings()[1]                       # chol S_j + L^-1 B of the last pass (HIP events on the context stream)
+                cf.set_timing(False)
+                tm5 = cf.timings()
+                cf.close()
                 insts, cus = fc["k_mw_factor"]["SQ_INSTS_VALU"], fc["k_mw_factor"]["workgroups"]
                 t_k = fc["k_mw_factor"]["share_of_stage"] * t_f
                 peak = cus * 4 * 2.4e9 / 4.0                # fp64 VALU wave instructions per second of the occupied compute units
@@ -636,7 +649,7 @@ def main():
                 out["roofline_timed"] = {"kernel": kname, "bound": "fp64 VALU issue of the occupied compute units", "unit": "G wave-instructions/s",
                                          "achieved": insts / t_k / 1e9, "peak": peak / 1e9, "frac": insts / t_k / peak, "traffic": None,
                                          "kernel_us": 1e6 * t_k, "compute_units": cus, "of_256_compute_units": cus / 256.0,
-                                         "valu_wave_instructions": insts, "source": fc["source"],
+                                         "valu_wave_instructions": insts, "source": fc["source"], "factor_limbs": kf,
                                          "what": "SQ_INSTS_VALU x 4 cycles / (occupied CUs x 4 SIMDs x kernel cycles): the chain of 32 dependent pivot steps of a "
                                                  "fraction-free elimination -- since round 4 a pipeline of column-block stages over workgroups (clrs_mw_pipe.hip.h) -- "
                                                  "keeps this many of 256 compute units busy at this share of their fp64 issue slots",

@@ -272,15 +272,27 @@ def main(argv=None, emit=True):
         bXc = np.concatenate([np.linalg.cholesky(bX[big.block_off[b]:big.block_off[b + 1]].reshape(int(big.block_n[b]), -1, order="F"))
                               .reshape(-1, order="F") for b in range(big.n_blocks)])
         tbXc, tbY = torch.from_numpy(bXc).to(dev), torch.from_numpy(bY).to(dev)
-        for _ in range(50):      # clocks and caches in their steady state before the timed launches
-            bctx.assemble_dev(tbXc.data_ptr(), tbY.data_ptr())
+        # clocks and caches in their steady state before the timed launches: the device ramps its clocks up over the first ~15 ms of sustained load (measured,
+        # scripts/w3_time.py: batches of 200 launches 63.6, 59.1, 58.2, 58.2, 58.3 us per launch) -- 50 launches, as this warm-up was until round 5, end in the
+        # middle of the ramp.  Batches of 100 until a batch is no longer 1 % faster than the one before it (at most 12).
+        warm_us = []
+        for _ in range(12):
+            w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            w0.record()
+            for _ in range(100):
+                bctx.assemble_dev(tbXc.data_ptr(), tbY.data_ptr())
+            w1.record()
+            w1.synchronize()
+            warm_us.append(10.0 * w0.elapsed_time(w1))
+            if len(warm_us) >= 3 and warm_us[-1] > 0.99 * warm_us[-2] and warm_us[-2] > 0.99 * warm_us[-3]:
+                break
         torch.cuda.synchronize()
         bprof = kernel_profile(bctx, lambda: bctx.assemble_dev(tbXc.data_ptr(), tbY.data_ptr()), 20)      # which kernels, launches per assembly
         # the timed region: 100 assemblies back to back between two HIP events on the stream the kernels run on (the library is
         # bound to torch's current stream).  One event pair per launch, as in kernel_profile, adds the event packets' own 3-5 us to
         # every launch; the batch includes the gaps between launches instead (conservative against rocprofv3's pure durations).
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        n_timed = 100
+        n_timed = 400
         ev0.record()
         for _ in range(n_timed):
             bctx.assemble_dev(tbXc.data_ptr(), tbY.data_ptr())
@@ -301,7 +313,8 @@ def main(argv=None, emit=True):
             err = np.max(np.abs(Sb[k * f.S_len:(k + 1) * f.S_len] - Sk)) / np.max(np.abs(Sk))
             assert err < 1e-10, ("roofline instance parity", k, err)
         out["roofline"] = {"bound": "hbm", "phase": "schur_assemble", "kernel": bdom[0], "kernel_avg_us": 1e6 * basm,
-                           "timed_region": f"{n_timed} launches back to back between two HIP events",
+                           "timed_region": f"{n_timed} launches back to back between two HIP events, behind warm-up batches of 100 launches until the batch time is steady",
+                           "warmup_batches_us_per_launch": warm_us,
                            "kernel_avg_us_event_pair_per_launch": 1e6 * per_launch_events_s,
                            "kernel_launches_per_assembly": bdom[1][1], "assembly_us": 1e6 * basm,
                            "achieved": bcnt["assemble_bytes"] / basm / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",

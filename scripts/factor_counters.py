@@ -34,8 +34,8 @@ d = {r[0]: r for r in rows}
 fk = "k_mw_factor_pipe<5>" if "k_mw_factor_pipe<5>" in d else "k_mw_factor<5>"
 f, l = d[fk], d["k_mw_linvb<5, 2>"]
 ent = lambda r: {"SQ_INSTS_VALU": r[3], "SQ_BUSY_CYCLES": r[4], "workgroups": r[2], "duration_us": r[6], "issue_utilisation": r[7]}
-json.dump({"source": f"profiles/r04/{tag}_pmc_iter_sq_counters.csv (rocprofv3 --pmc SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES -- python3 scripts/mw_iter_profile.py ce_8_15 2; durations from --kernel-trace of the same command)",
-           "limbs": 5, "k_mw_factor": dict(ent(f), kernel=fk.split("<")[0], share_of_stage=f[6] / (f[6] + l[6])),
+json.dump({"source": f"profiles/r05/{tag}_pmc_iter_sq_counters.csv (rocprofv3 --pmc SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES -- python3 scripts/mw_iter_profile.py ce_8_15 2; durations from --kernel-trace of the same command)",
+           "limbs": 5, "factor_limbs": "4 in 55 of the 56 iterations of the solve (mixed-precision refinement), 5 in the last", "k_mw_factor": dict(ent(f), kernel=fk.split("<")[0], share_of_stage=f[6] / (f[6] + l[6])),
            "k_mw_potrf_q": ent(d["k_mw_potrf_q<5>"]) if "k_mw_potrf_q<5>" in d else ent(d["k_mw_potrf_q_pipe<5>"]),
            "k_mw_potrf_x": ent(d["k_mw_potrf_x<5>"])},
           open(out_json, "w"), indent=1)
