@@ -31,6 +31,9 @@ struct MwIpmDev {
     int *wcnt;                         // [2 NB] workgroups of a (block, which) that have delivered their panel
     double *rec;                       // fp64 record of the iteration
     int *flags;                        // [0] pd_feas, [1] error_code, [2] Cholesky failure inside the step length
+    int klow, pad4;                    // limbs of the arithmetic of THIS launch of k_mwi_wA / k_mwi_Zi / k_mwi_dots: K, or (the predictor's dX, dY and the dot products
+                                       // that lead to beta_c, when the factor stage runs reduced: clrs_mw_ipm_host.inc) mw_kf_of(K) -- the predictor's (dx, dy) come from
+                                       // factors of that many limbs, unrefined, and feed beta_c and the second-order term of the corrector only
     double *tau, *ttau, *utau;         // the corrector's right-hand side is affine in mu_c (mw_ipm_enqueue): tau_g = <A_g, X^-1> (xlen; k_mwi_rows mode 0 forms it beside d),
                                        // t_tau = Si tau (xlen), u_tau = LB^T t_tau (J x N slabs; both ride on the Cholesky of Q); null: the corrector waits for mu_c
     int *sync;                         // [3] "the dot products behind the predictor are complete" (stored by the corrector's first launch), [4] "mu_c is there" (side stream); [0] the number of the last iteration whose side-stream work (everything the predictor's solve reads) is complete (k_mwi_mark)
@@ -569,6 +572,33 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_R(const MwDev q, const MwIpmDev p
 // sel bit 0: <X,Y>; bit 1: <X,dY>, <dX,Y>, <dX,dY>; bit 2: <C,Y>
 // r_tiles > 0: the launch carries r_tiles * NB more workgroups that form the corrector's R' = -XY - dX dY (mwi_R_body): it depends on the
 // predictor's dX, dY only, like the dot products, and not on the beta_c they lead to -- one launch, side by side, instead of two in a row
+template <int K, int KA, int DK>
+__device__ __forceinline__ void mwi_dots_body(const MwDev &q, const MwIpmDev &p, int sel) {
+    using namespace mwk;
+    const MwBlk &k = q.blk[blockIdx.x];
+    const int tid = threadIdx.x;
+    const long nn = (long)k.n * k.n;
+    acc<KA> a0, a1, a4;
+    acc_zero<KA>(a0); acc_zero<KA>(a1); acc_zero<KA>(a4);
+    for (long i = tid; i < nn; i += MW_NT) {
+        const long e = k.xyoff + i;
+        mw<KA> Y = ldx<KA>(p.Y, q.xylen, e);
+        if (sel & 1) acc_fma<KA, KA, KA>(a0, ldx<KA>(p.X, q.xylen, e), Y);
+        if (sel & 2) {
+            mw<KA> X = ldx<KA>(p.X, q.xylen, e), dX = ldx<KA>(p.dX, q.xylen, e), dY = ldx<KA>(p.dY, q.xylen, e);
+            acc_fma<KA, KA, KA>(a1, X, dY);                   // only the sum of the three is ever used (:429): one accumulator, one reduction
+            acc_fma<KA, KA, KA>(a1, dX, Y);
+            acc_fma<KA, KA, KA>(a1, dX, dY);
+        }
+        if (sel & 4) acc_fma<KA, KA, DK>(a4, Y, ldx<DK>(p.C, q.xylen, e));
+    }
+    lds_d *red = MW_LDS;
+    if (sel & 1) { mw<KA> r = wg_reduce_sum<KA>(acc_result<KA>(a0), red, tid); if (tid == 0) stx<K>(p.part, 5L * q.NB, 0L * q.NB + blockIdx.x, cvt<K, KA>(r)); }
+    if (sel & 2) {
+        mw<KA> r = wg_reduce_sum<KA>(acc_result<KA>(a1), red, tid); if (tid == 0) stx<K>(p.part, 5L * q.NB, 1L * q.NB + blockIdx.x, cvt<K, KA>(r));
+    }
+    if (sel & 4) { mw<KA> r = wg_reduce_sum<KA>(acc_result<KA>(a4), red, tid); if (tid == 0) stx<K>(p.part, 5L * q.NB, 4L * q.NB + blockIdx.x, cvt<K, KA>(r)); }
+}
 template <int K, int DK>
 __global__ __launch_bounds__(MW_NT) void k_mwi_dots(const MwDev q, const MwIpmDev p, int sel, int r_tiles) {
     using namespace mwk;
@@ -578,29 +608,8 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_dots(const MwDev q, const MwIpmDe
         else mwi_R_body<K, MWI_EW>(q, p, 1, w % r_tiles, w / r_tiles);
         return;
     }
-    const MwBlk &k = q.blk[blockIdx.x];
-    const int tid = threadIdx.x;
-    const long nn = (long)k.n * k.n;
-    acc<K> a0, a1, a4;
-    acc_zero<K>(a0); acc_zero<K>(a1); acc_zero<K>(a4);
-    for (long i = tid; i < nn; i += MW_NT) {
-        const long e = k.xyoff + i;
-        mw<K> Y = ldx<K>(p.Y, q.xylen, e);
-        if (sel & 1) acc_fma<K, K, K>(a0, ldx<K>(p.X, q.xylen, e), Y);
-        if (sel & 2) {
-            mw<K> X = ldx<K>(p.X, q.xylen, e), dX = ldx<K>(p.dX, q.xylen, e), dY = ldx<K>(p.dY, q.xylen, e);
-            acc_fma<K, K, K>(a1, X, dY);                   // only the sum of the three is ever used (:429): one accumulator, one reduction
-            acc_fma<K, K, K>(a1, dX, Y);
-            acc_fma<K, K, K>(a1, dX, dY);
-        }
-        if (sel & 4) acc_fma<K, K, DK>(a4, Y, ldx<DK>(p.C, q.xylen, e));
-    }
-    lds_d *red = MW_LDS;
-    if (sel & 1) { mw<K> r = wg_reduce_sum<K>(acc_result<K>(a0), red, tid); if (tid == 0) stx<K>(p.part, 5L * q.NB, 0L * q.NB + blockIdx.x, r); }
-    if (sel & 2) {
-        mw<K> r = wg_reduce_sum<K>(acc_result<K>(a1), red, tid); if (tid == 0) stx<K>(p.part, 5L * q.NB, 1L * q.NB + blockIdx.x, r);
-    }
-    if (sel & 4) { mw<K> r = wg_reduce_sum<K>(acc_result<K>(a4), red, tid); if (tid == 0) stx<K>(p.part, 5L * q.NB, 4L * q.NB + blockIdx.x, r); }
+    if constexpr (mw_kf_of(K) < K) { if (p.klow < K) { mwi_dots_body<K, mw_kf_of(K), DK>(q, p, sel); return; } }
+    mwi_dots_body<K, K, DK>(q, p, sel);
 }
 
 
@@ -622,8 +631,8 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_coef(const MwDev q, const MwIpmDe
 // products: cheaper than the launch of k_mwi_coef in front of this kernel); 0: read from p.coef (blocks with more terms than LDS holds)
 // EW lanes per entry: four, or sixteen for blocks with hundreds of terms (every term is a chain of dependent gathers: its flag, its two vector
 // indices, the vectors' entries -- the lanes of an entry walk their share of the terms one after the other)
-template <int K, int DK, int EW>
-__device__ __forceinline__ void mwi_wA_body(const MwDev &q, const MwIpmDev &p, int mode, int coef_lds, int use_B) {
+template <int K, int KA, int DK, int EW>
+__device__ __forceinline__ void mwi_wA_body_ka(const MwDev &q, const MwIpmDev &p, int mode, int coef_lds, int use_B) {
     using namespace mwk;
     const MwBlk &k = q.blk[blockIdx.y];
     const int n = k.n;
@@ -636,7 +645,7 @@ __device__ __forceinline__ void mwi_wA_body(const MwDev &q, const MwIpmDev &p, i
         const double *av = mode == 0 ? p.x : p.dx;
         const MwClu &cl0 = q.clu[k.j];
         for (int t = threadIdx.x; t < t_cnt; t += MW_NT)
-            stx<K>(cf, t_cnt, t, mulx<K, K, DK>(ldx<K>(av, q.xlen, cl0.coff + q.st_p[t_first + t]), ldx<DK>(q.st_lam, q.lamp, t_first + t)));
+            stx<KA>(cf, t_cnt, t, mulx<KA, KA, DK>(ldx<KA>(av, q.xlen, cl0.coff + q.st_p[t_first + t]), ldx<DK>(q.st_lam, q.lamp, t_first + t)));
         __syncthreads();
     }
     const int e = blockIdx.x * (MW_NT / EW) + threadIdx.x / EW, sub = threadIdx.x % EW;
@@ -644,8 +653,8 @@ __device__ __forceinline__ void mwi_wA_body(const MwDev &q, const MwIpmDev &p, i
     const double *a = mode == 0 ? p.x : p.dx;
     const bool mirror = (k.kind == 0 && k.m > 1);
     const bool live = e < n * n && !(mirror && c > i);     // the lower triangle is computed and mirrored (symmetric!(:L), :1462-1465)
-    acc<K> s;
-    acc_zero<K>(s);
+    acc<KA> s;
+    acc_zero<KA>(s);
     if (k.kind == 0) {
         const double *V = q.V + k.v_off;
         const int *tp = q.tptr + k.tptr_off;
@@ -654,29 +663,29 @@ __device__ __forceinline__ void mwi_wA_body(const MwDev &q, const MwIpmDev &p, i
             if (use_B) {                           // coefficient times right vector formed once per term and column (k_mwi_wB): a K x DK product per entry is left
                 const mw<DK> vi = ldx<DK>(V, q.Vp, i + (long)q.st_war[t] * n);
                 if (vi.l[0] == 0.0) continue;
-                acc_fma<K, K, DK>(s, ldx<K>(p.wB, q.T * (long)p.wBn, (long)t * p.wBn + c), vi);
+                acc_fma<KA, KA, DK>(s, ldx<KA>(p.wB, q.T * (long)p.wBn, (long)t * p.wBn + c), vi);
                 continue;
             }
             const mw<DK> vi = ldx<DK>(V, q.Vp, i + (long)q.st_war[t] * n), vc = ldx<DK>(V, q.Vp, c + (long)q.st_wac[t] * n);
             if (vi.l[0] == 0.0 || vc.l[0] == 0.0) continue;
-            constexpr int LL = (2 * DK + 1 < K) ? 2 * DK + 1 : K;
-            acc_fma<K, K, LL>(s, coef_lds ? ldx<K>(cf, t_cnt, t - t_first) : ldx<K>(p.coef, q.T, t), mulx<LL, DK, DK>(vi, vc));
+            constexpr int LL = (2 * DK + 1 < KA) ? 2 * DK + 1 : KA;
+            acc_fma<KA, KA, LL>(s, coef_lds ? ldx<KA>(cf, t_cnt, t - t_first) : ldx<KA>(p.coef, q.T, t), mulx<LL, DK, DK>(vi, vc));
         }
     } else {
         const MwClu &cl = q.clu[k.j];
         const long nn = (long)n * n;
         for (int en = sub; en < k.cnt; en += EW)
-            acc_fma<K, K, DK>(s, ldx<K>(a, q.xlen, cl.coff + q.dense_p[k.d0 + en]), ldx<DK>(q.dA, q.dAp, k.a_off + en * nn + ee));
+            acc_fma<KA, KA, DK>(s, ldx<KA>(a, q.xlen, cl.coff + q.dense_p[k.d0 + en]), ldx<DK>(q.dA, q.dAp, k.a_off + en * nn + ee));
     }
     if (sub == 0) {
         if (mode == 0) {
-            acc_add<K, K>(s, ldx<K>(p.X + k.xyoff, q.xylen, ee), -1.0);
-            acc_add<K, DK>(s, ldx<DK>(p.C, q.xylen, k.xyoff + ee), -p.sgn);
+            acc_add<KA, KA>(s, ldx<KA>(p.X + k.xyoff, q.xylen, ee), -1.0);
+            acc_add<KA, DK>(s, ldx<DK>(p.C, q.xylen, k.xyoff + ee), -p.sgn);
         } else {
-            acc_add<K, K>(s, ldx<K>(p.Pm + k.xyoff, q.xylen, ee));
+            acc_add<KA, KA>(s, ldx<KA>(p.Pm + k.xyoff, q.xylen, ee));
         }
     }
-    const mw<K> v = lanes_sum<K, EW>(acc_result<K>(s));
+    const mw<K> v = cvt<K, KA>(lanes_sum<KA, EW>(acc_result<KA>(s)));
     if (!live || sub != 0) return;
     if (mode == 0) {
         atomic_max_abs(&p.fmax[0], v.l[0]);
@@ -687,6 +696,11 @@ __device__ __forceinline__ void mwi_wA_body(const MwDev &q, const MwIpmDev &p, i
         stx<K>(p.dX + k.xyoff, q.xylen, e, v);
         if (mirror && c != i) stx<K>(p.dX + k.xyoff, q.xylen, c + (long)i * n, v);
     }
+}
+template <int K, int DK, int EW>
+__device__ __forceinline__ void mwi_wA_body(const MwDev &q, const MwIpmDev &p, int mode, int coef_lds, int use_B) {
+    if constexpr (mw_kf_of(K) < K) { if (p.klow < K) { mwi_wA_body_ka<K, mw_kf_of(K), DK, EW>(q, p, mode, coef_lds, use_B); return; } }
+    mwi_wA_body_ka<K, K, DK, EW>(q, p, mode, coef_lds, use_B);
 }
 template <int K, int DK>
 __global__ __launch_bounds__(MW_NT) void k_mwi_wA(const MwDev q, const MwIpmDev p, int mode, int coef_lds, int ew) {
@@ -1031,10 +1045,10 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_Z(const MwDev q, const MwIpmDev p
 // a scratch matrix and the workgroup of a block that finishes last symmetrises it (a counter per block).
 #define MWI_ZS 4
 #define MWI_ZL 8
-template <int K>
-__global__ __launch_bounds__(MW_PT) void k_mwi_Zi(const MwDev q, const MwIpmDev p, int which) {
+// KA <= K: limbs of the three products (MwIpmDev::klow); the panels in the scratch matrix and the symmetrised result carry K planes, the upper ones zero
+template <int K, int KA>
+__device__ __forceinline__ void mwi_Zi_body(const MwDev &q, const MwIpmDev &p, int which) {
     using namespace mwk;
-    mw_mark(q);
     const bool nomu = which == 2;                        // which 2: which 0 without the mu_s I of R (the corrector's Z0: mw_ipm_enqueue adds mu_c <A, X^-1> to the traces instead)
     if (nomu) which = 0;
     const MwBlk &k = q.blk[blockIdx.x];
@@ -1057,13 +1071,13 @@ __global__ __launch_bounds__(MW_PT) void k_mwi_Zi(const MwDev q, const MwIpmDev 
         const int e = e0 + tid / MWI_ZL;
         const bool live = e < n * pc;
         const int ee = live ? e : 0, i = ee % n, c = c0 + ee / n;
-        acc<K> s;
-        acc_zero<K>(s);
-        for (int kk = sub; kk < n; kk += MWI_ZL) acc_fma<K, K, K>(s, ldx<K>(A, q.xylen, i + (long)kk * n), ldx<K>(p.Y + k.xyoff, q.xylen, kk + (long)c * n), sg);
-        if (sub == 0) acc_add<K, K>(s, ldx<K>(p.R + k.xyoff, q.xylen, i + (long)c * n), -sg);
-        if (sub == 1 && i == c && !nomu) acc_add<K, K>(s, ldx<K>(p.sc, MSC_COUNT, MSC_MUS), -sg);      // R = mu_s I + R'
-        const mw<K> v = lanes_sum<K, MWI_ZL>(acc_result<K>(s));
-        if (live && sub == 0) stx<K>(M, np, ee, v);
+        acc<KA> s;
+        acc_zero<KA>(s);
+        for (int kk = sub; kk < n; kk += MWI_ZL) acc_fma<KA, KA, KA>(s, ldx<KA>(A, q.xylen, i + (long)kk * n), ldx<KA>(p.Y + k.xyoff, q.xylen, kk + (long)c * n), sg);
+        if (sub == 0) acc_add<KA, KA>(s, ldx<KA>(p.R + k.xyoff, q.xylen, i + (long)c * n), -sg);
+        if (sub == 1 && i == c && !nomu) acc_add<KA, KA>(s, ldx<KA>(p.sc, MSC_COUNT, MSC_MUS), -sg);      // R = mu_s I + R'
+        const mw<KA> v = lanes_sum<KA, MWI_ZL>(acc_result<KA>(s));
+        if (live && sub == 0) stx<KA>(M, np, ee, v);
     }
     __syncthreads();
     MWZ_STAMP();
@@ -1071,11 +1085,11 @@ __global__ __launch_bounds__(MW_PT) void k_mwi_Zi(const MwDev q, const MwIpmDev 
         const int e = e0 + tid / MWI_ZL;
         const bool live = e < n * pc;
         const int ee = live ? e : 0, i = ee % n, cl = ee / n;
-        acc<K> s;
-        acc_zero<K>(s);
-        for (int r = sub; r <= i; r += MWI_ZL) acc_fma<K, K, K>(s, ldx<K>(Xi, q.xylen, i + (long)r * n), ldx<K>(M, np, r + (long)cl * n));
-        const mw<K> v = lanes_sum<K, MWI_ZL>(acc_result<K>(s));
-        if (live && sub == 0) stx<K>(M2, np, ee, v);
+        acc<KA> s;
+        acc_zero<KA>(s);
+        for (int r = sub; r <= i; r += MWI_ZL) acc_fma<KA, KA, KA>(s, ldx<KA>(Xi, q.xylen, i + (long)r * n), ldx<KA>(M, np, r + (long)cl * n));
+        const mw<KA> v = lanes_sum<KA, MWI_ZL>(acc_result<KA>(s));
+        if (live && sub == 0) stx<KA>(M2, np, ee, v);
     }
     __syncthreads();
     MWZ_STAMP();
@@ -1083,11 +1097,11 @@ __global__ __launch_bounds__(MW_PT) void k_mwi_Zi(const MwDev q, const MwIpmDev 
         const int e = e0 + tid / MWI_ZL;
         const bool live = e < n * pc;
         const int ee = live ? e : 0, i = ee % n, cl = ee / n;
-        acc<K> s;
-        acc_zero<K>(s);
-        for (int r = i + sub; r < n; r += MWI_ZL) acc_fma<K, K, K>(s, ldx<K>(Xi, q.xylen, r + (long)i * n), ldx<K>(M2, np, r + (long)cl * n));
-        const mw<K> v = lanes_sum<K, MWI_ZL>(acc_result<K>(s));
-        if (live && sub == 0) stx<K>(p.Zs + k.xyoff, q.xylen, i + (long)(c0 + cl) * n, v);
+        acc<KA> s;
+        acc_zero<KA>(s);
+        for (int r = i + sub; r < n; r += MWI_ZL) acc_fma<KA, KA, KA>(s, ldx<KA>(Xi, q.xylen, r + (long)i * n), ldx<KA>(M2, np, r + (long)cl * n));
+        const mw<KA> v = lanes_sum<KA, MWI_ZL>(acc_result<KA>(s));
+        if (live && sub == 0) stx<K>(p.Zs + k.xyoff, q.xylen, i + (long)(c0 + cl) * n, cvt<K, KA>(v));
     }
     MWZ_STAMP();
     if (!mwi_last_block(&p.zcnt[blockIdx.x], zs)) return;
@@ -1095,12 +1109,18 @@ __global__ __launch_bounds__(MW_PT) void k_mwi_Zi(const MwDev q, const MwIpmDev 
     for (int e = tid; e < n * n; e += MW_PT) {
         const int i = e % n, c = e / n;
         if (c > i) continue;
-        mw<K> v = mul_pow2<K>(add<K>(ldx<K>(p.Zs + k.xyoff, q.xylen, i + (long)c * n), ldx<K>(p.Zs + k.xyoff, q.xylen, c + (long)i * n)), 0.5);
+        const mw<K> v = cvt<K, KA>(mul_pow2<KA>(add<KA>(ldx<KA>(p.Zs + k.xyoff, q.xylen, i + (long)c * n), ldx<KA>(p.Zs + k.xyoff, q.xylen, c + (long)i * n)), 0.5));
         stx<K>(p.dY + k.xyoff, q.xylen, i + (long)c * n, v);
         stx<K>(p.dY + k.xyoff, q.xylen, c + (long)i * n, v);
     }
     MWZ_STAMP();
 #undef MWZ_STAMP
+}
+template <int K>
+__global__ __launch_bounds__(MW_PT) void k_mwi_Zi(const MwDev q, const MwIpmDev p, int which) {
+    mw_mark(q);
+    if constexpr (mw_kf_of(K) < K) { if (p.klow < K) { mwi_Zi_body<K, mw_kf_of(K)>(q, p, which); return; } }
+    mwi_Zi_body<K, K>(q, p, which);
 }
 
 // The same three products for LARGE blocks (sides beyond ~24), as launches of their own over 8 x 8 output tiles, four lanes per entry: a column panel
