@@ -530,7 +530,7 @@ def main():
             import dataclasses
             from clrs_amd.sdp import FlatSDP
             z = np.load(os.path.join(ROOT, "tests", "golden", "min_f_2.npz"), allow_pickle=False)
-            mf = FlatSDP(**{fl.name: (z[fl.name] if z[fl.name].ndim else z[fl.name].item()) for fl in dataclasses.fields(FlatSDP)})
+            mf = FlatSDP(**{fl.name: (z[fl.name] if z[fl.name].ndim else z[fl.name].item()) for fl in dataclasses.fields(FlatSDP) if fl.name in z.files})
             cm = MwSchurContext(mf, limbs=K, device=local_rank)
             rm = solvesdp_mw(mf, ctx=cm, **thr)
             assert rm.error_code == 0 and rm.status == "Optimal" and abs(rm.primal_objective - (-2.112913881423605)) <= 1e-10, (rm.status, rm.primal_objective)

@@ -208,7 +208,7 @@ _UNITS = (
     *((f"clrs_mw_k{k}.o", "clrs_mw_inst.hip", ("-ffp-contract=off", f"-DMW_INST_K={k}"),
        lambda f: f.startswith("clrs_mw") and f not in ("clrs_mw.hip", "clrs_mw_ipm_host.inc")) for k in (4, 5, 6)),
     *((f"clrs_mw_k{k}p{part}.o", "clrs_mw_inst.hip", ("-ffp-contract=off", f"-DMW_INST_K={k}", f"-DMW_INST_PART={part}"),
-       lambda f: f.startswith("clrs_mw") and f not in ("clrs_mw.hip", "clrs_mw_ipm_host.inc")) for k in (8, 10) for part in (1, 2, 3)),
+       lambda f: f.startswith("clrs_mw") and f not in ("clrs_mw.hip", "clrs_mw_ipm_host.inc")) for k in (8, 10) for part in (1, 2, 3, 4)),
 )
 _COMMON = ("--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value")
 

@@ -212,7 +212,9 @@ static int mw_dmalloc(clrs_mw_ctx *c, double **d, i64 n) {
         MW_CASE(4, 1, __VA_ARGS__) MW_CASE(4, 2, __VA_ARGS__) MW_CASE(5, 1, __VA_ARGS__) MW_CASE(5, 2, __VA_ARGS__)  \
         MW_CASE(6, 1, __VA_ARGS__) MW_CASE(6, 2, __VA_ARGS__) MW_CASE(8, 1, __VA_ARGS__) MW_CASE(8, 2, __VA_ARGS__)  \
         MW_CASE(10, 1, __VA_ARGS__) MW_CASE(10, 2, __VA_ARGS__)                                                      \
-        return mw_fail(CLRS_ERR_INVALID, "limbs must be 2..6, 8 or 10 and data limbs 1 or 2");                      \
+        MW_CASE(3, 3, __VA_ARGS__) MW_CASE(4, 4, __VA_ARGS__) MW_CASE(5, 5, __VA_ARGS__) MW_CASE(6, 6, __VA_ARGS__)  \
+        MW_CASE(8, 8, __VA_ARGS__) MW_CASE(10, 10, __VA_ARGS__)                                                      \
+        return mw_fail(CLRS_ERR_INVALID, "limbs must be 2..6, 8 or 10 and data limbs 1, 2 or the limbs");           \
     } while (0)
 
 template <class F>
@@ -246,10 +248,12 @@ extern "C" int clrs_mw_create_opts(const clrs_sdp_desc *d, int data_limbs, int d
     int cfg_km = opts && opts->matmul_limbs > 0 ? opts->matmul_limbs : limbs;
     if (cfg_km > limbs) cfg_km = limbs;
     while (cfg_km < limbs && !mw_km_ok(limbs, cfg_km)) cfg_km++;
+    if (data_limbs > 2) cfg_exact = 0;                     // (the static digits of the exact slice products are cut from two data limbs)
     if (cfg_km < limbs) cfg_exact = 0;                     // (the exact slice products have one slice count per limb count: the expansion kernels take the reduced products)
     if (cfg_exact > 2 || cfg_refine > 2) return mw_fail(CLRS_ERR_INVALID, "clrs_mw_options: exact_products and refine are 0, 1 or 2 (or < 0 for the default)");
     if (limbs < 2 || limbs > 10 || limbs == 7 || limbs == 9) return mw_fail(CLRS_ERR_INVALID, "limbs must be 2..6, 8 or 10");
-    if (data_limbs < 1 || data_limbs > 2 || data_limbs > limbs) return mw_fail(CLRS_ERR_INVALID, "data limbs must be 1 or 2 (and at most limbs)");
+    if (data_limbs < 1 || data_limbs > limbs || (data_limbs > 2 && data_limbs != limbs))
+        return mw_fail(CLRS_ERR_INVALID, "data limbs must be 1, 2 or the context's limbs (the problem data at the working precision: src/interface.jl:1078-1112)");
     *out = nullptr;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device >= ndev) return mw_fail(CLRS_ERR_NO_DEVICE, "no usable HIP device");
@@ -566,7 +570,7 @@ extern "C" int clrs_mw_create_opts(const clrs_sdp_desc *d, int data_limbs, int d
         else {
             MW_TRY(mw_upload(c, hVs, &c->mws.Vs)); MW_TRY(mw_upload(c, hVe, &c->mws.Vexp));
             MW_TRY(mw_upload(c, hve_off, &c->mws.ve_off)); MW_TRY(mw_upload(c, hsv, &c->mws.sv));
-            MW_DISPATCH(c, { MW_TRY(mw_set_lds((k_mws_pair<KK, DD, 1>), c->sm_mws)); MW_TRY(mw_set_lds((k_mws_pair<KK, DD, 2>), c->sm_mws)); });
+            MW_DISPATCH(c, { if constexpr (DD <= 2) { MW_TRY(mw_set_lds((k_mws_pair<KK, DD, 1>), c->sm_mws)); MW_TRY(mw_set_lds((k_mws_pair<KK, DD, 2>), c->sm_mws)); } });
         }
         MW_TRY(mw_upload(c, mws_off, &c->mws.vs_off));
     }
@@ -682,7 +686,7 @@ extern "C" int clrs_mw_create_opts(const clrs_sdp_desc *d, int data_limbs, int d
             MW_TRY(mw_upload(c, tasks, &c->mwd.tasks));
             MW_TRY(mw_upload(c, hAd, &c->mwd.Ad)); MW_TRY(mw_upload(c, heA, &c->mwd.eA)); MW_TRY(mw_upload(c, he_off, &c->mwd.e_off));
             c->sm_mwd = (size_t)2 * S * sN * sizeof(float) + 128 * sizeof(int);
-            MW_DISPATCH(c, { MW_TRY(mw_set_lds((k_mwx_dense<KK, DD>), c->sm_mwd)); });
+            MW_DISPATCH(c, { if constexpr (DD <= 2) { MW_TRY(mw_set_lds((k_mwx_dense<KK, DD>), c->sm_mwd)); } });
         }
     }
     MW_TRY(mw_upload(c, mwd_off, &c->mwd.a_off));
@@ -940,8 +944,10 @@ extern "C" int clrs_mw_schur_assemble_dev(clrs_mw_ctx *c, const double *d_Xchol,
         const bool exact = c->mws_blocks > 0 && c->xinv_valid;      // the exact-product kernel needs chol(X)^-1 (k_mw_potrf_x of this context)
         bool dense_done = exact && q.ndn && !q.dn_big;          // 1 x 1 dense blocks ride on the launch of the exact pairing matrices ...
         const int pair_grid = q.nlr + (dense_done ? q.ndn : 0);
-        if (exact && c->mws_turns == 1) hipLaunchKernelGGL((k_mws_pair<KK, DD, 1>), dim3(pair_grid), dim3(MWS_NT), c->sm_mws, c->stream, q, c->mws, d_Y);
-        else if (exact) hipLaunchKernelGGL((k_mws_pair<KK, DD, 2>), dim3(pair_grid), dim3(MWS_NT), c->sm_mws, c->stream, q, c->mws, d_Y);
+        if constexpr (DD <= 2) {                             // (data at the working precision: the exact slice products are off, clrs_mw_create_opts)
+            if (exact && c->mws_turns == 1) hipLaunchKernelGGL((k_mws_pair<KK, DD, 1>), dim3(pair_grid), dim3(MWS_NT), c->sm_mws, c->stream, q, c->mws, d_Y);
+            else if (exact) hipLaunchKernelGGL((k_mws_pair<KK, DD, 2>), dim3(pair_grid), dim3(MWS_NT), c->sm_mws, c->stream, q, c->mws, d_Y);
+        }
         if (q.nlr && !(exact && c->mws_blocks == q.nlr)) {
             MwDev q2 = q;
             q2.mws_on = exact ? 1 : 0;
@@ -969,7 +975,7 @@ extern "C" int clrs_mw_schur_assemble_dev(clrs_mw_ctx *c, const double *d_Xchol,
                 if (c->mwd_blocks < q.ndn)
                     hipLaunchKernelGGL((k_mw_dense_tp<KK, DD>), dim3(q.ndn, c->maxcnt, (c->maxn_dense + pcmin - 1) / pcmin), dim3(MW_NT), (size_t)2 * KK * MW_NT * 8, c->stream, q3, d_Y);
                 c->mwd.stamps = c->mws.stamps;
-                if (q3.mwd_on) hipLaunchKernelGGL((k_mwx_dense<KK, DD>), dim3(c->mwd_tasks), dim3(MWS_NT), c->sm_mwd, c->stream, q3, c->mwd, d_Y);
+                if constexpr (DD <= 2) { if (q3.mwd_on) hipLaunchKernelGGL((k_mwx_dense<KK, DD>), dim3(c->mwd_tasks), dim3(MWS_NT), c->sm_mwd, c->stream, q3, c->mwd, d_Y); }
             }
             const int pairs = c->maxcnt * (c->maxcnt + 1) / 2;
             const int ds_lanes = c->maxn_dense * c->maxn_dense <= 128 ? 8 : c->maxn_dense * c->maxn_dense <= 512 ? 16 : 64;      // per pair of the table

@@ -39,11 +39,8 @@
 #define MW_KERNELS_KD(X, K, DK)                                                                                        \
     X __global__ void k_mw_zt<K, DK>(const MwDev, const double *, int, int, int);                                      \
     X __global__ void k_mw_gram<K, DK>(const MwDev, const double *);                                                                   \
-    X __global__ void k_mws_pair<K, DK, 1>(const MwDev, const MwsDev, const double *);                                 \
-    X __global__ void k_mws_pair<K, DK, 2>(const MwDev, const MwsDev, const double *);                                                                   \
     X __global__ void k_mw_dense_t<K, DK>(const MwDev, const double *, int, int, int);                                 \
     X __global__ void k_mw_dense_tp<K, DK>(const MwDev, const double *);                                               \
-    X __global__ void k_mwx_dense<K, DK>(const MwDev, const MwdDev, const double *);                                   \
     X __global__ void k_mw_dense_s<K, DK>(const MwDev, int);                                                           \
     X __global__ void k_mw_saccum<K, DK>(const MwDev, int);                                                                 \
     X __global__ void k_mw_saccum_one<K, DK>(const MwDev, int);                                                             \
@@ -68,6 +65,13 @@
     X __global__ void k_mwi_gpack<K, DK>(const MwDev, const MwIpmDev, int);                                               \
     X __global__ void k_mwi_step<K, DK>(const MwDev, const MwIpmDev, int, int, int, int);
 
-#define MW_KERNELS_ALL(X, K) MW_KERNELS_K(X, K) MW_KERNELS_KD(X, K, 1) MW_KERNELS_KD(X, K, 2)
+// the exact slice products on the matrix cores (clrs_mw_exact.hip.h): data limbs 1 and 2 only (their static digits are cut from two data limbs)
+#define MW_KERNELS_KDX(X, K, DK)                                                                                       \
+    X __global__ void k_mws_pair<K, DK, 1>(const MwDev, const MwsDev, const double *);                                 \
+    X __global__ void k_mws_pair<K, DK, 2>(const MwDev, const MwsDev, const double *);                                 \
+    X __global__ void k_mwx_dense<K, DK>(const MwDev, const MwdDev, const double *);
+
+// (data limbs 1, 2 and K: fp64 data, double-double data, data at the working precision)
+#define MW_KERNELS_ALL(X, K) MW_KERNELS_K(X, K) MW_KERNELS_KD(X, K, 1) MW_KERNELS_KDX(X, K, 1) MW_KERNELS_KD(X, K, 2) MW_KERNELS_KDX(X, K, 2) MW_KERNELS_KD(X, K, K)
 
 #endif

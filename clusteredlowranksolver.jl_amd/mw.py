@@ -99,13 +99,15 @@ class MwSchurContext:
         `pipeline`: Cholesky + inverse factor of matrices of at most 32 rows as a pipeline of workgroups (csrc/clrs_mw_pipe.hip.h): None = the library
         default (the clusters' S_j), False / 0 = never, 1 = S_j, True / 2 = S_j and Q.
         `data_limbs` = 2 (default): the problem data (sampled vectors, lambda, dense A_p, B and, in `solvesdp_mw`, C, c, b) are
-        passed as double-double, the (hi, lo) pairs a FlatSDP carries; 1: the fp64 roundings only."""
+        passed as double-double, the (hi, lo) pairs a FlatSDP carries; 1: the fp64 roundings only; `limbs`: at the working precision, as the reference holds
+        the sampled problem (convert_to_prec, src/interface.jl:1078-1112) -- the planes beyond (hi, lo) come from `FlatSDP.tails` (generators run under
+        `clrs_amd.sdp.data_planes(limbs)`; zero when the FlatSDP has none)."""
         self.flat: FlatSDP = sdp if isinstance(sdp, FlatSDP) else flatten(sdp)
         f = self.flat
         self.limbs = int(limbs)
         self.data_limbs = int(data_limbs)
-        if self.data_limbs not in (1, 2):
-            raise ValueError("data_limbs must be 1 or 2")
+        if self.data_limbs not in (1, 2, self.limbs):
+            raise ValueError("data_limbs must be 1, 2 or `limbs` (the problem data at the working precision: FlatSDP.tails, sdp.data_planes)")
         self.L = _lib.load()
         k = self._keep = {}
 
@@ -114,13 +116,10 @@ class MwSchurContext:
             return k[name]
 
         def data(name):
-            """planar (data_limbs, len) copy of a data array of the FlatSDP: hi [, lo]"""
-            hi = np.ascontiguousarray(getattr(f, name), dtype=np.float64).reshape(-1)
+            """planar (data_limbs, len) copy of a data array of the FlatSDP: hi [, lo [, the planes of FlatSDP.tails]]"""
             if self.data_limbs == 1:
-                return hold(name, hi, np.float64)
-            lo = getattr(f, name + "_lo", None)
-            lo = np.zeros_like(hi) if lo is None else np.ascontiguousarray(lo, dtype=np.float64).reshape(-1)
-            return hold(name, np.vstack([hi, lo]), np.float64)
+                return hold(name, np.ascontiguousarray(getattr(f, name), dtype=np.float64).reshape(-1), np.float64)
+            return hold(name, f.data_planes_of(name, self.data_limbs), np.float64)
 
         self._data = data
         d = _lib.SdpDesc()

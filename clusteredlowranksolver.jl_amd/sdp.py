@@ -22,6 +22,50 @@ except Exception:  # pragma: no cover
     mp = None
 
 
+# Limb planes a HiLo keeps of mpmath input: 2 = (hi, lo), ~106 bits -- what every committed fixture carries; more (`with data_planes(10): ...` around
+# a generator) = the sampled problem at the working precision of a K-limb solve, as the reference holds it (convert_to_prec, src/interface.jl:1078-1112):
+# planes 3.. go to `HiLo.tail` and, through `flatten`, to `FlatSDP.tails`.
+_DATA_PLANES = 2
+
+
+class data_planes:
+    """Context manager: mpmath numbers converted by `HiLo.of` inside it keep `n` fp64 limb planes (2 by default)."""
+
+    def __init__(self, n: int):
+        self.n = max(2, int(n))
+
+    def __enter__(self):
+        global _DATA_PLANES
+        self.old, _DATA_PLANES = _DATA_PLANES, self.n
+        return self
+
+    def __exit__(self, *a):
+        global _DATA_PLANES
+        _DATA_PLANES = self.old
+
+
+def split_planes(x, n: int):
+    """Array-like of mpmath numbers (or floats) -> n float64 arrays whose sum is x to ~53 n bits: successive roundings to nearest."""
+    a = np.asarray(x, dtype=object)
+    out = [np.zeros(a.shape, dtype=np.float64) for _ in range(n)]
+    it = np.nditer(a, flags=["multi_index", "refs_ok"])
+    for _ in it:
+        idx = it.multi_index
+        v = a[idx]
+        if isinstance(v, (float, int, np.floating, np.integer)):
+            out[0][idx] = float(v)
+            continue
+        with mp.workprec(max(mp.mp.prec, 64 * n + 64)):
+            r = mp.mpf(v)
+            for l in range(n):
+                h = float(r)
+                out[l][idx] = h
+                r = r - mp.mpf(h)
+                if r == 0:
+                    break
+    return out
+
+
 def split_hi_lo(x):
     """Split an array-like of mpmath numbers (or floats) into fp64 (hi, lo) with hi+lo ~ x."""
     a = np.asarray(x, dtype=object)
@@ -42,9 +86,10 @@ def split_hi_lo(x):
 
 @dataclass
 class HiLo:
-    """A float64 array plus an optional low-order correction (value = hi + lo)."""
+    """A float64 array plus an optional low-order correction (value = hi + lo [+ sum of `tail`: further limb planes, see `data_planes`])."""
     hi: np.ndarray
     lo: Optional[np.ndarray] = None
+    tail: Optional[List[np.ndarray]] = None
 
     @staticmethod
     def of(x) -> "HiLo":
@@ -52,9 +97,20 @@ class HiLo:
             return x
         a = np.asarray(x)
         if a.dtype == object:
+            if _DATA_PLANES > 2:
+                pl = split_planes(a, _DATA_PLANES)
+                return HiLo(pl[0], pl[1] if np.any(pl[1] != 0.0) else None, pl[2:])
             hi, lo = split_hi_lo(a)
             return HiLo(hi, lo if np.any(lo != 0.0) else None)
         return HiLo(np.asarray(a, dtype=np.float64), None)
+
+    def plane(self, t: int) -> np.ndarray:
+        """limb plane t (0 = hi, 1 = lo, 2.. = tail), zeros where this number has none"""
+        if t == 0:
+            return self.hi
+        if t == 1:
+            return self.lo_or_zero()
+        return self.tail[t - 2] if self.tail is not None and t - 2 < len(self.tail) else np.zeros_like(self.hi)
 
     @property
     def shape(self):
@@ -228,6 +284,24 @@ class FlatSDP:
     block_off: np.ndarray          # int64 [NB+1] offsets of each block in the X/Y layout
     cluster_off: np.ndarray        # int64 [J+1] offsets of each cluster in x (sum P_j)
     S_off: np.ndarray              # int64 [J+1] offsets of S_j (P_j^2) in the concatenated S layout
+    # limb planes 3.. of the data arrays (name -> array of shape (planes - 2, len)), when the generator ran under `data_planes(n > 2)`: the sampled problem
+    # at the working precision of a solve with more than two limbs.  Empty for every committed fixture; `shard_clusters` / `replicate_clusters` drop it.
+    tails: dict = field(default_factory=dict)
+
+    def data_planes_of(self, name: str, planes: int) -> np.ndarray:
+        """the data array `name` ('B', 'c', 'b', 'C', 'term_lambda', 'term_vs', 'term_ws', 'dense_A') as (planes, len): hi, lo, tail planes, zero padded"""
+        hi = np.ascontiguousarray(getattr(self, name), dtype=np.float64).reshape(-1)
+        out = np.zeros((planes, hi.size))
+        out[0] = hi
+        if planes > 1:
+            lo = getattr(self, name + "_lo", None)
+            if lo is not None:
+                out[1] = np.asarray(lo, dtype=np.float64).reshape(-1)
+        t = self.tails.get(name) if self.tails else None
+        if t is not None and planes > 2:
+            k = min(planes - 2, t.shape[0])
+            out[2:2 + k] = t[:k]
+        return out
 
     @property
     def xy_len(self) -> int:
@@ -246,10 +320,40 @@ class FlatSDP:
         return int(self.term_ptr[-1])
 
 
+DATA_ARRAYS = ("B", "c", "b", "C", "term_lambda", "term_vs", "term_ws", "dense_A")
+
+
+def _map_hilo(sdp: ClusteredLowRankSDP, fn) -> ClusteredLowRankSDP:
+    """the same SDP with every HiLo replaced by fn(HiLo) (structure shared)"""
+    def ent(e):
+        return LowRankMat(fn(e.lam), fn(e.vs), fn(e.ws)) if isinstance(e, LowRankMat) else fn(e)
+    blocks = [[Block(bl.m, bl.delta, {rs: {p: ent(e) for p, e in d.items()} for rs, d in bl.entries.items()}, bl.name) for bl in cl] for cl in sdp.blocks]
+    return ClusteredLowRankSDP(sdp.maximize, sdp.constant, blocks, [fn(x) for x in sdp.B], [fn(x) for x in sdp.c],
+                               [[fn(x) for x in cl] for cl in sdp.C], fn(sdp.b), sdp.names)
+
+
 def flatten(sdp: ClusteredLowRankSDP) -> FlatSDP:
-    """Flatten `sdp` into the C-ABI layout.  Terms of a block are emitted sorted by
-    (p, r, s, rank), which is also the order of the per-term A_Y output."""
-    sdp.check()
+    """Flatten `sdp` into the C-ABI layout (`_flatten_core`); limb planes beyond (hi, lo) of its numbers (`data_planes`) go to `FlatSDP.tails`: the layout is
+    linear in the data, so plane t of every data array is the `hi` array of the flattening of the SDP whose numbers are their plane t."""
+    flat = _flatten_core(sdp)
+    ntail = 0
+
+    def probe(h):
+        nonlocal ntail
+        if h.tail is not None:
+            ntail = max(ntail, len(h.tail))
+        return h
+    _map_hilo(sdp, probe)
+    if ntail:
+        planes = [_flatten_core(_map_hilo(sdp, lambda h, t=t: HiLo(h.plane(t + 2).copy(), None)), check=False) for t in range(ntail)]
+        flat.tails = {name: np.stack([np.asarray(getattr(pl, name), dtype=np.float64).reshape(-1) for pl in planes]) for name in DATA_ARRAYS}
+    return flat
+
+
+def _flatten_core(sdp: ClusteredLowRankSDP, check: bool = True) -> FlatSDP:
+    """Terms of a block are emitted sorted by (p, r, s, rank), which is also the order of the per-term A_Y output."""
+    if check:
+        sdp.check()
     J, N = sdp.n_clusters, sdp.n_free
     cluster_P = np.array(sdp.cluster_sizes(), dtype=np.int32)
 
@@ -421,6 +525,7 @@ def replicate_clusters(flat, copies: int):
     J = flat.n_clusters
     parts = [shard_clusters(flat, list(range(J))) for _ in range(copies)]
     f = copy.copy(parts[0])
+    f.tails = {}
     cat = np.concatenate
     f.n_clusters = J * copies
     f.n_blocks = flat.n_blocks * copies

@@ -50,7 +50,9 @@ struct SdpDesc
     dense_A::Ptr{Float64}
 end
 
-const DATA_LIMBS = 2
+# Limb planes of the problem data handed to the library: the reference holds the sampled problem at `prec` bits (convert_to_prec, src/interface.jl:1078-1112),
+# so a solve at `limbs` words per number passes its data with `limbs` planes (clrs_mw_create_opts: data_limbs = 1, 2 or limbs); the fp64 entry points take one.
+data_limbs_for(limbs::Integer) = limbs == 1 ? 1 : Int(limbs)
 
 """Device context + the host arrays that back the description (kept alive for the lifetime of the context)."""
 mutable struct HipContext
@@ -118,7 +120,7 @@ Replaces `precompute_matrices_bilinear_pairings` (src/solver.jl:985-1059) and th
 """
 function HipContext(sdp::CLRS.ClusteredLowRankSDP, cs_map; device::Integer=0, limbs::Integer=5, matmul_limbs::Integer=0)
     J = length(sdp.A)
-    DL = limbs == 1 ? 1 : DATA_LIMBS
+    DL = data_limbs_for(limbs)
     cluster_P = Int32[size(sdp.c[j], 1) for j in 1:J]
     N = size(sdp.B[1], 2)
     # data arrays are collected as Arb and split into DL limb planes at the end
@@ -459,7 +461,7 @@ function solvesdp(sdp::CLRS.ClusteredLowRankSDP;
     cs, var_rels = preprocess ? CLRS.preprocess!(sdp) : ((), nothing)
     cs_map = [renumber_kept(rows_before[j], (t[3] for t in cs if t[2] == j)) for j in eachindex(sdp.B)]
     ctx = HipContext(sdp, cs_map; device=device, limbs=K, matmul_limbs=(matmul_prec == prec ? 0 : min(K, limbs_for(matmul_prec))))
-    DL = DATA_LIMBS
+    DL = data_limbs_for(K)
     nxy, nx, N = ctx.block_off[end], ctx.cluster_off[end], ctx.n_free
     # objective data as DL limb planes: C in the xy layout, c in the x layout, b
     Cf = zeros(Float64, max(nxy, 1), DL); cf = zeros(Float64, max(nx, 1), DL); bf = zeros(Float64, max(N, 1), DL)

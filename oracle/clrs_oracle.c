@@ -75,6 +75,10 @@ typedef struct {
     const int *dense_p;
     const i64 *dense_A_ptr;
     const double *dense_A, *dense_A_lo;
+    /* limb planes 3.. of the data arrays (FlatSDP.tails: the sampled problem at the working precision, as the reference holds it at `prec` bits --
+     * convert_to_prec, src/interface.jl:1078-1112): n_tail planes each, planar with the array's own length; NULL / 0 = none */
+    int n_tail;
+    const double *B_tail, *c_tail, *b_tail, *C_tail, *term_lambda_tail, *term_vs_tail, *term_ws_tail, *dense_A_tail;
 } oracle_sdp;
 
 typedef struct {
@@ -140,6 +144,15 @@ static REAL *ralloc(i64 n) { REAL *p = (REAL *)calloc((size_t)(n > 0 ? n : 1), s
 static REAL *rload(const double *hi, const double *lo, i64 n) {
     REAL *p = ralloc(n);
     for (i64 i = 0; i < n; i++) p[i] = ld(hi, lo, i);
+    return p;
+}
+/* the same with nt more limb planes behind (hi, lo): tail[t * len + off + i], t < nt (the planes have the length of the whole array, `off` is where this
+ * piece starts in it) */
+static REAL *rload_t(const double *hi, const double *lo, const double *tail, int nt, i64 len, i64 off, i64 n) {
+    REAL *p = rload(hi, lo, n);
+    if (tail)
+        for (int t = 0; t < nt; t++)
+            for (i64 i = 0; i < n; i++) p[i] = p[i] + (REAL)tail[(i64)t * len + off + i];
     return p;
 }
 
@@ -278,18 +291,19 @@ octx *oracle_create(const oracle_sdp *d) {
     o->Soff = (i64 *)calloc(o->J + 1, sizeof(i64));
     o->B = (REAL **)calloc(o->J + 1, sizeof(REAL *));
     o->LinvB = (REAL **)calloc(o->J + 1, sizeof(REAL *));
-    i64 boff = 0;
+    i64 boff = 0, Blen_ = 0;
+    for (int j = 0; j < o->J; j++) Blen_ += (i64)d->cluster_P[j] * o->N;      /* length of the whole B array (the plane length of its tail) */
     for (int j = 0; j < o->J; j++) {
         o->P[j] = d->cluster_P[j];
         o->coff[j + 1] = o->coff[j] + o->P[j];
         o->Soff[j + 1] = o->Soff[j] + (i64)o->P[j] * o->P[j];
-        o->B[j] = rload(d->B + boff, d->B_lo ? d->B_lo + boff : NULL, (i64)o->P[j] * o->N);
+        o->B[j] = rload_t(d->B + boff, d->B_lo ? d->B_lo + boff : NULL, d->B_tail, d->n_tail, Blen_, boff, (i64)o->P[j] * o->N);
         o->LinvB[j] = ralloc((i64)o->P[j] * o->N);
         boff += (i64)o->P[j] * o->N;
     }
     o->xlen = o->coff[o->J]; o->Slen = o->Soff[o->J];
-    o->c = rload(d->c, d->c_lo, o->xlen);
-    o->b = rload(d->b, d->b_lo, o->N);
+    o->c = rload_t(d->c, d->c_lo, d->c_tail, d->n_tail, o->xlen, 0, o->xlen);
+    o->b = rload_t(d->b, d->b_lo, d->b_tail, d->n_tail, o->N, 0, o->N);
     o->T = d->term_ptr[o->NB]; o->D = d->dense_ptr[o->NB];
     o->tp = (int *)malloc(sizeof(int) * (o->T + 1)); o->tr = (int *)malloc(sizeof(int) * (o->T + 1));
     o->ts = (int *)malloc(sizeof(int) * (o->T + 1)); o->tk = (int *)malloc(sizeof(int) * (o->T + 1));
@@ -299,14 +313,14 @@ octx *oracle_create(const oracle_sdp *d) {
     memcpy(o->tp, d->term_p, sizeof(int) * o->T); memcpy(o->tr, d->term_r, sizeof(int) * o->T);
     memcpy(o->ts, d->term_s, sizeof(int) * o->T); memcpy(o->tk, d->term_rank, sizeof(int) * o->T);
     memcpy(o->tvptr, d->term_vec_ptr, sizeof(i64) * (o->T + 1));
-    o->tlam = rload(d->term_lambda, d->term_lambda_lo, o->T);
-    o->tvs = rload(d->term_vs, d->term_vs_lo, o->tvptr[o->T]);
-    o->tws = rload(d->term_ws, d->term_ws_lo, o->tvptr[o->T]);
+    o->tlam = rload_t(d->term_lambda, d->term_lambda_lo, d->term_lambda_tail, d->n_tail, o->T, 0, o->T);
+    o->tvs = rload_t(d->term_vs, d->term_vs_lo, d->term_vs_tail, d->n_tail, o->tvptr[o->T], 0, o->tvptr[o->T]);
+    o->tws = rload_t(d->term_ws, d->term_ws_lo, d->term_ws_tail, d->n_tail, o->tvptr[o->T], 0, o->tvptr[o->T]);
     o->dp = (int *)malloc(sizeof(int) * (o->D + 1));
     memcpy(o->dp, d->dense_p, sizeof(int) * o->D);
     o->dAptr = (i64 *)malloc(sizeof(i64) * (o->D + 1));
     memcpy(o->dAptr, d->dense_A_ptr, sizeof(i64) * (o->D + 1));
-    o->dA = rload(d->dense_A, d->dense_A_lo, o->dAptr[o->D]);
+    o->dA = rload_t(d->dense_A, d->dense_A_lo, d->dense_A_tail, d->n_tail, o->dAptr[o->D], 0, o->dAptr[o->D]);
     o->blk = (oblock *)calloc(o->NB + 1, sizeof(oblock));
     i64 off = 0;
     o->maxn = 1;
@@ -364,7 +378,7 @@ octx *oracle_create(const oracle_sdp *d) {
             }
     }
     o->xylen = off;
-    o->C = rload(d->C, d->C_lo, o->xylen);
+    o->C = rload_t(d->C, d->C_lo, d->C_tail, d->n_tail, o->xylen, 0, o->xylen);
     o->S = ralloc(o->Slen);
     o->Q = ralloc((i64)o->N * o->N);
     o->AY = ralloc(o->T);

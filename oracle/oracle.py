@@ -31,6 +31,8 @@ class _OracleSDP(C.Structure):
         ("term_lambda", _p_d), ("term_lambda_lo", _p_d), ("term_vec_ptr", _p_l),
         ("term_vs", _p_d), ("term_vs_lo", _p_d), ("term_ws", _p_d), ("term_ws_lo", _p_d),
         ("dense_ptr", _p_l), ("dense_p", _p_i), ("dense_A_ptr", _p_l), ("dense_A", _p_d), ("dense_A_lo", _p_d),
+        ("n_tail", C.c_int), ("B_tail", _p_d), ("c_tail", _p_d), ("b_tail", _p_d), ("C_tail", _p_d), ("term_lambda_tail", _p_d),
+        ("term_vs_tail", _p_d), ("term_ws_tail", _p_d), ("dense_A_tail", _p_d),
     ]
 
 
@@ -196,6 +198,14 @@ class Oracle:
         d.dense_p = _ip(hold("dp", f.dense_p, np.int32))
         d.dense_A_ptr = _lp(hold("dAp", f.dense_A_ptr, np.int64))
         d.dense_A, d.dense_A_lo = _dp(hold("dA", f.dense_A)), lo("dA_lo", f.dense_A_lo)
+        # limb planes 3.. of the data (FlatSDP.tails: generators run under clrs_amd.sdp.data_planes): the sampled problem at the working precision
+        tails = getattr(f, "tails", None) or {}
+        d.n_tail = 0
+        if tails and quad and use_lo:
+            d.n_tail = int(next(iter(tails.values())).shape[0])
+            for name in ("B", "c", "b", "C", "term_lambda", "term_vs", "term_ws", "dense_A"):
+                t = tails.get(name)
+                setattr(d, name + "_tail", _dp(hold(name + "_tail", t if t is not None and t.size else np.zeros((d.n_tail, 1)))))
         self.ctx = self.L.oracle_create(C.byref(d))
         if not self.ctx:
             raise RuntimeError("oracle_create failed")

@@ -514,6 +514,43 @@ def test_prec_512_and_gap_1e60_as_in_the_reference_tutorial():
     assert abs(r.primal_objective - r5.primal_objective) <= 1e-13
 
 
+def test_problem_data_at_the_working_precision(oracle_built):
+    """The reference holds the sampled problem at `prec` bits (convert_to_prec, src/interface.jl:1078-1112); `data_limbs = limbs` does the same here
+    (round-4 review: with 2-limb data a prec = 512, gap 1e-60 solve describes a neighbouring problem).  cohnelkies(8,15) generated with ten limb planes
+    (`sdp.data_planes`): the 10-limb solve on 10-limb data agrees with the 640-bit oracle on the same data to 1e-55; the solve on the first two planes only
+    is the solution of another problem -- how far away is measured here (its entries reach 1e27: a relative 2^-106 is 1e-5 absolute)."""
+    import mpmath as mp
+    from clrs_amd.mw import solvesdp_mw
+    from clrs_amd.problems import cohnelkies
+    from clrs_amd.sdp import data_planes, flatten
+    from oracle.oracle import Oracle
+    with data_planes(10):
+        f = flatten(cohnelkies(8, 15))
+    assert set(f.tails) >= {"B", "c", "b", "C", "term_lambda", "term_vs", "term_ws", "dense_A"} and f.tails["B"].shape == (8, f.B.size)
+    assert np.max(np.abs(f.tails["B"][0])) > 0 and np.max(np.abs(f.tails["B"][0])) < 1e-30 * np.max(np.abs(f.B))
+    kw = dict(duality_gap_threshold=1e-60, primal_error_threshold=1e-60, dual_error_threshold=1e-60)
+    r10 = solvesdp_mw(f, prec=512, data_limbs=10, **kw)
+    assert r10.timings["limbs"] == 10 and r10.error_code == 0 and r10.status == "Optimal" and r10.duality_gap <= 1e-60
+    o = Oracle(f, mp_bits=640)
+    o.set_num_threads(8)
+    ro = o.solvesdp(**kw)
+    assert ro["error_code"] == 0 and ro["gap"] <= 1e-60
+
+    def val(limbs):
+        return mp.fsum(mp.mpf(float(v)) for v in limbs)
+    with mp.workprec(800):
+        po, do = val(ro["objectives_limbs"][1]), val(ro["objectives_limbs"][0])
+        pg, dg = val(r10.timings["objectives_limbs"][1]), val(r10.timings["objectives_limbs"][0])
+        assert abs(pg - po) <= mp.mpf(10) ** -55 and abs(dg - do) <= mp.mpf(10) ** -55, (mp.nstr(pg - po, 5), mp.nstr(dg - do, 5))
+        r2 = solvesdp_mw(f, prec=512, data_limbs=2, **kw)
+        assert r2.error_code == 0 and r2.status == "Optimal"
+        far = abs(val(r2.timings["objectives_limbs"][1]) - po)
+        assert mp.mpf(10) ** -20 < far < mp.mpf(10) ** -6, mp.nstr(far, 5)      # measured: 5.5e-11 -- ten digits, not thirty
+    # the same at the reference's default precision: 5 limbs of data against 2
+    r5 = solvesdp_mw(f, limbs=5, data_limbs=5)
+    assert r5.error_code == 0 and r5.status == "Optimal" and abs(r5.primal_objective - float(po)) <= 1e-13, (r5.primal_objective, float(po))
+
+
 def test_duality_gap_1e30_as_in_the_reference_rounding_test(oracle_built):
     """test/runtests_solver.jl:90: three_point_spherical_codes(4, 1//6, -1, 4, prec=256, duality_gap_threshold=1e-30, omega=10^3)
     -- the solve the reference rounds to the exact optimum 10.  5 limbs reach the 1e-30 gap; 8 limbs (420 bits) reach 1e-45 and
