@@ -45,7 +45,7 @@ class IpmParams(C.Structure):
     """struct clrs_ipm_params"""
     _fields_ = [("beta_infeasible", C.c_double), ("beta_feasible", C.c_double), ("gamma", C.c_double),
                 ("dual_error_threshold", C.c_double), ("primal_error_threshold", C.c_double), ("max_complementary_gap", C.c_double),
-                ("step_length_threshold", C.c_double), ("safe_step", C.c_int32), ("reserved", C.c_int32)]
+                ("step_length_threshold", C.c_double), ("safe_step", C.c_int32), ("corrector_only", C.c_int32)]
 
 
 class IpmRecord(C.Structure):

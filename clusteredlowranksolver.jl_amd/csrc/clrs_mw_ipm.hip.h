@@ -42,7 +42,7 @@ struct MwIpmDev {
     double sgn, constant;
     int Ktot, pad;
     double beta_infeasible, beta_feasible, gamma, dual_thr, primal_thr, max_gap, step_thr;
-    int safe_step, pad2;
+    int safe_step, corrector_only;     // (corrector_only: the reference's correctoronly keyword, src/solver.jl:370-374, 945)
     // termination test of the loop (src/solver.jl:921-950) evaluated ON THE DEVICE at the end of an iteration when stop_on != 0
     // (clrs_mw_ipm_solve: the host runs one iteration ahead of the records it reads; an iteration that follows the last one must
     // not move the iterate): flags[6] = 1 makes k_mwi_update a no-op
@@ -407,7 +407,7 @@ __device__ void mwi_scalar_stage(const MwDev &q, const MwIpmDev &p, int stage, i
         p.rec[MREC_PDFEAS] = p.flags[0];
         if (p.stop_on) {                           // the test of :921-950 on the values the host will read from this record
             const bool df = p.rec[MREC_DERR] < p.dual_thr, pf = p.rec[MREC_PERR] < p.primal_thr;
-            if (p.flags[1] != 0 || (p.need_dual && df) || (p.need_primal && pf) || (df && pf && gap.l[0] < p.gap_thr)) p.flags[6] = 1;
+            if (p.flags[1] != 0 || (p.need_dual && df) || (p.need_primal && pf) || (!p.corrector_only && df && pf && gap.l[0] < p.gap_thr)) p.flags[6] = 1;      // (:945)
         }
         return;
     }
@@ -428,7 +428,7 @@ __device__ void mwi_scalar_stage(const MwDev &q, const MwIpmDev &p, int stage, i
         mw<K> mu = s_div<K>(xy, from_double<K>((double)p.Ktot));
         stx<K>(p.sc, SP, MSC_XY, xy);
         stx<K>(p.sc, SP, MSC_MU, mu);
-        stx<K>(p.sc, SP, MSC_MUS, p.flags[0] ? zero<K>() : s_mul_d<K>(mu, p.beta_infeasible));
+        stx<K>(p.sc, SP, MSC_MUS, p.corrector_only ? mu : p.flags[0] ? zero<K>() : s_mul_d<K>(mu, p.beta_infeasible));      // mu_p (:370-374)
         p.flags[1] = 0;
         p.flags[2] = 0;
         p.fmax[0] = p.fmax[1] = p.fmax[2] = 0ull;

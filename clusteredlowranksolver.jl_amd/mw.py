@@ -356,8 +356,10 @@ def solvesdp_mw(sdp, limbs: Optional[int] = None, prec: Optional[int] = None, ct
                 dual_error_threshold: float = 1e-30, primal_error_threshold: float = 1e-30, max_complementary_gap: float = 1e100,
                 need_dual_feasible: bool = False, need_primal_feasible: bool = False, verbose: bool = False,
                 step_length_threshold: float = 1e-7, safe_step: bool = True, step_by_step: bool = False, shard_info: Optional[dict] = None,
-                dualsol=None, primalsol=None, factor_limbs: Optional[int] = None, matmul_prec: Optional[int] = None):
+                dualsol=None, primalsol=None, factor_limbs: Optional[int] = None, matmul_prec: Optional[int] = None, correctoronly: bool = False):
     """`solvesdp(sdp; prec, ...)` (src/solver.jl:71-127) with the whole loop body on the GPU in multi-word fp64.
+    `correctoronly`: the reference's keyword (src/solver.jl:121, 370-374, 945): mu_p = mu, and the loop ends on `need_dual_feasible` / `need_primal_feasible`, an
+    error or `maxiterations` only.
     `matmul_prec`: the reference's keyword (src/solver.jl:125): bits of the products that form the pairing matrices (rounded up to whole limbs; ignored when
     `ctx` is given -- create it with `matmul_limbs`).
     `factor_limbs`: see `MwSchurContext` (ignored when `ctx` is given); `timings["refine_bits"]` of the result lists, per iteration, the bits the first
@@ -386,7 +388,7 @@ def solvesdp_mw(sdp, limbs: Optional[int] = None, prec: Optional[int] = None, ct
     data = _lib.IpmData(_dp(keep[0]), _dp(keep[1]), _dp(keep[2]), int(f.maximize), 0, float(f.constant))
     _lib.check(L.clrs_mw_ipm_create_ex(ctx.h, C.byref(data), ctx.data_limbs))
     prm = _lib.IpmParams(beta_infeasible, beta_feasible, gamma, dual_error_threshold, primal_error_threshold, max_complementary_gap,
-                         step_length_threshold, int(safe_step), 0)
+                         step_length_threshold, int(safe_step), int(bool(correctoronly)))
     _lib.check(L.clrs_mw_ipm_set_params(ctx.h, C.byref(prm)))
     if shard_info is not None:
         # `sdp` is this rank's share of a cluster-sharded problem (shard_problem) and `ctx` carries the rank's communicators: every call
@@ -461,7 +463,7 @@ def solvesdp_mw(sdp, limbs: Optional[int] = None, prec: Optional[int] = None, ct
             dual_feas, primal_feas = dual_error < dual_error_threshold, primal_error < primal_error_threshold
             if (need_dual_feasible and dual_feas) or (need_primal_feasible and primal_feas):          # src/solver.jl:921-950
                 break
-            if dual_feas and primal_feas and gap < duality_gap_threshold:
+            if not correctoronly and dual_feas and primal_feas and gap < duality_gap_threshold:      # (:945)
                 break
             if it > maxiterations:
                 error_code = 2

@@ -657,7 +657,7 @@ def solvesdp_device(sdp, ctx: Optional[SchurContext] = None, device: int = 0, ma
     data = _lib.IpmData(_dp(keep[0]), _dp(keep[1]), _dp(keep[2]), int(f.maximize), 0, float(f.constant))
     _lib.check(L.clrs_ipm_create(ctx.h, C.byref(data)))
     prm = _lib.IpmParams(beta_infeasible, beta_feasible, gamma, dual_error_threshold, primal_error_threshold, max_complementary_gap,
-                         step_length_threshold, int(safe_step), 0)
+                         step_length_threshold, int(safe_step), 0)      # (corrector_only: multi-word loop only)
     _lib.check(L.clrs_ipm_set_params(ctx.h, C.byref(prm)))
     _lib.check(L.clrs_ipm_init(ctx.h, float(omega_p), float(omega_d)))
     rec = _lib.IpmRecord()

@@ -174,7 +174,9 @@ typedef struct clrs_ipm_data {
 typedef struct clrs_ipm_params {   /* keyword arguments of solvesdp, src/solver.jl:100-127 */
     double beta_infeasible, beta_feasible, gamma;
     double dual_error_threshold, primal_error_threshold, max_complementary_gap, step_length_threshold;
-    int32_t safe_step, reserved;
+    int32_t safe_step;
+    int32_t corrector_only;   /* the reference's `correctoronly` keyword (src/solver.jl:121, 370-374, 945): mu_p = mu in the predictor's residual and no "optimal" termination
+                               * (the loop ends on need_dual_feasible / need_primal_feasible, errors or max_iterations only).  clrs_mw_ipm_*; the fp64 loop refuses it */
 } clrs_ipm_params;
 typedef struct clrs_ipm_record {   /* one row of the reference's iteration table (:566-582) + status */
     int32_t iter, pd_feas, error_code, factor_status, cholesky_status;

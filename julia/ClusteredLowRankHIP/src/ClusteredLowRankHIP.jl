@@ -329,7 +329,7 @@ struct IpmParams
     max_complementary_gap::Float64
     step_length_threshold::Float64
     safe_step::Int32
-    reserved::Int32
+    corrector_only::Int32
 end
 struct IpmRecord
     iter::Int32
@@ -430,8 +430,8 @@ end
 
 The reference's `solvesdp` (src/solver.jl:42-127: same keywords, same defaults, same return
 `status, dualsol, primalsol, solve_time, errorcode`) with the interior-point loop on the GPU at `limbs_for(prec)` words per number.
-`dualsol` / `primalsol` warm-start the device loop (`clrs_mw_ipm_set`).  `matmul_prec` selects the limbs of the pairing products (`clrs_mw_options.matmul_limbs`).  Keywords without a device counterpart (`save_settings`,
-`correctoronly`, `testing`) are accepted; a non-default value raises an `ArgumentError`, so that a caller never silently gets something else than it asked for.
+`dualsol` / `primalsol` warm-start the device loop (`clrs_mw_ipm_set`).  `matmul_prec` selects the limbs of the pairing products (`clrs_mw_options.matmul_limbs`), `correctoronly` is `clrs_ipm_params.corrector_only`.  Keywords without a
+device counterpart (`save_settings`, `testing`) are accepted; a non-default value raises an `ArgumentError`, so that a caller never silently gets something else than it asked for.
 """
 function solvesdp(problem::CLRS.Problem; prec=precision(BigFloat), kwargs...)
     sdp = CLRS.ClusteredLowRankSDP(problem, prec=prec)          # src/solver.jl:96-98
@@ -448,7 +448,6 @@ function solvesdp(sdp::CLRS.ClusteredLowRankSDP;
         verbose=true, step_length_threshold=1e-7,
         dualsol::Union{Nothing,CLRS.DualSolution}=nothing, primalsol::Union{Nothing,CLRS.PrimalSolution}=nothing,
         safe_step::Bool=true, correctoronly=false, save_settings=nothing, preprocess=true, matmul_prec=prec, testing=false)
-    correctoronly && throw(ArgumentError("correctoronly is not available with the HIP backend"))
     (save_settings === nothing || (save_settings.iter_interval === nothing && save_settings.time_interval === nothing && save_settings.callback === nothing)) ||
         throw(ArgumentError("save_settings is not available with the HIP backend"))
     matmul_prec <= prec || throw(ArgumentError("matmul_prec must not exceed prec"))
@@ -480,7 +479,7 @@ function solvesdp(sdp::CLRS.ClusteredLowRankSDP;
     end
     data = Ref(IpmData(pointer(Cf), pointer(cf), pointer(bf), sdp.maximize ? 1 : 0, 0, f64(sdp.constant)))
     prm = Ref(IpmParams(Float64(beta_infeasible), Float64(beta_feasible), Float64(gamma), Float64(dual_error_threshold),
-                        Float64(primal_error_threshold), Float64(max_complementary_gap), Float64(step_length_threshold), safe_step ? 1 : 0, 0))
+                        Float64(primal_error_threshold), Float64(max_complementary_gap), Float64(step_length_threshold), safe_step ? 1 : 0, correctoronly ? 1 : 0))
     GC.@preserve Cf cf bf begin
         check(ccall((:clrs_mw_ipm_create_ex, lib), Cint, (Ptr{Cvoid}, Ref{IpmData}, Cint), ctx.handle, data, DL))
     end
@@ -545,7 +544,7 @@ function solvesdp(sdp::CLRS.ClusteredLowRankSDP;
     if verbose
         if error_code == 2                                         # src/solver.jl:362-366
             println("The maximum number of iterations has been reached.")
-        elseif error_code == 0 && dual_error < dual_error_threshold && primal_error < primal_error_threshold && gap < duality_gap_threshold
+        elseif error_code == 0 && !correctoronly && dual_error < dual_error_threshold && primal_error < primal_error_threshold && gap < duality_gap_threshold
             println("Optimal solution found")
         end
     end

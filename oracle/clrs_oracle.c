@@ -917,6 +917,7 @@ typedef struct {
     double duality_gap_threshold, dual_error_threshold, primal_error_threshold;
     double max_complementary_gap, step_length_threshold;
     int need_dual_feasible, need_primal_feasible, safe_step, verbose;
+    int correctoronly;      /* src/solver.jl:121, 370-374, 945 */
 } oracle_params;
 
 void oracle_default_params(oracle_params *p) {       /* src/solver.jl:103-126 */
@@ -925,6 +926,7 @@ void oracle_default_params(oracle_params *p) {       /* src/solver.jl:103-126 */
     p->dual_error_threshold = 1e-30; p->primal_error_threshold = 1e-30;
     p->max_complementary_gap = 1e100; p->step_length_threshold = 1e-7;
     p->need_dual_feasible = 0; p->need_primal_feasible = 0; p->safe_step = 1; p->verbose = 0;
+    p->correctoronly = 0;
 }
 
 /* history row: iter, mu, d_obj, p_obj, gap, P-error, p-error, d-error, alpha_d, alpha_p, beta_c */
@@ -987,10 +989,10 @@ int oracle_solvesdp(octx *o, const oracle_params *prm, int *iters_out, double *o
         int dual_feas = dual_error < (REAL)prm->dual_error_threshold, primal_feas = primal_error < (REAL)prm->primal_error_threshold;
         if (prm->need_dual_feasible && dual_feas) break;
         if (prm->need_primal_feasible && primal_feas) break;
-        if (dual_feas && primal_feas && gap < (REAL)prm->duality_gap_threshold) break;
+        if (!prm->correctoronly && dual_feas && primal_feas && gap < (REAL)prm->duality_gap_threshold) break;      /* :945 */
         if (iter > prm->maxiterations) { error_code = 2; break; }                  /* :362-366 */
         mu = bdot(o, X, Y) / (REAL)K;                                             /* :369 */
-        REAL mu_p = pd_feas ? (REAL)0 : (REAL)prm->beta_infeasible * mu;          /* :373 */
+        REAL mu_p = prm->correctoronly ? mu : pd_feas ? (REAL)0 : (REAL)prm->beta_infeasible * mu;          /* :370-374 */
         if (mu > (REAL)prm->max_complementary_gap) { error_code = 3; break; }     /* :376-380 */
         /* R = mu_p I - X Y  (:961-970) */
         for (int b = 0; b < o->NB; b++) {

@@ -45,6 +45,7 @@ class OracleParams(C.Structure):
         ("primal_error_threshold", C.c_double), ("max_complementary_gap", C.c_double),
         ("step_length_threshold", C.c_double),
         ("need_dual_feasible", C.c_int), ("need_primal_feasible", C.c_int), ("safe_step", C.c_int), ("verbose", C.c_int),
+        ("correctoronly", C.c_int),
     ]
 
 

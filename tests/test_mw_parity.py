@@ -235,6 +235,30 @@ def test_matmul_prec_reduces_the_pairing_products_as_the_oracle_does(oracle_buil
     assert rg.duality_gap <= 10 * ro["gap"] and abs(rg.primal_objective - ro["p_obj"]) <= 1e-9, (rg.status, rg.error_code, rg.duality_gap, ro["gap"])
 
 
+def test_correctoronly_follows_the_oracle(oracle_built):
+    """The reference's `correctoronly` keyword (src/solver.jl:121, 370-374, 945): mu_p = mu in the predictor's residual and no "optimal" termination -- the loop
+    ends on need_dual_feasible / need_primal_feasible (or an error, or maxiterations).  Same iteration count and iterate as the oracle with the same keyword;
+    and without a feasibility target the loop runs to maxiterations (code 2) where the default loop would have stopped as optimal."""
+    from clrs_amd.mw import solvesdp_mw
+    from oracle.oracle import Oracle
+    f = flat("ce_8_15")
+    kw = dict(need_dual_feasible=True, dual_error_threshold=1e-20)
+    r = solvesdp_mw(f, limbs=5, correctoronly=True, **kw)
+    ro = Oracle(f, mp_bits=256).solvesdp(correctoronly=1, need_dual_feasible=1, dual_error_threshold=1e-20)
+    rd = solvesdp_mw(f, limbs=5, **kw)
+    # from the reference's starting point mu_p = mu leaves this problem no room: both stop after the same few iterations with "step length too small" (code 4),
+    # where the default loop reaches dual feasibility in 27 iterations
+    assert r.error_code == ro["error_code"] and r.iterations == ro["iterations"], (r.error_code, ro["error_code"], r.iterations, ro["iterations"])
+    n = min(len(r.history), len(ro["hist"]))
+    assert n >= 2 and np.allclose(r.history[:n, 1], ro["hist"][:n, 1], rtol=1e-6)                  # mu per iteration
+    assert rd.error_code == 0 and rd.iterations > r.iterations and not np.allclose(r.history[:2, 1], rd.history[:2, 1], rtol=1e-3)
+    g = flat("ce_8_3")
+    kw3 = dict(duality_gap_threshold=1e-10, dual_error_threshold=1e-20, primal_error_threshold=1e-20)
+    r2 = solvesdp_mw(g, limbs=4, correctoronly=True, maxiterations=40, **kw3)
+    o2 = Oracle(g, mp_bits=212).solvesdp(correctoronly=1, maxiterations=40, **kw3)
+    assert r2.error_code == o2["error_code"] and r2.error_code != 0 and abs(r2.iterations - o2["iterations"]) <= 1, (r2.error_code, o2["error_code"], r2.iterations, o2["iterations"])
+
+
 def test_refined_predictor_option_and_comm_probe_without_communicator(oracle_built):
     """clrs_mw_options.refine_predictor = 1: both solves of an iteration take the refinement step (the default refines the corrector's only): same
     iteration count, objectives equal far inside the tolerances of the solve.  clrs_mw_comm_probe on a context without a communicator reports that."""

@@ -92,6 +92,27 @@ PINNED = [
 ]
 
 
+def test_sdpa_writer_round_trips(tmp_path):
+    """`write_sdpa` (the export half of src/SDPAtoCLRS.jl's format): the reference's example file and a synthetic instance with a diagonal block
+    survive write -> read unchanged (block sizes incl. the sign of a diagonal block, c, every matrix), and flatten to the same arrays."""
+    import clrs_amd
+    from clrs_amd.problems import read_sdpa, sdpa_scaled, sdpa_to_sdp, write_sdpa
+    from clrs_amd.problems.sdpa import SDPAData
+    a = read_sdpa(os.path.join(GOLD, "example.dat-s"))
+    b = sdpa_scaled(nb=3, bs=4, m=5, seed=7)
+    rng = np.random.default_rng(3)
+    diag = [np.diag(rng.standard_normal(3)) for _ in range(b.m + 1)]
+    b = SDPAData(b.m, b.block_sizes + [-3], b.c, [F + [diag[k]] for k, F in enumerate(b.F)])
+    for i, d in enumerate((a, b)):
+        path = str(tmp_path / f"rt{i}.dat-s")
+        write_sdpa(path, d)
+        e = read_sdpa(path)
+        assert e.m == d.m and e.block_sizes == d.block_sizes and np.array_equal(e.c, d.c)
+        assert all(np.array_equal(x, y) for Fe, Fd in zip(e.F, d.F) for x, y in zip(Fe, Fd))
+        fe, fd = clrs_amd.flatten(sdpa_to_sdp(e)), clrs_amd.flatten(sdpa_to_sdp(d))
+        assert np.array_equal(fe.dense_A, fd.dense_A) and np.array_equal(fe.C, fd.C) and np.array_equal(fe.c, fd.c) and list(fe.block_n) == list(fd.block_n)
+
+
 def test_sdpa_example_file_parses_like_the_reference(oracle_built):
     """BASELINE config 5: test/example.dat-s (copied as a data fixture).  The reference pins only the parse
     (test/runtests_solver.jl:228-235): F0 block 2 = [3 0; 0 4], F2 block 2 = [5 2; 2 6]; the empty third constraint is
