@@ -8,7 +8,7 @@ Workload (BASELINE.json: "SpherePacking d=8, 2d=30"): the Cohn-Elkies sphere-pac
 examples/SpherePacking.jl:117-185 -- 2 clusters of P = 32 constraints, PSD blocks 16x16 (rank-1 constraint matrices) + one 1x1
 dense block, N = 31 free variables -- at the precision the reference solves it at: test/runtests_solver.jl:19-20 runs it with
 prec = 256 bits (Arb midpoints); here every number is 5 limbs of fp64 (~262 bits; `--limbs 4` = ~209 bits), the problem data
-2 limbs.  In fp64 this instance cannot be factored at all (`fp64.parity.factor_status` below).
+included (round 5: the sampled problem at the working precision, as the reference holds it; `full_solve_two_data_limbs` = the form of rounds 1-4).  In fp64 this instance cannot be factored at all (`fp64.parity.factor_status` below).
 
 One STEP = one whole interior-point iteration of `solvesdp` (src/solver.jl:348-589) with the reference's default options, device
 resident: mu, residuals, Cholesky of the X blocks, the hot path (Schur assembly :1062-1226, chol S_j / L^-1 B / Q / chol Q :1244-1279,
@@ -183,7 +183,11 @@ def main():
     thr = dict(dual_error_threshold=1e-30, primal_error_threshold=1e-30, duality_gap_threshold=1e-15) if K >= 5 else \
         dict(dual_error_threshold=1e-25, primal_error_threshold=1e-25, duality_gap_threshold=1e-12)      # what ~209 bits can reach
     t0 = time.time()
-    flat = clrs_amd.flatten(cohnelkies(8, 15))
+    # the sampled problem at the working precision, as the reference holds it (convert_to_prec, src/interface.jl:1078-1112): K limb planes per number
+    # (round 5; rounds 1-4 passed two -- a neighbouring problem whose optimum differs in the 10th digit: `full_solve_two_data_limbs` below keeps that form)
+    from clrs_amd.sdp import data_planes
+    with data_planes(K):
+        flat = clrs_amd.flatten(cohnelkies(8, 15))
     log(f"problem: cohnelkies(8,15), {flat.n_clusters} clusters P={list(flat.cluster_P)} N={flat.n_free} blocks n={list(flat.block_n)}, generated in {time.time() - t0:.1f}s")
 
     # ---- the job's problem: the named one on one GPU, the 2N-cluster weak-scaled one sharded over N ranks ----
@@ -208,7 +212,7 @@ def main():
         prob, shard_info, ctx = sharded_context(full)
         log(f"rank {rank}: clusters {list(shard_info['cluster_ids'])} of {full.n_clusters}")
     else:
-        ctx = MwSchurContext(prob, limbs=K, device=local_rank)
+        ctx = MwSchurContext(prob, limbs=K, device=local_rank, data_limbs=K)
 
     def solve(**kw):
         return solvesdp_mw(prob, ctx=ctx, shard_info=shard_info, **thr, **kw)
@@ -337,23 +341,21 @@ def main():
             ctx_f.close()
             multi["filled_regime"] = filled
 
-    # ---- the same solve with the problem DATA at the working precision (data_limbs = limbs; the reference holds the sampled problem at `prec` bits,
-    # src/interface.jl:1078-1112): the headline keeps the two data limbs of rounds 1-4 (comparable numbers), this says what the faithful form costs ----
+    # ---- the same solve with TWO data limbs (the form rounds 1-4 measured: a neighbouring problem, entries of B reach 1e27) for comparison ----
     data_k = None
     if rank == 0 and not sharded and K > 2:
         try:
-            from clrs_amd.sdp import data_planes, flatten as _flatten
-            with data_planes(K):
-                flat_k = _flatten(cohnelkies(8, 15))
-            ck = MwSchurContext(flat_k, limbs=K, device=local_rank, data_limbs=K)
-            solvesdp_mw(flat_k, ctx=ck, **thr)
-            rk = min((solvesdp_mw(flat_k, ctx=ck, **thr) for _ in range(3)), key=lambda r_: r_.time_total)
-            ck.close()
-            data_k = {"data_limbs": K, "status": rk.status, "iterations": rk.iterations, "primal_objective": rk.primal_objective,
-                      "ms_per_iteration": 1e3 * rk.time_total / rk.iterations, "headline_primal_objective_2_data_limbs": r.primal_objective,
-                      "what": "whole solves of cohnelkies(8,15) generated with %d limb planes per number (sdp.data_planes) and passed with data_limbs = %d: the problem "
-                              "the reference solves at prec = 256.  Its optimum differs from that of the two-limb data in the 10th digit (entries of B reach 1e27: "
-                              "tests/test_mw_parity.py::test_problem_data_at_the_working_precision)" % (K, K)}
+            import copy as _copy
+            flat_2 = _copy.copy(flat)
+            flat_2.tails = {}
+            c2 = MwSchurContext(flat_2, limbs=K, device=local_rank, data_limbs=2)
+            solvesdp_mw(flat_2, ctx=c2, **thr)
+            r2 = min((solvesdp_mw(flat_2, ctx=c2, **thr) for _ in range(3)), key=lambda r_: r_.time_total)
+            c2.close()
+            data_k = {"data_limbs": 2, "status": r2.status, "iterations": r2.iterations, "primal_objective": r2.primal_objective,
+                      "ms_per_iteration": 1e3 * r2.time_total / r2.iterations, "headline_primal_objective": r.primal_objective,
+                      "what": "whole solves of the same instance with the first two limb planes of its data only (what rounds 1-4 timed): another problem -- its optimum "
+                              "differs from the headline's in the 10th digit (tests/test_mw_parity.py::test_problem_data_at_the_working_precision)"}
         except Exception as e:
             data_k = {"error": repr(e)}
 
@@ -428,12 +430,12 @@ def main():
         "metric": "interior-point iterations/sec",
         "value": value, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,      # (BASELINE.json publishes no number for this workload)
-        "dtype": f"f64x{K} (multi-word fp64: {K} limbs per number, ~{bits} bits; problem data f64x2)",
+        "dtype": f"f64x{K} (multi-word fp64: {K} limbs per number, ~{bits} bits; problem data f64x{2 if sharded else K})",
         "data": "generated: cohnelkies(8,15) built from the mathematics of the reference's examples/SpherePacking.jl (no dataset, no checkpoint); every "
                 "iterate is the solve's own, from the reference's starting point X = Y = 1e10 I",
         "config": {"workload": "SpherePacking cohnelkies(8,15): d=8, 2d=30; 2 clusters P=32, blocks 16x16 r1 + 1x1 dense, N=31; whole interior-point "
                                f"iterations with the reference's default options at its precision (prec=256 -> {K} limbs), {n_it} per solve",
-                   "clusters": int(full.n_clusters) if sharded else int(flat.n_clusters), "n_free": int(flat.n_free), "limbs": K, "data_limbs": 2,
+                   "clusters": int(full.n_clusters) if sharded else int(flat.n_clusters), "n_free": int(flat.n_free), "limbs": K, "data_limbs": 2 if sharded else K,
                    "unit_of_work": "one interior-point iteration over one 2-cluster share; a step of the N-GPU job (one iteration of the 2N-cluster problem) = N units",
                    "multi_gpu": (f"{int(full.n_clusters)} clusters partitioned over {world} ranks (partition_clusters); per iteration RCCL all-gathers of the partial Q, the partial u "
                                  "(three times: predictor, corrector and its refinement step) and three scalar records (objectives + mu + p; beta_c and errors; step lengths) inside the C ABI, two communicators "
@@ -442,7 +444,7 @@ def main():
         "full_solve": full_solve,
     }
     if data_k is not None:
-        out["full_solve_data_at_working_precision"] = data_k
+        out["full_solve_two_data_limbs"] = data_k
     if multi is not None:
         out["multi_gpu"] = multi
     if hot is not None:

@@ -38,6 +38,7 @@ MW_KERNELS_ALL(extern template, 10)
 typedef long long i64;
 
 extern int g_cfg_mw_stream_words;                        // clrs_hip.hip, clrs_config_set("mw_stream_words", 0 / 1); env CLRS_MW_STREAM_WORDS
+extern int g_cfg_mw_pipeline64;                          // clrs_hip.hip, clrs_config_set("mw_pipeline64", 0 / 1): the 64-row form for clusters of 33 .. 64 rows
 extern int g_cfg_mw_pipeline;                            // clrs_hip.hip, clrs_config_set("mw_pipeline", 0 / 1): read at context creation
 extern int g_cfg_mw_refine_predictor;                    // clrs_hip.hip, clrs_config_set("mw_refine_predictor", 0 / 1)
 extern int g_cfg_mw_refine;                              // clrs_hip.hip, clrs_config_set("mw_refine", 0 / 1): read at context creation
@@ -171,7 +172,9 @@ struct clrs_mw_ctx {
     int mws_turns = 1;                   // 2: some eligible block has more than four T / Z tiles
     size_t sm_mws = 0;
     bool pipe_bp = false;                // the diagonal blocks of the blocked factorisation as pipelines (k_mw_bp_diag_pipe)
+    bool pipe_S64 = false;               // ... the clusters' S_j of 33 .. 64 rows through the 64-row form of the pipeline (k_mw_factor_pipe64; limbs <= 6)
     bool pipe_S = false, pipe_Q = false;  // the factorisations of the clusters / of Q as pipelines of workgroups (clrs_mw_pipe.hip.h): every matrix <= 32 rows, few clusters
+    unsigned long long *pipe_pc64 = nullptr;   // hand-off granules of k_mw_factor_pipe64: [J][MWP_PC_WORDS_N(K, 64)]
     int pipe_pcQ = 0;                    // index of Q's hand-off region in pipe_pc
     unsigned pipe_epoch = 0;             // launch counter: the tag of the hand-off granules
     bool stream_words = true;            // the interior-point iteration synchronises its two streams through words (clrs_mw_ipm_host.inc) where it can; false: events only
@@ -794,6 +797,12 @@ extern "C" int clrs_mw_create_opts(const clrs_sdp_desc *d, int data_limbs, int d
         for (auto &cl : c->clu) small = small && cl.lds;
         c->pipe_S = cfg_pipe != 0 && (K <= 6 || cfg_pipe >= 2) && small && (i64)J * ((MWP_N / MWP_W) + MWP_WW) <= 256;      // (8, 10 limbs: measured slower than one workgroup, 2.42 against 2.34 ms per iteration: opt-in)
         c->pipe_Q = cfg_pipe >= 2 && N > 0 && N <= MWP_N;      // (Q: slower than the one-workgroup kernel on the named problem, 83 against 80 us: opt-in)
+        bool lds_all = !c->clu.empty();
+        for (auto &cl : c->clu) lds_all = lds_all && cl.lds;
+        // (measured at 5 limbs, factor stage in 4: PolyOpt 2d = 40, P = 41 -- six stages, five hops -- 0.478 -> 0.487 ms per iteration; the tested three-point instance,
+        // P = 50, 0.648 -> 0.638: by default from 48 rows on, with pipeline = 2 for every cluster of 33 .. 64 rows)
+        c->pipe_S64 = cfg_pipe != 0 && K <= 6 && lds_all && c->maxP > MWP_N && c->maxP <= MWP_N64 && (i64)J * 16 <= 256 && g_cfg_mw_pipeline64 != 0 &&
+                      (cfg_pipe >= 2 || c->maxP >= 48);
         // the diagonal blocks of the blocked factorisation (k_mw_bp_diag_pipe): the same pipeline per 32-column block of every matrix beyond LDS
         const size_t nbp = c->bp_S.size() + c->bp_Q.size();
         const bool any_bp = !c->bp_S.empty() || (N > 0 && !c->lds_q);
@@ -802,6 +811,15 @@ extern "C" int clrs_mw_create_opts(const clrs_sdp_desc *d, int data_limbs, int d
         q.pipe_pc = nullptr;
         q.pipe_stamps = nullptr;
         q.pipe_bp = 0;
+        if (c->pipe_S64) {                                    // (its own hand-off region: 64-row columns; no other pipeline runs in such a context's factor stage but Q's / the blocked path's below)
+            const size_t words64 = (size_t)J * MWP_PC_WORDS_N(K, MWP_N64);
+            unsigned long long *pc64 = nullptr;
+            if (hipMalloc((void **)&pc64, words64 * sizeof(unsigned long long)) != hipSuccess) MW_BAIL(CLRS_ERR_HIP, "hipMalloc failed");
+            c->allocs.push_back(pc64);
+            if (hipMemset(pc64, 0xff, words64 * sizeof(unsigned long long)) != hipSuccess) MW_BAIL(CLRS_ERR_HIP, "hipMemset failed");
+            c->pipe_pc64 = pc64;
+            MW_DISPATCH(c, { if constexpr (KK <= 6) { MW_TRY(mw_set_lds(k_mw_factor_pipe64<KK>, MWP_LDS_ALONE64)); } });
+        }
         if (c->pipe_S || c->pipe_Q || c->pipe_bp) {
             const size_t own = (size_t)(c->pipe_S ? J : 0) + 1;
             const size_t words = (own + (c->pipe_bp ? nbp : 0)) * MWP_PC_WORDS(K);
@@ -1224,7 +1242,12 @@ extern "C" int clrs_mw_schur_factor_local_dev(clrs_mw_ctx *c) {
     // clusters that do not fit in LDS: blocked over many workgroups, all of them side by side; the others ride on the first of those launches
     // when they take the same number of workgroups per matrix, else they have their launch (k_mw_factor)
     const bool ride = !c->bp_S.empty() && c->nw_factor == MW_INV_WG && c->any_lds_cluster;
-    if (c->pipe_S) {
+    if (c->pipe_S64) {
+        c->pipe_epoch = (c->pipe_epoch + 1) & 0x3ffffff;
+        MwDev q64 = q;
+        q64.pipe_pc = c->pipe_pc64;
+        MW_DISPATCH(c, { if constexpr (KK <= 6) { hipLaunchKernelGGL(k_mw_factor_pipe64<KK>, dim3(mwp_blocks64(q.J)), dim3(MWP_NT64), MWP_LDS_ALONE64, c->stream, q64, c->pipe_epoch); } });
+    } else if (c->pipe_S) {
         c->pipe_epoch = (c->pipe_epoch + 1) & 0x3ffffff;
         MW_DISPATCH(c, { hipLaunchKernelGGL(k_mw_factor_pipe<KK>, dim3(mwp_blocks(q.J)), dim3(MWP_NT), MWP_LDS_ALONE, c->stream, q, c->pipe_epoch); });
     } else if (!ride && c->any_lds_cluster) MW_DISPATCH(c, { hipLaunchKernelGGL(k_mw_factor<KK>, dim3(q.J, c->nw_factor), dim3(MW_PT), c->sm_factor, c->stream, q); });

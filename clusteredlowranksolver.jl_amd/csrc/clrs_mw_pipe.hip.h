@@ -46,6 +46,12 @@
 #define MWP_SPIN_LIMIT (1 << 22)
 #define MWP_GRANULES(K) ((K) * MWP_N * 2)                 // granules of one published pivot column
 #define MWP_PC_WORDS(K) ((long)MWP_N * MWP_GRANULES(K))    // ... of one matrix (MWP_N pivots)
+// The same pipeline for matrices of 33 .. 64 rows (round 5: template parameter NR = 32 or 64 rows per column; MWP_N above is the 32 of the blocked path's
+// diagonal blocks and of the first form): 8 NR entry threads + four loader waves per workgroup, NR / 8 stages + NR / 8 workgroups for W.
+#define MWP_N64 64
+#define MWP_NT64 (MWP_W * MWP_N64 + 64 * MWP_NL)
+#define MWP_GRANULES_N(K, NR) ((K) * (NR) * 2)
+#define MWP_PC_WORDS_N(K, NR) ((long)(NR) * MWP_GRANULES_N(K, NR))
 
 struct MwPipeMat {           // one matrix of a pipelined factorisation
     double *keep;            // null, or where a copy of the input goes (same layout as `in`)
@@ -77,14 +83,14 @@ __device__ __forceinline__ void mwp_publish(unsigned long long *pcol, unsigned t
     }
 }
 // the loader wave (64 lanes) publishes rows r0 .. n-1 of a pivot column held in LDS (planar, plane MWP_N)
-template <int K>
+template <int K, int NR>
 __device__ __forceinline__ void mwp_publish_column(unsigned long long *pcol, unsigned tag, int r0, int n, const lds_d *buf, int lane) {
     const int rows = n - r0, cnt = rows * K;
     const unsigned long long t = (unsigned long long)tag << 32;
     for (int e = lane; e < cnt; e += 64) {
         const int l = e / rows, i = r0 + e % rows;
-        const unsigned long long b = (unsigned long long)__double_as_longlong((double)buf[(long)l * MWP_N + i]);
-        unsigned long long *g = pcol + ((long)l * MWP_N + i) * 2;
+        const unsigned long long b = (unsigned long long)__double_as_longlong((double)buf[(long)l * NR + i]);
+        unsigned long long *g = pcol + ((long)l * NR + i) * 2;
         const unsigned long long g0 = t | (b & 0xffffffffull), g1 = t | (b >> 32);
 #ifdef MWP_PLAIN_PUBLISH
         *(volatile unsigned long long *)g = g0;
@@ -108,9 +114,9 @@ __device__ __forceinline__ void mwp_publish_column(unsigned long long *pcol, uns
 // stores drop the line from its L2, the consumer's sc1 loads go to memory; 4-5 us when the first poll comes too early), the producers publish a column
 // every 1.5 us: with ONE column in flight a consumer ran at 2.6 us per step, with two at 2.1.  So MWP_NL loader waves take turns: wave p fetches the
 // columns j = p (mod MWP_NL), sends for column j + MWP_NL the moment it has delivered column j, and so has MWP_NL steps per column.
-template <int K>
+template <int K, int NR>
 struct MwpFetch {
-    static constexpr int R = (K * MWP_N + 63) / 64;            // passes of the wave over the K MWP_N numbers of a whole column
+    static constexpr int R = (K * NR + 63) / 64;               // passes of the wave over the K NR numbers of a whole column
     unsigned long long a[R], b[R];
     int off[R];                                                 // (l MWP_N + i) of this lane's numbers: the same for every column (no index arithmetic per step)
     bool want[R];                                               // of the column in flight: the rows this workgroup reads (the pivot, and rows r0 ..)
@@ -118,8 +124,8 @@ struct MwpFetch {
     __device__ __forceinline__ void init(int n, int lane) {
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            const int t = lane + 64 * r, l = t / MWP_N, i = t % MWP_N;
-            off[r] = (l < K && i < n) ? l * MWP_N + i : -1;
+            const int t = lane + 64 * r, l = t / NR, i = t % NR;
+            off[r] = (l < K && i < n) ? l * NR + i : -1;
             want[r] = false; a[r] = b[r] = 0;
         }
         col = nullptr;
@@ -128,7 +134,7 @@ struct MwpFetch {
         col = pcol;
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            const int i = off[r] & (MWP_N - 1);
+            const int i = off[r] & (NR - 1);
             want[r] = off[r] >= 0 && (i == prow || i >= r0);
             if (want[r]) {
                 const unsigned long long *g = pcol + (long)off[r] * 2;
@@ -183,38 +189,40 @@ __device__ __forceinline__ mw<K> mwp_step(const mw<K> &dh, double ph, const mw<K
 }
 
 // LDS of one workgroup: two pivot-column buffers, the products s_k of the scaled pivots, the pivots, the post-processing factors, W's row k
-template <int K>
+template <int K, int NR>
 struct MwpLds {                                      // (no arrays of pointers: indexing one with k & 1 would put it in scratch memory, a round trip per pivot)
     lds_d *col0, *us, *dd, *fs, *rs, *wrow0;
     int *flag;
     __device__ __forceinline__ MwpLds(lds_d *base) {
         col0 = base;
-        us = col0 + 2L * K * MWP_N; dd = us + (long)K * (MWP_N + 1); fs = dd + (long)K * MWP_N; rs = fs + (long)K * MWP_N;
-        wrow0 = rs + (long)K * MWP_N;
+        us = col0 + 2L * K * NR; dd = us + (long)K * (NR + 1); fs = dd + (long)K * NR; rs = fs + (long)K * NR;
+        wrow0 = rs + (long)K * NR;
         flag = (int *)(wrow0 + 2L * K * MWP_W);
     }
-    __device__ __forceinline__ lds_d *col(int k) const { return col0 + (long)(k & 1) * K * MWP_N; }
+    __device__ __forceinline__ lds_d *col(int k) const { return col0 + (long)(k & 1) * K * NR; }
     __device__ __forceinline__ lds_d *wrow(int k) const { return wrow0 + (long)(k & 1) * K * MWP_W; }
 };
 // LDS a workgroup asks for.  (Asking for more than half of a compute unit's 160 KB, so that no two workgroups share a compute unit, was tried with the
 // plain-store hand-offs below and changed nothing: their 3.5 us steps came from the stores, not from sharing.)
 #define MWP_LDS_ALONE (MWP_LDS_DOUBLES(10) * sizeof(double))
 #define MWP_LDS_DOUBLES(K) ((K) * (6 * MWP_N + 1 + 2 * MWP_W) + 2)
+#define MWP_LDS_ALONE64 (((10) * (6 * MWP_N64 + 1 + 2 * MWP_W) + 2) * sizeof(double))
 
 // role < stages: stage `role` of the elimination of M; role >= stages: workgroup role - stages of the MWP_WW that form W.  Returns false at a
 // non-positive pivot (or a hand-off that never arrived); every workgroup of the matrix then stops at the same pivot.
 // KS: limbs of the arrays in memory (input, keep, L, rd, Inv); K <= KS: limbs of the elimination (MwDev::kf).  K < KS: the input is truncated to K limbs
 // (the copy `keep` carries all KS), the results are stored with their upper KS - K planes zero.
-template <int KS, int K>
+template <int KS, int K, int NR = MWP_N>
 __device__ __forceinline__ bool mwp_run(const MwPipeMat &m, int role, unsigned epoch, int *info, int tid) {
     const int n = m.n, stages = (n + MWP_W - 1) / MWP_W;
-    MwpLds<K> S(MW_LDS);
-    const bool loader = tid >= MWP_ET;                                       // waves 4 ..: hand-offs and the running product s_k
-    const int lw = (tid - MWP_ET) >> 6, lane = (tid - MWP_ET) & 63;          // (loader waves only)
-    const int cc = (tid >> 5) & 7, i = tid & 31;
+    constexpr int ET = MWP_W * NR, WW = NR / MWP_W;             // entry threads (one entry each: MWP_W columns x NR rows); workgroups that share W's columns
+    MwpLds<K, NR> S(MW_LDS);
+    const bool loader = tid >= ET;                                           // the last four waves: hand-offs and the running product s_k
+    const int lw = (tid - ET) >> 6, lane = (tid - ET) & 63;                  // (loader waves only)
+    const int cc = (tid / NR) & 7, i = tid % NR;
     const bool is_w = role >= stages;
     const int c0 = is_w ? 0 : role * MWP_W, c1 = is_w ? n : min(c0 + MWP_W, n);
-    const int c = is_w ? (role - stages) + MWP_WW * cc : c0 + cc;            // my column
+    const int c = is_w ? (role - stages) + WW * cc : c0 + cc;                // my column
     const bool live = !loader && c < c1 && i >= c && i < n;
     const int nfetch = is_w ? n : c0;                                        // columns 0 .. nfetch - 1 come from other workgroups
     mw<K> v = zero<K>();
@@ -232,20 +240,20 @@ __device__ __forceinline__ bool mwp_run(const MwPipeMat &m, int role, unsigned e
         }
         v = cvt<K, KS>(vin);
     }
-    if (tid == MWP_ET) { stx<K>(S.us, MWP_N + 1, 0, from_double<K>(1.0)); *S.flag = 1; }
-    MwpFetch<K> F;
+    if (tid == ET) { stx<K>(S.us, NR + 1, 0, from_double<K>(1.0)); *S.flag = 1; }
+    MwpFetch<K, NR> F;
     F.init(n, lane);
-    const unsigned tag0 = epoch << 5;
+    const unsigned tag0 = epoch << (NR > 32 ? 6 : 5);                          // tag = (launch epoch, pivot): 26 bits of epoch, 5 or 6 of pivot
     // column 0: stage 0 owns it, everybody else fetches it; columns 1 .. MWP_NL are on their way when step 0 begins
     if (!is_w && c0 == 0) {
-        if (live && c == 0) stx<K>(S.col(0), MWP_N, i, v);
+        if (live && c == 0) stx<K>(S.col(0), NR, i, v);
     } else if (loader && lw == 0) {
         F.issue(m.pc, 0, is_w ? 0 : c0);
-        if (!F.complete(tag0, S.col(0), m.pc + ((long)(K - 1) * MWP_N + n - 1) * 2 + 1)) *S.flag = 0;
+        if (!F.complete(tag0, S.col(0), m.pc + ((long)(K - 1) * NR + n - 1) * 2 + 1)) *S.flag = 0;
     }
     if (loader) {
         const int j = lw == 0 ? MWP_NL : lw;
-        if (j < nfetch) F.issue(m.pc + (long)j * MWP_GRANULES(K), j, is_w ? j : c0);
+        if (j < nfetch) F.issue(m.pc + (long)j * MWP_GRANULES_N(K, NR), j, is_w ? j : c0);
     }
     __syncthreads();
     const int kend = is_w ? n : c1;                                          // pivots this workgroup looks at: 0 .. kend - 1
@@ -258,40 +266,40 @@ __device__ __forceinline__ bool mwp_run(const MwPipeMat &m, int role, unsigned e
         if (stamps && tid == 0) stamps[k] = wall_clock64();
 #endif
         lds_d *cur = S.col(k), *nxt = S.col(k + 1);
-        const mw<K> d = ldx<K>(cur, MWP_N, k);
+        const mw<K> d = ldx<K>(cur, NR, k);
         if (!(*S.flag) || !(d.l[0] > 0.0)) {                                 // uniform: every thread reads the same words
             // the owner of a column with a non-positive pivot publishes it all the same: the workgroups behind it read the pivot there and stop at the same
             // step -- without it they would poll for the column until their bound (1.3 s: found on the 16-cluster weak-scaling instance, whose solve ends
             // with a failed factorisation)
-            if (loader && lw == 0 && !is_w && k >= c0) mwp_publish_column<K>(m.pc + (long)k * MWP_GRANULES(K), tag0 | (unsigned)k, k, n, cur, lane);
+            if (loader && lw == 0 && !is_w && k >= c0) mwp_publish_column<K, NR>(m.pc + (long)k * MWP_GRANULES_N(K, NR), tag0 | (unsigned)k, k, n, cur, lane);
             if (tid == 0) atomicMin(info, m.fail_code);
             return false;
         }
-        if (is_w && tid == MWP_ET) stx<K>(S.dd, MWP_N, k, d);
+        if (is_w && tid == ET) stx<K>(S.dd, NR, k, d);
         // a column this stage owns goes to the stages and the W workgroups behind it from HERE, out of LDS, by a loader wave: a store of the entry waves
         // would put its wait for the write-through on the dependent chain (the compiler guards the stored registers with s_waitcnt vmcnt)
-        if (loader && lw == 0 && !is_w && k >= c0) mwp_publish_column<K>(m.pc + (long)k * MWP_GRANULES(K), tag0 | (unsigned)k, k, n, cur, lane);
+        if (loader && lw == 0 && !is_w && k >= c0) mwp_publish_column<K, NR>(m.pc + (long)k * MWP_GRANULES_N(K, NR), tag0 | (unsigned)k, k, n, cur, lane);
         if (k + 1 >= kend) break;
         double p1, ph;
         pivot_scale(d.l[0], p1, ph);
         const mw<K> dh = mul_pow2<K>(d, p1);
         if (loader) {
             if ((k + 1) % MWP_NL == lw) {                                    // my turn: deliver column k + 1 (sent for MWP_NL steps ago), send for the next of mine
-                if (k + 1 < nfetch && !F.complete(tag0 | (unsigned)(k + 1), nxt, m.pc + (long)(k + 1) * MWP_GRANULES(K) + ((long)(K - 1) * MWP_N + n - 1) * 2 + 1)) *S.flag = 0;
+                if (k + 1 < nfetch && !F.complete(tag0 | (unsigned)(k + 1), nxt, m.pc + (long)(k + 1) * MWP_GRANULES_N(K, NR) + ((long)(K - 1) * NR + n - 1) * 2 + 1)) *S.flag = 0;
                 const int j = k + 1 + MWP_NL;
-                if (j < nfetch) F.issue(m.pc + (long)j * MWP_GRANULES(K), j, is_w ? j : c0);
+                if (j < nfetch) F.issue(m.pc + (long)j * MWP_GRANULES_N(K, NR), j, is_w ? j : c0);
             }
             // s_(k+1) = s_k dh_k: one K-limb product per step, off the chain, on the first loader wave: it shares its SIMD with entry wave 0, which in a
             // stage's own steps is the first to run out of live columns (moving it to another SIMD made those steps 1.9-2.9 us instead of 1.45: measured)
-            if (tid == MWP_ET) stx<K>(S.us, MWP_N + 1, k + 1, mul<K>(ldx<K>(S.us, MWP_N + 1, k), dh));
+            if (tid == ET) stx<K>(S.us, NR + 1, k + 1, mul<K>(ldx<K>(S.us, NR + 1, k), dh));
         } else if (!is_w) {
-            if (live && c > k) v = mwp_step<K>(dh, ph, v, ldx<K>(cur, MWP_N, i), ldx<K>(cur, MWP_N, c));
-            if (k + 1 >= c0 && live && c == k + 1) stx<K>(nxt, MWP_N, i, v);      // my stage's column k + 1 is final now: to this stage's next step
+            if (live && c > k) v = mwp_step<K>(dh, ph, v, ldx<K>(cur, NR, i), ldx<K>(cur, NR, c));
+            if (k + 1 >= c0 && live && c == k + 1) stx<K>(nxt, NR, i, v);      // my stage's column k + 1 is final now: to this stage's next step
         } else {
             // W: entries (i, c) with c <= k < i; row k of W comes from the thread that owns (k, c), through LDS; w_kk = s_k
             if (live && c <= k && i > k) {
-                const mw<K> wk = c == k ? ldx<K>(S.us, MWP_N + 1, k) : ldx<K>(S.wrow(k), MWP_W, cc);
-                v = mwp_step<K>(dh, ph, v, ldx<K>(cur, MWP_N, i), wk);
+                const mw<K> wk = c == k ? ldx<K>(S.us, NR + 1, k) : ldx<K>(S.wrow(k), MWP_W, cc);
+                v = mwp_step<K>(dh, ph, v, ldx<K>(cur, NR, i), wk);
             }
             if (live && i == k + 1 && c <= k) stx<K>(S.wrow(k + 1), MWP_W, cc, v);
         }
@@ -301,20 +309,20 @@ __device__ __forceinline__ bool mwp_run(const MwPipeMat &m, int role, unsigned e
     // post-processing (wg_potrf's): f_k = 1 / sqrt(s_k d~_k); L_kk = d~_k f_k, 1 / L_kk = f_k s_k; L_ik = a~_ik f_k; (L^-1)_ij = W_ij f_i
     if (!is_w) {
         if (live && i == c) {
-            const mw<K> sk = ldx<K>(S.us, MWP_N + 1, c), f = rsqrt<K>(mul<K>(sk, v)), r = mul<K>(f, sk);
-            stx<K>(S.fs, MWP_N, cc, f);
+            const mw<K> sk = ldx<K>(S.us, NR + 1, c), f = rsqrt<K>(mul<K>(sk, v)), r = mul<K>(f, sk);
+            stx<K>(S.fs, NR, cc, f);
             stx<KS>(m.rd, m.rdplane, c, cvt<KS, K>(r));
         }
         __syncthreads();
-        if (!loader && c < c1 && i < n) stx<KS>(m.L, m.lplane, i + (long)c * m.l_ld, i >= c ? cvt<KS, K>(mul<K>(v, ldx<K>(S.fs, MWP_N, cc))) : zero<KS>());
+        if (!loader && c < c1 && i < n) stx<KS>(m.L, m.lplane, i + (long)c * m.l_ld, i >= c ? cvt<KS, K>(mul<K>(v, ldx<K>(S.fs, NR, cc))) : zero<KS>());
     } else {
         if (tid < n) {                                                       // (every W workgroup needs every f_i: n reciprocal square roots side by side)
-            const mw<K> sk = ldx<K>(S.us, MWP_N + 1, tid), dt = ldx<K>(S.dd, MWP_N, tid), f = rsqrt<K>(mul<K>(sk, dt));
-            stx<K>(S.fs, MWP_N, tid, f);
-            stx<K>(S.rs, MWP_N, tid, mul<K>(f, sk));
+            const mw<K> sk = ldx<K>(S.us, NR + 1, tid), dt = ldx<K>(S.dd, NR, tid), f = rsqrt<K>(mul<K>(sk, dt));
+            stx<K>(S.fs, NR, tid, f);
+            stx<K>(S.rs, NR, tid, mul<K>(f, sk));
         }
         __syncthreads();
-        if (!loader && c < n && i < n) stx<KS>(m.Inv, m.invplane, i + (long)c * m.inv_ld, cvt<KS, K>(i > c ? mul<K>(v, ldx<K>(S.fs, MWP_N, i)) : i == c ? ldx<K>(S.rs, MWP_N, i) : zero<K>()));
+        if (!loader && c < n && i < n) stx<KS>(m.Inv, m.invplane, i + (long)c * m.inv_ld, cvt<KS, K>(i > c ? mul<K>(v, ldx<K>(S.fs, NR, i)) : i == c ? ldx<K>(S.rs, NR, i) : zero<K>()));
     }
 #ifdef CLRS_MW_STAMPS
     if (stamps && tid == 0) stamps[38] = wall_clock64();
@@ -354,6 +362,37 @@ __global__ __launch_bounds__(MWP_NT) void k_mw_factor_pipe(const MwDev q, unsign
     m.stamps = j == 0 && q.pipe_stamps ? q.pipe_stamps : nullptr;
     if constexpr (mw_kf_of(K) < K) { if (q.kf < K) { mwp_run<K, mw_kf_of(K)>(m, role, epoch, &q.info[0], threadIdx.x); return; } }
     mwp_run<K, K>(m, role, epoch, &q.info[0], threadIdx.x);
+}
+
+// The same for clusters of 33 .. 64 rows (MWP_NT64 threads: 8 x 64 entry threads + four loader waves; up to eight stages and eight workgroups for W per
+// matrix: sixteen roles, blocks 128 (j / 8) + (j % 8) + 8 role).  Bit for bit the factors of the one-workgroup kernel, like the 32-row form.
+__device__ __forceinline__ void mwp_block_map64(int b, int &matrix, int &role) {
+    matrix = (b & 7) + 8 * (b >> 7);
+    role = (b >> 3) & 15;
+}
+__host__ __device__ static inline int mwp_blocks64(int matrices) { return 128 * ((matrices + 7) / 8); }
+template <int K>
+__global__ __launch_bounds__(MWP_NT64) void k_mw_factor_pipe64(const MwDev q, unsigned epoch) {
+    using namespace mwk;
+    if constexpr (K > 6) return;                        // (never launched beyond six limbs: twelve waves of that many registers do not fit a compute unit)
+    else {
+    mw_mark(q);
+    int j, role;
+    mwp_block_map64(blockIdx.x, j, role);
+    if (j >= q.J) return;
+    const MwClu &c = q.clu[j];
+    const int P = c.P, stages = (P + MWP_W - 1) / MWP_W;
+    if (role >= stages + MWP_N64 / MWP_W) return;
+    MwPipeMat m;
+    m.in = q.S + c.Soff; m.inplane = q.Slen; m.in_stride = 0; m.in_slots = 1; m.n = P; m.keep = q.S0 + c.Soff;
+    m.in_ld = m.l_ld = m.inv_ld = P;
+    m.L = q.S + c.Soff; m.lplane = q.Slen; m.rd = q.srd + c.coff; m.rdplane = q.xlen; m.Inv = q.Si + c.Soff; m.invplane = q.Slen;
+    m.pc = q.pipe_pc + (long)j * MWP_PC_WORDS_N(K, MWP_N64);
+    m.fail_code = j + 1;
+    m.stamps = nullptr;
+    if constexpr (mw_kf_of(K) < K) { if (q.kf < K) { mwp_run<K, mw_kf_of(K), MWP_N64>(m, role, epoch, &q.info[0], threadIdx.x); return; } }
+    mwp_run<K, K, MWP_N64>(m, role, epoch, &q.info[0], threadIdx.x);
+    }
 }
 
 // L_Q = chol(Q), Q = the sum of the ranks' partial sums, and L_Q^-1: the blocks 0, 8, 16, ... of the first 64 (one XCD); the blocks from 64 on carry the

@@ -334,12 +334,13 @@ def test_inverse_factor_columns_of_a_large_block_are_shared(K, oracle_built):
 
 
 @pytest.mark.parametrize("K", [3, 5, 6, 10])
-@pytest.mark.parametrize("name", ["ce_8_15", "ce_8_3", "polyopt8", "delsarte_3_10", "polyopt40", "sdpa_small", "ns_8_15_2", "polyopt_scaled_100"])
+@pytest.mark.parametrize("name", ["ce_8_15", "ce_8_3", "polyopt8", "delsarte_3_10", "polyopt40", "threepoint_4", "sdpa_small", "ns_8_15_2", "polyopt_scaled_100"])
 def test_pipelined_factorisation_is_bit_identical(name, K, oracle_built):
     """csrc/clrs_mw_pipe.hip.h: chol(S_j), chol(Q) and their inverse factors as pipelines of workgroups (column blocks of eight as stages, four more
     workgroups for the inverse, pivot columns handed on as tagged granules) do the arithmetic of the one-workgroup elimination entry by entry and
     pivot by pivot: factors, reciprocal diagonals (through LinvB and the solves) and solutions agree BIT FOR BIT with `pipeline=False`, on matrix sides
-    1 ... 32 including sides that are no multiple of the stage width (31, 22, 9), with and without free variables.  Matrices beyond LDS (the last two
+    1 ... 32 including sides that are no multiple of the stage width (31, 22, 9), with and without free variables; clusters of 33 ... 64 rows (polyopt40:
+    41, threepoint_4: 50) through the 64-row form of the pipeline (k_mw_factor_pipe64, up to six limbs).  Matrices beyond LDS (the last two
     instances: P = 96 with N = 97 free variables beside clusters that ride on the first launch; P = 201): the diagonal blocks of the blocked factorisation
     go through the same pipeline (k_mw_bp_diag_pipe), last blocks of 1 and 9 columns included."""
     from clrs_amd.mw import MwSchurContext
@@ -363,6 +364,46 @@ def test_pipelined_factorisation_is_bit_identical(name, K, oracle_built):
         ctx.close()
     for a, b in zip(out[0][0] + out[0][1], out[1][0] + out[1][1]):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("K", [5, 6])
+@pytest.mark.parametrize("name", ["ce_8_15", "polyopt40", "threepoint_4", "ns_8_15_2"])
+def test_reduced_factor_limbs_in_the_stand_alone_entry_points(name, K, oracle_built):
+    """clrs_mw_options.factor_limbs = limbs - 1 (mixed-precision refinement, clrs_mw_kernels.hip.h::mw_kf_of): the factor stage and the inverse-factor products
+    of the solve stage in one limb less, the residuals of the refinement step and the solution in all limbs.  Every factorisation form (one workgroup,
+    pipeline of 32 / 64 rows, blocked) computes the same reduced factors bit for bit; their upper limb plane is zero; the refined solution has the KKT
+    backward error of the working precision to within 20 bits of 53 K on these synthetic iterates (12 with full-limb factors: inside the interior-point loop the
+    measured first-pass accuracy decides when the reduced form is left)."""
+    from clrs_amd.mw import MwSchurContext
+    from oracle.oracle import Oracle
+    f = flat(name)
+    X, Y = _iterates(f, K)
+    X, Y = _sym_limbs(f, X), _sym_limbs(f, Y)
+    rng = np.random.default_rng(5)
+    rx, ry = mw_with_tails(rng.standard_normal(f.x_len), K, 1), mw_with_tails(rng.standard_normal(max(f.n_free, 1)), K, 2)[:, :f.n_free]
+    o = Oracle(f, mp_bits=320 if K <= 5 else 640)
+    pad = lambda a: np.vstack([a, np.zeros((1, a.shape[1]))])
+    out = []
+    for pipe in (False, True):
+        ctx = MwSchurContext(f, limbs=K, pipeline=pipe, factor_limbs=K - 1)
+        Xc = ctx.cholesky_blocks(X)
+        ctx.compute_S_integrated(Xc, Y)
+        S_ref, _ = o.schur_assemble_mw(pad(Xc), pad(Y))
+        assert ctx.factor() == 0
+        fac = ctx.get_factor()
+        dx, dy = ctx.solve(rx, ry)
+        ctx.close()
+        out.append((fac, (dx, dy)))
+        for a in fac:
+            if a.size:
+                assert np.all(a[K - 1] == 0.0) and np.any(a[K - 2] != 0.0)
+        bx, by = o.kkt_backward_error_mw(S_ref, dx, dy, rx, ry if f.n_free else np.zeros((K, 0)))
+        slack = 60 if name == "ns_8_15_2" else 20      # (Nsphere_packing: the products alone lose 82 bits on this iterate -- the loop would leave the reduced form here)
+        assert 53 * K + np.log2(bx) <= slack and (f.n_free == 0 or 53 * K + np.log2(by) <= slack), (53 * K + np.log2(bx), 53 * K + np.log2(by) if f.n_free else None)
+    for a, b in zip(out[0][0] + out[0][1], out[1][0] + out[1][1]):
+        assert np.array_equal(a, b)
+    with pytest.raises(Exception):
+        MwSchurContext(f, limbs=K, factor_limbs=K - 2)
 
 
 def test_pipelined_factorisation_reports_a_nonpositive_pivot_and_does_not_hang(oracle_built):
