@@ -282,9 +282,16 @@ __device__ __noinline__ void householder_regs_big(lds_d *A, int n, lds_d *dd, ld
     if (n <= 48) householder_regs<48>(A, n, dd, ee, lane);
     else householder_regs<64>(A, n, dd, ee, lane);
 }
-// work: LDS, at least 2 n + 160 doubles (3 n + 2 MW_NT are there); 2 <= n <= 64; MW_NT = 256 threads
+#ifdef CLRS_MW_STAMPS            // diagnostic builds only: phase stamps of the workgroup of k_mwi_step that ends the launch (scripts/step_stamps.py)
+__device__ unsigned long long g_mws_stamp[256][8];
+#define MWS_STAMP(i) do { if (threadIdx.x == 0) mwk::g_mws_stamp[blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)][i] = wall_clock64(); } while (0)
+#else
+#define MWS_STAMP(i) do { } while (0)
+#endif
+// work: LDS, at least 2 n + 160 doubles (3 n + 2 MW_NT are there); 2 <= n <= 64; NT threads (NT + 1 sections per round)
+template <int NT = MW_NT>
 __device__ double wg_min_eig32(lds_d *A, int n, lds_d *work, int tid) {
-    __shared__ int zc[2][MW_NT / 64];
+    __shared__ int zc[2][NT / 64];
     lds_d *dd = work, *ee = work + n, *d2 = work + 2 * n, *e2s = d2 + 80;
     const int wave = tid >> 6, lane = tid & 63;
     if (wave == 0) {
@@ -294,6 +301,7 @@ __device__ double wg_min_eig32(lds_d *A, int n, lds_d *work, int tid) {
         else householder_regs_big(A, n, dd, ee, lane);
     }
     __syncthreads();
+    MWS_STAMP(6);
     double lo = dd[0], hi = dd[0];                          // Gershgorin interval, by every thread
     for (int i = 0; i < n; i++) {
         const double rr = (i > 0 ? __builtin_fabs(ee[i - 1]) : 0.0) + (i < n - 1 ? __builtin_fabs(ee[i]) : 0.0);
@@ -310,8 +318,10 @@ __device__ double wg_min_eig32(lds_d *A, int n, lds_d *work, int tid) {
     lo = ldexp(lo, -sexp) - 1e-3;
     hi = ldexp(hi, -sexp) + 1e-3;
     __syncthreads();
-    for (int round = 0; round < 7; round++) {      // 257^7 > 1e16: the bracket shrinks to rounding level
-        const double h = (hi - lo) * (1.0 / 257.0);
+    MWS_STAMP(7);
+    constexpr int ROUNDS = NT >= 1024 ? 6 : 7;      // 257^7, 1025^6 > 1e16: the bracket shrinks to rounding level
+    for (int round = 0; round < ROUNDS; round++) {
+        const double h = (hi - lo) * (1.0 / (NT + 1));
         const double sft = lo + h * (tid + 1);
         double pm = 1.0, pc = (d2[0] - sft) + 1e-300;     // p_0, p_1
         auto hi32 = [](double v) { return (unsigned)(__double_as_longlong(v) >> 32); };
@@ -338,9 +348,9 @@ __device__ double wg_min_eig32(lds_d *A, int n, lds_d *work, int tid) {
         __syncthreads();
         int idx = 0;
 #pragma unroll
-        for (int w = 0; w < MW_NT / 64; w++) idx += zc[round & 1][w];
+        for (int w = 0; w < NT / 64; w++) idx += zc[round & 1][w];
         const double nlo = lo + h * idx;
-        hi = (idx == MW_NT) ? hi : lo + h * (idx + 1);
+        hi = (idx == NT) ? hi : lo + h * (idx + 1);
         lo = nlo;
     }
     return ldexp(0.5 * (lo + hi), sexp);
@@ -375,6 +385,71 @@ __device__ __noinline__ mwa::mw<K> mwi_gsum(const MwDev &q, const double *gs, in
         acc_add<K, K>(s, v);
     }
     return acc_result<K>(s);
+}
+// step lengths (:1684-1691, 470-483), by one lane.  A function of its own, inlined into k_mwi_step: through the call of mwi_scalar_stage (not inlined: its other
+// stages are chains of K-limb operations) the kernel's argument structures had their addresses taken, so the kernel opened with a copy of both to scratch
+// (80 stores per lane) and read every field of them from there, and the stage ran behind a call with a stack frame -- 12 of the 45 us of k_mwi_step.
+template <int K>
+__device__ __forceinline__ void mwi_scalar_stage3(const MwDev &q, const MwIpmDev &p) {
+    using namespace mwk;
+    // this stage ends k_mwi_step, on the critical path of the iteration: everything it reads is asked for at once, in front of the arithmetic and
+    // of the first store (one round trip to memory instead of one per dependent group of loads; 10 -> ~4 us)
+    const bool pre = q.world <= 1 && q.NB <= 8;
+    double pev[2][8];
+#pragma unroll
+    for (int w = 0; w < 2; w++)
+#pragma unroll
+        for (int b = 0; b < 8; b++) pev[w][b] = (pre && b < q.NB) ? p.eig[(long)w * q.NB + b] : 1e300;
+    const int f0 = p.flags[0];
+    int f1 = p.flags[1], f2 = p.flags[2];
+    unsigned long long rs[4] = {0ull, 0ull, 0ull, 0ull};
+    if (q.refstat) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) rs[i] = q.refstat[i];
+    }
+    double al[2];
+    for (int w = 0; w < 2; w++) {
+        double mn;
+        if (q.world > 1) {
+            mn = p.gsM[MWG_D(K, q.N) + 2 + w];
+            for (int r = 1; r < q.world; r++) mn = fmin(mn, p.gsM[(long)r * p.GL + MWG_D(K, q.N) + 2 + w]);
+            for (int r = 0; r < q.world; r++) if (p.gsM[(long)r * p.GL + MWG_D(K, q.N) + 6] != 0.0) f2 = 1;
+        } else if (pre) {
+            mn = pev[w][0];
+#pragma unroll
+            for (int b = 1; b < 8; b++) mn = fmin(mn, pev[w][b]);
+        } else {
+            mn = p.eig[(long)w * q.NB];
+            for (int b = 1; b < q.NB; b++) mn = fmin(mn, p.eig[(long)w * q.NB + b]);
+        }
+        const bool unsafe = f0 && !p.safe_step;
+        al[w] = (mn > -p.gamma && !unsafe) ? 1.0 : -p.gamma / mn;
+    }
+    if (f2 && f1 == 0) f1 = 1;
+    double amin = fmin(al[0], al[1]);
+    if (!(amin >= p.step_thr) && f1 == 0) f1 = 4;
+    // how good the first pass of the corrector's refined solve was: -log2(max|correction| / max|solution|) over dx and dy (k_mw_solve_bwd MODE 2 left the
+    // four maxima in q.refstat).  The host returns the factor stage to all K limbs when this falls to one limb plus a margin (mw_kf_of, clrs_mw_ipm_host.inc).
+    double refb = 0.0;
+    if (q.refstat) {
+        const double c0 = __longlong_as_double((long long)rs[0]), v0 = __longlong_as_double((long long)rs[1]);
+        const double c1 = __longlong_as_double((long long)rs[2]), v1 = __longlong_as_double((long long)rs[3]);
+        double ratio = 0.0;
+        if (v0 > 0.0) ratio = fmax(ratio, c0 / v0);
+        if (v1 > 0.0) ratio = fmax(ratio, c1 / v1);
+        refb = (v0 > 0.0 || v1 > 0.0) ? (ratio > 0.0 ? fmin(1023.0, fmax(1.0, -log2(ratio))) : 1023.0) : 0.0;
+    }
+    p.flags[2] = f2;
+    p.flags[1] = f1;
+    p.rec[MREC_AD] = al[0]; p.rec[MREC_AP] = al[1];           // the table row shows the values before they are equalised
+    if (f0 && p.safe_step) al[0] = al[1] = amin;
+    p.sc[MSC_COUNT * 0 + 10] = al[0];                          // slots 10 / 11 of limb plane 0: alpha_d / alpha_p as plain doubles
+    p.sc[MSC_COUNT * 0 + 11] = al[1];
+    p.rec[MREC_ERR] = f1;
+    if (q.refstat) {
+        p.rec[MREC_REFB] = refb;
+        q.refstat[0] = q.refstat[1] = q.refstat[2] = q.refstat[3] = 0ull;
+    }
 }
 // called by the first wave of a workgroup (threadIdx.x < 64); stages 0-3 use its first lane only
 template <int K, int DK>
@@ -502,41 +577,7 @@ __device__ void mwi_scalar_stage(const MwDev &q, const MwIpmDev &p, int stage, i
         p.flags[0] = (p.rec[MREC_DERR] < p.dual_thr && p.rec[MREC_PERR] < p.primal_thr) ? 1 : 0;
         p.rec[MREC_PDFEAS] = p.flags[0];
     }
-    if (stage == 3) {                              // step lengths (:1684-1691, 470-483)
-        double al[2];
-        for (int w = 0; w < 2; w++) {
-            double mn;
-            if (q.world > 1) {
-                mn = p.gsM[MWG_D(K, q.N) + 2 + w];
-                for (int r = 1; r < q.world; r++) mn = fmin(mn, p.gsM[(long)r * p.GL + MWG_D(K, q.N) + 2 + w]);
-                for (int r = 0; r < q.world; r++) if (p.gsM[(long)r * p.GL + MWG_D(K, q.N) + 6] != 0.0) p.flags[2] = 1;
-            } else {
-                mn = p.eig[(long)w * q.NB];
-                for (int b = 1; b < q.NB; b++) mn = fmin(mn, p.eig[(long)w * q.NB + b]);
-            }
-            const bool unsafe = p.flags[0] && !p.safe_step;
-            al[w] = (mn > -p.gamma && !unsafe) ? 1.0 : -p.gamma / mn;
-        }
-        if (p.flags[2] && p.flags[1] == 0) p.flags[1] = 1;
-        double amin = fmin(al[0], al[1]);
-        if (!(amin >= p.step_thr) && p.flags[1] == 0) p.flags[1] = 4;
-        p.rec[MREC_AD] = al[0]; p.rec[MREC_AP] = al[1];           // the table row shows the values before they are equalised
-        if (p.flags[0] && p.safe_step) al[0] = al[1] = amin;
-        p.sc[MSC_COUNT * 0 + 10] = al[0];                          // slots 10 / 11 of limb plane 0: alpha_d / alpha_p as plain doubles
-        p.sc[MSC_COUNT * 0 + 11] = al[1];
-        p.rec[MREC_ERR] = p.flags[1];
-        // how good the first pass of the corrector's refined solve was: -log2(max|correction| / max|solution|) over dx and dy (k_mw_solve_bwd MODE 2 left the
-        // four maxima in q.refstat).  The host returns the factor stage to all K limbs when this falls to one limb plus a margin (mw_kf_of, clrs_mw_ipm_host.inc).
-        if (q.refstat) {
-            const double c0 = __longlong_as_double((long long)q.refstat[0]), v0 = __longlong_as_double((long long)q.refstat[1]);
-            const double c1 = __longlong_as_double((long long)q.refstat[2]), v1 = __longlong_as_double((long long)q.refstat[3]);
-            double ratio = 0.0;
-            if (v0 > 0.0) ratio = fmax(ratio, c0 / v0);
-            if (v1 > 0.0) ratio = fmax(ratio, c1 / v1);
-            p.rec[MREC_REFB] = (v0 > 0.0 || v1 > 0.0) ? (ratio > 0.0 ? fmin(1023.0, fmax(1.0, -log2(ratio))) : 1023.0) : 0.0;
-            q.refstat[0] = q.refstat[1] = q.refstat[2] = q.refstat[3] = 0ull;
-        }
-    }
+    if (stage == 3) mwi_scalar_stage3<K>(q, p);
 }
 template <int K, int DK>
 __global__ void k_mwi_scalar(const MwDev q, const MwIpmDev p, int stage, int iter) {
@@ -1254,37 +1295,50 @@ __device__ __forceinline__ void mwi_step_congruence(PF F, PR rd, PW W, long wpla
 // the panels go to p.Wd as fp64 heads, the workgroup of a (block, which) that arrives last mirrors them in LDS and takes the eigenvalue.
 // One workgroup issues the two 16-term products of a 16 x 16 block no faster than its four SIMDs allow (14 us); four share them.
 #define MWI_SW 4
-template <int K>
-__device__ __forceinline__ bool mwi_step_panels(const MwDev &q, const MwIpmDev &p, const MwBlk &k, int which, const double *Li, const double *dMg) {
+// KA: limbs of the two products (the factor stage's count while the refined solves run on reduced factors: the congruence is rounded to fp64, and the
+// inverse factor it is taken with was computed in KA limbs); SW: lanes per entry -- 16 with one-column panels of blocks of at most 16 rows, where a
+// product is then ONE term per lane and phase instead of up to four (12 -> 6 us of the 46 of k_mwi_step on the named problem)
+template <int K, int KA, int SW>
+__device__ __forceinline__ bool mwi_step_panels_ka(const MwDev &q, const MwIpmDev &p, const MwBlk &k, int which, const double *Li, const double *dMg) {
     using namespace mwk;
-    const int n = k.n, tid = threadIdx.x, sub = tid % MWI_SW;
+    const int n = k.n, tid = threadIdx.x, sub = tid % SW;
     const int zs = gridDim.z, pc0 = (n + zs - 1) / zs, c0 = blockIdx.z * pc0, pc = max(0, min(pc0, n - c0));
     const long np = (long)n * pc0;
-    lds_d *Us = MW_LDS;                                   // U = dM Li^T[:, panel], n x pc0, K limbs planar
-    for (int e0 = 0; e0 < n * pc; e0 += MW_NT / MWI_SW) {
-        const int e = e0 + tid / MWI_SW;
+    lds_d *Us = MW_LDS;                                   // U = dM Li^T[:, panel], n x pc0, KA limbs planar
+    for (int e0 = 0; e0 < n * pc; e0 += MW_NT / SW) {
+        const int e = e0 + tid / SW;
         const bool live = e < n * pc;
         const int ee = live ? e : 0, r = ee % n, c = c0 + ee / n;
-        acc<K> s;
-        acc_zero<K>(s);
-        for (int t = sub; t <= c; t += MWI_SW) acc_fma<K, K, K>(s, ldx<K>(dMg, q.xylen, r + (long)t * n), ldx<K>(Li, q.xylen, c + (long)t * n));
-        const mw<K> v = lanes_sum<K, MWI_SW>(acc_result<K>(s));
-        if (live && sub == 0) stx<K>(Us, np, ee, v);
+        acc<KA> s;
+        acc_zero<KA>(s);
+        for (int t = sub; t <= c; t += SW) acc_fma<KA, KA, KA>(s, ldx<KA>(dMg, q.xylen, r + (long)t * n), ldx<KA>(Li, q.xylen, c + (long)t * n));
+        const mw<KA> v = lanes_sum<KA, SW>(acc_result<KA>(s));
+        if (live && sub == 0) stx<KA>(Us, np, ee, v);
     }
     __syncthreads();
+    MWS_STAMP(1);
     double *Wg = p.Wd + (long)which * q.xylen + k.xyoff;
-    for (int e0 = 0; e0 < n * pc; e0 += MW_NT / MWI_SW) {
-        const int e = e0 + tid / MWI_SW;
+    for (int e0 = 0; e0 < n * pc; e0 += MW_NT / SW) {
+        const int e = e0 + tid / SW;
         const bool live = e < n * pc;
         const int ee = live ? e : 0, i = ee % n, cl = ee / n, c = c0 + cl;
-        acc<K> s;
-        acc_zero<K>(s);
+        acc<KA> s;
+        acc_zero<KA>(s);
         if (i >= c)
-            for (int r = sub; r <= i; r += MWI_SW) acc_fma<K, K, K>(s, ldx<K>(Li, q.xylen, i + (long)r * n), ldx<K>(Us, np, r + (long)cl * n));
-        const mw<K> v = lanes_sum<K, MWI_SW>(acc_result<K>(s));
+            for (int r = sub; r <= i; r += SW) acc_fma<KA, KA, KA>(s, ldx<KA>(Li, q.xylen, i + (long)r * n), ldx<KA>(Us, np, r + (long)cl * n));
+        const mw<KA> v = lanes_sum<KA, SW>(acc_result<KA>(s));
         if (live && sub == 0 && i >= c) Wg[i + (long)c * n] = v.l[0];
     }
+    MWS_STAMP(2);
     return mwi_last_block(&p.wcnt[which * q.NB + blockIdx.x], zs);
+}
+template <int K>
+__device__ __forceinline__ bool mwi_step_panels(const MwDev &q, const MwIpmDev &p, const MwBlk &k, int which, const double *Li, const double *dMg) {
+    const bool wide = (int)gridDim.z >= k.n && k.n <= 16;        // one column per workgroup
+    if constexpr (mw_kf_of(K) < K) {
+        if (q.kf < K) return wide ? mwi_step_panels_ka<K, mw_kf_of(K), 16>(q, p, k, which, Li, dMg) : mwi_step_panels_ka<K, mw_kf_of(K), MWI_SW>(q, p, k, which, Li, dMg);
+    }
+    return wide ? mwi_step_panels_ka<K, K, 16>(q, p, k, which, Li, dMg) : mwi_step_panels_ka<K, K, MWI_SW>(q, p, k, which, Li, dMg);
 }
 
 // ---- compute_step_length (:1620-1693) per block: smallest eigenvalue of L^-1 dM L^-T, L = chol(M) -----------------------
@@ -1293,6 +1347,7 @@ template <int K>
 __device__ __forceinline__ bool mwi_step_body(const MwDev &q, const MwIpmDev &p, int w_in_lds, int inv_path, int which_base) {
     using namespace mwk;
     const int which = which_base + blockIdx.y;          // both step lengths in one launch (grid.y = 2), or one launch each
+    MWS_STAMP(0);
     const MwBlk &k = q.blk[blockIdx.x];
     const int n = k.n, tid = threadIdx.x;
     const long nn = (long)n * n;
@@ -1316,6 +1371,7 @@ __device__ __forceinline__ bool mwi_step_body(const MwDev &q, const MwIpmDev &p,
         }
         if (gridDim.z > 1 || inv_path == 3) {             // 3: the congruence is in Wd already (tiled launches of k_mwi_bmm, large blocks)
             if (inv_path == 2 && !mwi_step_panels<K>(q, p, k, which, (which == 0 ? q.Xi : p.Yi) + k.xyoff, dMg)) return false;      // not the last workgroup of this (block, which)
+            MWS_STAMP(3);
             lds_d *Wl = MW_LDS, *wk = Wl + nn;
             const double *Wg = p.Wd + (long)which * q.xylen + k.xyoff;
             for (int e = tid; e < nn; e += MW_NT) {
@@ -1323,8 +1379,10 @@ __device__ __forceinline__ bool mwi_step_body(const MwDev &q, const MwIpmDev &p,
                 Wl[e] = i >= c ? Wg[e] : Wg[c + (long)i * n];
             }
             __syncthreads();
+            MWS_STAMP(4);
             const double ev = n <= 64 ? wg_min_eig32(Wl, n, wk, tid) : wg_min_eig(Wl, n, wk, tid);
             if (tid == 0) p.eig[(long)which * q.NB + blockIdx.x] = ev - 1e-5;            // :1662
+            MWS_STAMP(5);
             return true;
         }
         mwi_step_congruence_inv<K>((which == 0 ? q.Xi : p.Yi) + k.xyoff, q.xylen, n, dMg, q.xylen, T1, Wd, tid);
@@ -1426,7 +1484,22 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_step(const MwDev q, const MwIpmDe
     // the workgroup that arrives last -- of the 2 NB that end a (block, which), in one launch or two -- takes the step lengths
     // (moving the iterate here as well, by this one workgroup, is slower than the launch of k_mwi_update it saves: 45 against 35 + 6 us)
     if (q.world > 1) return;                            // sharded: the minima travel first (k_mwi_gpack, all-gather, k_mwi_scalar stage 3)
-    if (mwi_last_block(&p.flags[4], 2u * q.NB) && threadIdx.x < 64) mwi_scalar_stage<K, DK>(q, p, 3, iter);
+#ifdef CLRS_MW_STAMPS
+    if (mwi_last_block(&p.flags[4], 2u * q.NB)) {
+        if (threadIdx.x == 0) mwi_scalar_stage3<K>(q, p);
+        if (threadIdx.x == 0 && p.stamps) {
+            const int me = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+            unsigned long long t0 = ~0ull;
+            const int nw = gridDim.x * gridDim.y * gridDim.z;
+            for (int w = 0; w < nw && w < 256; w++) t0 = mwk::g_mws_stamp[w][0] < t0 ? mwk::g_mws_stamp[w][0] : t0;
+            p.stamps[8] = t0;
+            { const int sel[6] = {0, 2, 4, 6, 7, 5}; for (int i = 0; i < 6; i++) p.stamps[9 + i] = mwk::g_mws_stamp[me][sel[i]]; }
+            p.stamps[15] = wall_clock64();
+        }
+    }
+    return;
+#endif
+    if (mwi_last_block(&p.flags[4], 2u * q.NB) && threadIdx.x == 0) mwi_scalar_stage3<K>(q, p);
 }
 
 // X = omega_p I, Y = omega_d I, x = y = 0 (:187-201)
