@@ -796,7 +796,10 @@ extern "C" int clrs_mw_create_opts(const clrs_sdp_desc *d, int data_limbs, int d
         bool small = c->maxP <= MWP_N;
         for (auto &cl : c->clu) small = small && cl.lds;
         c->pipe_S = cfg_pipe != 0 && (K <= 6 || cfg_pipe >= 2) && small && (i64)J * ((MWP_N / MWP_W) + MWP_WW) <= 256;      // (8, 10 limbs: measured slower than one workgroup, 2.42 against 2.34 ms per iteration: opt-in)
-        c->pipe_Q = cfg_pipe >= 2 && N > 0 && N <= MWP_N;      // (Q: slower than the one-workgroup kernel on the named problem, 83 against 80 us: opt-in)
+        // (Q: with the columns asked for four steps ahead the pipeline was slower than the one-workgroup kernel on the named problem, 83 against 80 us; with
+        // MWP_AHEAD = 0 it is faster -- whole iterations 0.4197 -> 0.4165 ms on cohnelkies(8,15), 0.4113 -> 0.4057 on delsarte(3,10,1/2): on from two stages,
+        // and with pipeline = 2 for every Q of at most MWP_N rows)
+        c->pipe_Q = (cfg_pipe >= 2 || (cfg_pipe == 1 && K <= 6 && N > MWP_W)) && N > 0 && N <= MWP_N;
         bool lds_all = !c->clu.empty();
         for (auto &cl : c->clu) lds_all = lds_all && cl.lds;
         // (measured at 5 limbs, factor stage in 4: PolyOpt 2d = 40, P = 41 -- six stages, five hops -- 0.478 -> 0.487 ms per iteration; the tested three-point instance,
@@ -1481,7 +1484,8 @@ extern "C" int clrs_mw_get_S(clrs_mw_ctx *c, double *S_out, double *AY_out) {
 }
 
 // diagnostic (-DCLRS_MW_STAMPS builds): step stamps of the pipelined factorisations, [16 roles][40]: rows 0-7 the workgroups of cluster 0 in
-// k_mw_factor_pipe, rows 8-15 those of Q in k_mw_potrf_q_pipe; columns 0..n-1 the top of step k, 39 start, 38 end (100 MHz wall clock)
+// k_mw_factor_pipe, rows 8-15 those of Q in k_mw_potrf_q_pipe; columns 0..n-1 the top of step k, 39 start, 38 end (100 MHz wall clock); behind them
+// [8 roles][32 steps][4 who][4 points]: the stamps inside the steps of cluster 0 (clrs_mw_pipe.hip.h; scripts/pipe_substamps.py)
 extern "C" int clrs_mw_debug_pipe_stamps(clrs_mw_ctx *c, unsigned long long *out) {
     if (!c) return mw_fail(CLRS_ERR_INVALID, "null context");
 #ifndef CLRS_MW_STAMPS
@@ -1491,10 +1495,10 @@ extern "C" int clrs_mw_debug_pipe_stamps(clrs_mw_ctx *c, unsigned long long *out
     MWCHECK(hipStreamSynchronize(c->stream));
     if (!c->d.pipe_stamps) {
         double *p = nullptr;
-        int rc = mw_dmalloc(c, &p, 16 * 40);
+        int rc = mw_dmalloc(c, &p, 16 * 40 + 8 * 32 * 4 * 4);
         if (rc) return rc;
         c->d.pipe_stamps = (unsigned long long *)p;
-    } else if (out) MWCHECK(hipMemcpy(out, c->d.pipe_stamps, 16 * 40 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    } else if (out) MWCHECK(hipMemcpy(out, c->d.pipe_stamps, (16 * 40 + 8 * 32 * 4 * 4) * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return 0;
 }
 // diagnostic: phase stamps (100 MHz wall clock) of wave 0 of the first workgroup of the next k_mws_pair launches; out[16] = the last ones

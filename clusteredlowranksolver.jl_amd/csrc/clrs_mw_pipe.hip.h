@@ -41,6 +41,12 @@
 #define MWP_W 8              // columns per stage
 #define MWP_WW 4             // workgroups that share the columns of W
 #define MWP_ET 256           // entry threads per workgroup: MWP_W columns x MWP_N rows
+#ifndef MWP_AHEAD
+#define MWP_AHEAD 0          // steps between the loads of a pivot column and its delivery (< MWP_NL).  A workgroup settles this many steps (plus the publisher's
+                             // delay and one round trip) behind the stage it reads from: a column asked for before it exists comes back stale, and the poll and
+                             // the second round trip of that case (1.4 us) sit on the step until the workgroup has fallen far enough behind to find its columns at
+                             // the first try.  With the loads MWP_NL = 4 steps ahead (round 4) that was 4.6-4.9 us per stage boundary (scripts/pipe_substamps.py).
+#endif
 #define MWP_NL 4             // LOADER waves: each fetches every MWP_NL-th pivot column, MWP_NL steps ahead of the entry waves (the first one also publishes this stage's own)
 #define MWP_NT (MWP_ET + 64 * MWP_NL)
 #define MWP_SPIN_LIMIT (1 << 22)
@@ -65,6 +71,7 @@ struct MwPipeMat {           // one matrix of a pipelined factorisation
     unsigned long long *pc;  // MWP_PC_WORDS granules: the published pivot columns
     int fail_code;           // atomicMin'ed into info[0] at a non-positive pivot
     unsigned long long *stamps;   // diagnostic builds (-DCLRS_MW_STAMPS): [roles][40] time stamps, or null
+    unsigned long long *sub = nullptr;      // diagnostic builds: [8 roles][32 steps][4 who][4 points] stamps inside the steps, or null
 };
 
 namespace mwk {
@@ -251,21 +258,32 @@ __device__ __forceinline__ bool mwp_run(const MwPipeMat &m, int role, unsigned e
         F.issue(m.pc, 0, is_w ? 0 : c0);
         if (!F.complete(tag0, S.col(0), m.pc + ((long)(K - 1) * NR + n - 1) * 2 + 1)) *S.flag = 0;
     }
-    if (loader) {
+    if (loader) {                                                            // columns 1 .. MWP_AHEAD: asked for now, by the waves that will deliver them
         const int j = lw == 0 ? MWP_NL : lw;
-        if (j < nfetch) F.issue(m.pc + (long)j * MWP_GRANULES_N(K, NR), j, is_w ? j : c0);
+        if (j <= MWP_AHEAD && j < nfetch) F.issue(m.pc + (long)j * MWP_GRANULES_N(K, NR), j, is_w ? j : c0);
     }
     __syncthreads();
     const int kend = is_w ? n : c1;                                          // pivots this workgroup looks at: 0 .. kend - 1
 #ifdef CLRS_MW_STAMPS            // diagnostic builds: wall clock (100 MHz) of thread 0 at the top of every step, per role, for the matrix with m.stamps != null
     unsigned long long *stamps = m.stamps ? m.stamps + (long)role * 40 : nullptr;
     if (stamps && tid == 0) stamps[39] = wall_clock64();
+    // ... and inside the steps (g_mwp_sub[role][step][who][point], scripts/pipe_substamps.py): who 0 / 1 = first lane of entry wave 0 / of the last entry wave,
+    // 2 = first loader wave, 3 = the loader wave whose turn the step is; points: top, pivot read and scaled, arithmetic / hand-off done, behind the barrier
+    const int sub_who = !m.sub || role >= 8 ? -1 : tid == 0 ? 0 : tid == ET - 64 ? 1 : tid == ET ? 2 : -1;
+#define MWP_SUB(k_, who_, pt_) do { if ((who_) >= 0 && (k_) < 32) m.sub[((role * 32 + (k_)) * 4 + (who_)) * 4 + (pt_)] = wall_clock64(); } while (0)
+#else
+#define MWP_SUB(k_, who_, pt_) do { } while (0)
 #endif
     for (int k = 0; k < kend; k++) {
 #ifdef CLRS_MW_STAMPS
         if (stamps && tid == 0) stamps[k] = wall_clock64();
 #endif
         lds_d *cur = S.col(k), *nxt = S.col(k + 1);
+#ifdef CLRS_MW_STAMPS
+        const int sub_turn = (m.sub && role < 8 && loader && lane == 0 && (k + 1) % MWP_NL == lw) ? 3 : -1;
+#endif
+        MWP_SUB(k, sub_who, 0); MWP_SUB(k, sub_turn, 0);
+        if (MWP_AHEAD == 0 && loader && (k + 1) % MWP_NL == lw && k + 1 < nfetch) F.issue(m.pc + (long)(k + 1) * MWP_GRANULES_N(K, NR), k + 1, is_w ? k + 1 : c0);
         const mw<K> d = ldx<K>(cur, NR, k);
         if (!(*S.flag) || !(d.l[0] > 0.0)) {                                 // uniform: every thread reads the same words
             // the owner of a column with a non-positive pivot publishes it all the same: the workgroups behind it read the pivot there and stop at the same
@@ -283,10 +301,13 @@ __device__ __forceinline__ bool mwp_run(const MwPipeMat &m, int role, unsigned e
         double p1, ph;
         pivot_scale(d.l[0], p1, ph);
         const mw<K> dh = mul_pow2<K>(d, p1);
+        MWP_SUB(k, sub_who, 1); MWP_SUB(k, sub_turn, 1);
         if (loader) {
-            if ((k + 1) % MWP_NL == lw) {                                    // my turn: deliver column k + 1 (sent for MWP_NL steps ago), send for the next of mine
+            if ((k + 1) % MWP_NL == lw) {                                    // my turn: deliver column k + 1 (sent for MWP_AHEAD steps ago)
                 if (k + 1 < nfetch && !F.complete(tag0 | (unsigned)(k + 1), nxt, m.pc + (long)(k + 1) * MWP_GRANULES_N(K, NR) + ((long)(K - 1) * NR + n - 1) * 2 + 1)) *S.flag = 0;
-                const int j = k + 1 + MWP_NL;
+            }
+            if (MWP_AHEAD > 0 && (k + 1 + MWP_AHEAD) % MWP_NL == lw) {       // ... and the wave that delivers column k + 1 + MWP_AHEAD sends for it (MWP_AHEAD = 0: at the top of the step)
+                const int j = k + 1 + MWP_AHEAD;
                 if (j < nfetch) F.issue(m.pc + (long)j * MWP_GRANULES_N(K, NR), j, is_w ? j : c0);
             }
             // s_(k+1) = s_k dh_k: one K-limb product per step, off the chain, on the first loader wave: it shares its SIMD with entry wave 0, which in a
@@ -303,7 +324,9 @@ __device__ __forceinline__ bool mwp_run(const MwPipeMat &m, int role, unsigned e
             }
             if (live && i == k + 1 && c <= k) stx<K>(S.wrow(k + 1), MWP_W, cc, v);
         }
+        MWP_SUB(k, sub_who, 2); MWP_SUB(k, sub_turn, 2);
         mwp_barrier();
+        MWP_SUB(k, sub_who, 3); MWP_SUB(k, sub_turn, 3);
     }
     __syncthreads();
     // post-processing (wg_potrf's): f_k = 1 / sqrt(s_k d~_k); L_kk = d~_k f_k, 1 / L_kk = f_k s_k; L_ik = a~_ik f_k; (L^-1)_ij = W_ij f_i
@@ -360,6 +383,7 @@ __global__ __launch_bounds__(MWP_NT) void k_mw_factor_pipe(const MwDev q, unsign
     m.pc = q.pipe_pc + (long)j * MWP_PC_WORDS(K);
     m.fail_code = j + 1;
     m.stamps = j == 0 && q.pipe_stamps ? q.pipe_stamps : nullptr;
+    m.sub = m.stamps ? m.stamps + 16 * 40 : nullptr;
     if constexpr (mw_kf_of(K) < K) { if (q.kf < K) { mwp_run<K, mw_kf_of(K)>(m, role, epoch, &q.info[0], threadIdx.x); return; } }
     mwp_run<K, K>(m, role, epoch, &q.info[0], threadIdx.x);
 }

@@ -11,9 +11,9 @@ ctx = MwSchurContext(f, limbs=5)
 solvesdp_mw(f, ctx=ctx, maxiterations=5)
 assert ctx.L.clrs_mw_debug_pipe_stamps(ctx.h, None) == 0
 solvesdp_mw(f, ctx=ctx, maxiterations=20)
-st = (C.c_uint64 * (16 * 40))()
+st = (C.c_uint64 * (16 * 40 + 8 * 32 * 4 * 4))()      # (behind the step stamps: the stamps inside the steps, scripts/pipe_substamps.py)
 assert ctx.L.clrs_mw_debug_pipe_stamps(ctx.h, st) == 0
-v = np.array(list(st), dtype=np.int64).reshape(16, 40)
+v = np.array(list(st), dtype=np.int64)[:16 * 40].reshape(16, 40)
 for base, name in ((0, "k_mw_factor_pipe, cluster 0"),):      # (rows 8.. hold k_mw_potrf_q_pipe's stamps when the pipeline of Q is on: mw_pipeline = 2; else scripts/chain_stamps.py's)
     t0 = min(int(v[base + r, 39]) for r in range(8) if v[base + r, 39])
     print(name, "(us from the first workgroup's start; role 0-3 stages, 4-7 W)")
