@@ -222,13 +222,15 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str =
     objs, jobs = [], []
     # CLRS_MW_STAMPS=1: the diagnostic variant of the multi-word units with phase stamps in k_mwi_Zi / k_mws_pair / k_mwx_dense (compile-time: the
     # product library carries none), built beside the product as csrc/_diag/libclrs_hip_mwstamps.so (objects there too; load it with CLRS_HIP_LIB=...)
-    mw_stamps = bool(os.environ.get("CLRS_MW_STAMPS")) and out is None
+    # CLRS_MW_DEFS="-DX ...": an experimental variant of the multi-word units with those definitions, csrc/_diag/libclrs_hip_mwexp.so (same mechanism)
+    mw_defs = tuple(os.environ.get("CLRS_MW_DEFS", "").split()) if out is None else ()
+    mw_stamps = (bool(os.environ.get("CLRS_MW_STAMPS")) or bool(mw_defs)) and out is None
     if mw_stamps:
         os.makedirs(os.path.join(CSRC, "_diag"), exist_ok=True)
-        out = os.path.join(CSRC, "_diag", "libclrs_hip_mwstamps.so")
+        out = os.path.join(CSRC, "_diag", "libclrs_hip_mwexp.so" if mw_defs else "libclrs_hip_mwstamps.so")
     for obj, src, flags, mine in _UNITS:
         if mw_stamps:
-            flags = (*flags, "-DCLRS_MW_STAMPS") if src != "clrs_hip.hip" else flags
+            flags = (*flags, *(mw_defs if mw_defs else ("-DCLRS_MW_STAMPS",))) if src != "clrs_hip.hip" else flags
             obj = os.path.join("_diag", obj) if src != "clrs_hip.hip" else obj
         o = os.path.join(CSRC, obj if out is None or src != "clrs_hip.hip" or mw_stamps else os.path.join("_diag", os.path.basename(out) + ".o"))
         os.makedirs(os.path.dirname(o), exist_ok=True)

@@ -89,14 +89,18 @@ __device__ __forceinline__ void mwp_publish(unsigned long long *pcol, unsigned t
         mwp_store(pcol + ((long)l * MWP_N + i) * 2 + 1, t | (b >> 32));
     }
 }
-// the loader wave (64 lanes) publishes rows r0 .. n-1 of a pivot column held in LDS (planar, plane MWP_N)
+// the loader wave (64 lanes) publishes rows r0 .. n-1 of a pivot column held in LDS (planar, plane MWP_N) -- and, in the granules of row 0 (which no
+// column k >= 1 uses), the running product s_k of the scaled pivots (sk: limb l at sk[l splane]; null for column 0, whose s_0 = 1): the workgroups behind
+// this one read s_k there instead of repeating the chain of K-limb products s_(k+1) = s_k dh_k step by step (0.9 us on the first loader wave of every step
+// that applies an incoming column, 0.2 us of it on the step's barrier: scripts/pipe_substamps.py).  The same products in the same order: the same bits.
 template <int K, int NR>
-__device__ __forceinline__ void mwp_publish_column(unsigned long long *pcol, unsigned tag, int r0, int n, const lds_d *buf, int lane) {
-    const int rows = n - r0, cnt = rows * K;
+__device__ __forceinline__ void mwp_publish_column(unsigned long long *pcol, unsigned tag, int r0, int n, const lds_d *buf, int lane, const lds_d *sk = nullptr, int splane = 0) {
+    const int rows = n - r0, ks = sk ? K : 0, cnt = rows * K + ks;
     const unsigned long long t = (unsigned long long)tag << 32;
-    for (int e = lane; e < cnt; e += 64) {
-        const int l = e / rows, i = r0 + e % rows;
-        const unsigned long long b = (unsigned long long)__double_as_longlong((double)buf[(long)l * NR + i]);
+    for (int e = lane; e < cnt; e += 64) {                       // s_k first: the sentinel (limb K - 1 of row n - 1) stays the last granule stored
+        const int e2 = e - ks;
+        const int l = e < ks ? e : e2 / rows, i = e < ks ? 0 : r0 + e2 % rows;
+        const unsigned long long b = (unsigned long long)__double_as_longlong(e < ks ? (double)sk[(long)l * splane] : (double)buf[(long)l * NR + i]);
         unsigned long long *g = pcol + ((long)l * NR + i) * 2;
         const unsigned long long g0 = t | (b & 0xffffffffull), g1 = t | (b >> 32);
 #ifdef MWP_PLAIN_PUBLISH
@@ -137,12 +141,12 @@ struct MwpFetch {
         }
         col = nullptr;
     }
-    __device__ __forceinline__ void issue(const unsigned long long *pcol, int prow, int r0) {
+    __device__ __forceinline__ void issue(const unsigned long long *pcol, int prow, int r0) {      // (columns >= 1: row 0 carries the running product s_k)
         col = pcol;
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const int i = off[r] & (NR - 1);
-            want[r] = off[r] >= 0 && (i == prow || i >= r0);
+            want[r] = off[r] >= 0 && (i == prow || i >= r0 || (i == 0 && prow > 0));
             if (want[r]) {
                 const unsigned long long *g = pcol + (long)off[r] * 2;
                 a[r] = mwp_load(g);
@@ -161,6 +165,8 @@ struct MwpFetch {
 #pragma unroll
             for (int r = 0; r < R; r++) mine = mine && (!want[r] || ((unsigned)(a[r] >> 32) == tag && (unsigned)(b[r] >> 32) == tag));
             if (__all(mine)) break;
+            // (asking for the rows themselves again instead of the sentinel first -- one round trip less once the column is there -- moves nothing: 0.4157
+            // against 0.4156 ms per iteration on cohnelkies(8,15), 2.061 against 2.062 on Nsphere_packing N = 3)
             while ((unsigned)(mwp_load(sentinel) >> 32) != tag && spins < MWP_SPIN_LIMIT) {
                 __builtin_amdgcn_s_sleep(2);
                 spins++;
@@ -289,14 +295,16 @@ __device__ __forceinline__ bool mwp_run(const MwPipeMat &m, int role, unsigned e
             // the owner of a column with a non-positive pivot publishes it all the same: the workgroups behind it read the pivot there and stop at the same
             // step -- without it they would poll for the column until their bound (1.3 s: found on the 16-cluster weak-scaling instance, whose solve ends
             // with a failed factorisation)
-            if (loader && lw == 0 && !is_w && k >= c0) mwp_publish_column<K, NR>(m.pc + (long)k * MWP_GRANULES_N(K, NR), tag0 | (unsigned)k, k, n, cur, lane);
+            if (loader && lw == 0 && !is_w && k >= c0) mwp_publish_column<K, NR>(m.pc + (long)k * MWP_GRANULES_N(K, NR), tag0 | (unsigned)k, k, n, cur, lane, k ? S.us + k : nullptr, NR + 1);
             if (tid == 0) atomicMin(info, m.fail_code);
             return false;
         }
         if (is_w && tid == ET) stx<K>(S.dd, NR, k, d);
         // a column this stage owns goes to the stages and the W workgroups behind it from HERE, out of LDS, by a loader wave: a store of the entry waves
         // would put its wait for the write-through on the dependent chain (the compiler guards the stored registers with s_waitcnt vmcnt)
-        if (loader && lw == 0 && !is_w && k >= c0) mwp_publish_column<K, NR>(m.pc + (long)k * MWP_GRANULES_N(K, NR), tag0 | (unsigned)k, k, n, cur, lane);
+        if (loader && lw == 0 && !is_w && k >= c0) mwp_publish_column<K, NR>(m.pc + (long)k * MWP_GRANULES_N(K, NR), tag0 | (unsigned)k, k, n, cur, lane, k ? S.us + k : nullptr, NR + 1);
+        // s_k of a column that came from another workgroup: it travelled in the granules of row 0 (kept for the post-processing)
+        if (tid == ET && k >= 1 && k < nfetch) stx<K>(S.us, NR + 1, k, ldx<K>(cur, NR, 0));
         if (k + 1 >= kend) break;
         double p1, ph;
         pivot_scale(d.l[0], p1, ph);
@@ -312,14 +320,15 @@ __device__ __forceinline__ bool mwp_run(const MwPipeMat &m, int role, unsigned e
             }
             // s_(k+1) = s_k dh_k: one K-limb product per step, off the chain, on the first loader wave: it shares its SIMD with entry wave 0, which in a
             // stage's own steps is the first to run out of live columns (moving it to another SIMD made those steps 1.9-2.9 us instead of 1.45: measured)
-            if (tid == ET) stx<K>(S.us, NR + 1, k + 1, mul<K>(ldx<K>(S.us, NR + 1, k), dh));
+            // (only where column k + 1 is this stage's own: the s_k of the others arrive with their columns)
+            if (tid == ET && k + 1 >= nfetch) stx<K>(S.us, NR + 1, k + 1, mul<K>(k >= 1 && k < nfetch ? ldx<K>(cur, NR, 0) : ldx<K>(S.us, NR + 1, k), dh));
         } else if (!is_w) {
             if (live && c > k) v = mwp_step<K>(dh, ph, v, ldx<K>(cur, NR, i), ldx<K>(cur, NR, c));
             if (k + 1 >= c0 && live && c == k + 1) stx<K>(nxt, NR, i, v);      // my stage's column k + 1 is final now: to this stage's next step
         } else {
             // W: entries (i, c) with c <= k < i; row k of W comes from the thread that owns (k, c), through LDS; w_kk = s_k
             if (live && c <= k && i > k) {
-                const mw<K> wk = c == k ? ldx<K>(S.us, NR + 1, k) : ldx<K>(S.wrow(k), MWP_W, cc);
+                const mw<K> wk = c == k ? (k == 0 ? ldx<K>(S.us, NR + 1, 0) : ldx<K>(cur, NR, 0)) : ldx<K>(S.wrow(k), MWP_W, cc);
                 v = mwp_step<K>(dh, ph, v, ldx<K>(cur, NR, i), wk);
             }
             if (live && i == k + 1 && c <= k) stx<K>(S.wrow(k + 1), MWP_W, cc, v);
