@@ -27,6 +27,7 @@
 #include "clrs_kernels.hip.h"
 #include "clrs_fused.hip.h"
 #include "clrs_assemble_w3.hip.h"
+#include "clrs_assemble_w4.hip.h"
 #include "clrs_solve_small.hip.h"
 #include "clrs_factor_small.hip.h"
 #include "clrs_ipm.hip.h"
@@ -55,6 +56,7 @@ static int g_cfg_split_blocks = 1;      // fused general assembly: one workgroup
 static int g_cfg_fused_factor = 1;
 static int g_cfg_wave_assemble = 1;
 static int g_cfg_wave2_assemble = 1;
+static int g_cfg_wave4_assemble = 1;   // k_cluster_assemble_w4: the register-resident form for simple blocks of up to 32 rows and up to 64 constraints; 0: the general kernels
 static int g_cfg_wave3_assemble = 1;   // register-resident form of the cluster-per-wave assembly (U <= 32); 0: k_cluster_assemble_w2
 static int g_cfg_dense_block = 1;
 static int g_cfg_trsm_blockinv = 1;  // triangular solves with n > TRSM_IB through inverted diagonal blocks (plan_trsm_blockinv)
@@ -79,10 +81,10 @@ static const int LDS_BUDGET_DOUBLES = 20000;   // of the 20480 doubles (160 KiB)
 // ------------------------------------------------------------------------------------------------
 // launch plan
 // ------------------------------------------------------------------------------------------------
-enum StepKind { STEP_MEMCPY, STEP_GEMM, STEP_TRSM, STEP_POTRF, STEP_GATHER_S, STEP_GATHER_SCALAR, STEP_SUB, STEP_MEMSET_INFO, STEP_ZERO_UPPER, STEP_FUSED_ASSEMBLE, STEP_SMALL_POTRF, STEP_CLUSTER_FACTOR, STEP_GEMV_T, STEP_CSOLVE_FWD, STEP_Q_SOLVE, STEP_CSOLVE_BWD, STEP_SUM_SLABS, STEP_ASSEMBLE_W1, STEP_GRAM_SMALL, STEP_ASSEMBLE_W2, STEP_SOLVE_SMALL, STEP_DENSE_BLOCK, STEP_ASSEMBLE_W3, STEP_FACTOR_SMALL, STEP_SUM_S_SLABS, STEP_TRTRI32, STEP_DENSE_T32, STEP_TRTRI_DIAG, STEP_COPY2D, STEP_CHOL_LEVEL, STEP_CHOL_PACK, STEP_CHOL_UNPACK, STEP_NKINDS };
+enum StepKind { STEP_MEMCPY, STEP_GEMM, STEP_TRSM, STEP_POTRF, STEP_GATHER_S, STEP_GATHER_SCALAR, STEP_SUB, STEP_MEMSET_INFO, STEP_ZERO_UPPER, STEP_FUSED_ASSEMBLE, STEP_SMALL_POTRF, STEP_CLUSTER_FACTOR, STEP_GEMV_T, STEP_CSOLVE_FWD, STEP_Q_SOLVE, STEP_CSOLVE_BWD, STEP_SUM_SLABS, STEP_ASSEMBLE_W1, STEP_GRAM_SMALL, STEP_ASSEMBLE_W2, STEP_SOLVE_SMALL, STEP_DENSE_BLOCK, STEP_ASSEMBLE_W3, STEP_FACTOR_SMALL, STEP_SUM_S_SLABS, STEP_TRTRI32, STEP_DENSE_T32, STEP_TRTRI_DIAG, STEP_COPY2D, STEP_CHOL_LEVEL, STEP_CHOL_PACK, STEP_CHOL_UNPACK, STEP_ASSEMBLE_W4, STEP_NKINDS };
 static const char *const STEP_NAMES[STEP_NKINDS] = {"hipMemcpyAsync(D2D)", "k_gemm_f64_t", "k_trsm_diag", "k_potrf_diag", "k_schur_gather",
                                                     "k_gather_scalar", "k_sub", "hipMemsetAsync", "k_zero_upper", "k_cluster_assemble", "k_small_potrf", "k_cluster_factor", "k_gemv_t",
-                                                    "k_cluster_solve_fwd", "k_q_solve", "k_cluster_solve_bwd", "k_sum_slabs", "k_cluster_assemble_w1", "k_gram_small", "k_cluster_assemble_w2", "k_solve_small", "k_dense_block", "k_cluster_assemble_w3", "k_factor_small", "k_sum_S_slabs", "k_trtri32", "k_dense_T32", "k_trtri_diag", "k_copy2d", "k_chol_level", "k_chol_pack", "k_chol_unpack"};
+                                                    "k_cluster_solve_fwd", "k_q_solve", "k_cluster_solve_bwd", "k_sum_slabs", "k_cluster_assemble_w1", "k_gram_small", "k_cluster_assemble_w2", "k_solve_small", "k_dense_block", "k_cluster_assemble_w3", "k_factor_small", "k_sum_S_slabs", "k_trtri32", "k_dense_T32", "k_trtri_diag", "k_copy2d", "k_chol_level", "k_chol_pack", "k_chol_unpack", "k_cluster_assemble_w4"};
 static const int KT_MAX_EVENTS = 8192;   // event pairs kept between two clrs_get_kernel_times calls
 
 struct Step {
@@ -187,6 +189,7 @@ struct clrs_ctx {
     Plan p_assemble, p_cholS, p_linvB, p_Q, p_cholQ, p_fwd, p_bwd, p_cholX;
     FTables ftables = {};
     W3Tables w3tables = {};
+    W4Tables w4tables = {};
     CSolve8 solve8 = {};          // host copy of the (<= 8) CSolve descriptors: kernel argument of k_solve_small2
     struct SolveSmall2 {          // its staging job table, per phase: 0 = whole stage, 1 / 2 = before / after the exchange of u (sharded path)
         StageJobs jobs = {};
@@ -211,7 +214,7 @@ struct clrs_ctx {
     bool times_pending = false, solve_time_pending = false;
     double cnt_bytes = 0, cnt_flops = 0, cnt_factor_flops = 0, cnt_solve_flops = 0;
     std::vector<char> cluster_fused;         // per cluster: assembled by the fused kernel
-    int n_fused_clusters = 0, n_wave_clusters = 0, n_wave2_clusters = 0;
+    int n_fused_clusters = 0, n_wave_clusters = 0, n_wave2_clusters = 0, n_wave4_clusters = 0;
     std::vector<int> host_UR, host_UL;       // flattened per (block, r) for clrs_get_unique_counts
     std::vector<i64> host_U_off;
 };
@@ -769,6 +772,15 @@ static int run_steps(clrs_ctx *c, const Plan &pl) {
                     hipLaunchKernelGGL((k_cluster_assemble_w3<false>), dim3(s.aux0), dim3(256), 0, st, (const int *)s.d0, (const W3Block *)s.d1, tb, (int)s.n, s.aux1);
                 break;
             }
+            case STEP_ASSEMBLE_W4: {
+                W4Tables tb = *(const W4Tables *)s.src;
+                tb.Xc = c->ftables.Xc; tb.Y = c->ftables.Y;      // the iterates bound for this call
+                if (s.nmax <= 3)
+                    hipLaunchKernelGGL((k_cluster_assemble_w4<3>), dim3(s.aux0), dim3(256), s.bytes, st, (const int *)s.d0, (const W3Block *)s.d1, tb, (int)s.n, s.aux1, s.grid);
+                else
+                    hipLaunchKernelGGL((k_cluster_assemble_w4<4>), dim3(s.aux0), dim3(256), s.bytes, st, (const int *)s.d0, (const W3Block *)s.d1, tb, (int)s.n, s.aux1, s.grid);
+                break;
+            }
             case STEP_ASSEMBLE_W1: {
                 const FTables *tb = (const FTables *)s.src;
                 const int nw = (int)s.n, mb = (int)(intptr_t)s.dst;
@@ -1094,6 +1106,108 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
 
     // ---- which clusters does the fused kernel take?  (everything of the cluster must fit in LDS) ----
     c->cluster_fused.assign(J, 0);
+    // ---- k_cluster_assemble_w4: clusters whose low-rank blocks are all "simple" (one sub-block, rank-1 symmetric terms, one term per constraint, U = P, the
+    //      same constraint order in every block) with n <= 32 and P <= 64, dense blocks 1 x 1, and at least one block beyond the reach of
+    //      k_cluster_assemble_w3 (n > 16 or P > 32): the register-resident kernel of clrs_assemble_w4.hip.h ----
+    std::vector<W3Block> w4b;
+    std::vector<W3Dense> w4d;
+    std::vector<int> w4_cl_blk0, w4_pmap, w4_ay;
+    std::vector<double> w4_lam, w4_vop;
+    int w4_nu = 0;
+    if (g_cfg_fused_assemble && g_cfg_wave_assemble && g_cfg_wave4_assemble) {
+        int b = 0;
+        for (int j = 0; j < J; j++) {
+            const int b_first = b;
+            int b_end = b;
+            while (b_end < NB && c->blk[b_end].j == j) b_end++;
+            b = b_end;
+            const int Pj = c->P[j];
+            if (Pj < 1 || Pj > 64) continue;
+            bool ok = true, beyond_w3 = Pj > 32;
+            int nlr = 0;
+            std::vector<int> pm0;
+            std::vector<std::vector<int>> ays;
+            std::vector<std::vector<double>> lams;
+            for (int bb = b_first; bb < b_end && ok; bb++) {
+                const BlockInfo &k = c->blk[bb];
+                if (k.kind == 0) {
+                    const int Tn = (int)(k.t1 - k.t0);
+                    if (Tn == 0) continue;
+                    if (k.m != 1 || k.n > 32 || !k.sym || k.URt != Tn || Tn != Pj) { ok = false; break; }
+                    std::vector<int> pm(Tn, -1), ay(Tn, -1);
+                    std::vector<double> lam(Tn, 0.0);
+                    for (i64 q = k.t0; q < k.t1 && ok; q++) {
+                        const i64 t = perm[q];
+                        const int u = s_tR[q];
+                        if (s_tL[q] != u || u < 0 || u >= Tn || pm[u] >= 0) { ok = false; break; }
+                        pm[u] = d->term_p[t]; lam[u] = d->term_lambda[t]; ay[u] = (int)t;
+                    }
+                    if (!ok) break;
+                    std::vector<int> seen(pm);
+                    std::sort(seen.begin(), seen.end());
+                    for (int i2 = 0; i2 < Tn; i2++) if (seen[i2] != i2) ok = false;      // a permutation of the cluster's constraints
+                    if (!ok) break;
+                    if (pm0.empty()) pm0 = pm;
+                    else if (pm != pm0) { ok = false; break; }
+                    if (k.n > 16) beyond_w3 = true;
+                    ays.push_back(ay); lams.push_back(lam);
+                    nlr++;
+                } else if (k.cnt > 0 && k.n != 1) ok = false;
+            }
+            if (!ok || nlr == 0 || !beyond_w3) continue;
+            std::vector<int> inv(Pj, -1);
+            for (int u = 0; u < Pj; u++) inv[pm0[u]] = u;
+            const int nu = (Pj + 15) / 16 <= 3 ? 3 : 4;
+            w4_nu = std::max(w4_nu, nu);
+            w4_cl_blk0.push_back((int)w4b.size());
+            const int pm_off = (int)w4_pmap.size();
+            w4_pmap.insert(w4_pmap.end(), pm0.begin(), pm0.end());
+            bool ident = true;
+            for (int u = 0; u < Pj; u++) if (pm0[u] != u) ident = false;
+            const int dense0 = (int)w4d.size();
+            size_t last_lr = 0;
+            int ilr = 0;
+            for (int bb = b_first; bb < b_end; bb++) {
+                const BlockInfo &k = c->blk[bb];
+                if (k.kind != 0) {
+                    if (k.cnt == 0) continue;
+                    W3Dense de; de.xyoff = k.xyoff; de.lam_off = (int)w4_lam.size(); de.pad = 0;
+                    std::vector<double> a(Pj, 0.0);
+                    for (i64 e = k.d0; e < k.d1; e++) a[inv[d->dense_p[e]]] = d->dense_A[d->dense_A_ptr[e]];
+                    w4_lam.insert(w4_lam.end(), a.begin(), a.end());
+                    w4d.push_back(de);
+                    continue;
+                }
+                if (k.t1 == k.t0) continue;
+                W3Block k4;
+                std::memset(&k4, 0, sizeof(k4));
+                k4.xyoff = k.xyoff; k4.n = k.n; k4.U = Pj; k4.pmap_off = pm_off; k4.pmap_identity = ident ? 1 : 0;
+                k4.lam_off = (int)w4_lam.size();
+                w4_lam.insert(w4_lam.end(), lams[ilr].begin(), lams[ilr].end());
+                k4.ay_base = (int)w4_ay.size();
+                w4_ay.insert(w4_ay.end(), ays[ilr].begin(), ays[ilr].end());
+                ilr++;
+                k4.vop_off = (int)(w4_vop.size() / 512);
+                w4_vop.resize(w4_vop.size() + (size_t)4 * 512, 0.0);      // (four column tiles for every block: the launch's NU is the largest of its clusters')
+                double *dst = w4_vop.data() + (size_t)k4.vop_off * 512;
+                const double *V = h_static.data() + k.zr_off;
+                for (int t = 0; t < nu; t++)
+                    for (int q = 0; q < 8; q++)
+                        for (int ln = 0; ln < 64; ln++) {
+                            const int row = 4 * q + (ln >> 4), col = 16 * t + (ln & 15);
+                            if (row < k.n && col < Pj) dst[((t * 4 + (q >> 1)) * 64 + ln) * 2 + (q & 1)] = V[row + (i64)col * k.n];
+                        }
+                last_lr = w4b.size();
+                w4b.push_back(k4);
+            }
+            W3Block &kl = w4b[last_lr];
+            kl.last = 1; kl.S_off = c->Soff[j];
+            kl.ndense = (int)w4d.size() - dense0; kl.dense0 = dense0;
+            c->cluster_fused[j] = 4;
+            for (int bb = b_first; bb < b_end; bb++) c->blk[bb].fused = true;
+        }
+    }
+    c->n_wave4_clusters = (int)w4_cl_blk0.size();
     // ---- wave-per-block assembly (k_cluster_assemble_w1): clusters made of "simple" rank-1 blocks with n <= 16 and small dense blocks ----
     std::vector<WCluster> wcl;
     std::vector<WBlock> wbl;
@@ -1113,7 +1227,7 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
         int b = 0;
         for (int j = 0; j < J; j++) {
             const int b_first = b;
-            bool ok = true;
+            bool ok = c->cluster_fused[j] == 0;      // (not taken by k_cluster_assemble_w4)
             int work = 0, ut = 1, nblk = 0;
             std::vector<WBlock> mine;
             std::vector<size_t> mine_off;
@@ -1314,7 +1428,7 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
             fused_lds = std::max(fused_lds, (size_t)o * sizeof(double));
         }
     }
-    c->n_fused_clusters = (int)fcl.size() + (int)wcl.size() + (int)w2cl.size();
+    c->n_fused_clusters = (int)fcl.size() + (int)wcl.size() + (int)w2cl.size() + c->n_wave4_clusters;
     // Few clusters with several blocks each: the blocks of a cluster are independent until their contributions meet in S_j.  One
     // workgroup per block (groups of blocks beyond 32 per cluster) writes its contribution as a P x P slab, k_sum_S_slabs adds
     // the slabs in block order -- the same additions in the same order as the one-workgroup form, so S_j is bit-identical.
@@ -1528,6 +1642,31 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
             s.kind = STEP_GATHER_SCALAR;
             s.dst = c->d_AY; s.src = c->d_G; s.d0 = c->d_ayidx; s.n = T;
             pl.steps.push_back(s);
+        }
+        if (!w4b.empty()) {
+            if (w4d.empty()) { W3Dense de; std::memset(&de, 0, sizeof(de)); w4d.push_back(de); }
+            if (w4_ay.empty()) w4_ay.push_back(0);
+            int *dcb, *dpm, *day; W3Block *db4; W3Dense *dd4; double *dvop, *dlam;
+            CK(upload(c, w4_cl_blk0, &dcb)); CK(upload(c, w4b, &db4)); CK(upload(c, w4d, &dd4)); CK(upload(c, w4_vop, &dvop));
+            CK(upload(c, w4_pmap, &dpm)); CK(upload(c, w4_ay, &day)); CK(upload(c, w4_lam, &dlam));
+            c->w4tables.Xc = c->d_Xc; c->w4tables.Y = c->d_Y; c->w4tables.S = c->d_S; c->w4tables.AY = c->d_AY;
+            c->w4tables.vop = dvop; c->w4tables.lam = dlam; c->w4tables.pmap = dpm; c->w4tables.ay = day; c->w4tables.dense = dd4;
+            c->ftables.Xc = c->d_Xc; c->ftables.Y = c->d_Y;
+            int cus = 256, dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+            Step s;
+            s.kind = STEP_ASSEMBLE_W4;
+            s.d0 = dcb; s.d1 = db4; s.src = &c->w4tables; s.n = (i64)w4_cl_blk0.size(); s.nmax = w4_nu;
+            int maxP = 1;
+            for (const W3Block &kb : w4b) maxP = std::max(maxP, kb.U);
+            s.grid = maxP;                                                                   // rows of the staged S_j
+            s.bytes = W4_LDS_BYTES(w4_nu <= 3 ? 3 : 4, maxP);
+            s.aux0 = (int)std::min<i64>(((i64)w4_cl_blk0.size() + 3) / 4, (i64)cus * W4_WGS_PER_CU(w4_nu <= 3 ? 3 : 4));      // as many workgroups as are resident at once
+            s.aux1 = (int)w4b.size();
+            pl.steps.push_back(s);
+            if (w4_nu <= 3) HIPCK(hipFuncSetAttribute((const void *)k_cluster_assemble_w4<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s.bytes));
+            else HIPCK(hipFuncSetAttribute((const void *)k_cluster_assemble_w4<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s.bytes));
         }
         if (!w2cl.empty()) {
             int *dpm, *day; double *dlam;
@@ -2448,6 +2587,7 @@ extern "C" int clrs_config_set(const char *key, int value) {
     if (!std::strcmp(key, "wave_assemble")) { g_cfg_wave_assemble = value; return 0; }
     if (!std::strcmp(key, "wave2_assemble")) { g_cfg_wave2_assemble = value; return 0; }
     if (!std::strcmp(key, "wave3_assemble")) { g_cfg_wave3_assemble = value; return 0; }
+    if (!std::strcmp(key, "wave4_assemble")) { g_cfg_wave4_assemble = value; return 0; }
     if (!std::strcmp(key, "dense_block")) { g_cfg_dense_block = value; return 0; }
     if (!std::strcmp(key, "dense_wave")) { g_cfg_dense_wave = value; return 0; }
     if (!std::strcmp(key, "factor_aug")) { g_cfg_factor_aug = value; return 0; }
@@ -2502,6 +2642,7 @@ extern "C" int clrs_debug_stamps(clrs_ctx *c, uint64_t out[64]) {
 extern "C" int clrs_fused_clusters(const clrs_ctx *c) { return c ? c->n_fused_clusters : 0; }
 extern "C" int clrs_wave_clusters(const clrs_ctx *c) { return c ? c->n_wave_clusters + c->n_wave2_clusters : 0; }
 extern "C" int clrs_wave2_clusters(const clrs_ctx *c) { return c ? c->n_wave2_clusters : 0; }
+extern "C" int clrs_wave4_clusters(const clrs_ctx *c) { return c ? c->n_wave4_clusters : 0; }
 
 extern "C" const char *clrs_kernel_name(int kind) { return (kind >= 0 && kind < STEP_NKINDS) ? STEP_NAMES[kind] : ""; }
 

@@ -47,7 +47,7 @@ class SchurContext:
     src/solver.jl:298-317 -- all device resident."""
 
     def __init__(self, sdp, device: int = 0, graph: bool = False, timing: bool = False, fused: Optional[bool] = None,
-                 wave: Optional[bool] = None, wave2: Optional[bool] = None, wave3: Optional[bool] = None,
+                 wave: Optional[bool] = None, wave2: Optional[bool] = None, wave3: Optional[bool] = None, wave4: Optional[bool] = None,
                  solve_small2: Optional[bool] = None, factor_small: Optional[int] = None,
                  split_blocks: Optional[bool] = None):
         """`fused=False` forces the staged grouped-GEMM / blocked-BLAS path everywhere (default: clusters that fit in
@@ -55,6 +55,7 @@ class SchurContext:
         fused assembly on the 4-waves-per-block kernel even where the wave-per-block kernel applies.  `wave2=True`
         takes the cluster-per-wave assembly even for few clusters (default: from 64 clusters on); `wave3=False` keeps it on
         the LDS-staged kernel (k_cluster_assemble_w2) instead of the register-resident one (k_cluster_assemble_w3);
+        `wave4=False` keeps simple blocks of 17-32 rows / clusters of 33-64 constraints off k_cluster_assemble_w4 (on the general kernels);
         `solve_small2=False` keeps the one-launch solve stage on k_solve_small instead of k_solve_small2; `factor_small`
         (0 / 1 / 2) selects when the factorisation stage is the single launch k_factor_small (include/clrs_hip.h);
         `split_blocks=False` keeps the general fused assembly at one workgroup per cluster (default: one per PSD block when
@@ -71,6 +72,8 @@ class SchurContext:
             _lib.check(self.L.clrs_config_set(b"wave2_assemble", 2 if wave2 else 0))
         if wave3 is not None:
             _lib.check(self.L.clrs_config_set(b"wave3_assemble", int(bool(wave3))))
+        if wave4 is not None:
+            _lib.check(self.L.clrs_config_set(b"wave4_assemble", int(bool(wave4))))
         if solve_small2 is not None:
             _lib.check(self.L.clrs_config_set(b"solve_small2", int(bool(solve_small2))))
         if factor_small is not None:
@@ -106,6 +109,8 @@ class SchurContext:
                 self.L.clrs_config_set(b"wave2_assemble", 1)
             if wave3 is not None:
                 self.L.clrs_config_set(b"wave3_assemble", 1)
+            if wave4 is not None:
+                self.L.clrs_config_set(b"wave4_assemble", 1)
             if solve_small2 is not None:
                 self.L.clrs_config_set(b"solve_small2", 1)
             if factor_small is not None:
@@ -157,6 +162,10 @@ class SchurContext:
         """Number of clusters assembled by one wave per cluster with S in registers (k_cluster_assemble_w2)."""
         return int(self.L.clrs_wave2_clusters(self.h))
 
+    def wave4_clusters(self) -> int:
+        """Number of clusters assembled by k_cluster_assemble_w4 (simple blocks of up to 32 rows, up to 64 constraints)."""
+        return int(self.L.clrs_wave4_clusters(self.h))
+
     def high_ranks(self) -> List[bool]:
         """`high_ranks[j][l]` flattened over blocks (src/solver.jl:1000)."""
         return [bool(v) for v in self.flat.block_kind]
@@ -187,10 +196,10 @@ class SchurContext:
 
     def kernel_times(self) -> dict:
         """{kernel name: (kind, total seconds, launches)} since the last set_kernel_timing."""
-        sec = np.zeros(32)
-        cnt = np.zeros(32, dtype=np.int64)
-        n = _lib.check(self.L.clrs_get_kernel_times(self.h, 32, _dp(sec), cnt.ctypes.data_as(_lib.p_i64)))
-        return {self.L.clrs_kernel_name(k).decode(): (k, float(sec[k]), int(cnt[k])) for k in range(n) if cnt[k]}
+        sec = np.zeros(64)
+        cnt = np.zeros(64, dtype=np.int64)
+        n = _lib.check(self.L.clrs_get_kernel_times(self.h, 64, _dp(sec), cnt.ctypes.data_as(_lib.p_i64)))
+        return {self.L.clrs_kernel_name(k).decode(): (k, float(sec[k]), int(cnt[k])) for k in range(min(n, 64)) if cnt[k]}
 
     def plan_info(self):
         v = [C.c_int32() for _ in range(3)]

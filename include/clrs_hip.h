@@ -231,6 +231,8 @@ int clrs_wave_clusters(const clrs_ctx *ctx);
  * (U <= 64, or "wave3_assemble" = 0) it is the LDS-staged k_cluster_assemble_w2 and "automatic" means >= 64 clusters.
  * clrs_wave2_clusters counts the clusters either kernel takes. */
 int clrs_wave2_clusters(const clrs_ctx *ctx);
+/* ... and the clusters k_cluster_assemble_w4 takes (simple blocks of up to 32 rows, up to 64 constraints: csrc/clrs_assemble_w4.hip.h). */
+int clrs_wave4_clusters(const clrs_ctx *ctx);
 /* "factor_small" (default 1): a context with ONE cluster (P, N <= 64) runs clrs_schur_factor as one launch of k_factor_small
  * (S_j and B_j staged in one trip, Q never leaves LDS before it is factored); 2 = also for 2-4 clusters, one wave per cluster
  * (slower than the workgroup-per-cluster kernels on the named problems: kept for measurement); 0 = never.

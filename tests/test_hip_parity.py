@@ -184,8 +184,9 @@ ASSEMBLE_CASES = ["x2p1", "polyopt8", "polyopt40", "delsarte_3_10", "delsarte_8_
                   "threepoint_4", "sdpa_small", "sdpa_mid", "polyopt_scaled_100", "polyopt_scaled_300"]
 
 
-PATHS = {"wave3": dict(fused=True, wave=True, wave2=True, wave3=True), "wave2": dict(fused=True, wave=True, wave2=True, wave3=False),
-         "wave": dict(fused=True, wave=True, wave2=False), "fused": dict(fused=True, wave=False), "staged": dict(fused=False)}
+PATHS = {"wave3": dict(fused=True, wave=True, wave2=True, wave3=True), "wave2": dict(fused=True, wave=True, wave2=True, wave3=False, wave4=False),
+         "wave": dict(fused=True, wave=True, wave2=False, wave4=False), "fused": dict(fused=True, wave=False), "staged": dict(fused=False)}
+WAVE4_CASES = {"polyopt40": 1}            # clusters taken by k_cluster_assemble_w4 (simple blocks of 17-32 rows or 33-64 constraints) on the default path
 WAVE2_CASES = {"x2p1": 1, "polyopt8": 1, "delsarte_8_3": 0, "ce_8_15": 2, "ce_8_3": 2}    # clusters taken by k_cluster_assemble_w2
 WAVE_CASES = {"x2p1", "polyopt8", "delsarte_3_10", "delsarte_8_3", "ce_8_15", "ce_8_3", "sdpa_small"}   # every cluster takes k_cluster_assemble_w1
 
@@ -205,6 +206,7 @@ def test_schur_assemble_matches_oracle(name, path, oracle_built):
         assert ctx.wave_clusters() == f.n_clusters
     if path in ("wave2", "wave3") and name in WAVE2_CASES:
         assert ctx.wave2_clusters() == WAVE2_CASES[name]
+    assert ctx.wave4_clusters() == (WAVE4_CASES.get(name, 0) if path == "wave3" else 0)
     if path == "wave":
         assert ctx.wave2_clusters() == 0
     if path in ("fused", "staged"):
@@ -1084,3 +1086,85 @@ def test_inverse_blocks_of_S_are_formed_once_per_factorisation(oracle_built):
         ctx.set_kernel_timing(-2)
     ctx.close()
 
+
+
+@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("max_n,max_P", [(32, 48), (24, 64), (16, 64)])
+def test_wave4_random_structures(seed, max_n, max_P, oracle_built):
+    """k_cluster_assemble_w4 on randomised structure: clusters of different sizes P <= 48 (three column tiles) or <= 64 (four) in one context, 1-3
+    low-rank blocks of different sides n <= 32 per cluster (blocks of at most 16 rows beside blocks of two row tiles, partial tiles and partial
+    k-steps), 0-2 dense 1 x 1 blocks touching a subset of the constraints, placed anywhere among them.  Clusters within reach of
+    k_cluster_assemble_w3 (every n <= 16 and P <= 32) stay there.  Assembly against the oracle, entry by entry, and S_j exactly symmetric."""
+    import clrs_amd
+    from clrs_amd.solver import SchurContext
+    from oracle.oracle import Oracle
+    from tests.util import random_simple_sdp
+    f = clrs_amd.flatten(random_simple_sdp(1000 + seed, J=4 + seed % 3, n_free=seed % 3, max_P=max_P, max_n=max_n))
+    X, Y = spd_iterates(f, seed=seed + 300)
+    Xc = chol_blocks_np(f, X)
+    o = Oracle(f, quad=False)
+    S_ref, AY_ref = o.schur_assemble(Xc, Y)
+    beyond = 0
+    for j in range(f.n_clusters):
+        bl = [b for b in range(f.n_blocks) if f.block_cluster[b] == j and f.block_kind[b] == 0]
+        if int(f.cluster_P[j]) > 32 or any(int(f.block_n[b]) > 16 for b in bl):
+            beyond += 1
+    ctx = SchurContext(f, wave2=True)
+    assert ctx.wave4_clusters() == beyond
+    assert ctx.wave4_clusters() + ctx.wave2_clusters() == f.n_clusters
+    S, AY = ctx.compute_S_integrated(Xc, Y)
+    ctx.close()
+    for j in range(f.n_clusters):
+        sl = slice(int(f.S_off[j]), int(f.S_off[j + 1]))
+        assert np.max(np.abs(S[sl] - S_ref[sl])) <= 1e-11 * np.max(np.abs(S_ref[sl])), j
+        P = int(f.cluster_P[j])
+        Sj = S[sl].reshape(P, P, order="F")
+        assert np.array_equal(Sj, Sj.T)
+    assert np.max(np.abs(AY - AY_ref)) <= 1e-11 * max(1.0, np.max(np.abs(AY_ref)))
+    # the general kernels on the same problem: the same numbers to rounding
+    ctx0 = SchurContext(f, wave2=True, wave4=False)
+    assert ctx0.wave4_clusters() == 0
+    S0, AY0 = ctx0.compute_S_integrated(Xc, Y)
+    ctx0.close()
+    assert np.max(np.abs(S - S0)) <= 1e-11 * np.max(np.abs(S_ref))
+
+
+@pytest.mark.parametrize("name,copies", [("polyopt40", 1), ("polyopt40", 1500)])
+def test_wave4_many_clusters_and_rare_paths(name, copies, oracle_built):
+    """k_cluster_assemble_w4 with several clusters per wave (more clusters than resident waves) and its rarely taken paths: the constraints of a
+    cluster in a permuted order (S_j stored through the vector -> constraint table), a second low-rank block with negative lambdas in the cluster;
+    every cluster against the oracle, and the device-pointer entry on other iterates."""
+    import torch
+    torch.cuda.set_device(0)
+    from clrs_amd.sdp import replicate_clusters
+    from clrs_amd.solver import SchurContext
+    from clrs_amd.sharded import _DevArray
+    from oracle.oracle import Oracle
+    from tests.util import duplicate_block, permute_cluster_constraints
+    f = flat(name)
+    g = duplicate_block(f, 0, -0.75)
+    g = permute_cluster_constraints(g, seed=5)
+    big = replicate_clusters(g, copies) if copies > 1 else g
+    X, Y = spd_iterates(big, seed=21)
+    Xc = chol_blocks_np(big, X)
+    ctx = SchurContext(big)
+    assert ctx.wave4_clusters() == big.n_clusters
+    S, AY = ctx.compute_S_integrated(Xc, Y)
+    X2, Y2 = spd_iterates(big, seed=22)
+    Xc2 = chol_blocks_np(big, X2)
+    tX, tY = torch.from_numpy(Xc2).to("cuda:0"), torch.from_numpy(Y2).to("cuda:0")
+    torch.cuda.synchronize()
+    ctx.assemble_dev(tX.data_ptr(), tY.data_ptr())
+    torch.cuda.synchronize()
+    S2 = torch.as_tensor(_DevArray(ctx.S_buffer(), big.S_len), device="cuda:0").cpu().numpy()
+    ctx.close()
+    o = Oracle(g, quad=False)
+    nxy, nS, nT = g.xy_len, g.S_len, g.n_terms
+    for k in sorted(set((0, copies // 2, copies - 1))):
+        Sk, _ = o.schur_assemble(Xc2[k * nxy:(k + 1) * nxy], Y2[k * nxy:(k + 1) * nxy])
+        assert np.max(np.abs(S2[k * nS:(k + 1) * nS] - Sk)) <= 1e-11 * np.max(np.abs(Sk))
+    step = max(1, copies // 40)
+    for k in list(range(0, copies, step)) + [copies - 1]:
+        Sk, AYk = o.schur_assemble(Xc[k * nxy:(k + 1) * nxy], Y[k * nxy:(k + 1) * nxy])
+        assert np.max(np.abs(S[k * nS:(k + 1) * nS] - Sk)) <= 1e-11 * np.max(np.abs(Sk)), k
+        assert np.max(np.abs(AY[k * nT:(k + 1) * nT] - AYk)) <= 1e-11 * max(1.0, np.max(np.abs(AYk))), k
