@@ -699,6 +699,7 @@ def main():
                 out["roofline_named"] = f64.get("roofline_named")
                 out["roofline_R"] = f64.get("roofline_R")
                 out["roofline_dense"] = f64.get("roofline_dense")
+                out["roofline_shapes"] = f64.get("roofline_shapes")
                 out["fp64"] = {"what": "the fp64 kernels on the same problem SHAPES with synthetic well-conditioned iterates; the factorisation of S_j fails in fp64 "
                                        "(factor_status != 0 = the reference's SolverFailure, src/solver.jl:1249), so this is a kernel cost, not a rate of solvable iterations",
                                "steps_per_s": f64["value"], "ms_per_step": f64["ms_per_step"], "parity": f64["parity"],

@@ -51,6 +51,21 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s 
 FP64_PEAK_TFLOPS = 78.6      # MI355X fp64 vector = matrix peak (256 CU x 128 flop/clk x 2.4 GHz)
 
 
+
+def _polyopt40_flat():
+    """BASELINE config 2: PolyOpt at 2d = 40 (one cluster, one simple block n = 21, P = 41)."""
+    import clrs_amd
+    from clrs_amd import problems as P
+    return clrs_amd.flatten(P.polyopt_random(20, seed=0)[0])
+
+
+def _ns2_flat():
+    """BASELINE config 3: Nsphere_packing(8, 15, [1/2, 1/2])."""
+    import clrs_amd
+    from clrs_amd import problems as P
+    return clrs_amd.flatten(P.nsphere_packing(8, 15, [0.5, 0.5]))
+
+
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
@@ -378,6 +393,44 @@ def main(argv=None, emit=True):
             dctx.close()
         except Exception as e:
             out["roofline_dense"] = {"error": repr(e)}
+
+        # ---- the assembly on the other block shapes of BASELINE's configurations, many clusters per launch: PolyOpt 2d = 40 (one simple
+        #      block n = 21, P = 41 per cluster: k_cluster_assemble_w4 since round 5) and Nsphere_packing(8,15,[1/2,1/2]) (its 2 x 2 block of 16 x 16
+        #      sub-blocks, P = 96, stays on the general LDS-staged kernel) ----
+        out["roofline_shapes"] = {}
+        for sname, builder, copies in (("polyopt_2d40", lambda: _polyopt40_flat(), 4096), ("Nsphere_packing(8,15,[1/2,1/2])", lambda: _ns2_flat(), 256)):
+            try:
+                fs = builder()
+                bigs = replicate_clusters(fs, copies)
+                sctx = SchurContext(bigs, device=local_rank)
+                sctx.set_stream(torch.cuda.current_stream().cuda_stream)
+                sX, sY = seeded_iterates(bigs, seed=5)
+                sXc = np.concatenate([np.linalg.cholesky(sX[bigs.block_off[b]:bigs.block_off[b + 1]].reshape(int(bigs.block_n[b]), -1, order="F"))
+                                      .reshape(-1, order="F") for b in range(bigs.n_blocks)])
+                tsXc, tsY = torch.from_numpy(sXc).to(dev), torch.from_numpy(sY).to(dev)
+                for _ in range(60):
+                    sctx.assemble_dev(tsXc.data_ptr(), tsY.data_ptr())
+                torch.cuda.synchronize()
+                sprof = kernel_profile(sctx, lambda: sctx.assemble_dev(tsXc.data_ptr(), tsY.data_ptr()), 10)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(100):
+                    sctx.assemble_dev(tsXc.data_ptr(), tsY.data_ptr())
+                e1.record(); e1.synchronize()
+                s_s = 1e-3 * e0.elapsed_time(e1) / 100
+                scnt = sctx.counters()
+                sdom = max(sprof.items(), key=lambda kv: kv[1][2])
+                shapes = sorted(set((int(n_), int(P_)) for n_, P_ in zip(fs.block_n, fs.cluster_P[fs.block_cluster])))
+                out["roofline_shapes"][sname] = {
+                    "bound": "hbm", "phase": "schur_assemble", "kernel": sdom[0], "assembly_us": 1e6 * s_s,
+                    "achieved": scnt["assemble_bytes"] / s_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": scnt["assemble_bytes"] / s_s / 1e9 / HBM_PEAK_GBS,
+                    "traffic": None, "achieved_tflops": scnt["assemble_flops"] / s_s / 1e12, "frac_of_fp64_mfma_peak": scnt["assemble_flops"] / s_s / 1e12 / FP64_PEAK_TFLOPS,
+                    "algorithmic_bytes": scnt["assemble_bytes"], "algorithmic_flops": scnt["assemble_flops"],
+                    "workload": "%d clusters / %d PSD blocks with the shapes (n, P) %s in one assembly" % (bigs.n_clusters, bigs.n_blocks, shapes),
+                    "clusters_by_k_cluster_assemble_w4": sctx.wave4_clusters(), "kernels_us": {k: round(1e6 * v[2], 3) for k, v in sprof.items()}}
+                sctx.close()
+            except Exception as e:
+                out["roofline_shapes"][sname] = {"error": repr(e)}
 
         # ---- staged (large-block) regime on roofline instance R: config-2 structure at n = 1025, P = 2049 ----
         try:
