@@ -231,7 +231,10 @@ int clrs_wave_clusters(const clrs_ctx *ctx);
  * (U <= 64, or "wave3_assemble" = 0) it is the LDS-staged k_cluster_assemble_w2 and "automatic" means >= 64 clusters.
  * clrs_wave2_clusters counts the clusters either kernel takes. */
 int clrs_wave2_clusters(const clrs_ctx *ctx);
-/* ... and the clusters k_cluster_assemble_w4 takes (simple blocks of up to 32 rows, up to 64 constraints: csrc/clrs_assemble_w4.hip.h). */
+/* "wave4_assemble" (default 1): clusters of the same kind (every low-rank block simple, U = P, one constraint order; dense blocks 1 x 1) with a block
+ * of 17 .. 32 rows or 33 .. 64 constraints -- out of reach of k_cluster_assemble_w3 -- take k_cluster_assemble_w4 (csrc/clrs_assemble_w4.hip.h: two
+ * row tiles, three or four column tiles, L^-1 V by blocks without forming L^-1); 0 leaves them on the general LDS-staged kernel.
+ * clrs_wave4_clusters counts them (they are not in clrs_wave_clusters / clrs_wave2_clusters). */
 int clrs_wave4_clusters(const clrs_ctx *ctx);
 /* "factor_small" (default 1): a context with ONE cluster (P, N <= 64) runs clrs_schur_factor as one launch of k_factor_small
  * (S_j and B_j staged in one trip, Q never leaves LDS before it is factored); 2 = also for 2-4 clusters, one wave per cluster
@@ -304,7 +307,9 @@ int clrs_mw_create_ex(const clrs_sdp_desc *desc, int data_limbs, int device, int
 typedef struct clrs_mw_options {
     int32_t exact_products;
     int32_t refine;
-    int32_t pipeline;        /* factorisations of matrices of at most 32 rows as a pipeline of workgroups: 0 never / 1 the clusters' S_j (default) / 2 and Q */
+    int32_t pipeline;        /* factorisations of small matrices as a pipeline of workgroups: 0 never / 1 (default) the clusters' S_j of at most 32 rows, of 48 .. 64
+                              * rows (the 64-row form; clrs_config_set("mw_pipeline64", 0) switches that form off) and Q from 9 rows on / 2 every S_j and Q of at
+                              * most 64 / 32 rows, and at 8 and 10 limbs as well */
     int32_t refine_predictor; /* clrs_mw_ipm_*: 0 (default) the predictor's solve is one pass of products, the corrector's is refined; 1 both are refined */
     int32_t factor_limbs;    /* Mixed-precision iterative refinement: limbs of the FACTOR stage (L_j, L_j^-1, L^-1 B, Q, L_Q, L_Q^-1) and of the inverse-factor products of
                               * the solve stage; the residuals of the refinement step, S_j itself and the solution carry all `limbs`.  0 (default) = automatic: inside

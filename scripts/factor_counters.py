@@ -19,6 +19,8 @@ for k in sorted(cnt, key=lambda k: -sum(dur.get(k, [0]))):
     d = sum(dur[k]) / max(len(dur[k]), 1) / 1e3 if k in dur else float("nan")
     if k.startswith("k_mw_factor_pipe"):      # grid of 64 blocks per 8 clusters, of which 8 per cluster work (4 stages + 4 for the inverse; the others return at once): 2 clusters here
         wgs[k] = 16
+    if k.startswith("k_mw_potrf_q_pipe"):     # the first 64 blocks are one matrix' roles (4 stages + 4 for the inverse work), the blocks behind them the riding forward products (2 per cluster)
+        wgs[k] = 8 + max(0, wgs.get(k, 64) - 64)
     cus = min(wgs.get(k, 0), 256)
     # share of the fp64 VALU issue slots (4 cycles per wave instruction, 4 SIMDs per CU) of the compute units the kernel occupies, over its duration at 2.4 GHz
     util = m.get("SQ_INSTS_VALU", 0) * 4.0 / (max(cus, 1) * 4 * d * 1e-6 * 2.4e9) if d == d and d > 0 else float("nan")
