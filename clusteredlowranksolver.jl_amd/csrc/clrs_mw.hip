@@ -39,6 +39,7 @@ typedef long long i64;
 
 extern int g_cfg_mw_stream_words;                        // clrs_hip.hip, clrs_config_set("mw_stream_words", 0 / 1); env CLRS_MW_STREAM_WORDS
 extern int g_cfg_mw_pipeline64;                          // clrs_hip.hip, clrs_config_set("mw_pipeline64", 0 / 1): the 64-row form for clusters of 33 .. 64 rows
+extern int g_cfg_mw_sharded_factor_limbs;                // clrs_hip.hip, clrs_config_set("mw_sharded_factor_limbs", 0 / 1)
 extern int g_cfg_mw_pipeline;                            // clrs_hip.hip, clrs_config_set("mw_pipeline", 0 / 1): read at context creation
 extern int g_cfg_mw_refine_predictor;                    // clrs_hip.hip, clrs_config_set("mw_refine_predictor", 0 / 1)
 extern int g_cfg_mw_refine;                              // clrs_hip.hip, clrs_config_set("mw_refine", 0 / 1): read at context creation

@@ -404,8 +404,17 @@ __device__ __forceinline__ void mwi_scalar_stage3(const MwDev &q, const MwIpmDev
     int f1 = p.flags[1], f2 = p.flags[2];
     unsigned long long rs[4] = {0ull, 0ull, 0ull, 0ull};
     if (q.refstat) {
+        if (q.world > 1) {                             // the largest over the ranks (k_mwi_gpack stage 3): the same number on every rank
 #pragma unroll
-        for (int i = 0; i < 4; i++) rs[i] = q.refstat[i];
+            for (int i = 0; i < 4; i++) {
+                double m = 0.0;
+                for (int r = 0; r < q.world; r++) m = fmax(m, p.gsM[(long)r * p.GL + MWG_S1(K, q.N) + i]);
+                rs[i] = (unsigned long long)__double_as_longlong(m);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) rs[i] = q.refstat[i];
+        }
     }
     double al[2];
     for (int w = 0; w < 2; w++) {
@@ -988,6 +997,12 @@ __global__ void k_mwi_gpack(const MwDev q, const MwIpmDev p, int stage) {
             D[2 + w] = mn;
         }
         D[6] = p.flags[2];
+        // the first-pass accuracy of the corrector's solve must be judged alike on every rank (the factor stage's limb count follows from it, and Q is factored
+        // by all of them): this rank's four maxima travel with the step lengths, in the K-limb slots this record does not use
+        if (q.refstat) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) slot[MWG_S1(K, N) + i] = __longlong_as_double((long long)q.refstat[i]);
+        }
     }
 }
 // sharded: p = +-b + sum over the ranks (rank order) of their -B^T x, max|p|; and the maxima of |P|, |d| over the ranks
