@@ -119,6 +119,7 @@ SYMBOLS = {
     "clrs_wave_clusters": (C.c_int, [C.c_void_p]),
     "clrs_wave2_clusters": (C.c_int, [C.c_void_p]),
     "clrs_wave4_clusters": (C.c_int, [C.c_void_p]),
+    "clrs_wave5_clusters": (C.c_int, [C.c_void_p]),
     "clrs_debug_stamps": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "clrs_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "clrs_set_kernel_timing": (C.c_int, [C.c_void_p, C.c_int]),

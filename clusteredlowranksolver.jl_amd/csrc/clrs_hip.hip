@@ -28,6 +28,7 @@
 #include "clrs_fused.hip.h"
 #include "clrs_assemble_w3.hip.h"
 #include "clrs_assemble_w4.hip.h"
+#include "clrs_assemble_w5.hip.h"
 #include "clrs_solve_small.hip.h"
 #include "clrs_factor_small.hip.h"
 #include "clrs_ipm.hip.h"
@@ -56,6 +57,7 @@ static int g_cfg_split_blocks = 1;      // fused general assembly: one workgroup
 static int g_cfg_fused_factor = 1;
 static int g_cfg_wave_assemble = 1;
 static int g_cfg_wave2_assemble = 1;
+static int g_cfg_wave5_assemble = 1;   // k_cluster_assemble_w5: the register-resident form for 2 x 2 blocks of 16 x 16 sub-blocks with shared sample vectors (Nsphere_packing); 0: the general kernels
 static int g_cfg_wave4_assemble = 1;   // k_cluster_assemble_w4: the register-resident form for simple blocks of up to 32 rows and up to 64 constraints; 0: the general kernels
 static int g_cfg_wave3_assemble = 1;   // register-resident form of the cluster-per-wave assembly (U <= 32); 0: k_cluster_assemble_w2
 static int g_cfg_dense_block = 1;
@@ -82,10 +84,10 @@ static const int LDS_BUDGET_DOUBLES = 20000;   // of the 20480 doubles (160 KiB)
 // ------------------------------------------------------------------------------------------------
 // launch plan
 // ------------------------------------------------------------------------------------------------
-enum StepKind { STEP_MEMCPY, STEP_GEMM, STEP_TRSM, STEP_POTRF, STEP_GATHER_S, STEP_GATHER_SCALAR, STEP_SUB, STEP_MEMSET_INFO, STEP_ZERO_UPPER, STEP_FUSED_ASSEMBLE, STEP_SMALL_POTRF, STEP_CLUSTER_FACTOR, STEP_GEMV_T, STEP_CSOLVE_FWD, STEP_Q_SOLVE, STEP_CSOLVE_BWD, STEP_SUM_SLABS, STEP_ASSEMBLE_W1, STEP_GRAM_SMALL, STEP_ASSEMBLE_W2, STEP_SOLVE_SMALL, STEP_DENSE_BLOCK, STEP_ASSEMBLE_W3, STEP_FACTOR_SMALL, STEP_SUM_S_SLABS, STEP_TRTRI32, STEP_DENSE_T32, STEP_TRTRI_DIAG, STEP_COPY2D, STEP_CHOL_LEVEL, STEP_CHOL_PACK, STEP_CHOL_UNPACK, STEP_ASSEMBLE_W4, STEP_NKINDS };
+enum StepKind { STEP_MEMCPY, STEP_GEMM, STEP_TRSM, STEP_POTRF, STEP_GATHER_S, STEP_GATHER_SCALAR, STEP_SUB, STEP_MEMSET_INFO, STEP_ZERO_UPPER, STEP_FUSED_ASSEMBLE, STEP_SMALL_POTRF, STEP_CLUSTER_FACTOR, STEP_GEMV_T, STEP_CSOLVE_FWD, STEP_Q_SOLVE, STEP_CSOLVE_BWD, STEP_SUM_SLABS, STEP_ASSEMBLE_W1, STEP_GRAM_SMALL, STEP_ASSEMBLE_W2, STEP_SOLVE_SMALL, STEP_DENSE_BLOCK, STEP_ASSEMBLE_W3, STEP_FACTOR_SMALL, STEP_SUM_S_SLABS, STEP_TRTRI32, STEP_DENSE_T32, STEP_TRTRI_DIAG, STEP_COPY2D, STEP_CHOL_LEVEL, STEP_CHOL_PACK, STEP_CHOL_UNPACK, STEP_ASSEMBLE_W4, STEP_ASSEMBLE_W5, STEP_NKINDS };
 static const char *const STEP_NAMES[STEP_NKINDS] = {"hipMemcpyAsync(D2D)", "k_gemm_f64_t", "k_trsm_diag", "k_potrf_diag", "k_schur_gather",
                                                     "k_gather_scalar", "k_sub", "hipMemsetAsync", "k_zero_upper", "k_cluster_assemble", "k_small_potrf", "k_cluster_factor", "k_gemv_t",
-                                                    "k_cluster_solve_fwd", "k_q_solve", "k_cluster_solve_bwd", "k_sum_slabs", "k_cluster_assemble_w1", "k_gram_small", "k_cluster_assemble_w2", "k_solve_small", "k_dense_block", "k_cluster_assemble_w3", "k_factor_small", "k_sum_S_slabs", "k_trtri32", "k_dense_T32", "k_trtri_diag", "k_copy2d", "k_chol_level", "k_chol_pack", "k_chol_unpack", "k_cluster_assemble_w4"};
+                                                    "k_cluster_solve_fwd", "k_q_solve", "k_cluster_solve_bwd", "k_sum_slabs", "k_cluster_assemble_w1", "k_gram_small", "k_cluster_assemble_w2", "k_solve_small", "k_dense_block", "k_cluster_assemble_w3", "k_factor_small", "k_sum_S_slabs", "k_trtri32", "k_dense_T32", "k_trtri_diag", "k_copy2d", "k_chol_level", "k_chol_pack", "k_chol_unpack", "k_cluster_assemble_w4", "k_cluster_assemble_w5"};
 static const int KT_MAX_EVENTS = 8192;   // event pairs kept between two clrs_get_kernel_times calls
 
 struct Step {
@@ -191,6 +193,7 @@ struct clrs_ctx {
     FTables ftables = {};
     W3Tables w3tables = {};
     W4Tables w4tables = {};
+    W5Tables w5tables = {};
     CSolve8 solve8 = {};          // host copy of the (<= 8) CSolve descriptors: kernel argument of k_solve_small2
     struct SolveSmall2 {          // its staging job table, per phase: 0 = whole stage, 1 / 2 = before / after the exchange of u (sharded path)
         StageJobs jobs = {};
@@ -215,7 +218,7 @@ struct clrs_ctx {
     bool times_pending = false, solve_time_pending = false;
     double cnt_bytes = 0, cnt_flops = 0, cnt_factor_flops = 0, cnt_solve_flops = 0;
     std::vector<char> cluster_fused;         // per cluster: assembled by the fused kernel
-    int n_fused_clusters = 0, n_wave_clusters = 0, n_wave2_clusters = 0, n_wave4_clusters = 0;
+    int n_fused_clusters = 0, n_wave_clusters = 0, n_wave2_clusters = 0, n_wave4_clusters = 0, n_wave5_clusters = 0;
     std::vector<int> host_UR, host_UL;       // flattened per (block, r) for clrs_get_unique_counts
     std::vector<i64> host_U_off;
 };
@@ -782,6 +785,12 @@ static int run_steps(clrs_ctx *c, const Plan &pl) {
                     hipLaunchKernelGGL((k_cluster_assemble_w4<4>), dim3(s.aux0), dim3(256), s.bytes, st, (const int *)s.d0, (const W3Block *)s.d1, tb, (int)s.n, s.aux1, s.grid);
                 break;
             }
+            case STEP_ASSEMBLE_W5: {
+                W5Tables tb = *(const W5Tables *)s.src;
+                tb.Xc = c->ftables.Xc; tb.Y = c->ftables.Y;      // the iterates bound for this call
+                hipLaunchKernelGGL(k_cluster_assemble_w5, dim3(s.aux0), dim3(256), 0, st, (const int *)s.d0, (const W3Block *)s.d1, tb, (int)s.n, s.aux1);
+                break;
+            }
             case STEP_ASSEMBLE_W1: {
                 const FTables *tb = (const FTables *)s.src;
                 const int nw = (int)s.n, mb = (int)(intptr_t)s.dst;
@@ -1107,6 +1116,107 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
 
     // ---- which clusters does the fused kernel take?  (everything of the cluster must fit in LDS) ----
     c->cluster_fused.assign(J, 0);
+    // ---- k_cluster_assemble_w5: clusters whose PSD blocks are all 2 x 2 blocks of 16 x 16 sub-blocks with constraint matrices E_rs (x) v_u v_u^T on the SAME
+    //      U <= 32 vectors in (0,0), (1,1) and as the two terms (0,1) + (1,0): 3 U constraints, every (pair, u) once (Nsphere_packing; clrs_assemble_w5.hip.h) ----
+    std::vector<W3Block> w5b;
+    std::vector<int> w5_cl_blk0, w5_ay;
+    std::vector<double> w5_lam, w5_vop;
+    if (g_cfg_fused_assemble && g_cfg_wave_assemble && g_cfg_wave5_assemble) {
+        int b = 0;
+        for (int j = 0; j < J; j++) {
+            const int b_first = b;
+            int b_end = b;
+            while (b_end < NB && c->blk[b_end].j == j) b_end++;
+            b = b_end;
+            const int Pj = c->P[j];
+            if (Pj < 3 || Pj % 3 != 0 || Pj > 96) continue;
+            const int U = Pj / 3;
+            bool ok = true;
+            int nlr = 0;
+            std::vector<int> pm0;
+            struct Blk5 { std::vector<int> ay; std::vector<double> lam; };
+            std::vector<Blk5> b5;
+            for (int bb = b_first; bb < b_end && ok; bb++) {
+                const BlockInfo &k = c->blk[bb];
+                if (k.kind != 0) { if (k.cnt > 0) ok = false; continue; }
+                const int Tn = (int)(k.t1 - k.t0);
+                if (Tn == 0) continue;
+                if (k.m != 2 || k.delta != 16 || !k.sym || Tn != 4 * U || (int)k.UR.size() != 2 || k.UR[0] != U || k.UR[1] != U) { ok = false; break; }
+                // the same vectors in both sub-blocks
+                const double *V = h_static.data() + k.zr_off;
+                for (int u = 0; u < U && ok; u++)
+                    for (int i2 = 0; i2 < 16; i2++)
+                        if (V[i2 + (i64)(k.offR[0] + u) * k.n] != V[16 + i2 + (i64)(k.offR[1] + u) * k.n]) { ok = false; break; }
+                if (!ok) break;
+                Blk5 e;
+                e.ay.assign(4 * 32, -1);
+                e.lam.assign(3 * U, 0.0);
+                std::vector<int> pm(3 * U, -1), seen_terms(4 * U, 0);
+                for (i64 q = k.t0; q < k.t1 && ok; q++) {
+                    const i64 t = perm[q];
+                    const int r = d->term_r[t], s2 = d->term_s[t];
+                    if (r < 0 || r > 1 || s2 < 0 || s2 > 1) { ok = false; break; }
+                    const int uR = s_tR[q] - k.offR[r], uL = s_tL[q] - k.offL[s2];
+                    if (uR != uL || uR < 0 || uR >= U) { ok = false; break; }
+                    const int pair = r + s2;                              // 0: (0,0); 1: (0,1) and (1,0); 2: (1,1)
+                    const int vi = pair * U + uR, ti2 = (2 * r + s2) * U + uR;
+                    if (seen_terms[ti2]++) { ok = false; break; }
+                    const int pc = d->term_p[t];
+                    const double lm = d->term_lambda[t];
+                    if (pm[vi] < 0) { pm[vi] = pc; e.lam[vi] = lm; }
+                    else if (pm[vi] != pc || e.lam[vi] != lm) { ok = false; break; }      // the two terms of an off-diagonal pair: one constraint, one lambda
+                    e.ay[(2 * r + s2) * 32 + uR] = (int)t;
+                }
+                if (!ok) break;
+                for (int i2 = 0; i2 < 4 * U; i2++) if (seen_terms[i2] != 1) ok = false;
+                std::vector<int> seen(pm);
+                std::sort(seen.begin(), seen.end());
+                for (int i2 = 0; i2 < 3 * U && ok; i2++) if (seen[i2] != i2) ok = false;      // a permutation of the cluster's constraints
+                if (!ok) break;
+                if (pm0.empty()) pm0 = pm;
+                else if (pm != pm0) { ok = false; break; }
+                b5.push_back(e);
+                nlr++;
+            }
+            if (!ok || nlr == 0) continue;
+            const int pm_off = 0;
+            bool ident = true;
+            for (int u = 0; u < 3 * U; u++) if (pm0[u] != u) ident = false;
+            if (!ident) continue;                          // (constraints in pair-major vector order only: a table lookup per stored entry costs the kernel its registers)
+            w5_cl_blk0.push_back((int)w5b.size());
+            int ilr = 0;
+            for (int bb = b_first; bb < b_end; bb++) {
+                const BlockInfo &k = c->blk[bb];
+                if (k.kind != 0 || k.t1 == k.t0) continue;
+                W3Block k5;
+                std::memset(&k5, 0, sizeof(k5));
+                k5.xyoff = k.xyoff; k5.n = k.n; k5.U = U; k5.pmap_off = pm_off; k5.pmap_identity = ident ? 1 : 0;
+                k5.ndense = ilr == 0 ? 1 : 0;              // (first block of its cluster: it stores S_j, the others add to it)
+                k5.S_off = c->Soff[j];                     // (every block of the cluster writes S_j: it accumulates in memory)
+                k5.lam_off = (int)w5_lam.size();
+                w5_lam.insert(w5_lam.end(), b5[ilr].lam.begin(), b5[ilr].lam.end());
+                k5.ay_base = (int)w5_ay.size();
+                w5_ay.insert(w5_ay.end(), b5[ilr].ay.begin(), b5[ilr].ay.end());
+                ilr++;
+                k5.vop_off = (int)(w5_vop.size() / 512);
+                w5_vop.resize(w5_vop.size() + 512, 0.0);
+                double *dst = w5_vop.data() + (size_t)k5.vop_off * 512;
+                const double *V = h_static.data() + k.zr_off;
+                for (int t = 0; t < 2; t++)
+                    for (int q = 0; q < 4; q++)
+                        for (int ln = 0; ln < 64; ln++) {
+                            const int row = 4 * q + (ln >> 4), col = 16 * t + (ln & 15);
+                            if (col < U) dst[((t * 2 + (q >> 1)) * 64 + ln) * 2 + (q & 1)] = V[row + (i64)(k.offR[0] + col) * k.n];
+                        }
+                w5b.push_back(k5);
+            }
+            W3Block &kl = w5b.back();
+            kl.last = 1; kl.S_off = c->Soff[j];
+            c->cluster_fused[j] = 5;
+            for (int bb = b_first; bb < b_end; bb++) c->blk[bb].fused = true;
+        }
+    }
+    c->n_wave5_clusters = (int)w5_cl_blk0.size();
     // ---- k_cluster_assemble_w4: clusters whose low-rank blocks are all "simple" (one sub-block, rank-1 symmetric terms, one term per constraint, U = P, the
     //      same constraint order in every block) with n <= 32 and P <= 64, dense blocks 1 x 1, and at least one block beyond the reach of
     //      k_cluster_assemble_w3 (n > 16 or P > 32): the register-resident kernel of clrs_assemble_w4.hip.h ----
@@ -1123,7 +1233,7 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
             while (b_end < NB && c->blk[b_end].j == j) b_end++;
             b = b_end;
             const int Pj = c->P[j];
-            if (Pj < 1 || Pj > 64) continue;
+            if (Pj < 1 || Pj > 64 || c->cluster_fused[j] != 0) continue;
             bool ok = true, beyond_w3 = Pj > 32;
             int nlr = 0;
             std::vector<int> pm0;
@@ -1429,7 +1539,7 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
             fused_lds = std::max(fused_lds, (size_t)o * sizeof(double));
         }
     }
-    c->n_fused_clusters = (int)fcl.size() + (int)wcl.size() + (int)w2cl.size() + c->n_wave4_clusters;
+    c->n_fused_clusters = (int)fcl.size() + (int)wcl.size() + (int)w2cl.size() + c->n_wave4_clusters + c->n_wave5_clusters;
     // Few clusters with several blocks each: the blocks of a cluster are independent until their contributions meet in S_j.  One
     // workgroup per block (groups of blocks beyond 32 per cluster) writes its contribution as a P x P slab, k_sum_S_slabs adds
     // the slabs in block order -- the same additions in the same order as the one-workgroup form, so S_j is bit-identical.
@@ -1642,6 +1752,23 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
             Step s;
             s.kind = STEP_GATHER_SCALAR;
             s.dst = c->d_AY; s.src = c->d_G; s.d0 = c->d_ayidx; s.n = T;
+            pl.steps.push_back(s);
+        }
+        if (!w5b.empty()) {
+            int *dcb, *day; W3Block *db5; double *dvop, *dlam;
+            CK(upload(c, w5_cl_blk0, &dcb)); CK(upload(c, w5b, &db5)); CK(upload(c, w5_vop, &dvop));
+            CK(upload(c, w5_ay, &day)); CK(upload(c, w5_lam, &dlam));
+            c->w5tables.Xc = c->d_Xc; c->w5tables.Y = c->d_Y; c->w5tables.S = c->d_S; c->w5tables.AY = c->d_AY;
+            c->w5tables.vop = dvop; c->w5tables.lam = dlam; c->w5tables.ay = day;
+            c->ftables.Xc = c->d_Xc; c->ftables.Y = c->d_Y;
+            int cus = 256, dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+            Step s;
+            s.kind = STEP_ASSEMBLE_W5;
+            s.d0 = dcb; s.d1 = db5; s.src = &c->w5tables; s.n = (i64)w5_cl_blk0.size();
+            s.aux0 = (int)std::min<i64>(((i64)w5_cl_blk0.size() + 3) / 4, (i64)cus);
+            s.aux1 = (int)w5b.size();
             pl.steps.push_back(s);
         }
         if (!w4b.empty()) {
@@ -2589,6 +2716,7 @@ extern "C" int clrs_config_set(const char *key, int value) {
     if (!std::strcmp(key, "wave2_assemble")) { g_cfg_wave2_assemble = value; return 0; }
     if (!std::strcmp(key, "wave3_assemble")) { g_cfg_wave3_assemble = value; return 0; }
     if (!std::strcmp(key, "wave4_assemble")) { g_cfg_wave4_assemble = value; return 0; }
+    if (!std::strcmp(key, "wave5_assemble")) { g_cfg_wave5_assemble = value; return 0; }
     if (!std::strcmp(key, "dense_block")) { g_cfg_dense_block = value; return 0; }
     if (!std::strcmp(key, "dense_wave")) { g_cfg_dense_wave = value; return 0; }
     if (!std::strcmp(key, "factor_aug")) { g_cfg_factor_aug = value; return 0; }
@@ -2645,6 +2773,7 @@ extern "C" int clrs_fused_clusters(const clrs_ctx *c) { return c ? c->n_fused_cl
 extern "C" int clrs_wave_clusters(const clrs_ctx *c) { return c ? c->n_wave_clusters + c->n_wave2_clusters : 0; }
 extern "C" int clrs_wave2_clusters(const clrs_ctx *c) { return c ? c->n_wave2_clusters : 0; }
 extern "C" int clrs_wave4_clusters(const clrs_ctx *c) { return c ? c->n_wave4_clusters : 0; }
+extern "C" int clrs_wave5_clusters(const clrs_ctx *c) { return c ? c->n_wave5_clusters : 0; }
 
 extern "C" const char *clrs_kernel_name(int kind) { return (kind >= 0 && kind < STEP_NKINDS) ? STEP_NAMES[kind] : ""; }
 

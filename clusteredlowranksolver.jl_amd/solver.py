@@ -47,7 +47,7 @@ class SchurContext:
     src/solver.jl:298-317 -- all device resident."""
 
     def __init__(self, sdp, device: int = 0, graph: bool = False, timing: bool = False, fused: Optional[bool] = None,
-                 wave: Optional[bool] = None, wave2: Optional[bool] = None, wave3: Optional[bool] = None, wave4: Optional[bool] = None,
+                 wave: Optional[bool] = None, wave2: Optional[bool] = None, wave3: Optional[bool] = None, wave4: Optional[bool] = None, wave5: Optional[bool] = None,
                  solve_small2: Optional[bool] = None, factor_small: Optional[int] = None,
                  split_blocks: Optional[bool] = None):
         """`fused=False` forces the staged grouped-GEMM / blocked-BLAS path everywhere (default: clusters that fit in
@@ -74,6 +74,8 @@ class SchurContext:
             _lib.check(self.L.clrs_config_set(b"wave3_assemble", int(bool(wave3))))
         if wave4 is not None:
             _lib.check(self.L.clrs_config_set(b"wave4_assemble", int(bool(wave4))))
+        if wave5 is not None:
+            _lib.check(self.L.clrs_config_set(b"wave5_assemble", int(bool(wave5))))
         if solve_small2 is not None:
             _lib.check(self.L.clrs_config_set(b"solve_small2", int(bool(solve_small2))))
         if factor_small is not None:
@@ -111,6 +113,8 @@ class SchurContext:
                 self.L.clrs_config_set(b"wave3_assemble", 1)
             if wave4 is not None:
                 self.L.clrs_config_set(b"wave4_assemble", 1)
+            if wave5 is not None:
+                self.L.clrs_config_set(b"wave5_assemble", 1)
             if solve_small2 is not None:
                 self.L.clrs_config_set(b"solve_small2", 1)
             if factor_small is not None:
@@ -161,6 +165,10 @@ class SchurContext:
     def wave2_clusters(self) -> int:
         """Number of clusters assembled by one wave per cluster with S in registers (k_cluster_assemble_w2)."""
         return int(self.L.clrs_wave2_clusters(self.h))
+
+    def wave5_clusters(self) -> int:
+        """Number of clusters assembled by k_cluster_assemble_w5 (2 x 2 blocks of 16 x 16 sub-blocks on shared sample vectors)."""
+        return int(self.L.clrs_wave5_clusters(self.h))
 
     def wave4_clusters(self) -> int:
         """Number of clusters assembled by k_cluster_assemble_w4 (simple blocks of up to 32 rows, up to 64 constraints)."""

@@ -236,6 +236,10 @@ int clrs_wave2_clusters(const clrs_ctx *ctx);
  * row tiles, three or four column tiles, L^-1 V by blocks without forming L^-1); 0 leaves them on the general LDS-staged kernel.
  * clrs_wave4_clusters counts them (they are not in clrs_wave_clusters / clrs_wave2_clusters). */
 int clrs_wave4_clusters(const clrs_ctx *ctx);
+/* "wave5_assemble" (default 1): clusters whose PSD blocks are all 2 x 2 blocks of 16 x 16 sub-blocks carrying E_rs (x) v v^T on the same <= 32 sample vectors in
+ * (0,0), (1,1) and the symmetrised off-diagonal pair (the matrix-valued constraints of Nsphere_packing) take k_cluster_assemble_w5
+ * (csrc/clrs_assemble_w5.hip.h); clrs_wave5_clusters counts them. */
+int clrs_wave5_clusters(const clrs_ctx *ctx);
 /* "factor_small" (default 1): a context with ONE cluster (P, N <= 64) runs clrs_schur_factor as one launch of k_factor_small
  * (S_j and B_j staged in one trip, Q never leaves LDS before it is factored); 2 = also for 2-4 clusters, one wave per cluster
  * (slower than the workgroup-per-cluster kernels on the named problems: kept for measurement); 0 = never.

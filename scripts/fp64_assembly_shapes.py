@@ -43,7 +43,7 @@ def run(name, copies, check=True):
         best.append(1e3 * e0.elapsed_time(e1) / 50)
     us = float(np.median(best))
     shapes = sorted(set((int(n), int(P)) for n, P in zip(f.block_n, f.cluster_P[f.block_cluster])))
-    print("%s x %d: %d clusters (%d by k_cluster_assemble_w4), %d blocks (n, P of its cluster: %s)" % (name, copies, big.n_clusters, ctx.wave4_clusters(), big.n_blocks, shapes))
+    print("%s x %d: %d clusters (%d by k_cluster_assemble_w4, %d by _w5), %d blocks (n, P of its cluster: %s)" % (name, copies, big.n_clusters, ctx.wave4_clusters(), ctx.wave5_clusters(), big.n_blocks, shapes))
     print("   assembly %.1f us; algorithmic %.1f MB -> %.0f GB/s = %.3f of 8 TB/s; %.2f GFLOP -> %.1f TFLOP/s = %.3f of 78.6" %
           (us, c["assemble_bytes"] / 1e6, c["assemble_bytes"] / us / 1e3, c["assemble_bytes"] / us / 1e3 / 8000, c["assemble_flops"] / 1e9,
            c["assemble_flops"] / us / 1e6, c["assemble_flops"] / us / 1e6 / 78.6))

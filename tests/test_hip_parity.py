@@ -184,8 +184,9 @@ ASSEMBLE_CASES = ["x2p1", "polyopt8", "polyopt40", "delsarte_3_10", "delsarte_8_
                   "threepoint_4", "sdpa_small", "sdpa_mid", "polyopt_scaled_100", "polyopt_scaled_300"]
 
 
-PATHS = {"wave3": dict(fused=True, wave=True, wave2=True, wave3=True), "wave2": dict(fused=True, wave=True, wave2=True, wave3=False, wave4=False),
-         "wave": dict(fused=True, wave=True, wave2=False, wave4=False), "fused": dict(fused=True, wave=False), "staged": dict(fused=False)}
+PATHS = {"wave3": dict(fused=True, wave=True, wave2=True, wave3=True), "wave2": dict(fused=True, wave=True, wave2=True, wave3=False, wave4=False, wave5=False),
+         "wave": dict(fused=True, wave=True, wave2=False, wave4=False, wave5=False), "fused": dict(fused=True, wave=False), "staged": dict(fused=False)}
+WAVE5_CASES = {"ns_8_15_2": 1}            # clusters taken by k_cluster_assemble_w5 (2 x 2 blocks of 16 x 16 sub-blocks on shared sample vectors) on the default path
 WAVE4_CASES = {"polyopt40": 1}            # clusters taken by k_cluster_assemble_w4 (simple blocks of 17-32 rows or 33-64 constraints) on the default path
 WAVE2_CASES = {"x2p1": 1, "polyopt8": 1, "delsarte_8_3": 0, "ce_8_15": 2, "ce_8_3": 2}    # clusters taken by k_cluster_assemble_w2
 WAVE_CASES = {"x2p1", "polyopt8", "delsarte_3_10", "delsarte_8_3", "ce_8_15", "ce_8_3", "sdpa_small"}   # every cluster takes k_cluster_assemble_w1
@@ -207,6 +208,7 @@ def test_schur_assemble_matches_oracle(name, path, oracle_built):
     if path in ("wave2", "wave3") and name in WAVE2_CASES:
         assert ctx.wave2_clusters() == WAVE2_CASES[name]
     assert ctx.wave4_clusters() == (WAVE4_CASES.get(name, 0) if path == "wave3" else 0)
+    assert ctx.wave5_clusters() == (WAVE5_CASES.get(name, 0) if path == "wave3" else 0)
     if path == "wave":
         assert ctx.wave2_clusters() == 0
     if path in ("fused", "staged"):
@@ -1168,3 +1170,50 @@ def test_wave4_many_clusters_and_rare_paths(name, copies, oracle_built):
         Sk, AYk = o.schur_assemble(Xc[k * nxy:(k + 1) * nxy], Y[k * nxy:(k + 1) * nxy])
         assert np.max(np.abs(S[k * nS:(k + 1) * nS] - Sk)) <= 1e-11 * np.max(np.abs(Sk)), k
         assert np.max(np.abs(AY[k * nT:(k + 1) * nT] - AYk)) <= 1e-11 * max(1.0, np.max(np.abs(AYk))), k
+
+
+@pytest.mark.parametrize("copies,extra_block", [(1, False), (1, True), (600, True)])
+def test_wave5_matrix_valued_blocks(copies, extra_block, oracle_built):
+    """k_cluster_assemble_w5 on the 2 x 2 blocks of 16 x 16 sub-blocks of Nsphere_packing(8, 15, [1/2, 1/2]) (3 x 32 constraints on 32 shared sample vectors,
+    two such blocks per cluster, the second with lambda_u != 1): S_j accumulates in memory across the cluster's blocks -- alone, with a third block of
+    negative lambdas in the cluster, and with several clusters per wave; every checked cluster against the oracle (S_j and A_Y), S_j exactly symmetric,
+    and the general kernels on the same problem to rounding.  A cluster whose constraints are not in pair-major vector order stays on the general kernel."""
+    from clrs_amd.sdp import replicate_clusters
+    from clrs_amd.solver import SchurContext
+    from oracle.oracle import Oracle
+    from tests.util import duplicate_block, permute_cluster_constraints
+    f = flat("ns_8_15_2")
+    big_block = [b for b in range(f.n_blocks) if int(f.block_m[b]) == 2 and int(f.block_delta[b]) == 16][0]
+    g = duplicate_block(f, big_block, -0.6) if extra_block else f
+    big = replicate_clusters(g, copies) if copies > 1 else g
+    X, Y = spd_iterates(big, seed=31)
+    Xc = chol_blocks_np(big, X)
+    ctx = SchurContext(big)
+    assert ctx.wave5_clusters() == copies
+    S, AY = ctx.compute_S_integrated(Xc, Y)
+    ctx.close()
+    ctx0 = SchurContext(big, wave5=False)
+    assert ctx0.wave5_clusters() == 0
+    S0, AY0 = ctx0.compute_S_integrated(Xc, Y)
+    ctx0.close()
+    assert np.max(np.abs(S - S0)) <= 1e-11 * np.max(np.abs(S0))
+    assert np.max(np.abs(AY - AY0)) <= 1e-11 * max(1.0, np.max(np.abs(AY0)))
+    o = Oracle(g, quad=False)
+    nxy, nS, nT = g.xy_len, g.S_len, g.n_terms
+    j5 = int(g.block_cluster[big_block]); P5 = int(g.cluster_P[j5])
+    for k in sorted(set(list(range(0, copies, max(1, copies // 12))) + [copies - 1])):
+        Sk, AYk = o.schur_assemble(Xc[k * nxy:(k + 1) * nxy], Y[k * nxy:(k + 1) * nxy])
+        for j in range(g.n_clusters):
+            sl = slice(int(g.S_off[j]), int(g.S_off[j + 1]))
+            assert np.max(np.abs(S[k * nS:(k + 1) * nS][sl] - Sk[sl])) <= 1e-11 * np.max(np.abs(Sk[sl])), (k, j)
+        assert np.max(np.abs(AY[k * nT:(k + 1) * nT] - AYk)) <= 1e-11 * max(1.0, np.max(np.abs(AYk))), k
+        Sj = S[k * nS:(k + 1) * nS][int(g.S_off[j5]):int(g.S_off[j5 + 1])].reshape(P5, P5, order="F")
+        assert np.array_equal(Sj, Sj.T)
+    if copies == 1:
+        h = permute_cluster_constraints(g, seed=3)
+        ctxp = SchurContext(h)
+        assert ctxp.wave5_clusters() == 0
+        Sp, AYp = ctxp.compute_S_integrated(Xc, Y)
+        ctxp.close()
+        Sr, AYr = Oracle(h, quad=False).schur_assemble(Xc, Y)
+        assert np.max(np.abs(Sp - Sr)) <= 1e-11 * np.max(np.abs(Sr))
