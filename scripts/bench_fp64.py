@@ -395,8 +395,8 @@ def main(argv=None, emit=True):
             out["roofline_dense"] = {"error": repr(e)}
 
         # ---- the assembly on the other block shapes of BASELINE's configurations, many clusters per launch: PolyOpt 2d = 40 (one simple
-        #      block n = 21, P = 41 per cluster: k_cluster_assemble_w4 since round 5) and Nsphere_packing(8,15,[1/2,1/2]) (its 2 x 2 block of 16 x 16
-        #      sub-blocks, P = 96, stays on the general LDS-staged kernel) ----
+        #      block n = 21, P = 41 per cluster: k_cluster_assemble_w4 since round 5) and Nsphere_packing(8,15,[1/2,1/2]) (its two 2 x 2 blocks of 16 x 16
+        #      sub-blocks, P = 96: k_cluster_assemble_w5; the 2 x 2 block of 1 x 1 sub-blocks and the 1 x 1 dense clusters stay on the general kernel) ----
         out["roofline_shapes"] = {}
         for sname, builder, copies in (("polyopt_2d40", lambda: _polyopt40_flat(), 4096), ("Nsphere_packing(8,15,[1/2,1/2])", lambda: _ns2_flat(), 256)):
             try:
@@ -427,7 +427,8 @@ def main(argv=None, emit=True):
                     "traffic": None, "achieved_tflops": scnt["assemble_flops"] / s_s / 1e12, "frac_of_fp64_mfma_peak": scnt["assemble_flops"] / s_s / 1e12 / FP64_PEAK_TFLOPS,
                     "algorithmic_bytes": scnt["assemble_bytes"], "algorithmic_flops": scnt["assemble_flops"],
                     "workload": "%d clusters / %d PSD blocks with the shapes (n, P) %s in one assembly" % (bigs.n_clusters, bigs.n_blocks, shapes),
-                    "clusters_by_k_cluster_assemble_w4": sctx.wave4_clusters(), "kernels_us": {k: round(1e6 * v[2], 3) for k, v in sprof.items()}}
+                    "clusters_by_k_cluster_assemble_w4": sctx.wave4_clusters(), "clusters_by_k_cluster_assemble_w5": sctx.wave5_clusters(),
+                    "kernels_us": {k: round(1e6 * v[2], 3) for k, v in sprof.items()}}
                 sctx.close()
             except Exception as e:
                 out["roofline_shapes"][sname] = {"error": repr(e)}
