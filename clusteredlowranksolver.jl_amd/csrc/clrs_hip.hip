@@ -1179,7 +1179,6 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
                 nlr++;
             }
             if (!ok || nlr == 0) continue;
-            const int pm_off = 0;
             bool ident = true;
             for (int u = 0; u < 3 * U; u++) if (pm0[u] != u) ident = false;
             if (!ident) continue;                          // (constraints in pair-major vector order only: a table lookup per stored entry costs the kernel its registers)
@@ -1190,7 +1189,7 @@ extern "C" int clrs_ctx_create(const clrs_sdp_desc *d, int device, clrs_ctx **ou
                 if (k.kind != 0 || k.t1 == k.t0) continue;
                 W3Block k5;
                 std::memset(&k5, 0, sizeof(k5));
-                k5.xyoff = k.xyoff; k5.n = k.n; k5.U = U; k5.pmap_off = pm_off; k5.pmap_identity = ident ? 1 : 0;
+                k5.xyoff = k.xyoff; k5.n = k.n; k5.U = U; k5.pmap_identity = 1;
                 k5.ndense = ilr == 0 ? 1 : 0;              // (first block of its cluster: it stores S_j, the others add to it)
                 k5.S_off = c->Soff[j];                     // (every block of the cluster writes S_j: it accumulates in memory)
                 k5.lam_off = (int)w5_lam.size();

@@ -1,3 +1,5 @@
+"""k_cluster_assemble_w5 against the general kernel and against a numpy restatement of its formulas, pair-block by pair-block of S_j,
+on Nsphere_packing(8, 15, [1/2, 1/2]): the diagnostic that found the kernel's first bug (S_off of the cluster's first block)."""
 import sys; sys.path.insert(0,'.')
 import numpy as np
 from tests.util import flat, spd_iterates, chol_blocks_np
@@ -72,14 +74,3 @@ print("c2  diag", np.diag(contrib[2])[:8], np.diag(contrib[2])[24:32])
 print("c1  diag", np.diag(contrib[1])[:8])
 for (r_, c_) in ((0, 0), (5, 3), (3, 5), (20, 4), (40, 2), (40, 36), (70, 3), (70, 40), (90, 80)):
     print((r_, c_), "w5 %.6e  general %.6e  c1 %.6e  c2 %.6e" % (B[r_, c_], A[r_, c_], contrib[1][r_, c_], contrib[2][r_, c_]))
-import os
-one = os.environ.get("CLRS_W5_DEBUG_ONE")
-if one is not None:
-    cb = contrib[1 + int(one)]
-    print("ONE-block mode (block %d): w5 vs its numpy contribution: max err %.3e (scale %.3e)" % (1 + int(one), np.max(np.abs(B - cb)), np.max(np.abs(cb))))
-    for i in range(3):
-        for jj in range(i + 1):
-            for ti in range(2):
-                for tj in range(2):
-                    e = (B - cb)[i*U+16*ti:i*U+16*ti+16, jj*U+16*tj:jj*U+16*tj+16]; r_ = cb[i*U+16*ti:i*U+16*ti+16, jj*U+16*tj:jj*U+16*tj+16]
-                    print("  pair-block", i, jj, "tile", ti, tj, "err %.2e of %.2e" % (np.max(np.abs(e)), np.max(np.abs(r_))))
