@@ -1100,7 +1100,9 @@ __global__ __launch_bounds__(MW_NT) void k_mwi_Z(const MwDev q, const MwIpmDev p
 // allow, so a block is split over MWI_ZS or more workgroups (panels of at most eight columns) by column panels (eight lanes per entry, MW_PT threads); the panels go to
 // a scratch matrix and the workgroup of a block that finishes last symmetrises it (a counter per block).
 #define MWI_ZS 4
-#define MWI_ZL 8
+#ifndef MWI_ZL
+#define MWI_ZL 8          // (16 lanes per entry with two-column panels -- one term per lane and product -- is slower: 0.4178 against 0.4150 ms per iteration)
+#endif
 // KA <= K: limbs of the three products (MwIpmDev::klow); the panels in the scratch matrix and the symmetrised result carry K planes, the upper ones zero
 template <int K, int KA>
 __device__ __forceinline__ void mwi_Zi_body(const MwDev &q, const MwIpmDev &p, int which) {
