@@ -21,7 +21,9 @@
 //
 // Measured (cohnelkies(8,15), 5 limbs, scripts/pipe_stamps.py, profiles/r04): a stage's own steps 1.45 us, steps that apply an incoming column 1.9 us, a
 // hop 4 us (not the 1 us of an idle hand-off: the column is asked for before it exists and found by polling); k_mw_factor 93 -> 85 us, k_mw_potrf_q
-// 80 -> 83 us (its launch also carries the first products of the next solve): the default (clrs_mw_options.pipeline = 1) pipelines the clusters only.
+// 80 -> 83 us (its launch also carries the first products of the next solve): the default (clrs_mw_options.pipeline = 1) pipelined the clusters only.
+// Round 5: that hop was the consumers' own look-ahead (MWP_AHEAD below): with the columns asked for in the step that needs them k_mw_factor_pipe is
+// 53 us at 4 limbs and the pipeline wins for Q as well (the default from two stages on).
 //
 // The tail (scripts/pipe_stamps.py at the end of round 4): a consumer that runs less than MWP_NL steps behind its producer sends for every column before it
 // exists and finds it at its turn only -- one sc1 round trip (2-3.5 us) on its step instead of the step's arithmetic.  The workgroups of W catch up with the
