@@ -39,6 +39,7 @@ typedef long long i64;
 
 extern int g_cfg_mw_stream_words;                        // clrs_hip.hip, clrs_config_set("mw_stream_words", 0 / 1); env CLRS_MW_STREAM_WORDS
 extern int g_cfg_mw_pipeline64;                          // clrs_hip.hip, clrs_config_set("mw_pipeline64", 0 / 1): the 64-row form for clusters of 33 .. 64 rows
+extern int g_cfg_mw_pipeline_x, g_cfg_mw_pipeline_x_min; // clrs_hip.hip, clrs_config_set("mw_pipeline_x", 0 / 1), ("mw_pipeline_x_min", rows): the Cholesky of the X blocks through the pipelines
 extern int g_cfg_mw_sharded_factor_limbs;                // clrs_hip.hip, clrs_config_set("mw_sharded_factor_limbs", 0 / 1)
 extern int g_cfg_mw_pipeline;                            // clrs_hip.hip, clrs_config_set("mw_pipeline", 0 / 1): read at context creation
 extern int g_cfg_mw_refine_predictor;                    // clrs_hip.hip, clrs_config_set("mw_refine_predictor", 0 / 1)
@@ -174,6 +175,10 @@ struct clrs_mw_ctx {
     size_t sm_mws = 0;
     bool pipe_bp = false;                // the diagonal blocks of the blocked factorisation as pipelines (k_mw_bp_diag_pipe)
     bool pipe_S64 = false;               // ... the clusters' S_j of 33 .. 64 rows through the 64-row form of the pipeline (k_mw_factor_pipe64; limbs <= 6)
+    bool pipe_X = false;                 // ... the Cholesky of the X blocks (and of the Y blocks beside it) through the pipelines (k_mw_potrf_x_pipe): every block with its explicit inverse factor, <= 64 rows
+    unsigned long long *pipe_pcx = nullptr;    // its hand-off granules: [2 NB][MWP_PC_WORDS_N(K, 64)]
+    double *xpipe_L = nullptr, *xpipe_rd = nullptr;   // where the factors / reciprocal diagonals of the Y blocks go (only their inverses are kept)
+    int *xpipe_info = nullptr;
     bool pipe_S = false, pipe_Q = false;  // the factorisations of the clusters / of Q as pipelines of workgroups (clrs_mw_pipe.hip.h): every matrix <= 32 rows, few clusters
     unsigned long long *pipe_pc64 = nullptr;   // hand-off granules of k_mw_factor_pipe64: [J][MWP_PC_WORDS_N(K, 64)]
     int pipe_pcQ = 0;                    // index of Q's hand-off region in pipe_pc
@@ -815,6 +820,31 @@ extern "C" int clrs_mw_create_opts(const clrs_sdp_desc *d, int data_limbs, int d
         q.pipe_pc = nullptr;
         q.pipe_stamps = nullptr;
         q.pipe_bp = 0;
+        {   // the Cholesky of the X blocks through the pipelines: every block carries its inverse factor in LDS form (inv == 1) and has at most 64 rows
+            // (measured at 5 limbs, whole iterations: blocks of 32 and 48 rows -- Nsphere_packing N = 2 1.146 -> 1.122 ms, N = 3 2.059 -> 2.027; blocks of at most 21 rows:
+            // nothing either way; 64 blocks of 32 rows -- 2 x 64 x 8 working workgroups for 256 compute units -- 1.69 -> 1.87: by default from 24 rows of the largest
+            // block on and while every working workgroup of the launch has a compute unit of its own)
+            bool all_inv = c->d.NB > 0 && c->lds_x;
+            int maxn_x = 0;
+            i64 working = 0;
+            for (auto &kb : c->blk) {
+                all_inv = all_inv && kb.inv == 1;
+                maxn_x = std::max(maxn_x, kb.n);
+                working += 2 * ((kb.n + MWP_W - 1) / MWP_W + (kb.n > MWP_N ? MWP_N64 / MWP_W : MWP_WW));
+            }
+            c->pipe_X = cfg_pipe != 0 && K <= 6 && all_inv && maxn_x <= MWP_N64 && g_cfg_mw_pipeline_x != 0 &&
+                        (cfg_pipe >= 2 || (maxn_x >= g_cfg_mw_pipeline_x_min && working <= 256));
+            if (c->pipe_X) {
+                double *pcx = nullptr, *ti = nullptr;
+                MW_TRY(mw_dmalloc(c, &pcx, (i64)2 * c->d.NB * MWP_PC_WORDS_N(K, MWP_N64)));
+                c->pipe_pcx = (unsigned long long *)pcx;
+                MW_TRY(mw_dmalloc(c, &c->xpipe_L, c->d.xylen * K));
+                MW_TRY(mw_dmalloc(c, &c->xpipe_rd, c->d.xrdlen * K));
+                MW_TRY(mw_dmalloc(c, &ti, c->d.NB + 1));
+                c->xpipe_info = (int *)ti;
+                MW_DISPATCH(c, { if constexpr (KK <= 6) { MW_TRY(mw_set_lds(k_mw_potrf_x_pipe<KK>, MWP_LDS_ALONE64)); } });
+            }
+        }
         if (c->pipe_S64) {                                    // (its own hand-off region: 64-row columns; no other pipeline runs in such a context's factor stage but Q's / the blocked path's below)
             const size_t words64 = (size_t)J * MWP_PC_WORDS_N(K, MWP_N64);
             unsigned long long *pc64 = nullptr;
@@ -944,6 +974,11 @@ static int mw_cholesky_blocks_dev2(clrs_mw_ctx *c, const double *d_X, double *d_
     const int grid = d_Y2 ? 2 * c->d.NB : c->d.NB;
     bool in_mem = false;                                  // some block forms its inverse factor in memory, or in LDS beside a large block: four workgroups share its columns
     for (auto &k : c->blk) in_mem = in_mem || k.inv == 2 || mw_x_shares(k);
+    if (c->pipe_X) {
+        c->pipe_epoch = (c->pipe_epoch + 1) & 0x3ffffff;
+        MW_DISPATCH(c, { if constexpr (KK <= 6) { hipLaunchKernelGGL(k_mw_potrf_x_pipe<KK>, dim3(mwp_blocks64(grid)), dim3(MWP_NT64), MWP_LDS_ALONE64, c->stream, c->d, d_X, d_Xchol, d_Y2, d_Yi, d_yfail,
+                                                                     c->xpipe_L, c->xpipe_rd, c->xpipe_info, c->pipe_pcx, c->pipe_epoch); } });
+    } else
     MW_DISPATCH(c, hipLaunchKernelGGL(k_mw_potrf_x<KK>, dim3(grid, in_mem && c->lds_x ? MW_INV_WG : 1), dim3(MW_PT), c->sm_x, c->stream, c->d, d_X, d_Xchol, c->lds_x ? 1 : 0, d_Y2, d_Yi, d_yfail));
     MWCHECK(hipGetLastError());
     c->xinv_valid = true;

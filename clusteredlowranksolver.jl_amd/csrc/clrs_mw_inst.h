@@ -12,6 +12,7 @@
     X __global__ void k_mw_potrf_q<K>(const MwDev, int, const double *, const int *, int);                             \
     X __global__ void k_mw_factor_pipe<K>(const MwDev, unsigned);                                                      \
     X __global__ void k_mw_factor_pipe64<K>(const MwDev, unsigned);                                                    \
+    X __global__ void k_mw_potrf_x_pipe<K>(const MwDev, const double *, double *, const double *, double *, int *, double *, double *, int *, unsigned long long *, unsigned); \
     X __global__ void k_mw_potrf_q_pipe<K>(const MwDev, unsigned, const double *, const int *, int);                   \
     X __global__ void k_mw_bp_diag_pipe<K>(const MwDev, const MwBp *, int, int, unsigned, int, int);                   \
     X __global__ void k_mw_bp_inv_row<K>(const MwDev, const MwBp *, int);                                               \

@@ -430,6 +430,46 @@ __global__ __launch_bounds__(MWP_NT64) void k_mw_factor_pipe64(const MwDev q, un
     }
 }
 
+// The Cholesky of the X blocks (and, beside it, of a second block-diagonal matrix Y whose inverse factors alone are kept: the step length's) through the same
+// pipelines -- k_mw_potrf_x's work for contexts whose every block carries its explicit inverse factor (MwBlk::inv == 1): the 32-row form for blocks of at
+// most 32 rows (its 512 threads: the other 256 of this launch leave at once), the 64-row form beyond.  What k_mw_potrf_x leaves besides -- the scaled
+// triangles Xf / Xb of the substitution paths -- has no reader in such a context.  Bit for bit the factors and inverses of the one-workgroup kernel.
+// Block index -> (matrix, role) as in k_mw_factor_pipe64 (sixteen roles per matrix); matrices NB .. 2 NB - 1 are the blocks of Y.
+template <int K>
+__global__ __launch_bounds__(MWP_NT64) void k_mw_potrf_x_pipe(const MwDev q, const double *__restrict__ X, double *__restrict__ Xc, const double *__restrict__ Y2, double *__restrict__ Yi,
+                                                              int *__restrict__ yfail, double *__restrict__ scrL, double *__restrict__ scrRd, int *__restrict__ scrInfo,
+                                                              unsigned long long *__restrict__ pcx, unsigned epoch) {
+    using namespace mwk;
+    if constexpr (K > 6) return;
+    else {
+    mw_mark(q);
+    int mi, role;
+    mwp_block_map64(blockIdx.x, mi, role);
+    const int nmat = Y2 ? 2 * q.NB : q.NB;
+    if (mi >= nmat) return;
+    const bool second = mi >= q.NB;
+    const int b = second ? mi - q.NB : mi;
+    const MwBlk &k = q.blk[b];
+    const int n = k.n;
+    const bool big = n > MWP_N;
+    const int stages = (n + MWP_W - 1) / MWP_W;
+    if (role >= stages + (big ? MWP_N64 / MWP_W : MWP_WW)) return;
+    if (!big && threadIdx.x >= MWP_NT) return;
+    MwPipeMat m;
+    m.in = (second ? Y2 : X) + k.xyoff; m.inplane = q.xylen; m.in_stride = 0; m.in_slots = 1; m.n = n; m.keep = nullptr;
+    m.in_ld = m.l_ld = m.inv_ld = n;
+    m.L = (second ? scrL : Xc) + k.xyoff; m.lplane = q.xylen;
+    m.rd = (second ? scrRd : q.xrd) + k.rd_off; m.rdplane = q.xrdlen;
+    m.Inv = (second ? Yi : q.Xi) + k.xyoff; m.invplane = q.xylen;
+    m.pc = pcx + (long)mi * MWP_PC_WORDS_N(K, MWP_N64);
+    m.fail_code = b + 1;
+    m.stamps = nullptr;
+    int *info = second ? scrInfo + b : &q.info[1];
+    const bool ok = big ? mwp_run<K, K, MWP_N64>(m, role, epoch, info, threadIdx.x) : mwp_run<K, K, MWP_N>(m, role, epoch, info, threadIdx.x);
+    if (second && role == 0 && threadIdx.x == 0) yfail[b] = ok ? 0 : 1;
+    }
+}
+
 // L_Q = chol(Q), Q = the sum of the ranks' partial sums, and L_Q^-1: the blocks 0, 8, 16, ... of the first 64 (one XCD); the blocks from 64 on carry the
 // first product pair of the next solve (as in k_mw_potrf_q), one cluster each
 template <int K>
