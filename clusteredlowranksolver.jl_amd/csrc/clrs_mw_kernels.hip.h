@@ -1673,11 +1673,15 @@ __global__ __launch_bounds__(MW_NT) void k_mw_solve_bwd(const MwDev q, const dou
 
 // The same solve for clusters or a Q of more than ~64 rows: with one workgroup per cluster (and one for Q) the six products of the stage run one
 // after the other on one compute unit each (55 us per launch at P = 96, N = 97).  Here every product is a launch of its own whose ROWS are
-// spread over workgroups, sixteen lanes per row:
+// spread over workgroups, MW_SW_L lanes (a whole wave) per row:
 //   1  t = Si rhs_x (per cluster)          2  v = rhs_y - LB^T t (one dot product over all rows of all clusters)     3  z = Qi v
 //   4  dy = Qi^T z                         5  t <- t + LB dy                                                          6  dx = Si^T t (per cluster)
 // vz: 2 N numbers of scratch (v, then z), planar with plane 2 N.  Unsharded contexts only (the sharded solve exchanges the partial u_j).
-#define MW_SW_L 16
+#ifndef MW_SW_L
+#define MW_SW_L 64           // lanes per row.  Sixteen until the end of round 5: a row of 192 was twelve dependent K-limb multiply-adds per lane and four shuffle steps; with a
+                             // whole wave per row it is three and six, on four times the workgroups (whole iterations at 5 limbs: Nsphere_packing N = 3 2.030 -> 1.930 ms
+                             // with 64 lanes, 1.955 with 32; N = 2 1.124 -> 1.087; three-point as named 2.106 -> 2.074; SDPA x64 1.694 -> 1.654)
+#endif
 // KA <= K: limbs of the products (MwDev::kf); the difference rhs_y - [uadd] - LB^T t of stage 2 -- which cancels to the size of a residual in the refinement's
 // second pass -- is accumulated in K limbs from KA-limb operands; what is stored carries K planes, the upper ones zero
 template <int K, int KA>
@@ -1754,7 +1758,7 @@ __global__ __launch_bounds__(MW_NT) void k_mw_solve_wide(const MwDev q, int stag
 //     r_x = rhs_x - S dx + B dy,        r_y = rhs_y - B^T dx,
 // are formed in K limbs from the matrices as ASSEMBLED (S0) and solved for with the same inverse-factor products: the sum has the backward
 // error of the working precision (measured: scripts/refine_check.py; cohnelkies(8,15) y rows 2^-208 -> 2^-268 at 5 limbs).
-// This kernel is the form with rows over many workgroups, sixteen lanes per row, beside k_mw_solve_wide (clusters or Q beyond 64 rows):
+// This kernel is the form with rows over many workgroups, MW_SW_L lanes per row, beside k_mw_solve_wide (clusters or Q beyond 64 rows):
 //   stage 1   rx2 = rhs_x - S_j dx_j + B_j dy (grid.y = cluster)   and, in the workgroups with blockIdx.y = J,   u2 = B^T dx over this rank's rows
 //   stage 3   dx += dx2, dy += dy2
 // The small systems take the same step inside the launches of the solve itself (k_mw_solve_bwd, MODE 1 / 2).
