@@ -71,6 +71,7 @@ static int g_cfg_solve_small_max = 32768;     // one-workgroup solve stage only 
 static int g_cfg_ipm_wmfma = 3;         // device interior-point loop, bit 0: sum_i a_i A_i of a low-rank block as an MFMA contraction over its terms; bit 1: Z V by MFMA (0: per-entry loops)
 int g_cfg_mw_stream_words = 1;        // multi-word interior-point iteration: its two streams synchronise through words that kernels store and await (1) or through events only (0: for counter-collection runs, whose profiler serialises kernels -- a kernel that waits for one that cannot start sits in its bounded polls); env CLRS_MW_STREAM_WORDS overrides
 int g_cfg_mw_pipeline64 = 1;          // multi-word path: clusters of 33 .. 64 rows through the 64-row form of the pipelined factorisation (k_mw_factor_pipe64); 0: the one-workgroup kernels
+int g_cfg_mw_zt_small_maxn = 64;       // multi-word path: T = Y V, Z = chol(X)^-1 V with two columns per workgroup and eight lanes per entry (instead of eight columns, two lanes) for blocks of at most this many rows
 int g_cfg_mw_pipeline_x = 1;           // multi-word path: the Cholesky of the X (and Y) blocks through the pipelines of workgroups (k_mw_potrf_x_pipe) where every block carries its inverse factor; 0: k_mw_potrf_x
 int g_cfg_mw_pipeline_x_min = 24;      // ... from this many rows of the largest block on (pipeline = 2: always)
 int g_cfg_mw_sharded_factor_limbs = 1; // multi-word loop, sharded contexts: the reduced factor limbs of the mixed-precision refinement there too (the measured first-pass accuracy is gathered with the step lengths); 0: all limbs
@@ -2735,6 +2736,7 @@ extern "C" int clrs_config_set(const char *key, int value) {
     if (!std::strcmp(key, "mw_affine_corrector")) { g_cfg_mw_affine_corrector = value; return 0; }
     if (!std::strcmp(key, "mw_pipeline")) { g_cfg_mw_pipeline = value; return 0; }
     if (!std::strcmp(key, "mw_pipeline64")) { g_cfg_mw_pipeline64 = value; return 0; }
+    if (!std::strcmp(key, "mw_zt_small_maxn")) { g_cfg_mw_zt_small_maxn = value; return 0; }
     if (!std::strcmp(key, "mw_pipeline_x")) { g_cfg_mw_pipeline_x = value; return 0; }
     if (!std::strcmp(key, "mw_pipeline_x_min")) { g_cfg_mw_pipeline_x_min = value; return 0; }
     if (!std::strcmp(key, "mw_sharded_factor_limbs")) { g_cfg_mw_sharded_factor_limbs = value; return 0; }

@@ -39,6 +39,7 @@ typedef long long i64;
 
 extern int g_cfg_mw_stream_words;                        // clrs_hip.hip, clrs_config_set("mw_stream_words", 0 / 1); env CLRS_MW_STREAM_WORDS
 extern int g_cfg_mw_pipeline64;                          // clrs_hip.hip, clrs_config_set("mw_pipeline64", 0 / 1): the 64-row form for clusters of 33 .. 64 rows
+extern int g_cfg_mw_zt_small_maxn;                       // clrs_hip.hip, clrs_config_set("mw_zt_small_maxn", rows): k_mw_zt with two columns per workgroup and eight lanes per entry up to this block side
 extern int g_cfg_mw_pipeline_x, g_cfg_mw_pipeline_x_min; // clrs_hip.hip, clrs_config_set("mw_pipeline_x", 0 / 1), ("mw_pipeline_x_min", rows): the Cholesky of the X blocks through the pipelines
 extern int g_cfg_mw_sharded_factor_limbs;                // clrs_hip.hip, clrs_config_set("mw_sharded_factor_limbs", 0 / 1)
 extern int g_cfg_mw_pipeline;                            // clrs_hip.hip, clrs_config_set("mw_pipeline", 0 / 1): read at context creation
@@ -1010,7 +1011,7 @@ extern "C" int clrs_mw_schur_assemble_dev(clrs_mw_ctx *c, const double *d_Xchol,
             q2.mws_on = exact ? 1 : 0;
             const int gper = MW_NT / MW_GRAM_W;
             // few blocks, every one with its inverse factor: two columns per workgroup and eight lanes per entry
-            const int zt_ct = (c->xinv_valid && c->all_inv && (i64)q.nlr * c->maxU <= 2048 && c->maxn <= 32) ? 2 : MW_CT;
+            const int zt_ct = (c->xinv_valid && c->all_inv && (i64)q.nlr * c->maxU <= 2048 && c->maxn <= g_cfg_mw_zt_small_maxn) ? 2 : MW_CT;
             hipLaunchKernelGGL((k_mw_zt<KK, DD>), dim3((c->maxU + zt_ct - 1) / zt_ct, q.nlr), dim3(MW_NT), c->sm_zt, c->stream, q2, d_Y, c->lds_zt_L ? 1 : 0, c->xinv_valid ? 1 : 0, zt_ct);
             const bool ride_gram = !dense_done && q.ndn && !q.dn_big;      // ... or on that of the expansion kernel
             dense_done = dense_done || ride_gram;
