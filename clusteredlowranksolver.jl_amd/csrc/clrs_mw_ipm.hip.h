@@ -1185,7 +1185,9 @@ __global__ __launch_bounds__(MW_PT) void k_mwi_Zi(const MwDev q, const MwIpmDev 
 // of k_mwi_Zi walks whole matrices with 64 entries at a time (21 passes of seven multiply-adds per lane at n = 54, every workgroup reading all of A
 // and Xi), a tile reads eight rows and eight columns and its lanes take n / 4 multiply-adds.  op 0: Zt = sg (A Y - R' - mu_s I); 1: Zs = Xi Zt;
 // 2: Zt = Xi^T Zs; 3: dY = sym(Zt).  Blocks without an inverse factor stay with k_mwi_Z.
-#define MWI_BT 8
+#ifndef MWI_BT
+#define MWI_BT 8             // (4 x 4 tiles with sixteen lanes per entry: Nsphere_packing N = 3 1.888 -> 1.877 ms per iteration, but SDPA x64 -- 64 blocks of 32 rows -- 1.64 -> 1.91)
+#endif
 template <int K>
 __global__ __launch_bounds__(MW_NT) void k_mwi_bmm(const MwDev q, const MwIpmDev p, int op, int which) {
     using namespace mwk;
