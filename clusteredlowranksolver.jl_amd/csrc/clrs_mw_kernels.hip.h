@@ -1257,7 +1257,10 @@ __global__ __launch_bounds__(MW_NT) void k_mw_qsum(const MwDev q) {
 #define MW_BP_PR 2           // rows of the panel per workgroup: eight lanes per entry (the chain of 5 - 7 launches per block column is latency bound: few
                              // multiply-adds per lane matter more than full lanes)
 #define MW_BP_IC 1           // columns of an inverse block per workgroup: sixteen lanes per entry
-#define MW_BP_SW 4           // lanes per entry of the trailing update
+#ifndef MW_BP_SW
+#define MW_BP_SW 16          // lanes per entry of the trailing update (four until the end of round 5: eight dependent multiply-adds with two loads from memory each per lane;
+                             // sixteen: Nsphere_packing N = 3 1.891 -> 1.862 ms per iteration, N = 2 1.083 -> 1.059, three-point as named 2.068 -> 2.055, SDPA x64 1.647 -> 1.631)
+#endif
 struct MwBp {                // one matrix being factored: planar M and its inverse factor Mi (same plane length and leading dimension), reciprocal diagonal rd
     double *M, *Mi, *rd;
     mwi64 plane, rdplane;
@@ -1346,7 +1349,7 @@ __global__ __launch_bounds__(MW_PT) void k_mw_bp_panel(const MwDev q, const MwBp
 }
 // trailing update: A[i, j] -= sum_c L[i, j0 + c] L[j, j0 + c], i >= j >= j0 + nb
 // (split into the first MW_PB columns -- all the next diagonal block and panel need -- and a rest that rides on the next diagonal block's launch: measured,
-// no gain: the launch of the first columns takes what the whole update takes, a 32-term dot product over four lanes per entry, whatever the entry count)
+// no gain: the launch of the first columns takes what the whole update takes, a 32-term dot product over the lanes of an entry, whatever the entry count)
 template <int K, int KA>
 __device__ __forceinline__ void mw_bp_syrk_body(const MwDev &q, const MwBp &m, int j0) {
     using namespace mwk;
