@@ -1254,8 +1254,9 @@ __global__ __launch_bounds__(MW_NT) void k_mw_qsum(const MwDev q) {
 // With L^-1 explicit, LinvB and every solve of a large cluster are products over many lanes, like those of a small one.
 // ---------------------------------------------------------------------------------------------------------------------
 #define MW_PB_OF(K) 32       // panel width: a MW_PB x MW_PB matrix and the packed inverse of its factor, K limbs each, fit in LDS up to K = 10 (k_mw_bp_diag)
-#define MW_BP_PR 2           // rows of the panel per workgroup: eight lanes per entry (the chain of 5 - 7 launches per block column is latency bound: few
-                             // multiply-adds per lane matter more than full lanes)
+#ifndef MW_BP_PR
+#define MW_BP_PR 1           // rows of the panel per workgroup: sixteen lanes per entry (the chain of launches per block column is latency bound: few multiply-adds per
+#endif                       // lane matter more than full lanes; two rows / eight lanes until the end of round 5: Nsphere_packing N = 3 1.869 -> 1.859 ms per iteration)
 #define MW_BP_IC 1           // columns of an inverse block per workgroup: sixteen lanes per entry
 #ifndef MW_BP_SW
 #define MW_BP_SW 16          // lanes per entry of the trailing update (four until the end of round 5: eight dependent multiply-adds with two loads from memory each per lane;
@@ -1392,7 +1393,7 @@ __device__ __forceinline__ void mw_bp_inv_block_ka(const MwDev &q, const MwBp &m
     const int pc = min(MW_BP_IC, ni - c0);
     lds_d *T = MW_LDS;
     const long tp = (long)MW_PB * MW_BP_IC;
-    constexpr int LW = MW_PT / (MW_PB * MW_BP_IC);             // lanes per entry: 4
+    constexpr int LW = MW_PT / (MW_PB * MW_BP_IC);             // lanes per entry: 16
     const int e = tid / LW, sub = tid % LW, r = e % MW_PB, cl = e / MW_PB;
     const bool live = r < nj && cl < pc;
     const int rr = live ? r : 0, col = ci0 + c0 + (live ? cl : 0);
