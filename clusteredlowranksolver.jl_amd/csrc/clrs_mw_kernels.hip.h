@@ -644,7 +644,9 @@ __global__ __launch_bounds__(MW_NT) void k_mw_zt(const MwDev q, const double *__
 // Pairing matrices of a low-rank block: GX = Z^T Z = V^T X^-1 V, GY = V^T T = V^T Y V (U x U, symmetric; the
 // reference's bilinear_pairings_Xinv / _Y, src/solver.jl:1131, 1143).  Four lanes per entry of the lower triangle.
 // ---------------------------------------------------------------------------------------------------------------------
-#define MW_GRAM_W 4
+#ifndef MW_GRAM_W
+#define MW_GRAM_W 4          // (sixteen lanes per entry: PolyOpt 2d = 40 0.462 -> 0.458 ms per iteration, Nsphere_packing N = 3 1.853 -> 1.860, the named problem unchanged: left at four)
+#endif
 // a 1 x 1 dense block: T_e = (Y / X) a_e and the table Sd[e, e'] = a_e' T_e right behind it, one thread per matrix, then per pair
 template <int K, int DK>
 __device__ __forceinline__ void mw_dense_1x1(const MwDev &q, const MwBlk &k, const double *__restrict__ Y, int tid) {
